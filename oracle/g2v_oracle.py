@@ -1,0 +1,441 @@
+"""CPU oracle for the Gesture2Vec hot path  --  TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module.  The product path (gesture2vec_amd/) never does, and fails loudly when the HIP
+extension is missing.
+
+This is a from-scratch functional restatement (torch CPU fp32 tensors + explicit
+formulas, no reference classes, no nn.Module) of what the reference computes on the
+path BASELINE.json names.  Citations are `file:line` into /root/reference/scripts/.
+Parity status: PINNED -- tests/test_oracle_golden.py checks every function here
+against golden vectors captured by importing the reference in the build container
+(tests/golden/make_fixtures.py), because the reference itself ships no tests
+(SURVEY.md §4).
+
+Conventions
+  sd        dict[str, Tensor] with the reference's state_dict keys
+            (e.g. "encoder.gru.weight_ih_l0_reverse", "decoder.decoder.pre_linear.1.running_mean",
+            "vq_layer._ema_w")
+  masks     explicit dropout KEEP masks (uint8/bool/float 0-1); a dropped element is 0, a kept
+            one is scaled by 1/(1-p) exactly as ATen's dropout does
+  shapes    B batch, T frames, D pose dim, H hidden, L layers (2), E = H*L, K codes
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# elementary pieces
+# ----------------------------------------------------------------------------------------------
+def linear(x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    """nn.Linear: y = x W^T + b."""
+    y = x @ w.t()
+    return y if b is None else y + b
+
+
+def dropout_apply(x: Tensor, keep: Optional[Tensor], p: float) -> Tensor:
+    """ATen dropout with an explicit keep mask: x * keep / (1 - p)."""
+    if keep is None or p == 0.0:
+        return x
+    return x * keep.to(x.dtype) / (1.0 - p)
+
+
+def gru_cell(gi: Tensor, h: Tensor, w_hh: Tensor, b_hh: Tensor) -> Tensor:
+    """One PyTorch GRU cell given the input projection gi = x W_ih^T + b_ih  (B,3H).
+
+    r = sigmoid(gi_r + gh_r); z = sigmoid(gi_z + gh_z); n = tanh(gi_n + r * gh_n);
+    h' = (1 - z) * n + z * h        (torch.nn.GRU docs; gate order r,z,n)
+    Used by Autoencoder_VQVAE_model.py:94 (encoder nn.GRU) and :584 (decoder nn.GRU).
+    """
+    H = h.shape[-1]
+    gh = h @ w_hh.t() + b_hh
+    r = torch.sigmoid(gi[..., :H] + gh[..., :H])
+    z = torch.sigmoid(gi[..., H:2 * H] + gh[..., H:2 * H])
+    n = torch.tanh(gi[..., 2 * H:] + r * gh[..., 2 * H:])
+    return (1.0 - z) * n + z * h
+
+
+def gru_direction(x: Tensor, w_ih: Tensor, w_hh: Tensor, b_ih: Tensor, b_hh: Tensor,
+                  reverse: bool, lengths: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    """A full-sequence single-direction GRU layer, h0 = 0.  x (T,B,I) -> out (T,B,H), h_n (B,H).
+
+    With `lengths` (B,) it reproduces pack_padded_sequence semantics
+    (text2embedding_model.py:126-133): rows stop updating after their own last valid step,
+    padded output positions are zero, reverse direction starts at each row's own last step.
+    """
+    T, B, _ = x.shape
+    H = w_hh.shape[1]
+    gi_all = linear(x, w_ih, b_ih)
+    h = x.new_zeros(B, H)
+    outs: List[Optional[Tensor]] = [None] * T
+    steps = range(T - 1, -1, -1) if reverse else range(T)
+    for t in steps:
+        hn = gru_cell(gi_all[t], h, w_hh, b_hh)
+        if lengths is not None:
+            valid = (lengths > t).to(x.dtype).unsqueeze(1)
+            h = valid * hn + (1.0 - valid) * h
+            outs[t] = valid * hn
+        else:
+            h = hn
+            outs[t] = hn
+    return torch.stack(outs), h
+
+
+def bigru(x: Tensor, sd: Dict[str, Tensor], prefix: str, n_layers: int, p: float,
+          inter_masks: Optional[List[Tensor]] = None, lengths: Optional[Tensor] = None
+          ) -> Tuple[Tensor, Tensor]:
+    """nn.GRU(I, H, n_layers, dropout=p, bidirectional=True), h0 = 0.
+
+    Returns (out (T,B,2H) of the last layer, h_n (2*n_layers,B,H) ordered l0f,l0b,l1f,l1b).
+    inter_masks[l] is the keep mask (T,B,2H) ATen draws on layer l's output (l < n_layers-1).
+    """
+    hs = []
+    inp = x
+    for l in range(n_layers):
+        of, hf = gru_direction(inp, sd[f"{prefix}weight_ih_l{l}"], sd[f"{prefix}weight_hh_l{l}"],
+                               sd[f"{prefix}bias_ih_l{l}"], sd[f"{prefix}bias_hh_l{l}"], False, lengths)
+        ob, hb = gru_direction(inp, sd[f"{prefix}weight_ih_l{l}_reverse"], sd[f"{prefix}weight_hh_l{l}_reverse"],
+                               sd[f"{prefix}bias_ih_l{l}_reverse"], sd[f"{prefix}bias_hh_l{l}_reverse"], True, lengths)
+        out = torch.cat([of, ob], dim=2)
+        hs += [hf, hb]
+        if l < n_layers - 1 and p > 0.0 and inter_masks is not None:
+            out = dropout_apply(out, inter_masks[l], p)
+        inp = out
+    return inp, torch.stack(hs)
+
+
+def batchnorm1d(x: Tensor, weight: Tensor, bias: Tensor, running_mean: Tensor, running_var: Tensor,
+                training: bool, momentum: float = 0.1, eps: float = 1e-5
+                ) -> Tuple[Tensor, Tensor, Tensor]:
+    """nn.BatchNorm1d on (B,H).  Returns (y, new_running_mean, new_running_var).
+
+    train: normalise with the batch mean and BIASED batch variance; running stats move by
+    `momentum` towards the batch mean / UNBIASED variance.  eval: use running stats.
+    (Autoencoder_VQVAE_model.py:478, invoked once per decode step :572.)
+    """
+    if training:
+        B = x.shape[0]
+        mean = x.mean(0)
+        var_b = ((x - mean) ** 2).mean(0)
+        y = (x - mean) / torch.sqrt(var_b + eps) * weight + bias
+        var_u = var_b * (B / max(B - 1, 1))
+        nrm = (1 - momentum) * running_mean + momentum * mean.detach()
+        nrv = (1 - momentum) * running_var + momentum * var_u.detach()
+        return y, nrm, nrv
+    y = (x - running_mean) / torch.sqrt(running_var + eps) * weight + bias
+    return y, running_mean, running_var
+
+
+# ----------------------------------------------------------------------------------------------
+# quantizers
+# ----------------------------------------------------------------------------------------------
+def vq_distances(flat: Tensor, codebook: Tensor) -> Tensor:
+    """||x||^2 + ||W||^2 - 2 x W^T, in exactly this algebraic form (Autoencoder_VQVAE_model.py:1234-1238)."""
+    return (flat ** 2).sum(1, keepdim=True) + (codebook ** 2).sum(1) - 2 * flat @ codebook.t()
+
+
+def vq_ema_forward(inputs: Tensor, sd: Dict[str, Tensor], prefix: str, commitment_cost: float,
+                   training: bool, decay: float = 0.85, eps: float = 1e-5, use_pre_linear: bool = True
+                   ) -> Dict[str, Tensor]:
+    """VQ_Payam_EMA.forward (Autoencoder_VQVAE_model.py:1217-1296).
+
+    * rows are the contiguous reinterpretation `inputs.view(-1, E)` (:1229)
+    * distances/argmin use pre_linear(z) (:1230,1234-1244); loss and straight-through use RAW z (:1285,1292)
+    * `quantized` uses the PRE-update codebook (:1256); the EMA update happens afterwards (:1262-1282)
+    Returns dict(loss, quantized, perplexity, idx, flat, new _ema_cluster_size/_ema_w/_embedding.weight).
+    The (N,K) one-hot `encodings` the reference returns is onehot(idx).
+    """
+    W = sd[prefix + "_embedding.weight"]
+    K, E = W.shape
+    z_flat = inputs.reshape(-1, E)
+    flat = linear(z_flat, sd[prefix + "pre_linear.weight"], sd[prefix + "pre_linear.bias"]) if use_pre_linear else z_flat
+    flat_d = flat.detach()
+    d = vq_distances(flat_d, W.detach())
+    idx = torch.argmin(d, dim=1)
+    q = W.detach()[idx].reshape(inputs.shape)                       # == onehot @ W bit-exactly (:1256)
+    out = {"idx": idx, "flat": flat_d, "dist": d}
+    N = z_flat.shape[0]
+    cnt = torch.bincount(idx, minlength=K).to(W.dtype)
+    if training:
+        cs = sd[prefix + "_ema_cluster_size"] * decay + (1 - decay) * cnt              # :1263-1265
+        n = cs.sum()
+        cs = (cs + eps) / (n + K * eps) * n                                              # :1268-1273
+        onehot = torch.zeros(N, K, dtype=W.dtype)
+        onehot[torch.arange(N), idx] = 1.0
+        dw = onehot.t() @ flat_d                                                         # :1275
+        ema_w = sd[prefix + "_ema_w"].detach() * decay + (1 - decay) * dw                # :1276-1278
+        out["_ema_cluster_size"] = cs
+        out["_ema_w"] = ema_w
+        out["_embedding.weight"] = ema_w / cs.unsqueeze(1)                               # :1280-1282
+    e_latent = ((q - inputs) ** 2).mean()                                                # :1285
+    out["loss"] = commitment_cost * e_latent                                             # :1289
+    out["quantized"] = inputs + (q - inputs).detach()                                    # :1292
+    avg = cnt / N
+    out["perplexity"] = torch.exp(-(avg * torch.log(avg + 1e-10)).sum())                 # :1293-1294
+    return out
+
+
+def vq_plain_forward(inputs: Tensor, codebook: Tensor, commitment_cost: float) -> Dict[str, Tensor]:
+    """VQ_Payam.forward (Autoencoder_VQVAE_model.py:1114-1173): no pre_linear, codebook learns by gradient,
+    loss = q_latent + beta * e_latent."""
+    K, E = codebook.shape
+    flat = inputs.reshape(-1, E)
+    d = vq_distances(flat.detach(), codebook.detach())
+    idx = torch.argmin(d, 1)
+    q = codebook[idx].reshape(inputs.shape)
+    e_latent = ((q.detach() - inputs) ** 2).mean()
+    q_latent = ((q - inputs.detach()) ** 2).mean()
+    cnt = torch.bincount(idx, minlength=K).to(codebook.dtype)
+    avg = cnt / flat.shape[0]
+    return {"idx": idx, "loss": q_latent + commitment_cost * e_latent,
+            "quantized": inputs + (q - inputs).detach(),
+            "perplexity": torch.exp(-(avg * torch.log(avg + 1e-10)).sum())}
+
+
+# ----------------------------------------------------------------------------------------------
+# Part-b chunk VQ-VAE
+# ----------------------------------------------------------------------------------------------
+def encoder_forward(x_tbd: Tensor, sd: Dict[str, Tensor], n_layers: int, p: float,
+                    inter_masks: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
+    """EncoderRNN.forward (Autoencoder_VQVAE_model.py:73-100): Linear(D->H) -> bi-GRU -> sum directions."""
+    H = sd["encoder.in_layer.weight"].shape[0]
+    xin = linear(x_tbd, sd["encoder.in_layer.weight"], sd["encoder.in_layer.bias"])      # :93
+    out, hidden = bigru(xin, sd, "encoder.gru.", n_layers, p, inter_masks)               # :94
+    return out[:, :, :H] + out[:, :, H:], hidden                                         # :95-97
+
+
+def decoder_step(y_prev: Tensor, hidden: Tensor, sd: Dict[str, Tensor], n_layers: int, training: bool,
+                 keep95: Tensor, p: float, inter_mask: Optional[Tensor], bn_state: Dict[str, Tensor],
+                 conditioned: bool = True) -> Tuple[Tensor, Tensor]:
+    """Generator.forward -> BahdanauAttnDecoderRNN.forward, no attention (Autoencoder_VQVAE_model.py:499-592).
+
+    Dropout(0.95) is constructed inline (:570) so it is ACTIVE IN EVAL TOO; BN batch stats in train (:572).
+    bn_state holds running_mean / running_var / num_batches_tracked and is updated in place.
+    """
+    pre = "decoder.decoder."
+    inp = y_prev if conditioned else torch.zeros_like(y_prev)                            # :568-569
+    u = dropout_apply(inp, keep95, 0.95)                                                 # :570
+    u = linear(u, sd[pre + "pre_linear.0.weight"], sd[pre + "pre_linear.0.bias"])
+    a, nrm, nrv = batchnorm1d(u, sd[pre + "pre_linear.1.weight"], sd[pre + "pre_linear.1.bias"],
+                              bn_state["running_mean"], bn_state["running_var"], training)
+    if training:
+        bn_state["running_mean"], bn_state["running_var"] = nrm, nrv
+        bn_state["num_batches_tracked"] = bn_state["num_batches_tracked"] + 1
+    a = torch.relu(a)
+    new_h = []
+    layer_in = a
+    for l in range(n_layers):                                                            # :584 nn.GRU(H,H,L), seq len 1
+        gi = linear(layer_in, sd[pre + f"gru.weight_ih_l{l}"], sd[pre + f"gru.bias_ih_l{l}"])
+        h = gru_cell(gi, hidden[l], sd[pre + f"gru.weight_hh_l{l}"], sd[pre + f"gru.bias_hh_l{l}"])
+        new_h.append(h)
+        layer_in = h
+        if l < n_layers - 1 and training and p > 0.0 and inter_mask is not None:
+            layer_in = dropout_apply(h, inter_mask, p)
+    y = linear(new_h[-1], sd[pre + "out_layer.weight"], sd[pre + "out_layer.bias"])      # :590
+    return y, torch.stack(new_h)
+
+
+def vqvae_forward(sd: Dict[str, Tensor], in_poses: Tensor, out_poses: Tensor, cfg: dict, training: bool,
+                  masks: dict) -> Dict[str, Tensor]:
+    """Autoencoder_VQVAE.forward with vq=True, vae=False, CNN=False, att=False
+    (Autoencoder_VQVAE_model.py:901-1072).
+
+    cfg: n_layers, dropout_prob, commitment_cost, n_pre_poses, conditioned (bool)
+    masks: 'in' (T,B,D) [if p>0 and training], 'enc_l0' (T,B,2H) [same], 'dec' (T-1,B,D) ALWAYS,
+           'dec_l0' (T-1,B,H) [if p>0 and training]
+    Returns outputs (B,T,D), first_hidden (L,B,H), loss_vq, perplexity, idx, encoder_hidden and the
+    updated buffers (EMA state, BN running stats).
+    """
+    L, p = cfg["n_layers"], cfg["dropout_prob"]
+    x = in_poses.transpose(0, 1)                                                         # :956
+    if training and p > 0.0:
+        x = dropout_apply(x, masks["in"], p)                                             # :957
+    tgt = out_poses.transpose(0, 1)                                                      # :958
+    T, B, D = tgt.shape
+    enc_out, enc_hidden = encoder_forward(x, sd, L, p if training else 0.0,
+                                          [masks["enc_l0"]] if (training and p > 0.0) else None)  # :966
+    dec_hidden = enc_hidden[:L].contiguous()                                             # :971-973 (layer-0 fwd/bwd!)
+    vq = vq_ema_forward(dec_hidden, sd, "vq_layer.", cfg["commitment_cost"], training)   # :977
+    hidden = vq["quantized"]                                                             # :978
+    first_hidden = hidden
+    bn = {"running_mean": sd["decoder.decoder.pre_linear.1.running_mean"],
+          "running_var": sd["decoder.decoder.pre_linear.1.running_var"],
+          "num_batches_tracked": sd["decoder.decoder.pre_linear.1.num_batches_tracked"]}
+    outs = [tgt[0]]                                                                      # :1039-1040
+    dec_in = tgt[0]
+    for t in range(1, T):                                                                # :1041-1054
+        il = masks["dec_l0"][t - 1] if (training and p > 0.0) else None
+        y, hidden = decoder_step(dec_in, hidden, sd, L, training, masks["dec"][t - 1], p, il, bn,
+                                 cfg.get("conditioned", True))
+        outs.append(y)
+        dec_in = tgt[t] if t < cfg["n_pre_poses"] else y                                 # :1049-1052
+    outputs = torch.stack(outs).transpose(0, 1)                                          # :1066
+    return {"outputs": outputs, "first_hidden": first_hidden, "loss_vq": vq["loss"],
+            "perplexity": vq["perplexity"], "idx": vq["idx"], "encoder_hidden": enc_hidden,
+            "flat": vq["flat"], "dist": vq["dist"], "vq": vq, "bn": bn}
+
+
+def custom_loss(output: Tensor, target: Tensor, w_l1: float, w_cont: float, w_var: float) -> Tensor:
+    """train_eval/train_seq2seq.py:40-88.  output/target (B,T,D)."""
+    n = output.numel()
+    l1 = (output - target).abs().mean() * w_l1                                           # :58-59
+    cont = (output[:, 1:, :] - output[:, :-1, :]).abs().sum() / n * w_cont               # :62-67
+    norm = torch.sqrt((output ** 2).sum(dim=1))                                          # :70 torch.norm(output, 2, 1): over TIME
+    var = -norm.sum() / n * w_var                                                        # :71-72
+    return l1 + cont + var
+
+
+# ----------------------------------------------------------------------------------------------
+# optimiser pieces
+# ----------------------------------------------------------------------------------------------
+def clip_grad_norm(grads: Dict[str, Tensor], max_norm: float) -> Tuple[Dict[str, Tensor], Tensor]:
+    """torch.nn.utils.clip_grad_norm_ (train_seq2seq.py:743): coef = min(1, max_norm / (||g||_2 + 1e-6))."""
+    total = torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(g) for g in grads.values()]))
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    return {k: g * coef for k, g in grads.items()}, total
+
+
+def adam_step(params: Dict[str, Tensor], grads: Dict[str, Tensor], state: dict, lr: float,
+              betas=(0.5, 0.999), eps: float = 1e-8) -> None:
+    """torch.optim.Adam defaults (train_autoencoder_VQVAE.py:193-195): in-place on params/state."""
+    b1, b2 = betas
+    for k, g in grads.items():
+        st = state.setdefault(k, {"step": 0, "m": torch.zeros_like(g), "v": torch.zeros_like(g)})
+        st["step"] += 1
+        t = st["step"]
+        st["m"] = st["m"] * b1 + (1 - b1) * g
+        st["v"] = st["v"] * b2 + (1 - b2) * g * g
+        bc1 = 1 - b1 ** t
+        bc2 = 1 - b2 ** t
+        denom = st["v"].sqrt() / math.sqrt(bc2) + eps
+        params[k] = params[k] - (lr / bc1) * st["m"] / denom
+
+
+VQVAE_TRAINABLE_PREFIXES = ("encoder.", "decoder.")
+
+
+def vqvae_trainable_keys(sd: Dict[str, Tensor]) -> List[str]:
+    """Parameters that receive a (possibly all-zero) gradient in the reference's step [SURVEY §0 probe]:
+    everything under encoder.* and decoder.* except BN buffers.  out_layer_encoder/decoder,
+    vq_layer.pre_linear, vq_layer._ema_w and vq_layer._embedding.weight get grad=None and are therefore
+    neither clipped nor stepped."""
+    return [k for k in sd if k.startswith(VQVAE_TRAINABLE_PREFIXES)
+            and "running_" not in k and "num_batches_tracked" not in k]
+
+
+def vqvae_train_step(sd: Dict[str, Tensor], adam_state: dict, x: Tensor, masks: dict, cfg: dict,
+                     epoch: int = 1) -> Dict[str, Tensor]:
+    """train_iter_Autoencoder_VQ_seq2seq (train_eval/train_seq2seq.py:664-758) on (x, x):
+    zero_grad; forward; loss = custom_loss + loss_vq/400 (epoch>0); backward; clip 5; Adam; returns loss/perplexity.
+    sd and adam_state are updated IN PLACE (new tensors stored under the same keys)."""
+    keys = vqvae_trainable_keys(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(leaves)
+    fw = vqvae_forward(work, x, x, cfg, True, masks)
+    closs = custom_loss(fw["outputs"], x, cfg["w_l1"], cfg["w_cont"], cfg["w_var"])      # :707
+    loss = closs + fw["loss_vq"] / 400 if epoch > 0 else closs                           # :731-738
+    gl = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(leaves[k])) for k, g in zip(keys, gl)}
+    raw_grads = {k: g.clone() for k, g in grads.items()}
+    grads, gnorm = clip_grad_norm(grads, 5.0)                                            # :743
+    params = {k: sd[k] for k in keys}
+    adam_step(params, grads, adam_state, cfg["lr"])                                      # :744
+    sd.update(params)
+    for k in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
+        sd["vq_layer." + k] = fw["vq"][k]
+    pre = "decoder.decoder.pre_linear.1."
+    sd[pre + "running_mean"], sd[pre + "running_var"] = fw["bn"]["running_mean"], fw["bn"]["running_var"]
+    sd[pre + "num_batches_tracked"] = fw["bn"]["num_batches_tracked"]
+    return {"loss": loss.detach(), "custom_loss": closs.detach(), "loss_vq": fw["loss_vq"].detach(),
+            "perplexity": fw["perplexity"].detach(), "idx": fw["idx"], "outputs": fw["outputs"].detach(),
+            "grads": raw_grads, "grad_norm": gnorm, "encoder_hidden": fw["encoder_hidden"].detach(),
+            "quantized": fw["first_hidden"].detach(), "flat": fw["flat"], "dist": fw["dist"]}
+
+
+# ----------------------------------------------------------------------------------------------
+# Part-a frame DAE
+# ----------------------------------------------------------------------------------------------
+def dae_forward(x: Tensor, sd: Dict[str, Tensor], keep: Optional[Tensor], training: bool) -> Tuple[Tensor, Tensor]:
+    """DAE_Network.forward (model/DAE_model.py:105-114): squeeze -> Dropout(0.2) -> Linear+ReLU -> Linear -> unsqueeze(2)."""
+    inp = torch.squeeze(x)
+    if training:
+        inp = dropout_apply(inp, keep, 0.2)
+    lat = torch.relu(linear(inp, sd["encoder.0.weight"], sd["encoder.0.bias"]))
+    out = linear(lat, sd["decoder.0.weight"], sd["decoder.0.bias"])
+    return out.unsqueeze(2), lat
+
+
+def dae_train_step(sd: Dict[str, Tensor], adam_state: dict, x: Tensor, target: Tensor, keep: Tensor,
+                   lr: float) -> Dict[str, Tensor]:
+    """train_iter_DAE, vq=False, vae=False (train_eval/train_seq2seq.py:161-241): MSE, clip 5, Adam."""
+    keys = list(sd.keys())
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    out, _ = dae_forward(x, leaves, keep, True)
+    loss = ((out - target) ** 2).mean()
+    gl = torch.autograd.grad(loss, [leaves[k] for k in keys])
+    grads = dict(zip(keys, gl))
+    raw = {k: g.clone() for k, g in grads.items()}
+    grads, _ = clip_grad_norm(grads, 5.0)
+    params = {k: sd[k] for k in keys}
+    adam_step(params, grads, adam_state, lr)
+    sd.update(params)
+    return {"loss": loss.detach(), "grads": raw}
+
+
+# ----------------------------------------------------------------------------------------------
+# helpers shared by tests / bench
+# ----------------------------------------------------------------------------------------------
+def unpack_mask(bits: np.ndarray, shape) -> Tensor:
+    n = int(np.prod(shape))
+    return torch.from_numpy(np.unpackbits(bits)[:n].reshape(shape).copy())
+
+
+def init_vqvae_state(D: int, H: int, L: int, K: int, seed: int = 0) -> Dict[str, Tensor]:
+    """Random-init weights with the reference's state_dict keys/shapes/init distributions
+    (nn.Linear/nn.GRU default U(-1/sqrt(fan), 1/sqrt(fan)); codebook U(-1,1) :1204; _ema_w N(0,1) :1211)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: Dict[str, Tensor] = {}
+
+    def U(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    def lin(name, out_f, in_f):
+        b = 1.0 / math.sqrt(in_f)
+        sd[name + ".weight"], sd[name + ".bias"] = U((out_f, in_f), b), U((out_f,), b)
+
+    def gru(prefix, in_f, bidir):
+        b = 1.0 / math.sqrt(H)
+        for l in range(L):
+            i_f = in_f if l == 0 else (2 * H if bidir else H)
+            for suf in ([""] + (["_reverse"] if bidir else [])):
+                sd[f"{prefix}weight_ih_l{l}{suf}"] = U((3 * H, i_f), b)
+                sd[f"{prefix}weight_hh_l{l}{suf}"] = U((3 * H, H), b)
+                sd[f"{prefix}bias_ih_l{l}{suf}"] = U((3 * H,), b)
+                sd[f"{prefix}bias_hh_l{l}{suf}"] = U((3 * H,), b)
+
+    lin("encoder.in_layer", H, D)
+    gru("encoder.gru.", H, True)
+    lin("out_layer_encoder.0", H, H)
+    lin("out_layer_decoder.0", D, H)
+    lin("decoder.decoder.pre_linear.0", H, D)
+    sd["decoder.decoder.pre_linear.1.weight"] = torch.ones(H)
+    sd["decoder.decoder.pre_linear.1.bias"] = torch.zeros(H)
+    sd["decoder.decoder.pre_linear.1.running_mean"] = torch.zeros(H)
+    sd["decoder.decoder.pre_linear.1.running_var"] = torch.ones(H)
+    sd["decoder.decoder.pre_linear.1.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+    gru("decoder.decoder.gru.", H, False)
+    lin("decoder.decoder.out_layer", D, H)
+    E = H * L
+    sd["vq_layer._ema_cluster_size"] = torch.zeros(K)
+    sd["vq_layer._ema_w"] = torch.randn(K, E, generator=g)
+    lin("vq_layer.pre_linear", E, E)
+    sd["vq_layer._embedding.weight"] = U((K, E), 1.0)
+    return sd
