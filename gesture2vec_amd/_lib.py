@@ -1,0 +1,108 @@
+"""ctypes binding of libg2v_hip.so (include/g2v.h).  No torch types cross the boundary: only raw
+device pointers, sizes and a hipStream_t.  Loading FAILS LOUDLY when the library is missing; there is
+no CPU or PyTorch fallback anywhere in the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libg2v_hip.so")
+
+c_fp = C.c_void_p  # device pointers travel as void*
+c_i64 = C.c_int64
+c_int = C.c_int
+c_f = C.c_float
+c_sz = C.c_size_t
+c_u64 = C.c_uint64
+
+
+class DecWeights(C.Structure):
+    """g2v_dec_weights"""
+    _fields_ = [(n, c_fp) for n in (
+        "w_pre", "b_pre", "bn_w", "bn_b", "bn_running_mean", "bn_running_var",
+        "w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out")]
+
+
+class DecSaved(C.Structure):
+    """g2v_dec_saved"""
+    _fields_ = [(n, c_fp) for n in (
+        "y", "xin", "u", "a", "h0", "h1", "x1", "gates0", "gates1", "bn_partial", "bn_stats")]
+
+
+class DecGrads(C.Structure):
+    """g2v_dec_grads"""
+    _fields_ = [(n, c_fp) for n in (
+        "dy", "du", "dbn", "dgi0", "dgh0", "dgi1", "dgh1", "dh_init", "d_bn_w", "d_bn_b", "bn_bwd_partial")]
+
+
+_SIGS = {
+    "g2v_version": (C.c_char_p, []),
+    "g2v_last_error": (C.c_char_p, []),
+    "g2v_device_ok": (c_int, []),
+    "g2v_linear_fwd": (c_int, [c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_f, c_fp, c_fp, c_fp, c_i64,
+                               c_int, c_int, c_int, c_int, c_fp]),
+    "g2v_linear_bwd_data": (c_int, [c_fp, c_i64, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_int, c_fp]),
+    "g2v_linear_bwd_weight_workspace": (c_sz, [c_int, c_int, c_int]),
+    "g2v_linear_bwd_weight": (c_int, [c_fp, c_i64, c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_f, c_fp, c_fp,
+                                      c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_vq_assign_blocks": (c_int, [c_int]),
+    "g2v_vq_code_sqnorm": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_vq_assign_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_vq_stats_workspace": (c_sz, [c_int, c_int, c_int]),
+    "g2v_vq_stats": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_vq_ema_update": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
+                                  c_f, c_f, c_f, c_int, c_fp]),
+    "g2v_vq_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_fp]),
+    "g2v_gru_seq_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_i64, c_fp, c_fp,
+                                c_int, c_int, c_int, c_fp]),
+    "g2v_gru_seq_bwd_workspace": (c_sz, [c_int]),
+    "g2v_gru_seq_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp,
+                                c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_dec_rollout_blocks": (c_int, [c_int]),
+    "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp]),
+    "g2v_dec_rollout_bwd_workspace": (c_sz, [c_int, c_int]),
+    "g2v_dec_rollout_bwd": (c_int, [C.POINTER(DecWeights), C.POINTER(DecSaved), C.POINTER(DecGrads), c_fp, c_fp,
+                                    c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_custom_loss_blocks": (c_int, [c_int, c_int]),
+    "g2v_custom_loss_fwd_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_fp]),
+    "g2v_adam_blocks": (c_int, [c_i64]),
+    "g2v_clip_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),
+    "g2v_keep_mask": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_fp]),
+    "g2v_fill_f32": (c_int, [c_fp, c_f, c_i64, c_fp]),
+    "g2v_transpose": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_add_halves": (c_int, [c_fp, c_i64, c_fp, c_i64, c_fp, c_i64, c_i64, c_int, c_fp]),
+}
+
+EXPORTS = tuple(_SIGS.keys())
+
+_lib = None
+
+
+class G2VLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libg2v_hip.so once and attach the signatures.  Raises if the library is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise G2VLibraryError(
+            f"{LIB_PATH} is missing: build it with `make -C gesture2vec_amd/csrc` "
+            "(or `python -c 'import __graft_entry__ as g; g.build()'`).  There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().g2v_last_error().decode()
+        raise G2VLibraryError(f"g2v call failed ({rc}) {what}: {msg}")

@@ -1,0 +1,159 @@
+// common.hpp -- shared device helpers for the gfx950 kernels (wave64, fp32 MFMA 16x16x4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/g2v.h"
+
+namespace g2v {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+constexpr int TILE = 16;  // MFMA 16x16x4 tile edge
+
+void set_error(const char* fmt, ...);
+
+#define G2V_REQUIRE(cond, msg)                                  \
+  do {                                                          \
+    if (!(cond)) {                                              \
+      g2v::set_error("%s: %s", __func__, msg);                  \
+      return G2V_ERR_ARG;                                       \
+    }                                                           \
+  } while (0)
+
+#define G2V_CHECK_LAUNCH()                                                          \
+  do {                                                                              \
+    hipError_t e_ = hipGetLastError();                                              \
+    if (e_ != hipSuccess) {                                                         \
+      g2v::set_error("%s: launch failed: %s", __func__, hipGetErrorString(e_));     \
+      return G2V_ERR_LAUNCH;                                                        \
+    }                                                                               \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------------------------------------
+// v_mfma_f32_16x16x4_f32:  D(16x16) = A(16x4) * B(4x16) + C.   Lane l supplies
+//   a = A[i = l & 15][k = l >> 4],  b = B[k = l >> 4][j = l & 15];
+// it receives D[i = 4*(l >> 4) + r][j = l & 15] in element r of the accumulator.
+// Numerics: bit-for-bit a k-ordered chain of fp32 fmas (no wider accumulation).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// Four consecutive k-values (k..k+3) of one row of a row-major global matrix, zero-filled where
+// !valid or k >= K.  `p_row` points at the row start.
+__device__ __forceinline__ float4 ldg_frag(const float* __restrict__ p_row, bool valid, int k, int K, bool vec_ok) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (valid) {
+    const float* p = p_row + k;
+    if (vec_ok && k + 3 < K) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (k < K) v.x = p[0];
+      if (k + 1 < K) v.y = p[1];
+      if (k + 2 < K) v.z = p[2];
+      if (k + 3 < K) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ bool ptr_vec_ok(const void* p, int64_t ld) {
+  return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0);
+}
+
+// One wave accumulates NT 16x16 tiles over a K-deep contraction:
+//   acc[t][r] += sum_k W[n0 + t*nstride + 4q + r][k] * X[j][k]      (q = lane>>4, j = lane&15)
+// W: global row-major [.. ][ldw] (weights; L2 resident), rows valid while (feature-in-tile index) < nvalid.
+// Xs: LDS [16][ldx], zero padded to a multiple of 16 columns >= K.
+// Each lane fetches float4s along k for both operands (k = k0 + 4q + e), i.e. MFMA e of a group
+// contracts the k-set {k0 + 4q' + e : q' = 0..3}; any pairing is valid as long as A and B agree.
+template <int NT>
+__device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NT], const float* __restrict__ W, int64_t ldw, bool wvec,
+                                          int n0, int nstride, int nvalid, int K,
+                                          const float* Xs, int ldx, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const int Kp = (K + 15) & ~15;
+  const bool valid = i < nvalid;
+  const float* wrow[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wrow[t] = W + (int64_t)(n0 + t * nstride + (valid ? i : 0)) * ldw;
+  for (int k0 = 0; k0 < Kp; k0 += 16) {
+    const float4 xb = *reinterpret_cast<const float4*>(Xs + i * ldx + k0 + 4 * q);
+    float4 wa[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wa[t] = ldg_frag(wrow[t], valid, k0 + 4 * q, K, wvec);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      acc[t] = mfma16(wa[t].x, xb.x, acc[t]);
+      acc[t] = mfma16(wa[t].y, xb.y, acc[t]);
+      acc[t] = mfma16(wa[t].z, xb.z, acc[t]);
+      acc[t] = mfma16(wa[t].w, xb.w, acc[t]);
+    }
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// sum over the 16 lanes that share lane>>4 (i.e. over j = lane & 15)
+__device__ __forceinline__ float reduce16(float v) {
+  v += __shfl_xor(v, 1);
+  v += __shfl_xor(v, 2);
+  v += __shfl_xor(v, 4);
+  v += __shfl_xor(v, 8);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Stage a [16][K] row tile into LDS [16][ldx] with zero padding up to Kp columns.
+// rows >= nrows_valid are zero.  256 threads.
+__device__ __forceinline__ void stage_rows(float* Xs, int ldx, int Kp, const float* __restrict__ src, int64_t ld,
+                                           int nrows_valid, int K, int tid, int nthreads) {
+  const int total = 16 * Kp;
+  for (int e = tid; e < total; e += nthreads) {
+    const int r = e / Kp, k = e - r * Kp;
+    float v = 0.f;
+    if (r < nrows_valid && k < K) v = src[(int64_t)r * ld + k];
+    Xs[r * ldx + k] = v;
+  }
+}
+
+
+// sum of `nsplit` slabs of n floats, in slab order (deterministic), optionally on top of `out`
+static __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
+                                          float* __restrict__ out, int accumulate) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = accumulate ? out[e] : 0.f;
+  for (int p = 0; p < nsplit; ++p) s += slab[(int64_t)p * n + e];
+  out[e] = s;
+}
+
+static __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int r = r0 + j, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[j][threadIdx.x] = in[(int64_t)r * cols + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+    const int c = c0 + j, r = r0 + threadIdx.x;
+    if (r < rows && c < cols) out[(int64_t)c * rows + r] = tile[threadIdx.x][j];
+  }
+}
+static inline void launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(32, 8), 0, st, in, out, rows, cols);
+}
+
+}  // namespace g2v

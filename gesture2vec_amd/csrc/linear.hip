@@ -1,0 +1,272 @@
+// linear.hip -- dense-layer forward / data-gradient / weight-gradient on fp32 MFMA (gfx950).
+//
+// Replaces the nn.Linear call sites named in include/g2v.h (EncoderRNN.in_layer
+// Autoencoder_VQVAE_model.py:93, VQ_Payam_EMA.pre_linear :1230, nn.GRU input projections,
+// DAE_Network model/DAE_model.py:107-110) and all their autograd matmuls.
+//
+// Shapes on this path are "tall and thin": M = rows (T*B up to ~1.4e5), K,N <= ~600.  Both
+// kernels tile 64x64 outputs per 256-thread workgroup, stage operands through LDS and issue
+// v_mfma_f32_16x16x4_f32.  They are HBM-bound (one read of x, one write of y); the weight tile
+// is re-read from L2.
+#include "common.hpp"
+
+namespace g2v {
+
+struct RowMap {
+  int64_t ld;
+  int rows_inner;
+  int64_t so, si;
+};
+__device__ __forceinline__ int64_t row_off(const RowMap& m, int r) {
+  return m.rows_inner > 0 ? (int64_t)(r / m.rows_inner) * m.so + (int64_t)(r % m.rows_inner) * m.si
+                          : (int64_t)r * m.ld;
+}
+
+constexpr int BM = 64, BN = 64, BC = 32, LDT = BC + 4;
+
+// C[m][n] (+)= act( sum_c A[m][c] * Bop[n][c] + bias[n] )
+//   TRANS_B == false: Bop[n][c] = Bm[n*ldb + c]     (forward: Bm = w [N][K])
+//   TRANS_B == true : Bop[n][c] = Bm[c*ldb + n]     (data gradient: Bm = w [N][K], output feature = k)
+template <bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, RowMap am,
+                                                      const uint8_t* __restrict__ keep, float scale,
+                                                      const float* __restrict__ Bm, int64_t ldb,
+                                                      const float* __restrict__ bias, float* __restrict__ Cout,
+                                                      int64_t ldc, int M, int C, int N, int act, int accumulate) {
+  __shared__ __attribute__((aligned(16))) float As[BM * LDT];
+  __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int i = lane & 15, q = lane >> 4;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int c0 = 0; c0 < C; c0 += BC) {
+    // ---- stage A tile [64][32]: consecutive threads along c (contiguous) ----
+    {
+      const int c = tid & 31;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = (tid >> 5) + 8 * it;
+        const int m = m0 + r, cc = c0 + c;
+        float v = 0.f;
+        if (m < M && cc < C) {
+          v = A[row_off(am, m) + cc];
+          if (keep) v = keep[(int64_t)m * C + cc] ? v * scale : 0.f;
+        }
+        As[r * LDT + c] = v;
+      }
+    }
+    // ---- stage B tile [64 n][32 c] ----
+    if (!TRANS_B) {
+      const int c = tid & 31;
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int r = (tid >> 5) + 8 * it;
+        const int n = n0 + r, cc = c0 + c;
+        Bs[r * LDT + c] = (n < N && cc < C) ? Bm[(int64_t)n * ldb + cc] : 0.f;
+      }
+    } else {
+      const int r = tid & 63;  // n (contiguous in memory)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int c = (tid >> 6) + 4 * it;
+        const int n = n0 + r, cc = c0 + c;
+        Bs[r * LDT + c] = (n < N && cc < C) ? Bm[(int64_t)cc * ldb + n] : 0.f;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k0 = 0; k0 < BC; k0 += 16) {
+      const float4 xb = *reinterpret_cast<const float4*>(&As[(16 * wave + i) * LDT + k0 + 4 * q]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float4 wa = *reinterpret_cast<const float4*>(&Bs[(16 * t + i) * LDT + k0 + 4 * q]);
+        acc[t] = mfma16(wa.x, xb.x, acc[t]);
+        acc[t] = mfma16(wa.y, xb.y, acc[t]);
+        acc[t] = mfma16(wa.z, xb.z, acc[t]);
+        acc[t] = mfma16(wa.w, xb.w, acc[t]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane holds row m = m0 + 16*wave + (lane&15), features n0 + 16t + 4q + r
+  const int m = m0 + 16 * wave + i;
+  if (m >= M) return;
+  float* crow = Cout + (int64_t)m * ldc;
+  const bool cvec = ptr_vec_ok(Cout, ldc);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int n = n0 + 16 * t + 4 * q;
+    if (n >= N) continue;
+    float v[4] = {acc[t][0], acc[t][1], acc[t][2], acc[t][3]};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (n + r < N) {
+        if (bias) v[r] += bias[n + r];
+        if (act == 1) v[r] = fmaxf(v[r], 0.f);
+        else if (act == 2) v[r] = tanhf(v[r]);
+        if (accumulate) v[r] += crow[n + r];
+      }
+    }
+    if (cvec && n + 3 < N) {
+      *reinterpret_cast<float4*>(crow + n) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < N) crow[n + r] = v[r];
+    }
+  }
+}
+
+// ---- weight gradient: slab[split][n][k] = sum_{m in split} dy[m][n] * xin[m][k] -------------------
+constexpr int TM = 32, LDW = 64 + 16;
+
+__global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                      const float* __restrict__ X, RowMap xm,
+                                                      const uint8_t* __restrict__ keep, float scale,
+                                                      float* __restrict__ slab, float* __restrict__ slab_db,
+                                                      int M, int K, int N, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float Ds[TM * LDW];
+  __shared__ __attribute__((aligned(16))) float Xs[TM * LDW];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z;
+  const int mb = split * rows_per_split;
+  const int me = min(M, mb + rows_per_split);
+  const int i = lane & 15, q = lane >> 4;
+
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbsum = 0.f;
+
+  for (int mc = mb; mc < me; mc += TM) {
+    const int c = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = (tid >> 6) + 4 * it;
+      const int m = mc + r;
+      float dv = 0.f, xv = 0.f;
+      if (m < me) {
+        if (n0 + c < N) dv = dY[(int64_t)m * lddy + n0 + c];
+        if (k0 + c < K) {
+          xv = X[row_off(xm, m) + k0 + c];
+          if (keep) xv = keep[(int64_t)m * K + k0 + c] ? xv * scale : 0.f;
+        }
+      }
+      Ds[r * LDW + c] = dv;
+      Xs[r * LDW + c] = xv;
+    }
+    __syncthreads();
+    if (slab_db && blockIdx.y == 0 && tid < 64) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < TM; ++r) s += Ds[r * LDW + tid];
+      dbsum += s;
+    }
+#pragma unroll
+    for (int s4 = 0; s4 < TM; s4 += 4) {
+      const float a = Ds[(s4 + q) * LDW + 16 * wave + i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float b = Xs[(s4 + q) * LDW + 16 * t + i];
+        acc[t] = mfma16(a, b, acc[t]);
+      }
+    }
+    __syncthreads();
+  }
+  // lane holds dw[n = n0 + 16*wave + 4q + r][k = k0 + 16t + (lane&15)]
+  float* sl = slab + (int64_t)split * N * K;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int k = k0 + 16 * t + i;
+    if (k >= K) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n = n0 + 16 * wave + 4 * q + r;
+      if (n < N) sl[(int64_t)n * K + k] = acc[t][r];
+    }
+  }
+  if (slab_db && blockIdx.y == 0 && tid < 64 && n0 + tid < N) slab_db[(int64_t)split * N + n0 + tid] = dbsum;
+}
+
+static int tn_splits(int M, int K, int N) {
+  const int tiles = cdiv(N, 64) * cdiv(K, 64);
+  int splits = cdiv(1024, tiles);
+  const int max_splits = cdiv(M, 4 * TM);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
+                              const uint8_t* x_keep, float x_scale, const float* w, const float* bias, float* y,
+                              int64_t ldy, int M, int K, int N, int act, g2v_stream_t stream) {
+  G2V_REQUIRE(x && w && y, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  G2V_REQUIRE(act >= 0 && act <= 2, "bad activation");
+  RowMap am{ldx, rows_inner, stride_outer, stride_inner};
+  dim3 grid(cdiv(M, BM), cdiv(N, BN));
+  hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, am, x_keep, x_scale, w,
+                     (int64_t)K, bias, y, ldy, M, K, N, act, 0);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int M, int K,
+                                   int N, int accumulate, g2v_stream_t stream) {
+  G2V_REQUIRE(dy && w && dx, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  RowMap am{lddy, 0, 0, 0};
+  dim3 grid(cdiv(M, BM), cdiv(K, BN));
+  // output feature = k (K of them), contraction over n (N): Bop[k][n] = w[n*K + k]
+  hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, am, (const uint8_t*)nullptr,
+                     1.0f, w, (int64_t)K, (const float*)nullptr, dx, lddx, M, N, K, 0, accumulate);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
+  if (M <= 0 || K <= 0 || N <= 0) return 0;
+  const int splits = tn_splits(M, K, N);
+  return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
+}
+
+extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, int rows_inner,
+                                     int64_t stride_outer, int64_t stride_inner, const uint8_t* x_keep, float x_scale,
+                                     float* dw, float* db, int M, int K, int N, int accumulate, void* workspace,
+                                     size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(dy && x && dw && workspace, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  if (workspace_bytes < g2v_linear_bwd_weight_workspace(M, K, N)) {
+    set_error("g2v_linear_bwd_weight: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const int splits = tn_splits(M, K, N);
+  int rows_per_split = cdiv(M, splits);
+  rows_per_split = round_up(rows_per_split, TM);
+  float* slab = (float*)workspace;
+  float* slab_db = db ? slab + (size_t)splits * N * K : nullptr;
+  RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
+  dim3 grid(cdiv(N, 64), cdiv(K, 64), splits);
+  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
+                     slab_db, M, K, N, rows_per_split);
+  G2V_CHECK_LAUNCH();
+  const int64_t n = (int64_t)N * K;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, splits, n, dw,
+                     accumulate);
+  G2V_CHECK_LAUNCH();
+  if (db) {
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, slab_db, splits,
+                       (int64_t)N, db, accumulate);
+    G2V_CHECK_LAUNCH();
+  }
+  return G2V_OK;
+}

@@ -1,0 +1,280 @@
+// misc.hip -- custom_loss (K10), fused clip+Adam (K11), keep-mask generator, small helpers, error plumbing.
+#include <stdarg.h>
+
+#include "common.hpp"
+
+namespace g2v {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+// ---- custom_loss: train_eval/train_seq2seq.py:40-88 ----------------------------------------------------
+// One thread per (b,d) column walks the T frames twice (norm over TIME, :70).  y is (T,B,D), target (B,T,D).
+__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restrict__ y, const float* __restrict__ tgt,
+                                                          float* __restrict__ dy, float* __restrict__ partial, float c1,
+                                                          float c2, float c3, float g_scale, int T, int B, int D) {
+  __shared__ float red[3][4];
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t BD = (int64_t)B * D;
+  float l1 = 0.f, cont = 0.f, nrm = 0.f;
+  if (col < BD) {
+    const int b = (int)(col / D), d = (int)(col - (int64_t)b * D);
+    float ss = 0.f, prev = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const float v = y[(int64_t)t * BD + col];
+      const float tv = tgt[((int64_t)b * T + t) * D + d];
+      l1 += fabsf(v - tv);
+      if (t > 0) cont += fabsf(v - prev);
+      ss += v * v;
+      prev = v;
+    }
+    nrm = sqrtf(ss);
+    if (dy) {
+      const float inv = (nrm > 0.f) ? 1.0f / nrm : 0.f;
+      float vm = 0.f, v = y[col], vp;
+      for (int t = 0; t < T; ++t) {
+        vp = (t + 1 < T) ? y[(int64_t)(t + 1) * BD + col] : 0.f;
+        const float tv = tgt[((int64_t)b * T + t) * D + d];
+        float g = c1 * sgnf(v - tv) - c3 * v * inv;
+        if (t > 0) g += c2 * sgnf(v - vm);
+        if (t + 1 < T) g -= c2 * sgnf(vp - v);
+        dy[(int64_t)t * BD + col] = g * g_scale;
+        vm = v;
+        v = vp;
+      }
+    }
+  }
+  l1 = wave_sum(l1);
+  cont = wave_sum(cont);
+  nrm = wave_sum(nrm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = l1;
+    red[1][wave] = cont;
+    red[2][wave] = nrm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    partial[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
+__global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ terms,
+                                            float c1, float c2, float c3) {
+  __shared__ float red[3][4];
+  float s[3] = {0.f, 0.f, 0.f};
+  for (int k = threadIdx.x; k < nblk; k += 256)
+    for (int j = 0; j < 3; ++j) s[j] += partial[(int64_t)k * 3 + j];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int j = 0; j < 3; ++j) {
+    s[j] = wave_sum(s[j]);
+    if (lane == 0) red[j][wave] = s[j];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float l1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * c1;
+    const float cont = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * c2;
+    const float var = -((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * c3;
+    terms[0] = l1 + cont + var;
+    terms[1] = l1;
+    terms[2] = cont;
+    terms[3] = var;
+  }
+}
+
+// ---- clip_grad_norm_ + Adam -------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
+                                                    int32_t* __restrict__ step_counter) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) s += g[e] * g[e];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (blockIdx.x == 0) step_counter[0] += 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                        float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                        const float* __restrict__ partial, int npart,
+                                                        const int32_t* __restrict__ step_counter,
+                                                        float* __restrict__ gnorm_out, float max_norm, float grad_scale,
+                                                        float lr, float b1, float b2, float eps) {
+  __shared__ float red[4];
+  __shared__ float bc;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < npart; k += 256) s += partial[k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) bc = sqrtf((red[0] + red[1]) + (red[2] + red[3]));
+  __syncthreads();
+  const float total = bc * grad_scale;       // norm of the (scaled) gradient
+  float coef = max_norm / (total + 1e-6f);
+  coef = fminf(coef, 1.0f) * grad_scale;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && gnorm_out) gnorm_out[0] = total;
+  const int t = step_counter[0];
+  const float bc1 = (float)(1.0 - pow((double)b1, (double)t));
+  const float bc2s = (float)sqrt(1.0 - pow((double)b2, (double)t));
+  const float step_size = lr / bc1;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float gg = g[e] * coef;
+    const float mm = m[e] * b1 + (1.0f - b1) * gg;
+    const float vv = v[e] * b2 + (1.0f - b2) * gg * gg;
+    m[e] = mm;
+    v[e] = vv;
+    const float denom = sqrtf(vv) / bc2s + eps;
+    p[e] = p[e] - step_size * (mm / denom);
+  }
+}
+
+// ---- philox4x32-10 keep masks ------------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+__global__ void keep_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float keep_prob, uint64_t seed,
+                                 const int64_t* __restrict__ offset_counter) {
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one philox block = 4 outputs
+  if (g * 4 >= n) return;
+  const uint64_t off = (uint64_t)offset_counter[0];
+  uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)off, (uint32_t)(off >> 32)};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t e = g * 4 + j;
+    if (e < n) keep[e] = ((float)(c[j] >> 8) * (1.0f / 16777216.0f) < keep_prob) ? 1 : 0;
+  }
+}
+__global__ void tick_kernel(int64_t* c) { c[0] += 1; }
+
+__global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
+}
+
+__global__ void add_halves_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
+                                  float* __restrict__ out, int64_t ldo, int64_t M, int H) {
+  const int64_t total = M * H;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / H;
+    const int c = (int)(e - r * H);
+    out[r * ldo + c] = a[r * lda + c] + b[r * ldb + c];
+  }
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+extern "C" const char* g2v_version(void) { return "g2v-hip 0.1 (gfx950, fp32 MFMA 16x16x4)"; }
+extern "C" const char* g2v_last_error(void) { return g_err; }
+extern "C" int g2v_device_ok(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return 0;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, 0) != hipSuccess) return 0;
+  return strstr(prop.gcnArchName, "gfx950") != nullptr ? 1 : 0;
+}
+
+extern "C" int g2v_custom_loss_blocks(int B, int D) { return (B > 0 && D > 0) ? cdiv((int64_t)B * D, 256) : 0; }
+
+extern "C" int g2v_custom_loss_fwd_bwd(const float* y, const float* target, float* dy, float* terms, float* partial,
+                                       float w_l1, float w_cont, float w_var, float g_scale, int T, int B, int D,
+                                       g2v_stream_t stream) {
+  G2V_REQUIRE(y && target && terms && partial, "null pointer");
+  G2V_REQUIRE(T > 0 && B > 0 && D > 0, "bad size");
+  const float n = (float)T * (float)B * (float)D;
+  const float c1 = w_l1 / n, c2 = w_cont / n, c3 = w_var / n;
+  const int nblk = g2v_custom_loss_blocks(B, D);
+  hipLaunchKernelGGL(custom_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, c1, c2,
+                     c3, g_scale, T, B, D);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(custom_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, terms, c1,
+                     c2, c3);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_adam_blocks(int64_t n) {
+  if (n <= 0) return 0;
+  int64_t b = (n + 1023) / 1024;
+  return (int)(b > 1024 ? 1024 : b);
+}
+
+extern "C" int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float* partial,
+                                  int32_t* step_counter, float* gnorm_out, float max_norm, float grad_scale, float lr,
+                                  float beta1, float beta2, float eps, g2v_stream_t stream) {
+  G2V_REQUIRE(param && grad && m && v && partial && step_counter, "null pointer");
+  G2V_REQUIRE(n > 0, "bad size");
+  const int nblk = g2v_adam_blocks(n);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, n, partial, step_counter);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, partial,
+                     nblk, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int64_t* offset_counter,
+                             g2v_stream_t stream) {
+  G2V_REQUIRE(keep && offset_counter, "null pointer");
+  G2V_REQUIRE(n > 0, "bad size");
+  const int64_t nthreads = (n + 3) / 4;
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
+                     seed, offset_counter);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, offset_counter);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(p, "null pointer");
+  if (n <= 0) return G2V_OK;
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream) {
+  G2V_REQUIRE(in && out, "null pointer");
+  G2V_REQUIRE(rows > 0 && cols > 0, "bad size");
+  launch_transpose(in, out, rows, cols, (hipStream_t)stream);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_add_halves(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                              int64_t M, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(a && b && out, "null pointer");
+  G2V_REQUIRE(M > 0 && H > 0, "bad size");
+  int blocks = cdiv(M * H, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(add_halves_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, M, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}

@@ -1,0 +1,384 @@
+// vq.hip -- EMA vector quantiser kernels (K1..K5') for gfx950.
+//
+// Replaces VQ_Payam_EMA.forward and its autograd (model/Autoencoder_VQVAE_model.py:1217-1296),
+// VQ_Payam (:1114-1173) and the code-assignment call sites (lmdb_data_loader.py:1274-1281,
+// Clustering.py:151-157).
+//
+//   vq_assign_kernel   d = ||x||^2 + ||W||^2 - 2 x W^T on v_mfma_f32_16x16x4_f32 (exact fp32 fma
+//                      chains, same algebraic form as :1234-1238 so that near-ties round alike),
+//                      running argmin in registers (lowest index wins ties, = torch.argmin),
+//                      q = W[idx], straight-through output z + (q - z), per-block SSE partial.
+//                      16 rows per workgroup, the K codes are split over the 4 waves; the codebook
+//                      (K*E*4 B, 256 KB at K=512,E=128) is streamed from L2 as MFMA A-fragments.
+//   vq_stats_kernel    cnt / dw as a one-hot^T x flat contraction on MFMA, the one-hot generated
+//                      from idx on the fly, split over rows into slabs that are summed in order
+//                      (deterministic; no float atomics, no contention when the codebook collapses).
+//   vq_ema_*           K4 (EMA + Laplace smoothing + codebook refresh) and the loss / perplexity scalars.
+//   vq_bwd_kernel      K5' straight-through + commitment gradient.
+#include "common.hpp"
+
+namespace g2v {
+
+constexpr int VQ_ROWS = 16;
+
+__global__ void code_sqnorm_kernel(const float* __restrict__ W, float* __restrict__ out, int K, int E) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= K) return;
+  const float* w = W + (int64_t)wave * E;
+  float s = 0.f;
+  for (int e = lane; e < E; e += 64) s += w[e] * w[e];
+  s = wave_sum(s);
+  if (lane == 0) out[wave] = s;
+}
+
+__device__ __forceinline__ void argmin_merge(float& d, int& k, float d2, int k2) {
+  if (d2 < d || (d2 == d && k2 < k)) {
+    d = d2;
+    k = k2;
+  }
+}
+
+__global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict__ flat, const float* __restrict__ z,
+                                                        const float* __restrict__ W, const float* __restrict__ wsq,
+                                                        int64_t* __restrict__ idx_out, float* __restrict__ quant,
+                                                        float* __restrict__ dist_min, float* __restrict__ sse_partial,
+                                                        int N, int E, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Ep = (E + 15) & ~15, ldx = Ep + 4;
+  float* Xs = smem;                       // [16][ldx]
+  float* xx = Xs + VQ_ROWS * ldx;         // [16]
+  float* wbest_d = xx + 16;               // [4][16]
+  int* wbest_k = (int*)(wbest_d + 64);    // [4][16]
+  int* best_k = wbest_k + 64;             // [16]
+  float* red = (float*)(best_k + 16);     // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  stage_rows(Xs, ldx, Ep, flat + (int64_t)r0 * E, E, nrows, E, tid, 256);
+  __syncthreads();
+  {  // ||x||^2 per row: 16 threads per row
+    const int row = tid >> 4, part = tid & 15;
+    float s = 0.f;
+    for (int k = part; k < E; k += 16) s += Xs[row * ldx + k] * Xs[row * ldx + k];
+    s = reduce16(s);
+    if (part == 0) xx[row] = s;
+  }
+  __syncthreads();
+
+  const int i = lane & 15, q = lane >> 4;
+  const bool wvec = ptr_vec_ok(W, E);
+  const float xr = xx[i];
+  float bd = INFINITY;
+  int bk = 0x7fffffff;
+  const int ntile = (K + 15) >> 4;
+  for (int kt = wave; kt < ntile; kt += 4) {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int nvalid = min(16, K - 16 * kt);
+    wave_gemm<1>(acc, W, (int64_t)E, wvec, 16 * kt, 16, nvalid, E, Xs, ldx, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int code = 16 * kt + 4 * q + r;
+      if (code < K) {
+        const float d = (xr + wsq[code]) - 2.0f * acc[0][r];   // (||x||^2 + ||W||^2) - 2 x.W  (:1234-1238)
+        if (d < bd) {
+          bd = d;
+          bk = code;
+        }
+      }
+    }
+  }
+  // merge the 4 lanes (q = 0..3) that hold the same row
+  {
+    float d2 = __shfl_xor(bd, 16);
+    int k2 = __shfl_xor(bk, 16);
+    argmin_merge(bd, bk, d2, k2);
+    d2 = __shfl_xor(bd, 32);
+    k2 = __shfl_xor(bk, 32);
+    argmin_merge(bd, bk, d2, k2);
+  }
+  if (lane < 16) {
+    wbest_d[wave * 16 + lane] = bd;
+    wbest_k[wave * 16 + lane] = bk;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float d = wbest_d[tid];
+    int k = wbest_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) argmin_merge(d, k, wbest_d[w * 16 + tid], wbest_k[w * 16 + tid]);
+    best_k[tid] = k;
+    if (tid < nrows) {
+      idx_out[r0 + tid] = (int64_t)k;
+      if (dist_min) dist_min[r0 + tid] = d;
+    }
+  }
+  __syncthreads();
+  if (quant) {
+    const int row = tid >> 4, part = tid & 15;
+    float sse = 0.f;
+    if (row < nrows) {
+      const float* wq = W + (int64_t)best_k[row] * E;
+      const float* zr = z + (int64_t)(r0 + row) * E;
+      float* qo = quant + (int64_t)(r0 + row) * E;
+      for (int k = part; k < E; k += 16) {
+        const float zv = zr[k];
+        const float diff = wq[k] - zv;
+        qo[k] = zv + diff;                 // inputs + (quantized - inputs).detach()  (:1292)
+        sse += diff * diff;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// ---- K3: slab[split] = onehot(idx)^T (K x rows) * flat (rows x E); cnt via a ones column --------------
+constexpr int SM = 32, SLD = 64 + 16;
+__global__ __launch_bounds__(256) void vq_stats_kernel(const int64_t* __restrict__ idx, const float* __restrict__ flat,
+                                                       float* __restrict__ slab_dw, float* __restrict__ slab_cnt,
+                                                       int N, int E, int K, int rows_per_split) {
+  __shared__ __attribute__((aligned(16))) float Xs[SM * SLD];
+  __shared__ int Is[SM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 64, e0 = blockIdx.y * 64, split = blockIdx.z;
+  const int mb = split * rows_per_split, me = min(N, mb + rows_per_split);
+  const int i = lane & 15, q = lane >> 4;
+  f32x4 acc[4], accn = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int mycode = c0 + 16 * wave + i;
+  for (int mc = mb; mc < me; mc += SM) {
+    const int c = tid & 63;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = (tid >> 6) + 4 * it, m = mc + r;
+      Xs[r * SLD + c] = (m < me && e0 + c < E) ? flat[(int64_t)m * E + e0 + c] : 0.f;
+    }
+    if (tid < SM) Is[tid] = (mc + tid < me) ? (int)idx[mc + tid] : -1;
+    __syncthreads();
+#pragma unroll
+    for (int s4 = 0; s4 < SM; s4 += 4) {
+      const float a = (Is[s4 + q] == mycode) ? 1.0f : 0.0f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = mfma16(a, Xs[(s4 + q) * SLD + 16 * t + i], acc[t]);
+      if (blockIdx.y == 0) accn = mfma16(a, 1.0f, accn);
+    }
+    __syncthreads();
+  }
+  float* sl = slab_dw + (int64_t)split * K * E;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = e0 + 16 * t + i;
+    if (e >= E) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int code = c0 + 16 * wave + 4 * q + r;
+      if (code < K) sl[(int64_t)code * E + e] = acc[t][r];
+    }
+  }
+  if (blockIdx.y == 0 && i == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int code = c0 + 16 * wave + 4 * q + r;
+      if (code < K) slab_cnt[(int64_t)split * K + code] = accn[r];
+    }
+  }
+}
+
+static int stats_splits(int N, int E, int K) {
+  const int tiles = cdiv(K, 64) * cdiv(E, 64);
+  int splits = cdiv(512, tiles);
+  const int max_splits = cdiv(N, 2 * SM);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  return splits;
+}
+
+// ---- K4 scalars: cluster-size EMA + Laplace smoothing, loss, perplexity (one workgroup) --------------
+__global__ __launch_bounds__(1024) void vq_ema_scalars_kernel(const float* __restrict__ stats,
+                                                              const float* __restrict__ sse_partial, int n_sse,
+                                                              float* __restrict__ cs, float* __restrict__ scalars,
+                                                              int N_loss, int N_cnt, int E, int K, float beta,
+                                                              float decay, float eps, int update) {
+  __shared__ float red[16];
+  __shared__ float bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // perplexity = exp(-sum p log(p + 1e-10)), p = cnt / N   (:1293-1294)
+  float ent = 0.f, nsum = 0.f, sse = 0.f;
+  for (int k = tid; k < K; k += 1024) {
+    const float cnt = stats[k];
+    const float p = cnt / (float)N_cnt;
+    ent += p * logf(p + 1e-10f);
+    if (update) {
+      const float c = cs[k] * decay + (1.0f - decay) * cnt;   // :1263-1265
+      cs[k] = c;
+      nsum += c;
+    }
+  }
+  for (int j = tid; j < n_sse; j += 1024) sse += sse_partial[j];
+  ent = wave_sum(ent);
+  nsum = wave_sum(nsum);
+  sse = wave_sum(sse);
+  if (lane == 0) red[wave] = ent;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    scalars[1] = expf(-s);
+  }
+  __syncthreads();
+  if (lane == 0) red[wave] = sse;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    scalars[0] = beta * (s / ((float)N_loss * (float)E));     // beta * mse(q, z)  (:1285-1289)
+  }
+  __syncthreads();
+  if (update) {
+    if (lane == 0) red[wave] = nsum;
+    __syncthreads();
+    if (tid == 0) {
+      float s = 0.f;
+      for (int w = 0; w < 16; ++w) s += red[w];
+      bc[0] = s;
+    }
+    __syncthreads();
+    const float n = bc[0];
+    for (int k = tid; k < K; k += 1024) cs[k] = (cs[k] + eps) / (n + (float)K * eps) * n;   // :1268-1273
+  }
+}
+
+// ---- K4 rows: ema_w, codebook, ||W||^2 (one wave per code) -------------------------------------------
+__global__ void vq_ema_rows_kernel(const float* __restrict__ stats, const float* __restrict__ cs,
+                                   float* __restrict__ ema_w, float* __restrict__ W, float* __restrict__ wsq, int E,
+                                   int K, float decay) {
+  const int code = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (code >= K) return;
+  const float* dw = stats + K + (int64_t)code * E;
+  float* ew = ema_w + (int64_t)code * E;
+  float* w = W + (int64_t)code * E;
+  const float c = cs[code];
+  float s = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    const float v = ew[e] * decay + (1.0f - decay) * dw[e];   // :1276-1278
+    ew[e] = v;
+    const float wv = v / c;                                    // :1280-1282
+    w[e] = wv;
+    s += wv * wv;
+  }
+  s = wave_sum(s);
+  if (lane == 0) wsq[code] = s;
+}
+
+__global__ void vq_bwd_kernel(const float* __restrict__ gq, const float* __restrict__ gloss,
+                              const float* __restrict__ z, const float* __restrict__ W,
+                              const int64_t* __restrict__ idx, float* __restrict__ gz, int64_t total, int E,
+                              float coef) {
+  const float c = gloss ? gloss[0] * coef : 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = e / E;
+    const int col = (int)(e - row * E);
+    const float q = W[idx[row] * E + col];
+    float g = c * (z[e] - q);
+    if (gq) g += gq[e];
+    gz[e] = g;
+  }
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+extern "C" int g2v_vq_assign_blocks(int N) { return N > 0 ? cdiv(N, VQ_ROWS) : 0; }
+
+extern "C" int g2v_vq_code_sqnorm(const float* codebook, float* code_sqnorm, int K, int E, g2v_stream_t stream) {
+  G2V_REQUIRE(codebook && code_sqnorm, "null pointer");
+  G2V_REQUIRE(K > 0 && E > 0, "non-positive size");
+  hipLaunchKernelGGL(code_sqnorm_kernel, dim3(cdiv((int64_t)K * 64, 256)), dim3(256), 0, (hipStream_t)stream, codebook,
+                     code_sqnorm, K, E);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float* codebook, const float* code_sqnorm,
+                                 int64_t* idx, float* quantized, float* dist_min, float* sse_partial, int N, int E,
+                                 int K, g2v_stream_t stream) {
+  G2V_REQUIRE(flat && codebook && code_sqnorm && idx, "null pointer");
+  G2V_REQUIRE(!quantized || z, "z required with quantized");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  const int Ep = (E + 15) & ~15;
+  const size_t lds = (size_t)(VQ_ROWS * (Ep + 4) + 16 + 64 + 64 + 16 + 4) * sizeof(float);
+  G2V_REQUIRE(lds <= 160 * 1024, "embedding dim too large for LDS");
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)vq_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(vq_assign_kernel, dim3(cdiv(N, VQ_ROWS)), dim3(256), lds, (hipStream_t)stream, flat, z, codebook,
+                     code_sqnorm, idx, quantized, dist_min, sse_partial, N, E, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" size_t g2v_vq_stats_workspace(int N, int E, int K) {
+  if (N <= 0 || E <= 0 || K <= 0) return 0;
+  return (size_t)stats_splits(N, E, K) * ((size_t)K * E + K) * sizeof(float);
+}
+
+extern "C" int g2v_vq_stats(const int64_t* idx, const float* flat, float* stats, int N, int E, int K, void* workspace,
+                            size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(idx && flat && stats && workspace, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (workspace_bytes < g2v_vq_stats_workspace(N, E, K)) {
+    set_error("g2v_vq_stats: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const int splits = stats_splits(N, E, K);
+  const int rows_per_split = round_up(cdiv(N, splits), SM);
+  float* slab_dw = (float*)workspace;
+  float* slab_cnt = slab_dw + (size_t)splits * K * E;
+  hipLaunchKernelGGL(vq_stats_kernel, dim3(cdiv(K, 64), cdiv(E, 64), splits), dim3(256), 0, (hipStream_t)stream, idx,
+                     flat, slab_dw, slab_cnt, N, E, K, rows_per_split);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, slab_cnt, splits,
+                     (int64_t)K, stats, 0);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, (hipStream_t)stream, slab_dw,
+                     splits, (int64_t)K * E, stats + K, 0);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_ema_update(const float* stats, const float* sse_partial, int n_sse_partial,
+                                 float* ema_cluster_size, float* ema_w, float* codebook, float* code_sqnorm,
+                                 float* scalars, int N_loss, int N_cnt, int E, int K, float beta, float decay,
+                                 float eps, int update, g2v_stream_t stream) {
+  G2V_REQUIRE(stats && scalars, "null pointer");
+  G2V_REQUIRE(!update || (ema_cluster_size && ema_w && codebook && code_sqnorm), "null EMA state");
+  G2V_REQUIRE(N_loss > 0 && N_cnt > 0 && E > 0 && K > 0, "non-positive size");
+  hipLaunchKernelGGL(vq_ema_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, sse_partial,
+                     sse_partial ? n_sse_partial : 0, ema_cluster_size, scalars, N_loss, N_cnt, E, K, beta, decay, eps,
+                     update);
+  G2V_CHECK_LAUNCH();
+  if (update) {
+    hipLaunchKernelGGL(vq_ema_rows_kernel, dim3(cdiv((int64_t)K * 64, 256)), dim3(256), 0, (hipStream_t)stream, stats,
+                       ema_cluster_size, ema_w, codebook, code_sqnorm, E, K, decay);
+    G2V_CHECK_LAUNCH();
+  }
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, const float* codebook,
+                          const int64_t* idx, float* gz, int N, int E, float beta, g2v_stream_t stream) {
+  G2V_REQUIRE(z && codebook && idx && gz, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0, "non-positive size");
+  const int64_t total = (int64_t)N * E;
+  const float coef = 2.0f * beta / ((float)N * (float)E);
+  int blocks = cdiv(total, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(vq_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_quantized, g_loss, z, codebook,
+                     idx, gz, total, E, coef);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}

@@ -1,0 +1,264 @@
+"""Tensor-level wrappers over the C-ABI (include/g2v.h).  PyTorch is plumbing only: it owns device
+memory and the stream; every number is produced by the HIP kernels in libg2v_hip.so.
+
+All tensors must live on the GPU, be fp32 (uint8 masks, int64 indices, int32 lengths) and contiguous
+unless a stride argument says otherwise.  Nothing here falls back to torch arithmetic."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DecGrads, DecSaved, DecWeights, check
+
+
+def _lib_():
+    return _lib.load()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.G2VLibraryError(f"{name} must be a GPU tensor: the g2v kernels have no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name} must be contiguous")
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
+    """A reusable byte buffer per (device, tag); grows monotonically (allocation never happens inside the C-ABI)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------ linear
+def linear_fwd(x, w, bias=None, act=0, *, M=None, ldx=None, row_map=None, keep=None, scale=1.0, out=None, ldy=None):
+    """y = act(x w^T + b).  row_map = (rows_inner, stride_outer, stride_inner) in elements."""
+    N, K = w.shape
+    if M is None:
+        M = x.numel() // K
+    if ldx is None:
+        ldx = K
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    if ldy is None:
+        ldy = N
+    ri, so, si = row_map if row_map is not None else (0, 0, 0)
+    check(_lib_().g2v_linear_fwd(_p(x), ldx, ri, so, si, _p(keep), float(scale), _p(_chk(w, name="w")), _p(bias),
+                                 _p(out), ldy, M, K, N, act, _stream()), "linear_fwd")
+    return out
+
+
+def linear_bwd_data(dy, w, *, M=None, lddy=None, out=None, lddx=None, accumulate=False):
+    N, K = w.shape
+    if M is None:
+        M = dy.numel() // N
+    if lddy is None:
+        lddy = N
+    if out is None:
+        out = torch.empty((M, K), dtype=torch.float32, device=dy.device)
+    if lddx is None:
+        lddx = K
+    check(_lib_().g2v_linear_bwd_data(_p(dy), lddy, _p(w), _p(out), lddx, M, K, N, int(accumulate), _stream()),
+          "linear_bwd_data")
+    return out
+
+
+def linear_bwd_weight(dy, x, N, K, *, M=None, lddy=None, ldx=None, row_map=None, keep=None, scale=1.0,
+                      dw=None, db=None, want_bias=True, accumulate=False):
+    if M is None:
+        M = dy.numel() // N
+    if lddy is None:
+        lddy = N
+    if ldx is None:
+        ldx = K
+    dev = dy.device
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    if db is None and want_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dev)
+    lib = _lib_()
+    nbytes = lib.g2v_linear_bwd_weight_workspace(M, K, N)
+    ws = workspace(nbytes, dev, "bwdw")
+    ri, so, si = row_map if row_map is not None else (0, 0, 0)
+    check(lib.g2v_linear_bwd_weight(_p(dy), lddy, _p(x), ldx, ri, so, si, _p(keep), float(scale), _p(dw), _p(db),
+                                    M, K, N, int(accumulate), _p(ws), ws.numel(), _stream()), "linear_bwd_weight")
+    return dw, db
+
+
+# ------------------------------------------------------------------------------------------ quantiser
+def vq_code_sqnorm(codebook, out=None):
+    K, E = codebook.shape
+    if out is None:
+        out = torch.empty((K,), dtype=torch.float32, device=codebook.device)
+    check(_lib_().g2v_vq_code_sqnorm(_p(_chk(codebook)), _p(out), K, E, _stream()), "vq_code_sqnorm")
+    return out
+
+
+def vq_assign(flat, z, codebook, code_sqnorm, want_quantized=True, want_dist=False):
+    """-> idx (N) int64, quantized (N,E) | None, dist_min (N) | None, sse_partial | None"""
+    N, E = flat.shape
+    K = codebook.shape[0]
+    dev = flat.device
+    lib = _lib_()
+    idx = torch.empty((N,), dtype=torch.int64, device=dev)
+    quant = torch.empty((N, E), dtype=torch.float32, device=dev) if want_quantized else None
+    dmin = torch.empty((N,), dtype=torch.float32, device=dev) if want_dist else None
+    sse = torch.empty((lib.g2v_vq_assign_blocks(N),), dtype=torch.float32, device=dev) if want_quantized else None
+    check(lib.g2v_vq_assign_fwd(_p(_chk(flat)), _p(z), _p(_chk(codebook)), _p(code_sqnorm), _p(idx), _p(quant),
+                                _p(dmin), _p(sse), N, E, K, _stream()), "vq_assign_fwd")
+    return idx, quant, dmin, sse
+
+
+def vq_stats(idx, flat, K, out=None):
+    N, E = flat.shape
+    dev = flat.device
+    lib = _lib_()
+    if out is None:
+        out = torch.empty((K + K * E,), dtype=torch.float32, device=dev)
+    ws = workspace(lib.g2v_vq_stats_workspace(N, E, K), dev, "vqstats")
+    check(lib.g2v_vq_stats(_p(_chk(idx, torch.int64)), _p(_chk(flat)), _p(out), N, E, K, _p(ws), ws.numel(),
+                           _stream()), "vq_stats")
+    return out
+
+
+def vq_ema_update(stats, sse_partial, ema_cluster_size, ema_w, codebook, code_sqnorm, N_loss, N_cnt, E, K,
+                  beta, decay, eps, update, scalars=None):
+    if scalars is None:
+        scalars = torch.empty((2,), dtype=torch.float32, device=stats.device)
+    check(_lib_().g2v_vq_ema_update(_p(stats), _p(sse_partial), 0 if sse_partial is None else sse_partial.numel(),
+                                    _p(ema_cluster_size), _p(ema_w), _p(codebook), _p(code_sqnorm), _p(scalars),
+                                    N_loss, N_cnt, E, K, float(beta), float(decay), float(eps), int(update),
+                                    _stream()), "vq_ema_update")
+    return scalars
+
+
+def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta):
+    N, E = z.shape
+    gz = torch.empty_like(z)
+    check(_lib_().g2v_vq_bwd(_p(g_quantized), _p(g_loss), _p(_chk(z)), _p(_chk(codebook)), _p(idx), _p(gz), N, E,
+                             float(beta), _stream()), "vq_bwd")
+    return gz
+
+
+# ------------------------------------------------------------------------------------------ GRU direction
+def gru_seq_fwd(gi, w_hh, b_hh, T, B, H, *, h0=None, lengths=None, reverse=False, hs=None, hs_ld=None,
+                save_gates=True):
+    dev = gi.device
+    if hs is None:
+        hs = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        hs_ld = H
+    h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
+    gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev) if save_gates else None
+    check(_lib_().g2v_gru_seq_fwd(_p(_chk(gi)), _p(_chk(w_hh)), _p(b_hh), _p(h0), _p(lengths), int(reverse),
+                                  _p(hs), hs_ld, _p(h_n), _p(gates), T, B, H, _stream()), "gru_seq_fwd")
+    return hs, h_n, gates
+
+
+def gru_seq_bwd(d_hs, d_hs_ld, d_hn, hs, hs_ld, h0, gates, w_hh, T, B, H, *, lengths=None, reverse=False,
+                want_dh0=False):
+    dev = hs.device
+    lib = _lib_()
+    dgi = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+    dgh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+    dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if want_dh0 else None
+    ws = workspace(lib.g2v_gru_seq_bwd_workspace(H), dev, "grubwd")
+    check(lib.g2v_gru_seq_bwd(_p(d_hs), d_hs_ld, _p(d_hn), _p(hs), hs_ld, _p(h0), _p(gates), _p(w_hh), _p(lengths),
+                              int(reverse), _p(dgi), _p(dgh), _p(dh0), T, B, H, _p(ws), ws.numel(), _stream()),
+          "gru_seq_bwd")
+    return dgi, dgh, dh0
+
+
+# ------------------------------------------------------------------------------------------ decoder rollout
+def dec_weights_struct(wd: dict) -> DecWeights:
+    s = DecWeights()
+    for name, _ in DecWeights._fields_:
+        setattr(s, name, _p(wd[name]))
+    return s
+
+
+def struct_from(cls, d: dict):
+    s = cls()
+    for name, _ in cls._fields_:
+        setattr(s, name, _p(d.get(name)))
+    return s
+
+
+def dec_rollout_blocks(B):
+    return _lib_().g2v_dec_rollout_blocks(B)
+
+
+def dec_rollout_fwd(target, h_init, wstruct, saved: dict, keep95, keep_l0, p_drop, n_pre, conditioned, training,
+                    T, B, D, H):
+    sv = struct_from(DecSaved, saved)
+    check(_lib_().g2v_dec_rollout_fwd(_p(_chk(target)), _p(_chk(h_init)), C.byref(wstruct), C.byref(sv),
+                                      _p(_chk(keep95, torch.uint8)), _p(keep_l0), float(p_drop), int(n_pre),
+                                      int(conditioned), int(training), T, B, D, H, _stream()), "dec_rollout_fwd")
+
+
+def dec_rollout_bwd(wstruct, saved: dict, grads: dict, keep95, keep_l0, p_drop, n_pre, conditioned, T, B, D, H):
+    lib = _lib_()
+    sv = struct_from(DecSaved, saved)
+    gr = struct_from(DecGrads, grads)
+    ws = workspace(lib.g2v_dec_rollout_bwd_workspace(D, H), grads["dy"].device, "decbwd")
+    check(lib.g2v_dec_rollout_bwd(C.byref(wstruct), C.byref(sv), C.byref(gr), _p(keep95), _p(keep_l0),
+                                  float(p_drop), int(n_pre), int(conditioned), T, B, D, H, _p(ws), ws.numel(),
+                                  _stream()), "dec_rollout_bwd")
+
+
+# ------------------------------------------------------------------------------------------ loss / optimiser / rng
+def custom_loss_fwd_bwd(y_tbd, target_btd, w_l1, w_cont, w_var, g_scale=1.0, want_grad=True):
+    T, B, D = y_tbd.shape
+    dev = y_tbd.device
+    lib = _lib_()
+    dy = torch.empty_like(y_tbd) if want_grad else None
+    terms = torch.empty((4,), dtype=torch.float32, device=dev)
+    partial = torch.empty((lib.g2v_custom_loss_blocks(B, D) * 3,), dtype=torch.float32, device=dev)
+    check(lib.g2v_custom_loss_fwd_bwd(_p(_chk(y_tbd)), _p(_chk(target_btd)), _p(dy), _p(terms), _p(partial),
+                                      float(w_l1), float(w_cont), float(w_var), float(g_scale), T, B, D, _stream()),
+          "custom_loss_fwd_bwd")
+    return terms, dy
+
+
+def clip_adam_step(param, grad, m, v, step_counter, partial, gnorm_out, max_norm, grad_scale, lr, b1, b2, eps):
+    check(_lib_().g2v_clip_adam_step(_p(_chk(param)), _p(_chk(grad)), _p(m), _p(v), param.numel(), _p(partial),
+                                     _p(step_counter), _p(gnorm_out), float(max_norm), float(grad_scale), float(lr),
+                                     float(b1), float(b2), float(eps), _stream()), "clip_adam_step")
+
+
+def adam_blocks(n):
+    return _lib_().g2v_adam_blocks(n)
+
+
+def keep_mask(out_u8, keep_prob, seed, offset_counter):
+    check(_lib_().g2v_keep_mask(_p(_chk(out_u8, torch.uint8)), out_u8.numel(), float(keep_prob), int(seed),
+                                _p(offset_counter), _stream()), "keep_mask")
+    return out_u8
+
+
+def fill(t, v):
+    check(_lib_().g2v_fill_f32(_p(t), float(v), t.numel(), _stream()), "fill")
+    return t
+
+
+def add_halves(a, lda, b, ldb, out, ldo, M, H):
+    check(_lib_().g2v_add_halves(_p(a), lda, _p(b), ldb, _p(out), ldo, M, H, _stream()), "add_halves")
+    return out

@@ -1,0 +1,245 @@
+/* g2v.h -- C-ABI of the MI355X-native Gesture2Vec hot path (libg2v_hip.so).
+ *
+ * The reference (pjyazdian/Gesture2Vec) is pure Python on PyTorch: it has no FFI / plugin
+ * boundary of its own.  The boundary it DOES have is the Python operator
+ * surface (scripts/model/ classes, scripts/train_eval/train_seq2seq.py functions); each
+ * entry point below names the reference call site whose arithmetic it replaces.  The Python
+ * host in gesture2vec_amd/ binds these with ctypes (INTEGRATION.md shows the stub) and exposes
+ * the reference's own class / function names on top.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory (PyTorch-ROCm allocations);
+ *     the library never allocates, frees, synchronises or touches the default stream;
+ *   - `stream` is a hipStream_t passed as void*; all work is stream-ordered, capture-safe
+ *     (hipGraph), re-entrant per stream;
+ *   - return value: 0 = success, negative = G2V_ERR_*; g2v_last_error() gives a message;
+ *   - all arithmetic is IEEE fp32 (MFMA v_mfma_f32_16x16x4_f32 = exact fp32 fma chains);
+ *     code indices are int64 (the reference's torch.argmin dtype), masks are uint8 keep-masks;
+ *   - matrices are row-major; "ld" = row stride in elements;
+ *   - sequence tensors are (T,B,F) "time-major" unless stated.
+ */
+#ifndef G2V_H
+#define G2V_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* g2v_stream_t; /* hipStream_t */
+
+#define G2V_OK 0
+#define G2V_ERR_ARG (-1)         /* bad argument (null pointer, non-positive size, misalignment) */
+#define G2V_ERR_LAUNCH (-2)      /* hipLaunch / runtime error */
+#define G2V_ERR_WORKSPACE (-3)   /* workspace too small */
+#define G2V_ERR_UNSUPPORTED (-4) /* configuration outside what the kernels implement */
+
+const char* g2v_version(void);
+const char* g2v_last_error(void);
+/* 1 when a gfx950 device is visible to this process, else 0 (never throws). */
+int g2v_device_ok(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layers.  Replaces nn.Linear call sites on the path:
+ *   EncoderRNN.in_layer            model/Autoencoder_VQVAE_model.py:93
+ *   VQ_Payam_EMA.pre_linear        model/Autoencoder_VQVAE_model.py:1230
+ *   GRU input projections          (nn.GRU internals, :94, text2embedding_model.py:131)
+ *   DAE_Network encoder/decoder    model/DAE_model.py:107-110
+ * y[m, n] = act( sum_k xin[m, k] * w[n, k] + bias[n] ),  xin = x * keep * x_scale (keep optional)
+ * Row m of x is read at  x + (m / rows_inner) * stride_outer + (m % rows_inner) * stride_inner
+ * when rows_inner > 0 (lets a (B,T,D) tensor be consumed in (T,B) row order without a copy),
+ * else at x + m * ldx.  x_keep (uint8, may be NULL) is indexed [m * K + k].
+ * act: 0 = identity, 1 = ReLU, 2 = tanh.
+ * ------------------------------------------------------------------------------------------ */
+int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
+                   const uint8_t* x_keep, float x_scale,
+                   const float* w, const float* bias, float* y, int64_t ldy,
+                   int M, int K, int N, int act, g2v_stream_t stream);
+
+/* dx[m, k] (+)= sum_n dy[m, n] * w[n, k]      (w is the forward weight, [N][K] row-major) */
+int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
+                        int M, int K, int N, int accumulate, g2v_stream_t stream);
+
+/* dw[n, k] (+)= sum_m dy[m, n] * xin[m, k];  db[n] (+)= sum_m dy[m, n]  (db may be NULL).
+ * xin addressing / keep-mask exactly as in g2v_linear_fwd.  Deterministic (split-M slabs + ordered
+ * reduction, no float atomics).  workspace >= g2v_linear_bwd_weight_workspace(M,K,N) bytes. */
+size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
+int g2v_linear_bwd_weight(const float* dy, int64_t lddy,
+                          const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
+                          const uint8_t* x_keep, float x_scale,
+                          float* dw, float* db, int M, int K, int N, int accumulate,
+                          void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Vector quantiser.  Replaces VQ_Payam_EMA.forward / its autograd
+ * (model/Autoencoder_VQVAE_model.py:1217-1296), also VQ_Payam (:1114-1173) and the
+ * code-assignment call sites (data_loader/lmdb_data_loader.py:1274-1281, Clustering.py:151-157).
+ *
+ * g2v_vq_assign_fwd   K1+K2+K5:  d = ||x||^2 + ||W||^2 - 2 x W^T  (x = flat rows, fp32 MFMA),
+ *                     idx = argmin_k d (lowest index on ties), q = W[idx],
+ *                     quantized = z + (q - z), sse_partial[block] = sum (q - z)^2.
+ *   flat      (N,E) rows the distances are computed from (pre_linear(z) for the EMA variant, :1230)
+ *   z         (N,E) raw rows used for the loss and the straight-through output (:1285,1292)
+ *   codebook  (K,E);  code_sqnorm (K) = sum_e W^2  (from g2v_vq_code_sqnorm)
+ *   idx (N) int64 out; quantized (N,E) out (may be NULL); dist_min (N) out (may be NULL);
+ *   sse_partial (g2v_vq_assign_blocks(N)) out (may be NULL when quantized is NULL).
+ * ------------------------------------------------------------------------------------------ */
+int g2v_vq_assign_blocks(int N);
+int g2v_vq_code_sqnorm(const float* codebook, float* code_sqnorm, int K, int E, g2v_stream_t stream);
+int g2v_vq_assign_fwd(const float* flat, const float* z, const float* codebook, const float* code_sqnorm,
+                      int64_t* idx, float* quantized, float* dist_min, float* sse_partial,
+                      int N, int E, int K, g2v_stream_t stream);
+
+/* K3: cnt[k] = #{i: idx[i]=k};  dw[k,:] = sum_{i: idx[i]=k} flat[i,:]   (:1265,1275).
+ * Deterministic one-hot^T x flat MFMA contraction (the one-hot is generated on the fly from idx).
+ * stats layout: [cnt (K) | dw (K*E)] contiguous fp32, so it can be all-reduced as one buffer. */
+size_t g2v_vq_stats_workspace(int N, int E, int K);
+int g2v_vq_stats(const int64_t* idx, const float* flat, float* stats /* K + K*E */, int N, int E, int K,
+                 void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* K4 + K5 scalars (:1263-1282, :1285-1294).  In place on ema_cluster_size (K), ema_w (K,E), codebook (K,E):
+ *   cs = cs*decay + (1-decay)*cnt; n = sum cs; cs = (cs+eps)/(n+K*eps)*n;
+ *   ema_w = ema_w*decay + (1-decay)*dw; codebook = ema_w / cs[:,None]; code_sqnorm refreshed.
+ * update = 0 skips the EMA part (eval mode, :1262) and only produces the scalars.
+ * scalars out (2 floats): [0] loss = beta * sum(sse_partial) / (N_loss*E), [1] perplexity = exp(-sum p log(p+1e-10)),
+ * p = cnt / N_cnt.  N_cnt is the number of rows behind `stats` (global batch under data parallelism). */
+int g2v_vq_ema_update(const float* stats, const float* sse_partial, int n_sse_partial,
+                      float* ema_cluster_size, float* ema_w, float* codebook, float* code_sqnorm,
+                      float* scalars, int N_loss, int N_cnt, int E, int K,
+                      float beta, float decay, float eps, int update, g2v_stream_t stream);
+
+/* K5': gz = g_quantized + g_loss * 2*beta/(N*E) * (z - W[idx])   (autograd of :1285-1292).
+ * g_loss is a device scalar (d total / d loss_vq), g_quantized may be NULL. */
+int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, const float* codebook,
+               const int64_t* idx, float* gz, int N, int E, float beta, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Full-sequence GRU direction (K8, K12).  Replaces one direction of one layer of
+ * nn.GRU in EncoderRNN (model/Autoencoder_VQVAE_model.py:94, model/text2embedding_model.py:131).
+ *   gi (T,B,3H) = x W_ih^T + b_ih (from g2v_linear_fwd), gate order r,z,n (PyTorch)
+ *   r = s(gi_r + W_hr h + b_hr); z = s(gi_z + W_hz h + b_hz); n = tanh(gi_n + r*(W_hn h + b_hn)); h' = (1-z) n + z h
+ *   lengths (B) int32 or NULL: pack_padded_sequence semantics (rows freeze after their last valid step,
+ *   padded outputs are zero, the reverse direction starts at each row's own last step).
+ *   hs row (t,b) is written at hs + (t*B + b)*hs_ld  (hs_ld >= H lets both directions share a (T,B,2H) buffer).
+ *   gates (T,B,4H) = r,z,n,W_hn h + b_hn  saved for the backward (NULL = inference).
+ * ------------------------------------------------------------------------------------------ */
+int g2v_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0,
+                    const int32_t* lengths, int reverse,
+                    float* hs, int64_t hs_ld, float* h_n, float* gates,
+                    int T, int B, int H, g2v_stream_t stream);
+
+/* BPTT of the above.  d_hs (row stride d_hs_ld) / d_hn may be NULL.  Produces dgi (T,B,3H) (grad wrt gi:
+ * feeds W_ih, b_ih, x grads through g2v_linear_bwd_*), dgh (T,B,3H) (feeds W_hh, b_hh) and dh0 (B,H) (may be NULL). */
+size_t g2v_gru_seq_bwd_workspace(int H);   /* room for W_hh^T */
+int g2v_gru_seq_bwd(const float* d_hs, int64_t d_hs_ld, const float* d_hn,
+                    const float* hs, int64_t hs_ld, const float* h0, const float* gates,
+                    const float* w_hh, const int32_t* lengths, int reverse,
+                    float* dgi, float* dgh, float* dh0,
+                    int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Autoregressive pose-decoder rollout (K9).  Replaces the T-1 step loop
+ * model/Autoencoder_VQVAE_model.py:1039-1054 over Generator.forward (:646-683) ->
+ * BahdanauAttnDecoderRNN.forward (:499-592) with autoencoder_att == "False", n_layers == 2:
+ *   xin_t = keep95_t * y_{t-1} / 0.05   (inline nn.Dropout(0.95), ALWAYS active :570; zeros if !conditioned :568)
+ *   u_t   = xin_t W_pre^T + b_pre;  a_t = ReLU(BatchNorm1d(u_t))   (batch stats if training, running stats else)
+ *   h0_t  = GRUcell0(a_t, h0_{t-1});  x1_t = keep_l0_t * h0_t / (1-p)  (nn.GRU inter-layer dropout, training only)
+ *   h1_t  = GRUcell1(x1_t, h1_{t-1});  y_t = h1_t W_out^T + b_out;  y_0 = target frame 0;
+ *   next input = target[t] if t < n_pre_poses else y_t (:1049-1052).
+ * One launch per time step (the BatchNorm batch statistics are a grid-wide reduction: the seam is a
+ * kernel boundary), 16 batch rows per workgroup.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* w_pre;  const float* b_pre;     /* (H,D), (H)   decoder.decoder.pre_linear.0 */
+  const float* bn_w;   const float* bn_b;      /* (H), (H)     decoder.decoder.pre_linear.1 */
+  float* bn_running_mean; float* bn_running_var; /* (H) each, updated in place when training */
+  const float* w_ih0; const float* w_hh0; const float* b_ih0; const float* b_hh0; /* (3H,H),(3H,H),(3H),(3H) */
+  const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1;
+  const float* w_out;  const float* b_out;     /* (D,H), (D)   decoder.decoder.out_layer */
+} g2v_dec_weights;
+
+typedef struct {           /* saved-for-backward / state arrays, all caller-owned */
+  float* y;                /* (T,B,D)   outputs, y[0] = target frame 0                       */
+  float* xin;              /* (T-1,B,D) dropped decoder inputs xin_t (t = 1..T-1 at index t-1) */
+  float* u;                /* (T-1,B,H) pre-BatchNorm activations                             */
+  float* a;                /* (T-1,B,H) post BN+ReLU                                          */
+  float* h0;               /* (T,B,H)   layer-0 hidden states, h0[0] = initial state          */
+  float* h1;               /* (T,B,H)   layer-1 hidden states, h1[0] = initial state          */
+  float* x1;               /* (T-1,B,H) dropped layer-0 outputs (NULL => aliases h0[1:], p == 0 or eval) */
+  float* gates0;           /* (T-1,B,4H) r,z,n,ghn of layer 0 (NULL in inference)             */
+  float* gates1;           /* (T-1,B,4H)                                                      */
+  float* bn_partial;       /* (2, nblk, 2, H) ping-pong per-block sums of (u-b), (u-b)^2      */
+  float* bn_stats;         /* (T-1,2,H) batch mean / biased var per step (training)           */
+} g2v_dec_saved;
+
+int g2v_dec_rollout_blocks(int B);
+int g2v_dec_rollout_fwd(const float* target /* (B,T,D) row-major */, const float* h_init /* (2,B,H) */,
+                        const g2v_dec_weights* w, const g2v_dec_saved* s,
+                        const uint8_t* keep95 /* (T-1,B,D) */, const uint8_t* keep_l0 /* (T-1,B,H) or NULL */,
+                        float p_drop, int n_pre_poses, int conditioned, int training,
+                        int T, int B, int D, int H, g2v_stream_t stream);
+
+typedef struct {           /* gradient outputs of the rollout backward, caller-owned */
+  float* dy;               /* (T,B,D) in: dLoss/dy_t (t=0 row ignored); out: total dL/dy_t incl. feedback */
+  float* du;               /* (T-1,B,H) grad wrt pre-BN activations          -> W_pre, b_pre        */
+  float* dbn;              /* (T-1,B,H) scratch: grad wrt BN output after ReLU                     */
+  float* dgi0; float* dgh0;/* (T-1,B,3H) each                                -> W_ih0/b_ih0, W_hh0/b_hh0 */
+  float* dgi1; float* dgh1;/* (T-1,B,3H)                                                             */
+  float* dh_init;          /* (2,B,H) grad wrt the initial hidden state (the quantised latent)     */
+  float* d_bn_w; float* d_bn_b; /* (H) each, overwritten                                           */
+  float* bn_bwd_partial;   /* (2, nblk, 2, H) ping-pong per-block sums                              */
+} g2v_dec_grads;
+
+/* workspace: transposed weight copies. */
+size_t g2v_dec_rollout_bwd_workspace(int D, int H);
+int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
+                        const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                        int conditioned, int T, int B, int D, int H,
+                        void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * custom_loss forward + gradient (K10), train_eval/train_seq2seq.py:40-88.
+ *   loss = w_l1*mean|y-tgt| + w_cont*sum_t|y_t-y_{t-1}|/numel - w_var*sum_{b,d}||y[b,:,d]||_2/numel
+ * y is time-major (T,B,D) (the rollout's buffer), target is (B,T,D).  dy (T,B,D) = g_scale * dloss/dy
+ * (may be NULL).  terms out (4 floats): total, l1, cont, var.  partial: >= g2v_custom_loss_blocks(B,D)*3 floats.
+ * ------------------------------------------------------------------------------------------ */
+int g2v_custom_loss_blocks(int B, int D);
+int g2v_custom_loss_fwd_bwd(const float* y, const float* target, float* dy, float* terms, float* partial,
+                            float w_l1, float w_cont, float w_var, float g_scale,
+                            int T, int B, int D, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused clip_grad_norm_(5) + Adam over one flat parameter buffer (K11),
+ * train_eval/train_seq2seq.py:743-744, train_autoencoder_VQVAE.py:193-195.
+ *   total = ||grad||_2; coef = min(1, max_norm/(total+1e-6)); g = grad*coef*grad_scale;
+ *   m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * step_counter: device int32, incremented by this call before use (so hipGraph replays advance it).
+ * gnorm_out (1 float, may be NULL).  partial: >= g2v_adam_blocks(n) floats.
+ * ------------------------------------------------------------------------------------------ */
+int g2v_adam_blocks(int64_t n);
+int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
+                       float* partial, int32_t* step_counter, float* gnorm_out,
+                       float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                       g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Keep-mask generator: keep[i] = (philox4x32-10(seed, offset_counter, i) uniform < keep_prob).
+ * Replaces the RNG draws of nn.Dropout / nn.GRU dropout on the path (e.g. :570).  offset_counter is a
+ * device int64 that the call advances by 1 (so graph replays draw fresh masks).
+ * ------------------------------------------------------------------------------------------ */
+int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int64_t* offset_counter,
+                  g2v_stream_t stream);
+
+/* small helpers used by the host */
+int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream);
+int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream); /* out[c][r] = in[r][c] */
+/* out[m, 0:H] = a[m, 0:H] + b[m, 0:H] with row strides (sum of the two GRU directions, :95-97) */
+int g2v_add_halves(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
+                   int64_t M, int H, g2v_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* G2V_H */

@@ -1,0 +1,415 @@
+"""GPU parity tests of every C-ABI entry point against the CPU oracle (oracle/g2v_oracle.py).
+Run on the MI355X box:  python -m pytest tests -m gpu -x -q
+
+Tolerances: code indices bit-exact (rows whose top-2 distance gap exceeds fp32 rounding noise);
+floating-point outputs within 1e-4 relative (BASELINE.json north_star), most far tighter."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import g2v_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gesture2vec_amd import _lib, ops as _ops
+    lib = _lib.load()
+    assert lib.g2v_device_ok() == 1, "no gfx950 device visible"
+    return _ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def close(got, ref, rtol=1e-4, atol=1e-5, msg=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = (got - ref).abs()
+    tol = atol + rtol * ref.abs()
+    bad = err > tol
+    assert not bad.any(), f"{msg}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e}, ref max {float(ref.abs().max()):.3e}"
+
+
+def relclose(got, ref, rel=1e-4, msg=""):
+    """max-norm relative error"""
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    scale = max(float(ref.abs().max()), 1e-12)
+    err = float((got - ref).abs().max())
+    assert err <= rel * scale, f"{msg}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+
+
+# ----------------------------------------------------------------------------------------------- linear
+@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (4096, 128, 128), (1, 3, 5), (130, 64, 192)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_linear_fwd(ops, M, K, N, act):
+    x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
+    ref = O.linear(x, w, b)
+    if act == 1:
+        ref = torch.relu(ref)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act=act)
+    relclose(y, ref, 2e-6, "linear_fwd")
+
+
+def test_linear_fwd_rowmap_and_mask(ops):
+    B, T, D, H = 7, 5, 135, 64
+    x_btd = rnd(B, T, D, seed=4)
+    keep = (torch.rand(T, B, D, generator=torch.Generator().manual_seed(5)) < 0.8).to(torch.uint8)
+    w, b = rnd(H, D, seed=6, scale=0.1), rnd(H, seed=7)
+    x_tbd = x_btd.transpose(0, 1)
+    ref = O.linear(O.dropout_apply(x_tbd, keep, 0.2), w, b).reshape(T * B, H)
+    y = ops.linear_fwd(x_btd.to(DEV), w.to(DEV), b.to(DEV), M=T * B, row_map=(B, D, T * D),
+                       keep=keep.to(DEV), scale=1.0 / 0.8)
+    relclose(y, ref, 2e-6, "linear_fwd rowmap")
+    dy = rnd(T * B, H, seed=8)
+    dw_ref = dy.t() @ O.dropout_apply(x_tbd, keep, 0.2).reshape(T * B, D)
+    dw, db = ops.linear_bwd_weight(dy.to(DEV), x_btd.to(DEV), H, D, M=T * B, row_map=(B, D, T * D),
+                                   keep=keep.to(DEV), scale=1.0 / 0.8)
+    relclose(dw, dw_ref, 5e-6, "bwd_weight rowmap")
+    relclose(db, dy.sum(0), 5e-6, "bwd_bias")
+
+
+@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192)])
+def test_linear_bwd(ops, M, K, N):
+    x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
+    dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
+    relclose(dx, dy @ w, 2e-6, "bwd_data")
+    dw, db = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K)
+    relclose(dw, (dy.double().t() @ x.double()).float(), 1e-5, "bwd_weight")
+    relclose(db, dy.double().sum(0).float(), 1e-5, "bwd_bias")
+    dw2, _ = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K, dw=dw.clone(), db=db.clone(), accumulate=True)
+    relclose(dw2, 2 * (dy.double().t() @ x.double()).float(), 1e-5, "bwd_weight accumulate")
+    # deterministic
+    dw3, _ = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K)
+    assert torch.equal(dw3, dw)
+
+
+# ----------------------------------------------------------------------------------------------- quantiser
+def _vq_fixture(golden_dir):
+    return np.load(os.path.join(golden_dir, "vq_layers.npz"))
+
+
+def test_vq_assign_matches_golden_indices(ops, golden_dir):
+    fx = _vq_fixture(golden_dir)
+    W = torch.from_numpy(fx["ema/w0/_embedding.weight"].copy())
+    flat = torch.from_numpy(fx["ema/c1/flat"].copy())
+    z = torch.from_numpy(fx["z1"].copy()).reshape(-1, W.shape[1])
+    wsq = ops.vq_code_sqnorm(W.to(DEV))
+    relclose(wsq, (W ** 2).sum(1), 1e-6, "code_sqnorm")
+    idx, quant, dmin, sse = ops.vq_assign(flat.to(DEV), z.to(DEV), W.to(DEV), wsq, want_dist=True)
+    gap = fx["ema/c1/gap"]
+    safe = gap > 1e-4
+    assert safe.mean() > 0.99
+    got = idx.cpu().numpy()
+    assert np.array_equal(got[safe], fx["ema/c1/idx"][safe]), "code indices differ from the reference"
+    close(dmin, torch.from_numpy(fx["ema/c1/dist_min"].copy()), 1e-5, 1e-4, "dist_min")
+    close(quant.reshape(-1), torch.from_numpy(fx["ema/c1/quantized"].copy()).reshape(-1), 1e-6, 1e-6, "quantized")
+    loss = 0.25 * sse.sum().item() / z.numel()
+    assert abs(loss - float(fx["ema/c1/loss"])) <= 1e-5 * abs(float(fx["ema/c1/loss"]))
+
+
+@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (33, 100, 512), (128, 400, 512), (1000, 128, 64), (17, 20, 7)])
+def test_vq_assign_vs_oracle(ops, N, E, K):
+    flat, z = rnd(N, E, seed=11), rnd(N, E, seed=12)
+    W = torch.rand(K, E, generator=torch.Generator().manual_seed(13)) * 2 - 1
+    d = O.vq_distances(flat, W)
+    ref_idx = d.argmin(1)
+    top2 = torch.topk(d, 2, dim=1, largest=False).values if K > 1 else None
+    gap = (top2[:, 1] - top2[:, 0]).numpy()
+    wsq = ops.vq_code_sqnorm(W.to(DEV))
+    idx, quant, dmin, sse = ops.vq_assign(flat.to(DEV), z.to(DEV), W.to(DEV), wsq, want_dist=True)
+    got = idx.cpu().numpy()
+    safe = gap > 1e-4 * np.maximum(1.0, np.abs(top2[:, 0].numpy()))
+    assert safe.mean() > 0.98
+    assert np.array_equal(got[safe], ref_idx.numpy()[safe])
+    # ambiguous rows must still pick a code whose distance is within rounding of the minimum
+    dd = d[torch.arange(N), torch.from_numpy(got)]
+    assert float((dd - d.min(1).values).max()) <= 1e-3
+    q_ref = z + (W[torch.from_numpy(got)] - z)
+    close(quant, q_ref, 1e-6, 1e-6, "quantized")
+    sse_ref = ((W[torch.from_numpy(got)] - z) ** 2).double().sum()
+    assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
+
+
+def test_vq_assign_ties_pick_lowest_index(ops):
+    E, K, N = 32, 48, 40
+    W = rnd(K, E, seed=3)
+    W[17] = W[5]
+    W[40] = W[5]
+    flat = W[5].unsqueeze(0).repeat(N, 1) + 0.0
+    wsq = ops.vq_code_sqnorm(W.to(DEV))
+    idx, *_ = ops.vq_assign(flat.to(DEV), flat.to(DEV), W.to(DEV), wsq)
+    assert (idx.cpu() == 5).all()
+
+
+@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64)])
+@pytest.mark.parametrize("collapsed", [False, True])
+def test_vq_stats_and_ema(ops, N, E, K, collapsed):
+    flat = rnd(N, E, seed=21)
+    idx = torch.randint(0, K, (N,), generator=torch.Generator().manual_seed(22))
+    if collapsed:
+        idx[:] = 3
+    stats = ops.vq_stats(idx.to(DEV), flat.to(DEV), K)
+    cnt_ref = torch.bincount(idx, minlength=K).float()
+    onehot = torch.zeros(N, K, dtype=torch.float64)
+    onehot[torch.arange(N), idx] = 1
+    dw_ref = (onehot.t() @ flat.double()).float()
+    assert torch.equal(stats[:K].cpu(), cnt_ref)
+    relclose(stats[K:].reshape(K, E), dw_ref, 2e-6, "dw")
+    # EMA update (K4) against the oracle formulas
+    cs = torch.rand(K, generator=torch.Generator().manual_seed(23)) * 5
+    ema_w = rnd(K, E, seed=24)
+    Wd = torch.zeros(K, E, device=DEV)
+    wsq = torch.zeros(K, device=DEV)
+    sse = torch.rand(7, generator=torch.Generator().manual_seed(25))
+    csd, ewd = cs.to(DEV), ema_w.to(DEV)
+    sc = ops.vq_ema_update(stats, sse.to(DEV), csd, ewd, Wd, wsq, N, N, E, K, 0.25, 0.85, 1e-5, True)
+    cs_ref = cs * 0.85 + 0.15 * cnt_ref
+    n = cs_ref.sum()
+    cs_ref = (cs_ref + 1e-5) / (n + K * 1e-5) * n
+    ew_ref = ema_w * 0.85 + 0.15 * dw_ref
+    close(csd, cs_ref, 1e-5, 1e-7, "ema_cluster_size")
+    close(ewd, ew_ref, 1e-5, 1e-6, "ema_w")
+    close(Wd, ew_ref / cs_ref.unsqueeze(1), 2e-5, 1e-6, "codebook")
+    close(wsq, ((ew_ref / cs_ref.unsqueeze(1)) ** 2).sum(1), 1e-4, 1e-6, "code_sqnorm")
+    p = cnt_ref / N
+    perp = torch.exp(-(p * torch.log(p + 1e-10)).sum())
+    assert abs(sc[1].item() - perp.item()) <= 1e-4 * perp.item()
+    assert abs(sc[0].item() - 0.25 * sse.sum().item() / (N * E)) <= 1e-5 * sc[0].item()
+
+
+def test_vq_bwd(ops):
+    N, E, K = 300, 128, 64
+    z, W, gq = rnd(N, E, seed=1), rnd(K, E, seed=2), rnd(N, E, seed=3)
+    idx = torch.randint(0, K, (N,), generator=torch.Generator().manual_seed(4))
+    gl = torch.tensor([1.0 / 400])
+    gz = ops.vq_bwd(gq.to(DEV), gl.to(DEV), z.to(DEV), W.to(DEV), idx.to(DEV), 0.25)
+    ref = gq + gl * 2 * 0.25 / (N * E) * (z - W[idx])
+    close(gz, ref, 1e-6, 1e-8, "vq_bwd")
+
+
+# ----------------------------------------------------------------------------------------------- GRU direction
+@pytest.mark.parametrize("T,B,H", [(34, 32, 64), (20, 8, 50), (5, 19, 200), (12, 37, 64)])
+@pytest.mark.parametrize("reverse", [False, True])
+@pytest.mark.parametrize("use_len", [False, True])
+def test_gru_seq(ops, T, B, H, reverse, use_len):
+    I = 24
+    x = rnd(T, B, I, seed=31)
+    w_ih, w_hh = rnd(3 * H, I, seed=32, scale=0.2), rnd(3 * H, H, seed=33, scale=1 / math.sqrt(H))
+    b_ih, b_hh = rnd(3 * H, seed=34, scale=0.1), rnd(3 * H, seed=35, scale=0.1)
+    lengths = None
+    if use_len:
+        lengths = torch.randint(1, T + 1, (B,), generator=torch.Generator().manual_seed(36)).sort(descending=True).values
+        lengths[0] = T
+    leaves = [t.clone().requires_grad_(True) for t in (x, w_ih, w_hh, b_ih, b_hh)]
+    out_ref, hn_ref = O.gru_direction(leaves[0], leaves[1], leaves[2], leaves[3], leaves[4], reverse, lengths)
+    g_out, g_hn = rnd(T, B, H, seed=37), rnd(B, H, seed=38)
+    grads_ref = torch.autograd.grad((out_ref * g_out).sum() + (hn_ref * g_hn).sum(), leaves)
+
+    gi = ops.linear_fwd(x.to(DEV), w_ih.to(DEV), b_ih.to(DEV))
+    len_d = lengths.to(torch.int32).to(DEV) if use_len else None
+    hs, h_n, gates = ops.gru_seq_fwd(gi, w_hh.to(DEV), b_hh.to(DEV), T, B, H, lengths=len_d, reverse=reverse)
+    relclose(hs, out_ref, 2e-5, "gru hs")
+    relclose(h_n, hn_ref, 2e-5, "gru h_n")
+    dgi, dgh, _ = ops.gru_seq_bwd(g_out.to(DEV), H, g_hn.to(DEV), hs, H, None, gates, w_hh.to(DEV), T, B, H,
+                                  lengths=len_d, reverse=reverse)
+    # weight / input gradients through the dense-layer kernels
+    M = T * B
+    dx = ops.linear_bwd_data(dgi, w_ih.to(DEV))
+    dw_ih, db_ih = ops.linear_bwd_weight(dgi, x.to(DEV), 3 * H, I)
+    # h_prev sequence for W_hh: shifted hs (zeros at the sequence start)
+    hprev = torch.zeros(T, B, H, device=DEV)
+    if reverse:
+        hprev[:-1] = hs[1:]
+    else:
+        hprev[1:] = hs[:-1]
+    dw_hh, db_hh = ops.linear_bwd_weight(dgh, hprev, 3 * H, H)
+    relclose(dx.reshape(T, B, I), grads_ref[0], 5e-5, "gru dx")
+    relclose(dw_ih, grads_ref[1], 5e-5, "gru dW_ih")
+    relclose(dw_hh, grads_ref[2], 5e-5, "gru dW_hh")
+    relclose(db_ih, grads_ref[3], 5e-5, "gru db_ih")
+    relclose(db_hh, grads_ref[4], 5e-5, "gru db_hh")
+
+
+# ----------------------------------------------------------------------------------------------- decoder rollout
+def _dec_state(D, H, seed):
+    sd = O.init_vqvae_state(D, H, 2, 8, seed=seed)
+    pre = "decoder.decoder."
+    g = torch.Generator().manual_seed(seed + 100)
+    sd[pre + "pre_linear.1.weight"] = 1 + 0.1 * torch.randn(H, generator=g)
+    sd[pre + "pre_linear.1.bias"] = 0.1 * torch.randn(H, generator=g)
+    return sd
+
+
+def _dec_weight_tensors(sd, dev):
+    pre = "decoder.decoder."
+    m = {
+        "w_pre": pre + "pre_linear.0.weight", "b_pre": pre + "pre_linear.0.bias",
+        "bn_w": pre + "pre_linear.1.weight", "bn_b": pre + "pre_linear.1.bias",
+        "bn_running_mean": pre + "pre_linear.1.running_mean", "bn_running_var": pre + "pre_linear.1.running_var",
+        "w_ih0": pre + "gru.weight_ih_l0", "w_hh0": pre + "gru.weight_hh_l0",
+        "b_ih0": pre + "gru.bias_ih_l0", "b_hh0": pre + "gru.bias_hh_l0",
+        "w_ih1": pre + "gru.weight_ih_l1", "w_hh1": pre + "gru.weight_hh_l1",
+        "b_ih1": pre + "gru.bias_ih_l1", "b_hh1": pre + "gru.bias_hh_l1",
+        "w_out": pre + "out_layer.weight", "b_out": pre + "out_layer.bias",
+    }
+    return {k: sd[v].clone().to(dev).contiguous() for k, v in m.items()}, m
+
+
+def _oracle_rollout(sd, target, h_init, keep95, keep_l0, p, training, n_pre=1):
+    B, T, D = target.shape
+    tgt = target.transpose(0, 1)
+    bn = {"running_mean": sd["decoder.decoder.pre_linear.1.running_mean"].clone(),
+          "running_var": sd["decoder.decoder.pre_linear.1.running_var"].clone(),
+          "num_batches_tracked": torch.zeros((), dtype=torch.int64)}
+    outs = [tgt[0]]
+    dec_in = tgt[0]
+    hidden = h_init
+    for t in range(1, T):
+        il = keep_l0[t - 1] if (training and p > 0) else None
+        y, hidden = O.decoder_step(dec_in, hidden, sd, 2, training, keep95[t - 1], p, il, bn)
+        outs.append(y)
+        dec_in = tgt[t] if t < n_pre else y
+    return torch.stack(outs), bn
+
+
+def _alloc_saved(T, B, D, H, nblk, dev, p):
+    z = lambda *s: torch.zeros(*s, device=dev)
+    return {"y": z(T, B, D), "xin": z(T - 1, B, D), "u": z(T - 1, B, H), "a": z(T - 1, B, H), "h0": z(T, B, H),
+            "h1": z(T, B, H), "x1": z(T - 1, B, H) if p > 0 else None, "gates0": z(T - 1, B, 4 * H),
+            "gates1": z(T - 1, B, 4 * H), "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H)}
+
+
+@pytest.mark.parametrize("T,B,D,H,p", [(34, 32, 135, 64, 0.0), (20, 8, 40, 50, 0.2), (6, 37, 135, 64, 0.3), (3, 16, 40, 200, 0.0)])
+def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
+    sd = _dec_state(D, H, seed=5)
+    g = torch.Generator().manual_seed(77)
+    target = torch.randn(B, T, D, generator=g)
+    h_init = torch.randn(2, B, H, generator=g) * 0.5
+    keep95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)
+    keep_l0 = (torch.rand(T - 1, B, H, generator=g) < (1 - p)).to(torch.uint8) if p > 0 else None
+
+    pre = "decoder.decoder."
+    pkeys = [k for k in sd if k.startswith(pre) and "running" not in k and "num_batches" not in k]
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in pkeys}
+    work = dict(sd); work.update(leaves)
+    h_leaf = h_init.clone().requires_grad_(True)
+    y_ref, bn_ref = _oracle_rollout(work, target, h_leaf, keep95, keep_l0, p, True)
+    gy = torch.randn(T, B, D, generator=g) / (T * B * D) * 100
+    gl = torch.autograd.grad((y_ref * gy).sum(), [h_leaf] + [leaves[k] for k in pkeys])
+    g_ref = dict(zip(["h_init"] + pkeys, gl))
+
+    wt, names = _dec_weight_tensors(sd, DEV)
+    ws = ops.dec_weights_struct(wt)
+    nblk = ops.dec_rollout_blocks(B)
+    saved = _alloc_saved(T, B, D, H, nblk, DEV, p)
+    k95, kl0 = keep95.to(DEV), (keep_l0.to(DEV) if p > 0 else None)
+    ops.dec_rollout_fwd(target.to(DEV), h_init.to(DEV), ws, saved, k95, kl0, p, 1, True, True, T, B, D, H)
+    relclose(saved["y"], y_ref, 1e-4, "rollout outputs")
+    close(wt["bn_running_mean"], bn_ref["running_mean"], 1e-4, 1e-5, "running_mean")
+    close(wt["bn_running_var"], bn_ref["running_var"], 1e-4, 1e-5, "running_var")
+
+    G = 3 * H
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    grads = {"dy": gy.to(DEV).clone(), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G),
+             "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G), "dh_init": z(2, B, H),
+             "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
+    ops.dec_rollout_bwd(ws, saved, grads, k95, kl0, p, 1, True, T, B, D, H)
+    M = (T - 1) * B
+    relclose(grads["dh_init"], g_ref["h_init"], 2e-4, "d h_init")
+    relclose(grads["d_bn_w"], g_ref[pre + "pre_linear.1.weight"], 2e-4, "d bn weight")
+    relclose(grads["d_bn_b"], g_ref[pre + "pre_linear.1.bias"], 2e-4, "d bn bias")
+    x1 = saved["x1"] if p > 0 else saved["h0"][1:]
+    checks = [
+        ("pre_linear.0.weight", grads["du"], saved["xin"], H, D, None),
+        ("gru.weight_ih_l0", grads["dgi0"], saved["a"], G, H, "gru.bias_ih_l0"),
+        ("gru.weight_hh_l0", grads["dgh0"], saved["h0"][:-1], G, H, "gru.bias_hh_l0"),
+        ("gru.weight_ih_l1", grads["dgi1"], x1, G, H, "gru.bias_ih_l1"),
+        ("gru.weight_hh_l1", grads["dgh1"], saved["h1"][:-1], G, H, "gru.bias_hh_l1"),
+        ("out_layer.weight", grads["dy"][1:], saved["h1"][1:], D, H, "out_layer.bias"),
+    ]
+    for wname, dyv, xv, N_, K_, bname in checks:
+        dw, db = ops.linear_bwd_weight(dyv.contiguous(), xv.contiguous(), N_, K_, M=M)
+        relclose(dw, g_ref[pre + wname], 3e-4, wname)
+        if bname:
+            relclose(db, g_ref[pre + bname], 3e-4, bname)
+
+
+def test_dec_rollout_eval_mode(ops):
+    T, B, D, H = 10, 20, 135, 64
+    sd = _dec_state(D, H, seed=9)
+    g = torch.Generator().manual_seed(78)
+    sd["decoder.decoder.pre_linear.1.running_mean"] = torch.randn(H, generator=g) * 0.1
+    sd["decoder.decoder.pre_linear.1.running_var"] = torch.rand(H, generator=g) + 0.5
+    target = torch.randn(B, T, D, generator=g)
+    h_init = torch.randn(2, B, H, generator=g) * 0.5
+    keep95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)
+    with torch.no_grad():
+        y_ref, _ = _oracle_rollout(sd, target, h_init, keep95, None, 0.2, False)
+    wt, _ = _dec_weight_tensors(sd, DEV)
+    nblk = ops.dec_rollout_blocks(B)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    saved = {"y": z(T, B, D), "u": z(T - 1, B, H), "h0": z(T, B, H), "h1": z(T, B, H), "bn_partial": z(2, nblk, 2, H)}
+    ops.dec_rollout_fwd(target.to(DEV), h_init.to(DEV), ops.dec_weights_struct(wt), saved, keep95.to(DEV), None,
+                        0.2, 1, True, False, T, B, D, H)
+    relclose(saved["y"], y_ref, 1e-4, "eval rollout")
+    close(wt["bn_running_mean"], sd["decoder.decoder.pre_linear.1.running_mean"], 0, 0, "running stats untouched")
+
+
+# ----------------------------------------------------------------------------------------------- loss / optimiser / rng
+def test_custom_loss_matches_golden(ops, golden_dir):
+    fx = np.load(os.path.join(golden_dir, "custom_loss.npz"))
+    w = [float(v) for v in fx["weights"]]
+    for tag in ("a", "b"):
+        out = torch.from_numpy(fx[f"{tag}/output"].copy())
+        tgt = torch.from_numpy(fx[f"{tag}/target"].copy())
+        terms, dy = ops.custom_loss_fwd_bwd(out.transpose(0, 1).contiguous().to(DEV), tgt.to(DEV), *w)
+        assert abs(terms[0].item() - float(fx[f"{tag}/loss"])) <= 2e-6 * abs(float(fx[f"{tag}/loss"]))
+        close(dy.transpose(0, 1), torch.from_numpy(fx[f"{tag}/grad"].copy()), 1e-5, 1e-9, "custom_loss grad")
+
+
+def test_clip_adam(ops):
+    n = 100_003
+    p0, g0 = rnd(n, seed=1), rnd(n, seed=2, scale=0.05)
+    for scale_g in (1.0, 100.0):   # unclipped and clipped regimes
+        params = {"w": p0.clone()}
+        state = {}
+        pd, md, vd = p0.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        partial = torch.zeros(ops.adam_blocks(n), device=DEV)
+        gn = torch.zeros(1, device=DEV)
+        for it in range(3):
+            g = g0 * scale_g * (it + 1)
+            grads, total = O.clip_grad_norm({"w": g}, 5.0)
+            O.adam_step(params, grads, state, 5e-4)
+            ops.clip_adam_step(pd, g.to(DEV), md, vd, step, partial, gn, 5.0, 1.0, 5e-4, 0.5, 0.999, 1e-8)
+            assert abs(gn.item() - total.item()) <= 1e-5 * total.item()
+        assert step.item() == 3
+        close(pd, params["w"], 1e-5, 1e-7, "adam params")
+
+
+def test_keep_mask(ops):
+    n = 1_000_003
+    off = torch.zeros(1, dtype=torch.int64, device=DEV)
+    a = ops.keep_mask(torch.empty(n, dtype=torch.uint8, device=DEV), 0.05, 1234, off).clone()
+    assert off.item() == 1
+    b = ops.keep_mask(torch.empty(n, dtype=torch.uint8, device=DEV), 0.05, 1234, off).clone()
+    assert off.item() == 2
+    assert not torch.equal(a, b)
+    off.zero_()
+    c = ops.keep_mask(torch.empty(n, dtype=torch.uint8, device=DEV), 0.05, 1234, off)
+    assert torch.equal(a, c)
+    for m in (a, b):
+        frac = m.float().mean().item()
+        assert abs(frac - 0.05) < 4 * math.sqrt(0.05 * 0.95 / n)
+    full = ops.keep_mask(torch.empty(1000, dtype=torch.uint8, device=DEV), 1.0, 1, off)
+    assert full.all()
