@@ -178,9 +178,9 @@ def test_vq_stats_and_ema(ops, N, E, K, collapsed):
     cs_ref = (cs_ref + 1e-5) / (n + K * 1e-5) * n
     ew_ref = ema_w * 0.85 + 0.15 * dw_ref
     close(csd, cs_ref, 1e-5, 1e-7, "ema_cluster_size")
-    close(ewd, ew_ref, 1e-5, 1e-6, "ema_w")
-    close(Wd, ew_ref / cs_ref.unsqueeze(1), 2e-5, 1e-6, "codebook")
-    close(wsq, ((ew_ref / cs_ref.unsqueeze(1)) ** 2).sum(1), 1e-4, 1e-6, "code_sqnorm")
+    relclose(ewd, ew_ref, 2e-6, "ema_w")
+    relclose(Wd, ew_ref / cs_ref.unsqueeze(1), 1e-5, "codebook")
+    relclose(wsq, ((ew_ref / cs_ref.unsqueeze(1)) ** 2).sum(1), 2e-5, "code_sqnorm")
     p = cnt_ref / N
     perp = torch.exp(-(p * torch.log(p + 1e-10)).sum())
     assert abs(sc[1].item() - perp.item()) <= 1e-4 * perp.item()
