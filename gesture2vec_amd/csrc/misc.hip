@@ -174,6 +174,11 @@ __global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
 }
 
+__global__ void scale_kernel(const float* __restrict__ in, const float* __restrict__ s, float* __restrict__ out, int64_t n) {
+  const float f = s[0];
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) out[e] = in[e] * f;
+}
+
 __global__ void add_halves_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                                   float* __restrict__ out, int64_t ldo, int64_t M, int H) {
   const int64_t total = M * H;
@@ -256,6 +261,16 @@ extern "C" int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream) {
   int blocks = cdiv(n, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, v, n);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(in && scalar && out, "null pointer");
+  if (n <= 0) return G2V_OK;
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, scalar, out, n);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -282,7 +282,7 @@ __global__ void vq_bwd_kernel(const float* __restrict__ gq, const float* __restr
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = e / E;
     const int col = (int)(e - row * E);
-    const float q = W[idx[row] * E + col];
+    const float q = idx ? W[idx[row] * E + col] : W[e];   // idx == NULL: W is the dense (N,E) quantised tensor
     float g = c * (z[e] - q);
     if (gq) g += gq[e];
     gz[e] = g;
@@ -371,7 +371,7 @@ extern "C" int g2v_vq_ema_update(const float* stats, const float* sse_partial, i
 
 extern "C" int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, const float* codebook,
                           const int64_t* idx, float* gz, int N, int E, float beta, g2v_stream_t stream) {
-  G2V_REQUIRE(z && codebook && idx && gz, "null pointer");
+  G2V_REQUIRE(z && codebook && gz, "null pointer");
   G2V_REQUIRE(N > 0 && E > 0, "non-positive size");
   const int64_t total = (int64_t)N * E;
   const float coef = 2.0f * beta / ((float)N * (float)E);

@@ -1,0 +1,360 @@
+"""VQVAEEngine -- host-side orchestration of the chunk VQ-VAE hot path over the C-ABI.
+
+Mirrors, call for call, what `Autoencoder_VQVAE.forward` (model/Autoencoder_VQVAE_model.py:901-1072),
+`custom_loss` (train_eval/train_seq2seq.py:40-88) and `train_iter_Autoencoder_VQ_seq2seq` (:664-758) do in the
+reference, but every tensor op is one of the HIP kernels behind include/g2v.h.  The engine owns
+
+  * ONE flat fp32 parameter buffer (and matching flat grad / Adam m / Adam v buffers) holding every trainable
+    tensor of the model; the nn.Parameters the user sees are views into it, so clip+Adam is a single fused
+    launch pair and the data-parallel gradient exchange is a single RCCL all-reduce;
+  * all activations / saved-for-backward tensors, preallocated per batch size (static addresses: the whole
+    train step can be captured into a hipGraph);
+  * explicit dropout keep-masks (drawn by the Philox kernel, or supplied by the caller for parity tests).
+
+Scope: autoencoder_vq == "True", autoencoder_vae == "False", autoencoder_att == "False", n_layers == 2 (every
+shipped VQ-VAE config).  With attention off the decoder only consumes encoder_hidden[:2] = the layer-0
+forward/backward final states (:971-973), so encoder GRU layer 1 is never evaluated: its outputs reach nothing and
+its gradients are exactly zero in the reference [SURVEY.md §0]; its weights stay in the state_dict untouched.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import DecGrads, DecSaved, DecWeights, check
+
+_p = ops._p
+
+
+def _enc_gru_names(L):
+    names = []
+    for l in range(L):
+        for suf in ("", "_reverse"):
+            names += [f"weight_ih_l{l}{suf}", f"weight_hh_l{l}{suf}", f"bias_ih_l{l}{suf}", f"bias_hh_l{l}{suf}"]
+    return names
+
+
+def _dec_gru_names(L):
+    names = []
+    for l in range(L):
+        names += [f"weight_ih_l{l}", f"weight_hh_l{l}", f"bias_ih_l{l}", f"bias_hh_l{l}"]
+    return names
+
+
+def trainable_layout(D: int, H: int, L: int):
+    """(name, shape) of every tensor that receives a gradient in the reference's step, in flat-buffer order."""
+    out = [("encoder.in_layer.weight", (H, D)), ("encoder.in_layer.bias", (H,))]
+    for n in _enc_gru_names(L):
+        l = int(n.split("_l")[1][0])
+        if n.startswith("weight_ih"):
+            shp = (3 * H, H if l == 0 else 2 * H)
+        elif n.startswith("weight_hh"):
+            shp = (3 * H, H)
+        else:
+            shp = (3 * H,)
+        out.append(("encoder.gru." + n, shp))
+    out += [("decoder.decoder.pre_linear.0.weight", (H, D)), ("decoder.decoder.pre_linear.0.bias", (H,)),
+            ("decoder.decoder.pre_linear.1.weight", (H,)), ("decoder.decoder.pre_linear.1.bias", (H,))]
+    for n in _dec_gru_names(L):
+        shp = (3 * H, H) if n.startswith("weight") else (3 * H,)
+        out.append(("decoder.decoder.gru." + n, shp))
+    out += [("decoder.decoder.out_layer.weight", (D, H)), ("decoder.decoder.out_layer.bias", (D,))]
+    return out
+
+
+class VQVAEEngine:
+    def __init__(self, D: int, H: int, L: int, K: int, T: int, *, beta: float, dropout_prob: float,
+                 n_pre_poses: int = 1, conditioned: bool = True, decay: float = 0.85, eps: float = 1e-5,
+                 device="cuda:0", seed: int = 0):
+        if L != 2:
+            raise NotImplementedError("the gfx950 rollout kernels implement n_layers == 2 (every shipped config)")
+        self.lib = _lib.load()
+        self.D, self.H, self.L, self.K, self.T = D, H, L, K, T
+        self.E = H * L
+        self.beta, self.p, self.n_pre, self.conditioned = float(beta), float(dropout_prob), int(n_pre_poses), bool(conditioned)
+        self.decay, self.eps = float(decay), float(eps)
+        self.device = torch.device(device)
+        self.seed = int(seed)
+        self.layout = trainable_layout(D, H, L)
+        self.offsets: Dict[str, tuple] = {}
+        off = 0
+        for name, shp in self.layout:
+            n = 1
+            for s in shp:
+                n *= s
+            self.offsets[name] = (off, n, shp)
+            off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned inside the flat buffer
+        self.n_flat = off
+        dev = self.device
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.adam_partial = torch.zeros(self.lib.g2v_adam_blocks(off), dtype=torch.float32, device=dev)
+        self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # quantiser state (not trainable by gradient: grad=None in the reference, :1276-1282)
+        E = self.E
+        self.vq_pre_w = torch.zeros(E, E, device=dev)
+        self.vq_pre_b = torch.zeros(E, device=dev)
+        self.codebook = torch.zeros(K, E, device=dev)
+        self.ema_w = torch.zeros(K, E, device=dev)
+        self.ema_cs = torch.zeros(K, device=dev)
+        self.code_sqnorm = torch.zeros(K, device=dev)
+        self.bn_rm = torch.zeros(H, device=dev)
+        self.bn_rv = torch.ones(H, device=dev)
+        self.vq_stats = torch.zeros(K + K * E, device=dev)
+        self.vq_scalars = torch.zeros(2, device=dev)          # loss_vq, perplexity
+        self.loss_terms = torch.zeros(4, device=dev)          # custom_loss total, l1, cont, var
+        self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
+        self._bufs: Dict[int, dict] = {}
+        self._wstruct = None
+
+    # ------------------------------------------------------------------ parameter views
+    def view(self, name: str, grad: bool = False) -> torch.Tensor:
+        off, n, shp = self.offsets[name]
+        return (self.gflat if grad else self.flat)[off:off + n].view(shp)
+
+    def _w(self, name):
+        return self.view(name).data_ptr()
+
+    def _g(self, name):
+        return self.view(name, True).data_ptr()
+
+    def dec_wstruct(self) -> DecWeights:
+        if self._wstruct is None:
+            pre = "decoder.decoder."
+            s = DecWeights()
+            s.w_pre, s.b_pre = self._w(pre + "pre_linear.0.weight"), self._w(pre + "pre_linear.0.bias")
+            s.bn_w, s.bn_b = self._w(pre + "pre_linear.1.weight"), self._w(pre + "pre_linear.1.bias")
+            s.bn_running_mean, s.bn_running_var = self.bn_rm.data_ptr(), self.bn_rv.data_ptr()
+            for l in (0, 1):
+                setattr(s, f"w_ih{l}", self._w(pre + f"gru.weight_ih_l{l}"))
+                setattr(s, f"w_hh{l}", self._w(pre + f"gru.weight_hh_l{l}"))
+                setattr(s, f"b_ih{l}", self._w(pre + f"gru.bias_ih_l{l}"))
+                setattr(s, f"b_hh{l}", self._w(pre + f"gru.bias_hh_l{l}"))
+            s.w_out, s.b_out = self._w(pre + "out_layer.weight"), self._w(pre + "out_layer.bias")
+            self._wstruct = s
+        return self._wstruct
+
+    # ------------------------------------------------------------------ buffers
+    def buffers(self, B: int) -> dict:
+        b = self._bufs.get(B)
+        if b is not None:
+            return b
+        T, D, H, E, K = self.T, self.D, self.H, self.E, self.K
+        dev = self.device
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+        u8 = lambda *s: torch.ones(*s, dtype=torch.uint8, device=dev)
+        nblk = self.lib.g2v_dec_rollout_blocks(B)
+        G = 3 * H
+        b = {
+            "keep_in": u8(T, B, D) if self.p > 0 else None,
+            "keep95": u8(T - 1, B, D),
+            "keep_l0": u8(T - 1, B, H) if self.p > 0 else None,
+            "xin": z(T * B, H), "gi_f": z(T * B, G), "gi_b": z(T * B, G),
+            # (T+1) slots: slot 0 (forward dir) / slot T (reverse dir) stays zero = h_prev of the first step
+            "hs_f": z(T + 1, B, H), "hs_b": z(T + 1, B, H),
+            "gates_f": z(T, B, 4 * H), "gates_b": z(T, B, 4 * H),
+            "enc_hidden": z(2, B, H),            # encoder_hidden[:2] = (layer-0 fwd, layer-0 bwd) final states
+            "flat": z(B, E), "idx": torch.zeros(B, dtype=torch.int64, device=dev), "quant": z(2, B, H),
+            "sse": z(self.lib.g2v_vq_assign_blocks(B)),
+            "y": z(T, B, D), "dec_xin": z(T - 1, B, D), "u": z(T - 1, B, H), "a": z(T - 1, B, H),
+            "h0": z(T, B, H), "h1": z(T, B, H), "x1": z(T - 1, B, H) if self.p > 0 else None,
+            "gates0": z(T - 1, B, 4 * H), "gates1": z(T - 1, B, 4 * H),
+            "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H),
+            "loss_partial": z(self.lib.g2v_custom_loss_blocks(B, D) * 3),
+            # backward
+            "dy": z(T, B, D), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H),
+            "dgi0": z(T - 1, B, G), "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G),
+            "dh_init": z(2, B, H), "bn_bwd_partial": z(2, nblk, 2, H),
+            "gz": z(2, B, H),
+            "dgi_f": z(T, B, G), "dgh_f": z(T, B, G), "dgi_b": z(T, B, G), "dgh_b": z(T, B, G),
+            "dxin": z(T * B, H),
+        }
+        sv = DecSaved()
+        sv.y, sv.xin, sv.u, sv.a = _p(b["y"]), _p(b["dec_xin"]), _p(b["u"]), _p(b["a"])
+        sv.h0, sv.h1, sv.x1 = _p(b["h0"]), _p(b["h1"]), _p(b["x1"])
+        sv.gates0, sv.gates1 = _p(b["gates0"]), _p(b["gates1"])
+        sv.bn_partial, sv.bn_stats = _p(b["bn_partial"]), _p(b["bn_stats"])
+        b["sv"] = sv
+        sve = DecSaved()          # inference: nothing saved for backward
+        sve.y, sve.u, sve.h0, sve.h1, sve.bn_partial = sv.y, sv.u, sv.h0, sv.h1, sv.bn_partial
+        b["sv_eval"] = sve
+        pre = "decoder.decoder."
+        gr = DecGrads()
+        gr.dy, gr.du, gr.dbn = _p(b["dy"]), _p(b["du"]), _p(b["dbn"])
+        gr.dgi0, gr.dgh0, gr.dgi1, gr.dgh1 = _p(b["dgi0"]), _p(b["dgh0"]), _p(b["dgi1"]), _p(b["dgh1"])
+        gr.dh_init = _p(b["dh_init"])
+        gr.d_bn_w, gr.d_bn_b = self._g(pre + "pre_linear.1.weight"), self._g(pre + "pre_linear.1.bias")
+        gr.bn_bwd_partial = _p(b["bn_bwd_partial"])
+        b["gr"] = gr
+        ws_bytes = max(self.lib.g2v_dec_rollout_bwd_workspace(D, H), self.lib.g2v_gru_seq_bwd_workspace(H),
+                       self.lib.g2v_vq_stats_workspace(B, E, K),
+                       self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
+                       self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)))
+        b["ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        self._bufs[B] = b
+        return b
+
+    # ------------------------------------------------------------------ pieces
+    def _stream(self):
+        return torch.cuda.current_stream().cuda_stream
+
+    def draw_masks(self, B: int, training: bool):
+        b = self.buffers(B)
+        st = self._stream()
+        check(self.lib.g2v_keep_mask(_p(b["keep95"]), b["keep95"].numel(), 0.05, self.seed, _p(self.rng_counter), st))
+        if training and self.p > 0:
+            check(self.lib.g2v_keep_mask(_p(b["keep_in"]), b["keep_in"].numel(), 1 - self.p, self.seed + 1, _p(self.rng_counter), st))
+            check(self.lib.g2v_keep_mask(_p(b["keep_l0"]), b["keep_l0"].numel(), 1 - self.p, self.seed + 2, _p(self.rng_counter), st))
+
+    def set_masks(self, B: int, keep95, keep_in=None, keep_l0=None):
+        """Explicit keep masks (parity tests): keep95 (T-1,B,D), keep_in (T,B,D), keep_l0 (T-1,B,H)."""
+        b = self.buffers(B)
+        b["keep95"].copy_(keep95)
+        if self.p > 0:
+            if keep_in is not None:
+                b["keep_in"].copy_(keep_in)
+            if keep_l0 is not None:
+                b["keep_l0"].copy_(keep_l0)
+
+    def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
+                n_global: Optional[int] = None):
+        """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
+        Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
+        lib, st = self.lib, self._stream()
+        B, T, D = in_poses.shape
+        assert T == self.T and D == self.D, "shape does not match the engine"
+        ops._chk(in_poses, name="in_poses"); ops._chk(out_poses, name="out_poses")
+        H, E, K, G = self.H, self.E, self.K, 3 * self.H
+        b = self.buffers(B)
+        drop_in = training and self.p > 0
+        enc = "encoder."
+        # ---- EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU -----------------------
+        check(lib.g2v_linear_fwd(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]) if drop_in else None,
+                                 1.0 / (1.0 - self.p) if drop_in else 1.0,
+                                 self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
+                                 _p(b["xin"]), H, T * B, D, H, 0, st))
+        for suf, gi in (("", b["gi_f"]), ("_reverse", b["gi_b"])):
+            check(lib.g2v_linear_fwd(_p(b["xin"]), H, 0, 0, 0, None, 1.0, self._w(enc + "gru.weight_ih_l0" + suf),
+                                     self._w(enc + "gru.bias_ih_l0" + suf), _p(gi), G, T * B, H, G, 0, st))
+        gates_f = _p(b["gates_f"]) if training else None
+        gates_b = _p(b["gates_b"]) if training else None
+        check(lib.g2v_gru_seq_fwd(_p(b["gi_f"]), self._w(enc + "gru.weight_hh_l0"), self._w(enc + "gru.bias_hh_l0"),
+                                  None, None, 0, b["hs_f"][1:].data_ptr(), H, b["enc_hidden"][0].data_ptr(), gates_f,
+                                  T, B, H, st))
+        check(lib.g2v_gru_seq_fwd(_p(b["gi_b"]), self._w(enc + "gru.weight_hh_l0_reverse"),
+                                  self._w(enc + "gru.bias_hh_l0_reverse"), None, None, 1, b["hs_b"].data_ptr(), H,
+                                  b["enc_hidden"][1].data_ptr(), gates_b, T, B, H, st))
+        # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
+        N = (2 * B * H) // E
+        check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
+                                 _p(b["flat"]), E, N, E, E, 0, st))
+        check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
+        check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
+                                    _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
+        check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws"]), b["ws"].numel(), st))
+        if ema_update:
+            self.vq_finish(B, training, n_global)
+        # ---- decoder rollout (:1039-1054) -----------------------------------------------------------------------
+        check(lib.g2v_dec_rollout_fwd(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
+                                      C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
+                                      _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
+                                      int(self.conditioned), int(training), T, B, D, H, st))
+        return b
+
+    def vq_finish(self, B: int, training: bool, n_global: Optional[int] = None):
+        """K4 + the loss / perplexity scalars; under data parallelism call it after vq_stats has been all-reduced."""
+        b = self.buffers(B)
+        N = (2 * B * self.H) // self.E
+        check(self.lib.g2v_vq_ema_update(_p(self.vq_stats), _p(b["sse"]), b["sse"].numel(), _p(self.ema_cs),
+                                         _p(self.ema_w), _p(self.codebook), _p(self.code_sqnorm), _p(self.vq_scalars),
+                                         N, n_global or N, self.E, self.K, self.beta, self.decay, self.eps,
+                                         int(training), self._stream()))
+
+    def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):
+        """custom_loss on the rollout output; fills loss_terms and (want_grad) the dy buffer with dLoss/dy."""
+        b = self.buffers(B)
+        check(self.lib.g2v_custom_loss_fwd_bwd(_p(b["y"]), _p(target), _p(b["dy"]) if want_grad else None,
+                                               _p(self.loss_terms), _p(b["loss_partial"]), w_l1, w_cont, w_var, 1.0,
+                                               self.T, B, self.D, self._stream()))
+
+    def backward(self, in_poses: torch.Tensor, B: int, g_loss_vq: Optional[torch.Tensor] = None):
+        """Backward of forward(training=True): expects buffers['dy'] = dLoss/d y (T,B,D).  Writes every parameter
+        gradient into the flat grad buffer (overwrite, not accumulate)."""
+        lib, st = self.lib, self._stream()
+        T, D, H, E, G = self.T, self.D, self.H, self.E, 3 * self.H
+        b = self.buffers(B)
+        ws, wsn = _p(b["ws"]), b["ws"].numel()
+        drop = self.p > 0
+        check(lib.g2v_dec_rollout_bwd(C.byref(self.dec_wstruct()), C.byref(b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
+                                      _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
+                                      T, B, D, H, ws, wsn, st))
+        pre = "decoder.decoder."
+        M = (T - 1) * B
+        x1 = b["x1"] if drop else b["h0"][1:]
+
+        def wgrad(dy, lddy, x, ldx, wname, bname, N_, K_, rows=M, row_map=(0, 0, 0), keep=None, scale=1.0):
+            check(lib.g2v_linear_bwd_weight(dy, lddy, x, ldx, row_map[0], row_map[1], row_map[2], keep, scale,
+                                            self._g(wname), self._g(bname) if bname else None, rows, K_, N_, 0, ws, wsn, st))
+
+        wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
+        wgrad(_p(b["dgi0"]), G, _p(b["a"]), H, pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0", G, H)
+        wgrad(_p(b["dgh0"]), G, _p(b["h0"]), H, pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0", G, H)
+        wgrad(_p(b["dgi1"]), G, x1.data_ptr(), H, pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1", G, H)
+        wgrad(_p(b["dgh1"]), G, _p(b["h1"]), H, pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1", G, H)
+        wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
+        # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
+        N = (2 * B * H) // E
+        gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
+        check(lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
+                             self.beta, st))
+        # ---- encoder layer-0 BPTT -----------------------------------------------------------------------------------
+        enc = "encoder."
+        check(lib.g2v_gru_seq_bwd(None, 0, b["gz"][0].data_ptr(), b["hs_f"][1:].data_ptr(), H, None, _p(b["gates_f"]),
+                                  self._w(enc + "gru.weight_hh_l0"), None, 0, _p(b["dgi_f"]), _p(b["dgh_f"]), None,
+                                  T, B, H, ws, wsn, st))
+        check(lib.g2v_gru_seq_bwd(None, 0, b["gz"][1].data_ptr(), b["hs_b"].data_ptr(), H, None, _p(b["gates_b"]),
+                                  self._w(enc + "gru.weight_hh_l0_reverse"), None, 1, _p(b["dgi_b"]), _p(b["dgh_b"]), None,
+                                  T, B, H, ws, wsn, st))
+        TB = T * B
+        wgrad(_p(b["dgi_f"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0", G, H, rows=TB)
+        wgrad(_p(b["dgh_f"]), G, b["hs_f"].data_ptr(), H, enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0", G, H, rows=TB)
+        wgrad(_p(b["dgi_b"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse", G, H, rows=TB)
+        wgrad(_p(b["dgh_b"]), G, b["hs_b"][1:].data_ptr(), H, enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse", G, H, rows=TB)
+        check(lib.g2v_linear_bwd_data(_p(b["dgi_f"]), G, self._w(enc + "gru.weight_ih_l0"), _p(b["dxin"]), H, TB, H, G, 0, st))
+        check(lib.g2v_linear_bwd_data(_p(b["dgi_b"]), G, self._w(enc + "gru.weight_ih_l0_reverse"), _p(b["dxin"]), H, TB, H, G, 1, st))
+        wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
+              row_map=(B, D, T * D), keep=_p(b["keep_in"]) if drop else None,
+              scale=1.0 / (1.0 - self.p) if drop else 1.0)
+        # encoder GRU layer 1 receives exactly-zero gradients (dead compute in the reference); the flat grad
+        # buffer is zero there from construction and nothing ever writes it.
+
+    def optimizer_step(self, lr: float, betas=(0.5, 0.999), eps: float = 1e-8, max_norm: float = 5.0,
+                       grad_scale: float = 1.0):
+        check(self.lib.g2v_clip_adam_step(_p(self.flat), _p(self.gflat), _p(self.m), _p(self.v), self.n_flat,
+                                          _p(self.adam_partial), _p(self.step_counter), _p(self.gnorm), max_norm,
+                                          grad_scale, lr, betas[0], betas[1], eps, self._stream()))
+
+    # ------------------------------------------------------------------ one fused train iteration
+    def train_step(self, x: torch.Tensor, target: torch.Tensor, *, lr: float, w_l1: float, w_cont: float,
+                   w_var: float, epoch: int = 1, draw_masks: bool = True, reduce_fn=None, world: int = 1):
+        """train_iter_Autoencoder_VQ_seq2seq (train_eval/train_seq2seq.py:664-758) without host syncs.
+        reduce_fn(flat_grad, vq_stats) performs the data-parallel SUM all-reduce (RCCL) when world > 1."""
+        B = x.shape[0]
+        if draw_masks:
+            self.draw_masks(B, True)
+        dp = reduce_fn is not None and world > 1
+        self.forward(x, target, True, ema_update=not dp)
+        self.loss(B, target, w_l1, w_cont, w_var, True)
+        g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
+        self.backward(x, B, g_vq)
+        if dp:
+            reduce_fn(self.gflat, self.vq_stats)
+            self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
+        self.optimizer_step(lr, grad_scale=1.0 / world if dp else 1.0)

@@ -1,0 +1,338 @@
+"""Part b: gesture-chunk VQ-VAE -- the reference's operator surface on the MI355X-native kernels.
+
+Mirrors `scripts/model/Autoencoder_VQVAE_model.py` of pjyazdian/Gesture2Vec: same class names, constructor
+signatures, `forward` signatures / return tuples and `state_dict` keys (so reference `.bin` checkpoints load
+and vice-versa), but no arithmetic happens in torch.nn: `nn.Linear` / `nn.BatchNorm1d` / `nn.Embedding` are
+used purely as parameter containers (names, shapes, init), and every forward/backward number comes from the HIP
+kernels behind include/g2v.h via `gesture2vec_amd.engine.VQVAEEngine`.
+
+Differences from the reference, all deliberate:
+  * `Autoencoder_VQVAE` wires `VQ_Payam_EMA` (the reference constructs it :801-807 and then overwrites it with the
+    soft GSSoft quantiser :816-820; the task's north star is the EMA quantiser with hard argmin codes).
+  * `_ema_w` / `_embedding.weight` are updated IN PLACE by the EMA kernel instead of being re-created as new
+    nn.Parameter objects every forward (:1276-1282); values and state_dict keys are identical, and like in the
+    reference they never receive a gradient.
+  * Dropout masks come from a counter-based Philox kernel (or are supplied explicitly, `set_dropout_masks`),
+    because CPU and GPU RNG streams cannot agree anyway.
+  * GPU only: `.forward` raises if the module is not on an MI355X (no CPU path).
+Supported configuration: autoencoder_vq "True", autoencoder_vae "False", autoencoder_att "False", n_layers 2.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..engine import VQVAEEngine
+
+debug = False
+
+
+class _GRUParams(nn.Module):
+    """Parameter container with nn.GRU's names, shapes and init (U(-1/sqrt(H), 1/sqrt(H)))."""
+
+    def __init__(self, input_size: int, hidden_size: int, num_layers: int, dropout: float = 0.0,
+                 bidirectional: bool = False):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, num_layers
+        self.dropout, self.bidirectional = dropout, bidirectional
+        H = hidden_size
+        k = 1.0 / math.sqrt(H)
+        for l in range(num_layers):
+            in_f = input_size if l == 0 else H * (2 if bidirectional else 1)
+            for suf in ([""] + (["_reverse"] if bidirectional else [])):
+                for name, shape in ((f"weight_ih_l{l}{suf}", (3 * H, in_f)), (f"weight_hh_l{l}{suf}", (3 * H, H)),
+                                    (f"bias_ih_l{l}{suf}", (3 * H,)), (f"bias_hh_l{l}{suf}", (3 * H,))):
+                    self.register_parameter(name, nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def flatten_parameters(self):  # API compatibility; the flat buffer is managed by the engine
+        return None
+
+
+class EncoderRNN(nn.Module):
+    """Linear(D->H) + bidirectional GRU, directions summed (reference :30-100)."""
+
+    def __init__(self, input_size: int, hidden_size: int, n_layers: int = 1, dropout: float = 0.5,
+                 pre_trained_embedding=None):
+        super().__init__()
+        self.input_size, self.hidden_size, self.n_layers, self.dropout = input_size, hidden_size, n_layers, dropout
+        self.in_layer = nn.Linear(input_size, hidden_size)
+        self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout, bidirectional=True)
+        self.do_flatten_parameters = False
+
+    def forward(self, input_seqs: torch.Tensor, hidden: Optional[torch.Tensor] = None):
+        """(T,B,D) -> outputs (T,B,H) [sum of directions of the LAST layer], hidden (2L,B,H).  Inference-only
+        standalone path (all layers evaluated); inside Autoencoder_VQVAE the engine runs the fused training path."""
+        if hidden is not None:
+            raise NotImplementedError("non-zero initial hidden state")
+        T, B, D = input_seqs.shape
+        H, L = self.hidden_size, self.n_layers
+        x = input_seqs.contiguous()
+        xin = ops.linear_fwd(x, self.in_layer.weight.data, self.in_layer.bias.data, M=T * B)
+        layer_in, in_f = xin, H
+        hiddens = []
+        out = None
+        for l in range(L):
+            out = torch.empty((T, B, 2 * H), dtype=torch.float32, device=x.device)
+            for d, suf in enumerate(("", "_reverse")):
+                g = self.gru
+                gi = ops.linear_fwd(layer_in, getattr(g, f"weight_ih_l{l}{suf}").data, getattr(g, f"bias_ih_l{l}{suf}").data,
+                                    M=T * B)
+                _, h_n, _ = ops.gru_seq_fwd(gi, getattr(g, f"weight_hh_l{l}{suf}").data.contiguous(),
+                                            getattr(g, f"bias_hh_l{l}{suf}").data, T, B, H, reverse=bool(d),
+                                            hs=out[:, :, d * H:], hs_ld=2 * H, save_gates=False)
+                hiddens.append(h_n)
+            layer_in, in_f = out.view(T * B, 2 * H), 2 * H   # (inter-layer dropout is a training-only effect)
+        summed = torch.empty((T, B, H), dtype=torch.float32, device=x.device)
+        ops.add_halves(out, 2 * H, out[:, :, H:], 2 * H, summed, H, T * B, H)
+        return summed, torch.stack(hiddens)
+
+
+class BahdanauAttnDecoderRNN(nn.Module):
+    """One decode step's parameters (reference :401-592).  The step itself runs inside the rollout kernels."""
+
+    def __init__(self, args, input_size: int, hidden_size: int, output_size: int, n_layers: int = 1,
+                 dropout_p: float = 0.1, discrete_representation: bool = False, speaker_model=None):
+        super().__init__()
+        self.hidden_size, self.output_size, self.n_layers, self.dropout_p = hidden_size, output_size, n_layers, dropout_p
+        self.discrete_representation = discrete_representation
+        self.speaker_model = speaker_model
+        if discrete_representation:
+            raise NotImplementedError("discrete_representation decoder belongs to Part d (text2embedding_model)")
+        self.autoencoder_conditioned = args.autoencoder_conditioned == "True"
+        if args.autoencoder_att == "True":
+            raise NotImplementedError("autoencoder_att == 'True' (attention decoder) is not on the accelerated path yet")
+        self.att_use = False
+        self.pre_linear = nn.Sequential(nn.Linear(input_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
+        self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout_p)
+        if args.autoencoder_fixed_weight == "True":
+            self.autoencoder_fixed_weight = True
+            for param in self.gru.parameters():
+                param.requires_grad = False
+        self.out_layer = nn.Linear(hidden_size, output_size)
+        self.do_flatten_parameters = False
+
+
+class Generator(nn.Module):
+    """Decoder wrapper (reference :595-683)."""
+
+    def __init__(self, args, motion_dim: int, discrete_representation: bool = False, speaker_model=None):
+        super().__init__()
+        self.output_size = motion_dim
+        self.n_layers = args.n_layers
+        self.discrete_representation = discrete_representation
+        self.decoder = BahdanauAttnDecoderRNN(args=args, input_size=args.rep_learning_dim, hidden_size=args.hidden_size,
+                                              output_size=args.rep_learning_dim, n_layers=self.n_layers,
+                                              dropout_p=args.dropout_prob,
+                                              discrete_representation=discrete_representation, speaker_model=speaker_model)
+        self.is_training = True
+
+
+class VQ_Payam_EMA(nn.Module):
+    """EMA vector quantiser (reference :1182-1301).  forward(inputs) -> (loss, quantized, perplexity, encodings)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float, decay: float,
+                 epsilon: float = 1e-5):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self.pre_linear = nn.Linear(embedding_dim, embedding_dim)
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.uniform_(-1, 1)                                  # :1204
+        self._commitment_cost = commitment_cost
+        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
+        self._ema_w = nn.Parameter(torch.Tensor(num_embeddings, embedding_dim))
+        self._ema_w.data.normal_()                                                   # :1211
+        self._decay, self._epsilon = decay, epsilon
+        for p in (self._ema_w, self._embedding.weight, self.pre_linear.weight, self.pre_linear.bias):
+            p.requires_grad_(False)   # they never get a gradient in the reference either
+
+    def forward(self, inputs: torch.Tensor):
+        """Standalone call (datasets / clustering / inference call sites, lmdb_data_loader.py:1274-1281): rows are
+        `inputs.view(-1, E)`.  Gradient wrt `inputs` flows through `_VQFn` (straight-through + commitment)."""
+        return _VQFn.apply(inputs, self)
+
+    def assign(self, inputs: torch.Tensor) -> torch.Tensor:
+        """Code indices only (bulk code-assignment path): argmin_k ||pre_linear(x) - W_k||^2, int64 (N,)."""
+        E, K = self._embedding_dim, self._num_embeddings
+        z = inputs.contiguous().view(-1, E)
+        flat = ops.linear_fwd(z, self.pre_linear.weight.data, self.pre_linear.bias.data)
+        wsq = ops.vq_code_sqnorm(self._embedding.weight.data)
+        idx, _, _, _ = ops.vq_assign(flat, None, self._embedding.weight.data, wsq, want_quantized=False)
+        return idx
+
+
+class _VQFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, mod: VQ_Payam_EMA):
+        E, K = mod._embedding_dim, mod._num_embeddings
+        z = inputs.contiguous().view(-1, E)
+        N = z.shape[0]
+        W = mod._embedding.weight.data
+        flat = ops.linear_fwd(z, mod.pre_linear.weight.data, mod.pre_linear.bias.data)
+        wsq = ops.vq_code_sqnorm(W)
+        idx, quant, _, sse = ops.vq_assign(flat, z, W, wsq)
+        stats = ops.vq_stats(idx, flat, K)
+        scalars = ops.vq_ema_update(stats, sse, mod._ema_cluster_size, mod._ema_w.data, W, wsq, N, N, E, K,
+                                    mod._commitment_cost, mod._decay, mod._epsilon, mod.training)
+        encodings = torch.zeros((N, K), dtype=torch.float32, device=z.device)
+        encodings.scatter_(1, idx.unsqueeze(1), 1.0)     # layout glue: the (N,K) one-hot callers argmax over (:1246-1250)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, quant)
+        ctx.beta, ctx.shape = mod._commitment_cost, inputs.shape
+        ctx.mark_non_differentiable(encodings)
+        return scalars[0].clone(), quant.view(inputs.shape), scalars[1].clone(), encodings
+
+    @staticmethod
+    def backward(ctx, g_loss, g_quant, g_perp, g_enc):
+        z, quant = ctx.saved_tensors
+        gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
+        gq = g_quant.contiguous().view(z.shape) if g_quant is not None else None
+        gz = ops.vq_bwd(gq, gl, z, quant, None, ctx.beta)
+        return gz.view(ctx.shape), None
+
+
+class Autoencoder_VQVAE(nn.Module):
+    """Chunk autoencoder: EncoderRNN -> VQ_Payam_EMA on encoder_hidden[:L] -> T-1 autoregressive decode steps
+    (reference :686-1085).  forward(in_poses, out_poses, vq_layer_active) ->
+    (outputs (B,T,D), decoder_first_hidden (L,B,H), loss_vq, perplexity_vq)."""
+
+    def __init__(self, args, pose_dim: int, n_frames: int):
+        super().__init__()
+        self.CNN = False
+        self.encoder = EncoderRNN(args.rep_learning_dim, args.hidden_size, args.n_layers, dropout=args.dropout_prob,
+                                  pre_trained_embedding=None)
+        # unused by forward but part of the reference's state_dict (:750-755)
+        self.out_layer_encoder = nn.Sequential(nn.Linear(args.hidden_size, args.hidden_size), nn.Tanh())
+        self.out_layer_decoder = nn.Sequential(nn.Linear(args.hidden_size, pose_dim))
+        self.decoder = Generator(args, pose_dim, speaker_model=None)
+        if args.autoencoder_vae == "True":
+            raise NotImplementedError("autoencoder_vae == 'True' is outside the accelerated hot path")
+        self.VAE = False
+        if args.autoencoder_vq != "True":
+            raise NotImplementedError("autoencoder_vq == 'False' is outside the accelerated hot path")
+        self.vq = True
+        self.vq_components = int(args.autoencoder_vq_components)
+        self.commitment_cost = float(args.autoencoder_vq_commitment_cost)
+        self.vq_layer = VQ_Payam_EMA(self.vq_components, args.hidden_size * args.n_layers, self.commitment_cost, 0.85)
+        self.n_frames = n_frames
+        self.n_pre_poses = args.n_pre_poses
+        self.pose_dim = args.rep_learning_dim
+        self.autoencoder_conditioned = args.autoencoder_conditioned == "True"
+        self.dropout_prob = float(args.dropout_prob)
+        self.hidden_size, self.n_layers = args.hidden_size, args.n_layers
+        for p in list(self.out_layer_encoder.parameters()) + list(self.out_layer_decoder.parameters()):
+            p.requires_grad_(False)   # grad is None in the reference: never reached by forward
+        self._engine: Optional[VQVAEEngine] = None
+        self._explicit_masks = False
+        self.rng_seed = 0
+
+    # ------------------------------------------------------------------ engine binding
+    def engine(self) -> VQVAEEngine:
+        dev = self.encoder.in_layer.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("Autoencoder_VQVAE runs on the MI355X kernels only: move the module to the GPU first "
+                               "(there is deliberately no CPU fallback)")
+        eng = self._engine
+        sd_params = dict(self.named_parameters())
+        if eng is None or eng.device != dev:
+            eng = VQVAEEngine(self.pose_dim, self.hidden_size, self.n_layers, self.vq_components, self.n_frames,
+                              beta=self.commitment_cost, dropout_prob=self.dropout_prob, n_pre_poses=self.n_pre_poses,
+                              conditioned=self.autoencoder_conditioned, device=dev, seed=self.rng_seed)
+            self._engine = eng
+        # (re)home every trainable tensor into the flat buffer; cheap pointer check per call
+        for name, _ in eng.layout:
+            p = sd_params[name]
+            v = eng.view(name)
+            if p.data_ptr() != v.data_ptr():
+                v.copy_(p.data)
+                p.data = v
+            g = eng.view(name, True)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+        vq, bn = self.vq_layer, self.decoder.decoder.pre_linear[1]
+        eng.vq_pre_w, eng.vq_pre_b = vq.pre_linear.weight.data, vq.pre_linear.bias.data
+        eng.codebook, eng.ema_w, eng.ema_cs = vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size
+        if eng.bn_rm.data_ptr() != bn.running_mean.data_ptr() or eng.bn_rv.data_ptr() != bn.running_var.data_ptr():
+            eng.bn_rm, eng.bn_rv = bn.running_mean, bn.running_var
+            eng._wstruct = None
+        return eng
+
+    def set_dropout_masks(self, keep95, keep_in=None, keep_l0=None):
+        """Explicit keep masks for the NEXT forward calls (parity tests): keep95 (T-1,B,D) for the inline
+        Dropout(0.95) (:570), keep_in (T,B,D) for self.do (:957), keep_l0 (T-1,B,H) for the decoder GRU."""
+        eng = self.engine()
+        eng.set_masks(keep95.shape[1], keep95, keep_in, keep_l0)
+        self._explicit_masks = True
+
+    def use_random_masks(self):
+        self._explicit_masks = False
+
+    def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, vq_layer_active: bool = False):
+        eng = self.engine()
+        in_poses = in_poses.contiguous()
+        out_poses = out_poses.contiguous()
+        B = in_poses.shape[0]
+        if not self._explicit_masks:
+            eng.draw_masks(B, self.training)
+        if self.training and torch.is_grad_enabled():
+            y, first_hidden, loss_vq, perp = _VQVAEFn.apply(self.encoder.in_layer.weight, self, in_poses, out_poses)
+        else:
+            b = eng.forward(in_poses, out_poses, self.training)
+            y, first_hidden = b["y"].clone(), b["quant"].clone()
+            loss_vq, perp = eng.vq_scalars[0].clone(), eng.vq_scalars[1].clone()
+        if self.training:
+            self.decoder.decoder.pre_linear[1].num_batches_tracked += self.n_frames - 1   # one BN call per decode step
+        return y.transpose(0, 1), first_hidden[: self.n_layers], loss_vq, perp
+
+
+class _VQVAEFn(torch.autograd.Function):
+    """Training-mode forward/backward of the whole module as ONE autograd node: the backward writes every parameter
+    gradient straight into the engine's flat grad buffer (the parameters' .grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, anchor, net: Autoencoder_VQVAE, in_poses, out_poses):
+        eng = net._engine
+        b = eng.forward(in_poses, out_poses, True)
+        ctx.net, ctx.B = net, in_poses.shape[0]
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(in_poses)
+        perp = eng.vq_scalars[1].clone()
+        ctx.mark_non_differentiable(perp)
+        return b["y"].clone(), b["quant"].clone(), eng.vq_scalars[0].clone(), perp
+
+    @staticmethod
+    def backward(ctx, gy, g_first_hidden, g_loss_vq, g_perp):
+        net, B = ctx.net, ctx.B
+        eng = net._engine
+        (in_poses,) = ctx.saved_tensors
+        b = eng.buffers(B)
+        if gy is None:
+            b["dy"].zero_()
+        else:
+            b["dy"].copy_(gy)
+        gl = g_loss_vq.reshape(1).contiguous() if g_loss_vq is not None else torch.zeros(1, device=eng.device)
+        if g_first_hidden is not None:
+            raise NotImplementedError("gradient through decoder_first_hidden is not used by the reference's losses")
+        eng.backward(in_poses, B, gl)
+        for name, _ in eng.layout:      # re-bind in case zero_grad(set_to_none=True) dropped the views
+            p = net.get_parameter(name)
+            g = eng.view(name, True)
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g
+        return None, None, None, None
+
+
+# ---- names the reference also exports but that are outside the accelerated hot path -------------------------------
+def _not_on_path(name):
+    class _Stub(nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(f"{name} is outside the MI355X hot path (SURVEY.md §8a: secondary/unused in the reference)")
+    _Stub.__name__ = name
+    return _Stub
+
+
+VQ_Payam_GSSoft = _not_on_path("VQ_Payam_GSSoft")
+VectorQuantizer = _not_on_path("VectorQuantizer")

@@ -151,9 +151,10 @@ def vq_ema_update(stats, sse_partial, ema_cluster_size, ema_w, codebook, code_sq
     return scalars
 
 
-def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta):
+def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta, out=None):
+    """idx=None: `codebook` is the dense (N,E) saved `quantized` output."""
     N, E = z.shape
-    gz = torch.empty_like(z)
+    gz = torch.empty_like(z) if out is None else out
     check(_lib_().g2v_vq_bwd(_p(g_quantized), _p(g_loss), _p(_chk(z)), _p(_chk(codebook)), _p(idx), _p(gz), N, E,
                              float(beta), _stream()), "vq_bwd")
     return gz
@@ -261,4 +262,11 @@ def fill(t, v):
 
 def add_halves(a, lda, b, ldb, out, ldo, M, H):
     check(_lib_().g2v_add_halves(_p(a), lda, _p(b), ldb, _p(out), ldo, M, H, _stream()), "add_halves")
+    return out
+
+
+def scale(inp, scalar_dev, out=None):
+    if out is None:
+        out = torch.empty_like(inp)
+    check(_lib_().g2v_scale_f32(_p(_chk(inp)), _p(scalar_dev), _p(out), inp.numel(), _stream()), "scale")
     return out

@@ -1,0 +1,88 @@
+"""Per-iteration training functions -- mirror of `scripts/train_eval/train_seq2seq.py` of the reference on the
+MI355X kernels: `custom_loss` (:40-88), `train_iter_Autoencoder_VQ_seq2seq` (:664-758), plus the fused
+clip_grad_norm_(5)+Adam optimiser that replaces `torch.nn.utils.clip_grad_norm_` + `optim.Adam.step` (:743-744)."""
+from __future__ import annotations
+
+import logging
+from typing import Tuple
+
+import torch
+
+from .. import ops
+
+debug = False
+loss_i = 0
+
+
+class _CustomLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, output, target, w1, w2, w3):
+        # the rollout's buffer is time-major; `output` normally IS its transposed view, so this is copy-free
+        y_tbd = output.transpose(0, 1).contiguous()
+        terms, dy = ops.custom_loss_fwd_bwd(y_tbd, target.contiguous(), w1, w2, w3, 1.0, want_grad=True)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(dy)
+        ctx.terms = terms
+        return terms[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dy,) = ctx.saved_tensors
+        out = ops.scale(dy, g.reshape(1).contiguous())
+        return out.transpose(0, 1), None, None, None, None
+
+
+def custom_loss(output: torch.Tensor, target: torch.Tensor, args) -> torch.Tensor:
+    """w_l1 * mean|o-t| + w_cont * sum_t|o_t-o_{t-1}|/numel - w_var * sum ||o[:, :, d]||_2 (over time)/numel."""
+    global loss_i
+    loss = _CustomLossFn.apply(output, target, float(args.loss_l1_weight), float(args.loss_cont_weight),
+                               float(args.loss_var_weight))
+    if loss_i == 100:
+        logging.debug("  (loss) %.5f" % loss.item())
+        loss_i = 0
+    loss_i += 1
+    return loss
+
+
+class FusedClipAdam:
+    """Adam(lr, betas=(0.5, 0.999)) + clip_grad_norm_(max_norm) as one fused kernel pair over the model's flat
+    parameter buffer (train_autoencoder_VQVAE.py:193-195, train_seq2seq.py:743-744).  API subset of
+    torch.optim.Optimizer: zero_grad(), step(), state_dict(), load_state_dict()."""
+
+    def __init__(self, net, lr: float, betas=(0.5, 0.999), eps: float = 1e-8, max_norm: float = 5.0):
+        self.net, self.lr, self.betas, self.eps, self.max_norm = net, float(lr), tuple(betas), float(eps), float(max_norm)
+        self.grad_scale = 1.0
+
+    def zero_grad(self, set_to_none: bool = False):
+        # every backward OVERWRITES the flat grad buffer, so there is nothing to clear
+        return None
+
+    def step(self):
+        eng = self.net.engine()
+        eng.optimizer_step(self.lr, self.betas, self.eps, self.max_norm, self.grad_scale)
+
+    def state_dict(self):
+        eng = self.net.engine()
+        return {"m": eng.m.clone(), "v": eng.v.clone(), "step": eng.step_counter.clone(), "lr": self.lr,
+                "betas": self.betas, "eps": self.eps}
+
+    def load_state_dict(self, sd):
+        eng = self.net.engine()
+        eng.m.copy_(sd["m"]); eng.v.copy_(sd["v"]); eng.step_counter.copy_(sd["step"])
+        self.lr, self.betas, self.eps = float(sd["lr"]), tuple(sd["betas"]), float(sd["eps"])
+
+
+def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tensor, target_poses: torch.Tensor,
+                                      net: torch.nn.Module, optim) -> Tuple[dict, torch.Tensor]:
+    """One training iteration of the chunk VQ-VAE; same signature / return value as the reference."""
+    if not isinstance(optim, FusedClipAdam):
+        raise TypeError("use gesture2vec_amd.train_eval.train_seq2seq.FusedClipAdam (clip + Adam are one fused HIP launch)")
+    optim.zero_grad()
+    vq_start_epoch = 0
+    outputs, _, loss_vq, perplexity_vq = net(input_poses, target_poses, epoch > vq_start_epoch)
+    loss = custom_loss(outputs, target_poses, args)
+    if epoch > vq_start_epoch:
+        loss = loss + 1 * loss_vq / 400
+    loss.backward()
+    optim.step()            # clip_grad_norm_(net.parameters(), 5) is fused into the step
+    return {"loss": loss.item()}, perplexity_vq.detach()

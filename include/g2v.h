@@ -111,7 +111,9 @@ int g2v_vq_ema_update(const float* stats, const float* sse_partial, int n_sse_pa
                       float beta, float decay, float eps, int update, g2v_stream_t stream);
 
 /* K5': gz = g_quantized + g_loss * 2*beta/(N*E) * (z - W[idx])   (autograd of :1285-1292).
- * g_loss is a device scalar (d total / d loss_vq), g_quantized may be NULL. */
+ * g_loss is a device scalar (d total / d loss_vq), g_quantized may be NULL.
+ * idx == NULL: `codebook` is instead the dense (N,E) forward output `quantized` (= z + (W[idx]-z)), so the
+ * backward does not depend on a codebook that the EMA update has already moved. */
 int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, const float* codebook,
                const int64_t* idx, float* gz, int N, int E, float beta, g2v_stream_t stream);
 
@@ -234,6 +236,8 @@ int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int6
 
 /* small helpers used by the host */
 int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream);
+/* out[i] = in[i] * scalar[0]   (scalar is a DEVICE float: chains an upstream autograd scalar without a host sync) */
+int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g2v_stream_t stream);
 int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream); /* out[c][r] = in[r][c] */
 /* out[m, 0:H] = a[m, 0:H] + b[m, 0:H] with row strides (sum of the two GRU directions, :95-97) */
 int g2v_add_halves(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
