@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- gesture-chunks/sec of one full VQ-VAE train iteration (BASELINE.json metric).
+
+One "step" = one `train_iter_Autoencoder_VQ_seq2seq` equivalent on a batch of synthetic pose chunks already
+resident in HBM: Philox dropout masks -> encoder -> EMA quantiser (assign + stats + EMA update) -> T-1 step decoder
+rollout -> custom_loss -> full backward -> [DP: one RCCL all-reduce of grads + EMA stats] -> fused clip+Adam.
+Workload at N=1: BASELINE.json configs[1] "VQ-VAE.yml full" = B=4096, T=34, D=135, H=64, L=2 (E=128), K=512, fp32.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      the VQ assign kernel (the kernel BASELINE.json's north star names), timed live with events on the
+                launch stream; fp32 MFMA bound (arithmetic intensity K/4 flop/B > fp32 ridge)
+  cpu_baseline  the CPU oracle (oracle/g2v_oracle.py, kind "port") timed on this host's cores on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CFG = dict(B=4096, T=34, D=135, H=64, L=2, K=512, beta=0.25, dropout_prob=0.0, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def model_args():
+    return argparse.Namespace(
+        rep_learning_dim=CFG["D"], hidden_size=CFG["H"], n_layers=CFG["L"], dropout_prob=CFG["dropout_prob"],
+        autoencoder_vae="False", autoencoder_vq="True", autoencoder_vq_components=CFG["K"],
+        autoencoder_vq_commitment_cost=CFG["beta"], n_pre_poses=1, autoencoder_conditioned="True",
+        autoencoder_att="False", autoencoder_fixed_weight="False", n_poses=CFG["T"])
+
+
+def cpu_baseline(budget_s: float = 12.0):
+    """Oracle (CPU restatement, parity-pinned to the reference) on the host cores: bounded sample of the same workload."""
+    from oracle import g2v_oracle as O
+    torch.set_num_threads(os.cpu_count() or 1)
+    B, T, D, H, K = CFG["B"], CFG["T"], CFG["D"], CFG["H"], CFG["K"]
+    sd = O.init_vqvae_state(D, H, 2, K, seed=0)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(B, T, D, generator=g)
+    cfg = dict(n_layers=2, dropout_prob=0.0, commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
+               w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], lr=CFG["lr"])
+    adam = {}
+    masks = {"dec": (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)}
+    O.vqvae_train_step(sd, adam, x, masks, cfg)        # warm-up (allocator, thread pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.vqvae_train_step(sd, adam, x, masks, cfg)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 8:
+            break
+    return {"value": round(B * n / dt, 1), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} full train steps at B={B} (oracle/g2v_oracle.py on torch-CPU fp32, {dt:.1f}s after 1 warm-up)"}
+
+
+def vq_kernel_roofline(eng, B, reps: int = 200):
+    """Average duration of the VQ assign kernel (K1+K2+K5) at the benchmark size, events on the launch stream."""
+    from gesture2vec_amd._lib import check
+    lib = eng.lib
+    b = eng.buffers(B)
+    N, E, K = (2 * B * eng.H) // eng.E, eng.E, eng.K
+    st = torch.cuda.current_stream()
+    args = (b["flat"].data_ptr(), b["enc_hidden"].data_ptr(), eng.codebook.data_ptr(), eng.code_sqnorm.data_ptr(),
+            b["idx"].data_ptr(), b["quant"].data_ptr(), None, b["sse"].data_ptr(), N, E, K, st.cuda_stream)
+    for _ in range(20):
+        check(lib.g2v_vq_assign_fwd(*args))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(reps):
+        check(lib.g2v_vq_assign_fwd(*args))
+    e1.record(st)
+    e1.synchronize()
+    us = e0.elapsed_time(e1) * 1e3 / reps
+    flops = 2.0 * N * K * E                      # 2KE flop per quantiser row
+    bytes_alg = N * (8 * E + 4) + 4 * K * E      # 8E+4 B per row (read flat+z... see DESIGN.md) + one codebook read
+    tf = flops / (us * 1e-6) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": "vq_assign_kernel", "avg_us": round(us, 3), "flops_per_launch": flops,
+            "algorithmic_bytes_per_launch": bytes_alg,
+            "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (weak scaling)")
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} needs torch.distributed.run with --nproc-per-node {a.gpus} (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    lib = _lib.load()                              # raises if the HIP library is not built
+    assert lib.g2v_device_ok() == 1, "bench.py needs an MI355X (gfx950)"
+
+    B, T, D = a.batch, CFG["T"], CFG["D"]
+    torch.manual_seed(0)                            # identical initial weights on every rank
+    net = Autoencoder_VQVAE(model_args(), D, T).to(dev)
+    net.rng_seed = 1234 + rank
+    net.train(True)
+    eng = net.engine()
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)   # rank-dependent shard
+
+    reduce_fn = None
+    if world > 1:
+        def reduce_fn(buf):
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    def step():
+        eng.train_step(x, x, lr=CFG["lr"], w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], epoch=1,
+                       draw_masks=True, reduce_fn=reduce_fn, world=world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # untimed warm-up (also sizes every workspace so that addresses are final before capture)
+    for _ in range(max(a.warmup, 2)):
+        step()
+    torch.cuda.synchronize()
+    graph = None
+    if not a.no_graph and world == 1:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                step()
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            graph = g
+            for _ in range(2):
+                graph.replay()
+            torch.cuda.synchronize()
+        except Exception as e:   # capture is an optimisation, never a correctness requirement
+            print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
+            graph = None
+
+    run = graph.replay if graph is not None else step
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        run()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    loss = eng.loss_terms[0].item() + eng.vq_scalars[0].item() / 400
+    assert loss == loss, "loss is NaN"
+
+    if rank == 0:
+        out = {
+            "metric": "gesture-chunks/sec VQ-VAE fwd+bwd (T=34,D=135,K=512)", "value": round(B * world * a.steps / dt, 1),
+            "unit": "chunks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "VQ-VAE.yml full (BASELINE configs[1]): train_iter_Autoencoder_VQ_seq2seq on "
+                                   f"synthetic N(0,1) pose chunks, B={B}/GPU, T=34, D=135, H=64, L=2 (E=128), K=512, "
+                                   "dropout_prob=0 (+ always-on Dropout(0.95)), Adam lr=5e-4, random-init weights",
+                       "global_batch": B * world, "per_gpu_batch": B,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "launch": "hipGraph replay" if graph is not None else "eager launches",
+                       "final_loss": round(loss, 6)},
+        }
+        if world == 1:
+            out["roofline"] = vq_kernel_roofline(eng, B)
+            if not a.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,7 +90,9 @@ class VQVAEEngine:
         self.n_flat = off
         dev = self.device
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        self.gflat = torch.zeros(off, dtype=torch.float32, device=dev)
+        # ONE communication buffer [flat grads | cnt (K) | dw (K*E)]: a single RCCL all-reduce per step under DP
+        self.comm = torch.zeros(off + K + K * (H * L), dtype=torch.float32, device=dev)
+        self.gflat = self.comm[:off]
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.step_counter = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -107,7 +109,7 @@ class VQVAEEngine:
         self.code_sqnorm = torch.zeros(K, device=dev)
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
-        self.vq_stats = torch.zeros(K + K * E, device=dev)
+        self.vq_stats = self.comm[self.n_flat:]
         self.vq_scalars = torch.zeros(2, device=dev)          # loss_vq, perplexity
         self.loss_terms = torch.zeros(4, device=dev)          # custom_loss total, l1, cont, var
         self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
@@ -345,7 +347,7 @@ class VQVAEEngine:
     def train_step(self, x: torch.Tensor, target: torch.Tensor, *, lr: float, w_l1: float, w_cont: float,
                    w_var: float, epoch: int = 1, draw_masks: bool = True, reduce_fn=None, world: int = 1):
         """train_iter_Autoencoder_VQ_seq2seq (train_eval/train_seq2seq.py:664-758) without host syncs.
-        reduce_fn(flat_grad, vq_stats) performs the data-parallel SUM all-reduce (RCCL) when world > 1."""
+        reduce_fn(comm) performs the data-parallel SUM all-reduce (RCCL) of [grads | EMA stats] when world > 1."""
         B = x.shape[0]
         if draw_masks:
             self.draw_masks(B, True)
@@ -355,6 +357,6 @@ class VQVAEEngine:
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)
         if dp:
-            reduce_fn(self.gflat, self.vq_stats)
+            reduce_fn(self.comm)
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, grad_scale=1.0 / world if dp else 1.0)
