@@ -41,27 +41,43 @@ def model_args():
 
 
 def cpu_baseline(budget_s: float = 12.0):
-    """Oracle (CPU restatement, parity-pinned to the reference) on the host cores: bounded sample of the same workload."""
+    """Oracle (CPU restatement, parity-pinned to the reference) on the host cores: BOUNDED sample of the same workload.
+    The thread count is calibrated (8/16/32) on one small step first: on a 256-core host the many tiny ops of the
+    T-1 step Python loop get slower, not faster, with every core in the pool."""
     from oracle import g2v_oracle as O
-    torch.set_num_threads(os.cpu_count() or 1)
-    B, T, D, H, K = CFG["B"], CFG["T"], CFG["D"], CFG["H"], CFG["K"]
-    sd = O.init_vqvae_state(D, H, 2, K, seed=0)
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(B, T, D, generator=g)
+    Bs, T, D, H, K = 1024, CFG["T"], CFG["D"], CFG["H"], CFG["K"]     # sample batch: 1/4 of the GPU batch
     cfg = dict(n_layers=2, dropout_prob=0.0, commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
                w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], lr=CFG["lr"])
-    adam = {}
-    masks = {"dec": (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)}
-    O.vqvae_train_step(sd, adam, x, masks, cfg)        # warm-up (allocator, thread pool)
-    n, t0 = 0, time.perf_counter()
-    while True:
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(Bs, T, D, generator=g)
+    masks = {"dec": (torch.rand(T - 1, Bs, D, generator=g) < 0.05).to(torch.uint8)}
+
+    def one(sd, adam):
+        t0 = time.perf_counter()
         O.vqvae_train_step(sd, adam, x, masks, cfg)
-        n += 1
-        dt = time.perf_counter() - t0
-        if dt >= budget_s or n >= 8:
+        return time.perf_counter() - t0
+
+    ncpu = os.cpu_count() or 1
+    best_thr, best_t = 1, float("inf")
+    for thr in sorted({min(ncpu, c) for c in (8, 16, 32)}):
+        torch.set_num_threads(thr)
+        sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
+        one(sd, adam)                       # warm-up at this thread count
+        t = one(sd, adam)
+        if t < best_t:
+            best_thr, best_t = thr, t
+        if t > 20.0:                        # pathological host: stop calibrating
             break
-    return {"value": round(B * n / dt, 1), "unit": "chunks/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} full train steps at B={B} (oracle/g2v_oracle.py on torch-CPU fp32, {dt:.1f}s after 1 warm-up)"}
+    torch.set_num_threads(best_thr)
+    sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
+    one(sd, adam)
+    n, tot = 0, 0.0
+    while tot < budget_s and n < 40:
+        tot += one(sd, adam)
+        n += 1
+    return {"value": round(Bs * n / tot, 1), "unit": "chunks/s", "cores": best_thr, "kind": "port",
+            "sample": f"{n} full train steps at B={Bs} (1/4 of the GPU batch; oracle/g2v_oracle.py, torch-CPU fp32, "
+                      f"{best_thr} threads of {ncpu} host cores, {tot:.1f}s after warm-up)"}
 
 
 def vq_kernel_roofline(eng, B, reps: int = 200):

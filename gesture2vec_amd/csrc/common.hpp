@@ -129,14 +129,74 @@ __device__ __forceinline__ void stage_rows(float* Xs, int ldx, int Kp, const flo
 }
 
 
-// sum of `nsplit` slabs of n floats, in slab order (deterministic), optionally on top of `out`
-static __global__ void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
-                                          float* __restrict__ out, int accumulate) {
-  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n) return;
-  float s = accumulate ? out[e] : 0.f;
-  for (int p = 0; p < nsplit; ++p) s += slab[(int64_t)p * n + e];
-  out[e] = s;
+// sum of `nsplit` slabs of n floats, in a fixed order (deterministic), optionally on top of `out`.
+// 256 threads = 64 consecutive elements x 4 split-groups; each group keeps 4 independent accumulators so that
+// 16 loads per element are in flight (the slabs were just written by another kernel: every load is an L2/MALL miss).
+static __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slab, int nsplit, int64_t n,
+                                                                 float* __restrict__ out, int accumulate) {
+  __shared__ float red[4][64];
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)blockIdx.x * 64 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    int p = grp;
+    for (; p + 12 < nsplit; p += 16) {
+      s0 += slab[(int64_t)p * n + e];
+      s1 += slab[(int64_t)(p + 4) * n + e];
+      s2 += slab[(int64_t)(p + 8) * n + e];
+      s3 += slab[(int64_t)(p + 12) * n + e];
+    }
+    for (; p < nsplit; p += 4) s0 += slab[(int64_t)p * n + e];
+  }
+  red[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+static inline void launch_slab_reduce(const float* slab, int nsplit, int64_t n, float* out, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, slab, nsplit, n, out, accumulate);
+}
+
+// Column sums of a [nblk][ncol] array of per-workgroup partials into LDS `out[ncol]`, by all 256 threads, in a fixed
+// order.  The partials were written by OTHER CUs in the previous launch, so every load is a miss: keep many of them
+// in flight (16 independent accumulators per thread) instead of a serial per-column chain.
+// scratch: LDS, >= 256 floats.  Ends with a __syncthreads(); out is valid for every thread afterwards.
+__device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblk, int ncol, float* out,
+                                                float* scratch, int tid) {
+  for (int c0 = 0; c0 < ncol; c0 += 256) {
+    const int nc = min(256, ncol - c0);
+    const int nseg = max(1, 256 / nc);
+    const int seg = tid / nc, col = tid - seg * nc;
+    const int per = (nblk + nseg - 1) / nseg;
+    float tot = 0.f;
+    if (seg < nseg) {
+      const int kb = seg * per, ke = min(nblk, kb + per);
+      const float* p = part + c0 + col;
+      float s[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s[j] = 0.f;
+      int k = kb;
+      for (; k + 16 <= ke; k += 16) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) s[j] += p[(int64_t)(k + j) * ncol];
+      }
+      for (; k < ke; ++k) s[0] += p[(int64_t)k * ncol];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += s[j + 8];
+      tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+    }
+    __syncthreads();             // scratch may still be read from the previous chunk
+    if (seg < nseg) scratch[seg * nc + col] = tot;
+    __syncthreads();
+    if (tid < nc) {
+      float t = 0.f;
+      for (int g = 0; g < nseg; ++g) t += scratch[g * nc + tid];
+      out[c0 + tid] = t;
+    }
+  }
+  __syncthreads();
 }
 
 static __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {

@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   float* Xh1n = Xx1 + 16 * ldh;     // h1_t
   float* Xy = Xh1n + 16 * ldh;      // xin_{t+1}         [16][ldd]
   float* st = Xy + 16 * ldd;        // mean[Hp], invstd[Hp]
+  float* red = st + 2 * Hp;         // column sums of the BN partials [2H]
+  float* red_scratch = red + 2 * Hp;  // [256]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16;
@@ -117,12 +119,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     const float* ut = sv.u + (int64_t)(t - 1) * B * H;
     if (dm.training) {
       const float* part = sv.bn_partial + (int64_t)((t - 1) & 1) * dm.nblk * 2 * H;
+      reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
       for (int f = tid; f < H; f += 256) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < dm.nblk; ++k) {
-          s1 += part[(int64_t)k * 2 * H + f];
-          s2 += part[(int64_t)k * 2 * H + H + f];
-        }
+        const float s1 = red[f], s2 = red[H + f];
         const float mv = s1 / (float)B;
         const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);   // biased batch variance
         const float mean = mv + w.b_pre[f];
@@ -308,6 +307,8 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   float* Dd = Gh + 16 * ldg;        // dh * z            [16][ldh]
   float* Xdx = Dd + 16 * ldh;       // dh0 incoming      [16][ldh]
   float* st = Xdx + 16 * ldh;       // S1[Hp], S2[Hp]
+  float* red = st + 2 * Hp;         // [2H]
+  float* red_scratch = red + 2 * Hp;  // [256]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16;
@@ -322,12 +323,9 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   // ================= Part A: finish BatchNorm backward of step t+1 ===================================
   if (!last) {
     const float* part = gr.bn_bwd_partial + (int64_t)((t + 1) & 1) * dm.nblk * 2 * H;
+    reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
     for (int f = tid; f < H; f += 256) {
-      float s1 = 0.f, s2 = 0.f;
-      for (int k = 0; k < dm.nblk; ++k) {
-        s1 += part[(int64_t)k * 2 * H + f];
-        s2 += part[(int64_t)k * 2 * H + H + f];
-      }
+      const float s1 = red[f], s2 = red[H + f];
       st[f] = s1;
       st[Hp + f] = s2;
       if (blockIdx.x == 0) {   // d gamma / d beta accumulate over the steps (one writer, stream ordered)
@@ -472,11 +470,11 @@ extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 static size_t dec_fwd_lds(int D, int H) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15;
-  return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 2 * Hp) * sizeof(float);
+  return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp + 256) * sizeof(float);
 }
 static size_t dec_bwd_lds(int D, int H) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, Gp = (3 * H + 15) & ~15;
-  return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 2 * Hp) * sizeof(float);
+  return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp + 256) * sizeof(float);
 }
 
 extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,

@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 
 static int tn_splits(int M, int K, int N) {
   const int tiles = cdiv(N, 64) * cdiv(K, 64);
-  int splits = cdiv(1024, tiles);
+  int splits = cdiv(512, tiles);
+  if (splits > 128) splits = 128;
   const int max_splits = cdiv(M, 4 * TM);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -260,12 +261,10 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
                      slab_db, M, K, N, rows_per_split);
   G2V_CHECK_LAUNCH();
   const int64_t n = (int64_t)N * K;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, slab, splits, n, dw,
-                     accumulate);
+  launch_slab_reduce(slab, splits, n, dw, accumulate, (hipStream_t)stream);
   G2V_CHECK_LAUNCH();
   if (db) {
-    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, slab_db, splits,
-                       (int64_t)N, db, accumulate);
+    launch_slab_reduce(slab_db, splits, (int64_t)N, db, accumulate, (hipStream_t)stream);
     G2V_CHECK_LAUNCH();
   }
   return G2V_OK;

@@ -341,11 +341,9 @@ extern "C" int g2v_vq_stats(const int64_t* idx, const float* flat, float* stats,
   hipLaunchKernelGGL(vq_stats_kernel, dim3(cdiv(K, 64), cdiv(E, 64), splits), dim3(256), 0, (hipStream_t)stream, idx,
                      flat, slab_dw, slab_cnt, N, E, K, rows_per_split);
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(K, 256)), dim3(256), 0, (hipStream_t)stream, slab_cnt, splits,
-                     (int64_t)K, stats, 0);
+  launch_slab_reduce(slab_cnt, splits, (int64_t)K, stats, 0, (hipStream_t)stream);
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, (hipStream_t)stream, slab_dw,
-                     splits, (int64_t)K * E, stats + K, 0);
+  launch_slab_reduce(slab_dw, splits, (int64_t)K * E, stats + K, 0, (hipStream_t)stream);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
