@@ -99,6 +99,104 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NT], const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Packed ("fragment-major") weights.  A weight matrix used as the MFMA A operand is re-laid-out once per
+// call so that the 64 lanes of a wave read one fully coalesced, 16-byte-aligned 1 KiB block per
+// (16-feature tile, 16-deep k-step), with zero padding baked in (no bounds checks, no alignment cases):
+//   P[((tile * KS + s) * 64 + lane) * 4 + e] = W[row(tile, lane & 15)][16 s + 4 (lane >> 4) + e]
+// Gate matrices (3H x H) are packed gate-major: tile = g * ntile_g + f covers rows g*H + 16 f + i.
+// ---------------------------------------------------------------------------------------------
+struct PackDesc {
+  const float* src;
+  float* dst;
+  int rows_per_group, ngroups, group_row_stride, K, ld, transposed;   // transposed: elem(r,c) = src[c*ld + r]
+};
+static inline int pack_ntile_g(int rows_per_group) { return (rows_per_group + 15) >> 4; }
+static inline int pack_ks(int K) { return (K + 15) >> 4; }
+static inline size_t pack_floats(int rows_per_group, int ngroups, int K) {
+  return (size_t)ngroups * pack_ntile_g(rows_per_group) * pack_ks(K) * 256;
+}
+constexpr int MAX_PACK = 8;
+struct PackBatch {
+  PackDesc d[MAX_PACK];
+  int n;
+};
+static __global__ __launch_bounds__(256) void pack_kernel(PackBatch pb) {
+  const PackDesc d = pb.d[blockIdx.y];
+  const int ntg = (d.rows_per_group + 15) >> 4, KS = (d.K + 15) >> 4;
+  const int nblocks = d.ngroups * ntg * KS;            // one 256-float block per (tile, kstep) = 64 lanes x 4
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int s = blk % KS, tile = blk / KS;
+    const int g = tile / ntg, f = tile - g * ntg;
+    const int lane = threadIdx.x >> 2, e = threadIdx.x & 3;
+    const int i = lane & 15, q = lane >> 4;
+    const int rg = 16 * f + i, c = 16 * s + 4 * q + e;
+    float v = 0.f;
+    if (rg < d.rows_per_group && c < d.K) {
+      const int r = g * d.group_row_stride + rg;
+      v = d.transposed ? d.src[(int64_t)c * d.ld + r] : d.src[(int64_t)r * d.ld + c];
+    }
+    d.dst[(int64_t)blk * 256 + threadIdx.x] = v;
+  }
+}
+static inline void launch_pack(const PackBatch& pb, hipStream_t st) {
+  hipLaunchKernelGGL(pack_kernel, dim3(64, pb.n), dim3(256), 0, st, pb);
+}
+
+// One wave accumulates NT tiles from PACKED weights: tile index of accumulator t is tile0 + t * tile_stride.
+// KS_T > 0: compile-time k-steps, every fragment load is issued before the first MFMA (registers: NT*KS_T*4).
+// KS_T == 0: run-time k-steps with a one-step register prefetch.
+template <int NT, int KS_T>
+__device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __restrict__ P, int KS, int tile0,
+                                            int tile_stride, const float* Xs, int ldx, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const float* xrow = Xs + i * ldx + 4 * q;
+  if constexpr (KS_T > 0) {
+    float4 wa[NT][KS_T];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int s = 0; s < KS_T; ++s)
+        wa[t][s] = *reinterpret_cast<const float4*>(P + ((int64_t)((tile0 + t * tile_stride) * KS_T + s) * 64 + lane) * 4);
+#pragma unroll
+    for (int s = 0; s < KS_T; ++s) {
+      const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(wa[t][s].x, xb.x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(wa[t][s].y, xb.y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(wa[t][s].z, xb.z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(wa[t][s].w, xb.w, acc[t]);
+    }
+  } else {
+    const float* pt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) pt[t] = P + ((int64_t)(tile0 + t * tile_stride) * KS * 64 + lane) * 4;
+    float4 cur[NT], nxt[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cur[t] = *reinterpret_cast<const float4*>(pt[t]);
+    for (int s = 0; s < KS; ++s) {
+      if (s + 1 < KS) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) nxt[t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)(s + 1) * 256);
+      }
+      const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].x, xb.x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].y, xb.y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].z, xb.z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].w, xb.w, acc[t]);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
+    }
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // sum over the 16 lanes that share lane>>4 (i.e. over j = lane & 15)

@@ -21,16 +21,35 @@
 
 namespace g2v {
 
+#ifdef G2V_STAMPS
+__device__ unsigned long long g2v_stamps[64 * 16];
+#define STAMP(k)                                                                                   \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 4 && t == 5)                                              \
+      g2v_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                           \
+  } while (0)
+#else
+#define STAMP(k)
+#endif
+
 struct DecDims {
   int T, B, D, H;
   float p_drop;
   int n_pre, conditioned, training, nblk;
 };
 
+// packed forward weights (fragment-major, see common.hpp): offsets in floats into the workspace
+struct DecPackF {
+  const float* pre;    // rows H, K = D
+  const float* ih0; const float* hh0; const float* ih1; const float* hh1;   // 3 gate groups x H rows, K = H
+  const float* out;    // rows D, K = H
+};
+
 // ---- one GRU cell for the feature tiles of this wave ------------------------------------------------
-// x-operand Xin [16][ldh] (layer input), Xh [16][ldh] (previous hidden).  Writes h_new to `Hout` LDS
-// (after optional inter-layer dropout into `Xdrop`), to global h_out, and the gates.
-__device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ w_ih, const float* __restrict__ w_hh,
+// x-operand Xin [16][ldh] (layer input), Xh [16][ldh] (previous hidden).  Writes h_new (after optional
+// inter-layer dropout) to `Hnext_lds`, h_new to global h_out, and the gates.
+template <int KSH_T>
+__device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, const float* __restrict__ p_hh,
                                              const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                              const float* Xin, const float* Xh, int ldh, int H, int Hp,
                                              float* Hnext_lds,            // [16][ldh]: what the next stage consumes
@@ -40,8 +59,7 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ w_ih, con
                                              float* __restrict__ xdrop_out,  // global (B,H) dropped output or null
                                              int nrows, int lane, int wave) {
   const int i = lane & 15, q = lane >> 4;
-  const bool wv1 = ptr_vec_ok(w_ih, H), wv2 = ptr_vec_ok(w_hh, H);
-  const int ntile = Hp >> 4;
+  const int ntile = Hp >> 4, KS = Hp >> 4;
   for (int ft = wave; ft < ntile; ft += 4) {
     f32x4 ai[3], ah[3];
 #pragma unroll
@@ -49,9 +67,8 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ w_ih, con
       ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    const int nvalid = min(16, H - 16 * ft);
-    wave_gemm<3>(ai, w_ih, (int64_t)H, wv1, 16 * ft, H, nvalid, H, Xin, ldh, lane);
-    wave_gemm<3>(ah, w_hh, (int64_t)H, wv2, 16 * ft, H, nvalid, H, Xh, ldh, lane);
+    wave_gemm_p<3, KSH_T>(ai, p_ih, KS, ft, ntile, Xin, ldh, lane);
+    wave_gemm_p<3, KSH_T>(ah, p_hh, KS, ft, ntile, Xh, ldh, lane);
     const int f0 = 16 * ft + 4 * q;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -78,9 +95,11 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ w_ih, con
   }
 }
 
+template <int HS>
 __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restrict__ target,
                                                            const float* __restrict__ h_init, g2v_dec_weights w,
-                                                           g2v_dec_saved sv, const uint8_t* __restrict__ keep95,
+                                                           DecPackF pk, g2v_dec_saved sv,
+                                                           const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int T = dm.T, B = dm.B, D = dm.D, H = dm.H;
@@ -101,9 +120,11 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   const int i = lane & 15, q = lane >> 4;
   const bool has_next = (t < T - 1);
 
+  STAMP(0);
   // zero the operand tiles once (padding columns / rows must be 0 for the MFMA contractions)
   for (int e = tid; e < 5 * 16 * ldh + 16 * ldd; e += 256) smem[e] = 0.f;
   __syncthreads();
+  STAMP(1);
 
   if (t == 0) {
     // seed the state arrays: h0[0], h1[0] = h_init (the quantised latent)
@@ -120,6 +141,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     if (dm.training) {
       const float* part = sv.bn_partial + (int64_t)((t - 1) & 1) * dm.nblk * 2 * H;
       reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
+      STAMP(2);
       for (int f = tid; f < H; f += 256) {
         const float s1 = red[f], s2 = red[H + f];
         const float mv = s1 / (float)B;
@@ -153,30 +175,32 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       Xh1[r * ldh + f] = sv.h1[(int64_t)(t - 1) * B * H + row];
     }
     __syncthreads();
+    STAMP(3);
     // ---- (c) GRU layer 0 ---------------------------------------------------------------------------
     const bool drop = dm.training && keep_l0 && dm.p_drop > 0.f;
-    gru_cell_fwd(w.w_ih0, w.w_hh0, w.b_ih0, w.b_hh0, Xa, Xh0, ldh, H, Hp, Xx1,
+    constexpr int KSH_T = HS / 16;
+    gru_cell_fwd<KSH_T>(pk.ih0, pk.hh0, w.b_ih0, w.b_hh0, Xa, Xh0, ldh, H, Hp, Xx1,
                  sv.h0 + ((int64_t)t * B + b0) * H,
                  sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
                  drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr, 1.0f / (1.0f - dm.p_drop),
                  (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, lane, wave);
     __syncthreads();
+    STAMP(4);
     // ---- (d) GRU layer 1 ---------------------------------------------------------------------------
-    gru_cell_fwd(w.w_ih1, w.w_hh1, w.b_ih1, w.b_hh1, Xx1, Xh1, ldh, H, Hp, Xh1n,
+    gru_cell_fwd<KSH_T>(pk.ih1, pk.hh1, w.b_ih1, w.b_hh1, Xx1, Xh1, ldh, H, Hp, Xh1n,
                  sv.h1 + ((int64_t)t * B + b0) * H,
                  sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, 1.0f, nullptr, nrows,
                  lane, wave);
     __syncthreads();
+    STAMP(5);
   }
 
   // ---- (e) y_t = out_layer(h1_t)  (t == 0: y_0 = target frame 0), next decoder input ---------------
   {
-    const bool wv = ptr_vec_ok(w.w_out, H);
     const int ntile = Dp >> 4;
     for (int ft = wave; ft < ntile; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, D - 16 * ft);
-      if (t > 0) wave_gemm<1>(acc, w.w_out, (int64_t)H, wv, 16 * ft, 16, nvalid, H, Xh1n, ldh, lane);
+      if (t > 0) wave_gemm_p<1, HS / 16>(acc, pk.out, Hp >> 4, ft, 0, Xh1n, ldh, lane);
       const int d0 = 16 * ft + 4 * q;
       if (i < nrows) {
         const int b = b0 + i;
@@ -201,15 +225,14 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   }
   if (!has_next) return;
   __syncthreads();
+  STAMP(6);
   // ---- (f) u_{t+1} = pre_linear.0(xin_{t+1}) and per-block BN partial sums of (u - b) ----------------
   {
-    const bool wv = ptr_vec_ok(w.w_pre, D);
     const int ntile = Hp >> 4;
     float* part = sv.bn_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
     for (int ft = wave; ft < ntile; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<1>(acc, w.w_pre, (int64_t)D, wv, 16 * ft, 16, nvalid, D, Xy, ldd, lane);
+      wave_gemm_p<1, 0>(acc, pk.pre, Dp >> 4, ft, 0, Xy, ldd, lane);
       const int f0 = 16 * ft + 4 * q;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -224,6 +247,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       }
     }
   }
+  STAMP(7);
 }
 
 // running_mean / running_var (momentum 0.1, unbiased variance), applied T-1 times in step order
@@ -244,10 +268,10 @@ __global__ void bn_running_update_kernel(const float* __restrict__ bn_stats, flo
 // =====================================================================================================
 // backward
 // =====================================================================================================
-struct DecTW {   // transposed weights (contraction index contiguous)
-  const float* w_pre_t;   // (D,H)   = W_pre^T
-  const float* w_out_t;   // (H,D)   = W_out^T
-  const float* w_ih0_t; const float* w_hh0_t; const float* w_ih1_t; const float* w_hh1_t;   // (H,3H) each
+struct DecTW {   // PACKED transposed weights (fragment-major; rows = output feature of the backward contraction)
+  const float* w_pre_t;   // rows D, K = H    (W_pre^T)
+  const float* w_out_t;   // rows H, K = D    (W_out^T)
+  const float* w_ih0_t; const float* w_hh0_t; const float* w_ih1_t; const float* w_hh1_t;   // rows H, K = 3H each
 };
 
 // GRU cell backward for the feature tiles of this wave.
@@ -293,6 +317,7 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
   }
 }
 
+template <int HS>
 __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, DecTW tw, g2v_dec_saved sv,
                                                            g2v_dec_grads gr, const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
@@ -356,11 +381,9 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   // ================= Part B: dy_t (loss + feedback) ===================================================
   {
     const bool feedback = (!last) && dm.conditioned && (t >= dm.n_pre);
-    const bool wv = ptr_vec_ok(tw.w_pre_t, H);
     for (int ft = wave; ft < ntd; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, D - 16 * ft);
-      if (feedback) wave_gemm<1>(acc, tw.w_pre_t, (int64_t)H, wv, 16 * ft, 16, nvalid, H, Xdu, ldh, lane);
+      if (feedback) wave_gemm_p<1, HS / 16>(acc, tw.w_pre_t, Hp >> 4, ft, 0, Xdu, ldh, lane);
       const int d0 = 16 * ft + 4 * q;
       if (i < nrows) {
 #pragma unroll
@@ -383,11 +406,9 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   float* carry1_w = gr.dh_init + ((int64_t)B + b0) * H;
   // ---- dh1 = carry + dy W_out ; GRU cell 1 backward -------------------------------------------------
   {
-    const bool wv = ptr_vec_ok(tw.w_out_t, D);
     for (int ft = wave; ft < nth; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<1>(acc, tw.w_out_t, (int64_t)D, wv, 16 * ft, 16, nvalid, D, Xdy, ldd, lane);
+      wave_gemm_p<1, 0>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
       gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
                         sv.h1 + ((int64_t)(t - 1) * B + b0) * H, gr.dgi1 + ((int64_t)(t - 1) * B + b0) * G,
                         gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane);
@@ -396,12 +417,10 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   __syncthreads();
   // ---- carry1' = dh1*z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout bwd) ----------------
   {
-    const bool wv1 = ptr_vec_ok(tw.w_hh1_t, G), wv2 = ptr_vec_ok(tw.w_ih1_t, G);
     for (int ft = wave; ft < nth; ft += 4) {
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<1>(a1, tw.w_hh1_t, (int64_t)G, wv1, 16 * ft, 16, nvalid, G, Gh, ldg, lane);
-      wave_gemm<1>(a2, tw.w_ih1_t, (int64_t)G, wv2, 16 * ft, 16, nvalid, G, Gi, ldg, lane);
+      wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh1_t, Gp >> 4, ft, 0, Gh, ldg, lane);
+      wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih1_t, Gp >> 4, ft, 0, Gi, ldg, lane);
       const int f0 = 16 * ft + 4 * q;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -431,14 +450,12 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   __syncthreads();
   // ---- carry0' = dh0*z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU bwd -> dbn_t + BN-backward partial sums ----
   {
-    const bool wv1 = ptr_vec_ok(tw.w_hh0_t, G), wv2 = ptr_vec_ok(tw.w_ih0_t, G);
     const float* stats = sv.bn_stats + (int64_t)(t - 1) * 2 * H;
     float* part = gr.bn_bwd_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
     for (int ft = wave; ft < nth; ft += 4) {
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<1>(a1, tw.w_hh0_t, (int64_t)G, wv1, 16 * ft, 16, nvalid, G, Gh, ldg, lane);
-      wave_gemm<1>(a2, tw.w_ih0_t, (int64_t)G, wv2, 16 * ft, 16, nvalid, G, Gi, ldg, lane);
+      wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh0_t, Gp >> 4, ft, 0, Gh, ldg, lane);
+      wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih0_t, Gp >> 4, ft, 0, Gi, ldg, lane);
       const int f0 = 16 * ft + 4 * q;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -466,6 +483,12 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
 
 using namespace g2v;
 
+#ifdef G2V_STAMPS
+extern "C" int g2v_read_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+#endif
+
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 static size_t dec_fwd_lds(int D, int H) {
@@ -477,39 +500,71 @@ static size_t dec_bwd_lds(int D, int H) {
   return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp + 256) * sizeof(float);
 }
 
+static size_t pack_fwd_total(int D, int H) {
+  return pack_floats(H, 1, D) + 4 * pack_floats(H, 3, H) + pack_floats(D, 1, H);
+}
+static size_t pack_bwd_total(int D, int H) {
+  return pack_floats(D, 1, H) + pack_floats(H, 1, D) + 4 * pack_floats(H, 1, 3 * H);
+}
+
+extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return pack_fwd_total(D, H) * sizeof(float); }
+
 extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,
                                    const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
                                    int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
-                                   g2v_stream_t stream) {
-  G2V_REQUIRE(target && h_init && w && s && keep95, "null pointer");
+                                   void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(target && h_init && w && s && keep95 && workspace, "null pointer");
   G2V_REQUIRE(T >= 2 && B > 0 && D > 0 && H > 0, "bad size");
   G2V_REQUIRE(s->y && s->u && s->h0 && s->h1 && s->bn_partial, "missing state buffer");
   G2V_REQUIRE(!training || (s->xin && s->a && s->gates0 && s->gates1 && s->bn_stats), "missing saved buffer");
   G2V_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  if (workspace_bytes < g2v_dec_rollout_fwd_workspace(D, H)) {
+    set_error("g2v_dec_rollout_fwd: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
   const size_t lds = dec_fwd_lds(D, H);
   if (lds > 160 * 1024) {
     set_error("g2v_dec_rollout_fwd: D/H too large for LDS");
     return G2V_ERR_UNSUPPORTED;
   }
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipStream_t st = (hipStream_t)stream;
+  // ---- pack the weights into MFMA fragment order (one launch) ----
+  float* p = (float*)workspace;
+  DecPackF pk;
+  PackBatch pb;
+  pb.n = 6;
+  pb.d[0] = PackDesc{w->w_pre, p, H, 1, 0, D, D, 0}; pk.pre = p; p += pack_floats(H, 1, D);
+  pb.d[1] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
+  pb.d[2] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
+  pb.d[3] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
+  pb.d[4] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
+  pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0}; pk.out = p; p += pack_floats(D, 1, H);
+  launch_pack(pb, st);
+  G2V_CHECK_LAUNCH();
   DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16)};
+  const bool fast = (H == 64);
+  if (lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   for (int t = 0; t < T; ++t) {
-    hipLaunchKernelGGL(dec_step_fwd_kernel, dim3(dm.nblk), dim3(256), lds, (hipStream_t)stream, target, h_init, *w, *s,
-                       keep95, keep_l0, dm, t);
+    if (fast)
+      hipLaunchKernelGGL(dec_step_fwd_kernel<64>, dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
+                         keep_l0, dm, t);
+    else
+      hipLaunchKernelGGL(dec_step_fwd_kernel<0>, dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
+                         keep_l0, dm, t);
   }
   G2V_CHECK_LAUNCH();
   if (training) {
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, s->bn_stats,
+    hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, s->bn_stats,
                        w->bn_running_mean, w->bn_running_var, T - 1, H, B);
     G2V_CHECK_LAUNCH();
   }
   return G2V_OK;
 }
 
-extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
-  return (size_t)(2 * D * H + 4 * 3 * H * H) * sizeof(float);
-}
+extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) { return pack_bwd_total(D, H) * sizeof(float); }
 
 extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
                                    const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
@@ -531,21 +586,30 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
     return G2V_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
-  float* ws = (float*)workspace;
+  float* p = (float*)workspace;
   DecTW tw;
-  float* p = ws;
-  launch_transpose(w->w_pre, p, H, D, st); tw.w_pre_t = p; p += (size_t)D * H;       // (H,D) -> (D,H)
-  launch_transpose(w->w_out, p, D, H, st); tw.w_out_t = p; p += (size_t)D * H;       // (D,H) -> (H,D)
-  launch_transpose(w->w_ih0, p, 3 * H, H, st); tw.w_ih0_t = p; p += (size_t)3 * H * H;
-  launch_transpose(w->w_hh0, p, 3 * H, H, st); tw.w_hh0_t = p; p += (size_t)3 * H * H;
-  launch_transpose(w->w_ih1, p, 3 * H, H, st); tw.w_ih1_t = p; p += (size_t)3 * H * H;
-  launch_transpose(w->w_hh1, p, 3 * H, H, st); tw.w_hh1_t = p; p += (size_t)3 * H * H;
+  PackBatch pb;
+  pb.n = 6;
+  const int G = 3 * H;
+  pb.d[0] = PackDesc{w->w_pre, p, D, 1, 0, H, D, 1}; tw.w_pre_t = p; p += pack_floats(D, 1, H);   // rows d, k = f: W_pre[f][d]
+  pb.d[1] = PackDesc{w->w_out, p, H, 1, 0, D, H, 1}; tw.w_out_t = p; p += pack_floats(H, 1, D);   // rows f, k = d: W_out[d][f]
+  pb.d[2] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1}; tw.w_ih0_t = p; p += pack_floats(H, 1, G);   // rows k, contraction g: W[g][k]
+  pb.d[3] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1}; tw.w_hh0_t = p; p += pack_floats(H, 1, G);
+  pb.d[4] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1}; tw.w_ih1_t = p; p += pack_floats(H, 1, G);
+  pb.d[5] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1}; tw.w_hh1_t = p; p += pack_floats(H, 1, G);
+  launch_pack(pb, st);
   G2V_CHECK_LAUNCH();
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (lds > 48 * 1024) {
+    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16)};
+  const bool fast = (H == 64);
   for (int t = T - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(dec_step_bwd_kernel, dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
+    if (fast)
+      hipLaunchKernelGGL(dec_step_bwd_kernel<64>, dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
+    else
+      hipLaunchKernelGGL(dec_step_bwd_kernel<0>, dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
   }
   G2V_CHECK_LAUNCH();
   return G2V_OK;

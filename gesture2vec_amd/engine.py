@@ -195,7 +195,8 @@ class VQVAEEngine:
         gr.d_bn_w, gr.d_bn_b = self._g(pre + "pre_linear.1.weight"), self._g(pre + "pre_linear.1.bias")
         gr.bn_bwd_partial = _p(b["bn_bwd_partial"])
         b["gr"] = gr
-        ws_bytes = max(self.lib.g2v_dec_rollout_bwd_workspace(D, H), self.lib.g2v_gru_seq_bwd_workspace(H),
+        ws_bytes = max(self.lib.g2v_dec_rollout_bwd_workspace(D, H), self.lib.g2v_dec_rollout_fwd_workspace(D, H),
+                       self.lib.g2v_gru_seq_bwd_workspace(H),
                        self.lib.g2v_vq_stats_workspace(B, E, K),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)))
@@ -267,7 +268,7 @@ class VQVAEEngine:
         check(lib.g2v_dec_rollout_fwd(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
                                       C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
                                       _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
-                                      int(self.conditioned), int(training), T, B, D, H, st))
+                                      int(self.conditioned), int(training), T, B, D, H, _p(b["ws"]), b["ws"].numel(), st))
         return b
 
     def vq_finish(self, B: int, training: bool, n_global: Optional[int] = None):

@@ -210,9 +210,12 @@ def dec_rollout_blocks(B):
 def dec_rollout_fwd(target, h_init, wstruct, saved: dict, keep95, keep_l0, p_drop, n_pre, conditioned, training,
                     T, B, D, H):
     sv = struct_from(DecSaved, saved)
-    check(_lib_().g2v_dec_rollout_fwd(_p(_chk(target)), _p(_chk(h_init)), C.byref(wstruct), C.byref(sv),
-                                      _p(_chk(keep95, torch.uint8)), _p(keep_l0), float(p_drop), int(n_pre),
-                                      int(conditioned), int(training), T, B, D, H, _stream()), "dec_rollout_fwd")
+    lib = _lib_()
+    ws = workspace(lib.g2v_dec_rollout_fwd_workspace(D, H), target.device, "decfwd")
+    check(lib.g2v_dec_rollout_fwd(_p(_chk(target)), _p(_chk(h_init)), C.byref(wstruct), C.byref(sv),
+                                  _p(_chk(keep95, torch.uint8)), _p(keep_l0), float(p_drop), int(n_pre),
+                                  int(conditioned), int(training), T, B, D, H, _p(ws), ws.numel(), _stream()),
+          "dec_rollout_fwd")
 
 
 def dec_rollout_bwd(wstruct, saved: dict, grads: dict, keep95, keep_l0, p_drop, n_pre, conditioned, T, B, D, H):

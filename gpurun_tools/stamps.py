@@ -1,0 +1,25 @@
+"""Diagnostic only (never shipped/timed): per-phase s_memtime stamps of dec_step_fwd_kernel at t=5."""
+import ctypes, subprocess, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gesture2vec_amd", "csrc")
+dbg = os.path.join(root, "gesture2vec_amd", "libg2v_hip.so")
+subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG2V_STAMPS -shared linear.hip vq.hip gru.hip dec_rollout.hip misc.hip -o {dbg}", shell=True)
+import torch, argparse
+from gesture2vec_amd import _lib
+import bench
+from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+lib = _lib.load()
+dev = "cuda:0"
+net = Autoencoder_VQVAE(bench.model_args(), 135, 34).to(dev); net.train(True)
+eng = net.engine()
+x = torch.randn(4096, 34, 135, device=dev)
+for _ in range(3):
+    eng.train_step(x, x, lr=5e-4, w_l1=5, w_cont=.1, w_var=.5)
+torch.cuda.synchronize()
+raw = ctypes.CDLL(dbg)
+buf = (ctypes.c_ulonglong * (64 * 16))()
+print("rc", raw.g2v_read_stamps(buf))
+for b in range(4):
+    st = [buf[b * 16 + k] for k in range(8)]
+    print("block", b, "deltas(ticks@100MHz):", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])

@@ -177,11 +177,13 @@ typedef struct {           /* saved-for-backward / state arrays, all caller-owne
 } g2v_dec_saved;
 
 int g2v_dec_rollout_blocks(int B);
+/* workspace: the weights re-laid-out in MFMA fragment order (packed once per call). */
+size_t g2v_dec_rollout_fwd_workspace(int D, int H);
 int g2v_dec_rollout_fwd(const float* target /* (B,T,D) row-major */, const float* h_init /* (2,B,H) */,
                         const g2v_dec_weights* w, const g2v_dec_saved* s,
                         const uint8_t* keep95 /* (T-1,B,D) */, const uint8_t* keep_l0 /* (T-1,B,H) or NULL */,
                         float p_drop, int n_pre_poses, int conditioned, int training,
-                        int T, int B, int D, int H, g2v_stream_t stream);
+                        int T, int B, int D, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
 typedef struct {           /* gradient outputs of the rollout backward, caller-owned */
   float* dy;               /* (T,B,D) in: dLoss/dy_t (t=0 row ignored); out: total dL/dy_t incl. feedback */
@@ -194,7 +196,7 @@ typedef struct {           /* gradient outputs of the rollout backward, caller-o
   float* bn_bwd_partial;   /* (2, nblk, 2, H) ping-pong per-block sums                              */
 } g2v_dec_grads;
 
-/* workspace: transposed weight copies. */
+/* workspace: transposed weights in MFMA fragment order. */
 size_t g2v_dec_rollout_bwd_workspace(int D, int H);
 int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
                         const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
