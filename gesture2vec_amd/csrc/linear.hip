@@ -123,81 +123,108 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 }
 
 // ---- weight gradient: slab[split][n][k] = sum_{m in split} dy[m][n] * xin[m][k] -------------------
-constexpr int TM = 32, LDW = 64 + 16;
+// One workgroup owns a (64*NTW) x 64 block of dW for a contiguous range of rows m, so with N <= 192 every
+// dy / x element is read from HBM exactly once.  Rows are consumed in chunks of TM = 32: the NEXT chunk's global
+// loads are issued into registers before the MFMAs of the current chunk (HBM latency hidden behind 8*4*NTW MFMAs),
+// then written to LDS.  Wave w owns n-tiles {w, w+4, w+8}; the contraction index (rows) sits on the MFMA k slots.
+constexpr int TM = 32, LDX = 64 + 16;
 
+template <int NTW>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ dY, int64_t lddy,
                                                       const float* __restrict__ X, RowMap xm,
                                                       const uint8_t* __restrict__ keep, float scale,
                                                       float* __restrict__ slab, float* __restrict__ slab_db,
                                                       int M, int K, int N, int rows_per_split) {
-  __shared__ __attribute__((aligned(16))) float Ds[TM * LDW];
-  __shared__ __attribute__((aligned(16))) float Xs[TM * LDW];
+  constexpr int NB = 64 * NTW, LDD = NB + 16;
+  __shared__ __attribute__((aligned(16))) float Ds[TM * LDD];
+  __shared__ __attribute__((aligned(16))) float Xs[TM * LDX];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 64, split = blockIdx.z;
+  const int n0 = blockIdx.x * NB, k0 = blockIdx.y * 64, split = blockIdx.z;
   const int mb = split * rows_per_split;
   const int me = min(M, mb + rows_per_split);
   const int i = lane & 15, q = lane >> 4;
 
-  f32x4 acc[4];
+  f32x4 acc[NTW][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < NTW; ++j)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[j][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbsum = 0.f;
 
-  for (int mc = mb; mc < me; mc += TM) {
-    const int c = tid & 63;
+  // register staging: thread -> column c = tid & 63 (coalesced), rows r = (tid >> 6) + 4 * it
+  float rd[NTW][8], rx[8];
+  const int c = tid & 63, rbase = tid >> 6;
+  auto load_chunk = [&](int mc) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
-      const int r = (tid >> 6) + 4 * it;
-      const int m = mc + r;
-      float dv = 0.f, xv = 0.f;
-      if (m < me) {
-        if (n0 + c < N) dv = dY[(int64_t)m * lddy + n0 + c];
-        if (k0 + c < K) {
-          xv = X[row_off(xm, m) + k0 + c];
-          if (keep) xv = keep[(int64_t)m * K + k0 + c] ? xv * scale : 0.f;
-        }
+      const int m = mc + rbase + 4 * it;
+      const bool mv = m < me;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = n0 + 64 * j + c;
+        rd[j][it] = (mv && n < N) ? dY[(int64_t)m * lddy + n] : 0.f;
       }
-      Ds[r * LDW + c] = dv;
-      Xs[r * LDW + c] = xv;
+      float xv = 0.f;
+      if (mv && k0 + c < K) {
+        xv = X[row_off(xm, m) + k0 + c];
+        if (keep) xv = keep[(int64_t)m * K + k0 + c] ? xv * scale : 0.f;
+      }
+      rx[it] = xv;
+    }
+  };
+  if (mb < me) load_chunk(mb);
+  for (int mc = mb; mc < me; mc += TM) {
+    __syncthreads();   // the previous chunk's MFMAs are done with the LDS tiles
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int r = rbase + 4 * it;
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) Ds[r * LDD + 64 * j + c] = rd[j][it];
+      Xs[r * LDX + c] = rx[it];
     }
     __syncthreads();
-    if (slab_db && blockIdx.y == 0 && tid < 64) {
-      float s = 0.f;
+    if (mc + TM < me) load_chunk(mc + TM);   // in flight while this chunk is multiplied
+    if (slab_db && blockIdx.y == 0 && tid < NB) {
+      float sacc = 0.f;
 #pragma unroll 8
-      for (int r = 0; r < TM; ++r) s += Ds[r * LDW + tid];
-      dbsum += s;
+      for (int r = 0; r < TM; ++r) sacc += Ds[r * LDD + tid];
+      dbsum += sacc;
     }
 #pragma unroll
     for (int s4 = 0; s4 < TM; s4 += 4) {
-      const float a = Ds[(s4 + q) * LDW + 16 * wave + i];
+      float a[NTW], bb[4];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const float b = Xs[(s4 + q) * LDW + 16 * t + i];
-        acc[t] = mfma16(a, b, acc[t]);
-      }
+      for (int j = 0; j < NTW; ++j) a[j] = Ds[(s4 + q) * LDD + 16 * (wave + 4 * j) + i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bb[t] = Xs[(s4 + q) * LDX + 16 * t + i];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[j][t] = mfma16(a[j], bb[t], acc[j][t]);
     }
-    __syncthreads();
   }
-  // lane holds dw[n = n0 + 16*wave + 4q + r][k = k0 + 16t + (lane&15)]
+  // lane holds dw[n = n0 + 16*(wave + 4j) + 4q + r][k = k0 + 16t + (lane&15)]
   float* sl = slab + (int64_t)split * N * K;
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int k = k0 + 16 * t + i;
-    if (k >= K) continue;
+  for (int j = 0; j < NTW; ++j)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int n = n0 + 16 * wave + 4 * q + r;
-      if (n < N) sl[(int64_t)n * K + k] = acc[t][r];
+    for (int t = 0; t < 4; ++t) {
+      const int k = k0 + 16 * t + i;
+      if (k >= K) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * (wave + 4 * j) + 4 * q + r;
+        if (n < N) sl[(int64_t)n * K + k] = acc[j][t][r];
+      }
     }
-  }
-  if (slab_db && blockIdx.y == 0 && tid < 64 && n0 + tid < N) slab_db[(int64_t)split * N + n0 + tid] = dbsum;
+  if (slab_db && blockIdx.y == 0 && tid < NB && n0 + tid < N) slab_db[(int64_t)split * N + n0 + tid] = dbsum;
 }
 
+static int tn_ntw(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 3); }
 static int tn_splits(int M, int K, int N) {
-  const int tiles = cdiv(N, 64) * cdiv(K, 64);
+  const int tiles = cdiv(N, 64 * tn_ntw(N)) * cdiv(K, 64);
   int splits = cdiv(512, tiles);
-  if (splits > 128) splits = 128;
-  const int max_splits = cdiv(M, 4 * TM);
+  const int max_splits = cdiv(M, 2 * TM);
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
   return splits;
@@ -256,9 +283,17 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
   float* slab = (float*)workspace;
   float* slab_db = db ? slab + (size_t)splits * N * K : nullptr;
   RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
-  dim3 grid(cdiv(N, 64), cdiv(K, 64), splits);
-  hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
-                     slab_db, M, K, N, rows_per_split);
+  const int ntw = tn_ntw(N);
+  dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
+  if (ntw == 1)
+    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
+                       slab_db, M, K, N, rows_per_split);
+  else if (ntw == 2)
+    hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
+                       slab_db, M, K, N, rows_per_split);
+  else
+    hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
+                       slab_db, M, K, N, rows_per_split);
   G2V_CHECK_LAUNCH();
   const int64_t n = (int64_t)N * K;
   launch_slab_reduce(slab, splits, n, dw, accumulate, (hipStream_t)stream);
