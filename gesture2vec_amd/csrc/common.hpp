@@ -42,6 +42,12 @@ static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 // it receives D[i = 4*(l >> 4) + r][j = l & 15] in element r of the accumulator.
 // Numerics: bit-for-bit a k-ordered chain of fp32 fmas (no wider accumulation).
 // ---------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic ONLY.  `__syncthreads()` also drains the vector-memory counter
+// (s_waitcnt vmcnt(0)): every barrier would then wait for this wave's outstanding global loads AND stores
+// (an HBM round trip, ~2-3k cycles), serialising the prefetches and the saved-for-backward stores with the MFMAs.
+// Use it wherever the barrier protects LDS data only (never for global-memory hand-offs between threads).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -110,6 +116,7 @@ struct PackDesc {
   const float* src;
   float* dst;
   int rows_per_group, ngroups, group_row_stride, K, ld, transposed;   // transposed: elem(r,c) = src[c*ld + r]
+  int ntile_alloc;   // tiles written per group (>= ceil(rows/16); extra tiles are zero) ; 0 = exactly ceil(rows/16)
 };
 static inline int pack_ntile_g(int rows_per_group) { return (rows_per_group + 15) >> 4; }
 static inline int pack_ks(int K) { return (K + 15) >> 4; }
@@ -123,7 +130,7 @@ struct PackBatch {
 };
 static __global__ __launch_bounds__(256) void pack_kernel(PackBatch pb) {
   const PackDesc d = pb.d[blockIdx.y];
-  const int ntg = (d.rows_per_group + 15) >> 4, KS = (d.K + 15) >> 4;
+  const int ntg = d.ntile_alloc > 0 ? d.ntile_alloc : ((d.rows_per_group + 15) >> 4), KS = (d.K + 15) >> 4;
   const int nblocks = d.ngroups * ntg * KS;            // one 256-float block per (tile, kstep) = 64 lanes x 4
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
     const int s = blk % KS, tile = blk / KS;
@@ -158,6 +165,7 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
 #pragma unroll
       for (int s = 0; s < KS_T; ++s)
         wa[t][s] = *reinterpret_cast<const float4*>(P + ((int64_t)((tile0 + t * tile_stride) * KS_T + s) * 64 + lane) * 4);
+    __builtin_amdgcn_sched_barrier(0);   // keep every fragment load ahead of the MFMAs (hipcc otherwise re-rolls them)
 #pragma unroll
     for (int s = 0; s < KS_T; ++s) {
       const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
@@ -197,7 +205,53 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
   }
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
+// ~1e-7 on values in [-1,1], far inside the 1e-4 relative parity budget, at ~6 instructions instead of ~100.
+// Two contractions into two accumulator sets with ALL weight fragments of both issued before the first MFMA
+// (static k-steps only): used by the GRU cells (input-side and hidden-side products of the same feature tile).
+template <int NT, int KS_T>
+__device__ __forceinline__ void wave_gemm_p2(f32x4 (&acc1)[NT], const float* __restrict__ P1, const float* X1,
+                                             f32x4 (&acc2)[NT], const float* __restrict__ P2, const float* X2,
+                                             int tile0, int tile_stride, int ldx, int lane) {
+  static_assert(KS_T > 0, "static k-steps only");
+  const int i = lane & 15, q = lane >> 4;
+  float4 w1[NT][KS_T], w2[NT][KS_T];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS_T; ++s) {
+      const int64_t off = ((int64_t)((tile0 + t * tile_stride) * KS_T + s) * 64 + lane) * 4;
+      w1[t][s] = *reinterpret_cast<const float4*>(P1 + off);
+      w2[t][s] = *reinterpret_cast<const float4*>(P2 + off);
+    }
+  __builtin_amdgcn_sched_barrier(0);   // all 2*NT*KS_T fragment loads are in flight before the first MFMA
+  const float* x1 = X1 + i * ldx + 4 * q;
+  const float* x2 = X2 + i * ldx + 4 * q;
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) {
+    const float4 a = *reinterpret_cast<const float4*>(x1 + 16 * s);
+    const float4 b = *reinterpret_cast<const float4*>(x2 + 16 * s);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc1[t] = mfma16(w1[t][s].x, a.x, acc1[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[t] = mfma16(w2[t][s].x, b.x, acc2[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc1[t] = mfma16(w1[t][s].y, a.y, acc1[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[t] = mfma16(w2[t][s].y, b.y, acc2[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc1[t] = mfma16(w1[t][s].z, a.z, acc1[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[t] = mfma16(w2[t][s].z, b.z, acc2[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc1[t] = mfma16(w1[t][s].w, a.w, acc1[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc2[t] = mfma16(w2[t][s].w, b.w, acc2[t]);
+  }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
 // sum over the 16 lanes that share lane>>4 (i.e. over j = lane & 15)
 __device__ __forceinline__ float reduce16(float v) {
@@ -258,11 +312,57 @@ static inline void launch_slab_reduce(const float* slab, int nsplit, int64_t n, 
 }
 
 // Column sums of a [nblk][ncol] array of per-workgroup partials into LDS `out[ncol]`, by all 256 threads, in a fixed
-// order.  The partials were written by OTHER CUs in the previous launch, so every load is a miss: keep many of them
-// in flight (16 independent accumulators per thread) instead of a serial per-column chain.
-// scratch: LDS, >= 256 floats.  Ends with a __syncthreads(); out is valid for every thread afterwards.
+// order.  The partials were written by OTHER CUs in the previous launch, so every load is an L2 miss (~1500 cycles):
+// the point is to have (almost) all of a thread's loads in flight at once.  ncol % 4 == 0: float4 columns, up to
+// 8 row segments, 16 loads in flight per thread; else a scalar fallback.
+// scratch: LDS, >= 1024 floats.  Ends with a __syncthreads(); out is valid for every thread afterwards.
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblk, int ncol, float* out,
                                                 float* scratch, int tid) {
+  if ((ncol & 3) == 0 && ncol <= 1024) {
+    const int nc4 = ncol >> 2;                       // float4 columns
+    for (int c0 = 0; c0 < nc4; c0 += 256) {
+      const int nc = min(256, nc4 - c0);
+      const int nseg = max(1, 256 / nc);
+      const int seg = tid / nc, col = tid - seg * nc;
+      const int per = (nblk + nseg - 1) / nseg;
+      float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (seg < nseg) {
+        const int kb = seg * per, ke = min(nblk, kb + per);
+        const float4* p = reinterpret_cast<const float4*>(part) + c0 + col;
+        float4 s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        int k = kb;
+        for (; k + 16 <= ke; k += 16) {
+          float4 v[16];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v[j] = p[(int64_t)(k + j) * nc4];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            s[j & 3].x += v[j].x; s[j & 3].y += v[j].y; s[j & 3].z += v[j].z; s[j & 3].w += v[j].w;
+          }
+        }
+        for (; k < ke; ++k) {
+          const float4 v = p[(int64_t)k * nc4];
+          s[0].x += v.x; s[0].y += v.y; s[0].z += v.z; s[0].w += v.w;
+        }
+        tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+        tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+        tot.z = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+        tot.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+      }
+      lds_barrier();
+      if (seg < nseg) reinterpret_cast<float4*>(scratch)[seg * nc + col] = tot;
+      lds_barrier();
+      for (int e = tid; e < 4 * nc; e += 256) {
+        float t = 0.f;
+        for (int g = 0; g < nseg; ++g) t += scratch[g * 4 * nc + e];
+        out[4 * c0 + e] = t;
+      }
+    }
+    lds_barrier();
+    return;
+  }
   for (int c0 = 0; c0 < ncol; c0 += 256) {
     const int nc = min(256, ncol - c0);
     const int nseg = max(1, 256 / nc);
@@ -285,16 +385,16 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
       for (int j = 0; j < 8; ++j) s[j] += s[j + 8];
       tot = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
-    __syncthreads();             // scratch may still be read from the previous chunk
+    lds_barrier();             // scratch may still be read from the previous chunk
     if (seg < nseg) scratch[seg * nc + col] = tot;
-    __syncthreads();
+    lds_barrier();
     if (tid < nc) {
       float t = 0.f;
       for (int g = 0; g < nseg; ++g) t += scratch[g * nc + tid];
       out[c0 + tid] = t;
     }
   }
-  __syncthreads();
+  lds_barrier();
 }
 
 static __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {

@@ -47,7 +47,8 @@ struct DecPackF {
 
 // ---- one GRU cell for the feature tiles of this wave ------------------------------------------------
 // x-operand Xin [16][ldh] (layer input), Xh [16][ldh] (previous hidden).  Writes h_new (after optional
-// inter-layer dropout) to `Hnext_lds`, h_new to global h_out, and the gates.
+// inter-layer dropout) to `Hnext_lds`, h_new to global h_out, and the gates.  When H % 4 == 0 every global /
+// LDS access of the epilogue is a 16-byte vector (4 consecutive features live in one lane).
 template <int KSH_T>
 __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, const float* __restrict__ p_hh,
                                              const float* __restrict__ b_ih, const float* __restrict__ b_hh,
@@ -60,49 +61,100 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, con
                                              int nrows, int lane, int wave) {
   const int i = lane & 15, q = lane >> 4;
   const int ntile = Hp >> 4, KS = Hp >> 4;
+  const bool hvec = (H & 3) == 0;
   for (int ft = wave; ft < ntile; ft += 4) {
+    const int f0 = 16 * ft + 4 * q;
+    const bool vec = hvec && (f0 + 3 < H);
+    // biases / keep flags first: independent of the MFMAs below, their latency hides behind them
+    float4 bi[3], bh[3];
+    uint32_t kp = 0x01010101u;
+    if (vec) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        bi[g] = *reinterpret_cast<const float4*>(b_ih + g * H + f0);
+        bh[g] = *reinterpret_cast<const float4*>(b_hh + g * H + f0);
+      }
+      if (keep && i < nrows) kp = *reinterpret_cast<const uint32_t*>(keep + (int64_t)i * H + f0);
+    }
     f32x4 ai[3], ah[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
       ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    wave_gemm_p<3, KSH_T>(ai, p_ih, KS, ft, ntile, Xin, ldh, lane);
-    wave_gemm_p<3, KSH_T>(ah, p_hh, KS, ft, ntile, Xh, ldh, lane);
-    const int f0 = 16 * ft + 4 * q;
+    if constexpr (KSH_T > 0) {
+      wave_gemm_p2<3, KSH_T>(ai, p_ih, Xin, ah, p_hh, Xh, ft, ntile, ldh, lane);
+    } else {
+      wave_gemm_p<3, 0>(ai, p_ih, KS, ft, ntile, Xin, ldh, lane);
+      wave_gemm_p<3, 0>(ah, p_hh, KS, ft, ntile, Xh, ldh, lane);
+    }
+    if (vec) {
+      const float4 hp4 = *reinterpret_cast<const float4*>(Xh + i * ldh + f0);
+      const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+      const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
+                  bin[4] = {bi[2].x, bi[2].y, bi[2].z, bi[2].w};
+      const float bhr[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bhz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+                  bhn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+      float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = f0 + r;
-      if (f >= H) continue;
-      const float hp = Xh[i * ldh + f];
-      const float rr = sigmoidf_((ai[0][r] + b_ih[f]) + (ah[0][r] + b_hh[f]));
-      const float zz = sigmoidf_((ai[1][r] + b_ih[H + f]) + (ah[1][r] + b_hh[H + f]));
-      const float ghn = ah[2][r] + b_hh[2 * H + f];
-      const float nn = tanhf((ai[2][r] + b_ih[2 * H + f]) + rr * ghn);
-      const float hn = (1.0f - zz) * nn + zz * hp;
-      float xd = hn;
-      if (keep) xd = (i < nrows && keep[(int64_t)i * H + f]) ? hn * keep_scale : 0.f;
-      Hnext_lds[i * ldh + f] = xd;
+      for (int r = 0; r < 4; ++r) {
+        const float rr = sigmoidf_((ai[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+        const float zz = sigmoidf_((ai[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+        const float ghn = ah[2][r] + bhn[r];
+        const float nn = tanhf_((ai[2][r] + bin[r]) + rr * ghn);
+        hn[r] = (1.0f - zz) * nn + zz * hp[r];
+        xd[r] = keep ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * keep_scale : 0.f) : hn[r];
+        gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+      }
+      *reinterpret_cast<float4*>(Hnext_lds + i * ldh + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
       if (i < nrows) {
-        h_out[(int64_t)i * H + f] = hn;
-        if (xdrop_out) xdrop_out[(int64_t)i * H + f] = xd;
+        *reinterpret_cast<float4*>(h_out + (int64_t)i * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (xdrop_out) *reinterpret_cast<float4*>(xdrop_out + (int64_t)i * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
         if (gates) {
-          float* go = gates + (int64_t)i * 4 * H;
-          go[f] = rr; go[H + f] = zz; go[2 * H + f] = nn; go[3 * H + f] = ghn;
+          float* go = gates + (int64_t)i * 4 * H + f0;
+          *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+          *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+          *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+          *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = f0 + r;
+        if (f >= H) continue;
+        const float hp = Xh[i * ldh + f];
+        const float rr = sigmoidf_((ai[0][r] + b_ih[f]) + (ah[0][r] + b_hh[f]));
+        const float zz = sigmoidf_((ai[1][r] + b_ih[H + f]) + (ah[1][r] + b_hh[H + f]));
+        const float ghn = ah[2][r] + b_hh[2 * H + f];
+        const float nn = tanhf_((ai[2][r] + b_ih[2 * H + f]) + rr * ghn);
+        const float hn = (1.0f - zz) * nn + zz * hp;
+        float xd = hn;
+        if (keep) xd = (i < nrows && keep[(int64_t)i * H + f]) ? hn * keep_scale : 0.f;
+        Hnext_lds[i * ldh + f] = xd;
+        if (i < nrows) {
+          h_out[(int64_t)i * H + f] = hn;
+          if (xdrop_out) xdrop_out[(int64_t)i * H + f] = xd;
+          if (gates) {
+            float* go = gates + (int64_t)i * 4 * H;
+            go[f] = rr; go[H + f] = zz; go[2 * H + f] = nn; go[3 * H + f] = ghn;
+          }
         }
       }
     }
   }
 }
 
-template <int HS>
+template <int HS, int DS>
 __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restrict__ target,
                                                            const float* __restrict__ h_init, g2v_dec_weights w,
                                                            DecPackF pk, g2v_dec_saved sv,
                                                            const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int T = dm.T, B = dm.B, D = dm.D, H = dm.H;
+  // HS / DS > 0: the model dims are compile-time constants (every stride, tile count and k-loop folds)
+  const int T = dm.T, B = dm.B, D = DS > 0 ? DS : dm.D, H = HS > 0 ? HS : dm.H;
+  constexpr int KSD_T = (DS + 15) / 16;
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, ldh = Hp + 4, ldd = Dp + 4;
   float* Xa = smem;                 // a_t               [16][ldh]
   float* Xh0 = Xa + 16 * ldh;       // h0_{t-1}
@@ -112,18 +164,44 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   float* Xy = Xh1n + 16 * ldh;      // xin_{t+1}         [16][ldd]
   float* st = Xy + 16 * ldd;        // mean[Hp], invstd[Hp]
   float* red = st + 2 * Hp;         // column sums of the BN partials [2H]
-  float* red_scratch = red + 2 * Hp;  // [256]
+  float* red_scratch = red + 2 * Hp;  // [1024]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16;
   const int nrows = min(16, B - b0);
   const int i = lane & 15, q = lane >> 4;
   const bool has_next = (t < T - 1);
+  const bool hvec = (H & 3) == 0;
+  const int H4 = H >> 2;
 
   STAMP(0);
-  // zero the operand tiles once (padding columns / rows must be 0 for the MFMA contractions)
-  for (int e = tid; e < 5 * 16 * ldh + 16 * ldd; e += 256) smem[e] = 0.f;
-  __syncthreads();
+  // Prefetch this block's rows of u_t, h0_{t-1}, h1_{t-1} (written by the previous launch on some other CU: each is
+  // an L2 miss).  Issued first so that their latency overlaps the BatchNorm partial reduction below.
+  float4 pu = make_float4(0.f, 0.f, 0.f, 0.f), ph0 = pu, ph1 = pu;
+  const bool pre_ok = hvec && (16 * H4 <= 256) && t > 0;     // one float4 per thread covers the 16 x H tile
+  const int pr = pre_ok ? tid / H4 : 0, pc = pre_ok ? (tid - pr * H4) * 4 : 0;
+  const bool pvalid = pre_ok && tid < 16 * H4 && pr < nrows;
+  if (pvalid) {
+    const int64_t row = ((int64_t)(t - 1) * B + b0 + pr) * H + pc;
+    pu = *reinterpret_cast<const float4*>(sv.u + row);
+    ph0 = *reinterpret_cast<const float4*>(sv.h0 + row);
+    ph1 = *reinterpret_cast<const float4*>(sv.h1 + row);
+  }
+  // Zero what the MFMA contractions must see as zero: padding columns and rows >= nrows of every operand tile.
+  // (full tiles of an H % 16 == 0 model have no H padding at all: only the D padding of Xy is touched)
+  {
+    const bool full = (nrows == 16);
+    if (!full || Hp != H) {
+      for (int e = tid; e < 5 * 16 * ldh; e += 256) smem[e] = 0.f;
+    }
+    if (!full) {
+      for (int e = tid; e < 16 * ldd; e += 256) Xy[e] = 0.f;
+    } else {
+      const int padc = ldd - D;
+      for (int e = tid; e < 16 * padc; e += 256) Xy[(e / padc) * ldd + D + (e % padc)] = 0.f;
+    }
+  }
+  lds_barrier();
   STAMP(1);
 
   if (t == 0) {
@@ -160,21 +238,37 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         st[Hp + f] = 1.0f / sqrtf(w.bn_running_var[f] + 1e-5f);
       }
     }
-    __syncthreads();
+    lds_barrier();
     // ---- (b) a_t = ReLU(BN(u_t)); stage previous hidden states ------------------------------------
-    for (int e = tid; e < 16 * H; e += 256) {
-      const int r = e / H, f = e - r * H;
-      if (r >= nrows) continue;
-      const int64_t row = (int64_t)(b0 + r) * H + f;
-      const float u = ut[row];
-      float a = (u - st[f]) * st[Hp + f] * w.bn_w[f] + w.bn_b[f];
-      a = fmaxf(a, 0.f);
-      Xa[r * ldh + f] = a;
-      if (sv.a) sv.a[(int64_t)(t - 1) * B * H + row] = a;
-      Xh0[r * ldh + f] = sv.h0[(int64_t)(t - 1) * B * H + row];
-      Xh1[r * ldh + f] = sv.h1[(int64_t)(t - 1) * B * H + row];
+    if (pre_ok) {
+      if (pvalid) {
+        const float4 g4 = *reinterpret_cast<const float4*>(w.bn_w + pc), b4 = *reinterpret_cast<const float4*>(w.bn_b + pc);
+        const float4 m4 = *reinterpret_cast<const float4*>(st + pc), i4 = *reinterpret_cast<const float4*>(st + Hp + pc);
+        float4 a4;
+        a4.x = fmaxf((pu.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+        a4.y = fmaxf((pu.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+        a4.z = fmaxf((pu.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+        a4.w = fmaxf((pu.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+        *reinterpret_cast<float4*>(Xa + pr * ldh + pc) = a4;
+        *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
+        *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
+        if (sv.a) *reinterpret_cast<float4*>(sv.a + ((int64_t)(t - 1) * B + b0 + pr) * H + pc) = a4;
+      }
+    } else {
+      for (int e = tid; e < 16 * H; e += 256) {
+        const int r = e / H, f = e - r * H;
+        if (r >= nrows) continue;
+        const int64_t row = (int64_t)(b0 + r) * H + f;
+        const float u = ut[row];
+        float a = (u - st[f]) * st[Hp + f] * w.bn_w[f] + w.bn_b[f];
+        a = fmaxf(a, 0.f);
+        Xa[r * ldh + f] = a;
+        if (sv.a) sv.a[(int64_t)(t - 1) * B * H + row] = a;
+        Xh0[r * ldh + f] = sv.h0[(int64_t)(t - 1) * B * H + row];
+        Xh1[r * ldh + f] = sv.h1[(int64_t)(t - 1) * B * H + row];
+      }
     }
-    __syncthreads();
+    lds_barrier();
     STAMP(3);
     // ---- (c) GRU layer 0 ---------------------------------------------------------------------------
     const bool drop = dm.training && keep_l0 && dm.p_drop > 0.f;
@@ -184,65 +278,173 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
                  sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
                  drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr, 1.0f / (1.0f - dm.p_drop),
                  (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, lane, wave);
-    __syncthreads();
+    lds_barrier();
     STAMP(4);
     // ---- (d) GRU layer 1 ---------------------------------------------------------------------------
     gru_cell_fwd<KSH_T>(pk.ih1, pk.hh1, w.b_ih1, w.b_hh1, Xx1, Xh1, ldh, H, Hp, Xh1n,
                  sv.h1 + ((int64_t)t * B + b0) * H,
                  sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, 1.0f, nullptr, nrows,
                  lane, wave);
-    __syncthreads();
+    lds_barrier();
     STAMP(5);
   }
 
   // ---- (e) y_t = out_layer(h1_t)  (t == 0: y_0 = target frame 0), next decoder input ---------------
-  {
+  // The 16 rows of this block are CONTIGUOUS in the time-major (T,B,D) arrays (y, xin, keep95): 16*D floats.
+  // Fast path: accumulators -> dense LDS tile -> coalesced 16-byte global stores by all 256 threads
+  // (the per-lane path touches 64 different cache lines per instruction when D = 135).
+  const bool dense_e = (nrows == 16) && t > 0 && !(has_next && t < dm.n_pre) && ((((int64_t)t * B + b0) * D) & 3) == 0 &&
+                       ((16 * D) & 3) == 0 && (16 * D <= 2 * 16 * ldh) && dm.conditioned;
+  if (dense_e) {
+    float* Yt = Xa;   // Xa|Xh0 are dead by now: 2*16*ldh floats >= 16*D
     const int ntile = Dp >> 4;
-    for (int ft = wave; ft < ntile; ft += 4) {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      if (t > 0) wave_gemm_p<1, HS / 16>(acc, pk.out, Hp >> 4, ft, 0, Xh1n, ldh, lane);
-      const int d0 = 16 * ft + 4 * q;
-      if (i < nrows) {
-        const int b = b0 + i;
+    const bool three = ntile > 4;
+    const int per = three ? 3 : 1, group = 4 * per;
+    for (int base = 0; base < ntile; base += group) {
+      float bo[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int d = d0 + r;
-          if (d >= D) continue;
-          float y;
-          if (t == 0) y = target[((int64_t)b * T + 0) * D + d];
-          else y = acc[0][r] + w.b_out[d];
-          sv.y[((int64_t)t * B + b) * D + d] = y;
-          if (has_next) {
-            const float src = (t < dm.n_pre) ? target[((int64_t)b * T + t) * D + d] : y;   // :1049-1052
-            float xin = 0.f;
-            if (dm.conditioned && keep95[((int64_t)t * B + b) * D + d]) xin = src * 20.0f;   // Dropout(0.95): 1/(1-0.95)
-            Xy[i * ldd + d] = xin;
-            if (sv.xin) sv.xin[((int64_t)t * B + b) * D + d] = xin;
+          const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+          bo[j][r] = (j < per && d < D) ? w.b_out[d] : 0.f;
+        }
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (three) {
+        wave_gemm_p<3, HS / 16>(acc, pk.out, Hp >> 4, base + wave, 4, Xh1n, ldh, lane);
+      } else {
+        f32x4 a1[1] = {acc[0]};
+        wave_gemm_p<1, HS / 16>(a1, pk.out, Hp >> 4, base + wave, 0, Xh1n, ldh, lane);
+        acc[0] = a1[0];
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+          if (j < per && d < D) Yt[i * D + d] = acc[j][r] + bo[j][r];
+        }
+    }
+    lds_barrier();
+    const int64_t tile = ((int64_t)t * B + b0) * D;     // element offset of this block's 16 x D tile
+    const int n4 = (16 * D) >> 2;
+    for (int e4 = tid; e4 < n4; e4 += 256) {
+      const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
+      reinterpret_cast<float4*>(sv.y + tile)[e4] = y4;
+      if (has_next) {
+        const uint32_t k4 = reinterpret_cast<const uint32_t*>(keep95 + tile)[e4];
+        float4 x4;
+        x4.x = (k4 & 0xffu) ? y4.x * 20.0f : 0.f;            // Dropout(0.95): 1/(1-0.95)
+        x4.y = (k4 & 0xff00u) ? y4.y * 20.0f : 0.f;
+        x4.z = (k4 & 0xff0000u) ? y4.z * 20.0f : 0.f;
+        x4.w = (k4 & 0xff000000u) ? y4.w * 20.0f : 0.f;
+        if (sv.xin) reinterpret_cast<float4*>(sv.xin + tile)[e4] = x4;
+        const int e = 4 * e4;
+        const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = (e + j) / D, c = (e + j) - r * D;
+          Xy[r * ldd + c] = xv[j];
+        }
+      }
+    }
+  } else
+  // D tiles are dealt to the waves in groups of 12 (3 per wave, one NT=3 contraction that shares the X fragments);
+  // the packed matrix is zero-padded to a multiple of 12 tiles (4 when D <= 64, then one tile per wave).
+  {
+    const int ntile = Dp >> 4;
+    const bool three = ntile > 4;
+    const int per = three ? 3 : 1, group = 4 * per;
+    const bool teacher = (t < dm.n_pre);
+    const int b = b0 + i;
+    for (int base = 0; base < ntile; base += group) {
+      float bo[3][4], tg[3][4];
+      uint8_t kp[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bo[j][r] = 0.f; tg[j][r] = 0.f; kp[j][r] = 0;
+          const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+          if (j < per && i < nrows && d < D) {
+            bo[j][r] = w.b_out[d];
+            if (t == 0 || (has_next && teacher)) tg[j][r] = target[((int64_t)b * T + t) * D + d];
+            if (has_next && dm.conditioned) kp[j][r] = keep95[((int64_t)t * B + b) * D + d];
           }
         }
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t > 0) {
+        if (three) {
+          wave_gemm_p<3, HS / 16>(acc, pk.out, Hp >> 4, base + wave, 4, Xh1n, ldh, lane);
+        } else {
+          f32x4 a1[1] = {acc[0]};
+          wave_gemm_p<1, HS / 16>(a1, pk.out, Hp >> 4, base + wave, 0, Xh1n, ldh, lane);
+          acc[0] = a1[0];
+        }
+      }
+      if (i < nrows) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+            if (j >= per || d >= D) continue;
+            const float y = (t == 0) ? tg[j][r] : acc[j][r] + bo[j][r];
+            sv.y[((int64_t)t * B + b) * D + d] = y;
+            if (has_next) {
+              const float src = teacher ? tg[j][r] : y;                                 // :1049-1052
+              const float xin = kp[j][r] ? src * 20.0f : 0.f;                            // Dropout(0.95): 1/(1-0.95)
+              Xy[i * ldd + d] = xin;
+              if (sv.xin) sv.xin[((int64_t)t * B + b) * D + d] = xin;
+            }
+          }
       }
     }
   }
   if (!has_next) return;
-  __syncthreads();
+  lds_barrier();
   STAMP(6);
   // ---- (f) u_{t+1} = pre_linear.0(xin_{t+1}) and per-block BN partial sums of (u - b) ----------------
   {
     const int ntile = Hp >> 4;
     float* part = sv.bn_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
     for (int ft = wave; ft < ntile; ft += 4) {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, 0>(acc, pk.pre, Dp >> 4, ft, 0, Xy, ldd, lane);
       const int f0 = 16 * ft + 4 * q;
+      const bool vec = hvec && (f0 + 3 < H);
+      float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec) bp = *reinterpret_cast<const float4*>(w.b_pre + f0);
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, KSD_T>(acc, pk.pre, Dp >> 4, ft, 0, Xy, ldd, lane);
+      float s1[4], s2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = f0 + r;
         const float v = (i < nrows && f < H) ? acc[0][r] : 0.f;
-        if (i < nrows && f < H) sv.u[((int64_t)t * B + b0 + i) * H + f] = v + w.b_pre[f];
-        const float s1 = reduce16(v), s2 = reduce16(v * v);
-        if (i == 0 && f < H) {
-          part[f] = s1;
-          part[H + f] = s2;
+        s1[r] = reduce16(v);
+        s2[r] = reduce16(v * v);
+      }
+      if (vec) {
+        if (i < nrows)
+          *reinterpret_cast<float4*>(sv.u + ((int64_t)t * B + b0 + i) * H + f0) =
+              make_float4(acc[0][0] + bp.x, acc[0][1] + bp.y, acc[0][2] + bp.z, acc[0][3] + bp.w);
+        if (i == 0) {
+          *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+          *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = f0 + r;
+          if (f >= H) continue;
+          if (i < nrows) sv.u[((int64_t)t * B + b0 + i) * H + f] = acc[0][r] + w.b_pre[f];
+          if (i == 0) {
+            part[f] = s1[r];
+            part[H + f] = s2[r];
+          }
         }
       }
     }
@@ -274,10 +476,10 @@ struct DecTW {   // PACKED transposed weights (fragment-major; rows = output fea
   const float* w_ih0_t; const float* w_hh0_t; const float* w_ih1_t; const float* w_hh1_t;   // rows H, K = 3H each
 };
 
-// GRU cell backward for the feature tiles of this wave.
-//   dh_in(row,f) = carry (global, may be null on the first step) + [add_lds ? Add[row][f] : 0] + acc (from the caller's GEMM)
+// GRU cell backward for one 16-feature tile of this wave.
+//   dh(row,f) = keep ? acc * extra_scale * keep : acc   (+ carry from the later time step)
 // writes dgi / dgh (global), Gi / Gh tiles (LDS, MFMA B operands for the next contractions) and
-// direct = dh * z into Dd (LDS).
+// direct = dh * z into Dd (LDS).  H % 4 == 0: all accesses are 16-byte vectors.
 __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float* __restrict__ carry, float extra_scale,
                                                   const uint8_t* __restrict__ keep,   // applied to acc (inter-layer dropout bwd)
                                                   const float* __restrict__ gates, const float* __restrict__ hprev,
@@ -286,6 +488,52 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
   const int i = lane & 15, q = lane >> 4;
   const int f0 = 16 * ft + 4 * q;
   const int G = 3 * H;
+  if (((H & 3) == 0) && f0 + 3 < H) {
+    float g_r[4] = {0.f, 0.f, 0.f, 0.f}, g_z[4] = {0.f, 0.f, 0.f, 0.f}, g_n[4] = {0.f, 0.f, 0.f, 0.f},
+          g_hn[4] = {0.f, 0.f, 0.f, 0.f}, direct[4] = {0.f, 0.f, 0.f, 0.f};
+    if (i < nrows) {
+      const float* go = gates + (int64_t)i * 4 * H + f0;
+      const float4 r4 = *reinterpret_cast<const float4*>(go), z4 = *reinterpret_cast<const float4*>(go + H),
+                   n4 = *reinterpret_cast<const float4*>(go + 2 * H), h4 = *reinterpret_cast<const float4*>(go + 3 * H);
+      const float4 hp4 = *reinterpret_cast<const float4*>(hprev + (int64_t)i * H + f0);
+      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (carry) c4 = *reinterpret_cast<const float4*>(carry + (int64_t)i * H + f0);
+      uint32_t kp = 0x01010101u;
+      if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (int64_t)i * H + f0);
+      const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w},
+                  gh[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float dh = acc[r];
+        if (keep) dh = ((kp >> (8 * r)) & 0xffu) ? dh * extra_scale : 0.f;
+        dh += cc[r];
+        const float dn = dh * (1.0f - zz[r]);
+        const float dz = dh * (hp[r] - nn[r]);
+        const float dnp = dn * (1.0f - nn[r] * nn[r]);
+        g_n[r] = dnp;
+        g_hn[r] = dnp * rr[r];
+        g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+        g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+        direct[r] = dh * zz[r];
+      }
+      float* o1 = dgi + (int64_t)i * G + f0;
+      float* o2 = dgh + (int64_t)i * G + f0;
+      const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+                   vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+      *reinterpret_cast<float4*>(o1) = vr; *reinterpret_cast<float4*>(o1 + H) = vz; *reinterpret_cast<float4*>(o1 + 2 * H) = vn;
+      *reinterpret_cast<float4*>(o2) = vr; *reinterpret_cast<float4*>(o2 + H) = vz; *reinterpret_cast<float4*>(o2 + 2 * H) = vh;
+    }
+    const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+                 vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+    *reinterpret_cast<float4*>(Gi + i * ldg + f0) = vr;
+    *reinterpret_cast<float4*>(Gi + i * ldg + H + f0) = vz;
+    *reinterpret_cast<float4*>(Gi + i * ldg + 2 * H + f0) = vn;
+    *reinterpret_cast<float4*>(Gh + i * ldg + f0) = vr;
+    *reinterpret_cast<float4*>(Gh + i * ldg + H + f0) = vz;
+    *reinterpret_cast<float4*>(Gh + i * ldg + 2 * H + f0) = vh;
+    *reinterpret_cast<float4*>(Dd + i * ldh + f0) = make_float4(direct[0], direct[1], direct[2], direct[3]);
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int f = f0 + r;
@@ -317,12 +565,13 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
   }
 }
 
-template <int HS>
+template <int HS, int DS>
 __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, DecTW tw, g2v_dec_saved sv,
                                                            g2v_dec_grads gr, const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int T = dm.T, B = dm.B, D = dm.D, H = dm.H, G = 3 * H;
+  const int T = dm.T, B = dm.B, D = DS > 0 ? DS : dm.D, H = HS > 0 ? HS : dm.H, G = 3 * H;
+  constexpr int KSD_T = (DS + 15) / 16;
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, Gp = (G + 15) & ~15;
   const int ldh = Hp + 4, ldd = Dp + 4, ldg = Gp + 4;
   float* Xdu = smem;                // du_{t+1}          [16][ldh]
@@ -333,7 +582,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   float* Xdx = Dd + 16 * ldh;       // dh0 incoming      [16][ldh]
   float* st = Xdx + 16 * ldh;       // S1[Hp], S2[Hp]
   float* red = st + 2 * Hp;         // [2H]
-  float* red_scratch = red + 2 * Hp;  // [256]
+  float* red_scratch = red + 2 * Hp;  // [1024]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * 16;
@@ -341,9 +590,32 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   const int i = lane & 15, q = lane >> 4;
   const bool last = (t == T - 1);   // first kernel of the backward sweep
   const int nth = Hp >> 4, ntd = Dp >> 4;
+  const bool hvec = (H & 3) == 0;
+  const int H4 = H >> 2;
 
-  for (int e = tid; e < 16 * (3 * ldh + ldd + 2 * ldg); e += 256) smem[e] = 0.f;
-  __syncthreads();
+  // prefetch this block's rows of u_{t+1} and dbn_{t+1} (Part A inputs; L2 misses) before anything else
+  float4 pu = make_float4(0.f, 0.f, 0.f, 0.f), pdb = pu;
+  const bool pre_ok = hvec && (16 * H4 <= 256) && !last;
+  const int pr = pre_ok ? tid / H4 : 0, pc = pre_ok ? (tid - pr * H4) * 4 : 0;
+  const bool pvalid = pre_ok && tid < 16 * H4 && pr < nrows;
+  if (pvalid) {
+    const int64_t row = ((int64_t)t * B + b0 + pr) * H + pc;
+    pu = *reinterpret_cast<const float4*>(sv.u + row);
+    pdb = *reinterpret_cast<const float4*>(gr.dbn + row);
+  }
+  // zero padding columns / rows of the MFMA operand tiles
+  {
+    const bool full = (nrows == 16);
+    if (!full || Hp != H || Gp != G) {
+      for (int e = tid; e < 16 * (3 * ldh + ldd + 2 * ldg); e += 256) smem[e] = 0.f;
+    } else {
+      const int padc = ldd - D;
+      for (int e = tid; e < 16 * padc; e += 256) Xdy[(e / padc) * ldd + D + (e % padc)] = 0.f;
+      if (last)
+        for (int e = tid; e < 16 * ldh; e += 256) Xdu[e] = 0.f;
+    }
+  }
+  lds_barrier();
 
   // ================= Part A: finish BatchNorm backward of step t+1 ===================================
   if (!last) {
@@ -359,47 +631,141 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
         gr.d_bn_b[f] = (first_acc ? 0.f : gr.d_bn_b[f]) + s1;
       }
     }
-    __syncthreads();
+    lds_barrier();
     const float invB = 1.0f / (float)B;
     const float* stats = sv.bn_stats + (int64_t)t * 2 * H;   // step t+1 is stored at index t
-    for (int e = tid; e < 16 * H; e += 256) {
-      const int r = e / H, f = e - r * H;
-      if (r >= nrows) continue;
-      const int64_t row = ((int64_t)t * B + b0 + r) * H + f;
-      const float invstd = 1.0f / sqrtf(stats[H + f] + 1e-5f);
-      const float xhat = (sv.u[row] - stats[f]) * invstd;
-      const float du = w.bn_w[f] * invstd * (gr.dbn[row] - st[f] * invB - xhat * st[Hp + f] * invB);
-      gr.du[row] = du;
-      Xdu[r * ldh + f] = du;
+    if (pre_ok) {
+      if (pvalid) {
+        const float4 mean4 = *reinterpret_cast<const float4*>(stats + pc), var4 = *reinterpret_cast<const float4*>(stats + H + pc);
+        const float4 g4 = *reinterpret_cast<const float4*>(w.bn_w + pc);
+        const float4 s14 = *reinterpret_cast<const float4*>(st + pc), s24 = *reinterpret_cast<const float4*>(st + Hp + pc);
+        const float uu[4] = {pu.x, pu.y, pu.z, pu.w}, db[4] = {pdb.x, pdb.y, pdb.z, pdb.w};
+        const float mm[4] = {mean4.x, mean4.y, mean4.z, mean4.w}, vv[4] = {var4.x, var4.y, var4.z, var4.w};
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w}, a1[4] = {s14.x, s14.y, s14.z, s14.w}, a2[4] = {s24.x, s24.y, s24.z, s24.w};
+        float du[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+          const float xhat = (uu[r] - mm[r]) * invstd;
+          du[r] = gg[r] * invstd * (db[r] - a1[r] * invB - xhat * a2[r] * invB);
+        }
+        const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
+        *reinterpret_cast<float4*>(gr.du + ((int64_t)t * B + b0 + pr) * H + pc) = du4;
+        *reinterpret_cast<float4*>(Xdu + pr * ldh + pc) = du4;
+      }
+    } else {
+      for (int e = tid; e < 16 * H; e += 256) {
+        const int r = e / H, f = e - r * H;
+        if (r >= nrows) continue;
+        const int64_t row = ((int64_t)t * B + b0 + r) * H + f;
+        const float invstd = 1.0f / sqrtf(stats[H + f] + 1e-5f);
+        const float xhat = (sv.u[row] - stats[f]) * invstd;
+        const float du = w.bn_w[f] * invstd * (gr.dbn[row] - st[f] * invB - xhat * st[Hp + f] * invB);
+        gr.du[row] = du;
+        Xdu[r * ldh + f] = du;
+      }
     }
-    __syncthreads();
-  } else if (blockIdx.x == 0 && T == 2) {
-    // degenerate: single decode step, no Part A ever accumulates
+    lds_barrier();
   }
   if (t == 0) return;   // only the BN finish of step 1 was left (y_0 is data: no feedback needed)
 
   // ================= Part B: dy_t (loss + feedback) ===================================================
-  {
+  // Same contiguity as in the forward: the block's 16 x D tile of dy / keep95 is one dense run in memory.
+  const bool dense_b = (nrows == 16) && ((((int64_t)t * B + b0) * D) & 3) == 0 && ((16 * D) & 3) == 0 && (16 * D <= 16 * ldg);
+  if (dense_b) {
     const bool feedback = (!last) && dm.conditioned && (t >= dm.n_pre);
-    for (int ft = wave; ft < ntd; ft += 4) {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      if (feedback) wave_gemm_p<1, HS / 16>(acc, tw.w_pre_t, Hp >> 4, ft, 0, Xdu, ldh, lane);
-      const int d0 = 16 * ft + 4 * q;
-      if (i < nrows) {
+    float* Dt = Gi;                                        // dense dy tile [16*D]
+    uint32_t* Kt = reinterpret_cast<uint32_t*>(Gh);        // keep95 bytes of the tile, 4 per word
+    const int64_t tile = ((int64_t)t * B + b0) * D;
+    const int n4 = (16 * D) >> 2;
+    for (int e4 = tid; e4 < n4; e4 += 256) {
+      reinterpret_cast<float4*>(Dt)[e4] = reinterpret_cast<const float4*>(gr.dy + tile)[e4];
+      if (feedback) Kt[e4] = reinterpret_cast<const uint32_t*>(keep95 + tile)[e4];
+    }
+    lds_barrier();
+    const bool three = ntd > 4;
+    const int per = three ? 3 : 1, group = 4 * per;
+    const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
+    for (int base = 0; base < ntd; base += group) {
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (feedback) {
+        if (three) {
+          wave_gemm_p<3, HS / 16>(acc, tw.w_pre_t, Hp >> 4, base + wave, 4, Xdu, ldh, lane);
+        } else {
+          f32x4 a1[1] = {acc[0]};
+          wave_gemm_p<1, HS / 16>(a1, tw.w_pre_t, Hp >> 4, base + wave, 0, Xdu, ldh, lane);
+          acc[0] = a1[0];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int d = d0 + r;
-          if (d >= D) continue;
-          const int64_t idx = ((int64_t)t * B + b0 + i) * D + d;
-          float dy = gr.dy[idx];
-          if (feedback && keep95[idx]) dy += acc[0][r] * 20.0f;
-          gr.dy[idx] = dy;
+          const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+          if (j >= per || d >= D) continue;
+          float dy = Dt[i * D + d];
+          if (feedback && Kb[i * D + d]) dy += acc[j][r] * 20.0f;
+          Dt[i * D + d] = dy;
           Xdy[i * ldd + d] = dy;
         }
+    }
+    lds_barrier();
+    if (feedback)
+      for (int e4 = tid; e4 < n4; e4 += 256) reinterpret_cast<float4*>(gr.dy + tile)[e4] = reinterpret_cast<const float4*>(Dt)[e4];
+    lds_barrier();
+  } else
+  {
+  {
+    const bool feedback = (!last) && dm.conditioned && (t >= dm.n_pre);
+    const bool three = ntd > 4;
+    const int per = three ? 3 : 1, group = 4 * per;
+    for (int base = 0; base < ntd; base += group) {
+      float dyv[3][4];
+      uint8_t kp[3][4];
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          dyv[j][r] = 0.f; kp[j][r] = 0;
+          const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+          if (j < per && i < nrows && d < D) {
+            const int64_t idx = ((int64_t)t * B + b0 + i) * D + d;
+            dyv[j][r] = gr.dy[idx];
+            if (feedback) kp[j][r] = keep95[idx];
+          }
+        }
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (feedback) {
+        if (three) {
+          wave_gemm_p<3, HS / 16>(acc, tw.w_pre_t, Hp >> 4, base + wave, 4, Xdu, ldh, lane);
+        } else {
+          f32x4 a1[1] = {acc[0]};
+          wave_gemm_p<1, HS / 16>(a1, tw.w_pre_t, Hp >> 4, base + wave, 0, Xdu, ldh, lane);
+          acc[0] = a1[0];
+        }
+      }
+      if (i < nrows) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int d = 16 * (base + wave + 4 * j) + 4 * q + r;
+            if (j >= per || d >= D) continue;
+            const int64_t idx = ((int64_t)t * B + b0 + i) * D + d;
+            float dy = dyv[j][r];
+            if (kp[j][r]) dy += acc[j][r] * 20.0f;
+            if (feedback) gr.dy[idx] = dy;
+            Xdy[i * ldd + d] = dy;
+          }
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
+  }
   const float* carry0 = last ? nullptr : gr.dh_init + (int64_t)b0 * H;
   const float* carry1 = last ? nullptr : gr.dh_init + ((int64_t)B + b0) * H;
   float* carry0_w = gr.dh_init + (int64_t)b0 * H;
@@ -408,13 +774,13 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   {
     for (int ft = wave; ft < nth; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, 0>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
+      wave_gemm_p<1, KSD_T>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
       gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
                         sv.h1 + ((int64_t)(t - 1) * B + b0) * H, gr.dgi1 + ((int64_t)(t - 1) * B + b0) * G,
                         gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // ---- carry1' = dh1*z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout bwd) ----------------
   {
     for (int ft = wave; ft < nth; ft += 4) {
@@ -422,16 +788,24 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
       wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh1_t, Gp >> 4, ft, 0, Gh, ldg, lane);
       wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih1_t, Gp >> 4, ft, 0, Gi, ldg, lane);
       const int f0 = 16 * ft + 4 * q;
+      if (hvec && f0 + 3 < H) {
+        const float4 d4 = *reinterpret_cast<const float4*>(Dd + i * ldh + f0);
+        if (i < nrows)
+          *reinterpret_cast<float4*>(carry1_w + (int64_t)i * H + f0) =
+              make_float4(d4.x + a1[0][0], d4.y + a1[0][1], d4.z + a1[0][2], d4.w + a1[0][3]);
+        *reinterpret_cast<float4*>(Xdx + i * ldh + f0) = make_float4(a2[0][0], a2[0][1], a2[0][2], a2[0][3]);
+      } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int f = f0 + r;
-        if (f >= H) continue;
-        if (i < nrows) carry1_w[(int64_t)i * H + f] = Dd[i * ldh + f] + a1[0][r];
-        Xdx[i * ldh + f] = a2[0][r];
+        for (int r = 0; r < 4; ++r) {
+          const int f = f0 + r;
+          if (f >= H) continue;
+          if (i < nrows) carry1_w[(int64_t)i * H + f] = Dd[i * ldh + f] + a1[0][r];
+          Xdx[i * ldh + f] = a2[0][r];
+        }
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   // ---- GRU cell 0 backward (Gi/Gh/Dd are reused) ------------------------------------------------------
   {
     const bool drop = keep_l0 && dm.p_drop > 0.f;
@@ -447,32 +821,78 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
                         ldg, Dd, ldh, H, ft, nrows, lane);
     }
   }
-  __syncthreads();
+  lds_barrier();
   // ---- carry0' = dh0*z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU bwd -> dbn_t + BN-backward partial sums ----
   {
     const float* stats = sv.bn_stats + (int64_t)(t - 1) * 2 * H;
     float* part = gr.bn_bwd_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
     for (int ft = wave; ft < nth; ft += 4) {
+      const int f0 = 16 * ft + 4 * q;
+      const bool vec = hvec && (f0 + 3 < H);
+      // inputs of the epilogue that do not depend on the MFMAs
+      float av[4] = {0.f, 0.f, 0.f, 0.f}, uv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {1.f, 1.f, 1.f, 1.f};
+      if (vec) {
+        const float4 m4 = *reinterpret_cast<const float4*>(stats + f0), v4 = *reinterpret_cast<const float4*>(stats + H + f0);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+        if (i < nrows) {
+          const int64_t row = ((int64_t)(t - 1) * B + b0 + i) * H + f0;
+          const float4 a4 = *reinterpret_cast<const float4*>(sv.a + row), u4 = *reinterpret_cast<const float4*>(sv.u + row);
+          av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+          uv[0] = u4.x; uv[1] = u4.y; uv[2] = u4.z; uv[3] = u4.w;
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = f0 + r;
+          if (f < H) {
+            mv[r] = stats[f];
+            vv[r] = stats[H + f];
+            if (i < nrows) {
+              const int64_t row = ((int64_t)(t - 1) * B + b0 + i) * H + f;
+              av[r] = sv.a[row];
+              uv[r] = sv.u[row];
+            }
+          }
+        }
+      }
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh0_t, Gp >> 4, ft, 0, Gh, ldg, lane);
       wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih0_t, Gp >> 4, ft, 0, Gi, ldg, lane);
-      const int f0 = 16 * ft + 4 * q;
+      float dbn[4], s1[4], s2[4], cw[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = f0 + r;
-        float dbn = 0.f, dbx = 0.f;
-        if (f < H && i < nrows) {
-          carry0_w[(int64_t)i * H + f] = Dd[i * ldh + f] + a1[0][r];
-          const int64_t row = ((int64_t)(t - 1) * B + b0 + i) * H + f;
-          dbn = (sv.a[row] > 0.f) ? a2[0][r] : 0.f;
-          gr.dbn[row] = dbn;
-          const float invstd = 1.0f / sqrtf(stats[H + f] + 1e-5f);
-          dbx = dbn * ((sv.u[row] - stats[f]) * invstd);
+        const bool ok = (f < H) && (i < nrows);
+        cw[r] = Dd[i * ldh + ((f < Hp) ? f : 0)] + a1[0][r];
+        dbn[r] = (ok && av[r] > 0.f) ? a2[0][r] : 0.f;
+        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float dbx = ok ? dbn[r] * ((uv[r] - mv[r]) * invstd) : 0.f;
+        s1[r] = reduce16(dbn[r]);
+        s2[r] = reduce16(dbx);
+      }
+      if (vec) {
+        if (i < nrows) {
+          *reinterpret_cast<float4*>(carry0_w + (int64_t)i * H + f0) = make_float4(cw[0], cw[1], cw[2], cw[3]);
+          *reinterpret_cast<float4*>(gr.dbn + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
         }
-        const float s1 = reduce16(dbn), s2 = reduce16(dbx);
-        if (i == 0 && f < H) {
-          part[f] = s1;
-          part[H + f] = s2;
+        if (i == 0) {
+          *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+          *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = f0 + r;
+          if (f >= H) continue;
+          if (i < nrows) {
+            carry0_w[(int64_t)i * H + f] = cw[r];
+            gr.dbn[((int64_t)(t - 1) * B + b0 + i) * H + f] = dbn[r];
+          }
+          if (i == 0) {
+            part[f] = s1[r];
+            part[H + f] = s2[r];
+          }
         }
       }
     }
@@ -493,18 +913,22 @@ extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 static size_t dec_fwd_lds(int D, int H) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15;
-  return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp + 256) * sizeof(float);
+  return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp + 1024) * sizeof(float);
 }
 static size_t dec_bwd_lds(int D, int H) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, Gp = (3 * H + 15) & ~15;
-  return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp + 256) * sizeof(float);
+  return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp + 1024) * sizeof(float);
 }
 
+static int dtiles_pad(int D) {   // D-row matrices: tiles padded to a multiple of 12 (3 per wave) or 4 (1 per wave)
+  const int nt = (D + 15) >> 4;
+  return nt > 4 ? (nt + 11) / 12 * 12 : 4;
+}
 static size_t pack_fwd_total(int D, int H) {
-  return pack_floats(H, 1, D) + 4 * pack_floats(H, 3, H) + pack_floats(D, 1, H);
+  return pack_floats(H, 1, D) + 4 * pack_floats(H, 3, H) + (size_t)dtiles_pad(D) * pack_ks(H) * 256;
 }
 static size_t pack_bwd_total(int D, int H) {
-  return pack_floats(D, 1, H) + pack_floats(H, 1, D) + 4 * pack_floats(H, 1, 3 * H);
+  return (size_t)dtiles_pad(D) * pack_ks(H) * 256 + pack_floats(H, 1, D) + 4 * pack_floats(H, 1, 3 * H);
 }
 
 extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return pack_fwd_total(D, H) * sizeof(float); }
@@ -533,26 +957,26 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   DecPackF pk;
   PackBatch pb;
   pb.n = 6;
-  pb.d[0] = PackDesc{w->w_pre, p, H, 1, 0, D, D, 0}; pk.pre = p; p += pack_floats(H, 1, D);
-  pb.d[1] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
-  pb.d[2] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
-  pb.d[3] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
-  pb.d[4] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
-  pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0}; pk.out = p; p += pack_floats(D, 1, H);
+  pb.d[0] = PackDesc{w->w_pre, p, H, 1, 0, D, D, 0, 0}; pk.pre = p; p += pack_floats(H, 1, D);
+  pb.d[1] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
+  pb.d[2] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
+  pb.d[3] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
+  pb.d[4] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
+  pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0, dtiles_pad(D)}; pk.out = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;
   launch_pack(pb, st);
   G2V_CHECK_LAUNCH();
   DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16)};
-  const bool fast = (H == 64);
+  const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
   if (lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   for (int t = 0; t < T; ++t) {
     if (fast)
-      hipLaunchKernelGGL(dec_step_fwd_kernel<64>, dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
+      hipLaunchKernelGGL((dec_step_fwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
     else
-      hipLaunchKernelGGL(dec_step_fwd_kernel<0>, dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
+      hipLaunchKernelGGL((dec_step_fwd_kernel<0, 0>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
   }
   G2V_CHECK_LAUNCH();
@@ -591,25 +1015,25 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
   PackBatch pb;
   pb.n = 6;
   const int G = 3 * H;
-  pb.d[0] = PackDesc{w->w_pre, p, D, 1, 0, H, D, 1}; tw.w_pre_t = p; p += pack_floats(D, 1, H);   // rows d, k = f: W_pre[f][d]
-  pb.d[1] = PackDesc{w->w_out, p, H, 1, 0, D, H, 1}; tw.w_out_t = p; p += pack_floats(H, 1, D);   // rows f, k = d: W_out[d][f]
-  pb.d[2] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1}; tw.w_ih0_t = p; p += pack_floats(H, 1, G);   // rows k, contraction g: W[g][k]
-  pb.d[3] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1}; tw.w_hh0_t = p; p += pack_floats(H, 1, G);
-  pb.d[4] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1}; tw.w_ih1_t = p; p += pack_floats(H, 1, G);
-  pb.d[5] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1}; tw.w_hh1_t = p; p += pack_floats(H, 1, G);
+  pb.d[0] = PackDesc{w->w_pre, p, D, 1, 0, H, D, 1, dtiles_pad(D)}; tw.w_pre_t = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;   // rows d, k = f: W_pre[f][d]
+  pb.d[1] = PackDesc{w->w_out, p, H, 1, 0, D, H, 1, 0}; tw.w_out_t = p; p += pack_floats(H, 1, D);   // rows f, k = d: W_out[d][f]
+  pb.d[2] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1, 0}; tw.w_ih0_t = p; p += pack_floats(H, 1, G);   // rows k, contraction g: W[g][k]
+  pb.d[3] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1, 0}; tw.w_hh0_t = p; p += pack_floats(H, 1, G);
+  pb.d[4] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1, 0}; tw.w_ih1_t = p; p += pack_floats(H, 1, G);
+  pb.d[5] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1, 0}; tw.w_hh1_t = p; p += pack_floats(H, 1, G);
   launch_pack(pb, st);
   G2V_CHECK_LAUNCH();
   if (lds > 48 * 1024) {
-    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
   DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16)};
-  const bool fast = (H == 64);
+  const bool fast = (H == 64) && (D == 135);
   for (int t = T - 1; t >= 0; --t) {
     if (fast)
-      hipLaunchKernelGGL(dec_step_bwd_kernel<64>, dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
+      hipLaunchKernelGGL((dec_step_bwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
     else
-      hipLaunchKernelGGL(dec_step_bwd_kernel<0>, dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
+      hipLaunchKernelGGL((dec_step_bwd_kernel<0, 0>), dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
   }
   G2V_CHECK_LAUNCH();
   return G2V_OK;

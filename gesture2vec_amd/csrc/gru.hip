@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
             const float rr = sigmoidf_(ir[r] + (acc[0][r] + b_hh[f]));
             const float zz = sigmoidf_(iz[r] + (acc[1][r] + b_hh[H + f]));
             const float ghn = acc[2][r] + b_hh[2 * H + f];
-            const float nn = tanhf(in_[r] + rr * ghn);
+            const float nn = tanhf_(in_[r] + rr * ghn);
             hn[r] = (1.0f - zz) * nn + zz * hp[r];
             gr[r] = rr; gz[r] = zz; gn[r] = nn; gh[r] = ghn;
           } else {
