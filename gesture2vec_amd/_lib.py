@@ -30,6 +30,16 @@ class DecSaved(C.Structure):
         "y", "xin", "u", "a", "h0", "h1", "x1", "gates0", "gates1", "bn_partial", "bn_stats")]
 
 
+class GruDir(C.Structure):
+    """g2v_gru_dir"""
+    _fields_ = [(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)]
+
+
+class GruDirBwd(C.Structure):
+    """g2v_gru_dir_bwd"""
+    _fields_ = [(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)]
+
+
 class DecGrads(C.Structure):
     """g2v_dec_grads"""
     _fields_ = [(n, c_fp) for n in (
@@ -54,11 +64,10 @@ _SIGS = {
     "g2v_vq_ema_update": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                                   c_f, c_f, c_f, c_int, c_fp]),
     "g2v_vq_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_fp]),
-    "g2v_gru_seq_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_i64, c_fp, c_fp,
-                                c_int, c_int, c_int, c_fp]),
-    "g2v_gru_seq_bwd_workspace": (c_sz, [c_int]),
-    "g2v_gru_seq_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp,
-                                c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_gru_seq_fwd_workspace": (c_sz, [c_int, c_int]),
+    "g2v_gru_seq_fwd": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_gru_seq_bwd_workspace": (c_sz, [c_int, c_int]),
+    "g2v_gru_seq_bwd": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_blocks": (c_int, [c_int]),
     "g2v_dec_rollout_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,

@@ -206,48 +206,320 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
     }
 }
 
+
+// =====================================================================================================
+// Fast path, H == 64 (the BASELINE shape): dims are compile-time, each wave owns ONE 16-feature tile whose
+// W_hh fragments (3 gates x 4 k-steps x float4 = 48 VGPRs) stay in registers for the whole sequence, the gi
+// rows of step s+1 are prefetched while step s runs, epilogues are 16-byte vectors, barriers order LDS only,
+// and both directions of a bidirectional layer run in ONE launch (blockIdx.y) so that 2 workgroups share a CU.
+// =====================================================================================================
+struct GruDirF {
+  const float* gi; const float* p_hh; const float* b_hh; const float* h0;
+  float* hs; float* h_n; float* gates;
+  int reverse;
+};
+struct GruDirB {
+  const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* p_hh_t;
+  float* dgi; float* dgh; float* dh0;
+  int reverse;
+};
+
+template <int HS>
+__global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d1, const int32_t* __restrict__ lengths,
+                                                           int64_t hs_ld, int T, int B) {
+  constexpr int H = HS, KS = H / 16, NT = H / 16, ldx = H + 4, G = 3 * H;
+  static_assert(NT == 4, "one feature tile per wave");
+  __shared__ __attribute__((aligned(16))) float hb[2][16 * ldx];
+  const GruDirF d = blockIdx.y ? d1 : d0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0), b = b0 + i;
+  const bool rvalid = i < nrows;
+  const int f0 = 16 * wave + 4 * q;
+  float4 wf[3][KS];
+#pragma unroll
+  for (int g = 0; g < 3; ++g)
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+      wf[g][s] = *reinterpret_cast<const float4*>(d.p_hh + ((int64_t)((g * NT + wave) * KS + s) * 64 + lane) * 4);
+  float4 bh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) bh[g] = *reinterpret_cast<const float4*>(d.b_hh + g * H + f0);
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  for (int e = tid; e < 16 * ldx; e += 256) {
+    const int r = e / ldx, k = e - r * ldx;
+    hb[0][e] = (d.h0 && r < nrows && k < H) ? d.h0[(int64_t)(b0 + r) * H + k] : 0.f;
+    hb[1][e] = 0.f;
+  }
+  float4 gin[3];
+  {
+    const int t0 = d.reverse ? T - 1 : 0;
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+      gin[g] = rvalid ? *reinterpret_cast<const float4*>(d.gi + ((int64_t)t0 * B + b) * G + g * H + f0)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int s = 0; s < T; ++s) {
+    const int t = d.reverse ? (T - 1 - s) : s;
+    float4 gic[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gic[g] = gin[g];
+    if (s + 1 < T && rvalid) {
+      const int tn = d.reverse ? (T - 2 - s) : (s + 1);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gin[g] = *reinterpret_cast<const float4*>(d.gi + ((int64_t)tn * B + b) * G + g * H + f0);
+    }
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* hx = hb[cur] + i * ldx + 4 * q;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 xb = *reinterpret_cast<const float4*>(hx + 16 * ks);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].x, xb.x, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].y, xb.y, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].z, xb.z, acc[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].w, xb.w, acc[g]);
+    }
+    const float4 hp4 = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
+    const bool valid = rvalid && (t < len);
+    const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+    const float ir[4] = {gic[0].x, gic[0].y, gic[0].z, gic[0].w}, iz[4] = {gic[1].x, gic[1].y, gic[1].z, gic[1].w},
+                in_[4] = {gic[2].x, gic[2].y, gic[2].z, gic[2].w};
+    const float br[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+                bn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+    float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float rr = sigmoidf_(ir[r] + (acc[0][r] + br[r]));
+      const float zz = sigmoidf_(iz[r] + (acc[1][r] + bz[r]));
+      const float ghn = acc[2][r] + bn[r];
+      const float nn = tanhf_(in_[r] + rr * ghn);
+      hn[r] = valid ? (1.0f - zz) * nn + zz * hp[r] : hp[r];
+      gr_[r] = valid ? rr : 0.f; gz_[r] = valid ? zz : 0.f; gn_[r] = valid ? nn : 0.f; gh_[r] = valid ? ghn : 0.f;
+    }
+    *reinterpret_cast<float4*>(hb[cur ^ 1] + i * ldx + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    if (rvalid) {
+      const int64_t row = (int64_t)t * B + b;
+      *reinterpret_cast<float4*>(d.hs + row * hs_ld + f0) =
+          valid ? make_float4(hn[0], hn[1], hn[2], hn[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d.gates) {
+        float* go = d.gates + row * 4 * H + f0;
+        *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+        *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+        *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+        *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+      }
+    }
+    lds_barrier();
+    cur ^= 1;
+  }
+  if (d.h_n && rvalid) *reinterpret_cast<float4*>(d.h_n + (int64_t)b * H + f0) = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
+}
+
+template <int HS>
+__global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d1, const int32_t* __restrict__ lengths,
+                                                           int64_t d_hs_ld, int64_t hs_ld, int T, int B) {
+  constexpr int H = HS, G = 3 * H, KSG = G / 16, ldg = G + 4;
+  __shared__ __attribute__((aligned(16))) float Gs[2][16 * ldg];
+  const GruDirB d = blockIdx.y ? d1 : d0;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0), b = b0 + i;
+  const bool rvalid = i < nrows;
+  const int f0 = 16 * wave + 4 * q;
+  float4 wf[KSG];
+#pragma unroll
+  for (int s = 0; s < KSG; ++s) wf[s] = *reinterpret_cast<const float4*>(d.p_hh_t + ((int64_t)(wave * KSG + s) * 64 + lane) * 4);
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dh = (d.d_hn && rvalid) ? *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0) : z4;
+  for (int e = tid; e < 2 * 16 * ldg; e += 256) (&Gs[0][0])[e] = 0.f;
+
+  auto load_step = [&](int s, float4& gr4, float4& gz4, float4& gn4, float4& gh4, float4& hp4, float4& dhs4) {
+    const int t = d.reverse ? (T - 1 - s) : s;
+    const int tprev = d.reverse ? t + 1 : t - 1;
+    gr4 = gz4 = gn4 = gh4 = hp4 = dhs4 = z4;
+    if (rvalid && t < len) {
+      const int64_t row = (int64_t)t * B + b;
+      const float* go = d.gates + row * 4 * H + f0;
+      gr4 = *reinterpret_cast<const float4*>(go);
+      gz4 = *reinterpret_cast<const float4*>(go + H);
+      gn4 = *reinterpret_cast<const float4*>(go + 2 * H);
+      gh4 = *reinterpret_cast<const float4*>(go + 3 * H);
+      if (d.d_hs) dhs4 = *reinterpret_cast<const float4*>(d.d_hs + row * d_hs_ld + f0);
+      if (s == 0 || tprev >= len) {
+        if (d.h0) hp4 = *reinterpret_cast<const float4*>(d.h0 + (int64_t)b * H + f0);
+      } else {
+        hp4 = *reinterpret_cast<const float4*>(d.hs + ((int64_t)tprev * B + b) * hs_ld + f0);
+      }
+    }
+  };
+  float4 n_r, n_z, n_n, n_h, n_hp, n_dhs;
+  load_step(T - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs);
+  __syncthreads();
+  int cur = 0;
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = d.reverse ? (T - 1 - s) : s;
+    const float4 c_r = n_r, c_z = n_z, c_n = n_n, c_h = n_h, c_hp = n_hp, c_dhs = n_dhs;
+    if (s > 0) load_step(s - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs);
+    const bool valid = rvalid && (t < len);
+    const float rr[4] = {c_r.x, c_r.y, c_r.z, c_r.w}, zz[4] = {c_z.x, c_z.y, c_z.z, c_z.w}, nn[4] = {c_n.x, c_n.y, c_n.z, c_n.w},
+                gh[4] = {c_h.x, c_h.y, c_h.z, c_h.w}, hp[4] = {c_hp.x, c_hp.y, c_hp.z, c_hp.w},
+                ds[4] = {c_dhs.x, c_dhs.y, c_dhs.z, c_dhs.w};
+    float dhv[4] = {dh.x, dh.y, dh.z, dh.w};
+    float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (valid) {
+        const float dd = dhv[r] + ds[r];
+        const float dn = dd * (1.0f - zz[r]);
+        const float dz = dd * (hp[r] - nn[r]);
+        const float dnp = dn * (1.0f - nn[r] * nn[r]);
+        g_n[r] = dnp;
+        g_hn[r] = dnp * rr[r];
+        g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+        g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+        direct[r] = dd * zz[r];
+      } else {
+        g_n[r] = g_hn[r] = g_r[r] = g_z[r] = 0.f;
+        direct[r] = dhv[r];
+      }
+    }
+    const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+                 vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+    if (rvalid) {
+      const int64_t row = (int64_t)t * B + b;
+      float* o1 = d.dgi + row * G + f0;
+      float* o2 = d.dgh + row * G + f0;
+      *reinterpret_cast<float4*>(o1) = vr; *reinterpret_cast<float4*>(o1 + H) = vz; *reinterpret_cast<float4*>(o1 + 2 * H) = vn;
+      *reinterpret_cast<float4*>(o2) = vr; *reinterpret_cast<float4*>(o2 + H) = vz; *reinterpret_cast<float4*>(o2 + 2 * H) = vh;
+    }
+    float* gs = Gs[cur] + i * ldg;
+    *reinterpret_cast<float4*>(gs + f0) = vr;
+    *reinterpret_cast<float4*>(gs + H + f0) = vz;
+    *reinterpret_cast<float4*>(gs + 2 * H + f0) = vh;
+    lds_barrier();
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* gx = gs + 4 * q;
+#pragma unroll
+    for (int ks = 0; ks < KSG; ++ks) {
+      const float4 xb = *reinterpret_cast<const float4*>(gx + 16 * ks);
+      acc = mfma16(wf[ks].x, xb.x, acc);
+      acc = mfma16(wf[ks].y, xb.y, acc);
+      acc = mfma16(wf[ks].z, xb.z, acc);
+      acc = mfma16(wf[ks].w, xb.w, acc);
+    }
+    dh = make_float4(direct[0] + acc[0], direct[1] + acc[1], direct[2] + acc[2], direct[3] + acc[3]);
+    cur ^= 1;
+  }
+  if (d.dh0 && rvalid) *reinterpret_cast<float4*>(d.dh0 + (int64_t)b * H + f0) = dh;
+}
+
 }  // namespace g2v
 
 using namespace g2v;
 
-extern "C" int g2v_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0,
-                               const int32_t* lengths, int reverse, float* hs, int64_t hs_ld, float* h_n, float* gates,
-                               int T, int B, int H, g2v_stream_t stream) {
-  G2V_REQUIRE(gi && w_hh && b_hh && hs, "null pointer");
+static bool gru_fast_ok(int H, int64_t hs_ld) { return H == 64 && (hs_ld & 3) == 0; }
+
+extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) { return (size_t)ndir * pack_floats(H, 3, H) * sizeof(float); }
+
+extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
+                               int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(dirs && workspace, "null pointer");
+  G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && hs_ld >= H, "bad size");
+  for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].gi && dirs[k].w_hh && dirs[k].b_hh && dirs[k].hs, "null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  if (gru_fast_ok(H, hs_ld)) {
+    if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
+      set_error("g2v_gru_seq_fwd: workspace too small");
+      return G2V_ERR_WORKSPACE;
+    }
+    float* p = (float*)workspace;
+    PackBatch pb;
+    pb.n = ndir;
+    GruDirF f[2];
+    for (int k = 0; k < ndir; ++k) {
+      pb.d[k] = PackDesc{dirs[k].w_hh, p, H, 3, H, H, H, 0, 0};
+      f[k] = GruDirF{dirs[k].gi, p, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+      p += pack_floats(H, 3, H);
+    }
+    if (ndir == 1) f[1] = f[0];
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gru_fwd_fast_kernel<64>, dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   const int Hp = (H + 15) & ~15;
   const size_t lds = (size_t)2 * 16 * (Hp + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, (hipStream_t)stream, gi, w_hh, b_hh, h0,
-                     lengths, reverse, hs, hs_ld, h_n, gates, T, B, H);
+  for (int k = 0; k < ndir; ++k) {
+    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, st, dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh,
+                       dirs[k].h0, lengths, dirs[k].reverse, dirs[k].hs, hs_ld, dirs[k].h_n, dirs[k].gates, T, B, H);
+  }
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
 
-extern "C" size_t g2v_gru_seq_bwd_workspace(int H) { return (size_t)3 * H * H * sizeof(float); }
+extern "C" size_t g2v_gru_seq_bwd_workspace(int ndir, int H) {
+  const size_t a = (size_t)ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H;
+  return (a > b ? a : b) * sizeof(float);
+}
 
-extern "C" int g2v_gru_seq_bwd(const float* d_hs, int64_t d_hs_ld, const float* d_hn, const float* hs, int64_t hs_ld,
-                               const float* h0, const float* gates, const float* w_hh, const int32_t* lengths,
-                               int reverse, float* dgi, float* dgh, float* dh0, int T, int B, int H,
-                               void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
-  G2V_REQUIRE(hs && gates && w_hh && dgi && dgh && workspace, "null pointer");
+extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
+                               int64_t hs_ld, int T, int B, int H, void* workspace, size_t workspace_bytes,
+                               g2v_stream_t stream) {
+  G2V_REQUIRE(dirs && workspace, "null pointer");
+  G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0, "bad size");
-  if (workspace_bytes < g2v_gru_seq_bwd_workspace(H)) {
+  for (int k = 0; k < ndir; ++k)
+    G2V_REQUIRE(dirs[k].hs && dirs[k].gates && dirs[k].w_hh && dirs[k].dgi && dirs[k].dgh, "null pointer");
+  if (workspace_bytes < g2v_gru_seq_bwd_workspace(ndir, H)) {
     set_error("g2v_gru_seq_bwd: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
-  float* wt = (float*)workspace;
-  launch_transpose(w_hh, wt, 3 * H, H, (hipStream_t)stream);  // (3H,H) -> (H,3H)
-  G2V_CHECK_LAUNCH();
+  hipStream_t st = (hipStream_t)stream;
+  float* p = (float*)workspace;
+  if (gru_fast_ok(H, hs_ld) && (d_hs_ld & 3) == 0) {
+    PackBatch pb;
+    pb.n = ndir;
+    GruDirB f[2];
+    for (int k = 0; k < ndir; ++k) {
+      pb.d[k] = PackDesc{dirs[k].w_hh, p, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden feature), contraction over the 3H gates
+      f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p,
+                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse};
+      p += pack_floats(H, 1, 3 * H);
+    }
+    if (ndir == 1) f[1] = f[0];
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+    hipLaunchKernelGGL(gru_bwd_fast_kernel<64>, dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
+                       hs_ld, T, B);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   const int Hp = (H + 15) & ~15, Gp = (3 * H + 15) & ~15;
   const size_t lds = (size_t)16 * ((Gp + 4) + (Hp + 4)) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, (hipStream_t)stream, d_hs, d_hs_ld, d_hn,
-                     hs, hs_ld, h0, gates, wt, lengths, reverse, dgi, dgh, dh0, T, B, H);
+  for (int k = 0; k < ndir; ++k) {
+    float* wt = p + (size_t)k * 3 * H * H;
+    launch_transpose(dirs[k].w_hh, wt, 3 * H, H, st);  // (3H,H) -> (H,3H)
+    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, st, dirs[k].d_hs, d_hs_ld, dirs[k].d_hn,
+                       dirs[k].hs, hs_ld, dirs[k].h0, dirs[k].gates, wt, lengths, dirs[k].reverse, dirs[k].dgi, dirs[k].dgh,
+                       dirs[k].dh0, T, B, H);
+  }
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -196,7 +196,7 @@ class VQVAEEngine:
         gr.bn_bwd_partial = _p(b["bn_bwd_partial"])
         b["gr"] = gr
         ws_bytes = max(self.lib.g2v_dec_rollout_bwd_workspace(D, H), self.lib.g2v_dec_rollout_fwd_workspace(D, H),
-                       self.lib.g2v_gru_seq_bwd_workspace(H),
+                       self.lib.g2v_gru_seq_bwd_workspace(2, H), self.lib.g2v_gru_seq_fwd_workspace(2, H),
                        self.lib.g2v_vq_stats_workspace(B, E, K),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)))
@@ -246,14 +246,17 @@ class VQVAEEngine:
         for suf, gi in (("", b["gi_f"]), ("_reverse", b["gi_b"])):
             check(lib.g2v_linear_fwd(_p(b["xin"]), H, 0, 0, 0, None, 1.0, self._w(enc + "gru.weight_ih_l0" + suf),
                                      self._w(enc + "gru.bias_ih_l0" + suf), _p(gi), G, T * B, H, G, 0, st))
-        gates_f = _p(b["gates_f"]) if training else None
-        gates_b = _p(b["gates_b"]) if training else None
-        check(lib.g2v_gru_seq_fwd(_p(b["gi_f"]), self._w(enc + "gru.weight_hh_l0"), self._w(enc + "gru.bias_hh_l0"),
-                                  None, None, 0, b["hs_f"][1:].data_ptr(), H, b["enc_hidden"][0].data_ptr(), gates_f,
-                                  T, B, H, st))
-        check(lib.g2v_gru_seq_fwd(_p(b["gi_b"]), self._w(enc + "gru.weight_hh_l0_reverse"),
-                                  self._w(enc + "gru.bias_hh_l0_reverse"), None, None, 1, b["hs_b"].data_ptr(), H,
-                                  b["enc_hidden"][1].data_ptr(), gates_b, T, B, H, st))
+        dirs = (_lib.GruDir * 2)()
+        for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):
+            dirs[k].gi = _p(b["gi_" + key])
+            dirs[k].w_hh = self._w(enc + "gru.weight_hh_l0" + suf)
+            dirs[k].b_hh = self._w(enc + "gru.bias_hh_l0" + suf)
+            dirs[k].h0 = None
+            dirs[k].hs = hs_ptr
+            dirs[k].h_n = b["enc_hidden"][k].data_ptr()
+            dirs[k].gates = _p(b["gates_" + key]) if training else None
+            dirs[k].reverse = k
+        check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
         # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
         N = (2 * B * H) // E
         check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
@@ -319,12 +322,19 @@ class VQVAEEngine:
                              self.beta, st))
         # ---- encoder layer-0 BPTT -----------------------------------------------------------------------------------
         enc = "encoder."
-        check(lib.g2v_gru_seq_bwd(None, 0, b["gz"][0].data_ptr(), b["hs_f"][1:].data_ptr(), H, None, _p(b["gates_f"]),
-                                  self._w(enc + "gru.weight_hh_l0"), None, 0, _p(b["dgi_f"]), _p(b["dgh_f"]), None,
-                                  T, B, H, ws, wsn, st))
-        check(lib.g2v_gru_seq_bwd(None, 0, b["gz"][1].data_ptr(), b["hs_b"].data_ptr(), H, None, _p(b["gates_b"]),
-                                  self._w(enc + "gru.weight_hh_l0_reverse"), None, 1, _p(b["dgi_b"]), _p(b["dgh_b"]), None,
-                                  T, B, H, ws, wsn, st))
+        dirs = (_lib.GruDirBwd * 2)()
+        for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):
+            dirs[k].d_hs = None
+            dirs[k].d_hn = b["gz"][k].data_ptr()
+            dirs[k].hs = hs_ptr
+            dirs[k].h0 = None
+            dirs[k].gates = _p(b["gates_" + key])
+            dirs[k].w_hh = self._w(enc + "gru.weight_hh_l0" + suf)
+            dirs[k].dgi = _p(b["dgi_" + key])
+            dirs[k].dgh = _p(b["dgh_" + key])
+            dirs[k].dh0 = None
+            dirs[k].reverse = k
+        check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
         wgrad(_p(b["dgi_f"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0", G, H, rows=TB)
         wgrad(_p(b["dgh_f"]), G, b["hs_f"].data_ptr(), H, enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0", G, H, rows=TB)

@@ -160,7 +160,35 @@ def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta, out=None):
     return gz
 
 
-# ------------------------------------------------------------------------------------------ GRU direction
+# ------------------------------------------------------------------------------------------ GRU direction(s)
+def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None):
+    """dirs: list (1 or 2) of dicts gi, w_hh, b_hh, h0, hs, h_n, gates, reverse -- ONE launch for both directions."""
+    lib = _lib_()
+    arr = (_lib.GruDir * len(dirs))()
+    for k, d in enumerate(dirs):
+        for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates"):
+            setattr(arr[k], name, _p(d.get(name)))
+        arr[k].reverse = int(bool(d.get("reverse", False)))
+    dev = dirs[0]["gi"].device
+    ws = workspace(lib.g2v_gru_seq_fwd_workspace(len(dirs), H), dev, "grufwd")
+    check(lib.g2v_gru_seq_fwd(arr, len(dirs), _p(lengths), hs_ld if hs_ld is not None else H, T, B, H, _p(ws),
+                              ws.numel(), _stream()), "gru_seq_fwd")
+
+
+def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None):
+    """dirs: list of dicts d_hs, d_hn, hs, h0, gates, w_hh, dgi, dgh, dh0, reverse."""
+    lib = _lib_()
+    arr = (_lib.GruDirBwd * len(dirs))()
+    for k, d in enumerate(dirs):
+        for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0"):
+            setattr(arr[k], name, _p(d.get(name)))
+        arr[k].reverse = int(bool(d.get("reverse", False)))
+    dev = dirs[0]["hs"].device
+    ws = workspace(lib.g2v_gru_seq_bwd_workspace(len(dirs), H), dev, "grubwd")
+    check(lib.g2v_gru_seq_bwd(arr, len(dirs), _p(lengths), d_hs_ld if d_hs_ld is not None else H,
+                              hs_ld if hs_ld is not None else H, T, B, H, _p(ws), ws.numel(), _stream()), "gru_seq_bwd")
+
+
 def gru_seq_fwd(gi, w_hh, b_hh, T, B, H, *, h0=None, lengths=None, reverse=False, hs=None, hs_ld=None,
                 save_gates=True):
     dev = gi.device
@@ -169,22 +197,19 @@ def gru_seq_fwd(gi, w_hh, b_hh, T, B, H, *, h0=None, lengths=None, reverse=False
         hs_ld = H
     h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
     gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev) if save_gates else None
-    check(_lib_().g2v_gru_seq_fwd(_p(_chk(gi)), _p(_chk(w_hh)), _p(b_hh), _p(h0), _p(lengths), int(reverse),
-                                  _p(hs), hs_ld, _p(h_n), _p(gates), T, B, H, _stream()), "gru_seq_fwd")
+    gru_dirs_fwd([dict(gi=_chk(gi), w_hh=_chk(w_hh), b_hh=b_hh, h0=h0, hs=hs, h_n=h_n, gates=gates, reverse=reverse)],
+                 T, B, H, lengths=lengths, hs_ld=hs_ld)
     return hs, h_n, gates
 
 
 def gru_seq_bwd(d_hs, d_hs_ld, d_hn, hs, hs_ld, h0, gates, w_hh, T, B, H, *, lengths=None, reverse=False,
                 want_dh0=False):
     dev = hs.device
-    lib = _lib_()
     dgi = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
     dgh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
     dh0 = torch.empty((B, H), dtype=torch.float32, device=dev) if want_dh0 else None
-    ws = workspace(lib.g2v_gru_seq_bwd_workspace(H), dev, "grubwd")
-    check(lib.g2v_gru_seq_bwd(_p(d_hs), d_hs_ld, _p(d_hn), _p(hs), hs_ld, _p(h0), _p(gates), _p(w_hh), _p(lengths),
-                              int(reverse), _p(dgi), _p(dgh), _p(dh0), T, B, H, _p(ws), ws.numel(), _stream()),
-          "gru_seq_bwd")
+    gru_dirs_bwd([dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=h0, gates=gates, w_hh=w_hh, dgi=dgi, dgh=dgh, dh0=dh0,
+                       reverse=reverse)], T, B, H, lengths=lengths, d_hs_ld=d_hs_ld, hs_ld=hs_ld)
     return dgi, dgh, dh0
 
 

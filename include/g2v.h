@@ -127,18 +127,32 @@ int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, co
  *   hs row (t,b) is written at hs + (t*B + b)*hs_ld  (hs_ld >= H lets both directions share a (T,B,2H) buffer).
  *   gates (T,B,4H) = r,z,n,W_hn h + b_hn  saved for the backward (NULL = inference).
  * ------------------------------------------------------------------------------------------ */
-int g2v_gru_seq_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h0,
-                    const int32_t* lengths, int reverse,
-                    float* hs, int64_t hs_ld, float* h_n, float* gates,
-                    int T, int B, int H, g2v_stream_t stream);
+typedef struct {          /* one direction of one layer, forward */
+  const float* gi;        /* (T,B,3H) input projections incl. b_ih          */
+  const float* w_hh;      /* (3H,H)                                         */
+  const float* b_hh;      /* (3H)                                           */
+  const float* h0;        /* (B,H) or NULL = zeros                          */
+  float* hs;              /* out: hidden states, row (t,b) at hs + (t*B+b)*hs_ld */
+  float* h_n;             /* out: (B,H) final state (may be NULL)           */
+  float* gates;           /* out: (T,B,4H) saved for backward (NULL = inference) */
+  int reverse;            /* 0: t = 0..T-1, 1: t = T-1..0                   */
+} g2v_gru_dir;
+
+/* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
+size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */
+int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld,
+                    int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
 /* BPTT of the above.  d_hs (row stride d_hs_ld) / d_hn may be NULL.  Produces dgi (T,B,3H) (grad wrt gi:
  * feeds W_ih, b_ih, x grads through g2v_linear_bwd_*), dgh (T,B,3H) (feeds W_hh, b_hh) and dh0 (B,H) (may be NULL). */
-size_t g2v_gru_seq_bwd_workspace(int H);   /* room for W_hh^T */
-int g2v_gru_seq_bwd(const float* d_hs, int64_t d_hs_ld, const float* d_hn,
-                    const float* hs, int64_t hs_ld, const float* h0, const float* gates,
-                    const float* w_hh, const int32_t* lengths, int reverse,
-                    float* dgi, float* dgh, float* dh0,
+typedef struct {
+  const float* d_hs; const float* d_hn;       /* incoming gradients (either may be NULL)            */
+  const float* hs; const float* h0; const float* gates; const float* w_hh;   /* forward tensors */
+  float* dgi; float* dgh; float* dh0;         /* outputs (dh0 may be NULL)                          */
+  int reverse;
+} g2v_gru_dir_bwd;
+size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragment order) */
+int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,
                     int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
