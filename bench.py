@@ -146,8 +146,11 @@ def main():
 
     reduce_fn = None
     if world > 1:
-        def reduce_fn(buf):
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        from gesture2vec_amd.dp import GradStatsAllReduce, broadcast_state
+        vq = net.vq_layer
+        broadcast_state([eng.flat, vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size,
+                         vq.pre_linear.weight.data, vq.pre_linear.bias.data])
+        reduce_fn = GradStatsAllReduce()        # ONE RCCL all-reduce of [grads | EMA stats] per step
 
     def step():
         eng.train_step(x, x, lr=CFG["lr"], w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], epoch=1,

@@ -20,10 +20,10 @@ __device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 
 __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restrict__ y, const float* __restrict__ tgt,
                                                           float* __restrict__ dy, float* __restrict__ partial, float c1,
                                                           float c2, float c3, float g_scale, int T, int B, int D) {
-  __shared__ float red[3][4];
+  __shared__ float red[4][4];
   const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t BD = (int64_t)B * D;
-  float l1 = 0.f, cont = 0.f, nrm = 0.f;
+  float l1 = 0.f, cont = 0.f, nrm = 0.f, sq = 0.f;
   if (col < BD) {
     const int b = (int)(col / D), d = (int)(col - (int64_t)b * D);
     float ss = 0.f, prev = 0.f;
@@ -31,6 +31,7 @@ __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restric
       const float v = y[(int64_t)t * BD + col];
       const float tv = tgt[((int64_t)b * T + t) * D + d];
       l1 += fabsf(v - tv);
+      sq += (v - tv) * (v - tv);
       if (t > 0) cont += fabsf(v - prev);
       ss += v * v;
       prev = v;
@@ -54,26 +55,28 @@ __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restric
   l1 = wave_sum(l1);
   cont = wave_sum(cont);
   nrm = wave_sum(nrm);
+  sq = wave_sum(sq);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if (lane == 0) {
     red[0][wave] = l1;
     red[1][wave] = cont;
     red[2][wave] = nrm;
+    red[3][wave] = sq;
   }
   __syncthreads();
-  if (threadIdx.x < 3)
-    partial[(int64_t)blockIdx.x * 3 + threadIdx.x] =
+  if (threadIdx.x < 4)
+    partial[(int64_t)blockIdx.x * 4 + threadIdx.x] =
         (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
 __global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ terms,
-                                            float c1, float c2, float c3) {
-  __shared__ float red[3][4];
-  float s[3] = {0.f, 0.f, 0.f};
+                                            float c1, float c2, float c3, float inv_n) {
+  __shared__ float red[4][4];
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
   for (int k = threadIdx.x; k < nblk; k += 256)
-    for (int j = 0; j < 3; ++j) s[j] += partial[(int64_t)k * 3 + j];
+    for (int j = 0; j < 4; ++j) s[j] += partial[(int64_t)k * 4 + j];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < 4; ++j) {
     s[j] = wave_sum(s[j]);
     if (lane == 0) red[j][wave] = s[j];
   }
@@ -86,6 +89,7 @@ __global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, i
     terms[1] = l1;
     terms[2] = cont;
     terms[3] = var;
+    terms[4] = ((red[3][0] + red[3][1]) + (red[3][2] + red[3][3])) * inv_n;   // plain MSE (evaluate_testset's metric)
   }
 }
 
@@ -217,7 +221,7 @@ extern "C" int g2v_custom_loss_fwd_bwd(const float* y, const float* target, floa
                      c3, g_scale, T, B, D);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(custom_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, terms, c1,
-                     c2, c3);
+                     c2, c3, 1.0f / n);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

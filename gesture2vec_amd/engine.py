@@ -111,7 +111,7 @@ class VQVAEEngine:
         self.bn_rv = torch.ones(H, device=dev)
         self.vq_stats = self.comm[self.n_flat:]
         self.vq_scalars = torch.zeros(2, device=dev)          # loss_vq, perplexity
-        self.loss_terms = torch.zeros(4, device=dev)          # custom_loss total, l1, cont, var
+        self.loss_terms = torch.zeros(5, device=dev)          # custom_loss total, l1, cont, var, mse
         self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
         self._bufs: Dict[int, dict] = {}
         self._wstruct = None
@@ -169,7 +169,7 @@ class VQVAEEngine:
             "h0": z(T, B, H), "h1": z(T, B, H), "x1": z(T - 1, B, H) if self.p > 0 else None,
             "gates0": z(T - 1, B, 4 * H), "gates1": z(T - 1, B, 4 * H),
             "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H),
-            "loss_partial": z(self.lib.g2v_custom_loss_blocks(B, D) * 3),
+            "loss_partial": z(self.lib.g2v_custom_loss_blocks(B, D) * 4),
             # backward
             "dy": z(T, B, D), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H),
             "dgi0": z(T - 1, B, G), "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G),

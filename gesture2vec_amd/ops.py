@@ -259,8 +259,8 @@ def custom_loss_fwd_bwd(y_tbd, target_btd, w_l1, w_cont, w_var, g_scale=1.0, wan
     dev = y_tbd.device
     lib = _lib_()
     dy = torch.empty_like(y_tbd) if want_grad else None
-    terms = torch.empty((4,), dtype=torch.float32, device=dev)
-    partial = torch.empty((lib.g2v_custom_loss_blocks(B, D) * 3,), dtype=torch.float32, device=dev)
+    terms = torch.empty((5,), dtype=torch.float32, device=dev)
+    partial = torch.empty((lib.g2v_custom_loss_blocks(B, D) * 4,), dtype=torch.float32, device=dev)
     check(lib.g2v_custom_loss_fwd_bwd(_p(_chk(y_tbd)), _p(_chk(target_btd)), _p(dy), _p(terms), _p(partial),
                                       float(w_l1), float(w_cont), float(w_var), float(g_scale), T, B, D, _stream()),
           "custom_loss_fwd_bwd")

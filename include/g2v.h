@@ -221,7 +221,8 @@ int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const 
  * custom_loss forward + gradient (K10), train_eval/train_seq2seq.py:40-88.
  *   loss = w_l1*mean|y-tgt| + w_cont*sum_t|y_t-y_{t-1}|/numel - w_var*sum_{b,d}||y[b,:,d]||_2/numel
  * y is time-major (T,B,D) (the rollout's buffer), target is (B,T,D).  dy (T,B,D) = g_scale * dloss/dy
- * (may be NULL).  terms out (4 floats): total, l1, cont, var.  partial: >= g2v_custom_loss_blocks(B,D)*3 floats.
+ * (may be NULL).  terms out (5 floats): total, l1, cont, var, mse (= mean (y-tgt)^2, the metric of
+ * evaluate_testset train_autoencoder_VQVAE.py:350-410).  partial: >= g2v_custom_loss_blocks(B,D)*4 floats.
  * ------------------------------------------------------------------------------------------ */
 int g2v_custom_loss_blocks(int B, int D);
 int g2v_custom_loss_fwd_bwd(const float* y, const float* target, float* dy, float* terms, float* partial,

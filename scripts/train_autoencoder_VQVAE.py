@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Part b trainer -- drop-in for the reference's `scripts/train_autoencoder_VQVAE.py` on the MI355X kernels.
+
+    python train_autoencoder_VQVAE.py --config=../config/VQ-VAE_synthetic.yml --synthetic
+
+Same surface: `init_model(args, lang_model, pose_dim, _device)`, `train_epochs(...)`, `evaluate_testset(...)`,
+`main(config)`, `save_config`; Adam(lr, betas=(0.5, 0.999)); evaluation before training and every epoch; the epoch log
+line `EP <epoch> (<iter>) | <elapsed>, <n> samples/s | loss: <avg>, `; checkpoint dict keys / file naming of
+`train_autoencoder_VQVAE.py:223-244`.  Plotting / t-SNE / BVH inference shell-outs are visualisation only and omitted.
+The LMDB datasets need third-party packages that are not available here; `--synthetic` feeds N(0,1) pose chunks
+of the configured shape."""
+from __future__ import annotations
+
+import logging
+import os
+import pprint
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+for _p in (_HERE, _ROOT):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+from config.parse_args import parse_args  # noqa: E402
+from model.Autoencoder_VQVAE_model import Autoencoder_VQVAE  # noqa: E402
+from train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq  # noqa: E402
+import utils.train_utils  # noqa: E402
+from utils.average_meter import AverageMeter  # noqa: E402
+
+device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+debug = False
+
+
+class _EvalMSE:
+    """loss_fn returned by init_model (the reference returns torch.nn.MSELoss()); evaluated by the loss kernel."""
+
+    def __call__(self, out_poses, target_poses):
+        from gesture2vec_amd import ops
+        terms, _ = ops.custom_loss_fwd_bwd(out_poses.transpose(0, 1).contiguous(), target_poses.contiguous(), 0.0, 0.0, 0.0,
+                                           want_grad=False)
+        return terms[4]
+
+
+def init_model(args, lang_model, pose_dim: int, _device):
+    n_frames = args.n_poses
+    generator = Autoencoder_VQVAE(args, pose_dim, n_frames).to(_device)
+    return generator, _EvalMSE()
+
+
+class SyntheticChunks:
+    """Iterable of (encoded_input, encoded_output) = (x, x) batches of N(0,1) pose chunks (B, n_poses, rep_learning_dim),
+    the shape `TrinityDataset_DAEed_Autoencoder.__getitem__` yields (lmdb_data_loader.py:674)."""
+
+    def __init__(self, args, n_batches: int, seed: int):
+        self.shape = (args.batch_size, args.n_poses, args.rep_learning_dim)
+        self.n_batches, self.seed = n_batches, seed
+
+    def __len__(self):
+        return self.n_batches
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        for _ in range(self.n_batches):
+            x = torch.randn(self.shape, generator=g)
+            yield x, x
+
+
+def evaluate_testset(test_data_loader, generator, loss_fn, args) -> float:
+    generator.train(False)
+    losses = AverageMeter("loss")
+    start = time.time()
+    with torch.no_grad():
+        for in_poses, target_poses in test_data_loader:
+            batch_size = in_poses.size(0)
+            in_poses, target_poses = in_poses.to(device), target_poses.to(device)
+            out_poses, _latent, _loss_vq, _perp = generator(in_poses, target_poses)
+            losses.update(float(loss_fn(out_poses, target_poses)), batch_size)
+    generator.train(True)
+    logging.info("[VAL] loss: {:.3f} / {:.1f}s".format(losses.avg, time.time() - start))
+    return losses.avg
+
+
+def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, lang_model, pose_dim, trial_id=None):
+    start = time.time()
+    loss_meters = [AverageMeter("loss"), AverageMeter("var_loss")]
+    print_interval = int(len(train_data_loader))
+    save_model_epoch_interval = args.epochs
+    generator, loss_fn = init_model(args, lang_model, pose_dim, device)
+    gen_optimizer = FusedClipAdam(generator, lr=args.learning_rate, betas=(0.5, 0.999))
+    evaluate_testset(test_data_loader, generator, loss_fn, args)
+    val_metrics_list, loss_list = [], []
+    global_iter = 0
+    for epoch in range(1, args.epochs + 1):
+        val_metrics_list.append(evaluate_testset(test_data_loader, generator, loss_fn, args))
+        if epoch % save_model_epoch_interval == 0 and epoch > 0:
+            save_name = "{}/{}_checkpoint_{:03d}.bin".format(args.model_save_path, args.name, epoch)
+            utils.train_utils.save_checkpoint(
+                {"args": args, "epoch": epoch, "lang_model": lang_model, "pose_dim": pose_dim,
+                 "gen_dict": generator.state_dict(), "val_metrics_list": val_metrics_list, "loss_list": loss_list},
+                save_name)
+        iter_start_time = time.time()
+        loss_epoch = AverageMeter("loss")
+        for iter_idx, (encoded_input, encoded_output) in enumerate(train_data_loader, 0):
+            global_iter += 1
+            batch_size = encoded_output.size(0)
+            encoded_input, encoded_output = encoded_input.to(device), encoded_output.to(device)
+            loss, perplexity = train_iter_Autoencoder_VQ_seq2seq(args, epoch, encoded_input, encoded_output, generator,
+                                                                 gen_optimizer)
+            loss_epoch.update(loss["loss"], batch_size)
+            for m in loss_meters:
+                if m.name in loss:
+                    m.update(loss[m.name], batch_size)
+            if (iter_idx + 1) % print_interval == 0:
+                summary = "EP {} ({:3d}) | {:>8s}, {:.0f} samples/s | ".format(
+                    epoch, iter_idx + 1, utils.train_utils.time_since(start), batch_size / (time.time() - iter_start_time))
+                for m in loss_meters:
+                    if m.count > 0:
+                        summary += "{}: {:.3f}, ".format(m.name, m.avg)
+                        m.reset()
+                logging.info(summary)
+            iter_start_time = time.time()
+        loss_list.append(loss_epoch.avg)
+    return generator, val_metrics_list, loss_list
+
+
+def save_config(_args) -> None:
+    os.makedirs(_args.model_save_path, exist_ok=True)
+    with open(os.path.join(_args.model_save_path, "conf"), "w") as conf:
+        for k, v in sorted(vars(_args).items()):
+            conf.write("{}={}\n".format(k, v))
+
+
+def main(config: dict):
+    args = config["args"]
+    if args.random_seed >= 0:
+        torch.manual_seed(args.random_seed)
+        np.random.seed(args.random_seed)
+        random.seed(args.random_seed)
+        os.environ["PYTHONHASHSEED"] = str(args.random_seed)
+    utils.train_utils.set_logger(args.model_save_path, os.path.basename(__file__).replace(".py", ".log"))
+    logging.info("PyTorch version: {}".format(torch.__version__))
+    logging.info("HIP version: {}".format(torch.version.hip))
+    logging.info(pprint.pformat(vars(args)))
+    if not getattr(args, "synthetic", False):
+        raise SystemExit("the LMDB datasets of the reference need lmdb / legacy pyarrow, which are not available here: "
+                         "run with --synthetic (SURVEY.md §8f ranks the real-data reader as follow-up work)")
+    nb = getattr(args, "synthetic_batches", 8)
+    train_loader = SyntheticChunks(args, nb, seed=1234)
+    test_loader = SyntheticChunks(args, max(1, nb // 4), seed=4321)
+    return train_epochs(args, train_loader, None, test_loader, None, pose_dim=args.rep_learning_dim)
+
+
+if __name__ == "__main__":
+    _args = parse_args()
+    if _args.use_derivative == "True":
+        _args.rep_learning_dim = _args.rep_learning_dim * 2
+    save_config(_args)
+    main({"args": _args})

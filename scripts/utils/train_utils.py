@@ -1,0 +1,57 @@
+"""Logging / checkpoint helpers with the reference's contract (scripts/utils/train_utils.py:43-175):
+checkpoint = torch.save({"args", "epoch", "lang_model", "pose_dim", "gen_dict"[, "val_metrics_list", "loss_list"]}),
+`load_checkpoint_and_model(path, device, what)` rebuilds the model through the matching train script's init_model.
+Only the branches on the accelerated path exist here ("autoencoder_vq"); the others raise."""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import time
+from logging.handlers import RotatingFileHandler
+
+import torch
+
+
+def set_logger(log_path: str = None, log_filename: str = "log") -> None:
+    for h in logging.root.handlers[:]:
+        logging.root.removeHandler(h)
+    handlers = [logging.StreamHandler()]
+    if log_path is not None:
+        os.makedirs(log_path, exist_ok=True)
+        handlers.append(RotatingFileHandler(os.path.join(log_path, log_filename), maxBytes=10 * 1024 * 1024, backupCount=5))
+    logging.basicConfig(level=logging.DEBUG, format="%(asctime)s: %(message)s", handlers=handlers)
+
+
+def as_minutes(s: float) -> str:
+    m = math.floor(s / 60)
+    return "%dm %ds" % (m, s - m * 60)
+
+
+def time_since(since: float) -> str:
+    return as_minutes(time.time() - since)
+
+
+def save_checkpoint(state: dict, filename: str) -> None:
+    torch.save(state, filename)
+    logging.info("Saved the checkpoint")
+
+
+def load_checkpoint_and_model(checkpoint_path, _device="cpu", what: str = ""):
+    """-> (args, generator, loss_fn, lang_model, pose_dim); the model is returned in eval mode."""
+    print("loading checkpoint {}".format(checkpoint_path))
+    # the reference pickles an argparse.Namespace (and a Vocab) next to the weights: weights_only must be off
+    checkpoint = torch.load(checkpoint_path, map_location="cpu", weights_only=False)
+    args, epoch = checkpoint["args"], checkpoint["epoch"]
+    lang_model, pose_dim = checkpoint["lang_model"], checkpoint["pose_dim"]
+    print("epoch {}".format(epoch))
+    if what == "autoencoder_vq":
+        from train_autoencoder_VQVAE import init_model as VQVAE_init
+        generator, loss_fn = VQVAE_init(args, lang_model, pose_dim, "cpu")
+        # reference checkpoints trained with the shipped GSSoft override carry mean_layer/logvar_layer keys: refuse them
+        generator.load_state_dict(checkpoint["gen_dict"], strict=True)
+        generator = generator.to(_device)
+    else:
+        raise NotImplementedError(f"load_checkpoint_and_model(what={what!r}) is outside the accelerated hot path")
+    generator.train(False)
+    return args, generator, loss_fn, lang_model, pose_dim

@@ -1,0 +1,32 @@
+"""GPU: the drop-in entry point runs end to end (config -> model -> epochs -> checkpoint -> reload)."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_train_autoencoder_vqvae_synthetic(tmp_path):
+    out = os.path.join(tmp_path, "run")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"),
+           "--config", os.path.join(ROOT, "config", "VQ-VAE_synthetic.yml"), "--synthetic", "--synthetic_batches", "3",
+           "--batch_size", "64", "--epochs", "2", "--model_save_path", out, "--name", "t"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    assert "[VAL] loss:" in log and "EP 2 (  3) |" in log and "samples/s | loss:" in log
+    ckpt = os.path.join(out, "t_checkpoint_002.bin")
+    assert os.path.exists(ckpt) and os.path.exists(os.path.join(out, "conf"))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import utils.train_utils as tu
+    args, net, loss_fn, lang, pose_dim = tu.load_checkpoint_and_model(ckpt, "cuda:0", "autoencoder_vq")
+    assert pose_dim == 135 and not net.training
+    x = torch.randn(8, 34, 135, device="cuda:0")
+    with torch.no_grad():
+        out_poses, latent, loss_vq, perp = net(x, x)
+    assert out_poses.shape == (8, 34, 135) and torch.isfinite(out_poses).all()
+    assert float(loss_fn(out_poses, x)) > 0
