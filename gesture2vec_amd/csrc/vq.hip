@@ -20,6 +20,7 @@
 namespace g2v {
 
 constexpr int VQ_ROWS = 16;
+static inline bool ptr_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 __global__ void code_sqnorm_kernel(const float* __restrict__ W, float* __restrict__ out, int K, int E) {
   const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
@@ -126,6 +127,280 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
         const float diff = wq[k] - zv;
         qo[k] = zv + diff;                 // inputs + (quantized - inputs).detach()  (:1292)
         sse += diff * diff;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// Fast path for E == 128 and K % 128 == 0 (the BASELINE shape E = 128, K = 512).  Same arithmetic, but:
+//  * the 16 x E row tile's MFMA B-fragments (8 x float4) live in registers for the whole kernel,
+//  * each wave walks its code tiles in PAIRS (two independent accumulator chains: the 16x16x4 fp32 MFMA has a
+//    40-cycle dependent latency against a 32-cycle issue slot), and the NEXT pair's 16 fragment loads are issued
+//    before the current pair's 64 MFMAs, so the L2 latency of the codebook stream hides behind ~2k cycles of math,
+//  * codebook rows are read straight from the row-major (K,E) array: per k-step a wave touches 16 rows x 64 B and
+//    the neighbouring k-step consumes the other half of each 128-byte line (L1 hit).
+template <int E>
+__global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __restrict__ flat, const float* __restrict__ z,
+                                                             const float* __restrict__ W, const float* __restrict__ wsq,
+                                                             int64_t* __restrict__ idx_out, float* __restrict__ quant,
+                                                             float* __restrict__ dist_min, float* __restrict__ sse_partial,
+                                                             int N, int K) {
+  constexpr int KS = E / 16, ldx = E + 4;
+  __shared__ __attribute__((aligned(16))) float Xs[VQ_ROWS * ldx];
+  __shared__ float xx[16];
+  __shared__ float wbest_d[64];
+  __shared__ int wbest_k[64];
+  __shared__ int best_k[16];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  const int i = lane & 15, q = lane >> 4;
+  {  // stage the row tile (coalesced float4) and ||x||^2
+    const int row = tid >> 4, part = tid & 15;   // 16 threads per row, 2 float4 each (E = 128)
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int c = 4 * (part + 16 * j);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) v = *reinterpret_cast<const float4*>(flat + (int64_t)(r0 + row) * E + c);
+      *reinterpret_cast<float4*>(Xs + row * ldx + c) = v;
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = reduce16(s);
+    if (part == 0) xx[row] = s;
+  }
+  __syncthreads();
+  float4 xb[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xs + i * ldx + 16 * s + 4 * q);
+  const float xr = xx[i];
+  float bd = INFINITY;
+  int bk = 0x7fffffff;
+  const int npair = K >> 7;   // tiles of this wave: kt = wave + 4 j ; pairs (j, j+1)  -> K / 16 / 4 / 2
+  auto load_pair = [&](int p, float4 (&w0)[KS], float4 (&w1)[KS], float4& q0, float4& q1) {
+    const int kt0 = wave + 8 * p, kt1 = kt0 + 4;
+    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      w0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
+      w1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+    }
+    q0 = *reinterpret_cast<const float4*>(wsq + 16 * kt0 + 4 * q);
+    q1 = *reinterpret_cast<const float4*>(wsq + 16 * kt1 + 4 * q);
+  };
+  float4 wa0[KS], wa1[KS], wb0[KS], wb1[KS], qa0, qa1, qb0, qb1;
+  load_pair(0, wa0, wa1, qa0, qa1);
+  auto consume = [&](int p, const float4 (&w0)[KS], const float4 (&w1)[KS], const float4& q0, const float4& q1) {
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      a0 = mfma16(w0[s].x, xb[s].x, a0); a1 = mfma16(w1[s].x, xb[s].x, a1);
+      a0 = mfma16(w0[s].y, xb[s].y, a0); a1 = mfma16(w1[s].y, xb[s].y, a1);
+      a0 = mfma16(w0[s].z, xb[s].z, a0); a1 = mfma16(w1[s].z, xb[s].z, a1);
+      a0 = mfma16(w0[s].w, xb[s].w, a0); a1 = mfma16(w1[s].w, xb[s].w, a1);
+    }
+    const int c0 = 16 * (wave + 8 * p) + 4 * q, c1 = c0 + 64;
+    const float s0[4] = {q0.x, q0.y, q0.z, q0.w}, s1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {      // codes in increasing order within the lane: strict '<' keeps the lowest index
+      const float d = (xr + s0[r]) - 2.0f * a0[r];
+      if (d < bd) { bd = d; bk = c0 + r; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = (xr + s1[r]) - 2.0f * a1[r];
+      if (d < bd) { bd = d; bk = c1 + r; }
+    }
+  };
+  for (int p = 0; p < npair; p += 2) {
+    if (p + 1 < npair) load_pair(p + 1, wb0, wb1, qb0, qb1);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(p, wa0, wa1, qa0, qa1);
+    if (p + 1 < npair) {
+      if (p + 2 < npair) load_pair(p + 2, wa0, wa1, qa0, qa1);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(p + 1, wb0, wb1, qb0, qb1);
+    }
+  }
+  {
+    float d2 = __shfl_xor(bd, 16);
+    int k2 = __shfl_xor(bk, 16);
+    argmin_merge(bd, bk, d2, k2);
+    d2 = __shfl_xor(bd, 32);
+    k2 = __shfl_xor(bk, 32);
+    argmin_merge(bd, bk, d2, k2);
+  }
+  if (lane < 16) {
+    wbest_d[wave * 16 + lane] = bd;
+    wbest_k[wave * 16 + lane] = bk;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float d = wbest_d[tid];
+    int k = wbest_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) argmin_merge(d, k, wbest_d[w * 16 + tid], wbest_k[w * 16 + tid]);
+    best_k[tid] = k;
+    if (tid < nrows) {
+      idx_out[r0 + tid] = (int64_t)k;
+      if (dist_min) dist_min[r0 + tid] = d;
+    }
+  }
+  __syncthreads();
+  if (quant) {
+    const int row = tid >> 4, part = tid & 15;
+    float sse = 0.f;
+    if (row < nrows) {
+      const float* wq = W + (int64_t)best_k[row] * E;
+      const float* zr = z + (int64_t)(r0 + row) * E;
+      float* qo = quant + (int64_t)(r0 + row) * E;
+#pragma unroll
+      for (int j = 0; j < E / 64; ++j) {
+        const int c = 4 * (part + 16 * j);
+        const float4 zv = *reinterpret_cast<const float4*>(zr + c), wv = *reinterpret_cast<const float4*>(wq + c);
+        const float4 df = make_float4(wv.x - zv.x, wv.y - zv.y, wv.z - zv.z, wv.w - zv.w);
+        *reinterpret_cast<float4*>(qo + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);   // :1292
+        sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// Row-tiled variant: RT row tiles (16*RT rows) per workgroup.  Every codebook fragment a wave pulls from L2 now feeds
+// RT MFMAs (one per row tile) instead of one, so the L2 traffic of the codebook stream drops RT-fold.  At N = 4096
+// the 16-rows-per-workgroup kernel above is L2-bandwidth-bound (256 workgroups x 256 KB = 64 MB per launch); RT = 2
+// halves that at the price of filling only half the CUs; for bulk assignment (N >= 16384) RT = 4 is MFMA-bound.
+template <int E, int RT>
+__global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restrict__ flat, const float* __restrict__ z,
+                                                           const float* __restrict__ W, const float* __restrict__ wsq,
+                                                           int64_t* __restrict__ idx_out, float* __restrict__ quant,
+                                                           float* __restrict__ dist_min, float* __restrict__ sse_partial,
+                                                           int N, int K) {
+  constexpr int KS = E / 16, ldx = E + 4, ROWS = 16 * RT;
+  __shared__ __attribute__((aligned(16))) float Xs[ROWS * ldx];
+  __shared__ float xx[ROWS];
+  __shared__ float wbest_d[4 * ROWS];
+  __shared__ int wbest_k[4 * ROWS];
+  __shared__ int best_k[ROWS];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * ROWS;
+  const int nrows = min(ROWS, N - r0);
+  const int i = lane & 15, q = lane >> 4;
+  for (int e = tid; e < ROWS * (E / 4); e += 256) {     // coalesced float4 staging
+    const int row = e / (E / 4), c = 4 * (e - row * (E / 4));
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nrows) v = *reinterpret_cast<const float4*>(flat + (int64_t)(r0 + row) * E + c);
+    *reinterpret_cast<float4*>(Xs + row * ldx + c) = v;
+  }
+  __syncthreads();
+  for (int row = tid >> 4; row < ROWS; row += 16) {     // ||x||^2: 16 threads per row
+    const int part = tid & 15;
+    float s = 0.f;
+    for (int k = part; k < E; k += 16) s += Xs[row * ldx + k] * Xs[row * ldx + k];
+    s = reduce16(s);
+    if (part == 0) xx[row] = s;
+  }
+  __syncthreads();
+  float xr[RT], bd[RT];
+  int bk[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { xr[t] = xx[16 * t + i]; bd[t] = INFINITY; bk[t] = 0x7fffffff; }
+  const int ntw = K >> 6;     // code tiles of this wave: kt = wave + 4 j
+  auto load_tile = [&](int j, float4 (&w)[KS], float4& sq) {
+    const int kt = wave + 4 * j;
+    const float* rp = W + (int64_t)(16 * kt + i) * E + 4 * q;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) w[s] = *reinterpret_cast<const float4*>(rp + 16 * s);
+    sq = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
+  };
+  auto consume = [&](int j, const float4 (&w)[KS], const float4& sq) {
+    f32x4 acc[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      float4 xb[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) xb[t] = *reinterpret_cast<const float4*>(Xs + (16 * t + i) * ldx + 16 * s + 4 * q);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].x, xb[t].x, acc[t]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].y, xb[t].y, acc[t]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].z, xb[t].z, acc[t]);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].w, xb[t].w, acc[t]);
+    }
+    const int c0 = 16 * (wave + 4 * j) + 4 * q;
+    const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
+#pragma unroll
+    for (int t = 0; t < RT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = (xr[t] + sv[r]) - 2.0f * acc[t][r];
+        if (d < bd[t]) { bd[t] = d; bk[t] = c0 + r; }
+      }
+  };
+  float4 wa[KS], wb[KS], qa, qb;
+  load_tile(0, wa, qa);
+  for (int j = 0; j < ntw; j += 2) {
+    if (j + 1 < ntw) load_tile(j + 1, wb, qb);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(j, wa, qa);
+    if (j + 1 < ntw) {
+      if (j + 2 < ntw) load_tile(j + 2, wa, qa);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(j + 1, wb, qb);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    float d2 = __shfl_xor(bd[t], 16);
+    int k2 = __shfl_xor(bk[t], 16);
+    argmin_merge(bd[t], bk[t], d2, k2);
+    d2 = __shfl_xor(bd[t], 32);
+    k2 = __shfl_xor(bk[t], 32);
+    argmin_merge(bd[t], bk[t], d2, k2);
+    if (lane < 16) {
+      wbest_d[wave * ROWS + 16 * t + lane] = bd[t];
+      wbest_k[wave * ROWS + 16 * t + lane] = bk[t];
+    }
+  }
+  __syncthreads();
+  if (tid < ROWS) {
+    float d = wbest_d[tid];
+    int k = wbest_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) argmin_merge(d, k, wbest_d[w * ROWS + tid], wbest_k[w * ROWS + tid]);
+    best_k[tid] = k;
+    if (tid < nrows) {
+      idx_out[r0 + tid] = (int64_t)k;
+      if (dist_min) dist_min[r0 + tid] = d;
+    }
+  }
+  __syncthreads();
+  if (quant) {
+    float sse = 0.f;
+    for (int e = tid; e < ROWS * (E / 4); e += 256) {
+      const int row = e / (E / 4), c = 4 * (e - row * (E / 4));
+      if (row < nrows) {
+        const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + row) * E + c);
+        const float4 wv = *reinterpret_cast<const float4*>(W + (int64_t)best_k[row] * E + c);
+        const float4 df = make_float4(wv.x - zv.x, wv.y - zv.y, wv.z - zv.z, wv.w - zv.w);
+        *reinterpret_cast<float4*>(quant + (int64_t)(r0 + row) * E + c) =
+            make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);   // :1292
+        sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
       }
     }
     sse = wave_sum(sse);
@@ -293,6 +568,9 @@ __global__ void vq_bwd_kernel(const float* __restrict__ gq, const float* __restr
 
 using namespace g2v;
 
+// rows per workgroup: 16 (fill the chip; the codebook stream is then L2-bound), 64 for bulk assignment (MFMA-bound)
+static int vq_rows_per_block(int N) { return N >= 16384 ? 64 : 16; }   // measured: 32 rows at N = 4096 is slower (18.8 vs 13.7 us)
+// upper bound on the number of SSE partials any path writes for N rows (callers size sse_partial with it)
 extern "C" int g2v_vq_assign_blocks(int N) { return N > 0 ? cdiv(N, VQ_ROWS) : 0; }
 
 extern "C" int g2v_vq_code_sqnorm(const float* codebook, float* code_sqnorm, int K, int E, g2v_stream_t stream) {
@@ -310,6 +588,25 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
   G2V_REQUIRE(flat && codebook && code_sqnorm && idx, "null pointer");
   G2V_REQUIRE(!quantized || z, "z required with quantized");
   G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (E == 128 && (K & 127) == 0 && ptr_aligned16(flat) && ptr_aligned16(codebook) && ptr_aligned16(code_sqnorm) &&
+      (!quantized || (ptr_aligned16(z) && ptr_aligned16(quantized)))) {
+    const int rows = vq_rows_per_block(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (sse_partial && rows > VQ_ROWS) {   // fewer, larger blocks leave the tail of the partial array untouched: zero it
+      (void)hipMemsetAsync(sse_partial, 0, sizeof(float) * (size_t)cdiv(N, VQ_ROWS), st);
+    }
+    if (rows == 64)
+      hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, z, codebook,
+                         code_sqnorm, idx, quantized, dist_min, sse_partial, N, K);
+    else if (rows == 32)
+      hipLaunchKernelGGL((vq_assign_rt_kernel<128, 2>), dim3(cdiv(N, 32)), dim3(256), 0, st, flat, z, codebook,
+                         code_sqnorm, idx, quantized, dist_min, sse_partial, N, K);
+    else
+      hipLaunchKernelGGL(vq_assign_fast_kernel<128>, dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, st, flat, z, codebook,
+                         code_sqnorm, idx, quantized, dist_min, sse_partial, N, K);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   const int Ep = (E + 15) & ~15;
   const size_t lds = (size_t)(VQ_ROWS * (Ep + 4) + 16 + 64 + 64 + 16 + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "embedding dim too large for LDS");
