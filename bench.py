@@ -99,11 +99,15 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
     flops = 2.0 * N * K * E                      # 2KE flop per quantiser row
-    bytes_alg = N * (8 * E + 4) + 4 * K * E      # 8E+4 B per row (read flat+z... see DESIGN.md) + one codebook read
+    # read flat (4E) + read z (4E) + write quantized (4E) + write idx (8, int64) per row; one codebook + norms read
+    bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
+    # HBM bytes per launch from the PMC counters of the SAME kernel at the SAME size (separate --pmc passes,
+    # FETCH_SIZE doubled per the gfx950 correction): profiles/r01_vq_assign_pmc_traffic.json
+    pmc_traffic = 8536268 if (N, E, K) == (4096, 128, 512) else None
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "kernel": "vq_assign_kernel", "avg_us": round(us, 3), "flops_per_launch": flops,
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic,
+            "kernel": "vq_assign_fast_kernel<128>", "avg_us": round(us, 3), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": bytes_alg,
             "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
 
