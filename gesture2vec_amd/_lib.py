@@ -77,11 +77,15 @@ _SIGS = {
                                     c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_custom_loss_blocks": (c_int, [c_int, c_int]),
     "g2v_custom_loss_fwd_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_int, c_int, c_int, c_fp]),
+    "g2v_vq_codebook_grad": (c_int, [c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_mse_blocks": (c_int, [c_i64]),
+    "g2v_mse_fwd_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
     "g2v_adam_blocks": (c_int, [c_i64]),
     "g2v_clip_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),
     "g2v_keep_mask": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_fp]),
     "g2v_fill_f32": (c_int, [c_fp, c_f, c_i64, c_fp]),
     "g2v_scale_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp]),
+    "g2v_mask_mul": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_i64, c_fp]),
     "g2v_transpose": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_add_halves": (c_int, [c_fp, c_i64, c_fp, c_i64, c_fp, c_i64, c_i64, c_int, c_fp]),
 }

@@ -93,6 +93,32 @@ __global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, i
   }
 }
 
+// ---- MSE (DAE reconstruction loss, train_eval/train_seq2seq.py:208-222) -----------------------------------------
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ y, const float* __restrict__ t,
+                                                  float* __restrict__ dy, float* __restrict__ partial, int64_t n,
+                                                  float gcoef) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float d = y[e] - t[e];
+    s += d * d;
+    if (dy) dy[e] = gcoef * d;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ void mse_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ out, float inv_n) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < nblk; k += 256) s += partial[k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
 // ---- clip_grad_norm_ + Adam -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
                                                     int32_t* __restrict__ step_counter) {
@@ -183,6 +209,14 @@ __global__ void scale_kernel(const float* __restrict__ in, const float* __restri
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) out[e] = in[e] * f;
 }
 
+__global__ void mask_mul_kernel(const float* __restrict__ in, const uint8_t* __restrict__ keep,
+                                const float* __restrict__ pos_of, float scale, float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const bool on = keep ? (keep[e] != 0) : (pos_of[e] > 0.f);
+    out[e] = on ? in[e] * scale : 0.f;
+  }
+}
+
 __global__ void add_halves_kernel(const float* __restrict__ a, int64_t lda, const float* __restrict__ b, int64_t ldb,
                                   float* __restrict__ out, int64_t ldo, int64_t M, int H) {
   const int64_t total = M * H;
@@ -222,6 +256,25 @@ extern "C" int g2v_custom_loss_fwd_bwd(const float* y, const float* target, floa
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(custom_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, terms, c1,
                      c2, c3, 1.0f / n);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_mse_blocks(int64_t n) {
+  if (n <= 0) return 0;
+  int64_t b = (n + 1023) / 1024;
+  return (int)(b > 1024 ? 1024 : b);
+}
+
+extern "C" int g2v_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss, float* partial, int64_t n,
+                               float g_scale, g2v_stream_t stream) {
+  G2V_REQUIRE(y && target && loss && partial, "null pointer");
+  G2V_REQUIRE(n > 0, "bad size");
+  const int nblk = g2v_mse_blocks(n);
+  hipLaunchKernelGGL(mse_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, n,
+                     2.0f * g_scale / (float)n);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, loss, 1.0f / (float)n);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -275,6 +328,17 @@ extern "C" int g2v_scale_f32(const float* in, const float* scalar, float* out, i
   int blocks = cdiv(n, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, scalar, out, n);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_mask_mul(const float* in, const uint8_t* keep, const float* positive_of, float scale, float* out,
+                            int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(in && out && (keep || positive_of), "null pointer");
+  if (n <= 0) return G2V_OK;
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(mask_mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, keep, positive_of, scale, out, n);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

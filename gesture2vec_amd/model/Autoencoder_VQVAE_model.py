@@ -166,12 +166,13 @@ class VQ_Payam_EMA(nn.Module):
 
 class _VQFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, inputs, mod: VQ_Payam_EMA):
+    def forward(ctx, inputs, mod, use_pre=True):
         E, K = mod._embedding_dim, mod._num_embeddings
         z = inputs.contiguous().view(-1, E)
         N = z.shape[0]
         W = mod._embedding.weight.data
-        flat = ops.linear_fwd(z, mod.pre_linear.weight.data, mod.pre_linear.bias.data)
+        # VQ_Payam_EMA measures distances on pre_linear(z) but takes loss / straight-through on the raw z (:1230,1285)
+        flat = ops.linear_fwd(z, mod.pre_linear.weight.data, mod.pre_linear.bias.data) if use_pre else z
         wsq = ops.vq_code_sqnorm(W)
         idx, quant, _, sse = ops.vq_assign(flat, z, W, wsq)
         stats = ops.vq_stats(idx, flat, K)
@@ -191,7 +192,7 @@ class _VQFn(torch.autograd.Function):
         gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
         gq = g_quant.contiguous().view(z.shape) if g_quant is not None else None
         gz = ops.vq_bwd(gq, gl, z, quant, None, ctx.beta)
-        return gz.view(ctx.shape), None
+        return gz.view(ctx.shape), None, None
 
 
 class Autoencoder_VQVAE(nn.Module):
@@ -323,6 +324,83 @@ class _VQVAEFn(torch.autograd.Function):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
         return None, None, None, None
+
+
+class VectorQuantizerEMA(nn.Module):
+    """The EMA quantiser variant of reference :1713-1812 (unused by the reference's model): input (2,B,H) is
+    hstack-ed per sample to (B,2H), `pre_lin` is applied IN the graph (it does receive gradients), loss and
+    straight-through use the projected input, output is the row-major reinterpretation `reshape(q, (2, B, -1))` (:1810)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float, decay: float, epsilon: float = 1e-5):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self.pre_lin = nn.Linear(embedding_dim, embedding_dim)
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.normal_()
+        self._commitment_cost = commitment_cost
+        self.register_buffer("_ema_cluster_size", torch.zeros(num_embeddings))
+        self._ema_w = nn.Parameter(torch.Tensor(num_embeddings, embedding_dim))
+        self._ema_w.data.normal_()
+        self._decay, self._epsilon = decay, epsilon
+        for p in (self._ema_w, self._embedding.weight):
+            p.requires_grad_(False)
+
+    def forward(self, inputs: torch.Tensor):
+        from .. import functional as Fn
+        x = torch.hstack((inputs[0], inputs[1]))                       # layout only (:1751)
+        zp = Fn.linear(x, self.pre_lin.weight, self.pre_lin.bias)      # in-graph projection (:1754)
+        loss, quant, perp, enc = _VQFn.apply(zp, self, False)
+        return loss, torch.reshape(quant, (2, quant.shape[0], -1)).contiguous(), perp, enc
+
+
+class VQ_Payam(nn.Module):
+    """Non-EMA quantiser of reference :1088-1179: no pre_linear in the path, loss = q_latent + beta * e_latent,
+    the codebook learns by gradient."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self.pre_linear = nn.Linear(embedding_dim, embedding_dim)      # present in the state_dict, unused (:1099,1123)
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.normal_()                           # :1104
+        self._commitment_cost = commitment_cost
+
+    def embedding_grad(self, what: bool) -> None:
+        for p in self._embedding.parameters():
+            p.requires_grad = what
+
+    def forward(self, inputs: torch.Tensor):
+        return _VQPlainFn.apply(inputs, self._embedding.weight, self)
+
+
+class _VQPlainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inputs, weight, mod):
+        E, K = mod._embedding_dim, mod._num_embeddings
+        z = inputs.contiguous().view(-1, E)
+        N = z.shape[0]
+        W = weight.data.contiguous()
+        wsq = ops.vq_code_sqnorm(W)
+        idx, quant, _, sse = ops.vq_assign(z, z, W, wsq)
+        stats = ops.vq_stats(idx, z, K)
+        beta = mod._commitment_cost
+        scalars = ops.vq_ema_update(stats, sse, None, None, None, None, N, N, E, K, 1.0 + beta, 0.0, 0.0, False)
+        encodings = torch.zeros((N, K), dtype=torch.float32, device=z.device)
+        encodings.scatter_(1, idx.unsqueeze(1), 1.0)
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(z, quant, stats, W)
+        ctx.beta, ctx.shape, ctx.N = beta, inputs.shape, N
+        ctx.mark_non_differentiable(encodings)
+        return scalars[0].clone(), quant.view(inputs.shape), scalars[1].clone(), encodings
+
+    @staticmethod
+    def backward(ctx, g_loss, g_quant, g_perp, g_enc):
+        z, quant, stats, W = ctx.saved_tensors
+        gl = g_loss.reshape(1).contiguous() if g_loss is not None else None
+        gq = g_quant.contiguous().view(z.shape) if g_quant is not None else None
+        gz = ops.vq_bwd(gq, gl, z, quant, None, ctx.beta)              # e_latent term + straight-through (:1158,1166)
+        gw = ops.vq_codebook_grad(stats, W, gl, ctx.N) if gl is not None else None      # q_latent term (:1159)
+        return gz.view(ctx.shape), gw, None
 
 
 # ---- names the reference also exports but that are outside the accelerated hot path -------------------------------

@@ -298,3 +298,31 @@ def scale(inp, scalar_dev, out=None):
         out = torch.empty_like(inp)
     check(_lib_().g2v_scale_f32(_p(_chk(inp)), _p(scalar_dev), _p(out), inp.numel(), _stream()), "scale")
     return out
+
+
+def mse_fwd_bwd(y, target, want_grad=True, g_scale=1.0):
+    lib = _lib_()
+    n = y.numel()
+    dy = torch.empty_like(y) if want_grad else None
+    loss = torch.empty((1,), dtype=torch.float32, device=y.device)
+    partial = torch.empty((lib.g2v_mse_blocks(n),), dtype=torch.float32, device=y.device)
+    check(lib.g2v_mse_fwd_bwd(_p(_chk(y)), _p(_chk(target)), _p(dy), _p(loss), _p(partial), n, float(g_scale), _stream()),
+          "mse_fwd_bwd")
+    return loss, dy
+
+
+def vq_codebook_grad(stats, codebook, g_loss, N):
+    K, E = codebook.shape
+    out = torch.empty_like(codebook)
+    check(_lib_().g2v_vq_codebook_grad(_p(stats), _p(_chk(codebook)), _p(g_loss), _p(out), N, E, K, _stream()),
+          "vq_codebook_grad")
+    return out
+
+
+def mask_mul(inp, mask, scale=1.0, positive_of=False):
+    """out = inp * scale where the mask is on (uint8 keep mask, or `mask > 0` for a float tensor when positive_of)."""
+    out = torch.empty_like(inp)
+    keep = None if positive_of else mask
+    pos = mask if positive_of else None
+    check(_lib_().g2v_mask_mul(_p(_chk(inp)), _p(keep), _p(pos), float(scale), _p(out), inp.numel(), _stream()), "mask_mul")
+    return out

@@ -86,3 +86,20 @@ def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tenso
     loss.backward()
     optim.step()            # clip_grad_norm_(net.parameters(), 5) is fused into the step
     return {"loss": loss.item()}, perplexity_vq.detach()
+
+
+def train_iter_DAE(args, epoch: int, noisy_poses: torch.Tensor, target_poses: torch.Tensor, net: torch.nn.Module, optim):
+    """One training iteration of the Part-a frame DAE (reference :161-241, autoencoder_vq/vae == "False"):
+    MSE(outputs, target) -> backward -> clip_grad_norm_(5) + Adam (fused in `optim`, a gesture2vec_amd.flat.FlatClipAdam)."""
+    from ..flat import FlatClipAdam
+    from ..functional import mse_loss
+    if not isinstance(optim, FlatClipAdam):
+        raise TypeError("use gesture2vec_amd.flat.FlatClipAdam (clip + Adam are one fused HIP launch)")
+    if getattr(args, "autoencoder_vq", "False") == "True" or getattr(args, "autoencoder_vae", "False") == "True":
+        raise NotImplementedError("VQ_Frame / VAE_Network variants of Part a are outside the accelerated hot path")
+    optim.zero_grad()
+    outputs = net(noisy_poses)
+    loss = mse_loss(outputs, target_poses)
+    loss.backward()
+    optim.step()
+    return {"loss": loss.item()}

@@ -117,6 +117,12 @@ int g2v_vq_ema_update(const float* stats, const float* sse_partial, int n_sse_pa
 int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const float* z, const float* codebook,
                const int64_t* idx, float* gz, int N, int E, float beta, g2v_stream_t stream);
 
+/* Codebook gradient of the NON-EMA quantiser VQ_Payam (:1114-1173, loss = q_latent + beta*e_latent):
+ *   g_codebook[k,:] = g_loss * 2/(N*E) * (cnt[k]*W[k,:] - sum_{i: idx[i]=k} z[i,:])
+ * with `stats` = g2v_vq_stats(idx, z).  The gradient wrt z is g2v_vq_bwd (e_latent term only, :1158-1159). */
+int g2v_vq_codebook_grad(const float* stats, const float* codebook, const float* g_loss, float* g_codebook,
+                         int N, int E, int K, g2v_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Full-sequence GRU direction (K8, K12).  Replaces one direction of one layer of
  * nn.GRU in EncoderRNN (model/Autoencoder_VQVAE_model.py:94, model/text2embedding_model.py:131).
@@ -229,6 +235,12 @@ int g2v_custom_loss_fwd_bwd(const float* y, const float* target, float* dy, floa
                             float w_l1, float w_cont, float w_var, float g_scale,
                             int T, int B, int D, g2v_stream_t stream);
 
+/* MSE loss + gradient (train_iter_DAE, train_eval/train_seq2seq.py:208-222): loss[0] = mean((y-t)^2),
+ * dy = g_scale * 2 (y-t)/n (dy may be NULL).  partial: >= g2v_mse_blocks(n) floats. */
+int g2v_mse_blocks(int64_t n);
+int g2v_mse_fwd_bwd(const float* y, const float* target, float* dy, float* loss, float* partial, int64_t n,
+                    float g_scale, g2v_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused clip_grad_norm_(5) + Adam over one flat parameter buffer (K11),
  * train_eval/train_seq2seq.py:743-744, train_autoencoder_VQVAE.py:193-195.
@@ -255,6 +267,10 @@ int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int6
 int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream);
 /* out[i] = in[i] * scalar[0]   (scalar is a DEVICE float: chains an upstream autograd scalar without a host sync) */
 int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g2v_stream_t stream);
+/* out[i] = on(i) ? in[i]*scale : 0, on(i) = keep[i] != 0 (uint8 mask) or, when keep is NULL, positive_of[i] > 0
+ * (dropout / ReLU backward of the thin dense models). */
+int g2v_mask_mul(const float* in, const uint8_t* keep, const float* positive_of, float scale, float* out,
+                 int64_t n, g2v_stream_t stream);
 int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream); /* out[c][r] = in[r][c] */
 /* out[m, 0:H] = a[m, 0:H] + b[m, 0:H] with row strides (sum of the two GRU directions, :95-97) */
 int g2v_add_halves(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,

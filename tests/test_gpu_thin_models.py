@@ -1,0 +1,123 @@
+"""GPU parity of the thin models against the reference's golden vectors: DAE_Network + train_iter_DAE (a17),
+VQ_Payam_EMA standalone, VQ_Payam (non-EMA) and VectorQuantizerEMA (a5, a7, a8)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+
+
+def state_from(fx, prefix):
+    return {k[len(prefix):]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith(prefix)}
+
+
+def test_dae_matches_reference_golden(golden_dir):
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.DAE_model import DAE_Network
+    from gesture2vec_amd.train_eval.train_seq2seq import train_iter_DAE
+    fx = np.load(os.path.join(golden_dir, "dae.npz"))
+    net = DAE_Network(135, 40)
+    net.load_state_dict(state_from(fx, "w0/"), strict=True)
+    net = net.to(DEV)
+    net.train(True)
+    optim = FlatClipAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    args = argparse.Namespace(autoencoder_vq="False", autoencoder_vae="False")
+    x = torch.from_numpy(fx["x"].copy()).to(DEV)
+    for step in (1, 2):
+        net.set_dropout_mask(torch.from_numpy(fx[f"s{step}/mask"].copy()).to(DEV))
+        loss = train_iter_DAE(args, 1, x, x, net, optim)
+        assert abs(loss["loss"] - float(fx[f"s{step}/loss"])) <= 2e-6 * float(fx[f"s{step}/loss"])
+        if step == 1:
+            for n, p in net.named_parameters():
+                assert relerr(p.grad, fx[f"s1/grad/{n}"]) < 1e-4, n
+    for n, v in net.state_dict().items():
+        assert relerr(v, fx["wN/" + n]) < 1e-5, n
+    net.train(False)
+    with torch.no_grad():
+        out, lat = net(x, get_latent=True)
+        enc_only = net.encode(x.squeeze())
+    assert relerr(out, fx["eval/out"]) < 1e-5 and relerr(lat, fx["eval/latent"]) < 1e-5
+    assert relerr(enc_only, fx["eval/enc_only"]) < 1e-5
+    assert DAE_Network(135, -1)(x) is x            # ablation sentinel: identity (:52-55)
+
+
+def test_vq_payam_ema_module_matches_reference_golden(golden_dir):
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import VQ_Payam_EMA
+    fx = np.load(os.path.join(golden_dir, "vq_layers.npz"))
+    q = VQ_Payam_EMA(512, 128, 0.25, 0.85)
+    q.load_state_dict(state_from(fx, "ema/w0/"), strict=True)
+    q = q.to(DEV)
+    q.train(True)
+    for i, zk in ((1, "z1"), (2, "z2")):
+        z = torch.from_numpy(fx[zk].copy()).to(DEV).requires_grad_(True)
+        loss, quant, perp, enc = q(z)
+        safe = fx[f"ema/c{i}/gap"] > 1e-4
+        assert np.array_equal(enc.argmax(1).cpu().numpy()[safe], fx[f"ema/c{i}/idx"][safe])
+        assert enc.shape == (256, 512) and float(enc.sum()) == 256
+        assert abs(float(loss) - float(fx[f"ema/c{i}/loss"])) <= 1e-5 * float(fx[f"ema/c{i}/loss"])
+        assert abs(float(perp) - float(fx[f"ema/c{i}/perplexity"])) <= 1e-4 * float(fx[f"ema/c{i}/perplexity"])
+        assert relerr(quant, fx[f"ema/c{i}/quantized"]) < 1e-5
+        gq = torch.from_numpy(fx[f"ema/c{i}/gq"].copy()).to(DEV)
+        (g1,) = torch.autograd.grad((quant * gq).sum(), z, retain_graph=True)
+        (g2,) = torch.autograd.grad(loss, z)
+        assert relerr(g1, fx[f"ema/c{i}/gz_from_q"]) < 1e-6
+        assert relerr(g2, fx[f"ema/c{i}/gz_from_loss"]) < 1e-5
+        sd = q.state_dict()
+        for k in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
+            assert relerr(sd[k], fx[f"ema/w{i}/{k}"]) < 2e-5, k
+    q.train(False)
+    with torch.no_grad():
+        loss, quant, perp, enc = q(torch.from_numpy(fx["z1"].copy()).to(DEV))
+    assert np.array_equal(enc.argmax(1).cpu().numpy(), fx["ema/eval/idx"])
+    assert relerr(quant, fx["ema/eval/quantized"]) < 1e-5
+    assert np.array_equal(q.assign(torch.from_numpy(fx["z1"].copy()).to(DEV)).cpu().numpy(), fx["ema/eval/idx"])
+
+
+def test_vq_payam_plain_matches_reference_golden(golden_dir):
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import VQ_Payam
+    fx = np.load(os.path.join(golden_dir, "vq_layers.npz"))
+    q = VQ_Payam(512, 128, 0.25)
+    q.load_state_dict(state_from(fx, "plain/w0/"), strict=True)
+    q = q.to(DEV)
+    z = torch.from_numpy(fx["z1"].copy()).to(DEV).requires_grad_(True)
+    loss, quant, perp, enc = q(z)
+    assert np.array_equal(enc.argmax(1).cpu().numpy(), fx["plain/idx"])
+    assert abs(float(loss) - float(fx["plain/loss"])) <= 1e-5 * float(fx["plain/loss"])
+    assert abs(float(perp) - float(fx["plain/perplexity"])) <= 1e-4 * float(fx["plain/perplexity"])
+    gq = torch.from_numpy(fx["plain/gq"].copy()).to(DEV)
+    ((quant * gq).sum() + loss).backward()
+    assert relerr(z.grad, fx["plain/gz"]) < 1e-5
+    assert relerr(q._embedding.weight.grad, fx["plain/g_embedding"]) < 1e-4
+
+
+def test_vector_quantizer_ema_matches_reference_golden(golden_dir):
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import VectorQuantizerEMA
+    fx = np.load(os.path.join(golden_dir, "vq_layers.npz"))
+    q = VectorQuantizerEMA(512, 128, 0.25, 0.85)
+    q.load_state_dict(state_from(fx, "vqema/w0/"), strict=True)
+    q = q.to(DEV)
+    q.train(True)
+    z = torch.from_numpy(fx["z1"].copy()).to(DEV).requires_grad_(True)
+    loss, quant, perp, enc = q(z)
+    assert quant.shape == (2, 256, 64)
+    assert np.array_equal(enc.argmax(1).cpu().numpy(), fx["vqema/idx"])
+    assert abs(float(loss) - float(fx["vqema/loss"])) <= 1e-5 * float(fx["vqema/loss"])
+    assert relerr(quant, fx["vqema/quantized"]) < 1e-5
+    gq = torch.from_numpy(fx["vqema/gq"].copy()).to(DEV)
+    ((quant * gq).sum() + loss).backward()
+    assert relerr(z.grad, fx["vqema/gz"]) < 1e-4
+    assert relerr(q.pre_lin.weight.grad, fx["vqema/grad/pre_lin.weight"]) < 1e-4
+    assert relerr(q.pre_lin.bias.grad, fx["vqema/grad/pre_lin.bias"]) < 1e-4
+    sd = q.state_dict()
+    for k in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
+        assert relerr(sd[k], fx[f"vqema/w1/{k}"]) < 2e-5, k
