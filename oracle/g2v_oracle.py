@@ -391,6 +391,90 @@ def dae_train_step(sd: Dict[str, Tensor], adam_state: dict, x: Tensor, target: T
 
 
 # ----------------------------------------------------------------------------------------------
+# Part-d text -> gesture-code seq2seq
+# ----------------------------------------------------------------------------------------------
+def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tensor, cfg: dict, training: bool,
+                masks: dict) -> Dict[str, Tensor]:
+    """text2embedding_model.forward, discrete codes, EncoderRNN path, attention off
+    (model/text2embedding_model.py:606-746; encoder :126-135; decoder step :338-395).
+
+    ids (B,Tw) int64 word ids (0 = PAD), lengths (B,) sorted descending, codes (B,S) int64 code ids.
+    cfg: n_layers, dropout_prob, n_pre_poses.  masks: 'emb' (S-1,B,H) keep mask of Dropout(0.5) on the code embedding,
+    'dec_l0' (S-1,B,H) decoder GRU inter-layer dropout (both training only).
+    Without attention the decoder reads only encoder_hidden[:L] = layer-0 final states (:667-669), so the encoder's
+    inter-layer dropout (drawn on the packed data) cannot influence any output and is not modelled.
+    Returns outputs (B,S,K) with outputs[:,0] = one_hot(codes[:,0]) (:676-677)."""
+    L, p = cfg["n_layers"], cfg["dropout_prob"]
+    x = sd["encoder.embedding.weight"][ids.t()]                                           # (Tw,B,300)  :126
+    _, enc_hidden = bigru(x, sd, "encoder.gru.", L, 0.0, None, lengths)                   # :127-131
+    hidden = enc_hidden[:L]                                                               # :667-669
+    pre = "decoder.decoder."
+    K = sd[pre + "out.weight"].shape[0]
+    bn = {"running_mean": sd[pre + "pre_linear.1.running_mean"], "running_var": sd[pre + "pre_linear.1.running_var"],
+          "num_batches_tracked": sd[pre + "pre_linear.1.num_batches_tracked"]}
+    cod = codes.t()                                                                       # (S,B)
+    S = cod.shape[0]
+    outs = [torch.nn.functional.one_hot(cod[0], K).to(x.dtype)]
+    dec_in = cod[0]
+    for t in range(1, S):                                                                 # :701-744
+        e = sd[pre + "embedding.weight"][dec_in]                                          # :340-343
+        if training:
+            e = dropout_apply(e, masks["emb"][t - 1], 0.5)                                # nn.Dropout(0.5) :253
+        u = linear(e, sd[pre + "pre_linear.0.weight"], sd[pre + "pre_linear.0.bias"])
+        a, nrm, nrv = batchnorm1d(u, sd[pre + "pre_linear.1.weight"], sd[pre + "pre_linear.1.bias"],
+                                  bn["running_mean"], bn["running_var"], training)
+        if training:
+            bn["running_mean"], bn["running_var"] = nrm, nrv
+            bn["num_batches_tracked"] = bn["num_batches_tracked"] + 1
+        a = torch.relu(a)
+        new_h, layer_in = [], a
+        for l in range(L):
+            gi = linear(layer_in, sd[pre + f"gru.weight_ih_l{l}"], sd[pre + f"gru.bias_ih_l{l}"])
+            h = gru_cell(gi, hidden[l], sd[pre + f"gru.weight_hh_l{l}"], sd[pre + f"gru.bias_hh_l{l}"])
+            new_h.append(h)
+            layer_in = h
+            if l < L - 1 and training and p > 0.0:
+                layer_in = dropout_apply(h, masks["dec_l0"][t - 1], p)
+        hidden = torch.stack(new_h)
+        logits = linear(new_h[-1], sd[pre + "out.weight"], sd[pre + "out.bias"])         # :390
+        outs.append(logits)
+        dec_in = cod[t] if t < cfg["n_pre_poses"] else logits.argmax(1)                   # :734-744
+    return {"outputs": torch.stack(outs).transpose(0, 1), "bn": bn, "encoder_hidden": enc_hidden}
+
+
+def t2e_loss(outputs: Tensor, codes: Tensor) -> Tensor:
+    """CrossEntropyLoss over decode steps 1..S-1 (train_eval/train_seq2seq.py:520-530)."""
+    K = outputs.shape[2]
+    return torch.nn.functional.cross_entropy(outputs[:, 1:, :].reshape(-1, K), codes[:, 1:].reshape(-1))
+
+
+def t2e_trainable_keys(sd: Dict[str, Tensor]) -> List[str]:
+    return [k for k in sd if "running_" not in k and "num_batches_tracked" not in k]
+
+
+def t2e_train_step(sd: Dict[str, Tensor], adam_state: dict, ids: Tensor, lengths: Tensor, codes: Tensor, masks: dict,
+                   cfg: dict) -> Dict[str, Tensor]:
+    """train_iter_text2embedding (train_eval/train_seq2seq.py:462-538): CE, clip 5, Adam(betas (0.5,0.999))."""
+    keys = t2e_trainable_keys(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(leaves)
+    fw = t2e_forward(work, ids, lengths, codes, cfg, True, masks)
+    loss = t2e_loss(fw["outputs"], codes)
+    gl = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(leaves[k])) for k, g in zip(keys, gl)}
+    raw = {k: g.clone() for k, g in grads.items()}
+    grads, gnorm = clip_grad_norm(grads, 5.0)
+    params = {k: sd[k] for k in keys}
+    adam_step(params, grads, adam_state, cfg["lr"])
+    sd.update(params)
+    pre = "decoder.decoder.pre_linear.1."
+    sd[pre + "running_mean"], sd[pre + "running_var"] = fw["bn"]["running_mean"], fw["bn"]["running_var"]
+    sd[pre + "num_batches_tracked"] = fw["bn"]["num_batches_tracked"]
+    return {"loss": loss.detach(), "outputs": fw["outputs"].detach(), "grads": raw, "grad_norm": gnorm}
+
+
+# ----------------------------------------------------------------------------------------------
 # helpers shared by tests / bench
 # ----------------------------------------------------------------------------------------------
 def unpack_mask(bits: np.ndarray, shape) -> Tensor:

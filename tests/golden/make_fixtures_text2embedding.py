@@ -1,0 +1,90 @@
+#!/usr/bin/env python3
+"""Golden vectors for Part d (text -> gesture-code seq2seq) by IMPORTING the reference (build container only).
+
+Exercises model/text2embedding_model.py::text2embedding_model (:488-746, EncoderRNN path) and
+train_eval/train_seq2seq.py::train_iter_text2embedding (:462-538).  Adjustments from outside the reference:
+`use_TCN = False` on the module before construction (as checked in, use_TCN=True makes forward crash);
+recorded / replayed dropout masks exactly as in make_fixtures.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_fixtures as mf  # noqa: E402
+
+
+def main():
+    vq, dae, ts = mf._import_reference()
+    import model.text2embedding_model as t2e
+    t2e.use_TCN = False
+    torch.set_num_threads(1)
+    for name, att, p in (("t2e_noatt", "False", 0.2),):
+        H, L, K, NW, EMB, S, Tw, B = 32, 2, 64, 120, 300, 6, 12, 16
+        args = mf.make_args(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
+                            n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True")
+        torch.manual_seed(3)
+        emb = torch.randn(NW, EMB).numpy()
+        net = t2e.text2embedding_model(args, 135, args.n_poses, NW, EMB, emb, None)
+        net.train(True)
+        g = torch.Generator().manual_seed(77)
+        lengths = torch.randint(4, Tw + 1, (B,), generator=g).sort(descending=True).values
+        lengths[0] = Tw
+        ids = torch.zeros(B, Tw, dtype=torch.int64)
+        for b in range(B):
+            ids[b, : lengths[b]] = torch.randint(4, NW, (int(lengths[b]),), generator=g)
+        codes = torch.randint(0, K, (B, S), generator=g)
+        fx = dict(mf.sd_np(net, "w0/"))
+        fx.update(ids=ids.numpy(), lengths=lengths.numpy(), codes=codes.numpy(),
+                  cfg=np.array([B, Tw, S, H, L, K, NW, EMB], dtype=np.int64), cfg_f=np.array([p, 5e-4]))
+        optim = torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.5, 0.999))
+        n_steps = 2
+        for step in range(1, n_steps + 1):
+            seed = 5000 + step
+            cap = {}
+            orig_fwd = net.forward
+
+            def spy(*a, **k):
+                out = orig_fwd(*a, **k)
+                cap["outputs"] = out[0].detach().numpy().copy()
+                return out
+
+            net.forward = spy
+            torch.manual_seed(seed)
+            with mf.MaskRecorder() as rec:
+                loss = ts.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+            net.forward = orig_fwd
+            # F.dropout order: per decode step t = 1..S-1 the Dropout(0.5) on the code embedding (1,B,H)
+            assert len(rec.masks) == S - 1
+            fx[f"s{step}/mask_emb"] = np.stack([m.reshape(B, H) for m in rec.masks])
+            # ATen-internal draws: encoder inter-layer dropout on the PACKED data (sum(lengths), 2H) first, then per
+            # step the decoder GRU's inter-layer dropout (1,B,H) after that step's embedding dropout
+            plan = [((int(lengths.sum()), 2 * H), p)]
+            for _ in range(S - 1):
+                plan += [((1, B, H), 0.5), ((1, B, H), p)]
+            rp = mf.replay_gru_masks(seed, plan)
+            for t in range(S - 1):
+                assert np.array_equal(rp[1 + 2 * t].reshape(B, H), fx[f"s{step}/mask_emb"][t]), "RNG replay misaligned"
+            fx[f"s{step}/mask_dec_l0"] = np.stack([rp[2 + 2 * t].reshape(B, H) for t in range(S - 1)])
+            fx[f"s{step}/loss"] = np.float64(loss["loss"])
+            fx[f"s{step}/outputs"] = cap["outputs"]
+            if step == 1:
+                for n_, p_ in net.named_parameters():
+                    if p_.grad is not None:
+                        fx[f"s1/grad/{n_}"] = p_.grad.detach().numpy().copy()
+                    else:
+                        fx[f"s1/gradnone/{n_}"] = np.zeros(0, dtype=np.float32)
+        fx.update(mf.sd_np(net, "wN/"))
+        net.train(False)
+        with torch.no_grad():
+            out, _ = net(ids, lengths, None, codes, None, None)
+        fx["eval/outputs"] = out.numpy().copy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
+        print(name, "losses", [float(fx[f"s{s}/loss"]) for s in (1, 2)],
+              "grad keys", sum(k.startswith("s1/grad/") for k in fx), "none", [k for k in fx if k.startswith("s1/gradnone/")])
+
+
+if __name__ == "__main__":
+    main()

@@ -179,3 +179,41 @@ def test_dae_matches_reference(golden_dir):
     np.testing.assert_allclose(out.numpy(), fx["eval/out"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lat.numpy(), fx["eval/latent"], rtol=1e-5, atol=1e-6)
     np.testing.assert_allclose(lat.numpy(), fx["eval/enc_only"], rtol=1e-5, atol=1e-6)
+
+
+def test_text2embedding_matches_reference(golden_dir):
+    """Part d (a13-a16): oracle vs the reference's train_iter_text2embedding, 2 steps + eval forward."""
+    fx = load(golden_dir, "t2e_noatt")
+    B, Tw, S, H, L, K, NW, EMB = [int(v) for v in fx["cfg"]]
+    p, lr = [float(v) for v in fx["cfg_f"]]
+    cfg = dict(n_layers=L, dropout_prob=p, n_pre_poses=1, lr=lr)
+    sd = state_from(fx, "w0/")
+    ids, lengths, codes = (torch.from_numpy(fx[k].copy()) for k in ("ids", "lengths", "codes"))
+    adam = {}
+    for step in (1, 2):
+        masks = {"emb": torch.from_numpy(fx[f"s{step}/mask_emb"].copy()), "dec_l0": torch.from_numpy(fx[f"s{step}/mask_dec_l0"].copy())}
+        r = O.t2e_train_step(sd, adam, ids, lengths, codes, masks, cfg)
+        np.testing.assert_allclose(float(r["loss"]), float(fx[f"s{step}/loss"]), rtol=2e-6)
+        np.testing.assert_allclose(r["outputs"].numpy(), fx[f"s{step}/outputs"], rtol=1e-4, atol=2e-6)
+        if step == 1:
+            for k in fx.files:
+                if k.startswith("s1/grad/"):
+                    n = k[len("s1/grad/"):]
+                    ref = fx[k]
+                    scale = max(np.abs(ref).max(), 1e-12)
+                    if n == "decoder.decoder.pre_linear.0.bias":
+                        continue        # feeds BatchNorm: mathematically zero gradient (rounding noise on both sides)
+                    assert np.abs(r["grads"][n].numpy() - ref).max() <= 3e-4 * scale + 1e-10, n
+    for k in fx.files:
+        if k.startswith("wN/"):
+            n = k[3:]
+            ref, got = fx[k], sd[n].numpy()
+            if n in ("decoder.decoder.pre_linear.0.bias", "decoder.decoder.pre_linear.1.running_mean"):
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1.01 * 2 * lr, err_msg=n)
+            elif ref.dtype.kind == "f":
+                np.testing.assert_allclose(got, ref, rtol=1e-4, atol=0.02 * 2 * lr, err_msg=n)
+            else:
+                assert np.array_equal(got, ref), n
+    with torch.no_grad():
+        r = O.t2e_forward(sd, ids, lengths, codes, cfg, False, {})
+    np.testing.assert_allclose(r["outputs"].numpy(), fx["eval/outputs"], rtol=1e-4, atol=5e-6)
