@@ -1,0 +1,272 @@
+// seq2seq.hip -- the remaining operators of Part d (text -> gesture-code seq2seq):
+//   embedding gather / scatter-add        nn.Embedding in EncoderRNN (model/text2embedding_model.py:90-92,126) and in the
+//                                         code decoder (:252,340-343), with the decoder's nn.Dropout(0.5) fused in
+//   BatchNorm1d (+ReLU) forward/backward  decoder.pre_linear[1:] (:286-290), one call per decode step
+//   cross-entropy forward+backward        torch.nn.CrossEntropyLoss over the code logits (train_eval/train_seq2seq.py:520-530)
+//   row argmax                            greedy feedback `decoder_output.argmax(1)` (:740)
+// All HBM-bound element/row-wise kernels; the contractions of Part d run on the dense-layer and GRU kernels.
+#include "common.hpp"
+
+namespace g2v {
+
+__global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
+                                     const uint8_t* __restrict__ keep, float scale, float* __restrict__ out, int64_t n,
+                                     int dim, int64_t V) {
+  const int64_t total = n * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / dim;
+    const int c = (int)(e - r * dim);
+    const int64_t id = ids[r];
+    float v = (id >= 0 && id < V) ? table[id * dim + c] : 0.f;
+    if (keep) v = keep[e] ? v * scale : 0.f;
+    out[e] = v;
+  }
+}
+
+// d_table[ids[r], :] += d_out[r, :] * keep * scale.  Float atomics: rows hit by several tokens are summed in arrival
+// order (the only non-bitwise-reproducible kernel in the library; contention is low: one 4-byte add per element).
+__global__ void embedding_bwd_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                     const uint8_t* __restrict__ keep, float scale, float* __restrict__ d_table,
+                                     int64_t n, int dim, int64_t V) {
+  const int64_t total = n * dim;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / dim;
+    const int c = (int)(e - r * dim);
+    const int64_t id = ids[r];
+    if (id < 0 || id >= V) continue;
+    float g = d_out[e];
+    if (keep) g = keep[e] ? g * scale : 0.f;
+    if (g != 0.f) atomicAdd(d_table + id * dim + c, g);
+  }
+}
+
+// ---- BatchNorm1d over (B,H), 16 features per workgroup, 16 row lanes x 16 feature lanes -----------------------------
+__global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ b, float* __restrict__ rm,
+                                                     float* __restrict__ rv, int training, int relu,
+                                                     float* __restrict__ y, float* __restrict__ save_mean,
+                                                     float* __restrict__ save_invstd, int B, int H) {
+  __shared__ float red[16][17];
+  __shared__ float st[2][16];
+  const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + fl;
+  const bool fv = f < H;
+  float mean, invstd;
+  if (training) {
+    float s = 0.f;
+    if (fv)
+      for (int r = rl; r < B; r += 16) s += x[(int64_t)r * H + f];
+    red[rl][fl] = s;
+    __syncthreads();
+    if (rl == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += red[k][fl];
+      st[0][fl] = t / (float)B;
+    }
+    __syncthreads();
+    mean = st[0][fl];
+    float q = 0.f;
+    if (fv)
+      for (int r = rl; r < B; r += 16) {
+        const float d = x[(int64_t)r * H + f] - mean;
+        q += d * d;
+      }
+    __syncthreads();
+    red[rl][fl] = q;
+    __syncthreads();
+    if (rl == 0) {
+      float t = 0.f;
+      for (int k = 0; k < 16; ++k) t += red[k][fl];
+      const float var = t / (float)B;                      // biased: used for normalisation
+      st[1][fl] = 1.0f / sqrtf(var + 1e-5f);
+      if (fv) {
+        const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
+        rm[f] = 0.9f * rm[f] + 0.1f * mean;                // momentum 0.1, unbiased variance
+        rv[f] = 0.9f * rv[f] + 0.1f * unb;
+        if (save_mean) save_mean[f] = mean;
+        if (save_invstd) save_invstd[f] = st[1][fl];
+      }
+    }
+    __syncthreads();
+    invstd = st[1][fl];
+  } else {
+    mean = fv ? rm[f] : 0.f;
+    invstd = fv ? 1.0f / sqrtf(rv[f] + 1e-5f) : 0.f;
+  }
+  if (!fv) return;
+  const float g = w[f], bb = b[f];
+  for (int r = rl; r < B; r += 16) {
+    float v = (x[(int64_t)r * H + f] - mean) * invstd * g + bb;
+    if (relu) v = fmaxf(v, 0.f);
+    y[(int64_t)r * H + f] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ y, const float* __restrict__ w,
+                                                     const float* __restrict__ save_mean,
+                                                     const float* __restrict__ save_invstd, int relu,
+                                                     float* __restrict__ dx, float* __restrict__ dw,
+                                                     float* __restrict__ db, int B, int H) {
+  __shared__ float red1[16][17], red2[16][17];
+  __shared__ float st[2][16];
+  const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int f = blockIdx.x * 16 + fl;
+  const bool fv = f < H;
+  const float mean = fv ? save_mean[f] : 0.f, invstd = fv ? save_invstd[f] : 0.f;
+  float s1 = 0.f, s2 = 0.f;
+  if (fv)
+    for (int r = rl; r < B; r += 16) {
+      const int64_t e = (int64_t)r * H + f;
+      float g = dy[e];
+      if (relu && !(y[e] > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * ((x[e] - mean) * invstd);
+    }
+  red1[rl][fl] = s1;
+  red2[rl][fl] = s2;
+  __syncthreads();
+  if (rl == 0) {
+    float a = 0.f, c = 0.f;
+    for (int k = 0; k < 16; ++k) { a += red1[k][fl]; c += red2[k][fl]; }
+    st[0][fl] = a;
+    st[1][fl] = c;
+    if (fv) { db[f] = a; dw[f] = c; }
+  }
+  __syncthreads();
+  if (!fv) return;
+  const float S1 = st[0][fl], S2 = st[1][fl], g0 = w[f] * invstd, invB = 1.0f / (float)B;
+  for (int r = rl; r < B; r += 16) {
+    const int64_t e = (int64_t)r * H + f;
+    float g = dy[e];
+    if (relu && !(y[e] > 0.f)) g = 0.f;
+    const float xhat = (x[e] - mean) * invstd;
+    dx[e] = g0 * (g - S1 * invB - xhat * S2 * invB);
+  }
+}
+
+// ---- cross entropy: one wave per row ----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ tgt,
+                                                 float* __restrict__ row_loss, float* __restrict__ dlogits, int64_t ldd,
+                                                 int M, int K, float gcoef) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* z = logits + (int64_t)row * ld;
+  float mx = -INFINITY;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, z[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s += expf(z[k] - mx);
+  s = wave_sum(s);
+  const float lse = mx + logf(s);
+  const int t = (int)tgt[row];
+  if (lane == 0) row_loss[row] = lse - z[t];
+  if (dlogits) {
+    float* d = dlogits + (int64_t)row * ldd;
+    for (int k = lane; k < K; k += 64) d[k] = gcoef * (expf(z[k] - lse) - (k == t ? 1.0f : 0.0f));
+  }
+}
+__global__ void mean_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) s += v[k];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ld, int64_t* __restrict__ out,
+                                                          int M, int K) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (row >= M) return;
+  const float* z = x + (int64_t)row * ld;
+  float bv = -INFINITY;
+  int bk = 0x7fffffff;
+  for (int k = lane; k < K; k += 64) {
+    const float v = z[k];
+    if (v > bv) { bv = v; bk = k; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_xor(bv, o);
+    const int k2 = __shfl_xor(bk, o);
+    if (v2 > bv || (v2 == bv && k2 < bk)) { bv = v2; bk = k2; }
+  }
+  if (lane == 0) out[row] = (int64_t)bk;
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+static int blocks_for(int64_t n) {
+  int b = cdiv(n, 256);
+  return b > 4096 ? 4096 : (b < 1 ? 1 : b);
+}
+
+extern "C" int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out,
+                                 int64_t n, int dim, int64_t V, g2v_stream_t stream) {
+  G2V_REQUIRE(table && ids && out, "null pointer");
+  G2V_REQUIRE(n > 0 && dim > 0 && V > 0, "bad size");
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, (hipStream_t)stream, table, ids, keep,
+                     scale, out, n, dim, V);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* keep, float scale, float* d_table,
+                                 int64_t n, int dim, int64_t V, int zero_first, g2v_stream_t stream) {
+  G2V_REQUIRE(d_out && ids && d_table, "null pointer");
+  G2V_REQUIRE(n > 0 && dim > 0 && V > 0, "bad size");
+  if (zero_first) (void)hipMemsetAsync(d_table, 0, sizeof(float) * (size_t)V * dim, (hipStream_t)stream);
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, (hipStream_t)stream, d_out, ids, keep,
+                     scale, d_table, n, dim, V);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_batchnorm_fwd(const float* x, const float* weight, const float* bias, float* running_mean,
+                                 float* running_var, int training, int relu, float* y, float* save_mean,
+                                 float* save_invstd, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(x && weight && bias && running_mean && running_var && y, "null pointer");
+  G2V_REQUIRE(B > 0 && H > 0, "bad size");
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(cdiv(H, 16)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean,
+                     running_var, training, relu, y, save_mean, save_invstd, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y, const float* weight,
+                                 const float* save_mean, const float* save_invstd, int relu, float* dx, float* dw,
+                                 float* db, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(dy && x && weight && save_mean && save_invstd && dx && dw && db, "null pointer");
+  G2V_REQUIRE(!relu || y, "y required for the ReLU mask");
+  G2V_REQUIRE(B > 0 && H > 0, "bad size");
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(H, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
+                     save_invstd, relu, dx, dw, db, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* targets, float* loss,
+                                         float* row_loss, float* dlogits, int64_t ldd, int M, int K, float g_scale,
+                                         g2v_stream_t stream) {
+  G2V_REQUIRE(logits && targets && loss && row_loss, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && ld >= K, "bad size");
+  hipLaunchKernelGGL(ce_kernel, dim3(cdiv((int64_t)M * 64, 256)), dim3(256), 0, (hipStream_t)stream, logits, ld, targets,
+                     row_loss, dlogits, ldd, M, K, g_scale / (float)M);
+  G2V_CHECK_LAUNCH();
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, row_loss, M, loss);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(x && out, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && ld >= K, "bad size");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(cdiv((int64_t)M * 64, 256)), dim3(256), 0, (hipStream_t)stream, x, ld, out, M, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}

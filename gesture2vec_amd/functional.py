@@ -75,3 +75,100 @@ class MseFn(torch.autograd.Function):
 
 def mse_loss(y, target):
     return MseFn.apply(y, target)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """rows = table[ids] * keep * scale (nn.Embedding + optional fused dropout); gradient = scatter-add into the table."""
+
+    @staticmethod
+    def forward(ctx, table, ids, keep, scale):
+        ids = ids.contiguous().view(-1)
+        out = ops.embedding_fwd(table.contiguous(), ids, keep, scale)
+        ctx.save_for_backward(ids, keep)
+        ctx.V, ctx.scale = table.shape[0], scale
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, keep = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
+        return ops.embedding_bwd(g.contiguous(), ids, ctx.V, keep, ctx.scale), None, None, None
+
+
+class BatchNormReluFn(torch.autograd.Function):
+    """nn.BatchNorm1d(+ReLU) on (B,H): batch statistics (and running-stat update) in training, running stats in eval."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, training, relu):
+        x = x.contiguous()
+        y, sm, si = ops.batchnorm_fwd(x, weight, bias, running_mean, running_var, training, relu)
+        if training:
+            ctx.save_for_backward(x, y, weight, sm, si)
+        ctx.training, ctx.relu = training, relu
+        ctx.set_materialize_grads(False)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if gy is None:
+            return (None,) * 7
+        if not ctx.training:
+            raise NotImplementedError("BatchNorm backward in eval mode is not used on the training path")
+        x, y, weight, sm, si = ctx.saved_tensors
+        dx, dw, db = ops.batchnorm_bwd(gy.contiguous(), x, y, weight, sm, si, ctx.relu)
+        return dx, dw, db, None, None, None, None
+
+
+class GRUDirFn(torch.autograd.Function):
+    """One direction of one GRU layer over a (T,B,.) sequence given its input projections gi = x W_ih^T + b_ih.
+    Returns (hs (T,B,H), h_n (B,H)).  `lengths` (int32, B) gives pack_padded_sequence semantics (h0 must be None)."""
+
+    @staticmethod
+    def forward(ctx, gi, w_hh, b_hh, h0, lengths, reverse):
+        T, B, G = gi.shape
+        H = G // 3
+        gi = gi.contiguous()
+        w = w_hh.contiguous()
+        hs, h_n, gates = ops.gru_seq_fwd(gi, w, b_hh, T, B, H, h0=h0.contiguous() if h0 is not None else None,
+                                         lengths=lengths, reverse=reverse, save_gates=True)
+        ctx.save_for_backward(hs, gates, w, h0 if h0 is not None else None, lengths)
+        ctx.dims, ctx.reverse, ctx.has_h0 = (T, B, H), reverse, h0 is not None
+        ctx.set_materialize_grads(False)
+        return hs, h_n
+
+    @staticmethod
+    def backward(ctx, g_hs, g_hn):
+        hs, gates, w, h0, lengths = ctx.saved_tensors
+        T, B, H = ctx.dims
+        d_hs = g_hs.contiguous() if g_hs is not None else None
+        d_hn = g_hn.contiguous() if g_hn is not None else None
+        if d_hs is None and d_hn is None:
+            return (None,) * 6
+        dgi, dgh, dh0 = ops.gru_seq_bwd(d_hs, H, d_hn, hs, H, h0, gates, w, T, B, H, lengths=lengths, reverse=ctx.reverse,
+                                        want_dh0=ctx.has_h0)
+        # h_prev sequence for the W_hh gradient (data movement only): shifted hs with the initial state at the open end
+        first = h0.unsqueeze(0) if h0 is not None else torch.zeros((1, B, H), dtype=hs.dtype, device=hs.device)
+        hprev = torch.cat([hs[1:], first], 0) if ctx.reverse else torch.cat([first, hs[:-1]], 0)
+        dw, db = ops.linear_bwd_weight(dgh, hprev.contiguous(), 3 * H, H, M=T * B)
+        return dgi, dw, db, (dh0 if ctx.has_h0 else None), None, None
+
+
+class CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        lg = logits.contiguous()
+        loss, dl = ops.cross_entropy_fwd_bwd(lg, targets.contiguous().view(-1), want_grad=True)
+        ctx.save_for_backward(dl)
+        ctx.shape = logits.shape
+        return loss[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return ops.scale(dl, g.reshape(1).contiguous()).view(ctx.shape), None
+
+
+def cross_entropy(logits, targets):
+    return CrossEntropyFn.apply(logits, targets)

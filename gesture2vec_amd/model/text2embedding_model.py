@@ -1,0 +1,204 @@
+"""Part d: text -> gesture-code seq2seq -- mirror of `scripts/model/text2embedding_model.py` (reference :46-746) on the
+MI355X kernels: `EncoderRNN` (word Embedding -> length-packed bi-GRU -> sum of directions), `BahdanauAttnDecoderRNN`
+(code Embedding + Dropout(0.5) -> Linear + BatchNorm1d + ReLU -> GRU(L) -> Linear(H->K) logits), `Generator`,
+`text2embedding_model` (S-1 decode steps with greedy argmax feedback).  Same class names, ctor/forward signatures and
+state_dict keys.  Every operator is a HIP kernel behind include/g2v.h, chained by small autograd nodes
+(gesture2vec_amd/functional.py).
+
+Module-level switches of the reference (:40-43) are all False here: `use_TCN = True` as checked in makes the
+reference's forward crash, `audio_context`, `noisy`, `GPT3_embedding_active` select out-of-scope
+encoders.  Scope this round: text2_embedding_discrete == "True", autoencoder_att == "False" (config/seq2seq.yml:27);
+the Bahdanau attention variant (seq2seqtxt.yml) raises NotImplementedError."""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import functional as Fn
+from .. import ops
+from .Autoencoder_VQVAE_model import _GRUParams
+
+debug = False
+noisy = False
+audio_context = False
+use_TCN = False
+GPT3_embedding_active = False
+
+
+class EncoderRNN(nn.Module):
+    def __init__(self, input_size: int, embed_size: int, hidden_size: int, n_layers: int = 1, dropout: float = 0.5,
+                 pre_trained_embedding: np.ndarray = None):
+        super().__init__()
+        self.input_size, self.hidden_size, self.embed_size = input_size, hidden_size, embed_size
+        self.n_layers, self.dropout = n_layers, dropout
+        if pre_trained_embedding is not None:
+            assert pre_trained_embedding.shape[0] == input_size
+            assert pre_trained_embedding.shape[1] == embed_size
+            self.embedding = nn.Embedding.from_pretrained(torch.FloatTensor(pre_trained_embedding), freeze=False)
+        else:
+            self.embedding = nn.Embedding(input_size, embed_size)
+        self.gru = _GRUParams(embed_size, hidden_size, n_layers, dropout=dropout, bidirectional=True)
+        self.do_flatten_parameters = False
+
+    def forward(self, input_seqs: torch.Tensor, input_lengths: torch.Tensor, hidden=None, n_layers_needed: Optional[int] = None):
+        """(Tw,B) ids + lengths (sorted descending) -> outputs (Tw,B,H) [sum of the LAST evaluated layer's directions],
+        hidden (2*layers_evaluated, B, H) ordered l0f,l0b,l1f,l1b.  `n_layers_needed` lets the caller skip layers whose
+        result it never reads (the attention-free decoder only needs layer 0)."""
+        if hidden is not None:
+            raise NotImplementedError("non-zero initial hidden state")
+        Tw, B = input_seqs.shape
+        H = self.hidden_size
+        L = self.n_layers if n_layers_needed is None else min(self.n_layers, n_layers_needed)
+        dev = input_seqs.device
+        lengths = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+        x = Fn.EmbeddingFn.apply(self.embedding.weight, input_seqs.contiguous().view(-1), None, 1.0)   # (Tw*B, E)
+        hiddens, layer_in = [], x
+        out_f = out_b = None
+        for l in range(L):
+            outs = []
+            for suf, rev in (("", False), ("_reverse", True)):
+                g = self.gru
+                gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"))
+                hs, h_n = Fn.GRUDirFn.apply(gi.view(Tw, B, 3 * H), getattr(g, f"weight_hh_l{l}{suf}"),
+                                            getattr(g, f"bias_hh_l{l}{suf}"), None, lengths, rev)
+                outs.append(hs)
+                hiddens.append(h_n)
+            out_f, out_b = outs
+            if l + 1 < L:
+                cat = torch.cat([out_f, out_b], dim=2).view(Tw * B, 2 * H)       # layout only
+                layer_in = cat                                                    # (inter-layer dropout: see class doc)
+        outputs = torch.empty((Tw, B, H), dtype=torch.float32, device=dev)
+        ops.add_halves(out_f.detach().contiguous(), H, out_b.detach().contiguous(), H, outputs, H, Tw * B, H)
+        return outputs, torch.stack(hiddens)
+
+
+class Attn(nn.Module):
+    def __init__(self, hidden_size: int):
+        super().__init__()
+        raise NotImplementedError("Bahdanau attention (autoencoder_att == 'True') is not on the accelerated path yet")
+
+
+class BahdanauAttnDecoderRNN(nn.Module):
+    def __init__(self, args, input_size: int, hidden_size: int, output_size: int, n_layers: int = 1,
+                 dropout_p: float = 0.1, discrete_representation: bool = False, speaker_model=None):
+        super().__init__()
+        self.hidden_size, self.output_size, self.n_layers, self.dropout_p = hidden_size, output_size, n_layers, dropout_p
+        self.discrete_representation, self.speaker_model = discrete_representation, speaker_model
+        if not discrete_representation:
+            raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
+        if speaker_model:
+            raise NotImplementedError("speaker embedding is outside the accelerated hot path")
+        self.embedding = nn.Embedding(output_size, hidden_size)
+        self.dropout = nn.Dropout(0.5)
+        if args.autoencoder_att == "True":
+            self.attn = Attn(hidden_size)
+        self.att_use = False
+        self.pre_linear = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
+        self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout_p)
+        self.out = nn.Linear(hidden_size, output_size)
+        self.softmax = nn.Softmax(dim=1)
+        self.do_flatten_parameters = False
+
+    def forward(self, motion_input, last_hidden, encoder_outputs=None, vid_indices=None, keep_emb=None, keep_l0=None):
+        """One decode step: code ids (B,) + hidden (L,B,H) -> logits (B,K), new hidden (L,B,H), None."""
+        B = motion_input.shape[0]
+        H, L = self.hidden_size, self.n_layers
+        training = self.training
+        e = Fn.EmbeddingFn.apply(self.embedding.weight, motion_input, keep_emb if training else None, 2.0)   # Dropout(0.5)
+        lin, bn = self.pre_linear[0], self.pre_linear[1]
+        u = Fn.linear(e, lin.weight, lin.bias)
+        a = Fn.BatchNormReluFn.apply(u, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, True)
+        if training:
+            bn.num_batches_tracked += 1
+        new_h, layer_in, keep, scale = [], a, None, 1.0
+        for l in range(L):
+            g = self.gru
+            gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}"), getattr(g, f"bias_ih_l{l}"), keep=keep, scale=scale)
+            _, h_n = Fn.GRUDirFn.apply(gi.view(1, B, 3 * H), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"),
+                                       last_hidden[l], None, False)
+            new_h.append(h_n)
+            layer_in = h_n
+            if training and self.dropout_p > 0 and keep_l0 is not None:
+                keep, scale = keep_l0, 1.0 / (1.0 - self.dropout_p)      # nn.GRU inter-layer dropout, fused into the next Linear
+        logits = Fn.linear(new_h[-1], self.out.weight, self.out.bias)
+        return logits, torch.stack(new_h), None
+
+
+class Generator(nn.Module):
+    def __init__(self, args, motion_dim: int, discrete_representation: bool = False, speaker_model=None):
+        super().__init__()
+        self.output_size = motion_dim
+        self.n_layers = args.n_layers
+        self.discrete_representation = discrete_representation
+        self.decoder = BahdanauAttnDecoderRNN(args, input_size=motion_dim, hidden_size=args.hidden_size,
+                                              output_size=self.output_size, n_layers=self.n_layers,
+                                              dropout_p=args.dropout_prob, discrete_representation=discrete_representation,
+                                              speaker_model=speaker_model)
+
+    def forward(self, z, motion_input, last_hidden, encoder_output, vid_indices=None, **kw):
+        assert z is None
+        return self.decoder(motion_input, last_hidden, encoder_output, vid_indices, **kw)
+
+
+class text2embedding_model(nn.Module):
+    def __init__(self, args, pose_dim: int, n_frames: int, n_words: int, word_embed_size: int, word_embeddings,
+                 speaker_model=None):
+        super().__init__()
+        self.text2_embedding_discrete = args.text2_embedding_discrete == "True"
+        if not self.text2_embedding_discrete:
+            raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
+        self.n_layers = args.n_layers
+        pose_dim = int(args.autoencoder_vq_components)
+        self.encoder = EncoderRNN(n_words, word_embed_size, args.hidden_size, args.n_layers, dropout=args.dropout_prob,
+                                  pre_trained_embedding=word_embeddings)
+        self.decoder = Generator(args, pose_dim, discrete_representation=True, speaker_model=speaker_model)
+        self.n_frames, self.n_pre_poses, self.pose_dim = n_frames, args.n_pre_poses, pose_dim
+        self.sentence_frame_length = args.sentence_frame_length
+        self.dropout_prob = float(args.dropout_prob)
+        self._masks = None
+        self._rng_counter = None
+        self.rng_seed = 0
+
+    def set_dropout_masks(self, mask_emb, mask_dec_l0=None):
+        """Explicit keep masks for the next training forward: (S-1,B,H) each (parity tests)."""
+        self._masks = (mask_emb, mask_dec_l0)
+
+    def _draw(self, shape, keep_prob, dev):
+        if self._rng_counter is None or self._rng_counter.device != dev:
+            self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        return ops.keep_mask(torch.empty(shape, dtype=torch.uint8, device=dev), keep_prob, self.rng_seed, self._rng_counter)
+
+    def forward(self, in_text, in_lengths, in_audio, poses, GPT3_embeddings, vid_indices):
+        if not in_text.is_cuda:
+            raise RuntimeError("text2embedding_model runs on the MI355X kernels only (no CPU fallback)")
+        if vid_indices is not None:
+            raise NotImplementedError("the vid_indices inference branch (:685-692) is outside the accelerated path")
+        dev = in_text.device
+        ids = in_text.transpose(0, 1).contiguous()                 # (Tw,B)
+        cod = poses.transpose(0, 1).contiguous().to(torch.int64)   # (S,B)
+        S_model = self.sentence_frame_length // self.n_frames
+        B, K, H, L = cod.shape[1], self.pose_dim, self.encoder.hidden_size, self.n_layers
+        training = self.training
+        # the attention-free decoder reads only encoder_hidden[:L] = the layer-0 final states (:667-669)
+        _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1)
+        hidden = enc_hidden[:L]
+        outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
+        dec_in = cod[0]
+        if training:
+            if self._masks is not None:
+                mask_emb, mask_l0 = self._masks
+            else:
+                mask_emb = self._draw((S_model - 1, B, H), 0.5, dev)
+                mask_l0 = self._draw((S_model - 1, B, H), 1.0 - self.dropout_prob, dev) if self.dropout_prob > 0 else None
+        for t in range(1, S_model):                                                    # :701-744
+            ke = mask_emb[t - 1].contiguous() if training else None
+            kl = mask_l0[t - 1].contiguous() if (training and mask_l0 is not None) else None
+            logits, hidden, _ = self.decoder(None, dec_in, hidden, None, None, keep_emb=ke, keep_l0=kl)
+            outs.append(logits)
+            dec_in = cod[t] if t < self.n_pre_poses else ops.argmax_rows(logits.detach().contiguous())
+        return torch.stack(outs).transpose(0, 1), []

@@ -326,3 +326,59 @@ def mask_mul(inp, mask, scale=1.0, positive_of=False):
     pos = mask if positive_of else None
     check(_lib_().g2v_mask_mul(_p(_chk(inp)), _p(keep), _p(pos), float(scale), _p(out), inp.numel(), _stream()), "mask_mul")
     return out
+
+
+# ------------------------------------------------------------------------------------------ Part d operators
+def embedding_fwd(table, ids, keep=None, scale=1.0):
+    V, dim = table.shape
+    n = ids.numel()
+    out = torch.empty((n, dim), dtype=torch.float32, device=table.device)
+    check(_lib_().g2v_embedding_fwd(_p(_chk(table)), _p(_chk(ids, torch.int64)), _p(keep), float(scale), _p(out), n, dim, V,
+                                    _stream()), "embedding_fwd")
+    return out
+
+
+def embedding_bwd(d_out, ids, V, keep=None, scale=1.0):
+    n, dim = d_out.shape
+    d_table = torch.empty((V, dim), dtype=torch.float32, device=d_out.device)
+    check(_lib_().g2v_embedding_bwd(_p(_chk(d_out)), _p(_chk(ids, torch.int64)), _p(keep), float(scale), _p(d_table), n, dim,
+                                    V, 1, _stream()), "embedding_bwd")
+    return d_table
+
+
+def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, relu=True):
+    B, H = x.shape
+    y = torch.empty_like(x)
+    sm = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
+    si = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
+    check(_lib_().g2v_batchnorm_fwd(_p(_chk(x)), _p(weight), _p(bias), _p(running_mean), _p(running_var), int(training),
+                                    int(relu), _p(y), _p(sm), _p(si), B, H, _stream()), "batchnorm_fwd")
+    return y, sm, si
+
+
+def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True):
+    B, H = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty((H,), dtype=torch.float32, device=x.device)
+    db = torch.empty((H,), dtype=torch.float32, device=x.device)
+    check(_lib_().g2v_batchnorm_bwd(_p(_chk(dy)), _p(x), _p(y), _p(weight), _p(save_mean), _p(save_invstd), int(relu), _p(dx),
+                                    _p(dw), _p(db), B, H, _stream()), "batchnorm_bwd")
+    return dx, dw, db
+
+
+def cross_entropy_fwd_bwd(logits, targets, want_grad=True, ld=None):
+    M, K = logits.shape
+    dev = logits.device
+    loss = torch.empty((1,), dtype=torch.float32, device=dev)
+    row = torch.empty((M,), dtype=torch.float32, device=dev)
+    dl = torch.empty((M, K), dtype=torch.float32, device=dev) if want_grad else None
+    check(_lib_().g2v_cross_entropy_fwd_bwd(_p(logits), ld if ld is not None else K, _p(_chk(targets, torch.int64)), _p(loss),
+                                            _p(row), _p(dl), K, M, K, 1.0, _stream()), "cross_entropy")
+    return loss, dl
+
+
+def argmax_rows(x):
+    M, K = x.shape
+    out = torch.empty((M,), dtype=torch.int64, device=x.device)
+    check(_lib_().g2v_argmax_rows(_p(_chk(x)), K, _p(out), M, K, _stream()), "argmax_rows")
+    return out

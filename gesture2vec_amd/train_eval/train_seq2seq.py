@@ -103,3 +103,24 @@ def train_iter_DAE(args, epoch: int, noisy_poses: torch.Tensor, target_poses: to
     loss.backward()
     optim.step()
     return {"loss": loss.item()}
+
+
+def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, target_poses, cluster_targets,
+                              GPT3_Embedding, net: torch.nn.Module, optim):
+    """One training iteration of Part d (reference :462-538), discrete codes: CrossEntropyLoss over decode steps 1..S-1,
+    clip_grad_norm_(5) + Adam (fused in `optim`, a gesture2vec_amd.flat.FlatClipAdam)."""
+    from ..flat import FlatClipAdam
+    from ..functional import cross_entropy
+    if not isinstance(optim, FlatClipAdam):
+        raise TypeError("use gesture2vec_amd.flat.FlatClipAdam (clip + Adam are one fused HIP launch)")
+    if args.text2_embedding_discrete != "True":
+        raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
+    optim.zero_grad()
+    outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
+    K = outputs.shape[2]
+    logits = outputs[:, 1:, :].reshape(-1, K)
+    targets = cluster_targets[:, 1:].reshape(-1)
+    loss = cross_entropy(logits, targets.long())
+    loss.backward()
+    optim.step()
+    return {"loss": loss.item()}

@@ -256,6 +256,33 @@ int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int6
                        g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).
+ *   g2v_embedding_fwd   out[r,:] = table[ids[r],:] * keep * scale   (nn.Embedding :90-92,126 / :252,340-343 with the
+ *                       decoder's nn.Dropout(0.5) fused; keep may be NULL)
+ *   g2v_embedding_bwd   d_table[ids[r],:] += d_out[r,:] * keep * scale   (float atomics; zero_first clears d_table)
+ *   g2v_batchnorm_fwd   nn.BatchNorm1d(H) on (B,H) (+ optional fused ReLU), decoder.pre_linear[1:] :286-290; training:
+ *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance; save_* for bwd
+ *   g2v_batchnorm_bwd   dx, dweight, dbias (overwritten) from dy (the ReLU mask is taken from y > 0 when relu)
+ *   g2v_cross_entropy_fwd_bwd   loss[0] = mean_r( logsumexp(logits[r]) - logits[r, t_r] ), dlogits = g_scale *
+ *                       (softmax - onehot)/M  (torch.nn.CrossEntropyLoss, train_eval/train_seq2seq.py:520-530);
+ *                       row_loss: M floats of scratch; dlogits may be NULL
+ *   g2v_argmax_rows     out[r] = argmax_k x[r,k] (lowest index on ties): greedy feedback :740
+ * ------------------------------------------------------------------------------------------ */
+int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out,
+                      int64_t n, int dim, int64_t V, g2v_stream_t stream);
+int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* keep, float scale, float* d_table,
+                      int64_t n, int dim, int64_t V, int zero_first, g2v_stream_t stream);
+int g2v_batchnorm_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
+                      int training, int relu, float* y, float* save_mean, float* save_invstd, int B, int H,
+                      g2v_stream_t stream);
+int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y, const float* weight, const float* save_mean,
+                      const float* save_invstd, int relu, float* dx, float* dw, float* db, int B, int H,
+                      g2v_stream_t stream);
+int g2v_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* targets, float* loss, float* row_loss,
+                              float* dlogits, int64_t ldd, int M, int K, float g_scale, g2v_stream_t stream);
+int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, int K, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Keep-mask generator: keep[i] = (philox4x32-10(seed, offset_counter, i) uniform < keep_prob).
  * Replaces the RNG draws of nn.Dropout / nn.GRU dropout on the path (e.g. :570).  offset_counter is a
  * device int64 that the call advances by 1 (so graph replays draw fresh masks).

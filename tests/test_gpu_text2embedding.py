@@ -1,0 +1,70 @@
+"""GPU parity of Part d (text -> gesture-code seq2seq) against the reference's golden vectors (2 train steps + eval)."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+
+
+def test_text2embedding_matches_reference_golden(golden_dir):
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
+    fx = np.load(os.path.join(golden_dir, "t2e_noatt.npz"))
+    B, Tw, S, H, L, K, NW, EMB = [int(v) for v in fx["cfg"]]
+    p, lr = [float(v) for v in fx["cfg_f"]]
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att="False",
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    net = text2embedding_model(args, 135, 20, NW, EMB, np.zeros((NW, EMB), dtype=np.float32), None)
+    sd0 = {k[3:]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("w0/")}
+    net.load_state_dict(sd0, strict=True)
+    net = net.to(DEV)
+    net.train(True)
+    optim = FlatClipAdam(net.parameters(), lr=lr, betas=(0.5, 0.999))
+    ids = torch.from_numpy(fx["ids"].copy()).to(DEV)
+    lengths = torch.from_numpy(fx["lengths"].copy())
+    codes = torch.from_numpy(fx["codes"].copy()).to(DEV)
+    for step in (1, 2):
+        net.set_dropout_masks(torch.from_numpy(fx[f"s{step}/mask_emb"].copy()).to(DEV),
+                              torch.from_numpy(fx[f"s{step}/mask_dec_l0"].copy()).to(DEV))
+        outputs_ref = fx[f"s{step}/outputs"]
+        loss = train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+        assert abs(loss["loss"] - float(fx[f"s{step}/loss"])) <= 1e-5 * float(fx[f"s{step}/loss"]), (loss, float(fx[f"s{step}/loss"]))
+        if step == 1:
+            for n, prm in net.named_parameters():
+                ref = fx["s1/grad/" + n]
+                if n == "decoder.decoder.pre_linear.0.bias":
+                    continue                       # feeds BatchNorm: mathematically zero
+                if np.abs(ref).max() == 0:
+                    assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n     # encoder layer 1: dead compute
+                else:
+                    assert prm.grad is not None and relerr(prm.grad, ref) < 5e-4, (n, relerr(prm.grad, ref))
+    for k in fx.files:
+        if k.startswith("wN/"):
+            n = k[3:]
+            ref, got = torch.from_numpy(fx[k].copy()), net.state_dict()[n].cpu()
+            if n in ("decoder.decoder.pre_linear.0.bias", "decoder.decoder.pre_linear.1.running_mean"):
+                assert float((got - ref).abs().max()) <= 1.01 * 2 * lr, n
+            elif ref.dtype.is_floating_point:
+                err = float((got.double() - ref.double()).abs().max())
+                assert err <= 1e-4 * float(ref.abs().max()) + 0.02 * 2 * lr, (n, err)
+            else:
+                assert torch.equal(got, ref), n
+    net.train(False)
+    with torch.no_grad():
+        out, att = net(ids, lengths, None, codes, None, None)
+    assert out.shape == (B, S, K) and att == []
+    assert relerr(out, fx["eval/outputs"]) < 1e-4
+    # greedy codes of the eval rollout are exactly the reference's
+    assert np.array_equal(out[:, 1:].argmax(2).cpu().numpy(), fx["eval/outputs"][:, 1:].argmax(2))
