@@ -413,3 +413,65 @@ def test_keep_mask(ops):
         assert abs(frac - 0.05) < 4 * math.sqrt(0.05 * 0.95 / n)
     full = ops.keep_mask(torch.empty(1000, dtype=torch.uint8, device=DEV), 1.0, 1, off)
     assert full.all()
+
+
+# ----------------------------------------------------------------------------------------------- Part d operators
+@pytest.mark.parametrize("B,H", [(128, 200), (37, 50), (4096, 64), (5, 16)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_fwd_bwd(ops, B, H, relu):
+    x = rnd(B, H, seed=1) * 2 + 0.5
+    w, b = 1 + 0.1 * rnd(H, seed=2), 0.1 * rnd(H, seed=3)
+    rm, rv = rnd(H, seed=4) * 0.1, torch.rand(H, generator=torch.Generator().manual_seed(5)) + 0.5
+    xl, wl, bl = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref, nrm, nrv = O.batchnorm1d(xl, wl, bl, rm, rv, True)
+    if relu:
+        y_ref = torch.relu(y_ref)
+    gy = rnd(B, H, seed=6)
+    gx, gw, gb = torch.autograd.grad((y_ref * gy).sum(), [xl, wl, bl])
+    rmd, rvd = rm.clone().to(DEV), rv.clone().to(DEV)
+    y, sm, si = ops.batchnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rmd, rvd, True, relu)
+    relclose(y, y_ref, 2e-5, "bn y")
+    close(rmd, nrm, 1e-5, 1e-6, "running_mean")
+    close(rvd, nrv, 1e-5, 1e-6, "running_var")
+    dx, dw, db = ops.batchnorm_bwd(gy.to(DEV), x.to(DEV), y, w.to(DEV), sm, si, relu)
+    relclose(dx, gx, 2e-4, "bn dx")
+    relclose(dw, gw, 1e-4, "bn dw")
+    relclose(db, gb, 1e-4, "bn db")
+    # eval mode uses (and leaves untouched) the running statistics
+    y_e, _, _ = O.batchnorm1d(x, w, b, rm, rv, False)
+    rme = rm.clone().to(DEV)
+    ye, _, _ = ops.batchnorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), rme, rv.clone().to(DEV), False, False)
+    relclose(ye, y_e, 1e-5, "bn eval")
+    assert torch.equal(rme.cpu(), rm)
+
+
+@pytest.mark.parametrize("M,K", [(640, 512), (33, 64), (7, 400)])
+def test_cross_entropy_and_argmax(ops, M, K):
+    z = rnd(M, K, seed=1) * 3
+    t = torch.randint(0, K, (M,), generator=torch.Generator().manual_seed(2))
+    zl = z.clone().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(zl, t)
+    (g,) = torch.autograd.grad(ref, zl)
+    loss, dl = ops.cross_entropy_fwd_bwd(z.to(DEV), t.to(DEV))
+    assert abs(loss.item() - ref.item()) <= 2e-6 * abs(ref.item())
+    relclose(dl, g, 2e-5, "ce grad")
+    z[3, 5] = z[3, 9] = 50.0                      # tie: lowest index wins
+    am = ops.argmax_rows(z.to(DEV)).cpu()
+    assert torch.equal(am, z.argmax(1)) and int(am[3]) == 5
+
+
+def test_embedding_fwd_bwd(ops):
+    V, dim, n = 300, 300, 1000
+    table = rnd(V, dim, seed=1)
+    ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
+    keep = (torch.rand(n, dim, generator=torch.Generator().manual_seed(3)) < 0.5).to(torch.uint8)
+    out = ops.embedding_fwd(table.to(DEV), ids.to(DEV), keep.to(DEV), 2.0)
+    ref = table[ids] * keep * 2.0
+    assert torch.equal(out.cpu(), ref)
+    g = rnd(n, dim, seed=4)
+    dt = ops.embedding_bwd(g.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
+    ref_dt = torch.zeros(V, dim, dtype=torch.float64)
+    ref_dt.index_add_(0, ids, (g * keep * 2.0).double())
+    relclose(dt, ref_dt.float(), 2e-6, "embedding grad")
+    out2 = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
+    assert torch.equal(out2.cpu(), table[ids])

@@ -30,3 +30,17 @@ def test_train_autoencoder_vqvae_synthetic(tmp_path):
         out_poses, latent, loss_vq, perp = net(x, x)
     assert out_poses.shape == (8, 34, 135) and torch.isfinite(out_poses).all()
     assert float(loss_fn(out_poses, x)) > 0
+
+
+def test_train_text2embedding_synthetic(tmp_path):
+    out = os.path.join(tmp_path, "run_t2e")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_text2embedding.py"),
+           "--config", os.path.join(ROOT, "config", "seq2seq_synthetic.yml"), "--synthetic", "--synthetic_batches", "2",
+           "--batch_size", "32", "--epochs", "10", "--hidden_size", "64", "--model_save_path", out, "--name", "t"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    assert "[VAL] loss:" in log and "EP 10 (  2) |" in log
+    ckpt = torch.load(os.path.join(out, "t_checkpoint_010.bin"), map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"args", "epoch", "lang_model", "pose_dim", "gen_dict"} and ckpt["pose_dim"] == 512
+    assert "encoder.embedding.weight" in ckpt["gen_dict"] and "decoder.decoder.out.weight" in ckpt["gen_dict"]
