@@ -220,6 +220,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   if (slab_db && blockIdx.y == 0 && tid < NB && n0 + tid < N) slab_db[(int64_t)split * N + n0 + tid] = dbsum;
 }
 
+// two slab families in one launch: blocks [0, nblk_a) reduce (slab_a -> out_a), the rest (slab_b -> out_b)
+__global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ slab_a, int64_t na, float* __restrict__ out_a,
+                                                           const float* __restrict__ slab_b, int64_t nb, float* __restrict__ out_b,
+                                                           int nsplit, int accumulate, int nblk_a) {
+  __shared__ float red[4][64];
+  const bool first = (int)blockIdx.x < nblk_a;
+  const float* slab = first ? slab_a : slab_b;
+  const int64_t n = first ? na : nb;
+  float* out = first ? out_a : out_b;
+  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int64_t e = (int64_t)(first ? blockIdx.x : blockIdx.x - nblk_a) * 64 + col;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (e < n) {
+    int p = grp;
+    for (; p + 12 < nsplit; p += 16) {
+      s0 += slab[(int64_t)p * n + e];
+      s1 += slab[(int64_t)(p + 4) * n + e];
+      s2 += slab[(int64_t)(p + 8) * n + e];
+      s3 += slab[(int64_t)(p + 12) * n + e];
+    }
+    for (; p < nsplit; p += 4) s0 += slab[(int64_t)p * n + e];
+  }
+  red[grp][col] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (grp == 0 && e < n) {
+    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
+    out[e] = accumulate ? out[e] + t : t;
+  }
+}
+
 static int tn_ntw(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 3); }
 static int tn_splits(int M, int K, int N) {
   const int tiles = cdiv(N, 64 * tn_ntw(N)) * cdiv(K, 64);
@@ -296,11 +326,9 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
                        slab_db, M, K, N, rows_per_split);
   G2V_CHECK_LAUNCH();
   const int64_t n = (int64_t)N * K;
-  launch_slab_reduce(slab, splits, n, dw, accumulate, (hipStream_t)stream);
+  // one launch reduces both the weight slabs and (when requested) the bias slabs
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 64) + (db ? cdiv(N, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
+                     slab, n, dw, slab_db, (int64_t)N, db, splits, accumulate, cdiv(n, 64));
   G2V_CHECK_LAUNCH();
-  if (db) {
-    launch_slab_reduce(slab_db, splits, (int64_t)N, db, accumulate, (hipStream_t)stream);
-    G2V_CHECK_LAUNCH();
-  }
   return G2V_OK;
 }
