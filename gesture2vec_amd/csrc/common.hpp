@@ -70,7 +70,7 @@ __device__ __forceinline__ float4 ldg_frag(const float* __restrict__ p_row, bool
   return v;
 }
 
-__device__ __forceinline__ bool ptr_vec_ok(const void* p, int64_t ld) {
+__host__ __device__ __forceinline__ bool ptr_vec_ok(const void* p, int64_t ld) {
   return ((reinterpret_cast<uintptr_t>(p) & 15) == 0) && ((ld & 3) == 0);
 }
 

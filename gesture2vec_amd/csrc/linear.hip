@@ -122,6 +122,119 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
   }
 }
 
+// ---- wave-autonomous streaming forward / data-gradient kernel ----------------------------------------------------------
+// For 16-byte-aligned A rows without row map / keep mask (the GRU input projections, the dX products, pre_linear):
+// the (<= 192 x C) weight block is packed in MFMA fragment order into LDS ONCE per workgroup; after that there is NO
+// workgroup barrier: every wave walks its own 16-row groups, pulling its MFMA B-fragments straight from global memory
+// into registers (the group after next is prefetched while the current one is multiplied), reading the weight fragments
+// from LDS with ds_read_b128, and storing its accumulators.  Waves drift apart, so the matrix pipe of a SIMD is shared
+// smoothly between its resident waves instead of all waves hitting the same phase at once.
+template <int NTW, int KS, bool TRANS_B>
+__global__ __launch_bounds__(256) void gemm_nt_stream_kernel(const float* __restrict__ A, int64_t lda,
+                                                             const float* __restrict__ Bm, int64_t ldb,
+                                                             const float* __restrict__ bias, float* __restrict__ Cout,
+                                                             int64_t ldc, int M, int C, int N, int act, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // packed W: [NTW][KS][64 lanes][4]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  // ---- pack the weights: P[((t*KS + s)*64 + l)*4 + e] = Wop[16 t + (l & 15)][16 s + 4 (l >> 4) + e] ----
+  for (int blk = wave; blk < NTW * KS; blk += 4) {
+    const int t = blk / KS, s2 = blk - t * KS;
+    const int n = 16 * t + i;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = 16 * s2 + 4 * q + e;
+      const bool ok = (n < N) && (c < C);
+      const int64_t off = TRANS_B ? ((int64_t)(ok ? c : 0) * ldb + (ok ? n : 0)) : ((int64_t)(ok ? n : 0) * ldb + (ok ? c : 0));
+      const float w = Bm[off];
+      v[e] = ok ? w : 0.f;
+    }
+    *reinterpret_cast<float4*>(smem + ((int64_t)blk * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  float4 bia[NTW];
+#pragma unroll
+  for (int t = 0; t < NTW; ++t) {
+    bia[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int n = 16 * t + 4 * q;
+    if (bias && n + 3 < N) bia[t] = *reinterpret_cast<const float4*>(bias + n);
+  }
+  __syncthreads();
+  const int ngroups = (M + 15) >> 4;
+  const int gstride = gridDim.x * 4;
+  int g = blockIdx.x * 4 + wave;
+  float4 xa[KS], xn[KS];
+  auto load_group = [&](int grp, float4 (&x)[KS]) {
+    const int m = 16 * grp + i;
+    const bool ok = m < M;
+    const float* p = A + (int64_t)(ok ? m : 0) * lda + 4 * q;
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) {
+      float4 v = (16 * s2 + 4 * q < C) ? *reinterpret_cast<const float4*>(p + 16 * s2) : make_float4(0.f, 0.f, 0.f, 0.f);
+      x[s2] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (g < ngroups) load_group(g, xa);
+  for (; g < ngroups; g += gstride) {
+    const int gn = g + gstride;
+    if (gn < ngroups) load_group(gn, xn);
+    const int m = 16 * g + i;
+    float* crow = Cout + (int64_t)(m < M ? m : 0) * ldc;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* wp = smem + ((int64_t)t * KS * 64 + lane) * 4;
+#pragma unroll
+      for (int s2 = 0; s2 < KS; ++s2) {
+        const float4 wa = *reinterpret_cast<const float4*>(wp + s2 * 256);
+        acc = mfma16(wa.x, xa[s2].x, acc);
+        acc = mfma16(wa.y, xa[s2].y, acc);
+        acc = mfma16(wa.z, xa[s2].z, acc);
+        acc = mfma16(wa.w, xa[s2].w, acc);
+      }
+      const int n = 16 * t + 4 * q;
+      if (m < M && n + 3 < N) {
+        float4 v = make_float4(acc[0] + bia[t].x, acc[1] + bia[t].y, acc[2] + bia[t].z, acc[3] + bia[t].w);
+        if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+        if (accumulate) {
+          const float4 o = *reinterpret_cast<const float4*>(crow + n);
+          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
+        *reinterpret_cast<float4*>(crow + n) = v;
+      }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < KS; ++s2) xa[s2] = xn[s2];
+  }
+}
+
+template <bool TRANS_B>
+static bool launch_stream(const float* A, int64_t lda, const float* Bm, int64_t ldb, const float* bias, float* Cout,
+                          int64_t ldc, int M, int C, int N, int act, int accumulate, hipStream_t st) {
+  // eligibility: aligned rows, whole float4s, N a multiple of 16 up to 192, identity / ReLU epilogue, enough rows
+  if (M < 1024 || (C & 3) || (N & 15) || N > 192 || act == 2) return false;
+  if (!ptr_vec_ok(A, lda) || !ptr_vec_ok(Cout, ldc) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
+  const int ks = (C + 15) >> 4, ntw = N >> 4;
+  int gx = cdiv(M, 16 * 4 * 4);                     // >= 4 row groups per wave
+  if (gx > 512) gx = 512;
+#define G2V_STREAM(NTW, KS)                                                                                              \
+  do {                                                                                                                   \
+    const size_t lds = (size_t)NTW * KS * 256 * sizeof(float);                                                           \
+    if (lds > 48 * 1024)                                                                                                 \
+      (void)hipFuncSetAttribute((const void*)gemm_nt_stream_kernel<NTW, KS, TRANS_B>,                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+    hipLaunchKernelGGL((gemm_nt_stream_kernel<NTW, KS, TRANS_B>), dim3(gx), dim3(256), lds, st, A, lda, Bm, ldb, bias,    \
+                       Cout, ldc, M, C, N, act, accumulate);                                                             \
+    return true;                                                                                                         \
+  } while (0)
+  if (ntw == 12 && ks == 4) G2V_STREAM(12, 4);       // gi = xin W_ih^T            (64 -> 192)
+  if (ntw == 4 && ks == 12) G2V_STREAM(4, 12);       // dxin = dgi W_ih            (192 -> 64)
+  if (ntw == 8 && ks == 8) G2V_STREAM(8, 8);         // VQ pre_linear              (128 -> 128)
+  if (ntw == 4 && ks == 4) G2V_STREAM(4, 4);         // 64 -> 64
+#undef G2V_STREAM
+  return false;
+}
+
 // ---- weight gradient: slab[split][n][k] = sum_{m in split} dy[m][n] * xin[m][k] -------------------
 // One workgroup owns a (64*NTW) x 64 block of dW for a contiguous range of rows m, so with N <= 192 every
 // dy / x element is read from HBM exactly once.  Rows are consumed in chunks of TM = 32: the NEXT chunk's global
@@ -271,6 +384,11 @@ extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64
   G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
   G2V_REQUIRE(act >= 0 && act <= 2, "bad activation");
   RowMap am{ldx, rows_inner, stride_outer, stride_inner};
+  if (rows_inner == 0 && !x_keep &&
+      launch_stream<false>(x, ldx, w, (int64_t)K, bias, y, ldy, M, K, N, act, 0, (hipStream_t)stream)) {
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   dim3 grid(cdiv(M, BM), cdiv(N, BN));
   hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, am, x_keep, x_scale, w,
                      (int64_t)K, bias, y, ldy, M, K, N, act, 0);
@@ -283,6 +401,10 @@ extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w
   G2V_REQUIRE(dy && w && dx, "null pointer");
   G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
   RowMap am{lddy, 0, 0, 0};
+  if (launch_stream<true>(dy, lddy, w, (int64_t)K, nullptr, dx, lddx, M, N, K, 0, accumulate, (hipStream_t)stream)) {
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   dim3 grid(cdiv(M, BM), cdiv(K, BN));
   // output feature = k (K of them), contraction over n (N): Bop[k][n] = w[n*K + k]
   hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, am, (const uint8_t*)nullptr,
