@@ -333,6 +333,161 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
   if (slab_db && blockIdx.y == 0 && tid < NB && n0 + tid < N) slab_db[(int64_t)split * N + n0 + tid] = dbsum;
 }
 
+// ---- wave-autonomous weight gradient -------------------------------------------------------------------------------
+// A wave keeps a (16 TN_) x (16 TK_) block of dW in its accumulators, so there is no LDS tile and no barrier in the
+// streaming loop: lane (i, q) pulls dY[m0 + q][n0 + 16 t + i] and X[m0 + q][k0 + 16 u + i] straight into the MFMA
+// operand registers with dword loads (no alignment requirement, so D = 135 rows and the (B,T,D) -> (T,B,D) row map
+// cost nothing), the next 16 rows are in flight while the current 16 are multiplied, and TN_*TK_ independent
+// accumulators keep the matrix pipe issuing back to back.  A workgroup has 8 waves = 4 row ranges x 2 tile groups
+// (SN x SK = 2 halves of the output block, <= 256 registers each, so two waves share every SIMD and one fills the
+// matrix pipe while the other waits); the four row ranges are summed through LDS once at the end and the workgroup
+// partial goes to a slab for the deterministic slab reduction.
+template <int TN_, int TK_, int SN, int SK, bool MAPPED>
+__global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restrict__ dY, int64_t lddy,
+                                                           const float* __restrict__ X, RowMap xm,
+                                                           float* __restrict__ slab, float* __restrict__ slab_db, int M,
+                                                           int K, int N, int rows_per_wave) {
+  static_assert(SN * SK == 2, "two tile groups per workgroup");
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // 4 regions x [TN_*TK_][64][4] + db [8][TN_][16]
+  constexpr int NTILE = TN_ * TK_;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int rr = wave & 3, grp = wave >> 2;            // row range, tile group
+  const int n0 = 16 * TN_ * (grp % SN), k0 = 16 * TK_ * (grp / SN);
+  const int mb = (blockIdx.x * 4 + rr) * rows_per_wave;
+  const int me = min(M, mb + rows_per_wave);
+
+  f32x4 acc[TN_][TK_];
+  float dbs[TN_];
+#pragma unroll
+  for (int t = 0; t < TN_; ++t) {
+    dbs[t] = 0.f;
+#pragma unroll
+    for (int u = 0; u < TK_; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // per-lane column offsets: i for whole tiles (immediate offsets 64 t bytes), clamped for a ragged last tile
+  const bool okn = n0 + 16 * (TN_ - 1) + i < N, okk = k0 + 16 * (TK_ - 1) + i < K;
+  const int in_last = okn ? i : 0, ik_last = okk ? i : 0;
+
+  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_];
+  auto load_group = [&](int m0, float (&a)[4][TN_], float (&b)[4][TK_]) {
+    // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
+    // (B,T,D) -> (T,B,D) row map, then the three following row quads step the (outer, inner) pair.
+    int mrow = m0 + q, outer = 0, inner = 0;
+    if (MAPPED) { outer = mrow / xm.rows_inner; inner = mrow - outer * xm.rows_inner; }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const float* dr = dY + (int64_t)mrow * lddy + n0;
+      const float* xr = X + (MAPPED ? (int64_t)outer * xm.so + (int64_t)inner * xm.si : (int64_t)mrow * xm.ld) + k0;
+      const float* dri = dr + i;
+      const float* xri = xr + i;
+#pragma unroll
+      for (int t = 0; t < TN_ - 1; ++t) a[qd][t] = dri[16 * t];
+      a[qd][TN_ - 1] = dr[16 * (TN_ - 1) + in_last];
+#pragma unroll
+      for (int u = 0; u < TK_ - 1; ++u) b[qd][u] = xri[16 * u];
+      b[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+      mrow += 4;
+      if (MAPPED) {
+        inner += 4;
+        if (inner >= xm.rows_inner) { inner -= xm.rows_inner; ++outer; }
+      }
+    }
+  };
+  auto compute = [&](float (&a)[4][TN_], float (&b)[4][TK_]) {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;     // ragged last tiles: the clamped column is masked at use time
+      b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TN_; ++t) {
+        dbs[t] += a[qd][t];
+#pragma unroll
+        for (int u = 0; u < TK_; ++u) acc[t][u] = mfma16(a[qd][t], b[qd][u], acc[t][u]);
+      }
+    }
+  };
+  if (mb < me) load_group(mb, ca, cb);
+  for (int m0 = mb; m0 < me; m0 += 16) {
+    load_group(min(m0 + 16, M - 16), na, nb);   // past the end of the range: a valid, unused group
+    __builtin_amdgcn_sched_barrier(0);
+    compute(ca, cb);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+#pragma unroll
+      for (int t = 0; t < TN_; ++t) ca[qd][t] = na[qd][t];
+#pragma unroll
+      for (int u = 0; u < TK_; ++u) cb[qd][u] = nb[qd][u];
+    }
+  }
+  // ---- sum the four row ranges of each tile group: (2,3) -> LDS -> (0,1); 1 -> LDS -> 0; range 0 writes the slab ----
+  float* dbl = smem + 4 * NTILE * 256;
+#pragma unroll
+  for (int t = 0; t < TN_; ++t) {
+    float v = dbs[t];
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (q == 0) dbl[(wave * TN_ + t) * 16 + i] = v;
+  }
+  auto dump = [&](float* reg) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t)
+#pragma unroll
+      for (int u = 0; u < TK_; ++u)
+        *reinterpret_cast<float4*>(reg + ((t * TK_ + u) * 64 + lane) * 4) =
+            make_float4(acc[t][u][0], acc[t][u][1], acc[t][u][2], acc[t][u][3]);
+  };
+  auto absorb = [&](const float* reg) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t)
+#pragma unroll
+      for (int u = 0; u < TK_; ++u) {
+        const float4 v = *reinterpret_cast<const float4*>(reg + ((t * TK_ + u) * 64 + lane) * 4);
+        acc[t][u][0] += v.x; acc[t][u][1] += v.y; acc[t][u][2] += v.z; acc[t][u][3] += v.w;
+      }
+  };
+  if (rr >= 2) dump(smem + (2 * grp + rr - 2) * NTILE * 256);
+  __syncthreads();
+  if (rr < 2) absorb(smem + (2 * grp + rr) * NTILE * 256);
+  __syncthreads();
+  if (rr == 1) dump(smem + grp * NTILE * 256);
+  __syncthreads();
+  if (rr != 0) return;
+  absorb(smem + grp * NTILE * 256);
+  float* sl = slab + (int64_t)blockIdx.x * N * K;
+#pragma unroll
+  for (int t = 0; t < TN_; ++t)
+#pragma unroll
+    for (int u = 0; u < TK_; ++u) {
+      const int k = k0 + 16 * u + i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int n = n0 + 16 * t + 4 * q + r;
+        if (n < N && k < K) sl[(int64_t)n * K + k] = acc[t][u][r];
+      }
+    }
+  if (slab_db && grp / SN == 0) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t) {
+      const int n = n0 + 16 * t + i;
+      const float* d0 = dbl + (4 * grp * TN_ + t) * 16 + i;
+      if (q == 0 && n < N)
+        slab_db[(int64_t)blockIdx.x * N + n] = (d0[0] + d0[TN_ * 16]) + (d0[2 * TN_ * 16] + d0[3 * TN_ * 16]);
+    }
+  }
+}
+
+// grid (= number of slabs) and rows per wave of the wave-autonomous path; 0 when the shape is not covered
+static int tn_wave_grid(int M, int K, int N, bool has_keep, int* rows_per_wave) {
+  const int tn = cdiv(N, 16), tk = cdiv(K, 16);
+  const bool covered = (tn == 12 && tk == 4) || (tn == 4 && tk == 9) || (tn == 9 && tk == 4) || (tn == 4 && tk == 4);
+  if (!covered || has_keep || M < 4096 || (M & 15)) return 0;
+  int rpw = round_up(cdiv(M, 1024), 16);
+  if (rows_per_wave) *rows_per_wave = rpw;
+  return cdiv(M, 4 * rpw);
+}
+
 // two slab families in one launch: blocks [0, nblk_a) reduce (slab_a -> out_a), the rest (slab_b -> out_b)
 __global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ slab_a, int64_t na, float* __restrict__ out_a,
                                                            const float* __restrict__ slab_b, int64_t nb, float* __restrict__ out_b,
@@ -415,7 +570,9 @@ extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w
 
 extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
-  const int splits = tn_splits(M, K, N);
+  int splits = tn_splits(M, K, N);
+  const int wg = tn_wave_grid(M, K, N, false, nullptr);
+  if (wg > splits) splits = wg;
   return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
 }
 
@@ -429,15 +586,40 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
     set_error("g2v_linear_bwd_weight: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
-  const int splits = tn_splits(M, K, N);
+  int splits = tn_splits(M, K, N);
   int rows_per_split = cdiv(M, splits);
   rows_per_split = round_up(rows_per_split, TM);
   float* slab = (float*)workspace;
-  float* slab_db = db ? slab + (size_t)splits * N * K : nullptr;
   RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
+  int rpw = 0;
+  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw);
+  if (wg > 0) splits = wg;
+  float* slab_db = db ? slab + (size_t)splits * N * K : nullptr;
   const int ntw = tn_ntw(N);
   dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
-  if (ntw == 1)
+  if (wg > 0) {
+    const int tn = cdiv(N, 16), tk = cdiv(K, 16);
+#define G2V_TNW(TN_, TK_, SN, SK)                                                                                        \
+  do {                                                                                                                   \
+    const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
+    if (rows_inner > 0) {                                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true>,                                \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true>), dim3(wg), dim3(512), lds, (hipStream_t)stream,   \
+                         dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                                                  \
+    } else {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false>,                               \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false>), dim3(wg), dim3(512), lds, (hipStream_t)stream,  \
+                         dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                                                  \
+    }                                                                                                                    \
+  } while (0)
+    if (tn == 12 && tk == 4) G2V_TNW(6, 4, 2, 1);
+    else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1);
+    else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2);
+    else G2V_TNW(2, 4, 2, 1);
+#undef G2V_TNW
+  } else if (ntw == 1)
     hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
                        slab_db, M, K, N, rows_per_split);
   else if (ntw == 2)
