@@ -459,9 +459,20 @@ __global__ void bn_running_update_kernel(const float* __restrict__ bn_stats, flo
   if (f >= H) return;
   float m = rm[f], v = rv[f];
   const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
-  for (int s = 0; s < steps; ++s) {
-    m = 0.9f * m + 0.1f * bn_stats[(int64_t)s * 2 * H + f];
-    v = 0.9f * v + 0.1f * (bn_stats[(int64_t)s * 2 * H + H + f] * unbias);
+  for (int s0 = 0; s0 < steps; s0 += 8) {   // 16 independent loads in flight, then the 8 dependent updates
+    float sm[8], svv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int s = min(s0 + j, steps - 1);
+      sm[j] = bn_stats[(int64_t)s * 2 * H + f];
+      svv[j] = bn_stats[(int64_t)s * 2 * H + H + f];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (s0 + j < steps) {
+        m = 0.9f * m + 0.1f * sm[j];
+        v = 0.9f * v + 0.1f * (svv[j] * unbias);
+      }
   }
   rm[f] = m;
   rv[f] = v;

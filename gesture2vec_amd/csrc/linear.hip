@@ -235,6 +235,94 @@ static bool launch_stream(const float* A, int64_t lda, const float* Bm, int64_t 
   return false;
 }
 
+// ---- wave-autonomous forward for UNALIGNED / row-mapped inputs (encoder in_layer: x (B,T,135) read as (T,B,135)) ----
+// Rows of 135 floats are not 16-byte aligned, so the B-operand fragments are pulled with dword loads exactly in MFMA
+// layout: lane (i, q) reads x[row m0 + i][4 s + q] for the KS4 = ceil(C / 4) k-steps (a 128-byte line is consumed by
+// 8 consecutive loads, the vector L1 serves the repeats); the next 16 rows are in flight while the current 16 are
+// multiplied.  N = 64 outputs: the four 16-row weight tiles are interleaved per k-step in LDS so ONE ds_read_b128
+// yields the A operands of all four MFMAs.  No workgroup barrier after the weights are staged.
+template <int KS4, bool MAPPED>
+__global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict__ A, RowMap am,
+                                                         const float* __restrict__ W, const float* __restrict__ bias,
+                                                         float* __restrict__ Cout, int64_t ldc, int M, int C, int act) {
+  __shared__ __attribute__((aligned(16))) float4 Wp[KS4 * 64];   // [s][lane] = W[{0,16,32,48} + i][4 s + q]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  for (int e = tid; e < KS4 * 64; e += 256) {
+    const int s2 = e >> 6, l = e & 63, c = 4 * s2 + (l >> 4), n = l & 15;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    const float w0 = W[(int64_t)n * C + cc], w1 = W[(int64_t)(n + 16) * C + cc], w2 = W[(int64_t)(n + 32) * C + cc],
+                w3 = W[(int64_t)(n + 48) * C + cc];
+    Wp[e] = ok ? make_float4(w0, w1, w2, w3) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 bia[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    bia[t] = bias ? *reinterpret_cast<const float4*>(bias + 16 * t + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int ngroups = M >> 4;                         // M is a multiple of 16 (checked by the launcher)
+  const int gstride = gridDim.x * 4;
+  // clamped column of the last (ragged) k-step: the matching weight is zero, any finite x value of the row will do
+  const int col_last = min(4 * (KS4 - 1) + q, C - 1);
+  float xa[KS4], xn[KS4];
+  auto load_group = [&](int grp, float (&x)[KS4]) {
+    const int m = 16 * grp + i;
+    int64_t off;
+    if (MAPPED) {
+      const int outer = m / am.rows_inner, inner = m - outer * am.rows_inner;
+      off = (int64_t)outer * am.so + (int64_t)inner * am.si;
+    } else {
+      off = (int64_t)m * am.ld;
+    }
+    const float* p = A + off;
+    const float* pq = p + q;
+#pragma unroll
+    for (int s2 = 0; s2 < KS4 - 1; ++s2) x[s2] = pq[4 * s2];
+    x[KS4 - 1] = p[col_last];
+  };
+  int g = blockIdx.x * 4 + wave;
+  if (g < ngroups) load_group(g, xa);
+  for (; g < ngroups; g += gstride) {
+    load_group(min(g + gstride, ngroups - 1), xn);    // past the end: a valid, unused group
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s2 = 0; s2 < KS4; ++s2) {
+      const float4 wa = Wp[s2 * 64 + lane];
+      acc[0] = mfma16(wa.x, xa[s2], acc[0]);
+      acc[1] = mfma16(wa.y, xa[s2], acc[1]);
+      acc[2] = mfma16(wa.z, xa[s2], acc[2]);
+      acc[3] = mfma16(wa.w, xa[s2], acc[3]);
+    }
+    float* crow = Cout + (int64_t)(16 * g + i) * ldc + 4 * q;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float4 v = make_float4(acc[t][0] + bia[t].x, acc[t][1] + bia[t].y, acc[t][2] + bia[t].z, acc[t][3] + bia[t].w);
+      if (act == 1) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+      *reinterpret_cast<float4*>(crow + 16 * t) = v;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s2 = 0; s2 < KS4; ++s2) xa[s2] = xn[s2];
+  }
+}
+
+static bool launch_k4(const float* A, const RowMap& am, const float* W, const float* bias, float* Cout, int64_t ldc, int M,
+                      int C, int N, int act, hipStream_t st) {
+  if (N != 64 || C != 135 || M < 4096 || (M & 15) || act == 2) return false;
+  if (!ptr_vec_ok(Cout, ldc) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
+  int gx = cdiv(M, 16 * 4 * 4);
+  if (gx > 512) gx = 512;
+  if (am.rows_inner > 0)
+    hipLaunchKernelGGL((gemm_nt_k4_kernel<34, true>), dim3(gx), dim3(256), 0, st, A, am, W, bias, Cout, ldc, M, C, act);
+  else
+    hipLaunchKernelGGL((gemm_nt_k4_kernel<34, false>), dim3(gx), dim3(256), 0, st, A, am, W, bias, Cout, ldc, M, C, act);
+  return true;
+}
+
 // ---- weight gradient: slab[split][n][k] = sum_{m in split} dy[m][n] * xin[m][k] -------------------
 // One workgroup owns a (64*NTW) x 64 block of dW for a contiguous range of rows m, so with N <= 192 every
 // dy / x element is read from HBM exactly once.  Rows are consumed in chunks of TM = 32: the NEXT chunk's global
@@ -541,6 +629,10 @@ extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64
   RowMap am{ldx, rows_inner, stride_outer, stride_inner};
   if (rows_inner == 0 && !x_keep &&
       launch_stream<false>(x, ldx, w, (int64_t)K, bias, y, ldy, M, K, N, act, 0, (hipStream_t)stream)) {
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
+  if (!x_keep && launch_k4(x, am, w, bias, y, ldy, M, K, N, act, (hipStream_t)stream)) {
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }

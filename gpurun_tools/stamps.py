@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gesture2vec_amd", "csrc")
 dbg = os.path.join(root, "gesture2vec_amd", "libg2v_hip.so")
-subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG2V_STAMPS -shared linear.hip vq.hip gru.hip dec_rollout.hip misc.hip -o {dbg}", shell=True)
+subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG2V_STAMPS -shared linear.hip vq.hip gru.hip dec_rollout.hip seq2seq.hip misc.hip -o {dbg}", shell=True)
 import torch, argparse
 from gesture2vec_amd import _lib
 import bench
