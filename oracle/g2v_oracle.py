@@ -393,20 +393,42 @@ def dae_train_step(sd: Dict[str, Tensor], adam_state: dict, x: Tensor, target: T
 # ----------------------------------------------------------------------------------------------
 # Part-d text -> gesture-code seq2seq
 # ----------------------------------------------------------------------------------------------
+def attn_weights(h_top: Tensor, enc_out: Tensor, w_attn: Tensor, b_attn: Tensor, v: Tensor) -> Tensor:
+    """Attn.forward / Attn.score (model/text2embedding_model.py:160-198): energy = tanh(attn([h ; enc_out[t]])),
+    score = v . energy, softmax over ALL Tw positions (padded positions are not masked; their encoder rows are 0).
+    h_top (B,H), enc_out (Tw,B,H) -> weights (B,Tw)."""
+    Tw = enc_out.shape[0]
+    hrep = h_top.unsqueeze(0).expand(Tw, -1, -1)                                          # :177
+    energy = torch.tanh(linear(torch.cat([hrep, enc_out], 2), w_attn, b_attn))            # (Tw,B,H)  :192-194
+    score = (energy * v).sum(2)                                                           # (Tw,B)    :195-198
+    return torch.softmax(score.t(), dim=1)                                                # :180
+
+
 def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tensor, cfg: dict, training: bool,
                 masks: dict) -> Dict[str, Tensor]:
-    """text2embedding_model.forward, discrete codes, EncoderRNN path, attention off
-    (model/text2embedding_model.py:606-746; encoder :126-135; decoder step :338-395).
+    """text2embedding_model.forward, discrete codes, EncoderRNN path
+    (model/text2embedding_model.py:606-746; encoder :126-135; attention :160-198; decoder step :338-395).
 
     ids (B,Tw) int64 word ids (0 = PAD), lengths (B,) sorted descending, codes (B,S) int64 code ids.
-    cfg: n_layers, dropout_prob, n_pre_poses.  masks: 'emb' (S-1,B,H) keep mask of Dropout(0.5) on the code embedding,
-    'dec_l0' (S-1,B,H) decoder GRU inter-layer dropout (both training only).
+    cfg: n_layers, dropout_prob, n_pre_poses, att (bool, autoencoder_att).  masks: 'emb' (S-1,B,H) keep mask of
+    Dropout(0.5) on the code embedding, 'dec_l0' (S-1,B,H) decoder GRU inter-layer dropout, 'enc_l0' (Tw,B,2H) encoder
+    GRU inter-layer dropout in the padded layout (ATen draws it on the packed data; padded rows are zero either way)
+    (all training only).
     Without attention the decoder reads only encoder_hidden[:L] = layer-0 final states (:667-669), so the encoder's
-    inter-layer dropout (drawn on the packed data) cannot influence any output and is not modelled.
+    inter-layer dropout cannot influence any output and is not modelled.  With attention the decoder also reads
+    encoder_outputs = sum of the LAST layer's two directions (:133-135).
     Returns outputs (B,S,K) with outputs[:,0] = one_hot(codes[:,0]) (:676-677)."""
     L, p = cfg["n_layers"], cfg["dropout_prob"]
+    att = bool(cfg.get("att", False))
     x = sd["encoder.embedding.weight"][ids.t()]                                           # (Tw,B,300)  :126
-    _, enc_hidden = bigru(x, sd, "encoder.gru.", L, 0.0, None, lengths)                   # :127-131
+    H = sd["encoder.gru.weight_hh_l0"].shape[1]
+    if att:
+        inter = [masks["enc_l0"]] if (training and p > 0.0 and L > 1) else None
+        enc_cat, enc_hidden = bigru(x, sd, "encoder.gru.", L, p if inter is not None else 0.0, inter, lengths)
+        enc_out = enc_cat[:, :, :H] + enc_cat[:, :, H:]                                   # :133-135
+    else:
+        _, enc_hidden = bigru(x, sd, "encoder.gru.", L, 0.0, None, lengths)               # :127-131
+        enc_out = None
     hidden = enc_hidden[:L]                                                               # :667-669
     pre = "decoder.decoder."
     K = sd[pre + "out.weight"].shape[0]
@@ -416,10 +438,17 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
     S = cod.shape[0]
     outs = [torch.nn.functional.one_hot(cod[0], K).to(x.dtype)]
     dec_in = cod[0]
+    attn_list = []
     for t in range(1, S):                                                                 # :701-744
         e = sd[pre + "embedding.weight"][dec_in]                                          # :340-343
         if training:
             e = dropout_apply(e, masks["emb"][t - 1], 0.5)                                # nn.Dropout(0.5) :253
+        if att:
+            w = attn_weights(hidden[-1], enc_out, sd[pre + "attn.attn.weight"], sd[pre + "attn.attn.bias"],
+                             sd[pre + "attn.v"])                                          # :353-355
+            context = torch.einsum("bt,tbh->bh", w, enc_out)                              # :356-359
+            e = torch.cat([e, context], 1)                                                # :362-364
+            attn_list.append(w)
         u = linear(e, sd[pre + "pre_linear.0.weight"], sd[pre + "pre_linear.0.bias"])
         a, nrm, nrv = batchnorm1d(u, sd[pre + "pre_linear.1.weight"], sd[pre + "pre_linear.1.bias"],
                                   bn["running_mean"], bn["running_var"], training)
@@ -439,7 +468,8 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
         logits = linear(new_h[-1], sd[pre + "out.weight"], sd[pre + "out.bias"])         # :390
         outs.append(logits)
         dec_in = cod[t] if t < cfg["n_pre_poses"] else logits.argmax(1)                   # :734-744
-    return {"outputs": torch.stack(outs).transpose(0, 1), "bn": bn, "encoder_hidden": enc_hidden}
+    return {"outputs": torch.stack(outs).transpose(0, 1), "bn": bn, "encoder_hidden": enc_hidden,
+            "encoder_outputs": enc_out, "attn": attn_list}
 
 
 def t2e_loss(outputs: Tensor, codes: Tensor) -> Tensor:

@@ -21,7 +21,7 @@ def main():
     import model.text2embedding_model as t2e
     t2e.use_TCN = False
     torch.set_num_threads(1)
-    for name, att, p in (("t2e_noatt", "False", 0.2),):
+    for name, att, p in (("t2e_noatt", "False", 0.2), ("t2e_att", "True", 0.2)):
         H, L, K, NW, EMB, S, Tw, B = 32, 2, 64, 120, 300, 6, 12, 16
         args = mf.make_args(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
                             n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True")
@@ -68,6 +68,16 @@ def main():
             for t in range(S - 1):
                 assert np.array_equal(rp[1 + 2 * t].reshape(B, H), fx[f"s{step}/mask_emb"][t]), "RNG replay misaligned"
             fx[f"s{step}/mask_dec_l0"] = np.stack([rp[2 + 2 * t].reshape(B, H) for t in range(S - 1)])
+            # encoder inter-layer mask: packed rows are time-major over the still-valid batch rows (lengths sorted
+            # descending), i.e. packed index of (t, b) = sum_{t' < t} #{lengths > t'} + b.  Padded layout, pads = keep.
+            enc = np.ones((Tw, B, 2 * H), dtype=bool)
+            pk, off = rp[0].reshape(-1, 2 * H), 0
+            for t in range(Tw):
+                nb = int((lengths > t).sum())
+                enc[t, :nb] = pk[off:off + nb]
+                off += nb
+            assert off == pk.shape[0]
+            fx[f"s{step}/mask_enc_l0"] = enc
             fx[f"s{step}/loss"] = np.float64(loss["loss"])
             fx[f"s{step}/outputs"] = cap["outputs"]
             if step == 1:
