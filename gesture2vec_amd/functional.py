@@ -172,3 +172,41 @@ class CrossEntropyFn(torch.autograd.Function):
 
 def cross_entropy(logits, targets):
     return CrossEntropyFn.apply(logits, targets)
+
+
+class AttnFn(torch.autograd.Function):
+    """Bahdanau attention of one decode step (reference Attn :160-198 + context :353-359) given the two halves of the
+    energy pre-activation: hp (B,H) = h W_h^T + b, ep (T,B,H) = enc W_e^T.  Returns (context (B,H), weights (B,T))."""
+
+    @staticmethod
+    def forward(ctx, hp, ep, enc, v):
+        hp, ep, enc, v = hp.contiguous(), ep.contiguous(), enc.contiguous(), v.contiguous()
+        weights, context = ops.attn_fwd(hp, ep, enc, v)
+        ctx.save_for_backward(hp, ep, enc, v, weights)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(weights)
+        return context, weights
+
+    @staticmethod
+    def backward(ctx, g_ctx, _g_w):
+        if g_ctx is None:
+            return None, None, None, None
+        hp, ep, enc, v, weights = ctx.saved_tensors
+        d_hp, d_ep, d_enc, d_v = ops.attn_bwd(g_ctx.contiguous(), hp, ep, enc, v, weights)
+        return d_hp, d_ep, d_enc, d_v
+
+
+class SumHalvesFn(torch.autograd.Function):
+    """out = a + b (the two GRU directions, :133-135); the gradient goes unchanged to both."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        H = a.shape[-1]
+        out = torch.empty_like(a)
+        ops.add_halves(a, H, b, H, out, H, a.numel() // H, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g

@@ -7,8 +7,8 @@ state_dict keys.  Every operator is a HIP kernel behind include/g2v.h, chained b
 
 Module-level switches of the reference (:40-43) are all False here: `use_TCN = True` as checked in makes the
 reference's forward crash, `audio_context`, `noisy`, `GPT3_embedding_active` select out-of-scope
-encoders.  Scope this round: text2_embedding_discrete == "True", autoencoder_att == "False" (config/seq2seq.yml:27);
-the Bahdanau attention variant (seq2seqtxt.yml) raises NotImplementedError."""
+encoders.  Scope: text2_embedding_discrete == "True"; autoencoder_att == "False" (config/seq2seq.yml:27) and "True"
+(config/seq2seqtxt.yml:37, Bahdanau attention `Attn` :138-198 through g2v_attn_fwd / g2v_attn_bwd)."""
 from __future__ import annotations
 
 import math
@@ -45,10 +45,13 @@ class EncoderRNN(nn.Module):
         self.gru = _GRUParams(embed_size, hidden_size, n_layers, dropout=dropout, bidirectional=True)
         self.do_flatten_parameters = False
 
-    def forward(self, input_seqs: torch.Tensor, input_lengths: torch.Tensor, hidden=None, n_layers_needed: Optional[int] = None):
+    def forward(self, input_seqs: torch.Tensor, input_lengths: torch.Tensor, hidden=None, n_layers_needed: Optional[int] = None,
+                keep_inter: Optional[torch.Tensor] = None):
         """(Tw,B) ids + lengths (sorted descending) -> outputs (Tw,B,H) [sum of the LAST evaluated layer's directions],
         hidden (2*layers_evaluated, B, H) ordered l0f,l0b,l1f,l1b.  `n_layers_needed` lets the caller skip layers whose
-        result it never reads (the attention-free decoder only needs layer 0)."""
+        result it never reads (the attention-free decoder only needs layer 0).  `keep_inter` (Tw,B,2H) uint8 is the
+        keep mask of nn.GRU's inter-layer dropout (training, dropout > 0; fused into the next layer's input product;
+        ATen draws it on the packed rows, padded rows are zero either way)."""
         if hidden is not None:
             raise NotImplementedError("non-zero initial hidden state")
         Tw, B = input_seqs.shape
@@ -59,11 +62,13 @@ class EncoderRNN(nn.Module):
         x = Fn.EmbeddingFn.apply(self.embedding.weight, input_seqs.contiguous().view(-1), None, 1.0)   # (Tw*B, E)
         hiddens, layer_in = [], x
         out_f = out_b = None
+        keep, scale = None, 1.0
         for l in range(L):
             outs = []
             for suf, rev in (("", False), ("_reverse", True)):
                 g = self.gru
-                gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"))
+                gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
+                               keep=keep, scale=scale)
                 hs, h_n = Fn.GRUDirFn.apply(gi.view(Tw, B, 3 * H), getattr(g, f"weight_hh_l{l}{suf}"),
                                             getattr(g, f"bias_hh_l{l}{suf}"), None, lengths, rev)
                 outs.append(hs)
@@ -71,16 +76,42 @@ class EncoderRNN(nn.Module):
             out_f, out_b = outs
             if l + 1 < L:
                 cat = torch.cat([out_f, out_b], dim=2).view(Tw * B, 2 * H)       # layout only
-                layer_in = cat                                                    # (inter-layer dropout: see class doc)
-        outputs = torch.empty((Tw, B, H), dtype=torch.float32, device=dev)
-        ops.add_halves(out_f.detach().contiguous(), H, out_b.detach().contiguous(), H, outputs, H, Tw * B, H)
+                layer_in = cat
+                if self.training and self.dropout > 0 and keep_inter is not None:
+                    keep, scale = keep_inter.contiguous().view(Tw * B, 2 * H), 1.0 / (1.0 - self.dropout)
+        outputs = Fn.SumHalvesFn.apply(out_f, out_b)                              # :133-135
         return outputs, torch.stack(hiddens)
 
 
 class Attn(nn.Module):
+    """Reference `Attn` (:138-198): parameters `attn` = Linear(2H -> H) and `v` (H); forward(hidden (B,H),
+    encoder_outputs (T,B,H)) -> softmax attention weights (B,1,T)."""
+
     def __init__(self, hidden_size: int):
         super().__init__()
-        raise NotImplementedError("Bahdanau attention (autoencoder_att == 'True') is not on the accelerated path yet")
+        self.hidden_size = hidden_size
+        self.attn = nn.Linear(hidden_size * 2, hidden_size)
+        self.v = nn.Parameter(torch.rand(hidden_size))
+        stdv = 1.0 / math.sqrt(self.v.size(0))
+        self.v.data.normal_(mean=0, std=stdv)
+
+    def project_encoder(self, encoder_outputs: torch.Tensor) -> torch.Tensor:
+        """ep = enc W_attn[:, H:]^T (T,B,H): the step-independent half of the energy pre-activation."""
+        H = self.hidden_size
+        T, B, _ = encoder_outputs.shape
+        return Fn.linear(encoder_outputs.reshape(T * B, H), self.attn.weight[:, H:]).view(T, B, H)
+
+    def context(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor, enc_proj: Optional[torch.Tensor] = None):
+        """(context (B,H), weights (B,T)) for decoder state `hidden` (B,H)."""
+        H = self.hidden_size
+        if enc_proj is None:
+            enc_proj = self.project_encoder(encoder_outputs)
+        hp = Fn.linear(hidden, self.attn.weight[:, :H], self.attn.bias)
+        return Fn.AttnFn.apply(hp, enc_proj, encoder_outputs, self.v)
+
+    def forward(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor) -> torch.Tensor:
+        _, w = self.context(hidden, encoder_outputs)
+        return w.unsqueeze(1)
 
 
 class BahdanauAttnDecoderRNN(nn.Module):
@@ -95,21 +126,34 @@ class BahdanauAttnDecoderRNN(nn.Module):
             raise NotImplementedError("speaker embedding is outside the accelerated hot path")
         self.embedding = nn.Embedding(output_size, hidden_size)
         self.dropout = nn.Dropout(0.5)
-        if args.autoencoder_att == "True":
+        self.att_use = args.autoencoder_att == "True"
+        if self.att_use:
             self.attn = Attn(hidden_size)
-        self.att_use = False
-        self.pre_linear = nn.Sequential(nn.Linear(hidden_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
+        linear_input_size = 2 * hidden_size if self.att_use else hidden_size          # :277-281
+        self.pre_linear = nn.Sequential(nn.Linear(linear_input_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
         self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout_p)
         self.out = nn.Linear(hidden_size, output_size)
         self.softmax = nn.Softmax(dim=1)
         self.do_flatten_parameters = False
 
-    def forward(self, motion_input, last_hidden, encoder_outputs=None, vid_indices=None, keep_emb=None, keep_l0=None):
-        """One decode step: code ids (B,) + hidden (L,B,H) -> logits (B,K), new hidden (L,B,H), None."""
+    def freeze_attn(self) -> None:
+        for param in self.attn.parameters():
+            param.requires_grad = False
+
+    def forward(self, motion_input, last_hidden, encoder_outputs=None, vid_indices=None, keep_emb=None, keep_l0=None,
+                enc_proj=None):
+        """One decode step: code ids (B,) + hidden (L,B,H) [+ encoder outputs (T,B,H) with attention] -> logits (B,K),
+        new hidden (L,B,H), attention weights (B,1,T) or None.  `enc_proj` = Attn.project_encoder(encoder_outputs)
+        may be passed in so that the S-1 steps share it."""
         B = motion_input.shape[0]
         H, L = self.hidden_size, self.n_layers
         training = self.training
         e = Fn.EmbeddingFn.apply(self.embedding.weight, motion_input, keep_emb if training else None, 2.0)   # Dropout(0.5)
+        attn_weights = None
+        if self.att_use:
+            context, w = self.attn.context(last_hidden[-1], encoder_outputs, enc_proj)     # :353-359
+            e = torch.cat((e, context), 1)                                                 # :362-364 (layout only)
+            attn_weights = w.unsqueeze(1)
         lin, bn = self.pre_linear[0], self.pre_linear[1]
         u = Fn.linear(e, lin.weight, lin.bias)
         a = Fn.BatchNormReluFn.apply(u, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, True)
@@ -126,7 +170,7 @@ class BahdanauAttnDecoderRNN(nn.Module):
             if training and self.dropout_p > 0 and keep_l0 is not None:
                 keep, scale = keep_l0, 1.0 / (1.0 - self.dropout_p)      # nn.GRU inter-layer dropout, fused into the next Linear
         logits = Fn.linear(new_h[-1], self.out.weight, self.out.bias)
-        return logits, torch.stack(new_h), None
+        return logits, torch.stack(new_h), attn_weights
 
 
 class Generator(nn.Module):
@@ -164,9 +208,10 @@ class text2embedding_model(nn.Module):
         self._rng_counter = None
         self.rng_seed = 0
 
-    def set_dropout_masks(self, mask_emb, mask_dec_l0=None):
-        """Explicit keep masks for the next training forward: (S-1,B,H) each (parity tests)."""
-        self._masks = (mask_emb, mask_dec_l0)
+    def set_dropout_masks(self, mask_emb, mask_dec_l0=None, mask_enc_l0=None):
+        """Explicit keep masks for the next training forward (parity tests): (S-1,B,H) for the code-embedding dropout and
+        the decoder GRU inter-layer dropout, (Tw,B,2H) for the encoder GRU inter-layer dropout (attention only)."""
+        self._masks = (mask_emb, mask_dec_l0, mask_enc_l0)
 
     def _draw(self, shape, keep_prob, dev):
         if self._rng_counter is None or self._rng_counter.device != dev:
@@ -184,21 +229,37 @@ class text2embedding_model(nn.Module):
         S_model = self.sentence_frame_length // self.n_frames
         B, K, H, L = cod.shape[1], self.pose_dim, self.encoder.hidden_size, self.n_layers
         training = self.training
-        # the attention-free decoder reads only encoder_hidden[:L] = the layer-0 final states (:667-669)
-        _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1)
+        att = self.decoder.decoder.att_use
+        Tw = ids.shape[0]
+        mask_emb = mask_l0 = mask_enc = None
+        if training:
+            if self._masks is not None:
+                mask_emb, mask_l0, mask_enc = self._masks
+            else:
+                mask_emb = self._draw((S_model - 1, B, H), 0.5, dev)
+                if self.dropout_prob > 0:
+                    mask_l0 = self._draw((S_model - 1, B, H), 1.0 - self.dropout_prob, dev)
+                    if att and L > 1:
+                        mask_enc = self._draw((Tw, B, 2 * H), 1.0 - self.dropout_prob, dev)
+        if att:
+            # attention reads encoder_outputs = sum of the LAST layer's directions (:133-135): every layer is evaluated
+            enc_out, enc_hidden = self.encoder(ids, in_lengths, None, keep_inter=mask_enc)
+            enc_proj = self.decoder.decoder.attn.project_encoder(enc_out)
+        else:
+            # the attention-free decoder reads only encoder_hidden[:L] = the layer-0 final states (:667-669)
+            _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1)
+            enc_out = enc_proj = None
         hidden = enc_hidden[:L]
         outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
         dec_in = cod[0]
-        if training:
-            if self._masks is not None:
-                mask_emb, mask_l0 = self._masks
-            else:
-                mask_emb = self._draw((S_model - 1, B, H), 0.5, dev)
-                mask_l0 = self._draw((S_model - 1, B, H), 1.0 - self.dropout_prob, dev) if self.dropout_prob > 0 else None
+        attentions_list = []
         for t in range(1, S_model):                                                    # :701-744
             ke = mask_emb[t - 1].contiguous() if training else None
             kl = mask_l0[t - 1].contiguous() if (training and mask_l0 is not None) else None
-            logits, hidden, _ = self.decoder(None, dec_in, hidden, None, None, keep_emb=ke, keep_l0=kl)
+            logits, hidden, attn_w = self.decoder(None, dec_in, hidden, enc_out, None, keep_emb=ke, keep_l0=kl,
+                                                  enc_proj=enc_proj)
+            if att:
+                attentions_list.append(attn_w)
             outs.append(logits)
             dec_in = cod[t] if t < self.n_pre_poses else ops.argmax_rows(logits.detach().contiguous())
-        return torch.stack(outs).transpose(0, 1), []
+        return torch.stack(outs).transpose(0, 1), attentions_list

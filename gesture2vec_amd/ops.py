@@ -382,3 +382,29 @@ def argmax_rows(x):
     out = torch.empty((M,), dtype=torch.int64, device=x.device)
     check(_lib_().g2v_argmax_rows(_p(_chk(x)), K, _p(out), M, K, _stream()), "argmax_rows")
     return out
+
+
+def attn_fwd(hp, ep, enc, v, ctx_out=None, ldctx=None):
+    """Bahdanau attention step: hp (B,H), ep/enc (T,B,H), v (H) -> weights (B,T), context (B,H) (optionally written
+    into `ctx_out` with row stride ldctx, e.g. the second half of the decoder's (B,2H) input)."""
+    T, B, H = enc.shape
+    weights = torch.empty((B, T), dtype=torch.float32, device=enc.device)
+    if ctx_out is None:
+        ctx_out, ldctx = torch.empty((B, H), dtype=torch.float32, device=enc.device), H
+    check(_lib_().g2v_attn_fwd(_p(_chk(hp)), _p(_chk(ep)), _p(_chk(enc)), _p(_chk(v)), _p(weights), ctx_out.data_ptr(),
+                               ldctx, T, B, H, _stream()), "attn_fwd")
+    return weights, ctx_out
+
+
+def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None):
+    T, B, H = enc.shape
+    dev = enc.device
+    d_hp = torch.empty((B, H), dtype=torch.float32, device=dev)
+    d_ep = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+    d_enc = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+    d_v = torch.empty((H,), dtype=torch.float32, device=dev)
+    nb = _lib_().g2v_attn_bwd_workspace(B, H)
+    ws = workspace(nb, dev, "attn")
+    check(_lib_().g2v_attn_bwd(d_ctx.data_ptr(), ldd if ldd is not None else H, _p(hp), _p(ep), _p(enc), _p(v), _p(weights),
+                               _p(d_hp), _p(d_ep), _p(d_enc), _p(d_v), 0, T, B, H, _p(ws), ws.numel(), _stream()), "attn_bwd")
+    return d_hp, d_ep, d_enc, d_v

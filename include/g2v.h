@@ -283,6 +283,26 @@ int g2v_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* ta
 int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, int K, g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Bahdanau attention of the code decoder (autoencoder_att == "True", config/seq2seqtxt.yml:37):
+ * Attn.forward / Attn.score (model/text2embedding_model.py:160-198) + the context product :353-359.
+ *   energy[t,b,:] = tanh(attn([h_b ; enc[t,b,:]])) = tanh(hp[b,:] + ep[t,b,:]) with
+ *     hp (B,H) = h W_attn[:, :H]^T + b_attn   (g2v_linear_fwd, once per decode step)
+ *     ep (T,B,H) = enc W_attn[:, H:]^T        (g2v_linear_fwd, once per batch of sentences)
+ *   weights[b,:] = softmax_t( v . energy[t,b,:] )  over ALL T positions (no padding mask, as in the reference)
+ *   ctx[b,:]     = sum_t weights[b,t] * enc[t,b,:]           (written with row stride ldctx, e.g. into the second
+ *                                                              half of the (B,2H) decoder input)
+ * g2v_attn_bwd: from d_ctx (row stride ldd) computes d_hp (B,H), d_ep (T,B,H), d_enc (T,B,H) [the direct context
+ * term only; the ep path continues through g2v_linear_bwd_data] and d_v (H); accumulate != 0 adds into d_ep / d_enc /
+ * d_v (the S-1 decode steps share them).  Deterministic (fixed summation order, no atomics).
+ * ------------------------------------------------------------------------------------------ */
+int g2v_attn_fwd(const float* hp, const float* ep, const float* enc, const float* v, float* weights, float* ctx,
+                 int64_t ldctx, int T, int B, int H, g2v_stream_t stream);
+size_t g2v_attn_bwd_workspace(int B, int H);
+int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, const float* ep, const float* enc, const float* v,
+                 const float* weights, float* d_hp, float* d_ep, float* d_enc, float* d_v, int accumulate, int T, int B,
+                 int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Keep-mask generator: keep[i] = (philox4x32-10(seed, offset_counter, i) uniform < keep_prob).
  * Replaces the RNG draws of nn.Dropout / nn.GRU dropout on the path (e.g. :570).  offset_counter is a
  * device int64 that the call advances by 1 (so graph replays draw fresh masks).

@@ -12,18 +12,19 @@ DEV = "cuda:0"
 
 def relerr(got, ref):
     got = got.detach().cpu().double().reshape(-1)
-    ref = torch.as_tensor(ref).double().reshape(-1)
+    ref = torch.as_tensor(ref).detach().double().reshape(-1)
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
 
 
-def test_text2embedding_matches_reference_golden(golden_dir):
+@pytest.mark.parametrize("name,att", [("t2e_noatt", "False"), ("t2e_att", "True")])
+def test_text2embedding_matches_reference_golden(golden_dir, name, att):
     from gesture2vec_amd.flat import FlatClipAdam
     from gesture2vec_amd.model.text2embedding_model import text2embedding_model
     from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
-    fx = np.load(os.path.join(golden_dir, "t2e_noatt.npz"))
+    fx = np.load(os.path.join(golden_dir, name + ".npz"))
     B, Tw, S, H, L, K, NW, EMB = [int(v) for v in fx["cfg"]]
     p, lr = [float(v) for v in fx["cfg_f"]]
-    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att="False",
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
                               n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
                               autoencoder_conditioned="True", autoencoder_fixed_weight="False")
     net = text2embedding_model(args, 135, 20, NW, EMB, np.zeros((NW, EMB), dtype=np.float32), None)
@@ -37,7 +38,8 @@ def test_text2embedding_matches_reference_golden(golden_dir):
     codes = torch.from_numpy(fx["codes"].copy()).to(DEV)
     for step in (1, 2):
         net.set_dropout_masks(torch.from_numpy(fx[f"s{step}/mask_emb"].copy()).to(DEV),
-                              torch.from_numpy(fx[f"s{step}/mask_dec_l0"].copy()).to(DEV))
+                              torch.from_numpy(fx[f"s{step}/mask_dec_l0"].copy()).to(DEV),
+                              torch.from_numpy(fx[f"s{step}/mask_enc_l0"].copy()).to(DEV).to(torch.uint8))
         outputs_ref = fx[f"s{step}/outputs"]
         loss = train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
         assert abs(loss["loss"] - float(fx[f"s{step}/loss"])) <= 1e-5 * float(fx[f"s{step}/loss"]), (loss, float(fx[f"s{step}/loss"]))
@@ -63,8 +65,38 @@ def test_text2embedding_matches_reference_golden(golden_dir):
                 assert torch.equal(got, ref), n
     net.train(False)
     with torch.no_grad():
-        out, att = net(ids, lengths, None, codes, None, None)
-    assert out.shape == (B, S, K) and att == []
+        out, attn_list = net(ids, lengths, None, codes, None, None)
+    assert out.shape == (B, S, K)
+    if att == "True":
+        assert len(attn_list) == S - 1 and attn_list[0].shape == (B, 1, Tw)
+        assert float((attn_list[0].sum(2) - 1).abs().max()) < 1e-5
+    else:
+        assert attn_list == []
     assert relerr(out, fx["eval/outputs"]) < 1e-4
     # greedy codes of the eval rollout are exactly the reference's
     assert np.array_equal(out[:, 1:].argmax(2).cpu().numpy(), fx["eval/outputs"][:, 1:].argmax(2))
+
+
+def test_attention_op_matches_torch_reference():
+    """g2v_attn_fwd / g2v_attn_bwd vs the plain torch fp32 formula (reference Attn :160-198 + context :353-359), at a
+    ragged shape (H not a multiple of 64, B not a multiple of 4)."""
+    from gesture2vec_amd import functional as Fn
+    torch.manual_seed(5)
+    T, B, H = 11, 37, 40
+    hp = torch.randn(B, H, device=DEV, requires_grad=True)
+    ep = torch.randn(T, B, H, device=DEV, requires_grad=True)
+    enc = torch.randn(T, B, H, device=DEV, requires_grad=True)
+    v = torch.randn(H, device=DEV, requires_grad=True)
+    ctx, w = Fn.AttnFn.apply(hp, ep, enc, v)
+    g = torch.randn(B, H, device=DEV)
+    (ctx * g).sum().backward()
+    got = [t.grad.clone() for t in (hp, ep, enc, v)]
+    ref_in = [t.detach().clone().cpu().double().requires_grad_(True) for t in (hp, ep, enc, v)]
+    hp2, ep2, enc2, v2 = ref_in
+    score = (torch.tanh(hp2.unsqueeze(0) + ep2) * v2).sum(2)            # (T,B)
+    w2 = torch.softmax(score.t(), 1)
+    ctx2 = torch.einsum("bt,tbh->bh", w2, enc2)
+    (ctx2 * g.cpu().double()).sum().backward()
+    assert relerr(w, w2) < 1e-5 and relerr(ctx, ctx2) < 1e-5
+    for a, b2, n in zip(got, ref_in, ("hp", "ep", "enc", "v")):
+        assert relerr(a, b2.grad) < 2e-5, (n, relerr(a, b2.grad))
