@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the data-parallel code path (split graphs + RCCL all-reduce) even with one rank (diagnostic)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,9 +132,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dp = world > 1 or a.force_dp
+    if use_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # "nccl" is RCCL on ROCm
 
     from gesture2vec_amd import _lib
@@ -149,59 +153,85 @@ def main():
     x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)   # rank-dependent shard
 
     reduce_fn = None
-    if world > 1:
+    if use_dp:
         from gesture2vec_amd.dp import GradStatsAllReduce, broadcast_state
         vq = net.vq_layer
         broadcast_state([eng.flat, vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size,
                          vq.pre_linear.weight.data, vq.pre_linear.bias.data])
         reduce_fn = GradStatsAllReduce()        # ONE RCCL all-reduce of [grads | EMA stats] per step
 
+    kw = dict(w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], epoch=1, draw_masks=True)
+
+    def local():
+        eng.train_step_local(x, x, dp=use_dp, **kw)
+
+    def apply():
+        eng.train_step_apply(B, lr=CFG["lr"], world=world, dp=use_dp)
+
     def step():
-        eng.train_step(x, x, lr=CFG["lr"], w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], epoch=1,
-                       draw_masks=True, reduce_fn=reduce_fn, world=world)
+        local()
+        if use_dp:
+            reduce_fn(eng.comm)
+        apply()
 
     def barrier():
-        if world > 1:
+        if use_dp:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
 
     # untimed warm-up (also sizes every workspace so that addresses are final before capture)
     for _ in range(max(a.warmup, 2)):
         step()
     torch.cuda.synchronize()
     graph = None
-    if not a.no_graph and world == 1:
+    run = step
+    if not a.no_graph:
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                step()
-            torch.cuda.current_stream().wait_stream(side)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                step()
-            graph = g
+            if use_dp:
+                # two hipGraphs around the exchange: [masks..backward]  ->  RCCL all-reduce(comm)  ->  [EMA + clip/Adam]
+                g_local, g_apply = capture(local), capture(apply)
+
+                def run():
+                    g_local.replay()
+                    reduce_fn(eng.comm)
+                    g_apply.replay()
+                graph = (g_local, g_apply)
+            else:
+                g_step = capture(step)
+                run = g_step.replay
+                graph = g_step
             for _ in range(2):
-                graph.replay()
+                run()
             torch.cuda.synchronize()
         except Exception as e:   # capture is an optimisation, never a correctness requirement
             print(f"[bench] hipGraph capture unavailable ({type(e).__name__}: {e}); timing eager launches", file=sys.stderr)
-            graph = None
+            graph, run = None, step
 
-    run = graph.replay if graph is not None else step
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         run()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = eng.loss_terms[0].item() + eng.vq_scalars[0].item() / 400
     assert loss == loss, "loss is NaN"
 
+    out = None
     if rank == 0:
         out = {
             "metric": "gesture-chunks/sec VQ-VAE fwd+bwd (T=34,D=135,K=512)", "value": round(B * world * a.steps / dt, 1),
@@ -213,17 +243,26 @@ def main():
                                    "dropout_prob=0 (+ always-on Dropout(0.95)), Adam lr=5e-4, random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "launch": "hipGraph replay" if graph is not None else "eager launches",
+                       "launch": ("eager launches" if graph is None else
+                                  "2 hipGraph replays around one RCCL all-reduce" if use_dp else "hipGraph replay"),
                        "final_loss": round(loss, 6)},
         }
         if world == 1:
             out["roofline"] = vq_kernel_roofline(eng, B)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dp:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL prints its version banner through C stdio, which is flushed at exit: flush it now so that the JSON line
+        # is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

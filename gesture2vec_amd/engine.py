@@ -359,15 +359,27 @@ class VQVAEEngine:
                    w_var: float, epoch: int = 1, draw_masks: bool = True, reduce_fn=None, world: int = 1):
         """train_iter_Autoencoder_VQ_seq2seq (train_eval/train_seq2seq.py:664-758) without host syncs.
         reduce_fn(comm) performs the data-parallel SUM all-reduce (RCCL) of [grads | EMA stats] when world > 1."""
+        dp = reduce_fn is not None and world > 1
+        self.train_step_local(x, target, w_l1=w_l1, w_cont=w_cont, w_var=w_var, epoch=epoch, draw_masks=draw_masks, dp=dp)
+        if dp:
+            reduce_fn(self.comm)
+        self.train_step_apply(x.shape[0], lr=lr, world=world, dp=dp)
+
+    # The two halves around the data-parallel exchange.  Each is a fixed kernel sequence with no host sync, so each can
+    # be captured in its own hipGraph; the RCCL all-reduce of `comm` runs between the two replays.
+    def train_step_local(self, x: torch.Tensor, target: torch.Tensor, *, w_l1: float, w_cont: float, w_var: float,
+                         epoch: int = 1, draw_masks: bool = True, dp: bool = False):
+        """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
         if draw_masks:
             self.draw_masks(B, True)
-        dp = reduce_fn is not None and world > 1
         self.forward(x, target, True, ema_update=not dp)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)
+
+    def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False):
+        """(after the all-reduce) EMA codebook update from the GLOBAL statistics, then clip + Adam on the averaged grads."""
         if dp:
-            reduce_fn(self.comm)
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, grad_scale=1.0 / world if dp else 1.0)

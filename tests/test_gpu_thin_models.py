@@ -121,3 +121,61 @@ def test_vector_quantizer_ema_matches_reference_golden(golden_dir):
     sd = q.state_dict()
     for k in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
         assert relerr(sd[k], fx[f"vqema/w1/{k}"]) < 2e-5, k
+
+
+def _vq_args(D, H, L, K):
+    import argparse
+    return argparse.Namespace(rep_learning_dim=D, hidden_size=H, n_layers=L, dropout_prob=0.0, autoencoder_vq="True",
+                              autoencoder_vae="False", autoencoder_vq_components=K, autoencoder_vq_commitment_cost=0.25,
+                              autoencoder_conditioned="True", autoencoder_att="False", autoencoder_fixed_weight="False",
+                              n_pre_poses=1, n_poses=34)
+
+
+def test_bulk_code_assignment_matches_oracle():
+    """§8f-2: N chunks -> latents -> codes in one encoder pass + one assign launch; oracle: the reference's per-chunk
+    route (encoder with batch 1, [l0;l1] row, argmin of distances on pre_linear(row))."""
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.pipeline import chunks_to_codes
+    from oracle import g2v_oracle as O
+    torch.manual_seed(11)
+    D, H, L, K, T, N = 40, 64, 2, 128, 20, 67
+    net = Autoencoder_VQVAE(_vq_args(D, H, L, K), D, T).to(DEV)
+    net.train(False)
+    chunks = torch.randn(N, T, D)
+    lat, codes = chunks_to_codes(net, chunks.to(DEV))
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    _, hidden = O.encoder_forward(chunks.transpose(0, 1), sd, L, 0.0, None)
+    lat_ref = hidden[:L].transpose(0, 1).reshape(N, L * H)
+    assert relerr(lat, lat_ref) < 2e-5
+    flat = O.linear(lat_ref, sd["vq_layer.pre_linear.weight"], sd["vq_layer.pre_linear.bias"])
+    d = O.vq_distances(flat, sd["vq_layer._embedding.weight"])
+    top2 = d.topk(2, dim=1, largest=False)
+    clear = (top2.values[:, 1] - top2.values[:, 0]) > 1e-3 * top2.values[:, 1].abs()
+    assert clear.sum() > N // 2
+    assert torch.equal(codes.cpu()[clear], top2.indices[:, 0][clear])     # bit-exact wherever the decision is not a near-tie
+
+
+def test_stacked_dae_vqvae_dae_matches_oracle():
+    """Config 3: raw (B,T,135) -> DAE encoder -> VQ-VAE(D=40) -> DAE decoder, eval mode with replayed Dropout(0.95) masks."""
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.model.DAE_model import DAE_Network
+    from gesture2vec_amd.pipeline import stacked_autoencode
+    from oracle import g2v_oracle as O
+    torch.manual_seed(12)
+    B, T, DR, D, H, L, K = 24, 34, 135, 40, 64, 2, 64
+    dae = DAE_Network(DR, D).to(DEV)
+    dae.train(False)
+    net = Autoencoder_VQVAE(_vq_args(D, H, L, K), D, T).to(DEV)
+    net.train(False)
+    x = torch.randn(B, T, DR)
+    keep95 = (torch.rand(T - 1, B, D) < 0.05)                 # Dropout(0.95) keeps 5 %
+    net.set_dropout_masks(keep95=keep95.to(DEV).to(torch.uint8))
+    rec, lat_out, _ = stacked_autoencode(dae, net, x.to(DEV))
+    dsd = {k: v.detach().cpu() for k, v in dae.state_dict().items()}
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    lat = torch.relu(O.linear(x.reshape(B * T, DR), dsd["encoder.0.weight"], dsd["encoder.0.bias"])).view(B, T, D)
+    cfg = dict(n_layers=L, dropout_prob=0.0, n_pre_poses=1, commitment_cost=0.25, decay=0.85, epsilon=1e-5)
+    fw = O.vqvae_forward(sd, lat, lat, cfg, False, {"dec": keep95})
+    rec_ref = O.linear(fw["outputs"].reshape(B * T, D), dsd["decoder.0.weight"], dsd["decoder.0.bias"]).view(B, T, DR)
+    assert relerr(lat_out, fw["outputs"]) < 1e-4
+    assert relerr(rec, rec_ref) < 1e-4
