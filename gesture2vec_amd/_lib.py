@@ -88,6 +88,10 @@ _SIGS = {
     "g2v_batchnorm_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_cross_entropy_fwd_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_f, c_fp]),
     "g2v_argmax_rows": (c_int, [c_fp, c_i64, c_fp, c_int, c_int, c_fp]),
+    "g2v_vq_soft_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_vq_soft_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_rowscale_combine": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp]),
+    "g2v_ste_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     "g2v_attn_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp]),
     "g2v_attn_bwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_attn_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,

@@ -575,6 +575,117 @@ __global__ void vq_codebook_grad_kernel(const float* __restrict__ stats, const f
   }
 }
 
+
+// ---- soft quantiser VQ_Payam_GSSoft (reference :1304-1438) ----------------------------------------------------------
+// One wave per row n.  dots[n,k] = flat_n . W_k comes from the dense-layer kernel; here
+//   d = |flat_n|^2 + |W_k|^2 - 2 dots,  smooth = 1 / exp(logvar)^2,
+//   prob = exp(-(d / 400) * (0.5 * smooth)) / sqrt(smooth),  probs = prob / sum_k prob          (:1349-1372, :1396-1411)
+// `dots` is overwritten with d (kept for the backward).
+__global__ __launch_bounds__(256) void vq_soft_fwd_kernel(const float* __restrict__ flat, float* __restrict__ dots,
+                                                          const float* __restrict__ logvar,
+                                                          const float* __restrict__ wsq, float* __restrict__ probs,
+                                                          int N, int E, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float fs = 0.f;
+  for (int e = lane; e < E; e += 64) {
+    const float v = flat[(int64_t)n * E + e];
+    fs += v * v;
+  }
+  fs = wave_sum(fs);
+  float sum = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const int64_t o = (int64_t)n * K + k;
+    const float d = (fs + wsq[k]) - 2.0f * dots[o];
+    const float ex = expf(logvar[o]);
+    const float smooth = 1.0f / (ex * ex);
+    const float pr = expf(-((d / 400.0f) * (0.5f * smooth))) / sqrtf(smooth);
+    dots[o] = d;
+    probs[o] = pr;
+    sum += pr;
+  }
+  sum = wave_sum(sum);
+  for (int k = lane; k < K; k += 64) probs[(int64_t)n * K + k] /= sum;
+}
+
+// Backward of the map (d, logvar) -> probs for one row per wave:
+//   g_k = p_k (dp_k - sum_j dp_j p_j)        [d log(prob_k)]
+//   log prob_k = -d_k s_k / 800 + logvar_k,  s_k = exp(-2 logvar_k)
+//   dd_k = -g_k s_k / 800 ;  dlogvar_k = g_k (1 + d_k s_k / 400) ;  rowsum[n] = sum_k dd_k
+__global__ __launch_bounds__(256) void vq_soft_bwd_kernel(const float* __restrict__ probs, const float* __restrict__ dprobs,
+                                                          const float* __restrict__ dist, const float* __restrict__ logvar,
+                                                          float* __restrict__ dd, float* __restrict__ dlogvar,
+                                                          float* __restrict__ rowsum, int N, int K) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float dot = 0.f;
+  for (int k = lane; k < K; k += 64) dot += dprobs[(int64_t)n * K + k] * probs[(int64_t)n * K + k];
+  dot = wave_sum(dot);
+  float rs = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const int64_t o = (int64_t)n * K + k;
+    const float g = probs[o] * (dprobs[o] - dot);
+    const float ex = expf(logvar[o]);
+    const float s_ = 1.0f / (ex * ex);
+    const float v = -g * s_ / 800.0f;
+    dd[o] = v;
+    dlogvar[o] = g * (1.0f + dist[o] * s_ / 400.0f);
+    rs += v;
+  }
+  rs = wave_sum(rs);
+  if (lane == 0) rowsum[n] = rs;
+}
+
+// out[r,c] = 2 * A[r,c] * v[r] - 2 * T[r,c]    (the two gradients of d = |f|^2 + |W|^2 - 2 f.W)
+__global__ __launch_bounds__(256) void rowscale_combine_kernel(const float* __restrict__ A, const float* __restrict__ v,
+                                                               const float* __restrict__ Tm, float* __restrict__ out,
+                                                               int64_t rows, int cols) {
+  const int64_t total = rows * cols;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t r = e / cols;
+    out[e] = 2.0f * A[e] * v[r] - 2.0f * Tm[e];
+  }
+}
+
+// perplexity of the mean assignment: avg_k = mean_n probs[n,k]; exp(-sum_k avg_k log(avg_k + 1e-10))   (:1432-1433)
+// One workgroup, fixed summation order (column k is summed by thread k % 1024 over n = 0..N-1).
+__global__ __launch_bounds__(1024) void vq_soft_perplexity_kernel(const float* __restrict__ probs, float* __restrict__ out,
+                                                                  int N, int K) {
+  __shared__ float red[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float ent = 0.f;
+  for (int k = tid; k < K; k += 1024) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int n = 0;
+    for (; n + 3 < N; n += 4) {
+      s0 += probs[(int64_t)n * K + k];
+      s1 += probs[(int64_t)(n + 1) * K + k];
+      s2 += probs[(int64_t)(n + 2) * K + k];
+      s3 += probs[(int64_t)(n + 3) * K + k];
+    }
+    for (; n < N; ++n) s0 += probs[(int64_t)n * K + k];
+    const float avg = ((s0 + s1) + (s2 + s3)) / (float)N;
+    ent += avg * logf(avg + 1e-10f);
+  }
+  ent = wave_sum(ent);
+  if (lane == 0) red[wave] = ent;
+  __syncthreads();
+  if (tid == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    out[0] = expf(-s);
+  }
+}
+
+// straight-through value z + (q - z) exactly as the reference evaluates it (:1431)
+__global__ __launch_bounds__(256) void ste_kernel(const float* __restrict__ z, const float* __restrict__ q,
+                                                  float* __restrict__ out, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256)
+    out[e] = z[e] + (q[e] - z[e]);
+}
+
 }  // namespace g2v
 
 using namespace g2v;
@@ -697,6 +808,51 @@ extern "C" int g2v_vq_bwd(const float* g_quantized, const float* g_loss, const f
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(vq_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g_quantized, g_loss, z, codebook,
                      idx, gz, total, E, coef);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_soft_fwd(const float* flat, float* dots_to_dist, const float* logvar, const float* code_sqnorm,
+                               float* probs, float* perplexity, int N, int E, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(flat && dots_to_dist && logvar && code_sqnorm && probs, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  hipLaunchKernelGGL(vq_soft_fwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, flat, dots_to_dist, logvar,
+                     code_sqnorm, probs, N, E, K);
+  G2V_CHECK_LAUNCH();
+  if (perplexity) {
+    hipLaunchKernelGGL(vq_soft_perplexity_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, probs, perplexity, N, K);
+    G2V_CHECK_LAUNCH();
+  }
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_soft_bwd(const float* probs, const float* dprobs, const float* dist, const float* logvar, float* dd,
+                               float* dlogvar, float* rowsum, int N, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(probs && dprobs && dist && logvar && dd && dlogvar && rowsum, "null pointer");
+  G2V_REQUIRE(N > 0 && K > 0, "non-positive size");
+  hipLaunchKernelGGL(vq_soft_bwd_kernel, dim3(cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, probs, dprobs, dist, logvar,
+                     dd, dlogvar, rowsum, N, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_rowscale_combine(const float* a, const float* v, const float* t, float* out, int64_t rows, int cols,
+                                    g2v_stream_t stream) {
+  G2V_REQUIRE(a && v && t && out, "null pointer");
+  G2V_REQUIRE(rows > 0 && cols > 0, "non-positive size");
+  int blocks = cdiv(rows * cols, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(rowscale_combine_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, v, t, out, rows, cols);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(z && q && out, "null pointer");
+  G2V_REQUIRE(n > 0, "non-positive size");
+  int blocks = cdiv(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(ste_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, z, q, out, n);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

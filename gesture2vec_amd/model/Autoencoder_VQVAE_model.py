@@ -25,6 +25,7 @@ from typing import Optional, Tuple
 import torch
 import torch.nn as nn
 
+from .. import functional as Fn
 from .. import ops
 from ..engine import VQVAEEngine
 
@@ -412,5 +413,101 @@ def _not_on_path(name):
     return _Stub
 
 
-VQ_Payam_GSSoft = _not_on_path("VQ_Payam_GSSoft")
+class _SoftAssignFn(torch.autograd.Function):
+    """(flat (N,E), logvar (N,K), codebook (K,E)) -> (probs (N,K), perplexity): distances + the soft assignment
+    probabilities of VQ_Payam_GSSoft.soft_prob (reference :1349-1372,1396-1411)."""
+
+    @staticmethod
+    def forward(ctx, flat, logvar, weight):
+        flat, logvar, W = flat.contiguous(), logvar.contiguous(), weight.contiguous()
+        dots = ops.linear_fwd(flat, W)
+        probs, dist, perp = ops.vq_soft_fwd(flat, dots, logvar, ops.vq_code_sqnorm(W))
+        ctx.save_for_backward(flat, logvar, W, probs, dist)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(perp)
+        return probs, perp
+
+    @staticmethod
+    def backward(ctx, dprobs, _dperp):
+        if dprobs is None:
+            return None, None, None
+        flat, logvar, W, probs, dist = ctx.saved_tensors
+        K, E = W.shape
+        dd, dlv, rowsum = ops.vq_soft_bwd(probs, dprobs.contiguous(), dist, logvar)
+        dflat = ops.rowscale_combine(flat, rowsum, ops.linear_bwd_data(dd, W))       # 2 f sum_k dd - 2 dd W
+        tw, colsum = ops.linear_bwd_weight(dd, flat, K, E, want_bias=True)            # dd^T f, column sums of dd
+        dW = ops.rowscale_combine(W, colsum, tw)                                      # 2 W sum_n dd - 2 dd^T f
+        return dflat, dlv, dW
+
+
+class _ProbsCodebookFn(torch.autograd.Function):
+    """q = probs @ W (reference :1417-1419)."""
+
+    @staticmethod
+    def forward(ctx, probs, weight):
+        probs, W = probs.contiguous(), weight.contiguous()
+        ctx.save_for_backward(probs, W)
+        ctx.set_materialize_grads(False)
+        return ops.linear_bwd_data(probs, W)
+
+    @staticmethod
+    def backward(ctx, dq):
+        if dq is None:
+            return None, None
+        probs, W = ctx.saved_tensors
+        K, E = W.shape
+        dq = dq.contiguous()
+        dprobs = ops.linear_fwd(dq, W)
+        dW, _ = ops.linear_bwd_weight(probs, dq, K, E, want_bias=False)
+        return dprobs, dW
+
+
+class _STEFn(torch.autograd.Function):
+    """inputs + (q - inputs).detach(): value from the kernel, gradient to `inputs` only (:1431)."""
+
+    @staticmethod
+    def forward(ctx, z, q):
+        return ops.ste(z.contiguous(), q.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class VQ_Payam_GSSoft(nn.Module):
+    """The soft quantiser the reference's Autoencoder_VQVAE ships with (:816-820; class :1304-1438): mean_layer ->
+    distances -> probabilities with a learnt per-code smoothness (logvar_layer) -> q = probs @ W; both latent losses;
+    `encodings` are the soft probabilities.  Same parameters / state_dict keys (pre_linear exists but is unused,
+    :1389).  Standalone module (the fused Autoencoder_VQVAE engine uses the EMA quantiser of the north star)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self.pre_linear = nn.Linear(embedding_dim, embedding_dim)
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.normal_()
+        self._commitment_cost = commitment_cost
+        self.mean_layer = nn.Linear(embedding_dim, embedding_dim)
+        self.logvar_layer = nn.Linear(embedding_dim, num_embeddings)
+
+    def embedding_grad(self, what: bool) -> None:
+        for param in self._embedding.parameters():
+            param.requires_grad = what
+
+    def forward(self, inputs: torch.Tensor):
+        if not inputs.is_cuda:
+            raise RuntimeError("VQ_Payam_GSSoft runs on the MI355X kernels only (no CPU fallback)")
+        E = self._embedding_dim
+        x = inputs.contiguous().view(-1, E)
+        flat = Fn.linear(x, self.mean_layer.weight, self.mean_layer.bias)
+        logvar = Fn.linear(flat, self.logvar_layer.weight, self.logvar_layer.bias)
+        probs, perplexity = _SoftAssignFn.apply(flat, logvar, self._embedding.weight)
+        q = _ProbsCodebookFn.apply(probs, self._embedding.weight)
+        e_latent = Fn.mse_loss(x, q.detach())                                  # gradient to the input only  (:1424)
+        q_latent = Fn.mse_loss(q, x.detach())                                  # gradient to probs / codebook (:1425)
+        loss = q_latent + self._commitment_cost * e_latent                     # :1427 (scalar glue)
+        quantized = _STEFn.apply(x, q).view(inputs.shape)
+        return loss, quantized, perplexity[0], probs
+
+
 VectorQuantizer = _not_on_path("VectorQuantizer")

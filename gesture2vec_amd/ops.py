@@ -408,3 +408,39 @@ def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None):
     check(_lib_().g2v_attn_bwd(d_ctx.data_ptr(), ldd if ldd is not None else H, _p(hp), _p(ep), _p(enc), _p(v), _p(weights),
                                _p(d_hp), _p(d_ep), _p(d_enc), _p(d_v), 0, T, B, H, _p(ws), ws.numel(), _stream()), "attn_bwd")
     return d_hp, d_ep, d_enc, d_v
+
+
+# ------------------------------------------------------------------------------------------ soft quantiser (GSSoft)
+def vq_soft_fwd(flat, dots, logvar, wsq, want_perplexity=True):
+    """dots (N,K) = flat W^T is overwritten with the squared distances; returns (probs (N,K), dist, perplexity (1,))."""
+    N, E = flat.shape
+    K = dots.shape[1]
+    probs = torch.empty((N, K), dtype=torch.float32, device=flat.device)
+    perp = torch.empty((1,), dtype=torch.float32, device=flat.device) if want_perplexity else None
+    check(_lib_().g2v_vq_soft_fwd(_p(_chk(flat)), _p(_chk(dots)), _p(_chk(logvar)), _p(_chk(wsq)), _p(probs), _p(perp), N, E, K,
+                                  _stream()), "vq_soft_fwd")
+    return probs, dots, perp
+
+
+def vq_soft_bwd(probs, dprobs, dist, logvar):
+    N, K = probs.shape
+    dd = torch.empty_like(probs)
+    dlv = torch.empty_like(probs)
+    rowsum = torch.empty((N,), dtype=torch.float32, device=probs.device)
+    check(_lib_().g2v_vq_soft_bwd(_p(_chk(probs)), _p(_chk(dprobs)), _p(_chk(dist)), _p(_chk(logvar)), _p(dd), _p(dlv), _p(rowsum),
+                                  N, K, _stream()), "vq_soft_bwd")
+    return dd, dlv, rowsum
+
+
+def rowscale_combine(a, v, t):
+    """out[r,c] = 2 a[r,c] v[r] - 2 t[r,c]"""
+    rows, cols = a.shape
+    out = torch.empty_like(a)
+    check(_lib_().g2v_rowscale_combine(_p(_chk(a)), _p(_chk(v)), _p(_chk(t)), _p(out), rows, cols, _stream()), "rowscale_combine")
+    return out
+
+
+def ste(z, q):
+    out = torch.empty_like(z)
+    check(_lib_().g2v_ste_f32(_p(_chk(z)), _p(_chk(q)), _p(out), z.numel(), _stream()), "ste")
+    return out

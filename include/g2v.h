@@ -256,6 +256,26 @@ int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int6
                        g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Soft quantiser VQ_Payam_GSSoft (model/Autoencoder_VQVAE_model.py:1304-1438; the variant Autoencoder_VQVAE ships with,
+ * :816-820).  flat = mean_layer(x) and logvar = logvar_layer(flat) are g2v_linear_fwd calls, dots = flat W^T too.
+ *   g2v_vq_soft_fwd   d = |flat|^2 + |W|^2 - 2 dots (written over `dots_to_dist`), smooth = 1/exp(logvar)^2,
+ *                     probs = row-normalised exp(-(d/400) * 0.5 * smooth)/sqrt(smooth) (:1349-1372,1396-1411);
+ *                     perplexity[0] = exp(-sum_k avg_k log(avg_k + 1e-10)), avg = mean_n probs (:1432-1433; may be NULL)
+ *   g2v_vq_soft_bwd   from dprobs: dd (N,K) = dL/d distance, dlogvar (N,K), rowsum (N) = sum_k dd
+ *   g2v_rowscale_combine  out[r,c] = 2 a[r,c] v[r] - 2 t[r,c]: the gradient of d wrt flat (a = flat, v = rowsum,
+ *                     t = dd W) and wrt the codebook (a = W, v = column sums of dd, t = dd^T flat)
+ *   g2v_ste_f32       out = z + (q - z)   (the straight-through value, :1431)
+ * q = probs W is g2v_linear_bwd_data(probs, W); its gradients are g2v_linear_fwd / g2v_linear_bwd_weight.
+ * ------------------------------------------------------------------------------------------ */
+int g2v_vq_soft_fwd(const float* flat, float* dots_to_dist, const float* logvar, const float* code_sqnorm, float* probs,
+                    float* perplexity, int N, int E, int K, g2v_stream_t stream);
+int g2v_vq_soft_bwd(const float* probs, const float* dprobs, const float* dist, const float* logvar, float* dd,
+                    float* dlogvar, float* rowsum, int N, int K, g2v_stream_t stream);
+int g2v_rowscale_combine(const float* a, const float* v, const float* t, float* out, int64_t rows, int cols,
+                         g2v_stream_t stream);
+int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).
  *   g2v_embedding_fwd   out[r,:] = table[ids[r],:] * keep * scale   (nn.Embedding :90-92,126 / :252,340-343 with the
  *                       decoder's nn.Dropout(0.5) fused; keep may be NULL)

@@ -202,6 +202,29 @@ def vq_plain_forward(inputs: Tensor, codebook: Tensor, commitment_cost: float) -
 # ----------------------------------------------------------------------------------------------
 # Part-b chunk VQ-VAE
 # ----------------------------------------------------------------------------------------------
+def vq_gssoft_forward(inputs: Tensor, sd: Dict[str, Tensor], prefix: str, commitment_cost: float) -> Dict[str, Tensor]:
+    """VQ_Payam_GSSoft.forward (Autoencoder_VQVAE_model.py:1377-1433), the soft quantiser the reference's
+    Autoencoder_VQVAE ships with (:816-820).  flat = mean_layer(x) (pre_linear is unused, :1389); distances to the
+    codebook; smooth = 1/exp(logvar_layer(flat))^2; prob = exp(-(d/400) * 0.5 * smooth)/sqrt(smooth), row-normalised
+    (:1349-1372); q = probs @ W; loss = mse(q, x.detach()) + beta * mse(q.detach(), x); straight-through output."""
+    E = sd[prefix + "_embedding.weight"].shape[1]
+    W = sd[prefix + "_embedding.weight"]
+    flat = linear(inputs.reshape(-1, E), sd[prefix + "mean_layer.weight"], sd[prefix + "mean_layer.bias"])   # :1391
+    z_logvar = linear(flat, sd[prefix + "logvar_layer.weight"], sd[prefix + "logvar_layer.bias"])            # :1392
+    d = vq_distances(flat, W)                                                                                # :1396-1400
+    smooth = 1.0 / torch.exp(z_logvar) ** 2                                                                  # :1411
+    prob = torch.exp(-((d / 400) * (0.5 * smooth))) / torch.sqrt(smooth)                                     # :1351,1361
+    probs = prob / prob.sum(1, keepdim=True)                                                                 # :1368
+    q = (probs @ W).reshape(inputs.shape)                                                                    # :1417-1421
+    e_latent = ((q.detach() - inputs) ** 2).mean()                                                           # :1424
+    q_latent = ((q - inputs.detach()) ** 2).mean()                                                           # :1425
+    loss = q_latent + commitment_cost * e_latent                                                             # :1427
+    quantized = inputs + (q - inputs).detach()                                                               # :1431
+    avg = probs.mean(0)
+    perplexity = torch.exp(-(avg * torch.log(avg + 1e-10)).sum())                                            # :1432-1433
+    return {"loss": loss, "quantized": quantized, "perplexity": perplexity, "probs": probs, "flat": flat, "dist": d}
+
+
 def encoder_forward(x_tbd: Tensor, sd: Dict[str, Tensor], n_layers: int, p: float,
                     inter_masks: Optional[List[Tensor]] = None) -> Tuple[Tensor, Tensor]:
     """EncoderRNN.forward (Autoencoder_VQVAE_model.py:73-100): Linear(D->H) -> bi-GRU -> sum directions."""

@@ -345,6 +345,38 @@ def gen_vq_layers(vq):
           "min gap:", fx["ema/c1/gap"].min(), fx["ema/c2/gap"].min())
 
 
+def gen_vq_gssoft(vq):
+    """VQ_Payam_GSSoft (:1304-1438), the quantiser the reference's Autoencoder_VQVAE actually ships with (:816-820):
+    soft assignment probabilities, q = probs @ W, both latent losses; forward + every gradient, N=256, E=128, K=512."""
+    torch.manual_seed(21)
+    K, H, L, B = 512, 64, 2, 256
+    E = H * L
+    fx = {}
+    q = vq.VQ_Payam_GSSoft(K, E, 0.25)
+    q.train(True)
+    fx.update(sd_np(q, "w0/"))
+    for i, scale in enumerate((1.0, 0.3), 1):
+        z = (torch.randn(L, B, H, generator=torch.Generator().manual_seed(40 + i)) * scale).requires_grad_(True)
+        for p_ in q.parameters():
+            p_.grad = None
+        loss, quant, perp, probs = q(z)
+        gq = torch.randn(quant.shape, generator=torch.Generator().manual_seed(400 + i))
+        ((quant * gq).sum() + 3.0 * loss).backward()
+        fx[f"c{i}/z"], fx[f"c{i}/gq"] = z.detach().numpy().copy(), gq.numpy().copy()
+        fx[f"c{i}/loss"] = np.float64(float(loss)); fx[f"c{i}/perplexity"] = np.float64(float(perp))
+        fx[f"c{i}/quantized"] = quant.detach().numpy().copy()
+        fx[f"c{i}/probs"] = probs.detach().numpy().copy()
+        fx[f"c{i}/gz"] = z.grad.numpy().copy()
+        for n_, p_ in q.named_parameters():
+            if p_.grad is not None:
+                fx[f"c{i}/grad/{n_}"] = p_.grad.numpy().copy()
+            else:
+                fx[f"c{i}/gradnone/{n_}"] = np.zeros(0, dtype=np.float32)
+    np.savez_compressed(os.path.join(OUT, "vq_gssoft.npz"), **fx)
+    print("[vq_gssoft] loss", fx["c1/loss"], fx["c2/loss"], "perp", fx["c1/perplexity"], fx["c2/perplexity"],
+          "none:", [k for k in fx if "gradnone" in k])
+
+
 def gen_custom_loss(ts):
     g = torch.Generator().manual_seed(5)
     fx = {}
@@ -395,6 +427,9 @@ def gen_dae(dae, ts):
 def main():
     vq, dae, ts = _import_reference()
     torch.set_num_threads(1)  # deterministic summation order for the golden numbers
+    if len(sys.argv) > 1 and sys.argv[1] == "gssoft":      # regenerate only vq_gssoft.npz
+        gen_vq_gssoft(vq)
+        return
     # 1. tiny (BASELINE configs[0]): B=32,T=34,D=135,H=64,L=2,K=64, p=0
     gen_vqvae_train(vq, ts, "vqvae_tiny", make_args(), B=32, seed=1, n_steps=3)
     # 2. native-lite with every dropout active: B=8,T=20,D=40,H=50,L=2,K=512, p=0.2
@@ -403,6 +438,7 @@ def main():
                               autoencoder_vq_components=512, n_poses=20),
                     B=8, seed=2, n_steps=2)
     gen_vq_layers(vq)
+    gen_vq_gssoft(vq)
     gen_custom_loss(ts)
     gen_dae(dae, ts)
 

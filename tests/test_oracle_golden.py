@@ -221,3 +221,27 @@ def test_text2embedding_matches_reference(golden_dir, name, att):
         r = O.t2e_forward(sd, ids, lengths, codes, cfg, False, {})
     # eval runs on the post-Adam weights, which carry the 0.02 * n_steps * lr rounding allowance checked above
     np.testing.assert_allclose(r["outputs"].numpy(), fx["eval/outputs"], rtol=1e-4, atol=2e-5)
+
+
+def test_vq_gssoft_matches_reference(golden_dir):
+    """a8: the soft quantiser VQ_Payam_GSSoft (:1304-1438): forward values and every gradient, two inputs."""
+    fx = load(golden_dir, "vq_gssoft")
+    sd = state_from(fx, "w0/")
+    for i in (1, 2):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        z = torch.from_numpy(fx[f"c{i}/z"].copy()).requires_grad_(True)
+        r = O.vq_gssoft_forward(z, leaves, "", 0.25)
+        gq = torch.from_numpy(fx[f"c{i}/gq"].copy())
+        ((r["quantized"] * gq).sum() + 3.0 * r["loss"]).backward()
+        np.testing.assert_allclose(float(r["loss"]), float(fx[f"c{i}/loss"]), rtol=2e-6)
+        np.testing.assert_allclose(float(r["perplexity"]), float(fx[f"c{i}/perplexity"]), rtol=2e-6)
+        np.testing.assert_allclose(r["probs"].detach().numpy(), fx[f"c{i}/probs"], rtol=2e-5, atol=1e-9)
+        np.testing.assert_allclose(r["quantized"].detach().numpy(), fx[f"c{i}/quantized"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(z.grad.numpy(), fx[f"c{i}/gz"], rtol=1e-4, atol=1e-7)
+        for k in fx.files:
+            if k.startswith(f"c{i}/grad/"):
+                n = k[len(f"c{i}/grad/"):]
+                ref = fx[k]
+                assert np.abs(leaves[n].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, n
+            if k.startswith(f"c{i}/gradnone/"):
+                assert leaves[k[len(f"c{i}/gradnone/"):]].grad is None
