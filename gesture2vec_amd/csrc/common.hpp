@@ -250,6 +250,40 @@ __device__ __forceinline__ void wave_gemm_p2(f32x4 (&acc1)[NT], const float* __r
   }
 }
 
+// ---- register-resident weight fragments --------------------------------------------------------------------------
+// frag_load issues every 16-byte fragment load of NT tiles x KS_T k-steps of a packed matrix; frag_mma consumes them.
+// Splitting the two lets a kernel issue fragment loads long before the product that needs them (vmcnt retires in
+// order, so a later wait for these fragments does not wait for anything issued after them).
+template <int NT, int KS_T>
+struct WFrag {
+  float4 w[NT][KS_T];
+};
+template <int NT, int KS_T>
+__device__ __forceinline__ void frag_load(WFrag<NT, KS_T>& f, const float* __restrict__ P, int tile0, int tile_stride,
+                                          int lane) {
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int s = 0; s < KS_T; ++s)
+      f.w[t][s] = *reinterpret_cast<const float4*>(P + ((int64_t)((tile0 + t * tile_stride) * KS_T + s) * 64 + lane) * 4);
+}
+template <int NT, int KS_T>
+__device__ __forceinline__ void frag_mma(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane) {
+  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) {
+    const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].x, xb.x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].y, xb.y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].z, xb.z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].w, xb.w, acc[t]);
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
@@ -393,6 +427,65 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
       for (int g = 0; g < nseg; ++g) t += scratch[g * nc + tid];
       out[c0 + tid] = t;
     }
+  }
+  lds_barrier();
+}
+
+// reduce_partials for ncol = 128 (32 float4 columns x 8 row segments, every thread active) with a hook: `between()`
+// runs after the first 16 loads of every thread are in flight and before they are consumed, so independent work
+// (e.g. the hidden-side GRU products of a decoder step) executes inside the L2 round trip of the partials.
+// `between` may contain workgroup barriers: every thread calls it exactly once, from straight-line code.
+template <class Between>
+__device__ __forceinline__ void reduce_partials_128_hook(const float* __restrict__ part, int nblk, float* out, float* scratch,
+                                                         int tid, Between between) {
+  constexpr int nc4 = 32, nseg = 8;
+  const int seg = tid >> 5, col = tid & 31;
+  const int per = (nblk + nseg - 1) / nseg;
+  const int kb = seg * per, ke = min(nblk, kb + per);
+  const float4* p = reinterpret_cast<const float4*>(part) + col;
+  float4 s[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int k = kb + j;
+    v[j] = p[(int64_t)(k < ke ? k : 0) * nc4];      // clamped address: no branch around the load
+  }
+  __builtin_amdgcn_sched_barrier(0);                // the loads stay ahead of the hook (hipcc would sink them below it)
+  between();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const bool ok = kb + j < ke;
+    s[j & 3].x += ok ? v[j].x : 0.f; s[j & 3].y += ok ? v[j].y : 0.f;
+    s[j & 3].z += ok ? v[j].z : 0.f; s[j & 3].w += ok ? v[j].w : 0.f;
+  }
+  int k = kb + 16;
+  for (; k + 16 <= ke; k += 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = p[(int64_t)(k + j) * nc4];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      s[j & 3].x += v[j].x; s[j & 3].y += v[j].y; s[j & 3].z += v[j].z; s[j & 3].w += v[j].w;
+    }
+  }
+  for (; k < ke; ++k) {
+    const float4 w = p[(int64_t)k * nc4];
+    s[0].x += w.x; s[0].y += w.y; s[0].z += w.z; s[0].w += w.w;
+  }
+  float4 tot;
+  tot.x = (s[0].x + s[1].x) + (s[2].x + s[3].x);
+  tot.y = (s[0].y + s[1].y) + (s[2].y + s[3].y);
+  tot.z = (s[0].z + s[1].z) + (s[2].z + s[3].z);
+  tot.w = (s[0].w + s[1].w) + (s[2].w + s[3].w);
+  lds_barrier();
+  reinterpret_cast<float4*>(scratch)[seg * nc4 + col] = tot;
+  lds_barrier();
+  for (int e = tid; e < 4 * nc4; e += 256) {
+    float t = 0.f;
+    for (int g = 0; g < nseg; ++g) t += scratch[g * 4 * nc4 + e];
+    out[e] = t;
   }
   lds_barrier();
 }

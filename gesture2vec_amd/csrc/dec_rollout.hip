@@ -45,6 +45,43 @@ struct DecPackF {
   const float* out;    // rows D, K = H
 };
 
+// Gate math + stores of one GRU cell for the 4 consecutive features [f0, f0+4) of row i held by this lane.
+__device__ __forceinline__ void gru_cell_fwd_epilogue(const f32x4 (&ai)[3], const f32x4 (&ah)[3], const float4 (&bi)[3],
+                                                      const float4 (&bh)[3], uint32_t kp, bool keep, float keep_scale,
+                                                      const float* Xh, int ldh, int H, float* Hnext_lds,
+                                                      float* __restrict__ h_out, float* __restrict__ gates,
+                                                      float* __restrict__ xdrop_out, int nrows, int i, int f0) {
+  const float4 hp4 = *reinterpret_cast<const float4*>(Xh + i * ldh + f0);
+  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
+              bin[4] = {bi[2].x, bi[2].y, bi[2].z, bi[2].w};
+  const float bhr[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bhz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+              bhn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+  float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float rr = sigmoidf_((ai[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+    const float zz = sigmoidf_((ai[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+    const float ghn = ah[2][r] + bhn[r];
+    const float nn = tanhf_((ai[2][r] + bin[r]) + rr * ghn);
+    hn[r] = (1.0f - zz) * nn + zz * hp[r];
+    xd[r] = keep ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * keep_scale : 0.f) : hn[r];
+    gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+  }
+  *reinterpret_cast<float4*>(Hnext_lds + i * ldh + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+  if (i < nrows) {
+    *reinterpret_cast<float4*>(h_out + (int64_t)i * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    if (xdrop_out) *reinterpret_cast<float4*>(xdrop_out + (int64_t)i * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+    if (gates) {
+      float* go = gates + (int64_t)i * 4 * H + f0;
+      *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+      *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+      *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+      *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+    }
+  }
+}
+
 // ---- one GRU cell for the feature tiles of this wave ------------------------------------------------
 // x-operand Xin [16][ldh] (layer input), Xh [16][ldh] (previous hidden).  Writes h_new (after optional
 // inter-layer dropout) to `Hnext_lds`, h_new to global h_out, and the gates.  When H % 4 == 0 every global /
@@ -89,35 +126,8 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, con
       wave_gemm_p<3, 0>(ah, p_hh, KS, ft, ntile, Xh, ldh, lane);
     }
     if (vec) {
-      const float4 hp4 = *reinterpret_cast<const float4*>(Xh + i * ldh + f0);
-      const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
-      const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
-                  bin[4] = {bi[2].x, bi[2].y, bi[2].z, bi[2].w};
-      const float bhr[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bhz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
-                  bhn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
-      float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float rr = sigmoidf_((ai[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
-        const float zz = sigmoidf_((ai[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
-        const float ghn = ah[2][r] + bhn[r];
-        const float nn = tanhf_((ai[2][r] + bin[r]) + rr * ghn);
-        hn[r] = (1.0f - zz) * nn + zz * hp[r];
-        xd[r] = keep ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * keep_scale : 0.f) : hn[r];
-        gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
-      }
-      *reinterpret_cast<float4*>(Hnext_lds + i * ldh + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
-      if (i < nrows) {
-        *reinterpret_cast<float4*>(h_out + (int64_t)i * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-        if (xdrop_out) *reinterpret_cast<float4*>(xdrop_out + (int64_t)i * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
-        if (gates) {
-          float* go = gates + (int64_t)i * 4 * H + f0;
-          *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
-          *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
-          *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
-          *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
-        }
-      }
+      gru_cell_fwd_epilogue(ai, ah, bi, bh, kp, keep != nullptr, keep_scale, Xh, ldh, H, Hnext_lds, h_out, gates, xdrop_out,
+                            nrows, i, f0);
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -187,6 +197,47 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     ph0 = *reinterpret_cast<const float4*>(sv.h0 + row);
     ph1 = *reinterpret_cast<const float4*>(sv.h1 + row);
   }
+  // Fast shape (compile-time dims, H = 64 so wave w owns feature tile w, full 16-row tile): the hidden-side GRU
+  // products gh0 = W_hh0 h0_{t-1} and gh1 = W_hh1 h1_{t-1} do not depend on this step's BatchNorm, so their weight
+  // fragments are requested now and the products run INSIDE the L2 round trip of the BatchNorm partials (below).
+  constexpr bool FASTC = (HS == 64);
+  const bool early = FASTC && pre_ok && (nrows == 16);
+  constexpr int KSH_F = FASTC ? HS / 16 : 1;
+  WFrag<3, KSH_F> f_hh0, f_hh1;
+  f32x4 gh0[3], gh1[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    gh0[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gh1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (early) {
+    frag_load(f_hh0, pk.hh0, wave, 4, lane);
+    frag_load(f_hh1, pk.hh1, wave, 4, lane);
+  }
+  // keep flags of the Dropout(0.95) on y_t (dense epilogue below): requested now, consumed after the out_layer
+  const bool dense_e = (nrows == 16) && t > 0 && !(has_next && t < dm.n_pre) && ((((int64_t)t * B + b0) * D) & 3) == 0 &&
+                       ((16 * D) & 3) == 0 && (16 * D <= 2 * 16 * ldh) && dm.conditioned;
+  constexpr int KPRE = FASTC ? (16 * DS / 4 + 255) / 256 : 1;
+  uint32_t kpre[KPRE];
+  if (FASTC && dense_e && has_next) {
+    const int n4 = (16 * D) >> 2;
+    const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(keep95 + ((int64_t)t * B + b0) * D);
+#pragma unroll
+    for (int j = 0; j < KPRE; ++j) {
+      const int e4 = tid + 256 * j;
+      kpre[j] = kp4[e4 < n4 ? e4 : 0];
+    }
+  }
+  auto early_products = [&]() {
+    // stage h0_{t-1}, h1_{t-1} and run the two hidden-side products (3 gates x 4 k-steps x 4 MFMAs each)
+    if (pvalid) {
+      *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
+      *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
+    }
+    lds_barrier();
+    frag_mma(gh0, f_hh0, Xh0, ldh, lane);
+    frag_mma(gh1, f_hh1, Xh1, ldh, lane);
+  };
   // Zero what the MFMA contractions must see as zero: padding columns and rows >= nrows of every operand tile.
   // (full tiles of an H % 16 == 0 model have no H padding at all: only the D padding of Xy is touched)
   {
@@ -218,7 +269,8 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     const float* ut = sv.u + (int64_t)(t - 1) * B * H;
     if (dm.training) {
       const float* part = sv.bn_partial + (int64_t)((t - 1) & 1) * dm.nblk * 2 * H;
-      reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
+      if (early) reduce_partials_128_hook(part, dm.nblk, red, red_scratch, tid, early_products);
+      else reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
       STAMP(2);
       for (int f = tid; f < H; f += 256) {
         const float s1 = red[f], s2 = red[H + f];
@@ -233,6 +285,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         }
       }
     } else {
+      if (early) early_products();
       for (int f = tid; f < H; f += 256) {
         st[f] = w.bn_running_mean[f];
         st[Hp + f] = 1.0f / sqrtf(w.bn_running_var[f] + 1e-5f);
@@ -250,8 +303,10 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         a4.z = fmaxf((pu.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
         a4.w = fmaxf((pu.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
         *reinterpret_cast<float4*>(Xa + pr * ldh + pc) = a4;
-        *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
-        *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
+        if (!early) {
+          *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
+          *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
+        }
         if (sv.a) *reinterpret_cast<float4*>(sv.a + ((int64_t)(t - 1) * B + b0 + pr) * H + pc) = a4;
       }
     } else {
@@ -273,6 +328,41 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     // ---- (c) GRU layer 0 ---------------------------------------------------------------------------
     const bool drop = dm.training && keep_l0 && dm.p_drop > 0.f;
     constexpr int KSH_T = HS / 16;
+    if (early) {
+      // input-side products only: the hidden-side halves gh0 / gh1 are already in registers
+      const int f0 = 16 * wave + 4 * q;
+      const uint8_t* kl0 = drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr;
+      uint32_t kp = 0x01010101u;
+      if (kl0) kp = *reinterpret_cast<const uint32_t*>(kl0 + (int64_t)i * H + f0);
+      float4 bi[3], bh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        bi[g] = *reinterpret_cast<const float4*>(w.b_ih0 + g * H + f0);
+        bh[g] = *reinterpret_cast<const float4*>(w.b_hh0 + g * H + f0);
+      }
+      f32x4 ai[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      wave_gemm_p<3, KSH_F>(ai, pk.ih0, KSH_F, wave, 4, Xa, ldh, lane);
+      gru_cell_fwd_epilogue(ai, gh0, bi, bh, kp, kl0 != nullptr, 1.0f / (1.0f - dm.p_drop), Xh0, ldh, H, Xx1,
+                            sv.h0 + ((int64_t)t * B + b0) * H,
+                            sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                            (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, i, f0);
+      lds_barrier();
+      STAMP(4);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        bi[g] = *reinterpret_cast<const float4*>(w.b_ih1 + g * H + f0);
+        bh[g] = *reinterpret_cast<const float4*>(w.b_hh1 + g * H + f0);
+        ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      wave_gemm_p<3, KSH_F>(ai, pk.ih1, KSH_F, wave, 4, Xx1, ldh, lane);
+      gru_cell_fwd_epilogue(ai, gh1, bi, bh, 0x01010101u, false, 1.0f, Xh1, ldh, H, Xh1n,
+                            sv.h1 + ((int64_t)t * B + b0) * H,
+                            sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, nrows, i, f0);
+      lds_barrier();
+      STAMP(5);
+    } else {
     gru_cell_fwd<KSH_T>(pk.ih0, pk.hh0, w.b_ih0, w.b_hh0, Xa, Xh0, ldh, H, Hp, Xx1,
                  sv.h0 + ((int64_t)t * B + b0) * H,
                  sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
@@ -287,14 +377,13 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
                  lane, wave);
     lds_barrier();
     STAMP(5);
+    }
   }
 
   // ---- (e) y_t = out_layer(h1_t)  (t == 0: y_0 = target frame 0), next decoder input ---------------
   // The 16 rows of this block are CONTIGUOUS in the time-major (T,B,D) arrays (y, xin, keep95): 16*D floats.
   // Fast path: accumulators -> dense LDS tile -> coalesced 16-byte global stores by all 256 threads
   // (the per-lane path touches 64 different cache lines per instruction when D = 135).
-  const bool dense_e = (nrows == 16) && t > 0 && !(has_next && t < dm.n_pre) && ((((int64_t)t * B + b0) * D) & 3) == 0 &&
-                       ((16 * D) & 3) == 0 && (16 * D <= 2 * 16 * ldh) && dm.conditioned;
   if (dense_e) {
     float* Yt = Xa;   // Xa|Xh0 are dead by now: 2*16*ldh floats >= 16*D
     const int ntile = Dp >> 4;
@@ -330,11 +419,19 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     lds_barrier();
     const int64_t tile = ((int64_t)t * B + b0) * D;     // element offset of this block's 16 x D tile
     const int n4 = (16 * D) >> 2;
-    for (int e4 = tid; e4 < n4; e4 += 256) {
+    int jj = 0;
+    for (int e4 = tid; e4 < n4; e4 += 256, ++jj) {
       const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
       reinterpret_cast<float4*>(sv.y + tile)[e4] = y4;
       if (has_next) {
-        const uint32_t k4 = reinterpret_cast<const uint32_t*>(keep95 + tile)[e4];
+        uint32_t k4;
+        if constexpr (FASTC) {
+          k4 = kpre[0];
+#pragma unroll
+          for (int j = 1; j < KPRE; ++j) k4 = (jj == j) ? kpre[j] : k4;
+        } else {
+          k4 = reinterpret_cast<const uint32_t*>(keep95 + tile)[e4];
+        }
         float4 x4;
         x4.x = (k4 & 0xffu) ? y4.x * 20.0f : 0.f;            // Dropout(0.95): 1/(1-0.95)
         x4.y = (k4 & 0xff00u) ? y4.y * 20.0f : 0.f;
