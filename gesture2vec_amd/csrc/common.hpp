@@ -288,11 +288,18 @@ __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 
 // sum over the 16 lanes that share lane>>4 (i.e. over j = lane & 15)
+// Sum over the 16 lanes of a DPP row (= the 16 batch rows of an MFMA tile), result in every lane.  Same pairwise tree
+// as xor-shuffles 1, 2, 4, 8 (after the first two steps a quad is uniform, so the half-row / full-row mirrors pair the
+// same partial sums as xor 4 / xor 8) but on the DPP path: four VALU ops instead of four LDS-crossbar round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float reduce16(float v) {
-  v += __shfl_xor(v, 1);
-  v += __shfl_xor(v, 2);
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
+  v += dpp_mov<0xB1>(v);     // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);     // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);    // row_half_mirror
+  v += dpp_mov<0x140>(v);    // row_mirror
   return v;
 }
 __device__ __forceinline__ float wave_sum(float v) {

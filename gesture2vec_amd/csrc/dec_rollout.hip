@@ -28,8 +28,10 @@ __device__ unsigned long long g2v_stamps[64 * 16];
     if (threadIdx.x == 0 && blockIdx.x < 4 && t == 5)                                              \
       g2v_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                           \
   } while (0)
+#define STAMPB(k) STAMP(8 + (k))
 #else
 #define STAMP(k)
+#define STAMPB(k)
 #endif
 
 struct DecDims {
@@ -711,6 +713,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     pu = *reinterpret_cast<const float4*>(sv.u + row);
     pdb = *reinterpret_cast<const float4*>(gr.dbn + row);
   }
+  STAMPB(0);
   // zero padding columns / rows of the MFMA operand tiles
   {
     const bool full = (nrows == 16);
@@ -729,6 +732,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   if (!last) {
     const float* part = gr.bn_bwd_partial + (int64_t)((t + 1) & 1) * dm.nblk * 2 * H;
     reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
+    STAMPB(1);
     for (int f = tid; f < H; f += 256) {
       const float s1 = red[f], s2 = red[H + f];
       st[f] = s1;
@@ -775,6 +779,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
     lds_barrier();
   }
+  STAMPB(2);
   if (t == 0) return;   // only the BN finish of step 1 was left (y_0 is data: no feedback needed)
 
   // ================= Part B: dy_t (loss + feedback) ===================================================
@@ -874,6 +879,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   }
   lds_barrier();
   }
+  STAMPB(3);
   const float* carry0 = last ? nullptr : gr.dh_init + (int64_t)b0 * H;
   const float* carry1 = last ? nullptr : gr.dh_init + ((int64_t)B + b0) * H;
   float* carry0_w = gr.dh_init + (int64_t)b0 * H;
@@ -889,6 +895,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
   }
   lds_barrier();
+  STAMPB(4);
   // ---- carry1' = dh1*z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout bwd) ----------------
   {
     for (int ft = wave; ft < nth; ft += 4) {
@@ -914,6 +921,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
   }
   lds_barrier();
+  STAMPB(5);
   // ---- GRU cell 0 backward (Gi/Gh/Dd are reused) ------------------------------------------------------
   {
     const bool drop = keep_l0 && dm.p_drop > 0.f;
@@ -930,6 +938,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
   }
   lds_barrier();
+  STAMPB(6);
   // ---- carry0' = dh0*z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU bwd -> dbn_t + BN-backward partial sums ----
   {
     const float* stats = sv.bn_stats + (int64_t)(t - 1) * 2 * H;
@@ -1005,6 +1014,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
       }
     }
   }
+  STAMPB(7);
 }
 
 }  // namespace g2v

@@ -1,4 +1,4 @@
-"""Diagnostic only (never shipped/timed): per-phase s_memtime stamps of dec_step_fwd_kernel at t=5."""
+"""Diagnostic only (never shipped/timed): per-phase s_memtime stamps of the decoder step kernels (fwd and bwd) at t=5."""
 import ctypes, subprocess, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,4 +22,7 @@ buf = (ctypes.c_ulonglong * (64 * 16))()
 print("rc", raw.g2v_read_stamps(buf))
 for b in range(4):
     st = [buf[b * 16 + k] for k in range(8)]
-    print("block", b, "deltas(ticks@100MHz):", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
+    print("fwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
+for b in range(4):
+    st = [buf[b * 16 + 8 + k] for k in range(8)]
+    print("bwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
