@@ -430,12 +430,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // (SN x SK = 2 halves of the output block, <= 256 registers each, so two waves share every SIMD and one fills the
 // matrix pipe while the other waits); the four row ranges are summed through LDS once at the end and the workgroup
 // partial goes to a slab for the deterministic slab reduction.
-template <int TN_, int TK_, int SN, int SK, bool MAPPED>
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW>
 __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restrict__ dY, int64_t lddy,
                                                            const float* __restrict__ X, RowMap xm,
                                                            float* __restrict__ slab, float* __restrict__ slab_db, int M,
                                                            int K, int N, int rows_per_wave) {
   static_assert(SN * SK == 2, "two tile groups per workgroup");
+  static_assert(VW == 1 || (VW == 2 && TN_ % 2 == 0 && TK_ % 2 == 0), "pairs of tiles per 8-byte load");
+  // VW == 2 (8-byte-aligned rows, whole tiles): the 16 MFMA rows of a PAIR of tiles are interleaved over 32 columns,
+  // lane i <-> columns 32 g + 2 i + {0, 1}, so one global_load_dwordx2 (a full 128-byte line per matrix row) feeds the
+  // operands of two tiles.  The accumulator of tile (2g + t', 2h + u') then holds rows n = 32 g + 2 (4 q + r) + t' and
+  // column k = 32 h + 2 j + u' (j = lane & 15).
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 4 regions x [TN_*TK_][64][4] + db [8][TN_][16]
   constexpr int NTILE = TN_ * TK_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -469,12 +474,27 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
       const float* xr = X + (MAPPED ? (int64_t)outer * xm.so + (int64_t)inner * xm.si : (int64_t)mrow * xm.ld) + k0;
       const float* dri = dr + i;
       const float* xri = xr + i;
+      if constexpr (VW == 2) {
+#pragma unroll
+        for (int g = 0; g < TN_ / 2; ++g) {
+          const float2 v = *reinterpret_cast<const float2*>(dr + 32 * g + 2 * i);
+          a[qd][2 * g] = v.x;
+          a[qd][2 * g + 1] = v.y;
+        }
+#pragma unroll
+        for (int h = 0; h < TK_ / 2; ++h) {
+          const float2 v = *reinterpret_cast<const float2*>(xr + 32 * h + 2 * i);
+          b[qd][2 * h] = v.x;
+          b[qd][2 * h + 1] = v.y;
+        }
+      } else {
 #pragma unroll
       for (int t = 0; t < TN_ - 1; ++t) a[qd][t] = dri[16 * t];
       a[qd][TN_ - 1] = dr[16 * (TN_ - 1) + in_last];
 #pragma unroll
       for (int u = 0; u < TK_ - 1; ++u) b[qd][u] = xri[16 * u];
       b[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+      }
       mrow += 4;
       if (MAPPED) {
         inner += 4;
@@ -485,8 +505,10 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
   auto compute = [&](float (&a)[4][TN_], float (&b)[4][TK_]) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;     // ragged last tiles: the clamped column is masked at use time
-      b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
+      if constexpr (VW == 1) {
+        a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;   // ragged last tiles: the clamped column is masked at use time
+        b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
+      }
 #pragma unroll
       for (int t = 0; t < TN_; ++t) {
         dbs[t] += a[qd][t];
@@ -495,20 +517,21 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
       }
     }
   };
-  if (mb < me) load_group(mb, ca, cb);
-  for (int m0 = mb; m0 < me; m0 += 16) {
-    load_group(min(m0 + 16, M - 16), na, nb);   // past the end of the range: a valid, unused group
+  // ping-pong over two register buffers (no copies): the loads of the next 16 rows are always in flight while the
+  // current 16 are multiplied
+  int m0 = mb;
+  if (m0 < me) load_group(m0, ca, cb);
+  for (; m0 + 32 <= me; m0 += 32) {
+    load_group(m0 + 16, na, nb);
     __builtin_amdgcn_sched_barrier(0);
     compute(ca, cb);
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-#pragma unroll
-      for (int t = 0; t < TN_; ++t) ca[qd][t] = na[qd][t];
-#pragma unroll
-      for (int u = 0; u < TK_; ++u) cb[qd][u] = nb[qd][u];
-    }
+    load_group(min(m0 + 32, M - 16), ca, cb);   // past the end of the range: a valid, unused group
+    __builtin_amdgcn_sched_barrier(0);
+    compute(na, nb);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  if (m0 < me) compute(ca, cb);                 // odd number of groups: the last one is already loaded
   // ---- sum the four row ranges of each tile group: (2,3) -> LDS -> (0,1); 1 -> LDS -> 0; range 0 writes the slab ----
   float* dbl = smem + 4 * NTILE * 256;
 #pragma unroll
@@ -544,6 +567,17 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
   if (rr != 0) return;
   absorb(smem + grp * NTILE * 256);
   float* sl = slab + (int64_t)blockIdx.x * N * K;
+  if constexpr (VW == 2) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t)
+#pragma unroll
+      for (int h = 0; h < TK_ / 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int n = n0 + 32 * (t >> 1) + 2 * (4 * q + r) + (t & 1);
+          *reinterpret_cast<float2*>(sl + (int64_t)n * K + k0 + 32 * h + 2 * i) = make_float2(acc[t][2 * h][r], acc[t][2 * h + 1][r]);
+        }
+  } else {
 #pragma unroll
   for (int t = 0; t < TN_; ++t)
 #pragma unroll
@@ -555,10 +589,11 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
         if (n < N && k < K) sl[(int64_t)n * K + k] = acc[t][u][r];
       }
     }
+  }
   if (slab_db && grp / SN == 0) {
 #pragma unroll
     for (int t = 0; t < TN_; ++t) {
-      const int n = n0 + 16 * t + i;
+      const int n = (VW == 2) ? n0 + 32 * (t >> 1) + 2 * i + (t & 1) : n0 + 16 * t + i;
       const float* d0 = dbl + (4 * grp * TN_ + t) * 16 + i;
       if (q == 0 && n < N)
         slab_db[(int64_t)blockIdx.x * N + n] = (d0[0] + d0[TN_ * 16]) + (d0[2 * TN_ * 16] + d0[3 * TN_ * 16]);
@@ -691,25 +726,28 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
   dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
   if (wg > 0) {
     const int tn = cdiv(N, 16), tk = cdiv(K, 16);
-#define G2V_TNW(TN_, TK_, SN, SK)                                                                                        \
+#define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
   do {                                                                                                                   \
     const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
     if (rows_inner > 0) {                                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true>,                                \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true>), dim3(wg), dim3(512), lds, (hipStream_t)stream,   \
-                         dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                                                  \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW>), dim3(wg), dim3(512), lds,                    \
+                         (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
     } else {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false>,                               \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW>,                           \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false>), dim3(wg), dim3(512), lds, (hipStream_t)stream,  \
-                         dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                                                  \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW>), dim3(wg), dim3(512), lds,                   \
+                         (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
     }                                                                                                                    \
   } while (0)
-    if (tn == 12 && tk == 4) G2V_TNW(6, 4, 2, 1);
-    else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1);
-    else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2);
-    else G2V_TNW(2, 4, 2, 1);
+    // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles
+    const bool vec2 = (N % 32 == 0) && (K % 32 == 0) && rows_inner == 0 && (lddy % 2 == 0) && (ldx % 2 == 0) &&
+                      (reinterpret_cast<uintptr_t>(dy) % 8 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+    if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
+    else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1, 1);
+    else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2, 1);
+    else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
 #undef G2V_TNW
   } else if (ntw == 1)
     hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
