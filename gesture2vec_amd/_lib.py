@@ -32,7 +32,8 @@ class DecSaved(C.Structure):
 
 class GruDir(C.Structure):
     """g2v_gru_dir"""
-    _fields_ = [(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)]
+    _fields_ = ([(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)] +
+                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)])
 
 
 class GruDirBwd(C.Structure):

@@ -217,6 +217,7 @@ struct GruDirF {
   const float* gi; const float* p_hh; const float* b_hh; const float* h0;
   float* hs; float* h_n; float* gates;
   int reverse;
+  const float* x; const float* p_ih; const float* b_ih;   // FUSE_IN: gi = x W_ih^T + b_ih is computed in the kernel
 };
 struct GruDirB {
   const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* p_hh_t;
@@ -224,12 +225,17 @@ struct GruDirB {
   int reverse;
 };
 
-template <int HS>
+// FUSE_IN: the input projection gi_t = x_t W_ih^T + b_ih (input width == H) is computed in the kernel, one step ahead
+// of its use: the recurrence is latency-bound (one dependent MFMA chain + gate math per step), so the 48 extra,
+// h-independent MFMAs per step ride in otherwise idle matrix-pipe slots, and the (T,B,3H) gi array -- its GEMM, its
+// HBM write and its read -- disappears.  W_ih fragments live in registers next to W_hh for all T steps.
+template <int HS, bool FUSE_IN>
 __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d1, const int32_t* __restrict__ lengths,
                                                            int64_t hs_ld, int T, int B) {
   constexpr int H = HS, KS = H / 16, NT = H / 16, ldx = H + 4, G = 3 * H;
   static_assert(NT == 4, "one feature tile per wave");
   __shared__ __attribute__((aligned(16))) float hb[2][16 * ldx];
+  __shared__ __attribute__((aligned(16))) float xb[FUSE_IN ? 2 : 1][FUSE_IN ? 16 * ldx : 4];
   const GruDirF d = blockIdx.y ? d1 : d0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -252,7 +258,49 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
     hb[1][e] = 0.f;
   }
   float4 gin[3];
-  {
+  float4 wi[3][FUSE_IN ? KS : 1], bi[3];
+  // x tile staging: thread -> (row xr_, 4 features xc_) of the 16 x H tile (16 * H / 4 = 256 float4 = one per thread)
+  const int xr_ = tid >> 4, xc_ = (tid & 15) * 4;
+  auto step_t = [&](int s) { return d.reverse ? (T - 1 - s) : s; };
+  auto load_x = [&](int s) {
+    const bool ok = (s < T) && (xr_ < nrows);
+    const int t = ok ? step_t(s) : 0;
+    const float4 v = *reinterpret_cast<const float4*>(d.x + ((int64_t)t * B + b0 + (ok ? xr_ : 0)) * H + xc_);
+    return ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto project = [&](const float* xs, float4 (&out)[3]) {     // out = W_ih x + b_ih for this lane's 4 features
+    f32x4 a[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) a[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xx = xs + i * ldx + 4 * q;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 xv = *reinterpret_cast<const float4*>(xx + 16 * ks);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) a[g] = mfma16(wi[g][FUSE_IN ? ks : 0].x, xv.x, a[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) a[g] = mfma16(wi[g][FUSE_IN ? ks : 0].y, xv.y, a[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) a[g] = mfma16(wi[g][FUSE_IN ? ks : 0].z, xv.z, a[g]);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) a[g] = mfma16(wi[g][FUSE_IN ? ks : 0].w, xv.w, a[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 3; ++g) out[g] = make_float4(a[g][0] + bi[g].x, a[g][1] + bi[g].y, a[g][2] + bi[g].z, a[g][3] + bi[g].w);
+  };
+  if constexpr (FUSE_IN) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int s = 0; s < KS; ++s)
+        wi[g][s] = *reinterpret_cast<const float4*>(d.p_ih + ((int64_t)((g * NT + wave) * KS + s) * 64 + lane) * 4);
+      bi[g] = *reinterpret_cast<const float4*>(d.b_ih + g * H + f0);
+    }
+    *reinterpret_cast<float4*>(&xb[0][xr_ * ldx + xc_]) = load_x(0);
+    *reinterpret_cast<float4*>(&xb[1][xr_ * ldx + xc_]) = load_x(1);
+    __syncthreads();
+    project(xb[0], gin);                                     // gi of the first step
+  } else {
     const int t0 = d.reverse ? T - 1 : 0;
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -266,7 +314,10 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
     float4 gic[3];
 #pragma unroll
     for (int g = 0; g < 3; ++g) gic[g] = gin[g];
-    if (s + 1 < T && rvalid) {
+    float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (FUSE_IN) {
+      xnext = load_x(s + 2);                                 // consumed at the end of this iteration
+    } else if (s + 1 < T && rvalid) {
       const int tn = d.reverse ? (T - 2 - s) : (s + 1);
 #pragma unroll
       for (int g = 0; g < 3; ++g) gin[g] = *reinterpret_cast<const float4*>(d.gi + ((int64_t)tn * B + b) * G + g * H + f0);
@@ -287,6 +338,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].w, xb.w, acc[g]);
     }
+    if constexpr (FUSE_IN) project(xb[(s + 1) & 1], gin);     // gi of step s+1: independent of h, fills idle MFMA slots
     const float4 hp4 = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
     const bool valid = rvalid && (t < len);
     const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
@@ -317,6 +369,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
         *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
       }
     }
+    if constexpr (FUSE_IN) *reinterpret_cast<float4*>(&xb[s & 1][xr_ * ldx + xc_]) = xnext;   // x of step s+2
     lds_barrier();
     cur ^= 1;
   }
@@ -428,15 +481,25 @@ using namespace g2v;
 
 static bool gru_fast_ok(int H, int64_t hs_ld) { return H == 64 && (hs_ld & 3) == 0; }
 
-extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) { return (size_t)ndir * pack_floats(H, 3, H) * sizeof(float); }
+extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) { return (size_t)2 * ndir * pack_floats(H, 3, H) * sizeof(float); }
 
 extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
                                int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
   G2V_REQUIRE(dirs && workspace, "null pointer");
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && hs_ld >= H, "bad size");
-  for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].gi && dirs[k].w_hh && dirs[k].b_hh && dirs[k].hs, "null pointer");
+  for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].w_hh && dirs[k].b_hh && dirs[k].hs, "null pointer");
+  // gi == NULL: the input projection is fused (x, w_ih, b_ih given, in_dim == H == 64); all directions alike
+  const bool fuse = dirs[0].gi == nullptr;
+  for (int k = 0; k < ndir; ++k) {
+    G2V_REQUIRE((dirs[k].gi == nullptr) == fuse, "directions must agree on gi / fused input projection");
+    if (fuse) G2V_REQUIRE(dirs[k].x && dirs[k].w_ih && dirs[k].b_ih, "gi == NULL needs x, w_ih, b_ih");
+  }
   hipStream_t st = (hipStream_t)stream;
+  if (fuse && !(gru_fast_ok(H, hs_ld) && dirs[0].in_dim == H && (ndir == 1 || dirs[1].in_dim == H))) {
+    set_error("g2v_gru_seq_fwd: fused input projection needs H == in_dim == 64 (compute gi with g2v_linear_fwd otherwise)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   if (gru_fast_ok(H, hs_ld)) {
     if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
       set_error("g2v_gru_seq_fwd: workspace too small");
@@ -444,17 +507,26 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
     }
     float* p = (float*)workspace;
     PackBatch pb;
-    pb.n = ndir;
+    pb.n = 0;
     GruDirF f[2];
     for (int k = 0; k < ndir; ++k) {
-      pb.d[k] = PackDesc{dirs[k].w_hh, p, H, 3, H, H, H, 0, 0};
-      f[k] = GruDirF{dirs[k].gi, p, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, p, H, 3, H, H, H, 0, 0};
+      f[k] = GruDirF{dirs[k].gi, p, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse,
+                     dirs[k].x, nullptr, dirs[k].b_ih};
       p += pack_floats(H, 3, H);
+      if (fuse) {
+        pb.d[pb.n++] = PackDesc{dirs[k].w_ih, p, H, 3, H, H, H, 0, 0};
+        f[k].p_ih = p;
+        p += pack_floats(H, 3, H);
+      }
     }
     if (ndir == 1) f[1] = f[0];
     launch_pack(pb, st);
     G2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gru_fwd_fast_kernel<64>, dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
+    if (fuse)
+      hipLaunchKernelGGL((gru_fwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
+    else
+      hipLaunchKernelGGL((gru_fwd_fast_kernel<64, false>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }

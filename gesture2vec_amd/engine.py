@@ -243,12 +243,20 @@ class VQVAEEngine:
                                  1.0 / (1.0 - self.p) if drop_in else 1.0,
                                  self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
                                  _p(b["xin"]), H, T * B, D, H, 0, st))
-        for suf, gi in (("", b["gi_f"]), ("_reverse", b["gi_b"])):
-            check(lib.g2v_linear_fwd(_p(b["xin"]), H, 0, 0, 0, None, 1.0, self._w(enc + "gru.weight_ih_l0" + suf),
-                                     self._w(enc + "gru.bias_ih_l0" + suf), _p(gi), G, T * B, H, G, 0, st))
+        # H == 64: the input projections x W_ih^T + b_ih are fused into the recurrent kernel (no gi array at all);
+        # other sizes compute gi with the dense-layer kernel first
+        fuse_gi = (H == 64)
+        if not fuse_gi:
+            for suf, gi in (("", b["gi_f"]), ("_reverse", b["gi_b"])):
+                check(lib.g2v_linear_fwd(_p(b["xin"]), H, 0, 0, 0, None, 1.0, self._w(enc + "gru.weight_ih_l0" + suf),
+                                         self._w(enc + "gru.bias_ih_l0" + suf), _p(gi), G, T * B, H, G, 0, st))
         dirs = (_lib.GruDir * 2)()
         for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):
-            dirs[k].gi = _p(b["gi_" + key])
+            dirs[k].gi = None if fuse_gi else _p(b["gi_" + key])
+            dirs[k].x = _p(b["xin"])
+            dirs[k].w_ih = self._w(enc + "gru.weight_ih_l0" + suf)
+            dirs[k].b_ih = self._w(enc + "gru.bias_ih_l0" + suf)
+            dirs[k].in_dim = H
             dirs[k].w_hh = self._w(enc + "gru.weight_hh_l0" + suf)
             dirs[k].b_hh = self._w(enc + "gru.bias_hh_l0" + suf)
             dirs[k].h0 = None

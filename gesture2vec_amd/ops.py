@@ -162,14 +162,16 @@ def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta, out=None):
 
 # ------------------------------------------------------------------------------------------ GRU direction(s)
 def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None):
-    """dirs: list (1 or 2) of dicts gi, w_hh, b_hh, h0, hs, h_n, gates, reverse -- ONE launch for both directions."""
+    """dirs: list (1 or 2) of dicts gi, w_hh, b_hh, h0, hs, h_n, gates, reverse -- ONE launch for both directions.
+    With gi=None and x, w_ih, b_ih, in_dim given the input projection is fused into the kernel (H == in_dim == 64)."""
     lib = _lib_()
     arr = (_lib.GruDir * len(dirs))()
     for k, d in enumerate(dirs):
-        for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates"):
+        for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates", "x", "w_ih", "b_ih"):
             setattr(arr[k], name, _p(d.get(name)))
         arr[k].reverse = int(bool(d.get("reverse", False)))
-    dev = dirs[0]["gi"].device
+        arr[k].in_dim = int(d.get("in_dim", 0))
+    dev = dirs[0]["hs"].device
     ws = workspace(lib.g2v_gru_seq_fwd_workspace(len(dirs), H), dev, "grufwd")
     check(lib.g2v_gru_seq_fwd(arr, len(dirs), _p(lengths), hs_ld if hs_ld is not None else H, T, B, H, _p(ws),
                               ws.numel(), _stream()), "gru_seq_fwd")

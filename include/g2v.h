@@ -142,6 +142,13 @@ typedef struct {          /* one direction of one layer, forward */
   float* h_n;             /* out: (B,H) final state (may be NULL)           */
   float* gates;           /* out: (T,B,4H) saved for backward (NULL = inference) */
   int reverse;            /* 0: t = 0..T-1, 1: t = T-1..0                   */
+  /* Fused input projection (gi == NULL): gi_t = x_t W_ih^T + b_ih is computed inside the recurrent kernel, one step
+   * ahead of its use (the gi array, its GEMM and its HBM round trip disappear).  Supported for in_dim == H == 64;
+   * otherwise G2V_ERR_UNSUPPORTED and the caller computes gi with g2v_linear_fwd. */
+  const float* x;         /* (T,B,in_dim) layer input                       */
+  const float* w_ih;      /* (3H,in_dim)                                    */
+  const float* b_ih;      /* (3H)                                           */
+  int in_dim;
 } g2v_gru_dir;
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */

@@ -475,3 +475,39 @@ def test_embedding_fwd_bwd(ops):
     relclose(dt, ref_dt.float(), 2e-6, "embedding grad")
     out2 = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
     assert torch.equal(out2.cpu(), table[ids])
+
+
+def test_gru_fused_input_projection_matches_unfused():
+    """g2v_gru_seq_fwd with gi == NULL (projection fused into the recurrent kernel) vs the two-kernel route and the
+    oracle; both directions, ragged batch, packed lengths."""
+    from gesture2vec_amd import ops
+    from oracle import g2v_oracle as O
+    torch.manual_seed(3)
+    T, B, H = 9, 37, 64
+    x = torch.randn(T, B, H, device=DEV)
+    lengths = torch.randint(3, T + 1, (B,)).sort(descending=True).values
+    lengths[0] = T
+    ws = [dict(w_ih=torch.randn(3 * H, H, device=DEV) * 0.2, b_ih=torch.randn(3 * H, device=DEV) * 0.1,
+               w_hh=torch.randn(3 * H, H, device=DEV) * 0.2, b_hh=torch.randn(3 * H, device=DEV) * 0.1) for _ in range(2)]
+    for use_len in (False, True):
+        ln = lengths.to(DEV).to(torch.int32) if use_len else None
+        outs = {}
+        for fused in (False, True):
+            dirs = []
+            for k, w in enumerate(ws):
+                d = dict(w_hh=w["w_hh"], b_hh=w["b_hh"], hs=torch.zeros(T, B, H, device=DEV), h_n=torch.zeros(B, H, device=DEV),
+                         gates=torch.zeros(T, B, 4 * H, device=DEV), reverse=bool(k))
+                if fused:
+                    d.update(gi=None, x=x, w_ih=w["w_ih"], b_ih=w["b_ih"], in_dim=H)
+                else:
+                    d.update(gi=ops.linear_fwd(x.view(T * B, H), w["w_ih"], w["b_ih"]))
+                dirs.append(d)
+            ops.gru_dirs_fwd(dirs, T, B, H, lengths=ln)
+            outs[fused] = dirs
+        for k, w in enumerate(ws):
+            hs_ref, hn_ref = O.gru_direction(x.cpu(), w["w_ih"].cpu(), w["w_hh"].cpu(), w["b_ih"].cpu(), w["b_hh"].cpu(), bool(k),
+                                             lengths if use_len else None)
+            for fused in (False, True):
+                relclose(outs[fused][k]["hs"], hs_ref, 2e-5, f"hs dir{k} fused={fused} lengths={use_len}")
+                relclose(outs[fused][k]["h_n"], hn_ref, 2e-5, f"h_n dir{k} fused={fused} lengths={use_len}")
+            relclose(outs[True][k]["gates"], outs[False][k]["gates"], 2e-5, f"gates dir{k}")
