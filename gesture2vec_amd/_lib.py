@@ -38,7 +38,8 @@ class GruDir(C.Structure):
 
 class GruDirBwd(C.Structure):
     """g2v_gru_dir_bwd"""
-    _fields_ = [(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)]
+    _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
+                [(n, c_fp) for n in ("w_ih", "dx")] + [("in_dim", c_int)])
 
 
 class DecGrads(C.Structure):

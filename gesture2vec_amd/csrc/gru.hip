@@ -223,6 +223,7 @@ struct GruDirB {
   const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* p_hh_t;
   float* dgi; float* dgh; float* dh0;
   int reverse;
+  const float* p_ih_t; float* dx;    // FUSE_DX: dx_t = dgi_t W_ih is produced in the kernel
 };
 
 // FUSE_IN: the input projection gi_t = x_t W_ih^T + b_ih (input width == H) is computed in the kernel, one step ahead
@@ -376,11 +377,16 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
   if (d.h_n && rvalid) *reinterpret_cast<float4*>(d.h_n + (int64_t)b * H + f0) = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
 }
 
-template <int HS>
+// FUSE_DX: the input gradient dx_t = dgi_t W_ih (input width == H) is produced here as a second, independent MFMA chain
+// next to the dh chain (which is a 48-deep DEPENDENT chain: the extra chain fills its issue bubbles); the separate
+// (T*B,3H) x (3H,H) product and its re-read of dgi disappear.  dgi = (g_r, g_z, g_n) and dgh = (g_r, g_z, g_hn) share
+// their first 2H columns in LDS; the n-gate columns of dgi sit in a second small tile.
+template <int HS, bool FUSE_DX>
 __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d1, const int32_t* __restrict__ lengths,
                                                            int64_t d_hs_ld, int64_t hs_ld, int T, int B) {
-  constexpr int H = HS, G = 3 * H, KSG = G / 16, ldg = G + 4;
+  constexpr int H = HS, G = 3 * H, KSG = G / 16, ldg = G + 4, ldn = H + 4;
   __shared__ __attribute__((aligned(16))) float Gs[2][16 * ldg];
+  __shared__ __attribute__((aligned(16))) float Gn[FUSE_DX ? 2 : 1][FUSE_DX ? 16 * ldn : 4];
   const GruDirB d = blockIdx.y ? d1 : d0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -390,6 +396,11 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
   float4 wf[KSG];
 #pragma unroll
   for (int s = 0; s < KSG; ++s) wf[s] = *reinterpret_cast<const float4*>(d.p_hh_t + ((int64_t)(wave * KSG + s) * 64 + lane) * 4);
+  float4 wx[FUSE_DX ? KSG : 1];
+  if constexpr (FUSE_DX) {
+#pragma unroll
+    for (int s = 0; s < KSG; ++s) wx[s] = *reinterpret_cast<const float4*>(d.p_ih_t + ((int64_t)(wave * KSG + s) * 64 + lane) * 4);
+  }
   const int len = (lengths && rvalid) ? lengths[b] : T;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 dh = (d.d_hn && rvalid) ? *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0) : z4;
@@ -458,9 +469,30 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
     *reinterpret_cast<float4*>(gs + f0) = vr;
     *reinterpret_cast<float4*>(gs + H + f0) = vz;
     *reinterpret_cast<float4*>(gs + 2 * H + f0) = vh;
+    if constexpr (FUSE_DX) *reinterpret_cast<float4*>(&Gn[cur][i * ldn + f0]) = vn;
     lds_barrier();
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* gx = gs + 4 * q;
+    if constexpr (FUSE_DX) {
+      f32x4 accx = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* gnx = &Gn[cur][i * ldn + 4 * q];
+#pragma unroll
+      for (int ks = 0; ks < KSG; ++ks) {
+        const float4 xb = *reinterpret_cast<const float4*>(gx + 16 * ks);
+        // the r and z columns are common to dgi and dgh; the last H columns are g_hn (dh chain) / g_n (dx chain)
+        const float4 xn = (ks < 2 * H / 16) ? xb : *reinterpret_cast<const float4*>(gnx + 16 * (ks - 2 * H / 16));
+        acc = mfma16(wf[ks].x, xb.x, acc);
+        accx = mfma16(wx[ks].x, xn.x, accx);
+        acc = mfma16(wf[ks].y, xb.y, acc);
+        accx = mfma16(wx[ks].y, xn.y, accx);
+        acc = mfma16(wf[ks].z, xb.z, acc);
+        accx = mfma16(wx[ks].z, xn.z, accx);
+        acc = mfma16(wf[ks].w, xb.w, acc);
+        accx = mfma16(wx[ks].w, xn.w, accx);
+      }
+      if (rvalid)
+        *reinterpret_cast<float4*>(d.dx + ((int64_t)t * B + b) * H + f0) = make_float4(accx[0], accx[1], accx[2], accx[3]);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KSG; ++ks) {
       const float4 xb = *reinterpret_cast<const float4*>(gx + 16 * ks);
@@ -468,6 +500,7 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
       acc = mfma16(wf[ks].y, xb.y, acc);
       acc = mfma16(wf[ks].z, xb.z, acc);
       acc = mfma16(wf[ks].w, xb.w, acc);
+    }
     }
     dh = make_float4(direct[0] + acc[0], direct[1] + acc[1], direct[2] + acc[2], direct[3] + acc[3]);
     cur ^= 1;
@@ -544,7 +577,7 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
 }
 
 extern "C" size_t g2v_gru_seq_bwd_workspace(int ndir, int H) {
-  const size_t a = (size_t)ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H;
+  const size_t a = (size_t)2 * ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H;
   return (a > b ? a : b) * sizeof(float);
 }
 
@@ -562,21 +595,41 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
   }
   hipStream_t st = (hipStream_t)stream;
   float* p = (float*)workspace;
-  if (gru_fast_ok(H, hs_ld) && (d_hs_ld & 3) == 0) {
+  // dx != NULL: the input gradient dx = dgi W_ih is fused (w_ih given, in_dim == H == 64); all directions alike
+  const bool fuse = dirs[0].dx != nullptr;
+  for (int k = 0; k < ndir; ++k) {
+    G2V_REQUIRE((dirs[k].dx != nullptr) == fuse, "directions must agree on the fused input gradient");
+    if (fuse) G2V_REQUIRE(dirs[k].w_ih, "dx != NULL needs w_ih");
+  }
+  const bool fast = gru_fast_ok(H, hs_ld) && (d_hs_ld & 3) == 0;
+  if (fuse && !(fast && dirs[0].in_dim == H && (ndir == 1 || dirs[1].in_dim == H))) {
+    set_error("g2v_gru_seq_bwd: fused input gradient needs H == in_dim == 64 (use g2v_linear_bwd_data otherwise)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  if (fast) {
     PackBatch pb;
-    pb.n = ndir;
+    pb.n = 0;
     GruDirB f[2];
     for (int k = 0; k < ndir; ++k) {
-      pb.d[k] = PackDesc{dirs[k].w_hh, p, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden feature), contraction over the 3H gates
+      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, p, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden feature), contraction over the 3H gates
       f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p,
-                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse};
+                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, nullptr, dirs[k].dx};
       p += pack_floats(H, 1, 3 * H);
+      if (fuse) {
+        pb.d[pb.n++] = PackDesc{dirs[k].w_ih, p, H, 1, 0, 3 * H, H, 1, 0};
+        f[k].p_ih_t = p;
+        p += pack_floats(H, 1, 3 * H);
+      }
     }
     if (ndir == 1) f[1] = f[0];
     launch_pack(pb, st);
     G2V_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gru_bwd_fast_kernel<64>, dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
-                       hs_ld, T, B);
+    if (fuse)
+      hipLaunchKernelGGL((gru_bwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
+                         hs_ld, T, B);
+    else
+      hipLaunchKernelGGL((gru_bwd_fast_kernel<64, false>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
+                         hs_ld, T, B);
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }

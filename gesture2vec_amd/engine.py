@@ -342,14 +342,21 @@ class VQVAEEngine:
             dirs[k].dgh = _p(b["dgh_" + key])
             dirs[k].dh0 = None
             dirs[k].reverse = k
+            # H == 64: dxin = dgi W_ih comes out of the recurrent kernel (per direction, into the unused gi buffers)
+            dirs[k].w_ih = self._w(enc + "gru.weight_ih_l0" + suf)
+            dirs[k].dx = _p(b["gi_" + key]) if H == 64 else None
+            dirs[k].in_dim = H
         check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
         wgrad(_p(b["dgi_f"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0", G, H, rows=TB)
         wgrad(_p(b["dgh_f"]), G, b["hs_f"].data_ptr(), H, enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0", G, H, rows=TB)
         wgrad(_p(b["dgi_b"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse", G, H, rows=TB)
         wgrad(_p(b["dgh_b"]), G, b["hs_b"][1:].data_ptr(), H, enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse", G, H, rows=TB)
-        check(lib.g2v_linear_bwd_data(_p(b["dgi_f"]), G, self._w(enc + "gru.weight_ih_l0"), _p(b["dxin"]), H, TB, H, G, 0, st))
-        check(lib.g2v_linear_bwd_data(_p(b["dgi_b"]), G, self._w(enc + "gru.weight_ih_l0_reverse"), _p(b["dxin"]), H, TB, H, G, 1, st))
+        if H == 64:
+            check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
+        else:
+            check(lib.g2v_linear_bwd_data(_p(b["dgi_f"]), G, self._w(enc + "gru.weight_ih_l0"), _p(b["dxin"]), H, TB, H, G, 0, st))
+            check(lib.g2v_linear_bwd_data(_p(b["dgi_b"]), G, self._w(enc + "gru.weight_ih_l0_reverse"), _p(b["dxin"]), H, TB, H, G, 1, st))
         wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
               row_map=(B, D, T * D), keep=_p(b["keep_in"]) if drop else None,
               scale=1.0 / (1.0 - self.p) if drop else 1.0)

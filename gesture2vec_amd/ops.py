@@ -182,9 +182,10 @@ def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None):
     lib = _lib_()
     arr = (_lib.GruDirBwd * len(dirs))()
     for k, d in enumerate(dirs):
-        for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0"):
+        for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0", "w_ih", "dx"):
             setattr(arr[k], name, _p(d.get(name)))
         arr[k].reverse = int(bool(d.get("reverse", False)))
+        arr[k].in_dim = int(d.get("in_dim", 0))
     dev = dirs[0]["hs"].device
     ws = workspace(lib.g2v_gru_seq_bwd_workspace(len(dirs), H), dev, "grubwd")
     check(lib.g2v_gru_seq_bwd(arr, len(dirs), _p(lengths), d_hs_ld if d_hs_ld is not None else H,

@@ -163,6 +163,12 @@ typedef struct {
   const float* hs; const float* h0; const float* gates; const float* w_hh;   /* forward tensors */
   float* dgi; float* dgh; float* dh0;         /* outputs (dh0 may be NULL)                          */
   int reverse;
+  /* Fused input gradient (dx != NULL): dx (T,B,in_dim) = dgi W_ih is produced by the recurrent kernel itself (a second,
+   * independent MFMA chain next to the dh chain).  in_dim == H == 64 only; otherwise G2V_ERR_UNSUPPORTED and the caller
+   * uses g2v_linear_bwd_data on dgi.  Each direction writes its own dx (the caller sums the two directions). */
+  const float* w_ih;      /* (3H,in_dim) */
+  float* dx;              /* out: (T,B,in_dim), overwritten */
+  int in_dim;
 } g2v_gru_dir_bwd;
 size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragment order) */
 int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,

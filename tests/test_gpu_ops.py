@@ -511,3 +511,33 @@ def test_gru_fused_input_projection_matches_unfused():
                 relclose(outs[fused][k]["hs"], hs_ref, 2e-5, f"hs dir{k} fused={fused} lengths={use_len}")
                 relclose(outs[fused][k]["h_n"], hn_ref, 2e-5, f"h_n dir{k} fused={fused} lengths={use_len}")
             relclose(outs[True][k]["gates"], outs[False][k]["gates"], 2e-5, f"gates dir{k}")
+
+
+def test_gru_bwd_fused_input_gradient_matches_unfused():
+    """g2v_gru_seq_bwd with dx != NULL (dx = dgi W_ih produced by the recurrent kernel) vs g2v_linear_bwd_data on the dgi
+    it also writes; both directions, ragged batch, packed lengths."""
+    from gesture2vec_amd import ops
+    torch.manual_seed(4)
+    T, B, H = 7, 21, 64
+    x = torch.randn(T, B, H, device=DEV)
+    lengths = torch.randint(2, T + 1, (B,)).sort(descending=True).values
+    lengths[0] = T
+    ln = lengths.to(DEV).to(torch.int32)
+    for k in range(2):
+        w_ih, b_ih = torch.randn(3 * H, H, device=DEV) * 0.2, torch.randn(3 * H, device=DEV) * 0.1
+        w_hh, b_hh = torch.randn(3 * H, H, device=DEV) * 0.2, torch.randn(3 * H, device=DEV) * 0.1
+        gi = ops.linear_fwd(x.view(T * B, H), w_ih, b_ih)
+        hs, h_n, gates = ops.gru_seq_fwd(gi, w_hh, b_hh, T, B, H, lengths=ln, reverse=bool(k))
+        d_hs, d_hn = torch.randn(T, B, H, device=DEV), torch.randn(B, H, device=DEV)
+        res = {}
+        for fused in (False, True):
+            d = dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w_hh, dgi=torch.zeros(T, B, 3 * H, device=DEV),
+                     dgh=torch.zeros(T, B, 3 * H, device=DEV), dh0=None, reverse=bool(k))
+            if fused:
+                d.update(w_ih=w_ih, dx=torch.full((T, B, H), 7.0, device=DEV), in_dim=H)
+            ops.gru_dirs_bwd([d], T, B, H, lengths=ln)
+            res[fused] = d
+        relclose(res[True]["dgi"], res[False]["dgi"], 1e-6, "dgi")
+        relclose(res[True]["dgh"], res[False]["dgh"], 1e-6, "dgh")
+        dx_ref = ops.linear_bwd_data(res[False]["dgi"].view(T * B, 3 * H), w_ih).view(T, B, H)
+        relclose(res[True]["dx"], dx_ref, 2e-5, f"dx dir{k}")
