@@ -69,6 +69,64 @@ __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restric
         (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
 
+// Compile-time T: the whole (b, d) column of y and of the target lives in registers (2 * TT values), every load is
+// issued before the first use (one HBM round trip instead of 2 * TT dependent ones), and the gradient pass re-reads
+// nothing: 2 reads + 1 write of (T,B,D), the algorithmic minimum.
+template <int TT>
+__global__ __launch_bounds__(256) void custom_loss_reg_kernel(const float* __restrict__ y, const float* __restrict__ tgt,
+                                                              float* __restrict__ dy, float* __restrict__ partial, float c1,
+                                                              float c2, float c3, float g_scale, int B, int D) {
+  __shared__ float red[4][4];
+  const int64_t col = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t BD = (int64_t)B * D;
+  float l1 = 0.f, cont = 0.f, nrm = 0.f, sq = 0.f;
+  if (col < BD) {
+    const int b = (int)(col / D), d = (int)(col - (int64_t)b * D);
+    float v[TT], tv[TT];
+    const float* yp = y + col;
+    const float* tp = tgt + (int64_t)b * TT * D + d;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) v[t] = yp[(int64_t)t * BD];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) tv[t] = tp[(int64_t)t * D];
+    float ss = 0.f;
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+      l1 += fabsf(v[t] - tv[t]);
+      sq += (v[t] - tv[t]) * (v[t] - tv[t]);
+      if (t > 0) cont += fabsf(v[t] - v[t - 1]);
+      ss += v[t] * v[t];
+    }
+    nrm = sqrtf(ss);
+    if (dy) {
+      const float inv = (nrm > 0.f) ? 1.0f / nrm : 0.f;
+      float* dp = dy + col;
+#pragma unroll
+      for (int t = 0; t < TT; ++t) {
+        float g = c1 * sgnf(v[t] - tv[t]) - c3 * v[t] * inv;
+        if (t > 0) g += c2 * sgnf(v[t] - v[t - 1]);
+        if (t + 1 < TT) g -= c2 * sgnf(v[t + 1] - v[t]);
+        dp[(int64_t)t * BD] = g * g_scale;
+      }
+    }
+  }
+  l1 = wave_sum(l1);
+  cont = wave_sum(cont);
+  nrm = wave_sum(nrm);
+  sq = wave_sum(sq);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = l1;
+    red[1][wave] = cont;
+    red[2][wave] = nrm;
+    red[3][wave] = sq;
+  }
+  __syncthreads();
+  if (threadIdx.x < 4)
+    partial[(int64_t)blockIdx.x * 4 + threadIdx.x] =
+        (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+}
+
 __global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ terms,
                                             float c1, float c2, float c3, float inv_n) {
   __shared__ float red[4][4];
@@ -251,8 +309,15 @@ extern "C" int g2v_custom_loss_fwd_bwd(const float* y, const float* target, floa
   const float n = (float)T * (float)B * (float)D;
   const float c1 = w_l1 / n, c2 = w_cont / n, c3 = w_var / n;
   const int nblk = g2v_custom_loss_blocks(B, D);
-  hipLaunchKernelGGL(custom_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, c1, c2,
-                     c3, g_scale, T, B, D);
+  if (T == 34)        // the BASELINE chunk length: whole columns in registers (see custom_loss_reg_kernel)
+    hipLaunchKernelGGL(custom_loss_reg_kernel<34>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, c1,
+                       c2, c3, g_scale, B, D);
+  else if (T == 20)   // config/VQ-VAE.yml n_poses
+    hipLaunchKernelGGL(custom_loss_reg_kernel<20>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, c1,
+                       c2, c3, g_scale, B, D);
+  else
+    hipLaunchKernelGGL(custom_loss_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, y, target, dy, partial, c1, c2,
+                       c3, g_scale, T, B, D);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(custom_loss_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partial, nblk, terms, c1,
                      c2, c3, 1.0f / n);
