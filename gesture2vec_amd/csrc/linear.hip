@@ -137,18 +137,27 @@ __global__ __launch_bounds__(256) void gemm_nt_stream_kernel(const float* __rest
   extern __shared__ __attribute__((aligned(16))) float smem[];   // packed W: [NTW][KS][64 lanes][4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
+  const bool wvec = ((ldb & 3) == 0) && ((reinterpret_cast<uintptr_t>(Bm) & 15) == 0);
   // ---- pack the weights: P[((t*KS + s)*64 + l)*4 + e] = Wop[16 t + (l & 15)][16 s + 4 (l >> 4) + e] ----
   for (int blk = wave; blk < NTW * KS; blk += 4) {
     const int t = blk / KS, s2 = blk - t * KS;
     const int n = 16 * t + i;
     float v[4];
+    if (!TRANS_B && wvec) {
+      // forward: the fragment IS 4 consecutive weights of row n: one 16-byte load
+      const int c = 16 * s2 + 4 * q;
+      const bool ok = (n < N) && (c < C);               // C % 4 == 0: the float4 is all-in or all-out
+      const float4 w4 = *reinterpret_cast<const float4*>(Bm + (int64_t)(ok ? n : 0) * ldb + (ok ? c : 0));
+      v[0] = ok ? w4.x : 0.f; v[1] = ok ? w4.y : 0.f; v[2] = ok ? w4.z : 0.f; v[3] = ok ? w4.w : 0.f;
+    } else {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int c = 16 * s2 + 4 * q + e;
-      const bool ok = (n < N) && (c < C);
-      const int64_t off = TRANS_B ? ((int64_t)(ok ? c : 0) * ldb + (ok ? n : 0)) : ((int64_t)(ok ? n : 0) * ldb + (ok ? c : 0));
-      const float w = Bm[off];
-      v[e] = ok ? w : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int c = 16 * s2 + 4 * q + e;
+        const bool ok = (n < N) && (c < C);
+        const int64_t off = TRANS_B ? ((int64_t)(ok ? c : 0) * ldb + (ok ? n : 0)) : ((int64_t)(ok ? n : 0) * ldb + (ok ? c : 0));
+        const float w = Bm[off];
+        v[e] = ok ? w : 0.f;
+      }
     }
     *reinterpret_cast<float4*>(smem + ((int64_t)blk * 64 + lane) * 4) = make_float4(v[0], v[1], v[2], v[3]);
   }
@@ -215,7 +224,9 @@ static bool launch_stream(const float* A, int64_t lda, const float* Bm, int64_t 
   if (M < 1024 || (C & 3) || (N & 15) || N > 192 || act == 2) return false;
   if (!ptr_vec_ok(A, lda) || !ptr_vec_ok(Cout, ldc) || (bias && (reinterpret_cast<uintptr_t>(bias) & 15))) return false;
   const int ks = (C + 15) >> 4, ntw = N >> 4;
-  int gx = cdiv(M, 16 * 4 * 4);                     // >= 4 row groups per wave
+  // large M: >= 4 row groups per wave (the per-workgroup weight pack amortises); small M: one group per wave so that
+  // the launch still covers the chip
+  int gx = (M >= 65536) ? cdiv(M, 16 * 4 * 4) : cdiv(M, 16 * 4);
   if (gx > 512) gx = 512;
 #define G2V_STREAM(NTW, KS)                                                                                              \
   do {                                                                                                                   \
