@@ -339,7 +339,7 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].w, xb.w, acc[g]);
     }
-    if constexpr (FUSE_IN) project(xb[(s + 1) & 1], gin);     // gi of step s+1: independent of h, fills idle MFMA slots
+    if constexpr (FUSE_IN) project(xb[(s + 1) & 1], gin);     // gi of step s+1: independent of h
     const float4 hp4 = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
     const bool valid = rvalid && (t < len);
     const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
@@ -354,7 +354,8 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
       const float zz = sigmoidf_(iz[r] + (acc[1][r] + bz[r]));
       const float ghn = acc[2][r] + bn[r];
       const float nn = tanhf_(in_[r] + rr * ghn);
-      hn[r] = valid ? (1.0f - zz) * nn + zz * hp[r] : hp[r];
+      const float hnew = (1.0f - zz) * nn + zz * hp[r];
+      hn[r] = valid ? hnew : hp[r];        // selects, not branches: the gate math runs for every lane
       gr_[r] = valid ? rr : 0.f; gz_[r] = valid ? zz : 0.f; gn_[r] = valid ? nn : 0.f; gh_[r] = valid ? ghn : 0.f;
     }
     *reinterpret_cast<float4*>(hb[cur ^ 1] + i * ldx + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
