@@ -124,3 +124,45 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
     loss.backward()
     optim.step()
     return {"loss": loss.item()}
+
+
+class GraphedText2EmbeddingStep:
+    """train_iter_text2embedding as ONE hipGraph: zero_grad -> forward -> CE -> backward -> clip+Adam are captured once and
+    replayed (the operator chain of Part d is ~100 small launches per step: host-bound when launched one by one at the
+    reference's B=128).  Inputs are static device tensors: overwrite `in_text` / `codes` / `lengths` in place between
+    replays.  Dropout masks come from the Philox kernels (device-side counters), so every replay draws fresh masks.
+    `loss` is a device scalar updated by each replay (read it when needed: no per-step host sync)."""
+
+    def __init__(self, args, net, optim, in_text, in_lengths, codes, warmup: int = 3):
+        from ..flat import FlatClipAdam
+        from ..functional import cross_entropy
+        if not isinstance(optim, FlatClipAdam):
+            raise TypeError("use gesture2vec_amd.flat.FlatClipAdam")
+        dev = in_text.device
+        self.in_text = in_text
+        self.codes = codes
+        self.lengths = in_lengths.to(device=dev, dtype=torch.int32).contiguous()   # EncoderRNN takes a device tensor as is
+        self.net, self.optim = net, optim
+
+        def step():
+            optim.zero_grad()
+            outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
+            K = outputs.shape[2]
+            loss = cross_entropy(outputs[:, 1:, :].reshape(-1, K), self.codes[:, 1:].reshape(-1).long())
+            loss.backward()
+            optim.step()
+            return loss
+
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(warmup, 1)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = step()
+
+    def replay(self):
+        self.graph.replay()
+        return self.loss

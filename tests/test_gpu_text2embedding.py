@@ -100,3 +100,30 @@ def test_attention_op_matches_torch_reference():
     assert relerr(w, w2) < 1e-5 and relerr(ctx, ctx2) < 1e-5
     for a, b2, n in zip(got, ref_in, ("hp", "ep", "enc", "v")):
         assert relerr(a, b2.grad) < 2e-5, (n, relerr(a, b2.grad))
+
+
+def test_graphed_text2embedding_step_trains():
+    """GraphedText2EmbeddingStep: the whole Part-d train iteration replayed from one hipGraph lowers the loss like the
+    eager iteration does (same kernels; dropout masks are drawn on the device at every replay)."""
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import GraphedText2EmbeddingStep
+    torch.manual_seed(0)
+    B, Tw, S, H, L, K, NW, EMB = 32, 10, 6, 32, 2, 64, 100, 300
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=0.1, autoencoder_vq_components=K, autoencoder_att="True",
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True")
+    net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(0).randn(NW, EMB).astype(np.float32), None).to(DEV)
+    net.train(True)
+    optim = FlatClipAdam(net.parameters(), lr=2e-3, betas=(0.5, 0.999))
+    lengths = torch.randint(3, Tw + 1, (B,)).sort(descending=True).values
+    lengths[0] = Tw
+    ids = torch.zeros(B, Tw, dtype=torch.int64)
+    for b in range(B):
+        ids[b, : lengths[b]] = torch.randint(4, NW, (int(lengths[b]),))
+    codes = torch.randint(0, K, (B, S))
+    step = GraphedText2EmbeddingStep(args, net, optim, ids.to(DEV), lengths, codes.to(DEV))
+    first = float(step.replay().detach())
+    for _ in range(60):
+        step.replay()
+    last = float(step.loss.detach())
+    assert np.isfinite(first) and np.isfinite(last) and last < 0.8 * first, (first, last)
