@@ -120,6 +120,8 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgrad-bf16x3", action="store_true",
+                    help="opt-in: weight-gradient products as 3-term bf16 splits (reported in config.wgrad); default exact fp32")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (split graphs + RCCL all-reduce) even with one rank (diagnostic)")
     a = ap.parse_args()
@@ -150,6 +152,7 @@ def main():
     net.rng_seed = 1234 + rank
     net.train(True)
     eng = net.engine()
+    eng.wgrad_bf16x3 = bool(a.wgrad_bf16x3)
     x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)   # rank-dependent shard
 
     reduce_fn = None
@@ -245,6 +248,7 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "launch": ("eager launches" if graph is None else
                                   "2 hipGraph replays around one RCCL all-reduce" if use_dp else "hipGraph replay"),
+                       "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "final_loss": round(loss, 6)},
         }
         if world == 1:

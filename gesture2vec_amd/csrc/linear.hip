@@ -441,7 +441,23 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const float* __restrict__ 
 // (SN x SK = 2 halves of the output block, <= 256 registers each, so two waves share every SIMD and one fills the
 // matrix pipe while the other waits); the four row ranges are summed through LDS once at the end and the workgroup
 // partial goes to a slab for the deterministic slab reduction.
-template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW>
+// BF3: the products run on the bf16 matrix pipe as a 3-term split (x = hi + lo, two bf16 each; hi*hi + hi*lo + lo*hi,
+// fp32 accumulation; the dropped lo*lo term and the truncation of lo are ~2^-16 relative per product), 2.7x fewer
+// matrix-pipe cycles than fp32 MFMA.  Opt-in per call (G2V_WGRAD_BF16X3): a weight GRADIENT tolerates 1e-5 relative noise.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void split_bf16x4(const float (&v)[4], s16x4& hi, s16x4& lo) {
+  uint32_t h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const uint32_t bits = __float_as_uint(v[j]);
+    h[j] = bits & 0xffff0000u;                                   // hi = truncation to bf16
+    l[j] = __float_as_uint(v[j] - __uint_as_float(h[j]));         // exact remainder, then truncated to bf16
+  }
+  hi = (s16x4){(short)(h[0] >> 16), (short)(h[1] >> 16), (short)(h[2] >> 16), (short)(h[3] >> 16)};
+  lo = (s16x4){(short)(l[0] >> 16), (short)(l[1] >> 16), (short)(l[2] >> 16), (short)(l[3] >> 16)};
+}
+
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3>
 __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restrict__ dY, int64_t lddy,
                                                            const float* __restrict__ X, RowMap xm,
                                                            float* __restrict__ slab, float* __restrict__ slab_db, int M,
@@ -477,7 +493,10 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
   auto load_group = [&](int m0, float (&a)[4][TN_], float (&b)[4][TK_]) {
     // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
     // (B,T,D) -> (T,B,D) row map, then the three following row quads step the (outer, inner) pair.
-    int mrow = m0 + q, outer = 0, inner = 0;
+    // fp32 MFMA (16x16x4): k-slot q of step qd is row m0 + 4 qd + q.  bf16 MFMA (16x16x16): lane group q supplies the four
+    // consecutive rows m0 + 4 q + j.  (Any assignment works as long as both operands use the same one.)
+    constexpr int RSTEP = BF3 ? 1 : 4;
+    int mrow = BF3 ? m0 + 4 * q : m0 + q, outer = 0, inner = 0;
     if (MAPPED) { outer = mrow / xm.rows_inner; inner = mrow - outer * xm.rows_inner; }
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
@@ -506,9 +525,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
       for (int u = 0; u < TK_ - 1; ++u) b[qd][u] = xri[16 * u];
       b[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
       }
-      mrow += 4;
+      mrow += RSTEP;
       if (MAPPED) {
-        inner += 4;
+        inner += RSTEP;
         if (inner >= xm.rows_inner) { inner -= xm.rows_inner; ++outer; }
       }
     }
@@ -520,12 +539,37 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
         a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;   // ragged last tiles: the clamped column is masked at use time
         b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
       }
+    }
+    if constexpr (BF3) {
+      s16x4 bh[TK_], bl[TK_];
+#pragma unroll
+      for (int u = 0; u < TK_; ++u) {
+        const float v[4] = {b[0][u], b[1][u], b[2][u], b[3][u]};
+        split_bf16x4(v, bh[u], bl[u]);
+      }
+#pragma unroll
+      for (int t = 0; t < TN_; ++t) {
+        const float v[4] = {a[0][t], a[1][t], a[2][t], a[3][t]};
+        dbs[t] += (v[0] + v[1]) + (v[2] + v[3]);
+        s16x4 ah, al;
+        split_bf16x4(v, ah, al);
+#pragma unroll
+        for (int u = 0; u < TK_; ++u) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bh[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ah, bl[u], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(al, bh[u], acc[t][u], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
 #pragma unroll
       for (int t = 0; t < TN_; ++t) {
         dbs[t] += a[qd][t];
 #pragma unroll
         for (int u = 0; u < TK_; ++u) acc[t][u] = mfma16(a[qd][t], b[qd][u], acc[t][u]);
       }
+    }
     }
   };
   // ping-pong over two register buffers (no copies): the loads of the next 16 rows are always in flight while the
@@ -720,6 +764,8 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
                                      size_t workspace_bytes, g2v_stream_t stream) {
   G2V_REQUIRE(dy && x && dw && workspace, "null pointer");
   G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  const bool bf3 = (accumulate & G2V_WGRAD_BF16X3) != 0;      // flag bits: 1 = accumulate, 2 = bf16x3 products
+  accumulate &= 1;
   if (workspace_bytes < g2v_linear_bwd_weight_workspace(M, K, N)) {
     set_error("g2v_linear_bwd_weight: workspace too small");
     return G2V_ERR_WORKSPACE;
@@ -737,20 +783,25 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
   dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
   if (wg > 0) {
     const int tn = cdiv(N, 16), tk = cdiv(K, 16);
-#define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
+#define G2V_TNW2(TN_, TK_, SN, SK, VW, BF)                                                                               \
   do {                                                                                                                   \
     const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
     if (rows_inner > 0) {                                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW>,                            \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>,                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW>), dim3(wg), dim3(512), lds,                    \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>), dim3(wg), dim3(512), lds,                \
                          (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
     } else {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW>,                           \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>,                       \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW>), dim3(wg), dim3(512), lds,                   \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>), dim3(wg), dim3(512), lds,               \
                          (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
     }                                                                                                                    \
+  } while (0)
+#define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
+  do {                                                                                                                   \
+    if (bf3) G2V_TNW2(TN_, TK_, SN, SK, VW, true);                                                                       \
+    else G2V_TNW2(TN_, TK_, SN, SK, VW, false);                                                                          \
   } while (0)
     // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles
     const bool vec2 = (N % 32 == 0) && (K % 32 == 0) && rows_inner == 0 && (lddy % 2 == 0) && (ldx % 2 == 0) &&
@@ -760,6 +811,7 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
     else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2, 1);
     else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
 #undef G2V_TNW
+#undef G2V_TNW2
   } else if (ntw == 1)
     hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
                        slab_db, M, K, N, rows_per_split);

@@ -83,7 +83,8 @@ def linear_bwd_data(dy, w, *, M=None, lddy=None, out=None, lddx=None, accumulate
 
 
 def linear_bwd_weight(dy, x, N, K, *, M=None, lddy=None, ldx=None, row_map=None, keep=None, scale=1.0,
-                      dw=None, db=None, want_bias=True, accumulate=False):
+                      dw=None, db=None, want_bias=True, accumulate=False, bf16x3=False):
+    """dw = dy^T xin (+ db).  bf16x3=True allows the 3-term bf16 split products (G2V_WGRAD_BF16X3, ~1.5e-5 relative)."""
     if M is None:
         M = dy.numel() // N
     if lddy is None:
@@ -100,7 +101,8 @@ def linear_bwd_weight(dy, x, N, K, *, M=None, lddy=None, ldx=None, row_map=None,
     ws = workspace(nbytes, dev, "bwdw")
     ri, so, si = row_map if row_map is not None else (0, 0, 0)
     check(lib.g2v_linear_bwd_weight(_p(dy), lddy, _p(x), ldx, ri, so, si, _p(keep), float(scale), _p(dw), _p(db),
-                                    M, K, N, int(accumulate), _p(ws), ws.numel(), _stream()), "linear_bwd_weight")
+                                    M, K, N, int(bool(accumulate)) | (2 if bf16x3 else 0), _p(ws), ws.numel(), _stream()),
+          "linear_bwd_weight")
     return dw, db
 
 

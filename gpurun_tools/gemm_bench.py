@@ -22,6 +22,12 @@ res["bwd_data N192->K64 (143MB)"] = timeit(lambda: ops.linear_bwd_data(dy, w192,
 dw = torch.empty(192, 64, device=dev); db = torch.empty(192, device=dev)
 res["bwd_weight N192 K64 (143MB)"] = timeit(lambda: ops.linear_bwd_weight(dy, x64, 192, 64, dw=dw, db=db))
 res["bwd_weight N64 K135 rowmap (111MB)"] = timeit(lambda: ops.linear_bwd_weight(y64, x135, 64, 135, M=M, row_map=(4096, 135, 34 * 135)))
+res["bwd_weight N192 K64 bf16x3"] = timeit(lambda: ops.linear_bwd_weight(dy, x64, 192, 64, dw=dw, db=db, bf16x3=True))
+res["bwd_weight N64 K135 rowmap bf16x3"] = timeit(lambda: ops.linear_bwd_weight(y64, x135, 64, 135, M=M, row_map=(4096, 135, 34 * 135), bf16x3=True))
+a, _ = ops.linear_bwd_weight(dy, x64, 192, 64)
+b2, _ = ops.linear_bwd_weight(dy, x64, 192, 64, bf16x3=True)
+ref = dy.double().t() @ x64.double()
+res["relerr fp32 / bf16x3 (max-norm)"] = [float((a.double() - ref).abs().max() / ref.abs().max()), float((b2.double() - ref).abs().max() / ref.abs().max())]
 t = torch.empty(M * 64, device=dev)
 res["torch copy 2x143MB ref"] = timeit(lambda: y192.copy_(dy))
-print(json.dumps({k: round(v, 1) for k, v in res.items()}))
+print(json.dumps({k: (round(v, 1) if isinstance(v, float) else v) for k, v in res.items()}))

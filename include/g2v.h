@@ -64,7 +64,13 @@ int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx
 
 /* dw[n, k] (+)= sum_m dy[m, n] * xin[m, k];  db[n] (+)= sum_m dy[m, n]  (db may be NULL).
  * xin addressing / keep-mask exactly as in g2v_linear_fwd.  Deterministic (split-M slabs + ordered
- * reduction, no float atomics).  workspace >= g2v_linear_bwd_weight_workspace(M,K,N) bytes. */
+ * reduction, no float atomics).  workspace >= g2v_linear_bwd_weight_workspace(M,K,N) bytes.
+ * `accumulate` is a flag word: bit 0 = add into dw / db; bit 1 (G2V_WGRAD_BF16X3) = allow the products to run on
+ * the bf16 matrix pipe as a 3-term split (x = hi + lo; hi*hi + hi*lo + lo*hi, fp32 accumulation, ~1.5e-5 relative per
+ * product instead of fp32's 6e-8; db stays exact fp32).  Honoured by the wave-autonomous kernels (large M), ignored
+ * elsewhere.  Default (bit clear) is exact fp32 MFMA. */
+#define G2V_WGRAD_ACCUMULATE 1
+#define G2V_WGRAD_BF16X3 2
 size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
 int g2v_linear_bwd_weight(const float* dy, int64_t lddy,
                           const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,

@@ -541,3 +541,20 @@ def test_gru_bwd_fused_input_gradient_matches_unfused():
         relclose(res[True]["dgh"], res[False]["dgh"], 1e-6, "dgh")
         dx_ref = ops.linear_bwd_data(res[False]["dgi"].view(T * B, 3 * H), w_ih).view(T, B, H)
         relclose(res[True]["dx"], dx_ref, 2e-5, f"dx dir{k}")
+
+
+def test_linear_bwd_weight_bf16x3_option_is_bounded():
+    """G2V_WGRAD_BF16X3 (opt-in): the 3-term bf16 split of the weight-gradient products stays within 1e-4 (max-norm
+    relative) of the exact product at the BASELINE-sized contraction; db stays fp32-exact; default path is unchanged."""
+    from gesture2vec_amd import ops
+    torch.manual_seed(9)
+    M, N, K = 34 * 512, 192, 64
+    dy = torch.randn(M, N, device=DEV)
+    x = torch.randn(M, K, device=DEV)
+    ref = dy.double().t() @ x.double()
+    dw32, db32 = ops.linear_bwd_weight(dy, x, N, K)
+    dwb, dbb = ops.linear_bwd_weight(dy, x, N, K, bf16x3=True)
+    scale = float(ref.abs().max())
+    assert float((dw32.double() - ref).abs().max()) <= 2e-6 * scale
+    assert float((dwb.double() - ref).abs().max()) <= 1e-4 * scale
+    relclose(dbb, dy.double().sum(0).float(), 2e-6, "db")
