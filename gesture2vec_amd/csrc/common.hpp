@@ -284,6 +284,46 @@ __device__ __forceinline__ void frag_mma(f32x4 (&acc)[NT], const WFrag<NT, KS_T>
   }
 }
 
+// frag_mma with the fragment loads of a LATER product interleaved into the MFMA stream: one 16-byte load after every
+// STRIDE MFMAs, pinned with sched_barrier.  A burst of fragment loads in front of a product costs the wave ~80 cycles
+// per load (the CU's vector-memory front end moves ~48 B/clk, shared by its 4 waves) during which its matrix pipe
+// idles; spread between MFMAs (32 cycles each) the same loads are absorbed at the rate the front end accepts them.
+template <int NT, int KS_T, int NT2, int KS2>
+__device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane,
+                                            WFrag<NT2, KS2>& nxt, const float* __restrict__ P2, int tile0_2, int tile_stride_2,
+                                            bool do_load) {
+  constexpr int NM = NT * KS_T * 4, NL = NT2 * KS2;
+  constexpr int STRIDE = (NM / NL) > 0 ? (NM / NL) : 1;
+  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) {
+    const float4 xb4 = *reinterpret_cast<const float4*>(xrow + 16 * s);
+    const float xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const float wv[4] = {f.w[t][s].x, f.w[t][s].y, f.w[t][s].z, f.w[t][s].w};
+        acc[t] = mfma16(wv[c], xb[c], acc[t]);
+        const int m = (s * 4 + c) * NT + t;
+        if ((m % STRIDE) == STRIDE - 1 && (m / STRIDE) < NL) {
+          const int k = m / STRIDE, t2 = k / KS2, s2 = k % KS2;
+          if (do_load)
+            nxt.w[t2][s2] = *reinterpret_cast<const float4*>(P2 + ((int64_t)((tile0_2 + t2 * tile_stride_2) * KS2 + s2) * 64 + lane) * 4);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+  }
+  // loads that did not fit the stride pattern (NL > NM): issue the rest
+#pragma unroll
+  for (int k = NM / STRIDE; k < NL; ++k) {
+    const int t2 = k / KS2, s2 = k % KS2;
+    if (do_load)
+      nxt.w[t2][s2] = *reinterpret_cast<const float4*>(P2 + ((int64_t)((tile0_2 + t2 * tile_stride_2) * KS2 + s2) * 64 + lane) * 4);
+  }
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 

@@ -205,7 +205,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   constexpr bool FASTC = (HS == 64);
   const bool early = FASTC && pre_ok && (nrows == 16);
   constexpr int KSH_F = FASTC ? HS / 16 : 1;
-  WFrag<3, KSH_F> f_hh0, f_hh1;
+  constexpr int KSD_F = FASTC ? KSD_T : 1;
+  WFrag<3, KSH_F> f_hh0, f_hh1, f_ih0, f_ih1, f_out;
+  WFrag<1, KSD_F> f_pre;
   f32x4 gh0[3], gh1[3];
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
@@ -237,8 +239,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
     }
     lds_barrier();
-    frag_mma(gh0, f_hh0, Xh0, ldh, lane);
-    frag_mma(gh1, f_hh1, Xh1, ldh, lane);
+    // ... and while they run, the fragments of the two input-side products stream in BETWEEN the MFMAs
+    frag_mma_pf(gh0, f_hh0, Xh0, ldh, lane, f_ih0, pk.ih0, wave, 4, true);
+    frag_mma_pf(gh1, f_hh1, Xh1, ldh, lane, f_ih1, pk.ih1, wave, 4, true);
   };
   // Zero what the MFMA contractions must see as zero: padding columns and rows >= nrows of every operand tile.
   // (full tiles of an H % 16 == 0 model have no H padding at all: only the D padding of Xy is touched)
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       f32x4 ai[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      wave_gemm_p<3, KSH_F>(ai, pk.ih0, KSH_F, wave, 4, Xa, ldh, lane);
+      frag_mma_pf(ai, f_ih0, Xa, ldh, lane, f_out, pk.out, wave, 4, true);          // out_layer fragments ride along
       gru_cell_fwd_epilogue(ai, gh0, bi, bh, kp, kl0 != nullptr, 1.0f / (1.0f - dm.p_drop), Xh0, ldh, H, Xx1,
                             sv.h0 + ((int64_t)t * B + b0) * H,
                             sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         bh[g] = *reinterpret_cast<const float4*>(w.b_hh1 + g * H + f0);
         ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
-      wave_gemm_p<3, KSH_F>(ai, pk.ih1, KSH_F, wave, 4, Xx1, ldh, lane);
+      frag_mma_pf(ai, f_ih1, Xx1, ldh, lane, f_pre, pk.pre, wave, 0, has_next);      // pre_linear fragments ride along
       gru_cell_fwd_epilogue(ai, gh1, bi, bh, 0x01010101u, false, 1.0f, Xh1, ldh, H, Xh1n,
                             sv.h1 + ((int64_t)t * B + b0) * H,
                             sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, nrows, i, f0);
@@ -403,7 +406,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       f32x4 acc[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (three) {
+      if (FASTC && KSD_T > 4 && KSD_T <= 12 && early) {
+        frag_mma(acc, f_out, Xh1n, ldh, lane);     // one group of 12 tiles; fragments streamed in during GRU layer 0
+      } else if (three) {
         wave_gemm_p<3, HS / 16>(acc, pk.out, Hp >> 4, base + wave, 4, Xh1n, ldh, lane);
       } else {
         f32x4 a1[1] = {acc[0]};
@@ -477,7 +482,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (t > 0) {
-        if (three) {
+        if (FASTC && KSD_T > 4 && KSD_T <= 12 && early) {
+          frag_mma(acc, f_out, Xh1n, ldh, lane);
+        } else if (three) {
           wave_gemm_p<3, HS / 16>(acc, pk.out, Hp >> 4, base + wave, 4, Xh1n, ldh, lane);
         } else {
           f32x4 a1[1] = {acc[0]};
@@ -517,7 +524,8 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
       if (vec) bp = *reinterpret_cast<const float4*>(w.b_pre + f0);
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, KSD_T>(acc, pk.pre, Dp >> 4, ft, 0, Xy, ldd, lane);
+      if (FASTC && early) frag_mma(acc, f_pre, Xy, ldd, lane);     // fragments streamed in during GRU layer 1
+      else wave_gemm_p<1, KSD_T>(acc, pk.pre, Dp >> 4, ft, 0, Xy, ldd, lane);
       float s1[4], s2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
