@@ -284,16 +284,16 @@ __device__ __forceinline__ void frag_mma(f32x4 (&acc)[NT], const WFrag<NT, KS_T>
   }
 }
 
-// frag_mma with the fragment loads of a LATER product interleaved into the MFMA stream: one 16-byte load after every
-// STRIDE MFMAs, pinned with sched_barrier.  A burst of fragment loads in front of a product costs the wave ~80 cycles
-// per load (the CU's vector-memory front end moves ~48 B/clk, shared by its 4 waves) during which its matrix pipe
-// idles; spread between MFMAs (32 cycles each) the same loads are absorbed at the rate the front end accepts them.
-template <int NT, int KS_T, int NT2, int KS2>
-__device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane,
-                                            WFrag<NT2, KS2>& nxt, const float* __restrict__ P2, int tile0_2, int tile_stride_2,
-                                            bool do_load) {
-  constexpr int NM = NT * KS_T * 4, NL = NT2 * KS2;
-  constexpr int STRIDE = (NM / NL) > 0 ? (NM / NL) : 1;
+// frag_mma with loads for LATER phases interleaved into the MFMA stream: `issue(k)`, k = 0..NL-1, is called once after
+// every STRIDE MFMAs (pinned with sched_barrier); k is a compile-time constant at each call site after unrolling, so
+// `issue` may switch on it freely.  A burst of loads in front of a product costs the wave ~80 cycles per load (the
+// CU's vector-memory front end moves ~48 B/clk, shared by its 4 waves) during which its matrix pipe idles; spread between
+// MFMAs (32 cycles each) the same loads are absorbed at the rate the front end accepts them.
+template <int NL, int NT, int KS_T, class Issue>
+__device__ __forceinline__ void frag_mma_issue(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane,
+                                               Issue issue) {
+  constexpr int NM = NT * KS_T * 4;
+  constexpr int STRIDE = (NL > 0 && NM / (NL > 0 ? NL : 1) > 0) ? NM / (NL > 0 ? NL : 1) : 1;
   const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
 #pragma unroll
   for (int s = 0; s < KS_T; ++s) {
@@ -307,21 +307,25 @@ __device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS
         acc[t] = mfma16(wv[c], xb[c], acc[t]);
         const int m = (s * 4 + c) * NT + t;
         if ((m % STRIDE) == STRIDE - 1 && (m / STRIDE) < NL) {
-          const int k = m / STRIDE, t2 = k / KS2, s2 = k % KS2;
-          if (do_load)
-            nxt.w[t2][s2] = *reinterpret_cast<const float4*>(P2 + ((int64_t)((tile0_2 + t2 * tile_stride_2) * KS2 + s2) * 64 + lane) * 4);
+          issue(m / STRIDE);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
   }
-  // loads that did not fit the stride pattern (NL > NM): issue the rest
 #pragma unroll
-  for (int k = NM / STRIDE; k < NL; ++k) {
+  for (int k = NM / STRIDE; k < NL; ++k) issue(k);     // more loads than MFMA slots: the rest in a burst
+}
+// the common case: the interleaved loads are the fragments of ONE later product
+template <int NT, int KS_T, int NT2, int KS2>
+__device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane,
+                                            WFrag<NT2, KS2>& nxt, const float* __restrict__ P2, int tile0_2, int tile_stride_2,
+                                            bool do_load) {
+  frag_mma_issue<NT2 * KS2>(acc, f, Xs, ldx, lane, [&](int k) {
     const int t2 = k / KS2, s2 = k % KS2;
     if (do_load)
       nxt.w[t2][s2] = *reinterpret_cast<const float4*>(P2 + ((int64_t)((tile0_2 + t2 * tile_stride_2) * KS2 + s2) * 64 + lane) * 4);
-  }
+  });
 }
 
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }

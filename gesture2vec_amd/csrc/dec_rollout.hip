@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   WFrag<3, KSH_F> f_hh0, f_hh1, f_ih0, f_ih1, f_out;
   WFrag<1, KSD_F> f_pre;
   f32x4 gh0[3], gh1[3];
+  float4 bi0[3], bh0[3], bi1[3], bh1[3];           // GRU biases of this lane's 4 features (early path: prefetched)
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
     gh0[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -240,8 +241,22 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     }
     lds_barrier();
     // ... and while they run, the fragments of the two input-side products stream in BETWEEN the MFMAs
-    frag_mma_pf(gh0, f_hh0, Xh0, ldh, lane, f_ih0, pk.ih0, wave, 4, true);
-    frag_mma_pf(gh1, f_hh1, Xh1, ldh, lane, f_ih1, pk.ih1, wave, 4, true);
+    const int fb = 16 * wave + 4 * q;
+    auto frag_or_bias = [&](int k, WFrag<3, KSH_F>& fr, const float* P, float4 (&b_i)[3], float4 (&b_h)[3], const float* bih,
+                            const float* bhh) {
+      if (k < 3 * KSH_F) {
+        const int t2 = k / KSH_F, s2 = k % KSH_F;
+        fr.w[t2][s2] = *reinterpret_cast<const float4*>(P + ((int64_t)((wave + 4 * t2) * KSH_F + s2) * 64 + lane) * 4);
+      } else if (k < 3 * KSH_F + 3) {
+        b_i[k - 3 * KSH_F] = *reinterpret_cast<const float4*>(bih + (k - 3 * KSH_F) * HS + fb);
+      } else {
+        b_h[k - 3 * KSH_F - 3] = *reinterpret_cast<const float4*>(bhh + (k - 3 * KSH_F - 3) * HS + fb);
+      }
+    };
+    frag_mma_issue<3 * KSH_F + 6>(gh0, f_hh0, Xh0, ldh, lane,
+                                  [&](int k) { frag_or_bias(k, f_ih0, pk.ih0, bi0, bh0, w.b_ih0, w.b_hh0); });
+    frag_mma_issue<3 * KSH_F + 6>(gh1, f_hh1, Xh1, ldh, lane,
+                                  [&](int k) { frag_or_bias(k, f_ih1, pk.ih1, bi1, bh1, w.b_ih1, w.b_hh1); });
   };
   // Zero what the MFMA contractions must see as zero: padding columns and rows >= nrows of every operand tile.
   // (full tiles of an H % 16 == 0 model have no H padding at all: only the D padding of Xy is touched)
@@ -339,30 +354,20 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       const uint8_t* kl0 = drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr;
       uint32_t kp = 0x01010101u;
       if (kl0) kp = *reinterpret_cast<const uint32_t*>(kl0 + (int64_t)i * H + f0);
-      float4 bi[3], bh[3];
-#pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        bi[g] = *reinterpret_cast<const float4*>(w.b_ih0 + g * H + f0);
-        bh[g] = *reinterpret_cast<const float4*>(w.b_hh0 + g * H + f0);
-      }
       f32x4 ai[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       frag_mma_pf(ai, f_ih0, Xa, ldh, lane, f_out, pk.out, wave, 4, true);          // out_layer fragments ride along
-      gru_cell_fwd_epilogue(ai, gh0, bi, bh, kp, kl0 != nullptr, 1.0f / (1.0f - dm.p_drop), Xh0, ldh, H, Xx1,
+      gru_cell_fwd_epilogue(ai, gh0, bi0, bh0, kp, kl0 != nullptr, 1.0f / (1.0f - dm.p_drop), Xh0, ldh, H, Xx1,
                             sv.h0 + ((int64_t)t * B + b0) * H,
                             sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
                             (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, i, f0);
       lds_barrier();
       STAMP(4);
 #pragma unroll
-      for (int g = 0; g < 3; ++g) {
-        bi[g] = *reinterpret_cast<const float4*>(w.b_ih1 + g * H + f0);
-        bh[g] = *reinterpret_cast<const float4*>(w.b_hh1 + g * H + f0);
-        ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+      for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       frag_mma_pf(ai, f_ih1, Xx1, ldh, lane, f_pre, pk.pre, wave, 0, has_next);      // pre_linear fragments ride along
-      gru_cell_fwd_epilogue(ai, gh1, bi, bh, 0x01010101u, false, 1.0f, Xh1, ldh, H, Xh1n,
+      gru_cell_fwd_epilogue(ai, gh1, bi1, bh1, 0x01010101u, false, 1.0f, Xh1, ldh, H, Xh1n,
                             sv.h1 + ((int64_t)t * B + b0) * H,
                             sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, nrows, i, f0);
       lds_barrier();
