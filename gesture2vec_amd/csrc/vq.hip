@@ -196,14 +196,29 @@ __global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __rest
   };
   float4 wa0[KS], wa1[KS], wb0[KS], wb1[KS], qa0, qa1, qb0, qb1;
   load_pair(0, wa0, wa1, qa0, qa1);
-  auto consume = [&](int p, const float4 (&w0)[KS], const float4 (&w1)[KS], const float4& q0, const float4& q1) {
+  // consume pair p from (w0, w1) while the fragments of pair pn stream into (n0, n1) BETWEEN the MFMAs: a burst of 18
+  // fragment loads in front of the 64 MFMAs would cost the wave ~1.5k cycles of vector-memory issue with an idle matrix
+  // pipe; two loads per k-step (8 MFMAs = 256 cycles) are absorbed at the rate the CU's memory front end accepts them.
+  auto consume = [&](int p, const float4 (&w0)[KS], const float4 (&w1)[KS], const float4& q0, const float4& q1, bool ld,
+                     int pn, float4 (&n0)[KS], float4 (&n1)[KS], float4& nq0, float4& nq1) {
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kt0 = wave + 8 * pn, kt1 = kt0 + 4;
+    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       a0 = mfma16(w0[s].x, xb[s].x, a0); a1 = mfma16(w1[s].x, xb[s].x, a1);
       a0 = mfma16(w0[s].y, xb[s].y, a0); a1 = mfma16(w1[s].y, xb[s].y, a1);
+      if (ld) n0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
       a0 = mfma16(w0[s].z, xb[s].z, a0); a1 = mfma16(w1[s].z, xb[s].z, a1);
       a0 = mfma16(w0[s].w, xb[s].w, a0); a1 = mfma16(w1[s].w, xb[s].w, a1);
+      if (ld) n1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ld) {
+      nq0 = *reinterpret_cast<const float4*>(wsq + 16 * kt0 + 4 * q);
+      nq1 = *reinterpret_cast<const float4*>(wsq + 16 * kt1 + 4 * q);
     }
     const int c0 = 16 * (wave + 8 * p) + 4 * q, c1 = c0 + 64;
     const float s0[4] = {q0.x, q0.y, q0.z, q0.w}, s1[4] = {q1.x, q1.y, q1.z, q1.w};
@@ -219,14 +234,8 @@ __global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __rest
     }
   };
   for (int p = 0; p < npair; p += 2) {
-    if (p + 1 < npair) load_pair(p + 1, wb0, wb1, qb0, qb1);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(p, wa0, wa1, qa0, qa1);
-    if (p + 1 < npair) {
-      if (p + 2 < npair) load_pair(p + 2, wa0, wa1, qa0, qa1);
-      __builtin_amdgcn_sched_barrier(0);
-      consume(p + 1, wb0, wb1, qb0, qb1);
-    }
+    consume(p, wa0, wa1, qa0, qa1, p + 1 < npair, p + 1, wb0, wb1, qb0, qb1);
+    if (p + 1 < npair) consume(p + 1, wb0, wb1, qb0, qb1, p + 2 < npair, p + 2, wa0, wa1, qa0, qa1);
   }
   {
     float d2 = __shfl_xor(bd, 16);
