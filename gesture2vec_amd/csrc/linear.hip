@@ -572,19 +572,81 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restri
     }
     }
   };
+  // fp32 path: multiply group (a, b) while the operand loads of group `mn` are issued BETWEEN the MFMAs into (an, bn): a
+  // burst of 20-40 loads in front of the 96 MFMAs stalls the wave on the CU's vector-memory front end with an idle matrix
+  // pipe; one load per few MFMAs is absorbed at the rate the front end accepts it.
+  auto compute_and_load = [&](float (&a)[4][TN_], float (&b)[4][TK_], int mn, float (&an)[4][TN_], float (&bn)[4][TK_]) {
+    constexpr int NMQ = TN_ * TK_, NLQ = (TN_ + TK_) / VW;
+    constexpr int STRIDE = (NMQ / NLQ) > 0 ? (NMQ / NLQ) : 1;
+    int mrow = mn + q, outer = 0, inner = 0;
+    if (MAPPED) { outer = mrow / xm.rows_inner; inner = mrow - outer * xm.rows_inner; }
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      if constexpr (VW == 1) {
+        a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;
+        b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
+      }
+      const float* dr = dY + (int64_t)mrow * lddy + n0;
+      const float* xr = X + (MAPPED ? (int64_t)outer * xm.so + (int64_t)inner * xm.si : (int64_t)mrow * xm.ld) + k0;
+      auto issue = [&](int k) {
+        if constexpr (VW == 2) {
+          if (k < TN_ / 2) {
+            const float2 v = *reinterpret_cast<const float2*>(dr + 32 * k + 2 * i);
+            an[qd][2 * k] = v.x;
+            an[qd][2 * k + 1] = v.y;
+          } else {
+            const int h = k - TN_ / 2;
+            const float2 v = *reinterpret_cast<const float2*>(xr + 32 * h + 2 * i);
+            bn[qd][2 * h] = v.x;
+            bn[qd][2 * h + 1] = v.y;
+          }
+        } else {
+          if (k < TN_ - 1) an[qd][k] = dr[16 * k + i];
+          else if (k == TN_ - 1) an[qd][k] = dr[16 * (TN_ - 1) + in_last];
+          else if (k < TN_ + TK_ - 1) bn[qd][k - TN_] = xr[16 * (k - TN_) + i];
+          else bn[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+        }
+      };
+#pragma unroll
+      for (int t = 0; t < TN_; ++t) {
+        dbs[t] += a[qd][t];
+#pragma unroll
+        for (int u = 0; u < TK_; ++u) {
+          acc[t][u] = mfma16(a[qd][t], b[qd][u], acc[t][u]);
+          const int m = t * TK_ + u;
+          if ((m % STRIDE) == STRIDE - 1 && (m / STRIDE) < NLQ) {
+            issue(m / STRIDE);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = NMQ / STRIDE; k < NLQ; ++k) issue(k);
+      mrow += 4;
+      if (MAPPED) {
+        inner += 4;
+        if (inner >= xm.rows_inner) { inner -= xm.rows_inner; ++outer; }
+      }
+    }
+  };
   // ping-pong over two register buffers (no copies): the loads of the next 16 rows are always in flight while the
   // current 16 are multiplied
   int m0 = mb;
   if (m0 < me) load_group(m0, ca, cb);
   for (; m0 + 32 <= me; m0 += 32) {
-    load_group(m0 + 16, na, nb);
-    __builtin_amdgcn_sched_barrier(0);
-    compute(ca, cb);
-    __builtin_amdgcn_sched_barrier(0);
-    load_group(min(m0 + 32, M - 16), ca, cb);   // past the end of the range: a valid, unused group
-    __builtin_amdgcn_sched_barrier(0);
-    compute(na, nb);
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (BF3) {
+      load_group(m0 + 16, na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+      compute(ca, cb);
+      __builtin_amdgcn_sched_barrier(0);
+      load_group(min(m0 + 32, M - 16), ca, cb);   // past the end of the range: a valid, unused group
+      __builtin_amdgcn_sched_barrier(0);
+      compute(na, nb);
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
+      compute_and_load(ca, cb, m0 + 16, na, nb);
+      compute_and_load(na, nb, min(m0 + 32, M - 16), ca, cb);
+    }
   }
   if (m0 < me) compute(ca, cb);                 // odd number of groups: the last one is already loaded
   // ---- sum the four row ranges of each tile group: (2,3) -> LDS -> (0,1); 1 -> LDS -> 0; range 0 writes the slab ----
