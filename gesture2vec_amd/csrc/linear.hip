@@ -295,8 +295,19 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
   int g = blockIdx.x * 4 + wave;
   if (g < ngroups) load_group(g, xa);
   for (; g < ngroups; g += gstride) {
-    load_group(min(g + gstride, ngroups - 1), xn);    // past the end: a valid, unused group
-    __builtin_amdgcn_sched_barrier(0);
+    // the next group's KS4 operand loads are issued one per k-step, BETWEEN the MFMAs (a burst in front of them would
+    // stall the wave on the vector-memory front end with an idle matrix pipe)
+    const int gn = min(g + gstride, ngroups - 1);      // past the end: a valid, unused group
+    const int mn = 16 * gn + i;
+    int64_t offn;
+    if (MAPPED) {
+      const int outer = mn / am.rows_inner, inner = mn - outer * am.rows_inner;
+      offn = (int64_t)outer * am.so + (int64_t)inner * am.si;
+    } else {
+      offn = (int64_t)mn * am.ld;
+    }
+    const float* pn = A + offn;
+    const float* pqn = pn + q;
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -307,6 +318,8 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
       acc[1] = mfma16(wa.y, xa[s2], acc[1]);
       acc[2] = mfma16(wa.z, xa[s2], acc[2]);
       acc[3] = mfma16(wa.w, xa[s2], acc[3]);
+      xn[s2] = (s2 < KS4 - 1) ? pqn[4 * s2] : pn[col_last];
+      __builtin_amdgcn_sched_barrier(0);
     }
     float* crow = Cout + (int64_t)(16 * g + i) * ldc + 4 * q;
 #pragma unroll
