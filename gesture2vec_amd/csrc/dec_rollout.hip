@@ -25,8 +25,10 @@ namespace g2v {
 __device__ unsigned long long g2v_stamps[64 * 16];
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
-    if (threadIdx.x == 0 && blockIdx.x < 4 && t == 5)                                              \
-      g2v_stamps[blockIdx.x * 16 + (k)] = __builtin_amdgcn_s_memtime();                           \
+    const int sb_ = blockIdx.x < 4 ? (int)blockIdx.x                                               \
+                    : (blockIdx.x == 100 ? 4 : (blockIdx.x == 150 ? 5 : (blockIdx.x == 200 ? 6 : (blockIdx.x == 255 ? 7 : -1)))); \
+    if (threadIdx.x == 0 && sb_ >= 0 && t == 5)                                                    \
+      g2v_stamps[sb_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                                   \
   } while (0)
 #define STAMPB(k) STAMP(8 + (k))
 #else

@@ -20,9 +20,9 @@ torch.cuda.synchronize()
 raw = ctypes.CDLL(dbg)
 buf = (ctypes.c_ulonglong * (64 * 16))()
 print("rc", raw.g2v_read_stamps(buf))
-for b in range(4):
+for b in range(8):
     st = [buf[b * 16 + k] for k in range(8)]
     print("fwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
-for b in range(4):
+for b in range(8):
     st = [buf[b * 16 + 8 + k] for k in range(8)]
-    print("bwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
+    print("bwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0], "start-vs-blk0", st[0] - buf[8], "end-vs-blk0start", st[7] - buf[8])
