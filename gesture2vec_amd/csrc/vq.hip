@@ -333,10 +333,13 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
     for (int s = 0; s < KS; ++s) w[s] = *reinterpret_cast<const float4*>(rp + 16 * s);
     sq = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
   };
-  auto consume = [&](int j, const float4 (&w)[KS], const float4& sq) {
+  // consume tile j from w while the fragments of tile jn stream into wn, one load per k-step BETWEEN the MFMAs
+  auto consume = [&](int j, const float4 (&w)[KS], const float4& sq, bool ld, int jn, float4 (&wn)[KS], float4& sqn) {
     f32x4 acc[RT];
 #pragma unroll
     for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int ktn = wave + 4 * jn;
+    const float* rpn = W + (int64_t)(16 * ktn + i) * E + 4 * q;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       float4 xb[RT];
@@ -346,11 +349,14 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
       for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].x, xb[t].x, acc[t]);
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].y, xb[t].y, acc[t]);
+      if (ld) wn[s] = *reinterpret_cast<const float4*>(rpn + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].z, xb[t].z, acc[t]);
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = mfma16(w[s].w, xb[t].w, acc[t]);
     }
+    if (ld) sqn = *reinterpret_cast<const float4*>(wsq + 16 * ktn + 4 * q);
     const int c0 = 16 * (wave + 4 * j) + 4 * q;
     const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
 #pragma unroll
@@ -364,14 +370,8 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   float4 wa[KS], wb[KS], qa, qb;
   load_tile(0, wa, qa);
   for (int j = 0; j < ntw; j += 2) {
-    if (j + 1 < ntw) load_tile(j + 1, wb, qb);
-    __builtin_amdgcn_sched_barrier(0);
-    consume(j, wa, qa);
-    if (j + 1 < ntw) {
-      if (j + 2 < ntw) load_tile(j + 2, wa, qa);
-      __builtin_amdgcn_sched_barrier(0);
-      consume(j + 1, wb, qb);
-    }
+    consume(j, wa, qa, j + 1 < ntw, j + 1, wb, qb);
+    if (j + 1 < ntw) consume(j + 1, wb, qb, j + 2 < ntw, j + 2, wa, qa);
   }
 #pragma unroll
   for (int t = 0; t < RT; ++t) {
