@@ -497,14 +497,19 @@ __device__ __forceinline__ void reduce_partials_128_hook(const float* __restrict
   float4 s[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) s[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 v[16];
+  float4 v[16], v2[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int k = kb + j;
     v[j] = p[(int64_t)(k < ke ? k : 0) * nc4];      // clamped address: no branch around the load
   }
   __builtin_amdgcn_sched_barrier(0);                // the loads stay ahead of the hook (hipcc would sink them below it)
-  between();
+  // The hook receives `issue2(j)`, j = 0..15: the second batch of 16 rows, to be requested one at a time from INSIDE the
+  // hook's MFMA stream (a second burst after the hook would expose a full L2 round trip).  It must call each j once.
+  between([&](int j) {
+    const int k = kb + 16 + j;
+    v2[j] = p[(int64_t)(k < ke ? k : 0) * nc4];
+  });
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
@@ -512,16 +517,13 @@ __device__ __forceinline__ void reduce_partials_128_hook(const float* __restrict
     s[j & 3].x += ok ? v[j].x : 0.f; s[j & 3].y += ok ? v[j].y : 0.f;
     s[j & 3].z += ok ? v[j].z : 0.f; s[j & 3].w += ok ? v[j].w : 0.f;
   }
-  int k = kb + 16;
-  for (; k + 16 <= ke; k += 16) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = p[(int64_t)(k + j) * nc4];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      s[j & 3].x += v[j].x; s[j & 3].y += v[j].y; s[j & 3].z += v[j].z; s[j & 3].w += v[j].w;
-    }
+  for (int j = 0; j < 16; ++j) {
+    const bool ok = kb + 16 + j < ke;
+    s[j & 3].x += ok ? v2[j].x : 0.f; s[j & 3].y += ok ? v2[j].y : 0.f;
+    s[j & 3].z += ok ? v2[j].z : 0.f; s[j & 3].w += ok ? v2[j].w : 0.f;
   }
-  for (; k < ke; ++k) {
+  for (int k = kb + 32; k < ke; ++k) {              // nblk > 256: the remainder, one by one
     const float4 w = p[(int64_t)k * nc4];
     s[0].x += w.x; s[0].y += w.y; s[0].z += w.z; s[0].w += w.w;
   }

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       kpre[j] = kp4[e4 < n4 ? e4 : 0];
     }
   }
-  auto early_products = [&]() {
+  auto early_products = [&](auto issue2) {
     // stage h0_{t-1}, h1_{t-1} and run the two hidden-side products (3 gates x 4 k-steps x 4 MFMAs each)
     if (pvalid) {
       *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
@@ -257,8 +257,11 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     };
     frag_mma_issue<3 * KSH_F + 6>(gh0, f_hh0, Xh0, ldh, lane,
                                   [&](int k) { frag_or_bias(k, f_ih0, pk.ih0, bi0, bh0, w.b_ih0, w.b_hh0); });
-    frag_mma_issue<3 * KSH_F + 6>(gh1, f_hh1, Xh1, ldh, lane,
-                                  [&](int k) { frag_or_bias(k, f_ih1, pk.ih1, bi1, bh1, w.b_ih1, w.b_hh1); });
+    // the second product also carries the second batch of BatchNorm-partial rows (issue2)
+    frag_mma_issue<3 * KSH_F + 6 + 16>(gh1, f_hh1, Xh1, ldh, lane, [&](int k) {
+      if (k < 3 * KSH_F + 6) frag_or_bias(k, f_ih1, pk.ih1, bi1, bh1, w.b_ih1, w.b_hh1);
+      else issue2(k - (3 * KSH_F + 6));
+    });
   };
   // Zero what the MFMA contractions must see as zero: padding columns and rows >= nrows of every operand tile.
   // (full tiles of an H % 16 == 0 model have no H padding at all: only the D padding of Xy is touched)
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         }
       }
     } else {
-      if (early) early_products();
+      if (early) early_products([](int) {});
       for (int f = tid; f < H; f += 256) {
         st[f] = w.bn_running_mean[f];
         st[Hp + f] = 1.0f / sqrtf(w.bn_running_var[f] + 1e-5f);
