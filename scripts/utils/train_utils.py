@@ -1,7 +1,7 @@
 """Logging / checkpoint helpers with the reference's contract (scripts/utils/train_utils.py:43-175):
 checkpoint = torch.save({"args", "epoch", "lang_model", "pose_dim", "gen_dict"[, "val_metrics_list", "loss_list"]}),
 `load_checkpoint_and_model(path, device, what)` rebuilds the model through the matching train script's init_model.
-Only the branches on the accelerated path exist here ("autoencoder_vq"); the others raise."""
+The three model kinds on the accelerated path exist here ("autoencoder_vq", "DAE", "text2embedding"); others raise."""
 from __future__ import annotations
 
 import logging
@@ -49,6 +49,16 @@ def load_checkpoint_and_model(checkpoint_path, _device="cpu", what: str = ""):
         from train_autoencoder_VQVAE import init_model as VQVAE_init
         generator, loss_fn = VQVAE_init(args, lang_model, pose_dim, "cpu")
         # reference checkpoints trained with the shipped GSSoft override carry mean_layer/logvar_layer keys: refuse them
+        generator.load_state_dict(checkpoint["gen_dict"], strict=True)
+        generator = generator.to(_device)
+    elif what == "DAE":
+        from train_DAE import init_model as DAE_init
+        generator, loss_fn = DAE_init(args, lang_model, pose_dim, "cpu")
+        generator.load_state_dict(checkpoint["gen_dict"], strict=True)
+        generator = generator.to(_device)
+    elif what == "text2embedding":
+        from train_text2embedding import init_model as t2e_init
+        generator, loss_fn = t2e_init(args, lang_model, pose_dim, "cpu")
         generator.load_state_dict(checkpoint["gen_dict"], strict=True)
         generator = generator.to(_device)
     else:

@@ -44,3 +44,44 @@ def test_train_text2embedding_synthetic(tmp_path):
     ckpt = torch.load(os.path.join(out, "t_checkpoint_010.bin"), map_location="cpu", weights_only=False)
     assert set(ckpt) == {"args", "epoch", "lang_model", "pose_dim", "gen_dict"} and ckpt["pose_dim"] == 512
     assert "encoder.embedding.weight" in ckpt["gen_dict"] and "decoder.decoder.out.weight" in ckpt["gen_dict"]
+
+
+def test_train_dae_synthetic_and_reload(tmp_path):
+    """Part a trainer (train_DAE.py counterpart): epochs -> checkpoint with the reference's keys / file name -> reload
+    through load_checkpoint_and_model(what="DAE"); the loss goes down on the synthetic frames."""
+    out = os.path.join(tmp_path, "run_dae")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_DAE.py"),
+           "--config", os.path.join(ROOT, "config", "DAE_synthetic.yml"), "--synthetic", "--synthetic_batches", "10",
+           "--batch_size", "256", "--epochs", "20", "--model_save_path", out, "--name", "t"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    vals = [float(l.split("[VAL] loss:")[1].split("/")[0]) for l in log.splitlines() if "[VAL] loss:" in l]
+    assert len(vals) == 20 and vals[-1] < 0.9 * vals[0], vals
+    path = os.path.join(out, "t_H40_checkpoint_020.bin")
+    ckpt = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ckpt) == {"args", "epoch", "lang_model", "pose_dim", "gen_dict"} and ckpt["pose_dim"] == 135
+    assert set(ckpt["gen_dict"]) == {"encoder.0.weight", "encoder.0.bias", "decoder.0.weight", "decoder.0.bias"}
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import utils.train_utils as tu
+    args, net, loss_fn, lang, pose_dim = tu.load_checkpoint_and_model(path, "cuda:0", "DAE")
+    x = torch.randn(16, 135, 1, device="cuda:0")
+    with torch.no_grad():
+        y = net(x)
+    assert y.shape == (16, 135, 1) and not net.training and torch.isfinite(y).all()
+
+
+def test_text2embedding_checkpoint_reload(tmp_path):
+    out = os.path.join(tmp_path, "run_t2e2")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_text2embedding.py"),
+           "--config", os.path.join(ROOT, "config", "seq2seq_synthetic.yml"), "--synthetic", "--synthetic_batches", "1",
+           "--batch_size", "16", "--epochs", "10", "--hidden_size", "32", "--autoencoder_att", "True", "--model_save_path", out,
+           "--name", "t"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import utils.train_utils as tu
+    args, net, loss_fn, lang, pose_dim = tu.load_checkpoint_and_model(os.path.join(out, "t_checkpoint_010.bin"), "cuda:0",
+                                                                       "text2embedding")
+    assert args.autoencoder_att == "True" and not net.training
+    assert any(k.startswith("decoder.decoder.attn.") for k in net.state_dict())
