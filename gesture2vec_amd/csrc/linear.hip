@@ -741,33 +741,58 @@ static int tn_wave_grid(int M, int K, int N, bool has_keep, int* rows_per_wave) 
   return cdiv(M, 4 * rpw);
 }
 
-// two slab families in one launch: blocks [0, nblk_a) reduce (slab_a -> out_a), the rest (slab_b -> out_b)
+// two slab families in one launch: blocks [0, nblk_a) reduce (slab_a -> out_a), the rest (slab_b -> out_b).
+// A workgroup owns 32 consecutive outputs: 8 float4 columns x 32 slab groups (thread (grp, c4) sums slabs grp, grp+32,
+// ... of its float4 column, every load independent), then the 32 group partials are summed through LDS in a fixed
+// order.  n % 4 == 0 for the float4 path; otherwise (the 135-wide bias vectors) a scalar path with the same structure.
 __global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ slab_a, int64_t na, float* __restrict__ out_a,
                                                            const float* __restrict__ slab_b, int64_t nb, float* __restrict__ out_b,
                                                            int nsplit, int accumulate, int nblk_a) {
-  __shared__ float red[4][64];
+  __shared__ __attribute__((aligned(16))) float red[32][36];
   const bool first = (int)blockIdx.x < nblk_a;
   const float* slab = first ? slab_a : slab_b;
   const int64_t n = first ? na : nb;
   float* out = first ? out_a : out_b;
-  const int col = threadIdx.x & 63, grp = threadIdx.x >> 6;
-  const int64_t e = (int64_t)(first ? blockIdx.x : blockIdx.x - nblk_a) * 64 + col;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  if (e < n) {
-    int p = grp;
-    for (; p + 12 < nsplit; p += 16) {
-      s0 += slab[(int64_t)p * n + e];
-      s1 += slab[(int64_t)(p + 4) * n + e];
-      s2 += slab[(int64_t)(p + 8) * n + e];
-      s3 += slab[(int64_t)(p + 12) * n + e];
+  const int64_t e0 = (int64_t)(first ? blockIdx.x : blockIdx.x - nblk_a) * 32;
+  const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  if ((n & 3) == 0) {
+    const int64_t e = e0 + 4 * c4;
+    if (e < n) {
+      float4 t0 = s, t1 = s;
+      int p = grp;
+      for (; p + 32 < nsplit; p += 64) {
+        const float4 a = *reinterpret_cast<const float4*>(slab + (int64_t)p * n + e);
+        const float4 b2 = *reinterpret_cast<const float4*>(slab + (int64_t)(p + 32) * n + e);
+        t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
+        t1.x += b2.x; t1.y += b2.y; t1.z += b2.z; t1.w += b2.w;
+      }
+      if (p < nsplit) {
+        const float4 a = *reinterpret_cast<const float4*>(slab + (int64_t)p * n + e);
+        t0.x += a.x; t0.y += a.y; t0.z += a.z; t0.w += a.w;
+      }
+      s = make_float4(t0.x + t1.x, t0.y + t1.y, t0.z + t1.z, t0.w + t1.w);
     }
-    for (; p < nsplit; p += 4) s0 += slab[(int64_t)p * n + e];
+  } else {
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = e0 + 4 * c4 + j;
+      if (e < n)
+        for (int p = grp; p < nsplit; p += 32) v[j] += slab[(int64_t)p * n + e];
+    }
+    s = make_float4(v[0], v[1], v[2], v[3]);
   }
-  red[grp][col] = (s0 + s1) + (s2 + s3);
+  *reinterpret_cast<float4*>(&red[grp][4 * c4]) = s;
   __syncthreads();
-  if (grp == 0 && e < n) {
-    const float t = (red[0][col] + red[1][col]) + (red[2][col] + red[3][col]);
-    out[e] = accumulate ? out[e] + t : t;
+  if (threadIdx.x < 32) {
+    const int64_t e = e0 + threadIdx.x;
+    if (e < n) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 32; ++g) t += red[g][threadIdx.x];
+      out[e] = accumulate ? out[e] + t : t;
+    }
   }
 }
 
@@ -899,8 +924,8 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
   G2V_CHECK_LAUNCH();
   const int64_t n = (int64_t)N * K;
   // one launch reduces both the weight slabs and (when requested) the bias slabs
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 64) + (db ? cdiv(N, 64) : 0)), dim3(256), 0, (hipStream_t)stream,
-                     slab, n, dw, slab_db, (int64_t)N, db, splits, accumulate, cdiv(n, 64));
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 32) + (db ? cdiv(N, 32) : 0)), dim3(256), 0, (hipStream_t)stream,
+                     slab, n, dw, slab_db, (int64_t)N, db, splits, accumulate, cdiv(n, 32));
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
