@@ -558,3 +558,42 @@ def test_linear_bwd_weight_bf16x3_option_is_bounded():
     assert float((dw32.double() - ref).abs().max()) <= 2e-6 * scale
     assert float((dwb.double() - ref).abs().max()) <= 1e-4 * scale
     relclose(dbb, dy.double().sum(0).float(), 2e-6, "db")
+
+
+def test_linear_wave_kernels_at_rollout_shapes(ops):
+    """The wave-autonomous dense-layer kernels at the shapes that select them (M >= 4096, the BASELINE layer widths):
+    unaligned row-mapped in_layer forward (K = 135), streaming forward / data gradient (64 <-> 192), weight gradients
+    192x64, 64x135 (row-mapped x) and 135x64, all against float64 references."""
+    B, T, D, H, G = 256, 32, 135, 64, 192
+    M = B * T
+    x_btd = rnd(B, T, D, seed=11)
+    x_tbd = x_btd.transpose(0, 1).reshape(M, D)
+    w_in, b_in = rnd(H, D, seed=12, scale=0.1), rnd(H, seed=13)
+    # forward, K = 135, rows read in (T,B) order straight from the (B,T,D) tensor, and from a plain (M,D) tensor
+    y = ops.linear_fwd(x_btd.to(DEV), w_in.to(DEV), b_in.to(DEV), M=M, row_map=(B, D, T * D))
+    ref = (x_tbd.double() @ w_in.double().t() + b_in.double()).float()
+    relclose(y, ref, 2e-6, "in_layer fwd (row map)")
+    y2 = ops.linear_fwd(x_tbd.contiguous().to(DEV), w_in.to(DEV), b_in.to(DEV), act=1)
+    relclose(y2, torch.relu(ref), 2e-6, "in_layer fwd (plain, relu)")
+    # streaming forward 64 -> 192 and data gradient 192 -> 64
+    xin, w_ih, b_ih = rnd(M, H, seed=14), rnd(G, H, seed=15, scale=0.2), rnd(G, seed=16)
+    gi = ops.linear_fwd(xin.to(DEV), w_ih.to(DEV), b_ih.to(DEV))
+    relclose(gi, (xin.double() @ w_ih.double().t() + b_ih.double()).float(), 2e-6, "gi fwd")
+    dgi = rnd(M, G, seed=17)
+    dx = ops.linear_bwd_data(dgi.to(DEV), w_ih.to(DEV))
+    relclose(dx, (dgi.double() @ w_ih.double()).float(), 2e-6, "bwd_data 192->64")
+    dx2 = ops.linear_bwd_data(dgi.to(DEV), w_ih.to(DEV), out=dx.clone(), accumulate=True)
+    relclose(dx2, 2 * (dgi.double() @ w_ih.double()).float(), 2e-6, "bwd_data accumulate")
+    # weight gradients
+    dw, db = ops.linear_bwd_weight(dgi.to(DEV), xin.to(DEV), G, H)
+    relclose(dw, (dgi.double().t() @ xin.double()).float(), 1e-5, "dW 192x64")
+    relclose(db, dgi.double().sum(0).float(), 1e-5, "db 192")
+    du = rnd(M, H, seed=18)
+    dw_in, db_in = ops.linear_bwd_weight(du.to(DEV), x_btd.to(DEV), H, D, M=M, row_map=(B, D, T * D))
+    relclose(dw_in, (du.double().t() @ x_tbd.double()).float(), 1e-5, "dW 64x135 (row map)")
+    relclose(db_in, du.double().sum(0).float(), 1e-5, "db 64")
+    dy, h1 = rnd(M, D, seed=19), rnd(M, H, seed=20)
+    dw_out, db_out = ops.linear_bwd_weight(dy.to(DEV), h1.to(DEV), D, H)
+    relclose(dw_out, (dy.double().t() @ h1.double()).float(), 1e-5, "dW 135x64")
+    relclose(db_out, dy.double().sum(0).float(), 1e-5, "db 135")
+    assert torch.equal(ops.linear_bwd_weight(dy.to(DEV), h1.to(DEV), D, H)[0], dw_out), "weight gradient must be deterministic"
