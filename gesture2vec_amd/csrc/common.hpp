@@ -90,6 +90,53 @@ __device__ __forceinline__ void wave_gemm(f32x4 (&acc)[NT], const float* __restr
   const float* wrow[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) wrow[t] = W + (int64_t)(n0 + t * nstride + (valid ? i : 0)) * ldw;
+  if (wvec) {
+    // 16-byte-aligned rows (K % 4 == 0): branch-free fragment loads (clamped address + select), four k-steps per chunk,
+    // the NEXT chunk's 4*NT loads in flight while the current chunk's 16*NT MFMAs run (one exposed L2 round trip per
+    // 4 k-steps instead of one per k-step).
+    constexpr int CH = 4;
+    const int nks = Kp >> 4, nch = (nks + CH - 1) / CH;
+    float4 wa[CH][NT], wb[CH][NT];
+    auto loadc = [&](int c, float4 (&w)[CH][NT]) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int k = 16 * (c * CH + j) + 4 * q;
+        const bool ok = valid && (k < K);
+        const int kk = ok ? k : 0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const float4 v = *reinterpret_cast<const float4*>(wrow[t] + kk);
+          w[j][t] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+    };
+    auto mmac = [&](int c, const float4 (&w)[CH][NT]) {
+#pragma unroll
+      for (int j = 0; j < CH; ++j) {
+        const int ks = c * CH + j;
+        if (ks < nks) {
+          const float4 xb = *reinterpret_cast<const float4*>(Xs + i * ldx + 16 * ks + 4 * q);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            acc[t] = mfma16(w[j][t].x, xb.x, acc[t]);
+            acc[t] = mfma16(w[j][t].y, xb.y, acc[t]);
+            acc[t] = mfma16(w[j][t].z, xb.z, acc[t]);
+            acc[t] = mfma16(w[j][t].w, xb.w, acc[t]);
+          }
+        }
+      }
+    };
+    loadc(0, wa);
+    for (int c = 0; c < nch; c += 2) {
+      loadc(c + 1, wb);                    // past the end: clamped addresses, zero fragments
+      __builtin_amdgcn_sched_barrier(0);
+      mmac(c, wa);
+      loadc(c + 2, wa);
+      __builtin_amdgcn_sched_barrier(0);
+      if (c + 1 < nch) mmac(c + 1, wb);
+    }
+    return;
+  }
   for (int k0 = 0; k0 < Kp; k0 += 16) {
     const float4 xb = *reinterpret_cast<const float4*>(Xs + i * ldx + k0 + 4 * q);
     float4 wa[NT];
