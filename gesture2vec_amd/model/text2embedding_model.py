@@ -263,3 +263,144 @@ class text2embedding_model(nn.Module):
             outs.append(logits)
             dec_in = cod[t] if t < self.n_pre_poses else ops.argmax_rows(logits.detach().contiguous())
         return torch.stack(outs).transpose(0, 1), attentions_list
+
+
+# ---- the "*_New" tutorial-style classes (reference :754-1002; imported by train_text2embedding.py:57, never
+# instantiated there).  Same parameters / state_dict keys / forward semantics on the HIP operators. ------------------------
+class _GRULayer1(nn.Module):
+    """Parameters of a 1-layer nn.GRU (optionally bidirectional) under nn.GRU's own names."""
+
+    def __init__(self, input_size: int, hidden_size: int, bidirectional: bool):
+        super().__init__()
+        self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
+        k = 1.0 / math.sqrt(hidden_size)
+        for suf in ("", "_reverse") if bidirectional else ("",):
+            for name, shape in (("weight_ih_l0", (3 * hidden_size, input_size)), ("weight_hh_l0", (3 * hidden_size, hidden_size)),
+                                ("bias_ih_l0", (3 * hidden_size,)), ("bias_hh_l0", (3 * hidden_size,))):
+                self.register_parameter(name + suf, nn.Parameter(torch.empty(*shape).uniform_(-k, k)))
+
+
+class EncoderRNN_New(nn.Module):
+    """Embedding(input_size, 300) -> 1-layer bidirectional nn.GRU that the reference feeds ONE time step per call with the
+    carried hidden state (:953-955): both "directions" therefore run forward in time (two independent GRUs with the
+    l0 / l0_reverse weights).  `forward(input (B,), hidden (2,B,H))` is that single step; `run(ids (Tw,B))` is the whole
+    loop as two full-sequence kernels."""
+
+    def __init__(self, input_size: int, hidden_size: int, n_layer: int = 2, pre_trained_embedding=None):
+        super().__init__()
+        if n_layer != 1:
+            raise NotImplementedError("text2embedding_model_New builds EncoderRNN_New with n_layer = 1 (:918)")
+        self.hidden_size, self.n_layer, self.embed_size = hidden_size, n_layer, 300
+        if pre_trained_embedding is not None:
+            assert pre_trained_embedding.shape[0] == input_size and pre_trained_embedding.shape[1] == self.embed_size
+            self.embedding = nn.Embedding.from_pretrained(torch.FloatTensor(pre_trained_embedding), freeze=False)
+        else:
+            self.embedding = nn.Embedding(input_size, self.embed_size)
+        self.gru = _GRULayer1(self.embed_size, hidden_size, bidirectional=True)
+
+    def run(self, ids_tb: torch.Tensor, hidden: Optional[torch.Tensor] = None):
+        """(Tw,B) ids -> (outputs (Tw,B,2H), hidden (2,B,H)): every time step of the reference's loop at once."""
+        Tw, B = ids_tb.shape
+        H = self.hidden_size
+        x = Fn.EmbeddingFn.apply(self.embedding.weight, ids_tb.contiguous().view(-1), None, 1.0)
+        outs, hs = [], []
+        for k, suf in enumerate(("", "_reverse")):
+            gi = Fn.linear(x, getattr(self.gru, "weight_ih_l0" + suf), getattr(self.gru, "bias_ih_l0" + suf))
+            h0 = hidden[k].contiguous() if hidden is not None else None
+            o, h = Fn.GRUDirFn.apply(gi.view(Tw, B, 3 * H), getattr(self.gru, "weight_hh_l0" + suf),
+                                     getattr(self.gru, "bias_hh_l0" + suf), h0, None, False)      # forward in time, both
+            outs.append(o)
+            hs.append(h)
+        return torch.cat(outs, 2), torch.stack(hs)
+
+    def forward(self, input: torch.Tensor, hidden: torch.Tensor):
+        out, hidden = self.run(input.view(1, -1), hidden)
+        return out, hidden
+
+    def initHidden(self) -> torch.Tensor:
+        return torch.zeros(2 * self.n_layer, 128, self.hidden_size, device=self.embedding.weight.device)   # batch 128 (:795-802)
+
+
+class DecoderRNN_New(nn.Module):
+    """Embedding(output_size, H) -> nn.GRU(H, H, 1 layer) -> Linear(H, output_size); one step per call (:805-844)."""
+
+    def __init__(self, hidden_size: int, output_size: int, n_layer: int = 2):
+        super().__init__()
+        if n_layer != 1:
+            raise NotImplementedError("text2embedding_model_New builds DecoderRNN_New with n_layer = 1 (:918)")
+        self.hidden_size, self.ouput_size, self.n_layer = hidden_size, output_size, n_layer
+        self.embedding = nn.Embedding(output_size, hidden_size)
+        self.gru = _GRULayer1(hidden_size, hidden_size, bidirectional=False)
+        self.fc_out = nn.Linear(hidden_size, output_size)
+
+    def forward(self, input: torch.Tensor, hidden: torch.Tensor):
+        """input (B,) code ids, hidden (1,B,H) -> (output (1,B,output_size), hidden (1,B,H))"""
+        B, H = input.shape[0], self.hidden_size
+        e = Fn.EmbeddingFn.apply(self.embedding.weight, input, None, 1.0)
+        gi = Fn.linear(e, self.gru.weight_ih_l0, self.gru.bias_ih_l0)
+        _, h = Fn.GRUDirFn.apply(gi.view(1, B, 3 * H), self.gru.weight_hh_l0, self.gru.bias_hh_l0, hidden[0].contiguous(), None, False)
+        out = Fn.linear(h, self.fc_out.weight, self.fc_out.bias)
+        return out.unsqueeze(0), h.unsqueeze(0)
+
+    def initHidden(self) -> torch.Tensor:
+        return torch.zeros(1, 1, self.hidden_size, device=self.embedding.weight.device)
+
+
+MAX_LENGTH = 4
+
+
+class AttnDecoderRNN_New(nn.Module):
+    """Parameters of the reference's batch-1 tutorial attention decoder (:847-903) so that its state_dict round-trips;
+    the class is dead code in the reference (nothing constructs it) and its forward is not on the accelerated path."""
+
+    def __init__(self, hidden_size: int, output_size: int, dropout_p: float = 0.1, max_length: int = MAX_LENGTH):
+        super().__init__()
+        self.hidden_size, self.output_size, self.dropout_p, self.max_length = hidden_size, output_size, dropout_p, max_length
+        self.embedding = nn.Embedding(output_size, hidden_size)
+        self.attn = nn.Linear(hidden_size * 2, max_length)
+        self.attn_combine = nn.Linear(hidden_size * 2, hidden_size)
+        self.dropout = nn.Dropout(dropout_p)
+        self.gru = _GRULayer1(hidden_size, hidden_size, bidirectional=False)
+        self.out = nn.Linear(hidden_size, output_size)
+
+    def forward(self, input, hidden, encoder_outputs):
+        raise NotImplementedError("AttnDecoderRNN_New.forward (batch-1 tutorial code, never called by the reference) is not built")
+
+
+class text2embedding_model_New(nn.Module):
+    """Reference :906-1002: EncoderRNN_New(3863, H, 1) + DecoderRNN_New(H, K + 2, 1); SOS = 512 / EOS = 513 and the one-hot
+    width 514 are hard-coded there (:929-930,:968); decoder_hidden = h_dir0 + h_dir1; teacher forcing decided by
+    `random.random() < 0.5` once per call (:976-977)."""
+
+    def __init__(self, args, pose_dim: int, n_frames: int, n_words: int, word_embed_size: int, word_embeddings, speaker_model=None):
+        super().__init__()
+        self.n_layer = 1
+        self.encoder = EncoderRNN_New(3863, args.hidden_size, self.n_layer, pre_trained_embedding=word_embeddings)
+        pose_dim = int(args.autoencoder_vq_components) + 2
+        self.decoder = DecoderRNN_New(args.hidden_size, pose_dim, self.n_layer)
+        self.max_length, self.SOS_token, self.eos_token = 90, 512, 513
+
+    def forward(self, in_text: torch.Tensor, in_lengths, poses: torch.Tensor, vid_indices):
+        import random
+        if not in_text.is_cuda:
+            raise RuntimeError("text2embedding_model_New runs on the MI355X kernels only (no CPU fallback)")
+        ids = in_text.transpose(0, 1).contiguous()
+        cod = poses.transpose(0, 1).contiguous().to(torch.int64)
+        S, B = cod.shape
+        Kp = self.decoder.ouput_size
+        _, enc_hidden = self.encoder.run(ids, None)                       # the reference's per-time-step loop :953-955
+        hidden = (enc_hidden[: self.decoder.n_layer] + enc_hidden[self.decoder.n_layer:])     # :971-974 (layout glue)
+        outs = [F.one_hot(cod[0], 514).to(torch.float32)] + [None] * (S - 1)
+        dec_in = cod[0]
+        if random.random() < 0.5:                                          # teacher forcing :979-986
+            for di in range(S):
+                out, hidden = self.decoder(dec_in, hidden)
+                dec_in = cod[di]
+                outs[di] = out[0]
+        else:                                                              # free running :987-996
+            for di in range(1, S):
+                out, hidden = self.decoder(dec_in, hidden)
+                dec_in = ops.argmax_rows(out[0].detach().contiguous())
+                outs[di] = out[0]
+        zero = torch.zeros((B, Kp), dtype=torch.float32, device=in_text.device)
+        return torch.stack([o if o is not None else zero for o in outs])

@@ -495,6 +495,46 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
             "encoder_outputs": enc_out, "attn": attn_list}
 
 
+def t2e_new_forward(sd: Dict[str, Tensor], ids: Tensor, codes: Tensor, teacher_forcing: bool) -> Tensor:
+    """text2embedding_model_New.forward (model/text2embedding_model.py:933-1002) with EncoderRNN_New (:754-802) and
+    DecoderRNN_New (:805-844), n_layer = 1.  The encoder's bidirectional nn.GRU is fed ONE time step per call with the
+    carried hidden state (:953-955), so BOTH of its "directions" run forward in time (two independent GRUs with the
+    l0 / l0_reverse weights); no length masking.  decoder_hidden = h_dir0 + h_dir1 (:971-974).  Teacher forcing
+    (:979-986) runs di = 0..S-1 (overwriting outputs[0]) with inputs codes[0], codes[0], codes[1], ...; the free-running
+    branch (:987-996) runs di = 1..S-1 feeding back argmax.  Returns outputs (S,B,K+2); outputs[0] = one_hot(codes[0], 514)
+    unless overwritten."""
+    ids_t, cod = ids.t(), codes.t()                                                       # (Tw,B), (S,B)
+    x = sd["encoder.embedding.weight"][ids_t]                                             # (Tw,B,300)
+    hs = []
+    for suf in ("", "_reverse"):
+        _, h = gru_direction(x, sd["encoder.gru.weight_ih_l0" + suf], sd["encoder.gru.weight_hh_l0" + suf],
+                             sd["encoder.gru.bias_ih_l0" + suf], sd["encoder.gru.bias_hh_l0" + suf], False, None)
+        hs.append(h)
+    hidden = hs[0] + hs[1]                                                                # (B,H)
+    S, B = cod.shape
+    Kp = sd["decoder.fc_out.weight"].shape[0]
+    outs = [torch.nn.functional.one_hot(cod[0], Kp).to(x.dtype)] + [x.new_zeros(B, Kp) for _ in range(S - 1)]
+
+    def dec_step(inp, h):
+        e = sd["decoder.embedding.weight"][inp]
+        gi = linear(e, sd["decoder.gru.weight_ih_l0"], sd["decoder.gru.bias_ih_l0"])
+        h = gru_cell(gi, h, sd["decoder.gru.weight_hh_l0"], sd["decoder.gru.bias_hh_l0"])
+        return linear(h, sd["decoder.fc_out.weight"], sd["decoder.fc_out.bias"]), h
+
+    dec_in = cod[0]
+    if teacher_forcing:
+        for di in range(S):
+            out, hidden = dec_step(dec_in, hidden)
+            dec_in = cod[di]
+            outs[di] = out
+    else:
+        for di in range(1, S):
+            out, hidden = dec_step(dec_in, hidden)
+            dec_in = out.argmax(1)
+            outs[di] = out
+    return torch.stack(outs)
+
+
 def t2e_loss(outputs: Tensor, codes: Tensor) -> Tensor:
     """CrossEntropyLoss over decode steps 1..S-1 (train_eval/train_seq2seq.py:520-530)."""
     K = outputs.shape[2]

@@ -96,5 +96,57 @@ def main():
               "grad keys", sum(k.startswith("s1/grad/") for k in fx), "none", [k for k in fx if k.startswith("s1/gradnone/")])
 
 
+def gen_new_classes():
+    """text2embedding_model_New (+ EncoderRNN_New / DecoderRNN_New), reference :754-1002: forward in both teacher-forcing
+    branches (python `random` seeded so that the coin flip is known), loss = sum of logits * fixed weights, every gradient.
+    The classes hard-code batch 128 (initHidden) and vocabulary 3863 (:919); the 3863 x 300 embedding table is generated
+    from a seed on both sides instead of being stored, its gradient is stored for the rows that were used."""
+    import random
+    vq, dae, ts = mf._import_reference()
+    import model.text2embedding_model as t2e
+    t2e.device = torch.device("cpu")
+    torch.set_num_threads(1)
+    H, K, B, Tw, S, NW = 32, 512, 128, 4, 3, 3863
+    args = mf.make_args(hidden_size=H, autoencoder_vq_components=K)
+    emb = np.random.RandomState(0).randn(NW, 300).astype(np.float32)
+    torch.manual_seed(31)
+    net = t2e.text2embedding_model_New(args, 135, 20, NW, 300, emb, None)
+    g = torch.Generator().manual_seed(5)
+    ids = torch.randint(4, NW, (B, Tw), generator=g)
+    codes = torch.randint(0, K, (B, S), generator=g)
+    wts = torch.randn(S, B, K + 2, generator=torch.Generator().manual_seed(6))     # regenerated from the seed by the tests
+    fx = {k: v for k, v in mf.sd_np(net, "w0/").items() if "encoder.embedding" not in k}
+    fx.update(ids=ids.numpy(), codes=codes.numpy(), cfg=np.array([H, K, B, Tw, S, NW], dtype=np.int64))
+    used = np.unique(ids.numpy())
+    fx["used_rows"] = used
+    for tag, seed in (("tf", None), ("free", None)):
+        # find a python-random seed whose first draw lands in the wanted branch (< 0.5 = teacher forcing)
+        want_tf = tag == "tf"
+        seed = next(s for s in range(100) if (random.Random(s).random() < 0.5) == want_tf)
+        for p_ in net.parameters():
+            p_.grad = None
+        random.seed(seed)
+        out = net(ids, None, codes, None)
+        (out * wts).sum().backward()
+        fx[f"{tag}/seed"] = np.int64(seed)
+        fx[f"{tag}/out_even_rows"] = out.detach().numpy()[:, ::2].copy()      # every second batch row (fixture size)
+        for n_, p_ in net.named_parameters():
+            if p_.grad is None:
+                fx[f"{tag}/gradnone/{n_}"] = np.zeros(0, dtype=np.float32)
+            elif n_ == "encoder.embedding.weight":
+                gfull = p_.grad.numpy()
+                assert np.abs(np.delete(gfull, used, axis=0)).max() == 0
+                fx[f"{tag}/grad/{n_}@used"] = gfull[used].copy()
+            else:
+                fx[f"{tag}/grad/{n_}"] = p_.grad.numpy().copy()
+    np.savez_compressed(os.path.join(HERE, "t2e_new.npz"), **fx)
+    print("t2e_new", {t: int(fx[f"{t}/seed"]) for t in ("tf", "free")}, "keys", len(fx),
+          "none", [k for k in fx if "gradnone" in k])
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "new":      # only the *_New tutorial classes
+        gen_new_classes()
+    else:
+        main()
+        gen_new_classes()

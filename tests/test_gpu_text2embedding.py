@@ -127,3 +127,40 @@ def test_graphed_text2embedding_step_trains():
         step.replay()
     last = float(step.loss.detach())
     assert np.isfinite(first) and np.isfinite(last) and last < 0.8 * first, (first, last)
+
+
+def test_new_tutorial_classes_match_reference_golden(golden_dir):
+    """a15': text2embedding_model_New / EncoderRNN_New / DecoderRNN_New against the reference fixture, both branches of the
+    teacher-forcing coin flip (python `random` seeded as in the fixture)."""
+    import random
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model_New
+    fx = np.load(os.path.join(golden_dir, "t2e_new.npz"))
+    H, K, B, Tw, S, NW = [int(v) for v in fx["cfg"]]
+    emb = np.random.RandomState(0).randn(NW, 300).astype(np.float32)
+    args = argparse.Namespace(hidden_size=H, autoencoder_vq_components=K)
+    net = text2embedding_model_New(args, 135, 20, NW, 300, emb, None)
+    sd = {k[3:]: torch.from_numpy(fx[k].copy()) for k in fx.files if k.startswith("w0/")}
+    sd["encoder.embedding.weight"] = torch.from_numpy(emb)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(DEV)
+    wts = torch.randn(S, B, K + 2, generator=torch.Generator().manual_seed(6)).to(DEV)
+    ids, codes = torch.from_numpy(fx["ids"].copy()).to(DEV), torch.from_numpy(fx["codes"].copy()).to(DEV)
+    used = fx["used_rows"]
+    for tag in ("tf", "free"):
+        for p_ in net.parameters():
+            p_.grad = None
+        random.seed(int(fx[f"{tag}/seed"]))
+        out = net(ids, None, codes, None)
+        (out * wts).sum().backward()
+        assert relerr(out[:, ::2], fx[f"{tag}/out_even_rows"]) < 2e-5
+        params = dict(net.named_parameters())
+        for k in fx.files:
+            if k.startswith(f"{tag}/grad/"):
+                n = k[len(f"{tag}/grad/"):]
+                g = params[n.split("@")[0]].grad
+                assert g is not None, n
+                if n.endswith("@used"):
+                    rest = g.clone(); rest[torch.from_numpy(used).to(DEV)] = 0
+                    assert float(rest.abs().max()) == 0.0
+                    g = g[torch.from_numpy(used).to(DEV)]
+                assert relerr(g, fx[k]) < 3e-4, (tag, n, relerr(g, fx[k]))

@@ -245,3 +245,29 @@ def test_vq_gssoft_matches_reference(golden_dir):
                 assert np.abs(leaves[n].grad.numpy() - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, n
             if k.startswith(f"c{i}/gradnone/"):
                 assert leaves[k[len(f"c{i}/gradnone/"):]].grad is None
+
+
+def test_text2embedding_new_classes_match_reference(golden_dir):
+    """a15': text2embedding_model_New / EncoderRNN_New / DecoderRNN_New (:754-1002), both teacher-forcing branches."""
+    fx = load(golden_dir, "t2e_new")
+    H, K, B, Tw, S, NW = [int(v) for v in fx["cfg"]]
+    emb = torch.from_numpy(np.random.RandomState(0).randn(NW, 300).astype(np.float32))
+    wts = torch.randn(S, B, K + 2, generator=torch.Generator().manual_seed(6))
+    ids, codes = torch.from_numpy(fx["ids"].copy()), torch.from_numpy(fx["codes"].copy())
+    used = fx["used_rows"]
+    for tag, tf in (("tf", True), ("free", False)):
+        sd = state_from(fx, "w0/")
+        sd["encoder.embedding.weight"] = emb.clone()
+        leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+        out = O.t2e_new_forward(leaves, ids, codes, tf)
+        (out * wts).sum().backward()
+        np.testing.assert_allclose(out.detach().numpy()[:, ::2], fx[f"{tag}/out_even_rows"], rtol=2e-5, atol=2e-6)
+        for k in fx.files:
+            if k.startswith(f"{tag}/grad/"):
+                n = k[len(f"{tag}/grad/"):]
+                ref = fx[k]
+                got = leaves[n.split("@")[0]].grad.numpy()
+                if n.endswith("@used"):
+                    assert np.abs(np.delete(got, used, axis=0)).max() == 0
+                    got = got[used]
+                assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, (tag, n)
