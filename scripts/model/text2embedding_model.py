@@ -8,4 +8,5 @@ if _ROOT not in _sys.path:
     _sys.path.insert(0, _ROOT)
 
 from gesture2vec_amd.model.text2embedding_model import (  # noqa: E402,F401
-    Attn, BahdanauAttnDecoderRNN, EncoderRNN, Generator, text2embedding_model)
+    Attn, AttnDecoderRNN_New, BahdanauAttnDecoderRNN, DecoderRNN_New, EncoderRNN, EncoderRNN_New, Generator,
+    text2embedding_model, text2embedding_model_New)
