@@ -404,15 +404,6 @@ class _VQPlainFn(torch.autograd.Function):
         return gz.view(ctx.shape), gw, None
 
 
-# ---- names the reference also exports but that are outside the accelerated hot path -------------------------------
-def _not_on_path(name):
-    class _Stub(nn.Module):
-        def __init__(self, *a, **k):
-            raise NotImplementedError(f"{name} is outside the MI355X hot path (SURVEY.md §8a: secondary/unused in the reference)")
-    _Stub.__name__ = name
-    return _Stub
-
-
 class _SoftAssignFn(torch.autograd.Function):
     """(flat (N,E), logvar (N,K), codebook (K,E)) -> (probs (N,K), perplexity): distances + the soft assignment
     probabilities of VQ_Payam_GSSoft.soft_prob (reference :1349-1372,1396-1411)."""
@@ -510,4 +501,18 @@ class VQ_Payam_GSSoft(nn.Module):
         return loss, quantized, perplexity[0], probs
 
 
-VectorQuantizer = _not_on_path("VectorQuantizer")
+class VectorQuantizer(nn.Module):
+    """Reference `VectorQuantizer` (:1584-1710): its forward returns on its first statement (`return loss, inputs,
+    perplexity_vq, encodings` with zero scalars, :1617) -- an identity pass-through whose parameters (`pre_lin`,
+    `_embedding` ~ U(-1/K, 1/K)) never receive gradients.  Reproduced as is (no kernels involved)."""
+
+    def __init__(self, num_embeddings: int, embedding_dim: int, commitment_cost: float):
+        super().__init__()
+        self._embedding_dim, self._num_embeddings = embedding_dim, num_embeddings
+        self.pre_lin = nn.Linear(embedding_dim, embedding_dim)
+        self._embedding = nn.Embedding(num_embeddings, embedding_dim)
+        self._embedding.weight.data.uniform_(-1 / num_embeddings, 1 / num_embeddings)
+        self._commitment_cost = commitment_cost
+
+    def forward(self, inputs: torch.Tensor):
+        return torch.tensor(0), inputs, torch.tensor(0), torch.tensor(0)

@@ -86,3 +86,14 @@ def test_checkpoint_roundtrip(tmp_path):
         assert torch.equal(v, net2.state_dict()[k]), k
     with pytest.raises(NotImplementedError):
         tu.load_checkpoint_and_model(path, "cpu", "c2g")
+
+
+def test_vector_quantizer_passthrough_like_the_reference():
+    """`VectorQuantizer.forward` returns on its first statement in the reference (:1617): identity + zero scalars."""
+    from model.Autoencoder_VQVAE_model import VectorQuantizer
+    q = VectorQuantizer(16, 8, 0.25)
+    assert set(q.state_dict()) == {"pre_lin.weight", "pre_lin.bias", "_embedding.weight"}
+    assert float(q._embedding.weight.abs().max()) <= 1 / 16
+    x = torch.randn(2, 3, 4)
+    loss, out, perp, enc = q(x)
+    assert out is x and int(loss) == 0 and int(perp) == 0 and int(enc) == 0
