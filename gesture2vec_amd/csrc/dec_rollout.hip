@@ -23,6 +23,12 @@ namespace g2v {
 
 #ifdef G2V_STAMPS
 __device__ unsigned long long g2v_stamps[64 * 16];
+__device__ unsigned long long g2v_span[1024 * 4];      // [block][0 = bwd start, 1 = bwd end, 2 = fwd start, 3 = fwd end], realtime
+#define SPAN(slot)                                                                                 \
+  do {                                                                                             \
+    if (threadIdx.x == 0 && blockIdx.x < 1024 && t == 5)                                           \
+      g2v_span[blockIdx.x * 4 + (slot)] = __builtin_readcyclecounter();                            \
+  } while (0)
 #define STAMP(k)                                                                                   \
   do {                                                                                             \
     const int sb_ = blockIdx.x < 4 ? (int)blockIdx.x                                               \
@@ -32,6 +38,7 @@ __device__ unsigned long long g2v_stamps[64 * 16];
   } while (0)
 #define STAMPB(k) STAMP(8 + (k))
 #else
+#define SPAN(slot)
 #define STAMP(k)
 #define STAMPB(k)
 #endif
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   const bool hvec = (H & 3) == 0;
   const int H4 = H >> 2;
 
+  SPAN(2);
   STAMP(0);
   // Prefetch this block's rows of u_t, h0_{t-1}, h1_{t-1} (written by the previous launch on some other CU: each is
   // an L2 miss).  Issued first so that their latency overlaps the BatchNorm partial reduction below.
@@ -567,6 +575,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     }
   }
   STAMP(7);
+  SPAN(3);
 }
 
 // running_mean / running_var (momentum 0.1, unbiased variance), applied T-1 times in step order
@@ -721,6 +730,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   const bool hvec = (H & 3) == 0;
   const int H4 = H >> 2;
 
+  SPAN(0);
   // prefetch this block's rows of u_{t+1} and dbn_{t+1} (Part A inputs; L2 misses) before anything else
   float4 pu = make_float4(0.f, 0.f, 0.f, 0.f), pdb = pu;
   const bool pre_ok = hvec && (16 * H4 <= 256) && !last;
@@ -1033,6 +1043,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
   }
   STAMPB(7);
+  SPAN(1);
 }
 
 }  // namespace g2v
@@ -1042,6 +1053,9 @@ using namespace g2v;
 #ifdef G2V_STAMPS
 extern "C" int g2v_read_stamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_stamps), sizeof(unsigned long long) * 64 * 16);
+}
+extern "C" int g2v_read_spans(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_span), sizeof(unsigned long long) * 1024 * 4);
 }
 #endif
 

@@ -26,3 +26,14 @@ for b in range(8):
 for b in range(8):
     st = [buf[b * 16 + 8 + k] for k in range(8)]
     print("bwd block", b, "deltas:", [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0], "start-vs-blk0", st[0] - buf[8], "end-vs-blk0start", st[7] - buf[8])
+
+import numpy as np
+sp = (ctypes.c_ulonglong * (1024 * 4))()
+print("rc", raw.g2v_read_spans(sp))
+a = np.array(list(sp), dtype=np.float64).reshape(1024, 4)[:256]
+for name, c0, c1 in (("bwd", 0, 1), ("fwd", 2, 3)):
+    st, en = a[:, c0], a[:, c1]
+    t0 = st.min()
+    dur = en - st
+    print(name, "block duration ticks: min %.0f med %.0f max %.0f | start spread %.0f | last end - first start %.0f"
+          % (dur.min(), np.median(dur), dur.max(), st.max() - t0, en.max() - t0))
