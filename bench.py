@@ -103,7 +103,7 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
     bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
     # HBM bytes per launch from the PMC counters of the SAME kernel at the SAME size (separate --pmc passes,
     # FETCH_SIZE doubled per the gfx950 correction): profiles/r01_vq_assign_pmc_traffic.json
-    pmc_traffic = 8536268 if (N, E, K) == (4096, 128, 512) else None
+    pmc_traffic = 8543334 if (N, E, K) == (4096, 128, 512) else None
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic,
