@@ -55,6 +55,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("-c", "--config", required=True, help="YAML config file")
     ap.add_argument("--synthetic", action="store_true", help="train on synthetic N(0,1) pose chunks")
     ap.add_argument("--synthetic_batches", type=int, default=8, help="batches per epoch with --synthetic")
+    ap.add_argument("--save_every", type=int, default=0, help="checkpoint interval in epochs (0 = the script's reference default)")
+    ap.add_argument("--resume", type=str, default="", help="checkpoint written by this trainer to continue from (weights, EMA, "
+                                                          "BatchNorm stats, Adam moments and the dropout RNG counter)")
     for key, typ, _default, _req in _SPEC:
         ap.add_argument("--" + key, type=typ, default=None)
     for key in _LIST_PATH_KEYS:
@@ -64,7 +67,8 @@ def parse_args(argv=None) -> argparse.Namespace:
     cli = ap.parse_args(argv)
     with open(cli.config) as f:
         cfg = yaml.safe_load(f) or {}
-    out = argparse.Namespace(config=cli.config, synthetic=cli.synthetic, synthetic_batches=cli.synthetic_batches)
+    out = argparse.Namespace(config=cli.config, synthetic=cli.synthetic, synthetic_batches=cli.synthetic_batches,
+                             save_every=cli.save_every, resume=cli.resume)
     missing = []
     for key, typ, default, req in _SPEC:
         v = getattr(cli, key)

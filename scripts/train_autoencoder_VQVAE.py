@@ -90,19 +90,36 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
     start = time.time()
     loss_meters = [AverageMeter("loss"), AverageMeter("var_loss")]
     print_interval = int(len(train_data_loader))
-    save_model_epoch_interval = args.epochs
+    save_model_epoch_interval = getattr(args, "save_every", 0) or args.epochs
     generator, loss_fn = init_model(args, lang_model, pose_dim, device)
     gen_optimizer = FusedClipAdam(generator, lr=args.learning_rate, betas=(0.5, 0.999))
-    evaluate_testset(test_data_loader, generator, loss_fn, args)
     val_metrics_list, loss_list = [], []
+    first_epoch = 1
+    if getattr(args, "resume", ""):
+        # True resume: the reference's checkpoints carry weights only; ours add, under the extra key
+        # "resume", the Adam moments / step and the dropout RNG counter, so that a continued run is bit-identical to an
+        # uninterrupted one.  A checkpoint is written at the START of epoch `epoch` (reference order: evaluate, save, train).
+        ck = torch.load(args.resume, map_location="cpu", weights_only=False)
+        generator.load_state_dict(ck["gen_dict"], strict=True)
+        eng = generator.engine()
+        gen_optimizer.load_state_dict({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in ck["resume"]["optim"].items()})
+        eng.rng_counter.copy_(ck["resume"]["rng_counter"].to(device))
+        val_metrics_list, loss_list = list(ck.get("val_metrics_list", [])), list(ck.get("loss_list", []))
+        first_epoch = int(ck["epoch"])
+        logging.info("resumed from {} at epoch {}".format(args.resume, first_epoch))
+    else:
+        evaluate_testset(test_data_loader, generator, loss_fn, args)
     global_iter = 0
-    for epoch in range(1, args.epochs + 1):
-        val_metrics_list.append(evaluate_testset(test_data_loader, generator, loss_fn, args))
-        if epoch % save_model_epoch_interval == 0 and epoch > 0:
+    for epoch in range(first_epoch, args.epochs + 1):
+        if not (getattr(args, "resume", "") and epoch == first_epoch):     # the resumed epoch was evaluated before its save
+            val_metrics_list.append(evaluate_testset(test_data_loader, generator, loss_fn, args))
+        if epoch % save_model_epoch_interval == 0 and epoch > 0 and not (getattr(args, "resume", "") and epoch == first_epoch):
             save_name = "{}/{}_checkpoint_{:03d}.bin".format(args.model_save_path, args.name, epoch)
             utils.train_utils.save_checkpoint(
                 {"args": args, "epoch": epoch, "lang_model": lang_model, "pose_dim": pose_dim,
-                 "gen_dict": generator.state_dict(), "val_metrics_list": val_metrics_list, "loss_list": loss_list},
+                 "gen_dict": generator.state_dict(), "val_metrics_list": val_metrics_list, "loss_list": loss_list,
+                 "resume": {"optim": {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in gen_optimizer.state_dict().items()},
+                            "rng_counter": generator.engine().rng_counter.cpu().clone()}},
                 save_name)
         iter_start_time = time.time()
         loss_epoch = AverageMeter("loss")

@@ -85,3 +85,24 @@ def test_text2embedding_checkpoint_reload(tmp_path):
                                                                        "text2embedding")
     assert args.autoencoder_att == "True" and not net.training
     assert any(k.startswith("decoder.decoder.attn.") for k in net.state_dict())
+
+
+def test_train_autoencoder_vqvae_resume_is_bit_identical(tmp_path):
+    """Checkpoint/resume: a run continued from the epoch-2 checkpoint writes the same epoch-4 checkpoint,
+    bit for bit (weights, EMA codebook, BatchNorm statistics), as the uninterrupted run."""
+    def run(out, extra):
+        cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"),
+               "--config", os.path.join(ROOT, "config", "VQ-VAE_synthetic.yml"), "--synthetic", "--synthetic_batches", "3",
+               "--batch_size", "64", "--epochs", "4", "--save_every", "2", "--model_save_path", out, "--name", "t"] + extra
+        r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+    a, b = os.path.join(tmp_path, "full"), os.path.join(tmp_path, "resumed")
+    run(a, [])
+    run(b, ["--resume", os.path.join(a, "t_checkpoint_002.bin")])
+    ca = torch.load(os.path.join(a, "t_checkpoint_004.bin"), map_location="cpu", weights_only=False)
+    cb = torch.load(os.path.join(b, "t_checkpoint_004.bin"), map_location="cpu", weights_only=False)
+    assert set(ca["gen_dict"]) == set(cb["gen_dict"])
+    for k in ca["gen_dict"]:
+        assert torch.equal(ca["gen_dict"][k], cb["gen_dict"][k]), k
+    assert torch.equal(ca["resume"]["optim"]["m"], cb["resume"]["optim"]["m"])
+    assert ca["loss_list"] == cb["loss_list"]
