@@ -88,6 +88,26 @@ def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tenso
     return {"loss": loss.item()}, perplexity_vq.detach()
 
 
+def train_iter_Autoencoder_VQ_seq2seq_dp(args, epoch: int, input_poses: torch.Tensor, target_poses: torch.Tensor,
+                                         net: torch.nn.Module, optim, reduce_fn, world: int) -> Tuple[dict, torch.Tensor]:
+    """The data-parallel form of train_iter_Autoencoder_VQ_seq2seq (one process per GPU): this rank's shard goes through
+    forward / loss / backward, ONE all-reduce (`reduce_fn`, RCCL) sums [gradients | codebook EMA statistics] over the
+    ranks, then every rank applies the identical EMA update (global statistics) and clip + Adam on the mean gradient
+    (gesture2vec_amd/dp.py).  Returns this rank's loss and the perplexity of the global code histogram."""
+    if not isinstance(optim, FusedClipAdam):
+        raise TypeError("use gesture2vec_amd.train_eval.train_seq2seq.FusedClipAdam")
+    eng = net.engine()
+    if getattr(net, "_explicit_masks", False):
+        draw = False
+    else:
+        draw = True
+    eng.train_step(input_poses.contiguous(), target_poses.contiguous(), lr=optim.lr, w_l1=float(args.loss_l1_weight),
+                   w_cont=float(args.loss_cont_weight), w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=draw,
+                   reduce_fn=reduce_fn, world=world)
+    loss = eng.loss_terms[0].item() + (eng.vq_scalars[0].item() / 400 if epoch > 0 else 0.0)
+    return {"loss": loss}, eng.vq_scalars[1].detach().clone()
+
+
 def train_iter_DAE(args, epoch: int, noisy_poses: torch.Tensor, target_poses: torch.Tensor, net: torch.nn.Module, optim):
     """One training iteration of the Part-a frame DAE (reference :161-241, autoencoder_vq/vae == "False"):
     MSE(outputs, target) -> backward -> clip_grad_norm_(5) + Adam (fused in `optim`, a gesture2vec_amd.flat.FlatClipAdam)."""

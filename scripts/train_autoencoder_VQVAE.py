@@ -29,11 +29,19 @@ for _p in (_HERE, _ROOT):
 
 from config.parse_args import parse_args  # noqa: E402
 from model.Autoencoder_VQVAE_model import Autoencoder_VQVAE  # noqa: E402
-from train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq  # noqa: E402
+from train_eval.train_seq2seq import (FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq,  # noqa: E402
+                                      train_iter_Autoencoder_VQ_seq2seq_dp)
 import utils.train_utils  # noqa: E402
 from utils.average_meter import AverageMeter  # noqa: E402
 
-device = torch.device("cuda:0" if torch.cuda.is_available() else "cpu")
+# One process per GPU under `python -m torch.distributed.run` (RANK / LOCAL_RANK / WORLD_SIZE in the environment): the
+# batch shards over the ranks, gradients + codebook EMA statistics are all-reduced over RCCL once per step
+# (gesture2vec_amd/dp.py); rank 0 logs and writes checkpoints.  Without those variables: the single-GPU path.
+_DIST = "RANK" in os.environ and "WORLD_SIZE" in os.environ
+_RANK = int(os.environ.get("RANK", "0"))
+_WORLD = int(os.environ.get("WORLD_SIZE", "1"))
+_LOCAL_RANK = int(os.environ.get("LOCAL_RANK", "0"))
+device = torch.device("cuda", _LOCAL_RANK) if torch.cuda.is_available() else torch.device("cpu")
 debug = False
 
 
@@ -93,6 +101,14 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
     save_model_epoch_interval = getattr(args, "save_every", 0) or args.epochs
     generator, loss_fn = init_model(args, lang_model, pose_dim, device)
     gen_optimizer = FusedClipAdam(generator, lr=args.learning_rate, betas=(0.5, 0.999))
+    reduce_fn = None
+    if _DIST:
+        from gesture2vec_amd.dp import GradStatsAllReduce, broadcast_state
+        generator.rng_seed = 1234 + _RANK                               # independent dropout masks per shard
+        eng, vq = generator.engine(), generator.vq_layer
+        broadcast_state([eng.flat, vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size,
+                         vq.pre_linear.weight.data, vq.pre_linear.bias.data, eng.bn_rm, eng.bn_rv])
+        reduce_fn = GradStatsAllReduce()
     val_metrics_list, loss_list = [], []
     first_epoch = 1
     if getattr(args, "resume", ""):
@@ -113,7 +129,8 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
     for epoch in range(first_epoch, args.epochs + 1):
         if not (getattr(args, "resume", "") and epoch == first_epoch):     # the resumed epoch was evaluated before its save
             val_metrics_list.append(evaluate_testset(test_data_loader, generator, loss_fn, args))
-        if epoch % save_model_epoch_interval == 0 and epoch > 0 and not (getattr(args, "resume", "") and epoch == first_epoch):
+        if (epoch % save_model_epoch_interval == 0 and epoch > 0 and _RANK == 0
+                and not (getattr(args, "resume", "") and epoch == first_epoch)):
             save_name = "{}/{}_checkpoint_{:03d}.bin".format(args.model_save_path, args.name, epoch)
             utils.train_utils.save_checkpoint(
                 {"args": args, "epoch": epoch, "lang_model": lang_model, "pose_dim": pose_dim,
@@ -127,15 +144,20 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
             global_iter += 1
             batch_size = encoded_output.size(0)
             encoded_input, encoded_output = encoded_input.to(device), encoded_output.to(device)
-            loss, perplexity = train_iter_Autoencoder_VQ_seq2seq(args, epoch, encoded_input, encoded_output, generator,
-                                                                 gen_optimizer)
+            if _DIST:
+                loss, perplexity = train_iter_Autoencoder_VQ_seq2seq_dp(args, epoch, encoded_input, encoded_output, generator,
+                                                                        gen_optimizer, reduce_fn, _WORLD)
+            else:
+                loss, perplexity = train_iter_Autoencoder_VQ_seq2seq(args, epoch, encoded_input, encoded_output, generator,
+                                                                     gen_optimizer)
             loss_epoch.update(loss["loss"], batch_size)
             for m in loss_meters:
                 if m.name in loss:
                     m.update(loss[m.name], batch_size)
-            if (iter_idx + 1) % print_interval == 0:
+            if (iter_idx + 1) % print_interval == 0 and _RANK == 0:
                 summary = "EP {} ({:3d}) | {:>8s}, {:.0f} samples/s | ".format(
-                    epoch, iter_idx + 1, utils.train_utils.time_since(start), batch_size / (time.time() - iter_start_time))
+                    epoch, iter_idx + 1, utils.train_utils.time_since(start),
+                    _WORLD * batch_size / (time.time() - iter_start_time))
                 for m in loss_meters:
                     if m.count > 0:
                         summary += "{}: {:.3f}, ".format(m.name, m.avg)
@@ -160,7 +182,12 @@ def main(config: dict):
         np.random.seed(args.random_seed)
         random.seed(args.random_seed)
         os.environ["PYTHONHASHSEED"] = str(args.random_seed)
-    utils.train_utils.set_logger(args.model_save_path, os.path.basename(__file__).replace(".py", ".log"))
+    if _DIST:
+        import torch.distributed as dist
+        torch.cuda.set_device(_LOCAL_RANK)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=_RANK, world_size=_WORLD, device_id=device)      # "nccl" is RCCL on ROCm
+    utils.train_utils.set_logger(args.model_save_path if _RANK == 0 else None, os.path.basename(__file__).replace(".py", ".log"))
     logging.info("PyTorch version: {}".format(torch.__version__))
     logging.info("HIP version: {}".format(torch.version.hip))
     logging.info(pprint.pformat(vars(args)))
@@ -168,14 +195,20 @@ def main(config: dict):
         raise SystemExit("the LMDB datasets of the reference need lmdb / legacy pyarrow, which are not available here: "
                          "run with --synthetic (SURVEY.md §8f ranks the real-data reader as follow-up work)")
     nb = getattr(args, "synthetic_batches", 8)
-    train_loader = SyntheticChunks(args, nb, seed=1234)
+    train_loader = SyntheticChunks(args, nb, seed=1234 + _RANK)          # every rank draws its own shard
     test_loader = SyntheticChunks(args, max(1, nb // 4), seed=4321)
-    return train_epochs(args, train_loader, None, test_loader, None, pose_dim=args.rep_learning_dim)
+    out = train_epochs(args, train_loader, None, test_loader, None, pose_dim=args.rep_learning_dim)
+    if _DIST:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
 
 
 if __name__ == "__main__":
     _args = parse_args()
     if _args.use_derivative == "True":
         _args.rep_learning_dim = _args.rep_learning_dim * 2
-    save_config(_args)
+    if _RANK == 0:
+        save_config(_args)
     main({"args": _args})

@@ -7,4 +7,5 @@ if _ROOT not in _sys.path:
     _sys.path.insert(0, _ROOT)
 
 from gesture2vec_amd.train_eval.train_seq2seq import (  # noqa: E402,F401
-    FusedClipAdam, custom_loss, train_iter_Autoencoder_VQ_seq2seq, train_iter_DAE, train_iter_text2embedding)
+    FusedClipAdam, GraphedText2EmbeddingStep, custom_loss, train_iter_Autoencoder_VQ_seq2seq,
+    train_iter_Autoencoder_VQ_seq2seq_dp, train_iter_DAE, train_iter_text2embedding)

@@ -106,3 +106,21 @@ def test_train_autoencoder_vqvae_resume_is_bit_identical(tmp_path):
         assert torch.equal(ca["gen_dict"][k], cb["gen_dict"][k]), k
     assert torch.equal(ca["resume"]["optim"]["m"], cb["resume"]["optim"]["m"])
     assert ca["loss_list"] == cb["loss_list"]
+
+
+def test_train_autoencoder_vqvae_distributed_launch(tmp_path):
+    """BASELINE config 5 entry point: the trainer under `python -m torch.distributed.run` (one process per GPU; here one
+    rank, all a single-GPU box offers) runs the data-parallel iteration -- RCCL all-reduce of [grads | EMA stats], EMA update
+    from the reduced statistics -- at the GENEA shape and writes the usual checkpoint from rank 0."""
+    out = os.path.join(tmp_path, "run_dp")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"),
+           "--config", os.path.join(ROOT, "config", "VQ-VAE_GENEA_synthetic.yml"), "--synthetic", "--synthetic_batches", "3",
+           "--batch_size", "256", "--epochs", "2", "--model_save_path", out, "--name", "t"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    assert "EP 2 (  3) |" in log and "[VAL] loss:" in log
+    ck = torch.load(os.path.join(out, "t_checkpoint_002.bin"), map_location="cpu", weights_only=False)
+    assert ck["pose_dim"] == 45 and ck["gen_dict"]["vq_layer._embedding.weight"].shape == (400, 400)
+    assert all(torch.isfinite(v).all() for v in ck["gen_dict"].values() if v.dtype.is_floating_point)
