@@ -112,6 +112,33 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
             "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
 
 
+def calibrate(lib):
+    """What THIS box sustains (events on the launch stream): fp32 MFMA issue rate with no memory traffic, and a 2 x 1 GiB
+    streaming copy (larger than the 256 MB Infinity Cache).  Reported next to the datasheet peaks, not instead of them."""
+    from gesture2vec_amd._lib import check
+    st = torch.cuda.current_stream()
+    dev = torch.device("cuda", torch.cuda.current_device())
+    blocks, iters = 256 * 8, 2000                    # 8 workgroups per CU = 8 waves per SIMD
+    scratch = torch.empty(blocks * 256, device=dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    check(lib.g2v_probe_mfma_f32(scratch.data_ptr(), blocks, 50, st.cuda_stream))
+    e0.record(st)
+    check(lib.g2v_probe_mfma_f32(scratch.data_ptr(), blocks, iters, st.cuda_stream))
+    e1.record(st); e1.synchronize()
+    mfma_tf = blocks * 4 * iters * 8 * 2048.0 / (e0.elapsed_time(e1) * 1e-3) / 1e12
+    n = 1 << 28                                      # 1 GiB of floats
+    src, dst = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    src.fill_(1.0)
+    check(lib.g2v_probe_copy(src.data_ptr(), dst.data_ptr(), n, st.cuda_stream))
+    e0.record(st)
+    for _ in range(3):
+        check(lib.g2v_probe_copy(src.data_ptr(), dst.data_ptr(), n, st.cuda_stream))
+    e1.record(st); e1.synchronize()
+    copy_gbs = 3 * 2 * 4.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del src, dst
+    return {"mfma_f32_TFLOPs": round(mfma_tf, 1), "hbm_copy_GBps": round(copy_gbs, 0)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -253,6 +280,12 @@ def main():
         }
         if world == 1:
             out["roofline"] = vq_kernel_roofline(eng, B)
+            try:
+                cal = calibrate(lib)
+                out["roofline"]["measured_on_this_box"] = cal
+                out["roofline"]["frac_of_measured_mfma"] = round(out["roofline"]["achieved"] / cal["mfma_f32_TFLOPs"], 4)
+            except Exception as e:   # the calibration is context, never a reason to lose the bench line
+                print(f"[bench] calibration probe failed ({type(e).__name__}: {e})", file=sys.stderr)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline()
     if use_dp:

@@ -98,6 +98,8 @@ _SIGS = {
     "g2v_attn_bwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_attn_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                              c_fp, c_sz, c_fp]),
+    "g2v_probe_mfma_f32": (c_int, [c_fp, c_int, c_int, c_fp]),
+    "g2v_probe_copy": (c_int, [c_fp, c_fp, c_i64, c_fp]),
     "g2v_keep_mask": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_fp]),
     "g2v_fill_f32": (c_int, [c_fp, c_f, c_i64, c_fp]),
     "g2v_scale_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp]),

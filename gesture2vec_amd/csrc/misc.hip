@@ -285,6 +285,28 @@ __global__ void add_halves_kernel(const float* __restrict__ a, int64_t lda, cons
   }
 }
 
+
+// ---- calibration probes (bench.py only): what this box sustains, next to the datasheet peaks --------------------------
+// fp32 MFMA: every wave runs `iters` rounds of 8 independent v_mfma_f32_16x16x4_f32 chains (no memory traffic at all).
+__global__ __launch_bounds__(256) void mfma_probe_kernel(float* __restrict__ out, int iters) {
+  f32x4 acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float a = 1.0f + 1e-6f * (float)threadIdx.x, b = 1.0f - 1e-6f * (float)threadIdx.x;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = mfma16(a, b, acc[j]);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = s;
+}
+// streaming copy, 16 bytes per thread per iteration
+__global__ __launch_bounds__(256) void copy_probe_kernel(const float4* __restrict__ src, float4* __restrict__ dst, int64_t n4) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256) dst[e] = src[e];
+}
+
 }  // namespace g2v
 
 using namespace g2v;
@@ -423,6 +445,23 @@ extern "C" int g2v_add_halves(const float* a, int64_t lda, const float* b, int64
   int blocks = cdiv(M * H, 256);
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(add_halves_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, lda, b, ldb, out, ldo, M, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_probe_mfma_f32(float* scratch, int blocks, int iters, g2v_stream_t stream) {
+  G2V_REQUIRE(scratch, "null pointer");
+  G2V_REQUIRE(blocks > 0 && iters > 0, "bad size");
+  hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, scratch, iters);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_probe_copy(const float* src, float* dst, int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(src && dst, "null pointer");
+  G2V_REQUIRE(n > 0 && (n & 3) == 0, "n must be a positive multiple of 4");
+  hipLaunchKernelGGL(copy_probe_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float4*>(src),
+                     reinterpret_cast<float4*>(dst), n >> 2);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

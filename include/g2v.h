@@ -342,6 +342,14 @@ int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, const float* 
                  int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Calibration probes used by bench.py to report what the box sustains next to the datasheet peaks (no counterpart in the
+ * reference): g2v_probe_mfma_f32 runs `blocks` x 4 waves x `iters` x 8 independent v_mfma_f32_16x16x4_f32 (2048 flop each)
+ * without memory traffic (scratch: blocks * 256 floats); g2v_probe_copy streams n floats from src to dst.
+ * ------------------------------------------------------------------------------------------ */
+int g2v_probe_mfma_f32(float* scratch, int blocks, int iters, g2v_stream_t stream);
+int g2v_probe_copy(const float* src, float* dst, int64_t n, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Keep-mask generator: keep[i] = (philox4x32-10(seed, offset_counter, i) uniform < keep_prob).
  * Replaces the RNG draws of nn.Dropout / nn.GRU dropout on the path (e.g. :570).  offset_counter is a
  * device int64 that the call advances by 1 (so graph replays draw fresh masks).
