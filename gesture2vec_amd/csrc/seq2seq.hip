@@ -41,65 +41,66 @@ __global__ void embedding_bwd_kernel(const float* __restrict__ d_out, const int6
 }
 
 // ---- BatchNorm1d over (B,H), 16 features per workgroup, 16 row lanes x 16 feature lanes -----------------------------
+// A workgroup owns BN_FB = 4 features and splits the batch over BN_RL = 64 row lanes (H / 4 workgroups: enough to cover
+// the chip for H >= 64 even though the op is tiny); every row loop keeps 8 independent loads in flight.
+constexpr int BN_FB = 4, BN_RL = 64;
+
+template <class F>
+__device__ __forceinline__ void bn_rows(int rl, int B, F body) {      // body(r) for r = rl, rl + 64, ... (unrolled by 8)
+  int r = rl;
+  for (; r + 7 * BN_RL < B; r += 8 * BN_RL) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) body(r + j * BN_RL);
+  }
+  for (; r < B; r += BN_RL) body(r);
+}
+
+__device__ __forceinline__ float bn_block_sum(float v, float (*red)[BN_FB + 1], int rl, int fl) {
+  __syncthreads();                 // red may still be read from the previous use
+  red[rl][fl] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int k = 0; k < BN_RL; ++k) t += red[k][fl];     // fixed order: deterministic
+  return t;
+}
+
 __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ b, float* __restrict__ rm,
                                                      float* __restrict__ rv, int training, int relu,
                                                      float* __restrict__ y, float* __restrict__ save_mean,
                                                      float* __restrict__ save_invstd, int B, int H) {
-  __shared__ float red[16][17];
-  __shared__ float st[2][16];
-  const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int f = blockIdx.x * 16 + fl;
+  __shared__ float red[BN_RL][BN_FB + 1];
+  const int fl = threadIdx.x & (BN_FB - 1), rl = threadIdx.x / BN_FB;
+  const int f = blockIdx.x * BN_FB + fl;
   const bool fv = f < H;
+  const int fc = fv ? f : 0;
   float mean, invstd;
   if (training) {
     float s = 0.f;
-    if (fv)
-      for (int r = rl; r < B; r += 16) s += x[(int64_t)r * H + f];
-    red[rl][fl] = s;
-    __syncthreads();
-    if (rl == 0) {
-      float t = 0.f;
-      for (int k = 0; k < 16; ++k) t += red[k][fl];
-      st[0][fl] = t / (float)B;
-    }
-    __syncthreads();
-    mean = st[0][fl];
+    bn_rows(rl, B, [&](int r) { s += x[(int64_t)r * H + fc]; });
+    mean = bn_block_sum(s, red, rl, fl) / (float)B;
     float q = 0.f;
-    if (fv)
-      for (int r = rl; r < B; r += 16) {
-        const float d = x[(int64_t)r * H + f] - mean;
-        q += d * d;
-      }
-    __syncthreads();
-    red[rl][fl] = q;
-    __syncthreads();
-    if (rl == 0) {
-      float t = 0.f;
-      for (int k = 0; k < 16; ++k) t += red[k][fl];
-      const float var = t / (float)B;                      // biased: used for normalisation
-      st[1][fl] = 1.0f / sqrtf(var + 1e-5f);
-      if (fv) {
-        const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
-        rm[f] = 0.9f * rm[f] + 0.1f * mean;                // momentum 0.1, unbiased variance
-        rv[f] = 0.9f * rv[f] + 0.1f * unb;
-        if (save_mean) save_mean[f] = mean;
-        if (save_invstd) save_invstd[f] = st[1][fl];
-      }
+    bn_rows(rl, B, [&](int r) { const float d = x[(int64_t)r * H + fc] - mean; q += d * d; });
+    const float var = bn_block_sum(q, red, rl, fl) / (float)B;          // biased: used for normalisation
+    invstd = 1.0f / sqrtf(var + 1e-5f);
+    if (rl == 0 && fv) {
+      const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
+      rm[f] = 0.9f * rm[f] + 0.1f * mean;                               // momentum 0.1, unbiased variance
+      rv[f] = 0.9f * rv[f] + 0.1f * unb;
+      if (save_mean) save_mean[f] = mean;
+      if (save_invstd) save_invstd[f] = invstd;
     }
-    __syncthreads();
-    invstd = st[1][fl];
   } else {
-    mean = fv ? rm[f] : 0.f;
-    invstd = fv ? 1.0f / sqrtf(rv[f] + 1e-5f) : 0.f;
+    mean = rm[fc];
+    invstd = 1.0f / sqrtf(rv[fc] + 1e-5f);
   }
   if (!fv) return;
   const float g = w[f], bb = b[f];
-  for (int r = rl; r < B; r += 16) {
+  bn_rows(rl, B, [&](int r) {
     float v = (x[(int64_t)r * H + f] - mean) * invstd * g + bb;
     if (relu) v = fmaxf(v, 0.f);
     y[(int64_t)r * H + f] = v;
-  }
+  });
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -108,41 +109,32 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ save_invstd, int relu,
                                                      float* __restrict__ dx, float* __restrict__ dw,
                                                      float* __restrict__ db, int B, int H) {
-  __shared__ float red1[16][17], red2[16][17];
-  __shared__ float st[2][16];
-  const int fl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-  const int f = blockIdx.x * 16 + fl;
+  __shared__ float red[BN_RL][BN_FB + 1];
+  const int fl = threadIdx.x & (BN_FB - 1), rl = threadIdx.x / BN_FB;
+  const int f = blockIdx.x * BN_FB + fl;
   const bool fv = f < H;
-  const float mean = fv ? save_mean[f] : 0.f, invstd = fv ? save_invstd[f] : 0.f;
+  const int fc = fv ? f : 0;
+  const float mean = save_mean[fc], invstd = save_invstd[fc];
   float s1 = 0.f, s2 = 0.f;
-  if (fv)
-    for (int r = rl; r < B; r += 16) {
-      const int64_t e = (int64_t)r * H + f;
-      float g = dy[e];
-      if (relu && !(y[e] > 0.f)) g = 0.f;
-      s1 += g;
-      s2 += g * ((x[e] - mean) * invstd);
-    }
-  red1[rl][fl] = s1;
-  red2[rl][fl] = s2;
-  __syncthreads();
-  if (rl == 0) {
-    float a = 0.f, c = 0.f;
-    for (int k = 0; k < 16; ++k) { a += red1[k][fl]; c += red2[k][fl]; }
-    st[0][fl] = a;
-    st[1][fl] = c;
-    if (fv) { db[f] = a; dw[f] = c; }
-  }
-  __syncthreads();
+  bn_rows(rl, B, [&](int r) {
+    const int64_t e = (int64_t)r * H + fc;
+    float g = dy[e];
+    if (relu && !(y[e] > 0.f)) g = 0.f;
+    s1 += g;
+    s2 += g * ((x[e] - mean) * invstd);
+  });
+  const float S1 = bn_block_sum(s1, red, rl, fl);
+  const float S2 = bn_block_sum(s2, red, rl, fl);
   if (!fv) return;
-  const float S1 = st[0][fl], S2 = st[1][fl], g0 = w[f] * invstd, invB = 1.0f / (float)B;
-  for (int r = rl; r < B; r += 16) {
+  if (rl == 0) { db[f] = S1; dw[f] = S2; }
+  const float g0 = w[f] * invstd, invB = 1.0f / (float)B;
+  bn_rows(rl, B, [&](int r) {
     const int64_t e = (int64_t)r * H + f;
     float g = dy[e];
     if (relu && !(y[e] > 0.f)) g = 0.f;
     const float xhat = (x[e] - mean) * invstd;
     dx[e] = g0 * (g - S1 * invB - xhat * S2 * invB);
-  }
+  });
 }
 
 // ---- cross entropy: one wave per row ----------------------------------------------------------------------------------
@@ -335,7 +327,7 @@ extern "C" int g2v_batchnorm_fwd(const float* x, const float* weight, const floa
                                  float* save_invstd, int B, int H, g2v_stream_t stream) {
   G2V_REQUIRE(x && weight && bias && running_mean && running_var && y, "null pointer");
   G2V_REQUIRE(B > 0 && H > 0, "bad size");
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3(cdiv(H, 16)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean,
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean,
                      running_var, training, relu, y, save_mean, save_invstd, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
@@ -347,7 +339,7 @@ extern "C" int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y
   G2V_REQUIRE(dy && x && weight && save_mean && save_invstd && dx && dw && db, "null pointer");
   G2V_REQUIRE(!relu || y, "y required for the ReLU mask");
   G2V_REQUIRE(B > 0 && H > 0, "bad size");
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(H, 16)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
                      save_invstd, relu, dx, dw, db, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
