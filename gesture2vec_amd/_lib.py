@@ -36,6 +36,11 @@ class GruDir(C.Structure):
                 [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)])
 
 
+class WgradItem(C.Structure):
+    """g2v_wgrad_item"""
+    _fields_ = [(n, c_fp) for n in ("dy", "x", "dw", "db")]
+
+
 class GruDirBwd(C.Structure):
     """g2v_gru_dir_bwd"""
     _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
@@ -58,6 +63,7 @@ _SIGS = {
     "g2v_linear_bwd_weight_workspace": (c_sz, [c_int, c_int, c_int]),
     "g2v_linear_bwd_weight": (c_int, [c_fp, c_i64, c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_f, c_fp, c_fp,
                                       c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_linear_bwd_weight_batch": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_vq_assign_blocks": (c_int, [c_int]),
     "g2v_vq_code_sqnorm": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_assign_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),

@@ -470,11 +470,23 @@ __device__ __forceinline__ void split_bf16x4(const float (&v)[4], s16x4& hi, s16
   lo = (s16x4){(short)(l[0] >> 16), (short)(l[1] >> 16), (short)(l[2] >> 16), (short)(l[3] >> 16)};
 }
 
+// Up to G2V_TN_BATCH problems of identical shape per launch (blockIdx.y picks one): their workgroups fill each other's
+// prologue / epilogue / tail, and one slab reduction serves them all.
+constexpr int G2V_TN_BATCH = 4;
+struct TnBatch {
+  const float* dy[G2V_TN_BATCH];
+  const float* x[G2V_TN_BATCH];
+  float* slab[G2V_TN_BATCH];
+  float* slab_db[G2V_TN_BATCH];
+};
+
 template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3>
-__global__ __launch_bounds__(512) void gemm_tn_wave_kernel(const float* __restrict__ dY, int64_t lddy,
-                                                           const float* __restrict__ X, RowMap xm,
-                                                           float* __restrict__ slab, float* __restrict__ slab_db, int M,
-                                                           int K, int N, int rows_per_wave) {
+__global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t lddy, RowMap xm, int M, int K, int N,
+                                                           int rows_per_wave) {
+  const float* __restrict__ dY = bt.dy[blockIdx.y];
+  const float* __restrict__ X = bt.x[blockIdx.y];
+  float* __restrict__ slab = bt.slab[blockIdx.y];
+  float* __restrict__ slab_db = bt.slab_db[blockIdx.y];
   static_assert(SN * SK == 2, "two tile groups per workgroup");
   static_assert(VW == 1 || (VW == 2 && TN_ % 2 == 0 && TK_ % 2 == 0), "pairs of tiles per 8-byte load");
   // VW == 2 (8-byte-aligned rows, whole tiles): the 16 MFMA rows of a PAIR of tiles are interleaved over 32 columns,
@@ -745,11 +757,21 @@ static int tn_wave_grid(int M, int K, int N, bool has_keep, int* rows_per_wave) 
 // A workgroup owns 32 consecutive outputs: 8 float4 columns x 32 slab groups (thread (grp, c4) sums slabs grp, grp+32,
 // ... of its float4 column, every load independent), then the 32 group partials are summed through LDS in a fixed
 // order.  n % 4 == 0 for the float4 path; otherwise (the 135-wide bias vectors) a scalar path with the same structure.
-__global__ __launch_bounds__(256) void slab_reduce2_kernel(const float* __restrict__ slab_a, int64_t na, float* __restrict__ out_a,
-                                                           const float* __restrict__ slab_b, int64_t nb, float* __restrict__ out_b,
-                                                           int nsplit, int accumulate, int nblk_a) {
+struct SlabBatch {
+  const float* slab_a[G2V_TN_BATCH];
+  float* out_a[G2V_TN_BATCH];
+  const float* slab_b[G2V_TN_BATCH];
+  float* out_b[G2V_TN_BATCH];
+};
+__global__ __launch_bounds__(256) void slab_reduce2_kernel(SlabBatch sb, int64_t na, int64_t nb, int nsplit, int accumulate,
+                                                           int nblk_a) {
   __shared__ __attribute__((aligned(16))) float red[32][36];
+  const float* __restrict__ slab_a = sb.slab_a[blockIdx.y];
+  float* __restrict__ out_a = sb.out_a[blockIdx.y];
+  const float* __restrict__ slab_b = sb.slab_b[blockIdx.y];
+  float* __restrict__ out_b = sb.out_b[blockIdx.y];
   const bool first = (int)blockIdx.x < nblk_a;
+  if (!first && slab_b == nullptr) return;            // this problem has no bias gradient
   const float* slab = first ? slab_a : slab_b;
   const int64_t n = first ? na : nb;
   float* out = first ? out_a : out_b;
@@ -858,6 +880,96 @@ extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
   return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
 }
 
+// nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
+// the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
+struct WgradItem {
+  const float* dy; const float* x; float* dw; float* db;
+};
+static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx, int rows_inner, int64_t stride_outer,
+                      int64_t stride_inner, const uint8_t* x_keep, float x_scale, int M, int K, int N, int accumulate,
+                      bool bf3, float* workspace, g2v_stream_t stream) {
+  int splits = tn_splits(M, K, N);
+  int rows_per_split = cdiv(M, splits);
+  rows_per_split = round_up(rows_per_split, TM);
+  RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
+  int rpw = 0;
+  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw);
+  if (wg > 0) splits = wg;
+  const size_t slab_stride = (size_t)splits * ((size_t)N * K + N);
+  const int64_t n = (int64_t)N * K;
+  bool any_db = false;
+  for (int p = 0; p < nprob; ++p) any_db = any_db || it[p].db;
+  auto slab_of = [&](int p) { return workspace + (size_t)p * slab_stride; };
+  auto slab_db_of = [&](int p) { return it[p].db ? slab_of(p) + (size_t)splits * N * K : (float*)nullptr; };
+  if (wg > 0) {
+    TnBatch bt;
+    bool vec2 = (N % 32 == 0) && (K % 32 == 0) && rows_inner == 0 && (lddy % 2 == 0) && (ldx % 2 == 0);
+    bool all_db = true;
+    for (int p = 0; p < G2V_TN_BATCH; ++p) {
+      const int pp = p < nprob ? p : 0;
+      bt.dy[p] = it[pp].dy; bt.x[p] = it[pp].x; bt.slab[p] = slab_of(pp); bt.slab_db[p] = slab_db_of(pp);
+      vec2 = vec2 && (reinterpret_cast<uintptr_t>(it[pp].dy) % 8 == 0) && (reinterpret_cast<uintptr_t>(it[pp].x) % 8 == 0);
+      all_db = all_db && (it[pp].db != nullptr);
+    }
+    (void)all_db;
+    const int tn = cdiv(N, 16), tk = cdiv(K, 16);
+#define G2V_TNW2(TN_, TK_, SN, SK, VW, BF)                                                                               \
+  do {                                                                                                                   \
+    const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
+    if (rows_inner > 0) {                                                                                                \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>,                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>), dim3(wg, nprob), dim3(512), lds,         \
+                         (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                               \
+    } else {                                                                                                             \
+      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>,                       \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
+      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>), dim3(wg, nprob), dim3(512), lds,        \
+                         (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                               \
+    }                                                                                                                    \
+  } while (0)
+#define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
+  do {                                                                                                                   \
+    if (bf3) G2V_TNW2(TN_, TK_, SN, SK, VW, true);                                                                       \
+    else G2V_TNW2(TN_, TK_, SN, SK, VW, false);                                                                          \
+  } while (0)
+    // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles (checked above)
+    if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
+    else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1, 1);
+    else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2, 1);
+    else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
+#undef G2V_TNW
+#undef G2V_TNW2
+    G2V_CHECK_LAUNCH();
+  } else {
+    const int ntw = tn_ntw(N);
+    dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
+    for (int p = 0; p < nprob; ++p) {
+      if (ntw == 1)
+        hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, it[p].dy, lddy, it[p].x, xm, x_keep,
+                           x_scale, slab_of(p), slab_db_of(p), M, K, N, rows_per_split);
+      else if (ntw == 2)
+        hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, it[p].dy, lddy, it[p].x, xm, x_keep,
+                           x_scale, slab_of(p), slab_db_of(p), M, K, N, rows_per_split);
+      else
+        hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, it[p].dy, lddy, it[p].x, xm, x_keep,
+                           x_scale, slab_of(p), slab_db_of(p), M, K, N, rows_per_split);
+    }
+    G2V_CHECK_LAUNCH();
+  }
+  // one launch reduces the weight slabs and (where requested) the bias slabs of every problem
+  SlabBatch sb;
+  for (int p = 0; p < G2V_TN_BATCH; ++p) {
+    const int pp = p < nprob ? p : 0;
+    sb.slab_a[p] = slab_of(pp); sb.out_a[p] = it[pp].dw; sb.slab_b[p] = slab_db_of(pp); sb.out_b[p] = it[pp].db;
+  }
+  // problems without a bias gradient: their bias blocks find slab_b == nullptr and return
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 32) + (any_db ? cdiv(N, 32) : 0), nprob), dim3(256), 0, (hipStream_t)stream,
+                     sb, n, (int64_t)N, splits, accumulate, cdiv(n, 32));
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float* x, int64_t ldx, int rows_inner,
                                      int64_t stride_outer, int64_t stride_inner, const uint8_t* x_keep, float x_scale,
                                      float* dw, float* db, int M, int K, int N, int accumulate, void* workspace,
@@ -870,62 +982,25 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
     set_error("g2v_linear_bwd_weight: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
-  int splits = tn_splits(M, K, N);
-  int rows_per_split = cdiv(M, splits);
-  rows_per_split = round_up(rows_per_split, TM);
-  float* slab = (float*)workspace;
-  RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
-  int rpw = 0;
-  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw);
-  if (wg > 0) splits = wg;
-  float* slab_db = db ? slab + (size_t)splits * N * K : nullptr;
-  const int ntw = tn_ntw(N);
-  dim3 grid(cdiv(N, 64 * ntw), cdiv(K, 64), splits);
-  if (wg > 0) {
-    const int tn = cdiv(N, 16), tk = cdiv(K, 16);
-#define G2V_TNW2(TN_, TK_, SN, SK, VW, BF)                                                                               \
-  do {                                                                                                                   \
-    const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
-    if (rows_inner > 0) {                                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>), dim3(wg), dim3(512), lds,                \
-                         (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
-    } else {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>,                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>), dim3(wg), dim3(512), lds,               \
-                         (hipStream_t)stream, dy, lddy, x, xm, slab, slab_db, M, K, N, rpw);                             \
-    }                                                                                                                    \
-  } while (0)
-#define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
-  do {                                                                                                                   \
-    if (bf3) G2V_TNW2(TN_, TK_, SN, SK, VW, true);                                                                       \
-    else G2V_TNW2(TN_, TK_, SN, SK, VW, false);                                                                          \
-  } while (0)
-    // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles
-    const bool vec2 = (N % 32 == 0) && (K % 32 == 0) && rows_inner == 0 && (lddy % 2 == 0) && (ldx % 2 == 0) &&
-                      (reinterpret_cast<uintptr_t>(dy) % 8 == 0) && (reinterpret_cast<uintptr_t>(x) % 8 == 0);
-    if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
-    else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1, 1);
-    else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2, 1);
-    else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
-#undef G2V_TNW
-#undef G2V_TNW2
-  } else if (ntw == 1)
-    hipLaunchKernelGGL(gemm_tn_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
-                       slab_db, M, K, N, rows_per_split);
-  else if (ntw == 2)
-    hipLaunchKernelGGL(gemm_tn_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
-                       slab_db, M, K, N, rows_per_split);
-  else
-    hipLaunchKernelGGL(gemm_tn_kernel<3>, grid, dim3(256), 0, (hipStream_t)stream, dy, lddy, x, xm, x_keep, x_scale, slab,
-                       slab_db, M, K, N, rows_per_split);
-  G2V_CHECK_LAUNCH();
-  const int64_t n = (int64_t)N * K;
-  // one launch reduces both the weight slabs and (when requested) the bias slabs
-  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 32) + (db ? cdiv(N, 32) : 0)), dim3(256), 0, (hipStream_t)stream,
-                     slab, n, dw, slab_db, (int64_t)N, db, splits, accumulate, cdiv(n, 32));
-  G2V_CHECK_LAUNCH();
-  return G2V_OK;
+  const WgradItem item{dy, x, dw, db};
+  return wgrad_impl(&item, 1, lddy, ldx, rows_inner, stride_outer, stride_inner, x_keep, x_scale, M, K, N, accumulate, bf3,
+                    (float*)workspace, stream);
+}
+
+extern "C" int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int M, int K,
+                                           int N, int flags, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(items && workspace, "null pointer");
+  G2V_REQUIRE(nprob >= 1 && nprob <= G2V_TN_BATCH, "1..4 problems per call");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  WgradItem it[G2V_TN_BATCH];
+  for (int p = 0; p < nprob; ++p) {
+    G2V_REQUIRE(items[p].dy && items[p].x && items[p].dw, "null pointer");
+    it[p] = WgradItem{items[p].dy, items[p].x, items[p].dw, items[p].db};
+  }
+  if (workspace_bytes < (size_t)nprob * g2v_linear_bwd_weight_workspace(M, K, N)) {
+    set_error("g2v_linear_bwd_weight_batch: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  return wgrad_impl(it, nprob, lddy, ldx, 0, 0, 0, nullptr, 1.0f, M, K, N, flags & 1, (flags & G2V_WGRAD_BF16X3) != 0,
+                    (float*)workspace, stream);
 }

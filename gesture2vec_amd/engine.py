@@ -202,7 +202,8 @@ class VQVAEEngine:
                        self.lib.g2v_gru_seq_bwd_workspace(2, H), self.lib.g2v_gru_seq_fwd_workspace(2, H),
                        self.lib.g2v_vq_stats_workspace(B, E, K),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
-                       self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)))
+                       self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
+                       4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H))     # batches of four GRU weight gradients
         b["ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         self._bufs[B] = b
         return b
@@ -321,11 +322,18 @@ class VQVAEEngine:
                                             self._g(wname), self._g(bname) if bname else None, rows, K_, N_,
                                             2 if self.wgrad_bf16x3 else 0, ws, wsn, st))
 
+        def wgrad4(rows, items):
+            """four (3H x H) GRU weight gradients of one shape in ONE launch + one slab reduction"""
+            arr = (_lib.WgradItem * 4)()
+            for k, (dy, x, wname, bname) in enumerate(items):
+                arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = dy, x, self._g(wname), self._g(bname)
+            check(lib.g2v_linear_bwd_weight_batch(arr, 4, G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn, st))
+
         wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
-        wgrad(_p(b["dgi0"]), G, _p(b["a"]), H, pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0", G, H)
-        wgrad(_p(b["dgh0"]), G, _p(b["h0"]), H, pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0", G, H)
-        wgrad(_p(b["dgi1"]), G, x1.data_ptr(), H, pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1", G, H)
-        wgrad(_p(b["dgh1"]), G, _p(b["h1"]), H, pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1", G, H)
+        wgrad4(M, [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
+                   (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
+                   (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
+                   (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
         wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
         # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
         N = (2 * B * H) // E
@@ -352,10 +360,10 @@ class VQVAEEngine:
             dirs[k].in_dim = H
         check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
-        wgrad(_p(b["dgi_f"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0", G, H, rows=TB)
-        wgrad(_p(b["dgh_f"]), G, b["hs_f"].data_ptr(), H, enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0", G, H, rows=TB)
-        wgrad(_p(b["dgi_b"]), G, _p(b["xin"]), H, enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse", G, H, rows=TB)
-        wgrad(_p(b["dgh_b"]), G, b["hs_b"][1:].data_ptr(), H, enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse", G, H, rows=TB)
+        wgrad4(TB, [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
+                    (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
+                    (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
+                    (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")])
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
         else:

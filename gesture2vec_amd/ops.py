@@ -106,6 +106,19 @@ def linear_bwd_weight(dy, x, N, K, *, M=None, lddy=None, ldx=None, row_map=None,
     return dw, db
 
 
+def linear_bwd_weight_batch(items, N, K, *, M, lddy=None, ldx=None, accumulate=False, bf16x3=False):
+    """items: up to 4 tuples (dy, x, dw, db-or-None) of ONE shape -> one launch + one slab reduction (large M)."""
+    lib = _lib_()
+    arr = (_lib.WgradItem * len(items))()
+    for k, (dy, x, dw, db) in enumerate(items):
+        arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = _p(dy), _p(x), _p(dw), _p(db)
+    dev = items[0][0].device
+    ws = workspace(len(items) * lib.g2v_linear_bwd_weight_workspace(M, K, N), dev, "bwdw")
+    check(lib.g2v_linear_bwd_weight_batch(arr, len(items), lddy if lddy is not None else N, ldx if ldx is not None else K, M, K, N,
+                                          int(bool(accumulate)) | (2 if bf16x3 else 0), _p(ws), ws.numel(), _stream()),
+          "linear_bwd_weight_batch")
+
+
 # ------------------------------------------------------------------------------------------ quantiser
 def vq_code_sqnorm(codebook, out=None):
     K, E = codebook.shape

@@ -71,6 +71,18 @@ int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx
  * elsewhere.  Default (bit clear) is exact fp32 MFMA. */
 #define G2V_WGRAD_ACCUMULATE 1
 #define G2V_WGRAD_BF16X3 2
+
+/* Up to 4 weight-gradient problems of ONE shape (same M, K, N, row strides; plain row addressing, no keep mask) in one call:
+ * the large-M kernels run them in one launch (their workgroups fill each other's ramp-up / tail) followed by one slab
+ * reduction.  workspace >= nprob * g2v_linear_bwd_weight_workspace(M,K,N).  flags as above.  db may be NULL per item. */
+typedef struct {
+  const float* dy;   /* (M,N), row stride lddy */
+  const float* x;    /* (M,K), row stride ldx  */
+  float* dw;         /* (N,K) */
+  float* db;         /* (N) or NULL */
+} g2v_wgrad_item;
+int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int M, int K, int N,
+                                int flags, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
 int g2v_linear_bwd_weight(const float* dy, int64_t lddy,
                           const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,

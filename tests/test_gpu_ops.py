@@ -597,3 +597,21 @@ def test_linear_wave_kernels_at_rollout_shapes(ops):
     relclose(dw_out, (dy.double().t() @ h1.double()).float(), 1e-5, "dW 135x64")
     relclose(db_out, dy.double().sum(0).float(), 1e-5, "db 135")
     assert torch.equal(ops.linear_bwd_weight(dy.to(DEV), h1.to(DEV), D, H)[0], dw_out), "weight gradient must be deterministic"
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 192, 64), (300, 150, 50)])
+def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
+    """g2v_linear_bwd_weight_batch (four problems of one shape in one launch + one slab reduction; sequential fallback for
+    small / generic shapes) is bit-identical to four single calls; db is optional per item."""
+    items, refs = [], []
+    for p in range(4):
+        dy, x = rnd(M, N, seed=30 + p).to(DEV), rnd(M, K, seed=40 + p).to(DEV)
+        dw = torch.zeros(N, K, device=DEV)
+        db = torch.zeros(N, device=DEV) if p != 2 else None
+        items.append((dy, x, dw, db))
+        refs.append(ops.linear_bwd_weight(dy, x, N, K, want_bias=(p != 2)))
+    ops.linear_bwd_weight_batch(items, N, K, M=M)
+    for p in range(4):
+        assert torch.equal(items[p][2], refs[p][0]), f"dw of problem {p}"
+        if items[p][3] is not None:
+            assert torch.equal(items[p][3], refs[p][1]), f"db of problem {p}"
