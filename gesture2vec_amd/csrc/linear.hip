@@ -514,7 +514,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
   const bool okn = n0 + 16 * (TN_ - 1) + i < N, okk = k0 + 16 * (TK_ - 1) + i < K;
   const int in_last = okn ? i : 0, ik_last = okk ? i : 0;
 
-  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_];
+  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_], ea[BF3 ? 1 : 4][BF3 ? 1 : TN_], eb[BF3 ? 1 : 4][BF3 ? 1 : TK_];
   auto load_group = [&](int m0, float (&a)[4][TN_], float (&b)[4][TK_]) {
     // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
     // (B,T,D) -> (T,B,D) row map, then the three following row quads step the (outer, inner) pair.
@@ -669,11 +669,28 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
       compute(na, nb);
       __builtin_amdgcn_sched_barrier(0);
     } else {
-      compute_and_load(ca, cb, m0 + 16, na, nb);
-      compute_and_load(na, nb, min(m0 + 32, M - 16), ca, cb);
+      break;      // fp32 path: the triple-buffered loop below
     }
   }
-  if (m0 < me) compute(ca, cb);                 // odd number of groups: the last one is already loaded
+  if constexpr (!BF3) {
+    // three operand buffers in rotation: the loads for the group AFTER next are issued between the MFMAs of the current
+    // group, i.e. two groups (2 x 96 MFMAs per wave, ~6k cycles with two waves per SIMD) ahead of their use - one group
+    // of distance does not cover the HBM round trip under load.
+    auto clamp_g = [&](int m) { return min(m, M - 16); };      // past the end of the range: a valid, unused group
+    if (m0 < me) load_group(clamp_g(m0 + 16), na, nb);
+    while (m0 < me) {
+      compute_and_load(ca, cb, clamp_g(m0 + 32), ea, eb);
+      m0 += 16;
+      if (m0 >= me) break;
+      compute_and_load(na, nb, clamp_g(m0 + 32), ca, cb);
+      m0 += 16;
+      if (m0 >= me) break;
+      compute_and_load(ea, eb, clamp_g(m0 + 32), na, nb);
+      m0 += 16;
+    }
+  } else {
+    if (m0 < me) compute(ca, cb);               // odd number of groups: the last one is already loaded
+  }
   // ---- sum the four row ranges of each tile group: (2,3) -> LDS -> (0,1); 1 -> LDS -> 0; range 0 writes the slab ----
   float* dbl = smem + 4 * NTILE * 256;
 #pragma unroll
