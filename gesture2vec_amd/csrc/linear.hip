@@ -480,14 +480,22 @@ struct TnBatch {
   float* slab_db[G2V_TN_BATCH];
 };
 
-template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3>
-__global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t lddy, RowMap xm, int M, int K, int N,
-                                                           int rows_per_wave) {
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR = 4>
+__device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, const RowMap& xm, int M, int K, int N,
+                                             int rows_per_wave) {
   const float* __restrict__ dY = bt.dy[blockIdx.y];
   const float* __restrict__ X = bt.x[blockIdx.y];
   float* __restrict__ slab = bt.slab[blockIdx.y];
   float* __restrict__ slab_db = bt.slab_db[blockIdx.y];
-  static_assert(SN * SK == 2, "two tile groups per workgroup");
+  // NR row ranges x two tile groups.  NR = 2 (256 threads, ONE wave per SIMD, one workgroup per CU) is what the fp32 path
+  // launches: with the operand loads interleaved between its MFMAs a single wave keeps the matrix pipe busy on its own, and
+  // compared with NR = 4 (two waves per SIMD) every wave walks twice the rows and the final sum is 2-way (measured at the
+  // BASELINE shape, four 3H x H problems per launch: 137 us against 153 us).  NR = 4 remains for the bf16x3 path, whose
+  // split arithmetic leaves the second wave something to overlap.
+  constexpr int NG = SN * SK;
+  static_assert(NG == 2, "two tile groups per workgroup");
+  static_assert(NR == 2 || NR == 4, "two or four row ranges per workgroup");
+  constexpr bool TRIPLE = !BF3;
   static_assert(VW == 1 || (VW == 2 && TN_ % 2 == 0 && TK_ % 2 == 0), "pairs of tiles per 8-byte load");
   // VW == 2 (8-byte-aligned rows, whole tiles): the 16 MFMA rows of a PAIR of tiles are interleaved over 32 columns,
   // lane i <-> columns 32 g + 2 i + {0, 1}, so one global_load_dwordx2 (a full 128-byte line per matrix row) feeds the
@@ -497,9 +505,9 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
   constexpr int NTILE = TN_ * TK_;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int rr = wave & 3, grp = wave >> 2;            // row range, tile group
+  const int rr = wave % NR, grp = wave / NR;           // row range, tile group
   const int n0 = 16 * TN_ * (grp % SN), k0 = 16 * TK_ * (grp / SN);
-  const int mb = (blockIdx.x * 4 + rr) * rows_per_wave;
+  const int mb = (blockIdx.x * NR + rr) * rows_per_wave;
   const int me = min(M, mb + rows_per_wave);
 
   f32x4 acc[TN_][TK_];
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
   const bool okn = n0 + 16 * (TN_ - 1) + i < N, okk = k0 + 16 * (TK_ - 1) + i < K;
   const int in_last = okn ? i : 0, ik_last = okk ? i : 0;
 
-  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_], ea[BF3 ? 1 : 4][BF3 ? 1 : TN_], eb[BF3 ? 1 : 4][BF3 ? 1 : TK_];
+  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_], ea[TRIPLE ? 4 : 1][TRIPLE ? TN_ : 1], eb[TRIPLE ? 4 : 1][TRIPLE ? TK_ : 1];
   auto load_group = [&](int m0, float (&a)[4][TN_], float (&b)[4][TK_]) {
     // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
     // (B,T,D) -> (T,B,D) row map, then the three following row quads step the (outer, inner) pair.
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
       break;      // fp32 path: the triple-buffered loop below
     }
   }
-  if constexpr (!BF3) {
+  if constexpr (TRIPLE) {
     // three operand buffers in rotation: the loads for the group AFTER next are issued between the MFMAs of the current
     // group, i.e. two groups (2 x 96 MFMAs per wave, ~6k cycles with two waves per SIMD) ahead of their use - one group
     // of distance does not cover the HBM round trip under load.
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
     if (m0 < me) compute(ca, cb);               // odd number of groups: the last one is already loaded
   }
   // ---- sum the four row ranges of each tile group: (2,3) -> LDS -> (0,1); 1 -> LDS -> 0; range 0 writes the slab ----
-  float* dbl = smem + 4 * NTILE * 256;
+  float* dbl = smem + NR * NTILE * 256;
 #pragma unroll
   for (int t = 0; t < TN_; ++t) {
     float v = dbs[t];
@@ -717,10 +725,12 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
         acc[t][u][0] += v.x; acc[t][u][1] += v.y; acc[t][u][2] += v.z; acc[t][u][3] += v.w;
       }
   };
-  if (rr >= 2) dump(smem + (2 * grp + rr - 2) * NTILE * 256);
-  __syncthreads();
-  if (rr < 2) absorb(smem + (2 * grp + rr) * NTILE * 256);
-  __syncthreads();
+  if constexpr (NR == 4) {
+    if (rr >= 2) dump(smem + (2 * grp + rr - 2) * NTILE * 256);
+    __syncthreads();
+    if (rr < 2) absorb(smem + (2 * grp + rr) * NTILE * 256);
+    __syncthreads();
+  }
   if (rr == 1) dump(smem + grp * NTILE * 256);
   __syncthreads();
   if (rr != 0) return;
@@ -753,21 +763,32 @@ __global__ __launch_bounds__(512) void gemm_tn_wave_kernel(TnBatch bt, int64_t l
 #pragma unroll
     for (int t = 0; t < TN_; ++t) {
       const int n = (VW == 2) ? n0 + 32 * (t >> 1) + 2 * i + (t & 1) : n0 + 16 * t + i;
-      const float* d0 = dbl + (4 * grp * TN_ + t) * 16 + i;
+      const float* d0 = dbl + (NR * grp * TN_ + t) * 16 + i;
       if (q == 0 && n < N)
-        slab_db[(int64_t)blockIdx.x * N + n] = (d0[0] + d0[TN_ * 16]) + (d0[2 * TN_ * 16] + d0[3 * TN_ * 16]);
+        slab_db[(int64_t)blockIdx.x * N + n] =
+            NR == 4 ? (d0[0] + d0[TN_ * 16]) + (d0[2 * TN_ * 16] + d0[3 * TN_ * 16]) : d0[0] + d0[TN_ * 16];
     }
   }
 }
 
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR>
+__global__ __launch_bounds__(128 * NR) __attribute__((amdgpu_num_vgpr(128))) void gemm_tn_wave_kernel(TnBatch bt, int64_t lddy,
+                                                                                                      RowMap xm, int M, int K,
+                                                                                                      int N, int rows_per_wave) {
+  static_assert(SN * SK == 2, "two tile groups per workgroup");
+  tn_wave_body<TN_, TK_, SN, SK, MAPPED, VW, BF3, NR>(bt, lddy, xm, M, K, N, rows_per_wave);
+}
+
 // grid (= number of slabs) and rows per wave of the wave-autonomous path; 0 when the shape is not covered
-static int tn_wave_grid(int M, int K, int N, bool has_keep, int* rows_per_wave) {
+static int tn_wave_grid(int M, int K, int N, bool has_keep, int* rows_per_wave, int nprob = 1, int nr = 4) {
   const int tn = cdiv(N, 16), tk = cdiv(K, 16);
   const bool covered = (tn == 12 && tk == 4) || (tn == 4 && tk == 9) || (tn == 9 && tk == 4) || (tn == 4 && tk == 4);
   if (!covered || has_keep || M < 4096 || (M & 15)) return 0;
-  int rpw = round_up(cdiv(M, 1024), 16);
+  // one workgroup (4 row ranges) per CU over ALL problems of the launch: a workgroup occupies a whole CU's registers, so
+  // more workgroups than CUs only run as further rounds, each paying the prologue, the LDS sum and the slab write again
+  int rpw = round_up(cdiv((int64_t)M * nprob, 256 * nr), 16);
   if (rows_per_wave) *rows_per_wave = rpw;
-  return cdiv(M, 4 * rpw);
+  return cdiv(M, nr * rpw);
 }
 
 // two slab families in one launch: blocks [0, nblk_a) reduce (slab_a -> out_a), the rest (slab_b -> out_b).
@@ -892,8 +913,10 @@ extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w
 extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
   int splits = tn_splits(M, K, N);
-  const int wg = tn_wave_grid(M, K, N, false, nullptr);
-  if (wg > splits) splits = wg;
+  for (int nr = 2; nr <= 4; nr += 2) {       // either row-range variant of the wave-autonomous path
+    const int wg = tn_wave_grid(M, K, N, false, nullptr, 1, nr);
+    if (wg > splits) splits = wg;
+  }
   return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
 }
 
@@ -903,14 +926,17 @@ struct WgradItem {
   const float* dy; const float* x; float* dw; float* db;
 };
 static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx, int rows_inner, int64_t stride_outer,
-                      int64_t stride_inner, const uint8_t* x_keep, float x_scale, int M, int K, int N, int accumulate,
-                      bool bf3, float* workspace, g2v_stream_t stream) {
+                      int64_t stride_inner, const uint8_t* x_keep, float x_scale, int M, int K, int N, int flags,
+                      float* workspace, g2v_stream_t stream) {
+  const int accumulate = flags & G2V_WGRAD_ACCUMULATE;
+  const bool bf3 = (flags & G2V_WGRAD_BF16X3) != 0;
   int splits = tn_splits(M, K, N);
   int rows_per_split = cdiv(M, splits);
   rows_per_split = round_up(rows_per_split, TM);
   RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
   int rpw = 0;
-  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw);
+  const int nr = bf3 ? 4 : 2;                  // row ranges (waves per tile group) per workgroup, see tn_wave_body
+  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw, nprob, nr);
   if (wg > 0) splits = wg;
   const size_t slab_stride = (size_t)splits * ((size_t)N * K + N);
   const int64_t n = (int64_t)N * K;
@@ -930,25 +956,18 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     }
     (void)all_db;
     const int tn = cdiv(N, 16), tk = cdiv(K, 16);
-#define G2V_TNW2(TN_, TK_, SN, SK, VW, BF)                                                                               \
+#define G2V_TNW2(TN_, TK_, SN, SK, VW, BF, NR, MP)                                                                       \
   do {                                                                                                                   \
-    const size_t lds = ((size_t)4 * TN_ * TK_ * 256 + 8 * TN_ * 16) * sizeof(float);                                      \
-    if (rows_inner > 0) {                                                                                                \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>,                        \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, true, VW, BF>), dim3(wg, nprob), dim3(512), lds,         \
-                         (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                               \
-    } else {                                                                                                             \
-      (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>,                       \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                   \
-      hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, false, VW, BF>), dim3(wg, nprob), dim3(512), lds,        \
-                         (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                               \
-    }                                                                                                                    \
+    const size_t lds = ((size_t)NR * TN_ * TK_ * 256 + 2 * NR * TN_ * 16) * sizeof(float);                                \
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wave_kernel<TN_, TK_, SN, SK, MP, VW, BF, NR>,                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    hipLaunchKernelGGL((gemm_tn_wave_kernel<TN_, TK_, SN, SK, MP, VW, BF, NR>), dim3(wg, nprob), dim3(128 * NR), lds,    \
+                       (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                                 \
   } while (0)
 #define G2V_TNW(TN_, TK_, SN, SK, VW)                                                                                    \
   do {                                                                                                                   \
-    if (bf3) G2V_TNW2(TN_, TK_, SN, SK, VW, true);                                                                       \
-    else G2V_TNW2(TN_, TK_, SN, SK, VW, false);                                                                          \
+    if (bf3) { if (rows_inner > 0) G2V_TNW2(TN_, TK_, SN, SK, VW, true, 4, true); else G2V_TNW2(TN_, TK_, SN, SK, VW, true, 4, false); } \
+    else { if (rows_inner > 0) G2V_TNW2(TN_, TK_, SN, SK, VW, false, 2, true); else G2V_TNW2(TN_, TK_, SN, SK, VW, false, 2, false); }  \
   } while (0)
     // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles (checked above)
     if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
@@ -993,14 +1012,12 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
                                      size_t workspace_bytes, g2v_stream_t stream) {
   G2V_REQUIRE(dy && x && dw && workspace, "null pointer");
   G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
-  const bool bf3 = (accumulate & G2V_WGRAD_BF16X3) != 0;      // flag bits: 1 = accumulate, 2 = bf16x3 products
-  accumulate &= 1;
   if (workspace_bytes < g2v_linear_bwd_weight_workspace(M, K, N)) {
     set_error("g2v_linear_bwd_weight: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
   const WgradItem item{dy, x, dw, db};
-  return wgrad_impl(&item, 1, lddy, ldx, rows_inner, stride_outer, stride_inner, x_keep, x_scale, M, K, N, accumulate, bf3,
+  return wgrad_impl(&item, 1, lddy, ldx, rows_inner, stride_outer, stride_inner, x_keep, x_scale, M, K, N, accumulate,
                     (float*)workspace, stream);
 }
 
@@ -1018,6 +1035,5 @@ extern "C" int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int npro
     set_error("g2v_linear_bwd_weight_batch: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
-  return wgrad_impl(it, nprob, lddy, ldx, 0, 0, 0, nullptr, 1.0f, M, K, N, flags & 1, (flags & G2V_WGRAD_BF16X3) != 0,
-                    (float*)workspace, stream);
+  return wgrad_impl(it, nprob, lddy, ldx, 0, 0, 0, nullptr, 1.0f, M, K, N, flags, (float*)workspace, stream);
 }
