@@ -44,6 +44,20 @@ def _dec_gru_names(L):
     return names
 
 
+QUANTIZER_GSSOFT_PARAMS = ("vq_layer._embedding.weight", "vq_layer.mean_layer.weight", "vq_layer.mean_layer.bias",
+                           "vq_layer.logvar_layer.weight", "vq_layer.logvar_layer.bias")
+
+
+def quantizer_layout(quantizer: str, E: int, K: int):
+    """trainable tensors of the quantiser itself.  EMA (:1182-1301): none (codebook moves by EMA, pre_linear gets no gradient).
+    GSSoft (:1304-1438, what the reference's Autoencoder_VQVAE ships with): codebook, mean_layer, logvar_layer."""
+    if quantizer == "ema":
+        return []
+    if quantizer == "gssoft":
+        return list(zip(QUANTIZER_GSSOFT_PARAMS, ((K, E), (E, E), (E,), (K, E), (K,))))
+    raise ValueError(f"unknown quantizer {quantizer!r}")
+
+
 def trainable_layout(D: int, H: int, L: int):
     """(name, shape) of every tensor that receives a gradient in the reference's step, in flat-buffer order."""
     out = [("encoder.in_layer.weight", (H, D)), ("encoder.in_layer.bias", (H,))]
@@ -68,7 +82,7 @@ def trainable_layout(D: int, H: int, L: int):
 class VQVAEEngine:
     def __init__(self, D: int, H: int, L: int, K: int, T: int, *, beta: float, dropout_prob: float,
                  n_pre_poses: int = 1, conditioned: bool = True, decay: float = 0.85, eps: float = 1e-5,
-                 device="cuda:0", seed: int = 0):
+                 device="cuda:0", seed: int = 0, quantizer: str = "ema"):
         if L != 2:
             raise NotImplementedError("the gfx950 rollout kernels implement n_layers == 2 (every shipped config)")
         self.lib = _lib.load()
@@ -81,7 +95,11 @@ class VQVAEEngine:
         self.decay, self.eps = float(decay), float(eps)
         self.device = torch.device(device)
         self.seed = int(seed)
-        self.layout = trainable_layout(D, H, L)
+        # "ema": the fused path (north star).  "gssoft": the encoder / decoder stages of this engine around the
+        # VQ_Payam_GSSoft module (model/Autoencoder_VQVAE_model.py); its trainable tensors live at the END of the same flat
+        # buffer so that clip_grad_norm_ + Adam stay one fused launch over everything.
+        self.quantizer = quantizer
+        self.layout = trainable_layout(D, H, L) + quantizer_layout(quantizer, H * L, K)
         self.offsets: Dict[str, tuple] = {}
         off = 0
         for name, shp in self.layout:
@@ -91,6 +109,8 @@ class VQVAEEngine:
             self.offsets[name] = (off, n, shp)
             off += (n + 3) // 4 * 4          # keep every tensor 16-byte aligned inside the flat buffer
         self.n_flat = off
+        q_names = [n for n, _ in quantizer_layout(quantizer, H * L, K)]
+        self.q_off = self.offsets[q_names[0]][0] if q_names else off        # start of the quantiser's slice
         dev = self.device
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         # ONE communication buffer [flat grads | cnt (K) | dw (K*E)]: a single RCCL all-reduce per step under DP
@@ -234,11 +254,33 @@ class VQVAEEngine:
                 n_global: Optional[int] = None):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
+        if self.quantizer != "ema":
+            raise NotImplementedError("the fused forward is the EMA quantiser's; other quantisers go through "
+                                      "forward_encoder / forward_decoder (Autoencoder_VQVAE.forward does)")
+        lib, st = self.lib, self._stream()
+        B = in_poses.shape[0]
+        H, E, K = self.H, self.E, self.K
+        b = self.forward_encoder(in_poses, training)
+        # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
+        N = (2 * B * H) // E
+        check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
+                                 _p(b["flat"]), E, N, E, E, 0, st))
+        check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
+        check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
+                                    _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
+        check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws"]), b["ws"].numel(), st))
+        if ema_update:
+            self.vq_finish(B, training, n_global)
+        return self.forward_decoder(out_poses, B, training)
+
+    def forward_encoder(self, in_poses: torch.Tensor, training: bool):
+        """EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU.  Fills buffers['enc_hidden'] (2,B,H) =
+        the layer-0 forward / backward final states, i.e. encoder_hidden[:L] of the reference (:971-973)."""
         lib, st = self.lib, self._stream()
         B, T, D = in_poses.shape
         assert T == self.T and D == self.D, "shape does not match the engine"
-        ops._chk(in_poses, name="in_poses"); ops._chk(out_poses, name="out_poses")
-        H, E, K, G = self.H, self.E, self.K, 3 * self.H
+        ops._chk(in_poses, name="in_poses")
+        H, G = self.H, 3 * self.H
         b = self.buffers(B)
         drop_in = training and self.p > 0
         enc = "encoder."
@@ -269,17 +311,16 @@ class VQVAEEngine:
             dirs[k].gates = _p(b["gates_" + key]) if training else None
             dirs[k].reverse = k
         check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
-        # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
-        N = (2 * B * H) // E
-        check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
-                                 _p(b["flat"]), E, N, E, E, 0, st))
-        check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
-        check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
-                                    _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
-        check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws"]), b["ws"].numel(), st))
-        if ema_update:
-            self.vq_finish(B, training, n_global)
-        # ---- decoder rollout (:1039-1054) -----------------------------------------------------------------------
+        return b
+
+    def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool):
+        """decoder rollout (:1039-1054) from buffers['quant'] (2,B,H) = the initial hidden state; fills buffers['y'] (T,B,D)."""
+        lib, st = self.lib, self._stream()
+        T, D, H = self.T, self.D, self.H
+        ops._chk(out_poses, name="out_poses")
+        assert tuple(out_poses.shape) == (B, T, D), "shape does not match the engine"
+        b = self.buffers(B)
+        drop_in = training and self.p > 0
         check(lib.g2v_dec_rollout_fwd(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
                                       C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
                                       _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
@@ -305,6 +346,39 @@ class VQVAEEngine:
     def backward(self, in_poses: torch.Tensor, B: int, g_loss_vq: Optional[torch.Tensor] = None):
         """Backward of forward(training=True): expects buffers['dy'] = dLoss/d y (T,B,D).  Writes every parameter
         gradient into the flat grad buffer (overwrite, not accumulate)."""
+        if self.quantizer != "ema":
+            raise NotImplementedError("fused backward = EMA quantiser; see backward_decoder / backward_encoder")
+        H, E = self.H, self.E
+        b = self.backward_decoder(B)
+        # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
+        N = (2 * B * H) // E
+        gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
+        check(self.lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
+                                  self.beta, self._stream()))
+        self.backward_encoder(in_poses, B)
+
+    def _wgrad_fns(self, b, M_default):
+        lib = self.lib
+        ws, wsn = _p(b["ws"]), b["ws"].numel()
+        G, H = 3 * self.H, self.H
+
+        def wgrad(dy, lddy, x, ldx, wname, bname, N_, K_, rows=M_default, row_map=(0, 0, 0), keep=None, scale=1.0):
+            check(lib.g2v_linear_bwd_weight(dy, lddy, x, ldx, row_map[0], row_map[1], row_map[2], keep, scale,
+                                            self._g(wname), self._g(bname) if bname else None, rows, K_, N_,
+                                            2 if self.wgrad_bf16x3 else 0, ws, wsn, self._stream()))
+
+        def wgrad4(rows, items):
+            """four (3H x H) GRU weight gradients of one shape in ONE launch + one slab reduction"""
+            arr = (_lib.WgradItem * 4)()
+            for k, (dy, x, wname, bname) in enumerate(items):
+                arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = dy, x, self._g(wname), self._g(bname)
+            check(lib.g2v_linear_bwd_weight_batch(arr, 4, G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn,
+                                                  self._stream()))
+        return wgrad, wgrad4
+
+    def backward_decoder(self, B: int):
+        """Backward of forward_decoder(training=True): expects buffers['dy'] = dLoss/d y (T,B,D); writes the decoder's
+        parameter gradients (overwrite) and buffers['dh_init'] (2,B,H) = dLoss / d(initial hidden state)."""
         lib, st = self.lib, self._stream()
         T, D, H, E, G = self.T, self.D, self.H, self.E, 3 * self.H
         b = self.buffers(B)
@@ -316,31 +390,23 @@ class VQVAEEngine:
         pre = "decoder.decoder."
         M = (T - 1) * B
         x1 = b["x1"] if drop else b["h0"][1:]
-
-        def wgrad(dy, lddy, x, ldx, wname, bname, N_, K_, rows=M, row_map=(0, 0, 0), keep=None, scale=1.0):
-            check(lib.g2v_linear_bwd_weight(dy, lddy, x, ldx, row_map[0], row_map[1], row_map[2], keep, scale,
-                                            self._g(wname), self._g(bname) if bname else None, rows, K_, N_,
-                                            2 if self.wgrad_bf16x3 else 0, ws, wsn, st))
-
-        def wgrad4(rows, items):
-            """four (3H x H) GRU weight gradients of one shape in ONE launch + one slab reduction"""
-            arr = (_lib.WgradItem * 4)()
-            for k, (dy, x, wname, bname) in enumerate(items):
-                arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = dy, x, self._g(wname), self._g(bname)
-            check(lib.g2v_linear_bwd_weight_batch(arr, 4, G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn, st))
-
+        wgrad, wgrad4 = self._wgrad_fns(b, M)
         wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
         wgrad4(M, [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
                    (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
                    (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
                    (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
         wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
-        # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
-        N = (2 * B * H) // E
-        gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
-        check(lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
-                             self.beta, st))
-        # ---- encoder layer-0 BPTT -----------------------------------------------------------------------------------
+        return b
+
+    def backward_encoder(self, in_poses: torch.Tensor, B: int):
+        """Encoder layer-0 BPTT from buffers['gz'] (2,B,H) = dLoss / d enc_hidden; writes the encoder's parameter gradients."""
+        lib, st = self.lib, self._stream()
+        T, D, H, G = self.T, self.D, self.H, 3 * self.H
+        b = self.buffers(B)
+        ws, wsn = _p(b["ws"]), b["ws"].numel()
+        drop = self.p > 0
+        wgrad, wgrad4 = self._wgrad_fns(b, T * B)
         enc = "encoder."
         dirs = (_lib.GruDirBwd * 2)()
         for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):

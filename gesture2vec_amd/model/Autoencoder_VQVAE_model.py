@@ -218,7 +218,17 @@ class Autoencoder_VQVAE(nn.Module):
         self.vq = True
         self.vq_components = int(args.autoencoder_vq_components)
         self.commitment_cost = float(args.autoencoder_vq_commitment_cost)
-        self.vq_layer = VQ_Payam_EMA(self.vq_components, args.hidden_size * args.n_layers, self.commitment_cost, 0.85)
+        # The reference builds VQ_Payam_EMA (:801-807) and then overwrites it with VQ_Payam_GSSoft (:816-820).  The EMA
+        # quantiser is the north star and the fused engine path; `args.autoencoder_vq_quantizer = "gssoft"` (not a
+        # reference key; load_checkpoint_and_model sets it when a checkpoint carries the soft quantiser's tensors) builds the
+        # model exactly as the reference ships it: same state_dict, encoder / decoder stages of the engine around the module.
+        self.quantizer = str(getattr(args, "autoencoder_vq_quantizer", "ema")).lower()
+        if self.quantizer == "ema":
+            self.vq_layer = VQ_Payam_EMA(self.vq_components, args.hidden_size * args.n_layers, self.commitment_cost, 0.85)
+        elif self.quantizer == "gssoft":
+            self.vq_layer = VQ_Payam_GSSoft(self.vq_components, args.hidden_size * args.n_layers, self.commitment_cost)
+        else:
+            raise ValueError(f"autoencoder_vq_quantizer must be 'ema' or 'gssoft', got {self.quantizer!r}")
         self.n_frames = n_frames
         self.n_pre_poses = args.n_pre_poses
         self.pose_dim = args.rep_learning_dim
@@ -242,7 +252,8 @@ class Autoencoder_VQVAE(nn.Module):
         if eng is None or eng.device != dev:
             eng = VQVAEEngine(self.pose_dim, self.hidden_size, self.n_layers, self.vq_components, self.n_frames,
                               beta=self.commitment_cost, dropout_prob=self.dropout_prob, n_pre_poses=self.n_pre_poses,
-                              conditioned=self.autoencoder_conditioned, device=dev, seed=self.rng_seed)
+                              conditioned=self.autoencoder_conditioned, device=dev, seed=self.rng_seed,
+                              quantizer=self.quantizer)
             self._engine = eng
         # (re)home every trainable tensor into the flat buffer; cheap pointer check per call
         for name, _ in eng.layout:
@@ -255,8 +266,9 @@ class Autoencoder_VQVAE(nn.Module):
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g
         vq, bn = self.vq_layer, self.decoder.decoder.pre_linear[1]
-        eng.vq_pre_w, eng.vq_pre_b = vq.pre_linear.weight.data, vq.pre_linear.bias.data
-        eng.codebook, eng.ema_w, eng.ema_cs = vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size
+        if self.quantizer == "ema":
+            eng.vq_pre_w, eng.vq_pre_b = vq.pre_linear.weight.data, vq.pre_linear.bias.data
+            eng.codebook, eng.ema_w, eng.ema_cs = vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size
         if eng.bn_rm.data_ptr() != bn.running_mean.data_ptr() or eng.bn_rv.data_ptr() != bn.running_var.data_ptr():
             eng.bn_rm, eng.bn_rv = bn.running_mean, bn.running_var
             eng._wstruct = None
@@ -279,7 +291,9 @@ class Autoencoder_VQVAE(nn.Module):
         B = in_poses.shape[0]
         if not self._explicit_masks:
             eng.draw_masks(B, self.training)
-        if self.training and torch.is_grad_enabled():
+        if self.quantizer != "ema":
+            y, first_hidden, loss_vq, perp = self._forward_staged(eng, in_poses, out_poses)
+        elif self.training and torch.is_grad_enabled():
             y, first_hidden, loss_vq, perp = _VQVAEFn.apply(self.encoder.in_layer.weight, self, in_poses, out_poses)
         else:
             b = eng.forward(in_poses, out_poses, self.training)
@@ -288,6 +302,88 @@ class Autoencoder_VQVAE(nn.Module):
         if self.training:
             self.decoder.decoder.pre_linear[1].num_batches_tracked += self.n_frames - 1   # one BN call per decode step
         return y.transpose(0, 1), first_hidden[: self.n_layers], loss_vq, perp
+
+    def _forward_staged(self, eng, in_poses, out_poses):
+        """encoder stage -> self.vq_layer (an nn.Module of HIP-backed autograd functions) -> decoder stage.  The
+        quantiser's gradients accumulate into its slice of the engine's flat grad buffer (two uses of the codebook), so that
+        slice is cleared here; everything else is overwritten by the stage backwards."""
+        B = in_poses.shape[0]
+        if self.training and torch.is_grad_enabled():
+            eng.gflat[eng.q_off:eng.n_flat].zero_()
+            hidden = _EncFn.apply(self.encoder.in_layer.weight, self, in_poses)
+            loss_vq, quantized, perp, _ = self.vq_layer(hidden)
+            y = _DecFn.apply(quantized, self, out_poses)
+            return y, quantized, loss_vq, perp
+        with torch.no_grad():
+            b = eng.forward_encoder(in_poses, self.training)
+            loss_vq, quantized, perp, _ = self.vq_layer(b["enc_hidden"])
+            b["quant"].copy_(quantized.reshape(b["quant"].shape))
+            eng.forward_decoder(out_poses, B, self.training)
+            return b["y"].clone(), quantized.clone(), loss_vq, perp
+
+
+def _rebind_grads(net, eng):
+    for name, _ in eng.layout:      # in case zero_grad(set_to_none=True) dropped the views
+        p = net.get_parameter(name)
+        g = eng.view(name, True)
+        if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+            p.grad = g
+
+
+class _EncFn(torch.autograd.Function):
+    """in_poses -> encoder_hidden[:L] (2,B,H) through VQVAEEngine.forward_encoder / backward_encoder (module-level path of
+    the non-EMA quantisers)."""
+
+    @staticmethod
+    def forward(ctx, anchor, net, in_poses):
+        eng = net._engine
+        b = eng.forward_encoder(in_poses, True)
+        ctx.net = net
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(in_poses)
+        return b["enc_hidden"].clone()
+
+    @staticmethod
+    def backward(ctx, g_hidden):
+        net = ctx.net
+        eng = net._engine
+        (in_poses,) = ctx.saved_tensors
+        B = in_poses.shape[0]
+        b = eng.buffers(B)
+        if g_hidden is None:
+            b["gz"].zero_()
+        else:
+            b["gz"].copy_(g_hidden.reshape(b["gz"].shape))
+        eng.backward_encoder(in_poses, B)
+        _rebind_grads(net, eng)
+        return None, None, None
+
+
+class _DecFn(torch.autograd.Function):
+    """(initial hidden (2,B,H), out_poses) -> y (T,B,D) through VQVAEEngine.forward_decoder / backward_decoder."""
+
+    @staticmethod
+    def forward(ctx, hidden, net, out_poses):
+        eng = net._engine
+        B = out_poses.shape[0]
+        b = eng.buffers(B)
+        b["quant"].copy_(hidden.reshape(b["quant"].shape))
+        eng.forward_decoder(out_poses, B, True)
+        ctx.net, ctx.B, ctx.hshape = net, B, hidden.shape
+        ctx.set_materialize_grads(False)
+        return b["y"].clone()
+
+    @staticmethod
+    def backward(ctx, gy):
+        net, B = ctx.net, ctx.B
+        eng = net._engine
+        b = eng.buffers(B)
+        if gy is None:
+            b["dy"].zero_()
+        else:
+            b["dy"].copy_(gy)
+        eng.backward_decoder(B)
+        return b["dh_init"].clone().reshape(ctx.hshape), None, None
 
 
 class _VQVAEFn(torch.autograd.Function):
@@ -319,11 +415,7 @@ class _VQVAEFn(torch.autograd.Function):
         if g_first_hidden is not None:
             raise NotImplementedError("gradient through decoder_first_hidden is not used by the reference's losses")
         eng.backward(in_poses, B, gl)
-        for name, _ in eng.layout:      # re-bind in case zero_grad(set_to_none=True) dropped the views
-            p = net.get_parameter(name)
-            g = eng.view(name, True)
-            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
-                p.grad = g
+        _rebind_grads(net, eng)
         return None, None, None, None
 
 

@@ -47,8 +47,13 @@ def load_checkpoint_and_model(checkpoint_path, _device="cpu", what: str = ""):
     print("epoch {}".format(epoch))
     if what == "autoencoder_vq":
         from train_autoencoder_VQVAE import init_model as VQVAE_init
+        # the reference as shipped trains the VQ_Payam_GSSoft override (Autoencoder_VQVAE_model.py:816-820): such
+        # checkpoints carry mean_layer / logvar_layer and no EMA buffers; the EMA quantiser has _ema_w / _ema_cluster_size
+        if "vq_layer.mean_layer.weight" in checkpoint["gen_dict"]:
+            args.autoencoder_vq_quantizer = "gssoft"
+        elif "vq_layer._ema_w" in checkpoint["gen_dict"]:
+            args.autoencoder_vq_quantizer = "ema"
         generator, loss_fn = VQVAE_init(args, lang_model, pose_dim, "cpu")
-        # reference checkpoints trained with the shipped GSSoft override carry mean_layer/logvar_layer keys: refuse them
         generator.load_state_dict(checkpoint["gen_dict"], strict=True)
         generator = generator.to(_device)
     elif what == "DAE":
