@@ -35,6 +35,9 @@ _SPEC = [
     ("learning_rate", float, 0.001, False), ("loss_l1_weight", float, 50, False), ("loss_cont_weight", float, 0.1, False),
     ("loss_var_weight", float, 0.01, False),
     ("rep_learning_checkpoint", str, "", False), ("rep_learning_dim", int, -1, False), ("noise_dim", int, 200, False),
+    # not a reference key: "ema" (north star, fused step) or "gssoft" (the quantiser the reference's model actually ships
+    # with, Autoencoder_VQVAE_model.py:816-820; module-level step)
+    ("autoencoder_vq_quantizer", str, "ema", False),
 ]
 _LIST_PATH_KEYS = ("train_data_path", "val_data_path", "test_data_path")     # action="append" in the reference
 _LIST_FLOAT_KEYS = ("data_mean", "data_std")                                  # append + nargs="*": a list of lists

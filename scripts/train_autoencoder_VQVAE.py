@@ -103,6 +103,9 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
     gen_optimizer = FusedClipAdam(generator, lr=args.learning_rate, betas=(0.5, 0.999))
     reduce_fn = None
     if _DIST:
+        if generator.quantizer != "ema":
+            raise NotImplementedError("data-parallel training exchanges the EMA quantiser's statistics; "
+                                      "autoencoder_vq_quantizer='gssoft' trains on one GPU")
         from gesture2vec_amd.dp import GradStatsAllReduce, broadcast_state
         generator.rng_seed = 1234 + _RANK                               # independent dropout masks per shard
         eng, vq = generator.engine(), generator.vq_layer

@@ -32,6 +32,30 @@ def test_train_autoencoder_vqvae_synthetic(tmp_path):
     assert float(loss_fn(out_poses, x)) > 0
 
 
+def test_train_autoencoder_vqvae_shipped_quantizer(tmp_path):
+    """--autoencoder_vq_quantizer gssoft: the model as the reference ships it trains through the same entry point, its
+    checkpoint carries the soft quantiser's tensors and reloads as such."""
+    out = os.path.join(tmp_path, "run")
+    cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"),
+           "--config", os.path.join(ROOT, "config", "VQ-VAE_synthetic.yml"), "--synthetic", "--synthetic_batches", "3",
+           "--batch_size", "64", "--epochs", "2", "--model_save_path", out, "--name", "g", "--autoencoder_vq_quantizer", "gssoft"]
+    r = subprocess.run(cmd, cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    log = r.stderr + r.stdout
+    assert "[VAL] loss:" in log and "EP 2 (  3) |" in log
+    ckpt = os.path.join(out, "g_checkpoint_002.bin")
+    raw = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert "vq_layer.mean_layer.weight" in raw["gen_dict"] and "vq_layer._ema_w" not in raw["gen_dict"]
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import utils.train_utils as tu
+    args, net, loss_fn, lang, pose_dim = tu.load_checkpoint_and_model(ckpt, "cuda:0", "autoencoder_vq")
+    assert type(net.vq_layer).__name__ == "VQ_Payam_GSSoft"
+    x = torch.randn(8, 34, 135, device="cuda:0")
+    with torch.no_grad():
+        out_poses, latent, loss_vq, perp = net(x, x)
+    assert out_poses.shape == (8, 34, 135) and torch.isfinite(out_poses).all() and float(perp) > 1
+
+
 def test_train_text2embedding_synthetic(tmp_path):
     out = os.path.join(tmp_path, "run_t2e")
     cmd = [sys.executable, os.path.join(ROOT, "scripts", "train_text2embedding.py"),
