@@ -221,8 +221,8 @@ class text2embedding_model(nn.Module):
     def forward(self, in_text, in_lengths, in_audio, poses, GPT3_embeddings, vid_indices):
         if not in_text.is_cuda:
             raise RuntimeError("text2embedding_model runs on the MI355X kernels only (no CPU fallback)")
-        if vid_indices is not None:
-            raise NotImplementedError("the vid_indices inference branch (:685-692) is outside the accelerated path")
+        if vid_indices is not None and self.training:
+            raise NotImplementedError("vid_indices is the reference's inference branch (:685-692): call it in eval mode")
         dev = in_text.device
         ids = in_text.transpose(0, 1).contiguous()                 # (Tw,B)
         cod = poses.transpose(0, 1).contiguous().to(torch.int64)   # (S,B)
@@ -253,6 +253,12 @@ class text2embedding_model(nn.Module):
         outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
         dec_in = cod[0]
         attentions_list = []
+        if vid_indices is not None:
+            # inference (:685-692): one extra step fed with vid_indices; its logits replace outputs[0], its argmax is fed on
+            logits, hidden, _ = self.decoder(None, vid_indices.to(torch.int64).contiguous(), hidden, enc_out, vid_indices,
+                                             keep_emb=None, keep_l0=None, enc_proj=enc_proj)
+            outs[0] = logits
+            dec_in = ops.argmax_rows(logits.detach().contiguous())
         for t in range(1, S_model):                                                    # :701-744
             ke = mask_emb[t - 1].contiguous() if training else None
             kl = mask_l0[t - 1].contiguous() if (training and mask_l0 is not None) else None

@@ -428,7 +428,7 @@ def attn_weights(h_top: Tensor, enc_out: Tensor, w_attn: Tensor, b_attn: Tensor,
 
 
 def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tensor, cfg: dict, training: bool,
-                masks: dict) -> Dict[str, Tensor]:
+                masks: dict, vid_indices: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """text2embedding_model.forward, discrete codes, EncoderRNN path
     (model/text2embedding_model.py:606-746; encoder :126-135; attention :160-198; decoder step :338-395).
 
@@ -440,7 +440,9 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
     Without attention the decoder reads only encoder_hidden[:L] = layer-0 final states (:667-669), so the encoder's
     inter-layer dropout cannot influence any output and is not modelled.  With attention the decoder also reads
     encoder_outputs = sum of the LAST layer's two directions (:133-135).
-    Returns outputs (B,S,K) with outputs[:,0] = one_hot(codes[:,0]) (:676-677)."""
+    Returns outputs (B,S,K) with outputs[:,0] = one_hot(codes[:,0]) (:676-677).
+    vid_indices (B,) int64 (the reference's inference branch, :685-692; eval mode here): one extra decode step fed with
+    vid_indices runs first, its logits replace outputs[:,0] and its argmax is the next input."""
     L, p = cfg["n_layers"], cfg["dropout_prob"]
     att = bool(cfg.get("att", False))
     x = sd["encoder.embedding.weight"][ids.t()]                                           # (Tw,B,300)  :126
@@ -462,7 +464,12 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
     outs = [torch.nn.functional.one_hot(cod[0], K).to(x.dtype)]
     dec_in = cod[0]
     attn_list = []
-    for t in range(1, S):                                                                 # :701-744
+    if vid_indices is not None and training:
+        raise NotImplementedError("vid_indices is the inference branch: eval mode only in the oracle")
+    steps = ([0] if vid_indices is not None else []) + list(range(1, S))
+    for t in steps:                                                                       # :685-692, :701-744
+        if t == 0:
+            dec_in = vid_indices
         e = sd[pre + "embedding.weight"][dec_in]                                          # :340-343
         if training:
             e = dropout_apply(e, masks["emb"][t - 1], 0.5)                                # nn.Dropout(0.5) :253
@@ -489,6 +496,10 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
                 layer_in = dropout_apply(h, masks["dec_l0"][t - 1], p)
         hidden = torch.stack(new_h)
         logits = linear(new_h[-1], sd[pre + "out.weight"], sd[pre + "out.bias"])         # :390
+        if t == 0:
+            outs[0] = logits                                                              # :690
+            dec_in = logits.argmax(1)                                                     # :691
+            continue
         outs.append(logits)
         dec_in = cod[t] if t < cfg["n_pre_poses"] else logits.argmax(1)                   # :734-744
     return {"outputs": torch.stack(outs).transpose(0, 1), "bn": bn, "encoder_hidden": enc_hidden,

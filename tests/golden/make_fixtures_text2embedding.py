@@ -91,6 +91,12 @@ def main():
         with torch.no_grad():
             out, _ = net(ids, lengths, None, codes, None, None)
         fx["eval/outputs"] = out.numpy().copy()
+        # the inference branch (:685-692): one extra decode step fed with vid_indices produces outputs[0]
+        vid = torch.randint(0, K, (B,), generator=torch.Generator().manual_seed(99))
+        with torch.no_grad():
+            out_v, _ = net(ids, lengths, None, codes, None, vid)
+        fx["eval_vid/vid_indices"] = vid.numpy()
+        fx["eval_vid/outputs"] = out_v.numpy().copy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **fx)
         print(name, "losses", [float(fx[f"s{s}/loss"]) for s in (1, 2)],
               "grad keys", sum(k.startswith("s1/grad/") for k in fx), "none", [k for k in fx if k.startswith("s1/gradnone/")])

@@ -75,6 +75,16 @@ def test_text2embedding_matches_reference_golden(golden_dir, name, att):
     assert relerr(out, fx["eval/outputs"]) < 1e-4
     # greedy codes of the eval rollout are exactly the reference's
     assert np.array_equal(out[:, 1:].argmax(2).cpu().numpy(), fx["eval/outputs"][:, 1:].argmax(2))
+    # the inference branch (:685-692): an extra first step fed with vid_indices fills outputs[:, 0]
+    vid = torch.from_numpy(fx["eval_vid/vid_indices"].copy()).to(DEV)
+    with torch.no_grad():
+        out_v, _ = net(ids, lengths, None, codes, None, vid)
+    assert relerr(out_v, fx["eval_vid/outputs"]) < 1e-4
+    assert np.array_equal(out_v.argmax(2).cpu().numpy(), fx["eval_vid/outputs"].argmax(2))
+    net.train(True)
+    with pytest.raises(NotImplementedError):
+        net(ids, lengths, None, codes, None, vid)
+    net.train(False)
 
 
 def test_attention_op_matches_torch_reference():

@@ -221,6 +221,9 @@ def test_text2embedding_matches_reference(golden_dir, name, att):
         r = O.t2e_forward(sd, ids, lengths, codes, cfg, False, {})
     # eval runs on the post-Adam weights, which carry the 0.02 * n_steps * lr rounding allowance checked above
     np.testing.assert_allclose(r["outputs"].numpy(), fx["eval/outputs"], rtol=1e-4, atol=2e-5)
+    with torch.no_grad():       # the inference branch (:685-692)
+        rv = O.t2e_forward(sd, ids, lengths, codes, cfg, False, {}, vid_indices=torch.from_numpy(fx["eval_vid/vid_indices"].copy()))
+    np.testing.assert_allclose(rv["outputs"].numpy(), fx["eval_vid/outputs"], rtol=1e-4, atol=2e-5)
 
 
 def test_vq_gssoft_matches_reference(golden_dir):
