@@ -449,14 +449,15 @@ class VQVAEEngine:
 
     # ------------------------------------------------------------------ one fused train iteration
     def train_step(self, x: torch.Tensor, target: torch.Tensor, *, lr: float, w_l1: float, w_cont: float,
-                   w_var: float, epoch: int = 1, draw_masks: bool = True, reduce_fn=None, world: int = 1):
+                   w_var: float, epoch: int = 1, draw_masks: bool = True, reduce_fn=None, world: int = 1,
+                   betas=(0.5, 0.999), eps: float = 1e-8, max_norm: float = 5.0):
         """train_iter_Autoencoder_VQ_seq2seq (train_eval/train_seq2seq.py:664-758) without host syncs.
         reduce_fn(comm) performs the data-parallel SUM all-reduce (RCCL) of [grads | EMA stats] when world > 1."""
         dp = reduce_fn is not None and world > 1
         self.train_step_local(x, target, w_l1=w_l1, w_cont=w_cont, w_var=w_var, epoch=epoch, draw_masks=draw_masks, dp=dp)
         if dp:
             reduce_fn(self.comm)
-        self.train_step_apply(x.shape[0], lr=lr, world=world, dp=dp)
+        self.train_step_apply(x.shape[0], lr=lr, world=world, dp=dp, betas=betas, eps=eps, max_norm=max_norm)
 
     # The two halves around the data-parallel exchange.  Each is a fixed kernel sequence with no host sync, so each can
     # be captured in its own hipGraph; the RCCL all-reduce of `comm` runs between the two replays.
@@ -471,8 +472,9 @@ class VQVAEEngine:
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)
 
-    def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False):
+    def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),
+                         eps: float = 1e-8, max_norm: float = 5.0):
         """(after the all-reduce) EMA codebook update from the GLOBAL statistics, then clip + Adam on the averaged grads."""
         if dp:
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
-        self.optimizer_step(lr, grad_scale=1.0 / world if dp else 1.0)
+        self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0)

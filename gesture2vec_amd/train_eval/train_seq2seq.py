@@ -77,6 +77,9 @@ def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tenso
     """One training iteration of the chunk VQ-VAE; same signature / return value as the reference."""
     if not isinstance(optim, FusedClipAdam):
         raise TypeError("use gesture2vec_amd.train_eval.train_seq2seq.FusedClipAdam (clip + Adam are one fused HIP launch)")
+    if getattr(net, "quantizer", "ema") == "ema" and optim.net is net and net.training:
+        # the whole iteration as ONE kernel sequence of the engine (no autograd graph, one host sync for loss.item())
+        return _fused_iteration(args, epoch, input_poses, target_poses, net, optim, None, 1)
     optim.zero_grad()
     vq_start_epoch = 0
     outputs, _, loss_vq, perplexity_vq = net(input_poses, target_poses, epoch > vq_start_epoch)
@@ -96,15 +99,22 @@ def train_iter_Autoencoder_VQ_seq2seq_dp(args, epoch: int, input_poses: torch.Te
     (gesture2vec_amd/dp.py).  Returns this rank's loss and the perplexity of the global code histogram."""
     if not isinstance(optim, FusedClipAdam):
         raise TypeError("use gesture2vec_amd.train_eval.train_seq2seq.FusedClipAdam")
+    return _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_fn, world)
+
+
+def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_fn, world):
+    """masks -> forward -> custom_loss + loss_vq / 400 -> backward -> [all-reduce] -> EMA update -> clip + Adam through
+    VQVAEEngine.train_step; loss = custom_loss + loss_vq / 400 for epoch > 0 (:707,738)."""
     eng = net.engine()
-    if getattr(net, "_explicit_masks", False):
-        draw = False
-    else:
-        draw = True
-    eng.train_step(input_poses.contiguous(), target_poses.contiguous(), lr=optim.lr, w_l1=float(args.loss_l1_weight),
-                   w_cont=float(args.loss_cont_weight), w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=draw,
-                   reduce_fn=reduce_fn, world=world)
-    loss = eng.loss_terms[0].item() + (eng.vq_scalars[0].item() / 400 if epoch > 0 else 0.0)
+    x, tgt = input_poses.contiguous(), target_poses.contiguous()
+    kw = dict(lr=optim.lr, w_l1=float(args.loss_l1_weight), w_cont=float(args.loss_cont_weight),
+              w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=not getattr(net, "_explicit_masks", False),
+              betas=optim.betas, eps=optim.eps, max_norm=optim.max_norm)
+    # (replaying this from a hipGraph was measured: 2.56 -> 2.53 ms per iteration at B=4096 - the host is not the limit)
+    eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)
+    net.decoder.decoder.pre_linear[1].num_batches_tracked += net.n_frames - 1       # one BatchNorm call per decode step
+    both = torch.stack((eng.loss_terms[0], eng.vq_scalars[0])).tolist()            # the iteration's one host sync
+    loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
     return {"loss": loss}, eng.vq_scalars[1].detach().clone()
 
 
