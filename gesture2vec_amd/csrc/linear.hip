@@ -43,41 +43,55 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 #pragma unroll
   for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int c0 = 0; c0 < C; c0 += BC) {
-    // ---- stage A tile [64][32]: consecutive threads along c (contiguous) ----
-    {
-      const int c = tid & 31;
+  // Software pipeline: the global loads of chunk c+1 are issued (into registers) right after chunk c has been written to LDS,
+  // so their L2 / HBM round trip runs under the MFMAs of chunk c instead of in front of them.
+  float ra[8], rb[8];
+  const int lc = tid & 31, lr = tid >> 5;             // A (and non-transposed B): 32 consecutive threads along c
+  const int tr = tid & 63, tc = tid >> 6;             // transposed B: 64 consecutive threads along n
+  int64_t arow[8];
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int r = (tid >> 5) + 8 * it;
-        const int m = m0 + r, cc = c0 + c;
-        float v = 0.f;
-        if (m < M && cc < C) {
-          v = A[row_off(am, m) + cc];
-          if (keep) v = keep[(int64_t)m * C + cc] ? v * scale : 0.f;
-        }
-        As[r * LDT + c] = v;
+  for (int it = 0; it < 8; ++it) {
+    const int m = m0 + lr + 8 * it;
+    arow[it] = m < M ? row_off(am, m) : -1;
+  }
+  auto fetch = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = m0 + lr + 8 * it, cc = c0 + lc;
+      float v = 0.f;
+      if (arow[it] >= 0 && cc < C) {
+        v = A[arow[it] + cc];
+        if (keep) v = keep[(int64_t)m * C + cc] ? v * scale : 0.f;
       }
+      ra[it] = v;
     }
-    // ---- stage B tile [64 n][32 c] ----
     if (!TRANS_B) {
-      const int c = tid & 31;
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int r = (tid >> 5) + 8 * it;
-        const int n = n0 + r, cc = c0 + c;
-        Bs[r * LDT + c] = (n < N && cc < C) ? Bm[(int64_t)n * ldb + cc] : 0.f;
+        const int n = n0 + lr + 8 * it, cc = c0 + lc;
+        rb[it] = (n < N && cc < C) ? Bm[(int64_t)n * ldb + cc] : 0.f;
       }
     } else {
-      const int r = tid & 63;  // n (contiguous in memory)
 #pragma unroll
       for (int it = 0; it < 8; ++it) {
-        const int c = (tid >> 6) + 4 * it;
-        const int n = n0 + r, cc = c0 + c;
-        Bs[r * LDT + c] = (n < N && cc < C) ? Bm[(int64_t)cc * ldb + n] : 0.f;
+        const int n = n0 + tr, cc = c0 + tc + 4 * it;
+        rb[it] = (n < N && cc < C) ? Bm[(int64_t)cc * ldb + n] : 0.f;
       }
     }
+  };
+  fetch(0);
+  for (int c0 = 0; c0 < C; c0 += BC) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) As[(lr + 8 * it) * LDT + lc] = ra[it];
+    if (!TRANS_B) {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) Bs[(lr + 8 * it) * LDT + lc] = rb[it];
+    } else {
+#pragma unroll
+      for (int it = 0; it < 8; ++it) Bs[tr * LDT + tc + 4 * it] = rb[it];
+    }
     __syncthreads();
+    if (c0 + BC < C) fetch(c0 + BC);
 #pragma unroll
     for (int k0 = 0; k0 < BC; k0 += 16) {
       const float4 xb = *reinterpret_cast<const float4*>(&As[(16 * wave + i) * LDT + k0 + 4 * q]);
