@@ -13,11 +13,11 @@
 
 namespace g2v {
 
-__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restrict__ gi, const float* __restrict__ w_hh,
-                                                          const float* __restrict__ b_hh, const float* __restrict__ h0,
-                                                          const int32_t* __restrict__ lengths, int reverse,
-                                                          float* __restrict__ hs, int64_t hs_ld, float* __restrict__ h_n,
-                                                          float* __restrict__ gates, int T, int B, int H) {
+__device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                 const float* __restrict__ b_hh, const float* __restrict__ h0,
+                                                 const int32_t* __restrict__ lengths, int reverse,
+                                                 float* __restrict__ hs, int64_t hs_ld, float* __restrict__ h_n,
+                                                 float* __restrict__ gates, int T, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Hp = (H + 15) & ~15, ldx = Hp + 4;
   float* hbuf0 = smem;
@@ -125,16 +125,28 @@ __global__ __launch_bounds__(256) void gru_seq_fwd_kernel(const float* __restric
     }
 }
 
+// Generic hidden size: one workgroup per 16 batch rows walks all T steps; BOTH directions of a bidirectional layer run in
+// one launch (blockIdx.y): at small batch a direction has only B/16 workgroups, so two launches in a row would leave the
+// chip idle twice as long.
+struct GruGenF {
+  const float* gi; const float* w_hh; const float* b_hh; const float* h0; float* hs; float* h_n; float* gates; int reverse;
+};
+__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths,
+                                                          int64_t hs_ld, int T, int B, int H) {
+  const GruGenF d = blockIdx.y == 0 ? d0 : d1;
+  gru_seq_fwd_body(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
+}
+
 // BPTT.  w_hh_t = W_hh^T, (H, 3H) row-major (so that dh_prev = dgh W_hh is again "weights contiguous along
 // the contraction").  LDS: Gs [16][3H padded] (dgh tile = MFMA B operand), dhs [16][H padded] (carry).
-__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restrict__ d_hs, int64_t d_hs_ld,
-                                                          const float* __restrict__ d_hn, const float* __restrict__ hs,
-                                                          int64_t hs_ld, const float* __restrict__ h0,
-                                                          const float* __restrict__ gates,
-                                                          const float* __restrict__ w_hh_t,
-                                                          const int32_t* __restrict__ lengths, int reverse,
-                                                          float* __restrict__ dgi, float* __restrict__ dgh,
-                                                          float* __restrict__ dh0, int T, int B, int H) {
+__device__ __forceinline__ void gru_seq_bwd_body(const float* __restrict__ d_hs, int64_t d_hs_ld,
+                                                 const float* __restrict__ d_hn, const float* __restrict__ hs,
+                                                 int64_t hs_ld, const float* __restrict__ h0,
+                                                 const float* __restrict__ gates,
+                                                 const float* __restrict__ w_hh_t,
+                                                 const int32_t* __restrict__ lengths, int reverse,
+                                                 float* __restrict__ dgi, float* __restrict__ dgh,
+                                                 float* __restrict__ dh0, int T, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Hp = (H + 15) & ~15, G = 3 * H, Gp = (G + 15) & ~15, ldg = Gp + 4, ldh = Hp + 4;
   float* Gs = smem;              // [16][ldg]
@@ -204,6 +216,16 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(const float* __restric
       const int r = e / H, k = e - r * H;
       if (r < nrows) dh0[(int64_t)(b0 + r) * H + k] = dhs[r * ldh + k];
     }
+}
+
+struct GruGenB {
+  const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* w_hh_t;
+  float* dgi; float* dgh; float* dh0; int reverse;
+};
+__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
+                                                          int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
+  const GruGenB d = blockIdx.y == 0 ? d0 : d1;
+  gru_seq_bwd_body(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
 }
 
 
@@ -569,10 +591,11 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  for (int k = 0; k < ndir; ++k) {
-    hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, st, dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh,
-                       dirs[k].h0, lengths, dirs[k].reverse, dirs[k].hs, hs_ld, dirs[k].h_n, dirs[k].gates, T, B, H);
-  }
+  GruGenF g[2];
+  for (int k = 0; k < ndir; ++k)
+    g[k] = GruGenF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+  if (ndir == 1) g[1] = g[0];
+  hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -639,13 +662,15 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  GruGenB g[2];
   for (int k = 0; k < ndir; ++k) {
     float* wt = p + (size_t)k * 3 * H * H;
     launch_transpose(dirs[k].w_hh, wt, 3 * H, H, st);  // (3H,H) -> (H,3H)
-    hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16)), dim3(256), lds, st, dirs[k].d_hs, d_hs_ld, dirs[k].d_hn,
-                       dirs[k].hs, hs_ld, dirs[k].h0, dirs[k].gates, wt, lengths, dirs[k].reverse, dirs[k].dgi, dirs[k].dgh,
-                       dirs[k].dh0, T, B, H);
+    g[k] = GruGenB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, wt, dirs[k].dgi, dirs[k].dgh,
+                   dirs[k].dh0, dirs[k].reverse};
   }
+  if (ndir == 1) g[1] = g[0];
+  hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -155,6 +155,60 @@ class GRUDirFn(torch.autograd.Function):
         return dgi, dw, db, (dh0 if ctx.has_h0 else None), None, None
 
 
+class GRUBiDirFn(torch.autograd.Function):
+    """Both directions of one bidirectional GRU layer in ONE launch each way (at small batch a direction fills only B/16
+    workgroups, so one launch per direction leaves the chip idle twice as long).  Inputs: the two input projections
+    gi_f / gi_b (T,B,3H) and the recurrent weights; returns (hs_f, hn_f, hs_b, hn_b)."""
+
+    @staticmethod
+    def forward(ctx, gi_f, gi_b, w_f, b_f, w_b, b_b, lengths):
+        T, B, G = gi_f.shape
+        H = G // 3
+        dev = gi_f.device
+        gi_f, gi_b, w_f, w_b = gi_f.contiguous(), gi_b.contiguous(), w_f.contiguous(), w_b.contiguous()
+        out = []
+        dirs = []
+        for gi, w, b, rev in ((gi_f, w_f, b_f, False), (gi_b, w_b, b_b, True)):
+            hs = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
+            gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
+            dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev))
+            out += [hs, h_n]
+        ops.gru_dirs_fwd(dirs, T, B, H, lengths=lengths, hs_ld=H)
+        ctx.save_for_backward(dirs[0]["hs"], dirs[0]["gates"], w_f, dirs[1]["hs"], dirs[1]["gates"], w_b, lengths)
+        ctx.dims = (T, B, H)
+        ctx.set_materialize_grads(False)
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, g_hs_f, g_hn_f, g_hs_b, g_hn_b):
+        hs_f, gates_f, w_f, hs_b, gates_b, w_b, lengths = ctx.saved_tensors
+        T, B, H = ctx.dims
+        if all(g is None for g in (g_hs_f, g_hn_f, g_hs_b, g_hn_b)):
+            return (None,) * 7
+        dev = hs_f.device
+        dirs, outs = [], []
+        for g_hs, g_hn, hs, gates, w, rev in ((g_hs_f, g_hn_f, hs_f, gates_f, w_f, False), (g_hs_b, g_hn_b, hs_b, gates_b, w_b, True)):
+            d_hs = g_hs.contiguous() if g_hs is not None else None
+            d_hn = g_hn.contiguous() if g_hn is not None else None
+            if d_hs is None and d_hn is None:
+                d_hn = torch.zeros((B, H), dtype=torch.float32, device=dev)
+            dgi = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+            dgh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+            dirs.append(dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w, dgi=dgi, dgh=dgh, dh0=None, reverse=rev))
+            outs.append((dgi, dgh))
+        ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H)
+        zero = torch.zeros((1, B, H), dtype=torch.float32, device=dev)
+        hprev_f = torch.cat([zero, hs_f[:-1]], 0).contiguous()          # data movement only
+        hprev_b = torch.cat([hs_b[1:], zero], 0).contiguous()
+        items = []
+        for (dgi, dgh), hprev in zip(outs, (hprev_f, hprev_b)):
+            items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
+                          torch.empty((3 * H,), dtype=torch.float32, device=dev)))
+        ops.linear_bwd_weight_batch(items, 3 * H, H, M=T * B)
+        return outs[0][0], outs[1][0], items[0][2], items[0][3], items[1][2], items[1][3], None
+
+
 class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, targets):

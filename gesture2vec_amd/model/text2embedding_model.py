@@ -64,16 +64,14 @@ class EncoderRNN(nn.Module):
         out_f = out_b = None
         keep, scale = None, 1.0
         for l in range(L):
-            outs = []
-            for suf, rev in (("", False), ("_reverse", True)):
-                g = self.gru
-                gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
-                               keep=keep, scale=scale)
-                hs, h_n = Fn.GRUDirFn.apply(gi.view(Tw, B, 3 * H), getattr(g, f"weight_hh_l{l}{suf}"),
-                                            getattr(g, f"bias_hh_l{l}{suf}"), None, lengths, rev)
-                outs.append(hs)
-                hiddens.append(h_n)
-            out_f, out_b = outs
+            g = self.gru
+            gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
+                             keep=keep, scale=scale).view(Tw, B, 3 * H) for suf in ("", "_reverse")]
+            # both directions of the layer in one launch (each way)
+            out_f, hn_f, out_b, hn_b = Fn.GRUBiDirFn.apply(
+                gis[0], gis[1], getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"),
+                getattr(g, f"weight_hh_l{l}_reverse"), getattr(g, f"bias_hh_l{l}_reverse"), lengths)
+            hiddens += [hn_f, hn_b]
             if l + 1 < L:
                 cat = torch.cat([out_f, out_b], dim=2).view(Tw * B, 2 * H)       # layout only
                 layer_in = cat
