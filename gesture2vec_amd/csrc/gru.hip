@@ -229,6 +229,219 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1
 }
 
 
+// ---- small batch, generic hidden size: ONE LAUNCH PER TIME STEP, one wave per (16 rows, 16 hidden units, direction) -------
+// The persistent kernels above give a direction only B/16 workgroups, each re-streaming the whole W_hh (3H x H) per step:
+// at B = 128, H = 200 that is 8 busy CUs and ~32 us per step.  A hidden unit's new state needs only ITS three gate rows of
+// W_hh, so a step splits over hidden-unit tiles without any cross-workgroup reduction, and the kernel boundary is the step
+// barrier.  Each wave requests EVERYTHING it needs for the step up front (its W_hh rows and the 16 state rows over the whole
+// contraction, as MFMA fragments in registers: one memory round trip), multiplies, and finishes its 16 x 16 outputs.
+// Used when B/16 * ndir <= 64 workgroups, H % 4 == 0, H <= 256.
+constexpr int GRU_STEP_KS = 16;        // k-steps of the forward product (H <= 256)
+constexpr int GRU_STEP_KSB = 48;       // k-steps of the backward product (3H <= 768)
+
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+struct GruStepF {
+  const float* gi;      // (T,B,3H)
+  const float* w_hh; const float* b_hh;
+  const float* h_prev;  // (B,H) carried state entering the step, NULL = zeros
+  float* h_next;        // (B,H) carried state leaving it
+  float* hs; float* gates; float* h_n;   // outputs as in gru_seq_fwd_body; h_n only on the last step
+  int t;
+};
+__global__ __launch_bounds__(64) void gru_step_fwd_kernel(GruStepF d0, GruStepF d1, const int32_t* __restrict__ lengths,
+                                                          int64_t hs_ld, int T, int B, int H, int last) {
+  const GruStepF d = blockIdx.z == 0 ? d0 : d1;
+  const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y, t = d.t;
+  const int nrows = min(16, B - b0);
+  const int nks = (H + 15) >> 4;
+  const bool wrow_ok = 16 * ft + i < H, xrow_ok = (i < nrows) && d.h_prev != nullptr;
+  const float* wr = d.w_hh + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * H;
+  const float* xr = d.h_prev ? d.h_prev + (int64_t)(b0 + (i < nrows ? i : 0)) * H : d.w_hh;
+  // ---- every load of the step, issued back to back -----------------------------------------------------------------
+  float4 wa[3][GRU_STEP_KS], xb[GRU_STEP_KS];
+#pragma unroll
+  for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wa[g][ks] = ld4_or_zero(wr + (int64_t)g * H * H + (kok ? k : 0), kok && wrow_ok);
+    xb[ks] = ld4_or_zero(xr + (kok ? k : 0), kok && xrow_ok);
+  }
+  const int b = b0 + i, f0 = 16 * ft + 4 * q;          // the lane's outputs: batch row i, hidden units f0 .. f0 + 3
+  const bool rvalid = i < nrows, fvec = f0 + 3 < H;
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  const bool valid = rvalid && (t < len);
+  const int64_t row = (int64_t)t * B + (rvalid ? b : b0);
+  const float* gir = d.gi + row * 3 * H;
+  float4 gi4[3], bh4[3], hp4;
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    gi4[g] = ld4_or_zero(gir + g * H + (fvec ? f0 : 0), fvec && valid);
+    bh4[g] = ld4_or_zero(d.b_hh + g * H + (fvec ? f0 : 0), fvec);
+  }
+  hp4 = ld4_or_zero(d.h_prev ? d.h_prev + (int64_t)(rvalid ? b : b0) * H + (fvec ? f0 : 0) : d.w_hh, fvec && rvalid && d.h_prev);
+  // ---- products ---------------------------------------------------------------------------------------------------------
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+    if (ks < nks) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        acc[g] = mfma16(wa[g][ks].x, xb[ks].x, acc[g]);
+        acc[g] = mfma16(wa[g][ks].y, xb[ks].y, acc[g]);
+        acc[g] = mfma16(wa[g][ks].z, xb[ks].z, acc[g]);
+        acc[g] = mfma16(wa[g][ks].w, xb[ks].w, acc[g]);
+      }
+    }
+  }
+  if (!rvalid || f0 >= H) return;
+  // H % 4 == 0 (checked by the launcher): f0 + 3 < H whenever f0 < H
+  const float gir_[3][4] = {{gi4[0].x, gi4[0].y, gi4[0].z, gi4[0].w}, {gi4[1].x, gi4[1].y, gi4[1].z, gi4[1].w},
+                            {gi4[2].x, gi4[2].y, gi4[2].z, gi4[2].w}};
+  const float bh_[3][4] = {{bh4[0].x, bh4[0].y, bh4[0].z, bh4[0].w}, {bh4[1].x, bh4[1].y, bh4[1].z, bh4[1].w},
+                           {bh4[2].x, bh4[2].y, bh4[2].z, bh4[2].w}};
+  const float hp_[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  float hn[4], gr[4], gz[4], gn[4], gh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    hn[r] = hp_[r]; gr[r] = gz[r] = gn[r] = gh[r] = 0.f;
+    if (valid) {
+      gr[r] = sigmoidf_(gir_[0][r] + (acc[0][r] + bh_[0][r]));
+      gz[r] = sigmoidf_(gir_[1][r] + (acc[1][r] + bh_[1][r]));
+      gh[r] = acc[2][r] + bh_[2][r];
+      gn[r] = tanhf_(gir_[2][r] + gr[r] * gh[r]);
+      hn[r] = (1.0f - gz[r]) * gn[r] + gz[r] * hp_[r];
+    }
+  }
+  *reinterpret_cast<float4*>(d.h_next + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  float* ho = d.hs + row * hs_ld + f0;                  // hs_ld may be unaligned: scalar stores
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ho[r] = valid ? hn[r] : 0.f;       // padded positions of the output are zero
+  if (d.gates) {
+    float* go = d.gates + row * 4 * H + f0;
+    *reinterpret_cast<float4*>(go) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+    *reinterpret_cast<float4*>(go + H) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+    *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn[0], gn[1], gn[2], gn[3]);
+    *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+  }
+  if (last && d.h_n) *reinterpret_cast<float4*>(d.h_n + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+}
+
+// Backward: launch `it` (0 .. T) of a direction does, for its (16 rows, 16 hidden units):
+//   part A (it > 0): dh = carry + dgh[t_cur] W_hh restricted to its hidden units (t_cur = the step whose gate gradients the
+//                    PREVIOUS launch wrote: all 3H columns, by all the tile workgroups -> the kernel boundary is the barrier)
+//   part B (it < T): the gate gradients of the next step for its hidden units from that dh (element-wise, local), written
+//                    to dgi / dgh, and carry = dh * z for the following launch.
+// The carry is read and written only by the workgroup that owns the tile: one (B,H) buffer, no ping-pong.
+struct GruStepB {
+  const float* d_hs; const float* hs; const float* h0; const float* gates; const float* w_hh_t; const float* d_hn;
+  float* carry;           // (B,H)
+  float* dgi; float* dgh; float* dh0;
+  int t_cur, t_next, tprev_next;   // t_cur: step of part A (-1: none); t_next: step of part B (-1: none); tprev_next: where
+};                                 // h_prev of step t_next lives in hs (-1: the initial state)
+__global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB d1, const int32_t* __restrict__ lengths,
+                                                          int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
+  const GruStepB d = blockIdx.z == 0 ? d0 : d1;
+  const int G = 3 * H;
+  const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0), f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;                              // H % 4 == 0: whole float4 or nothing
+  float dh[4] = {0.f, 0.f, 0.f, 0.f};
+  // ---- loads of part B that do not depend on part A, requested first ---------------------------------------------------
+  const int tn = d.t_next;
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  const bool act = tn >= 0 && rvalid && fok && tn < len;
+  const int64_t rown = (int64_t)(tn >= 0 ? tn : 0) * B + b;
+  float4 g4[4], hp4, dhs4;
+  {
+    const float* go = d.gates + rown * 4 * H + (fok ? f0 : 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) g4[g] = ld4_or_zero(go + g * H, act);
+    const bool from_hs = act && d.tprev_next >= 0 && d.tprev_next < len;
+    const float* hpp = from_hs ? d.hs + ((int64_t)d.tprev_next * B + b) * hs_ld + f0
+                               : (d.h0 ? d.h0 + (int64_t)b * H + (fok ? f0 : 0) : d.gates);
+    if (from_hs) hp4 = make_float4(hpp[0], hpp[1], hpp[2], hpp[3]);        // hs_ld may be unaligned
+    else hp4 = ld4_or_zero(hpp, act && d.h0 != nullptr);
+    const float* dp = d.d_hs ? d.d_hs + rown * d_hs_ld + f0 : d.gates;
+    dhs4 = (act && d.d_hs) ? make_float4(dp[0], dp[1], dp[2], dp[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  if (d.t_cur >= 0) {
+    // ---- part A ---------------------------------------------------------------------------------------------------------
+    const int nks = (G + 15) >> 4;
+    const bool wrow_ok = 16 * ft + i < H;
+    const float* wr = d.w_hh_t + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * G;
+    const float* xr = d.dgh + ((int64_t)d.t_cur * B + b) * G;
+    float4 wa[GRU_STEP_KSB], xb[GRU_STEP_KSB];
+#pragma unroll
+    for (int ks = 0; ks < GRU_STEP_KSB; ++ks) {
+      const int k = 16 * ks + 4 * q;
+      const bool kok = ks < nks && k < G;
+      wa[ks] = ld4_or_zero(wr + (kok ? k : 0), kok && wrow_ok);
+      xb[ks] = ld4_or_zero(xr + (kok ? k : 0), kok && rvalid);
+    }
+    const float4 c4 = ld4_or_zero(d.carry + (int64_t)b * H + (fok ? f0 : 0), rvalid && fok);
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < GRU_STEP_KSB; ++ks) {
+      if (ks < nks) {
+        acc = mfma16(wa[ks].x, xb[ks].x, acc);
+        acc = mfma16(wa[ks].y, xb[ks].y, acc);
+        acc = mfma16(wa[ks].z, xb[ks].z, acc);
+        acc = mfma16(wa[ks].w, xb[ks].w, acc);
+      }
+    }
+    dh[0] = c4.x + acc[0]; dh[1] = c4.y + acc[1]; dh[2] = c4.z + acc[2]; dh[3] = c4.w + acc[3];
+  } else if (d.d_hn) {
+    const float4 v = ld4_or_zero(d.d_hn + (int64_t)b * H + (fok ? f0 : 0), rvalid && fok);
+    dh[0] = v.x; dh[1] = v.y; dh[2] = v.z; dh[3] = v.w;
+  }
+  if (!rvalid || !fok) return;
+  if (tn < 0) {                                          // after the last step: the gradient of the initial state
+    if (d.dh0) *reinterpret_cast<float4*>(d.dh0 + (int64_t)b * H + f0) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+    return;
+  }
+  // ---- part B -----------------------------------------------------------------------------------------------------------
+  const float rr_[4] = {g4[0].x, g4[0].y, g4[0].z, g4[0].w}, zz_[4] = {g4[1].x, g4[1].y, g4[1].z, g4[1].w};
+  const float nn_[4] = {g4[2].x, g4[2].y, g4[2].z, g4[2].w}, gh_[4] = {g4[3].x, g4[3].y, g4[3].z, g4[3].w};
+  const float hp_[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, dd_[4] = {dhs4.x, dhs4.y, dhs4.z, dhs4.w};
+  float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    g_r[r] = g_z[r] = g_n[r] = g_hn[r] = 0.f;
+    direct[r] = dh[r];
+    if (act) {
+      const float dht = dh[r] + dd_[r];
+      const float dn = dht * (1.0f - zz_[r]);
+      const float dz = dht * (hp_[r] - nn_[r]);
+      const float dnp = dn * (1.0f - nn_[r] * nn_[r]);
+      g_n[r] = dnp;
+      g_hn[r] = dnp * rr_[r];
+      g_r[r] = dnp * gh_[r] * rr_[r] * (1.0f - rr_[r]);
+      g_z[r] = dz * zz_[r] * (1.0f - zz_[r]);
+      direct[r] = dht * zz_[r];
+    }
+  }
+  float* gi_o = d.dgi + rown * G + f0;
+  float* gh_o = d.dgh + rown * G + f0;
+  *reinterpret_cast<float4*>(gi_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+  *reinterpret_cast<float4*>(gi_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+  *reinterpret_cast<float4*>(gi_o + 2 * H) = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]);
+  *reinterpret_cast<float4*>(gh_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+  *reinterpret_cast<float4*>(gh_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+  *reinterpret_cast<float4*>(gh_o + 2 * H) = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+  *reinterpret_cast<float4*>(d.carry + (int64_t)b * H + f0) = make_float4(direct[0], direct[1], direct[2], direct[3]);
+}
+
+
 // =====================================================================================================
 // Fast path, H == 64 (the BASELINE shape): dims are compile-time, each wave owns ONE 16-feature tile whose
 // W_hh fragments (3 gates x 4 k-steps x float4 = 48 VGPRs) stay in registers for the whole sequence, the gi
@@ -536,8 +749,18 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
 using namespace g2v;
 
 static bool gru_fast_ok(int H, int64_t hs_ld) { return H == 64 && (hs_ld & 3) == 0; }
+// per-time-step launches (gru_step_*_kernel) while a direction would otherwise get only a handful of workgroups
+constexpr int GRU_SPLIT_MAX_B = 512;
+static bool gru_split_ok(int B, int ndir, int H) {
+  return B <= GRU_SPLIT_MAX_B && cdiv(B, 16) * ndir <= 64 && (H & 3) == 0 && H <= 16 * GRU_STEP_KS && 3 * H <= 16 * GRU_STEP_KSB;
+}
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 * GRU_SPLIT_MAX_B * H; }
 
-extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) { return (size_t)2 * ndir * pack_floats(H, 3, H) * sizeof(float); }
+extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
+  const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H), b = gru_split_state_floats(ndir, H);
+  return (a > b ? a : b) * sizeof(float);
+}
 
 extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
                                int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
@@ -587,6 +810,32 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
     return G2V_OK;
   }
   const int Hp = (H + 15) & ~15;
+  bool split = gru_split_ok(B, ndir, H);
+  for (int k = 0; k < ndir && split; ++k)
+    split = aligned16(dirs[k].gi) && aligned16(dirs[k].w_hh) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].h0) &&
+            aligned16(dirs[k].gates) && aligned16(dirs[k].h_n) && aligned16(workspace);
+  if (split) {
+    // small batch: one launch per time step, (row groups x hidden-unit tiles x directions) single-wave workgroups
+    if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
+      set_error("g2v_gru_seq_fwd: workspace too small");
+      return G2V_ERR_WORKSPACE;
+    }
+    float* state = (float*)workspace;                  // [dir][2][B][H]
+    for (int s_ = 0; s_ < T; ++s_) {
+      GruStepF g[2];
+      for (int k = 0; k < ndir; ++k) {
+        float* cur = state + ((size_t)k * 2 + (s_ & 1)) * B * H;
+        float* nxt = state + ((size_t)k * 2 + ((s_ + 1) & 1)) * B * H;
+        g[k] = GruStepF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, s_ == 0 ? dirs[k].h0 : cur, nxt, dirs[k].hs, dirs[k].gates,
+                        dirs[k].h_n, dirs[k].reverse ? T - 1 - s_ : s_};
+      }
+      if (ndir == 1) g[1] = g[0];
+      hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(cdiv(B, 16), Hp >> 4, ndir), dim3(64), 0, st, g[0], g[1], lengths, hs_ld,
+                         T, B, H, s_ == T - 1 ? 1 : 0);
+    }
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   const size_t lds = (size_t)2 * 16 * (Hp + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
@@ -601,7 +850,7 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
 }
 
 extern "C" size_t g2v_gru_seq_bwd_workspace(int ndir, int H) {
-  const size_t a = (size_t)2 * ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H;
+  const size_t a = (size_t)2 * ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H + gru_split_state_floats(ndir, H);
   return (a > b ? a : b) * sizeof(float);
 }
 
@@ -662,6 +911,34 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  bool split = gru_split_ok(B, ndir, H) && aligned16(workspace);
+  for (int k = 0; k < ndir && split; ++k)
+    split = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].d_hn) &&
+            aligned16(dirs[k].h0) && aligned16(dirs[k].dh0);
+  if (split) {
+    const int Hp = (H + 15) & ~15;
+    float* carry = p + (size_t)ndir * 3 * H * H;      // [dir][B][H], after the transposed weights (3 H^2 floats: 16-byte multiple)
+    for (int k = 0; k < ndir; ++k) launch_transpose(dirs[k].w_hh, p + (size_t)k * 3 * H * H, 3 * H, H, st);
+    // launch `it`: part A finishes the step of forward iteration T - it, part B opens forward iteration T - 1 - it
+    for (int it = 0; it <= T; ++it) {
+      GruStepB g[2];
+      for (int k = 0; k < ndir; ++k) {
+        const bool rev = dirs[k].reverse != 0;
+        const int s_cur = T - it, s_next = T - 1 - it;
+        const int t_cur = it == 0 ? -1 : (rev ? T - 1 - s_cur : s_cur);
+        const int t_next = s_next < 0 ? -1 : (rev ? T - 1 - s_next : s_next);
+        const int tprev = (s_next <= 0) ? -1 : (rev ? t_next + 1 : t_next - 1);
+        g[k] = GruStepB{dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, p + (size_t)k * 3 * H * H, dirs[k].d_hn,
+                        carry + (size_t)k * B * H, dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, t_cur, t_next, tprev};
+      }
+      if (ndir == 1) g[1] = g[0];
+      if (it == T && !dirs[0].dh0 && (ndir == 1 || !dirs[1].dh0)) break;      // nobody wants the initial-state gradient
+      hipLaunchKernelGGL(gru_step_bwd_kernel, dim3(cdiv(B, 16), Hp >> 4, ndir), dim3(64), 0, st, g[0], g[1], lengths,
+                         d_hs_ld, hs_ld, T, B, H);
+    }
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   GruGenB g[2];
   for (int k = 0; k < ndir; ++k) {
     float* wt = p + (size_t)k * 3 * H * H;

@@ -198,7 +198,7 @@ def test_vq_bwd(ops):
 
 
 # ----------------------------------------------------------------------------------------------- GRU direction
-@pytest.mark.parametrize("T,B,H", [(34, 32, 64), (20, 8, 50), (5, 19, 200), (12, 37, 64)])
+@pytest.mark.parametrize("T,B,H", [(34, 32, 64), (20, 8, 50), (5, 19, 200), (12, 37, 64), (4, 530, 50)])
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("use_len", [False, True])
 def test_gru_seq(ops, T, B, H, reverse, use_len):
