@@ -375,6 +375,11 @@ __device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS
   });
 }
 
+// predicated 16-byte load (the address is not touched when !ok)
+__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
+  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
 __device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
 __device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
 

@@ -1083,6 +1083,306 @@ static size_t pack_bwd_total(int D, int H) {
 
 extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return pack_fwd_total(D, H) * sizeof(float); }
 
+// ====================================================================================================================
+// Small batch, generic dims: the forward step t >= 1 as THREE launches over (16 rows x 16 hidden units) workgroups.
+// dec_step_fwd_kernel gives a step only B/16 workgroups, each walking all of the step's ~16 k MFMAs (H = 200) on one CU:
+// 95 us per step at B = 128 with 8 of 256 CUs busy.  A GRU cell's hidden unit needs only its own rows of W_ih / W_hh, and
+// a pre_linear feature only its own row of W_pre, so the step splits over 16-unit tiles; what does need a whole row of the
+// previous stage (the cell inputs, the out layer) makes a launch boundary:
+//   dec_cell_split_kernel<true>  : [finish BN(u_t)] a_t = ReLU(BN(u_t)), GRU cell 0 for the tile  -> h0_t, gates0, x1
+//   dec_cell_split_kernel<false> : GRU cell 1 for the tile                                         -> h1_t, gates1
+//   dec_out_pre_split_kernel     : y_t = out_layer(h1_t) (recomputed by every tile workgroup: <= 4 D tiles), Dropout(0.95),
+//                                  u_{t+1} tile = pre_linear(xin_{t+1}) + the BN partial sums of the tile
+// Operands are requested up front as MFMA fragments in registers (one memory round trip per launch); the y accumulators of
+// the out layer ARE the B fragments of the pre_linear product (same lane <-> (row, 4 consecutive columns) mapping).
+// Writes exactly the arrays dec_step_fwd_kernel writes, so the backward is unchanged.  H % 4 == 0, H <= 256, D <= 64.
+// ====================================================================================================================
+constexpr int DSPLIT_KS = 16;       // k-steps over H (H <= 256)
+constexpr int DSPLIT_DT = 4;        // D tiles (D <= 64)
+
+struct DecCellArgs {
+  const float* x;         // (B,H) rows of the cell input (u_t for the BN variant)
+  const float* h_prev;    // (B,H)
+  const float* w_ih; const float* w_hh; const float* b_ih; const float* b_hh;   // (3H,H) row-major, (3H)
+  float* h_out;           // (B,H)
+  float* gates;           // (B,4H) or NULL
+  const uint8_t* keep;    // (B,H) inter-layer dropout keep flags or NULL
+  float keep_scale;
+  float* xdrop_out;       // (B,H) or NULL
+  // BN variant only
+  const float* bn_partial;   // (nblk, 2H) sums of (u - b), (u - b)^2 of this step
+  const float* b_pre; const float* bn_w; const float* bn_b; const float* run_mean; const float* run_var;
+  float* a_out;           // (B,H) or NULL
+  float* bn_stats;        // (2H) mean / biased var of this step (training) or NULL
+  int nblk, training;
+};
+
+template <bool BN>
+__global__ __launch_bounds__(128) void dec_cell_split_kernel(DecCellArgs a, int B, int H) {
+  __shared__ float st[2 * 16 * DSPLIT_KS];            // mean[H], invstd[H] (BN variant)
+  __shared__ __attribute__((aligned(16))) float4 xch[3 * 64];   // h-side accumulators handed to the x-side wave
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int nks = (H + 15) >> 4;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  // ---- this wave's operands: wave 0 = input side (W_ih, x), wave 1 = hidden side (W_hh, h_prev) -------------------------
+  const float* W = (wave == 0 ? a.w_ih : a.w_hh) + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * H;
+  const float* X = (wave == 0 ? a.x : a.h_prev) + (int64_t)b * H;
+  float4 wa[3][DSPLIT_KS], xb[DSPLIT_KS];
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wa[g][ks] = ld4_or_zero(W + (int64_t)g * H * H + (kok ? k : 0), kok && wrow_ok);
+    xb[ks] = ld4_or_zero(X + (kok ? k : 0), kok && rvalid);
+  }
+  // epilogue inputs of the x-side wave (4 hidden units f0 .. f0 + 3 of batch row i)
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  float4 bi[3], bh[3], hp4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  uint32_t kp = 0x01010101u;
+  if (wave == 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      bi[g] = ld4_or_zero(a.b_ih + g * H + (fok ? f0 : 0), fok);
+      bh[g] = ld4_or_zero(a.b_hh + g * H + (fok ? f0 : 0), fok);
+    }
+    hp4 = ld4_or_zero(a.h_prev + (int64_t)b * H + (fok ? f0 : 0), fok && rvalid);
+    if (a.keep && fok && rvalid) kp = *reinterpret_cast<const uint32_t*>(a.keep + (int64_t)b * H + f0);
+  }
+  if constexpr (BN) {
+    // ---- BatchNorm statistics of the step for every feature (each workgroup needs the whole input row) -----------------
+    for (int f = tid; f < H; f += 128) {
+      float mean, var;
+      if (a.training) {
+        float s1 = 0.f, s2 = 0.f;
+        for (int k = 0; k < a.nblk; ++k) {
+          s1 += a.bn_partial[(int64_t)k * 2 * H + f];
+          s2 += a.bn_partial[(int64_t)k * 2 * H + H + f];
+        }
+        const float mv = s1 / (float)B;
+        var = fmaxf(s2 / (float)B - mv * mv, 0.f);     // biased batch variance
+        mean = mv + a.b_pre[f];
+        if (a.bn_stats && blockIdx.x == 0 && blockIdx.y == 0) {
+          a.bn_stats[f] = mean;
+          a.bn_stats[H + f] = var;
+        }
+      } else {
+        mean = a.run_mean[f];
+        var = a.run_var[f];
+      }
+      st[f] = mean;
+      st[16 * DSPLIT_KS + f] = 1.0f / sqrtf(var + 1e-5f);
+    }
+    __syncthreads();
+    if (wave == 0) {
+      // a_t = ReLU(BN(u_t)) on the fragments; the workgroup's own 16 columns (k-step ft) are the ones it writes out
+#pragma unroll
+      for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+        const int k = 16 * ks + 4 * q;
+        if (ks < nks && k < H) {
+          const float4 g4 = *reinterpret_cast<const float4*>(a.bn_w + k), b4 = *reinterpret_cast<const float4*>(a.bn_b + k);
+          const float4 m4 = *reinterpret_cast<const float4*>(st + k), i4 = *reinterpret_cast<const float4*>(st + 16 * DSPLIT_KS + k);
+          float4 v = xb[ks];
+          v.x = fmaxf((v.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+          v.y = fmaxf((v.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+          v.z = fmaxf((v.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+          v.w = fmaxf((v.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+          xb[ks] = rvalid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ks == ft && a.a_out && rvalid) *reinterpret_cast<float4*>(a.a_out + (int64_t)b * H + k) = v;
+        }
+      }
+    }
+  }
+  // ---- products -----------------------------------------------------------------------------------------------------------
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    if (ks < nks) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        acc[g] = mfma16(wa[g][ks].x, xb[ks].x, acc[g]);
+        acc[g] = mfma16(wa[g][ks].y, xb[ks].y, acc[g]);
+        acc[g] = mfma16(wa[g][ks].z, xb[ks].z, acc[g]);
+        acc[g] = mfma16(wa[g][ks].w, xb[ks].w, acc[g]);
+      }
+    }
+  }
+  if (wave == 1) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) xch[g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+  }
+  __syncthreads();
+  if (wave != 0 || !rvalid || !fok) return;
+  // ---- GRU cell epilogue (same arithmetic order as gru_cell_fwd_epilogue) -------------------------------------------------
+  float ah[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float4 v = xch[g * 64 + lane];
+    ah[g][0] = v.x; ah[g][1] = v.y; ah[g][2] = v.z; ah[g][3] = v.w;
+  }
+  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
+              bin[4] = {bi[2].x, bi[2].y, bi[2].z, bi[2].w};
+  const float bhr[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bhz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+              bhn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+  float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float rr = sigmoidf_((acc[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+    const float zz = sigmoidf_((acc[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+    const float ghn = ah[2][r] + bhn[r];
+    const float nn = tanhf_((acc[2][r] + bin[r]) + rr * ghn);
+    hn[r] = (1.0f - zz) * nn + zz * hp[r];
+    xd[r] = a.keep ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * a.keep_scale : 0.f) : hn[r];
+    gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+  }
+  *reinterpret_cast<float4*>(a.h_out + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  if (a.xdrop_out) *reinterpret_cast<float4*>(a.xdrop_out + (int64_t)b * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+  if (a.gates) {
+    float* go = a.gates + (int64_t)b * 4 * H + f0;
+    *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+    *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+    *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+    *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+  }
+}
+
+struct DecOutPreArgs {
+  const float* h1;        // (B,H) h1_t
+  const float* w_out; const float* b_out;   // (D,H), (D)
+  const float* w_pre; const float* b_pre;   // (H,D), (H)
+  const float* target;    // (B,T,D)
+  const uint8_t* keep95;  // (B,D) flags of xin_{t+1} (index t of the (T-1,B,D) array)
+  float* y;               // (B,D) y_t
+  float* xin;             // (B,D) xin_{t+1} or NULL
+  float* u_next;          // (B,H) u_{t+1}
+  float* part;            // (nblk, 2H) BN partial sums of u_{t+1}
+  int t, T, has_next, teacher, conditioned;
+};
+
+__global__ __launch_bounds__(64) void dec_out_pre_split_kernel(DecOutPreArgs a, int B, int D, int H) {
+  const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int nks = (H + 15) >> 4, ndt = (D + 15) >> 4;
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0);
+  // ---- every load of the launch -------------------------------------------------------------------------------------------
+  float4 wo[DSPLIT_DT][DSPLIT_KS], xb[DSPLIT_KS];
+  const float* X = a.h1 + (int64_t)b * H;
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < H;
+    xb[ks] = ld4_or_zero(X + (kok ? k : 0), kok && rvalid);
+#pragma unroll
+    for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+      const int d = 16 * dt + i;
+      const bool dok = dt < ndt && d < D;
+      wo[dt][ks] = ld4_or_zero(a.w_out + (int64_t)(dok ? d : 0) * H + (kok ? k : 0), kok && dok);
+    }
+  }
+  // lane (i, q) ends up with y[row i][16 dt + 4 q + r]: bias, target and keep flags of exactly those elements
+  float bo[DSPLIT_DT][4], tg[DSPLIT_DT][4];
+  uint8_t kp[DSPLIT_DT][4];
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * dt + 4 * q + r;
+      const bool ok = dt < ndt && d < D && rvalid;
+      bo[dt][r] = ok ? a.b_out[d] : 0.f;
+      tg[dt][r] = (ok && a.has_next && a.teacher) ? a.target[((int64_t)b * a.T + a.t) * D + d] : 0.f;
+      kp[dt][r] = (ok && a.has_next && a.conditioned) ? a.keep95[(int64_t)b * D + d] : 0;
+    }
+  // pre_linear fragments of this workgroup's 16 features: W_pre[16 ft + i][d], d along k (row stride D: scalar loads)
+  float4 wp[DSPLIT_DT];
+  const bool prow_ok = 16 * ft + i < H;
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int d = 16 * dt + 4 * q + e;
+      v[e] = (a.has_next && prow_ok && dt < ndt && d < D) ? a.w_pre[(int64_t)(16 * ft + i) * D + d] : 0.f;
+    }
+    wp[dt] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  const float4 bp = ld4_or_zero(a.b_pre + (fok ? f0 : 0), fok && a.has_next);
+  // ---- y_t = out_layer(h1_t) ----------------------------------------------------------------------------------------------
+  f32x4 ya[DSPLIT_DT];
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt) ya[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    if (ks < nks) {
+#pragma unroll
+      for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+        if (dt < ndt) {
+          ya[dt] = mfma16(wo[dt][ks].x, xb[ks].x, ya[dt]);
+          ya[dt] = mfma16(wo[dt][ks].y, xb[ks].y, ya[dt]);
+          ya[dt] = mfma16(wo[dt][ks].z, xb[ks].z, ya[dt]);
+          ya[dt] = mfma16(wo[dt][ks].w, xb[ks].w, ya[dt]);
+        }
+      }
+    }
+  }
+  // y, the next decoder input xin = Dropout(0.95)(teacher ? target : y) (zeros when !conditioned), kept as MFMA B fragments
+  float4 xf[DSPLIT_DT];
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+    float xv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * dt + 4 * q + r;
+      const float y = ya[dt][r] + bo[dt][r];
+      const float src = a.teacher ? tg[dt][r] : y;                                  // :1049-1052
+      xv[r] = kp[dt][r] ? src * 20.0f : 0.f;                                         // Dropout(0.95): 1/(1-0.95)
+      if (ft == 0 && rvalid && dt < ndt && d < D) {
+        a.y[(int64_t)b * D + d] = y;
+        if (a.has_next && a.xin) a.xin[(int64_t)b * D + d] = xv[r];
+      }
+    }
+    xf[dt] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+  }
+  if (!a.has_next) return;
+  // ---- u_{t+1} tile = pre_linear.0(xin_{t+1}) and the BN partial sums of (u - b) over this workgroup's rows -------------------
+  f32x4 ua = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+    if (dt < ndt) {
+      ua = mfma16(wp[dt].x, xf[dt].x, ua);
+      ua = mfma16(wp[dt].y, xf[dt].y, ua);
+      ua = mfma16(wp[dt].z, xf[dt].z, ua);
+      ua = mfma16(wp[dt].w, xf[dt].w, ua);
+    }
+  }
+  float s1[4], s2[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = (rvalid && fok) ? ua[r] : 0.f;
+    s1[r] = reduce16(v);
+    s2[r] = reduce16(v * v);
+  }
+  if (!fok) return;
+  if (rvalid)
+    *reinterpret_cast<float4*>(a.u_next + (int64_t)b * H + f0) = make_float4(ua[0] + bp.x, ua[1] + bp.y, ua[2] + bp.z, ua[3] + bp.w);
+  if (i == 0) {
+    float* part = a.part + (int64_t)blockIdx.x * 2 * H;
+    *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  }
+}
+
 extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,
                                    const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
                                    int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
@@ -1121,13 +1421,49 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
     (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
+  auto al16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+  // small batch, generic dims: steps t >= 1 as three launches over (rows x 16-unit tiles) workgroups (see the kernels)
+  const bool split = !fast && dm.nblk <= 32 && (H & 3) == 0 && H <= 16 * DSPLIT_KS && D <= 16 * DSPLIT_DT &&
+                     al16(s->u) && al16(s->h0) && al16(s->h1) && al16(s->a) && al16(s->x1) && al16(s->gates0) &&
+                     al16(s->gates1) && al16(s->bn_partial) && al16(w->w_ih0) && al16(w->w_hh0) && al16(w->w_ih1) &&
+                     al16(w->w_hh1) && al16(w->w_out) && al16(w->b_ih0) && al16(w->b_hh0) && al16(w->b_ih1) && al16(w->b_hh1) &&
+                     al16(w->b_pre) && al16(w->bn_w) && al16(w->bn_b);
   for (int t = 0; t < T; ++t) {
-    if (fast)
+    if (fast) {
       hipLaunchKernelGGL((dec_step_fwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
-    else
+    } else if (!split || t == 0) {
       hipLaunchKernelGGL((dec_step_fwd_kernel<0, 0>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
+    } else {
+      const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
+      const bool drop = training && keep_l0 && p_drop > 0.f;
+      const dim3 grid(dm.nblk, (H + 15) >> 4);
+      DecCellArgs c0{};
+      c0.x = s->u + (t - 1) * BH; c0.h_prev = s->h0 + (t - 1) * BH;
+      c0.w_ih = w->w_ih0; c0.w_hh = w->w_hh0; c0.b_ih = w->b_ih0; c0.b_hh = w->b_hh0;
+      c0.h_out = s->h0 + t * BH; c0.gates = s->gates0 ? s->gates0 + (t - 1) * 4 * BH : nullptr;
+      c0.keep = drop ? keep_l0 + (t - 1) * BH : nullptr; c0.keep_scale = 1.0f / (1.0f - p_drop);
+      c0.xdrop_out = (drop && s->x1) ? s->x1 + (t - 1) * BH : nullptr;
+      c0.bn_partial = s->bn_partial + (int64_t)((t - 1) & 1) * dm.nblk * 2 * H;
+      c0.b_pre = w->b_pre; c0.bn_w = w->bn_w; c0.bn_b = w->bn_b; c0.run_mean = w->bn_running_mean; c0.run_var = w->bn_running_var;
+      c0.a_out = s->a ? s->a + (t - 1) * BH : nullptr;
+      c0.bn_stats = (training && s->bn_stats) ? s->bn_stats + (int64_t)(t - 1) * 2 * H : nullptr;
+      c0.nblk = dm.nblk; c0.training = training;
+      hipLaunchKernelGGL(dec_cell_split_kernel<true>, grid, dim3(128), 0, st, c0, B, H);
+      DecCellArgs c1{};
+      c1.x = (drop && s->x1) ? s->x1 + (t - 1) * BH : s->h0 + t * BH; c1.h_prev = s->h1 + (t - 1) * BH;
+      c1.w_ih = w->w_ih1; c1.w_hh = w->w_hh1; c1.b_ih = w->b_ih1; c1.b_hh = w->b_hh1;
+      c1.h_out = s->h1 + t * BH; c1.gates = s->gates1 ? s->gates1 + (t - 1) * 4 * BH : nullptr;
+      c1.keep = nullptr; c1.keep_scale = 1.0f; c1.xdrop_out = nullptr;
+      hipLaunchKernelGGL(dec_cell_split_kernel<false>, grid, dim3(128), 0, st, c1, B, H);
+      DecOutPreArgs o{};
+      o.h1 = s->h1 + t * BH; o.w_out = w->w_out; o.b_out = w->b_out; o.w_pre = w->w_pre; o.b_pre = w->b_pre;
+      o.target = target; o.keep95 = keep95 + t * BD; o.y = s->y + t * BD; o.xin = s->xin ? s->xin + t * BD : nullptr;
+      o.u_next = s->u + t * BH; o.part = s->bn_partial + (int64_t)(t & 1) * dm.nblk * 2 * H;
+      o.t = t; o.T = T; o.has_next = t < T - 1 ? 1 : 0; o.teacher = (t < T - 1 && t < n_pre_poses) ? 1 : 0; o.conditioned = conditioned;
+      hipLaunchKernelGGL(dec_out_pre_split_kernel, grid, dim3(64), 0, st, o, B, D, H);
+    }
   }
   G2V_CHECK_LAUNCH();
   if (training) {

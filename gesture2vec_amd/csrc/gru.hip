@@ -239,10 +239,6 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1
 constexpr int GRU_STEP_KS = 16;        // k-steps of the forward product (H <= 256)
 constexpr int GRU_STEP_KSB = 48;       // k-steps of the backward product (3H <= 768)
 
-__device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
-  return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
-}
-
 struct GruStepF {
   const float* gi;      // (T,B,3H)
   const float* w_hh; const float* b_hh;
