@@ -289,7 +289,8 @@ def _alloc_saved(T, B, D, H, nblk, dev, p):
             "gates1": z(T - 1, B, 4 * H), "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H)}
 
 
-@pytest.mark.parametrize("T,B,D,H,p", [(34, 32, 135, 64, 0.0), (20, 8, 40, 50, 0.2), (6, 37, 135, 64, 0.3), (3, 16, 40, 200, 0.0)])
+@pytest.mark.parametrize("T,B,D,H,p", [(34, 32, 135, 64, 0.0), (20, 8, 40, 50, 0.2), (6, 37, 135, 64, 0.3), (3, 16, 40, 200, 0.0),
+                                       (5, 37, 45, 200, 0.2), (4, 600, 40, 48, 0.1), (4, 130, 64, 256, 0.0)])
 def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
     sd = _dec_state(D, H, seed=5)
     g = torch.Generator().manual_seed(77)
@@ -344,8 +345,8 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
             relclose(db, g_ref[pre + bname], 3e-4, bname)
 
 
-def test_dec_rollout_eval_mode(ops):
-    T, B, D, H = 10, 20, 135, 64
+@pytest.mark.parametrize("T,B,D,H", [(10, 20, 135, 64), (6, 20, 40, 200)])      # fused step kernel / per-phase split kernels
+def test_dec_rollout_eval_mode(ops, T, B, D, H):
     sd = _dec_state(D, H, seed=9)
     g = torch.Generator().manual_seed(78)
     sd["decoder.decoder.pre_linear.1.running_mean"] = torch.randn(H, generator=g) * 0.1
