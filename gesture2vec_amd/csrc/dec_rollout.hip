@@ -1383,6 +1383,271 @@ __global__ __launch_bounds__(64) void dec_out_pre_split_kernel(DecOutPreArgs a, 
   }
 }
 
+// ---- backward of the same split: step t as up to four launches (the seams are where a product contracts over a whole
+// row of gate gradients that every tile workgroup of the previous launch contributed to) ------------------------------------
+//   dec_bwd_dy_split_kernel    (rows x D tiles): finish BN-backward of step t+1 -> du_{t+1}; dy_t += keep95 * 20 * (du W_pre)
+//   dec_bwd_cell1_split_kernel (rows x H tiles): dh1 = carry1 + dy_t W_out; GRU cell 1 gate gradients of the tile
+//   dec_bwd_pair_split_kernel<false>           : carry1' = dh1 z + dgh1 W_hh1 | dh0 = drop(dgi1 W_ih1) + carry0; cell 0 gates
+//   dec_bwd_pair_split_kernel<true>            : carry0' = dh0 z + dgh0 W_hh0 | da = dgi0 W_ih0 -> ReLU bwd -> dbn_t, BN sums
+// The transposed weights are plain row-major copies (output unit = row, contraction along the row).
+constexpr int DSPLIT_KSG = 48;      // k-steps over 3H (3H <= 768)
+
+struct DecBwdDyArgs {
+  const float* part;      // (nblk, 2H) BN-backward sums of step t+1
+  const float* stats;     // (2H) batch mean / var of step t+1
+  const float* u;         // (B,H) u_{t+1}
+  const float* dbn;       // (B,H) d(BN output) of step t+1
+  const float* bn_w;
+  float* du;              // (B,H) out: d u_{t+1}
+  float* d_bn_w; float* d_bn_b;   // (H) accumulated over the steps
+  const float* w_pre_t;   // (D,H) = W_pre^T
+  float* dy;              // (B,D) dy_t, updated in place with the feedback term
+  const uint8_t* keep95;  // (B,D)
+  int nblk, first_acc, feedback, only_a;
+};
+__global__ __launch_bounds__(64) void dec_bwd_dy_split_kernel(DecBwdDyArgs a, int B, int D, int H) {
+  __shared__ float st[2 * 16 * DSPLIT_KS];
+  const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, dt = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int nks = (H + 15) >> 4;
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0);
+  // weight fragments of this D tile and the row's inputs first (independent of the sums)
+  float4 wa[DSPLIT_KS], u4[DSPLIT_KS], g4[DSPLIT_KS];
+  const int drow = 16 * dt + i;
+  const bool dok = drow < D && a.feedback && !a.only_a;
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < H;
+    wa[ks] = ld4_or_zero(a.w_pre_t + (int64_t)(dok ? drow : 0) * H + (kok ? k : 0), kok && dok);
+    u4[ks] = ld4_or_zero(a.u + (int64_t)b * H + (kok ? k : 0), kok && rvalid);
+    g4[ks] = ld4_or_zero(a.dbn + (int64_t)b * H + (kok ? k : 0), kok && rvalid);
+  }
+  for (int f = lane; f < H; f += 64) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = 0; k < a.nblk; ++k) {
+      s1 += a.part[(int64_t)k * 2 * H + f];
+      s2 += a.part[(int64_t)k * 2 * H + H + f];
+    }
+    st[f] = s1;
+    st[16 * DSPLIT_KS + f] = s2;
+    if (blockIdx.x == 0 && blockIdx.y == 0) {      // d gamma / d beta accumulate over the steps (one writer, stream ordered)
+      a.d_bn_w[f] = (a.first_acc ? 0.f : a.d_bn_w[f]) + s2;
+      a.d_bn_b[f] = (a.first_acc ? 0.f : a.d_bn_b[f]) + s1;
+    }
+  }
+  __syncthreads();
+  const float invB = 1.0f / (float)B;
+  float4 xb[DSPLIT_KS];
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    xb[ks] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ks < nks && k < H) {
+      const float4 m4 = *reinterpret_cast<const float4*>(a.stats + k), v4 = *reinterpret_cast<const float4*>(a.stats + H + k);
+      const float4 w4 = *reinterpret_cast<const float4*>(a.bn_w + k);
+      const float4 s14 = *reinterpret_cast<const float4*>(st + k), s24 = *reinterpret_cast<const float4*>(st + 16 * DSPLIT_KS + k);
+      const float uu[4] = {u4[ks].x, u4[ks].y, u4[ks].z, u4[ks].w}, db[4] = {g4[ks].x, g4[ks].y, g4[ks].z, g4[ks].w};
+      const float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, gg[4] = {w4.x, w4.y, w4.z, w4.w};
+      const float a1[4] = {s14.x, s14.y, s14.z, s14.w}, a2[4] = {s24.x, s24.y, s24.z, s24.w};
+      float du[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float xhat = (uu[r] - mm[r]) * invstd;
+        du[r] = rvalid ? gg[r] * invstd * (db[r] - a1[r] * invB - xhat * a2[r] * invB) : 0.f;
+      }
+      xb[ks] = make_float4(du[0], du[1], du[2], du[3]);
+      if (dt == 0 && rvalid) *reinterpret_cast<float4*>(a.du + (int64_t)b * H + k) = xb[ks];
+    }
+  }
+  if (a.only_a || !a.feedback) return;              // without feedback dy_t is the loss gradient as it stands
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KS; ++ks) {
+    if (ks < nks) {
+      acc = mfma16(wa[ks].x, xb[ks].x, acc);
+      acc = mfma16(wa[ks].y, xb[ks].y, acc);
+      acc = mfma16(wa[ks].z, xb[ks].z, acc);
+      acc = mfma16(wa[ks].w, xb[ks].w, acc);
+    }
+  }
+  if (!rvalid) return;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int d = 16 * dt + 4 * q + r;
+    if (d < D && a.keep95[(int64_t)b * D + d]) a.dy[(int64_t)b * D + d] += acc[r] * 20.0f;
+  }
+}
+
+// gate gradients of one GRU cell for (row, 4 hidden units) held by a lane; returns dh * z (or dh for nothing: rows are valid)
+__device__ __forceinline__ void gru_cell_bwd_lane(const float (&dh)[4], const float* __restrict__ gates, const float* __restrict__ hprev,
+                                                  float* __restrict__ dgi, float* __restrict__ dgh, float* __restrict__ direct_out,
+                                                  int H, int f0) {
+  const float4 r4 = *reinterpret_cast<const float4*>(gates + f0), z4 = *reinterpret_cast<const float4*>(gates + H + f0),
+               n4 = *reinterpret_cast<const float4*>(gates + 2 * H + f0), h4 = *reinterpret_cast<const float4*>(gates + 3 * H + f0);
+  const float4 p4 = *reinterpret_cast<const float4*>(hprev + f0);
+  const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w},
+              gh[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {p4.x, p4.y, p4.z, p4.w};
+  float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float dn = dh[r] * (1.0f - zz[r]);
+    const float dz = dh[r] * (hp[r] - nn[r]);
+    const float dnp = dn * (1.0f - nn[r] * nn[r]);
+    g_n[r] = dnp;
+    g_hn[r] = dnp * rr[r];
+    g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+    g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+    direct[r] = dh[r] * zz[r];
+  }
+  const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+               vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+  *reinterpret_cast<float4*>(dgi + f0) = vr; *reinterpret_cast<float4*>(dgi + H + f0) = vz; *reinterpret_cast<float4*>(dgi + 2 * H + f0) = vn;
+  *reinterpret_cast<float4*>(dgh + f0) = vr; *reinterpret_cast<float4*>(dgh + H + f0) = vz; *reinterpret_cast<float4*>(dgh + 2 * H + f0) = vh;
+  *reinterpret_cast<float4*>(direct_out + f0) = make_float4(direct[0], direct[1], direct[2], direct[3]);
+}
+
+struct DecBwdCell1Args {
+  const float* dy;        // (B,D) dy_t
+  const float* w_out_t;   // (H,D) = W_out^T
+  const float* carry;     // (B,H) carry1 or NULL (last step)
+  const float* gates; const float* hprev;   // (B,4H), (B,H) of step t
+  float* dgi; float* dgh; // (B,3H)
+  float* direct;          // (B,H) scratch: dh1 * z
+};
+__global__ __launch_bounds__(64) void dec_bwd_cell1_split_kernel(DecBwdCell1Args a, int B, int D, int H) {
+  const int lane = threadIdx.x, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int ndt = (D + 15) >> 4;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_DT; ++ks) {
+    if (ks < ndt) {
+      float wv[4], xv[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = 16 * ks + 4 * q + e;
+        wv[e] = (d < D && wrow_ok) ? a.w_out_t[(int64_t)(16 * ft + i) * D + d] : 0.f;
+        xv[e] = (d < D && rvalid) ? a.dy[(int64_t)b * D + d] : 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = mfma16(wv[e], xv[e], acc);
+    }
+  }
+  const int f0 = 16 * ft + 4 * q;
+  if (!rvalid || f0 >= H) return;
+  float dh[4] = {acc[0], acc[1], acc[2], acc[3]};
+  if (a.carry) {
+    const float4 c4 = *reinterpret_cast<const float4*>(a.carry + (int64_t)b * H + f0);
+    dh[0] += c4.x; dh[1] += c4.y; dh[2] += c4.z; dh[3] += c4.w;
+  }
+  gru_cell_bwd_lane(dh, a.gates + (int64_t)b * 4 * H, a.hprev + (int64_t)b * H, a.dgi + (int64_t)b * 3 * H, a.dgh + (int64_t)b * 3 * H,
+                    a.direct + (int64_t)b * H, H, f0);
+}
+
+struct DecBwdPairArgs {
+  // wave 0: carry' = direct + dgh W_hh
+  const float* dgh; const float* w_hh_t;      // (B,3H), (H,3H)
+  const float* direct;                        // (B,H)
+  float* carry_out;                           // (B,H)
+  // wave 1: v = dgi W_ih, then the stage-specific epilogue
+  const float* dgi; const float* w_ih_t;
+  // BNSTAGE == false: GRU cell 0 backward
+  const uint8_t* keep; float keep_scale;      // inter-layer dropout of the forward (NULL: none)
+  const float* carry0;                        // (B,H) or NULL (last step)
+  const float* gates0; const float* hprev0;
+  float* dgi0; float* dgh0; float* direct0;
+  // BNSTAGE == true: ReLU backward + BN-backward sums
+  const float* a_act; const float* u; const float* stats;   // (B,H), (B,H), (2H)
+  float* dbn; float* part;                    // (B,H), (nblk, 2H)
+};
+template <bool BNSTAGE>
+__global__ __launch_bounds__(128) void dec_bwd_pair_split_kernel(DecBwdPairArgs a, int B, int H) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int G = 3 * H, nks = (G + 15) >> 4;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  const float* W = (wave == 0 ? a.w_hh_t : a.w_ih_t) + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * G;
+  const float* X = (wave == 0 ? a.dgh : a.dgi) + (int64_t)b * G;
+  float4 wa[DSPLIT_KSG], xb[DSPLIT_KSG];
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KSG; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < G;
+    wa[ks] = ld4_or_zero(W + (kok ? k : 0), kok && wrow_ok);
+    xb[ks] = ld4_or_zero(X + (kok ? k : 0), kok && rvalid);
+  }
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < DSPLIT_KSG; ++ks) {
+    if (ks < nks) {
+      acc = mfma16(wa[ks].x, xb[ks].x, acc);
+      acc = mfma16(wa[ks].y, xb[ks].y, acc);
+      acc = mfma16(wa[ks].z, xb[ks].z, acc);
+      acc = mfma16(wa[ks].w, xb[ks].w, acc);
+    }
+  }
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  if (wave == 0) {
+    if (rvalid && fok) {
+      const float4 d4 = *reinterpret_cast<const float4*>(a.direct + (int64_t)b * H + f0);
+      *reinterpret_cast<float4*>(a.carry_out + (int64_t)b * H + f0) = make_float4(d4.x + acc[0], d4.y + acc[1], d4.z + acc[2], d4.w + acc[3]);
+    }
+    return;
+  }
+  if constexpr (!BNSTAGE) {
+    if (!rvalid || !fok) return;
+    float dh[4] = {acc[0], acc[1], acc[2], acc[3]};
+    if (a.keep) {
+      const uint32_t kp = *reinterpret_cast<const uint32_t*>(a.keep + (int64_t)b * H + f0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = ((kp >> (8 * r)) & 0xffu) ? dh[r] * a.keep_scale : 0.f;
+    }
+    if (a.carry0) {
+      const float4 c4 = *reinterpret_cast<const float4*>(a.carry0 + (int64_t)b * H + f0);
+      dh[0] += c4.x; dh[1] += c4.y; dh[2] += c4.z; dh[3] += c4.w;
+    }
+    gru_cell_bwd_lane(dh, a.gates0 + (int64_t)b * 4 * H, a.hprev0 + (int64_t)b * H, a.dgi0 + (int64_t)b * G, a.dgh0 + (int64_t)b * G,
+                      a.direct0 + (int64_t)b * H, H, f0);
+  } else {
+    float dbn[4] = {0.f, 0.f, 0.f, 0.f}, s1[4], s2[4];
+    float dbx[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rvalid && fok) {
+      const float4 a4 = *reinterpret_cast<const float4*>(a.a_act + (int64_t)b * H + f0), u4 = *reinterpret_cast<const float4*>(a.u + (int64_t)b * H + f0);
+      const float4 m4 = *reinterpret_cast<const float4*>(a.stats + f0), v4 = *reinterpret_cast<const float4*>(a.stats + H + f0);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w},
+                  vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dbn[r] = av[r] > 0.f ? acc[r] : 0.f;
+        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        dbx[r] = dbn[r] * ((uv[r] - mv[r]) * invstd);
+      }
+      *reinterpret_cast<float4*>(a.dbn + (int64_t)b * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      s1[r] = reduce16(dbn[r]);
+      s2[r] = reduce16(dbx[r]);
+    }
+    if (i == 0 && fok) {
+      float* part = a.part + (int64_t)blockIdx.x * 2 * H;
+      *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+      *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    }
+  }
+}
+
 extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,
                                    const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
                                    int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
@@ -1474,7 +1739,12 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   return G2V_OK;
 }
 
-extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) { return pack_bwd_total(D, H) * sizeof(float); }
+// split path (small batch): six plain transposes + two (B <= 512, H) scratch arrays
+static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 512 * H; }
+extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
+  const size_t a = pack_bwd_total(D, H), b = split_bwd_total(D, H);
+  return (a > b ? a : b) * sizeof(float);
+}
 
 extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
                                    const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
@@ -1497,6 +1767,67 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
   }
   hipStream_t st = (hipStream_t)stream;
   float* p = (float*)workspace;
+  {
+    auto al16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+    const int nblk = cdiv(B, 16);
+    const bool split = !((H == 64) && (D == 135)) && nblk <= 32 && (H & 3) == 0 && H <= 16 * DSPLIT_KS && 3 * H <= 16 * DSPLIT_KSG &&
+                       D <= 16 * DSPLIT_DT && al16(workspace) && al16(s->u) && al16(s->a) && al16(s->h0) && al16(s->h1) &&
+                       al16(s->gates0) && al16(s->gates1) && al16(s->bn_stats) && al16(g->du) && al16(g->dbn) && al16(g->dgi0) &&
+                       al16(g->dgh0) && al16(g->dgi1) && al16(g->dgh1) && al16(g->dh_init) && al16(g->bn_bwd_partial) &&
+                       al16(w->bn_w);
+    if (split) {
+      const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D, BG = 3 * BH;
+      float* w_pre_t = p;                 p += (size_t)D * H;
+      float* w_out_t = p;                 p += (size_t)H * D;
+      float* w_hh1_t = p;                 p += (size_t)3 * H * H;
+      float* w_ih1_t = p;                 p += (size_t)3 * H * H;
+      float* w_hh0_t = p;                 p += (size_t)3 * H * H;
+      float* w_ih0_t = p;                 p += (size_t)3 * H * H;
+      float* direct1 = p;                 p += (size_t)BH;
+      float* direct0 = p;
+      launch_transpose(w->w_pre, w_pre_t, H, D, st);          // (H,D) -> (D,H)
+      launch_transpose(w->w_out, w_out_t, D, H, st);          // (D,H) -> (H,D)
+      launch_transpose(w->w_hh1, w_hh1_t, 3 * H, H, st);      // (3H,H) -> (H,3H)
+      launch_transpose(w->w_ih1, w_ih1_t, 3 * H, H, st);
+      launch_transpose(w->w_hh0, w_hh0_t, 3 * H, H, st);
+      launch_transpose(w->w_ih0, w_ih0_t, 3 * H, H, st);
+      const bool drop = keep_l0 && p_drop > 0.f;
+      const int nht = (H + 15) >> 4, ndt = (D + 15) >> 4;
+      for (int t = T - 1; t >= 0; --t) {
+        const bool last = (t == T - 1);
+        if (!last) {
+          DecBwdDyArgs a{};
+          a.part = g->bn_bwd_partial + (int64_t)((t + 1) & 1) * nblk * 2 * H;
+          a.stats = s->bn_stats + (int64_t)t * 2 * H; a.u = s->u + t * BH; a.dbn = g->dbn + t * BH; a.bn_w = w->bn_w;
+          a.du = g->du + t * BH; a.d_bn_w = g->d_bn_w; a.d_bn_b = g->d_bn_b; a.w_pre_t = w_pre_t;
+          a.dy = g->dy + t * BD; a.keep95 = keep95 + t * BD;
+          a.nblk = nblk; a.first_acc = (t == T - 2) ? 1 : 0; a.feedback = (conditioned && t >= n_pre_poses) ? 1 : 0; a.only_a = (t == 0) ? 1 : 0;
+          hipLaunchKernelGGL(dec_bwd_dy_split_kernel, dim3(nblk, (a.feedback && !a.only_a) ? ndt : 1), dim3(64), 0, st, a, B, D, H);
+        }
+        if (t == 0) break;
+        DecBwdCell1Args c{};
+        c.dy = g->dy + t * BD; c.w_out_t = w_out_t; c.carry = last ? nullptr : g->dh_init + BH;
+        c.gates = s->gates1 + (t - 1) * 4 * BH; c.hprev = s->h1 + (t - 1) * BH;
+        c.dgi = g->dgi1 + (t - 1) * BG; c.dgh = g->dgh1 + (t - 1) * BG; c.direct = direct1;
+        hipLaunchKernelGGL(dec_bwd_cell1_split_kernel, dim3(nblk, nht), dim3(64), 0, st, c, B, D, H);
+        DecBwdPairArgs e{};
+        e.dgh = g->dgh1 + (t - 1) * BG; e.w_hh_t = w_hh1_t; e.direct = direct1; e.carry_out = g->dh_init + BH;
+        e.dgi = g->dgi1 + (t - 1) * BG; e.w_ih_t = w_ih1_t;
+        e.keep = drop ? keep_l0 + (t - 1) * BH : nullptr; e.keep_scale = 1.0f / (1.0f - p_drop);
+        e.carry0 = last ? nullptr : g->dh_init; e.gates0 = s->gates0 + (t - 1) * 4 * BH; e.hprev0 = s->h0 + (t - 1) * BH;
+        e.dgi0 = g->dgi0 + (t - 1) * BG; e.dgh0 = g->dgh0 + (t - 1) * BG; e.direct0 = direct0;
+        hipLaunchKernelGGL(dec_bwd_pair_split_kernel<false>, dim3(nblk, nht), dim3(128), 0, st, e, B, H);
+        DecBwdPairArgs f{};
+        f.dgh = g->dgh0 + (t - 1) * BG; f.w_hh_t = w_hh0_t; f.direct = direct0; f.carry_out = g->dh_init;
+        f.dgi = g->dgi0 + (t - 1) * BG; f.w_ih_t = w_ih0_t;
+        f.a_act = s->a + (t - 1) * BH; f.u = s->u + (t - 1) * BH; f.stats = s->bn_stats + (int64_t)(t - 1) * 2 * H;
+        f.dbn = g->dbn + (t - 1) * BH; f.part = g->bn_bwd_partial + (int64_t)(t & 1) * nblk * 2 * H;
+        hipLaunchKernelGGL(dec_bwd_pair_split_kernel<true>, dim3(nblk, nht), dim3(128), 0, st, f, B, H);
+      }
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
+  }
   DecTW tw;
   PackBatch pb;
   pb.n = 6;
