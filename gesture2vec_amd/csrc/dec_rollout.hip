@@ -1098,6 +1098,7 @@ extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return pack_fwd_
 // Writes exactly the arrays dec_step_fwd_kernel writes, so the backward is unchanged.  H % 4 == 0, H <= 256, D <= 64.
 // ====================================================================================================================
 constexpr int DSPLIT_KS = 16;       // k-steps over H (H <= 256)
+constexpr int DSPLIT_MAX_NBLK = 64; // row groups (B <= 1024): beyond that the fused step kernels fill the chip on their own
 constexpr int DSPLIT_DT = 4;        // D tiles (D <= 64)
 
 struct DecCellArgs {
@@ -1688,7 +1689,8 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   }
   auto al16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
   // small batch, generic dims: steps t >= 1 as three launches over (rows x 16-unit tiles) workgroups (see the kernels)
-  const bool split = !fast && dm.nblk <= 32 && (H & 3) == 0 && H <= 16 * DSPLIT_KS && D <= 16 * DSPLIT_DT &&
+  // crossover measured at the VQ-VAE.yml dims: split 6.9 ms vs fused 9.2 ms per train step at B = 1024, 12.5 vs 11.1 at 2048
+  const bool split = !fast && dm.nblk <= DSPLIT_MAX_NBLK && (H & 3) == 0 && H <= 16 * DSPLIT_KS && D <= 16 * DSPLIT_DT &&
                      al16(s->u) && al16(s->h0) && al16(s->h1) && al16(s->a) && al16(s->x1) && al16(s->gates0) &&
                      al16(s->gates1) && al16(s->bn_partial) && al16(w->w_ih0) && al16(w->w_hh0) && al16(w->w_ih1) &&
                      al16(w->w_hh1) && al16(w->w_out) && al16(w->b_ih0) && al16(w->b_hh0) && al16(w->b_ih1) && al16(w->b_hh1) &&
@@ -1740,7 +1742,7 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
 }
 
 // split path (small batch): six plain transposes + two (B <= 512, H) scratch arrays
-static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 512 * H; }
+static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 16 * DSPLIT_MAX_NBLK * H; }
 extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   const size_t a = pack_bwd_total(D, H), b = split_bwd_total(D, H);
   return (a > b ? a : b) * sizeof(float);
@@ -1770,7 +1772,7 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
   {
     auto al16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
     const int nblk = cdiv(B, 16);
-    const bool split = !((H == 64) && (D == 135)) && nblk <= 32 && (H & 3) == 0 && H <= 16 * DSPLIT_KS && 3 * H <= 16 * DSPLIT_KSG &&
+    const bool split = !((H == 64) && (D == 135)) && nblk <= DSPLIT_MAX_NBLK && (H & 3) == 0 && H <= 16 * DSPLIT_KS && 3 * H <= 16 * DSPLIT_KSG &&
                        D <= 16 * DSPLIT_DT && al16(workspace) && al16(s->u) && al16(s->a) && al16(s->h0) && al16(s->h1) &&
                        al16(s->gates0) && al16(s->gates1) && al16(s->bn_stats) && al16(g->du) && al16(g->dbn) && al16(g->dgi0) &&
                        al16(g->dgh0) && al16(g->dgi1) && al16(g->dgh1) && al16(g->dh_init) && al16(g->bn_bwd_partial) &&
