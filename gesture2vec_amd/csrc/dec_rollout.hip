@@ -1101,6 +1101,23 @@ constexpr int DSPLIT_KS = 16;       // k-steps over H (H <= 256)
 constexpr int DSPLIT_MAX_NBLK = 64; // row groups (B <= 1024): beyond that the fused step kernels fill the chip on their own
 constexpr int DSPLIT_DT = 4;        // D tiles (D <= 64)
 
+// column f of the (nblk, 2H) per-row-group sums: eight row groups' loads in flight at a time, fixed summation order
+__device__ __forceinline__ void sum_partials(const float* __restrict__ part, int nblk, int H, int f, float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+  for (int k0 = 0; k0 < nblk; k0 += 8) {
+    float v1[8], v2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = k0 + j < nblk;
+      const float* p = part + (int64_t)(ok ? k0 + j : 0) * 2 * H;
+      v1[j] = ok ? p[f] : 0.f;
+      v2[j] = ok ? p[H + f] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { s1 += v1[j]; s2 += v2[j]; }
+  }
+}
+
 struct DecCellArgs {
   const float* x;         // (B,H) rows of the cell input (u_t for the BN variant)
   const float* h_prev;    // (B,H)
@@ -1160,11 +1177,8 @@ __global__ __launch_bounds__(128) void dec_cell_split_kernel(DecCellArgs a, int 
     for (int f = tid; f < H; f += 128) {
       float mean, var;
       if (a.training) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int k = 0; k < a.nblk; ++k) {
-          s1 += a.bn_partial[(int64_t)k * 2 * H + f];
-          s2 += a.bn_partial[(int64_t)k * 2 * H + H + f];
-        }
+        float s1, s2;
+        sum_partials(a.bn_partial, a.nblk, H, f, s1, s2);
         const float mv = s1 / (float)B;
         var = fmaxf(s2 / (float)B - mv * mv, 0.f);     // biased batch variance
         mean = mv + a.b_pre[f];
@@ -1427,11 +1441,8 @@ __global__ __launch_bounds__(64) void dec_bwd_dy_split_kernel(DecBwdDyArgs a, in
     g4[ks] = ld4_or_zero(a.dbn + (int64_t)b * H + (kok ? k : 0), kok && rvalid);
   }
   for (int f = lane; f < H; f += 64) {
-    float s1 = 0.f, s2 = 0.f;
-    for (int k = 0; k < a.nblk; ++k) {
-      s1 += a.part[(int64_t)k * 2 * H + f];
-      s2 += a.part[(int64_t)k * 2 * H + H + f];
-    }
+    float s1, s2;
+    sum_partials(a.part, a.nblk, H, f, s1, s2);
     st[f] = s1;
     st[16 * DSPLIT_KS + f] = s2;
     if (blockIdx.x == 0 && blockIdx.y == 0) {      // d gamma / d beta accumulate over the steps (one writer, stream ordered)
