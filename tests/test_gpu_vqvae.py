@@ -146,7 +146,8 @@ def _engine_from_state(sd, D, H, K, T, p, beta=0.25):
     return eng
 
 
-@pytest.mark.parametrize("B,T,D,H,K,p", [(256, 34, 135, 64, 512, 0.0), (48, 20, 40, 200, 512, 0.2), (37, 10, 45, 200, 400, 0.0)])
+@pytest.mark.parametrize("B,T,D,H,K,p", [(256, 34, 135, 64, 512, 0.0), (48, 20, 40, 200, 512, 0.2), (37, 10, 45, 200, 400, 0.0),
+                                         (1040, 4, 40, 48, 64, 0.1)])     # last: generic dims ABOVE the small-batch split thresholds
 def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
     """Engine.train_step (the path bench.py times) against the CPU oracle on seeded inputs, two steps."""
     sd = O.init_vqvae_state(D, H, 2, K, seed=3)
