@@ -494,7 +494,7 @@ struct TnBatch {
   float* slab_db[G2V_TN_BATCH];
 };
 
-template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR = 4>
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR = 4, bool GEN = false>
 __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, const RowMap& xm, int M, int K, int N,
                                              int rows_per_wave) {
   const float* __restrict__ dY = bt.dy[blockIdx.y];
@@ -509,7 +509,7 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   constexpr int NG = SN * SK;
   static_assert(NG == 2, "two tile groups per workgroup");
   static_assert(NR == 2 || NR == 4, "two or four row ranges per workgroup");
-  constexpr bool TRIPLE = !BF3;
+  constexpr bool TRIPLE = !BF3 && !GEN;          // (the 4 x 7 block of the output-blocked variant leaves room for two buffers)
   static_assert(VW == 1 || (VW == 2 && TN_ % 2 == 0 && TK_ % 2 == 0), "pairs of tiles per 8-byte load");
   // VW == 2 (8-byte-aligned rows, whole tiles): the 16 MFMA rows of a PAIR of tiles are interleaved over 32 columns,
   // lane i <-> columns 32 g + 2 i + {0, 1}, so one global_load_dwordx2 (a full 128-byte line per matrix row) feeds the
@@ -520,7 +520,19 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int rr = wave % NR, grp = wave / NR;           // row range, tile group
-  const int n0 = 16 * TN_ * (grp % SN), k0 = 16 * TK_ * (grp / SN);
+  // GEN: dW is larger than one workgroup's accumulators: blockIdx.z picks a (16 TN_ SN) x (16 TK_ SK) output block; tiles
+  // (or lanes of a tile) past N / K read an in-range column instead and their accumulators are never stored
+  static_assert(!GEN || (VW == 1 && !BF3), "output-blocked mode: dword loads, fp32 products");
+  const int nbn = GEN ? (N + 16 * TN_ * SN - 1) / (16 * TN_ * SN) : 1;
+  const int obn = GEN ? (int)blockIdx.z % nbn : 0, obk = GEN ? (int)blockIdx.z / nbn : 0;
+  const int n0 = 16 * TN_ * (SN * obn + grp % SN), k0 = 16 * TK_ * (SK * obk + grp / SN);
+  int offn[GEN ? TN_ : 1], offk[GEN ? TK_ : 1];
+  if constexpr (GEN) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t) offn[t] = (n0 + 16 * t + i < N) ? 16 * t + i : (n0 < N ? 0 : -n0);
+#pragma unroll
+    for (int u = 0; u < TK_; ++u) offk[u] = (k0 + 16 * u + i < K) ? 16 * u + i : (k0 < K ? 0 : -k0);
+  }
   const int mb = (blockIdx.x * NR + rr) * rows_per_wave;
   const int me = min(M, mb + rows_per_wave);
 
@@ -564,6 +576,11 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
           b[qd][2 * h] = v.x;
           b[qd][2 * h + 1] = v.y;
         }
+      } else if constexpr (GEN) {
+#pragma unroll
+        for (int t = 0; t < TN_; ++t) a[qd][t] = dr[offn[t]];
+#pragma unroll
+        for (int u = 0; u < TK_; ++u) b[qd][u] = xr[offk[u]];
       } else {
 #pragma unroll
       for (int t = 0; t < TN_ - 1; ++t) a[qd][t] = dri[16 * t];
@@ -582,7 +599,7 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   auto compute = [&](float (&a)[4][TN_], float (&b)[4][TK_]) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      if constexpr (VW == 1) {
+      if constexpr (VW == 1 && !GEN) {
         a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;   // ragged last tiles: the clamped column is masked at use time
         b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
       }
@@ -629,7 +646,7 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
     if (MAPPED) { outer = mrow / xm.rows_inner; inner = mrow - outer * xm.rows_inner; }
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
-      if constexpr (VW == 1) {
+      if constexpr (VW == 1 && !GEN) {
         a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;
         b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
       }
@@ -647,6 +664,9 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
             bn[qd][2 * h] = v.x;
             bn[qd][2 * h + 1] = v.y;
           }
+        } else if constexpr (GEN) {
+          if (k < TN_) an[qd][k] = dr[offn[k < TN_ ? k : 0]];
+          else bn[qd][k - TN_] = xr[offk[k - TN_ < TK_ ? k - TN_ : 0]];
         } else {
           if (k < TN_ - 1) an[qd][k] = dr[16 * k + i];
           else if (k == TN_ - 1) an[qd][k] = dr[16 * (TN_ - 1) + in_last];
@@ -708,6 +728,14 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
       m0 += 16;
       if (m0 >= me) break;
       compute_and_load(ea, eb, clamp_g(m0 + 32), na, nb);
+      m0 += 16;
+    }
+  } else if constexpr (!BF3) {
+    while (m0 < me) {      // two buffers: the next group streams in between the MFMAs of the current one
+      compute_and_load(ca, cb, min(m0 + 16, M - 16), na, nb);
+      m0 += 16;
+      if (m0 >= me) break;
+      compute_and_load(na, nb, min(m0 + 16, M - 16), ca, cb);
       m0 += 16;
     }
   } else {
@@ -773,7 +801,7 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
       }
     }
   }
-  if (slab_db && grp / SN == 0) {
+  if (slab_db && grp / SN == 0 && obk == 0) {
 #pragma unroll
     for (int t = 0; t < TN_; ++t) {
       const int n = (VW == 2) ? n0 + 32 * (t >> 1) + 2 * i + (t & 1) : n0 + 16 * t + i;
@@ -791,6 +819,36 @@ __global__ __launch_bounds__(128 * NR) __attribute__((amdgpu_num_vgpr(128))) voi
                                                                                                       int N, int rows_per_wave) {
   static_assert(SN * SK == 2, "two tile groups per workgroup");
   tn_wave_body<TN_, TK_, SN, SK, MAPPED, VW, BF3, NR>(bt, lddy, xm, M, K, N, rows_per_wave);
+}
+
+// Output-blocked variant for weight matrices larger than one workgroup's accumulators (H = 200: 600 x 200, 600 x 300 ...):
+// grid.z walks (16 TN_ SN) x (16 TK_ SK) blocks of dW, grid.x the row ranges; everything else as above.
+template <int TN_, int TK_, int SN, int SK, bool MAPPED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void gemm_tn_wave_gen_kernel(TnBatch bt, int64_t lddy,
+                                                                                                     RowMap xm, int M, int K,
+                                                                                                     int N, int rows_per_wave) {
+  tn_wave_body<TN_, TK_, SN, SK, MAPPED, 1, false, 2, true>(bt, lddy, xm, M, K, N, rows_per_wave);
+}
+
+// block shape of the output-blocked variant: 0 = 192 x 64 (TN 6, TK 4), 1 = 128 x 112 (TN 4, TK 7); the one that pads N x K
+// the least.  Returns the number of output blocks; rows per wave / row splits sized for ~256 workgroups per launch.
+static int tn_gen_grid(int M, int K, int N, bool has_keep, int nprob, int* cfg, int* rows_per_wave, int* nsplit) {
+  if (has_keep || M < 4096 || (M & 15)) return 0;
+  const int bn[2] = {192, 128}, bk[2] = {64, 112};
+  int best = 0;
+  int64_t best_area = -1;
+  for (int c = 0; c < 2; ++c) {
+    const int64_t area = (int64_t)cdiv(N, bn[c]) * bn[c] * cdiv(K, bk[c]) * bk[c];
+    if (best_area < 0 || area < best_area) { best = c; best_area = area; }
+  }
+  const int nob = cdiv(N, bn[best]) * cdiv(K, bk[best]);
+  int splits = 256 / (nob * nprob);
+  if (splits < 1) splits = 1;
+  const int rpw = round_up(cdiv(M, 2 * splits), 16);
+  if (cfg) *cfg = best;
+  if (rows_per_wave) *rows_per_wave = rpw;
+  if (nsplit) *nsplit = cdiv(M, 2 * rpw);
+  return nob;
 }
 
 // grid (= number of slabs) and rows per wave of the wave-autonomous path; 0 when the shape is not covered
@@ -931,6 +989,10 @@ extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
     const int wg = tn_wave_grid(M, K, N, false, nullptr, 1, nr);
     if (wg > splits) splits = wg;
   }
+  {
+    int gs = 0;
+    if (tn_gen_grid(M, K, N, false, 1, nullptr, nullptr, &gs) > 0 && gs > splits) splits = gs;
+  }
   return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
 }
 
@@ -950,7 +1012,13 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
   RowMap xm{ldx, rows_inner, stride_outer, stride_inner};
   int rpw = 0;
   const int nr = bf3 ? 4 : 2;                  // row ranges (waves per tile group) per workgroup, see tn_wave_body
-  const int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw, nprob, nr);
+  int wg = tn_wave_grid(M, K, N, x_keep != nullptr, &rpw, nprob, nr);
+  int gen_cfg = 0, gen_nob = 0;
+  if (wg == 0 && !bf3 && (N > 64 || K > 64)) {  // shapes beyond one workgroup's accumulators: output-blocked wave kernel
+    int gs = 0;
+    gen_nob = tn_gen_grid(M, K, N, x_keep != nullptr, nprob, &gen_cfg, &rpw, &gs);
+    if (gen_nob > 0) wg = gs;
+  }
   if (wg > 0) splits = wg;
   const size_t slab_stride = (size_t)splits * ((size_t)N * K + N);
   const int64_t n = (int64_t)N * K;
@@ -970,6 +1038,19 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     }
     (void)all_db;
     const int tn = cdiv(N, 16), tk = cdiv(K, 16);
+    if (gen_nob > 0) {
+#define G2V_TNG(TN_, TK_, MP)                                                                                             \
+  do {                                                                                                                   \
+    const size_t lds = ((size_t)2 * TN_ * TK_ * 256 + 4 * TN_ * 16) * sizeof(float);                                      \
+    (void)hipFuncSetAttribute((const void*)gemm_tn_wave_gen_kernel<TN_, TK_, 2, 1, MP>,                                  \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                                     \
+    hipLaunchKernelGGL((gemm_tn_wave_gen_kernel<TN_, TK_, 2, 1, MP>), dim3(wg, nprob, gen_nob), dim3(256), lds,          \
+                       (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);                                                 \
+  } while (0)
+      if (gen_cfg == 0) { if (rows_inner > 0) G2V_TNG(6, 4, true); else G2V_TNG(6, 4, false); }
+      else { if (rows_inner > 0) G2V_TNG(4, 7, true); else G2V_TNG(4, 7, false); }
+#undef G2V_TNG
+    } else {
 #define G2V_TNW2(TN_, TK_, SN, SK, VW, BF, NR, MP)                                                                       \
   do {                                                                                                                   \
     const size_t lds = ((size_t)NR * TN_ * TK_ * 256 + 2 * NR * TN_ * 16) * sizeof(float);                                \
@@ -990,6 +1071,7 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
 #undef G2V_TNW
 #undef G2V_TNW2
+    }
     G2V_CHECK_LAUNCH();
   } else {
     const int ntw = tn_ntw(N);

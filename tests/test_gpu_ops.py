@@ -78,7 +78,8 @@ def test_linear_fwd_rowmap_and_mask(ops):
     relclose(db, dy.sum(0), 5e-6, "bwd_bias")
 
 
-@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192)])
+@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
+                                   (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514)])   # output-blocked wave kernel
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
     dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
@@ -600,7 +601,7 @@ def test_linear_wave_kernels_at_rollout_shapes(ops):
     assert torch.equal(ops.linear_bwd_weight(dy.to(DEV), h1.to(DEV), D, H)[0], dw_out), "weight gradient must be deterministic"
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 192, 64), (300, 150, 50)])
+@pytest.mark.parametrize("M,N,K", [(8192, 192, 64), (300, 150, 50), (4096, 600, 200)])
 def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
     """g2v_linear_bwd_weight_batch (four problems of one shape in one launch + one slab reduction; sequential fallback for
     small / generic shapes) against four single calls; db is optional per item.  The wave-autonomous path sizes its row
@@ -630,3 +631,15 @@ def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
     ops.linear_bwd_weight_batch(items, N, K, M=M, accumulate=True)
     for p in range(4):
         relclose(items[p][2], 2 * first[p][0], 2e-6, f"dw of problem {p} accumulated")
+
+
+def test_linear_bwd_weight_output_blocked_with_row_map(ops):
+    """dW of an in_layer-like product at generic dims (N = 200, K = 40) with the (B,T,D) -> (T,B,D) row map: the
+    output-blocked wave kernel's MAPPED instantiation."""
+    B, T, D, H = 1024, 4, 40, 200
+    x = rnd(B, T, D, seed=71)
+    dy = rnd(T * B, H, seed=72)
+    dw, db = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), H, D, M=T * B, row_map=(B, D, T * D))
+    xt = x.transpose(0, 1).reshape(T * B, D)
+    relclose(dw, (dy.double().t() @ xt.double()).float(), 1e-5, "dW row-mapped")
+    relclose(db, dy.double().sum(0).float(), 1e-5, "db")
