@@ -643,3 +643,34 @@ def test_linear_bwd_weight_output_blocked_with_row_map(ops):
     xt = x.transpose(0, 1).reshape(T * B, D)
     relclose(dw, (dy.double().t() @ xt.double()).float(), 1e-5, "dW row-mapped")
     relclose(db, dy.double().sum(0).float(), 1e-5, "db")
+
+
+@pytest.mark.parametrize("T,B,D,H", [(6, 32, 135, 64), (6, 24, 40, 200)])       # fused step kernels / per-phase split kernels
+@pytest.mark.parametrize("n_pre,conditioned", [(3, True), (1, False)])
+def test_dec_rollout_teacher_forcing_and_unconditioned(ops, T, B, D, H, n_pre, conditioned):
+    """n_pre_poses > 1 feeds target frames for the first steps (:1049-1052, no feedback gradient there); conditioned ==
+    'False' zeroes the decoder input (:568-569).  Forward outputs and d h_init against the oracle."""
+    sd = _dec_state(D, H, seed=15)
+    g = torch.Generator().manual_seed(91)
+    target = torch.randn(B, T, D, generator=g)
+    h_init = torch.randn(2, B, H, generator=g) * 0.5
+    keep95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)
+    k_or = keep95 if conditioned else torch.zeros_like(keep95)          # oracle: an all-zero mask IS the zeroed input
+    h_leaf = h_init.clone().requires_grad_(True)
+    y_ref, _ = _oracle_rollout(sd, target, h_leaf, k_or, None, 0.0, True, n_pre=n_pre)
+    gy = torch.randn(T, B, D, generator=g) / (T * B * D) * 100
+    (g_h,) = torch.autograd.grad((y_ref * gy).sum(), [h_leaf])
+    wt, _ = _dec_weight_tensors(sd, DEV)
+    ws = ops.dec_weights_struct(wt)
+    nblk = ops.dec_rollout_blocks(B)
+    saved = _alloc_saved(T, B, D, H, nblk, DEV, 0.0)
+    k95 = keep95.to(DEV)
+    ops.dec_rollout_fwd(target.to(DEV), h_init.to(DEV), ws, saved, k95, None, 0.0, n_pre, conditioned, True, T, B, D, H)
+    relclose(saved["y"], y_ref, 1e-4, "rollout outputs")
+    G = 3 * H
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    grads = {"dy": gy.to(DEV).clone(), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G),
+             "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G), "dh_init": z(2, B, H),
+             "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
+    ops.dec_rollout_bwd(ws, saved, grads, k95, None, 0.0, n_pre, conditioned, T, B, D, H)
+    relclose(grads["dh_init"], g_h, 2e-4, "d h_init")
