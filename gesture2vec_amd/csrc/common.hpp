@@ -229,25 +229,35 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
     const float* pt[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) pt[t] = P + ((int64_t)(tile0 + t * tile_stride) * KS * 64 + lane) * 4;
-    float4 cur[NT], nxt[NT];
+    // PD k-steps of fragments in flight: step s is multiplied from ring slot s % PD, which is then refilled with step
+    // s + PD - a fragment has PD x 4 NT MFMAs (>= 1.5k cycles for NT = 3) to arrive instead of one k-step's 384, and the
+    // refills go out one k-step at a time between the MFMAs.
+    constexpr int PD = 4;
+    float4 ring[PD][NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) cur[t] = *reinterpret_cast<const float4*>(pt[t]);
-    for (int s = 0; s < KS; ++s) {
-      if (s + 1 < KS) {
+    for (int j = 0; j < PD; ++j)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) nxt[t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)(s + 1) * 256);
+      for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)min(j, KS - 1) * 256);
+    for (int s0 = 0; s0 < KS; s0 += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) {
+        const int s = s0 + j;
+        if (s < KS) {
+          const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = mfma16(ring[j][t].x, xb.x, acc[t]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = mfma16(ring[j][t].y, xb.y, acc[t]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = mfma16(ring[j][t].z, xb.z, acc[t]);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] = mfma16(ring[j][t].w, xb.w, acc[t]);
+          const int sn = min(s + PD, KS - 1);         // past the end: a valid, unused fragment
+#pragma unroll
+          for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-      const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].x, xb.x, acc[t]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].y, xb.y, acc[t]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].z, xb.z, acc[t]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma16(cur[t].w, xb.w, acc[t]);
-#pragma unroll
-      for (int t = 0; t < NT; ++t) cur[t] = nxt[t];
     }
   }
 }
