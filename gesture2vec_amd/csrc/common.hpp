@@ -232,7 +232,7 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
     // PD k-steps of fragments in flight: step s is multiplied from ring slot s % PD, which is then refilled with step
     // s + PD - a fragment has PD x 4 NT MFMAs (>= 1.5k cycles for NT = 3) to arrive instead of one k-step's 384, and the
     // refills go out one k-step at a time between the MFMAs.
-    constexpr int PD = 4;
+    constexpr int PD = 8;
     float4 ring[PD][NT];
 #pragma unroll
     for (int j = 0; j < PD; ++j)
