@@ -51,7 +51,8 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ gi, c
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<3>(acc, w_hh, (int64_t)H, wvec, 16 * ft, H, nvalid, H, cur, ldx, lane);
+      (void)nvalid; (void)wvec;
+      wave_gemm_p<3, 0>(acc, w_hh, Hp >> 4, ft, ntile, cur, ldx, lane);     // w_hh: fragment-major pack (3 gate groups x H rows)
       const int f0 = 16 * ft + 4 * q;
       const int64_t row = (int64_t)t * B + b;
       float hp[4], hn[4], gr[4], gz[4], gn[4], gh[4];
@@ -203,7 +204,8 @@ __device__ __forceinline__ void gru_seq_bwd_body(const float* __restrict__ d_hs,
     for (int ft = wave; ft < ntile; ft += 4) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       const int nvalid = min(16, H - 16 * ft);
-      wave_gemm<1>(acc, w_hh_t, (int64_t)G, wvec, 16 * ft, 16, nvalid, G, Gs, ldg, lane);
+      (void)nvalid; (void)wvec;
+      wave_gemm_p<1, 0>(acc, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);         // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
       const int f0 = 16 * ft + 4 * q;
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -837,9 +839,24 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
+    set_error("g2v_gru_seq_fwd: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
   GruGenF g[2];
-  for (int k = 0; k < ndir; ++k)
-    g[k] = GruGenF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+  {
+    // W_hh in MFMA fragment order (coalesced 1 KiB fragment loads, eight k-steps kept in flight by wave_gemm_p)
+    float* pp = (float*)workspace;
+    PackBatch pb;
+    pb.n = 0;
+    for (int k = 0; k < ndir; ++k) {
+      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, pp, H, 3, H, H, H, 0, 0};
+      g[k] = GruGenF{dirs[k].gi, pp, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+      pp += pack_floats(H, 3, H);
+    }
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+  }
   if (ndir == 1) g[1] = g[0];
   hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
   G2V_CHECK_LAUNCH();
@@ -937,11 +954,17 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
     return G2V_OK;
   }
   GruGenB g[2];
-  for (int k = 0; k < ndir; ++k) {
-    float* wt = p + (size_t)k * 3 * H * H;
-    launch_transpose(dirs[k].w_hh, wt, 3 * H, H, st);  // (3H,H) -> (H,3H)
-    g[k] = GruGenB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, wt, dirs[k].dgi, dirs[k].dgh,
-                   dirs[k].dh0, dirs[k].reverse};
+  {
+    PackBatch pb;
+    pb.n = 0;
+    for (int k = 0; k < ndir; ++k) {
+      float* wt = p + (size_t)k * pack_floats(H, 1, 3 * H);
+      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, wt, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden unit), contraction over the 3H gates
+      g[k] = GruGenB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, wt, dirs[k].dgi, dirs[k].dgh,
+                     dirs[k].dh0, dirs[k].reverse};
+    }
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
   }
   if (ndir == 1) g[1] = g[0];
   hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T, B, H);
