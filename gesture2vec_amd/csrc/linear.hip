@@ -27,7 +27,7 @@ constexpr int BM = 64, BN = 64, BC = 32, LDT = BC + 4;
 // C[m][n] (+)= act( sum_c A[m][c] * Bop[n][c] + bias[n] )
 //   TRANS_B == false: Bop[n][c] = Bm[n*ldb + c]     (forward: Bm = w [N][K])
 //   TRANS_B == true : Bop[n][c] = Bm[c*ldb + n]     (data gradient: Bm = w [N][K], output feature = k)
-template <bool TRANS_B>
+template <bool TRANS_B, bool VEC = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, RowMap am,
                                                       const uint8_t* __restrict__ keep, float scale,
                                                       const float* __restrict__ Bm, int64_t ldb,
@@ -45,6 +45,62 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
 
   // Software pipeline: the global loads of chunk c+1 are issued (into registers) right after chunk c has been written to LDS,
   // so their L2 / HBM round trip runs under the MFMAs of chunk c instead of in front of them.
+  if constexpr (VEC) {
+    // 16-byte-aligned operands, C % 4 == 0 (and N % 4 == 0 when transposed), no keep mask: one float4 per (row, 4 columns);
+    // thread -> row tid >> 3 (+32), columns 4 (tid & 7) of the 32-wide chunk; transposed B: c = tid >> 4 (+16), n = 4 (tid & 15)
+    float4 va[2], vb[2];
+    const int vr = tid >> 3, vc = 4 * (tid & 7);
+    const int wc = tid >> 4, wn = 4 * (tid & 15);
+    int64_t ao[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int m = m0 + vr + 32 * h;
+      ao[h] = m < M ? row_off(am, m) : -1;
+    }
+    auto vfetch = [&](int c0) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int cc = c0 + vc;
+        va[h] = ld4_or_zero(A + (ao[h] >= 0 ? ao[h] : 0) + (cc < C ? cc : 0), ao[h] >= 0 && cc < C);
+        if (!TRANS_B) {
+          const int n = n0 + vr + 32 * h;
+          vb[h] = ld4_or_zero(Bm + (int64_t)(n < N ? n : 0) * ldb + (cc < C ? cc : 0), n < N && cc < C);
+        } else {
+          const int c = c0 + wc + 16 * h, n = n0 + wn;
+          vb[h] = ld4_or_zero(Bm + (int64_t)(c < C ? c : 0) * ldb + (n < N ? n : 0), c < C && n < N);
+        }
+      }
+    };
+    vfetch(0);
+    for (int c0 = 0; c0 < C; c0 += BC) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        *reinterpret_cast<float4*>(&As[(vr + 32 * h) * LDT + vc]) = va[h];
+        if (!TRANS_B) {
+          *reinterpret_cast<float4*>(&Bs[(vr + 32 * h) * LDT + vc]) = vb[h];
+        } else {
+          const int c = wc + 16 * h;
+          Bs[(wn + 0) * LDT + c] = vb[h].x; Bs[(wn + 1) * LDT + c] = vb[h].y;
+          Bs[(wn + 2) * LDT + c] = vb[h].z; Bs[(wn + 3) * LDT + c] = vb[h].w;
+        }
+      }
+      __syncthreads();
+      if (c0 + BC < C) vfetch(c0 + BC);
+#pragma unroll
+      for (int k0 = 0; k0 < BC; k0 += 16) {
+        const float4 xb = *reinterpret_cast<const float4*>(&As[(16 * wave + i) * LDT + k0 + 4 * q]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const float4 wa = *reinterpret_cast<const float4*>(&Bs[(16 * t + i) * LDT + k0 + 4 * q]);
+          acc[t] = mfma16(wa.x, xb.x, acc[t]);
+          acc[t] = mfma16(wa.y, xb.y, acc[t]);
+          acc[t] = mfma16(wa.z, xb.z, acc[t]);
+          acc[t] = mfma16(wa.w, xb.w, acc[t]);
+        }
+      }
+      __syncthreads();
+    }
+  } else {
   float ra[8], rb[8];
   const int lc = tid & 31, lr = tid >> 5;             // A (and non-transposed B): 32 consecutive threads along c
   const int tr = tid & 63, tc = tid >> 6;             // transposed B: 64 consecutive threads along n
@@ -105,6 +161,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
       }
     }
     __syncthreads();
+  }
   }
 
   // epilogue: lane holds row m = m0 + 16*wave + (lane&15), features n0 + 16t + 4q + r
@@ -959,6 +1016,12 @@ extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64
     return G2V_OK;
   }
   dim3 grid(cdiv(M, BM), cdiv(N, BN));
+  const bool a_vec = !x_keep && (K & 3) == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                     (rows_inner > 0 ? ((stride_outer & 3) == 0 && (stride_inner & 3) == 0) : ((ldx & 3) == 0));
+  if (a_vec && (reinterpret_cast<uintptr_t>(w) & 15) == 0)
+    hipLaunchKernelGGL((gemm_nt_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, x, am, x_keep, x_scale, w,
+                       (int64_t)K, bias, y, ldy, M, K, N, act, 0);
+  else
   hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, am, x_keep, x_scale, w,
                      (int64_t)K, bias, y, ldy, M, K, N, act, 0);
   G2V_CHECK_LAUNCH();
@@ -976,6 +1039,11 @@ extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w
   }
   dim3 grid(cdiv(M, BM), cdiv(K, BN));
   // output feature = k (K of them), contraction over n (N): Bop[k][n] = w[n*K + k]
+  if ((N & 3) == 0 && (K & 3) == 0 && (lddy & 3) == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+      (reinterpret_cast<uintptr_t>(w) & 15) == 0)
+    hipLaunchKernelGGL((gemm_nt_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, am, (const uint8_t*)nullptr,
+                       1.0f, w, (int64_t)K, (const float*)nullptr, dx, lddx, M, N, K, 0, accumulate);
+  else
   hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, am, (const uint8_t*)nullptr,
                      1.0f, w, (int64_t)K, (const float*)nullptr, dx, lddx, M, N, K, 0, accumulate);
   G2V_CHECK_LAUNCH();
