@@ -40,44 +40,79 @@ def model_args():
         autoencoder_att="False", autoencoder_fixed_weight="False", n_poses=CFG["T"])
 
 
-def cpu_baseline(budget_s: float = 12.0):
-    """Oracle (CPU restatement, parity-pinned to the reference) on the host cores: BOUNDED sample of the same workload.
-    The thread count is calibrated (8/16/32) on one small step first: on a 256-core host the many tiny ops of the
+def cpu_baseline(B_main: int, budget_s: float = 14.0):
+    """Oracle (CPU restatement, parity-pinned to the reference) on the host cores, SURVEY.md 8(d): the same train step at
+    the benchmark's own batch (B = 4096) and at the reference's native batch (B = 128), a BOUNDED number of steps each.
+    The thread count is calibrated (8/16/32) on the B = 128 step first: on a 256-core host the many tiny ops of the
     T-1 step Python loop get slower, not faster, with every core in the pool."""
     from oracle import g2v_oracle as O
-    Bs, T, D, H, K = 1024, CFG["T"], CFG["D"], CFG["H"], CFG["K"]     # sample batch: 1/4 of the GPU batch
-    cfg = dict(n_layers=2, dropout_prob=0.0, commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
+    T, D, H, K = CFG["T"], CFG["D"], CFG["H"], CFG["K"]
+    cfg = dict(n_layers=2, dropout_prob=CFG["dropout_prob"], commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
                w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], lr=CFG["lr"])
-    g = torch.Generator().manual_seed(1234)
-    x = torch.randn(Bs, T, D, generator=g)
-    masks = {"dec": (torch.rand(T - 1, Bs, D, generator=g) < 0.05).to(torch.uint8)}
+    p = CFG["dropout_prob"]
 
-    def one(sd, adam):
+    def inputs(Bs):
+        g = torch.Generator().manual_seed(1234)
+        x = torch.randn(Bs, T, D, generator=g)
+        masks = {"dec": (torch.rand(T - 1, Bs, D, generator=g) < 0.05).to(torch.uint8)}
+        if p > 0:
+            masks["in"] = (torch.rand(T, Bs, D, generator=g) < 1 - p).to(torch.uint8)
+            masks["enc_l0"] = (torch.rand(T, Bs, 2 * H, generator=g) < 1 - p).to(torch.uint8)
+            masks["dec_l0"] = (torch.rand(T - 1, Bs, H, generator=g) < 1 - p).to(torch.uint8)
+        return x, masks
+
+    def one(sd, adam, x, masks):
         t0 = time.perf_counter()
         O.vqvae_train_step(sd, adam, x, masks, cfg)
         return time.perf_counter() - t0
 
+    def timed(Bs, budget, max_steps):
+        x, masks = inputs(Bs)
+        sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
+        one(sd, adam, x, masks)             # warm-up
+        n, tot = 0, 0.0
+        while tot < budget and n < max_steps:
+            tot += one(sd, adam, x, masks)
+            n += 1
+        return n, tot
+
     ncpu = os.cpu_count() or 1
     best_thr, best_t = 1, float("inf")
+    xs, ms = inputs(128)
     for thr in sorted({min(ncpu, c) for c in (8, 16, 32)}):
         torch.set_num_threads(thr)
         sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
-        one(sd, adam)                       # warm-up at this thread count
-        t = one(sd, adam)
+        one(sd, adam, xs, ms)               # warm-up at this thread count
+        t = one(sd, adam, xs, ms)
         if t < best_t:
             best_thr, best_t = thr, t
-        if t > 20.0:                        # pathological host: stop calibrating
+        if t > 10.0:                        # pathological host: stop calibrating
             break
     torch.set_num_threads(best_thr)
-    sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
-    one(sd, adam)
-    n, tot = 0, 0.0
-    while tot < budget_s and n < 40:
-        tot += one(sd, adam)
-        n += 1
-    return {"value": round(Bs * n / tot, 1), "unit": "chunks/s", "cores": best_thr, "kind": "port",
-            "sample": f"{n} full train steps at B={Bs} (1/4 of the GPU batch; oracle/g2v_oracle.py, torch-CPU fp32, "
-                      f"{best_thr} threads of {ncpu} host cores, {tot:.1f}s after warm-up)"}
+    n_s, t_s = timed(128, 0.25 * budget_s, 20)
+    n_m, t_m = timed(B_main, 0.75 * budget_s, 20)
+    return {"value": round(B_main * n_m / t_m, 1), "unit": "chunks/s", "cores": best_thr, "kind": "port",
+            "sample": f"{n_m} full train steps at B={B_main} (the GPU batch) in {t_m:.1f}s after warm-up; oracle/g2v_oracle.py, "
+                      f"torch-CPU fp32, {best_thr} threads of {ncpu} host cores",
+            "native_batch": {"B": 128, "value": round(128 * n_s / t_s, 1), "unit": "chunks/s",
+                             "sample": f"{n_s} steps in {t_s:.1f}s, same threads"}}
+
+
+def pmc_traffic(kernel: str, N: int):
+    """HBM bytes per launch of `kernel` at N rows, from the committed PMC summaries (separate rocprofv3 --pmc passes,
+    FETCH_SIZE doubled per the gfx950 correction): profiles/*pmc_traffic.json, newest round first.  None when no
+    summary holds this kernel at this size -- never a stale literal."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+        except Exception:
+            continue
+        e = d.get(f"N={N}")
+        if e and kernel in e.get("kernel", ""):
+            return int(e["hbm_bytes_per_launch_corrected"])
+    return None
 
 
 def vq_kernel_roofline(eng, B, reps: int = 200):
@@ -101,13 +136,11 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
     flops = 2.0 * N * K * E                      # 2KE flop per quantiser row
     # read flat (4E) + read z (4E) + write quantized (4E) + write idx (8, int64) per row; one codebook + norms read
     bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
-    # HBM bytes per launch from the PMC counters of the SAME kernel at the SAME size (separate --pmc passes,
-    # FETCH_SIZE doubled per the gfx950 correction): profiles/r01_vq_assign_pmc_traffic.json
-    pmc_traffic = 8543334 if (N, E, K) == (4096, 128, 512) else None
+    kernel = "vq_assign_rt_kernel<128, 4>" if N >= 16384 else "vq_assign_fast_kernel<128>"
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic,
-            "kernel": "vq_assign_fast_kernel<128>", "avg_us": round(us, 3), "flops_per_launch": flops,
+            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kernel, N) if (E, K) == (128, 512) else None,
+            "kernel": kernel, "avg_us": round(us, 3), "flops_per_launch": flops,
             "algorithmic_bytes_per_launch": bytes_alg,
             "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
 
@@ -147,6 +180,9 @@ def main():
     ap.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dropout", type=float, default=CFG["dropout_prob"],
+                    help="encoder-input / GRU inter-layer dropout_prob (config/VQ-VAE.yml ships 0.2; SURVEY.md 8(d) config 2 "
+                         "and the default here use 0: the always-on Dropout(0.95) of the decoder input is drawn either way)")
     ap.add_argument("--wgrad-bf16x3", action="store_true",
                     help="opt-in: weight-gradient products as 3-term bf16 splits (reported in config.wgrad); default exact fp32")
     ap.add_argument("--force-dp", action="store_true",
@@ -174,6 +210,7 @@ def main():
     assert lib.g2v_device_ok() == 1, "bench.py needs an MI355X (gfx950)"
 
     B, T, D = a.batch, CFG["T"], CFG["D"]
+    CFG["dropout_prob"] = float(a.dropout)
     torch.manual_seed(0)                            # identical initial weights on every rank
     net = Autoencoder_VQVAE(model_args(), D, T).to(dev)
     net.rng_seed = 1234 + rank
@@ -268,9 +305,10 @@ def main():
             "unit": "chunks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "VQ-VAE.yml full (BASELINE configs[1]): train_iter_Autoencoder_VQ_seq2seq on "
+            "config": {"workload": "BASELINE configs[1] (VQ-VAE full shape): train_iter_Autoencoder_VQ_seq2seq on "
                                    f"synthetic N(0,1) pose chunks, B={B}/GPU, T=34, D=135, H=64, L=2 (E=128), K=512, "
-                                   "dropout_prob=0 (+ always-on Dropout(0.95)), Adam lr=5e-4, random-init weights",
+                                   f"dropout_prob={CFG['dropout_prob']:g} (+ always-on Dropout(0.95)), Adam lr=5e-4, "
+                                   "random-init weights",
                        "global_batch": B * world, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "launch": ("eager launches" if graph is None else
@@ -287,7 +325,7 @@ def main():
             except Exception as e:   # the calibration is context, never a reason to lose the bench line
                 print(f"[bench] calibration probe failed ({type(e).__name__}: {e})", file=sys.stderr)
             if not a.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(B)
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

@@ -32,8 +32,14 @@ __global__ void code_sqnorm_kernel(const float* __restrict__ W, float* __restric
   if (lane == 0) out[wave] = s;
 }
 
+// torch.argmin semantics (the reference's :1259): lowest index among equal minima; a NaN distance counts as smaller than every
+// number and the FIRST NaN wins.  A candidate therefore beats the incumbent when it is smaller, or when it is NaN and the
+// incumbent is not; on a tie (equal values, or both NaN) the lower index stays.  No sentinel index ever leaves a kernel:
+// the running pair starts at (+inf, code 0), so an all-+inf row resolves to code 0 exactly like torch.
+__device__ __forceinline__ bool argmin_better(float d2, float d) { return d2 < d || (d2 != d2 && d == d); }
 __device__ __forceinline__ void argmin_merge(float& d, int& k, float d2, int k2) {
-  if (d2 < d || (d2 == d && k2 < k)) {
+  const bool tie = (d2 == d) || (d2 != d2 && d != d);
+  if (argmin_better(d2, d) || (tie && k2 < k)) {
     d = d2;
     k = k2;
   }
@@ -71,7 +77,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   const bool wvec = ptr_vec_ok(W, E);
   const float xr = xx[i];
   float bd = INFINITY;
-  int bk = 0x7fffffff;
+  int bk = 0;
   const int ntile = (K + 15) >> 4;
   for (int kt = wave; kt < ntile; kt += 4) {
     f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -82,7 +88,7 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
       const int code = 16 * kt + 4 * q + r;
       if (code < K) {
         const float d = (xr + wsq[code]) - 2.0f * acc[0][r];   // (||x||^2 + ||W||^2) - 2 x.W  (:1234-1238)
-        if (d < bd) {
+        if (argmin_better(d, bd)) {
           bd = d;
           bk = code;
         }
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __rest
   for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xs + i * ldx + 16 * s + 4 * q);
   const float xr = xx[i];
   float bd = INFINITY;
-  int bk = 0x7fffffff;
+  int bk = 0;
   const int npair = K >> 7;   // tiles of this wave: kt = wave + 4 j ; pairs (j, j+1)  -> K / 16 / 4 / 2
   auto load_pair = [&](int p, float4 (&w0)[KS], float4 (&w1)[KS], float4& q0, float4& q1) {
     const int kt0 = wave + 8 * p, kt1 = kt0 + 4;
@@ -225,12 +231,12 @@ __global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __rest
 #pragma unroll
     for (int r = 0; r < 4; ++r) {      // codes in increasing order within the lane: strict '<' keeps the lowest index
       const float d = (xr + s0[r]) - 2.0f * a0[r];
-      if (d < bd) { bd = d; bk = c0 + r; }
+      if (argmin_better(d, bd)) { bd = d; bk = c0 + r; }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const float d = (xr + s1[r]) - 2.0f * a1[r];
-      if (d < bd) { bd = d; bk = c1 + r; }
+      if (argmin_better(d, bd)) { bd = d; bk = c1 + r; }
     }
   };
   for (int p = 0; p < npair; p += 2) {
@@ -324,7 +330,7 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   float xr[RT], bd[RT];
   int bk[RT];
 #pragma unroll
-  for (int t = 0; t < RT; ++t) { xr[t] = xx[16 * t + i]; bd[t] = INFINITY; bk[t] = 0x7fffffff; }
+  for (int t = 0; t < RT; ++t) { xr[t] = xx[16 * t + i]; bd[t] = INFINITY; bk[t] = 0; }
   const int ntw = K >> 6;     // code tiles of this wave: kt = wave + 4 j
   auto load_tile = [&](int j, float4 (&w)[KS], float4& sq) {
     const int kt = wave + 4 * j;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const float d = (xr[t] + sv[r]) - 2.0f * acc[t][r];
-        if (d < bd[t]) { bd[t] = d; bk[t] = c0 + r; }
+        if (argmin_better(d, bd[t])) { bd[t] = d; bk[t] = c0 + r; }
       }
   };
   float4 wa[KS], wb[KS], qa, qb;
@@ -740,9 +746,6 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
     }
     if (rows == 64)
       hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, z, codebook,
-                         code_sqnorm, idx, quantized, dist_min, sse_partial, N, K);
-    else if (rows == 32)
-      hipLaunchKernelGGL((vq_assign_rt_kernel<128, 2>), dim3(cdiv(N, 32)), dim3(256), 0, st, flat, z, codebook,
                          code_sqnorm, idx, quantized, dist_min, sse_partial, N, K);
     else
       hipLaunchKernelGGL(vq_assign_fast_kernel<128>, dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, st, flat, z, codebook,

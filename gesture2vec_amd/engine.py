@@ -138,6 +138,10 @@ class VQVAEEngine:
         self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
         self._bufs: Dict[int, dict] = {}
         self._wstruct = None
+        # tensors with requires_grad == False in the reference (autoencoder_fixed_weight == "True" freezes the decoder GRU,
+        # :483-486): their gradient slots are zeroed after the backward, so they add nothing to the clip norm and Adam
+        # (m = v = 0, g = 0) leaves them exactly where they are -- what the reference's clip_grad_norm_ / Adam do by skipping them
+        self.frozen: list = []
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
@@ -397,6 +401,9 @@ class VQVAEEngine:
                    (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
                    (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
         wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
+        for name in self.frozen:
+            g = self.view(name, True)
+            check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), st))
         return b
 
     def backward_encoder(self, in_poses: torch.Tensor, B: int):

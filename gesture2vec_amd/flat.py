@@ -36,17 +36,32 @@ class FlatParams:
             p.data = v
 
     def gather_grads(self):
-        """Copy (device-to-device, stream ordered) each .grad into the flat grad buffer; missing grads count as zero."""
+        """Copy (device-to-device, stream ordered) each .grad into the flat grad buffer.  A parameter whose .grad is None
+        this step is remembered in `self.skipped`: torch.optim.Adam (the reference's optimizer) leaves such a parameter
+        and its moments completely untouched, and clip_grad_norm_ ignores it; step() reproduces that."""
         self.gflat.zero_()
+        self.skipped = []
         for p, o in zip(self.params, self.offsets):
             if p.grad is not None:
                 self.gflat[o:o + p.numel()].view(p.shape).copy_(p.grad)
+            else:
+                self.skipped.append((o, p.numel()))
 
     def step(self, lr, betas=(0.5, 0.999), eps=1e-8, max_norm=5.0, grad_scale=1.0):
         st = torch.cuda.current_stream().cuda_stream
+        # grad-less tensors: a zero gradient adds nothing to the clip norm, but the fused kernel would still decay their
+        # moments and move them by stale momentum -> keep (param, m, v) of those ranges and put them back afterwards.
+        # (Their bias-correction step count is the global one here, a per-parameter one in torch: only visible for a tensor
+        # that skips steps AND later receives gradients again.)
+        saved = [(o, n, self.flat[o:o + n].clone(), self.m[o:o + n].clone(), self.v[o:o + n].clone())
+                 for o, n in getattr(self, "skipped", [])]
         check(self.lib.g2v_clip_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                           self.n, self.partial.data_ptr(), self.step_counter.data_ptr(),
                                           self.gnorm.data_ptr(), max_norm, grad_scale, lr, betas[0], betas[1], eps, st))
+        for o, n, w, m, v in saved:
+            self.flat[o:o + n].copy_(w)
+            self.m[o:o + n].copy_(m)
+            self.v[o:o + n].copy_(v)
 
 
 class FlatClipAdam:

@@ -255,6 +255,8 @@ class Autoencoder_VQVAE(nn.Module):
                               conditioned=self.autoencoder_conditioned, device=dev, seed=self.rng_seed,
                               quantizer=self.quantizer)
             self._engine = eng
+            if getattr(self.decoder.decoder, "autoencoder_fixed_weight", False):
+                eng.frozen = ["decoder.decoder.gru." + n for n, _ in self.decoder.decoder.gru.named_parameters()]
         # (re)home every trainable tensor into the flat buffer; cheap pointer check per call
         for name, _ in eng.layout:
             p = sd_params[name]

@@ -37,14 +37,23 @@ def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
 
 
 _ws_cache = {}
+_ws_retired = []      # superseded workspaces stay allocated: see workspace()
 
 
 def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
-    """A reusable byte buffer per (device, tag); grows monotonically (allocation never happens inside the C-ABI)."""
+    """A reusable byte buffer per (device, tag); grows monotonically (allocation never happens inside the C-ABI).
+
+    A buffer that is outgrown is RETIRED, never freed: its address may be baked into a captured hipGraph
+    (train_eval.train_seq2seq.GraphedText2EmbeddingStep replays ops.* calls), and handing the block back to the caching
+    allocator would let a later replay scribble its weight-gradient slabs over whatever tensor reuses the memory.  The cost
+    is bounded: sizes only grow, so at most a geometric series of small blocks per tag stays behind."""
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _ws_retired.append(buf)
+        grow = max(int(nbytes), 256, 0 if buf is None else 2 * buf.numel())
+        buf = torch.empty(grow, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 

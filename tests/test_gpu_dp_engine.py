@@ -1,0 +1,126 @@
+"""Engine-level data-parallel parity on ONE GPU (reference statistics :1262-1282).
+
+Two VQVAEEngine replicas play rank 0 / rank 1 on the same device: each runs the product's `train_step_local` on its own
+shard (the HIP path: masks -> forward -> loss -> backward, leaving comm = [grads | cnt | dw]), the two comm buffers are
+summed by hand (what the RCCL SUM all-reduce does), and each replica runs `train_step_apply(world=2)`.  The result must
+equal the two-shard emulation of the CPU oracle (same formulas as tests/test_dp_gloo.py, which covers the collective
+itself on gloo): mean gradients -> clip 5 -> Adam, EMA codebook update from the GLOBAL statistics."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import g2v_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _cfg(p):
+    return dict(n_layers=2, dropout_prob=p, commitment_cost=0.25, n_pre_poses=1, conditioned=True, w_l1=5.0, w_cont=0.1,
+                w_var=0.5, lr=5e-4)
+
+
+def _shard(rank, step, B, T, D, H, p):
+    g = torch.Generator().manual_seed(1234 + 17 * rank + 1000 * step)
+    x = torch.randn(B, T, D, generator=g)
+    masks = {"dec": (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)}
+    if p > 0:
+        masks["in"] = (torch.rand(T, B, D, generator=g) < 1 - p).to(torch.uint8)
+        masks["enc_l0"] = torch.ones(T, B, 2 * H, dtype=torch.uint8)
+        masks["dec_l0"] = (torch.rand(T - 1, B, H, generator=g) < 1 - p).to(torch.uint8)
+    return x, masks
+
+
+def _oracle_local(sd, x, masks, cfg, K):
+    keys = O.vqvae_trainable_keys(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = dict(sd); work.update(leaves)
+    fw = O.vqvae_forward(work, x, x, cfg, True, masks)
+    loss = O.custom_loss(fw["outputs"], x, 5.0, 0.1, 0.5) + fw["loss_vq"] / 400
+    gl = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
+    grads = {k: (g if g is not None else torch.zeros_like(leaves[k])) for k, g in zip(keys, gl)}
+    idx = fw["idx"]
+    cnt = torch.bincount(idx, minlength=K).float()
+    onehot = torch.zeros(idx.numel(), K, dtype=torch.float64); onehot[torch.arange(idx.numel()), idx] = 1
+    dw = (onehot.t() @ fw["flat"].double()).float()
+    return grads, cnt, dw, fw
+
+
+def _oracle_apply(sd, grads_sum, cnt, dw, world, adam, K, lr):
+    grads = {k: g / world for k, g in grads_sum.items()}
+    grads, norm = O.clip_grad_norm(grads, 5.0)
+    params = {k: sd[k] for k in grads}
+    O.adam_step(params, grads, adam, lr)
+    sd.update(params)
+    cs = sd["vq_layer._ema_cluster_size"] * 0.85 + 0.15 * cnt
+    n = cs.sum()
+    cs = (cs + 1e-5) / (n + K * 1e-5) * n
+    ema_w = sd["vq_layer._ema_w"] * 0.85 + 0.15 * dw
+    sd["vq_layer._ema_cluster_size"], sd["vq_layer._ema_w"] = cs, ema_w
+    sd["vq_layer._embedding.weight"] = ema_w / cs.unsqueeze(1)
+    return norm
+
+
+def _engine(sd, D, H, K, T, p):
+    from gesture2vec_amd.engine import VQVAEEngine
+    eng = VQVAEEngine(D, H, 2, K, T, beta=0.25, dropout_prob=p, device=DEV)
+    for name, _ in eng.layout:
+        eng.view(name).copy_(sd[name])
+    eng.vq_pre_w.copy_(sd["vq_layer.pre_linear.weight"]); eng.vq_pre_b.copy_(sd["vq_layer.pre_linear.bias"])
+    eng.codebook.copy_(sd["vq_layer._embedding.weight"]); eng.ema_w.copy_(sd["vq_layer._ema_w"])
+    eng.ema_cs.copy_(sd["vq_layer._ema_cluster_size"])
+    return eng
+
+
+def relerr(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("B,T,D,H,K,p", [(64, 34, 135, 64, 512, 0.0), (48, 10, 45, 200, 400, 0.2), (512, 34, 135, 64, 512, 0.2)])
+def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p):
+    world, n_steps, lr = 2, 2, 5e-4
+    cfg = _cfg(p)
+    sd = O.init_vqvae_state(D, H, 2, K, seed=11)
+    engines = [_engine(sd, D, H, K, T, p) for _ in range(world)]
+    adam = {}
+    for step in range(n_steps):
+        tot_g, tot_c, tot_w = None, 0, 0
+        for r in range(world):
+            x, masks = _shard(r, step, B, T, D, H, p)
+            g, c, w, fw = _oracle_local(sd, x, masks, cfg, K)
+            tot_g = g if tot_g is None else {k: tot_g[k] + g[k] for k in g}
+            tot_c, tot_w = tot_c + c, tot_w + w
+            eng = engines[r]
+            eng.set_masks(B, masks["dec"].to(DEV), masks["in"].to(DEV) if p > 0 else None,
+                          masks["dec_l0"].to(DEV) if p > 0 else None)
+            xd = x.to(DEV)
+            eng.train_step_local(xd, xd, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=False, dp=True)
+            # this rank's contribution, before any exchange: local histogram and code sums
+            assert torch.equal(eng.vq_stats[:K].cpu(), c), "local code histogram"
+            assert relerr(eng.vq_stats[K:], w.reshape(-1)) < 1e-5
+        # the SUM all-reduce of [grads | cnt | dw], by hand
+        total = engines[0].comm + engines[1].comm
+        for eng in engines:
+            eng.comm.copy_(total)
+            eng.train_step_apply(B, lr=lr, world=world, dp=True)
+        norm = _oracle_apply(sd, tot_g, tot_c, tot_w, world, adam, K, lr)
+        assert abs(engines[0].gnorm.item() - float(norm)) <= 2e-4 * float(norm), "global mean-gradient norm"
+        # perplexity is computed from the GLOBAL histogram
+        pr = tot_c / (world * ((2 * B * H) // (2 * H)))
+        perp = torch.exp(-(pr * torch.log(pr + 1e-10)).sum())
+        assert abs(engines[0].vq_scalars[1].item() - perp.item()) <= 1e-4 * perp.item()
+    e0, e1 = engines
+    # replicas end bit-identical (same reduced buffer, deterministic update) ...
+    assert torch.equal(e0.flat, e1.flat) and torch.equal(e0.codebook, e1.codebook) and torch.equal(e0.ema_w, e1.ema_w)
+    assert torch.equal(e0.ema_cs, e1.ema_cs)
+    # ... and equal to the oracle's two-shard global-statistics update
+    for name, _ in e0.layout:
+        if name == "decoder.decoder.pre_linear.0.bias":     # zero-gradient tensor: Adam amplifies rounding noise (see DESIGN)
+            continue
+        err = float((e0.view(name).cpu().double() - sd[name].double()).abs().max())
+        assert err <= 1e-4 * float(sd[name].abs().max()) + 0.02 * n_steps * lr, (name, err)
+    assert relerr(e0.ema_cs, sd["vq_layer._ema_cluster_size"]) < 1e-5
+    assert relerr(e0.ema_w, sd["vq_layer._ema_w"]) < 1e-5
+    assert relerr(e0.codebook, sd["vq_layer._embedding.weight"]) < 1e-4

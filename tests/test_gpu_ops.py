@@ -118,7 +118,10 @@ def test_vq_assign_matches_golden_indices(ops, golden_dir):
     assert abs(loss - float(fx["ema/c1/loss"])) <= 1e-5 * abs(float(fx["ema/c1/loss"]))
 
 
-@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (33, 100, 512), (128, 400, 512), (1000, 128, 64), (17, 20, 7)])
+# N >= 16384 at E = 128, K % 128 == 0 runs vq_assign_rt_kernel<128,4> (64 rows per workgroup: the bulk code-assignment
+# kernel of pipeline.chunks_to_codes and of every N-sweep roofline figure); 16384 + 37 ends in a partial 64-row tile.
+@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (33, 100, 512), (128, 400, 512), (1000, 128, 64), (17, 20, 7),
+                                   (16384, 128, 512), (16384 + 37, 128, 512), (65536, 128, 512), (20000, 128, 128)])
 def test_vq_assign_vs_oracle(ops, N, E, K):
     flat, z = rnd(N, E, seed=11), rnd(N, E, seed=12)
     W = torch.rand(K, E, generator=torch.Generator().manual_seed(13)) * 2 - 1
@@ -141,15 +144,47 @@ def test_vq_assign_vs_oracle(ops, N, E, K):
     assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
 
 
-def test_vq_assign_ties_pick_lowest_index(ops):
-    E, K, N = 32, 48, 40
+@pytest.mark.parametrize("N,E,K", [(40, 32, 48), (40, 128, 512), (16384 + 5, 128, 512)])   # generic / fast / row-tiled kernel
+def test_vq_assign_ties_pick_lowest_index(ops, N, E, K):
     W = rnd(K, E, seed=3)
     W[17] = W[5]
     W[40] = W[5]
+    W[K - 1] = W[5]
     flat = W[5].unsqueeze(0).repeat(N, 1) + 0.0
     wsq = ops.vq_code_sqnorm(W.to(DEV))
     idx, *_ = ops.vq_assign(flat.to(DEV), flat.to(DEV), W.to(DEV), wsq)
     assert (idx.cpu() == 5).all()
+
+
+@pytest.mark.parametrize("N,E,K", [(40, 100, 512), (48, 128, 512), (16384 + 21, 128, 512)])    # generic / fast / row-tiled kernel
+def test_vq_assign_nonfinite_rows_follow_torch_argmin(ops, N, E, K):
+    """A diverged step feeds NaN / Inf rows to the quantiser.  torch.argmin (reference :1259) returns a VALID index
+    (first NaN, else first minimum); the kernels must do the same -- never an out-of-range sentinel that would then be
+    used as a gather offset into the codebook."""
+    flat, z = rnd(N, E, seed=31), rnd(N, E, seed=32)
+    W = torch.rand(K, E, generator=torch.Generator().manual_seed(33)) * 2 - 1
+    flat[3, 7] = float("nan")
+    flat[N - 2, :] = float("nan")
+    flat[5, 11] = float("inf")
+    flat[N - 9, E - 1] = float("-inf")
+    flat[17 % N, 0] = 1.0e30          # ||x||^2 overflows to +inf, dot products stay finite: every distance is +inf -> code 0
+    bad = [3, N - 2, 5, N - 9, 17 % N]
+    d = O.vq_distances(flat, W)
+    ref = d.argmin(1)
+    wsq = ops.vq_code_sqnorm(W.to(DEV))
+    idx, quant, dmin, sse = ops.vq_assign(flat.to(DEV), z.to(DEV), W.to(DEV), wsq, want_dist=True)
+    got = idx.cpu()
+    assert int(got.min()) >= 0 and int(got.max()) < K, "out-of-range code index"
+    assert torch.equal(got[bad], ref[bad]), (got[bad], ref[bad])
+    good = torch.ones(N, dtype=torch.bool)
+    good[bad] = False
+    dd = d[torch.arange(N), got]
+    assert float((dd[good] - d.min(1).values[good]).max()) <= 1e-3
+    # the gather really used the returned index (finite rows of z give finite quantised rows)
+    close(quant, z + (W[got] - z), 1e-6, 1e-6, "quantized")
+    # and the code statistics accept the result
+    stats = ops.vq_stats(idx, flat.nan_to_num(0.0, 0.0, 0.0).to(DEV), K)
+    assert torch.equal(stats[:K].cpu(), torch.bincount(got, minlength=K).float())
 
 
 @pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64)])
