@@ -385,6 +385,20 @@ __device__ __forceinline__ void frag_mma_pf(f32x4 (&acc)[NT], const WFrag<NT, KS
   });
 }
 
+// 16-byte store that is WRITE-THROUGH (sc1): the bytes leave the XCD's L2 while the kernel is still running instead of
+// sitting dirty until the end-of-kernel write-back.  For arrays this launch only produces (saved-for-backward tensors,
+// gradients consumed by a later GEMM): a launch that leaves B dirty bytes adds ~B / 6 TB/s to the kernel boundary
+// (MI355X_MICROARCH.md, price list row "boundary"), which is ~3 us behind the 18 MB a decoder step writes.
+// `wt == false` is a plain store (arrays the NEXT launch re-reads on the same XCD: states, carries, partial sums).
+__device__ __forceinline__ void st4(float* p, const float4& v, bool wt) {
+  if (wt) {
+    const f32x4 t = {v.x, v.y, v.z, v.w};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(t) : "memory");
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+
 // predicated 16-byte load (the address is not touched when !ok)
 __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);

@@ -1,0 +1,708 @@
+// dec_persist.hip -- PERSISTENT pose-decoder rollout for the BASELINE shape (H = 64, D = 135, 2 GRU layers, B % 16 == 0,
+// B / 16 <= CU count): ONE launch for all T steps, forward; ONE launch for the whole BPTT, backward.
+//
+// Same arithmetic, same saved-for-backward arrays and the same C-ABI entry points (g2v_dec_rollout_fwd / _bwd pick this
+// path when the shape allows) as the one-launch-per-step kernels of dec_rollout.hip, which replace
+// model/Autoencoder_VQVAE_model.py:1039-1054 (the T-1 step loop) over Generator.forward (:646-683) ->
+// BahdanauAttnDecoderRNN.forward (:499-592).  See dec_persist.hpp for the design and the exchange protocol.
+//
+// Forward, per workgroup (16 batch rows, 4 waves; wave w owns hidden features 16w..16w+15):
+//   registers : W_ih0, W_hh0, W_ih1, W_hh1 as MFMA A fragments (4 x 48 VGPRs), u_{t+1} tile, gate pre-activations
+//   LDS       : W_out / W_pre fragments (48 + 36 KB), all biases, a_t, h0, h1, x1 tiles, the dense y tile, xin tile
+//   per step  : [hidden-side products W_hh0 h0, W_hh1 h1 -- independent of BatchNorm, they run while the exchange of the
+//               previous step's partial sums is in flight] -> exchange -> BN + ReLU -> cell 0 -> cell 1 -> out layer ->
+//               Dropout(0.95) -> pre_linear -> partial sums -> publish
+#include "dec_persist.hpp"
+
+namespace g2v {
+
+namespace {
+constexpr int H = 64, D = 135, Dp = 144, LDH = 68, LDD = 148;
+constexpr int KSH = 4, KSD = 9;               // k-steps over H and over the padded D
+constexpr int OUT_TILES = 12;                 // D tiles padded to 3 per wave (tiles 9..11 are zero and never multiplied)
+// LDS layout (floats)
+constexpr int L_XA = 0, L_XH0 = L_XA + 16 * LDH, L_XH1 = L_XH0 + 16 * LDH, L_XX1 = L_XH1 + 16 * LDH;
+constexpr int L_XY = L_XX1 + 16 * LDH;                    // xin_{t+1} tile [16][LDD]
+constexpr int L_YT = L_XY + 16 * LDD;                     // dense y tile [16 * D] (+ pad)
+constexpr int L_POUT = L_YT + 2176;                       // packed W_out: 12 tiles x 4 k-steps x 256
+constexpr int L_PPRE = L_POUT + OUT_TILES * KSH * 256;    // packed W_pre: 4 tiles x 9 k-steps x 256
+constexpr int L_BIAS = L_PPRE + 4 * KSD * 256;            // b_ih0 b_hh0 b_ih1 b_hh1 (192 each) b_out (144) b_pre bn_w bn_b (64 each)
+constexpr int L_ST = L_BIAS + 4 * 192 + 144 + 3 * 64;     // mean[64], invstd[64]
+constexpr int L_RED = L_ST + 128;                         // [16][128]
+constexpr int L_TOT = L_RED + 16 * 128;                   // [128]
+constexpr int L_END = L_TOT + 128;
+constexpr int B_IH0 = 0, B_HH0 = 192, B_IH1 = 384, B_HH1 = 576, B_OUT = 768, B_PRE = 912, B_BNW = 976, B_BNB = 1040;
+}  // namespace
+
+size_t dec_persist_fwd_lds_bytes() { return (size_t)L_END * sizeof(float); }
+
+struct DecPersistArgs {
+  const float* target;      // (B,T,D)
+  const float* h_init;      // (2,B,H)
+  g2v_dec_weights w;
+  // fragment-major packed weights (pack_kernel): pre (4 tiles x 9), ih0/hh0/ih1/hh1 (3 gates x 4 tiles x 4), out (12 tiles x 4)
+  const float* p_pre; const float* p_ih0; const float* p_hh0; const float* p_ih1; const float* p_hh1; const float* p_out;
+  g2v_dec_saved sv;
+  const uint8_t* keep95;    // (T-1,B,D)
+  const uint8_t* keep_l0;   // (T-1,B,H) or null
+  PersistX x;
+  int T, B, nblk, n_pre, conditioned, training;
+  float p_drop;
+};
+
+// A-operand fragments from LDS (conflict-free ds_read_b128: consecutive lanes read consecutive 16 bytes)
+template <int NT, int KS_T>
+__device__ __forceinline__ void lds_frag_mma(f32x4 (&acc)[NT], const float* P, int tile0, int tile_stride, const float* Xs,
+                                             int ldx, int lane) {
+  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) {
+    const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+    float4 wv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wv[t] = *reinterpret_cast<const float4*>(P + ((tile0 + t * tile_stride) * KS_T + s) * 256 + lane * 4);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t].x, xb.x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t].y, xb.y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t].z, xb.z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t].w, xb.w, acc[t]);
+  }
+}
+
+// Gate math of one GRU cell for the 4 consecutive features [f0, f0+4) of batch row i held by this lane.
+// Reads h_prev from Xh (own columns) and overwrites it IN PLACE with h_new (the next step's hidden-side operand);
+// Xnext gets the (optionally dropped) value the next layer consumes.  Global: h_out, gates (r,z,n,ghn), dropped copy.
+__device__ __forceinline__ void cell_epilogue(const f32x4 (&ai)[3], const f32x4 (&ah)[3], const float* bias_i,
+                                              const float* bias_h, uint32_t kp, bool drop, float keep_scale, float* Xh,
+                                              float* Xnext, float* __restrict__ h_out, float* __restrict__ gates,
+                                              float* __restrict__ xdrop_out, int i, int f0) {
+  const float4 hp4 = *reinterpret_cast<const float4*>(Xh + i * LDH + f0);
+  const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  float4 bi[3], bh[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    bi[g] = *reinterpret_cast<const float4*>(bias_i + g * H + f0);
+    bh[g] = *reinterpret_cast<const float4*>(bias_h + g * H + f0);
+  }
+  const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
+              bin[4] = {bi[2].x, bi[2].y, bi[2].z, bi[2].w};
+  const float bhr[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bhz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+              bhn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+  float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float rr = sigmoidf_((ai[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+    const float zz = sigmoidf_((ai[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+    const float ghn = ah[2][r] + bhn[r];
+    const float nn = tanhf_((ai[2][r] + bin[r]) + rr * ghn);
+    hn[r] = (1.0f - zz) * nn + zz * hp[r];
+    xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * keep_scale : 0.f) : hn[r];
+    gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+  }
+  *reinterpret_cast<float4*>(Xh + i * LDH + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  if (Xnext) *reinterpret_cast<float4*>(Xnext + i * LDH + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+  if (h_out) *reinterpret_cast<float4*>(h_out + (int64_t)i * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  if (xdrop_out) *reinterpret_cast<float4*>(xdrop_out + (int64_t)i * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+  if (gates) {
+    float* go = gates + (int64_t)i * 4 * H + f0;
+    *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+    *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+    *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+    *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xa = smem + L_XA;
+  float* Xh0 = smem + L_XH0;
+  float* Xh1 = smem + L_XH1;
+  float* Xx1 = smem + L_XX1;
+  float* Xy = smem + L_XY;
+  float* Yt = smem + L_YT;
+  float* Pout = smem + L_POUT;
+  float* Ppre = smem + L_PPRE;
+  float* Bs = smem + L_BIAS;
+  float* st = smem + L_ST;
+  float* red = smem + L_RED;
+  float* tot = smem + L_TOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, b0 = b * 16;
+  const int T = a.T, B = a.B;
+  const int f0 = 16 * wave + 4 * q;                  // this lane's 4 hidden features
+  const bool training = a.training != 0;
+  const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
+  const float keep_scale = 1.0f / (1.0f - a.p_drop);
+  const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
+
+  // ---- prologue: weights into registers / LDS ---------------------------------------------------------------------
+  WFrag<3, KSH> f_ih0, f_hh0, f_ih1, f_hh1;
+  frag_load(f_hh0, a.p_hh0, wave, 4, lane);
+  frag_load(f_hh1, a.p_hh1, wave, 4, lane);
+  frag_load(f_ih0, a.p_ih0, wave, 4, lane);
+  frag_load(f_ih1, a.p_ih1, wave, 4, lane);
+  for (int e = tid; e < OUT_TILES * KSH * 64; e += 256)
+    reinterpret_cast<float4*>(Pout)[e] = reinterpret_cast<const float4*>(a.p_out)[e];
+  for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Ppre)[e] = reinterpret_cast<const float4*>(a.p_pre)[e];
+  for (int e = tid; e < 192; e += 256) {
+    Bs[B_IH0 + e] = a.w.b_ih0[e]; Bs[B_HH0 + e] = a.w.b_hh0[e];
+    Bs[B_IH1 + e] = a.w.b_ih1[e]; Bs[B_HH1 + e] = a.w.b_hh1[e];
+  }
+  for (int e = tid; e < 144; e += 256) Bs[B_OUT + e] = e < D ? a.w.b_out[e] : 0.f;
+  if (tid < H) {
+    Bs[B_PRE + tid] = a.w.b_pre[tid];
+    Bs[B_BNW + tid] = a.w.bn_w[tid];
+    Bs[B_BNB + tid] = a.w.bn_b[tid];
+    if (!training) {
+      st[tid] = a.w.bn_running_mean[tid];
+      st[H + tid] = 1.0f / sqrtf(a.w.bn_running_var[tid] + 1e-5f);
+    }
+  }
+  // zero the padding columns of the operand tiles once (the live columns are rewritten every step)
+  for (int e = tid; e < 16 * (LDD - D); e += 256) Xy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
+  for (int e = tid; e < 4 * 16 * LDH; e += 256) smem[L_XA + e] = 0.f;
+  lds_barrier();
+  // initial state: h0_0, h1_0 = the quantised latent
+  {
+    const int r = tid >> 4, c = (tid & 15) * 4;
+    const float4 v0 = *reinterpret_cast<const float4*>(a.h_init + (int64_t)(b0 + r) * H + c);
+    const float4 v1 = *reinterpret_cast<const float4*>(a.h_init + BH + (int64_t)(b0 + r) * H + c);
+    *reinterpret_cast<float4*>(Xh0 + r * LDH + c) = v0;
+    *reinterpret_cast<float4*>(Xh1 + r * LDH + c) = v1;
+    if (a.sv.h0) *reinterpret_cast<float4*>(a.sv.h0 + (int64_t)(b0 + r) * H + c) = v0;
+    if (a.sv.h1) *reinterpret_cast<float4*>(a.sv.h1 + (int64_t)(b0 + r) * H + c) = v1;
+  }
+
+  f32x4 u_acc = {0.f, 0.f, 0.f, 0.f};      // u_{t+1}[row i][f0..f0+3] WITHOUT the bias (what the BN partial sums are taken of)
+
+  for (int t = 0; t < T; ++t) {
+    const bool has_next = t < T - 1;
+    if (t > 0) {
+      // ---- hidden-side products (independent of this step's BatchNorm): they fill the exchange's latency -----------
+      f32x4 gh0[3], gh1[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        gh0[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gh1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+      frag_mma(gh0, f_hh0, Xh0, LDH, lane);
+      frag_mma(gh1, f_hh1, Xh1, LDH, lane);
+      // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
+      if (training) {
+        px_exchange(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+        if (tid < H) {
+          const float s1 = tot[tid], s2 = tot[H + tid];
+          const float mv = s1 / (float)B;
+          const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);       // biased batch variance
+          const float mean = mv + Bs[B_PRE + tid];
+          st[tid] = mean;
+          st[H + tid] = 1.0f / sqrtf(var + 1e-5f);
+          if (b == 0 && a.sv.bn_stats) {
+            a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + tid] = mean;
+            a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + tid] = var;
+          }
+        }
+        lds_barrier();
+      }
+      // ---- a_t = ReLU(BN(u_t)) from the register-resident u tile ---------------------------------------------------
+      {
+        const float4 m4 = *reinterpret_cast<const float4*>(st + f0), i4 = *reinterpret_cast<const float4*>(st + H + f0);
+        const float4 g4 = *reinterpret_cast<const float4*>(Bs + B_BNW + f0), b4 = *reinterpret_cast<const float4*>(Bs + B_BNB + f0);
+        const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
+        float4 a4;
+        a4.x = fmaxf(((u_acc[0] + p4.x) - m4.x) * i4.x * g4.x + b4.x, 0.f);
+        a4.y = fmaxf(((u_acc[1] + p4.y) - m4.y) * i4.y * g4.y + b4.y, 0.f);
+        a4.z = fmaxf(((u_acc[2] + p4.z) - m4.z) * i4.z * g4.z + b4.z, 0.f);
+        a4.w = fmaxf(((u_acc[3] + p4.w) - m4.w) * i4.w * g4.w + b4.w, 0.f);
+        *reinterpret_cast<float4*>(Xa + i * LDH + f0) = a4;
+        if (a.sv.a) *reinterpret_cast<float4*>(a.sv.a + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = a4;
+      }
+      lds_barrier();
+      // ---- GRU layer 0 --------------------------------------------------------------------------------------------
+      {
+        uint32_t kp = 0x01010101u;
+        if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + i) * H + f0);
+        f32x4 ai[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        frag_mma(ai, f_ih0, Xa, LDH, lane);
+        cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
+                      a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                      a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                      (drop && a.sv.x1) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+      }
+      lds_barrier();
+      // ---- GRU layer 1 --------------------------------------------------------------------------------------------
+      {
+        f32x4 ai[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        frag_mma(ai, f_ih1, Xx1, LDH, lane);
+        cell_epilogue(ai, gh1, Bs + B_IH1, Bs + B_HH1, 0x01010101u, false, 1.0f, Xh1, nullptr,
+                      a.sv.h1 ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
+                      a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
+      }
+      lds_barrier();
+      // ---- y_t = out_layer(h1_t) -> dense tile --------------------------------------------------------------------
+      {
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave == 0) {
+          lds_frag_mma<3, KSH>(acc, Pout, wave, 4, Xh1, LDH, lane);
+        } else {                               // tiles 9..11 are padding: two tiles for waves 1..3
+          f32x4 a2[2] = {acc[0], acc[1]};
+          lds_frag_mma<2, KSH>(a2, Pout, wave, 4, Xh1, LDH, lane);
+          acc[0] = a2[0]; acc[1] = a2[1];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int d0 = 16 * (wave + 4 * j) + 4 * q;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (d0 + r < D) Yt[i * D + d0 + r] = acc[j][r] + Bs[B_OUT + d0 + r];
+        }
+      }
+      lds_barrier();
+    }
+    // ---- y_t out, next decoder input xin_{t+1} = Dropout(0.95)(y_t | target_t)  (:1049-1052, :568-570) --------------
+    {
+      const int64_t tile = ((int64_t)t * B + b0) * D;        // the block's 16 x D tile is one dense run of the (T,B,D) arrays
+      const bool teacher = has_next && (t < a.n_pre);
+      const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
+      for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+        const int e = 4 * e4;
+        float yv[4], sv_[4];
+        if (t == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int r = (e + j) / D, c = (e + j) - r * D;
+            yv[j] = a.target[((int64_t)(b0 + r) * T) * D + c];         // y_0 = target frame 0 (:1039-1040)
+          }
+        } else {
+          const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
+          yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+        }
+        *reinterpret_cast<float4*>(a.sv.y + tile + e) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        if (!has_next) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          sv_[j] = yv[j];
+          if (teacher && t > 0) {
+            const int r = (e + j) / D, c = (e + j) - r * D;
+            sv_[j] = a.target[((int64_t)(b0 + r) * T + t) * D + c];
+          }
+        }
+        const uint32_t k4 = a.conditioned ? kp4[e4] : 0u;
+        float xv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;     // 1 / (1 - 0.95)
+        if (a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + e) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int r = (e + j) / D, c = (e + j) - r * D;
+          Xy[r * LDD + c] = xv[j];
+        }
+      }
+    }
+    if (!has_next) break;
+    lds_barrier();
+    // ---- u_{t+1} = pre_linear.0(xin_{t+1}); partial sums of (u - b) over this block's 16 rows; publish -----------------
+    {
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      lds_frag_mma<1, KSD>(acc, Ppre, wave, 0, Xy, LDD, lane);
+      u_acc = acc[0];
+      const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
+      if (a.sv.u)
+        *reinterpret_cast<float4*>(a.sv.u + ((int64_t)t * B + b0 + i) * H + f0) =
+            make_float4(u_acc[0] + p4.x, u_acc[1] + p4.y, u_acc[2] + p4.z, u_acc[3] + p4.w);
+      if (training) {
+        float s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          s1[r] = reduce16(u_acc[r]);
+          s2[r] = reduce16(u_acc[r] * u_acc[r]);
+        }
+        if (i == 0) {
+          const int par = (t + 1) & 1;
+          __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+              a.x.rec1 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0, PX_COLS * 8, 0x00020000);
+          const unsigned tag = (unsigned)(t + 1);
+          px_publish2(rr, (unsigned)f0, s1[0], s1[1], tag);
+          px_publish2(rr, (unsigned)f0 + 2, s1[2], s1[3], tag);
+          px_publish2(rr, (unsigned)(H + f0), s2[0], s2[1], tag);
+          px_publish2(rr, (unsigned)(H + f0) + 2, s2[2], s2[3], tag);
+        }
+      }
+    }
+    // (no barrier needed here: the next writers of Xy / Yt sit behind the barriers of step t+1)
+  }
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+// Host side: called by g2v_dec_rollout_fwd (dec_rollout.hip) when the persistent path applies.  `packed` points at the
+// six fragment-major matrices in the order pre, ih0, hh0, ih1, hh1, out; `xbase` at PX_BYTES of exchange state.
+int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
+                           const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
+                           int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
+                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st) {
+  DecPersistArgs a;
+  a.target = target; a.h_init = h_init; a.w = *w;
+  a.p_pre = p_pre; a.p_ih0 = p_ih0; a.p_hh0 = p_hh0; a.p_ih1 = p_ih1; a.p_hh1 = p_hh1; a.p_out = p_out;
+  a.sv = *s; a.keep95 = keep95; a.keep_l0 = keep_l0;
+  a.x = persist_x_at(xbase);
+  a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
+  a.p_drop = p_drop;
+  const size_t lds = dec_persist_fwd_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)dec_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("dec_persist_fwd: cannot reserve %zu bytes of LDS", lds);
+      return G2V_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  if (training) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);       // every polled word, every call (tags count steps 1..T)
+  hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("dec_persist_fwd: launch failed");
+    return G2V_ERR_LAUNCH;
+  }
+  return G2V_OK;
+}
+
+// =====================================================================================================================
+// backward (BPTT of the rollout), one persistent launch.  Per workgroup (16 rows; wave w owns hidden features 16w..16w+15):
+//   registers : W_ih0^T, W_hh0^T, W_ih1^T, W_hh1^T fragments (contraction over the 3H gate axis: 4 x 48 VGPRs), the two
+//               hidden-state gradient carries, dbn_t / xhat_t of the step whose BatchNorm-backward sums are in flight
+//   LDS       : W_pre^T (D rows) and W_out^T (K = D) fragments, du, dy, the gate-gradient tile [g_r | g_z | g_n | g_hn]
+//   per step t: [exchange of the BatchNorm-backward sums of step t+1] -> du_{t+1} -> feedback dxin = du W_pre through
+//               Dropout(0.95) into dy_t -> out_layer^T -> cell 1 backward -> cell 0 backward -> ReLU backward ->
+//               partial sums (sum dbn, sum dbn * xhat) over the block's rows -> publish
+// Produces exactly the arrays the per-step kernels produce (du, dy total, dgi/dgh of both cells, d_bn_w/b, dh_init);
+// the dbn scratch array is not needed (the values stay in registers).
+// =====================================================================================================================
+namespace g2v {
+namespace {
+constexpr int LDG = 4 * H + 4;                             // gate-gradient tile row stride
+constexpr int KSG = 12;                                    // k-steps over 3H
+constexpr int R_XDU = 0, R_XDY = R_XDU + 16 * LDH, R_G = R_XDY + 16 * LDD, R_DT = R_G + 16 * LDG, R_KT = R_DT + 2176;
+constexpr int R_PPRET = R_KT + 544;                        // packed W_pre^T: 12 tiles (d) x 4 k-steps (f)
+constexpr int R_POUTT = R_PPRET + OUT_TILES * KSH * 256;   // packed W_out^T: 4 tiles (f) x 9 k-steps (d)
+constexpr int R_BNW = R_POUTT + 4 * KSD * 256;
+constexpr int R_RED = R_BNW + 64;
+constexpr int R_TOT = R_RED + 16 * 128;
+constexpr int R_END = R_TOT + 128;
+}  // namespace
+
+size_t dec_persist_bwd_lds_bytes() { return (size_t)R_END * sizeof(float); }
+
+struct DecPersistBwdArgs {
+  g2v_dec_weights w;
+  const float* p_pre_t; const float* p_out_t; const float* p_ih0_t; const float* p_hh0_t; const float* p_ih1_t; const float* p_hh1_t;
+  g2v_dec_saved sv;
+  g2v_dec_grads gr;
+  const uint8_t* keep95; const uint8_t* keep_l0;
+  PersistX x;
+  int T, B, nblk, n_pre, conditioned;
+  float p_drop;
+};
+
+// one 16-feature output tile, contraction over the gate axis of the merged tile [g_r | g_z | g_n | g_hn]:
+// HH == false: columns 0..191 (g_r, g_z, g_n);  HH == true: g_r, g_z, g_hn (k-steps 8..11 read columns 192..255)
+template <bool HH>
+__device__ __forceinline__ void gate_frag_mma(f32x4& acc, const WFrag<1, KSG>& f, const float* G, int lane) {
+  const float* xrow = G + (lane & 15) * LDG + 4 * (lane >> 4);
+#pragma unroll
+  for (int s = 0; s < KSG; ++s) {
+    const int col = 16 * s + ((HH && s >= 8) ? 64 : 0);
+    const float4 xb = *reinterpret_cast<const float4*>(xrow + col);
+    acc = mfma16(f.w[0][s].x, xb.x, acc);
+    acc = mfma16(f.w[0][s].y, xb.y, acc);
+    acc = mfma16(f.w[0][s].z, xb.z, acc);
+    acc = mfma16(f.w[0][s].w, xb.w, acc);
+  }
+}
+
+struct CellSaved {      // this lane's slice of what the forward saved for one cell and step
+  float4 r, z, n, hn, hp;
+};
+__device__ __forceinline__ void load_cell(CellSaved& c, const float* __restrict__ gates, const float* __restrict__ hprev,
+                                          int64_t row, int f0) {
+  const float* go = gates + row * 4 * H + f0;
+  c.r = *reinterpret_cast<const float4*>(go);
+  c.z = *reinterpret_cast<const float4*>(go + H);
+  c.n = *reinterpret_cast<const float4*>(go + 2 * H);
+  c.hn = *reinterpret_cast<const float4*>(go + 3 * H);
+  c.hp = *reinterpret_cast<const float4*>(hprev + row * H + f0);
+}
+
+// GRU cell backward for this lane's (row, 4 features): dh = incoming gradient (already incl. carry).  Writes the gate
+// gradients to the global dgi / dgh rows and to the LDS tile; returns direct = dh * z (the path to h_{t-1}).
+__device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved& c, float* __restrict__ dgi,
+                                           float* __restrict__ dgh, float* G, int i, int f0) {
+  const float rr[4] = {c.r.x, c.r.y, c.r.z, c.r.w}, zz[4] = {c.z.x, c.z.y, c.z.z, c.z.w}, nn[4] = {c.n.x, c.n.y, c.n.z, c.n.w},
+              gh[4] = {c.hn.x, c.hn.y, c.hn.z, c.hn.w}, hp[4] = {c.hp.x, c.hp.y, c.hp.z, c.hp.w};
+  float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float dn = dh[r] * (1.0f - zz[r]);
+    const float dz = dh[r] * (hp[r] - nn[r]);
+    const float dnp = dn * (1.0f - nn[r] * nn[r]);
+    g_n[r] = dnp;
+    g_hn[r] = dnp * rr[r];
+    g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+    g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+    direct[r] = dh[r] * zz[r];
+  }
+  const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+               vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+  *reinterpret_cast<float4*>(dgi) = vr; *reinterpret_cast<float4*>(dgi + H) = vz; *reinterpret_cast<float4*>(dgi + 2 * H) = vn;
+  *reinterpret_cast<float4*>(dgh) = vr; *reinterpret_cast<float4*>(dgh + H) = vz; *reinterpret_cast<float4*>(dgh + 2 * H) = vh;
+  float* g = G + i * LDG + f0;
+  *reinterpret_cast<float4*>(g) = vr;
+  *reinterpret_cast<float4*>(g + H) = vz;
+  *reinterpret_cast<float4*>(g + 2 * H) = vn;
+  *reinterpret_cast<float4*>(g + 3 * H) = vh;
+  return make_float4(direct[0], direct[1], direct[2], direct[3]);
+}
+
+__global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xdu = smem + R_XDU;
+  float* Xdy = smem + R_XDY;
+  float* Gt = smem + R_G;
+  float* Dt = smem + R_DT;
+  uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + R_KT);
+  float* Ppre_t = smem + R_PPRET;
+  float* Pout_t = smem + R_POUTT;
+  float* bnw = smem + R_BNW;
+  float* red = smem + R_RED;
+  float* tot = smem + R_TOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x, b0 = b * 16;
+  const int T = a.T, B = a.B, G3 = 3 * H;
+  const int f0 = 16 * wave + 4 * q;
+  const bool drop = a.keep_l0 && a.p_drop > 0.f;
+  const float keep_scale = 1.0f / (1.0f - a.p_drop);
+  const float invB = 1.0f / (float)B;
+  const int64_t row_i = b0 + i;
+
+  WFrag<1, KSG> f_ih0, f_hh0, f_ih1, f_hh1;
+  frag_load(f_hh1, a.p_hh1_t, wave, 0, lane);
+  frag_load(f_ih1, a.p_ih1_t, wave, 0, lane);
+  frag_load(f_hh0, a.p_hh0_t, wave, 0, lane);
+  frag_load(f_ih0, a.p_ih0_t, wave, 0, lane);
+  for (int e = tid; e < OUT_TILES * KSH * 64; e += 256)
+    reinterpret_cast<float4*>(Ppre_t)[e] = reinterpret_cast<const float4*>(a.p_pre_t)[e];
+  for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Pout_t)[e] = reinterpret_cast<const float4*>(a.p_out_t)[e];
+  if (tid < H) bnw[tid] = a.w.bn_w[tid];
+  for (int e = tid; e < 16 * LDH; e += 256) Xdu[e] = 0.f;
+  for (int e = tid; e < 16 * (LDD - D); e += 256) Xdy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
+  lds_barrier();
+
+  float4 carry0 = make_float4(0.f, 0.f, 0.f, 0.f), carry1 = carry0;   // d h0 / d h1 flowing to the earlier step
+  float dbn[4] = {0.f, 0.f, 0.f, 0.f}, xhat[4] = {0.f, 0.f, 0.f, 0.f}, gis[4] = {0.f, 0.f, 0.f, 0.f};   // of the step in flight
+  float acc_w = 0.f, acc_b = 0.f;                                       // d gamma / d beta (workgroup 0, tid < H)
+
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = (t == T - 1);
+    const bool feedback = !last && a.conditioned && (t >= a.n_pre);
+    // ---- this step's saved values: requested before the exchange so that they arrive while it is in flight ------------
+    CellSaved c1, c0;
+    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), u4 = a4, mean4 = a4, var4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    uint32_t kl0 = 0x01010101u;
+    float4 dyt[3];
+    uint32_t k95[3] = {0u, 0u, 0u};
+    const int64_t tile = ((int64_t)t * B + b0) * D;
+    if (t > 0) {
+      const int64_t row = (int64_t)(t - 1) * B + row_i;
+      load_cell(c1, a.sv.gates1, a.sv.h1, row, f0);
+      load_cell(c0, a.sv.gates0, a.sv.h0, row, f0);
+      a4 = *reinterpret_cast<const float4*>(a.sv.a + row * H + f0);
+      u4 = *reinterpret_cast<const float4*>(a.sv.u + row * H + f0);
+      mean4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + f0);
+      var4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + H + f0);
+      if (drop) kl0 = *reinterpret_cast<const uint32_t*>(a.keep_l0 + row * H + f0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e4 = tid + 256 * j;
+        const int ec = e4 < (16 * D) / 4 ? e4 : 0;
+        dyt[j] = *reinterpret_cast<const float4*>(a.gr.dy + tile + 4 * (int64_t)ec);
+        if (feedback) k95[j] = reinterpret_cast<const uint32_t*>(a.keep95 + tile)[ec];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- Part A: finish BatchNorm backward of step t+1 -> du_{t+1} --------------------------------------------------------
+    if (!last) {
+      px_exchange(a.x, (t + 1) & 1, (unsigned)(T - 1 - t), a.nblk, b, red, tot, tid);
+      const float4 s14 = *reinterpret_cast<const float4*>(tot + f0), s24 = *reinterpret_cast<const float4*>(tot + H + f0);
+      const float a1[4] = {s14.x, s14.y, s14.z, s14.w}, a2[4] = {s24.x, s24.y, s24.z, s24.w};
+      float du[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) du[r] = gis[r] * (dbn[r] - a1[r] * invB - xhat[r] * a2[r] * invB);
+      const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
+      *reinterpret_cast<float4*>(a.gr.du + ((int64_t)t * B + row_i) * H + f0) = du4;
+      *reinterpret_cast<float4*>(Xdu + i * LDH + f0) = du4;
+      if (b == 0 && tid < H) {           // d gamma / d beta accumulate over the steps in step order
+        acc_w += tot[H + tid];
+        acc_b += tot[tid];
+      }
+    }
+    if (t == 0) break;                   // only the BatchNorm finish of step 1 was left (y_0 is data)
+    // ---- Part B: dy_t (loss gradient + feedback through Dropout(0.95) and pre_linear) -------------------------------------
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e4 = tid + 256 * j;
+      if (e4 < (16 * D) / 4) {
+        reinterpret_cast<float4*>(Dt)[e4] = dyt[j];
+        Kt[e4] = k95[j];
+      }
+    }
+    lds_barrier();                       // Xdu, Dt, Kt complete
+    {
+      f32x4 acc[3];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (feedback) {
+        if (wave == 0) {
+          lds_frag_mma<3, KSH>(acc, Ppre_t, wave, 4, Xdu, LDH, lane);
+        } else {
+          f32x4 a2[2] = {acc[0], acc[1]};
+          lds_frag_mma<2, KSH>(a2, Ppre_t, wave, 4, Xdu, LDH, lane);
+          acc[0] = a2[0]; acc[1] = a2[1];
+        }
+      }
+      const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int d0 = 16 * (wave + 4 * j) + 4 * q;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = d0 + r;
+          if (d < D) {
+            float dy = Dt[i * D + d];
+            if (feedback && Kb[i * D + d]) dy += acc[j][r] * 20.0f;
+            Dt[i * D + d] = dy;
+            Xdy[i * LDD + d] = dy;
+          }
+        }
+      }
+    }
+    lds_barrier();
+    if (feedback)
+      for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256)
+        *reinterpret_cast<float4*>(a.gr.dy + tile + 4 * (int64_t)e4) = reinterpret_cast<const float4*>(Dt)[e4];
+    // ---- dh1 = carry1 + dy W_out ; GRU cell 1 backward ---------------------------------------------------------------------
+    float4 direct1;
+    {
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      lds_frag_mma<1, KSD>(acc, Pout_t, wave, 0, Xdy, LDD, lane);
+      const float dh[4] = {acc[0][0] + carry1.x, acc[0][1] + carry1.y, acc[0][2] + carry1.z, acc[0][3] + carry1.w};
+      const int64_t row = (int64_t)(t - 1) * B + row_i;
+      direct1 = cell_bwd(dh, c1, a.gr.dgi1 + row * G3 + f0, a.gr.dgh1 + row * G3 + f0, Gt, i, f0);
+    }
+    lds_barrier();
+    // ---- carry1' = dh1 * z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout backward) -------------------------
+    float dh0[4];
+    {
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+      gate_frag_mma<true>(a1, f_hh1, Gt, lane);
+      gate_frag_mma<false>(a2, f_ih1, Gt, lane);
+      carry1 = make_float4(direct1.x + a1[0], direct1.y + a1[1], direct1.z + a1[2], direct1.w + a1[3]);
+      const float c0v[4] = {carry0.x, carry0.y, carry0.z, carry0.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = a2[r];
+        if (drop) v = ((kl0 >> (8 * r)) & 0xffu) ? v * keep_scale : 0.f;
+        dh0[r] = v + c0v[r];
+      }
+    }
+    lds_barrier();                       // every wave is done reading the cell-1 tile
+    // ---- GRU cell 0 backward ---------------------------------------------------------------------------------------------
+    float4 direct0;
+    {
+      const int64_t row = (int64_t)(t - 1) * B + row_i;
+      direct0 = cell_bwd(dh0, c0, a.gr.dgi0 + row * G3 + f0, a.gr.dgh0 + row * G3 + f0, Gt, i, f0);
+    }
+    lds_barrier();
+    // ---- carry0' = dh0 * z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU backward -> dbn_t, partial sums, publish -----------------
+    {
+      f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
+      gate_frag_mma<true>(a1, f_hh0, Gt, lane);
+      gate_frag_mma<false>(a2, f_ih0, Gt, lane);
+      carry0 = make_float4(direct0.x + a1[0], direct0.y + a1[1], direct0.z + a1[2], direct0.w + a1[3]);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, mv[4] = {mean4.x, mean4.y, mean4.z, mean4.w},
+                  vv[4] = {var4.x, var4.y, var4.z, var4.w};
+      const float4 g4 = *reinterpret_cast<const float4*>(bnw + f0);
+      const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+      float s1[4], s2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        dbn[r] = (av[r] > 0.f) ? a2[r] : 0.f;
+        xhat[r] = (uv[r] - mv[r]) * invstd;
+        gis[r] = gg[r] * invstd;
+        s1[r] = reduce16(dbn[r]);
+        s2[r] = reduce16(dbn[r] * xhat[r]);
+      }
+      if (i == 0) {
+        const int par = t & 1;
+        __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+            a.x.rec1 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0, PX_COLS * 8, 0x00020000);
+        const unsigned tag = (unsigned)(T - t);
+        px_publish2(rr, (unsigned)f0, s1[0], s1[1], tag);
+        px_publish2(rr, (unsigned)f0 + 2, s1[2], s1[3], tag);
+        px_publish2(rr, (unsigned)(H + f0), s2[0], s2[1], tag);
+        px_publish2(rr, (unsigned)(H + f0) + 2, s2[2], s2[3], tag);
+      }
+    }
+  }
+  // gradient wrt the initial hidden state (the quantised latent) and the BatchNorm affine parameters
+  *reinterpret_cast<float4*>(a.gr.dh_init + row_i * H + f0) = carry0;
+  *reinterpret_cast<float4*>(a.gr.dh_init + ((int64_t)B + row_i) * H + f0) = carry1;
+  if (b == 0 && tid < H) {
+    a.gr.d_bn_w[tid] = acc_w;
+    a.gr.d_bn_b[tid] = acc_b;
+  }
+}
+
+}  // namespace g2v
+
+int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
+                           const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
+                           const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st) {
+  DecPersistBwdArgs a;
+  a.w = *w; a.sv = *s; a.gr = *g;
+  a.p_pre_t = p_pre_t; a.p_out_t = p_out_t; a.p_ih0_t = p_ih0_t; a.p_hh0_t = p_hh0_t; a.p_ih1_t = p_ih1_t; a.p_hh1_t = p_hh1_t;
+  a.keep95 = keep95; a.keep_l0 = keep_l0;
+  a.x = persist_x_at(xbase);
+  a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.p_drop = p_drop;
+  const size_t lds = dec_persist_bwd_lds_bytes();
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)dec_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      set_error("dec_persist_bwd: cannot reserve %zu bytes of LDS", lds);
+      return G2V_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
+  hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("dec_persist_bwd: launch failed");
+    return G2V_ERR_LAUNCH;
+  }
+  return G2V_OK;
+}

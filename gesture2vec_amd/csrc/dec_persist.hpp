@@ -1,0 +1,139 @@
+// dec_persist.hpp -- shared pieces of the PERSISTENT decoder rollout kernels (dec_persist.hip) and their launcher
+// hooks in dec_rollout.hip.
+//
+// Why a persistent kernel: with one launch per time step (dec_rollout.hip) every workgroup re-streams 276 KB of weight
+// fragments and its state rows from L2 at every step, pays a kernel boundary plus the write-back of ~18 MB of dirty
+// lines, and ramps up from cold registers -- 16.4 / 21.9 us per forward / backward step against a 3.5 us MFMA floor.
+// Here one workgroup per 16 batch rows stays resident for all T steps with the four GRU matrices in registers
+// (192 VGPRs per lane), the out / pre_linear matrices and every bias in LDS, and the recurrent state in LDS.
+// What remains per step is BatchNorm1d's batch statistics: a grid-wide sum of 128 floats per workgroup.
+//
+// The exchange (measured on MI355X with gpurun_tools/exchange_bench.hip before this was written):
+//   * agent-scope (sc1) loads are served at the fabric, not by the XCD's L2: a flat all-to-all in which every workgroup
+//     reads all 256 records (32 MB of sc1 loads per step) costs ~10 us, and so does any scheme in which all 256
+//     workgroups read the SAME lines (one line serves ~1 request per 10 ns chip-wide);
+//   * so the sum runs as a fixed two-level tree of groups of 16 workgroups with 8-byte self-validating granules
+//     {value, tag = step} (MI355X_MICROARCH.md "R2": one aligned 8-byte sc1 store is observed untorn, no flag, no fence,
+//     no release): members publish 128 granules, the group's first workgroup sums its 16 records and publishes the
+//     group record ONCE PER READING GROUP (16 replicas: a line is then read by 16 workgroups, not 256), everybody sums
+//     the <= 16 group records of its own replica set.  Summation order is fixed -> bitwise reproducible.
+//   * records are double-buffered by step parity: a workgroup can only publish step s+1 after it has consumed every
+//     group record of step s, which exist only after every workgroup has published step s, i.e. finished reading s-1.
+//   * every polled word is zeroed by a memset node in front of the launch; tags count steps inside the call (1..T).
+//   * all workgroups must be co-resident: the launcher admits the path only when nblk <= the device's CU count and the
+//     kernel needs one workgroup per CU (256 threads, <= 512 VGPRs, ~135 KB LDS); every spin is bounded and traps.
+#pragma once
+#include "common.hpp"
+
+namespace g2v {
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PX_GROUP = 16;          // workgroups per exchange group
+constexpr int PX_MAX_NBLK = 256;      // one workgroup per CU on MI355X
+constexpr int PX_COLS = 128;          // floats per record (2 x H, H = 64)
+constexpr size_t PX_REC1_BYTES = (size_t)2 * PX_MAX_NBLK * PX_COLS * 8;
+constexpr int PX_MAX_GRP = PX_MAX_NBLK / PX_GROUP;
+constexpr size_t PX_REC2_BYTES = (size_t)2 * PX_MAX_GRP * PX_MAX_GRP * PX_COLS * 8;   // [parity][reading group][source group]
+constexpr size_t PX_BYTES = PX_REC1_BYTES + PX_REC2_BYTES;     // 1 MiB: a multiple of 16 (memset price, Guideline 16)
+
+struct PersistX {
+  unsigned long long* rec1;   // [2][PX_MAX_NBLK][128] granules {value (low dword), tag (high dword)}
+  unsigned long long* rec2;   // [2][PX_MAX_GRP (reader)][PX_MAX_GRP (source)][128]
+};
+static inline PersistX persist_x_at(void* base) {
+  PersistX x;
+  x.rec1 = reinterpret_cast<unsigned long long*>(base);
+  x.rec2 = x.rec1 + (size_t)2 * PX_MAX_NBLK * PX_COLS;
+  return x;
+}
+
+__device__ __forceinline__ u32x4 px_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 16);      // aux 16 = sc1 (agent scope, bypasses L1)
+}
+__device__ __forceinline__ void px_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);          // write-through
+}
+
+// Publish two values as two granules with ONE 16-byte store (each 8-byte half is self-validating).
+__device__ __forceinline__ void px_publish2(__amdgpu_buffer_rsrc_t r, unsigned granule, float v0, float v1, unsigned tag) {
+  u32x4 g;
+  g[0] = __float_as_uint(v0); g[1] = tag;
+  g[2] = __float_as_uint(v1); g[3] = tag;
+  px_st(r, granule * 8u, g);
+}
+
+// Column sums of `n` (<= 16) records of 128 granules each -> tot[128] (LDS), by all 256 threads, fixed order.
+// Thread (m = tid >> 4, c = tid & 15) owns granule pairs c, c+16, c+32, c+48 of record m and re-reads the ones whose
+// tag is stale.  red: LDS [16][128].  Ends with a barrier; tot is valid for every thread afterwards.
+__device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int n, unsigned tag, float* red, float* tot,
+                                             int tid) {
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(base), 0,
+                                                                n * PX_COLS * 8, 0x00020000);
+  const int m = tid >> 4, c = tid & 15;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (m < n) {
+    u32x4 g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = px_ld(rr, (unsigned)((m * PX_COLS + 2 * (c + 16 * k)) * 8));
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) ok &= (g[k][1] == tag) && (g[k][3] == tag);
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (g[k][1] != tag || g[k][3] != tag) g[k] = px_ld(rr, (unsigned)((m * PX_COLS + 2 * (c + 16 * k)) * 8));
+      if (++spins > 4000000u) __builtin_trap();      // a workgroup of this launch is not resident / died: fail loudly
+    }
+    // NB: copy the vector elements to scalars first.  `__builtin_bit_cast(float, g[k][2])` straight on an ext-vector
+    // element is compiled by ROCm 7.2's clang as a cast of ELEMENT 0 (seen in the IR: both floats come from lane 0 of
+    // the vector) -- every odd column of the sums silently became a copy of its even neighbour.
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const unsigned lo = g[k][0], hi = g[k][2];
+      v[2 * k] = __uint_as_float(lo);
+      v[2 * k + 1] = __uint_as_float(hi);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    *reinterpret_cast<float2*>(red + m * PX_COLS + 2 * (c + 16 * k)) = make_float2(v[2 * k], v[2 * k + 1]);
+  lds_barrier();
+  if (tid < PX_COLS) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g * PX_COLS + tid];
+    tot[tid] = t;
+  }
+  lds_barrier();
+}
+
+// The whole exchange of one step for workgroup b: this workgroup's 128 partial sums were already published into
+// rec1[par][b] (px_publish2 from the producing lanes).  On return tot[128] holds the sums over all nblk workgroups.
+__device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot,
+                                            int tid) {
+  const int ngrp = (nblk + PX_GROUP - 1) / PX_GROUP;
+  const int grp = b / PX_GROUP;
+  unsigned long long* r2 = x.rec2 + (size_t)par * PX_MAX_GRP * PX_MAX_GRP * PX_COLS;
+  if (b == grp * PX_GROUP) {
+    const int n = min(PX_GROUP, nblk - grp * PX_GROUP);
+    px_sweep_sum(x.rec1 + ((size_t)par * PX_MAX_NBLK + (size_t)grp * PX_GROUP) * PX_COLS, n, tag, red, tot, tid);
+    {   // one copy of the group record per reading group: thread (pair = tid & 63, replicas tid >> 6, +4, +8, +12)
+      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(r2, 0, PX_MAX_GRP * PX_MAX_GRP * PX_COLS * 8, 0x00020000);
+      const int pair = tid & 63;
+      const float v0 = tot[2 * pair], v1 = tot[2 * pair + 1];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int r = (tid >> 6) + 4 * k;
+        if (r < ngrp) px_publish2(rr, (unsigned)((r * PX_MAX_GRP + grp) * PX_COLS + 2 * pair), v0, v1, tag);
+      }
+    }
+    lds_barrier();     // tot is rewritten by the second sweep: every reader above is done
+  }
+  px_sweep_sum(r2 + (size_t)grp * PX_MAX_GRP * PX_COLS, ngrp, tag, red, tot, tid);
+}
+
+}  // namespace g2v

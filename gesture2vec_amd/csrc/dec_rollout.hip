@@ -17,9 +17,39 @@
 //
 // 16 batch rows per 256-thread workgroup; all contractions are v_mfma_f32_16x16x4_f32 with the
 // activations staged in LDS (B operand) and the weights streamed from L2 as A fragments.
-#include "common.hpp"
+#include <stdlib.h>
+
+#include "dec_persist.hpp"
+
+// dec_persist.hip
+int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
+                           const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
+                           int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
+                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st);
+int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
+                           const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
+                           const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st);
 
 namespace g2v {
+
+// The persistent path needs every workgroup of its launch resident at once: one per CU.
+static int device_cu_count() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  }
+  return n;
+}
+static int g_persist = -1;     // -1: not decided yet (environment G2V_NO_PERSIST=1 disables), 0 / 1: set
+static bool persist_enabled() {
+  if (g_persist < 0) {
+    const char* e = getenv("G2V_NO_PERSIST");
+    g_persist = (e && e[0] == '1') ? 0 : 1;
+  }
+  return g_persist != 0;
+}
 
 #ifdef G2V_STAMPS
 __device__ unsigned long long g2v_stamps[64 * 16];
@@ -47,7 +77,16 @@ struct DecDims {
   int T, B, D, H;
   float p_drop;
   int n_pre, conditioned, training, nblk;
+  int wt;   // write-through (sc1) stores for the arrays only later kernels read (see st4 in common.hpp)
 };
+static int dec_wt_stores() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("G2V_PLAIN_STORES");
+    v = (e && e[0] == '1') ? 0 : 1;
+  }
+  return v;
+}
 
 // packed forward weights (fragment-major, see common.hpp): offsets in floats into the workspace
 struct DecPackF {
@@ -61,7 +100,8 @@ __device__ __forceinline__ void gru_cell_fwd_epilogue(const f32x4 (&ai)[3], cons
                                                       const float4 (&bh)[3], uint32_t kp, bool keep, float keep_scale,
                                                       const float* Xh, int ldh, int H, float* Hnext_lds,
                                                       float* __restrict__ h_out, float* __restrict__ gates,
-                                                      float* __restrict__ xdrop_out, int nrows, int i, int f0) {
+                                                      float* __restrict__ xdrop_out, int nrows, int i, int f0,
+                                                      bool wt = false) {
   const float4 hp4 = *reinterpret_cast<const float4*>(Xh + i * ldh + f0);
   const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
   const float bir[4] = {bi[0].x, bi[0].y, bi[0].z, bi[0].w}, biz[4] = {bi[1].x, bi[1].y, bi[1].z, bi[1].w},
@@ -82,13 +122,13 @@ __device__ __forceinline__ void gru_cell_fwd_epilogue(const f32x4 (&ai)[3], cons
   *reinterpret_cast<float4*>(Hnext_lds + i * ldh + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
   if (i < nrows) {
     *reinterpret_cast<float4*>(h_out + (int64_t)i * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-    if (xdrop_out) *reinterpret_cast<float4*>(xdrop_out + (int64_t)i * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+    if (xdrop_out) st4(xdrop_out + (int64_t)i * H + f0, make_float4(xd[0], xd[1], xd[2], xd[3]), wt);
     if (gates) {
       float* go = gates + (int64_t)i * 4 * H + f0;
-      *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
-      *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
-      *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
-      *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+      st4(go, make_float4(gr_[0], gr_[1], gr_[2], gr_[3]), wt);
+      st4(go + H, make_float4(gz_[0], gz_[1], gz_[2], gz_[3]), wt);
+      st4(go + 2 * H, make_float4(gn_[0], gn_[1], gn_[2], gn_[3]), wt);
+      st4(go + 3 * H, make_float4(gh_[0], gh_[1], gh_[2], gh_[3]), wt);
     }
   }
 }
@@ -340,7 +380,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
           *reinterpret_cast<float4*>(Xh0 + pr * ldh + pc) = ph0;
           *reinterpret_cast<float4*>(Xh1 + pr * ldh + pc) = ph1;
         }
-        if (sv.a) *reinterpret_cast<float4*>(sv.a + ((int64_t)(t - 1) * B + b0 + pr) * H + pc) = a4;
+        if (sv.a) st4(sv.a + ((int64_t)(t - 1) * B + b0 + pr) * H + pc, a4, dm.wt != 0);
       }
     } else {
       for (int e = tid; e < 16 * H; e += 256) {
@@ -374,7 +414,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       gru_cell_fwd_epilogue(ai, gh0, bi0, bh0, kp, kl0 != nullptr, 1.0f / (1.0f - dm.p_drop), Xh0, ldh, H, Xx1,
                             sv.h0 + ((int64_t)t * B + b0) * H,
                             sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
-                            (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, i, f0);
+                            (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, i, f0, dm.wt != 0);
       lds_barrier();
       STAMP(4);
 #pragma unroll
@@ -382,7 +422,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       frag_mma_pf(ai, f_ih1, Xx1, ldh, lane, f_pre, pk.pre, wave, 0, has_next);      // pre_linear fragments ride along
       gru_cell_fwd_epilogue(ai, gh1, bi1, bh1, 0x01010101u, false, 1.0f, Xh1, ldh, H, Xh1n,
                             sv.h1 + ((int64_t)t * B + b0) * H,
-                            sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, nrows, i, f0);
+                            sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, nrows, i, f0, dm.wt != 0);
       lds_barrier();
       STAMP(5);
     } else {
@@ -447,7 +487,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     int jj = 0;
     for (int e4 = tid; e4 < n4; e4 += 256, ++jj) {
       const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
-      reinterpret_cast<float4*>(sv.y + tile)[e4] = y4;
+      st4(sv.y + tile + 4 * (int64_t)e4, y4, dm.wt != 0);
       if (has_next) {
         uint32_t k4;
         if constexpr (FASTC) {
@@ -462,7 +502,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         x4.y = (k4 & 0xff00u) ? y4.y * 20.0f : 0.f;
         x4.z = (k4 & 0xff0000u) ? y4.z * 20.0f : 0.f;
         x4.w = (k4 & 0xff000000u) ? y4.w * 20.0f : 0.f;
-        if (sv.xin) reinterpret_cast<float4*>(sv.xin + tile)[e4] = x4;
+        if (sv.xin) st4(sv.xin + tile + 4 * (int64_t)e4, x4, dm.wt != 0);
         const int e = 4 * e4;
         const float xv[4] = {x4.x, x4.y, x4.z, x4.w};
 #pragma unroll
@@ -621,7 +661,8 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
                                                   const uint8_t* __restrict__ keep,   // applied to acc (inter-layer dropout bwd)
                                                   const float* __restrict__ gates, const float* __restrict__ hprev,
                                                   float* __restrict__ dgi, float* __restrict__ dgh, float* Gi, float* Gh,
-                                                  int ldg, float* Dd, int ldh, int H, int ft, int nrows, int lane) {
+                                                  int ldg, float* Dd, int ldh, int H, int ft, int nrows, int lane,
+                                                  bool wt = false) {
   const int i = lane & 15, q = lane >> 4;
   const int f0 = 16 * ft + 4 * q;
   const int G = 3 * H;
@@ -657,8 +698,8 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
       float* o2 = dgh + (int64_t)i * G + f0;
       const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                    vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
-      *reinterpret_cast<float4*>(o1) = vr; *reinterpret_cast<float4*>(o1 + H) = vz; *reinterpret_cast<float4*>(o1 + 2 * H) = vn;
-      *reinterpret_cast<float4*>(o2) = vr; *reinterpret_cast<float4*>(o2 + H) = vz; *reinterpret_cast<float4*>(o2 + 2 * H) = vh;
+      st4(o1, vr, wt); st4(o1 + H, vz, wt); st4(o1 + 2 * H, vn, wt);
+      st4(o2, vr, wt); st4(o2 + H, vz, wt); st4(o2 + 2 * H, vh, wt);
     }
     const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                  vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
@@ -790,7 +831,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
           du[r] = gg[r] * invstd * (db[r] - a1[r] * invB - xhat * a2[r] * invB);
         }
         const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
-        *reinterpret_cast<float4*>(gr.du + ((int64_t)t * B + b0 + pr) * H + pc) = du4;
+        st4(gr.du + ((int64_t)t * B + b0 + pr) * H + pc, du4, dm.wt != 0);
         *reinterpret_cast<float4*>(Xdu + pr * ldh + pc) = du4;
       }
     } else {
@@ -854,7 +895,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
     lds_barrier();
     if (feedback)
-      for (int e4 = tid; e4 < n4; e4 += 256) reinterpret_cast<float4*>(gr.dy + tile)[e4] = reinterpret_cast<const float4*>(Dt)[e4];
+      for (int e4 = tid; e4 < n4; e4 += 256) st4(gr.dy + tile + 4 * (int64_t)e4, reinterpret_cast<const float4*>(Dt)[e4], dm.wt != 0);
     lds_barrier();
   } else
   {
@@ -919,7 +960,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
       wave_gemm_p<1, KSD_T>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
       gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
                         sv.h1 + ((int64_t)(t - 1) * B + b0) * H, gr.dgi1 + ((int64_t)(t - 1) * B + b0) * G,
-                        gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane);
+                        gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0);
     }
   }
   lds_barrier();
@@ -962,7 +1003,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
                         drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr,
                         sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H, sv.h0 + ((int64_t)(t - 1) * B + b0) * H,
                         gr.dgi0 + ((int64_t)(t - 1) * B + b0) * G, gr.dgh0 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh,
-                        ldg, Dd, ldh, H, ft, nrows, lane);
+                        ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0);
     }
   }
   lds_barrier();
@@ -1061,6 +1102,12 @@ extern "C" int g2v_read_spans(unsigned long long* out) {
 
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
+extern "C" int g2v_dec_rollout_set_persistent(int enable) {
+  const int prev = persist_enabled() ? 1 : 0;
+  g_persist = enable ? 1 : 0;
+  return prev;
+}
+
 static size_t dec_fwd_lds(int D, int H) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15;
   return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp + 1024) * sizeof(float);
@@ -1081,7 +1128,9 @@ static size_t pack_bwd_total(int D, int H) {
   return (size_t)dtiles_pad(D) * pack_ks(H) * 256 + pack_floats(H, 1, D) + 4 * pack_floats(H, 1, 3 * H);
 }
 
-extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return pack_fwd_total(D, H) * sizeof(float); }
+// [packed forward weights | (256-byte aligned) exchange state of the persistent kernel]
+static size_t fwd_pack_bytes_aligned(int D, int H) { return (pack_fwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
+extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return fwd_pack_bytes_aligned(D, H) + PX_BYTES; }
 
 // ====================================================================================================================
 // Small batch, generic dims: the forward step t >= 1 as THREE launches over (16 rows x 16 hidden units) workgroups.
@@ -1692,8 +1741,26 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0, dtiles_pad(D)}; pk.out = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;
   launch_pack(pb, st);
   G2V_CHECK_LAUNCH();
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16)};
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), dec_wt_stores()};
   const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
+  {
+    auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+    const bool persist = fast && persist_enabled() && (B % 16) == 0 && dm.nblk <= PX_MAX_NBLK && dm.nblk <= device_cu_count() &&
+                         a16(h_init) && a16(s->y) && a16(s->u) && a16(s->h0) && a16(s->h1) && a16(s->xin) && a16(s->a) &&
+                         a16(s->x1) && a16(s->gates0) && a16(s->gates1) && a16(keep95) && a16(keep_l0) && a16(workspace);
+    if (persist) {
+      void* xbase = (char*)workspace + fwd_pack_bytes_aligned(D, H);
+      const int rc = dec_persist_fwd_launch(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T,
+                                            B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st);
+      if (rc != G2V_OK) return rc;
+      if (training) {
+        hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, s->bn_stats,
+                           w->bn_running_mean, w->bn_running_var, T - 1, H, B);
+        G2V_CHECK_LAUNCH();
+      }
+      return G2V_OK;
+    }
+  }
   if (lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)dec_step_fwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1754,9 +1821,10 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
 
 // split path (small batch): six plain transposes + two (B <= 512, H) scratch arrays
 static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 16 * DSPLIT_MAX_NBLK * H; }
+static size_t bwd_pack_bytes_aligned(int D, int H) { return (pack_bwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
 extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
-  const size_t a = pack_bwd_total(D, H), b = split_bwd_total(D, H);
-  return (a > b ? a : b) * sizeof(float);
+  const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES, b = split_bwd_total(D, H) * sizeof(float);
+  return a > b ? a : b;
 }
 
 extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
@@ -1857,8 +1925,18 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16)};
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16), dec_wt_stores()};
   const bool fast = (H == 64) && (D == 135);
+  {
+    auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+    const bool persist = fast && persist_enabled() && (B % 16) == 0 && dm.nblk <= PX_MAX_NBLK && dm.nblk <= device_cu_count() &&
+                         a16(s->u) && a16(s->a) && a16(s->h0) && a16(s->h1) && a16(s->gates0) && a16(s->gates1) &&
+                         a16(s->bn_stats) && a16(g->dy) && a16(g->du) && a16(g->dgi0) && a16(g->dgh0) && a16(g->dgi1) &&
+                         a16(g->dgh1) && a16(g->dh_init) && a16(keep95) && a16(keep_l0) && a16(workspace);
+    if (persist)
+      return dec_persist_bwd_launch(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, tw.w_pre_t, tw.w_out_t,
+                                    tw.w_ih0_t, tw.w_hh0_t, tw.w_ih1_t, tw.w_hh1_t, (char*)workspace + bwd_pack_bytes_aligned(D, H), st);
+  }
   for (int t = T - 1; t >= 0; --t) {
     if (fast)
       hipLaunchKernelGGL((dec_step_bwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);

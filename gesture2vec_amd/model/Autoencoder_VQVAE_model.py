@@ -15,7 +15,8 @@ Differences from the reference, all deliberate:
   * Dropout masks come from a counter-based Philox kernel (or are supplied explicitly, `set_dropout_masks`),
     because CPU and GPU RNG streams cannot agree anyway.
   * GPU only: `.forward` raises if the module is not on an MI355X (no CPU path).
-Supported configuration: autoencoder_vq "True", autoencoder_vae "False", autoencoder_att "False", n_layers 2.
+Supported configuration: autoencoder_vq "True", autoencoder_vae "False", n_layers 2; autoencoder_att "False" (fused engine +
+rollout kernels) and "True" (module-level path: step-level decoder with Bahdanau attention).
 """
 from __future__ import annotations
 
@@ -64,11 +65,17 @@ class EncoderRNN(nn.Module):
         self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout, bidirectional=True)
         self.do_flatten_parameters = False
 
-    def forward(self, input_seqs: torch.Tensor, hidden: Optional[torch.Tensor] = None):
-        """(T,B,D) -> outputs (T,B,H) [sum of directions of the LAST layer], hidden (2L,B,H).  Inference-only
-        standalone path (all layers evaluated); inside Autoencoder_VQVAE the engine runs the fused training path."""
+    def forward(self, input_seqs: torch.Tensor, hidden: Optional[torch.Tensor] = None, keep_in: Optional[torch.Tensor] = None,
+                in_scale: float = 1.0, keep_inter: Optional[torch.Tensor] = None):
+        """(T,B,D) -> outputs (T,B,H) [sum of directions of the LAST layer], hidden (2L,B,H), all layers evaluated.
+        With autograd enabled the layers are chained through autograd nodes (the attention model trains through this path;
+        `keep_in` (T,B,D) / `keep_inter` (T,B,2H) are the uint8 keep masks of the input dropout and of nn.GRU's inter-layer
+        dropout); otherwise the plain inference sequence below runs.  Inside the attention-free Autoencoder_VQVAE the engine
+        runs the fused training path instead."""
         if hidden is not None:
             raise NotImplementedError("non-zero initial hidden state")
+        if torch.is_grad_enabled() or keep_in is not None or keep_inter is not None:
+            return self._forward_autograd(input_seqs, keep_in, in_scale, keep_inter)
         T, B, D = input_seqs.shape
         H, L = self.hidden_size, self.n_layers
         x = input_seqs.contiguous()
@@ -91,9 +98,67 @@ class EncoderRNN(nn.Module):
         ops.add_halves(out, 2 * H, out[:, :, H:], 2 * H, summed, H, T * B, H)
         return summed, torch.stack(hiddens)
 
+    def _forward_autograd(self, input_seqs, keep_in, in_scale, keep_inter):
+        T, B, D = input_seqs.shape
+        H, L = self.hidden_size, self.n_layers
+        x = input_seqs.contiguous().view(T * B, D)
+        k_in = keep_in.contiguous().view(T * B, D) if keep_in is not None else None
+        layer_in = Fn.linear(x, self.in_layer.weight, self.in_layer.bias, keep=k_in, scale=in_scale)
+        hiddens, keep, scale = [], None, 1.0
+        out_f = out_b = None
+        g = self.gru
+        for l in range(L):
+            gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
+                             keep=keep, scale=scale).view(T, B, 3 * H) for suf in ("", "_reverse")]
+            out_f, hn_f, out_b, hn_b = Fn.GRUBiDirFn.apply(
+                gis[0], gis[1], getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"),
+                getattr(g, f"weight_hh_l{l}_reverse"), getattr(g, f"bias_hh_l{l}_reverse"), None)
+            hiddens += [hn_f, hn_b]
+            if l + 1 < L:
+                layer_in = torch.cat([out_f, out_b], dim=2).view(T * B, 2 * H)       # layout only
+                if self.training and self.dropout > 0 and keep_inter is not None:
+                    keep, scale = keep_inter.contiguous().view(T * B, 2 * H), 1.0 / (1.0 - self.dropout)
+        return Fn.SumHalvesFn.apply(out_f, out_b), torch.stack(hiddens)
+
+
+class Attn(nn.Module):
+    """Bahdanau attention scoring (reference :337-398; the same class text2embedding_model.py:138-198 defines): parameters
+    `attn` = Linear(2H -> H) and `v` (H); forward(hidden (B,H), encoder_outputs (T,B,H)) -> softmax weights (B,1,T).
+    energy_t = v . tanh(W [h ; enc_t] + b) is evaluated as tanh(hp + ep_t) with hp = h W[:, :H]^T + b (per step) and
+    ep = enc W[:, H:]^T (once per sequence) by g2v_attn_fwd / g2v_attn_bwd."""
+
+    def __init__(self, hidden_size: int):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.attn = nn.Linear(hidden_size * 2, hidden_size)
+        self.v = nn.Parameter(torch.rand(hidden_size))
+        stdv = 1.0 / math.sqrt(self.v.size(0))
+        self.v.data.normal_(mean=0, std=stdv)
+
+    def project_encoder(self, encoder_outputs: torch.Tensor) -> torch.Tensor:
+        """ep = enc W_attn[:, H:]^T (T,B,H): the step-independent half of the energy pre-activation."""
+        H = self.hidden_size
+        T, B, _ = encoder_outputs.shape
+        return Fn.linear(encoder_outputs.reshape(T * B, H), self.attn.weight[:, H:]).view(T, B, H)
+
+    def context(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor, enc_proj: Optional[torch.Tensor] = None):
+        """(context (B,H), weights (B,T)) for decoder state `hidden` (B,H)."""
+        H = self.hidden_size
+        if enc_proj is None:
+            enc_proj = self.project_encoder(encoder_outputs)
+        hp = Fn.linear(hidden, self.attn.weight[:, :H], self.attn.bias)
+        return Fn.AttnFn.apply(hp, enc_proj, encoder_outputs, self.v)
+
+    def forward(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor) -> torch.Tensor:
+        _, w = self.context(hidden, encoder_outputs)
+        return w.unsqueeze(1)
+
 
 class BahdanauAttnDecoderRNN(nn.Module):
-    """One decode step's parameters (reference :401-592).  The step itself runs inside the rollout kernels."""
+    """One decode step (reference :401-592).  Inside `Autoencoder_VQVAE.forward` the T-1 steps run in the rollout kernels;
+    `forward` below is the reference's step-at-a-time API that its other callers use (inference_Autoencoder.py:207-214,
+    Clustering.py:217-224: `rnn.decoder(None, x, h, enc, None)`), composed from the same HIP operators through small
+    autograd nodes, with or without attention (`autoencoder_att`)."""
 
     def __init__(self, args, input_size: int, hidden_size: int, output_size: int, n_layers: int = 1,
                  dropout_p: float = 0.1, discrete_representation: bool = False, speaker_model=None):
@@ -104,10 +169,11 @@ class BahdanauAttnDecoderRNN(nn.Module):
         if discrete_representation:
             raise NotImplementedError("discrete_representation decoder belongs to Part d (text2embedding_model)")
         self.autoencoder_conditioned = args.autoencoder_conditioned == "True"
-        if args.autoencoder_att == "True":
-            raise NotImplementedError("autoencoder_att == 'True' (attention decoder) is not on the accelerated path yet")
-        self.att_use = False
-        self.pre_linear = nn.Sequential(nn.Linear(input_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
+        self.att_use = args.autoencoder_att == "True"
+        if self.att_use:
+            self.attn = Attn(hidden_size)
+        linear_input_size = input_size + hidden_size if self.att_use else input_size          # :472-475
+        self.pre_linear = nn.Sequential(nn.Linear(linear_input_size, hidden_size), nn.BatchNorm1d(hidden_size), nn.ReLU(inplace=True))
         self.gru = _GRUParams(hidden_size, hidden_size, n_layers, dropout=dropout_p)
         if args.autoencoder_fixed_weight == "True":
             self.autoencoder_fixed_weight = True
@@ -115,6 +181,66 @@ class BahdanauAttnDecoderRNN(nn.Module):
                 param.requires_grad = False
         self.out_layer = nn.Linear(hidden_size, output_size)
         self.do_flatten_parameters = False
+        self._mask_queue = []          # explicit (keep95, keep_l0) pairs for the next calls (parity tests)
+        self._rng_counter = None
+        self.rng_seed = 0
+
+    def freeze_attn(self) -> None:
+        for param in self.attn.parameters():
+            param.requires_grad = False
+
+    # ---- dropout masks: the inline nn.Dropout(0.95) (:570) is ALWAYS active, nn.GRU's inter-layer dropout in training only
+    def set_step_masks(self, keep95_list, keep_l0_list=None):
+        """Explicit uint8 keep masks for the next len(keep95_list) calls: keep95 (B, linear_input_size) for the inline
+        Dropout(0.95), keep_l0 (B,H) for the dropout between GRU layer 0 and 1."""
+        n = len(keep95_list)
+        l0 = list(keep_l0_list) if keep_l0_list is not None else [None] * n
+        self._mask_queue = [(k.contiguous(), (m.contiguous() if m is not None else None)) for k, m in zip(keep95_list, l0)]
+
+    def _draw(self, shape, keep_prob, dev):
+        if self._rng_counter is None or self._rng_counter.device != dev:
+            self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        return ops.keep_mask(torch.empty(shape, dtype=torch.uint8, device=dev), keep_prob, self.rng_seed, self._rng_counter)
+
+    def forward(self, motion_input: torch.Tensor, last_hidden: torch.Tensor, encoder_outputs: Optional[torch.Tensor] = None,
+                vid_indices=None, enc_proj: Optional[torch.Tensor] = None):
+        """motion_input (B,D), last_hidden (L,B,H), encoder_outputs (T,B,H) [read only with attention] ->
+        (output (B,D), hidden (L,B,H), attn_weights (B,1,T) | None)   (:499-592)."""
+        if not motion_input.is_cuda:
+            raise RuntimeError("BahdanauAttnDecoderRNN runs on the MI355X kernels only (no CPU fallback)")
+        B = motion_input.size(0)
+        H, L = self.hidden_size, self.n_layers
+        training = self.training
+        x = motion_input.reshape(B, -1)
+        attn_weights = None
+        if self.att_use:
+            context, w = self.attn.context(last_hidden[-1], encoder_outputs, enc_proj)       # :545-551
+            x = torch.cat((x, context), 1)                                                   # :554-556 (layout only)
+            attn_weights = w.unsqueeze(1)
+        if not self.autoencoder_conditioned:
+            x = torch.zeros_like(x)                                                          # :568-569
+        if self._mask_queue:
+            keep95, keep_l0 = self._mask_queue.pop(0)
+        else:
+            keep95 = self._draw(tuple(x.shape), 0.05, x.device)
+            keep_l0 = self._draw((B, H), 1.0 - self.dropout_p, x.device) if (training and self.dropout_p > 0 and L > 1) else None
+        lin, bn = self.pre_linear[0], self.pre_linear[1]
+        u = Fn.linear(x.contiguous(), lin.weight, lin.bias, keep=keep95, scale=20.0)          # Dropout(0.95) fused: 1/(1-0.95)
+        a = Fn.BatchNormReluFn.apply(u, bn.weight, bn.bias, bn.running_mean, bn.running_var, training, True)
+        if training:
+            bn.num_batches_tracked += 1
+        new_h, layer_in, keep, scale = [], a, None, 1.0
+        g = self.gru
+        for l in range(L):
+            gi = Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}"), getattr(g, f"bias_ih_l{l}"), keep=keep, scale=scale)
+            _, h_n = Fn.GRUDirFn.apply(gi.view(1, B, 3 * H), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"),
+                                       last_hidden[l], None, False)
+            new_h.append(h_n)
+            layer_in = h_n
+            if training and self.dropout_p > 0 and keep_l0 is not None:
+                keep, scale = keep_l0, 1.0 / (1.0 - self.dropout_p)      # nn.GRU inter-layer dropout, fused into the next Linear
+        output = Fn.linear(new_h[-1], self.out_layer.weight, self.out_layer.bias)
+        return output, torch.stack(new_h), attn_weights
 
 
 class Generator(nn.Module):
@@ -130,6 +256,19 @@ class Generator(nn.Module):
                                               dropout_p=args.dropout_prob,
                                               discrete_representation=discrete_representation, speaker_model=speaker_model)
         self.is_training = True
+
+    def freeze_attn(self) -> None:
+        self.decoder.freeze_attn()
+
+    def forward(self, z, motion_input: torch.Tensor, last_hidden: torch.Tensor, encoder_output: Optional[torch.Tensor],
+                vid_indices=None, **kw):
+        """One decode step (:646-683): `z` (noise vector) is appended to motion_input when given."""
+        if z is None:
+            input_with_noise_vec = motion_input
+        else:
+            assert not self.discrete_representation
+            input_with_noise_vec = torch.cat([motion_input, z], dim=1)
+        return self.decoder(input_with_noise_vec, last_hidden, encoder_output, vid_indices, **kw)
 
 
 class VQ_Payam_EMA(nn.Module):
@@ -240,9 +379,18 @@ class Autoencoder_VQVAE(nn.Module):
         self._engine: Optional[VQVAEEngine] = None
         self._explicit_masks = False
         self.rng_seed = 0
+        # autoencoder_att == "True": the decoder attends over the encoder outputs (:545-556).  That model runs through the
+        # module-level path (_forward_attention): full encoder -> quantiser -> T-1 step-level decoder calls, every operator a
+        # HIP kernel chained by autograd nodes; the fused engine / rollout kernels are the attention-free model's.
+        self.att_use = self.decoder.decoder.att_use
+        self._att_masks = None
+        self._rng_counter = None
 
     # ------------------------------------------------------------------ engine binding
     def engine(self) -> VQVAEEngine:
+        if self.att_use:
+            raise NotImplementedError("the fused engine implements the attention-free decoder; autoencoder_att == 'True' "
+                                      "models run through Autoencoder_VQVAE.forward's module-level path")
         dev = self.encoder.in_layer.weight.device
         if dev.type != "cuda":
             raise RuntimeError("Autoencoder_VQVAE runs on the MI355X kernels only: move the module to the GPU first "
@@ -286,7 +434,55 @@ class Autoencoder_VQVAE(nn.Module):
     def use_random_masks(self):
         self._explicit_masks = False
 
+    # ------------------------------------------------------------------ attention model (module-level path)
+    def set_attention_masks(self, keep_in, keep_enc_inter, keep95_list, keep_l0_list=None):
+        """Explicit keep masks for the NEXT forward of an autoencoder_att == "True" model (parity tests): keep_in (T,B,D) for
+        self.do (:957), keep_enc_inter (T,B,2H) for the encoder GRU's inter-layer dropout, keep95_list: T-1 masks (B,D+H)
+        for the decoder's inline Dropout(0.95), keep_l0_list: T-1 masks (B,H) for the decoder GRU's inter-layer dropout."""
+        self._att_masks = (keep_in, keep_enc_inter, list(keep95_list), list(keep_l0_list) if keep_l0_list is not None else None)
+
+    def _draw(self, shape, keep_prob, dev):
+        if self._rng_counter is None or self._rng_counter.device != dev:
+            self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        return ops.keep_mask(torch.empty(shape, dtype=torch.uint8, device=dev), keep_prob, self.rng_seed, self._rng_counter)
+
+    def _forward_attention(self, in_poses: torch.Tensor, out_poses: torch.Tensor):
+        """Autoencoder_VQVAE.forward (:901-1085) with attention: every layer of the encoder is evaluated (the decoder reads
+        encoder_outputs), the quantiser module runs on encoder_hidden[:L], then T-1 calls of the step-level decoder."""
+        if not in_poses.is_cuda:
+            raise RuntimeError("Autoencoder_VQVAE runs on the MI355X kernels only (no CPU fallback)")
+        B, T, L, H = in_poses.shape[0], self.n_frames, self.n_layers, self.hidden_size
+        dev, p = in_poses.device, self.dropout_prob
+        dec = self.decoder.decoder
+        x_tbd = in_poses.transpose(0, 1).contiguous()
+        tgt = out_poses.transpose(0, 1).contiguous()
+        keep_in = keep_inter = None
+        if self._att_masks is not None:
+            keep_in, keep_inter, k95, kl0 = self._att_masks
+            dec.set_step_masks(k95, kl0)
+            self._att_masks = None
+        elif self.training and p > 0:
+            keep_in = self._draw((T, B, self.pose_dim), 1.0 - p, dev)
+            keep_inter = self._draw((T, B, 2 * H), 1.0 - p, dev) if L > 1 else None
+        if not self.training:
+            keep_in = keep_inter = None
+        enc_out, enc_hidden = self.encoder(x_tbd, None, keep_in=keep_in, in_scale=1.0 / (1.0 - p) if keep_in is not None else 1.0,
+                                           keep_inter=keep_inter)
+        decoder_hidden = enc_hidden[:L]                                                   # :971-973
+        loss_vq, quantized, perp, _ = self.vq_layer(decoder_hidden.contiguous())
+        hidden = quantized
+        enc_proj = dec.attn.project_encoder(enc_out)                                      # shared by the T-1 steps
+        outputs = [tgt[0]]
+        dec_in = tgt[0]
+        for t in range(1, T):
+            y, hidden, _ = self.decoder(None, dec_in, hidden, enc_out, None, enc_proj=enc_proj)
+            outputs.append(y)
+            dec_in = tgt[t] if t < self.n_pre_poses else y                                # :1049-1052
+        return torch.stack(outputs).transpose(0, 1), quantized[:L], loss_vq, perp
+
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, vq_layer_active: bool = False):
+        if self.att_use:
+            return self._forward_attention(in_poses, out_poses)
         eng = self.engine()
         in_poses = in_poses.contiguous()
         out_poses = out_poses.contiguous()

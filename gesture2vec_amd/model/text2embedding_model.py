@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from .. import functional as Fn
 from .. import ops
-from .Autoencoder_VQVAE_model import _GRUParams
+from .Autoencoder_VQVAE_model import Attn, _GRUParams
 
 debug = False
 noisy = False
@@ -79,37 +79,6 @@ class EncoderRNN(nn.Module):
                     keep, scale = keep_inter.contiguous().view(Tw * B, 2 * H), 1.0 / (1.0 - self.dropout)
         outputs = Fn.SumHalvesFn.apply(out_f, out_b)                              # :133-135
         return outputs, torch.stack(hiddens)
-
-
-class Attn(nn.Module):
-    """Reference `Attn` (:138-198): parameters `attn` = Linear(2H -> H) and `v` (H); forward(hidden (B,H),
-    encoder_outputs (T,B,H)) -> softmax attention weights (B,1,T)."""
-
-    def __init__(self, hidden_size: int):
-        super().__init__()
-        self.hidden_size = hidden_size
-        self.attn = nn.Linear(hidden_size * 2, hidden_size)
-        self.v = nn.Parameter(torch.rand(hidden_size))
-        stdv = 1.0 / math.sqrt(self.v.size(0))
-        self.v.data.normal_(mean=0, std=stdv)
-
-    def project_encoder(self, encoder_outputs: torch.Tensor) -> torch.Tensor:
-        """ep = enc W_attn[:, H:]^T (T,B,H): the step-independent half of the energy pre-activation."""
-        H = self.hidden_size
-        T, B, _ = encoder_outputs.shape
-        return Fn.linear(encoder_outputs.reshape(T * B, H), self.attn.weight[:, H:]).view(T, B, H)
-
-    def context(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor, enc_proj: Optional[torch.Tensor] = None):
-        """(context (B,H), weights (B,T)) for decoder state `hidden` (B,H)."""
-        H = self.hidden_size
-        if enc_proj is None:
-            enc_proj = self.project_encoder(encoder_outputs)
-        hp = Fn.linear(hidden, self.attn.weight[:, :H], self.attn.bias)
-        return Fn.AttnFn.apply(hp, enc_proj, encoder_outputs, self.v)
-
-    def forward(self, hidden: torch.Tensor, encoder_outputs: torch.Tensor) -> torch.Tensor:
-        _, w = self.context(hidden, encoder_outputs)
-        return w.unsqueeze(1)
 
 
 class BahdanauAttnDecoderRNN(nn.Module):

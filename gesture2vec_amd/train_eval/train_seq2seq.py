@@ -75,6 +75,20 @@ class FusedClipAdam:
 def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tensor, target_poses: torch.Tensor,
                                       net: torch.nn.Module, optim) -> Tuple[dict, torch.Tensor]:
     """One training iteration of the chunk VQ-VAE; same signature / return value as the reference."""
+    if getattr(net, "att_use", False):
+        # attention decoder: module-level autograd path; its parameter set (attn.*, the wider pre_linear) is not the fused
+        # engine's flat layout, so clip + Adam run over a FlatClipAdam of net.parameters()
+        from ..flat import FlatClipAdam
+        if not isinstance(optim, FlatClipAdam):
+            raise TypeError("autoencoder_att == 'True': use gesture2vec_amd.flat.FlatClipAdam(net.parameters(), lr, betas=(0.5, 0.999))")
+        optim.zero_grad()
+        outputs, _, loss_vq, perplexity_vq = net(input_poses, target_poses, epoch > 0)
+        loss = custom_loss(outputs, target_poses, args)
+        if epoch > 0:
+            loss = loss + 1 * loss_vq / 400
+        loss.backward()
+        optim.step()
+        return {"loss": loss.item()}, perplexity_vq.detach()
     if not isinstance(optim, FusedClipAdam):
         raise TypeError("use gesture2vec_amd.train_eval.train_seq2seq.FusedClipAdam (clip + Adam are one fused HIP launch)")
     if getattr(net, "quantizer", "ema") == "ema" and optim.net is net and net.training:

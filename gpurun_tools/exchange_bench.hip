@@ -4,10 +4,15 @@
 // record (the BatchNorm partial sums of its 16 rows) and needs the column sums over ALL workgroups' records before it
 // can continue.  Variants (argv[1]):
 //   0  no exchange (compute phases only)                                  -> baseline
-//   1  flags + data : sc1 record stores -> vmcnt(0) -> barrier -> one sc1 flag store per workgroup;
-//                     readers poll the 256 flags (one per thread), then read the 256 records with sc1 loads
-//   2  self-tagged  : records as 16-byte granules {v0, v1, v2, tag = step}; readers sweep the granules with sc1 loads
-//                     and re-load the ones whose tag is stale (no flag, no second round trip)
+//   1  flat, all threads poll : sc1 record stores -> vmcnt(0) -> barrier -> one sc1 flag store per workgroup;
+//                     every thread polls one flag, then the 256 records are read with sc1 loads      (round 2a: 10 us)
+//   3  flat, ONE wave polls (64 lanes x 16 B = all 256 flags in one request per lane) with s_sleep, then as 1
+//   4  two-level tree, groups of G (argv[6], 8/16/32): members publish record + flag; the group's first workgroup sums
+//      its G records and publishes a level-2 record + flag; everybody polls the 256/G leader flags (one wave, one load)
+//      and sums the 256/G level-2 records.  Fixed summation tree: deterministic.
+//   5  as 4 but poll only (no record reads) -> isolates the flag latency of the two hops
+//   6  flat with fences: plain record stores -> vmcnt(0) -> barrier -> lane 0 release fence (agent) -> flag;
+//      consumer: one wave polls, one agent acquire, barrier, PLAIN loads of the 256 records
 // argv[2] = MFMAs per wave per step in the emulated compute phase, argv[3] = KB of plain stores per workgroup and step,
 // argv[4] = steps, argv[5] = skew (1: some workgroups sleep extra each step).
 // Every value received is checked against the closed form; a bounded spin turns a protocol bug into an error count.
@@ -19,7 +24,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-constexpr int NWG = 256, NCOL = 128, NG = 44;   // 44 granules x 3 floats >= 128
+constexpr int NWG = 256, NCOL = 128;
+constexpr int SPIN_MAX = 400000;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 
@@ -32,16 +38,72 @@ __device__ __forceinline__ void st_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);
 }
 
-__global__ __launch_bounds__(256) void bench_kernel(float* rec, unsigned* flags, float* sink, float* junk, unsigned* errs,
-                                                    int variant, int nmfma, int store_kb, int T, int skew) {
+struct Bufs {
+  float* rec;        // [2][NWG][128]   level-1 records
+  float* rec2;       // [2][32][128]    level-2 records
+  unsigned* flags;   // [2][NWG]        level-1 flags (group-contiguous)
+  unsigned* flags2;  // [2][32]         leader flags
+};
+
+// column sums of `n` records (n <= 256, multiple of 8) read with sc1 (or plain) loads -> tot[128] in LDS
+template <bool PLAIN>
+__device__ __forceinline__ void sum_records(const float* base, int n, float (*red)[NCOL], float* tot, int tid) {
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n * NCOL * 4, 0x00020000);
+  const int seg = tid >> 5, col = tid & 31;
+  const int per = n >> 3;                 // records per segment
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < per; k0 += 16) {
+    u32x4 v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int k = seg * per + min(k0 + j, per - 1);
+      if (PLAIN) v[j] = *reinterpret_cast<const u32x4*>(base + (size_t)k * NCOL + 4 * col);
+      else v[j] = ld_sc1(rr, (unsigned)((k * NCOL + 4 * col) * 4));
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      if (k0 + j < per) sum += __builtin_bit_cast(f32x4, v[j]);
+  }
+  for (int r = 0; r < 4; ++r) red[seg][4 * col + r] = sum[r];
+  __syncthreads();
+  if (tid < NCOL) {
+    float t = 0.f;
+    for (int g = 0; g < 8; ++g) t += red[g][tid];
+    tot[tid] = t;
+  }
+  __syncthreads();
+}
+
+// wave 0 polls `n` consecutive flags (n <= 256, multiple of 4) until all equal s; everybody leaves through a barrier
+__device__ __forceinline__ unsigned wait_flags(const unsigned* f, int n, unsigned s, int tid) {
+  unsigned fail = 0;
+  if (tid < 64) {
+    __amdgpu_buffer_rsrc_t fr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(f), 0, n * 4, 0x00020000);
+    const bool active = 4 * tid < n;
+    for (int spins = 0;; ++spins) {
+      bool ok = true;
+      if (active) {
+        const u32x4 v = ld_sc1(fr, (unsigned)(tid * 16));
+        ok = (v[0] == s) && (v[1] == s) && (v[2] == s) && (v[3] == s);
+      }
+      if (__all(ok)) break;
+      if (spins > SPIN_MAX) { fail = 1000000; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  return fail;
+}
+
+__global__ __launch_bounds__(256) void bench_kernel(Bufs B, float* sink, float* junk, unsigned* errs,
+                                                    int variant, int nmfma, int store_kb, int T, int skew, int G) {
   __shared__ float red[8][NCOL];
   __shared__ float tot[NCOL];
-  __shared__ int ok_s;
-  const int tid = threadIdx.x, b = blockIdx.x, lane = tid & 63;
+  const int tid = threadIdx.x, b = blockIdx.x;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   float a = 1.0f + tid * 1e-3f, bb = 0.5f;
   unsigned nerr = 0;
-  const size_t rec_bytes_a = (size_t)NWG * NCOL * 4, rec_bytes_b = (size_t)NWG * NG * 16;
+  const int NL = NWG / G;       // leaders
   for (int s = 1; s <= T; ++s) {
     // ---- emulated compute phase
     for (int m = 0; m < nmfma; ++m) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bb, acc, 0, 0, 0);
@@ -50,8 +112,24 @@ __global__ __launch_bounds__(256) void bench_kernel(float* rec, unsigned* flags,
     if (skew && ((b * 7 + s) & 15) == 0) __builtin_amdgcn_s_sleep(100);
     if (variant == 0) continue;
     const int par = s & 1;
-    if (variant == 1) {
-      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rec + (size_t)par * NWG * NCOL, 0, (int)rec_bytes_a, 0x00020000);
+    float* rec = B.rec + (size_t)par * NWG * NCOL;
+    unsigned* flags = B.flags + par * NWG;
+    // ---- publish this workgroup's record
+    if (variant == 6) {
+      if (tid < 32) {
+        f32x4 v;
+        for (int r = 0; r < 4; ++r) v[r] = rec_val(b, 4 * tid + r, s);
+        *reinterpret_cast<f32x4*>(rec + (size_t)b * NCOL + 4 * tid) = v;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(flags + b, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else {
+      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rec, 0, NWG * NCOL * 4, 0x00020000);
       if (tid < 32) {
         f32x4 v;
         for (int r = 0; r < 4; ++r) v[r] = rec_val(b, 4 * tid + r, s);
@@ -59,81 +137,51 @@ __global__ __launch_bounds__(256) void bench_kernel(float* rec, unsigned* flags,
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tid == 0) __hip_atomic_store(flags + par * NWG + b, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // poll: thread t watches workgroup t's flag
+      if (tid == 0) __hip_atomic_store(flags + b, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- gather
+    if (variant == 1) {
       int spins = 0;
       for (;;) {
-        const unsigned f = __hip_atomic_load(flags + par * NWG + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned f = __hip_atomic_load(flags + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int ok = __syncthreads_and(f == (unsigned)s);
         if (ok) break;
-        if (++spins > 2000000) { nerr += 1000000; break; }
+        if (++spins > SPIN_MAX) { nerr += 1000000; break; }
       }
-      const int seg = tid >> 5, col = tid & 31;
-      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      for (int k0 = 0; k0 < 32; k0 += 16) {
-        u32x4 v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = ld_sc1(rr, (unsigned)(((seg * 32 + k0 + j) * NCOL + 4 * col) * 4));
-#pragma unroll
-        for (int j = 0; j < 16; ++j) sum += __builtin_bit_cast(f32x4, v[j]);
-      }
-      for (int r = 0; r < 4; ++r) red[seg][4 * col + r] = sum[r];
-      __syncthreads();
-      if (tid < NCOL) {
-        float t = 0.f;
-        for (int g = 0; g < 8; ++g) t += red[g][tid];
-        tot[tid] = t;
+      sum_records<false>(rec, NWG, red, tot, tid);
+    } else if (variant == 3) {
+      nerr += wait_flags(flags, NWG, (unsigned)s, tid);
+      sum_records<false>(rec, NWG, red, tot, tid);
+    } else if (variant == 6) {
+      nerr += wait_flags(flags, NWG, (unsigned)s, tid);     // ends in a barrier
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();
-    } else {
-      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(rec + (size_t)par * NWG * NG * 4, 0, (int)rec_bytes_b, 0x00020000);
-      if (tid < NG) {
-        u32x4 v;
-        for (int r = 0; r < 3; ++r) {
-          const int e = 3 * tid + r;
-          v[r] = __builtin_bit_cast(unsigned, e < NCOL ? rec_val(b, e, s) : 0.f);
+      sum_records<true>(rec, NWG, red, tot, tid);
+    } else {   // 4, 5: two-level tree
+      float* rec2 = B.rec2 + (size_t)par * 32 * NCOL;
+      unsigned* flags2 = B.flags2 + par * 32;
+      const int grp = b / G;
+      if (b == grp * G) {     // leader of its group
+        nerr += wait_flags(flags + grp * G, G, (unsigned)s, tid);
+        if (variant == 4) sum_records<false>(rec + (size_t)grp * G * NCOL, G, red, tot, tid);
+        else { if (tid < NCOL) tot[tid] = 0.f; __syncthreads(); }
+        __amdgpu_buffer_rsrc_t r2 = __builtin_amdgcn_make_buffer_rsrc(rec2, 0, 32 * NCOL * 4, 0x00020000);
+        if (tid < 32) {
+          f32x4 v;
+          for (int r = 0; r < 4; ++r) v[r] = tot[4 * tid + r];
+          st_sc1(r2, (unsigned)(grp * NCOL * 4 + tid * 16), __builtin_bit_cast(u32x4, v));
         }
-        v[3] = (unsigned)s;
-        st_sc1(rr, (unsigned)((b * NG + tid) * 16), v);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(flags2 + grp, (unsigned)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // sweep: thread (seg, col) sums granule `col` of workgroups seg*52 .. seg*52+51 (5 segments x 44 columns)
-      const int seg = tid / NG, col = tid - seg * NG;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-      if (seg < 5) {
-        const int kb = seg * 52, ke = min(NWG, kb + 52);
-        for (int k0 = kb; k0 < ke; k0 += 13) {
-          u32x4 v[13];
-#pragma unroll
-          for (int j = 0; j < 13; ++j) v[j] = ld_sc1(rr, (unsigned)((min(k0 + j, ke - 1) * NG + col) * 16));
-#pragma unroll
-          for (int j = 0; j < 13; ++j) {
-            if (k0 + j >= ke) continue;
-            int spins = 0;
-            while (v[j][3] != (unsigned)s) {
-              v[j] = ld_sc1(rr, (unsigned)(((k0 + j) * NG + col) * 16));
-              if (++spins > 2000000) { nerr += 1000000; break; }
-            }
-            s0 += __builtin_bit_cast(float, v[j][0]);
-            s1 += __builtin_bit_cast(float, v[j][1]);
-            s2 += __builtin_bit_cast(float, v[j][2]);
-          }
-        }
-      }
-      __syncthreads();
-      if (seg < 5) {
-        if (3 * col < NCOL) red[seg][3 * col] = s0;
-        if (3 * col + 1 < NCOL) red[seg][3 * col + 1] = s1;
-        if (3 * col + 2 < NCOL) red[seg][3 * col + 2] = s2;
-      }
-      __syncthreads();
-      if (tid < NCOL) {
-        float t = 0.f;
-        for (int g = 0; g < 5; ++g) t += red[g][tid];
-        tot[tid] = t;
-      }
-      __syncthreads();
+      nerr += wait_flags(flags2, NL, (unsigned)s, tid);
+      if (variant == 4) sum_records<false>(rec2, NL, red, tot, tid);
     }
-    if (tid < NCOL) {
+    if (variant != 5 && tid < NCOL) {
       float expect = 0.f;
       for (int k = 0; k < NWG; ++k) expect += rec_val(k, tid, s);
       if (tot[tid] != expect) ++nerr;
@@ -146,11 +194,17 @@ __global__ __launch_bounds__(256) void bench_kernel(float* rec, unsigned* flags,
 
 int main(int argc, char** argv) {
   const int variant = argc > 1 ? atoi(argv[1]) : 1, nmfma = argc > 2 ? atoi(argv[2]) : 168, store_kb = argc > 3 ? atoi(argv[3]) : 64;
-  const int T = argc > 4 ? atoi(argv[4]) : 33, skew = argc > 5 ? atoi(argv[5]) : 0;
-  float *rec, *sink, *junk;
-  unsigned *flags, *errs;
-  CK(hipMalloc(&rec, 2 * NWG * NG * 16 + 2 * NWG * NCOL * 4));
-  CK(hipMalloc(&flags, 2 * NWG * 4));
+  const int T = argc > 4 ? atoi(argv[4]) : 33, skew = argc > 5 ? atoi(argv[5]) : 0, G = argc > 6 ? atoi(argv[6]) : 16;
+  Bufs B;
+  float *sink, *junk;
+  unsigned* errs;
+  char* state;
+  const size_t state_bytes = 2 * NWG * NCOL * 4 + 2 * 32 * NCOL * 4 + 2 * NWG * 4 + 2 * 32 * 4;
+  CK(hipMalloc(&state, state_bytes));
+  B.rec = (float*)state;
+  B.rec2 = B.rec + 2 * NWG * NCOL;
+  B.flags = (unsigned*)(B.rec2 + 2 * 32 * NCOL);
+  B.flags2 = B.flags + 2 * NWG;
   CK(hipMalloc(&sink, NWG * 256 * 4));
   CK(hipMalloc(&junk, (size_t)NWG * 64 * 4096));
   CK(hipMalloc(&errs, 4));
@@ -160,11 +214,10 @@ int main(int argc, char** argv) {
   const int reps = 20;
   unsigned herr = 0;
   for (int r = 0; r < reps + 3; ++r) {
-    CK(hipMemset(rec, 0, 2 * NWG * NG * 16 + 2 * NWG * NCOL * 4));
-    CK(hipMemset(flags, 0, 2 * NWG * 4));
+    CK(hipMemset(state, 0, state_bytes));
     CK(hipMemset(errs, 0, 4));
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(bench_kernel, dim3(NWG), dim3(256), 0, 0, rec, flags, sink, junk, errs, variant, nmfma, store_kb, T, skew);
+    hipLaunchKernelGGL(bench_kernel, dim3(NWG), dim3(256), 0, 0, B, sink, junk, errs, variant, nmfma, store_kb, T, skew, G);
     CK(hipEventRecord(e1));
     CK(hipEventSynchronize(e1));
     float ms;
@@ -174,7 +227,7 @@ int main(int argc, char** argv) {
     herr += e;
     if (r >= 3) { best = ms < best ? ms : best; sum += ms; }
   }
-  printf("variant %d nmfma %d store_kb %d T %d skew %d : avg %.2f us/step  best %.2f us/step  (kernel avg %.1f us)  errors %u\n",
-         variant, nmfma, store_kb, T, skew, sum / reps * 1e3f / T, best * 1e3f / T, sum / reps * 1e3f, herr);
+  printf("variant %d G %2d nmfma %3d store_kb %2d T %d skew %d : avg %6.2f us/step  best %6.2f us/step  errors %u\n",
+         variant, G, nmfma, store_kb, T, skew, sum / reps * 1e3f / T, best * 1e3f / T, herr);
   return herr ? 2 : 0;
 }

@@ -228,7 +228,15 @@ typedef struct {           /* saved-for-backward / state arrays, all caller-owne
 } g2v_dec_saved;
 
 int g2v_dec_rollout_blocks(int B);
-/* workspace: the weights re-laid-out in MFMA fragment order (packed once per call). */
+/* Two interchangeable implementations sit behind g2v_dec_rollout_fwd / _bwd (same arguments, same saved arrays):
+ * one launch per time step (any shape), and -- for H == 64, D == 135, B % 16 == 0, B / 16 <= the device's CU count --
+ * ONE persistent launch for the whole rollout with register/LDS-resident weights and an in-kernel two-level exchange of
+ * the BatchNorm partial sums (csrc/dec_persist.hpp).  The persistent one is used whenever it applies; this switch
+ * (default 1, or 0 with the environment variable G2V_NO_PERSIST=1) exists for A/B measurements and parity tests.
+ * Returns the previous setting. */
+int g2v_dec_rollout_set_persistent(int enable);
+/* workspace: the weights re-laid-out in MFMA fragment order (packed once per call) + the persistent kernel's exchange
+ * state (zeroed by a memset node in front of its launch). */
 size_t g2v_dec_rollout_fwd_workspace(int D, int H);
 int g2v_dec_rollout_fwd(const float* target /* (B,T,D) row-major */, const float* h_init /* (2,B,H) */,
                         const g2v_dec_weights* w, const g2v_dec_saved* s,

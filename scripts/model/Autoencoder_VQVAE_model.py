@@ -8,5 +8,5 @@ if _ROOT not in _sys.path:
     _sys.path.insert(0, _ROOT)
 
 from gesture2vec_amd.model.Autoencoder_VQVAE_model import (  # noqa: E402,F401
-    Autoencoder_VQVAE, BahdanauAttnDecoderRNN, EncoderRNN, Generator, VQ_Payam, VQ_Payam_EMA, VQ_Payam_GSSoft,
+    Attn, Autoencoder_VQVAE, BahdanauAttnDecoderRNN, EncoderRNN, Generator, VQ_Payam, VQ_Payam_EMA, VQ_Payam_GSSoft,
     VectorQuantizer, VectorQuantizerEMA)

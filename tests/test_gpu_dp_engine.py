@@ -102,6 +102,16 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
             assert relerr(eng.vq_stats[K:], w.reshape(-1)) < 1e-5
         # the SUM all-reduce of [grads | cnt | dw], by hand
         total = engines[0].comm + engines[1].comm
+        # the reduced gradients themselves (the sharp check: Adam below normalises every element by its own magnitude)
+        for name, _ in engines[0].layout:
+            if name == "decoder.decoder.pre_linear.0.bias":
+                continue
+            off, n, shp = engines[0].offsets[name]
+            ref = tot_g[name]
+            if float(ref.abs().max()) == 0.0:
+                assert float(total[off:off + n].abs().max()) == 0.0, name
+            else:
+                assert relerr(total[off:off + n], ref.reshape(-1)) < 5e-4, (name, relerr(total[off:off + n], ref.reshape(-1)))
         for eng in engines:
             eng.comm.copy_(total)
             eng.train_step_apply(B, lr=lr, world=world, dp=True)
@@ -119,8 +129,10 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
     for name, _ in e0.layout:
         if name == "decoder.decoder.pre_linear.0.bias":     # zero-gradient tensor: Adam amplifies rounding noise (see DESIGN)
             continue
+        # Adam moves an element by ~lr per step whatever its gradient's size, so an element whose gradient sits at the
+        # rounding-noise floor may legitimately travel differently: bound = 10 % of the total travel (gradients: above)
         err = float((e0.view(name).cpu().double() - sd[name].double()).abs().max())
-        assert err <= 1e-4 * float(sd[name].abs().max()) + 0.02 * n_steps * lr, (name, err)
+        assert err <= 1e-4 * float(sd[name].abs().max()) + 0.1 * n_steps * lr, (name, err)
     assert relerr(e0.ema_cs, sd["vq_layer._ema_cluster_size"]) < 1e-5
     assert relerr(e0.ema_w, sd["vq_layer._ema_w"]) < 1e-5
     assert relerr(e0.codebook, sd["vq_layer._embedding.weight"]) < 1e-4

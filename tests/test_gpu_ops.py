@@ -325,8 +325,11 @@ def _alloc_saved(T, B, D, H, nblk, dev, p):
             "gates1": z(T - 1, B, 4 * H), "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H)}
 
 
+# H = 64, D = 135 with B % 16 == 0 runs the PERSISTENT rollout kernels (csrc/dec_persist.hip): 32 rows = one exchange group of
+# two workgroups, 320 = a full group + a partial one, 4096 = the whole chip (256 workgroups, 16 groups).
 @pytest.mark.parametrize("T,B,D,H,p", [(34, 32, 135, 64, 0.0), (20, 8, 40, 50, 0.2), (6, 37, 135, 64, 0.3), (3, 16, 40, 200, 0.0),
-                                       (5, 37, 45, 200, 0.2), (4, 600, 40, 48, 0.1), (4, 130, 64, 256, 0.0)])
+                                       (5, 37, 45, 200, 0.2), (4, 600, 40, 48, 0.1), (4, 130, 64, 256, 0.0),
+                                       (12, 320, 135, 64, 0.2), (5, 4096, 135, 64, 0.0), (4, 4096, 135, 64, 0.25)])
 def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
     sd = _dec_state(D, H, seed=5)
     g = torch.Generator().manual_seed(77)
@@ -381,7 +384,7 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
             relclose(db, g_ref[pre + bname], 3e-4, bname)
 
 
-@pytest.mark.parametrize("T,B,D,H", [(10, 20, 135, 64), (6, 20, 40, 200)])      # fused step kernel / per-phase split kernels
+@pytest.mark.parametrize("T,B,D,H", [(10, 20, 135, 64), (6, 20, 40, 200), (10, 48, 135, 64)])   # fused step / split / persistent kernels
 def test_dec_rollout_eval_mode(ops, T, B, D, H):
     sd = _dec_state(D, H, seed=9)
     g = torch.Generator().manual_seed(78)
@@ -400,6 +403,50 @@ def test_dec_rollout_eval_mode(ops, T, B, D, H):
                         0.2, 1, True, False, T, B, D, H)
     relclose(saved["y"], y_ref, 1e-4, "eval rollout")
     close(wt["bn_running_mean"], sd["decoder.decoder.pre_linear.1.running_mean"], 0, 0, "running stats untouched")
+
+
+@pytest.mark.parametrize("B,p", [(4096, 0.0), (4096, 0.2), (336, 0.2)])
+def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p):
+    """The two implementations behind g2v_dec_rollout_fwd / _bwd (one launch per step vs one persistent launch with the
+    in-kernel exchange) produce the same saved arrays and gradients up to the summation order of the BatchNorm partial
+    sums, at the BASELINE shape; the persistent path is bitwise reproducible run to run."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    T, D, H = 34, 135, 64
+    sd = _dec_state(D, H, seed=21)
+    g = torch.Generator().manual_seed(5)
+    target = torch.randn(B, T, D, generator=g).to(DEV)
+    h_init = (torch.randn(2, B, H, generator=g) * 0.5).to(DEV)
+    k95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8).to(DEV)
+    kl0 = (torch.rand(T - 1, B, H, generator=g) < (1 - p)).to(torch.uint8).to(DEV) if p > 0 else None
+    gy = (torch.randn(T, B, D, generator=g) / (T * B * D) * 100).to(DEV)
+    nblk = ops.dec_rollout_blocks(B)
+    G = 3 * H
+    z = lambda *s: torch.zeros(*s, device=DEV)
+
+    def run(persistent):
+        prev = lib.g2v_dec_rollout_set_persistent(int(persistent))
+        try:
+            wt, _ = _dec_weight_tensors(sd, DEV)
+            ws = ops.dec_weights_struct(wt)
+            saved = _alloc_saved(T, B, D, H, nblk, DEV, p)
+            ops.dec_rollout_fwd(target, h_init, ws, saved, k95, kl0, p, 1, True, True, T, B, D, H)
+            grads = {"dy": gy.clone(), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G),
+                     "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G), "dh_init": z(2, B, H),
+                     "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
+            ops.dec_rollout_bwd(ws, saved, grads, k95, kl0, p, 1, True, T, B, D, H)
+            torch.cuda.synchronize()
+            out = {k: v for k, v in saved.items() if v is not None and k != "bn_partial"}
+            out.update({"g_" + k: v for k, v in grads.items() if k != "bn_bwd_partial"})
+            out["running_mean"], out["running_var"] = wt["bn_running_mean"], wt["bn_running_var"]
+            return out
+        finally:
+            lib.g2v_dec_rollout_set_persistent(prev)
+
+    a, b, c = run(True), run(False), run(True)
+    for k in a:
+        assert torch.equal(a[k], c[k]), f"persistent path not reproducible: {k}"
+        relclose(a[k], b[k], 2e-4 if k.startswith("g_") else 2e-5, f"persistent vs per-step: {k}")
 
 
 # ----------------------------------------------------------------------------------------------- loss / optimiser / rng

@@ -68,9 +68,23 @@ def test_cpu_forward_fails_loudly():
 def test_unsupported_configs_are_refused():
     from model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
     with pytest.raises(NotImplementedError):
-        Autoencoder_VQVAE(_args(autoencoder_att="True"), 40, 20)
-    with pytest.raises(NotImplementedError):
         Autoencoder_VQVAE(_args(autoencoder_vae="True"), 40, 20)
+
+
+def test_attention_model_surface():
+    """autoencoder_att == "True" builds the reference's parameter set (attn.attn.*, attn.v, pre_linear over D + H inputs,
+    :466-480) and the module names SURVEY.md 8(b) lists are importable with a step-level forward."""
+    import model.Autoencoder_VQVAE_model as M
+    net = M.Autoencoder_VQVAE(_args(autoencoder_att="True"), 40, 20)
+    sd = net.state_dict()
+    H = net.hidden_size
+    assert sd["decoder.decoder.attn.attn.weight"].shape == (H, 2 * H) and sd["decoder.decoder.attn.v"].shape == (H,)
+    assert sd["decoder.decoder.pre_linear.0.weight"].shape == (H, 40 + H)
+    for name in ("EncoderRNN", "Attn", "BahdanauAttnDecoderRNN", "Generator", "Autoencoder_VQVAE", "VQ_Payam", "VQ_Payam_EMA",
+                 "VQ_Payam_GSSoft", "VectorQuantizer", "VectorQuantizerEMA"):
+        assert hasattr(M, name), name
+    for cls in (M.Attn, M.BahdanauAttnDecoderRNN, M.Generator):
+        assert "forward" in cls.__dict__, cls.__name__
 
 
 def test_checkpoint_roundtrip(tmp_path):
