@@ -14,6 +14,20 @@
 //               Dropout(0.95) -> pre_linear -> partial sums -> publish
 #include "dec_persist.hpp"
 
+#ifdef G2V_PSTAMPS      // diagnostic build only (gpurun_tools/pstamps.py): shader-clock stamps of one step of four workgroups
+__device__ unsigned long long g2v_pstamps[2 * 4 * 24];
+#define PSTAMP(dir, k)                                                                                                   \
+  do {                                                                                                                   \
+    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
+    if (threadIdx.x == 0 && sb_ >= 0 && t == 10) g2v_pstamps[((dir) * 4 + sb_) * 24 + (k)] = __builtin_amdgcn_s_memtime();  \
+  } while (0)
+extern "C" int g2v_read_pstamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_pstamps), sizeof(unsigned long long) * 2 * 4 * 24);
+}
+#else
+#define PSTAMP(dir, k)
+#endif
+
 namespace g2v {
 
 namespace {
@@ -24,7 +38,9 @@ constexpr int OUT_TILES = 12;                 // D tiles padded to 3 per wave (t
 constexpr int L_XA = 0, L_XH0 = L_XA + 16 * LDH, L_XH1 = L_XH0 + 16 * LDH, L_XX1 = L_XH1 + 16 * LDH;
 constexpr int L_XY = L_XX1 + 16 * LDH;                    // xin_{t+1} tile [16][LDD]
 constexpr int L_YT = L_XY + 16 * LDD;                     // dense y tile [16 * D] (+ pad)
-constexpr int L_POUT = L_YT + 2176;                       // packed W_out: 12 tiles x 4 k-steps x 256
+constexpr int L_XT = L_YT + 2176;                         // dense xin tile [16 * D] (+ pad)
+constexpr int L_KT = L_XT + 2176;                         // keep95 bytes of the tile (16 * D bytes, padded)
+constexpr int L_POUT = L_KT + 544;                        // packed W_out: 12 tiles x 4 k-steps x 256
 constexpr int L_PPRE = L_POUT + OUT_TILES * KSH * 256;    // packed W_pre: 4 tiles x 9 k-steps x 256
 constexpr int L_BIAS = L_PPRE + 4 * KSD * 256;            // b_ih0 b_hh0 b_ih1 b_hh1 (192 each) b_out (144) b_pre bn_w bn_b (64 each)
 constexpr int L_ST = L_BIAS + 4 * 192 + 144 + 3 * 64;     // mean[64], invstd[64]
@@ -55,12 +71,24 @@ template <int NT, int KS_T>
 __device__ __forceinline__ void lds_frag_mma(f32x4 (&acc)[NT], const float* P, int tile0, int tile_stride, const float* Xs,
                                              int ldx, int lane) {
   const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+  // software pipeline: the fragments of k-step s+1 are requested before the MFMAs of k-step s (one wave per SIMD: an LDS
+  // round trip in front of every k-step would otherwise idle the matrix pipe ~150 cycles per step)
+  float4 wn[NT], xn;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wn[t] = *reinterpret_cast<const float4*>(P + ((tile0 + t * tile_stride) * KS_T) * 256 + lane * 4);
+  xn = *reinterpret_cast<const float4*>(xrow);
 #pragma unroll
   for (int s = 0; s < KS_T; ++s) {
-    const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+    const float4 xb = xn;
     float4 wv[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) wv[t] = *reinterpret_cast<const float4*>(P + ((tile0 + t * tile_stride) * KS_T + s) * 256 + lane * 4);
+    for (int t = 0; t < NT; ++t) wv[t] = wn[t];
+    if (s + 1 < KS_T) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        wn[t] = *reinterpret_cast<const float4*>(P + ((tile0 + t * tile_stride) * KS_T + s + 1) * 256 + lane * 4);
+      xn = *reinterpret_cast<const float4*>(xrow + 16 * (s + 1));
+    }
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = mfma16(wv[t].x, xb.x, acc[t]);
 #pragma unroll
@@ -123,6 +151,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   float* Xx1 = smem + L_XX1;
   float* Xy = smem + L_XY;
   float* Yt = smem + L_YT;
+  float* Xt = smem + L_XT;
+  uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + L_KT);
   float* Pout = smem + L_POUT;
   float* Ppre = smem + L_PPRE;
   float* Bs = smem + L_BIAS;
@@ -183,6 +213,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   for (int t = 0; t < T; ++t) {
     const bool has_next = t < T - 1;
     if (t > 0) {
+      PSTAMP(0, 0);
       // ---- hidden-side products (independent of this step's BatchNorm): they fill the exchange's latency -----------
       f32x4 gh0[3], gh1[3];
 #pragma unroll
@@ -190,11 +221,32 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         gh0[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         gh1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
       }
+      // keep flags of this step's Dropout(0.95) (consumed by the out-layer epilogue): requested now, landed in LDS below
+      uint32_t kreq[3] = {0u, 0u, 0u};
+      const bool fast_y = has_next && !(t < a.n_pre);      // the common case: feedback of the model's own output
+      if (fast_y && a.conditioned) {
+        const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)t * B + b0) * D);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int e4 = tid + 256 * j;
+          kreq[j] = kp4[e4 < (16 * D) / 4 ? e4 : 0];
+        }
+      }
+      // The exchange is threaded through the two products: the row's records, published at the end of the previous step,
+      // have arrived when the first product is done (hop 1: row sum, published again), and the row sums of the other rows
+      // travel while the second product runs (hop 2).
       frag_mma(gh0, f_hh0, Xh0, LDH, lane);
+      if (training) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
       frag_mma(gh1, f_hh1, Xh1, LDH, lane);
+      PSTAMP(0, 1);
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e4 = tid + 256 * j;
+        if (e4 < (16 * D) / 4) Kt[e4] = kreq[j];
+      }
       // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
       if (training) {
-        px_exchange(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+        px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
         if (tid < H) {
           const float s1 = tot[tid], s2 = tot[H + tid];
           const float mv = s1 / (float)B;
@@ -209,6 +261,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         }
         lds_barrier();
       }
+      PSTAMP(0, 2);
       // ---- a_t = ReLU(BN(u_t)) from the register-resident u tile ---------------------------------------------------
       {
         const float4 m4 = *reinterpret_cast<const float4*>(st + f0), i4 = *reinterpret_cast<const float4*>(st + H + f0);
@@ -223,6 +276,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         if (a.sv.a) *reinterpret_cast<float4*>(a.sv.a + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = a4;
       }
       lds_barrier();
+      PSTAMP(0, 3);
       // ---- GRU layer 0 --------------------------------------------------------------------------------------------
       {
         uint32_t kp = 0x01010101u;
@@ -237,6 +291,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
                       (drop && a.sv.x1) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
       }
       lds_barrier();
+      PSTAMP(0, 4);
       // ---- GRU layer 1 --------------------------------------------------------------------------------------------
       {
         f32x4 ai[3];
@@ -248,6 +303,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
                       a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
       }
       lds_barrier();
+      PSTAMP(0, 5);
       // ---- y_t = out_layer(h1_t) -> dense tile --------------------------------------------------------------------
       {
         f32x4 acc[3];
@@ -260,18 +316,36 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           lds_frag_mma<2, KSH>(a2, Pout, wave, 4, Xh1, LDH, lane);
           acc[0] = a2[0]; acc[1] = a2[1];
         }
+        const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
+        const bool fast_y = has_next && !(t < a.n_pre);
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int d0 = 16 * (wave + 4 * j) + 4 * q;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (d0 + r < D) Yt[i * D + d0 + r] = acc[j][r] + Bs[B_OUT + d0 + r];
+            if (d0 + r < D) {
+              const float y = acc[j][r] + Bs[B_OUT + d0 + r];
+              Yt[i * D + d0 + r] = y;
+              if (fast_y) {      // next decoder input = Dropout(0.95)(y_t): 1 / (1 - 0.95) = 20  (:568-570)
+                const float xin = Kb[i * D + d0 + r] ? y * 20.0f : 0.f;
+                Xt[i * D + d0 + r] = xin;
+                Xy[i * LDD + d0 + r] = xin;
+              }
+            }
         }
       }
       lds_barrier();
+      PSTAMP(0, 6);
     }
     // ---- y_t out, next decoder input xin_{t+1} = Dropout(0.95)(y_t | target_t)  (:1049-1052, :568-570) --------------
-    {
+    if (t > 0 && (!has_next || !(t < a.n_pre))) {
+      // fast path: the out-layer epilogue left y (and xin) as dense tiles -> coalesced 16-byte copies, nothing else
+      const int64_t tile = ((int64_t)t * B + b0) * D;
+      for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+        *reinterpret_cast<float4*>(a.sv.y + tile + 4 * e4) = reinterpret_cast<const float4*>(Yt)[e4];
+        if (has_next && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
+      }
+    } else {
       const int64_t tile = ((int64_t)t * B + b0) * D;        // the block's 16 x D tile is one dense run of the (T,B,D) arrays
       const bool teacher = has_next && (t < a.n_pre);
       const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
@@ -312,6 +386,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     }
     if (!has_next) break;
     lds_barrier();
+    PSTAMP(0, 7);
     // ---- u_{t+1} = pre_linear.0(xin_{t+1}); partial sums of (u - b) over this block's 16 rows; publish -----------------
     {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -340,6 +415,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         }
       }
     }
+    PSTAMP(0, 8);
     // (no barrier needed here: the next writers of Xy / Yt sit behind the barriers of step t+1)
   }
 }
@@ -511,6 +587,33 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   for (int e = tid; e < 16 * (LDD - D); e += 256) Xdy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
   lds_barrier();
 
+  // dy (loss gradient) and keep95 tiles of step `ts` -> LDS, as two phases so that the requests can sit in front of a
+  // product and the LDS writes behind it.  Clamped, always-valid addresses: no branch around a load, no stack array.
+  float4 dy_a, dy_b, dy_c;
+  uint32_t k_a, k_b, k_c;
+  auto tile_request = [&](int ts) {
+    const int e4c = tid + 512 < (16 * D) / 4 ? tid + 512 : 0;
+    const float* dyp = a.gr.dy + ((int64_t)ts * B + b0) * D;
+    const uint32_t* kp = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)min(ts, T - 2) * B + b0) * D);   // row T-1 does not exist
+    dy_a = *reinterpret_cast<const float4*>(dyp + 4 * tid);
+    dy_b = *reinterpret_cast<const float4*>(dyp + 4 * (tid + 256));
+    dy_c = *reinterpret_cast<const float4*>(dyp + 4 * e4c);
+    k_a = kp[tid]; k_b = kp[tid + 256]; k_c = kp[e4c];
+  };
+  auto tile_commit = [&](int ts) {
+    const bool fb = (ts != T - 1) && a.conditioned && (ts >= a.n_pre);
+    reinterpret_cast<float4*>(Dt)[tid] = dy_a;
+    reinterpret_cast<float4*>(Dt)[tid + 256] = dy_b;
+    Kt[tid] = fb ? k_a : 0u;
+    Kt[tid + 256] = fb ? k_b : 0u;
+    if (tid + 512 < (16 * D) / 4) {          // 16 * D / 4 = 540 float4: threads 0..27 own a third element
+      reinterpret_cast<float4*>(Dt)[tid + 512] = dy_c;
+      Kt[tid + 512] = fb ? k_c : 0u;
+    }
+  };
+  tile_request(T - 1);
+  tile_commit(T - 1);
+
   float4 carry0 = make_float4(0.f, 0.f, 0.f, 0.f), carry1 = carry0;   // d h0 / d h1 flowing to the earlier step
   float dbn[4] = {0.f, 0.f, 0.f, 0.f}, xhat[4] = {0.f, 0.f, 0.f, 0.f}, gis[4] = {0.f, 0.f, 0.f, 0.f};   // of the step in flight
   float acc_w = 0.f, acc_b = 0.f;                                       // d gamma / d beta (workgroup 0, tid < H)
@@ -518,31 +621,15 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   for (int t = T - 1; t >= 0; --t) {
     const bool last = (t == T - 1);
     const bool feedback = !last && a.conditioned && (t >= a.n_pre);
-    // ---- this step's saved values: requested before the exchange so that they arrive while it is in flight ------------
-    CellSaved c1, c0;
-    float4 a4 = make_float4(0.f, 0.f, 0.f, 0.f), u4 = a4, mean4 = a4, var4 = make_float4(1.f, 1.f, 1.f, 1.f);
-    uint32_t kl0 = 0x01010101u;
-    float4 dyt[3];
-    uint32_t k95[3] = {0u, 0u, 0u};
+    // ---- this step's inputs.  The dy / keep95 tiles of step t were staged into LDS during the previous iteration (see
+    // "stage the next step's tiles" below; the first iteration stages its own in the prologue), so the loop opens with the
+    // exchange.  Holding every saved value of the step in registers across the exchange made hipcc park them in AGPRs
+    // behind four `s_waitcnt vmcnt(0)` (+6 us per step): the cell-1 values are requested right after the exchange and land
+    // behind the feedback product, the cell-0 values after the cell-1 epilogue, behind the hh1 / ih1 products.
     const int64_t tile = ((int64_t)t * B + b0) * D;
-    if (t > 0) {
-      const int64_t row = (int64_t)(t - 1) * B + row_i;
-      load_cell(c1, a.sv.gates1, a.sv.h1, row, f0);
-      load_cell(c0, a.sv.gates0, a.sv.h0, row, f0);
-      a4 = *reinterpret_cast<const float4*>(a.sv.a + row * H + f0);
-      u4 = *reinterpret_cast<const float4*>(a.sv.u + row * H + f0);
-      mean4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + f0);
-      var4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + H + f0);
-      if (drop) kl0 = *reinterpret_cast<const uint32_t*>(a.keep_l0 + row * H + f0);
-#pragma unroll
-      for (int j = 0; j < 3; ++j) {
-        const int e4 = tid + 256 * j;
-        const int ec = e4 < (16 * D) / 4 ? e4 : 0;
-        dyt[j] = *reinterpret_cast<const float4*>(a.gr.dy + tile + 4 * (int64_t)ec);
-        if (feedback) k95[j] = reinterpret_cast<const uint32_t*>(a.keep95 + tile)[ec];
-      }
-    }
+    const int64_t srow = (int64_t)(t - 1) * B + row_i;      // row of the saved arrays this step reads (t >= 1)
     __builtin_amdgcn_sched_barrier(0);
+    PSTAMP(1, 0);
     // ---- Part A: finish BatchNorm backward of step t+1 -> du_{t+1} --------------------------------------------------------
     if (!last) {
       px_exchange(a.x, (t + 1) & 1, (unsigned)(T - 1 - t), a.nblk, b, red, tot, tid);
@@ -559,17 +646,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
         acc_b += tot[tid];
       }
     }
+    PSTAMP(1, 1);
     if (t == 0) break;                   // only the BatchNorm finish of step 1 was left (y_0 is data)
+    CellSaved c1;
+    load_cell(c1, a.sv.gates1, a.sv.h1, srow, f0);
+    __builtin_amdgcn_sched_barrier(0);
+    lds_barrier();                       // Xdu (and, first iteration, Dt / Kt) complete
+    PSTAMP(1, 2);
     // ---- Part B: dy_t (loss gradient + feedback through Dropout(0.95) and pre_linear) -------------------------------------
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int e4 = tid + 256 * j;
-      if (e4 < (16 * D) / 4) {
-        reinterpret_cast<float4*>(Dt)[e4] = dyt[j];
-        Kt[e4] = k95[j];
-      }
-    }
-    lds_barrier();                       // Xdu, Dt, Kt complete
     {
       f32x4 acc[3];
 #pragma unroll
@@ -603,16 +687,29 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     if (feedback)
       for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256)
         *reinterpret_cast<float4*>(a.gr.dy + tile + 4 * (int64_t)e4) = reinterpret_cast<const float4*>(Dt)[e4];
+    PSTAMP(1, 3);
     // ---- dh1 = carry1 + dy W_out ; GRU cell 1 backward ---------------------------------------------------------------------
     float4 direct1;
     {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       lds_frag_mma<1, KSD>(acc, Pout_t, wave, 0, Xdy, LDD, lane);
       const float dh[4] = {acc[0][0] + carry1.x, acc[0][1] + carry1.y, acc[0][2] + carry1.z, acc[0][3] + carry1.w};
-      const int64_t row = (int64_t)(t - 1) * B + row_i;
-      direct1 = cell_bwd(dh, c1, a.gr.dgi1 + row * G3 + f0, a.gr.dgh1 + row * G3 + f0, Gt, i, f0);
+      direct1 = cell_bwd(dh, c1, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt, i, f0);
     }
+    // cell-0 / BatchNorm inputs of this step: in flight during the next two products (96 MFMAs)
+    CellSaved c0;
+    load_cell(c0, a.sv.gates0, a.sv.h0, srow, f0);
+    const float4 a4 = *reinterpret_cast<const float4*>(a.sv.a + srow * H + f0);
+    const float4 u4 = *reinterpret_cast<const float4*>(a.sv.u + srow * H + f0);
+    const float4 mean4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + f0);
+    const float4 var4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + H + f0);
+    uint32_t kl0 = 0x01010101u;
+    if (drop) kl0 = *reinterpret_cast<const uint32_t*>(a.keep_l0 + srow * H + f0);
+    // stage the next step's tiles: Dt / Kt were last read by the feedback epilogue and the dy write-back above
+    if (t > 1) tile_request(t - 1);
+    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();
+    PSTAMP(1, 4);
     // ---- carry1' = dh1 * z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout backward) -------------------------
     float dh0[4];
     {
@@ -628,14 +725,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
         dh0[r] = v + c0v[r];
       }
     }
+    if (t > 1) tile_commit(t - 1);
     lds_barrier();                       // every wave is done reading the cell-1 tile
+    PSTAMP(1, 5);
     // ---- GRU cell 0 backward ---------------------------------------------------------------------------------------------
     float4 direct0;
-    {
-      const int64_t row = (int64_t)(t - 1) * B + row_i;
-      direct0 = cell_bwd(dh0, c0, a.gr.dgi0 + row * G3 + f0, a.gr.dgh0 + row * G3 + f0, Gt, i, f0);
-    }
+    direct0 = cell_bwd(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0);
     lds_barrier();
+    PSTAMP(1, 6);
     // ---- carry0' = dh0 * z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU backward -> dbn_t, partial sums, publish -----------------
     {
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
@@ -667,6 +764,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
         px_publish2(rr, (unsigned)(H + f0) + 2, s2[2], s2[3], tag);
       }
     }
+    PSTAMP(1, 7);
   }
   // gradient wrt the initial hidden state (the quantised latent) and the BatchNorm affine parameters
   *reinterpret_cast<float4*>(a.gr.dh_init + row_i * H + f0) = carry0;

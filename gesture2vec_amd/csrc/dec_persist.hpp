@@ -14,9 +14,13 @@
 //     workgroups read the SAME lines (one line serves ~1 request per 10 ns chip-wide);
 //   * so the sum runs as a fixed two-level tree of groups of 16 workgroups with 8-byte self-validating granules
 //     {value, tag = step} (MI355X_MICROARCH.md "R2": one aligned 8-byte sc1 store is observed untorn, no flag, no fence,
-//     no release): members publish 128 granules, the group's first workgroup sums its 16 records and publishes the
-//     group record ONCE PER READING GROUP (16 replicas: a line is then read by 16 workgroups, not 256), everybody sums
-//     the <= 16 group records of its own replica set.  Summation order is fixed -> bitwise reproducible.
+//     no release).  The 256 workgroups form a 16 x 16 grid (row = b / 16, column = b % 16): every workgroup publishes its
+//     128 granules, sums the 16 records of its ROW (hop 1) and publishes that row sum as its own second record, then sums
+//     the row sums published by the workgroups of its COLUMN (hop 2).  No leaders (nobody waits for a workgroup that has
+//     extra serial work), every line is read by ~16 workgroups, and the summation order is fixed -> bitwise reproducible.
+//     In-kernel stamps (gpurun_tools/px_test.hip, 256 workgroups): publish -> group sums visible 1.0 us, sweep (one
+//     fabric round trip) 0.75 us, LDS reduction 0.24 us, second hop the same: 3.1-4.2 us per exchange; waiting on one
+//     sentinel granule per record before the full sweep was measured 1.1 us SLOWER than polling with the sweep itself.
 //   * records are double-buffered by step parity: a workgroup can only publish step s+1 after it has consumed every
 //     group record of step s, which exist only after every workgroup has published step s, i.e. finished reading s-1.
 //   * every polled word is zeroed by a memset node in front of the launch; tags count steps inside the call (1..T).
@@ -24,6 +28,10 @@
 //     kernel needs one workgroup per CU (256 threads, <= 512 VGPRs, ~135 KB LDS); every spin is bounded and traps.
 #pragma once
 #include "common.hpp"
+
+#ifndef PX_STAMP          // diagnostic builds (gpurun_tools/px_test.hip) define it to record s_memrealtime stamps
+#define PX_STAMP(k)
+#endif
 
 namespace g2v {
 
@@ -34,12 +42,12 @@ constexpr int PX_MAX_NBLK = 256;      // one workgroup per CU on MI355X
 constexpr int PX_COLS = 128;          // floats per record (2 x H, H = 64)
 constexpr size_t PX_REC1_BYTES = (size_t)2 * PX_MAX_NBLK * PX_COLS * 8;
 constexpr int PX_MAX_GRP = PX_MAX_NBLK / PX_GROUP;
-constexpr size_t PX_REC2_BYTES = (size_t)2 * PX_MAX_GRP * PX_MAX_GRP * PX_COLS * 8;   // [parity][reading group][source group]
+constexpr size_t PX_REC2_BYTES = (size_t)2 * PX_MAX_NBLK * PX_COLS * 8;               // [parity][workgroup]: its row sum
 constexpr size_t PX_BYTES = PX_REC1_BYTES + PX_REC2_BYTES;     // 1 MiB: a multiple of 16 (memset price, Guideline 16)
 
 struct PersistX {
   unsigned long long* rec1;   // [2][PX_MAX_NBLK][128] granules {value (low dword), tag (high dword)}
-  unsigned long long* rec2;   // [2][PX_MAX_GRP (reader)][PX_MAX_GRP (source)][128]
+  unsigned long long* rec2;   // [2][PX_MAX_NBLK][128]: the row sum as published by each workgroup
 };
 static inline PersistX persist_x_at(void* base) {
   PersistX x;
@@ -66,16 +74,20 @@ __device__ __forceinline__ void px_publish2(__amdgpu_buffer_rsrc_t r, unsigned g
 // Column sums of `n` (<= 16) records of 128 granules each -> tot[128] (LDS), by all 256 threads, fixed order.
 // Thread (m = tid >> 4, c = tid & 15) owns granule pairs c, c+16, c+32, c+48 of record m and re-reads the ones whose
 // tag is stale.  red: LDS [16][128].  Ends with a barrier; tot is valid for every thread afterwards.
-__device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int n, unsigned tag, float* red, float* tot,
-                                             int tid) {
+// Record m of the sweep is record `rec_of(m)` of `base` (a [PX_MAX_NBLK][128] array).
+template <class RecOf>
+__device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int n, RecOf rec_of, unsigned tag, float* red,
+                                             float* tot, int tid, int stamp_off = 0) {
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(base), 0,
-                                                                n * PX_COLS * 8, 0x00020000);
+                                                                PX_MAX_NBLK * PX_COLS * 8, 0x00020000);
   const int m = tid >> 4, c = tid & 15;
+  const int rec = rec_of(m < n ? m : 0);
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  PX_STAMP(stamp_off + 0);
   if (m < n) {
     u32x4 g[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g[k] = px_ld(rr, (unsigned)((m * PX_COLS + 2 * (c + 16 * k)) * 8));
+    for (int k = 0; k < 4; ++k) g[k] = px_ld(rr, (unsigned)((rec * PX_COLS + 2 * (c + 16 * k)) * 8));
     unsigned spins = 0;
     for (;;) {
       bool ok = true;
@@ -85,7 +97,7 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
       __builtin_amdgcn_s_sleep(1);
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        if (g[k][1] != tag || g[k][3] != tag) g[k] = px_ld(rr, (unsigned)((m * PX_COLS + 2 * (c + 16 * k)) * 8));
+        if (g[k][1] != tag || g[k][3] != tag) g[k] = px_ld(rr, (unsigned)((rec * PX_COLS + 2 * (c + 16 * k)) * 8));
       if (++spins > 4000000u) __builtin_trap();      // a workgroup of this launch is not resident / died: fail loudly
     }
     // NB: copy the vector elements to scalars first.  `__builtin_bit_cast(float, g[k][2])` straight on an ext-vector
@@ -102,6 +114,7 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
   for (int k = 0; k < 4; ++k)
     *reinterpret_cast<float2*>(red + m * PX_COLS + 2 * (c + 16 * k)) = make_float2(v[2 * k], v[2 * k + 1]);
   lds_barrier();
+  PX_STAMP(stamp_off + 1);
   if (tid < PX_COLS) {
     float t = 0.f;
 #pragma unroll
@@ -109,31 +122,36 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
     tot[tid] = t;
   }
   lds_barrier();
+  PX_STAMP(stamp_off + 2);
 }
 
-// The whole exchange of one step for workgroup b: this workgroup's 128 partial sums were already published into
-// rec1[par][b] (px_publish2 from the producing lanes).  On return tot[128] holds the sums over all nblk workgroups.
+// The exchange of one step for workgroup b, in two calls so that independent work can sit between the hops.  This
+// workgroup's 128 partial sums were already published into rec1[par][b] (px_publish2 from the producing lanes).
+//   px_hop1 : sum the records of this workgroup's row (workgroups 16 r .. 16 r + 15) and publish the row sum as rec2[par][b].
+//   px_hop2 : sum one published copy of every row's sum: row r' is read from the workgroup of that row in this workgroup's
+//             column (column c modulo the row's length: the last row may be short).  On return tot[128] holds the sums
+//             over all nblk workgroups, bit-identical in every workgroup.
+__device__ __forceinline__ void px_hop1(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid) {
+  const int row = b / PX_GROUP;
+  const int n = min(PX_GROUP, nblk - row * PX_GROUP);
+  px_sweep_sum(x.rec1 + (size_t)par * PX_MAX_NBLK * PX_COLS, n, [&](int m) { return row * PX_GROUP + m; }, tag, red, tot, tid);
+  if (tid < 64) {
+    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(x.rec2 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0,
+                                                                  PX_COLS * 8, 0x00020000);
+    px_publish2(rr, 2u * tid, tot[2 * tid], tot[2 * tid + 1], tag);
+  }
+  lds_barrier();     // tot / red are rewritten by the second sweep: every reader above is done
+}
+__device__ __forceinline__ void px_hop2(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid) {
+  const int nrow = (nblk + PX_GROUP - 1) / PX_GROUP;
+  const int col = b % PX_GROUP;
+  px_sweep_sum(x.rec2 + (size_t)par * PX_MAX_NBLK * PX_COLS, nrow,
+               [&](int m) { return m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP); }, tag, red, tot, tid, 3);
+}
 __device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot,
                                             int tid) {
-  const int ngrp = (nblk + PX_GROUP - 1) / PX_GROUP;
-  const int grp = b / PX_GROUP;
-  unsigned long long* r2 = x.rec2 + (size_t)par * PX_MAX_GRP * PX_MAX_GRP * PX_COLS;
-  if (b == grp * PX_GROUP) {
-    const int n = min(PX_GROUP, nblk - grp * PX_GROUP);
-    px_sweep_sum(x.rec1 + ((size_t)par * PX_MAX_NBLK + (size_t)grp * PX_GROUP) * PX_COLS, n, tag, red, tot, tid);
-    {   // one copy of the group record per reading group: thread (pair = tid & 63, replicas tid >> 6, +4, +8, +12)
-      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(r2, 0, PX_MAX_GRP * PX_MAX_GRP * PX_COLS * 8, 0x00020000);
-      const int pair = tid & 63;
-      const float v0 = tot[2 * pair], v1 = tot[2 * pair + 1];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int r = (tid >> 6) + 4 * k;
-        if (r < ngrp) px_publish2(rr, (unsigned)((r * PX_MAX_GRP + grp) * PX_COLS + 2 * pair), v0, v1, tag);
-      }
-    }
-    lds_barrier();     // tot is rewritten by the second sweep: every reader above is done
-  }
-  px_sweep_sum(r2 + (size_t)grp * PX_MAX_GRP * PX_COLS, ngrp, tag, red, tot, tid);
+  px_hop1(x, par, tag, nblk, b, red, tot, tid);
+  px_hop2(x, par, tag, nblk, b, red, tot, tid);
 }
 
 }  // namespace g2v

@@ -1,5 +1,13 @@
 // px_test.hip -- the product's exchange (csrc/dec_persist.hpp) in isolation: 256 (or argv[1]) workgroups, T steps, every
 // received sum checked against the closed form, uneven load, timing.   hipcc --offload-arch=gfx950 -O3 -I.. px_test.hip
+__device__ unsigned long long px_stamps[4 * 16];     // [block slot][stamp]
+__device__ int px_stamp_base = 0;
+#define PX_STAMP(k)                                                                                                       \
+  do {                                                                                                                    \
+    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1)));  \
+    if (threadIdx.x == 0 && sb_ >= 0 && px_stamp_on) px_stamps[sb_ * 16 + (k)] = __builtin_amdgcn_s_memrealtime(); \
+  } while (0)
+__device__ int px_stamp_on = 0;
 #include "../gesture2vec_amd/csrc/dec_persist.hpp"
 #include <stdlib.h>
 namespace g2v { void set_error(const char*, ...) {} }
@@ -24,7 +32,13 @@ __global__ __launch_bounds__(256) void k(PersistX x, unsigned* errs, float* sink
       px_publish2(rr, 64 + f0, rec_val(b, 64 + f0, s), rec_val(b, 64 + f0 + 1, s), s);
       px_publish2(rr, 64 + f0 + 2, rec_val(b, 64 + f0 + 2, s), rec_val(b, 64 + f0 + 3, s), s);
     }
+    if (tid == 0) { px_stamp_on = (s == 20); }
+    __syncthreads();
+    { const int sb_ = b == 0 ? 0 : (b == 5 ? 1 : (b == 128 ? 2 : (b == 255 ? 3 : -1)));
+      if (tid == 0 && sb_ >= 0 && s == 20) px_stamps[sb_ * 16 + 15] = __builtin_amdgcn_s_memrealtime(); }
     px_exchange(x, s & 1, (unsigned)s, nblk, b, red, tot, tid);
+    { const int sb_ = b == 0 ? 0 : (b == 5 ? 1 : (b == 128 ? 2 : (b == 255 ? 3 : -1)));
+      if (tid == 0 && sb_ >= 0 && s == 20) px_stamps[sb_ * 16 + 14] = __builtin_amdgcn_s_memrealtime(); }
     if (tid < 128) {
       float expect = 0.f;
       for (int g = 0; g * 16 < nblk; ++g) { float t = 0.f; for (int m = g * 16; m < min(nblk, g * 16 + 16); ++m) t += rec_val(m, tid, s); expect += t; }
@@ -52,5 +66,12 @@ int main(int argc, char** argv) {
     if (r >= 3) sum += ms;
   }
   printf("px_exchange nblk %d T %d nmfma %d skew %d : %.2f us/step, errors %u\n", nblk, T, nmfma, skew, sum / reps * 1e3f / T, herr);
+  unsigned long long st[64];
+  CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(px_stamps), sizeof(st)));
+  for (int b = 0; b < 4; ++b) {
+    printf("  block slot %d (100 MHz ticks from exchange start):", b);
+    for (int k = 0; k < 6; ++k) printf(" s%d=%lld", k, (long long)(st[b * 16 + k] - st[b * 16 + 15]));
+    printf(" end=%lld\n", (long long)(st[b * 16 + 14] - st[b * 16 + 15]));
+  }
   return herr ? 2 : 0;
 }

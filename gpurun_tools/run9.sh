@@ -1,0 +1,13 @@
+#!/bin/bash
+mkdir -p gpurun_out/r2i
+for a in "256 33 0 0" "256 33 100 1" "20 33 50 1" "37 33 20 1" "2 33 0 0"; do ./gpurun_tools/px_test $a 2>&1 | head -3 >> gpurun_out/r2i/px.txt; done
+python gpurun_tools/pstamps.py > gpurun_out/r2i/pstamps.txt 2>&1
+timeout 900 python -m pytest tests/test_gpu_ops.py -m gpu -q --tb=short -k "dec_rollout" 2>&1 | grep -v "^E    .*where" | tail -40 > gpurun_out/r2i/pytest_dec.txt
+timeout 300 python bench.py --no-cpu-baseline --steps 50 > gpurun_out/r2i/bench_persist.json 2> gpurun_out/r2i/err.txt
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_a -o a -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --steps 30 > /tmp/prof_a.log 2>&1
+cd $GRAFT_REPO_ROOT
+find /tmp/prof_a -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/r2i/kernel_stats_persist.csv
+cat gpurun_out/r2i/px.txt; tail -12 gpurun_out/r2i/pstamps.txt; tail -30 gpurun_out/r2i/pytest_dec.txt
+for f in gpurun_out/r2i/bench_*.json; do python -c "import json,sys; d=json.load(open('$f')); print('$f', d['ms_per_step'], d['roofline']['avg_us'])"; done
+head -4 gpurun_out/r2i/kernel_stats_persist.csv
