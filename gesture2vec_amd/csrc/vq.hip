@@ -425,6 +425,245 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   }
 }
 
+// ---- fused pre_linear + assign for E == 128 (the BASELINE shape) -------------------------------------------------
+// One workgroup = 16 rows of z.  Phase 1: flat = z W_pre^T + b (:1230) on MFMA (wave w owns output tiles w and w + 4; the
+// 16 weight fragments of a wave are requested up front, the first codebook pair right behind them).  The projected tile
+// goes to LDS (it IS the B operand of the distance contraction) and to global (`flat_out`: the code statistics need it).
+// Phase 2 = vq_assign_fast_kernel's loop on that tile: distances, running argmin, gather + straight-through + SSE on raw z.
+// Replaces the launch sequence  gemm_nt_stream (pre_linear, 18 us) -> assign (12 us)  and one 2 MB round trip of `flat`.
+template <int E>
+__global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __restrict__ z, const float* __restrict__ Wp,
+                                                              const float* __restrict__ bp, const float* __restrict__ W,
+                                                              const float* __restrict__ wsq, float* __restrict__ flat_out,
+                                                              int64_t* __restrict__ idx_out, float* __restrict__ quant,
+                                                              float* __restrict__ sse_partial, int N, int K) {
+  constexpr int KS = E / 16, ldx = E + 4;
+  __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
+  __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
+  __shared__ float xx[16];
+  __shared__ float wbest_d[64];
+  __shared__ int wbest_k[64];
+  __shared__ int best_k[16];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  const int i = lane & 15, q = lane >> 4;
+  // pre_linear weight fragments of this wave (tiles wave, wave + 4), straight from the row-major (E,E) matrix
+  float4 wp0[KS], wp1[KS];
+  {
+    const float* p0 = Wp + (int64_t)(16 * wave + i) * E + 4 * q;
+    const float* p1 = Wp + (int64_t)(16 * (wave + 4) + i) * E + 4 * q;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      wp0[s] = *reinterpret_cast<const float4*>(p0 + 16 * s);
+      wp1[s] = *reinterpret_cast<const float4*>(p1 + 16 * s);
+    }
+  }
+  // ... and the first pair of codebook tiles right behind them: they travel during the staging and the projection
+  auto load_pair = [&](int p, float4 (&w0)[KS], float4 (&w1)[KS], float4& q0, float4& q1) {
+    const int kt0 = wave + 8 * p, kt1 = kt0 + 4;
+    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      w0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
+      w1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+    }
+    q0 = *reinterpret_cast<const float4*>(wsq + 16 * kt0 + 4 * q);
+    q1 = *reinterpret_cast<const float4*>(wsq + 16 * kt1 + 4 * q);
+  };
+  float4 wa0[KS], wa1[KS], wb0[KS], wb1[KS], qa0, qa1, qb0, qb1;
+  load_pair(0, wa0, wa1, qa0, qa1);
+  __builtin_amdgcn_sched_barrier(0);
+  {  // stage the raw row tile (coalesced float4)
+    const int row = tid >> 4, part = tid & 15;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int c = 4 * (part + 16 * j);
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < nrows) v = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + row) * E + c);
+      *reinterpret_cast<float4*>(Xz + row * ldx + c) = v;
+    }
+  }
+  lds_barrier();
+  {  // phase 1: the projection
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 xb = *reinterpret_cast<const float4*>(Xz + i * ldx + 16 * s + 4 * q);
+      a0 = mfma16(wp0[s].x, xb.x, a0); a1 = mfma16(wp1[s].x, xb.x, a1);
+      a0 = mfma16(wp0[s].y, xb.y, a0); a1 = mfma16(wp1[s].y, xb.y, a1);
+      a0 = mfma16(wp0[s].z, xb.z, a0); a1 = mfma16(wp1[s].z, xb.z, a1);
+      a0 = mfma16(wp0[s].w, xb.w, a0); a1 = mfma16(wp1[s].w, xb.w, a1);
+    }
+    const int f0 = 16 * wave + 4 * q, f1 = f0 + 64;
+    const float4 b0 = *reinterpret_cast<const float4*>(bp + f0), b1 = *reinterpret_cast<const float4*>(bp + f1);
+    const float4 v0 = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
+    const float4 v1 = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
+    *reinterpret_cast<float4*>(Xf + i * ldx + f0) = v0;
+    *reinterpret_cast<float4*>(Xf + i * ldx + f1) = v1;
+    if (i < nrows) {
+      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
+      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f1) = v1;
+    }
+  }
+  lds_barrier();
+  {  // ||x||^2 of the projected rows
+    const int row = tid >> 4, part = tid & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(Xf + row * ldx + 4 * (part + 16 * j));
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = reduce16(s);
+    if (part == 0) xx[row] = s;
+  }
+  lds_barrier();
+  float4 xb[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
+  const float xr = xx[i];
+  float bd = INFINITY;
+  int bk = 0;
+  const int npair = K >> 7;
+  auto consume = [&](int p, const float4 (&w0)[KS], const float4 (&w1)[KS], const float4& q0, const float4& q1, bool ld,
+                     int pn, float4 (&n0)[KS], float4 (&n1)[KS], float4& nq0, float4& nq1) {
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int kt0 = wave + 8 * pn, kt1 = kt0 + 4;
+    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      a0 = mfma16(w0[s].x, xb[s].x, a0); a1 = mfma16(w1[s].x, xb[s].x, a1);
+      a0 = mfma16(w0[s].y, xb[s].y, a0); a1 = mfma16(w1[s].y, xb[s].y, a1);
+      if (ld) n0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = mfma16(w0[s].z, xb[s].z, a0); a1 = mfma16(w1[s].z, xb[s].z, a1);
+      a0 = mfma16(w0[s].w, xb[s].w, a0); a1 = mfma16(w1[s].w, xb[s].w, a1);
+      if (ld) n1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ld) {
+      nq0 = *reinterpret_cast<const float4*>(wsq + 16 * kt0 + 4 * q);
+      nq1 = *reinterpret_cast<const float4*>(wsq + 16 * kt1 + 4 * q);
+    }
+    const int c0 = 16 * (wave + 8 * p) + 4 * q, c1 = c0 + 64;
+    const float s0[4] = {q0.x, q0.y, q0.z, q0.w}, s1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = (xr + s0[r]) - 2.0f * a0[r];
+      if (argmin_better(d, bd)) { bd = d; bk = c0 + r; }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float d = (xr + s1[r]) - 2.0f * a1[r];
+      if (argmin_better(d, bd)) { bd = d; bk = c1 + r; }
+    }
+  };
+  for (int p = 0; p < npair; p += 2) {
+    consume(p, wa0, wa1, qa0, qa1, p + 1 < npair, p + 1, wb0, wb1, qb0, qb1);
+    if (p + 1 < npair) consume(p + 1, wb0, wb1, qb0, qb1, p + 2 < npair, p + 2, wa0, wa1, qa0, qa1);
+  }
+  {
+    float d2 = __shfl_xor(bd, 16);
+    int k2 = __shfl_xor(bk, 16);
+    argmin_merge(bd, bk, d2, k2);
+    d2 = __shfl_xor(bd, 32);
+    k2 = __shfl_xor(bk, 32);
+    argmin_merge(bd, bk, d2, k2);
+  }
+  if (lane < 16) {
+    wbest_d[wave * 16 + lane] = bd;
+    wbest_k[wave * 16 + lane] = bk;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    float d = wbest_d[tid];
+    int k = wbest_k[tid];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) argmin_merge(d, k, wbest_d[w * 16 + tid], wbest_k[w * 16 + tid]);
+    best_k[tid] = k;
+    if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
+  }
+  __syncthreads();
+  {
+    const int row = tid >> 4, part = tid & 15;
+    float sse = 0.f;
+    if (row < nrows) {
+      const float* wq = W + (int64_t)best_k[row] * E;
+      float* qo = quant + (int64_t)(r0 + row) * E;
+#pragma unroll
+      for (int j = 0; j < E / 64; ++j) {
+        const int c = 4 * (part + 16 * j);
+        const float4 zv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq + c);
+        const float4 df = make_float4(wv.x - zv.x, wv.y - zv.y, wv.z - zv.z, wv.w - zv.w);
+        *reinterpret_cast<float4*>(qo + c) = make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w);   // :1292
+        sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
+// ---- K3, tile-owner form: one workgroup OWNS a 16-code x 16-column tile of dw (and, for column tile 0, the 16 counts) and
+// contracts over ALL rows: onehot(idx)^T (16 codes x rows) * flat (rows x 16 columns) on MFMA, the four waves taking a
+// quarter of the rows each, one in-workgroup sum at the end.  No slabs, no second launch, deterministic; cost independent
+// of how the codes are distributed (a collapsed codebook sends every row to one code).  N % 16 == 0, E % 16 == 0, K % 16 == 0.
+__global__ __launch_bounds__(256) void vq_stats_owner_kernel(const int64_t* __restrict__ idx, const float* __restrict__ flat,
+                                                             float* __restrict__ cnt, float* __restrict__ dw, int N, int E,
+                                                             int K) {
+  __shared__ float part[4][4][64];     // [wave][r][lane]
+  __shared__ float partn[4][4][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int c0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+  const int mycode = c0 + i;
+  const int per = ((N / 4) + 3) & ~3;                  // rows per wave (multiple of 4)
+  const int mb = wave * per, me = min(N, mb + per);
+  const int* idx32 = reinterpret_cast<const int*>(idx);          // low dwords of the int64 indices
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accn = {0.f, 0.f, 0.f, 0.f};
+  const bool want_cnt = (blockIdx.y == 0);
+  constexpr int U = 8;                                  // 8 groups of 4 rows in flight
+  for (int m0 = mb; m0 < me; m0 += 4 * U) {
+    int iv[U];
+    float fv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = m0 + 4 * u + q;
+      const bool ok = row < me;
+      const int rc = ok ? row : mb;
+      iv[u] = ok ? idx32[2 * (int64_t)rc] : -1;
+      fv[u] = flat[(int64_t)rc * E + e0 + i];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float a = (iv[u] == mycode) ? 1.0f : 0.0f;
+      acc = mfma16(a, fv[u], acc);
+      if (want_cnt) accn = mfma16(a, 1.0f, accn);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    part[wave][r][lane] = acc[r];
+    if (want_cnt) partn[wave][r][lane] = accn[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = (part[0][r][lane] + part[1][r][lane]) + (part[2][r][lane] + part[3][r][lane]);
+      dw[(int64_t)(c0 + 4 * q + r) * E + e0 + i] = v;           // D[4q + r][j = i]: code c0 + 4q + r, column e0 + i
+      if (want_cnt && i == 0)
+        cnt[c0 + 4 * q + r] = (partn[0][r][lane] + partn[1][r][lane]) + (partn[2][r][lane] + partn[3][r][lane]);
+    }
+  }
+}
+
 // ---- K3: slab[split] = onehot(idx)^T (K x rows) * flat (rows x E); cnt via a ones column --------------
 constexpr int SM = 32, SLD = 64 + 16;
 __global__ __launch_bounds__(256) void vq_stats_kernel(const int64_t* __restrict__ idx, const float* __restrict__ flat,
@@ -764,6 +1003,22 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
   return G2V_OK;
 }
 
+extern "C" int g2v_vq_fused_assign_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
+                                       const float* code_sqnorm, float* flat_out, int64_t* idx, float* quantized,
+                                       float* sse_partial, int N, int E, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(z && w_pre && b_pre && codebook && code_sqnorm && flat_out && idx && quantized, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (!(E == 128 && (K & 127) == 0 && ptr_aligned16(z) && ptr_aligned16(w_pre) && ptr_aligned16(b_pre) &&
+        ptr_aligned16(codebook) && ptr_aligned16(code_sqnorm) && ptr_aligned16(flat_out) && ptr_aligned16(quantized))) {
+    set_error("g2v_vq_fused_assign_fwd: needs E == 128, K %% 128 == 0 and 16-byte aligned operands");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(vq_fused_assign_kernel<128>, dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, (hipStream_t)stream, z, w_pre, b_pre,
+                     codebook, code_sqnorm, flat_out, idx, quantized, sse_partial, N, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" size_t g2v_vq_stats_workspace(int N, int E, int K) {
   if (N <= 0 || E <= 0 || K <= 0) return 0;
   return (size_t)stats_splits(N, E, K) * ((size_t)K * E + K) * sizeof(float);
@@ -776,6 +1031,14 @@ extern "C" int g2v_vq_stats(const int64_t* idx, const float* flat, float* stats,
   if (workspace_bytes < g2v_vq_stats_workspace(N, E, K)) {
     set_error("g2v_vq_stats: workspace too small");
     return G2V_ERR_WORKSPACE;
+  }
+  // enough rows for a whole-chip launch of tile owners (K / 16 x E / 16 workgroups, every one walking all N rows):
+  // one launch, no slabs.  Small problems keep the split kernel (a tile owner would leave most CUs idle).
+  if ((E & 15) == 0 && (K & 15) == 0 && N >= 1024 && (K / 16) * (E / 16) >= 128) {
+    hipLaunchKernelGGL(vq_stats_owner_kernel, dim3(K / 16, E / 16), dim3(256), 0, (hipStream_t)stream, idx, flat, stats,
+                       stats + K, N, E, K);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
   }
   const int splits = stats_splits(N, E, K);
   const int rows_per_split = round_up(cdiv(N, splits), SM);

@@ -142,6 +142,10 @@ class VQVAEEngine:
         # :483-486): their gradient slots are zeroed after the backward, so they add nothing to the clip norm and Adam
         # (m = v = 0, g = 0) leaves them exactly where they are -- what the reference's clip_grad_norm_ / Adam do by skipping them
         self.frozen: list = []
+        # code_sqnorm (||W_k||^2) is rewritten by the EMA update kernel together with the codebook; the fused training loop
+        # trusts it from one step to the next, every other entry (module-level forward, first step, after a state load)
+        # recomputes it first
+        self._wsq_fresh = False
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
@@ -255,7 +259,7 @@ class VQVAEEngine:
                 b["keep_l0"].copy_(keep_l0)
 
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
-                n_global: Optional[int] = None):
+                n_global: Optional[int] = None, trust_wsq: bool = False):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
         if self.quantizer != "ema":
@@ -267,11 +271,18 @@ class VQVAEEngine:
         b = self.forward_encoder(in_poses, training)
         # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
         N = (2 * B * H) // E
-        check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
-                                 _p(b["flat"]), E, N, E, E, 0, st))
-        check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
-        check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
-                                    _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
+        if not (trust_wsq and self._wsq_fresh):
+            check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
+        if E == 128 and K % 128 == 0:
+            # pre_linear + distances + argmin + straight-through / SSE in one launch (flat is written for the statistics)
+            check(lib.g2v_vq_fused_assign_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b), _p(self.codebook),
+                                              _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]), _p(b["quant"]), _p(b["sse"]),
+                                              N, E, K, st))
+        else:
+            check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
+                                     _p(b["flat"]), E, N, E, E, 0, st))
+            check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
+                                        _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
         check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws"]), b["ws"].numel(), st))
         if ema_update:
             self.vq_finish(B, training, n_global)
@@ -339,6 +350,8 @@ class VQVAEEngine:
                                          _p(self.ema_w), _p(self.codebook), _p(self.code_sqnorm), _p(self.vq_scalars),
                                          N, n_global or N, self.E, self.K, self.beta, self.decay, self.eps,
                                          int(training), self._stream()))
+        if training:
+            self._wsq_fresh = True          # the update kernel has just rewritten code_sqnorm with the new codebook
 
     def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):
         """custom_loss on the rollout output; fills loss_terms and (want_grad) the dy buffer with dLoss/dy."""
@@ -474,7 +487,7 @@ class VQVAEEngine:
         B = x.shape[0]
         if draw_masks:
             self.draw_masks(B, True)
-        self.forward(x, target, True, ema_update=not dp)
+        self.forward(x, target, True, ema_update=not dp, trust_wsq=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)

@@ -152,6 +152,21 @@ def vq_assign(flat, z, codebook, code_sqnorm, want_quantized=True, want_dist=Fal
     return idx, quant, dmin, sse
 
 
+def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm):
+    """pre_linear + assign in one launch (E == 128, K % 128 == 0) -> flat (N,E), idx (N) int64, quantized (N,E), sse_partial"""
+    N, E = z.shape
+    K = codebook.shape[0]
+    dev = z.device
+    lib = _lib_()
+    flat = torch.empty((N, E), dtype=torch.float32, device=dev)
+    idx = torch.empty((N,), dtype=torch.int64, device=dev)
+    quant = torch.empty((N, E), dtype=torch.float32, device=dev)
+    sse = torch.empty((lib.g2v_vq_assign_blocks(N),), dtype=torch.float32, device=dev)
+    check(lib.g2v_vq_fused_assign_fwd(_p(_chk(z)), _p(_chk(w_pre)), _p(_chk(b_pre)), _p(_chk(codebook)), _p(_chk(code_sqnorm)),
+                                      _p(flat), _p(idx), _p(quant), _p(sse), N, E, K, _stream()), "vq_fused_assign_fwd")
+    return flat, idx, quant, sse
+
+
 def vq_stats(idx, flat, K, out=None):
     N, E = flat.shape
     dev = flat.device

@@ -110,6 +110,12 @@ int g2v_vq_assign_fwd(const float* flat, const float* z, const float* codebook, 
                       int64_t* idx, float* quantized, float* dist_min, float* sse_partial,
                       int N, int E, int K, g2v_stream_t stream);
 
+/* pre_linear + assign in ONE launch (E == 128, K % 128 == 0; G2V_ERR_UNSUPPORTED otherwise -> g2v_linear_fwd +
+ * g2v_vq_assign_fwd): flat = z w_pre^T + b_pre (:1230) is written to flat_out (the code statistics read it), the
+ * distances / argmin use it from LDS, quantized / sse_partial use the raw z as in g2v_vq_assign_fwd. */
+int g2v_vq_fused_assign_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
+                            const float* code_sqnorm, float* flat_out, int64_t* idx, float* quantized,
+                            float* sse_partial, int N, int E, int K, g2v_stream_t stream);
 /* K3: cnt[k] = #{i: idx[i]=k};  dw[k,:] = sum_{i: idx[i]=k} flat[i,:]   (:1265,1275).
  * Deterministic one-hot^T x flat MFMA contraction (the one-hot is generated on the fly from idx).
  * stats layout: [cnt (K) | dw (K*E)] contiguous fp32, so it can be all-reduced as one buffer. */

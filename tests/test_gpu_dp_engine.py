@@ -10,6 +10,7 @@ import pytest
 import torch
 
 from oracle import g2v_oracle as O
+from _f64 import as64, default64
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -85,11 +86,18 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
     sd = O.init_vqvae_state(D, H, 2, K, seed=11)
     engines = [_engine(sd, D, H, K, T, p) for _ in range(world)]
     adam = {}
+    big = B >= 512           # large shards: float64 oracle (tests/_f64.py), same formulas
+    if big:
+        sd = as64(sd)
     for step in range(n_steps):
         tot_g, tot_c, tot_w = None, 0, 0
         for r in range(world):
             x, masks = _shard(r, step, B, T, D, H, p)
-            g, c, w, fw = _oracle_local(sd, x, masks, cfg, K)
+            if big:
+                with default64():
+                    g, c, w, fw = _oracle_local(sd, x.double(), masks, cfg, K)
+            else:
+                g, c, w, fw = _oracle_local(sd, x, masks, cfg, K)
             tot_g = g if tot_g is None else {k: tot_g[k] + g[k] for k in g}
             tot_c, tot_w = tot_c + c, tot_w + w
             eng = engines[r]
@@ -98,7 +106,7 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
             xd = x.to(DEV)
             eng.train_step_local(xd, xd, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=False, dp=True)
             # this rank's contribution, before any exchange: local histogram and code sums
-            assert torch.equal(eng.vq_stats[:K].cpu(), c), "local code histogram"
+            assert torch.equal(eng.vq_stats[:K].cpu().double(), c.double()), "local code histogram"
             assert relerr(eng.vq_stats[K:], w.reshape(-1)) < 1e-5
         # the SUM all-reduce of [grads | cnt | dw], by hand
         total = engines[0].comm + engines[1].comm
@@ -117,7 +125,11 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
         for eng in engines:
             eng.comm.copy_(total)
             eng.train_step_apply(B, lr=lr, world=world, dp=True)
-        norm = _oracle_apply(sd, tot_g, tot_c, tot_w, world, adam, K, lr)
+        if big:
+            with default64():
+                norm = _oracle_apply(sd, tot_g, tot_c, tot_w, world, adam, K, lr)
+        else:
+            norm = _oracle_apply(sd, tot_g, tot_c, tot_w, world, adam, K, lr)
         assert abs(engines[0].gnorm.item() - float(norm)) <= 2e-4 * float(norm), "global mean-gradient norm"
         # perplexity is computed from the GLOBAL histogram
         pr = tot_c / (world * ((2 * B * H) // (2 * H)))

@@ -11,6 +11,7 @@ import pytest
 import torch
 
 from oracle import g2v_oracle as O
+from _f64 import as64, default64
 
 pytestmark = pytest.mark.gpu
 
@@ -187,7 +188,34 @@ def test_vq_assign_nonfinite_rows_follow_torch_argmin(ops, N, E, K):
     assert torch.equal(stats[:K].cpu(), torch.bincount(got, minlength=K).float())
 
 
-@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64)])
+@pytest.mark.parametrize("N", [4096, 16, 37, 20000])
+def test_vq_fused_prelinear_assign_matches_unfused(ops, N):
+    """g2v_vq_fused_assign_fwd (pre_linear + distances + argmin + straight-through in one launch) against the two-launch
+    sequence it replaces and against the oracle's distances."""
+    E, K = 128, 512
+    z = rnd(N, E, seed=41)
+    Wp, bp = rnd(E, E, seed=42, scale=0.1), rnd(E, seed=43, scale=0.1)
+    W = torch.rand(K, E, generator=torch.Generator().manual_seed(44)) * 2 - 1
+    wsq = ops.vq_code_sqnorm(W.to(DEV))
+    flat, idx, quant, sse = ops.vq_fused_assign(z.to(DEV), Wp.to(DEV), bp.to(DEV), W.to(DEV), wsq)
+    flat_ref = z @ Wp.t() + bp
+    relclose(flat, flat_ref, 2e-6, "pre_linear rows")
+    flat2 = ops.linear_fwd(z.to(DEV), Wp.to(DEV), bp.to(DEV))
+    idx2, quant2, _, sse2 = ops.vq_assign(flat2, z.to(DEV), W.to(DEV), wsq)
+    d = O.vq_distances(flat_ref, W)
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    safe = ((top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 0].abs().clamp(min=1)).numpy()
+    got = idx.cpu().numpy()
+    assert np.array_equal(got[safe], d.argmin(1).numpy()[safe]) and np.array_equal(got[safe], idx2.cpu().numpy()[safe])
+    dd = d[torch.arange(N), torch.from_numpy(got)]
+    assert float((dd - d.min(1).values).max()) <= 1e-3
+    close(quant, z + (W[torch.from_numpy(got)] - z), 1e-6, 1e-6, "quantized")
+    sse_ref = ((W[torch.from_numpy(got)] - z) ** 2).double().sum()
+    assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
+
+
+@pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64), (4100, 128, 512), (20000, 128, 512),
+                                   (1024, 400, 512)])     # tile-owner kernel from N >= 1024 with >= 128 (16 x 16) tiles
 @pytest.mark.parametrize("collapsed", [False, True])
 def test_vq_stats_and_ema(ops, N, E, K, collapsed):
     flat = rnd(N, E, seed=21)
@@ -340,12 +368,21 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
 
     pre = "decoder.decoder."
     pkeys = [k for k in sd if k.startswith(pre) and "running" not in k and "num_batches" not in k]
-    leaves = {k: sd[k].clone().requires_grad_(True) for k in pkeys}
-    work = dict(sd); work.update(leaves)
-    h_leaf = h_init.clone().requires_grad_(True)
-    y_ref, bn_ref = _oracle_rollout(work, target, h_leaf, keep95, keep_l0, p, True)
     gy = torch.randn(T, B, D, generator=g) / (T * B * D) * 100
-    gl = torch.autograd.grad((y_ref * gy).sum(), [h_leaf] + [leaves[k] for k in pkeys])
+    if B >= 4096:            # large batch: float64 oracle (tests/_f64.py), same formulas
+        sd64 = as64(sd)
+        leaves = {k: sd64[k].clone().requires_grad_(True) for k in pkeys}
+        work = dict(sd64); work.update(leaves)
+        h_leaf = h_init.double().clone().requires_grad_(True)
+        with default64():
+            y_ref, bn_ref = _oracle_rollout(work, target.double(), h_leaf, keep95, keep_l0, p, True)
+            gl = torch.autograd.grad((y_ref * gy.double()).sum(), [h_leaf] + [leaves[k] for k in pkeys])
+    else:
+        leaves = {k: sd[k].clone().requires_grad_(True) for k in pkeys}
+        work = dict(sd); work.update(leaves)
+        h_leaf = h_init.clone().requires_grad_(True)
+        y_ref, bn_ref = _oracle_rollout(work, target, h_leaf, keep95, keep_l0, p, True)
+        gl = torch.autograd.grad((y_ref * gy).sum(), [h_leaf] + [leaves[k] for k in pkeys])
     g_ref = dict(zip(["h_init"] + pkeys, gl))
 
     wt, names = _dec_weight_tensors(sd, DEV)

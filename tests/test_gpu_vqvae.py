@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from oracle import g2v_oracle as O
+from _f64 import as64, default64
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -189,13 +190,20 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
     eng = _engine_from_state(sd, D, H, K, T, p)
     xd = x.to(DEV)
     adam = {}
+    big = B >= 4096          # large batch: float64 oracle (tests/_f64.py), same formulas
+    if big:
+        sd, x = as64(sd), x.double()
     for step in range(2):
         masks = {"dec": (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)}
         if p > 0:
             masks["in"] = (torch.rand(T, B, D, generator=g) < 1 - p).to(torch.uint8)
             masks["enc_l0"] = torch.ones(T, B, 2 * H, dtype=torch.uint8)   # layer 1 is dead compute: any mask works
             masks["dec_l0"] = (torch.rand(T - 1, B, H, generator=g) < 1 - p).to(torch.uint8)
-        r = O.vqvae_train_step(sd, adam, x, masks, cfg)
+        if big:
+            with default64():
+                r = O.vqvae_train_step(sd, adam, x, masks, cfg)
+        else:
+            r = O.vqvae_train_step(sd, adam, x, masks, cfg)
         eng.set_masks(B, masks["dec"].to(DEV), masks["in"].to(DEV) if p > 0 else None,
                       masks["dec_l0"].to(DEV) if p > 0 else None)
         eng.train_step(xd, xd, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=False)
