@@ -449,6 +449,17 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   const int r0 = blockIdx.x * VQ_ROWS;
   const int nrows = min(VQ_ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
+  // request order = consumption order (vmcnt retires in order): the raw row tile first, then the pre_linear fragments, then
+  // the first pair of codebook tiles
+  float4 zv[E / 64];
+  {
+    const int row = tid >> 4, part = tid & 15;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int rr = row < nrows ? row : 0;
+      zv[j] = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + rr) * E + 4 * (part + 16 * j));
+    }
+  }
   // pre_linear weight fragments of this wave (tiles wave, wave + 4), straight from the row-major (E,E) matrix
   float4 wp0[KS], wp1[KS];
   {
@@ -476,15 +487,11 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   float4 wa0[KS], wa1[KS], wb0[KS], wb1[KS], qa0, qa1, qb0, qb1;
   load_pair(0, wa0, wa1, qa0, qa1);
   __builtin_amdgcn_sched_barrier(0);
-  {  // stage the raw row tile (coalesced float4)
+  {  // stage the raw row tile
     const int row = tid >> 4, part = tid & 15;
 #pragma unroll
-    for (int j = 0; j < E / 64; ++j) {
-      const int c = 4 * (part + 16 * j);
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < nrows) v = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + row) * E + c);
-      *reinterpret_cast<float4*>(Xz + row * ldx + c) = v;
-    }
+    for (int j = 0; j < E / 64; ++j)
+      *reinterpret_cast<float4*>(Xz + row * ldx + 4 * (part + 16 * j)) = row < nrows ? zv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   lds_barrier();
   {  // phase 1: the projection

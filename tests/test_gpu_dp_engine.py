@@ -73,6 +73,12 @@ def _engine(sd, D, H, K, T, p):
     return eng
 
 
+def relerr_l2(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    return float((got - ref).norm()) / max(float(ref.norm()), 1e-30)
+
+
 def relerr(got, ref):
     got = got.detach().cpu().double().reshape(-1)
     ref = torch.as_tensor(ref).double().reshape(-1)
@@ -118,10 +124,11 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
             ref = tot_g[name]
             if float(ref.abs().max()) == 0.0:
                 assert float(total[off:off + n].abs().max()) == 0.0, name
+            elif big:     # L2 tight + max norm loose: single mask flips against the float64 oracle (see test_gpu_vqvae.py)
+                assert relerr_l2(total[off:off + n], ref.reshape(-1)) < 1e-3, (name, relerr_l2(total[off:off + n], ref.reshape(-1)))
+                assert relerr(total[off:off + n], ref.reshape(-1)) < 5e-3, (name, relerr(total[off:off + n], ref.reshape(-1)))
             else:
-                # (pre_linear.0.weight: a heavily cancelling sum behind BatchNorm's backward, see test_gpu_vqvae.py)
-                tol = 4e-3 if name == "decoder.decoder.pre_linear.0.weight" else 5e-4
-                assert relerr(total[off:off + n], ref.reshape(-1)) < tol, (name, relerr(total[off:off + n], ref.reshape(-1)))
+                assert relerr(total[off:off + n], ref.reshape(-1)) < 5e-4, (name, relerr(total[off:off + n], ref.reshape(-1)))
         for eng in engines:
             eng.comm.copy_(total)
             eng.train_step_apply(B, lr=lr, world=world, dp=True)
@@ -135,18 +142,26 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
         pr = tot_c / (world * ((2 * B * H) // (2 * H)))
         perp = torch.exp(-(pr * torch.log(pr + 1e-10)).sum())
         assert abs(engines[0].vq_scalars[1].item() - perp.item()) <= 1e-4 * perp.item()
-    e0, e1 = engines
-    # replicas end bit-identical (same reduced buffer, deterministic update) ...
-    assert torch.equal(e0.flat, e1.flat) and torch.equal(e0.codebook, e1.codebook) and torch.equal(e0.ema_w, e1.ema_w)
-    assert torch.equal(e0.ema_cs, e1.ema_cs)
-    # ... and equal to the oracle's two-shard global-statistics update
-    for name, _ in e0.layout:
-        if name == "decoder.decoder.pre_linear.0.bias":     # zero-gradient tensor: Adam amplifies rounding noise (see DESIGN)
-            continue
-        # Adam moves an element by ~lr per step whatever its gradient's size, so an element whose gradient sits at the
-        # rounding-noise floor may legitimately travel differently: bound = 10 % of the total travel (gradients: above)
-        err = float((e0.view(name).cpu().double() - sd[name].double()).abs().max())
-        assert err <= 1e-4 * float(sd[name].abs().max()) + 0.1 * n_steps * lr, (name, err)
-    assert relerr(e0.ema_cs, sd["vq_layer._ema_cluster_size"]) < 1e-5
-    assert relerr(e0.ema_w, sd["vq_layer._ema_w"]) < 1e-5
-    assert relerr(e0.codebook, sd["vq_layer._embedding.weight"]) < 1e-4
+        e0, e1 = engines
+        # replicas bit-identical (same reduced buffer, deterministic update), equal to the oracle's global-statistics update
+        assert torch.equal(e0.flat, e1.flat) and torch.equal(e0.codebook, e1.codebook) and torch.equal(e0.ema_w, e1.ema_w)
+        assert torch.equal(e0.ema_cs, e1.ema_cs)
+        for name, _ in e0.layout:
+            if name == "decoder.decoder.pre_linear.0.bias":     # zero-gradient tensor: Adam amplifies rounding noise (see DESIGN)
+                continue
+            diff = (e0.view(name).cpu().double() - sd[name].double()).abs()
+            err = float(diff.max())
+            if big:       # rounding-band gradients may take the opposite Adam sign (<= 2 lr away), a handful of elements at most
+                n_off = int((diff > 0.1 * lr).sum())
+                assert err <= 2.1 * lr and n_off <= max(2, diff.numel() // 500), (name, err, n_off)
+            else:
+                assert err <= 1e-4 * float(sd[name].abs().max()) + 0.1 * lr, (name, err)
+        assert relerr(e0.ema_cs, sd["vq_layer._ema_cluster_size"]) < 1e-5
+        assert relerr(e0.ema_w, sd["vq_layer._ema_w"]) < 1e-5
+        assert relerr(e0.codebook, sd["vq_layer._embedding.weight"]) < 1e-4
+        # next step from identical states (Adam turns rounding-floor gradients into +-lr steps: see sync_engine_from_oracle)
+        for r, eng in enumerate(engines):
+            from test_gpu_vqvae import sync_engine_from_oracle
+            bn = (eng.bn_rm.clone(), eng.bn_rv.clone())          # BatchNorm statistics stay per rank (north star)
+            sync_engine_from_oracle(eng, {**sd, "decoder.decoder.pre_linear.1.running_mean": bn[0].cpu(),
+                                          "decoder.decoder.pre_linear.1.running_var": bn[1].cpu()}, adam, step + 1)

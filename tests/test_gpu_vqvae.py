@@ -59,6 +59,31 @@ def check_code_indices(got_idx, ref_idx, dist, gap_rel_floor=None, gap=None):
     return safe
 
 
+def relerr_l2(got, ref):
+    got = got.detach().cpu().double().reshape(-1)
+    ref = torch.as_tensor(ref).double().reshape(-1)
+    return float((got - ref).norm()) / max(float(ref.norm()), 1e-30)
+
+
+def sync_engine_from_oracle(eng, sd, adam, step_count):
+    """Put the engine into EXACTLY the oracle's state (weights, Adam moments / step count, EMA codebook state, BatchNorm running
+    statistics).  Multi-step comparisons re-synchronise between steps: Adam moves an element whose gradient sits at the
+    rounding-noise floor by ~lr in either direction, and one step later those 1e-3-relative weight differences are 1e-3-relative
+    gradient differences that say nothing about the kernels."""
+    for name, _ in eng.layout:
+        eng.view(name).copy_(sd[name])
+        off, n, shp = eng.offsets[name]
+        st = adam.get(name)
+        if st is not None:
+            eng.m[off:off + n].copy_(st["m"].reshape(-1))
+            eng.v[off:off + n].copy_(st["v"].reshape(-1))
+    eng.step_counter.fill_(step_count)
+    eng.codebook.copy_(sd["vq_layer._embedding.weight"]); eng.ema_w.copy_(sd["vq_layer._ema_w"])
+    eng.ema_cs.copy_(sd["vq_layer._ema_cluster_size"])
+    eng.bn_rm.copy_(sd["decoder.decoder.pre_linear.1.running_mean"]); eng.bn_rv.copy_(sd["decoder.decoder.pre_linear.1.running_var"])
+    eng._wsq_fresh = False
+
+
 def relerr(got, ref):
     got = got.detach().cpu().double().reshape(-1)
     ref = torch.as_tensor(ref).double().reshape(-1)
@@ -221,23 +246,29 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
             ref = r["grads"][name]
             if float(ref.abs().max()) == 0.0:
                 assert float(eng.view(name, True).abs().max()) == 0.0, name     # encoder layer 1: exactly zero
+            elif big:
+                # max norm AND L2 norm: a ReLU / dropout-scaled activation within rounding of zero can flip its mask between
+                # fp32 and the float64 oracle, which moves single elements (max norm) but not the tensor (L2)
+                assert relerr_l2(eng.view(name, True), ref) < 1e-3, (name, relerr_l2(eng.view(name, True), ref))
+                assert relerr(eng.view(name, True), ref) < 5e-3, (name, relerr(eng.view(name, True), ref))
             else:
-                # dW of the layer feeding BatchNorm is what is left after BN's backward has projected out the batch mean and
-                # scale directions: a sum of (T-1) B products of size ~20 |y| that cancels to a small remainder, so fp32
-                # summation order (ours vs ATen's, both fp32) shows at ~1e-3 of its max norm once (T-1) B >= 1e5
-                tol = 3e-3 if (name == "decoder.decoder.pre_linear.0.weight" and B >= 4096) else 5e-4
-                assert relerr(eng.view(name, True), ref) < tol, (name, relerr(eng.view(name, True), ref))
-    for name, _ in eng.layout:
-        if name == "decoder.decoder.pre_linear.0.bias":
-            continue
-        # Adam normalises each element's gradient by its own magnitude, so elements whose gradient sits at the
-        # rounding-noise floor can move differently by a fraction of the total travel (2 steps x lr): allow 2 % of it
-        # (10 % at B = 4096, where batch-mean gradients are ~sqrt(16) smaller against the same summation noise; the
-        # gradients themselves are held to 5e-4 above).
-        err = float((eng.view(name).cpu().double() - sd[name].double()).abs().max())
-        frac = 0.02 if B < 4096 else 0.1
-        assert err <= 1e-4 * float(sd[name].abs().max()) + frac * 2 * 5e-4, (name, err)
-    assert relerr(eng.codebook, sd["vq_layer._embedding.weight"]) < 1e-4
+                assert relerr(eng.view(name, True), ref) < 5e-4, (name, relerr(eng.view(name, True), ref))
+        # post-step weights: Adam normalises each element's gradient by its own magnitude, so elements whose gradient sits at
+        # the rounding-noise floor can move differently by a fraction of the step (lr): allow 2 % of it (10 % at B = 4096,
+        # where batch-mean gradients are ~sqrt(16) smaller against the same summation noise; gradients are held above)
+        for name, _ in eng.layout:
+            if name == "decoder.decoder.pre_linear.0.bias":
+                continue
+            err = float((eng.view(name).cpu().double() - sd[name].double()).abs().max())
+            if big:
+                # the first Adam steps are ~lr * sign(g): an element whose gradient is inside the rounding band (see the
+                # gradient check above) may take the opposite sign, i.e. end up to 2 lr away -- but only a handful may
+                n_off = int(((eng.view(name).cpu().double() - sd[name].double()).abs() > 0.1 * 5e-4).sum())
+                assert err <= 2.1 * 5e-4 and n_off <= max(2, eng.view(name).numel() // 500), (name, err, n_off)
+            else:
+                assert err <= 1e-4 * float(sd[name].abs().max()) + 0.02 * 5e-4, (name, err)
+        assert relerr(eng.codebook, sd["vq_layer._embedding.weight"]) < 1e-4
+        sync_engine_from_oracle(eng, sd, adam, step + 1)          # the next step starts from identical states
 
 
 def test_full_size_properties():
