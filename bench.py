@@ -116,27 +116,38 @@ def pmc_traffic(kernel: str, N: int):
 
 
 def vq_kernel_roofline(eng, B, reps: int = 200):
-    """Average duration of the VQ assign kernel (K1+K2+K5) at the benchmark size, events on the launch stream."""
+    """Average duration of the VQ kernel of the product path at the benchmark size, events on the launch stream: the fused
+    pre_linear + assign kernel (K6+K1+K2+K5: projection, -2 z E^T distances, argmin, gather + straight-through + SSE)."""
     from gesture2vec_amd._lib import check
     lib = eng.lib
     b = eng.buffers(B)
     N, E, K = (2 * B * eng.H) // eng.E, eng.E, eng.K
     st = torch.cuda.current_stream()
-    args = (b["flat"].data_ptr(), b["enc_hidden"].data_ptr(), eng.codebook.data_ptr(), eng.code_sqnorm.data_ptr(),
-            b["idx"].data_ptr(), b["quant"].data_ptr(), None, b["sse"].data_ptr(), N, E, K, st.cuda_stream)
+    fused = (E == 128 and K % 128 == 0)
+    if fused:
+        args = (b["enc_hidden"].data_ptr(), eng.vq_pre_w.data_ptr(), eng.vq_pre_b.data_ptr(), eng.codebook.data_ptr(),
+                eng.code_sqnorm.data_ptr(), b["flat"].data_ptr(), b["idx"].data_ptr(), b["quant"].data_ptr(),
+                b["sse"].data_ptr(), N, E, K, st.cuda_stream)
+        fn, kernel = lib.g2v_vq_fused_assign_fwd, "vq_fused_assign_kernel<128>"
+        flops = 2.0 * N * K * E + 2.0 * N * E * E     # SURVEY.md 8(d): 2KE (distances) + 2E^2 (pre_linear) flop per row
+        # read z (4E) + write flat (4E) + write quantized (4E) + write idx (8, int64) per row; W_pre, b_pre, codebook, norms once
+        bytes_alg = N * (12 * E + 8) + 4 * E * E + 4 * E + 4 * K * E + 4 * K
+    else:
+        args = (b["flat"].data_ptr(), b["enc_hidden"].data_ptr(), eng.codebook.data_ptr(), eng.code_sqnorm.data_ptr(),
+                b["idx"].data_ptr(), b["quant"].data_ptr(), None, b["sse"].data_ptr(), N, E, K, st.cuda_stream)
+        fn = lib.g2v_vq_assign_fwd
+        kernel = "vq_assign_rt_kernel<128, 4>" if N >= 16384 else "vq_assign_fast_kernel<128>"
+        flops = 2.0 * N * K * E
+        bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
     for _ in range(20):
-        check(lib.g2v_vq_assign_fwd(*args))
+        check(fn(*args))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
     for _ in range(reps):
-        check(lib.g2v_vq_assign_fwd(*args))
+        check(fn(*args))
     e1.record(st)
     e1.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / reps
-    flops = 2.0 * N * K * E                      # SURVEY.md 8(d): 2KE flop per quantiser row
-    # read flat (4E) + read z (4E) + write quantized (4E) + write idx (8, int64) per row; one codebook + norms read
-    bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
-    kernel = "vq_assign_rt_kernel<128, 4>" if N >= 16384 else "vq_assign_fast_kernel<128>"
     tf = flops / (us * 1e-6) / 1e12
     return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
             "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kernel, N) if (E, K) == (128, 512) else None,
