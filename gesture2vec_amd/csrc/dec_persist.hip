@@ -338,13 +338,19 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       PSTAMP(0, 6);
     }
     // ---- y_t out, next decoder input xin_{t+1} = Dropout(0.95)(y_t | target_t)  (:1049-1052, :568-570) --------------
-    if (t > 0 && (!has_next || !(t < a.n_pre))) {
-      // fast path: the out-layer epilogue left y (and xin) as dense tiles -> coalesced 16-byte copies, nothing else
+    // fast path: the out-layer epilogue left y (and xin) as dense tiles -> coalesced 16-byte copies, nothing else; they are
+    // issued AFTER the pre_linear product and the publish (the tiles stay valid until the next step's out-layer epilogue),
+    // so that neither the stores nor their barrier sit in front of the exchange
+    const bool fast_dense = t > 0 && (!has_next || !(t < a.n_pre));
+    auto dense_stores = [&]() {
       const int64_t tile = ((int64_t)t * B + b0) * D;
       for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
         *reinterpret_cast<float4*>(a.sv.y + tile + 4 * e4) = reinterpret_cast<const float4*>(Yt)[e4];
         if (has_next && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
       }
+    };
+    if (fast_dense) {
+      if (!has_next) dense_stores();
     } else {
       const int64_t tile = ((int64_t)t * B + b0) * D;        // the block's 16 x D tile is one dense run of the (T,B,D) arrays
       const bool teacher = has_next && (t < a.n_pre);
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       }
     }
     if (!has_next) break;
-    lds_barrier();
+    if (!fast_dense) lds_barrier();      // fast path: Xy was completed by the out-layer epilogue, in front of its barrier
     PSTAMP(0, 7);
     // ---- u_{t+1} = pre_linear.0(xin_{t+1}); partial sums of (u - b) over this block's 16 rows; publish -----------------
     {
@@ -415,8 +421,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         }
       }
     }
+    if (fast_dense) dense_stores();
     PSTAMP(0, 8);
-    // (no barrier needed here: the next writers of Xy / Yt sit behind the barriers of step t+1)
+    // (no barrier needed here: the next writers of Xy / Yt / Xt sit behind the barriers of step t+1)
   }
 }
 
@@ -624,10 +631,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     // ---- this step's inputs.  The dy / keep95 tiles of step t were staged into LDS during the previous iteration (see
     // "stage the next step's tiles" below; the first iteration stages its own in the prologue), so the loop opens with the
     // exchange.  Holding every saved value of the step in registers across the exchange made hipcc park them in AGPRs
-    // behind four `s_waitcnt vmcnt(0)` (+6 us per step): the cell-1 values are requested right after the exchange and land
-    // behind the feedback product, the cell-0 values after the cell-1 epilogue, behind the hh1 / ih1 products.
+    // behind four `s_waitcnt vmcnt(0)` (+6 us per step): only the five cell-1 vectors are requested in front of the exchange
+    // (they travel while it is in flight), the cell-0 values after the cell-1 epilogue, behind the hh1 / ih1 products.
     const int64_t tile = ((int64_t)t * B + b0) * D;
     const int64_t srow = (int64_t)(t - 1) * B + row_i;      // row of the saved arrays this step reads (t >= 1)
+    CellSaved c1;
+    load_cell(c1, a.sv.gates1, a.sv.h1, t > 0 ? srow : row_i, f0);      // t == 0: a valid, unused row
     __builtin_amdgcn_sched_barrier(0);
     PSTAMP(1, 0);
     // ---- Part A: finish BatchNorm backward of step t+1 -> du_{t+1} --------------------------------------------------------
@@ -648,9 +657,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     }
     PSTAMP(1, 1);
     if (t == 0) break;                   // only the BatchNorm finish of step 1 was left (y_0 is data)
-    CellSaved c1;
-    load_cell(c1, a.sv.gates1, a.sv.h1, srow, f0);
-    __builtin_amdgcn_sched_barrier(0);
     lds_barrier();                       // Xdu (and, first iteration, Dt / Kt) complete
     PSTAMP(1, 2);
     // ---- Part B: dy_t (loss gradient + feedback through Dropout(0.95) and pre_linear) -------------------------------------

@@ -17,6 +17,20 @@
 //   vq_bwd_kernel      K5' straight-through + commitment gradient.
 #include "common.hpp"
 
+#ifdef G2V_VQSTAMPS       // diagnostic build only (gpurun_tools/vqstamps.py): shader-clock stamps of four workgroups
+__device__ unsigned long long g2v_vqstamps[4 * 16];
+#define VSTAMP(k)                                                                                                        \
+  do {                                                                                                                   \
+    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
+    if (threadIdx.x == 0 && sb_ >= 0) g2v_vqstamps[sb_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                        \
+  } while (0)
+extern "C" int g2v_read_vqstamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_vqstamps), sizeof(unsigned long long) * 64);
+}
+#else
+#define VSTAMP(k)
+#endif
+
 namespace g2v {
 
 constexpr int VQ_ROWS = 16;
@@ -449,6 +463,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   const int r0 = blockIdx.x * VQ_ROWS;
   const int nrows = min(VQ_ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
+  VSTAMP(0);
   // request order = consumption order (vmcnt retires in order): the raw row tile first, then the pre_linear fragments, then
   // the first pair of codebook tiles
   float4 zv[E / 64];
@@ -494,6 +509,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
       *reinterpret_cast<float4*>(Xz + row * ldx + 4 * (part + 16 * j)) = row < nrows ? zv[j] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   lds_barrier();
+  VSTAMP(1);
   {  // phase 1: the projection
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -516,6 +532,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     }
   }
   lds_barrier();
+  VSTAMP(2);
   {  // ||x||^2 of the projected rows
     const int row = tid >> 4, part = tid & 15;
     float s = 0.f;
@@ -528,6 +545,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     if (part == 0) xx[row] = s;
   }
   lds_barrier();
+  VSTAMP(3);
   float4 xb[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
@@ -573,6 +591,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     consume(p, wa0, wa1, qa0, qa1, p + 1 < npair, p + 1, wb0, wb1, qb0, qb1);
     if (p + 1 < npair) consume(p + 1, wb0, wb1, qb0, qb1, p + 2 < npair, p + 2, wa0, wa1, qa0, qa1);
   }
+  VSTAMP(4);
   {
     float d2 = __shfl_xor(bd, 16);
     int k2 = __shfl_xor(bk, 16);
@@ -595,6 +614,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
   }
   __syncthreads();
+  VSTAMP(5);
   {
     const int row = tid >> 4, part = tid & 15;
     float sse = 0.f;
@@ -615,6 +635,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     __syncthreads();
     if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
   }
+  VSTAMP(6);
 }
 
 // ---- K3, tile-owner form: one workgroup OWNS a 16-code x 16-column tile of dw (and, for column tile 0, the 16 counts) and

@@ -416,7 +416,10 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
         relclose(grads["dh_init"], g_ref["h_init"], 2e-2, "d h_init")
     else:
         relclose(grads["dh_init"], g_ref["h_init"], 2e-4, "d h_init")
-    bn_tol = 1e-3 if B >= 4096 else 2e-4      # sums over (T-1) B rows of terms that mostly cancel (BatchNorm backward)
+    # B >= 4096: sums over (T-1) B rows of terms that mostly cancel, and ONE activation within fp32 rounding of zero flips
+    # its ReLU mask against the float64 oracle (expected count ~1 in (T-1) B H = 8e5 activations): that element's whole
+    # gradient (~1e-6) lands in the 1e-3-sized sum
+    bn_tol = 5e-3 if B >= 4096 else 2e-4
     relclose(grads["d_bn_w"], g_ref[pre + "pre_linear.1.weight"], bn_tol, "d bn weight")
     relclose(grads["d_bn_b"], g_ref[pre + "pre_linear.1.bias"], bn_tol, "d bn bias")
     x1 = saved["x1"] if p > 0 else saved["h0"][1:]
