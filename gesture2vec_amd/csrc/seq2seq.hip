@@ -23,20 +23,49 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
   }
 }
 
-// d_table[ids[r], :] += d_out[r, :] * keep * scale.  Float atomics: rows hit by several tokens are summed in arrival
-// order (the only non-bitwise-reproducible kernel in the library; contention is low: one 4-byte add per element).
-__global__ void embedding_bwd_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
-                                     const uint8_t* __restrict__ keep, float scale, float* __restrict__ d_table,
-                                     int64_t n, int dim, int64_t V) {
-  const int64_t total = n * dim;
-  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = e / dim;
-    const int c = (int)(e - r * dim);
-    const int64_t id = ids[r];
-    if (id < 0 || id >= V) continue;
-    float g = d_out[e];
-    if (keep) g = keep[e] ? g * scale : 0.f;
-    if (g != 0.f) atomicAdd(d_table + id * dim + c, g);
+// d_table[v, :] (+)= sum over the tokens r with ids[r] == v, IN INCREASING r, of d_out[r, :] * keep * scale.
+// One wave OWNS one table row: it scans the id list 64 tokens at a time (ballot), and adds the matching rows in token
+// order, so the result is a fixed-order sum -- bitwise reproducible, no float atomics (round 1 used atomicAdd here: the one
+// kernel of the library whose output depended on arrival order).  Work: V waves x n / 64 ballots, e.g. 3863 x 50 at
+// B = 128 (3 us) and 3863 x 1600 at B = 4096 (~25 us, comparable to the atomic version under contention); rows nobody
+// refers to cost one pass over the ids and a zero (or no) store.
+template <int NE>     // elements per lane: dim <= 64 * NE
+__global__ __launch_bounds__(256) void embedding_bwd_owner_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                                                  const uint8_t* __restrict__ keep, float scale,
+                                                                  float* __restrict__ d_table, int64_t n, int dim, int64_t V,
+                                                                  int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (v >= V) return;
+  float acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  for (int64_t r0 = 0; r0 < n; r0 += 64) {
+    const int64_t r = r0 + lane;
+    const bool hit = (r < n) && (ids[r] == v);
+    unsigned long long m = __ballot(hit);
+    while (m) {
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      const int64_t row = (r0 + j) * (int64_t)dim;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int c = lane + 64 * k;
+        if (c < dim) {
+          float g = d_out[row + c];
+          if (keep) g = keep[row + c] ? g * scale : 0.f;
+          acc[k] += g;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int c = lane + 64 * k;
+    if (c < dim) {
+      float* o = d_table + v * dim + c;
+      *o = accumulate ? *o + acc[k] : acc[k];
+    }
   }
 }
 
@@ -315,9 +344,19 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
                                  int64_t n, int dim, int64_t V, int zero_first, g2v_stream_t stream) {
   G2V_REQUIRE(d_out && ids && d_table, "null pointer");
   G2V_REQUIRE(n > 0 && dim > 0 && V > 0, "bad size");
-  if (zero_first) (void)hipMemsetAsync(d_table, 0, sizeof(float) * (size_t)V * dim, (hipStream_t)stream);
-  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, (hipStream_t)stream, d_out, ids, keep,
-                     scale, d_table, n, dim, V);
+  G2V_REQUIRE(dim <= 64 * 16, "embedding dim > 1024");
+  const dim3 grid(cdiv(V, 4));
+  const int acc = zero_first ? 0 : 1;         // zero_first: every row is (over)written, rows without tokens with zeros
+#define G2V_EMB_BWD(NE)                                                                                                   \
+  hipLaunchKernelGGL((embedding_bwd_owner_kernel<NE>), grid, dim3(256), 0, (hipStream_t)stream, d_out, ids, keep, scale, \
+                     d_table, n, dim, V, acc)
+  if (dim <= 64) G2V_EMB_BWD(1);
+  else if (dim <= 128) G2V_EMB_BWD(2);
+  else if (dim <= 256) G2V_EMB_BWD(4);
+  else if (dim <= 320) G2V_EMB_BWD(5);
+  else if (dim <= 512) G2V_EMB_BWD(8);
+  else G2V_EMB_BWD(16);
+#undef G2V_EMB_BWD
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -324,7 +324,8 @@ int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_strea
  * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).
  *   g2v_embedding_fwd   out[r,:] = table[ids[r],:] * keep * scale   (nn.Embedding :90-92,126 / :252,340-343 with the
  *                       decoder's nn.Dropout(0.5) fused; keep may be NULL)
- *   g2v_embedding_bwd   d_table[ids[r],:] += d_out[r,:] * keep * scale   (float atomics; zero_first clears d_table)
+ *   g2v_embedding_bwd   d_table[v,:] (+)= sum_{r: ids[r]=v, r ascending} d_out[r,:] * keep * scale   (one wave owns a table row:
+ *                       fixed summation order, bitwise reproducible; zero_first: overwrite instead of accumulate)
  *   g2v_batchnorm_fwd   nn.BatchNorm1d(H) on (B,H) (+ optional fused ReLU), decoder.pre_linear[1:] :286-290; training:
  *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance; save_* for bwd
  *   g2v_batchnorm_bwd   dx, dweight, dbias (overwritten) from dy (the ReLU mask is taken from y > 0 when relu)

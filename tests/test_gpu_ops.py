@@ -433,8 +433,8 @@ def test_dec_rollout_fwd_bwd(ops, T, B, D, H, p):
     ]
     for wname, dyv, xv, N_, K_, bname in checks:
         dw, db = ops.linear_bwd_weight(dyv.contiguous(), xv.contiguous(), N_, K_, M=M)
-        relclose(dw, g_ref[pre + wname], 3e-3 if B >= 4096 else 3e-4, wname)
-        if B >= 4096:
+        relclose(dw, g_ref[pre + wname], 1e-2 if B >= 4096 else 3e-4, wname)      # B >= 4096: same single-flip argument as above,
+        if B >= 4096:                                                              # the L2 criterion is the tight one
             l2close(dw, g_ref[pre + wname], 1e-3, wname)
         if bname:
             relclose(db, g_ref[pre + bname], 3e-3 if B >= 4096 else 3e-4, bname)
@@ -620,10 +620,11 @@ def test_cross_entropy_and_argmax(ops, M, K):
     assert torch.equal(am, z.argmax(1)) and int(am[3]) == 5
 
 
-def test_embedding_fwd_bwd(ops):
-    V, dim, n = 300, 300, 1000
+@pytest.mark.parametrize("V,dim,n", [(300, 300, 1000), (3863, 300, 25 * 128), (514, 200, 6 * 4096), (7, 33, 500), (40, 1000, 90)])
+def test_embedding_fwd_bwd(ops, V, dim, n):
     table = rnd(V, dim, seed=1)
     ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
+    ids[: n // 3] = 3                               # a heavily shared row (PAD-like)
     keep = (torch.rand(n, dim, generator=torch.Generator().manual_seed(3)) < 0.5).to(torch.uint8)
     out = ops.embedding_fwd(table.to(DEV), ids.to(DEV), keep.to(DEV), 2.0)
     ref = table[ids] * keep * 2.0
@@ -633,6 +634,9 @@ def test_embedding_fwd_bwd(ops):
     ref_dt = torch.zeros(V, dim, dtype=torch.float64)
     ref_dt.index_add_(0, ids, (g * keep * 2.0).double())
     relclose(dt, ref_dt.float(), 2e-6, "embedding grad")
+    # fixed summation order (one wave owns a table row and adds its tokens in token order): bitwise reproducible
+    dt2 = ops.embedding_bwd(g.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
+    assert torch.equal(dt, dt2)
     out2 = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
     assert torch.equal(out2.cpu(), table[ids])
 
