@@ -23,49 +23,305 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
   }
 }
 
-// d_table[v, :] (+)= sum over the tokens r with ids[r] == v, IN INCREASING r, of d_out[r, :] * keep * scale.
-// One wave OWNS one table row: it scans the id list 64 tokens at a time (ballot), and adds the matching rows in token
-// order, so the result is a fixed-order sum -- bitwise reproducible, no float atomics (round 1 used atomicAdd here: the one
-// kernel of the library whose output depended on arrival order).  Work: V waves x n / 64 ballots, e.g. 3863 x 50 at
-// B = 128 (3 us) and 3863 x 1600 at B = 4096 (~25 us, comparable to the atomic version under contention); rows nobody
-// refers to cost one pass over the ids and a zero (or no) store.
-template <int NE>     // elements per lane: dim <= 64 * NE
-__global__ __launch_bounds__(256) void embedding_bwd_owner_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
-                                                                  const uint8_t* __restrict__ keep, float scale,
-                                                                  float* __restrict__ d_table, int64_t n, int dim, int64_t V,
-                                                                  int accumulate) {
-  const int lane = threadIdx.x & 63;
-  const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (v >= V) return;
-  float acc[NE];
-#pragma unroll
-  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
-  for (int64_t r0 = 0; r0 < n; r0 += 64) {
-    const int64_t r = r0 + lane;
-    const bool hit = (r < n) && (ids[r] == v);
-    unsigned long long m = __ballot(hit);
-    while (m) {
-      const int j = __builtin_ctzll(m);
-      m &= m - 1;
-      const int64_t row = (r0 + j) * (int64_t)dim;
-#pragma unroll
-      for (int k = 0; k < NE; ++k) {
-        const int c = lane + 64 * k;
-        if (c < dim) {
-          float g = d_out[row + c];
-          if (keep) g = keep[row + c] ? g * scale : 0.f;
-          acc[k] += g;
-        }
-      }
-    }
-  }
+// ---- embedding gradient: d_table[v, :] (+)= sum over the tokens r with ids[r] == v of d_out[r, :] * keep * scale --------------
+// No float atomics (round 1 used atomicAdd here, the one kernel of the library whose output depended on arrival order) and no
+// serial walk over a hot row either (a padded batch sends half of all tokens to row 0).
+//   n <= EMB_SMALL_N tokens (the code decoder's per-step lookup at small batch): ONE launch, a wave owns a table row, finds its
+//     tokens with a ballot scan over the ids and adds them in token order.
+//   otherwise the tokens are counting-sorted by table row, STABLY, in O(n) work --
+//       emb_rank_kernel     blocks of 1024 tokens: rank of every token among the equal ids before it in its block (ids held in
+//                           LDS, broadcast compares); (block, row) counts by integer atomicMax of rank + 1
+//       emb_colscan_kernel  per row: counts -> exclusive prefix over the blocks, and the row's total
+//       emb_scan_kernel     exclusive prefix sum of the row totals (one workgroup)
+//       emb_scatter_kernel  perm[off[row] + blockoff[block][row] + rank] = token
+//     -- the sorted list is cut into chunks that one wave each sums in list order (U rows in flight), and a row whose tokens
+//     straddle chunks is finished by one workgroup adding the chunk partials in chunk order:
+//       emb_chunk_sum       a row that lies wholly inside the chunk is written to d_table directly, the run that started before
+//                           the chunk goes to partial slot 0, the one that continues beyond it to slot 1
+//       emb_row_finish      rows without tokens are zeroed (overwrite mode); rows that span chunks sum their partials
+//   Either way a fixed summation tree: bitwise reproducible, with ~n / chunk waves of parallelism whatever the id distribution.
+constexpr int EMB_SMALL_N = 512;
+constexpr int EMB_TB = 1024;        // tokens per ranking block
+constexpr int EMB_MAX_CHUNK = 128;
+
+static inline int emb_chunk_for(int64_t n) { return n <= 16384 ? 16 : (n <= 32768 ? 32 : (n <= 65536 ? 64 : EMB_MAX_CHUNK)); }
+
+template <int NE>
+__device__ __forceinline__ void emb_store_row(float* __restrict__ dst, const float (&acc)[NE], int dim, int lane, int accumulate) {
 #pragma unroll
   for (int k = 0; k < NE; ++k) {
     const int c = lane + 64 * k;
-    if (c < dim) {
-      float* o = d_table + v * dim + c;
-      *o = accumulate ? *o + acc[k] : acc[k];
+    if (c < dim) dst[c] = accumulate ? dst[c] + acc[k] : acc[k];
+  }
+}
+
+// Row `base` of d_out * keep * scale, elements lane + 64 k.  Every load is UNCONDITIONAL (clamped column, caller passes a valid
+// row even for a dead slot) and the select comes afterwards: loads under per-element branches are issued one at a time behind
+// s_waitcnt vmcnt(0) by hipcc, which is the whole cost of these kernels.
+template <int NE, bool KEEP>
+__device__ __forceinline__ void emb_load_row(float (&g)[NE], const float* __restrict__ d_out, const uint8_t* __restrict__ keep,
+                                             float scale, int64_t base, int dim, int lane, bool valid) {
+  float x[NE];
+  uint8_t kp[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const int c = lane + 64 * k, cc = c < dim ? c : dim - 1;
+    x[k] = d_out[base + cc];
+    if (KEEP) kp[k] = keep[base + cc];
+  }
+#pragma unroll
+  for (int k = 0; k < NE; ++k) {
+    const bool live = valid && (lane + 64 * k < dim) && (!KEEP || kp[k]);
+    g[k] = live ? (KEEP ? x[k] * scale : x[k]) : 0.f;
+  }
+}
+
+template <int NE, bool KEEP>     // elements per lane: dim <= 64 * NE.  One workgroup per table row; its 4 waves split the tokens
+__global__ __launch_bounds__(256) void emb_owner_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                                        const uint8_t* __restrict__ keep, float scale,
+                                                        float* __restrict__ d_table, int n, int dim, int64_t V, int accumulate) {
+  constexpr int U = NE <= 5 ? 8 : (NE <= 8 ? 4 : 2);
+  __shared__ float comb[3][64 * NE];
+  __shared__ int any_hit;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t v = blockIdx.x;
+  if (threadIdx.x == 0) any_hit = 0;
+  __syncthreads();
+  float acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  const int per = (n + 3) / 4, lo = wave * per < n ? wave * per : n, hi = lo + per < n ? lo + per : n;
+  bool hit = false;
+  for (int r0 = lo; r0 < hi; r0 += 64) {
+    const int r = r0 + lane;
+    unsigned long long m = __ballot(r < hi && ids[r < hi ? r : lo] == v);
+    hit |= m != 0;
+    while (m) {
+      float g[U][NE];
+      bool ok[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        ok[u] = m != 0;
+        const int j = ok[u] ? __builtin_ctzll(m) : 0;
+        m &= m - 1;
+        emb_load_row<NE, KEEP>(g[u], d_out, keep, scale, (int64_t)(r0 + j) * dim, dim, lane, ok[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (ok[u]) {
+#pragma unroll
+          for (int k = 0; k < NE; ++k) acc[k] += g[u][k];
+        }
     }
+  }
+  if (hit && lane == 0) any_hit = 1;
+  __syncthreads();
+  if (!any_hit) {                                          // the common case: nobody refers to this row
+    if (!accumulate && wave == 0) emb_store_row<NE>(d_table + v * dim, acc, dim, lane, 0);
+    return;
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) comb[wave - 1][lane + 64 * k] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] += comb[w][lane + 64 * k];
+    emb_store_row<NE>(d_table + v * dim, acc, dim, lane, accumulate);
+  }
+}
+
+__global__ __launch_bounds__(EMB_TB) void emb_rank_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t V,
+                                                          int* __restrict__ blockcnt, int* __restrict__ rank) {
+  __shared__ __attribute__((aligned(16))) int sid[EMB_TB];
+  const int tid = threadIdx.x;
+  const int64_t r = (int64_t)blockIdx.x * EMB_TB + tid;
+  const int64_t id64 = r < n ? ids[r] : -1;
+  const int id = (id64 >= 0 && id64 < V) ? (int)id64 : -1;
+  sid[tid] = id;
+  __syncthreads();
+  // equal ids in the waves before this one (2 VALU ops per comparison), then this wave's own 64 with the position tests
+  const int wbase = __builtin_amdgcn_readfirstlane(tid >> 6) * 64;
+  int before = 0, after = 0;
+#pragma unroll 4
+  for (int j = 0; j < wbase; j += 4) {
+    const int4 q = *reinterpret_cast<const int4*>(&sid[j]);
+    before += (q.x == id) + (q.y == id) + (q.z == id) + (q.w == id);
+  }
+#pragma unroll 4
+  for (int j = wbase; j < wbase + 64; j += 4) {
+    const int4 q = *reinterpret_cast<const int4*>(&sid[j]);
+    const int e0 = q.x == id, e1 = q.y == id, e2 = q.z == id, e3 = q.w == id;
+    before += (e0 & (j < tid)) + (e1 & (j + 1 < tid)) + (e2 & (j + 2 < tid)) + (e3 & (j + 3 < tid));
+    after += (e0 & (j > tid)) + (e1 & (j + 1 > tid)) + (e2 & (j + 2 > tid)) + (e3 & (j + 3 > tid));
+  }
+  if (id >= 0) {
+    rank[r] = before;
+    // the last token of a (wave, row) pair proposes the pair's running count; the maximum over the block's waves is the
+    // (block, row) count.  Integer max: exact and order-free.
+    if (after == 0) atomicMax(blockcnt + (int64_t)blockIdx.x * V + id, before + 1);
+  }
+}
+
+__global__ void emb_colscan_kernel(int* __restrict__ blockcnt, int nb, int64_t V, int* __restrict__ cnt) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= V) return;
+  int run = 0;
+  for (int b = 0; b < nb; ++b) {
+    const int c = blockcnt[(int64_t)b * V + v];
+    blockcnt[(int64_t)b * V + v] = run;
+    run += c;
+  }
+  cnt[v] = run;
+}
+
+__global__ __launch_bounds__(1024) void emb_scan_kernel(const int* __restrict__ cnt, int* __restrict__ off, int64_t V) {
+  __shared__ int part[1024];
+  const int tid = threadIdx.x;
+  const int64_t per = (V + 1023) / 1024, lo = tid * per < V ? tid * per : V, hi = lo + per < V ? lo + per : V;
+  int s = 0;
+  for (int64_t v = lo; v < hi; ++v) s += cnt[v];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    const int add = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += add;
+    __syncthreads();
+  }
+  int run = part[tid] - s;
+  for (int64_t v = lo; v < hi; ++v) {
+    off[v] = run;
+    run += cnt[v];
+  }
+  if (tid == 1023) off[V] = part[1023];
+}
+
+__global__ void emb_scatter_kernel(const int64_t* __restrict__ ids, int64_t n, int64_t V, const int* __restrict__ blockoff,
+                                   const int* __restrict__ off, const int* __restrict__ rank, int* __restrict__ perm) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= n) return;
+  const int64_t id = ids[r];
+  if (id < 0 || id >= V) return;
+  perm[off[id] + blockoff[(r / EMB_TB) * V + id] + rank[r]] = (int)r;
+}
+
+template <int NE, bool KEEP>
+__global__ __launch_bounds__(64) void emb_chunk_sum_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                                           const uint8_t* __restrict__ keep, float scale,
+                                                           const int* __restrict__ off, const int* __restrict__ perm,
+                                                           float* __restrict__ d_table, float* __restrict__ partial, int dim,
+                                                           int64_t V, int chunk, int accumulate) {
+  constexpr int U = NE <= 5 ? 8 : (NE <= 8 ? 4 : 2);      // rows in flight
+  constexpr int Q = EMB_MAX_CHUNK / 64;
+  const int lane = threadIdx.x;
+  const int total = off[V];
+  const int begin = blockIdx.x * chunk;
+  if (begin >= total) return;
+  const int end = begin + chunk < total ? begin + chunk : total;
+  // per list position (lane + 64 q): token, row, and where the row's sum goes: 2 = d_table (the row lies inside this chunk),
+  // 0 / 1 = partial slot (the row started before this chunk / continues beyond it)
+  int tok[Q], row[Q], dst[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int p = begin + q * 64 + lane;
+    const bool in = p < end;
+    tok[q] = perm[in ? p : begin];                        // unconditional loads (see emb_load_row)
+    const int rw = (int)ids[tok[q]];
+    const int o0 = off[rw], o1 = off[rw + 1];
+    row[q] = in ? rw : -1;
+    dst[q] = (o0 >= begin && o1 <= end) ? 2 : (o0 < begin ? 0 : 1);
+  }
+  float acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  int cur = __builtin_amdgcn_readfirstlane(row[0]), cur_dst = __builtin_amdgcn_readfirstlane(dst[0]);
+  auto flush = [&]() {
+    float* o = cur_dst == 2 ? d_table + (int64_t)cur * dim : partial + ((int64_t)blockIdx.x * 2 + cur_dst) * dim;
+    emb_store_row<NE>(o, acc, dim, lane, cur_dst == 2 ? accumulate : 0);
+#pragma unroll
+    for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  };
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    for (int j0 = 0; j0 < 64; j0 += U) {
+      if (begin + q * 64 + j0 >= end) break;
+      float g[U][NE];
+      int rw[U], ds[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int t = __builtin_amdgcn_readlane(tok[q], j0 + u);
+        rw[u] = __builtin_amdgcn_readlane(row[q], j0 + u);          // -1 past the end of the list
+        ds[u] = __builtin_amdgcn_readlane(dst[q], j0 + u);
+        emb_load_row<NE, KEEP>(g[u], d_out, keep, scale, (int64_t)t * dim, dim, lane, rw[u] >= 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (rw[u] < 0) continue;
+        if (rw[u] != cur) {
+          flush();
+          cur = rw[u];
+          cur_dst = ds[u];
+        }
+#pragma unroll
+        for (int k = 0; k < NE; ++k) acc[k] += g[u][k];
+      }
+    }
+  }
+  flush();
+}
+
+template <int NE>     // one workgroup (4 waves) per table row; the waves split the row's chunk range, wave order fixes the sum
+__global__ __launch_bounds__(256) void emb_row_finish_kernel(const int* __restrict__ off, const float* __restrict__ partial,
+                                                             float* __restrict__ d_table, int dim, int64_t V, int chunk,
+                                                             int accumulate) {
+  constexpr int U = NE <= 5 ? 8 : (NE <= 8 ? 4 : 2);
+  __shared__ float comb[3][64 * NE];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t v = blockIdx.x;
+  const int lo = off[v], hi = off[v + 1];
+  float acc[NE];
+#pragma unroll
+  for (int k = 0; k < NE; ++k) acc[k] = 0.f;
+  if (hi == lo) {
+    if (!accumulate && wave == 0) emb_store_row<NE>(d_table + v * dim, acc, dim, lane, 0);
+    return;
+  }
+  const int c0 = lo / chunk, c1 = (hi - 1) / chunk;
+  if (c0 == c1) return;                                    // written by the chunk's wave
+  const int per = (c1 - c0 + 4) / 4;
+  const int wb = c0 + wave * per, we = wb + per - 1 < c1 ? wb + per - 1 : c1;
+  for (int cb = wb; cb <= we; cb += U) {
+    float g[U][NE];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int c = cb + u;
+      const float* src = partial + ((int64_t)c * 2 + (lo < c * chunk ? 0 : 1)) * dim;
+#pragma unroll
+      for (int k = 0; k < NE; ++k) {
+        const int col = lane + 64 * k;
+        g[u][k] = (c <= we && col < dim) ? src[col] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] += g[u][k];
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int k = 0; k < NE; ++k) comb[wave - 1][lane + 64 * k] = acc[k];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] += comb[w][lane + 64 * k];
+    emb_store_row<NE>(d_table + v * dim, acc, dim, lane, accumulate);
   }
 }
 
@@ -340,23 +596,74 @@ extern "C" int g2v_embedding_fwd(const float* table, const int64_t* ids, const u
   return G2V_OK;
 }
 
+static size_t emb_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+extern "C" size_t g2v_embedding_bwd_ws_bytes(int64_t n, int dim, int64_t V) {
+  if (n <= EMB_SMALL_N) return 256;
+  const size_t nb = (size_t)cdiv(n, EMB_TB), chunks = (size_t)cdiv(n, emb_chunk_for(n));
+  return emb_align(nb * V * 4) + emb_align((size_t)V * 4) + emb_align((size_t)(V + 1) * 4) + 2 * emb_align((size_t)n * 4) +
+         emb_align(chunks * 2 * dim * 4);
+}
+
 extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* keep, float scale, float* d_table,
-                                 int64_t n, int dim, int64_t V, int zero_first, g2v_stream_t stream) {
-  G2V_REQUIRE(d_out && ids && d_table, "null pointer");
+                                 int64_t n, int dim, int64_t V, int zero_first, void* ws, size_t ws_bytes,
+                                 g2v_stream_t stream) {
+  G2V_REQUIRE(d_out && ids && d_table && ws, "null pointer");
   G2V_REQUIRE(n > 0 && dim > 0 && V > 0, "bad size");
+  G2V_REQUIRE(n < (int64_t)1 << 31 && V < (int64_t)1 << 31, "more than 2^31 tokens or rows");
   G2V_REQUIRE(dim <= 64 * 16, "embedding dim > 1024");
-  const dim3 grid(cdiv(V, 4));
+  G2V_REQUIRE(ws_bytes >= g2v_embedding_bwd_ws_bytes(n, dim, V), "workspace too small (g2v_embedding_bwd_ws_bytes)");
+  hipStream_t st = (hipStream_t)stream;
   const int acc = zero_first ? 0 : 1;         // zero_first: every row is (over)written, rows without tokens with zeros
-#define G2V_EMB_BWD(NE)                                                                                                   \
-  hipLaunchKernelGGL((embedding_bwd_owner_kernel<NE>), grid, dim3(256), 0, (hipStream_t)stream, d_out, ids, keep, scale, \
-                     d_table, n, dim, V, acc)
-  if (dim <= 64) G2V_EMB_BWD(1);
-  else if (dim <= 128) G2V_EMB_BWD(2);
-  else if (dim <= 256) G2V_EMB_BWD(4);
-  else if (dim <= 320) G2V_EMB_BWD(5);
-  else if (dim <= 512) G2V_EMB_BWD(8);
-  else G2V_EMB_BWD(16);
-#undef G2V_EMB_BWD
+#define G2V_EMB_DISPATCH(LAUNCH)    \
+  if (dim <= 64) LAUNCH(1);         \
+  else if (dim <= 128) LAUNCH(2);   \
+  else if (dim <= 256) LAUNCH(4);   \
+  else if (dim <= 320) LAUNCH(5);   \
+  else if (dim <= 512) LAUNCH(8);   \
+  else LAUNCH(16)
+  if (n <= EMB_SMALL_N) {
+#define G2V_EMB_OWNER(NE)                                                                                                    \
+  do {                                                                                                                       \
+    if (keep)                                                                                                                \
+      hipLaunchKernelGGL((emb_owner_kernel<NE, true>), dim3((unsigned)V), dim3(256), 0, st, d_out, ids, keep, scale, d_table, \
+                         (int)n, dim, V, acc);                                                                               \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((emb_owner_kernel<NE, false>), dim3((unsigned)V), dim3(256), 0, st, d_out, ids, keep, scale,        \
+                         d_table, (int)n, dim, V, acc);                                                                      \
+  } while (0)
+    G2V_EMB_DISPATCH(G2V_EMB_OWNER);
+#undef G2V_EMB_OWNER
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
+  const int nb = cdiv(n, EMB_TB), chunk = emb_chunk_for(n), chunks = cdiv(n, chunk);
+  char* w = (char*)ws;
+  int* blockcnt = (int*)w;            w += emb_align((size_t)nb * V * 4);
+  int* cnt = (int*)w;                 w += emb_align((size_t)V * 4);
+  int* off = (int*)w;                 w += emb_align((size_t)(V + 1) * 4);
+  int* rank = (int*)w;                w += emb_align((size_t)n * 4);
+  int* perm = (int*)w;                w += emb_align((size_t)n * 4);
+  float* partial = (float*)w;
+  (void)hipMemsetAsync(blockcnt, 0, (size_t)nb * V * 4, st);
+  hipLaunchKernelGGL(emb_rank_kernel, dim3(nb), dim3(EMB_TB), 0, st, ids, n, V, blockcnt, rank);
+  hipLaunchKernelGGL(emb_colscan_kernel, dim3(cdiv(V, 64)), dim3(64), 0, st, blockcnt, nb, V, cnt);
+  hipLaunchKernelGGL(emb_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, off, V);
+  hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, V, blockcnt, off, rank, perm);
+#define G2V_EMB_SORTED(NE)                                                                                                 \
+  do {                                                                                                                     \
+    if (keep)                                                                                                              \
+      hipLaunchKernelGGL((emb_chunk_sum_kernel<NE, true>), dim3(chunks), dim3(64), 0, st, d_out, ids, keep, scale, off,    \
+                         perm, d_table, partial, dim, V, chunk, acc);                                                      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((emb_chunk_sum_kernel<NE, false>), dim3(chunks), dim3(64), 0, st, d_out, ids, keep, scale, off,   \
+                         perm, d_table, partial, dim, V, chunk, acc);                                                      \
+    hipLaunchKernelGGL((emb_row_finish_kernel<NE>), dim3((unsigned)V), dim3(256), 0, st, off, partial, d_table, dim, V,    \
+                       chunk, acc);                                                                                        \
+  } while (0)
+  G2V_EMB_DISPATCH(G2V_EMB_SORTED);
+#undef G2V_EMB_SORTED
+#undef G2V_EMB_DISPATCH
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

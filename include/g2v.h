@@ -324,8 +324,11 @@ int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_strea
  * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).
  *   g2v_embedding_fwd   out[r,:] = table[ids[r],:] * keep * scale   (nn.Embedding :90-92,126 / :252,340-343 with the
  *                       decoder's nn.Dropout(0.5) fused; keep may be NULL)
- *   g2v_embedding_bwd   d_table[v,:] (+)= sum_{r: ids[r]=v, r ascending} d_out[r,:] * keep * scale   (one wave owns a table row:
- *                       fixed summation order, bitwise reproducible; zero_first: overwrite instead of accumulate)
+ *   g2v_embedding_bwd   d_table[v,:] (+)= sum_{r: ids[r]=v} d_out[r,:] * keep * scale.  No float atomics: tokens are counting-
+ *                       sorted by row (stable), 128-token chunks of the sorted list are summed in order and rows that span
+ *                       chunks add their chunk partials in order -- a fixed summation tree, bitwise reproducible.
+ *                       zero_first: overwrite instead of accumulate.  ws: g2v_embedding_bwd_ws_bytes(n, dim, V) bytes of
+ *                       device scratch (ids outside [0,V) contribute nothing)
  *   g2v_batchnorm_fwd   nn.BatchNorm1d(H) on (B,H) (+ optional fused ReLU), decoder.pre_linear[1:] :286-290; training:
  *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance; save_* for bwd
  *   g2v_batchnorm_bwd   dx, dweight, dbias (overwritten) from dy (the ReLU mask is taken from y > 0 when relu)
@@ -336,8 +339,9 @@ int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_strea
  * ------------------------------------------------------------------------------------------ */
 int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out,
                       int64_t n, int dim, int64_t V, g2v_stream_t stream);
+size_t g2v_embedding_bwd_ws_bytes(int64_t n, int dim, int64_t V);
 int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* keep, float scale, float* d_table,
-                      int64_t n, int dim, int64_t V, int zero_first, g2v_stream_t stream);
+                      int64_t n, int dim, int64_t V, int zero_first, void* ws, size_t ws_bytes, g2v_stream_t stream);
 int g2v_batchnorm_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
                       int training, int relu, float* y, float* save_mean, float* save_invstd, int B, int H,
                       g2v_stream_t stream);

@@ -620,11 +620,19 @@ def test_cross_entropy_and_argmax(ops, M, K):
     assert torch.equal(am, z.argmax(1)) and int(am[3]) == 5
 
 
-@pytest.mark.parametrize("V,dim,n", [(300, 300, 1000), (3863, 300, 25 * 128), (514, 200, 6 * 4096), (7, 33, 500), (40, 1000, 90)])
-def test_embedding_fwd_bwd(ops, V, dim, n):
+@pytest.mark.parametrize("V,dim,n,pattern", [(300, 300, 1000, "head"), (3863, 300, 25 * 128, "stride"), (514, 200, 6 * 4096, "head"),
+                                             (7, 33, 500, "stride"), (40, 1000, 90, "head"), (9, 300, 1000, "one"),
+                                             (3863, 300, 30 * 4096, "stride"), (64, 64, 129, "head"), (514, 200, 12 * 4096, "stride"),
+                                             (514, 200, 4096, "uniform"), (514, 200, 128, "uniform")])
+def test_embedding_fwd_bwd(ops, V, dim, n, pattern):
     table = rnd(V, dim, seed=1)
     ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))
-    ids[: n // 3] = 3                               # a heavily shared row (PAD-like)
+    if pattern == "head":
+        ids[: n // 3] = 3                           # a heavily shared row (PAD-like), contiguous
+    elif pattern == "stride":
+        ids[::2] = 0                                # half of all tokens on row 0, interleaved (padded sentences)
+    elif pattern == "one":
+        ids[:] = 5                                  # every token on one row
     keep = (torch.rand(n, dim, generator=torch.Generator().manual_seed(3)) < 0.5).to(torch.uint8)
     out = ops.embedding_fwd(table.to(DEV), ids.to(DEV), keep.to(DEV), 2.0)
     ref = table[ids] * keep * 2.0
@@ -634,11 +642,18 @@ def test_embedding_fwd_bwd(ops, V, dim, n):
     ref_dt = torch.zeros(V, dim, dtype=torch.float64)
     ref_dt.index_add_(0, ids, (g * keep * 2.0).double())
     relclose(dt, ref_dt.float(), 2e-6, "embedding grad")
-    # fixed summation order (one wave owns a table row and adds its tokens in token order): bitwise reproducible
+    # fixed summation tree (stable counting sort, chunk sums in list order, chunk partials in chunk order): bitwise reproducible
     dt2 = ops.embedding_bwd(g.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
     assert torch.equal(dt, dt2)
     out2 = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
     assert torch.equal(out2.cpu(), table[ids])
+    # ids outside the table contribute nothing (the forward returns zeros for them)
+    bad = ids.clone()
+    bad[1], bad[n // 2], bad[n - 1] = V + 3, -1, V
+    ok = (bad >= 0) & (bad < V)
+    ref_bad = torch.zeros(V, dim, dtype=torch.float64)
+    ref_bad.index_add_(0, bad[ok], (g * keep * 2.0).double()[ok])
+    relclose(ops.embedding_bwd(g.to(DEV), bad.to(DEV), V, keep.to(DEV), 2.0), ref_bad.float(), 2e-6, "embedding grad, bad ids")
 
 
 def test_gru_fused_input_projection_matches_unfused():
