@@ -399,6 +399,51 @@ extern "C" int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t
   return G2V_OK;
 }
 
+// dst_k[i] = src_k[i] (src_k == NULL: 0) for up to COPY_SEGS segments per launch; blockIdx.y = segment.
+constexpr int COPY_SEGS = 48;
+struct CopyBatch {
+  const float* src[COPY_SEGS];
+  float* dst[COPY_SEGS];
+  int64_t n[COPY_SEGS];
+};
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopyBatch cb) {
+  const float* __restrict__ src = cb.src[blockIdx.y];
+  float* __restrict__ dst = cb.dst[blockIdx.y];
+  const int64_t n = cb.n[blockIdx.y];
+  const bool vec = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (vec) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = t0; i < n4; i += stride)
+      reinterpret_cast<float4*>(dst)[i] = src ? reinterpret_cast<const float4*>(src)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t i = (n4 << 2) + t0; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
+  } else {
+    for (int64_t i = t0; i < n; i += stride) dst[i] = src ? src[i] : 0.f;
+  }
+}
+
+extern "C" int g2v_copy_segments(const float* const* src, float* const* dst, const int64_t* n, int nseg,
+                                 g2v_stream_t stream) {
+  G2V_REQUIRE(src && dst && n, "null pointer");
+  G2V_REQUIRE(nseg >= 0, "bad size");
+  for (int s0 = 0; s0 < nseg; s0 += COPY_SEGS) {
+    CopyBatch cb;
+    const int cnt = nseg - s0 < COPY_SEGS ? nseg - s0 : COPY_SEGS;
+    int64_t nmax = 1;
+    for (int k = 0; k < COPY_SEGS; ++k) {
+      const int j = k < cnt ? s0 + k : s0;
+      G2V_REQUIRE(dst[j] && n[j] >= 0, "null destination / negative length");
+      cb.src[k] = src[j]; cb.dst[k] = dst[j]; cb.n[k] = k < cnt ? n[j] : 0;
+      if (cb.n[k] > nmax) nmax = cb.n[k];
+    }
+    int gx = cdiv(nmax, 1024);
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(copy_segments_kernel, dim3(gx, cnt), dim3(256), 0, (hipStream_t)stream, cb);
+    G2V_CHECK_LAUNCH();
+  }
+  return G2V_OK;
+}
+
 extern "C" int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream) {
   G2V_REQUIRE(p, "null pointer");
   if (n <= 0) return G2V_OK;

@@ -10,8 +10,8 @@
 namespace g2v {
 
 __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int64_t* __restrict__ ids,
-                                     const uint8_t* __restrict__ keep, float scale, float* __restrict__ out, int64_t n,
-                                     int dim, int64_t V) {
+                                     const uint8_t* __restrict__ keep, float scale, float* __restrict__ out, int64_t ldo,
+                                     int64_t n, int dim, int64_t V) {
   const int64_t total = n * dim;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = e / dim;
@@ -19,7 +19,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
     const int64_t id = ids[r];
     float v = (id >= 0 && id < V) ? table[id * dim + c] : 0.f;
     if (keep) v = keep[e] ? v * scale : 0.f;
-    out[e] = v;
+    out[r * ldo + c] = v;
   }
 }
 
@@ -587,11 +587,11 @@ static int blocks_for(int64_t n) {
 }
 
 extern "C" int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out,
-                                 int64_t n, int dim, int64_t V, g2v_stream_t stream) {
+                                 int64_t ldo, int64_t n, int dim, int64_t V, g2v_stream_t stream) {
   G2V_REQUIRE(table && ids && out, "null pointer");
-  G2V_REQUIRE(n > 0 && dim > 0 && V > 0, "bad size");
+  G2V_REQUIRE(n > 0 && dim > 0 && V > 0 && ldo >= dim, "bad size");
   hipLaunchKernelGGL(embedding_fwd_kernel, dim3(blocks_for(n * dim)), dim3(256), 0, (hipStream_t)stream, table, ids, keep,
-                     scale, out, n, dim, V);
+                     scale, out, ldo, n, dim, V);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

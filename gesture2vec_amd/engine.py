@@ -18,7 +18,9 @@ its gradients are exactly zero in the reference [SURVEY.md §0]; its weights sta
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import torch
@@ -146,6 +148,37 @@ class VQVAEEngine:
         # trusts it from one step to the next, every other entry (module-level forward, first step, after a state load)
         # recomputes it first
         self._wsq_fresh = False
+        # Independent kernel chains of the fused train step run as parallel branches (side HIP streams; parallel branches of
+        # the hipGraph when the step is captured) -- see _branch().  Bit 0: the dropout keep-masks beside the encoder
+        # forward; bit 1: the EMA statistics + codebook update beside the decoder rollout; bit 2: the decoder's weight
+        # gradients beside the encoder's backward; bit 3: the encoder GRU's weight gradients beside the input layer's.
+        # G2V_OVERLAP=0 serialises everything on the caller's stream.
+        self.overlap = int(os.environ.get("G2V_OVERLAP", "7"))
+        self._sides: Dict[int, torch.cuda.Stream] = {}
+        self._open: list = []
+
+    # ------------------------------------------------------------------ parallel branches
+    @contextlib.contextmanager
+    def _branch(self, k: int):
+        """Launch the enclosed kernels on side stream k, ordered after everything launched so far on the current stream.
+        The branch stays open until _join(k) makes the current stream wait for it.  A branch may only touch buffers (and a
+        workspace) that nothing launched on the main stream between the fork and the join touches."""
+        if not (self.overlap >> k) & 1:
+            yield
+            return
+        side = self._sides.get(k)
+        if side is None:
+            side = self._sides[k] = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("G2V_SIDE_PRIORITY", "0")))
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            yield
+        self._open.append(k)
+
+    def _join(self, k: Optional[int] = None):
+        """current stream waits for branch k (default: every open branch)"""
+        for j in [x for x in self._open if k is None or x == k]:
+            torch.cuda.current_stream().wait_stream(self._sides[j])
+            self._open.remove(j)
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
@@ -233,6 +266,13 @@ class VQVAEEngine:
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
                        4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H))     # batches of four GRU weight gradients
         b["ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        # scratch of the parallel branches (see _branch): never shared with the main chain
+        b["ws_stats"] = torch.zeros(max(self.lib.g2v_vq_stats_workspace(B, E, K), 256), dtype=torch.uint8, device=dev)
+        b["ws_dec_wgrad"] = torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
+                                            self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
+                                            4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
+                                        dtype=torch.uint8, device=dev)
+        b["ws_enc_wgrad"] = torch.zeros(4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H), dtype=torch.uint8, device=dev)
         self._bufs[B] = b
         return b
 
@@ -283,10 +323,17 @@ class VQVAEEngine:
                                      _p(b["flat"]), E, N, E, E, 0, st))
             check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
                                         _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
-        check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws"]), b["ws"].numel(), st))
-        if ema_update:
-            self.vq_finish(B, training, n_global)
-        return self.forward_decoder(out_poses, B, training)
+        # the statistics and the codebook update feed nothing in this forward (the rollout starts from `quant`, taken from the
+        # codebook as it was): a parallel branch beside the rollout
+        with self._branch(1):
+            check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws_stats"]),
+                                   b["ws_stats"].numel(), self._stream()))
+            if ema_update:
+                self.vq_finish(B, training, n_global)
+        self._join(0)                       # keep masks drawn beside the encoder (train_step_local)
+        b = self.forward_decoder(out_poses, B, training)
+        self._join(1)
+        return b
 
     def forward_encoder(self, in_poses: torch.Tensor, training: bool):
         """EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU.  Fills buffers['enc_hidden'] (2,B,H) =
@@ -366,17 +413,18 @@ class VQVAEEngine:
         if self.quantizer != "ema":
             raise NotImplementedError("fused backward = EMA quantiser; see backward_decoder / backward_encoder")
         H, E = self.H, self.E
-        b = self.backward_decoder(B)
+        b = self.backward_decoder(B, wgrad_branch=True)
         # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
         N = (2 * B * H) // E
         gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
         check(self.lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
                                   self.beta, self._stream()))
         self.backward_encoder(in_poses, B)
+        self._join(2)
 
-    def _wgrad_fns(self, b, M_default):
+    def _wgrad_fns(self, b, M_default, ws_key="ws"):
         lib = self.lib
-        ws, wsn = _p(b["ws"]), b["ws"].numel()
+        ws, wsn = _p(b[ws_key]), b[ws_key].numel()
         G, H = 3 * self.H, self.H
 
         def wgrad(dy, lddy, x, ldx, wname, bname, N_, K_, rows=M_default, row_map=(0, 0, 0), keep=None, scale=1.0):
@@ -393,9 +441,11 @@ class VQVAEEngine:
                                                   self._stream()))
         return wgrad, wgrad4
 
-    def backward_decoder(self, B: int):
+    def backward_decoder(self, B: int, wgrad_branch: bool = False):
         """Backward of forward_decoder(training=True): expects buffers['dy'] = dLoss/d y (T,B,D); writes the decoder's
-        parameter gradients (overwrite) and buffers['dh_init'] (2,B,H) = dLoss / d(initial hidden state)."""
+        parameter gradients (overwrite) and buffers['dh_init'] (2,B,H) = dLoss / d(initial hidden state).
+        wgrad_branch: the weight-gradient products are launched as parallel branch 2 (own workspace); the caller joins it
+        (backward() does, after the encoder's backward has been launched on the main chain)."""
         lib, st = self.lib, self._stream()
         T, D, H, E, G = self.T, self.D, self.H, self.E, 3 * self.H
         b = self.buffers(B)
@@ -407,16 +457,17 @@ class VQVAEEngine:
         pre = "decoder.decoder."
         M = (T - 1) * B
         x1 = b["x1"] if drop else b["h0"][1:]
-        wgrad, wgrad4 = self._wgrad_fns(b, M)
-        wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
-        wgrad4(M, [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
-                   (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
-                   (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
-                   (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
-        wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
-        for name in self.frozen:
-            g = self.view(name, True)
-            check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), st))
+        with (self._branch(2) if wgrad_branch else contextlib.nullcontext()):
+            wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws")
+            wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
+            wgrad4(M, [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
+                       (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
+                       (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
+                       (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
+            wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
+            for name in self.frozen:
+                g = self.view(name, True)
+                check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
         return b
 
     def backward_encoder(self, in_poses: torch.Tensor, B: int):
@@ -446,10 +497,12 @@ class VQVAEEngine:
             dirs[k].in_dim = H
         check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
-        wgrad4(TB, [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
-                    (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
-                    (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
-                    (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")])
+        with self._branch(3):       # beside the input layer's gradient below (joined there)
+            _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 3) & 1 else "ws")
+            wgrad4s(TB, [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
+                         (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
+                         (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
+                         (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")])
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
         else:
@@ -458,6 +511,7 @@ class VQVAEEngine:
         wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
               row_map=(B, D, T * D), keep=_p(b["keep_in"]) if drop else None,
               scale=1.0 / (1.0 - self.p) if drop else 1.0)
+        self._join(3)
         # encoder GRU layer 1 receives exactly-zero gradients (dead compute in the reference); the flat grad
         # buffer is zero there from construction and nothing ever writes it.
 
@@ -486,7 +540,11 @@ class VQVAEEngine:
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
         if draw_masks:
-            self.draw_masks(B, True)
+            if self.p > 0:          # the encoder's own input mask is needed straight away
+                self.draw_masks(B, True)
+            else:                   # only the rollout consumes keep95: drawn beside the encoder forward, joined in forward()
+                with self._branch(0):
+                    self.draw_masks(B, True)
         self.forward(x, target, True, ema_update=not dp, trust_wsq=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)

@@ -35,33 +35,66 @@ class FlatParams:
             v.copy_(p.data)
             p.data = v
 
+    def _copy_segments(self, src_ptrs, dst_ptrs, ns):
+        import ctypes as C
+        k = len(ns)
+        if k == 0:
+            return
+        src = (C.c_void_p * k)(*src_ptrs)
+        dst = (C.c_void_p * k)(*dst_ptrs)
+        n = (C.c_int64 * k)(*ns)
+        check(self.lib.g2v_copy_segments(src, dst, n, k, torch.cuda.current_stream().cuda_stream), "copy_segments")
+
     def gather_grads(self):
-        """Copy (device-to-device, stream ordered) each .grad into the flat grad buffer.  A parameter whose .grad is None
-        this step is remembered in `self.skipped`: torch.optim.Adam (the reference's optimizer) leaves such a parameter
-        and its moments completely untouched, and clip_grad_norm_ ignores it; step() reproduces that."""
-        self.gflat.zero_()
+        """Copy (device-to-device, stream ordered, ONE launch per 48 tensors) each .grad into the flat grad buffer.  A parameter
+        whose .grad is None this step gets zeros and is remembered in `self.skipped` (adjacent ones merged into one range):
+        torch.optim.Adam (the reference's optimizer) leaves such a parameter and its moments completely untouched, and
+        clip_grad_norm_ ignores it; step() reproduces that."""
+        src, dst, ns = [], [], []
         self.skipped = []
+        base = self.gflat.data_ptr()
         for p, o in zip(self.params, self.offsets):
-            if p.grad is not None:
-                self.gflat[o:o + p.numel()].view(p.shape).copy_(p.grad)
+            g = p.grad
+            if g is not None:
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.contiguous().float()
+                    p.grad = g
+                src.append(g.data_ptr())
             else:
-                self.skipped.append((o, p.numel()))
+                src.append(None)
+                span = (p.numel() + 3) // 4 * 4
+                if self.skipped and self.skipped[-1][0] + self.skipped[-1][1] == o:
+                    self.skipped[-1] = (self.skipped[-1][0], self.skipped[-1][1] + span)
+                else:
+                    self.skipped.append((o, span))
+            dst.append(base + 4 * o)
+            ns.append(p.numel())
+        self._copy_segments(src, dst, ns)
 
     def step(self, lr, betas=(0.5, 0.999), eps=1e-8, max_norm=5.0, grad_scale=1.0):
         st = torch.cuda.current_stream().cuda_stream
         # grad-less tensors: a zero gradient adds nothing to the clip norm, but the fused kernel would still decay their
-        # moments and move them by stale momentum -> keep (param, m, v) of those ranges and put them back afterwards.
-        # (Their bias-correction step count is the global one here, a per-parameter one in torch: only visible for a tensor
-        # that skips steps AND later receives gradients again.)
-        saved = [(o, n, self.flat[o:o + n].clone(), self.m[o:o + n].clone(), self.v[o:o + n].clone())
-                 for o, n in getattr(self, "skipped", [])]
+        # moments and move them by stale momentum -> keep (param, m, v) of those ranges (one launch) and put them back
+        # afterwards (one launch).  (Their bias-correction step count is the global one here, a per-parameter one in torch:
+        # only visible for a tensor that skips steps AND later receives gradients again.)
+        skipped = getattr(self, "skipped", [])
+        if skipped:
+            total = sum(n for _, n in skipped)
+            if getattr(self, "_keep", None) is None or self._keep.numel() < 3 * total:
+                self._keep = torch.empty(3 * total, device=self.flat.device)
+            live, kept, ns, off = [], [], [], 0
+            for o, n in skipped:
+                for buf in (self.flat, self.m, self.v):
+                    live.append(buf.data_ptr() + 4 * o)
+                    kept.append(self._keep.data_ptr() + 4 * off)
+                    ns.append(n)
+                    off += n
+            self._copy_segments(live, kept, ns)
         check(self.lib.g2v_clip_adam_step(self.flat.data_ptr(), self.gflat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                           self.n, self.partial.data_ptr(), self.step_counter.data_ptr(),
                                           self.gnorm.data_ptr(), max_norm, grad_scale, lr, betas[0], betas[1], eps, st))
-        for o, n, w, m, v in saved:
-            self.flat[o:o + n].copy_(w)
-            self.m[o:o + n].copy_(m)
-            self.v[o:o + n].copy_(v)
+        if skipped:
+            self._copy_segments(kept, live, ns)
 
 
 class FlatClipAdam:

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from .. import functional as Fn
 from .. import ops
+from ..rollout_t2e import CodeDecoderRollout, RolloutSpec, decoder_params
 from .Autoencoder_VQVAE_model import Attn, _GRUParams
 
 debug = False
@@ -174,6 +175,9 @@ class text2embedding_model(nn.Module):
         self._masks = None
         self._rng_counter = None
         self.rng_seed = 0
+        # training: the S-1 decode steps as one autograd node (gesture2vec_amd/rollout_t2e.py); False = one node per
+        # operator and step (the cross-check, and what inference uses either way)
+        self.fused_rollout = True
 
     def set_dropout_masks(self, mask_emb, mask_dec_l0=None, mask_enc_l0=None):
         """Explicit keep masks for the next training forward (parity tests): (S-1,B,H) for the code-embedding dropout and
@@ -217,6 +221,16 @@ class text2embedding_model(nn.Module):
             _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1)
             enc_out = enc_proj = None
         hidden = enc_hidden[:L]
+        if training and vid_indices is None and self.fused_rollout and S_model > 1:
+            dec = self.decoder.decoder
+            bn = dec.pre_linear[1]
+            spec = RolloutSpec(cod, S_model - 1, self.n_pre_poses, L, att, self.dropout_prob, mask_emb, mask_l0,
+                               bn.running_mean, bn.running_var)
+            logits, attw = CodeDecoderRollout.apply(hidden, enc_out, spec, *decoder_params(dec))
+            bn.num_batches_tracked += S_model - 1
+            first = F.one_hot(cod[0], K).to(torch.float32).unsqueeze(0)              # :676-677
+            attentions_list = [attw[t].unsqueeze(1) for t in range(S_model - 1)] if att else []
+            return torch.cat([first, logits], 0).transpose(0, 1), attentions_list
         outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
         dec_in = cod[0]
         attentions_list = []

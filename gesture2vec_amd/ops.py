@@ -361,9 +361,11 @@ def vq_codebook_grad(stats, codebook, g_loss, N):
     return out
 
 
-def mask_mul(inp, mask, scale=1.0, positive_of=False):
-    """out = inp * scale where the mask is on (uint8 keep mask, or `mask > 0` for a float tensor when positive_of)."""
-    out = torch.empty_like(inp)
+def mask_mul(inp, mask, scale=1.0, positive_of=False, out=None):
+    """out = inp * scale where the mask is on (uint8 keep mask, or `mask > 0` for a float tensor when positive_of);
+    out may be inp (elementwise)."""
+    if out is None:
+        out = torch.empty_like(inp)
     keep = None if positive_of else mask
     pos = mask if positive_of else None
     check(_lib_().g2v_mask_mul(_p(_chk(inp)), _p(keep), _p(pos), float(scale), _p(out), inp.numel(), _stream()), "mask_mul")
@@ -371,12 +373,13 @@ def mask_mul(inp, mask, scale=1.0, positive_of=False):
 
 
 # ------------------------------------------------------------------------------------------ Part d operators
-def embedding_fwd(table, ids, keep=None, scale=1.0):
+def embedding_fwd(table, ids, keep=None, scale=1.0, out=None, ldo=None):
     V, dim = table.shape
     n = ids.numel()
-    out = torch.empty((n, dim), dtype=torch.float32, device=table.device)
-    check(_lib_().g2v_embedding_fwd(_p(_chk(table)), _p(_chk(ids, torch.int64)), _p(keep), float(scale), _p(out), n, dim, V,
-                                    _stream()), "embedding_fwd")
+    if out is None:
+        out, ldo = torch.empty((n, dim), dtype=torch.float32, device=table.device), dim
+    check(_lib_().g2v_embedding_fwd(_p(_chk(table)), _p(_chk(ids, torch.int64)), _p(keep), float(scale), out.data_ptr(),
+                                    ldo if ldo is not None else dim, n, dim, V, _stream()), "embedding_fwd")
     return out
 
 
@@ -390,21 +393,29 @@ def embedding_bwd(d_out, ids, V, keep=None, scale=1.0):
     return d_table
 
 
-def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, relu=True):
+def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, relu=True, out=None, save=None):
+    """out: y buffer; save: (save_mean, save_invstd) buffers (training)"""
     B, H = x.shape
-    y = torch.empty_like(x)
-    sm = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
-    si = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
+    y = torch.empty_like(x) if out is None else out
+    if save is not None:
+        sm, si = save
+    else:
+        sm = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
+        si = torch.empty((H,), dtype=torch.float32, device=x.device) if training else None
     check(_lib_().g2v_batchnorm_fwd(_p(_chk(x)), _p(weight), _p(bias), _p(running_mean), _p(running_var), int(training),
                                     int(relu), _p(y), _p(sm), _p(si), B, H, _stream()), "batchnorm_fwd")
     return y, sm, si
 
 
-def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True):
+def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True, out=None):
+    """out: (dx, dw, db) buffers"""
     B, H = x.shape
-    dx = torch.empty_like(x)
-    dw = torch.empty((H,), dtype=torch.float32, device=x.device)
-    db = torch.empty((H,), dtype=torch.float32, device=x.device)
+    if out is not None:
+        dx, dw, db = out
+    else:
+        dx = torch.empty_like(x)
+        dw = torch.empty((H,), dtype=torch.float32, device=x.device)
+        db = torch.empty((H,), dtype=torch.float32, device=x.device)
     check(_lib_().g2v_batchnorm_bwd(_p(_chk(dy)), _p(x), _p(y), _p(weight), _p(save_mean), _p(save_invstd), int(relu), _p(dx),
                                     _p(dw), _p(db), B, H, _stream()), "batchnorm_bwd")
     return dx, dw, db
@@ -421,18 +432,20 @@ def cross_entropy_fwd_bwd(logits, targets, want_grad=True, ld=None):
     return loss, dl
 
 
-def argmax_rows(x):
+def argmax_rows(x, out=None):
     M, K = x.shape
-    out = torch.empty((M,), dtype=torch.int64, device=x.device)
+    if out is None:
+        out = torch.empty((M,), dtype=torch.int64, device=x.device)
     check(_lib_().g2v_argmax_rows(_p(_chk(x)), K, _p(out), M, K, _stream()), "argmax_rows")
     return out
 
 
-def attn_fwd(hp, ep, enc, v, ctx_out=None, ldctx=None):
+def attn_fwd(hp, ep, enc, v, ctx_out=None, ldctx=None, weights=None):
     """Bahdanau attention step: hp (B,H), ep/enc (T,B,H), v (H) -> weights (B,T), context (B,H) (optionally written
     into `ctx_out` with row stride ldctx, e.g. the second half of the decoder's (B,2H) input)."""
     T, B, H = enc.shape
-    weights = torch.empty((B, T), dtype=torch.float32, device=enc.device)
+    if weights is None:
+        weights = torch.empty((B, T), dtype=torch.float32, device=enc.device)
     if ctx_out is None:
         ctx_out, ldctx = torch.empty((B, H), dtype=torch.float32, device=enc.device), H
     check(_lib_().g2v_attn_fwd(_p(_chk(hp)), _p(_chk(ep)), _p(_chk(enc)), _p(_chk(v)), _p(weights), ctx_out.data_ptr(),
@@ -440,17 +453,22 @@ def attn_fwd(hp, ep, enc, v, ctx_out=None, ldctx=None):
     return weights, ctx_out
 
 
-def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None):
+def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None, out=None, accumulate=False):
+    """out: (d_hp, d_ep, d_enc, d_v) buffers; accumulate adds into d_ep / d_enc / d_v (d_hp is always overwritten)"""
     T, B, H = enc.shape
     dev = enc.device
-    d_hp = torch.empty((B, H), dtype=torch.float32, device=dev)
-    d_ep = torch.empty((T, B, H), dtype=torch.float32, device=dev)
-    d_enc = torch.empty((T, B, H), dtype=torch.float32, device=dev)
-    d_v = torch.empty((H,), dtype=torch.float32, device=dev)
+    if out is not None:
+        d_hp, d_ep, d_enc, d_v = out
+    else:
+        d_hp = torch.empty((B, H), dtype=torch.float32, device=dev)
+        d_ep = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        d_enc = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+        d_v = torch.empty((H,), dtype=torch.float32, device=dev)
     nb = _lib_().g2v_attn_bwd_workspace(B, H)
     ws = workspace(nb, dev, "attn")
     check(_lib_().g2v_attn_bwd(d_ctx.data_ptr(), ldd if ldd is not None else H, _p(hp), _p(ep), _p(enc), _p(v), _p(weights),
-                               _p(d_hp), _p(d_ep), _p(d_enc), _p(d_v), 0, T, B, H, _p(ws), ws.numel(), _stream()), "attn_bwd")
+                               _p(d_hp), _p(d_ep), _p(d_enc), _p(d_v), int(bool(accumulate)), T, B, H, _p(ws), ws.numel(),
+                               _stream()), "attn_bwd")
     return d_hp, d_ep, d_enc, d_v
 
 

@@ -1,0 +1,191 @@
+"""The S-1 training steps of the text -> gesture-code decoder as ONE autograd node.
+
+`text2embedding_model.forward` (reference model/text2embedding_model.py:701-744) calls `BahdanauAttnDecoderRNN.forward`
+(:338-395) once per code position: Embedding + Dropout(0.5) [-> Bahdanau context] -> Linear + BatchNorm1d + ReLU -> GRU(L)
+-> Linear(H -> K) -> greedy argmax feedback.  Chaining that through one small autograd node per operator costs, per
+training iteration, one weight-gradient product + one slab reduction + one torch add PER STEP AND WEIGHT, and a cat / copy
+around every slice -- about two thirds of the ~450 launches of an iteration at B = 128.  Here the forward writes every
+per-step activation straight into (S-1, B, .) arrays and the backward is written out by hand:
+
+  * the recurrence (GRU cells, BatchNorm, attention) is walked step by step, data gradients only;
+  * everything that does not feed the recurrence is batched over all S-1 steps: dLogits W_out before the loop, d(input)
+    = dU W_pre and the embedding gradient after it (without attention), and EVERY weight gradient -- one product over the
+    (S-1) B rows per weight, the four GRU matrices of L = 2 in a single launch.
+
+Same operators (include/g2v.h), same arithmetic per element as the step-at-a-time path (which stays as the module-level
+`forward` of BahdanauAttnDecoderRNN for inference and as the cross-check in tests/test_gpu_text2embedding.py); only the
+summation order of the weight gradients over the steps differs (one sum over (S-1) B rows instead of S-1 partial sums)."""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+from . import ops
+
+
+class RolloutSpec:
+    """Non-tensor arguments of CodeDecoderRollout (one object so that autograd sees a single opaque input)."""
+
+    def __init__(self, cod, steps, n_pre, L, att, dropout_p, mask_emb, mask_l0, bn_running_mean, bn_running_var):
+        self.cod, self.steps, self.n_pre, self.L, self.att, self.dropout_p = cod, steps, n_pre, L, att, dropout_p
+        self.mask_emb, self.mask_l0 = mask_emb, mask_l0
+        self.bn_running_mean, self.bn_running_var = bn_running_mean, bn_running_var
+
+
+def decoder_params(dec) -> List[torch.Tensor]:
+    """Parameter order of CodeDecoderRollout for a text2embedding BahdanauAttnDecoderRNN."""
+    lin, bn, g = dec.pre_linear[0], dec.pre_linear[1], dec.gru
+    ps = [dec.embedding.weight, lin.weight, lin.bias, bn.weight, bn.bias]
+    for l in range(dec.n_layers):
+        ps += [getattr(g, f"weight_ih_l{l}"), getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_ih_l{l}"), getattr(g, f"bias_hh_l{l}")]
+    ps += [dec.out.weight, dec.out.bias]
+    if dec.att_use:
+        ps += [dec.attn.attn.weight, dec.attn.attn.bias, dec.attn.v]
+    return ps
+
+
+class CodeDecoderRollout(torch.autograd.Function):
+    """(hidden0 (L,B,H), encoder_outputs (Tw,B,H) or None, spec, *decoder_params) -> logits (S-1,B,K), attention weights
+    (S-1,B,Tw) (empty without attention; not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, hidden0, enc_out, spec: RolloutSpec, *params):
+        L, att, S1 = spec.L, spec.att, spec.steps
+        emb_w, pre_w, pre_b, bn_w, bn_b = params[:5]
+        gru = [params[5 + 4 * l: 9 + 4 * l] for l in range(L)]            # (w_ih, w_hh, b_ih, b_hh) per layer
+        out_w, out_b = params[5 + 4 * L: 7 + 4 * L]
+        B, H, K = hidden0.shape[1], hidden0.shape[2], out_w.shape[0]
+        Hin = 2 * H if att else H
+        dev = hidden0.device
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        emb_w, pre_w, out_w = emb_w.contiguous(), pre_w.contiguous(), out_w.contiguous()
+        gru = [(w_ih.contiguous(), w_hh.contiguous(), b_ih, b_hh) for (w_ih, w_hh, b_ih, b_hh) in gru]
+        drop = spec.dropout_p > 0 and spec.mask_l0 is not None
+        scale_l0 = 1.0 / (1.0 - spec.dropout_p) if drop else 1.0
+        mask_emb = spec.mask_emb.contiguous()
+        mask_l0 = spec.mask_l0.contiguous() if drop else None
+
+        ids = torch.empty((S1, B), dtype=torch.int64, device=dev)
+        npre = max(1, min(spec.n_pre, S1))
+        ids[:npre].copy_(spec.cod[:npre])                              # teacher-forced positions (:740)
+        EC, U, A = f32(S1, B, Hin), f32(S1, B, H), f32(S1, B, H)
+        SM, SI = f32(S1, H), f32(S1, H)
+        Hs = [f32(S1 + 1, B, H) for _ in range(L)]
+        GATES = [f32(S1, B, 4 * H) for _ in range(L)]
+        GI, HN = f32(B, 3 * H), f32(B, H)
+        LOG = f32(S1, B, K)
+        for l in range(L):
+            Hs[l][0].copy_(hidden0[l])
+        if att:
+            attn_w, attn_b, attn_v = params[7 + 4 * L: 10 + 4 * L]
+            Tw = enc_out.shape[0]
+            enc = enc_out.contiguous()
+            W_h, W_e = attn_w[:, :H].contiguous(), attn_w[:, H:].contiguous()
+            attn_v = attn_v.contiguous()
+            EP = ops.linear_fwd(enc.view(Tw * B, H), W_e).view(Tw, B, H)          # step-independent half of the energies
+            HP, AW = f32(S1, B, H), f32(S1, B, Tw)
+        else:
+            AW = f32(0)
+        for t in range(S1):
+            ops.embedding_fwd(emb_w, ids[t], mask_emb[t], 2.0, out=EC[t], ldo=Hin)            # Embedding + Dropout(0.5)
+            if att:
+                ops.linear_fwd(Hs[L - 1][t], W_h, attn_b, out=HP[t])
+                ops.attn_fwd(HP[t], EP, enc, attn_v, ctx_out=EC[t][:, H:], ldctx=Hin, weights=AW[t])
+            ops.linear_fwd(EC[t], pre_w, pre_b, out=U[t])
+            ops.batchnorm_fwd(U[t], bn_w, bn_b, spec.bn_running_mean, spec.bn_running_var, True, True, out=A[t],
+                              save=(SM[t], SI[t]))
+            layer_in, keep, scale = A[t], None, 1.0
+            for l, (w_ih, w_hh, b_ih, b_hh) in enumerate(gru):
+                ops.linear_fwd(layer_in, w_ih, b_ih, keep=keep, scale=scale, out=GI)
+                ops.gru_dirs_fwd([dict(gi=GI, w_hh=w_hh, b_hh=b_hh, h0=Hs[l][t], hs=Hs[l][t + 1], h_n=HN, gates=GATES[l][t],
+                                       reverse=False)], 1, B, H)
+                layer_in = Hs[l][t + 1]
+                if drop:
+                    keep, scale = mask_l0[t], scale_l0                   # nn.GRU inter-layer dropout, fused into the next Linear
+            ops.linear_fwd(Hs[L - 1][t + 1], out_w, out_b, out=LOG[t])
+            if t + 1 < S1 and t + 1 >= npre:
+                ops.argmax_rows(LOG[t], out=ids[t + 1])                  # greedy feedback (:740)
+        ctx.save_for_backward(hidden0, enc_out, *params)
+        ctx.spec, ctx.dims = spec, (S1, B, H, K, Hin, L)
+        ctx.bufs = dict(ids=ids, EC=EC, U=U, A=A, SM=SM, SI=SI, Hs=Hs, GATES=GATES, mask_emb=mask_emb, mask_l0=mask_l0,
+                        scale_l0=scale_l0, emb_w=emb_w, pre_w=pre_w, out_w=out_w, gru=gru)
+        if att:
+            ctx.bufs.update(enc=enc, W_h=W_h, W_e=W_e, attn_v=attn_v, EP=EP, HP=HP, AW=AW)
+        ctx.mark_non_differentiable(AW)
+        ctx.set_materialize_grads(False)
+        return LOG, AW
+
+    @staticmethod
+    def backward(ctx, dLOG, _dAW):
+        S1, B, H, K, Hin, L = ctx.dims
+        n_in = 3 + 5 + 4 * L + 2 + (3 if ctx.spec.att else 0)
+        if dLOG is None:
+            return (None,) * n_in
+        b, att = ctx.bufs, ctx.spec.att
+        bn_w = ctx.saved_tensors[2 + 3]
+        dev = dLOG.device
+        f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+        Hs, GATES, gru, drop = b["Hs"], b["GATES"], b["gru"], b["mask_l0"] is not None
+        M = S1 * B
+        dLOG = dLOG.contiguous()
+        DH_top = ops.linear_bwd_data(dLOG.view(M, K), b["out_w"]).view(S1, B, H)        # every step's dLogits W_out at once
+        carry = [torch.zeros((B, H), dtype=torch.float32, device=dev) for _ in range(L)]   # dLoss / d(previous state), per layer
+        carry_next = [f32(B, H) for _ in range(L)]
+        DGI = [f32(S1, B, 3 * H) for _ in range(L)]
+        DGH = [f32(S1, B, 3 * H) for _ in range(L)]
+        DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
+        DXs = [f32(B, H) for _ in range(L)]                             # gradient w.r.t. each layer's input
+        if att:
+            DEC, DHP = f32(S1, B, Hin), f32(S1, B, H)
+            D_EP, D_ENC, D_V = torch.empty_like(b["EP"]), torch.empty_like(b["enc"]), f32(H)
+        for t in reversed(range(S1)):
+            d_in = DH_top[t]                                             # gradient arriving at Hs[l][t+1] from above
+            for l in reversed(range(L)):
+                w_ih, w_hh = gru[l][0], gru[l][1]
+                ops.gru_dirs_bwd([dict(d_hs=d_in, d_hn=carry[l], hs=Hs[l][t + 1], h0=Hs[l][t], gates=GATES[l][t], w_hh=w_hh,
+                                       dgi=DGI[l][t], dgh=DGH[l][t], dh0=carry_next[l], reverse=False)], 1, B, H)
+                ops.linear_bwd_data(DGI[l][t], w_ih, out=DXs[l])
+                if l > 0:
+                    if drop:
+                        ops.mask_mul(DXs[l], b["mask_l0"][t], b["scale_l0"], out=DXs[l])
+                    d_in = DXs[l]
+            ops.batchnorm_bwd(DXs[0], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
+            if att:
+                ops.linear_bwd_data(DU[t], b["pre_w"], out=DEC[t])
+                ops.attn_bwd(DEC[t][:, H:], b["HP"][t], b["EP"], b["enc"], b["attn_v"], b["AW"][t], ldd=Hin,
+                             out=(DHP[t], D_EP, D_ENC, D_V), accumulate=(t != S1 - 1))
+                ops.linear_bwd_data(DHP[t], b["W_h"], out=carry_next[L - 1], accumulate=True)     # the state the attention scored
+            carry, carry_next = carry_next, carry
+        # ---- everything that did not feed the recurrence: one launch over all (S-1) B rows each ---------------------------
+        if att:
+            d_e = DEC[:, :, :H].contiguous().view(M, H)
+        else:
+            d_e = ops.linear_bwd_data(DU.view(M, H), b["pre_w"])
+        V = b["emb_w"].shape[0]
+        d_emb = ops.embedding_bwd(d_e, b["ids"].view(-1), V, b["mask_emb"].view(M, H), 2.0)
+        d_out_w, d_out_b = ops.linear_bwd_weight(dLOG.view(M, K), Hs[L - 1][1:].view(M, H), K, H)
+        d_pre_w, d_pre_b = ops.linear_bwd_weight(DU.view(M, H), b["EC"].view(M, Hin), H, Hin)
+        items, g_gru = [], []
+        for l in range(L):
+            if l == 0:
+                x = b["A"].view(M, H)
+            else:
+                x = Hs[l - 1][1:].view(M, H)
+                if drop:
+                    x = ops.mask_mul(x, b["mask_l0"].view(M, H), b["scale_l0"])
+            dw_ih, dw_hh, db_ih, db_hh = f32(3 * H, H), f32(3 * H, H), f32(3 * H), f32(3 * H)
+            items += [(DGI[l].view(M, 3 * H), x, dw_ih, db_ih), (DGH[l].view(M, 3 * H), Hs[l][:-1].view(M, H), dw_hh, db_hh)]
+            g_gru += [dw_ih, dw_hh, db_ih, db_hh]
+        for k in range(0, len(items), 4):
+            ops.linear_bwd_weight_batch(items[k:k + 4], 3 * H, H, M=M)
+        grads = [d_emb, d_pre_w, d_pre_b, DBW.sum(0), DBB.sum(0)] + g_gru + [d_out_w, d_out_b]
+        d_enc = None
+        if att:
+            Tw = b["enc"].shape[0]
+            dW_h, d_attn_b = ops.linear_bwd_weight(DHP.view(M, H), Hs[L - 1][:-1].view(M, H), H, H)
+            dW_e, _ = ops.linear_bwd_weight(D_EP.view(Tw * B, H), b["enc"].view(Tw * B, H), H, H, want_bias=False)
+            ops.linear_bwd_data(D_EP.view(Tw * B, H), b["W_e"], out=D_ENC.view(Tw * B, H), accumulate=True)
+            grads += [torch.cat([dW_h, dW_e], 1), d_attn_b, D_V]
+            d_enc = D_ENC
+        return (torch.stack(carry), d_enc, None, *grads)

@@ -323,7 +323,8 @@ int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_strea
 /* ------------------------------------------------------------------------------------------
  * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).
  *   g2v_embedding_fwd   out[r,:] = table[ids[r],:] * keep * scale   (nn.Embedding :90-92,126 / :252,340-343 with the
- *                       decoder's nn.Dropout(0.5) fused; keep may be NULL)
+ *                       decoder's nn.Dropout(0.5) fused; keep may be NULL; row r of out starts at out + r * ldo, e.g. the
+ *                       first half of the attention decoder's (B,2H) input)
  *   g2v_embedding_bwd   d_table[v,:] (+)= sum_{r: ids[r]=v} d_out[r,:] * keep * scale.  No float atomics: tokens are counting-
  *                       sorted by row (stable), 128-token chunks of the sorted list are summed in order and rows that span
  *                       chunks add their chunk partials in order -- a fixed summation tree, bitwise reproducible.
@@ -337,7 +338,7 @@ int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_strea
  *                       row_loss: M floats of scratch; dlogits may be NULL
  *   g2v_argmax_rows     out[r] = argmax_k x[r,k] (lowest index on ties): greedy feedback :740
  * ------------------------------------------------------------------------------------------ */
-int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out,
+int g2v_embedding_fwd(const float* table, const int64_t* ids, const uint8_t* keep, float scale, float* out, int64_t ldo,
                       int64_t n, int dim, int64_t V, g2v_stream_t stream);
 size_t g2v_embedding_bwd_ws_bytes(int64_t n, int dim, int64_t V);
 int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* keep, float scale, float* d_table,
@@ -390,6 +391,10 @@ int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int6
 
 /* small helpers used by the host */
 int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream);
+/* dst[k][i] = src[k][i] for i < n[k], k < nseg (src[k] == NULL: zero fill), all segments in one launch per 48.  src / dst /
+ * n are HOST arrays (read at launch).  FlatParams.gather_grads: every parameter's .grad into the flat gradient buffer that
+ * g2v_clip_adam_step consumes (torch.nn.utils.clip_grad_norm_ + Adam.step over a parameter list, train_seq2seq.py:540-546). */
+int g2v_copy_segments(const float* const* src, float* const* dst, const int64_t* n, int nseg, g2v_stream_t stream);
 /* out[i] = in[i] * scalar[0]   (scalar is a DEVICE float: chains an upstream autograd scalar without a host sync) */
 int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g2v_stream_t stream);
 /* out[i] = on(i) ? in[i]*scale : 0, on(i) = keep[i] != 0 (uint8 mask) or, when keep is NULL, positive_of[i] > 0

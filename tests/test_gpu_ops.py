@@ -59,7 +59,8 @@ def relclose(got, ref, rel=1e-4, msg=""):
 
 
 # ----------------------------------------------------------------------------------------------- linear
-@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (4096, 128, 128), (1, 3, 5), (130, 64, 192)])
+@pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (4096, 128, 128), (1, 3, 5), (130, 64, 192),
+                                   (128, 200, 600), (128, 400, 200), (7, 48, 40), (512, 300, 514), (100, 1000, 33)])   # small-M wave-per-tile kernel
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_fwd(ops, M, K, N, act):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
@@ -68,6 +69,29 @@ def test_linear_fwd(ops, M, K, N, act):
         ref = torch.relu(ref)
     y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act=act)
     relclose(y, ref, 2e-6, "linear_fwd")
+
+
+@pytest.mark.parametrize("M,K,N", [(128, 200, 600), (24, 48, 144), (509, 132, 70)])
+def test_linear_small_m_mask_tanh_and_data_gradient(ops, M, K, N):
+    """M <= 512 rows: gemm_smallm_kernel (one wave per 16 x 16 output tile) -- keep mask on the input, tanh epilogue, output
+    into a wider buffer, data gradient with and without accumulation."""
+    x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.2), rnd(N, seed=13)
+    keep = (torch.rand(M, K, generator=torch.Generator().manual_seed(14)) < 0.8).to(torch.uint8)
+    ref = O.linear(x * keep * 1.25, w, b)
+    y = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), keep=keep.to(DEV), scale=1.25)
+    relclose(y, ref, 2e-6, "small-M masked forward")
+    yt = ops.linear_fwd(x.to(DEV), w.to(DEV), b.to(DEV), act=2)
+    relclose(yt, torch.tanh(O.linear(x, w, b)), 5e-6, "small-M tanh")
+    wide = torch.full((M, N + 8), 7.0, device=DEV)
+    ops.linear_fwd(x.to(DEV), w.to(DEV), None, out=wide, ldy=N + 8)
+    relclose(wide[:, :N], x @ w.t(), 2e-6, "small-M strided output")
+    assert float((wide[:, N:] - 7.0).abs().max()) == 0.0
+    dy = rnd(M, N, seed=15)
+    dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
+    relclose(dx, (dy.double() @ w.double()).float(), 2e-6, "small-M data gradient")
+    base = rnd(M, K, seed=16)
+    dx2 = ops.linear_bwd_data(dy.to(DEV), w.to(DEV), out=base.to(DEV).clone(), accumulate=True)
+    relclose(dx2, (base.double() + dy.double() @ w.double()).float(), 2e-6, "small-M data gradient, accumulate")
 
 
 def test_linear_fwd_rowmap_and_mask(ops):
@@ -89,7 +113,8 @@ def test_linear_fwd_rowmap_and_mask(ops):
 
 
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
-                                   (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514)])   # output-blocked wave kernel
+                                   (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514),      # output-blocked wave kernel
+                                   (128, 200, 600), (130, 600, 200), (16, 64, 514)])                            # small-M data gradient
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
     dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
