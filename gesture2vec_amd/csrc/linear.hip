@@ -288,52 +288,65 @@ __global__ __launch_bounds__(256) void gemm_nt_stream_kernel(const float* __rest
   }
 }
 
-// ---- small M (a decode step of Part d: 128 x 200 -> 600): one wave per 16 x 16 output tile, no LDS, no barriers -----------
+// ---- small / medium M (a decode step of Part d: 128..4096 x 200 -> 600): one wave per 16 x 16 TN output tile, no LDS ------
 // At M <= 512 rows the 64 x 64 LDS-tiled kernel launches a handful of workgroups that each walk the contraction in 32-wide
 // chunks with two barriers per chunk: 11-27 us for 15 MFLOP.  Here every 16 x 16 tile of the output is one wave (304 waves
 // for 128 x 600) that pulls its operand fragments straight from L2 in MFMA layout -- lane (i, q) reads 4 consecutive
 // contraction elements of A row m0 + i and of weight row n0 + i per 16-wide block -- with the next chunk's loads issued
 // before the current chunk's MFMAs.  TRANS_B (data gradient, contraction along the rows of w): dword loads of w.
 // Requirements: contraction length % 4 == 0, 16-byte aligned rows; identity / ReLU / tanh epilogue, optional keep mask on A.
-template <bool TRANS_B, bool KEEP>
+template <bool TRANS_B, bool KEEP, int TN, int NB>      // wave tile: 16 rows x 16 TN columns; NB blocks of 16 contraction elements per chunk
 __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restrict__ A, int64_t lda,
                                                           const uint8_t* __restrict__ keep, float scale,
                                                           const float* __restrict__ Bm, int64_t ldb,
                                                           const float* __restrict__ bias, float* __restrict__ Cout,
                                                           int64_t ldc, int M, int C, int N, int act, int accumulate) {
-  constexpr int NB = 8, CH = 16 * NB;                  // blocks of 16 contraction elements per chunk
+  constexpr int CH = 16 * NB;
   const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
-  const int tiles_n = (N + 15) >> 4;
+  const int tiles_n = (N + 16 * TN - 1) / (16 * TN);
   const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // consecutive waves share the A rows (same mt) and walk the weight rows: the 4 waves of a workgroup re-use A through L1/L2
   const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
   if (mt * 16 >= M) return;
-  const int m = mt * 16 + i, n = nt * 16 + i;
-  const bool mok = m < M, nok = n < N;
+  const int m = mt * 16 + i;
+  const bool mok = m < M;
   const float* arow = A + (int64_t)(mok ? m : 0) * lda;
   const uint8_t* krow = KEEP ? keep + (int64_t)(mok ? m : 0) * C : nullptr;
-  const float* brow = TRANS_B ? Bm + (nok ? n : 0) : Bm + (int64_t)(nok ? n : 0) * ldb;
-  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-  float4 xa[NB], wa[NB], xb[NB], wb[NB];
+  const float* brow[TN];
+  bool nok[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = (nt * TN + t) * 16 + i;
+    nok[t] = n < N;
+    brow[t] = TRANS_B ? Bm + (nok[t] ? n : 0) : Bm + (int64_t)(nok[t] ? n : 0) * ldb;
+  }
+  f32x4 acc[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 xa[NB], wa[TN][NB], xb[NB], wb[TN][NB];
   uint32_t ka[NB], kb[NB];
-  auto fetch = [&](int c0, float4 (&x)[NB], float4 (&w)[NB], uint32_t (&kp)[NB]) {
+  auto fetch = [&](int c0, float4 (&x)[NB], float4 (&w)[TN][NB], uint32_t (&kp)[NB]) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int c = c0 + 16 * b + 4 * q, cc = c < C ? c : 0;          // past the end: a valid address, zeroed in use()
       x[b] = *reinterpret_cast<const float4*>(arow + cc);
       if (KEEP) kp[b] = *reinterpret_cast<const uint32_t*>(krow + cc);
-      if (!TRANS_B) {
-        w[b] = *reinterpret_cast<const float4*>(brow + cc);
-      } else {
-        w[b] = make_float4(brow[(int64_t)cc * ldb], brow[(int64_t)(cc + 1) * ldb], brow[(int64_t)(cc + 2) * ldb],
-                           brow[(int64_t)(cc + 3) * ldb]);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        if (!TRANS_B) {
+          w[t][b] = *reinterpret_cast<const float4*>(brow[t] + cc);
+        } else {
+          w[t][b] = make_float4(brow[t][(int64_t)cc * ldb], brow[t][(int64_t)(cc + 1) * ldb],
+                                brow[t][(int64_t)(cc + 2) * ldb], brow[t][(int64_t)(cc + 3) * ldb]);
+        }
       }
     }
   };
-  auto use = [&](int c0, const float4 (&x)[NB], const float4 (&w)[NB], const uint32_t (&kp)[NB]) {
+  auto use = [&](int c0, const float4 (&x)[NB], const float4 (&w)[TN][NB], const uint32_t (&kp)[NB]) {
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const bool ok = c0 + 16 * b + 4 * q < C;
-      float4 xv = x[b], wv = w[b];
+      float4 xv = x[b];
       if (KEEP) {
         xv.x = (kp[b] & 0xffu) ? xv.x * scale : 0.f;
         xv.y = (kp[b] & 0xff00u) ? xv.y * scale : 0.f;
@@ -341,11 +354,15 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restric
         xv.w = (kp[b] & 0xff000000u) ? xv.w * scale : 0.f;
       }
       if (!(ok && mok)) xv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!(ok && nok)) wv = make_float4(0.f, 0.f, 0.f, 0.f);
-      acc = mfma16(wv.x, xv.x, acc);
-      acc = mfma16(wv.y, xv.y, acc);
-      acc = mfma16(wv.z, xv.z, acc);
-      acc = mfma16(wv.w, xv.w, acc);
+#pragma unroll
+      for (int t = 0; t < TN; ++t) {
+        float4 wv = w[t][b];
+        if (!(ok && nok[t])) wv = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc[t] = mfma16(wv.x, xv.x, acc[t]);
+        acc[t] = mfma16(wv.y, xv.y, acc[t]);
+        acc[t] = mfma16(wv.z, xv.z, acc[t]);
+        acc[t] = mfma16(wv.w, xv.w, acc[t]);
+      }
     }
   };
   fetch(0, xa, wa, ka);
@@ -356,33 +373,56 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restric
     if (c0 + 2 * CH < C) fetch(c0 + 2 * CH, xa, wa, ka);
     use(c0 + CH, xb, wb, kb);
   }
-  // lane holds C[m = mt*16 + (lane & 15)][n = nt*16 + 4 q + r], r = 0..3
-  const int mo = mt * 16 + i, no = nt * 16 + 4 * q;
-  if (mo >= M) return;
-  float* out = Cout + (int64_t)mo * ldc + no;
+  // lane holds C[m = mt*16 + (lane & 15)][n = (nt TN + t)*16 + 4 q + r], r = 0..3
+  if (!mok) return;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (no + r >= N) break;
-    float v = acc[r] + (bias ? bias[no + r] : 0.f);
-    if (act == 1) v = v > 0.f ? v : 0.f;
-    else if (act == 2) v = tanhf(v);
-    out[r] = accumulate ? out[r] + v : v;
+  for (int t = 0; t < TN; ++t) {
+    const int no = (nt * TN + t) * 16 + 4 * q;
+    float* out = Cout + (int64_t)m * ldc + no;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      if (no + r < N) {
+        float v = acc[t][r] + (bias ? bias[no + r] : 0.f);
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        else if (act == 2) v = tanhf(v);
+        out[r] = accumulate ? out[r] + v : v;
+      }
+    }
   }
+}
+
+// measured (gpurun_tools/gemm_bench.py, 200..400 -> 200..600): forward 9.7 vs 10.4 us and data gradient 11 vs 22 us at 128..640
+// rows, break-even near 2560 rows, the LDS-tiled kernel ahead beyond (50..86 TF/s at 4096..81920 rows)
+static int g_smallm_max_rows = 1024;      // g2v_linear_set_smallm_rows (measurement only)
+extern "C" int g2v_linear_set_smallm_rows(int rows) {
+  const int prev = g_smallm_max_rows;
+  if (rows >= 0) g_smallm_max_rows = rows;
+  return prev;
 }
 
 static bool launch_smallm(bool trans_b, const float* A, int64_t lda, const uint8_t* keep, float scale, const float* Bm,
                           int64_t ldb, const float* bias, float* Cout, int64_t ldc, int M, int C, int N, int act,
                           int accumulate, hipStream_t st) {
-  if (M > 512 || (C & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
+  if (M > g_smallm_max_rows || (C & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
   if (!trans_b && ((ldb & 3) || (reinterpret_cast<uintptr_t>(Bm) & 15))) return false;
   if (keep && (reinterpret_cast<uintptr_t>(keep) & 3)) return false;
-  const int tiles = cdiv(M, 16) * cdiv(N, 16);
+  // wider wave tiles (more re-use of the A fragment, fewer waves) once 16 x 16 tiles alone fill the chip a few times over
+  const int64_t tiles16 = (int64_t)cdiv(M, 16) * cdiv(N, 16);
+  const int tn = tiles16 <= 2048 ? 1 : (tiles16 <= 8192 ? 2 : 4);
+  const int tiles = cdiv(M, 16) * cdiv(N, 16 * tn);
   const dim3 grid(cdiv(tiles, 4));
-#define G2V_SMALLM(TB, KP)                                                                                             \
-  hipLaunchKernelGGL((gemm_smallm_kernel<TB, KP>), grid, dim3(256), 0, st, A, lda, keep, scale, Bm, ldb, bias, Cout, \
-                     ldc, M, C, N, act, accumulate)
-  if (trans_b) { if (keep) G2V_SMALLM(true, true); else G2V_SMALLM(true, false); }
-  else { if (keep) G2V_SMALLM(false, true); else G2V_SMALLM(false, false); }
+#define G2V_SMALLM(TB, KP, TN, NB)                                                                                        \
+  hipLaunchKernelGGL((gemm_smallm_kernel<TB, KP, TN, NB>), grid, dim3(256), 0, st, A, lda, keep, scale, Bm, ldb, bias,  \
+                     Cout, ldc, M, C, N, act, accumulate)
+#define G2V_SMALLM_TN(TB, KP)                     \
+  do {                                            \
+    if (tn == 1) G2V_SMALLM(TB, KP, 1, 8);        \
+    else if (tn == 2) G2V_SMALLM(TB, KP, 2, 4);   \
+    else G2V_SMALLM(TB, KP, 4, 4);                \
+  } while (0)
+  if (trans_b) { if (keep) G2V_SMALLM_TN(true, true); else G2V_SMALLM_TN(true, false); }
+  else { if (keep) G2V_SMALLM_TN(false, true); else G2V_SMALLM_TN(false, false); }
+#undef G2V_SMALLM_TN
 #undef G2V_SMALLM
   return true;
 }

@@ -40,7 +40,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
 //                           the chunk goes to partial slot 0, the one that continues beyond it to slot 1
 //       emb_row_finish      rows without tokens are zeroed (overwrite mode); rows that span chunks sum their partials
 //   Either way a fixed summation tree: bitwise reproducible, with ~n / chunk waves of parallelism whatever the id distribution.
-constexpr int EMB_SMALL_N = 512;
+constexpr int EMB_SMALL_N = 1024;
 constexpr int EMB_TB = 1024;        // tokens per ranking block
 constexpr int EMB_MAX_CHUNK = 128;
 

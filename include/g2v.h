@@ -53,6 +53,9 @@ int g2v_device_ok(void);
  * else at x + m * ldx.  x_keep (uint8, may be NULL) is indexed [m * K + k].
  * act: 0 = identity, 1 = ReLU, 2 = tanh.
  * ------------------------------------------------------------------------------------------ */
+/* measurement only: largest row count served by the wave-per-tile kernel of g2v_linear_fwd / g2v_linear_bwd_data
+ * (0 = never); returns the previous value, rows < 0 only queries */
+int g2v_linear_set_smallm_rows(int rows);
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
                    const float* w, const float* bias, float* y, int64_t ldy,

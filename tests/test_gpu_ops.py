@@ -60,7 +60,8 @@ def relclose(got, ref, rel=1e-4, msg=""):
 
 # ----------------------------------------------------------------------------------------------- linear
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (4096, 128, 128), (1, 3, 5), (130, 64, 192),
-                                   (128, 200, 600), (128, 400, 200), (7, 48, 40), (512, 300, 514), (100, 1000, 33)])   # small-M wave-per-tile kernel
+                                   (128, 200, 600), (128, 400, 200), (7, 48, 40), (512, 300, 514), (100, 1000, 33),    # wave-per-tile kernel
+                                   (1024, 200, 600), (1000, 64, 2100)])                                              # ... 2 / 4 tiles per wave
 @pytest.mark.parametrize("act", [0, 1])
 def test_linear_fwd(ops, M, K, N, act):
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(N, seed=3)
@@ -73,7 +74,7 @@ def test_linear_fwd(ops, M, K, N, act):
 
 @pytest.mark.parametrize("M,K,N", [(128, 200, 600), (24, 48, 144), (509, 132, 70)])
 def test_linear_small_m_mask_tanh_and_data_gradient(ops, M, K, N):
-    """M <= 512 rows: gemm_smallm_kernel (one wave per 16 x 16 output tile) -- keep mask on the input, tanh epilogue, output
+    """M <= 1024 rows: gemm_smallm_kernel (one wave per 16 x 16 output tile) -- keep mask on the input, tanh epilogue, output
     into a wider buffer, data gradient with and without accumulation."""
     x, w, b = rnd(M, K, seed=11), rnd(N, K, seed=12, scale=0.2), rnd(N, seed=13)
     keep = (torch.rand(M, K, generator=torch.Generator().manual_seed(14)) < 0.8).to(torch.uint8)
@@ -114,11 +115,11 @@ def test_linear_fwd_rowmap_and_mask(ops):
 
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
                                    (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514),      # output-blocked wave kernel
-                                   (128, 200, 600), (130, 600, 200), (16, 64, 514)])                            # small-M data gradient
+                                   (128, 200, 600), (130, 600, 200), (16, 64, 514), (1024, 200, 600), (1000, 64, 2100)])   # small-M data gradient
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
     dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
-    relclose(dx, dy @ w, 2e-6, "bwd_data")
+    relclose(dx, (dy.double() @ w.double()).float(), 2e-6, "bwd_data")
     dw, db = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K)
     relclose(dw, (dy.double().t() @ x.double()).float(), 1e-5, "bwd_weight")
     relclose(db, dy.double().sum(0).float(), 1e-5, "bwd_bias")
