@@ -1213,6 +1213,107 @@ extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
   return (size_t)splits * ((size_t)N * K + N) * sizeof(float);
 }
 
+// ---- small M weight gradient (Part d at B = 128: 640 x 600 -> dW 600 x 200): one workgroup per 16 x 16 tile of dW ----------
+// dW[n][k] (+)= sum_m dy[m][n] xin[m][k], db[n] (+)= sum_m dy[m][n].  The four waves split the rows, each pulls both operands
+// straight from L2 as MFMA fragments (dword loads: 16 lanes x 4 B contiguous along n / k, 4 rows per MFMA; SMW_NB 16-row
+// blocks per request burst, the next burst in flight during the MFMAs), the four partial tiles meet in LDS in a fixed order:
+// deterministic, no slabs, no second launch.  The LDS-tiled split kernel + slab reduction it replaces here cost 17 + 5 us.
+constexpr int SMW_NB = 8;
+struct SmallWgradBatch {
+  const float* dy[G2V_TN_BATCH];
+  const float* x[G2V_TN_BATCH];
+  float* dw[G2V_TN_BATCH];
+  float* db[G2V_TN_BATCH];
+};
+template <bool KEEP>
+__global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx,
+                                                             const uint8_t* __restrict__ keep, float scale, int M, int K,
+                                                             int N, int accumulate) {
+  __shared__ float red[3][64 * 4 + 16];
+  const float* __restrict__ dY = sb.dy[blockIdx.y];
+  const float* __restrict__ X = sb.x[blockIdx.y];
+  float* __restrict__ dW = sb.dw[blockIdx.y];
+  float* __restrict__ dB = sb.db[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int tiles_k = (K + 15) >> 4;
+  const int nt = blockIdx.x / tiles_k, kt = blockIdx.x - nt * tiles_k;
+  const int n = nt * 16 + i, k = kt * 16 + i;
+  const bool nok = n < N, kok = k < K;
+  const float* dyc = dY + (nok ? n : 0);
+  const float* xc = X + (kok ? k : 0);
+  const uint8_t* kc = KEEP ? keep + (kok ? k : 0) : nullptr;
+  const int per = (((M + 3) / 4) + 15) & ~15;                       // rows per wave, whole 16-row blocks
+  const int mb = wave * per, me = mb + per < M ? mb + per : M;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float dbs = 0.f;
+  float a0[SMW_NB][4], b0[SMW_NB][4], a1[SMW_NB][4], b1[SMW_NB][4];
+  uint8_t k0[SMW_NB][4], k1[SMW_NB][4];
+  auto fetch = [&](int m0, float (&a)[SMW_NB][4], float (&b)[SMW_NB][4], uint8_t (&kp)[SMW_NB][4]) {
+#pragma unroll
+    for (int blk = 0; blk < SMW_NB; ++blk)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const int m = m0 + 16 * blk + 4 * q + s, mc = m < me ? m : (M - 1);       // past the range: a valid row, zeroed in use()
+        a[blk][s] = dyc[(int64_t)mc * lddy];
+        b[blk][s] = xc[(int64_t)mc * ldx];
+        if (KEEP) kp[blk][s] = kc[(int64_t)mc * K];
+      }
+  };
+  auto use = [&](int m0, const float (&a)[SMW_NB][4], const float (&b)[SMW_NB][4], const uint8_t (&kp)[SMW_NB][4]) {
+#pragma unroll
+    for (int blk = 0; blk < SMW_NB; ++blk)
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const bool ok = m0 + 16 * blk + 4 * q + s < me;
+        const float av = (ok && nok) ? a[blk][s] : 0.f;
+        float bv = (ok && kok) ? b[blk][s] : 0.f;
+        if (KEEP) bv = kp[blk][s] ? bv * scale : 0.f;
+        dbs += av;
+        acc = mfma16(av, bv, acc);
+      }
+  };
+  constexpr int CH = 16 * SMW_NB;
+  if (mb < me) {
+    fetch(mb, a0, b0, k0);
+    for (int m0 = mb; m0 < me; m0 += 2 * CH) {
+      if (m0 + CH < me) fetch(m0 + CH, a1, b1, k1);
+      use(m0, a0, b0, k0);
+      if (m0 + CH >= me) break;
+      if (m0 + 2 * CH < me) fetch(m0 + 2 * CH, a0, b0, k0);
+      use(m0 + CH, a1, b1, k1);
+    }
+  }
+  dbs += __shfl_xor(dbs, 16);
+  dbs += __shfl_xor(dbs, 32);
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][lane * 4 + r] = acc[r];
+    if (q == 0) red[wave - 1][256 + i] = dbs;
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[w][lane * 4 + r];
+    dbs += red[w][256 + i];
+  }
+  // lane holds dW[n = nt*16 + 4 q + r][k = kt*16 + (lane & 15)]
+  if (kok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int no = nt * 16 + 4 * q + r;
+      if (no < N) {
+        float* o = dW + (int64_t)no * K + k;
+        *o = accumulate ? *o + acc[r] : acc[r];
+      }
+    }
+  }
+  if (dB && kt == 0 && q == 0 && nok) dB[n] = accumulate ? dB[n] + dbs : dbs;
+}
+
+static int g_smallm_wgrad_rows = 2048;
+
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
 struct WgradItem {
@@ -1223,6 +1324,22 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
                       float* workspace, g2v_stream_t stream) {
   const int accumulate = flags & G2V_WGRAD_ACCUMULATE;
   const bool bf3 = (flags & G2V_WGRAD_BF16X3) != 0;
+  if (M <= g_smallm_wgrad_rows && M <= g_smallm_max_rows * 2 && rows_inner == 0 && !bf3) {
+    SmallWgradBatch sb;
+    for (int p = 0; p < G2V_TN_BATCH; ++p) {
+      const int pp = p < nprob ? p : 0;
+      sb.dy[p] = it[pp].dy; sb.x[p] = it[pp].x; sb.dw[p] = it[pp].dw; sb.db[p] = it[pp].db;
+    }
+    const dim3 grid(cdiv(N, 16) * cdiv(K, 16), nprob);
+    if (x_keep)
+      hipLaunchKernelGGL(gemm_tn_smallm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep, x_scale,
+                         M, K, N, accumulate);
+    else
+      hipLaunchKernelGGL(gemm_tn_smallm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep, x_scale,
+                         M, K, N, accumulate);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   int splits = tn_splits(M, K, N);
   int rows_per_split = cdiv(M, splits);
   rows_per_split = round_up(rows_per_split, TM);

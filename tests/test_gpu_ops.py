@@ -93,6 +93,26 @@ def test_linear_small_m_mask_tanh_and_data_gradient(ops, M, K, N):
     base = rnd(M, K, seed=16)
     dx2 = ops.linear_bwd_data(dy.to(DEV), w.to(DEV), out=base.to(DEV).clone(), accumulate=True)
     relclose(dx2, (base.double() + dy.double() @ w.double()).float(), 2e-6, "small-M data gradient, accumulate")
+    # weight gradient: gemm_tn_smallm_kernel (one workgroup per 16 x 16 tile of dW), masked input, accumulation, batch of four
+    xm = (x * keep * 1.25).double()
+    dw, db = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K, keep=keep.to(DEV), scale=1.25)
+    relclose(dw, (dy.double().t() @ xm).float(), 3e-6, "small-M masked weight gradient")
+    relclose(db, dy.double().sum(0).float(), 3e-6, "small-M bias gradient")
+    dw2, db2 = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K, keep=keep.to(DEV), scale=1.25, dw=dw.clone(), db=db.clone(),
+                                     accumulate=True)
+    relclose(dw2, 2 * (dy.double().t() @ xm).float(), 3e-6, "small-M weight gradient, accumulate")
+    relclose(db2, 2 * dy.double().sum(0).float(), 3e-6, "small-M bias gradient, accumulate")
+    items = []
+    for j in range(4):
+        dyj, xj = rnd(M, N, seed=20 + j), rnd(M, K, seed=30 + j)
+        items.append((dyj, xj, torch.full((N, K), 9.0, device=DEV), torch.full((N,), 9.0, device=DEV) if j != 2 else None))
+    ops.linear_bwd_weight_batch([(a.to(DEV), b_.to(DEV), c, d) for a, b_, c, d in items], N, K, M=M)
+    for dyj, xj, dwj, dbj in items:
+        relclose(dwj, (dyj.double().t() @ xj.double()).float(), 3e-6, "small-M batched weight gradient")
+        if dbj is not None:
+            relclose(dbj, dyj.double().sum(0).float(), 3e-6, "small-M batched bias gradient")
+    dw3, _ = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K, keep=keep.to(DEV), scale=1.25)
+    assert torch.equal(dw3, dw)
 
 
 def test_linear_fwd_rowmap_and_mask(ops):
@@ -119,7 +139,7 @@ def test_linear_fwd_rowmap_and_mask(ops):
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
     dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
-    relclose(dx, (dy.double() @ w.double()).float(), 2e-6, "bwd_data")
+    relclose(dx, (dy.double() @ w.double()).float(), 2e-6 if N <= 1024 else 4e-6, "bwd_data")      # fp32 fma chain of length N
     dw, db = ops.linear_bwd_weight(dy.to(DEV), x.to(DEV), N, K)
     relclose(dw, (dy.double().t() @ x.double()).float(), 1e-5, "bwd_weight")
     relclose(db, dy.double().sum(0).float(), 1e-5, "bwd_bias")
