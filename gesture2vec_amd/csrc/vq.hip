@@ -309,12 +309,15 @@ __global__ __launch_bounds__(256) void vq_assign_fast_kernel(const float* __rest
 // RT MFMAs (one per row tile) instead of one, so the L2 traffic of the codebook stream drops RT-fold.  At N = 4096
 // the 16-rows-per-workgroup kernel above is L2-bandwidth-bound (256 workgroups x 256 KB = 64 MB per launch); RT = 2
 // halves that at the price of filling only half the CUs; for bulk assignment (N >= 16384) RT = 4 is MFMA-bound.
-template <int E, int RT>
+// LIST: the rows to assign are row_list[0 .. *row_count) (the exact re-check of vq_bx3_sweep_kernel's undecided rows); the
+// launch is sized for the worst case and workgroups beyond the count leave at once.  idx only (no quant / dist / SSE).
+template <int E, int RT, bool LIST = false>
 __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restrict__ flat, const float* __restrict__ z,
                                                            const float* __restrict__ W, const float* __restrict__ wsq,
                                                            int64_t* __restrict__ idx_out, float* __restrict__ quant,
                                                            float* __restrict__ dist_min, float* __restrict__ sse_partial,
-                                                           int N, int K) {
+                                                           int N, int K, const int* __restrict__ row_list = nullptr,
+                                                           const int* __restrict__ row_count = nullptr) {
   constexpr int KS = E / 16, ldx = E + 4, ROWS = 16 * RT;
   __shared__ __attribute__((aligned(16))) float Xs[ROWS * ldx];
   __shared__ float xx[ROWS];
@@ -324,12 +327,14 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * ROWS;
+  if (LIST) N = min(N, *row_count);
+  if (r0 >= N) return;
   const int nrows = min(ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
   for (int e = tid; e < ROWS * (E / 4); e += 256) {     // coalesced float4 staging
     const int row = e / (E / 4), c = 4 * (e - row * (E / 4));
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nrows) v = *reinterpret_cast<const float4*>(flat + (int64_t)(r0 + row) * E + c);
+    if (row < nrows) v = *reinterpret_cast<const float4*>(flat + (int64_t)(LIST ? row_list[r0 + row] : r0 + row) * E + c);
     *reinterpret_cast<float4*>(Xs + row * ldx + c) = v;
   }
   __syncthreads();
@@ -414,10 +419,11 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
     for (int w = 1; w < 4; ++w) argmin_merge(d, k, wbest_d[w * ROWS + tid], wbest_k[w * ROWS + tid]);
     best_k[tid] = k;
     if (tid < nrows) {
-      idx_out[r0 + tid] = (int64_t)k;
+      idx_out[LIST ? row_list[r0 + tid] : r0 + tid] = (int64_t)k;
       if (dist_min) dist_min[r0 + tid] = d;
     }
   }
+  if (LIST) return;
   __syncthreads();
   if (quant) {
     float sse = 0.f;
@@ -984,6 +990,161 @@ extern "C" int g2v_vq_codebook_grad(const float* stats, const float* codebook, c
   return G2V_OK;
 }
 
+// ---- bulk code assignment on the bf16 matrix pipe, EXACT where it matters: 3-term split screening + fp32 re-check --------
+// The distance contraction -2 x W^T in fp32 MFMA is the whole cost of bulk assignment (vq_assign_rt_kernel<128,4>: 64-68 % of
+// the fp32 matrix peak, i.e. it cannot get faster in fp32).  gfx950's bf16 MFMA moves 16x the FLOPs per cycle, and
+//     x . w  ~=  xh.wh + xh.wl + xl.wh        (xh = bf16(x), xl = bf16(x - xh); same for w)
+// misses only xl.wl and the second-order residuals: |error| <= 3 * 2^-16 * |x||w| + the fp32 accumulation of 3E terms.
+//   vq_bx3_split_kernel   codebook -> Wh, Wl (bf16, row-major), once per call
+//   vq_bx3_sweep_kernel   per row: best code, best and SECOND-best approximate distance; a row whose two best distances are
+//                         closer than margin = 2^-11 |x| max_k|w_k| (> 2x the bound above) is UNDECIDED: its id goes to a list
+//   vq_assign_rt_kernel<128,4,LIST>   the undecided rows again, in exact fp32 (the kernel the training path and the tests use)
+// A decided row's approximate winner beats every other code by more than twice the error bound, so it is the exact-arithmetic
+// argmin as well; an undecided row gets exactly what the fp32 kernel gives.  Cost: 12 bf16 MFMAs (16 cycles) per 16 x 16 x 128
+// tile instead of 32 fp32 ones (32 cycles) = 5.3x fewer matrix cycles, plus the re-check on the undecided fraction.
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+__global__ __launch_bounds__(256) void vq_bx3_split_kernel(const float* __restrict__ W, __bf16* __restrict__ Wh,
+                                                           __bf16* __restrict__ Wl, int64_t n) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float w = W[e];
+    const __bf16 h = (__bf16)w;
+    Wh[e] = h;
+    Wl[e] = (__bf16)(w - (float)h);
+  }
+}
+
+// 256 rows per workgroup: wave w owns rows 64 w .. 64 w + 63 (4 row tiles, fragments in registers for the whole sweep) and
+// walks ALL code tiles; the codebook passes through LDS in chunks of 64 codes (hi and lo images, double buffered, fetched
+// from L2 once per workgroup = 1 KiB per row -- with the codebook pulled per wave, as in vq_assign_rt_kernel, this kernel is
+// L2-bandwidth-bound at the fp32 kernel's speed: measured 1.28 vs 1.25 ms for 2^20 rows).
+constexpr int BX3_CODES = 64, BX3_LDW = 128 + 8;       // bf16 elements per LDS row: 272 B, conflict-free ds_read_b128 per 16 lanes
+// (best, second best) per row are kept as floats that carry the code index in their low mantissa bits (kbits = log2 K): one
+// v_and_or packs, med3(d1, d2, p) is the new second best, min(d1, p) the new best -- 3.5 VALU ops per candidate, which fit
+// into the issue slots the bf16 MFMAs leave; the 2^-(23 - kbits) relative truncation is added to the margin.
+__global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __restrict__ flat, const __bf16* __restrict__ Wh,
+                                                              const __bf16* __restrict__ Wl, const float* __restrict__ wsq,
+                                                              int64_t* __restrict__ idx_out, int* __restrict__ und_list,
+                                                              int* __restrict__ und_count, int N, int K, int kbits) {
+  constexpr int E = 128, KB = E / 32, RT = 4;
+  __shared__ __attribute__((aligned(16))) __bf16 Ls[2][2][BX3_CODES * BX3_LDW];      // [buffer][hi / lo][code][k]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int r0 = blockIdx.x * 256 + 64 * wave;
+  // ---- this wave's rows as B-operand fragments (hi / lo), straight from global; |x|^2 on the way ---------------------------
+  bf16x8 xh[RT][KB], xl[RT][KB];
+  float xr[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int row = r0 + 16 * t + i;
+    const float* xp = flat + (int64_t)(row < N ? row : N - 1) * E + 8 * q;
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + 32 * s), b = *reinterpret_cast<const float4*>(xp + 32 * s + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        xh[t][s][j] = h;
+        xl[t][s][j] = (__bf16)(v[j] - (float)h);
+        ss += v[j] * v[j];
+      }
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    xr[t] = ss;
+  }
+  float wm = 0.f;                                       // max_k |w_k|^2
+  for (int k = lane; k < K; k += 64) wm = fmaxf(wm, wsq[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+  float d1[RT], d2[RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { d1[t] = INFINITY; d2[t] = INFINITY; }
+  const unsigned kmask = (1u << kbits) - 1u;
+  // ---- codebook chunks: thread -> (row tid >> 4 (+16 p), 16-byte piece tid & 15) of the hi and of the lo image -----------
+  const int frow = tid >> 4, fpc = tid & 15;
+  bf16x8 fh[4], fl[4];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int64_t off = (int64_t)(c * BX3_CODES + frow + 16 * p) * E + 8 * fpc;
+      fh[p] = *reinterpret_cast<const bf16x8*>(Wh + off);
+      fl[p] = *reinterpret_cast<const bf16x8*>(Wl + off);
+    }
+  };
+  auto stash = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      *reinterpret_cast<bf16x8*>(&Ls[buf][0][(frow + 16 * p) * BX3_LDW + 8 * fpc]) = fh[p];
+      *reinterpret_cast<bf16x8*>(&Ls[buf][1][(frow + 16 * p) * BX3_LDW + 8 * fpc]) = fl[p];
+    }
+  };
+  const int nch = K / BX3_CODES;
+  fetch(0);
+  stash(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nch) fetch(c + 1);
+#pragma unroll
+    for (int tl = 0; tl < BX3_CODES / 16; ++tl) {
+      bf16x8 wh[KB], wl[KB];
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+        wh[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][0][(16 * tl + i) * BX3_LDW + 32 * s + 8 * q]);
+        wl[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][1][(16 * tl + i) * BX3_LDW + 32 * s + 8 * q]);
+      }
+      const int c0 = c * BX3_CODES + 16 * tl + 4 * q;
+      const float4 sq = *reinterpret_cast<const float4*>(wsq + c0);
+      f32x4 acc[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl[t][s], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {        // the large term last: the small ones are not absorbed by its rounding
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh[t][s], acc[t], 0, 0, 0);
+      }
+      const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = (xr[t] + sv[r]) - 2.0f * acc[t][r];
+          const float pk = __uint_as_float((__float_as_uint(d) & ~kmask) | (unsigned)(c0 + r));
+          d2[t] = __builtin_amdgcn_fmed3f(d1[t], d2[t], pk);      // d1 <= d2 always: the median is the second smallest
+          d1[t] = fminf(d1[t], pk);                               // a NaN candidate leaves both untouched (minNum)
+        }
+    }
+    if (c + 1 < nch) stash(buf ^ 1);          // buffer buf ^ 1 was last read in iteration c - 1, before the barrier below
+    __syncthreads();
+  }
+  const float trunc = ldexpf(1.0f, kbits - 22);          // 2 x the relative truncation of a packed distance
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {                 // (best, second best) of two disjoint code sets
+      const float e1 = __shfl_xor(d1[t], o), e2 = __shfl_xor(d2[t], o);
+      d2[t] = fminf(fmaxf(d1[t], e1), fminf(d2[t], e2));
+      d1[t] = fminf(d1[t], e1);
+    }
+    const int row = r0 + 16 * t + i;
+    if (q == 0 && row < N) {
+      idx_out[row] = (int64_t)(__float_as_uint(d1[t]) & kmask);
+      const float margin = 4.8828125e-4f * sqrtf(xr[t] * wm) + trunc * fabsf(d2[t]);       // 2^-11 |x| max|w| + truncation
+      // NaN / inf - inf (rows with non-finite distances) compare false: undecided, the exact kernel follows torch.argmin
+      if (!(d2[t] - d1[t] >= margin)) und_list[atomicAdd(und_count, 1)] = row;
+    }
+  }
+}
+
 // rows per workgroup: 16 (fill the chip; the codebook stream is then L2-bound), 64 for bulk assignment (MFMA-bound)
 static int vq_rows_per_block(int N) { return N >= 16384 ? 64 : 16; }   // measured: 32 rows at N = 4096 is slower (18.8 vs 13.7 us)
 // upper bound on the number of SSE partials any path writes for N rows (callers size sse_partial with it)
@@ -1027,6 +1188,48 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
     (void)hipFuncSetAttribute((const void*)vq_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(cdiv(N, VQ_ROWS)), dim3(256), lds, (hipStream_t)stream, flat, z, codebook,
                      code_sqnorm, idx, quantized, dist_min, sse_partial, N, E, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" size_t g2v_vq_assign_bulk_workspace(int N, int E, int K) {
+  if (N <= 0 || E <= 0 || K <= 0) return 0;
+  return 2 * (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256 + (size_t)N * 4;
+}
+
+// idx[n] = argmin_k |flat[n] - W[k]|^2 for MANY rows (bulk latent -> code assignment): bf16 split screening + exact fp32
+// re-check of the undecided rows (see vq_bx3_sweep_kernel).  undecided (device int, may be NULL) receives their count.
+extern "C" int g2v_vq_assign_bulk(const float* flat, const float* codebook, const float* code_sqnorm, int64_t* idx, int N,
+                                  int E, int K, void* workspace, size_t workspace_bytes, int* undecided,
+                                  g2v_stream_t stream) {
+  G2V_REQUIRE(flat && codebook && code_sqnorm && idx && workspace, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (!(E == 128 && (K & 127) == 0 && ptr_aligned16(flat) && ptr_aligned16(codebook) && ptr_aligned16(code_sqnorm) &&
+        ptr_aligned16(workspace))) {
+    set_error("g2v_vq_assign_bulk: needs E == 128, K %% 128 == 0 and 16-byte aligned operands");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < g2v_vq_assign_bulk_workspace(N, E, K)) {
+    set_error("g2v_vq_assign_bulk: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const size_t half = ((size_t)K * E * 2 + 255) & ~(size_t)255;
+  char* w = (char*)workspace;
+  __bf16* Wh = (__bf16*)w;
+  __bf16* Wl = (__bf16*)(w + half);
+  int* count = (int*)(w + 2 * half);
+  int* list = (int*)(w + 2 * half + 256);
+  (void)hipMemsetAsync(count, 0, sizeof(int), st);
+  hipLaunchKernelGGL(vq_bx3_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, Wh, Wl, (int64_t)K * E);
+  int kbits = 1;
+  while ((1 << kbits) < K) ++kbits;
+  G2V_REQUIRE(kbits <= 13, "codebook larger than 8192 codes");
+  hipLaunchKernelGGL(vq_bx3_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, code_sqnorm, idx, list, count, N,
+                     K, kbits);
+  hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4, true>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, (const float*)nullptr,
+                     codebook, code_sqnorm, idx, (float*)nullptr, (float*)nullptr, (float*)nullptr, N, K, list, count);
+  if (undecided) (void)hipMemcpyAsync(undecided, count, sizeof(int), hipMemcpyDeviceToDevice, st);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

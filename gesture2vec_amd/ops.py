@@ -152,6 +152,20 @@ def vq_assign(flat, z, codebook, code_sqnorm, want_quantized=True, want_dist=Fal
     return idx, quant, dmin, sse
 
 
+def vq_assign_bulk(flat, codebook, code_sqnorm, want_undecided=False):
+    """idx (N,) = argmin_k |flat - W_k|^2 for many rows: bf16 split screening + exact fp32 re-check (g2v_vq_assign_bulk)."""
+    N, E = flat.shape
+    K = codebook.shape[0]
+    lib = _lib_()
+    idx = torch.empty((N,), dtype=torch.int64, device=flat.device)
+    nb = int(lib.g2v_vq_assign_bulk_workspace(N, E, K))
+    ws = workspace(nb, flat.device, "vqbulk")
+    und = torch.zeros((1,), dtype=torch.int32, device=flat.device) if want_undecided else None
+    check(lib.g2v_vq_assign_bulk(_p(_chk(flat)), _p(_chk(codebook)), _p(_chk(code_sqnorm)), _p(idx), N, E, K, _p(ws), nb, _p(und),
+                                 _stream()), "vq_assign_bulk")
+    return (idx, und) if want_undecided else idx
+
+
 def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm):
     """pre_linear + assign in one launch (E == 128, K % 128 == 0) -> flat (N,E), idx (N) int64, quantized (N,E), sse_partial"""
     N, E = z.shape

@@ -116,6 +116,15 @@ int g2v_vq_assign_fwd(const float* flat, const float* z, const float* codebook, 
 /* pre_linear + assign in ONE launch (E == 128, K % 128 == 0; G2V_ERR_UNSUPPORTED otherwise -> g2v_linear_fwd +
  * g2v_vq_assign_fwd): flat = z w_pre^T + b_pre (:1230) is written to flat_out (the code statistics read it), the
  * distances / argmin use it from LDS, quantized / sse_partial use the raw z as in g2v_vq_assign_fwd. */
+/* Bulk code assignment (row f-2: latents of a whole corpus -> code indices, pipeline.chunks_to_codes): idx only, N large.
+ * The -2 x W^T contraction runs on the bf16 matrix pipe as a 3-term split (xh.wh + xh.wl + xl.wh, fp32 accumulate); a row
+ * whose best and second-best approximate distances are closer than 2^-11 |x| max|w| (more than twice the split's error
+ * bound) is assigned again by the exact fp32 kernel of g2v_vq_assign_fwd, so the result is the fp32 argmin
+ * (Autoencoder_VQVAE_model.py:1234-1259) at ~5x fewer matrix cycles.  E == 128, K % 128 == 0.  undecided (device int, may be
+ * NULL): number of rows that took the exact path. */
+size_t g2v_vq_assign_bulk_workspace(int N, int E, int K);
+int g2v_vq_assign_bulk(const float* flat, const float* codebook, const float* code_sqnorm, int64_t* idx, int N, int E, int K,
+                       void* workspace, size_t workspace_bytes, int* undecided, g2v_stream_t stream);
 int g2v_vq_fused_assign_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
                             const float* code_sqnorm, float* flat_out, int64_t* idx, float* quantized,
                             float* sse_partial, int N, int E, int K, g2v_stream_t stream);

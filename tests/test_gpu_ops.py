@@ -174,6 +174,39 @@ def test_vq_assign_matches_golden_indices(ops, golden_dir):
     assert abs(loss - float(fx["ema/c1/loss"])) <= 1e-5 * abs(float(fx["ema/c1/loss"]))
 
 
+@pytest.mark.parametrize("N,K,scale", [(65536, 512, 1.0), (20000 + 37, 512, 0.05), (4096, 128, 1.0), (100, 512, 3.0)])
+def test_vq_assign_bulk_equals_exact_assignment(ops, N, K, scale):
+    """g2v_vq_assign_bulk: bf16 3-term split screening on the bf16 matrix pipe + exact fp32 re-check of the undecided rows.
+    A decided row's winner leads by more than twice the split's error bound, an undecided one is assigned by the fp32 kernel
+    itself: the result must EQUAL the fp32 kernel's on every row -- including exact ties (duplicated codes: lowest index),
+    near-ties and non-finite rows -- and the oracle's on the safe rows."""
+    E = 128
+    g = torch.Generator().manual_seed(21)
+    W = torch.randn(K, E, generator=g) * scale
+    W[K // 2] = W[3]                                    # an exact tie for every row that picks code 3
+    flat = torch.randn(N, E, generator=g) * scale
+    flat[5] = W[7] + 1e-7 * torch.randn(E, generator=g)        # a row sitting on a code
+    flat[6] = 0.5 * (W[10] + W[11])                     # equidistant from two codes (up to rounding)
+    flat[9, 3] = float("nan")
+    flat[11, 0] = float("inf")
+    Wd, fd = W.to(DEV), flat.to(DEV)
+    wsq = ops.vq_code_sqnorm(Wd)
+    exact = ops.vq_assign(fd, fd, Wd, wsq, want_quantized=False)[0]
+    idx, und = ops.vq_assign_bulk(fd, Wd, wsq, want_undecided=True)
+    n_und = int(und.item())
+    assert torch.equal(idx, exact), f"{int((idx != exact).sum())} rows differ from the fp32 kernel ({n_und} undecided)"
+    assert 4 <= n_und <= max(8, N // 3), n_und           # the planted rows at least; screening must decide most rows
+    nchk = min(N, 2000)
+    dist = O.vq_distances(flat[:nchk].double(), W.double())
+    i_ref = dist.argmin(1)
+    d_sorted = dist.sort(1).values
+    safe = ((d_sorted[:, 1] - d_sorted[:, 0]) > 1e-4 * max(scale * scale, 1e-3)) & torch.isfinite(d_sorted[:, 0])
+    assert int(safe.sum()) > nchk // 2
+    assert torch.equal(idx[:nchk].cpu()[safe], i_ref[safe])
+    idx2 = ops.vq_assign_bulk(fd, Wd, wsq)              # dirty workspace, same answer
+    assert torch.equal(idx2, idx)
+
+
 # N >= 16384 at E = 128, K % 128 == 0 runs vq_assign_rt_kernel<128,4> (64 rows per workgroup: the bulk code-assignment
 # kernel of pipeline.chunks_to_codes and of every N-sweep roofline figure); 16384 + 37 ends in a partial 64-row tile.
 @pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (33, 100, 512), (128, 400, 512), (1000, 128, 64), (17, 20, 7),

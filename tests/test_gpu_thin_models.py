@@ -208,3 +208,18 @@ def test_vq_gssoft_matches_reference_golden(golden_dir):
                 assert g is not None and relerr(g, fx[k]) < 3e-4, (n, relerr(g, fx[k]))
             if k.startswith(f"c{i}/gradnone/"):
                 assert dict(q.named_parameters())[k[len(f"c{i}/gradnone/"):]].grad is None
+
+
+def test_bulk_assign_route_of_the_quantiser_module():
+    """VQ_Payam_EMA.assign switches to g2v_vq_assign_bulk (bf16 split screening + exact re-check) from 2^17 rows: same indices
+    as the fp32 kernel on the projected rows."""
+    from gesture2vec_amd import ops
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import VQ_Payam_EMA
+    torch.manual_seed(3)
+    q = VQ_Payam_EMA(512, 128, 0.25, 0.85).to(DEV)
+    z = torch.randn(131072 + 5, 128, device=DEV) * 0.3
+    idx = q.assign(z)
+    flat = ops.linear_fwd(z, q.pre_linear.weight.data, q.pre_linear.bias.data)
+    W = q._embedding.weight.data
+    ref = ops.vq_assign(flat, None, W, ops.vq_code_sqnorm(W), want_quantized=False)[0]
+    assert idx.dtype == torch.int64 and torch.equal(idx, ref)
