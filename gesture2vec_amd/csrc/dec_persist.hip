@@ -436,7 +436,8 @@ using namespace g2v;
 int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
                            const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
                            int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
-                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st) {
+                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st,
+                           bool clear) {
   DecPersistArgs a;
   a.target = target; a.h_init = h_init; a.w = *w;
   a.p_pre = p_pre; a.p_ih0 = p_ih0; a.p_hh0 = p_hh0; a.p_ih1 = p_ih1; a.p_hh1 = p_hh1; a.p_out = p_out;
@@ -453,7 +454,8 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
     }
     attr_set = true;
   }
-  if (training) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);       // every polled word, every call (tags count steps 1..T)
+  // every polled word, every call (tags count steps 1..T); !clear: g2v_dec_rollout_prepare has done it for this call
+  if (training && clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
   hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
   if (hipGetLastError() != hipSuccess) {
     set_error("dec_persist_fwd: launch failed");
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st) {
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear) {
   DecPersistBwdArgs a;
   a.w = *w; a.sv = *s; a.gr = *g;
   a.p_pre_t = p_pre_t; a.p_out_t = p_out_t; a.p_ih0_t = p_ih0_t; a.p_hh0_t = p_hh0_t; a.p_ih1_t = p_ih1_t; a.p_hh1_t = p_hh1_t;
@@ -802,7 +804,7 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
     }
     attr_set = true;
   }
-  (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
+  if (clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
   hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
   if (hipGetLastError() != hipSuccess) {
     set_error("dec_persist_bwd: launch failed");

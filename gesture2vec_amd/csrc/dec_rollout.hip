@@ -25,11 +25,12 @@
 int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
                            const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
                            int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
-                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st);
+                           const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st,
+                           bool clear);
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st);
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear);
 
 namespace g2v {
 
@@ -1709,10 +1710,40 @@ __global__ __launch_bounds__(128) void dec_bwd_pair_split_kernel(DecBwdPairArgs 
   }
 }
 
-extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,
-                                   const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
-                                   int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
-                                   void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+// The weight fragments of the fused kernels (per-step and persistent alike), in workspace order.
+static DecPackF dec_fwd_pack_layout(const g2v_dec_weights* w, int D, int H, void* workspace, PackBatch& pb) {
+  float* p = (float*)workspace;
+  DecPackF pk;
+  pb.n = 6;
+  pb.d[0] = PackDesc{w->w_pre, p, H, 1, 0, D, D, 0, 0}; pk.pre = p; p += pack_floats(H, 1, D);
+  pb.d[1] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
+  pb.d[2] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
+  pb.d[3] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
+  pb.d[4] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
+  pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0, dtiles_pad(D)}; pk.out = p;
+  return pk;
+}
+static DecTW dec_bwd_pack_layout(const g2v_dec_weights* w, int D, int H, void* workspace, PackBatch& pb) {
+  float* p = (float*)workspace;
+  DecTW tw;
+  pb.n = 6;
+  const int G = 3 * H;
+  pb.d[0] = PackDesc{w->w_pre, p, D, 1, 0, H, D, 1, dtiles_pad(D)}; tw.w_pre_t = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;   // rows d, k = f: W_pre[f][d]
+  pb.d[1] = PackDesc{w->w_out, p, H, 1, 0, D, H, 1, 0}; tw.w_out_t = p; p += pack_floats(H, 1, D);   // rows f, k = d: W_out[d][f]
+  pb.d[2] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1, 0}; tw.w_ih0_t = p; p += pack_floats(H, 1, G);   // rows k, contraction g: W[g][k]
+  pb.d[3] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1, 0}; tw.w_hh0_t = p; p += pack_floats(H, 1, G);
+  pb.d[4] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1, 0}; tw.w_ih1_t = p; p += pack_floats(H, 1, G);
+  pb.d[5] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1, 0}; tw.w_hh1_t = p;
+  return tw;
+}
+// prepared workspaces are honoured by the fused H = 64, D = 135 kernels only (the split kernels of other shapes transpose)
+static bool dec_prepared_shape(int D, int H) { return H == 64 && D == 135; }
+
+static int dec_rollout_fwd_impl(const float* target, const float* h_init, const g2v_dec_weights* w,
+                                const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
+                                int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
+                                void* workspace, size_t workspace_bytes, g2v_stream_t stream, bool prepared_req) {
+  const bool prepared = prepared_req && dec_prepared_shape(D, H);
   G2V_REQUIRE(target && h_init && w && s && keep95 && workspace, "null pointer");
   G2V_REQUIRE(T >= 2 && B > 0 && D > 0 && H > 0, "bad size");
   G2V_REQUIRE(s->y && s->u && s->h0 && s->h1 && s->bn_partial, "missing state buffer");
@@ -1729,18 +1760,12 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   }
   hipStream_t st = (hipStream_t)stream;
   // ---- pack the weights into MFMA fragment order (one launch) ----
-  float* p = (float*)workspace;
-  DecPackF pk;
   PackBatch pb;
-  pb.n = 6;
-  pb.d[0] = PackDesc{w->w_pre, p, H, 1, 0, D, D, 0, 0}; pk.pre = p; p += pack_floats(H, 1, D);
-  pb.d[1] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
-  pb.d[2] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
-  pb.d[3] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
-  pb.d[4] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
-  pb.d[5] = PackDesc{w->w_out, p, D, 1, 0, H, H, 0, dtiles_pad(D)}; pk.out = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;
-  launch_pack(pb, st);
-  G2V_CHECK_LAUNCH();
+  const DecPackF pk = dec_fwd_pack_layout(w, D, H, workspace, pb);
+  if (!prepared) {
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+  }
   DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), dec_wt_stores()};
   const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
   {
@@ -1751,7 +1776,7 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
     if (persist) {
       void* xbase = (char*)workspace + fwd_pack_bytes_aligned(D, H);
       const int rc = dec_persist_fwd_launch(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T,
-                                            B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st);
+                                            B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st, !prepared);
       if (rc != G2V_OK) return rc;
       if (training) {
         hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, s->bn_stats,
@@ -1819,6 +1844,22 @@ extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, con
   return G2V_OK;
 }
 
+extern "C" int g2v_dec_rollout_fwd(const float* target, const float* h_init, const g2v_dec_weights* w,
+                                   const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0, float p_drop,
+                                   int n_pre_poses, int conditioned, int training, int T, int B, int D, int H,
+                                   void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  return dec_rollout_fwd_impl(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T, B, D, H,
+                              workspace, workspace_bytes, stream, false);
+}
+// as g2v_dec_rollout_fwd, on a workspace that g2v_dec_rollout_prepare has filled for THIS call (no pack, no clearing launch)
+extern "C" int g2v_dec_rollout_fwd_prepared(const float* target, const float* h_init, const g2v_dec_weights* w,
+                                            const g2v_dec_saved* s, const uint8_t* keep95, const uint8_t* keep_l0,
+                                            float p_drop, int n_pre_poses, int conditioned, int training, int T, int B,
+                                            int D, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  return dec_rollout_fwd_impl(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T, B, D, H,
+                              workspace, workspace_bytes, stream, true);
+}
+
 // split path (small batch): six plain transposes + two (B <= 512, H) scratch arrays
 static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 16 * DSPLIT_MAX_NBLK * H; }
 static size_t bwd_pack_bytes_aligned(int D, int H) { return (pack_bwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
@@ -1827,10 +1868,38 @@ extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   return a > b ? a : b;
 }
 
-extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
-                                   const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
-                                   int conditioned, int T, int B, int D, int H, void* workspace, size_t workspace_bytes,
-                                   g2v_stream_t stream) {
+// Everything of a rollout pair that depends on the WEIGHTS only -- the fragment packs of the forward and of the backward -- and
+// the clearing of the two exchange regions, launched ahead of time (the engine runs it as a parallel branch at the start of the
+// step): g2v_dec_rollout_fwd_prepared / _bwd_prepared then start with their first real kernel.  The two workspaces must not be
+// touched between this call and the prepared calls.  bwd_workspace may be NULL (inference).  Other shapes: a no-op.
+extern "C" int g2v_dec_rollout_prepare(const g2v_dec_weights* w, int D, int H, void* fwd_workspace, size_t fwd_bytes,
+                                       void* bwd_workspace, size_t bwd_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(w && fwd_workspace, "null pointer");
+  G2V_REQUIRE(D > 0 && H > 0, "bad size");
+  if (!dec_prepared_shape(D, H)) return G2V_OK;
+  if (fwd_bytes < g2v_dec_rollout_fwd_workspace(D, H) || (bwd_workspace && bwd_bytes < g2v_dec_rollout_bwd_workspace(D, H))) {
+    set_error("g2v_dec_rollout_prepare: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  PackBatch pb;
+  (void)dec_fwd_pack_layout(w, D, H, fwd_workspace, pb);
+  launch_pack(pb, st);
+  (void)hipMemsetAsync((char*)fwd_workspace + fwd_pack_bytes_aligned(D, H), 0, PX_BYTES, st);
+  if (bwd_workspace) {
+    (void)dec_bwd_pack_layout(w, D, H, bwd_workspace, pb);
+    launch_pack(pb, st);
+    (void)hipMemsetAsync((char*)bwd_workspace + bwd_pack_bytes_aligned(D, H), 0, PX_BYTES, st);
+  }
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
+                                const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                                int conditioned, int T, int B, int D, int H, void* workspace, size_t workspace_bytes,
+                                g2v_stream_t stream, bool prepared_req) {
+  const bool prepared = prepared_req && dec_prepared_shape(D, H);
   G2V_REQUIRE(w && s && g && keep95 && workspace, "null pointer");
   G2V_REQUIRE(T >= 2 && B > 0 && D > 0 && H > 0, "bad size");
   G2V_REQUIRE(g->dy && g->du && g->dbn && g->dgi0 && g->dgh0 && g->dgi1 && g->dgh1 && g->dh_init && g->d_bn_w &&
@@ -1909,18 +1978,12 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
       return G2V_OK;
     }
   }
-  DecTW tw;
   PackBatch pb;
-  pb.n = 6;
-  const int G = 3 * H;
-  pb.d[0] = PackDesc{w->w_pre, p, D, 1, 0, H, D, 1, dtiles_pad(D)}; tw.w_pre_t = p; p += (size_t)dtiles_pad(D) * pack_ks(H) * 256;   // rows d, k = f: W_pre[f][d]
-  pb.d[1] = PackDesc{w->w_out, p, H, 1, 0, D, H, 1, 0}; tw.w_out_t = p; p += pack_floats(H, 1, D);   // rows f, k = d: W_out[d][f]
-  pb.d[2] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1, 0}; tw.w_ih0_t = p; p += pack_floats(H, 1, G);   // rows k, contraction g: W[g][k]
-  pb.d[3] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1, 0}; tw.w_hh0_t = p; p += pack_floats(H, 1, G);
-  pb.d[4] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1, 0}; tw.w_ih1_t = p; p += pack_floats(H, 1, G);
-  pb.d[5] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1, 0}; tw.w_hh1_t = p; p += pack_floats(H, 1, G);
-  launch_pack(pb, st);
-  G2V_CHECK_LAUNCH();
+  const DecTW tw = dec_bwd_pack_layout(w, D, H, workspace, pb);
+  if (!prepared) {
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+  }
   if (lds > 48 * 1024) {
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1935,7 +1998,8 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
                          a16(g->dgh1) && a16(g->dh_init) && a16(keep95) && a16(keep_l0) && a16(workspace);
     if (persist)
       return dec_persist_bwd_launch(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, tw.w_pre_t, tw.w_out_t,
-                                    tw.w_ih0_t, tw.w_hh0_t, tw.w_ih1_t, tw.w_hh1_t, (char*)workspace + bwd_pack_bytes_aligned(D, H), st);
+                                    tw.w_ih0_t, tw.w_hh0_t, tw.w_ih1_t, tw.w_hh1_t, (char*)workspace + bwd_pack_bytes_aligned(D, H), st,
+                                    !prepared);
   }
   for (int t = T - 1; t >= 0; --t) {
     if (fast)
@@ -1945,4 +2009,19 @@ extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved
   }
   G2V_CHECK_LAUNCH();
   return G2V_OK;
+}
+
+extern "C" int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
+                                   const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                                   int conditioned, int T, int B, int D, int H, void* workspace, size_t workspace_bytes,
+                                   g2v_stream_t stream) {
+  return dec_rollout_bwd_impl(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, D, H, workspace, workspace_bytes,
+                              stream, false);
+}
+extern "C" int g2v_dec_rollout_bwd_prepared(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
+                                            const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                                            int conditioned, int T, int B, int D, int H, void* workspace,
+                                            size_t workspace_bytes, g2v_stream_t stream) {
+  return dec_rollout_bwd_impl(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, D, H, workspace, workspace_bytes,
+                              stream, true);
 }

@@ -761,8 +761,68 @@ extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
   return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
-                               int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+// fragment packs of the H == 64 fast kernels, in workspace order: per direction W_hh (, W_ih when the projection is fused)
+static PackBatch gru_fwd_packs(const float* const* w_hh, const float* const* w_ih, int ndir, int H, bool fuse, float* p,
+                               const float** p_hh, const float** p_ih) {
+  PackBatch pb;
+  pb.n = 0;
+  for (int k = 0; k < ndir; ++k) {
+    pb.d[pb.n++] = PackDesc{w_hh[k], p, H, 3, H, H, H, 0, 0};
+    p_hh[k] = p;
+    p += pack_floats(H, 3, H);
+    p_ih[k] = nullptr;
+    if (fuse) {
+      pb.d[pb.n++] = PackDesc{w_ih[k], p, H, 3, H, H, H, 0, 0};
+      p_ih[k] = p;
+      p += pack_floats(H, 3, H);
+    }
+  }
+  return pb;
+}
+static PackBatch gru_bwd_packs(const float* const* w_hh, const float* const* w_ih, int ndir, int H, bool fuse, float* p,
+                               const float** p_hh_t, const float** p_ih_t) {
+  PackBatch pb;
+  pb.n = 0;
+  for (int k = 0; k < ndir; ++k) {
+    pb.d[pb.n++] = PackDesc{w_hh[k], p, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden feature), contraction over the 3H gates
+    p_hh_t[k] = p;
+    p += pack_floats(H, 1, 3 * H);
+    p_ih_t[k] = nullptr;
+    if (fuse) {
+      pb.d[pb.n++] = PackDesc{w_ih[k], p, H, 1, 0, 3 * H, H, 1, 0};
+      p_ih_t[k] = p;
+      p += pack_floats(H, 1, 3 * H);
+    }
+  }
+  return pb;
+}
+
+// The weight-fragment packs of one g2v_gru_seq_fwd + one g2v_gru_seq_bwd call (H == 64 fast kernels), launched ahead of time
+// into the two workspaces (the engine runs this as a parallel branch at the start of the step); the *_prepared entry points
+// then skip their pack launch.  fused != 0: the calls fuse the input projection / input gradient (w_ih packed too).
+// Either workspace may be NULL (that call packs for itself).  Other hidden sizes: a no-op (their kernels read the weights in place).
+extern "C" int g2v_gru_seq_prepare(const float* const* w_hh, const float* const* w_ih, int ndir, int H, int fused,
+                                   void* fwd_workspace, size_t fwd_bytes, void* bwd_workspace, size_t bwd_bytes,
+                                   g2v_stream_t stream) {
+  G2V_REQUIRE(w_hh && (fwd_workspace || bwd_workspace), "null pointer");
+  G2V_REQUIRE(ndir >= 1 && ndir <= 2 && H > 0, "bad size");
+  G2V_REQUIRE(!fused || w_ih, "fused needs w_ih");
+  if (H != 64) return G2V_OK;
+  if ((fwd_workspace && fwd_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) ||
+      (bwd_workspace && bwd_bytes < g2v_gru_seq_bwd_workspace(ndir, H))) {
+    set_error("g2v_gru_seq_prepare: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const float* a[2];
+  const float* b[2];
+  if (fwd_workspace) launch_pack(gru_fwd_packs(w_hh, w_ih, ndir, H, fused != 0, (float*)fwd_workspace, a, b), (hipStream_t)stream);
+  if (bwd_workspace) launch_pack(gru_bwd_packs(w_hh, w_ih, ndir, H, fused != 0, (float*)bwd_workspace, a, b), (hipStream_t)stream);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
+                            int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream, bool prepared) {
   G2V_REQUIRE(dirs && workspace, "null pointer");
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && hs_ld >= H, "bad size");
@@ -783,24 +843,20 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
       set_error("g2v_gru_seq_fwd: workspace too small");
       return G2V_ERR_WORKSPACE;
     }
-    float* p = (float*)workspace;
-    PackBatch pb;
-    pb.n = 0;
+    const float* whh[2] = {dirs[0].w_hh, dirs[ndir - 1].w_hh};
+    const float* wih[2] = {dirs[0].w_ih, dirs[ndir - 1].w_ih};
+    const float* p_hh[2];
+    const float* p_ih[2];
+    const PackBatch pb = gru_fwd_packs(whh, wih, ndir, H, fuse, (float*)workspace, p_hh, p_ih);
     GruDirF f[2];
-    for (int k = 0; k < ndir; ++k) {
-      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, p, H, 3, H, H, H, 0, 0};
-      f[k] = GruDirF{dirs[k].gi, p, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse,
-                     dirs[k].x, nullptr, dirs[k].b_ih};
-      p += pack_floats(H, 3, H);
-      if (fuse) {
-        pb.d[pb.n++] = PackDesc{dirs[k].w_ih, p, H, 3, H, H, H, 0, 0};
-        f[k].p_ih = p;
-        p += pack_floats(H, 3, H);
-      }
-    }
+    for (int k = 0; k < ndir; ++k)
+      f[k] = GruDirF{dirs[k].gi, p_hh[k], dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse,
+                     dirs[k].x, p_ih[k], dirs[k].b_ih};
     if (ndir == 1) f[1] = f[0];
-    launch_pack(pb, st);
-    G2V_CHECK_LAUNCH();
+    if (!prepared) {
+      launch_pack(pb, st);
+      G2V_CHECK_LAUNCH();
+    }
     if (fuse)
       hipLaunchKernelGGL((gru_fwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
     else
@@ -863,14 +919,24 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
   return G2V_OK;
 }
 
+extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
+                               int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  return gru_seq_fwd_impl(dirs, ndir, lengths, hs_ld, T, B, H, workspace, workspace_bytes, stream, false);
+}
+// as g2v_gru_seq_fwd / _bwd on workspaces that g2v_gru_seq_prepare has filled for THIS call (no pack launch)
+extern "C" int g2v_gru_seq_fwd_prepared(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T,
+                                        int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  return gru_seq_fwd_impl(dirs, ndir, lengths, hs_ld, T, B, H, workspace, workspace_bytes, stream, H == 64);
+}
+
 extern "C" size_t g2v_gru_seq_bwd_workspace(int ndir, int H) {
   const size_t a = (size_t)2 * ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H + gru_split_state_floats(ndir, H);
   return (a > b ? a : b) * sizeof(float);
 }
 
-extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
-                               int64_t hs_ld, int T, int B, int H, void* workspace, size_t workspace_bytes,
-                               g2v_stream_t stream) {
+static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
+                            int64_t hs_ld, int T, int B, int H, void* workspace, size_t workspace_bytes,
+                            g2v_stream_t stream, bool prepared) {
   G2V_REQUIRE(dirs && workspace, "null pointer");
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0, "bad size");
@@ -894,23 +960,20 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
     return G2V_ERR_UNSUPPORTED;
   }
   if (fast) {
-    PackBatch pb;
-    pb.n = 0;
+    const float* whh[2] = {dirs[0].w_hh, dirs[ndir - 1].w_hh};
+    const float* wih[2] = {dirs[0].w_ih, dirs[ndir - 1].w_ih};
+    const float* p_hh_t[2];
+    const float* p_ih_t[2];
+    const PackBatch pb = gru_bwd_packs(whh, wih, ndir, H, fuse, p, p_hh_t, p_ih_t);
     GruDirB f[2];
-    for (int k = 0; k < ndir; ++k) {
-      pb.d[pb.n++] = PackDesc{dirs[k].w_hh, p, H, 1, 0, 3 * H, H, 1, 0};   // rows k (hidden feature), contraction over the 3H gates
-      f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p,
-                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, nullptr, dirs[k].dx};
-      p += pack_floats(H, 1, 3 * H);
-      if (fuse) {
-        pb.d[pb.n++] = PackDesc{dirs[k].w_ih, p, H, 1, 0, 3 * H, H, 1, 0};
-        f[k].p_ih_t = p;
-        p += pack_floats(H, 1, 3 * H);
-      }
-    }
+    for (int k = 0; k < ndir; ++k)
+      f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p_hh_t[k],
+                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, p_ih_t[k], dirs[k].dx};
     if (ndir == 1) f[1] = f[0];
-    launch_pack(pb, st);
-    G2V_CHECK_LAUNCH();
+    if (!prepared) {
+      launch_pack(pb, st);
+      G2V_CHECK_LAUNCH();
+    }
     if (fuse)
       hipLaunchKernelGGL((gru_bwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
                          hs_ld, T, B);
@@ -970,4 +1033,15 @@ extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int3
   hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
+}
+
+extern "C" int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
+                               int64_t hs_ld, int T, int B, int H, void* workspace, size_t workspace_bytes,
+                               g2v_stream_t stream) {
+  return gru_seq_bwd_impl(dirs, ndir, lengths, d_hs_ld, hs_ld, T, B, H, workspace, workspace_bytes, stream, false);
+}
+extern "C" int g2v_gru_seq_bwd_prepared(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
+                                        int64_t hs_ld, int T, int B, int H, void* workspace, size_t workspace_bytes,
+                                        g2v_stream_t stream) {
+  return gru_seq_bwd_impl(dirs, ndir, lengths, d_hs_ld, hs_ld, T, B, H, workspace, workspace_bytes, stream, H == 64);
 }

@@ -1225,10 +1225,12 @@ struct SmallWgradBatch {
   float* dw[G2V_TN_BATCH];
   float* db[G2V_TN_BATCH];
 };
+// xmap.rows_inner > 0: row m of x is row (m_base + m) of a row-mapped tensor (the leftover rows of the ragged in_layer gradient)
 template <bool KEEP>
 __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx,
                                                              const uint8_t* __restrict__ keep, float scale, int M, int K,
-                                                             int N, int accumulate) {
+                                                             int N, int accumulate, RowMap xmap = RowMap{0, 0, 0, 0},
+                                                             int m_base = 0) {
   __shared__ float red[3][64 * 4 + 16];
   const float* __restrict__ dY = sb.dy[blockIdx.y];
   const float* __restrict__ X = sb.x[blockIdx.y];
@@ -1255,7 +1257,7 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
       for (int s = 0; s < 4; ++s) {
         const int m = m0 + 16 * blk + 4 * q + s, mc = m < me ? m : (M - 1);       // past the range: a valid row, zeroed in use()
         a[blk][s] = dyc[(int64_t)mc * lddy];
-        b[blk][s] = xc[(int64_t)mc * ldx];
+        b[blk][s] = xc[xmap.rows_inner > 0 ? row_off(xmap, m_base + mc) : (int64_t)mc * ldx];
         if (KEEP) kp[blk][s] = kc[(int64_t)mc * K];
       }
   };
@@ -1324,6 +1326,27 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
                       float* workspace, g2v_stream_t stream) {
   const int accumulate = flags & G2V_WGRAD_ACCUMULATE;
   const bool bf3 = (flags & G2V_WGRAD_BF16X3) != 0;
+  if ((M & 15) && M >= 4096 + 16 && !x_keep) {
+    // ragged row count (T B not a multiple of 16: B = 4100): the wave-autonomous kernels take the whole 16-row groups, the
+    // M % 16 leftover rows are added by the small-M kernel (accumulate) -- instead of the whole product falling back to the
+    // LDS-tiled kernel (95 vs 35-45 us per product at the BASELINE shape)
+    const int Mt = M & 15, Mm = M - Mt;
+    const int rc = wgrad_impl(it, nprob, lddy, ldx, rows_inner, stride_outer, stride_inner, nullptr, 1.0f, Mm, K, N, flags,
+                              workspace, stream);
+    if (rc != G2V_OK) return rc;
+    const bool mapped = rows_inner > 0;
+    SmallWgradBatch sb;
+    for (int p = 0; p < G2V_TN_BATCH; ++p) {
+      const int pp = p < nprob ? p : 0;
+      sb.dy[p] = it[pp].dy + (int64_t)Mm * lddy; sb.x[p] = mapped ? it[pp].x : it[pp].x + (int64_t)Mm * ldx;
+      sb.dw[p] = it[pp].dw; sb.db[p] = it[pp].db;
+    }
+    hipLaunchKernelGGL(gemm_tn_smallm_kernel<false>, dim3(cdiv(N, 16) * cdiv(K, 16), nprob), dim3(256), 0, (hipStream_t)stream, sb,
+                       lddy, ldx, (const uint8_t*)nullptr, 1.0f, Mt, K, N, 1, RowMap{ldx, rows_inner, stride_outer, stride_inner},
+                       mapped ? Mm : 0);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   if (M <= g_smallm_wgrad_rows && M <= g_smallm_max_rows * 2 && rows_inner == 0 && !bf3) {
     SmallWgradBatch sb;
     for (int p = 0; p < G2V_TN_BATCH; ++p) {

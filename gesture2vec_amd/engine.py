@@ -151,19 +151,23 @@ class VQVAEEngine:
         # Independent kernel chains of the fused train step run as parallel branches (side HIP streams; parallel branches of
         # the hipGraph when the step is captured) -- see _branch().  Bit 0: the dropout keep-masks beside the encoder
         # forward; bit 1: the EMA statistics + codebook update beside the decoder rollout; bit 2: the decoder's weight
-        # gradients beside the encoder's backward; bit 3: the encoder GRU's weight gradients beside the input layer's.
+        # gradients beside the encoder's backward; bit 3: the weight-fragment packs of the four recurrent launches and the clearing
+        # of the rollout's exchange regions (everything that depends on the weights only and is not needed at once) inside
+        # branch 0, beside the encoder (a branch of their own costs more at its fork and join than the 25 us it hides);
+        # bit 4 (off: measured +-0): the encoder GRU's weight gradients beside the input layer's.
         # G2V_OVERLAP=0 serialises everything on the caller's stream.
-        self.overlap = int(os.environ.get("G2V_OVERLAP", "7"))
+        self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
+        self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
-    def _branch(self, k: int):
+    def _branch(self, k: int, bit: Optional[int] = None):
         """Launch the enclosed kernels on side stream k, ordered after everything launched so far on the current stream.
         The branch stays open until _join(k) makes the current stream wait for it.  A branch may only touch buffers (and a
         workspace) that nothing launched on the main stream between the fork and the join touches."""
-        if not (self.overlap >> k) & 1:
+        if not (self.overlap >> (k if bit is None else bit)) & 1:
             yield
             return
         side = self._sides.get(k)
@@ -273,12 +277,34 @@ class VQVAEEngine:
                                             4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
                                         dtype=torch.uint8, device=dev)
         b["ws_enc_wgrad"] = torch.zeros(4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H), dtype=torch.uint8, device=dev)
+        # dedicated workspaces of the four recurrent launches: prepare_recurrent() fills them ahead of their kernels
+        for key, nbytes in (("ws_gruf", self.lib.g2v_gru_seq_fwd_workspace(2, H)), ("ws_grub", self.lib.g2v_gru_seq_bwd_workspace(2, H)),
+                            ("ws_decf", self.lib.g2v_dec_rollout_fwd_workspace(D, H)), ("ws_decb", self.lib.g2v_dec_rollout_bwd_workspace(D, H))):
+            b[key] = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
         self._bufs[B] = b
         return b
 
     # ------------------------------------------------------------------ pieces
     def _stream(self):
         return torch.cuda.current_stream().cuda_stream
+
+    def prepare_recurrent(self, B: int, which: str):
+        """Weight-fragment packs of the encoder GRU's backward (which == "gru_bwd") or of the decoder rollout forward /
+        backward plus the clearing of the rollout's two exchange regions (which == "dec"), into their dedicated workspaces
+        (g2v_gru_seq_prepare, g2v_dec_rollout_prepare).  Valid until the weights change: the fused train step calls both once
+        per step inside the branch that also draws the masks, and then uses the *_prepared entry points.  (The encoder GRU's
+        forward runs 40 us into the step: its pack stays in front of it.)"""
+        lib, st = self.lib, self._stream()
+        b = self.buffers(B)
+        if which == "gru_bwd":
+            enc = "encoder."
+            whh = (C.c_void_p * 2)(self._w(enc + "gru.weight_hh_l0"), self._w(enc + "gru.weight_hh_l0_reverse"))
+            wih = (C.c_void_p * 2)(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"))
+            check(lib.g2v_gru_seq_prepare(whh, wih, 2, self.H, int(self.H == 64), None, 0, _p(b["ws_grub"]),
+                                          b["ws_grub"].numel(), st))
+        else:
+            check(lib.g2v_dec_rollout_prepare(C.byref(self.dec_wstruct()), self.D, self.H, _p(b["ws_decf"]), b["ws_decf"].numel(),
+                                              _p(b["ws_decb"]), b["ws_decb"].numel(), st))
 
     def draw_masks(self, B: int, training: bool):
         b = self.buffers(B)
@@ -383,10 +409,11 @@ class VQVAEEngine:
         assert tuple(out_poses.shape) == (B, T, D), "shape does not match the engine"
         b = self.buffers(B)
         drop_in = training and self.p > 0
-        check(lib.g2v_dec_rollout_fwd(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
-                                      C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
-                                      _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
-                                      int(self.conditioned), int(training), T, B, D, H, _p(b["ws"]), b["ws"].numel(), st))
+        fn, ws = (lib.g2v_dec_rollout_fwd_prepared, b["ws_decf"]) if self._prepared else (lib.g2v_dec_rollout_fwd, b["ws"])
+        check(fn(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
+                 C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
+                 _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
+                 int(self.conditioned), int(training), T, B, D, H, _p(ws), ws.numel(), st))
         return b
 
     def vq_finish(self, B: int, training: bool, n_global: Optional[int] = None):
@@ -451,9 +478,10 @@ class VQVAEEngine:
         b = self.buffers(B)
         ws, wsn = _p(b["ws"]), b["ws"].numel()
         drop = self.p > 0
-        check(lib.g2v_dec_rollout_bwd(C.byref(self.dec_wstruct()), C.byref(b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
-                                      _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
-                                      T, B, D, H, ws, wsn, st))
+        fn, wsd = (lib.g2v_dec_rollout_bwd_prepared, b["ws_decb"]) if self._prepared else (lib.g2v_dec_rollout_bwd, b["ws"])
+        check(fn(C.byref(self.dec_wstruct()), C.byref(b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
+                 _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
+                 T, B, D, H, _p(wsd), wsd.numel(), st))
         pre = "decoder.decoder."
         M = (T - 1) * B
         x1 = b["x1"] if drop else b["h0"][1:]
@@ -495,10 +523,13 @@ class VQVAEEngine:
             dirs[k].w_ih = self._w(enc + "gru.weight_ih_l0" + suf)
             dirs[k].dx = _p(b["gi_" + key]) if H == 64 else None
             dirs[k].in_dim = H
-        check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
+        if self._prepared:
+            check(lib.g2v_gru_seq_bwd_prepared(dirs, 2, None, H, H, T, B, H, _p(b["ws_grub"]), b["ws_grub"].numel(), st))
+        else:
+            check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
-        with self._branch(3):       # beside the input layer's gradient below (joined there)
-            _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 3) & 1 else "ws")
+        with self._branch(4):       # beside the input layer's gradient below (joined there)
+            _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 4) & 1 else "ws")
             wgrad4s(TB, [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
                          (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
                          (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
@@ -511,7 +542,7 @@ class VQVAEEngine:
         wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
               row_map=(B, D, T * D), keep=_p(b["keep_in"]) if drop else None,
               scale=1.0 / (1.0 - self.p) if drop else 1.0)
-        self._join(3)
+        self._join(4)
         # encoder GRU layer 1 receives exactly-zero gradients (dead compute in the reference); the flat grad
         # buffer is zero there from construction and nothing ever writes it.
 
@@ -539,12 +570,22 @@ class VQVAEEngine:
                          epoch: int = 1, draw_masks: bool = True, dp: bool = False):
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
-        if draw_masks:
-            if self.p > 0:          # the encoder's own input mask is needed straight away
-                self.draw_masks(B, True)
-            else:                   # only the rollout consumes keep95: drawn beside the encoder forward, joined in forward()
-                with self._branch(0):
-                    self.draw_masks(B, True)
+        self._prepared = (self.overlap & 9) == 9 and self.quantizer == "ema"
+        try:
+            self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)
+        finally:
+            self._prepared = False
+
+    def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
+        if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
+            self.draw_masks(B, True)
+        if self._prepared or (draw_masks and self.p == 0):
+            with self._branch(0):              # beside the encoder forward, joined in forward() before the rollout
+                if draw_masks and self.p == 0:
+                    self.draw_masks(B, True)   # only the rollout consumes keep95
+                if self._prepared:
+                    self.prepare_recurrent(B, "dec")
+                    self.prepare_recurrent(B, "gru_bwd")
         self.forward(x, target, True, ema_update=not dp, trust_wsq=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)

@@ -210,6 +210,18 @@ size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragmen
 int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,
                     int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
+/* Ahead-of-time weight packs (the fused train step runs them as a parallel branch while the step's first kernels execute):
+ * g2v_gru_seq_prepare launches the fragment packs of ONE g2v_gru_seq_fwd + ONE g2v_gru_seq_bwd call of the H == 64 fast
+ * kernels into their two workspaces (w_hh / w_ih: one pointer per direction; fused != 0: the calls fuse the input projection /
+ * input gradient, so w_ih is packed too; either workspace may be NULL); the *_prepared entry points then skip their pack launch.
+ * Nothing else may touch the workspaces in between.  Other hidden sizes: prepare is a no-op and *_prepared == the plain call. */
+int g2v_gru_seq_prepare(const float* const* w_hh, const float* const* w_ih, int ndir, int H, int fused, void* fwd_workspace,
+                        size_t fwd_bytes, void* bwd_workspace, size_t bwd_bytes, g2v_stream_t stream);
+int g2v_gru_seq_fwd_prepared(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B, int H,
+                             void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+int g2v_gru_seq_bwd_prepared(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,
+                             int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Autoregressive pose-decoder rollout (K9).  Replaces the T-1 step loop
  * model/Autoencoder_VQVAE_model.py:1039-1054 over Generator.forward (:646-683) ->
@@ -279,6 +291,21 @@ int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const 
                         const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
                         int conditioned, int T, int B, int D, int H,
                         void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* The same for a rollout pair: the forward and backward fragment packs AND the clearing of the two exchange regions of the
+ * persistent kernels (everything of the pair that depends on the weights only), ahead of time; g2v_dec_rollout_fwd_prepared /
+ * _bwd_prepared then start with their first real kernel.  Honoured for H == 64, D == 135 (the fused kernels); other shapes:
+ * prepare is a no-op and *_prepared == the plain call.  bwd_workspace may be NULL (inference). */
+int g2v_dec_rollout_prepare(const g2v_dec_weights* w, int D, int H, void* fwd_workspace, size_t fwd_bytes,
+                            void* bwd_workspace, size_t bwd_bytes, g2v_stream_t stream);
+int g2v_dec_rollout_fwd_prepared(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
+                                 const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                                 int conditioned, int training, int T, int B, int D, int H, void* workspace,
+                                 size_t workspace_bytes, g2v_stream_t stream);
+int g2v_dec_rollout_bwd_prepared(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
+                                 const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
+                                 int conditioned, int T, int B, int D, int H, void* workspace, size_t workspace_bytes,
+                                 g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * custom_loss forward + gradient (K10), train_eval/train_seq2seq.py:40-88.

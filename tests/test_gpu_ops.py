@@ -133,9 +133,22 @@ def test_linear_fwd_rowmap_and_mask(ops):
     relclose(db, dy.sum(0), 5e-6, "bwd_bias")
 
 
+def test_linear_bwd_weight_ragged_rows_through_a_row_map(ops):
+    """The in_layer gradient of a ragged batch (T B % 16 != 0, x (B,T,D) read in (T,B) order): whole 16-row groups on the
+    wave-autonomous kernel, the leftover rows through the same row map on the small-M kernel."""
+    B, T, D, H = 129, 33, 135, 64
+    assert (T * B) % 16 == 1 and T * B >= 4112
+    x_btd, dy = rnd(B, T, D, seed=41), rnd(T * B, H, seed=42)
+    x_tbd = x_btd.transpose(0, 1).reshape(T * B, D)
+    dw, db = ops.linear_bwd_weight(dy.to(DEV), x_btd.to(DEV), H, D, M=T * B, row_map=(B, D, T * D))
+    relclose(dw, (dy.double().t() @ x_tbd.double()).float(), 1e-5, "ragged row-mapped weight gradient")
+    relclose(db, dy.double().sum(0).float(), 1e-5, "ragged row-mapped bias gradient")
+
+
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
                                    (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514),      # output-blocked wave kernel
-                                   (128, 200, 600), (130, 600, 200), (16, 64, 514), (1024, 200, 600), (1000, 64, 2100)])   # small-M data gradient
+                                   (128, 200, 600), (130, 600, 200), (16, 64, 514), (1024, 200, 600), (1000, 64, 2100),   # small-M data gradient
+                                   (8192 + 5, 64, 192), (33 * 4100 // 4, 135, 64), (4096 + 31, 200, 600)])   # ragged rows: whole groups + leftover
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
     dx = ops.linear_bwd_data(dy.to(DEV), w.to(DEV))
