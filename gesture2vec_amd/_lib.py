@@ -77,6 +77,8 @@ _SIGS = {
     "g2v_gru_seq_fwd": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_gru_seq_bwd": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_gru_cell_fwd": (c_int, [c_fp, c_int, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_gru_cell_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_gru_seq_prepare": (c_int, [c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_fwd_prepared": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_prepared": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),

@@ -440,6 +440,155 @@ __global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB 
 }
 
 
+// ---- one GRU CELL step at small batch, input projection included (the code decoder of Part d: T = 1 per call) --------------
+// g2v_gru_seq_fwd with T = 1 needs gi = x W_ih^T + b_ih from a dense-layer launch first; here a workgroup of TWO waves owns a
+// (16 rows x 16 hidden units) tile: wave 0 multiplies the input side (x, W_ih), wave 1 the hidden side (h_prev, W_hh), each with
+// its whole operand set requested up front as MFMA fragments (one memory round trip for both), wave 1 hands its three
+// accumulators over through LDS and wave 0 finishes the gates.  Same arithmetic as g2v_linear_fwd + gru_step_fwd_kernel
+// (gates bit-identical; h_new within half an ulp: the compiler contracts the final blend differently in the two kernels).  in_dim, H <= 256, multiples of 4; x_keep: dropout on the layer input (nn.GRU's).
+__global__ __launch_bounds__(128) void gru_cell_fwd_kernel(const float* __restrict__ x, int in_dim,
+                                                           const uint8_t* __restrict__ x_keep, float x_scale,
+                                                           const float* __restrict__ h_prev, const float* __restrict__ w_ih,
+                                                           const float* __restrict__ w_hh, const float* __restrict__ b_ih,
+                                                           const float* __restrict__ b_hh, float* __restrict__ h_new,
+                                                           float* __restrict__ gates, int B, int H) {
+  __shared__ __attribute__((aligned(16))) float hand[3][256];
+  const int lane = threadIdx.x & 63, side = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, ft = blockIdx.y;
+  const int nrows = min(16, B - b0);
+  const int C = side == 0 ? in_dim : H;
+  const float* __restrict__ W = side == 0 ? w_ih : w_hh;
+  const float* __restrict__ src = side == 0 ? x : h_prev;
+  const int nks = (C + 15) >> 4;
+  const bool wrow_ok = 16 * ft + i < H, xrow_ok = i < nrows;
+  const float* wr = W + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * C;
+  const float* xr = src + (int64_t)(b0 + (xrow_ok ? i : 0)) * C;
+  const uint8_t* kr = (side == 0 && x_keep) ? x_keep + (int64_t)(b0 + (xrow_ok ? i : 0)) * C : nullptr;
+  float4 wa[3][GRU_STEP_KS], xb[GRU_STEP_KS];
+  uint32_t kp[GRU_STEP_KS];
+#pragma unroll
+  for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < C;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wa[g][ks] = ld4_or_zero(wr + (int64_t)g * H * C + (kok ? k : 0), kok && wrow_ok);
+    xb[ks] = ld4_or_zero(xr + (kok ? k : 0), kok && xrow_ok);
+    kp[ks] = (kr && kok) ? *reinterpret_cast<const uint32_t*>(kr + k) : 0x01010101u;
+  }
+  const int b = b0 + i, f0 = 16 * ft + 4 * q;
+  const bool rvalid = i < nrows, fok = f0 < H;             // H % 4 == 0: whole float4 or nothing
+  float4 bi4[3], bh4[3], hp4;
+  if (side == 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      bi4[g] = ld4_or_zero(b_ih + g * H + (fok ? f0 : 0), fok);
+      bh4[g] = ld4_or_zero(b_hh + g * H + (fok ? f0 : 0), fok);
+    }
+    hp4 = ld4_or_zero(h_prev + (int64_t)(rvalid ? b : b0) * H + (fok ? f0 : 0), fok && rvalid);
+  }
+  f32x4 acc[3];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+    if (ks < nks) {
+      float4 xv = xb[ks];
+      if (side == 0 && x_keep) {
+        xv.x = (kp[ks] & 0xffu) ? xv.x * x_scale : 0.f;
+        xv.y = (kp[ks] & 0xff00u) ? xv.y * x_scale : 0.f;
+        xv.z = (kp[ks] & 0xff0000u) ? xv.z * x_scale : 0.f;
+        xv.w = (kp[ks] & 0xff000000u) ? xv.w * x_scale : 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        acc[g] = mfma16(wa[g][ks].x, xv.x, acc[g]);
+        acc[g] = mfma16(wa[g][ks].y, xv.y, acc[g]);
+        acc[g] = mfma16(wa[g][ks].z, xv.z, acc[g]);
+        acc[g] = mfma16(wa[g][ks].w, xv.w, acc[g]);
+      }
+    }
+  }
+  if (side == 1) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) *reinterpret_cast<float4*>(&hand[g][lane * 4]) = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+  }
+  __syncthreads();
+  if (side == 1 || !rvalid || !fok) return;
+  float ah[3][4];
+#pragma unroll
+  for (int g = 0; g < 3; ++g) {
+    const float4 v = *reinterpret_cast<const float4*>(&hand[g][lane * 4]);
+    ah[g][0] = v.x; ah[g][1] = v.y; ah[g][2] = v.z; ah[g][3] = v.w;
+  }
+  const float bi_[3][4] = {{bi4[0].x, bi4[0].y, bi4[0].z, bi4[0].w}, {bi4[1].x, bi4[1].y, bi4[1].z, bi4[1].w},
+                           {bi4[2].x, bi4[2].y, bi4[2].z, bi4[2].w}};
+  const float bh_[3][4] = {{bh4[0].x, bh4[0].y, bh4[0].z, bh4[0].w}, {bh4[1].x, bh4[1].y, bh4[1].z, bh4[1].w},
+                           {bh4[2].x, bh4[2].y, bh4[2].z, bh4[2].w}};
+  const float hp_[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+  float hn[4], gr[4], gz[4], gn[4], gh[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    gr[r] = sigmoidf_((acc[0][r] + bi_[0][r]) + (ah[0][r] + bh_[0][r]));
+    gz[r] = sigmoidf_((acc[1][r] + bi_[1][r]) + (ah[1][r] + bh_[1][r]));
+    gh[r] = ah[2][r] + bh_[2][r];
+    gn[r] = tanhf_(__fmaf_rn(gr[r], gh[r], acc[2][r] + bi_[2][r]));      // fused like gi_n + r * gh_n in gru_step_fwd_kernel
+    hn[r] = (1.0f - gz[r]) * gn[r] + gz[r] * hp_[r];
+  }
+  *reinterpret_cast<float4*>(h_new + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+  if (gates) {
+    float* go = gates + (int64_t)b * 4 * H + f0;
+    *reinterpret_cast<float4*>(go) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+    *reinterpret_cast<float4*>(go + H) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+    *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn[0], gn[1], gn[2], gn[3]);
+    *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+  }
+}
+
+// Backward of the cell, element-wise half: from d_h = d_h_a + d_h_b (gradient arriving at h_new: from above and from the next
+// step) the gate gradients dgi = (dr, dz, dn), dgh = (dr, dz, dn * r) and the direct path d_h * z (the base of d_hprev);
+// the two products d_hprev += dgh W_hh and dx = dgi W_ih follow in ONE launch of the dense small-M kernel (linear.hip).
+__global__ __launch_bounds__(256) void gru_cell_gates_bwd_kernel(const float* __restrict__ d_h_a, const float* __restrict__ d_h_b,
+                                                                 const float* __restrict__ gates, const float* __restrict__ h_prev,
+                                                                 float* __restrict__ dgi, float* __restrict__ dgh,
+                                                                 float* __restrict__ direct, int B, int H) {
+  const int H4 = H >> 2;
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= B * H4) return;
+  const int b = e / H4, f0 = 4 * (e - b * H4);
+  const float* go = gates + (int64_t)b * 4 * H + f0;
+  const float4 r4 = *reinterpret_cast<const float4*>(go), z4 = *reinterpret_cast<const float4*>(go + H);
+  const float4 n4 = *reinterpret_cast<const float4*>(go + 2 * H), g4 = *reinterpret_cast<const float4*>(go + 3 * H);
+  const float4 hp = *reinterpret_cast<const float4*>(h_prev + (int64_t)b * H + f0);
+  float4 da = make_float4(0.f, 0.f, 0.f, 0.f), db = da;
+  if (d_h_a) da = *reinterpret_cast<const float4*>(d_h_a + (int64_t)b * H + f0);
+  if (d_h_b) db = *reinterpret_cast<const float4*>(d_h_b + (int64_t)b * H + f0);
+  const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w};
+  const float gh[4] = {g4.x, g4.y, g4.z, g4.w}, hp_[4] = {hp.x, hp.y, hp.z, hp.w};
+  const float d0[4] = {da.x, da.y, da.z, da.w}, d1[4] = {db.x, db.y, db.z, db.w};
+  float g_r[4], g_z[4], g_n[4], g_hn[4], dir[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float dht = d1[r] + d0[r];                    // carry + gradient from above (the order of gru_step_bwd_kernel)
+    const float dn = dht * (1.0f - zz[r]);
+    const float dz = dht * (hp_[r] - nn[r]);
+    const float dnp = dn * (1.0f - nn[r] * nn[r]);
+    g_n[r] = dnp;
+    g_hn[r] = dnp * rr[r];
+    g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+    g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+    dir[r] = dht * zz[r];
+  }
+  float* gi_o = dgi + (int64_t)b * 3 * H + f0;
+  float* gh_o = dgh + (int64_t)b * 3 * H + f0;
+  *reinterpret_cast<float4*>(gi_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+  *reinterpret_cast<float4*>(gi_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+  *reinterpret_cast<float4*>(gi_o + 2 * H) = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]);
+  *reinterpret_cast<float4*>(gh_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+  *reinterpret_cast<float4*>(gh_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+  *reinterpret_cast<float4*>(gh_o + 2 * H) = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+  *reinterpret_cast<float4*>(direct + (int64_t)b * H + f0) = make_float4(dir[0], dir[1], dir[2], dir[3]);
+}
+
 // =====================================================================================================
 // Fast path, H == 64 (the BASELINE shape): dims are compile-time, each wave owns ONE 16-feature tile whose
 // W_hh fragments (3 gates x 4 k-steps x float4 = 48 VGPRs) stay in registers for the whole sequence, the gi
@@ -759,6 +908,52 @@ static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 
 extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
   const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H), b = gru_split_state_floats(ndir, H);
   return (a > b ? a : b) * sizeof(float);
+}
+
+int g2v_internal_cell_bwd_products(const float* dgh, const float* w_hh, float* d_hprev, int H, const float* dgi,
+                                   const float* w_ih, float* dx, int in_dim, const uint8_t* x_keep, float x_scale, int B,
+                                   hipStream_t st);      // linear.hip
+
+static bool cell_shape_ok(int in_dim, int H) { return (in_dim & 3) == 0 && (H & 3) == 0 && in_dim <= 16 * GRU_STEP_KS && H <= 16 * GRU_STEP_KS; }
+
+extern "C" int g2v_gru_cell_fwd(const float* x, int in_dim, const uint8_t* x_keep, float x_scale, const float* h_prev,
+                                const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, float* h_new,
+                                float* gates, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(x && h_prev && w_ih && w_hh && b_ih && b_hh && h_new, "null pointer");
+  G2V_REQUIRE(B > 0 && H > 0 && in_dim > 0, "bad size");
+  if (!cell_shape_ok(in_dim, H) || !(aligned16(x) && aligned16(h_prev) && aligned16(w_ih) && aligned16(w_hh) && aligned16(b_ih) &&
+                                     aligned16(b_hh) && aligned16(h_new) && aligned16(gates) &&
+                                     (reinterpret_cast<uintptr_t>(x_keep) & 3) == 0)) {
+    set_error("g2v_gru_cell_fwd: needs in_dim, H multiples of 4 and <= 256, 16-byte aligned operands (use g2v_linear_fwd + g2v_gru_seq_fwd)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3(cdiv(B, 16), cdiv(H, 16)), dim3(128), 0, (hipStream_t)stream, x, in_dim, x_keep,
+                     x_scale, h_prev, w_ih, w_hh, b_ih, b_hh, h_new, gates, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_gru_cell_bwd(const float* d_h_a, const float* d_h_b, const float* gates, const float* h_prev,
+                                const float* w_ih, const float* w_hh, const uint8_t* x_keep, float x_scale, float* dgi,
+                                float* dgh, float* d_hprev, float* dx, int in_dim, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(gates && h_prev && w_hh && dgi && dgh && d_hprev, "null pointer");
+  G2V_REQUIRE(d_h_a || d_h_b, "no incoming gradient");
+  G2V_REQUIRE(!dx || w_ih, "dx needs w_ih");
+  G2V_REQUIRE(B > 0 && H > 0 && in_dim > 0, "bad size");
+  if (!cell_shape_ok(in_dim, H) || !(aligned16(d_h_a) && aligned16(d_h_b) && aligned16(gates) && aligned16(h_prev) && aligned16(w_ih) &&
+                                     aligned16(w_hh) && aligned16(dgi) && aligned16(dgh) && aligned16(d_hprev) && aligned16(dx))) {
+    set_error("g2v_gru_cell_bwd: needs in_dim, H multiples of 4 and <= 256, 16-byte aligned operands (use g2v_gru_seq_bwd + g2v_linear_bwd_data)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(gru_cell_gates_bwd_kernel, dim3(cdiv((int64_t)B * (H >> 2), 256)), dim3(256), 0, st, d_h_a, d_h_b, gates, h_prev,
+                     dgi, dgh, d_hprev, B, H);
+  G2V_CHECK_LAUNCH();
+  if (g2v_internal_cell_bwd_products(dgh, w_hh, d_hprev, H, dgi, w_ih, dx, in_dim, x_keep, x_scale, B, st) != 0) {
+    set_error("g2v_gru_cell_bwd: launch failed");
+    return G2V_ERR_LAUNCH;
+  }
+  return G2V_OK;
 }
 
 // fragment packs of the H == 64 fast kernels, in workspace order: per direction W_hh (, W_ih when the projection is fused)

@@ -295,16 +295,17 @@ __global__ __launch_bounds__(256) void gemm_nt_stream_kernel(const float* __rest
 // contraction elements of A row m0 + i and of weight row n0 + i per 16-wide block -- with the next chunk's loads issued
 // before the current chunk's MFMAs.  TRANS_B (data gradient, contraction along the rows of w): dword loads of w.
 // Requirements: contraction length % 4 == 0, 16-byte aligned rows; identity / ReLU / tanh epilogue, optional keep mask on A.
+// out_keep (uint8, [m * N + n], may be NULL): the OUTPUT is multiplied by keep * out_scale (dropout on the quantity whose
+// gradient this is: dx = (dgi W_ih) * keep * scale).
 template <bool TRANS_B, bool KEEP, int TN, int NB>      // wave tile: 16 rows x 16 TN columns; NB blocks of 16 contraction elements per chunk
-__global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restrict__ A, int64_t lda,
-                                                          const uint8_t* __restrict__ keep, float scale,
-                                                          const float* __restrict__ Bm, int64_t ldb,
-                                                          const float* __restrict__ bias, float* __restrict__ Cout,
-                                                          int64_t ldc, int M, int C, int N, int act, int accumulate) {
+__device__ __forceinline__ void smallm_body(const float* __restrict__ A, int64_t lda, const uint8_t* __restrict__ keep,
+                                            float scale, const float* __restrict__ Bm, int64_t ldb,
+                                            const float* __restrict__ bias, float* __restrict__ Cout, int64_t ldc, int M, int C,
+                                            int N, int act, int accumulate, int tile, const uint8_t* __restrict__ out_keep,
+                                            float out_scale) {
   constexpr int CH = 16 * NB;
   const int lane = threadIdx.x & 63, i = lane & 15, q = lane >> 4;
   const int tiles_n = (N + 16 * TN - 1) / (16 * TN);
-  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
   // consecutive waves share the A rows (same mt) and walk the weight rows: the 4 waves of a workgroup re-use A through L1/L2
   const int mt = tile / tiles_n, nt = tile - mt * tiles_n;
   if (mt * 16 >= M) return;
@@ -385,10 +386,38 @@ __global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restric
         float v = acc[t][r] + (bias ? bias[no + r] : 0.f);
         if (act == 1) v = v > 0.f ? v : 0.f;
         else if (act == 2) v = tanhf(v);
+        if (out_keep) v = out_keep[(int64_t)m * N + no + r] ? v * out_scale : 0.f;
         out[r] = accumulate ? out[r] + v : v;
       }
     }
   }
+}
+
+template <bool TRANS_B, bool KEEP, int TN, int NB>
+__global__ __launch_bounds__(256) void gemm_smallm_kernel(const float* __restrict__ A, int64_t lda,
+                                                          const uint8_t* __restrict__ keep, float scale,
+                                                          const float* __restrict__ Bm, int64_t ldb,
+                                                          const float* __restrict__ bias, float* __restrict__ Cout,
+                                                          int64_t ldc, int M, int C, int N, int act, int accumulate) {
+  smallm_body<TRANS_B, KEEP, TN, NB>(A, lda, keep, scale, Bm, ldb, bias, Cout, ldc, M, C, N, act, accumulate,
+                                     blockIdx.x * 4 + (threadIdx.x >> 6), nullptr, 1.0f);
+}
+
+// Two data-gradient products in one launch (blockIdx.y): out_p (+)= A_p W_p with W_p (C x N_p) row-major, contraction over
+// its rows -- the backward of a GRU cell: d_hprev += dgh W_hh and dx = (dgi W_ih) * keep * scale (g2v_gru_cell_bwd).
+struct DualTrans {
+  const float* A[2];
+  const float* W[2];
+  float* out[2];
+  int N[2];
+  int accumulate[2];
+  const uint8_t* out_keep[2];
+  float out_scale[2];
+};
+__global__ __launch_bounds__(256) void gemm_smallm_dual_kernel(DualTrans d, int M, int C) {
+  const int p = blockIdx.y;
+  smallm_body<true, false, 1, 8>(d.A[p], (int64_t)C, nullptr, 1.0f, d.W[p], (int64_t)d.N[p], nullptr, d.out[p], (int64_t)d.N[p], M, C,
+                                 d.N[p], 0, d.accumulate[p], blockIdx.x * 4 + (threadIdx.x >> 6), d.out_keep[p], d.out_scale[p]);
 }
 
 // measured (gpurun_tools/gemm_bench.py, 200..400 -> 200..600): forward 9.7 vs 10.4 us and data gradient 11 vs 22 us at 128..640
@@ -426,6 +455,22 @@ static bool launch_smallm(bool trans_b, const float* A, int64_t lda, const uint8
 #undef G2V_SMALLM
   return true;
 }
+
+}  // namespace g2v
+// used by g2v_gru_cell_bwd (gru.hip): d_hprev (B,H) += dgh W_hh, dx (B,in_dim) = (dgi W_ih) * keep * scale; C = 3H
+int g2v_internal_cell_bwd_products(const float* dgh, const float* w_hh, float* d_hprev, int H, const float* dgi,
+                                   const float* w_ih, float* dx, int in_dim, const uint8_t* x_keep, float x_scale, int B,
+                                   hipStream_t st) {
+  using namespace g2v;
+  DualTrans d;
+  d.A[0] = dgh; d.W[0] = w_hh; d.out[0] = d_hprev; d.N[0] = H; d.accumulate[0] = 1; d.out_keep[0] = nullptr; d.out_scale[0] = 1.0f;
+  d.A[1] = dgi; d.W[1] = w_ih; d.out[1] = dx; d.N[1] = in_dim; d.accumulate[1] = 0; d.out_keep[1] = x_keep; d.out_scale[1] = x_scale;
+  const int nprob = dx ? 2 : 1;
+  const int tmax = cdiv(B, 16) * cdiv(nprob == 2 && in_dim > H ? in_dim : H, 16);
+  hipLaunchKernelGGL(gemm_smallm_dual_kernel, dim3(cdiv(tmax, 4), nprob), dim3(256), 0, st, d, B, 3 * H);
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+namespace g2v {
 
 template <bool TRANS_B>
 static bool launch_stream(const float* A, int64_t lda, const float* Bm, int64_t ldb, const float* bias, float* Cout,

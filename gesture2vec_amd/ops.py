@@ -269,6 +269,30 @@ def gru_seq_bwd(d_hs, d_hs_ld, d_hn, hs, hs_ld, h0, gates, w_hh, T, B, H, *, len
     return dgi, dgh, dh0
 
 
+def gru_cell_ok(in_dim, H, B):
+    """shapes served by the one-launch GRU cell (small batch, generic hidden size)"""
+    return in_dim % 4 == 0 and H % 4 == 0 and in_dim <= 256 and H <= 256 and B <= 1024
+
+
+def gru_cell_fwd(x, h_prev, w_ih, w_hh, b_ih, b_hh, *, keep=None, scale=1.0, h_new=None, gates=None):
+    """One GRU cell step incl. its input projection (g2v_gru_cell_fwd): x (B,in), h_prev (B,H) -> h_new (B,H), gates (B,4H)."""
+    B, in_dim = x.shape
+    H = h_prev.shape[1]
+    if h_new is None:
+        h_new = torch.empty((B, H), dtype=torch.float32, device=x.device)
+    check(_lib_().g2v_gru_cell_fwd(_p(_chk(x)), in_dim, _p(keep), float(scale), _p(_chk(h_prev)), _p(_chk(w_ih)), _p(_chk(w_hh)),
+                                   _p(b_ih), _p(b_hh), _p(h_new), _p(gates), B, H, _stream()), "gru_cell_fwd")
+    return h_new
+
+
+def gru_cell_bwd(d_h_a, d_h_b, gates, h_prev, w_ih, w_hh, *, keep=None, scale=1.0, dgi, dgh, d_hprev, dx=None):
+    """Backward of gru_cell_fwd (g2v_gru_cell_bwd): fills dgi, dgh (B,3H), d_hprev (B,H), dx (B,in) [masked by keep * scale]."""
+    B, H = h_prev.shape
+    in_dim = w_ih.shape[1]
+    check(_lib_().g2v_gru_cell_bwd(_p(d_h_a), _p(d_h_b), _p(_chk(gates)), _p(_chk(h_prev)), _p(_chk(w_ih)), _p(_chk(w_hh)), _p(keep),
+                                   float(scale), _p(dgi), _p(dgh), _p(d_hprev), _p(dx), in_dim, B, H, _stream()), "gru_cell_bwd")
+
+
 # ------------------------------------------------------------------------------------------ decoder rollout
 def dec_weights_struct(wd: dict) -> DecWeights:
     s = DecWeights()

@@ -74,6 +74,7 @@ class CodeDecoderRollout(torch.autograd.Function):
         Hs = [f32(S1 + 1, B, H) for _ in range(L)]
         GATES = [f32(S1, B, 4 * H) for _ in range(L)]
         GI, HN = f32(B, 3 * H), f32(B, H)
+        cell = ops.gru_cell_ok(H, H, B)
         LOG = f32(S1, B, K)
         for l in range(L):
             Hs[l][0].copy_(hidden0[l])
@@ -97,9 +98,13 @@ class CodeDecoderRollout(torch.autograd.Function):
                               save=(SM[t], SI[t]))
             layer_in, keep, scale = A[t], None, 1.0
             for l, (w_ih, w_hh, b_ih, b_hh) in enumerate(gru):
-                ops.linear_fwd(layer_in, w_ih, b_ih, keep=keep, scale=scale, out=GI)
-                ops.gru_dirs_fwd([dict(gi=GI, w_hh=w_hh, b_hh=b_hh, h0=Hs[l][t], hs=Hs[l][t + 1], h_n=HN, gates=GATES[l][t],
-                                       reverse=False)], 1, B, H)
+                if cell:        # small batch: input projection + cell in one launch
+                    ops.gru_cell_fwd(layer_in, Hs[l][t], w_ih, w_hh, b_ih, b_hh, keep=keep, scale=scale, h_new=Hs[l][t + 1],
+                                     gates=GATES[l][t])
+                else:
+                    ops.linear_fwd(layer_in, w_ih, b_ih, keep=keep, scale=scale, out=GI)
+                    ops.gru_dirs_fwd([dict(gi=GI, w_hh=w_hh, b_hh=b_hh, h0=Hs[l][t], hs=Hs[l][t + 1], h_n=HN, gates=GATES[l][t],
+                                           reverse=False)], 1, B, H)
                 layer_in = Hs[l][t + 1]
                 if drop:
                     keep, scale = mask_l0[t], scale_l0                   # nn.GRU inter-layer dropout, fused into the next Linear
@@ -107,7 +112,7 @@ class CodeDecoderRollout(torch.autograd.Function):
             if t + 1 < S1 and t + 1 >= npre:
                 ops.argmax_rows(LOG[t], out=ids[t + 1])                  # greedy feedback (:740)
         ctx.save_for_backward(hidden0, enc_out, *params)
-        ctx.spec, ctx.dims = spec, (S1, B, H, K, Hin, L)
+        ctx.spec, ctx.dims, ctx.cell = spec, (S1, B, H, K, Hin, L), cell
         ctx.bufs = dict(ids=ids, EC=EC, U=U, A=A, SM=SM, SI=SI, Hs=Hs, GATES=GATES, mask_emb=mask_emb, mask_l0=mask_l0,
                         scale_l0=scale_l0, emb_w=emb_w, pre_w=pre_w, out_w=out_w, gru=gru)
         if att:
@@ -143,12 +148,17 @@ class CodeDecoderRollout(torch.autograd.Function):
             d_in = DH_top[t]                                             # gradient arriving at Hs[l][t+1] from above
             for l in reversed(range(L)):
                 w_ih, w_hh = gru[l][0], gru[l][1]
-                ops.gru_dirs_bwd([dict(d_hs=d_in, d_hn=carry[l], hs=Hs[l][t + 1], h0=Hs[l][t], gates=GATES[l][t], w_hh=w_hh,
-                                       dgi=DGI[l][t], dgh=DGH[l][t], dh0=carry_next[l], reverse=False)], 1, B, H)
-                ops.linear_bwd_data(DGI[l][t], w_ih, out=DXs[l])
-                if l > 0:
-                    if drop:
+                if ctx.cell:    # gate gradients, then d_hprev += dgh W_hh and dx = (dgi W_ih) * mask in one launch
+                    ops.gru_cell_bwd(d_in, carry[l], GATES[l][t], Hs[l][t], w_ih, w_hh,
+                                     keep=b["mask_l0"][t] if (drop and l > 0) else None, scale=b["scale_l0"] if l > 0 else 1.0,
+                                     dgi=DGI[l][t], dgh=DGH[l][t], d_hprev=carry_next[l], dx=DXs[l])
+                else:
+                    ops.gru_dirs_bwd([dict(d_hs=d_in, d_hn=carry[l], hs=Hs[l][t + 1], h0=Hs[l][t], gates=GATES[l][t], w_hh=w_hh,
+                                           dgi=DGI[l][t], dgh=DGH[l][t], dh0=carry_next[l], reverse=False)], 1, B, H)
+                    ops.linear_bwd_data(DGI[l][t], w_ih, out=DXs[l])
+                    if l > 0 and drop:
                         ops.mask_mul(DXs[l], b["mask_l0"][t], b["scale_l0"], out=DXs[l])
+                if l > 0:
                     d_in = DXs[l]
             ops.batchnorm_bwd(DXs[0], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
             if att:

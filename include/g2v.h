@@ -210,6 +210,22 @@ size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragmen
 int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,
                     int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 
+/* ONE GRU cell step at small batch with the input projection included (nn.GRU cell, the code decoder of Part d,
+ * model/text2embedding_model.py:372-380, where every call is one time step):
+ *   gi = (x * x_keep * x_scale) W_ih^T + b_ih,  gh = h_prev W_hh^T + b_hh,  r, z, n as in g2v_gru_seq_fwd,  h_new = (1-z) n + z h_prev
+ *   gates (B,4H) = r, z, n, gh_n saved for the backward (NULL = inference).  x_keep (uint8 (B,in_dim), may be NULL): the
+ *   inter-layer dropout of nn.GRU on this layer's input.  One launch instead of g2v_linear_fwd + g2v_gru_seq_fwd(T = 1), same
+ *   contraction order (gates bit-identical, h_new within an ulp).  in_dim, H multiples of 4 and <= 256.
+ * g2v_gru_cell_bwd: d_h = d_h_a + d_h_b (gradient arriving at h_new from above / from the next step; either may be NULL) ->
+ *   dgi, dgh (B,3H), d_hprev (B,H) = d_h z + dgh W_hh, dx (B,in_dim) = (dgi W_ih) * x_keep * x_scale (dx may be NULL).
+ *   Two launches (gate gradients; both products) instead of four. */
+int g2v_gru_cell_fwd(const float* x, int in_dim, const uint8_t* x_keep, float x_scale, const float* h_prev, const float* w_ih,
+                     const float* w_hh, const float* b_ih, const float* b_hh, float* h_new, float* gates, int B, int H,
+                     g2v_stream_t stream);
+int g2v_gru_cell_bwd(const float* d_h_a, const float* d_h_b, const float* gates, const float* h_prev, const float* w_ih,
+                     const float* w_hh, const uint8_t* x_keep, float x_scale, float* dgi, float* dgh, float* d_hprev, float* dx,
+                     int in_dim, int B, int H, g2v_stream_t stream);
+
 /* Ahead-of-time weight packs (the fused train step runs them as a parallel branch while the step's first kernels execute):
  * g2v_gru_seq_prepare launches the fragment packs of ONE g2v_gru_seq_fwd + ONE g2v_gru_seq_bwd call of the H == 64 fast
  * kernels into their two workspaces (w_hh / w_ih: one pointer per direction; fused != 0: the calls fuse the input projection /

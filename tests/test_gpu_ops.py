@@ -748,6 +748,48 @@ def test_embedding_fwd_bwd(ops, V, dim, n, pattern):
     relclose(ops.embedding_bwd(g.to(DEV), bad.to(DEV), V, keep.to(DEV), 2.0), ref_bad.float(), 2e-6, "embedding grad, bad ids")
 
 
+@pytest.mark.parametrize("B,IN,H,p", [(128, 200, 200, 0.2), (24, 48, 48, 0.0), (7, 132, 64, 0.5), (130, 200, 200, 0.0)])
+def test_gru_cell_step_matches_the_two_launch_route(B, IN, H, p):
+    """g2v_gru_cell_fwd / _bwd (input projection + cell in one launch; gate gradients + both products in two) against
+    g2v_linear_fwd + g2v_gru_seq_fwd(T = 1) and g2v_gru_seq_bwd + g2v_linear_bwd_data + mask: gates bitwise equal (same
+    contraction order), the rest to rounding; and against the oracle's cell."""
+    from gesture2vec_amd import ops
+    from oracle import g2v_oracle as O
+    g = torch.Generator().manual_seed(17)
+    x, h = torch.randn(B, IN, generator=g), torch.randn(B, H, generator=g) * 0.5
+    w_ih, w_hh = torch.randn(3 * H, IN, generator=g) * 0.1, torch.randn(3 * H, H, generator=g) * 0.1
+    b_ih, b_hh = torch.randn(3 * H, generator=g) * 0.1, torch.randn(3 * H, generator=g) * 0.1
+    keep = (torch.rand(B, IN, generator=g) < 1 - p).to(torch.uint8) if p > 0 else None
+    scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    d = lambda t: t.to(DEV) if t is not None else None
+    xd, hd, wi, wh, bi, bh, kd = map(d, (x, h, w_ih, w_hh, b_ih, b_hh, keep))
+    gates = torch.empty(B, 4 * H, device=DEV)
+    h_new = ops.gru_cell_fwd(xd, hd, wi, wh, bi, bh, keep=kd, scale=scale, gates=gates)
+    gi = ops.linear_fwd(xd, wi, bi, keep=kd, scale=scale)
+    hs2, hn2, gates2 = ops.gru_seq_fwd(gi.view(1, B, 3 * H), wh, bh, 1, B, H, h0=hd)
+    assert torch.equal(gates, gates2.view(B, 4 * H))            # same contraction order, same gate arithmetic
+    relclose(h_new, hn2, 3e-7, "h_new vs the two-launch route")   # the final blend is contracted differently: <= 1 ulp
+    xin = x * keep * scale if keep is not None else x
+    relclose(h_new, O.gru_cell(O.linear(xin, w_ih, b_ih), h, w_hh, b_hh), 2e-6, "cell vs oracle")
+    da, db_ = torch.randn(B, H, generator=g).to(DEV), torch.randn(B, H, generator=g).to(DEV)
+    dgi, dgh = torch.empty(B, 3 * H, device=DEV), torch.empty(B, 3 * H, device=DEV)
+    dhp, dx = torch.empty(B, H, device=DEV), torch.empty(B, IN, device=DEV)
+    ops.gru_cell_bwd(da, db_, gates, hd, wi, wh, keep=kd, scale=scale, dgi=dgi, dgh=dgh, d_hprev=dhp, dx=dx)
+    dgi2, dgh2, dh02 = ops.gru_seq_bwd(da.view(1, B, H), H, db_, hs2, H, hd, gates2, wh, 1, B, H, want_dh0=True)
+    dx2 = ops.linear_bwd_data(dgi2.view(B, 3 * H), wi)
+    if keep is not None:
+        dx2 = ops.mask_mul(dx2, kd, scale)
+    relclose(dgi, dgi2.view(B, 3 * H), 2e-6, "dgi")
+    relclose(dgh, dgh2.view(B, 3 * H), 2e-6, "dgh")
+    relclose(dhp, dh02, 2e-6, "d h_prev")
+    relclose(dx, dx2, 2e-6, "d x")
+    # only one incoming gradient; no dx
+    ops.gru_cell_bwd(da, None, gates, hd, wi, wh, dgi=dgi, dgh=dgh, d_hprev=dhp, dx=None)
+    dgi3, dgh3, dh03 = ops.gru_seq_bwd(da.view(1, B, H), H, None, hs2, H, hd, gates2, wh, 1, B, H, want_dh0=True)
+    relclose(dgi, dgi3.view(B, 3 * H), 2e-6, "dgi, single gradient")
+    relclose(dhp, dh03, 2e-6, "d h_prev, single gradient")
+
+
 def test_gru_fused_input_projection_matches_unfused():
     """g2v_gru_seq_fwd with gi == NULL (projection fused into the recurrent kernel) vs the two-kernel route and the
     oracle; both directions, ragged batch, packed lengths."""
