@@ -478,52 +478,62 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 // ---- Bahdanau attention of the code decoder (model/text2embedding_model.py:160-198, 353-359) -------------------------
 // energy[t,b,:] = tanh(attn([h_b ; enc[t,b,:]])) is split as tanh(hp[b,:] + ep[t,b,:]) with hp = W_h h + bias (one small
 // product per decode step) and ep = enc W_e^T (ONE product per sentence batch, shared by all decode steps).
-// One wave per batch row; lane f owns features f, f+64, ...; the T scores live in LDS.  Softmax runs over ALL T
-// positions (the reference does not mask padded positions; their encoder rows are zero).
+// One WORKGROUP per batch row (round 1: one wave per row -- 128 waves on the whole chip at B = 128, each walking T serially
+// through dependent wave reductions: 32 / 79 us per call): the four waves split the T positions for the score / d_w dot products
+// (four positions in flight per wave), the softmax runs redundantly in every wave, and the feature loops run one thread per
+// feature with the T loads independent.  tanh on the hardware exp / rcp like every other gate of the library.  Softmax runs
+// over ALL T positions (the reference does not mask padded positions; their encoder rows are zero).
 __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ ep,
                                                        const float* __restrict__ enc, const float* __restrict__ v,
                                                        float* __restrict__ weights, float* __restrict__ ctx,
                                                        int64_t ldctx, int T, int B, int H) {
-  extern __shared__ float smem[];                     // [4 waves][T] scores / weights
+  extern __shared__ float smem[];                     // [T] scores / weights
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= B) return;
-  float* sc = smem + wave * T;
-  for (int t = 0; t < T; ++t) {
-    const float* er = ep + ((int64_t)t * B + b) * H;
-    float acc = 0.f;
-    for (int f = lane; f < H; f += 64) acc += v[f] * tanhf(hp[(int64_t)b * H + f] + er[f]);
-    acc = wave_sum(acc);
-    if (lane == 0) sc[t] = acc;
+  const int b = blockIdx.x;
+  float* sc = smem;
+  const float* hpr = hp + (int64_t)b * H;
+  for (int t0 = wave * 4; t0 < T; t0 += 16) {         // positions t0 .. t0 + 3 of this wave, together
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int f = lane; f < H; f += 64) {
+      const float vf = v[f], hf = hpr[f];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u < T ? t0 + u : T - 1;
+        acc[u] += vf * tanhf_(hf + ep[((int64_t)t * B + b) * H + f]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = wave_sum(acc[u]);
+      if (lane == 0 && t0 + u < T) sc[t0 + u] = a;
+    }
   }
-  __builtin_amdgcn_wave_barrier();
+  __syncthreads();
   float mx = -INFINITY;
   for (int t = lane; t < T; t += 64) mx = fmaxf(mx, sc[t]);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
   float sum = 0.f;
-  for (int t = lane; t < T; t += 64) {
-    const float e = expf(sc[t] - mx);
-    sc[t] = e;
-    sum += e;
-  }
+  for (int t = lane; t < T; t += 64) sum += expf(sc[t] - mx);
   sum = wave_sum(sum);
   const float inv = 1.0f / sum;
-  for (int t = lane; t < T; t += 64) {
-    const float w = sc[t] * inv;
-    sc[t] = w;
-    weights[(int64_t)b * T + t] = w;
-  }
-  __builtin_amdgcn_wave_barrier();
-  for (int f = lane; f < H; f += 64) {
+  __syncthreads();                                    // every wave has read the scores
+  if (wave == 0)
+    for (int t = lane; t < T; t += 64) {
+      const float w = expf(sc[t] - mx) * inv;
+      sc[t] = w;
+      weights[(int64_t)b * T + t] = w;
+    }
+  __syncthreads();
+  for (int f = threadIdx.x; f < H; f += 256) {
     float c = 0.f;
     for (int t = 0; t < T; ++t) c += sc[t] * enc[((int64_t)t * B + b) * H + f];
     ctx[(int64_t)b * ldctx + f] = c;
   }
 }
 
-// Backward of the step above for one batch row per wave.  d_ep / d_enc rows are written (or accumulated) by the wave
-// that owns row b only; d_v goes to per-workgroup partials [gridDim.x][H] (summed by the slab reduction).
+// Backward of the step above, one workgroup per batch row.  d_ep / d_enc rows of row b are written (or accumulated) by that
+// workgroup only; d_v goes to per-row partials [B][H] (summed by the slab reduction in a fixed order).
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__ d_ctx, int64_t ldd,
                                                        const float* __restrict__ hp, const float* __restrict__ ep,
                                                        const float* __restrict__ enc, const float* __restrict__ v,
@@ -531,50 +541,59 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
                                                        float* __restrict__ d_ep, float* __restrict__ d_enc,
                                                        float* __restrict__ dv_partial, int accumulate, int T, int B,
                                                        int H) {
-  extern __shared__ float smem[];                     // [4][T] ds  +  [4][H] dv
+  extern __shared__ float smem[];                     // [T] d_w -> ds
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  float* ds = smem + wave * T;
-  float* dvs = smem + 4 * T + wave * H;
-  for (int f = lane; f < H; f += 64) dvs[f] = 0.f;
-  if (b < B) {
-    // d_w[t] = <d_ctx, enc[t,b,:]> ; softmax backward ds[t] = w[t] (d_w[t] - sum_t' w[t'] d_w[t'])
-    float dot = 0.f;
-    for (int t = 0; t < T; ++t) {
-      float acc = 0.f;
-      for (int f = lane; f < H; f += 64) acc += d_ctx[(int64_t)b * ldd + f] * enc[((int64_t)t * B + b) * H + f];
-      acc = wave_sum(acc);
-      if (lane == 0) ds[t] = acc;
-      dot += weights[(int64_t)b * T + t] * acc;
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int t = lane; t < T; t += 64) ds[t] = weights[(int64_t)b * T + t] * (ds[t] - dot);
-    __builtin_amdgcn_wave_barrier();
+  const int b = blockIdx.x;
+  float* ds = smem;
+  const float* dcr = d_ctx + (int64_t)b * ldd;
+  const float* wr = weights + (int64_t)b * T;
+  // d_w[t] = <d_ctx, enc[t,b,:]>
+  for (int t0 = wave * 4; t0 < T; t0 += 16) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
     for (int f = lane; f < H; f += 64) {
-      const float hpf = hp[(int64_t)b * H + f], vf = v[f], dc = d_ctx[(int64_t)b * ldd + f];
-      float dh = 0.f, dvf = 0.f;
-      for (int t = 0; t < T; ++t) {
-        const int64_t row = ((int64_t)t * B + b) * H + f;
-        const float e = tanhf(hpf + ep[row]);
-        const float de = ds[t] * vf * (1.0f - e * e);
-        dh += de;
-        dvf += ds[t] * e;
-        const float dn = weights[(int64_t)b * T + t] * dc;
-        if (accumulate) {
-          d_ep[row] += de;
-          d_enc[row] += dn;
-        } else {
-          d_ep[row] = de;
-          d_enc[row] = dn;
-        }
+      const float dc = dcr[f];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int t = t0 + u < T ? t0 + u : T - 1;
+        acc[u] += dc * enc[((int64_t)t * B + b) * H + f];
       }
-      d_hp[(int64_t)b * H + f] = dh;
-      dvs[f] = dvf;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float a = wave_sum(acc[u]);
+      if (lane == 0 && t0 + u < T) ds[t0 + u] = a;
     }
   }
   __syncthreads();
-  for (int f = threadIdx.x; f < H; f += 256)
-    dv_partial[(int64_t)blockIdx.x * H + f] = (smem[4 * T + f] + smem[4 * T + H + f]) + (smem[4 * T + 2 * H + f] + smem[4 * T + 3 * H + f]);
+  // softmax backward ds[t] = w[t] (d_w[t] - sum_t' w[t'] d_w[t']), the sum in every wave
+  float dot = 0.f;
+  for (int t = lane; t < T; t += 64) dot += wr[t] * ds[t];
+  dot = wave_sum(dot);
+  __syncthreads();
+  if (wave == 0)
+    for (int t = lane; t < T; t += 64) ds[t] = wr[t] * (ds[t] - dot);
+  __syncthreads();
+  for (int f = threadIdx.x; f < H; f += 256) {
+    const float hpf = hp[(int64_t)b * H + f], vf = v[f], dc = dcr[f];
+    float dh = 0.f, dvf = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int64_t row = ((int64_t)t * B + b) * H + f;
+      const float e = tanhf_(hpf + ep[row]);
+      const float de = ds[t] * vf * (1.0f - e * e);
+      dh += de;
+      dvf += ds[t] * e;
+      const float dn = wr[t] * dc;
+      if (accumulate) {
+        d_ep[row] += de;
+        d_enc[row] += dn;
+      } else {
+        d_ep[row] = de;
+        d_enc[row] = dn;
+      }
+    }
+    d_hp[(int64_t)b * H + f] = dh;
+    dv_partial[(int64_t)b * H + f] = dvf;
+  }
 }
 
 }  // namespace g2v
@@ -713,16 +732,16 @@ extern "C" int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, 
 }
 
 extern "C" size_t g2v_attn_bwd_workspace(int B, int H) {
-  return (B > 0 && H > 0) ? (size_t)cdiv(B, 4) * H * sizeof(float) : 0;
+  return (B > 0 && H > 0) ? (size_t)B * H * sizeof(float) : 0;
 }
 
 extern "C" int g2v_attn_fwd(const float* hp, const float* ep, const float* enc, const float* v, float* weights, float* ctx,
                             int64_t ldctx, int T, int B, int H, g2v_stream_t stream) {
   G2V_REQUIRE(hp && ep && enc && v && weights && ctx, "null pointer");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && ldctx >= H, "bad size");
-  const size_t lds = (size_t)4 * T * sizeof(float);
+  const size_t lds = (size_t)T * sizeof(float);
   G2V_REQUIRE(lds <= 48 * 1024, "sequence too long for the attention kernel");
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), lds, (hipStream_t)stream, hp, ep, enc, v, weights, ctx,
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, hp, ep, enc, v, weights, ctx,
                      ldctx, T, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
@@ -738,9 +757,9 @@ extern "C" int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, co
     set_error("g2v_attn_bwd: workspace too small");
     return G2V_ERR_WORKSPACE;
   }
-  const size_t lds = (size_t)4 * (T + H) * sizeof(float);
-  G2V_REQUIRE(lds <= 48 * 1024, "sequence / hidden size too large for the attention kernel");
-  const int nblk = cdiv(B, 4);
+  const size_t lds = (size_t)T * sizeof(float);
+  G2V_REQUIRE(lds <= 48 * 1024, "sequence too long for the attention kernel");
+  const int nblk = B;
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_ctx, ldd, hp, ep, enc, v, weights,
                      d_hp, d_ep, d_enc, (float*)workspace, accumulate, T, B, H);
   G2V_CHECK_LAUNCH();
