@@ -158,6 +158,11 @@ class VQVAEEngine:
         # G2V_OVERLAP=0 serialises everything on the caller's stream.
         self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
+        # Eager launches pay an event record + wait per fork / join on the host: at small batch (a 2 ms step of ~300 launches)
+        # that costs more than the overlap returns (native VQ-VAE.yml shape, B = 128: 2.06 -> 2.30 ms), so outside a graph
+        # capture the branches are used from 1024 rows per batch only.
+        self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
+        self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
 
@@ -167,7 +172,7 @@ class VQVAEEngine:
         """Launch the enclosed kernels on side stream k, ordered after everything launched so far on the current stream.
         The branch stays open until _join(k) makes the current stream wait for it.  A branch may only touch buffers (and a
         workspace) that nothing launched on the main stream between the fork and the join touches."""
-        if not (self.overlap >> (k if bit is None else bit)) & 1:
+        if not self._branches_on or not (self.overlap >> (k if bit is None else bit)) & 1:
             yield
             return
         side = self._sides.get(k)
@@ -570,7 +575,8 @@ class VQVAEEngine:
                          epoch: int = 1, draw_masks: bool = True, dp: bool = False):
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
-        self._prepared = (self.overlap & 9) == 9 and self.quantizer == "ema"
+        self._branches_on = B >= self.overlap_min_rows or torch.cuda.is_current_stream_capturing()
+        self._prepared = self._branches_on and (self.overlap & 9) == 9 and self.quantizer == "ema"
         try:
             self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)
         finally:

@@ -165,3 +165,55 @@ def test_two_shard_engine_step_equals_global_statistics_update(B, T, D, H, K, p)
             bn = (eng.bn_rm.clone(), eng.bn_rv.clone())          # BatchNorm statistics stay per rank (north star)
             sync_engine_from_oracle(eng, {**sd, "decoder.decoder.pre_linear.1.running_mean": bn[0].cpu(),
                                           "decoder.decoder.pre_linear.1.running_var": bn[1].cpu()}, adam, step + 1)
+
+
+@pytest.mark.parametrize("B,T,D,H,K,p", [(64, 34, 135, 64, 512, 0.0), (48, 34, 135, 64, 512, 0.2), (32, 10, 45, 200, 400, 0.0)])
+def test_parallel_branches_and_prepared_launches_change_nothing(B, T, D, H, K, p):
+    """The fused step as ONE chain (G2V_OVERLAP = 0 semantics), as parallel branches on side streams (masks + ahead-of-time
+    packs / exchange clearing, EMA update, decoder weight gradients; `*_prepared` entry points) launched eagerly, and the same
+    replayed from a captured hipGraph: identical kernels on identical data, so weights, Adam moments, codebook, EMA state and
+    BatchNorm statistics must be BITWISE equal after three steps."""
+    sd = O.init_vqvae_state(D, H, 2, K, seed=5)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(70 + s)).to(DEV) for s in range(3)]
+    engines = {}
+    for mode in ("serial", "branches", "graph"):
+        eng = _engine(sd, D, H, K, T, p)
+        eng.seed = 99
+        eng.overlap = 0 if mode == "serial" else 15
+        eng.overlap_min_rows = 0                       # small batch: force the branches outside a capture too
+        if mode == "graph":
+            xbuf = xs[0].clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            state = [t.clone() for t in (eng.flat, eng.m, eng.v, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv,
+                                          eng.step_counter, eng.rng_counter, eng.code_sqnorm)]
+            with torch.cuda.stream(side):              # warm-up launch (sizes workspaces, creates the side streams) ...
+                eng.train_step(xbuf, xbuf, **kw)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            for t, s0 in zip((eng.flat, eng.m, eng.v, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv,
+                              eng.step_counter, eng.rng_counter, eng.code_sqnorm), state):
+                t.copy_(s0)                            # ... undone, so that the three replays start from the same state
+            # the captured step trusts the device-side |W|^2 (the EMA kernel rewrites it every step); seed it the way the
+            # eager engines' first step does
+            from gesture2vec_amd import ops
+            ops.vq_code_sqnorm(eng.codebook, out=eng.code_sqnorm)
+            eng._wsq_fresh = True
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                eng.train_step(xbuf, xbuf, **kw)
+            for x in xs:
+                xbuf.copy_(x)
+                g.replay()
+        else:
+            for x in xs:
+                eng.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        engines[mode] = eng
+    ref = engines["serial"]
+    for mode in ("branches", "graph"):
+        eng = engines[mode]
+        for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars", "loss_terms"):
+            assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, name)
+        assert int(eng.step_counter) == int(ref.step_counter) == 3
