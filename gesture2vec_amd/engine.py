@@ -158,9 +158,9 @@ class VQVAEEngine:
         # G2V_OVERLAP=0 serialises everything on the caller's stream.
         self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
-        # Eager launches pay an event record + wait per fork / join on the host: at small batch (a 2 ms step of ~300 launches)
-        # that costs more than the overlap returns (native VQ-VAE.yml shape, B = 128: 2.06 -> 2.30 ms), so outside a graph
-        # capture the branches are used from 1024 rows per batch only.
+        # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: at
+        # small batch (a 1-2 ms step of ~300 small launches) that is more than the overlap returns (native VQ-VAE.yml shape,
+        # B = 128, eager: 2.06 -> 2.30 ms), so the branches are used from 1024 rows per batch only.
         self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
@@ -575,7 +575,7 @@ class VQVAEEngine:
                          epoch: int = 1, draw_masks: bool = True, dp: bool = False):
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
-        self._branches_on = B >= self.overlap_min_rows or torch.cuda.is_current_stream_capturing()
+        self._branches_on = B >= self.overlap_min_rows
         self._prepared = self._branches_on and (self.overlap & 9) == 9 and self.quantizer == "ema"
         try:
             self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)

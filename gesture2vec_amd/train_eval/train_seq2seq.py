@@ -124,7 +124,8 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
     kw = dict(lr=optim.lr, w_l1=float(args.loss_l1_weight), w_cont=float(args.loss_cont_weight),
               w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=not getattr(net, "_explicit_masks", False),
               betas=optim.betas, eps=optim.eps, max_norm=optim.max_norm)
-    # (replaying this from a hipGraph was measured: 2.56 -> 2.53 ms per iteration at B=4096 - the host is not the limit)
+    # (replaying this from a hipGraph was measured: 2.56 -> 2.53 ms per iteration at B=4096, 2.26 -> 2.29 ms at the reference's own
+    # B=128 / H=200 shape - the host is not the limit at either end, the ~300 dependent launches are GPU-side latency)
     eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)
     net.decoder.decoder.pre_linear[1].num_batches_tracked += net.n_frames - 1       # one BatchNorm call per decode step
     both = torch.stack((eng.loss_terms[0], eng.vq_scalars[0])).tolist()            # the iteration's one host sync
