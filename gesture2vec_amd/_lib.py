@@ -50,7 +50,8 @@ class GruDirBwd(C.Structure):
 class DecGrads(C.Structure):
     """g2v_dec_grads"""
     _fields_ = [(n, c_fp) for n in (
-        "dy", "du", "dbn", "dgi0", "dgh0", "dgi1", "dgh1", "dh_init", "d_bn_w", "d_bn_b", "bn_bwd_partial")]
+        "dy", "du", "dbn", "dgi0", "dgh0", "dgi1", "dgh1", "dh_init", "d_bn_w", "d_bn_b", "bn_bwd_partial")] + [
+        ("dw_gru", c_fp * 4), ("db_gru", c_fp * 4)]          # optional fused GRU weight / bias gradients: ih0, hh0, ih1, hh1
 
 
 _SIGS = {
@@ -93,6 +94,7 @@ _SIGS = {
     "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_bwd_workspace": (c_sz, [c_int, c_int]),
+    "g2v_dec_rollout_bwd_fuses_wgrad": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_bwd": (c_int, [C.POINTER(DecWeights), C.POINTER(DecSaved), C.POINTER(DecGrads), c_fp, c_fp,
                                     c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_custom_loss_blocks": (c_int, [c_int, c_int]),

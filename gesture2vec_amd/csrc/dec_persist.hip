@@ -475,6 +475,9 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
 // Produces exactly the arrays the per-step kernels produce (du, dy total, dgi/dgh of both cells, d_bn_w/b, dh_init);
 // the dbn scratch array is not needed (the values stay in registers).
 // =====================================================================================================================
+int g2v_internal_slab_reduce4(const float* const* slab_w, float* const* out_w, const float* const* slab_b, float* const* out_b,
+                              int nprob, int64_t n, int64_t nb, int nsplit, hipStream_t st);      // linear.hip
+
 namespace g2v {
 namespace {
 constexpr int LDG = 4 * H + 4;                             // gate-gradient tile row stride
@@ -486,9 +489,15 @@ constexpr int R_BNW = R_POUTT + 4 * KSD * 256;
 constexpr int R_RED = R_BNW + 64;
 constexpr int R_TOT = R_RED + 16 * 128;
 constexpr int R_END = R_TOT + 128;
+// fused weight gradient (FW): the cell-1 gate-gradient tile keeps its own LDS image (the cell-0 one stays in R_G), so that it
+// is still there when its weight-gradient MFMAs run in the shadow of the NEXT iteration's exchange; plus one 16 x 16
+// transpose scratch per wave (an operand's rows from accumulator layout to B-fragment layout)
+constexpr int R_G1 = R_END, TRW = 16 * 17, R_TR = R_G1 + 16 * LDG, R_END_FW = R_TR + 4 * TRW;
+static_assert(R_END_FW * 4 <= 160 * 1024, "LDS budget of the fused-weight-gradient rollout backward");
 }  // namespace
 
-size_t dec_persist_bwd_lds_bytes() { return (size_t)R_END * sizeof(float); }
+size_t dec_persist_bwd_lds_bytes(bool fw) { return (size_t)(fw ? R_END_FW : R_END) * sizeof(float); }
+size_t dec_persist_bwd_wgrad_slab_floats() { return (size_t)(3 * H * H + 3 * H); }      // per workgroup: dW_hh1 192 x 64, db_hh1 192
 
 struct DecPersistBwdArgs {
   g2v_dec_weights w;
@@ -499,6 +508,7 @@ struct DecPersistBwdArgs {
   PersistX x;
   int T, B, nblk, n_pre, conditioned;
   float p_drop;
+  float* wslab;      // FW: [nblk][3H x H] partial dW_hh1, then [nblk][3H] partial db_hh1
 };
 
 // one 16-feature output tile, contraction over the gate axis of the merged tile [g_r | g_z | g_n | g_hn]:
@@ -532,6 +542,7 @@ __device__ __forceinline__ void load_cell(CellSaved& c, const float* __restrict_
 
 // GRU cell backward for this lane's (row, 4 features): dh = incoming gradient (already incl. carry).  Writes the gate
 // gradients to the global dgi / dgh rows and to the LDS tile; returns direct = dh * z (the path to h_{t-1}).
+template <bool STORE_GH>
 __device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved& c, float* __restrict__ dgi,
                                            float* __restrict__ dgh, float* G, int i, int f0) {
   const float rr[4] = {c.r.x, c.r.y, c.r.z, c.r.w}, zz[4] = {c.z.x, c.z.y, c.z.z, c.z.w}, nn[4] = {c.n.x, c.n.y, c.n.z, c.n.w},
@@ -551,7 +562,9 @@ __device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved
   const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
   *reinterpret_cast<float4*>(dgi) = vr; *reinterpret_cast<float4*>(dgi + H) = vz; *reinterpret_cast<float4*>(dgi + 2 * H) = vn;
-  *reinterpret_cast<float4*>(dgh) = vr; *reinterpret_cast<float4*>(dgh + H) = vz; *reinterpret_cast<float4*>(dgh + 2 * H) = vh;
+  if (STORE_GH) {    // (the fused kernel consumes dgh1 from the LDS tile: that (T-1,B,3H) array is never written)
+    *reinterpret_cast<float4*>(dgh) = vr; *reinterpret_cast<float4*>(dgh + H) = vz; *reinterpret_cast<float4*>(dgh + 2 * H) = vh;
+  }
   float* g = G + i * LDG + f0;
   *reinterpret_cast<float4*>(g) = vr;
   *reinterpret_cast<float4*>(g + H) = vz;
@@ -560,11 +573,19 @@ __device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved
   return make_float4(direct[0], direct[1], direct[2], direct[3]);
 }
 
+// FW: the weight (and bias) gradient of the decoder's W_hh of layer 1 -- dW = sum over steps and rows of dgh1^T h1_prev -- is
+// accumulated IN this kernel: each wave keeps the 12 accumulator tiles of its own 16 hidden-unit columns (48 registers: what
+// the 512-register budget has left next to the four register-resident weight-fragment sets; two matrices spill and cost
+// 0.2 ms, all four 0.65 ms: measured) and issues the step's 48 MFMAs in front of the next iteration's exchange, i.e. in the
+// fabric round trip the wave otherwise spins through.  dgh1 (104 MB per step at B = 4096) is neither written nor read back,
+// and the batched weight-gradient launch that follows has three matrices left instead of four.
+template <bool FW>
 __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xdu = smem + R_XDU;
   float* Xdy = smem + R_XDY;
   float* Gt = smem + R_G;
+  float* Gt1 = FW ? smem + R_G1 : Gt;
   float* Dt = smem + R_DT;
   uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + R_KT);
   float* Ppre_t = smem + R_PPRET;
@@ -623,6 +644,31 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   tile_request(T - 1);
   tile_commit(T - 1);
 
+  // ---- fused weight gradient: accumulators, the pending step's B fragment, column sums of the cell-1 tile ---------------
+  f32x4 wacc[FW ? 12 : 1];
+  float bfr[4] = {0.f, 0.f, 0.f, 0.f};
+  float dbc1 = 0.f;                      // thread tid <-> column tid of the merged tile [g_r | g_z | g_n | g_hn]
+  bool pending = false;
+#pragma unroll
+  for (int g = 0; g < (FW ? 12 : 1); ++g) wacc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // the pending step's MFMAs: A = tile^T (gate column on the lane, 4 rows per MFMA; g_r, g_z, g_hn), B = h1_prev fragment
+  auto wgrad_hh1 = [&]() {
+    const float* gp = Gt1 + q * LDG + i;
+#pragma unroll
+    for (int gt = 0; gt < 12; ++gt) {
+      const int col = 16 * gt + (gt >= 8 ? 64 : 0);
+      float av[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) av[ks] = gp[4 * ks * LDG + col];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) wacc[FW ? gt : 0] = mfma16(av[ks], bfr[ks], wacc[FW ? gt : 0]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sum += Gt1[r * LDG + tid];
+    dbc1 += sum;
+  };
+
   float4 carry0 = make_float4(0.f, 0.f, 0.f, 0.f), carry1 = carry0;   // d h0 / d h1 flowing to the earlier step
   float dbn[4] = {0.f, 0.f, 0.f, 0.f}, xhat[4] = {0.f, 0.f, 0.f, 0.f}, gis[4] = {0.f, 0.f, 0.f, 0.f};   // of the step in flight
   float acc_w = 0.f, acc_b = 0.f;                                       // d gamma / d beta (workgroup 0, tid < H)
@@ -643,6 +689,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     PSTAMP(1, 0);
     // ---- Part A: finish BatchNorm backward of step t+1 -> du_{t+1} --------------------------------------------------------
     if (!last) {
+      if (FW && pending) wgrad_hh1();      // in the shadow of the exchange: everybody's partial sums are still on the fabric
       px_exchange(a.x, (t + 1) & 1, (unsigned)(T - 1 - t), a.nblk, b, red, tot, tid);
       const float4 s14 = *reinterpret_cast<const float4*>(tot + f0), s24 = *reinterpret_cast<const float4*>(tot + H + f0);
       const float a1[4] = {s14.x, s14.y, s14.z, s14.w}, a2[4] = {s24.x, s24.y, s24.z, s24.w};
@@ -702,7 +749,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       lds_frag_mma<1, KSD>(acc, Pout_t, wave, 0, Xdy, LDD, lane);
       const float dh[4] = {acc[0][0] + carry1.x, acc[0][1] + carry1.y, acc[0][2] + carry1.z, acc[0][3] + carry1.w};
-      direct1 = cell_bwd(dh, c1, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt, i, f0);
+      direct1 = cell_bwd<!FW>(dh, c1, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt1, i, f0);
     }
     // cell-0 / BatchNorm inputs of this step: in flight during the next two products (96 MFMAs)
     CellSaved c0;
@@ -722,8 +769,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     float dh0[4];
     {
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-      gate_frag_mma<true>(a1, f_hh1, Gt, lane);
-      gate_frag_mma<false>(a2, f_ih1, Gt, lane);
+      gate_frag_mma<true>(a1, f_hh1, Gt1, lane);
+      gate_frag_mma<false>(a2, f_ih1, Gt1, lane);
       carry1 = make_float4(direct1.x + a1[0], direct1.y + a1[1], direct1.z + a1[2], direct1.w + a1[3]);
       const float c0v[4] = {carry0.x, carry0.y, carry0.z, carry0.w};
 #pragma unroll
@@ -738,7 +785,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     PSTAMP(1, 5);
     // ---- GRU cell 0 backward ---------------------------------------------------------------------------------------------
     float4 direct0;
-    direct0 = cell_bwd(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0);
+    direct0 = cell_bwd<true>(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0);
     lds_barrier();
     PSTAMP(1, 6);
     // ---- carry0' = dh0 * z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU backward -> dbn_t, partial sums, publish -----------------
@@ -772,7 +819,27 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
         px_publish2(rr, (unsigned)(H + f0) + 2, s2[2], s2[3], tag);
       }
     }
+    if (FW) {          // h1_prev of this step as a B fragment (lane (row i, q) holds columns f0 .. f0 + 3); its MFMAs run at the
+      float* tr = smem + R_TR + wave * TRW;                       // top of the next iteration.  Same wave, LDS ops in order.
+      tr[i * 17 + 4 * q + 0] = c1.hp.x; tr[i * 17 + 4 * q + 1] = c1.hp.y; tr[i * 17 + 4 * q + 2] = c1.hp.z; tr[i * 17 + 4 * q + 3] = c1.hp.w;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bfr[ks] = tr[(4 * ks + q) * 17 + i];
+      pending = true;
+    }
     PSTAMP(1, 7);
+  }
+  if (FW) {
+    // partial dW_hh1 of this workgroup's 16 rows over all steps: lane holds dW[16 gt + 4 q + r][16 wave + i]; partial db_hh1:
+    // column tid of the cell-1 tile (g_r, g_z <- columns 0..127, g_hn <- 192..255)
+    const int64_t nw = (int64_t)G3 * H;
+    float* sl = a.wslab + (int64_t)b * nw + 16 * wave + i;
+#pragma unroll
+    for (int gt = 0; gt < 12; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sl[(int64_t)(16 * gt + 4 * q + r) * H] = wacc[FW ? gt : 0][r];
+    float* dbs = a.wslab + (int64_t)a.nblk * nw + (int64_t)b * G3;
+    if (tid < 128) dbs[tid] = dbc1;
+    else if (tid >= 192) dbs[tid - 64] = dbc1;
   }
   // gradient wrt the initial hidden state (the quantised latent) and the BatchNorm affine parameters
   *reinterpret_cast<float4*>(a.gr.dh_init + row_i * H + f0) = carry0;
@@ -788,27 +855,42 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear) {
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab) {
+  const bool fw = wslab != nullptr;      // fused W_hh1 weight gradient requested (g->dw_gru[3] / db_gru[3] set)
   DecPersistBwdArgs a;
   a.w = *w; a.sv = *s; a.gr = *g;
   a.p_pre_t = p_pre_t; a.p_out_t = p_out_t; a.p_ih0_t = p_ih0_t; a.p_hh0_t = p_hh0_t; a.p_ih1_t = p_ih1_t; a.p_hh1_t = p_hh1_t;
   a.keep95 = keep95; a.keep_l0 = keep_l0;
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.p_drop = p_drop;
-  const size_t lds = dec_persist_bwd_lds_bytes();
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)dec_persist_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+  a.wslab = wslab;
+  const size_t lds = dec_persist_bwd_lds_bytes(fw);
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[fw]) {
+    const void* fn = fw ? (const void*)dec_persist_bwd_kernel<true> : (const void*)dec_persist_bwd_kernel<false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("dec_persist_bwd: cannot reserve %zu bytes of LDS", lds);
       return G2V_ERR_LAUNCH;
     }
-    attr_set = true;
+    attr_set[fw] = true;
   }
   if (clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
-  hipLaunchKernelGGL(dec_persist_bwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
+  if (fw) hipLaunchKernelGGL(dec_persist_bwd_kernel<true>, dim3(a.nblk), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(dec_persist_bwd_kernel<false>, dim3(a.nblk), dim3(256), lds, st, a);
   if (hipGetLastError() != hipSuccess) {
     set_error("dec_persist_bwd: launch failed");
     return G2V_ERR_LAUNCH;
+  }
+  if (fw) {          // sum the per-workgroup partials in a fixed order
+    const int64_t nw = (int64_t)3 * H * H, nb = 3 * H;
+    const float* sw[1] = {wslab};
+    const float* sb[1] = {wslab + (int64_t)a.nblk * nw};
+    float* ow[1] = {g->dw_gru[3]};
+    float* ob[1] = {g->db_gru[3]};
+    if (g2v_internal_slab_reduce4(sw, ow, sb, ob, 1, nw, nb, a.nblk, st) != 0) {
+      set_error("dec_persist_bwd: slab reduction launch failed");
+      return G2V_ERR_LAUNCH;
+    }
   }
   return G2V_OK;
 }

@@ -30,7 +30,10 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear);
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab);
+namespace g2v {
+size_t dec_persist_bwd_wgrad_slab_floats();
+}
 
 namespace g2v {
 
@@ -1863,9 +1866,25 @@ extern "C" int g2v_dec_rollout_fwd_prepared(const float* target, const float* h_
 // split path (small batch): six plain transposes + two (B <= 512, H) scratch arrays
 static size_t split_bwd_total(int D, int H) { return (size_t)2 * D * H + (size_t)12 * H * H + (size_t)2 * 16 * DSPLIT_MAX_NBLK * H; }
 static size_t bwd_pack_bytes_aligned(int D, int H) { return (pack_bwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
+// the fused-weight-gradient persistent backward appends its per-workgroup partial dW / db (PX_MAX_NBLK workgroups)
+static size_t bwd_wslab_bytes(int D, int H) {
+  return (H == 64 && D == 135) ? (size_t)PX_MAX_NBLK * dec_persist_bwd_wgrad_slab_floats() * sizeof(float) : 0;
+}
 extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
-  const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES, b = split_bwd_total(D, H) * sizeof(float);
+  const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES + bwd_wslab_bytes(D, H), b = split_bwd_total(D, H) * sizeof(float);
   return a > b ? a : b;
+}
+static bool fused_wgrad_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("G2V_NO_FUSED_WGRAD");
+    on = (e && e[0] == '1') ? 0 : 1;
+  }
+  return on != 0;
+}
+extern "C" int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H) {
+  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() &&
+          persist_enabled() && fused_wgrad_enabled()) ? 8 : 0;      // bit m <-> matrix m of (ih0, hh0, ih1, hh1): W_hh1
 }
 
 // Everything of a rollout pair that depends on the WEIGHTS only -- the fragment packs of the forward and of the backward -- and
@@ -1996,10 +2015,22 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
                          a16(s->u) && a16(s->a) && a16(s->h0) && a16(s->h1) && a16(s->gates0) && a16(s->gates1) &&
                          a16(s->bn_stats) && a16(g->dy) && a16(g->du) && a16(g->dgi0) && a16(g->dgh0) && a16(g->dgi1) &&
                          a16(g->dgh1) && a16(g->dh_init) && a16(keep95) && a16(keep_l0) && a16(workspace);
+    bool want_w = false, ok_w = true;
+    const int fmask = g2v_dec_rollout_bwd_fuses_wgrad(B, D, H);
+    for (int m = 0; m < 4; ++m) {
+      const bool has = g->dw_gru[m] || g->db_gru[m];
+      want_w = want_w || has;
+      ok_w = ok_w && (((fmask >> m) & 1) ? (g->dw_gru[m] && g->db_gru[m]) : !has);      // exactly the fused matrices, both pointers
+    }
+    if (want_w && !(ok_w && persist && fmask != 0)) {
+      set_error("g2v_dec_rollout_bwd: dw_gru / db_gru must name exactly the matrices of g2v_dec_rollout_bwd_fuses_wgrad(B, D, H)");
+      return G2V_ERR_UNSUPPORTED;
+    }
     if (persist)
       return dec_persist_bwd_launch(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, tw.w_pre_t, tw.w_out_t,
                                     tw.w_ih0_t, tw.w_hh0_t, tw.w_ih1_t, tw.w_hh1_t, (char*)workspace + bwd_pack_bytes_aligned(D, H), st,
-                                    !prepared);
+                                    !prepared,
+                                    want_w ? (float*)((char*)workspace + bwd_pack_bytes_aligned(D, H) + PX_BYTES) : nullptr);
   }
   for (int t = T - 1; t >= 0; --t) {
     if (fast)

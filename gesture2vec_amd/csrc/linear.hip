@@ -1181,6 +1181,21 @@ static int tn_splits(int M, int K, int N) {
 
 }  // namespace g2v
 
+// used by the persistent rollout backward (dec_persist.hip): out_w[p] (n floats) = sum over nsplit slabs slab_w[p][split][n],
+// out_b[p] (nb floats) likewise, for up to four problems in one launch; fixed summation order
+int g2v_internal_slab_reduce4(const float* const* slab_w, float* const* out_w, const float* const* slab_b, float* const* out_b,
+                              int nprob, int64_t n, int64_t nb, int nsplit, hipStream_t st) {
+  using namespace g2v;
+  SlabBatch sb;
+  for (int p = 0; p < G2V_TN_BATCH; ++p) {
+    const int pp = p < nprob ? p : 0;
+    sb.slab_a[p] = slab_w[pp]; sb.out_a[p] = out_w[pp]; sb.slab_b[p] = slab_b[pp]; sb.out_b[p] = out_b[pp];
+  }
+  hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 32) + cdiv(nb, 32), nprob), dim3(256), 0, st, sb, n, nb, nsplit, 0,
+                     cdiv(n, 32));
+  return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
 using namespace g2v;
 
 extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,

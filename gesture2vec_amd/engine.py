@@ -267,6 +267,14 @@ class VQVAEEngine:
         gr.dh_init = _p(b["dh_init"])
         gr.d_bn_w, gr.d_bn_b = self._g(pre + "pre_linear.1.weight"), self._g(pre + "pre_linear.1.bias")
         gr.bn_bwd_partial = _p(b["bn_bwd_partial"])
+        # GRU weight gradients accumulated inside the persistent backward kernel: bit m <-> (ih0, hh0, ih1, hh1)
+        b["fused_wgrad"] = int(self.lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H)) if self.quantizer == "ema" else 0
+        names = [("gru.weight_ih_l0", "gru.bias_ih_l0"), ("gru.weight_hh_l0", "gru.bias_hh_l0"),
+                 ("gru.weight_ih_l1", "gru.bias_ih_l1"), ("gru.weight_hh_l1", "gru.bias_hh_l1")]
+        for m, (wn, bn) in enumerate(names):
+            if (b["fused_wgrad"] >> m) & 1:
+                gr.dw_gru[m] = self._g(pre + wn)
+                gr.db_gru[m] = self._g(pre + bn)
         b["gr"] = gr
         ws_bytes = max(self.lib.g2v_dec_rollout_bwd_workspace(D, H), self.lib.g2v_dec_rollout_fwd_workspace(D, H),
                        self.lib.g2v_gru_seq_bwd_workspace(2, H), self.lib.g2v_gru_seq_fwd_workspace(2, H),
@@ -469,7 +477,7 @@ class VQVAEEngine:
             arr = (_lib.WgradItem * 4)()
             for k, (dy, x, wname, bname) in enumerate(items):
                 arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = dy, x, self._g(wname), self._g(bname)
-            check(lib.g2v_linear_bwd_weight_batch(arr, 4, G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn,
+            check(lib.g2v_linear_bwd_weight_batch(arr, len(items), G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn,
                                                   self._stream()))
         return wgrad, wgrad4
 
@@ -493,10 +501,13 @@ class VQVAEEngine:
         with (self._branch(2) if wgrad_branch else contextlib.nullcontext()):
             wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws")
             wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
-            wgrad4(M, [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
-                       (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
-                       (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
-                       (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")])
+            items = [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
+                     (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
+                     (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
+                     (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")]
+            rest = [it for m, it in enumerate(items) if not (b["fused_wgrad"] >> m) & 1]      # the others came out of the rollout kernel
+            if rest:
+                wgrad4(M, rest)
             wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
             for name in self.frozen:
                 g = self.view(name, True)

@@ -302,9 +302,15 @@ def dec_weights_struct(wd: dict) -> DecWeights:
 
 
 def struct_from(cls, d: dict):
+    """ctypes struct from a dict of tensors; array fields (e.g. DecGrads.dw_gru) take a list of tensors / None entries"""
     s = cls()
-    for name, _ in cls._fields_:
-        setattr(s, name, _p(d.get(name)))
+    for name, typ in cls._fields_:
+        v = d.get(name)
+        if isinstance(typ, type) and issubclass(typ, C.Array):
+            for k, t in enumerate(v or ()):
+                getattr(s, name)[k] = _p(t)
+        else:
+            setattr(s, name, _p(v))
     return s
 
 

@@ -299,10 +299,20 @@ typedef struct {           /* gradient outputs of the rollout backward, caller-o
   float* dh_init;          /* (2,B,H) grad wrt the initial hidden state (the quantised latent)     */
   float* d_bn_w; float* d_bn_b; /* (H) each, overwritten                                           */
   float* bn_bwd_partial;   /* (2, nblk, 2, H) ping-pong per-block sums                              */
+  /* Optional: GRU weight / bias gradients dW (3H,H), db (3H), indexed ih0, hh0, ih1, hh1, overwritten.  Set exactly the
+   * entries named by g2v_dec_rollout_bwd_fuses_wgrad() (or none): those are accumulated INSIDE the persistent backward kernel,
+   * in the shadow of its BatchNorm exchange, and the matching dgi / dgh array (dgh1 for W_hh1) is neither written nor needed. */
+  float* dw_gru[4];
+  float* db_gru[4];
 } g2v_dec_grads;
 
 /* workspace: transposed weights in MFMA fragment order. */
 size_t g2v_dec_rollout_bwd_workspace(int D, int H);
+/* Which GRU weight gradients g2v_dec_rollout_bwd can accumulate inside its persistent kernel at this batch / shape: bit m of
+ * the result <-> matrix m of (W_ih0, W_hh0, W_ih1, W_hh1).  Today 8 (W_hh1: what the kernel's register budget has room for) where
+ * the persistent path applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count), else 0; G2V_NO_FUSED_WGRAD=1 forces 0.
+ * The caller sets dw_gru[m] / db_gru[m] for exactly those matrices (or for none) and forms the other products itself. */
+int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H);
 int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,
                         const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
                         int conditioned, int T, int B, int D, int H,

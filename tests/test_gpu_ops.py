@@ -615,6 +615,27 @@ def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p, T):
         assert torch.equal(ga[k], gc[k]), f"persistent backward not reproducible: {k}"
         assert torch.isfinite(ga[k]).all()
         relclose(ga[k], gb[k], 2e-4 if T <= 8 else 0.25, f"persistent vs per-step backward: {k}")
+    # ---- the weight gradient the persistent kernel can accumulate itself (W_hh of layer 1) -------------------------------------
+    mask = lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H)
+    assert mask == 8, mask
+    dw, db = z(G, H), z(G)
+    grads = {"dy": gy.clone(), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G), "dgh0": z(T - 1, B, G),
+             "dgi1": z(T - 1, B, G), "dgh1": torch.full((T - 1, B, G), 7.0, device=DEV), "dh_init": z(2, B, H), "d_bn_w": z(H),
+             "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H), "dw_gru": [None, None, None, dw], "db_gru": [None, None, None, db]}
+    ops.dec_rollout_bwd(wsb, sb, grads, k95, kl0, p, 1, True, T, B, D, H)
+    torch.cuda.synchronize()
+    for k in ga:
+        if k not in ("dgh1",):
+            assert torch.equal(grads[k], ga[k]), f"fused-weight-gradient backward changed {k}"
+    assert float((grads["dgh1"] - 7.0).abs().max()) == 0.0          # the fused kernel never writes that array
+    M = (T - 1) * B
+    dw_ref, db_ref = ops.linear_bwd_weight(ga["dgh1"].view(M, G), sb["h1"][:-1].reshape(M, H).contiguous(), G, H)
+    relclose(dw, dw_ref, 2e-5, "fused dW_hh1")
+    relclose(db, db_ref, 2e-5, "fused db_hh1")
+    with pytest.raises(RuntimeError, match="exactly the matrices"):      # any other matrix is the caller's job
+        bad = dict(grads)
+        bad["dw_gru"], bad["db_gru"] = [dw, None, None, dw], [db, None, None, db]
+        ops.dec_rollout_bwd(wsb, sb, bad, k95, kl0, p, 1, True, T, B, D, H)
 
 
 # ----------------------------------------------------------------------------------------------- loss / optimiser / rng
