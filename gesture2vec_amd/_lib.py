@@ -44,7 +44,8 @@ class WgradItem(C.Structure):
 class GruDirBwd(C.Structure):
     """g2v_gru_dir_bwd"""
     _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
-                [(n, c_fp) for n in ("w_ih", "dx")] + [("in_dim", c_int)])
+                [(n, c_fp) for n in ("w_ih", "dx")] + [("in_dim", c_int)] +
+                [(n, c_fp) for n in ("x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab")])      # optional fused weight gradients
 
 
 class DecGrads(C.Structure):
@@ -77,6 +78,7 @@ _SIGS = {
     "g2v_gru_seq_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_gru_seq_fwd": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_workspace": (c_sz, [c_int, c_int]),
+    "g2v_gru_seq_bwd_wslab_bytes": (c_sz, [c_int, c_int]),
     "g2v_gru_seq_bwd": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_cell_fwd": (c_int, [c_fp, c_int, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_gru_cell_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_f, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),

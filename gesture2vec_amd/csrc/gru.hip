@@ -606,6 +606,7 @@ struct GruDirB {
   float* dgi; float* dgh; float* dh0;
   int reverse;
   const float* p_ih_t; float* dx;    // FUSE_DX: dx_t = dgi_t W_ih is produced in the kernel
+  const float* x; float* wslab;      // FUSE_W: the layer input (T,B,H) and this direction's partial dW / db slabs
 };
 
 // FUSE_IN: the input projection gi_t = x_t W_ih^T + b_ih (input width == H) is computed in the kernel, one step ahead
@@ -764,12 +765,20 @@ __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d
 // next to the dh chain (which is a 48-deep DEPENDENT chain: the extra chain fills its issue bubbles); the separate
 // (T*B,3H) x (3H,H) product and its re-read of dgi disappear.  dgi = (g_r, g_z, g_n) and dgh = (g_r, g_z, g_hn) share
 // their first 2H columns in LDS; the n-gate columns of dgi sit in a second small tile.
-template <int HS, bool FUSE_DX>
-__global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d1, const int32_t* __restrict__ lengths,
+// FUSE_W (with FUSE_DX): the direction's two weight gradients dW_hh = sum dgh^T h_prev, dW_ih = sum dgi^T x (and the bias
+// gradients) are accumulated here as well -- each wave its own 16 hidden-unit columns of both 192 x 64 matrices (24
+// accumulator tiles; the kernel has the registers: 104 -> ~210, still two workgroups per CU), A = the gate-gradient tile
+// transposed, B = h_prev / x through a per-wave 16 x 16 LDS transpose, 96 more MFMAs per wave and step.  The separate batched
+// weight-gradient launch of the encoder (135 us at the BASELINE shape, ON the critical path behind this kernel) and the dgi /
+// dgh arrays (4 x 107 MB written, then read back) disappear; the price is a matrix pipe that is now the limit of the step.
+template <int HS, bool FUSE_DX, int FUSE_W = 0>      // FUSE_W: 0 none, 1 W_hh only (fits two workgroups per CU), 2 W_hh and W_ih
+__global__ __launch_bounds__(256, FUSE_W == 2 ? 1 : 2) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d1, const int32_t* __restrict__ lengths,
                                                            int64_t d_hs_ld, int64_t hs_ld, int T, int B) {
+  static_assert(!FUSE_W || FUSE_DX, "fused weight gradients come with the fused input gradient");
   constexpr int H = HS, G = 3 * H, KSG = G / 16, ldg = G + 4, ldn = H + 4;
   __shared__ __attribute__((aligned(16))) float Gs[2][16 * ldg];
   __shared__ __attribute__((aligned(16))) float Gn[FUSE_DX ? 2 : 1][FUSE_DX ? 16 * ldn : 4];
+  __shared__ float Trs[FUSE_W ? 4 : 1][FUSE_W ? 2 * 16 * 17 : 1];       // per wave: h_prev and x, 16 x 16 each
   const GruDirB d = blockIdx.y ? d1 : d0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -789,13 +798,14 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
   float4 dh = (d.d_hn && rvalid) ? *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0) : z4;
   for (int e = tid; e < 2 * 16 * ldg; e += 256) (&Gs[0][0])[e] = 0.f;
 
-  auto load_step = [&](int s, float4& gr4, float4& gz4, float4& gn4, float4& gh4, float4& hp4, float4& dhs4) {
+  auto load_step = [&](int s, float4& gr4, float4& gz4, float4& gn4, float4& gh4, float4& hp4, float4& dhs4, float4& x4) {
     const int t = d.reverse ? (T - 1 - s) : s;
     const int tprev = d.reverse ? t + 1 : t - 1;
-    gr4 = gz4 = gn4 = gh4 = hp4 = dhs4 = z4;
+    gr4 = gz4 = gn4 = gh4 = hp4 = dhs4 = x4 = z4;
     if (rvalid && t < len) {
       const int64_t row = (int64_t)t * B + b;
       const float* go = d.gates + row * 4 * H + f0;
+      if constexpr (FUSE_W == 2) x4 = *reinterpret_cast<const float4*>(d.x + row * H + f0);
       gr4 = *reinterpret_cast<const float4*>(go);
       gz4 = *reinterpret_cast<const float4*>(go + H);
       gn4 = *reinterpret_cast<const float4*>(go + 2 * H);
@@ -808,14 +818,20 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
       }
     }
   };
-  float4 n_r, n_z, n_n, n_h, n_hp, n_dhs;
-  load_step(T - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs);
+  float4 n_r, n_z, n_n, n_h, n_hp, n_dhs, n_x;
+  load_step(T - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs, n_x);
+  f32x4 whh[FUSE_W ? 12 : 1], wih[FUSE_W == 2 ? 12 : 1];
+  float dbh = 0.f, dbn = 0.f;            // column sums: thread tid < 192 <-> (g_r, g_z, g_hn) column, tid < 64 <-> g_n column
+#pragma unroll
+  for (int g = 0; g < (FUSE_W ? 12 : 1); ++g) whh[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < (FUSE_W == 2 ? 12 : 1); ++g) wih[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   __syncthreads();
   int cur = 0;
   for (int s = T - 1; s >= 0; --s) {
     const int t = d.reverse ? (T - 1 - s) : s;
-    const float4 c_r = n_r, c_z = n_z, c_n = n_n, c_h = n_h, c_hp = n_hp, c_dhs = n_dhs;
-    if (s > 0) load_step(s - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs);
+    const float4 c_r = n_r, c_z = n_z, c_n = n_n, c_h = n_h, c_hp = n_hp, c_dhs = n_dhs, c_x = n_x;
+    if (s > 0) load_step(s - 1, n_r, n_z, n_n, n_h, n_hp, n_dhs, n_x);
     const bool valid = rvalid && (t < len);
     const float rr[4] = {c_r.x, c_r.y, c_r.z, c_r.w}, zz[4] = {c_z.x, c_z.y, c_z.z, c_z.w}, nn[4] = {c_n.x, c_n.y, c_n.z, c_n.w},
                 gh[4] = {c_h.x, c_h.y, c_h.z, c_h.w}, hp[4] = {c_hp.x, c_hp.y, c_hp.z, c_hp.w},
@@ -841,12 +857,23 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
     }
     const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                  vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
-    if (rvalid) {
+    if (rvalid) {                          // (a fused weight gradient consumes the tile from LDS: its (T,B,3H) array is not written)
       const int64_t row = (int64_t)t * B + b;
-      float* o1 = d.dgi + row * G + f0;
-      float* o2 = d.dgh + row * G + f0;
-      *reinterpret_cast<float4*>(o1) = vr; *reinterpret_cast<float4*>(o1 + H) = vz; *reinterpret_cast<float4*>(o1 + 2 * H) = vn;
-      *reinterpret_cast<float4*>(o2) = vr; *reinterpret_cast<float4*>(o2 + H) = vz; *reinterpret_cast<float4*>(o2 + 2 * H) = vh;
+      if constexpr (FUSE_W < 2) {
+        float* o1 = d.dgi + row * G + f0;
+        *reinterpret_cast<float4*>(o1) = vr; *reinterpret_cast<float4*>(o1 + H) = vz; *reinterpret_cast<float4*>(o1 + 2 * H) = vn;
+      }
+      if constexpr (FUSE_W < 1) {
+        float* o2 = d.dgh + row * G + f0;
+        *reinterpret_cast<float4*>(o2) = vr; *reinterpret_cast<float4*>(o2 + H) = vz; *reinterpret_cast<float4*>(o2 + 2 * H) = vh;
+      }
+    }
+    if constexpr (FUSE_W) {                // h_prev and x of this step, accumulator layout -> B-fragment layout (wave-private)
+      float* tr = Trs[wave];
+      tr[i * 17 + 4 * q + 0] = c_hp.x; tr[i * 17 + 4 * q + 1] = c_hp.y; tr[i * 17 + 4 * q + 2] = c_hp.z; tr[i * 17 + 4 * q + 3] = c_hp.w;
+      if constexpr (FUSE_W == 2) {
+        tr[272 + i * 17 + 4 * q + 0] = c_x.x; tr[272 + i * 17 + 4 * q + 1] = c_x.y; tr[272 + i * 17 + 4 * q + 2] = c_x.z; tr[272 + i * 17 + 4 * q + 3] = c_x.w;
+      }
     }
     float* gs = Gs[cur] + i * ldg;
     *reinterpret_cast<float4*>(gs + f0) = vr;
@@ -886,9 +913,66 @@ __global__ __launch_bounds__(256) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d
     }
     }
     dh = make_float4(direct[0] + acc[0], direct[1] + acc[1], direct[2] + acc[2], direct[3] + acc[3]);
+    if constexpr (FUSE_W) {
+      // weight gradients of this step: tile^T (gate column on the lane, 4 rows per MFMA) x this wave's 16 columns of h_prev / x
+      const float* tr = Trs[wave];
+      float bh[4], bx[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { bh[ks] = tr[(4 * ks + q) * 17 + i]; bx[ks] = FUSE_W == 2 ? tr[272 + (4 * ks + q) * 17 + i] : 0.f; }
+      const float* ga = Gs[cur ^ 0] + q * ldg + i;
+      const float* gna = &Gn[cur][q * ldn + i];
+#pragma unroll
+      for (int gt = 0; gt < 12; ++gt) {          // Gs columns: 0-3 g_r, 4-7 g_z, 8-11 g_hn; Gn: g_n
+        float av[4], an[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          av[ks] = ga[4 * ks * ldg + 16 * gt];
+          an[ks] = (FUSE_W == 2 && gt >= 8) ? gna[4 * ks * ldn + 16 * (gt - 8)] : av[ks];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          whh[FUSE_W ? gt : 0] = mfma16(av[ks], bh[ks], whh[FUSE_W ? gt : 0]);
+          if constexpr (FUSE_W == 2) wih[gt] = mfma16(an[ks], bx[ks], wih[gt]);
+        }
+      }
+      if (tid < G) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += Gs[cur][r * ldg + tid];
+        dbh += sum;
+      }
+      if (FUSE_W == 2 && tid < H) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += Gn[cur][r * ldn + tid];
+        dbn += sum;
+      }
+    }
     cur ^= 1;
   }
   if (d.dh0 && rvalid) *reinterpret_cast<float4*>(d.dh0 + (int64_t)b * H + f0) = dh;
+  if constexpr (FUSE_W) {
+    // this workgroup's partial sums over its 16 rows and all steps: slab layout [matrix hh, ih][nblk][G x H], then
+    // [matrix][nblk][G]; lane holds dW[16 gt + 4 q + r][16 wave + i]; dgh columns (r, z, hn), dgi columns (r, z, n)
+    const int nblk = gridDim.x;
+    const int64_t nw = (int64_t)G * H;
+    float* s_hh = d.wslab + (int64_t)blockIdx.x * nw + 16 * wave + i;
+    float* s_ih = d.wslab + ((int64_t)nblk + blockIdx.x) * nw + 16 * wave + i;
+#pragma unroll
+    for (int gt = 0; gt < 12; ++gt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        s_hh[(int64_t)(16 * gt + 4 * q + r) * H] = whh[FUSE_W ? gt : 0][r];
+        if constexpr (FUSE_W == 2) s_ih[(int64_t)(16 * gt + 4 * q + r) * H] = wih[gt][r];
+      }
+    float* b_hh = d.wslab + (int64_t)2 * nblk * nw + (int64_t)blockIdx.x * G;
+    float* b_ih = d.wslab + (int64_t)2 * nblk * nw + ((int64_t)nblk + blockIdx.x) * G;
+    if (tid < G) {
+      b_hh[tid] = dbh;
+      if (FUSE_W == 2 && tid < 2 * H) b_ih[tid] = dbh;
+    }
+    if (FUSE_W == 2 && tid < H) b_ih[2 * H + tid] = dbn;
+  }
 }
 
 }  // namespace g2v
@@ -910,6 +994,11 @@ extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
   return (a > b ? a : b) * sizeof(float);
 }
 
+int g2v_internal_slab_reduce4(const float* const* slab_w, float* const* out_w, const float* const* slab_b, float* const* out_b,
+                              int nprob, int64_t n, int64_t nb, int nsplit, hipStream_t st);      // linear.hip
+extern "C" size_t g2v_gru_seq_bwd_wslab_bytes(int B, int H) {
+  return (B > 0 && H > 0) ? (size_t)cdiv(B, 16) * 2 * ((size_t)3 * H * H + 3 * H) * sizeof(float) : 0;
+}
 int g2v_internal_cell_bwd_products(const float* dgh, const float* w_hh, float* d_hprev, int H, const float* dgi,
                                    const float* w_ih, float* dx, int in_dim, const uint8_t* x_keep, float x_scale, int B,
                                    hipStream_t st);      // linear.hip
@@ -1136,7 +1225,7 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0, "bad size");
   for (int k = 0; k < ndir; ++k)
-    G2V_REQUIRE(dirs[k].hs && dirs[k].gates && dirs[k].w_hh && dirs[k].dgi && dirs[k].dgh, "null pointer");
+    G2V_REQUIRE(dirs[k].hs && dirs[k].gates && dirs[k].w_hh && ((dirs[k].dgi && dirs[k].dgh) || dirs[k].dw_hh), "null pointer");
   if (workspace_bytes < g2v_gru_seq_bwd_workspace(ndir, H)) {
     set_error("g2v_gru_seq_bwd: workspace too small");
     return G2V_ERR_WORKSPACE;
@@ -1161,13 +1250,50 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     const float* p_ih_t[2];
     const PackBatch pb = gru_bwd_packs(whh, wih, ndir, H, fuse, p, p_hh_t, p_ih_t);
     GruDirB f[2];
+    // fused weight gradients: every direction names x, its four outputs and a slab buffer (or none does)
+    // fused weight gradients: W_hh only (dw_hh, db_hh, wslab) or W_hh and W_ih (plus dw_ih, db_ih, x); every direction alike
+    const bool fuse_w = dirs[0].dw_hh != nullptr, fuse_w2 = fuse_w && dirs[0].dw_ih != nullptr;
+    for (int k = 0; k < ndir; ++k) {
+      const bool hh = dirs[k].dw_hh && dirs[k].db_hh && dirs[k].wslab, ih = dirs[k].dw_ih && dirs[k].db_ih && dirs[k].x;
+      const bool no_hh = !dirs[k].dw_hh && !dirs[k].db_hh && !dirs[k].wslab, no_ih = !dirs[k].dw_ih && !dirs[k].db_ih;
+      G2V_REQUIRE(fuse_w ? (hh && fuse && (fuse_w2 ? (ih && aligned16(dirs[k].x)) : (no_ih && dirs[k].dgi != nullptr))) : (no_hh && no_ih),
+                  "fused weight gradients: dw_hh, db_hh, wslab (+ dw_ih, db_ih, x) for every direction, with the fused input gradient");
+    }
     for (int k = 0; k < ndir; ++k)
       f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p_hh_t[k],
-                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, p_ih_t[k], dirs[k].dx};
+                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, p_ih_t[k], dirs[k].dx, dirs[k].x, dirs[k].wslab};
     if (ndir == 1) f[1] = f[0];
     if (!prepared) {
       launch_pack(pb, st);
       G2V_CHECK_LAUNCH();
+    }
+    if (fuse_w) {
+      const int nblk = cdiv(B, 16);
+      if (fuse_w2)
+        hipLaunchKernelGGL((gru_bwd_fast_kernel<64, true, 2>), dim3(nblk, ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
+                           hs_ld, T, B);
+      else
+        hipLaunchKernelGGL((gru_bwd_fast_kernel<64, true, 1>), dim3(nblk, ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,
+                           hs_ld, T, B);
+      G2V_CHECK_LAUNCH();
+      const int64_t nw = (int64_t)3 * H * H, nb = 3 * H;
+      const float* sw[4]; const float* sb[4]; float* ow[4]; float* ob[4];
+      int np = 0;
+      for (int k = 0; k < ndir; ++k) {
+        sw[np] = dirs[k].wslab; ow[np] = dirs[k].dw_hh;
+        sb[np] = dirs[k].wslab + (int64_t)2 * nblk * nw; ob[np] = dirs[k].db_hh;
+        ++np;
+        if (fuse_w2) {
+          sw[np] = dirs[k].wslab + (int64_t)nblk * nw; ow[np] = dirs[k].dw_ih;
+          sb[np] = dirs[k].wslab + (int64_t)2 * nblk * nw + (int64_t)nblk * nb; ob[np] = dirs[k].db_ih;
+          ++np;
+        }
+      }
+      if (g2v_internal_slab_reduce4(sw, ow, sb, ob, np, nw, nb, nblk, st) != 0) {
+        set_error("g2v_gru_seq_bwd: slab reduction launch failed");
+        return G2V_ERR_LAUNCH;
+      }
+      return G2V_OK;
     }
     if (fuse)
       hipLaunchKernelGGL((gru_bwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, d_hs_ld,

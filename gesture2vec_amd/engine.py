@@ -289,6 +289,11 @@ class VQVAEEngine:
                                             self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
                                             4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
                                         dtype=torch.uint8, device=dev)
+        # encoder GRU weight gradients accumulated inside its backward kernel (H == 64): 0 none, 1 W_hh, 2 W_hh and W_ih
+        b["enc_fused_wgrad"] = int(os.environ.get("G2V_ENC_FUSED_WGRAD", "1")) if (H == 64 and self.quantizer == "ema") else 0
+        if b["enc_fused_wgrad"]:
+            n = int(self.lib.g2v_gru_seq_bwd_wslab_bytes(B, H))
+            b["enc_wslab"] = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
         b["ws_enc_wgrad"] = torch.zeros(4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H), dtype=torch.uint8, device=dev)
         # dedicated workspaces of the four recurrent launches: prepare_recurrent() fills them ahead of their kernels
         for key, nbytes in (("ws_gruf", self.lib.g2v_gru_seq_fwd_workspace(2, H)), ("ws_grub", self.lib.g2v_gru_seq_bwd_workspace(2, H)),
@@ -539,6 +544,12 @@ class VQVAEEngine:
             dirs[k].w_ih = self._w(enc + "gru.weight_ih_l0" + suf)
             dirs[k].dx = _p(b["gi_" + key]) if H == 64 else None
             dirs[k].in_dim = H
+            if b["enc_fused_wgrad"]:        # the recurrent kernel accumulates dW_hh (and, mode 2, dW_ih) itself
+                dirs[k].dw_hh, dirs[k].db_hh = self._g(enc + "gru.weight_hh_l0" + suf), self._g(enc + "gru.bias_hh_l0" + suf)
+                dirs[k].wslab = _p(b["enc_wslab"][k])
+                if b["enc_fused_wgrad"] == 2:
+                    dirs[k].dw_ih, dirs[k].db_ih = self._g(enc + "gru.weight_ih_l0" + suf), self._g(enc + "gru.bias_ih_l0" + suf)
+                    dirs[k].x = _p(b["xin"])
         if self._prepared:
             check(lib.g2v_gru_seq_bwd_prepared(dirs, 2, None, H, H, T, B, H, _p(b["ws_grub"]), b["ws_grub"].numel(), st))
         else:
@@ -546,10 +557,14 @@ class VQVAEEngine:
         TB = T * B
         with self._branch(4):       # beside the input layer's gradient below (joined there)
             _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 4) & 1 else "ws")
-            wgrad4s(TB, [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
-                         (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
-                         (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
-                         (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")])
+            items = [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
+                     (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
+                     (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
+                     (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")]
+            if b["enc_fused_wgrad"] == 1:
+                items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
+            if b["enc_fused_wgrad"] < 2:
+                wgrad4s(TB, items)
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
         else:

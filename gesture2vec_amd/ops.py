@@ -235,7 +235,8 @@ def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None):
     lib = _lib_()
     arr = (_lib.GruDirBwd * len(dirs))()
     for k, d in enumerate(dirs):
-        for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0", "w_ih", "dx"):
+        for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0", "w_ih", "dx",
+                     "x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab"):        # the last six: optional fused weight gradients
             setattr(arr[k], name, _p(d.get(name)))
         arr[k].reverse = int(bool(d.get("reverse", False)))
         arr[k].in_dim = int(d.get("in_dim", 0))

@@ -205,7 +205,15 @@ typedef struct {
   const float* w_ih;      /* (3H,in_dim) */
   float* dx;              /* out: (T,B,in_dim), overwritten */
   int in_dim;
+  /* Fused weight gradients (dw_hh != NULL; with the fused input gradient, H == in_dim == 64, every direction alike): the
+   * recurrent kernel also accumulates dW_hh = sum dgh^T h_prev, dW_ih = sum dgi^T x and the two bias gradients (overwritten);
+   * dgi / dgh are then neither written nor needed (may be NULL).  x: the layer input (T,B,in_dim); wslab: scratch of
+   * g2v_gru_seq_bwd_wslab_bytes(B, H) bytes PER DIRECTION. */
+  const float* x;
+  float* dw_hh; float* db_hh; float* dw_ih; float* db_ih;
+  float* wslab;
 } g2v_gru_dir_bwd;
+size_t g2v_gru_seq_bwd_wslab_bytes(int B, int H);
 size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragment order) */
 int g2v_gru_seq_bwd(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld, int64_t hs_ld,
                     int T, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);

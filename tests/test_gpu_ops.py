@@ -877,6 +877,56 @@ def test_gru_bwd_fused_input_gradient_matches_unfused():
         relclose(res[True]["dx"], dx_ref, 2e-5, f"dx dir{k}")
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_gru_bwd_fused_weight_gradients_match_separate_products(mode):
+    """g2v_gru_seq_bwd with dw_hh != NULL: the recurrent kernel accumulates dW_hh = sum dgh^T h_prev (mode 1) and also
+    dW_ih = sum dgi^T x (mode 2) with the bias gradients; against g2v_linear_bwd_weight on the dgi / dgh of the unfused call.
+    Both directions in one launch, ragged batch, packed lengths; the fused arrays are not written."""
+    from gesture2vec_amd import _lib, ops
+    lib = _lib.load()
+    torch.manual_seed(6)
+    T, B, H = 9, 37, 64
+    G = 3 * H
+    x = torch.randn(T, B, H, device=DEV)
+    lengths = torch.randint(2, T + 1, (B,)).sort(descending=True).values
+    lengths[0] = T
+    ln = lengths.to(DEV).to(torch.int32)
+    dirs_ref, dirs_fused, hprevs = [], [], []
+    for k in range(2):
+        w_ih, b_ih = torch.randn(G, H, device=DEV) * 0.2, torch.randn(G, device=DEV) * 0.1
+        w_hh, b_hh = torch.randn(G, H, device=DEV) * 0.2, torch.randn(G, device=DEV) * 0.1
+        gi = ops.linear_fwd(x.view(T * B, H), w_ih, b_ih)
+        hs, h_n, gates = ops.gru_seq_fwd(gi, w_hh, b_hh, T, B, H, lengths=ln, reverse=bool(k))
+        d_hs, d_hn = torch.randn(T, B, H, device=DEV), torch.randn(B, H, device=DEV)
+        base = dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w_hh, dh0=None, reverse=bool(k), w_ih=w_ih, in_dim=H)
+        dirs_ref.append(dict(base, dgi=torch.zeros(T, B, G, device=DEV), dgh=torch.zeros(T, B, G, device=DEV),
+                             dx=torch.zeros(T, B, H, device=DEV)))
+        f = dict(base, dgi=torch.full((T, B, G), 7.0, device=DEV), dgh=torch.full((T, B, G), 7.0, device=DEV),
+                 dx=torch.zeros(T, B, H, device=DEV), dw_hh=torch.full((G, H), 9.0, device=DEV), db_hh=torch.full((G,), 9.0, device=DEV),
+                 wslab=torch.zeros(lib.g2v_gru_seq_bwd_wslab_bytes(B, H), dtype=torch.uint8, device=DEV))
+        if mode == 2:
+            f.update(dw_ih=torch.full((G, H), 9.0, device=DEV), db_ih=torch.full((G,), 9.0, device=DEV), x=x)
+        dirs_fused.append(f)
+        zero = torch.zeros(1, B, H, device=DEV)
+        hprevs.append(torch.cat([hs[1:], zero], 0) if k else torch.cat([zero, hs[:-1]], 0))
+    ops.gru_dirs_bwd(dirs_ref, T, B, H, lengths=ln)
+    ops.gru_dirs_bwd(dirs_fused, T, B, H, lengths=ln)
+    for k in range(2):
+        r, f = dirs_ref[k], dirs_fused[k]
+        relclose(f["dx"], r["dx"], 1e-6, f"dx dir{k}")
+        dw, db = ops.linear_bwd_weight(r["dgh"].view(T * B, G), hprevs[k].reshape(T * B, H).contiguous(), G, H)
+        relclose(f["dw_hh"], dw, 1e-5, f"dW_hh dir{k}")
+        relclose(f["db_hh"], db, 1e-5, f"db_hh dir{k}")
+        assert float((f["dgh"] - 7.0).abs().max()) == 0.0
+        if mode == 2:
+            dw, db = ops.linear_bwd_weight(r["dgi"].view(T * B, G), x.view(T * B, H), G, H)
+            relclose(f["dw_ih"], dw, 1e-5, f"dW_ih dir{k}")
+            relclose(f["db_ih"], db, 1e-5, f"db_ih dir{k}")
+            assert float((f["dgi"] - 7.0).abs().max()) == 0.0
+        else:
+            relclose(f["dgi"], r["dgi"], 1e-6, f"dgi dir{k}")
+
+
 def test_linear_bwd_weight_bf16x3_option_is_bounded():
     """G2V_WGRAD_BF16X3 (opt-in): the 3-term bf16 split of the weight-gradient products stays within 1e-4 (max-norm
     relative) of the exact product at the BASELINE-sized contraction; db stays fp32-exact; default path is unchanged."""
