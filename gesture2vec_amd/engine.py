@@ -395,6 +395,12 @@ class VQVAEEngine:
                                  1.0 / (1.0 - self.p) if drop_in else 1.0,
                                  self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
                                  _p(b["xin"]), H, T * B, D, H, 0, st))
+        # work of branch 0 (rollout masks, ahead-of-time packs): forked HERE, behind the input layer -- beside that HBM-bound
+        # product the mask kernel doubled its time (36 -> 67 us on the main chain), beside the latency-bound GRU it is free
+        side, self._side_work = getattr(self, "_side_work", None), None
+        if side is not None:
+            with self._branch(0):
+                side()
         # H == 64: the input projections x W_ih^T + b_ih are fused into the recurrent kernel (no gi array at all);
         # other sizes compute gi with the dense-layer kernel first
         fuse_gi = (H == 64)
@@ -612,12 +618,13 @@ class VQVAEEngine:
         if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
             self.draw_masks(B, True)
         if self._prepared or (draw_masks and self.p == 0):
-            with self._branch(0):              # beside the encoder forward, joined in forward() before the rollout
+            def side():                        # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the rollout
                 if draw_masks and self.p == 0:
                     self.draw_masks(B, True)   # only the rollout consumes keep95
                 if self._prepared:
                     self.prepare_recurrent(B, "dec")
                     self.prepare_recurrent(B, "gru_bwd")
+            self._side_work = side
         self.forward(x, target, True, ema_update=not dp, trust_wsq=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
