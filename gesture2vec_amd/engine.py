@@ -613,6 +613,7 @@ class VQVAEEngine:
             self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)
         finally:
             self._prepared = False
+            self._side_work = None
 
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
