@@ -1261,6 +1261,11 @@ extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w
 
 extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
   if (M <= 0 || K <= 0 || N <= 0) return 0;
+  if ((M & 15) && M >= 4096 + 16) {      // ragged rows: the whole 16-row groups go through the kernels below as M & ~15 rows
+    const size_t a = g2v_linear_bwd_weight_workspace(M & ~15, K, N);
+    const size_t b = (size_t)tn_splits(M, K, N) * ((size_t)N * K + N) * sizeof(float);
+    return a > b ? a : b;
+  }
   int splits = tn_splits(M, K, N);
   for (int nr = 2; nr <= 4; nr += 2) {       // either row-range variant of the wave-autonomous path
     const int wg = tn_wave_grid(M, K, N, false, nullptr, 1, nr);
@@ -1374,7 +1379,9 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
   if (dB && kt == 0 && q == 0 && nok) dB[n] = accumulate ? dB[n] + dbs : dbs;
 }
 
-static int g_smallm_wgrad_rows = 2048;
+// measured at the reference's own VQ-VAE.yml shape (B = 128, T = 20: 2432 / 2560 rows, 600 x 200): the LDS-tiled kernel + slab
+// pass 20.6 + 7 us per product, so the one-launch form keeps the rows up to 4096
+static int g_smallm_wgrad_rows = 4096;
 
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
@@ -1407,7 +1414,7 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }
-  if (M <= g_smallm_wgrad_rows && M <= g_smallm_max_rows * 2 && rows_inner == 0 && !bf3) {
+  if (M <= g_smallm_wgrad_rows && rows_inner == 0 && !bf3) {
     SmallWgradBatch sb;
     for (int p = 0; p < G2V_TN_BATCH; ++p) {
       const int pp = p < nprob ? p : 0;

@@ -147,7 +147,7 @@ def test_linear_bwd_weight_ragged_rows_through_a_row_map(ops):
 
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
                                    (8192, 200, 600), (4096, 300, 600), (4096, 40, 200), (4112, 600, 514),      # output-blocked wave kernel
-                                   (128, 200, 600), (130, 600, 200), (16, 64, 514), (1024, 200, 600), (1000, 64, 2100),   # small-M data gradient
+                                   (128, 200, 600), (130, 600, 200), (16, 64, 514), (1024, 200, 600), (1000, 64, 2100), (2560, 200, 600), (4096, 40, 200),   # small-M data gradient / weight gradient up to 4096 rows
                                    (8192 + 5, 64, 192), (33 * 4100 // 4, 135, 64), (4096 + 31, 200, 600)])   # ragged rows: whole groups + leftover
 def test_linear_bwd(ops, M, K, N):
     x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.2), rnd(M, N, seed=3)
