@@ -143,6 +143,21 @@ def test_linear_bwd_weight_ragged_rows_through_a_row_map(ops):
     dw, db = ops.linear_bwd_weight(dy.to(DEV), x_btd.to(DEV), H, D, M=T * B, row_map=(B, D, T * D))
     relclose(dw, (dy.double().t() @ x_tbd.double()).float(), 1e-5, "ragged row-mapped weight gradient")
     relclose(db, dy.double().sum(0).float(), 1e-5, "ragged row-mapped bias gradient")
+    # the workspace query covers what the call touches (the whole-group sub-product runs the slab-writing wave kernel):
+    # exact-size workspace with a guard band behind it
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    for (M, K, N, mapped) in ((T * B, D, H, True), (8192 + 5, 64, 192, False), (4096 + 31, 200, 600, False)):
+        nbytes = int(lib.g2v_linear_bwd_weight_workspace(M, K, N))
+        ws = torch.full((nbytes + 65536,), 0x5A, dtype=torch.uint8, device=DEV)
+        dyv, xv = torch.randn(M, N, device=DEV), (x_btd.to(DEV) if mapped else torch.randn(M, K, device=DEV))
+        dw2, db2 = torch.empty(N, K, device=DEV), torch.empty(N, device=DEV)
+        rm = (B, D, T * D) if mapped else (0, 0, 0)
+        rc = lib.g2v_linear_bwd_weight(dyv.data_ptr(), N, xv.data_ptr(), K, rm[0], rm[1], rm[2], None, 1.0, dw2.data_ptr(), db2.data_ptr(),
+                                       M, K, N, 0, ws.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert int((ws[nbytes:] != 0x5A).sum()) == 0, (M, K, N, "wrote past its workspace")
 
 
 @pytest.mark.parametrize("M,K,N", [(200, 135, 64), (37, 50, 150), (5000, 64, 192), (139264 // 8, 64, 192),
