@@ -1071,3 +1071,82 @@ def test_dec_rollout_teacher_forcing_and_unconditioned(ops, T, B, D, H, n_pre, c
              "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
     ops.dec_rollout_bwd(ws, saved, grads, k95, None, 0.0, n_pre, conditioned, T, B, D, H)
     relclose(grads["dh_init"], g_h, 2e-4, "d h_init")
+
+
+def test_every_workspace_user_stays_inside_its_reported_size(ops, monkeypatch):
+    """Each op that takes a caller-owned workspace is run on a buffer of EXACTLY the size its query reports, with a guard band
+    behind it (ops.workspace is patched to hand those out): rollout forward / backward on the persistent path incl. the fused
+    weight gradient's slabs, the GRU's fused weight-gradient slabs, weight gradients (batched, ragged), the sorted embedding
+    gradient, bulk code assignment, code statistics, attention backward."""
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd import ops as ops_mod
+    lib = _lib.load()
+    GUARD, PAT = 1 << 16, 0x5A
+    handed = []
+
+    def exact_workspace(nbytes, device, tag="ws"):
+        buf = torch.full((int(nbytes) + GUARD,), PAT, dtype=torch.uint8, device=device)
+        handed.append((tag, int(nbytes), buf))
+        return buf[:int(nbytes)]
+
+    monkeypatch.setattr(ops_mod, "workspace", exact_workspace)
+    g = torch.Generator().manual_seed(12)
+    # ---- decoder rollout, persistent kernels, fused W_hh1 gradient -------------------------------------------------------------
+    T, B, D, H = 6, 64, 135, 64
+    G = 3 * H
+    sd = _dec_state(D, H, seed=3)
+    wt, _ = _dec_weight_tensors(sd, DEV)
+    ws = ops.dec_weights_struct(wt)
+    nblk = ops.dec_rollout_blocks(B)
+    saved = _alloc_saved(T, B, D, H, nblk, DEV, 0.0)
+    target = torch.randn(B, T, D, generator=g).to(DEV)
+    h_init = (torch.randn(2, B, H, generator=g) * 0.5).to(DEV)
+    k95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8).to(DEV)
+    ops.dec_rollout_fwd(target, h_init, ws, saved, k95, None, 0.0, 1, True, True, T, B, D, H)
+    z = lambda *s: torch.zeros(*s, device=DEV)
+    grads = {"dy": (torch.randn(T, B, D, generator=g) * 1e-3).to(DEV), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G),
+             "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G), "dh_init": z(2, B, H), "d_bn_w": z(H), "d_bn_b": z(H),
+             "bn_bwd_partial": z(2, nblk, 2, H)}
+    if lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H):
+        grads["dw_gru"], grads["db_gru"] = [None, None, None, z(G, H)], [None, None, None, z(G)]
+    ops.dec_rollout_bwd(ws, saved, grads, k95, None, 0.0, 1, True, T, B, D, H)
+    # ---- GRU with fused weight gradients (explicit slab buffers, exact size + guard) -----------------------------------------
+    Tg, Bg = 5, 40
+    x = torch.randn(Tg, Bg, H, generator=g).to(DEV)
+    dirs, slabs = [], []
+    for k in range(2):
+        w_ih, b_ih = (torch.randn(G, H, generator=g) * 0.2).to(DEV), z(G)
+        w_hh, b_hh = (torch.randn(G, H, generator=g) * 0.2).to(DEV), z(G)
+        gi = ops.linear_fwd(x.view(Tg * Bg, H), w_ih, b_ih)
+        hs, h_n, gates = ops.gru_seq_fwd(gi, w_hh, b_hh, Tg, Bg, H, reverse=bool(k))
+        nb = int(lib.g2v_gru_seq_bwd_wslab_bytes(Bg, H))
+        slab = torch.full((nb + GUARD,), PAT, dtype=torch.uint8, device=DEV)
+        slabs.append((nb, slab))
+        dirs.append(dict(d_hs=torch.randn(Tg, Bg, H, generator=g).to(DEV), d_hn=None, hs=hs, h0=None, gates=gates, w_hh=w_hh, dh0=None,
+                         reverse=bool(k), w_ih=w_ih, in_dim=H, dgi=z(Tg, Bg, G), dgh=z(Tg, Bg, G), dx=z(Tg, Bg, H), dw_hh=z(G, H),
+                         db_hh=z(G), dw_ih=z(G, H), db_ih=z(G), x=x, wslab=slab))
+    ops.gru_dirs_bwd(dirs, Tg, Bg, H)
+    # ---- the rest ----------------------------------------------------------------------------------------------------------------
+    for (M, K, N) in ((8192 + 5, 64, 192), (4096 + 31, 200, 600), (640, 200, 600), (5000, 64, 192)):
+        ops.linear_bwd_weight(torch.randn(M, N, device=DEV), torch.randn(M, K, device=DEV), N, K)
+    items = [(torch.randn(8192, 192, device=DEV), torch.randn(8192, 64, device=DEV), z(192, 64), z(192)) for _ in range(4)]
+    ops.linear_bwd_weight_batch(items, 192, 64, M=8192)
+    for (V, dim, n) in ((3863, 300, 25 * 128), (514, 200, 30 * 4096), (300, 64, 700)):
+        ids = torch.randint(0, V, (n,), generator=g).to(DEV)
+        ops.embedding_bwd(torch.randn(n, dim, device=DEV), ids, V)
+    W = torch.randn(512, 128, device=DEV)
+    flat = torch.randn(20000 + 37, 128, device=DEV)
+    wsq = ops.vq_code_sqnorm(W)
+    idx = ops.vq_assign_bulk(flat, W, wsq)
+    ops.vq_stats(idx, flat, 512)
+    Ta, Ba = 9, 33
+    enc, ep = torch.randn(Ta, Ba, H, device=DEV), torch.randn(Ta, Ba, H, device=DEV)
+    hp, v = torch.randn(Ba, H, device=DEV), torch.randn(H, device=DEV)
+    wts, ctx = ops.attn_fwd(hp, ep, enc, v)
+    ops.attn_bwd(torch.randn(Ba, H, device=DEV), hp, ep, enc, v, wts)
+    torch.cuda.synchronize()
+    assert len(handed) >= 10
+    for tag, nbytes, buf in handed:
+        assert int((buf[nbytes:] != PAT).sum()) == 0, f"{tag}: wrote past its {nbytes}-byte workspace"
+    for nb, slab in slabs:
+        assert int((slab[nb:] != PAT).sum()) == 0, "GRU weight-gradient slabs overran"
