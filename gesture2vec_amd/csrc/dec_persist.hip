@@ -169,6 +169,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
   const float keep_scale = 1.0f / (1.0f - a.p_drop);
   const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
+  const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
+  float run_m = 0.f, run_v = 0.f;                    // BatchNorm running statistics (workgroup 0, tid < H)
+  if (training && b == 0 && tid < H) {
+    run_m = a.w.bn_running_mean[tid];
+    run_v = a.w.bn_running_var[tid];
+  }
 
   // ---- prologue: weights into registers / LDS ---------------------------------------------------------------------
   WFrag<3, KSH> f_ih0, f_hh0, f_ih1, f_hh1;
@@ -258,6 +264,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
             a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + tid] = mean;
             a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + tid] = var;
           }
+          // running statistics (momentum 0.1, unbiased variance), one update per step in step order: workgroup 0 carries
+          // them in registers and writes them back once (this was a launch of its own behind the rollout)
+          run_m = 0.9f * run_m + 0.1f * mean;
+          run_v = 0.9f * run_v + 0.1f * (var * unbias);
         }
         lds_barrier();
       }
@@ -424,6 +434,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     if (fast_dense) dense_stores();
     PSTAMP(0, 8);
     // (no barrier needed here: the next writers of Xy / Yt / Xt sit behind the barriers of step t+1)
+  }
+  if (training && b == 0 && tid < H) {
+    a.w.bn_running_mean[tid] = run_m;
+    a.w.bn_running_var[tid] = run_v;
   }
 }
 

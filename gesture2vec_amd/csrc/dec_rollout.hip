@@ -1780,13 +1780,7 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
       void* xbase = (char*)workspace + fwd_pack_bytes_aligned(D, H);
       const int rc = dec_persist_fwd_launch(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T,
                                             B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st, !prepared);
-      if (rc != G2V_OK) return rc;
-      if (training) {
-        hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, s->bn_stats,
-                           w->bn_running_mean, w->bn_running_var, T - 1, H, B);
-        G2V_CHECK_LAUNCH();
-      }
-      return G2V_OK;
+      return rc;       // (the running statistics are updated by the kernel itself)
     }
   }
   if (lds > 48 * 1024) {
