@@ -332,6 +332,13 @@ def main():
         }
         if world == 1:
             out["roofline"] = vq_kernel_roofline(eng, B)
+            # the whole step as EXECUTED (the dead encoder layer 1 of the reference is skipped): forward
+            # flop per chunk x 3 (backward = data + weight gradients), against the same fp32 MFMA peak
+            T, D, H, E, K = CFG["T"], CFG["D"], CFG["H"], eng.E, eng.K
+            fl = 3.0 * (2 * T * D * H + 24 * T * H * H + (T - 1) * (4 * D * H + 24 * H * H) + 2 * E * E + 2 * K * E) * B
+            tf = fl / (dt / a.steps) / 1e12
+            out["roofline"]["whole_step"] = {"flops_executed": fl, "achieved": round(tf, 2), "unit": "TFLOP/s",
+                                             "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4)}
             try:
                 cal = calibrate(lib)
                 out["roofline"]["measured_on_this_box"] = cal

@@ -733,15 +733,22 @@ struct TnBatch {
   const float* x[G2V_TN_BATCH];
   float* slab[G2V_TN_BATCH];
   float* slab_db[G2V_TN_BATCH];
+  const float* dy2[G2V_TN_BATCH];     // DUAL instantiations: the product is (dy + dy2)^T x, the sum formed at use time
 };
 
-template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR = 4, bool GEN = false>
+template <int TN_, int TK_, int SN, int SK, bool MAPPED, int VW, bool BF3, int NR = 4, bool GEN = false, bool DUAL = false>
 __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, const RowMap& xm, int M, int K, int N,
                                              int rows_per_wave) {
   const float* __restrict__ dY = bt.dy[blockIdx.y];
   const float* __restrict__ X = bt.x[blockIdx.y];
   float* __restrict__ slab = bt.slab[blockIdx.y];
   float* __restrict__ slab_db = bt.slab_db[blockIdx.y];
+  // DUAL (the encoder input layer: dx arrives as one array per GRU direction): the second addend travels in columns
+  // TN_ .. 2 TN_ - 1 of the same operand buffers and is added when the fragment is used -- the same sum-then-multiply
+  // arithmetic as a separate add pass, without its 3 x M x N x 4 bytes of traffic
+  static_assert(!DUAL || (VW == 1 && !BF3 && !GEN), "two-addend operand: dword loads, fp32 products");
+  constexpr int TA = DUAL ? 2 * TN_ : TN_;
+  const float* __restrict__ dY2 = DUAL ? bt.dy2[blockIdx.y] : nullptr;
   // NR row ranges x two tile groups.  NR = 2 (256 threads, ONE wave per SIMD, one workgroup per CU) is what the fp32 path
   // launches: with the operand loads interleaved between its MFMAs a single wave keeps the matrix pipe busy on its own, and
   // compared with NR = 4 (two waves per SIMD) every wave walks twice the rows and the final sum is 2-way (measured at the
@@ -789,8 +796,8 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   const bool okn = n0 + 16 * (TN_ - 1) + i < N, okk = k0 + 16 * (TK_ - 1) + i < K;
   const int in_last = okn ? i : 0, ik_last = okk ? i : 0;
 
-  float ca[4][TN_], cb[4][TK_], na[4][TN_], nb[4][TK_], ea[TRIPLE ? 4 : 1][TRIPLE ? TN_ : 1], eb[TRIPLE ? 4 : 1][TRIPLE ? TK_ : 1];
-  auto load_group = [&](int m0, float (&a)[4][TN_], float (&b)[4][TK_]) {
+  float ca[4][TA], cb[4][TK_], na[4][TA], nb[4][TK_], ea[TRIPLE ? 4 : 1][TRIPLE ? TA : 1], eb[TRIPLE ? 4 : 1][TRIPLE ? TK_ : 1];
+  auto load_group = [&](int m0, float (&a)[4][TA], float (&b)[4][TK_]) {
     // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
     // (B,T,D) -> (T,B,D) row map, then the three following row quads step the (outer, inner) pair.
     // fp32 MFMA (16x16x4): k-slot q of step qd is row m0 + 4 qd + q.  bf16 MFMA (16x16x16): lane group q supplies the four
@@ -829,6 +836,12 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
 #pragma unroll
       for (int u = 0; u < TK_ - 1; ++u) b[qd][u] = xri[16 * u];
       b[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+      if constexpr (DUAL) {
+        const float* d2 = dY2 + (int64_t)mrow * lddy + n0;
+#pragma unroll
+        for (int t = 0; t < TN_ - 1; ++t) a[qd][TN_ + t] = d2[16 * t + i];
+        a[qd][2 * TN_ - 1] = d2[16 * (TN_ - 1) + in_last];
+      }
       }
       mrow += RSTEP;
       if (MAPPED) {
@@ -837,12 +850,16 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
       }
     }
   };
-  auto compute = [&](float (&a)[4][TN_], float (&b)[4][TK_]) {
+  auto compute = [&](float (&a)[4][TA], float (&b)[4][TK_]) {
 #pragma unroll
     for (int qd = 0; qd < 4; ++qd) {
       if constexpr (VW == 1 && !GEN) {
         a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;   // ragged last tiles: the clamped column is masked at use time
         b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
+      }
+      if constexpr (DUAL) {
+#pragma unroll
+        for (int t = 0; t < TN_; ++t) a[qd][t] += (t < TN_ - 1 || okn) ? a[qd][TN_ + t] : 0.f;
       }
     }
     if constexpr (BF3) {
@@ -880,8 +897,8 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   // fp32 path: multiply group (a, b) while the operand loads of group `mn` are issued BETWEEN the MFMAs into (an, bn): a
   // burst of 20-40 loads in front of the 96 MFMAs stalls the wave on the CU's vector-memory front end with an idle matrix
   // pipe; one load per few MFMAs is absorbed at the rate the front end accepts it.
-  auto compute_and_load = [&](float (&a)[4][TN_], float (&b)[4][TK_], int mn, float (&an)[4][TN_], float (&bn)[4][TK_]) {
-    constexpr int NMQ = TN_ * TK_, NLQ = (TN_ + TK_) / VW;
+  auto compute_and_load = [&](float (&a)[4][TA], float (&b)[4][TK_], int mn, float (&an)[4][TA], float (&bn)[4][TK_]) {
+    constexpr int NMQ = TN_ * TK_, NLQ = (TA + TK_) / VW;
     constexpr int STRIDE = (NMQ / NLQ) > 0 ? (NMQ / NLQ) : 1;
     int mrow = mn + q, outer = 0, inner = 0;
     if (MAPPED) { outer = mrow / xm.rows_inner; inner = mrow - outer * xm.rows_inner; }
@@ -891,7 +908,12 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
         a[qd][TN_ - 1] = okn ? a[qd][TN_ - 1] : 0.f;
         b[qd][TK_ - 1] = okk ? b[qd][TK_ - 1] : 0.f;
       }
+      if constexpr (DUAL) {
+#pragma unroll
+        for (int t = 0; t < TN_; ++t) a[qd][t] += (t < TN_ - 1 || okn) ? a[qd][TN_ + t] : 0.f;
+      }
       const float* dr = dY + (int64_t)mrow * lddy + n0;
+      const float* dr2 = DUAL ? dY2 + (int64_t)mrow * lddy + n0 : nullptr;
       const float* xr = X + (MAPPED ? (int64_t)outer * xm.so + (int64_t)inner * xm.si : (int64_t)mrow * xm.ld) + k0;
       auto issue = [&](int k) {
         if constexpr (VW == 2) {
@@ -912,7 +934,11 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
           if (k < TN_ - 1) an[qd][k] = dr[16 * k + i];
           else if (k == TN_ - 1) an[qd][k] = dr[16 * (TN_ - 1) + in_last];
           else if (k < TN_ + TK_ - 1) bn[qd][k - TN_] = xr[16 * (k - TN_) + i];
-          else bn[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+          else if (k == TN_ + TK_ - 1) bn[qd][TK_ - 1] = xr[16 * (TK_ - 1) + ik_last];
+          else if constexpr (DUAL) {
+            if (k < 2 * TN_ + TK_ - 1) an[qd][k - TK_] = dr2[16 * (k - TN_ - TK_) + i];
+            else an[qd][2 * TN_ - 1] = dr2[16 * (TN_ - 1) + in_last];
+          }
         }
       };
 #pragma unroll
@@ -1060,6 +1086,14 @@ __global__ __launch_bounds__(128 * NR) __attribute__((amdgpu_num_vgpr(128))) voi
                                                                                                       int N, int rows_per_wave) {
   static_assert(SN * SK == 2, "two tile groups per workgroup");
   tn_wave_body<TN_, TK_, SN, SK, MAPPED, VW, BF3, NR>(bt, lddy, xm, M, K, N, rows_per_wave);
+}
+
+// (dy + dy2)^T x for the 64 x 135 input-layer shape (see DUAL in tn_wave_body)
+template <bool MAPPED>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) void gemm_tn_wave_dual_kernel(TnBatch bt, int64_t lddy,
+                                                                                                      RowMap xm, int M, int K,
+                                                                                                      int N, int rows_per_wave) {
+  tn_wave_body<2, 9, 2, 1, MAPPED, 1, false, 2, false, true>(bt, lddy, xm, M, K, N, rows_per_wave);
 }
 
 // Output-blocked variant for weight matrices larger than one workgroup's accumulators (H = 200: 600 x 200, 600 x 300 ...):
@@ -1388,9 +1422,20 @@ static int g_smallm_wgrad_rows = 4096;
 struct WgradItem {
   const float* dy; const float* x; float* dw; float* db;
 };
+// (dy_a + dy_b)^T x is served by the wave-autonomous kernel's two-addend instantiation: 64 x 135-shaped dW, whole 16-row
+// groups, more rows than the small-M kernel takes
+static bool wgrad_sum2_ok(int M, int K, int N) {
+  int rpw = 0;
+  return M > g_smallm_wgrad_rows && (M & 15) == 0 && cdiv(N, 16) == 4 && cdiv(K, 16) == 9 &&
+         tn_wave_grid(M, K, N, false, &rpw, 1, 2) > 0;
+}
 static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx, int rows_inner, int64_t stride_outer,
                       int64_t stride_inner, const uint8_t* x_keep, float x_scale, int M, int K, int N, int flags,
-                      float* workspace, g2v_stream_t stream) {
+                      float* workspace, g2v_stream_t stream, const float* dy2 = nullptr) {
+  if (dy2 && !wgrad_sum2_ok(M, K, N)) {
+    set_error("g2v_linear_bwd_weight_sum2: shape not served (see g2v_linear_bwd_weight_sum2_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   const int accumulate = flags & G2V_WGRAD_ACCUMULATE;
   const bool bf3 = (flags & G2V_WGRAD_BF16X3) != 0;
   if ((M & 15) && M >= 4096 + 16 && !x_keep) {
@@ -1457,6 +1502,7 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     for (int p = 0; p < G2V_TN_BATCH; ++p) {
       const int pp = p < nprob ? p : 0;
       bt.dy[p] = it[pp].dy; bt.x[p] = it[pp].x; bt.slab[p] = slab_of(pp); bt.slab_db[p] = slab_db_of(pp);
+      bt.dy2[p] = dy2;
       vec2 = vec2 && (reinterpret_cast<uintptr_t>(it[pp].dy) % 8 == 0) && (reinterpret_cast<uintptr_t>(it[pp].x) % 8 == 0);
       all_db = all_db && (it[pp].db != nullptr);
     }
@@ -1489,7 +1535,17 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     else { if (rows_inner > 0) G2V_TNW2(TN_, TK_, SN, SK, VW, false, 2, true); else G2V_TNW2(TN_, TK_, SN, SK, VW, false, 2, false); }  \
   } while (0)
     // 8-byte vector operand loads need 8-byte-aligned rows on both sides and whole tiles (checked above)
-    if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
+    if (dy2) {
+      const size_t lds = ((size_t)2 * 2 * 9 * 256 + 2 * 2 * 2 * 16) * sizeof(float);
+      if (rows_inner > 0) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wave_dual_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gemm_tn_wave_dual_kernel<true>, dim3(wg, 1), dim3(256), lds, (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);
+      } else {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_wave_dual_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(gemm_tn_wave_dual_kernel<false>, dim3(wg, 1), dim3(256), lds, (hipStream_t)stream, bt, lddy, xm, M, K, N, rpw);
+      }
+    }
+    else if (tn == 12 && tk == 4) { if (vec2) G2V_TNW(6, 4, 2, 1, 2); else G2V_TNW(6, 4, 2, 1, 1); }
     else if (tn == 4 && tk == 9) G2V_TNW(2, 9, 2, 1, 1);
     else if (tn == 9 && tk == 4) G2V_TNW(9, 2, 1, 2, 1);
     else { if (vec2) G2V_TNW(2, 4, 2, 1, 2); else G2V_TNW(2, 4, 2, 1, 1); }
@@ -1539,6 +1595,23 @@ extern "C" int g2v_linear_bwd_weight(const float* dy, int64_t lddy, const float*
   const WgradItem item{dy, x, dw, db};
   return wgrad_impl(&item, 1, lddy, ldx, rows_inner, stride_outer, stride_inner, x_keep, x_scale, M, K, N, accumulate,
                     (float*)workspace, stream);
+}
+
+extern "C" int g2v_linear_bwd_weight_sum2_ok(int M, int K, int N) { return wgrad_sum2_ok(M, K, N) ? 1 : 0; }
+
+extern "C" int g2v_linear_bwd_weight_sum2(const float* dy_a, const float* dy_b, int64_t lddy, const float* x, int64_t ldx,
+                                          int rows_inner, int64_t stride_outer, int64_t stride_inner, float* dw, float* db,
+                                          int M, int K, int N, int accumulate, void* workspace, size_t workspace_bytes,
+                                          g2v_stream_t stream) {
+  G2V_REQUIRE(dy_a && dy_b && x && dw && workspace, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  if (workspace_bytes < g2v_linear_bwd_weight_workspace(M, K, N)) {
+    set_error("g2v_linear_bwd_weight_sum2: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const WgradItem item{dy_a, x, dw, db};
+  return wgrad_impl(&item, 1, lddy, ldx, rows_inner, stride_outer, stride_inner, nullptr, 1.0f, M, K, N,
+                    accumulate ? G2V_WGRAD_ACCUMULATE : 0, (float*)workspace, stream, dy_b);
 }
 
 extern "C" int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int M, int K,

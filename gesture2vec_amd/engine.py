@@ -571,6 +571,15 @@ class VQVAEEngine:
                 items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
             if b["enc_fused_wgrad"] < 2:
                 wgrad4s(TB, items)
+        sum2 = (H == 64 and not drop and not self.wgrad_bf16x3 and os.environ.get("G2V_WGRAD_SUM2", "1") != "0"
+                and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H))
+        if sum2:
+            # the two directions' dx are summed inside the input layer's weight-gradient product (no add pass)
+            check(lib.g2v_linear_bwd_weight_sum2(_p(b["gi_f"]), _p(b["gi_b"]), H, _p(in_poses), D, B, D, T * D,
+                                                 self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"),
+                                                 TB, D, H, 0, ws, wsn, st))
+            self._join(4)
+            return
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
         else:

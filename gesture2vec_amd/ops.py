@@ -115,6 +115,23 @@ def linear_bwd_weight(dy, x, N, K, *, M=None, lddy=None, ldx=None, row_map=None,
     return dw, db
 
 
+def linear_bwd_weight_sum2(dy_a, dy_b, x, N, K, *, M, lddy=None, ldx=None, row_map=None, dw=None, db=None, want_bias=True,
+                           accumulate=False):
+    """dw = (dy_a + dy_b)^T x (+ db) without the add pass; raises for shapes g2v_linear_bwd_weight_sum2_ok() rejects."""
+    dev = dy_a.device
+    if dw is None:
+        dw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    if db is None and want_bias:
+        db = torch.empty((N,), dtype=torch.float32, device=dev)
+    lib = _lib_()
+    ws = workspace(lib.g2v_linear_bwd_weight_workspace(M, K, N), dev, "bwdw")
+    ri, so, si = row_map if row_map is not None else (0, 0, 0)
+    check(lib.g2v_linear_bwd_weight_sum2(_p(dy_a), _p(dy_b), lddy if lddy is not None else N, _p(x),
+                                         ldx if ldx is not None else K, ri, so, si, _p(dw), _p(db), M, K, N,
+                                         int(bool(accumulate)), _p(ws), ws.numel(), _stream()), "linear_bwd_weight_sum2")
+    return dw, db
+
+
 def linear_bwd_weight_batch(items, N, K, *, M, lddy=None, ldx=None, accumulate=False, bf16x3=False):
     """items: up to 4 tuples (dy, x, dw, db-or-None) of ONE shape -> one launch + one slab reduction (large M)."""
     lib = _lib_()

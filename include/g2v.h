@@ -87,6 +87,16 @@ typedef struct {
 int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int M, int K, int N,
                                 int flags, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
+/* dw = (dy_a + dy_b)^T x (+ db = column sums of dy_a + dy_b): the addends are summed as the operand fragments are used --
+ * the arithmetic of "add, then g2v_linear_bwd_weight" without the add pass.  The encoder's input layer uses it: its dx
+ * arrives as one array per GRU direction (ref Autoencoder_VQVAE_model.py:447-464, the bidirectional nn.GRU's input
+ * gradient).  Served for dW shapes of 4 x 9 tiles (64 x 135) with M % 16 == 0 above the small-M threshold:
+ * g2v_linear_bwd_weight_sum2_ok() says so, G2V_ERR_UNSUPPORTED otherwise.  Row addressing of x and workspace as for
+ * g2v_linear_bwd_weight. */
+int g2v_linear_bwd_weight_sum2_ok(int M, int K, int N);
+int g2v_linear_bwd_weight_sum2(const float* dy_a, const float* dy_b, int64_t lddy, const float* x, int64_t ldx, int rows_inner,
+                               int64_t stride_outer, int64_t stride_inner, float* dw, float* db, int M, int K, int N,
+                               int accumulate, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 int g2v_linear_bwd_weight(const float* dy, int64_t lddy,
                           const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                           const uint8_t* x_keep, float x_scale,

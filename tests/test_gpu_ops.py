@@ -133,6 +133,29 @@ def test_linear_fwd_rowmap_and_mask(ops):
     relclose(db, dy.sum(0), 5e-6, "bwd_bias")
 
 
+@pytest.mark.parametrize("B,T,mapped", [(256, 34, True), (512, 9, False), (4096, 34, True)])
+def test_linear_bwd_weight_of_a_two_addend_gradient(ops, B, T, mapped):
+    """(dy_a + dy_b)^T x in one product (the encoder input layer: one dx per GRU direction,
+    ref Autoencoder_VQVAE_model.py:447-464) is BITWISE the add pass followed by the plain product, and matches float64."""
+    from gesture2vec_amd import _lib
+    D, H, M = 135, 64, T * B
+    assert _lib.load().g2v_linear_bwd_weight_sum2_ok(M, D, H) == 1
+    assert _lib.load().g2v_linear_bwd_weight_sum2_ok(M + 1, D, H) == 0 and _lib.load().g2v_linear_bwd_weight_sum2_ok(M, 64, 192) == 0
+    da, db_ = rnd(M, H, seed=51).to(DEV), rnd(M, H, seed=52).to(DEV)
+    x = rnd(B, T, D, seed=53).to(DEV) if mapped else rnd(M, D, seed=53).to(DEV)
+    rm = (B, D, T * D) if mapped else None
+    dw, db = ops.linear_bwd_weight_sum2(da, db_, x, H, D, M=M, row_map=rm)
+    s = torch.empty_like(da)
+    ops.add_halves(da, H, db_, H, s, H, M, H)
+    dw2, db2 = ops.linear_bwd_weight(s, x, H, D, M=M, row_map=rm)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)
+    xr = (x.transpose(0, 1).reshape(M, D) if mapped else x).double()
+    relclose(dw, ((da.double() + db_.double()).t() @ xr).float(), 1e-5, "two-addend weight gradient")
+    relclose(db, (da.double() + db_.double()).sum(0).float(), 1e-5, "two-addend bias gradient")
+    with pytest.raises(RuntimeError):
+        ops.linear_bwd_weight_sum2(da[:100], db_[:100], x, H, D, M=100)
+
+
 def test_linear_bwd_weight_ragged_rows_through_a_row_map(ops):
     """The in_layer gradient of a ragged batch (T B % 16 != 0, x (B,T,D) read in (T,B) order): whole 16-row groups on the
     wave-autonomous kernel, the leftover rows through the same row map on the small-M kernel."""
