@@ -13,6 +13,9 @@
 //               previous step's partial sums is in flight] -> exchange -> BN + ReLU -> cell 0 -> cell 1 -> out layer ->
 //               Dropout(0.95) -> pre_linear -> partial sums -> publish
 #include "dec_persist.hpp"
+#ifndef G2V_BWD_EPI
+#define G2V_BWD_EPI 1
+#endif
 
 #ifdef G2V_PSTAMPS      // diagnostic build only (gpurun_tools/pstamps.py): shader-clock stamps of one step of four workgroups
 __device__ unsigned long long g2v_pstamps[2 * 4 * 24];
@@ -328,18 +331,36 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         }
         const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
         const bool fast_y = has_next && !(t < a.n_pre);
+        // Every LDS read of the epilogue is issued up front and unconditionally (columns past D read in-bounds padding;
+        // the padding tiles 9..11 re-read tile 0): reads under the per-element `d < D` test were compiled into 24
+        // dependent LDS round trips, each behind its own s_waitcnt (~3000 cycles per step).  Only the stores are predicated.
+        float bo[3][4], yv[3][4], xv[3][4];
+        uint32_t kb[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int d0 = 16 * (wave + 4 * j) + 4 * q, d0c = d0 < Dp ? d0 : 4 * q;
+          const float4 b4 = *reinterpret_cast<const float4*>(Bs + B_OUT + d0c);
+          bo[j][0] = b4.x; bo[j][1] = b4.y; bo[j][2] = b4.z; bo[j][3] = b4.w;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) kb[j][r] = Kb[i * D + d0c + r];
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            yv[j][r] = acc[j][r] + bo[j][r];
+            xv[j][r] = kb[j][r] ? yv[j][r] * 20.0f : 0.f;      // next decoder input = Dropout(0.95)(y_t): 1 / (1 - 0.95) = 20  (:568-570)
+          }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
           const int d0 = 16 * (wave + 4 * j) + 4 * q;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             if (d0 + r < D) {
-              const float y = acc[j][r] + Bs[B_OUT + d0 + r];
-              Yt[i * D + d0 + r] = y;
-              if (fast_y) {      // next decoder input = Dropout(0.95)(y_t): 1 / (1 - 0.95) = 20  (:568-570)
-                const float xin = Kb[i * D + d0 + r] ? y * 20.0f : 0.f;
-                Xt[i * D + d0 + r] = xin;
-                Xy[i * LDD + d0 + r] = xin;
+              Yt[i * D + d0 + r] = yv[j][r];
+              if (fast_y) {
+                Xt[i * D + d0 + r] = xv[j][r];
+                Xy[i * LDD + d0 + r] = xv[j][r];
               }
             }
         }
@@ -728,14 +749,43 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (feedback) {
+        // the LDS addresses of these fragment reads are recomputed every step (the compiler cannot hoist past the empty
+        // asm): as loop invariants they were spilled to scratch and reloaded here behind an s_waitcnt vmcnt(0)
+        int lane_r = lane;
+        asm volatile("" : "+v"(lane_r));
         if (wave == 0) {
-          lds_frag_mma<3, KSH>(acc, Ppre_t, wave, 4, Xdu, LDH, lane);
+          lds_frag_mma<3, KSH>(acc, Ppre_t, wave, 4, Xdu, LDH, lane_r);
         } else {
           f32x4 a2[2] = {acc[0], acc[1]};
-          lds_frag_mma<2, KSH>(a2, Ppre_t, wave, 4, Xdu, LDH, lane);
+          lds_frag_mma<2, KSH>(a2, Ppre_t, wave, 4, Xdu, LDH, lane_r);
           acc[0] = a2[0]; acc[1] = a2[1];
         }
       }
+#if G2V_BWD_EPI
+      // LDS reads of a tile issued together and unconditionally, stores predicated (see the forward kernel's out-layer
+      // epilogue); one tile at a time: all three at once cost 24 live registers this kernel does not have (scratch spills)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int d0 = 16 * (wave + 4 * j) + 4 * q, d0c = d0 < Dp ? d0 : 4 * q;
+        float dyv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dyv[r] = Dt[i * D + d0c + r];
+        // the four keep bytes of the (unaligned, D is odd) run: two aligned words through v_alignbyte
+        const int kbyte = i * D + d0c;
+        const uint32_t klo = Kt[kbyte >> 2], khi = Kt[(kbyte >> 2) + 1];
+        const uint32_t kb4 = __builtin_amdgcn_alignbyte(khi, klo, (uint32_t)(kbyte & 3));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dyv[r] = (feedback && ((kb4 >> (8 * r)) & 0xffu)) ? dyv[r] + acc[j][r] * 20.0f : dyv[r];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int d = d0 + r;
+          if (d < D) {
+            Dt[i * D + d] = dyv[r];
+            Xdy[i * LDD + d] = dyv[r];
+          }
+        }
+      }
+#else
       const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -751,6 +801,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
           }
         }
       }
+#endif
     }
     lds_barrier();
     if (feedback)
