@@ -404,8 +404,14 @@ __device__ __forceinline__ float4 ld4_or_zero(const float* p, bool ok) {
   return ok ? *reinterpret_cast<const float4*>(p) : make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return __frcp_rn(1.0f + __expf(-x)); }
-__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __frcp_rn(1.0f + __expf(2.0f * x)); }
+// v_rcp_f32 / v_rsq_f32 (1 ulp) instead of the correctly rounded division: __frcp_rn and 1.0f / sqrtf() expand to the
+// ten-instruction IEEE sequence (v_div_scale x2, v_rcp, 4 x v_fma, v_div_fmas, v_div_fixup), twelve of them per lane in a GRU
+// cell epilogue that sits between two dependent MFMA phases of the recurrent kernels (~120 of its ~270 VALU instructions).
+// The exponent next to it (__expf = v_exp_f32) is a 1-2 ulp approximation already.
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __expf(2.0f * x)); }
+// 1 / sqrt(var + eps) of BatchNorm1d (eps = 1e-5), forward and backward of the decoder kernels use the same function
+__device__ __forceinline__ float bn_invstd_(float var) { return __builtin_amdgcn_rsqf(var + 1e-5f); }
 
 // sum over the 16 lanes that share lane>>4 (i.e. over j = lane & 15)
 // Sum over the 16 lanes of a DPP row (= the 16 batch rows of an MFMA tile), result in every lane.  Same pairwise tree

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     Bs[B_BNB + tid] = a.w.bn_b[tid];
     if (!training) {
       st[tid] = a.w.bn_running_mean[tid];
-      st[H + tid] = 1.0f / sqrtf(a.w.bn_running_var[tid] + 1e-5f);
+      st[H + tid] = bn_invstd_(a.w.bn_running_var[tid]);
     }
   }
   // zero the padding columns of the operand tiles once (the live columns are rewritten every step)
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);       // biased batch variance
           const float mean = mv + Bs[B_PRE + tid];
           st[tid] = mean;
-          st[H + tid] = 1.0f / sqrtf(var + 1e-5f);
+          st[H + tid] = bn_invstd_(var);
           if (b == 0 && a.sv.bn_stats) {
             a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + tid] = mean;
             a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + tid] = var;
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
       float s1[4], s2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float invstd = bn_invstd_(vv[r]);
         dbn[r] = (av[r] > 0.f) ? a2[r] : 0.f;
         xhat[r] = (uv[r] - mv[r]) * invstd;
         gis[r] = gg[r] * invstd;

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);   // biased batch variance
         const float mean = mv + w.b_pre[f];
         st[f] = mean;
-        st[Hp + f] = 1.0f / sqrtf(var + 1e-5f);
+        st[Hp + f] = bn_invstd_(var);
         if (blockIdx.x == 0) {
           sv.bn_stats[(int64_t)(t - 1) * 2 * H + f] = mean;
           sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + f] = var;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       if (early) early_products([](int) {});
       for (int f = tid; f < H; f += 256) {
         st[f] = w.bn_running_mean[f];
-        st[Hp + f] = 1.0f / sqrtf(w.bn_running_var[f] + 1e-5f);
+        st[Hp + f] = bn_invstd_(w.bn_running_var[f]);
       }
     }
     lds_barrier();
@@ -830,7 +830,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
         float du[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+          const float invstd = bn_invstd_(vv[r]);
           const float xhat = (uu[r] - mm[r]) * invstd;
           du[r] = gg[r] * invstd * (db[r] - a1[r] * invB - xhat * a2[r] * invB);
         }
@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
         const int r = e / H, f = e - r * H;
         if (r >= nrows) continue;
         const int64_t row = ((int64_t)t * B + b0 + r) * H + f;
-        const float invstd = 1.0f / sqrtf(stats[H + f] + 1e-5f);
+        const float invstd = bn_invstd_(stats[H + f]);
         const float xhat = (sv.u[row] - stats[f]) * invstd;
         const float du = w.bn_w[f] * invstd * (gr.dbn[row] - st[f] * invB - xhat * st[Hp + f] * invB);
         gr.du[row] = du;
@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
         const bool ok = (f < H) && (i < nrows);
         cw[r] = Dd[i * ldh + ((f < Hp) ? f : 0)] + a1[0][r];
         dbn[r] = (ok && av[r] > 0.f) ? a2[0][r] : 0.f;
-        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float invstd = bn_invstd_(vv[r]);
         const float dbx = ok ? dbn[r] * ((uv[r] - mv[r]) * invstd) : 0.f;
         s1[r] = reduce16(dbn[r]);
         s2[r] = reduce16(dbx);
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(128) void dec_cell_split_kernel(DecCellArgs a, int 
         var = a.run_var[f];
       }
       st[f] = mean;
-      st[16 * DSPLIT_KS + f] = 1.0f / sqrtf(var + 1e-5f);
+      st[16 * DSPLIT_KS + f] = bn_invstd_(var);
     }
     __syncthreads();
     if (wave == 0) {
@@ -1520,7 +1520,7 @@ __global__ __launch_bounds__(64) void dec_bwd_dy_split_kernel(DecBwdDyArgs a, in
       float du[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float invstd = bn_invstd_(vv[r]);
         const float xhat = (uu[r] - mm[r]) * invstd;
         du[r] = rvalid ? gg[r] * invstd * (db[r] - a1[r] * invB - xhat * a2[r] * invB) : 0.f;
       }
@@ -1695,7 +1695,7 @@ __global__ __launch_bounds__(128) void dec_bwd_pair_split_kernel(DecBwdPairArgs 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         dbn[r] = av[r] > 0.f ? acc[r] : 0.f;
-        const float invstd = 1.0f / sqrtf(vv[r] + 1e-5f);
+        const float invstd = bn_invstd_(vv[r]);
         dbx[r] = dbn[r] * ((uv[r] - mv[r]) * invstd);
       }
       *reinterpret_cast<float4*>(a.dbn + (int64_t)b * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
