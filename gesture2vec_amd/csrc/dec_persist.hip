@@ -103,6 +103,28 @@ __device__ __forceinline__ void lds_frag_mma(f32x4 (&acc)[NT], const float* P, i
   }
 }
 
+// frag_mma with every operand fragment of the activation tile requested before the first MFMA: one wave per SIMD, so a
+// ds_read + s_waitcnt lgkmcnt(0) in front of each k-step's 12 MFMAs leaves the matrix pipe idle for most of an LDS round
+// trip, four times per product
+template <int NT, int KS_T>
+__device__ __forceinline__ void frag_mma_x1st(f32x4 (&acc)[NT], const WFrag<NT, KS_T>& f, const float* Xs, int ldx, int lane) {
+  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+  float4 xb[KS_T];
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) xb[s] = *reinterpret_cast<const float4*>(xrow + 16 * s);
+#pragma unroll
+  for (int s = 0; s < KS_T; ++s) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].x, xb[s].x, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].y, xb[s].y, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].z, xb[s].z, acc[t]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = mfma16(f.w[t][s].w, xb[s].w, acc[t]);
+  }
+}
+
 // Gate math of one GRU cell for the 4 consecutive features [f0, f0+4) of batch row i held by this lane.
 // Reads h_prev from Xh (own columns) and overwrites it IN PLACE with h_new (the next step's hidden-side operand);
 // Xnext gets the (optionally dropped) value the next layer consumes.  Global: h_out, gates (r,z,n,ghn), dropped copy.
@@ -244,9 +266,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       // The exchange is threaded through the two products: the row's records, published at the end of the previous step,
       // have arrived when the first product is done (hop 1: row sum, published again), and the row sums of the other rows
       // travel while the second product runs (hop 2).
-      frag_mma(gh0, f_hh0, Xh0, LDH, lane);
+      frag_mma_x1st(gh0, f_hh0, Xh0, LDH, lane);
       if (training) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
-      frag_mma(gh1, f_hh1, Xh1, LDH, lane);
+      frag_mma_x1st(gh1, f_hh1, Xh1, LDH, lane);
       PSTAMP(0, 1);
 #pragma unroll
       for (int j = 0; j < 3; ++j) {
@@ -297,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         f32x4 ai[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        frag_mma(ai, f_ih0, Xa, LDH, lane);
+        frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
         cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
                       a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
                       a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
@@ -310,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         f32x4 ai[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        frag_mma(ai, f_ih1, Xx1, LDH, lane);
+        frag_mma_x1st(ai, f_ih1, Xx1, LDH, lane);
         cell_epilogue(ai, gh1, Bs + B_IH1, Bs + B_HH1, 0x01010101u, false, 1.0f, Xh1, nullptr,
                       a.sv.h1 ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
                       a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
@@ -559,6 +581,32 @@ __device__ __forceinline__ void gate_frag_mma(f32x4& acc, const WFrag<1, KSG>& f
     acc = mfma16(f.w[0][s].y, xb.y, acc);
     acc = mfma16(f.w[0][s].z, xb.z, acc);
     acc = mfma16(f.w[0][s].w, xb.w, acc);
+  }
+}
+
+// Both products of a cell's gate tile in one pass: a_hh += W_hh^T-tile x [g_r | g_z | g_hn], a_ih += W_ih^T-tile x [g_r | g_z | g_n].
+// Each accumulator is a 48-long dependent MFMA chain; issued one after the other the matrix pipe waits out the
+// result latency between every pair (measured: 42 cycles per MFMA instead of 32).  Alternating the two chains fills those
+// slots, the summation order of each chain is unchanged.  The operand fragment of the next k-step is requested before the
+// MFMAs of the current one.
+__device__ __forceinline__ void gate_frag_mma2(f32x4& a_hh, const WFrag<1, KSG>& f_hh, f32x4& a_ih, const WFrag<1, KSG>& f_ih,
+                                               const float* G, int lane) {
+  const float* xrow = G + (lane & 15) * LDG + 4 * (lane >> 4);
+  float4 xn = *reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+  for (int s = 0; s < KSG; ++s) {
+    const float4 xi = xn;
+    float4 xh = xi;
+    if (s >= 8) xh = *reinterpret_cast<const float4*>(xrow + 16 * s + 64);
+    if (s + 1 < KSG) xn = *reinterpret_cast<const float4*>(xrow + 16 * (s + 1));
+    a_hh = mfma16(f_hh.w[0][s].x, xh.x, a_hh);
+    a_ih = mfma16(f_ih.w[0][s].x, xi.x, a_ih);
+    a_hh = mfma16(f_hh.w[0][s].y, xh.y, a_hh);
+    a_ih = mfma16(f_ih.w[0][s].y, xi.y, a_ih);
+    a_hh = mfma16(f_hh.w[0][s].z, xh.z, a_hh);
+    a_ih = mfma16(f_ih.w[0][s].z, xi.z, a_ih);
+    a_hh = mfma16(f_hh.w[0][s].w, xh.w, a_hh);
+    a_ih = mfma16(f_ih.w[0][s].w, xi.w, a_ih);
   }
 }
 
@@ -834,8 +882,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     float dh0[4];
     {
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-      gate_frag_mma<true>(a1, f_hh1, Gt1, lane);
-      gate_frag_mma<false>(a2, f_ih1, Gt1, lane);
+      gate_frag_mma2(a1, f_hh1, a2, f_ih1, Gt1, lane);
       carry1 = make_float4(direct1.x + a1[0], direct1.y + a1[1], direct1.z + a1[2], direct1.w + a1[3]);
       const float c0v[4] = {carry0.x, carry0.y, carry0.z, carry0.w};
 #pragma unroll
@@ -856,8 +903,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     // ---- carry0' = dh0 * z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU backward -> dbn_t, partial sums, publish -----------------
     {
       f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = {0.f, 0.f, 0.f, 0.f};
-      gate_frag_mma<true>(a1, f_hh0, Gt, lane);
-      gate_frag_mma<false>(a2, f_ih0, Gt, lane);
+      gate_frag_mma2(a1, f_hh0, a2, f_ih0, Gt, lane);
       carry0 = make_float4(direct0.x + a1[0], direct0.y + a1[1], direct0.z + a1[2], direct0.w + a1[3]);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, mv[4] = {mean4.x, mean4.y, mean4.z, mean4.w},
                   vv[4] = {var4.x, var4.y, var4.z, var4.w};
