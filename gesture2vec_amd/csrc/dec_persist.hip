@@ -125,6 +125,40 @@ __device__ __forceinline__ void frag_mma_x1st(f32x4 (&acc)[NT], const WFrag<NT, 
   }
 }
 
+// One output tile, contraction over KS_T k-steps, as TWO accumulator chains (even / odd k-steps) that alternate in the
+// matrix pipe and are added at the end: a single 36-long dependent chain issues one MFMA per ~42 cycles at one wave per SIMD,
+// two alternating chains one per 32.
+template <int KS_T>
+__device__ __forceinline__ f32x4 lds_frag_mma_2chain(const float* P, int tile, const float* Xs, int ldx, int lane) {
+  const float* xrow = Xs + (lane & 15) * ldx + 4 * (lane >> 4);
+  const float* wp = P + (tile * KS_T) * 256 + lane * 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+  float4 w0 = *reinterpret_cast<const float4*>(wp), x0 = *reinterpret_cast<const float4*>(xrow);
+  float4 w1 = *reinterpret_cast<const float4*>(wp + 256), x1 = *reinterpret_cast<const float4*>(xrow + 16);
+#pragma unroll
+  for (int s = 0; s < KS_T; s += 2) {
+    const float4 wa = w0, xa = x0, wb = w1, xb = x1;
+    const bool two = s + 1 < KS_T;
+    if (s + 2 < KS_T) {
+      w0 = *reinterpret_cast<const float4*>(wp + (s + 2) * 256);
+      x0 = *reinterpret_cast<const float4*>(xrow + 16 * (s + 2));
+    }
+    if (s + 3 < KS_T) {
+      w1 = *reinterpret_cast<const float4*>(wp + (s + 3) * 256);
+      x1 = *reinterpret_cast<const float4*>(xrow + 16 * (s + 3));
+    }
+    a0 = mfma16(wa.x, xa.x, a0);
+    if (two) a1 = mfma16(wb.x, xb.x, a1);
+    a0 = mfma16(wa.y, xa.y, a0);
+    if (two) a1 = mfma16(wb.y, xb.y, a1);
+    a0 = mfma16(wa.z, xa.z, a0);
+    if (two) a1 = mfma16(wb.z, xb.z, a1);
+    a0 = mfma16(wa.w, xa.w, a0);
+    if (two) a1 = mfma16(wb.w, xb.w, a1);
+  }
+  return (f32x4){a0[0] + a1[0], a0[1] + a1[1], a0[2] + a1[2], a0[3] + a1[3]};
+}
+
 // Gate math of one GRU cell for the 4 consecutive features [f0, f0+4) of batch row i held by this lane.
 // Reads h_prev from Xh (own columns) and overwrites it IN PLACE with h_new (the next step's hidden-side operand);
 // Xnext gets the (optionally dropped) value the next layer consumes.  Global: h_out, gates (r,z,n,ghn), dropped copy.
@@ -448,9 +482,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     PSTAMP(0, 7);
     // ---- u_{t+1} = pre_linear.0(xin_{t+1}); partial sums of (u - b) over this block's 16 rows; publish -----------------
     {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      lds_frag_mma<1, KSD>(acc, Ppre, wave, 0, Xy, LDD, lane);
-      u_acc = acc[0];
+      u_acc = lds_frag_mma_2chain<KSD>(Ppre, wave, Xy, LDD, lane);
       const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
       if (a.sv.u)
         *reinterpret_cast<float4*>(a.sv.u + ((int64_t)t * B + b0 + i) * H + f0) =
@@ -859,9 +891,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
     // ---- dh1 = carry1 + dy W_out ; GRU cell 1 backward ---------------------------------------------------------------------
     float4 direct1;
     {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      lds_frag_mma<1, KSD>(acc, Pout_t, wave, 0, Xdy, LDD, lane);
-      const float dh[4] = {acc[0][0] + carry1.x, acc[0][1] + carry1.y, acc[0][2] + carry1.z, acc[0][3] + carry1.w};
+      const f32x4 acc0 = lds_frag_mma_2chain<KSD>(Pout_t, wave, Xdy, LDD, lane);
+      const float dh[4] = {acc0[0] + carry1.x, acc0[1] + carry1.y, acc0[2] + carry1.z, acc0[3] + carry1.w};
       direct1 = cell_bwd<!FW>(dh, c1, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt1, i, f0);
     }
     // cell-0 / BatchNorm inputs of this step: in flight during the next two products (96 MFMAs)
