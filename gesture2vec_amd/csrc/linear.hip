@@ -757,7 +757,8 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   constexpr int NG = SN * SK;
   static_assert(NG == 2, "two tile groups per workgroup");
   static_assert(NR == 2 || NR == 4, "two or four row ranges per workgroup");
-  constexpr bool TRIPLE = !BF3 && !GEN;          // (the 4 x 7 block of the output-blocked variant leaves room for two buffers)
+  constexpr bool TRIPLE = !BF3 && !GEN && !DUAL; // (the 4 x 7 block of the output-blocked variant leaves room for two buffers;
+                                                 //  the two-addend variant would need 222 + 64 registers with three)
   static_assert(VW == 1 || (VW == 2 && TN_ % 2 == 0 && TK_ % 2 == 0), "pairs of tiles per 8-byte load");
   // VW == 2 (8-byte-aligned rows, whole tiles): the 16 MFMA rows of a PAIR of tiles are interleaved over 32 columns,
   // lane i <-> columns 32 g + 2 i + {0, 1}, so one global_load_dwordx2 (a full 128-byte line per matrix row) feeds the
