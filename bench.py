@@ -126,9 +126,9 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
     fused = (E == 128 and K % 128 == 0)
     if fused:
         args = (b["enc_hidden"].data_ptr(), eng.vq_pre_w.data_ptr(), eng.vq_pre_b.data_ptr(), eng.codebook.data_ptr(),
-                eng.code_sqnorm.data_ptr(), b["flat"].data_ptr(), b["idx"].data_ptr(), b["quant"].data_ptr(),
-                b["sse"].data_ptr(), N, E, K, st.cuda_stream)
-        fn, kernel = lib.g2v_vq_fused_assign_fwd, "vq_fused_assign_kernel<128>"
+                eng.codebook_frag.data_ptr(), eng.code_sqnorm.data_ptr(), b["flat"].data_ptr(), b["idx"].data_ptr(),
+                b["quant"].data_ptr(), b["sse"].data_ptr(), N, E, K, st.cuda_stream)
+        fn, kernel = lib.g2v_vq_fused_assign_packed_fwd, "vq_fused_assign_kernel<128, true>"
         flops = 2.0 * N * K * E + 2.0 * N * E * E     # 2KE (distances) + 2E^2 (pre_linear) flop per row
         # read z (4E) + write flat (4E) + write quantized (4E) + write idx (8, int64) per row; W_pre, b_pre, codebook, norms once
         bytes_alg = N * (12 * E + 8) + 4 * E * E + 4 * E + 4 * K * E + 4 * K

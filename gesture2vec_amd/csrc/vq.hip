@@ -451,9 +451,14 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
 // goes to LDS (it IS the B operand of the distance contraction) and to global (`flat_out`: the code statistics need it).
 // Phase 2 = vq_assign_fast_kernel's loop on that tile: distances, running argmin, gather + straight-through + SSE on raw z.
 // Replaces the launch sequence  gemm_nt_stream (pre_linear, 18 us) -> assign (12 us)  and one 2 MB round trip of `flat`.
-template <int E>
+// PACKED: the codebook's MFMA A fragments are read from a fragment-major image Wf (g2v_vq_pack_codebook: tile, k-step, lane ->
+// 16 bytes), one contiguous 1 KB run per wave-level load = 8 full cache lines; straight from the row-major matrix the same
+// load touches 16 rows x 64 bytes = half of each of 16 lines.  Same values, same arithmetic; the gather of the chosen code
+// still reads the row-major matrix.
+template <int E, bool PACKED>
 __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __restrict__ z, const float* __restrict__ Wp,
                                                               const float* __restrict__ bp, const float* __restrict__ W,
+                                                              const float* __restrict__ Wf,
                                                               const float* __restrict__ wsq, float* __restrict__ flat_out,
                                                               int64_t* __restrict__ idx_out, float* __restrict__ quant,
                                                               float* __restrict__ sse_partial, int N, int K) {
@@ -495,12 +500,13 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   // ... and the first pair of codebook tiles right behind them: they travel during the staging and the projection
   auto load_pair = [&](int p, float4 (&w0)[KS], float4 (&w1)[KS], float4& q0, float4& q1) {
     const int kt0 = wave + 8 * p, kt1 = kt0 + 4;
-    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
-    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
+    constexpr int FS = PACKED ? 256 : 16;      // floats between the fragments of consecutive k-steps
+    const float* r0p = PACKED ? Wf + (int64_t)(kt0 * KS) * 256 + lane * 4 : W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = PACKED ? Wf + (int64_t)(kt1 * KS) * 256 + lane * 4 : W + (int64_t)(16 * kt1 + i) * E + 4 * q;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      w0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
-      w1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+      w0[s] = *reinterpret_cast<const float4*>(r0p + FS * s);
+      w1[s] = *reinterpret_cast<const float4*>(r1p + FS * s);
     }
     q0 = *reinterpret_cast<const float4*>(wsq + 16 * kt0 + 4 * q);
     q1 = *reinterpret_cast<const float4*>(wsq + 16 * kt1 + 4 * q);
@@ -563,17 +569,18 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
                      int pn, float4 (&n0)[KS], float4 (&n1)[KS], float4& nq0, float4& nq1) {
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int kt0 = wave + 8 * pn, kt1 = kt0 + 4;
-    const float* r0p = W + (int64_t)(16 * kt0 + i) * E + 4 * q;
-    const float* r1p = W + (int64_t)(16 * kt1 + i) * E + 4 * q;
+    constexpr int FS = PACKED ? 256 : 16;
+    const float* r0p = PACKED ? Wf + (int64_t)(kt0 * KS) * 256 + lane * 4 : W + (int64_t)(16 * kt0 + i) * E + 4 * q;
+    const float* r1p = PACKED ? Wf + (int64_t)(kt1 * KS) * 256 + lane * 4 : W + (int64_t)(16 * kt1 + i) * E + 4 * q;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       a0 = mfma16(w0[s].x, xb[s].x, a0); a1 = mfma16(w1[s].x, xb[s].x, a1);
       a0 = mfma16(w0[s].y, xb[s].y, a0); a1 = mfma16(w1[s].y, xb[s].y, a1);
-      if (ld) n0[s] = *reinterpret_cast<const float4*>(r0p + 16 * s);
+      if (ld) n0[s] = *reinterpret_cast<const float4*>(r0p + FS * s);
       __builtin_amdgcn_sched_barrier(0);
       a0 = mfma16(w0[s].z, xb[s].z, a0); a1 = mfma16(w1[s].z, xb[s].z, a1);
       a0 = mfma16(w0[s].w, xb[s].w, a0); a1 = mfma16(w1[s].w, xb[s].w, a1);
-      if (ld) n1[s] = *reinterpret_cast<const float4*>(r1p + 16 * s);
+      if (ld) n1[s] = *reinterpret_cast<const float4*>(r1p + FS * s);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (ld) {
@@ -1244,8 +1251,48 @@ extern "C" int g2v_vq_fused_assign_fwd(const float* z, const float* w_pre, const
     set_error("g2v_vq_fused_assign_fwd: needs E == 128, K %% 128 == 0 and 16-byte aligned operands");
     return G2V_ERR_UNSUPPORTED;
   }
-  hipLaunchKernelGGL(vq_fused_assign_kernel<128>, dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, (hipStream_t)stream, z, w_pre, b_pre,
-                     codebook, code_sqnorm, flat_out, idx, quantized, sse_partial, N, K);
+  hipLaunchKernelGGL((vq_fused_assign_kernel<128, false>), dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, (hipStream_t)stream, z, w_pre,
+                     b_pre, codebook, (const float*)nullptr, code_sqnorm, flat_out, idx, quantized, sse_partial, N, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// fragment-major image of a (K,E) matrix whose 16-row tiles are MFMA A operands: [K/16][E/16][64 lanes][4]; lane (q, i) of
+// tile kt, k-step s holds W[16 kt + i][16 s + 4 q .. + 3]
+__global__ __launch_bounds__(256) void vq_pack_codebook_kernel(const float* __restrict__ W, float* __restrict__ Wf, int K, int E) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16-byte fragment element per thread
+  const int ks = E / 16;
+  if (o >= (int64_t)K * E / 4) return;
+  const int lane = (int)(o & 63), i = lane & 15, q = lane >> 4;
+  const int64_t ts = o >> 6;
+  const int s = (int)(ts % ks), kt = (int)(ts / ks);
+  reinterpret_cast<float4*>(Wf)[o] = *reinterpret_cast<const float4*>(W + (int64_t)(16 * kt + i) * E + 16 * s + 4 * q);
+}
+
+extern "C" int g2v_vq_pack_codebook(const float* codebook, float* codebook_frag, int K, int E, g2v_stream_t stream) {
+  G2V_REQUIRE(codebook && codebook_frag, "null pointer");
+  G2V_REQUIRE(K > 0 && E > 0 && (K & 15) == 0 && (E & 15) == 0, "K and E must be multiples of 16");
+  G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(codebook_frag), "16-byte aligned operands");
+  hipLaunchKernelGGL(vq_pack_codebook_kernel, dim3(cdiv((int64_t)K * E / 4, 256)), dim3(256), 0, (hipStream_t)stream, codebook,
+                     codebook_frag, K, E);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
+                                              const float* codebook_frag, const float* code_sqnorm, float* flat_out,
+                                              int64_t* idx, float* quantized, float* sse_partial, int N, int E, int K,
+                                              g2v_stream_t stream) {
+  G2V_REQUIRE(z && w_pre && b_pre && codebook && codebook_frag && code_sqnorm && flat_out && idx && quantized, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (!(E == 128 && (K & 127) == 0 && ptr_aligned16(z) && ptr_aligned16(w_pre) && ptr_aligned16(b_pre) &&
+        ptr_aligned16(codebook) && ptr_aligned16(codebook_frag) && ptr_aligned16(code_sqnorm) && ptr_aligned16(flat_out) &&
+        ptr_aligned16(quantized))) {
+    set_error("g2v_vq_fused_assign_packed_fwd: needs E == 128, K %% 128 == 0 and 16-byte aligned operands");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  hipLaunchKernelGGL((vq_fused_assign_kernel<128, true>), dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, (hipStream_t)stream, z, w_pre,
+                     b_pre, codebook, codebook_frag, code_sqnorm, flat_out, idx, quantized, sse_partial, N, K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -132,6 +132,9 @@ class VQVAEEngine:
         self.ema_w = torch.zeros(K, E, device=dev)
         self.ema_cs = torch.zeros(K, device=dev)
         self.code_sqnorm = torch.zeros(K, device=dev)
+        # fragment-major image of the codebook for the fused assign kernel (kept fresh together with code_sqnorm)
+        self.codebook_frag = torch.zeros(K * self.E, device=dev) if (self.E == 128 and K % 128 == 0) else None
+        self._vq_packed = os.environ.get("G2V_VQ_PACKED", "1") != "0"       # 0: the fused kernel reads the row-major codebook (A/B)
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
         self.vq_stats = self.comm[self.n_flat:]
@@ -357,11 +360,17 @@ class VQVAEEngine:
         N = (2 * B * H) // E
         if not (trust_wsq and self._wsq_fresh):
             check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
-        if E == 128 and K % 128 == 0:
-            # pre_linear + distances + argmin + straight-through / SSE in one launch (flat is written for the statistics)
+            if self.codebook_frag is not None:
+                check(lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), K, E, st))
+        if self.codebook_frag is not None and not self._vq_packed:
             check(lib.g2v_vq_fused_assign_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b), _p(self.codebook),
                                               _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]), _p(b["quant"]), _p(b["sse"]),
                                               N, E, K, st))
+        elif self.codebook_frag is not None:
+            # pre_linear + distances + argmin + straight-through / SSE in one launch (flat is written for the statistics)
+            check(lib.g2v_vq_fused_assign_packed_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b),
+                                                     _p(self.codebook), _p(self.codebook_frag), _p(self.code_sqnorm),
+                                                     _p(b["flat"]), _p(b["idx"]), _p(b["quant"]), _p(b["sse"]), N, E, K, st))
         else:
             check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
                                      _p(b["flat"]), E, N, E, E, 0, st))
@@ -440,6 +449,14 @@ class VQVAEEngine:
                  int(self.conditioned), int(training), T, B, D, H, _p(ws), ws.numel(), st))
         return b
 
+    def refresh_codebook_state(self):
+        """Recompute what is derived from the codebook and kept on the device next to it -- the squared norms and the fragment
+        image the fused assign kernel reads -- after the codebook was changed from outside the engine's own EMA update."""
+        check(self.lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), self.K, self.E, self._stream()))
+        if self.codebook_frag is not None:
+            check(self.lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), self.K, self.E, self._stream()))
+        self._wsq_fresh = True
+
     def vq_finish(self, B: int, training: bool, n_global: Optional[int] = None):
         """K4 + the loss / perplexity scalars; under data parallelism call it after vq_stats has been all-reduced."""
         b = self.buffers(B)
@@ -449,6 +466,8 @@ class VQVAEEngine:
                                          N, n_global or N, self.E, self.K, self.beta, self.decay, self.eps,
                                          int(training), self._stream()))
         if training:
+            if self.codebook_frag is not None:      # ... and the fragment image follows the new codebook (same branch)
+                check(self.lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), self.K, self.E, self._stream()))
             self._wsq_fresh = True          # the update kernel has just rewritten code_sqnorm with the new codebook
 
     def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):

@@ -183,8 +183,18 @@ def vq_assign_bulk(flat, codebook, code_sqnorm, want_undecided=False):
     return (idx, und) if want_undecided else idx
 
 
-def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm):
-    """pre_linear + assign in one launch (E == 128, K % 128 == 0) -> flat (N,E), idx (N) int64, quantized (N,E), sse_partial"""
+def vq_pack_codebook(codebook, out=None):
+    """fragment-major image of the codebook for vq_fused_assign(..., codebook_frag=)"""
+    K, E = codebook.shape
+    if out is None:
+        out = torch.empty((K * E,), dtype=torch.float32, device=codebook.device)
+    check(_lib_().g2v_vq_pack_codebook(_p(_chk(codebook)), _p(out), K, E, _stream()), "vq_pack_codebook")
+    return out
+
+
+def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm, codebook_frag=None):
+    """pre_linear + assign in one launch (E == 128, K % 128 == 0) -> flat (N,E), idx (N) int64, quantized (N,E), sse_partial.
+    codebook_frag (vq_pack_codebook): read the distance operands from the fragment-major image (same results, faster loads)."""
     N, E = z.shape
     K = codebook.shape[0]
     dev = z.device
@@ -193,6 +203,11 @@ def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm):
     idx = torch.empty((N,), dtype=torch.int64, device=dev)
     quant = torch.empty((N, E), dtype=torch.float32, device=dev)
     sse = torch.empty((lib.g2v_vq_assign_blocks(N),), dtype=torch.float32, device=dev)
+    if codebook_frag is not None:
+        check(lib.g2v_vq_fused_assign_packed_fwd(_p(_chk(z)), _p(_chk(w_pre)), _p(_chk(b_pre)), _p(_chk(codebook)),
+                                                 _p(_chk(codebook_frag)), _p(_chk(code_sqnorm)), _p(flat), _p(idx), _p(quant),
+                                                 _p(sse), N, E, K, _stream()), "vq_fused_assign_packed_fwd")
+        return flat, idx, quant, sse
     check(lib.g2v_vq_fused_assign_fwd(_p(_chk(z)), _p(_chk(w_pre)), _p(_chk(b_pre)), _p(_chk(codebook)), _p(_chk(code_sqnorm)),
                                       _p(flat), _p(idx), _p(quant), _p(sse), N, E, K, _stream()), "vq_fused_assign_fwd")
     return flat, idx, quant, sse

@@ -1,5 +1,5 @@
 """Runs only the VQ kernel of the product path at the benchmark size (N=4096,E=128,K=512) for PMC collection:
-argv[2] = fused (default; pre_linear + assign, g2v_vq_fused_assign_fwd) | assign (g2v_vq_assign_fwd) | stats."""
+argv[2] = fused (default; pre_linear + assign, g2v_vq_fused_assign_fwd) | packed (the same from the fragment image) | assign (g2v_vq_assign_fwd) | stats."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -22,6 +22,10 @@ for _ in range(20):
     if which == "fused":
         check(lib.g2v_vq_fused_assign_fwd(z.data_ptr(), Wp.data_ptr(), bp.data_ptr(), W.data_ptr(), wsq.data_ptr(), flat.data_ptr(),
                                           idx.data_ptr(), quant.data_ptr(), sse.data_ptr(), N, E, K, st.cuda_stream))
+    elif which == "packed":
+        frag = ops.vq_pack_codebook(W)
+        check(lib.g2v_vq_fused_assign_packed_fwd(z.data_ptr(), Wp.data_ptr(), bp.data_ptr(), W.data_ptr(), frag.data_ptr(), wsq.data_ptr(),
+                                                 flat.data_ptr(), idx.data_ptr(), quant.data_ptr(), sse.data_ptr(), N, E, K, st.cuda_stream))
     elif which == "assign":
         check(lib.g2v_vq_assign_fwd(flat.data_ptr(), z.data_ptr(), W.data_ptr(), wsq.data_ptr(), idx.data_ptr(), quant.data_ptr(), None,
                                     sse.data_ptr(), N, E, K, st.cuda_stream))

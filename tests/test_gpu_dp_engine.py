@@ -195,11 +195,9 @@ def test_parallel_branches_and_prepared_launches_change_nothing(B, T, D, H, K, p
             for t, s0 in zip((eng.flat, eng.m, eng.v, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv,
                               eng.step_counter, eng.rng_counter, eng.code_sqnorm), state):
                 t.copy_(s0)                            # ... undone, so that the three replays start from the same state
-            # the captured step trusts the device-side |W|^2 (the EMA kernel rewrites it every step); seed it the way the
-            # eager engines' first step does
-            from gesture2vec_amd import ops
-            ops.vq_code_sqnorm(eng.codebook, out=eng.code_sqnorm)
-            eng._wsq_fresh = True
+            # the captured step trusts the device-side |W|^2 and codebook fragment image (the EMA update rewrites them every
+            # step); seed them the way the eager engines' first step does
+            eng.refresh_codebook_state()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 eng.train_step(xbuf, xbuf, **kw)

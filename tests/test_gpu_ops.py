@@ -351,6 +351,10 @@ def test_vq_fused_prelinear_assign_matches_unfused(ops, N):
     close(quant, z + (W[torch.from_numpy(got)] - z), 1e-6, 1e-6, "quantized")
     sse_ref = ((W[torch.from_numpy(got)] - z) ** 2).double().sum()
     assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
+    # the same launch reading the distance operands from the fragment-major codebook image: bitwise the same results
+    frag = ops.vq_pack_codebook(W.to(DEV))
+    flat_p, idx_p, quant_p, sse_p = ops.vq_fused_assign(z.to(DEV), Wp.to(DEV), bp.to(DEV), W.to(DEV), wsq, codebook_frag=frag)
+    assert torch.equal(flat_p, flat) and torch.equal(idx_p, idx) and torch.equal(quant_p, quant) and torch.equal(sse_p, sse)
 
 
 @pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64), (4100, 128, 512), (20000, 128, 512),
