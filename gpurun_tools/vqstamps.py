@@ -12,8 +12,9 @@ N, E, K = 4096, 128, 512
 W = (torch.rand(K, E, device=dev) * 2 - 1); wsq = ops.vq_code_sqnorm(W)
 Wp = torch.randn(E, E, device=dev) * 0.1; bp = torch.randn(E, device=dev) * 0.1
 z = torch.randn(N, E, device=dev)
+frag = ops.vq_pack_codebook(W) if (len(sys.argv) < 2 or sys.argv[1] != "rowmajor") else None
 for _ in range(10):
-    ops.vq_fused_assign(z, Wp, bp, W, wsq)
+    ops.vq_fused_assign(z, Wp, bp, W, wsq, codebook_frag=frag)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 64)()
