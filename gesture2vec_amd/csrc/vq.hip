@@ -1152,6 +1152,386 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
   }
 }
 
+// ---- fused pre_linear + assign with the distance SCREENING on the bf16 matrix pipe, exact by construction (round 3) ------------
+// At N = 4096 a batch has one 16-row tile per CU, and the fp32 kernel above spends 8.2 k of its cycles issuing the 256 fp32 MFMAs
+// per wave of the -2 x W^T contraction.  Only the ARGMIN of that contraction is an output, so it is screened on the bf16 pipe
+//     x . w  ~=  (xh + xl) . wh        (xh = bf16(x), xl = bf16(x - xh), wh = bf16(w): 8 MFMAs of 16 cycles per 16 x 16 x 128 tile
+//                                       instead of 32 of 32 cycles; TERMS == 1 drops the xl term)
+// and every code whose approximate distance lies within `margin` of the row's approximate minimum is re-evaluated with the EXACT
+// fp32 MFMA chain of vq_fused_assign_kernel (same operands, same k order => the same bits), the row's code being the torch.argmin
+// of those exact values.  margin = 2 x (bound on |d_approx - d_fp32|):
+//     |x.w - (xh+xl).wh| <= |x.(w - wh)| + |(x - xh - xl).wh| <= (2^-8 + 2^-16) |x||w|       (bf16 = 8 significant bits, RNE)
+//     + fp32 accumulation of 2E products inside the bf16 MFMAs, budgeted at 2^-14 |x||w| (16x the RNE-chain bound)
+//     + the fp32 chain's own 2^-17 |x||w|;  d carries 2 x that, + 2 roundings of (|x|^2 + |w|^2) - 2 x.w on either side
+// so margin = 2^-6 (1 + 2^-5) |x| max|w| + 2^-19 (|x|^2 + max|w|^2) + 1e-30  [TERMS == 1: 2^-5 (...)].  A code outside the margin cannot be
+// the fp32 kernel's argmin; the codes inside it get the fp32 kernel's own arithmetic: idx == vq_fused_assign_kernel's on EVERY row.
+// A tile with a non-finite approximate distance, more than BXF_CAP candidates on a row or more than BXF_MAXP in all takes the exact
+// fp32 sweep instead (exact_only != 0 forces it: the A/B reference of the tests and of bench.py).
+// 512 threads = 8 waves = two per SIMD: wave w owns pre_linear output tile w and code tiles w, w + 8, ...; operands: z tile (8 KB),
+// W_pre as fp32 MFMA fragments (64 KB image, g2v_vq_pack_codebook on the (E,E) matrix), the codebook's bf16 fragment image
+// (128 KB, g2v_vq_bx_pack) -- 200 KB per CU instead of the fp32 kernel's 328 KB, every request issued before the first wait.
+constexpr int BXF_CAP = 16;        // candidate codes kept per row
+constexpr int BXF_MAXP = 128;      // (row, candidate) pairs re-evaluated per tile: 8 waves x one 16-pair MFMA tile
+
+template <int TERMS, bool WARM>
+__global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restrict__ z, const float* __restrict__ Wpf,
+                                                          const float* __restrict__ bp, const float* __restrict__ W,
+                                                          const __bf16* __restrict__ Whf, const float* __restrict__ wmaxp,
+                                                          const float* __restrict__ wsq, float* __restrict__ flat_out,
+                                                          int64_t* __restrict__ idx_out, float* __restrict__ quant,
+                                                          float* __restrict__ sse_partial, int* __restrict__ diag, int N, int K,
+                                                          int exact_only) {
+  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NT = 4;
+  __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
+  __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
+  __shared__ float xx[16];
+  __shared__ float wmin[8 * 16];
+  __shared__ float thr[16];
+  __shared__ int cnt[16];
+  __shared__ int cand_k[16 * BXF_CAP];
+  __shared__ float cand_s[16 * BXF_CAP];
+  __shared__ int pbase[17];
+  __shared__ int p_row[BXF_MAXP];
+  __shared__ int p_code[BXF_MAXP];
+  __shared__ float p_s[BXF_MAXP];
+  __shared__ float p_d[BXF_MAXP];
+  __shared__ float wbest_d[8 * 16];
+  __shared__ int wbest_k[8 * 16];
+  __shared__ int best_k[16];
+  __shared__ float red[4];
+  __shared__ int s_exact;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  const int i = lane & 15, q = lane >> 4;
+  const int npass = K >> 7, ntile = K >> 4;
+  VSTAMP(0);
+  if (tid < 16) cnt[tid] = 0;
+  if (tid == 0) s_exact = exact_only;
+  // ---- every request of the launch, in consumption order (vmcnt retires in order) ------------------------------------------------
+  const int zrow = tid >> 5, zpart = tid & 31;
+  const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + (zrow < nrows ? zrow : 0)) * E + 4 * zpart);
+  float4 wp[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wp[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
+  bf16x8 wh[NT][KB];
+  float4 wq[NT];
+#pragma unroll
+  for (int p = 0; p < NT; ++p) {
+    const int kt = min(wave + 8 * p, ntile - 1);        // passes beyond K / 128 re-read a valid tile and are never used
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) wh[p][kb] = *reinterpret_cast<const bf16x8*>(Whf + ((int64_t)(kt * KB + kb) * 64 + lane) * 8);
+    wq[p] = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
+  }
+  float4 warm = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (WARM) {
+    // one 8 KB slice of the ROW-MAJOR fp32 codebook per workgroup, the 32 workgroups of an XCD (blockIdx % 8 under round-robin
+    // placement: speed only) covering all of it: the candidate rows of the re-check and the winners' rows then come from this
+    // XCD's L2 instead of a cold fabric round trip.  The value is never used.
+    const int nslice = (K * E / 4) / 512;
+    warm = *(reinterpret_cast<const float4*>(W) + (int64_t)((blockIdx.x >> 3) % nslice) * 512 + tid);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  *reinterpret_cast<float4*>(Xz + zrow * ldx + 4 * zpart) = zrow < nrows ? zv : make_float4(0.f, 0.f, 0.f, 0.f);
+  lds_barrier();
+  VSTAMP(1);
+  {  // ---- pre_linear (:1230), output tile `wave`: one fp32 chain over k, the chain of vq_fused_assign_kernel ---------------------
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const float4 xb = *reinterpret_cast<const float4*>(Xz + i * ldx + 16 * s + 4 * q);
+      a = mfma16(wp[s].x, xb.x, a);
+      a = mfma16(wp[s].y, xb.y, a);
+      a = mfma16(wp[s].z, xb.z, a);
+      a = mfma16(wp[s].w, xb.w, a);
+    }
+    const int f0 = 16 * wave + 4 * q;
+    const float4 b0 = *reinterpret_cast<const float4*>(bp + f0);
+    const float4 v0 = make_float4(a[0] + b0.x, a[1] + b0.y, a[2] + b0.z, a[3] + b0.w);
+    *reinterpret_cast<float4*>(Xf + i * ldx + f0) = v0;
+    if (i < nrows) *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
+  }
+  lds_barrier();
+  VSTAMP(2);
+  if (tid < 256) {  // ||x||^2 of the projected rows (same summation tree as the fp32 kernel)
+    const int row = tid >> 4, part = tid & 15;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(Xf + row * ldx + 4 * (part + 16 * j));
+      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    s = reduce16(s);
+    if (part == 0) xx[row] = s;
+  }
+  lds_barrier();
+  VSTAMP(3);
+  const float xr = xx[i];
+  float dv[NT][4];
+  {  // ---- screening sweep on the bf16 pipe ------------------------------------------------------------------------------------
+    bf16x8 xh[KB], xl[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      const float4 a = *reinterpret_cast<const float4*>(Xf + i * ldx + 32 * kb + 8 * q);
+      const float4 b = *reinterpret_cast<const float4*>(Xf + i * ldx + 32 * kb + 8 * q + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        xh[kb][j] = h;
+        xl[kb][j] = (__bf16)(v[j] - (float)h);
+      }
+    }
+    float dmin = INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p < npass) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (TERMS >= 2) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p][kb], xl[kb], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p][kb], xh[kb], acc, 0, 0, 0);
+        const float sv[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = (xr + sv[r]) - 2.0f * acc[r];
+          dv[p][r] = d;
+          dmin = fminf(dmin, d);
+          bad |= !(fabsf(d) < INFINITY);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dv[p][r] = INFINITY;
+      }
+    }
+    dmin = fminf(dmin, __shfl_xor(dmin, 16));
+    dmin = fminf(dmin, __shfl_xor(dmin, 32));
+    if (lane < 16) wmin[wave * 16 + lane] = dmin;
+    if (__any(bad) && lane == 0) s_exact = 1;
+  }
+  lds_barrier();
+  if (tid < 16) {
+    float m = wmin[tid];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + tid]);
+    const float xr_ = xx[tid], wm = *wmaxp;
+    const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;                 // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
+    const float t = m + (c1 * (sqrtf(xr_) * sqrtf(wm)) + 1.9073486e-6f * (xr_ + wm) + 1e-30f);   // 1e-30: denormal flushes
+    thr[tid] = t;
+    if (!(fabsf(t) < INFINITY)) s_exact = 1;      // non-finite norms: no usable bound
+  }
+  lds_barrier();
+  VSTAMP(4);
+  bool exact = s_exact != 0;
+  if (!exact) {
+    const float th = thr[i];
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      const float sv[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (dv[p][r] <= th) {
+          const int slot = atomicAdd(&cnt[i], 1);
+          if (slot < BXF_CAP) {
+            cand_k[i * BXF_CAP + slot] = 16 * (wave + 8 * p) + 4 * q + r;
+            cand_s[i * BXF_CAP + slot] = sv[r];
+          }
+        }
+      }
+    }
+  }
+  lds_barrier();
+  if (!exact && wave == 0) {     // pair list: rows in order, a row's candidates in arrival order (the choice below does not depend on it)
+    const int nraw = lane < 16 ? cnt[lane] : 0;
+    const int n = min(nraw, BXF_CAP);
+    int incl = n;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      const int t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const int total = __shfl(incl, 15);
+    const bool over = __any(nraw > BXF_CAP) || total > BXF_MAXP;
+    if (over) {
+      if (lane == 0) s_exact = 1;
+    } else if (lane < 16) {
+      const int b0 = incl - n;
+      pbase[lane] = b0;
+      if (lane == 15) pbase[16] = incl;
+      for (int s = 0; s < n; ++s) {
+        p_row[b0 + s] = lane;
+        p_code[b0 + s] = cand_k[lane * BXF_CAP + s];
+        p_s[b0 + s] = cand_s[lane * BXF_CAP + s];
+      }
+    }
+  }
+  lds_barrier();
+  VSTAMP(5);
+  exact = s_exact != 0;
+  int npairs = 0;
+  if (!exact) {
+    // ---- exact fp32 re-evaluation of the candidates: A = 16 candidate rows gathered from the row-major codebook, B = the tile's
+    // 16 projected rows; element (candidate, its own row) of the 16 x 16 product is the fp32 kernel's dot product, bit for bit
+    const int P = pbase[16];
+    npairs = P;
+    for (int chunk = wave; 16 * chunk < P; chunk += 8) {
+      const int pi = 16 * chunk + i;
+      const int code = pi < P ? p_code[pi] : 0;
+      const float* wrow = W + (int64_t)code * E + 4 * q;
+      float4 wf[KS], xb[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        a = mfma16(wf[s].x, xb[s].x, a);
+        a = mfma16(wf[s].y, xb[s].y, a);
+        a = mfma16(wf[s].z, xb[s].z, a);
+        a = mfma16(wf[s].w, xb[s].w, a);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int pj = 16 * chunk + 4 * q + r;
+        if (pj < P && p_row[pj] == i) p_d[pj] = (xr + p_s[pj]) - 2.0f * a[r];
+      }
+    }
+    lds_barrier();
+    if (tid < 16) {
+      const int b0 = pbase[tid], e0 = pbase[tid + 1];
+      float d = p_d[b0];
+      int k = p_code[b0];
+      for (int j = b0 + 1; j < e0; ++j) argmin_merge(d, k, p_d[j], p_code[j]);
+      best_k[tid] = k;
+      if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
+    }
+  } else {
+    // ---- exact fp32 sweep over every code (vq_fused_assign_kernel's arithmetic; slow path) ---------------------------------------
+    float4 xb[KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
+    float bd = INFINITY;
+    int bk = 0;
+    for (int p = 0; p < npass; ++p) {
+      const int kt = wave + 8 * p;
+      const float* wrow = W + (int64_t)(16 * kt + i) * E + 4 * q;
+      float4 wf[KS];
+#pragma unroll
+      for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+      const float4 sq = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
+      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        a = mfma16(wf[s].x, xb[s].x, a);
+        a = mfma16(wf[s].y, xb[s].y, a);
+        a = mfma16(wf[s].z, xb[s].z, a);
+        a = mfma16(wf[s].w, xb[s].w, a);
+      }
+      const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float d = (xr + sv[r]) - 2.0f * a[r];
+        if (argmin_better(d, bd)) { bd = d; bk = 16 * kt + 4 * q + r; }
+      }
+    }
+    {
+      float d2 = __shfl_xor(bd, 16);
+      int k2 = __shfl_xor(bk, 16);
+      argmin_merge(bd, bk, d2, k2);
+      d2 = __shfl_xor(bd, 32);
+      k2 = __shfl_xor(bk, 32);
+      argmin_merge(bd, bk, d2, k2);
+    }
+    if (lane < 16) {
+      wbest_d[wave * 16 + lane] = bd;
+      wbest_k[wave * 16 + lane] = bk;
+    }
+    lds_barrier();
+    if (tid < 16) {
+      float d = wbest_d[tid];
+      int k = wbest_k[tid];
+#pragma unroll
+      for (int w = 1; w < 8; ++w) argmin_merge(d, k, wbest_d[w * 16 + tid], wbest_k[w * 16 + tid]);
+      best_k[tid] = k;
+      if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
+    }
+  }
+  __syncthreads();
+  VSTAMP(6);
+  if (tid < 256) {  // ---- gather + straight-through + SSE on raw z (:1285-1292), the fp32 kernel's code and summation order ----------
+    const int row = tid >> 4, part = tid & 15;
+    float sse = 0.f;
+    if (row < nrows) {
+      const float* wq_ = W + (int64_t)best_k[row] * E;
+      float* qo = quant + (int64_t)(r0 + row) * E;
+#pragma unroll
+      for (int j = 0; j < E / 64; ++j) {
+        const int c = 4 * (part + 16 * j);
+        const float4 zz = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
+        const float4 df = make_float4(wv.x - zz.x, wv.y - zz.y, wv.z - zz.z, wv.w - zz.w);
+        *reinterpret_cast<float4*>(qo + c) = make_float4(zz.x + df.x, zz.y + df.y, zz.z + df.z, zz.w + df.w);   // :1292
+        sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    if (sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (diag) {
+      if (exact) atomicAdd(&diag[0], 1);
+      atomicAdd(&diag[1], npairs);
+      if (WARM && warm.x == -1.2345e38f && warm.w == 7.f) diag[2] = 1;     // keeps the warming load alive; never true in practice
+    }
+  }
+  VSTAMP(7);
+}
+
+// bf16 MFMA-fragment image of the codebook for vq_fused_bx_kernel: [K/16 tiles][E/32 k-blocks][64 lanes][8] with lane (q, i) of
+// tile kt, block kb holding bf16(W[16 kt + i][32 kb + 8 q .. + 7]); behind it one float: max_k |W_k|^2 (from code_sqnorm).
+__global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
+                                                         __bf16* __restrict__ Whf, float* __restrict__ wmax, int K, int E) {
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16-byte fragment element per thread
+  const int kbs = E / 32;
+  if (o < (int64_t)K * E / 8) {
+    const int lane = (int)(o & 63), i = lane & 15, q = lane >> 4;
+    const int64_t tb = o >> 6;
+    const int kb = (int)(tb % kbs), kt = (int)(tb / kbs);
+    const float* src = W + (int64_t)(16 * kt + i) * E + 32 * kb + 8 * q;
+    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    bf16x8 h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
+    *reinterpret_cast<bf16x8*>(Whf + o * 8) = h;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float red[4];
+    float m = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float s = wsq[k];
+      m = (s > m || s != s) ? s : m;              // a NaN norm poisons the bound: every tile then takes the exact path
+    }
+#pragma unroll
+    for (int o2 = 32; o2 > 0; o2 >>= 1) {
+      const float t = __shfl_xor(m, o2);
+      m = (t > m || t != t) ? t : m;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float r = red[0];
+      for (int w = 1; w < 4; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
+      *wmax = r;
+    }
+  }
+}
+
 // rows per workgroup: 16 (fill the chip; the codebook stream is then L2-bound), 64 for bulk assignment (MFMA-bound)
 static int vq_rows_per_block(int N) { return N >= 16384 ? 64 : 16; }   // measured: 32 rows at N = 4096 is slower (18.8 vs 13.7 us)
 // upper bound on the number of SSE partials any path writes for N rows (callers size sse_partial with it)
@@ -1293,6 +1673,55 @@ extern "C" int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre
   }
   hipLaunchKernelGGL((vq_fused_assign_kernel<128, true>), dim3(cdiv(N, VQ_ROWS)), dim3(256), 0, (hipStream_t)stream, z, w_pre,
                      b_pre, codebook, codebook_frag, code_sqnorm, flat_out, idx, quantized, sse_partial, N, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" size_t g2v_vq_bx_image_bytes(int K, int E) {
+  if (K <= 0 || E <= 0) return 0;
+  return (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256;
+}
+
+extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, void* image, int K, int E, g2v_stream_t stream) {
+  G2V_REQUIRE(codebook && code_sqnorm && image, "null pointer");
+  G2V_REQUIRE(K > 0 && E > 0 && (K & 15) == 0 && (E & 31) == 0, "K must be a multiple of 16 and E of 32");
+  G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
+  const size_t half = ((size_t)K * E * 2 + 255) & ~(size_t)255;
+  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(cdiv((int64_t)K * E / 8, 256)), dim3(256), 0, (hipStream_t)stream, codebook,
+                     code_sqnorm, (__bf16*)image, (float*)((char*)image + half), K, E);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_vq_fused_assign_bx_ok(int N, int E, int K) { return (N > 0 && E == 128 && (K & 127) == 0 && K >= 128 && K <= 512) ? 1 : 0; }
+
+extern "C" int g2v_vq_fused_assign_bx_fwd(const float* z, const float* w_pre_frag, const float* b_pre, const float* codebook,
+                                          const void* image, const float* code_sqnorm, float* flat_out, int64_t* idx,
+                                          float* quantized, float* sse_partial, int* diag, int N, int E, int K, int flags,
+                                          g2v_stream_t stream) {
+  G2V_REQUIRE(z && w_pre_frag && b_pre && codebook && image && code_sqnorm && flat_out && idx && quantized, "null pointer");
+  G2V_REQUIRE(N > 0 && E > 0 && K > 0, "non-positive size");
+  if (!(g2v_vq_fused_assign_bx_ok(N, E, K) && ptr_aligned16(z) && ptr_aligned16(w_pre_frag) && ptr_aligned16(b_pre) &&
+        ptr_aligned16(codebook) && ptr_aligned16(image) && ptr_aligned16(code_sqnorm) && ptr_aligned16(flat_out) &&
+        ptr_aligned16(quantized))) {
+    set_error("g2v_vq_fused_assign_bx_fwd: needs E == 128, K in {128, 256, 384, 512} and 16-byte aligned operands");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  const size_t half = ((size_t)K * E * 2 + 255) & ~(size_t)255;
+  const __bf16* whf = (const __bf16*)image;
+  const float* wmax = (const float*)((const char*)image + half);
+  const dim3 grid(cdiv(N, VQ_ROWS)), block(512);
+  hipStream_t st = (hipStream_t)stream;
+  const int exact = flags & G2V_VQ_BX_EXACT;
+#define G2V_BX_LAUNCH(T, WRM)                                                                                                  \
+  hipLaunchKernelGGL((vq_fused_bx_kernel<T, WRM>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, whf, wmax, code_sqnorm, \
+                     flat_out, idx, quantized, sse_partial, diag, N, K, exact)
+  if (flags & G2V_VQ_BX_ONE_TERM) {
+    if (flags & G2V_VQ_BX_NO_WARM) G2V_BX_LAUNCH(1, false); else G2V_BX_LAUNCH(1, true);
+  } else {
+    if (flags & G2V_VQ_BX_NO_WARM) G2V_BX_LAUNCH(2, false); else G2V_BX_LAUNCH(2, true);
+  }
+#undef G2V_BX_LAUNCH
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

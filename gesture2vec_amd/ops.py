@@ -213,6 +213,37 @@ def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm, codebook_frag=None):
     return flat, idx, quant, sse
 
 
+VQ_BX_EXACT, VQ_BX_ONE_TERM, VQ_BX_NO_WARM = 1, 2, 4          # include/g2v.h G2V_VQ_BX_*
+
+
+def vq_bx_pack(codebook, code_sqnorm, out=None):
+    """bf16 MFMA-fragment image of the codebook (+ max_k |W_k|^2) for vq_fused_assign_bx (g2v_vq_bx_pack)"""
+    K, E = codebook.shape
+    nb = int(_lib_().g2v_vq_bx_image_bytes(K, E))
+    if out is None:
+        out = torch.empty((nb,), dtype=torch.uint8, device=codebook.device)
+    check(_lib_().g2v_vq_bx_pack(_p(_chk(codebook)), _p(_chk(code_sqnorm)), _p(out), K, E, _stream()), "vq_bx_pack")
+    return out
+
+
+def vq_fused_assign_bx(z, w_pre_frag, b_pre, codebook, image, code_sqnorm, flags=0, want_diag=False):
+    """pre_linear + bf16-screened / fp32-re-checked assign in one launch (g2v_vq_fused_assign_bx_fwd) -> flat, idx, quantized,
+    sse_partial[, diag int32[4]: tiles on the exact sweep, pairs re-evaluated].  w_pre_frag = vq_pack_codebook(w_pre)."""
+    N, E = z.shape
+    K = codebook.shape[0]
+    dev = z.device
+    lib = _lib_()
+    flat = torch.empty((N, E), dtype=torch.float32, device=dev)
+    idx = torch.empty((N,), dtype=torch.int64, device=dev)
+    quant = torch.empty((N, E), dtype=torch.float32, device=dev)
+    sse = torch.empty((lib.g2v_vq_assign_blocks(N),), dtype=torch.float32, device=dev)
+    diag = torch.zeros((4,), dtype=torch.int32, device=dev) if want_diag else None
+    check(lib.g2v_vq_fused_assign_bx_fwd(_p(_chk(z)), _p(_chk(w_pre_frag)), _p(_chk(b_pre)), _p(_chk(codebook)), _p(image),
+                                         _p(_chk(code_sqnorm)), _p(flat), _p(idx), _p(quant), _p(sse), _p(diag), N, E, K,
+                                         int(flags), _stream()), "vq_fused_assign_bx_fwd")
+    return (flat, idx, quant, sse, diag) if want_diag else (flat, idx, quant, sse)
+
+
 def vq_stats(idx, flat, K, out=None):
     N, E = flat.shape
     dev = flat.device

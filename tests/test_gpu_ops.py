@@ -357,6 +357,94 @@ def test_vq_fused_prelinear_assign_matches_unfused(ops, N):
     assert torch.equal(flat_p, flat) and torch.equal(idx_p, idx) and torch.equal(quant_p, quant) and torch.equal(sse_p, sse)
 
 
+def _bx_case(kind, N, K, seed):
+    E = 128
+    g = torch.Generator().manual_seed(seed)
+    z = torch.randn(N, E, generator=g)
+    Wp, bp = torch.randn(E, E, generator=g) * 0.1, torch.randn(E, generator=g) * 0.1
+    W = torch.rand(K, E, generator=g) * 2 - 1
+    if kind == "trained":            # codes sit ON projected rows: many near-ties
+        flat = z @ Wp.t() + bp
+        W = flat[torch.randint(0, N, (K,), generator=g)] + 0.02 * torch.randn(K, E, generator=g)
+    elif kind == "ties":             # duplicated codes: exact ties, the lowest index must win
+        W[K // 2:] = W[:K // 2]
+    elif kind == "collapsed":        # every code within the margin of every other: the exact sweep everywhere
+        W = torch.randn(1, E, generator=g).repeat(K, 1) + 1e-4 * torch.randn(K, E, generator=g)
+    elif kind == "nonfinite":
+        z[3, 7] = float("nan")
+        z[N - 2, :] = float("nan")
+        z[5, 11] = float("inf")
+        z[17 % N, 0] = 1.0e30
+        W[9, 4] = 3.0e19             # |W_9|^2 overflows to +inf
+    elif kind == "tiny":             # everything at 1e-20: distances underflow to ties at zero
+        z *= 1e-20
+        Wp *= 1.0
+        W *= 1e-20
+        bp *= 1e-20
+    return z, Wp, bp, W
+
+
+@pytest.mark.parametrize("kind,N,K", [("uniform", 4096, 512), ("trained", 4096, 512), ("ties", 4096, 512), ("collapsed", 256, 512),
+                                      ("nonfinite", 4096, 512), ("tiny", 512, 512), ("uniform", 37, 512), ("uniform", 20000, 256),
+                                      ("trained", 1000, 128), ("ties", 16, 384)])
+@pytest.mark.parametrize("flags", [0, 2, 4])        # two-term screening (product path), one-term, no L2 warming
+def test_vq_fused_bx_equals_fp32_kernel_on_every_row(ops, kind, N, K, flags):
+    """g2v_vq_fused_assign_bx_fwd (round 3: distance screening on the bf16 matrix pipe, in-kernel exact fp32 re-check of every
+    code inside the error margin) must return, BITWISE, what the fp32 fused kernel returns -- flat, idx on every row
+    (near-ties, exact ties, NaN / Inf rows included), quantized and the SSE partials -- and so must its exact-only mode."""
+    z, Wp, bp, W = _bx_case(kind, N, K, seed=77 + N + K)
+    zd, Wpd, bpd, Wd = z.to(DEV), Wp.to(DEV), bp.to(DEV), W.to(DEV)
+    wsq = ops.vq_code_sqnorm(Wd)
+    ref = ops.vq_fused_assign(zd, Wpd, bpd, Wd, wsq)
+    wpf = ops.vq_pack_codebook(Wpd)
+    img = ops.vq_bx_pack(Wd, wsq)
+    assert ops._lib_().g2v_vq_fused_assign_bx_ok(N, 128, K) == 1
+    for fl in (flags, flags | 1):
+        got = ops.vq_fused_assign_bx(zd, wpf, bpd, Wd, img, wsq, flags=fl, want_diag=True)
+        names = ("flat", "idx", "quantized", "sse_partial")
+        for nm, a, b in zip(names, ref, got[:4]):
+            if nm in ("flat", "quantized", "sse_partial") and kind == "nonfinite":
+                assert torch.equal(torch.isnan(a), torch.isnan(b)) and torch.equal(a.nan_to_num(7.0), b.nan_to_num(7.0)), (nm, fl)
+            else:
+                assert torch.equal(a, b), f"{nm} differs from the fp32 kernel (flags {fl}): {int((a != b).sum())} elements"
+        exact_tiles, pairs = int(got[4][0]), int(got[4][1])
+        tiles = (N + 15) // 16
+        if fl & 1:
+            assert exact_tiles == tiles
+        elif kind == "collapsed":
+            assert exact_tiles == tiles                      # 512 candidates per row overflow the lists
+        elif kind in ("uniform", "trained"):
+            assert exact_tiles <= tiles // 8, (exact_tiles, tiles)     # the screening must decide (nearly) every tile
+            assert 16 * (tiles - exact_tiles) <= pairs <= 16 * tiles * 8, pairs
+    if kind in ("uniform", "trained"):       # and the oracle's argmin on the safe rows
+        flat_ref = z @ Wp.t() + bp
+        d = O.vq_distances(flat_ref, W)
+        top2 = torch.topk(d, 2, dim=1, largest=False).values
+        safe = ((top2[:, 1] - top2[:, 0]) > 1e-4 * top2[:, 0].abs().clamp(min=1)).numpy()
+        assert np.array_equal(got[1].cpu().numpy()[safe], d.argmin(1).numpy()[safe])
+
+
+def test_vq_fused_bx_matches_golden_indices(ops, golden_dir):
+    """the reference's own VQ_Payam_EMA numbers (tests/golden/vq_layers.npz) through the bf16-screened kernel"""
+    fx = _vq_fixture(golden_dir)
+    W = torch.from_numpy(fx["ema/w0/_embedding.weight"].copy())
+    if W.shape[1] != 128 or W.shape[0] % 128 or W.shape[0] > 512:
+        pytest.skip("fixture shape is outside the screened kernel's")
+    z = torch.from_numpy(fx["z1"].copy()).reshape(-1, W.shape[1])
+    Wp = torch.from_numpy(fx["ema/w0/pre_linear.weight"].copy())
+    bp = torch.from_numpy(fx["ema/w0/pre_linear.bias"].copy())
+    Wd = W.to(DEV)
+    wsq = ops.vq_code_sqnorm(Wd)
+    flat, idx, quant, sse = ops.vq_fused_assign_bx(z.to(DEV), ops.vq_pack_codebook(Wp.to(DEV)), bp.to(DEV), Wd,
+                                                   ops.vq_bx_pack(Wd, wsq), wsq)
+    safe = fx["ema/c1/gap"] > 1e-4
+    assert np.array_equal(idx.cpu().numpy()[safe], fx["ema/c1/idx"][safe]), "code indices differ from the reference"
+    close(flat, torch.from_numpy(fx["ema/c1/flat"].copy()), 1e-6, 1e-5, "pre_linear rows")
+    close(quant.reshape(-1), torch.from_numpy(fx["ema/c1/quantized"].copy()).reshape(-1), 1e-6, 1e-6, "quantized")
+    loss = 0.25 * sse.sum().item() / z.numel()
+    assert abs(loss - float(fx["ema/c1/loss"])) <= 1e-5 * abs(float(fx["ema/c1/loss"]))
+
+
 @pytest.mark.parametrize("N,E,K", [(4096, 128, 512), (100, 100, 512), (4096, 128, 64), (4100, 128, 512), (20000, 128, 512),
                                    (1024, 400, 512)])     # tile-owner kernel from N >= 1024 with >= 128 (16 x 16) tiles
 @pytest.mark.parametrize("collapsed", [False, True])
