@@ -76,7 +76,7 @@ _SIGS = {
     "g2v_vq_pack_codebook": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_fused_assign_packed_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_bx_image_bytes": (c_sz, [c_int, c_int]),
-    "g2v_vq_bx_pack": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_vq_bx_pack": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_fused_assign_bx_ok": (c_int, [c_int, c_int, c_int]),
     "g2v_vq_fused_assign_bx_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "g2v_vq_stats_workspace": (c_sz, [c_int, c_int, c_int]),

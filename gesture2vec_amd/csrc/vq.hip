@@ -1153,107 +1153,210 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 }
 
 // ---- fused pre_linear + assign with the distance SCREENING on the bf16 matrix pipe, exact by construction (round 3) ------------
-// At N = 4096 a batch has one 16-row tile per CU, and the fp32 kernel above spends 8.2 k of its cycles issuing the 256 fp32 MFMAs
-// per wave of the -2 x W^T contraction.  Only the ARGMIN of that contraction is an output, so it is screened on the bf16 pipe
-//     x . w  ~=  (xh + xl) . wh        (xh = bf16(x), xl = bf16(x - xh), wh = bf16(w): 8 MFMAs of 16 cycles per 16 x 16 x 128 tile
-//                                       instead of 32 of 32 cycles; TERMS == 1 drops the xl term)
-// and every code whose approximate distance lies within `margin` of the row's approximate minimum is re-evaluated with the EXACT
-// fp32 MFMA chain of vq_fused_assign_kernel (same operands, same k order => the same bits), the row's code being the torch.argmin
-// of those exact values.  margin = 2 x (bound on |d_approx - d_fp32|):
-//     |x.w - (xh+xl).wh| <= |x.(w - wh)| + |(x - xh - xl).wh| <= (2^-8 + 2^-16) |x||w|       (bf16 = 8 significant bits, RNE)
-//     + fp32 accumulation of 2E products inside the bf16 MFMAs, budgeted at 2^-14 |x||w| (16x the RNE-chain bound)
-//     + the fp32 chain's own 2^-17 |x||w|;  d carries 2 x that, + 2 roundings of (|x|^2 + |w|^2) - 2 x.w on either side
-// so margin = 2^-6 (1 + 2^-5) |x| max|w| + 2^-19 (|x|^2 + max|w|^2) + 1e-30  [TERMS == 1: 2^-5 (...)].  A code outside the margin cannot be
-// the fp32 kernel's argmin; the codes inside it get the fp32 kernel's own arithmetic: idx == vq_fused_assign_kernel's on EVERY row.
-// A tile with a non-finite approximate distance, more than BXF_CAP candidates on a row or more than BXF_MAXP in all takes the exact
-// fp32 sweep instead (exact_only != 0 forces it: the A/B reference of the tests and of bench.py).
-// 512 threads = 8 waves = two per SIMD: wave w owns pre_linear output tile w and code tiles w, w + 8, ...; operands: z tile (8 KB),
-// W_pre as fp32 MFMA fragments (64 KB image, g2v_vq_pack_codebook on the (E,E) matrix), the codebook's bf16 fragment image
-// (128 KB, g2v_vq_bx_pack) -- 200 KB per CU instead of the fp32 kernel's 328 KB, every request issued before the first wait.
-constexpr int BXF_CAP = 16;        // candidate codes kept per row
+// At N = 4096 a batch has one 16-row tile per CU; the fp32 kernel above spends 2.8 k cycles on the projection and then 14 k on the
+// 256 fp32 MFMAs per wave of the -2 x W^T contraction, one behind the other.  Only the ARGMIN of that contraction is an output, so
+//  (1) it is SCREENED on the bf16 pipe, in z-space:  flat.w_k = (W_pre z + b).w_k = z.u_k + b.w_k  with  u_k = W_pre^T w_k, so
+//          e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)      (zh = bf16(z), zl = bf16(z - zh); 8 MFMAs of 16 cycles per
+//          16 x 16 x 128 tile instead of 32 of 32 cycles; ONE_TERM drops the zl products)
+//      approximates d_k - |flat|^2 WITHOUT the projected rows: the sweep does not wait for the projection, the two run side by side
+//      (waves 0-3: the projection's two fp32 chains each + 2 code tiles; waves 4-7: 6 code tiles each), both fed by one 202 KB
+//      request stream per CU (z tile 8 KB, W_pre fp32 fragments 64 KB, bf16 fragments of U 128 KB, s'_k = |w_k|^2 - 2 b.w_k 2 KB)
+//      instead of the fp32 kernel's 328 KB;
+//  (2) every code whose e_k lies within `margin` of the row's minimum is re-evaluated with the EXACT fp32 MFMA chain of
+//      vq_fused_assign_kernel on the projected rows (same operands, same k order => the same bits): 16 (row, candidate) pairs per
+//      wave as one 16 x 16 x 128 product of gathered codebook rows with the tile, the row's code being torch.argmin (:1259) over
+//      its exact values (LDS atomicMin on (distance, index) keys).
+// margin = 2 x (bound on |e_k - (d_k - |flat|^2)|), with B1 = |z| max|u|, B2 = (|W_pre|_F |z| + |b|) max|w|, B3 = B2^2/max|w|^2 + max|w|^2:
+//     bf16(u) and the z residual: (2^-8 + 2^-16) B1; fp32 accumulation inside the bf16 MFMAs, budgeted 2^-14 B1 (16x the RNE bound);
+//     fp32 rounding of U, of the projection and of the fp32 kernel's chain: <= 3 E 2^-24 B2 = 2^-15.4 B2; (|x|^2 + |w|^2) - 2 x.w
+//     and s'_k roundings: <= 2^-21 B3 on either side
+//   => margin = 2^-6 (1 + 2^-5) B1 + 2^-12 B2 + 2^-19 B3 + 1e-30     [ONE_TERM: 2^-5 (1 + 2^-5) B1 + ...]
+// A code outside the margin cannot be the fp32 kernel's argmin; the codes inside it get the fp32 kernel's own arithmetic: flat,
+// idx, quantized and the SSE partials are bitwise vq_fused_assign_kernel's.  A tile with a non-finite screening value or more than
+// BXF_MAXP candidates takes the exact fp32 sweep over all K codes instead (exact_only != 0 forces it: the A/B reference).
 constexpr int BXF_MAXP = 128;      // (row, candidate) pairs re-evaluated per tile: 8 waves x one 16-pair MFMA tile
+constexpr int BXF_LDH = 128 + 8;   // bf16 elements per LDS row of the hi / lo images: 272 B, conflict-free ds_read_b128 per 16 lanes
+constexpr int BXF_NTA = 2, BXF_NTB = 6;      // code tiles of a projection wave (0-3) / of a sweep-only wave (4-7): 4 * (2 + 6) = 32
 
-template <int TERMS, bool WARM>
+// monotone map float -> uint32 (a < b  <=>  key(a) < key(b); no NaNs reach it), so that (key(d) << 32 | code) orders by
+// distance first and by code index second: an LDS atomicMin over a row's candidates IS torch.argmin's tie rule
+__device__ __forceinline__ unsigned long long bxf_key(float d, int code) {
+  unsigned u = __float_as_uint(d);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  return ((unsigned long long)u << 32) | (unsigned)code;
+}
+
+struct BxfScalars { float wm, um, wpf2, bb; };      // max|w_k|^2, max|u_k|^2, |W_pre|_F^2, |b|^2 (behind the image, g2v_vq_bx_pack)
+
+template <int TERMS>
 __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restrict__ z, const float* __restrict__ Wpf,
                                                           const float* __restrict__ bp, const float* __restrict__ W,
-                                                          const __bf16* __restrict__ Whf, const float* __restrict__ wmaxp,
-                                                          const float* __restrict__ wsq, float* __restrict__ flat_out,
-                                                          int64_t* __restrict__ idx_out, float* __restrict__ quant,
-                                                          float* __restrict__ sse_partial, int* __restrict__ diag, int N, int K,
-                                                          int exact_only) {
-  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NT = 4;
+                                                          const __bf16* __restrict__ Uhf, const float* __restrict__ sprime,
+                                                          const BxfScalars* __restrict__ scal, const float* __restrict__ wsq,
+                                                          float* __restrict__ flat_out, int64_t* __restrict__ idx_out,
+                                                          float* __restrict__ quant, float* __restrict__ sse_partial,
+                                                          int* __restrict__ diag, int N, int K, int exact_only) {
+  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NTB = BXF_NTB, NTA = BXF_NTA;
   __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
+  __shared__ __attribute__((aligned(16))) __bf16 Zh[VQ_ROWS * BXF_LDH];
+  __shared__ __attribute__((aligned(16))) __bf16 Zl[VQ_ROWS * BXF_LDH];
   __shared__ float xx[16];
   __shared__ float wmin[8 * 16];
-  __shared__ float thr[16];
-  __shared__ int cnt[16];
-  __shared__ int cand_k[16 * BXF_CAP];
-  __shared__ float cand_s[16 * BXF_CAP];
-  __shared__ int pbase[17];
+  __shared__ unsigned long long rowbest[16];
   __shared__ int p_row[BXF_MAXP];
   __shared__ int p_code[BXF_MAXP];
-  __shared__ float p_s[BXF_MAXP];
-  __shared__ float p_d[BXF_MAXP];
   __shared__ float wbest_d[8 * 16];
   __shared__ int wbest_k[8 * 16];
   __shared__ int best_k[16];
   __shared__ float red[4];
-  __shared__ int s_exact;
+  __shared__ int s_exact, s_np;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * VQ_ROWS;
   const int nrows = min(VQ_ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
-  const int npass = K >> 7, ntile = K >> 4;
+  const int ntile = K >> 4;
+  const bool projw = wave < 4;                 // wave-uniform role
   VSTAMP(0);
-  if (tid < 16) cnt[tid] = 0;
-  if (tid == 0) s_exact = exact_only;
-  // ---- every request of the launch, in consumption order (vmcnt retires in order) ------------------------------------------------
+  if (tid < 16) rowbest[tid] = ~0ull;
+  if (tid == 0) {
+    s_exact = exact_only;
+    s_np = 0;
+  }
+  const BxfScalars sc = *scal;
+  // ---- requests, in consumption order.  Code tiles: projection wave w owns w + 4 j (j < 2), sweep wave w owns 8 + (w - 4) + 4 j
+  // (j < 6); tiles at or beyond K / 16 (K < 512) re-read tile 0 and are ignored.
   const int zrow = tid >> 5, zpart = tid & 31;
   const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + (zrow < nrows ? zrow : 0)) * E + 4 * zpart);
-  float4 wp[KS];
+  float4 wp0[KS], wp1[KS];                     // projection waves only
+  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+  bf16x8 uf[NTB][KB];
+  float4 sp[NTB];
+  const int ct0 = projw ? wave : 8 + (wave - 4);
+  const int nct = projw ? NTA : NTB;
+  auto load_tile = [&](int j) {
+    const int kt = ct0 + 4 * j;
+    const int ktc = kt < ntile ? kt : 0;
 #pragma unroll
-  for (int s = 0; s < KS; ++s) wp[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
-  bf16x8 wh[NT][KB];
-  float4 wq[NT];
+    for (int kb = 0; kb < KB; ++kb) uf[j][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
+    sp[j] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
+  };
+  if (projw) {
 #pragma unroll
-  for (int p = 0; p < NT; ++p) {
-    const int kt = min(wave + 8 * p, ntile - 1);        // passes beyond K / 128 re-read a valid tile and are never used
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) wh[p][kb] = *reinterpret_cast<const bf16x8*>(Whf + ((int64_t)(kt * KB + kb) * 64 + lane) * 8);
-    wq[p] = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
-  }
-  float4 warm = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (WARM) {
-    // one 8 KB slice of the ROW-MAJOR fp32 codebook per workgroup, the 32 workgroups of an XCD (blockIdx % 8 under round-robin
-    // placement: speed only) covering all of it: the candidate rows of the re-check and the winners' rows then come from this
-    // XCD's L2 instead of a cold fabric round trip.  The value is never used.
-    const int nslice = (K * E / 4) / 512;
-    warm = *(reinterpret_cast<const float4*>(W) + (int64_t)((blockIdx.x >> 3) % nslice) * 512 + tid);
+    for (int s = 0; s < KS / 2; ++s) {
+      wp0[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
+      wp1[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)((wave + 4) * KS + s) * 64 + lane) * 4);
+    }
+  } else {
+    load_tile(0);
+    load_tile(1);
   }
   __builtin_amdgcn_sched_barrier(0);
-  *reinterpret_cast<float4*>(Xz + zrow * ldx + 4 * zpart) = zrow < nrows ? zv : make_float4(0.f, 0.f, 0.f, 0.f);
+  {  // stage the raw tile: fp32 (projection operand, straight-through) and its bf16 hi / lo images (screening operand)
+    const float4 zs = zrow < nrows ? zv : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(Xz + zrow * ldx + 4 * zpart) = zs;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const float v[4] = {zs.x, zs.y, zs.z, zs.w};
+    bf16x4 h4, l4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      h4[j] = h;
+      l4[j] = (__bf16)(v[j] - (float)h);
+    }
+    *reinterpret_cast<bf16x4*>(Zh + zrow * BXF_LDH + 4 * zpart) = h4;
+    *reinterpret_cast<bf16x4*>(Zl + zrow * BXF_LDH + 4 * zpart) = l4;
+  }
+  if (projw) {
+#pragma unroll
+    for (int s = KS / 2; s < KS; ++s) {
+      wp0[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
+      wp1[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)((wave + 4) * KS + s) * 64 + lane) * 4);
+    }
+    b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
+    b1 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q + 64);
+    load_tile(0);
+    load_tile(1);
+  } else {
+#pragma unroll
+    for (int j = 2; j < NTB; ++j) load_tile(j);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   lds_barrier();
   VSTAMP(1);
-  {  // ---- pre_linear (:1230), output tile `wave`: one fp32 chain over k, the chain of vq_fused_assign_kernel ---------------------
-    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (projw) {  // ---- pre_linear (:1230): vq_fused_assign_kernel's two alternating fp32 chains (output tiles wave, wave + 4) -------------
+    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
       const float4 xb = *reinterpret_cast<const float4*>(Xz + i * ldx + 16 * s + 4 * q);
-      a = mfma16(wp[s].x, xb.x, a);
-      a = mfma16(wp[s].y, xb.y, a);
-      a = mfma16(wp[s].z, xb.z, a);
-      a = mfma16(wp[s].w, xb.w, a);
+      a0 = mfma16(wp0[s].x, xb.x, a0); a1 = mfma16(wp1[s].x, xb.x, a1);
+      a0 = mfma16(wp0[s].y, xb.y, a0); a1 = mfma16(wp1[s].y, xb.y, a1);
+      a0 = mfma16(wp0[s].z, xb.z, a0); a1 = mfma16(wp1[s].z, xb.z, a1);
+      a0 = mfma16(wp0[s].w, xb.w, a0); a1 = mfma16(wp1[s].w, xb.w, a1);
     }
-    const int f0 = 16 * wave + 4 * q;
-    const float4 b0 = *reinterpret_cast<const float4*>(bp + f0);
-    const float4 v0 = make_float4(a[0] + b0.x, a[1] + b0.y, a[2] + b0.z, a[3] + b0.w);
+    const int f0 = 16 * wave + 4 * q, f1 = f0 + 64;
+    const float4 v0 = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
+    const float4 v1 = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
     *reinterpret_cast<float4*>(Xf + i * ldx + f0) = v0;
-    if (i < nrows) *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
+    *reinterpret_cast<float4*>(Xf + i * ldx + f1) = v1;
+    if (i < nrows) {
+      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
+      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f1) = v1;
+    }
+  }
+  VSTAMP(2);
+  float ev[NTB][4];        // screening values of this lane's codes (row i)
+  float zz;                // |z_i|^2 (from the bf16 pair: 2^-16 relative)
+  {  // ---- screening sweep on the bf16 pipe, in z-space ---------------------------------------------------------------------------
+    bf16x8 zh[KB], zl[KB];
+    float ssq = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < KB; ++kb) {
+      zh[kb] = *reinterpret_cast<const bf16x8*>(Zh + i * BXF_LDH + 32 * kb + 8 * q);
+      zl[kb] = *reinterpret_cast<const bf16x8*>(Zl + i * BXF_LDH + 32 * kb + 8 * q);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float v = (float)zh[kb][j] + (float)zl[kb][j];
+        ssq += v * v;
+      }
+    }
+    ssq += __shfl_xor(ssq, 16);
+    ssq += __shfl_xor(ssq, 32);
+    zz = ssq;
+    float emin = INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < NTB; ++j) {
+      const bool on = j < nct && ct0 + 4 * j < ntile;        // wave-uniform
+      if (on) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (TERMS >= 2) {
+#pragma unroll
+          for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zl[kb], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zh[kb], acc, 0, 0, 0);
+        const float sv[4] = {sp[j].x, sp[j].y, sp[j].z, sp[j].w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = sv[r] - 2.0f * acc[r];
+          ev[j][r] = e;
+          emin = fminf(emin, e);
+          bad |= !(fabsf(e) < INFINITY);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ev[j][r] = INFINITY;
+      }
+    }
+    emin = fminf(emin, __shfl_xor(emin, 16));
+    emin = fminf(emin, __shfl_xor(emin, 32));
+    if (lane < 16) wmin[wave * 16 + lane] = emin;
+    if (__any(bad) && lane == 0) s_exact = 1;
   }
   lds_barrier();
-  VSTAMP(2);
-  if (tid < 256) {  // ||x||^2 of the projected rows (same summation tree as the fp32 kernel)
+  VSTAMP(3);
+  if (tid < 256) {  // ||x||^2 of the projected rows (the fp32 kernel's summation tree); first read behind the next barrier
     const int row = tid >> 4, part = tid & 15;
     float s = 0.f;
 #pragma unroll
@@ -1264,119 +1367,38 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     s = reduce16(s);
     if (part == 0) xx[row] = s;
   }
-  lds_barrier();
-  VSTAMP(3);
-  const float xr = xx[i];
-  float dv[NT][4];
-  {  // ---- screening sweep on the bf16 pipe ------------------------------------------------------------------------------------
-    bf16x8 xh[KB], xl[KB];
+  {  // every lane: its row's threshold (8 LDS reads: cheaper than a barrier around 16 threads doing it), then its candidates
+    float m = wmin[i];
 #pragma unroll
-    for (int kb = 0; kb < KB; ++kb) {
-      const float4 a = *reinterpret_cast<const float4*>(Xf + i * ldx + 32 * kb + 8 * q);
-      const float4 b = *reinterpret_cast<const float4*>(Xf + i * ldx + 32 * kb + 8 * q + 4);
-      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const __bf16 h = (__bf16)v[j];
-        xh[kb][j] = h;
-        xl[kb][j] = (__bf16)(v[j] - (float)h);
-      }
-    }
-    float dmin = INFINITY;
-    bool bad = false;
-#pragma unroll
-    for (int p = 0; p < NT; ++p) {
-      if (p < npass) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (TERMS >= 2) {
-#pragma unroll
-          for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p][kb], xl[kb], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[p][kb], xh[kb], acc, 0, 0, 0);
-        const float sv[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float d = (xr + sv[r]) - 2.0f * acc[r];
-          dv[p][r] = d;
-          dmin = fminf(dmin, d);
-          bad |= !(fabsf(d) < INFINITY);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) dv[p][r] = INFINITY;
-      }
-    }
-    dmin = fminf(dmin, __shfl_xor(dmin, 16));
-    dmin = fminf(dmin, __shfl_xor(dmin, 32));
-    if (lane < 16) wmin[wave * 16 + lane] = dmin;
-    if (__any(bad) && lane == 0) s_exact = 1;
-  }
-  lds_barrier();
-  if (tid < 16) {
-    float m = wmin[tid];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + tid]);
-    const float xr_ = xx[tid], wm = *wmaxp;
+    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + i]);
+    const float zn = __builtin_amdgcn_sqrtf(zz) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
+    const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_i|
     const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;                 // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
-    const float t = m + (c1 * (sqrtf(xr_) * sqrtf(wm)) + 1.9073486e-6f * (xr_ + wm) + 1e-30f);   // 1e-30: denormal flushes
-    thr[tid] = t;
-    if (!(fabsf(t) < INFINITY)) s_exact = 1;      // non-finite norms: no usable bound
-  }
-  lds_barrier();
-  VSTAMP(4);
-  bool exact = s_exact != 0;
-  if (!exact) {
-    const float th = thr[i];
+    const float th = m + (c1 * (zn * __builtin_amdgcn_sqrtf(sc.um)) + 2.4414063e-4f * (fn * wn) +
+                          1.9073486e-6f * (fn * fn + sc.wm) + 1e-30f);
+    if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
 #pragma unroll
-    for (int p = 0; p < NT; ++p) {
-      const float sv[4] = {wq[p].x, wq[p].y, wq[p].z, wq[p].w};
+    for (int j = 0; j < NTB; ++j) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (dv[p][r] <= th) {
-          const int slot = atomicAdd(&cnt[i], 1);
-          if (slot < BXF_CAP) {
-            cand_k[i * BXF_CAP + slot] = 16 * (wave + 8 * p) + 4 * q + r;
-            cand_s[i * BXF_CAP + slot] = sv[r];
+        if (ev[j][r] <= th) {
+          const int slot = atomicAdd(&s_np, 1);
+          if (slot < BXF_MAXP) {
+            p_row[slot] = i;
+            p_code[slot] = 16 * (ct0 + 4 * j) + 4 * q + r;
           }
         }
       }
     }
   }
   lds_barrier();
-  if (!exact && wave == 0) {     // pair list: rows in order, a row's candidates in arrival order (the choice below does not depend on it)
-    const int nraw = lane < 16 ? cnt[lane] : 0;
-    const int n = min(nraw, BXF_CAP);
-    int incl = n;
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) {
-      const int t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
-    const int total = __shfl(incl, 15);
-    const bool over = __any(nraw > BXF_CAP) || total > BXF_MAXP;
-    if (over) {
-      if (lane == 0) s_exact = 1;
-    } else if (lane < 16) {
-      const int b0 = incl - n;
-      pbase[lane] = b0;
-      if (lane == 15) pbase[16] = incl;
-      for (int s = 0; s < n; ++s) {
-        p_row[b0 + s] = lane;
-        p_code[b0 + s] = cand_k[lane * BXF_CAP + s];
-        p_s[b0 + s] = cand_s[lane * BXF_CAP + s];
-      }
-    }
-  }
-  lds_barrier();
-  VSTAMP(5);
-  exact = s_exact != 0;
-  int npairs = 0;
+  VSTAMP(4);
+  const float xr = xx[i];
+  const int P = s_np;
+  bool exact = (s_exact != 0) || P > BXF_MAXP;
   if (!exact) {
     // ---- exact fp32 re-evaluation of the candidates: A = 16 candidate rows gathered from the row-major codebook, B = the tile's
     // 16 projected rows; element (candidate, its own row) of the 16 x 16 product is the fp32 kernel's dot product, bit for bit
-    const int P = pbase[16];
-    npairs = P;
     for (int chunk = wave; 16 * chunk < P; chunk += 8) {
       const int pi = 16 * chunk + i;
       const int code = pi < P ? p_code[pi] : 0;
@@ -1384,6 +1406,16 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       float4 wf[KS], xb[KS];
 #pragma unroll
       for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+      int prow[4], pc[4];
+      float ps[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {          // the pairs whose products land in this lane's accumulator: candidates 4 q + r
+        const int pj = 16 * chunk + 4 * q + r;
+        prow[r] = pj < P ? p_row[pj] : -1;
+        pc[r] = pj < P ? p_code[pj] : 0;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ps[r] = wsq[pc[r]];
 #pragma unroll
       for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1396,28 +1428,30 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int pj = 16 * chunk + 4 * q + r;
-        if (pj < P && p_row[pj] == i) p_d[pj] = (xr + p_s[pj]) - 2.0f * a[r];
+        if (prow[r] == i) {
+          const float d = (xr + ps[r]) - 2.0f * a[r];
+          if (!(fabsf(d) < INFINITY)) s_exact = 1;          // a non-finite exact value: the exact sweep decides (NaN rules)
+          atomicMin(&rowbest[i], bxf_key(d, pc[r]));
+        }
       }
     }
     lds_barrier();
-    if (tid < 16) {
-      const int b0 = pbase[tid], e0 = pbase[tid + 1];
-      float d = p_d[b0];
-      int k = p_code[b0];
-      for (int j = b0 + 1; j < e0; ++j) argmin_merge(d, k, p_d[j], p_code[j]);
+    exact = s_exact != 0;
+    if (!exact && tid < 16) {
+      const int k = (int)(unsigned)(rowbest[tid] & 0xffffffffull);
       best_k[tid] = k;
       if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
     }
-  } else {
+  }
+  VSTAMP(5);
+  if (exact) {
     // ---- exact fp32 sweep over every code (vq_fused_assign_kernel's arithmetic; slow path) ---------------------------------------
     float4 xb[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
     float bd = INFINITY;
     int bk = 0;
-    for (int p = 0; p < npass; ++p) {
-      const int kt = wave + 8 * p;
+    for (int kt = wave; kt < ntile; kt += 8) {
       const float* wrow = W + (int64_t)(16 * kt + i) * E + 4 * q;
       float4 wf[KS];
 #pragma unroll
@@ -1471,9 +1505,9 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
 #pragma unroll
       for (int j = 0; j < E / 64; ++j) {
         const int c = 4 * (part + 16 * j);
-        const float4 zz = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
-        const float4 df = make_float4(wv.x - zz.x, wv.y - zz.y, wv.z - zz.z, wv.w - zz.w);
-        *reinterpret_cast<float4*>(qo + c) = make_float4(zz.x + df.x, zz.y + df.y, zz.z + df.z, zz.w + df.w);   // :1292
+        const float4 zzv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
+        const float4 df = make_float4(wv.x - zzv.x, wv.y - zzv.y, wv.z - zzv.z, wv.w - zzv.w);
+        *reinterpret_cast<float4*>(qo + c) = make_float4(zzv.x + df.x, zzv.y + df.y, zzv.z + df.z, zzv.w + df.w);   // :1292
         sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
       }
     }
@@ -1485,49 +1519,71 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     if (sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
     if (diag) {
       if (exact) atomicAdd(&diag[0], 1);
-      atomicAdd(&diag[1], npairs);
-      if (WARM && warm.x == -1.2345e38f && warm.w == 7.f) diag[2] = 1;     // keeps the warming load alive; never true in practice
+      else atomicAdd(&diag[1], P);
     }
   }
   VSTAMP(7);
 }
 
-// bf16 MFMA-fragment image of the codebook for vq_fused_bx_kernel: [K/16 tiles][E/32 k-blocks][64 lanes][8] with lane (q, i) of
-// tile kt, block kb holding bf16(W[16 kt + i][32 kb + 8 q .. + 7]); behind it one float: max_k |W_k|^2 (from code_sqnorm).
+// Screening operands of vq_fused_bx_kernel, rebuilt whenever the codebook (or pre_linear) changed: one workgroup per 16 codes.
+//   U = W W_pre (u_k = W_pre^T w_k), as the bf16 MFMA-fragment image [K/16 tiles][E/32 k-blocks][64 lanes][8]: lane (q, i) of
+//   tile kt, block kb holds bf16(U[16 kt + i][32 kb + 8 q .. + 7]);  s'_k = |w_k|^2 - 2 b.w_k;  scalars max|w_k|^2, max|u_k|^2
+//   (atomicMax on the bit patterns of non-negative floats: the host clears them first), |W_pre|_F^2, |b|^2.
 __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
-                                                         __bf16* __restrict__ Whf, float* __restrict__ wmax, int K, int E) {
-  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;         // one 16-byte fragment element per thread
-  const int kbs = E / 32;
-  if (o < (int64_t)K * E / 8) {
-    const int lane = (int)(o & 63), i = lane & 15, q = lane >> 4;
-    const int64_t tb = o >> 6;
-    const int kb = (int)(tb % kbs), kt = (int)(tb / kbs);
-    const float* src = W + (int64_t)(16 * kt + i) * E + 32 * kb + 8 * q;
-    const float4 a = *reinterpret_cast<const float4*>(src), b = *reinterpret_cast<const float4*>(src + 4);
-    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                                                         const float* __restrict__ Wp, const float* __restrict__ bp,
+                                                         __bf16* __restrict__ Uhf, float* __restrict__ sprime,
+                                                         BxfScalars* __restrict__ scal, int K) {
+  constexpr int E = 128;
+  __shared__ float Ws[16][E + 1];
+  __shared__ float Us[16][E + 1];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, kt = blockIdx.x;
+  for (int e = tid; e < 16 * E; e += 256) Ws[e / E][e % E] = W[(int64_t)(16 * kt) * E + e];
+  __syncthreads();
+  {
+    const int j = tid & 127, kh = tid >> 7;           // column j of U, codes kh, kh + 2, ..
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    for (int e = 0; e < E; ++e) {
+      const float wv = Wp[e * E + j];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) acc[m] = fmaf(Ws[kh + 2 * m][e], wv, acc[m]);
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m) Us[kh + 2 * m][j] = acc[m];
+  }
+  __syncthreads();
+  for (int o = tid; o < 16 * E / 8; o += 256) {        // 16-byte fragment elements of this tile: [kb][lane]
+    const int lane = o & 63, kb = o >> 6, i = lane & 15, q = lane >> 4;
     bf16x8 h;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) h[j] = (__bf16)v[j];
-    *reinterpret_cast<bf16x8*>(Whf + o * 8) = h;
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)Us[i][32 * kb + 8 * q + e];
+    *reinterpret_cast<bf16x8*>(Uhf + ((int64_t)(kt * (E / 32) + kb) * 64 + lane) * 8) = h;
   }
-  if (blockIdx.x == 0) {
-    __shared__ float red[4];
-    float m = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256) {
-      const float s = wsq[k];
-      m = (s > m || s != s) ? s : m;              // a NaN norm poisons the bound: every tile then takes the exact path
+  if (tid < 16) {
+    float uu = 0.f, bw = 0.f;
+    for (int e = 0; e < E; ++e) {
+      uu = fmaf(Us[tid][e], Us[tid][e], uu);
+      bw = fmaf(bp[e], Ws[tid][e], bw);
     }
-#pragma unroll
-    for (int o2 = 32; o2 > 0; o2 >>= 1) {
-      const float t = __shfl_xor(m, o2);
-      m = (t > m || t != t) ? t : m;
-    }
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    const float s = wsq[16 * kt + tid];
+    sprime[16 * kt + tid] = s - 2.0f * bw;
+    // NaN bit patterns order above +inf: a NaN norm poisons the bound and every tile then takes the exact sweep
+    atomicMax(reinterpret_cast<unsigned*>(&scal->um), __float_as_uint(fabsf(uu)));
+    atomicMax(reinterpret_cast<unsigned*>(&scal->wm), __float_as_uint(fabsf(s)));
+  }
+  if (kt == 0) {
+    float f = 0.f;
+    for (int e = tid; e < E * E; e += 256) f = fmaf(Wp[e], Wp[e], f);
+    f = wave_sum(f);
+    if ((tid & 63) == 0) red[tid >> 6] = f;
     __syncthreads();
-    if (threadIdx.x == 0) {
-      float r = red[0];
-      for (int w = 1; w < 4; ++w) r = (red[w] > r || red[w] != red[w]) ? red[w] : r;
-      *wmax = r;
+    if (tid == 0) {
+      float bb = 0.f;
+      for (int e = 0; e < E; ++e) bb = fmaf(bp[e], bp[e], bb);
+      scal->wpf2 = (red[0] + red[1]) + (red[2] + red[3]);
+      scal->bb = bb;
     }
   }
 }
@@ -1679,21 +1735,27 @@ extern "C" int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre
 
 extern "C" size_t g2v_vq_bx_image_bytes(int K, int E) {
   if (K <= 0 || E <= 0) return 0;
-  return (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256;
-}
-
-extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, void* image, int K, int E, g2v_stream_t stream) {
-  G2V_REQUIRE(codebook && code_sqnorm && image, "null pointer");
-  G2V_REQUIRE(K > 0 && E > 0 && (K & 15) == 0 && (E & 31) == 0, "K must be a multiple of 16 and E of 32");
-  G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
-  const size_t half = ((size_t)K * E * 2 + 255) & ~(size_t)255;
-  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(cdiv((int64_t)K * E / 8, 256)), dim3(256), 0, (hipStream_t)stream, codebook,
-                     code_sqnorm, (__bf16*)image, (float*)((char*)image + half), K, E);
-  G2V_CHECK_LAUNCH();
-  return G2V_OK;
+  return (((size_t)K * E * 2 + 255) & ~(size_t)255) + (((size_t)K * 4 + 255) & ~(size_t)255) + 256;
 }
 
 extern "C" int g2v_vq_fused_assign_bx_ok(int N, int E, int K) { return (N > 0 && E == 128 && (K & 127) == 0 && K >= 128 && K <= 512) ? 1 : 0; }
+
+extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, const float* w_pre, const float* b_pre, void* image,
+                              int K, int E, g2v_stream_t stream) {
+  G2V_REQUIRE(codebook && code_sqnorm && w_pre && b_pre && image, "null pointer");
+  if (!g2v_vq_fused_assign_bx_ok(1, E, K)) {
+    set_error("g2v_vq_bx_pack: needs E == 128, K in {128, 256, 384, 512}");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
+  const size_t o1 = ((size_t)K * E * 2 + 255) & ~(size_t)255, o2 = o1 + (((size_t)K * 4 + 255) & ~(size_t)255);
+  hipStream_t st = (hipStream_t)stream;
+  (void)hipMemsetAsync((char*)image + o2, 0, sizeof(BxfScalars), st);
+  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), 0, st, codebook, code_sqnorm, w_pre, b_pre, (__bf16*)image,
+                     (float*)((char*)image + o1), (BxfScalars*)((char*)image + o2), K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
 
 extern "C" int g2v_vq_fused_assign_bx_fwd(const float* z, const float* w_pre_frag, const float* b_pre, const float* codebook,
                                           const void* image, const float* code_sqnorm, float* flat_out, int64_t* idx,
@@ -1707,21 +1769,19 @@ extern "C" int g2v_vq_fused_assign_bx_fwd(const float* z, const float* w_pre_fra
     set_error("g2v_vq_fused_assign_bx_fwd: needs E == 128, K in {128, 256, 384, 512} and 16-byte aligned operands");
     return G2V_ERR_UNSUPPORTED;
   }
-  const size_t half = ((size_t)K * E * 2 + 255) & ~(size_t)255;
-  const __bf16* whf = (const __bf16*)image;
-  const float* wmax = (const float*)((const char*)image + half);
+  const size_t o1 = ((size_t)K * E * 2 + 255) & ~(size_t)255, o2 = o1 + (((size_t)K * 4 + 255) & ~(size_t)255);
+  const __bf16* uhf = (const __bf16*)image;
+  const float* sprime = (const float*)((const char*)image + o1);
+  const BxfScalars* scal = (const BxfScalars*)((const char*)image + o2);
   const dim3 grid(cdiv(N, VQ_ROWS)), block(512);
   hipStream_t st = (hipStream_t)stream;
   const int exact = flags & G2V_VQ_BX_EXACT;
-#define G2V_BX_LAUNCH(T, WRM)                                                                                                  \
-  hipLaunchKernelGGL((vq_fused_bx_kernel<T, WRM>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, whf, wmax, code_sqnorm, \
-                     flat_out, idx, quantized, sse_partial, diag, N, K, exact)
-  if (flags & G2V_VQ_BX_ONE_TERM) {
-    if (flags & G2V_VQ_BX_NO_WARM) G2V_BX_LAUNCH(1, false); else G2V_BX_LAUNCH(1, true);
-  } else {
-    if (flags & G2V_VQ_BX_NO_WARM) G2V_BX_LAUNCH(2, false); else G2V_BX_LAUNCH(2, true);
-  }
-#undef G2V_BX_LAUNCH
+  if (flags & G2V_VQ_BX_ONE_TERM)
+    hipLaunchKernelGGL((vq_fused_bx_kernel<1>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, uhf, sprime, scal, code_sqnorm,
+                       flat_out, idx, quantized, sse_partial, diag, N, K, exact);
+  else
+    hipLaunchKernelGGL((vq_fused_bx_kernel<2>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, uhf, sprime, scal, code_sqnorm,
+                       flat_out, idx, quantized, sse_partial, diag, N, K, exact);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

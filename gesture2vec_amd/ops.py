@@ -213,16 +213,17 @@ def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm, codebook_frag=None):
     return flat, idx, quant, sse
 
 
-VQ_BX_EXACT, VQ_BX_ONE_TERM, VQ_BX_NO_WARM = 1, 2, 4          # include/g2v.h G2V_VQ_BX_*
+VQ_BX_EXACT, VQ_BX_ONE_TERM = 1, 2          # include/g2v.h G2V_VQ_BX_*
 
 
-def vq_bx_pack(codebook, code_sqnorm, out=None):
-    """bf16 MFMA-fragment image of the codebook (+ max_k |W_k|^2) for vq_fused_assign_bx (g2v_vq_bx_pack)"""
+def vq_bx_pack(codebook, code_sqnorm, w_pre, b_pre, out=None):
+    """screening operands of vq_fused_assign_bx (g2v_vq_bx_pack): bf16 fragments of U = W w_pre, s'_k, norm bounds"""
     K, E = codebook.shape
     nb = int(_lib_().g2v_vq_bx_image_bytes(K, E))
     if out is None:
         out = torch.empty((nb,), dtype=torch.uint8, device=codebook.device)
-    check(_lib_().g2v_vq_bx_pack(_p(_chk(codebook)), _p(_chk(code_sqnorm)), _p(out), K, E, _stream()), "vq_bx_pack")
+    check(_lib_().g2v_vq_bx_pack(_p(_chk(codebook)), _p(_chk(code_sqnorm)), _p(_chk(w_pre)), _p(_chk(b_pre)), _p(out), K, E,
+                                 _stream()), "vq_bx_pack")
     return out
 
 

@@ -14,7 +14,7 @@ flags = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 W = (torch.rand(K, E, device=dev) * 2 - 1); wsq = ops.vq_code_sqnorm(W)
 Wp = torch.randn(E, E, device=dev) * 0.1; bp = torch.randn(E, device=dev) * 0.1
 z = torch.randn(N, E, device=dev)
-wpf = ops.vq_pack_codebook(Wp); img = ops.vq_bx_pack(W, wsq)
+wpf = ops.vq_pack_codebook(Wp); img = ops.vq_bx_pack(W, wsq, Wp, bp)
 for _ in range(10):
     ops.vq_fused_assign_bx(z, wpf, bp, W, img, wsq, flags=flags)
 torch.cuda.synchronize()

@@ -147,23 +147,25 @@ int g2v_vq_pack_codebook(const float* codebook, float* codebook_frag, int K, int
 int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
                                    const float* codebook_frag, const float* code_sqnorm, float* flat_out, int64_t* idx,
                                    float* quantized, float* sse_partial, int N, int E, int K, g2v_stream_t stream);
-/* The north-star form (round 3): pre_linear in fp32 MFMA, the -2 x W^T contraction SCREENED on the bf16 matrix pipe
- * ((xh + xl) . bf16(w), fp32 accumulate, 8 v_mfma_f32_16x16x32_bf16 per 16 x 16 x 128 tile instead of 32 fp32 MFMAs), every code
- * within margin = 2^-6 (1 + 2^-5) |x| max|w| + 2^-19 (|x|^2 + max|w|^2) of the row's approximate minimum (> 2x the screening's
- * error bound) re-evaluated IN THE SAME LAUNCH with the exact fp32 MFMA chain of g2v_vq_fused_assign_fwd, the row's code being
- * the torch.argmin (:1259) of those exact distances: flat_out, idx, quantized and sse_partial are bitwise those of
- * g2v_vq_fused_assign_fwd.  A 16-row tile with a non-finite distance or more candidates than the kernel lists (16 per row, 128
- * per tile) takes the exact fp32 sweep over all K codes instead.  E == 128, K in {128, 256, 384, 512} (g2v_vq_fused_assign_bx_ok).
+/* The north-star form (round 3): pre_linear in fp32 MFMA and, BESIDE it in the same launch, the -2 x W^T contraction SCREENED on
+ * the bf16 matrix pipe in z-space: flat.w_k = z.u_k + b.w_k with u_k = w_pre^T w_k, so e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)
+ * (fp32 accumulate, 8 v_mfma_f32_16x16x32_bf16 per 16 x 16 x 128 tile instead of 32 fp32 MFMAs) needs no projected row.  Every code
+ * whose e_k is within margin = 2^-6 (1 + 2^-5) |z| max|u| + 2^-12 |flat|^ max|w| + 2^-19 (|flat|^^2 + max|w|^2) of the row's minimum
+ * (|flat|^ = |w_pre|_F |z| + |b| >= |flat|; more than twice the screening's error bound, derivation in vq.hip) is re-evaluated IN THE
+ * SAME LAUNCH with the exact fp32 MFMA chain of g2v_vq_fused_assign_fwd on the projected rows, the row's code being the
+ * torch.argmin (:1259) of those exact distances: flat_out, idx, quantized and sse_partial are bitwise those of
+ * g2v_vq_fused_assign_fwd.  A 16-row tile with a non-finite screening value or more than 128 candidates takes the exact fp32
+ * sweep over all K codes instead.  E == 128, K in {128, 256, 384, 512} (g2v_vq_fused_assign_bx_ok).
  *   w_pre_frag  g2v_vq_pack_codebook(w_pre, ., E, E): pre_linear's weight as fp32 MFMA fragments (E * E floats)
- *   image       g2v_vq_bx_pack(codebook, code_sqnorm, ., K, E): bf16 MFMA fragments of the codebook + max_k |W_k|^2
- *               (g2v_vq_bx_image_bytes(K, E) bytes); rewrite it whenever the codebook (and code_sqnorm) changed
+ *   image       g2v_vq_bx_pack(codebook, code_sqnorm, w_pre, b_pre, ., K, E): bf16 MFMA fragments of U = W w_pre, s'_k and the norm
+ *               bounds (g2v_vq_bx_image_bytes(K, E) bytes); rewrite it whenever the codebook / code_sqnorm / pre_linear changed
  *   diag        device int[4] or NULL: [0] += tiles that took the exact sweep, [1] += (row, candidate) pairs re-evaluated
  *   flags       G2V_VQ_BX_*: explicit per-call switches (no process-global state) */
 #define G2V_VQ_BX_EXACT 1      /* every tile takes the exact fp32 sweep: the A/B reference of the screened path */
-#define G2V_VQ_BX_ONE_TERM 2   /* screen with xh . wh only (4 MFMAs per tile, margin 2^-5 (...)) */
-#define G2V_VQ_BX_NO_WARM 4    /* do not pre-touch the row-major codebook slice of this workgroup */
+#define G2V_VQ_BX_ONE_TERM 2   /* screen with zh . bf16(u) only (4 MFMAs per tile, margin 2^-5 (...)) */
 size_t g2v_vq_bx_image_bytes(int K, int E);
-int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, void* image, int K, int E, g2v_stream_t stream);
+int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, const float* w_pre, const float* b_pre, void* image, int K, int E,
+                   g2v_stream_t stream);
 int g2v_vq_fused_assign_bx_ok(int N, int E, int K);
 int g2v_vq_fused_assign_bx_fwd(const float* z, const float* w_pre_frag, const float* b_pre, const float* codebook,
                                const void* image, const float* code_sqnorm, float* flat_out, int64_t* idx, float* quantized,

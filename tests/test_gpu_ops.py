@@ -387,7 +387,7 @@ def _bx_case(kind, N, K, seed):
 @pytest.mark.parametrize("kind,N,K", [("uniform", 4096, 512), ("trained", 4096, 512), ("ties", 4096, 512), ("collapsed", 256, 512),
                                       ("nonfinite", 4096, 512), ("tiny", 512, 512), ("uniform", 37, 512), ("uniform", 20000, 256),
                                       ("trained", 1000, 128), ("ties", 16, 384)])
-@pytest.mark.parametrize("flags", [0, 2, 4])        # two-term screening (product path), one-term, no L2 warming
+@pytest.mark.parametrize("flags", [0, 2])        # two-term screening (product path), one-term
 def test_vq_fused_bx_equals_fp32_kernel_on_every_row(ops, kind, N, K, flags):
     """g2v_vq_fused_assign_bx_fwd (round 3: distance screening on the bf16 matrix pipe, in-kernel exact fp32 re-check of every
     code inside the error margin) must return, BITWISE, what the fp32 fused kernel returns -- flat, idx on every row
@@ -397,7 +397,7 @@ def test_vq_fused_bx_equals_fp32_kernel_on_every_row(ops, kind, N, K, flags):
     wsq = ops.vq_code_sqnorm(Wd)
     ref = ops.vq_fused_assign(zd, Wpd, bpd, Wd, wsq)
     wpf = ops.vq_pack_codebook(Wpd)
-    img = ops.vq_bx_pack(Wd, wsq)
+    img = ops.vq_bx_pack(Wd, wsq, Wpd, bpd)
     assert ops._lib_().g2v_vq_fused_assign_bx_ok(N, 128, K) == 1
     for fl in (flags, flags | 1):
         got = ops.vq_fused_assign_bx(zd, wpf, bpd, Wd, img, wsq, flags=fl, want_diag=True)
@@ -436,7 +436,7 @@ def test_vq_fused_bx_matches_golden_indices(ops, golden_dir):
     Wd = W.to(DEV)
     wsq = ops.vq_code_sqnorm(Wd)
     flat, idx, quant, sse = ops.vq_fused_assign_bx(z.to(DEV), ops.vq_pack_codebook(Wp.to(DEV)), bp.to(DEV), Wd,
-                                                   ops.vq_bx_pack(Wd, wsq), wsq)
+                                                   ops.vq_bx_pack(Wd, wsq, Wp.to(DEV), bp.to(DEV)), wsq)
     safe = fx["ema/c1/gap"] > 1e-4
     assert np.array_equal(idx.cpu().numpy()[safe], fx["ema/c1/idx"][safe]), "code indices differ from the reference"
     close(flat, torch.from_numpy(fx["ema/c1/flat"].copy()), 1e-6, 1e-5, "pre_linear rows")
