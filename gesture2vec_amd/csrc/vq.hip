@@ -27,8 +27,14 @@ __device__ unsigned long long g2v_vqstamps[4 * 16];
 extern "C" int g2v_read_vqstamps(unsigned long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_vqstamps), sizeof(unsigned long long) * 64);
 }
+#define VSTAMP_B(k)                                                                                                      \
+  do {                                                                                                                   \
+    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
+    if (threadIdx.x == 256 && sb_ >= 0) g2v_vqstamps[sb_ * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime();                  \
+  } while (0)
 #else
 #define VSTAMP(k)
+#define VSTAMP_B(k)
 #endif
 
 namespace g2v {
@@ -1159,7 +1165,7 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 //          e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)      (zh = bf16(z), zl = bf16(z - zh); 8 MFMAs of 16 cycles per
 //          16 x 16 x 128 tile instead of 32 of 32 cycles; ONE_TERM drops the zl products)
 //      approximates d_k - |flat|^2 WITHOUT the projected rows: the sweep does not wait for the projection, the two run side by side
-//      (waves 0-3: the projection's two fp32 chains each + 2 code tiles; waves 4-7: 6 code tiles each), both fed by one 202 KB
+//      (waves 0-3: the projection's two fp32 chains each; waves 4-7: 8 code tiles each), both fed by one 202 KB
 //      request stream per CU (z tile 8 KB, W_pre fp32 fragments 64 KB, bf16 fragments of U 128 KB, s'_k = |w_k|^2 - 2 b.w_k 2 KB)
 //      instead of the fp32 kernel's 328 KB;
 //  (2) every code whose e_k lies within `margin` of the row's minimum is re-evaluated with the EXACT fp32 MFMA chain of
@@ -1176,7 +1182,7 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 // BXF_MAXP candidates takes the exact fp32 sweep over all K codes instead (exact_only != 0 forces it: the A/B reference).
 constexpr int BXF_MAXP = 128;      // (row, candidate) pairs re-evaluated per tile: 8 waves x one 16-pair MFMA tile
 constexpr int BXF_LDH = 128 + 8;   // bf16 elements per LDS row of the hi / lo images: 272 B, conflict-free ds_read_b128 per 16 lanes
-constexpr int BXF_NTA = 2, BXF_NTB = 6;      // code tiles of a projection wave (0-3) / of a sweep-only wave (4-7): 4 * (2 + 6) = 32
+constexpr int BXF_LDE = 512 + 4;   // floats per LDS row of the screening values
 
 // monotone map float -> uint32 (a < b  <=>  key(a) < key(b); no NaNs reach it), so that (key(d) << 32 | code) orders by
 // distance first and by code index second: an LDS atomicMin over a row's candidates IS torch.argmin's tie rule
@@ -1188,6 +1194,16 @@ __device__ __forceinline__ unsigned long long bxf_key(float d, int code) {
 
 struct BxfScalars { float wm, um, wpf2, bb; };      // max|w_k|^2, max|u_k|^2, |W_pre|_F^2, |b|^2 (behind the image, g2v_vq_bx_pack)
 
+// Roles (wave-uniform), synchronised by ONE workgroup barrier at the end of both:
+//   waves 0-3  the projection.  Each reads the raw tile straight from global in MFMA B-fragment layout (8 requests, in front of
+//              its 16 W_pre fragment requests), stages its share of it in LDS (fp32 for the straight-through epilogue, bf16
+//              hi / lo images for the sweep waves, then a counter in LDS), and runs the fp32 kernel's two alternating chains.
+//   waves 4-7  the screening sweep.  Wave 4 + b owns code tiles b, b + 4, .. (8 at K = 512) and requests every fragment of them
+//              at once, from the first cycle of the launch (a ring of four sets re-requested behind their MFMAs, and requests
+//              that started behind the staging barrier, both ended the sweep at 10-11 k cycles: the 202 KB arrive at ~40 B/clk
+//              from the moment the LAST of them is requested); it waits for the staged images by polling the LDS counter.
+// The screening values go to LDS (16 x K floats); after the barrier all 512 threads scan them (thread -> 16 codes of one row) and
+// list the candidates; the re-check takes 16 pairs per wave.
 template <int TERMS>
 __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restrict__ z, const float* __restrict__ Wpf,
                                                           const float* __restrict__ bp, const float* __restrict__ W,
@@ -1196,118 +1212,117 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
                                                           float* __restrict__ flat_out, int64_t* __restrict__ idx_out,
                                                           float* __restrict__ quant, float* __restrict__ sse_partial,
                                                           int* __restrict__ diag, int N, int K, int exact_only) {
-  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NTB = BXF_NTB, NTA = BXF_NTA;
+  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NTW = 8;
   __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) __bf16 Zh[VQ_ROWS * BXF_LDH];
   __shared__ __attribute__((aligned(16))) __bf16 Zl[VQ_ROWS * BXF_LDH];
+  __shared__ __attribute__((aligned(16))) float Es[VQ_ROWS * BXF_LDE];
   __shared__ float xx[16];
-  __shared__ float wmin[8 * 16];
+  __shared__ float zzs[16];
+  __shared__ float wmin[4 * 16];
   __shared__ unsigned long long rowbest[16];
   __shared__ int p_row[BXF_MAXP];
   __shared__ int p_code[BXF_MAXP];
   __shared__ float wbest_d[8 * 16];
   __shared__ int wbest_k[8 * 16];
   __shared__ int best_k[16];
-  __shared__ float red[4];
-  __shared__ int s_exact, s_np;
+  __shared__ float rowsse[16];
+  __shared__ int s_exact, s_np, s_zready;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.x * VQ_ROWS;
   const int nrows = min(VQ_ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
   const int ntile = K >> 4;
   const bool projw = wave < 4;                 // wave-uniform role
+  const int bw = wave - 4;
   VSTAMP(0);
+  const BxfScalars sc = *scal;
+  VSTAMP_B(0);
   if (tid < 16) rowbest[tid] = ~0ull;
   if (tid == 0) {
     s_exact = exact_only;
     s_np = 0;
+    s_zready = 0;
   }
-  const BxfScalars sc = *scal;
-  // ---- requests, in consumption order.  Code tiles: projection wave w owns w + 4 j (j < 2), sweep wave w owns 8 + (w - 4) + 4 j
-  // (j < 6); tiles at or beyond K / 16 (K < 512) re-read tile 0 and are ignored.
-  const int zrow = tid >> 5, zpart = tid & 31;
-  const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + (zrow < nrows ? zrow : 0)) * E + 4 * zpart);
-  float4 wp0[KS], wp1[KS];                     // projection waves only
-  float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
-  bf16x8 uf[NTB][KB];
-  float4 sp[NTB];
-  const int ct0 = projw ? wave : 8 + (wave - 4);
-  const int nct = projw ? NTA : NTB;
-  auto load_tile = [&](int j) {
-    const int kt = ct0 + 4 * j;
-    const int ktc = kt < ntile ? kt : 0;
-#pragma unroll
-    for (int kb = 0; kb < KB; ++kb) uf[j][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
-    sp[j] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
-  };
+  lds_barrier();        // the only purpose of this barrier: the polled counter is zero before anybody adds to it (LDS is not cleared)
+  // the projection's 26 requests per wave must reach the memory pipeline BEFORE the sweep waves' 40 (first requested, first
+  // served: with both bursts issued at once the raw tile arrived at 7.4 k cycles): the projection waves issue at priority 3
+  if (projw) __builtin_amdgcn_s_setprio(3);
   if (projw) {
+    // ================================================ projection waves ================================================================
+    float4 zf[KS], wp0[KS], wp1[KS];
+    {
+      const float* zr = z + (int64_t)(r0 + (i < nrows ? i : 0)) * E + 4 * q;
 #pragma unroll
-    for (int s = 0; s < KS / 2; ++s) {
+      for (int s = 0; s < KS; ++s) zf[s] = *reinterpret_cast<const float4*>(zr + 16 * s);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
       wp0[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
       wp1[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)((wave + 4) * KS + s) * 64 + lane) * 4);
     }
-  } else {
-    load_tile(0);
-    load_tile(1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  {  // stage the raw tile: fp32 (projection operand, straight-through) and its bf16 hi / lo images (screening operand)
-    const float4 zs = zrow < nrows ? zv : make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(Xz + zrow * ldx + 4 * zpart) = zs;
-    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-    const float v[4] = {zs.x, zs.y, zs.z, zs.w};
-    bf16x4 h4, l4;
+    const float4 b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
+    const float4 b1 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q + 64);
+    __builtin_amdgcn_sched_barrier(0);
+    VSTAMP(7);
+    if (i >= nrows) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const __bf16 h = (__bf16)v[j];
-      h4[j] = h;
-      l4[j] = (__bf16)(v[j] - (float)h);
+      for (int s = 0; s < KS; ++s) zf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    *reinterpret_cast<bf16x4*>(Zh + zrow * BXF_LDH + 4 * zpart) = h4;
-    *reinterpret_cast<bf16x4*>(Zl + zrow * BXF_LDH + 4 * zpart) = l4;
-  }
-  if (projw) {
+    {  // stage k-steps 2 wave, 2 wave + 1 of the raw tile: fp32 + bf16 hi / lo
+      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 #pragma unroll
-    for (int s = KS / 2; s < KS; ++s) {
-      wp0[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
-      wp1[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)((wave + 4) * KS + s) * 64 + lane) * 4);
+      for (int t = 0; t < 2; ++t) {
+        const float4 v4 = t == 0 ? (wave == 0 ? zf[0] : wave == 1 ? zf[2] : wave == 2 ? zf[4] : zf[6])
+                                 : (wave == 0 ? zf[1] : wave == 1 ? zf[3] : wave == 2 ? zf[5] : zf[7]);
+        const int col = 16 * (2 * wave + t) + 4 * q;
+        *reinterpret_cast<float4*>(Xz + i * ldx + col) = v4;
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        bf16x4 h4, l4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const __bf16 h = (__bf16)v[j];
+          h4[j] = h;
+          l4[j] = (__bf16)(v[j] - (float)h);
+        }
+        *reinterpret_cast<bf16x4*>(Zh + i * BXF_LDH + col) = h4;
+        *reinterpret_cast<bf16x4*>(Zl + i * BXF_LDH + col) = l4;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (lane == 0) atomicAdd(&s_zready, 1);
     }
-    b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
-    b1 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q + 64);
-    load_tile(0);
-    load_tile(1);
-  } else {
-#pragma unroll
-    for (int j = 2; j < NTB; ++j) load_tile(j);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  lds_barrier();
-  VSTAMP(1);
-  if (projw) {  // ---- pre_linear (:1230): vq_fused_assign_kernel's two alternating fp32 chains (output tiles wave, wave + 4) -------------
+    VSTAMP(1);
+    // ---- pre_linear (:1230): vq_fused_assign_kernel's two alternating fp32 chains (output tiles wave, wave + 4) -------------------
     f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const float4 xb = *reinterpret_cast<const float4*>(Xz + i * ldx + 16 * s + 4 * q);
+      const float4 xb = zf[s];
       a0 = mfma16(wp0[s].x, xb.x, a0); a1 = mfma16(wp1[s].x, xb.x, a1);
       a0 = mfma16(wp0[s].y, xb.y, a0); a1 = mfma16(wp1[s].y, xb.y, a1);
       a0 = mfma16(wp0[s].z, xb.z, a0); a1 = mfma16(wp1[s].z, xb.z, a1);
       a0 = mfma16(wp0[s].w, xb.w, a0); a1 = mfma16(wp1[s].w, xb.w, a1);
     }
     const int f0 = 16 * wave + 4 * q, f1 = f0 + 64;
-    const float4 v0 = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
-    const float4 v1 = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
-    *reinterpret_cast<float4*>(Xf + i * ldx + f0) = v0;
-    *reinterpret_cast<float4*>(Xf + i * ldx + f1) = v1;
-    if (i < nrows) {
-      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
-      *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f1) = v1;
+    *reinterpret_cast<float4*>(Xf + i * ldx + f0) = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
+    *reinterpret_cast<float4*>(Xf + i * ldx + f1) = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
+    VSTAMP(8);
+  } else {
+    // ================================================== sweep waves ===================================================================
+    bf16x8 uf[NTW][KB];
+    float4 sp[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int kt = bw + 4 * j;
+      const int ktc = kt < ntile ? kt : 0;       // beyond K / 16: a valid tile, its values are dropped
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) uf[j][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
+      sp[j] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
     }
-  }
-  VSTAMP(2);
-  float ev[NTB][4];        // screening values of this lane's codes (row i)
-  float zz;                // |z_i|^2 (from the bf16 pair: 2^-16 relative)
-  {  // ---- screening sweep on the bf16 pipe, in z-space ---------------------------------------------------------------------------
+    __builtin_amdgcn_sched_barrier(0);
+    VSTAMP_B(1);
+    while (*reinterpret_cast<volatile int*>(&s_zready) < 4) __builtin_amdgcn_s_sleep(2);      // the four staged slices
+    VSTAMP_B(2);
     bf16x8 zh[KB], zl[KB];
     float ssq = 0.f;
 #pragma unroll
@@ -1322,40 +1337,35 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     }
     ssq += __shfl_xor(ssq, 16);
     ssq += __shfl_xor(ssq, 32);
-    zz = ssq;
-    float emin = INFINITY;
-    bool bad = false;
+    if (bw == 0 && lane < 16) zzs[lane] = ssq;             // |z_i|^2 (from the bf16 pair: 2^-16 relative)
+    VSTAMP_B(3);
+    float emin = INFINITY, esum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-      const bool on = j < nct && ct0 + 4 * j < ntile;        // wave-uniform
-      if (on) {
-        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (TERMS >= 2) {
+    for (int j = 0; j < NTW; ++j) {
+      const int kt = bw + 4 * j;
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (TERMS >= 2) {
 #pragma unroll
-          for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zl[kb], acc, 0, 0, 0);
-        }
+        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zl[kb], acc, 0, 0, 0);
+      }
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zh[kb], acc, 0, 0, 0);
-        const float sv[4] = {sp[j].x, sp[j].y, sp[j].z, sp[j].w};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = sv[r] - 2.0f * acc[r];
-          ev[j][r] = e;
-          emin = fminf(emin, e);
-          bad |= !(fabsf(e) < INFINITY);
-        }
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) ev[j][r] = INFINITY;
+      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zh[kb], acc, 0, 0, 0);
+      if (j == 0) VSTAMP_B(4);
+      if (kt < ntile) {                                    // wave-uniform; every request above is consumed either way
+        const float4 e4 = make_float4(sp[j].x - 2.0f * acc[0], sp[j].y - 2.0f * acc[1], sp[j].z - 2.0f * acc[2], sp[j].w - 2.0f * acc[3]);
+        *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = e4;
+        emin = fminf(fminf(emin, e4.x), fminf(e4.y, fminf(e4.z, e4.w)));
+        esum += (e4.x + e4.y) + (e4.z + e4.w);             // NaN / inf anywhere poisons the sum
       }
     }
     emin = fminf(emin, __shfl_xor(emin, 16));
     emin = fminf(emin, __shfl_xor(emin, 32));
-    if (lane < 16) wmin[wave * 16 + lane] = emin;
-    if (__any(bad) && lane == 0) s_exact = 1;
+    if (lane < 16) wmin[bw * 16 + lane] = emin;
+    if (__any(!(fabsf(esum) < INFINITY)) && lane == 0) s_exact = 1;
+    VSTAMP_B(5);
   }
   lds_barrier();
-  VSTAMP(3);
+  VSTAMP(2);
   if (tid < 256) {  // ||x||^2 of the projected rows (the fp32 kernel's summation tree); first read behind the next barrier
     const int row = tid >> 4, part = tid & 15;
     float s = 0.f;
@@ -1367,32 +1377,41 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     s = reduce16(s);
     if (part == 0) xx[row] = s;
   }
-  {  // every lane: its row's threshold (8 LDS reads: cheaper than a barrier around 16 threads doing it), then its candidates
-    float m = wmin[i];
+  {  // candidate scan by all 512 threads: thread -> row tid >> 5, 16 of its codes
+    const int row = tid >> 5, c0 = 4 * (tid & 31);          // codes c0 + 128 g + (0..3): a wave-level read is 2 x 512 contiguous bytes
+    float4 e[4];
 #pragma unroll
-    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + i]);
-    const float zn = __builtin_amdgcn_sqrtf(zz) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
-    const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_i|
+    for (int g = 0; g < 4; ++g) e[g] = 128 * g < K ? *reinterpret_cast<const float4*>(Es + row * BXF_LDE + c0 + 128 * g) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    const float m = fminf(fminf(wmin[row], wmin[16 + row]), fminf(wmin[32 + row], wmin[48 + row]));
+    const float zn = __builtin_amdgcn_sqrtf(zzs[row]) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
+    const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_row|
     const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;                 // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
     const float th = m + (c1 * (zn * __builtin_amdgcn_sqrtf(sc.um)) + 2.4414063e-4f * (fn * wn) +
                           1.9073486e-6f * (fn * fn + sc.wm) + 1e-30f);
     if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
+    const float ev[16] = {e[0].x, e[0].y, e[0].z, e[0].w, e[1].x, e[1].y, e[1].z, e[1].w,
+                          e[2].x, e[2].y, e[2].z, e[2].w, e[3].x, e[3].y, e[3].z, e[3].w};
+    const float em = fminf(fminf(fminf(ev[0], ev[1]), fminf(ev[2], ev[3])), fminf(fminf(ev[4], ev[5]), fminf(ev[6], ev[7])));
+    const float en = fminf(fminf(fminf(ev[8], ev[9]), fminf(ev[10], ev[11])), fminf(fminf(ev[12], ev[13]), fminf(ev[14], ev[15])));
+    (void)em; (void)en;
+    unsigned cm = 0;                      // candidate bits of this thread's 16 codes: branch-free, ONE conditional block per wave
 #pragma unroll
-    for (int j = 0; j < NTB; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (ev[j][r] <= th) {
-          const int slot = atomicAdd(&s_np, 1);
-          if (slot < BXF_MAXP) {
-            p_row[slot] = i;
-            p_code[slot] = 16 * (ct0 + 4 * j) + 4 * q + r;
-          }
+    for (int c = 0; c < 16; ++c) cm |= (ev[c] <= th) ? (1u << c) : 0u;
+    if (cm) {                             // about 1.4 threads per row get here
+      int slot = atomicAdd(&s_np, __popc(cm));
+      while (cm) {
+        const int c = __ffs(cm) - 1;
+        cm &= cm - 1;
+        if (slot < BXF_MAXP) {
+          p_row[slot] = row;
+          p_code[slot] = c0 + 128 * (c >> 2) + (c & 3);
         }
+        ++slot;
       }
     }
   }
   lds_barrier();
-  VSTAMP(4);
+  VSTAMP(3);
   const float xr = xx[i];
   const int P = s_np;
   bool exact = (s_exact != 0) || P > BXF_MAXP;
@@ -1443,7 +1462,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
     }
   }
-  VSTAMP(5);
+  VSTAMP(4);
   if (exact) {
     // ---- exact fp32 sweep over every code (vq_fused_assign_kernel's arithmetic; slow path) ---------------------------------------
     float4 xb[KS];
@@ -1495,34 +1514,47 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     }
   }
   __syncthreads();
-  VSTAMP(6);
-  if (tid < 256) {  // ---- gather + straight-through + SSE on raw z (:1285-1292), the fp32 kernel's code and summation order ----------
-    const int row = tid >> 4, part = tid & 15;
-    float sse = 0.f;
-    if (row < nrows) {
-      const float* wq_ = W + (int64_t)best_k[row] * E;
-      float* qo = quant + (int64_t)(r0 + row) * E;
+  VSTAMP(5);
+  {
+    const int row = (tid & 255) >> 4, part = tid & 15;
+    if (tid < 256) {  // ---- gather + straight-through + SSE on raw z (:1285-1292) -------------------------------------------------------
+      float sse = 0.f;
+      if (row < nrows) {
+        const float* wq_ = W + (int64_t)best_k[row] * E;
+        float* qo = quant + (int64_t)(r0 + row) * E;
+#pragma unroll
+        for (int j = 0; j < E / 64; ++j) {
+          const int c = 4 * (part + 16 * j);
+          const float4 zzv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
+          const float4 df = make_float4(wv.x - zzv.x, wv.y - zzv.y, wv.z - zzv.z, wv.w - zzv.w);
+          *reinterpret_cast<float4*>(qo + c) = make_float4(zzv.x + df.x, zzv.y + df.y, zzv.z + df.z, zzv.w + df.w);   // :1292
+          sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+        }
+      }
+      sse = reduce16(sse);                 // the row's 16 threads (DPP), then the 16 rows in order below
+      if (part == 0) rowsse[row] = sse;
+    } else if (row < nrows) {   // the sweep waves write the projected rows (the code statistics read them in a later launch)
 #pragma unroll
       for (int j = 0; j < E / 64; ++j) {
         const int c = 4 * (part + 16 * j);
-        const float4 zzv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
-        const float4 df = make_float4(wv.x - zzv.x, wv.y - zzv.y, wv.z - zzv.z, wv.w - zzv.w);
-        *reinterpret_cast<float4*>(qo + c) = make_float4(zzv.x + df.x, zzv.y + df.y, zzv.z + df.z, zzv.w + df.w);   // :1292
-        sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+        *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + row) * E + c) = *reinterpret_cast<const float4*>(Xf + row * ldx + c);
       }
     }
-    sse = wave_sum(sse);
-    if (lane == 0) red[wave] = sse;
   }
   __syncthreads();
   if (tid == 0) {
-    if (sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+    if (sse_partial) {
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += rowsse[r];
+      sse_partial[blockIdx.x] = t;
+    }
     if (diag) {
       if (exact) atomicAdd(&diag[0], 1);
       else atomicAdd(&diag[1], P);
     }
   }
-  VSTAMP(7);
+  VSTAMP(6);
 }
 
 // Screening operands of vq_fused_bx_kernel, rebuilt whenever the codebook (or pre_linear) changed: one workgroup per 16 codes.

@@ -21,9 +21,12 @@ torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 64)()
 raw.g2v_read_vqstamps(buf)
-names = ["requests+stage", "projection", "||x||^2", "sweep+thr", "cand lists", "re-check / exact", "gather+STE"]
+names = ["z staged", "projection || sweep", "||x||^2 + scan", "re-check / exact", "sync", "gather+STE"]
 print("flags", flags)
 for b in range(4):
-    st = [buf[b * 16 + k] for k in range(8)]
-    print("slot", b, [st[k + 1] - st[k] for k in range(7)], "total", st[7] - st[0])
+    st = [buf[b * 16 + k] for k in range(16)]
+    print("slot", b, [st[k + 1] - st[k] for k in range(6)], "total", st[6] - st[0])
+    print("   wave 0 (projection): requests issued at", st[7] - st[0], "tile staged", st[1] - st[0], "projection done", st[8] - st[0],
+          "| wave 4 (sweep): start", st[8 + 0] - st[0], "requests issued", st[8 + 1] - st[0], "images seen", st[8 + 2] - st[0],
+          "z frags ready", st[8 + 3] - st[0], "first tile done", st[8 + 4] - st[0], "sweep done", st[8 + 5] - st[0])
 print(names)
