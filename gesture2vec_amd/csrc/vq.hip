@@ -18,19 +18,19 @@
 #include "common.hpp"
 
 #ifdef G2V_VQSTAMPS       // diagnostic build only (gpurun_tools/vqstamps.py): shader-clock stamps of four workgroups
-__device__ unsigned long long g2v_vqstamps[4 * 16];
+__device__ unsigned long long g2v_vqstamps[4 * 32];
 #define VSTAMP(k)                                                                                                        \
   do {                                                                                                                   \
     const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
-    if (threadIdx.x == 0 && sb_ >= 0) g2v_vqstamps[sb_ * 16 + (k)] = __builtin_amdgcn_s_memtime();                        \
+    if (threadIdx.x == 0 && sb_ >= 0) g2v_vqstamps[sb_ * 32 + (k)] = __builtin_amdgcn_s_memtime();                        \
   } while (0)
 extern "C" int g2v_read_vqstamps(unsigned long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_vqstamps), sizeof(unsigned long long) * 64);
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g2v_vqstamps), sizeof(unsigned long long) * 128);
 }
 #define VSTAMP_B(k)                                                                                                      \
   do {                                                                                                                   \
     const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
-    if (threadIdx.x == 256 && sb_ >= 0) g2v_vqstamps[sb_ * 16 + 8 + (k)] = __builtin_amdgcn_s_memtime();                  \
+    if (threadIdx.x == 256 && sb_ >= 0) g2v_vqstamps[sb_ * 32 + 16 + (k)] = __builtin_amdgcn_s_memtime();                  \
   } while (0)
 #else
 #define VSTAMP(k)
@@ -451,6 +451,21 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   }
 }
 
+
+// ||x||^2 of a projected row as the fused kernels form it (shared so that vq_fused_assign_kernel and vq_fused_bx_kernel agree
+// bitwise): a lane holding 4 consecutive features adds their squares as an fma chain, the four lanes (q) that hold one row of a
+// 16-feature tile add up through xor-16 / xor-32 shuffles, and the 8 tile partials of a row are summed pairwise in a fixed order.
+__device__ __forceinline__ float sq4_chain(float x, float y, float z, float w) { return fmaf(w, w, fmaf(z, z, fmaf(y, y, x * x))); }
+__device__ __forceinline__ float tile_partial_sumsq(float x, float y, float z, float w) {
+  float p = sq4_chain(x, y, z, w);
+  p += __shfl_xor(p, 16);
+  p += __shfl_xor(p, 32);
+  return p;
+}
+__device__ __forceinline__ float sum8_partials(const float* xxp, int row) {        // xxp[tile][16]
+  return ((xxp[row] + xxp[16 + row]) + (xxp[32 + row] + xxp[48 + row])) + ((xxp[64 + row] + xxp[80 + row]) + (xxp[96 + row] + xxp[112 + row]));
+}
+
 // ---- fused pre_linear + assign for E == 128 (the BASELINE shape) -------------------------------------------------
 // One workgroup = 16 rows of z.  Phase 1: flat = z W_pre^T + b (:1230) on MFMA (wave w owns output tiles w and w + 4; the
 // 16 weight fragments of a wave are requested up front, the first codebook pair right behind them).  The projected tile
@@ -472,6 +487,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
   __shared__ float xx[16];
+  __shared__ float xxp[8 * 16];
   __shared__ float wbest_d[64];
   __shared__ int wbest_k[64];
   __shared__ int best_k[16];
@@ -544,6 +560,11 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
     const float4 v1 = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
     *reinterpret_cast<float4*>(Xf + i * ldx + f0) = v0;
     *reinterpret_cast<float4*>(Xf + i * ldx + f1) = v1;
+    const float p0 = tile_partial_sumsq(v0.x, v0.y, v0.z, v0.w), p1 = tile_partial_sumsq(v1.x, v1.y, v1.z, v1.w);
+    if (lane < 16) {
+      xxp[wave * 16 + lane] = p0;
+      xxp[(wave + 4) * 16 + lane] = p1;
+    }
     if (i < nrows) {
       *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f0) = v0;
       *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + i) * E + f1) = v1;
@@ -551,17 +572,7 @@ __global__ __launch_bounds__(256) void vq_fused_assign_kernel(const float* __res
   }
   lds_barrier();
   VSTAMP(2);
-  {  // ||x||^2 of the projected rows
-    const int row = tid >> 4, part = tid & 15;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < E / 64; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(Xf + row * ldx + 4 * (part + 16 * j));
-      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    s = reduce16(s);
-    if (part == 0) xx[row] = s;
-  }
+  if (tid < 16) xx[tid] = sum8_partials(xxp, tid);       // ||x||^2 of the projected rows
   lds_barrier();
   VSTAMP(3);
   float4 xb[KS];
@@ -1165,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 //          e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)      (zh = bf16(z), zl = bf16(z - zh); 8 MFMAs of 16 cycles per
 //          16 x 16 x 128 tile instead of 32 of 32 cycles; ONE_TERM drops the zl products)
 //      approximates d_k - |flat|^2 WITHOUT the projected rows: the sweep does not wait for the projection, the two run side by side
-//      (waves 0-3: the projection's two fp32 chains each; waves 4-7: 8 code tiles each), both fed by one 202 KB
+//      (the projection's MFMA chain runs while the candidates' codebook rows travel), both fed by one 202 KB
 //      request stream per CU (z tile 8 KB, W_pre fp32 fragments 64 KB, bf16 fragments of U 128 KB, s'_k = |w_k|^2 - 2 b.w_k 2 KB)
 //      instead of the fp32 kernel's 328 KB;
 //  (2) every code whose e_k lies within `margin` of the row's minimum is re-evaluated with the EXACT fp32 MFMA chain of
@@ -1194,16 +1205,19 @@ __device__ __forceinline__ unsigned long long bxf_key(float d, int code) {
 
 struct BxfScalars { float wm, um, wpf2, bb; };      // max|w_k|^2, max|u_k|^2, |W_pre|_F^2, |b|^2 (behind the image, g2v_vq_bx_pack)
 
-// Roles (wave-uniform), synchronised by ONE workgroup barrier at the end of both:
-//   waves 0-3  the projection.  Each reads the raw tile straight from global in MFMA B-fragment layout (8 requests, in front of
-//              its 16 W_pre fragment requests), stages its share of it in LDS (fp32 for the straight-through epilogue, bf16
-//              hi / lo images for the sweep waves, then a counter in LDS), and runs the fp32 kernel's two alternating chains.
-//   waves 4-7  the screening sweep.  Wave 4 + b owns code tiles b, b + 4, .. (8 at K = 512) and requests every fragment of them
-//              at once, from the first cycle of the launch (a ring of four sets re-requested behind their MFMAs, and requests
-//              that started behind the staging barrier, both ended the sweep at 10-11 k cycles: the 202 KB arrive at ~40 B/clk
-//              from the moment the LAST of them is requested); it waits for the staged images by polling the LDS counter.
-// The screening values go to LDS (16 x K floats); after the barrier all 512 threads scan them (thread -> 16 codes of one row) and
-// list the candidates; the re-check takes 16 pairs per wave.
+// Eight waves, all doing the same (role splits -- projection waves beside sweep waves -- were built and measured: whatever puts
+// partial-line or duplicate requests of several waves into the CU's one in-order memory pipeline, e.g. every projection wave
+// reading the raw tile as fragments from global, or leaves only four waves to issue most of the requests, drops the request stream
+// from ~50 to ~20 B/clk).  Phases, one workgroup barrier between two:
+//   requests, all up front, in consumption order: raw tile (16 B per thread), this wave's W_pre fragments (output tile `wave`) and
+//   bias, its 4 code tiles of the U image + s';  z staged as fp32 + bf16 hi / lo, |z_row|^2 and the row's margin on the way
+//   | projection (the fp32 kernel's chain) -> Xf + ||x||^2 tile partials, then the bf16 sweep -> screening values to LDS (16 x K)
+//   | scan: 512 threads x 16 codes against the row threshold -> (row, code) pair list
+//   | exact distances: ONE pair per thread as a 128-long fmaf chain in the MFMA's k order (s, component, q ascending: measured
+//     bitwise equal to the v_mfma_f32_16x16x4_f32 chain, gpurun_tools/mfma_chain_test.hip), the code's row straight from global,
+//     LDS atomicMin on (distance, index) keys -- 1.4 k cycles whatever the number of pairs, where a 16 x 16 x 128 MFMA tile per 16
+//     pairs cost a gather round trip plus a 32-deep dependent MFMA chain behind yet another barrier
+//   | gather + straight-through + SSE.
 template <int TERMS>
 __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restrict__ z, const float* __restrict__ Wpf,
                                                           const float* __restrict__ bp, const float* __restrict__ W,
@@ -1212,15 +1226,16 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
                                                           float* __restrict__ flat_out, int64_t* __restrict__ idx_out,
                                                           float* __restrict__ quant, float* __restrict__ sse_partial,
                                                           int* __restrict__ diag, int N, int K, int exact_only) {
-  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NTW = 8;
+  constexpr int E = 128, KS = E / 16, KB = E / 32, ldx = E + 4, NT = 5;
   __shared__ __attribute__((aligned(16))) float Xz[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) float Xf[VQ_ROWS * ldx];
   __shared__ __attribute__((aligned(16))) __bf16 Zh[VQ_ROWS * BXF_LDH];
   __shared__ __attribute__((aligned(16))) __bf16 Zl[VQ_ROWS * BXF_LDH];
   __shared__ __attribute__((aligned(16))) float Es[VQ_ROWS * BXF_LDE];
+  __shared__ float xxp[8 * 16];                // ||flat_row||^2 partials per 16-feature tile
   __shared__ float xx[16];
-  __shared__ float zzs[16];
-  __shared__ float wmin[4 * 16];
+  __shared__ float marg[16];
+  __shared__ float wmin[8 * 16];
   __shared__ unsigned long long rowbest[16];
   __shared__ int p_row[BXF_MAXP];
   __shared__ int p_code[BXF_MAXP];
@@ -1228,131 +1243,117 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   __shared__ int wbest_k[8 * 16];
   __shared__ int best_k[16];
   __shared__ float rowsse[16];
-  __shared__ int s_exact, s_np, s_zready;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ int s_exact, s_np;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * VQ_ROWS;
   const int nrows = min(VQ_ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
   const int ntile = K >> 4;
-  const bool projw = wave < 4;                 // wave-uniform role
-  const int bw = wave - 4;
   VSTAMP(0);
   const BxfScalars sc = *scal;
-  VSTAMP_B(0);
+  // ---- every request of the first half, in consumption order ----------------------------------------------------------------------
+  const int zrow = tid >> 5, zpart = tid & 31;
+  const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + (zrow < nrows ? zrow : 0)) * E + 4 * zpart);
+  float4 wp[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) wp[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
+  const float4 b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
+  bf16x8 uf[NT][KB];
+  float4 sp[NT];
+  // code tiles: waves 0-3 (which request theirs first, below) own 5 each -- w + 4 p --, waves 4-7 own 3 each -- 20 + (w - 4) + 4 p
+  const int kt0 = wave < 4 ? wave : 16 + wave, nown = wave < 4 ? 5 : 3;
+  auto request_u = [&]() {
+#pragma unroll
+    for (int p = 0; p < NT; ++p) {
+      if (p >= nown) break;
+      const int kt = kt0 + 4 * p;
+      const int ktc = kt < ntile ? kt : 0;       // beyond K / 16: a valid tile, its values are dropped
+#pragma unroll
+      for (int kb = 0; kb < KB; ++kb) uf[p][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
+      sp[p] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
+    }
+  };
+  __builtin_amdgcn_sched_barrier(0);
   if (tid < 16) rowbest[tid] = ~0ull;
   if (tid == 0) {
     s_exact = exact_only;
     s_np = 0;
-    s_zready = 0;
   }
-  lds_barrier();        // the only purpose of this barrier: the polled counter is zero before anybody adds to it (LDS is not cleared)
-  // the projection's 26 requests per wave must reach the memory pipeline BEFORE the sweep waves' 40 (first requested, first
-  // served: with both bursts issued at once the raw tile arrived at 7.4 k cycles): the projection waves issue at priority 3
-  if (projw) __builtin_amdgcn_s_setprio(3);
-  if (projw) {
-    // ================================================ projection waves ================================================================
-    float4 zf[KS], wp0[KS], wp1[KS];
-    {
-      const float* zr = z + (int64_t)(r0 + (i < nrows ? i : 0)) * E + 4 * q;
+  {  // stage the raw tile: fp32 (projection operand, straight-through) and its bf16 hi / lo images (screening operand); the
+     // row's 32 threads (two DPP rows of one wave) add up |z_row|^2 and one of them prices the row's margin
+    const float4 zs = zrow < nrows ? zv : make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(Xz + zrow * ldx + 4 * zpart) = zs;
+    typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+    const float v[4] = {zs.x, zs.y, zs.z, zs.w};
+    bf16x4 h4, l4;
 #pragma unroll
-      for (int s = 0; s < KS; ++s) zf[s] = *reinterpret_cast<const float4*>(zr + 16 * s);
+    for (int j = 0; j < 4; ++j) {
+      const __bf16 h = (__bf16)v[j];
+      h4[j] = h;
+      l4[j] = (__bf16)(v[j] - (float)h);
     }
+    *reinterpret_cast<bf16x4*>(Zh + zrow * BXF_LDH + 4 * zpart) = h4;
+    *reinterpret_cast<bf16x4*>(Zl + zrow * BXF_LDH + 4 * zpart) = l4;
+    float zz = reduce16(sq4_chain(zs.x, zs.y, zs.z, zs.w));
+    zz += __shfl_xor(zz, 16);
+    if (zpart == 0) {
+      const float zn = __builtin_amdgcn_sqrtf(zz) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
+      const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_row|
+      const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;               // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
+      marg[zrow] = c1 * (zn * __builtin_amdgcn_sqrtf(sc.um)) + 2.4414063e-4f * (fn * wn) + 1.9073486e-6f * (fn * fn + sc.wm) + 1e-30f;
+    }
+  }
+  lds_barrier();
+  VSTAMP(1);
+  // A wave that is issuing requests into the saturated memory pipeline (~130 cycles each) cannot issue MFMAs meanwhile, and a
+  // wave inside the projection's dependent MFMA chain issues nothing else: the two waves of a SIMD (w, w + 4) take turns --
+  // waves 0-3 request their code tiles first and project afterwards, waves 4-7 project first and request afterwards.
+  if (wave < 4) {
+    request_u();
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {  // ---- pre_linear (:1230), output tile `wave`: one fp32 chain over k, the chain of vq_fused_assign_kernel ---------------------
+    f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      wp0[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
-      wp1[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)((wave + 4) * KS + s) * 64 + lane) * 4);
+      const float4 xb = *reinterpret_cast<const float4*>(Xz + i * ldx + 16 * s + 4 * q);
+      a = mfma16(wp[s].x, xb.x, a);
+      a = mfma16(wp[s].y, xb.y, a);
+      a = mfma16(wp[s].z, xb.z, a);
+      a = mfma16(wp[s].w, xb.w, a);
     }
-    const float4 b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
-    const float4 b1 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q + 64);
+    const float4 v0 = make_float4(a[0] + b0.x, a[1] + b0.y, a[2] + b0.z, a[3] + b0.w);
+    *reinterpret_cast<float4*>(Xf + i * ldx + 16 * wave + 4 * q) = v0;
+    const float p0 = tile_partial_sumsq(v0.x, v0.y, v0.z, v0.w);
+    if (lane < 16) xxp[wave * 16 + lane] = p0;
+  }
+  if (wave >= 4) {
     __builtin_amdgcn_sched_barrier(0);
-    VSTAMP(7);
-    if (i >= nrows) {
-#pragma unroll
-      for (int s = 0; s < KS; ++s) zf[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    {  // stage k-steps 2 wave, 2 wave + 1 of the raw tile: fp32 + bf16 hi / lo
-      typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const float4 v4 = t == 0 ? (wave == 0 ? zf[0] : wave == 1 ? zf[2] : wave == 2 ? zf[4] : zf[6])
-                                 : (wave == 0 ? zf[1] : wave == 1 ? zf[3] : wave == 2 ? zf[5] : zf[7]);
-        const int col = 16 * (2 * wave + t) + 4 * q;
-        *reinterpret_cast<float4*>(Xz + i * ldx + col) = v4;
-        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        bf16x4 h4, l4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const __bf16 h = (__bf16)v[j];
-          h4[j] = h;
-          l4[j] = (__bf16)(v[j] - (float)h);
-        }
-        *reinterpret_cast<bf16x4*>(Zh + i * BXF_LDH + col) = h4;
-        *reinterpret_cast<bf16x4*>(Zl + i * BXF_LDH + col) = l4;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      if (lane == 0) atomicAdd(&s_zready, 1);
-    }
-    VSTAMP(1);
-    // ---- pre_linear (:1230): vq_fused_assign_kernel's two alternating fp32 chains (output tiles wave, wave + 4) -------------------
-    f32x4 a0 = (f32x4){0.f, 0.f, 0.f, 0.f}, a1 = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      const float4 xb = zf[s];
-      a0 = mfma16(wp0[s].x, xb.x, a0); a1 = mfma16(wp1[s].x, xb.x, a1);
-      a0 = mfma16(wp0[s].y, xb.y, a0); a1 = mfma16(wp1[s].y, xb.y, a1);
-      a0 = mfma16(wp0[s].z, xb.z, a0); a1 = mfma16(wp1[s].z, xb.z, a1);
-      a0 = mfma16(wp0[s].w, xb.w, a0); a1 = mfma16(wp1[s].w, xb.w, a1);
-    }
-    const int f0 = 16 * wave + 4 * q, f1 = f0 + 64;
-    *reinterpret_cast<float4*>(Xf + i * ldx + f0) = make_float4(a0[0] + b0.x, a0[1] + b0.y, a0[2] + b0.z, a0[3] + b0.w);
-    *reinterpret_cast<float4*>(Xf + i * ldx + f1) = make_float4(a1[0] + b1.x, a1[1] + b1.y, a1[2] + b1.z, a1[3] + b1.w);
-    VSTAMP(8);
-  } else {
-    // ================================================== sweep waves ===================================================================
-    bf16x8 uf[NTW][KB];
-    float4 sp[NTW];
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int kt = bw + 4 * j;
-      const int ktc = kt < ntile ? kt : 0;       // beyond K / 16: a valid tile, its values are dropped
-#pragma unroll
-      for (int kb = 0; kb < KB; ++kb) uf[j][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
-      sp[j] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
-    }
+    request_u();
     __builtin_amdgcn_sched_barrier(0);
-    VSTAMP_B(1);
-    while (*reinterpret_cast<volatile int*>(&s_zready) < 4) __builtin_amdgcn_s_sleep(2);      // the four staged slices
-    VSTAMP_B(2);
+  }
+  {  // ---- screening sweep on the bf16 pipe, in z-space ---------------------------------------------------------------------------
     bf16x8 zh[KB], zl[KB];
-    float ssq = 0.f;
 #pragma unroll
     for (int kb = 0; kb < KB; ++kb) {
       zh[kb] = *reinterpret_cast<const bf16x8*>(Zh + i * BXF_LDH + 32 * kb + 8 * q);
       zl[kb] = *reinterpret_cast<const bf16x8*>(Zl + i * BXF_LDH + 32 * kb + 8 * q);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float v = (float)zh[kb][j] + (float)zl[kb][j];
-        ssq += v * v;
-      }
     }
-    ssq += __shfl_xor(ssq, 16);
-    ssq += __shfl_xor(ssq, 32);
-    if (bw == 0 && lane < 16) zzs[lane] = ssq;             // |z_i|^2 (from the bf16 pair: 2^-16 relative)
-    VSTAMP_B(3);
     float emin = INFINITY, esum = 0.f;
 #pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int kt = bw + 4 * j;
+    for (int p = 0; p < NT; ++p) {
+      if (p >= nown) break;
+      const int kt = kt0 + 4 * p;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (TERMS >= 2) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zl[kb], acc, 0, 0, 0);
+        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[p][kb], zl[kb], acc, 0, 0, 0);
       }
 #pragma unroll
-      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[j][kb], zh[kb], acc, 0, 0, 0);
-      if (j == 0) VSTAMP_B(4);
+      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[p][kb], zh[kb], acc, 0, 0, 0);
       if (kt < ntile) {                                    // wave-uniform; every request above is consumed either way
-        const float4 e4 = make_float4(sp[j].x - 2.0f * acc[0], sp[j].y - 2.0f * acc[1], sp[j].z - 2.0f * acc[2], sp[j].w - 2.0f * acc[3]);
+        const float4 e4 = make_float4(sp[p].x - 2.0f * acc[0], sp[p].y - 2.0f * acc[1], sp[p].z - 2.0f * acc[2], sp[p].w - 2.0f * acc[3]);
         *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = e4;
         emin = fminf(fminf(emin, e4.x), fminf(e4.y, fminf(e4.z, e4.w)));
         esum += (e4.x + e4.y) + (e4.z + e4.w);             // NaN / inf anywhere poisons the sum
@@ -1360,40 +1361,24 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     }
     emin = fminf(emin, __shfl_xor(emin, 16));
     emin = fminf(emin, __shfl_xor(emin, 32));
-    if (lane < 16) wmin[bw * 16 + lane] = emin;
+    if (lane < 16) wmin[wave * 16 + lane] = emin;
     if (__any(!(fabsf(esum) < INFINITY)) && lane == 0) s_exact = 1;
-    VSTAMP_B(5);
   }
   lds_barrier();
   VSTAMP(2);
-  if (tid < 256) {  // ||x||^2 of the projected rows (the fp32 kernel's summation tree); first read behind the next barrier
-    const int row = tid >> 4, part = tid & 15;
-    float s = 0.f;
-#pragma unroll
-    for (int j = 0; j < E / 64; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(Xf + row * ldx + 4 * (part + 16 * j));
-      s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
-    }
-    s = reduce16(s);
-    if (part == 0) xx[row] = s;
-  }
   {  // candidate scan by all 512 threads: thread -> row tid >> 5, 16 of its codes
     const int row = tid >> 5, c0 = 4 * (tid & 31);          // codes c0 + 128 g + (0..3): a wave-level read is 2 x 512 contiguous bytes
     float4 e[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) e[g] = 128 * g < K ? *reinterpret_cast<const float4*>(Es + row * BXF_LDE + c0 + 128 * g) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-    const float m = fminf(fminf(wmin[row], wmin[16 + row]), fminf(wmin[32 + row], wmin[48 + row]));
-    const float zn = __builtin_amdgcn_sqrtf(zzs[row]) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
-    const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_row|
-    const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;                 // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
-    const float th = m + (c1 * (zn * __builtin_amdgcn_sqrtf(sc.um)) + 2.4414063e-4f * (fn * wn) +
-                          1.9073486e-6f * (fn * fn + sc.wm) + 1e-30f);
+    float m = wmin[row];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + row]);
+    const float th = m + marg[row];
     if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
+    if (tid < 16) xx[tid] = sum8_partials(xxp, tid);
     const float ev[16] = {e[0].x, e[0].y, e[0].z, e[0].w, e[1].x, e[1].y, e[1].z, e[1].w,
                           e[2].x, e[2].y, e[2].z, e[2].w, e[3].x, e[3].y, e[3].z, e[3].w};
-    const float em = fminf(fminf(fminf(ev[0], ev[1]), fminf(ev[2], ev[3])), fminf(fminf(ev[4], ev[5]), fminf(ev[6], ev[7])));
-    const float en = fminf(fminf(fminf(ev[8], ev[9]), fminf(ev[10], ev[11])), fminf(fminf(ev[12], ev[13]), fminf(ev[14], ev[15])));
-    (void)em; (void)en;
     unsigned cm = 0;                      // candidate bits of this thread's 16 codes: branch-free, ONE conditional block per wave
 #pragma unroll
     for (int c = 0; c < 16; ++c) cm |= (ev[c] <= th) ? (1u << c) : 0u;
@@ -1412,47 +1397,35 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   }
   lds_barrier();
   VSTAMP(3);
-  const float xr = xx[i];
   const int P = s_np;
   bool exact = (s_exact != 0) || P > BXF_MAXP;
   if (!exact) {
-    // ---- exact fp32 re-evaluation of the candidates: A = 16 candidate rows gathered from the row-major codebook, B = the tile's
-    // 16 projected rows; element (candidate, its own row) of the 16 x 16 product is the fp32 kernel's dot product, bit for bit
-    for (int chunk = wave; 16 * chunk < P; chunk += 8) {
-      const int pi = 16 * chunk + i;
-      const int code = pi < P ? p_code[pi] : 0;
-      const float* wrow = W + (int64_t)code * E + 4 * q;
-      float4 wf[KS], xb[KS];
+    if (tid < P) {     // ---- one pair per thread: the fp32 kernel's dot product of (projected row, code) as its fmaf chain -------------
+      const int row = p_row[tid], code = p_code[tid];
+      const float* wr = W + (int64_t)code * E;
+      const float* xr_ = Xf + row * ldx;
+      float4 wv[E / 4];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
-      int prow[4], pc[4];
-      float ps[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {          // the pairs whose products land in this lane's accumulator: candidates 4 q + r
-        const int pj = 16 * chunk + 4 * q + r;
-        prow[r] = pj < P ? p_row[pj] : -1;
-        pc[r] = pj < P ? p_code[pj] : 0;
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ps[r] = wsq[pc[r]];
-#pragma unroll
-      for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
-      f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < E / 4; ++t) wv[t] = *reinterpret_cast<const float4*>(wr + 4 * t);
+      const float sq = wsq[code];
+      float a = 0.f;
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        a = mfma16(wf[s].x, xb[s].x, a);
-        a = mfma16(wf[s].y, xb[s].y, a);
-        a = mfma16(wf[s].z, xb[s].z, a);
-        a = mfma16(wf[s].w, xb[s].w, a);
-      }
+        float4 xv[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (prow[r] == i) {
-          const float d = (xr + ps[r]) - 2.0f * a[r];
-          if (!(fabsf(d) < INFINITY)) s_exact = 1;          // a non-finite exact value: the exact sweep decides (NaN rules)
-          atomicMin(&rowbest[i], bxf_key(d, pc[r]));
-        }
+        for (int qq = 0; qq < 4; ++qq) xv[qq] = *reinterpret_cast<const float4*>(xr_ + 16 * s + 4 * qq);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].x, xv[qq].x, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].y, xv[qq].y, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].z, xv[qq].z, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].w, xv[qq].w, a);
       }
+      const float d = (xx[row] + sq) - 2.0f * a;
+      if (!(fabsf(d) < INFINITY)) s_exact = 1;              // a non-finite exact value: the exact sweep decides (NaN rules)
+      atomicMin(&rowbest[row], bxf_key(d, code));
     }
     lds_barrier();
     exact = s_exact != 0;
@@ -1465,6 +1438,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   VSTAMP(4);
   if (exact) {
     // ---- exact fp32 sweep over every code (vq_fused_assign_kernel's arithmetic; slow path) ---------------------------------------
+    const float xr = xx[i];
     float4 xb[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
@@ -1472,17 +1446,17 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     int bk = 0;
     for (int kt = wave; kt < ntile; kt += 8) {
       const float* wrow = W + (int64_t)(16 * kt + i) * E + 4 * q;
-      float4 wf[KS];
+      float4 wg[KS];
 #pragma unroll
-      for (int s = 0; s < KS; ++s) wf[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
+      for (int s = 0; s < KS; ++s) wg[s] = *reinterpret_cast<const float4*>(wrow + 16 * s);
       const float4 sq = *reinterpret_cast<const float4*>(wsq + 16 * kt + 4 * q);
       f32x4 a = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int s = 0; s < KS; ++s) {
-        a = mfma16(wf[s].x, xb[s].x, a);
-        a = mfma16(wf[s].y, xb[s].y, a);
-        a = mfma16(wf[s].z, xb[s].z, a);
-        a = mfma16(wf[s].w, xb[s].w, a);
+        a = mfma16(wg[s].x, xb[s].x, a);
+        a = mfma16(wg[s].y, xb[s].y, a);
+        a = mfma16(wg[s].z, xb[s].z, a);
+        a = mfma16(wg[s].w, xb[s].w, a);
       }
       const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
 #pragma unroll
@@ -1533,7 +1507,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       }
       sse = reduce16(sse);                 // the row's 16 threads (DPP), then the 16 rows in order below
       if (part == 0) rowsse[row] = sse;
-    } else if (row < nrows) {   // the sweep waves write the projected rows (the code statistics read them in a later launch)
+    } else if (row < nrows) {   // waves 4-7 write the projected rows (the code statistics read them in a later launch)
 #pragma unroll
       for (int j = 0; j < E / 64; ++j) {
         const int c = 4 * (part + 16 * j);

@@ -68,7 +68,7 @@ def main():
             for name, flags in (("bx2", 0), ("bx1", 2), ("bx_exact", 1)):
                 got = ops.vq_fused_assign_bx(z, wpf, bp, W, img, wsq, flags=flags, want_diag=True)
                 torch.cuda.synchronize()
-                eq = [bool(torch.equal(a, b)) for a, b in zip(ref[:3], got[:3])] + [bool(torch.allclose(ref[3], got[3], rtol=2e-6, atol=0))]
+                eq = [bool(torch.equal(a, b)) for a, b in zip(ref[:3], got[:3])] + [bool(torch.allclose(ref[3], got[3], rtol=2e-6, atol=0, equal_nan=True))]
                 nd = int((ref[1] != got[1]).sum())
                 d = got[4].cpu().tolist()
                 rec[name] = {"flat_idx_quant_sse_bitwise": eq, "idx_mismatch": nd, "exact_tiles": d[0], "pairs": d[1],

@@ -17,10 +17,10 @@ for _ in range(10):
     ops.vq_fused_assign(z, Wp, bp, W, wsq, codebook_frag=frag)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 128)()
 raw.g2v_read_vqstamps(buf)
 names = ["requests+stage", "projection", "||x||^2", "xb + loop", "merge", "gather+STE"]
 for b in range(4):
-    st = [buf[b * 16 + k] for k in range(7)]
+    st = [buf[b * 32 + k] for k in range(7)]
     print("slot", b, [st[k + 1] - st[k] for k in range(6)], "total", st[6] - st[0])
 print(names)

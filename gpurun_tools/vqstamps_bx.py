@@ -19,14 +19,11 @@ for _ in range(10):
     ops.vq_fused_assign_bx(z, wpf, bp, W, img, wsq, flags=flags)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
-buf = (ctypes.c_ulonglong * 64)()
+buf = (ctypes.c_ulonglong * 128)()
 raw.g2v_read_vqstamps(buf)
-names = ["z staged", "projection || sweep", "||x||^2 + scan", "re-check / exact", "sync", "gather+STE"]
+names = ["z staged", "projection + sweep", "scan", "exact chains", "sync", "gather+STE"]
 print("flags", flags)
 for b in range(4):
-    st = [buf[b * 16 + k] for k in range(16)]
+    st = [buf[b * 32 + k] for k in range(32)]
     print("slot", b, [st[k + 1] - st[k] for k in range(6)], "total", st[6] - st[0])
-    print("   wave 0 (projection): requests issued at", st[7] - st[0], "tile staged", st[1] - st[0], "projection done", st[8] - st[0],
-          "| wave 4 (sweep): start", st[8 + 0] - st[0], "requests issued", st[8 + 1] - st[0], "images seen", st[8 + 2] - st[0],
-          "z frags ready", st[8 + 3] - st[0], "first tile done", st[8 + 4] - st[0], "sweep done", st[8 + 5] - st[0])
 print(names)
