@@ -117,43 +117,81 @@ def pmc_traffic(kernel: str, N: int):
 
 def vq_kernel_roofline(eng, B, reps: int = 200):
     """Average duration of the VQ kernel of the product path at the benchmark size, events on the launch stream: the fused
-    pre_linear + assign kernel (K6+K1+K2+K5: projection, -2 z E^T distances, argmin, gather + straight-through + SSE)."""
+    pre_linear + assign kernel (K6+K1+K2+K5: projection, -2 z E^T distances, argmin, gather + straight-through + SSE) on the
+    engine's CURRENT state (codebook after the timed training steps).  Product path (round 3): pre_linear in fp32 MFMA, the
+    distance contraction SCREENED on the bf16 matrix pipe and every code inside the error margin re-evaluated in exact fp32 in
+    the same launch (results bitwise those of the fp32 kernel, tests/test_gpu_ops.py); the fp32 kernel is timed beside it."""
     from gesture2vec_amd._lib import check
     lib = eng.lib
     b = eng.buffers(B)
     N, E, K = (2 * B * eng.H) // eng.E, eng.E, eng.K
     st = torch.cuda.current_stream()
     fused = (E == 128 and K % 128 == 0)
-    if fused:
+    flops = 2.0 * N * K * E + (2.0 * N * E * E if fused else 0.0)     # SURVEY.md 8(d): 2KE (distances) + 2E^2 (pre_linear) per row
+    # read z (4E) + write flat (4E) + write quantized (4E) + write idx (8, int64) per row; W_pre, b_pre, codebook, norms once
+    bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K + ((4 * E * E + 4 * E) if fused else 0)
+
+    def timed(fn, args):
+        for _ in range(20):
+            check(fn(*args))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(reps):
+            check(fn(*args))
+        e1.record(st)
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / reps
+
+    extra = {}
+    eng.vq_derive()                         # operand images of the current codebook
+    if fused and eng._vq_bx:
+        diag = torch.zeros(4, dtype=torch.int32, device=b["flat"].device)
+        mk = lambda flags, dg: (b["enc_hidden"].data_ptr(), eng.vq_wpre_frag.data_ptr(), eng.vq_pre_b.data_ptr(),
+                                eng.codebook.data_ptr(), eng.vq_bx_image.data_ptr(), eng.code_sqnorm.data_ptr(),
+                                b["flat"].data_ptr(), b["idx"].data_ptr(), b["quant"].data_ptr(), b["sse"].data_ptr(), dg,
+                                N, E, K, flags, st.cuda_stream)
+        fn, kernel = lib.g2v_vq_fused_assign_bx_fwd, "vq_fused_bx_kernel"
+        us = timed(fn, mk(eng.vq_bx_flags, None))
+        check(fn(*mk(eng.vq_bx_flags, diag.data_ptr())))
+        idx_s = b["idx"].clone()
+        us_exact = timed(fn, mk(1, None))                       # the same launch with every tile on the exact fp32 sweep
+        torch.cuda.synchronize()
+        d = diag.cpu().tolist()
+        tiles = (N + 15) // 16
+        extra = {"screening": {"tiles": tiles, "tiles_on_exact_sweep": d[0], "pairs_re_evaluated_per_tile": round(d[1] / max(tiles - d[0], 1), 2),
+                               "idx_equal_to_exact_fp32_sweep_on_every_row": bool(torch.equal(idx_s, b["idx"])),
+                               "avg_us_exact_fp32_sweep_same_kernel": round(us_exact, 3)},
+                 "pipes": "pre_linear + candidate re-evaluation: fp32 (v_mfma_f32_16x16x4_f32 / v_fma_f32 chains); distance "
+                          "screening: bf16 MFMA (v_mfma_f32_16x16x32_bf16); flops counted are the ALGORITHMIC 2NKE + 2NE^2"}
+        # the round-2 fp32 kernel on the same inputs (A/B)
+        frag = torch.empty(K * E, device=b["flat"].device)
+        check(lib.g2v_vq_pack_codebook(eng.codebook.data_ptr(), frag.data_ptr(), K, E, st.cuda_stream))
+        a_old = (b["enc_hidden"].data_ptr(), eng.vq_pre_w.data_ptr(), eng.vq_pre_b.data_ptr(), eng.codebook.data_ptr(), frag.data_ptr(),
+                 eng.code_sqnorm.data_ptr(), b["flat"].data_ptr(), b["idx"].data_ptr(), b["quant"].data_ptr(), b["sse"].data_ptr(),
+                 N, E, K, st.cuda_stream)
+        extra["fp32_kernel_round2"] = {"kernel": "vq_fused_assign_kernel<128, true>", "avg_us": round(timed(lib.g2v_vq_fused_assign_packed_fwd, a_old), 3),
+                                       "idx_equal_on_every_row": bool(torch.equal(idx_s, b["idx"]))}
+        extra["fp32_kernel_round2"]["frac"] = round(flops / (extra["fp32_kernel_round2"]["avg_us"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)
+    elif fused:
         args = (b["enc_hidden"].data_ptr(), eng.vq_pre_w.data_ptr(), eng.vq_pre_b.data_ptr(), eng.codebook.data_ptr(),
                 eng.codebook_frag.data_ptr(), eng.code_sqnorm.data_ptr(), b["flat"].data_ptr(), b["idx"].data_ptr(),
                 b["quant"].data_ptr(), b["sse"].data_ptr(), N, E, K, st.cuda_stream)
         fn, kernel = lib.g2v_vq_fused_assign_packed_fwd, "vq_fused_assign_kernel<128, true>"
-        flops = 2.0 * N * K * E + 2.0 * N * E * E     # SURVEY.md 8(d): 2KE (distances) + 2E^2 (pre_linear) flop per row
-        # read z (4E) + write flat (4E) + write quantized (4E) + write idx (8, int64) per row; W_pre, b_pre, codebook, norms once
-        bytes_alg = N * (12 * E + 8) + 4 * E * E + 4 * E + 4 * K * E + 4 * K
+        us = timed(fn, args)
     else:
         args = (b["flat"].data_ptr(), b["enc_hidden"].data_ptr(), eng.codebook.data_ptr(), eng.code_sqnorm.data_ptr(),
                 b["idx"].data_ptr(), b["quant"].data_ptr(), None, b["sse"].data_ptr(), N, E, K, st.cuda_stream)
         fn = lib.g2v_vq_assign_fwd
         kernel = "vq_assign_rt_kernel<128, 4>" if N >= 16384 else "vq_assign_fast_kernel<128>"
-        flops = 2.0 * N * K * E
-        bytes_alg = N * (12 * E + 8) + 4 * K * E + 4 * K
-    for _ in range(20):
-        check(fn(*args))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(st)
-    for _ in range(reps):
-        check(fn(*args))
-    e1.record(st)
-    e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / reps
+        us = timed(fn, args)
     tf = flops / (us * 1e-6) / 1e12
-    return {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kernel, N) if (E, K) == (128, 512) else None,
-            "kernel": kernel, "avg_us": round(us, 3), "flops_per_launch": flops,
-            "algorithmic_bytes_per_launch": bytes_alg,
-            "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
+    out = {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+           "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "traffic": pmc_traffic(kernel, N) if (E, K) == (128, 512) else None,
+           "kernel": kernel, "avg_us": round(us, 3), "flops_per_launch": flops,
+           "algorithmic_bytes_per_launch": bytes_alg,
+           "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
+    out.update(extra)
+    return out
 
 
 def calibrate(lib):

@@ -1174,23 +1174,26 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 // 256 fp32 MFMAs per wave of the -2 x W^T contraction, one behind the other.  Only the ARGMIN of that contraction is an output, so
 //  (1) it is SCREENED on the bf16 pipe, in z-space:  flat.w_k = (W_pre z + b).w_k = z.u_k + b.w_k  with  u_k = W_pre^T w_k, so
 //          e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)      (zh = bf16(z), zl = bf16(z - zh); 8 MFMAs of 16 cycles per
-//          16 x 16 x 128 tile instead of 32 of 32 cycles; ONE_TERM drops the zl products)
-//      approximates d_k - |flat|^2 WITHOUT the projected rows: the sweep does not wait for the projection, the two run side by side
-//      (the projection's MFMA chain runs while the candidates' codebook rows travel), both fed by one 202 KB
-//      request stream per CU (z tile 8 KB, W_pre fp32 fragments 64 KB, bf16 fragments of U 128 KB, s'_k = |w_k|^2 - 2 b.w_k 2 KB)
-//      instead of the fp32 kernel's 328 KB;
-//  (2) every code whose e_k lies within `margin` of the row's minimum is re-evaluated with the EXACT fp32 MFMA chain of
-//      vq_fused_assign_kernel on the projected rows (same operands, same k order => the same bits): 16 (row, candidate) pairs per
-//      wave as one 16 x 16 x 128 product of gathered codebook rows with the tile, the row's code being torch.argmin (:1259) over
-//      its exact values (LDS atomicMin on (distance, index) keys).
-// margin = 2 x (bound on |e_k - (d_k - |flat|^2)|), with B1 = |z| max|u|, B2 = (|W_pre|_F |z| + |b|) max|w|, B3 = B2^2/max|w|^2 + max|w|^2:
-//     bf16(u) and the z residual: (2^-8 + 2^-16) B1; fp32 accumulation inside the bf16 MFMAs, budgeted 2^-14 B1 (16x the RNE bound);
-//     fp32 rounding of U, of the projection and of the fp32 kernel's chain: <= 3 E 2^-24 B2 = 2^-15.4 B2; (|x|^2 + |w|^2) - 2 x.w
-//     and s'_k roundings: <= 2^-21 B3 on either side
-//   => margin = 2^-6 (1 + 2^-5) B1 + 2^-12 B2 + 2^-19 B3 + 1e-30     [ONE_TERM: 2^-5 (1 + 2^-5) B1 + ...]
-// A code outside the margin cannot be the fp32 kernel's argmin; the codes inside it get the fp32 kernel's own arithmetic: flat,
-// idx, quantized and the SSE partials are bitwise vq_fused_assign_kernel's.  A tile with a non-finite screening value or more than
-// BXF_MAXP candidates takes the exact fp32 sweep over all K codes instead (exact_only != 0 forces it: the A/B reference).
+//          16 x 16 x 128 tile instead of 32 of 32 cycles)
+//      approximates d_k - |flat|^2 WITHOUT the projected rows: the sweep does not wait for the projection, both are fed by one
+//      ~205 KB request stream per CU (z tile 8 KB, W_pre fp32 fragments 64 KB, bf16 fragments of U 128 KB, s'_k and radius
+//      coefficients 4 KB) instead of the fp32 kernel's 328 KB;
+//  (2) every code that can still be the fp32 kernel's argmin is re-evaluated with the EXACT fp32 chain of vq_fused_assign_kernel
+//      on the projected rows (same operands, same k order => the same bits), the row's code being torch.argmin (:1259) over its
+//      exact values (LDS atomicMin on (distance, index) keys).
+// Which codes: |e_k - (d_k - |flat|^2)| <= r_k for the fp32 kernel's d_k, with the PER-CODE radius
+//     r_k = 2^-7 (1 + 2^-5) |z||u_k|                   bf16(u) (2^-8), the z residual (2^-16) and the fp32 accumulation inside the
+//                                                      bf16 MFMAs (budgeted 2^-14: 16x the RNE bound), all x 2 for the -2 x.w
+//         + 2^-13 |flat|^ |w_k|                        fp32 rounding of U, of the projection and of the fp32 kernel's chain
+//                                                      (<= 3 E 2^-24 x 2);  |flat|^ = |W_pre|_F |z| + |b| >= |flat|
+//         + 2^-20 (|flat|^^2 + |w_k|^2) + 5e-31        roundings of (|x|^2 + |w|^2) - 2 x.w and of s'_k; denormal flushes
+// so d_k - |flat|^2 lies in [e_k - r_k, e_k + r_k]: a code with e_k - r_k > min_j (e_j + r_j) cannot be the argmin; all others are
+// candidates.  (A global margin from max|u|, max|w| fails on a TRAINED codebook: the EMA update leaves dead codes with norms
+// hundreds of times the live ones', and their bound made every code a candidate.  Per code those are simply far away.)
+// r_k = |z| P_k + Q_k + R_row: P_k, Q_k come packed as two bf16 (rounded up) per code from g2v_vq_bx_pack, R_row is added to the
+// row's threshold.  The candidates get the fp32 kernel's own arithmetic: flat, idx and quantized are bitwise
+// vq_fused_assign_kernel's.  A tile with a non-finite screening value or more than BXF_MAXP candidates takes the exact fp32
+// sweep over all K codes instead (exact_only != 0 forces it: the A/B reference).
 constexpr int BXF_MAXP = 128;      // (row, candidate) pairs re-evaluated per tile: 8 waves x one 16-pair MFMA tile
 constexpr int BXF_LDH = 128 + 8;   // bf16 elements per LDS row of the hi / lo images: 272 B, conflict-free ds_read_b128 per 16 lanes
 constexpr int BXF_LDE = 512 + 4;   // floats per LDS row of the screening values
@@ -1203,7 +1206,7 @@ __device__ __forceinline__ unsigned long long bxf_key(float d, int code) {
   return ((unsigned long long)u << 32) | (unsigned)code;
 }
 
-struct BxfScalars { float wm, um, wpf2, bb; };      // max|w_k|^2, max|u_k|^2, |W_pre|_F^2, |b|^2 (behind the image, g2v_vq_bx_pack)
+struct BxfScalars { float wpf2, bb, pad0, pad1; };      // |W_pre|_F^2, |b|^2 (behind the image, g2v_vq_bx_pack)
 
 // Eight waves, all doing the same (role splits -- projection waves beside sweep waves -- were built and measured: whatever puts
 // partial-line or duplicate requests of several waves into the CU's one in-order memory pipeline, e.g. every projection wave
@@ -1218,10 +1221,10 @@ struct BxfScalars { float wm, um, wpf2, bb; };      // max|w_k|^2, max|u_k|^2, |
 //     LDS atomicMin on (distance, index) keys -- 1.4 k cycles whatever the number of pairs, where a 16 x 16 x 128 MFMA tile per 16
 //     pairs cost a gather round trip plus a 32-deep dependent MFMA chain behind yet another barrier
 //   | gather + straight-through + SSE.
-template <int TERMS>
 __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restrict__ z, const float* __restrict__ Wpf,
                                                           const float* __restrict__ bp, const float* __restrict__ W,
                                                           const __bf16* __restrict__ Uhf, const float* __restrict__ sprime,
+                                                          const unsigned* __restrict__ pqk,
                                                           const BxfScalars* __restrict__ scal, const float* __restrict__ wsq,
                                                           float* __restrict__ flat_out, int64_t* __restrict__ idx_out,
                                                           float* __restrict__ quant, float* __restrict__ sse_partial,
@@ -1235,6 +1238,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   __shared__ float xxp[8 * 16];                // ||flat_row||^2 partials per 16-feature tile
   __shared__ float xx[16];
   __shared__ float marg[16];
+  __shared__ float znrow[16];
   __shared__ float wmin[8 * 16];
   __shared__ unsigned long long rowbest[16];
   __shared__ int p_row[BXF_MAXP];
@@ -1243,6 +1247,8 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   __shared__ int wbest_k[8 * 16];
   __shared__ int best_k[16];
   __shared__ float rowsse[16];
+  __shared__ int rowcnt[16];
+  __shared__ int rowcode[16];
   __shared__ int s_exact, s_np;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1261,6 +1267,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   const float4 b0 = *reinterpret_cast<const float4*>(bp + 16 * wave + 4 * q);
   bf16x8 uf[NT][KB];
   float4 sp[NT];
+  uint4 pq[NT];
   // code tiles: waves 0-3 (which request theirs first, below) own 5 each -- w + 4 p --, waves 4-7 own 3 each -- 20 + (w - 4) + 4 p
   const int kt0 = wave < 4 ? wave : 16 + wave, nown = wave < 4 ? 5 : 3;
   auto request_u = [&]() {
@@ -1272,10 +1279,15 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) uf[p][kb] = *reinterpret_cast<const bf16x8*>(Uhf + ((int64_t)(ktc * KB + kb) * 64 + lane) * 8);
       sp[p] = *reinterpret_cast<const float4*>(sprime + 16 * ktc + 4 * q);
+      pq[p] = *reinterpret_cast<const uint4*>(pqk + 16 * ktc + 4 * q);
     }
   };
   __builtin_amdgcn_sched_barrier(0);
-  if (tid < 16) rowbest[tid] = ~0ull;
+  if (tid < 16) {
+    rowbest[tid] = ~0ull;
+    rowcnt[tid] = 0;
+    rowsse[tid] = 0.f;
+  }
   if (tid == 0) {
     s_exact = exact_only;
     s_np = 0;
@@ -1298,10 +1310,10 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
     float zz = reduce16(sq4_chain(zs.x, zs.y, zs.z, zs.w));
     zz += __shfl_xor(zz, 16);
     if (zpart == 0) {
-      const float zn = __builtin_amdgcn_sqrtf(zz) * 1.001f, wn = __builtin_amdgcn_sqrtf(sc.wm);
+      const float zn = __builtin_amdgcn_sqrtf(zz) * 1.001f;
       const float fn = __builtin_amdgcn_sqrtf(sc.wpf2) * zn + __builtin_amdgcn_sqrtf(sc.bb);       // >= |flat_row|
-      const float c1 = TERMS >= 2 ? 0.01612f : 0.03224f;               // 2^-6 (1 + 2^-5), 2^-5 (1 + 2^-5)
-      marg[zrow] = c1 * (zn * __builtin_amdgcn_sqrtf(sc.um)) + 2.4414063e-4f * (fn * wn) + 1.9073486e-6f * (fn * fn + sc.wm) + 1e-30f;
+      znrow[zrow] = zn;
+      marg[zrow] = 2.0f * (9.5367432e-7f * (fn * fn) + 5e-31f);       // 2 R_row: the part of the radius common to the row's codes
     }
   }
   lds_barrier();
@@ -1340,23 +1352,30 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       zh[kb] = *reinterpret_cast<const bf16x8*>(Zh + i * BXF_LDH + 32 * kb + 8 * q);
       zl[kb] = *reinterpret_cast<const bf16x8*>(Zl + i * BXF_LDH + 32 * kb + 8 * q);
     }
+    const float zn = znrow[i];
     float emin = INFINITY, esum = 0.f;
 #pragma unroll
     for (int p = 0; p < NT; ++p) {
       if (p >= nown) break;
       const int kt = kt0 + 4 * p;
       f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (TERMS >= 2) {
 #pragma unroll
-        for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[p][kb], zl[kb], acc, 0, 0, 0);
-      }
+      for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[p][kb], zl[kb], acc, 0, 0, 0);
 #pragma unroll
       for (int kb = 0; kb < KB; ++kb) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(uf[p][kb], zh[kb], acc, 0, 0, 0);
       if (kt < ntile) {                                    // wave-uniform; every request above is consumed either way
-        const float4 e4 = make_float4(sp[p].x - 2.0f * acc[0], sp[p].y - 2.0f * acc[1], sp[p].z - 2.0f * acc[2], sp[p].w - 2.0f * acc[3]);
-        *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = e4;
-        emin = fminf(fminf(emin, e4.x), fminf(e4.y, fminf(e4.z, e4.w)));
-        esum += (e4.x + e4.y) + (e4.z + e4.w);             // NaN / inf anywhere poisons the sum
+        const float ev_[4] = {sp[p].x - 2.0f * acc[0], sp[p].y - 2.0f * acc[1], sp[p].z - 2.0f * acc[2], sp[p].w - 2.0f * acc[3]};
+        const unsigned pk_[4] = {pq[p].x, pq[p].y, pq[p].z, pq[p].w};
+        float lo[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          // radius of code k for this row: |z| P_k + Q_k (+ R_row, added to the threshold): lo / hi bracket d_k - |flat|^2
+          const float rk = fmaf(zn, __uint_as_float(pk_[r] & 0xffff0000u), __uint_as_float(pk_[r] << 16));
+          lo[r] = ev_[r] - rk;
+          emin = fminf(emin, ev_[r] + rk);
+          esum += ev_[r];                                  // NaN / inf anywhere poisons the sum
+        }
+        *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = make_float4(lo[0], lo[1], lo[2], lo[3]);
       }
     }
     emin = fminf(emin, __shfl_xor(emin, 16));
@@ -1366,6 +1385,7 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   }
   lds_barrier();
   VSTAMP(2);
+  float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f;
   {  // candidate scan by all 512 threads: thread -> row tid >> 5, 16 of its codes
     const int row = tid >> 5, c0 = 4 * (tid & 31);          // codes c0 + 128 g + (0..3): a wave-level read is 2 x 512 contiguous bytes
     float4 e[4];
@@ -1383,15 +1403,26 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
 #pragma unroll
     for (int c = 0; c < 16; ++c) cm |= (ev[c] <= th) ? (1u << c) : 0u;
     if (cm) {                             // about 1.4 threads per row get here
-      int slot = atomicAdd(&s_np, __popc(cm));
+      const int n = __popc(cm);
+      int slot = atomicAdd(&s_np, n);
+      atomicAdd(&rowcnt[row], n);
+      rowcode[row] = c0 + 128 * ((__ffs(cm) - 1) >> 2) + ((__ffs(cm) - 1) & 3);      // THE code of a row that ends with one candidate
       while (cm) {
         const int c = __ffs(cm) - 1;
         cm &= cm - 1;
+        const int code = c0 + 128 * (c >> 2) + (c & 3);
         if (slot < BXF_MAXP) {
           p_row[slot] = row;
-          p_code[slot] = c0 + 128 * (c >> 2) + (c & 3);
+          p_code[slot] = code;
         }
         ++slot;
+        if (slot > BXF_MAXP) break;       // the list is full: this tile takes the exact sweep, nothing more to list or to touch
+        // touch the code's four cache lines now: the exact chain (another thread, behind the barrier) then reads them from L1
+        // instead of paying an L2 round trip.  Fire and forget: the values are never used, the registers are pinned below.
+        const float* wr = W + (int64_t)code * E;
+        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:128\n\t"
+                     "global_load_dword %2, %4, off offset:256\n\tglobal_load_dword %3, %4, off offset:384"
+                     : "=&v"(pf0), "=&v"(pf1), "=&v"(pf2), "=&v"(pf3) : "v"(wr) : "memory");
       }
     }
   }
@@ -1399,6 +1430,26 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
   VSTAMP(3);
   const int P = s_np;
   bool exact = (s_exact != 0) || P > BXF_MAXP;
+  // gather + straight-through + SSE on raw z (:1285-1292) of one row by its 16 threads; the row's SSE goes to rowsse
+  auto finish_row = [&](int row, int part, int code) {
+    const float* wq_ = W + (int64_t)code * E;
+    float* qo = quant + (int64_t)(r0 + row) * E;
+    float sse = 0.f;
+#pragma unroll
+    for (int j = 0; j < E / 64; ++j) {
+      const int c = 4 * (part + 16 * j);
+      const float4 zzv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
+      const float4 df = make_float4(wv.x - zzv.x, wv.y - zzv.y, wv.z - zzv.z, wv.w - zzv.w);
+      *reinterpret_cast<float4*>(qo + c) = make_float4(zzv.x + df.x, zzv.y + df.y, zzv.z + df.z, zzv.w + df.w);   // :1292
+      sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+    }
+    sse = reduce16(sse);                 // the row's 16 threads (DPP); the 16 rows are added in order at the end
+    if (part == 0) {
+      rowsse[row] = sse;
+      idx_out[r0 + row] = (int64_t)code;
+    }
+  };
+  const int frow = (tid & 255) >> 4, fpart = tid & 15;
   if (!exact) {
     if (tid < P) {     // ---- one pair per thread: the fp32 kernel's dot product of (projected row, code) as its fmaf chain -------------
       const int row = p_row[tid], code = p_code[tid];
@@ -1426,14 +1477,22 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       const float d = (xx[row] + sq) - 2.0f * a;
       if (!(fabsf(d) < INFINITY)) s_exact = 1;              // a non-finite exact value: the exact sweep decides (NaN rules)
       atomicMin(&rowbest[row], bxf_key(d, code));
+    } else if (tid >= 256) {
+      // ---- beside the chains (waves 4-7): the rows that ended the scan with ONE candidate are decided, finish them now; and the
+      // projected rows go to global (the code statistics read them in a later launch)
+      if (frow < nrows) {
+        if (rowcnt[frow] == 1) finish_row(frow, fpart, rowcode[frow]);
+#pragma unroll
+        for (int j = 0; j < E / 64; ++j) {
+          const int c = 4 * (fpart + 16 * j);
+          *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + frow) * E + c) = *reinterpret_cast<const float4*>(Xf + frow * ldx + c);
+        }
+      }
     }
     lds_barrier();
     exact = s_exact != 0;
-    if (!exact && tid < 16) {
-      const int k = (int)(unsigned)(rowbest[tid] & 0xffffffffull);
-      best_k[tid] = k;
-      if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
-    }
+    if (!exact && tid < 256 && frow < nrows && rowcnt[frow] != 1)
+      finish_row(frow, fpart, (int)(unsigned)(rowbest[frow] & 0xffffffffull));
   }
   VSTAMP(4);
   if (exact) {
@@ -1484,38 +1543,22 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
 #pragma unroll
       for (int w = 1; w < 8; ++w) argmin_merge(d, k, wbest_d[w * 16 + tid], wbest_k[w * 16 + tid]);
       best_k[tid] = k;
-      if (tid < nrows) idx_out[r0 + tid] = (int64_t)k;
+    }
+    lds_barrier();
+    if (frow < nrows) {
+      if (tid < 256) {
+        finish_row(frow, fpart, best_k[frow]);
+      } else {
+#pragma unroll
+        for (int j = 0; j < E / 64; ++j) {
+          const int c = 4 * (fpart + 16 * j);
+          *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + frow) * E + c) = *reinterpret_cast<const float4*>(Xf + frow * ldx + c);
+        }
+      }
     }
   }
   __syncthreads();
   VSTAMP(5);
-  {
-    const int row = (tid & 255) >> 4, part = tid & 15;
-    if (tid < 256) {  // ---- gather + straight-through + SSE on raw z (:1285-1292) -------------------------------------------------------
-      float sse = 0.f;
-      if (row < nrows) {
-        const float* wq_ = W + (int64_t)best_k[row] * E;
-        float* qo = quant + (int64_t)(r0 + row) * E;
-#pragma unroll
-        for (int j = 0; j < E / 64; ++j) {
-          const int c = 4 * (part + 16 * j);
-          const float4 zzv = *reinterpret_cast<const float4*>(Xz + row * ldx + c), wv = *reinterpret_cast<const float4*>(wq_ + c);
-          const float4 df = make_float4(wv.x - zzv.x, wv.y - zzv.y, wv.z - zzv.z, wv.w - zzv.w);
-          *reinterpret_cast<float4*>(qo + c) = make_float4(zzv.x + df.x, zzv.y + df.y, zzv.z + df.z, zzv.w + df.w);   // :1292
-          sse += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
-        }
-      }
-      sse = reduce16(sse);                 // the row's 16 threads (DPP), then the 16 rows in order below
-      if (part == 0) rowsse[row] = sse;
-    } else if (row < nrows) {   // waves 4-7 write the projected rows (the code statistics read them in a later launch)
-#pragma unroll
-      for (int j = 0; j < E / 64; ++j) {
-        const int c = 4 * (part + 16 * j);
-        *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + row) * E + c) = *reinterpret_cast<const float4*>(Xf + row * ldx + c);
-      }
-    }
-  }
-  __syncthreads();
   if (tid == 0) {
     if (sse_partial) {
       float t = 0.f;
@@ -1528,24 +1571,49 @@ __global__ __launch_bounds__(512) void vq_fused_bx_kernel(const float* __restric
       else atomicAdd(&diag[1], P);
     }
   }
+  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));          // the prefetch destinations stay reserved until here
   VSTAMP(6);
 }
 
 // Screening operands of vq_fused_bx_kernel, rebuilt whenever the codebook (or pre_linear) changed: one workgroup per 16 codes.
 //   U = W W_pre (u_k = W_pre^T w_k), as the bf16 MFMA-fragment image [K/16 tiles][E/32 k-blocks][64 lanes][8]: lane (q, i) of
-//   tile kt, block kb holds bf16(U[16 kt + i][32 kb + 8 q .. + 7]);  s'_k = |w_k|^2 - 2 b.w_k;  scalars max|w_k|^2, max|u_k|^2
-//   (atomicMax on the bit patterns of non-negative floats: the host clears them first), |W_pre|_F^2, |b|^2.
+//   tile kt, block kb holds bf16(U[16 kt + i][32 kb + 8 q .. + 7]);  s'_k = |w_k|^2 - 2 b.w_k;  the per-code radius
+//   coefficients P_k = 2^-7 (1 + 2^-5) |u_k| + 2^-13 |W_pre|_F |w_k|,  Q_k = 2^-13 |b| |w_k| + 2^-20 |w_k|^2, each rounded UP to
+//   bf16 and packed (P_k << 16 | Q_k);  scalars |W_pre|_F^2, |b|^2.
+__device__ __forceinline__ unsigned bf16_ceil_bits(float v) {      // v >= 0 (or NaN / inf, which stay what they are)
+  const unsigned u = __float_as_uint(v);
+  return (u & 0x7f800000u) == 0x7f800000u ? (u | ((u & 0xffffu) ? 0x10000u : 0u)) : (u + 0xffffu);      // upper 16 bits are the result
+}
 __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
                                                          const float* __restrict__ Wp, const float* __restrict__ bp,
                                                          __bf16* __restrict__ Uhf, float* __restrict__ sprime,
-                                                         BxfScalars* __restrict__ scal, int K) {
+                                                         unsigned* __restrict__ pqk, BxfScalars* __restrict__ scal, int K) {
   constexpr int E = 128;
   __shared__ float Ws[16][E + 1];
   __shared__ float Us[16][E + 1];
   __shared__ float red[4];
+  __shared__ float s_wpf2, s_bb;
   const int tid = threadIdx.x, kt = blockIdx.x;
   for (int e = tid; e < 16 * E; e += 256) Ws[e / E][e % E] = W[(int64_t)(16 * kt) * E + e];
+  {  // |W_pre|_F^2 and |b|^2 (every workgroup for itself: the radius coefficients below need them)
+    float f = 0.f;
+    for (int e = tid; e < E * E; e += 256) f = fmaf(Wp[e], Wp[e], f);
+    f = wave_sum(f);
+    if ((tid & 63) == 0) red[tid >> 6] = f;
+  }
   __syncthreads();
+  if (tid == 0) {
+    float bb = 0.f;
+    for (int e = 0; e < E; ++e) bb = fmaf(bp[e], bp[e], bb);
+    s_wpf2 = (red[0] + red[1]) + (red[2] + red[3]);
+    s_bb = bb;
+    if (kt == 0) {
+      scal->wpf2 = s_wpf2;
+      scal->bb = bb;
+      scal->pad0 = 0.f;
+      scal->pad1 = 0.f;
+    }
+  }
   {
     const int j = tid & 127, kh = tid >> 7;           // column j of U, codes kh, kh + 2, ..
     float acc[8];
@@ -1575,22 +1643,10 @@ __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict
     }
     const float s = wsq[16 * kt + tid];
     sprime[16 * kt + tid] = s - 2.0f * bw;
-    // NaN bit patterns order above +inf: a NaN norm poisons the bound and every tile then takes the exact sweep
-    atomicMax(reinterpret_cast<unsigned*>(&scal->um), __float_as_uint(fabsf(uu)));
-    atomicMax(reinterpret_cast<unsigned*>(&scal->wm), __float_as_uint(fabsf(s)));
-  }
-  if (kt == 0) {
-    float f = 0.f;
-    for (int e = tid; e < E * E; e += 256) f = fmaf(Wp[e], Wp[e], f);
-    f = wave_sum(f);
-    if ((tid & 63) == 0) red[tid >> 6] = f;
-    __syncthreads();
-    if (tid == 0) {
-      float bb = 0.f;
-      for (int e = 0; e < E; ++e) bb = fmaf(bp[e], bp[e], bb);
-      scal->wpf2 = (red[0] + red[1]) + (red[2] + red[3]);
-      scal->bb = bb;
-    }
+    const float un = sqrtf(uu) * 1.0001f, wn = sqrtf(fabsf(s)) * 1.0001f;      // a NaN norm gives NaN coefficients: never a candidate
+    const float P = 0.008056641f * un + 1.2207031e-4f * (sqrtf(s_wpf2) * 1.0001f) * wn;      // by the radius, but s' is NaN too ->
+    const float Q = 1.2207031e-4f * (sqrtf(s_bb) * 1.0001f) * wn + 9.5367432e-7f * fabsf(s);  // the tile takes the exact sweep
+    pqk[16 * kt + tid] = (bf16_ceil_bits(P) & 0xffff0000u) | (bf16_ceil_bits(Q) >> 16);
   }
 }
 
@@ -1739,9 +1795,11 @@ extern "C" int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre
   return G2V_OK;
 }
 
+static inline size_t bx_pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+// image layout: [U fragments, bf16: K * E * 2][s'_k: K floats][P_k / Q_k packed: K words][scalars], each part padded to 256 B
 extern "C" size_t g2v_vq_bx_image_bytes(int K, int E) {
   if (K <= 0 || E <= 0) return 0;
-  return (((size_t)K * E * 2 + 255) & ~(size_t)255) + (((size_t)K * 4 + 255) & ~(size_t)255) + 256;
+  return bx_pad256((size_t)K * E * 2) + 2 * bx_pad256((size_t)K * 4) + 256;
 }
 
 extern "C" int g2v_vq_fused_assign_bx_ok(int N, int E, int K) { return (N > 0 && E == 128 && (K & 127) == 0 && K >= 128 && K <= 512) ? 1 : 0; }
@@ -1754,11 +1812,9 @@ extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, c
     return G2V_ERR_UNSUPPORTED;
   }
   G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
-  const size_t o1 = ((size_t)K * E * 2 + 255) & ~(size_t)255, o2 = o1 + (((size_t)K * 4 + 255) & ~(size_t)255);
-  hipStream_t st = (hipStream_t)stream;
-  (void)hipMemsetAsync((char*)image + o2, 0, sizeof(BxfScalars), st);
-  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), 0, st, codebook, code_sqnorm, w_pre, b_pre, (__bf16*)image,
-                     (float*)((char*)image + o1), (BxfScalars*)((char*)image + o2), K);
+  const size_t o1 = bx_pad256((size_t)K * E * 2), o2 = o1 + bx_pad256((size_t)K * 4), o3 = o2 + bx_pad256((size_t)K * 4);
+  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), 0, (hipStream_t)stream, codebook, code_sqnorm, w_pre, b_pre,
+                     (__bf16*)image, (float*)((char*)image + o1), (unsigned*)((char*)image + o2), (BxfScalars*)((char*)image + o3), K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -1775,19 +1831,11 @@ extern "C" int g2v_vq_fused_assign_bx_fwd(const float* z, const float* w_pre_fra
     set_error("g2v_vq_fused_assign_bx_fwd: needs E == 128, K in {128, 256, 384, 512} and 16-byte aligned operands");
     return G2V_ERR_UNSUPPORTED;
   }
-  const size_t o1 = ((size_t)K * E * 2 + 255) & ~(size_t)255, o2 = o1 + (((size_t)K * 4 + 255) & ~(size_t)255);
-  const __bf16* uhf = (const __bf16*)image;
-  const float* sprime = (const float*)((const char*)image + o1);
-  const BxfScalars* scal = (const BxfScalars*)((const char*)image + o2);
-  const dim3 grid(cdiv(N, VQ_ROWS)), block(512);
-  hipStream_t st = (hipStream_t)stream;
-  const int exact = flags & G2V_VQ_BX_EXACT;
-  if (flags & G2V_VQ_BX_ONE_TERM)
-    hipLaunchKernelGGL((vq_fused_bx_kernel<1>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, uhf, sprime, scal, code_sqnorm,
-                       flat_out, idx, quantized, sse_partial, diag, N, K, exact);
-  else
-    hipLaunchKernelGGL((vq_fused_bx_kernel<2>), grid, block, 0, st, z, w_pre_frag, b_pre, codebook, uhf, sprime, scal, code_sqnorm,
-                       flat_out, idx, quantized, sse_partial, diag, N, K, exact);
+  const size_t o1 = bx_pad256((size_t)K * E * 2), o2 = o1 + bx_pad256((size_t)K * 4), o3 = o2 + bx_pad256((size_t)K * 4);
+  hipLaunchKernelGGL(vq_fused_bx_kernel, dim3(cdiv(N, VQ_ROWS)), dim3(512), 0, (hipStream_t)stream, z, w_pre_frag, b_pre, codebook,
+                     (const __bf16*)image, (const float*)((const char*)image + o1), (const unsigned*)((const char*)image + o2),
+                     (const BxfScalars*)((const char*)image + o3), code_sqnorm, flat_out, idx, quantized, sse_partial, diag, N, K,
+                     flags & G2V_VQ_BX_EXACT);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

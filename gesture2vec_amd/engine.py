@@ -132,9 +132,19 @@ class VQVAEEngine:
         self.ema_w = torch.zeros(K, E, device=dev)
         self.ema_cs = torch.zeros(K, device=dev)
         self.code_sqnorm = torch.zeros(K, device=dev)
-        # fragment-major image of the codebook for the fused assign kernel (kept fresh together with code_sqnorm)
-        self.codebook_frag = torch.zeros(K * self.E, device=dev) if (self.E == 128 and K % 128 == 0) else None
-        self._vq_packed = os.environ.get("G2V_VQ_PACKED", "1") != "0"       # 0: the fused kernel reads the row-major codebook (A/B)
+        # What the fused assign kernels read besides the codebook itself, all DERIVED from (codebook, pre_linear) by vq_derive():
+        #   bf16-screened kernel (g2v_vq_fused_assign_bx_fwd, E == 128, K in {128..512}; G2V_VQ_BX=0 selects the fp32 kernel):
+        #     pre_linear's weight as fp32 MFMA fragments + the screening image (bf16 fragments of U = W w_pre, s'_k, norm bounds);
+        #   fp32 kernel: fragment-major image of the codebook (G2V_VQ_PACKED=0: it reads the row-major codebook instead, A/B).
+        self._vq_bx = bool(self.lib.g2v_vq_fused_assign_bx_ok(1, self.E, K)) and os.environ.get("G2V_VQ_BX", "1") != "0"
+        self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
+        self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
+        self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
+                            if self._vq_bx else None)
+        self.vq_diag = torch.zeros(4, dtype=torch.int32, device=dev)          # [0] tiles on the exact sweep, [1] pairs re-evaluated
+        self._vq_diag_on = False
+        self.codebook_frag = torch.zeros(K * self.E, device=dev) if (self.E == 128 and K % 128 == 0 and not self._vq_bx) else None
+        self._vq_packed = os.environ.get("G2V_VQ_PACKED", "1") != "0"
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
         self.vq_stats = self.comm[self.n_flat:]
@@ -147,10 +157,11 @@ class VQVAEEngine:
         # :483-486): their gradient slots are zeroed after the backward, so they add nothing to the clip norm and Adam
         # (m = v = 0, g = 0) leaves them exactly where they are -- what the reference's clip_grad_norm_ / Adam do by skipping them
         self.frozen: list = []
-        # code_sqnorm (||W_k||^2) is rewritten by the EMA update kernel together with the codebook; the fused training loop
-        # trusts it from one step to the next, every other entry (module-level forward, first step, after a state load)
-        # recomputes it first
-        self._wsq_fresh = False
+        # code_sqnorm (||W_k||^2) and the images above are recomputed from the codebook by EVERY entry point that assigns codes
+        # (vq_derive: 2-3 small launches; the fused train step runs them in the branch beside the encoder, so they are captured
+        # in its hipGraph and cost nothing on the chain).  Round 2 trusted them from one step to the next behind a Python flag
+        # that in-place writers of the codebook (vq_layer(x) in train mode, a state load on the sub-module, a broadcast) did not
+        # clear: nothing is trusted across calls any more.
         # Independent kernel chains of the fused train step run as parallel branches (side HIP streams; parallel branches of
         # the hipGraph when the step is captured) -- see _branch().  Bit 0: the dropout keep-masks beside the encoder
         # forward; bit 1: the EMA statistics + codebook update beside the decoder rollout; bit 2: the decoder's weight
@@ -346,7 +357,7 @@ class VQVAEEngine:
                 b["keep_l0"].copy_(keep_l0)
 
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
-                n_global: Optional[int] = None, trust_wsq: bool = False):
+                n_global: Optional[int] = None, derived_ready: bool = False):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
         if self.quantizer != "ema":
@@ -358,11 +369,17 @@ class VQVAEEngine:
         b = self.forward_encoder(in_poses, training)
         # ---- VQ_Payam_EMA (:1217-1296) on decoder_hidden.view(-1, E) ---------------------------------------
         N = (2 * B * H) // E
-        if not (trust_wsq and self._wsq_fresh):
-            check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
-            if self.codebook_frag is not None:
-                check(lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), K, E, st))
-        if self.codebook_frag is not None and not self._vq_packed:
+        self._join(0)                       # branch 0: keep masks, ahead-of-time packs and (derived_ready) vq_derive()
+        if not derived_ready:
+            self.vq_derive()
+        if self._vq_bx:
+            # pre_linear (fp32 MFMA) + distances screened on the bf16 pipe + exact fp32 re-evaluation of every candidate +
+            # argmin + straight-through / SSE in one launch (flat is written for the statistics)
+            check(lib.g2v_vq_fused_assign_bx_fwd(_p(b["enc_hidden"]), _p(self.vq_wpre_frag), _p(self.vq_pre_b), _p(self.codebook),
+                                                 _p(self.vq_bx_image), _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]),
+                                                 _p(b["quant"]), _p(b["sse"]), _p(self.vq_diag) if self._vq_diag_on else None,
+                                                 N, E, K, self.vq_bx_flags, st))
+        elif self.codebook_frag is not None and not self._vq_packed:
             check(lib.g2v_vq_fused_assign_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b), _p(self.codebook),
                                               _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]), _p(b["quant"]), _p(b["sse"]),
                                               N, E, K, st))
@@ -383,7 +400,6 @@ class VQVAEEngine:
                                    b["ws_stats"].numel(), self._stream()))
             if ema_update:
                 self.vq_finish(B, training, n_global)
-        self._join(0)                       # keep masks drawn beside the encoder (train_step_local)
         b = self.forward_decoder(out_poses, B, training)
         self._join(1)
         return b
@@ -449,13 +465,22 @@ class VQVAEEngine:
                  int(self.conditioned), int(training), T, B, D, H, _p(ws), ws.numel(), st))
         return b
 
+    def vq_derive(self):
+        """Everything the assign kernels read that is derived from (codebook, pre_linear): ||W_k||^2, and the operand images of
+        the fused kernel in use.  Launched on the current stream (inside branch 0 of the fused train step)."""
+        lib, st = self.lib, self._stream()
+        K, E = self.K, self.E
+        check(lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), K, E, st))
+        if self._vq_bx:
+            check(lib.g2v_vq_pack_codebook(_p(self.vq_pre_w), _p(self.vq_wpre_frag), E, E, st))
+            check(lib.g2v_vq_bx_pack(_p(self.codebook), _p(self.code_sqnorm), _p(self.vq_pre_w), _p(self.vq_pre_b),
+                                     _p(self.vq_bx_image), K, E, st))
+        elif self.codebook_frag is not None:
+            check(lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), K, E, st))
+
     def refresh_codebook_state(self):
-        """Recompute what is derived from the codebook and kept on the device next to it -- the squared norms and the fragment
-        image the fused assign kernel reads -- after the codebook was changed from outside the engine's own EMA update."""
-        check(self.lib.g2v_vq_code_sqnorm(_p(self.codebook), _p(self.code_sqnorm), self.K, self.E, self._stream()))
-        if self.codebook_frag is not None:
-            check(self.lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), self.K, self.E, self._stream()))
-        self._wsq_fresh = True
+        """kept for callers of round 2: the derived state is recomputed by every entry point now"""
+        self.vq_derive()
 
     def vq_finish(self, B: int, training: bool, n_global: Optional[int] = None):
         """K4 + the loss / perplexity scalars; under data parallelism call it after vq_stats has been all-reduced."""
@@ -465,10 +490,6 @@ class VQVAEEngine:
                                          _p(self.ema_w), _p(self.codebook), _p(self.code_sqnorm), _p(self.vq_scalars),
                                          N, n_global or N, self.E, self.K, self.beta, self.decay, self.eps,
                                          int(training), self._stream()))
-        if training:
-            if self.codebook_frag is not None:      # ... and the fragment image follows the new codebook (same branch)
-                check(self.lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), self.K, self.E, self._stream()))
-            self._wsq_fresh = True          # the update kernel has just rewritten code_sqnorm with the new codebook
 
     def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):
         """custom_loss on the rollout output; fills loss_terms and (want_grad) the dy buffer with dLoss/dy."""
@@ -646,15 +667,15 @@ class VQVAEEngine:
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
             self.draw_masks(B, True)
-        if self._prepared or (draw_masks and self.p == 0):
-            def side():                        # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the rollout
-                if draw_masks and self.p == 0:
-                    self.draw_masks(B, True)   # only the rollout consumes keep95
-                if self._prepared:
-                    self.prepare_recurrent(B, "dec")
-                    self.prepare_recurrent(B, "gru_bwd")
-            self._side_work = side
-        self.forward(x, target, True, ema_update=not dp, trust_wsq=True)
+        def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
+            self.vq_derive()                   # needed first: the quantiser follows the encoder directly
+            if draw_masks and self.p == 0:
+                self.draw_masks(B, True)       # only the rollout consumes keep95
+            if self._prepared:
+                self.prepare_recurrent(B, "dec")
+                self.prepare_recurrent(B, "gru_bwd")
+        self._side_work = side
+        self.forward(x, target, True, ema_update=not dp, derived_ready=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)

@@ -422,20 +422,12 @@ class Autoencoder_VQVAE(nn.Module):
                 p.grad = g
         vq, bn = self.vq_layer, self.decoder.decoder.pre_linear[1]
         if self.quantizer == "ema":
-            if eng.codebook.data_ptr() != vq._embedding.weight.data_ptr():
-                eng._wsq_fresh = False                       # another codebook tensor: its squared norms are not known yet
             eng.vq_pre_w, eng.vq_pre_b = vq.pre_linear.weight.data, vq.pre_linear.bias.data
             eng.codebook, eng.ema_w, eng.ema_cs = vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size
         if eng.bn_rm.data_ptr() != bn.running_mean.data_ptr() or eng.bn_rv.data_ptr() != bn.running_var.data_ptr():
             eng.bn_rm, eng.bn_rv = bn.running_mean, bn.running_var
             eng._wstruct = None
         return eng
-
-    def load_state_dict(self, *args, **kw):
-        out = super().load_state_dict(*args, **kw)
-        if self._engine is not None:
-            self._engine._wsq_fresh = False                  # the codebook was overwritten in place
-        return out
 
     def set_dropout_masks(self, keep95, keep_in=None, keep_l0=None):
         """Explicit keep masks for the NEXT forward calls (parity tests): keep95 (T-1,B,D) for the inline

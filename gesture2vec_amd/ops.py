@@ -213,11 +213,11 @@ def vq_fused_assign(z, w_pre, b_pre, codebook, code_sqnorm, codebook_frag=None):
     return flat, idx, quant, sse
 
 
-VQ_BX_EXACT, VQ_BX_ONE_TERM = 1, 2          # include/g2v.h G2V_VQ_BX_*
+VQ_BX_EXACT = 1          # include/g2v.h G2V_VQ_BX_*
 
 
 def vq_bx_pack(codebook, code_sqnorm, w_pre, b_pre, out=None):
-    """screening operands of vq_fused_assign_bx (g2v_vq_bx_pack): bf16 fragments of U = W w_pre, s'_k, norm bounds"""
+    """screening operands of vq_fused_assign_bx (g2v_vq_bx_pack): bf16 fragments of U = W w_pre, s'_k, per-code radius coefficients"""
     K, E = codebook.shape
     nb = int(_lib_().g2v_vq_bx_image_bytes(K, E))
     if out is None:

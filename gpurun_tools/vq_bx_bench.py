@@ -65,7 +65,7 @@ def main():
             img = ops.vq_bx_pack(W, wsq, Wp, bp)
             ref = ops.vq_fused_assign(z, Wp, bp, W, wsq, codebook_frag=frag)
             rec = {"N": N, "data": kind}
-            for name, flags in (("bx2", 0), ("bx1", 2), ("bx_exact", 1)):
+            for name, flags in (("bx2", 0), ("bx_exact", 1)):
                 got = ops.vq_fused_assign_bx(z, wpf, bp, W, img, wsq, flags=flags, want_diag=True)
                 torch.cuda.synchronize()
                 eq = [bool(torch.equal(a, b)) for a, b in zip(ref[:3], got[:3])] + [bool(torch.allclose(ref[3], got[3], rtol=2e-6, atol=0, equal_nan=True))]
@@ -78,7 +78,7 @@ def main():
             a_old = (z.data_ptr(), Wp.data_ptr(), bp.data_ptr(), W.data_ptr(), frag.data_ptr(), wsq.data_ptr(), flat.data_ptr(),
                      idx.data_ptr(), quant.data_ptr(), sse.data_ptr(), N, E, K, st)
             rec["us_fp32_packed"] = round(timeit(lambda: check(lib.g2v_vq_fused_assign_packed_fwd(*a_old))), 3)
-            for name, flags in (("bx2", 0), ("bx1", 2), ("bx_exact", 1)):
+            for name, flags in (("bx2", 0), ("bx_exact", 1)):
                 a_new = (z.data_ptr(), wpf.data_ptr(), bp.data_ptr(), W.data_ptr(), img.data_ptr(), wsq.data_ptr(), flat.data_ptr(),
                          idx.data_ptr(), quant.data_ptr(), sse.data_ptr(), None, N, E, K, flags, st)
                 rec["us_" + name] = round(timeit(lambda: check(lib.g2v_vq_fused_assign_bx_fwd(*a_new))), 3)

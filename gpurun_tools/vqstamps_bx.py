@@ -21,7 +21,7 @@ torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 128)()
 raw.g2v_read_vqstamps(buf)
-names = ["z staged", "projection + sweep", "scan", "exact chains", "sync", "gather+STE"]
+names = ["z staged", "projection + sweep", "scan", "exact chains || decided rows, then the rest", "sync", "sse"]
 print("flags", flags)
 for b in range(4):
     st = [buf[b * 32 + k] for k in range(32)]

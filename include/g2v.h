@@ -149,20 +149,20 @@ int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre, const flo
                                    float* quantized, float* sse_partial, int N, int E, int K, g2v_stream_t stream);
 /* The north-star form (round 3): pre_linear in fp32 MFMA and, BESIDE it in the same launch, the -2 x W^T contraction SCREENED on
  * the bf16 matrix pipe in z-space: flat.w_k = z.u_k + b.w_k with u_k = w_pre^T w_k, so e_k = (|w_k|^2 - 2 b.w_k) - 2 (zh + zl).bf16(u_k)
- * (fp32 accumulate, 8 v_mfma_f32_16x16x32_bf16 per 16 x 16 x 128 tile instead of 32 fp32 MFMAs) needs no projected row.  Every code
- * whose e_k is within margin = 2^-6 (1 + 2^-5) |z| max|u| + 2^-12 |flat|^ max|w| + 2^-19 (|flat|^^2 + max|w|^2) of the row's minimum
- * (|flat|^ = |w_pre|_F |z| + |b| >= |flat|; more than twice the screening's error bound, derivation in vq.hip) is re-evaluated IN THE
- * SAME LAUNCH with the exact fp32 MFMA chain of g2v_vq_fused_assign_fwd on the projected rows, the row's code being the
- * torch.argmin (:1259) of those exact distances: flat_out, idx, quantized and sse_partial are bitwise those of
- * g2v_vq_fused_assign_fwd.  A 16-row tile with a non-finite screening value or more than 128 candidates takes the exact fp32
- * sweep over all K codes instead.  E == 128, K in {128, 256, 384, 512} (g2v_vq_fused_assign_bx_ok).
+ * (fp32 accumulate, 8 v_mfma_f32_16x16x32_bf16 per 16 x 16 x 128 tile instead of 32 fp32 MFMAs) needs no projected row.  With the
+ * per-code radius r_k = 2^-7 (1 + 2^-5) |z||u_k| + 2^-13 |flat|^ |w_k| + 2^-20 (|flat|^^2 + |w_k|^2)  (|flat|^ = |w_pre|_F |z| + |b|; an
+ * upper bound of |e_k - (d_k - |flat|^2)| for the fp32 kernel's d_k, derivation in vq.hip) every code with e_k - r_k <= min_j (e_j + r_j)
+ * is re-evaluated IN THE SAME LAUNCH with the exact fp32 chain of g2v_vq_fused_assign_fwd on the projected rows, the row's code
+ * being the torch.argmin (:1259) of those exact distances: flat_out, idx and quantized are bitwise those of
+ * g2v_vq_fused_assign_fwd (sse_partial: the same sum in another order).  A 16-row tile with a non-finite screening value or more
+ * than 128 candidates takes the exact fp32 sweep over all K codes instead.  E == 128, K in {128, 256, 384, 512}
+ * (g2v_vq_fused_assign_bx_ok).
  *   w_pre_frag  g2v_vq_pack_codebook(w_pre, ., E, E): pre_linear's weight as fp32 MFMA fragments (E * E floats)
- *   image       g2v_vq_bx_pack(codebook, code_sqnorm, w_pre, b_pre, ., K, E): bf16 MFMA fragments of U = W w_pre, s'_k and the norm
- *               bounds (g2v_vq_bx_image_bytes(K, E) bytes); rewrite it whenever the codebook / code_sqnorm / pre_linear changed
+ *   image       g2v_vq_bx_pack(codebook, code_sqnorm, w_pre, b_pre, ., K, E): bf16 MFMA fragments of U = W w_pre, s'_k, the radius
+ *               coefficients (g2v_vq_bx_image_bytes(K, E) bytes); rewrite it whenever the codebook / code_sqnorm / pre_linear changed
  *   diag        device int[4] or NULL: [0] += tiles that took the exact sweep, [1] += (row, candidate) pairs re-evaluated
  *   flags       G2V_VQ_BX_*: explicit per-call switches (no process-global state) */
 #define G2V_VQ_BX_EXACT 1      /* every tile takes the exact fp32 sweep: the A/B reference of the screened path */
-#define G2V_VQ_BX_ONE_TERM 2   /* screen with zh . bf16(u) only (4 MFMAs per tile, margin 2^-5 (...)) */
 size_t g2v_vq_bx_image_bytes(int K, int E);
 int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, const float* w_pre, const float* b_pre, void* image, int K, int E,
                    g2v_stream_t stream);

@@ -215,3 +215,47 @@ def test_parallel_branches_and_prepared_launches_change_nothing(B, T, D, H, K, p
         for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars", "loss_terms"):
             assert torch.equal(getattr(eng, name), getattr(ref, name)), (mode, name)
         assert int(eng.step_counter) == int(ref.step_counter) == 3
+
+
+@pytest.mark.parametrize("mode", ["eager", "graph"])
+def test_codebook_written_between_fused_steps_is_what_the_next_step_assigns_against(mode):
+    """(round-2 advisor finding) The fused step used to trust ||W||^2 and the codebook's operand image from one step to the next
+    behind a Python flag that an in-place write of the codebook from OUTSIDE the step (vq_layer(x) in train mode, a state load
+    on the sub-module, a broadcast) did not clear -- and a captured hipGraph never contained the recompute kernels at all.
+    Now every step derives them itself: overwrite the codebook between two (replayed) steps and check the second step's code
+    indices against an independent fp32 assignment on the codebook as it was when that step started."""
+    from gesture2vec_amd import ops
+    B, T, D, H, K = 1024, 8, 135, 64, 512
+    sd = O.init_vqvae_state(D, H, 2, K, seed=5)
+    eng = _engine(sd, D, H, K, T, 0.0)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=True)
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(B, T, D, generator=g).to(DEV)
+    run = lambda: eng.train_step(x, x, **kw)
+    if mode == "graph":
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            run()
+        run = graph.replay
+    run()
+    torch.cuda.synchronize()
+    # an outside writer: a completely different codebook, in place
+    new_w = (torch.rand(K, 2 * H, generator=g) * 2 - 1).to(DEV)
+    eng.codebook.copy_(new_w)
+    eng.ema_w.copy_(new_w)
+    eng.ema_cs.fill_(1.0)
+    run()
+    torch.cuda.synchronize()
+    b = eng.buffers(B)
+    z = b["enc_hidden"].reshape(-1, 2 * H)
+    wsq = ops.vq_code_sqnorm(new_w)
+    flat, idx_ref, quant_ref, _ = ops.vq_fused_assign(z, eng.vq_pre_w, eng.vq_pre_b, new_w, wsq)
+    assert torch.equal(b["idx"], idx_ref), f"{int((b['idx'] != idx_ref).sum())} rows were assigned against a stale codebook image"
+    assert torch.equal(b["quant"].reshape(-1, 2 * H), quant_ref)
+    assert len(torch.unique(idx_ref)) > K // 4          # the planted codebook really spreads the rows

@@ -81,7 +81,6 @@ def sync_engine_from_oracle(eng, sd, adam, step_count):
     eng.codebook.copy_(sd["vq_layer._embedding.weight"]); eng.ema_w.copy_(sd["vq_layer._ema_w"])
     eng.ema_cs.copy_(sd["vq_layer._ema_cluster_size"])
     eng.bn_rm.copy_(sd["decoder.decoder.pre_linear.1.running_mean"]); eng.bn_rv.copy_(sd["decoder.decoder.pre_linear.1.running_var"])
-    eng._wsq_fresh = False
 
 
 def relerr(got, ref):
