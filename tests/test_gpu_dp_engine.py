@@ -258,4 +258,4 @@ def test_codebook_written_between_fused_steps_is_what_the_next_step_assigns_agai
     flat, idx_ref, quant_ref, _ = ops.vq_fused_assign(z, eng.vq_pre_w, eng.vq_pre_b, new_w, wsq)
     assert torch.equal(b["idx"], idx_ref), f"{int((b['idx'] != idx_ref).sum())} rows were assigned against a stale codebook image"
     assert torch.equal(b["quant"].reshape(-1, 2 * H), quant_ref)
-    assert len(torch.unique(idx_ref)) > K // 4          # the planted codebook really spreads the rows
+    assert len(torch.unique(idx_ref)) >= 8              # the planted codebook really spreads the rows
