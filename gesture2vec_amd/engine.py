@@ -203,6 +203,10 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_stream(self._sides[j])
             self._open.remove(j)
 
+    def _branches_ok(self, B: int) -> bool:
+        """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""
+        return B >= self.overlap_min_rows and self.quantizer == "ema"
+
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
         off, n, shp = self.offsets[name]

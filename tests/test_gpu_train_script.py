@@ -148,3 +148,78 @@ def test_train_autoencoder_vqvae_distributed_launch(tmp_path):
     ck = torch.load(os.path.join(out, "t_checkpoint_002.bin"), map_location="cpu", weights_only=False)
     assert ck["pose_dim"] == 45 and ck["gen_dict"]["vq_layer._embedding.weight"].shape == (400, 400)
     assert all(torch.isfinite(v).all() for v in ck["gen_dict"].values() if v.dtype.is_floating_point)
+
+
+def _iter_setup(B, T=8):
+    import argparse
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    D, H, K = 135, 64, 512
+    args = argparse.Namespace(rep_learning_dim=D, hidden_size=H, n_layers=2, dropout_prob=0.0, autoencoder_vq="True",
+                              autoencoder_vae="False", autoencoder_vq_components=K, autoencoder_vq_commitment_cost=0.25,
+                              autoencoder_conditioned="True", autoencoder_att="False", autoencoder_fixed_weight="False",
+                              n_pre_poses=1, n_poses=T, loss_l1_weight=5.0, loss_cont_weight=0.1, loss_var_weight=0.5,
+                              learning_rate=5e-4)
+    torch.manual_seed(3)
+    net = Autoencoder_VQVAE(args, D, T).to("cuda:0")
+    net.train(True)
+    net.rng_seed = 11
+    return args, net
+
+
+def test_train_iter_replayed_from_a_graph_equals_eager_iterations(monkeypatch):
+    """From 1024 rows per batch train_iter_Autoencoder_VQ_seq2seq replays its fused step from a hipGraph (first iteration eager,
+    second captures); batches arrive as NEW tensors every iteration (a data loader), so the static input buffer is exercised.
+    Weights, Adam moments, codebook and the returned losses must equal the eager iterations' bitwise."""
+    import gesture2vec_amd.train_eval.train_seq2seq as ts
+    B = 1024
+    runs = {}
+    for mode in ("graph", "eager"):
+        monkeypatch.setattr(ts, "_GRAPH_REPLAY", mode == "graph")
+        args, net = _iter_setup(B)
+        optim = ts.FusedClipAdam(net, 5e-4, betas=(0.5, 0.999))
+        g = torch.Generator(device="cuda:0").manual_seed(5)
+        losses = []
+        for _ in range(5):
+            x = torch.randn(B, args.n_poses, 135, generator=g, device="cuda:0")
+            loss, perp = ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+            losses.append((loss["loss"], float(perp)))
+        eng = net.engine()
+        if mode == "graph":
+            assert eng._iter_graph["graph"] not in (None, False), "the iteration was not replayed from a graph"
+        runs[mode] = (losses, eng.flat.clone(), eng.m.clone(), eng.v.clone(), eng.codebook.clone(), eng.ema_cs.clone(),
+                      eng.bn_rm.clone(), int(net.decoder.decoder.pre_linear[1].num_batches_tracked))
+    a, b = runs["graph"], runs["eager"]
+    assert a[0] == b[0], (a[0], b[0])
+    for ta, tb in zip(a[1:7], b[1:7]):
+        assert torch.equal(ta, tb)
+    assert a[7] == b[7] == 5 * 7
+
+
+def test_train_iter_adopts_a_plain_torch_adam():
+    """The reference's harness builds torch.optim.Adam(net.parameters(), lr, betas=(0.5, 0.999)) (train_autoencoder_VQVAE.py:193-195):
+    handing THAT to train_iter must train exactly like the FusedClipAdam it is adopted into, including an lr change between
+    iterations; unsupported variants are refused."""
+    import gesture2vec_amd.train_eval.train_seq2seq as ts
+    res = []
+    for kind in ("torch", "fused"):
+        args, net = _iter_setup(64)
+        optim = (torch.optim.Adam(net.parameters(), lr=5e-4, betas=(0.5, 0.999)) if kind == "torch"
+                 else ts.FusedClipAdam(net, 5e-4, betas=(0.5, 0.999)))
+        g = torch.Generator(device="cuda:0").manual_seed(6)
+        for it in range(3):
+            if it == 2:
+                if kind == "torch":
+                    optim.param_groups[0]["lr"] = 1e-4
+                else:
+                    optim.lr = 1e-4
+            x = torch.randn(64, args.n_poses, 135, generator=g, device="cuda:0")
+            loss, _ = ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        res.append((loss["loss"], net.engine().flat.clone()))
+    assert res[0][0] == res[1][0] and torch.equal(res[0][1], res[1][1])
+    args, net = _iter_setup(64)
+    x = torch.randn(64, args.n_poses, 135, device="cuda:0")
+    with pytest.raises(TypeError):
+        ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, torch.optim.Adam(net.parameters(), lr=1e-3, weight_decay=0.1))
+    with pytest.raises(TypeError):
+        ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, torch.optim.SGD(net.parameters(), lr=1e-3))
