@@ -344,7 +344,14 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    comm_sums = None
+    if use_dp:
+        cs = torch.tensor([float(eng.comm.double().sum())], device=dev, dtype=torch.float64)
+        allc = [torch.zeros_like(cs) for _ in range(world)]
+        dist.all_gather(allc, cs)
+        comm_sums = [float(c.item()) for c in allc]
     loss = eng.loss_terms[0].item() + eng.vq_scalars[0].item() / 400
+    assert lib.g2v_dec_rollout_persist_fault(0) == 0, "the persistent rollout kernel latched a residency fault: the timed steps are invalid"
     assert loss == loss, "loss is NaN"
 
     out = None
@@ -366,7 +373,11 @@ def main():
                        "graph_branches_mask": int(eng.overlap),
                        "wgrad_inside_recurrent_kernels": {"decoder_mask_ih0_hh0_ih1_hh1": int(eng.buffers(B).get("fused_wgrad", 0)),
                                                           "encoder_mode": int(eng.buffers(B).get("enc_fused_wgrad", 0))},
-                       "final_loss": round(loss, 6)},
+                       "final_loss": round(loss, 6),
+                       # what the collective really ran over: the process group's size, and the reduced comm buffer's checksum of
+                       # the last step as every rank saw it (identical values = every rank applied the same update)
+                       "dist_world_size": (dist.get_world_size() if use_dp else 1),
+                       "reduced_comm_checksum_per_rank": comm_sums},
         }
         if world == 1:
             out["roofline"] = vq_kernel_roofline(eng, B)

@@ -101,6 +101,7 @@ _SIGS = {
                                              c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_blocks": (c_int, [c_int]),
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
+    "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
     "g2v_dec_rollout_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),

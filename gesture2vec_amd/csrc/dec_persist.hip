@@ -520,6 +520,26 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
 
 using namespace g2v;
 
+// The fault latch of the persistent kernels (dec_persist.hpp): 1 if a bounded wait of the grid-wide exchange ever ran out since the
+// last clear.  SYNCHRONOUS (a device-to-host copy of one word): call it where the host synchronises anyway.
+extern "C" int g2v_dec_rollout_persist_fault(int clear) {
+  unsigned v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g2v_persist_fault), sizeof(v)) != hipSuccess) return -1;
+  if (v && clear) {
+    const unsigned zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g2v_persist_fault), &zero, sizeof(zero));
+  }
+  return (int)v;
+}
+
+// Residency check of a persistent kernel (once per kernel): at least one workgroup of its shape must fit a CU; together with
+// nblk <= CU count (dec_rollout.hip) this is what a plain launch can know.  It cannot see CU masks or other tenants of the
+// device: that is what the fault latch is for.
+static bool persist_fits(const void* fn, size_t lds) {
+  int n = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 256, lds) == hipSuccess && n >= 1;
+}
+
 // Host side: called by g2v_dec_rollout_fwd (dec_rollout.hip) when the persistent path applies.  `packed` points at the
 // six fragment-major matrices in the order pre, ih0, hh0, ih1, hh1, out; `xbase` at PX_BYTES of exchange state.
 int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
@@ -539,6 +559,10 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)dec_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("dec_persist_fwd: cannot reserve %zu bytes of LDS", lds);
+      return G2V_ERR_LAUNCH;
+    }
+    if (!persist_fits((const void*)dec_persist_fwd_kernel, lds)) {
+      set_error("dec_persist_fwd: the kernel does not fit a CU (occupancy query)");
       return G2V_ERR_LAUNCH;
     }
     attr_set = true;
@@ -1012,6 +1036,10 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
     const void* fn = fw ? (const void*)dec_persist_bwd_kernel<true> : (const void*)dec_persist_bwd_kernel<false>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
       set_error("dec_persist_bwd: cannot reserve %zu bytes of LDS", lds);
+      return G2V_ERR_LAUNCH;
+    }
+    if (!persist_fits(fn, lds)) {
+      set_error("dec_persist_bwd: the kernel does not fit a CU (occupancy query)");
       return G2V_ERR_LAUNCH;
     }
     attr_set[fw] = true;

@@ -25,7 +25,12 @@
 //     group record of step s, which exist only after every workgroup has published step s, i.e. finished reading s-1.
 //   * every polled word is zeroed by a memset node in front of the launch; tags count steps inside the call (1..T).
 //   * all workgroups must be co-resident: the launcher admits the path only when nblk <= the device's CU count and the
-//     kernel needs one workgroup per CU (256 threads, <= 512 VGPRs, ~135 KB LDS); every spin is bounded and traps.
+//     kernel needs one workgroup per CU (256 threads, <= 512 VGPRs, ~135 KB LDS).  Every spin is bounded; a thread whose
+//     bound runs out (a workgroup of the launch is not resident: CU mask, another persistent launch interleaved on the same
+//     device ...) LATCHES g2v_persist_fault and stops waiting, every other spinning thread sees the latch within 4096 polls
+//     and stops waiting too: the launch ends (with garbage in its outputs) instead of trapping -- a GPU fault would kill
+//     the process and, under data parallelism, hang the peers at the next collective.  The host reads the latch with
+//     g2v_dec_rollout_persist_fault() at its own sync points (round-2 advisor finding).
 #pragma once
 #include "common.hpp"
 
@@ -36,6 +41,9 @@
 namespace g2v {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// sticky fault latch of the persistent kernels (translation-unit local: only dec_persist.hip's kernels and reader use it)
+static __device__ unsigned g2v_persist_fault;
 
 constexpr int PX_GROUP = 16;          // workgroups per exchange group
 constexpr int PX_MAX_NBLK = 256;      // one workgroup per CU on MI355X
@@ -98,7 +106,13 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         if (g[k][1] != tag || g[k][3] != tag) g[k] = px_ld(rr, (unsigned)((rec * PX_COLS + 2 * (c + 16 * k)) * 8));
-      if (++spins > 4000000u) __builtin_trap();      // a workgroup of this launch is not resident / died: fail loudly
+      ++spins;
+      if (spins > 4000000u || ((spins & 4095u) == 0 &&
+                               __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+        // a workgroup of this launch is not resident / died: latch the fault and stop waiting (see the header comment)
+        __hip_atomic_store(&g2v_persist_fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
     }
     // NB: copy the vector elements to scalars first.  `__builtin_bit_cast(float, g[k][2])` straight on an ext-vector
     // element is compiled by ROCm 7.2's clang as a cast of ELEMENT 0 (seen in the IR: both floats come from lane 0 of

@@ -203,6 +203,18 @@ class VQVAEEngine:
             torch.cuda.current_stream().wait_stream(self._sides[j])
             self._open.remove(j)
 
+    def check_faults(self):
+        """The persistent rollout kernels' fault latch (include/g2v.h: a bounded wait of the grid-wide exchange ran out because a
+        workgroup of the launch was not resident).  Synchronous one-word read: call it at a host sync point.  On a fault the
+        persistent path is switched off for the process and the caller is told to repeat the step."""
+        f = int(self.lib.g2v_dec_rollout_persist_fault(1))
+        if f != 0:
+            self.lib.g2v_dec_rollout_set_persistent(0)
+            self._iter_graph = None
+            raise RuntimeError("persistent rollout kernel: a workgroup of the launch was not resident (CU mask / another tenant of "
+                               "the device?) -- the step's results are invalid; the per-step kernels are selected from now on, "
+                               "repeat the step")
+
     def _branches_ok(self, B: int) -> bool:
         """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""
         return B >= self.overlap_min_rows and self.quantizer == "ema"

@@ -56,6 +56,14 @@ int g2v_device_ok(void);
 /* measurement only: largest row count served by the wave-per-tile kernel of g2v_linear_fwd / g2v_linear_bwd_data
  * (0 = never); returns the previous value, rows < 0 only queries */
 int g2v_linear_set_smallm_rows(int rows);
+/* PROCESS-GLOBAL SWITCHES of the library, complete list (everything else is per call).  All of them select between
+ * implementations that produce the same results (A/B measurements, parity tests); none is needed in production:
+ *   g2v_linear_set_smallm_rows(rows)        row count up to which the wave-per-tile dense kernels are used (default 1024)
+ *   g2v_dec_rollout_set_persistent(0 / 1)   persistent rollout kernels vs one launch per step (default 1)
+ *   environment, read ONCE at first use:  G2V_NO_PERSIST=1 (initial value 0 of the switch above), G2V_PLAIN_STORES=1 (no
+ *   write-through stores for the saved tensors of the per-step rollout kernels), G2V_NO_FUSED_WGRAD=1 (the persistent
+ *   backward does not accumulate dW_hh1 itself).
+ * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
                    const float* w, const float* bias, float* y, int64_t ldy,
@@ -331,6 +339,14 @@ int g2v_dec_rollout_blocks(int B);
  * (default 1, or 0 with the environment variable G2V_NO_PERSIST=1) exists for A/B measurements and parity tests.
  * Returns the previous setting. */
 int g2v_dec_rollout_set_persistent(int enable);
+/* The persistent kernels need every workgroup of their launch resident at once; what a plain launch can check is checked
+ * (B / 16 <= CU count, the occupancy query).  What it cannot see -- a CU mask, another tenant or a second persistent launch
+ * interleaved on the same device -- ends in a bounded wait running out: the kernel then LATCHES a device-side fault word and
+ * stops waiting (its outputs are garbage) instead of trapping.  g2v_dec_rollout_persist_fault returns the latch (0 / 1; -1 if
+ * it cannot be read) and clears it when `clear` != 0.  It is SYNCHRONOUS (a one-word device-to-host copy): call it where the
+ * host synchronises anyway (the engine does after a training iteration's loss read-back, bench.py at the end of the timed
+ * region); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step kernels. */
+int g2v_dec_rollout_persist_fault(int clear);
 /* workspace: the weights re-laid-out in MFMA fragment order (packed once per call) + the persistent kernel's exchange
  * state (zeroed by a memset node in front of its launch). */
 size_t g2v_dec_rollout_fwd_workspace(int D, int H);

@@ -1,0 +1,77 @@
+"""Two ranks on two GPUs over RCCL: the product's data-parallel step against the two-shard oracle emulation.
+
+Runs only where the box has >= 2 GPUs (the pool's single-GPU boxes skip it); the same exchange logic runs on gloo in
+tests/test_dp_gloo.py and the engine halves on one GPU in tests/test_gpu_dp_engine.py."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from oracle import g2v_oracle as O
+from test_gpu_dp_engine import _cfg, _oracle_apply, _oracle_local, _shard, relerr
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL all-reduce between two ranks)")
+@pytest.mark.parametrize("B,T,D,H,K", [(64, 34, 135, 64, 512), (1024, 8, 135, 64, 512), (48, 10, 45, 200, 400)])
+def test_two_ranks_over_rccl_equal_the_two_shard_oracle(tmp_path, B, T, D, H, K):
+    world, n_steps, lr = 2, 2, 5e-4
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dp_nccl_worker.py"), str(tmp_path),
+           *[str(v) for v in (B, T, D, H, K, n_steps)]]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    s0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    s1 = torch.load(os.path.join(tmp_path, "rank1.pt"), weights_only=False)
+    assert s0["world"] == s1["world"] == world
+    # every rank saw the same reduced buffer and applied the same deterministic update: replicas bit-identical
+    assert s0["comm_sums"] == s1["comm_sums"]
+    for k in ("flat", "codebook", "ema_w", "ema_cs"):
+        assert torch.equal(s0[k], s1[k]), k
+    # ... and equal to the oracle visiting the two shards in turn (mean gradient -> clip -> Adam; EMA from GLOBAL statistics)
+    cfg = _cfg(0.0)
+    sd = O.init_vqvae_state(D, H, 2, K, seed=11)
+    adam = {}
+    for step in range(n_steps):
+        tot_g, tot_c, tot_w = None, 0, 0
+        for rk in range(world):
+            x, masks = _shard(rk, step, B, T, D, H, 0.0)
+            g, c, w, _ = _oracle_local(sd, x, masks, cfg, K)
+            tot_g = g if tot_g is None else {k: tot_g[k] + g[k] for k in g}
+            tot_c, tot_w = tot_c + c, tot_w + w
+        norm = _oracle_apply(sd, tot_g, tot_c, tot_w, world, adam, K, lr)
+    assert abs(s0["gnorm"] - float(norm)) <= 5e-4 * float(norm), "global mean-gradient norm"
+    for name, (off, n, shp) in s0["offsets"].items():
+        if name == "decoder.decoder.pre_linear.0.bias" or name not in sd:      # zero-gradient tensor: Adam amplifies rounding noise
+            continue
+        got, ref = s0["flat"][off:off + n], sd[name].reshape(-1)
+        assert float((got - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 0.05 * lr * n_steps, name
+    assert relerr(s0["ema_cs"], sd["vq_layer._ema_cluster_size"]) < 1e-5
+    assert relerr(s0["ema_w"], sd["vq_layer._ema_w"]) < 1e-4
+
+
+def test_the_rccl_worker_runs_with_one_rank(tmp_path):
+    """the 2-GPU test above is skipped on this pool's single-GPU boxes; its worker (process group on "nccl", broadcast, the DP
+    train_step, fault latch, state dump) must at least run as a world of one there"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_dp_nccl_worker.py"), str(tmp_path),
+           "64", "8", "135", "64", "512", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-4000:]
+    s0 = torch.load(os.path.join(tmp_path, "rank0.pt"), weights_only=False)
+    assert s0["world"] == 1 and len(s0["comm_sums"]) == 2 and torch.isfinite(s0["flat"]).all()
