@@ -1589,15 +1589,20 @@ __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict
                                                          __bf16* __restrict__ Uhf, float* __restrict__ sprime,
                                                          unsigned* __restrict__ pqk, BxfScalars* __restrict__ scal, int K) {
   constexpr int E = 128;
-  __shared__ float Ws[16][E + 1];
-  __shared__ float Us[16][E + 1];
+  extern __shared__ __attribute__((aligned(16))) float WpS[];      // [E][E]: all of W_pre, staged once (the first version read it
+  __shared__ float Ws[16][E + 1];                                   // from global inside the contraction loop: 128 dependent L2
+  __shared__ float Us[16][E + 1];                                   // round trips = 143 us; from LDS the kernel takes ~10 us)
   __shared__ float red[4];
   __shared__ float s_wpf2, s_bb;
   const int tid = threadIdx.x, kt = blockIdx.x;
   for (int e = tid; e < 16 * E; e += 256) Ws[e / E][e % E] = W[(int64_t)(16 * kt) * E + e];
-  {  // |W_pre|_F^2 and |b|^2 (every workgroup for itself: the radius coefficients below need them)
+  {  // stage W_pre; |W_pre|_F^2 and |b|^2 on the way (every workgroup for itself: the radius coefficients below need them)
     float f = 0.f;
-    for (int e = tid; e < E * E; e += 256) f = fmaf(Wp[e], Wp[e], f);
+    for (int e4 = tid; e4 < E * E / 4; e4 += 256) {
+      const float4 v = reinterpret_cast<const float4*>(Wp)[e4];
+      reinterpret_cast<float4*>(WpS)[e4] = v;
+      f = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, f))));
+    }
     f = wave_sum(f);
     if ((tid & 63) == 0) red[tid >> 6] = f;
   }
@@ -1619,8 +1624,9 @@ __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict
     float acc[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+#pragma unroll 4
     for (int e = 0; e < E; ++e) {
-      const float wv = Wp[e * E + j];
+      const float wv = WpS[e * E + j];
 #pragma unroll
       for (int m = 0; m < 8; ++m) acc[m] = fmaf(Ws[kh + 2 * m][e], wv, acc[m]);
     }
@@ -1813,7 +1819,15 @@ extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, c
   }
   G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
   const size_t o1 = bx_pad256((size_t)K * E * 2), o2 = o1 + bx_pad256((size_t)K * 4), o3 = o2 + bx_pad256((size_t)K * 4);
-  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), 0, (hipStream_t)stream, codebook, code_sqnorm, w_pre, b_pre,
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)vq_bx_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E * E * 4) != hipSuccess) {
+      set_error("g2v_vq_bx_pack: cannot reserve LDS");
+      return G2V_ERR_LAUNCH;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), E * E * 4, (hipStream_t)stream, codebook, code_sqnorm, w_pre, b_pre,
                      (__bf16*)image, (float*)((char*)image + o1), (unsigned*)((char*)image + o2), (BxfScalars*)((char*)image + o3), K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;

@@ -559,11 +559,11 @@ class VQVAEEngine:
         ws, wsn = _p(b["ws"]), b["ws"].numel()
         drop = self.p > 0
         fn, wsd = (lib.g2v_dec_rollout_bwd_prepared, b["ws_decb"]) if self._prepared else (lib.g2v_dec_rollout_bwd, b["ws"])
+        pre = "decoder.decoder."
+        M = (T - 1) * B
         check(fn(C.byref(self.dec_wstruct()), C.byref(b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
                  _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
                  T, B, D, H, _p(wsd), wsd.numel(), st))
-        pre = "decoder.decoder."
-        M = (T - 1) * B
         x1 = b["x1"] if drop else b["h0"][1:]
         with (self._branch(2) if wgrad_branch else contextlib.nullcontext()):
             wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws")
@@ -575,6 +575,8 @@ class VQVAEEngine:
             rest = [it for m, it in enumerate(items) if not (b["fused_wgrad"] >> m) & 1]      # the others came out of the rollout kernel
             if rest:
                 wgrad4(M, rest)
+            # (the rollout's backward ADDS the feedback path's gradient into dy: this product needs the finished dy, it cannot run
+            # beside the rollout -- tried in round 3, wrong by construction)
             wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
             for name in self.frozen:
                 g = self.view(name, True)
