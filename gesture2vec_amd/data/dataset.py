@@ -107,3 +107,129 @@ class TrinityDataset_DAEed_Autoencoder:
 def write_cache(cache_dir: str, samples: List[list]) -> None:
     """samples: list of `[words, poses, audio, aux_info]` -> an LMDB cache directory in the reference's layout"""
     write_lmdb(cache_dir, {sample_key(i): serialize(s) for i, s in enumerate(samples)})
+
+
+class CacheLoader:
+    """What the trainers iterate over: `len()` = batches per epoch, `iter()` = a fresh pass over `make_batches(epoch_seed)`.
+    Stands where the reference builds `DataLoader(dataset, batch_size, shuffle=True, drop_last=True, num_workers=...)`
+    (train_autoencoder_VQVAE.py:639-653): the per-item work left on the host is a memcpy-sized normalisation, the device work is
+    one launch per batch, so no worker processes are needed."""
+
+    def __init__(self, n_items: int, batch_size: int, make_batches, shuffle: bool = True, drop_last: bool = True, seed: int = 0):
+        self.n_items, self.batch_size, self.make_batches = n_items, batch_size, make_batches
+        self.shuffle, self.drop_last, self.seed, self.epoch = shuffle, drop_last, seed, 0
+
+    def __len__(self) -> int:
+        return self.n_items // self.batch_size if self.drop_last else -(-self.n_items // self.batch_size)
+
+    def __iter__(self):
+        self.epoch += 1
+        return iter(self.make_batches(self.batch_size, self.shuffle, self.seed + self.epoch, self.drop_last))
+
+
+class TrinityDataset_DAE:
+    """Part-a frame dataset (reference lmdb_data_loader.py:272-508): every frame of every cached chunk, normalised with
+    `(x - mean) / clip(std, 0.01)` (:380-382), as (noisy, original) = (x, x) of shape (D, 1) -- the DAE's own dropout is the
+    noise (:388-389).  All frames are kept in ONE float32 array (the reference keeps a Python list of per-frame dicts)."""
+
+    def __init__(self, args, lmdb_dir: str, n_poses: int, subdivision_stride: int, pose_resampling_fps: int,
+                 data_mean: Sequence[float], data_std: Sequence[float]):
+        preloaded_dir = lmdb_dir + "_cache"
+        if not os.path.exists(preloaded_dir):
+            raise FileNotFoundError(f"{preloaded_dir}: the sample cache is produced by the reference's DataPreprocessor")
+        chunks = TrinityChunks(preloaded_dir)
+        mean = np.array(data_mean, dtype=np.float64).squeeze()
+        std = np.clip(np.array(data_std, dtype=np.float64).squeeze(), a_min=0.01, a_max=None)
+        frames = [((chunks[i][1] - mean) / std).astype(np.float32) for i in range(len(chunks))]
+        self.frames = torch.from_numpy(np.concatenate(frames, axis=0)) if frames else torch.zeros(0, mean.size)
+        self.n_samples = self.frames.shape[0]
+
+    def __len__(self) -> int:
+        return self.n_samples
+
+    def __getitem__(self, idx: int):
+        x = self.frames[idx].reshape(-1, 1)
+        return x, x
+
+    def batches(self, batch_size: int, device, shuffle: bool = True, seed: int = 0, drop_last: bool = True):
+        order = torch.randperm(self.n_samples, generator=torch.Generator().manual_seed(seed)) if shuffle else torch.arange(self.n_samples)
+        for s in range(0, self.n_samples, batch_size):
+            ids = order[s:s + batch_size]
+            if drop_last and len(ids) < batch_size:
+                break
+            x = self.frames[ids].unsqueeze(2).to(device, non_blocking=True)
+            yield x, x
+
+
+class TrinityDataset_sentencelevel:
+    """Part-d sentence dataset (reference lmdb_data_loader.py:1045-1313) + `word_seq_collate_fn` (:29-122) in one place.
+
+    Cached sample = `[word_seq, pose_seq, audio_raws, audio_mels, aux_info, sentence_leve_latents (S, L*H), GPT3_Embedding]`
+    (:1209-1221).  Per item the reference normalises the poses, maps words to vocabulary ids up to `aux_info["end_time"]`
+    (:1223-1236: no SOS / EOS) and -- on the CPU, inside `__getitem__` -- runs the frozen VQ-VAE's `vq_layer` on the item's (S, E)
+    latent rows and takes `argmax(encodings)` (:1274-1281).  Here the per-item part stops before the quantiser; `batches()`
+    collates B items (sorted by word count, descending, ids padded with 0 -- `pad_sequence`), moves the (B, S, E) latents to the
+    device once and assigns ALL B*S rows with ONE launch of the VQ-VAE's own assignment kernel (`VQ_Payam_EMA.assign`: the
+    same codes), then yields the collate function's 8-tuple
+    `(word_seq, words_lengths, poses_seq, audio, aux_info, sentence_leve_latents, cluster_ids, GPT3_Embedding)`."""
+
+    def __init__(self, args, lmdb_dir: str, n_poses: int, subdivision_stride: int, pose_resampling_fps: int,
+                 data_mean: Sequence[float], data_std: Sequence[float], lang_model=None, vq_net=None):
+        preloaded_dir = lmdb_dir + "_cache"
+        if not os.path.exists(preloaded_dir):
+            raise FileNotFoundError(f"{preloaded_dir}: the sentence-level cache is produced by the reference's DataPreprocessor")
+        self.env = LMDBReader(preloaded_dir)
+        self.n_samples = len(self.env)
+        self.data_mean = np.array(data_mean, dtype=np.float64).squeeze()
+        self.data_std = np.array(data_std, dtype=np.float64).squeeze()
+        self.lang_model, self.vq_net = lang_model, vq_net
+
+    def set_lang_model(self, lang_model) -> None:
+        self.lang_model = lang_model
+
+    def __len__(self) -> int:
+        return self.n_samples
+
+    def __getitem__(self, idx: int):
+        """-> (word ids (Tw,) int64, poses (n, D) float32, audio float32, aux_info, latents (S, E) float32, GPT3 embedding)"""
+        raw = self.env.get(sample_key(idx))
+        if raw is None:
+            raise IndexError(idx)
+        word_seq, pose_seq, _audio_raws, audio_mels, aux_info, latents, gpt3 = deserialize(raw)[:7]
+        std = np.clip(self.data_std, a_min=0.01, a_max=None)
+        pose = np.asarray(pose_seq)
+        pose = torch.from_numpy(((pose - self.data_mean) / std)).reshape(pose.shape[0], -1).float()
+        ids = []
+        for w in word_seq:
+            if aux_info.get("end_time") is not None and w[1] > aux_info["end_time"]:
+                break
+            ids.append(self.lang_model.get_word_index(w[0]))
+        lat = torch.from_numpy(np.array(latents, dtype=np.float32)).reshape(np.asarray(latents).shape[0], -1)
+        audio = torch.from_numpy(np.array(audio_mels, dtype=np.float32))
+        try:
+            gpt3 = torch.from_numpy(np.array(gpt3, dtype=np.float32))
+        except Exception:
+            gpt3 = torch.zeros(1)
+        return torch.tensor(ids, dtype=torch.int64), pose, audio, aux_info, lat, gpt3
+
+    def batches(self, batch_size: int, device, shuffle: bool = True, seed: int = 0, drop_last: bool = True):
+        order = np.arange(self.n_samples)
+        if shuffle:
+            np.random.default_rng(seed).shuffle(order)
+        for s in range(0, self.n_samples, batch_size):
+            ids = order[s:s + batch_size]
+            if drop_last and len(ids) < batch_size:
+                break
+            items = [self[int(i)] for i in ids]
+            items.sort(key=lambda it: len(it[0]), reverse=True)            # pack_padded_sequence wants descending lengths (:75)
+            lengths = torch.tensor([len(it[0]) for it in items], dtype=torch.int64)
+            words = torch.nn.utils.rnn.pad_sequence([it[0] for it in items], batch_first=True).long()
+            poses = torch.stack([it[1] for it in items])
+            audio = torch.stack([it[2] for it in items]) if all(it[2].shape == items[0][2].shape for it in items) else items[0][2]
+            aux = {k: [it[3][k] for it in items] for k in items[0][3]}
+            lat = torch.stack([it[4] for it in items])                     # (B, S, E)
+            gpt3 = torch.stack([it[5] for it in items]) if all(it[5].shape == items[0][5].shape for it in items) else items[0][5]
+            lat_d = lat.to(device, non_blocking=True)
+            B, S, E = lat_d.shape
+            codes = self.vq_net.vq_layer.assign(lat_d.reshape(B * S, E).contiguous()).view(B, S)       # one launch for the batch
+            yield words, lengths, poses, audio, aux, lat_d, codes, gpt3

@@ -124,11 +124,22 @@ def main(config: dict) -> None:
     utils.train_utils.set_logger(args.model_save_path, os.path.basename(__file__).replace(".py", ".log"))
     logging.info("PyTorch version: {}".format(torch.__version__))
     logging.info(pprint.pformat(vars(args)))
-    if not getattr(args, "synthetic", False):
-        raise NotImplementedError("the LMDB frame dataset is not ported; run with --synthetic")
-    n_batches = int(getattr(args, "synthetic_batches", 20))
-    train = SyntheticFrames(args, n_batches, seed=args.random_seed if args.random_seed >= 0 else 0)
-    test = SyntheticFrames(args, max(1, n_batches // 5), seed=4321)
+    if getattr(args, "synthetic", False):
+        n_batches = int(getattr(args, "synthetic_batches", 20))
+        train = SyntheticFrames(args, n_batches, seed=args.random_seed if args.random_seed >= 0 else 0)
+        test = SyntheticFrames(args, max(1, n_batches // 5), seed=4321)
+    else:
+        # the reference's frame dataset (train_DAE.py:258-285: TrinityDataset_DAE over <train_data_path[0]>_cache), read by
+        # gesture2vec_amd/data (pure-Python LMDB + legacy-pyarrow readers, parity unpinned: DESIGN.md)
+        from gesture2vec_amd.data.dataset import CacheLoader, TrinityDataset_DAE
+        loaders = []
+        for k, (paths, shuffle) in enumerate(((args.train_data_path, True), (args.val_data_path, False))):
+            ds = TrinityDataset_DAE(args, lmdb_dir=paths[0], n_poses=args.n_poses, subdivision_stride=args.subdivision_stride,
+                                    pose_resampling_fps=args.motion_resampling_framerate, data_mean=args.data_mean, data_std=args.data_std)
+            loaders.append(CacheLoader(len(ds), args.batch_size,
+                                       lambda bs, sh, seed, dl, ds=ds: ds.batches(bs, device, shuffle=sh, seed=seed, drop_last=dl),
+                                       shuffle=shuffle, drop_last=True, seed=77 + k))
+        train, test = loaders
     train_epochs(args, train, test, None, pose_dim=args.input_motion_dim)
 
 

@@ -81,6 +81,30 @@ class SyntheticChunks:
             yield x, x
 
 
+def cached_chunk_loaders(args):
+    """The reference's data side of this trainer (train_autoencoder_VQVAE.py:617-653): `TrinityDataset_DAEed_Autoencoder` over
+    `<train_data_path[0]>_cache` / `<val_data_path[0]>_cache` with the frozen frame DAE of `args.rep_learning_checkpoint` as
+    `rep_model` (no checkpoint / rep_learning_dim == raw pose dim: the reference's ablation, lmdb_data_loader.py:650-651).  The
+    caches are read by gesture2vec_amd/data (pure-Python LMDB + legacy-pyarrow readers, parity unpinned: DESIGN.md); the DAE
+    encode runs as one device GEMM per batch instead of per item in DataLoader workers."""
+    from gesture2vec_amd.data.dataset import CacheLoader, TrinityDataset_DAEed_Autoencoder
+    rep_model = None
+    ckpt = getattr(args, "rep_learning_checkpoint", "") or ""
+    if ckpt and os.path.exists(ckpt):
+        _a, rep_model, _l, _lang, _dim = utils.train_utils.load_checkpoint_and_model(ckpt, device, "DAE")
+        rep_model.train(False)
+    loaders = []
+    for k, (paths, shuffle) in enumerate(((args.train_data_path, True), (args.val_data_path, False))):
+        ds = TrinityDataset_DAEed_Autoencoder(args, lmdb_dir=paths[0], n_poses=args.n_poses, subdivision_stride=args.subdivision_stride,
+                                              pose_resampling_fps=args.motion_resampling_framerate, data_mean=args.data_mean,
+                                              data_std=args.data_std, rep_model=rep_model)
+        # data parallel: every rank walks its own shuffle of the cache (rank-dependent seed), like the synthetic shards
+        loaders.append(CacheLoader(len(ds), args.batch_size,
+                                   lambda bs, sh, seed, dl, ds=ds: ds.batches(bs, device, shuffle=sh, seed=seed, drop_last=dl),
+                                   shuffle=shuffle, drop_last=True, seed=1234 + 1000 * k + _RANK))
+    return loaders[0], loaders[1]
+
+
 def evaluate_testset(test_data_loader, generator, loss_fn, args) -> float:
     generator.train(False)
     losses = AverageMeter("loss")
@@ -196,12 +220,12 @@ def main(config: dict):
     logging.info("PyTorch version: {}".format(torch.__version__))
     logging.info("HIP version: {}".format(torch.version.hip))
     logging.info(pprint.pformat(vars(args)))
-    if not getattr(args, "synthetic", False):
-        raise SystemExit("the LMDB datasets of the reference need lmdb / legacy pyarrow, which are not available here: "
-                         "run with --synthetic (SURVEY.md §8f ranks the real-data reader as follow-up work)")
-    nb = getattr(args, "synthetic_batches", 8)
-    train_loader = SyntheticChunks(args, nb, seed=1234 + _RANK)          # every rank draws its own shard
-    test_loader = SyntheticChunks(args, max(1, nb // 4), seed=4321)
+    if getattr(args, "synthetic", False):
+        nb = getattr(args, "synthetic_batches", 8)
+        train_loader = SyntheticChunks(args, nb, seed=1234 + _RANK)          # every rank draws its own shard
+        test_loader = SyntheticChunks(args, max(1, nb // 4), seed=4321)
+    else:
+        train_loader, test_loader = cached_chunk_loaders(args)
     out = train_epochs(args, train_loader, None, test_loader, None, pose_dim=args.rep_learning_dim)
     if _DIST:
         import torch.distributed as dist

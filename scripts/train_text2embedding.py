@@ -6,9 +6,10 @@
 Same surface: `init_model(args, lang_model, pose_dim, _device)` (lang_model needs `.n_words` and
 `.word_embedding_weights`), `train_epochs`, `evaluate_testset` (cross-entropy + code-usage perplexity), `main`;
 Adam(lr, betas=(0.5, 0.999)) (:179-181), evaluation every epoch (:195), checkpoint every 10 epochs with the keys
-`args, epoch, lang_model, pose_dim, gen_dict` (:202-221).  The sentence-level LMDB dataset (frozen DAE + VQ-VAE inside
-`__getitem__`, fastText vocabulary) is not ported; `--synthetic` feeds batches of the collate function's 8-tuple shape
-(lmdb_data_loader.py:111-120) with random word ids / lengths / code ids."""
+`args, epoch, lang_model, pose_dim, gen_dict` (:202-221).  Without `--synthetic` the sentence-level cache is read
+(`cached_sentence_loaders`: code ids from the frozen VQ-VAE in one device launch per batch); `--synthetic` feeds batches of
+the collate function's 8-tuple shape (lmdb_data_loader.py:111-120) with random word ids / lengths / code ids (SURVEY.md §8d
+config 4)."""
 from __future__ import annotations
 
 import logging
@@ -147,7 +148,8 @@ def main(config: dict):
     utils.train_utils.set_logger(args.model_save_path, os.path.basename(__file__).replace(".py", ".log"))
     logging.info(pprint.pformat(vars(args)))
     if not getattr(args, "synthetic", False):
-        raise SystemExit("the sentence-level LMDB dataset is not ported: run with --synthetic")
+        train_loader, test_loader, lang_model = cached_sentence_loaders(args)
+        return train_epochs(args, train_loader, test_loader, lang_model, pose_dim=int(args.autoencoder_vq_components))
     n_words = 3863                                      # the vocabulary size hard-coded at text2embedding_model.py:919
     g = torch.Generator().manual_seed(7)
     lang_model = SimpleNamespace(n_words=n_words,
@@ -156,6 +158,32 @@ def main(config: dict):
     train_loader = SyntheticSentences(args, n_words, nb, seed=1234)
     test_loader = SyntheticSentences(args, n_words, max(1, nb // 4), seed=4321)
     return train_epochs(args, train_loader, test_loader, lang_model, pose_dim=int(args.autoencoder_vq_components))
+
+
+def cached_sentence_loaders(args):
+    """The reference's data side of Part d (train_text2embedding.py:510-570): `TrinityDataset_sentencelevel` over
+    `<train_data_path[0]>_cache` / `<val_data_path[0]>_cache`, the frozen chunk VQ-VAE of `args.autoencoder_checkpoint` assigning the
+    code ids, and the vocabulary pickled next to the data (`vocab_cache.pkl`, :552-556; built by the reference's `build_vocab` with
+    fastText, which is outside the hot path).  Code assignment runs as ONE device launch per batch (gesture2vec_amd/data/dataset.py)
+    instead of per item on the CPU."""
+    import pickle
+    from gesture2vec_amd.data.dataset import CacheLoader, TrinityDataset_sentencelevel
+    vocab_path = os.path.join(os.path.split(args.train_data_path[0])[0], "vocab_cache.pkl")
+    if not os.path.exists(vocab_path):
+        raise SystemExit(f"{vocab_path}: the vocabulary cache is written by the reference's build_vocab (fastText); not found")
+    with open(vocab_path, "rb") as f:
+        lang_model = pickle.load(f)
+    _a, vq_net, _l, _lang, _dim = utils.train_utils.load_checkpoint_and_model(args.autoencoder_checkpoint, device, "autoencoder_vq")
+    vq_net.train(False)
+    loaders = []
+    for k, (paths, shuffle) in enumerate(((args.train_data_path, True), (args.val_data_path, False))):
+        ds = TrinityDataset_sentencelevel(args, lmdb_dir=paths[0], n_poses=args.n_poses, subdivision_stride=args.subdivision_stride,
+                                          pose_resampling_fps=args.motion_resampling_framerate, data_mean=args.data_mean,
+                                          data_std=args.data_std, lang_model=lang_model, vq_net=vq_net)
+        loaders.append(CacheLoader(len(ds), args.batch_size,
+                                   lambda bs, sh, seed, dl, ds=ds: ds.batches(bs, device, shuffle=sh, seed=seed, drop_last=dl),
+                                   shuffle=shuffle, drop_last=True, seed=99 + k))
+    return loaders[0], loaders[1], lang_model
 
 
 if __name__ == "__main__":

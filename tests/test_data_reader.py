@@ -82,3 +82,76 @@ def test_dataset_normalisation_and_batches(tmp_path):
     torch.testing.assert_close(e[:, 1:, D:], e[:, 1:, :D] - e[:, :-1, :D])
     with pytest.raises(FileNotFoundError):
         TrinityDataset_DAEed_Autoencoder(args, str(tmp_path / "missing"), T, 10, 20, mean, std)
+
+
+def _chunk_samples(n, T, D, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        poses = (rng.standard_normal((T, D)) * 2).astype(np.float16)
+        out.append([[["w", 0.0, 0.1]] * 4, poses, [0], {"vid": "v", "start_frame_no": i, "end_frame_no": i + T,
+                                                        "start_time": 0.0, "end_time": 1.0}])
+    return out
+
+
+def test_frame_dataset_of_the_dae_trainer(tmp_path):
+    """TrinityDataset_DAE (reference lmdb_data_loader.py:272-508): every frame of every chunk, normalised, (noisy, original) = (x, x)
+    of shape (D, 1); the loader wrapper reshuffles per epoch and drops the ragged tail.  (parity unpinned: the cache is written by
+    this repo's own writer)"""
+    from gesture2vec_amd.data.dataset import CacheLoader, TrinityDataset_DAE
+    T, D, n = 6, 5, 7
+    rng = np.random.default_rng(2)
+    mean, std = rng.standard_normal(D), np.abs(rng.standard_normal(D)) + 0.1
+    samples = _chunk_samples(n, T, D, 3)
+    write_cache(str(tmp_path / "trn_cache"), samples)
+    ds = TrinityDataset_DAE(argparse.Namespace(), str(tmp_path / "trn"), T, 10, 20, mean, std)
+    assert len(ds) == n * T
+    noisy, orig = ds[T + 2]                                              # chunk 1, frame 2
+    ref = torch.from_numpy(((samples[1][1] - mean) / np.clip(std, 0.01, None))[2].astype(np.float32))
+    assert noisy.shape == (D, 1) and torch.equal(noisy, orig) and torch.equal(noisy[:, 0], ref)
+    loader = CacheLoader(len(ds), 8, lambda bs, sh, seed, dl: ds.batches(bs, "cpu", shuffle=sh, seed=seed, drop_last=dl), shuffle=True)
+    assert len(loader) == (n * T) // 8
+    e1 = [b[0] for b in loader]
+    e2 = [b[0] for b in loader]
+    assert len(e1) == len(loader) and e1[0].shape == (8, D, 1) and not torch.equal(torch.cat(e1), torch.cat(e2))     # reshuffled
+    allf = torch.cat([b[0] for b in ds.batches(8, "cpu", shuffle=False, drop_last=False)])
+    assert torch.equal(allf[:, :, 0], ds.frames)
+
+
+def test_sentence_dataset_collates_like_word_seq_collate_fn(tmp_path):
+    """TrinityDataset_sentencelevel + the collate function (reference lmdb_data_loader.py:1045-1313, :29-122): word ids up to
+    aux_info['end_time'] (no SOS / EOS), sorted by length descending, padded with 0; latents (B, S, E); code ids from ONE call of the
+    frozen quantiser's assign() over all B * S rows.  (parity unpinned, see above; the quantiser here is a CPU stand-in)"""
+    from gesture2vec_amd.data.dataset import TrinityDataset_sentencelevel
+    from gesture2vec_amd.data import write_lmdb
+    rng = np.random.default_rng(5)
+    S, E, D, n = 3, 8, 4, 5
+    vocab = {"a": 4, "b": 5, "c": 6, "d": 7}
+    lang = argparse.Namespace(get_word_index=lambda w: vocab.get(w, 3))
+    samples, lens = [], [2, 4, 1, 3, 4]
+    for i in range(n):
+        words = [[("abcd"[j % 4]), 0.1 * j, 0.1 * j + 0.05] for j in range(lens[i])] + [["zzz", 9.0, 9.1]]     # past end_time: dropped
+        samples.append([words, (rng.standard_normal((12, D))).astype(np.float16), [0], [[0.0, 1.0]],
+                        {"vid": "v", "start_time": 0.0, "end_time": 5.0}, rng.standard_normal((S, E)).astype(np.float32),
+                        np.zeros(3, dtype=np.float32)])
+    write_lmdb(str(tmp_path / "trn_cache"), {sample_key(i): serialize(s) for i, s in enumerate(samples)})
+    calls = []
+
+    class FakeVQ:
+        def assign(self, rows):
+            calls.append(tuple(rows.shape))
+            return (rows.sum(1) > 0).long() + 2 * (rows[:, 0] > 0).long()
+    net = argparse.Namespace(vq_layer=FakeVQ())
+    ds = TrinityDataset_sentencelevel(argparse.Namespace(), str(tmp_path / "trn"), 4, 10, 20, np.zeros(D), np.ones(D), lang_model=lang,
+                                      vq_net=net)
+    assert len(ds) == n
+    ids0, pose0, _, aux0, lat0, _ = ds[1]
+    assert ids0.tolist() == [4, 5, 6, 7] and pose0.shape == (12, D) and lat0.shape == (S, E) and aux0["vid"] == "v"
+    (words, lengths, poses, audio, aux, lat, codes, gpt3), = list(ds.batches(5, "cpu", shuffle=False))
+    assert calls == [(5 * S, E)]                                          # one assignment call for the whole batch
+    assert lengths.tolist() == [4, 4, 3, 2, 1] and words.shape == (5, 4) and words.dtype == torch.int64
+    assert words[3].tolist() == [4, 5, 0, 0] and words[4].tolist() == [4, 0, 0, 0]
+    assert poses.shape == (5, 12, D) and lat.shape == (5, S, E) and codes.shape == (5, S) and len(aux["vid"]) == 5
+    order = [1, 4, 3, 0, 2]                                               # stable sort by length, descending
+    ref_lat = torch.from_numpy(np.stack([samples[i][5] for i in order]))
+    assert torch.equal(lat, ref_lat) and torch.equal(codes, FakeVQ().assign(ref_lat.reshape(-1, E)).view(5, S))

@@ -1,0 +1,161 @@
+"""GPU: the real-data side of the three trainers (SURVEY.md 8(f) row 4 + Part d's data side).
+
+PARITY UNPINNED: neither `lmdb` nor legacy `pyarrow.serialize` exists in this image and the reference ships no data file, so the
+caches read here are written by this repo's own writers of the same published layouts (tests/test_data_reader.py).  What IS checked
+against the reference's semantics is everything behind the reader: normalisation + per-batch device DAE encode against the
+reference's per-item route (lmdb_data_loader.py:640-674), bulk code assignment against the per-item `vq_layer(...)` + argmax route
+(:1274-1281), and the trainers running end to end on caches instead of --synthetic."""
+import argparse
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEV = "cuda:0"
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+
+
+def _write_chunk_cache(path, n, T, D, seed):
+    from gesture2vec_amd.data.dataset import write_cache
+    rng = np.random.default_rng(seed)
+    samples = [[[["w", 0.0, 0.1]], (rng.standard_normal((T, D)) * 1.5).astype(np.float16), [0],
+                {"vid": "v", "start_frame_no": i, "end_frame_no": i + T, "start_time": 0.0, "end_time": 1.0}] for i in range(n)]
+    write_cache(path, samples)
+    return samples
+
+
+def test_device_dae_encode_per_batch_equals_the_per_item_route_and_trains(tmp_path):
+    from gesture2vec_amd.data.dataset import TrinityDataset_DAEed_Autoencoder
+    from gesture2vec_amd.model.DAE_model import DAE_Network
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq
+    T, D, R, n = 34, 135, 40, 48
+    rng = np.random.default_rng(0)
+    mean, std = rng.standard_normal(D), np.abs(rng.standard_normal(D)) * 0.7 + 0.005
+    samples = _write_chunk_cache(str(tmp_path / "trn_cache"), n, T, D, 1)
+    torch.manual_seed(1235)
+    dae = DAE_Network(D, R).to(DEV)
+    dae.train(False)
+    args = argparse.Namespace(use_derivative="False", rep_learning_dim=R)
+    ds = TrinityDataset_DAEed_Autoencoder(args, str(tmp_path / "trn"), T, 10, 20, mean, std, rep_model=dae)
+    batches = list(ds.batches(16, DEV, shuffle=False))
+    assert len(batches) == 3 and batches[0][0].shape == (16, T, R) and batches[0][0].is_cuda
+    # the reference's per-item route: normalise (float64, as numpy does), float32, rep_model.encoder = Linear + ReLU in eval mode
+    W, b = dae.encoder[0].weight.detach().cpu().double(), dae.encoder[0].bias.detach().cpu().double()
+    stdc = np.clip(std, 0.01, None)
+    for k in (0, 17, 47):
+        x = torch.from_numpy((samples[k][1] - mean) / stdc).float().double()
+        ref = torch.relu(x @ W.t() + b)
+        got = batches[k // 16][0][k % 16].cpu().double()
+        assert float((got - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+    # and a training iteration runs on what the loader yields
+    a = argparse.Namespace(rep_learning_dim=R, hidden_size=64, n_layers=2, dropout_prob=0.0, autoencoder_vq="True",
+                           autoencoder_vae="False", autoencoder_vq_components=128, autoencoder_vq_commitment_cost=0.25,
+                           autoencoder_conditioned="True", autoencoder_att="False", autoencoder_fixed_weight="False", n_pre_poses=1,
+                           n_poses=T, loss_l1_weight=5.0, loss_cont_weight=0.1, loss_var_weight=0.5)
+    net = Autoencoder_VQVAE(a, R, T).to(DEV)
+    net.train(True)
+    opt = FusedClipAdam(net, 5e-4)
+    for enc_in, enc_out in batches:
+        loss, perp = train_iter_Autoencoder_VQ_seq2seq(a, 1, enc_in, enc_out, net, opt)
+        assert np.isfinite(loss["loss"]) and float(perp) >= 1.0
+
+
+def _yaml(path, base, **over):
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, "config", base)))
+    cfg.update(over)
+    yaml.safe_dump(cfg, open(path, "w"))
+    return path
+
+
+def test_vqvae_and_dae_trainers_run_on_caches(tmp_path):
+    """scripts/train_DAE.py and scripts/train_autoencoder_VQVAE.py WITHOUT --synthetic: caches under train_data_path / val_data_path,
+    the VQ-VAE trainer taking its frozen frame DAE from rep_learning_checkpoint (the checkpoint the DAE trainer has just written)."""
+    T, D = 34, 135
+    for name, n in (("trn", 64), ("val", 32)):
+        _write_chunk_cache(str(tmp_path / f"{name}_cache"), n, T, D, 7 if name == "trn" else 8)
+    mean, std = [0.1] * D, [1.3] * D
+    common = dict(train_data_path=[str(tmp_path / "trn")], val_data_path=[str(tmp_path / "val")], data_mean=mean, data_std=std)
+    out_d = str(tmp_path / "dae")
+    cfg = _yaml(str(tmp_path / "dae.yml"), "DAE_synthetic.yml", **common)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_DAE.py"), "--config", cfg, "--batch_size", "128",
+                        "--epochs", "20", "--model_save_path", out_d, "--name", "d"], cwd=os.path.join(ROOT, "scripts"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    dae_ckpt = os.path.join(out_d, "d_H40_checkpoint_020.bin")
+    assert os.path.exists(dae_ckpt)
+    vals = [float(l.split("[VAL] loss:")[1].split("/")[0]) for l in (r.stdout + r.stderr).splitlines() if "[VAL] loss:" in l]
+    assert vals[-1] < vals[0]
+    out_v = str(tmp_path / "vq")
+    cfg = _yaml(str(tmp_path / "vq.yml"), "VQ-VAE_synthetic.yml", rep_learning_checkpoint=dae_ckpt, rep_learning_dim=40, **common)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"), "--config", cfg, "--batch_size", "32",
+                        "--epochs", "2", "--model_save_path", out_v, "--name", "v"], cwd=os.path.join(ROOT, "scripts"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    log = r.stdout + r.stderr
+    assert "EP 2 (  2) |" in log and "[VAL] loss:" in log            # 64 chunks / 32 per batch = 2 iterations per epoch
+    ck = torch.load(os.path.join(out_v, "v_checkpoint_002.bin"), map_location="cpu", weights_only=False)
+    assert ck["pose_dim"] == 40 and ck["gen_dict"]["encoder.in_layer.weight"].shape == (64, 40)
+
+
+def test_sentence_loader_assigns_the_codes_the_per_item_quantiser_call_gives_and_part_d_trains_on_it(tmp_path):
+    """TrinityDataset_sentencelevel.batches(): code ids of all B * S latent rows from ONE device assignment == the reference's
+    per-item `vq_layer(latents)` -> argmax(encodings) route (lmdb_data_loader.py:1274-1281); then scripts/train_text2embedding.py
+    trains on the sentence cache (frozen VQ-VAE checkpoint, pickled vocabulary) without --synthetic."""
+    from gesture2vec_amd.data.dataset import TrinityDataset_sentencelevel, sample_key
+    from gesture2vec_amd.data import serialize, write_lmdb
+    from model.vocab import Vocab
+    import utils.train_utils as tu
+    # a frozen chunk VQ-VAE checkpoint from a short synthetic run of the product trainer
+    out_v = str(tmp_path / "vq")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_autoencoder_VQVAE.py"), "--config",
+                        os.path.join(ROOT, "config", "VQ-VAE_synthetic.yml"), "--synthetic", "--synthetic_batches", "2", "--batch_size", "64",
+                        "--epochs", "1", "--save_every", "1", "--model_save_path", out_v, "--name", "v"], cwd=os.path.join(ROOT, "scripts"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    vq_ckpt = os.path.join(out_v, "v_checkpoint_001.bin")
+    _a, vq_net, _l, _lang, _dim = tu.load_checkpoint_and_model(vq_ckpt, DEV, "autoencoder_vq")
+    vq_net.train(False)
+    E, S, D = 128, 6, 135
+    rng = np.random.default_rng(11)
+    vocab = Vocab("t")
+    for w in ("so", "we", "went", "there", "and", "then", "home"):
+        vocab.index_word(w)
+    vocab.word_embedding_weights = rng.standard_normal((vocab.n_words, 300)).astype(np.float32)
+    os.makedirs(tmp_path / "data")
+    pickle.dump(vocab, open(tmp_path / "data" / "vocab_cache.pkl", "wb"))
+    words_all = list(vocab.word2index)
+    for name, n in (("trn", 24), ("val", 8)):
+        items = {}
+        for i in range(n):
+            nw = int(rng.integers(2, 7))
+            words = [[words_all[int(rng.integers(0, len(words_all)))], 0.2 * j, 0.2 * j + 0.1] for j in range(nw)]
+            lat = (rng.standard_normal((S, E)) * 0.5).astype(np.float32)
+            items[sample_key(i)] = serialize([words, rng.standard_normal((120, D)).astype(np.float16), [0], [[0.0]],
+                                              {"vid": "v", "start_time": 0.0, "end_time": 9.0}, lat, np.zeros(2, dtype=np.float32)])
+        write_lmdb(str(tmp_path / "data" / f"{name}_cache"), items)
+    ds = TrinityDataset_sentencelevel(argparse.Namespace(), str(tmp_path / "data" / "trn"), 20, 10, 20, np.zeros(D), np.ones(D),
+                                      lang_model=vocab, vq_net=vq_net)
+    (words, lengths, poses, audio, aux, lat, codes, gpt3), = list(ds.batches(24, DEV, shuffle=False))
+    assert codes.shape == (24, S) and codes.dtype == torch.int64 and lengths.tolist() == sorted(lengths.tolist(), reverse=True)
+    for bidx in (0, 5, 23):                                   # the per-item route of the reference on the same rows
+        _loss, _q, _perp, enc = vq_net.vq_layer(lat[bidx])
+        assert torch.equal(torch.argmax(enc, dim=1), codes[bidx])
+    out_t = str(tmp_path / "t2e")
+    cfg = _yaml(str(tmp_path / "t2e.yml"), "seq2seq_synthetic.yml", train_data_path=[str(tmp_path / "data" / "trn")],
+                val_data_path=[str(tmp_path / "data" / "val")], data_mean=[0.0] * D, data_std=[1.0] * D, autoencoder_checkpoint=vq_ckpt)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_text2embedding.py"), "--config", cfg, "--batch_size", "8",
+                        "--epochs", "10", "--hidden_size", "64", "--model_save_path", out_t, "--name", "t"], cwd=os.path.join(ROOT, "scripts"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    log = r.stdout + r.stderr
+    assert "EP 10 (  3) |" in log and "[VAL] loss:" in log
+    ck = torch.load(os.path.join(out_t, "t_checkpoint_010.bin"), map_location="cpu", weights_only=False)
+    assert ck["gen_dict"]["encoder.embedding.weight"].shape[0] == vocab.n_words
