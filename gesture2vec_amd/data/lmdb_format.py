@@ -90,6 +90,10 @@ class LMDBReader:
         return bytes(self._m[node_off + NODEHDR: node_off + NODEHDR + ksize])
 
     def _leaf_value(self, node_off: int, lo: int, hi: int, nflags: int, ksize: int) -> bytes:
+        if nflags & ~F_BIGDATA:
+            # F_SUBDATA (0x02) / F_DUPDATA (0x04): sub-databases and sorted duplicates -- not used by the reference's caches
+            # (plain put() of one value per key); anything unknown is refused rather than mis-decoded
+            raise ValueError(f"{self.path}: unsupported LMDB node flags {nflags:#x} (only plain values and F_BIGDATA are read)")
         size = lo | (hi << 16)
         d = node_off + NODEHDR + ksize
         if nflags & F_BIGDATA:

@@ -320,13 +320,16 @@ class VQVAEEngine:
                                             4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
                                         dtype=torch.uint8, device=dev)
         # encoder GRU weight gradients accumulated inside its backward kernel (H == 64): 0 none, 1 W_hh, 2 W_hh and W_ih
-        b["enc_fused_wgrad"] = int(os.environ.get("G2V_ENC_FUSED_WGRAD", "1")) if (H == 64 and self.quantizer == "ema") else 0
+        mode = int(os.environ.get("G2V_ENC_FUSED_WGRAD", "1"))
+        if mode not in (0, 1, 2):
+            raise ValueError(f"G2V_ENC_FUSED_WGRAD={mode}: 0 (separate products), 1 (W_hh inside the recurrent kernel) or 2 (W_hh and W_ih)")
+        b["enc_fused_wgrad"] = mode if (H == 64 and self.quantizer == "ema") else 0
         if b["enc_fused_wgrad"]:
             n = int(self.lib.g2v_gru_seq_bwd_wslab_bytes(B, H))
             b["enc_wslab"] = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
         b["ws_enc_wgrad"] = torch.zeros(4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H), dtype=torch.uint8, device=dev)
         # dedicated workspaces of the four recurrent launches: prepare_recurrent() fills them ahead of their kernels
-        for key, nbytes in (("ws_gruf", self.lib.g2v_gru_seq_fwd_workspace(2, H)), ("ws_grub", self.lib.g2v_gru_seq_bwd_workspace(2, H)),
+        for key, nbytes in (("ws_grub", self.lib.g2v_gru_seq_bwd_workspace(2, H)),
                             ("ws_decf", self.lib.g2v_dec_rollout_fwd_workspace(D, H)), ("ws_decb", self.lib.g2v_dec_rollout_bwd_workspace(D, H))):
             b[key] = torch.zeros(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
         self._bufs[B] = b

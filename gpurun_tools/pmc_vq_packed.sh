@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the fused VQ kernel (fragment-image form) at N=4096: separate --pmc passes (FETCH_SIZE, WRITE_SIZE), kernel trace only
-cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp; cd "${GRAFT_REPO_ROOT:?}"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d gpurun_out/pmc_vqp_$c -- python3 gpurun_tools/vq_only.py 4096 packed > gpurun_out/pmc_vqp_$c.log 2>&1
 done

@@ -3,8 +3,12 @@ import ctypes, subprocess, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gesture2vec_amd", "csrc")
-dbg = os.path.join(root, "gesture2vec_amd", "libg2v_hip.so")
-subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG2V_STAMPS -shared linear.hip vq.hip gru.hip dec_rollout.hip seq2seq.hip misc.hip -o {dbg}", shell=True)
+# every source of the library (the Makefile's SRCS), stamps compiled in, into a library of its OWN (never over the product's)
+dbg = os.path.join(root, "gpurun_tools", "libg2v_stamps.so")
+srcs = subprocess.check_output(["make", "-s", "-C", src, "--eval", "print-srcs: ; @echo $(SRCS)", "print-srcs"], text=True).split()
+subprocess.check_call(f"cd {src} && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DG2V_STAMPS -shared {' '.join(srcs)} -o {dbg}", shell=True)
+from gesture2vec_amd import _lib as _l0
+_l0.LIB_PATH = dbg
 import torch, argparse
 from gesture2vec_amd import _lib
 import bench
