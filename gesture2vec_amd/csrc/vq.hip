@@ -1588,23 +1588,32 @@ __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict
                                                          const float* __restrict__ Wp, const float* __restrict__ bp,
                                                          __bf16* __restrict__ Uhf, float* __restrict__ sprime,
                                                          unsigned* __restrict__ pqk, BxfScalars* __restrict__ scal, int K) {
-  constexpr int E = 128;
-  extern __shared__ __attribute__((aligned(16))) float WpS[];      // [E][E]: all of W_pre, staged once (the first version read it
-  __shared__ float Ws[16][E + 1];                                   // from global inside the contraction loop: 128 dependent L2
-  __shared__ float Us[16][E + 1];                                   // round trips = 143 us; from LDS the kernel takes ~10 us)
+  constexpr int E = 128, LDP = E + 1, LDW = E + 4;
+  // U tile = Ws (16 codes x E) W_pre (E x E) on the fp32 MFMA: A = W_pre^T (column on the lane) read from an LDS copy of W_pre,
+  // B = the 16 code rows.  (The first version contracted on the VALU with W_pre read from global inside the loop: 143 us, and
+  // 71 us from LDS -- in the branch beside the encoder GRU that made the quantiser wait.)
+  extern __shared__ __attribute__((aligned(16))) float smem_pack[];
+  float* WpS = smem_pack;                         // [E][LDP]
+  float* Ws = WpS + E * LDP;                      // [16][LDW]   (16-byte aligned: E * LDP * 4 = 66048)
+  float* Us = Ws + 16 * LDW;                      // [16][LDW]
   __shared__ float red[4];
   __shared__ float s_wpf2, s_bb;
-  const int tid = threadIdx.x, kt = blockIdx.x;
-  for (int e = tid; e < 16 * E; e += 256) Ws[e / E][e % E] = W[(int64_t)(16 * kt) * E + e];
+  const int tid = threadIdx.x, kt = blockIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  for (int e4 = tid; e4 < 16 * E / 4; e4 += 256) {
+    const int r = e4 / (E / 4), c = 4 * (e4 % (E / 4));
+    *reinterpret_cast<float4*>(Ws + r * LDW + c) = *reinterpret_cast<const float4*>(W + (int64_t)(16 * kt + r) * E + c);
+  }
   {  // stage W_pre; |W_pre|_F^2 and |b|^2 on the way (every workgroup for itself: the radius coefficients below need them)
     float f = 0.f;
     for (int e4 = tid; e4 < E * E / 4; e4 += 256) {
       const float4 v = reinterpret_cast<const float4*>(Wp)[e4];
-      reinterpret_cast<float4*>(WpS)[e4] = v;
+      const int r = e4 / (E / 4), c = 4 * (e4 % (E / 4));
+      float* d = WpS + r * LDP + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
       f = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, f))));
     }
     f = wave_sum(f);
-    if ((tid & 63) == 0) red[tid >> 6] = f;
+    if (lane == 0) red[wave] = f;
   }
   __syncthreads();
   if (tid == 0) {
@@ -1619,33 +1628,35 @@ __global__ __launch_bounds__(256) void vq_bx_pack_kernel(const float* __restrict
       scal->pad1 = 0.f;
     }
   }
-  {
-    const int j = tid & 127, kh = tid >> 7;           // column j of U, codes kh, kh + 2, ..
-    float acc[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
-#pragma unroll 4
-    for (int e = 0; e < E; ++e) {
-      const float wv = WpS[e * E + j];
+  for (int t = 0; t < 2; ++t) {                    // column tiles wave, wave + 4 of U
+    const int jt = wave + 4 * t;
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int m = 0; m < 8; ++m) acc[m] = fmaf(Ws[kh + 2 * m][e], wv, acc[m]);
+    for (int s = 0; s < E / 16; ++s) {
+      const float4 xb = *reinterpret_cast<const float4*>(Ws + i * LDW + 16 * s + 4 * q);
+      const float* ap = WpS + (16 * s + 4 * q) * LDP + 16 * jt + i;
+      acc = mfma16(ap[0], xb.x, acc);
+      acc = mfma16(ap[LDP], xb.y, acc);
+      acc = mfma16(ap[2 * LDP], xb.z, acc);
+      acc = mfma16(ap[3 * LDP], xb.w, acc);
     }
-#pragma unroll
-    for (int m = 0; m < 8; ++m) Us[kh + 2 * m][j] = acc[m];
+    // lane (code i, q) holds U[code][16 jt + 4 q .. + 3]
+    *reinterpret_cast<float4*>(Us + i * LDW + 16 * jt + 4 * q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
   }
   __syncthreads();
   for (int o = tid; o < 16 * E / 8; o += 256) {        // 16-byte fragment elements of this tile: [kb][lane]
-    const int lane = o & 63, kb = o >> 6, i = lane & 15, q = lane >> 4;
+    const int ln = o & 63, kb = o >> 6, ii = ln & 15, qq = ln >> 4;
     bf16x8 h;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) h[e] = (__bf16)Us[i][32 * kb + 8 * q + e];
-    *reinterpret_cast<bf16x8*>(Uhf + ((int64_t)(kt * (E / 32) + kb) * 64 + lane) * 8) = h;
+    for (int e = 0; e < 8; ++e) h[e] = (__bf16)Us[ii * LDW + 32 * kb + 8 * qq + e];
+    *reinterpret_cast<bf16x8*>(Uhf + ((int64_t)(kt * (E / 32) + kb) * 64 + ln) * 8) = h;
   }
   if (tid < 16) {
     float uu = 0.f, bw = 0.f;
     for (int e = 0; e < E; ++e) {
-      uu = fmaf(Us[tid][e], Us[tid][e], uu);
-      bw = fmaf(bp[e], Ws[tid][e], bw);
+      uu = fmaf(Us[tid * LDW + e], Us[tid * LDW + e], uu);
+      bw = fmaf(bp[e], Ws[tid * LDW + e], bw);
     }
     const float s = wsq[16 * kt + tid];
     sprime[16 * kt + tid] = s - 2.0f * bw;
@@ -1819,15 +1830,16 @@ extern "C" int g2v_vq_bx_pack(const float* codebook, const float* code_sqnorm, c
   }
   G2V_REQUIRE(ptr_aligned16(codebook) && ptr_aligned16(image), "16-byte aligned operands");
   const size_t o1 = bx_pad256((size_t)K * E * 2), o2 = o1 + bx_pad256((size_t)K * 4), o3 = o2 + bx_pad256((size_t)K * 4);
+  const size_t pack_lds = ((size_t)E * (E + 1) + 2 * 16 * (E + 4)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)vq_bx_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, E * E * 4) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)vq_bx_pack_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)pack_lds) != hipSuccess) {
       set_error("g2v_vq_bx_pack: cannot reserve LDS");
       return G2V_ERR_LAUNCH;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), E * E * 4, (hipStream_t)stream, codebook, code_sqnorm, w_pre, b_pre,
+  hipLaunchKernelGGL(vq_bx_pack_kernel, dim3(K / 16), dim3(256), pack_lds, (hipStream_t)stream, codebook, code_sqnorm, w_pre, b_pre,
                      (__bf16*)image, (float*)((char*)image + o1), (unsigned*)((char*)image + o2), (BxfScalars*)((char*)image + o3), K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
