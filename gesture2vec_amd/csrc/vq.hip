@@ -679,31 +679,47 @@ __global__ __launch_bounds__(256) void vq_stats_owner_kernel(const int64_t* __re
   __shared__ float partn[4][4][64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int c0 = blockIdx.x * 16, e0 = blockIdx.y * 16;
+  // (staging the code ids in LDS -- they are half of the loop's requests, 16 useful bytes each -- was measured: 21 -> 32 us)
+  // blockIdx.x = COLUMN tile: workgroups are dealt round-robin over the 8 XCDs in linear order, so with E / 16 = 8 column tiles
+  // every XCD's L2 fetches one 64-byte column slice of `flat` instead of all of it (round 2: code tile on x -> each of the eight
+  // L2s pulled the whole array, 17.3 MB of HBM traffic for 2.4 MB algorithmic).  Speed only, never correctness.
+  const int c0 = blockIdx.y * 16, e0 = blockIdx.x * 16;
   const int mycode = c0 + i;
   const int per = ((N / 4) + 3) & ~3;                  // rows per wave (multiple of 4)
   const int mb = wave * per, me = min(N, mb + per);
   const int* idx32 = reinterpret_cast<const int*>(idx);          // low dwords of the int64 indices
   f32x4 acc = {0.f, 0.f, 0.f, 0.f}, accn = {0.f, 0.f, 0.f, 0.f};
-  const bool want_cnt = (blockIdx.y == 0);
-  constexpr int U = 8;                                  // 8 groups of 4 rows in flight
-  for (int m0 = mb; m0 < me; m0 += 4 * U) {
-    int iv[U];
-    float fv[U];
+  const bool want_cnt = (blockIdx.x == 0);
+  constexpr int U = 8;                                  // groups of 4 rows per batch of requests; TWO batches in flight: the loop
+  int iv[2][U];                                         // was one L2 round trip per batch (32 batches per wave = the kernel's 25 us)
+  float fv[2][U];
+  auto request = [&](int m0, int (&ivb)[U], float (&fvb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int row = m0 + 4 * u + q;
       const bool ok = row < me;
       const int rc = ok ? row : mb;
-      iv[u] = ok ? idx32[2 * (int64_t)rc] : -1;
-      fv[u] = flat[(int64_t)rc * E + e0 + i];
+      const int v = idx32[2 * (int64_t)rc];
+      ivb[u] = ok ? v : -1;
+      fvb[u] = flat[(int64_t)rc * E + e0 + i];
     }
+  };
+  auto consume = [&](const int (&ivb)[U], const float (&fvb)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float a = (iv[u] == mycode) ? 1.0f : 0.0f;
-      acc = mfma16(a, fv[u], acc);
+      const float a = (ivb[u] == mycode) ? 1.0f : 0.0f;
+      acc = mfma16(a, fvb[u], acc);
       if (want_cnt) accn = mfma16(a, 1.0f, accn);
     }
+  };
+  request(mb, iv[0], fv[0]);
+  for (int m0 = mb; m0 < me; m0 += 8 * U) {
+    request(m0 + 4 * U, iv[1], fv[1]);                  // rows past `me` read a valid row and contribute nothing
+    __builtin_amdgcn_sched_barrier(0);
+    consume(iv[0], fv[0]);
+    request(m0 + 8 * U, iv[0], fv[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    consume(iv[1], fv[1]);
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -1882,7 +1898,7 @@ extern "C" int g2v_vq_stats(const int64_t* idx, const float* flat, float* stats,
   // enough rows for a whole-chip launch of tile owners (K / 16 x E / 16 workgroups, every one walking all N rows):
   // one launch, no slabs.  Small problems keep the split kernel (a tile owner would leave most CUs idle).
   if ((E & 15) == 0 && (K & 15) == 0 && N >= 1024 && (K / 16) * (E / 16) >= 128) {
-    hipLaunchKernelGGL(vq_stats_owner_kernel, dim3(K / 16, E / 16), dim3(256), 0, (hipStream_t)stream, idx, flat, stats,
+    hipLaunchKernelGGL(vq_stats_owner_kernel, dim3(E / 16, K / 16), dim3(256), 0, (hipStream_t)stream, idx, flat, stats,
                        stats + K, N, E, K);
     G2V_CHECK_LAUNCH();
     return G2V_OK;
