@@ -27,7 +27,8 @@ class DecWeights(C.Structure):
 class DecSaved(C.Structure):
     """g2v_dec_saved"""
     _fields_ = [(n, c_fp) for n in (
-        "y", "xin", "u", "a", "h0", "h1", "x1", "gates0", "gates1", "bn_partial", "bn_stats")]
+        "y", "xin", "u", "a", "h0", "h1", "x1", "gates0", "gates1", "bn_partial", "bn_stats",
+        "loss_code", "loss_coef", "loss_partial", "loss_terms")] + [("loss_w", c_f * 3)]     # optional: custom_loss folded in
 
 
 class GruDir(C.Structure):
@@ -102,6 +103,7 @@ _SIGS = {
     "g2v_dec_rollout_blocks": (c_int, [c_int]),
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
+    "g2v_dec_rollout_fuses_loss": (c_int, [c_int, c_int, c_int, c_int]),
     "g2v_dec_rollout_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),

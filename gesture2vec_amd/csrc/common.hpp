@@ -434,6 +434,34 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// ---- custom_loss (train_eval/train_seq2seq.py:40-88) gradient, in the one form every kernel that produces it uses (misc.hip's
+// custom_loss kernels and the persistent rollouts, which fold the loss in): bitwise identical results by construction.
+//   d loss / d y[t,b,d] = c1 sign(y_t - tgt_t) + c2 sign(y_t - y_{t-1}) - c2 sign(y_{t+1} - y_t) - c3 y_t / ||y[:,b,d]||_2
+// The three signs travel as one code byte: bits 0-1 sign(y_t - tgt_t) + 1, bits 2-3 sign(y_t - y_{t-1}) + 1 (1 at t = 0),
+// bits 4-5 sign(y_{t+1} - y_t) + 1 (1 at t = T-1); bit 6 is free for the carrier (the rollouts keep the Dropout(0.95) flag there).
+__device__ __forceinline__ int loss_sign_code(float x) { return (x > 0.f) ? 2 : ((x < 0.f) ? 0 : 1); }
+__device__ __forceinline__ float loss_grad_const(float c1, float c2, int code) {
+  const float s1 = (float)((code & 3) - 1), sa = (float)(((code >> 2) & 3) - 1), sb = (float)(((code >> 4) & 3) - 1);
+  return __fsub_rn(__fadd_rn(__fmul_rn(c1, s1), __fmul_rn(c2, sa)), __fmul_rn(c2, sb));
+}
+// cn = c3 / ||y[:,b,d]||_2 (0 for a zero column), as one rounded product c3 * (1 / norm)
+__device__ __forceinline__ float loss_col_coef(float c3, float sumsq, float& norm) {
+  norm = sqrtf(sumsq);
+  return __fmul_rn(c3, (norm > 0.f) ? 1.0f / norm : 0.f);
+}
+__device__ __forceinline__ float loss_grad(float gconst, float cn, float v) { return fmaf(-cn, v, gconst); }
+// terms (5 floats: total, l1, cont, var, mse) from the four grand sums (sum |y - tgt|, sum |y_t - y_{t-1}|, sum of column norms,
+// sum (y - tgt)^2)
+__device__ __forceinline__ void loss_terms_write(float* __restrict__ terms, float s_l1, float s_cont, float s_norm, float s_sq,
+                                                 float c1, float c2, float c3, float inv_n) {
+  const float l1 = s_l1 * c1, cont = s_cont * c2, var = -s_norm * c3;
+  terms[0] = l1 + cont + var;
+  terms[1] = l1;
+  terms[2] = cont;
+  terms[3] = var;
+  terms[4] = s_sq * inv_n;   // plain MSE (evaluate_testset's metric)
+}
+
 // Stage a [16][K] row tile into LDS [16][ldx] with zero padding up to Kp columns.
 // rows >= nrows_valid are zero.  256 threads.
 __device__ __forceinline__ void stage_rows(float* Xs, int ldx, int Kp, const float* __restrict__ src, int64_t ld,

@@ -13,6 +13,7 @@
 //               previous step's partial sums is in flight] -> exchange -> BN + ReLU -> cell 0 -> cell 1 -> out layer ->
 //               Dropout(0.95) -> pre_linear -> partial sums -> publish
 #include "dec_persist.hpp"
+#include <utility>
 #ifndef G2V_BWD_EPI
 #define G2V_BWD_EPI 1
 #endif
@@ -49,7 +50,14 @@ constexpr int L_BIAS = L_PPRE + 4 * KSD * 256;            // b_ih0 b_hh0 b_ih1 b
 constexpr int L_ST = L_BIAS + 4 * 192 + 144 + 3 * 64;     // mean[64], invstd[64]
 constexpr int L_RED = L_ST + 128;                         // [16][128]
 constexpr int L_TOT = L_RED + 16 * 128;                   // [128]
-constexpr int L_END = L_TOT + 128;
+constexpr int L_TT = L_TOT + 128;                         // loss fold: the target values of the tile, [9 column groups][16 rows][16]
+constexpr int L_END = L_TT + 9 * 256;
+// the three padding tiles at the end of the packed W_out image (tiles 9..11: zero, never multiplied, never copied in) hold the
+// second y tile (y_t and y_{t-1} alternate between the two: the loss fold reads both) and the fold's code bytes
+constexpr int L_YT2 = L_POUT + 9 * KSH * 256;             // dense y tile of the odd steps
+constexpr int L_GB = L_YT2 + 2176;                        // code bytes of one step's tile (16 * D bytes, + 16 bytes nobody reads)
+static_assert(L_GB + 544 <= L_PPRE, "the second y tile and the code tile fit the padding of the packed W_out image");
+static_assert(L_END * 4 <= 160 * 1024, "LDS budget of the persistent rollout forward");
 constexpr int B_IH0 = 0, B_HH0 = 192, B_IH1 = 384, B_HH1 = 576, B_OUT = 768, B_PRE = 912, B_BNW = 976, B_BNB = 1040;
 }  // namespace
 
@@ -67,6 +75,7 @@ struct DecPersistArgs {
   PersistX x;
   int T, B, nblk, n_pre, conditioned, training;
   float p_drop;
+  float lc3;                // loss fold (sv.loss_code set): w_var / (T B D)
 };
 
 // A-operand fragments from LDS (conflict-free ds_read_b128: consecutive lanes read consecutive 16 bytes)
@@ -125,6 +134,15 @@ __device__ __forceinline__ void frag_mma_x1st(f32x4 (&acc)[NT], const WFrag<NT, 
   }
 }
 
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>) -- register arrays indexed by the counter
+template <class F, int... Ks>
+__device__ __forceinline__ void static_for_(F&& f, std::integer_sequence<int, Ks...>) {
+  (f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {      // f(integral_constant<int, 0>) ... f(integral_constant<int, N-1>)
+  static_for_(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 // One output tile, contraction over KS_T k-steps, as TWO accumulator chains (even / odd k-steps) that alternate in the
 // matrix pipe and are added at the end: a single 36-long dependent chain issues one MFMA per ~42 cycles at one wave per SIMD,
 // two alternating chains one per 32.
@@ -209,7 +227,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   float* Xh1 = smem + L_XH1;
   float* Xx1 = smem + L_XX1;
   float* Xy = smem + L_XY;
-  float* Yt = smem + L_YT;
   float* Xt = smem + L_XT;
   uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + L_KT);
   float* Pout = smem + L_POUT;
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   float* st = smem + L_ST;
   float* red = smem + L_RED;
   float* tot = smem + L_TOT;
+  uint8_t* Gb = reinterpret_cast<uint8_t*>(smem + L_GB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -225,9 +243,118 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   const int T = a.T, B = a.B;
   const int f0 = 16 * wave + 4 * q;                  // this lane's 4 hidden features
   const bool training = a.training != 0;
+  // custom_loss folded in (g2v.h, g2v_dec_saved.loss_*).  Every VALU instruction of this kernel costs its full issue time where
+  // it stands -- one wave per SIMD, and nothing hides beside fp32 MFMAs (measured: a slice of 2-3 plain VALU instructions behind
+  // each of the 96 hidden-side MFMAs cost its full 26 cycles per MFMA) -- EXCEPT inside the exchange: between the sweep's requests
+  // and their return the wave only waits, one fabric round trip (~1800 cycles) per hop.  So the loss arithmetic of step s runs
+  // at the top of step s + 1 as the `filler` of hop 1 (dec_persist.hpp); hop 2's filler requests the next target tile.
+  // It reads y_s and y_{s-1} back from the two LDS y tiles and the target values from the LDS target tile in the out-layer
+  // epilogue's own element mapping -- this lane owns the same 12 (row, d) elements at every step -- so the column sums of
+  // squares, the previous step's half-finished codes and the loss sums live in registers for the whole rollout.  Branch-free:
+  // tiles past D select zeros and store their byte into the 16 spare bytes behind the code tile.
+  // (Measured on the way, per step: loss terms in the out-layer epilogue, branchy +3200 cycles, branch-free +1800; element-wise
+  // target loads in front of a hop +2000-2400: vmcnt counts in order, the hop's polling waited for their HBM latency.)
+  const bool fold = training && a.sv.loss_code != nullptr;
+  float ls_l1 = 0.f, ls_cont = 0.f, ls_sq = 0.f, ls_norm = 0.f;
+  float lss[3][4];           // sum over the steps so far of y^2, per owned element
+  float* Tt = smem + L_TT;   // target values of the step in flight: LDS-DMA inside hop 2, read by the next step's loss terms
+  const float* l_tp = a.target + (int64_t)(b0 + i) * T * D;      // + t D + element
+  int l_el[3];               // first of this lane's 4 columns of tile j (the padding tiles 9..11 re-read tile 0's, masked out below)
+  uint32_t l_ok[3];          // bit r: element r of tile j is a real column
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int d0 = 16 * (wave + 4 * j) + 4 * q;
+    l_el[j] = d0 < Dp ? d0 : 4 * q;
+    l_ok[j] = d0 + 3 < D ? 15u : (d0 < D ? (1u << (D - d0)) - 1u : 0u);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      lss[j][r] = 0.f;
+      if (fold) {            // y_0 = target frame 0 (:1039-1040)
+        const float y0 = l_tp[(j == 2) ? min(l_el[j] + r, D - 1) : l_el[j] + r];
+        lss[j][r] = fmaf(y0, y0, 0.f);
+      }
+    }
+  }
+  // loss terms of one step, elements [6 h, 6 h + 6): Yc = the step's y tile, Yp = the tile of the step before, Tt = its target
+  // values, Kt = its keep flags (all 12 read in the first half: Kt is rewritten behind the second product).  No compares (VCC
+  // hazards: s_nop), all in float arithmetic:
+  //   sign(x) = med3(x 2^254, -1, 1) (exact for every finite x, denormals included);
+  //   code = 21 + sign(y - tgt) + 4 sign(y - y_prev) + 16 sign(y_next - y) + 64 keep (exact), one cvt per byte
+  //        = the digits of common.hpp's code byte: (s + 1) | (s + 1) << 2 | (s + 1) << 4 | keep << 6
+  float l_kf[3][4];          // 21 + 64 keep of the step in hand
+  float lhf[3][4];           // the previous step's code (as a float), sign(y_{t+1} - y_t) still missing
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { lhf[j][r] = 0.f; l_kf[j][r] = 0.f; }
+  auto loss_half = [&](const float* Yc, const float* Yp, auto hc) {
+    constexpr int h = decltype(hc)::value;
+    if constexpr (h == 0) {
+      const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          l_kf[j][r] = fmaf(fminf((float)Kb[i * D + l_el[j] + r], 1.0f), 64.0f, 21.0f);
+          asm volatile("" : "+v"(l_kf[j][r]));      // (the pins: left alone the compiler SINKS this arithmetic out of the hop, to
+        }                                           //  where its results are next used -- behind the exchange, in the open)
+    }
+    float yc[6], yp[6], tg[6];
+    {
+      // elements 6 h .. 6 h + 5 = tiles (0: r 0-3, 1: r 0-1) or (1: r 2-3, 2: r 0-3)
+      const float4 ta = *reinterpret_cast<const float4*>(Tt + min(wave + 4 * h, 8) * 256 + i * 16 + 4 * q);
+      const float4 tb = *reinterpret_cast<const float4*>(Tt + min(wave + 4 * (h + 1), 8) * 256 + i * 16 + 4 * q);
+      if constexpr (h == 0) { tg[0] = ta.x; tg[1] = ta.y; tg[2] = ta.z; tg[3] = ta.w; tg[4] = tb.x; tg[5] = tb.y; }
+      else { tg[0] = ta.z; tg[1] = ta.w; tg[2] = tb.x; tg[3] = tb.y; tg[4] = tb.z; tg[5] = tb.w; }
+    }
+    static_for<6>([&](auto ec) {
+      constexpr int e = 6 * h + decltype(ec)::value, j = e >> 2, r = e & 3;
+      yc[e - 6 * h] = Yc[i * D + l_el[j] + r];
+      yp[e - 6 * h] = Yp[i * D + l_el[j] + r];
+    });
+    static_for<6>([&](auto ec) {
+      constexpr int n = decltype(ec)::value, e = 6 * h + n, j = e >> 2, r = e & 3;
+      const bool valid = (l_ok[j] >> r) & 1u;
+      float v = yc[n], dlt = v - tg[n], stp = v - yp[n];
+      if (j == 2) {          // tiles 8..11: zeros in the lanes past D
+        v = valid ? v : 0.f; dlt = valid ? dlt : 0.f; stp = valid ? stp : 0.f;
+      }
+      ls_l1 += fabsf(dlt);
+      ls_sq = fmaf(dlt, dlt, ls_sq);
+      ls_cont += fabsf(stp);
+      lss[j][r] = fmaf(v, v, lss[j][r]);
+      const float s1 = __builtin_amdgcn_fmed3f(ldexpf(dlt, 254), -1.0f, 1.0f), sa = __builtin_amdgcn_fmed3f(ldexpf(stp, 254), -1.0f, 1.0f);
+      const int done = (int)fmaf(sa, 16.0f, lhf[j][r]);
+      Gb[(j == 2 && !valid) ? 16 * D + r : i * D + 16 * (wave + 4 * j) + 4 * q + r] = (uint8_t)done;
+      lhf[j][r] = fmaf(sa, 4.0f, s1 + l_kf[j][r]);
+      asm volatile("" : "+v"(lhf[j][r]), "+v"(lss[j][r]));
+    });
+    asm volatile("" : "+v"(ls_l1), "+v"(ls_sq), "+v"(ls_cont));
+  };
+  // The target tile of a step, 16 rows of D contiguous floats, straight into LDS (global_load_lds_dword: no register destination).
+  // Thread (row tid >> 4, column c = tid & 15) fetches columns c, c + 16, ..., c + 128 (the last one clamped into the row: the
+  // lanes past it repeat column D - 1); instruction k of wave w lands in Tt[k][64 w .. 64 w + 63], i.e. Tt[k][row][c]: the four
+  // target values of a lane's tile j are one 16-byte read.  Issued as the first thing of hop 2's filler, so that its HBM latency
+  // runs beside the sweep's own round trip and ends at the sweep's vmcnt(0).  What does not work (all measured, per step):
+  // element-wise loads in the out-layer epilogue's mapping (16 rows x 16 bytes per instruction): ~3000 cycles in the address
+  // coalescer; row-contiguous loads into registers anywhere: they land in AGPRs, and the next v_accvgpr_read of ANYTHING waits
+  // for them (+1300 in the BatchNorm statistics); this LDS-DMA issued outside a hop: every LDS read that follows waits vmcnt(0)
+  // while it is in flight (+1300 again); any of them in front of a hop: the polling's vmcnt(0) takes their latency on (+2000-2400).
+  const int t_c8 = min(128, D - 1 - (tid & 15));
+  auto target_request = [&](int ts) {
+    const float* tp = a.target + ((int64_t)(b0 + (tid >> 4)) * T + ts) * D + (tid & 15);
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tp + (k < 8 ? 16 * k : t_c8)),
+                                       (__attribute__((address_space(3))) void*)(Tt + k * 256 + wave * 64), 4, 0, 0);
+  };
+  auto code_store = [&](int ts) {        // the finished code bytes of step ts: LDS tile -> (T,B,D) array
+    uint32_t* gp = reinterpret_cast<uint32_t*>(a.sv.loss_code + ((int64_t)ts * B + b0) * D);
+    for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) gp[e4] = reinterpret_cast<const uint32_t*>(Gb)[e4];
+  };
   const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
   const float keep_scale = 1.0f / (1.0f - a.p_drop);
-  const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
+  const int64_t BH = (int64_t)B * H;
   const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
   float run_m = 0.f, run_v = 0.f;                    // BatchNorm running statistics (workgroup 0, tid < H)
   if (training && b == 0 && tid < H) {
@@ -241,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   frag_load(f_hh1, a.p_hh1, wave, 4, lane);
   frag_load(f_ih0, a.p_ih0, wave, 4, lane);
   frag_load(f_ih1, a.p_ih1, wave, 4, lane);
-  for (int e = tid; e < OUT_TILES * KSH * 64; e += 256)
+  for (int e = tid; e < 9 * KSH * 64; e += 256)              // tiles 9..11 are padding (see L_YT2)
     reinterpret_cast<float4*>(Pout)[e] = reinterpret_cast<const float4*>(a.p_out)[e];
   for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Ppre)[e] = reinterpret_cast<const float4*>(a.p_pre)[e];
   for (int e = tid; e < 192; e += 256) {
@@ -277,6 +404,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
 
   for (int t = 0; t < T; ++t) {
     const bool has_next = t < T - 1;
+    float* Yt = smem + ((t & 1) ? L_YT2 : L_YT);              // y_t's dense tile
+    const float* Yp = smem + ((t & 1) ? L_YT : L_YT2);        // y_{t-1}'s
     if (t > 0) {
       PSTAMP(0, 0);
       // ---- hidden-side products (independent of this step's BatchNorm): they fill the exchange's latency -----------
@@ -300,18 +429,35 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       // The exchange is threaded through the two products: the row's records, published at the end of the previous step,
       // have arrived when the first product is done (hop 1: row sum, published again), and the row sums of the other rows
       // travel while the second product runs (hop 2).
+      // loss fold: the terms of step t-1 (y_{t-1} sits in Yp; Yt still holds y_{t-2}; Kt the keep flags of t-1; Tt its target
+      // values) ride inside hop 1 of the exchange
+      const bool lstep = fold && t >= 2;
       frag_mma_x1st(gh0, f_hh0, Xh0, LDH, lane);
-      if (training) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+      PSTAMP(0, 9);
+      if (lstep) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() {
+        loss_half(Yp, Yt, std::integral_constant<int, 0>{});
+        loss_half(Yp, Yt, std::integral_constant<int, 1>{});
+      });
+      else if (training) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+      PSTAMP(0, 10);
       frag_mma_x1st(gh1, f_hh1, Xh1, LDH, lane);
       PSTAMP(0, 1);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < 3; ++j) {      // (the loss terms read Kt's previous content inside hop 1, in front of its barriers)
         const int e4 = tid + 256 * j;
         if (e4 < (16 * D) / 4) Kt[e4] = kreq[j];
       }
       // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
       if (training) {
-        px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+        // (fold: this step's target values travel beside the sweep; every reader of the tile finished inside hop 1)
+        if (fold) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() { target_request(t); });
+        else px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+        PSTAMP(0, 11);
+        // (a wave whose lanes all sit out the sweep -- small batches -- has not waited for its LDS-DMA yet; the readers of the
+        // tile are a step and many barriers away)
+        if (fold) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (fold && t >= 3) code_store(t - 2);        // completed inside hop 1, in front of its barriers
+        PSTAMP(0, 12);
         if (tid < H) {
           const float s1 = tot[tid], s2 = tot[H + tid];
           const float mv = s1 / (float)B;
@@ -456,6 +602,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
         }
         *reinterpret_cast<float4*>(a.sv.y + tile + e) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+        if (t == 0) reinterpret_cast<float4*>(Yt)[e4] = make_float4(yv[0], yv[1], yv[2], yv[3]);      // y_{t-1} of step 1's loss terms (the fold)
         if (!has_next) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -514,6 +661,36 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     a.w.bn_running_mean[tid] = run_m;
     a.w.bn_running_var[tid] = run_v;
   }
+  if (fold) {
+    // the last step's loss terms (its y tile is complete: the barrier behind the out-layer epilogue), the bytes they finish,
+    // the last step's own bytes (no y_{t+1}: complete at once), the column coefficients, this workgroup's four loss sums
+    // (the backward launch adds the workgroups' and writes the terms)
+    const float* Yc = smem + (((T - 1) & 1) ? L_YT2 : L_YT);
+    const float* Yq = smem + (((T - 1) & 1) ? L_YT : L_YT2);
+    loss_half(Yc, Yq, std::integral_constant<int, 0>{});
+    loss_half(Yc, Yq, std::integral_constant<int, 1>{});
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int d0 = 16 * (wave + 4 * j) + 4 * q;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if ((l_ok[j] >> r) & 1u) {
+          a.sv.loss_code[((int64_t)(T - 1) * B + b0 + i) * D + d0 + r] = (uint8_t)(int)lhf[j][r];      // (sign(y_T - y_{T-1}) = 0 is in the 21)
+          float nrm;
+          const float cn = loss_col_coef(a.lc3, lss[j][r], nrm);
+          a.sv.loss_coef[(int64_t)(b0 + i) * D + d0 + r] = cn;
+          ls_norm += nrm;
+        }
+    }
+    const float s4[4] = {wave_sum(ls_l1), wave_sum(ls_cont), wave_sum(ls_norm), wave_sum(ls_sq)};
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) red[wave * 4 + k] = s4[k];
+    }
+    lds_barrier();
+    if (T >= 3) code_store(T - 2);
+    if (tid < 4) a.sv.loss_partial[(int64_t)b * 4 + tid] = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
+  }
 }
 
 }  // namespace g2v
@@ -554,6 +731,7 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
   a.p_drop = p_drop;
+  a.lc3 = s->loss_w[2] / ((float)T * (float)B * (float)D);      // as g2v_custom_loss_fwd_bwd forms it
   const size_t lds = dec_persist_fwd_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
@@ -606,6 +784,10 @@ constexpr int R_END = R_TOT + 128;
 // is still there when its weight-gradient MFMAs run in the shadow of the NEXT iteration's exchange; plus one 16 x 16
 // transpose scratch per wave (an operand's rows from accumulator layout to B-fragment layout)
 constexpr int R_G1 = R_END, TRW = 16 * 17, R_TR = R_G1 + 16 * LDG, R_END_FW = R_TR + 4 * TRW;
+// loss fold: the column coefficients of the workgroup's tile (16 * D floats) and the 64 values of loss_grad_const live in the
+// three padding tiles at the end of the packed W_pre^T image (tiles 9..11: zero, never multiplied, never copied in)
+constexpr int R_LCN = R_PPRET + 9 * KSH * 256, R_LTAB = R_LCN + 2176;
+static_assert(R_LTAB + 64 <= R_POUTT, "the loss-fold tiles fit the padding of the packed W_pre^T image");
 static_assert(R_END_FW * 4 <= 160 * 1024, "LDS budget of the fused-weight-gradient rollout backward");
 }  // namespace
 
@@ -622,6 +804,7 @@ struct DecPersistBwdArgs {
   int T, B, nblk, n_pre, conditioned;
   float p_drop;
   float* wslab;      // FW: [nblk][3H x H] partial dW_hh1, then [nblk][3H] partial db_hh1
+  float lc1, lc2, lc3, linv_n;      // loss fold (sv.loss_code set): w_l1, w_cont, w_var over T B D, and 1 / (T B D)
 };
 
 // one 16-feature output tile, contraction over the gate axis of the merged tile [g_r | g_z | g_n | g_hn]:
@@ -748,10 +931,34 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   frag_load(f_ih1, a.p_ih1_t, wave, 0, lane);
   frag_load(f_hh0, a.p_hh0_t, wave, 0, lane);
   frag_load(f_ih0, a.p_ih0_t, wave, 0, lane);
-  for (int e = tid; e < OUT_TILES * KSH * 64; e += 256)
+  for (int e = tid; e < 9 * KSH * 64; e += 256)            // tiles 9..11 are padding (see R_LCN)
     reinterpret_cast<float4*>(Ppre_t)[e] = reinterpret_cast<const float4*>(a.p_pre_t)[e];
   for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Pout_t)[e] = reinterpret_cast<const float4*>(a.p_out_t)[e];
   if (tid < H) bnw[tid] = a.w.bn_w[tid];
+  // custom_loss folded in (g2v.h, g2v_dec_saved.loss_*): dLoss/dy_t is formed in tile_commit below from y_t, the code byte the
+  // forward left and the column coefficient -- `dy` is never read.  Workgroup 0 also adds up the forward's loss sums.
+  const bool fold = a.sv.loss_code != nullptr;
+  float* Lcn = smem + R_LCN;
+  float* Ltab = smem + R_LTAB;
+  if (fold) {
+    for (int e = tid; e < (16 * D) / 4; e += 256)
+      reinterpret_cast<float4*>(Lcn)[e] = reinterpret_cast<const float4*>(a.sv.loss_coef + (int64_t)b0 * D)[e];
+    if (tid < 64) Ltab[tid] = loss_grad_const(a.lc1, a.lc2, tid);
+    if (b == 0) {
+      float s4[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) s4[k] = wave_sum(tid < a.nblk ? a.sv.loss_partial[(int64_t)tid * 4 + k] : 0.f);
+      if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[wave * 4 + k] = s4[k];
+      }
+      lds_barrier();
+      if (tid == 0)
+        loss_terms_write(a.sv.loss_terms, (red[0] + red[4]) + (red[8] + red[12]), (red[1] + red[5]) + (red[9] + red[13]),
+                         (red[2] + red[6]) + (red[10] + red[14]), (red[3] + red[7]) + (red[11] + red[15]), a.lc1, a.lc2, a.lc3,
+                         a.linv_n);
+    }
+  }
   for (int e = tid; e < 16 * LDH; e += 256) Xdu[e] = 0.f;
   for (int e = tid; e < 16 * (LDD - D); e += 256) Xdy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
   lds_barrier();
@@ -760,17 +967,32 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   // product and the LDS writes behind it.  Clamped, always-valid addresses: no branch around a load, no stack array.
   float4 dy_a, dy_b, dy_c;
   uint32_t k_a, k_b, k_c;
+  const uint32_t kmask = fold ? 0x40u : 0xffu;      // the Dropout(0.95) flag inside a Kt byte
   auto tile_request = [&](int ts) {
     const int e4c = tid + 512 < (16 * D) / 4 ? tid + 512 : 0;
-    const float* dyp = a.gr.dy + ((int64_t)ts * B + b0) * D;
-    const uint32_t* kp = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)min(ts, T - 2) * B + b0) * D);   // row T-1 does not exist
+    // fold: y_t and the code bytes (which carry the keep flag) take the places of dy_t and the keep95 bytes
+    const float* dyp = (fold ? a.sv.y : a.gr.dy) + ((int64_t)ts * B + b0) * D;
+    const uint32_t* kp = fold ? reinterpret_cast<const uint32_t*>(a.sv.loss_code + ((int64_t)ts * B + b0) * D)
+                              : reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)min(ts, T - 2) * B + b0) * D);   // row T-1 does not exist
     dy_a = *reinterpret_cast<const float4*>(dyp + 4 * tid);
     dy_b = *reinterpret_cast<const float4*>(dyp + 4 * (tid + 256));
     dy_c = *reinterpret_cast<const float4*>(dyp + 4 * e4c);
     k_a = kp[tid]; k_b = kp[tid + 256]; k_c = kp[e4c];
   };
+  auto loss_dy = [&](float4& v, uint32_t code, int e4) {      // common.hpp: loss_grad(loss_grad_const(code), cn, y)
+    const float4 cn = reinterpret_cast<const float4*>(Lcn)[e4];
+    v.x = loss_grad(Ltab[code & 63u], cn.x, v.x);
+    v.y = loss_grad(Ltab[(code >> 8) & 63u], cn.y, v.y);
+    v.z = loss_grad(Ltab[(code >> 16) & 63u], cn.z, v.z);
+    v.w = loss_grad(Ltab[(code >> 24) & 63u], cn.w, v.w);
+  };
   auto tile_commit = [&](int ts) {
     const bool fb = (ts != T - 1) && a.conditioned && (ts >= a.n_pre);
+    if (fold) {
+      loss_dy(dy_a, k_a, tid);
+      loss_dy(dy_b, k_b, tid + 256);
+      loss_dy(dy_c, k_c, tid + 512 < (16 * D) / 4 ? tid + 512 : 0);
+    }
     reinterpret_cast<float4*>(Dt)[tid] = dy_a;
     reinterpret_cast<float4*>(Dt)[tid + 256] = dy_b;
     Kt[tid] = fb ? k_a : 0u;
@@ -879,7 +1101,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
         const uint32_t klo = Kt[kbyte >> 2], khi = Kt[(kbyte >> 2) + 1];
         const uint32_t kb4 = __builtin_amdgcn_alignbyte(khi, klo, (uint32_t)(kbyte & 3));
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dyv[r] = (feedback && ((kb4 >> (8 * r)) & 0xffu)) ? dyv[r] + acc[j][r] * 20.0f : dyv[r];
+        for (int r = 0; r < 4; ++r) dyv[r] = (feedback && ((kb4 >> (8 * r)) & kmask)) ? dyv[r] + acc[j][r] * 20.0f : dyv[r];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int d = d0 + r;
@@ -899,7 +1121,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
           const int d = d0 + r;
           if (d < D) {
             float dy = Dt[i * D + d];
-            if (feedback && Kb[i * D + d]) dy += acc[j][r] * 20.0f;
+            if (feedback && (Kb[i * D + d] & kmask)) dy += acc[j][r] * 20.0f;
             Dt[i * D + d] = dy;
             Xdy[i * LDD + d] = dy;
           }
@@ -908,7 +1130,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
 #endif
     }
     lds_barrier();
-    if (feedback)
+    if (feedback || fold)      // (fold: nobody has written the loss part of dy_t to memory; out_layer's weight gradient reads it)
       for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256)
         *reinterpret_cast<float4*>(a.gr.dy + tile + 4 * (int64_t)e4) = reinterpret_cast<const float4*>(Dt)[e4];
     PSTAMP(1, 3);
@@ -1030,6 +1252,10 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.p_drop = p_drop;
   a.wslab = wslab;
+  {      // as g2v_custom_loss_fwd_bwd forms them
+    const float n = (float)T * (float)B * (float)D;
+    a.lc1 = s->loss_w[0] / n; a.lc2 = s->loss_w[1] / n; a.lc3 = s->loss_w[2] / n; a.linv_n = 1.0f / n;
+  }
   const size_t lds = dec_persist_bwd_lds_bytes(fw);
   static bool attr_set[2] = {false, false};
   if (!attr_set[fw]) {

@@ -83,19 +83,29 @@ __device__ __forceinline__ void px_publish2(__amdgpu_buffer_rsrc_t r, unsigned g
 // Thread (m = tid >> 4, c = tid & 15) owns granule pairs c, c+16, c+32, c+48 of record m and re-reads the ones whose
 // tag is stale.  red: LDS [16][128].  Ends with a barrier; tot is valid for every thread afterwards.
 // Record m of the sweep is record `rec_of(m)` of `base` (a [PX_MAX_NBLK][128] array).
-template <class RecOf>
+// `filler()` runs between the first requests and the first look at what they returned: one fabric round trip (~1800 cycles)
+// in which the wave would only wait -- the one place in these kernels where independent VALU / LDS work is free (beside the
+// fp32 MFMAs it is not: measured, every filler instruction costs its full issue time there).  No vector-memory instruction
+// in a filler: vmcnt counts in order, the sweep's wait would include it.
+struct PxNoFiller {
+  __device__ __forceinline__ void operator()() const {}
+};
+template <class RecOf, class Filler = PxNoFiller>
 __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int n, RecOf rec_of, unsigned tag, float* red,
-                                             float* tot, int tid, int stamp_off = 0) {
+                                             float* tot, int tid, int stamp_off = 0, Filler&& filler = Filler()) {
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned long long*>(base), 0,
                                                                 PX_MAX_NBLK * PX_COLS * 8, 0x00020000);
   const int m = tid >> 4, c = tid & 15;
   const int rec = rec_of(m < n ? m : 0);
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   PX_STAMP(stamp_off + 0);
+  u32x4 g[4];
   if (m < n) {
-    u32x4 g[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) g[k] = px_ld(rr, (unsigned)((rec * PX_COLS + 2 * (c + 16 * k)) * 8));
+  }
+  filler();      // (every lane: outside the m < n test)
+  if (m < n) {
     unsigned spins = 0;
     for (;;) {
       bool ok = true;
@@ -130,9 +140,16 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
   lds_barrier();
   PX_STAMP(stamp_off + 1);
   if (tid < PX_COLS) {
+    // every read requested before the first add (same order of the adds: bitwise the same sums): as `t += red[...]` the compiler
+    // waited out one LDS round trip per pair of records, ~1000 cycles per sweep with half of the workgroup idle at the barrier
+    float v16[16];
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v16[g] = red[g * PX_COLS + tid];
+    asm volatile("" : "+v"(v16[0]), "+v"(v16[1]), "+v"(v16[2]), "+v"(v16[3]), "+v"(v16[4]), "+v"(v16[5]), "+v"(v16[6]), "+v"(v16[7]));
+    asm volatile("" : "+v"(v16[8]), "+v"(v16[9]), "+v"(v16[10]), "+v"(v16[11]), "+v"(v16[12]), "+v"(v16[13]), "+v"(v16[14]), "+v"(v16[15]));
     float t = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g * PX_COLS + tid];
+    for (int g = 0; g < 16; ++g) t += v16[g];
     tot[tid] = t;
   }
   lds_barrier();
@@ -145,10 +162,13 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
 //   px_hop2 : sum one published copy of every row's sum: row r' is read from the workgroup of that row in this workgroup's
 //             column (column c modulo the row's length: the last row may be short).  On return tot[128] holds the sums
 //             over all nblk workgroups, bit-identical in every workgroup.
-__device__ __forceinline__ void px_hop1(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid) {
+template <class Filler = PxNoFiller>
+__device__ __forceinline__ void px_hop1(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid,
+                                        Filler&& filler = Filler()) {
   const int row = b / PX_GROUP;
   const int n = min(PX_GROUP, nblk - row * PX_GROUP);
-  px_sweep_sum(x.rec1 + (size_t)par * PX_MAX_NBLK * PX_COLS, n, [&](int m) { return row * PX_GROUP + m; }, tag, red, tot, tid);
+  px_sweep_sum(x.rec1 + (size_t)par * PX_MAX_NBLK * PX_COLS, n, [&](int m) { return row * PX_GROUP + m; }, tag, red, tot, tid, 0,
+               static_cast<Filler&&>(filler));
   if (tid < 64) {
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(x.rec2 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0,
                                                                   PX_COLS * 8, 0x00020000);
@@ -156,11 +176,14 @@ __device__ __forceinline__ void px_hop1(const PersistX& x, int par, unsigned tag
   }
   lds_barrier();     // tot / red are rewritten by the second sweep: every reader above is done
 }
-__device__ __forceinline__ void px_hop2(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid) {
+template <class Filler = PxNoFiller>
+__device__ __forceinline__ void px_hop2(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid,
+                                        Filler&& filler = Filler()) {
   const int nrow = (nblk + PX_GROUP - 1) / PX_GROUP;
   const int col = b % PX_GROUP;
   px_sweep_sum(x.rec2 + (size_t)par * PX_MAX_NBLK * PX_COLS, nrow,
-               [&](int m) { return m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP); }, tag, red, tot, tid, 3);
+               [&](int m) { return m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP); }, tag, red, tot, tid, 3,
+               static_cast<Filler&&>(filler));
 }
 __device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot,
                                             int tid) {

@@ -1776,6 +1776,12 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     const bool persist = fast && persist_enabled() && (B % 16) == 0 && dm.nblk <= PX_MAX_NBLK && dm.nblk <= device_cu_count() &&
                          a16(h_init) && a16(s->y) && a16(s->u) && a16(s->h0) && a16(s->h1) && a16(s->xin) && a16(s->a) &&
                          a16(s->x1) && a16(s->gates0) && a16(s->gates1) && a16(keep95) && a16(keep_l0) && a16(workspace);
+    if (s->loss_code && !(persist && training && s->loss_coef && s->loss_partial && s->loss_terms &&
+                          g2v_dec_rollout_fuses_loss(B, D, H, T))) {
+      set_error("g2v_dec_rollout_fwd: the loss_* fields are set where g2v_dec_rollout_fuses_loss(B, D, H, T) does not hold "
+                "(or not training, or one of them is NULL)");
+      return G2V_ERR_UNSUPPORTED;
+    }
     if (persist) {
       void* xbase = (char*)workspace + fwd_pack_bytes_aligned(D, H);
       const int rc = dec_persist_fwd_launch(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T,
@@ -1875,6 +1881,18 @@ static bool fused_wgrad_enabled() {
     on = (e && e[0] == '1') ? 0 : 1;
   }
   return on != 0;
+}
+static bool fused_loss_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("G2V_NO_FUSED_LOSS");
+    on = (e && e[0] == '1') ? 0 : 1;
+  }
+  return on != 0;
+}
+extern "C" int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T) {
+  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() && T >= 2 &&
+          T <= 256 && persist_enabled() && fused_loss_enabled()) ? 1 : 0;
 }
 extern "C" int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H) {
   return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() &&
@@ -2018,6 +2036,11 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
     }
     if (want_w && !(ok_w && persist && fmask != 0)) {
       set_error("g2v_dec_rollout_bwd: dw_gru / db_gru must name exactly the matrices of g2v_dec_rollout_bwd_fuses_wgrad(B, D, H)");
+      return G2V_ERR_UNSUPPORTED;
+    }
+    if (s->loss_code && !(persist && s->loss_coef && s->loss_partial && s->loss_terms && s->y && a16(s->y) &&
+                          g2v_dec_rollout_fuses_loss(B, D, H, T))) {
+      set_error("g2v_dec_rollout_bwd: the loss_* fields are set where g2v_dec_rollout_fuses_loss(B, D, H, T) does not hold");
       return G2V_ERR_UNSUPPORTED;
     }
     if (persist)

@@ -15,7 +15,6 @@ void set_error(const char* fmt, ...) {
 
 // ---- custom_loss: train_eval/train_seq2seq.py:40-88 ----------------------------------------------------
 // One thread per (b,d) column walks the T frames twice (norm over TIME, :70).  y is (T,B,D), target (B,T,D).
-__device__ __forceinline__ float sgnf(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
 
 __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restrict__ y, const float* __restrict__ tgt,
                                                           float* __restrict__ dy, float* __restrict__ partial, float c1,
@@ -33,20 +32,18 @@ __global__ __launch_bounds__(256) void custom_loss_kernel(const float* __restric
       l1 += fabsf(v - tv);
       sq += (v - tv) * (v - tv);
       if (t > 0) cont += fabsf(v - prev);
-      ss += v * v;
+      ss = fmaf(v, v, ss);
       prev = v;
     }
-    nrm = sqrtf(ss);
+    const float cn = loss_col_coef(c3, ss, nrm);
     if (dy) {
-      const float inv = (nrm > 0.f) ? 1.0f / nrm : 0.f;
       float vm = 0.f, v = y[col], vp;
       for (int t = 0; t < T; ++t) {
         vp = (t + 1 < T) ? y[(int64_t)(t + 1) * BD + col] : 0.f;
         const float tv = tgt[((int64_t)b * T + t) * D + d];
-        float g = c1 * sgnf(v - tv) - c3 * v * inv;
-        if (t > 0) g += c2 * sgnf(v - vm);
-        if (t + 1 < T) g -= c2 * sgnf(vp - v);
-        dy[(int64_t)t * BD + col] = g * g_scale;
+        const int code = loss_sign_code(v - tv) | ((t > 0 ? loss_sign_code(v - vm) : 1) << 2) |
+                         ((t + 1 < T ? loss_sign_code(vp - v) : 1) << 4);
+        dy[(int64_t)t * BD + col] = loss_grad(loss_grad_const(c1, c2, code), cn, v) * g_scale;
         vm = v;
         v = vp;
       }
@@ -95,18 +92,16 @@ __global__ __launch_bounds__(256) void custom_loss_reg_kernel(const float* __res
       l1 += fabsf(v[t] - tv[t]);
       sq += (v[t] - tv[t]) * (v[t] - tv[t]);
       if (t > 0) cont += fabsf(v[t] - v[t - 1]);
-      ss += v[t] * v[t];
+      ss = fmaf(v[t], v[t], ss);
     }
-    nrm = sqrtf(ss);
+    const float cn = loss_col_coef(c3, ss, nrm);
     if (dy) {
-      const float inv = (nrm > 0.f) ? 1.0f / nrm : 0.f;
       float* dp = dy + col;
 #pragma unroll
       for (int t = 0; t < TT; ++t) {
-        float g = c1 * sgnf(v[t] - tv[t]) - c3 * v[t] * inv;
-        if (t > 0) g += c2 * sgnf(v[t] - v[t - 1]);
-        if (t + 1 < TT) g -= c2 * sgnf(v[t + 1] - v[t]);
-        dp[(int64_t)t * BD] = g * g_scale;
+        const int code = loss_sign_code(v[t] - tv[t]) | ((t > 0 ? loss_sign_code(v[t] - v[t - 1]) : 1) << 2) |
+                         ((t + 1 < TT ? loss_sign_code(v[t + 1] - v[t]) : 1) << 4);
+        dp[(int64_t)t * BD] = loss_grad(loss_grad_const(c1, c2, code), cn, v[t]) * g_scale;
       }
     }
   }
@@ -139,16 +134,10 @@ __global__ void custom_loss_finalize_kernel(const float* __restrict__ partial, i
     if (lane == 0) red[j][wave] = s[j];
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    const float l1 = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) * c1;
-    const float cont = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) * c2;
-    const float var = -((red[2][0] + red[2][1]) + (red[2][2] + red[2][3])) * c3;
-    terms[0] = l1 + cont + var;
-    terms[1] = l1;
-    terms[2] = cont;
-    terms[3] = var;
-    terms[4] = ((red[3][0] + red[3][1]) + (red[3][2] + red[3][3])) * inv_n;   // plain MSE (evaluate_testset's metric)
-  }
+  if (threadIdx.x == 0)
+    loss_terms_write(terms, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]),
+                     (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]), (red[3][0] + red[3][1]) + (red[3][2] + red[3][3]), c1, c2,
+                     c3, inv_n);
 }
 
 // ---- MSE (DAE reconstruction loss, train_eval/train_seq2seq.py:208-222) -----------------------------------------

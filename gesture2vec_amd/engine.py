@@ -137,6 +137,11 @@ class VQVAEEngine:
         #     pre_linear's weight as fp32 MFMA fragments + the screening image (bf16 fragments of U = W w_pre, s'_k, norm bounds);
         #   fp32 kernel: fragment-major image of the codebook (G2V_VQ_PACKED=0: it reads the row-major codebook instead, A/B).
         self._vq_bx = bool(self.lib.g2v_vq_fused_assign_bx_ok(1, self.E, K)) and os.environ.get("G2V_VQ_BX", "1") != "0"
+        # custom_loss carried by the rollout pair (g2v_dec_saved.loss_*) instead of its own launch between the rollouts: bitwise
+        # the same gradients, 150 MB less HBM traffic and two launches fewer per step -- and NOT faster (the
+        # elementwise work costs 55-60 us inside the one-wave-per-SIMD rollout kernels against the 62 + 6 us it removes), so it is
+        # opt-in: G2V_LOSS_FOLD=1
+        self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
         self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
         self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
         self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
@@ -273,6 +278,8 @@ class VQVAEEngine:
             "gates0": z(T - 1, B, 4 * H), "gates1": z(T - 1, B, 4 * H),
             "bn_partial": z(2, nblk, 2, H), "bn_stats": z(T - 1, 2, H),
             "loss_partial": z(self.lib.g2v_custom_loss_blocks(B, D) * 4),
+            # custom_loss folded into the rollout pair (g2v_dec_saved.loss_*): sign codes + Dropout(0.95) flags, column coefficients
+            "loss_code": torch.zeros(T, B, D, dtype=torch.uint8, device=dev), "loss_coef": z(B, D),
             # backward
             "dy": z(T, B, D), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H),
             "dgi0": z(T - 1, B, G), "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G),
@@ -287,6 +294,12 @@ class VQVAEEngine:
         sv.gates0, sv.gates1 = _p(b["gates0"]), _p(b["gates1"])
         sv.bn_partial, sv.bn_stats = _p(b["bn_partial"]), _p(b["bn_stats"])
         b["sv"] = sv
+        svl = DecSaved()          # the same arrays + the loss fold's (weights filled in by forward_decoder)
+        C.memmove(C.byref(svl), C.byref(sv), C.sizeof(DecSaved))
+        svl.loss_code, svl.loss_coef = _p(b["loss_code"]), _p(b["loss_coef"])
+        svl.loss_partial, svl.loss_terms = _p(b["loss_partial"]), _p(self.loss_terms)
+        b["sv_loss"] = svl
+        b["loss_folded"] = False
         sve = DecSaved()          # inference: nothing saved for backward
         sve.y, sve.u, sve.h0, sve.h1, sve.bn_partial = sv.y, sv.u, sv.h0, sv.h1, sv.bn_partial
         b["sv_eval"] = sve
@@ -376,7 +389,7 @@ class VQVAEEngine:
                 b["keep_l0"].copy_(keep_l0)
 
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
-                n_global: Optional[int] = None, derived_ready: bool = False):
+                n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
         if self.quantizer != "ema":
@@ -419,7 +432,7 @@ class VQVAEEngine:
                                    b["ws_stats"].numel(), self._stream()))
             if ema_update:
                 self.vq_finish(B, training, n_global)
-        b = self.forward_decoder(out_poses, B, training)
+        b = self.forward_decoder(out_poses, B, training, loss_w=loss_w)
         self._join(1)
         return b
 
@@ -469,8 +482,11 @@ class VQVAEEngine:
         check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
         return b
 
-    def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool):
-        """decoder rollout (:1039-1054) from buffers['quant'] (2,B,H) = the initial hidden state; fills buffers['y'] (T,B,D)."""
+    def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool, loss_w=None):
+        """decoder rollout (:1039-1054) from buffers['quant'] (2,B,H) = the initial hidden state; fills buffers['y'] (T,B,D).
+        loss_w = (w_l1, w_cont, w_var): custom_loss(y, out_poses) is to follow with these weights and a backward_decoder after
+        it -- where the rollout kernels can carry the loss themselves (g2v_dec_rollout_fuses_loss) they do: buffers['loss_folded']
+        says so, loss() then launches nothing and loss_terms is written by backward_decoder's launch."""
         lib, st = self.lib, self._stream()
         T, D, H = self.T, self.D, self.H
         ops._chk(out_poses, name="out_poses")
@@ -478,8 +494,13 @@ class VQVAEEngine:
         b = self.buffers(B)
         drop_in = training and self.p > 0
         fn, ws = (lib.g2v_dec_rollout_fwd_prepared, b["ws_decf"]) if self._prepared else (lib.g2v_dec_rollout_fwd, b["ws"])
+        fold = bool(training and loss_w is not None and self._loss_fold and lib.g2v_dec_rollout_fuses_loss(B, D, H, T))
+        b["loss_folded"] = fold
+        if fold:
+            b["sv_loss"].loss_w[0], b["sv_loss"].loss_w[1], b["sv_loss"].loss_w[2] = (float(w) for w in loss_w)
+            b["loss_target"] = out_poses.data_ptr()
         check(fn(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
-                 C.byref(b["sv"] if training else b["sv_eval"]), _p(b["keep95"]),
+                 C.byref((b["sv_loss"] if fold else b["sv"]) if training else b["sv_eval"]), _p(b["keep95"]),
                  _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
                  int(self.conditioned), int(training), T, B, D, H, _p(ws), ws.numel(), st))
         return b
@@ -513,6 +534,13 @@ class VQVAEEngine:
     def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):
         """custom_loss on the rollout output; fills loss_terms and (want_grad) the dy buffer with dLoss/dy."""
         b = self.buffers(B)
+        if b["loss_folded"]:           # forward_decoder(loss_w=...) took the loss along: backward_decoder finishes it
+            w = b["sv_loss"].loss_w
+            if not (want_grad and target.data_ptr() == b["loss_target"] and
+                    (w[0], w[1], w[2]) == tuple(C.c_float(float(v)).value for v in (w_l1, w_cont, w_var))):
+                raise ValueError("loss(): the rollout was run with the loss folded in (forward_decoder(loss_w=...)) "
+                                 "for another target / other weights, or without the gradient")
+            return
         check(self.lib.g2v_custom_loss_fwd_bwd(_p(b["y"]), _p(target), _p(b["dy"]) if want_grad else None,
                                                _p(self.loss_terms), _p(b["loss_partial"]), w_l1, w_cont, w_var, 1.0,
                                                self.T, B, self.D, self._stream()))
@@ -564,7 +592,7 @@ class VQVAEEngine:
         fn, wsd = (lib.g2v_dec_rollout_bwd_prepared, b["ws_decb"]) if self._prepared else (lib.g2v_dec_rollout_bwd, b["ws"])
         pre = "decoder.decoder."
         M = (T - 1) * B
-        check(fn(C.byref(self.dec_wstruct()), C.byref(b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
+        check(fn(C.byref(self.dec_wstruct()), C.byref(b["sv_loss"] if b["loss_folded"] else b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
                  _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
                  T, B, D, H, _p(wsd), wsd.numel(), st))
         x1 = b["x1"] if drop else b["h0"][1:]
@@ -696,7 +724,7 @@ class VQVAEEngine:
                 self.prepare_recurrent(B, "dec")
                 self.prepare_recurrent(B, "gru_bwd")
         self._side_work = side
-        self.forward(x, target, True, ema_update=not dp, derived_ready=True)
+        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var))
         self.loss(B, target, w_l1, w_cont, w_var, True)
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)

@@ -62,7 +62,7 @@ int g2v_linear_set_smallm_rows(int rows);
  *   g2v_dec_rollout_set_persistent(0 / 1)   persistent rollout kernels vs one launch per step (default 1)
  *   environment, read ONCE at first use:  G2V_NO_PERSIST=1 (initial value 0 of the switch above), G2V_PLAIN_STORES=1 (no
  *   write-through stores for the saved tensors of the per-step rollout kernels), G2V_NO_FUSED_WGRAD=1 (the persistent
- *   backward does not accumulate dW_hh1 itself).
+ *   backward does not accumulate dW_hh1 itself), G2V_NO_FUSED_LOSS=1 (g2v_dec_rollout_fuses_loss answers 0).
  * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
@@ -329,6 +329,19 @@ typedef struct {           /* saved-for-backward / state arrays, all caller-owne
   float* gates1;           /* (T-1,B,4H)                                                      */
   float* bn_partial;       /* (2, nblk, 2, H) ping-pong per-block sums of (u-b), (u-b)^2      */
   float* bn_stats;         /* (T-1,2,H) batch mean / biased var per step (training)           */
+  /* Optional, all NULL / 0 = off: custom_loss (K10, train_eval/train_seq2seq.py:40-88) folded into the rollout pair, with the
+   * rollout's `target` as the loss target.  Set them (training only) where g2v_dec_rollout_fuses_loss() says 1, in BOTH calls of
+   * the pair.  The forward then accumulates the loss sums and the column norms while it produces y_t and leaves one code byte
+   * per element; the backward forms dLoss/dy_t from y_t, the byte and the column coefficient in its own tile load, so that
+   * g2v_custom_loss_fwd_bwd is not called, `dy` of g2v_dec_grads is OUTPUT only, and loss_terms is written by the BACKWARD
+   * call.  Same dy bits as g2v_custom_loss_fwd_bwd(g_scale = 1); the four loss sums are added in a different order.
+   * Saves 150 MB of HBM traffic and two launches per step at B = 4096, T = 34 -- and no time: the elementwise work costs the
+   * one-wave-per-SIMD rollout kernels about what the separate launch costs, so callers opt in. */
+  uint8_t* loss_code;      /* (T,B,D)   sign codes of the three |.| terms + the Dropout(0.95) flag */
+  float* loss_coef;        /* (B,D)     w_var / numel / ||y[:,b,d]||_2                             */
+  float* loss_partial;     /* (nblk,4)  per-workgroup loss sums                                    */
+  float* loss_terms;       /* (5)       total, l1, cont, var, mse -- as g2v_custom_loss_fwd_bwd    */
+  float loss_w[3];         /* w_l1, w_cont, w_var (custom_loss's loss_regularization weights)     */
 } g2v_dec_saved;
 
 int g2v_dec_rollout_blocks(int B);
@@ -347,6 +360,11 @@ int g2v_dec_rollout_set_persistent(int enable);
  * host synchronises anyway (the engine does after a training iteration's loss read-back, bench.py at the end of the timed
  * region); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step kernels. */
 int g2v_dec_rollout_persist_fault(int clear);
+/* 1 where the rollout pair can carry custom_loss itself (the loss_* fields of g2v_dec_saved): wherever the persistent path
+ * applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent enabled), 2 <= T <= 256; G2V_NO_FUSED_LOSS=1 forces 0.
+ * Elsewhere leave the loss_* fields NULL and call g2v_custom_loss_fwd_bwd between the two rollouts (setting them anyway is
+ * refused with G2V_ERR_UNSUPPORTED, never silently ignored). */
+int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T);
 /* workspace: the weights re-laid-out in MFMA fragment order (packed once per call) + the persistent kernel's exchange
  * state (zeroed by a memset node in front of its launch). */
 size_t g2v_dec_rollout_fwd_workspace(int D, int H);

@@ -1,0 +1,65 @@
+"""custom_loss (train_eval/train_seq2seq.py:40-88) carried by the persistent rollout pair (g2v_dec_saved.loss_*, include/g2v.h)
+against the separate g2v_custom_loss_fwd_bwd launch between the two rollouts: both form dLoss/dy through the same device
+functions (csrc/common.hpp: loss_sign_code / loss_grad_const / loss_col_coef / loss_grad), so every gradient, and with it every
+weight, Adam moment and the codebook, must be BITWISE equal after three fused train steps; the four loss sums are added in a
+different order (per workgroup tile instead of per 256 columns), so the loss terms agree to fp32 summation accuracy."""
+import pytest
+import torch
+
+from oracle import g2v_oracle as O
+from test_gpu_dp_engine import _engine
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("B,p,n_pre,conditioned", [(64, 0.0, 1, True), (48, 0.2, 1, True), (32, 0.0, 4, True), (32, 0.2, 1, False),
+                                                   (1024, 0.0, 1, True)])
+def test_loss_folded_into_the_rollouts_equals_the_separate_loss_kernel(B, p, n_pre, conditioned):
+    T, D, H, K = 34, 135, 64, 512
+    sd = O.init_vqvae_state(D, H, 2, K, seed=11)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(170 + s)).to(DEV) for s in range(3)]
+    xs[1][:, :, 7] = xs[1][:, :1, 7]       # a column the model cannot match exactly but whose target is constant in time
+    got = {}
+    for fold in (False, True):
+        eng = _engine(sd, D, H, K, T, p)
+        eng.seed = 5
+        eng.n_pre, eng.conditioned = n_pre, conditioned
+        eng._loss_fold = fold
+        terms, dys = [], []
+        for x in xs:
+            eng.train_step(x, x, **kw)
+            assert eng.buffers(B)["loss_folded"] is fold          # the path under test is the one that ran
+            terms.append(eng.loss_terms.clone())
+            dys.append(eng.buffers(B)["dy"][1:].clone())
+        torch.cuda.synchronize()
+        eng.check_faults()
+        got[fold] = (eng, terms, dys)
+    (ref, t_ref, dy_ref), (eng, t_got, dy_got) = got[False], got[True]
+    for s in range(3):
+        assert torch.equal(dy_got[s], dy_ref[s]), ("dy", s)
+        torch.testing.assert_close(t_got[s], t_ref[s], rtol=2e-5, atol=1e-7)
+    for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars"):
+        assert torch.equal(getattr(eng, name), getattr(ref, name)), name
+
+
+def test_loss_fields_are_refused_where_the_rollout_cannot_carry_the_loss():
+    """B = 40 is not a multiple of 16: the per-step kernels run, g2v_dec_rollout_fuses_loss says 0, the engine keeps the
+    separate loss kernel -- and the C entry point refuses the loss_* fields instead of ignoring them."""
+    import ctypes as C
+    from gesture2vec_amd._lib import check
+    T, D, H, K, B = 34, 135, 64, 512, 40
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    eng = _engine(sd, D, H, K, T, 0.0)
+    assert eng.lib.g2v_dec_rollout_fuses_loss(B, D, H, T) == 0
+    assert eng.lib.g2v_dec_rollout_fuses_loss(64, D, H, T) == 1
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(1)).to(DEV)
+    eng.train_step(x, x, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    b = eng.buffers(B)
+    assert b["loss_folded"] is False
+    ws = b["ws"]
+    rc = eng.lib.g2v_dec_rollout_fwd(x.data_ptr(), b["quant"].data_ptr(), C.byref(eng.dec_wstruct()), C.byref(b["sv_loss"]),
+                                     b["keep95"].data_ptr(), None, 0.0, 1, 1, 1, T, B, D, H, ws.data_ptr(), ws.numel(), None)
+    assert rc != 0 and b"fuses_loss" in eng.lib.g2v_last_error()
+    torch.cuda.synchronize()
