@@ -226,11 +226,10 @@ __device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint
   c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
-__global__ void keep_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float keep_prob, uint64_t seed,
-                                 const int64_t* __restrict__ offset_counter) {
-  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // one philox block = 4 outputs
-  if (g * 4 >= n) return;
-  const uint64_t off = (uint64_t)offset_counter[0];
+// One philox block = 4 consecutive outputs (block g <-> elements 4g .. 4g+3, counter (g, offset), key = seed): the mapping every
+// version of this kernel has had.  A thread takes FOUR consecutive blocks and stores its 16 flags with one 16-byte store (the
+// first version stored them byte by byte: 84 us for the 18 M flags of a B = 4096 step, store-issue bound; the arithmetic is ~10 us).
+__device__ __forceinline__ uint32_t philox_keep4(int64_t g, uint64_t off, uint64_t seed, float keep_prob) {
   uint32_t c[4] = {(uint32_t)g, (uint32_t)((uint64_t)g >> 32), (uint32_t)off, (uint32_t)(off >> 32)};
   uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
@@ -239,10 +238,28 @@ __global__ void keep_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float ke
     k0 += 0x9E3779B9u;
     k1 += 0xBB67AE85u;
   }
+  uint32_t w = 0u;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t e = g * 4 + j;
-    if (e < n) keep[e] = ((float)(c[j] >> 8) * (1.0f / 16777216.0f) < keep_prob) ? 1 : 0;
+  for (int j = 0; j < 4; ++j) w |= (((float)(c[j] >> 8) * (1.0f / 16777216.0f) < keep_prob) ? 1u : 0u) << (8 * j);
+  return w;
+}
+template <bool ALIGNED16>
+__global__ __launch_bounds__(256) void keep_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float keep_prob, uint64_t seed,
+                                                        const int64_t* __restrict__ offset_counter) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // elements 16 i .. 16 i + 15
+  if (i * 16 >= n) return;
+  const uint64_t off = (uint64_t)offset_counter[0];
+  uint32_t w[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) w[k] = philox_keep4(4 * i + k, off, seed, keep_prob);
+  if (ALIGNED16 && i * 16 + 16 <= n) {
+    *reinterpret_cast<uint4*>(keep + i * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int64_t e = i * 16 + k;
+      if (e < n) keep[e] = (uint8_t)((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+    }
   }
 }
 __global__ void tick_kernel(int64_t* c) { c[0] += 1; }
@@ -379,9 +396,13 @@ extern "C" int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t
                              g2v_stream_t stream) {
   G2V_REQUIRE(keep && offset_counter, "null pointer");
   G2V_REQUIRE(n > 0, "bad size");
-  const int64_t nthreads = (n + 3) / 4;
-  hipLaunchKernelGGL(keep_mask_kernel, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
-                     seed, offset_counter);
+  const int64_t nthreads = (n + 15) / 16;
+  if ((reinterpret_cast<uintptr_t>(keep) & 15) == 0)
+    hipLaunchKernelGGL(keep_mask_kernel<true>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
+                       seed, offset_counter);
+  else
+    hipLaunchKernelGGL(keep_mask_kernel<false>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
+                       seed, offset_counter);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, offset_counter);
   G2V_CHECK_LAUNCH();

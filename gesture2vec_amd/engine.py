@@ -142,6 +142,7 @@ class VQVAEEngine:
         # elementwise work costs 55-60 us inside the one-wave-per-SIMD rollout kernels against the 62 + 6 us it removes), so it is
         # opt-in: G2V_LOSS_FOLD=1
         self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
+        self._wgrad_small_first = os.environ.get("G2V_WGRAD_ORDER", "0") == "1"      # round-2 launch order of the decoder's products (A/B)
         self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
         self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
         self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
@@ -184,6 +185,12 @@ class VQVAEEngine:
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
+        self._deferred: list = []
+        # bit k: branch k is launched behind the main chain's next kernel (_fork).  Measured per branch at B = 4096: branch 0 (masks,
+        # packs, vq_derive beside the encoder GRU) -5..-9 us per step; branch 1 (EMA statistics beside the forward rollout) +30 us --
+        # arriving behind the persistent kernel it waits for the whole rollout; branch 2 (decoder weight gradients) +10 us -- they
+        # must be resident before the encoder's BPTT kernel (backward_decoder).  Hence 1.
+        self._fork_late = int(os.environ.get("G2V_FORK_ORDER", "1"))
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
@@ -202,8 +209,37 @@ class VQVAEEngine:
             yield
         self._open.append(k)
 
+    def _fork(self, k: int, fn):
+        """Branch k = fn(), ordered after everything launched so far on the current stream -- but LAUNCHED by the next _release(),
+        which the caller places behind the main chain's next kernel.  In a captured hipGraph the first successor recorded at a
+        fork stays on the hardware queue of the fork node and the others move to another queue, whose first packet pays a
+        cross-queue dependency (measured in the replayed step's timeline: ~5 us to the next kernel of the same queue, 10-19 us
+        across queues): where nothing else decides, the main chain should be that first successor.  Per branch: self._fork_late."""
+        if not self._branches_on or not (self.overlap >> k) & 1:
+            fn()
+            return
+        if not (self._fork_late >> k) & 1:
+            with self._branch(k):
+                fn()
+            return
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self._deferred.append((k, ev, fn))
+
+    def _release(self):
+        for k, ev, fn in self._deferred:
+            side = self._sides.get(k)
+            if side is None:
+                side = self._sides[k] = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("G2V_SIDE_PRIORITY", "0")))
+            side.wait_event(ev)
+            with torch.cuda.stream(side):
+                fn()
+            self._open.append(k)
+        self._deferred.clear()
+
     def _join(self, k: Optional[int] = None):
         """current stream waits for branch k (default: every open branch)"""
+        assert not self._deferred, "a forked branch was never released"
         for j in [x for x in self._open if k is None or x == k]:
             torch.cuda.current_stream().wait_stream(self._sides[j])
             self._open.remove(j)
@@ -427,12 +463,14 @@ class VQVAEEngine:
                                         _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
         # the statistics and the codebook update feed nothing in this forward (the rollout starts from `quant`, taken from the
         # codebook as it was): a parallel branch beside the rollout
-        with self._branch(1):
+        def stats():
             check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws_stats"]),
                                    b["ws_stats"].numel(), self._stream()))
             if ema_update:
                 self.vq_finish(B, training, n_global)
+        self._fork(1, stats)
         b = self.forward_decoder(out_poses, B, training, loss_w=loss_w)
+        self._release()
         self._join(1)
         return b
 
@@ -456,8 +494,7 @@ class VQVAEEngine:
         # product the mask kernel doubled its time (36 -> 67 us on the main chain), beside the latency-bound GRU it is free
         side, self._side_work = getattr(self, "_side_work", None), None
         if side is not None:
-            with self._branch(0):
-                side()
+            self._fork(0, side)
         # H == 64: the input projections x W_ih^T + b_ih are fused into the recurrent kernel (no gi array at all);
         # other sizes compute gi with the dense-layer kernel first
         fuse_gi = (H == 64)
@@ -480,6 +517,7 @@ class VQVAEEngine:
             dirs[k].gates = _p(b["gates_" + key]) if training else None
             dirs[k].reverse = k
         check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
+        self._release()                     # branch 0 (forked above) is launched behind the main chain's kernel
         return b
 
     def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool, loss_w=None):
@@ -557,6 +595,7 @@ class VQVAEEngine:
         gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
         check(self.lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
                                   self.beta, self._stream()))
+        self._release()                     # branch 2 (the decoder's weight gradients, forked in backward_decoder)
         self.backward_encoder(in_poses, B)
         self._join(2)
 
@@ -596,15 +635,23 @@ class VQVAEEngine:
                  _p(b["keep_l0"]) if drop else None, self.p, self.n_pre, int(self.conditioned),
                  T, B, D, H, _p(wsd), wsd.numel(), st))
         x1 = b["x1"] if drop else b["h0"][1:]
-        with (self._branch(2) if wgrad_branch else contextlib.nullcontext()):
+        def products():
             wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws")
-            wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
             items = [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
                      (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
                      (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
                      (_p(b["dgh1"]), _p(b["h1"]), pre + "gru.weight_hh_l1", pre + "gru.bias_hh_l1")]
             rest = [it for m, it in enumerate(items) if not (b["fused_wgrad"] >> m) & 1]      # the others came out of the rollout kernel
-            if rest:
+            # The largest product FIRST.  A product and the encoder's BPTT kernel do not share a CU's registers (the BPTT's two
+            # workgroups per CU hold ~430 of the 512 registers per lane, a product's wave needs 128-256): a product dispatched
+            # while the BPTT is resident makes no progress until its workgroups drain (gpurun_tools/corun_test.py: 65 us alone,
+            # 225 us beside it); one that is resident first -- the fork is 18 us ahead of the BPTT -- runs at its stand-alone
+            # speed and the BPTT waits for the registers instead (235 -> 293 us).  Largest first is the better of the two orders
+            # by 4-12 us per step (G2V_WGRAD_ORDER=1: the other one).
+            if rest and not self._wgrad_small_first:
+                wgrad4(M, rest)
+            wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
+            if rest and self._wgrad_small_first:
                 wgrad4(M, rest)
             # (the rollout's backward ADDS the feedback path's gradient into dy: this product needs the finished dy, it cannot run
             # beside the rollout -- tried in round 3, wrong by construction)
@@ -612,6 +659,10 @@ class VQVAEEngine:
             for name in self.frozen:
                 g = self.view(name, True)
                 check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
+        if wgrad_branch:
+            self._fork(2, products)          # launched by backward()'s _release(), behind the quantiser's backward
+        else:
+            products()
         return b
 
     def backward_encoder(self, in_poses: torch.Tensor, B: int):

@@ -20,6 +20,6 @@ if len(idx) >= 4:
         s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
         gap = (s - prev) / 1e3 if prev else 0.0
         busy += e - s
-        print(f"{(s - t0) / 1e3:9.1f} dur {(e - s) / 1e3:7.1f} gap {gap:6.1f} {r['Kernel_Name'][:80]}")
+        print(f"{(s - t0) / 1e3:9.1f} dur {(e - s) / 1e3:7.1f} gap {gap:6.1f} q{r.get('Queue_Id', '?'):>2} {r['Kernel_Name'][:80]}")
         prev = e
     print("period", (int(rows[b]["Start_Timestamp"]) - t0) / 1e3, "us; kernel time", busy / 1e3, "us")

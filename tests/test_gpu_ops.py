@@ -820,6 +820,33 @@ def test_keep_mask(ops):
     assert full.all()
 
 
+def _philox_keep_reference(n, keep_prob, seed, offset):
+    """philox4x32-10, block g <-> elements 4g .. 4g+3, counter (g lo, g hi, offset lo, offset hi), key = seed: the documented
+    stream of g2v_keep_mask (numpy restatement, uint64 arithmetic)."""
+    g = np.arange((n + 3) // 4, dtype=np.uint64)
+    c = [g & 0xFFFFFFFF, g >> 32, np.full_like(g, offset & 0xFFFFFFFF), np.full_like(g, offset >> 32)]
+    k0, k1 = seed & 0xFFFFFFFF, seed >> 32
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[0]
+        p1 = np.uint64(0xCD9E8D57) * c[2]
+        c = [(p1 >> 32) ^ c[1] ^ np.uint64(k0), p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ np.uint64(k1), p0 & 0xFFFFFFFF]
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    u = np.stack(c, axis=1).reshape(-1)[:n]
+    return (((u >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)) < np.float32(keep_prob)).astype(np.uint8)
+
+
+@pytest.mark.parametrize("n,shift", [(16, 0), (1000, 0), (1003, 0), (4099, 1), (70001, 3), (5, 0)])
+def test_keep_mask_is_the_documented_philox_stream(ops, n, shift):
+    """Bit-exact against the numpy restatement, on 16-byte-aligned and unaligned destinations, whole and ragged counts (the
+    kernel stores 16 flags per thread where it can, byte by byte where it cannot)."""
+    off = torch.full((1,), 7, dtype=torch.int64, device=DEV)
+    buf = torch.full((n + 64,), 9, dtype=torch.uint8, device=DEV)
+    out = ops.keep_mask(buf[shift:shift + n], 0.3, (5 << 32) | 1234, off)
+    assert off.item() == 8
+    assert np.array_equal(out.cpu().numpy(), _philox_keep_reference(n, 0.3, (5 << 32) | 1234, 7))
+    assert (buf[:shift] == 9).all() and (buf[shift + n:] == 9).all()          # nothing written outside
+
+
 # ----------------------------------------------------------------------------------------------- Part d operators
 @pytest.mark.parametrize("B,H", [(128, 200), (37, 50), (4096, 64), (5, 16)])
 @pytest.mark.parametrize("relu", [True, False])
