@@ -426,6 +426,8 @@ def main():
                                   "2 hipGraph replays around one RCCL all-reduce" if use_dp else "hipGraph replay"),
                        "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "graph_branches_mask": int(eng.overlap),
+                       "custom_loss": ("inside the rollout kernels (G2V_LOSS_FOLD=1)" if eng.buffers(B).get("loss_folded")
+                                       else "own launch between the rollouts"),
                        "wgrad_inside_recurrent_kernels": {"decoder_mask_ih0_hh0_ih1_hh1": int(eng.buffers(B).get("fused_wgrad", 0)),
                                                           "encoder_mode": int(eng.buffers(B).get("enc_fused_wgrad", 0))},
                        "final_loss": round(loss, 6),

@@ -646,8 +646,8 @@ class VQVAEEngine:
             # workgroups per CU hold ~430 of the 512 registers per lane, a product's wave needs 128-256): a product dispatched
             # while the BPTT is resident makes no progress until its workgroups drain (gpurun_tools/corun_test.py: 65 us alone,
             # 225 us beside it); one that is resident first -- the fork is 18 us ahead of the BPTT -- runs at its stand-alone
-            # speed and the BPTT waits for the registers instead (235 -> 293 us).  Largest first is the better of the two orders
-            # by 4-12 us per step (G2V_WGRAD_ORDER=1: the other one).
+            # speed and the BPTT waits for the registers instead (235 -> 293 us).  Largest first measured 0-12 us per step better
+            # than the other order (G2V_WGRAD_ORDER=1) -- the work only moves between the BPTT and the tail behind it.
             if rest and not self._wgrad_small_first:
                 wgrad4(M, rest)
             wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
