@@ -13,10 +13,11 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("B,p,n_pre,conditioned", [(64, 0.0, 1, True), (48, 0.2, 1, True), (32, 0.0, 4, True), (32, 0.2, 1, False),
-                                                   (1024, 0.0, 1, True)])
-def test_loss_folded_into_the_rollouts_equals_the_separate_loss_kernel(B, p, n_pre, conditioned):
-    T, D, H, K = 34, 135, 64, 512
+@pytest.mark.parametrize("B,p,n_pre,conditioned,T", [(64, 0.0, 1, True, 34), (48, 0.2, 1, True, 34), (32, 0.0, 4, True, 34),
+                                                     (32, 0.2, 1, False, 34), (1024, 0.0, 1, True, 34), (32, 0.0, 1, True, 2),
+                                                     (32, 0.0, 1, True, 3), (16, 0.0, 1, True, 4)])
+def test_loss_folded_into_the_rollouts_equals_the_separate_loss_kernel(B, p, n_pre, conditioned, T):
+    D, H, K = 135, 64, 512
     sd = O.init_vqvae_state(D, H, 2, K, seed=11)
     kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
     xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(170 + s)).to(DEV) for s in range(3)]
