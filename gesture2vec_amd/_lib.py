@@ -46,7 +46,8 @@ class GruDirBwd(C.Structure):
     """g2v_gru_dir_bwd"""
     _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
                 [(n, c_fp) for n in ("w_ih", "dx")] + [("in_dim", c_int)] +
-                [(n, c_fp) for n in ("x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab")])      # optional fused weight gradients
+                [(n, c_fp) for n in ("x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab")] +      # optional fused weight gradients
+                [(n, c_fp) for n in ("hn_z", "hn_q", "hn_gloss")] + [("hn_coef", c_f)])         # optional fused quantiser backward
 
 
 class DecGrads(C.Structure):

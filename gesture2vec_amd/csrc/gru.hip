@@ -607,6 +607,7 @@ struct GruDirB {
   int reverse;
   const float* p_ih_t; float* dx;    // FUSE_DX: dx_t = dgi_t W_ih is produced in the kernel
   const float* x; float* wslab;      // FUSE_W: the layer input (T,B,H) and this direction's partial dW / db slabs
+  const float* hn_z; const float* hn_q; const float* hn_gloss; float hn_coef;   // optional: quantiser backward folded into d_hn
 };
 
 // FUSE_IN: the input projection gi_t = x_t W_ih^T + b_ih (input width == H) is computed in the kernel, one step ahead
@@ -796,6 +797,13 @@ __global__ __launch_bounds__(256, FUSE_W == 2 ? 1 : 2) void gru_bwd_fast_kernel(
   const int len = (lengths && rvalid) ? lengths[b] : T;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 dh = (d.d_hn && rvalid) ? *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0) : z4;
+  if (d.hn_z && rvalid) {      // + gloss coef (z - q): vq_bwd_kernel's arithmetic (vq.hip), its launch saved
+    const float c = d.hn_gloss[0] * d.hn_coef;
+    const float4 zv = *reinterpret_cast<const float4*>(d.hn_z + (int64_t)b * H + f0);
+    const float4 qv = *reinterpret_cast<const float4*>(d.hn_q + (int64_t)b * H + f0);
+    dh.x = fmaf(c, zv.x - qv.x, dh.x); dh.y = fmaf(c, zv.y - qv.y, dh.y);
+    dh.z = fmaf(c, zv.z - qv.z, dh.z); dh.w = fmaf(c, zv.w - qv.w, dh.w);
+  }
   for (int e = tid; e < 2 * 16 * ldg; e += 256) (&Gs[0][0])[e] = 0.f;
 
   auto load_step = [&](int s, float4& gr4, float4& gz4, float4& gn4, float4& gh4, float4& hp4, float4& dhs4, float4& x4) {
@@ -1239,6 +1247,11 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     if (fuse) G2V_REQUIRE(dirs[k].w_ih, "dx != NULL needs w_ih");
   }
   const bool fast = gru_fast_ok(H, hs_ld) && (d_hs_ld & 3) == 0;
+  for (int k = 0; k < ndir; ++k)
+    if (dirs[k].hn_z && !(fast && dirs[k].hn_q && dirs[k].hn_gloss && aligned16(dirs[k].hn_z) && aligned16(dirs[k].hn_q))) {
+      set_error("g2v_gru_seq_bwd: the fused quantiser backward (hn_z, hn_q, hn_gloss) needs the H == 64 kernels and 16-byte-aligned slices");
+      return G2V_ERR_UNSUPPORTED;
+    }
   if (fuse && !(fast && dirs[0].in_dim == H && (ndir == 1 || dirs[1].in_dim == H))) {
     set_error("g2v_gru_seq_bwd: fused input gradient needs H == in_dim == 64 (use g2v_linear_bwd_data otherwise)");
     return G2V_ERR_UNSUPPORTED;
@@ -1261,7 +1274,8 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     }
     for (int k = 0; k < ndir; ++k)
       f[k] = GruDirB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, p_hh_t[k],
-                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, p_ih_t[k], dirs[k].dx, dirs[k].x, dirs[k].wslab};
+                     dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, dirs[k].reverse, p_ih_t[k], dirs[k].dx, dirs[k].x, dirs[k].wslab,
+                     dirs[k].hn_z, dirs[k].hn_q, dirs[k].hn_gloss, dirs[k].hn_coef};
     if (ndir == 1) f[1] = f[0];
     if (!prepared) {
       launch_pack(pb, st);

@@ -886,9 +886,7 @@ __global__ void vq_bwd_kernel(const float* __restrict__ gq, const float* __restr
     const int64_t row = e / E;
     const int col = (int)(e - row * E);
     const float q = idx ? W[idx[row] * E + col] : W[e];   // idx == NULL: W is the dense (N,E) quantised tensor
-    float g = c * (z[e] - q);
-    if (gq) g += gq[e];
-    gz[e] = g;
+    gz[e] = gq ? fmaf(c, z[e] - q, gq[e]) : c * (z[e] - q);      // (the form gru_bwd_fast_kernel folds into its d_hn load)
   }
 }
 

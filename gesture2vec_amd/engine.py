@@ -143,6 +143,7 @@ class VQVAEEngine:
         # opt-in: G2V_LOSS_FOLD=1
         self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
         self._wgrad_small_first = os.environ.get("G2V_WGRAD_ORDER", "0") == "1"      # round-2 launch order of the decoder's products (A/B)
+        self._fuse_vq_bwd = os.environ.get("G2V_FUSE_VQ_BWD", "1") != "0"           # quantiser backward inside the encoder's BPTT kernel
         self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
         self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
         self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
@@ -593,10 +594,16 @@ class VQVAEEngine:
         # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
         N = (2 * B * H) // E
         gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
-        check(self.lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
-                                  self.beta, self._stream()))
-        self._release()                     # branch 2 (the decoder's weight gradients, forked in backward_decoder)
-        self.backward_encoder(in_poses, B)
+        if self._fuse_vq_bwd and H == 64:
+            # straight-through + commitment gradient formed by the BPTT kernel where it reads its incoming gradient: a 4 us kernel
+            # that took 12-15 us beside the decoder's products, plus a kernel boundary, off the critical chain
+            self._release()                 # branch 2 (the decoder's weight gradients, forked in backward_decoder)
+            self.backward_encoder(in_poses, B, quant_bwd=(gl, 2.0 * self.beta / (float(N) * float(E))))
+        else:
+            check(self.lib.g2v_vq_bwd(_p(b["dh_init"]), _p(gl), _p(b["enc_hidden"]), _p(b["quant"]), None, _p(b["gz"]), N, E,
+                                      self.beta, self._stream()))
+            self._release()
+            self.backward_encoder(in_poses, B)
         self._join(2)
 
     def _wgrad_fns(self, b, M_default, ws_key="ws"):
@@ -665,8 +672,10 @@ class VQVAEEngine:
             products()
         return b
 
-    def backward_encoder(self, in_poses: torch.Tensor, B: int):
-        """Encoder layer-0 BPTT from buffers['gz'] (2,B,H) = dLoss / d enc_hidden; writes the encoder's parameter gradients."""
+    def backward_encoder(self, in_poses: torch.Tensor, B: int, quant_bwd=None):
+        """Encoder layer-0 BPTT from buffers['gz'] (2,B,H) = dLoss / d enc_hidden; writes the encoder's parameter gradients.
+        quant_bwd = (g_loss_vq tensor, coef): the quantiser's backward has NOT been run -- the recurrent kernel forms
+        gz = dh_init + g_loss_vq coef (enc_hidden - quant) where it reads its incoming gradient (g2v_gru_dir_bwd.hn_*)."""
         lib, st = self.lib, self._stream()
         T, D, H, G = self.T, self.D, self.H, 3 * self.H
         b = self.buffers(B)
@@ -677,7 +686,10 @@ class VQVAEEngine:
         dirs = (_lib.GruDirBwd * 2)()
         for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):
             dirs[k].d_hs = None
-            dirs[k].d_hn = b["gz"][k].data_ptr()
+            dirs[k].d_hn = b["gz"][k].data_ptr() if quant_bwd is None else b["dh_init"][k].data_ptr()
+            if quant_bwd is not None:
+                dirs[k].hn_z, dirs[k].hn_q = b["enc_hidden"][k].data_ptr(), b["quant"][k].data_ptr()
+                dirs[k].hn_gloss, dirs[k].hn_coef = _p(quant_bwd[0]), float(quant_bwd[1])
             dirs[k].hs = hs_ptr
             dirs[k].h0 = None
             dirs[k].gates = _p(b["gates_" + key])

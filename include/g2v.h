@@ -262,6 +262,14 @@ typedef struct {
   const float* x;
   float* dw_hh; float* db_hh; float* dw_ih; float* db_ih;
   float* wslab;
+  /* Optional (hn_z != NULL; H == 64 fast kernels only, G2V_ERR_UNSUPPORTED elsewhere): the quantiser's backward (K5', g2v_vq_bwd
+   * with a dense quantised tensor) applied where d_hn is read,
+   *   d_hn_effective[b,h] = d_hn[b,h] + hn_gloss[0] * hn_coef * (hn_z[b,h] - hn_q[b,h]),
+   * i.e. the straight-through gradient plus the commitment term (model/Autoencoder_VQVAE_model.py:1285-1292) when the final
+   * state of this direction IS the quantiser's input: hn_z / hn_q are the (B,H) slices of the encoder state and of its
+   * quantised value, hn_coef = 2 beta / (N E).  Same arithmetic as g2v_vq_bwd; saves its launch on the critical chain. */
+  const float* hn_z; const float* hn_q; const float* hn_gloss;
+  float hn_coef;
 } g2v_gru_dir_bwd;
 size_t g2v_gru_seq_bwd_wslab_bytes(int B, int H);
 size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragment order) */

@@ -64,3 +64,26 @@ def test_loss_fields_are_refused_where_the_rollout_cannot_carry_the_loss():
                                      b["keep95"].data_ptr(), None, 0.0, 1, 1, 1, T, B, D, H, ws.data_ptr(), ws.numel(), None)
     assert rc != 0 and b"fuses_loss" in eng.lib.g2v_last_error()
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B,p", [(64, 0.0), (48, 0.2), (1024, 0.0)])
+def test_quantiser_backward_inside_the_bptt_kernel_changes_nothing(B, p):
+    """g2v_gru_dir_bwd.hn_*: the straight-through + commitment gradient (g2v_vq_bwd, reference :1285-1292) formed by the encoder's
+    BPTT kernel where it reads its incoming gradient, against the separate launch: the same fma per element, so three fused
+    train steps must leave bitwise equal state (epoch 0 -- the commitment term switched off -- included)."""
+    T, D, H, K = 34, 135, 64, 512
+    sd = O.init_vqvae_state(D, H, 2, K, seed=21)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(270 + s)).to(DEV) for s in range(3)]
+    got = {}
+    for fused in (False, True):
+        eng = _engine(sd, D, H, K, T, p)
+        eng.seed = 5
+        eng._fuse_vq_bwd = fused
+        for s, x in enumerate(xs):
+            eng.train_step(x, x, epoch=s, **kw)          # epoch 0: g_loss_vq = 0
+        torch.cuda.synchronize()
+        got[fused] = eng
+    ref, eng = got[False], got[True]
+    for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars", "loss_terms"):
+        assert torch.equal(getattr(eng, name), getattr(ref, name)), name
