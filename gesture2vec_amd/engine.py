@@ -158,6 +158,10 @@ class VQVAEEngine:
         self.vq_scalars = torch.zeros(2, device=dev)          # loss_vq, perplexity
         self.loss_terms = torch.zeros(5, device=dev)          # custom_loss total, l1, cont, var, mse
         self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
+        # the soft quantiser's fused sequence (_forward_gssoft / _backward_gssoft): d total / d loss_vq as the step has it (host
+        # float baked into the launch arguments + the same value on the device), and 1 + beta
+        self._g_vq_host, self._g_vq_dev = 1.0 / 400.0, self.g_loss_vq
+        self._one_plus_beta = torch.full((1,), 1.0 + float(beta), device=dev)
         self._bufs: Dict[int, dict] = {}
         self._wstruct = None
         # tensors with requires_grad == False in the reference (autoencoder_fixed_weight == "True" freezes the decoder GRU,
@@ -259,7 +263,7 @@ class VQVAEEngine:
 
     def _branches_ok(self, B: int) -> bool:
         """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""
-        return B >= self.overlap_min_rows and self.quantizer == "ema"
+        return B >= self.overlap_min_rows
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
@@ -348,7 +352,7 @@ class VQVAEEngine:
         gr.d_bn_w, gr.d_bn_b = self._g(pre + "pre_linear.1.weight"), self._g(pre + "pre_linear.1.bias")
         gr.bn_bwd_partial = _p(b["bn_bwd_partial"])
         # GRU weight gradients accumulated inside the persistent backward kernel: bit m <-> (ih0, hh0, ih1, hh1)
-        b["fused_wgrad"] = int(self.lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H)) if self.quantizer == "ema" else 0
+        b["fused_wgrad"] = int(self.lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H))
         names = [("gru.weight_ih_l0", "gru.bias_ih_l0"), ("gru.weight_hh_l0", "gru.bias_hh_l0"),
                  ("gru.weight_ih_l1", "gru.bias_ih_l1"), ("gru.weight_hh_l1", "gru.bias_hh_l1")]
         for m, (wn, bn) in enumerate(names):
@@ -373,7 +377,7 @@ class VQVAEEngine:
         mode = int(os.environ.get("G2V_ENC_FUSED_WGRAD", "1"))
         if mode not in (0, 1, 2):
             raise ValueError(f"G2V_ENC_FUSED_WGRAD={mode}: 0 (separate products), 1 (W_hh inside the recurrent kernel) or 2 (W_hh and W_ih)")
-        b["enc_fused_wgrad"] = mode if (H == 64 and self.quantizer == "ema") else 0
+        b["enc_fused_wgrad"] = mode if H == 64 else 0
         if b["enc_fused_wgrad"]:
             n = int(self.lib.g2v_gru_seq_bwd_wslab_bytes(B, H))
             b["enc_wslab"] = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -429,9 +433,8 @@ class VQVAEEngine:
                 n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
-        if self.quantizer != "ema":
-            raise NotImplementedError("the fused forward is the EMA quantiser's; other quantisers go through "
-                                      "forward_encoder / forward_decoder (Autoencoder_VQVAE.forward does)")
+        if self.quantizer == "gssoft":
+            return self._forward_gssoft(in_poses, out_poses, training, loss_w)
         lib, st = self.lib, self._stream()
         B = in_poses.shape[0]
         H, E, K = self.H, self.E, self.K
@@ -587,8 +590,8 @@ class VQVAEEngine:
     def backward(self, in_poses: torch.Tensor, B: int, g_loss_vq: Optional[torch.Tensor] = None):
         """Backward of forward(training=True): expects buffers['dy'] = dLoss/d y (T,B,D).  Writes every parameter
         gradient into the flat grad buffer (overwrite, not accumulate)."""
-        if self.quantizer != "ema":
-            raise NotImplementedError("fused backward = EMA quantiser; see backward_decoder / backward_encoder")
+        if self.quantizer == "gssoft":
+            return self._backward_gssoft(in_poses, B)
         H, E = self.H, self.E
         b = self.backward_decoder(B, wgrad_branch=True)
         # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
@@ -604,6 +607,89 @@ class VQVAEEngine:
                                       self.beta, self._stream()))
             self._release()
             self.backward_encoder(in_poses, B)
+        self._join(2)
+
+    # ------------------------------------------------------------------ the as-shipped soft quantiser, without autograd
+    def _gs_buffers(self, B: int) -> dict:
+        b = self.buffers(B)
+        if "gs_probs" not in b:
+            N, E, K, dev = (2 * B * self.H) // self.E, self.E, self.K, self.device
+            z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=dev)
+            b.update({"gs_flat": z(N, E), "gs_logvar": z(N, K), "gs_dist": z(N, K), "gs_probs": z(N, K), "gs_q": z(N, E),
+                      "gs_dq": z(N, E), "gs_dprobs": z(N, K), "gs_dd": z(N, K), "gs_dlv": z(N, K), "gs_rowsum": z(N),
+                      "gs_t": z(N, E), "gs_dflat": z(N, E), "gs_tw": z(K, E), "gs_colsum": z(K), "gs_mse": z(1),
+                      "gs_mse_partial": z(self.lib.g2v_mse_blocks(N * E)),
+                      "gs_ws": torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(N, E, K),
+                                               self.lib.g2v_linear_bwd_weight_workspace(N, E, E), 256), dtype=torch.uint8, device=dev)})
+        return b
+
+    def _forward_gssoft(self, in_poses, out_poses, training, loss_w):
+        """Autoencoder_VQVAE.forward with VQ_Payam_GSSoft (reference :816-820, class :1304-1438) as one kernel sequence:
+        mean_layer -> logvar_layer, distances -> soft assignment probabilities (+ perplexity) -> q = probs W ->
+        loss_vq = q_latent + beta e_latent, straight-through value -> rollout.  The arithmetic (and the kernels) of the module
+        path gesture2vec_amd/model/Autoencoder_VQVAE_model.py: VQ_Payam_GSSoft.forward, no autograd graph."""
+        lib, st = self.lib, self._stream()
+        B = in_poses.shape[0]
+        H, E, K = self.H, self.E, self.K
+        N = (2 * B * H) // E
+        b = self.forward_encoder(in_poses, training)
+        self._join(0)
+        g = self._gs_buffers(B)
+        vq = "vq_layer."
+        W = self._w(vq + "_embedding.weight")
+        x = _p(b["enc_hidden"])
+        check(lib.g2v_linear_fwd(x, E, 0, 0, 0, None, 1.0, self._w(vq + "mean_layer.weight"), self._w(vq + "mean_layer.bias"),
+                                 _p(g["gs_flat"]), E, N, E, E, 0, st))
+        check(lib.g2v_linear_fwd(_p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, self._w(vq + "logvar_layer.weight"),
+                                 self._w(vq + "logvar_layer.bias"), _p(g["gs_logvar"]), K, N, E, K, 0, st))
+        check(lib.g2v_vq_code_sqnorm(W, _p(self.code_sqnorm), K, E, st))
+        check(lib.g2v_linear_fwd(_p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dist"]), K, N, E, K, 0, st))
+        check(lib.g2v_vq_soft_fwd(_p(g["gs_flat"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(self.code_sqnorm), _p(g["gs_probs"]),
+                                  self.vq_scalars[1:].data_ptr(), N, E, K, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_probs"]), K, W, _p(g["gs_q"]), E, N, E, K, 0, st))          # q = probs W (:1417-1419)
+        # both latent losses are mean((x - q)^2) (:1424-1425); their gradients go to x and to q separately (backward)
+        check(lib.g2v_mse_fwd_bwd(_p(g["gs_q"]), x, _p(g["gs_dq"]), _p(g["gs_mse"]), _p(g["gs_mse_partial"]), N * E,
+                                  float(self._g_vq_host), st))
+        check(lib.g2v_scale_f32(_p(g["gs_mse"]), _p(self._one_plus_beta), _p(self.vq_scalars), 1, st))      # loss_vq (:1427)
+        check(lib.g2v_ste_f32(x, _p(g["gs_q"]), _p(b["quant"]), N * E, st))                                 # inputs + (q - inputs).detach()
+        return self.forward_decoder(out_poses, B, training, loss_w=loss_w)
+
+    def _backward_gssoft(self, in_poses, B):
+        """Backward of _forward_gssoft (expects buffers['dy']): the module path's autograd functions (_STEFn, _ProbsCodebookFn,
+        _SoftAssignFn, the two nn.Linear) as one kernel sequence; every parameter gradient into the flat grad buffer."""
+        lib, st = self.lib, self._stream()
+        H, E, K = self.H, self.E, self.K
+        N = (2 * B * H) // E
+        b = self.backward_decoder(B, wgrad_branch=True)
+        self._release()
+        g = self._gs_buffers(B)
+        vq = "vq_layer."
+        W, gW = self._w(vq + "_embedding.weight"), self._g(vq + "_embedding.weight")
+        ws, wsn = _p(g["gs_ws"]), g["gs_ws"].numel()
+        x = _p(b["enc_hidden"])
+        # to the encoder state directly: the straight-through path + the commitment term (gs_dq holds g 2 (q - x) / n)
+        check(lib.g2v_vq_bwd(_p(b["dh_init"]), _p(self._g_vq_dev), x, _p(g["gs_q"]), None, _p(b["gz"]), N, E, self.beta, st))
+        # q = probs W  <-  dq (the q_latent term):  dprobs = dq W^T,  dW += probs^T dq
+        check(lib.g2v_linear_fwd(_p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dprobs"]), K, N, E, K, 0, st))
+        # probabilities <- distances, logvar (reference :1349-1372, 1396-1411)
+        check(lib.g2v_vq_soft_bwd(_p(g["gs_probs"]), _p(g["gs_dprobs"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(g["gs_dd"]),
+                                  _p(g["gs_dlv"]), _p(g["gs_rowsum"]), N, K, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_dd"]), K, W, _p(g["gs_t"]), E, N, E, K, 0, st))
+        check(lib.g2v_rowscale_combine(_p(g["gs_flat"]), _p(g["gs_rowsum"]), _p(g["gs_t"]), _p(g["gs_dflat"]), N, E, st))
+        check(lib.g2v_linear_bwd_weight(_p(g["gs_dd"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, _p(g["gs_tw"]),
+                                        _p(g["gs_colsum"]), N, E, K, 0, ws, wsn, st))
+        check(lib.g2v_rowscale_combine(W, _p(g["gs_colsum"]), _p(g["gs_tw"]), gW, K, E, st))               # 2 W sum_n dd - 2 dd^T f
+        check(lib.g2v_linear_bwd_weight(_p(g["gs_probs"]), K, _p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, gW, None, N, E, K, 1,
+                                        ws, wsn, st))                                                       # += probs^T dq
+        # logvar_layer, mean_layer
+        check(lib.g2v_linear_bwd_weight(_p(g["gs_dlv"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0,
+                                        self._g(vq + "logvar_layer.weight"), self._g(vq + "logvar_layer.bias"), N, E, K, 0,
+                                        ws, wsn, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_dlv"]), K, self._w(vq + "logvar_layer.weight"), _p(g["gs_dflat"]), E, N, E, K, 1, st))
+        check(lib.g2v_linear_bwd_weight(_p(g["gs_dflat"]), E, x, E, 0, 0, 0, None, 1.0, self._g(vq + "mean_layer.weight"),
+                                        self._g(vq + "mean_layer.bias"), N, E, E, 0, ws, wsn, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_dflat"]), E, self._w(vq + "mean_layer.weight"), _p(b["gz"]), E, N, E, E, 1, st))
+        self.backward_encoder(in_poses, B)
         self._join(2)
 
     def _wgrad_fns(self, b, M_default, ws_key="ws"):
@@ -769,7 +855,7 @@ class VQVAEEngine:
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
         self._branches_on = B >= self.overlap_min_rows
-        self._prepared = self._branches_on and (self.overlap & 9) == 9 and self.quantizer == "ema"
+        self._prepared = self._branches_on and (self.overlap & 9) == 9
         try:
             self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)
         finally:
@@ -780,21 +866,23 @@ class VQVAEEngine:
         if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
             self.draw_masks(B, True)
         def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
-            self.vq_derive()                   # needed first: the quantiser follows the encoder directly
+            if self.quantizer == "ema":
+                self.vq_derive()               # needed first: the quantiser follows the encoder directly
             if draw_masks and self.p == 0:
                 self.draw_masks(B, True)       # only the rollout consumes keep95
             if self._prepared:
                 self.prepare_recurrent(B, "dec")
                 self.prepare_recurrent(B, "gru_bwd")
         self._side_work = side
+        g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
+        self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)
         self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var))
         self.loss(B, target, w_l1, w_cont, w_var, True)
-        g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self.backward(x, B, g_vq)
 
     def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),
                          eps: float = 1e-8, max_norm: float = 5.0):
         """(after the all-reduce) EMA codebook update from the GLOBAL statistics, then clip + Adam on the averaged grads."""
-        if dp:
+        if dp and self.quantizer == "ema":
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0)

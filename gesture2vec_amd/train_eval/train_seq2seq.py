@@ -90,7 +90,7 @@ def train_iter_Autoencoder_VQ_seq2seq(args, epoch: int, input_poses: torch.Tenso
         optim.step()
         return {"loss": loss.item()}, perplexity_vq.detach()
     optim = _as_fused(net, optim)
-    if getattr(net, "quantizer", "ema") == "ema" and optim.net is net and net.training:
+    if getattr(net, "quantizer", "ema") in ("ema", "gssoft") and optim.net is net and net.training and _FUSED_GSSOFT_OK(net):
         # the whole iteration as ONE kernel sequence of the engine (no autograd graph, one host sync for loss.item())
         return _fused_iteration(args, epoch, input_poses, target_poses, net, optim, None, 1)
     optim.zero_grad()
@@ -159,6 +159,12 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
 
 import os as _os
 _GRAPH_REPLAY = _os.environ.get("G2V_TRAIN_ITER_GRAPH", "1") != "0"
+
+
+def _FUSED_GSSOFT_OK(net) -> bool:
+    """the EMA quantiser always takes the fused iteration; the soft quantiser (what the reference ships) does unless
+    G2V_GSSOFT_FUSED=0 selects the module-level autograd path (A/B, parity tests)"""
+    return getattr(net, "quantizer", "ema") == "ema" or _os.environ.get("G2V_GSSOFT_FUSED", "1") != "0"
 
 
 def _replayed_step(eng, x, tgt, kw):

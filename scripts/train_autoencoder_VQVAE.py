@@ -129,14 +129,14 @@ def train_epochs(args, train_data_loader, train_sim_dataset, test_data_loader, l
     gen_optimizer = FusedClipAdam(generator, lr=args.learning_rate, betas=(0.5, 0.999))
     reduce_fn = None
     if _DIST:
-        if generator.quantizer != "ema":
-            raise NotImplementedError("data-parallel training exchanges the EMA quantiser's statistics; "
-                                      "autoencoder_vq_quantizer='gssoft' trains on one GPU")
         from gesture2vec_amd.dp import GradStatsAllReduce, broadcast_state
         generator.rng_seed = 1234 + _RANK                               # independent dropout masks per shard
         eng, vq = generator.engine(), generator.vq_layer
-        broadcast_state([eng.flat, vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size,
-                         vq.pre_linear.weight.data, vq.pre_linear.bias.data, eng.bn_rm, eng.bn_rv])
+        if generator.quantizer == "ema":
+            broadcast_state([eng.flat, vq._embedding.weight.data, vq._ema_w.data, vq._ema_cluster_size,
+                             vq.pre_linear.weight.data, vq.pre_linear.bias.data, eng.bn_rm, eng.bn_rv])
+        else:       # the soft quantiser (what the reference ships): every trainable tensor lives in the flat buffer; gradients only
+            broadcast_state([eng.flat, vq.pre_linear.weight.data, vq.pre_linear.bias.data, eng.bn_rm, eng.bn_rv])
         reduce_fn = GradStatsAllReduce()
     val_metrics_list, loss_list = [], []
     first_epoch = 1
