@@ -146,3 +146,41 @@ def test_fused_soft_quantiser_step_equals_the_autograd_path(B, p, mode, monkeypa
         assert abs(l0 - l1) <= 2e-5 * abs(l0) and abs(p0 - p1) <= 1e-4 * abs(p0), (l0, l1, p0, p1)
     err = float((out["0"][1] - out["1"][1]).abs().max())
     assert err <= 4 * 5e-4 * 0.02 + 1e-6, err          # a few per cent of the 4 Adam steps' lr
+
+
+def test_soft_quantiser_data_parallel_halves_on_one_gpu():
+    """Two engine replicas play rank 0 / 1 (as tests/test_gpu_dp_engine.py does for the EMA model): train_step_local on each
+    shard, the comm buffers summed by hand (= the RCCL SUM all-reduce), train_step_apply(world=2) on both.  The replicas must end
+    bitwise identical, and equal to a third engine that is handed the MEAN of the two local gradients."""
+    from gesture2vec_amd.engine import VQVAEEngine
+    B, T, D, H, K = 64, 34, 135, 64, 512
+    kw = dict(w_l1=5.0, w_cont=0.1, w_var=0.5)
+    g = torch.Generator().manual_seed(9)
+    init = None
+    engs = []
+    for r in range(3):
+        eng = VQVAEEngine(D, H, 2, K, T, beta=0.25, dropout_prob=0.0, device=DEV, quantizer="gssoft")
+        if init is None:
+            init = (torch.randn(eng.n_flat, generator=g) * 0.08).to(DEV)
+        eng.flat.copy_(init)
+        eng.bn_rv.fill_(1.0)
+        eng.seed = 100 + r
+        engs.append(eng)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(50 + r)).to(DEV) for r in range(2)]
+    for step in range(2):
+        for r in range(2):
+            engs[r].train_step_local(xs[r], xs[r], dp=True, epoch=1, **kw)
+        torch.cuda.synchronize()
+        local = [engs[r].comm.clone() for r in range(2)]
+        total = local[0] + local[1]
+        for r in range(2):
+            engs[r].comm.copy_(total)
+            engs[r].train_step_apply(B, lr=5e-4, world=2, dp=True)
+        # the reference of the apply half: mean gradient -> clip 5 -> Adam, on the third engine
+        engs[2].gflat.copy_(total[:engs[2].n_flat] / 2)
+        engs[2].optimizer_step(5e-4)
+        torch.cuda.synchronize()
+        assert torch.equal(engs[0].flat, engs[1].flat), step
+        err = float((engs[0].flat - engs[2].flat).abs().max())
+        assert err <= 1e-6, (step, err)
+        xs = [x + 0.01 for x in xs]
