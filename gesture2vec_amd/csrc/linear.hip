@@ -1415,8 +1415,13 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
 }
 
 // measured at the reference's own VQ-VAE.yml shape (B = 128, T = 20: 2432 / 2560 rows, 600 x 200): the LDS-tiled kernel + slab
-// pass 20.6 + 7 us per product, so the one-launch form keeps the rows up to 4096
-static int g_smallm_wgrad_rows = 4096;
+// pass 20.6 + 7 us per product, so the one-launch form keeps the rows BELOW 4096; from 4096 rows the output-blocked wave
+// kernel takes over (the soft quantiser's products at N = 4096: 512 x 128 22 us against 32, 128 x 128 16 against 31)
+static int smallm_wgrad_rows_init() {      // G2V_SMALLM_WGRAD_ROWS: measurement only
+  const char* e = getenv("G2V_SMALLM_WGRAD_ROWS");
+  return e ? atoi(e) : 4095;
+}
+static int g_smallm_wgrad_rows = smallm_wgrad_rows_init();
 
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.

@@ -620,7 +620,8 @@ class VQVAEEngine:
                       "gs_t": z(N, E), "gs_dflat": z(N, E), "gs_tw": z(K, E), "gs_colsum": z(K), "gs_mse": z(1),
                       "gs_mse_partial": z(self.lib.g2v_mse_blocks(N * E)),
                       "gs_ws": torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(N, E, K),
-                                               self.lib.g2v_linear_bwd_weight_workspace(N, E, E), 256), dtype=torch.uint8, device=dev)})
+                                               self.lib.g2v_linear_bwd_weight_workspace(N, E, E),
+                                               self.lib.g2v_vq_soft_perplexity_workspace(N, K), 256), dtype=torch.uint8, device=dev)})
         return b
 
     def _forward_gssoft(self, in_poses, out_poses, training, loss_w):
@@ -645,7 +646,9 @@ class VQVAEEngine:
         check(lib.g2v_vq_code_sqnorm(W, _p(self.code_sqnorm), K, E, st))
         check(lib.g2v_linear_fwd(_p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dist"]), K, N, E, K, 0, st))
         check(lib.g2v_vq_soft_fwd(_p(g["gs_flat"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(self.code_sqnorm), _p(g["gs_probs"]),
-                                  self.vq_scalars[1:].data_ptr(), N, E, K, st))
+                                  None, N, E, K, st))
+        check(lib.g2v_vq_soft_perplexity(_p(g["gs_probs"]), self.vq_scalars[1:].data_ptr(), N, K, _p(g["gs_ws"]),
+                                         g["gs_ws"].numel(), st))
         check(lib.g2v_linear_bwd_data(_p(g["gs_probs"]), K, W, _p(g["gs_q"]), E, N, E, K, 0, st))          # q = probs W (:1417-1419)
         # both latent losses are mean((x - q)^2) (:1424-1425); their gradients go to x and to q separately (backward)
         check(lib.g2v_mse_fwd_bwd(_p(g["gs_q"]), x, _p(g["gs_dq"]), _p(g["gs_mse"]), _p(g["gs_mse_partial"]), N * E,

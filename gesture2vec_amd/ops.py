@@ -588,8 +588,11 @@ def vq_soft_fwd(flat, dots, logvar, wsq, want_perplexity=True):
     K = dots.shape[1]
     probs = torch.empty((N, K), dtype=torch.float32, device=flat.device)
     perp = torch.empty((1,), dtype=torch.float32, device=flat.device) if want_perplexity else None
-    check(_lib_().g2v_vq_soft_fwd(_p(_chk(flat)), _p(_chk(dots)), _p(_chk(logvar)), _p(_chk(wsq)), _p(probs), _p(perp), N, E, K,
+    check(_lib_().g2v_vq_soft_fwd(_p(_chk(flat)), _p(_chk(dots)), _p(_chk(logvar)), _p(_chk(wsq)), _p(probs), None, N, E, K,
                                   _stream()), "vq_soft_fwd")
+    if want_perplexity:        # its own device-wide pair of launches (the one built into g2v_vq_soft_fwd is a single workgroup)
+        ws = torch.empty(int(_lib_().g2v_vq_soft_perplexity_workspace(N, K)), dtype=torch.uint8, device=flat.device)
+        check(_lib_().g2v_vq_soft_perplexity(_p(probs), _p(perp), N, K, _p(ws), ws.numel(), _stream()), "vq_soft_perplexity")
     return probs, dots, perp
 
 
