@@ -146,6 +146,7 @@ _SIGS = {
     "g2v_fill_f32": (c_int, [c_fp, c_f, c_i64, c_fp]),
     "g2v_scale_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     "g2v_mask_mul": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_i64, c_fp]),
+    "g2v_mask_rows": (c_int, [c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_f, c_fp, c_i64, c_int, c_int, c_fp]),
     "g2v_transpose": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_add_halves": (c_int, [c_fp, c_i64, c_fp, c_i64, c_fp, c_i64, c_i64, c_int, c_fp]),
 }

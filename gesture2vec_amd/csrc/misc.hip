@@ -485,6 +485,31 @@ extern "C" int g2v_mask_mul(const float* in, const uint8_t* keep, const float* p
   return G2V_OK;
 }
 
+// one wave per row: K consecutive floats of the (row-mapped) input, the K keep bytes of the output row
+__global__ __launch_bounds__(256) void mask_rows_kernel(const float* __restrict__ x, int64_t ldx, int rows_inner, int64_t so, int64_t si,
+                                                        const uint8_t* __restrict__ keep, float scale, float* __restrict__ out,
+                                                        int64_t ldo, int M, int K) {
+  const int lane = threadIdx.x & 63;
+  for (int m = blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += gridDim.x * 4) {
+    const float* xr = x + (rows_inner > 0 ? (int64_t)(m / rows_inner) * so + (int64_t)(m % rows_inner) * si : (int64_t)m * ldx);
+    const uint8_t* kr = keep + (int64_t)m * K;
+    float* o = out + (int64_t)m * ldo;
+    for (int k = lane; k < K; k += 64) o[k] = kr[k] ? xr[k] * scale : 0.f;
+  }
+}
+
+extern "C" int g2v_mask_rows(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
+                             const uint8_t* keep, float scale, float* out, int64_t ldo, int M, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(x && keep && out, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && ldo >= K, "bad size");
+  int blocks = cdiv(M, 4);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows_inner, stride_outer,
+                     stride_inner, keep, scale, out, ldo, M, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream) {
   G2V_REQUIRE(in && out, "null pointer");
   G2V_REQUIRE(rows > 0 && cols > 0, "bad size");

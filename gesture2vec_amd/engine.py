@@ -305,6 +305,9 @@ class VQVAEEngine:
         G = 3 * H
         b = {
             "keep_in": u8(T, B, D) if self.p > 0 else None,
+            # the encoder's dropped input self.do(inputs) (:88-93) as a (T,B,D) tensor of its own: in_layer's forward product and
+            # its weight gradient then run on their unmasked fast kernels (the masked forms: 79 + 196 us at B = 4096, these 82 + 53)
+            "x_drop": z(T * B, D) if self.p > 0 else None,
             "keep95": u8(T - 1, B, D),
             "keep_l0": u8(T - 1, B, H) if self.p > 0 else None,
             "xin": z(T * B, H), "gi_f": z(T * B, G), "gi_b": z(T * B, G),
@@ -411,13 +414,19 @@ class VQVAEEngine:
             check(lib.g2v_dec_rollout_prepare(C.byref(self.dec_wstruct()), self.D, self.H, _p(b["ws_decf"]), b["ws_decf"].numel(),
                                               _p(b["ws_decb"]), b["ws_decb"].numel(), st))
 
-    def draw_masks(self, B: int, training: bool):
+    def draw_masks(self, B: int, training: bool, which: str = "all"):
+        """which: "all"; "in" = only the encoder's input mask (needed by the step's first kernel); "rest" = the others (the fused
+        step draws them in branch 0, beside the encoder GRU).  The Philox offset counter ticks once per mask in launch order:
+        in, 95, l0."""
         b = self.buffers(B)
         st = self._stream()
-        check(self.lib.g2v_keep_mask(_p(b["keep95"]), b["keep95"].numel(), 0.05, self.seed, _p(self.rng_counter), st))
-        if training and self.p > 0:
+        drop = training and self.p > 0
+        if drop and which in ("all", "in"):
             check(self.lib.g2v_keep_mask(_p(b["keep_in"]), b["keep_in"].numel(), 1 - self.p, self.seed + 1, _p(self.rng_counter), st))
-            check(self.lib.g2v_keep_mask(_p(b["keep_l0"]), b["keep_l0"].numel(), 1 - self.p, self.seed + 2, _p(self.rng_counter), st))
+        if which in ("all", "rest"):
+            check(self.lib.g2v_keep_mask(_p(b["keep95"]), b["keep95"].numel(), 0.05, self.seed, _p(self.rng_counter), st))
+            if drop:
+                check(self.lib.g2v_keep_mask(_p(b["keep_l0"]), b["keep_l0"].numel(), 1 - self.p, self.seed + 2, _p(self.rng_counter), st))
 
     def set_masks(self, B: int, keep95, keep_in=None, keep_l0=None):
         """Explicit keep masks (parity tests): keep95 (T-1,B,D), keep_in (T,B,D), keep_l0 (T-1,B,H)."""
@@ -490,10 +499,16 @@ class VQVAEEngine:
         drop_in = training and self.p > 0
         enc = "encoder."
         # ---- EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU -----------------------
-        check(lib.g2v_linear_fwd(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]) if drop_in else None,
-                                 1.0 / (1.0 - self.p) if drop_in else 1.0,
-                                 self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
-                                 _p(b["xin"]), H, T * B, D, H, 0, st))
+        b["enc_dropped"] = drop_in
+        if drop_in:
+            check(lib.g2v_mask_rows(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]), 1.0 / (1.0 - self.p), _p(b["x_drop"]), D,
+                                    T * B, D, st))
+            check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
+                                     self._w(enc + "in_layer.bias"), _p(b["xin"]), H, T * B, D, H, 0, st))
+        else:
+            check(lib.g2v_linear_fwd(_p(in_poses), D, B, D, T * D, None, 1.0,
+                                     self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
+                                     _p(b["xin"]), H, T * B, D, H, 0, st))
         # work of branch 0 (rollout masks, ahead-of-time packs): forked HERE, behind the input layer -- beside that HBM-bound
         # product the mask kernel doubled its time (36 -> 67 us on the main chain), beside the latency-bound GRU it is free
         side, self._side_work = getattr(self, "_side_work", None), None
@@ -769,7 +784,7 @@ class VQVAEEngine:
         T, D, H, G = self.T, self.D, self.H, 3 * self.H
         b = self.buffers(B)
         ws, wsn = _p(b["ws"]), b["ws"].numel()
-        drop = self.p > 0
+        drop = bool(b.get("enc_dropped", False))      # did this batch's forward_encoder drop its input (x_drop is its tensor)
         wgrad, wgrad4 = self._wgrad_fns(b, T * B)
         enc = "encoder."
         dirs = (_lib.GruDirBwd * 2)()
@@ -812,13 +827,19 @@ class VQVAEEngine:
                 items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
             if b["enc_fused_wgrad"] < 2:
                 wgrad4s(TB, items)
-        sum2 = (H == 64 and not drop and not self.wgrad_bf16x3 and os.environ.get("G2V_WGRAD_SUM2", "1") != "0"
+        sum2 = (H == 64 and not self.wgrad_bf16x3 and os.environ.get("G2V_WGRAD_SUM2", "1") != "0"
                 and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H))
         if sum2:
-            # the two directions' dx are summed inside the input layer's weight-gradient product (no add pass)
-            check(lib.g2v_linear_bwd_weight_sum2(_p(b["gi_f"]), _p(b["gi_b"]), H, _p(in_poses), D, B, D, T * D,
-                                                 self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"),
-                                                 TB, D, H, 0, ws, wsn, st))
+            # the two directions' dx are summed inside the input layer's weight-gradient product (no add pass); with input
+            # dropout the layer's input is the dropped tensor the forward left in x_drop
+            if drop:
+                check(lib.g2v_linear_bwd_weight_sum2(_p(b["gi_f"]), _p(b["gi_b"]), H, _p(b["x_drop"]), D, 0, 0, 0,
+                                                     self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"),
+                                                     TB, D, H, 0, ws, wsn, st))
+            else:
+                check(lib.g2v_linear_bwd_weight_sum2(_p(b["gi_f"]), _p(b["gi_b"]), H, _p(in_poses), D, B, D, T * D,
+                                                     self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"),
+                                                     TB, D, H, 0, ws, wsn, st))
             self._join(4)
             return
         if H == 64:
@@ -826,9 +847,11 @@ class VQVAEEngine:
         else:
             check(lib.g2v_linear_bwd_data(_p(b["dgi_f"]), G, self._w(enc + "gru.weight_ih_l0"), _p(b["dxin"]), H, TB, H, G, 0, st))
             check(lib.g2v_linear_bwd_data(_p(b["dgi_b"]), G, self._w(enc + "gru.weight_ih_l0_reverse"), _p(b["dxin"]), H, TB, H, G, 1, st))
-        wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
-              row_map=(B, D, T * D), keep=_p(b["keep_in"]) if drop else None,
-              scale=1.0 / (1.0 - self.p) if drop else 1.0)
+        if drop:
+            wgrad(_p(b["dxin"]), H, _p(b["x_drop"]), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB)
+        else:
+            wgrad(_p(b["dxin"]), H, _p(in_poses), D, enc + "in_layer.weight", enc + "in_layer.bias", H, D, rows=TB,
+                  row_map=(B, D, T * D))
         self._join(4)
         # encoder GRU layer 1 receives exactly-zero gradients (dead compute in the reference); the flat grad
         # buffer is zero there from construction and nothing ever writes it.
@@ -867,12 +890,12 @@ class VQVAEEngine:
 
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
-            self.draw_masks(B, True)
+            self.draw_masks(B, True, "in")
         def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
             if self.quantizer == "ema":
                 self.vq_derive()               # needed first: the quantiser follows the encoder directly
-            if draw_masks and self.p == 0:
-                self.draw_masks(B, True)       # only the rollout consumes keep95
+            if draw_masks:
+                self.draw_masks(B, True, "rest")       # only the rollout consumes keep95 / keep_l0
             if self._prepared:
                 self.prepare_recurrent(B, "dec")
                 self.prepare_recurrent(B, "gru_bwd")

@@ -566,6 +566,12 @@ int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g
  * (dropout / ReLU backward of the thin dense models). */
 int g2v_mask_mul(const float* in, const uint8_t* keep, const float* positive_of, float scale, float* out,
                  int64_t n, g2v_stream_t stream);
+/* out[m, k] = keep[m K + k] ? x[row(m), k] * scale : 0 for m < M, k < K -- the dropped input of a dense layer as a tensor of its
+ * own (row addressing of x as in g2v_linear_fwd; out rows at stride ldo).  The encoder's input dropout
+ * (model/Autoencoder_VQVAE_model.py:88-93: self.do(inputs) in front of in_layer) uses it once per step, so that the forward
+ * product and the weight-gradient product both run on their unmasked fast kernels. */
+int g2v_mask_rows(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner, const uint8_t* keep,
+                  float scale, float* out, int64_t ldo, int M, int K, g2v_stream_t stream);
 int g2v_transpose(const float* in, float* out, int rows, int cols, g2v_stream_t stream); /* out[c][r] = in[r][c] */
 /* out[m, 0:H] = a[m, 0:H] + b[m, 0:H] with row strides (sum of the two GRU directions, :95-97) */
 int g2v_add_halves(const float* a, int64_t lda, const float* b, int64_t ldb, float* out, int64_t ldo,
