@@ -450,7 +450,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
       if (training) {
         // (fold: this step's target values travel beside the sweep; every reader of the tile finished inside hop 1)
-        if (fold) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() { target_request(t); });
+        if (!px_two_hops(a.nblk)) {          // one row of workgroups: hop 1's row sum is the total
+          if (fold) target_request(t);
+        } else if (fold) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() { target_request(t); });
         else px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
         PSTAMP(0, 11);
         // (a wave whose lanes all sit out the sweep -- small batches -- has not waited for its LDS-DMA yet; the readers of the

@@ -185,10 +185,13 @@ __device__ __forceinline__ void px_hop2(const PersistX& x, int par, unsigned tag
                [&](int m) { return m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP); }, tag, red, tot, tid, 3,
                static_cast<Filler&&>(filler));
 }
+// One row of workgroups only (nblk <= PX_GROUP, i.e. batches up to 256 rows -- the reference's own 128): the row sum hop 1
+// leaves in tot IS the total (hop 2 would add one record to zero: the same bits), so the second hop is skipped.
+__device__ __forceinline__ bool px_two_hops(int nblk) { return nblk > PX_GROUP; }
 __device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot,
                                             int tid) {
   px_hop1(x, par, tag, nblk, b, red, tot, tid);
-  px_hop2(x, par, tag, nblk, b, red, tot, tid);
+  if (px_two_hops(nblk)) px_hop2(x, par, tag, nblk, b, red, tot, tid);
 }
 
 }  // namespace g2v
