@@ -143,6 +143,9 @@ _SIGS = {
     "g2v_probe_mfma_f32": (c_int, [c_fp, c_int, c_int, c_fp]),
     "g2v_probe_copy": (c_int, [c_fp, c_fp, c_i64, c_fp]),
     "g2v_keep_mask": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_fp]),
+    "g2v_keep_mask_at": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_i64, c_fp]),
+    "g2v_counter_add": (c_int, [c_fp, c_i64, c_fp]),
+    "g2v_dropout_rows": (c_int, [c_fp, c_i64, c_int, c_i64, c_i64, c_f, c_f, c_u64, c_fp, c_i64, c_fp, c_i64, c_int, c_int, c_fp]),
     "g2v_fill_f32": (c_int, [c_fp, c_f, c_i64, c_fp]),
     "g2v_scale_f32": (c_int, [c_fp, c_fp, c_fp, c_i64, c_fp]),
     "g2v_mask_mul": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_i64, c_fp]),

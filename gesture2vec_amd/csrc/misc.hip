@@ -245,10 +245,10 @@ __device__ __forceinline__ uint32_t philox_keep4(int64_t g, uint64_t off, uint64
 }
 template <bool ALIGNED16>
 __global__ __launch_bounds__(256) void keep_mask_kernel(uint8_t* __restrict__ keep, int64_t n, float keep_prob, uint64_t seed,
-                                                        const int64_t* __restrict__ offset_counter) {
+                                                        const int64_t* __restrict__ offset_counter, int64_t offset_add) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;   // elements 16 i .. 16 i + 15
   if (i * 16 >= n) return;
-  const uint64_t off = (uint64_t)offset_counter[0];
+  const uint64_t off = (uint64_t)(offset_counter[0] + offset_add);
   uint32_t w[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) w[k] = philox_keep4(4 * i + k, off, seed, keep_prob);
@@ -262,7 +262,30 @@ __global__ __launch_bounds__(256) void keep_mask_kernel(uint8_t* __restrict__ ke
     }
   }
 }
-__global__ void tick_kernel(int64_t* c) { c[0] += 1; }
+__global__ void tick_kernel(int64_t* c, int64_t n) { c[0] += n; }
+
+// Dropout of a (row-mapped) dense-layer input with the mask drawn in the same kernel: out[m, k] = keep(m K + k) ? x[row(m), k] *
+// scale : 0, keep(e) = element e of the g2v_keep_mask stream (seed, offset_counter[0] + offset_add): bit for bit what
+// g2v_keep_mask + g2v_mask_rows produce, without the mask tensor and its two passes.  One philox block (4 elements) per thread.
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ x, int64_t ldx, int rows_inner, int64_t so,
+                                                           int64_t si, float keep_prob, float scale, uint64_t seed,
+                                                           const int64_t* __restrict__ offset_counter, int64_t offset_add,
+                                                           float* __restrict__ out, int64_t ldo, int M, int K) {
+  const int64_t n = (int64_t)M * K;
+  const uint64_t off = (uint64_t)(offset_counter[0] + offset_add);
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g * 4 < n; g += (int64_t)gridDim.x * 256) {
+    const uint32_t w = philox_keep4(g, off, seed, keep_prob);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t e = g * 4 + j;
+      if (e < n) {
+        const int m = (int)(e / K), k = (int)(e - (int64_t)m * K);
+        const float* xr = x + (rows_inner > 0 ? (int64_t)(m / rows_inner) * so + (int64_t)(m % rows_inner) * si : (int64_t)m * ldx);
+        out[(int64_t)m * ldo + k] = ((w >> (8 * j)) & 0xffu) ? xr[k] * scale : 0.f;
+      }
+    }
+  }
+}
 
 __global__ void fill_kernel(float* __restrict__ p, float v, int64_t n) {
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) p[e] = v;
@@ -392,19 +415,40 @@ extern "C" int g2v_clip_adam_step(float* param, const float* grad, float* m, flo
   return G2V_OK;
 }
 
-extern "C" int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int64_t* offset_counter,
-                             g2v_stream_t stream) {
+extern "C" int g2v_keep_mask_at(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, const int64_t* offset_counter,
+                                int64_t offset_add, g2v_stream_t stream) {
   G2V_REQUIRE(keep && offset_counter, "null pointer");
   G2V_REQUIRE(n > 0, "bad size");
   const int64_t nthreads = (n + 15) / 16;
   if ((reinterpret_cast<uintptr_t>(keep) & 15) == 0)
     hipLaunchKernelGGL(keep_mask_kernel<true>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
-                       seed, offset_counter);
+                       seed, offset_counter, offset_add);
   else
     hipLaunchKernelGGL(keep_mask_kernel<false>, dim3(cdiv(nthreads, 256)), dim3(256), 0, (hipStream_t)stream, keep, n, keep_prob,
-                       seed, offset_counter);
+                       seed, offset_counter, offset_add);
   G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, offset_counter);
+  return G2V_OK;
+}
+extern "C" int g2v_counter_add(int64_t* counter, int64_t n, g2v_stream_t stream) {
+  G2V_REQUIRE(counter, "null pointer");
+  hipLaunchKernelGGL(tick_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, n);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+extern "C" int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int64_t* offset_counter,
+                             g2v_stream_t stream) {
+  const int rc = g2v_keep_mask_at(keep, n, keep_prob, seed, offset_counter, 0, stream);
+  return rc != G2V_OK ? rc : g2v_counter_add(offset_counter, 1, stream);
+}
+extern "C" int g2v_dropout_rows(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
+                                float keep_prob, float scale, uint64_t seed, const int64_t* offset_counter, int64_t offset_add,
+                                float* out, int64_t ldo, int M, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(x && out && offset_counter, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && ldo >= K, "bad size");
+  int64_t blocks = cdiv(((int64_t)M * K + 3) / 4, 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(dropout_rows_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, rows_inner, stride_outer,
+                     stride_inner, keep_prob, scale, seed, offset_counter, offset_add, out, ldo, M, K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -191,6 +191,7 @@ class VQVAEEngine:
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
         self._deferred: list = []
+        self._fused_in_drop = False
         # bit k: branch k is launched behind the main chain's next kernel (_fork).  Measured per branch at B = 4096: branch 0 (masks,
         # packs, vq_derive beside the encoder GRU) -5..-9 us per step; branch 1 (EMA statistics beside the forward rollout) +30 us --
         # arriving behind the persistent kernel it waits for the whole rollout; branch 2 (decoder weight gradients) +10 us -- they
@@ -415,18 +416,20 @@ class VQVAEEngine:
                                               _p(b["ws_decb"]), b["ws_decb"].numel(), st))
 
     def draw_masks(self, B: int, training: bool, which: str = "all"):
-        """which: "all"; "in" = only the encoder's input mask (needed by the step's first kernel); "rest" = the others (the fused
-        step draws them in branch 0, beside the encoder GRU).  The Philox offset counter ticks once per mask in launch order:
-        in, 95, l0."""
+        """The step's keep masks from the Philox stream (seed, offset counter): the encoder's input mask at counter + 0 (with input
+        dropout), the rollout's Dropout(0.95) mask at + 1 (+ 0 without input dropout), the decoder GRU's inter-layer mask at + 2;
+        ONE advance of the counter behind them.  which = "all", or "rest": everything but the input mask -- the fused step forms
+        the dropped input with the mask drawn inside that kernel (forward_encoder, g2v_dropout_rows: the same stream at + 0)."""
         b = self.buffers(B)
         st = self._stream()
         drop = training and self.p > 0
-        if drop and which in ("all", "in"):
-            check(self.lib.g2v_keep_mask(_p(b["keep_in"]), b["keep_in"].numel(), 1 - self.p, self.seed + 1, _p(self.rng_counter), st))
-        if which in ("all", "rest"):
-            check(self.lib.g2v_keep_mask(_p(b["keep95"]), b["keep95"].numel(), 0.05, self.seed, _p(self.rng_counter), st))
-            if drop:
-                check(self.lib.g2v_keep_mask(_p(b["keep_l0"]), b["keep_l0"].numel(), 1 - self.p, self.seed + 2, _p(self.rng_counter), st))
+        lib, ctr = self.lib, _p(self.rng_counter)
+        if drop and which == "all":
+            check(lib.g2v_keep_mask_at(_p(b["keep_in"]), b["keep_in"].numel(), 1 - self.p, self.seed + 1, ctr, 0, st))
+        check(lib.g2v_keep_mask_at(_p(b["keep95"]), b["keep95"].numel(), 0.05, self.seed, ctr, 1 if drop else 0, st))
+        if drop:
+            check(lib.g2v_keep_mask_at(_p(b["keep_l0"]), b["keep_l0"].numel(), 1 - self.p, self.seed + 2, ctr, 2, st))
+        check(lib.g2v_counter_add(ctr, 3 if drop else 1, st))
 
     def set_masks(self, B: int, keep95, keep_in=None, keep_l0=None):
         """Explicit keep masks (parity tests): keep95 (T-1,B,D), keep_in (T,B,D), keep_l0 (T-1,B,H)."""
@@ -500,9 +503,13 @@ class VQVAEEngine:
         enc = "encoder."
         # ---- EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU -----------------------
         b["enc_dropped"] = drop_in
-        if drop_in:
+        if drop_in and self._fused_in_drop:          # mask drawn inside the kernel (the fused step; draw_masks("rest") follows)
+            check(lib.g2v_dropout_rows(_p(in_poses), D, B, D, T * D, 1 - self.p, 1.0 / (1.0 - self.p), self.seed + 1,
+                                       _p(self.rng_counter), 0, _p(b["x_drop"]), D, T * B, D, st))
+        elif drop_in:
             check(lib.g2v_mask_rows(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]), 1.0 / (1.0 - self.p), _p(b["x_drop"]), D,
                                     T * B, D, st))
+        if drop_in:
             check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
                                      self._w(enc + "in_layer.bias"), _p(b["xin"]), H, T * B, D, H, 0, st))
         else:
@@ -887,10 +894,10 @@ class VQVAEEngine:
         finally:
             self._prepared = False
             self._side_work = None
+            self._fused_in_drop = False
 
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
-        if draw_masks and self.p > 0:          # the encoder's own input mask is needed straight away
-            self.draw_masks(B, True, "in")
+        self._fused_in_drop = bool(draw_masks and self.p > 0)      # the encoder's input mask is drawn inside its dropout kernel
         def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
             if self.quantizer == "ema":
                 self.vq_derive()               # needed first: the quantiser follows the encoder directly

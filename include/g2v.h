@@ -553,6 +553,16 @@ int g2v_probe_copy(const float* src, float* dst, int64_t n, g2v_stream_t stream)
  * ------------------------------------------------------------------------------------------ */
 int g2v_keep_mask(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, int64_t* offset_counter,
                   g2v_stream_t stream);
+/* The same stream at offset_counter[0] + offset_add WITHOUT advancing the counter, and the advance as its own call: several
+ * masks of one step (offset_add = 0, 1, 2 ...) then cost one counter launch instead of one each. */
+int g2v_keep_mask_at(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, const int64_t* offset_counter, int64_t offset_add,
+                     g2v_stream_t stream);
+int g2v_counter_add(int64_t* counter, int64_t n, g2v_stream_t stream);
+/* g2v_keep_mask_at + g2v_mask_rows in one kernel, without the mask tensor: out[m, k] = keep(m K + k) ? x[row(m), k] * scale : 0
+ * with keep(e) = element e of the stream (seed, offset_counter[0] + offset_add) -- bit for bit what the two calls produce. */
+int g2v_dropout_rows(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner, float keep_prob,
+                     float scale, uint64_t seed, const int64_t* offset_counter, int64_t offset_add, float* out, int64_t ldo,
+                     int M, int K, g2v_stream_t stream);
 
 /* small helpers used by the host */
 int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream);

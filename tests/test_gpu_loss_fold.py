@@ -87,3 +87,27 @@ def test_quantiser_backward_inside_the_bptt_kernel_changes_nothing(B, p):
     ref, eng = got[False], got[True]
     for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars", "loss_terms"):
         assert torch.equal(getattr(eng, name), getattr(ref, name)), name
+
+
+def test_input_dropout_drawn_inside_its_kernel_equals_the_explicit_mask_route():
+    """The fused step forms the encoder's dropped input with the mask drawn INSIDE the kernel (g2v_dropout_rows) and draws the
+    other masks at counter offsets + 1 / + 2 with one advance of the counter; an engine whose masks are drawn beforehand
+    (draw_masks("all"): the mask tensors, g2v_mask_rows) and which is then stepped with draw_masks=False must end bitwise equal,
+    Philox counter included."""
+    B, p = 64, 0.2
+    T, D, H, K = 34, 135, 64, 512
+    sd = O.init_vqvae_state(D, H, 2, K, seed=31)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(370 + s)).to(DEV) for s in range(3)]
+    a, b = _engine(sd, D, H, K, T, p), _engine(sd, D, H, K, T, p)
+    a.seed = b.seed = 77
+    for x in xs:
+        a.train_step(x, x, **kw)                           # masks drawn by the step (input mask inside its kernel)
+        b.draw_masks(B, True)                              # the same stream, as tensors
+        b.train_step(x, x, draw_masks=False, **kw)
+    torch.cuda.synchronize()
+    assert int(a.rng_counter) == int(b.rng_counter) == 9
+    for name in ("flat", "m", "v", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv", "vq_scalars", "loss_terms"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    for k in ("keep95", "keep_l0", "x_drop"):
+        assert torch.equal(a.buffers(B)[k], b.buffers(B)[k]), k
