@@ -144,6 +144,9 @@ class VQVAEEngine:
         self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
         self._wgrad_small_first = os.environ.get("G2V_WGRAD_ORDER", "0") == "1"      # round-2 launch order of the decoder's products (A/B)
         self._fuse_vq_bwd = os.environ.get("G2V_FUSE_VQ_BWD", "1") != "0"           # quantiser backward inside the encoder's BPTT kernel
+        # statistics branch recorded behind the rollout and joined at step end: measured +7..9 us per step (the 32 us of small
+        # kernels then run beside custom_loss, which is HBM-bound, instead of beside the rollout's first steps) -- off
+        self._defer_stats = os.environ.get("G2V_DEFER_STATS", "0") == "1"
         self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
         self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
         self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
@@ -215,7 +218,7 @@ class VQVAEEngine:
             yield
         self._open.append(k)
 
-    def _fork(self, k: int, fn):
+    def _fork(self, k: int, fn, late: Optional[bool] = None):
         """Branch k = fn(), ordered after everything launched so far on the current stream -- but LAUNCHED by the next _release(),
         which the caller places behind the main chain's next kernel.  In a captured hipGraph the first successor recorded at a
         fork stays on the hardware queue of the fork node and the others move to another queue, whose first packet pays a
@@ -224,7 +227,7 @@ class VQVAEEngine:
         if not self._branches_on or not (self.overlap >> k) & 1:
             fn()
             return
-        if not (self._fork_late >> k) & 1:
+        if not ((self._fork_late >> k) & 1 if late is None else late):
             with self._branch(k):
                 fn()
             return
@@ -442,7 +445,7 @@ class VQVAEEngine:
                 b["keep_l0"].copy_(keep_l0)
 
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
-                n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None):
+                n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None, defer_stats_join: bool = False):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
         if self.quantizer == "gssoft":
@@ -484,10 +487,14 @@ class VQVAEEngine:
                                    b["ws_stats"].numel(), self._stream()))
             if ema_update:
                 self.vq_finish(B, training, n_global)
-        self._fork(1, stats)
+        # Forked first (it runs beside the rollout's first steps) and joined here.  G2V_DEFER_STATS=1 (A/B; measured slower):
+        # recorded BEHIND the rollout instead -- the rollout keeps the quantiser's hardware queue -- it then runs once the
+        # persistent kernel has drained, beside custom_loss, and the fused step joins it at its end.
+        self._fork(1, stats, late=True if (defer_stats_join and self._defer_stats) else None)
         b = self.forward_decoder(out_poses, B, training, loss_w=loss_w)
         self._release()
-        self._join(1)
+        if not (defer_stats_join and self._defer_stats):
+            self._join(1)
         return b
 
     def forward_encoder(self, in_poses: torch.Tensor, training: bool):
@@ -909,9 +916,10 @@ class VQVAEEngine:
         self._side_work = side
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)
-        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var))
+        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var), defer_stats_join=True)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         self.backward(x, B, g_vq)
+        self._join(1)                          # the statistics / codebook-update branch (forward(defer_stats_join=True))
 
     def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),
                          eps: float = 1e-8, max_norm: float = 5.0):
