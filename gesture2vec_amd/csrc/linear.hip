@@ -1414,6 +1414,140 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
   if (dB && kt == 0 && q == 0 && nok) dB[n] = accumulate ? dB[n] + dbs : dbs;
 }
 
+// The same with TN x TK tiles of dW per workgroup (register tiling): every operand value a wave loads feeds TK (TN) MFMAs
+// instead of one, so the L2 traffic per MFMA drops by 2 TN TK / (TN + TK) -- at the reference's own shape (2432 rows, four
+// 600 x 200 products per launch) the 1 x 1 kernel moves 150 MB per product through L2 and takes ~100 us per launch.  Same
+// row split over the waves, same accumulation order per output element, same cross-wave sum: bitwise the 1 x 1 kernel's dW.
+// Plain rows only (no keep mask, no row map).
+template <int TN, int TK, int SMW_NB2>
+__global__ __launch_bounds__(256) void gemm_tn_smallm_rt_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx, int M, int K,
+                                                                int N, int accumulate) {
+  __shared__ float red[3][TN * TK * 256 + TN * 16];
+  const float* __restrict__ dY = sb.dy[blockIdx.y];
+  const float* __restrict__ X = sb.x[blockIdx.y];
+  float* __restrict__ dW = sb.dw[blockIdx.y];
+  float* __restrict__ dB = sb.db[blockIdx.y];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int groups_k = (((K + 15) >> 4) + TK - 1) / TK;
+  const int ng = blockIdx.x / groups_k, kg = blockIdx.x - ng * groups_k;
+  bool nok[TN], kok[TK];
+  const float* dyc[TN];
+  const float* xc[TK];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int n = (ng * TN + t) * 16 + i;
+    nok[t] = n < N;
+    dyc[t] = dY + (nok[t] ? n : 0);
+  }
+#pragma unroll
+  for (int u = 0; u < TK; ++u) {
+    const int k = (kg * TK + u) * 16 + i;
+    kok[u] = k < K;
+    xc[u] = X + (kok[u] ? k : 0);
+  }
+  const int per = (((M + 3) / 4) + 15) & ~15;                       // rows per wave, whole 16-row blocks (as the 1 x 1 kernel)
+  const int mb = wave * per, me = mb + per < M ? mb + per : M;
+  f32x4 acc[TN][TK];
+  float dbs[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    dbs[t] = 0.f;
+#pragma unroll
+    for (int u = 0; u < TK; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float a0[SMW_NB2][4][TN], b0[SMW_NB2][4][TK], a1[SMW_NB2][4][TN], b1[SMW_NB2][4][TK];
+  auto fetch = [&](int m0, float (&a)[SMW_NB2][4][TN], float (&b)[SMW_NB2][4][TK]) {
+#pragma unroll
+    for (int blk = 0; blk < SMW_NB2; ++blk)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int m = m0 + 16 * blk + 4 * q + s2, mc = m < me ? m : (M - 1);       // past the range: a valid row, zeroed in use()
+#pragma unroll
+        for (int t = 0; t < TN; ++t) a[blk][s2][t] = dyc[t][(int64_t)mc * lddy];
+#pragma unroll
+        for (int u = 0; u < TK; ++u) b[blk][s2][u] = xc[u][(int64_t)mc * ldx];
+      }
+  };
+  auto use = [&](int m0, const float (&a)[SMW_NB2][4][TN], const float (&b)[SMW_NB2][4][TK]) {
+#pragma unroll
+    for (int blk = 0; blk < SMW_NB2; ++blk)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const bool ok = m0 + 16 * blk + 4 * q + s2 < me;
+        float av[TN], bv[TK];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          av[t] = (ok && nok[t]) ? a[blk][s2][t] : 0.f;
+          dbs[t] += av[t];
+        }
+#pragma unroll
+        for (int u = 0; u < TK; ++u) bv[u] = (ok && kok[u]) ? b[blk][s2][u] : 0.f;
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int u = 0; u < TK; ++u) acc[t][u] = mfma16(av[t], bv[u], acc[t][u]);
+      }
+  };
+  constexpr int CH = 16 * SMW_NB2;
+  if (mb < me) {
+    fetch(mb, a0, b0);
+    for (int m0 = mb; m0 < me; m0 += 2 * CH) {
+      if (m0 + CH < me) fetch(m0 + CH, a1, b1);
+      use(m0, a0, b0);
+      if (m0 + CH >= me) break;
+      if (m0 + 2 * CH < me) fetch(m0 + 2 * CH, a0, b0);
+      use(m0 + CH, a1, b1);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    dbs[t] += __shfl_xor(dbs[t], 16);
+    dbs[t] += __shfl_xor(dbs[t], 32);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+#pragma unroll
+      for (int u = 0; u < TK; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][(t * TK + u) * 256 + lane * 4 + r] = acc[t][u][r];
+      if (q == 0) red[wave - 1][TN * TK * 256 + t * 16 + i] = dbs[t];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+#pragma unroll
+      for (int u = 0; u < TK; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][u][r] += red[w][(t * TK + u) * 256 + lane * 4 + r];
+      dbs[t] += red[w][TN * TK * 256 + t * 16 + i];
+    }
+  // lane holds dW[n = tile_n*16 + 4 q + r][k = tile_k*16 + (lane & 15)]
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+#pragma unroll
+    for (int u = 0; u < TK; ++u) {
+      const int k = (kg * TK + u) * 16 + i;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int no = (ng * TN + t) * 16 + 4 * q + r;
+          if (no < N) {
+            float* o = dW + (int64_t)no * K + k;
+            *o = accumulate ? *o + acc[t][u][r] : acc[t][u][r];
+          }
+        }
+      }
+    }
+    const int n = (ng * TN + t) * 16 + i;
+    if (dB && kg == 0 && q == 0 && n < N) dB[n] = accumulate ? dB[n] + dbs[t] : dbs[t];
+  }
+}
+
 // measured at the reference's own VQ-VAE.yml shape (B = 128, T = 20: 2432 / 2560 rows, 600 x 200): the LDS-tiled kernel + slab
 // pass 20.6 + 7 us per product, so the one-launch form keeps the rows BELOW 4096; from 4096 rows the output-blocked wave
 // kernel takes over (the soft quantiser's products at N = 4096: 512 x 128 22 us against 32, 128 x 128 16 against 31)
@@ -1472,7 +1606,13 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
       sb.dy[p] = it[pp].dy; sb.x[p] = it[pp].x; sb.dw[p] = it[pp].dw; sb.db[p] = it[pp].db;
     }
     const dim3 grid(cdiv(N, 16) * cdiv(K, 16), nprob);
-    if (x_keep)
+    static const int rt_mode = [] { const char* e = getenv("G2V_SMALLM_WGRAD_RT"); return e ? atoi(e) : 1; }();      // 0: A/B
+    // enough tiles that 2 x 2 of them per workgroup still cover the chip, enough rows that the streaming dominates (four
+    // 600 x 200 products at 2432 rows: 72 us against 94; 4 x 2, 3 x 3 and 4 x 4 tiles measured within +-5 % of 2 x 2)
+    if (rt_mode == 1 && !x_keep && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
+      hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), dim3(cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2), nprob), dim3(256), 0,
+                         (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate);
+    else if (x_keep)
       hipLaunchKernelGGL(gemm_tn_smallm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep, x_scale,
                          M, K, N, accumulate);
     else
