@@ -143,7 +143,7 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
     kw = dict(lr=optim.lr, w_l1=float(args.loss_l1_weight), w_cont=float(args.loss_cont_weight),
               w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=not getattr(net, "_explicit_masks", False),
               betas=optim.betas, eps=optim.eps, max_norm=optim.max_norm)
-    if reduce_fn is None and world == 1 and eng._branches_ok(x.shape[0]) and _GRAPH_REPLAY:
+    if reduce_fn is None and world == 1 and x.shape[0] >= _GRAPH_MIN_ROWS and _GRAPH_REPLAY:
         _replayed_step(eng, x, tgt, kw)
     else:
         eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)
@@ -159,6 +159,10 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
 
 import os as _os
 _GRAPH_REPLAY = _os.environ.get("G2V_TRAIN_ITER_GRAPH", "1") != "0"
+# rows per batch from which the iteration is replayed from a hipGraph.  Small batches are launch-bound (the reference's own
+# config/VQ-VAE.yml shape at B = 128: ~220 launches per iteration), so they gain the most; the parallel branches inside the
+# step stay a large-batch matter (VQVAEEngine.overlap_min_rows).
+_GRAPH_MIN_ROWS = int(_os.environ.get("G2V_TRAIN_ITER_GRAPH_MIN_ROWS", "0"))
 
 
 def _FUSED_GSSOFT_OK(net) -> bool:
