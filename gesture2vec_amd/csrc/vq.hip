@@ -99,21 +99,35 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   float bd = INFINITY;
   int bk = 0;
   const int ntile = (K + 15) >> 4;
-  for (int kt = wave; kt < ntile; kt += 4) {
-    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int nvalid = min(16, K - 16 * kt);
-    wave_gemm<1>(acc, W, (int64_t)E, wvec, 16 * kt, 16, nvalid, E, Xs, ldx, lane);
+  auto take = [&](const f32x4& acc, int kt) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int code = 16 * kt + 4 * q + r;
       if (code < K) {
-        const float d = (xr + wsq[code]) - 2.0f * acc[0][r];   // (||x||^2 + ||W||^2) - 2 x.W  (:1234-1238)
+        const float d = (xr + wsq[code]) - 2.0f * acc[r];   // (||x||^2 + ||W||^2) - 2 x.W  (:1234-1238)
         if (argmin_better(d, bd)) {
           bd = d;
           bk = code;
         }
       }
     }
+  };
+  int kt = wave;
+  // two whole code tiles per pass (kt and kt + 4, taken in that order: the lane's codes stay ascending): two independent
+  // accumulator chains instead of one 100-long dependent MFMA chain per tile at E = 400 (the reference's own shape, 128 rows:
+  // 57 -> 50 us; what remains is eight workgroups each streaming the whole 0.8 MB codebook -- a split over the codes with a
+  // second-stage argmin is the next step for small N)
+  for (; 16 * (kt + 4) + 16 <= K; kt += 8) {
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    wave_gemm<2>(acc, W, (int64_t)E, wvec, 16 * kt, 64, 16, E, Xs, ldx, lane);
+    take(acc[0], kt);
+    take(acc[1], kt + 4);
+  }
+  for (; kt < ntile; kt += 4) {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int nvalid = min(16, K - 16 * kt);
+    wave_gemm<1>(acc, W, (int64_t)E, wvec, 16 * kt, 16, nvalid, E, Xs, ldx, lane);
+    take(acc[0], kt);
   }
   // merge the 4 lanes (q = 0..3) that hold the same row
   {
