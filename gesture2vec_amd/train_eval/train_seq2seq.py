@@ -181,12 +181,20 @@ def _replayed_step(eng, x, tgt, kw):
     key = (tuple(x.shape), kw["lr"], tuple(kw["betas"]), kw["eps"], kw["max_norm"], kw["w_l1"], kw["w_cont"], kw["w_var"],
            kw["epoch"] > 0, kw["draw_masks"], eng.flat.data_ptr(), eng.codebook.data_ptr(), eng.vq_pre_w.data_ptr(),
            eng.bn_rm.data_ptr(), eng.overlap)
-    st = getattr(eng, "_iter_graph", None)
-    if st is None or st["key"] != key:
-        if st is None or st.get("seen_key") != key:
-            eng.train_step(x, tgt, **kw)                       # first sight of this configuration: a plain eager step
-            eng._iter_graph = {"key": None, "seen_key": key, "graph": None}
-            return
+    # one slot per configuration (a data loader's short last batch alternates with the full ones: neither may evict the other),
+    # at most _GRAPH_SLOTS of them; eng._iter_graph = the slot of the latest call (tests / check_faults look at it)
+    slots = getattr(eng, "_iter_graphs", None)
+    if slots is None or getattr(eng, "_iter_graph", 0) is None:          # (check_faults() drops every graph by setting it to None)
+        slots = eng._iter_graphs = {}
+    st = slots.get(key)
+    if st is None:
+        eng.train_step(x, tgt, **kw)                           # first sight of this configuration: a plain eager step
+        if len(slots) >= _GRAPH_SLOTS:
+            slots.pop(next(iter(slots)))                       # oldest configuration out
+        eng._iter_graph = slots[key] = {"key": key, "seen_key": key, "graph": None}
+        return
+    eng._iter_graph = st
+    if st["graph"] is None:
         gx = torch.empty_like(x)
         gt = gx if tgt.data_ptr() == x.data_ptr() else torch.empty_like(tgt)
         gx.copy_(x)
@@ -199,10 +207,10 @@ def _replayed_step(eng, x, tgt, kw):
                 eng.train_step(gx, gt, **kw)
         except Exception as e:                                  # capture is an optimisation, never a requirement
             logging.warning("train_iter: hipGraph capture unavailable (%s: %s); eager launches from now on", type(e).__name__, e)
-            eng._iter_graph = {"key": key, "seen_key": key, "graph": False, "gx": None, "gt": None, "same": True}
+            st.update({"graph": False, "gx": None, "gt": None, "same": True})
             eng.train_step(x, tgt, **kw)
             return
-        st = eng._iter_graph = {"key": key, "seen_key": key, "graph": graph, "gx": gx, "gt": gt, "same": gt is gx}
+        st.update({"graph": graph, "gx": gx, "gt": gt, "same": gt is gx})
         graph.replay()
         return
     if st["graph"] is False:
@@ -214,10 +222,13 @@ def _replayed_step(eng, x, tgt, kw):
         st["gt"].copy_(tgt)
     elif st["same"] and tgt.data_ptr() != x.data_ptr():
         # captured with target == input; a separate target now: leave the replayed path for good
-        eng._iter_graph = {"key": key, "seen_key": key, "graph": False, "gx": None, "gt": None, "same": True}
+        st.update({"graph": False, "gx": None, "gt": None, "same": True})
         eng.train_step(x, tgt, **kw)
         return
     st["graph"].replay()
+
+
+_GRAPH_SLOTS = 4
 
 
 def train_iter_DAE(args, epoch: int, noisy_poses: torch.Tensor, target_poses: torch.Tensor, net: torch.nn.Module, optim):

@@ -196,6 +196,33 @@ def test_train_iter_replayed_from_a_graph_equals_eager_iterations(monkeypatch):
     assert a[7] == b[7] == 5 * 7
 
 
+def test_train_iter_keeps_one_graph_per_batch_shape(monkeypatch):
+    """A data loader's short last batch alternates with the full ones (and the reference's own batch of 128 is replayed from a
+    graph too): each shape keeps its own captured graph, neither evicts the other, and the result equals the eager iterations'."""
+    import gesture2vec_amd.train_eval.train_seq2seq as ts
+    sizes = [128, 128, 128, 48, 128, 128, 48, 48, 128]
+    runs = {}
+    for mode in ("graph", "eager"):
+        monkeypatch.setattr(ts, "_GRAPH_REPLAY", mode == "graph")
+        args, net = _iter_setup(128)
+        optim = ts.FusedClipAdam(net, 5e-4, betas=(0.5, 0.999))
+        g = torch.Generator(device="cuda:0").manual_seed(6)
+        losses = []
+        for B in sizes:
+            x = torch.randn(B, args.n_poses, 135, generator=g, device="cuda:0")
+            loss, perp = ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+            losses.append((loss["loss"], float(perp)))
+        eng = net.engine()
+        if mode == "graph":
+            slots = eng._iter_graphs
+            assert len(slots) == 2 and all(st["graph"] not in (None, False) for st in slots.values()), slots
+        runs[mode] = (losses, eng.flat.clone(), eng.m.clone(), eng.codebook.clone())
+    a, b = runs["graph"], runs["eager"]
+    assert a[0] == b[0], (a[0], b[0])
+    for ta, tb in zip(a[1:], b[1:]):
+        assert torch.equal(ta, tb)
+
+
 def test_train_iter_adopts_a_plain_torch_adam():
     """The reference's harness builds torch.optim.Adam(net.parameters(), lr, betas=(0.5, 0.999)) (train_autoencoder_VQVAE.py:193-195):
     handing THAT to train_iter must train exactly like the FusedClipAdam it is adopted into, including an lr change between
