@@ -176,6 +176,120 @@ __global__ __launch_bounds__(256) void vq_assign_kernel(const float* __restrict_
   }
 }
 
+// ---- few rows (the reference's own batch: 128 latent rows at E = 400): the codes are split over gridDim.y workgroups per row tile
+// and the row minima meet in a 64-bit atomicMin on (order-preserving image of the distance, code index) -- torch.argmin's rule:
+// lowest distance, lowest index among equals, a NaN distance beats every number and the first NaN wins (image 0).  The keys live
+// in the idx array itself (set to all ones in front of the launch); vq_assign_finish_kernel turns them into indices and does the
+// gather / straight-through / SSE part.  Eight workgroups sweeping the whole codebook each took 50-57 us.
+__device__ __forceinline__ unsigned long long argmin_key(float d, int code) {
+  unsigned hi = 0u;                                  // NaN
+  if (d == d) {
+    unsigned u = (d == 0.f) ? 0u : __float_as_uint(d);            // -0 and +0 are one value
+    hi = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+  }
+  return ((unsigned long long)hi << 32) | (unsigned)code;
+}
+__device__ __forceinline__ float argmin_key_value(unsigned long long key) {
+  const unsigned hi = (unsigned)(key >> 32);
+  if (hi == 0u) return __uint_as_float(0x7fc00000u);
+  return __uint_as_float((hi & 0x80000000u) ? (hi & 0x7fffffffu) : ~hi);
+}
+
+__global__ __launch_bounds__(256) void vq_assign_split_kernel(const float* __restrict__ flat, const float* __restrict__ W,
+                                                              const float* __restrict__ wsq, unsigned long long* __restrict__ keys,
+                                                              int N, int E, int K, int tiles_per_split) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Ep = (E + 15) & ~15, ldx = Ep + 4;
+  float* Xs = smem;                       // [16][ldx]
+  float* xx = Xs + VQ_ROWS * ldx;         // [16]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  stage_rows(Xs, ldx, Ep, flat + (int64_t)r0 * E, E, nrows, E, tid, 256);
+  __syncthreads();
+  {  // ||x||^2 per row: 16 threads per row (the arithmetic of vq_assign_kernel)
+    const int row = tid >> 4, part = tid & 15;
+    float s2 = 0.f;
+    for (int k = part; k < E; k += 16) s2 += Xs[row * ldx + k] * Xs[row * ldx + k];
+    s2 = reduce16(s2);
+    if (part == 0) xx[row] = s2;
+  }
+  __syncthreads();
+  const int i = lane & 15, q = lane >> 4;
+  const bool wvec = ptr_vec_ok(W, E);
+  const float xr = xx[i];
+  float bd = INFINITY;
+  int bk = 0;
+  const int ntile = (K + 15) >> 4;
+  const int t0 = blockIdx.y * tiles_per_split, t1 = min(ntile, t0 + tiles_per_split);
+  for (int kt = t0 + wave; kt < t1; kt += 4) {
+    f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    const int nvalid = min(16, K - 16 * kt);
+    wave_gemm<1>(acc, W, (int64_t)E, wvec, 16 * kt, 16, nvalid, E, Xs, ldx, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int code = 16 * kt + 4 * q + r;
+      if (code < K) {
+        const float d = (xr + wsq[code]) - 2.0f * acc[0][r];
+        if (argmin_better(d, bd)) {
+          bd = d;
+          bk = code;
+        }
+      }
+    }
+  }
+  {
+    float d2 = __shfl_xor(bd, 16);
+    int k2 = __shfl_xor(bk, 16);
+    argmin_merge(bd, bk, d2, k2);
+    d2 = __shfl_xor(bd, 32);
+    k2 = __shfl_xor(bk, 32);
+    argmin_merge(bd, bk, d2, k2);
+  }
+  // (a wave without a tile in this split, or an all-+inf slice, offers (+inf, its first code or 0): +inf never beats a real
+  // candidate, and among all-+inf rows code 0 -- offered by split 0 -- is the lowest index, as torch resolves it)
+  const bool has_tile = t0 + wave < t1;
+  if (lane < nrows && lane < 16 && (has_tile || (blockIdx.y == 0 && wave == 0))) atomicMin(&keys[r0 + lane], argmin_key(bd, bk));
+}
+
+__global__ __launch_bounds__(256) void vq_assign_finish_kernel(unsigned long long* __restrict__ keys_idx, const float* __restrict__ z,
+                                                               const float* __restrict__ W, float* __restrict__ quant,
+                                                               float* __restrict__ dist_min, float* __restrict__ sse_partial,
+                                                               int N, int E) {
+  __shared__ int best_k[VQ_ROWS];
+  __shared__ float red[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * VQ_ROWS;
+  const int nrows = min(VQ_ROWS, N - r0);
+  if (tid < nrows) {
+    const unsigned long long key = keys_idx[r0 + tid];
+    const int k = (int)(unsigned)(key & 0xffffffffull);
+    best_k[tid] = k;
+    keys_idx[r0 + tid] = (unsigned long long)k;            // the int64 index, in place
+    if (dist_min) dist_min[r0 + tid] = argmin_key_value(key);
+  }
+  __syncthreads();
+  if (quant) {
+    const int row = tid >> 4, part = tid & 15;
+    float sse = 0.f;
+    if (row < nrows) {
+      const float* wq = W + (int64_t)best_k[row] * E;
+      const float* zr = z + (int64_t)(r0 + row) * E;
+      float* qo = quant + (int64_t)(r0 + row) * E;
+      for (int k = part; k < E; k += 16) {
+        const float zv = zr[k];
+        const float diff = wq[k] - zv;
+        qo[k] = zv + diff;                 // inputs + (quantized - inputs).detach()  (:1292)
+        sse += diff * diff;
+      }
+    }
+    sse = wave_sum(sse);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+}
+
 // Fast path for E == 128 and K % 128 == 0 (the BASELINE shape E = 128, K = 512).  Same arithmetic, but:
 //  * the 16 x E row tile's MFMA B-fragments (8 x float4) live in registers for the whole kernel,
 //  * each wave walks its code tiles in PAIRS (two independent accumulator chains: the 16x16x4 fp32 MFMA has a
@@ -1766,6 +1880,31 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
   const int Ep = (E + 15) & ~15;
   const size_t lds = (size_t)(VQ_ROWS * (Ep + 4) + 16 + 64 + 64 + 16 + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "embedding dim too large for LDS");
+  {
+    // few row tiles: split the codes over workgroups (see vq_assign_split_kernel); G2V_VQ_ASSIGN_SPLIT=0: the one-pass kernel
+    static const bool split_on = [] { const char* e = getenv("G2V_VQ_ASSIGN_SPLIT"); return !(e && e[0] == '0'); }();
+    const int ntile = cdiv(K, 16), nrt = cdiv(N, VQ_ROWS);
+    if (split_on && nrt <= 64 && ntile >= 8) {
+      int nsplit = ntile / 4;                          // >= one code tile per wave
+      if (nsplit > 8) nsplit = 8;
+      const int tps = cdiv(ntile, nsplit);
+      nsplit = cdiv(ntile, tps);
+      hipStream_t st = (hipStream_t)stream;
+      if (lds > 48 * 1024)
+        (void)hipFuncSetAttribute((const void*)vq_assign_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (hipMemsetAsync(idx, 0xFF, sizeof(int64_t) * (size_t)N, st) != hipSuccess) {
+        set_error("g2v_vq_assign_fwd: memset failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(vq_assign_split_kernel, dim3(nrt, nsplit), dim3(256), lds, st, flat, codebook, code_sqnorm,
+                         reinterpret_cast<unsigned long long*>(idx), N, E, K, tps);
+      G2V_CHECK_LAUNCH();
+      hipLaunchKernelGGL(vq_assign_finish_kernel, dim3(nrt), dim3(256), 0, st, reinterpret_cast<unsigned long long*>(idx), z, codebook,
+                         quantized, dist_min, sse_partial, N, E);
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
+  }
   if (lds > 48 * 1024)
     (void)hipFuncSetAttribute((const void*)vq_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(cdiv(N, VQ_ROWS)), dim3(256), lds, (hipStream_t)stream, flat, z, codebook,

@@ -64,7 +64,8 @@ int g2v_linear_set_smallm_rows(int rows);
  *   write-through stores for the saved tensors of the per-step rollout kernels), G2V_NO_FUSED_WGRAD=1 (the persistent
  *   backward does not accumulate dW_hh1 itself), G2V_NO_FUSED_LOSS=1 (g2v_dec_rollout_fuses_loss answers 0),
  *   G2V_SMALLM_WGRAD_ROWS=n (row count up to which g2v_linear_bwd_weight uses its one-launch tile kernel; default 4095),
- *   G2V_SMALLM_WGRAD_RT=0 (that kernel with one 16 x 16 tile of dW per workgroup instead of 2 x 2; same bits).
+ *   G2V_SMALLM_WGRAD_RT=0 (that kernel with one 16 x 16 tile of dW per workgroup instead of 2 x 2; same bits),
+ *   G2V_VQ_ASSIGN_SPLIT=0 (g2v_vq_assign_fwd at few rows as one pass per row tile instead of the codes split over workgroups).
  * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,

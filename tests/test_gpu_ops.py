@@ -284,7 +284,7 @@ def test_vq_assign_vs_oracle(ops, N, E, K):
     assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
 
 
-@pytest.mark.parametrize("N,E,K", [(40, 32, 48), (40, 128, 512), (16384 + 5, 128, 512)])   # generic / fast / row-tiled kernel
+@pytest.mark.parametrize("N,E,K", [(40, 32, 48), (40, 100, 512), (40, 128, 512), (16384 + 5, 128, 512)])   # generic / generic with the codes split over workgroups / fast / row-tiled kernel
 def test_vq_assign_ties_pick_lowest_index(ops, N, E, K):
     W = rnd(K, E, seed=3)
     W[17] = W[5]
