@@ -34,7 +34,8 @@ class DecSaved(C.Structure):
 class GruDir(C.Structure):
     """g2v_gru_dir"""
     _fields_ = ([(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)] +
-                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)])
+                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)] +
+                [(n, c_fp) for n in ("x_raw", "w_in", "b_in")] + [("raw_dim", c_int), ("raw_stride_b", c_i64), ("raw_stride_t", c_i64)])
 
 
 class WgradItem(C.Structure):

@@ -144,6 +144,10 @@ class VQVAEEngine:
         self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
         self._wgrad_small_first = os.environ.get("G2V_WGRAD_ORDER", "0") == "1"      # round-2 launch order of the decoder's products (A/B)
         self._fuse_vq_bwd = os.environ.get("G2V_FUSE_VQ_BWD", "1") != "0"           # quantiser backward inside the encoder's BPTT kernel
+        # in_layer inside the encoder's forward GRU kernel (g2v_gru_dir.x_raw): correct, and SLOWER -- 1.72 against 1.62 ms per step:
+        # that kernel runs two waves per SIMD with its fp32 MFMAs and its gate arithmetic sharing the SIMD serially, so the 36 extra
+        # MFMAs per wave and step (+ the raw tile's staging) cost more inside it than the 37 us HBM-bound launch they replace.  Opt-in.
+        self._enc_fused_in = os.environ.get("G2V_ENC_FUSED_IN", "0") == "1"
         # statistics branch recorded behind the rollout and joined at step end: measured +7..9 us per step (the 32 us of small
         # kernels then run beside custom_loss, which is HBM-bound, instead of beside the rollout's first steps) -- off
         self._defer_stats = os.environ.get("G2V_DEFER_STATS", "0") == "1"
@@ -516,7 +520,12 @@ class VQVAEEngine:
         elif drop_in:
             check(lib.g2v_mask_rows(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]), 1.0 / (1.0 - self.p), _p(b["x_drop"]), D,
                                     T * B, D, st))
-        if drop_in:
+        # in_layer (:93).  Optionally (G2V_ENC_FUSED_IN=1, H == 64; measured slower, see __init__) computed INSIDE the recurrent
+        # kernel two steps ahead of its use (g2v_gru_dir.x_raw); the kernel then leaves xin for the backward.
+        fuse_in_layer = (H == 64 and D <= 144 and self._enc_fused_in)
+        if fuse_in_layer:
+            pass
+        elif drop_in:
             check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
                                      self._w(enc + "in_layer.bias"), _p(b["xin"]), H, T * B, D, H, 0, st))
         else:
@@ -549,6 +558,11 @@ class VQVAEEngine:
             dirs[k].h_n = b["enc_hidden"][k].data_ptr()
             dirs[k].gates = _p(b["gates_" + key]) if training else None
             dirs[k].reverse = k
+            if fuse_in_layer:          # the dropped input tensor is (T,B,D) row-major, the caller's poses (B,T,D)
+                dirs[k].x_raw = _p(b["x_drop"]) if drop_in else _p(in_poses)
+                dirs[k].raw_stride_b, dirs[k].raw_stride_t = (D, B * D) if drop_in else (T * D, D)
+                dirs[k].w_in, dirs[k].b_in = self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias")
+                dirs[k].raw_dim = D
         check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
         self._release()                     # branch 0 (forked above) is launched behind the main chain's kernel
         return b

@@ -234,10 +234,20 @@ typedef struct {          /* one direction of one layer, forward */
   /* Fused input projection (gi == NULL): gi_t = x_t W_ih^T + b_ih is computed inside the recurrent kernel, one step
    * ahead of its use (the gi array, its GEMM and its HBM round trip disappear).  Supported for in_dim == H == 64;
    * otherwise G2V_ERR_UNSUPPORTED and the caller computes gi with g2v_linear_fwd. */
-  const float* x;         /* (T,B,in_dim) layer input                       */
+  const float* x;         /* (T,B,in_dim) layer input (an OUTPUT with the fused input layer below) */
   const float* w_ih;      /* (3H,in_dim)                                    */
   const float* b_ih;      /* (3H)                                           */
   int in_dim;
+  /* Fused input LAYER (x_raw != NULL; with the fused input projection at H == 64, plain call only, every direction alike):
+   * the layer input is itself a dense layer of a raw input, x = x_raw W_in^T + b_in (the encoder's in_layer,
+   * model/Autoencoder_VQVAE_model.py:93).  It is computed inside the recurrent kernel two steps ahead of its use instead of by
+   * a g2v_linear_fwd launch in front of it; `x` is then an OUTPUT (T,B,H), written once, for the backward's weight gradients.
+   * Row (t, b) of x_raw sits at x_raw + b * raw_stride_b + t * raw_stride_t (a (B,T,D) tensor: T D and D); raw_dim <= 144. */
+  const float* x_raw;     /* raw input                                       */
+  const float* w_in;      /* (H, raw_dim)                                    */
+  const float* b_in;      /* (H)                                             */
+  int raw_dim;
+  int64_t raw_stride_b, raw_stride_t;
 } g2v_gru_dir;
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */

@@ -111,3 +111,26 @@ def test_input_dropout_drawn_inside_its_kernel_equals_the_explicit_mask_route():
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     for k in ("keep95", "keep_l0", "x_drop"):
         assert torch.equal(a.buffers(B)[k], b.buffers(B)[k]), k
+
+
+@pytest.mark.parametrize("B,p", [(64, 0.0), (48, 0.2)])
+def test_input_layer_inside_the_encoder_gru_kernel_matches_the_separate_launch(B, p):
+    """g2v_gru_dir.x_raw: in_layer (Linear(D -> H), reference :93) computed by the encoder's forward GRU kernel two steps ahead of
+    its use, against the dense-layer launch in front of it.  Another kernel, another k order of the 135-long dot products: the
+    encoder input agrees to fp32 rounding, and with it two fused train steps."""
+    T, D, H, K = 34, 135, 64, 512
+    sd = O.init_vqvae_state(D, H, 2, K, seed=41)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(470 + s)).to(DEV) for s in range(2)]
+    got = {}
+    for fused in (False, True):
+        eng = _engine(sd, D, H, K, T, p)
+        eng.seed = 5
+        eng._enc_fused_in = fused
+        for x in xs:
+            eng.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        got[fused] = (eng.buffers(B)["xin"].clone(), eng.flat.clone(), eng.loss_terms.clone())
+    torch.testing.assert_close(got[True][0], got[False][0], rtol=2e-5, atol=2e-6)
+    torch.testing.assert_close(got[True][2], got[False][2], rtol=1e-4, atol=1e-6)
+    assert float((got[True][1] - got[False][1]).abs().max()) <= 2 * 5e-4 * 0.05
