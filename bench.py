@@ -289,6 +289,8 @@ def main():
                          "and the default here use 0: the always-on Dropout(0.95) of the decoder input is drawn either way)")
     ap.add_argument("--wgrad-bf16x3", action="store_true",
                     help="opt-in: weight-gradient products as 3-term bf16 splits (reported in config.wgrad); default exact fp32")
+    ap.add_argument("--no-loss-chase", action="store_true",
+                    help="A/B: custom_loss as its own launch between the rollouts instead of the chaser kernel beside the forward rollout")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (split graphs + RCCL all-reduce) even with one rank (diagnostic)")
     a = ap.parse_args()
@@ -321,6 +323,7 @@ def main():
     net.train(True)
     eng = net.engine()
     eng.wgrad_bf16x3 = bool(a.wgrad_bf16x3)
+    eng.loss_chase = not a.no_loss_chase
     x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(1234 + rank)).to(dev)   # rank-dependent shard
 
     reduce_fn = None
@@ -426,8 +429,8 @@ def main():
                                   "2 hipGraph replays around one RCCL all-reduce" if use_dp else "hipGraph replay"),
                        "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "graph_branches_mask": int(eng.overlap),
-                       "custom_loss": ("inside the rollout kernels (G2V_LOSS_FOLD=1)" if eng.buffers(B).get("loss_folded")
-                                       else "own launch between the rollouts"),
+                       "custom_loss": ("chaser kernel co-resident with the forward rollout + the backward rollout's tile load"
+                                       if eng.buffers(B).get("loss_folded") else "own launch between the rollouts"),
                        "wgrad_inside_recurrent_kernels": {"decoder_mask_ih0_hh0_ih1_hh1": int(eng.buffers(B).get("fused_wgrad", 0)),
                                                           "encoder_mode": int(eng.buffers(B).get("enc_fused_wgrad", 0))},
                        "final_loss": round(loss, 6),

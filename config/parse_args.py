@@ -61,6 +61,9 @@ def parse_args(argv=None) -> argparse.Namespace:
     ap.add_argument("--save_every", type=int, default=0, help="checkpoint interval in epochs (0 = the script's reference default)")
     ap.add_argument("--resume", type=str, default="", help="checkpoint written by this trainer to continue from (weights, EMA, "
                                                           "BatchNorm stats, Adam moments and the dropout RNG counter)")
+    ap.add_argument("--dae_all_frames", action="store_true",
+                    help="train_DAE.py: an epoch visits every frame of every cached chunk (the reference's epoch visits only the "
+                         "first n_chunks frames: its __len__ counts LMDB entries, lmdb_data_loader.py:357-364)")
     for key, typ, _default, _req in _SPEC:
         ap.add_argument("--" + key, type=typ, default=None)
     for key in _LIST_PATH_KEYS:
@@ -71,7 +74,7 @@ def parse_args(argv=None) -> argparse.Namespace:
     with open(cli.config) as f:
         cfg = yaml.safe_load(f) or {}
     out = argparse.Namespace(config=cli.config, synthetic=cli.synthetic, synthetic_batches=cli.synthetic_batches,
-                             save_every=cli.save_every, resume=cli.resume)
+                             save_every=cli.save_every, resume=cli.resume, dae_all_frames=cli.dae_all_frames)
     missing = []
     for key, typ, default, req in _SPEC:
         v = getattr(cli, key)

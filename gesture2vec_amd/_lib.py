@@ -28,14 +28,13 @@ class DecSaved(C.Structure):
     """g2v_dec_saved"""
     _fields_ = [(n, c_fp) for n in (
         "y", "xin", "u", "a", "h0", "h1", "x1", "gates0", "gates1", "bn_partial", "bn_stats",
-        "loss_code", "loss_coef", "loss_partial", "loss_terms")] + [("loss_w", c_f * 3)]     # optional: custom_loss folded in
+        "loss_code", "loss_coef", "loss_partial", "loss_terms")] + [("loss_w", c_f * 3)]     # optional: custom_loss by the chaser + the backward
 
 
 class GruDir(C.Structure):
     """g2v_gru_dir"""
     _fields_ = ([(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)] +
-                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)] +
-                [(n, c_fp) for n in ("x_raw", "w_in", "b_in")] + [("raw_dim", c_int), ("raw_stride_b", c_i64), ("raw_stride_t", c_i64)])
+                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)])
 
 
 class WgradItem(C.Structure):
@@ -106,6 +105,7 @@ _SIGS = {
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
     "g2v_dec_rollout_fuses_loss": (c_int, [c_int, c_int, c_int, c_int]),
+    "g2v_custom_loss_chase": (c_int, [c_fp, C.POINTER(DecSaved), c_fp, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_dec_rollout_fwd": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),

@@ -7,6 +7,12 @@
 
 #include "../../include/g2v.h"
 
+// Device address of the persistent rollouts' fault latch (dec_persist.hip; NULL if it cannot be resolved).  The kernels that
+// COMMIT a training step's results to the model state -- clip + Adam, the EMA codebook update, the BatchNorm running statistics --
+// read it and leave the state untouched when a fault is latched: the step's gradients / statistics are garbage then, and the host
+// (which reads the latch at its next sync point) can simply repeat the step on the per-step kernels.
+const unsigned* g2v_internal_persist_fault_ptr();
+
 namespace g2v {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

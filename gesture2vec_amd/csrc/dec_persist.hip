@@ -32,6 +32,9 @@ extern "C" int g2v_read_pstamps(unsigned long long* out) {
 #define PSTAMP(dir, k)
 #endif
 
+int g2v_dbg_flags = 0;
+extern "C" void g2v_dbg_set(int v) { g2v_dbg_flags = v; }
+
 namespace g2v {
 
 namespace {
@@ -44,19 +47,13 @@ constexpr int L_XY = L_XX1 + 16 * LDH;                    // xin_{t+1} tile [16]
 constexpr int L_YT = L_XY + 16 * LDD;                     // dense y tile [16 * D] (+ pad)
 constexpr int L_XT = L_YT + 2176;                         // dense xin tile [16 * D] (+ pad)
 constexpr int L_KT = L_XT + 2176;                         // keep95 bytes of the tile (16 * D bytes, padded)
-constexpr int L_POUT = L_KT + 544;                        // packed W_out: 12 tiles x 4 k-steps x 256
-constexpr int L_PPRE = L_POUT + OUT_TILES * KSH * 256;    // packed W_pre: 4 tiles x 9 k-steps x 256
+constexpr int L_POUT = L_KT + 544;                        // packed W_out: the 9 real tiles x 4 k-steps x 256 (the packed image's
+constexpr int L_PPRE = L_POUT + 9 * KSH * 256;            //   padding tiles 9..11 are never multiplied); packed W_pre: 4 tiles x 9 x 256
 constexpr int L_BIAS = L_PPRE + 4 * KSD * 256;            // b_ih0 b_hh0 b_ih1 b_hh1 (192 each) b_out (144) b_pre bn_w bn_b (64 each)
 constexpr int L_ST = L_BIAS + 4 * 192 + 144 + 3 * 64;     // mean[64], invstd[64]
 constexpr int L_RED = L_ST + 128;                         // [16][128]
 constexpr int L_TOT = L_RED + 16 * 128;                   // [128]
-constexpr int L_TT = L_TOT + 128;                         // loss fold: the target values of the tile, [9 column groups][16 rows][16]
-constexpr int L_END = L_TT + 9 * 256;
-// the three padding tiles at the end of the packed W_out image (tiles 9..11: zero, never multiplied, never copied in) hold the
-// second y tile (y_t and y_{t-1} alternate between the two: the loss fold reads both) and the fold's code bytes
-constexpr int L_YT2 = L_POUT + 9 * KSH * 256;             // dense y tile of the odd steps
-constexpr int L_GB = L_YT2 + 2176;                        // code bytes of one step's tile (16 * D bytes, + 16 bytes nobody reads)
-static_assert(L_GB + 544 <= L_PPRE, "the second y tile and the code tile fit the padding of the packed W_out image");
+constexpr int L_END = L_TOT + 128;
 static_assert(L_END * 4 <= 160 * 1024, "LDS budget of the persistent rollout forward");
 constexpr int B_IH0 = 0, B_HH0 = 192, B_IH1 = 384, B_HH1 = 576, B_OUT = 768, B_PRE = 912, B_BNW = 976, B_BNB = 1040;
 }  // namespace
@@ -75,7 +72,7 @@ struct DecPersistArgs {
   PersistX x;
   int T, B, nblk, n_pre, conditioned, training;
   float p_drop;
-  float lc3;                // loss fold (sv.loss_code set): w_var / (T B D)
+  int dbg;
 };
 
 // A-operand fragments from LDS (conflict-free ds_read_b128: consecutive lanes read consecutive 16 bytes)
@@ -235,7 +232,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   float* st = smem + L_ST;
   float* red = smem + L_RED;
   float* tot = smem + L_TOT;
-  uint8_t* Gb = reinterpret_cast<uint8_t*>(smem + L_GB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -243,115 +239,20 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   const int T = a.T, B = a.B;
   const int f0 = 16 * wave + 4 * q;                  // this lane's 4 hidden features
   const bool training = a.training != 0;
-  // custom_loss folded in (g2v.h, g2v_dec_saved.loss_*).  Every VALU instruction of this kernel costs its full issue time where
-  // it stands -- one wave per SIMD, and nothing hides beside fp32 MFMAs (measured: a slice of 2-3 plain VALU instructions behind
-  // each of the 96 hidden-side MFMAs cost its full 26 cycles per MFMA) -- EXCEPT inside the exchange: between the sweep's requests
-  // and their return the wave only waits, one fabric round trip (~1800 cycles) per hop.  So the loss arithmetic of step s runs
-  // at the top of step s + 1 as the `filler` of hop 1 (dec_persist.hpp); hop 2's filler requests the next target tile.
-  // It reads y_s and y_{s-1} back from the two LDS y tiles and the target values from the LDS target tile in the out-layer
-  // epilogue's own element mapping -- this lane owns the same 12 (row, d) elements at every step -- so the column sums of
-  // squares, the previous step's half-finished codes and the loss sums live in registers for the whole rollout.  Branch-free:
-  // tiles past D select zeros and store their byte into the 16 spare bytes behind the code tile.
-  // (Measured on the way, per step: loss terms in the out-layer epilogue, branchy +3200 cycles, branch-free +1800; element-wise
-  // target loads in front of a hop +2000-2400: vmcnt counts in order, the hop's polling waited for their HBM latency.)
-  const bool fold = training && a.sv.loss_code != nullptr;
-  float ls_l1 = 0.f, ls_cont = 0.f, ls_sq = 0.f, ls_norm = 0.f;
-  float lss[3][4];           // sum over the steps so far of y^2, per owned element
-  float* Tt = smem + L_TT;   // target values of the step in flight: LDS-DMA inside hop 2, read by the next step's loss terms
-  const float* l_tp = a.target + (int64_t)(b0 + i) * T * D;      // + t D + element
-  int l_el[3];               // first of this lane's 4 columns of tile j (the padding tiles 9..11 re-read tile 0's, masked out below)
-  uint32_t l_ok[3];          // bit r: element r of tile j is a real column
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int d0 = 16 * (wave + 4 * j) + 4 * q;
-    l_el[j] = d0 < Dp ? d0 : 4 * q;
-    l_ok[j] = d0 + 3 < D ? 15u : (d0 < D ? (1u << (D - d0)) - 1u : 0u);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      lss[j][r] = 0.f;
-      if (fold) {            // y_0 = target frame 0 (:1039-1040)
-        const float y0 = l_tp[(j == 2) ? min(l_el[j] + r, D - 1) : l_el[j] + r];
-        lss[j][r] = fmaf(y0, y0, 0.f);
-      }
-    }
-  }
-  // loss terms of one step, elements [6 h, 6 h + 6): Yc = the step's y tile, Yp = the tile of the step before, Tt = its target
-  // values, Kt = its keep flags (all 12 read in the first half: Kt is rewritten behind the second product).  No compares (VCC
-  // hazards: s_nop), all in float arithmetic:
-  //   sign(x) = med3(x 2^254, -1, 1) (exact for every finite x, denormals included);
-  //   code = 21 + sign(y - tgt) + 4 sign(y - y_prev) + 16 sign(y_next - y) + 64 keep (exact), one cvt per byte
-  //        = the digits of common.hpp's code byte: (s + 1) | (s + 1) << 2 | (s + 1) << 4 | keep << 6
-  float l_kf[3][4];          // 21 + 64 keep of the step in hand
-  float lhf[3][4];           // the previous step's code (as a float), sign(y_{t+1} - y_t) still missing
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { lhf[j][r] = 0.f; l_kf[j][r] = 0.f; }
-  auto loss_half = [&](const float* Yc, const float* Yp, auto hc) {
-    constexpr int h = decltype(hc)::value;
-    if constexpr (h == 0) {
-      const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
-#pragma unroll
-      for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          l_kf[j][r] = fmaf(fminf((float)Kb[i * D + l_el[j] + r], 1.0f), 64.0f, 21.0f);
-          asm volatile("" : "+v"(l_kf[j][r]));      // (the pins: left alone the compiler SINKS this arithmetic out of the hop, to
-        }                                           //  where its results are next used -- behind the exchange, in the open)
-    }
-    float yc[6], yp[6], tg[6];
-    {
-      // elements 6 h .. 6 h + 5 = tiles (0: r 0-3, 1: r 0-1) or (1: r 2-3, 2: r 0-3)
-      const float4 ta = *reinterpret_cast<const float4*>(Tt + min(wave + 4 * h, 8) * 256 + i * 16 + 4 * q);
-      const float4 tb = *reinterpret_cast<const float4*>(Tt + min(wave + 4 * (h + 1), 8) * 256 + i * 16 + 4 * q);
-      if constexpr (h == 0) { tg[0] = ta.x; tg[1] = ta.y; tg[2] = ta.z; tg[3] = ta.w; tg[4] = tb.x; tg[5] = tb.y; }
-      else { tg[0] = ta.z; tg[1] = ta.w; tg[2] = tb.x; tg[3] = tb.y; tg[4] = tb.z; tg[5] = tb.w; }
-    }
-    static_for<6>([&](auto ec) {
-      constexpr int e = 6 * h + decltype(ec)::value, j = e >> 2, r = e & 3;
-      yc[e - 6 * h] = Yc[i * D + l_el[j] + r];
-      yp[e - 6 * h] = Yp[i * D + l_el[j] + r];
-    });
-    static_for<6>([&](auto ec) {
-      constexpr int n = decltype(ec)::value, e = 6 * h + n, j = e >> 2, r = e & 3;
-      const bool valid = (l_ok[j] >> r) & 1u;
-      float v = yc[n], dlt = v - tg[n], stp = v - yp[n];
-      if (j == 2) {          // tiles 8..11: zeros in the lanes past D
-        v = valid ? v : 0.f; dlt = valid ? dlt : 0.f; stp = valid ? stp : 0.f;
-      }
-      ls_l1 += fabsf(dlt);
-      ls_sq = fmaf(dlt, dlt, ls_sq);
-      ls_cont += fabsf(stp);
-      lss[j][r] = fmaf(v, v, lss[j][r]);
-      const float s1 = __builtin_amdgcn_fmed3f(ldexpf(dlt, 254), -1.0f, 1.0f), sa = __builtin_amdgcn_fmed3f(ldexpf(stp, 254), -1.0f, 1.0f);
-      const int done = (int)fmaf(sa, 16.0f, lhf[j][r]);
-      Gb[(j == 2 && !valid) ? 16 * D + r : i * D + 16 * (wave + 4 * j) + 4 * q + r] = (uint8_t)done;
-      lhf[j][r] = fmaf(sa, 4.0f, s1 + l_kf[j][r]);
-      asm volatile("" : "+v"(lhf[j][r]), "+v"(lss[j][r]));
-    });
-    asm volatile("" : "+v"(ls_l1), "+v"(ls_sq), "+v"(ls_cont));
-  };
-  // The target tile of a step, 16 rows of D contiguous floats, straight into LDS (global_load_lds_dword: no register destination).
-  // Thread (row tid >> 4, column c = tid & 15) fetches columns c, c + 16, ..., c + 128 (the last one clamped into the row: the
-  // lanes past it repeat column D - 1); instruction k of wave w lands in Tt[k][64 w .. 64 w + 63], i.e. Tt[k][row][c]: the four
-  // target values of a lane's tile j are one 16-byte read.  Issued as the first thing of hop 2's filler, so that its HBM latency
-  // runs beside the sweep's own round trip and ends at the sweep's vmcnt(0).  What does not work (all measured, per step):
-  // element-wise loads in the out-layer epilogue's mapping (16 rows x 16 bytes per instruction): ~3000 cycles in the address
-  // coalescer; row-contiguous loads into registers anywhere: they land in AGPRs, and the next v_accvgpr_read of ANYTHING waits
-  // for them (+1300 in the BatchNorm statistics); this LDS-DMA issued outside a hop: every LDS read that follows waits vmcnt(0)
-  // while it is in flight (+1300 again); any of them in front of a hop: the polling's vmcnt(0) takes their latency on (+2000-2400).
-  const int t_c8 = min(128, D - 1 - (tid & 15));
-  auto target_request = [&](int ts) {
-    const float* tp = a.target + ((int64_t)(b0 + (tid >> 4)) * T + ts) * D + (tid & 15);
-#pragma unroll
-    for (int k = 0; k < 9; ++k)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(tp + (k < 8 ? 16 * k : t_c8)),
-                                       (__attribute__((address_space(3))) void*)(Tt + k * 256 + wave * 64), 4, 0, 0);
-  };
-  auto code_store = [&](int ts) {        // the finished code bytes of step ts: LDS tile -> (T,B,D) array
-    uint32_t* gp = reinterpret_cast<uint32_t*>(a.sv.loss_code + ((int64_t)ts * B + b0) * D);
-    for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) gp[e4] = reinterpret_cast<const uint32_t*>(Gb)[e4];
-  };
+  // The serial chain of the step owns the SIMD: whatever is co-resident (the loss chaser's wave, a statistics kernel) issues in
+  // the gaps only.  Without it the chaser's ~300 VALU instructions per step and wave interleaved with the gate epilogues at equal
+  // priority (arbitration is by priority, then age): cell phases +500..2000 cycles in the stamped workgroups.
+  if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
+  // custom_loss rides beside this kernel, not inside it (round 3 measured the fold: every VALU instruction costs its full issue
+  // time in a one-wave-per-SIMD kernel on a serial chain, 55-60 us for the 68 us it removed).  With sv.loss_code set the kernel only
+  // HANDS y_t OVER to the co-resident chaser (loss_chase_kernel below): y tiles are stored write-through (sc1) and, once every wave
+  // has waited out its stores (the sweep of the next step's exchange does, vmcnt counts in order) and the workgroup has met at a
+  // barrier, one lane publishes the step number in this workgroup's progress word (MI355X_MICROARCH.md, "Valid forms": sc1
+  // payload, drained, barrier, sc1 flag by one lane).  Cost here: one 4-byte store per step.
+  const bool chase = training && a.sv.loss_code != nullptr;
+  const bool wt_y = chase && !(a.dbg & 1);
+  const bool step_flags = chase && !(a.dbg & 16);
+  unsigned* const yflag = a.x.yflag + (size_t)b * PX_FLAG_STRIDE;
   const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
   const float keep_scale = 1.0f / (1.0f - a.p_drop);
   const int64_t BH = (int64_t)B * H;
@@ -368,7 +269,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   frag_load(f_hh1, a.p_hh1, wave, 4, lane);
   frag_load(f_ih0, a.p_ih0, wave, 4, lane);
   frag_load(f_ih1, a.p_ih1, wave, 4, lane);
-  for (int e = tid; e < 9 * KSH * 64; e += 256)              // tiles 9..11 are padding (see L_YT2)
+  for (int e = tid; e < 9 * KSH * 64; e += 256)              // tiles 9..11 of the packed image are padding
     reinterpret_cast<float4*>(Pout)[e] = reinterpret_cast<const float4*>(a.p_out)[e];
   for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Ppre)[e] = reinterpret_cast<const float4*>(a.p_pre)[e];
   for (int e = tid; e < 192; e += 256) {
@@ -401,11 +302,20 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   }
 
   f32x4 u_acc = {0.f, 0.f, 0.f, 0.f};      // u_{t+1}[row i][f0..f0+3] WITHOUT the bias (what the BN partial sums are taken of)
+  // fast path of the outputs: the out-layer epilogue leaves y_t (and xin_{t+1}) as dense LDS tiles -> coalesced 16-byte copies
+  bool pend_dense = false;
+  auto dense_stores = [&](int ts, bool nxt) {
+    const int64_t tile = ((int64_t)ts * B + b0) * D;
+    const float* Ys = smem + L_YT;
+    for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+      st4(a.sv.y + tile + 4 * e4, reinterpret_cast<const float4*>(Ys)[e4], wt_y);      // (chase: write-through, the chaser reads it)
+      if (nxt && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
+    }
+  };
 
   for (int t = 0; t < T; ++t) {
     const bool has_next = t < T - 1;
-    float* Yt = smem + ((t & 1) ? L_YT2 : L_YT);              // y_t's dense tile
-    const float* Yp = smem + ((t & 1) ? L_YT : L_YT2);        // y_{t-1}'s
+    float* Yt = smem + L_YT;                                  // y_t's dense tile
     if (t > 0) {
       PSTAMP(0, 0);
       // ---- hidden-side products (independent of this step's BatchNorm): they fill the exchange's latency -----------
@@ -429,37 +339,26 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       // The exchange is threaded through the two products: the row's records, published at the end of the previous step,
       // have arrived when the first product is done (hop 1: row sum, published again), and the row sums of the other rows
       // travel while the second product runs (hop 2).
-      // loss fold: the terms of step t-1 (y_{t-1} sits in Yp; Yt still holds y_{t-2}; Kt the keep flags of t-1; Tt its target
-      // values) ride inside hop 1 of the exchange
-      const bool lstep = fold && t >= 2;
       frag_mma_x1st(gh0, f_hh0, Xh0, LDH, lane);
       PSTAMP(0, 9);
-      if (lstep) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() {
-        loss_half(Yp, Yt, std::integral_constant<int, 0>{});
-        loss_half(Yp, Yt, std::integral_constant<int, 1>{});
-      });
-      else if (training) px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+      if (training) {
+        // (a wave whose lanes all sit out the sweep -- batches of fewer than 256 rows -- has no vmcnt(0) of its own in there)
+        // chase: every wave waits out its stores here -- y_{t-2} among them, issued a whole step ago (below, behind hop 2)
+        if (chase) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        px_hop1(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+      }
       PSTAMP(0, 10);
       frag_mma_x1st(gh1, f_hh1, Xh1, LDH, lane);
       PSTAMP(0, 1);
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {      // (the loss terms read Kt's previous content inside hop 1, in front of its barriers)
+      for (int j = 0; j < 3; ++j) {
         const int e4 = tid + 256 * j;
         if (e4 < (16 * D) / 4) Kt[e4] = kreq[j];
       }
       // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
       if (training) {
-        // (fold: this step's target values travel beside the sweep; every reader of the tile finished inside hop 1)
-        if (!px_two_hops(a.nblk)) {          // one row of workgroups: hop 1's row sum is the total
-          if (fold) target_request(t);
-        } else if (fold) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid, [&]() { target_request(t); });
-        else px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);
+        if (px_two_hops(a.nblk)) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);      // (one row of workgroups: hop 1's row sum is the total)
         PSTAMP(0, 11);
-        // (a wave whose lanes all sit out the sweep -- small batches -- has not waited for its LDS-DMA yet; the readers of the
-        // tile are a step and many barriers away)
-        if (fold) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (fold && t >= 3) code_store(t - 2);        // completed inside hop 1, in front of its barriers
-        PSTAMP(0, 12);
         if (tid < H) {
           const float s1 = tot[tid], s2 = tot[H + tid];
           const float mv = s1 / (float)B;
@@ -477,6 +376,18 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           run_v = 0.9f * run_v + 0.1f * (var * unbias);
         }
         lds_barrier();
+        // chase: y_0 .. y_{t-2} of these 16 rows are in memory (every wave drained its stores in front of hop 1, the workgroup
+        // has met at barriers since): tell the chaser.  HERE, not earlier: its burst of loads shares this CU's in-order memory
+        // pipeline with the exchange's sweeps; from here to the next step's hop 1 the rollout only stores.
+        if (step_flags && t >= 2 && tid == 0) __hip_atomic_store(yflag, (unsigned)(t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      // y_{t-1} (and xin_{t-1}) out, from the dense tiles the previous step's out-layer epilogue left (valid until this step's):
+      // issued HERE so that the next wait on vector memory -- the sweep of the NEXT step's hop 1 -- is a whole step away.  Right
+      // behind the previous step's publish they sat in front of this step's sweep: vmcnt counts in order, and the write-through
+      // stores of the chase mode are acknowledged by the fabric, not by the L2 (+1.2 us per step, measured).
+      if (pend_dense) {
+        dense_stores(t - 1, true);
+        pend_dense = false;
       }
       PSTAMP(0, 2);
       // ---- a_t = ReLU(BN(u_t)) from the register-resident u tile ---------------------------------------------------
@@ -519,7 +430,12 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
                       a.sv.h1 ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
                       a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
       }
+      // chase, last step: y_{T-2} (stored behind hop 2 above, two products ago) is waited out and announced now, so that only
+      // y_{T-1} is left for the chaser when the rollout ends
+      if (chase && !has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
+      if (step_flags && !has_next && t >= 2 && tid == 0)
+        __hip_atomic_store(yflag, (unsigned)(t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       PSTAMP(0, 5);
       // ---- y_t = out_layer(h1_t) -> dense tile --------------------------------------------------------------------
       {
@@ -574,18 +490,11 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     }
     // ---- y_t out, next decoder input xin_{t+1} = Dropout(0.95)(y_t | target_t)  (:1049-1052, :568-570) --------------
     // fast path: the out-layer epilogue left y (and xin) as dense tiles -> coalesced 16-byte copies, nothing else; they are
-    // issued AFTER the pre_linear product and the publish (the tiles stay valid until the next step's out-layer epilogue),
-    // so that neither the stores nor their barrier sit in front of the exchange
+    // issued in the NEXT step behind its exchange (dense_stores above; the tiles stay valid until the next step's out-layer
+    // epilogue), the last step's at once
     const bool fast_dense = t > 0 && (!has_next || !(t < a.n_pre));
-    auto dense_stores = [&]() {
-      const int64_t tile = ((int64_t)t * B + b0) * D;
-      for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
-        *reinterpret_cast<float4*>(a.sv.y + tile + 4 * e4) = reinterpret_cast<const float4*>(Yt)[e4];
-        if (has_next && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
-      }
-    };
     if (fast_dense) {
-      if (!has_next) dense_stores();
+      if (!has_next) dense_stores(t, false);
     } else {
       const int64_t tile = ((int64_t)t * B + b0) * D;        // the block's 16 x D tile is one dense run of the (T,B,D) arrays
       const bool teacher = has_next && (t < a.n_pre);
@@ -603,8 +512,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
           yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
         }
-        *reinterpret_cast<float4*>(a.sv.y + tile + e) = make_float4(yv[0], yv[1], yv[2], yv[3]);
-        if (t == 0) reinterpret_cast<float4*>(Yt)[e4] = make_float4(yv[0], yv[1], yv[2], yv[3]);      // y_{t-1} of step 1's loss terms (the fold)
+        st4(a.sv.y + tile + e, make_float4(yv[0], yv[1], yv[2], yv[3]), wt_y);
         if (!has_next) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -655,44 +563,186 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         }
       }
     }
-    if (fast_dense) dense_stores();
+    if (fast_dense) pend_dense = true;      // (stored behind hop 2 of the next step)
     PSTAMP(0, 8);
     // (no barrier needed here: the next writers of Xy / Yt / Xt sit behind the barriers of step t+1)
   }
-  if (training && b == 0 && tid < H) {
+  // (a latched fault -- a bounded wait of the exchange ran out -- means garbage statistics: the model's state stays as it was)
+  if (training && b == 0 && tid < H && __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
     a.w.bn_running_mean[tid] = run_m;
     a.w.bn_running_var[tid] = run_v;
   }
-  if (fold) {
-    // the last step's loss terms (its y tile is complete: the barrier behind the out-layer epilogue), the bytes they finish,
-    // the last step's own bytes (no y_{t+1}: complete at once), the column coefficients, this workgroup's four loss sums
-    // (the backward launch adds the workgroups' and writes the terms)
-    const float* Yc = smem + (((T - 1) & 1) ? L_YT2 : L_YT);
-    const float* Yq = smem + (((T - 1) & 1) ? L_YT : L_YT2);
-    loss_half(Yc, Yq, std::integral_constant<int, 0>{});
-    loss_half(Yc, Yq, std::integral_constant<int, 1>{});
+  if (chase) {      // y_{T-1}: drained by every wave, then published
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+    if (tid == 0) __hip_atomic_store(yflag, (unsigned)(T - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+
+// =====================================================================================================================
+// custom_loss (train_eval/train_seq2seq.py:40-88) as a CHASER of the forward rollout: a second, light kernel (one 256-thread
+// workgroup per row tile, <= 128 registers per lane, 64 bytes of LDS) that is co-resident with dec_persist_fwd_kernel -- which
+// runs one wave per SIMD and leaves ~140 registers per lane and ~29 KB of LDS of every CU unused -- and consumes each y_t tile as
+// the rollout hands it over (progress word per workgroup, dec_persist.hpp PX_FLAG_*; sc1 payload, sc1 polls and loads).  It
+// accumulates the four loss sums and the per-column sum of squares as the steps arrive and writes, per element, ONE code byte
+// (common.hpp: the three signs of the |.| terms + the Dropout(0.95) keep flag in bit 6) and, after the last step, the column
+// coefficient c3 / ||y[:,b,d]||.  dec_persist_bwd_kernel then forms dLoss/dy_t = loss_grad(table[code], cn, y_t) where it used to
+// read dy_t: the separate custom_loss launch (62 + 6 us alone between the two rollouts, 225 MB of HBM traffic) is gone, and the
+// loss costs the chain ~3 us behind the forward instead.  Same device functions as misc.hip's kernels: dy is bitwise theirs.
+//   Round 3 had the same arithmetic INSIDE the forward kernel: +55-60 us, because a one-wave-per-SIMD kernel on a serial chain
+//   pays every VALU instruction at its issue time.  On other wave slots of the same SIMDs it is free.
+// Residency: the chaser depends on the rollout, never the other way round; it must be dispatched BEHIND the rollout (the engine
+// launches it behind the quantiser's statistics kernels on the side stream) -- a CU that already holds two chaser workgroups has
+// no room for a rollout workgroup.  Every wait is bounded and ends in the fault latch, like the exchange's.
+// =====================================================================================================================
+struct LossChaseArgs {
+  const float* target;      // (B,T,D)
+  const float* y;           // (T,B,D): the forward's output, stored write-through
+  const uint8_t* keep95;    // (T-1,B,D)
+  uint8_t* code;            // (T,B,D)
+  float* coef;              // (B,D)
+  float* partial;           // (nblk,4): sum |y - tgt|, sum |y_t - y_{t-1}|, sum of column norms, sum (y - tgt)^2
+  const unsigned* yflag;
+  int T, B;
+  float lc3;                // w_var / (T B D)
+  int dbg;
+};
+
+__global__ __launch_bounds__(256, 4) void loss_chase_kernel(LossChaseArgs a) {
+  __shared__ float red[16];
+  constexpr int NQ = (16 * D) / 4;                   // 540 float4 per 16 x D tile: threads 0..27 own a third one
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.x, b0 = b * 16;
+  const int T = a.T, B = a.B;
+  const bool has3 = tid + 512 < NQ;
+  const int q4[3] = {tid, tid + 256, has3 ? tid + 512 : 0};
+  // tile-linear element e = 4 q + r <-> (row e / D, column e % D); the target is (B,T,D): row stride T * D
+  int toff[3][4];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int e = 4 * q4[j] + r, row = e / D;
+      toff[j][r] = row * T * D + (e - row * D);
+    }
+  const float* tp = a.target + (int64_t)b0 * T * D;
+  const unsigned* flag = a.yflag + (size_t)b * PX_FLAG_STRIDE;
+  float yprev[3][4], ss[3][4];
+  uint32_t pend[3];                                  // step t-1's code bytes, sign(y_t - y_{t-1}) still missing
+  float l1 = 0.f, cont = 0.f, sq = 0.f, nrm_sum = 0.f;
+  auto keep_bits = [&](int t, int j) -> uint32_t {   // bit 6 of each byte: the element's Dropout(0.95) keep flag of step t
+    if (t >= T - 1) return 0u;                       // (row T-1 does not exist: nothing is fed back from the last step)
+    const uint32_t k = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)t * B + b0) * D)[q4[j]];
+    return ((k & 0xffu) ? 0x40u : 0u) | ((k & 0xff00u) ? 0x4000u : 0u) | ((k & 0xff0000u) ? 0x400000u : 0u) |
+           ((k & 0xff000000u) ? 0x40000000u : 0u);
+  };
+  // step 0: y_0 = target frame 0 (:1039-1040): sign(y - tgt) = 0, no y_{-1}
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float v = tp[toff[j][r]];
+      yprev[j][r] = v;
+      ss[j][r] = fmaf(v, v, 0.f);
+    }
+    pend[j] = 0x05050505u | keep_bits(0, j);         // (0 + 1) | (0 + 1) << 2
+  }
+  for (int t = 1; t < T; ++t) {
+    // what does not depend on the rollout first: target values and keep flags of step t
+    float tg[3][4];
+    uint32_t kb[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int d0 = 16 * (wave + 4 * j) + 4 * q;
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if ((l_ok[j] >> r) & 1u) {
-          a.sv.loss_code[((int64_t)(T - 1) * B + b0 + i) * D + d0 + r] = (uint8_t)(int)lhf[j][r];      // (sign(y_T - y_{T-1}) = 0 is in the 21)
-          float nrm;
-          const float cn = loss_col_coef(a.lc3, lss[j][r], nrm);
-          a.sv.loss_coef[(int64_t)(b0 + i) * D + d0 + r] = cn;
-          ls_norm += nrm;
+      for (int r = 0; r < 4; ++r) tg[j][r] = (a.dbg & 128) ? (float)(t + r) : tp[toff[j][r] + t * D];
+      kb[j] = (a.dbg & 128) ? (uint32_t)t : keep_bits(t, j);
+    }
+    if (tid == 0) {
+      unsigned spins = 0;
+      const unsigned need = (a.dbg & 8) ? (unsigned)(T - 1) : (unsigned)t;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+        if (a.dbg & 4) __builtin_amdgcn_s_sleep(64); else
+        __builtin_amdgcn_s_sleep(8);
+        ++spins;
+        if (spins > 4000000u || ((spins & 1023u) == 0 &&
+                                 __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+          __hip_atomic_store(&g2v_persist_fault, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (2: the chaser's wait) the rollout is not running
+          break;
         }
+      }
     }
-    const float s4[4] = {wave_sum(ls_l1), wave_sum(ls_cont), wave_sum(ls_norm), wave_sum(ls_sq)};
-    if (lane == 0) {
+    __syncthreads();
+    __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + ((int64_t)t * B + b0) * D, 0,
+                                                                  16 * D * 4, 0x00020000);
+    u32x4 yv4[3];
+    if (a.dbg & 128) {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) red[wave * 4 + k] = s4[k];
+      for (int j = 0; j < 3; ++j) yv4[j] = (u32x4){kb[j], kb[j] + 1u, 3u, 4u};
+    } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) yv4[j] = px_ld(yr, (unsigned)q4[j] * 16u);      // sc1: past this CU's L1, never a stale line
     }
-    lds_barrier();
-    if (T >= 3) code_store(T - 2);
-    if (tid < 4) a.sv.loss_partial[(int64_t)b * 4 + tid] = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
+    uint32_t done[3];
+    if (a.dbg & 64) {
+      uint32_t* cp = reinterpret_cast<uint32_t*>(a.code + ((int64_t)(t - 1) * B + b0) * D);
+      cp[q4[0]] = yv4[0][0] | __float_as_uint(tg[0][0]) | kb[0];
+      cp[q4[1]] = yv4[1][0] | __float_as_uint(tg[1][1]) | kb[1];
+      if (has3) cp[q4[2]] = yv4[2][0] | __float_as_uint(tg[2][2]) | kb[2];
+      continue;
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool live = j < 2 || has3;
+      uint32_t nb = 0u, cur = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned bits = yv4[j][r];
+        const float v = __uint_as_float(bits);
+        const float dlt = v - tg[j][r], stp = v - yprev[j][r];
+        if (live) {
+          l1 += fabsf(dlt);
+          sq += dlt * dlt;
+          cont += fabsf(stp);
+        }
+        ss[j][r] = fmaf(v, v, ss[j][r]);
+        const uint32_t sa = (uint32_t)loss_sign_code(stp);
+        nb |= (sa << 4) << (8 * r);                  // sign(y_t - y_{t-1}) completes step t-1's byte ...
+        cur |= ((uint32_t)loss_sign_code(dlt) | (sa << 2)) << (8 * r);      // ... and opens step t's
+        yprev[j][r] = v;
+      }
+      done[j] = pend[j] | nb;
+      pend[j] = cur | kb[j];
+    }
+    uint32_t* cp = reinterpret_cast<uint32_t*>(a.code + ((int64_t)(t - 1) * B + b0) * D);
+    cp[q4[0]] = done[0];
+    cp[q4[1]] = done[1];
+    if (has3) cp[q4[2]] = done[2];
   }
+  {      // the last step has no y_{t+1}: digit 1
+    uint32_t* cp = reinterpret_cast<uint32_t*>(a.code + ((int64_t)(T - 1) * B + b0) * D);
+    cp[q4[0]] = pend[0] | 0x10101010u;
+    cp[q4[1]] = pend[1] | 0x10101010u;
+    if (has3) cp[q4[2]] = pend[2] | 0x10101010u;
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    float cn[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float nrm;
+      cn[r] = loss_col_coef(a.lc3, ss[j][r], nrm);
+      if (j < 2 || has3) nrm_sum += nrm;
+    }
+    if (j < 2 || has3) reinterpret_cast<float4*>(a.coef + (int64_t)b0 * D)[q4[j]] = make_float4(cn[0], cn[1], cn[2], cn[3]);
+  }
+  const float s4[4] = {wave_sum(l1), wave_sum(cont), wave_sum(nrm_sum), wave_sum(sq)};
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) red[wave * 4 + k] = s4[k];
+  }
+  __syncthreads();
+  if (tid < 4) a.partial[(int64_t)b * 4 + tid] = (red[tid] + red[4 + tid]) + (red[8 + tid] + red[12 + tid]);
 }
 
 }  // namespace g2v
@@ -709,6 +759,14 @@ extern "C" int g2v_dec_rollout_persist_fault(int clear) {
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g2v_persist_fault), &zero, sizeof(zero));
   }
   return (int)v;
+}
+
+const unsigned* g2v_internal_persist_fault_ptr() {
+  static const unsigned* p = [] {
+    void* q = nullptr;
+    return hipGetSymbolAddress(&q, HIP_SYMBOL(g2v_persist_fault)) == hipSuccess ? (const unsigned*)q : (const unsigned*)nullptr;
+  }();
+  return p;
 }
 
 // Residency check of a persistent kernel (once per kernel): at least one workgroup of its shape must fit a CU; together with
@@ -733,7 +791,7 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
   a.p_drop = p_drop;
-  a.lc3 = s->loss_w[2] / ((float)T * (float)B * (float)D);      // as g2v_custom_loss_fwd_bwd forms it
+  a.dbg = g2v_dbg_flags;
   const size_t lds = dec_persist_fwd_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
@@ -752,6 +810,25 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   hipLaunchKernelGGL(dec_persist_fwd_kernel, dim3(a.nblk), dim3(256), lds, st, a);
   if (hipGetLastError() != hipSuccess) {
     set_error("dec_persist_fwd: launch failed");
+    return G2V_ERR_LAUNCH;
+  }
+  return G2V_OK;
+}
+
+// Host side of the chaser: called by g2v_custom_loss_chase (dec_rollout.hip).  `xbase`: the exchange state of the forward
+// workspace this call's forward rollout runs on (its progress words).
+int dec_persist_loss_chase_launch(const float* target, const g2v_dec_saved* s, const uint8_t* keep95, int T, int B, void* xbase,
+                                  hipStream_t st) {
+  LossChaseArgs a;
+  a.target = target; a.y = s->y; a.keep95 = keep95;
+  a.code = s->loss_code; a.coef = s->loss_coef; a.partial = s->loss_partial;
+  a.yflag = persist_x_at(xbase).yflag;
+  a.T = T; a.B = B;
+  a.lc3 = s->loss_w[2] / ((float)T * (float)B * (float)D);      // as g2v_custom_loss_fwd_bwd forms it
+  a.dbg = g2v_dbg_flags;
+  hipLaunchKernelGGL(loss_chase_kernel, dim3(B / 16), dim3(256), 0, st, a);
+  if (hipGetLastError() != hipSuccess) {
+    set_error("custom_loss chaser: launch failed");
     return G2V_ERR_LAUNCH;
   }
   return G2V_OK;

@@ -51,16 +51,23 @@ constexpr int PX_COLS = 128;          // floats per record (2 x H, H = 64)
 constexpr size_t PX_REC1_BYTES = (size_t)2 * PX_MAX_NBLK * PX_COLS * 8;
 constexpr int PX_MAX_GRP = PX_MAX_NBLK / PX_GROUP;
 constexpr size_t PX_REC2_BYTES = (size_t)2 * PX_MAX_NBLK * PX_COLS * 8;               // [parity][workgroup]: its row sum
-constexpr size_t PX_BYTES = PX_REC1_BYTES + PX_REC2_BYTES;     // 1 MiB: a multiple of 16 (memset price, Guideline 16)
+// progress words of the forward rollout for the co-resident custom_loss chaser (dec_persist.hip, loss_chase_kernel): one word per
+// workgroup, each on a 64-byte line of its own; value t = "y_0 .. y_t of this workgroup's 16 rows are in memory".  Cleared with the
+// exchange records (same memset).
+constexpr int PX_FLAG_STRIDE = 16;    // dwords
+constexpr size_t PX_FLAG_BYTES = (size_t)PX_MAX_NBLK * PX_FLAG_STRIDE * 4;
+constexpr size_t PX_BYTES = PX_REC1_BYTES + PX_REC2_BYTES + PX_FLAG_BYTES;     // 1 MiB + 16 KiB: a multiple of 16 (memset price, Guideline 16)
 
 struct PersistX {
   unsigned long long* rec1;   // [2][PX_MAX_NBLK][128] granules {value (low dword), tag (high dword)}
   unsigned long long* rec2;   // [2][PX_MAX_NBLK][128]: the row sum as published by each workgroup
+  unsigned* yflag;            // [PX_MAX_NBLK][PX_FLAG_STRIDE]: forward progress (see PX_FLAG_STRIDE)
 };
 static inline PersistX persist_x_at(void* base) {
   PersistX x;
   x.rec1 = reinterpret_cast<unsigned long long*>(base);
   x.rec2 = x.rec1 + (size_t)2 * PX_MAX_NBLK * PX_COLS;
+  x.yflag = reinterpret_cast<unsigned*>(x.rec2 + (size_t)2 * PX_MAX_NBLK * PX_COLS);
   return x;
 }
 

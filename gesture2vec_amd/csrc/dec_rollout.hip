@@ -31,6 +31,8 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
                            const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab);
+int dec_persist_loss_chase_launch(const float* target, const g2v_dec_saved* s, const uint8_t* keep95, int T, int B, void* xbase,
+                                  hipStream_t st);
 namespace g2v {
 size_t dec_persist_bwd_wgrad_slab_floats();
 }
@@ -46,14 +48,8 @@ static int device_cu_count() {
   }
   return n;
 }
-static int g_persist = -1;     // -1: not decided yet (environment G2V_NO_PERSIST=1 disables), 0 / 1: set
-static bool persist_enabled() {
-  if (g_persist < 0) {
-    const char* e = getenv("G2V_NO_PERSIST");
-    g_persist = (e && e[0] == '1') ? 0 : 1;
-  }
-  return g_persist != 0;
-}
+static int g_persist = 1;      // g2v_dec_rollout_set_persistent (the library reads no environment variable)
+static bool persist_enabled() { return g_persist != 0; }
 
 #ifdef G2V_STAMPS
 __device__ unsigned long long g2v_stamps[64 * 16];
@@ -83,14 +79,7 @@ struct DecDims {
   int n_pre, conditioned, training, nblk;
   int wt;   // write-through (sc1) stores for the arrays only later kernels read (see st4 in common.hpp)
 };
-static int dec_wt_stores() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("G2V_PLAIN_STORES");
-    v = (e && e[0] == '1') ? 0 : 1;
-  }
-  return v;
-}
+static int dec_wt_stores() { return 1; }
 
 // packed forward weights (fragment-major, see common.hpp): offsets in floats into the workspace
 struct DecPackF {
@@ -1874,29 +1863,32 @@ extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES + bwd_wslab_bytes(D, H), b = split_bwd_total(D, H) * sizeof(float);
   return a > b ? a : b;
 }
-static bool fused_wgrad_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("G2V_NO_FUSED_WGRAD");
-    on = (e && e[0] == '1') ? 0 : 1;
-  }
-  return on != 0;
-}
-static bool fused_loss_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("G2V_NO_FUSED_LOSS");
-    on = (e && e[0] == '1') ? 0 : 1;
-  }
-  return on != 0;
-}
 extern "C" int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T) {
   return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() && T >= 2 &&
-          T <= 256 && persist_enabled() && fused_loss_enabled()) ? 1 : 0;
+          T <= 256 && persist_enabled()) ? 1 : 0;
 }
 extern "C" int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H) {
   return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() &&
-          persist_enabled() && fused_wgrad_enabled()) ? 8 : 0;      // bit m <-> matrix m of (ih0, hh0, ih1, hh1): W_hh1
+          persist_enabled()) ? 8 : 0;      // bit m <-> matrix m of (ih0, hh0, ih1, hh1): W_hh1
+}
+
+// custom_loss as a chaser of the persistent forward rollout (dec_persist.hip, loss_chase_kernel; include/g2v.h).
+extern "C" int g2v_custom_loss_chase(const float* target, const g2v_dec_saved* s, const uint8_t* keep95, int T, int B, int D, int H,
+                                     void* fwd_workspace, size_t fwd_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(target && s && keep95 && fwd_workspace, "null pointer");
+  G2V_REQUIRE(s->y && s->loss_code && s->loss_coef && s->loss_partial, "missing loss_* buffer");
+  if (!g2v_dec_rollout_fuses_loss(B, D, H, T)) {
+    set_error("g2v_custom_loss_chase: g2v_dec_rollout_fuses_loss(B, D, H, T) does not hold");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+  G2V_REQUIRE(a16(s->y) && a16(s->loss_code) && a16(s->loss_coef) && a16(keep95) && a16(fwd_workspace), "16-byte alignment");
+  if (fwd_bytes < g2v_dec_rollout_fwd_workspace(D, H)) {
+    set_error("g2v_custom_loss_chase: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  return dec_persist_loss_chase_launch(target, s, keep95, T, B, (char*)fwd_workspace + fwd_pack_bytes_aligned(D, H),
+                                       (hipStream_t)stream);
 }
 
 // Everything of a rollout pair that depends on the WEIGHTS only -- the fragment packs of the forward and of the backward -- and

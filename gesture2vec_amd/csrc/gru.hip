@@ -600,10 +600,6 @@ struct GruDirF {
   float* hs; float* h_n; float* gates;
   int reverse;
   const float* x; const float* p_ih; const float* b_ih;   // FUSE_IN: gi = x W_ih^T + b_ih is computed in the kernel
-  // FUSE_X (with FUSE_IN): x itself = x_raw W_in^T + b_in is computed in the kernel, two steps ahead; row (t, b) of x_raw at
-  // x_raw + b * raw_sb + t * raw_st, raw_dim <= 144 columns; x_out (= x, written by direction 0) keeps the layer input for the
-  // backward's weight gradients
-  const float* x_raw; const float* p_in; const float* b_in; float* x_out; int raw_dim; int64_t raw_sb, raw_st;
 };
 struct GruDirB {
   const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* p_hh_t;
@@ -618,21 +614,16 @@ struct GruDirB {
 // of its use: the recurrence is latency-bound (one dependent MFMA chain + gate math per step), so the 48 extra,
 // h-independent MFMAs per step ride in otherwise idle matrix-pipe slots, and the (T,B,3H) gi array -- its GEMM, its
 // HBM write and its read -- disappears.  W_ih fragments live in registers next to W_hh for all T steps.
-// FUSE_X: the layer input is a dense layer of a raw input (the encoder's in_layer, Linear(D -> H), model :93): x_{s+2} = raw_{s+2}
-// W_in^T + b_in is computed HERE, two steps ahead of its use -- 36 more h-independent MFMAs per wave and step (W_in fragments in
-// registers, the raw 16 x D tile staged through LDS three steps ahead) -- instead of by a launch of its own in front of this
-// kernel (37 us at the BASELINE shape, HBM-bound, plus a kernel boundary).  Direction 0 writes x for the backward.
-template <int HS, bool FUSE_IN, bool FUSE_X>
+// (Round 3 also built the layer in FRONT of this one -- the encoder's in_layer, Linear(D -> H) -- into this kernel, two steps
+// ahead of its use: parity-green and +0.1 ms per step, the 36 extra MFMAs per wave and step cost more inside a kernel whose two
+// waves per SIMD already share the SIMD serially than the 37 us HBM-bound launch they replaced.  Removed in round 4.)
+template <int HS, bool FUSE_IN>
 __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDirF& d1, const int32_t* __restrict__ lengths,
                                                   int64_t hs_ld, int T, int B) {
   constexpr int H = HS, KS = H / 16, NT = H / 16, ldx = H + 4, G = 3 * H;
-  constexpr int KSR = 9, ldr = 16 * KSR + 4;            // raw tile: up to 144 columns
   static_assert(NT == 4, "one feature tile per wave");
-  static_assert(!FUSE_X || FUSE_IN, "the fused input layer feeds the fused input projection");
   __shared__ __attribute__((aligned(16))) float hb[2][16 * ldx];
   __shared__ __attribute__((aligned(16))) float xb[FUSE_IN ? 2 : 1][FUSE_IN ? 16 * ldx : 4];
-  __shared__ __attribute__((aligned(16))) float rawb[FUSE_X ? 2 : 1][FUSE_X ? 16 * ldr : 4];
-  __shared__ __attribute__((aligned(16))) float Win[FUSE_X ? NT * KSR * 256 : 4];      // W_in fragments (all four feature tiles)
   const GruDirF d = blockIdx.y ? d1 : d0;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
@@ -685,42 +676,6 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
 #pragma unroll
     for (int g = 0; g < 3; ++g) out[g] = make_float4(a[g][0] + bi[g].x, a[g][1] + bi[g].y, a[g][2] + bi[g].z, a[g][3] + bi[g].w);
   };
-  // ---- FUSE_X: raw tile staging (thread -> elements tid + 256 j of the 16 x raw_dim tile) and the input layer itself ------
-  float4 bin4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  float rawreg[FUSE_X ? 9 : 1];
-  // thread (row tid >> 4, column group tid & 15) takes columns (tid & 15) + 16 j of its row: no divisions, 64-byte row segments
-  const int rr_ = tid >> 4, rc_ = tid & 15;
-  const float* rawrow = d.x_raw + (int64_t)(b0 + (rr_ < nrows ? rr_ : 0)) * d.raw_sb + rc_;
-  auto raw_request = [&](int s) {                           // raw rows of step s -> registers (zeros past T / past the rows)
-    const bool live = (s < T) && (rr_ < nrows);
-    const float* p = rawrow + (int64_t)(s < T ? step_t(s) : 0) * d.raw_st;
-#pragma unroll
-    for (int j = 0; j < 9; ++j) {
-      const bool ok = live && (rc_ + 16 * j < d.raw_dim);
-      const float v = p[ok ? 16 * j : 0];
-      rawreg[j] = ok ? v : 0.f;
-    }
-  };
-  auto raw_commit = [&](float* dst) {                       // (columns past raw_dim receive zeros: they are padding of the k-steps)
-#pragma unroll
-    for (int j = 0; j < 9; ++j) dst[rr_ * ldr + rc_ + 16 * j] = rawreg[j];
-  };
-  auto in_layer = [&](const float* raw, float* xdst, int s) {      // x_s = raw_s W_in^T + b_in: this wave's 16 features
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    const float* rr = raw + i * ldr + 4 * q;
-#pragma unroll
-    for (int ks = 0; ks < KSR; ++ks) {
-      const float4 xv = *reinterpret_cast<const float4*>(rr + 16 * ks);
-      const float4 wv = *reinterpret_cast<const float4*>(Win + ((FUSE_X ? wave * KSR + ks : 0) * 64 + lane) * 4);
-      a = mfma16(wv.x, xv.x, a);
-      a = mfma16(wv.y, xv.y, a);
-      a = mfma16(wv.z, xv.z, a);
-      a = mfma16(wv.w, xv.w, a);
-    }
-    const float4 v = make_float4(a[0] + bin4.x, a[1] + bin4.y, a[2] + bin4.z, a[3] + bin4.w);
-    *reinterpret_cast<float4*>(xdst + i * ldx + f0) = v;
-    if (!d.reverse && rvalid && s < T) *reinterpret_cast<float4*>(d.x_out + ((int64_t)step_t(s) * B + b) * H + f0) = v;
-  };
   if constexpr (FUSE_IN) {
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
@@ -729,23 +684,8 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
         wi[g][s] = *reinterpret_cast<const float4*>(d.p_ih + ((int64_t)((g * NT + wave) * KS + s) * 64 + lane) * 4);
       bi[g] = *reinterpret_cast<const float4*>(d.b_ih + g * H + f0);
     }
-    if constexpr (FUSE_X) {
-      for (int e = tid; e < NT * KSR * 64; e += 256)
-        reinterpret_cast<float4*>(Win)[e] = reinterpret_cast<const float4*>(d.p_in)[e];
-      bin4 = *reinterpret_cast<const float4*>(d.b_in + f0);
-      for (int e = tid; e < 2 * 16 * ldr; e += 256) (&rawb[0][0])[e] = 0.f;        // (the columns past raw_dim stay zero)
-      __syncthreads();
-      raw_request(0); raw_commit(rawb[0]);
-      raw_request(1); raw_commit(rawb[1]);
-      __syncthreads();
-      in_layer(rawb[0], xb[0], 0);
-      in_layer(rawb[1], xb[1], 1);
-      __syncthreads();
-      raw_request(2); raw_commit(rawb[0]);                   // consumed by iteration 0
-    } else {
-      *reinterpret_cast<float4*>(&xb[0][xr_ * ldx + xc_]) = load_x(0);
-      *reinterpret_cast<float4*>(&xb[1][xr_ * ldx + xc_]) = load_x(1);
-    }
+    *reinterpret_cast<float4*>(&xb[0][xr_ * ldx + xc_]) = load_x(0);
+    *reinterpret_cast<float4*>(&xb[1][xr_ * ldx + xc_]) = load_x(1);
     __syncthreads();
     project(xb[0], gin);                                     // gi of the first step
   } else {
@@ -763,9 +703,7 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
 #pragma unroll
     for (int g = 0; g < 3; ++g) gic[g] = gin[g];
     float4 xnext = make_float4(0.f, 0.f, 0.f, 0.f);
-    if constexpr (FUSE_X) {
-      raw_request(s + 3);                                    // stored to LDS at the end of this iteration
-    } else if constexpr (FUSE_IN) {
+    if constexpr (FUSE_IN) {
       xnext = load_x(s + 2);                                 // consumed at the end of this iteration
     } else if (s + 1 < T && rvalid) {
       const int tn = d.reverse ? (T - 2 - s) : (s + 1);
@@ -788,7 +726,6 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = mfma16(wf[g][ks].w, xb.w, acc[g]);
     }
-    if constexpr (FUSE_X) in_layer(rawb[s & 1], xb[s & 1], s + 2);       // x of step s+2 (raw_{s+2} was staged an iteration ago)
     if constexpr (FUSE_IN) project(xb[(s + 1) & 1], gin);     // gi of step s+1: independent of h
     const float4 hp4 = *reinterpret_cast<const float4*>(hb[cur] + i * ldx + f0);
     const bool valid = rvalid && (t < len);
@@ -821,8 +758,7 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
         *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
       }
     }
-    if constexpr (FUSE_X) raw_commit(rawb[(s + 1) & 1]);                                       // raw rows of step s+3
-    else if constexpr (FUSE_IN) *reinterpret_cast<float4*>(&xb[s & 1][xr_ * ldx + xc_]) = xnext;   // x of step s+2
+    if constexpr (FUSE_IN) *reinterpret_cast<float4*>(&xb[s & 1][xr_ * ldx + xc_]) = xnext;   // x of step s+2
     lds_barrier();
     cur ^= 1;
   }
@@ -832,13 +768,7 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
 template <int HS, bool FUSE_IN>
 __global__ __launch_bounds__(256) void gru_fwd_fast_kernel(GruDirF d0, GruDirF d1, const int32_t* __restrict__ lengths,
                                                            int64_t hs_ld, int T, int B) {
-  gru_fwd_fast_body<HS, FUSE_IN, false>(d0, d1, lengths, hs_ld, T, B);
-}
-// with the fused input layer: two workgroups per CU must still fit (both directions of a row tile side by side)
-template <int HS>
-__global__ __launch_bounds__(256, 2) void gru_fwd_fast_x_kernel(GruDirF d0, GruDirF d1, const int32_t* __restrict__ lengths,
-                                                                int64_t hs_ld, int T, int B) {
-  gru_fwd_fast_body<HS, true, true>(d0, d1, lengths, hs_ld, T, B);
+  gru_fwd_fast_body<HS, FUSE_IN>(d0, d1, lengths, hs_ld, T, B);
 }
 
 // FUSE_DX: the input gradient dx_t = dgi_t W_ih (input width == H) is produced here as a second, independent MFMA chain
@@ -1077,8 +1007,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 * GRU_SPLIT_MAX_B * H; }
 
 extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
-  // (+ the fused input layer's W_in fragments: 64 x 144)
-  const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H) + pack_floats(64, 1, 144), b = gru_split_state_floats(ndir, H);
+  const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H), b = gru_split_state_floats(ndir, H);
   return (a > b ? a : b) * sizeof(float);
 }
 
@@ -1135,15 +1064,9 @@ extern "C" int g2v_gru_cell_bwd(const float* d_h_a, const float* d_h_b, const fl
 
 // fragment packs of the H == 64 fast kernels, in workspace order: per direction W_hh (, W_ih when the projection is fused)
 static PackBatch gru_fwd_packs(const float* const* w_hh, const float* const* w_ih, int ndir, int H, bool fuse, float* p,
-                               const float** p_hh, const float** p_ih, const float* w_in = nullptr, int raw_dim = 0,
-                               const float** p_in = nullptr) {
+                               const float** p_hh, const float** p_ih) {
   PackBatch pb;
   pb.n = 0;
-  if (w_in) {          // fused input layer (H x raw_dim, shared by the directions): first in the workspace
-    pb.d[pb.n++] = PackDesc{w_in, p, H, 1, 0, raw_dim, raw_dim, 0, 0};
-    *p_in = p;
-    p += pack_floats(64, 1, 144);
-  }
   for (int k = 0; k < ndir; ++k) {
     pb.d[pb.n++] = PackDesc{w_hh[k], p, H, 3, H, H, H, 0, 0};
     p_hh[k] = p;
@@ -1225,34 +1148,17 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
     const float* wih[2] = {dirs[0].w_ih, dirs[ndir - 1].w_ih};
     const float* p_hh[2];
     const float* p_ih[2];
-    // fused input layer: every direction names the same raw input / weights, x is then an OUTPUT
-    const bool fuse_x = dirs[0].x_raw != nullptr;
-    for (int k = 0; k < ndir; ++k) {
-      const bool same = dirs[k].x_raw == dirs[0].x_raw && dirs[k].w_in == dirs[0].w_in && dirs[k].b_in == dirs[0].b_in &&
-                        dirs[k].raw_dim == dirs[0].raw_dim && dirs[k].x == dirs[0].x;
-      if ((dirs[k].x_raw != nullptr) != fuse_x || (fuse_x && !(fuse && same && dirs[k].w_in && dirs[k].b_in && dirs[k].raw_dim >= 1 &&
-                                                                dirs[k].raw_dim <= 144 && aligned16(dirs[k].b_in) && !prepared))) {
-        set_error("g2v_gru_seq_fwd: the fused input layer (x_raw, w_in, b_in, raw_dim <= 144) needs the fused input projection at "
-                  "H == 64, the same raw input for every direction, and the plain (not _prepared) call");
-        return G2V_ERR_UNSUPPORTED;
-      }
-    }
-    const float* p_in = nullptr;
-    const PackBatch pb = gru_fwd_packs(whh, wih, ndir, H, fuse, (float*)workspace, p_hh, p_ih, fuse_x ? dirs[0].w_in : nullptr,
-                                       fuse_x ? dirs[0].raw_dim : 0, &p_in);
+    const PackBatch pb = gru_fwd_packs(whh, wih, ndir, H, fuse, (float*)workspace, p_hh, p_ih);
     GruDirF f[2];
     for (int k = 0; k < ndir; ++k)
       f[k] = GruDirF{dirs[k].gi, p_hh[k], dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse,
-                     dirs[k].x, p_ih[k], dirs[k].b_ih, dirs[k].x_raw, p_in, dirs[k].b_in, const_cast<float*>(dirs[k].x),
-                     dirs[k].raw_dim, dirs[k].raw_stride_b, dirs[k].raw_stride_t};
+                     dirs[k].x, p_ih[k], dirs[k].b_ih};
     if (ndir == 1) f[1] = f[0];
     if (!prepared) {
       launch_pack(pb, st);
       G2V_CHECK_LAUNCH();
     }
-    if (fuse_x)
-      hipLaunchKernelGGL(gru_fwd_fast_x_kernel<64>, dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
-    else if (fuse)
+    if (fuse)
       hipLaunchKernelGGL((gru_fwd_fast_kernel<64, true>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);
     else
       hipLaunchKernelGGL((gru_fwd_fast_kernel<64, false>), dim3(cdiv(B, 16), ndir), dim3(256), 0, st, f[0], f[1], lengths, hs_ld, T, B);

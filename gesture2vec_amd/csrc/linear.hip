@@ -1551,11 +1551,7 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_rt_kernel(SmallWgradBatch 
 // measured at the reference's own VQ-VAE.yml shape (B = 128, T = 20: 2432 / 2560 rows, 600 x 200): the LDS-tiled kernel + slab
 // pass 20.6 + 7 us per product, so the one-launch form keeps the rows BELOW 4096; from 4096 rows the output-blocked wave
 // kernel takes over (the soft quantiser's products at N = 4096: 512 x 128 22 us against 32, 128 x 128 16 against 31)
-static int smallm_wgrad_rows_init() {      // G2V_SMALLM_WGRAD_ROWS: measurement only
-  const char* e = getenv("G2V_SMALLM_WGRAD_ROWS");
-  return e ? atoi(e) : 4095;
-}
-static int g_smallm_wgrad_rows = smallm_wgrad_rows_init();
+static constexpr int g_smallm_wgrad_rows = 4095;
 
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
@@ -1606,10 +1602,9 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
       sb.dy[p] = it[pp].dy; sb.x[p] = it[pp].x; sb.dw[p] = it[pp].dw; sb.db[p] = it[pp].db;
     }
     const dim3 grid(cdiv(N, 16) * cdiv(K, 16), nprob);
-    static const int rt_mode = [] { const char* e = getenv("G2V_SMALLM_WGRAD_RT"); return e ? atoi(e) : 1; }();      // 0: A/B
     // enough tiles that 2 x 2 of them per workgroup still cover the chip, enough rows that the streaming dominates (four
     // 600 x 200 products at 2432 rows: 72 us against 94; 4 x 2, 3 x 3 and 4 x 4 tiles measured within +-5 % of 2 x 2)
-    if (rt_mode == 1 && !x_keep && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
+    if (!x_keep && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
       hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), dim3(cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2), nprob), dim3(256), 0,
                          (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate);
     else if (x_keep)

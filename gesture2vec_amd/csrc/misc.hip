@@ -168,7 +168,7 @@ __global__ void mse_finalize_kernel(const float* __restrict__ partial, int nblk,
 
 // ---- clip_grad_norm_ + Adam -------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ partial,
-                                                    int32_t* __restrict__ step_counter) {
+                                                    int32_t* __restrict__ step_counter, const unsigned* __restrict__ fault) {
   __shared__ float red[4];
   float s = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) s += g[e] * g[e];
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   __syncthreads();
   if (threadIdx.x == 0) {
     partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
-    if (blockIdx.x == 0) step_counter[0] += 1;
+    if (blockIdx.x == 0 && !(fault && *fault != 0u)) step_counter[0] += 1;
   }
 }
 
@@ -186,9 +186,11 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         const float* __restrict__ partial, int npart,
                                                         const int32_t* __restrict__ step_counter,
                                                         float* __restrict__ gnorm_out, float max_norm, float grad_scale,
-                                                        float lr, float b1, float b2, float eps) {
+                                                        float lr, float b1, float b2, float eps,
+                                                        const unsigned* __restrict__ fault) {
   __shared__ float red[4];
   __shared__ float bc;
+  if (fault && *fault != 0u) return;      // a latched rollout fault: the gradients are garbage, the parameters and moments stay
   float s = 0.f;
   for (int k = threadIdx.x; k < npart; k += 256) s += partial[k];
   s = wave_sum(s);
@@ -407,10 +409,11 @@ extern "C" int g2v_clip_adam_step(float* param, const float* grad, float* m, flo
   G2V_REQUIRE(param && grad && m && v && partial && step_counter, "null pointer");
   G2V_REQUIRE(n > 0, "bad size");
   const int nblk = g2v_adam_blocks(n);
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, n, partial, step_counter);
+  const unsigned* fault = g2v_internal_persist_fault_ptr();
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, n, partial, step_counter, fault);
   G2V_CHECK_LAUNCH();
   hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, partial,
-                     nblk, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps);
+                     nblk, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps, fault);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -929,17 +929,25 @@ static int stats_splits(int N, int E, int K) {
 }
 
 // ---- K4 scalars: cluster-size EMA + Laplace smoothing, loss, perplexity (one workgroup) --------------
-__global__ __launch_bounds__(1024) void vq_ema_scalars_kernel(const float* __restrict__ stats,
-                                                              const float* __restrict__ sse_partial, int n_sse,
-                                                              float* __restrict__ cs, float* __restrict__ scalars,
-                                                              int N_loss, int N_cnt, int E, int K, float beta,
-                                                              float decay, float eps, int update) {
-  __shared__ float red[16];
-  __shared__ float bc[2];
+// 256 threads = one wave per SIMD at 32 registers: the kernel runs in the branch beside the persistent forward rollout, which
+// leaves ~140 registers per lane of every SIMD free.  Round 3's 1024-thread form (4 waves per SIMD) did not fit beside it: a 5 us
+// kernel that reported 294 us because it could not be placed until the rollout had drained, with the rest of its hardware
+// queue waiting behind it.
+// `fault`: the persistent rollouts' fault latch (dec_persist.hpp).  A latched fault means this step's statistics are garbage:
+// the EMA state and the codebook stay as they were (the host raises at its next sync point and repeats the step).
+__global__ __launch_bounds__(256) void vq_ema_scalars_kernel(const float* __restrict__ stats,
+                                                             const float* __restrict__ sse_partial, int n_sse,
+                                                             float* __restrict__ cs, float* __restrict__ scalars,
+                                                             int N_loss, int N_cnt, int E, int K, float beta,
+                                                             float decay, float eps, int update,
+                                                             const unsigned* __restrict__ fault) {
+  __shared__ float red[3][4];
+  __shared__ float bc[1];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (fault && *fault != 0u) update = 0;
   // perplexity = exp(-sum p log(p + 1e-10)), p = cnt / N   (:1293-1294)
   float ent = 0.f, nsum = 0.f, sse = 0.f;
-  for (int k = tid; k < K; k += 1024) {
+  for (int k = tid; k < K; k += 256) {
     const float cnt = stats[k];
     const float p = cnt / (float)N_cnt;
     ent += p * logf(p + 1e-10f);
@@ -949,46 +957,34 @@ __global__ __launch_bounds__(1024) void vq_ema_scalars_kernel(const float* __res
       nsum += c;
     }
   }
-  for (int j = tid; j < n_sse; j += 1024) sse += sse_partial[j];
+  for (int j = tid; j < n_sse; j += 256) sse += sse_partial[j];
   ent = wave_sum(ent);
   nsum = wave_sum(nsum);
   sse = wave_sum(sse);
-  if (lane == 0) red[wave] = ent;
-  __syncthreads();
-  if (tid == 0) {
-    float s = 0.f;
-    for (int w = 0; w < 16; ++w) s += red[w];
-    scalars[1] = expf(-s);
+  if (lane == 0) {
+    red[0][wave] = ent;
+    red[1][wave] = sse;
+    red[2][wave] = nsum;
   }
   __syncthreads();
-  if (lane == 0) red[wave] = sse;
-  __syncthreads();
   if (tid == 0) {
-    float s = 0.f;
-    for (int w = 0; w < 16; ++w) s += red[w];
-    scalars[0] = beta * (s / ((float)N_loss * (float)E));     // beta * mse(q, z)  (:1285-1289)
+    scalars[1] = expf(-((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])));
+    scalars[0] = beta * (((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / ((float)N_loss * (float)E));     // beta * mse(q, z)  (:1285-1289)
+    bc[0] = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
   }
   __syncthreads();
   if (update) {
-    if (lane == 0) red[wave] = nsum;
-    __syncthreads();
-    if (tid == 0) {
-      float s = 0.f;
-      for (int w = 0; w < 16; ++w) s += red[w];
-      bc[0] = s;
-    }
-    __syncthreads();
     const float n = bc[0];
-    for (int k = tid; k < K; k += 1024) cs[k] = (cs[k] + eps) / (n + (float)K * eps) * n;   // :1268-1273
+    for (int k = tid; k < K; k += 256) cs[k] = (cs[k] + eps) / (n + (float)K * eps) * n;   // :1268-1273
   }
 }
 
 // ---- K4 rows: ema_w, codebook, ||W||^2 (one wave per code) -------------------------------------------
 __global__ void vq_ema_rows_kernel(const float* __restrict__ stats, const float* __restrict__ cs,
                                    float* __restrict__ ema_w, float* __restrict__ W, float* __restrict__ wsq, int E,
-                                   int K, float decay) {
+                                   int K, float decay, const unsigned* __restrict__ fault) {
   const int code = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-  if (code >= K) return;
+  if (code >= K || (fault && *fault != 0u)) return;
   const float* dw = stats + K + (int64_t)code * E;
   float* ew = ema_w + (int64_t)code * E;
   float* w = W + (int64_t)code * E;
@@ -1881,10 +1877,9 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
   const size_t lds = (size_t)(VQ_ROWS * (Ep + 4) + 16 + 64 + 64 + 16 + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "embedding dim too large for LDS");
   {
-    // few row tiles: split the codes over workgroups (see vq_assign_split_kernel); G2V_VQ_ASSIGN_SPLIT=0: the one-pass kernel
-    static const bool split_on = [] { const char* e = getenv("G2V_VQ_ASSIGN_SPLIT"); return !(e && e[0] == '0'); }();
+    // few row tiles: split the codes over workgroups (see vq_assign_split_kernel)
     const int ntile = cdiv(K, 16), nrt = cdiv(N, VQ_ROWS);
-    if (split_on && nrt <= 64 && ntile >= 8) {
+    if (nrt <= 64 && ntile >= 8) {
       int nsplit = ntile / 4;                          // >= one code tile per wave
       if (nsplit > 8) nsplit = 8;
       const int tps = cdiv(ntile, nsplit);
@@ -2107,13 +2102,14 @@ extern "C" int g2v_vq_ema_update(const float* stats, const float* sse_partial, i
   G2V_REQUIRE(stats && scalars, "null pointer");
   G2V_REQUIRE(!update || (ema_cluster_size && ema_w && codebook && code_sqnorm), "null EMA state");
   G2V_REQUIRE(N_loss > 0 && N_cnt > 0 && E > 0 && K > 0, "non-positive size");
-  hipLaunchKernelGGL(vq_ema_scalars_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats, sse_partial,
+  const unsigned* fault = g2v_internal_persist_fault_ptr();
+  hipLaunchKernelGGL(vq_ema_scalars_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, sse_partial,
                      sse_partial ? n_sse_partial : 0, ema_cluster_size, scalars, N_loss, N_cnt, E, K, beta, decay, eps,
-                     update);
+                     update, fault);
   G2V_CHECK_LAUNCH();
   if (update) {
     hipLaunchKernelGGL(vq_ema_rows_kernel, dim3(cdiv((int64_t)K * 64, 256)), dim3(256), 0, (hipStream_t)stream, stats,
-                       ema_cluster_size, ema_w, codebook, code_sqnorm, E, K, decay);
+                       ema_cluster_size, ema_w, codebook, code_sqnorm, E, K, decay, fault);
     G2V_CHECK_LAUNCH();
   }
   return G2V_OK;

@@ -128,12 +128,18 @@ class CacheLoader:
 
 
 class TrinityDataset_DAE:
-    """Part-a frame dataset (reference lmdb_data_loader.py:272-508): every frame of every cached chunk, normalised with
+    """Part-a frame dataset (reference lmdb_data_loader.py:272-508): the frames of the cached chunks, normalised with
     `(x - mean) / clip(std, 0.01)` (:380-382), as (noisy, original) = (x, x) of shape (D, 1) -- the DAE's own dropout is the
-    noise (:388-389).  All frames are kept in ONE float32 array (the reference keeps a Python list of per-frame dicts)."""
+    noise (:388-389).  All frames are kept in ONE float32 array (the reference keeps a Python list of per-frame dicts).
+
+    Epoch length.  The reference's `__len__` returns the number of LMDB ENTRIES (chunks, :357-364) while `__getitem__` indexes the
+    per-FRAME list `all_poses[idx]` (:366-390): one of its epochs visits only the first `n_chunks` frames.  `all_frames=False`
+    (the default here, and what `scripts/train_DAE.py` uses) reproduces exactly that -- same samples per epoch, same updates per
+    epoch, same 20-epoch checkpoint cadence; `all_frames=True` iterates every frame of every chunk (n_poses times longer
+    epochs; a deliberate deviation, for training the DAE on all the data)."""
 
     def __init__(self, args, lmdb_dir: str, n_poses: int, subdivision_stride: int, pose_resampling_fps: int,
-                 data_mean: Sequence[float], data_std: Sequence[float]):
+                 data_mean: Sequence[float], data_std: Sequence[float], all_frames: bool = False):
         preloaded_dir = lmdb_dir + "_cache"
         if not os.path.exists(preloaded_dir):
             raise FileNotFoundError(f"{preloaded_dir}: the sample cache is produced by the reference's DataPreprocessor")
@@ -142,7 +148,8 @@ class TrinityDataset_DAE:
         std = np.clip(np.array(data_std, dtype=np.float64).squeeze(), a_min=0.01, a_max=None)
         frames = [((chunks[i][1] - mean) / std).astype(np.float32) for i in range(len(chunks))]
         self.frames = torch.from_numpy(np.concatenate(frames, axis=0)) if frames else torch.zeros(0, mean.size)
-        self.n_samples = self.frames.shape[0]
+        self.n_frames_total = self.frames.shape[0]
+        self.n_samples = self.n_frames_total if all_frames else min(len(chunks), self.n_frames_total)
 
     def __len__(self) -> int:
         return self.n_samples
@@ -173,11 +180,28 @@ class TrinityDataset_sentencelevel:
     same codes), then yields the collate function's 8-tuple
     `(word_seq, words_lengths, poses_seq, audio, aux_info, sentence_leve_latents, cluster_ids, GPT3_Embedding)`."""
 
+    N_FIELDS = 7          # [word_seq, pose_seq, audio_raws, audio_mels, aux_info, sentence_leve_latents, GPT3_Embedding] (:1209-1221)
+
+    @staticmethod
+    def cache_dir(args, lmdb_dir: str) -> str:
+        """Where the reference's dataset opens its cache (lmdb_data_loader.py:1107-1127): NOT `<lmdb_dir>_cache` (that is the 4-field
+        chunk cache of Parts a / b) but `args.model_save_path + "lmdb/" + basename(lmdb_dir) + "_sentence_level" + "_cache"`
+        (`_cache` alone when `args.sentence_level != "True"`), with `model_save_path` already reset by the trainer's main to
+        `dirname(autoencoder_checkpoint) + "/text2mbedding/"` (train_text2embedding.py:506-508; the string concatenation, not a
+        path join, is the reference's).  An `args` without `model_save_path` (direct construction in tests / notebooks) falls back
+        to `<lmdb_dir>_sentence_level_cache` next to the data."""
+        suffix = "_sentence_level_cache" if str(getattr(args, "sentence_level", "True")) == "True" else "_cache"
+        msp = getattr(args, "model_save_path", None)
+        if msp:
+            return msp + "lmdb/" + os.path.basename(lmdb_dir) + suffix
+        return lmdb_dir + suffix
+
     def __init__(self, args, lmdb_dir: str, n_poses: int, subdivision_stride: int, pose_resampling_fps: int,
                  data_mean: Sequence[float], data_std: Sequence[float], lang_model=None, vq_net=None):
-        preloaded_dir = lmdb_dir + "_cache"
+        preloaded_dir = self.cache_dir(args, lmdb_dir)
         if not os.path.exists(preloaded_dir):
-            raise FileNotFoundError(f"{preloaded_dir}: the sentence-level cache is produced by the reference's DataPreprocessor")
+            raise FileNotFoundError(f"{preloaded_dir}: the sentence-level cache is produced by the reference's DataPreprocessor "
+                                    "(clip slicing + per-chunk VQ-VAE latents; outside the hot path)")
         self.env = LMDBReader(preloaded_dir)
         self.n_samples = len(self.env)
         self.data_mean = np.array(data_mean, dtype=np.float64).squeeze()
@@ -195,7 +219,11 @@ class TrinityDataset_sentencelevel:
         raw = self.env.get(sample_key(idx))
         if raw is None:
             raise IndexError(idx)
-        word_seq, pose_seq, _audio_raws, audio_mels, aux_info, latents, gpt3 = deserialize(raw)[:7]
+        sample = deserialize(raw)
+        if len(sample) < self.N_FIELDS:
+            raise ValueError(f"sample {idx} has {len(sample)} fields, a sentence-level sample has {self.N_FIELDS} (words, poses, audio, "
+                             "mels, aux_info, per-chunk latents, GPT3 embedding): is this the 4-field CHUNK cache of Parts a / b?")
+        word_seq, pose_seq, _audio_raws, audio_mels, aux_info, latents, gpt3 = sample[:7]
         std = np.clip(self.data_std, a_min=0.01, a_max=None)
         pose = np.asarray(pose_seq)
         pose = torch.from_numpy(((pose - self.data_mean) / std)).reshape(pose.shape[0], -1).float()
@@ -231,5 +259,11 @@ class TrinityDataset_sentencelevel:
             gpt3 = torch.stack([it[5] for it in items]) if all(it[5].shape == items[0][5].shape for it in items) else items[0][5]
             lat_d = lat.to(device, non_blocking=True)
             B, S, E = lat_d.shape
-            codes = self.vq_net.vq_layer.assign(lat_d.reshape(B * S, E).contiguous()).view(B, S)       # one launch for the batch
+            rows = lat_d.reshape(B * S, E).contiguous()
+            assign = getattr(self.vq_net.vq_layer, "assign", None)         # one launch sequence for the batch
+            if assign is not None:
+                codes = assign(rows).view(B, S)
+            else:                                                          # any other quantiser: the reference's own route (:1274-1281)
+                with torch.no_grad():
+                    codes = torch.argmax(self.vq_net.vq_layer(rows)[3], dim=1).view(B, S)
             yield words, lengths, poses, audio, aux, lat_d, codes, gpt3

@@ -88,6 +88,9 @@ class VQVAEEngine:
         if L != 2:
             raise NotImplementedError("the gfx950 rollout kernels implement n_layers == 2 (every shipped config)")
         self.lib = _lib.load()
+        if os.environ.get("G2V_DBG"):
+            import ctypes as _C
+            _C.CDLL(_lib.LIB_PATH).g2v_dbg_set(int(os.environ["G2V_DBG"]))
         # Opt-in: run the weight-gradient products on the bf16 matrix pipe as 3-term splits (G2V_WGRAD_BF16X3: ~3e-5 max-norm
         # relative error on dW instead of 3e-7; -0.17 ms / step at the BASELINE shape).  Default: exact fp32 MFMA.
         self.wgrad_bf16x3 = False
@@ -136,29 +139,22 @@ class VQVAEEngine:
         #   bf16-screened kernel (g2v_vq_fused_assign_bx_fwd, E == 128, K in {128..512}; G2V_VQ_BX=0 selects the fp32 kernel):
         #     pre_linear's weight as fp32 MFMA fragments + the screening image (bf16 fragments of U = W w_pre, s'_k, norm bounds);
         #   fp32 kernel: fragment-major image of the codebook (G2V_VQ_PACKED=0: it reads the row-major codebook instead, A/B).
-        self._vq_bx = bool(self.lib.g2v_vq_fused_assign_bx_ok(1, self.E, K)) and os.environ.get("G2V_VQ_BX", "1") != "0"
-        # custom_loss carried by the rollout pair (g2v_dec_saved.loss_*) instead of its own launch between the rollouts: bitwise
-        # the same gradients, 150 MB less HBM traffic and two launches fewer per step -- and NOT faster (the
-        # elementwise work costs 55-60 us inside the one-wave-per-SIMD rollout kernels against the 62 + 6 us it removes), so it is
-        # opt-in: G2V_LOSS_FOLD=1
-        self._loss_fold = os.environ.get("G2V_LOSS_FOLD", "0") == "1"
-        self._wgrad_small_first = os.environ.get("G2V_WGRAD_ORDER", "0") == "1"      # round-2 launch order of the decoder's products (A/B)
-        self._fuse_vq_bwd = os.environ.get("G2V_FUSE_VQ_BWD", "1") != "0"           # quantiser backward inside the encoder's BPTT kernel
-        # in_layer inside the encoder's forward GRU kernel (g2v_gru_dir.x_raw): correct, and SLOWER -- 1.72 against 1.62 ms per step:
-        # that kernel runs two waves per SIMD with its fp32 MFMAs and its gate arithmetic sharing the SIMD serially, so the 36 extra
-        # MFMAs per wave and step (+ the raw tile's staging) cost more inside it than the 37 us HBM-bound launch they replace.  Opt-in.
-        self._enc_fused_in = os.environ.get("G2V_ENC_FUSED_IN", "0") == "1"
-        # statistics branch recorded behind the rollout and joined at step end: measured +7..9 us per step (the 32 us of small
-        # kernels then run beside custom_loss, which is HBM-bound, instead of beside the rollout's first steps) -- off
-        self._defer_stats = os.environ.get("G2V_DEFER_STATS", "0") == "1"
-        self.vq_bx_flags = int(os.environ.get("G2V_VQ_BX_FLAGS", "0"))       # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (A/B)
+        self._vq_bx = bool(self.lib.g2v_vq_fused_assign_bx_ok(1, self.E, K))
+        # custom_loss by the CHASER kernel beside the persistent forward rollout + the backward rollout's own tile load
+        # (include/g2v.h: g2v_custom_loss_chase, g2v_dec_saved.loss_*) instead of its own launch between the rollouts, wherever the
+        # fused train step runs its parallel branches and g2v_dec_rollout_fuses_loss says so.  Bitwise the same gradients.
+        self.loss_chase = True
+        self._fuse_vq_bwd = True            # quantiser backward inside the encoder's BPTT kernel (H == 64); False: its own launch (parity tests)
+        self.vq_bx_flags = 0                # include/g2v.h G2V_VQ_BX_*: 1 = exact fp32 sweep on every tile (the A/B reference of the screening)
+        self.vq_bx_check_every = 0          # > 0: every n-th fused train step re-assigns the batch with the exact sweep and compares (debug)
+        self._vq_bx_mismatch = torch.zeros(1, dtype=torch.int64, device=dev)
+        self._steps = 0
         self.vq_wpre_frag = torch.zeros(self.E * self.E, device=dev) if self._vq_bx else None
         self.vq_bx_image = (torch.zeros(int(self.lib.g2v_vq_bx_image_bytes(K, self.E)), dtype=torch.uint8, device=dev)
                             if self._vq_bx else None)
         self.vq_diag = torch.zeros(4, dtype=torch.int32, device=dev)          # [0] tiles on the exact sweep, [1] pairs re-evaluated
         self._vq_diag_on = False
         self.codebook_frag = torch.zeros(K * self.E, device=dev) if (self.E == 128 and K % 128 == 0 and not self._vq_bx) else None
-        self._vq_packed = os.environ.get("G2V_VQ_PACKED", "1") != "0"
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
         self.vq_stats = self.comm[self.n_flat:]
@@ -185,25 +181,24 @@ class VQVAEEngine:
         # forward; bit 1: the EMA statistics + codebook update beside the decoder rollout; bit 2: the decoder's weight
         # gradients beside the encoder's backward; bit 3: the weight-fragment packs of the four recurrent launches and the clearing
         # of the rollout's exchange regions (everything that depends on the weights only and is not needed at once) inside
-        # branch 0, beside the encoder (a branch of their own costs more at its fork and join than the 25 us it hides);
-        # bit 4 (off: measured +-0): the encoder GRU's weight gradients beside the input layer's.
-        # G2V_OVERLAP=0 serialises everything on the caller's stream.
+        # branch 0, beside the encoder (a branch of their own costs more at its fork and join than the 25 us it hides).
+        # G2V_OVERLAP=0 serialises everything on the caller's stream (debugging).
         self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
         # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: at
         # small batch (a 1-2 ms step of ~300 small launches) that is more than the overlap returns (native VQ-VAE.yml shape,
         # B = 128, eager: 2.06 -> 2.30 ms), so the branches are used from 1024 rows per batch only.
-        self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
+        self.overlap_min_rows = 1024
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
         self._deferred: list = []
         self._fused_in_drop = False
-        # bit k: branch k is launched behind the main chain's next kernel (_fork).  Measured per branch at B = 4096: branch 0 (masks,
-        # packs, vq_derive beside the encoder GRU) -5..-9 us per step; branch 1 (EMA statistics beside the forward rollout) +30 us --
-        # arriving behind the persistent kernel it waits for the whole rollout; branch 2 (decoder weight gradients) +10 us -- they
-        # must be resident before the encoder's BPTT kernel (backward_decoder).  Hence 1.
-        self._fork_late = int(os.environ.get("G2V_FORK_ORDER", "1"))
+        # bit k: branch k is launched behind the main chain's next kernel (_fork): in a captured hipGraph the first successor
+        # recorded at a fork keeps the fork node's hardware queue.  Measured per branch at B = 4096 (round 3): branch 0 (masks, packs,
+        # vq_derive beside the encoder GRU) -5..-9 us per step; branch 1 (EMA statistics beside the forward rollout) +30 us; branch 2
+        # (decoder weight gradients) +10 us.  Hence 1.
+        self._fork_late = 1
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
@@ -216,7 +211,7 @@ class VQVAEEngine:
             return
         side = self._sides.get(k)
         if side is None:
-            side = self._sides[k] = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("G2V_SIDE_PRIORITY", "0")))
+            side = self._sides[k] = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             yield
@@ -243,7 +238,7 @@ class VQVAEEngine:
         for k, ev, fn in self._deferred:
             side = self._sides.get(k)
             if side is None:
-                side = self._sides[k] = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("G2V_SIDE_PRIORITY", "0")))
+                side = self._sides[k] = torch.cuda.Stream(device=self.device)
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 fn()
@@ -258,16 +253,23 @@ class VQVAEEngine:
             self._open.remove(j)
 
     def check_faults(self):
-        """The persistent rollout kernels' fault latch (include/g2v.h: a bounded wait of the grid-wide exchange ran out because a
-        workgroup of the launch was not resident).  Synchronous one-word read: call it at a host sync point.  On a fault the
-        persistent path is switched off for the process and the caller is told to repeat the step."""
+        """The persistent rollout kernels' fault latch (include/g2v.h: a bounded wait of the grid-wide exchange, or of the loss
+        chaser, ran out because a workgroup of the launch was not resident).  Synchronous one-word read: call it at a host sync
+        point (train_iter does, every iteration, where it reads the loss back).  The kernels that COMMIT a step to the model state
+        -- clip + Adam, the EMA codebook update, the BatchNorm running statistics -- read the same latch on the device and leave the
+        state untouched when it is set, so a faulted step (and every step replayed until the host notices) changes nothing: the
+        persistent path is switched off for the process, the graphs are dropped, and the caller repeats the step."""
         f = int(self.lib.g2v_dec_rollout_persist_fault(1))
         if f != 0:
             self.lib.g2v_dec_rollout_set_persistent(0)
             self._iter_graph = None
-            raise RuntimeError("persistent rollout kernel: a workgroup of the launch was not resident (CU mask / another tenant of "
-                               "the device?) -- the step's results are invalid; the per-step kernels are selected from now on, "
-                               "repeat the step")
+            self._open.clear()
+            self._deferred.clear()
+            raise RuntimeError(f"persistent rollout kernel (latch {f}: {'the loss chaser waited for the rollout' if f == 2 else 'the exchange'}): "
+                               "a workgroup of the launch was not resident (CU mask / another tenant of "
+                               "the device?) -- this step's results are invalid and were NOT applied (parameters, Adam moments, "
+                               "codebook, EMA and BatchNorm statistics are as before the step); the per-step kernels are selected "
+                               "from now on: repeat the step")
 
     def _branches_ok(self, B: int) -> bool:
         """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""
@@ -384,11 +386,9 @@ class VQVAEEngine:
                                             self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
                                             4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
                                         dtype=torch.uint8, device=dev)
-        # encoder GRU weight gradients accumulated inside its backward kernel (H == 64): 0 none, 1 W_hh, 2 W_hh and W_ih
-        mode = int(os.environ.get("G2V_ENC_FUSED_WGRAD", "1"))
-        if mode not in (0, 1, 2):
-            raise ValueError(f"G2V_ENC_FUSED_WGRAD={mode}: 0 (separate products), 1 (W_hh inside the recurrent kernel) or 2 (W_hh and W_ih)")
-        b["enc_fused_wgrad"] = mode if H == 64 else 0
+        # encoder GRU weight gradients accumulated inside its backward kernel (H == 64): 1 = W_hh (0 = separate products and
+        # 2 = W_ih as well were measured +50 / +90 us per step in round 3; the kernel keeps both forms, g2v_gru_dir_bwd)
+        b["enc_fused_wgrad"] = 1 if H == 64 else 0
         if b["enc_fused_wgrad"]:
             n = int(self.lib.g2v_gru_seq_bwd_wslab_bytes(B, H))
             b["enc_wslab"] = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -449,7 +449,7 @@ class VQVAEEngine:
                 b["keep_l0"].copy_(keep_l0)
 
     def forward(self, in_poses: torch.Tensor, out_poses: torch.Tensor, training: bool, ema_update: bool = True,
-                n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None, defer_stats_join: bool = False):
+                n_global: Optional[int] = None, derived_ready: bool = False, loss_w=None, join_stats: bool = True):
         """Autoencoder_VQVAE.forward.  in_poses/out_poses (B,T,D) contiguous fp32 on the GPU.
         Fills buffers: y (T,B,D), quant (2,B,H) first hidden, idx, vq_scalars (loss_vq, perplexity)."""
         if self.quantizer == "gssoft":
@@ -470,10 +470,6 @@ class VQVAEEngine:
                                                  _p(self.vq_bx_image), _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]),
                                                  _p(b["quant"]), _p(b["sse"]), _p(self.vq_diag) if self._vq_diag_on else None,
                                                  N, E, K, self.vq_bx_flags, st))
-        elif self.codebook_frag is not None and not self._vq_packed:
-            check(lib.g2v_vq_fused_assign_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b), _p(self.codebook),
-                                              _p(self.code_sqnorm), _p(b["flat"]), _p(b["idx"]), _p(b["quant"]), _p(b["sse"]),
-                                              N, E, K, st))
         elif self.codebook_frag is not None:
             # pre_linear + distances + argmin + straight-through / SSE in one launch (flat is written for the statistics)
             check(lib.g2v_vq_fused_assign_packed_fwd(_p(b["enc_hidden"]), _p(self.vq_pre_w), _p(self.vq_pre_b),
@@ -484,22 +480,41 @@ class VQVAEEngine:
                                      _p(b["flat"]), E, N, E, E, 0, st))
             check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
                                         _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
-        # the statistics and the codebook update feed nothing in this forward (the rollout starts from `quant`, taken from the
-        # codebook as it was): a parallel branch beside the rollout
+        # The statistics and the codebook update feed nothing in this forward (the rollout starts from `quant`, taken from the
+        # codebook as it was): a parallel branch beside the rollout.  The custom_loss CHASER rides at the end of the same branch:
+        # it must be dispatched behind the rollout (g2v.h), and these ~30 us of small kernels -- every one of them fits beside the
+        # rollout's one wave per SIMD -- put it there.
+        chase = self._chase_ok(B, training, loss_w)
+        if chase:
+            b["sv_loss"].loss_w[0], b["sv_loss"].loss_w[1], b["sv_loss"].loss_w[2] = (float(w) for w in loss_w)
+            b["loss_target"] = out_poses.data_ptr()
         def stats():
             check(lib.g2v_vq_stats(_p(b["idx"]), _p(b["flat"]), _p(self.vq_stats), N, E, K, _p(b["ws_stats"]),
                                    b["ws_stats"].numel(), self._stream()))
             if ema_update:
                 self.vq_finish(B, training, n_global)
-        # Forked first (it runs beside the rollout's first steps) and joined here.  G2V_DEFER_STATS=1 (A/B; measured slower):
-        # recorded BEHIND the rollout instead -- the rollout keeps the quantiser's hardware queue -- it then runs once the
-        # persistent kernel has drained, beside custom_loss, and the fused step joins it at its end.
-        self._fork(1, stats, late=True if (defer_stats_join and self._defer_stats) else None)
-        b = self.forward_decoder(out_poses, B, training, loss_w=loss_w)
+        def chaser():
+            check(lib.g2v_custom_loss_chase(_p(out_poses), C.byref(b["sv_loss"]), _p(b["keep95"]), self.T, B, self.D, self.H,
+                                            _p(b["ws_decf"]), b["ws_decf"].numel(), self._stream()))
+        self._fork(1, stats)
+        if chase and not (int(os.environ.get("G2V_DBG", "0")) & 2):
+            # LATE: enqueued by _release(), i.e. behind the rollout in host order.  Two HIP streams may share one hardware queue
+            # (they are dealt round-robin onto a few); a chaser enqueued AHEAD of the rollout on a shared queue would wait for a
+            # kernel that cannot start behind it (seen: the bounded wait ran out, latch 2).  Behind it, sharing a queue only
+            # costs the overlap.
+            self._fork(1, chaser, late=True)
+        b = self.forward_decoder(out_poses, B, training, chase=chase)
         self._release()
-        if not (defer_stats_join and self._defer_stats):
+        if join_stats or chase:             # (the backward rollout reads what the chaser writes)
             self._join(1)
         return b
+
+    def _chase_ok(self, B: int, training: bool, loss_w) -> bool:
+        """custom_loss by the chaser (self.loss_chase): a training forward that is told the loss weights, inside the fused step's
+        parallel-branch regime (the chaser needs the side stream and the prepared workspace whose progress words
+        g2v_dec_rollout_prepare has cleared), where the persistent pair runs."""
+        return bool(training and loss_w is not None and self.loss_chase and self._prepared and self._branches_on and
+                    (self.overlap >> 1) & 1 and self.lib.g2v_dec_rollout_fuses_loss(B, self.D, self.H, self.T))
 
     def forward_encoder(self, in_poses: torch.Tensor, training: bool):
         """EncoderRNN (:73-100): in_layer, then layer-0 of the bidirectional GRU.  Fills buffers['enc_hidden'] (2,B,H) =
@@ -520,12 +535,8 @@ class VQVAEEngine:
         elif drop_in:
             check(lib.g2v_mask_rows(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]), 1.0 / (1.0 - self.p), _p(b["x_drop"]), D,
                                     T * B, D, st))
-        # in_layer (:93).  Optionally (G2V_ENC_FUSED_IN=1, H == 64; measured slower, see __init__) computed INSIDE the recurrent
-        # kernel two steps ahead of its use (g2v_gru_dir.x_raw); the kernel then leaves xin for the backward.
-        fuse_in_layer = (H == 64 and D <= 144 and self._enc_fused_in)
-        if fuse_in_layer:
-            pass
-        elif drop_in:
+        # in_layer (:93)
+        if drop_in:
             check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
                                      self._w(enc + "in_layer.bias"), _p(b["xin"]), H, T * B, D, H, 0, st))
         else:
@@ -558,20 +569,14 @@ class VQVAEEngine:
             dirs[k].h_n = b["enc_hidden"][k].data_ptr()
             dirs[k].gates = _p(b["gates_" + key]) if training else None
             dirs[k].reverse = k
-            if fuse_in_layer:          # the dropped input tensor is (T,B,D) row-major, the caller's poses (B,T,D)
-                dirs[k].x_raw = _p(b["x_drop"]) if drop_in else _p(in_poses)
-                dirs[k].raw_stride_b, dirs[k].raw_stride_t = (D, B * D) if drop_in else (T * D, D)
-                dirs[k].w_in, dirs[k].b_in = self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias")
-                dirs[k].raw_dim = D
         check(lib.g2v_gru_seq_fwd(dirs, 2, None, H, T, B, H, _p(b["ws"]), b["ws"].numel(), st))
         self._release()                     # branch 0 (forked above) is launched behind the main chain's kernel
         return b
 
-    def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool, loss_w=None):
+    def forward_decoder(self, out_poses: torch.Tensor, B: int, training: bool, chase: bool = False):
         """decoder rollout (:1039-1054) from buffers['quant'] (2,B,H) = the initial hidden state; fills buffers['y'] (T,B,D).
-        loss_w = (w_l1, w_cont, w_var): custom_loss(y, out_poses) is to follow with these weights and a backward_decoder after
-        it -- where the rollout kernels can carry the loss themselves (g2v_dec_rollout_fuses_loss) they do: buffers['loss_folded']
-        says so, loss() then launches nothing and loss_terms is written by backward_decoder's launch."""
+        chase (forward() decides): the rollout hands every y_t over to the custom_loss chaser that forward() has forked;
+        buffers['loss_folded'] then says so, loss() launches nothing and loss_terms is written by backward_decoder's launch."""
         lib, st = self.lib, self._stream()
         T, D, H = self.T, self.D, self.H
         ops._chk(out_poses, name="out_poses")
@@ -579,11 +584,7 @@ class VQVAEEngine:
         b = self.buffers(B)
         drop_in = training and self.p > 0
         fn, ws = (lib.g2v_dec_rollout_fwd_prepared, b["ws_decf"]) if self._prepared else (lib.g2v_dec_rollout_fwd, b["ws"])
-        fold = bool(training and loss_w is not None and self._loss_fold and lib.g2v_dec_rollout_fuses_loss(B, D, H, T))
-        b["loss_folded"] = fold
-        if fold:
-            b["sv_loss"].loss_w[0], b["sv_loss"].loss_w[1], b["sv_loss"].loss_w[2] = (float(w) for w in loss_w)
-            b["loss_target"] = out_poses.data_ptr()
+        fold = b["loss_folded"] = bool(training and chase)
         check(fn(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
                  C.byref((b["sv_loss"] if fold else b["sv"]) if training else b["sv_eval"]), _p(b["keep95"]),
                  _p(b["keep_l0"]) if drop_in else None, self.p, self.n_pre,
@@ -619,11 +620,11 @@ class VQVAEEngine:
     def loss(self, B: int, target: torch.Tensor, w_l1: float, w_cont: float, w_var: float, want_grad: bool = True):
         """custom_loss on the rollout output; fills loss_terms and (want_grad) the dy buffer with dLoss/dy."""
         b = self.buffers(B)
-        if b["loss_folded"]:           # forward_decoder(loss_w=...) took the loss along: backward_decoder finishes it
+        if b["loss_folded"]:           # forward(loss_w=...) sent the chaser along: backward_decoder finishes the loss
             w = b["sv_loss"].loss_w
             if not (want_grad and target.data_ptr() == b["loss_target"] and
                     (w[0], w[1], w[2]) == tuple(C.c_float(float(v)).value for v in (w_l1, w_cont, w_var))):
-                raise ValueError("loss(): the rollout was run with the loss folded in (forward_decoder(loss_w=...)) "
+                raise ValueError("loss(): the forward was run with the loss chaser (forward(loss_w=...)) "
                                  "for another target / other weights, or without the gradient")
             return
         check(self.lib.g2v_custom_loss_fwd_bwd(_p(b["y"]), _p(target), _p(b["dy"]) if want_grad else None,
@@ -698,7 +699,7 @@ class VQVAEEngine:
                                   float(self._g_vq_host), st))
         check(lib.g2v_scale_f32(_p(g["gs_mse"]), _p(self._one_plus_beta), _p(self.vq_scalars), 1, st))      # loss_vq (:1427)
         check(lib.g2v_ste_f32(x, _p(g["gs_q"]), _p(b["quant"]), N * E, st))                                 # inputs + (q - inputs).detach()
-        return self.forward_decoder(out_poses, B, training, loss_w=loss_w)
+        return self.forward_decoder(out_poses, B, training)
 
     def _backward_gssoft(self, in_poses, B):
         """Backward of _forward_gssoft (expects buffers['dy']): the module path's autograd functions (_STEFn, _ProbsCodebookFn,
@@ -783,15 +784,13 @@ class VQVAEEngine:
             rest = [it for m, it in enumerate(items) if not (b["fused_wgrad"] >> m) & 1]      # the others came out of the rollout kernel
             # The largest product FIRST.  A product and the encoder's BPTT kernel do not share a CU's registers (the BPTT's two
             # workgroups per CU hold ~430 of the 512 registers per lane, a product's wave needs 128-256): a product dispatched
-            # while the BPTT is resident makes no progress until its workgroups drain (gpurun_tools/corun_test.py: 65 us alone,
+            # while the BPTT is resident makes no progress until its workgroups drain (gpurun_tools/corun_probe.py: 65 us alone,
             # 225 us beside it); one that is resident first -- the fork is 18 us ahead of the BPTT -- runs at its stand-alone
             # speed and the BPTT waits for the registers instead (235 -> 293 us).  Largest first measured 0-12 us per step better
-            # than the other order (G2V_WGRAD_ORDER=1) -- the work only moves between the BPTT and the tail behind it.
-            if rest and not self._wgrad_small_first:
+            # than the other order (round 3) -- the work only moves between the BPTT and the tail behind it.
+            if rest:
                 wgrad4(M, rest)
             wgrad(_p(b["du"]), H, _p(b["dec_xin"]), D, pre + "pre_linear.0.weight", pre + "pre_linear.0.bias", H, D)
-            if rest and self._wgrad_small_first:
-                wgrad4(M, rest)
             # (the rollout's backward ADDS the feedback path's gradient into dy: this product needs the finished dy, it cannot run
             # beside the rollout -- tried in round 3, wrong by construction)
             wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
@@ -855,8 +854,7 @@ class VQVAEEngine:
                 items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
             if b["enc_fused_wgrad"] < 2:
                 wgrad4s(TB, items)
-        sum2 = (H == 64 and not self.wgrad_bf16x3 and os.environ.get("G2V_WGRAD_SUM2", "1") != "0"
-                and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H))
+        sum2 = H == 64 and not self.wgrad_bf16x3 and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H)
         if sum2:
             # the two directions' dx are summed inside the input layer's weight-gradient product (no add pass); with input
             # dropout the layer's input is the dropped tensor the forward left in x_drop
@@ -930,10 +928,10 @@ class VQVAEEngine:
         self._side_work = side
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)
-        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var), defer_stats_join=True)
+        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var), join_stats=False)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         self.backward(x, B, g_vq)
-        self._join(1)                          # the statistics / codebook-update branch (forward(defer_stats_join=True))
+        self._join(1)                          # the statistics / codebook-update branch (forward(join_stats=False); a no-op behind the chaser's join)
 
     def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),
                          eps: float = 1e-8, max_norm: float = 5.0):

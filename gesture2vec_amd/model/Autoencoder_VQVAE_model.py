@@ -690,6 +690,14 @@ class VQ_Payam(nn.Module):
     def forward(self, inputs: torch.Tensor):
         return _VQPlainFn.apply(inputs, self._embedding.weight, self)
 
+    def assign(self, inputs: torch.Tensor) -> torch.Tensor:
+        """Code indices only, int64 (N,): what callers take as `argmax(encodings, 1)` of forward() (lmdb_data_loader.py:1274-1281)
+        -- argmin_k ||x - W_k||^2 on the raw rows (this quantiser has no projection in its path, :1123)."""
+        z = inputs.contiguous().view(-1, self._embedding_dim)
+        W = self._embedding.weight.data.contiguous()
+        idx, _, _, _ = ops.vq_assign(z, None, W, ops.vq_code_sqnorm(W), want_quantized=False)
+        return idx
+
 
 class _VQPlainFn(torch.autograd.Function):
     @staticmethod
@@ -816,6 +824,18 @@ class VQ_Payam_GSSoft(nn.Module):
         loss = q_latent + self._commitment_cost * e_latent                     # :1427 (scalar glue)
         quantized = _STEFn.apply(x, q).view(inputs.shape)
         return loss, quantized, perplexity[0], probs
+
+    def assign(self, inputs: torch.Tensor) -> torch.Tensor:
+        """Code indices only, int64 (N,): `argmax(encodings, 1)` of forward() -- the soft probabilities' mode -- which is what
+        the sentence-level dataset takes from whichever quantiser the checkpoint carries (lmdb_data_loader.py:1274-1281).
+        mean_layer -> logvar_layer, distances -> probabilities, no autograd graph, no state change."""
+        with torch.no_grad():
+            x = inputs.contiguous().view(-1, self._embedding_dim)
+            flat = ops.linear_fwd(x, self.mean_layer.weight.data, self.mean_layer.bias.data)
+            logvar = ops.linear_fwd(flat, self.logvar_layer.weight.data, self.logvar_layer.bias.data)
+            W = self._embedding.weight.data.contiguous()
+            probs, _, _ = ops.vq_soft_fwd(flat, ops.linear_fwd(flat, W), logvar, ops.vq_code_sqnorm(W))
+            return torch.argmax(probs, dim=1)
 
 
 class VectorQuantizer(nn.Module):

@@ -149,10 +149,7 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
         eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)
     net.decoder.decoder.pre_linear[1].num_batches_tracked += net.n_frames - 1       # one BatchNorm call per decode step
     both = torch.stack((eng.loss_terms[0], eng.vq_scalars[0])).tolist()            # the iteration's one host sync
-    eng._iters_since_fault_check = getattr(eng, "_iters_since_fault_check", 0) + 1
-    if eng._iters_since_fault_check >= 16 or both[0] != both[0]:                   # every 16th iteration, and on a NaN loss
-        eng._iters_since_fault_check = 0
-        eng.check_faults()
+    eng.check_faults()            # one more word at the same sync point; a faulted step was not applied (the commit kernels gate on the latch)
     loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
     return {"loss": loss}, eng.vq_scalars[1].detach().clone()
 
@@ -208,6 +205,9 @@ def _replayed_step(eng, x, tgt, kw):
         except Exception as e:                                  # capture is an optimisation, never a requirement
             logging.warning("train_iter: hipGraph capture unavailable (%s: %s); eager launches from now on", type(e).__name__, e)
             st.update({"graph": False, "gx": None, "gt": None, "same": True})
+            # the aborted capture may have left branches recorded as open / deferred: the eager retry starts from a clean slate
+            eng._open.clear()
+            eng._deferred.clear()
             eng.train_step(x, tgt, **kw)
             return
         st.update({"graph": graph, "gx": gx, "gt": gt, "same": gt is gx})

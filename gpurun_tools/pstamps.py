@@ -27,7 +27,7 @@ for d, nk in ((0, 9), (1, 8)):
         deltas = [st[k + 1] - st[k] for k in range(nk - 1)]
         print("fwd" if d == 0 else "bwd", "slot", b, "cycles:", deltas, "total", st[nk - 1] - st[0])
         if d == 0:      # extra stamps inside phase 0: after the first product, after hop 1
-            x = [buf[(d * 4 + b) * 24 + k] for k in (9, 10, 11, 12)]
+            x = [buf[(d * 4 + b) * 24 + k] for k in (9, 10, 11)]
             print("      phase 0 split: product 1", x[0] - st[0], "hop 1", x[1] - x[0], "product 2", st[1] - x[1],
-                  "| phase 1 split: Kt + hop 2", x[2] - st[1], "target request + code store", x[3] - x[2], "stats", st[2] - x[3])
+                  "| phase 1 split: Kt + hop 2", x[2] - st[1], "stats + deferred y stores", st[2] - x[2])
     print("   phases:", names[d])

@@ -6,8 +6,8 @@ cd "${GRAFT_REPO_ROOT:?}"
   bash gpurun_tools/fold_ab.sh 2>&1
 } > gpurun_out/r03_loss_fold_ab.log
 {
-  echo "# gpurun_tools/corun_test.py: a side-stream kernel beside the encoder BPTT (eager launches, events)"
-  timeout 300 python gpurun_tools/corun_test.py 2>&1 < /dev/null | tail -2
+  echo "# gpurun_tools/corun_probe.py: a side-stream kernel beside the encoder BPTT (eager launches, events)"
+  timeout 300 python gpurun_tools/corun_probe.py 2>&1 < /dev/null | tail -2
   echo "# G2V_WGRAD_ORDER (1 = the small product first, round 2's order) inside the default bench step"
   bash gpurun_tools/order_ab.sh 2>&1
   echo "# G2V_FORK_ORDER (bit k: branch k launched behind the main chain's next kernel) inside the default bench step"

@@ -56,16 +56,11 @@ int g2v_device_ok(void);
 /* measurement only: largest row count served by the wave-per-tile kernel of g2v_linear_fwd / g2v_linear_bwd_data
  * (0 = never); returns the previous value, rows < 0 only queries */
 int g2v_linear_set_smallm_rows(int rows);
-/* PROCESS-GLOBAL SWITCHES of the library, complete list (everything else is per call).  All of them select between
- * implementations that produce the same results (A/B measurements, parity tests); none is needed in production:
+/* PROCESS-GLOBAL SWITCHES of the library, complete list (everything else is per call).  The library reads NO environment
+ * variable.  Both select between implementations that produce the same results (measurements, parity tests, and the fall-back
+ * after a latched residency fault of the persistent rollout):
  *   g2v_linear_set_smallm_rows(rows)        row count up to which the wave-per-tile dense kernels are used (default 1024)
  *   g2v_dec_rollout_set_persistent(0 / 1)   persistent rollout kernels vs one launch per step (default 1)
- *   environment, read ONCE at first use:  G2V_NO_PERSIST=1 (initial value 0 of the switch above), G2V_PLAIN_STORES=1 (no
- *   write-through stores for the saved tensors of the per-step rollout kernels), G2V_NO_FUSED_WGRAD=1 (the persistent
- *   backward does not accumulate dW_hh1 itself), G2V_NO_FUSED_LOSS=1 (g2v_dec_rollout_fuses_loss answers 0),
- *   G2V_SMALLM_WGRAD_ROWS=n (row count up to which g2v_linear_bwd_weight uses its one-launch tile kernel; default 4095),
- *   G2V_SMALLM_WGRAD_RT=0 (that kernel with one 16 x 16 tile of dW per workgroup instead of 2 x 2; same bits),
- *   G2V_VQ_ASSIGN_SPLIT=0 (g2v_vq_assign_fwd at few rows as one pass per row tile instead of the codes split over workgroups).
  * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
@@ -234,20 +229,10 @@ typedef struct {          /* one direction of one layer, forward */
   /* Fused input projection (gi == NULL): gi_t = x_t W_ih^T + b_ih is computed inside the recurrent kernel, one step
    * ahead of its use (the gi array, its GEMM and its HBM round trip disappear).  Supported for in_dim == H == 64;
    * otherwise G2V_ERR_UNSUPPORTED and the caller computes gi with g2v_linear_fwd. */
-  const float* x;         /* (T,B,in_dim) layer input (an OUTPUT with the fused input layer below) */
+  const float* x;         /* (T,B,in_dim) layer input                       */
   const float* w_ih;      /* (3H,in_dim)                                    */
   const float* b_ih;      /* (3H)                                           */
   int in_dim;
-  /* Fused input LAYER (x_raw != NULL; with the fused input projection at H == 64, plain call only, every direction alike):
-   * the layer input is itself a dense layer of a raw input, x = x_raw W_in^T + b_in (the encoder's in_layer,
-   * model/Autoencoder_VQVAE_model.py:93).  It is computed inside the recurrent kernel two steps ahead of its use instead of by
-   * a g2v_linear_fwd launch in front of it; `x` is then an OUTPUT (T,B,H), written once, for the backward's weight gradients.
-   * Row (t, b) of x_raw sits at x_raw + b * raw_stride_b + t * raw_stride_t (a (B,T,D) tensor: T D and D); raw_dim <= 144. */
-  const float* x_raw;     /* raw input                                       */
-  const float* w_in;      /* (H, raw_dim)                                    */
-  const float* b_in;      /* (H)                                             */
-  int raw_dim;
-  int64_t raw_stride_b, raw_stride_t;
 } g2v_gru_dir;
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
@@ -350,14 +335,20 @@ typedef struct {           /* saved-for-backward / state arrays, all caller-owne
   float* gates1;           /* (T-1,B,4H)                                                      */
   float* bn_partial;       /* (2, nblk, 2, H) ping-pong per-block sums of (u-b), (u-b)^2      */
   float* bn_stats;         /* (T-1,2,H) batch mean / biased var per step (training)           */
-  /* Optional, all NULL / 0 = off: custom_loss (K10, train_eval/train_seq2seq.py:40-88) folded into the rollout pair, with the
-   * rollout's `target` as the loss target.  Set them (training only) where g2v_dec_rollout_fuses_loss() says 1, in BOTH calls of
-   * the pair.  The forward then accumulates the loss sums and the column norms while it produces y_t and leaves one code byte
-   * per element; the backward forms dLoss/dy_t from y_t, the byte and the column coefficient in its own tile load, so that
-   * g2v_custom_loss_fwd_bwd is not called, `dy` of g2v_dec_grads is OUTPUT only, and loss_terms is written by the BACKWARD
-   * call.  Same dy bits as g2v_custom_loss_fwd_bwd(g_scale = 1); the four loss sums are added in a different order.
-   * Saves 150 MB of HBM traffic and two launches per step at B = 4096, T = 34 -- and no time: the elementwise work costs the
-   * one-wave-per-SIMD rollout kernels about what the separate launch costs, so callers opt in. */
+  /* Optional, all NULL / 0 = off: custom_loss (K10, train_eval/train_seq2seq.py:40-88) carried by the rollout pair and a
+   * CHASER kernel, with the rollout's `target` as the loss target.  Where g2v_dec_rollout_fuses_loss() says 1 (training only):
+   *   g2v_dec_rollout_prepare(...)                      (clears the forward's progress words with its exchange records)
+   *   g2v_dec_rollout_fwd_prepared(..., s with loss_* set, ...)   on stream A: stores y_t write-through and publishes, per
+   *                                                     workgroup and step, that y_t is in memory
+   *   g2v_custom_loss_chase(..., same s, same workspace) on stream B, ordered behind g2v_dec_rollout_prepare and dispatched
+   *                                                     BEHIND the forward (see its comment): consumes y_t as it lands,
+   *                                                     writes loss_code, loss_coef, loss_partial
+   *   (join A and B)
+   *   g2v_dec_rollout_bwd[_prepared](..., same s, ...)  forms dLoss/dy_t from y_t, the code byte and the column coefficient in
+   *                                                     its own tile load; `dy` of g2v_dec_grads is OUTPUT only; writes loss_terms
+   * g2v_custom_loss_fwd_bwd is not called.  Same dy bits as g2v_custom_loss_fwd_bwd(g_scale = 1); the four loss sums are added
+   * in a different order.  Removes the 62 + 6 us launch pair that sat alone between the rollouts and 150 MB of HBM traffic per
+   * step at B = 4096, T = 34. */
   uint8_t* loss_code;      /* (T,B,D)   sign codes of the three |.| terms + the Dropout(0.95) flag */
   float* loss_coef;        /* (B,D)     w_var / numel / ||y[:,b,d]||_2                             */
   float* loss_partial;     /* (nblk,4)  per-workgroup loss sums                                    */
@@ -370,8 +361,7 @@ int g2v_dec_rollout_blocks(int B);
  * one launch per time step (any shape), and -- for H == 64, D == 135, B % 16 == 0, B / 16 <= the device's CU count --
  * ONE persistent launch for the whole rollout with register/LDS-resident weights and an in-kernel two-level exchange of
  * the BatchNorm partial sums (csrc/dec_persist.hpp).  The persistent one is used whenever it applies; this switch
- * (default 1, or 0 with the environment variable G2V_NO_PERSIST=1) exists for A/B measurements and parity tests.
- * Returns the previous setting. */
+ * (default 1) exists for A/B measurements, parity tests and the fall-back after a latched fault.  Returns the previous setting. */
 int g2v_dec_rollout_set_persistent(int enable);
 /* The persistent kernels need every workgroup of their launch resident at once; what a plain launch can check is checked
  * (B / 16 <= CU count, the occupancy query).  What it cannot see -- a CU mask, another tenant or a second persistent launch
@@ -381,11 +371,21 @@ int g2v_dec_rollout_set_persistent(int enable);
  * host synchronises anyway (the engine does after a training iteration's loss read-back, bench.py at the end of the timed
  * region); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step kernels. */
 int g2v_dec_rollout_persist_fault(int clear);
-/* 1 where the rollout pair can carry custom_loss itself (the loss_* fields of g2v_dec_saved): wherever the persistent path
- * applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent enabled), 2 <= T <= 256; G2V_NO_FUSED_LOSS=1 forces 0.
- * Elsewhere leave the loss_* fields NULL and call g2v_custom_loss_fwd_bwd between the two rollouts (setting them anyway is
- * refused with G2V_ERR_UNSUPPORTED, never silently ignored). */
+/* 1 where the rollout pair + chaser can carry custom_loss (the loss_* fields of g2v_dec_saved): wherever the persistent path
+ * applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent enabled), 2 <= T <= 256.  Elsewhere leave the loss_*
+ * fields NULL and call g2v_custom_loss_fwd_bwd between the two rollouts (setting them anyway is refused with
+ * G2V_ERR_UNSUPPORTED, never silently ignored). */
 int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T);
+/* The chaser (csrc/dec_persist.hip, loss_chase_kernel): one light workgroup per 16 batch rows (256 threads, <= 128 registers per
+ * lane, 64 B of LDS) that is CO-RESIDENT with the persistent forward rollout -- which runs one wave per SIMD and leaves a third of
+ * every CU's registers unused -- polls that workgroup's progress word and consumes y_t as it lands.  `s`: the SAME struct the
+ * forward of this call runs with (y, loss_code, loss_coef, loss_partial, loss_w); `fwd_workspace`: the SAME workspace (its
+ * progress words).  Launch it on a second stream, ordered behind g2v_dec_rollout_prepare, and so that it is DISPATCHED BEHIND the
+ * forward (the engine puts it behind the ~30 us of quantiser-statistics kernels of its side branch): the chaser waits for the
+ * rollout, never the other way round, but a CU that already holds two chaser workgroups has no room for a rollout workgroup.
+ * Every wait is bounded and ends in the fault latch (g2v_dec_rollout_persist_fault), as the exchange's do. */
+int g2v_custom_loss_chase(const float* target /* (B,T,D) */, const g2v_dec_saved* s, const uint8_t* keep95 /* (T-1,B,D) */,
+                          int T, int B, int D, int H, void* fwd_workspace, size_t fwd_workspace_bytes, g2v_stream_t stream);
 /* workspace: the weights re-laid-out in MFMA fragment order (packed once per call) + the persistent kernel's exchange
  * state (zeroed by a memset node in front of its launch). */
 size_t g2v_dec_rollout_fwd_workspace(int D, int H);
@@ -415,7 +415,7 @@ typedef struct {           /* gradient outputs of the rollout backward, caller-o
 size_t g2v_dec_rollout_bwd_workspace(int D, int H);
 /* Which GRU weight gradients g2v_dec_rollout_bwd can accumulate inside its persistent kernel at this batch / shape: bit m of
  * the result <-> matrix m of (W_ih0, W_hh0, W_ih1, W_hh1).  Today 8 (W_hh1: what the kernel's register budget has room for) where
- * the persistent path applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count), else 0; G2V_NO_FUSED_WGRAD=1 forces 0.
+ * the persistent path applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count), else 0.
  * The caller sets dw_gru[m] / db_gru[m] for exactly those matrices (or for none) and forms the other products itself. */
 int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H);
 int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g,

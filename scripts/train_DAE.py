@@ -135,7 +135,8 @@ def main(config: dict) -> None:
         loaders = []
         for k, (paths, shuffle) in enumerate(((args.train_data_path, True), (args.val_data_path, False))):
             ds = TrinityDataset_DAE(args, lmdb_dir=paths[0], n_poses=args.n_poses, subdivision_stride=args.subdivision_stride,
-                                    pose_resampling_fps=args.motion_resampling_framerate, data_mean=args.data_mean, data_std=args.data_std)
+                                    pose_resampling_fps=args.motion_resampling_framerate, data_mean=args.data_mean, data_std=args.data_std,
+                                    all_frames=bool(getattr(args, "dae_all_frames", False)))
             loaders.append(CacheLoader(len(ds), args.batch_size,
                                        lambda bs, sh, seed, dl, ds=ds: ds.batches(bs, device, shuffle=sh, seed=seed, drop_last=dl),
                                        shuffle=shuffle, drop_last=True, seed=77 + k))

@@ -90,7 +90,10 @@ def cached_chunk_loaders(args):
     from gesture2vec_amd.data.dataset import CacheLoader, TrinityDataset_DAEed_Autoencoder
     rep_model = None
     ckpt = getattr(args, "rep_learning_checkpoint", "") or ""
-    if ckpt and os.path.exists(ckpt):
+    if ckpt:
+        if not os.path.exists(ckpt):      # the reference fails here too (load_checkpoint_and_model): never train on un-encoded poses by accident
+            raise FileNotFoundError(f"rep_learning_checkpoint {ckpt!r} does not exist (leave the option empty for the raw-pose "
+                                    "ablation, lmdb_data_loader.py:650-651)")
         _a, rep_model, _l, _lang, _dim = utils.train_utils.load_checkpoint_and_model(ckpt, device, "DAE")
         rep_model.train(False)
     loaders = []

@@ -141,6 +141,11 @@ def train_epochs(args, train_data_loader, test_data_loader, lang_model, pose_dim
 
 def main(config: dict):
     args = config["args"]
+    if not getattr(args, "synthetic", False):
+        # as the reference's main does (train_text2embedding.py:506-508): checkpoints, the log and the sentence-level cache
+        # (TrinityDataset_sentencelevel.cache_dir) all live next to the chunk VQ-VAE's checkpoint
+        args.model_save_path = os.path.dirname(args.autoencoder_checkpoint) + "/text2mbedding/"
+        os.makedirs(args.model_save_path, exist_ok=True)
     if args.random_seed >= 0:
         torch.manual_seed(args.random_seed)
         np.random.seed(args.random_seed)
@@ -162,7 +167,8 @@ def main(config: dict):
 
 def cached_sentence_loaders(args):
     """The reference's data side of Part d (train_text2embedding.py:510-570): `TrinityDataset_sentencelevel` over
-    `<train_data_path[0]>_cache` / `<val_data_path[0]>_cache`, the frozen chunk VQ-VAE of `args.autoencoder_checkpoint` assigning the
+    `<model_save_path>lmdb/<basename(train_data_path[0])>_sentence_level_cache` (and the same for `val_data_path[0]`;
+    lmdb_data_loader.py:1107-1127), the frozen chunk VQ-VAE of `args.autoencoder_checkpoint` assigning the
     code ids, and the vocabulary pickled next to the data (`vocab_cache.pkl`, :552-556; built by the reference's `build_vocab` with
     fastText, which is outside the hot path).  Code assignment runs as ONE device launch per batch (gesture2vec_amd/data/dataset.py)
     instead of per item on the CPU."""

@@ -104,7 +104,11 @@ def test_frame_dataset_of_the_dae_trainer(tmp_path):
     mean, std = rng.standard_normal(D), np.abs(rng.standard_normal(D)) + 0.1
     samples = _chunk_samples(n, T, D, 3)
     write_cache(str(tmp_path / "trn_cache"), samples)
-    ds = TrinityDataset_DAE(argparse.Namespace(), str(tmp_path / "trn"), T, 10, 20, mean, std)
+    # the reference's epoch: __len__ = LMDB entries (chunks), __getitem__ indexes the per-frame list (:357-390) -> the first n frames
+    ref_ds = TrinityDataset_DAE(argparse.Namespace(), str(tmp_path / "trn"), T, 10, 20, mean, std)
+    assert len(ref_ds) == n and ref_ds.n_frames_total == n * T
+    assert torch.equal(torch.cat([b[0] for b in ref_ds.batches(4, "cpu", shuffle=False, drop_last=False)])[:, :, 0], ref_ds.frames[:n])
+    ds = TrinityDataset_DAE(argparse.Namespace(), str(tmp_path / "trn"), T, 10, 20, mean, std, all_frames=True)
     assert len(ds) == n * T
     noisy, orig = ds[T + 2]                                              # chunk 1, frame 2
     ref = torch.from_numpy(((samples[1][1] - mean) / np.clip(std, 0.01, None))[2].astype(np.float32))
@@ -134,7 +138,7 @@ def test_sentence_dataset_collates_like_word_seq_collate_fn(tmp_path):
         samples.append([words, (rng.standard_normal((12, D))).astype(np.float16), [0], [[0.0, 1.0]],
                         {"vid": "v", "start_time": 0.0, "end_time": 5.0}, rng.standard_normal((S, E)).astype(np.float32),
                         np.zeros(3, dtype=np.float32)])
-    write_lmdb(str(tmp_path / "trn_cache"), {sample_key(i): serialize(s) for i, s in enumerate(samples)})
+    write_lmdb(str(tmp_path / "trn_sentence_level_cache"), {sample_key(i): serialize(s) for i, s in enumerate(samples)})
     calls = []
 
     class FakeVQ:
@@ -155,3 +159,42 @@ def test_sentence_dataset_collates_like_word_seq_collate_fn(tmp_path):
     order = [1, 4, 3, 0, 2]                                               # stable sort by length, descending
     ref_lat = torch.from_numpy(np.stack([samples[i][5] for i in order]))
     assert torch.equal(lat, ref_lat) and torch.equal(codes, FakeVQ().assign(ref_lat.reshape(-1, E)).view(5, S))
+
+
+def test_sentence_cache_location_arity_and_quantisers_without_assign(tmp_path):
+    """Round-3 advisor findings.  (1) The dataset opens the cache where the reference's does (lmdb_data_loader.py:1107-1127):
+    `model_save_path + "lmdb/" + basename(lmdb_dir) + "_sentence_level_cache"` (`_cache` with sentence_level != "True"), not the
+    4-field chunk cache `<lmdb_dir>_cache`; (2) a chunk-cache sample is refused with a clear message; (3) a quantiser module with no
+    assign() (any other nn.Module with the reference's 4-tuple forward) takes the reference's own route, argmax(encodings)."""
+    from gesture2vec_amd.data.dataset import TrinityDataset_sentencelevel
+    from gesture2vec_amd.data import write_lmdb
+    S, E, D = 2, 4, 3
+    rng = np.random.default_rng(9)
+    msp = str(tmp_path / "ckpt") + "/text2mbedding/"
+    args = argparse.Namespace(model_save_path=msp, sentence_level="True")
+    assert TrinityDataset_sentencelevel.cache_dir(args, "/data/trn/lmdb_train") == msp + "lmdb/lmdb_train_sentence_level_cache"
+    args.sentence_level = "False"
+    assert TrinityDataset_sentencelevel.cache_dir(args, "/data/trn/lmdb_train") == msp + "lmdb/lmdb_train_cache"
+    args.sentence_level = "True"
+    with pytest.raises(FileNotFoundError, match="lmdb_train_sentence_level_cache"):
+        TrinityDataset_sentencelevel(args, "/data/trn/lmdb_train", 4, 10, 20, np.zeros(D), np.ones(D))
+    sent = [[["a", 0.0, 0.1]], rng.standard_normal((6, D)).astype(np.float16), [0], [[0.0]], {"vid": "v", "end_time": 5.0},
+            rng.standard_normal((S, E)).astype(np.float32), np.zeros(2, dtype=np.float32)]
+    os.makedirs(msp + "lmdb")
+    write_lmdb(msp + "lmdb/lmdb_train_sentence_level_cache", {sample_key(0): serialize(sent), sample_key(1): serialize(sent)})
+    lang = argparse.Namespace(get_word_index=lambda w: 4)
+
+    class NoAssign(torch.nn.Module):          # the reference's quantiser contract only: forward -> (loss, quantized, perplexity, encodings)
+        def forward(self, rows):
+            enc = torch.zeros(rows.shape[0], 5)
+            enc[torch.arange(rows.shape[0]), (rows[:, 0] > 0).long() * 3] = 1.0
+            return torch.tensor(0.0), rows, torch.tensor(0.0), enc
+    ds = TrinityDataset_sentencelevel(args, "/data/trn/lmdb_train", 4, 10, 20, np.zeros(D), np.ones(D), lang_model=lang,
+                                      vq_net=argparse.Namespace(vq_layer=NoAssign()))
+    (_w, _l, _p, _a, _x, lat, codes, _g), = list(ds.batches(2, "cpu", shuffle=False))
+    assert torch.equal(codes, ((lat[:, :, 0] > 0).long() * 3))
+    # a chunk cache (4 fields) at that place: a clear error instead of an unpack failure
+    write_cache(msp + "lmdb/lmdb_val_sentence_level_cache", _chunk_samples(1, 6, D, 1))
+    bad = TrinityDataset_sentencelevel(args, "/data/val/lmdb_val", 4, 10, 20, np.zeros(D), np.ones(D), lang_model=lang)
+    with pytest.raises(ValueError, match="4 fields"):
+        bad[0]

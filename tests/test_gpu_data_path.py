@@ -86,7 +86,7 @@ def test_vqvae_and_dae_trainers_run_on_caches(tmp_path):
     out_d = str(tmp_path / "dae")
     cfg = _yaml(str(tmp_path / "dae.yml"), "DAE_synthetic.yml", **common)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_DAE.py"), "--config", cfg, "--batch_size", "128",
-                        "--epochs", "20", "--model_save_path", out_d, "--name", "d"], cwd=os.path.join(ROOT, "scripts"),
+                        "--epochs", "20", "--dae_all_frames", "--model_save_path", out_d, "--name", "d"], cwd=os.path.join(ROOT, "scripts"),
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     dae_ckpt = os.path.join(out_d, "d_H40_checkpoint_020.bin")
@@ -132,6 +132,10 @@ def test_sentence_loader_assigns_the_codes_the_per_item_quantiser_call_gives_and
     os.makedirs(tmp_path / "data")
     pickle.dump(vocab, open(tmp_path / "data" / "vocab_cache.pkl", "wb"))
     words_all = list(vocab.word2index)
+    # where the reference's dataset looks (lmdb_data_loader.py:1107-1127) once its trainer has reset model_save_path to
+    # dirname(autoencoder_checkpoint) + "/text2mbedding/" (train_text2embedding.py:506-508)
+    msp = os.path.dirname(vq_ckpt) + "/text2mbedding/"
+    os.makedirs(msp + "lmdb")
     for name, n in (("trn", 24), ("val", 8)):
         items = {}
         for i in range(n):
@@ -140,22 +144,35 @@ def test_sentence_loader_assigns_the_codes_the_per_item_quantiser_call_gives_and
             lat = (rng.standard_normal((S, E)) * 0.5).astype(np.float32)
             items[sample_key(i)] = serialize([words, rng.standard_normal((120, D)).astype(np.float16), [0], [[0.0]],
                                               {"vid": "v", "start_time": 0.0, "end_time": 9.0}, lat, np.zeros(2, dtype=np.float32)])
-        write_lmdb(str(tmp_path / "data" / f"{name}_cache"), items)
-    ds = TrinityDataset_sentencelevel(argparse.Namespace(), str(tmp_path / "data" / "trn"), 20, 10, 20, np.zeros(D), np.ones(D),
+        write_lmdb(msp + f"lmdb/{name}_sentence_level_cache", items)
+    ds_args = argparse.Namespace(model_save_path=msp, sentence_level="True")
+    ds = TrinityDataset_sentencelevel(ds_args, str(tmp_path / "data" / "trn"), 20, 10, 20, np.zeros(D), np.ones(D),
                                       lang_model=vocab, vq_net=vq_net)
     (words, lengths, poses, audio, aux, lat, codes, gpt3), = list(ds.batches(24, DEV, shuffle=False))
     assert codes.shape == (24, S) and codes.dtype == torch.int64 and lengths.tolist() == sorted(lengths.tolist(), reverse=True)
     for bidx in (0, 5, 23):                                   # the per-item route of the reference on the same rows
         _loss, _q, _perp, enc = vq_net.vq_layer(lat[bidx])
         assert torch.equal(torch.argmax(enc, dim=1), codes[bidx])
-    out_t = str(tmp_path / "t2e")
+    # the quantisers the reference's checkpoints actually carry (VQ_Payam_GSSoft: Autoencoder_VQVAE_model.py:816-820) and the
+    # plain VQ_Payam: the same loader, codes = argmax(encodings) of the module's own forward (round-3 advisor finding: only the
+    # EMA quantiser had assign())
+    from model.Autoencoder_VQVAE_model import VQ_Payam, VQ_Payam_GSSoft
+    torch.manual_seed(3)
+    for q in (VQ_Payam_GSSoft(512, E, 0.25).to(DEV), VQ_Payam(512, E, 0.25).to(DEV)):
+        q.train(False)
+        ds_q = TrinityDataset_sentencelevel(ds_args, str(tmp_path / "data" / "trn"), 20, 10, 20, np.zeros(D), np.ones(D),
+                                            lang_model=vocab, vq_net=argparse.Namespace(vq_layer=q))
+        (_w, _l, _p, _a, _x, lat_q, codes_q, _g), = list(ds_q.batches(24, DEV, shuffle=False))
+        with torch.no_grad():
+            ref_codes = torch.argmax(q(lat_q.reshape(24 * S, E))[3], dim=1).view(24, S)
+        assert torch.equal(codes_q, ref_codes), type(q).__name__
     cfg = _yaml(str(tmp_path / "t2e.yml"), "seq2seq_synthetic.yml", train_data_path=[str(tmp_path / "data" / "trn")],
                 val_data_path=[str(tmp_path / "data" / "val")], data_mean=[0.0] * D, data_std=[1.0] * D, autoencoder_checkpoint=vq_ckpt)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "train_text2embedding.py"), "--config", cfg, "--batch_size", "8",
-                        "--epochs", "10", "--hidden_size", "64", "--model_save_path", out_t, "--name", "t"], cwd=os.path.join(ROOT, "scripts"),
-                       capture_output=True, text=True, timeout=900)
+                        "--epochs", "10", "--hidden_size", "64", "--model_save_path", str(tmp_path / "ignored"), "--name", "t"],
+                       cwd=os.path.join(ROOT, "scripts"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     log = r.stdout + r.stderr
     assert "EP 10 (  3) |" in log and "[VAL] loss:" in log
-    ck = torch.load(os.path.join(out_t, "t_checkpoint_010.bin"), map_location="cpu", weights_only=False)
+    ck = torch.load(os.path.join(msp, "t_checkpoint_010.bin"), map_location="cpu", weights_only=False)      # next to the VQ-VAE's checkpoint
     assert ck["gen_dict"]["encoder.embedding.weight"].shape[0] == vocab.n_words

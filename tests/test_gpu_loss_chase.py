@@ -1,8 +1,9 @@
-"""custom_loss (train_eval/train_seq2seq.py:40-88) carried by the persistent rollout pair (g2v_dec_saved.loss_*, include/g2v.h)
-against the separate g2v_custom_loss_fwd_bwd launch between the two rollouts: both form dLoss/dy through the same device
-functions (csrc/common.hpp: loss_sign_code / loss_grad_const / loss_col_coef / loss_grad), so every gradient, and with it every
-weight, Adam moment and the codebook, must be BITWISE equal after three fused train steps; the four loss sums are added in a
-different order (per workgroup tile instead of per 256 columns), so the loss terms agree to fp32 summation accuracy."""
+"""custom_loss (train_eval/train_seq2seq.py:40-88) carried by the CHASER kernel beside the persistent forward rollout and by the
+backward rollout's tile load (g2v_custom_loss_chase, g2v_dec_saved.loss_*; include/g2v.h) against the separate
+g2v_custom_loss_fwd_bwd launch between the two rollouts: both form dLoss/dy through the same device functions (csrc/common.hpp:
+loss_sign_code / loss_grad_const / loss_col_coef / loss_grad), so every gradient, and with it every weight, Adam moment and the
+codebook, must be BITWISE equal after three fused train steps; the four loss sums are added in a different order (per workgroup
+tile instead of per 256 columns), so the loss terms agree to fp32 summation accuracy."""
 import pytest
 import torch
 
@@ -14,29 +15,47 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("B,p,n_pre,conditioned,T", [(64, 0.0, 1, True, 34), (48, 0.2, 1, True, 34), (32, 0.0, 4, True, 34),
-                                                     (32, 0.2, 1, False, 34), (1024, 0.0, 1, True, 34), (32, 0.0, 1, True, 2),
-                                                     (32, 0.0, 1, True, 3), (16, 0.0, 1, True, 4)])
-def test_loss_folded_into_the_rollouts_equals_the_separate_loss_kernel(B, p, n_pre, conditioned, T):
+                                                     (32, 0.2, 1, False, 34), (1024, 0.0, 1, True, 34), (4096, 0.0, 1, True, 34),
+                                                     (32, 0.0, 1, True, 2), (32, 0.0, 1, True, 3), (16, 0.0, 1, True, 4)])
+@pytest.mark.parametrize("graph", [False, True])
+def test_loss_chaser_beside_the_rollout_equals_the_separate_loss_kernel(B, p, n_pre, conditioned, T, graph):
+    """eager launches and the step replayed from a hipGraph (the chaser is a parallel branch of the graph); small batches run
+    the branch regime through overlap_min_rows = 0 (one row of workgroups: the exchange's one-hop form; teacher forcing, the
+    unconditioned decoder, inter-layer dropout, T = 2 .. 4: no / one / two chased steps)."""
+    if graph and B not in (64, 1024, 4096):
+        pytest.skip("graph replay is covered at three sizes")
     D, H, K = 135, 64, 512
     sd = O.init_vqvae_state(D, H, 2, K, seed=11)
     kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
     xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(170 + s)).to(DEV) for s in range(3)]
     xs[1][:, :, 7] = xs[1][:, :1, 7]       # a column the model cannot match exactly but whose target is constant in time
     got = {}
-    for fold in (False, True):
+    for chase in (False, True):
         eng = _engine(sd, D, H, K, T, p)
         eng.seed = 5
         eng.n_pre, eng.conditioned = n_pre, conditioned
-        eng._loss_fold = fold
+        eng.loss_chase = chase
+        eng.overlap_min_rows = 0
         terms, dys = [], []
-        for x in xs:
-            eng.train_step(x, x, **kw)
-            assert eng.buffers(B)["loss_folded"] is fold          # the path under test is the one that ran
+        xg = torch.empty_like(xs[0])
+        g = None
+        for s, x in enumerate(xs):
+            xg.copy_(x)
+            if graph and s == 1:             # step 0 ran eagerly (it sizes the workspaces); capture, then replay steps 1 and 2
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                with torch.cuda.graph(g):
+                    eng.train_step(xg, xg, **kw)
+            if g is not None:
+                g.replay()
+            else:
+                eng.train_step(xg, xg, **kw)
+            assert eng.buffers(B)["loss_folded"] is chase          # the path under test is the one that ran
             terms.append(eng.loss_terms.clone())
             dys.append(eng.buffers(B)["dy"][1:].clone())
         torch.cuda.synchronize()
         eng.check_faults()
-        got[fold] = (eng, terms, dys)
+        got[chase] = (eng, terms, dys)
     (ref, t_ref, dy_ref), (eng, t_got, dy_got) = got[False], got[True]
     for s in range(3):
         assert torch.equal(dy_got[s], dy_ref[s]), ("dy", s)
@@ -111,26 +130,3 @@ def test_input_dropout_drawn_inside_its_kernel_equals_the_explicit_mask_route():
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     for k in ("keep95", "keep_l0", "x_drop"):
         assert torch.equal(a.buffers(B)[k], b.buffers(B)[k]), k
-
-
-@pytest.mark.parametrize("B,p", [(64, 0.0), (48, 0.2)])
-def test_input_layer_inside_the_encoder_gru_kernel_matches_the_separate_launch(B, p):
-    """g2v_gru_dir.x_raw: in_layer (Linear(D -> H), reference :93) computed by the encoder's forward GRU kernel two steps ahead of
-    its use, against the dense-layer launch in front of it.  Another kernel, another k order of the 135-long dot products: the
-    encoder input agrees to fp32 rounding, and with it two fused train steps."""
-    T, D, H, K = 34, 135, 64, 512
-    sd = O.init_vqvae_state(D, H, 2, K, seed=41)
-    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
-    xs = [torch.randn(B, T, D, generator=torch.Generator().manual_seed(470 + s)).to(DEV) for s in range(2)]
-    got = {}
-    for fused in (False, True):
-        eng = _engine(sd, D, H, K, T, p)
-        eng.seed = 5
-        eng._enc_fused_in = fused
-        for x in xs:
-            eng.train_step(x, x, **kw)
-        torch.cuda.synchronize()
-        got[fused] = (eng.buffers(B)["xin"].clone(), eng.flat.clone(), eng.loss_terms.clone())
-    torch.testing.assert_close(got[True][0], got[False][0], rtol=2e-5, atol=2e-6)
-    torch.testing.assert_close(got[True][2], got[False][2], rtol=1e-4, atol=1e-6)
-    assert float((got[True][1] - got[False][1]).abs().max()) <= 2 * 5e-4 * 0.05
