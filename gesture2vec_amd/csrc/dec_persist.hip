@@ -32,9 +32,6 @@ extern "C" int g2v_read_pstamps(unsigned long long* out) {
 #define PSTAMP(dir, k)
 #endif
 
-int g2v_dbg_flags = 0;
-extern "C" void g2v_dbg_set(int v) { g2v_dbg_flags = v; }
-
 namespace g2v {
 
 namespace {
@@ -72,7 +69,6 @@ struct DecPersistArgs {
   PersistX x;
   int T, B, nblk, n_pre, conditioned, training;
   float p_drop;
-  int dbg;
 };
 
 // A-operand fragments from LDS (conflict-free ds_read_b128: consecutive lanes read consecutive 16 bytes)
@@ -239,10 +235,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   const int T = a.T, B = a.B;
   const int f0 = 16 * wave + 4 * q;                  // this lane's 4 hidden features
   const bool training = a.training != 0;
-  // The serial chain of the step owns the SIMD: whatever is co-resident (the loss chaser's wave, a statistics kernel) issues in
-  // the gaps only.  Without it the chaser's ~300 VALU instructions per step and wave interleaved with the gate epilogues at equal
-  // priority (arbitration is by priority, then age): cell phases +500..2000 cycles in the stamped workgroups.
-  if (!(a.dbg & 32)) __builtin_amdgcn_s_setprio(3);
   // custom_loss rides beside this kernel, not inside it (round 3 measured the fold: every VALU instruction costs its full issue
   // time in a one-wave-per-SIMD kernel on a serial chain, 55-60 us for the 68 us it removed).  With sv.loss_code set the kernel only
   // HANDS y_t OVER to the co-resident chaser (loss_chase_kernel below): y tiles are stored write-through (sc1) and, once every wave
@@ -250,8 +242,6 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   // barrier, one lane publishes the step number in this workgroup's progress word (MI355X_MICROARCH.md, "Valid forms": sc1
   // payload, drained, barrier, sc1 flag by one lane).  Cost here: one 4-byte store per step.
   const bool chase = training && a.sv.loss_code != nullptr;
-  const bool wt_y = chase && !(a.dbg & 1);
-  const bool step_flags = chase && !(a.dbg & 16);
   unsigned* const yflag = a.x.yflag + (size_t)b * PX_FLAG_STRIDE;
   const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
   const float keep_scale = 1.0f / (1.0f - a.p_drop);
@@ -308,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     const int64_t tile = ((int64_t)ts * B + b0) * D;
     const float* Ys = smem + L_YT;
     for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
-      st4(a.sv.y + tile + 4 * e4, reinterpret_cast<const float4*>(Ys)[e4], wt_y);      // (chase: write-through, the chaser reads it)
+      st4(a.sv.y + tile + 4 * e4, reinterpret_cast<const float4*>(Ys)[e4], chase);      // (chase: write-through, the chaser reads it)
       if (nxt && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
     }
   };
@@ -379,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         // chase: y_0 .. y_{t-2} of these 16 rows are in memory (every wave drained its stores in front of hop 1, the workgroup
         // has met at barriers since): tell the chaser.  HERE, not earlier: its burst of loads shares this CU's in-order memory
         // pipeline with the exchange's sweeps; from here to the next step's hop 1 the rollout only stores.
-        if (step_flags && t >= 2 && tid == 0) __hip_atomic_store(yflag, (unsigned)(t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (chase && t >= 2 && tid == 0) __hip_atomic_store(yflag, (unsigned)(t - 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       // y_{t-1} (and xin_{t-1}) out, from the dense tiles the previous step's out-layer epilogue left (valid until this step's):
       // issued HERE so that the next wait on vector memory -- the sweep of the NEXT step's hop 1 -- is a whole step away.  Right
@@ -434,7 +424,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       // y_{T-1} is left for the chaser when the rollout ends
       if (chase && !has_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       lds_barrier();
-      if (step_flags && !has_next && t >= 2 && tid == 0)
+      if (chase && !has_next && t >= 2 && tid == 0)
         __hip_atomic_store(yflag, (unsigned)(t - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       PSTAMP(0, 5);
       // ---- y_t = out_layer(h1_t) -> dense tile --------------------------------------------------------------------
@@ -512,7 +502,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
           yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
         }
-        st4(a.sv.y + tile + e, make_float4(yv[0], yv[1], yv[2], yv[3]), wt_y);
+        st4(a.sv.y + tile + e, make_float4(yv[0], yv[1], yv[2], yv[3]), chase);
         if (!has_next) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -606,27 +596,57 @@ struct LossChaseArgs {
   const unsigned* yflag;
   int T, B;
   float lc3;                // w_var / (T B D)
-  int dbg;
 };
 
 __global__ __launch_bounds__(256, 4) void loss_chase_kernel(LossChaseArgs a) {
+  // Target rows of one step, fetched as 16-byte ALIGNED spans and staged as a dense tile: row r of the tile sits in the (B,T,D)
+  // target at a float offset that is only 4-byte aligned (D = 135), so each row's 540 bytes are fetched as the <= 35 aligned
+  // 16-byte pieces that cover them and written to LDS shifted back by the row's misalignment (0..3 floats): Lt[buf] is then the
+  // step's target tile in the same tile-linear order as y, read back as three aligned 16-byte vectors per thread.  Why through
+  // LDS at all: read element-wise in the tile-linear mapping (12 dwords per thread, lanes 16 bytes apart, two or three rows per
+  // wave-instruction) the target was 48 wave-instructions and ~480 line requests per step and CU; now 12 and ~110.
+  // What the chaser costs the co-resident rollout (measured by switching its parts off in turn, 300-step runs on one box): its
+  // arithmetic nothing, its polls nothing, its write-through y loads ~5 us, the target's 75 MB from HBM 35-45 us with default-policy
+  // loads in either mapping, ~12 us when the same instructions hit in cache -- the rollout writes 17 MB of saved tensors per step
+  // at ~7 B / clock / CU in its cell phases, about what a CU can stream, so every byte of HBM traffic beside it is paid for; with
+  // non-temporal loads ~30 us.
+  __shared__ __attribute__((aligned(16))) float Lt[2][16 * D + 16];
   __shared__ float red[16];
   constexpr int NQ = (16 * D) / 4;                   // 540 float4 per 16 x D tile: threads 0..27 own a third one
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.x, b0 = b * 16;
   const int T = a.T, B = a.B;
   const bool has3 = tid + 512 < NQ;
-  const int q4[3] = {tid, tid + 256, has3 ? tid + 512 : 0};
-  // tile-linear element e = 4 q + r <-> (row e / D, column e % D); the target is (B,T,D): row stride T * D
-  int toff[3][4];
+  const int q4[3] = {tid, tid + 256, has3 ? tid + 512 : 0};      // tile-linear element e = 4 q + r <-> (row e / D, column e % D)
+  // staging role: thread (row tid >> 4, piece column tid & 15) fetches pieces c, c + 16, c + 32 (< 35) of its row
+  const int srow = tid >> 4, scol = tid & 15;
+  const int64_t srow_off = (int64_t)(b0 + srow) * T * D;          // float offset of the row's frame 0
+  const int64_t tgt_floats = (int64_t)B * T * D;
+  float4 stg[3];
+  auto stage_request = [&](int t) {
+    const int64_t base = (srow_off + (int64_t)t * D) & ~(int64_t)3;      // aligned span start
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int e = 4 * q4[j] + r, row = e / D;
-      toff[j][r] = row * T * D + (e - row * D);
+    for (int k = 0; k < 3; ++k) {
+      const int pc = scol + 16 * k;
+      const int64_t o = base + 4 * pc;
+      const bool ok = pc < 35 && o + 3 < tgt_floats;                 // (the last row's span may end past the tensor)
+      // non-temporal: each byte is read once; with default-policy loads the same burst cost the co-resident rollout 13 us more
+      const f32x4 v = ok ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(a.target + o)) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      stg[k] = make_float4(v[0], v[1], v[2], v[3]);
     }
-  const float* tp = a.target + (int64_t)b0 * T * D;
+  };
+  auto stage_commit = [&](int buf, int t) {
+    const int sh = (int)((srow_off + (int64_t)t * D) & 3);            // the row's misalignment at this step
+    float* dst = &Lt[buf][srow * D] - sh;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int c0 = 4 * (scol + 16 * k) - sh;                        // column of the piece's first float
+      const float v[4] = {stg[k].x, stg[k].y, stg[k].z, stg[k].w};
+#pragma unroll
+      for (int i2 = 0; i2 < 4; ++i2)
+        if (c0 + i2 >= 0 && c0 + i2 < D) dst[4 * (scol + 16 * k) + i2] = v[i2];
+    }
+  };
   const unsigned* flag = a.yflag + (size_t)b * PX_FLAG_STRIDE;
   float yprev[3][4], ss[3][4];
   uint32_t pend[3];                                  // step t-1's code bytes, sign(y_t - y_{t-1}) still missing
@@ -638,31 +658,31 @@ __global__ __launch_bounds__(256, 4) void loss_chase_kernel(LossChaseArgs a) {
            ((k & 0xff000000u) ? 0x40000000u : 0u);
   };
   // step 0: y_0 = target frame 0 (:1039-1040): sign(y - tgt) = 0, no y_{-1}
+  stage_request(0);
+  stage_commit(0, 0);
+  if (T > 1) stage_request(1);
+  __syncthreads();
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
+    const float4 t4 = *reinterpret_cast<const float4*>(&Lt[0][4 * q4[j]]);
+    const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float v = tp[toff[j][r]];
-      yprev[j][r] = v;
-      ss[j][r] = fmaf(v, v, 0.f);
+      yprev[j][r] = tv[r];
+      ss[j][r] = fmaf(tv[r], tv[r], 0.f);
     }
     pend[j] = 0x05050505u | keep_bits(0, j);         // (0 + 1) | (0 + 1) << 2
   }
   for (int t = 1; t < T; ++t) {
-    // what does not depend on the rollout first: target values and keep flags of step t
-    float tg[3][4];
+    const int buf = t & 1;
+    // what does not depend on the rollout first: the target rows of step t (requested an iteration ago) and its keep flags
+    stage_commit(buf, t);                            // (its previous readers passed the barrier of the iteration before)
     uint32_t kb[3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tg[j][r] = (a.dbg & 128) ? (float)(t + r) : tp[toff[j][r] + t * D];
-      kb[j] = (a.dbg & 128) ? (uint32_t)t : keep_bits(t, j);
-    }
+    for (int j = 0; j < 3; ++j) kb[j] = keep_bits(t, j);
     if (tid == 0) {
       unsigned spins = 0;
-      const unsigned need = (a.dbg & 8) ? (unsigned)(T - 1) : (unsigned)t;
-      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
-        if (a.dbg & 4) __builtin_amdgcn_s_sleep(64); else
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)t) {
         __builtin_amdgcn_s_sleep(8);
         ++spins;
         if (spins > 4000000u || ((spins & 1023u) == 0 &&
@@ -672,34 +692,25 @@ __global__ __launch_bounds__(256, 4) void loss_chase_kernel(LossChaseArgs a) {
         }
       }
     }
-    __syncthreads();
+    __syncthreads();                                 // the flag has been seen; the staged tile is complete
     __amdgpu_buffer_rsrc_t yr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.y) + ((int64_t)t * B + b0) * D, 0,
                                                                   16 * D * 4, 0x00020000);
     u32x4 yv4[3];
-    if (a.dbg & 128) {
-#pragma unroll
-      for (int j = 0; j < 3; ++j) yv4[j] = (u32x4){kb[j], kb[j] + 1u, 3u, 4u};
-    } else {
 #pragma unroll
     for (int j = 0; j < 3; ++j) yv4[j] = px_ld(yr, (unsigned)q4[j] * 16u);      // sc1: past this CU's L1, never a stale line
-    }
+    if (t + 1 < T) stage_request(t + 1);             // all of this step's vector-memory loads leave together, right at the flag
     uint32_t done[3];
-    if (a.dbg & 64) {
-      uint32_t* cp = reinterpret_cast<uint32_t*>(a.code + ((int64_t)(t - 1) * B + b0) * D);
-      cp[q4[0]] = yv4[0][0] | __float_as_uint(tg[0][0]) | kb[0];
-      cp[q4[1]] = yv4[1][0] | __float_as_uint(tg[1][1]) | kb[1];
-      if (has3) cp[q4[2]] = yv4[2][0] | __float_as_uint(tg[2][2]) | kb[2];
-      continue;
-    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const bool live = j < 2 || has3;
       uint32_t nb = 0u, cur = 0u;
+      const float4 t4 = *reinterpret_cast<const float4*>(&Lt[buf][4 * q4[j]]);
+      const float tv[4] = {t4.x, t4.y, t4.z, t4.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned bits = yv4[j][r];
         const float v = __uint_as_float(bits);
-        const float dlt = v - tg[j][r], stp = v - yprev[j][r];
+        const float dlt = v - tv[r], stp = v - yprev[j][r];
         if (live) {
           l1 += fabsf(dlt);
           sq += dlt * dlt;
@@ -791,7 +802,6 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
   a.p_drop = p_drop;
-  a.dbg = g2v_dbg_flags;
   const size_t lds = dec_persist_fwd_lds_bytes();
   static bool attr_set = false;
   if (!attr_set) {
@@ -825,7 +835,6 @@ int dec_persist_loss_chase_launch(const float* target, const g2v_dec_saved* s, c
   a.yflag = persist_x_at(xbase).yflag;
   a.T = T; a.B = B;
   a.lc3 = s->loss_w[2] / ((float)T * (float)B * (float)D);      // as g2v_custom_loss_fwd_bwd forms it
-  a.dbg = g2v_dbg_flags;
   hipLaunchKernelGGL(loss_chase_kernel, dim3(B / 16), dim3(256), 0, st, a);
   if (hipGetLastError() != hipSuccess) {
     set_error("custom_loss chaser: launch failed");

@@ -88,9 +88,6 @@ class VQVAEEngine:
         if L != 2:
             raise NotImplementedError("the gfx950 rollout kernels implement n_layers == 2 (every shipped config)")
         self.lib = _lib.load()
-        if os.environ.get("G2V_DBG"):
-            import ctypes as _C
-            _C.CDLL(_lib.LIB_PATH).g2v_dbg_set(int(os.environ["G2V_DBG"]))
         # Opt-in: run the weight-gradient products on the bf16 matrix pipe as 3-term splits (G2V_WGRAD_BF16X3: ~3e-5 max-norm
         # relative error on dW instead of 3e-7; -0.17 ms / step at the BASELINE shape).  Default: exact fp32 MFMA.
         self.wgrad_bf16x3 = False
@@ -497,7 +494,7 @@ class VQVAEEngine:
             check(lib.g2v_custom_loss_chase(_p(out_poses), C.byref(b["sv_loss"]), _p(b["keep95"]), self.T, B, self.D, self.H,
                                             _p(b["ws_decf"]), b["ws_decf"].numel(), self._stream()))
         self._fork(1, stats)
-        if chase and not (int(os.environ.get("G2V_DBG", "0")) & 2):
+        if chase:
             # LATE: enqueued by _release(), i.e. behind the rollout in host order.  Two HIP streams may share one hardware queue
             # (they are dealt round-robin onto a few); a chaser enqueued AHEAD of the rollout on a shared queue would wait for a
             # kernel that cannot start behind it (seen: the bounded wait ran out, latch 2).  Behind it, sharing a queue only
