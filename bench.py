@@ -28,6 +28,19 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CFG = dict(B=4096, T=34, D=135, H=64, L=2, K=512, beta=0.25, dropout_prob=0.0, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+# --config: the workload.  "full" is the contract line (BASELINE.json configs[1]); the others put the shapes the reference's own
+# YAMLs ship on the same line format, e.g. for the driver's multi-GPU runs of configs[4]:
+#   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N --config genea
+CONFIGS = {
+    "full": dict(B=4096, T=34, D=135, H=64, K=512, dropout_prob=0.0, lr=5e-4,
+                 name="BASELINE configs[1] (VQ-VAE full shape)"),
+    "native": dict(B=128, T=20, D=40, H=200, K=512, dropout_prob=0.2, lr=5e-4,
+                   name="config/VQ-VAE.yml as shipped (n_poses 20, rep_learning_dim 40 = the DAE-stacked input of BASELINE configs[2], "
+                        "hidden_size 200, K 512, batch_size 128, dropout_prob 0.2)"),
+    "genea": dict(B=4096, T=10, D=45, H=200, K=400, dropout_prob=0.0, lr=1e-4,
+                  name="BASELINE configs[4] (config/VQ-VAE_GENEA.yml shape: n_poses 10, rep_learning_dim 45, hidden_size 200, K 400, "
+                       "lr 1e-4; B_local 4096 per GPU, weak scaling)"),
+}
 PEAK_F32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
 PEAK_HBM_GBS = 8000.0
 
@@ -100,15 +113,15 @@ def cpu_baseline(B_main: int):
             break
     torch.set_num_threads(best_thr)
     t_small = timed(128, 10, 10.0)
-    t_main = timed(B_main, 10, 60.0)
+    t_main = timed(B_main, 10, 60.0) if B_main != 128 else t_small
     # every host core: in a child process under a hard wall-clock limit (on the pool's 256-core hosts the oracle's many small ops
     # take minutes per step with 256 threads -- the first version of this leg ran into the driver's time limit)
     t_all, all_note = [], ""
     if ncpu != best_thr:
         import subprocess
         try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(ncpu), str(B_main), "3"],
-                               capture_output=True, text=True, timeout=75)
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", str(ncpu), str(B_main), "3",
+                                CFG.get("config", "full")], capture_output=True, text=True, timeout=75)
             t_all = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else []
             if not t_all:
                 all_note = "the child process failed"
@@ -118,8 +131,28 @@ def cpu_baseline(B_main: int):
             all_note = f"{type(e).__name__}: {e}"
     else:
         t_all = t_main
+    # second leg: the same step on torch.nn.GRU modules (ATen's fused CPU RNN kernels, the way the reference builds its model):
+    # oracle/g2v_oracle_nn.py, pinned to the functional oracle in tests/test_oracle_golden.py
+    fused = None
+    try:
+        from oracle import g2v_oracle_nn as ONN
+        torch.set_num_threads(best_thr)
+        x, masks = inputs(B_main)
+        m, opt, vq_sd = ONN.make(O.init_vqvae_state(D, H, 2, K, seed=0), D, H, 2, cfg)
+        ONN.train_step(m, opt, vq_sd, x, masks["dec"], cfg)          # warm-up
+        tf = []
+        while len(tf) < 10 and (sum(tf) < 30.0 or len(tf) < 3):
+            t0 = time.perf_counter()
+            ONN.train_step(m, opt, vq_sd, x, masks["dec"], cfg)
+            tf.append(time.perf_counter() - t0)
+        fused = {"value": round(B_main / statistics.median(tf), 1), "unit": "chunks/s", "threads": best_thr,
+                 "sample": f"median of {len(tf)} steps at B={B_main}, oracle/g2v_oracle_nn.py: torch.nn.GRU modules (fused CPU RNN), "
+                           "all L encoder layers executed as the reference does"}
+    except Exception as e:          # a baseline leg never costs the bench line
+        fused = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
     med = statistics.median(t_main)
     return {"value": round(B_main / med, 1), "unit": "chunks/s", "cores": best_thr, "kind": "port", "cpu_model": model,
+            "fused_rnn": fused,
             "host_cores": ncpu,
             "sample": f"median of {len(t_main)} full train steps at B={B_main} (the GPU batch), {sum(t_main):.1f}s after warm-up; "
                       f"oracle/g2v_oracle.py, torch-CPU fp32, {best_thr} threads (calibrated) of {ncpu} host cores ({model})",
@@ -127,8 +160,9 @@ def cpu_baseline(B_main: int):
                                "sample": (f"median of {len(t_all)} steps at B={B_main} with torch.set_num_threads({ncpu})" if t_all else all_note)},
             "native_batch": {"B": 128, "value": round(128 / statistics.median(t_small), 1), "unit": "chunks/s",
                              "sample": f"median of {len(t_small)} steps, {best_thr} threads"},
-            "note": "this Python-loop port is about 2x slower than the reference's own nn.GRU modules measured at survey time "
-                    "(1,947 chunks/s, 8 threads of the build container: BASELINE.md section 2); a reported baseline, not a target"}
+            "note": "`value` is the functional oracle (explicit per-step formulas: the parity checker); `fused_rnn` is the same step on "
+                    "torch.nn.GRU modules like the reference's own (1,947 chunks/s at survey time on 8 threads of the build "
+                    "container, BASELINE.md section 2); reported baselines, not targets"}
 
 
 def pmc_traffic(kernel: str, N: int):
@@ -145,6 +179,22 @@ def pmc_traffic(kernel: str, N: int):
         e = d.get(f"N={N}")
         if e and kernel in e.get("kernel", ""):
             return int(e["hbm_bytes_per_launch_corrected"])
+    return None
+
+
+def in_graph_us(kernel: str):
+    """duration of `kernel` INSIDE the replayed step, from the newest committed one-step timeline (profiles/*step_timeline.txt,
+    rocprofv3 --kernel-trace of this command): there the kernel starts while the branch beside the encoder still holds CUs"""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_timeline.txt")), reverse=True):
+        try:
+            for line in open(path):
+                m = re.match(r"\s*[-0-9.]+ dur\s+([0-9.]+) gap", line)
+                if m and kernel in line:
+                    return {"us": float(m.group(1)), "source": os.path.relpath(path, ROOT)}
+        except OSError:
+            continue
     return None
 
 
@@ -224,7 +274,73 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
            "algorithmic_bytes_per_launch": bytes_alg,
            "hbm_view_GBps": round(bytes_alg / (us * 1e-6) / 1e9, 1), "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
     out.update(extra)
+    if (E, K, N) == (128, 512, 4096):
+        out["in_step_graph"] = in_graph_us(kernel.split("<")[0])
     return out
+
+
+def part_d(with_cpu: bool):
+    """"Also report text2embedding samples/s" -- config 4: n_words 3863, 300-d embeddings, lengths U{4..20} sorted
+    descending, codes U{0..511} (B,6), hidden 200, 2 layers, dropout 0.2 (config/seq2seq.yml), `autoencoder_att` False and True;
+    one step = train_iter_text2embedding (reference train_eval/train_seq2seq.py:462-538: forward, CE over steps 1..S-1, backward,
+    clip 5, Adam) replayed from a hipGraph, B = 128 (the yml's) and 4096.  CPU: the oracle's t2e_train_step at B = 128."""
+    import numpy as np
+    import statistics
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import GraphedText2EmbeddingStep
+    from train_text2embedding import SyntheticSentences
+    res = {"unit": "samples/s", "workload": "SURVEY.md 8(d) config 4 (config/seq2seq.yml shape: H=200, L=2, K=512, S=6, 300-d embeddings, "
+                                             "3863 words), train_iter_text2embedding, hipGraph replay", "runs": []}
+    keep = None
+    for att in ("False", "True"):
+        for B in (128, 4096):
+            args = argparse.Namespace(hidden_size=200, n_layers=2, dropout_prob=0.2, autoencoder_vq_components=512, autoencoder_att=att,
+                                      n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True", batch_size=B)
+            torch.manual_seed(0)
+            net = text2embedding_model(args, 512, 20, 3863, 300, np.random.RandomState(0).randn(3863, 300).astype(np.float32), None).to("cuda:0")
+            net.train(True)
+            opt = FlatClipAdam(net.parameters(), lr=5e-4)
+            data = list(SyntheticSentences(args, 3863, 1, seed=1))[0]
+            ids, lengths, codes = data[0].to("cuda:0"), data[1], data[6].to("cuda:0")
+            if att == "False" and B == 128:
+                keep = ({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, data[0].clone(), data[1].clone(), data[6].clone())
+            g = GraphedText2EmbeddingStep(args, net, opt, ids, lengths, codes)
+            for _ in range(3):
+                g.replay()
+            torch.cuda.synchronize()
+            n = 30
+            t0 = time.perf_counter()
+            for _ in range(n):
+                g.replay()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            res["runs"].append({"att": att == "True", "B": B, "ms_per_step": round(dt / n * 1e3, 4), "samples_per_s": round(B * n / dt, 1),
+                                "loss": round(float(g.loss), 4)})
+            del g, net, opt
+    if with_cpu and keep is not None:
+        try:
+            from oracle import g2v_oracle as O
+            sd, ids, lengths, codes = keep
+            B, S, H = ids.shape[0], codes.shape[1], 200
+            gm = torch.Generator().manual_seed(3)
+            masks = {"emb": (torch.rand(S - 1, B, H, generator=gm) < 0.5).to(torch.uint8),
+                     "dec_l0": (torch.rand(S - 1, B, H, generator=gm) < 0.8).to(torch.uint8)}
+            cfg = dict(n_layers=2, dropout_prob=0.2, n_pre_poses=1, lr=5e-4, att=False)
+            torch.set_num_threads(min(os.cpu_count() or 1, 8))
+            adam = {}
+            O.t2e_train_step(sd, adam, ids, lengths.long(), codes.long(), masks, cfg)
+            ts = []
+            while len(ts) < 10 and (sum(ts) < 10.0 or len(ts) < 3):
+                t0 = time.perf_counter()
+                O.t2e_train_step(sd, adam, ids, lengths.long(), codes.long(), masks, cfg)
+                ts.append(time.perf_counter() - t0)
+            res["cpu_baseline"] = {"value": round(B / statistics.median(ts), 1), "unit": "samples/s", "cores": min(os.cpu_count() or 1, 8),
+                                   "kind": "port", "sample": f"median of {len(ts)} oracle t2e_train_step calls at B={B}, no attention"}
+        except Exception as e:
+            res["cpu_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    return res
 
 
 def calibrate(lib):
@@ -259,11 +375,16 @@ def _cpu_baseline_worker(threads: int, B: int, n: int):
     from oracle import g2v_oracle as O
     torch.set_num_threads(threads)
     T, D, H, K = CFG["T"], CFG["D"], CFG["H"], CFG["K"]
-    cfg = dict(n_layers=2, dropout_prob=0.0, commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
+    p = CFG["dropout_prob"]
+    cfg = dict(n_layers=2, dropout_prob=p, commitment_cost=CFG["beta"], n_pre_poses=1, conditioned=True,
                w_l1=CFG["w_l1"], w_cont=CFG["w_cont"], w_var=CFG["w_var"], lr=CFG["lr"])
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(B, T, D, generator=g)
     masks = {"dec": (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)}
+    if p > 0:
+        masks["in"] = (torch.rand(T, B, D, generator=g) < 1 - p).to(torch.uint8)
+        masks["enc_l0"] = (torch.rand(T, B, 2 * H, generator=g) < 1 - p).to(torch.uint8)
+        masks["dec_l0"] = (torch.rand(T - 1, B, H, generator=g) < 1 - p).to(torch.uint8)
     sd, adam = O.init_vqvae_state(D, H, 2, K, seed=0), {}
     ts = []
     for i in range(n + 1):
@@ -276,15 +397,19 @@ def _cpu_baseline_worker(threads: int, B: int, n: int):
 
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--cpu-baseline-worker":
+        if len(sys.argv) >= 6:
+            CFG.update({k: v for k, v in CONFIGS[sys.argv[5]].items() if k != "name"})
         return _cpu_baseline_worker(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=CFG["B"], help="per-GPU batch (weak scaling)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="full", help="workload shape (see CONFIGS); the contract line is `full`")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default: the config's")
+    ap.add_argument("--no-part-d", action="store_true", help="skip the text2embedding (Part d) samples/s object of the line")
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dropout", type=float, default=CFG["dropout_prob"],
+    ap.add_argument("--dropout", type=float, default=None,
                     help="encoder-input / GRU inter-layer dropout_prob (config/VQ-VAE.yml ships 0.2; SURVEY.md 8(d) config 2 "
                          "and the default here use 0: the always-on Dropout(0.95) of the decoder input is drawn either way)")
     ap.add_argument("--wgrad-bf16x3", action="store_true",
@@ -294,6 +419,12 @@ def main():
     ap.add_argument("--force-dp", action="store_true",
                     help="run the data-parallel code path (split graphs + RCCL all-reduce) even with one rank (diagnostic)")
     a = ap.parse_args()
+    CFG.update({k: v for k, v in CONFIGS[a.config].items() if k != "name"})
+    CFG["config"] = a.config
+    if a.batch is None:
+        a.batch = CFG["B"]
+    if a.dropout is None:
+        a.dropout = CFG["dropout_prob"]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -369,18 +500,30 @@ def main():
         step()
     torch.cuda.synchronize()
     graph = None
+    dp_launch = "eager launches"
     run = step
     if not a.no_graph:
         try:
             if use_dp:
-                # two hipGraphs around the exchange: [masks..backward]  ->  RCCL all-reduce(comm)  ->  [EMA + clip/Adam]
-                g_local, g_apply = capture(local), capture(apply)
+                # ONE hipGraph with the RCCL all-reduce captured inside it (one replay per step, nothing of the exchange on the
+                # host); where the collective cannot be captured: two hipGraphs around it, [masks..backward] -> all-reduce(comm)
+                # -> [EMA + clip/Adam]
+                try:
+                    g_step = capture(step)
+                    run = g_step.replay
+                    graph = g_step
+                    dp_launch = "one hipGraph replay, RCCL all-reduce captured inside"
+                except Exception as e:
+                    print(f"[bench] all-reduce not capturable ({type(e).__name__}: {e}); two graphs around it", file=sys.stderr)
+                    torch.cuda.synchronize()
+                    g_local, g_apply = capture(local), capture(apply)
 
-                def run():
-                    g_local.replay()
-                    reduce_fn(eng.comm)
-                    g_apply.replay()
-                graph = (g_local, g_apply)
+                    def run():
+                        g_local.replay()
+                        reduce_fn(eng.comm)
+                        g_apply.replay()
+                    graph = (g_local, g_apply)
+                    dp_launch = "2 hipGraph replays around one RCCL all-reduce"
             else:
                 g_step = capture(step)
                 run = g_step.replay
@@ -415,18 +558,18 @@ def main():
     out = None
     if rank == 0:
         out = {
-            "metric": "gesture-chunks/sec VQ-VAE fwd+bwd (T=34,D=135,K=512)", "value": round(B * world * a.steps / dt, 1),
+            "metric": f"gesture-chunks/sec VQ-VAE fwd+bwd (T={CFG['T']},D={CFG['D']},K={CFG['K']})", "value": round(B * world * a.steps / dt, 1),
             "unit": "chunks/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1] (VQ-VAE full shape): train_iter_Autoencoder_VQ_seq2seq on "
-                                   f"synthetic N(0,1) pose chunks, B={B}/GPU, T=34, D=135, H=64, L=2 (E=128), K=512, "
-                                   f"dropout_prob={CFG['dropout_prob']:g} (+ always-on Dropout(0.95)), Adam lr=5e-4, "
+            "config": {"workload": f"{CONFIGS[a.config]['name']}: train_iter_Autoencoder_VQ_seq2seq on "
+                                   f"synthetic N(0,1) pose chunks, B={B}/GPU, T={CFG['T']}, D={CFG['D']}, H={CFG['H']}, L=2 (E={2 * CFG['H']}), "
+                                   f"K={CFG['K']}, dropout_prob={CFG['dropout_prob']:g} (+ always-on Dropout(0.95)), Adam lr={CFG['lr']:g}, "
                                    "random-init weights",
+                       "name": a.config,
                        "global_batch": B * world, "per_gpu_batch": B,
                        "parallelism": f"dp{world}" if world > 1 else "single",
-                       "launch": ("eager launches" if graph is None else
-                                  "2 hipGraph replays around one RCCL all-reduce" if use_dp else "hipGraph replay"),
+                       "launch": ("eager launches" if graph is None else dp_launch if use_dp else "hipGraph replay"),
                        "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "graph_branches_mask": int(eng.overlap),
                        "custom_loss": ("chaser kernel co-resident with the forward rollout + the backward rollout's tile load"
@@ -456,6 +599,12 @@ def main():
                 print(f"[bench] calibration probe failed ({type(e).__name__}: {e})", file=sys.stderr)
             if not a.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(B)
+            if not a.no_part_d and a.config == "full":
+                try:
+                    out["text2embedding"] = part_d(with_cpu=not a.no_cpu_baseline)
+                except Exception as e:   # an extra object of the line, never a reason to lose it
+                    print(f"[bench] Part d failed ({type(e).__name__}: {e})", file=sys.stderr)
+                    out["text2embedding"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()

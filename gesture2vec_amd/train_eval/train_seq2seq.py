@@ -143,7 +143,7 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
     kw = dict(lr=optim.lr, w_l1=float(args.loss_l1_weight), w_cont=float(args.loss_cont_weight),
               w_var=float(args.loss_var_weight), epoch=epoch, draw_masks=not getattr(net, "_explicit_masks", False),
               betas=optim.betas, eps=optim.eps, max_norm=optim.max_norm)
-    if reduce_fn is None and world == 1 and x.shape[0] >= _GRAPH_MIN_ROWS and _GRAPH_REPLAY:
+    if reduce_fn is None and world == 1 and x.shape[0] >= _GRAPH_MIN_ROWS and _GRAPH_REPLAY and eng.vq_bx_check_every == 0:
         _replayed_step(eng, x, tgt, kw)
     else:
         eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)

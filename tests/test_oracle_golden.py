@@ -274,3 +274,32 @@ def test_text2embedding_new_classes_match_reference(golden_dir):
                     assert np.abs(np.delete(got, used, axis=0)).max() == 0
                     got = got[used]
                 assert np.abs(got - ref).max() <= 2e-4 * np.abs(ref).max() + 1e-9, (tag, n)
+
+
+def test_fused_rnn_cpu_baseline_leg_equals_the_functional_oracle():
+    """oracle/g2v_oracle_nn.py (the `cpu_baseline.fused_rnn` leg of bench.py: the same train step on torch.nn.GRU modules, as the
+    reference builds them) against the functional oracle, which is pinned to the reference's golden vectors above: same loss,
+    same code indices, same weights after two steps (dropout_prob = 0, explicit Dropout(0.95) masks)."""
+    from oracle import g2v_oracle_nn as ONN
+    B, T, D, H, K = 16, 7, 9, 12, 16
+    cfg = dict(n_layers=2, dropout_prob=0.0, commitment_cost=0.25, n_pre_poses=1, conditioned=True, w_l1=5.0, w_cont=0.1, w_var=0.5,
+               lr=5e-4)
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    m, opt, vq_sd = ONN.make(sd, D, H, 2, cfg)
+    adam = {}
+    g = torch.Generator().manual_seed(5)
+    for step in range(2):
+        x = torch.randn(B, T, D, generator=g)
+        keep = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8)
+        ref = O.vqvae_train_step(sd, adam, x, {"dec": keep}, cfg)
+        got = ONN.train_step(m, opt, vq_sd, x, keep, cfg)
+        assert torch.equal(ref["idx"], got["idx"])
+        np.testing.assert_allclose(float(got["loss"]), float(ref["loss"]), rtol=2e-6)
+        np.testing.assert_allclose(got["outputs"].numpy(), ref["outputs"].numpy(), rtol=1e-5, atol=1e-6)
+    own = m.state_dict()
+    for k in O.vqvae_trainable_keys(sd):
+        if k == "decoder.decoder.pre_linear.0.bias":
+            continue                                   # feeds BatchNorm: a mathematically zero gradient that Adam turns into +-lr noise
+        np.testing.assert_allclose(own[k].numpy(), sd[k].numpy(), rtol=1e-4, atol=2e-6, err_msg=k)
+    for k in ("_ema_cluster_size", "_ema_w", "_embedding.weight"):
+        np.testing.assert_allclose(vq_sd["vq_layer." + k].numpy(), sd["vq_layer." + k].numpy(), rtol=1e-5, atol=1e-7)
