@@ -244,12 +244,17 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
     for (int j = 0; j < PD; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)min(j, KS - 1) * 256);
+    // (round 4) the activation fragment of k-step s+1 is read from LDS BEFORE the MFMAs of k-step s: behind the sched_barrier
+    // that pins the ring refills, the read used to be issued only after the previous k-step's MFMAs and its ~130-cycle LDS round
+    // trip stood in front of every group of 4 NT MFMAs
+    float4 xn = *reinterpret_cast<const float4*>(xrow);
     for (int s0 = 0; s0 < KS; s0 += PD) {
 #pragma unroll
       for (int j = 0; j < PD; ++j) {
         const int s = s0 + j;
         if (s < KS) {
-          const float4 xb = *reinterpret_cast<const float4*>(xrow + 16 * s);
+          const float4 xb = xn;
+          xn = *reinterpret_cast<const float4*>(xrow + 16 * min(s + 1, KS - 1));
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] = mfma16(ring[j][t].x, xb.x, acc[t]);
 #pragma unroll
@@ -263,6 +268,63 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
           for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
+    }
+  }
+}
+
+// wave_gemm_p (run-time k-steps, PD fragments in flight) over NR 16-row tiles of the SAME activation matrix that share every
+// weight fragment: acc[t][r] += tile t of P (A operand) x rows [16 r, 16 r + 16) of Xs.  A kernel that streams its weights from
+// L2 every time step does 4 NT NR MFMAs per 1 KiB fragment instead of 4 NT: at 16 rows per workgroup the generic recurrent
+// kernels were bound by the fragment stream (one KiB per 128 cycles and wave = the CU's whole L1 rate at two workgroups per CU).
+template <int NT, int NR>
+__device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const float* __restrict__ P, int KS, int tile0,
+                                                 int tile_stride, const float* Xs, int ldx, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const float* xrow = Xs + i * ldx + 4 * q;
+  const float* pt[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) pt[t] = P + ((int64_t)(tile0 + t * tile_stride) * KS * 64 + lane) * 4;
+  constexpr int PD = 8;
+  float4 ring[PD][NT];
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)min(j, KS - 1) * 256);
+  float4 xn[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx);
+  for (int s0 = 0; s0 < KS; s0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int s = s0 + j;
+      if (s < KS) {
+        float4 xb[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {          // (one k-step ahead: see wave_gemm_p)
+          xb[r] = xn[r];
+          xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx + 16 * min(s + 1, KS - 1));
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].x, xb[r].x, acc[t][r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].y, xb[r].y, acc[t][r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].z, xb[r].z, acc[t][r]);
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].w, xb[r].w, acc[t][r]);
+        const int sn = min(s + PD, KS - 1);         // past the end: a valid, unused fragment
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }

@@ -126,16 +126,142 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ gi, c
     }
 }
 
+// The same forward for H % 4 == 0, H <= 256, 16-byte aligned operands (round 4; every shipped YAML: H = 200).  The body above
+// loads a tile's gi rows and biases AFTER its product, element by element, in front of the gate math (one exposed memory round
+// trip per tile, three or four tiles per wave and step).  Here the gi vectors and biases of the wave's NEXT tile are requested
+// before the current tile's product, as 16-byte vectors.
+template <int NR>      // 16-row tiles per workgroup (256 NR threads): every W_hh fragment multiplies 16 NR rows
+__device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi, const float* __restrict__ w_hh,
+                                                    const float* __restrict__ b_hh, const float* __restrict__ h0,
+                                                    const int32_t* __restrict__ lengths, int reverse,
+                                                    float* __restrict__ hs, int64_t hs_ld, float* __restrict__ h_n,
+                                                    float* __restrict__ gates, int T, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ROWS = 16 * NR, NTHR = 256 * NR, NWAVE = 4 * NR;
+  const int Hp = (H + 15) & ~15, ldx = Hp + 4;
+  float* hbuf0 = smem;
+  float* hbuf1 = smem + ROWS * ldx;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * ROWS;
+  const int nrows = min(ROWS, B - b0);
+  const int i = lane & 15, q = lane >> 4;
+  bool rvalid[NR];
+  int brow[NR], len[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    rvalid[r] = 16 * r + i < nrows;
+    brow[r] = b0 + (rvalid[r] ? 16 * r + i : 0);
+    len[r] = (lengths && rvalid[r]) ? lengths[brow[r]] : T;
+  }
+  for (int e = tid; e < ROWS * ldx; e += NTHR) {
+    const int r = e / ldx, k = e - r * ldx;
+    float v = 0.f;
+    if (h0 && r < nrows && k < H) v = h0[(int64_t)(b0 + r) * H + k];
+    hbuf0[e] = v;
+    hbuf1[e] = 0.f;
+  }
+  const int ntile = Hp >> 4;
+  const int mt = (ntile - wave + NWAVE - 1) / NWAVE;      // this wave's tiles: wave, wave + NWAVE, ...
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // one tile ahead: the gi vectors and biases of the NEXT (step, tile) of this wave are requested before the current tile's
+  // product (13 k-steps x 12 NR MFMAs: more than an HBM round trip)
+  float4 gin[NR][3], bhn[3];
+  auto prefetch = [&](int s, int j) {
+    const int t = reverse ? (T - 1 - s) : s;
+    const int f0 = 16 * (wave + NWAVE * j) + 4 * q;
+    const bool col = f0 + 3 < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bhn[g] = col ? *reinterpret_cast<const float4*>(b_hh + g * H + f0) : z4;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const bool ok = rvalid[r] && s < T && t < len[r] && col;
+      const float* gir = gi + ((int64_t)(ok ? t : 0) * B + brow[r]) * 3 * H + (ok ? f0 : 0);
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gin[r][g] = ok ? *reinterpret_cast<const float4*>(gir + g * H) : z4;
+    }
+  };
+  prefetch(0, 0);
+  __syncthreads();
+  float* cur = hbuf0;
+  float* nxt = hbuf1;
+  for (int s = 0; s < T; ++s) {
+    const int t = reverse ? (T - 1 - s) : s;
+#pragma unroll 1
+    for (int j = 0; j < mt; ++j) {
+      const int ft = wave + NWAVE * j;
+      float4 gic[NR][3], bh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        bh[g] = bhn[g];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) gic[r][g] = gin[r][g];
+      }
+      if (j + 1 < mt) prefetch(s, j + 1); else prefetch(s + 1, 0);
+      f32x4 acc[3][NR];
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      wave_gemm_p_rows<3, NR>(acc, w_hh, Hp >> 4, ft, ntile, cur, ldx, lane);
+      const int f0 = 16 * ft + 4 * q;
+      if (f0 + 3 >= H) continue;
+      const float br[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+                  bn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        const int li = 16 * r + i;
+        const bool valid = rvalid[r] && (t < len[r]);
+        const int64_t row = (int64_t)t * B + brow[r];
+        const float4 hp4 = *reinterpret_cast<const float4*>(cur + li * ldx + f0);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        const float ir[4] = {gic[r][0].x, gic[r][0].y, gic[r][0].z, gic[r][0].w}, iz[4] = {gic[r][1].x, gic[r][1].y, gic[r][1].z, gic[r][1].w},
+                    in_[4] = {gic[r][2].x, gic[r][2].y, gic[r][2].z, gic[r][2].w};
+        float hn[4], gr[4], gz[4], gn[4], gh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float rr = sigmoidf_(ir[e] + (acc[0][r][e] + br[e]));
+          const float zz = sigmoidf_(iz[e] + (acc[1][r][e] + bz[e]));
+          const float ghn = acc[2][r][e] + bn[e];
+          const float nn = tanhf_(in_[e] + rr * ghn);
+          const float hnew = (1.0f - zz) * nn + zz * hp[e];
+          hn[e] = valid ? hnew : hp[e];
+          gr[e] = valid ? rr : 0.f; gz[e] = valid ? zz : 0.f; gn[e] = valid ? nn : 0.f; gh[e] = valid ? ghn : 0.f;
+        }
+        *reinterpret_cast<float4*>(nxt + li * ldx + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (rvalid[r]) {
+          *reinterpret_cast<float4*>(hs + row * hs_ld + f0) = valid ? make_float4(hn[0], hn[1], hn[2], hn[3]) : z4;   // padded positions are zero
+          if (gates) {
+            float* go = gates + row * 4 * H + f0;
+            *reinterpret_cast<float4*>(go) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+            *reinterpret_cast<float4*>(go + H) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+            *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn[0], gn[1], gn[2], gn[3]);
+            *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+    float* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  if (h_n)
+    for (int e = tid; e < ROWS * H; e += NTHR) {
+      const int r = e / H, k = e - r * H;
+      if (r < nrows) h_n[(int64_t)(b0 + r) * H + k] = cur[r * ldx + k];
+    }
+}
+
 // Generic hidden size: one workgroup per 16 batch rows walks all T steps; BOTH directions of a bidirectional layer run in
 // one launch (blockIdx.y): at small batch a direction has only B/16 workgroups, so two launches in a row would leave the
 // chip idle twice as long.
 struct GruGenF {
   const float* gi; const float* w_hh; const float* b_hh; const float* h0; float* hs; float* h_n; float* gates; int reverse;
 };
-__global__ __launch_bounds__(256) void gru_seq_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths,
-                                                          int64_t hs_ld, int T, int B, int H) {
+template <int V4>      // 0: scalar body; NR = 1 / 2: the vector body with NR row tiles per workgroup
+__global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths,
+                                                                         int64_t hs_ld, int T, int B, int H) {
   const GruGenF d = blockIdx.y == 0 ? d0 : d1;
-  gru_seq_fwd_body(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
+  if constexpr (V4 > 0) gru_seq_fwd_body_v4<V4>(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
+  else gru_seq_fwd_body(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
 }
 
 // BPTT.  w_hh_t = W_hh^T, (H, 3H) row-major (so that dh_prev = dgh W_hh is again "weights contiguous along
@@ -220,14 +346,157 @@ __device__ __forceinline__ void gru_seq_bwd_body(const float* __restrict__ d_hs,
     }
 }
 
+// The same BPTT for H % 4 == 0, H <= 256 and 16-byte aligned operands (round 4), what every shipped YAML runs at large batch
+// (H = 200).  Round 3's body above spent ~85 % of a step in phase 1: per element FIVE dependent global loads issued one after the
+// other (12-13 elements per thread: an HBM round trip each, the saved gates are 262 MB per direction at B = 4096) behind
+// integer divisions -- 2.06 ms per call at the native shape, 12 % of the matrix rate.  Here a thread owns up to four 4-column
+// groups of ONE row (row = tid / 16), every load of a step is a 16-byte vector, and ALL the loads of step s-1 (gates r, z, n, hn,
+// h_prev, the upstream gradient: 24 vectors) are requested before phase 2 of step s, so that they travel while the matrix pipe
+// works through dgh W_hh.
+struct GruBwdPre {        // one step's inputs of this thread: [column group][...]
+  float4 r[4], z[4], n[4], hn[4], hp[4], up[4];
+};
+template <int NR>      // 16-row tiles per workgroup (256 NR threads)
+__device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_hs, int64_t d_hs_ld,
+                                                    const float* __restrict__ d_hn, const float* __restrict__ hs,
+                                                    int64_t hs_ld, const float* __restrict__ h0,
+                                                    const float* __restrict__ gates, const float* __restrict__ w_hh_t,
+                                                    const int32_t* __restrict__ lengths, int reverse,
+                                                    float* __restrict__ dgi, float* __restrict__ dgh,
+                                                    float* __restrict__ dh0, int T, int B, int H) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int Hp = (H + 15) & ~15, G = 3 * H, Gp = (G + 15) & ~15, ldg = Gp + 4, ldh = Hp + 4;
+  constexpr int ROWS = 16 * NR, NTHR = 256 * NR, NWAVE = 4 * NR;
+  float* Gs = smem;                // [ROWS][ldg]
+  float* dhs = smem + ROWS * ldg;  // [ROWS][ldh]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * ROWS;
+  const int nrows = min(ROWS, B - b0);
+  const int i = lane & 15, q = lane >> 4;
+  const int row_l = tid >> 4, cg = tid & 15;              // this thread's row of the tile, first column group
+  const bool rowv = row_l < nrows;
+  const int b = b0 + (rowv ? row_l : 0);
+  const int len = (lengths && rowv) ? lengths[b] : T;
+  const int H4 = H >> 2;
+
+  for (int e = tid; e < ROWS * ldg; e += NTHR) Gs[e] = 0.f;
+  for (int e = tid; e < ROWS * ldh; e += NTHR) {
+    const int r = e / ldh, k = e - r * ldh;
+    dhs[e] = (d_hn && r < nrows && k < H) ? d_hn[(int64_t)(b0 + r) * H + k] : 0.f;
+  }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  GruBwdPre P;
+  auto prefetch = [&](int s) {
+    const int t = reverse ? (T - 1 - s) : s, tprev = reverse ? t + 1 : t - 1;
+    const bool live = rowv && t < len;
+    const int64_t row = (int64_t)t * B + b;
+    const float* go = gates + row * 4 * H;
+    // h_prev of this step: the forward's previous output, or the initial state (first step; reverse direction: first valid step)
+    const bool from_h0 = (s == 0) || (tprev >= len);
+    const float* hpp = from_h0 ? (h0 ? h0 + (int64_t)b * H : nullptr) : hs + ((int64_t)tprev * B + b) * hs_ld;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = cg + 16 * k;
+      const bool ok = live && c4 < H4;
+      const int c = 4 * (ok ? c4 : 0);
+      P.r[k] = ok ? *reinterpret_cast<const float4*>(go + c) : z4;
+      P.z[k] = ok ? *reinterpret_cast<const float4*>(go + H + c) : z4;
+      P.n[k] = ok ? *reinterpret_cast<const float4*>(go + 2 * H + c) : z4;
+      P.hn[k] = ok ? *reinterpret_cast<const float4*>(go + 3 * H + c) : z4;
+      P.hp[k] = (ok && hpp) ? *reinterpret_cast<const float4*>(hpp + c) : z4;
+      P.up[k] = (ok && d_hs) ? *reinterpret_cast<const float4*>(d_hs + row * d_hs_ld + c) : z4;
+    }
+  };
+  prefetch(T - 1);
+  __syncthreads();
+  const int ntile = Hp >> 4;
+  for (int s = T - 1; s >= 0; --s) {
+    const int t = reverse ? (T - 1 - s) : s;
+    const bool live = rowv && t < len;
+    const int64_t row = (int64_t)t * B + b;
+    // phase 1: gate gradients of this thread's column groups (inputs arrived during the previous step's phase 2)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c4 = cg + 16 * k;
+      if (c4 >= H4) continue;
+      const int c = 4 * c4;
+      const float4 dc = *reinterpret_cast<const float4*>(dhs + row_l * ldh + c);
+      const float dh_in[4] = {dc.x, dc.y, dc.z, dc.w};
+      const float rr[4] = {P.r[k].x, P.r[k].y, P.r[k].z, P.r[k].w}, zz[4] = {P.z[k].x, P.z[k].y, P.z[k].z, P.z[k].w};
+      const float nn[4] = {P.n[k].x, P.n[k].y, P.n[k].z, P.n[k].w}, gh[4] = {P.hn[k].x, P.hn[k].y, P.hn[k].z, P.hn[k].w};
+      const float hp[4] = {P.hp[k].x, P.hp[k].y, P.hp[k].z, P.hp[k].w}, up[4] = {P.up[k].x, P.up[k].y, P.up[k].z, P.up[k].w};
+      float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (live) {
+          const float dh = dh_in[e] + up[e];
+          const float dn = dh * (1.0f - zz[e]);
+          const float dz = dh * (hp[e] - nn[e]);
+          const float dnp = dn * (1.0f - nn[e] * nn[e]);
+          g_n[e] = dnp;
+          g_hn[e] = dnp * rr[e];
+          g_r[e] = dnp * gh[e] * rr[e] * (1.0f - rr[e]);
+          g_z[e] = dz * zz[e] * (1.0f - zz[e]);
+          direct[e] = dh * zz[e];
+        } else {
+          g_r[e] = g_z[e] = g_n[e] = g_hn[e] = 0.f;
+          direct[e] = dh_in[e];
+        }
+      }
+      const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+                   vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+      if (rowv) {
+        float* gi_o = dgi + row * G + c;
+        float* gh_o = dgh + row * G + c;
+        *reinterpret_cast<float4*>(gi_o) = vr; *reinterpret_cast<float4*>(gi_o + H) = vz; *reinterpret_cast<float4*>(gi_o + 2 * H) = vn;
+        *reinterpret_cast<float4*>(gh_o) = vr; *reinterpret_cast<float4*>(gh_o + H) = vz; *reinterpret_cast<float4*>(gh_o + 2 * H) = vh;
+      }
+      float* gs = Gs + row_l * ldg + c;
+      *reinterpret_cast<float4*>(gs) = vr; *reinterpret_cast<float4*>(gs + H) = vz; *reinterpret_cast<float4*>(gs + 2 * H) = vh;
+      *reinterpret_cast<float4*>(dhs + row_l * ldh + c) = make_float4(direct[0], direct[1], direct[2], direct[3]);
+    }
+    __syncthreads();
+    // phase 2: dh_prev = direct + dgh W_hh.  The next step's inputs are requested in front of this wave's LAST tile: vmcnt
+    // retires in order, so weight fragments requested BEHIND those 24 HBM loads wait for them -- in front of the first tile the
+    // whole product stood behind the prefetch (measured: no overlap at all); now only the last tile's ring does.
+    if (s > 0 && wave >= ntile) prefetch(s - 1);          // (a wave without a tile)
+    for (int ft = wave; ft < ntile; ft += NWAVE) {
+      if (s > 0 && ft + NWAVE >= ntile) prefetch(s - 1);
+      f32x4 acc[1][NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[0][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      wave_gemm_p_rows<1, NR>(acc, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);   // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
+      const int f0 = 16 * ft + 4 * q;
+      if (f0 + 3 < H) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+          float4 v = *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0);
+          v.x += acc[0][r][0]; v.y += acc[0][r][1]; v.z += acc[0][r][2]; v.w += acc[0][r][3];
+          *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0) = v;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (dh0)
+    for (int e = tid; e < ROWS * H4; e += NTHR) {
+      const int r = e / H4, c = 4 * (e - r * H4);
+      if (r < nrows) *reinterpret_cast<float4*>(dh0 + (int64_t)(b0 + r) * H + c) = *reinterpret_cast<const float4*>(dhs + r * ldh + c);
+    }
+}
+
 struct GruGenB {
   const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* w_hh_t;
   float* dgi; float* dgh; float* dh0; int reverse;
 };
-__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
-                                                          int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
+template <int V4>      // 0: scalar body; NR = 1 / 2: the vector body with NR row tiles per workgroup
+__global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
+                                                                         int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
   const GruGenB d = blockIdx.y == 0 ? d0 : d1;
-  gru_seq_bwd_body(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
+  if constexpr (V4 > 0)
+    gru_seq_bwd_body_v4<V4>(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
+  else
+    gru_seq_bwd_body(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
 }
 
 
@@ -1194,8 +1463,10 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   }
   const size_t lds = (size_t)2 * 16 * (Hp + 4) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (2 * lds <= 160 * 1024)
+    (void)hipFuncSetAttribute((const void*)gru_seq_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
   if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
     set_error("g2v_gru_seq_fwd: workspace too small");
     return G2V_ERR_WORKSPACE;
@@ -1215,7 +1486,15 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
     G2V_CHECK_LAUNCH();
   }
   if (ndir == 1) g[1] = g[0];
-  hipLaunchKernelGGL(gru_seq_fwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+  bool v4 = (H & 3) == 0 && H <= 256 && (hs_ld & 3) == 0;
+  for (int k = 0; k < ndir && v4; ++k)
+    v4 = aligned16(dirs[k].gi) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].hs) && aligned16(dirs[k].gates);
+  if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)      // (see gru_seq_bwd_impl)
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+  else if (v4)
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+  else
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<0>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -1330,8 +1609,10 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   const int Hp = (H + 15) & ~15, Gp = (3 * H + 15) & ~15;
   const size_t lds = (size_t)16 * ((Gp + 4) + (Hp + 4)) * sizeof(float);
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
-  if (lds > 48 * 1024)
-    (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (2 * lds <= 160 * 1024)
+    (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
   bool split = gru_split_ok(B, ndir, H) && aligned16(workspace);
   for (int k = 0; k < ndir && split; ++k)
     split = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].d_hn) &&
@@ -1374,7 +1655,20 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     G2V_CHECK_LAUNCH();
   }
   if (ndir == 1) g[1] = g[0];
-  hipLaunchKernelGGL(gru_seq_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T, B, H);
+  bool v4 = (H & 3) == 0 && H <= 256 && (hs_ld & 3) == 0 && (d_hs_ld & 3) == 0;
+  for (int k = 0; k < ndir && v4; ++k)
+    v4 = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].hs) &&
+         aligned16(dirs[k].h0) && aligned16(dirs[k].dh0) && aligned16(dirs[k].d_hs);
+  // two row tiles per workgroup (every weight fragment multiplies 32 rows) once that still leaves a workgroup for most CUs
+  if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)
+    hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
+                       B, H);
+  else if (v4)
+    hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
+                       B, H);
+  else
+    hipLaunchKernelGGL(gru_seq_bwd_kernel<0>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
+                       B, H);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

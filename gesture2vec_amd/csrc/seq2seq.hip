@@ -422,6 +422,76 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   });
 }
 
+// Large batch (B >= 1024): the kernel above gives the whole batch to H / 4 workgroups and reads 16 bytes per row and thread
+// group (81 us at B = 4096, H = 200: 50 workgroups on a 256-CU chip, a quarter of every fetched line used).  Three short launches
+// instead, every load a full row segment: (1) per 16-row block, thread <-> feature: partial sums of g and g * xhat; (2) the
+// partials of a feature added up in block order (deterministic) into db / dw -- which ARE the two sums; (3) dx element-wise.
+// The partials live in the first B * H / 8 floats of dx (overwritten by (3) afterwards): no workspace in the C-ABI.
+constexpr int BN_RB = 16;
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ y, const float* __restrict__ save_mean,
+                                                             const float* __restrict__ save_invstd, int relu,
+                                                             float* __restrict__ partial, int B, int H) {
+  const int r0 = blockIdx.x * BN_RB, nr = min(BN_RB, B - r0);
+  for (int f = threadIdx.x; f < H; f += 256) {
+    const float mean = save_mean[f], invstd = save_invstd[f];
+    float s1 = 0.f, s2 = 0.f;
+    float gv[BN_RB], xv[BN_RB];
+#pragma unroll
+    for (int r = 0; r < BN_RB; ++r) {            // every load of the column slice issued before the first use
+      const int64_t e = (int64_t)(r0 + (r < nr ? r : 0)) * H + f;
+      float g = dy[e];
+      if (relu && !(y[e] > 0.f)) g = 0.f;
+      gv[r] = r < nr ? g : 0.f;
+      xv[r] = x[e];
+    }
+#pragma unroll
+    for (int r = 0; r < BN_RB; ++r) {
+      s1 += gv[r];
+      s2 += gv[r] * ((xv[r] - mean) * invstd);
+    }
+    partial[((int64_t)blockIdx.x * 2 + 0) * H + f] = s1;
+    partial[((int64_t)blockIdx.x * 2 + 1) * H + f] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_finish_kernel(const float* __restrict__ partial, int nrb, float* __restrict__ dw,
+                                                            float* __restrict__ db, int H) {
+  __shared__ float red[2][4][64];
+  const int fl = threadIdx.x & 63, grp = threadIdx.x >> 6, f = blockIdx.x * 64 + fl;
+  float s1 = 0.f, s2 = 0.f;
+  if (f < H)
+    for (int k = grp; k < nrb; k += 4) {
+      s1 += partial[((int64_t)k * 2 + 0) * H + f];
+      s2 += partial[((int64_t)k * 2 + 1) * H + f];
+    }
+  red[0][grp][fl] = s1;
+  red[1][grp][fl] = s2;
+  __syncthreads();
+  if (grp == 0 && f < H) {
+    db[f] = (red[0][0][fl] + red[0][1][fl]) + (red[0][2][fl] + red[0][3][fl]);
+    dw[f] = (red[1][0][fl] + red[1][1][fl]) + (red[1][2][fl] + red[1][3][fl]);
+  }
+}
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ w,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, int relu,
+                                                           const float* __restrict__ dw, const float* __restrict__ db,
+                                                           float* __restrict__ dx, int B, int H) {
+  const float invB = 1.0f / (float)B;
+  const int r0 = blockIdx.x * BN_RB, nr = min(BN_RB, B - r0);
+  for (int f = threadIdx.x; f < H; f += 256) {
+    const float mean = save_mean[f], invstd = save_invstd[f], g0 = w[f] * invstd, S1 = db[f], S2 = dw[f];
+    for (int r = 0; r < nr; ++r) {
+      const int64_t e = (int64_t)(r0 + r) * H + f;
+      float g = dy[e];
+      if (relu && !(y[e] > 0.f)) g = 0.f;
+      const float xhat = (x[e] - mean) * invstd;
+      dx[e] = g0 * (g - S1 * invB - xhat * S2 * invB);
+    }
+  }
+}
+
 // ---- cross entropy: one wave per row ----------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, int64_t ld, const int64_t* __restrict__ tgt,
                                                  float* __restrict__ row_loss, float* __restrict__ dlogits, int64_t ldd,
@@ -704,6 +774,16 @@ extern "C" int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y
   G2V_REQUIRE(dy && x && weight && save_mean && save_invstd && dx && dw && db, "null pointer");
   G2V_REQUIRE(!relu || y, "y required for the ReLU mask");
   G2V_REQUIRE(B > 0 && H > 0, "bad size");
+  if (B >= 1024) {        // (see bn_bwd_partial_kernel; the partials need B * H / 8 floats of dx)
+    const int nrb = cdiv(B, BN_RB);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nrb), dim3(256), 0, (hipStream_t)stream, dy, x, y, save_mean, save_invstd, relu,
+                       dx, B, H);
+    hipLaunchKernelGGL(bn_bwd_finish_kernel, dim3(cdiv(H, 64)), dim3(256), 0, (hipStream_t)stream, dx, nrb, dw, db, H);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(nrb), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean, save_invstd,
+                       relu, dw, db, dx, B, H);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
                      save_invstd, relu, dx, dw, db, B, H);
   G2V_CHECK_LAUNCH();

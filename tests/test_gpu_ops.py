@@ -568,7 +568,8 @@ def test_vq_bwd(ops):
 
 
 # ----------------------------------------------------------------------------------------------- GRU direction
-@pytest.mark.parametrize("T,B,H", [(34, 32, 64), (20, 8, 50), (5, 19, 200), (12, 37, 64), (4, 530, 50)])
+@pytest.mark.parametrize("T,B,H", [(34, 32, 64), (20, 8, 50), (5, 19, 200), (12, 37, 64), (4, 530, 50), (3, 6200, 200), (2, 6145, 52),
+                                   (3, 2100, 200)])      # (the last three: the vector bodies, two row tiles / one row tile per workgroup)
 @pytest.mark.parametrize("reverse", [False, True])
 @pytest.mark.parametrize("use_len", [False, True])
 def test_gru_seq(ops, T, B, H, reverse, use_len):
@@ -921,7 +922,7 @@ def test_keep_mask_is_the_documented_philox_stream(ops, n, shift):
 
 
 # ----------------------------------------------------------------------------------------------- Part d operators
-@pytest.mark.parametrize("B,H", [(128, 200), (37, 50), (4096, 64), (5, 16)])
+@pytest.mark.parametrize("B,H", [(128, 200), (37, 50), (4096, 64), (5, 16), (4096, 200), (1030, 300), (2048, 7)])
 @pytest.mark.parametrize("relu", [True, False])
 def test_batchnorm_fwd_bwd(ops, B, H, relu):
     x = rnd(B, H, seed=1) * 2 + 0.5
