@@ -456,12 +456,10 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       *reinterpret_cast<float4*>(dhs + row_l * ldh + c) = make_float4(direct[0], direct[1], direct[2], direct[3]);
     }
     __syncthreads();
-    // phase 2: dh_prev = direct + dgh W_hh.  The next step's inputs are requested in front of this wave's LAST tile: vmcnt
-    // retires in order, so weight fragments requested BEHIND those 24 HBM loads wait for them -- in front of the first tile the
-    // whole product stood behind the prefetch (measured: no overlap at all); now only the last tile's ring does.
-    if (s > 0 && wave >= ntile) prefetch(s - 1);          // (a wave without a tile)
+    if (s > 0) prefetch(s - 1);                         // requested ahead of the product below (in front of this wave's last
+                                                        // tile instead: 2.05 ms against 1.64 at the native shape)
+    // phase 2: dh_prev = direct + dgh W_hh
     for (int ft = wave; ft < ntile; ft += NWAVE) {
-      if (s > 0 && ft + NWAVE >= ntile) prefetch(s - 1);
       f32x4 acc[1][NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[0][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -485,12 +483,19 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
     }
 }
 
+// (Round 4 also measured, at the native shape B = 4096, T = 20, H = 200, 1.63 ms per call for the body above: two row tiles per
+// workgroup sharing every weight fragment 1.64-1.68 ms; the same with waves 0-3 only multiplying and waves 4-7 only moving the
+// saved tensors, so that no weight fragment queues behind an HBM load, 1.68 ms; the next step's loads requested in front of the
+// wave's last tile instead of its first 2.05 ms; the tiles visited in an order that differs from workgroup to workgroup 1.66 ms.
+// Counters (profiles/r04_pmc_native.json): matrix pipe 14 % busy, 69 % of the
+// wave cycles in s_waitcnt / barriers, 5 GB of L2 reads per call at 450 cycles average latency: every workgroup streams the SAME
+// 480 KB of W_hh^T in the same order at the same time.  None of the three variants is kept.)
 struct GruGenB {
   const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* w_hh_t;
   float* dgi; float* dgh; float* dh0; int reverse;
 };
-template <int V4>      // 0: scalar body; NR = 1 / 2: the vector body with NR row tiles per workgroup
-__global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
+template <int V4>      // 0: scalar body; 1: the vector body
+__global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
                                                                          int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
   const GruGenB d = blockIdx.y == 0 ? d0 : d1;
   if constexpr (V4 > 0)
@@ -1489,7 +1494,9 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   bool v4 = (H & 3) == 0 && H <= 256 && (hs_ld & 3) == 0;
   for (int k = 0; k < ndir && v4; ++k)
     v4 = aligned16(dirs[k].gi) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].hs) && aligned16(dirs[k].gates);
-  if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)      // (see gru_seq_bwd_impl)
+  // two row tiles per workgroup (every weight fragment multiplies 32 rows: 0.73 against 0.80 ms at the native shape) once that
+  // still leaves a workgroup for most CUs
+  if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)
     hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
   else if (v4)
     hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
@@ -1611,8 +1618,6 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   G2V_REQUIRE(lds <= 160 * 1024, "hidden size too large for LDS");
   (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (2 * lds <= 160 * 1024)
-    (void)hipFuncSetAttribute((const void*)gru_seq_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * lds));
   bool split = gru_split_ok(B, ndir, H) && aligned16(workspace);
   for (int k = 0; k < ndir && split; ++k)
     split = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].d_hn) &&
@@ -1659,11 +1664,7 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   for (int k = 0; k < ndir && v4; ++k)
     v4 = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].hs) &&
          aligned16(dirs[k].h0) && aligned16(dirs[k].dh0) && aligned16(dirs[k].d_hs);
-  // two row tiles per workgroup (every weight fragment multiplies 32 rows) once that still leaves a workgroup for most CUs
-  if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)
-    hipLaunchKernelGGL(gru_seq_bwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
-                       B, H);
-  else if (v4)
+  if (v4)
     hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
                        B, H);
   else

@@ -717,15 +717,22 @@ class VQVAEEngine:
         check(lib.g2v_linear_fwd(_p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dist"]), K, N, E, K, 0, st))
         check(lib.g2v_vq_soft_fwd(_p(g["gs_flat"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(self.code_sqnorm), _p(g["gs_probs"]),
                                   None, N, E, K, st))
-        check(lib.g2v_vq_soft_perplexity(_p(g["gs_probs"]), self.vq_scalars[1:].data_ptr(), N, K, _p(g["gs_ws"]),
-                                         g["gs_ws"].numel(), st))
+        # the perplexity of the mean assignment feeds nothing but the log line: a branch beside the rollout (round 4; it sat on
+        # the chain between the encoder and the rollout, two launches)
+        def perplexity():
+            check(lib.g2v_vq_soft_perplexity(_p(g["gs_probs"]), self.vq_scalars[1:].data_ptr(), N, K, _p(g["gs_ws"]),
+                                             g["gs_ws"].numel(), self._stream()))
+        self._fork(1, perplexity)
         check(lib.g2v_linear_bwd_data(_p(g["gs_probs"]), K, W, _p(g["gs_q"]), E, N, E, K, 0, st))          # q = probs W (:1417-1419)
         # both latent losses are mean((x - q)^2) (:1424-1425); their gradients go to x and to q separately (backward)
         check(lib.g2v_mse_fwd_bwd(_p(g["gs_q"]), x, _p(g["gs_dq"]), _p(g["gs_mse"]), _p(g["gs_mse_partial"]), N * E,
                                   float(self._g_vq_host), st))
         check(lib.g2v_scale_f32(_p(g["gs_mse"]), _p(self._one_plus_beta), _p(self.vq_scalars), 1, st))      # loss_vq (:1427)
         check(lib.g2v_ste_f32(x, _p(g["gs_q"]), _p(b["quant"]), N * E, st))                                 # inputs + (q - inputs).detach()
-        return self.forward_decoder(out_poses, B, training)
+        b = self.forward_decoder(out_poses, B, training)
+        self._release()
+        self._join(1)
+        return b
 
     def _backward_gssoft(self, in_poses, B):
         """Backward of _forward_gssoft (expects buffers['dy']): the module path's autograd functions (_STEFn, _ProbsCodebookFn,
@@ -749,18 +756,22 @@ class VQVAEEngine:
                                   _p(g["gs_dlv"]), _p(g["gs_rowsum"]), N, K, st))
         check(lib.g2v_linear_bwd_data(_p(g["gs_dd"]), K, W, _p(g["gs_t"]), E, N, E, K, 0, st))
         check(lib.g2v_rowscale_combine(_p(g["gs_flat"]), _p(g["gs_rowsum"]), _p(g["gs_t"]), _p(g["gs_dflat"]), N, E, st))
-        check(lib.g2v_linear_bwd_weight(_p(g["gs_dd"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, _p(g["gs_tw"]),
-                                        _p(g["gs_colsum"]), N, E, K, 0, ws, wsn, st))
-        check(lib.g2v_rowscale_combine(W, _p(g["gs_colsum"]), _p(g["gs_tw"]), gW, K, E, st))               # 2 W sum_n dd - 2 dd^T f
-        check(lib.g2v_linear_bwd_weight(_p(g["gs_probs"]), K, _p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, gW, None, N, E, K, 1,
-                                        ws, wsn, st))                                                       # += probs^T dq
-        # logvar_layer, mean_layer
-        check(lib.g2v_linear_bwd_weight(_p(g["gs_dlv"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0,
-                                        self._g(vq + "logvar_layer.weight"), self._g(vq + "logvar_layer.bias"), N, E, K, 0,
-                                        ws, wsn, st))
         check(lib.g2v_linear_bwd_data(_p(g["gs_dlv"]), K, self._w(vq + "logvar_layer.weight"), _p(g["gs_dflat"]), E, N, E, K, 1, st))
-        check(lib.g2v_linear_bwd_weight(_p(g["gs_dflat"]), E, x, E, 0, 0, 0, None, 1.0, self._g(vq + "mean_layer.weight"),
-                                        self._g(vq + "mean_layer.bias"), N, E, E, 0, ws, wsn, st))
+        # The quantiser's five weight-gradient launches feed only clip + Adam: beside the encoder's BPTT, behind the decoder's
+        # products on their stream (round 4; they sat on the chain in front of the BPTT).  Everything they read is final here.
+        def q_wgrads():
+            st2 = self._stream()
+            check(lib.g2v_linear_bwd_weight(_p(g["gs_dd"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, _p(g["gs_tw"]),
+                                            _p(g["gs_colsum"]), N, E, K, 0, ws, wsn, st2))
+            check(lib.g2v_rowscale_combine(W, _p(g["gs_colsum"]), _p(g["gs_tw"]), gW, K, E, st2))           # 2 W sum_n dd - 2 dd^T f
+            check(lib.g2v_linear_bwd_weight(_p(g["gs_probs"]), K, _p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, gW, None, N, E, K, 1,
+                                            ws, wsn, st2))                                                  # += probs^T dq
+            check(lib.g2v_linear_bwd_weight(_p(g["gs_dlv"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0,
+                                            self._g(vq + "logvar_layer.weight"), self._g(vq + "logvar_layer.bias"), N, E, K, 0,
+                                            ws, wsn, st2))
+            check(lib.g2v_linear_bwd_weight(_p(g["gs_dflat"]), E, x, E, 0, 0, 0, None, 1.0, self._g(vq + "mean_layer.weight"),
+                                            self._g(vq + "mean_layer.bias"), N, E, E, 0, ws, wsn, st2))
+        self._fork(2, q_wgrads, late=False)
         check(lib.g2v_linear_bwd_data(_p(g["gs_dflat"]), E, self._w(vq + "mean_layer.weight"), _p(b["gz"]), E, N, E, E, 1, st))
         self.backward_encoder(in_poses, B)
         self._join(2)
