@@ -55,7 +55,7 @@ static_assert(L_END * 4 <= 160 * 1024, "LDS budget of the persistent rollout for
 constexpr int B_IH0 = 0, B_HH0 = 192, B_IH1 = 384, B_HH1 = 576, B_OUT = 768, B_PRE = 912, B_BNW = 976, B_BNB = 1040;
 }  // namespace
 
-size_t dec_persist_fwd_lds_bytes() { return (size_t)L_END * sizeof(float); }
+size_t dec_persist_fwd_lds_bytes(int tiles_per_wg) { return (size_t)(L_END + (tiles_per_wg - 1) * 2 * 16 * LDH) * sizeof(float); }
 
 struct DecPersistArgs {
   const float* target;      // (B,T,D)
@@ -571,6 +571,314 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
 
 
 // =====================================================================================================================
+// The same forward rollout for MORE row tiles than CUs (round 4): R tiles per workgroup, B / 16 <= R x CU count.  Until now
+// a batch of more than 256 row tiles fell back to one launch per time step (B = 8192: 4.0 ms per train step, BELOW the rate at
+// B = 4096).  Workgroup b owns tiles b, b + nwg, b + 2 nwg ... (< ntiles) and walks them one after the other inside every time
+// step: the four GRU matrices stay in its registers and W_out / W_pre in its LDS, a tile's two hidden states live in LDS across
+// the steps (8.7 KB per extra tile), its pre-BatchNorm u tile in 4 registers, and the BatchNorm partial sums of all its tiles are
+// added up and published as ONE record per step -- the exchange (dec_persist.hpp) runs once per step over the nwg workgroups,
+// threaded through the first tile's hidden-side products exactly as in the one-tile kernel above.  What the one-tile kernel
+// hides and this one does not: the other tiles' hidden-side products (no exchange to hide them in) and the deferral of the y /
+// xin stores.  The loss chaser is not offered here (one chaser workgroup per tile would not be co-resident).
+// =====================================================================================================================
+template <int R>
+__global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistArgs a, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xa = smem + L_XA;
+  float* Xx1 = smem + L_XX1;
+  float* Xy = smem + L_XY;
+  float* Xt = smem + L_XT;
+  float* Yt = smem + L_YT;
+  uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + L_KT);
+  float* Pout = smem + L_POUT;
+  float* Ppre = smem + L_PPRE;
+  float* Bs = smem + L_BIAS;
+  float* st = smem + L_ST;
+  float* red = smem + L_RED;
+  float* tot = smem + L_TOT;
+  auto Xh0_of = [&](int r) { return r == 0 ? smem + L_XH0 : smem + L_END + (r - 1) * 2 * 16 * LDH; };
+  auto Xh1_of = [&](int r) { return r == 0 ? smem + L_XH1 : smem + L_END + (r - 1) * 2 * 16 * LDH + 16 * LDH; };
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+  const int T = a.T, B = a.B, ntiles = a.nblk;
+  const int f0 = 16 * wave + 4 * q;
+  const bool training = a.training != 0;
+  const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
+  const float keep_scale = 1.0f / (1.0f - a.p_drop);
+  const int64_t BH = (int64_t)B * H;
+  const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
+  float run_m = 0.f, run_v = 0.f;
+  if (training && b == 0 && tid < H) {
+    run_m = a.w.bn_running_mean[tid];
+    run_v = a.w.bn_running_var[tid];
+  }
+  WFrag<3, KSH> f_ih0, f_hh0, f_ih1, f_hh1;
+  frag_load(f_hh0, a.p_hh0, wave, 4, lane);
+  frag_load(f_hh1, a.p_hh1, wave, 4, lane);
+  frag_load(f_ih0, a.p_ih0, wave, 4, lane);
+  frag_load(f_ih1, a.p_ih1, wave, 4, lane);
+  for (int e = tid; e < 9 * KSH * 64; e += 256)
+    reinterpret_cast<float4*>(Pout)[e] = reinterpret_cast<const float4*>(a.p_out)[e];
+  for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Ppre)[e] = reinterpret_cast<const float4*>(a.p_pre)[e];
+  for (int e = tid; e < 192; e += 256) {
+    Bs[B_IH0 + e] = a.w.b_ih0[e]; Bs[B_HH0 + e] = a.w.b_hh0[e];
+    Bs[B_IH1 + e] = a.w.b_ih1[e]; Bs[B_HH1 + e] = a.w.b_hh1[e];
+  }
+  for (int e = tid; e < 144; e += 256) Bs[B_OUT + e] = e < D ? a.w.b_out[e] : 0.f;
+  if (tid < H) {
+    Bs[B_PRE + tid] = a.w.b_pre[tid];
+    Bs[B_BNW + tid] = a.w.bn_w[tid];
+    Bs[B_BNB + tid] = a.w.bn_b[tid];
+    if (!training) {
+      st[tid] = a.w.bn_running_mean[tid];
+      st[H + tid] = bn_invstd_(a.w.bn_running_var[tid]);
+    }
+  }
+  for (int e = tid; e < 16 * (LDD - D); e += 256) Xy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
+  for (int e = tid; e < 4 * 16 * LDH; e += 256) smem[L_XA + e] = 0.f;
+  for (int e = tid; e < (R - 1) * 2 * 16 * LDH; e += 256) smem[L_END + e] = 0.f;
+  lds_barrier();
+  // initial state of every tile: h0_0, h1_0 = the quantised latent
+  static_for<R>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    const int tb = b + r * nwg;
+    if (tb < ntiles) {
+      const int rr = tid >> 4, c = (tid & 15) * 4, b0 = 16 * tb;
+      const float4 v0 = *reinterpret_cast<const float4*>(a.h_init + (int64_t)(b0 + rr) * H + c);
+      const float4 v1 = *reinterpret_cast<const float4*>(a.h_init + BH + (int64_t)(b0 + rr) * H + c);
+      *reinterpret_cast<float4*>(Xh0_of(r) + rr * LDH + c) = v0;
+      *reinterpret_cast<float4*>(Xh1_of(r) + rr * LDH + c) = v1;
+      if (a.sv.h0) *reinterpret_cast<float4*>(a.sv.h0 + (int64_t)(b0 + rr) * H + c) = v0;
+      if (a.sv.h1) *reinterpret_cast<float4*>(a.sv.h1 + (int64_t)(b0 + rr) * H + c) = v1;
+    }
+  });
+  lds_barrier();
+
+  f32x4 u_acc[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) u_acc[r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int t = 0; t < T; ++t) {
+    const bool has_next = t < T - 1;
+    float s1a[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f};      // BatchNorm partial sums over this workgroup's tiles
+    static_for<R>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      const int tb = b + r * nwg;
+      if (tb >= ntiles) return;                       // (uniform per workgroup)
+      const int b0 = 16 * tb;
+      float* Xh0 = Xh0_of(r);
+      float* Xh1 = Xh1_of(r);
+      if (t > 0) {
+        f32x4 gh0[3], gh1[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          gh0[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          gh1[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        uint32_t kreq[3] = {0u, 0u, 0u};
+        const bool fast_y = has_next && !(t < a.n_pre);
+        if (fast_y && a.conditioned) {
+          const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)t * B + b0) * D);
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int e4 = tid + 256 * j;
+            kreq[j] = kp4[e4 < (16 * D) / 4 ? e4 : 0];
+          }
+        }
+        // the exchange of this step's BatchNorm sums is threaded through the FIRST tile's hidden-side products
+        frag_mma_x1st(gh0, f_hh0, Xh0, LDH, lane);
+        if (r == 0 && training) px_hop1(a.x, t & 1, (unsigned)t, nwg, b, red, tot, tid);
+        frag_mma_x1st(gh1, f_hh1, Xh1, LDH, lane);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int e4 = tid + 256 * j;
+          if (e4 < (16 * D) / 4) Kt[e4] = kreq[j];
+        }
+        if (r == 0 && training) {
+          if (px_two_hops(nwg)) px_hop2(a.x, t & 1, (unsigned)t, nwg, b, red, tot, tid);
+          if (tid < H) {
+            const float s1 = tot[tid], s2 = tot[H + tid];
+            const float mv = s1 / (float)B;
+            const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);
+            const float mean = mv + Bs[B_PRE + tid];
+            st[tid] = mean;
+            st[H + tid] = bn_invstd_(var);
+            if (b == 0 && a.sv.bn_stats) {
+              a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + tid] = mean;
+              a.sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + tid] = var;
+            }
+            run_m = 0.9f * run_m + 0.1f * mean;
+            run_v = 0.9f * run_v + 0.1f * (var * unbias);
+          }
+          lds_barrier();
+        }
+        // a_t = ReLU(BN(u_t)) from the tile's register-resident u
+        {
+          const float4 m4 = *reinterpret_cast<const float4*>(st + f0), i4 = *reinterpret_cast<const float4*>(st + H + f0);
+          const float4 g4 = *reinterpret_cast<const float4*>(Bs + B_BNW + f0), b4 = *reinterpret_cast<const float4*>(Bs + B_BNB + f0);
+          const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
+          float4 a4;
+          a4.x = fmaxf(((u_acc[r][0] + p4.x) - m4.x) * i4.x * g4.x + b4.x, 0.f);
+          a4.y = fmaxf(((u_acc[r][1] + p4.y) - m4.y) * i4.y * g4.y + b4.y, 0.f);
+          a4.z = fmaxf(((u_acc[r][2] + p4.z) - m4.z) * i4.z * g4.z + b4.z, 0.f);
+          a4.w = fmaxf(((u_acc[r][3] + p4.w) - m4.w) * i4.w * g4.w + b4.w, 0.f);
+          *reinterpret_cast<float4*>(Xa + i * LDH + f0) = a4;
+          if (a.sv.a) *reinterpret_cast<float4*>(a.sv.a + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = a4;
+        }
+        lds_barrier();
+        {
+          uint32_t kp = 0x01010101u;
+          if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + i) * H + f0);
+          f32x4 ai[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
+          cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
+                        a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                        (drop && a.sv.x1) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+        }
+        lds_barrier();
+        {
+          f32x4 ai[3];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          frag_mma_x1st(ai, f_ih1, Xx1, LDH, lane);
+          cell_epilogue(ai, gh1, Bs + B_IH1, Bs + B_HH1, 0x01010101u, false, 1.0f, Xh1, nullptr,
+                        a.sv.h1 ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
+        }
+        lds_barrier();
+        {      // y_t = out_layer(h1_t) -> dense tile (see the one-tile kernel for the shape of this epilogue)
+          f32x4 acc[3];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (wave == 0) {
+            lds_frag_mma<3, KSH>(acc, Pout, wave, 4, Xh1, LDH, lane);
+          } else {
+            f32x4 a2[2] = {acc[0], acc[1]};
+            lds_frag_mma<2, KSH>(a2, Pout, wave, 4, Xh1, LDH, lane);
+            acc[0] = a2[0]; acc[1] = a2[1];
+          }
+          const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
+          float bo[3][4], yv[3][4], xv[3][4];
+          uint32_t kb[3][4];
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int d0 = 16 * (wave + 4 * j) + 4 * q, d0c = d0 < Dp ? d0 : 4 * q;
+            const float4 b4 = *reinterpret_cast<const float4*>(Bs + B_OUT + d0c);
+            bo[j][0] = b4.x; bo[j][1] = b4.y; bo[j][2] = b4.z; bo[j][3] = b4.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) kb[j][e] = Kb[i * D + d0c + e];
+          }
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              yv[j][e] = acc[j][e] + bo[j][e];
+              xv[j][e] = kb[j][e] ? yv[j][e] * 20.0f : 0.f;
+            }
+#pragma unroll
+          for (int j = 0; j < 3; ++j) {
+            const int d0 = 16 * (wave + 4 * j) + 4 * q;
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (d0 + e < D) {
+                Yt[i * D + d0 + e] = yv[j][e];
+                if (fast_y) {
+                  Xt[i * D + d0 + e] = xv[j][e];
+                  Xy[i * LDD + d0 + e] = xv[j][e];
+                }
+              }
+          }
+        }
+        lds_barrier();
+      }
+      // ---- y_t out, next decoder input xin_{t+1} = Dropout(0.95)(y_t | target_t) ------------------------------------------
+      const bool fast_dense = t > 0 && (!has_next || !(t < a.n_pre));
+      const int64_t tile = ((int64_t)t * B + b0) * D;
+      if (fast_dense) {
+        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+          *reinterpret_cast<float4*>(a.sv.y + tile + 4 * e4) = reinterpret_cast<const float4*>(Yt)[e4];
+          if (has_next && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
+        }
+      } else {
+        const bool teacher = has_next && (t < a.n_pre);
+        const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
+        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+          const int e = 4 * e4;
+          float yv[4], sv_[4];
+          if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int rr = (e + j) / D, c = (e + j) - rr * D;
+              yv[j] = a.target[((int64_t)(b0 + rr) * T) * D + c];
+            }
+          } else {
+            const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
+            yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
+          }
+          *reinterpret_cast<float4*>(a.sv.y + tile + e) = make_float4(yv[0], yv[1], yv[2], yv[3]);
+          if (!has_next) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            sv_[j] = yv[j];
+            if (teacher && t > 0) {
+              const int rr = (e + j) / D, c = (e + j) - rr * D;
+              sv_[j] = a.target[((int64_t)(b0 + rr) * T + t) * D + c];
+            }
+          }
+          const uint32_t k4 = a.conditioned ? kp4[e4] : 0u;
+          float xv[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;
+          if (a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + e) = make_float4(xv[0], xv[1], xv[2], xv[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int rr = (e + j) / D, c = (e + j) - rr * D;
+            Xy[rr * LDD + c] = xv[j];
+          }
+        }
+        lds_barrier();
+      }
+      if (!has_next) return;
+      // ---- u_{t+1} = pre_linear.0(xin_{t+1}) of this tile; its partial sums join the workgroup's ---------------------------
+      u_acc[r] = lds_frag_mma_2chain<KSD>(Ppre, wave, Xy, LDD, lane);
+      const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
+      if (a.sv.u)
+        *reinterpret_cast<float4*>(a.sv.u + ((int64_t)t * B + b0 + i) * H + f0) =
+            make_float4(u_acc[r][0] + p4.x, u_acc[r][1] + p4.y, u_acc[r][2] + p4.z, u_acc[r][3] + p4.w);
+      if (training) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s1a[e] += reduce16(u_acc[r][e]);
+          s2a[e] += reduce16(u_acc[r][e] * u_acc[r][e]);
+        }
+      }
+      // (the dense y / xin copies above read Yt / Xt and the product read Xy: the next tile rewrites them three barriers on;
+      //  Kt is rewritten behind its hidden-side products -- its last reader, this tile's out-layer epilogue, sits behind a barrier)
+    });
+    if (!has_next) break;
+    if (training && i == 0) {
+      const int par = (t + 1) & 1;
+      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+          a.x.rec1 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0, PX_COLS * 8, 0x00020000);
+      const unsigned tag = (unsigned)(t + 1);
+      px_publish2(rr, (unsigned)f0, s1a[0], s1a[1], tag);
+      px_publish2(rr, (unsigned)f0 + 2, s1a[2], s1a[3], tag);
+      px_publish2(rr, (unsigned)(H + f0), s2a[0], s2a[1], tag);
+      px_publish2(rr, (unsigned)(H + f0) + 2, s2a[2], s2a[3], tag);
+    }
+  }
+  if (training && b == 0 && tid < H && __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+    a.w.bn_running_mean[tid] = run_m;
+    a.w.bn_running_var[tid] = run_v;
+  }
+}
+
+// =====================================================================================================================
 // custom_loss (train_eval/train_seq2seq.py:40-88) as a CHASER of the forward rollout: a second, light kernel (one 256-thread
 // workgroup per row tile, <= 128 registers per lane, 64 bytes of LDS) that is co-resident with dec_persist_fwd_kernel -- which
 // runs one wave per SIMD and leaves ~140 registers per lane and ~29 KB of LDS of every CU unused -- and consumes each y_t tile as
@@ -794,7 +1102,7 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
                            const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
                            int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
                            const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st,
-                           bool clear) {
+                           bool clear, int tiles_per_wg) {
   DecPersistArgs a;
   a.target = target; a.h_init = h_init; a.w = *w;
   a.p_pre = p_pre; a.p_ih0 = p_ih0; a.p_hh0 = p_hh0; a.p_ih1 = p_ih1; a.p_hh1 = p_hh1; a.p_out = p_out;
@@ -802,7 +1110,33 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   a.x = persist_x_at(xbase);
   a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
   a.p_drop = p_drop;
-  const size_t lds = dec_persist_fwd_lds_bytes();
+  if (tiles_per_wg > 1) {
+    // more row tiles than CUs: R tiles per workgroup (dec_persist_fwd_mt_kernel); no chaser there
+    const int R = tiles_per_wg, nwg = (a.nblk + R - 1) / R;
+    const size_t lds = dec_persist_fwd_lds_bytes(R);
+    const void* fn = R == 2 ? (const void*)dec_persist_fwd_mt_kernel<2> : (const void*)dec_persist_fwd_mt_kernel<3>;
+    static bool mt_set[2] = {false, false};
+    if (R > 3 || s->loss_code) {
+      set_error("dec_persist_fwd: %d tiles per workgroup / a chased rollout is not offered", R);
+      return G2V_ERR_ARG;
+    }
+    if (!mt_set[R - 2]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || !persist_fits(fn, lds)) {
+        set_error("dec_persist_fwd: the %d-tile kernel does not fit a CU (%zu bytes of LDS)", R, lds);
+        return G2V_ERR_LAUNCH;
+      }
+      mt_set[R - 2] = true;
+    }
+    if (training && clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
+    if (R == 2) hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    else hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<3>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    if (hipGetLastError() != hipSuccess) {
+      set_error("dec_persist_fwd: launch failed");
+      return G2V_ERR_LAUNCH;
+    }
+    return G2V_OK;
+  }
+  const size_t lds = dec_persist_fwd_lds_bytes(1);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)dec_persist_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -1326,12 +1660,256 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_kernel(DecPersistBwdAr
   }
 }
 
+
+// The backward rollout for more row tiles than CUs: R tiles per workgroup (see dec_persist_fwd_mt_kernel).  The four transposed
+// GRU matrices stay in registers and W_pre^T / W_out^T in LDS; per tile the workgroup carries the two hidden-state gradients and
+// dbn / xhat / gamma * invstd of the step whose BatchNorm-backward sums are in flight (20 registers), and publishes ONE record of
+// partial sums per step.  The exchange runs once per step; du of every tile is finished from the same totals.  The dy / keep95
+// tiles and the five cell-1 vectors of the NEXT unit of work -- (t, next tile) or (t-1, first tile) -- are requested behind the
+// cell-1 epilogue of the current one.  Neither the fused W_hh1 weight gradient nor the loss fold is offered here.
+template <int R>
+__global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBwdArgs a, int nwg) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xdu = smem + R_XDU;
+  float* Xdy = smem + R_XDY;
+  float* Gt = smem + R_G;
+  float* Dt = smem + R_DT;
+  uint32_t* Kt = reinterpret_cast<uint32_t*>(smem + R_KT);
+  float* Ppre_t = smem + R_PPRET;
+  float* Pout_t = smem + R_POUTT;
+  float* bnw = smem + R_BNW;
+  float* red = smem + R_RED;
+  float* tot = smem + R_TOT;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b = blockIdx.x;
+  const int T = a.T, B = a.B, G3 = 3 * H, ntiles = a.nblk;
+  const int f0 = 16 * wave + 4 * q;
+  const bool drop = a.keep_l0 && a.p_drop > 0.f;
+  const float keep_scale = 1.0f / (1.0f - a.p_drop);
+  const float invB = 1.0f / (float)B;
+  const int Rv = min(R, (ntiles - b + nwg - 1) / nwg);      // this workgroup's tiles: b, b + nwg, ... (>= 1 of them)
+
+  WFrag<1, KSG> f_ih0, f_hh0, f_ih1, f_hh1;
+  frag_load(f_hh1, a.p_hh1_t, wave, 0, lane);
+  frag_load(f_ih1, a.p_ih1_t, wave, 0, lane);
+  frag_load(f_hh0, a.p_hh0_t, wave, 0, lane);
+  frag_load(f_ih0, a.p_ih0_t, wave, 0, lane);
+  for (int e = tid; e < 9 * KSH * 64; e += 256)
+    reinterpret_cast<float4*>(Ppre_t)[e] = reinterpret_cast<const float4*>(a.p_pre_t)[e];
+  for (int e = tid; e < 4 * KSD * 64; e += 256) reinterpret_cast<float4*>(Pout_t)[e] = reinterpret_cast<const float4*>(a.p_out_t)[e];
+  if (tid < H) bnw[tid] = a.w.bn_w[tid];
+  for (int e = tid; e < 16 * LDH; e += 256) Xdu[e] = 0.f;
+  for (int e = tid; e < 16 * (LDD - D); e += 256) Xdy[(e / (LDD - D)) * LDD + D + (e % (LDD - D))] = 0.f;
+  lds_barrier();
+
+  float4 dy_a, dy_b, dy_c;
+  uint32_t k_a, k_b, k_c;
+  CellSaved c1;
+  // the unit (step ts >= 1, rows b0x ..): dy / keep95 tiles and the cell-1 saved vectors
+  auto unit_request = [&](int ts, int b0x) {
+    const int e4c = tid + 512 < (16 * D) / 4 ? tid + 512 : 0;
+    const float* dyp = a.gr.dy + ((int64_t)ts * B + b0x) * D;
+    const uint32_t* kp = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)min(ts, T - 2) * B + b0x) * D);
+    dy_a = *reinterpret_cast<const float4*>(dyp + 4 * tid);
+    dy_b = *reinterpret_cast<const float4*>(dyp + 4 * (tid + 256));
+    dy_c = *reinterpret_cast<const float4*>(dyp + 4 * e4c);
+    k_a = kp[tid]; k_b = kp[tid + 256]; k_c = kp[e4c];
+    load_cell(c1, a.sv.gates1, a.sv.h1, (int64_t)(ts - 1) * B + b0x + i, f0);
+  };
+  auto tile_commit = [&](int ts) {
+    const bool fb = (ts != T - 1) && a.conditioned && (ts >= a.n_pre);
+    reinterpret_cast<float4*>(Dt)[tid] = dy_a;
+    reinterpret_cast<float4*>(Dt)[tid + 256] = dy_b;
+    Kt[tid] = fb ? k_a : 0u;
+    Kt[tid + 256] = fb ? k_b : 0u;
+    if (tid + 512 < (16 * D) / 4) {
+      reinterpret_cast<float4*>(Dt)[tid + 512] = dy_c;
+      Kt[tid + 512] = fb ? k_c : 0u;
+    }
+  };
+  unit_request(T - 1, 16 * b);
+  tile_commit(T - 1);
+
+  float4 carry0[R], carry1[R];
+  float dbn[R][4], xhat[R][4], gis[R][4];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    carry0[r] = carry1[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dbn[r][e] = xhat[r][e] = gis[r][e] = 0.f;
+  }
+  float acc_w = 0.f, acc_b = 0.f;
+
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = (t == T - 1);
+    const bool feedback = !last && a.conditioned && (t >= a.n_pre);
+    float a1[4] = {0.f, 0.f, 0.f, 0.f}, a2s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (!last) {      // BatchNorm-backward sums of step t+1 over ALL rows: one exchange for the workgroup's tiles
+      px_exchange(a.x, (t + 1) & 1, (unsigned)(T - 1 - t), nwg, b, red, tot, tid);
+      const float4 s14 = *reinterpret_cast<const float4*>(tot + f0), s24 = *reinterpret_cast<const float4*>(tot + H + f0);
+      a1[0] = s14.x; a1[1] = s14.y; a1[2] = s14.z; a1[3] = s14.w;
+      a2s[0] = s24.x; a2s[1] = s24.y; a2s[2] = s24.z; a2s[3] = s24.w;
+      if (b == 0 && tid < H) {
+        acc_w += tot[H + tid];
+        acc_b += tot[tid];
+      }
+    }
+    float s1a[4] = {0.f, 0.f, 0.f, 0.f}, s2a[4] = {0.f, 0.f, 0.f, 0.f};
+    static_for<R>([&](auto rc) {
+      constexpr int r = decltype(rc)::value;
+      if (r >= Rv) return;
+      const int b0 = 16 * (b + r * nwg);
+      const int64_t row_i = b0 + i;
+      const int64_t tile = ((int64_t)t * B + b0) * D;
+      const int64_t srow = (int64_t)(t - 1) * B + row_i;
+      const CellSaved c1u = c1;
+      // ---- Part A: du_{t+1} of this tile ----------------------------------------------------------------------------------
+      if (!last) {
+        float du[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) du[e] = gis[r][e] * (dbn[r][e] - a1[e] * invB - xhat[r][e] * a2s[e] * invB);
+        const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
+        *reinterpret_cast<float4*>(a.gr.du + ((int64_t)t * B + row_i) * H + f0) = du4;
+        if (t > 0) *reinterpret_cast<float4*>(Xdu + i * LDH + f0) = du4;
+      }
+      if (t == 0) return;
+      lds_barrier();
+      // ---- Part B: dy_t = loss gradient + feedback through Dropout(0.95) and pre_linear ----------------------------------------
+      {
+        f32x4 acc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (feedback) {
+          int lane_r = lane;
+          asm volatile("" : "+v"(lane_r));
+          if (wave == 0) {
+            lds_frag_mma<3, KSH>(acc, Ppre_t, wave, 4, Xdu, LDH, lane_r);
+          } else {
+            f32x4 a2[2] = {acc[0], acc[1]};
+            lds_frag_mma<2, KSH>(a2, Ppre_t, wave, 4, Xdu, LDH, lane_r);
+            acc[0] = a2[0]; acc[1] = a2[1];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int d0 = 16 * (wave + 4 * j) + 4 * q, d0c = d0 < Dp ? d0 : 4 * q;
+          float dyv[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dyv[e] = Dt[i * D + d0c + e];
+          const int kbyte = i * D + d0c;
+          const uint32_t klo = Kt[kbyte >> 2], khi = Kt[(kbyte >> 2) + 1];
+          const uint32_t kb4 = __builtin_amdgcn_alignbyte(khi, klo, (uint32_t)(kbyte & 3));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dyv[e] = (feedback && ((kb4 >> (8 * e)) & 0xffu)) ? dyv[e] + acc[j][e] * 20.0f : dyv[e];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int d = d0 + e;
+            if (d < D) {
+              Dt[i * D + d] = dyv[e];
+              Xdy[i * LDD + d] = dyv[e];
+            }
+          }
+        }
+      }
+      lds_barrier();
+      if (feedback)
+        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256)
+          *reinterpret_cast<float4*>(a.gr.dy + tile + 4 * (int64_t)e4) = reinterpret_cast<const float4*>(Dt)[e4];
+      // ---- dh1 = carry1 + dy W_out ; GRU cell 1 backward -------------------------------------------------------------------
+      float4 direct1;
+      {
+        const f32x4 acc0 = lds_frag_mma_2chain<KSD>(Pout_t, wave, Xdy, LDD, lane);
+        const float dh[4] = {acc0[0] + carry1[r].x, acc0[1] + carry1[r].y, acc0[2] + carry1[r].z, acc0[3] + carry1[r].w};
+        direct1 = cell_bwd<true>(dh, c1u, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt, i, f0);
+      }
+      CellSaved c0;
+      load_cell(c0, a.sv.gates0, a.sv.h0, srow, f0);
+      const float4 a4 = *reinterpret_cast<const float4*>(a.sv.a + srow * H + f0);
+      const float4 u4 = *reinterpret_cast<const float4*>(a.sv.u + srow * H + f0);
+      const float4 mean4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + f0);
+      const float4 var4 = *reinterpret_cast<const float4*>(a.sv.bn_stats + (int64_t)(t - 1) * 2 * H + H + f0);
+      uint32_t kl0 = 0x01010101u;
+      if (drop) kl0 = *reinterpret_cast<const uint32_t*>(a.keep_l0 + srow * H + f0);
+      // the next unit of work of this workgroup
+      const bool wrap = (r + 1 >= Rv);
+      const int nt = wrap ? t - 1 : t;
+      const int nb0 = wrap ? 16 * b : 16 * (b + (r + 1) * nwg);
+      if (nt >= 1) unit_request(nt, nb0);
+      __builtin_amdgcn_sched_barrier(0);
+      lds_barrier();
+      // ---- carry1' = dh1 * z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 ---------------------------------------------------------
+      float dh0[4];
+      {
+        f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+        gate_frag_mma2(p1, f_hh1, p2, f_ih1, Gt, lane);
+        carry1[r] = make_float4(direct1.x + p1[0], direct1.y + p1[1], direct1.z + p1[2], direct1.w + p1[3]);
+        const float c0v[4] = {carry0[r].x, carry0[r].y, carry0[r].z, carry0[r].w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = p2[e];
+          if (drop) v = ((kl0 >> (8 * e)) & 0xffu) ? v * keep_scale : 0.f;
+          dh0[e] = v + c0v[e];
+        }
+      }
+      if (nt >= 1) tile_commit(nt);
+      lds_barrier();
+      // ---- GRU cell 0 backward -------------------------------------------------------------------------------------------------
+      const float4 direct0 = cell_bwd<true>(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0);
+      lds_barrier();
+      // ---- carry0' ; da -> ReLU backward -> dbn_t of this tile, partial sums --------------------------------------------------
+      {
+        f32x4 p1 = {0.f, 0.f, 0.f, 0.f}, p2 = {0.f, 0.f, 0.f, 0.f};
+        gate_frag_mma2(p1, f_hh0, p2, f_ih0, Gt, lane);
+        carry0[r] = make_float4(direct0.x + p1[0], direct0.y + p1[1], direct0.z + p1[2], direct0.w + p1[3]);
+        const float av[4] = {a4.x, a4.y, a4.z, a4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, mv[4] = {mean4.x, mean4.y, mean4.z, mean4.w},
+                    vv[4] = {var4.x, var4.y, var4.z, var4.w};
+        const float4 g4 = *reinterpret_cast<const float4*>(bnw + f0);
+        const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float invstd = bn_invstd_(vv[e]);
+          dbn[r][e] = (av[e] > 0.f) ? p2[e] : 0.f;
+          xhat[r][e] = (uv[e] - mv[e]) * invstd;
+          gis[r][e] = gg[e] * invstd;
+          s1a[e] += reduce16(dbn[r][e]);
+          s2a[e] += reduce16(dbn[r][e] * xhat[r][e]);
+        }
+      }
+    });
+    if (t == 0) break;
+    if (i == 0) {
+      const int par = t & 1;
+      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(
+          a.x.rec1 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0, PX_COLS * 8, 0x00020000);
+      const unsigned tag = (unsigned)(T - t);
+      px_publish2(rr, (unsigned)f0, s1a[0], s1a[1], tag);
+      px_publish2(rr, (unsigned)f0 + 2, s1a[2], s1a[3], tag);
+      px_publish2(rr, (unsigned)(H + f0), s2a[0], s2a[1], tag);
+      px_publish2(rr, (unsigned)(H + f0) + 2, s2a[2], s2a[3], tag);
+    }
+  }
+  static_for<R>([&](auto rc) {
+    constexpr int r = decltype(rc)::value;
+    if (r >= Rv) return;
+    const int64_t row_i = 16 * (b + r * nwg) + i;
+    *reinterpret_cast<float4*>(a.gr.dh_init + row_i * H + f0) = carry0[r];
+    *reinterpret_cast<float4*>(a.gr.dh_init + ((int64_t)B + row_i) * H + f0) = carry1[r];
+  });
+  if (b == 0 && tid < H) {
+    a.gr.d_bn_w[tid] = acc_w;
+    a.gr.d_bn_b[tid] = acc_b;
+  }
+}
+
 }  // namespace g2v
 
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab) {
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab,
+                           int tiles_per_wg) {
   const bool fw = wslab != nullptr;      // fused W_hh1 weight gradient requested (g->dw_gru[3] / db_gru[3] set)
   DecPersistBwdArgs a;
   a.w = *w; a.sv = *s; a.gr = *g;
@@ -1343,6 +1921,31 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
   {      // as g2v_custom_loss_fwd_bwd forms them
     const float n = (float)T * (float)B * (float)D;
     a.lc1 = s->loss_w[0] / n; a.lc2 = s->loss_w[1] / n; a.lc3 = s->loss_w[2] / n; a.linv_n = 1.0f / n;
+  }
+  if (tiles_per_wg > 1) {
+    const int R = tiles_per_wg, nwg = (a.nblk + R - 1) / R;
+    const size_t lds = dec_persist_bwd_lds_bytes(false);
+    const void* fn = R == 2 ? (const void*)dec_persist_bwd_mt_kernel<2> : (const void*)dec_persist_bwd_mt_kernel<3>;
+    static bool mt_set[2] = {false, false};
+    if (R > 3 || fw || s->loss_code) {
+      set_error("dec_persist_bwd: %d tiles per workgroup with a fused weight gradient / loss fold is not offered", R);
+      return G2V_ERR_ARG;
+    }
+    if (!mt_set[R - 2]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || !persist_fits(fn, lds)) {
+        set_error("dec_persist_bwd: the %d-tile kernel does not fit a CU", R);
+        return G2V_ERR_LAUNCH;
+      }
+      mt_set[R - 2] = true;
+    }
+    if (clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
+    if (R == 2) hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    else hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<3>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    if (hipGetLastError() != hipSuccess) {
+      set_error("dec_persist_bwd: launch failed");
+      return G2V_ERR_LAUNCH;
+    }
+    return G2V_OK;
   }
   const size_t lds = dec_persist_bwd_lds_bytes(fw);
   static bool attr_set[2] = {false, false};

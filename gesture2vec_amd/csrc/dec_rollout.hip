@@ -26,11 +26,12 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
                            const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned,
                            int training, int T, int B, const float* p_pre, const float* p_ih0, const float* p_hh0,
                            const float* p_ih1, const float* p_hh1, const float* p_out, void* xbase, hipStream_t st,
-                           bool clear);
+                           bool clear, int tiles_per_wg);
 int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, const g2v_dec_grads* g, const uint8_t* keep95,
                            const uint8_t* keep_l0, float p_drop, int n_pre, int conditioned, int T, int B,
                            const float* p_pre_t, const float* p_out_t, const float* p_ih0_t, const float* p_hh0_t,
-                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab);
+                           const float* p_ih1_t, const float* p_hh1_t, void* xbase, hipStream_t st, bool clear, float* wslab,
+                           int tiles_per_wg);
 int dec_persist_loss_chase_launch(const float* target, const g2v_dec_saved* s, const uint8_t* keep95, int T, int B, void* xbase,
                                   hipStream_t st);
 namespace g2v {
@@ -50,6 +51,18 @@ static int device_cu_count() {
 }
 static int g_persist = 1;      // g2v_dec_rollout_set_persistent (the library reads no environment variable)
 static bool persist_enabled() { return g_persist != 0; }
+// Row tiles per workgroup of a persistent rollout over `nblk` row tiles: 1 while there is a CU per tile, 2 or 3 beyond that
+// (dec_persist.hip, the *_mt kernels); 0: not offered.  g_persist = 2 / 3 asks for at least that many (parity tests of the
+// multi-tile kernels at small batches).
+constexpr int PERSIST_MAX_TILES_PER_WG = 3;
+static int persist_tiles_per_wg(int nblk) {
+  if (!persist_enabled() || nblk <= 0) return 0;
+  const int cus = device_cu_count() < PX_MAX_NBLK ? device_cu_count() : PX_MAX_NBLK;
+  if (cus <= 0) return 0;
+  int r = cdiv(nblk, cus);
+  if (g_persist > r) r = g_persist < nblk ? g_persist : (nblk > 1 ? nblk : 1);
+  return r <= PERSIST_MAX_TILES_PER_WG ? r : 0;
+}
 
 #ifdef G2V_STAMPS
 __device__ unsigned long long g2v_stamps[64 * 16];
@@ -1096,8 +1109,8 @@ extern "C" int g2v_read_spans(unsigned long long* out) {
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 extern "C" int g2v_dec_rollout_set_persistent(int enable) {
-  const int prev = persist_enabled() ? 1 : 0;
-  g_persist = enable ? 1 : 0;
+  const int prev = g_persist;
+  g_persist = enable <= 0 ? 0 : (enable > PERSIST_MAX_TILES_PER_WG ? PERSIST_MAX_TILES_PER_WG : enable);
   return prev;
 }
 
@@ -1762,7 +1775,8 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
   const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
-    const bool persist = fast && persist_enabled() && (B % 16) == 0 && dm.nblk <= PX_MAX_NBLK && dm.nblk <= device_cu_count() &&
+    const int ptiles = persist_tiles_per_wg(dm.nblk);
+    const bool persist = fast && ptiles >= 1 && (B % 16) == 0 &&
                          a16(h_init) && a16(s->y) && a16(s->u) && a16(s->h0) && a16(s->h1) && a16(s->xin) && a16(s->a) &&
                          a16(s->x1) && a16(s->gates0) && a16(s->gates1) && a16(keep95) && a16(keep_l0) && a16(workspace);
     if (s->loss_code && !(persist && training && s->loss_coef && s->loss_partial && s->loss_terms &&
@@ -1774,7 +1788,7 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     if (persist) {
       void* xbase = (char*)workspace + fwd_pack_bytes_aligned(D, H);
       const int rc = dec_persist_fwd_launch(target, h_init, w, s, keep95, keep_l0, p_drop, n_pre_poses, conditioned, training, T,
-                                            B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st, !prepared);
+                                            B, pk.pre, pk.ih0, pk.hh0, pk.ih1, pk.hh1, pk.out, xbase, st, !prepared, ptiles);
       return rc;       // (the running statistics are updated by the kernel itself)
     }
   }
@@ -1864,12 +1878,10 @@ extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   return a > b ? a : b;
 }
 extern "C" int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T) {
-  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() && T >= 2 &&
-          T <= 256 && persist_enabled()) ? 1 : 0;
+  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && persist_tiles_per_wg(B / 16) == 1 && T >= 2 && T <= 256) ? 1 : 0;
 }
 extern "C" int g2v_dec_rollout_bwd_fuses_wgrad(int B, int D, int H) {
-  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && B / 16 <= PX_MAX_NBLK && B / 16 <= device_cu_count() &&
-          persist_enabled()) ? 8 : 0;      // bit m <-> matrix m of (ih0, hh0, ih1, hh1): W_hh1
+  return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && persist_tiles_per_wg(B / 16) == 1) ? 8 : 0;      // bit m <-> matrix m of (ih0, hh0, ih1, hh1): W_hh1
 }
 
 // custom_loss as a chaser of the persistent forward rollout (dec_persist.hip, loss_chase_kernel; include/g2v.h).
@@ -2015,7 +2027,8 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
   const bool fast = (H == 64) && (D == 135);
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
-    const bool persist = fast && persist_enabled() && (B % 16) == 0 && dm.nblk <= PX_MAX_NBLK && dm.nblk <= device_cu_count() &&
+    const int ptiles = persist_tiles_per_wg(dm.nblk);
+    const bool persist = fast && ptiles >= 1 && (B % 16) == 0 &&
                          a16(s->u) && a16(s->a) && a16(s->h0) && a16(s->h1) && a16(s->gates0) && a16(s->gates1) &&
                          a16(s->bn_stats) && a16(g->dy) && a16(g->du) && a16(g->dgi0) && a16(g->dgh0) && a16(g->dgi1) &&
                          a16(g->dgh1) && a16(g->dh_init) && a16(keep95) && a16(keep_l0) && a16(workspace);
@@ -2039,7 +2052,7 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
       return dec_persist_bwd_launch(w, s, g, keep95, keep_l0, p_drop, n_pre_poses, conditioned, T, B, tw.w_pre_t, tw.w_out_t,
                                     tw.w_ih0_t, tw.w_hh0_t, tw.w_ih1_t, tw.w_hh1_t, (char*)workspace + bwd_pack_bytes_aligned(D, H), st,
                                     !prepared,
-                                    want_w ? (float*)((char*)workspace + bwd_pack_bytes_aligned(D, H) + PX_BYTES) : nullptr);
+                                    want_w ? (float*)((char*)workspace + bwd_pack_bytes_aligned(D, H) + PX_BYTES) : nullptr, ptiles);
   }
   for (int t = T - 1; t >= 0; --t) {
     if (fast)

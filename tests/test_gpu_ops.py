@@ -844,6 +844,73 @@ def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p, T):
         ops.dec_rollout_bwd(wsb, sb, bad, k95, kl0, p, 1, True, T, B, D, H)
 
 
+# More row tiles than CUs: R = 2 or 3 tiles per workgroup (csrc/dec_persist.hip, the *_mt kernels).  `mode` is what
+# g2v_dec_rollout_set_persistent gets: 1 = the library's own choice (8192 rows -> 2 tiles, 12288 -> 3, 4112 = 257 tiles: one
+# workgroup with a single tile), 2 / 3 = at least that many, which reaches the same kernels at small batches (80 rows = 5 tiles
+# over 3 workgroups, 112 = 7 tiles over 3 workgroups, 32 = 2 tiles in ONE workgroup: no exchange partner).
+@pytest.mark.parametrize("B,mode,T,p,n_pre", [(8192, 1, 8, 0.2, 1), (8192, 1, 34, 0.0, 1), (12288, 1, 6, 0.2, 1), (4112, 1, 8, 0.0, 1),
+                                              (80, 2, 34, 0.2, 1), (112, 3, 8, 0.2, 3), (32, 2, 8, 0.0, 1), (48, 3, 5, 0.3, 1)])
+def test_dec_rollout_multi_tile_persistent_matches_per_step_kernels(ops, B, mode, T, p, n_pre):
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    D, H = 135, 64
+    sd = _dec_state(D, H, seed=23)
+    g = torch.Generator().manual_seed(6)
+    target = torch.randn(B, T, D, generator=g).to(DEV)
+    h_init = (torch.randn(2, B, H, generator=g) * 0.5).to(DEV)
+    k95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8).to(DEV)
+    kl0 = (torch.rand(T - 1, B, H, generator=g) < (1 - p)).to(torch.uint8).to(DEV) if p > 0 else None
+    gy = (torch.randn(T, B, D, generator=g) / (T * B * D) * 100).to(DEV)
+    nblk = ops.dec_rollout_blocks(B)
+    G = 3 * H
+    z = lambda *s: torch.zeros(*s, device=DEV)
+
+    def fwd(setting, training=True):
+        prev = lib.g2v_dec_rollout_set_persistent(setting)
+        try:
+            assert lib.g2v_dec_rollout_fuses_loss(B, D, H, T) == 0      # no chaser beside the multi-tile kernel
+            wt, _ = _dec_weight_tensors(sd, DEV)
+            ws = ops.dec_weights_struct(wt)
+            saved = _alloc_saved(T, B, D, H, nblk, DEV, p)
+            ops.dec_rollout_fwd(target, h_init, ws, saved, k95, kl0, p, n_pre, True, training, T, B, D, H)
+            torch.cuda.synchronize()
+            return saved, ws, wt
+        finally:
+            lib.g2v_dec_rollout_set_persistent(prev)
+
+    def bwd(setting, saved, ws):
+        prev = lib.g2v_dec_rollout_set_persistent(setting)
+        try:
+            assert setting == 0 or lib.g2v_dec_rollout_bwd_fuses_wgrad(B, D, H) == 0      # the multi-tile kernel fuses nothing
+            grads = {"dy": gy.clone(), "du": z(T - 1, B, H), "dbn": z(T - 1, B, H), "dgi0": z(T - 1, B, G),
+                     "dgh0": z(T - 1, B, G), "dgi1": z(T - 1, B, G), "dgh1": z(T - 1, B, G), "dh_init": z(2, B, H),
+                     "d_bn_w": z(H), "d_bn_b": z(H), "bn_bwd_partial": z(2, nblk, 2, H)}
+            ops.dec_rollout_bwd(ws, saved, grads, k95, kl0, p, n_pre, True, T, B, D, H)
+            torch.cuda.synchronize()
+            return {k: v for k, v in grads.items() if k not in ("bn_bwd_partial", "dbn")}
+        finally:
+            lib.g2v_dec_rollout_set_persistent(prev)
+
+    (sa, _, wta), (sb, wsb, wtb), (sc, _, wtc) = fwd(mode), fwd(0), fwd(mode)
+    for k in sa:
+        if sa[k] is None or k == "bn_partial":
+            continue
+        assert torch.equal(sa[k], sc[k]), f"multi-tile forward not reproducible: {k}"
+        relclose(sa[k], sb[k], 2e-5, f"multi-tile vs per-step forward: {k}")
+    for k in ("bn_running_mean", "bn_running_var"):
+        assert torch.equal(wta[k], wtc[k])
+        relclose(wta[k], wtb[k], 2e-5, k)
+    ga, gb, gc = bwd(mode, sb, wsb), bwd(0, sb, wsb), bwd(mode, sb, wsb)
+    for k in ga:
+        assert torch.equal(ga[k], gc[k]), f"multi-tile backward not reproducible: {k}"
+        assert torch.isfinite(ga[k]).all()
+        relclose(ga[k], gb[k], 2e-4 if T <= 8 else 0.25, f"multi-tile vs per-step backward: {k}")
+    # eval mode (running statistics, no exchange)
+    (ea, _, wea), (eb, _, _) = fwd(mode, False), fwd(0, False)
+    relclose(ea["y"], eb["y"], 2e-5, "multi-tile vs per-step eval forward")
+    assert lib.g2v_dec_rollout_persist_fault(1) == 0
+
+
 # ----------------------------------------------------------------------------------------------- loss / optimiser / rng
 def test_custom_loss_matches_golden(ops, golden_dir):
     fx = np.load(os.path.join(golden_dir, "custom_loss.npz"))
