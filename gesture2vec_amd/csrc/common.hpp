@@ -578,14 +578,15 @@ static inline void launch_slab_reduce(const float* slab, int nsplit, int64_t n, 
 // order.  The partials were written by OTHER CUs in the previous launch, so every load is an L2 miss (~1500 cycles):
 // the point is to have (almost) all of a thread's loads in flight at once.  ncol % 4 == 0: float4 columns, up to
 // 8 row segments, 16 loads in flight per thread; else a scalar fallback.
-// scratch: LDS, >= 1024 floats.  Ends with a __syncthreads(); out is valid for every thread afterwards.
+// scratch: LDS, `scratch_floats` (>= 1024) floats: more of it = more row segments.  Ends with a __syncthreads(); out is valid for every thread afterwards.
+template <int NTHR = 256>
 __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, int nblk, int ncol, float* out,
-                                                float* scratch, int tid) {
+                                                float* scratch, int tid, int scratch_floats = 1024) {
   if ((ncol & 3) == 0 && ncol <= 1024) {
     const int nc4 = ncol >> 2;                       // float4 columns
-    for (int c0 = 0; c0 < nc4; c0 += 256) {
-      const int nc = min(256, nc4 - c0);
-      const int nseg = max(1, 256 / nc);
+    for (int c0 = 0; c0 < nc4; c0 += NTHR) {
+      const int nc = min(NTHR, nc4 - c0);
+      const int nseg = max(1, min(NTHR, scratch_floats >> 2) / nc);
       const int seg = tid / nc, col = tid - seg * nc;
       const int per = (nblk + nseg - 1) / nseg;
       float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -617,7 +618,7 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
       lds_barrier();
       if (seg < nseg) reinterpret_cast<float4*>(scratch)[seg * nc + col] = tot;
       lds_barrier();
-      for (int e = tid; e < 4 * nc; e += 256) {
+      for (int e = tid; e < 4 * nc; e += NTHR) {
         float t = 0.f;
         for (int g = 0; g < nseg; ++g) t += scratch[g * 4 * nc + e];
         out[4 * c0 + e] = t;
@@ -626,9 +627,9 @@ __device__ __forceinline__ void reduce_partials(const float* __restrict__ part, 
     lds_barrier();
     return;
   }
-  for (int c0 = 0; c0 < ncol; c0 += 256) {
-    const int nc = min(256, ncol - c0);
-    const int nseg = max(1, 256 / nc);
+  for (int c0 = 0; c0 < ncol; c0 += NTHR) {
+    const int nc = min(NTHR, ncol - c0);
+    const int nseg = max(1, min(NTHR, scratch_floats) / nc);
     const int seg = tid / nc, col = tid - seg * nc;
     const int per = (nblk + nseg - 1) / nseg;
     float tot = 0.f;

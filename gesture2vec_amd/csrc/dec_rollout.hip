@@ -91,6 +91,7 @@ struct DecDims {
   float p_drop;
   int n_pre, conditioned, training, nblk;
   int wt;   // write-through (sc1) stores for the arrays only later kernels read (see st4 in common.hpp)
+  int scratch;      // floats of reduce_partials scratch at the end of the kernel's LDS (1024, or 2048 where it fits)
 };
 static int dec_wt_stores() { return 1; }
 
@@ -152,11 +153,11 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, con
                                              float* __restrict__ gates,   // global (B,4H) row block base or null
                                              const uint8_t* __restrict__ keep, float keep_scale,  // inter-layer dropout
                                              float* __restrict__ xdrop_out,  // global (B,H) dropped output or null
-                                             int nrows, int lane, int wave) {
+                                             int nrows, int lane, int wave, int nwaves = 4) {
   const int i = lane & 15, q = lane >> 4;
   const int ntile = Hp >> 4, KS = Hp >> 4;
   const bool hvec = (H & 3) == 0;
-  for (int ft = wave; ft < ntile; ft += 4) {
+  for (int ft = wave; ft < ntile; ft += nwaves) {
     const int f0 = 16 * ft + 4 * q;
     const bool vec = hvec && (f0 + 3 < H);
     // biases / keep flags first: independent of the MFMAs below, their latency hides behind them
@@ -213,13 +214,18 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, con
 }
 
 template <int HS, int DS>
-__global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restrict__ target,
+__global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_fwd_kernel(const float* __restrict__ target,
                                                            const float* __restrict__ h_init, g2v_dec_weights w,
                                                            DecPackF pk, g2v_dec_saved sv,
                                                            const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   // HS / DS > 0: the model dims are compile-time constants (every stride, tile count and k-loop folds)
+  // Generic dims run with EIGHT waves (two per SIMD): at H = 200 a wave streams ~0.5 MB of weight fragments per step out of
+  // L2 through an 8-deep register ring, which bounds it at ring bytes / L2 latency; a second wave per SIMD doubles the bytes in
+  // flight and takes the matrix pipe while the first one waits (the feature tiles are dealt over 8 waves instead of 4).
+  constexpr int NTHR = HS > 0 ? 256 : 512, NW = NTHR / 64;
+  constexpr int NPF = HS > 0 ? 1 : 2;      // float4 per thread of the 16 x H prefetch below
   const int T = dm.T, B = dm.B, D = DS > 0 ? DS : dm.D, H = HS > 0 ? HS : dm.H;
   constexpr int KSD_T = (DS + 15) / 16;
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, ldh = Hp + 4, ldd = Dp + 4;
@@ -246,7 +252,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   // Prefetch this block's rows of u_t, h0_{t-1}, h1_{t-1} (written by the previous launch on some other CU: each is
   // an L2 miss).  Issued first so that their latency overlaps the BatchNorm partial reduction below.
   float4 pu = make_float4(0.f, 0.f, 0.f, 0.f), ph0 = pu, ph1 = pu;
-  const bool pre_ok = hvec && (16 * H4 <= 256) && t > 0;     // one float4 per thread covers the 16 x H tile
+  const bool pre_ok = hvec && (16 * H4 <= NPF * NTHR) && t > 0;     // NPF float4 per thread cover the 16 x H tile
   const int pr = pre_ok ? tid / H4 : 0, pc = pre_ok ? (tid - pr * H4) * 4 : 0;
   const bool pvalid = pre_ok && tid < 16 * H4 && pr < nrows;
   if (pvalid) {
@@ -254,6 +260,17 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     pu = *reinterpret_cast<const float4*>(sv.u + row);
     ph0 = *reinterpret_cast<const float4*>(sv.h0 + row);
     ph1 = *reinterpret_cast<const float4*>(sv.h1 + row);
+  }
+  // second float4 of the generic prefetch (elements NTHR .. 2 NTHR - 1 of the tile)
+  float4 pu2 = make_float4(0.f, 0.f, 0.f, 0.f), ph02 = pu2, ph12 = pu2;
+  const int e2 = tid + NTHR;
+  const int pr2 = (NPF > 1 && pre_ok) ? e2 / H4 : 0, pc2 = (NPF > 1 && pre_ok) ? (e2 - pr2 * H4) * 4 : 0;
+  const bool pvalid2 = NPF > 1 && pre_ok && e2 < 16 * H4 && pr2 < nrows;
+  if (pvalid2) {
+    const int64_t row = ((int64_t)(t - 1) * B + b0 + pr2) * H + pc2;
+    pu2 = *reinterpret_cast<const float4*>(sv.u + row);
+    ph02 = *reinterpret_cast<const float4*>(sv.h0 + row);
+    ph12 = *reinterpret_cast<const float4*>(sv.h1 + row);
   }
   // Fast shape (compile-time dims, H = 64 so wave w owns feature tile w, full 16-row tile): the hidden-side GRU
   // products gh0 = W_hh0 h0_{t-1} and gh1 = W_hh1 h1_{t-1} do not depend on this step's BatchNorm, so their weight
@@ -322,13 +339,13 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   {
     const bool full = (nrows == 16);
     if (!full || Hp != H) {
-      for (int e = tid; e < 5 * 16 * ldh; e += 256) smem[e] = 0.f;
+      for (int e = tid; e < 5 * 16 * ldh; e += NTHR) smem[e] = 0.f;
     }
     if (!full) {
-      for (int e = tid; e < 16 * ldd; e += 256) Xy[e] = 0.f;
+      for (int e = tid; e < 16 * ldd; e += NTHR) Xy[e] = 0.f;
     } else {
       const int padc = ldd - D;
-      for (int e = tid; e < 16 * padc; e += 256) Xy[(e / padc) * ldd + D + (e % padc)] = 0.f;
+      for (int e = tid; e < 16 * padc; e += NTHR) Xy[(e / padc) * ldd + D + (e % padc)] = 0.f;
     }
   }
   lds_barrier();
@@ -336,7 +353,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
 
   if (t == 0) {
     // seed the state arrays: h0[0], h1[0] = h_init (the quantised latent)
-    for (int e = tid; e < 16 * H; e += 256) {
+    for (int e = tid; e < 16 * H; e += NTHR) {
       const int r = e / H, f = e - r * H;
       if (r < nrows) {
         sv.h0[(int64_t)(b0 + r) * H + f] = h_init[(int64_t)(b0 + r) * H + f];
@@ -349,9 +366,9 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     if (dm.training) {
       const float* part = sv.bn_partial + (int64_t)((t - 1) & 1) * dm.nblk * 2 * H;
       if (early) reduce_partials_128_hook(part, dm.nblk, red, red_scratch, tid, early_products);
-      else reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
+      else reduce_partials<NTHR>(part, dm.nblk, 2 * H, red, red_scratch, tid, dm.scratch);
       STAMP(2);
-      for (int f = tid; f < H; f += 256) {
+      for (int f = tid; f < H; f += NTHR) {
         const float s1 = red[f], s2 = red[H + f];
         const float mv = s1 / (float)B;
         const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);   // biased batch variance
@@ -365,7 +382,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
       }
     } else {
       if (early) early_products([](int) {});
-      for (int f = tid; f < H; f += 256) {
+      for (int f = tid; f < H; f += NTHR) {
         st[f] = w.bn_running_mean[f];
         st[Hp + f] = bn_invstd_(w.bn_running_var[f]);
       }
@@ -388,8 +405,21 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
         }
         if (sv.a) st4(sv.a + ((int64_t)(t - 1) * B + b0 + pr) * H + pc, a4, dm.wt != 0);
       }
+      if (pvalid2) {
+        const float4 g4 = *reinterpret_cast<const float4*>(w.bn_w + pc2), b4 = *reinterpret_cast<const float4*>(w.bn_b + pc2);
+        const float4 m4 = *reinterpret_cast<const float4*>(st + pc2), i4 = *reinterpret_cast<const float4*>(st + Hp + pc2);
+        float4 a4;
+        a4.x = fmaxf((pu2.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+        a4.y = fmaxf((pu2.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+        a4.z = fmaxf((pu2.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+        a4.w = fmaxf((pu2.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+        *reinterpret_cast<float4*>(Xa + pr2 * ldh + pc2) = a4;
+        *reinterpret_cast<float4*>(Xh0 + pr2 * ldh + pc2) = ph02;
+        *reinterpret_cast<float4*>(Xh1 + pr2 * ldh + pc2) = ph12;
+        if (sv.a) st4(sv.a + ((int64_t)(t - 1) * B + b0 + pr2) * H + pc2, a4, dm.wt != 0);
+      }
     } else {
-      for (int e = tid; e < 16 * H; e += 256) {
+      for (int e = tid; e < 16 * H; e += NTHR) {
         const int r = e / H, f = e - r * H;
         if (r >= nrows) continue;
         const int64_t row = (int64_t)(b0 + r) * H + f;
@@ -436,14 +466,14 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
                  sv.h0 + ((int64_t)t * B + b0) * H,
                  sv.gates0 ? sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
                  drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr, 1.0f / (1.0f - dm.p_drop),
-                 (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, lane, wave);
+                 (drop && sv.x1) ? sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, nrows, lane, wave, NW);
     lds_barrier();
     STAMP(4);
     // ---- (d) GRU layer 1 ---------------------------------------------------------------------------
     gru_cell_fwd<KSH_T>(pk.ih1, pk.hh1, w.b_ih1, w.b_hh1, Xx1, Xh1, ldh, H, Hp, Xh1n,
                  sv.h1 + ((int64_t)t * B + b0) * H,
                  sv.gates1 ? sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, 1.0f, nullptr, nrows,
-                 lane, wave);
+                 lane, wave, NW);
     lds_barrier();
     STAMP(5);
     }
@@ -459,6 +489,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     const bool three = ntile > 4;
     const int per = three ? 3 : 1, group = 4 * per;
     for (int base = 0; base < ntile; base += group) {
+      if (wave >= 4) continue;      // (generic dims: 8 waves; the few D tiles stay dealt over the first four)
       float bo[3][4];
 #pragma unroll
       for (int j = 0; j < 3; ++j)
@@ -491,7 +522,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     const int64_t tile = ((int64_t)t * B + b0) * D;     // element offset of this block's 16 x D tile
     const int n4 = (16 * D) >> 2;
     int jj = 0;
-    for (int e4 = tid; e4 < n4; e4 += 256, ++jj) {
+    for (int e4 = tid; e4 < n4; e4 += NTHR, ++jj) {
       const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
       st4(sv.y + tile + 4 * (int64_t)e4, y4, dm.wt != 0);
       if (has_next) {
@@ -528,6 +559,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
     const bool teacher = (t < dm.n_pre);
     const int b = b0 + i;
     for (int base = 0; base < ntile; base += group) {
+      if (wave >= 4) continue;
       float bo[3][4], tg[3][4];
       uint8_t kp[3][4];
 #pragma unroll
@@ -582,7 +614,7 @@ __global__ __launch_bounds__(256) void dec_step_fwd_kernel(const float* __restri
   {
     const int ntile = Hp >> 4;
     float* part = sv.bn_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
-    for (int ft = wave; ft < ntile; ft += 4) {
+    for (int ft = wave; ft < ntile; ft += NW) {
       const int f0 = 16 * ft + 4 * q;
       const bool vec = hvec && (f0 + 3 < H);
       float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -750,10 +782,11 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
 }
 
 template <int HS, int DS>
-__global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, DecTW tw, g2v_dec_saved sv,
+__global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_dec_weights w, DecTW tw, g2v_dec_saved sv,
                                                            g2v_dec_grads gr, const uint8_t* __restrict__ keep95,
                                                            const uint8_t* __restrict__ keep_l0, DecDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTHR = HS > 0 ? 256 : 512, NW = NTHR / 64, NPF = HS > 0 ? 1 : 2;      // generic dims: eight waves (see the forward)
   const int T = dm.T, B = dm.B, D = DS > 0 ? DS : dm.D, H = HS > 0 ? HS : dm.H, G = 3 * H;
   constexpr int KSD_T = (DS + 15) / 16;
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, Gp = (G + 15) & ~15;
@@ -780,7 +813,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   SPAN(0);
   // prefetch this block's rows of u_{t+1} and dbn_{t+1} (Part A inputs; L2 misses) before anything else
   float4 pu = make_float4(0.f, 0.f, 0.f, 0.f), pdb = pu;
-  const bool pre_ok = hvec && (16 * H4 <= 256) && !last;
+  const bool pre_ok = hvec && (16 * H4 <= NPF * NTHR) && !last;
   const int pr = pre_ok ? tid / H4 : 0, pc = pre_ok ? (tid - pr * H4) * 4 : 0;
   const bool pvalid = pre_ok && tid < 16 * H4 && pr < nrows;
   if (pvalid) {
@@ -788,17 +821,26 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     pu = *reinterpret_cast<const float4*>(sv.u + row);
     pdb = *reinterpret_cast<const float4*>(gr.dbn + row);
   }
+  float4 pu2 = make_float4(0.f, 0.f, 0.f, 0.f), pdb2 = pu2;      // second float4 of the generic prefetch
+  const int e2 = tid + NTHR;
+  const int pr2 = (NPF > 1 && pre_ok) ? e2 / H4 : 0, pc2 = (NPF > 1 && pre_ok) ? (e2 - pr2 * H4) * 4 : 0;
+  const bool pvalid2 = NPF > 1 && pre_ok && e2 < 16 * H4 && pr2 < nrows;
+  if (pvalid2) {
+    const int64_t row = ((int64_t)t * B + b0 + pr2) * H + pc2;
+    pu2 = *reinterpret_cast<const float4*>(sv.u + row);
+    pdb2 = *reinterpret_cast<const float4*>(gr.dbn + row);
+  }
   STAMPB(0);
   // zero padding columns / rows of the MFMA operand tiles
   {
     const bool full = (nrows == 16);
     if (!full || Hp != H || Gp != G) {
-      for (int e = tid; e < 16 * (3 * ldh + ldd + 2 * ldg); e += 256) smem[e] = 0.f;
+      for (int e = tid; e < 16 * (3 * ldh + ldd + 2 * ldg); e += NTHR) smem[e] = 0.f;
     } else {
       const int padc = ldd - D;
-      for (int e = tid; e < 16 * padc; e += 256) Xdy[(e / padc) * ldd + D + (e % padc)] = 0.f;
+      for (int e = tid; e < 16 * padc; e += NTHR) Xdy[(e / padc) * ldd + D + (e % padc)] = 0.f;
       if (last)
-        for (int e = tid; e < 16 * ldh; e += 256) Xdu[e] = 0.f;
+        for (int e = tid; e < 16 * ldh; e += NTHR) Xdu[e] = 0.f;
     }
   }
   lds_barrier();
@@ -806,9 +848,9 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   // ================= Part A: finish BatchNorm backward of step t+1 ===================================
   if (!last) {
     const float* part = gr.bn_bwd_partial + (int64_t)((t + 1) & 1) * dm.nblk * 2 * H;
-    reduce_partials(part, dm.nblk, 2 * H, red, red_scratch, tid);
+    reduce_partials<NTHR>(part, dm.nblk, 2 * H, red, red_scratch, tid, dm.scratch);
     STAMPB(1);
-    for (int f = tid; f < H; f += 256) {
+    for (int f = tid; f < H; f += NTHR) {
       const float s1 = red[f], s2 = red[H + f];
       st[f] = s1;
       st[Hp + f] = s2;
@@ -822,7 +864,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     const float invB = 1.0f / (float)B;
     const float* stats = sv.bn_stats + (int64_t)t * 2 * H;   // step t+1 is stored at index t
     if (pre_ok) {
-      if (pvalid) {
+      auto du_of = [&](const float4& pu, const float4& pdb, int pr, int pc) {
         const float4 mean4 = *reinterpret_cast<const float4*>(stats + pc), var4 = *reinterpret_cast<const float4*>(stats + H + pc);
         const float4 g4 = *reinterpret_cast<const float4*>(w.bn_w + pc);
         const float4 s14 = *reinterpret_cast<const float4*>(st + pc), s24 = *reinterpret_cast<const float4*>(st + Hp + pc);
@@ -839,9 +881,11 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
         const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
         st4(gr.du + ((int64_t)t * B + b0 + pr) * H + pc, du4, dm.wt != 0);
         *reinterpret_cast<float4*>(Xdu + pr * ldh + pc) = du4;
-      }
+      };
+      if (pvalid) du_of(pu, pdb, pr, pc);
+      if (pvalid2) du_of(pu2, pdb2, pr2, pc2);
     } else {
-      for (int e = tid; e < 16 * H; e += 256) {
+      for (int e = tid; e < 16 * H; e += NTHR) {
         const int r = e / H, f = e - r * H;
         if (r >= nrows) continue;
         const int64_t row = ((int64_t)t * B + b0 + r) * H + f;
@@ -866,7 +910,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     uint32_t* Kt = reinterpret_cast<uint32_t*>(Gh);        // keep95 bytes of the tile, 4 per word
     const int64_t tile = ((int64_t)t * B + b0) * D;
     const int n4 = (16 * D) >> 2;
-    for (int e4 = tid; e4 < n4; e4 += 256) {
+    for (int e4 = tid; e4 < n4; e4 += NTHR) {
       reinterpret_cast<float4*>(Dt)[e4] = reinterpret_cast<const float4*>(gr.dy + tile)[e4];
       if (feedback) Kt[e4] = reinterpret_cast<const uint32_t*>(keep95 + tile)[e4];
     }
@@ -875,6 +919,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     const int per = three ? 3 : 1, group = 4 * per;
     const uint8_t* Kb = reinterpret_cast<const uint8_t*>(Kt);
     for (int base = 0; base < ntd; base += group) {
+      if (wave >= 4) continue;      // (generic dims: 8 waves; the few D tiles stay dealt over the first four)
       f32x4 acc[3];
 #pragma unroll
       for (int j = 0; j < 3; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -901,7 +946,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     }
     lds_barrier();
     if (feedback)
-      for (int e4 = tid; e4 < n4; e4 += 256) st4(gr.dy + tile + 4 * (int64_t)e4, reinterpret_cast<const float4*>(Dt)[e4], dm.wt != 0);
+      for (int e4 = tid; e4 < n4; e4 += NTHR) st4(gr.dy + tile + 4 * (int64_t)e4, reinterpret_cast<const float4*>(Dt)[e4], dm.wt != 0);
     lds_barrier();
   } else
   {
@@ -910,6 +955,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
     const bool three = ntd > 4;
     const int per = three ? 3 : 1, group = 4 * per;
     for (int base = 0; base < ntd; base += group) {
+      if (wave >= 4) continue;
       float dyv[3][4];
       uint8_t kp[3][4];
 #pragma unroll
@@ -961,7 +1007,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   float* carry1_w = gr.dh_init + ((int64_t)B + b0) * H;
   // ---- dh1 = carry + dy W_out ; GRU cell 1 backward -------------------------------------------------
   {
-    for (int ft = wave; ft < nth; ft += 4) {
+    for (int ft = wave; ft < nth; ft += NW) {
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       wave_gemm_p<1, KSD_T>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
       gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
@@ -973,7 +1019,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   STAMPB(4);
   // ---- carry1' = dh1*z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 (inter-layer dropout bwd) ----------------
   {
-    for (int ft = wave; ft < nth; ft += 4) {
+    for (int ft = wave; ft < nth; ft += NW) {
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
       wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh1_t, Gp >> 4, ft, 0, Gh, ldg, lane);
       wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih1_t, Gp >> 4, ft, 0, Gi, ldg, lane);
@@ -1000,7 +1046,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   // ---- GRU cell 0 backward (Gi/Gh/Dd are reused) ------------------------------------------------------
   {
     const bool drop = keep_l0 && dm.p_drop > 0.f;
-    for (int ft = wave; ft < nth; ft += 4) {
+    for (int ft = wave; ft < nth; ft += NW) {
       const int f0 = 16 * ft + 4 * q;
       f32x4 acc;
 #pragma unroll
@@ -1018,7 +1064,7 @@ __global__ __launch_bounds__(256) void dec_step_bwd_kernel(g2v_dec_weights w, De
   {
     const float* stats = sv.bn_stats + (int64_t)(t - 1) * 2 * H;
     float* part = gr.bn_bwd_partial + ((int64_t)(t & 1) * dm.nblk + blockIdx.x) * 2 * H;
-    for (int ft = wave; ft < nth; ft += 4) {
+    for (int ft = wave; ft < nth; ft += NW) {
       const int f0 = 16 * ft + 4 * q;
       const bool vec = hvec && (f0 + 3 < H);
       // inputs of the epilogue that do not depend on the MFMAs
@@ -1114,13 +1160,19 @@ extern "C" int g2v_dec_rollout_set_persistent(int enable) {
   return prev;
 }
 
-static size_t dec_fwd_lds(int D, int H) {
+// reduce_partials scratch: 2048 floats (every row segment of the 512-thread generic kernels) where the LDS has room, else 1024
+static int dec_scratch(size_t base_floats) { return (base_floats + 2048) * sizeof(float) <= 160 * 1024 ? 2048 : 1024; }
+static size_t dec_fwd_lds(int D, int H, int* scratch = nullptr) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15;
-  return (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp + 1024) * sizeof(float);
+  const size_t base = (size_t)(5 * 16 * (Hp + 4) + 16 * (Dp + 4) + 4 * Hp);
+  if (scratch) *scratch = dec_scratch(base);
+  return (base + dec_scratch(base)) * sizeof(float);
 }
-static size_t dec_bwd_lds(int D, int H) {
+static size_t dec_bwd_lds(int D, int H, int* scratch = nullptr) {
   const int Hp = (H + 15) & ~15, Dp = (D + 15) & ~15, Gp = (3 * H + 15) & ~15;
-  return (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp + 1024) * sizeof(float);
+  const size_t base = (size_t)(16 * (3 * (Hp + 4) + (Dp + 4) + 2 * (Gp + 4)) + 4 * Hp);
+  if (scratch) *scratch = dec_scratch(base);
+  return (base + dec_scratch(base)) * sizeof(float);
 }
 
 static int dtiles_pad(int D) {   // D-row matrices: tiles padded to a multiple of 12 (3 per wave) or 4 (1 per wave)
@@ -1771,7 +1823,9 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     launch_pack(pb, st);
     G2V_CHECK_LAUNCH();
   }
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), dec_wt_stores()};
+  int scratch = 1024;
+  (void)dec_fwd_lds(D, H, &scratch);
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), dec_wt_stores(), scratch};
   const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
@@ -1809,7 +1863,7 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
       hipLaunchKernelGGL((dec_step_fwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
     } else if (!split || t == 0) {
-      hipLaunchKernelGGL((dec_step_fwd_kernel<0, 0>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
+      hipLaunchKernelGGL((dec_step_fwd_kernel<0, 0>), dim3(dm.nblk), dim3(512), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);
     } else {
       const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
@@ -2023,7 +2077,9 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipFuncSetAttribute((const void*)dec_step_bwd_kernel<64, 135>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   }
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16), dec_wt_stores()};
+  int scratch = 1024;
+  (void)dec_bwd_lds(D, H, &scratch);
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16), dec_wt_stores(), scratch};
   const bool fast = (H == 64) && (D == 135);
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
@@ -2058,7 +2114,7 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
     if (fast)
       hipLaunchKernelGGL((dec_step_bwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
     else
-      hipLaunchKernelGGL((dec_step_bwd_kernel<0, 0>), dim3(dm.nblk), dim3(256), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
+      hipLaunchKernelGGL((dec_step_bwd_kernel<0, 0>), dim3(dm.nblk), dim3(512), lds, st, *w, tw, *s, *g, keep95, keep_l0, dm, t);
   }
   G2V_CHECK_LAUNCH();
   return G2V_OK;

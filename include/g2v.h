@@ -60,7 +60,7 @@ int g2v_linear_set_smallm_rows(int rows);
  * variable.  Both select between implementations that produce the same results (measurements, parity tests, and the fall-back
  * after a latched residency fault of the persistent rollout):
  *   g2v_linear_set_smallm_rows(rows)        row count up to which the wave-per-tile dense kernels are used (default 1024)
- *   g2v_dec_rollout_set_persistent(0 / 1)   persistent rollout kernels vs one launch per step (default 1)
+ *   g2v_dec_rollout_set_persistent(0..3)    persistent rollout kernels vs one launch per step (default 1; see below)
  * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
@@ -358,10 +358,13 @@ typedef struct {           /* saved-for-backward / state arrays, all caller-owne
 
 int g2v_dec_rollout_blocks(int B);
 /* Two interchangeable implementations sit behind g2v_dec_rollout_fwd / _bwd (same arguments, same saved arrays):
- * one launch per time step (any shape), and -- for H == 64, D == 135, B % 16 == 0, B / 16 <= the device's CU count --
+ * one launch per time step (any shape), and -- for H == 64, D == 135, B % 16 == 0, B / 16 <= 3 x the device's CU count --
  * ONE persistent launch for the whole rollout with register/LDS-resident weights and an in-kernel two-level exchange of
- * the BatchNorm partial sums (csrc/dec_persist.hpp).  The persistent one is used whenever it applies; this switch
- * (default 1) exists for A/B measurements, parity tests and the fall-back after a latched fault.  Returns the previous setting. */
+ * the BatchNorm partial sums (csrc/dec_persist.hpp): one 16-row tile per workgroup while there is a CU per tile, 2 or 3 tiles
+ * per workgroup beyond that (no fused weight gradient / loss chaser there: the two queries below return 0).  The persistent
+ * one is used whenever it applies; this switch (default 1; 0 = one launch per step; 2 / 3 = persistent with AT LEAST that many
+ * tiles per workgroup, which is how the parity tests reach the multi-tile kernels at small batches) exists for A/B
+ * measurements, parity tests and the fall-back after a latched fault.  Returns the previous setting. */
 int g2v_dec_rollout_set_persistent(int enable);
 /* The persistent kernels need every workgroup of their launch resident at once; what a plain launch can check is checked
  * (B / 16 <= CU count, the occupancy query).  What it cannot see -- a CU mask, another tenant or a second persistent launch
@@ -372,7 +375,7 @@ int g2v_dec_rollout_set_persistent(int enable);
  * region); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step kernels. */
 int g2v_dec_rollout_persist_fault(int clear);
 /* 1 where the rollout pair + chaser can carry custom_loss (the loss_* fields of g2v_dec_saved): wherever the persistent path
- * applies (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent enabled), 2 <= T <= 256.  Elsewhere leave the loss_*
+ * applies with ONE row tile per workgroup (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent setting 1), 2 <= T <= 256.  Elsewhere leave the loss_*
  * fields NULL and call g2v_custom_loss_fwd_bwd between the two rollouts (setting them anyway is refused with
  * G2V_ERR_UNSUPPORTED, never silently ignored). */
 int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T);
