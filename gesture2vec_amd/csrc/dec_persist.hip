@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
   static_for<R>([&](auto rc) {
     constexpr int r = decltype(rc)::value;
     const int tb = b + r * nwg;
-    if (tb < ntiles) {
+    if (tb < ntiles && (tid >> 4) < min(16, B - 16 * tb)) {      // (rows past B: the LDS rows stay zero)
       const int rr = tid >> 4, c = (tid & 15) * 4, b0 = 16 * tb;
       const float4 v0 = *reinterpret_cast<const float4*>(a.h_init + (int64_t)(b0 + rr) * H + c);
       const float4 v1 = *reinterpret_cast<const float4*>(a.h_init + BH + (int64_t)(b0 + rr) * H + c);
@@ -668,6 +668,13 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
       const int tb = b + r * nwg;
       if (tb >= ntiles) return;                       // (uniform per workgroup)
       const int b0 = 16 * tb;
+      // ragged last tile (B % 16 != 0, B % 4 == 0): rows >= nrows are computed like the others from whatever their LDS rows hold
+      // (finite values; an MFMA row never mixes with another row), read clamped addresses, store nothing and are left out of
+      // the BatchNorm sums
+      const int nrows = min(16, B - b0);
+      const bool rowok = i < nrows;
+      const int ic = rowok ? i : nrows - 1;
+      const int n4v = (nrows * D) / 4;                // float4s of the tile's dense (nrows x D) run
       float* Xh0 = Xh0_of(r);
       float* Xh1 = Xh1_of(r);
       if (t > 0) {
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
 #pragma unroll
           for (int j = 0; j < 3; ++j) {
             const int e4 = tid + 256 * j;
-            kreq[j] = kp4[e4 < (16 * D) / 4 ? e4 : 0];
+            kreq[j] = kp4[e4 < n4v ? e4 : 0];
           }
         }
         // the exchange of this step's BatchNorm sums is threaded through the FIRST tile's hidden-side products
@@ -725,20 +732,20 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
           a4.z = fmaxf(((u_acc[r][2] + p4.z) - m4.z) * i4.z * g4.z + b4.z, 0.f);
           a4.w = fmaxf(((u_acc[r][3] + p4.w) - m4.w) * i4.w * g4.w + b4.w, 0.f);
           *reinterpret_cast<float4*>(Xa + i * LDH + f0) = a4;
-          if (a.sv.a) *reinterpret_cast<float4*>(a.sv.a + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = a4;
+          if (a.sv.a && rowok) *reinterpret_cast<float4*>(a.sv.a + ((int64_t)(t - 1) * B + b0 + i) * H + f0) = a4;
         }
         lds_barrier();
         {
           uint32_t kp = 0x01010101u;
-          if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + i) * H + f0);
+          if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + ic) * H + f0);
           f32x4 ai[3];
 #pragma unroll
           for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
           frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
           cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
-                        a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
-                        a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
-                        (drop && a.sv.x1) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+                        (a.sv.h0 && rowok) ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                        (a.sv.gates0 && rowok) ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                        (drop && a.sv.x1 && rowok) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
         }
         lds_barrier();
         {
@@ -747,8 +754,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
           for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
           frag_mma_x1st(ai, f_ih1, Xx1, LDH, lane);
           cell_epilogue(ai, gh1, Bs + B_IH1, Bs + B_HH1, 0x01010101u, false, 1.0f, Xh1, nullptr,
-                        a.sv.h1 ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
-                        a.sv.gates1 ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
+                        (a.sv.h1 && rowok) ? a.sv.h1 + ((int64_t)t * B + b0) * H : nullptr,
+                        (a.sv.gates1 && rowok) ? a.sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
         }
         lds_barrier();
         {      // y_t = out_layer(h1_t) -> dense tile (see the one-tile kernel for the shape of this epilogue)
@@ -800,14 +807,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
       const bool fast_dense = t > 0 && (!has_next || !(t < a.n_pre));
       const int64_t tile = ((int64_t)t * B + b0) * D;
       if (fast_dense) {
-        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+        for (int e4 = tid; e4 < n4v; e4 += 256) {
           *reinterpret_cast<float4*>(a.sv.y + tile + 4 * e4) = reinterpret_cast<const float4*>(Yt)[e4];
           if (has_next && a.sv.xin) *reinterpret_cast<float4*>(a.sv.xin + tile + 4 * e4) = reinterpret_cast<const float4*>(Xt)[e4];
         }
       } else {
         const bool teacher = has_next && (t < a.n_pre);
         const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
-        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
+        for (int e4 = tid; e4 < n4v; e4 += 256) {
           const int e = 4 * e4;
           float yv[4], sv_[4];
           if (t == 0) {
@@ -847,14 +854,15 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
       // ---- u_{t+1} = pre_linear.0(xin_{t+1}) of this tile; its partial sums join the workgroup's ---------------------------
       u_acc[r] = lds_frag_mma_2chain<KSD>(Ppre, wave, Xy, LDD, lane);
       const float4 p4 = *reinterpret_cast<const float4*>(Bs + B_PRE + f0);
-      if (a.sv.u)
+      if (a.sv.u && rowok)
         *reinterpret_cast<float4*>(a.sv.u + ((int64_t)t * B + b0 + i) * H + f0) =
             make_float4(u_acc[r][0] + p4.x, u_acc[r][1] + p4.y, u_acc[r][2] + p4.z, u_acc[r][3] + p4.w);
       if (training) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          s1a[e] += reduce16(u_acc[r][e]);
-          s2a[e] += reduce16(u_acc[r][e] * u_acc[r][e]);
+          const float uv = rowok ? u_acc[r][e] : 0.f;
+          s1a[e] += reduce16(uv);
+          s2a[e] += reduce16(uv * uv);
         }
       }
       // (the dense y / xin copies above read Yt / Xt and the product read Xy: the next tile rewrites them three barriers on;
@@ -1108,27 +1116,29 @@ int dec_persist_fwd_launch(const float* target, const float* h_init, const g2v_d
   a.p_pre = p_pre; a.p_ih0 = p_ih0; a.p_hh0 = p_hh0; a.p_ih1 = p_ih1; a.p_hh1 = p_hh1; a.p_out = p_out;
   a.sv = *s; a.keep95 = keep95; a.keep_l0 = keep_l0;
   a.x = persist_x_at(xbase);
-  a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
+  a.T = T; a.B = B; a.nblk = (B + 15) / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.training = training;
   a.p_drop = p_drop;
-  if (tiles_per_wg > 1) {
+  if (tiles_per_wg > 1 || (B & 15)) {      // (a ragged last tile is the multi-tile kernel's job too, also with one tile each)
     // more row tiles than CUs: R tiles per workgroup (dec_persist_fwd_mt_kernel); no chaser there
     const int R = tiles_per_wg, nwg = (a.nblk + R - 1) / R;
     const size_t lds = dec_persist_fwd_lds_bytes(R);
-    const void* fn = R == 2 ? (const void*)dec_persist_fwd_mt_kernel<2> : (const void*)dec_persist_fwd_mt_kernel<3>;
-    static bool mt_set[2] = {false, false};
-    if (R > 3 || s->loss_code) {
+    const void* fn = R == 1 ? (const void*)dec_persist_fwd_mt_kernel<1>
+                            : (R == 2 ? (const void*)dec_persist_fwd_mt_kernel<2> : (const void*)dec_persist_fwd_mt_kernel<3>);
+    static bool mt_set[3] = {false, false, false};
+    if (R < 1 || R > 3 || s->loss_code) {
       set_error("dec_persist_fwd: %d tiles per workgroup / a chased rollout is not offered", R);
       return G2V_ERR_ARG;
     }
-    if (!mt_set[R - 2]) {
+    if (!mt_set[R - 1]) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || !persist_fits(fn, lds)) {
         set_error("dec_persist_fwd: the %d-tile kernel does not fit a CU (%zu bytes of LDS)", R, lds);
         return G2V_ERR_LAUNCH;
       }
-      mt_set[R - 2] = true;
+      mt_set[R - 1] = true;
     }
     if (training && clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
-    if (R == 2) hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    if (R == 1) hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<1>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    else if (R == 2) hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
     else hipLaunchKernelGGL(dec_persist_fwd_mt_kernel<3>, dim3(nwg), dim3(256), lds, st, a, nwg);
     if (hipGetLastError() != hipSuccess) {
       set_error("dec_persist_fwd: launch failed");
@@ -1288,7 +1298,7 @@ __device__ __forceinline__ void load_cell(CellSaved& c, const float* __restrict_
 // gradients to the global dgi / dgh rows and to the LDS tile; returns direct = dh * z (the path to h_{t-1}).
 template <bool STORE_GH>
 __device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved& c, float* __restrict__ dgi,
-                                           float* __restrict__ dgh, float* G, int i, int f0) {
+                                           float* __restrict__ dgh, float* G, int i, int f0, bool store = true) {
   const float rr[4] = {c.r.x, c.r.y, c.r.z, c.r.w}, zz[4] = {c.z.x, c.z.y, c.z.z, c.z.w}, nn[4] = {c.n.x, c.n.y, c.n.z, c.n.w},
               gh[4] = {c.hn.x, c.hn.y, c.hn.z, c.hn.w}, hp[4] = {c.hp.x, c.hp.y, c.hp.z, c.hp.w};
   float g_r[4], g_z[4], g_n[4], g_hn[4], direct[4];
@@ -1305,8 +1315,10 @@ __device__ __forceinline__ float4 cell_bwd(const float (&dh)[4], const CellSaved
   }
   const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
-  *reinterpret_cast<float4*>(dgi) = vr; *reinterpret_cast<float4*>(dgi + H) = vz; *reinterpret_cast<float4*>(dgi + 2 * H) = vn;
-  if (STORE_GH) {    // (the fused kernel consumes dgh1 from the LDS tile: that (T-1,B,3H) array is never written)
+  if (store) {
+    *reinterpret_cast<float4*>(dgi) = vr; *reinterpret_cast<float4*>(dgi + H) = vz; *reinterpret_cast<float4*>(dgi + 2 * H) = vn;
+  }
+  if (STORE_GH && store) {    // (the fused kernel consumes dgh1 from the LDS tile: that (T-1,B,3H) array is never written)
     *reinterpret_cast<float4*>(dgh) = vr; *reinterpret_cast<float4*>(dgh + H) = vz; *reinterpret_cast<float4*>(dgh + 2 * H) = vh;
   }
   float* g = G + i * LDG + f0;
@@ -1708,15 +1720,17 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
   uint32_t k_a, k_b, k_c;
   CellSaved c1;
   // the unit (step ts >= 1, rows b0x ..): dy / keep95 tiles and the cell-1 saved vectors
+  // (a ragged last tile, B % 16 != 0: clamped addresses for the rows past B -- see the forward kernel)
   auto unit_request = [&](int ts, int b0x) {
-    const int e4c = tid + 512 < (16 * D) / 4 ? tid + 512 : 0;
+    const int nr = min(16, B - b0x), n4v = (nr * D) / 4;
+    const int ea = tid < n4v ? tid : 0, eb = tid + 256 < n4v ? tid + 256 : 0, ec = tid + 512 < n4v ? tid + 512 : 0;
     const float* dyp = a.gr.dy + ((int64_t)ts * B + b0x) * D;
     const uint32_t* kp = reinterpret_cast<const uint32_t*>(a.keep95 + ((int64_t)min(ts, T - 2) * B + b0x) * D);
-    dy_a = *reinterpret_cast<const float4*>(dyp + 4 * tid);
-    dy_b = *reinterpret_cast<const float4*>(dyp + 4 * (tid + 256));
-    dy_c = *reinterpret_cast<const float4*>(dyp + 4 * e4c);
-    k_a = kp[tid]; k_b = kp[tid + 256]; k_c = kp[e4c];
-    load_cell(c1, a.sv.gates1, a.sv.h1, (int64_t)(ts - 1) * B + b0x + i, f0);
+    dy_a = *reinterpret_cast<const float4*>(dyp + 4 * ea);
+    dy_b = *reinterpret_cast<const float4*>(dyp + 4 * eb);
+    dy_c = *reinterpret_cast<const float4*>(dyp + 4 * ec);
+    k_a = kp[ea]; k_b = kp[eb]; k_c = kp[ec];
+    load_cell(c1, a.sv.gates1, a.sv.h1, (int64_t)(ts - 1) * B + b0x + min(i, nr - 1), f0);
   };
   auto tile_commit = [&](int ts) {
     const bool fb = (ts != T - 1) && a.conditioned && (ts >= a.n_pre);
@@ -1761,7 +1775,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
       constexpr int r = decltype(rc)::value;
       if (r >= Rv) return;
       const int b0 = 16 * (b + r * nwg);
-      const int64_t row_i = b0 + i;
+      const int nrows = min(16, B - b0);
+      const bool rowok = i < nrows;
+      const int64_t row_i = b0 + (rowok ? i : nrows - 1);      // rows past B: the last row's addresses, nothing stored
       const int64_t tile = ((int64_t)t * B + b0) * D;
       const int64_t srow = (int64_t)(t - 1) * B + row_i;
       const CellSaved c1u = c1;
@@ -1771,7 +1787,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
 #pragma unroll
         for (int e = 0; e < 4; ++e) du[e] = gis[r][e] * (dbn[r][e] - a1[e] * invB - xhat[r][e] * a2s[e] * invB);
         const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
-        *reinterpret_cast<float4*>(a.gr.du + ((int64_t)t * B + row_i) * H + f0) = du4;
+        if (rowok) *reinterpret_cast<float4*>(a.gr.du + ((int64_t)t * B + row_i) * H + f0) = du4;
         if (t > 0) *reinterpret_cast<float4*>(Xdu + i * LDH + f0) = du4;
       }
       if (t == 0) return;
@@ -1815,14 +1831,14 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
       }
       lds_barrier();
       if (feedback)
-        for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256)
+        for (int e4 = tid; e4 < (nrows * D) / 4; e4 += 256)
           *reinterpret_cast<float4*>(a.gr.dy + tile + 4 * (int64_t)e4) = reinterpret_cast<const float4*>(Dt)[e4];
       // ---- dh1 = carry1 + dy W_out ; GRU cell 1 backward -------------------------------------------------------------------
       float4 direct1;
       {
         const f32x4 acc0 = lds_frag_mma_2chain<KSD>(Pout_t, wave, Xdy, LDD, lane);
         const float dh[4] = {acc0[0] + carry1[r].x, acc0[1] + carry1[r].y, acc0[2] + carry1[r].z, acc0[3] + carry1[r].w};
-        direct1 = cell_bwd<true>(dh, c1u, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt, i, f0);
+        direct1 = cell_bwd<true>(dh, c1u, a.gr.dgi1 + srow * G3 + f0, a.gr.dgh1 + srow * G3 + f0, Gt, i, f0, rowok);
       }
       CellSaved c0;
       load_cell(c0, a.sv.gates0, a.sv.h0, srow, f0);
@@ -1856,7 +1872,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
       if (nt >= 1) tile_commit(nt);
       lds_barrier();
       // ---- GRU cell 0 backward -------------------------------------------------------------------------------------------------
-      const float4 direct0 = cell_bwd<true>(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0);
+      const float4 direct0 = cell_bwd<true>(dh0, c0, a.gr.dgi0 + srow * G3 + f0, a.gr.dgh0 + srow * G3 + f0, Gt, i, f0, rowok);
       lds_barrier();
       // ---- carry0' ; da -> ReLU backward -> dbn_t of this tile, partial sums --------------------------------------------------
       {
@@ -1870,7 +1886,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float invstd = bn_invstd_(vv[e]);
-          dbn[r][e] = (av[e] > 0.f) ? p2[e] : 0.f;
+          dbn[r][e] = (rowok && av[e] > 0.f) ? p2[e] : 0.f;
           xhat[r][e] = (uv[e] - mv[e]) * invstd;
           gis[r][e] = gg[e] * invstd;
           s1a[e] += reduce16(dbn[r][e]);
@@ -1894,6 +1910,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_bwd_mt_kernel(DecPersistBw
     constexpr int r = decltype(rc)::value;
     if (r >= Rv) return;
     const int64_t row_i = 16 * (b + r * nwg) + i;
+    if (row_i >= B) return;
     *reinterpret_cast<float4*>(a.gr.dh_init + row_i * H + f0) = carry0[r];
     *reinterpret_cast<float4*>(a.gr.dh_init + ((int64_t)B + row_i) * H + f0) = carry1[r];
   });
@@ -1916,30 +1933,32 @@ int dec_persist_bwd_launch(const g2v_dec_weights* w, const g2v_dec_saved* s, con
   a.p_pre_t = p_pre_t; a.p_out_t = p_out_t; a.p_ih0_t = p_ih0_t; a.p_hh0_t = p_hh0_t; a.p_ih1_t = p_ih1_t; a.p_hh1_t = p_hh1_t;
   a.keep95 = keep95; a.keep_l0 = keep_l0;
   a.x = persist_x_at(xbase);
-  a.T = T; a.B = B; a.nblk = B / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.p_drop = p_drop;
+  a.T = T; a.B = B; a.nblk = (B + 15) / 16; a.n_pre = n_pre; a.conditioned = conditioned; a.p_drop = p_drop;
   a.wslab = wslab;
   {      // as g2v_custom_loss_fwd_bwd forms them
     const float n = (float)T * (float)B * (float)D;
     a.lc1 = s->loss_w[0] / n; a.lc2 = s->loss_w[1] / n; a.lc3 = s->loss_w[2] / n; a.linv_n = 1.0f / n;
   }
-  if (tiles_per_wg > 1) {
+  if (tiles_per_wg > 1 || (B & 15)) {
     const int R = tiles_per_wg, nwg = (a.nblk + R - 1) / R;
     const size_t lds = dec_persist_bwd_lds_bytes(false);
-    const void* fn = R == 2 ? (const void*)dec_persist_bwd_mt_kernel<2> : (const void*)dec_persist_bwd_mt_kernel<3>;
-    static bool mt_set[2] = {false, false};
-    if (R > 3 || fw || s->loss_code) {
+    const void* fn = R == 1 ? (const void*)dec_persist_bwd_mt_kernel<1>
+                            : (R == 2 ? (const void*)dec_persist_bwd_mt_kernel<2> : (const void*)dec_persist_bwd_mt_kernel<3>);
+    static bool mt_set[3] = {false, false, false};
+    if (R < 1 || R > 3 || fw || s->loss_code) {
       set_error("dec_persist_bwd: %d tiles per workgroup with a fused weight gradient / loss fold is not offered", R);
       return G2V_ERR_ARG;
     }
-    if (!mt_set[R - 2]) {
+    if (!mt_set[R - 1]) {
       if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess || !persist_fits(fn, lds)) {
         set_error("dec_persist_bwd: the %d-tile kernel does not fit a CU", R);
         return G2V_ERR_LAUNCH;
       }
-      mt_set[R - 2] = true;
+      mt_set[R - 1] = true;
     }
     if (clear) (void)hipMemsetAsync(xbase, 0, PX_BYTES, st);
-    if (R == 2) hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    if (R == 1) hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<1>, dim3(nwg), dim3(256), lds, st, a, nwg);
+    else if (R == 2) hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<2>, dim3(nwg), dim3(256), lds, st, a, nwg);
     else hipLaunchKernelGGL(dec_persist_bwd_mt_kernel<3>, dim3(nwg), dim3(256), lds, st, a, nwg);
     if (hipGetLastError() != hipSuccess) {
       set_error("dec_persist_bwd: launch failed");

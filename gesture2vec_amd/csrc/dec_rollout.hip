@@ -1830,7 +1830,8 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
     const int ptiles = persist_tiles_per_wg(dm.nblk);
-    const bool persist = fast && ptiles >= 1 && (B % 16) == 0 &&
+    const bool persist = fast && ptiles >= 1 && (B % 4) == 0 &&      // (B % 16 != 0: a ragged last tile, the multi-tile kernels)
+                        
                          a16(h_init) && a16(s->y) && a16(s->u) && a16(s->h0) && a16(s->h1) && a16(s->xin) && a16(s->a) &&
                          a16(s->x1) && a16(s->gates0) && a16(s->gates1) && a16(keep95) && a16(keep_l0) && a16(workspace);
     if (s->loss_code && !(persist && training && s->loss_coef && s->loss_partial && s->loss_terms &&
@@ -2084,7 +2085,8 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
     const int ptiles = persist_tiles_per_wg(dm.nblk);
-    const bool persist = fast && ptiles >= 1 && (B % 16) == 0 &&
+    const bool persist = fast && ptiles >= 1 && (B % 4) == 0 &&      // (B % 16 != 0: a ragged last tile, the multi-tile kernels)
+                        
                          a16(s->u) && a16(s->a) && a16(s->h0) && a16(s->h1) && a16(s->gates0) && a16(s->gates1) &&
                          a16(s->bn_stats) && a16(g->dy) && a16(g->du) && a16(g->dgi0) && a16(g->dgh0) && a16(g->dgi1) &&
                          a16(g->dgh1) && a16(g->dh_init) && a16(keep95) && a16(keep_l0) && a16(workspace);

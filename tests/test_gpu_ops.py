@@ -847,9 +847,12 @@ def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p, T):
 # More row tiles than CUs: R = 2 or 3 tiles per workgroup (csrc/dec_persist.hip, the *_mt kernels).  `mode` is what
 # g2v_dec_rollout_set_persistent gets: 1 = the library's own choice (8192 rows -> 2 tiles, 12288 -> 3, 4112 = 257 tiles: one
 # workgroup with a single tile), 2 / 3 = at least that many, which reaches the same kernels at small batches (80 rows = 5 tiles
-# over 3 workgroups, 112 = 7 tiles over 3 workgroups, 32 = 2 tiles in ONE workgroup: no exchange partner).
+# over 3 workgroups, 112 = 7 tiles over 3 workgroups, 32 = 2 tiles in ONE workgroup: no exchange partner).  The same kernels
+# (also with one tile per workgroup) serve a batch that is not a multiple of 16 rows.
 @pytest.mark.parametrize("B,mode,T,p,n_pre", [(8192, 1, 8, 0.2, 1), (8192, 1, 34, 0.0, 1), (12288, 1, 6, 0.2, 1), (4112, 1, 8, 0.0, 1),
-                                              (80, 2, 34, 0.2, 1), (112, 3, 8, 0.2, 3), (32, 2, 8, 0.0, 1), (48, 3, 5, 0.3, 1)])
+                                              (80, 2, 34, 0.2, 1), (112, 3, 8, 0.2, 3), (32, 2, 8, 0.0, 1), (48, 3, 5, 0.3, 1),
+                                              # B % 16 != 0 (B % 4 == 0): a ragged last tile -- 4100 = 256 tiles + 4 rows
+                                              (4100, 1, 8, 0.2, 1), (100, 1, 34, 0.0, 1), (36, 2, 6, 0.2, 2), (8200, 1, 5, 0.0, 1)])
 def test_dec_rollout_multi_tile_persistent_matches_per_step_kernels(ops, B, mode, T, p, n_pre):
     from gesture2vec_amd import _lib
     lib = _lib.load()
