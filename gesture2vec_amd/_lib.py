@@ -133,6 +133,11 @@ _SIGS = {
     "g2v_argmax_rows": (c_int, [c_fp, c_i64, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_soft_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_soft_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_vq_soft_fused_ok": (c_int, [c_int, c_int, c_int]),
+    "g2v_vq_soft_fused_blocks": (c_int, [c_int]),
+    "g2v_vq_soft_fused_fwd": (c_int, [c_fp] * 16 + [c_f, c_int, c_int, c_int, c_fp]),
+    "g2v_vq_soft_finish": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_vq_soft_fused_bwd": (c_int, [c_fp] * 16 + [c_f, c_int, c_int, c_int, c_fp]),
     "g2v_vq_soft_perplexity_workspace": (c_sz, [c_int, c_int]),
     "g2v_vq_soft_perplexity": (c_int, [c_fp, c_fp, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_rowscale_combine": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp]),

@@ -688,7 +688,7 @@ class VQVAEEngine:
             b.update({"gs_flat": z(N, E), "gs_logvar": z(N, K), "gs_dist": z(N, K), "gs_probs": z(N, K), "gs_q": z(N, E),
                       "gs_dq": z(N, E), "gs_dprobs": z(N, K), "gs_dd": z(N, K), "gs_dlv": z(N, K), "gs_rowsum": z(N),
                       "gs_t": z(N, E), "gs_dflat": z(N, E), "gs_tw": z(K, E), "gs_colsum": z(K), "gs_mse": z(1),
-                      "gs_mse_partial": z(self.lib.g2v_mse_blocks(N * E)),
+                      "gs_mse_partial": z(max(self.lib.g2v_mse_blocks(N * E), self.lib.g2v_vq_soft_fused_blocks(N))),
                       "gs_ws": torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(N, E, K),
                                                self.lib.g2v_linear_bwd_weight_workspace(N, E, E),
                                                self.lib.g2v_vq_soft_perplexity_workspace(N, K), 256), dtype=torch.uint8, device=dev)})
@@ -709,6 +709,24 @@ class VQVAEEngine:
         vq = "vq_layer."
         W = self._w(vq + "_embedding.weight")
         x = _p(b["enc_hidden"])
+        if lib.g2v_vq_soft_fused_ok(N, E, K):
+            # round 4: the whole quantiser forward as ONE launch (csrc/vq_soft.hip) + a one-workgroup finish (loss mean,
+            # perplexity) beside the rollout; the separate kernels below remain for the shapes it does not serve
+            check(lib.g2v_vq_code_sqnorm(W, _p(self.code_sqnorm), K, E, st))
+            check(lib.g2v_vq_soft_fused_fwd(x, self._w(vq + "mean_layer.weight"), self._w(vq + "mean_layer.bias"),
+                                            self._w(vq + "logvar_layer.weight"), self._w(vq + "logvar_layer.bias"), W,
+                                            _p(self.code_sqnorm), _p(g["gs_flat"]), _p(g["gs_logvar"]), _p(g["gs_dist"]),
+                                            _p(g["gs_probs"]), _p(g["gs_q"]), _p(g["gs_dq"]), _p(b["quant"]), _p(g["gs_mse_partial"]),
+                                            _p(g["gs_ws"]), float(self._g_vq_host), N, E, K, st))
+
+            def finish():
+                check(lib.g2v_vq_soft_finish(_p(g["gs_mse_partial"]), _p(g["gs_ws"]), _p(self._one_plus_beta), _p(g["gs_mse"]),
+                                             _p(self.vq_scalars), self.vq_scalars[1:].data_ptr(), N, E, K, self._stream()))
+            self._fork(1, finish)
+            b = self.forward_decoder(out_poses, B, training)
+            self._release()
+            self._join(1)
+            return b
         check(lib.g2v_linear_fwd(x, E, 0, 0, 0, None, 1.0, self._w(vq + "mean_layer.weight"), self._w(vq + "mean_layer.bias"),
                                  _p(g["gs_flat"]), E, N, E, E, 0, st))
         check(lib.g2v_linear_fwd(_p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, self._w(vq + "logvar_layer.weight"),
@@ -747,16 +765,16 @@ class VQVAEEngine:
         W, gW = self._w(vq + "_embedding.weight"), self._g(vq + "_embedding.weight")
         ws, wsn = _p(g["gs_ws"]), g["gs_ws"].numel()
         x = _p(b["enc_hidden"])
-        # to the encoder state directly: the straight-through path + the commitment term (gs_dq holds g 2 (q - x) / n)
-        check(lib.g2v_vq_bwd(_p(b["dh_init"]), _p(self._g_vq_dev), x, _p(g["gs_q"]), None, _p(b["gz"]), N, E, self.beta, st))
-        # q = probs W  <-  dq (the q_latent term):  dprobs = dq W^T,  dW += probs^T dq
-        check(lib.g2v_linear_fwd(_p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dprobs"]), K, N, E, K, 0, st))
-        # probabilities <- distances, logvar (reference :1349-1372, 1396-1411)
-        check(lib.g2v_vq_soft_bwd(_p(g["gs_probs"]), _p(g["gs_dprobs"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(g["gs_dd"]),
-                                  _p(g["gs_dlv"]), _p(g["gs_rowsum"]), N, K, st))
-        check(lib.g2v_linear_bwd_data(_p(g["gs_dd"]), K, W, _p(g["gs_t"]), E, N, E, K, 0, st))
-        check(lib.g2v_rowscale_combine(_p(g["gs_flat"]), _p(g["gs_rowsum"]), _p(g["gs_t"]), _p(g["gs_dflat"]), N, E, st))
-        check(lib.g2v_linear_bwd_data(_p(g["gs_dlv"]), K, self._w(vq + "logvar_layer.weight"), _p(g["gs_dflat"]), E, N, E, K, 1, st))
+        fused = bool(lib.g2v_vq_soft_fused_ok(N, E, K))
+        if fused:
+            # ONE launch: straight-through + commitment term, dprobs, the (distance, logvar) -> probs backward, dflat, and
+            # gz = ... + dflat W_mean (csrc/vq_soft.hip); dd / dlogvar / dflat are written for the weight gradients
+            check(lib.g2v_vq_soft_fused_bwd(_p(b["dh_init"]), _p(self._g_vq_dev), x, _p(g["gs_q"]), _p(g["gs_dq"]), _p(g["gs_flat"]),
+                                            _p(g["gs_probs"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), self._w(vq + "mean_layer.weight"),
+                                            self._w(vq + "logvar_layer.weight"), W, _p(g["gs_dd"]), _p(g["gs_dlv"]),
+                                            _p(g["gs_dflat"]), _p(b["gz"]), self.beta, N, E, K, st))
+        else:
+            self._backward_gssoft_chain(b, g, N, x, W, st)
         # The quantiser's five weight-gradient launches feed only clip + Adam: beside the encoder's BPTT, behind the decoder's
         # products on their stream (round 4; they sat on the chain in front of the BPTT).  Everything they read is final here.
         def q_wgrads():
@@ -772,9 +790,25 @@ class VQVAEEngine:
             check(lib.g2v_linear_bwd_weight(_p(g["gs_dflat"]), E, x, E, 0, 0, 0, None, 1.0, self._g(vq + "mean_layer.weight"),
                                             self._g(vq + "mean_layer.bias"), N, E, E, 0, ws, wsn, st2))
         self._fork(2, q_wgrads, late=False)
-        check(lib.g2v_linear_bwd_data(_p(g["gs_dflat"]), E, self._w(vq + "mean_layer.weight"), _p(b["gz"]), E, N, E, E, 1, st))
+        if not fused:
+            check(lib.g2v_linear_bwd_data(_p(g["gs_dflat"]), E, self._w(vq + "mean_layer.weight"), _p(b["gz"]), E, N, E, E, 1, st))
         self.backward_encoder(in_poses, B)
         self._join(2)
+
+    def _backward_gssoft_chain(self, b, g, N, x, W, st):
+        """the quantiser's data gradients as separate launches (shapes csrc/vq_soft.hip does not serve); gz lacks the mean_layer
+        term, which the caller adds"""
+        lib, E, K, vq = self.lib, self.E, self.K, "vq_layer."
+        # to the encoder state directly: the straight-through path + the commitment term (gs_dq holds g 2 (q - x) / n)
+        check(lib.g2v_vq_bwd(_p(b["dh_init"]), _p(self._g_vq_dev), x, _p(g["gs_q"]), None, _p(b["gz"]), N, E, self.beta, st))
+        # q = probs W  <-  dq (the q_latent term):  dprobs = dq W^T,  dW += probs^T dq
+        check(lib.g2v_linear_fwd(_p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, W, None, _p(g["gs_dprobs"]), K, N, E, K, 0, st))
+        # probabilities <- distances, logvar (reference :1349-1372, 1396-1411)
+        check(lib.g2v_vq_soft_bwd(_p(g["gs_probs"]), _p(g["gs_dprobs"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), _p(g["gs_dd"]),
+                                  _p(g["gs_dlv"]), _p(g["gs_rowsum"]), N, K, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_dd"]), K, W, _p(g["gs_t"]), E, N, E, K, 0, st))
+        check(lib.g2v_rowscale_combine(_p(g["gs_flat"]), _p(g["gs_rowsum"]), _p(g["gs_t"]), _p(g["gs_dflat"]), N, E, st))
+        check(lib.g2v_linear_bwd_data(_p(g["gs_dlv"]), K, self._w(vq + "logvar_layer.weight"), _p(g["gs_dflat"]), E, N, E, K, 1, st))
 
     def _wgrad_fns(self, b, M_default, ws_key="ws"):
         lib = self.lib

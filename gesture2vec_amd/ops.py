@@ -606,6 +606,45 @@ def vq_soft_bwd(probs, dprobs, dist, logvar):
     return dd, dlv, rowsum
 
 
+def vq_soft_fused_ok(N, E, K):
+    return bool(_lib_().g2v_vq_soft_fused_ok(N, E, K))
+
+
+def vq_soft_fused_fwd(x, w_mean, b_mean, w_logvar, b_logvar, codebook, beta, g_scale=1.0, want_perplexity=True):
+    """The whole soft-quantiser forward (csrc/vq_soft.hip): returns a dict flat, logvar, dist, probs, q, dq, quant, mse (1,),
+    loss_vq (1,), perplexity (1,) or None."""
+    lib = _lib_()
+    N, E = x.shape
+    K = codebook.shape[0]
+    dev = x.device
+    f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    wsq = vq_code_sqnorm(codebook)
+    nblk = lib.g2v_vq_soft_fused_blocks(N)
+    o = {"flat": f(N, E), "logvar": f(N, K), "dist": f(N, K), "probs": f(N, K), "q": f(N, E), "dq": f(N, E), "quant": f(N, E),
+         "mse": f(1), "loss_vq": f(1), "perplexity": f(1) if want_perplexity else None}
+    part, colsum = f(nblk), f(nblk, K) if want_perplexity else None
+    check(lib.g2v_vq_soft_fused_fwd(_p(_chk(x)), _p(_chk(w_mean)), _p(_chk(b_mean)), _p(_chk(w_logvar)), _p(_chk(b_logvar)),
+                                    _p(_chk(codebook)), _p(wsq), _p(o["flat"]), _p(o["logvar"]), _p(o["dist"]), _p(o["probs"]),
+                                    _p(o["q"]), _p(o["dq"]), _p(o["quant"]), _p(part), _p(colsum), float(g_scale), N, E, K, _stream()),
+          "vq_soft_fused_fwd")
+    opb = torch.full((1,), 1.0 + float(beta), dtype=torch.float32, device=dev)
+    check(lib.g2v_vq_soft_finish(_p(part), _p(colsum), _p(opb), _p(o["mse"]), _p(o["loss_vq"]), _p(o["perplexity"]), N, E, K,
+                                 _stream()), "vq_soft_finish")
+    return o
+
+
+def vq_soft_fused_bwd(dh, g_loss, x, fwd, w_mean, w_logvar, codebook, beta):
+    """Backward of vq_soft_fused_fwd (`fwd` = its dict): returns (gz (N,E), dd (N,K), dlogvar (N,K), dflat (N,E))."""
+    N, E = x.shape
+    K = codebook.shape[0]
+    gz, dflat = torch.empty_like(x), torch.empty_like(x)
+    dd, dlv = torch.empty_like(fwd["probs"]), torch.empty_like(fwd["probs"])
+    check(_lib_().g2v_vq_soft_fused_bwd(_p(dh), _p(g_loss), _p(_chk(x)), _p(fwd["q"]), _p(fwd["dq"]), _p(fwd["flat"]), _p(fwd["probs"]),
+                                        _p(fwd["dist"]), _p(fwd["logvar"]), _p(_chk(w_mean)), _p(_chk(w_logvar)), _p(_chk(codebook)),
+                                        _p(dd), _p(dlv), _p(dflat), _p(gz), float(beta), N, E, K, _stream()), "vq_soft_fused_bwd")
+    return gz, dd, dlv, dflat
+
+
 def rowscale_combine(a, v, t):
     """out[r,c] = 2 a[r,c] v[r] - 2 t[r,c]"""
     rows, cols = a.shape

@@ -499,6 +499,30 @@ int g2v_vq_soft_bwd(const float* probs, const float* dprobs, const float* dist, 
 int g2v_rowscale_combine(const float* a, const float* v, const float* t, float* out, int64_t rows, int cols,
                          g2v_stream_t stream);
 int g2v_ste_f32(const float* z, const float* q, float* out, int64_t n, g2v_stream_t stream);
+/* The same quantiser, fused (csrc/vq_soft.hip; E == 128, K % 128 == 0, K <= 1024: g2v_vq_soft_fused_ok, else use the calls above).
+ * A workgroup owns 16 rows of x (N,E); nothing (N,K)-sized travels between launches:
+ *   g2v_vq_soft_fused_fwd   flat = mean_layer(x), logvar = logvar_layer(flat), dist, probs, q = probs W (all written: the
+ *                           backward and the weight gradients read them), dq = 2 g_scale (q - x) / (N E) (the q_latent gradient),
+ *                           quant = x + (q - x), mse_partial[blk] = sum over the workgroup's rows of (q - x)^2 and -- colsum may be
+ *                           NULL -- colsum[blk][K] = column sums of probs; blk < g2v_vq_soft_fused_blocks(N)
+ *   g2v_vq_soft_finish      mse = sum mse_partial / (N E) (mse may be NULL), loss_vq = mse * one_plus_beta[0] (device scalar),
+ *                           perplexity = exp(-sum_k avg_k log(avg_k + 1e-10)) from colsum (both may be NULL); one workgroup
+ *   g2v_vq_soft_fused_bwd   gz = [dh + g_loss[0] 2 beta (x - q) / (N E)] + dflat W_mean with dflat = (2 flat sum_k dd - 2 dd W) +
+ *                           dlogvar W_logvar, (dd, dlogvar) = the backward of probs wrt (dist, logvar) at dprobs = dq W^T; dd,
+ *                           dlogvar (N,K) and dflat (N,E) are written for g2v_linear_bwd_weight.  dh / g_loss may be NULL (= 0).
+ * Element-wise arithmetic as in the separate kernels; the K- and E-long sums meet in another fixed order (fp32 rounding). */
+int g2v_vq_soft_fused_ok(int N, int E, int K);
+int g2v_vq_soft_fused_blocks(int N);
+int g2v_vq_soft_fused_fwd(const float* x, const float* w_mean, const float* b_mean, const float* w_logvar, const float* b_logvar,
+                          const float* codebook, const float* code_sqnorm, float* flat, float* logvar, float* dist, float* probs,
+                          float* q, float* dq, float* quant, float* mse_partial, float* colsum, float g_scale, int N, int E, int K,
+                          g2v_stream_t stream);
+int g2v_vq_soft_finish(const float* mse_partial, const float* colsum, const float* one_plus_beta, float* mse, float* loss_vq,
+                       float* perplexity, int N, int E, int K, g2v_stream_t stream);
+int g2v_vq_soft_fused_bwd(const float* dh, const float* g_loss, const float* x, const float* q, const float* dq, const float* flat,
+                          const float* probs, const float* dist, const float* logvar, const float* w_mean, const float* w_logvar,
+                          const float* codebook, float* dd, float* dlogvar, float* dflat, float* gz, float beta, int N, int E, int K,
+                          g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Remaining operators of Part d (text -> gesture-code seq2seq, model/text2embedding_model.py).

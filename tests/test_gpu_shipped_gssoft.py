@@ -145,7 +145,11 @@ def test_fused_soft_quantiser_step_equals_the_autograd_path(B, p, mode, monkeypa
     for (l0, p0), (l1, p1) in zip(out["0"][0], out["1"][0]):
         assert abs(l0 - l1) <= 2e-5 * abs(l0) and abs(p0 - p1) <= 1e-4 * abs(p0), (l0, l1, p0, p1)
     err = float((out["0"][1] - out["1"][1]).abs().max())
-    assert err <= 4 * 5e-4 * 0.02 + 1e-6, err          # a few per cent of the 4 Adam steps' lr
+    # a few per cent of the 4 Adam steps' lr: Adam turns the RELATIVE rounding difference of a small gradient element into a
+    # difference of that fraction of lr (the engine's quantiser is one fused kernel each way since round 4, csrc/vq_soft.hip,
+    # whose K- and E-long sums meet in another order than the separate launches'; element-wise parity of the two at 3e-4:
+    # tests/test_gpu_thin_models.py::test_fused_soft_quantiser_kernels_equal_the_separate_kernels)
+    assert err <= 4 * 5e-4 * 0.05 + 1e-6, err
 
 
 def test_soft_quantiser_data_parallel_halves_on_one_gpu():

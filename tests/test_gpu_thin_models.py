@@ -13,7 +13,7 @@ DEV = "cuda:0"
 
 def relerr(got, ref):
     got = got.detach().cpu().double().reshape(-1)
-    ref = torch.as_tensor(ref).double().reshape(-1)
+    ref = torch.as_tensor(ref).detach().cpu().double().reshape(-1)
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
 
 
@@ -208,6 +208,53 @@ def test_vq_gssoft_matches_reference_golden(golden_dir):
                 assert g is not None and relerr(g, fx[k]) < 3e-4, (n, relerr(g, fx[k]))
             if k.startswith(f"c{i}/gradnone/"):
                 assert dict(q.named_parameters())[k[len(f"c{i}/gradnone/"):]].grad is None
+
+
+@pytest.mark.parametrize("N,K,scale", [(4096, 512, 0.3), (100, 512, 1.0), (37, 1024, 0.1), (16, 128, 0.5)])
+def test_fused_soft_quantiser_kernels_equal_the_separate_kernels(N, K, scale):
+    """csrc/vq_soft.hip (one launch forward, one backward) against the sequence of separate launches it replaces (dense products,
+    vq_soft_fwd / _bwd, rowscale_combine, mse, ste, vq_bwd): same element-wise expressions, K- and E-long sums in another order.
+    N % 16 != 0 exercises the ragged row tile."""
+    from gesture2vec_amd import ops
+    E, beta, gs = 128, 0.25, 0.7
+    assert ops.vq_soft_fused_ok(N, E, K) and not ops.vq_soft_fused_ok(N, 400, K) and not ops.vq_soft_fused_ok(N, E, 400)
+    g = torch.Generator().manual_seed(N + K)
+    r = lambda *s, m=1.0: (torch.randn(*s, generator=g) * m).to(DEV)
+    x = r(N, E, m=scale)
+    Wm, bm = r(E, E, m=E ** -0.5), r(E, m=0.1)
+    Wl, bl = r(K, E, m=0.3 * E ** -0.5), r(K, m=0.1)
+    W = r(K, E, m=scale)
+    dh, gl = r(N, E, m=1e-3), torch.full((1,), 0.4, device=DEV)
+    # ---- the separate kernels ---------------------------------------------------------------------------------------------------
+    flat = ops.linear_fwd(x, Wm, bm)
+    logvar = ops.linear_fwd(flat, Wl, bl)
+    dots = ops.linear_fwd(flat, W, None)
+    probs, dist, perp = ops.vq_soft_fwd(flat, dots, logvar, ops.vq_code_sqnorm(W))
+    q = ops.linear_bwd_data(probs, W)
+    mse, dq = ops.mse_fwd_bwd(q, x, True, gs)
+    quant = ops.ste(x, q)
+    gz = ops.vq_bwd(dh, gl, x, q, None, beta)
+    dprobs = ops.linear_fwd(dq, W, None)
+    dd, dlv, rowsum = ops.vq_soft_bwd(probs, dprobs, dist, logvar)
+    dflat = ops.rowscale_combine(flat, rowsum, ops.linear_bwd_data(dd, W))
+    ops.linear_bwd_data(dlv, Wl, out=dflat, accumulate=True)
+    ops.linear_bwd_data(dflat, Wm, out=gz, accumulate=True)
+    # ---- fused ------------------------------------------------------------------------------------------------------------------
+    o = ops.vq_soft_fused_fwd(x, Wm, bm, Wl, bl, W, beta, gs)
+    o2 = ops.vq_soft_fused_fwd(x, Wm, bm, Wl, bl, W, beta, gs)
+    gz_f, dd_f, dlv_f, dflat_f = ops.vq_soft_fused_bwd(dh, gl, x, o, Wm, Wl, W, beta)
+    gz_f2 = ops.vq_soft_fused_bwd(dh, gl, x, o2, Wm, Wl, W, beta)[0]
+    for k in ("flat", "logvar", "dist", "probs", "q", "dq", "quant"):
+        assert torch.equal(o[k], o2[k]), f"{k}: not reproducible"
+    assert torch.equal(gz_f, gz_f2)
+    for name, got, ref, tol in (("flat", o["flat"], flat, 1e-5), ("logvar", o["logvar"], logvar, 1e-5), ("dist", o["dist"], dist, 2e-5),
+                                ("probs", o["probs"], probs, 5e-5), ("q", o["q"], q, 2e-5), ("dq", o["dq"], dq, 1e-4),
+                                ("quant", o["quant"], quant, 2e-5), ("dd", dd_f, dd, 3e-4), ("dlogvar", dlv_f, dlv, 3e-4),
+                                ("dflat", dflat_f, dflat, 3e-4), ("gz", gz_f, gz, 3e-4)):
+        assert relerr(got, ref) < tol, (name, relerr(got, ref))
+    assert abs(float(o["mse"]) - float(mse)) <= 1e-5 * float(mse)
+    assert abs(float(o["loss_vq"]) - (1 + beta) * float(mse)) <= 1e-5 * float(mse) * (1 + beta)
+    assert abs(float(o["perplexity"]) - float(perp)) <= 1e-5 * float(perp)
 
 
 def test_bulk_assign_route_of_the_quantiser_module():
