@@ -511,6 +511,26 @@ extern "C" int g2v_fill_f32(float* p, float v, int64_t n, g2v_stream_t stream) {
   return G2V_OK;
 }
 
+// The scalars a training iteration reads back, gathered into ONE small array so that the host needs one device-to-host copy
+// (train_eval/train_seq2seq.py: loss.item() of the reference): out[k] = *src[k] (NULL: 0) for k < 3, out[3] = the persistent
+// rollouts' fault latch as a float (0 / 1 / 2).
+__global__ void iteration_readback_kernel(const float* __restrict__ s0, const float* __restrict__ s1, const float* __restrict__ s2,
+                                          const unsigned* __restrict__ fault, float* __restrict__ out) {
+  if (threadIdx.x == 0) {
+    out[0] = s0 ? s0[0] : 0.f;
+    out[1] = s1 ? s1[0] : 0.f;
+    out[2] = s2 ? s2[0] : 0.f;
+    out[3] = fault ? (float)fault[0] : 0.f;
+  }
+}
+extern "C" int g2v_iteration_readback(const float* s0, const float* s1, const float* s2, float* out4, g2v_stream_t stream) {
+  G2V_REQUIRE(out4, "null pointer");
+  hipLaunchKernelGGL(iteration_readback_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, s0, s1, s2,
+                     g2v_internal_persist_fault_ptr(), out4);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" int g2v_scale_f32(const float* in, const float* scalar, float* out, int64_t n, g2v_stream_t stream) {
   G2V_REQUIRE(in && scalar && out, "null pointer");
   if (n <= 0) return G2V_OK;

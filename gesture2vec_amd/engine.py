@@ -124,6 +124,8 @@ class VQVAEEngine:
         self.rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         self.adam_partial = torch.zeros(self.lib.g2v_adam_blocks(off), dtype=torch.float32, device=dev)
         self.gnorm = torch.zeros(1, dtype=torch.float32, device=dev)
+        # [custom_loss, loss_vq, perplexity, fault latch] of the latest train_step_apply: train_iter's ONE device-to-host copy
+        self.readback = torch.zeros(4, dtype=torch.float32, device=dev)
         # quantiser state (not trainable by gradient: grad=None in the reference, :1276-1282)
         E = self.E
         self.vq_pre_w = torch.zeros(E, E, device=dev)
@@ -231,11 +233,16 @@ class VQVAEEngine:
         ev.record(torch.cuda.current_stream())
         self._deferred.append((k, ev, fn))
 
-    def _release(self):
+    def _release(self, behind_current: bool = False):
+        """launch the deferred branches; behind_current: ordered after everything launched on the current stream SO FAR (not only
+        up to their _fork), for a branch that should not compete with the kernel just launched on the main chain"""
         for k, ev, fn in self._deferred:
             side = self._sides.get(k)
             if side is None:
                 side = self._sides[k] = torch.cuda.Stream(device=self.device)
+            if behind_current:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
             side.wait_event(ev)
             with torch.cuda.stream(side):
                 fn()
@@ -723,7 +730,17 @@ class VQVAEEngine:
                 check(lib.g2v_vq_soft_finish(_p(g["gs_mse_partial"]), _p(g["gs_ws"]), _p(self._one_plus_beta), _p(g["gs_mse"]),
                                              _p(self.vq_scalars), self.vq_scalars[1:].data_ptr(), N, E, K, self._stream()))
             self._fork(1, finish)
-            b = self.forward_decoder(out_poses, B, training)
+            # custom_loss by the chaser beside the rollout, exactly as forward() sends it along (see there)
+            chase = self._chase_ok(B, training, loss_w)
+            if chase:
+                b["sv_loss"].loss_w[0], b["sv_loss"].loss_w[1], b["sv_loss"].loss_w[2] = (float(w) for w in loss_w)
+                b["loss_target"] = out_poses.data_ptr()
+
+                def chaser():
+                    check(lib.g2v_custom_loss_chase(_p(out_poses), C.byref(b["sv_loss"]), _p(b["keep95"]), self.T, B, self.D, self.H,
+                                                    _p(b["ws_decf"]), b["ws_decf"].numel(), self._stream()))
+                self._fork(1, chaser, late=True)
+            b = self.forward_decoder(out_poses, B, training, chase=chase)
             self._release()
             self._join(1)
             return b
@@ -758,14 +775,15 @@ class VQVAEEngine:
         lib, st = self.lib, self._stream()
         H, E, K = self.H, self.E, self.K
         N = (2 * B * H) // E
-        b = self.backward_decoder(B, wgrad_branch=True)
-        self._release()
+        fused = bool(lib.g2v_vq_soft_fused_ok(N, E, K))
+        b = self.backward_decoder(B, wgrad_branch=True, wgrad_late=True if fused else None)
         g = self._gs_buffers(B)
         vq = "vq_layer."
         W, gW = self._w(vq + "_embedding.weight"), self._g(vq + "_embedding.weight")
         ws, wsn = _p(g["gs_ws"]), g["gs_ws"].numel()
         x = _p(b["enc_hidden"])
-        fused = bool(lib.g2v_vq_soft_fused_ok(N, E, K))
+        if not fused:
+            self._release()
         if fused:
             # ONE launch: straight-through + commitment term, dprobs, the (distance, logvar) -> probs backward, dflat, and
             # gz = ... + dflat W_mean (csrc/vq_soft.hip); dd / dlogvar / dflat are written for the weight gradients
@@ -773,6 +791,9 @@ class VQVAEEngine:
                                             _p(g["gs_probs"]), _p(g["gs_dist"]), _p(g["gs_logvar"]), self._w(vq + "mean_layer.weight"),
                                             self._w(vq + "logvar_layer.weight"), W, _p(g["gs_dd"]), _p(g["gs_dlv"]),
                                             _p(g["gs_dflat"]), _p(b["gz"]), self.beta, N, E, K, st))
+            # the decoder's weight-gradient branch (forked in backward_decoder) starts BEHIND this kernel: it sits on the chain to
+            # the encoder's BPTT, they do not (beside a product that fills every CU it took 124 us instead of ~45)
+            self._release(behind_current=True)
         else:
             self._backward_gssoft_chain(b, g, N, x, W, st)
         # The quantiser's five weight-gradient launches feed only clip + Adam: beside the encoder's BPTT, behind the decoder's
@@ -829,7 +850,7 @@ class VQVAEEngine:
                                                   self._stream()))
         return wgrad, wgrad4
 
-    def backward_decoder(self, B: int, wgrad_branch: bool = False):
+    def backward_decoder(self, B: int, wgrad_branch: bool = False, wgrad_late: Optional[bool] = None):
         """Backward of forward_decoder(training=True): expects buffers['dy'] = dLoss/d y (T,B,D); writes the decoder's
         parameter gradients (overwrite) and buffers['dh_init'] (2,B,H) = dLoss / d(initial hidden state).
         wgrad_branch: the weight-gradient products are launched as parallel branch 2 (own workspace); the caller joins it
@@ -869,7 +890,7 @@ class VQVAEEngine:
                 g = self.view(name, True)
                 check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
         if wgrad_branch:
-            self._fork(2, products)          # launched by backward()'s _release(), behind the quantiser's backward
+            self._fork(2, products, late=wgrad_late)      # (wgrad_late: launched by the caller's _release())
         else:
             products()
         return b
@@ -1011,3 +1032,5 @@ class VQVAEEngine:
         if dp and self.quantizer == "ema":
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0)
+        check(self.lib.g2v_iteration_readback(_p(self.loss_terms), _p(self.vq_scalars), self.vq_scalars[1:].data_ptr(),
+                                              _p(self.readback), self._stream()))

@@ -148,10 +148,12 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
     else:
         eng.train_step(x, tgt, reduce_fn=reduce_fn, world=world, **kw)
     net.decoder.decoder.pre_linear[1].num_batches_tracked += net.n_frames - 1       # one BatchNorm call per decode step
-    both = torch.stack((eng.loss_terms[0], eng.vq_scalars[0])).tolist()            # the iteration's one host sync
-    eng.check_faults()            # one more word at the same sync point; a faulted step was not applied (the commit kernels gate on the latch)
+    # the iteration's one host sync: [custom_loss, loss_vq, perplexity, fault latch] gathered on the device by train_step_apply
+    both = eng.readback.tolist()
+    if both[3] != 0.0 or eng.vq_bx_check_every > 0:
+        eng.check_faults()        # raises: a faulted step was not applied (the commit kernels gate on the latch)
     loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
-    return {"loss": loss}, eng.vq_scalars[1].detach().clone()
+    return {"loss": loss}, eng.readback[2].clone()
 
 
 import os as _os
