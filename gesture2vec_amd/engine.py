@@ -696,7 +696,8 @@ class VQVAEEngine:
                       "gs_dq": z(N, E), "gs_dprobs": z(N, K), "gs_dd": z(N, K), "gs_dlv": z(N, K), "gs_rowsum": z(N),
                       "gs_t": z(N, E), "gs_dflat": z(N, E), "gs_tw": z(K, E), "gs_colsum": z(K), "gs_mse": z(1),
                       "gs_mse_partial": z(max(self.lib.g2v_mse_blocks(N * E), self.lib.g2v_vq_soft_fused_blocks(N))),
-                      "gs_ws": torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(N, E, K),
+                      "gs_tp": z(K, E),
+                      "gs_ws": torch.zeros(max(3 * self.lib.g2v_linear_bwd_weight_workspace(N, E, K),
                                                self.lib.g2v_linear_bwd_weight_workspace(N, E, E),
                                                self.lib.g2v_vq_soft_perplexity_workspace(N, K), 256), dtype=torch.uint8, device=dev)})
         return b
@@ -719,7 +720,9 @@ class VQVAEEngine:
         if lib.g2v_vq_soft_fused_ok(N, E, K):
             # round 4: the whole quantiser forward as ONE launch (csrc/vq_soft.hip) + a one-workgroup finish (loss mean,
             # perplexity) beside the rollout; the separate kernels below remain for the shapes it does not serve
-            check(lib.g2v_vq_code_sqnorm(W, _p(self.code_sqnorm), K, E, st))
+            if not getattr(self, "_gs_wsq_ready", False):      # (train_step computes it in the branch beside the encoder)
+                check(lib.g2v_vq_code_sqnorm(W, _p(self.code_sqnorm), K, E, st))
+            self._gs_wsq_ready = False
             check(lib.g2v_vq_soft_fused_fwd(x, self._w(vq + "mean_layer.weight"), self._w(vq + "mean_layer.bias"),
                                             self._w(vq + "logvar_layer.weight"), self._w(vq + "logvar_layer.bias"), W,
                                             _p(self.code_sqnorm), _p(g["gs_flat"]), _p(g["gs_logvar"]), _p(g["gs_dist"]),
@@ -800,14 +803,16 @@ class VQVAEEngine:
         # products on their stream (round 4; they sat on the chain in front of the BPTT).  Everything they read is final here.
         def q_wgrads():
             st2 = self._stream()
-            check(lib.g2v_linear_bwd_weight(_p(g["gs_dd"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0, _p(g["gs_tw"]),
-                                            _p(g["gs_colsum"]), N, E, K, 0, ws, wsn, st2))
+            # the three (K x E) products -- dd^T flat (+ column sums of dd), probs^T dq, dlogvar^T flat (+ its bias gradient) -- have
+            # one shape: ONE launch + one slab reduction (round 4; three of each before)
+            arr = (_lib.WgradItem * 3)()
+            arr[0].dy, arr[0].x, arr[0].dw, arr[0].db = _p(g["gs_dd"]), _p(g["gs_flat"]), _p(g["gs_tw"]), _p(g["gs_colsum"])
+            arr[1].dy, arr[1].x, arr[1].dw, arr[1].db = _p(g["gs_probs"]), _p(g["gs_dq"]), _p(g["gs_tp"]), None
+            arr[2].dy, arr[2].x, arr[2].dw, arr[2].db = (_p(g["gs_dlv"]), _p(g["gs_flat"]), self._g(vq + "logvar_layer.weight"),
+                                                         self._g(vq + "logvar_layer.bias"))
+            check(lib.g2v_linear_bwd_weight_batch(arr, 3, K, E, N, E, K, 0, ws, wsn, st2))
             check(lib.g2v_rowscale_combine(W, _p(g["gs_colsum"]), _p(g["gs_tw"]), gW, K, E, st2))           # 2 W sum_n dd - 2 dd^T f
-            check(lib.g2v_linear_bwd_weight(_p(g["gs_probs"]), K, _p(g["gs_dq"]), E, 0, 0, 0, None, 1.0, gW, None, N, E, K, 1,
-                                            ws, wsn, st2))                                                  # += probs^T dq
-            check(lib.g2v_linear_bwd_weight(_p(g["gs_dlv"]), K, _p(g["gs_flat"]), E, 0, 0, 0, None, 1.0,
-                                            self._g(vq + "logvar_layer.weight"), self._g(vq + "logvar_layer.bias"), N, E, K, 0,
-                                            ws, wsn, st2))
+            check(lib.g2v_add_halves(gW, E, _p(g["gs_tp"]), E, gW, E, K, E, st2))                            # += probs^T dq
             check(lib.g2v_linear_bwd_weight(_p(g["gs_dflat"]), E, x, E, 0, 0, 0, None, 1.0, self._g(vq + "mean_layer.weight"),
                                             self._g(vq + "mean_layer.bias"), N, E, E, 0, ws, wsn, st2))
         self._fork(2, q_wgrads, late=False)
@@ -1013,6 +1018,10 @@ class VQVAEEngine:
         def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
             if self.quantizer == "ema":
                 self.vq_derive()               # needed first: the quantiser follows the encoder directly
+            elif self.quantizer == "gssoft":   # |W_k|^2 of the codebook as it is now: off the chain in front of the fused quantiser kernel
+                check(self.lib.g2v_vq_code_sqnorm(self._w("vq_layer._embedding.weight"), _p(self.code_sqnorm), self.K, self.E,
+                                                  self._stream()))
+                self._gs_wsq_ready = True
             if draw_masks:
                 self.draw_masks(B, True, "rest")       # only the rollout consumes keep95 / keep_l0
             if self._prepared:
