@@ -1079,6 +1079,10 @@ using namespace g2v;
 // The fault latch of the persistent kernels (dec_persist.hpp): 1 if a bounded wait of the grid-wide exchange ever ran out since the
 // last clear.  SYNCHRONOUS (a device-to-host copy of one word): call it where the host synchronises anyway.
 extern "C" int g2v_dec_rollout_persist_fault(int clear) {
+  if (clear < 0) {      // test hook: LATCH a fault of value -clear (what a bounded wait running out does on the device)
+    const unsigned inj = (unsigned)(-clear);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g2v_persist_fault), &inj, sizeof(inj)) == hipSuccess ? (int)inj : -1;
+  }
   unsigned v = 0;
   if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g2v_persist_fault), sizeof(v)) != hipSuccess) return -1;
   if (v && clear) {

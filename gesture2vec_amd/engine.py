@@ -274,6 +274,9 @@ class VQVAEEngine:
             self._iter_graph = None
             self._open.clear()
             self._deferred.clear()
+            # the per-batch-size buffers cache what the persistent pair fuses (the W_hh1 gradient pointers in the rollout's
+            # argument struct, g2v_dec_rollout_bwd_fuses_wgrad): rebuilt on the next call, for the per-step kernels
+            self._bufs.clear()
             raise RuntimeError(f"persistent rollout kernel (latch {f}: {'the loss chaser waited for the rollout' if f == 2 else 'the exchange'}): "
                                "a workgroup of the launch was not resident (CU mask / another tenant of "
                                "the device?) -- this step's results are invalid and were NOT applied (parameters, Adam moments, "

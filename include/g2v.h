@@ -371,8 +371,9 @@ int g2v_dec_rollout_set_persistent(int enable);
  * interleaved on the same device -- ends in a bounded wait running out: the kernel then LATCHES a device-side fault word and
  * stops waiting (its outputs are garbage) instead of trapping.  g2v_dec_rollout_persist_fault returns the latch (0 / 1; -1 if
  * it cannot be read) and clears it when `clear` != 0.  It is SYNCHRONOUS (a one-word device-to-host copy): call it where the
- * host synchronises anyway (the engine does after a training iteration's loss read-back, bench.py at the end of the timed
- * region); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step kernels. */
+ * host synchronises anyway (bench.py at the end of the timed region; train_iter reads the latch as part of its one read-back,
+ * g2v_iteration_readback); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step
+ * kernels.  clear < 0 is the test hook of that path: it LATCHES the value -clear, as a bounded wait running out would. */
 int g2v_dec_rollout_persist_fault(int clear);
 /* 1 where the rollout pair + chaser can carry custom_loss (the loss_* fields of g2v_dec_saved): wherever the persistent path
  * applies with ONE row tile per workgroup (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent setting 1), 2 <= T <= 256.  Elsewhere leave the loss_*

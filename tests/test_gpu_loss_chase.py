@@ -130,3 +130,41 @@ def test_input_dropout_drawn_inside_its_kernel_equals_the_explicit_mask_route():
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     for k in ("keep95", "keep_l0", "x_drop"):
         assert torch.equal(a.buffers(B)[k], b.buffers(B)[k]), k
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_latched_fault_reaches_train_iter_and_the_step_is_not_applied(B):
+    """A latched residency fault of the persistent rollouts (include/g2v.h; injected through the test hook
+    g2v_dec_rollout_persist_fault(-1)): train_iter sees it in its one read-back (g2v_iteration_readback) and raises; the kernels
+    that commit a step -- clip + Adam, the EMA codebook update, the BatchNorm running statistics -- left the model state as it
+    was; the persistent path is switched off and the SAME call repeated runs on the per-step kernels and trains."""
+    import bench
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq
+    lib = _lib.load()
+    args = bench.model_args()
+    args.loss_l1_weight, args.loss_cont_weight, args.loss_var_weight, args.learning_rate = 5.0, 0.1, 0.5, 5e-4
+    T, D = 34, 135
+    torch.manual_seed(5)
+    net = Autoencoder_VQVAE(args, D, T).to(DEV)
+    net.train(True)
+    optim = FusedClipAdam(net, lr=5e-4, betas=(0.5, 0.999))
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(2)).to(DEV)
+    try:
+        for _ in range(3):                                  # eager, capture, replay
+            loss, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        eng = net.engine()
+        snap = [t.clone() for t in (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)]
+        assert lib.g2v_dec_rollout_persist_fault(-1) == 1
+        with pytest.raises(RuntimeError, match="persistent rollout kernel"):
+            train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        for was, now in zip(snap, (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)):
+            assert torch.equal(was, now), "a faulted step must not be applied"
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0    # check_faults() cleared the latch ...
+        assert lib.g2v_dec_rollout_set_persistent(0) == 0   # ... and switched the persistent path off
+        loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        assert abs(loss2["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"]) and not torch.equal(snap[0], eng.flat)
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_dec_rollout_set_persistent(1)
