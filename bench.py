@@ -572,6 +572,9 @@ def main():
                        "launch": ("eager launches" if graph is None else dp_launch if use_dp else "hipGraph replay"),
                        "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "graph_branches_mask": int(eng.overlap),
+                       "decoder_rollout": (lambda r: "one launch per time step" if r == 0 else
+                                           f"persistent: one launch each way, {r} row tile(s) of 16 per workgroup")(
+                                               int(lib.g2v_dec_rollout_tiles_per_workgroup(B, CFG["D"], CFG["H"]))),
                        "custom_loss": ("chaser kernel co-resident with the forward rollout + the backward rollout's tile load"
                                        if eng.buffers(B).get("loss_folded") else "own launch between the rollouts"),
                        "wgrad_inside_recurrent_kernels": {"decoder_mask_ih0_hh0_ih1_hh1": int(eng.buffers(B).get("fused_wgrad", 0)),

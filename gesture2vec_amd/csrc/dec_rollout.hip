@@ -1932,6 +1932,10 @@ extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES + bwd_wslab_bytes(D, H), b = split_bwd_total(D, H) * sizeof(float);
   return a > b ? a : b;
 }
+// 0: one launch per time step; R >= 1: ONE persistent launch each way with R row tiles per workgroup (see g2v.h)
+extern "C" int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H) {
+  return (H == 64 && D == 135 && B > 0 && (B % 4) == 0) ? persist_tiles_per_wg(cdiv(B, 16)) : 0;
+}
 extern "C" int g2v_dec_rollout_fuses_loss(int B, int D, int H, int T) {
   return (H == 64 && D == 135 && B > 0 && (B % 16) == 0 && persist_tiles_per_wg(B / 16) == 1 && T >= 2 && T <= 256) ? 1 : 0;
 }

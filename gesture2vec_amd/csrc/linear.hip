@@ -27,6 +27,9 @@ constexpr int BM = 64, BN = 64, BC = 32, LDT = BC + 4;
 // C[m][n] (+)= act( sum_c A[m][c] * Bop[n][c] + bias[n] )
 //   TRANS_B == false: Bop[n][c] = Bm[n*ldb + c]     (forward: Bm = w [N][K])
 //   TRANS_B == true : Bop[n][c] = Bm[c*ldb + n]     (data gradient: Bm = w [N][K], output feature = k)
+// (Round 4, measured and dropped: 64-wide chunks with the global loads two chunks ahead.  35 KB of LDS and twice the staging
+//  registers per workgroup cost more co-resident workgroups -- which is what hides a chunk's memory round trip here -- than the
+//  longer lead bought: native shape 7.97 -> 8.24 ms, Part d at B = 4096 6.79 -> 7.11 ms.)
 template <bool TRANS_B, bool VEC = false>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ A, RowMap am,
                                                       const uint8_t* __restrict__ keep, float scale,

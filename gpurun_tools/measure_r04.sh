@@ -19,7 +19,7 @@ rm -rf gpurun_out/prof_r4${tag}
 : > gpurun_out/r04_${tag}_bench_variants.jsonl
 for args in "--steps 300 --warmup 10" "--steps 300 --warmup 10 --no-loss-chase" "--steps 300 --warmup 10" "--steps 300 --warmup 10 --no-loss-chase" \
             "--steps 200 --warmup 10 --force-dp" "--steps 200 --warmup 10 --no-graph" "--steps 200 --warmup 10 --dropout 0.2" \
-            "--batch 128 --steps 300" "--batch 1024 --steps 300" "--batch 2048 --steps 300" "--batch 4100 --steps 50" "--batch 8192 --steps 50" \
+            "--batch 128 --steps 300" "--batch 1024 --steps 300" "--batch 2048 --steps 300" "--batch 4100 --steps 50" "--batch 8192 --steps 50" "--batch 12288 --steps 30" \
             "--config native --steps 200" "--config native --batch 4096 --steps 50" "--config genea --steps 50" "--config genea --batch 128 --steps 200"; do
   HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 300 python bench.py --no-cpu-baseline --no-part-d $args 2>/dev/null | tail -1 | python -c "
 import sys, json
@@ -29,3 +29,10 @@ keep['args'] = '$args'; keep['launch'] = d['config']['launch']; keep['custom_los
 keep['whole_step_frac'] = d['roofline']['whole_step']['frac']; keep['vq_us'] = d['roofline']['avg_us']
 print(json.dumps(keep))" | tee -a gpurun_out/r04_${tag}_bench_variants.jsonl
 done
+# the as-shipped soft-quantiser model through train_iter (graph replay), and its one-step timeline
+for b in 4096 128; do G2V_ONLY=1 timeout 300 python gpurun_tools/gssoft_bench.py $b 2>/dev/null | tail -1; done | tee gpurun_out/r04_${tag}_gssoft_bench.jsonl
+bash gpurun_tools/gssoft_tl.sh 4096 > /dev/null; cp gpurun_out/gssoft_tl_B4096.txt gpurun_out/r04_${tag}_gssoft_step_timeline_B4096.txt; tail -1 gpurun_out/gssoft_tl_B4096.txt
+# kernel statistics of the other workloads: the yml's own dims at the bench batch, two row tiles per workgroup, Part d
+bash gpurun_tools/r04_prof_cfg.sh native 4096 | head -12; mv gpurun_out/r04_kernel_stats_native_B4096.csv gpurun_out/r04_${tag}_kernel_stats_native_B4096.csv
+bash gpurun_tools/r04_prof_cfg.sh full 8192 | head -8; mv gpurun_out/r04_kernel_stats_full_B8192.csv gpurun_out/r04_${tag}_kernel_stats_full_B8192.csv
+bash gpurun_tools/r04_prof_t2e.sh 4096 False | head -10; mv gpurun_out/r04_e_kernel_stats_part_d_B4096_attFalse.csv gpurun_out/r04_${tag}_kernel_stats_part_d_B4096_noatt.csv
