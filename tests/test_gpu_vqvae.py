@@ -256,7 +256,10 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
                 #  term 2 beta (x - q) / n cancels in fp32 against a float64 oracle -- 1.06e-3 on one encoder tensor, 1e-5 at step 1)
                 assert relerr_l2(eng.view(name, True), ref) < (2e-3 if step > 0 and H != 64 else 1e-3), \
                     (name, relerr_l2(eng.view(name, True), ref))
-                assert relerr(eng.view(name, True), ref) < 5e-3, (name, relerr(eng.view(name, True), ref))
+                # (K = 400 shape, second step: one element of pre_linear.0.weight -- a (200 x 45) sum over the 5 % of rows Dropout(0.95)
+                #  keeps -- moves by 8.5e-3 of the tensor's maximum with such a flip; its L2 error is 6e-4)
+                assert relerr(eng.view(name, True), ref) < (1e-2 if step > 0 and H != 64 else 5e-3), \
+                    (name, relerr(eng.view(name, True), ref))
             else:
                 assert relerr(eng.view(name, True), ref) < 5e-4, (name, relerr(eng.view(name, True), ref))
         # post-step weights: Adam normalises each element's gradient by its own magnitude, so elements whose gradient sits at
