@@ -121,6 +121,8 @@ _SIGS = {
     "g2v_mse_fwd_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_f, c_fp]),
     "g2v_adam_blocks": (c_int, [c_i64]),
     "g2v_iteration_readback": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "g2v_clip_adam_step_readback": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_f, c_f,
+                                            c_fp, c_fp, c_fp, c_fp, c_fp]),
     "g2v_clip_adam_step": (c_int, [c_fp, c_fp, c_fp, c_fp, c_i64, c_fp, c_fp, c_fp, c_f, c_f, c_f, c_f, c_f, c_f, c_fp]),
     "g2v_linear_set_smallm_rows": (c_int, [c_int]),
     "g2v_vq_assign_bulk_workspace": (c_sz, [c_int, c_int, c_int]),

@@ -187,9 +187,17 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(float* __restrict__ p, c
                                                         const int32_t* __restrict__ step_counter,
                                                         float* __restrict__ gnorm_out, float max_norm, float grad_scale,
                                                         float lr, float b1, float b2, float eps,
-                                                        const unsigned* __restrict__ fault) {
+                                                        const unsigned* __restrict__ fault, const float* __restrict__ rb0,
+                                                        const float* __restrict__ rb1, const float* __restrict__ rb2,
+                                                        float* __restrict__ rb_out) {
   __shared__ float red[4];
   __shared__ float bc;
+  if (rb_out && blockIdx.x == 0 && threadIdx.x == 0) {      // the iteration's read-back (g2v_iteration_readback), latch included
+    rb_out[0] = rb0 ? rb0[0] : 0.f;
+    rb_out[1] = rb1 ? rb1[0] : 0.f;
+    rb_out[2] = rb2 ? rb2[0] : 0.f;
+    rb_out[3] = fault ? (float)fault[0] : 0.f;
+  }
   if (fault && *fault != 0u) return;      // a latched rollout fault: the gradients are garbage, the parameters and moments stay
   float s = 0.f;
   for (int k = threadIdx.x; k < npart; k += 256) s += partial[k];
@@ -403,21 +411,40 @@ extern "C" int g2v_adam_blocks(int64_t n) {
   return (int)(b > 1024 ? 1024 : b);
 }
 
+static int clip_adam_impl(float* param, const float* grad, float* m, float* v, int64_t n, float* partial, int32_t* step_counter,
+                          float* gnorm_out, float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                          const float* rb0, const float* rb1, const float* rb2, float* rb_out, g2v_stream_t stream) {
+  const int nblk = g2v_adam_blocks(n);
+  const unsigned* fault = g2v_internal_persist_fault_ptr();
+  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, n, partial, step_counter, fault);
+  if (hipGetLastError() != hipSuccess) return G2V_ERR_LAUNCH;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, partial,
+                     nblk, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps, fault, rb0, rb1, rb2, rb_out);
+  return hipGetLastError() == hipSuccess ? G2V_OK : G2V_ERR_LAUNCH;
+}
 extern "C" int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n, float* partial,
                                   int32_t* step_counter, float* gnorm_out, float max_norm, float grad_scale, float lr,
                                   float beta1, float beta2, float eps, g2v_stream_t stream) {
   G2V_REQUIRE(param && grad && m && v && partial && step_counter, "null pointer");
   G2V_REQUIRE(n > 0, "bad size");
-  const int nblk = g2v_adam_blocks(n);
-  const unsigned* fault = g2v_internal_persist_fault_ptr();
-  hipLaunchKernelGGL(sumsq_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, grad, n, partial, step_counter, fault);
-  G2V_CHECK_LAUNCH();
-  hipLaunchKernelGGL(clip_adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, param, grad, m, v, n, partial,
-                     nblk, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps, fault);
-  G2V_CHECK_LAUNCH();
-  return G2V_OK;
+  const int rc = clip_adam_impl(param, grad, m, v, n, partial, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps,
+                                nullptr, nullptr, nullptr, nullptr, stream);
+  if (rc != G2V_OK) set_error("g2v_clip_adam_step: launch failed");
+  return rc;
 }
-
+// the same step with g2v_iteration_readback folded into its second launch (no launch of its own at the end of the iteration):
+// out4 is written whether or not the fault latch holds the update back
+extern "C" int g2v_clip_adam_step_readback(float* param, const float* grad, float* m, float* v, int64_t n, float* partial,
+                                           int32_t* step_counter, float* gnorm_out, float max_norm, float grad_scale, float lr,
+                                           float beta1, float beta2, float eps, const float* s0, const float* s1,
+                                           const float* s2, float* out4, g2v_stream_t stream) {
+  G2V_REQUIRE(param && grad && m && v && partial && step_counter && out4, "null pointer");
+  G2V_REQUIRE(n > 0, "bad size");
+  const int rc = clip_adam_impl(param, grad, m, v, n, partial, step_counter, gnorm_out, max_norm, grad_scale, lr, beta1, beta2, eps,
+                                s0, s1, s2, out4, stream);
+  if (rc != G2V_OK) set_error("g2v_clip_adam_step_readback: launch failed");
+  return rc;
+}
 extern "C" int g2v_keep_mask_at(uint8_t* keep, int64_t n, float keep_prob, uint64_t seed, const int64_t* offset_counter,
                                 int64_t offset_add, g2v_stream_t stream) {
   G2V_REQUIRE(keep && offset_counter, "null pointer");

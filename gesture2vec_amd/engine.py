@@ -983,7 +983,16 @@ class VQVAEEngine:
         # buffer is zero there from construction and nothing ever writes it.
 
     def optimizer_step(self, lr: float, betas=(0.5, 0.999), eps: float = 1e-8, max_norm: float = 5.0,
-                       grad_scale: float = 1.0):
+                       grad_scale: float = 1.0, readback: bool = False):
+        """clip_grad_norm_ + Adam over the flat buffers; readback: the same launch also gathers [custom_loss, loss_vq, perplexity,
+        fault latch] into self.readback (train_iter's one device-to-host copy; written also when the latch holds the update back)"""
+        if readback:
+            check(self.lib.g2v_clip_adam_step_readback(_p(self.flat), _p(self.gflat), _p(self.m), _p(self.v), self.n_flat,
+                                                       _p(self.adam_partial), _p(self.step_counter), _p(self.gnorm), max_norm,
+                                                       grad_scale, lr, betas[0], betas[1], eps, _p(self.loss_terms),
+                                                       _p(self.vq_scalars), self.vq_scalars[1:].data_ptr(), _p(self.readback),
+                                                       self._stream()))
+            return
         check(self.lib.g2v_clip_adam_step(_p(self.flat), _p(self.gflat), _p(self.m), _p(self.v), self.n_flat,
                                           _p(self.adam_partial), _p(self.step_counter), _p(self.gnorm), max_norm,
                                           grad_scale, lr, betas[0], betas[1], eps, self._stream()))
@@ -1043,6 +1052,4 @@ class VQVAEEngine:
         """(after the all-reduce) EMA codebook update from the GLOBAL statistics, then clip + Adam on the averaged grads."""
         if dp and self.quantizer == "ema":
             self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
-        self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0)
-        check(self.lib.g2v_iteration_readback(_p(self.loss_terms), _p(self.vq_scalars), self.vq_scalars[1:].data_ptr(),
-                                              _p(self.readback), self._stream()))
+        self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0, readback=True)

@@ -475,6 +475,12 @@ int g2v_adam_blocks(int64_t n);
 /* out4[k] = *s_k (NULL: 0), k < 3; out4[3] = g2v_dec_rollout_persist_fault's latch as a float: the scalars an iteration reads
  * back (loss terms, perplexity) plus the latch in ONE device array, i.e. one device-to-host copy at the iteration's sync point. */
 int g2v_iteration_readback(const float* s0, const float* s1, const float* s2, float* out4, g2v_stream_t stream);
+/* g2v_clip_adam_step with g2v_iteration_readback(s0, s1, s2, out4) folded into its second launch (out4 is written also when the
+ * fault latch holds the update back) */
+int g2v_clip_adam_step_readback(float* param, const float* grad, float* m, float* v, int64_t n,
+                                float* partial, int32_t* step_counter, float* gnorm_out,
+                                float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                                const float* s0, const float* s1, const float* s2, float* out4, g2v_stream_t stream);
 int g2v_clip_adam_step(float* param, const float* grad, float* m, float* v, int64_t n,
                        float* partial, int32_t* step_counter, float* gnorm_out,
                        float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
