@@ -852,7 +852,9 @@ def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p, T):
 @pytest.mark.parametrize("B,mode,T,p,n_pre", [(8192, 1, 8, 0.2, 1), (8192, 1, 34, 0.0, 1), (12288, 1, 6, 0.2, 1), (4112, 1, 8, 0.0, 1),
                                               (80, 2, 34, 0.2, 1), (112, 3, 8, 0.2, 3), (32, 2, 8, 0.0, 1), (48, 3, 5, 0.3, 1),
                                               # B % 16 != 0 (B % 4 == 0): a ragged last tile -- 4100 = 256 tiles + 4 rows
-                                              (4100, 1, 8, 0.2, 1), (100, 1, 34, 0.0, 1), (36, 2, 6, 0.2, 2), (8200, 1, 5, 0.0, 1)])
+                                              (4100, 1, 8, 0.2, 1), (100, 1, 34, 0.0, 1), (36, 2, 6, 0.2, 2), (8200, 1, 5, 0.0, 1),
+                                              # the smallest batches / shortest rollouts the persistent path takes: one ragged tile, T = 2
+                                              (4, 1, 3, 0.0, 1), (12, 1, 2, 0.2, 1), (8, 3, 2, 0.0, 1)])
 def test_dec_rollout_multi_tile_persistent_matches_per_step_kernels(ops, B, mode, T, p, n_pre):
     from gesture2vec_amd import _lib
     lib = _lib.load()
