@@ -695,12 +695,35 @@ struct DecTW {   // PACKED transposed weights (fragment-major; rows = output fea
 //   dh(row,f) = keep ? acc * extra_scale * keep : acc   (+ carry from the later time step)
 // writes dgi / dgh (global), Gi / Gh tiles (LDS, MFMA B operands for the next contractions) and
 // direct = dh * z into Dd (LDS).  H % 4 == 0: all accesses are 16-byte vectors.
+// what gru_cell_bwd_tile reads from memory for one lane (the 16-byte path), so that a caller can request it ahead of the
+// products / the barrier in front of the cell (one memory round trip per tile stood in front of every cell epilogue)
+struct CellBwdIn {
+  float4 r4, z4, n4, h4, hp4, c4;
+  uint32_t kp;
+};
+__device__ __forceinline__ void cell_bwd_prefetch(CellBwdIn& in, const float* __restrict__ carry, const uint8_t* __restrict__ keep,
+                                                  const float* __restrict__ gates, const float* __restrict__ hprev, int H, int ft,
+                                                  int nrows, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const int f0 = 16 * ft + 4 * q;
+  in.c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  in.r4 = in.z4 = in.n4 = in.h4 = in.hp4 = in.c4;
+  in.kp = 0x01010101u;
+  if (((H & 3) == 0) && f0 + 3 < H && i < nrows) {
+    const float* go = gates + (int64_t)i * 4 * H + f0;
+    in.r4 = *reinterpret_cast<const float4*>(go); in.z4 = *reinterpret_cast<const float4*>(go + H);
+    in.n4 = *reinterpret_cast<const float4*>(go + 2 * H); in.h4 = *reinterpret_cast<const float4*>(go + 3 * H);
+    in.hp4 = *reinterpret_cast<const float4*>(hprev + (int64_t)i * H + f0);
+    if (carry) in.c4 = *reinterpret_cast<const float4*>(carry + (int64_t)i * H + f0);
+    if (keep) in.kp = *reinterpret_cast<const uint32_t*>(keep + (int64_t)i * H + f0);
+  }
+}
 __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float* __restrict__ carry, float extra_scale,
                                                   const uint8_t* __restrict__ keep,   // applied to acc (inter-layer dropout bwd)
                                                   const float* __restrict__ gates, const float* __restrict__ hprev,
                                                   float* __restrict__ dgi, float* __restrict__ dgh, float* Gi, float* Gh,
                                                   int ldg, float* Dd, int ldh, int H, int ft, int nrows, int lane,
-                                                  bool wt = false) {
+                                                  bool wt, bool use_pre, const CellBwdIn& pre) {
   const int i = lane & 15, q = lane >> 4;
   const int f0 = 16 * ft + 4 * q;
   const int G = 3 * H;
@@ -709,13 +732,17 @@ __device__ __forceinline__ void gru_cell_bwd_tile(const f32x4& acc, const float*
           g_hn[4] = {0.f, 0.f, 0.f, 0.f}, direct[4] = {0.f, 0.f, 0.f, 0.f};
     if (i < nrows) {
       const float* go = gates + (int64_t)i * 4 * H + f0;
-      const float4 r4 = *reinterpret_cast<const float4*>(go), z4 = *reinterpret_cast<const float4*>(go + H),
-                   n4 = *reinterpret_cast<const float4*>(go + 2 * H), h4 = *reinterpret_cast<const float4*>(go + 3 * H);
-      const float4 hp4 = *reinterpret_cast<const float4*>(hprev + (int64_t)i * H + f0);
-      float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (carry) c4 = *reinterpret_cast<const float4*>(carry + (int64_t)i * H + f0);
+      float4 r4, z4, n4, h4, hp4, c4 = make_float4(0.f, 0.f, 0.f, 0.f);
       uint32_t kp = 0x01010101u;
-      if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (int64_t)i * H + f0);
+      if (use_pre) {
+        r4 = pre.r4; z4 = pre.z4; n4 = pre.n4; h4 = pre.h4; hp4 = pre.hp4; c4 = pre.c4; kp = pre.kp;
+      } else {
+        r4 = *reinterpret_cast<const float4*>(go); z4 = *reinterpret_cast<const float4*>(go + H);
+        n4 = *reinterpret_cast<const float4*>(go + 2 * H); h4 = *reinterpret_cast<const float4*>(go + 3 * H);
+        hp4 = *reinterpret_cast<const float4*>(hprev + (int64_t)i * H + f0);
+        if (carry) c4 = *reinterpret_cast<const float4*>(carry + (int64_t)i * H + f0);
+        if (keep) kp = *reinterpret_cast<const uint32_t*>(keep + (int64_t)i * H + f0);
+      }
       const float rr[4] = {r4.x, r4.y, r4.z, r4.w}, zz[4] = {z4.x, z4.y, z4.z, z4.w}, nn[4] = {n4.x, n4.y, n4.z, n4.w},
                   gh[4] = {h4.x, h4.y, h4.z, h4.w}, hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, cc[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
@@ -829,6 +856,21 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_de
     const int64_t row = ((int64_t)t * B + b0 + pr2) * H + pc2;
     pu2 = *reinterpret_cast<const float4*>(sv.u + row);
     pdb2 = *reinterpret_cast<const float4*>(gr.dbn + row);
+  }
+  // generic dims: what the two cell epilogues read from HBM (saved gates, previous state, carry, keep flags) is requested well
+  // ahead -- cell 1's here, cell 0's in front of cell 1 (vector-memory results return in order: a request placed directly in
+  // front of a product's L2 weight stream delays that stream by an HBM round trip, measured) -- instead of one round trip per
+  // tile in front of each epilogue (17 + 21 k of the kernel's 184 k ticks, gpurun_tools/stamps_native.py); H <= 256: <= 2 tiles per wave
+  constexpr int MAXT = HS > 0 ? 1 : 2;
+  const bool pf = HS == 0 && hvec && nth <= MAXT * NW && t > 0;
+  CellBwdIn cin[MAXT];
+  if (pf) {
+    const float* carry1_p = last ? nullptr : gr.dh_init + ((int64_t)B + b0) * H;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j)
+      if (wave + NW * j < nth)
+        cell_bwd_prefetch(cin[j], carry1_p, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
+                          sv.h1 + ((int64_t)(t - 1) * B + b0) * H, H, wave + NW * j, nrows, lane);
   }
   STAMPB(0);
   // zero padding columns / rows of the MFMA operand tiles
@@ -1005,14 +1047,31 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_de
   const float* carry1 = last ? nullptr : gr.dh_init + ((int64_t)B + b0) * H;
   float* carry0_w = gr.dh_init + (int64_t)b0 * H;
   float* carry1_w = gr.dh_init + ((int64_t)B + b0) * H;
+  // (cell 0's inputs: requested here, consumed two phases on)
+  constexpr int MAXT0 = MAXT;
+  const bool pf0 = pf;
+  CellBwdIn cin0[MAXT0];
+  if (pf0) {
+    const bool drop0 = keep_l0 && dm.p_drop > 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXT0; ++j)
+      if (wave + NW * j < nth)
+        cell_bwd_prefetch(cin0[j], carry0, drop0 ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr,
+                          sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H, sv.h0 + ((int64_t)(t - 1) * B + b0) * H, H,
+                          wave + NW * j, nrows, lane);
+  }
   // ---- dh1 = carry + dy W_out ; GRU cell 1 backward -------------------------------------------------
   {
-    for (int ft = wave; ft < nth; ft += NW) {
-      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, KSD_T>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
-      gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
-                        sv.h1 + ((int64_t)(t - 1) * B + b0) * H, gr.dgi1 + ((int64_t)(t - 1) * B + b0) * G,
-                        gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0);
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {
+      for (int ft = wave + NW * j; ft < nth; ft += NW * MAXT) {
+        f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+        wave_gemm_p<1, KSD_T>(acc, tw.w_out_t, Dp >> 4, ft, 0, Xdy, ldd, lane);
+        gru_cell_bwd_tile(acc[0], carry1, 1.0f, nullptr, sv.gates1 + ((int64_t)(t - 1) * B + b0) * 4 * H,
+                          sv.h1 + ((int64_t)(t - 1) * B + b0) * H, gr.dgi1 + ((int64_t)(t - 1) * B + b0) * G,
+                          gr.dgh1 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0,
+                          pf && ft == wave + NW * j, cin[j]);
+      }
     }
   }
   lds_barrier();
@@ -1046,16 +1105,19 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_de
   // ---- GRU cell 0 backward (Gi/Gh/Dd are reused) ------------------------------------------------------
   {
     const bool drop = keep_l0 && dm.p_drop > 0.f;
-    for (int ft = wave; ft < nth; ft += NW) {
-      const int f0 = 16 * ft + 4 * q;
-      f32x4 acc;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = (f0 + r < H) ? Xdx[i * ldh + f0 + r] : 0.f;
-      gru_cell_bwd_tile(acc, carry0, 1.0f / (1.0f - dm.p_drop),
-                        drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr,
-                        sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H, sv.h0 + ((int64_t)(t - 1) * B + b0) * H,
-                        gr.dgi0 + ((int64_t)(t - 1) * B + b0) * G, gr.dgh0 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh,
-                        ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0);
+    for (int j = 0; j < MAXT0; ++j) {
+      for (int ft = wave + NW * j; ft < nth; ft += NW * MAXT0) {
+        const int f0 = 16 * ft + 4 * q;
+        f32x4 acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = (f0 + r < H) ? Xdx[i * ldh + f0 + r] : 0.f;
+        gru_cell_bwd_tile(acc, carry0, 1.0f / (1.0f - dm.p_drop),
+                          drop ? keep_l0 + ((int64_t)(t - 1) * B + b0) * H : nullptr,
+                          sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H, sv.h0 + ((int64_t)(t - 1) * B + b0) * H,
+                          gr.dgi0 + ((int64_t)(t - 1) * B + b0) * G, gr.dgh0 + ((int64_t)(t - 1) * B + b0) * G, Gi, Gh,
+                          ldg, Dd, ldh, H, ft, nrows, lane, dm.wt != 0, pf0 && ft == wave + NW * j, cin0[j]);
+      }
     }
   }
   lds_barrier();
@@ -1825,7 +1887,7 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
   }
   int scratch = 1024;
   (void)dec_fwd_lds(D, H, &scratch);
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), dec_wt_stores(), scratch};
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, training, cdiv(B, 16), (H == 64 && D == 135) ? dec_wt_stores() : 0, scratch};
   const bool fast = (H == 64) && (D == 135);   // the BASELINE shape: dims are compile-time constants
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
@@ -2084,7 +2146,7 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
   }
   int scratch = 1024;
   (void)dec_bwd_lds(D, H, &scratch);
-  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16), dec_wt_stores(), scratch};
+  DecDims dm{T, B, D, H, p_drop, n_pre_poses, conditioned, 1, cdiv(B, 16), (H == 64 && D == 135) ? dec_wt_stores() : 0, scratch};
   const bool fast = (H == 64) && (D == 135);
   {
     auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
