@@ -334,6 +334,63 @@ __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const flo
 // ~1e-7 on values in [-1,1], far inside the 1e-4 relative parity budget, at ~6 instructions instead of ~100.
 // Two contractions into two accumulator sets with ALL weight fragments of both issued before the first MFMA
 // (static k-steps only): used by the GRU cells (input-side and hidden-side products of the same feature tile).
+// wave_gemm_p for run-time k-steps over TWO weight streams at once (a GRU cell's input-side and hidden-side products of one
+// feature tile): one prologue and one tail per tile instead of two, 8 NT MFMAs between refills; PD k-steps of each stream in flight.
+template <int NT, int PD = 4>
+__device__ __forceinline__ void wave_gemm_p_dual(f32x4 (&acc1)[NT], const float* __restrict__ P1, const float* X1,
+                                                 f32x4 (&acc2)[NT], const float* __restrict__ P2, const float* X2, int KS,
+                                                 int tile0, int tile_stride, int ldx, int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const float* x1 = X1 + i * ldx + 4 * q;
+  const float* x2 = X2 + i * ldx + 4 * q;
+  int64_t off[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) off[t] = ((int64_t)(tile0 + t * tile_stride) * KS * 64 + lane) * 4;
+  float4 r1[PD][NT], r2[PD][NT];
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int64_t o = off[t] + (int64_t)min(j, KS - 1) * 256;
+      r1[j][t] = *reinterpret_cast<const float4*>(P1 + o);
+      r2[j][t] = *reinterpret_cast<const float4*>(P2 + o);
+    }
+  float4 an = *reinterpret_cast<const float4*>(x1), bn = *reinterpret_cast<const float4*>(x2);
+  for (int s0 = 0; s0 < KS; s0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) {
+      const int s = s0 + j;
+      if (s < KS) {
+        const float4 a = an, b = bn;
+        an = *reinterpret_cast<const float4*>(x1 + 16 * min(s + 1, KS - 1));
+        bn = *reinterpret_cast<const float4*>(x2 + 16 * min(s + 1, KS - 1));
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma16(r1[j][t].x, a.x, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = mfma16(r2[j][t].x, b.x, acc2[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma16(r1[j][t].y, a.y, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = mfma16(r2[j][t].y, b.y, acc2[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma16(r1[j][t].z, a.z, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = mfma16(r2[j][t].z, b.z, acc2[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma16(r1[j][t].w, a.w, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = mfma16(r2[j][t].w, b.w, acc2[t]);
+        const int64_t on = (int64_t)min(s + PD, KS - 1) * 256;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          r1[j][t] = *reinterpret_cast<const float4*>(P1 + off[t] + on);
+          r2[j][t] = *reinterpret_cast<const float4*>(P2 + off[t] + on);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  }
+}
 template <int NT, int KS_T>
 __device__ __forceinline__ void wave_gemm_p2(f32x4 (&acc1)[NT], const float* __restrict__ P1, const float* X1,
                                              f32x4 (&acc2)[NT], const float* __restrict__ P2, const float* X2,

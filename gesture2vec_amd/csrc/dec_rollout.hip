@@ -180,8 +180,7 @@ __device__ __forceinline__ void gru_cell_fwd(const float* __restrict__ p_ih, con
     if constexpr (KSH_T > 0) {
       wave_gemm_p2<3, KSH_T>(ai, p_ih, Xin, ah, p_hh, Xh, ft, ntile, ldh, lane);
     } else {
-      wave_gemm_p<3, 0>(ai, p_ih, KS, ft, ntile, Xin, ldh, lane);
-      wave_gemm_p<3, 0>(ah, p_hh, KS, ft, ntile, Xh, ldh, lane);
+      wave_gemm_p_dual<3>(ai, p_ih, Xin, ah, p_hh, Xh, KS, ft, ntile, ldh, lane);
     }
     if (vec) {
       gru_cell_fwd_epilogue(ai, ah, bi, bh, kp, keep != nullptr, keep_scale, Xh, ldh, H, Hnext_lds, h_out, gates, xdrop_out,
@@ -1080,8 +1079,12 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_de
   {
     for (int ft = wave; ft < nth; ft += NW) {
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh1_t, Gp >> 4, ft, 0, Gh, ldg, lane);
-      wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih1_t, Gp >> 4, ft, 0, Gi, ldg, lane);
+      if constexpr (HS == 0) {
+        wave_gemm_p_dual<1, 8>(a1, tw.w_hh1_t, Gh, a2, tw.w_ih1_t, Gi, Gp >> 4, ft, 0, ldg, lane);
+      } else {
+        wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh1_t, Gp >> 4, ft, 0, Gh, ldg, lane);
+        wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih1_t, Gp >> 4, ft, 0, Gi, ldg, lane);
+      }
       const int f0 = 16 * ft + 4 * q;
       if (hvec && f0 + 3 < H) {
         const float4 d4 = *reinterpret_cast<const float4*>(Dd + i * ldh + f0);
@@ -1157,8 +1160,12 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_bwd_kernel(g2v_de
         }
       }
       f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh0_t, Gp >> 4, ft, 0, Gh, ldg, lane);
-      wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih0_t, Gp >> 4, ft, 0, Gi, ldg, lane);
+      if constexpr (HS == 0) {
+        wave_gemm_p_dual<1, 8>(a1, tw.w_hh0_t, Gh, a2, tw.w_ih0_t, Gi, Gp >> 4, ft, 0, ldg, lane);
+      } else {
+        wave_gemm_p<1, 3 * HS / 16>(a1, tw.w_hh0_t, Gp >> 4, ft, 0, Gh, ldg, lane);
+        wave_gemm_p<1, 3 * HS / 16>(a2, tw.w_ih0_t, Gp >> 4, ft, 0, Gi, ldg, lane);
+      }
       float dbn[4], s1[4], s2[4], cw[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
