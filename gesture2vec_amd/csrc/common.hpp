@@ -277,7 +277,7 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
 // weight fragment: acc[t][r] += tile t of P (A operand) x rows [16 r, 16 r + 16) of Xs.  A kernel that streams its weights from
 // L2 every time step does 4 NT NR MFMAs per 1 KiB fragment instead of 4 NT: at 16 rows per workgroup the generic recurrent
 // kernels were bound by the fragment stream (one KiB per 128 cycles and wave = the CU's whole L1 rate at two workgroups per CU).
-template <int NT, int NR>
+template <int NT, int NR, int PD = 8>
 __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const float* __restrict__ P, int KS, int tile0,
                                                  int tile_stride, const float* Xs, int ldx, int lane) {
   const int i = lane & 15, q = lane >> 4;
@@ -285,7 +285,6 @@ __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const flo
   const float* pt[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) pt[t] = P + ((int64_t)(tile0 + t * tile_stride) * KS * 64 + lane) * 4;
-  constexpr int PD = 8;
   float4 ring[PD][NT];
 #pragma unroll
   for (int j = 0; j < PD; ++j)

@@ -356,7 +356,7 @@ __device__ __forceinline__ void gru_seq_bwd_body(const float* __restrict__ d_hs,
 struct GruBwdPre {        // one step's inputs of this thread: [column group][...]
   float4 r[4], z[4], n[4], hn[4], hp[4], up[4];
 };
-template <int NR>      // 16-row tiles per workgroup (256 NR threads)
+template <int NR, int NWV = 4 * NR>      // 16-row tiles per workgroup, waves per workgroup (64 NWV threads; 16 NR rows x TPR threads)
 __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_hs, int64_t d_hs_ld,
                                                     const float* __restrict__ d_hn, const float* __restrict__ hs,
                                                     int64_t hs_ld, const float* __restrict__ h0,
@@ -366,14 +366,16 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
                                                     float* __restrict__ dh0, int T, int B, int H) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Hp = (H + 15) & ~15, G = 3 * H, Gp = (G + 15) & ~15, ldg = Gp + 4, ldh = Hp + 4;
-  constexpr int ROWS = 16 * NR, NTHR = 256 * NR, NWAVE = 4 * NR;
+  constexpr int ROWS = 16 * NR, NTHR = 64 * NWV, NWAVE = NWV;
+  constexpr int TPR = NTHR / ROWS, KG = 64 / TPR;      // threads per row; 4-column groups per thread (covers H <= 256)
+  static_assert(TPR == 16 || TPR == 32, "16 or 32 threads per row");
   float* Gs = smem;                // [ROWS][ldg]
   float* dhs = smem + ROWS * ldg;  // [ROWS][ldh]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * ROWS;
   const int nrows = min(ROWS, B - b0);
   const int i = lane & 15, q = lane >> 4;
-  const int row_l = tid >> 4, cg = tid & 15;              // this thread's row of the tile, first column group
+  const int row_l = tid / TPR, cg = tid % TPR;            // this thread's row of the tile, first column group
   const bool rowv = row_l < nrows;
   const int b = b0 + (rowv ? row_l : 0);
   const int len = (lengths && rowv) ? lengths[b] : T;
@@ -395,8 +397,8 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
     const bool from_h0 = (s == 0) || (tprev >= len);
     const float* hpp = from_h0 ? (h0 ? h0 + (int64_t)b * H : nullptr) : hs + ((int64_t)tprev * B + b) * hs_ld;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c4 = cg + 16 * k;
+    for (int k = 0; k < KG; ++k) {
+      const int c4 = cg + TPR * k;
       const bool ok = live && c4 < H4;
       const int c = 4 * (ok ? c4 : 0);
       P.r[k] = ok ? *reinterpret_cast<const float4*>(go + c) : z4;
@@ -416,8 +418,8 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
     const int64_t row = (int64_t)t * B + b;
     // phase 1: gate gradients of this thread's column groups (inputs arrived during the previous step's phase 2)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int c4 = cg + 16 * k;
+    for (int k = 0; k < KG; ++k) {
+      const int c4 = cg + TPR * k;
       if (c4 >= H4) continue;
       const int c = 4 * c4;
       const float4 dc = *reinterpret_cast<const float4*>(dhs + row_l * ldh + c);
@@ -455,26 +457,41 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       *reinterpret_cast<float4*>(gs) = vr; *reinterpret_cast<float4*>(gs + H) = vz; *reinterpret_cast<float4*>(gs + 2 * H) = vh;
       *reinterpret_cast<float4*>(dhs + row_l * ldh + c) = make_float4(direct[0], direct[1], direct[2], direct[3]);
     }
-    __syncthreads();
+    lds_barrier();      // (LDS hazards only: __syncthreads() would also drain this step's 19 gate-gradient stores / 24 prefetched vectors per thread)
     if (s > 0) prefetch(s - 1);                         // requested ahead of the product below (in front of this wave's last
                                                         // tile instead: 2.05 ms against 1.64 at the native shape)
     // phase 2: dh_prev = direct + dgh W_hh
-    for (int ft = wave; ft < ntile; ft += NWAVE) {
-      f32x4 acc[1][NR];
+    // (this wave's feature tiles two at a time: two independent accumulator chains -- one chain issues a dependent MFMA every
+    //  ~42 cycles, two alternate at 32 -- that share the LDS operand reads, and half the ring prologues)
+    for (int ft = wave; ft < ntile; ft += 2 * NWAVE) {
+      const bool two = ft + NWAVE < ntile;
+      f32x4 acc[2][NR];
 #pragma unroll
-      for (int r = 0; r < NR; ++r) acc[0][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      wave_gemm_p_rows<1, NR>(acc, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);   // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
-      const int f0 = 16 * ft + 4 * q;
-      if (f0 + 3 < H) {
+      for (int r = 0; r < NR; ++r) acc[0][r] = acc[1][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (two) {
+        wave_gemm_p_rows<2, NR>(acc, w_hh_t, Gp >> 4, ft, NWAVE, Gs, ldg, lane);   // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
+      } else {
+        f32x4 a1[1][NR];
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-          float4 v = *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0);
-          v.x += acc[0][r][0]; v.y += acc[0][r][1]; v.z += acc[0][r][2]; v.w += acc[0][r][3];
-          *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0) = v;
+        for (int r = 0; r < NR; ++r) a1[0][r] = acc[0][r];
+        wave_gemm_p_rows<1, NR>(a1, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) acc[0][r] = a1[0][r];
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int f0 = 16 * (ft + u * NWAVE) + 4 * q;
+        if ((u == 0 || two) && f0 + 3 < H) {
+#pragma unroll
+          for (int r = 0; r < NR; ++r) {
+            float4 v = *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0);
+            v.x += acc[u][r][0]; v.y += acc[u][r][1]; v.z += acc[u][r][2]; v.w += acc[u][r][3];
+            *reinterpret_cast<float4*>(dhs + (16 * r + i) * ldh + f0) = v;
+          }
         }
       }
     }
-    __syncthreads();
+    lds_barrier();      // (LDS hazards only: __syncthreads() would also drain this step's 19 gate-gradient stores / 24 prefetched vectors per thread)
   }
   if (dh0)
     for (int e = tid; e < ROWS * H4; e += NTHR) {
@@ -483,6 +500,12 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
     }
 }
 
+// (Second half of round 4, same shape, kernel time under rocprofv3 with eager launches: 1.70 ms -> 1.57 with the wave's tiles taken
+// two at a time.  Ablations of that build: without the product 0.65 ms, without the gate-gradient stores 1.47, without the
+// prefetch 1.39, product alone 1.34 against 0.24 for the empty loop -- the product phase is 46-55 us per workgroup and step for an
+// MFMA floor of 8, and it stays there with EIGHT waves per 16-row tile (1.93 ms; 167 registers), with a 16-deep fragment ring
+// (2.0 ms, scratch), and with the k-loop rotated per workgroup so that workgroups do not request the same L2 lines at the same
+// moment (1.53).  The decoder's per-step kernels run the same products at half that time per tile; why is open.)
 // (Round 4 also measured, at the native shape B = 4096, T = 20, H = 200, 1.63 ms per call for the body above: two row tiles per
 // workgroup sharing every weight fragment 1.64-1.68 ms; the same with waves 0-3 only multiplying and waves 4-7 only moving the
 // saved tensors, so that no weight fragment queues behind an HBM load, 1.68 ms; the next step's loads requested in front of the
