@@ -248,11 +248,8 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
     // that pins the ring refills, the read used to be issued only after the previous k-step's MFMAs and its ~130-cycle LDS round
     // trip stood in front of every group of 4 NT MFMAs
     float4 xn = *reinterpret_cast<const float4*>(xrow);
-    for (int s0 = 0; s0 < KS; s0 += PD) {
-#pragma unroll
-      for (int j = 0; j < PD; ++j) {
-        const int s = s0 + j;
-        if (s < KS) {
+    auto kstep = [&](int s, int j) {
+        {
           const float4 xb = xn;
           xn = *reinterpret_cast<const float4*>(xrow + 16 * min(s + 1, KS - 1));
 #pragma unroll
@@ -268,8 +265,17 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
           for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
           __builtin_amdgcn_sched_barrier(0);
         }
-      }
+    };
+    // (whole groups of PD k-steps branch-free, then the tail: see wave_gemm_p_rows)
+    int s0 = 0;
+    for (; s0 + PD <= KS; s0 += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) kstep(s0 + j, j);
     }
+    const int rem = KS - s0;
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+      if (j < rem) kstep(s0 + j, j);
   }
 }
 
@@ -277,7 +283,7 @@ __device__ __forceinline__ void wave_gemm_p(f32x4 (&acc)[NT], const float* __res
 // weight fragment: acc[t][r] += tile t of P (A operand) x rows [16 r, 16 r + 16) of Xs.  A kernel that streams its weights from
 // L2 every time step does 4 NT NR MFMAs per 1 KiB fragment instead of 4 NT: at 16 rows per workgroup the generic recurrent
 // kernels were bound by the fragment stream (one KiB per 128 cycles and wave = the CU's whole L1 rate at two workgroups per CU).
-template <int NT, int NR, int PD = 8>
+template <int NT, int NR, int PD = 8, bool WHOLE_GROUPS = true>
 __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const float* __restrict__ P, int KS, int tile0,
                                                  int tile_stride, const float* Xs, int ldx, int lane) {
   const int i = lane & 15, q = lane >> 4;
@@ -293,46 +299,65 @@ __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const flo
   float4 xn[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx);
-  for (int s0 = 0; s0 < KS; s0 += PD) {
+  auto kstep = [&](int s, int j, bool refill) {
+    float4 xb[NR];
 #pragma unroll
-    for (int j = 0; j < PD; ++j) {
-      const int s = s0 + j;
-      if (s < KS) {
-        float4 xb[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {          // (one k-step ahead: see wave_gemm_p)
-          xb[r] = xn[r];
-          xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx + 16 * min(s + 1, KS - 1));
-        }
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].x, xb[r].x, acc[t][r]);
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].y, xb[r].y, acc[t][r]);
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].z, xb[r].z, acc[t][r]);
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-#pragma unroll
-          for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].w, xb[r].w, acc[t][r]);
-        const int sn = min(s + PD, KS - 1);         // past the end: a valid, unused fragment
-#pragma unroll
-        for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
-        __builtin_amdgcn_sched_barrier(0);
-      }
+    for (int r = 0; r < NR; ++r) {          // (one k-step ahead: see wave_gemm_p)
+      xb[r] = xn[r];
+      xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx + 16 * min(s + 1, KS - 1));
     }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].x, xb[r].x, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].y, xb[r].y, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].z, xb[r].z, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].w, xb[r].w, acc[t][r]);
+    if (refill) {
+      const int sn = min(s + PD, KS - 1);         // past the end: a valid, unused fragment
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // Whole groups of PD k-steps as a BRANCH-FREE body: every path into the loop header then carries the same queue of PD x NT
+  // pending fragment loads in the same order, and hipcc's wait-count pass can wait for exactly the oldest slot
+  // (s_waitcnt vmcnt((PD - 1) NT)).  With a per-k-step `if (s < KS)` inside the loop it fell back to vmcnt(0) at the head of every
+  // group: all PD refills -- the newest issued a few cycles earlier -- had to land before the first MFMA of the group, i.e. one full
+  // L2 round trip per PD k-steps stood in the stream (seen in the ISA of every generic recurrent kernel; round 4).
+  // WHOLE_GROUPS = false keeps the per-k-step test (and with it the vmcnt(0) at every group head).  The encoder's recurrent
+  // kernels (gru.hip) use it: with the precise waits they are 6 % / 12 % faster themselves (native shape, B = 4096: forward 722 ->
+  // 681 us, BPTT 1.64 -> 1.44 ms), and the four-matrix weight-gradient launch that FOLLOWS the BPTT -- an unchanged kernel on
+  // unchanged data -- then takes 1.84 ms instead of 0.97 in every run (same box, alternating libraries; step 7.44 -> 8.05 ms), at
+  // the GENEA shape (T = 10: half as long a BPTT) it does not (3.78 -> 3.74 ms).  Unexplained (a power-management reaction to the
+  // denser kernel is the only candidate left); the slower, measured-better form stays until it is.
+  if constexpr (!WHOLE_GROUPS) {
+    for (int s0 = 0; s0 < KS; s0 += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j)
+        if (s0 + j < KS) kstep(s0 + j, j, true);
+    }
+  } else {
+    int s0 = 0;
+    for (; s0 + PD <= KS; s0 += PD) {
+#pragma unroll
+      for (int j = 0; j < PD; ++j) kstep(s0 + j, j, true);
+    }
+    const int rem = KS - s0;
+#pragma unroll
+    for (int j = 0; j < PD; ++j)
+      if (j < rem) kstep(s0 + j, j, false);
   }
 }
-
-// Gate non-linearities on the hardware exp2/rcp units (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error
-// ~1e-7 on values in [-1,1], far inside the 1e-4 relative parity budget, at ~6 instructions instead of ~100.
-// Two contractions into two accumulator sets with ALL weight fragments of both issued before the first MFMA
-// (static k-steps only): used by the GRU cells (input-side and hidden-side products of the same feature tile).
 // wave_gemm_p for run-time k-steps over TWO weight streams at once (a GRU cell's input-side and hidden-side products of one
 // feature tile): one prologue and one tail per tile instead of two, 8 NT MFMAs between refills; PD k-steps of each stream in flight.
 template <int NT, int PD = 4>
@@ -355,11 +380,8 @@ __device__ __forceinline__ void wave_gemm_p_dual(f32x4 (&acc1)[NT], const float*
       r2[j][t] = *reinterpret_cast<const float4*>(P2 + o);
     }
   float4 an = *reinterpret_cast<const float4*>(x1), bn = *reinterpret_cast<const float4*>(x2);
-  for (int s0 = 0; s0 < KS; s0 += PD) {
-#pragma unroll
-    for (int j = 0; j < PD; ++j) {
-      const int s = s0 + j;
-      if (s < KS) {
+  auto kstep = [&](int s, int j) {
+      {
         const float4 a = an, b = bn;
         an = *reinterpret_cast<const float4*>(x1 + 16 * min(s + 1, KS - 1));
         bn = *reinterpret_cast<const float4*>(x2 + 16 * min(s + 1, KS - 1));
@@ -387,8 +409,17 @@ __device__ __forceinline__ void wave_gemm_p_dual(f32x4 (&acc1)[NT], const float*
         }
         __builtin_amdgcn_sched_barrier(0);
       }
-    }
+  };
+  // (whole groups of PD k-steps branch-free, then the tail: see wave_gemm_p_rows)
+  int s0 = 0;
+  for (; s0 + PD <= KS; s0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) kstep(s0 + j, j);
   }
+  const int rem = KS - s0;
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+    if (j < rem) kstep(s0 + j, j);
 }
 template <int NT, int KS_T>
 __device__ __forceinline__ void wave_gemm_p2(f32x4 (&acc1)[NT], const float* __restrict__ P1, const float* X1,
