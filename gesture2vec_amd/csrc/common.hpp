@@ -334,12 +334,7 @@ __device__ __forceinline__ void wave_gemm_p_rows(f32x4 (&acc)[NT][NR], const flo
   // (s_waitcnt vmcnt((PD - 1) NT)).  With a per-k-step `if (s < KS)` inside the loop it fell back to vmcnt(0) at the head of every
   // group: all PD refills -- the newest issued a few cycles earlier -- had to land before the first MFMA of the group, i.e. one full
   // L2 round trip per PD k-steps stood in the stream (seen in the ISA of every generic recurrent kernel; round 4).
-  // WHOLE_GROUPS = false keeps the per-k-step test (and with it the vmcnt(0) at every group head).  The encoder's recurrent
-  // kernels (gru.hip) use it: with the precise waits they are 6 % / 12 % faster themselves (native shape, B = 4096: forward 722 ->
-  // 681 us, BPTT 1.64 -> 1.44 ms), and the four-matrix weight-gradient launch that FOLLOWS the BPTT -- an unchanged kernel on
-  // unchanged data -- then takes 1.84 ms instead of 0.97 in every run (same box, alternating libraries; step 7.44 -> 8.05 ms), at
-  // the GENEA shape (T = 10: half as long a BPTT) it does not (3.78 -> 3.74 ms).  Unexplained (a power-management reaction to the
-  // denser kernel is the only candidate left); the slower, measured-better form stays until it is.
+  // (WHOLE_GROUPS = false keeps the per-k-step test, and with it the vmcnt(0) at every group head: A/B only)
   if constexpr (!WHOLE_GROUPS) {
     for (int s0 = 0; s0 < KS; s0 += PD) {
 #pragma unroll

@@ -202,7 +202,7 @@ __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi
       for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[g][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      wave_gemm_p_rows<3, NR, 8, false>(acc, w_hh, Hp >> 4, ft, ntile, cur, ldx, lane);
+      wave_gemm_p_rows<3, NR>(acc, w_hh, Hp >> 4, ft, ntile, cur, ldx, lane);
       const int f0 = 16 * ft + 4 * q;
       if (f0 + 3 >= H) continue;
       const float br[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
@@ -469,12 +469,12 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
 #pragma unroll
       for (int r = 0; r < NR; ++r) acc[0][r] = acc[1][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (two) {
-        wave_gemm_p_rows<2, NR, 8, false>(acc, w_hh_t, Gp >> 4, ft, NWAVE, Gs, ldg, lane);   // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
+        wave_gemm_p_rows<2, NR>(acc, w_hh_t, Gp >> 4, ft, NWAVE, Gs, ldg, lane);   // w_hh_t: fragment-major pack of W_hh^T (H rows, K = 3H)
       } else {
         f32x4 a1[1][NR];
 #pragma unroll
         for (int r = 0; r < NR; ++r) a1[0][r] = acc[0][r];
-        wave_gemm_p_rows<1, NR, 8, false>(a1, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);
+        wave_gemm_p_rows<1, NR>(a1, w_hh_t, Gp >> 4, ft, 0, Gs, ldg, lane);
 #pragma unroll
         for (int r = 0; r < NR; ++r) acc[0][r] = a1[0][r];
       }

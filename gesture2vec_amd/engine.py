@@ -953,6 +953,13 @@ class VQVAEEngine:
             if b["enc_fused_wgrad"] == 1:
                 items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
             if b["enc_fused_wgrad"] < 2:
+                if H != 64:
+                    # Generic dims: the four-matrix launch is ONE statically partitioned workgroup per CU for ~1 ms.  Started while
+                    # the decoder's weight-gradient branch is still finishing (its last product, the same kernel, ~100 us) the
+                    # dispatcher doubles some of its workgroups up on the CUs that happen to be free and leaves the others idle
+                    # once that product ends: 1.84 ms instead of 0.97, every time the BPTT ends 20 us earlier than the branch
+                    # (round 4: seen when the recurrent kernels got faster).  Wait for the branch: it is ~25 us.
+                    self._join(2)
                 wgrad4s(TB, items)
         sum2 = H == 64 and not self.wgrad_bf16x3 and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H)
         if sum2:
