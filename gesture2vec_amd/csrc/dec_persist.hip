@@ -345,6 +345,11 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         const int e4 = tid + 256 * j;
         if (e4 < (16 * D) / 4) Kt[e4] = kreq[j];
       }
+      // Every load of this step has been consumed (kreq just now; hop 1 drained everything older): say so.  hipcc's wait-count pass
+      // loses track across the loop's paths and otherwise puts an `s_waitcnt vmcnt(0)` behind the BatchNorm barrier below (a
+      // register it re-uses there MIGHT still be the target of a load) -- right behind the chase mode's progress-flag store, whose
+      // write-through acknowledgement (1-2 us) wave 0 then sat out every step, with the workgroup waiting at the next barrier.
+      __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0), nothing else
       // ---- BatchNorm statistics of u_t -----------------------------------------------------------------------------
       if (training) {
         if (px_two_hops(a.nblk)) px_hop2(a.x, t & 1, (unsigned)t, a.nblk, b, red, tot, tid);      // (one row of workgroups: hop 1's row sum is the total)

@@ -1043,6 +1043,10 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
       gr_[r] = valid ? rr : 0.f; gz_[r] = valid ? zz : 0.f; gn_[r] = valid ? nn : 0.f; gh_[r] = valid ? ghn : 0.f;
     }
     *reinterpret_cast<float4*>(hb[cur ^ 1] + i * ldx + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+    // x of step s+2 into LDS BEFORE this step's global stores are issued: the wait for `xnext` is a vmcnt(0) (hipcc cannot count
+    // across the loop's branches), and vector-memory operations retire in order -- behind the stores it drained the five 16-byte
+    // stores just issued, a store round trip per step (seen in the ISA, round 4); in front of them only last step's, long done
+    if constexpr (FUSE_IN) *reinterpret_cast<float4*>(&xb[s & 1][xr_ * ldx + xc_]) = xnext;
     if (rvalid) {
       const int64_t row = (int64_t)t * B + b;
       *reinterpret_cast<float4*>(d.hs + row * hs_ld + f0) =
@@ -1055,7 +1059,6 @@ __device__ __forceinline__ void gru_fwd_fast_body(const GruDirF& d0, const GruDi
         *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
       }
     }
-    if constexpr (FUSE_IN) *reinterpret_cast<float4*>(&xb[s & 1][xr_ * ldx + xc_]) = xnext;   // x of step s+2
     lds_barrier();
     cur ^= 1;
   }
