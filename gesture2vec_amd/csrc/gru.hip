@@ -506,6 +506,7 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
 // MFMA floor of 8, and it stays there with EIGHT waves per 16-row tile (1.93 ms; 167 registers), with a 16-deep fragment ring
 // (2.0 ms, scratch), and with the k-loop rotated per workgroup so that workgroups do not request the same L2 lines at the same
 // moment (1.53).  The decoder's per-step kernels run the same products at half that time per tile; why is open.)
+// (With the precise wait counts the BPTT is 1.44-1.47 ms; two row tiles per workgroup again, now on top of them: 1.53 ms.)
 // (Round 4 also measured, at the native shape B = 4096, T = 20, H = 200, 1.63 ms per call for the body above: two row tiles per
 // workgroup sharing every weight fragment 1.64-1.68 ms; the same with waves 0-3 only multiplying and waves 4-7 only moving the
 // saved tensors, so that no weight fragment queues behind an HBM load, 1.68 ms; the next step's loads requested in front of the
