@@ -232,3 +232,58 @@ def test_fused_decoder_rollout_matches_per_operator_path(att, p, B):
         assert relerr(pa.grad, pb.grad.cpu()) < 2e-5, (n, relerr(pa.grad, pb.grad.cpu()))
         checked += 1
     assert checked >= 20
+
+
+@pytest.mark.parametrize("att,B", [("False", 4096), ("True", 1024)])
+def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
+    """Part d END TO END against the CPU oracle (oracle/g2v_oracle.py: t2e_train_step, pinned to the reference's golden vectors)
+    at the batch sizes bench.py times -- until round 4 it was checked against the oracle only at the fixtures' B <= 24 and
+    fused-vs-per-operator above that.  One train_iter_text2embedding on synthetic sentences (config/seq2seq.yml dims: H = 200,
+    2 layers, K = 512, S = 6, dropout 0.2), explicit dropout masks on both sides: loss, greedy codes fed back (free-running from
+    step 1), every gradient.  A greedy-code decision inside fp32 rounding of a tie may differ on a handful of rows (each changes
+    that row's later steps): the L2 criterion carries the gradients, the max criterion is loose."""
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from oracle import g2v_oracle as O
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
+    from train_text2embedding import SyntheticSentences
+    H, L, K, NW, EMB, p, lr = 200, 2, 512, 500, 300, 0.2, 5e-4
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True", batch_size=B)
+    torch.manual_seed(4)
+    net = text2embedding_model(args, K, 20, NW, EMB, np.random.RandomState(1).randn(NW, EMB).astype(np.float32), None)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    net.train(True)
+    optim = FlatClipAdam(net.parameters(), lr=lr, betas=(0.5, 0.999))
+    data = list(SyntheticSentences(args, NW, 1, seed=2))[0]
+    ids, lengths, codes = data[0], data[1], data[6]
+    S, Tw = codes.shape[1], ids.shape[1]
+    g = torch.Generator().manual_seed(7)
+    masks = {"emb": (torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8),
+             "dec_l0": (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8),
+             "enc_l0": (torch.rand(Tw, B, 2 * H, generator=g) < 1 - p).to(torch.uint8)}
+    cfg = dict(n_layers=L, dropout_prob=p, n_pre_poses=1, lr=lr, att=(att == "True"))
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
+    r = O.t2e_train_step(sd, {}, ids, lengths.long(), codes.long(), masks, cfg)
+    net.set_dropout_masks(masks["emb"].to(DEV), masks["dec_l0"].to(DEV), masks["enc_l0"].to(DEV))
+    loss = train_iter_text2embedding(args, 1, ids.to(DEV), lengths, None, None, codes.to(DEV), None, net, optim)
+    assert abs(loss["loss"] - float(r["loss"])) <= 2e-5 * float(r["loss"]), (loss, float(r["loss"]))
+    worst = ("", 0.0)
+    for n, prm in net.named_parameters():
+        ref = r["grads"].get(n)
+        if ref is None or n == "decoder.decoder.pre_linear.0.bias":
+            continue
+        if float(ref.abs().max()) == 0.0:
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n      # encoder layer 1 without attention: dead compute
+            continue
+        got = prm.grad.detach().cpu().double().reshape(-1)
+        rf = ref.double().reshape(-1)
+        l2 = float((got - rf).norm() / rf.norm())
+        worst = max(worst, (n, l2), key=lambda v: v[1])
+        assert l2 < 1e-3, (n, l2)
+        assert relerr(prm.grad, ref) < 2e-2, (n, relerr(prm.grad, ref))
+    assert worst[1] > 0.0
