@@ -505,7 +505,8 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
 // prefetch 1.39, product alone 1.34 against 0.24 for the empty loop -- the product phase is 46-55 us per workgroup and step for an
 // MFMA floor of 8, and it stays there with EIGHT waves per 16-row tile (1.93 ms; 167 registers), with a 16-deep fragment ring
 // (2.0 ms, scratch), and with the k-loop rotated per workgroup so that workgroups do not request the same L2 lines at the same
-// moment (1.53).  The decoder's per-step kernels run the same products at half that time per tile; why is open.)
+// moment (1.53).  The cause was in the ISA: an `s_waitcnt vmcnt(0)` at the head of every group of 8 k-steps of the streaming loop
+// (wave_gemm_p_rows in common.hpp has the story); with whole branch-free groups the call is 1.44-1.47 ms.)
 // (With the precise wait counts the BPTT is 1.44-1.47 ms; two row tiles per workgroup again, now on top of them: 1.53 ms.)
 // (Round 4 also measured, at the native shape B = 4096, T = 20, H = 200, 1.63 ms per call for the body above: two row tiles per
 // workgroup sharing every weight fragment 1.64-1.68 ms; the same with waves 0-3 only multiplying and waves 4-7 only moving the
