@@ -402,16 +402,26 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       PSTAMP(0, 3);
       // ---- GRU layer 0 --------------------------------------------------------------------------------------------
       {
-        uint32_t kp = 0x01010101u;
-        if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + i) * H + f0);
         f32x4 ai[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
-        cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
-                      a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
-                      a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
-                      (drop && a.sv.x1) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+        // Two code paths, not one with a selected keep word: with the load of the keep flags on a conditional path hipcc waits for
+        // it (vmcnt(0)) in front of the common epilogue whether or not it was issued, and vector-memory operations retire in
+        // order -- without inter-layer dropout (the bench shape) that wait sat out the write-through y / xin / a stores issued one
+        // product earlier, every step (ISA, round 4).
+        if (drop) {
+          const uint32_t kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + i) * H + f0);
+          frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
+          cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, true, keep_scale, Xh0, Xx1,
+                        a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                        a.sv.x1 ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+        } else {
+          frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
+          cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, 0x01010101u, false, 1.0f, Xh0, Xx1,
+                        a.sv.h0 ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates0 ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
+        }
       }
       lds_barrier();
       PSTAMP(0, 4);
@@ -741,16 +751,22 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
         }
         lds_barrier();
         {
-          uint32_t kp = 0x01010101u;
-          if (drop) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + ic) * H + f0);
           f32x4 ai[3];
 #pragma unroll
           for (int g = 0; g < 3; ++g) ai[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-          frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
-          cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, drop, keep_scale, Xh0, Xx1,
-                        (a.sv.h0 && rowok) ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
-                        (a.sv.gates0 && rowok) ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
-                        (drop && a.sv.x1 && rowok) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+          if (drop) {      // (two code paths: see the one-tile kernel)
+            const uint32_t kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + ((int64_t)(t - 1) * B + b0 + ic) * H + f0);
+            frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
+            cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, kp, true, keep_scale, Xh0, Xx1,
+                          (a.sv.h0 && rowok) ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                          (a.sv.gates0 && rowok) ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr,
+                          (a.sv.x1 && rowok) ? a.sv.x1 + ((int64_t)(t - 1) * B + b0) * H : nullptr, i, f0);
+          } else {
+            frag_mma_x1st(ai, f_ih0, Xa, LDH, lane);
+            cell_epilogue(ai, gh0, Bs + B_IH0, Bs + B_HH0, 0x01010101u, false, 1.0f, Xh0, Xx1,
+                          (a.sv.h0 && rowok) ? a.sv.h0 + ((int64_t)t * B + b0) * H : nullptr,
+                          (a.sv.gates0 && rowok) ? a.sv.gates0 + ((int64_t)(t - 1) * B + b0) * 4 * H : nullptr, nullptr, i, f0);
+          }
         }
         lds_barrier();
         {
