@@ -213,6 +213,16 @@ __device__ __forceinline__ void cell_epilogue(const f32x4 (&ai)[3], const f32x4 
   }
 }
 
+// One dword from global memory, waited for on the spot, invisible to hipcc's wait-count pass.  For the rollout's RARE paths
+// (y_0 = target frame 0, teacher-forced steps): as ordinary loads their target registers stay "possibly pending" in the pass's
+// view of the time-step loop, and it waits vmcnt(0) at the top of EVERY step -- behind the keep-flag requests and in front of the
+// hidden-side products that are there to hide the exchange (ISA, round 4).
+__device__ __forceinline__ float ldg_sync(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+
 __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xa = smem + L_XA;
@@ -511,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = (e + j) / D, c = (e + j) - r * D;
-            yv[j] = a.target[((int64_t)(b0 + r) * T) * D + c];         // y_0 = target frame 0 (:1039-1040)
+            yv[j] = ldg_sync(a.target + ((int64_t)(b0 + r) * T) * D + c);         // y_0 = target frame 0 (:1039-1040)
           }
         } else {
           const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
@@ -524,10 +534,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
           sv_[j] = yv[j];
           if (teacher && t > 0) {
             const int r = (e + j) / D, c = (e + j) - r * D;
-            sv_[j] = a.target[((int64_t)(b0 + r) * T + t) * D + c];
+            sv_[j] = ldg_sync(a.target + ((int64_t)(b0 + r) * T + t) * D + c);
           }
         }
-        const uint32_t k4 = a.conditioned ? kp4[e4] : 0u;
+        const uint32_t k4 = a.conditioned ? __float_as_uint(ldg_sync(reinterpret_cast<const float*>(kp4 + e4))) : 0u;
         float xv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;     // 1 / (1 - 0.95)
@@ -842,7 +852,7 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int rr = (e + j) / D, c = (e + j) - rr * D;
-              yv[j] = a.target[((int64_t)(b0 + rr) * T) * D + c];
+              yv[j] = ldg_sync(a.target + ((int64_t)(b0 + rr) * T) * D + c);
             }
           } else {
             const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
@@ -855,10 +865,10 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
             sv_[j] = yv[j];
             if (teacher && t > 0) {
               const int rr = (e + j) / D, c = (e + j) - rr * D;
-              sv_[j] = a.target[((int64_t)(b0 + rr) * T + t) * D + c];
+              sv_[j] = ldg_sync(a.target + ((int64_t)(b0 + rr) * T + t) * D + c);
             }
           }
-          const uint32_t k4 = a.conditioned ? kp4[e4] : 0u;
+          const uint32_t k4 = a.conditioned ? __float_as_uint(ldg_sync(reinterpret_cast<const float*>(kp4 + e4))) : 0u;
           float xv[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;
