@@ -769,7 +769,9 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   // column k = 32 h + 2 j + u' (j = lane & 15).
   extern __shared__ __attribute__((aligned(16))) float smem[];   // 4 regions x [TN_*TK_][64][4] + db [8][TN_][16]
   constexpr int NTILE = TN_ * TK_;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // (GEN: the wave index as a scalar, so that the row bases below live in scalar registers)
+  const int wave = GEN ? __builtin_amdgcn_readfirstlane(tid >> 6) : tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   const int rr = wave % NR, grp = wave / NR;           // row range, tile group
   // GEN: dW is larger than one workgroup's accumulators: blockIdx.z picks a (16 TN_ SN) x (16 TK_ SK) output block; tiles
@@ -784,6 +786,18 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
     for (int t = 0; t < TN_; ++t) offn[t] = (n0 + 16 * t + i < N) ? 16 * t + i : (n0 < N ? 0 : -n0);
 #pragma unroll
     for (int u = 0; u < TK_; ++u) offk[u] = (k0 + 16 * u + i < K) ? 16 * u + i : (k0 < K ? 0 : -k0);
+  }
+  // GEN with plain rows: every operand load is  (wave-uniform row base, scalar registers) + (one constant 32-bit byte offset
+  // per lane and tile)  -- the saddr form of global_load, no per-load 64-bit vector address arithmetic and 2 x 11 fewer
+  // live registers (round 4: the address temporaries were reusing registers of loads still in flight, and the loop head
+  // waited vmcnt(0) for them)
+  constexpr bool SADDR = GEN && !MAPPED;
+  uint32_t goa[SADDR ? TN_ : 1], gob[SADDR ? TK_ : 1];
+  if constexpr (SADDR) {
+#pragma unroll
+    for (int t = 0; t < TN_; ++t) goa[t] = (uint32_t)(((int64_t)q * lddy + n0 + offn[t]) * 4);
+#pragma unroll
+    for (int u = 0; u < TK_; ++u) gob[u] = (uint32_t)(((int64_t)q * xm.ld + k0 + offk[u]) * 4);
   }
   const int mb = (blockIdx.x * NR + rr) * rows_per_wave;
   const int me = min(M, mb + rows_per_wave);
@@ -800,6 +814,18 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
   const bool okn = n0 + 16 * (TN_ - 1) + i < N, okk = k0 + 16 * (TK_ - 1) + i < K;
   const int in_last = okn ? i : 0, ik_last = okk ? i : 0;
 
+  // row m of a row-major matrix as a pointer in SCALAR registers; a lane offset passed through in_block() is zero-extended
+  // in the block that uses it (hoisted out of the loop, the extension hides the base + 32-bit-offset form from instruction
+  // selection and every load gets a 64-bit vector add again)
+  auto srow = [&](const float* p, int m, int64_t ld) {
+    const int64_t off = (int64_t)m * ld * 4;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)off), hi = __builtin_amdgcn_readfirstlane((uint32_t)(off >> 32));
+    return reinterpret_cast<const char*>(p) + (((uint64_t)hi << 32) | lo);
+  };
+  auto in_block = [](uint32_t o) {
+    asm volatile("" : "+v"(o));
+    return o;
+  };
   float ca[4][TA], cb[4][TK_], na[4][TA], nb[4][TK_], ea[TRIPLE ? 4 : 1][TRIPLE ? TA : 1], eb[TRIPLE ? 4 : 1][TRIPLE ? TK_ : 1];
   auto load_group = [&](int m0, float (&a)[4][TA], float (&b)[4][TK_]) {
     // M and the wave ranges are multiples of 16: every row of a group is valid.  One division per group for the
@@ -828,6 +854,13 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
           b[qd][2 * h] = v.x;
           b[qd][2 * h + 1] = v.y;
         }
+      } else if constexpr (SADDR) {
+        const char* ba = srow(dY, m0 + 4 * qd, lddy);
+        const char* bb = srow(X, m0 + 4 * qd, xm.ld);
+#pragma unroll
+        for (int t = 0; t < TN_; ++t) a[qd][t] = *reinterpret_cast<const float*>(ba + in_block(goa[t]));
+#pragma unroll
+        for (int u = 0; u < TK_; ++u) b[qd][u] = *reinterpret_cast<const float*>(bb + in_block(gob[u]));
       } else if constexpr (GEN) {
 #pragma unroll
         for (int t = 0; t < TN_; ++t) a[qd][t] = dr[offn[t]];
@@ -919,6 +952,8 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
       const float* dr = dY + (int64_t)mrow * lddy + n0;
       const float* dr2 = DUAL ? dY2 + (int64_t)mrow * lddy + n0 : nullptr;
       const float* xr = X + (MAPPED ? (int64_t)outer * xm.so + (int64_t)inner * xm.si : (int64_t)mrow * xm.ld) + k0;
+      const char* sba = SADDR ? srow(dY, mn + 4 * qd, lddy) : nullptr;
+      const char* sbb = SADDR ? srow(X, mn + 4 * qd, xm.ld) : nullptr;
       auto issue = [&](int k) {
         if constexpr (VW == 2) {
           if (k < TN_ / 2) {
@@ -931,6 +966,9 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
             bn[qd][2 * h] = v.x;
             bn[qd][2 * h + 1] = v.y;
           }
+        } else if constexpr (SADDR) {
+          if (k < TN_) an[qd][k] = *reinterpret_cast<const float*>(sba + in_block(goa[k < TN_ ? k : 0]));
+          else bn[qd][k - TN_] = *reinterpret_cast<const float*>(sbb + in_block(gob[k - TN_ < TK_ ? k - TN_ : 0]));
         } else if constexpr (GEN) {
           if (k < TN_) an[qd][k] = dr[offn[k < TN_ ? k : 0]];
           else bn[qd][k - TN_] = xr[offk[k - TN_ < TK_ ? k - TN_ : 0]];
@@ -966,6 +1004,9 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
         if (inner >= xm.rows_inner) { inner -= xm.rows_inner; ++outer; }
       }
     }
+    // (Round 4, measured and dropped: the bias-gradient column sums behind the group's products instead of in front of each row
+    //  quad's -- the compiler gathers them at the top of the group, where their wait counts look too strict -- 1.569 -> 1.588 ms;
+    //  two operand buffers instead of three for the 44-loads-per-group shapes (2 x 9, 9 x 2): no difference.)
   };
   // ping-pong over two register buffers (no copies): the loads of the next 16 rows are always in flight while the
   // current 16 are multiplied
@@ -1102,6 +1143,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(160))) void gem
 
 // Output-blocked variant for weight matrices larger than one workgroup's accumulators (H = 200: 600 x 200, 600 x 300 ...):
 // grid.z walks (16 TN_ SN) x (16 TK_ SK) blocks of dW, grid.x the row ranges; everything else as above.
+// (Round 4, measured: without the register attribute the accumulators move to AGPRs and the loop gains ~1 v_accvgpr copy per
+//  MFMA -- native shape at B = 4096 7.26 -> 7.53 ms; three operand buffers do not fit the 6-bit vmcnt: with 88 loads in
+//  flight every wait for the oldest group also waits for most of the youngest.)
 template <int TN_, int TK_, int SN, int SK, bool MAPPED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void gemm_tn_wave_gen_kernel(TnBatch bt, int64_t lddy,
                                                                                                      RowMap xm, int M, int K,
