@@ -183,6 +183,7 @@ class VQVAEEngine:
         # branch 0, beside the encoder (a branch of their own costs more at its fork and join than the 25 us it hides).
         # G2V_OVERLAP=0 serialises everything on the caller's stream (debugging).
         self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
+        self.tracked_counters = []          # [(int64 device tensor, increment)]: bumped once per train step on the side branch
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
         # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: at
         # small batch (a 1-2 ms step of ~300 small launches) that is more than the overlap returns (native VQ-VAE.yml shape,
@@ -1043,6 +1044,8 @@ class VQVAEEngine:
                 self._gs_wsq_ready = True
             if draw_masks:
                 self.draw_masks(B, True, "rest")       # only the rollout consumes keep95 / keep_l0
+            for t, n in self.tracked_counters:         # (train_iter: BatchNorm's num_batches_tracked)
+                check(self.lib.g2v_counter_add(_p(t), int(n), self._stream()))
             if self._prepared:
                 self.prepare_recurrent(B, "dec")
                 self.prepare_recurrent(B, "gru_bwd")

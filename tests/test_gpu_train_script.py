@@ -196,6 +196,39 @@ def test_train_iter_replayed_from_a_graph_equals_eager_iterations(monkeypatch):
     assert a[7] == b[7] == 5 * 7
 
 
+def test_train_iter_inputs_at_a_recurring_address_are_read_in_place(monkeypatch):
+    """Batches that arrive at an address seen before (a loader's resident device buffers refilled in place) get a graph of their own
+    from the second sighting on, which reads that address directly instead of copying into the static input buffers; contents
+    change every iteration, input and target are separate tensors.  Bitwise equal to the eager iterations."""
+    import gesture2vec_amd.train_eval.train_seq2seq as ts
+    B = 1024
+    runs = {}
+    for mode in ("graph", "eager"):
+        monkeypatch.setattr(ts, "_GRAPH_REPLAY", mode == "graph")
+        args, net = _iter_setup(B)
+        optim = ts.FusedClipAdam(net, 5e-4, betas=(0.5, 0.999))
+        g = torch.Generator(device="cuda:0").manual_seed(8)
+        bufs = [(torch.empty(B, args.n_poses, 135, device="cuda:0"), torch.empty(B, args.n_poses, 135, device="cuda:0")) for _ in range(2)]
+        losses = []
+        for it in range(9):
+            x, t = bufs[it % 2]
+            x.copy_(torch.randn(B, args.n_poses, 135, generator=g, device="cuda:0"))
+            t.copy_(x + 0.01 * torch.randn(B, args.n_poses, 135, generator=g, device="cuda:0"))
+            loss, perp = ts.train_iter_Autoencoder_VQ_seq2seq(args, 1, x, t, net, optim)
+            losses.append((loss["loss"], float(perp)))
+        eng = net.engine()
+        if mode == "graph":
+            st = eng._iter_graph
+            assert st["graph"] not in (None, False) and len(st.get("by_addr", {})) == 2, st.get("by_addr")
+        runs[mode] = (losses, eng.flat.clone(), eng.m.clone(), eng.v.clone(), eng.codebook.clone(),
+                      int(net.decoder.decoder.pre_linear[1].num_batches_tracked))
+    a, b = runs["graph"], runs["eager"]
+    assert a[0] == b[0], (a[0], b[0])
+    for ta, tb in zip(a[1:5], b[1:5]):
+        assert torch.equal(ta, tb)
+    assert a[5] == b[5] == 9 * 7
+
+
 def test_train_iter_keeps_one_graph_per_batch_shape(monkeypatch):
     """A data loader's short last batch alternates with the full ones (and the reference's own batch of 128 is replayed from a
     graph too): each shape keeps its own captured graph, neither evicts the other, and the result equals the eager iterations'."""
