@@ -1087,6 +1087,8 @@ template <int HS, bool FUSE_DX, int FUSE_W = 0>      // FUSE_W: 0 none, 1 W_hh o
 __global__ __launch_bounds__(256, FUSE_W == 2 ? 1 : 2) void gru_bwd_fast_kernel(GruDirB d0, GruDirB d1, const int32_t* __restrict__ lengths,
                                                            int64_t d_hs_ld, int64_t hs_ld, int T, int B) {
   static_assert(!FUSE_W || FUSE_DX, "fused weight gradients come with the fused input gradient");
+  // (Round 4, measured and dropped: s_setprio(3) here, so that this latency chain issues ahead of the weight-gradient products
+  //  co-resident on the CU -- the step got 50 us SLOWER (1.573 -> 1.624 ms): what the chain gains, the products lose twice.)
   constexpr int H = HS, G = 3 * H, KSG = G / 16, ldg = G + 4, ldn = H + 4;
   __shared__ __attribute__((aligned(16))) float Gs[2][16 * ldg];
   __shared__ __attribute__((aligned(16))) float Gn[FUSE_DX ? 2 : 1][FUSE_DX ? 16 * ldn : 4];
