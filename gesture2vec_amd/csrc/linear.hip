@@ -1030,6 +1030,9 @@ __device__ __forceinline__ void tn_wave_body(const TnBatch& bt, int64_t lddy, co
     // three operand buffers in rotation: the loads for the group AFTER next are issued between the MFMAs of the current
     // group, i.e. two groups (2 x 96 MFMAs per wave, ~6k cycles with two waves per SIMD) ahead of their use - one group
     // of distance does not cover the HBM round trip under load.
+    // (Round 4, measured and dropped: whole rotations without the two mid-loop exits + a tail for the 0-2 groups left over.
+    //  The wait counts of the 2 x 9 shape become lenient, those of the 9 x 2 shape collapse to vmcnt(0) at 256 registers:
+    //  1.587 -> 1.632 ms at the headline shape.)
     auto clamp_g = [&](int m) { return min(m, M - 16); };      // past the end of the range: a valid, unused group
     if (m0 < me) load_group(clamp_g(m0 + 16), na, nb);
     while (m0 < me) {
