@@ -77,13 +77,74 @@ __device__ __forceinline__ u32x4 px_ld(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 __device__ __forceinline__ void px_st(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 16);          // write-through
 }
+__device__ __forceinline__ void px_st_l2(__amdgpu_buffer_rsrc_t r, unsigned byte_off, u32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(v, r, byte_off, 0, 0);           // plain: the line stays in this XCD's L2
+}
 
 // Publish two values as two granules with ONE 16-byte store (each 8-byte half is self-validating).
-__device__ __forceinline__ void px_publish2(__amdgpu_buffer_rsrc_t r, unsigned granule, float v0, float v1, unsigned tag) {
+__device__ __forceinline__ void px_publish2(__amdgpu_buffer_rsrc_t r, unsigned granule, float v0, float v1, unsigned tag,
+                                            bool xcd_local = false) {
   u32x4 g;
   g[0] = __float_as_uint(v0); g[1] = tag;
   g[2] = __float_as_uint(v1); g[3] = tag;
-  px_st(r, granule * 8u, g);
+  if (xcd_local) px_st_l2(r, granule * 8u, g);
+  else px_st(r, granule * 8u, g);
+}
+
+// The 16 x 16 grid by XCD affinity.  Workgroups b and b + 8 share an XCD under the dispatcher's round-robin placement (observed,
+// never promised): with nblk a multiple of 128 the workgroups are renumbered L = (b % 8) (nblk / 8) + b / 8, so that the 16
+// workgroups of a ROW (hop 1) are workgroups of one residue class.  The renumbering itself is placement-independent: it only
+// decides which records a workgroup sums, in which order.
+#ifndef PX_AFFINE_GRID      // the product keeps the plain 16 x 16 grid (see "measured, not shipped" below); px_test.hip defines it
+#define PX_AFFINE_GRID 0
+#endif
+__device__ __forceinline__ bool px_affine(int nblk) { return PX_AFFINE_GRID && (nblk & 127) == 0; }
+__device__ __forceinline__ int px_logical(int b, int nblk) { return px_affine(nblk) ? (b & 7) * (nblk >> 3) + (b >> 3) : b; }
+__device__ __forceinline__ int px_physical(int L, int nblk) {
+  if (!px_affine(nblk)) return L;
+  const int cs = nblk >> 3;
+  return (L % cs) * 8 + L / cs;
+}
+
+// Hop 1 through the XCD's own L2 (round 4: built, verified, measured -- NOT shipped: the kernels in dec_persist.hip do not call
+// px_announce and pass no decision word).  In the harness the exchange drops from 3.3-3.9 to 2.4-2.9 us and all 256 workgroups
+// decide for the L2 path; in the train step the same change bought 4 us of 1590 (1.5896 -> 1.5854 ms, 3 x 300 steps): the forward
+// rollout already hides hop 1 under a hidden-side product, and in both rollouts the wait is for the LAST workgroup to publish,
+// not for the fabric.  A quarter of a percent does not pay for a second memory-ordering regime in the kernels that everything
+// else depends on.  What was built:
+// A record published with PLAIN stores stays in the publishing XCD's L2, where the
+// sc1 loads of a reader ON THE SAME XCD find it without the fabric round trip (MI355X_MICROARCH.md, stores / loads table:
+// "plain KEEP the line in the XCD's L2", "sc1 loads bypass L1 only"): publish -> row sums visible ~1.0 -> ~0.4 us, the exchange
+// 3.3-3.9 -> 2.4-2.9 us (gpurun_tools/px_test.hip, last argument).  A reader on ANOTHER XCD would never see such a record, and
+// placement is not promised -- so it is verified, per launch and per row, with what the hardware reports:
+//   * every workgroup announces the XCC it runs on (HW_REG_XCC_ID, + 1 so that the cleared word means "not yet") in word 1 of its
+//     flag line, write-through, acknowledged (vmcnt(0)) in front of the workgroup barrier that precedes its first publish;
+//   * the FIRST exchange of a launch is published write-through (the placement-independent form);
+//   * behind its first hop 1 -- every row mate has published, hence announced -- a workgroup reads its 16 row mates' words: all
+//     equal => this row's records go through L2 from now on.  All 16 see the same 16 words: the row decides as one, and the
+//     readers' loads are the same sc1 loads either way.  Rows that are not on one XCD (placement other than round-robin, nblk not
+//     a multiple of 128) simply stay write-through.  Hop 2 crosses XCDs by construction and is always write-through.
+// The decision lives in one LDS word of the kernel (*xl: -1 undecided, 0 write-through, 1 through L2).
+__device__ __forceinline__ void px_announce(const PersistX& x, int b, int* xl) {      // ONE lane, in front of a workgroup barrier
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  *xl = -1;
+  __hip_atomic_store(x.yflag + (size_t)b * PX_FLAG_STRIDE + 1, (xcc & 0xfu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ int px_row_on_one_xcd(const PersistX& x, int nblk, int b) {
+  if (!px_affine(nblk)) return 0;
+  const int row = px_logical(b, nblk) / PX_GROUP;
+  unsigned first = 0u;
+  bool same = true;
+#pragma unroll
+  for (int m = 0; m < PX_GROUP; ++m) {
+    const unsigned v = __hip_atomic_load(x.yflag + (size_t)px_physical(row * PX_GROUP + m, nblk) * PX_FLAG_STRIDE + 1,
+                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (m == 0) first = v;
+    same = same && v == first && v != 0u;
+  }
+  return same ? 1 : 0;
 }
 
 // Column sums of `n` (<= 16) records of 128 granules each -> tot[128] (LDS), by all 256 threads, fixed order.
@@ -171,11 +232,16 @@ __device__ __forceinline__ void px_sweep_sum(const unsigned long long* base, int
 //             over all nblk workgroups, bit-identical in every workgroup.
 template <class Filler = PxNoFiller>
 __device__ __forceinline__ void px_hop1(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid,
-                                        Filler&& filler = Filler()) {
-  const int row = b / PX_GROUP;
+                                        int* xl = nullptr, Filler&& filler = Filler()) {
+  const int row = px_logical(b, nblk) / PX_GROUP;
   const int n = min(PX_GROUP, nblk - row * PX_GROUP);
-  px_sweep_sum(x.rec1 + (size_t)par * PX_MAX_NBLK * PX_COLS, n, [&](int m) { return row * PX_GROUP + m; }, tag, red, tot, tid, 0,
-               static_cast<Filler&&>(filler));
+  px_sweep_sum(x.rec1 + (size_t)par * PX_MAX_NBLK * PX_COLS, n, [&](int m) { return px_physical(row * PX_GROUP + m, nblk); }, tag,
+               red, tot, tid, 0, static_cast<Filler&&>(filler));
+  if (xl != nullptr && *xl < 0) {      // (uniform) the launch's first exchange: may this row's records go through L2 from now on?
+    const int v = px_row_on_one_xcd(x, nblk, b);
+    lds_barrier();                     // every thread has read *xl
+    if (tid == 0) *xl = v;             // (visible behind the barrier below)
+  }
   if (tid < 64) {
     __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(x.rec2 + ((size_t)par * PX_MAX_NBLK + b) * PX_COLS, 0,
                                                                   PX_COLS * 8, 0x00020000);
@@ -187,17 +253,17 @@ template <class Filler = PxNoFiller>
 __device__ __forceinline__ void px_hop2(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot, int tid,
                                         Filler&& filler = Filler()) {
   const int nrow = (nblk + PX_GROUP - 1) / PX_GROUP;
-  const int col = b % PX_GROUP;
+  const int col = px_logical(b, nblk) % PX_GROUP;
   px_sweep_sum(x.rec2 + (size_t)par * PX_MAX_NBLK * PX_COLS, nrow,
-               [&](int m) { return m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP); }, tag, red, tot, tid, 3,
-               static_cast<Filler&&>(filler));
+               [&](int m) { return px_physical(m * PX_GROUP + col % min(PX_GROUP, nblk - m * PX_GROUP), nblk); }, tag, red, tot,
+               tid, 3, static_cast<Filler&&>(filler));
 }
 // One row of workgroups only (nblk <= PX_GROUP, i.e. batches up to 256 rows -- the reference's own 128): the row sum hop 1
 // leaves in tot IS the total (hop 2 would add one record to zero: the same bits), so the second hop is skipped.
 __device__ __forceinline__ bool px_two_hops(int nblk) { return nblk > PX_GROUP; }
 __device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned tag, int nblk, int b, float* red, float* tot,
-                                            int tid) {
-  px_hop1(x, par, tag, nblk, b, red, tot, tid);
+                                            int tid, int* xl = nullptr) {
+  px_hop1(x, par, tag, nblk, b, red, tot, tid, xl);
   if (px_two_hops(nblk)) px_hop2(x, par, tag, nblk, b, red, tot, tid);
 }
 
