@@ -222,6 +222,17 @@ __device__ __forceinline__ float ldg_sync(const float* p) {
   asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
   return v;
 }
+// the same for the five dwords one thread of the rare paths needs per 4-element group (four target values, the group's keep
+// flags): five requests in flight, ONE wait -- one memory round trip per group instead of five
+__device__ __forceinline__ void ldg_sync5(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
+                                          float (&v)[4], uint32_t& w) {
+  asm volatile(
+      "global_load_dword %0, %5, off\n\tglobal_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\t"
+      "global_load_dword %3, %8, off\n\tglobal_load_dword %4, %9, off\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(w)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3), "v"(p4)
+      : "memory");
+}
 
 __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -516,13 +527,22 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
       const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
       for (int e4 = tid; e4 < (16 * D) / 4; e4 += 256) {
         const int e = 4 * e4;
-        float yv[4], sv_[4];
-        if (t == 0) {
+        float yv[4], sv_[4], tv[4];
+        uint32_t kraw;
+        {   // target frame t of the group's four elements (frame 0 IS y_0, :1039-1040) and its keep flags: one round trip
+          const float* tp[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int r = (e + j) / D, c = (e + j) - r * D;
-            yv[j] = ldg_sync(a.target + ((int64_t)(b0 + r) * T) * D + c);         // y_0 = target frame 0 (:1039-1040)
+            tp[j] = a.target + ((int64_t)(b0 + r) * T + t) * D + c;
           }
+          const bool needk = has_next && a.conditioned;
+          ldg_sync5(tp[0], tp[1], tp[2], tp[3], needk ? reinterpret_cast<const float*>(kp4 + e4) : tp[0], tv, kraw);
+          if (!needk) kraw = 0u;
+        }
+        if (t == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) yv[j] = tv[j];
         } else {
           const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
           yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
@@ -531,13 +551,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
         if (!has_next) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          sv_[j] = yv[j];
-          if (teacher && t > 0) {
-            const int r = (e + j) / D, c = (e + j) - r * D;
-            sv_[j] = ldg_sync(a.target + ((int64_t)(b0 + r) * T + t) * D + c);
-          }
+          sv_[j] = (teacher && t > 0) ? tv[j] : yv[j];
         }
-        const uint32_t k4 = a.conditioned ? __float_as_uint(ldg_sync(reinterpret_cast<const float*>(kp4 + e4))) : 0u;
+        const uint32_t k4 = kraw;
         float xv[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;     // 1 / (1 - 0.95)
@@ -847,13 +863,22 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
         const uint32_t* kp4 = reinterpret_cast<const uint32_t*>(a.keep95 + tile);
         for (int e4 = tid; e4 < n4v; e4 += 256) {
           const int e = 4 * e4;
-          float yv[4], sv_[4];
-          if (t == 0) {
+          float yv[4], sv_[4], tv[4];
+          uint32_t kraw;
+          {   // (as in the one-tile kernel: the group's target frame t and keep flags in one round trip)
+            const float* tp[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
               const int rr = (e + j) / D, c = (e + j) - rr * D;
-              yv[j] = ldg_sync(a.target + ((int64_t)(b0 + rr) * T) * D + c);
+              tp[j] = a.target + ((int64_t)(b0 + rr) * T + t) * D + c;
             }
+            const bool needk = has_next && a.conditioned;
+            ldg_sync5(tp[0], tp[1], tp[2], tp[3], needk ? reinterpret_cast<const float*>(kp4 + e4) : tp[0], tv, kraw);
+            if (!needk) kraw = 0u;
+          }
+          if (t == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) yv[j] = tv[j];
           } else {
             const float4 y4 = reinterpret_cast<const float4*>(Yt)[e4];
             yv[0] = y4.x; yv[1] = y4.y; yv[2] = y4.z; yv[3] = y4.w;
@@ -862,13 +887,9 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
           if (!has_next) continue;
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            sv_[j] = yv[j];
-            if (teacher && t > 0) {
-              const int rr = (e + j) / D, c = (e + j) - rr * D;
-              sv_[j] = ldg_sync(a.target + ((int64_t)(b0 + rr) * T + t) * D + c);
-            }
+            sv_[j] = (teacher && t > 0) ? tv[j] : yv[j];
           }
-          const uint32_t k4 = a.conditioned ? __float_as_uint(ldg_sync(reinterpret_cast<const float*>(kp4 + e4))) : 0u;
+          const uint32_t k4 = kraw;
           float xv[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) xv[j] = ((k4 >> (8 * j)) & 0xffu) ? sv_[j] * 20.0f : 0.f;
