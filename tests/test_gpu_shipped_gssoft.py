@@ -141,9 +141,10 @@ def test_fused_soft_quantiser_step_equals_the_autograd_path(B, p, mode, monkeypa
         assert ("gs_probs" in eng.buffers(B)) == (fused == "1")
         if fused == "1" and mode == "graph":
             assert getattr(eng, "_iter_graph", None) and eng._iter_graph["graph"], "the large-batch iteration was to be replayed"
-        out[fused] = (losses, eng.flat.clone())
+        out[fused] = (losses, eng.flat.clone(), int(net.decoder.decoder.pre_linear[1].num_batches_tracked))
     for (l0, p0), (l1, p1) in zip(out["0"][0], out["1"][0]):
         assert abs(l0 - l1) <= 2e-5 * abs(l0) and abs(p0 - p1) <= 1e-4 * abs(p0), (l0, l1, p0, p1)
+    assert out["0"][2] == out["1"][2] == len(xs) * (T - 1)      # BatchNorm's call counter: bumped by the fused step itself (side branch)
     err = float((out["0"][1] - out["1"][1]).abs().max())
     # a few per cent of the 4 Adam steps' lr: Adam turns the RELATIVE rounding difference of a small gradient element into a
     # difference of that fraction of lr (the engine's quantiser is one fused kernel each way since round 4, csrc/vq_soft.hip,
