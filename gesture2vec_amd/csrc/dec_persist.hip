@@ -213,17 +213,11 @@ __device__ __forceinline__ void cell_epilogue(const f32x4 (&ai)[3], const f32x4 
   }
 }
 
-// One dword from global memory, waited for on the spot, invisible to hipcc's wait-count pass.  For the rollout's RARE paths
-// (y_0 = target frame 0, teacher-forced steps): as ordinary loads their target registers stay "possibly pending" in the pass's
+// Loads of the rollout's RARE paths (y_0 = target frame 0, teacher-forced steps), issued and waited for on the spot inside one asm
+// statement, invisible to hipcc's wait-count pass: as ordinary loads their target registers stay "possibly pending" in the pass's
 // view of the time-step loop, and it waits vmcnt(0) at the top of EVERY step -- behind the keep-flag requests and in front of the
-// hidden-side products that are there to hide the exchange (ISA, round 4).
-__device__ __forceinline__ float ldg_sync(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-// the same for the five dwords one thread of the rare paths needs per 4-element group (four target values, the group's keep
-// flags): five requests in flight, ONE wait -- one memory round trip per group instead of five
+// hidden-side products that are there to hide the exchange (ISA, round 4).  The five dwords one thread needs per 4-element group
+// (four target values, the group's keep flags): five requests in flight, ONE wait.
 __device__ __forceinline__ void ldg_sync5(const float* p0, const float* p1, const float* p2, const float* p3, const float* p4,
                                           float (&v)[4], uint32_t& w) {
   asm volatile(
