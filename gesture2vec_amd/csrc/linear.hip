@@ -514,11 +514,16 @@ template <int KS4, bool MAPPED>
 __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict__ A, RowMap am,
                                                          const float* __restrict__ W, const float* __restrict__ bias,
                                                          float* __restrict__ Cout, int64_t ldc, int M, int C, int act) {
-  __shared__ __attribute__((aligned(16))) float4 Wp[KS4 * 64];   // [s][lane] = W[{0,16,32,48} + i][4 s + q]
+  // k-slot q of k-step s is input column KS4 q + s (any assignment of columns to (step, slot) pairs works as long as the weight
+  // image uses the same one): a lane's KS4 operands are KS4 ADJACENT floats of its row -- 16-byte loads (4-byte aligned: rows of
+  // 135 floats; legal on gfx950, gpurun_tools/unaligned_x4_test.hip) instead of KS4 dword loads
+  typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+  static_assert(KS4 % 4 == 2, "KS4 = 4 j + 2: whole 16-byte loads plus two dwords");
+  __shared__ __attribute__((aligned(16))) float4 Wp[KS4 * 64];   // [s][lane] = W[{0,16,32,48} + i][KS4 q + s]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
   for (int e = tid; e < KS4 * 64; e += 256) {
-    const int s2 = e >> 6, l = e & 63, c = 4 * s2 + (l >> 4), n = l & 15;
+    const int s2 = e >> 6, l = e & 63, c = KS4 * (l >> 4) + s2, n = l & 15;
     const bool ok = c < C;
     const int cc = ok ? c : 0;
     const float w0 = W[(int64_t)n * C + cc], w1 = W[(int64_t)(n + 16) * C + cc], w2 = W[(int64_t)(n + 32) * C + cc],
@@ -532,10 +537,12 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
   __syncthreads();
   const int ngroups = M >> 4;                         // M is a multiple of 16 (checked by the launcher)
   const int gstride = gridDim.x * 4;
-  // clamped column of the last (ragged) k-step: the matching weight is zero, any finite x value of the row will do
-  const int col_last = min(4 * (KS4 - 1) + q, C - 1);
+  // the lane's run of columns, and the clamped column of a slot past the row (its weight is zero: any finite value will do)
+  const int c0 = KS4 * q;
+  const int c_a = min(c0 + KS4 - 2, C - 1) - c0, c_b = min(c0 + KS4 - 1, C - 1) - c0;
+  constexpr int NV = KS4 / 4;                          // 16-byte loads per row
   float xa[KS4], xn[KS4];
-  auto load_group = [&](int grp, float (&x)[KS4]) {
+  auto row_ptr = [&](int grp) {
     const int m = 16 * grp + i;
     int64_t off;
     if (MAPPED) {
@@ -544,42 +551,45 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
     } else {
       off = (int64_t)m * am.ld;
     }
-    const float* p = A + off;
-    const float* pq = p + q;
-#pragma unroll
-    for (int s2 = 0; s2 < KS4 - 1; ++s2) x[s2] = pq[4 * s2];
-    x[KS4 - 1] = p[col_last];
+    return A + off + c0;
+  };
+  auto load_piece = [&](const float* p, int k, float (&x)[KS4]) {      // piece k of NV + 2
+    if (k < NV) {
+      const f4u v = *reinterpret_cast<const f4u*>(p + 4 * k);
+      x[4 * k] = v[0]; x[4 * k + 1] = v[1]; x[4 * k + 2] = v[2]; x[4 * k + 3] = v[3];
+    } else if (k == NV) {
+      x[KS4 - 2] = p[c_a];
+    } else {
+      x[KS4 - 1] = p[c_b];
+    }
   };
   int g = blockIdx.x * 4 + wave;
-  if (g < ngroups) load_group(g, xa);
-  for (; g < ngroups; g += gstride) {
-    // the next group's KS4 operand loads are issued one per k-step, BETWEEN the MFMAs (a burst in front of them would
-    // stall the wave on the vector-memory front end with an idle matrix pipe)
-    const int gn = min(g + gstride, ngroups - 1);      // past the end: a valid, unused group
-    const int mn = 16 * gn + i;
-    int64_t offn;
-    if (MAPPED) {
-      const int outer = mn / am.rows_inner, inner = mn - outer * am.rows_inner;
-      offn = (int64_t)outer * am.so + (int64_t)inner * am.si;
-    } else {
-      offn = (int64_t)mn * am.ld;
-    }
-    const float* pn = A + offn;
-    const float* pqn = pn + q;
+  if (g < ngroups) {
+    const float* p = row_ptr(g);
+#pragma unroll
+    for (int k = 0; k < NV + 2; ++k) load_piece(p, k, xa);
+  }
+  // one group: multiply `cur` (loaded while the previous group was multiplied), stream the next group into `nxt` BETWEEN the
+  // MFMAs, one load every few k-steps (a burst in front of them would stall the wave on the vector-memory front end with an idle
+  // matrix pipe).  Called with the two buffers in alternating roles: no register copies, each k-step waits for its own operand.
+  auto group = [&](int gc, const float (&cur)[KS4], float (&nxt)[KS4]) {
+    const int gn = min(gc + gstride, ngroups - 1);      // past the end: a valid, unused group
+    const float* pn = row_ptr(gn);
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    constexpr int EVERY = KS4 / (NV + 2);              // k-steps between two loads
 #pragma unroll
     for (int s2 = 0; s2 < KS4; ++s2) {
       const float4 wa = Wp[s2 * 64 + lane];
-      acc[0] = mfma16(wa.x, xa[s2], acc[0]);
-      acc[1] = mfma16(wa.y, xa[s2], acc[1]);
-      acc[2] = mfma16(wa.z, xa[s2], acc[2]);
-      acc[3] = mfma16(wa.w, xa[s2], acc[3]);
-      xn[s2] = (s2 < KS4 - 1) ? pqn[4 * s2] : pn[col_last];
+      acc[0] = mfma16(wa.x, cur[s2], acc[0]);
+      acc[1] = mfma16(wa.y, cur[s2], acc[1]);
+      acc[2] = mfma16(wa.z, cur[s2], acc[2]);
+      acc[3] = mfma16(wa.w, cur[s2], acc[3]);
+      if (s2 % EVERY == 0 && s2 / EVERY < NV + 2) load_piece(pn, s2 / EVERY, nxt);
       __builtin_amdgcn_sched_barrier(0);
     }
-    float* crow = Cout + (int64_t)(16 * g + i) * ldc + 4 * q;
+    float* crow = Cout + (int64_t)(16 * gc + i) * ldc + 4 * q;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       float4 v = make_float4(acc[t][0] + bia[t].x, acc[t][1] + bia[t].y, acc[t][2] + bia[t].z, acc[t][3] + bia[t].w);
@@ -587,8 +597,13 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
       *reinterpret_cast<float4*>(crow + 16 * t) = v;
     }
     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int s2 = 0; s2 < KS4; ++s2) xa[s2] = xn[s2];
+  };
+  while (g < ngroups) {
+    group(g, xa, xn);
+    g += gstride;
+    if (g >= ngroups) break;
+    group(g, xn, xa);
+    g += gstride;
   }
 }
 
