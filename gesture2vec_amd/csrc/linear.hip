@@ -598,6 +598,7 @@ __global__ __launch_bounds__(256) void gemm_nt_k4_kernel(const float* __restrict
     }
     __builtin_amdgcn_sched_barrier(0);
   };
+  // (three buffers, the loads two groups ahead: measured 39.4 us alone against 37.1 with two, the train step the same)
   while (g < ngroups) {
     group(g, xa, xn);
     g += gstride;
