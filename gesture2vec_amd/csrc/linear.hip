@@ -1172,6 +1172,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(128))) void gem
   tn_wave_body<TN_, TK_, SN, SK, MAPPED, 1, false, 2, true>(bt, lddy, xm, M, K, N, rows_per_wave);
 }
 
+// (Round 4, tried: a 4 x 13 block for K = 200 -- 13 tiles, no padding tile, no second K block.  208 accumulators + two operand
+//  buffers of 4 x 17: 512 registers AND 276-444 bytes of scratch per lane; not launched.)
 // block shape of the output-blocked variant: 0 = 192 x 64 (TN 6, TK 4), 1 = 128 x 112 (TN 4, TK 7); the one that pads N x K
 // the least.  Returns the number of output blocks; rows per wave / row splits sized for ~256 workgroups per launch.
 static int tn_gen_grid(int M, int K, int N, bool has_keep, int nprob, int* cfg, int* rows_per_wave, int* nsplit) {
