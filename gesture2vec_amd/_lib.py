@@ -50,6 +50,26 @@ class GruDirBwd(C.Structure):
                 [(n, c_fp) for n in ("hn_z", "hn_q", "hn_gloss")] + [("hn_coef", c_f)])         # optional fused quantiser backward
 
 
+class CodeDecWeights(C.Structure):
+    """g2v_code_dec_weights"""
+    _fields_ = [(n, c_fp) for n in (
+        "emb", "w_pre", "b_pre", "bn_w", "bn_b", "bn_running_mean", "bn_running_var",
+        "w_ih0", "w_hh0", "b_ih0", "b_hh0", "w_ih1", "w_hh1", "b_ih1", "b_hh1", "w_out", "b_out", "w_attn", "b_attn", "v_attn")]
+
+
+class CodeDecSaved(C.Structure):
+    """g2v_code_dec_saved"""
+    _fields_ = [(n, c_fp) for n in (
+        "ids", "ec", "u", "a", "bn_stats", "h0", "h1", "x1", "gates0", "gates1", "logits", "bn_partial", "hp", "attw")]
+
+
+class CodeDecGrads(C.Structure):
+    """g2v_code_dec_grads"""
+    _fields_ = [(n, c_fp) for n in (
+        "d_hidden0", "d_emb", "d_w_pre", "d_b_pre", "d_bn_w", "d_bn_b", "d_w_ih0", "d_w_hh0", "d_b_ih0", "d_b_hh0",
+        "d_w_ih1", "d_w_hh1", "d_b_ih1", "d_b_hh1", "d_w_out", "d_b_out", "d_w_attn", "d_b_attn", "d_v_attn", "d_enc")]
+
+
 class DecGrads(C.Structure):
     """g2v_dec_grads"""
     _fields_ = [(n, c_fp) for n in (
@@ -97,6 +117,8 @@ _SIGS = {
     "g2v_gru_seq_fwd_prepared": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_prepared": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_prepare": (c_int, [C.POINTER(DecWeights), c_int, c_int, c_fp, c_sz, c_fp, c_sz, c_fp]),
+    "g2v_train_step_prepare": (c_int, [C.POINTER(DecWeights), c_int, c_int, c_fp, c_sz, c_fp, c_sz, c_fp, c_fp, c_int, c_int, c_fp,
+                                       c_sz, c_fp]),
     "g2v_dec_rollout_fwd_prepared": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,
                                              c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_bwd_prepared": (c_int, [C.POINTER(DecWeights), C.POINTER(DecSaved), C.POINTER(DecGrads), c_fp, c_fp,
@@ -150,6 +172,15 @@ _SIGS = {
     "g2v_attn_bwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_attn_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                              c_fp, c_sz, c_fp]),
+    "g2v_attn_code_rollout_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "g2v_attn_code_rollout_blocks": (c_int, [c_int]),
+    "g2v_attn_code_rollout_fwd_workspace": (c_sz, [c_int, c_int, c_int]),
+    "g2v_attn_code_rollout_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, C.POINTER(CodeDecWeights), C.POINTER(CodeDecSaved), c_fp, c_fp, c_f,
+                                          c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
+    "g2v_attn_code_rollout_bwd_workspace": (c_sz, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "g2v_attn_code_rollout_bwd": (c_int, [c_fp, c_fp, c_fp, C.POINTER(CodeDecWeights), C.POINTER(CodeDecSaved),
+                                          C.POINTER(CodeDecGrads), c_fp, c_fp, c_f, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz,
+                                          c_fp]),
     "g2v_probe_mfma_f32": (c_int, [c_fp, c_int, c_int, c_fp]),
     "g2v_probe_copy": (c_int, [c_fp, c_fp, c_i64, c_fp]),
     "g2v_keep_mask": (c_int, [c_fp, c_i64, c_f, c_u64, c_fp, c_fp]),

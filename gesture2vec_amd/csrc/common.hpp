@@ -181,8 +181,7 @@ struct PackBatch {
   PackDesc d[MAX_PACK];
   int n;
 };
-static __global__ __launch_bounds__(256) void pack_kernel(PackBatch pb) {
-  const PackDesc d = pb.d[blockIdx.y];
+__device__ __forceinline__ void pack_one(const PackDesc& d) {
   const int ntg = d.ntile_alloc > 0 ? d.ntile_alloc : ((d.rows_per_group + 15) >> 4), KS = (d.K + 15) >> 4;
   const int nblocks = d.ngroups * ntg * KS;            // one 256-float block per (tile, kstep) = 64 lanes x 4
   for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
@@ -198,6 +197,30 @@ static __global__ __launch_bounds__(256) void pack_kernel(PackBatch pb) {
     }
     d.dst[(int64_t)blk * 256 + threadIdx.x] = v;
   }
+}
+static __global__ __launch_bounds__(256) void pack_kernel(PackBatch pb) { pack_one(pb.d[blockIdx.y]); }
+// The packs of SEVERAL launches' workspaces plus the zero-fill of up to two regions (16-byte aligned, multiples of 16 bytes:
+// the persistent rollouts' exchange records) as ONE launch: g2v_train_step_prepare.
+constexpr int MAX_PACK_L = 16, MAX_FILL = 2;
+struct PackBatchL {
+  PackDesc d[MAX_PACK_L];
+  int n, nfill;
+  float4* fill_dst[MAX_FILL];
+  int64_t fill_n4[MAX_FILL];
+};
+static __global__ __launch_bounds__(256) void pack_fill_kernel(PackBatchL pb) {
+  if ((int)blockIdx.y < pb.n) {
+    pack_one(pb.d[blockIdx.y]);
+    return;
+  }
+  const int k = blockIdx.y - pb.n;
+  float4* dst = pb.fill_dst[k];
+  const int64_t n4 = pb.fill_n4[k];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n4; e += (int64_t)gridDim.x * 256)
+    dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+static inline void launch_pack_fill(const PackBatchL& pb, hipStream_t st) {
+  hipLaunchKernelGGL(pack_fill_kernel, dim3(64, pb.n + pb.nfill), dim3(256), 0, st, pb);
 }
 static inline void launch_pack(const PackBatch& pb, hipStream_t st) {
   hipLaunchKernelGGL(pack_kernel, dim3(64, pb.n), dim3(256), 0, st, pb);

@@ -1540,6 +1540,21 @@ extern "C" int g2v_gru_seq_fwd(const g2v_gru_dir* dirs, int ndir, const int32_t*
                                int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
   return gru_seq_fwd_impl(dirs, ndir, lengths, hs_ld, T, B, H, workspace, workspace_bytes, stream, false);
 }
+// g2v_train_step_prepare (dec_rollout.hip): the pack descriptors of g2v_gru_seq_prepare's BACKWARD workspace, appended to `out`
+// (returns how many; 0: this hidden size reads its weights in place, or the workspace is too small)
+namespace g2v {
+int gru_bwd_prepare_descs(const float* const* w_hh, const float* const* w_ih, int ndir, int H, bool fused, void* bwd_workspace,
+                          size_t bwd_bytes, PackDesc* out, int max_out) {
+  if (H != 64 || !bwd_workspace || bwd_bytes < g2v_gru_seq_bwd_workspace(ndir, H)) return 0;
+  const float* a[2];
+  const float* b[2];
+  const PackBatch pb = gru_bwd_packs(w_hh, w_ih, ndir, H, fused, (float*)bwd_workspace, a, b);
+  if (pb.n > max_out) return 0;
+  for (int k = 0; k < pb.n; ++k) out[k] = pb.d[k];
+  return pb.n;
+}
+}  // namespace g2v
+
 // as g2v_gru_seq_fwd / _bwd on workspaces that g2v_gru_seq_prepare has filled for THIS call (no pack launch)
 extern "C" int g2v_gru_seq_fwd_prepared(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T,
                                         int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {

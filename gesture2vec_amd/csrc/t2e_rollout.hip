@@ -1,0 +1,1076 @@
+// t2e_rollout.hip -- Part d: the greedy gesture-code decoder of text2embedding_model as fused per-step kernels
+// (g2v_attn_code_rollout_fwd / _bwd, SURVEY.md 8(b) K13 + K14).
+//
+// Replaces the loop model/text2embedding_model.py:701-744 over BahdanauAttnDecoderRNN.forward (:338-395) and its autograd:
+// per decode step  Embedding + Dropout(0.5) [-> Bahdanau attention context] -> Linear + BatchNorm1d + ReLU -> GRU (2 layers)
+// -> Linear(H -> K) -> argmax feedback.  Rounds 1-4 chained one launch per operator from Python (~30 launches per step with
+// torch cat / add / copy kernels between them).
+//
+// Structure (the pose decoder's, dec_rollout.hip): a step is row-local except for BatchNorm1d's batch statistics, and a kernel
+// boundary is the cheapest grid-wide seam on this chip, so the forward is S1 + 1 launches of one kernel, 16 batch rows per
+// 512-thread workgroup (two waves per SIMD: at H = 200 a wave streams ~0.3 MB of weight fragments per step out of L2):
+//
+//   launch j:  [tail of step j-1]  finish BN(u_{j-1}) from the per-workgroup partials -> ReLU -> GRU cell 0 -> inter-layer dropout
+//                                  -> GRU cell 1 -> out layer -> logits_{j-1} -> row argmax -> id_j
+//              [head of step j]    e_j = Embedding(id_j) * keep * 2 [-> hp = W_h h1_j + b -> energies -> softmax -> context]
+//                                  -> u_j = pre_linear(x_j) + per-workgroup partial sums of (u_j - b)
+//
+// Backward without attention: the argmax feedback carries no gradient and du_t feeds only weight / embedding gradients, so NO
+// grid-wide quantity sits on the chain between two steps: the BPTT over all S1 steps is ONE launch (state gradients carried in
+// LDS), then BatchNorm's backward for all steps at once, then the products over the S1 x B rows (data gradient of pre_linear,
+// embedding gradient, every weight gradient) as batched launches of the library's dense kernels.
+// Backward with attention: d(context_t) = du_t W_pre[:, H:] needs BatchNorm's backward sums of step t, and flows into h1_t: one
+// launch per step, [finish BN backward of step t+1 -> du_{t+1} -> d(ctx) -> attention backward -> d(h1) carry] + [cells of step t].
+#include <stdlib.h>
+
+#include "gru_cells.hpp"
+
+namespace g2v {
+
+constexpr int CT_NTHR = 512, CT_NW = CT_NTHR / 64;
+constexpr int CT_MAX_TW = 64;
+
+struct CodePackF {      // packed forward weights (fragment-major, common.hpp)
+  const float* pre;     // rows H, K = Hin
+  const float* ih0; const float* hh0; const float* ih1; const float* hh1;   // 3 gate groups x H rows, K = H
+  const float* out;     // rows K (tiles padded to a multiple of 4 * CT_NW), K = H
+  const float* attn_h;  // rows H, K = H  (W_attn[:, :H])
+};
+struct CodePackB {      // packed transposed weights for the backward
+  const float* out_t;   // rows H, K = Kdim   (W_out^T)
+  const float* ih0_t; const float* hh0_t; const float* ih1_t; const float* hh1_t;   // rows H, K = 3H
+  const float* pre_ctx_t;   // rows H (context features), K = H: W_pre[:, H:2H]^T          (attention)
+  const float* attn_h_t;    // rows H (state features), K = H: W_attn[:, :H]^T              (attention)
+};
+struct CodeDims {
+  int S1, B, H, K, Hin, Tw;
+  float p_drop;
+  int n_pre, training, nblk, att, scratch;
+};
+
+static inline int ct_ktiles_alloc(int K) { return round_up((K + 15) >> 4, 4 * CT_NW); }
+
+// LDS carve of the forward kernel (floats)
+struct CtFwdLds {
+  int xa, xh0, xh1, xx1, xh1n, xe, st, red, scratch, amv, amk, ids, sc, total;
+};
+static __host__ __device__ inline CtFwdLds ct_fwd_lds(int H, int Hin, int Tw, int scratch) {
+  const int Hp = (H + 15) & ~15, ldh = Hp + 4, ldx = ((Hin + 15) & ~15) + 4;
+  CtFwdLds l;
+  int o = 0;
+  l.xa = o; o += 16 * ldh;
+  l.xh0 = o; o += 16 * ldh;
+  l.xh1 = o; o += 16 * ldh;
+  l.xx1 = o; o += 16 * ldh;
+  l.xh1n = o; o += 16 * ldh;
+  l.xe = o; o += 16 * ldx;
+  l.st = o; o += 2 * Hp;
+  l.red = o; o += 2 * Hp;
+  l.scratch = o; o += scratch;
+  l.amv = o; o += CT_NW * 16;
+  l.amk = o; o += CT_NW * 16;
+  l.ids = o; o += 16;
+  l.sc = o; o += 16 * (Tw > 0 ? Tw : 1);
+  l.total = o;
+  return l;
+}
+
+// =====================================================================================================================
+// forward: launch j of S1 + 1
+// =====================================================================================================================
+__global__ __launch_bounds__(CT_NTHR) void code_step_fwd_kernel(const int64_t* __restrict__ codes, const float* __restrict__ h_init,
+                                                                const float* __restrict__ enc, const float* __restrict__ ep,
+                                                                g2v_code_dec_weights w, CodePackF pk, g2v_code_dec_saved sv,
+                                                                const uint8_t* __restrict__ keep_emb,
+                                                                const uint8_t* __restrict__ keep_l0, CodeDims dm, int j) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTHR = CT_NTHR, NW = CT_NW;
+  const int S1 = dm.S1, B = dm.B, H = dm.H, K = dm.K, Hin = dm.Hin, Tw = dm.Tw;
+  const int Hp = (H + 15) & ~15, ldh = Hp + 4, Hinp = (Hin + 15) & ~15, ldx = Hinp + 4;
+  const CtFwdLds L = ct_fwd_lds(H, Hin, Tw, dm.scratch);
+  float* Xa = smem + L.xa;          // a_t                [16][ldh]   (head, attention: hp)
+  float* Xh0 = smem + L.xh0;        // h0_t
+  float* Xh1 = smem + L.xh1;        // h1_t
+  float* Xx1 = smem + L.xx1;        // dropped h0_{t+1}
+  float* Xh1n = smem + L.xh1n;      // h1_{t+1}
+  float* Xe = smem + L.xe;          // x_j = [e_j | ctx_j] [16][ldx]
+  float* st = smem + L.st;          // mean[Hp], invstd[Hp]
+  float* red = smem + L.red;
+  float* red_scratch = smem + L.scratch;
+  float* amv = smem + L.amv;        // argmax: per wave and row, best value / index
+  int* amk = reinterpret_cast<int*>(smem + L.amk);
+  int* ids_l = reinterpret_cast<int*>(smem + L.ids);
+  float* sc = smem + L.sc;          // attention scores / weights [16][Tw]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * 16;
+  const int nrows = min(16, B - b0);
+  const int i = lane & 15, q = lane >> 4;
+  const int H4 = H >> 2;
+  const bool training = dm.training != 0;
+  const bool has_tail = j > 0, has_head = j < S1;
+  const int t = j - 1;                                   // the step whose tail this launch runs
+  const int npre = max(1, min(dm.n_pre, S1));            // steps fed from `codes` (teacher forcing :737-739; step 0 always)
+
+  // ---- prefetch this block's rows of u_t, h0_t, h1_t (written by the previous launch on some other CU) -------------------
+  constexpr int NPF = 2;                                  // 16 x H / 4 <= 1024 float4 (H <= 256)
+  float4 pu[NPF], ph0[NPF], ph1[NPF];
+  int pr[NPF], pc[NPF];
+  bool pv[NPF];
+#pragma unroll
+  for (int k = 0; k < NPF; ++k) {
+    const int e = tid + k * NTHR;
+    pr[k] = e / H4;
+    pc[k] = (e - pr[k] * H4) * 4;
+    pv[k] = e < 16 * H4 && pr[k] < nrows;
+    pu[k] = ph0[k] = ph1[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (pv[k]) {
+      if (has_tail) {
+        const int64_t row = ((int64_t)t * B + b0 + pr[k]) * H + pc[k];
+        pu[k] = *reinterpret_cast<const float4*>(sv.u + row);
+        ph0[k] = *reinterpret_cast<const float4*>(sv.h0 + row);
+        ph1[k] = *reinterpret_cast<const float4*>(sv.h1 + row);
+      } else {
+        ph0[k] = *reinterpret_cast<const float4*>(h_init + (int64_t)(b0 + pr[k]) * H + pc[k]);
+        ph1[k] = *reinterpret_cast<const float4*>(h_init + ((int64_t)B + b0 + pr[k]) * H + pc[k]);
+      }
+    }
+  }
+  // zero what the MFMA contractions must see as zero: padding columns, rows >= nrows
+  if (nrows < 16 || Hp != H || Hinp != Hin) {
+    for (int e = tid; e < 5 * 16 * ldh + 16 * ldx; e += NTHR) smem[e] = 0.f;
+  }
+  lds_barrier();
+
+  if (!has_tail) {
+    // state in front of step 0 = encoder_hidden[:2] (:667-669)
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (pv[k]) {
+        *reinterpret_cast<float4*>(sv.h0 + (int64_t)(b0 + pr[k]) * H + pc[k]) = ph0[k];
+        *reinterpret_cast<float4*>(sv.h1 + (int64_t)(b0 + pr[k]) * H + pc[k]) = ph1[k];
+        *reinterpret_cast<float4*>(Xh1n + pr[k] * ldh + pc[k]) = ph1[k];      // (attention of step 0 scores h1_0)
+      }
+  } else {
+    // ---- (a) BatchNorm statistics of u_t -------------------------------------------------------------------------------
+    if (training) {
+      const float* part = sv.bn_partial + (int64_t)(t & 1) * dm.nblk * 2 * H;
+      reduce_partials<NTHR>(part, dm.nblk, 2 * H, red, red_scratch, tid, dm.scratch);
+      for (int f = tid; f < H; f += NTHR) {
+        const float s1 = red[f], s2 = red[H + f];
+        const float mv = s1 / (float)B;
+        const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);   // biased batch variance
+        const float mean = mv + w.b_pre[f];
+        const float invstd = bn_invstd_(var);
+        st[f] = mean;
+        st[Hp + f] = invstd;
+        if (blockIdx.x == 0) {
+          sv.bn_stats[(int64_t)t * 2 * H + f] = mean;
+          sv.bn_stats[(int64_t)t * 2 * H + H + f] = invstd;
+          // running statistics: momentum 0.1, unbiased variance; one update per decode step, in step order (stream order)
+          const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
+          w.bn_running_mean[f] = 0.9f * w.bn_running_mean[f] + 0.1f * mean;
+          w.bn_running_var[f] = 0.9f * w.bn_running_var[f] + 0.1f * unb;
+        }
+      }
+    } else {
+      for (int f = tid; f < H; f += NTHR) {
+        st[f] = w.bn_running_mean[f];
+        st[Hp + f] = bn_invstd_(w.bn_running_var[f]);
+      }
+    }
+    lds_barrier();
+    // ---- (b) a_t = ReLU(BN(u_t)); stage the previous hidden states -----------------------------------------------------
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (pv[k]) {
+        const int c = pc[k];
+        const float4 g4 = *reinterpret_cast<const float4*>(w.bn_w + c), b4 = *reinterpret_cast<const float4*>(w.bn_b + c);
+        const float4 m4 = *reinterpret_cast<const float4*>(st + c), i4 = *reinterpret_cast<const float4*>(st + Hp + c);
+        float4 a4;
+        a4.x = fmaxf((pu[k].x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+        a4.y = fmaxf((pu[k].y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+        a4.z = fmaxf((pu[k].z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+        a4.w = fmaxf((pu[k].w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+        *reinterpret_cast<float4*>(Xa + pr[k] * ldh + c) = a4;
+        *reinterpret_cast<float4*>(Xh0 + pr[k] * ldh + c) = ph0[k];
+        *reinterpret_cast<float4*>(Xh1 + pr[k] * ldh + c) = ph1[k];
+        if (sv.a) *reinterpret_cast<float4*>(sv.a + ((int64_t)t * B + b0 + pr[k]) * H + c) = a4;
+      }
+    lds_barrier();
+    // ---- (c) GRU layer 0, (d) GRU layer 1 ------------------------------------------------------------------------------
+    const bool drop = training && keep_l0 && dm.p_drop > 0.f;
+    gru_cell_fwd<0>(pk.ih0, pk.hh0, w.b_ih0, w.b_hh0, Xa, Xh0, ldh, H, Hp, Xx1, sv.h0 + ((int64_t)(t + 1) * B + b0) * H,
+                    sv.gates0 ? sv.gates0 + ((int64_t)t * B + b0) * 4 * H : nullptr,
+                    drop ? keep_l0 + ((int64_t)t * B + b0) * H : nullptr, 1.0f / (1.0f - dm.p_drop),
+                    (drop && sv.x1) ? sv.x1 + ((int64_t)t * B + b0) * H : nullptr, nrows, lane, wave, NW);
+    lds_barrier();
+    gru_cell_fwd<0>(pk.ih1, pk.hh1, w.b_ih1, w.b_hh1, Xx1, Xh1, ldh, H, Hp, Xh1n, sv.h1 + ((int64_t)(t + 1) * B + b0) * H,
+                    sv.gates1 ? sv.gates1 + ((int64_t)t * B + b0) * 4 * H : nullptr, nullptr, 1.0f, nullptr, nrows, lane, wave,
+                    NW);
+    lds_barrier();
+    // ---- (e) logits_t = out(h1_{t+1}); row argmax (greedy feedback :740-744) -------------------------------------------
+    {
+      const int ntile = (K + 15) >> 4;
+      float bv = -INFINITY;
+      int bk = 0x7fffffff;
+      for (int base = 0; base < ntile; base += 4 * NW) {
+        f32x4 acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        wave_gemm_p<4, 0>(acc, pk.out, Hp >> 4, base + wave, NW, Xh1n, ldh, lane);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int k0 = 16 * (base + wave + NW * u) + 4 * q;
+          if (k0 + 3 < K) {
+            const float4 bo = *reinterpret_cast<const float4*>(w.b_out + k0);
+            const float v[4] = {acc[u][0] + bo.x, acc[u][1] + bo.y, acc[u][2] + bo.z, acc[u][3] + bo.w};
+            if (i < nrows) *reinterpret_cast<float4*>(sv.logits + ((int64_t)t * B + b0 + i) * K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (v[r] > bv) { bv = v[r]; bk = k0 + r; }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int k = k0 + r;
+              if (k >= K) continue;
+              const float v = acc[u][r] + w.b_out[k];
+              if (i < nrows) sv.logits[((int64_t)t * B + b0 + i) * K + k] = v;
+              if (v > bv) { bv = v; bk = k; }
+            }
+          }
+        }
+      }
+      // over the four lanes that hold row i (q = 0..3), then over the waves: the largest value, the lowest index among equals
+#pragma unroll
+      for (int o = 16; o < 64; o <<= 1) {
+        const float v2 = __shfl_xor(bv, o);
+        const int k2 = __shfl_xor(bk, o);
+        if (v2 > bv || (v2 == bv && k2 < bk)) { bv = v2; bk = k2; }
+      }
+      if (q == 0) {
+        amv[wave * 16 + i] = bv;
+        amk[wave * 16 + i] = bk;
+      }
+      lds_barrier();
+      if (tid < 16) {
+        float v = amv[tid];
+        int k = amk[tid];
+        for (int wv = 1; wv < NW; ++wv) {
+          const float v2 = amv[wv * 16 + tid];
+          const int k2 = amk[wv * 16 + tid];
+          if (v2 > v || (v2 == v && k2 < k)) { v = v2; k = k2; }
+        }
+        ids_l[tid] = (k >= 0 && k < K) ? k : 0;      // (a row of NaNs never compares greater: code 0)
+      }
+    }
+  }
+  if (!has_head) return;
+  lds_barrier();
+
+  // ---- head of step j: id_j -> e_j = Embedding(id_j) * keep * 2  (:340-343) ------------------------------------------------
+  if (tid < 16) {
+    int id = 0;
+    if (tid < nrows) {
+      if (j < npre) {
+        const int64_t c = codes[(int64_t)j * B + b0 + tid];
+        id = (c >= 0 && c < K) ? (int)c : 0;
+      } else {
+        id = ids_l[tid];
+      }
+      sv.ids[(int64_t)j * B + b0 + tid] = id;
+    }
+    ids_l[tid] = id;
+  }
+  lds_barrier();
+  {
+    const bool edrop = training && keep_emb != nullptr;
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (pv[k]) {
+        const int r = pr[k], c = pc[k];
+        float4 e4 = *reinterpret_cast<const float4*>(w.emb + (int64_t)ids_l[r] * H + c);
+        if (edrop) {
+          const uint32_t kp = *reinterpret_cast<const uint32_t*>(keep_emb + ((int64_t)j * B + b0 + r) * H + c);
+          e4.x = (kp & 0xffu) ? e4.x * 2.0f : 0.f;
+          e4.y = (kp & 0xff00u) ? e4.y * 2.0f : 0.f;
+          e4.z = (kp & 0xff0000u) ? e4.z * 2.0f : 0.f;
+          e4.w = (kp & 0xff000000u) ? e4.w * 2.0f : 0.f;
+        }
+        *reinterpret_cast<float4*>(Xe + r * ldx + c) = e4;
+        *reinterpret_cast<float4*>(sv.ec + ((int64_t)j * B + b0 + r) * Hin + c) = e4;
+      }
+  }
+  // ---- Bahdanau attention on h1_j (Attn.forward / score :160-198, context :353-359) ----------------------------------------
+  if (dm.att) {
+    float* Xhp = Xa;                   // a_t is dead
+    const int ntile = Hp >> 4;
+    lds_barrier();                     // (Xa readers of cell 0 are long past; ids / Xe writes above)
+    for (int ft = wave; ft < ntile; ft += NW) {
+      const int f0 = 16 * ft + 4 * q;
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, 0>(acc, pk.attn_h, Hp >> 4, ft, 0, Xh1n, ldh, lane);
+      if (f0 + 3 < H) {
+        const float4 ba = *reinterpret_cast<const float4*>(w.b_attn + f0);
+        const float4 h4 = make_float4(acc[0][0] + ba.x, acc[0][1] + ba.y, acc[0][2] + ba.z, acc[0][3] + ba.w);
+        *reinterpret_cast<float4*>(Xhp + i * ldh + f0) = h4;
+        if (i < nrows && sv.hp) *reinterpret_cast<float4*>(sv.hp + ((int64_t)j * B + b0 + i) * H + f0) = h4;
+      }
+    }
+    lds_barrier();
+    // scores: one thread per (row, position); 16 x Tw <= 1024 pairs
+    for (int p = tid; p < 16 * Tw; p += NTHR) {
+      const int r = p / Tw, tw = p - r * Tw;
+      float e = 0.f;
+      if (r < nrows) {
+        const float* epr = ep + ((int64_t)tw * B + b0 + r) * H;
+        const float* hpr = Xhp + r * ldh;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+        for (int c = 0; c < H; c += 4) {
+          const float4 p4 = *reinterpret_cast<const float4*>(epr + c), h4 = *reinterpret_cast<const float4*>(hpr + c);
+          const float4 v4 = *reinterpret_cast<const float4*>(w.v_attn + c);
+          e0 += v4.x * tanhf_(h4.x + p4.x);
+          e1 += v4.y * tanhf_(h4.y + p4.y);
+          e2 += v4.z * tanhf_(h4.z + p4.z);
+          e3 += v4.w * tanhf_(h4.w + p4.w);
+        }
+        e = (e0 + e1) + (e2 + e3);
+      }
+      sc[r * Tw + tw] = e;
+    }
+    lds_barrier();
+    if (tid < 16 && tid < nrows) {      // softmax over ALL Tw positions (the reference does not mask padded positions)
+      float mx = -INFINITY;
+      for (int tw = 0; tw < Tw; ++tw) mx = fmaxf(mx, sc[tid * Tw + tw]);
+      float sum = 0.f;
+      for (int tw = 0; tw < Tw; ++tw) sum += expf(sc[tid * Tw + tw] - mx);
+      const float inv = 1.0f / sum;
+      for (int tw = 0; tw < Tw; ++tw) {
+        const float ww = expf(sc[tid * Tw + tw] - mx) * inv;
+        sc[tid * Tw + tw] = ww;
+        if (sv.attw) sv.attw[((int64_t)j * B + b0 + tid) * Tw + tw] = ww;
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < NPF; ++k)
+      if (pv[k]) {
+        const int r = pr[k], c = pc[k];
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int tw = 0; tw < Tw; ++tw) {
+          const float ww = sc[r * Tw + tw];
+          const float4 n4 = *reinterpret_cast<const float4*>(enc + ((int64_t)tw * B + b0 + r) * H + c);
+          c4.x += ww * n4.x; c4.y += ww * n4.y; c4.z += ww * n4.z; c4.w += ww * n4.w;
+        }
+        *reinterpret_cast<float4*>(Xe + r * ldx + H + c) = c4;
+        *reinterpret_cast<float4*>(sv.ec + ((int64_t)j * B + b0 + r) * Hin + H + c) = c4;
+      }
+  }
+  lds_barrier();
+  // ---- u_j = pre_linear.0(x_j) and per-workgroup BatchNorm partial sums of (u - b) --------------------------------------------
+  {
+    const int ntile = Hp >> 4;
+    float* part = sv.bn_partial + ((int64_t)(j & 1) * dm.nblk + blockIdx.x) * 2 * H;
+    for (int ft = wave; ft < ntile; ft += NW) {
+      const int f0 = 16 * ft + 4 * q;
+      if (f0 + 3 >= H) continue;       // (H % 4 == 0: a group of four is whole or padding; the MFMA below is wave-uniform per ft)
+      const float4 bp = *reinterpret_cast<const float4*>(w.b_pre + f0);
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, 0>(acc, pk.pre, Hinp >> 4, ft, 0, Xe, ldx, lane);
+      float s1[4], s2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (i < nrows) ? acc[0][r] : 0.f;
+        s1[r] = reduce16(v);
+        s2[r] = reduce16(v * v);
+      }
+      if (i < nrows)
+        *reinterpret_cast<float4*>(sv.u + ((int64_t)j * B + b0 + i) * H + f0) =
+            make_float4(acc[0][0] + bp.x, acc[0][1] + bp.y, acc[0][2] + bp.z, acc[0][3] + bp.w);
+      if (i == 0) {
+        *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================
+// backward
+// =====================================================================================================================
+struct CodeBwdArgs {
+  const float* d_logits;     // (S1,B,K)
+  const float* enc; const float* ep;
+  g2v_code_dec_weights w;
+  CodePackB tw;
+  g2v_code_dec_saved sv;
+  const uint8_t* keep_l0;
+  float* dgi0; float* dgh0; float* dgi1; float* dgh1;     // (S1,B,3H)
+  float* dbn;                // (S1,B,H)   d loss / d BN output (behind the ReLU mask)
+  float* du;                 // (S1,B,H)
+  float* dec;                // (S1,B,H)   d loss / d e_t (the embedding half of d x_t)
+  float* dhp;                // (S1,B,H)   attention: d loss / d hp_t
+  float* d_ep; float* d_enc; // (Tw,B,H)   attention: accumulated over the steps by the owning workgroup
+  float* dv_partial;         // (nblk,H)   attention: per-workgroup sums of d v, accumulated over the steps
+  float* bn_part;            // (S1,nblk,2,H) per-workgroup sums of BN backward, one slot per step
+  float* bn_sums;            // (S1,2,H)
+  float* d_hidden0;          // (2,B,H)
+};
+
+struct CtBwdLds {
+  int xdl, gi, gh, dd, xdx, c0, c1, st, red, scratch, sc, total;
+};
+static __host__ __device__ inline CtBwdLds ct_bwd_lds(int H, int K, int Tw, int scratch, bool att) {
+  const int Hp = (H + 15) & ~15, ldh = Hp + 4, Gp = (3 * H + 15) & ~15, ldg = Gp + 4, Kp = (K + 15) & ~15, ldk = Kp + 4;
+  CtBwdLds l;
+  int o = 0;
+  l.xdl = o; o += 16 * ldk;      // d logits tile; attention phase: du tile [16][ldh] + d ctx tile [16][ldh] alias its front
+  l.gi = o; o += 16 * ldg;
+  l.gh = o; o += 16 * ldg;
+  l.dd = o; o += 16 * ldh;
+  l.xdx = o; o += 16 * ldh;
+  l.c0 = o; o += 16 * ldh;
+  l.c1 = o; o += 16 * ldh;
+  l.st = o; o += att ? 2 * Hp : 0;
+  l.red = o; o += att ? 2 * Hp : 0;
+  l.scratch = o; o += att ? scratch : 0;
+  l.sc = o; o += att ? 2 * 16 * (Tw > 0 ? Tw : 1) : 0;
+  l.total = o;
+  return l;
+}
+
+// One step of the BPTT for this workgroup's 16 rows.  dh1 arrives as dlogits_t W_out (+ the carry in C1), the carries C0 / C1
+// (LDS, [16][ldh]) hold d loss / d h0_t, d h1_t on exit.  Leaves dbn_t in global memory and this workgroup's BN-backward sums.
+__device__ __forceinline__ void code_bwd_cells(const CodeBwdArgs& a, const CodeDims& dm, const CtBwdLds& L, float* smem, int t,
+                                               int b0, int nrows, int tid, bool first) {
+  constexpr int NTHR = CT_NTHR, NW = CT_NW;
+  const int B = dm.B, H = dm.H, K = dm.K, G = 3 * H;
+  const int Hp = (H + 15) & ~15, ldh = Hp + 4, Gp = (G + 15) & ~15, ldg = Gp + 4, Kp = (K + 15) & ~15, ldk = Kp + 4;
+  float* Xdl = smem + L.xdl;
+  float* Gi = smem + L.gi;
+  float* Gh = smem + L.gh;
+  float* Dd = smem + L.dd;
+  float* Xdx = smem + L.xdx;
+  float* C0 = smem + L.c0;
+  float* C1 = smem + L.c1;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int nth = Hp >> 4;
+  constexpr int MAXT = 2;                 // H <= 256: at most two feature tiles per wave
+  // cell 1's saved inputs and its carry (LDS: final since the previous step's last barrier), requested before the d logits tile
+  // (vector-memory results return in order)
+  CellBwdIn cin1[MAXT];
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m)
+    if (wave + NW * m < nth)
+      cell_bwd_prefetch(cin1[m], first ? nullptr : C1, nullptr, a.sv.gates1 + ((int64_t)t * B + b0) * 4 * H,
+                        a.sv.h1 + ((int64_t)t * B + b0) * H, H, wave + NW * m, nrows, lane, ldh);
+  // d logits tile of step t: 16 rows x K, 16-byte vectors
+  {
+    const int K4 = K >> 2;
+    for (int e = tid; e < 16 * K4; e += NTHR) {
+      const int r = e / K4, c = (e - r * K4) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < nrows) v = *reinterpret_cast<const float4*>(a.d_logits + ((int64_t)t * B + b0 + r) * K + c);
+      *reinterpret_cast<float4*>(Xdl + r * ldk + c) = v;
+    }
+  }
+  CellBwdIn cin0[MAXT];
+  const bool drop = a.keep_l0 && dm.p_drop > 0.f;
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m)
+    if (wave + NW * m < nth)
+      cell_bwd_prefetch(cin0[m], first ? nullptr : C0, drop ? a.keep_l0 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates0 + ((int64_t)t * B + b0) * 4 * H, a.sv.h0 + ((int64_t)t * B + b0) * H, H, wave + NW * m,
+                        nrows, lane, ldh);
+  lds_barrier();
+  // ---- dh1 = carry1 + dlogits W_out ; GRU cell 1 backward ---------------------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    const int ft = wave + NW * m;
+    if (ft < nth) {
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, 0>(acc, a.tw.out_t, Kp >> 4, ft, 0, Xdl, ldk, lane);
+      gru_cell_bwd_tile(acc[0], first ? nullptr : C1, 1.0f, nullptr, a.sv.gates1 + ((int64_t)t * B + b0) * 4 * H,
+                        a.sv.h1 + ((int64_t)t * B + b0) * H, a.dgi1 + ((int64_t)t * B + b0) * G, a.dgh1 + ((int64_t)t * B + b0) * G,
+                        Gi, Gh, ldg, Dd, ldh, H, ft, nrows, lane, false, true, cin1[m], ldh);
+    }
+  }
+  lds_barrier();
+  // ---- carry1' = dh1 * z + dgh1 W_hh1 ;  dx1 = dgi1 W_ih1 -> dh0 ---------------------------------------------------------
+  for (int ft = wave; ft < nth; ft += NW) {
+    f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+    wave_gemm_p_dual<1, 8>(a1, a.tw.hh1_t, Gh, a2, a.tw.ih1_t, Gi, Gp >> 4, ft, 0, ldg, lane);
+    const int f0 = 16 * ft + 4 * q;
+    if (f0 + 3 < H) {
+      const float4 d4 = *reinterpret_cast<const float4*>(Dd + i * ldh + f0);
+      *reinterpret_cast<float4*>(C1 + i * ldh + f0) = make_float4(d4.x + a1[0][0], d4.y + a1[0][1], d4.z + a1[0][2], d4.w + a1[0][3]);
+      *reinterpret_cast<float4*>(Xdx + i * ldh + f0) = make_float4(a2[0][0], a2[0][1], a2[0][2], a2[0][3]);
+    }
+  }
+  lds_barrier();
+  // ---- GRU cell 0 backward (Gi / Gh / Dd are reused) ----------------------------------------------------------------------
+#pragma unroll
+  for (int m = 0; m < MAXT; ++m) {
+    const int ft = wave + NW * m;
+    if (ft < nth) {
+      const int f0 = 16 * ft + 4 * q;
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = (f0 + r < H) ? Xdx[i * ldh + f0 + r] : 0.f;
+      gru_cell_bwd_tile(acc, first ? nullptr : C0, 1.0f / (1.0f - dm.p_drop), drop ? a.keep_l0 + ((int64_t)t * B + b0) * H : nullptr,
+                        a.sv.gates0 + ((int64_t)t * B + b0) * 4 * H, a.sv.h0 + ((int64_t)t * B + b0) * H,
+                        a.dgi0 + ((int64_t)t * B + b0) * G, a.dgh0 + ((int64_t)t * B + b0) * G, Gi, Gh, ldg, Dd, ldh, H, ft, nrows,
+                        lane, false, true, cin0[m], ldh);
+    }
+  }
+  lds_barrier();
+  // ---- carry0' = dh0 * z + dgh0 W_hh0 ;  da = dgi0 W_ih0 -> ReLU backward -> dbn_t + BN-backward partial sums --------------
+  {
+    const float* stats = a.sv.bn_stats + (int64_t)t * 2 * H;
+    float* part = a.bn_part + ((int64_t)t * dm.nblk + blockIdx.x) * 2 * H;
+    for (int ft = wave; ft < nth; ft += NW) {
+      const int f0 = 16 * ft + 4 * q;
+      const bool vec = f0 + 3 < H;
+      float av[4] = {0.f, 0.f, 0.f, 0.f}, uv[4] = {0.f, 0.f, 0.f, 0.f}, mv[4] = {0.f, 0.f, 0.f, 0.f}, iv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (vec) {
+        const float4 m4 = *reinterpret_cast<const float4*>(stats + f0), i4 = *reinterpret_cast<const float4*>(stats + H + f0);
+        mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+        iv[0] = i4.x; iv[1] = i4.y; iv[2] = i4.z; iv[3] = i4.w;
+        if (i < nrows) {
+          const int64_t row = ((int64_t)t * B + b0 + i) * H + f0;
+          const float4 a4 = *reinterpret_cast<const float4*>(a.sv.a + row), u4 = *reinterpret_cast<const float4*>(a.sv.u + row);
+          av[0] = a4.x; av[1] = a4.y; av[2] = a4.z; av[3] = a4.w;
+          uv[0] = u4.x; uv[1] = u4.y; uv[2] = u4.z; uv[3] = u4.w;
+        }
+      }
+      f32x4 a1[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}}, a2[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p_dual<1, 8>(a1, a.tw.hh0_t, Gh, a2, a.tw.ih0_t, Gi, Gp >> 4, ft, 0, ldg, lane);
+      if (!vec) continue;
+      float dbn[4], s1[4], s2[4], cw[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool ok = i < nrows;
+        cw[r] = Dd[i * ldh + f0 + r] + a1[0][r];
+        dbn[r] = (ok && av[r] > 0.f) ? a2[0][r] : 0.f;
+        const float dbx = ok ? dbn[r] * ((uv[r] - mv[r]) * iv[r]) : 0.f;
+        s1[r] = reduce16(dbn[r]);
+        s2[r] = reduce16(dbx);
+      }
+      *reinterpret_cast<float4*>(C0 + i * ldh + f0) = make_float4(cw[0], cw[1], cw[2], cw[3]);
+      if (i < nrows)
+        *reinterpret_cast<float4*>(a.dbn + ((int64_t)t * B + b0 + i) * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
+      if (i == 0) {
+        *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+        *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+      }
+    }
+  }
+  lds_barrier();
+}
+
+__device__ __forceinline__ void code_bwd_write_hidden0(const CodeBwdArgs& a, const CodeDims& dm, const CtBwdLds& L, float* smem,
+                                                       int b0, int nrows, int tid) {
+  const int B = dm.B, H = dm.H, Hp = (H + 15) & ~15, ldh = Hp + 4, H4 = H >> 2;
+  const float* C0 = smem + L.c0;
+  const float* C1 = smem + L.c1;
+  for (int e = tid; e < 16 * H4; e += CT_NTHR) {
+    const int r = e / H4, c = (e - r * H4) * 4;
+    if (r >= nrows) continue;
+    *reinterpret_cast<float4*>(a.d_hidden0 + (int64_t)(b0 + r) * H + c) = *reinterpret_cast<const float4*>(C0 + r * ldh + c);
+    *reinterpret_cast<float4*>(a.d_hidden0 + ((int64_t)B + b0 + r) * H + c) = *reinterpret_cast<const float4*>(C1 + r * ldh + c);
+  }
+}
+
+// no attention: the whole BPTT in one launch
+__global__ __launch_bounds__(CT_NTHR) void code_bptt_kernel(CodeBwdArgs a, CodeDims dm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K, dm.Tw, dm.scratch, false);
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * 16, nrows = min(16, dm.B - b0);
+  for (int e = tid; e < L.total; e += CT_NTHR) smem[e] = 0.f;      // padding columns / rows >= nrows of every operand tile, carries
+  lds_barrier();
+  for (int t = dm.S1 - 1; t >= 0; --t) code_bwd_cells(a, dm, L, smem, t, b0, nrows, tid, t == dm.S1 - 1);
+  code_bwd_write_hidden0(a, dm, L, smem, b0, nrows, tid);
+}
+
+// BatchNorm backward of ALL steps (no attention): grid (nblk, S1); workgroup (b, t) sums step t's per-workgroup partials and
+// forms du_t for its 16 rows; workgroup (0, t) leaves the sums for the weight / bias gradient.
+__global__ __launch_bounds__(256) void code_bn_bwd_apply_kernel(CodeBwdArgs a, CodeDims dm) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int B = dm.B, H = dm.H, t = blockIdx.y, tid = threadIdx.x;
+  float* red = smem;               // [2H]
+  float* scratch = smem + 2 * H;   // [1024]
+  reduce_partials<256>(a.bn_part + (int64_t)t * dm.nblk * 2 * H, dm.nblk, 2 * H, red, scratch, tid, 1024);
+  if (blockIdx.x == 0)
+    for (int f = tid; f < 2 * H; f += 256) a.bn_sums[(int64_t)t * 2 * H + f] = red[f];
+  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0), H4 = H >> 2;
+  const float invB = 1.0f / (float)B;
+  const float* stats = a.sv.bn_stats + (int64_t)t * 2 * H;
+  for (int e = tid; e < 16 * H4; e += 256) {
+    const int r = e / H4, c = (e - r * H4) * 4;
+    if (r >= nrows) continue;
+    const int64_t row = ((int64_t)t * B + b0 + r) * H + c;
+    const float4 u4 = *reinterpret_cast<const float4*>(a.sv.u + row), d4 = *reinterpret_cast<const float4*>(a.dbn + row);
+    const float4 m4 = *reinterpret_cast<const float4*>(stats + c), i4 = *reinterpret_cast<const float4*>(stats + H + c);
+    const float4 g4 = *reinterpret_cast<const float4*>(a.w.bn_w + c);
+    const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, db[4] = {d4.x, d4.y, d4.z, d4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+                ii[4] = {i4.x, i4.y, i4.z, i4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float du[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float xhat = (uu[k] - mm[k]) * ii[k];
+      du[k] = gg[k] * ii[k] * (db[k] - red[c + k] * invB - xhat * red[H + c + k] * invB);
+    }
+    *reinterpret_cast<float4*>(a.du + row) = make_float4(du[0], du[1], du[2], du[3]);
+  }
+}
+
+// d bn_w = sum_t S2_t, d bn_b = sum_t S1_t; [attention] d v = sum over the workgroups' partials
+__global__ __launch_bounds__(256) void code_small_sums_kernel(const float* __restrict__ bn_sums, int S1, int H,
+                                                              float* __restrict__ d_bn_w, float* __restrict__ d_bn_b,
+                                                              const float* __restrict__ dv_partial, int nblk,
+                                                              float* __restrict__ d_v) {
+  for (int f = threadIdx.x; f < H; f += 256) {
+    float sw = 0.f, sb = 0.f;
+    for (int t = 0; t < S1; ++t) {
+      sb += bn_sums[(int64_t)t * 2 * H + f];
+      sw += bn_sums[(int64_t)t * 2 * H + H + f];
+    }
+    d_bn_w[f] = sw;
+    d_bn_b[f] = sb;
+    if (d_v) {
+      float s = 0.f;
+      for (int k = 0; k < nblk; ++k) s += dv_partial[(int64_t)k * H + f];
+      d_v[f] = s;
+    }
+  }
+}
+
+// attention: contiguous copies of the two column halves a dense kernel cannot address (its weights are [N][K] with ld = K):
+// out0 = W_pre[:, :H], out1 = W_attn[:, H:]   (src row stride 2H)
+__global__ void code_split_cols_kernel(const float* __restrict__ w_pre, const float* __restrict__ w_attn, float* __restrict__ out0,
+                                       float* __restrict__ out1, int H) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * H; e += gridDim.x * 256) {
+    const int r = e / H, c = e - r * H;
+    out0[e] = w_pre[(int64_t)r * 2 * H + c];
+    out1[e] = w_attn[(int64_t)r * 2 * H + H + c];
+  }
+}
+// d attn.attn.weight (H,2H) = [dW_h | dW_e]
+__global__ void code_join_cols_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int H) {
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < H * H; e += gridDim.x * 256) {
+    const int r = e / H, c = e - r * H;
+    out[(int64_t)r * 2 * H + c] = a[e];
+    out[(int64_t)r * 2 * H + H + c] = b[e];
+  }
+}
+
+// attention: launch for step t (t = S1-1 .. 0), plus a last launch t = -1 that only finishes step 0's BatchNorm / attention
+// backward and writes d_hidden0.  Part A (t < S1-1): finish the BN backward of step t+1 from the per-workgroup partials ->
+// du_{t+1} -> d x_{t+1} = du W_pre (context half) -> attention backward (d_ep, d_enc accumulated in place by the owning
+// workgroup, d hp_{t+1} saved, d v into this workgroup's partial) -> carry1 += d hp W_attn[:, :H].  Part B: the cells of step t.
+// The carries travel between the launches in d_hidden0.
+__global__ __launch_bounds__(CT_NTHR) void code_step_bwd_att_kernel(CodeBwdArgs a, CodeDims dm, int t) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int NTHR = CT_NTHR, NW = CT_NW;
+  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K, dm.Tw, dm.scratch, true);
+  const int S1 = dm.S1, B = dm.B, H = dm.H, Tw = dm.Tw;
+  const int Hp = (H + 15) & ~15, ldh = Hp + 4, H4 = H >> 2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0);
+  float* C0 = smem + L.c0;
+  float* C1 = smem + L.c1;
+  float* Xdu = smem + L.xdl;               // [16][ldh]   (the d logits tile is staged after Part A)
+  float* Xdc = Xdu + 16 * ldh;             // [16][ldh]   d ctx
+  float* Xdhp = smem + L.gi;               // [16][ldh]   d hp (Gi is free until the cells)
+  float* red = smem + L.red;
+  float* red_scratch = smem + L.scratch;
+  float* dsc = smem + L.sc;                // [16][Tw] d_w -> ds
+  float* wsc = dsc + 16 * Tw;              // [16][Tw] attention weights of step t+1
+  const bool last = (t == S1 - 1);
+  for (int e = tid; e < L.total; e += NTHR) smem[e] = 0.f;
+  lds_barrier();
+  if (!last) {
+    // carries of step t+1 (written by the previous launch)
+    for (int e = tid; e < 16 * H4; e += NTHR) {
+      const int r = e / H4, c = (e - r * H4) * 4;
+      if (r >= nrows) continue;
+      *reinterpret_cast<float4*>(C0 + r * ldh + c) = *reinterpret_cast<const float4*>(a.d_hidden0 + (int64_t)(b0 + r) * H + c);
+      *reinterpret_cast<float4*>(C1 + r * ldh + c) = *reinterpret_cast<const float4*>(a.d_hidden0 + ((int64_t)B + b0 + r) * H + c);
+    }
+    // ================= Part A: BatchNorm backward of step s = t+1, attention backward of step s ==========================
+    const int s = t + 1;
+    reduce_partials<NTHR>(a.bn_part + (int64_t)s * dm.nblk * 2 * H, dm.nblk, 2 * H, red, red_scratch, tid, dm.scratch);
+    if (blockIdx.x == 0)
+      for (int f = tid; f < 2 * H; f += NTHR) a.bn_sums[(int64_t)s * 2 * H + f] = red[f];
+    const float invB = 1.0f / (float)B;
+    const float* stats = a.sv.bn_stats + (int64_t)s * 2 * H;
+    for (int e = tid; e < 16 * H4; e += NTHR) {
+      const int r = e / H4, c = (e - r * H4) * 4;
+      if (r >= nrows) continue;
+      const int64_t row = ((int64_t)s * B + b0 + r) * H + c;
+      const float4 u4 = *reinterpret_cast<const float4*>(a.sv.u + row), d4 = *reinterpret_cast<const float4*>(a.dbn + row);
+      const float4 m4 = *reinterpret_cast<const float4*>(stats + c), i4 = *reinterpret_cast<const float4*>(stats + H + c);
+      const float4 g4 = *reinterpret_cast<const float4*>(a.w.bn_w + c);
+      const float uu[4] = {u4.x, u4.y, u4.z, u4.w}, db[4] = {d4.x, d4.y, d4.z, d4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w},
+                  ii[4] = {i4.x, i4.y, i4.z, i4.w}, gg[4] = {g4.x, g4.y, g4.z, g4.w};
+      float du[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float xhat = (uu[k] - mm[k]) * ii[k];
+        du[k] = gg[k] * ii[k] * (db[k] - red[c + k] * invB - xhat * red[H + c + k] * invB);
+      }
+      const float4 du4 = make_float4(du[0], du[1], du[2], du[3]);
+      *reinterpret_cast<float4*>(a.du + row) = du4;
+      *reinterpret_cast<float4*>(Xdu + r * ldh + c) = du4;
+    }
+    // attention weights of step s
+    for (int p = tid; p < 16 * Tw; p += NTHR) {
+      const int r = p / Tw, tw = p - r * Tw;
+      wsc[p] = (r < nrows) ? a.sv.attw[((int64_t)s * B + b0 + r) * Tw + tw] : 0.f;
+    }
+    lds_barrier();
+    // d ctx_s = du_s W_pre[:, H:2H]   (rows = context feature, contraction over the H outputs of pre_linear)
+    const int nth = Hp >> 4;
+    for (int ft = wave; ft < nth; ft += NW) {
+      const int f0 = 16 * ft + 4 * q;
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, 0>(acc, a.tw.pre_ctx_t, Hp >> 4, ft, 0, Xdu, ldh, lane);
+      if (f0 + 3 < H) {
+        const float4 c4 = make_float4(acc[0][0], acc[0][1], acc[0][2], acc[0][3]);
+        *reinterpret_cast<float4*>(Xdc + i * ldh + f0) = c4;
+      }
+    }
+    lds_barrier();
+    // d_w[r][tw] = <d ctx[r], enc[tw, r]>
+    for (int p = tid; p < 16 * Tw; p += NTHR) {
+      const int r = p / Tw, tw = p - r * Tw;
+      float e = 0.f;
+      if (r < nrows) {
+        const float* er = a.enc + ((int64_t)tw * B + b0 + r) * H;
+        const float* dc = Xdc + r * ldh;
+        float e0 = 0.f, e1 = 0.f, e2 = 0.f, e3 = 0.f;
+        for (int c = 0; c < H; c += 4) {
+          const float4 n4 = *reinterpret_cast<const float4*>(er + c), d4 = *reinterpret_cast<const float4*>(dc + c);
+          e0 += d4.x * n4.x; e1 += d4.y * n4.y; e2 += d4.z * n4.z; e3 += d4.w * n4.w;
+        }
+        e = (e0 + e1) + (e2 + e3);
+      }
+      dsc[p] = e;
+    }
+    lds_barrier();
+    if (tid < 16) {     // softmax backward: ds = w (d_w - <w, d_w>)
+      float dot = 0.f;
+      for (int tw = 0; tw < Tw; ++tw) dot += wsc[tid * Tw + tw] * dsc[tid * Tw + tw];
+      for (int tw = 0; tw < Tw; ++tw) dsc[tid * Tw + tw] = wsc[tid * Tw + tw] * (dsc[tid * Tw + tw] - dot);
+    }
+    lds_barrier();
+    // per (row, feature group): d hp, d v partial, d_ep / d_enc rows (accumulated over the steps by this workgroup alone)
+    {
+      float* dvp = smem + L.gh;        // [16][ldh] d v contributions per row (Gh is free until the cells)
+      const bool acc_steps = (s != S1 - 1);
+      for (int e = tid; e < 16 * H4; e += NTHR) {
+        const int r = e / H4, c = (e - r * H4) * 4;
+        float dh[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < nrows) {
+          const float4 hp4 = *reinterpret_cast<const float4*>(a.sv.hp + ((int64_t)s * B + b0 + r) * H + c);
+          const float4 v4 = *reinterpret_cast<const float4*>(a.w.v_attn + c);
+          const float4 dc4 = *reinterpret_cast<const float4*>(Xdc + r * ldh + c);
+          const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, dc[4] = {dc4.x, dc4.y, dc4.z, dc4.w};
+          for (int tw = 0; tw < Tw; ++tw) {
+            const int64_t row = ((int64_t)tw * B + b0 + r) * H + c;
+            const float4 p4 = *reinterpret_cast<const float4*>(a.ep + row);
+            const float pp[4] = {p4.x, p4.y, p4.z, p4.w};
+            const float ds = dsc[r * Tw + tw], ww = wsc[r * Tw + tw];
+            float de[4], dn[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float en = tanhf_(hp[k] + pp[k]);
+              de[k] = ds * vv[k] * (1.0f - en * en);
+              dh[k] += de[k];
+              dv[k] += ds * en;
+              dn[k] = ww * dc[k];
+            }
+            float4 o1 = make_float4(de[0], de[1], de[2], de[3]), o2 = make_float4(dn[0], dn[1], dn[2], dn[3]);
+            if (acc_steps) {
+              const float4 q1 = *reinterpret_cast<const float4*>(a.d_ep + row), q2 = *reinterpret_cast<const float4*>(a.d_enc + row);
+              o1.x += q1.x; o1.y += q1.y; o1.z += q1.z; o1.w += q1.w;
+              o2.x += q2.x; o2.y += q2.y; o2.z += q2.z; o2.w += q2.w;
+            }
+            *reinterpret_cast<float4*>(a.d_ep + row) = o1;
+            *reinterpret_cast<float4*>(a.d_enc + row) = o2;
+          }
+          *reinterpret_cast<float4*>(a.dhp + ((int64_t)s * B + b0 + r) * H + c) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+        }
+        *reinterpret_cast<float4*>(Xdhp + r * ldh + c) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+        *reinterpret_cast<float4*>(dvp + r * ldh + c) = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      }
+      lds_barrier();
+      for (int f = tid; f < H; f += NTHR) {
+        float sdv = 0.f;
+        for (int r = 0; r < 16; ++r) sdv += dvp[r * ldh + f];
+        float* o = a.dv_partial + (int64_t)blockIdx.x * H + f;
+        *o = acc_steps ? *o + sdv : sdv;
+      }
+    }
+    // carry1 += d hp W_attn[:, :H]     (the state the attention of step s scored = h1 in front of step s = output of step t)
+    for (int ft = wave; ft < nth; ft += NW) {
+      const int f0 = 16 * ft + 4 * q;
+      f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
+      wave_gemm_p<1, 0>(acc, a.tw.attn_h_t, Hp >> 4, ft, 0, Xdhp, ldh, lane);
+      if (f0 + 3 < H) {
+        float4 c4 = *reinterpret_cast<const float4*>(C1 + i * ldh + f0);
+        c4.x += acc[0][0]; c4.y += acc[0][1]; c4.z += acc[0][2]; c4.w += acc[0][3];
+        *reinterpret_cast<float4*>(C1 + i * ldh + f0) = c4;
+      }
+    }
+    lds_barrier();
+    // Gi / Gh / the front of Xdl were borrowed: padding back to zero for the cells
+    for (int e = tid; e < L.dd; e += NTHR) smem[e] = 0.f;
+    lds_barrier();
+  }
+  if (t >= 0) code_bwd_cells(a, dm, L, smem, t, b0, nrows, tid, last);
+  code_bwd_write_hidden0(a, dm, L, smem, b0, nrows, tid);
+}
+
+}  // namespace g2v
+
+using namespace g2v;
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------------------------------------------------
+static size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+static bool ct_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int g2v_attn_code_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
+
+extern "C" int g2v_attn_code_rollout_ok(int S1, int B, int H, int K, int Tw, int attention) {
+  if (S1 < 1 || B < 1 || H < 16 || (H & 3) || H > 256 || K < 4 || (K & 3) || K > 1024) return 0;
+  if (attention && (Tw < 1 || Tw > CT_MAX_TW)) return 0;
+  const int Hin = attention ? 2 * H : H;
+  const size_t lf = (size_t)ct_fwd_lds(H, Hin, attention ? Tw : 0, 1024).total * 4;
+  const size_t lb = (size_t)ct_bwd_lds(H, K, attention ? Tw : 0, 1024, attention != 0).total * 4;
+  return lf <= 160 * 1024 && lb <= 160 * 1024;
+}
+
+static size_t ct_fwd_pack_floats(int H, int K, int att) {
+  const int Hin = att ? 2 * H : H;
+  return pack_floats(H, 1, Hin) + 4 * pack_floats(H, 3, H) + (size_t)ct_ktiles_alloc(K) * pack_ks(H) * 256 +
+         (att ? pack_floats(H, 1, H) : 0);
+}
+extern "C" size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention) {
+  return al256(ct_fwd_pack_floats(H, K, attention) * sizeof(float));
+}
+
+static int ct_scratch(size_t base_floats) { return (base_floats + 2048) * sizeof(float) <= 160 * 1024 ? 2048 : 1024; }
+
+extern "C" int g2v_attn_code_rollout_fwd(const int64_t* codes, const float* h_init, const float* enc, const float* enc_proj,
+                                         const g2v_code_dec_weights* w, const g2v_code_dec_saved* s, const uint8_t* keep_emb,
+                                         const uint8_t* keep_l0, float p_drop, int n_pre, int training, int S1, int B, int H,
+                                         int K, int Tw, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(codes && h_init && w && s && workspace, "null pointer");
+  const int att = w->w_attn != nullptr;
+  G2V_REQUIRE(w->emb && w->w_pre && w->b_pre && w->bn_w && w->bn_b && w->bn_running_mean && w->bn_running_var && w->w_ih0 &&
+              w->w_hh0 && w->b_ih0 && w->b_hh0 && w->w_ih1 && w->w_hh1 && w->b_ih1 && w->b_hh1 && w->w_out && w->b_out,
+              "missing weight");
+  G2V_REQUIRE(!att || (w->b_attn && w->v_attn && enc && enc_proj && s->hp && s->attw), "attention: missing array");
+  G2V_REQUIRE(s->ids && s->ec && s->u && s->h0 && s->h1 && s->logits && s->bn_partial, "missing state buffer");
+  G2V_REQUIRE(!training || (s->a && s->bn_stats && s->gates0 && s->gates1), "missing saved buffer");
+  G2V_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  if (!g2v_attn_code_rollout_ok(S1, B, H, K, Tw, att)) {
+    set_error("g2v_attn_code_rollout_fwd: shape not served (g2v_attn_code_rollout_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < g2v_attn_code_rollout_fwd_workspace(H, K, att)) {
+    set_error("g2v_attn_code_rollout_fwd: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const void* al[] = {h_init, enc, enc_proj, w->emb, w->b_pre, w->bn_w, w->bn_b, w->b_ih0, w->b_hh0, w->b_ih1, w->b_hh1, w->b_out,
+                      w->b_attn, w->v_attn, s->ec, s->u, s->a, s->h0, s->h1, s->x1, s->gates0, s->gates1, s->logits, s->bn_partial,
+                      s->hp, keep_emb, keep_l0, workspace};
+  for (const void* p : al) G2V_REQUIRE(ct_al16(p), "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const int Hin = att ? 2 * H : H;
+  // ---- pack the weights into MFMA fragment order (one launch) ----
+  float* p = (float*)workspace;
+  PackBatch pb;
+  CodePackF pk{};
+  pb.n = 0;
+  pb.d[pb.n++] = PackDesc{w->w_pre, p, H, 1, 0, Hin, Hin, 0, 0}; pk.pre = p; p += pack_floats(H, 1, Hin);
+  pb.d[pb.n++] = PackDesc{w->w_ih0, p, H, 3, H, H, H, 0, 0}; pk.ih0 = p; p += pack_floats(H, 3, H);
+  pb.d[pb.n++] = PackDesc{w->w_hh0, p, H, 3, H, H, H, 0, 0}; pk.hh0 = p; p += pack_floats(H, 3, H);
+  pb.d[pb.n++] = PackDesc{w->w_ih1, p, H, 3, H, H, H, 0, 0}; pk.ih1 = p; p += pack_floats(H, 3, H);
+  pb.d[pb.n++] = PackDesc{w->w_hh1, p, H, 3, H, H, H, 0, 0}; pk.hh1 = p; p += pack_floats(H, 3, H);
+  pb.d[pb.n++] = PackDesc{w->w_out, p, K, 1, 0, H, H, 0, ct_ktiles_alloc(K)}; pk.out = p; p += (size_t)ct_ktiles_alloc(K) * pack_ks(H) * 256;
+  if (att) {
+    pb.d[pb.n++] = PackDesc{w->w_attn, p, H, 1, 0, H, 2 * H, 0, 0}; pk.attn_h = p; p += pack_floats(H, 1, H);
+  }
+  launch_pack(pb, st);
+  G2V_CHECK_LAUNCH();
+  const int scratch = ct_scratch((size_t)ct_fwd_lds(H, Hin, att ? Tw : 0, 0).total);
+  CodeDims dm{S1, B, H, K, Hin, att ? Tw : 0, p_drop, n_pre, training, cdiv(B, 16), att, scratch};
+  const size_t lds = (size_t)ct_fwd_lds(H, Hin, dm.Tw, scratch).total * sizeof(float);
+  if (lds > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)code_step_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int j = 0; j <= S1; ++j)
+    hipLaunchKernelGGL(code_step_fwd_kernel, dim3(dm.nblk), dim3(CT_NTHR), lds, st, codes, h_init, enc, enc_proj, *w, pk, *s,
+                       keep_emb, keep_l0, dm, j);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// ---- backward workspace layout (bytes, every region 256-byte aligned) ----------------------------------------------------
+struct CtBwdWs {
+  size_t pack, dgi0, dgh0, dgi1, dgh1, dbn, du, dec, dhp, d_ep, dvp, bn_part, bn_sums, x1m, wg, emb, total;
+};
+static CtBwdWs ct_bwd_ws(int S1, int B, int H, int K, int Tw, int att) {
+  const size_t M = (size_t)S1 * B, G = 3 * (size_t)H, Hin = att ? 2 * (size_t)H : (size_t)H, nblk = cdiv(B, 16);
+  CtBwdWs l;
+  size_t o = 0;
+  auto take = [&](size_t bytes) { const size_t at = o; o += al256(bytes); return at; };
+  l.pack = take((pack_floats(H, 1, K) + 4 * pack_floats(H, 1, 3 * H) + (att ? 2 * pack_floats(H, 1, H) : 0)) * 4);
+  l.dgi0 = take(M * G * 4); l.dgh0 = take(M * G * 4); l.dgi1 = take(M * G * 4); l.dgh1 = take(M * G * 4);
+  l.dbn = take(M * H * 4);
+  l.du = take(M * H * 4);
+  l.dec = take(M * H * 4);
+  l.dhp = take(att ? M * H * 4 : 0);
+  l.d_ep = take(att ? (size_t)Tw * B * H * 4 : 0);
+  l.dvp = take(att ? nblk * H * 4 : 0);
+  l.bn_part = take((size_t)S1 * nblk * 2 * H * 4);
+  l.bn_sums = take((size_t)S1 * 2 * H * 4);
+  l.x1m = take(att ? (size_t)4 * H * H * 4 : 0);      // attention: W_pre[:, :H], W_attn[:, H:], dW_h, dW_e
+  size_t wg = 4 * g2v_linear_bwd_weight_workspace((int)M, H, 3 * H);
+  wg = wg > g2v_linear_bwd_weight_workspace((int)M, H, K) ? wg : g2v_linear_bwd_weight_workspace((int)M, H, K);
+  wg = wg > g2v_linear_bwd_weight_workspace((int)M, (int)Hin, H) ? wg : g2v_linear_bwd_weight_workspace((int)M, (int)Hin, H);
+  if (att) {
+    const size_t w2 = g2v_linear_bwd_weight_workspace(Tw * B, H, H);
+    wg = wg > w2 ? wg : w2;
+  }
+  l.wg = take(wg);
+  l.emb = take(g2v_embedding_bwd_ws_bytes((int64_t)M, H, K));
+  l.total = o;
+  return l;
+}
+extern "C" size_t g2v_attn_code_rollout_bwd_workspace(int S1, int B, int H, int K, int Tw, int attention) {
+  if (S1 < 1 || B < 1 || H < 1 || K < 1) return 0;
+  return ct_bwd_ws(S1, B, H, K, Tw, attention).total;
+}
+
+extern "C" int g2v_attn_code_rollout_bwd(const float* d_logits, const float* enc, const float* enc_proj,
+                                         const g2v_code_dec_weights* w, const g2v_code_dec_saved* s, const g2v_code_dec_grads* g,
+                                         const uint8_t* keep_emb, const uint8_t* keep_l0, float p_drop, int S1, int B, int H, int K,
+                                         int Tw, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(d_logits && w && s && g && workspace, "null pointer");
+  const int att = w->w_attn != nullptr;
+  G2V_REQUIRE(s->ids && s->ec && s->u && s->a && s->bn_stats && s->h0 && s->h1 && s->gates0 && s->gates1, "missing saved buffer");
+  G2V_REQUIRE(g->d_hidden0 && g->d_emb && g->d_w_pre && g->d_b_pre && g->d_bn_w && g->d_bn_b && g->d_w_ih0 && g->d_w_hh0 &&
+              g->d_b_ih0 && g->d_b_hh0 && g->d_w_ih1 && g->d_w_hh1 && g->d_b_ih1 && g->d_b_hh1 && g->d_w_out && g->d_b_out,
+              "missing gradient buffer");
+  G2V_REQUIRE(!att || (enc && enc_proj && s->hp && s->attw && g->d_w_attn && g->d_b_attn && g->d_v_attn && g->d_enc),
+              "attention: missing array");
+  const bool drop = keep_l0 && p_drop > 0.f;
+  G2V_REQUIRE(!drop || s->x1, "inter-layer dropout: x1 was not saved");
+  if (!g2v_attn_code_rollout_ok(S1, B, H, K, Tw, att)) {
+    set_error("g2v_attn_code_rollout_bwd: shape not served (g2v_attn_code_rollout_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  const CtBwdWs L = ct_bwd_ws(S1, B, H, K, Tw, att);
+  if (workspace_bytes < L.total) {
+    set_error("g2v_attn_code_rollout_bwd: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  G2V_REQUIRE(ct_al16(workspace) && ct_al16(d_logits) && ct_al16(g->d_hidden0), "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  char* base = (char*)workspace;
+  const int Hin = att ? 2 * H : H, G = 3 * H, M = S1 * B;
+  // ---- transposed packs ----
+  float* p = (float*)(base + L.pack);
+  PackBatch pb;
+  CodeBwdArgs a{};
+  pb.n = 0;
+  pb.d[pb.n++] = PackDesc{w->w_out, p, H, 1, 0, K, H, 1, 0}; a.tw.out_t = p; p += pack_floats(H, 1, K);      // rows f, k = code: W_out[k][f]
+  pb.d[pb.n++] = PackDesc{w->w_ih0, p, H, 1, 0, G, H, 1, 0}; a.tw.ih0_t = p; p += pack_floats(H, 1, G);
+  pb.d[pb.n++] = PackDesc{w->w_hh0, p, H, 1, 0, G, H, 1, 0}; a.tw.hh0_t = p; p += pack_floats(H, 1, G);
+  pb.d[pb.n++] = PackDesc{w->w_ih1, p, H, 1, 0, G, H, 1, 0}; a.tw.ih1_t = p; p += pack_floats(H, 1, G);
+  pb.d[pb.n++] = PackDesc{w->w_hh1, p, H, 1, 0, G, H, 1, 0}; a.tw.hh1_t = p; p += pack_floats(H, 1, G);
+  if (att) {
+    // rows c (context feature), k = f: W_pre[f][H + c]  -> src offset H, ld = 2H, transposed
+    pb.d[pb.n++] = PackDesc{w->w_pre + H, p, H, 1, 0, H, 2 * H, 1, 0}; a.tw.pre_ctx_t = p; p += pack_floats(H, 1, H);
+    // rows c (state feature), k = f: W_attn[f][c]
+    pb.d[pb.n++] = PackDesc{w->w_attn, p, H, 1, 0, H, 2 * H, 1, 0}; a.tw.attn_h_t = p; p += pack_floats(H, 1, H);
+  }
+  launch_pack(pb, st);
+  G2V_CHECK_LAUNCH();
+  a.d_logits = d_logits; a.enc = enc; a.ep = enc_proj; a.w = *w; a.sv = *s; a.keep_l0 = drop ? keep_l0 : nullptr;
+  a.dgi0 = (float*)(base + L.dgi0); a.dgh0 = (float*)(base + L.dgh0); a.dgi1 = (float*)(base + L.dgi1); a.dgh1 = (float*)(base + L.dgh1);
+  a.dbn = (float*)(base + L.dbn); a.du = (float*)(base + L.du); a.dec = (float*)(base + L.dec);
+  a.dhp = att ? (float*)(base + L.dhp) : nullptr; a.d_ep = att ? (float*)(base + L.d_ep) : nullptr; a.d_enc = att ? g->d_enc : nullptr;
+  a.dv_partial = att ? (float*)(base + L.dvp) : nullptr;
+  a.bn_part = (float*)(base + L.bn_part); a.bn_sums = (float*)(base + L.bn_sums); a.d_hidden0 = g->d_hidden0;
+  const int scratch = ct_scratch((size_t)ct_bwd_lds(H, K, att ? Tw : 0, 0, att != 0).total);
+  CodeDims dm{S1, B, H, K, Hin, att ? Tw : 0, drop ? p_drop : 0.f, 0, 1, cdiv(B, 16), att, scratch};
+  const size_t lds = (size_t)ct_bwd_lds(H, K, dm.Tw, scratch, att != 0).total * sizeof(float);
+  void* wgws = base + L.wg;
+  const size_t wgn = L.emb - L.wg;
+  int rc;
+  float* wpe = (float*)(base + L.x1m);      // attention: W_pre[:, :H] | W_attn[:, H:] | dW_h | dW_e, H x H each
+  float* wae = wpe + (size_t)H * H;
+  float* dwh = wae + (size_t)H * H;
+  float* dwe = dwh + (size_t)H * H;
+  if (!att) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute((const void*)code_bptt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(code_bptt_kernel, dim3(dm.nblk), dim3(CT_NTHR), lds, st, a, dm);
+    hipLaunchKernelGGL(code_bn_bwd_apply_kernel, dim3(dm.nblk, S1), dim3(256), (2 * H + 1024) * sizeof(float), st, a, dm);
+    G2V_CHECK_LAUNCH();
+    // d e = du W_pre over all S1 x B rows
+    if ((rc = g2v_linear_bwd_data(a.du, H, w->w_pre, a.dec, H, M, H, H, 0, stream)) != G2V_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(code_split_cols_kernel, dim3(cdiv(H * H, 256)), dim3(256), 0, st, w->w_pre, w->w_attn, wpe, wae, H);
+    if (lds > 48 * 1024)
+      (void)hipFuncSetAttribute((const void*)code_step_bwd_att_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    for (int t = S1 - 1; t >= -1; --t)
+      hipLaunchKernelGGL(code_step_bwd_att_kernel, dim3(dm.nblk), dim3(CT_NTHR), lds, st, a, dm, t);
+    G2V_CHECK_LAUNCH();
+    // the embedding half of d x = du W_pre[:, :H] (the context half was formed step by step)
+    if ((rc = g2v_linear_bwd_data(a.du, H, wpe, a.dec, H, M, H, H, 0, stream)) != G2V_OK) return rc;
+  }
+  hipLaunchKernelGGL(code_small_sums_kernel, dim3(1), dim3(256), 0, st, a.bn_sums, S1, H, g->d_bn_w, g->d_bn_b,
+                     att ? a.dv_partial : nullptr, dm.nblk, att ? g->d_v_attn : nullptr);
+  G2V_CHECK_LAUNCH();
+  // ---- embedding gradient, weight gradients: one launch over the S1 x B rows each -------------------------------------------
+  if ((rc = g2v_embedding_bwd(a.dec, s->ids, keep_emb, keep_emb ? 2.0f : 1.0f, g->d_emb, M, H, K, 1, base + L.emb,
+                              L.total - L.emb, stream)) != G2V_OK)
+    return rc;
+  if ((rc = g2v_linear_bwd_weight(d_logits, K, s->h1 + (size_t)B * H, H, 0, 0, 0, nullptr, 1.0f, g->d_w_out, g->d_b_out, M, H, K, 0,
+                                  wgws, wgn, stream)) != G2V_OK)
+    return rc;
+  if ((rc = g2v_linear_bwd_weight(a.du, H, s->ec, Hin, 0, 0, 0, nullptr, 1.0f, g->d_w_pre, g->d_b_pre, M, Hin, H, 0, wgws, wgn,
+                                  stream)) != G2V_OK)
+    return rc;
+  {
+    g2v_wgrad_item it[4];
+    const float* x1 = drop ? s->x1 : s->h0 + (size_t)B * H;     // layer 1's input: dropped h0_{t+1}
+    it[0] = g2v_wgrad_item{a.dgi0, s->a, g->d_w_ih0, g->d_b_ih0};
+    it[1] = g2v_wgrad_item{a.dgh0, s->h0, g->d_w_hh0, g->d_b_hh0};
+    it[2] = g2v_wgrad_item{a.dgi1, x1, g->d_w_ih1, g->d_b_ih1};
+    it[3] = g2v_wgrad_item{a.dgh1, s->h1, g->d_w_hh1, g->d_b_hh1};
+    if ((rc = g2v_linear_bwd_weight_batch(it, 4, G, H, M, H, G, 0, wgws, wgn, stream)) != G2V_OK) return rc;
+  }
+  if (att) {
+    // attn.attn.weight = [W_h | W_e]: d W_h = dhp^T h1_t (the state in front of each step), d W_e = d_ep^T enc; bias from dhp
+    if ((rc = g2v_linear_bwd_weight(a.dhp, H, s->h1, H, 0, 0, 0, nullptr, 1.0f, dwh, g->d_b_attn, M, H, H, 0, wgws, wgn, stream)) !=
+        G2V_OK)
+      return rc;
+    if ((rc = g2v_linear_bwd_weight(a.d_ep, H, enc, H, 0, 0, 0, nullptr, 1.0f, dwe, nullptr, Tw * B, H, H, 0, wgws, wgn, stream)) !=
+        G2V_OK)
+      return rc;
+    hipLaunchKernelGGL(code_join_cols_kernel, dim3(cdiv(H * H, 256)), dim3(256), 0, st, dwh, dwe, g->d_w_attn, H);
+    G2V_CHECK_LAUNCH();
+    // d enc (the context term, written by the step kernels) += d_ep W_attn[:, H:]
+    if ((rc = g2v_linear_bwd_data(a.d_ep, H, wae, g->d_enc, H, Tw * B, H, H, 1, stream)) != G2V_OK) return rc;
+  }
+  return G2V_OK;
+}

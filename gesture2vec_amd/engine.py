@@ -199,6 +199,10 @@ class VQVAEEngine:
         # vq_derive beside the encoder GRU) -5..-9 us per step; branch 1 (EMA statistics beside the forward rollout) +30 us; branch 2
         # (decoder weight gradients) +10 us.  Hence 1.
         self._fork_late = 1
+        # round 5: branch 0 forked in front of the input layer, masks last; its packs + exchange clears as one launch
+        # (same-box A/B, 3 x 300 steps each, profiles/r05_b_side_ab.log: 1.558 -> 1.540 ms with both; attributes, not environment)
+        self.side_early = True
+        self.merged_prepare = True
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
@@ -425,10 +429,15 @@ class VQVAEEngine:
         forward runs 40 us into the step: its pack stays in front of it.)"""
         lib, st = self.lib, self._stream()
         b = self.buffers(B)
-        if which == "gru_bwd":
-            enc = "encoder."
+        enc = "encoder."
+        if which in ("gru_bwd", "all"):
             whh = (C.c_void_p * 2)(self._w(enc + "gru.weight_hh_l0"), self._w(enc + "gru.weight_hh_l0_reverse"))
             wih = (C.c_void_p * 2)(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"))
+        if which == "all":      # both rollout workspaces + the BPTT workspace in ONE launch (H == 64, D == 135)
+            check(lib.g2v_train_step_prepare(C.byref(self.dec_wstruct()), self.D, self.H, _p(b["ws_decf"]), b["ws_decf"].numel(),
+                                             _p(b["ws_decb"]), b["ws_decb"].numel(), whh, wih, 2, 1, _p(b["ws_grub"]),
+                                             b["ws_grub"].numel(), st))
+        elif which == "gru_bwd":
             check(lib.g2v_gru_seq_prepare(whh, wih, 2, self.H, int(self.H == 64), None, 0, _p(b["ws_grub"]),
                                           b["ws_grub"].numel(), st))
         else:
@@ -572,6 +581,16 @@ class VQVAEEngine:
         elif drop_in:
             check(lib.g2v_mask_rows(_p(in_poses), D, B, D, T * D, _p(b["keep_in"]), 1.0 / (1.0 - self.p), _p(b["x_drop"]), D,
                                     T * B, D, st))
+        # work of branch 0 (operand images of the quantiser, ahead-of-time packs, rollout masks).  Round 5 (side_early): forked
+        # HERE, in front of the input layer, and ordered so that the HBM-heavy mask kernel comes LAST -- the small MFMA / pack
+        # kernels run beside the (HBM-bound) input layer, the masks beside the (latency-bound) GRU.  Up to round 4 the whole
+        # branch was forked behind the input layer with the masks in the middle: beside the input layer the mask kernel doubled
+        # that kernel's time (36 -> 67 us on the main chain), but behind it the branch (163 us of kernels) outlasted the 137 us
+        # GRU and the quantiser waited 36 us for it (profiles/r04_h_step_timeline.txt).
+        side, self._side_work = getattr(self, "_side_work", None), None
+        early = side is not None and self.side_early
+        if early:
+            self._fork(0, side)
         # in_layer (:93)
         if drop_in:
             check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
@@ -580,10 +599,9 @@ class VQVAEEngine:
             check(lib.g2v_linear_fwd(_p(in_poses), D, B, D, T * D, None, 1.0,
                                      self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
                                      _p(b["xin"]), H, T * B, D, H, 0, st))
-        # work of branch 0 (rollout masks, ahead-of-time packs): forked HERE, behind the input layer -- beside that HBM-bound
-        # product the mask kernel doubled its time (36 -> 67 us on the main chain), beside the latency-bound GRU it is free
-        side, self._side_work = getattr(self, "_side_work", None), None
-        if side is not None:
+        if early:
+            self._release()                 # launched behind the input layer in host order (the main chain keeps its queue)
+        elif side is not None:
             self._fork(0, side)
         # H == 64: the input projections x W_ih^T + b_ih are fused into the recurrent kernel (no gi array at all);
         # other sizes compute gi with the dense-layer kernel first
@@ -1042,13 +1060,18 @@ class VQVAEEngine:
                 check(self.lib.g2v_vq_code_sqnorm(self._w("vq_layer._embedding.weight"), _p(self.code_sqnorm), self.K, self.E,
                                                   self._stream()))
                 self._gs_wsq_ready = True
-            if draw_masks:
+            if draw_masks and not self.side_early:
                 self.draw_masks(B, True, "rest")       # only the rollout consumes keep95 / keep_l0
             for t, n in self.tracked_counters:         # (train_iter: BatchNorm's num_batches_tracked)
                 check(self.lib.g2v_counter_add(_p(t), int(n), self._stream()))
             if self._prepared:
-                self.prepare_recurrent(B, "dec")
-                self.prepare_recurrent(B, "gru_bwd")
+                if self.merged_prepare and self.H == 64 and self.D == 135:
+                    self.prepare_recurrent(B, "all")   # one launch (g2v_train_step_prepare)
+                else:
+                    self.prepare_recurrent(B, "dec")
+                    self.prepare_recurrent(B, "gru_bwd")
+            if draw_masks and self.side_early:
+                self.draw_masks(B, True, "rest")       # last: the one HBM-heavy kernel of the branch (see forward_encoder)
         self._side_work = side
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)

@@ -11,7 +11,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import DecGrads, DecSaved, DecWeights, check
+from ._lib import CodeDecGrads, CodeDecSaved, CodeDecWeights, DecGrads, DecSaved, DecWeights, check
 
 
 def _lib_():
@@ -402,6 +402,34 @@ def dec_rollout_bwd(wstruct, saved: dict, grads: dict, keep95, keep_l0, p_drop, 
     check(lib.g2v_dec_rollout_bwd(C.byref(wstruct), C.byref(sv), C.byref(gr), _p(keep95), _p(keep_l0),
                                   float(p_drop), int(n_pre), int(conditioned), T, B, D, H, _p(ws), ws.numel(),
                                   _stream()), "dec_rollout_bwd")
+
+
+# ------------------------------------------------------------------------------------------ Part d: fused code-decoder rollout
+def code_rollout_ok(S1, B, H, K, Tw, att) -> bool:
+    return bool(_lib_().g2v_attn_code_rollout_ok(int(S1), int(B), int(H), int(K), int(Tw), int(bool(att))))
+
+
+def code_rollout_fwd(codes, h_init, enc, enc_proj, weights: dict, saved: dict, keep_emb, keep_l0, p_drop, n_pre, training,
+                     S1, B, H, K, Tw):
+    """g2v_attn_code_rollout_fwd: S1 + 1 launches of the fused decoder-step kernel (weights / saved: dicts of tensors named as
+    the fields of g2v_code_dec_weights / g2v_code_dec_saved; missing = NULL)."""
+    lib = _lib_()
+    att = weights.get("w_attn") is not None
+    ws = workspace(lib.g2v_attn_code_rollout_fwd_workspace(H, K, int(att)), h_init.device, "codefwd")
+    check(lib.g2v_attn_code_rollout_fwd(_p(_chk(codes, torch.int64)), _p(_chk(h_init)), _p(enc), _p(enc_proj),
+                                        C.byref(struct_from(CodeDecWeights, weights)), C.byref(struct_from(CodeDecSaved, saved)),
+                                        _p(keep_emb), _p(keep_l0), float(p_drop), int(n_pre), int(training), S1, B, H, K, int(Tw),
+                                        _p(ws), ws.numel(), _stream()), "attn_code_rollout_fwd")
+
+
+def code_rollout_bwd(d_logits, enc, enc_proj, weights: dict, saved: dict, grads: dict, keep_emb, keep_l0, p_drop, S1, B, H, K, Tw):
+    lib = _lib_()
+    att = weights.get("w_attn") is not None
+    ws = workspace(lib.g2v_attn_code_rollout_bwd_workspace(S1, B, H, K, int(Tw), int(att)), d_logits.device, "codebwd")
+    check(lib.g2v_attn_code_rollout_bwd(_p(_chk(d_logits)), _p(enc), _p(enc_proj), C.byref(struct_from(CodeDecWeights, weights)),
+                                        C.byref(struct_from(CodeDecSaved, saved)), C.byref(struct_from(CodeDecGrads, grads)),
+                                        _p(keep_emb), _p(keep_l0), float(p_drop), S1, B, H, K, int(Tw), _p(ws), ws.numel(),
+                                        _stream()), "attn_code_rollout_bwd")
 
 
 # ------------------------------------------------------------------------------------------ loss / optimiser / rng

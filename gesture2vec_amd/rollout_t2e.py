@@ -45,6 +45,93 @@ def decoder_params(dec) -> List[torch.Tensor]:
     return ps
 
 
+# Batch size from which the decode steps run as the FUSED per-step kernels (g2v_attn_code_rollout_fwd / _bwd, csrc/t2e_rollout.hip:
+# one 512-thread workgroup per 16 batch rows, everything between two BatchNorm seams in one launch).  Below it a batch has too
+# few row tiles to fill the chip and the column-split per-operator kernels (one launch each, every CU streaming a slice of the
+# weights) are faster -- the same crossover as the pose decoder's (dec_rollout.hip, "split" kernels).
+FUSED_MIN_ROWS = 1024
+
+
+def _fused_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
+    if spec.L != 2 or hidden0.shape[1] < FUSED_MIN_ROWS:
+        return False
+    B, H = hidden0.shape[1], hidden0.shape[2]
+    K = params[5 + 4 * spec.L].shape[0]
+    Tw = enc_out.shape[0] if spec.att else 0
+    return ops.code_rollout_ok(spec.steps, B, H, K, Tw, spec.att)
+
+
+def _fused_weights(spec, params, H):
+    emb_w, pre_w, pre_b, bn_w, bn_b = params[:5]
+    (w_ih0, w_hh0, b_ih0, b_hh0), (w_ih1, w_hh1, b_ih1, b_hh1) = params[5:9], params[9:13]
+    out_w, out_b = params[13:15]
+    wd = dict(emb=emb_w.contiguous(), w_pre=pre_w.contiguous(), b_pre=pre_b, bn_w=bn_w, bn_b=bn_b,
+              bn_running_mean=spec.bn_running_mean, bn_running_var=spec.bn_running_var,
+              w_ih0=w_ih0.contiguous(), w_hh0=w_hh0.contiguous(), b_ih0=b_ih0, b_hh0=b_hh0,
+              w_ih1=w_ih1.contiguous(), w_hh1=w_hh1.contiguous(), b_ih1=b_ih1, b_hh1=b_hh1,
+              w_out=out_w.contiguous(), b_out=out_b)
+    if spec.att:
+        attn_w, attn_b, attn_v = params[15:18]
+        wd.update(w_attn=attn_w.contiguous(), b_attn=attn_b, v_attn=attn_v.contiguous())
+    return wd
+
+
+def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
+    """The S1 decode steps as S1 + 1 launches of ONE kernel (include/g2v.h: g2v_attn_code_rollout_fwd)."""
+    S1, att = spec.steps, spec.att
+    B, H = hidden0.shape[1], hidden0.shape[2]
+    K = params[13].shape[0]
+    Hin = 2 * H if att else H
+    dev = hidden0.device
+    f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    wd = _fused_weights(spec, params, H)
+    drop = spec.dropout_p > 0 and spec.mask_l0 is not None
+    mask_emb = spec.mask_emb.contiguous()
+    mask_l0 = spec.mask_l0.contiguous() if drop else None
+    nblk = (B + 15) // 16
+    Tw = enc_out.shape[0] if att else 0
+    sv = dict(ids=torch.empty((S1, B), dtype=torch.int64, device=dev), ec=f32(S1, B, Hin), u=f32(S1, B, H), a=f32(S1, B, H),
+              bn_stats=f32(S1, 2, H), h0=f32(S1 + 1, B, H), h1=f32(S1 + 1, B, H), x1=f32(S1, B, H) if drop else None,
+              gates0=f32(S1, B, 4 * H), gates1=f32(S1, B, 4 * H), logits=f32(S1, B, K), bn_partial=f32(2, nblk, 2, H))
+    enc = ep = None
+    if att:
+        enc = enc_out.contiguous()
+        W_e = wd["w_attn"][:, H:].contiguous()
+        ep = ops.linear_fwd(enc.view(Tw * B, H), W_e).view(Tw, B, H)          # step-independent half of the energies
+        sv.update(hp=f32(S1, B, H), attw=f32(S1, B, Tw))
+    ops.code_rollout_fwd(spec.cod.contiguous(), hidden0.contiguous(), enc, ep, wd, sv, mask_emb, mask_l0,
+                         spec.dropout_p if drop else 0.0, spec.n_pre, True, S1, B, H, K, Tw)
+    ctx.save_for_backward(hidden0, enc_out, *params)
+    ctx.spec, ctx.dims, ctx.fused = spec, (S1, B, H, K, Hin, spec.L), True
+    ctx.bufs = dict(wd=wd, sv=sv, enc=enc, ep=ep, mask_emb=mask_emb, mask_l0=mask_l0, drop=drop, Tw=Tw)
+    AW = sv["attw"] if att else f32(0)
+    ctx.mark_non_differentiable(AW)
+    ctx.set_materialize_grads(False)
+    return sv["logits"], AW
+
+
+def _fused_backward(ctx, dLOG):
+    S1, B, H, K, Hin, L = ctx.dims
+    b, spec = ctx.bufs, ctx.spec
+    att = spec.att
+    dev = dLOG.device
+    f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    G = 3 * H
+    gr = dict(d_hidden0=f32(2, B, H), d_emb=f32(K, H), d_w_pre=f32(H, Hin), d_b_pre=f32(H), d_bn_w=f32(H), d_bn_b=f32(H),
+              d_w_ih0=f32(G, H), d_w_hh0=f32(G, H), d_b_ih0=f32(G), d_b_hh0=f32(G),
+              d_w_ih1=f32(G, H), d_w_hh1=f32(G, H), d_b_ih1=f32(G), d_b_hh1=f32(G), d_w_out=f32(K, H), d_b_out=f32(K))
+    if att:
+        gr.update(d_w_attn=f32(H, 2 * H), d_b_attn=f32(H), d_v_attn=f32(H), d_enc=f32(b["Tw"], B, H))
+    ops.code_rollout_bwd(dLOG.contiguous(), b["enc"], b["ep"], b["wd"], b["sv"], gr, b["mask_emb"], b["mask_l0"],
+                         spec.dropout_p if b["drop"] else 0.0, S1, B, H, K, b["Tw"])
+    grads = [gr["d_emb"], gr["d_w_pre"], gr["d_b_pre"], gr["d_bn_w"], gr["d_bn_b"],
+             gr["d_w_ih0"], gr["d_w_hh0"], gr["d_b_ih0"], gr["d_b_hh0"], gr["d_w_ih1"], gr["d_w_hh1"], gr["d_b_ih1"], gr["d_b_hh1"],
+             gr["d_w_out"], gr["d_b_out"]]
+    if att:
+        grads += [gr["d_w_attn"], gr["d_b_attn"], gr["d_v_attn"]]
+    return (gr["d_hidden0"], gr["d_enc"] if att else None, None, *grads)
+
+
 class CodeDecoderRollout(torch.autograd.Function):
     """(hidden0 (L,B,H), encoder_outputs (Tw,B,H) or None, spec, *decoder_params) -> logits (S-1,B,K), attention weights
     (S-1,B,Tw) (empty without attention; not differentiable)."""
@@ -52,6 +139,9 @@ class CodeDecoderRollout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, hidden0, enc_out, spec: RolloutSpec, *params):
         L, att, S1 = spec.L, spec.att, spec.steps
+        if _fused_ok(hidden0, enc_out, spec, params):
+            return _fused_forward(ctx, hidden0, enc_out, spec, params)
+        ctx.fused = False
         emb_w, pre_w, pre_b, bn_w, bn_b = params[:5]
         gru = [params[5 + 4 * l: 9 + 4 * l] for l in range(L)]            # (w_ih, w_hh, b_ih, b_hh) per layer
         out_w, out_b = params[5 + 4 * L: 7 + 4 * L]
@@ -127,6 +217,8 @@ class CodeDecoderRollout(torch.autograd.Function):
         n_in = 3 + 5 + 4 * L + 2 + (3 if ctx.spec.att else 0)
         if dLOG is None:
             return (None,) * n_in
+        if ctx.fused:
+            return _fused_backward(ctx, dLOG)
         b, att = ctx.bufs, ctx.spec.att
         bn_w = ctx.saved_tensors[2 + 3]
         dev = dLOG.device

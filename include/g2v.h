@@ -436,6 +436,13 @@ int g2v_dec_rollout_bwd(const g2v_dec_weights* w, const g2v_dec_saved* s, const 
  * prepare is a no-op and *_prepared == the plain call.  bwd_workspace may be NULL (inference). */
 int g2v_dec_rollout_prepare(const g2v_dec_weights* w, int D, int H, void* fwd_workspace, size_t fwd_bytes,
                             void* bwd_workspace, size_t bwd_bytes, g2v_stream_t stream);
+/* Round 5: g2v_dec_rollout_prepare (both workspaces) AND g2v_gru_seq_prepare (backward workspace only; w_hh / w_ih: one pointer
+ * per direction) of one fused train step as ONE launch instead of six (three packs, two memset nodes, one pack).  H == 64,
+ * D == 135 only (G2V_ERR_UNSUPPORTED otherwise, nothing launched: call the two functions). */
+int g2v_train_step_prepare(const g2v_dec_weights* w, int D, int H, void* dec_fwd_workspace, size_t dec_fwd_bytes,
+                           void* dec_bwd_workspace, size_t dec_bwd_bytes, const float* const* gru_w_hh,
+                           const float* const* gru_w_ih, int gru_ndir, int gru_fused, void* gru_bwd_workspace,
+                           size_t gru_bwd_bytes, g2v_stream_t stream);
 int g2v_dec_rollout_fwd_prepared(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
                                  const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
                                  int conditioned, int training, int T, int B, int D, int H, void* workspace,
@@ -589,6 +596,90 @@ size_t g2v_attn_bwd_workspace(int B, int H);
 int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, const float* ep, const float* enc, const float* v,
                  const float* weights, float* d_hp, float* d_ep, float* d_enc, float* d_v, int accumulate, int T, int B,
                  int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K13 + K14 (SURVEY.md 8(b) "attn_code_rollout_fwd/bwd"): the greedy gesture-code decoder of Part d as FUSED PER-STEP KERNELS.
+ * Replaces the loop model/text2embedding_model.py:701-744 over BahdanauAttnDecoderRNN.forward (:338-395), n_layers == 2,
+ * discrete_representation (code ids in, logits out):
+ *   e_t   = Dropout(0.5)(Embedding(id_t))                                  (:340-343; keep_emb, scale 2)
+ *   [att] w_t = softmax_tw( v . tanh(attn([h1_{t} ; enc[tw]])) ), ctx_t = sum_tw w_t[tw] enc[tw]; x_t = [e_t | ctx_t]   (:347-359)
+ *   u_t   = x_t W_pre^T + b_pre;  a_t = ReLU(BatchNorm1d(u_t))              (:376, batch statistics when training)
+ *   h0_{t+1}, h1_{t+1} = GRU(a_t; h0_t, h1_t)  (inter-layer dropout p on h0: keep_l0)      (:380)
+ *   logits_t = h1_{t+1} W_out^T + b_out                                     (:390)
+ *   id_{t+1} = codes[t+1] while t + 1 < n_pre, else argmax_k logits_t (lowest index on ties)    (:737-744)
+ * for t = 0 .. S1-1 (S1 = sentence_frame_length // n_frames - 1; id_0 = codes[0]).  The step is row-local except for
+ * BatchNorm's batch statistics, so the forward is S1 + 1 launches of ONE kernel (16 batch rows per 512-thread workgroup; launch j =
+ * [BatchNorm finish of u_{j-1}, both GRU cells, out layer, argmax] + [embedding, attention, pre_linear of step j, per-workgroup
+ * partial sums]); every contraction is v_mfma_f32_16x16x4_f32 on weights packed once per call.  Without attention nothing in
+ * the BACKWARD couples batch rows between steps (the argmax feedback carries no gradient), so the whole BPTT over the S1 steps is
+ * ONE launch (carries in LDS), followed by the BatchNorm backward of all steps at once and the batched products that do not
+ * feed the recurrence (embedding gradient, every weight gradient over the S1 x B rows).  With attention the context gradient
+ * needs BatchNorm's backward sums of the same step: the backward is S1 launches, each [BatchNorm backward finish of step t+1 ->
+ * d(input) -> attention backward -> d(h1_t)] + [cells of step t].
+ * H % 4 == 0, H <= 256, K <= 1024, Tw <= 64; g2v_attn_code_rollout_ok() says whether a shape is served (0: chain the operators
+ * above from the host, as rounds 1-4 did).  All arrays caller-owned, time-major, fp32 unless said.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* emb;              /* (K,H)    decoder.embedding.weight                         */
+  const float* w_pre;            /* (H,Hin)  decoder.pre_linear.0.weight; Hin = H, or 2H with attention */
+  const float* b_pre;            /* (H)                                                       */
+  const float* bn_w;             /* (H)      pre_linear.1.weight                              */
+  const float* bn_b;             /* (H)                                                       */
+  float* bn_running_mean;        /* (H)      updated once per step when training              */
+  float* bn_running_var;         /* (H)                                                       */
+  const float* w_ih0; const float* w_hh0; const float* b_ih0; const float* b_hh0;   /* (3H,H), (3H) */
+  const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1;
+  const float* w_out;            /* (K,H)    decoder.out.weight                               */
+  const float* b_out;            /* (K)                                                       */
+  const float* w_attn;           /* (H,2H)   attn.attn.weight: [:, :H] on the state, [:, H:] on the encoder outputs; NULL = no attention */
+  const float* b_attn;           /* (H)                                                       */
+  const float* v_attn;           /* (H)      attn.v                                           */
+} g2v_code_dec_weights;
+
+typedef struct {                 /* outputs + saved for backward                              */
+  int64_t* ids;                  /* (S1,B)    the code fed at every step                      */
+  float* ec;                     /* (S1,B,Hin) dropped embedding [| context]                  */
+  float* u;                      /* (S1,B,H)                                                  */
+  float* a;                      /* (S1,B,H)                                                  */
+  float* bn_stats;               /* (S1,2,H)  batch mean / 1/sqrt(biased var + eps) per step  */
+  float* h0;                     /* (S1+1,B,H) slot t = state in front of step t              */
+  float* h1;                     /* (S1+1,B,H)                                                */
+  float* x1;                     /* (S1,B,H)  dropped h0_{t+1} (layer 1's input); NULL without inter-layer dropout */
+  float* gates0;                 /* (S1,B,4H) r, z, n, W_hn h + b_hn                          */
+  float* gates1;                 /* (S1,B,4H)                                                 */
+  float* logits;                 /* (S1,B,K)                                                  */
+  float* bn_partial;             /* (2,nblk,2,H) scratch, nblk = g2v_attn_code_rollout_blocks(B) */
+  float* hp;                     /* (S1,B,H)  attention: h1_t W_attn[:, :H]^T + b_attn; NULL without attention */
+  float* attw;                   /* (S1,B,Tw) attention weights                               */
+} g2v_code_dec_saved;
+
+typedef struct {                 /* gradients (overwritten)                                   */
+  float* d_hidden0;              /* (2,B,H)   w.r.t. the initial state                        */
+  float* d_emb;                  /* (K,H)                                                     */
+  float* d_w_pre; float* d_b_pre; float* d_bn_w; float* d_bn_b;
+  float* d_w_ih0; float* d_w_hh0; float* d_b_ih0; float* d_b_hh0;
+  float* d_w_ih1; float* d_w_hh1; float* d_b_ih1; float* d_b_hh1;
+  float* d_w_out; float* d_b_out;
+  float* d_w_attn; float* d_b_attn; float* d_v_attn;      /* attention only                    */
+  float* d_enc;                  /* (Tw,B,H)  w.r.t. the encoder outputs (context + energies)  */
+} g2v_code_dec_grads;
+
+int g2v_attn_code_rollout_ok(int S1, int B, int H, int K, int Tw, int attention);
+int g2v_attn_code_rollout_blocks(int B);
+size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention);
+/* codes (S,B) int64 (rows 0 .. max(1, n_pre) - 1 are read); h_init (2,B,H); enc (Tw,B,H) and enc_proj = enc W_attn[:, H:]^T
+ * (Tw,B,H) with attention, else NULL; keep_emb / keep_l0 (S1,B,H) uint8 keep masks (NULL: no dropout; training == 0: eval
+ * BatchNorm on the running statistics). */
+int g2v_attn_code_rollout_fwd(const int64_t* codes, const float* h_init, const float* enc, const float* enc_proj,
+                              const g2v_code_dec_weights* w, const g2v_code_dec_saved* s, const uint8_t* keep_emb,
+                              const uint8_t* keep_l0, float p_drop, int n_pre, int training, int S1, int B, int H, int K,
+                              int Tw, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+size_t g2v_attn_code_rollout_bwd_workspace(int S1, int B, int H, int K, int Tw, int attention);
+/* d_logits (S1,B,K); everything else as passed to the forward of the same call. */
+int g2v_attn_code_rollout_bwd(const float* d_logits, const float* enc, const float* enc_proj, const g2v_code_dec_weights* w,
+                              const g2v_code_dec_saved* s, const g2v_code_dec_grads* g, const uint8_t* keep_emb,
+                              const uint8_t* keep_l0, float p_drop, int S1, int B, int H, int K, int Tw, void* workspace,
+                              size_t workspace_bytes, g2v_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Calibration probes used by bench.py to report what the box sustains next to the datasheet peaks (no counterpart in the
