@@ -117,6 +117,7 @@ _SIGS = {
     "g2v_gru_seq_fwd_prepared": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_prepared": (c_int, [C.POINTER(GruDirBwd), c_int, c_fp, c_i64, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_prepare": (c_int, [C.POINTER(DecWeights), c_int, c_int, c_fp, c_sz, c_fp, c_sz, c_fp]),
+    "g2v_bn_running_update": (c_int, [c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_train_step_prepare": (c_int, [C.POINTER(DecWeights), c_int, c_int, c_fp, c_sz, c_fp, c_sz, c_fp, c_fp, c_int, c_int, c_fp,
                                        c_sz, c_fp]),
     "g2v_dec_rollout_fwd_prepared": (c_int, [c_fp, c_fp, C.POINTER(DecWeights), C.POINTER(DecSaved), c_fp, c_fp, c_f,

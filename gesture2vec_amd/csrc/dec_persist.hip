@@ -12,6 +12,7 @@
 //   per step  : [hidden-side products W_hh0 h0, W_hh1 h1 -- independent of BatchNorm, they run while the exchange of the
 //               previous step's partial sums is in flight] -> exchange -> BN + ReLU -> cell 0 -> cell 1 -> out layer ->
 //               Dropout(0.95) -> pre_linear -> partial sums -> publish
+#define G2V_PERSIST_DEVICE_CODE      // this translation unit owns the fault latch (dec_persist.hpp)
 #include "dec_persist.hpp"
 #include <utility>
 #ifndef G2V_BWD_EPI
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
   const int64_t BH = (int64_t)B * H;
   const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
   float run_m = 0.f, run_v = 0.f;                    // BatchNorm running statistics (workgroup 0, tid < H)
-  if (training && b == 0 && tid < H) {
+  // (w.bn_running_mean == NULL while training: the caller commits the running statistics itself, g2v_bn_running_update)
+  if (training && b == 0 && tid < H && a.w.bn_running_mean) {
     run_m = a.w.bn_running_mean[tid];
     run_v = a.w.bn_running_var[tid];
   }
@@ -593,7 +595,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_kernel(DecPersistArgs 
     // (no barrier needed here: the next writers of Xy / Yt / Xt sit behind the barriers of step t+1)
   }
   // (a latched fault -- a bounded wait of the exchange ran out -- means garbage statistics: the model's state stays as it was)
-  if (training && b == 0 && tid < H && __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+  if (training && b == 0 && tid < H && a.w.bn_running_mean &&
+      __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
     a.w.bn_running_mean[tid] = run_m;
     a.w.bn_running_var[tid] = run_v;
   }
@@ -645,7 +648,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
   const int64_t BH = (int64_t)B * H;
   const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
   float run_m = 0.f, run_v = 0.f;
-  if (training && b == 0 && tid < H) {
+  // (w.bn_running_mean == NULL while training: the caller commits the running statistics itself, g2v_bn_running_update)
+  if (training && b == 0 && tid < H && a.w.bn_running_mean) {
     run_m = a.w.bn_running_mean[tid];
     run_v = a.w.bn_running_var[tid];
   }
@@ -926,7 +930,8 @@ __global__ __launch_bounds__(256, 1) void dec_persist_fwd_mt_kernel(DecPersistAr
       px_publish2(rr, (unsigned)(H + f0) + 2, s2a[2], s2a[3], tag);
     }
   }
-  if (training && b == 0 && tid < H && __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+  if (training && b == 0 && tid < H && a.w.bn_running_mean &&
+      __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
     a.w.bn_running_mean[tid] = run_m;
     a.w.bn_running_var[tid] = run_v;
   }

@@ -42,8 +42,14 @@ namespace g2v {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// sticky fault latch of the persistent kernels (translation-unit local: only dec_persist.hip's kernels and reader use it)
+// Sticky fault latch of the persistent kernels.  ONE translation unit owns it -- dec_persist.hip, which holds every kernel that
+// latches it, its host reader / clear and g2v_internal_persist_fault_ptr() -- and defines G2V_PERSIST_DEVICE_CODE in front of
+// this header; every other includer (dec_rollout.hip: the layout constants) gets neither the latch nor the device functions that
+// use it, so no kernel elsewhere can fault into a private copy nobody reads (round-4 advisor finding).  Stand-alone tools
+// (gpurun_tools/px_test.hip) define the macro themselves.
+#ifdef G2V_PERSIST_DEVICE_CODE
 static __device__ unsigned g2v_persist_fault;
+#endif
 
 constexpr int PX_GROUP = 16;          // workgroups per exchange group
 constexpr int PX_MAX_NBLK = 256;      // one workgroup per CU on MI355X
@@ -155,6 +161,7 @@ __device__ __forceinline__ int px_row_on_one_xcd(const PersistX& x, int nblk, in
 // in which the wave would only wait -- the one place in these kernels where independent VALU / LDS work is free (beside the
 // fp32 MFMAs it is not: measured, every filler instruction costs its full issue time there).  No vector-memory instruction
 // in a filler: vmcnt counts in order, the sweep's wait would include it.
+#ifdef G2V_PERSIST_DEVICE_CODE
 struct PxNoFiller {
   __device__ __forceinline__ void operator()() const {}
 };
@@ -266,5 +273,7 @@ __device__ __forceinline__ void px_exchange(const PersistX& x, int par, unsigned
   px_hop1(x, par, tag, nblk, b, red, tot, tid, xl);
   if (px_two_hops(nblk)) px_hop2(x, par, tag, nblk, b, red, tot, tid);
 }
+
+#endif      // G2V_PERSIST_DEVICE_CODE
 
 }  // namespace g2v

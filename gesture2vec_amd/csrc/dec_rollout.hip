@@ -548,9 +548,10 @@ __global__ __launch_bounds__(HS > 0 ? 256 : 512) void dec_step_fwd_kernel(const 
 
 // running_mean / running_var (momentum 0.1, unbiased variance), applied T-1 times in step order
 __global__ void bn_running_update_kernel(const float* __restrict__ bn_stats, float* __restrict__ rm,
-                                         float* __restrict__ rv, int steps, int H, int B) {
+                                         float* __restrict__ rv, int steps, int H, int B, const unsigned* __restrict__ fault) {
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= H) return;
+  if (fault && *fault != 0u) return;      // a latched fault of the persistent rollouts: the statistics are garbage, the state stays
   float m = rm[f], v = rv[f];
   const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
   for (int s0 = 0; s0 < steps; s0 += 8) {   // 16 independent loads in flight, then the 8 dependent updates
@@ -1647,7 +1648,11 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
   G2V_REQUIRE(target && h_init && w && s && keep95 && workspace, "null pointer");
   G2V_REQUIRE(T >= 2 && B > 0 && D > 0 && H > 0, "bad size");
   G2V_REQUIRE(s->y && s->u && s->h0 && s->h1 && s->bn_partial, "missing state buffer");
-  G2V_REQUIRE(!training || (s->xin && s->a && s->gates0 && s->gates1 && s->bn_stats), "missing saved buffer");
+  // (training: xin / a / x1 / gates0 / gates1 left NULL are simply not saved -- a training-mode forward without a backward, and
+  //  how gpurun_tools/r05_saved_diet_probe.py prices the stores; g2v_dec_rollout_bwd requires all of them)
+  G2V_REQUIRE(!training || s->bn_stats, "missing saved buffer");
+  G2V_REQUIRE(training || (w->bn_running_mean && w->bn_running_var), "eval mode needs the running statistics");
+  G2V_REQUIRE((w->bn_running_mean == nullptr) == (w->bn_running_var == nullptr), "running mean / var: both or neither");
   G2V_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
   if (workspace_bytes < g2v_dec_rollout_fwd_workspace(D, H)) {
     set_error("g2v_dec_rollout_fwd: workspace too small");
@@ -1740,11 +1745,26 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     }
   }
   G2V_CHECK_LAUNCH();
-  if (training) {
+  if (training && w->bn_running_mean) {      // (NULL: the caller commits them later, g2v_bn_running_update)
     hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, st, s->bn_stats,
-                       w->bn_running_mean, w->bn_running_var, T - 1, H, B);
+                       w->bn_running_mean, w->bn_running_var, T - 1, H, B, (const unsigned*)nullptr);
     G2V_CHECK_LAUNCH();
   }
+  return G2V_OK;
+}
+
+// BatchNorm1d's running statistics from the per-step batch statistics a TRAINING rollout saved (g2v_dec_saved.bn_stats), for a
+// caller that passed g2v_dec_weights.bn_running_mean / _var = NULL to that rollout: the commit then happens HERE, where the
+// caller knows the whole step is valid -- the kernel reads the persistent rollouts' fault latch and leaves the statistics
+// untouched when it is set (round 5, advisor finding: the forward rollout used to commit them at its end, before a fault of the
+// backward rollout or of the loss chaser could be known).
+extern "C" int g2v_bn_running_update(const float* bn_stats, float* running_mean, float* running_var, int steps, int H, int B,
+                                     g2v_stream_t stream) {
+  G2V_REQUIRE(bn_stats && running_mean && running_var, "null pointer");
+  G2V_REQUIRE(steps > 0 && H > 0 && B > 0, "bad size");
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, bn_stats, running_mean,
+                     running_var, steps, H, B, g2v_internal_persist_fault_ptr());
+  G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
 

@@ -373,10 +373,12 @@ __global__ __launch_bounds__(CT_NTHR) void code_step_fwd_kernel(const int64_t* _
     float* part = sv.bn_partial + ((int64_t)(j & 1) * dm.nblk + blockIdx.x) * 2 * H;
     for (int ft = wave; ft < ntile; ft += NW) {
       const int f0 = 16 * ft + 4 * q;
-      if (f0 + 3 >= H) continue;       // (H % 4 == 0: a group of four is whole or padding; the MFMA below is wave-uniform per ft)
-      const float4 bp = *reinterpret_cast<const float4*>(w.b_pre + f0);
+      const bool vec = f0 + 3 < H;       // (H % 4 == 0: a lane's group of four features is whole or padding)
+      float4 bp = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec) bp = *reinterpret_cast<const float4*>(w.b_pre + f0);
       f32x4 acc[1] = {(f32x4){0.f, 0.f, 0.f, 0.f}};
-      wave_gemm_p<1, 0>(acc, pk.pre, Hinp >> 4, ft, 0, Xe, ldx, lane);
+      wave_gemm_p<1, 0>(acc, pk.pre, Hinp >> 4, ft, 0, Xe, ldx, lane);      // (every lane of the wave: an MFMA is not predicated)
+      if (!vec) continue;               // (uniform per DPP row of 16 lanes: the reductions below stay whole)
       float s1[4], s2[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -417,24 +419,22 @@ struct CodeBwdArgs {
   float* d_hidden0;          // (2,B,H)
 };
 
+// LDS carve of the backward kernels (floats).  H = 200, K = 512: 152 KB of the CU's 160 -- the d logits tile [16][K] doubles as
+// the layer-0 incoming gradient tile (written after the out-layer product has consumed it), and the attention phase (Part A of
+// code_step_bwd_att_kernel, in front of the cells) borrows the gate tiles: nothing of its own.
 struct CtBwdLds {
-  int xdl, gi, gh, dd, xdx, c0, c1, st, red, scratch, sc, total;
+  int xdl, gi, gh, dd, c0, c1, total;
 };
-static __host__ __device__ inline CtBwdLds ct_bwd_lds(int H, int K, int Tw, int scratch, bool att) {
+static __host__ __device__ inline CtBwdLds ct_bwd_lds(int H, int K) {
   const int Hp = (H + 15) & ~15, ldh = Hp + 4, Gp = (3 * H + 15) & ~15, ldg = Gp + 4, Kp = (K + 15) & ~15, ldk = Kp + 4;
   CtBwdLds l;
   int o = 0;
-  l.xdl = o; o += 16 * ldk;      // d logits tile; attention phase: du tile [16][ldh] + d ctx tile [16][ldh] alias its front
-  l.gi = o; o += 16 * ldg;
-  l.gh = o; o += 16 * ldg;
-  l.dd = o; o += 16 * ldh;
-  l.xdx = o; o += 16 * ldh;
+  l.xdl = o; o += 16 * (ldk > 2 * ldh ? ldk : 2 * ldh);   // d logits tile; then Xdx [16][ldh]; attention: du | d ctx tiles
+  l.gi = o; o += 16 * ldg;                                // attention: d hp tile
+  l.gh = o; o += 16 * ldg;                                // attention: BatchNorm sums + reduction scratch, then the d v rows
+  l.dd = o; o += 16 * ldh;                                // attention: d_w / ds and the attention weights [2][16][Tw]
   l.c0 = o; o += 16 * ldh;
   l.c1 = o; o += 16 * ldh;
-  l.st = o; o += att ? 2 * Hp : 0;
-  l.red = o; o += att ? 2 * Hp : 0;
-  l.scratch = o; o += att ? scratch : 0;
-  l.sc = o; o += att ? 2 * 16 * (Tw > 0 ? Tw : 1) : 0;
   l.total = o;
   return l;
 }
@@ -450,7 +450,7 @@ __device__ __forceinline__ void code_bwd_cells(const CodeBwdArgs& a, const CodeD
   float* Gi = smem + L.gi;
   float* Gh = smem + L.gh;
   float* Dd = smem + L.dd;
-  float* Xdx = smem + L.xdx;
+  float* Xdx = smem + L.xdl;      // (the d logits tile is dead once cell 1's products have read it: barrier in between)
   float* C0 = smem + L.c0;
   float* C1 = smem + L.c1;
   const int lane = tid & 63, wave = tid >> 6;
@@ -466,12 +466,13 @@ __device__ __forceinline__ void code_bwd_cells(const CodeBwdArgs& a, const CodeD
       cell_bwd_prefetch(cin1[m], first ? nullptr : C1, nullptr, a.sv.gates1 + ((int64_t)t * B + b0) * 4 * H,
                         a.sv.h1 + ((int64_t)t * B + b0) * H, H, wave + NW * m, nrows, lane, ldh);
   // d logits tile of step t: 16 rows x K, 16-byte vectors
+  // (padding columns and rows rewritten every step: the region doubles as the Xdx tile, below)
   {
-    const int K4 = K >> 2;
+    const int K4 = Kp >> 2;
     for (int e = tid; e < 16 * K4; e += NTHR) {
       const int r = e / K4, c = (e - r * K4) * 4;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < nrows) v = *reinterpret_cast<const float4*>(a.d_logits + ((int64_t)t * B + b0 + r) * K + c);
+      if (r < nrows && c < K) v = *reinterpret_cast<const float4*>(a.d_logits + ((int64_t)t * B + b0 + r) * K + c);
       *reinterpret_cast<float4*>(Xdl + r * ldk + c) = v;
     }
   }
@@ -585,7 +586,7 @@ __device__ __forceinline__ void code_bwd_write_hidden0(const CodeBwdArgs& a, con
 // no attention: the whole BPTT in one launch
 __global__ __launch_bounds__(CT_NTHR) void code_bptt_kernel(CodeBwdArgs a, CodeDims dm) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K, dm.Tw, dm.scratch, false);
+  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K);
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * 16, nrows = min(16, dm.B - b0);
   for (int e = tid; e < L.total; e += CT_NTHR) smem[e] = 0.f;      // padding columns / rows >= nrows of every operand tile, carries
@@ -674,7 +675,7 @@ __global__ void code_join_cols_kernel(const float* __restrict__ a, const float* 
 __global__ __launch_bounds__(CT_NTHR) void code_step_bwd_att_kernel(CodeBwdArgs a, CodeDims dm, int t) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int NTHR = CT_NTHR, NW = CT_NW;
-  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K, dm.Tw, dm.scratch, true);
+  const CtBwdLds L = ct_bwd_lds(dm.H, dm.K);
   const int S1 = dm.S1, B = dm.B, H = dm.H, Tw = dm.Tw;
   const int Hp = (H + 15) & ~15, ldh = Hp + 4, H4 = H >> 2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -685,9 +686,9 @@ __global__ __launch_bounds__(CT_NTHR) void code_step_bwd_att_kernel(CodeBwdArgs 
   float* Xdu = smem + L.xdl;               // [16][ldh]   (the d logits tile is staged after Part A)
   float* Xdc = Xdu + 16 * ldh;             // [16][ldh]   d ctx
   float* Xdhp = smem + L.gi;               // [16][ldh]   d hp (Gi is free until the cells)
-  float* red = smem + L.red;
-  float* red_scratch = smem + L.scratch;
-  float* dsc = smem + L.sc;                // [16][Tw] d_w -> ds
+  float* red = smem + L.gh;                // [2H] BatchNorm backward sums (Gh is free until the cells; dead before the d v rows land)
+  float* red_scratch = red + 2 * Hp;       // [dm.scratch]
+  float* dsc = smem + L.dd;                // [16][Tw] d_w -> ds          (Dd is free until the cells: 2 x 16 x 64 <= 16 x ldh)
   float* wsc = dsc + 16 * Tw;              // [16][Tw] attention weights of step t+1
   const bool last = (t == S1 - 1);
   for (int e = tid; e < L.total; e += NTHR) smem[e] = 0.f;
@@ -827,8 +828,8 @@ __global__ __launch_bounds__(CT_NTHR) void code_step_bwd_att_kernel(CodeBwdArgs 
       }
     }
     lds_barrier();
-    // Gi / Gh / the front of Xdl were borrowed: padding back to zero for the cells
-    for (int e = tid; e < L.dd; e += NTHR) smem[e] = 0.f;
+    // Xdl / Gi / Gh / Dd were borrowed: padding back to zero for the cells
+    for (int e = tid; e < L.c0; e += NTHR) smem[e] = 0.f;
     lds_barrier();
   }
   if (t >= 0) code_bwd_cells(a, dm, L, smem, t, b0, nrows, tid, last);
@@ -852,7 +853,9 @@ extern "C" int g2v_attn_code_rollout_ok(int S1, int B, int H, int K, int Tw, int
   if (attention && (Tw < 1 || Tw > CT_MAX_TW)) return 0;
   const int Hin = attention ? 2 * H : H;
   const size_t lf = (size_t)ct_fwd_lds(H, Hin, attention ? Tw : 0, 1024).total * 4;
-  const size_t lb = (size_t)ct_bwd_lds(H, K, attention ? Tw : 0, 1024, attention != 0).total * 4;
+  const size_t lb = (size_t)ct_bwd_lds(H, K).total * 4;
+  const int Hp = (H + 15) & ~15;
+  if (attention && (2 * Hp + 1024 > 16 * (((3 * H + 15) & ~15) + 4) || 2 * 16 * Tw > 16 * (Hp + 4))) return 0;   // what Part A borrows
   return lf <= 160 * 1024 && lb <= 160 * 1024;
 }
 
@@ -1010,9 +1013,10 @@ extern "C" int g2v_attn_code_rollout_bwd(const float* d_logits, const float* enc
   a.dhp = att ? (float*)(base + L.dhp) : nullptr; a.d_ep = att ? (float*)(base + L.d_ep) : nullptr; a.d_enc = att ? g->d_enc : nullptr;
   a.dv_partial = att ? (float*)(base + L.dvp) : nullptr;
   a.bn_part = (float*)(base + L.bn_part); a.bn_sums = (float*)(base + L.bn_sums); a.d_hidden0 = g->d_hidden0;
-  const int scratch = ct_scratch((size_t)ct_bwd_lds(H, K, att ? Tw : 0, 0, att != 0).total);
+  const int Hp = (H + 15) & ~15;
+  const int scratch = (2 * Hp + 2048 <= 16 * (((3 * H + 15) & ~15) + 4)) ? 2048 : 1024;      // (Part A's reduction scratch lives in Gh)
   CodeDims dm{S1, B, H, K, Hin, att ? Tw : 0, drop ? p_drop : 0.f, 0, 1, cdiv(B, 16), att, scratch};
-  const size_t lds = (size_t)ct_bwd_lds(H, K, dm.Tw, scratch, att != 0).total * sizeof(float);
+  const size_t lds = (size_t)ct_bwd_lds(H, K).total * sizeof(float);
   void* wgws = base + L.wg;
   const size_t wgn = L.emb - L.wg;
   int rc;

@@ -135,9 +135,9 @@ class VQVAEEngine:
         self.ema_cs = torch.zeros(K, device=dev)
         self.code_sqnorm = torch.zeros(K, device=dev)
         # What the fused assign kernels read besides the codebook itself, all DERIVED from (codebook, pre_linear) by vq_derive():
-        #   bf16-screened kernel (g2v_vq_fused_assign_bx_fwd, E == 128, K in {128..512}; G2V_VQ_BX=0 selects the fp32 kernel):
+        #   bf16-screened kernel (g2v_vq_fused_assign_bx_fwd, where g2v_vq_fused_assign_bx_ok says so: E == 128, K in {128..512}):
         #     pre_linear's weight as fp32 MFMA fragments + the screening image (bf16 fragments of U = W w_pre, s'_k, norm bounds);
-        #   fp32 kernel: fragment-major image of the codebook (G2V_VQ_PACKED=0: it reads the row-major codebook instead, A/B).
+        #   fp32 kernel (every other shape): fragment-major image of the codebook.
         self._vq_bx = bool(self.lib.g2v_vq_fused_assign_bx_ok(1, self.E, K))
         # custom_loss by the CHASER kernel beside the persistent forward rollout + the backward rollout's own tile load
         # (include/g2v.h: g2v_custom_loss_chase, g2v_dec_saved.loss_*) instead of its own launch between the rollouts, wherever the
@@ -203,6 +203,12 @@ class VQVAEEngine:
         # (same-box A/B, 3 x 300 steps each, profiles/r05_b_side_ab.log: 1.558 -> 1.540 ms with both; attributes, not environment)
         self.side_early = True
         self.merged_prepare = True
+        # Round 5 (advisor finding): inside the fused train step the kernels that COMMIT the step to the model state beside Adam --
+        # the EMA codebook update and the BatchNorm running statistics -- run BEHIND the backward rollout (end of branch 2), where the
+        # persistent rollouts' and the chaser's fault latch is final; they used to run beside / at the end of the FORWARD rollout, i.e.
+        # before a fault of this very step could be known, so "the step was not applied" did not hold for them.
+        self._defer_commit = False          # set for the duration of _train_step_local
+        self._commit_pending = None         # (B, ema: bool) between forward() and _commit_state()
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
@@ -317,7 +323,13 @@ class VQVAEEngine:
                 setattr(s, f"b_hh{l}", self._w(pre + f"gru.bias_hh_l{l}"))
             s.w_out, s.b_out = self._w(pre + "out_layer.weight"), self._w(pre + "out_layer.bias")
             self._wstruct = s
-        return self._wstruct
+            # the same weights WITHOUT the running statistics: a training rollout given this one does not commit them (the fused
+            # train step does, behind the backward rollout: _commit_state)
+            d = DecWeights()
+            C.memmove(C.byref(d), C.byref(s), C.sizeof(DecWeights))
+            d.bn_running_mean = d.bn_running_var = None
+            self._wstruct_deferred = d
+        return self._wstruct_deferred if self._defer_commit else self._wstruct
 
     # ------------------------------------------------------------------ buffers
     def buffers(self, B: int) -> dict:
@@ -877,6 +889,20 @@ class VQVAEEngine:
                                                   self._stream()))
         return wgrad, wgrad4
 
+    def _commit_state(self):
+        """The fused train step's deferred commits (see __init__): EMA codebook update + loss / perplexity scalars (single GPU;
+        under data parallelism train_step_apply runs it behind the all-reduce) and BatchNorm's running statistics from the
+        rollout's saved batch statistics.  Both kernels are gated on the persistent rollouts' fault latch on the device.  Launched
+        on the current stream: backward_decoder calls it at the end of its weight-gradient branch, i.e. behind the backward rollout."""
+        if self._commit_pending is None:
+            return
+        B, ema = self._commit_pending
+        self._commit_pending = None
+        b = self.buffers(B)
+        if ema:
+            self.vq_finish(B, True)
+        check(self.lib.g2v_bn_running_update(_p(b["bn_stats"]), _p(self.bn_rm), _p(self.bn_rv), self.T - 1, self.H, B, self._stream()))
+
     def backward_decoder(self, B: int, wgrad_branch: bool = False, wgrad_late: Optional[bool] = None):
         """Backward of forward_decoder(training=True): expects buffers['dy'] = dLoss/d y (T,B,D); writes the decoder's
         parameter gradients (overwrite) and buffers['dh_init'] (2,B,H) = dLoss / d(initial hidden state).
@@ -916,6 +942,7 @@ class VQVAEEngine:
             for name in self.frozen:
                 g = self.view(name, True)
                 check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
+            self._commit_state()            # behind the backward rollout: the fault latch of this step is final
         if wgrad_branch:
             self._fork(2, products, late=wgrad_late)      # (wgrad_late: launched by the caller's _release())
         else:
@@ -1050,6 +1077,8 @@ class VQVAEEngine:
             self._prepared = False
             self._side_work = None
             self._fused_in_drop = False
+            self._defer_commit = False
+            self._commit_pending = None
 
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         self._fused_in_drop = bool(draw_masks and self.p > 0)      # the encoder's input mask is drawn inside its dropout kernel
@@ -1075,9 +1104,13 @@ class VQVAEEngine:
         self._side_work = side
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)
-        self.forward(x, target, True, ema_update=not dp, derived_ready=True, loss_w=(w_l1, w_cont, w_var), join_stats=False)
+        self._defer_commit = True
+        self._commit_pending = (B, (not dp) and self.quantizer == "ema")
+        self.forward(x, target, True, ema_update=False, derived_ready=True, loss_w=(w_l1, w_cont, w_var),
+                     join_stats=False)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         self.backward(x, B, g_vq)
+        self._commit_state()                   # (a no-op when backward_decoder's branch has run it)
         self._join(1)                          # the statistics / codebook-update branch (forward(join_stats=False); a no-op behind the chaser's join)
 
     def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),

@@ -50,6 +50,7 @@ def decoder_params(dec) -> List[torch.Tensor]:
 # few row tiles to fill the chip and the column-split per-operator kernels (one launch each, every CU streaming a slice of the
 # weights) are faster -- the same crossover as the pose decoder's (dec_rollout.hip, "split" kernels).
 FUSED_MIN_ROWS = 1024
+FUSED_CALLS = 0          # forwards served by the fused kernels (tests assert that the path under test actually ran)
 
 
 def _fused_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
@@ -78,6 +79,8 @@ def _fused_weights(spec, params, H):
 
 def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     """The S1 decode steps as S1 + 1 launches of ONE kernel (include/g2v.h: g2v_attn_code_rollout_fwd)."""
+    global FUSED_CALLS
+    FUSED_CALLS += 1
     S1, att = spec.steps, spec.att
     B, H = hidden0.shape[1], hidden0.shape[2]
     K = params[13].shape[0]
@@ -103,7 +106,11 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
                          spec.dropout_p if drop else 0.0, spec.n_pre, True, S1, B, H, K, Tw)
     ctx.save_for_backward(hidden0, enc_out, *params)
     ctx.spec, ctx.dims, ctx.fused = spec, (S1, B, H, K, Hin, spec.L), True
-    ctx.bufs = dict(wd=wd, sv=sv, enc=enc, ep=ep, mask_emb=mask_emb, mask_l0=mask_l0, drop=drop, Tw=Tw)
+    # (the logits are this node's OUTPUT: kept on ctx they would close a reference cycle output -> grad_fn -> ctx -> output, the
+    #  step's buffers would live until the garbage collector runs -- inside a hipGraph capture that ended in a segfault of
+    #  capture_end; the backward does not read them)
+    ctx.bufs = dict(wd=wd, sv={k: t for k, t in sv.items() if k != "logits"}, enc=enc, ep=ep, mask_emb=mask_emb, mask_l0=mask_l0,
+                    drop=drop, Tw=Tw)
     AW = sv["attw"] if att else f32(0)
     ctx.mark_non_differentiable(AW)
     ctx.set_materialize_grads(False)

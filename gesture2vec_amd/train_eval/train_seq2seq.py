@@ -153,7 +153,22 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
     # the iteration's one host sync: [custom_loss, loss_vq, perplexity, fault latch] gathered on the device by train_step_apply
     both = eng.readback.tolist()
     if both[3] != 0.0 or eng.vq_bx_check_every > 0:
-        eng.check_faults()        # raises: a faulted step was not applied (the commit kernels gate on the latch)
+        try:
+            eng.check_faults()    # raises: a faulted step was not applied (the commit kernels gate on the latch)
+        except RuntimeError as e:
+            # A residency fault of the persistent rollouts (another tenant on the device, a CU mask): the step changed nothing and
+            # the engine has switched itself to the per-step kernels -- repeat the SAME iteration once, in-process and eagerly,
+            # instead of ending a training run (round-4 advisor finding).  Not under data parallelism: the other ranks applied
+            # nothing either (their all-reduced gradients were poisoned by this rank's), but only this rank knows -- raise there.
+            if "persistent rollout kernel" not in str(e) or reduce_fn is not None or world != 1:
+                raise
+            logging.warning("train_iter: %s -- repeating the iteration on the per-step kernels", str(e).split(" -- ")[0])
+            for t, n in eng.tracked_counters:         # (the faulted step bumped them; the repeated one does it again)
+                t.sub_(int(n))
+            eng.train_step(x, tgt, reduce_fn=None, world=1, **kw)
+            both = eng.readback.tolist()
+            if both[3] != 0.0:
+                eng.check_faults()
     loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
     return {"loss": loss}, eng.readback[2].clone()
 

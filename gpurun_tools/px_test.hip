@@ -10,6 +10,7 @@ __device__ int px_stamp_base = 0;
   } while (0)
 __device__ int px_stamp_on = 0;
 #define PX_AFFINE_GRID 1      // rows of the 16 x 16 grid = workgroups of one residue class mod 8 (one XCD under round-robin placement)
+#define G2V_PERSIST_DEVICE_CODE      // this translation unit owns the fault latch (dec_persist.hpp)
 #include "../gesture2vec_amd/csrc/dec_persist.hpp"
 #include <stdlib.h>
 namespace g2v { void set_error(const char*, ...) {} }

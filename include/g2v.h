@@ -317,7 +317,7 @@ int g2v_gru_seq_bwd_prepared(const g2v_gru_dir_bwd* dirs, int ndir, const int32_
 typedef struct {
   const float* w_pre;  const float* b_pre;     /* (H,D), (H)   decoder.decoder.pre_linear.0 */
   const float* bn_w;   const float* bn_b;      /* (H), (H)     decoder.decoder.pre_linear.1 */
-  float* bn_running_mean; float* bn_running_var; /* (H) each, updated in place when training */
+  float* bn_running_mean; float* bn_running_var; /* (H) each, updated in place when training; both NULL while training: not updated (g2v_bn_running_update) */
   const float* w_ih0; const float* w_hh0; const float* b_ih0; const float* b_hh0; /* (3H,H),(3H,H),(3H),(3H) */
   const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1;
   const float* w_out;  const float* b_out;     /* (D,H), (D)   decoder.decoder.out_layer */
@@ -443,6 +443,12 @@ int g2v_train_step_prepare(const g2v_dec_weights* w, int D, int H, void* dec_fwd
                            void* dec_bwd_workspace, size_t dec_bwd_bytes, const float* const* gru_w_hh,
                            const float* const* gru_w_ih, int gru_ndir, int gru_fused, void* gru_bwd_workspace,
                            size_t gru_bwd_bytes, g2v_stream_t stream);
+/* Deferred commit of BatchNorm1d's running statistics (momentum 0.1, unbiased variance, `steps` = T-1 updates in step order)
+ * from g2v_dec_saved.bn_stats of a TRAINING rollout that was given bn_running_mean = bn_running_var = NULL: the forward rollout
+ * then leaves them alone, and this call -- placed where the whole step is known to be valid, e.g. behind the backward rollout --
+ * applies them unless the persistent rollouts' fault latch is set (g2v_dec_rollout_persist_fault). */
+int g2v_bn_running_update(const float* bn_stats, float* running_mean, float* running_var, int steps, int H, int B,
+                          g2v_stream_t stream);
 int g2v_dec_rollout_fwd_prepared(const float* target, const float* h_init, const g2v_dec_weights* w, const g2v_dec_saved* s,
                                  const uint8_t* keep95, const uint8_t* keep_l0, float p_drop, int n_pre_poses,
                                  int conditioned, int training, int T, int B, int D, int H, void* workspace,

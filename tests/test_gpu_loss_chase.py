@@ -135,9 +135,10 @@ def test_input_dropout_drawn_inside_its_kernel_equals_the_explicit_mask_route():
 @pytest.mark.parametrize("B", [256, 4096])
 def test_latched_fault_reaches_train_iter_and_the_step_is_not_applied(B):
     """A latched residency fault of the persistent rollouts (include/g2v.h; injected through the test hook
-    g2v_dec_rollout_persist_fault(-1)): train_iter sees it in its one read-back (g2v_iteration_readback) and raises; the kernels
-    that commit a step -- clip + Adam, the EMA codebook update, the BatchNorm running statistics -- left the model state as it
-    was; the persistent path is switched off and the SAME call repeated runs on the per-step kernels and trains."""
+    g2v_dec_rollout_persist_fault(-1)): the kernels that commit a step -- clip + Adam, the EMA codebook update, the BatchNorm
+    running statistics -- leave the model state as it was; train_iter sees the latch in its one read-back
+    (g2v_iteration_readback), the persistent path is switched off and the iteration is repeated in-process on the per-step
+    kernels."""
     import bench
     from gesture2vec_amd import _lib
     from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
@@ -157,14 +158,67 @@ def test_latched_fault_reaches_train_iter_and_the_step_is_not_applied(B):
         eng = net.engine()
         snap = [t.clone() for t in (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)]
         assert lib.g2v_dec_rollout_persist_fault(-1) == 1
-        with pytest.raises(RuntimeError, match="persistent rollout kernel"):
-            train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        # the engine alone: the faulted step is not applied
+        eng.train_step(x, x, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+        torch.cuda.synchronize()
+        nbt = int(net.decoder.decoder.pre_linear[1].num_batches_tracked)
         for was, now in zip(snap, (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)):
             assert torch.equal(was, now), "a faulted step must not be applied"
+        # train_iter (round 5): sees the latch in its read-back, logs a warning and REPEATS the iteration in-process on the
+        # per-step kernels -- one valid step is applied, the training run goes on
+        assert lib.g2v_dec_rollout_persist_fault(0) == 1
+        loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
         assert lib.g2v_dec_rollout_persist_fault(0) == 0    # check_faults() cleared the latch ...
         assert lib.g2v_dec_rollout_set_persistent(0) == 0   # ... and switched the persistent path off
-        loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
         assert abs(loss2["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"]) and not torch.equal(snap[0], eng.flat)
+        assert int(eng.step_counter) == int(snap[6]) + 1, "exactly one step was applied"
+        assert int(net.decoder.decoder.pre_linear[1].num_batches_tracked) == nbt + (T - 1)
+        loss3, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        assert abs(loss3["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"])
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_dec_rollout_set_persistent(1)
+
+
+@pytest.mark.parametrize("B", [256, 4096])
+def test_fault_latched_in_the_middle_of_a_step_leaves_the_whole_model_state_untouched(B):
+    """Round 5 (advisor finding): a fault that appears AFTER the forward rollout -- in the backward rollout, or the chaser's latch 2 --
+    used to find the EMA codebook update already committed (it ran beside the first steps of the forward rollout) and BatchNorm's
+    running statistics written (end of the forward rollout).  Both commits now sit behind the backward rollout, gated on the
+    latch like clip + Adam: latch injected between the forward and the backward of ONE fused step (eager launches, host sync in
+    between) -> parameters, Adam moments, step counter, codebook, EMA statistics and BatchNorm running statistics are bitwise
+    what they were; the same step without the injection changes all of them."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    D, H, K, T, p = 135, 64, 512, 34, 0.0
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    eng = _engine(sd, D, H, K, T, p)
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(11)).to(DEV)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    names = ("flat", "m", "v", "step_counter", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv")
+    try:
+        eng.train_step(x, x, **kw)                          # a first, ordinary step (EMA statistics no longer at their init)
+        torch.cuda.synchronize()
+        snap = {n: getattr(eng, n).clone() for n in names}
+        real_loss = eng.loss
+        def loss_then_fault(*a, **k):                       # between the forward (rollout + chaser joined by backward) and the backward
+            real_loss(*a, **k)
+            torch.cuda.synchronize()
+            assert lib.g2v_dec_rollout_persist_fault(-2) == 2
+        eng.loss = loss_then_fault
+        eng.train_step(x, x, **kw)
+        eng.loss = real_loss
+        torch.cuda.synchronize()
+        for n in names:
+            assert torch.equal(snap[n], getattr(eng, n)), f"{n} changed in a faulted step"
+        with pytest.raises(RuntimeError, match="persistent rollout kernel"):
+            eng.check_faults()
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0
+        lib.g2v_dec_rollout_set_persistent(1)               # (check_faults switched it off: this test goes on with the same kernels)
+        eng.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        for n in names:
+            assert not torch.equal(snap[n], getattr(eng, n)), f"{n} did not change in a valid step"
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)

@@ -24,6 +24,7 @@ def test_text2embedding_matches_reference_golden(golden_dir, name, att, kernels,
     from gesture2vec_amd import rollout_t2e
     from gesture2vec_amd.flat import FlatClipAdam
     monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", 1 if kernels == "fused_step" else 1 << 30)
+    calls0 = rollout_t2e.FUSED_CALLS
     from gesture2vec_amd.model.text2embedding_model import text2embedding_model
     from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -57,6 +58,7 @@ def test_text2embedding_matches_reference_golden(golden_dir, name, att, kernels,
                     assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, n     # encoder layer 1: dead compute
                 else:
                     assert prm.grad is not None and relerr(prm.grad, ref) < 5e-4, (n, relerr(prm.grad, ref))
+    assert rollout_t2e.FUSED_CALLS - calls0 == (2 if kernels == "fused_step" else 0)
     for k in fx.files:
         if k.startswith("wN/"):
             n = k[3:]
@@ -272,12 +274,14 @@ def test_fused_step_kernels_match_per_operator_path(att, p, B, n_pre, H, K, monk
              (torch.rand(Tw, B, 2 * H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None)
     w = torch.randn(B, S, K, generator=g).to(DEV)
     outs = []
+    calls0 = rollout_t2e.FUSED_CALLS
     for net, min_rows in zip(nets, (1, 1 << 30)):
         monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", min_rows)
         net.set_dropout_masks(*masks)
         out, attn = net(ids, lengths, None, codes, None, None)
         (out * w).sum().backward()
         outs.append((out.detach(), attn))
+    assert rollout_t2e.FUSED_CALLS - calls0 == 1, "the fused step kernels did not serve this shape (g2v_attn_code_rollout_ok)"
     assert relerr(outs[0][0], outs[1][0].cpu()) < 3e-5
     same = (outs[0][0][:, 1:].argmax(2) == outs[1][0][:, 1:].argmax(2)).all(1)
     assert float(same.float().mean()) > 0.995           # (a greedy decision inside fp32 rounding of a tie changes that row's later steps)
