@@ -96,6 +96,8 @@ _SIGS = {
     "g2v_vq_assign_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_fused_assign_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_pack_codebook": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_vq_assign_packed_ok": (c_int, [c_int, c_int, c_int]),
+    "g2v_vq_assign_packed_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_fused_assign_packed_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_bx_image_bytes": (c_sz, [c_int, c_int]),
     "g2v_vq_bx_pack": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),

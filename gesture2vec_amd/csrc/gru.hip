@@ -163,6 +163,28 @@ __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi
   const int ntile = Hp >> 4;
   const int mt = (ntile - wave + NWAVE - 1) / NWAVE;      // this wave's tiles: wave, wave + NWAVE, ...
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // Packed lengths (round 5): a step at which NO row of this workgroup's tile is inside its sequence changes nothing (every row
+  // keeps its state, its output is the zero of a padded position) -- the forward direction runs steps [0, lmax), the reverse
+  // direction [T - lmax, T), lmax = the tile's longest sequence; the other steps' outputs are zero-filled up front and their W_hh
+  // products (the whole cost of a step) are not executed.  Part d sorts a batch by length (pack_padded_sequence's
+  // enforce_sorted): lengths U{4..20} leave ~40 % of the (tile, step) pairs out.  Same results bit for bit (the skipped steps
+  // were select-masked no-ops); their `gates` rows are left unwritten -- the backward reads gates only where t < length.
+  int lmax = T;
+  if (lengths) {
+    lmax = 0;
+    for (int r = 0; r < nrows; ++r) lmax = max(lmax, (int)lengths[b0 + r]);
+    lmax = min(max(lmax, 0), T);
+  }
+  const int s_lo = reverse ? T - lmax : 0, s_hi = reverse ? T : lmax;
+  if (lmax < T) {
+    const int H4z = H >> 2, nskip = T - lmax;
+    for (int e = tid; e < nskip * nrows * H4z; e += NTHR) {
+      const int k = e / (nrows * H4z), rem = e - k * nrows * H4z, r = rem / H4z, c = 4 * (rem - r * H4z);
+      const int sk = reverse ? k : lmax + k;              // a skipped step
+      const int tk = reverse ? (T - 1 - sk) : sk;
+      *reinterpret_cast<float4*>(hs + ((int64_t)tk * B + b0 + r) * hs_ld + c) = z4;
+    }
+  }
   // one tile ahead: the gi vectors and biases of the NEXT (step, tile) of this wave are requested before the current tile's
   // product (13 k-steps x 12 NR MFMAs: more than an HBM round trip)
   float4 gin[NR][3], bhn[3];
@@ -180,11 +202,11 @@ __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi
       for (int g = 0; g < 3; ++g) gin[r][g] = ok ? *reinterpret_cast<const float4*>(gir + g * H) : z4;
     }
   };
-  prefetch(0, 0);
+  prefetch(s_lo, 0);
   __syncthreads();
   float* cur = hbuf0;
   float* nxt = hbuf1;
-  for (int s = 0; s < T; ++s) {
+  for (int s = s_lo; s < s_hi; ++s) {
     const int t = reverse ? (T - 1 - s) : s;
 #pragma unroll 1
     for (int j = 0; j < mt; ++j) {
@@ -409,10 +431,31 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       P.up[k] = (ok && d_hs) ? *reinterpret_cast<const float4*>(d_hs + row * d_hs_ld + c) : z4;
     }
   };
-  prefetch(T - 1);
+  // Packed lengths (round 5, see the forward body): steps at which no row of the tile is inside its sequence -- s >= lmax for the
+  // forward direction (the FIRST steps of this sweep), s < T - lmax for the reverse direction (its last) -- only have zero gate
+  // gradients to deliver (the weight-gradient products read every row): zero-filled up front, their dgh W_hh products skipped.
+  int lmax = T;
+  if (lengths) {
+    lmax = 0;
+    for (int r = 0; r < nrows; ++r) lmax = max(lmax, (int)lengths[b0 + r]);
+    lmax = min(max(lmax, 0), T);
+  }
+  const int s_first = reverse ? T - 1 : lmax - 1, s_last = reverse ? T - lmax : 0;      // executed: s_first down to s_last
+  if (lmax < T) {
+    const int G4 = G >> 2, nskip = T - lmax;
+    for (int e = tid; e < nskip * nrows * G4; e += NTHR) {
+      const int k = e / (nrows * G4), rem = e - k * nrows * G4, r = rem / G4, c = 4 * (rem - r * G4);
+      const int sk = reverse ? k : lmax + k;
+      const int tk = reverse ? (T - 1 - sk) : sk;
+      const int64_t rowk = ((int64_t)tk * B + b0 + r) * G + c;
+      *reinterpret_cast<float4*>(dgi + rowk) = z4;
+      *reinterpret_cast<float4*>(dgh + rowk) = z4;
+    }
+  }
+  if (s_first >= s_last) prefetch(s_first);
   __syncthreads();
   const int ntile = Hp >> 4;
-  for (int s = T - 1; s >= 0; --s) {
+  for (int s = s_first; s >= s_last; --s) {
     const int t = reverse ? (T - 1 - s) : s;
     const bool live = rowv && t < len;
     const int64_t row = (int64_t)t * B + b;
@@ -458,7 +501,7 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       *reinterpret_cast<float4*>(dhs + row_l * ldh + c) = make_float4(direct[0], direct[1], direct[2], direct[3]);
     }
     lds_barrier();      // (LDS hazards only: __syncthreads() would also drain this step's 19 gate-gradient stores / 24 prefetched vectors per thread)
-    if (s > 0) prefetch(s - 1);                         // requested ahead of the product below (in front of this wave's last
+    if (s > s_last) prefetch(s - 1);                    // requested ahead of the product below (in front of this wave's last
                                                         // tile instead: 2.05 ms against 1.64 at the native shape)
     // phase 2: dh_prev = direct + dgh W_hh
     // (this wave's feature tiles two at a time: two independent accumulator chains -- one chain issues a dependent MFMA every

@@ -290,6 +290,205 @@ __global__ __launch_bounds__(256) void vq_assign_finish_kernel(unsigned long lon
   }
 }
 
+// ---- any E % 16 == 0, K % 16 == 0 (round 5: the reference's OWN shapes, E = H L = 400 with K = 512 / 400 -- every shipped YAML;
+// until now they took vq_assign_kernel above: 48.9 us at N = 4096, 0.22 of the fp32 matrix peak) --------------------------------
+// vq_assign_kernel's arithmetic bit for bit (the same row norms, one accumulator chain per code tile in the same k order, the
+// same merges: idx, dist_min, quantized and the SSE partials are bitwise equal), restructured around the weight stream:
+//  * the codebook comes as the fragment-major image of g2v_vq_pack_codebook: one coalesced 1 KiB block per (code tile, k-step)
+//    instead of 16 rows x 64 B -- and a PD-deep ring of them per wave (wave_gemm_p_rows' whole-group / tail form: the wait-count
+//    pass waits for the oldest slot only),
+//  * EIGHT waves (two per SIMD: twice the bytes in flight, one wave's MFMAs under the other's waits), NT = 4 code tiles per pass:
+//    K = 512 is ONE pass per wave, one ring prologue per wave,
+//  * NR row tiles per workgroup share every fragment (bulk assignment: NR = 2 / 4 where row tiles outnumber the CUs).
+// Per-SIMD MFMA floor at N = 4096, E = 400, K = 512: 800 x 32 cycles = 11.6 us.
+template <int NT, int NR, int PD = 8>
+__device__ __forceinline__ void wave_gemm_pt_rows(f32x4 (&acc)[NT][NR], const float* const (&pt)[NT], int KS, const float* Xs, int ldx,
+                                                  int lane) {
+  const int i = lane & 15, q = lane >> 4;
+  const float* xrow = Xs + i * ldx + 4 * q;
+  float4 ring[PD][NT];
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)min(j, KS - 1) * 256);
+  float4 xn[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx);
+  auto kstep = [&](int s, int j, bool refill) {
+    float4 xb[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      xb[r] = xn[r];
+      xn[r] = *reinterpret_cast<const float4*>(xrow + r * 16 * ldx + 16 * min(s + 1, KS - 1));
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].x, xb[r].x, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].y, xb[r].y, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].z, xb[r].z, acc[t][r]);
+#pragma unroll
+    for (int r = 0; r < NR; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t][r] = mfma16(ring[j][t].w, xb[r].w, acc[t][r]);
+    if (refill) {
+      const int sn = min(s + PD, KS - 1);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) ring[j][t] = *reinterpret_cast<const float4*>(pt[t] + (int64_t)sn * 256);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  int s0 = 0;
+  for (; s0 + PD <= KS; s0 += PD) {
+#pragma unroll
+    for (int j = 0; j < PD; ++j) kstep(s0 + j, j, true);
+  }
+  const int rem = KS - s0;
+#pragma unroll
+  for (int j = 0; j < PD; ++j)
+    if (j < rem) kstep(s0 + j, j, false);
+}
+
+template <int NR, int NT>
+__global__ __launch_bounds__(512) void vq_assign_p_kernel(const float* __restrict__ flat, const float* __restrict__ z,
+                                                          const float* __restrict__ W, const float* __restrict__ Wf,
+                                                          const float* __restrict__ wsq, int64_t* __restrict__ idx_out,
+                                                          float* __restrict__ quant, float* __restrict__ dist_min,
+                                                          float* __restrict__ sse_partial, int N, int E, int K) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int ROWS = 16 * NR, NW = 8;
+  const int ldx = E + 4, KS = E >> 4, ntile = K >> 4;
+  float* Xs = smem;                             // [ROWS][ldx]
+  float* xx = Xs + ROWS * ldx;                  // [ROWS]
+  float* wbest_d = xx + ROWS;                   // [NW][ROWS]
+  int* wbest_k = (int*)(wbest_d + NW * ROWS);   // [NW][ROWS]
+  int* best_k = wbest_k + NW * ROWS;            // [ROWS]
+  float* red = (float*)(best_k + ROWS);         // [NW]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.x * ROWS;
+  const int nrows = min(ROWS, N - r0);
+  const int E4 = E >> 2;
+  for (int e = tid; e < ROWS * E4; e += 512) {
+    const int r = e / E4, c = 4 * (e - r * E4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (r < nrows) v = *reinterpret_cast<const float4*>(flat + (int64_t)(r0 + r) * E + c);
+    *reinterpret_cast<float4*>(Xs + r * ldx + c) = v;
+  }
+  __syncthreads();
+  for (int rb = 0; rb < ROWS; rb += 32) {  // ||x||^2 per row: 16 threads per row, vq_assign_kernel's summation order
+    const int row = rb + (tid >> 4), part = tid & 15;
+    float sacc = 0.f;
+    if (row < ROWS)
+      for (int k = part; k < E; k += 16) sacc += Xs[row * ldx + k] * Xs[row * ldx + k];
+    sacc = reduce16(sacc);
+    if (part == 0 && row < ROWS) xx[row] = sacc;
+  }
+  __syncthreads();
+  const int i = lane & 15, q = lane >> 4;
+  float xr[NR], bd[NR];
+  int bk[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    xr[r] = xx[16 * r + i];
+    bd[r] = INFINITY;
+    bk[r] = 0;
+  }
+  for (int base = wave; base < ntile; base += NW * NT) {
+    const float* pt[NT];
+    int tile[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      tile[t] = base + NW * t;
+      const int tc = tile[t] < ntile ? tile[t] : base;      // past the last tile: a valid tile again, its result unused
+      pt[t] = Wf + ((int64_t)tc * KS * 64 + lane) * 4;
+    }
+    float4 wq[NT];                                           // ||W||^2 of this lane's four codes per tile, ahead of the product
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wq[t] = *reinterpret_cast<const float4*>(wsq + 16 * (tile[t] < ntile ? tile[t] : base) + 4 * q);
+    f32x4 acc[NT][NR];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < NR; ++r) acc[t][r] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    wave_gemm_pt_rows<NT, NR>(acc, pt, KS, Xs, ldx, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {                           // tiles ascending: the lane's codes stay in increasing order
+      if (tile[t] >= ntile) continue;
+      const float sq[4] = {wq[t].x, wq[t].y, wq[t].z, wq[t].w};
+#pragma unroll
+      for (int r = 0; r < NR; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float d = (xr[r] + sq[e]) - 2.0f * acc[t][r][e];   // (||x||^2 + ||W||^2) - 2 x.W  (:1234-1238)
+          if (argmin_better(d, bd[r])) {
+            bd[r] = d;
+            bk[r] = 16 * tile[t] + 4 * q + e;
+          }
+        }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {     // the 4 lanes (q = 0..3) that hold the same row, then the 8 waves
+    float d2 = __shfl_xor(bd[r], 16);
+    int k2 = __shfl_xor(bk[r], 16);
+    argmin_merge(bd[r], bk[r], d2, k2);
+    d2 = __shfl_xor(bd[r], 32);
+    k2 = __shfl_xor(bk[r], 32);
+    argmin_merge(bd[r], bk[r], d2, k2);
+    if (lane < 16) {
+      wbest_d[wave * ROWS + 16 * r + lane] = bd[r];
+      wbest_k[wave * ROWS + 16 * r + lane] = bk[r];
+    }
+  }
+  __syncthreads();
+  if (tid < ROWS) {
+    float d = wbest_d[tid];
+    int k = wbest_k[tid];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) argmin_merge(d, k, wbest_d[w * ROWS + tid], wbest_k[w * ROWS + tid]);
+    best_k[tid] = k;
+    if (tid < nrows) {
+      idx_out[r0 + tid] = (int64_t)k;
+      if (dist_min) dist_min[r0 + tid] = d;
+    }
+  }
+  __syncthreads();
+  if (quant) {
+    // gather / straight-through / SSE: per 16-row block exactly vq_assign_kernel's (16 threads per row, 256 threads per block,
+    // its wave_sum and four-way add): two blocks of 16 rows at a time with 512 threads
+    for (int rb = 0; rb < ROWS; rb += 32) {
+      const int half = tid >> 8, t2 = tid & 255, w4 = t2 >> 6;
+      const int row = rb + 16 * half + (t2 >> 4), part = t2 & 15;
+      float sse = 0.f;
+      if (row < nrows && row < ROWS) {
+        const float* wq2 = W + (int64_t)best_k[row] * E;
+        const float* zr = z + (int64_t)(r0 + row) * E;
+        float* qo = quant + (int64_t)(r0 + row) * E;
+        for (int k = part; k < E; k += 16) {
+          const float zv = zr[k];
+          const float diff = wq2[k] - zv;
+          qo[k] = zv + diff;                 // inputs + (quantized - inputs).detach()  (:1292)
+          sse += diff * diff;
+        }
+      }
+      sse = wave_sum(sse);
+      __syncthreads();
+      if (lane == 0) red[wave] = sse;
+      __syncthreads();
+      const int blk = (r0 + rb) / 16 + half;
+      if (t2 == 0 && sse_partial && rb + 16 * half < ROWS && r0 + rb + 16 * half < N)
+        sse_partial[blk] = (red[4 * half] + red[4 * half + 1]) + (red[4 * half + 2] + red[4 * half + 3]);
+      (void)w4;
+    }
+  }
+}
+
 // Fast path for E == 128 and K % 128 == 0 (the BASELINE shape E = 128, K = 512).  Same arithmetic, but:
 //  * the 16 x E row tile's MFMA B-fragments (8 x float4) live in registers for the whole kernel,
 //  * each wave walks its code tiles in PAIRS (two independent accumulator chains: the 16x16x4 fp32 MFMA has a
@@ -1920,6 +2119,41 @@ extern "C" int g2v_vq_assign_fwd(const float* flat, const float* z, const float*
     (void)hipFuncSetAttribute((const void*)vq_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(vq_assign_kernel, dim3(cdiv(N, VQ_ROWS)), dim3(256), lds, (hipStream_t)stream, flat, z, codebook,
                      code_sqnorm, idx, quantized, dist_min, sse_partial, N, E, K);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// g2v_vq_assign_fwd on the fragment-major codebook image of g2v_vq_pack_codebook (K * E floats), any E % 16 == 0, K % 16 == 0:
+// the same outputs bit for bit (vq_assign_p_kernel above).
+extern "C" int g2v_vq_assign_packed_ok(int N, int E, int K) {
+  return (N > 0 && E >= 16 && (E & 15) == 0 && K >= 16 && (K & 15) == 0 &&
+          ((size_t)64 * (E + 4) + 64 + 2 * 8 * 64 + 64 + 8) * sizeof(float) <= 160 * 1024) ? 1 : 0;
+}
+extern "C" int g2v_vq_assign_packed_fwd(const float* flat, const float* z, const float* codebook, const float* codebook_frag,
+                                        const float* code_sqnorm, int64_t* idx, float* quantized, float* dist_min,
+                                        float* sse_partial, int N, int E, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(flat && codebook && codebook_frag && code_sqnorm && idx, "null pointer");
+  G2V_REQUIRE(!quantized || z, "z required with quantized");
+  if (!g2v_vq_assign_packed_ok(N, E, K)) {
+    set_error("g2v_vq_assign_packed_fwd: needs E %% 16 == 0, K %% 16 == 0 (g2v_vq_assign_packed_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  G2V_REQUIRE(ptr_aligned16(flat) && ptr_aligned16(codebook_frag) && ptr_aligned16(code_sqnorm), "16-byte aligned operands");
+  hipStream_t st = (hipStream_t)stream;
+  // row tiles per workgroup: one while there is a CU per tile or two, more for bulk assignment (every fragment then feeds NR tiles)
+  const int nr = N >= 32768 ? 4 : (N >= 8192 ? 2 : 1);
+  const size_t lds = ((size_t)16 * nr * (E + 4) + 16 * nr + 2 * 8 * 16 * nr + 16 * nr + 8) * sizeof(float);
+#define G2V_VQP(NR_, NT_)                                                                                                  \
+  do {                                                                                                                     \
+    if (lds > 48 * 1024)                                                                                                   \
+      (void)hipFuncSetAttribute((const void*)vq_assign_p_kernel<NR_, NT_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipLaunchKernelGGL((vq_assign_p_kernel<NR_, NT_>), dim3(cdiv(N, 16 * NR_)), dim3(512), lds, st, flat, z, codebook,     \
+                       codebook_frag, code_sqnorm, idx, quantized, dist_min, sse_partial, N, E, K);                        \
+  } while (0)
+  if (nr == 4) G2V_VQP(4, 2);
+  else if (nr == 2) G2V_VQP(2, 4);
+  else G2V_VQP(1, 4);
+#undef G2V_VQP
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

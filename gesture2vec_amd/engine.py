@@ -154,6 +154,11 @@ class VQVAEEngine:
         self.vq_diag = torch.zeros(4, dtype=torch.int32, device=dev)          # [0] tiles on the exact sweep, [1] pairs re-evaluated
         self._vq_diag_on = False
         self.codebook_frag = torch.zeros(K * self.E, device=dev) if (self.E == 128 and K % 128 == 0 and not self._vq_bx) else None
+        # every other shape the packed kernel serves (E = 400: the reference's own): pre_linear as a dense launch + the eight-wave
+        # assignment kernel on the fragment-major codebook image (round 5; g2v_vq_assign_packed_fwd), from 2048 rows
+        self.codebook_frag_generic = (torch.zeros(K * self.E, device=dev)
+                                      if (not self._vq_bx and self.codebook_frag is None and
+                                          self.lib.g2v_vq_assign_packed_ok(1, self.E, K)) else None)
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
         self.vq_stats = self.comm[self.n_flat:]
@@ -514,8 +519,12 @@ class VQVAEEngine:
         else:
             check(lib.g2v_linear_fwd(_p(b["enc_hidden"]), E, 0, 0, 0, None, 1.0, _p(self.vq_pre_w), _p(self.vq_pre_b),
                                      _p(b["flat"]), E, N, E, E, 0, st))
-            check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
-                                        _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
+            if self.codebook_frag_generic is not None and N >= ops.VQ_PACKED_MIN_ROWS:
+                check(lib.g2v_vq_assign_packed_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.codebook_frag_generic),
+                                                   _p(self.code_sqnorm), _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
+            else:
+                check(lib.g2v_vq_assign_fwd(_p(b["flat"]), _p(b["enc_hidden"]), _p(self.codebook), _p(self.code_sqnorm),
+                                            _p(b["idx"]), _p(b["quant"]), None, _p(b["sse"]), N, E, K, st))
         # The statistics and the codebook update feed nothing in this forward (the rollout starts from `quant`, taken from the
         # codebook as it was): a parallel branch beside the rollout.  The custom_loss CHASER rides at the end of the same branch:
         # it must be dispatched behind the rollout (g2v.h), and these ~30 us of small kernels -- every one of them fits beside the
@@ -670,6 +679,8 @@ class VQVAEEngine:
                                      _p(self.vq_bx_image), K, E, st))
         elif self.codebook_frag is not None:
             check(lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag), K, E, st))
+        elif self.codebook_frag_generic is not None:
+            check(lib.g2v_vq_pack_codebook(_p(self.codebook), _p(self.codebook_frag_generic), K, E, st))
 
     def refresh_codebook_state(self):
         """kept for callers of round 2: the derived state is recomputed by every entry point now"""

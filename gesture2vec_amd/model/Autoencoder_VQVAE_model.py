@@ -305,6 +305,8 @@ class VQ_Payam_EMA(nn.Module):
             # a corpus' worth of rows: bf16 split screening on the bf16 matrix pipe + exact fp32 re-check of the undecided
             # rows (g2v_vq_assign_bulk: the fp32 kernel's indices, 2.0x faster at 2^18 rows and 2.6x at 2^20; break-even 2^16)
             return ops.vq_assign_bulk(flat, W, wsq)
+        # (every other shape, e.g. the checkpoints' E = 400: ops.vq_assign takes the packed eight-wave kernel from 2048 rows, with
+        #  2 / 4 row tiles per workgroup for a corpus' worth of rows -- round 5; it used to degrade to the generic kernel)
         idx, _, _, _ = ops.vq_assign(flat, None, W, wsq, want_quantized=False)
         return idx
 

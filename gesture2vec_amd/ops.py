@@ -164,9 +164,25 @@ def vq_assign(flat, z, codebook, code_sqnorm, want_quantized=True, want_dist=Fal
     quant = torch.empty((N, E), dtype=torch.float32, device=dev) if want_quantized else None
     dmin = torch.empty((N,), dtype=torch.float32, device=dev) if want_dist else None
     sse = torch.empty((lib.g2v_vq_assign_blocks(N),), dtype=torch.float32, device=dev) if want_quantized else None
+    if vq_assign_packed_pays(N, E, K):
+        # the reference's own quantiser shapes (E = 400): fragment-major codebook image + the eight-wave kernel, same outputs bit
+        # for bit (g2v_vq_assign_packed_fwd); the image is rebuilt per call (6 us: nothing is trusted across calls)
+        frag = workspace(K * E * 4, flat.device, "vqpack").view(torch.float32)[:K * E]
+        check(lib.g2v_vq_pack_codebook(_p(_chk(codebook)), _p(frag), K, E, _stream()), "vq_pack_codebook")
+        check(lib.g2v_vq_assign_packed_fwd(_p(_chk(flat)), _p(z), _p(codebook), _p(frag), _p(code_sqnorm), _p(idx), _p(quant),
+                                           _p(dmin), _p(sse), N, E, K, _stream()), "vq_assign_packed_fwd")
+        return idx, quant, dmin, sse
     check(lib.g2v_vq_assign_fwd(_p(_chk(flat)), _p(z), _p(_chk(codebook)), _p(code_sqnorm), _p(idx), _p(quant),
                                 _p(dmin), _p(sse), N, E, K, _stream()), "vq_assign_fwd")
     return idx, quant, dmin, sse
+
+
+VQ_PACKED_MIN_ROWS = 2048      # below: g2v_vq_assign_fwd splits the CODES over workgroups (few row tiles), which is faster there
+
+
+def vq_assign_packed_pays(N, E, K) -> bool:
+    """shapes g2v_vq_assign_fwd has no tuned kernel for (anything but E = 128 with K % 128 = 0) at enough rows to fill the chip"""
+    return bool(N >= VQ_PACKED_MIN_ROWS and not (E == 128 and K % 128 == 0) and _lib_().g2v_vq_assign_packed_ok(int(N), int(E), int(K)))
 
 
 def vq_assign_bulk(flat, codebook, code_sqnorm, want_undecided=False):

@@ -150,6 +150,14 @@ int g2v_vq_fused_assign_fwd(const float* z, const float* w_pre, const float* b_p
  * the row-major codebook is still read for the gather of the chosen codes.  Results are bitwise those of
  * g2v_vq_fused_assign_fwd. */
 int g2v_vq_pack_codebook(const float* codebook, float* codebook_frag, int K, int E, g2v_stream_t stream);
+/* Round 5: g2v_vq_assign_fwd for ANY E % 16 == 0, K % 16 == 0 on that image (K * E floats) -- the reference's own quantiser
+ * shapes, E = hidden_size * n_layers = 400 with K = 512 (config/VQ-VAE.yml) or 400 (VQ-VAE_GENEA.yml), which g2v_vq_assign_fwd
+ * serves at 0.22 of the fp32 matrix peak.  Same outputs bit for bit (idx, dist_min, quantized, the SSE partials per 16 rows);
+ * eight waves per workgroup, 1 / 2 / 4 row tiles per workgroup by N (bulk assignment: every fragment feeds all of them). */
+int g2v_vq_assign_packed_ok(int N, int E, int K);
+int g2v_vq_assign_packed_fwd(const float* flat, const float* z, const float* codebook, const float* codebook_frag,
+                             const float* code_sqnorm, int64_t* idx, float* quantized, float* dist_min, float* sse_partial,
+                             int N, int E, int K, g2v_stream_t stream);
 int g2v_vq_fused_assign_packed_fwd(const float* z, const float* w_pre, const float* b_pre, const float* codebook,
                                    const float* codebook_frag, const float* code_sqnorm, float* flat_out, int64_t* idx,
                                    float* quantized, float* sse_partial, int N, int E, int K, g2v_stream_t stream);

@@ -142,8 +142,8 @@ def vq_distances(flat: Tensor, codebook: Tensor) -> Tensor:
 
 
 def vq_ema_forward(inputs: Tensor, sd: Dict[str, Tensor], prefix: str, commitment_cost: float,
-                   training: bool, decay: float = 0.85, eps: float = 1e-5, use_pre_linear: bool = True
-                   ) -> Dict[str, Tensor]:
+                   training: bool, decay: float = 0.85, eps: float = 1e-5, use_pre_linear: bool = True,
+                   forced_idx: Optional[Tensor] = None) -> Dict[str, Tensor]:
     """VQ_Payam_EMA.forward (Autoencoder_VQVAE_model.py:1217-1296).
 
     * rows are the contiguous reinterpretation `inputs.view(-1, E)` (:1229)
@@ -158,7 +158,7 @@ def vq_ema_forward(inputs: Tensor, sd: Dict[str, Tensor], prefix: str, commitmen
     flat = linear(z_flat, sd[prefix + "pre_linear.weight"], sd[prefix + "pre_linear.bias"]) if use_pre_linear else z_flat
     flat_d = flat.detach()
     d = vq_distances(flat_d, W.detach())
-    idx = torch.argmin(d, dim=1)
+    idx = torch.argmin(d, dim=1) if forced_idx is None else forced_idx      # (forced_idx: see vqvae_forward, cfg["forced"])
     q = W.detach()[idx].reshape(inputs.shape)                       # == onehot @ W bit-exactly (:1256)
     out = {"idx": idx, "flat": flat_d, "dist": d}
     N = z_flat.shape[0]
@@ -236,7 +236,7 @@ def encoder_forward(x_tbd: Tensor, sd: Dict[str, Tensor], n_layers: int, p: floa
 
 def decoder_step(y_prev: Tensor, hidden: Tensor, sd: Dict[str, Tensor], n_layers: int, training: bool,
                  keep95: Tensor, p: float, inter_mask: Optional[Tensor], bn_state: Dict[str, Tensor],
-                 conditioned: bool = True) -> Tuple[Tensor, Tensor]:
+                 conditioned: bool = True, relu_mask: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """Generator.forward -> BahdanauAttnDecoderRNN.forward, no attention (Autoencoder_VQVAE_model.py:499-592).
 
     Dropout(0.95) is constructed inline (:570) so it is ACTIVE IN EVAL TOO; BN batch stats in train (:572).
@@ -251,7 +251,7 @@ def decoder_step(y_prev: Tensor, hidden: Tensor, sd: Dict[str, Tensor], n_layers
     if training:
         bn_state["running_mean"], bn_state["running_var"] = nrm, nrv
         bn_state["num_batches_tracked"] = bn_state["num_batches_tracked"] + 1
-    a = torch.relu(a)
+    a = torch.relu(a) if relu_mask is None else a * relu_mask      # (relu_mask: see vqvae_forward, cfg["forced"])
     new_h = []
     layer_in = a
     for l in range(n_layers):                                                            # :584 nn.GRU(H,H,L), seq len 1
@@ -285,7 +285,14 @@ def vqvae_forward(sd: Dict[str, Tensor], in_poses: Tensor, out_poses: Tensor, cf
     enc_out, enc_hidden = encoder_forward(x, sd, L, p if training else 0.0,
                                           [masks["enc_l0"]] if (training and p > 0.0) else None)  # :966
     dec_hidden = enc_hidden[:L].contiguous()                                             # :971-973 (layer-0 fwd/bwd!)
-    vq = vq_ema_forward(dec_hidden, sd, "vq_layer.", cfg["commitment_cost"], training)   # :977
+    # cfg["forced"] (tests of the LARGE-batch parity only; absent everywhere else): the DISCRETE decisions of the run under test --
+    # "idx" (N,) code indices, "relu" (T-1,B,H) 0/1 mask of the decoder's ReLU, "sign_l1" (B,T,D) / "sign_cont" (B,T-1,D) signs
+    # of custom_loss's |.| terms.  A float64 oracle and an fp32 kernel legitimately disagree on a decision whose argument is
+    # inside fp32 rounding of its threshold, and one flipped ReLU / sign moves single gradient elements by far more than
+    # rounding; with the decisions pinned the two sides compute the same smooth function and differ by rounding only.
+    forced = cfg.get("forced") or {}
+    vq = vq_ema_forward(dec_hidden, sd, "vq_layer.", cfg["commitment_cost"], training,   # :977
+                        forced_idx=forced.get("idx"))
     hidden = vq["quantized"]                                                             # :978
     first_hidden = hidden
     bn = {"running_mean": sd["decoder.decoder.pre_linear.1.running_mean"],
@@ -296,7 +303,8 @@ def vqvae_forward(sd: Dict[str, Tensor], in_poses: Tensor, out_poses: Tensor, cf
     for t in range(1, T):                                                                # :1041-1054
         il = masks["dec_l0"][t - 1] if (training and p > 0.0) else None
         y, hidden = decoder_step(dec_in, hidden, sd, L, training, masks["dec"][t - 1], p, il, bn,
-                                 cfg.get("conditioned", True))
+                                 cfg.get("conditioned", True),
+                                 relu_mask=forced["relu"][t - 1] if "relu" in forced else None)
         outs.append(y)
         dec_in = tgt[t] if t < cfg["n_pre_poses"] else y                                 # :1049-1052
     outputs = torch.stack(outs).transpose(0, 1)                                          # :1066
@@ -305,11 +313,17 @@ def vqvae_forward(sd: Dict[str, Tensor], in_poses: Tensor, out_poses: Tensor, cf
             "flat": vq["flat"], "dist": vq["dist"], "vq": vq, "bn": bn}
 
 
-def custom_loss(output: Tensor, target: Tensor, w_l1: float, w_cont: float, w_var: float) -> Tensor:
-    """train_eval/train_seq2seq.py:40-88.  output/target (B,T,D)."""
+def custom_loss(output: Tensor, target: Tensor, w_l1: float, w_cont: float, w_var: float,
+                forced: Optional[dict] = None) -> Tensor:
+    """train_eval/train_seq2seq.py:40-88.  output/target (B,T,D).  forced: see vqvae_forward (|x| as x * sign with the signs
+    of the run under test: the same value wherever the sign is the true one, and the same gradient everywhere)."""
     n = output.numel()
-    l1 = (output - target).abs().mean() * w_l1                                           # :58-59
-    cont = (output[:, 1:, :] - output[:, :-1, :]).abs().sum() / n * w_cont               # :62-67
+    if forced and "sign_l1" in forced:
+        l1 = ((output - target) * forced["sign_l1"]).mean() * w_l1
+        cont = ((output[:, 1:, :] - output[:, :-1, :]) * forced["sign_cont"]).sum() / n * w_cont
+    else:
+        l1 = (output - target).abs().mean() * w_l1                                       # :58-59
+        cont = (output[:, 1:, :] - output[:, :-1, :]).abs().sum() / n * w_cont           # :62-67
     norm = torch.sqrt((output ** 2).sum(dim=1))                                          # :70 torch.norm(output, 2, 1): over TIME
     var = -norm.sum() / n * w_var                                                        # :71-72
     return l1 + cont + var
@@ -363,7 +377,7 @@ def vqvae_train_step(sd: Dict[str, Tensor], adam_state: dict, x: Tensor, masks: 
     work = dict(sd)
     work.update(leaves)
     fw = vqvae_forward(work, x, x, cfg, True, masks)
-    closs = custom_loss(fw["outputs"], x, cfg["w_l1"], cfg["w_cont"], cfg["w_var"])      # :707
+    closs = custom_loss(fw["outputs"], x, cfg["w_l1"], cfg["w_cont"], cfg["w_var"], cfg.get("forced"))      # :707
     loss = closs + fw["loss_vq"] / 400 if epoch > 0 else closs                           # :731-738
     gl = torch.autograd.grad(loss, [leaves[k] for k in keys], allow_unused=True)
     grads = {k: (g if g is not None else torch.zeros_like(leaves[k])) for k, g in zip(keys, gl)}

@@ -284,6 +284,59 @@ def test_vq_assign_vs_oracle(ops, N, E, K):
     assert abs(sse.double().sum().item() - sse_ref.item()) <= 1e-5 * sse_ref.item()
 
 
+@pytest.mark.parametrize("N,E,K", [(4096, 400, 512), (4096, 400, 400), (2048 + 37, 400, 512), (8192 + 5, 400, 512), (40000, 400, 400),
+                                   (4096, 48, 64), (3000, 256, 1024), (33000, 128, 48)])
+def test_vq_assign_packed_kernel_equals_the_generic_kernel_bitwise(ops, N, E, K):
+    """g2v_vq_assign_packed_fwd (round 5: any E % 16 == 0, K % 16 == 0 on the fragment-major codebook image -- the reference's own
+    E = 400 shapes; 1 / 2 / 4 row tiles per workgroup by N) against g2v_vq_assign_fwd's generic kernel: idx, dist_min, quantized
+    and the SSE partials are BITWISE equal on every row (same row norms, the same k order per code tile, the same merges), on
+    random data, exact ties, NaN / Inf rows, a ragged last tile; and both against the oracle on the rows outside the rounding band."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    flat, z = rnd(N, E, seed=41), rnd(N, E, seed=42)
+    W = torch.rand(K, E, generator=torch.Generator().manual_seed(43)) * 2 - 1
+    W[K - 3] = W[5]                                   # exact ties: the lowest index must win
+    flat[7] = W[5]
+    flat[11, 3] = float("nan")
+    flat[13, :] = float("nan")
+    flat[17, 0] = float("inf")
+    flat[N - 1, E - 1] = 1.0e30
+    fd, zd, Wd = flat.to(DEV), z.to(DEV), W.to(DEV)
+    wsq = ops.vq_code_sqnorm(Wd)
+    p = lambda t: None if t is None else t.data_ptr()
+    def run(packed):
+        idx = torch.full((N,), -7, dtype=torch.int64, device=DEV)
+        quant, dmin = torch.full((N, E), 7.0, device=DEV), torch.full((N,), 7.0, device=DEV)
+        sse = torch.full((lib.g2v_vq_assign_blocks(N),), 7.0, device=DEV)
+        st = torch.cuda.current_stream().cuda_stream
+        if packed:
+            assert lib.g2v_vq_assign_packed_ok(N, E, K) == 1
+            frag = torch.empty(K * E, device=DEV)
+            assert lib.g2v_vq_pack_codebook(p(Wd), p(frag), K, E, st) == 0
+            assert lib.g2v_vq_assign_packed_fwd(p(fd), p(zd), p(Wd), p(frag), p(wsq), p(idx), p(quant), p(dmin), p(sse), N, E, K, st) == 0
+        else:
+            prev = ops.VQ_PACKED_MIN_ROWS
+            assert lib.g2v_vq_assign_fwd(p(fd), p(zd), p(Wd), p(wsq), p(idx), p(quant), p(dmin), p(sse), N, E, K, st) == 0
+        torch.cuda.synchronize()
+        return idx, quant, dmin, sse
+    a, b = run(True), run(False)
+    assert torch.equal(a[0], b[0]), int((a[0] != b[0]).sum())
+    assert int(a[0][7]) == 5
+    for x, y, name in zip(a[1:], b[1:], ("quantized", "dist_min", "sse_partial")):
+        same = (x == y) | (torch.isnan(x) & torch.isnan(y))
+        if not (E == 128 and K % 128 == 0):           # (at E = 128, K % 128 = 0 g2v_vq_assign_fwd runs its own tuned kernels: another row-norm tree)
+            assert bool(same.all()), (name, int((~same).sum()))
+    d = O.vq_distances(flat, W)
+    ref = d.argmin(1)
+    top2 = torch.topk(d.nan_to_num(float("inf")), 2, dim=1, largest=False).values
+    safe = ((top2[:, 1] - top2[:, 0]) > 1e-4 * torch.clamp(top2[:, 0].abs(), min=1.0)) & torch.isfinite(d).all(1)
+    assert torch.equal(a[0].cpu()[safe], ref[safe])
+    assert torch.equal(a[0].cpu()[[11, 13, 17]], ref[[11, 13, 17]])      # NaN / Inf rows follow torch.argmin
+    # ops.vq_assign takes the packed kernel by itself from VQ_PACKED_MIN_ROWS rows (shapes without a tuned kernel of their own)
+    idx2, _, _, _ = ops.vq_assign(fd, zd, Wd, wsq)
+    assert torch.equal(idx2, a[0])
+
+
 @pytest.mark.parametrize("N,E,K", [(40, 32, 48), (40, 100, 512), (40, 128, 512), (16384 + 5, 128, 512)])   # generic / generic with the codes split over workgroups / fast / row-tiled kernel
 def test_vq_assign_ties_pick_lowest_index(ops, N, E, K):
     W = rnd(K, E, seed=3)

@@ -59,6 +59,9 @@ def check_code_indices(got_idx, ref_idx, dist, gap_rel_floor=None, gap=None):
     return safe
 
 
+WORST = []      # (shape, step, tensor, L2, max) of the large-batch gradient comparisons: printed by the last test of the module
+
+
 def relerr_l2(got, ref):
     got = got.detach().cpu().double().reshape(-1)
     ref = torch.as_tensor(ref).double().reshape(-1)
@@ -227,17 +230,40 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
             masks["in"] = (torch.rand(T, B, D, generator=g) < 1 - p).to(torch.uint8)
             masks["enc_l0"] = torch.ones(T, B, 2 * H, dtype=torch.uint8)   # layer 1 is dead compute: any mask works
             masks["dec_l0"] = (torch.rand(T - 1, B, H, generator=g) < 1 - p).to(torch.uint8)
-        if big:
-            with default64():
-                r = O.vqvae_train_step(sd, adam, x, masks, cfg)
-        else:
-            r = O.vqvae_train_step(sd, adam, x, masks, cfg)
         eng.set_masks(B, masks["dec"].to(DEV), masks["in"].to(DEV) if p > 0 else None,
                       masks["dec_l0"].to(DEV) if p > 0 else None)
         eng.train_step(xd, xd, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=False)
         b = eng.buffers(B)
-        safe = check_code_indices(b["idx"].cpu().numpy(), r["idx"].numpy(), r["dist"], gap_rel_floor=True)
-        assert safe.mean() > 0.95
+        if big:
+            # Large batch: the float64 oracle is told the DISCRETE decisions the kernels took -- code indices, the decoder's ReLU
+            # pattern, the signs of custom_loss's |.| terms (oracle/g2v_oracle.py: cfg["forced"]).  A decision whose argument is
+            # inside fp32 rounding of its threshold may legitimately fall the other way in float64, and ONE flipped ReLU / sign
+            # moves single gradient elements by 1e-3..1e-2 of a tensor's maximum: until round 4 this test carried tolerances wide
+            # enough for such flips (L2 1e-3, max 5e-3), i.e. wide enough for a real kernel error of that size.  With the
+            # decisions pinned both sides evaluate the same smooth function; what is left is fp32 rounding.  The decisions
+            # themselves are checked separately: the indices against the oracle's own argmin (check_code_indices below), the
+            # signs against the oracle's own values wherever those are outside a rounding band; a wrong ReLU pattern would show
+            # in the reconstructed poses (1e-4 below), which the pinned oracle computes with that pattern.
+            y_e = b["y"].transpose(0, 1)
+            forced = {"idx": b["idx"].cpu(), "relu": (b["a"] > 0).cpu().double(),
+                      "sign_l1": torch.sign(y_e - xd).cpu().double(),
+                      "sign_cont": torch.sign(y_e[:, 1:] - y_e[:, :-1]).cpu().double()}
+            with default64():
+                r = O.vqvae_train_step(sd, adam, x, masks, dict(cfg, forced=forced))
+            # the pinned decisions are the oracle's own wherever the oracle's argument is clear of the threshold
+            ro = r["outputs"]
+            clear = (ro - x).abs() > 1e-5 * (1 + ro.abs())
+            assert torch.equal(torch.sign(ro - x)[clear], forced["sign_l1"][clear]), "sign(y - target) outside the rounding band"
+            dc = ro[:, 1:] - ro[:, :-1]
+            clear = dc.abs() > 1e-5 * (1 + ro[:, 1:].abs())
+            assert torch.equal(torch.sign(dc)[clear], forced["sign_cont"][clear]), "sign(y_t - y_{t-1}) outside the rounding band"
+        else:
+            r = O.vqvae_train_step(sd, adam, x, masks, cfg)
+        ref_idx = torch.argmin(torch.as_tensor(r["dist"]), dim=1).numpy()       # (the oracle's OWN argmin, also when idx was pinned)
+        safe = check_code_indices(b["idx"].cpu().numpy(), ref_idx, r["dist"], gap_rel_floor=True)
+        # rows whose top-2 gap is inside the rounding band (1e-4 relative: 0.01 on distances of order 100): measured <= 3 rows at
+        # B <= 1040 and 0.2 .. 0.6 % of the rows at B >= 4096 on these seeds (round 5; the bound used to be 5 %)
+        assert (~safe).sum() <= max(3, B // 100), int((~safe).sum())
         assert relerr(b["y"].transpose(0, 1), r["outputs"]) < 1e-4, "reconstructed poses"
         total = eng.loss_terms[0].item() + eng.vq_scalars[0].item() / 400
         assert abs(total - float(r["loss"])) <= 1e-5 * abs(float(r["loss"]))
@@ -250,16 +276,11 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
             if float(ref.abs().max()) == 0.0:
                 assert float(eng.view(name, True).abs().max()) == 0.0, name     # encoder layer 1: exactly zero
             elif big:
-                # max norm AND L2 norm: a ReLU / dropout-scaled activation within rounding of zero can flip its mask between
-                # fp32 and the float64 oracle, which moves single elements (max norm) but not the tensor (L2)
-                # (second step of the K = 400 shape: the EMA update has moved the codes onto the encoder states, the commitment
-                #  term 2 beta (x - q) / n cancels in fp32 against a float64 oracle -- 1.06e-3 on one encoder tensor, 1e-5 at step 1)
-                assert relerr_l2(eng.view(name, True), ref) < (2e-3 if step > 0 and H != 64 else 1e-3), \
-                    (name, relerr_l2(eng.view(name, True), ref))
-                # (K = 400 shape, second step: one element of pre_linear.0.weight -- a (200 x 45) sum over the 5 % of rows Dropout(0.95)
-                #  keeps -- moves by 8.5e-3 of the tensor's maximum with such a flip; its L2 error is 6e-4)
-                assert relerr(eng.view(name, True), ref) < (1e-2 if step > 0 and H != 64 else 5e-3), \
-                    (name, relerr(eng.view(name, True), ref))
+                # (decisions pinned, see above: fp32 rounding of sums over 1e5..1e6 rows is what is left)
+                l2, mx = relerr_l2(eng.view(name, True), ref), relerr(eng.view(name, True), ref)
+                WORST.append((B, T, H, K, p, step, name, l2, mx))
+                assert l2 < 2e-4, (name, l2)
+                assert mx < 1e-3, (name, mx)
             else:
                 assert relerr(eng.view(name, True), ref) < 5e-4, (name, relerr(eng.view(name, True), ref))
         # post-step weights: Adam normalises each element's gradient by its own magnitude, so elements whose gradient sits at
@@ -278,6 +299,14 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
                 assert err <= 1e-4 * float(sd[name].abs().max()) + 0.02 * 5e-4, (name, err)
         assert relerr(eng.codebook, sd["vq_layer._embedding.weight"]) < 1e-4
         sync_engine_from_oracle(eng, sd, adam, step + 1)          # the next step starts from identical states
+
+
+def test_report_large_batch_gradient_errors():
+    """not a check: prints the worst pinned-decision gradient errors of the large-batch cases above (pytest -s / -rP)"""
+    for rec in sorted(WORST, key=lambda r: -r[7])[:8]:
+        print("worst L2", rec)
+    for rec in sorted(WORST, key=lambda r: -r[8])[:8]:
+        print("worst max", rec)
 
 
 def test_full_size_properties():
