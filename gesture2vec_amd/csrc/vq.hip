@@ -1397,14 +1397,17 @@ extern "C" int g2v_vq_codebook_grad(const float* stats, const float* codebook, c
 // tile instead of 32 fp32 ones (32 cycles) = 5.3x fewer matrix cycles, plus the re-check on the undecided fraction.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
-__global__ __launch_bounds__(256) void vq_bx3_split_kernel(const float* __restrict__ W, __bf16* __restrict__ Wh,
-                                                           __bf16* __restrict__ Wl, int64_t n) {
+__global__ __launch_bounds__(256) void vq_bx3_split_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
+                                                           __bf16* __restrict__ Wh, __bf16* __restrict__ Wl,
+                                                           float* __restrict__ wn, int64_t n, int K) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const float w = W[e];
     const __bf16 h = (__bf16)w;
     Wh[e] = h;
     Wl[e] = (__bf16)(w - (float)h);
   }
+  // |w_k| (rounded up), for the PER-CODE error radius of the sweep
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) wn[k] = sqrtf(wsq[k]) * 1.001f;
 }
 
 // 256 rows per workgroup: wave w owns rows 64 w .. 64 w + 63 (4 row tiles, fragments in registers for the whole sweep) and
@@ -1415,8 +1418,14 @@ constexpr int BX3_CODES = 64, BX3_LDW = 128 + 8;       // bf16 elements per LDS 
 // (best, second best) per row are kept as floats that carry the code index in their low mantissa bits (kbits = log2 K): one
 // v_and_or packs, med3(d1, d2, p) is the new second best, min(d1, p) the new best -- 3.5 VALU ops per candidate, which fit
 // into the issue slots the bf16 MFMAs leave; the 2^-(23 - kbits) relative truncation is added to the margin.
+// Round 5: the margin is PER CODE.  The sweep ranks LOWER BOUNDS  L_k = e_k - r_k,  r_k = 2^-12 |x| |w_k| (the 3-term split's
+// error bound, x 2 for the -2 x.w, with the same 2x allowance as before); U* = L_a + 2 r_a of the best-ranked code a bounds the
+// row's minimum from above, so the row is decided iff the second-smallest lower bound clears U*.  With the global margin
+// 2^-11 |x| max_k |w_k| a TRAINED codebook -- the EMA update leaves dead codes with norms hundreds of times the live ones' --
+// made every row undecided (all 2^20 rows through the fp32 kernel: 1.7 ms instead of 0.49); per code those are simply far away.
 __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __restrict__ flat, const __bf16* __restrict__ Wh,
                                                               const __bf16* __restrict__ Wl, const float* __restrict__ wsq,
+                                                              const float* __restrict__ wn,
                                                               int64_t* __restrict__ idx_out, int* __restrict__ und_list,
                                                               int* __restrict__ und_count, int N, int K, int kbits) {
   constexpr int E = 128, KB = E / 32, RT = 4;
@@ -1447,10 +1456,9 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
     ss += __shfl_xor(ss, 32);
     xr[t] = ss;
   }
-  float wm = 0.f;                                       // max_k |w_k|^2
-  for (int k = lane; k < K; k += 64) wm = fmaxf(wm, wsq[k]);
+  float cx[RT];                                         // 2^-12 |x|
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o));
+  for (int t = 0; t < RT; ++t) cx[t] = 2.44140625e-4f * sqrtf(xr[t]);
   float d1[RT], d2[RT];
 #pragma unroll
   for (int t = 0; t < RT; ++t) { d1[t] = INFINITY; d2[t] = INFINITY; }
@@ -1489,7 +1497,7 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
         wl[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][1][(16 * tl + i) * BX3_LDW + 32 * s + 8 * q]);
       }
       const int c0 = c * BX3_CODES + 16 * tl + 4 * q;
-      const float4 sq = *reinterpret_cast<const float4*>(wsq + c0);
+      const float4 sq = *reinterpret_cast<const float4*>(wsq + c0), nq = *reinterpret_cast<const float4*>(wn + c0);
       f32x4 acc[RT];
 #pragma unroll
       for (int t = 0; t < RT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1505,12 +1513,12 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 #pragma unroll
         for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh[t][s], acc[t], 0, 0, 0);
       }
-      const float sv[4] = {sq.x, sq.y, sq.z, sq.w};
+      const float sv[4] = {sq.x, sq.y, sq.z, sq.w}, nv[4] = {nq.x, nq.y, nq.z, nq.w};
 #pragma unroll
       for (int t = 0; t < RT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float d = (xr[t] + sv[r]) - 2.0f * acc[t][r];
+          const float d = (xr[t] + fmaf(-cx[t], nv[r], sv[r])) - 2.0f * acc[t][r];      // the LOWER bound e_k - r_k
           const float pk = __uint_as_float((__float_as_uint(d) & ~kmask) | (unsigned)(c0 + r));
           d2[t] = __builtin_amdgcn_fmed3f(d1[t], d2[t], pk);      // d1 <= d2 always: the median is the second smallest
           d1[t] = fminf(d1[t], pk);                               // a NaN candidate leaves both untouched (minNum)
@@ -1530,8 +1538,9 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
     }
     const int row = r0 + 16 * t + i;
     if (q == 0 && row < N) {
-      idx_out[row] = (int64_t)(__float_as_uint(d1[t]) & kmask);
-      const float margin = 4.8828125e-4f * sqrtf(xr[t] * wm) + trunc * fabsf(d2[t]);       // 2^-11 |x| max|w| + truncation
+      const int ca = (int)(__float_as_uint(d1[t]) & kmask);
+      idx_out[row] = (int64_t)ca;
+      const float margin = 2.0f * cx[t] * wn[ca < K ? ca : 0] + trunc * fabsf(d2[t]);       // 2 r_a + the packing's truncation
       // NaN / inf - inf (rows with non-finite distances) compare false: undecided, the exact kernel follows torch.argmin
       if (!(d2[t] - d1[t] >= margin)) und_list[atomicAdd(und_count, 1)] = row;
     }
@@ -2160,7 +2169,7 @@ extern "C" int g2v_vq_assign_packed_fwd(const float* flat, const float* z, const
 
 extern "C" size_t g2v_vq_assign_bulk_workspace(int N, int E, int K) {
   if (N <= 0 || E <= 0 || K <= 0) return 0;
-  return 2 * (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256 + (size_t)N * 4;
+  return 2 * (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256 + (((size_t)K * 4 + 255) & ~(size_t)255) + (size_t)N * 4;
 }
 
 // idx[n] = argmin_k |flat[n] - W[k]|^2 for MANY rows (bulk latent -> code assignment): bf16 split screening + exact fp32
@@ -2185,13 +2194,15 @@ extern "C" int g2v_vq_assign_bulk(const float* flat, const float* codebook, cons
   __bf16* Wh = (__bf16*)w;
   __bf16* Wl = (__bf16*)(w + half);
   int* count = (int*)(w + 2 * half);
-  int* list = (int*)(w + 2 * half + 256);
+  float* wn = (float*)(w + 2 * half + 256);
+  int* list = (int*)(w + 2 * half + 256 + (((size_t)K * 4 + 255) & ~(size_t)255));
   (void)hipMemsetAsync(count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(vq_bx3_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, Wh, Wl, (int64_t)K * E);
+  hipLaunchKernelGGL(vq_bx3_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, wn,
+                     (int64_t)K * E, K);
   int kbits = 1;
   while ((1 << kbits) < K) ++kbits;
   G2V_REQUIRE(kbits <= 13, "codebook larger than 8192 codes");
-  hipLaunchKernelGGL(vq_bx3_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, code_sqnorm, idx, list, count, N,
+  hipLaunchKernelGGL(vq_bx3_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, code_sqnorm, wn, idx, list, count, N,
                      K, kbits);
   hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4, true>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, (const float*)nullptr,
                      codebook, code_sqnorm, idx, (float*)nullptr, (float*)nullptr, (float*)nullptr, N, K, list, count);

@@ -51,6 +51,7 @@ def decoder_params(dec) -> List[torch.Tensor]:
 # weights) are faster -- the same crossover as the pose decoder's (dec_rollout.hip, "split" kernels).
 FUSED_MIN_ROWS = 1024
 FUSED_CALLS = 0          # forwards served by the fused kernels (tests assert that the path under test actually ran)
+LAST_SAVED = None        # weak reference to the last fused forward's saved arrays (tests read the decisions the kernels took)
 
 
 def _fused_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
@@ -79,7 +80,7 @@ def _fused_weights(spec, params, H):
 
 def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     """The S1 decode steps as S1 + 1 launches of ONE kernel (include/g2v.h: g2v_attn_code_rollout_fwd)."""
-    global FUSED_CALLS
+    global FUSED_CALLS, LAST_SAVED
     FUSED_CALLS += 1
     S1, att = spec.steps, spec.att
     B, H = hidden0.shape[1], hidden0.shape[2]
@@ -111,6 +112,7 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     #  capture_end; the backward does not read them)
     ctx.bufs = dict(wd=wd, sv={k: t for k, t in sv.items() if k != "logits"}, enc=enc, ep=ep, mask_emb=mask_emb, mask_l0=mask_l0,
                     drop=drop, Tw=Tw)
+    LAST_SAVED = {"ids": sv["ids"], "a": sv["a"]}
     AW = sv["attw"] if att else f32(0)
     ctx.mark_non_differentiable(AW)
     ctx.set_materialize_grads(False)

@@ -14,9 +14,15 @@ def timeit(fn, n=20):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / n * 1e3
 out = []
-for scale, tag in ((1.0, "N(0,1) rows and codes"), (0.05, "rows and codes scaled 0.05 (a trained model's range)")):
+for scale, tag in ((1.0, "N(0,1) rows and codes"), (0.05, "rows and codes scaled 0.05 (a trained model's range)"),
+                   (-1.0, "N(0,1) rows and codes, 32 dead codes of 300x the norm")):
     g = torch.Generator().manual_seed(3)
-    W = (torch.randn(K, E, generator=g) * scale).to(dev)
+    dead = scale < 0
+    scale = abs(scale)
+    W = torch.randn(K, E, generator=g) * scale
+    if dead:
+        W[64:96] *= 300.0
+    W = W.to(dev)
     wsq = ops.vq_code_sqnorm(W)
     for logn in (14, 16, 18, 20):
         N = 1 << logn
@@ -31,4 +37,4 @@ for scale, tag in ((1.0, "N(0,1) rows and codes"), (0.05, "rows and codes scaled
                    bulk_GBps=round((N * E * 4 + N * 8) / t_bulk / 1e3, 1))
         print(json.dumps(rec)); out.append(rec)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/bulk_assign_sweep.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r05_vq_bulk_assign_sweep.json", "w"), indent=1)

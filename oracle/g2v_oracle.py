@@ -499,7 +499,10 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
         if training:
             bn["running_mean"], bn["running_var"] = nrm, nrv
             bn["num_batches_tracked"] = bn["num_batches_tracked"] + 1
-        a = torch.relu(a)
+        # cfg["forced"] (large-batch parity tests only, see vqvae_forward): "relu" (S-1,B,H) 0/1 pattern of the decoder's ReLU,
+        # "ids" (S-1,B) the code fed at every decode step (the greedy argmax of the run under test)
+        forced = cfg.get("forced") or {}
+        a = torch.relu(a) if "relu" not in forced else a * forced["relu"][t - 1]
         new_h, layer_in = [], a
         for l in range(L):
             gi = linear(layer_in, sd[pre + f"gru.weight_ih_l{l}"], sd[pre + f"gru.bias_ih_l{l}"])
@@ -516,6 +519,8 @@ def t2e_forward(sd: Dict[str, Tensor], ids: Tensor, lengths: Tensor, codes: Tens
             continue
         outs.append(logits)
         dec_in = cod[t] if t < cfg["n_pre_poses"] else logits.argmax(1)                   # :734-744
+        if "ids" in forced and t < S - 1:
+            dec_in = forced["ids"][t]                                                     # (ids[t] feeds decode step t + 1)
     return {"outputs": torch.stack(outs).transpose(0, 1), "bn": bn, "encoder_hidden": enc_hidden,
             "encoder_outputs": enc_out, "attn": attn_list}
 

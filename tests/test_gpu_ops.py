@@ -235,6 +235,8 @@ def test_vq_assign_bulk_equals_exact_assignment(ops, N, K, scale):
     g = torch.Generator().manual_seed(21)
     W = torch.randn(K, E, generator=g) * scale
     W[K // 2] = W[3]                                    # an exact tie for every row that picks code 3
+    W[20:28] *= 300.0                                   # dead codes far away from every row (what an EMA update leaves behind:
+                                                        # the global margin of rounds 2-4 made EVERY row undecided there)
     flat = torch.randn(N, E, generator=g) * scale
     flat[5] = W[7] + 1e-7 * torch.randn(E, generator=g)        # a row sitting on a code
     flat[6] = 0.5 * (W[10] + W[11])                     # equidistant from two codes (up to rounding)
@@ -246,7 +248,7 @@ def test_vq_assign_bulk_equals_exact_assignment(ops, N, K, scale):
     idx, und = ops.vq_assign_bulk(fd, Wd, wsq, want_undecided=True)
     n_und = int(und.item())
     assert torch.equal(idx, exact), f"{int((idx != exact).sum())} rows differ from the fp32 kernel ({n_und} undecided)"
-    assert 4 <= n_und <= max(8, N // 3), n_und           # the planted rows at least; screening must decide most rows
+    assert 4 <= n_und <= max(8, N // 8), n_und           # the planted rows at least; screening must decide most rows
     nchk = min(N, 2000)
     dist = O.vq_distances(flat[:nchk].double(), W.double())
     i_ref = dist.argmin(1)

@@ -313,7 +313,7 @@ def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
     fused-vs-per-operator above that.  One train_iter_text2embedding on synthetic sentences (config/seq2seq.yml dims: H = 200,
     2 layers, K = 512, S = 6, dropout 0.2), explicit dropout masks on both sides: loss, greedy codes fed back (free-running from
     step 1), every gradient.  A greedy-code decision inside fp32 rounding of a tie may differ on a handful of rows (each changes
-    that row's later steps): the L2 criterion carries the gradients, the max criterion is loose."""
+    that row's later steps): since round 5 the oracle is told the codes and the ReLU pattern the kernels used."""
     import sys
     ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -340,9 +340,22 @@ def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
              "enc_l0": (torch.rand(Tw, B, 2 * H, generator=g) < 1 - p).to(torch.uint8)}
     cfg = dict(n_layers=L, dropout_prob=p, n_pre_poses=1, lr=lr, att=(att == "True"))
     torch.set_num_threads(min(os.cpu_count() or 1, 16))
-    r = O.t2e_train_step(sd, {}, ids, lengths.long(), codes.long(), masks, cfg)
+    from gesture2vec_amd import rollout_t2e
     net.set_dropout_masks(masks["emb"].to(DEV), masks["dec_l0"].to(DEV), masks["enc_l0"].to(DEV))
     loss = train_iter_text2embedding(args, 1, ids.to(DEV), lengths, None, None, codes.to(DEV), None, net, optim)
+    # Round 5: the oracle is told the DISCRETE decisions of the run -- the greedy code fed at every decode step and the decoder's
+    # ReLU pattern (oracle/g2v_oracle.py: cfg["forced"]); a greedy decision inside fp32 rounding of a tie used to change a row's
+    # later steps on a handful of rows, which is why this test carried L2 < 1e-3 / max < 2e-2.  The decisions themselves: the
+    # greedy codes must be the argmax of the oracle's own logits wherever its top-2 gap is clear of rounding (below).
+    sv = rollout_t2e.LAST_SAVED
+    assert sv is not None and sv["ids"].shape == (S - 1, B), "the fused step kernels did not serve this shape"
+    forced = {"ids": sv["ids"].cpu(), "relu": (sv["a"] > 0).cpu().to(torch.float32)}
+    r = O.t2e_train_step(sd, {}, ids, lengths.long(), codes.long(), masks, dict(cfg, forced=forced))
+    lo = r["outputs"][:, 1:S - 1]                                  # logits of decode steps 0 .. S-3 decide ids[1 ..]
+    top2 = torch.topk(lo, 2, dim=2).values
+    clear = (top2[..., 0] - top2[..., 1]) > 1e-4 * (1 + top2[..., 0].abs())
+    assert float(clear.float().mean()) > 0.99
+    assert torch.equal(lo.argmax(2)[clear], forced["ids"][1:].t()[clear]), "a greedy code outside the rounding band differs"
     assert abs(loss["loss"] - float(r["loss"])) <= 2e-5 * float(r["loss"]), (loss, float(r["loss"]))
     worst = ("", 0.0)
     for n, prm in net.named_parameters():
@@ -355,7 +368,8 @@ def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
         got = prm.grad.detach().cpu().double().reshape(-1)
         rf = ref.double().reshape(-1)
         l2 = float((got - rf).norm() / rf.norm())
-        worst = max(worst, (n, l2), key=lambda v: v[1])
-        assert l2 < 1e-3, (n, l2)
-        assert relerr(prm.grad, ref) < 2e-2, (n, relerr(prm.grad, ref))
+        worst = max(worst, (n, l2, relerr(prm.grad, ref)), key=lambda v: v[1])
+        assert l2 < 1e-4, (n, l2)
+        assert relerr(prm.grad, ref) < 2e-4, (n, relerr(prm.grad, ref))
     assert worst[1] > 0.0
+    print("worst gradient error (pinned decisions)", worst)

@@ -279,8 +279,9 @@ def test_fused_train_step_vs_oracle(B, T, D, H, K, p):
                 # (decisions pinned, see above: fp32 rounding of sums over 1e5..1e6 rows is what is left)
                 l2, mx = relerr_l2(eng.view(name, True), ref), relerr(eng.view(name, True), ref)
                 WORST.append((B, T, H, K, p, step, name, l2, mx))
-                assert l2 < 2e-4, (name, l2)
-                assert mx < 1e-3, (name, mx)
+                # measured on all eight large shapes, both steps: <= 4.0e-6 / 4.6e-6 (profiles/r05_i_large_batch_grad_errors.txt)
+                assert l2 < 2e-5, (name, l2)
+                assert mx < 5e-5, (name, mx)
             else:
                 assert relerr(eng.view(name, True), ref) < 5e-4, (name, relerr(eng.view(name, True), ref))
         # post-step weights: Adam normalises each element's gradient by its own magnitude, so elements whose gradient sits at
