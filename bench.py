@@ -324,8 +324,22 @@ def part_d(with_cpu: bool):
                 g.replay()
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            res["runs"].append({"att": att == "True", "B": B, "ms_per_step": round(dt / n * 1e3, 4), "samples_per_s": round(B * n / dt, 1),
-                                "loss": round(float(g.loss), 4)})
+            # flops as EXECUTED: forward x 3.  Layer 0's input projections run on the sum(lengths) packed positions, the recurrent
+            # products on the padded Tw steps (a row tile skips only the steps past its longest sentence); without attention only
+            # encoder layer 0 is evaluated
+            H, K, Tw, S1, att_b = 200, 512, int(ids.shape[1]), int(codes.shape[1]) - 1, att == "True"
+            Hin = 2 * H if att_b else H
+            mean_len = float(lengths.double().mean())
+            enc = mean_len * (2 * 300 * 3 * H * 2) + Tw * (2 * H * 3 * H * 2) + \
+                (Tw * (2 * 2 * H * 3 * H * 2 + 2 * H * 3 * H * 2 + 2 * H * H) if att_b else 0)
+            dec = S1 * (2 * Hin * H + 2 * (2 * H * 3 * H * 2) + 2 * H * K + ((2 * H * H + 4 * Tw * H) if att_b else 0))
+            fl = 3.0 * (enc + dec) * B
+            tf = fl / (dt / n) / 1e12
+            res["runs"].append({"att": att_b, "B": B, "ms_per_step": round(dt / n * 1e3, 4), "samples_per_s": round(B * n / dt, 1),
+                                "loss": round(float(g.loss), 4), "flops_executed": fl, "achieved_TFLOPs": round(tf, 2),
+                                "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
+                                "decoder_steps": ("fused per-step kernels (g2v_attn_code_rollout_fwd / _bwd)"
+                                                  if B >= 1024 else "column-split per-operator kernels (B < 1024)")})
             del g, net, opt
     if with_cpu and keep is not None:
         try:

@@ -34,7 +34,8 @@ class DecSaved(C.Structure):
 class GruDir(C.Structure):
     """g2v_gru_dir"""
     _fields_ = ([(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)] +
-                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)])
+                [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)] +
+                [("gi_row_off", C.POINTER(C.c_int32))])                 # HOST array of T packed row offsets, or NULL
 
 
 class WgradItem(C.Structure):
@@ -47,7 +48,8 @@ class GruDirBwd(C.Structure):
     _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
                 [(n, c_fp) for n in ("w_ih", "dx")] + [("in_dim", c_int)] +
                 [(n, c_fp) for n in ("x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab")] +      # optional fused weight gradients
-                [(n, c_fp) for n in ("hn_z", "hn_q", "hn_gloss")] + [("hn_coef", c_f)])         # optional fused quantiser backward
+                [(n, c_fp) for n in ("hn_z", "hn_q", "hn_gloss")] + [("hn_coef", c_f)] +        # optional fused quantiser backward
+                [("dgi_row_off", C.POINTER(C.c_int32))])                # HOST array of T packed row offsets, or NULL
 
 
 class CodeDecWeights(C.Structure):
@@ -108,6 +110,7 @@ _SIGS = {
     "g2v_vq_ema_update": (c_int, [c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                                   c_f, c_f, c_f, c_int, c_fp]),
     "g2v_vq_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_fp]),
+    "g2v_gru_seq_packed_ok": (c_int, [c_int, c_int, c_int]),
     "g2v_gru_seq_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_gru_seq_fwd": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_workspace": (c_sz, [c_int, c_int]),

@@ -130,12 +130,24 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ gi, c
 // loads a tile's gi rows and biases AFTER its product, element by element, in front of the gate math (one exposed memory round
 // trip per tile, three or four tiles per wave and step).  Here the gi vectors and biases of the wave's NEXT tile are requested
 // before the current tile's product, as 16-byte vectors.
+// Packed input projections (round 5): with `on`, row (t, b) of gi / dgi lives at row off[t] + b of a COMPACT array that holds only
+// the positions inside their sequences (lengths sorted descending: at step t the first n_t rows of the batch; off[t] = sum of
+// n_t' for t' < t) -- what pack_padded_sequence does for the reference.  The dense products that make gi and consume dgi
+// (input projection, its data and weight gradients, the embedding gradient) then run over sum(lengths) rows instead of T x B:
+// 40 % fewer at Part d's lengths U{4..20}.  hs / gates / dgh keep the (T,B,.) layout.  By value: T <= 64.
+constexpr int GRU_MAX_OFF = 64;
+struct RowOff {
+  int on;
+  int off[GRU_MAX_OFF];
+};
+__device__ __forceinline__ int64_t gi_row_base(const RowOff& ro, int t, int B) { return ro.on ? (int64_t)ro.off[t] : (int64_t)t * B; }
+
 template <int NR>      // 16-row tiles per workgroup (256 NR threads): every W_hh fragment multiplies 16 NR rows
 __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi, const float* __restrict__ w_hh,
                                                     const float* __restrict__ b_hh, const float* __restrict__ h0,
                                                     const int32_t* __restrict__ lengths, int reverse,
                                                     float* __restrict__ hs, int64_t hs_ld, float* __restrict__ h_n,
-                                                    float* __restrict__ gates, int T, int B, int H) {
+                                                    float* __restrict__ gates, int T, int B, int H, const RowOff& ro) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int ROWS = 16 * NR, NTHR = 256 * NR, NWAVE = 4 * NR;
   const int Hp = (H + 15) & ~15, ldx = Hp + 4;
@@ -197,7 +209,7 @@ __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
       const bool ok = rvalid[r] && s < T && t < len[r] && col;
-      const float* gir = gi + ((int64_t)(ok ? t : 0) * B + brow[r]) * 3 * H + (ok ? f0 : 0);
+      const float* gir = gi + ((ok ? gi_row_base(ro, t, B) + brow[r] : (int64_t)0)) * 3 * H + (ok ? f0 : 0);
 #pragma unroll
       for (int g = 0; g < 3; ++g) gin[r][g] = ok ? *reinterpret_cast<const float4*>(gir + g * H) : z4;
     }
@@ -280,9 +292,9 @@ struct GruGenF {
 };
 template <int V4>      // 0: scalar body; NR = 1 / 2: the vector body with NR row tiles per workgroup
 __global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths,
-                                                                         int64_t hs_ld, int T, int B, int H) {
+                                                                         int64_t hs_ld, int T, int B, int H, RowOff ro) {
   const GruGenF d = blockIdx.y == 0 ? d0 : d1;
-  if constexpr (V4 > 0) gru_seq_fwd_body_v4<V4>(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
+  if constexpr (V4 > 0) gru_seq_fwd_body_v4<V4>(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H, ro);
   else gru_seq_fwd_body(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
 }
 
@@ -385,7 +397,7 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
                                                     const float* __restrict__ gates, const float* __restrict__ w_hh_t,
                                                     const int32_t* __restrict__ lengths, int reverse,
                                                     float* __restrict__ dgi, float* __restrict__ dgh,
-                                                    float* __restrict__ dh0, int T, int B, int H) {
+                                                    float* __restrict__ dh0, int T, int B, int H, const RowOff& ro) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int Hp = (H + 15) & ~15, G = 3 * H, Gp = (G + 15) & ~15, ldg = Gp + 4, ldh = Hp + 4;
   constexpr int ROWS = 16 * NR, NTHR = 64 * NWV, NWAVE = NWV;
@@ -448,7 +460,7 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       const int sk = reverse ? k : lmax + k;
       const int tk = reverse ? (T - 1 - sk) : sk;
       const int64_t rowk = ((int64_t)tk * B + b0 + r) * G + c;
-      *reinterpret_cast<float4*>(dgi + rowk) = z4;
+      if (!ro.on) *reinterpret_cast<float4*>(dgi + rowk) = z4;      // (packed dgi: positions outside the sequences do not exist)
       *reinterpret_cast<float4*>(dgh + rowk) = z4;
     }
   }
@@ -491,10 +503,12 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
                    vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
       if (rowv) {
-        float* gi_o = dgi + row * G + c;
         float* gh_o = dgh + row * G + c;
-        *reinterpret_cast<float4*>(gi_o) = vr; *reinterpret_cast<float4*>(gi_o + H) = vz; *reinterpret_cast<float4*>(gi_o + 2 * H) = vn;
         *reinterpret_cast<float4*>(gh_o) = vr; *reinterpret_cast<float4*>(gh_o + H) = vz; *reinterpret_cast<float4*>(gh_o + 2 * H) = vh;
+        if (live || !ro.on) {
+          float* gi_o = dgi + (gi_row_base(ro, t, B) + b) * G + c;
+          *reinterpret_cast<float4*>(gi_o) = vr; *reinterpret_cast<float4*>(gi_o + H) = vz; *reinterpret_cast<float4*>(gi_o + 2 * H) = vn;
+        }
       }
       float* gs = Gs + row_l * ldg + c;
       *reinterpret_cast<float4*>(gs) = vr; *reinterpret_cast<float4*>(gs + H) = vz; *reinterpret_cast<float4*>(gs + 2 * H) = vh;
@@ -564,10 +578,10 @@ struct GruGenB {
 };
 template <int V4>      // 0: scalar body; 1: the vector body
 __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
-                                                                         int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
+                                                                         int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H, RowOff ro) {
   const GruGenB d = blockIdx.y == 0 ? d0 : d1;
   if constexpr (V4 > 0)
-    gru_seq_bwd_body_v4<V4>(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
+    gru_seq_bwd_body_v4<V4>(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H, ro);
   else
     gru_seq_bwd_body(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
 }
@@ -590,6 +604,7 @@ struct GruStepF {
   float* h_next;        // (B,H) carried state leaving it
   float* hs; float* gates; float* h_n;   // outputs as in gru_seq_fwd_body; h_n only on the last step
   int t;
+  int64_t gi_row;      // row of gi that holds (t, b = 0): t * B, or the packed offset of step t (RowOff)
 };
 __global__ __launch_bounds__(64) void gru_step_fwd_kernel(GruStepF d0, GruStepF d1, const int32_t* __restrict__ lengths,
                                                           int64_t hs_ld, int T, int B, int H, int last) {
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(64) void gru_step_fwd_kernel(GruStepF d0, GruStepF 
   const int len = (lengths && rvalid) ? lengths[b] : T;
   const bool valid = rvalid && (t < len);
   const int64_t row = (int64_t)t * B + (rvalid ? b : b0);
-  const float* gir = d.gi + row * 3 * H;
+  const float* gir = d.gi + (valid ? d.gi_row + b : (int64_t)0) * 3 * H;      // (packed gi: only rows inside their sequence exist)
   float4 gi4[3], bh4[3], hp4;
 #pragma unroll
   for (int g = 0; g < 3; ++g) {
@@ -684,7 +699,10 @@ struct GruStepB {
   float* carry;           // (B,H)
   float* dgi; float* dgh; float* dh0;
   int t_cur, t_next, tprev_next;   // t_cur: step of part A (-1: none); t_next: step of part B (-1: none); tprev_next: where
-};                                 // h_prev of step t_next lives in hs (-1: the initial state)
+                                   // h_prev of step t_next lives in hs (-1: the initial state)
+  int64_t dgi_row;                 // row of dgi that holds (t_next, b = 0); < 0 with `dgi_packed`: see below
+  int dgi_packed;                  // dgi is the packed array: only rows inside their sequence are written
+};
 __global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB d1, const int32_t* __restrict__ lengths,
                                                           int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H) {
   const GruStepB d = blockIdx.z == 0 ? d0 : d1;
@@ -770,11 +788,13 @@ __global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB 
       direct[r] = dht * zz_[r];
     }
   }
-  float* gi_o = d.dgi + rown * G + f0;
   float* gh_o = d.dgh + rown * G + f0;
-  *reinterpret_cast<float4*>(gi_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
-  *reinterpret_cast<float4*>(gi_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
-  *reinterpret_cast<float4*>(gi_o + 2 * H) = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]);
+  if (act || !d.dgi_packed) {
+    float* gi_o = d.dgi + (d.dgi_row + b) * G + f0;
+    *reinterpret_cast<float4*>(gi_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+    *reinterpret_cast<float4*>(gi_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+    *reinterpret_cast<float4*>(gi_o + 2 * H) = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]);
+  }
   *reinterpret_cast<float4*>(gh_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
   *reinterpret_cast<float4*>(gh_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
   *reinterpret_cast<float4*>(gh_o + 2 * H) = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
@@ -1469,12 +1489,21 @@ extern "C" int g2v_gru_seq_prepare(const float* const* w_hh, const float* const*
   return G2V_OK;
 }
 
+// packed gi / dgi (g2v_gru_dir.gi_row_off): the generic kernels with 16-byte accesses, offsets by value in the kernel arguments
+extern "C" int g2v_gru_seq_packed_ok(int T, int B, int H) {
+  return (T >= 1 && T <= GRU_MAX_OFF && B >= 1 && H >= 4 && (H & 3) == 0 && H <= 256 && H != 64) ? 1 : 0;
+}
+
 static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* lengths, int64_t hs_ld, int T, int B,
                             int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream, bool prepared) {
   G2V_REQUIRE(dirs && workspace, "null pointer");
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && hs_ld >= H, "bad size");
   for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].w_hh && dirs[k].b_hh && dirs[k].hs, "null pointer");
+  if (dirs[0].gi_row_off && !g2v_gru_seq_packed_ok(T, B, H)) {
+    set_error("g2v_gru_seq_fwd: packed gi is not served for this shape (g2v_gru_seq_packed_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   // gi == NULL: the input projection is fused (x, w_ih, b_ih given, in_dim == H == 64); all directions alike
   const bool fuse = dirs[0].gi == nullptr;
   for (int k = 0; k < ndir; ++k) {
@@ -1517,6 +1546,21 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   for (int k = 0; k < ndir && split; ++k)
     split = aligned16(dirs[k].gi) && aligned16(dirs[k].w_hh) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].h0) &&
             aligned16(dirs[k].gates) && aligned16(dirs[k].h_n) && aligned16(workspace);
+  RowOff ro;
+  ro.on = 0;
+  if (dirs[0].gi_row_off) {
+    for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].gi_row_off != nullptr, "packed gi: every direction or none");
+    if (!g2v_gru_seq_packed_ok(T, B, H) || lengths == nullptr) {
+      set_error("g2v_gru_seq_fwd: packed gi needs lengths, T <= 64 and the generic kernels with H %% 4 == 0 (g2v_gru_seq_packed_ok)");
+      return G2V_ERR_UNSUPPORTED;
+    }
+    ro.on = 1;
+    for (int t = 0; t < GRU_MAX_OFF; ++t) ro.off[t] = t < T ? dirs[0].gi_row_off[t] : 0;
+    for (int k = 1; k < ndir; ++k)
+      for (int t = 0; t < T; ++t) G2V_REQUIRE(dirs[k].gi_row_off[t] == ro.off[t], "packed gi: the directions' offsets differ");
+  } else {
+    for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].gi_row_off == nullptr, "packed gi: every direction or none");
+  }
   if (split) {
     // small batch: one launch per time step, (row groups x hidden-unit tiles x directions) single-wave workgroups
     if (workspace_bytes < g2v_gru_seq_fwd_workspace(ndir, H)) {
@@ -1529,8 +1573,9 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
       for (int k = 0; k < ndir; ++k) {
         float* cur = state + ((size_t)k * 2 + (s_ & 1)) * B * H;
         float* nxt = state + ((size_t)k * 2 + ((s_ + 1) & 1)) * B * H;
+        const int tk = dirs[k].reverse ? T - 1 - s_ : s_;
         g[k] = GruStepF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, s_ == 0 ? dirs[k].h0 : cur, nxt, dirs[k].hs, dirs[k].gates,
-                        dirs[k].h_n, dirs[k].reverse ? T - 1 - s_ : s_};
+                        dirs[k].h_n, tk, ro.on ? (int64_t)ro.off[tk] : (int64_t)tk * B};
       }
       if (ndir == 1) g[1] = g[0];
       hipLaunchKernelGGL(gru_step_fwd_kernel, dim3(cdiv(B, 16), Hp >> 4, ndir), dim3(64), 0, st, g[0], g[1], lengths, hs_ld,
@@ -1570,11 +1615,14 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   // two row tiles per workgroup (every weight fragment multiplies 32 rows: 0.73 against 0.80 ms at the native shape) once that
   // still leaves a workgroup for most CUs
   if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)
-    hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<2>, dim3(cdiv(B, 32), ndir), dim3(512), 2 * lds, st, g[0], g[1], lengths, hs_ld, T, B, H, ro);
   else if (v4)
-    hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H, ro);
   else
-    hipLaunchKernelGGL(gru_seq_fwd_kernel<0>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H);
+  {
+    G2V_REQUIRE(!ro.on, "packed gi: the scalar generic body does not serve it");
+    hipLaunchKernelGGL(gru_seq_fwd_kernel<0>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, hs_ld, T, B, H, ro);
+  }
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -1623,6 +1671,10 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   }
   hipStream_t st = (hipStream_t)stream;
   float* p = (float*)workspace;
+  if (dirs[0].dgi_row_off && !g2v_gru_seq_packed_ok(T, B, H)) {
+    set_error("g2v_gru_seq_bwd: packed dgi is not served for this shape (g2v_gru_seq_packed_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   // dx != NULL: the input gradient dx = dgi W_ih is fused (w_ih given, in_dim == H == 64); all directions alike
   const bool fuse = dirs[0].dx != nullptr;
   for (int k = 0; k < ndir; ++k) {
@@ -1710,6 +1762,21 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   for (int k = 0; k < ndir && split; ++k)
     split = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].d_hn) &&
             aligned16(dirs[k].h0) && aligned16(dirs[k].dh0);
+  RowOff ro;
+  ro.on = 0;
+  if (dirs[0].dgi_row_off) {
+    for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].dgi_row_off != nullptr, "packed dgi: every direction or none");
+    if (!g2v_gru_seq_packed_ok(T, B, H) || lengths == nullptr) {
+      set_error("g2v_gru_seq_bwd: packed dgi needs lengths, T <= 64 and the generic kernels with H %% 4 == 0 (g2v_gru_seq_packed_ok)");
+      return G2V_ERR_UNSUPPORTED;
+    }
+    ro.on = 1;
+    for (int t = 0; t < GRU_MAX_OFF; ++t) ro.off[t] = t < T ? dirs[0].dgi_row_off[t] : 0;
+    for (int k = 1; k < ndir; ++k)
+      for (int t = 0; t < T; ++t) G2V_REQUIRE(dirs[k].dgi_row_off[t] == ro.off[t], "packed dgi: the directions' offsets differ");
+  } else {
+    for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].dgi_row_off == nullptr, "packed dgi: every direction or none");
+  }
   if (split) {
     const int Hp = (H + 15) & ~15;
     float* carry = p + (size_t)ndir * 3 * H * H;      // [dir][B][H], after the transposed weights (3 H^2 floats: 16-byte multiple)
@@ -1724,7 +1791,8 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
         const int t_next = s_next < 0 ? -1 : (rev ? T - 1 - s_next : s_next);
         const int tprev = (s_next <= 0) ? -1 : (rev ? t_next + 1 : t_next - 1);
         g[k] = GruStepB{dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, p + (size_t)k * 3 * H * H, dirs[k].d_hn,
-                        carry + (size_t)k * B * H, dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, t_cur, t_next, tprev};
+                        carry + (size_t)k * B * H, dirs[k].dgi, dirs[k].dgh, dirs[k].dh0, t_cur, t_next, tprev,
+                        t_next < 0 ? (int64_t)0 : (ro.on ? (int64_t)ro.off[t_next] : (int64_t)t_next * B), ro.on};
       }
       if (ndir == 1) g[1] = g[0];
       if (it == T && !dirs[0].dh0 && (ndir == 1 || !dirs[1].dh0)) break;      // nobody wants the initial-state gradient
@@ -1754,10 +1822,12 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
          aligned16(dirs[k].h0) && aligned16(dirs[k].dh0) && aligned16(dirs[k].d_hs);
   if (v4)
     hipLaunchKernelGGL(gru_seq_bwd_kernel<1>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
-                       B, H);
-  else
+                       B, H, ro);
+  else {
+    G2V_REQUIRE(!ro.on, "packed dgi: the scalar generic body does not serve it");
     hipLaunchKernelGGL(gru_seq_bwd_kernel<0>, dim3(cdiv(B, 16), ndir), dim3(256), lds, st, g[0], g[1], lengths, d_hs_ld, hs_ld, T,
-                       B, H);
+                       B, H, ro);
+  }
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

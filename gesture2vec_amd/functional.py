@@ -172,8 +172,15 @@ class GRUBiDirFn(torch.autograd.Function):
     gi_f / gi_b (T,B,3H) and the recurrent weights; returns (hs_f, hn_f, hs_b, hn_b)."""
 
     @staticmethod
-    def forward(ctx, gi_f, gi_b, w_f, b_f, w_b, b_b, lengths):
-        T, B, G = gi_f.shape
+    def forward(ctx, gi_f, gi_b, w_f, b_f, w_b, b_b, lengths, packed=None):
+        """packed = (T, B, row_off): gi_f / gi_b are (sum(lengths), 3H) PACKED arrays (ops.gru_dirs_fwd); their gradients
+        come back packed too."""
+        if packed is None:
+            T, B, G = gi_f.shape
+            row_off = None
+        else:
+            T, B, row_off = packed
+            G = gi_f.shape[1]
         H = G // 3
         dev = gi_f.device
         gi_f, gi_b, w_f, w_b = gi_f.contiguous(), gi_b.contiguous(), w_f.contiguous(), w_b.contiguous()
@@ -185,9 +192,10 @@ class GRUBiDirFn(torch.autograd.Function):
             gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
             dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev))
             out += [hs, h_n]
-        ops.gru_dirs_fwd(dirs, T, B, H, lengths=lengths, hs_ld=H)
+        ops.gru_dirs_fwd(dirs, T, B, H, lengths=lengths, hs_ld=H, row_off=row_off)
         ctx.save_for_backward(dirs[0]["hs"], dirs[0]["gates"], w_f, dirs[1]["hs"], dirs[1]["gates"], w_b, lengths)
         ctx.dims = (T, B, H)
+        ctx.packed = (row_off, gi_f.shape[0]) if packed is not None else None
         ctx.set_materialize_grads(False)
         return tuple(out)
 
@@ -196,7 +204,8 @@ class GRUBiDirFn(torch.autograd.Function):
         hs_f, gates_f, w_f, hs_b, gates_b, w_b, lengths = ctx.saved_tensors
         T, B, H = ctx.dims
         if all(g is None for g in (g_hs_f, g_hn_f, g_hs_b, g_hn_b)):
-            return (None,) * 7
+            return (None,) * 8
+        row_off, n_packed = ctx.packed if ctx.packed is not None else (None, 0)
         dev = hs_f.device
         dirs, outs = [], []
         for g_hs, g_hn, hs, gates, w, rev in ((g_hs_f, g_hn_f, hs_f, gates_f, w_f, False), (g_hs_b, g_hn_b, hs_b, gates_b, w_b, True)):
@@ -204,11 +213,11 @@ class GRUBiDirFn(torch.autograd.Function):
             d_hn = g_hn.contiguous() if g_hn is not None else None
             if d_hs is None and d_hn is None:
                 d_hn = torch.zeros((B, H), dtype=torch.float32, device=dev)
-            dgi = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
+            dgi = torch.empty((T, B, 3 * H) if row_off is None else (n_packed, 3 * H), dtype=torch.float32, device=dev)
             dgh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
             dirs.append(dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w, dgi=dgi, dgh=dgh, dh0=None, reverse=rev))
             outs.append((dgi, dgh))
-        ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H)
+        ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H, row_off=row_off)
         zero = torch.zeros((1, B, H), dtype=torch.float32, device=dev)
         hprev_f = torch.cat([zero, hs_f[:-1]], 0).contiguous()          # data movement only
         hprev_b = torch.cat([hs_b[1:], zero], 0).contiguous()
@@ -217,7 +226,7 @@ class GRUBiDirFn(torch.autograd.Function):
             items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
                           torch.empty((3 * H,), dtype=torch.float32, device=dev)))
         ops.linear_bwd_weight_batch(items, 3 * H, H, M=T * B)
-        return outs[0][0], outs[1][0], items[0][2], items[0][3], items[1][2], items[1][3], None
+        return outs[0][0], outs[1][0], items[0][2], items[0][3], items[1][2], items[1][3], None, None
 
 
 class CrossEntropyFn(torch.autograd.Function):

@@ -294,27 +294,46 @@ def vq_bwd(g_quantized, g_loss, z, codebook, idx, beta, out=None):
 
 
 # ------------------------------------------------------------------------------------------ GRU direction(s)
-def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None):
+def gru_packed_ok(T, B, H) -> bool:
+    return bool(_lib_().g2v_gru_seq_packed_ok(int(T), int(B), int(H)))
+
+
+def _row_off_array(row_off, T):
+    """ctypes int32 array of the T packed row offsets (host memory: the library reads it at call time)"""
+    if row_off is None:
+        return None
+    assert len(row_off) == T
+    return (C.c_int32 * T)(*[int(v) for v in row_off])
+
+
+def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None, row_off=None):
     """dirs: list (1 or 2) of dicts gi, w_hh, b_hh, h0, hs, h_n, gates, reverse -- ONE launch for both directions.
-    With gi=None and x, w_ih, b_ih, in_dim given the input projection is fused into the kernel (H == in_dim == 64)."""
+    With gi=None and x, w_ih, b_ih, in_dim given the input projection is fused into the kernel (H == in_dim == 64).
+    row_off (T ints): gi is PACKED -- row (t,b) at row_off[t] + b, only positions inside their sequences (g2v.h)."""
     lib = _lib_()
     arr = (_lib.GruDir * len(dirs))()
+    ro = _row_off_array(row_off, T)
     for k, d in enumerate(dirs):
         for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates", "x", "w_ih", "b_ih"):
             setattr(arr[k], name, _p(d.get(name)))
         arr[k].reverse = int(bool(d.get("reverse", False)))
         arr[k].in_dim = int(d.get("in_dim", 0))
+        if ro is not None:
+            arr[k].gi_row_off = ro
     dev = dirs[0]["hs"].device
     ws = workspace(lib.g2v_gru_seq_fwd_workspace(len(dirs), H), dev, "grufwd")
     check(lib.g2v_gru_seq_fwd(arr, len(dirs), _p(lengths), hs_ld if hs_ld is not None else H, T, B, H, _p(ws),
                               ws.numel(), _stream()), "gru_seq_fwd")
 
 
-def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None):
-    """dirs: list of dicts d_hs, d_hn, hs, h0, gates, w_hh, dgi, dgh, dh0, reverse."""
+def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None, row_off=None):
+    """dirs: list of dicts d_hs, d_hn, hs, h0, gates, w_hh, dgi, dgh, dh0, reverse.  row_off: dgi is PACKED (see gru_dirs_fwd)."""
     lib = _lib_()
     arr = (_lib.GruDirBwd * len(dirs))()
+    ro = _row_off_array(row_off, T)
     for k, d in enumerate(dirs):
+        if ro is not None:
+            arr[k].dgi_row_off = ro
         for name in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0", "w_ih", "dx",
                      "x", "dw_hh", "db_hh", "dw_ih", "db_ih", "wslab"):        # the last six: optional fused weight gradients
             setattr(arr[k], name, _p(d.get(name)))

@@ -325,11 +325,11 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
 class GraphedText2EmbeddingStep:
     """train_iter_text2embedding as ONE hipGraph: zero_grad -> forward -> CE -> backward -> clip+Adam are captured once and
     replayed (the operator chain of Part d is ~100 small launches per step: host-bound when launched one by one at the
-    reference's B=128).  Inputs are static device tensors: overwrite `in_text` / `codes` / `lengths` in place between
-    replays.  Dropout masks come from the Philox kernels (device-side counters), so every replay draws fresh masks.
+    reference's B=128).  Inputs are static device tensors: overwrite `in_text` / `codes` in place between replays (and
+    `lengths` with static_lengths=False).  Dropout masks come from the Philox kernels (device-side counters), so every replay draws fresh masks.
     `loss` is a device scalar updated by each replay (read it when needed: no per-step host sync)."""
 
-    def __init__(self, args, net, optim, in_text, in_lengths, codes, warmup: int = 3):
+    def __init__(self, args, net, optim, in_text, in_lengths, codes, warmup: int = 3, static_lengths: bool = True):
         from ..flat import FlatClipAdam
         from ..functional import cross_entropy
         if not isinstance(optim, FlatClipAdam):
@@ -337,7 +337,10 @@ class GraphedText2EmbeddingStep:
         dev = in_text.device
         self.in_text = in_text
         self.codes = codes
-        self.lengths = in_lengths.to(device=dev, dtype=torch.int32).contiguous()   # EncoderRNN takes a device tensor as is
+        # static_lengths (round 5): the sentence lengths are part of the captured graph -- the encoder then runs its layer-0 products
+        # on the packed positions only (EncoderRNN.forward), whose row counts are baked into the launches: replay with OTHER
+        # lengths needs a new object.  False: lengths stay a device tensor that may be overwritten between replays (padded grid).
+        self.lengths = (in_lengths.cpu() if static_lengths else in_lengths.to(device=dev, dtype=torch.int32).contiguous())
         self.net, self.optim = net, optim
 
         def step():

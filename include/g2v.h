@@ -241,7 +241,14 @@ typedef struct {          /* one direction of one layer, forward */
   const float* w_ih;      /* (3H,in_dim)                                    */
   const float* b_ih;      /* (3H)                                           */
   int in_dim;
+  /* Packed input projections (round 5; NULL = the (T,B,3H) layout): a HOST array of T row offsets.  gi then holds only the
+   * positions inside their sequences, step-major: row (t,b) at gi + (gi_row_off[t] + b) * 3H for b < n_t = #{lengths > t}
+   * (lengths sorted descending, as pack_padded_sequence(enforce_sorted) requires; gi_row_off[t] = n_0 + ... + n_{t-1}) -- the
+   * dense product that makes gi runs over sum(lengths) rows instead of T x B.  T <= 64, the generic kernels with H % 4 == 0
+   * (g2v_gru_seq_packed_ok); every direction of the call must carry the same offsets.  hs / gates keep the (T,B,.) layout. */
+  const int32_t* gi_row_off;
 } g2v_gru_dir;
+int g2v_gru_seq_packed_ok(int T, int B, int H);
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
 size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */
@@ -276,6 +283,9 @@ typedef struct {
    * quantised value, hn_coef = 2 beta / (N E).  Same arithmetic as g2v_vq_bwd; saves its launch on the critical chain. */
   const float* hn_z; const float* hn_q; const float* hn_gloss;
   float hn_coef;
+  /* Packed dgi (NULL = (T,B,3H)): as g2v_gru_dir.gi_row_off -- dgi row (t,b) at dgi + (dgi_row_off[t] + b) * 3H, only positions
+   * inside their sequences are written (sum(lengths) rows); dgh keeps the (T,B,3H) layout with zero rows at padded positions. */
+  const int32_t* dgi_row_off;
 } g2v_gru_dir_bwd;
 size_t g2v_gru_seq_bwd_wslab_bytes(int B, int H);
 size_t g2v_gru_seq_bwd_workspace(int ndir, int H);   /* room for W_hh^T (fragment order) */

@@ -306,6 +306,61 @@ def test_fused_step_kernels_match_per_operator_path(att, p, B, n_pre, H, K, monk
     assert checked >= 20
 
 
+@pytest.mark.parametrize("att,p,B,H", [("False", 0.2, 24, 48), ("True", 0.2, 130, 48), ("False", 0.0, 2100, 200), ("True", 0.1, 3100, 200),
+                                       ("False", 0.0, 7, 200)])
+def test_packed_encoder_inputs_equal_the_padded_grid(att, p, B, H):
+    """EncoderRNN with host lengths (round 5): layer 0's embeddings / input projections / their gradients on the sum(lengths)
+    positions inside the sentences (g2v_gru_dir.gi_row_off: the recurrent kernels address the packed arrays through per-step
+    row offsets -- per-step kernels at small batch, the sequence kernels above) against the padded (Tw,B) grid: outputs and
+    hidden states bitwise (a position's arithmetic does not change), gradients to summation order (the padded grid adds exact
+    zeros in other places of the row-split sums)."""
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    L, K, NW, EMB, Tw, S = 2, 64, 50, 30, 13, 6
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    g = torch.Generator().manual_seed(8)
+    nets = []
+    for packed in (True, False):
+        torch.manual_seed(5)
+        net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(0).randn(NW, EMB).astype(np.float32), None).to(DEV)
+        net.train(True)
+        net.encoder.packed_inputs = packed
+        nets.append(net)
+    nets[1].load_state_dict(nets[0].state_dict())
+    lengths = torch.sort(torch.randint(2, Tw + 1, (B,), generator=g), descending=True).values
+    lengths[0] = Tw
+    ids = torch.zeros(B, Tw, dtype=torch.int64)
+    for b in range(B):
+        ids[b, : lengths[b]] = torch.randint(1, NW, (int(lengths[b]),), generator=g)
+    ids = ids.to(DEV)
+    codes = torch.randint(0, K, (B, S), generator=g).to(DEV)
+    masks = ((torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8).to(DEV),
+             (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None,
+             (torch.rand(Tw, B, 2 * H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None)
+    w = torch.randn(B, S, K, generator=g).to(DEV)
+    outs = []
+    for net in nets:
+        net.set_dropout_masks(*masks)
+        out, _ = net(ids, lengths, None, codes, None, None)
+        (out * w).sum().backward()
+        outs.append(out.detach())
+    assert nets[0].encoder._len_cache["packed"] is not None and nets[1].encoder._len_cache.get("packed") is None
+    assert torch.equal(outs[0], outs[1])
+    checked = 0
+    for (n, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None or float(pa.grad.abs().max()) == 0.0, n
+            continue
+        assert pa.grad is not None, n
+        if n.startswith("decoder."):
+            assert torch.equal(pa.grad, pb.grad), n         # behind the encoder everything is the same launch sequence
+        else:
+            assert relerr(pa.grad, pb.grad.cpu()) < 3e-6, (n, relerr(pa.grad, pb.grad.cpu()))
+        checked += 1
+    assert checked >= 20
+
+
 @pytest.mark.parametrize("att,B", [("False", 4096), ("True", 1024)])
 def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
     """Part d END TO END against the CPU oracle (oracle/g2v_oracle.py: t2e_train_step, pinned to the reference's golden vectors)
