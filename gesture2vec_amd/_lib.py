@@ -133,6 +133,7 @@ _SIGS = {
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
     "g2v_dec_rollout_tiles_per_workgroup": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
+    "g2v_dec_rollout_fault_flag": (c_int, [c_fp, c_int, c_fp]),
     "g2v_dec_rollout_fuses_loss": (c_int, [c_int, c_int, c_int, c_int]),
     "g2v_custom_loss_chase": (c_int, [c_fp, C.POINTER(DecSaved), c_fp, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_fwd_workspace": (c_sz, [c_int, c_int]),

@@ -1143,6 +1143,25 @@ extern "C" int g2v_dec_rollout_persist_fault(int clear) {
   return (int)v;
 }
 
+// Data parallelism: the latch is per process, but a rank whose rollout faulted has already fed garbage gradients into the
+// all-reduce -- every rank must skip the step.  to_flag: flag[0] = 1 if this rank's latch is set else 0 (in front of the SUM
+// all-reduce, in a slot of the communication buffer); from_flag: a non-zero sum latches THIS rank too (value 3 where it was clear),
+// so its commit kernels -- EMA update, BatchNorm statistics, clip + Adam -- leave the state alone like the faulting rank's.
+__global__ void fault_flag_kernel(float* __restrict__ flag, int from_flag) {
+  if (!from_flag) flag[0] = __hip_atomic_load(&g2v_persist_fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u ? 1.0f : 0.0f;
+  else if (flag[0] != 0.0f) {
+    unsigned expected = 0u;
+    (void)__hip_atomic_compare_exchange_strong(&g2v_persist_fault, &expected, 3u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+extern "C" int g2v_dec_rollout_fault_flag(float* flag, int from_flag, g2v_stream_t stream) {
+  G2V_REQUIRE(flag, "null pointer");
+  hipLaunchKernelGGL(fault_flag_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, from_flag);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 const unsigned* g2v_internal_persist_fault_ptr() {
   static const unsigned* p = [] {
     void* q = nullptr;

@@ -116,7 +116,8 @@ class VQVAEEngine:
         dev = self.device
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
         # ONE communication buffer [flat grads | cnt (K) | dw (K*E)]: a single RCCL all-reduce per step under DP
-        self.comm = torch.zeros(off + K + K * (H * L), dtype=torch.float32, device=dev)
+        # [grads | cnt (K) | dw (K E) | fault flag (4 floats: one used)]: the flag travels in the same all-reduce (round 5)
+        self.comm = torch.zeros(off + K + K * (H * L) + 4, dtype=torch.float32, device=dev)
         self.gflat = self.comm[:off]
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
@@ -161,7 +162,8 @@ class VQVAEEngine:
                                           self.lib.g2v_vq_assign_packed_ok(1, self.E, K)) else None)
         self.bn_rm = torch.zeros(H, device=dev)
         self.bn_rv = torch.ones(H, device=dev)
-        self.vq_stats = self.comm[self.n_flat:]
+        self.vq_stats = self.comm[self.n_flat:self.n_flat + K + K * self.E]
+        self.fault_flag = self.comm[self.n_flat + K + K * self.E:]
         self.vq_scalars = torch.zeros(2, device=dev)          # loss_vq, perplexity
         self.loss_terms = torch.zeros(5, device=dev)          # custom_loss total, l1, cont, var, mse
         self.g_loss_vq = torch.full((1,), 1.0 / 400.0, device=dev)
@@ -214,6 +216,7 @@ class VQVAEEngine:
         # before a fault of this very step could be known, so "the step was not applied" did not hold for them.
         self._defer_commit = False          # set for the duration of _train_step_local
         self._commit_pending = None         # (B, ema: bool) between forward() and _commit_state()
+        self._commit_in_apply = False
 
     # ------------------------------------------------------------------ parallel branches
     @contextlib.contextmanager
@@ -900,7 +903,7 @@ class VQVAEEngine:
                                                   self._stream()))
         return wgrad, wgrad4
 
-    def _commit_state(self):
+    def _commit_state(self, n_global: Optional[int] = None):
         """The fused train step's deferred commits (see __init__): EMA codebook update + loss / perplexity scalars (single GPU;
         under data parallelism train_step_apply runs it behind the all-reduce) and BatchNorm's running statistics from the
         rollout's saved batch statistics.  Both kernels are gated on the persistent rollouts' fault latch on the device.  Launched
@@ -911,7 +914,7 @@ class VQVAEEngine:
         self._commit_pending = None
         b = self.buffers(B)
         if ema:
-            self.vq_finish(B, True)
+            self.vq_finish(B, True, n_global=n_global)
         check(self.lib.g2v_bn_running_update(_p(b["bn_stats"]), _p(self.bn_rm), _p(self.bn_rv), self.T - 1, self.H, B, self._stream()))
 
     def backward_decoder(self, B: int, wgrad_branch: bool = False, wgrad_late: Optional[bool] = None):
@@ -953,7 +956,8 @@ class VQVAEEngine:
             for name in self.frozen:
                 g = self.view(name, True)
                 check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
-            self._commit_state()            # behind the backward rollout: the fault latch of this step is final
+            if not self._commit_in_apply:
+                self._commit_state()        # behind the backward rollout: the fault latch of this step is final
         if wgrad_branch:
             self._fork(2, products, late=wgrad_late)      # (wgrad_late: launched by the caller's _release())
         else:
@@ -1089,7 +1093,8 @@ class VQVAEEngine:
             self._side_work = None
             self._fused_in_drop = False
             self._defer_commit = False
-            self._commit_pending = None
+            if not dp:
+                self._commit_pending = None
 
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         self._fused_in_drop = bool(draw_masks and self.p > 0)      # the encoder's input mask is drawn inside its dropout kernel
@@ -1116,17 +1121,29 @@ class VQVAEEngine:
         g_vq = self.g_loss_vq if epoch > 0 else torch.zeros_like(self.g_loss_vq)
         self._g_vq_host, self._g_vq_dev = (1.0 / 400.0 if epoch > 0 else 0.0), g_vq       # (:707, 738: loss + loss_vq / 400 from epoch 1)
         self._defer_commit = True
-        self._commit_pending = (B, (not dp) and self.quantizer == "ema")
+        self._commit_pending = (B, self.quantizer == "ema")
+        self._commit_in_apply = dp          # data parallel: every commit behind the all-reduce (global statistics, global fault flag)
         self.forward(x, target, True, ema_update=False, derived_ready=True, loss_w=(w_l1, w_cont, w_var),
                      join_stats=False)
         self.loss(B, target, w_l1, w_cont, w_var, True)
         self.backward(x, B, g_vq)
-        self._commit_state()                   # (a no-op when backward_decoder's branch has run it)
+        if dp:
+            # this rank's latch into the communication buffer's flag slot: a rank whose rollout faulted has fed garbage into the
+            # SUM, so all ranks must skip the step (train_step_apply turns a non-zero reduced flag into every rank's latch)
+            check(self.lib.g2v_dec_rollout_fault_flag(_p(self.fault_flag), 0, self._stream()))
+        else:
+            self._commit_state()               # (a no-op when backward_decoder's branch has run it)
         self._join(1)                          # the statistics / codebook-update branch (forward(join_stats=False); a no-op behind the chaser's join)
 
     def train_step_apply(self, B: int, *, lr: float, world: int = 1, dp: bool = False, betas=(0.5, 0.999),
                          eps: float = 1e-8, max_norm: float = 5.0):
         """(after the all-reduce) EMA codebook update from the GLOBAL statistics, then clip + Adam on the averaged grads."""
-        if dp and self.quantizer == "ema":
-            self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
+        if dp:
+            check(self.lib.g2v_dec_rollout_fault_flag(_p(self.fault_flag), 1, self._stream()))
+            pend, self._commit_pending = self._commit_pending, None
+            if pend is not None:            # (train_step_local left them: global statistics, global fault flag)
+                self._commit_pending = pend
+                self._commit_state(n_global=world * ((2 * B * self.H) // self.E))
+            elif self.quantizer == "ema":   # (a caller that ran the local half some other way)
+                self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0, readback=True)

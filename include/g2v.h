@@ -396,6 +396,10 @@ int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H);
  * g2v_iteration_readback); on 1 discard the step, g2v_dec_rollout_set_persistent(0), and run the step again on the per-step
  * kernels.  clear < 0 is the test hook of that path: it LATCHES the value -clear, as a bounded wait running out would. */
 int g2v_dec_rollout_persist_fault(int clear);
+/* Data parallelism (one process per GPU): the latch is per process.  from_flag == 0: flag[0] = 1.0f if this process' latch is set,
+ * else 0.0f -- in front of the SUM all-reduce, with `flag` a slot of the communication buffer; from_flag != 0: a non-zero
+ * (reduced) flag latches this process too (value 3), so that EVERY rank's commit kernels skip the step a faulting rank poisoned. */
+int g2v_dec_rollout_fault_flag(float* flag, int from_flag, g2v_stream_t stream);
 /* 1 where the rollout pair + chaser can carry custom_loss (the loss_* fields of g2v_dec_saved): wherever the persistent path
  * applies with ONE row tile per workgroup (H == 64, D == 135, B % 16 == 0, B / 16 <= CU count, persistent setting 1), 2 <= T <= 256.  Elsewhere leave the loss_*
  * fields NULL and call g2v_custom_loss_fwd_bwd between the two rollouts (setting them anyway is refused with

@@ -222,3 +222,46 @@ def test_fault_latched_in_the_middle_of_a_step_leaves_the_whole_model_state_unto
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)
+
+
+def test_a_faulting_rank_makes_every_rank_skip_the_step_under_data_parallelism():
+    """Round 5 (advisor finding): the fault latch is per process, but a rank whose rollout faulted has already fed garbage gradients
+    into the all-reduce.  Each rank writes its latch into the flag slot of the communication buffer in front of the SUM
+    (g2v_dec_rollout_fault_flag), and a non-zero reduced flag latches every rank behind it: EMA update, BatchNorm statistics and
+    clip + Adam -- all behind the all-reduce under data parallelism -- leave the state alone everywhere.  One process here:
+    (i) a latched rank reports 1 in its slot, (ii) a rank with a clear latch that receives a non-zero flag skips the step."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    D, H, K, T, B = 135, 64, 512, 34, 256
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    eng = _engine(sd, D, H, K, T, 0.0)
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(11)).to(DEV)
+    kw = dict(w_l1=5.0, w_cont=0.1, w_var=0.5)
+    names = ("flat", "m", "v", "step_counter", "codebook", "ema_w", "ema_cs", "bn_rm", "bn_rv")
+    try:
+        eng.train_step_local(x, x, dp=True, **kw)
+        eng.train_step_apply(B, lr=5e-4, world=1, dp=True)            # an ordinary data-parallel step (a world of one)
+        torch.cuda.synchronize()
+        assert float(eng.fault_flag[0]) == 0.0
+        snap = {n: getattr(eng, n).clone() for n in names}
+        # (i) this rank faults: its slot says so
+        assert lib.g2v_dec_rollout_persist_fault(-1) == 1
+        eng.train_step_local(x, x, dp=True, **kw)
+        torch.cuda.synchronize()
+        assert float(eng.fault_flag[0]) == 1.0
+        assert lib.g2v_dec_rollout_persist_fault(1) == 1              # read + clear: now THIS rank is healthy ...
+        eng.fault_flag[0] = 2.0                                       # ... and the reduced flag says two OTHER ranks faulted
+        eng.train_step_apply(B, lr=5e-4, world=1, dp=True)
+        torch.cuda.synchronize()
+        assert lib.g2v_dec_rollout_persist_fault(0) == 3              # (ii) latched by the flag
+        for n in names:
+            assert torch.equal(snap[n], getattr(eng, n)), f"{n} changed in a step another rank poisoned"
+        assert lib.g2v_dec_rollout_persist_fault(1) == 3
+        eng.train_step_local(x, x, dp=True, **kw)
+        eng.train_step_apply(B, lr=5e-4, world=1, dp=True)
+        torch.cuda.synchronize()
+        for n in names:
+            assert not torch.equal(snap[n], getattr(eng, n)), f"{n} did not change in a valid step"
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_dec_rollout_set_persistent(1)
