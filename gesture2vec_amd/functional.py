@@ -187,13 +187,17 @@ class GRUBiDirFn(torch.autograd.Function):
         out = []
         dirs = []
         for gi, w, b, rev in ((gi_f, w_f, b_f, False), (gi_b, w_b, b_b, True)):
-            hs = torch.empty((T, B, H), dtype=torch.float32, device=dev)
+            # one extra zero step in front of (behind, for the reverse direction) the states: the BPTT's weight-gradient product
+            # reads "the state before step t" as a VIEW of the same buffer (it was two 65 MB cat copies per call at B = 4096)
+            full = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
+            full[T if rev else 0].zero_()
+            hs = full[:T] if rev else full[1:]
             h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
             gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
-            dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev))
+            dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev, full=full))
             out += [hs, h_n]
         ops.gru_dirs_fwd(dirs, T, B, H, lengths=lengths, hs_ld=H, row_off=row_off)
-        ctx.save_for_backward(dirs[0]["hs"], dirs[0]["gates"], w_f, dirs[1]["hs"], dirs[1]["gates"], w_b, lengths)
+        ctx.save_for_backward(dirs[0]["full"], dirs[0]["gates"], w_f, dirs[1]["full"], dirs[1]["gates"], w_b, lengths)
         ctx.dims = (T, B, H)
         ctx.packed = (row_off, gi_f.shape[0]) if packed is not None else None
         ctx.set_materialize_grads(False)
@@ -201,8 +205,10 @@ class GRUBiDirFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_hs_f, g_hn_f, g_hs_b, g_hn_b):
-        hs_f, gates_f, w_f, hs_b, gates_b, w_b, lengths = ctx.saved_tensors
+        full_f, gates_f, w_f, full_b, gates_b, w_b, lengths = ctx.saved_tensors
         T, B, H = ctx.dims
+        hs_f, hprev_f = full_f[1:], full_f[:T]                           # (forward() laid the zero step beside the states)
+        hs_b, hprev_b = full_b[:T], full_b[1:]
         if all(g is None for g in (g_hs_f, g_hn_f, g_hs_b, g_hn_b)):
             return (None,) * 8
         row_off, n_packed = ctx.packed if ctx.packed is not None else (None, 0)
@@ -218,9 +224,6 @@ class GRUBiDirFn(torch.autograd.Function):
             dirs.append(dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w, dgi=dgi, dgh=dgh, dh0=None, reverse=rev))
             outs.append((dgi, dgh))
         ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H, row_off=row_off)
-        zero = torch.zeros((1, B, H), dtype=torch.float32, device=dev)
-        hprev_f = torch.cat([zero, hs_f[:-1]], 0).contiguous()          # data movement only
-        hprev_b = torch.cat([hs_b[1:], zero], 0).contiguous()
         items = []
         for (dgi, dgh), hprev in zip(outs, (hprev_f, hprev_b)):
             items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
@@ -231,9 +234,18 @@ class GRUBiDirFn(torch.autograd.Function):
 
 class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, targets):
+    def forward(ctx, logits, targets, skip_rows=0):
+        """Mean cross entropy over rows [skip_rows:] of logits (M,K) / targets (M); the gradient comes back for all M rows
+        (zero on the skipped ones).  skip_rows lets the caller hand over a whole step-major (S*B, K) buffer whose first step is
+        not part of the loss WITHOUT slicing it (a slice's backward is a zero fill + a copy of the full array)."""
         lg = logits.contiguous()
-        loss, dl = ops.cross_entropy_fwd_bwd(lg, targets.contiguous().view(-1), want_grad=True)
+        tg = targets.contiguous().view(-1)
+        if skip_rows:
+            dl = torch.empty_like(lg)
+            dl[:skip_rows].zero_()
+            loss, _ = ops.cross_entropy_fwd_bwd(lg[skip_rows:], tg[skip_rows:], want_grad=True, dl_out=dl[skip_rows:])
+        else:
+            loss, dl = ops.cross_entropy_fwd_bwd(lg, tg, want_grad=True)
         ctx.save_for_backward(dl)
         ctx.shape = logits.shape
         return loss[0].clone()
@@ -241,11 +253,11 @@ class CrossEntropyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return ops.scale(dl, g.reshape(1).contiguous()).view(ctx.shape), None
+        return ops.scale(dl, g.reshape(1).contiguous()).view(ctx.shape), None, None
 
 
-def cross_entropy(logits, targets):
-    return CrossEntropyFn.apply(logits, targets)
+def cross_entropy(logits, targets, skip_rows=0):
+    return CrossEntropyFn.apply(logits, targets, skip_rows)
 
 
 class AttnFn(torch.autograd.Function):

@@ -49,7 +49,7 @@ class EncoderRNN(nn.Module):
         self._len_cache = None
 
     def forward(self, input_seqs: torch.Tensor, input_lengths: torch.Tensor, hidden=None, n_layers_needed: Optional[int] = None,
-                keep_inter: Optional[torch.Tensor] = None):
+                keep_inter: Optional[torch.Tensor] = None, want_outputs: bool = True):
         """(Tw,B) ids + lengths (sorted descending) -> outputs (Tw,B,H) [sum of the LAST evaluated layer's directions],
         hidden (2*layers_evaluated, B, H) ordered l0f,l0b,l1f,l1b.  `n_layers_needed` lets the caller skip layers whose
         result it never reads (the attention-free decoder only needs layer 0).  `keep_inter` (Tw,B,2H) uint8 is the
@@ -115,7 +115,8 @@ class EncoderRNN(nn.Module):
                 layer_in = cat
                 if self.training and self.dropout > 0 and keep_inter is not None:
                     keep, scale = keep_inter.contiguous().view(Tw * B, 2 * H), 1.0 / (1.0 - self.dropout)
-        outputs = Fn.SumHalvesFn.apply(out_f, out_b)                              # :133-135
+        # :133-135 (want_outputs=False: a caller that reads the final states only -- the sum is a 200 MB pass at B = 4096)
+        outputs = Fn.SumHalvesFn.apply(out_f, out_b) if want_outputs else None
         return outputs, torch.stack(hiddens)
 
 
@@ -255,7 +256,7 @@ class text2embedding_model(nn.Module):
             enc_proj = self.decoder.decoder.attn.project_encoder(enc_out)
         else:
             # the attention-free decoder reads only encoder_hidden[:L] = the layer-0 final states (:667-669)
-            _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1)
+            _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1, want_outputs=False)
             enc_out = enc_proj = None
         hidden = enc_hidden[:L]
         if training and vid_indices is None and self.fused_rollout and S_model > 1:
@@ -263,11 +264,14 @@ class text2embedding_model(nn.Module):
             bn = dec.pre_linear[1]
             spec = RolloutSpec(cod, S_model - 1, self.n_pre_poses, L, att, self.dropout_prob, mask_emb, mask_l0,
                                bn.running_mean, bn.running_var)
-            logits, attw = CodeDecoderRollout.apply(hidden, enc_out, spec, *decoder_params(dec))
+            full, attw = CodeDecoderRollout.apply(hidden, enc_out, spec, *decoder_params(dec))   # (S,B,K), slot 0 = one-hot :676-677
             bn.num_batches_tracked += S_model - 1
-            first = F.one_hot(cod[0], K).to(torch.float32).unsqueeze(0)              # :676-677
             attentions_list = [attw[t].unsqueeze(1) for t in range(S_model - 1)] if att else []
-            return torch.cat([first, logits], 0).transpose(0, 1), attentions_list
+            outputs = full.transpose(0, 1)                                            # (B,S,K), a view
+            # the step-major array behind the view: train_iter_text2embedding takes its loss on it directly (the reference's
+            # outputs[:, 1:, :].reshape(-1, K) on the view is a 50 MB strided copy each way at B = 4096)
+            outputs._g2v_step_major = full
+            return outputs, attentions_list
         outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
         dec_in = cod[0]
         attentions_list = []

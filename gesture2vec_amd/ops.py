@@ -593,12 +593,14 @@ def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True, out=None)
     return dx, dw, db
 
 
-def cross_entropy_fwd_bwd(logits, targets, want_grad=True, ld=None):
+def cross_entropy_fwd_bwd(logits, targets, want_grad=True, ld=None, dl_out=None):
     M, K = logits.shape
     dev = logits.device
     loss = torch.empty((1,), dtype=torch.float32, device=dev)
     row = torch.empty((M,), dtype=torch.float32, device=dev)
-    dl = torch.empty((M, K), dtype=torch.float32, device=dev) if want_grad else None
+    dl = (dl_out if dl_out is not None else torch.empty((M, K), dtype=torch.float32, device=dev)) if want_grad else None
+    if dl is not None and (tuple(dl.shape) != (M, K) or not dl.is_contiguous()):
+        raise ValueError("cross_entropy: dl_out must be a contiguous (M, K) array")
     check(_lib_().g2v_cross_entropy_fwd_bwd(_p(logits), ld if ld is not None else K, _p(_chk(targets, torch.int64)), _p(loss),
                                             _p(row), _p(dl), K, M, K, 1.0, _stream()), "cross_entropy")
     return loss, dl

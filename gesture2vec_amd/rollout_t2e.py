@@ -96,7 +96,9 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     Tw = enc_out.shape[0] if att else 0
     sv = dict(ids=torch.empty((S1, B), dtype=torch.int64, device=dev), ec=f32(S1, B, Hin), u=f32(S1, B, H), a=f32(S1, B, H),
               bn_stats=f32(S1, 2, H), h0=f32(S1 + 1, B, H), h1=f32(S1 + 1, B, H), x1=f32(S1, B, H) if drop else None,
-              gates0=f32(S1, B, 4 * H), gates1=f32(S1, B, 4 * H), logits=f32(S1, B, K), bn_partial=f32(2, nblk, 2, H))
+              gates0=f32(S1, B, 4 * H), gates1=f32(S1, B, 4 * H), bn_partial=f32(2, nblk, 2, H))
+    full = _outputs_buffer(spec, S1, B, K, dev)
+    sv["logits"] = full[1:]
     enc = ep = None
     if att:
         enc = enc_out.contiguous()
@@ -116,7 +118,16 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     AW = sv["attw"] if att else f32(0)
     ctx.mark_non_differentiable(AW)
     ctx.set_materialize_grads(False)
-    return sv["logits"], AW
+    return full, AW
+
+
+def _outputs_buffer(spec: RolloutSpec, S1, B, K, dev):
+    """The model's `outputs` in step-major order, (S1 + 1, B, K): slot 0 = one_hot(codes[0]) (reference :676-677), slots 1.. =
+    the decode steps' logits, written in place by the kernels (it used to be a torch.cat of the two: a 110 MB copy at B = 4096)."""
+    full = torch.empty((S1 + 1, B, K), dtype=torch.float32, device=dev)
+    full[0].zero_()
+    full[0].scatter_(1, spec.cod[0].view(B, 1), 1.0)
+    return full
 
 
 def _fused_backward(ctx, dLOG):
@@ -131,7 +142,7 @@ def _fused_backward(ctx, dLOG):
               d_w_ih1=f32(G, H), d_w_hh1=f32(G, H), d_b_ih1=f32(G), d_b_hh1=f32(G), d_w_out=f32(K, H), d_b_out=f32(K))
     if att:
         gr.update(d_w_attn=f32(H, 2 * H), d_b_attn=f32(H), d_v_attn=f32(H), d_enc=f32(b["Tw"], B, H))
-    ops.code_rollout_bwd(dLOG.contiguous(), b["enc"], b["ep"], b["wd"], b["sv"], gr, b["mask_emb"], b["mask_l0"],
+    ops.code_rollout_bwd(dLOG, b["enc"], b["ep"], b["wd"], b["sv"], gr, b["mask_emb"], b["mask_l0"],
                          spec.dropout_p if b["drop"] else 0.0, S1, B, H, K, b["Tw"])
     grads = [gr["d_emb"], gr["d_w_pre"], gr["d_b_pre"], gr["d_bn_w"], gr["d_bn_b"],
              gr["d_w_ih0"], gr["d_w_hh0"], gr["d_b_ih0"], gr["d_b_hh0"], gr["d_w_ih1"], gr["d_w_hh1"], gr["d_b_ih1"], gr["d_b_hh1"],
@@ -142,8 +153,8 @@ def _fused_backward(ctx, dLOG):
 
 
 class CodeDecoderRollout(torch.autograd.Function):
-    """(hidden0 (L,B,H), encoder_outputs (Tw,B,H) or None, spec, *decoder_params) -> logits (S-1,B,K), attention weights
-    (S-1,B,Tw) (empty without attention; not differentiable)."""
+    """(hidden0 (L,B,H), encoder_outputs (Tw,B,H) or None, spec, *decoder_params) -> outputs (S,B,K) [slot 0 = one_hot(codes[0]),
+    slots 1.. = the S-1 decode steps' logits], attention weights (S-1,B,Tw) (empty without attention; not differentiable)."""
 
     @staticmethod
     def forward(ctx, hidden0, enc_out, spec: RolloutSpec, *params):
@@ -174,7 +185,8 @@ class CodeDecoderRollout(torch.autograd.Function):
         GATES = [f32(S1, B, 4 * H) for _ in range(L)]
         GI, HN = f32(B, 3 * H), f32(B, H)
         cell = ops.gru_cell_ok(H, H, B)
-        LOG = f32(S1, B, K)
+        LOGF = _outputs_buffer(spec, S1, B, K, dev)
+        LOG = LOGF[1:]
         for l in range(L):
             Hs[l][0].copy_(hidden0[l])
         if att:
@@ -218,14 +230,15 @@ class CodeDecoderRollout(torch.autograd.Function):
             ctx.bufs.update(enc=enc, W_h=W_h, W_e=W_e, attn_v=attn_v, EP=EP, HP=HP, AW=AW)
         ctx.mark_non_differentiable(AW)
         ctx.set_materialize_grads(False)
-        return LOG, AW
+        return LOGF, AW
 
     @staticmethod
-    def backward(ctx, dLOG, _dAW):
+    def backward(ctx, dFULL, _dAW):
         S1, B, H, K, Hin, L = ctx.dims
         n_in = 3 + 5 + 4 * L + 2 + (3 if ctx.spec.att else 0)
-        if dLOG is None:
+        if dFULL is None:
             return (None,) * n_in
+        dLOG = dFULL.contiguous()[1:]                                    # slot 0 is a constant
         if ctx.fused:
             return _fused_backward(ctx, dLOG)
         b, att = ctx.bufs, ctx.spec.att

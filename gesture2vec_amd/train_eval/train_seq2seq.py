@@ -301,6 +301,19 @@ def train_iter_DAE(args, epoch: int, noisy_poses: torch.Tensor, target_poses: to
     return {"loss": loss.item()}
 
 
+def _code_loss(outputs, codes):
+    """CrossEntropyLoss(outputs[:, 1:, :].reshape(-1, K), codes[:, 1:].reshape(-1)) (reference :506-513).  The model's outputs
+    (B,S,K) are a transposed view of a step-major (S,B,K) array; when the model says so the loss runs on that array in place
+    (same set of (sample, step) rows, same mean) instead of on a strided copy of it."""
+    from ..functional import cross_entropy
+    K = outputs.shape[2]
+    full = getattr(outputs, "_g2v_step_major", None)
+    if full is not None and full.shape[0] == outputs.shape[1] and full.shape[1] == outputs.shape[0]:
+        S, B = full.shape[0], full.shape[1]
+        return cross_entropy(full.view(S * B, K), codes.t().reshape(-1).long(), skip_rows=B)
+    return cross_entropy(outputs[:, 1:, :].reshape(-1, K), codes[:, 1:].reshape(-1).long())
+
+
 def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, target_poses, cluster_targets,
                               GPT3_Embedding, net: torch.nn.Module, optim):
     """One training iteration of Part d (reference :462-538), discrete codes: CrossEntropyLoss over decode steps 1..S-1,
@@ -313,10 +326,7 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
     optim.zero_grad()
     outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
-    K = outputs.shape[2]
-    logits = outputs[:, 1:, :].reshape(-1, K)
-    targets = cluster_targets[:, 1:].reshape(-1)
-    loss = cross_entropy(logits, targets.long())
+    loss = _code_loss(outputs, cluster_targets)
     loss.backward()
     optim.step()
     return {"loss": loss.item()}
@@ -346,8 +356,7 @@ class GraphedText2EmbeddingStep:
         def step():
             optim.zero_grad()
             outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
-            K = outputs.shape[2]
-            loss = cross_entropy(outputs[:, 1:, :].reshape(-1, K), self.codes[:, 1:].reshape(-1).long())
+            loss = _code_loss(outputs, self.codes)
             loss.backward()
             optim.step()
             return loss

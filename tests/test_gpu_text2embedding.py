@@ -361,6 +361,53 @@ def test_packed_encoder_inputs_equal_the_padded_grid(att, p, B, H):
     assert checked >= 20
 
 
+@pytest.mark.parametrize("att,B,force_fused", [("False", 40, False), ("True", 24, True), ("False", 1040, True)])
+def test_loss_on_the_step_major_outputs_equals_the_reference_form(att, B, force_fused, monkeypatch):
+    """train_iter_text2embedding takes CrossEntropyLoss on the step-major (S,B,K) array behind the model's outputs view
+    (train_seq2seq._code_loss: no strided copy of the logits, no zero-filled slice gradient) -- against the reference's literal
+    form outputs[:, 1:, :].reshape(-1, K) on the view: same loss (the mean runs over the same rows in another order), same
+    gradients; slot 0 of the outputs is one_hot(codes[:, 0]) (reference :676-677)."""
+    from gesture2vec_amd import rollout_t2e
+    from gesture2vec_amd.functional import cross_entropy
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import _code_loss
+    monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", 1 if force_fused else 1 << 30)
+    H, L, K, NW, EMB, Tw, S, p = 48, 2, 64, 50, 30, 9, 6, 0.1
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    g = torch.Generator().manual_seed(21)
+    torch.manual_seed(6)
+    net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(1).randn(NW, EMB).astype(np.float32), None).to(DEV)
+    net.train(True)
+    lengths = torch.sort(torch.randint(2, Tw + 1, (B,), generator=g), descending=True).values
+    lengths[0] = Tw
+    ids = torch.randint(1, NW, (B, Tw), generator=g).to(DEV)
+    codes = torch.randint(0, K, (B, S), generator=g).to(DEV)
+    masks = ((torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8).to(DEV),
+             (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV),
+             (torch.rand(Tw, B, 2 * H, generator=g) < 1 - p).to(torch.uint8).to(DEV))
+    res = []
+    for form in ("step_major", "reference"):
+        net.zero_grad(set_to_none=True)
+        net.set_dropout_masks(*masks)
+        out, _ = net(ids, lengths, None, codes, None, None)
+        assert out.shape == (B, S, K) and getattr(out, "_g2v_step_major").shape == (S, B, K)
+        assert torch.equal(out[:, 0], torch.nn.functional.one_hot(codes[:, 0], K).float())
+        if form == "step_major":
+            loss = _code_loss(out, codes)
+        else:
+            loss = cross_entropy(out[:, 1:, :].reshape(-1, K), codes[:, 1:].reshape(-1).long())
+        loss.backward()
+        res.append((float(loss), {n: q.grad.clone() for n, q in net.named_parameters() if q.grad is not None}))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0]), (res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) >= 20
+    for n, ga in res[0][1].items():
+        if n == "decoder.decoder.pre_linear.0.bias":          # feeds BatchNorm: rounding noise around zero on both sides
+            continue
+        assert relerr(ga, res[1][1][n].cpu()) < 1e-5, (n, relerr(ga, res[1][1][n].cpu()))
+
+
 @pytest.mark.parametrize("att,B", [("False", 4096), ("True", 1024)])
 def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
     """Part d END TO END against the CPU oracle (oracle/g2v_oracle.py: t2e_train_step, pinned to the reference's golden vectors)
