@@ -131,6 +131,7 @@ _SIGS = {
                                              c_f, c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_blocks": (c_int, [c_int]),
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
+    "g2v_gru_seq_set_cluster": (c_int, [c_int]),
     "g2v_dec_rollout_tiles_per_workgroup": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
     "g2v_dec_rollout_fault_flag": (c_int, [c_fp, c_int, c_fp]),

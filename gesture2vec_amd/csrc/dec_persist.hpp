@@ -153,6 +153,108 @@ __device__ __forceinline__ int px_row_on_one_xcd(const PersistX& x, int nblk, in
   return same ? 1 : 0;
 }
 
+// ---- the cluster kernels' exchange (gru.hip: gru_cluster_*_kernel, dec_rollout.hip: dec_cluster_fwd_kernel) ----------------------
+// A "row record" holds 16 batch rows x (16 NT) columns as granules {value, tag}, TILE-MAJOR: granule ((tile 16 + row) 4 + q) 4 + e is
+// column 16 tile + 4 q + e of that row.  The producer of a tile -- lane (row i, q) of the wave that holds the 16 x 16 result as an
+// MFMA accumulator -- writes its four granules as 32 contiguous bytes, the whole tile as 2 KiB; a consumer sweeps whole tiles with
+// fully used 16-byte lanes (chunk c of a tile: row c / 8, q = (c / 2) % 4, e = 2 (c % 2)) and scatters them into the MFMA B-fragment
+// layout in LDS (xs[tile][q 16 + row], a float4 per lane = the k-step `tile` fragment).  sc1 loads are served at the fabric at
+// ~25 GB/s per CU (measured with in-kernel stamps: a 26 KiB sweep whose lanes used half of every line took 2.1 us with the data
+// already there), so the bytes a workgroup requests per step are what an exchange costs.
+__device__ __forceinline__ bool cx_give_up(unsigned& spins, unsigned* fault) {
+  ++spins;
+  if (spins > 4000000u ||
+      ((spins & 4095u) == 0 && fault && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+    if (fault) __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+  }
+  return false;
+}
+__device__ __forceinline__ unsigned cx_tile_granule(int tile, int i, int q) { return (unsigned)(((tile * 16 + i) * 4 + q) * 4); }
+// lane (i, q) publishes v[0..3] = columns 16 tile + 4 q .. + 3 of row i
+__device__ __forceinline__ void cx_publish4(__amdgpu_buffer_rsrc_t rr, unsigned rec_granule0, int tile, int i, int q, const float* v,
+                                            unsigned tag) {
+  u32x4 a, b;
+  a[0] = __float_as_uint(v[0]); a[1] = tag; a[2] = __float_as_uint(v[1]); a[3] = tag;
+  b[0] = __float_as_uint(v[2]); b[1] = tag; b[2] = __float_as_uint(v[3]); b[3] = tag;
+  const unsigned off = (rec_granule0 + cx_tile_granule(tile, i, q)) * 8u;
+  px_st(rr, off, a);
+  px_st(rr, off + 16u, b);
+}
+// One wave sweeps NTL tiles t0, t0 + tstr, ... (those < nt) of a row record into xs (LDS: [tile][64] float4, fragment layout).
+// Rows >= nrows and columns >= K are never published: zeros are written for them.  First a SENTINEL poll -- lane j watches the
+// first granule pair of tile j, one 16-byte load per round -- and only then the bulk: a round of the full sweep costs 1.2-2.7 us
+// at the fabric (in-kernel stamps), so a round issued before the producers have published is that much lost.  The sentinel proves
+// only itself: every granule of the bulk is still validated (and re-read while stale).
+template <int NTL>
+__device__ __forceinline__ void cx_sweep_tiles(__amdgpu_buffer_rsrc_t rr, unsigned rec_granule0, int t0, int tstr, int nt, int nrows,
+                                               int K, unsigned tag, float4* xs, int lane, unsigned* fault,
+                                               unsigned long long* dbg = nullptr) {
+  if (dbg && lane == 0) dbg[0] = __builtin_amdgcn_s_memtime();
+  unsigned spins = 0;
+  {
+    const int tile = t0 + lane * tstr;
+    const bool watch = lane < NTL && tile < nt;      // (row 0 and the tile's first columns always exist)
+    const unsigned off = (rec_granule0 + (unsigned)((watch ? tile : 0) * 256)) * 8u;
+    for (;;) {
+      u32x4 sgl = (u32x4){0u, tag, 0u, tag};
+      if (watch) sgl = px_ld(rr, off);
+      const bool ok = sgl[1] == tag && sgl[3] == tag;
+      if (__builtin_amdgcn_ballot_w64(!ok) == 0ull) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (cx_give_up(spins, fault)) break;
+    }
+  }
+  if (dbg && lane == 0) dbg[1] = __builtin_amdgcn_s_memtime();
+  u32x4 g[NTL][2];
+  bool need[NTL][2];
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int tile = t0 + j * tstr;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int c = h * 64 + lane;                       // chunk of the tile: row c / 8, q = (c / 2) % 4, e = 2 (c % 2)
+      const int i = c >> 3, q = (c >> 1) & 3;
+      need[j][h] = tile < nt && i < nrows && 16 * tile + 4 * q < K;
+      if (need[j][h]) g[j][h] = px_ld(rr, (rec_granule0 + (unsigned)(tile * 256)) * 8u + (unsigned)c * 16u);
+      else g[j][h] = (u32x4){0u, tag, 0u, tag};
+    }
+  }
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) ok &= g[j][0][1] == tag && g[j][0][3] == tag && g[j][1][1] == tag && g[j][1][3] == tag;
+    if (dbg && lane == 0 && spins < 12) dbg[2 + spins] = __builtin_amdgcn_s_memtime();
+    if (ok) break;
+    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      const int tile = t0 + j * tstr;
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (g[j][h][1] != tag || g[j][h][3] != tag)
+          g[j][h] = px_ld(rr, (rec_granule0 + (unsigned)(tile * 256)) * 8u + (unsigned)(h * 64 + lane) * 16u);
+    }
+    if (cx_give_up(spins, fault)) break;
+  }
+  if (dbg && lane == 0) dbg[15] = spins;
+#pragma unroll
+  for (int j = 0; j < NTL; ++j) {
+    const int tile = t0 + j * tstr;
+    if (tile < nt) {      // (uniform)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = h * 64 + lane;
+        const int i = c >> 3, q = (c >> 1) & 3, e = (c & 1) * 2;
+        // (through scalars: a bit cast straight on an ext-vector element reads element 0 under ROCm 7.2's clang)
+        const unsigned lo = g[j][h][0], hi = g[j][h][2];
+        float* dst = reinterpret_cast<float*>(xs + (size_t)tile * 64 + (q * 16 + i)) + e;
+        *reinterpret_cast<float2*>(dst) = make_float2(__uint_as_float(lo), __uint_as_float(hi));      // (zeros where nothing exists)
+      }
+    }
+  }
+}
+
 // Column sums of `n` (<= 16) records of 128 granules each -> tot[128] (LDS), by all 256 threads, fixed order.
 // Thread (m = tid >> 4, c = tid & 15) owns granule pairs c, c+16, c+32, c+48 of record m and re-reads the ones whose
 // tag is stale.  red: LDS [16][128].  Ends with a barrier; tot is valid for every thread afterwards.

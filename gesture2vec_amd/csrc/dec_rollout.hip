@@ -1032,7 +1032,24 @@ static size_t pack_bwd_total(int D, int H) {
 
 // [packed forward weights | (256-byte aligned) exchange state of the persistent kernel]
 static size_t fwd_pack_bytes_aligned(int D, int H) { return (pack_fwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
-extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) { return fwd_pack_bytes_aligned(D, H) + PX_BYTES; }
+// exchange records of dec_cluster_fwd_kernel: three (16 x Hp) row records + one (2 x Hp) record of partial sums per (parity, row group)
+static size_t dec_cluster_fwd_xch_bytes(int nblk, int H) {
+  const size_t Hp = (size_t)((H + 15) & ~15);
+  return (size_t)2 * nblk * (3 * 16 + 2) * Hp * 8;
+}
+// (H <= 208 = 13 k-steps: with 16 the weight fragments + a sweep's granules no longer fit the register file -- 186 spills)
+constexpr int DCL_KS = 13;
+static size_t dec_cluster_fwd_dyn_lds() { return ((size_t)4 * DCL_KS + (size_t)4 * 4 /* DSPLIT_DT */) * 64 * sizeof(float4); }
+static bool dec_cluster_shape(int D, int H) { return !(H == 64 && D == 135) && (H & 3) == 0 && H <= 16 * DCL_KS && D <= 64 && H >= 4; }
+extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) {
+  size_t x = PX_BYTES;
+  if (dec_cluster_shape(D, H)) {      // the largest grid the cluster kernel is admitted for: one workgroup per CU
+    const int nt = (H + 15) >> 4, cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    const size_t c = dec_cluster_fwd_xch_bytes(cus / nt + 1, H);
+    if (c > x) x = c;
+  }
+  return fwd_pack_bytes_aligned(D, H) + x;
+}
 
 // ====================================================================================================================
 // Small batch, generic dims: the forward step t >= 1 as THREE launches over (16 rows x 16 hidden units) workgroups.
@@ -1346,6 +1363,500 @@ __global__ __launch_bounds__(64) void dec_out_pre_split_kernel(DecOutPreArgs a, 
     float* part = a.part + (int64_t)blockIdx.x * 2 * H;
     *reinterpret_cast<float4*>(part + f0) = make_float4(s1[0], s1[1], s1[2], s1[3]);
     *reinterpret_cast<float4*>(part + H + f0) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+  }
+}
+
+// ---- the same three stages for ALL steps t >= 1 in ONE launch (round 5): a persistent cluster of the tile workgroups -------------
+// At B = 128, H = 200 the three launches of a step take 27 us for ~5 us of arithmetic: each is a kernel boundary plus two or three
+// dependent memory round trips from cold registers, and each re-requests its weight rows.  Here the (hidden-unit tile x row group)
+// workgroups stay resident for the whole rollout -- four waves, one per (cell, side): W_ih0 / W_hh0 / W_ih1 / W_hh1 rows of the tile
+// in registers, plus one D tile of W_out each -- and what the kernel boundaries did is an exchange of 8-byte self-validating
+// granules {value, tag = step} through memory (write-through stores, sc1 loads; gru.hip's cluster kernels and dec_persist.hpp have
+// the protocol and its measurements):
+//   u_t tiles + the BatchNorm partial sums of every row group  (out/pre stage of step t-1  ->  cell 0 of step t)
+//   h0_t tiles of the row group                                (cell 0 -> cell 1; kept in LDS for cell 0's hidden side at t+1)
+//   h1_t tiles of the row group                                (cell 1 -> out layer; kept in LDS for cell 1's hidden side at t+1)
+// A record is swept by ONE wave per workgroup (sc1 loads are served at the fabric, ~3 TB/s chip-wide) and passed on through LDS.
+// Arithmetic and summation orders are those of the three kernels above (same saved arrays, same backward).  Records are double-
+// buffered by step parity; a workgroup reaches step t+2 only after every workgroup has published step t+1, i.e. consumed step t.
+// Residency: every workgroup of the grid must be resident at once (the BN sums couple all row groups): the launcher admits the
+// path while the grid has at most one workgroup per CU; every spin is bounded and latches the persistent kernels' fault word.
+#ifdef G2V_STAMPS      // diagnostic build only (gpurun_tools/stamps_dcl.py): s_memtime stamps of step t = 5, two workgroups, every wave
+#define DCL_STAMP(k)                                                                                                              \
+  do {                                                                                                                            \
+    const int sw_ = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 5 && blockIdx.y == 3) ? 1 : -1);                  \
+    if ((threadIdx.x & 63) == 0 && sw_ >= 0 && t == 5) g2v_stamps[(sw_ * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define DCL_STAMP(k)
+#endif
+struct DecClFwdArgs {
+  const float* target; const uint8_t* keep95; const uint8_t* keep_l0;
+  g2v_dec_weights w; g2v_dec_saved sv;
+  unsigned long long* xu;      // [2][nblk][16][Hp]  u rows
+  unsigned long long* xp;      // [2][nblk][2][Hp]   BN partial sums of (u - b), (u - b)^2 per row group
+  unsigned long long* xh0;     // [2][nblk][16][Hp]
+  unsigned long long* xh1;     // [2][nblk][16][Hp]
+  unsigned* fault;
+  int T, B, D, H, n_pre, conditioned, training;
+  float p_drop;
+};
+
+__device__ __forceinline__ void dcl_publish4(__amdgpu_buffer_rsrc_t rr, unsigned granule, const float* v, unsigned tag) {
+  u32x4 a, b;
+  a[0] = __float_as_uint(v[0]); a[1] = tag; a[2] = __float_as_uint(v[1]); a[3] = tag;
+  b[0] = __float_as_uint(v[2]); b[1] = tag; b[2] = __float_as_uint(v[3]); b[3] = tag;
+  px_st(rr, granule * 8u, a);
+  px_st(rr, granule * 8u + 16u, b);
+}
+// column f of the per-row-group partial sums, from the granule records [nblk][2][Hp]: the order of sum_partials()
+__device__ __forceinline__ void dcl_sum_partials(const unsigned long long* rec, int nblk, int Hp, int f, unsigned tag, unsigned* fault,
+                                                 float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+  for (int k0 = 0; k0 < nblk; k0 += 8) {
+    unsigned long long a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = k0 + j < nblk;
+      const unsigned long long* p = rec + (size_t)(ok ? k0 + j : 0) * 2 * Hp + f;
+      a[j] = ok ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+      b[j] = ok ? __hip_atomic_load(p + Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+    }
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ok &= (unsigned)(a[j] >> 32) == tag && (unsigned)(b[j] >> 32) == tag;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long* p = rec + (size_t)(k0 + j < nblk ? k0 + j : 0) * 2 * Hp + f;
+        if ((unsigned)(a[j] >> 32) != tag) a[j] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(b[j] >> 32) != tag) b[j] = __hip_atomic_load(p + Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (cx_give_up(spins, fault)) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s1 += __uint_as_float((unsigned)a[j]);
+      s2 += __uint_as_float((unsigned)b[j]);
+    }
+  }
+}
+
+// GRU cell epilogue of the lane's 4 units (the arithmetic of dec_cell_split_kernel); bs: [b_ih r z n, b_hh r z n][q] in LDS
+__device__ __forceinline__ void dcl_cell_epilogue(const f32x4 (&acc)[3], const float4* xch, const float4 (*bs)[4], int lane, int q,
+                                                  const float (&hown)[4], float (&hn)[4], float (&gr_)[4], float (&gz_)[4],
+                                                  float (&gn_)[4], float (&gh_)[4]) {
+  const float4 bi0 = bs[0][q], bi1 = bs[1][q], bi2 = bs[2][q], bh0 = bs[3][q], bh1 = bs[4][q], bh2 = bs[5][q];
+  const float bir[4] = {bi0.x, bi0.y, bi0.z, bi0.w}, biz[4] = {bi1.x, bi1.y, bi1.z, bi1.w}, bin[4] = {bi2.x, bi2.y, bi2.z, bi2.w};
+  const float bhr[4] = {bh0.x, bh0.y, bh0.z, bh0.w}, bhz[4] = {bh1.x, bh1.y, bh1.z, bh1.w}, bhn[4] = {bh2.x, bh2.y, bh2.z, bh2.w};
+  const float4 v0 = xch[lane], v1 = xch[64 + lane], v2 = xch[128 + lane];
+  const float ah[3][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w}};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float rr = sigmoidf_((acc[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+    const float zz = sigmoidf_((acc[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+    const float ghn = ah[2][r] + bhn[r];
+    const float nn = tanhf_((acc[2][r] + bin[r]) + rr * ghn);
+    hn[r] = (1.0f - zz) * nn + zz * hown[r];
+    gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+  }
+}
+
+template <int KS>      // k-steps over H the kernel is built for: 13 (H <= 208: the shipped configurations' H = 200)
+__global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
+  __shared__ float st[2 * 16 * DSPLIT_KS];                                        // mean[H], invstd[H] (offsets as in the split kernels)
+  __shared__ __attribute__((aligned(16))) float4 xch2[2][3 * 64];                // [cell] hidden-side accumulators -> the input-side wave
+  __shared__ __attribute__((aligned(16))) float4 xs_u[KS][64];                   // u_t rows as B fragments ([k-step][lane])
+  __shared__ __attribute__((aligned(16))) float4 xs_h0[KS][64];                  // h0 rows
+  __shared__ __attribute__((aligned(16))) float4 xs_h1[KS][64];                  // h1 rows
+  __shared__ __attribute__((aligned(16))) float4 xfs[DSPLIT_DT][64];             // xin_{t+1} as B fragments, one D tile per wave
+  __shared__ __attribute__((aligned(16))) float4 bias_s[2][6][4];                // [cell][b_ih r z n, b_hh r z n][q]: the tile's units
+  __shared__ __attribute__((aligned(16))) float4 wp_s[DSPLIT_DT + 1][64];        // pre_linear fragments of the tile + its bias
+  __shared__ __attribute__((aligned(16))) float bnw_s[2 * 16 * DSPLIT_KS];       // BatchNorm weight[H], bias[H] (same offsets as st)
+  extern __shared__ __attribute__((aligned(16))) float4 wo_s[];                  // [D tile][KS][64]: W_out fragments; then [wave][D tile][64]:
+                                                                                  // the waves' partial out-layer products
+  const int T = a.T, B = a.B, D = a.D, H = a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int cell = wave >> 1, side = wave & 1;                  // waves 0 / 1: cell 0 input / hidden side; 2 / 3: cell 1
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const int Hp = nt << 4, ndt = (D + 15) >> 4;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D;
+  const g2v_dec_weights& w = a.w;
+  const g2v_dec_saved& sv = a.sv;
+  // ---- resident operands (zero beyond H: the products below run over all KS k-steps unconditionally) ---------------------------
+  const float* Wc = cell == 0 ? (side == 0 ? w.w_ih0 : w.w_hh0) : (side == 0 ? w.w_ih1 : w.w_hh1);
+  const float* wr = Wc + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * H;
+  float4 wa[3][KS];
+  const int drow = 16 * wave + i;                               // this wave's D tile of the out layer: dt = wave
+  const bool dok = wave < ndt && drow < D;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = k < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) wa[g][ks] = ld4_or_zero(wr + (int64_t)g * H * H + (kok ? k : 0), kok && wrow_ok);
+    wo_s[(wave * KS + ks) * 64 + lane] = ld4_or_zero(w.w_out + (int64_t)(dok ? drow : 0) * H + (kok ? k : 0), kok && dok);
+  }
+  // operands that are read once per step live in LDS (the weight fragments leave no registers for them)
+  if (side == 0 && i == 0) {
+    const float* bip = cell == 0 ? w.b_ih0 : w.b_ih1;
+    const float* bhp = cell == 0 ? w.b_hh0 : w.b_hh1;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      bias_s[cell][g][q] = ld4_or_zero(bip + g * H + (fok ? f0 : 0), fok);
+      bias_s[cell][3 + g][q] = ld4_or_zero(bhp + g * H + (fok ? f0 : 0), fok);
+    }
+  }
+  // out layer: lane (i, q) of wave dt ends up with y[row i][16 dt + 4 q + r]
+  float bo[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int d = 16 * wave + 4 * q + r;
+    bo[r] = (wave < ndt && d < D) ? w.b_out[d] : 0.f;
+  }
+  if (wave == 0) {      // pre_linear fragments of the tile's 16 features: W_pre[16 ft + i][d], d along k
+#pragma unroll
+    for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int d = 16 * dt + 4 * q + e;
+        v[e] = (wrow_ok && dt < ndt && d < D) ? w.w_pre[(int64_t)(16 * ft + i) * D + d] : 0.f;
+      }
+      wp_s[dt][lane] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    wp_s[DSPLIT_DT][lane] = ld4_or_zero(w.b_pre + (fok ? f0 : 0), fok);
+  }
+  for (int f = tid; f < H; f += 256) {
+    bnw_s[f] = w.bn_w[f];
+    bnw_s[16 * DSPLIT_KS + f] = w.bn_b[f];
+  }
+  float4* yp_s = wo_s + (size_t)4 * KS * 64;      // [wave][D tile][64]
+  // the rows entering step 1, from the arrays the t = 0 launch wrote: as fragments, zeros in rows / columns that do not exist (the
+  // sweeps never touch those entries)
+  for (int ks = wave; ks < KS; ks += 4) {
+    const int k = 16 * ks + 4 * q;
+    const bool ok = k < H && rvalid;
+    xs_u[ks][lane] = ld4_or_zero(sv.u + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_h0[ks][lane] = ld4_or_zero(sv.h0 + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_h1[ks][lane] = ld4_or_zero(sv.h1 + (int64_t)b * H + (ok ? k : 0), ok);
+  }
+  const bool drop = a.training && a.keep_l0 && a.p_drop > 0.f;
+  const float scale_l0 = 1.0f / (1.0f - a.p_drop);
+  const unsigned rowrec = 256u * (unsigned)nt, prec = 2u * (unsigned)Hp;
+  __amdgpu_buffer_rsrc_t r_u = __builtin_amdgcn_make_buffer_rsrc(a.xu, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, (int)(2u * (unsigned)nblk * prec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_h0 = __builtin_amdgcn_make_buffer_rsrc(a.xh0, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(a.xh1, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  float hown[4] = {0.f, 0.f, 0.f, 0.f};      // the epilogue waves: this tile's own state entering the step (h0 / h1 of the lane's 4 units)
+  if (side == 0 && rvalid && fok) {
+    const float4 v = *reinterpret_cast<const float4*>((cell == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0);      // index 0 of the state arrays
+    hown[0] = v.x; hown[1] = v.y; hown[2] = v.z; hown[3] = v.w;
+  }
+  lds_barrier();      // the LDS operands above are complete (wave 1 multiplies xs_h0 first thing in the step)
+  for (int t = 1; t < T; ++t) {
+    const unsigned par_prev = (unsigned)((t - 1) & 1), par = (unsigned)(t & 1), tag = (unsigned)t;
+    DCL_STAMP(0);
+    // ---- cell 0: waves 0 (a_t W_ih0) and 1 (h0_{t-1} W_hh0).  The u_t row is swept by the three waves that wait for it anyway, IN
+    // FRONT of the BatchNorm sums: both wait for the same publish of the previous step, and a round at the fabric costs ~1 us ----------
+    f32x4 acc[3];
+#pragma unroll
+    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t kp = 0x01010101u;
+    if (wave != 1 && t > 1)
+      cx_sweep_tiles<(KS + 2) / 3>(r_u, (par_prev * (unsigned)nblk + (unsigned)rg) * rowrec, wave == 0 ? 0 : wave - 1, 3, nt, nrows, H, tag,
+                                   &xs_u[0][0], lane, a.fault);
+    // ---- BatchNorm statistics of step t: every feature (each workgroup needs the whole input row) -------------------------------
+    // (by the waves 0, 2, 3: wave 1 multiplies the hidden side of cell 0 meanwhile, its operand has been in LDS since the last step)
+    for (int f = (wave == 0 ? lane : (wave - 1) * 64 + lane); f < H && wave != 1; f += 192) {
+      float mean, var;
+      if (a.training) {
+        float s1, s2;
+        if (t == 1) sum_partials(sv.bn_partial, nblk, H, f, s1, s2);      // (parity 0: written by the t = 0 launch)
+        else dcl_sum_partials(a.xp + (size_t)par_prev * nblk * prec, nblk, Hp, f, tag, a.fault, s1, s2);
+        const float mv = s1 / (float)B;
+        var = fmaxf(s2 / (float)B - mv * mv, 0.f);     // biased batch variance
+        mean = mv + w.b_pre[f];
+        if (sv.bn_stats && ft == 0 && rg == 0) {
+          sv.bn_stats[(int64_t)(t - 1) * 2 * H + f] = mean;
+          sv.bn_stats[(int64_t)(t - 1) * 2 * H + H + f] = var;
+        }
+      } else {
+        mean = w.bn_running_mean[f];
+        var = w.bn_running_var[f];
+      }
+      st[f] = mean;
+      st[16 * DSPLIT_KS + f] = bn_invstd_(var);
+    }
+    DCL_STAMP(1);
+    if (wave == 1) {
+      // (hidden side: its operand has been in LDS since the previous step)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xs_h0[ks][lane];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = mfma16(wa[g][ks].x, x4.x, acc[g]);
+          acc[g] = mfma16(wa[g][ks].y, x4.y, acc[g]);
+          acc[g] = mfma16(wa[g][ks].z, x4.z, acc[g]);
+          acc[g] = mfma16(wa[g][ks].w, x4.w, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) xch2[0][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    }
+    lds_barrier();
+    DCL_STAMP(2);
+    if (wave == 0) {
+      if (drop && fok && rvalid) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + f0);
+      DCL_STAMP(3);
+      // a_t = ReLU(BN(u_t)) on the fragments (k-step by k-step in front of its products: the VALU work runs under the MFMAs of the
+      // k-step before); the workgroup's own 16 columns (k-step ft) are the ones it writes out
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        float4 xk;
+        {
+          const int k = 16 * ks + 4 * q;
+          const bool kok = k < H;
+          const int kk = kok ? k : 0;
+          const float4 g4 = *reinterpret_cast<const float4*>(bnw_s + kk), b4 = *reinterpret_cast<const float4*>(bnw_s + 16 * DSPLIT_KS + kk);
+          const float4 m4 = *reinterpret_cast<const float4*>(st + kk), i4 = *reinterpret_cast<const float4*>(st + 16 * DSPLIT_KS + kk);
+          float4 v = xs_u[ks][lane];
+          v.x = fmaxf((v.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+          v.y = fmaxf((v.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+          v.z = fmaxf((v.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+          v.w = fmaxf((v.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+          xk = (kok && rvalid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ks == ft && sv.a && rvalid && kok) *reinterpret_cast<float4*>(sv.a + (int64_t)(t - 1) * BH + (int64_t)b * H + k) = v;
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = mfma16(wa[g][ks].x, xk.x, acc[g]);
+          acc[g] = mfma16(wa[g][ks].y, xk.y, acc[g]);
+          acc[g] = mfma16(wa[g][ks].z, xk.z, acc[g]);
+          acc[g] = mfma16(wa[g][ks].w, xk.w, acc[g]);
+        }
+      }
+      DCL_STAMP(4);
+    }
+    DCL_STAMP(5);
+    if (wave == 0 && rvalid && fok) {
+      float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
+      dcl_cell_epilogue(acc, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * scale_l0 : 0.f) : hn[r];
+      cx_publish4(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+      *reinterpret_cast<float4*>(sv.h0 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      if (drop && sv.x1) *reinterpret_cast<float4*>(sv.x1 + (int64_t)(t - 1) * BH + (int64_t)b * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+      if (sv.gates0) {
+        float* go = sv.gates0 + (int64_t)(t - 1) * 4 * BH + (int64_t)b * 4 * H + f0;
+        *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+        *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+        *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+        *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hown[r] = hn[r];
+    }
+    DCL_STAMP(6);
+    // ---- cell 1: waves 2 (Dropout(h0_t) W_ih1) and 3 (h1_{t-1} W_hh1); the h0_t row is swept by the other three waves ----------------
+    if (wave != 0 && wave != 2) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    uint32_t km[KS];      // wave 2: the keep flags of its input fragments, requested in front of the exchange
+    if (wave == 2 && drop) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int k = 16 * ks + 4 * q;
+        const bool ok = k < H && rvalid;
+        km[ks] = ok ? *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + k) : 0u;
+      }
+    }
+    if (wave == 3) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xs_h1[ks][lane];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = mfma16(wa[g][ks].x, x4.x, acc[g]);
+          acc[g] = mfma16(wa[g][ks].y, x4.y, acc[g]);
+          acc[g] = mfma16(wa[g][ks].z, x4.z, acc[g]);
+          acc[g] = mfma16(wa[g][ks].w, x4.w, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) xch2[1][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    }
+    // (the h0_t row is swept by the waves 1, 2, 3 -- wave 3 behind its products; wave 0, which has just published its tile, only stores)
+    if (wave != 0) {
+#ifdef G2V_STAMPS
+      cx_sweep_tiles<(KS + 2) / 3>(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave - 1, 3, nt, nrows, H, tag, &xs_h0[0][0], lane, a.fault,
+                                   (t == 5 && blockIdx.x == 0 && blockIdx.y == 0 && wave == 2) ? g2v_stamps + 128 : nullptr);
+#else
+      cx_sweep_tiles<(KS + 2) / 3>(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave - 1, 3, nt, nrows, H, tag, &xs_h0[0][0], lane, a.fault);
+#endif
+    }
+    lds_barrier();
+    if (wave == 2) {
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      DCL_STAMP(7);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {      // (xs_h0 keeps the undropped row: wave 1 multiplies it at step t + 1)
+        float4 v = xs_h0[ks][lane];
+        {
+          if (drop) {
+            const uint32_t m = km[ks];
+            v.x = (m & 0xffu) ? v.x * scale_l0 : 0.f;
+            v.y = ((m >> 8) & 0xffu) ? v.y * scale_l0 : 0.f;
+            v.z = ((m >> 16) & 0xffu) ? v.z * scale_l0 : 0.f;
+            v.w = ((m >> 24) & 0xffu) ? v.w * scale_l0 : 0.f;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = mfma16(wa[g][ks].x, v.x, acc[g]);
+          acc[g] = mfma16(wa[g][ks].y, v.y, acc[g]);
+          acc[g] = mfma16(wa[g][ks].z, v.z, acc[g]);
+          acc[g] = mfma16(wa[g][ks].w, v.w, acc[g]);
+        }
+      }
+      DCL_STAMP(8);
+    }
+    DCL_STAMP(9);
+    if (wave == 2 && rvalid && fok) {
+      float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
+      dcl_cell_epilogue(acc, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+      cx_publish4(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+      *reinterpret_cast<float4*>(sv.h1 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      if (sv.gates1) {
+        float* go = sv.gates1 + (int64_t)(t - 1) * 4 * BH + (int64_t)b * 4 * H + f0;
+        *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+        *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+        *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+        *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hown[r] = hn[r];
+    }
+    DCL_STAMP(10);
+    // ---- y_t = out_layer(h1_t): wave 3 sweeps the row, every wave multiplies its D tile ------------------------------------------------
+    const bool has_next = t < T - 1, teacher = has_next && t < a.n_pre;
+    float tgv[4];      // teacher-forced inputs / Dropout(0.95) flags of the lane's four y elements: requested in front of the exchange
+    uint8_t k95v[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * wave + 4 * q + r;
+      const bool ok = wave < ndt && d < D && rvalid;
+      tgv[r] = (ok && teacher) ? a.target[((int64_t)b * T + t) * D + d] : 0.f;
+      k95v[r] = (ok && has_next && a.conditioned) ? a.keep95[(int64_t)t * BD + (int64_t)b * D + d] : 0;
+    }
+    if (wave != 2)      // (wave 2 has just published its tile: the other three sweep)
+      cx_sweep_tiles<(KS + 2) / 3>(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave == 3 ? 2 : wave, 3, nt, nrows, H, tag, &xs_h1[0][0], lane,
+                                   a.fault);
+    DCL_STAMP(11);
+    lds_barrier();
+    DCL_STAMP(12);
+    {
+      // every wave: the k-steps wave, wave + 4, ... of all D tiles (independent chains); the four partial products of a D tile are
+      // added by wave dt in the order 0, 1, 2, 3 (the split kernels run one chain over all k-steps: equal to summation order)
+      f32x4 yq[DSPLIT_DT];
+#pragma unroll
+      for (int dt = 0; dt < DSPLIT_DT; ++dt) yq[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < (KS + 3) / 4; ++j) {
+        const int ks = wave + 4 * j;
+        if (ks < KS) {
+          const float4 x4 = xs_h1[ks][lane];
+#pragma unroll
+          for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+            if (dt < ndt) {
+              const float4 w4 = wo_s[(dt * KS + ks) * 64 + lane];
+              yq[dt] = mfma16(w4.x, x4.x, yq[dt]);
+              yq[dt] = mfma16(w4.y, x4.y, yq[dt]);
+              yq[dt] = mfma16(w4.z, x4.z, yq[dt]);
+              yq[dt] = mfma16(w4.w, x4.w, yq[dt]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int dt = 0; dt < DSPLIT_DT; ++dt)
+        if (dt < ndt) yp_s[(wave * DSPLIT_DT + dt) * 64 + lane] = make_float4(yq[dt][0], yq[dt][1], yq[dt][2], yq[dt][3]);
+      lds_barrier();
+      float ya[4] = {0.f, 0.f, 0.f, 0.f};
+      if (wave < ndt) {
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw) {
+          const float4 v = yp_s[(pw * DSPLIT_DT + wave) * 64 + lane];
+          ya[0] += v.x; ya[1] += v.y; ya[2] += v.z; ya[3] += v.w;
+        }
+      }
+      // y, the next decoder input xin = Dropout(0.95)(teacher ? target : y) (zeros when !conditioned), kept as MFMA B fragments
+      float xv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int d = 16 * wave + 4 * q + r;
+        const bool ok = wave < ndt && d < D && rvalid;
+        const float y = ya[r] + bo[r];
+        const float tg = tgv[r];
+        const uint8_t k95 = k95v[r];
+        const float src = teacher ? tg : y;                                           // :1049-1052
+        xv[r] = k95 ? src * 20.0f : 0.f;                                              // Dropout(0.95): 1/(1-0.95)
+        if (ft == 0 && ok) {
+          sv.y[(int64_t)t * BD + (int64_t)b * D + d] = y;
+          if (has_next && sv.xin) sv.xin[(int64_t)t * BD + (int64_t)b * D + d] = xv[r];
+        }
+      }
+      xfs[wave][lane] = make_float4(xv[0], xv[1], xv[2], xv[3]);
+      DCL_STAMP(13);
+    }
+    lds_barrier();
+    DCL_STAMP(14);
+    if (has_next && wave == 0) {
+      // ---- u_{t+1} tile = pre_linear.0(xin_{t+1}) and the BN partial sums of (u - b) over this workgroup's rows ----------------------
+      f32x4 ua = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+        if (dt < ndt) {
+          const float4 x4 = xfs[dt][lane], w4 = wp_s[dt][lane];
+          ua = mfma16(w4.x, x4.x, ua);
+          ua = mfma16(w4.y, x4.y, ua);
+          ua = mfma16(w4.z, x4.z, ua);
+          ua = mfma16(w4.w, x4.w, ua);
+        }
+      }
+      float s1[4], s2[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = (rvalid && fok) ? ua[r] : 0.f;
+        s1[r] = reduce16(v);
+        s2[r] = reduce16(v * v);
+      }
+      if (fok) {
+        if (rvalid) {
+          const float4 bp = wp_s[DSPLIT_DT][lane];
+          const float un[4] = {ua[0] + bp.x, ua[1] + bp.y, ua[2] + bp.z, ua[3] + bp.w};
+          cx_publish4(r_u, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, tag + 1u);
+          *reinterpret_cast<float4*>(sv.u + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(un[0], un[1], un[2], un[3]);
+        }
+        if (i == 0) {
+          const unsigned g0 = (par * (unsigned)nblk + (unsigned)rg) * prec + (unsigned)f0;
+          dcl_publish4(r_p, g0, s1, tag + 1u);
+          dcl_publish4(r_p, g0 + (unsigned)Hp, s2, tag + 1u);
+        }
+      }
+    }
+    DCL_STAMP(15);
   }
 }
 
@@ -1707,7 +2218,36 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
                      al16(s->gates1) && al16(s->bn_partial) && al16(w->w_ih0) && al16(w->w_hh0) && al16(w->w_ih1) &&
                      al16(w->w_hh1) && al16(w->w_out) && al16(w->b_ih0) && al16(w->b_hh0) && al16(w->b_ih1) && al16(w->b_hh1) &&
                      al16(w->b_pre) && al16(w->bn_w) && al16(w->bn_b);
+  // ... or ONE persistent launch for all steps t >= 1 while the tile grid has a CU per workgroup (dec_cluster_fwd_kernel)
+  bool cluster = split && persist_enabled() && T >= 3 && dec_cluster_shape(D, H) &&
+                 (int64_t)dm.nblk * ((H + 15) >> 4) <= device_cu_count() && (!training || s->bn_stats) &&
+                 (!keep_l0 || al16(keep_l0)) &&
+                 fwd_pack_bytes_aligned(D, H) + dec_cluster_fwd_xch_bytes(dm.nblk, H) <= workspace_bytes;
+  if (cluster) {
+    int nocc = 0;
+    const void* fn = (const void*)dec_cluster_fwd_kernel<DCL_KS>;
+    const size_t dyn = dec_cluster_fwd_dyn_lds();      // W_out fragments + partial out-layer products (the static arrays take ~60 KB more)
+    static bool attr_set = false;
+    if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess;
+    cluster = attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, dyn) == hipSuccess && nocc >= 1;
+  }
   for (int t = 0; t < T; ++t) {
+    if (cluster && t == 1) {
+      const size_t Hp = (size_t)((H + 15) & ~15), rowrec = (size_t)2 * dm.nblk * 16 * Hp;
+      unsigned long long* x0 = reinterpret_cast<unsigned long long*>((char*)workspace + fwd_pack_bytes_aligned(D, H));
+      DecClFwdArgs ca;
+      ca.target = target; ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
+      ca.xu = x0; ca.xh0 = x0 + rowrec; ca.xh1 = x0 + 2 * rowrec; ca.xp = x0 + 3 * rowrec;
+      ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
+      ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.training = training;
+      ca.p_drop = p_drop;
+      if (hipMemsetAsync(x0, 0, dec_cluster_fwd_xch_bytes(dm.nblk, H), st) != hipSuccess) {
+        set_error("g2v_dec_rollout_fwd: clearing the exchange records failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(dec_cluster_fwd_kernel<DCL_KS>, dim3((H + 15) >> 4, dm.nblk), dim3(256), dec_cluster_fwd_dyn_lds(), st, ca);
+      break;
+    }
     if (fast) {
       hipLaunchKernelGGL((dec_step_fwd_kernel<64, 135>), dim3(dm.nblk), dim3(256), lds, st, target, h_init, *w, pk, *s, keep95,
                          keep_l0, dm, t);

@@ -10,6 +10,7 @@
 // pre-activations with three v_mfma_f32_16x16x4_f32 accumulators so that the whole gate math for a
 // (row, feature) happens in one lane.
 #include "common.hpp"
+#include "dec_persist.hpp"      // the exchange primitives (px_ld / px_st) of the cluster kernels; not the fault latch
 
 namespace g2v {
 
@@ -802,6 +803,341 @@ __global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB 
 }
 
 
+// ---- small batch, generic hidden size, ONE LAUNCH FOR ALL STEPS (round 5): the step kernels above as a persistent cluster ----
+// The per-step launches cost what a launch costs whatever it does: at B = 128, H = 200 a forward step is 6.3 us and a backward
+// step 8.3 us for ~2 us of arithmetic each, and every launch re-requests its W_hh rows.  Here the same (16 rows x 16 hidden
+// units x direction) workgroups stay resident for all T steps with their W_hh rows in registers; what a kernel boundary did --
+// hand every workgroup of a row group the WHOLE state row (forward) / the whole row of hidden-side gate gradients (backward) --
+// is an exchange of 8-byte self-validating granules {value, tag = step} through memory (write-through stores, sc1 loads: no flag,
+// no fence; dec_persist.hpp has the measurements behind that protocol).  Records are double-buffered by step parity: a workgroup
+// publishes step s + 1 only after it has read every record of step s, which exist only after every workgroup of the row group has
+// read step s - 1.  A workgroup is THREE waves: in the forward each owns one gate's rows of W_hh (the same k-ordered chain per gate
+// as gru_step_fwd_kernel: results bitwise equal), in the backward a third of the 3H-long contraction (three partial chains, summed
+// in a fixed order: equal to summation order); waves 1 and 2 hand their accumulators to wave 0 through LDS.
+// Residency: the workgroups of one (row group, direction) wait for each other, so they must be co-resident -- blockIdx.x is the
+// hidden-unit tile (a partially resident grid holds whole clusters) and the launcher admits the path only while the grid has at
+// most one workgroup per CU.  Every spin is bounded and latches the persistent kernels' fault word (dec_persist.hip) when it runs out.
+struct GruClF {
+  const float* gi; const float* w_hh; const float* b_hh; const float* h0;
+  float* hs; float* gates; float* h_n;
+  unsigned long long* xch;     // [2][nblk][16][Hp] granules {state value, tag}
+  int reverse;
+};
+struct GruClB {
+  const float* d_hs; const float* hs; const float* h0; const float* gates; const float* w_hh; const float* d_hn;
+  float* dgi; float* dgh; float* dh0;
+  unsigned long long* xch;     // [2][nblk][16][Gp] granules {dgh value, tag}
+  int reverse;
+};
+
+// Forward.  sc1 loads are served at the fabric (~25 GB/s per CU: dec_persist.hpp), so a record is swept ONCE per workgroup, with
+// fully used lanes: the three waves take every third tile each and pass the fragments to each other through LDS.
+constexpr int GRU_CL_KSW = (GRU_STEP_KS + 2) / 3;      // tiles a wave sweeps
+__global__ __launch_bounds__(192) void gru_cluster_fwd_kernel(GruClF d0, GruClF d1, const int32_t* __restrict__ lengths,
+                                                              int64_t hs_ld, int T, int B, int H, RowOff ro, unsigned* fault) {
+  __shared__ __attribute__((aligned(16))) float4 xacc[2][2][64];     // [step parity][wave 1 / 2][lane]
+  __shared__ __attribute__((aligned(16))) float4 xs[GRU_STEP_KS + 2][64];      // the state row as B fragments, [k-step][lane]
+  const GruClF d = blockIdx.z == 0 ? d0 : d1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const int nks = nt;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  // ---- resident: this wave's gate rows of W_hh for the tile's 16 hidden units, as MFMA A fragments -----------------------
+  const float* wr = d.w_hh + ((int64_t)wave * H + 16 * ft + (wrow_ok ? i : 0)) * H;
+  float4 wa[GRU_STEP_KS];
+#pragma unroll
+  for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = ks < nks && k < H;
+    wa[ks] = ld4_or_zero(wr + (kok ? k : 0), kok && wrow_ok);
+  }
+  const int b = b0 + (rvalid ? i : 0), f0 = 16 * ft + 4 * q;     // wave 0's outputs: batch row i, hidden units f0 .. f0 + 3
+  const bool fvec = f0 < H;                                       // (H % 4 == 0: a whole float4 or nothing)
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  float bh_[3][4], hp_[4] = {0.f, 0.f, 0.f, 0.f};
+  if (wave == 0) {
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const float4 v = ld4_or_zero(d.b_hh + g * H + (fvec ? f0 : 0), fvec);
+      bh_[g][0] = v.x; bh_[g][1] = v.y; bh_[g][2] = v.z; bh_[g][3] = v.w;
+    }
+    if (d.h0) {
+      const float4 v = ld4_or_zero(d.h0 + (int64_t)b * H + (fvec ? f0 : 0), fvec && rvalid);
+      hp_[0] = v.x; hp_[1] = v.y; hp_[2] = v.z; hp_[3] = v.w;
+    }
+  }
+  // the initial state as fragments (zeros in rows / columns that do not exist: the sweeps never touch those entries)
+#pragma unroll
+  for (int j = 0; j < GRU_CL_KSW; ++j) {
+    const int k = 16 * (wave + 3 * j) + 4 * q;
+    const bool kok = k < H;
+    xs[wave + 3 * j][lane] = ld4_or_zero(d.h0 ? d.h0 + (int64_t)b * H + (kok ? k : 0) : d.w_hh, kok && rvalid && d.h0 != nullptr);
+  }
+  const unsigned rec_granules = 256u * (unsigned)nt;
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(2u * (unsigned)nblk * rec_granules * 8u), 0x00020000);
+  for (int s = 0; s < T; ++s) {
+    const int t = d.reverse ? T - 1 - s : s;
+    const bool valid = rvalid && t < len;
+    float4 gi4[3];
+    if (wave == 0) {      // the step's input projection: independent of the exchange, requested in front of it
+      const float* gir = d.gi + (valid ? gi_row_base(ro, t, B) + b : (int64_t)0) * 3 * H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) gi4[g] = ld4_or_zero(gir + g * H + (fvec ? f0 : 0), fvec && valid);
+    }
+    // the state row entering the step: tiles wave, wave + 3, ... by this wave, to everybody through LDS
+    if (s > 0)
+      cx_sweep_tiles<GRU_CL_KSW>(rr, ((unsigned)((s - 1) & 1) * (unsigned)nblk + (unsigned)rg) * rec_granules, wave, 3, nt, nrows, H,
+                                 (unsigned)s, &xs[0][0], lane, fault);
+    lds_barrier();
+    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < GRU_STEP_KS; ++ks) {
+      if (ks < nks) {
+        const float4 x4 = xs[ks][lane];
+        acc = mfma16(wa[ks].x, x4.x, acc);
+        acc = mfma16(wa[ks].y, x4.y, acc);
+        acc = mfma16(wa[ks].z, x4.z, acc);
+        acc = mfma16(wa[ks].w, x4.w, acc);
+      }
+    }
+    if (wave > 0) xacc[s & 1][wave - 1][lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    lds_barrier();      // (also: every wave is done with xs before the next step's fragments are written)
+    if (wave == 0 && rvalid && fvec) {
+      const float4 az = xacc[s & 1][0][lane], an = xacc[s & 1][1][lane];
+      const float a1[4] = {az.x, az.y, az.z, az.w}, a2[4] = {an.x, an.y, an.z, an.w};
+      const float gir_[3][4] = {{gi4[0].x, gi4[0].y, gi4[0].z, gi4[0].w}, {gi4[1].x, gi4[1].y, gi4[1].z, gi4[1].w},
+                                {gi4[2].x, gi4[2].y, gi4[2].z, gi4[2].w}};
+      float hn[4], gr[4], gz[4], gn[4], gh[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        hn[r] = hp_[r]; gr[r] = gz[r] = gn[r] = gh[r] = 0.f;
+        if (valid) {      // (the arithmetic of gru_step_fwd_kernel)
+          gr[r] = sigmoidf_(gir_[0][r] + (acc[r] + bh_[0][r]));
+          gz[r] = sigmoidf_(gir_[1][r] + (a1[r] + bh_[1][r]));
+          gh[r] = a2[r] + bh_[2][r];
+          gn[r] = tanhf_(gir_[2][r] + gr[r] * gh[r]);
+          hn[r] = (1.0f - gz[r]) * gn[r] + gz[r] * hp_[r];
+        }
+      }
+      if (s + 1 < T) cx_publish4(rr, ((unsigned)(s & 1) * (unsigned)nblk + (unsigned)rg) * rec_granules, ft, i, q, hn, (unsigned)(s + 1));
+      const int64_t row = (int64_t)t * B + b;
+      float* ho = d.hs + row * hs_ld + f0;                  // hs_ld may be unaligned: scalar stores
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ho[r] = valid ? hn[r] : 0.f;       // padded positions of the output are zero
+      if (d.gates) {
+        float* go = d.gates + row * 4 * H + f0;
+        *reinterpret_cast<float4*>(go) = make_float4(gr[0], gr[1], gr[2], gr[3]);
+        *reinterpret_cast<float4*>(go + H) = make_float4(gz[0], gz[1], gz[2], gz[3]);
+        *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn[0], gn[1], gn[2], gn[3]);
+        *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh[0], gh[1], gh[2], gh[3]);
+      }
+      if (s == T - 1 && d.h_n) *reinterpret_cast<float4*>(d.h_n + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hp_[r] = hn[r];
+    }
+  }
+}
+
+// Backward cluster: iteration `it` (0 .. T) as gru_step_bwd_kernel's launch `it`; the carry never leaves wave 0's registers.
+// The product dgh W_hh contracts over all 3H gate columns, which the tile workgroups of a row group hold 48 each.  Handing every
+// workgroup the whole 3H-wide row would be three times the forward's exchange; instead a workgroup multiplies ITS 48 gate columns
+// (straight from wave 0's registers: the lane layout of the gate gradients IS the MFMA B fragment of three k-steps) with its 48
+// rows of W_hh for ALL hidden units and publishes that (16 x H) partial product as a row record; the owner of a hidden-unit tile
+// then adds the NT partial products of its tile -- one contiguous 2 KiB block per producer -- in a fixed order (producer 0, 1, ...).
+// Wave w multiplies the output tiles w, w + 3, ...
+constexpr int GRU_CL_OT = (GRU_STEP_KS + 2) / 3;      // output tiles per wave
+__global__ __launch_bounds__(192) void gru_cluster_bwd_kernel(GruClB d0, GruClB d1, const int32_t* __restrict__ lengths,
+                                                              int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H, RowOff ro,
+                                                              int last_it, unsigned* fault) {
+  __shared__ __attribute__((aligned(16))) float4 xs[3][64];      // this tile's gate gradients (r, z, hn) as B fragments
+  __shared__ __attribute__((aligned(16))) float4 dsum3[3][64];   // [wave] its producers' partial products of this tile, [q 16 + row]
+  const GruClB d = blockIdx.z == 0 ? d0 : d1;
+  const int G = 3 * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0), f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  // ---- resident: rows g H + 16 ft + 4 q + e of W_hh (this tile's gate rows) at the columns of this wave's output tiles, as MFMA
+  // A fragments: a = W_hh[g H + 16 ft + 4 q + e][16 ot + i] ------------------------------------------------------------------------
+  float4 wt[GRU_CL_OT][3];
+#pragma unroll
+  for (int j = 0; j < GRU_CL_OT; ++j) {
+    const int col = 16 * (wave + 3 * j) + i;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      float v[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = (fok && col < H) ? d.w_hh[((int64_t)g * H + f0 + e) * H + col] : 0.f;
+      wt[j][g] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  }
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  float carry[4] = {0.f, 0.f, 0.f, 0.f};
+  // records: [parity][row group][producer tile] row records of 256 nt granules
+  const unsigned rec_granules = 256u * (unsigned)nt;
+  __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(2u * (unsigned)nblk * (unsigned)nt * rec_granules * 8u), 0x00020000);
+  const bool rev = d.reverse != 0;
+  for (int it = 0; it <= last_it; ++it) {
+    const int s_next = T - 1 - it;
+    const int tn = s_next < 0 ? -1 : (rev ? T - 1 - s_next : s_next);
+    const int tprev = (s_next <= 0) ? -1 : (rev ? tn + 1 : tn - 1);
+    // ---- wave 0: the loads of part B that do not depend on part A, requested first ---------------------------------------------------
+    const bool act = wave == 0 && tn >= 0 && rvalid && fok && tn < len;
+    const int64_t rown = (int64_t)(tn >= 0 ? tn : 0) * B + b;
+    float4 g4[4], hp4 = make_float4(0.f, 0.f, 0.f, 0.f), dhs4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (wave == 0) {
+      const float* go = d.gates + rown * 4 * H + (fok ? f0 : 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g4[g] = ld4_or_zero(go + g * H, act);
+      const bool from_hs = act && tprev >= 0 && tprev < len;
+      if (from_hs) {
+        const float* hpp = d.hs + ((int64_t)tprev * B + b) * hs_ld + f0;      // hs_ld may be unaligned
+        hp4 = make_float4(hpp[0], hpp[1], hpp[2], hpp[3]);
+      } else if (act && d.h0) {
+        hp4 = *reinterpret_cast<const float4*>(d.h0 + (int64_t)b * H + f0);
+      }
+      if (act && d.d_hs) {
+        const float* dp = d.d_hs + rown * d_hs_ld + f0;
+        dhs4 = make_float4(dp[0], dp[1], dp[2], dp[3]);
+      }
+    }
+    if (it > 0) {
+      // ---- every wave: the partial products of this tile from the producers wave, wave + 3, ... (producer p's block of the tile is
+      // 128 chunks of 16 bytes: the lane takes chunks lane and 64 + lane), summed in ascending order, to LDS in accumulator layout ----
+      const unsigned base = ((unsigned)((it - 1) & 1) * (unsigned)nblk + (unsigned)rg) * (unsigned)nt * rec_granules + (unsigned)(ft * 256);
+      const unsigned tag = (unsigned)it;
+      u32x4 gq[GRU_CL_OT][2];
+      bool need[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int c = h * 64 + lane;
+        need[h] = (c >> 3) < nrows && 16 * ft + 4 * ((c >> 1) & 3) < H;
+      }
+#pragma unroll
+      for (int j = 0; j < GRU_CL_OT; ++j)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int p = wave + 3 * j;
+          if (need[h] && p < nt) gq[j][h] = px_ld(rr, (base + (unsigned)p * rec_granules) * 8u + (unsigned)(h * 64 + lane) * 16u);
+          else gq[j][h] = (u32x4){0u, tag, 0u, tag};
+        }
+      unsigned spins = 0;
+      for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (int j = 0; j < GRU_CL_OT; ++j) ok &= gq[j][0][1] == tag && gq[j][0][3] == tag && gq[j][1][1] == tag && gq[j][1][3] == tag;
+        if (ok) break;
+        __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int j = 0; j < GRU_CL_OT; ++j)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (gq[j][h][1] != tag || gq[j][h][3] != tag)
+              gq[j][h] = px_ld(rr, (base + (unsigned)(wave + 3 * j) * rec_granules) * 8u + (unsigned)(h * 64 + lane) * 16u);
+        if (cx_give_up(spins, fault)) break;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int j = 0; j < GRU_CL_OT; ++j) {
+          const unsigned lo = gq[j][h][0], hi = gq[j][h][2];
+          s0 += __uint_as_float(lo);
+          s1 += __uint_as_float(hi);
+        }
+        const int c = h * 64 + lane;
+        float* dst = reinterpret_cast<float*>(&dsum3[wave][((c >> 1) & 3) * 16 + (c >> 3)]) + (c & 1) * 2;
+        *reinterpret_cast<float2*>(dst) = make_float2(s0, s1);      // (zeros where nothing exists)
+      }
+    }
+    lds_barrier();
+    if (wave == 0) {
+      // ---- part A: dh = carry + the NT partial products of this tile (summed by the three waves, see below) ------------------------
+      float dh[4] = {0.f, 0.f, 0.f, 0.f};
+      if (it > 0) {
+        const float4 v0 = dsum3[0][lane], v1 = dsum3[1][lane], v2 = dsum3[2][lane];
+        dh[0] = carry[0] + ((v0.x + v1.x) + v2.x); dh[1] = carry[1] + ((v0.y + v1.y) + v2.y);
+        dh[2] = carry[2] + ((v0.z + v1.z) + v2.z); dh[3] = carry[3] + ((v0.w + v1.w) + v2.w);
+      } else if (d.d_hn && rvalid && fok) {
+        const float4 v = *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0);
+        dh[0] = v.x; dh[1] = v.y; dh[2] = v.z; dh[3] = v.w;
+      }
+      float g_r[4] = {0.f, 0.f, 0.f, 0.f}, g_z[4] = {0.f, 0.f, 0.f, 0.f}, g_n[4] = {0.f, 0.f, 0.f, 0.f}, g_hn[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tn < 0) {                                          // after the last step: the gradient of the initial state
+        if (d.dh0 && rvalid && fok) *reinterpret_cast<float4*>(d.dh0 + (int64_t)b * H + f0) = make_float4(dh[0], dh[1], dh[2], dh[3]);
+      } else {
+        // ---- part B (the arithmetic of gru_step_bwd_kernel) -------------------------------------------------------------------------
+        const float rr_[4] = {g4[0].x, g4[0].y, g4[0].z, g4[0].w}, zz_[4] = {g4[1].x, g4[1].y, g4[1].z, g4[1].w};
+        const float nn_[4] = {g4[2].x, g4[2].y, g4[2].z, g4[2].w}, gh_[4] = {g4[3].x, g4[3].y, g4[3].z, g4[3].w};
+        const float hpv[4] = {hp4.x, hp4.y, hp4.z, hp4.w}, dd_[4] = {dhs4.x, dhs4.y, dhs4.z, dhs4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          carry[r] = dh[r];
+          if (act) {
+            const float dht = dh[r] + dd_[r];
+            const float dn = dht * (1.0f - zz_[r]);
+            const float dz = dht * (hpv[r] - nn_[r]);
+            const float dnp = dn * (1.0f - nn_[r] * nn_[r]);
+            g_n[r] = dnp;
+            g_hn[r] = dnp * rr_[r];
+            g_r[r] = dnp * gh_[r] * rr_[r] * (1.0f - rr_[r]);
+            g_z[r] = dz * zz_[r] * (1.0f - zz_[r]);
+            carry[r] = dht * zz_[r];
+          }
+        }
+        if (rvalid && fok) {
+          float* gh_o = d.dgh + rown * G + f0;
+          if (act || !ro.on) {
+            float* gi_o = d.dgi + (gi_row_base(ro, tn, B) + b) * G + f0;
+            *reinterpret_cast<float4*>(gi_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+            *reinterpret_cast<float4*>(gi_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+            *reinterpret_cast<float4*>(gi_o + 2 * H) = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]);
+          }
+          *reinterpret_cast<float4*>(gh_o) = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+          *reinterpret_cast<float4*>(gh_o + H) = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+          *reinterpret_cast<float4*>(gh_o + 2 * H) = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+        }
+      }
+      // the tile's hidden-side gate gradients as the B fragments of three k-steps (zeros in rows / units that do not exist)
+      xs[0][lane] = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]);
+      xs[1][lane] = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]);
+      xs[2][lane] = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+    }
+    lds_barrier();
+    if (it < last_it) {
+      // ---- this workgroup's partial product for every hidden unit: (16 rows x 48 gate columns) x (48 x H) -----------------------
+      const float4 x0 = xs[0][lane], x1 = xs[1][lane], x2 = xs[2][lane];
+      const unsigned rec0 = (((unsigned)(it & 1) * (unsigned)nblk + (unsigned)rg) * (unsigned)nt + (unsigned)ft) * rec_granules;
+      f32x4 acc[GRU_CL_OT];
+#pragma unroll
+      for (int j = 0; j < GRU_CL_OT; ++j) {
+        acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (wave + 3 * j < nt) {
+          acc[j] = mfma16(wt[j][0].x, x0.x, acc[j]); acc[j] = mfma16(wt[j][0].y, x0.y, acc[j]);
+          acc[j] = mfma16(wt[j][0].z, x0.z, acc[j]); acc[j] = mfma16(wt[j][0].w, x0.w, acc[j]);
+          acc[j] = mfma16(wt[j][1].x, x1.x, acc[j]); acc[j] = mfma16(wt[j][1].y, x1.y, acc[j]);
+          acc[j] = mfma16(wt[j][1].z, x1.z, acc[j]); acc[j] = mfma16(wt[j][1].w, x1.w, acc[j]);
+          acc[j] = mfma16(wt[j][2].x, x2.x, acc[j]); acc[j] = mfma16(wt[j][2].y, x2.y, acc[j]);
+          acc[j] = mfma16(wt[j][2].z, x2.z, acc[j]); acc[j] = mfma16(wt[j][2].w, x2.w, acc[j]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < GRU_CL_OT; ++j) {
+        const int ot = wave + 3 * j;      // the lane's result: batch row i, hidden units 16 ot + 4 q .. + 3
+        if (ot < nt && rvalid && 16 * ot + 4 * q < H) {
+          const float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+          cx_publish4(rr, rec0, ot, i, q, v, (unsigned)(it + 1));
+        }
+      }
+    }
+    lds_barrier();      // xs is rewritten by wave 0 in the next iteration
+  }
+}
+
+
 // ---- one GRU CELL step at small batch, input projection included (the code decoder of Part d: T = 1 per call) --------------
 // g2v_gru_seq_fwd with T = 1 needs gi = x W_ih^T + b_ih from a dense-layer launch first; here a workgroup of TWO waves owns a
 // (16 rows x 16 hidden units) tile: wave 0 multiplies the input side (x, W_ih), wave 1 the hidden side (h_prev, W_hh), each with
@@ -1373,9 +1709,47 @@ static bool gru_split_ok(int B, int ndir, int H) {
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 * GRU_SPLIT_MAX_B * H; }
 
+// The cluster kernels (gru_cluster_*_kernel): the split path's shapes while the whole grid is resident at once -- at most one
+// 192-thread workgroup per CU (the workgroups of a row group wait for each other).  g2v_gru_seq_set_cluster(0) keeps the
+// per-step launches (parity tests, A/B).
+static int g_gru_cluster = 1;
+extern "C" int g2v_gru_seq_set_cluster(int enable) {
+  const int prev = g_gru_cluster;
+  g_gru_cluster = enable ? 1 : 0;
+  return prev;
+}
+static int gru_device_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  }
+  return n;
+}
+// exchange records of the cluster kernels: forward one (16 x Hp) record of granules per (parity, row group, direction), backward one
+// per (parity, row group, producer tile, direction)
+static size_t gru_cluster_xch_bytes(int B, int ndir, int H, bool bwd) {
+  const size_t Hp = (size_t)((H + 15) & ~15);
+  return (size_t)ndir * 2 * cdiv(B, 16) * (bwd ? Hp / 16 : 1) * 16 * Hp * 8;
+}
+// the largest exchange region a cluster launch can need at this H: the grid has at most one workgroup per CU
+static size_t gru_cluster_max_xch_bytes(int H, bool bwd) {
+  if ((H & 3) != 0 || H > 16 * GRU_STEP_KS || H == 64 || H < 4) return 0;
+  const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16, cus = (size_t)gru_device_cus();
+  return (bwd ? cus : cus / nt + 1) * 2 * 16 * Hp * 8;
+}
+static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn) {
+  if (!g_gru_cluster || !gru_split_ok(B, ndir, H) || T < 2 || T > (1 << 20)) return false;
+  if ((int64_t)cdiv(B, 16) * cdiv(H, 16) * ndir > gru_device_cus()) return false;
+  int n = 0;
+  return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 192, 0) == hipSuccess && n >= 1;
+}
+
 extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
   const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H), b = gru_split_state_floats(ndir, H);
-  return (a > b ? a : b) * sizeof(float);
+  const size_t c = gru_cluster_max_xch_bytes(H, false);
+  const size_t ab = (a > b ? a : b) * sizeof(float);
+  return ab > c ? ab : c;
 }
 
 int g2v_internal_slab_reduce4(const float* const* slab_w, float* const* out_w, const float* const* slab_b, float* const* out_b,
@@ -1567,6 +1941,23 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
       set_error("g2v_gru_seq_fwd: workspace too small");
       return G2V_ERR_WORKSPACE;
     }
+    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, false);
+    if (gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_fwd_kernel) && xbytes <= workspace_bytes) {
+      // ... or ONE launch for all steps: the same workgroups resident, the state rows exchanged through tagged granules
+      GruClF c[2];
+      for (int k = 0; k < ndir; ++k)
+        c[k] = GruClF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].gates, dirs[k].h_n,
+                      reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (xbytes / ndir)), dirs[k].reverse};
+      if (ndir == 1) c[1] = c[0];
+      if (hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
+        set_error("g2v_gru_seq_fwd: clearing the exchange records failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(gru_cluster_fwd_kernel, dim3(Hp >> 4, cdiv(B, 16), ndir), dim3(192), 0, st, c[0], c[1], lengths, hs_ld, T,
+                         B, H, ro, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
     float* state = (float*)workspace;                  // [dir][2][B][H]
     for (int s_ = 0; s_ < T; ++s_) {
       GruStepF g[2];
@@ -1654,7 +2045,9 @@ extern "C" int g2v_gru_seq_fwd_prepared(const g2v_gru_dir* dirs, int ndir, const
 
 extern "C" size_t g2v_gru_seq_bwd_workspace(int ndir, int H) {
   const size_t a = (size_t)2 * ndir * pack_floats(H, 1, 3 * H), b = (size_t)ndir * 3 * H * H + gru_split_state_floats(ndir, H);
-  return (a > b ? a : b) * sizeof(float);
+  const size_t c = gru_cluster_max_xch_bytes(H, true);      // the cluster kernel's exchange records (whatever B it admits)
+  const size_t ab = (a > b ? a : b) * sizeof(float);
+  return ab > c ? ab : c;
 }
 
 static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t* lengths, int64_t d_hs_ld,
@@ -1779,6 +2172,24 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   }
   if (split) {
     const int Hp = (H + 15) & ~15;
+    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, true);
+    if (gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_bwd_kernel) && xbytes <= workspace_bytes) {
+      GruClB c[2];
+      for (int k = 0; k < ndir; ++k)
+        c[k] = GruClB{dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, dirs[k].w_hh, dirs[k].d_hn, dirs[k].dgi, dirs[k].dgh,
+                      dirs[k].dh0, reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (xbytes / ndir)),
+                      dirs[k].reverse};
+      if (ndir == 1) c[1] = c[0];
+      const bool want_dh0 = dirs[0].dh0 || (ndir == 2 && dirs[1].dh0);
+      if (hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
+        set_error("g2v_gru_seq_bwd: clearing the exchange records failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(gru_cluster_bwd_kernel, dim3(Hp >> 4, cdiv(B, 16), ndir), dim3(192), 0, st, c[0], c[1], lengths, d_hs_ld,
+                         hs_ld, T, B, H, ro, want_dh0 ? T : T - 1, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
     float* carry = p + (size_t)ndir * 3 * H * H;      // [dir][B][H], after the transposed weights (3 H^2 floats: 16-byte multiple)
     for (int k = 0; k < ndir; ++k) launch_transpose(dirs[k].w_hh, p + (size_t)k * 3 * H * H, 3 * H, H, st);
     // launch `it`: part A finishes the step of forward iteration T - it, part B opens forward iteration T - 1 - it

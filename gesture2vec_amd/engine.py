@@ -290,6 +290,7 @@ class VQVAEEngine:
         f = int(self.lib.g2v_dec_rollout_persist_fault(1))
         if f != 0:
             self.lib.g2v_dec_rollout_set_persistent(0)
+            self.lib.g2v_gru_seq_set_cluster(0)
             self._iter_graph = None
             self._open.clear()
             self._deferred.clear()

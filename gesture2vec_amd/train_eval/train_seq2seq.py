@@ -324,12 +324,33 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         raise TypeError("use gesture2vec_amd.flat.FlatClipAdam (clip + Adam are one fused HIP launch)")
     if args.text2_embedding_discrete != "True":
         raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
-    optim.zero_grad()
-    outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
-    loss = _code_loss(outputs, cluster_targets)
-    loss.backward()
-    optim.step()
-    return {"loss": loss.item()}
+    from .. import _lib
+    lib = _lib.load()
+    for attempt in (0, 1):
+        optim.zero_grad()
+        outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
+        loss = _code_loss(outputs, cluster_targets)
+        loss.backward()
+        optim.step()
+        ret = {"loss": loss.item()}
+        # The encoder's small-batch GRU kernels keep their workgroups resident for the whole sequence (include/g2v.h:
+        # g2v_gru_seq_set_cluster) and latch the persistent kernels' fault word when a bounded wait runs out (a workgroup of the
+        # launch was not resident: CU mask, another tenant).  A faulted iteration changed nothing -- clip + Adam and BatchNorm's
+        # running statistics read the latch on the device -- so it is repeated once on the per-step kernels.
+        f = int(lib.g2v_dec_rollout_persist_fault(0))      # (one 4-byte read at the point where loss.item() synchronised anyway)
+        if f == 0:
+            return ret
+        lib.g2v_dec_rollout_persist_fault(1)               # clear
+        lib.g2v_gru_seq_set_cluster(0)
+        if attempt == 1:
+            raise RuntimeError(f"persistent kernel fault latch {f} set again on the per-step kernels")
+        import warnings
+        warnings.warn(f"persistent GRU kernels: fault latch {f} (a workgroup of the launch was not resident); the iteration was not "
+                      "applied and is repeated on the per-step kernels, which stay selected", RuntimeWarning)
+        bn = getattr(getattr(getattr(net, "decoder", None), "decoder", None), "pre_linear", None)
+        if bn is not None and hasattr(bn[1], "num_batches_tracked"):
+            bn[1].num_batches_tracked -= outputs.shape[1] - 1      # (the repeated iteration counts its decode steps again)
+    return ret
 
 
 class GraphedText2EmbeddingStep:

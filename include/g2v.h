@@ -57,10 +57,11 @@ int g2v_device_ok(void);
  * (0 = never); returns the previous value, rows < 0 only queries */
 int g2v_linear_set_smallm_rows(int rows);
 /* PROCESS-GLOBAL SWITCHES of the library, complete list (everything else is per call).  The library reads NO environment
- * variable.  Both select between implementations that produce the same results (measurements, parity tests, and the fall-back
- * after a latched residency fault of the persistent rollout):
+ * variable.  All three select between implementations that produce the same results (measurements, parity tests, and the
+ * fall-back after a latched residency fault of the persistent kernels):
  *   g2v_linear_set_smallm_rows(rows)        row count up to which the wave-per-tile dense kernels are used (default 1024)
  *   g2v_dec_rollout_set_persistent(0..3)    persistent rollout kernels vs one launch per step (default 1; see below)
+ *   g2v_gru_seq_set_cluster(0 / 1)          small-batch g2v_gru_seq_fwd / _bwd: one persistent launch vs one launch per step
  * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
@@ -249,6 +250,15 @@ typedef struct {          /* one direction of one layer, forward */
   const int32_t* gi_row_off;
 } g2v_gru_dir;
 int g2v_gru_seq_packed_ok(int T, int B, int H);
+/* Round 5.  At small batch (B <= 1024, H % 4 == 0, H <= 256, H != 64) g2v_gru_seq_fwd / _bwd run one launch per time step over
+ * (16 rows x 16 hidden units x direction) workgroups.  While that grid fits the device with one workgroup per CU (B = 128 at
+ * H = 200, both directions: 208 workgroups) the same workgroups instead stay resident for ALL steps of ONE launch, their W_hh rows
+ * in registers, and hand each other the state rows (forward) / the hidden-side gate gradients (backward) through tagged 8-byte
+ * granules in the call's workspace (csrc/gru.hip: gru_cluster_*_kernel).  Forward results are bitwise those of the per-step
+ * launches, backward results equal to summation order.  Like the persistent rollouts these kernels need their workgroups
+ * co-resident; a bounded wait that runs out latches g2v_dec_rollout_persist_fault.  This switch (default 1; 0 = one launch per
+ * step) exists for parity tests, A/B measurements and the fall-back after a latched fault.  Returns the previous setting. */
+int g2v_gru_seq_set_cluster(int enable);
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
 size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */

@@ -666,6 +666,78 @@ def test_gru_seq(ops, T, B, H, reverse, use_len):
     relclose(db_hh, grads_ref[4], 5e-5, "gru db_hh")
 
 
+@pytest.mark.parametrize("T,B,H,ndir,use_len,packed,use_h0", [
+    (20, 128, 200, 2, False, False, False),      # the reference's own VQ-VAE.yml encoder: 208 workgroups of three waves
+    (20, 128, 200, 2, True, True, False),        # Part d's encoder at B = 128: packed input projections
+    (7, 19, 200, 1, True, False, True),          # ragged last row group, an initial state
+    (34, 40, 52, 2, True, False, True),          # H not a multiple of 16: a partial last hidden-unit tile
+    (2, 16, 16, 2, False, False, False),         # two steps, one tile: a single exchange
+    (12, 300, 200, 1, True, True, False),        # 19 row groups x 13 tiles = 247 workgroups: the largest grid admitted on 256 CUs
+])
+def test_gru_cluster_kernels_equal_the_per_step_launches(ops, T, B, H, ndir, use_len, packed, use_h0):
+    """g2v_gru_seq_fwd / _bwd at small batch: ONE persistent launch for all steps (csrc/gru.hip, gru_cluster_*_kernel: W_hh rows
+    resident, states / gate gradients exchanged through tagged granules) against one launch per step
+    (g2v_gru_seq_set_cluster(0)).  Equal to rounding: the forward runs the same k-ordered chain per gate (the blend of the new state
+    is contracted differently: <= 1 ulp per step), the backward's 3H-long contraction is three partial chains there."""
+    lib = ops._lib_()
+    g = torch.Generator().manual_seed(1000 + T + B)
+    lengths = None
+    if use_len:
+        lengths = torch.randint(1, T + 1, (B,), generator=g).sort(descending=True).values
+        lengths[0] = T
+    len_d = lengths.to(torch.int32).to(DEV) if use_len else None
+    row_off, n_rows = None, T * B
+    if packed:
+        assert use_len and ops.gru_packed_ok(T, B, H)
+        n_t = [int((lengths > t).sum()) for t in range(T)]
+        row_off = [sum(n_t[:t]) for t in range(T)]
+        n_rows = sum(n_t)
+    rev = [False, True][:ndir]
+    w = [rnd(3 * H, H, seed=50 + k, scale=1 / math.sqrt(H)).to(DEV) for k in range(ndir)]
+    bh = [rnd(3 * H, seed=60 + k, scale=0.1).to(DEV) for k in range(ndir)]
+    gi = [rnd(n_rows, 3 * H, seed=70 + k).to(DEV) for k in range(ndir)]
+    h0 = [rnd(B, H, seed=80 + k).to(DEV) if use_h0 else None for k in range(ndir)]
+    g_hs = [rnd(T, B, H, seed=90 + k).to(DEV) for k in range(ndir)]
+    g_hn = [rnd(B, H, seed=95 + k).to(DEV) for k in range(ndir)]
+
+    def run():
+        f32 = lambda *sh: torch.full(sh, float("nan"), dtype=torch.float32, device=DEV)
+        fw = [dict(gi=gi[k], w_hh=w[k], b_hh=bh[k], h0=h0[k], hs=f32(T, B, H), h_n=f32(B, H), gates=f32(T, B, 4 * H), reverse=rev[k])
+              for k in range(ndir)]
+        ops.gru_dirs_fwd(fw, T, B, H, lengths=len_d, row_off=row_off)
+        bw = [dict(d_hs=g_hs[k], d_hn=g_hn[k], hs=fw[k]["hs"], h0=h0[k], gates=fw[k]["gates"], w_hh=w[k], dgi=f32(n_rows, 3 * H),
+                   dgh=f32(T, B, 3 * H), dh0=f32(B, H) if use_h0 else None, reverse=rev[k]) for k in range(ndir)]
+        ops.gru_dirs_bwd(bw, T, B, H, lengths=len_d, row_off=row_off)
+        torch.cuda.synchronize()
+        return fw, bw
+
+    assert lib.g2v_dec_rollout_persist_fault(0) == 0
+    prev = lib.g2v_gru_seq_set_cluster(0)
+    try:
+        fw_s, bw_s = run()
+        lib.g2v_gru_seq_set_cluster(1)
+        fw_c, bw_c = run()
+    finally:
+        lib.g2v_gru_seq_set_cluster(prev)
+    assert lib.g2v_dec_rollout_persist_fault(0) == 0, "a bounded wait of the cluster kernels ran out"
+    for k in range(ndir):
+        for name in ("hs", "h_n", "gates"):
+            a, b = fw_s[k][name], fw_c[k][name]
+            if name == "gates" and use_len:      # (padded positions of the saved gates are not defined by either path)
+                m = (torch.arange(T, device=DEV)[:, None] < len_d[None, :])[:, :, None].expand_as(a)
+                a, b = a[m], b[m]
+            # gates of ONE step from equal inputs are bitwise equal (same k-ordered chain per gate, same gate arithmetic); the
+            # final blend (1 - z) n + z h is contracted differently by the compiler in the two kernels (<= 1 ulp), and the
+            # recurrence carries that on: rounding-level differences after T steps
+            relclose(b, a.cpu(), 3e-6, f"dir {k} {name}")
+        for name in ("dgi", "dgh", "dh0"):
+            a, b = bw_s[k][name], bw_c[k][name]
+            if a is None:
+                continue
+            assert not torch.isnan(b).any(), (k, name)
+            relclose(b, a.cpu(), 1e-5, f"dir {k} {name}")
+
+
 # ----------------------------------------------------------------------------------------------- decoder rollout
 def _dec_state(D, H, seed):
     sd = O.init_vqvae_state(D, H, 2, 8, seed=seed)
@@ -897,6 +969,60 @@ def test_dec_rollout_persistent_matches_per_step_kernels(ops, B, p, T):
         bad = dict(grads)
         bad["dw_gru"], bad["db_gru"] = [dw, None, None, dw], [db, None, None, db]
         ops.dec_rollout_bwd(wsb, sb, bad, k95, kl0, p, 1, True, T, B, D, H)
+
+
+@pytest.mark.parametrize("T,B,D,H,p,n_pre,training", [
+    (20, 128, 40, 200, 0.2, 1, True),        # config/VQ-VAE.yml as shipped: 8 row groups x 13 tiles = 104 resident workgroups
+    (10, 128, 45, 200, 0.0, 1, True),        # the GENEA / TWH dims at the reference's batch size
+    (7, 37, 45, 200, 0.2, 3, True),          # ragged last row group, teacher-forced prefix
+    (9, 300, 40, 52, 0.1, 1, True),          # H not a multiple of 16, 19 row groups
+    (6, 40, 40, 200, 0.0, 1, False),         # eval mode: running statistics, no exchange of partial sums
+])
+def test_dec_cluster_forward_matches_the_per_step_launches(ops, T, B, D, H, p, n_pre, training):
+    """Generic dims at small batch: the steps t >= 1 of g2v_dec_rollout_fwd as ONE persistent launch (csrc/dec_rollout.hip,
+    dec_cluster_fwd_kernel: weights resident, u / h0 / h1 rows and the BatchNorm partial sums exchanged through tagged granules)
+    against three launches per step (g2v_dec_rollout_set_persistent(0)).  Same arithmetic and summation orders: every saved array
+    equal to rounding (the blend of a cell's new state is contracted differently by the compiler: <= 1 ulp per step), reproducible
+    run to run bit for bit."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    sd = _dec_state(D, H, seed=23)
+    g = torch.Generator().manual_seed(6)
+    sd["decoder.decoder.pre_linear.1.running_mean"] = torch.randn(H, generator=g) * 0.1
+    sd["decoder.decoder.pre_linear.1.running_var"] = torch.rand(H, generator=g) + 0.5
+    target = torch.randn(B, T, D, generator=g).to(DEV)
+    h_init = (torch.randn(2, B, H, generator=g) * 0.5).to(DEV)
+    k95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8).to(DEV)
+    kl0 = (torch.rand(T - 1, B, H, generator=g) < (1 - p)).to(torch.uint8).to(DEV) if p > 0 else None
+    nblk = ops.dec_rollout_blocks(B)
+
+    def fwd(setting):
+        prev = lib.g2v_dec_rollout_set_persistent(setting)
+        try:
+            wt, _ = _dec_weight_tensors(sd, DEV)
+            saved = _alloc_saved(T, B, D, H, nblk, DEV, p)
+            for v in saved.values():
+                if v is not None:
+                    v.fill_(float("nan"))
+            ops.dec_rollout_fwd(target, h_init, ops.dec_weights_struct(wt), saved, k95, kl0, p, n_pre, True, training, T, B, D, H)
+            torch.cuda.synchronize()
+            return saved, wt
+        finally:
+            lib.g2v_dec_rollout_set_persistent(prev)
+
+    assert lib.g2v_dec_rollout_persist_fault(0) == 0
+    (sa, wa), (sb, wb), (sc, wc) = fwd(1), fwd(0), fwd(1)
+    assert lib.g2v_dec_rollout_persist_fault(0) == 0, "a bounded wait of the cluster kernel ran out"
+    keys = [k for k in sa if sa[k] is not None and k != "bn_partial"]
+    if not training:
+        keys = ["y", "u", "h0", "h1"]
+    for k in keys:
+        assert not torch.isnan(sa[k]).any(), k
+        assert torch.equal(sa[k], sc[k]), f"cluster forward not reproducible: {k}"
+        relclose(sa[k], sb[k].cpu(), 5e-6, f"cluster vs per-step forward: {k}")
+    for k in ("bn_running_mean", "bn_running_var"):
+        assert torch.equal(wa[k], wc[k])
+        relclose(wa[k], wb[k].cpu(), 5e-6, k)
 
 
 # More row tiles than CUs: R = 2 or 3 tiles per workgroup (csrc/dec_persist.hip, the *_mt kernels).  `mode` is what

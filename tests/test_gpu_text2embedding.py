@@ -361,6 +361,61 @@ def test_packed_encoder_inputs_equal_the_padded_grid(att, p, B, H):
     assert checked >= 20
 
 
+def test_train_iter_repeats_an_iteration_whose_persistent_kernels_faulted():
+    """The encoder's small-batch GRU kernels are persistent (g2v_gru_seq_set_cluster) and latch the fault word of the persistent
+    kernels when a bounded wait runs out.  A latched iteration must change NOTHING (clip + Adam and BatchNorm's running statistics
+    read the latch on the device) and train_iter_text2embedding repeats it once on the per-step kernels: the model after a
+    faulted-and-repeated iteration equals the model after a clean one."""
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
+    lib = _lib.load()
+    B, H, L, K, NW, EMB, Tw, S, p = 32, 48, 2, 64, 50, 30, 9, 6, 0.1
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att="False",
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.sort(torch.randint(2, Tw + 1, (B,), generator=g), descending=True).values
+    lengths[0] = Tw
+    ids = torch.randint(1, NW, (B, Tw), generator=g).to(DEV)
+    codes = torch.randint(0, K, (B, S), generator=g).to(DEV)
+    masks = ((torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8).to(DEV),
+             (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV), None)
+    states = []
+    prev = lib.g2v_gru_seq_set_cluster(1)
+    try:
+        for fault in (False, True):
+            torch.manual_seed(9)
+            net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(2).randn(NW, EMB).astype(np.float32), None).to(DEV)
+            net.train(True)
+            optim = FlatClipAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+            net.set_dropout_masks(*masks)
+            assert lib.g2v_dec_rollout_persist_fault(1) == 0
+            lib.g2v_gru_seq_set_cluster(1 if fault else 0)      # (the clean run on the kernels the repeated iteration ends up on)
+            if fault:
+                lib.g2v_dec_rollout_persist_fault(-1)          # as a bounded wait running out would
+                orig = net.forward                               # (the repeated iteration needs the same explicit masks again)
+
+                def fwd(*a, **k):
+                    net.set_dropout_masks(*masks)
+                    return orig(*a, **k)
+                net.forward = fwd
+                with pytest.warns(RuntimeWarning, match="repeated on the per-step kernels"):
+                    r = train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+                assert lib.g2v_gru_seq_set_cluster(1) == 0      # the per-step kernels were selected
+            else:
+                r = train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+            assert lib.g2v_dec_rollout_persist_fault(0) == 0
+            states.append((r["loss"], {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_gru_seq_set_cluster(prev)
+    assert states[0][0] == states[1][0]
+    for k, v in states[0][1].items():      # the same kernels on the same inputs: the discarded attempt left no trace at all
+        assert torch.equal(v, states[1][1][k]), k
+
+
 @pytest.mark.parametrize("att,B,force_fused", [("False", 40, False), ("True", 24, True), ("False", 1040, True)])
 def test_loss_on_the_step_major_outputs_equals_the_reference_form(att, B, force_fused, monkeypatch):
     """train_iter_text2embedding takes CrossEntropyLoss on the step-major (S,B,K) array behind the model's outputs view
