@@ -255,6 +255,58 @@ __device__ __forceinline__ void cx_sweep_tiles(__amdgpu_buffer_rsrc_t rr, unsign
   }
 }
 
+// One wave adds the 16 x 16 tile `tile` of NP row records -- record p0, p0 + pstr, ... (those < np; `rec_stride` granules apart,
+// record 0 at `rec_granule0`) -- in ascending order and leaves the sum in dst (LDS: [64] float4, accumulator layout q 16 + row;
+// zeros where nothing exists).  A producer's tile is 128 chunks of 16 bytes: the lane takes chunks lane and 64 + lane.
+template <int NP>
+__device__ __forceinline__ void cx_sweep_tile_sum(__amdgpu_buffer_rsrc_t rr, unsigned rec_granule0, unsigned rec_stride, int p0, int pstr,
+                                                  int np, int tile, int nrows, int K, unsigned tag, float4* dst, int lane,
+                                                  unsigned* fault) {
+  u32x4 g[NP][2];
+  bool need[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int c = h * 64 + lane;
+    need[h] = (c >> 3) < nrows && 16 * tile + 4 * ((c >> 1) & 3) < K;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int p = p0 + j * pstr;
+      if (need[h] && p < np) g[j][h] = px_ld(rr, (rec_granule0 + (unsigned)p * rec_stride + (unsigned)(tile * 256)) * 8u + (unsigned)(h * 64 + lane) * 16u);
+      else g[j][h] = (u32x4){0u, tag, 0u, tag};
+    }
+  unsigned spins = 0;
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) ok &= g[j][0][1] == tag && g[j][0][3] == tag && g[j][1][1] == tag && g[j][1][3] == tag;
+    if (ok) break;
+    __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+    for (int j = 0; j < NP; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (g[j][h][1] != tag || g[j][h][3] != tag)
+          g[j][h] = px_ld(rr, (rec_granule0 + (unsigned)(p0 + j * pstr) * rec_stride + (unsigned)(tile * 256)) * 8u + (unsigned)(h * 64 + lane) * 16u);
+    if (cx_give_up(spins, fault)) break;
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const unsigned lo = g[j][h][0], hi = g[j][h][2];
+      s0 += __uint_as_float(lo);
+      s1 += __uint_as_float(hi);
+    }
+    const int c = h * 64 + lane;
+    float* d = reinterpret_cast<float*>(dst + (((c >> 1) & 3) * 16 + (c >> 3))) + (c & 1) * 2;
+    *reinterpret_cast<float2*>(d) = make_float2(s0, s1);
+  }
+}
+
 // Column sums of `n` (<= 16) records of 128 granules each -> tot[128] (LDS), by all 256 threads, fixed order.
 // Thread (m = tid >> 4, c = tid & 15) owns granule pairs c, c+16, c+32, c+48 of record m and re-reads the ones whose
 // tag is stale.  red: LDS [16][128].  Ends with a barrier; tot is valid for every thread afterwards.

@@ -1039,6 +1039,12 @@ static size_t dec_cluster_fwd_xch_bytes(int nblk, int H) {
 }
 // (H <= 208 = 13 k-steps: with 16 the weight fragments + a sweep's granules no longer fit the register file -- 186 spills)
 constexpr int DCL_KS = 13;
+// backward: dbn row records + partial sums (both parities) and four partial-product row records per (row group, producer tile)
+static size_t dec_cluster_bwd_xch_bytes(int nblk, int H) {
+  const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
+  return ((size_t)2 * nblk * (16 + 2) * Hp + (size_t)nblk * 4 * nt * 16 * Hp) * 8;
+}
+static size_t dec_cluster_bwd_dyn_lds() { return (size_t)4 * 13 /* DCL_KS */ * 64 * sizeof(float4); }
 static size_t dec_cluster_fwd_dyn_lds() { return ((size_t)4 * DCL_KS + (size_t)4 * 4 /* DSPLIT_DT */) * 64 * sizeof(float4); }
 static bool dec_cluster_shape(int D, int H) { return !(H == 64 && D == 135) && (H & 3) == 0 && H <= 16 * DCL_KS && D <= 64 && H >= 4; }
 extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) {
@@ -1860,6 +1866,368 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   }
 }
 
+// ---- the backward of the cluster (round 5): the four split launches per step (below) as ONE persistent launch -------------------------
+// Same tile workgroups, four waves.  The two products of a stage that contract over all 3H gate columns -- carry' = direct + dgh W_hh
+// and dgi W_ih -- are formed the other way round: a workgroup multiplies ITS 48 gate columns (its own gate-gradient tile, straight
+// from LDS as the B fragments of three k-steps) with its 48 rows of W_hh / W_ih for ALL hidden units, publishes the two (16 x H)
+// partial products as row records, and the owner of a hidden-unit tile adds the NT partial products of its tile in a fixed order
+// (gru.hip's backward cluster has the argument: the exchange is a third of handing every workgroup the whole 3H-wide rows).
+// Exchanges per step: the dbn rows + the BatchNorm-backward partial sums of every row group (-> du, dy feedback), the partial
+// products of cell 1, the partial products of cell 0.  Wave 0 owns the element-wise stages and keeps both carries in registers.
+// The pair records are single-buffered (a workgroup publishes the next stage's records only after it has swept this stage's, and
+// sweeping needs every workgroup of the row group to have published, i.e. to be done with the stage before); dbn rows / partial sums
+// are double-buffered by step parity as in the forward.
+struct DecClBwdArgs {
+  const uint8_t* keep95; const uint8_t* keep_l0;
+  g2v_dec_weights w; g2v_dec_saved sv; g2v_dec_grads g;
+  unsigned long long* xd;      // [2][nblk] row records: dbn rows
+  unsigned long long* xp;      // [2][nblk][2][Hp]: BatchNorm-backward partial sums
+  unsigned long long* xq;      // [nblk][hh1, ih1, hh0, ih0][producer tile] row records: partial products
+  unsigned* fault;
+  int T, B, D, H, n_pre, conditioned;
+  float p_drop;
+};
+
+// gate gradients of one GRU cell for the lane's (row, 4 units): the arithmetic of gru_cell_bwd_lane on values in registers
+__device__ __forceinline__ void dcl_cell_bwd(const float (&dh)[4], const float4 (&gt)[4], const float4& hp4, float (&g_r)[4],
+                                             float (&g_z)[4], float (&g_n)[4], float (&g_hn)[4], float (&direct)[4]) {
+  const float rr[4] = {gt[0].x, gt[0].y, gt[0].z, gt[0].w}, zz[4] = {gt[1].x, gt[1].y, gt[1].z, gt[1].w},
+              nn[4] = {gt[2].x, gt[2].y, gt[2].z, gt[2].w}, gh[4] = {gt[3].x, gt[3].y, gt[3].z, gt[3].w},
+              hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float dn = dh[r] * (1.0f - zz[r]);
+    const float dz = dh[r] * (hp[r] - nn[r]);
+    const float dnp = dn * (1.0f - nn[r] * nn[r]);
+    g_n[r] = dnp;
+    g_hn[r] = dnp * rr[r];
+    g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+    g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+    direct[r] = dh[r] * zz[r];
+  }
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
+  constexpr int NU = (2 * KS + 3) / 4;                                           // (matrix, output tile) units of a pair per wave
+  constexpr int NPW = (KS + 1) / 2;                                              // producers a wave adds up
+  __shared__ float st[4 * 16 * DSPLIT_KS];                                        // s1[H], s2[H] of the step, mean[H], invstd[H]
+  __shared__ float bnw_s[16 * DSPLIT_KS];
+  __shared__ __attribute__((aligned(16))) float4 xs_dbn[KS][64];                 // dbn rows as B fragments
+  __shared__ __attribute__((aligned(16))) float4 xs_du[KS][64];                  // du rows
+  __shared__ __attribute__((aligned(16))) float4 xs_dy[DSPLIT_DT][64];           // dy rows (D tiles as k-steps)
+  __shared__ __attribute__((aligned(16))) float4 xs_g[6][64];                    // the stage's gate gradients: dgh r z hn, dgi r z n
+  __shared__ __attribute__((aligned(16))) float4 dsum[4][64];                    // [wave] its share of the partial products, summed
+  extern __shared__ __attribute__((aligned(16))) float4 wpt_s[];                 // [D tile][KS][64]: W_pre^T fragments
+  const int T = a.T, B = a.B, D = a.D, H = a.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const int Hp = nt << 4, ndt = (D + 15) >> 4, G = 3 * H;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H, own = rvalid && fok;
+  const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D, BG = 3 * BH;
+  const g2v_dec_weights& w = a.w;
+  const g2v_dec_saved& sv = a.sv;
+  const g2v_dec_grads& gr = a.g;
+  // ---- resident: this wave's (matrix, output tile) units of both pairs: rows g H + f0 + e of the matrix at columns 16 ot + i ----------
+  float4 wq[2][NU][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = wave + 4 * j, m = u >= nt ? 1 : 0, ot = u - m * nt;
+      const float* W = c == 1 ? (m == 0 ? w.w_hh1 : w.w_ih1) : (m == 0 ? w.w_hh0 : w.w_ih0);
+      const int col = 16 * ot + i;
+      const bool ok = u < 2 * nt && fok && col < H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? W[((int64_t)g * H + f0 + e) * H + col] : 0.f;
+        wq[c][j][g] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  // W_out^T fragments of the tile (wave 0's dy W_out product): W_out[16 dt + 4 q + e][16 ft + i]
+  float4 wot[DSPLIT_DT];
+#pragma unroll
+  for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int d = 16 * dt + 4 * q + e;
+      v[e] = (wrow_ok && d < D) ? w.w_out[(int64_t)d * H + 16 * ft + i] : 0.f;
+    }
+    wot[dt] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  // W_pre^T fragments (rows d, contraction over the H features): wave dt fills its D tile
+  for (int ks = 0; ks < KS; ++ks) {
+    const int d = 16 * wave + i;
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = 16 * ks + 4 * q + e;
+      v[e] = (wave < ndt && d < D && k < H) ? w.w_pre[(int64_t)k * D + d] : 0.f;
+    }
+    wpt_s[(wave * KS + ks) * 64 + lane] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  for (int f = tid; f < 16 * DSPLIT_KS; f += 256) bnw_s[f] = f < H ? w.bn_w[f] : 0.f;
+  for (int ks = wave; ks < KS; ks += 4) {
+    xs_dbn[ks][lane] = make_float4(0.f, 0.f, 0.f, 0.f);      // (the sweeps leave zeros where nothing exists; before the first one: zeros)
+    xs_du[ks][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const bool drop = a.keep_l0 && a.p_drop > 0.f;
+  const float scale_l0 = 1.0f / (1.0f - a.p_drop);
+  const unsigned rowrec = 256u * (unsigned)nt, prec = 2u * (unsigned)Hp;
+  __amdgpu_buffer_rsrc_t r_d = __builtin_amdgcn_make_buffer_rsrc(a.xd, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, (int)(2u * (unsigned)nblk * prec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(a.xq, 0, (int)((unsigned)nblk * 4u * (unsigned)nt * rowrec * 8u), 0x00020000);
+  const unsigned q_rg = (unsigned)rg * 4u * (unsigned)nt * rowrec;      // this row group's pair records
+  float carry1[4] = {0.f, 0.f, 0.f, 0.f}, carry0[4] = {0.f, 0.f, 0.f, 0.f};      // (wave 0)
+  float acc_bw = 0.f, acc_bb = 0.f;                                                // d bn weight / bias of feature tid (workgroup (0, 0))
+  lds_barrier();
+  for (int t = T - 1; t >= 0; --t) {
+    const bool last = t == T - 1;
+    const unsigned tag = (unsigned)(T - t), par = (unsigned)(t & 1), par_next = (unsigned)((t + 1) & 1);
+    const bool feedback = a.conditioned && t >= a.n_pre;
+    // ---- requests that do not depend on this step's exchanges ------------------------------------------------------------------
+    // every wave: its k-steps of u_t (ks = wave, wave + 4, ...) for the du stage; waves dt < ndt: dy_t / keep flags of their D tile
+    float4 uq[(KS + 3) / 4];
+    float dyo[4] = {0.f, 0.f, 0.f, 0.f};
+    uint8_t k95[4] = {0, 0, 0, 0};
+    if (!last) {
+#pragma unroll
+      for (int j = 0; j < (KS + 3) / 4; ++j) {
+        const int k = 16 * (wave + 4 * j) + 4 * q;
+        const bool ok = wave + 4 * j < KS && k < H && rvalid;
+        uq[j] = ld4_or_zero(sv.u + (int64_t)t * BH + (int64_t)b * H + (ok ? k : 0), ok);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int d = 16 * wave + 4 * q + r;
+      const bool ok = wave < ndt && d < D && rvalid;
+      dyo[r] = ok ? gr.dy[(int64_t)t * BD + (int64_t)b * D + d] : 0.f;
+      k95[r] = (ok && !last && feedback && t > 0) ? a.keep95[(int64_t)t * BD + (int64_t)b * D + d] : 0;
+    }
+    // wave 0: the saved values of the two cells' tiles (step index t - 1) and of the BatchNorm stage
+    float4 gt1[4], gt0[4], hp1 = make_float4(0.f, 0.f, 0.f, 0.f), hp0 = hp1, a4 = hp1, u4 = hp1, m4 = hp1, v4 = hp1;
+    uint32_t kp = 0x01010101u;
+    if (wave == 0 && t > 0) {
+      const int64_t o4 = (int64_t)(t - 1) * 4 * BH + (int64_t)b * 4 * H + (fok ? f0 : 0), o1 = (int64_t)(t - 1) * BH + (int64_t)b * H + (fok ? f0 : 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        gt1[g] = ld4_or_zero(sv.gates1 + o4 + g * H, own);
+        gt0[g] = ld4_or_zero(sv.gates0 + o4 + g * H, own);
+      }
+      hp1 = ld4_or_zero(sv.h1 + o1, own);
+      hp0 = ld4_or_zero(sv.h0 + o1, own);
+      a4 = ld4_or_zero(sv.a + o1, own);
+      u4 = ld4_or_zero(sv.u + o1, own);
+      m4 = ld4_or_zero(sv.bn_stats + (int64_t)(t - 1) * 2 * H + (fok ? f0 : 0), fok);
+      v4 = ld4_or_zero(sv.bn_stats + (int64_t)(t - 1) * 2 * H + H + (fok ? f0 : 0), fok);
+      if (drop && own) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + o1);
+    }
+    if (!last) {
+      // ---- du_t: finish the BatchNorm backward of step index t from the dbn rows and the partial sums the stage before published ----
+      cx_sweep_tiles<(KS + 3) / 4>(r_d, (par_next * (unsigned)nblk + (unsigned)rg) * rowrec, wave, 4, nt, nrows, H, tag - 1u, &xs_dbn[0][0], lane,
+                                   a.fault);
+      if (tid < H) {
+        float s1, s2;
+        dcl_sum_partials(a.xp + (size_t)par_next * nblk * prec, nblk, Hp, tid, tag - 1u, a.fault, s1, s2);
+        st[tid] = s1;
+        st[16 * DSPLIT_KS + tid] = s2;
+        st[2 * 16 * DSPLIT_KS + tid] = sv.bn_stats[(int64_t)t * 2 * H + tid];
+        st[3 * 16 * DSPLIT_KS + tid] = bn_invstd_(sv.bn_stats[(int64_t)t * 2 * H + H + tid]);
+        acc_bw += s2;      // (d gamma / d beta accumulate over the steps, in step order: workgroup (0, 0) writes them at the end)
+        acc_bb += s1;
+      }
+      lds_barrier();
+      const float invB = 1.0f / (float)B;
+#pragma unroll
+      for (int j = 0; j < (KS + 3) / 4; ++j) {
+        const int ks = wave + 4 * j;
+        if (ks < KS) {      // (uniform)
+          const int k = 16 * ks + 4 * q;
+          const bool kok = k < H;
+          const int kk = kok ? k : 0;
+          const float4 db4 = xs_dbn[ks][lane];
+          const float4 s14 = *reinterpret_cast<const float4*>(st + kk), s24 = *reinterpret_cast<const float4*>(st + 16 * DSPLIT_KS + kk);
+          const float4 mm4 = *reinterpret_cast<const float4*>(st + 2 * 16 * DSPLIT_KS + kk), ii4 = *reinterpret_cast<const float4*>(st + 3 * 16 * DSPLIT_KS + kk);
+          const float4 w4 = *reinterpret_cast<const float4*>(bnw_s + kk);
+          const float uu[4] = {uq[j].x, uq[j].y, uq[j].z, uq[j].w}, db[4] = {db4.x, db4.y, db4.z, db4.w};
+          const float mm[4] = {mm4.x, mm4.y, mm4.z, mm4.w}, is[4] = {ii4.x, ii4.y, ii4.z, ii4.w}, gg[4] = {w4.x, w4.y, w4.z, w4.w};
+          const float a1[4] = {s14.x, s14.y, s14.z, s14.w}, a2[4] = {s24.x, s24.y, s24.z, s24.w};
+          float du[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {      // (the arithmetic of dec_bwd_dy_split_kernel)
+            const float xhat = (uu[r] - mm[r]) * is[r];
+            du[r] = (rvalid && kok) ? gg[r] * is[r] * (db[r] - a1[r] * invB - xhat * a2[r] * invB) : 0.f;
+          }
+          const float4 d4 = make_float4(du[0], du[1], du[2], du[3]);
+          xs_du[ks][lane] = d4;
+          if (ft == 0 && rvalid && kok) *reinterpret_cast<float4*>(gr.du + (int64_t)t * BH + (int64_t)b * H + k) = d4;
+        }
+      }
+      lds_barrier();
+    }
+    if (t == 0) break;      // (the last dy stage forms du_0 only)
+    // ---- dy_t: + keep95 * 20 * (du_t W_pre^T) where the step's input was its own previous output; as the B fragments of S2 ----------
+    {
+      float dyv[4] = {dyo[0], dyo[1], dyo[2], dyo[3]};
+      if (!last && feedback && wave < ndt) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 x4 = xs_du[ks][lane], w4 = wpt_s[(wave * KS + ks) * 64 + lane];
+          acc = mfma16(w4.x, x4.x, acc);
+          acc = mfma16(w4.y, x4.y, acc);
+          acc = mfma16(w4.z, x4.z, acc);
+          acc = mfma16(w4.w, x4.w, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (k95[r]) dyv[r] += acc[r] * 20.0f;
+          const int d = 16 * wave + 4 * q + r;
+          if (ft == 0 && rvalid && d < D && k95[r]) gr.dy[(int64_t)t * BD + (int64_t)b * D + d] = dyv[r];
+        }
+      }
+      if (wave < DSPLIT_DT) xs_dy[wave][lane] = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
+    }
+    lds_barrier();
+    // ---- cell 1 (wave 0): dh1 = carry1 + dy_t W_out restricted to the tile; its gate gradients --------------------------------------
+    float direct[4] = {0.f, 0.f, 0.f, 0.f};
+    if (wave == 0) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+        if (dt < ndt) {
+          const float4 x4 = xs_dy[dt][lane];
+          acc = mfma16(wot[dt].x, x4.x, acc);
+          acc = mfma16(wot[dt].y, x4.y, acc);
+          acc = mfma16(wot[dt].z, x4.z, acc);
+          acc = mfma16(wot[dt].w, x4.w, acc);
+        }
+      }
+      float dh[4], g_r[4], g_z[4], g_n[4], g_hn[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) dh[r] = acc[r] + (last ? 0.f : carry1[r]);
+      dcl_cell_bwd(dh, gt1, hp1, g_r, g_z, g_n, g_hn, direct);
+      const float4 vr = own ? make_float4(g_r[0], g_r[1], g_r[2], g_r[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vz = own ? make_float4(g_z[0], g_z[1], g_z[2], g_z[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vn = own ? make_float4(g_n[0], g_n[1], g_n[2], g_n[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vh = own ? make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      xs_g[0][lane] = vr; xs_g[1][lane] = vz; xs_g[2][lane] = vh;
+      xs_g[3][lane] = vr; xs_g[4][lane] = vz; xs_g[5][lane] = vn;
+      if (own) {
+        float* gi = gr.dgi1 + (int64_t)(t - 1) * BG + (int64_t)b * G + f0;
+        float* gh = gr.dgh1 + (int64_t)(t - 1) * BG + (int64_t)b * G + f0;
+        *reinterpret_cast<float4*>(gi) = vr; *reinterpret_cast<float4*>(gi + H) = vz; *reinterpret_cast<float4*>(gi + 2 * H) = vn;
+        *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
+      }
+    }
+    // ---- the two stages with a partial-product exchange: c = 1 (cell 1's W_hh1 / W_ih1), then c = 0 -----------------------------------
+#pragma unroll
+    for (int c = 1; c >= 0; --c) {
+      lds_barrier();      // xs_g of the stage is complete
+      {
+        const float4 xh0 = xs_g[0][lane], xh1 = xs_g[1][lane], xh2 = xs_g[2][lane];
+        const float4 xi0 = xs_g[3][lane], xi1 = xs_g[4][lane], xi2 = xs_g[5][lane];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const int u = wave + 4 * j, m = u >= nt ? 1 : 0, ot = u - m * nt;
+          if (u < 2 * nt) {      // (uniform)
+            const float4 x0 = m ? xi0 : xh0, x1 = m ? xi1 : xh1, x2 = m ? xi2 : xh2;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(wq[c][j][0].x, x0.x, acc); acc = mfma16(wq[c][j][0].y, x0.y, acc);
+            acc = mfma16(wq[c][j][0].z, x0.z, acc); acc = mfma16(wq[c][j][0].w, x0.w, acc);
+            acc = mfma16(wq[c][j][1].x, x1.x, acc); acc = mfma16(wq[c][j][1].y, x1.y, acc);
+            acc = mfma16(wq[c][j][1].z, x1.z, acc); acc = mfma16(wq[c][j][1].w, x1.w, acc);
+            acc = mfma16(wq[c][j][2].x, x2.x, acc); acc = mfma16(wq[c][j][2].y, x2.y, acc);
+            acc = mfma16(wq[c][j][2].z, x2.z, acc); acc = mfma16(wq[c][j][2].w, x2.w, acc);
+            if (rvalid && 16 * ot + 4 * q < H) {
+              const float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag);
+            }
+          }
+        }
+      }
+      // wave w adds the partial products of matrix w & 1 from the producers w >> 1, (w >> 1) + 2, ... for this tile
+      cx_sweep_tile_sum<NPW>(r_q, q_rg + (unsigned)((1 - c) * 2 + (wave & 1)) * (unsigned)nt * rowrec, rowrec, wave >> 1, 2, nt, ft, nrows, H, tag,
+                             &dsum[wave][0], lane, a.fault);
+      lds_barrier();
+      if (wave == 0) {
+        const float4 h_a = dsum[0][lane], h_b = dsum[2][lane], i_a = dsum[1][lane], i_b = dsum[3][lane];
+        const float shh[4] = {h_a.x + h_b.x, h_a.y + h_b.y, h_a.z + h_b.z, h_a.w + h_b.w};
+        const float sih[4] = {i_a.x + i_b.x, i_a.y + i_b.y, i_a.z + i_b.z, i_a.w + i_b.w};
+        if (c == 1) {
+          // carry1' = dh1 z + dgh1 W_hh1 | dh0 = Dropout'(dgi1 W_ih1) + carry0; cell 0's gate gradients
+          float dh[4], g_r[4], g_z[4], g_n[4], g_hn[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            carry1[r] = direct[r] + shh[r];
+            float v = sih[r];
+            if (drop) v = ((kp >> (8 * r)) & 0xffu) ? v * scale_l0 : 0.f;
+            dh[r] = v + (last ? 0.f : carry0[r]);
+          }
+          dcl_cell_bwd(dh, gt0, hp0, g_r, g_z, g_n, g_hn, direct);
+          const float4 vr = own ? make_float4(g_r[0], g_r[1], g_r[2], g_r[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 vz = own ? make_float4(g_z[0], g_z[1], g_z[2], g_z[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 vn = own ? make_float4(g_n[0], g_n[1], g_n[2], g_n[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 vh = own ? make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+          xs_g[0][lane] = vr; xs_g[1][lane] = vz; xs_g[2][lane] = vh;
+          xs_g[3][lane] = vr; xs_g[4][lane] = vz; xs_g[5][lane] = vn;
+          if (own) {
+            float* gi = gr.dgi0 + (int64_t)(t - 1) * BG + (int64_t)b * G + f0;
+            float* gh = gr.dgh0 + (int64_t)(t - 1) * BG + (int64_t)b * G + f0;
+            *reinterpret_cast<float4*>(gi) = vr; *reinterpret_cast<float4*>(gi + H) = vz; *reinterpret_cast<float4*>(gi + 2 * H) = vn;
+            *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
+          }
+        } else {
+          // carry0' = dh0 z + dgh0 W_hh0 | da = dgi0 W_ih0 -> ReLU backward -> dbn of step index t - 1 and its BatchNorm sums
+          float dbn[4] = {0.f, 0.f, 0.f, 0.f}, dbx[4] = {0.f, 0.f, 0.f, 0.f}, s1[4], s2[4];
+          const float av[4] = {a4.x, a4.y, a4.z, a4.w}, uv[4] = {u4.x, u4.y, u4.z, u4.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w},
+                      vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            carry0[r] = direct[r] + shh[r];
+            if (own) {
+              dbn[r] = av[r] > 0.f ? sih[r] : 0.f;
+              dbx[r] = dbn[r] * ((uv[r] - mv[r]) * bn_invstd_(vv[r]));
+            }
+          }
+          if (own) {
+            cx_publish4(r_d, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, dbn, tag);
+            *reinterpret_cast<float4*>(gr.dbn + (int64_t)(t - 1) * BH + (int64_t)b * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            s1[r] = reduce16(dbn[r]);
+            s2[r] = reduce16(dbx[r]);
+          }
+          if (i == 0 && fok) {
+            const unsigned g0 = (par * (unsigned)nblk + (unsigned)rg) * prec + (unsigned)f0;
+            dcl_publish4(r_p, g0, s1, tag);
+            dcl_publish4(r_p, g0 + (unsigned)Hp, s2, tag);
+          }
+        }
+      }
+    }
+    lds_barrier();      // (xs_g / dsum / st of this step are done with)
+  }
+  // ---- the gradient of the initial states, d gamma / d beta ---------------------------------------------------------------------
+  if (wave == 0 && own) {
+    *reinterpret_cast<float4*>(gr.dh_init + (int64_t)b * H + f0) = make_float4(carry0[0], carry0[1], carry0[2], carry0[3]);
+    *reinterpret_cast<float4*>(gr.dh_init + BH + (int64_t)b * H + f0) = make_float4(carry1[0], carry1[1], carry1[2], carry1[3]);
+  }
+  if (ft == 0 && rg == 0 && tid < H) {
+    gr.d_bn_w[tid] = acc_bw;
+    gr.d_bn_b[tid] = acc_bb;
+  }
+}
+
 // ---- backward of the same split: step t as up to four launches (the seams are where a product contracts over a whole
 // row of gate gradients that every tile workgroup of the previous launch contributed to) ------------------------------------
 //   dec_bwd_dy_split_kernel    (rows x D tiles): finish BN-backward of step t+1 -> du_{t+1}; dy_t += keep95 * 20 * (du W_pre)
@@ -2333,7 +2701,13 @@ static size_t bwd_wslab_bytes(int D, int H) {
 }
 extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   const size_t a = bwd_pack_bytes_aligned(D, H) + PX_BYTES + bwd_wslab_bytes(D, H), b = split_bwd_total(D, H) * sizeof(float);
-  return a > b ? a : b;
+  size_t c = 0;
+  if (dec_cluster_shape(D, H)) {      // the cluster kernel's exchange records at the largest grid it is admitted for
+    const int nt = (H + 15) >> 4, cus = device_cu_count() > 0 ? device_cu_count() : 256;
+    c = dec_cluster_bwd_xch_bytes(cus / nt + 1, H);
+  }
+  const size_t ab = a > b ? a : b;
+  return ab > c ? ab : c;
 }
 // 0: one launch per time step; R >= 1: ONE persistent launch each way with R row tiles per workgroup (see g2v.h)
 extern "C" int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H) {
@@ -2470,6 +2844,33 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
                        al16(s->gates0) && al16(s->gates1) && al16(s->bn_stats) && al16(g->du) && al16(g->dbn) && al16(g->dgi0) &&
                        al16(g->dgh0) && al16(g->dgi1) && al16(g->dgh1) && al16(g->dh_init) && al16(g->bn_bwd_partial) &&
                        al16(w->bn_w);
+    bool cluster = split && persist_enabled() && T >= 3 && dec_cluster_shape(D, H) && (int64_t)nblk * ((H + 15) >> 4) <= device_cu_count() &&
+                   (!keep_l0 || al16(keep_l0)) && dec_cluster_bwd_xch_bytes(nblk, H) <= workspace_bytes && !g->dw_gru[0] && !g->dw_gru[1] &&
+                   !g->dw_gru[2] && !g->dw_gru[3] && !s->loss_code;
+    if (cluster) {
+      const void* fn = (const void*)dec_cluster_bwd_kernel<DCL_KS>;
+      static bool attr_set = false;
+      int nocc = 0;
+      if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_cluster_bwd_dyn_lds()) == hipSuccess;
+      cluster = attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, dec_cluster_bwd_dyn_lds()) == hipSuccess && nocc >= 1;
+    }
+    if (cluster) {
+      // ONE persistent launch for the whole BPTT (dec_cluster_bwd_kernel): weights read in place, no transposes
+      const size_t Hp = (size_t)((H + 15) & ~15);
+      unsigned long long* x0 = reinterpret_cast<unsigned long long*>(workspace);
+      DecClBwdArgs ca;
+      ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s; ca.g = *g;
+      ca.xd = x0; ca.xp = x0 + (size_t)2 * nblk * 16 * Hp; ca.xq = ca.xp + (size_t)2 * nblk * 2 * Hp;
+      ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
+      ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.p_drop = p_drop;
+      if (hipMemsetAsync(x0, 0, dec_cluster_bwd_xch_bytes(nblk, H), st) != hipSuccess) {
+        set_error("g2v_dec_rollout_bwd: clearing the exchange records failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(dec_cluster_bwd_kernel<DCL_KS>, dim3((H + 15) >> 4, nblk), dim3(256), dec_cluster_bwd_dyn_lds(), st, ca);
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
     if (split) {
       const int64_t BH = (int64_t)B * H, BD = (int64_t)B * D, BG = 3 * BH;
       float* w_pre_t = p;                 p += (size_t)D * H;
