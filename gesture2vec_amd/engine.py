@@ -195,7 +195,7 @@ class VQVAEEngine:
         # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: at
         # small batch (a 1-2 ms step of ~300 small launches) that is more than the overlap returns (native VQ-VAE.yml shape,
         # B = 128, eager: 2.06 -> 2.30 ms), so the branches are used from 1024 rows per batch only.
-        self.overlap_min_rows = 1024
+        self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []

@@ -392,7 +392,14 @@ int g2v_dec_rollout_blocks(int B);
  * per workgroup beyond that (no fused weight gradient / loss chaser there: the two queries below return 0).  The persistent
  * one is used whenever it applies; this switch (default 1; 0 = one launch per step; 2 / 3 = persistent with AT LEAST that many
  * tiles per workgroup, which is how the parity tests reach the multi-tile kernels at small batches) exists for A/B
- * measurements, parity tests and the fall-back after a latched fault.  Returns the previous setting. */
+ * measurements, parity tests and the fall-back after a latched fault.  Returns the previous setting.
+ * Round 5: the same switch covers the CLUSTER kernels of the generic dims (H % 4 == 0, H <= 208, D <= 64 -- every shipped YAML's
+ * H = 200 -- at small batch): where the per-step path runs three / four launches per step over (hidden-unit tile x row group)
+ * workgroups, and that grid fits the device with one workgroup per CU (B <= 304 at H = 200), the steps t >= 1 of the forward and the
+ * whole backward are ONE launch each with those workgroups resident: weight rows in registers, the rows a kernel boundary used to
+ * hand over (u / h0 / h1 and the BatchNorm sums forward; dbn rows, BatchNorm-backward sums and the partial products of the
+ * 3H-long contractions backward) exchanged through tagged 8-byte granules in the call's workspace (csrc/dec_rollout.hip:
+ * dec_cluster_fwd_kernel / dec_cluster_bwd_kernel).  Same saved arrays, results equal to summation order, bitwise reproducible. */
 int g2v_dec_rollout_set_persistent(int enable);
 /* which of the two g2v_dec_rollout_fwd / _bwd take for this shape under the current setting: 0 = one launch per time step,
  * R = 1..3 = the persistent pair with R row tiles per workgroup (B % 4 == 0; a ragged last tile where B % 16 != 0) */
