@@ -133,6 +133,7 @@ _SIGS = {
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
     "g2v_gru_seq_set_cluster": (c_int, [c_int]),
     "g2v_dec_rollout_tiles_per_workgroup": (c_int, [c_int, c_int, c_int]),
+    "g2v_dec_rollout_cluster_ok": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),
     "g2v_dec_rollout_fault_flag": (c_int, [c_fp, c_int, c_fp]),
     "g2v_dec_rollout_fuses_loss": (c_int, [c_int, c_int, c_int, c_int]),

@@ -2709,6 +2709,12 @@ extern "C" size_t g2v_dec_rollout_bwd_workspace(int D, int H) {
   const size_t ab = a > b ? a : b;
   return ab > c ? ab : c;
 }
+// 1: g2v_dec_rollout_fwd / _bwd take the small-batch cluster kernels for this shape (T >= 3) under the current setting
+extern "C" int g2v_dec_rollout_cluster_ok(int B, int D, int H) {
+  if (B <= 0 || !persist_enabled() || !dec_cluster_shape(D, H)) return 0;
+  const int nblk = cdiv(B, 16);
+  return (nblk <= DSPLIT_MAX_NBLK && (int64_t)nblk * ((H + 15) >> 4) <= device_cu_count()) ? 1 : 0;
+}
 // 0: one launch per time step; R >= 1: ONE persistent launch each way with R row tiles per workgroup (see g2v.h)
 extern "C" int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H) {
   return (H == 64 && D == 135 && B > 0 && (B % 4) == 0) ? persist_tiles_per_wg(cdiv(B, 16)) : 0;

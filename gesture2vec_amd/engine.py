@@ -192,9 +192,12 @@ class VQVAEEngine:
         self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
         self.tracked_counters = []          # [(int64 device tensor, increment)]: bumped once per train step on the side branch
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
-        # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: at
-        # small batch (a 1-2 ms step of ~300 small launches) that is more than the overlap returns (native VQ-VAE.yml shape,
-        # B = 128, eager: 2.06 -> 2.30 ms), so the branches are used from 1024 rows per batch only.
+        # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: where
+        # the step is ~300 small launches (generic dims on the per-step kernels) that is more than the overlap returns (native
+        # VQ-VAE.yml dims at B = 512: 2.61 -> 2.79 ms), so there the branches are used from 1024 rows per batch only.  Where the
+        # recurrent stages are single launches -- the persistent rollouts at H = 64, the cluster kernels of the generic dims at small
+        # batch (round 5) -- they pay at every batch size: full shape B = 128 1.035 -> 0.970 ms, B = 512 1.136 -> 1.046, native
+        # B = 128 1.352 -> 1.303 (profiles/r05_u_branches_small_batch.log); _branches_ok() asks the library which case a shape is.
         self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
@@ -305,7 +308,10 @@ class VQVAEEngine:
 
     def _branches_ok(self, B: int) -> bool:
         """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""
-        return B >= self.overlap_min_rows
+        if B >= self.overlap_min_rows:
+            return True
+        return bool(self.lib.g2v_dec_rollout_tiles_per_workgroup(B, self.D, self.H) >= 1 or
+                    self.lib.g2v_dec_rollout_cluster_ok(B, self.D, self.H))
 
     # ------------------------------------------------------------------ parameter views
     def view(self, name: str, grad: bool = False) -> torch.Tensor:
@@ -1084,7 +1090,7 @@ class VQVAEEngine:
                          epoch: int = 1, draw_masks: bool = True, dp: bool = False):
         """masks -> forward -> loss -> backward; leaves comm = [grads | cnt | dw] holding this rank's contribution."""
         B = x.shape[0]
-        self._branches_on = B >= self.overlap_min_rows
+        self._branches_on = self._branches_ok(B)
         self._prepared = self._branches_on and (self.overlap & 9) == 9
         try:
             self._train_step_local(x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# A/B at the native shape (B = 128): the step's parallel branches (off below 1024 rows by default) now that the step is 54 launches
+# A/B: the step's parallel branches below 1024 rows per batch (off by default until round 5), several shapes
+for cfg in "--config native" "--config genea --batch 128" "--batch 128" "--batch 512" "--config native --batch 512"; do
 for rep in 1 2; do
-for v in "15 1024" "4 0" "6 0" "15 0"; do
-  set -- $v
-  r=$(G2V_OVERLAP=$1 G2V_OVERLAP_MIN_ROWS=$2 timeout 300 python bench.py --config native --steps 300 --warmup 10 --no-cpu-baseline --no-part-d --sustained 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])")
-  echo "G2V_OVERLAP=$1 MIN_ROWS=$2 $r"
+for v in 1024 0; do
+  r=$(G2V_OVERLAP_MIN_ROWS=$v timeout 300 python bench.py $cfg --steps 300 --warmup 10 --no-cpu-baseline --no-part-d --sustained 0 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'])")
+  echo "$cfg MIN_ROWS=$v $r"
+done
 done
 done

@@ -404,6 +404,9 @@ int g2v_dec_rollout_set_persistent(int enable);
 /* which of the two g2v_dec_rollout_fwd / _bwd take for this shape under the current setting: 0 = one launch per time step,
  * R = 1..3 = the persistent pair with R row tiles per workgroup (B % 4 == 0; a ragged last tile where B % 16 != 0) */
 int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H);
+/* 1: for this shape g2v_dec_rollout_fwd / _bwd run as the small-batch cluster kernels (one launch for the steps t >= 1 of the
+ * forward, one for the backward; needs T >= 3 and a workspace of the queried size) under the current setting, 0: not */
+int g2v_dec_rollout_cluster_ok(int B, int D, int H);
 /* The persistent kernels need every workgroup of their launch resident at once; what a plain launch can check is checked
  * (B / 16 <= CU count, the occupancy query).  What it cannot see -- a CU mask, another tenant or a second persistent launch
  * interleaved on the same device -- ends in a bounded wait running out: the kernel then LATCHES a device-side fault word and
