@@ -178,6 +178,53 @@ def test_latched_fault_reaches_train_iter_and_the_step_is_not_applied(B):
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)
+        lib.g2v_gru_seq_set_cluster(1)
+
+
+def test_latched_fault_on_the_cluster_kernels_of_the_shipped_shape_is_repeated_on_the_per_step_launches():
+    """config/VQ-VAE.yml as shipped (B = 128, H = 200): encoder GRU and decoder rollout run as persistent CLUSTER kernels (round 5),
+    which latch the same fault word.  The same contract as above: a faulted step is not applied, train_iter repeats the iteration
+    on the per-step launches (g2v_dec_rollout_set_persistent(0) + g2v_gru_seq_set_cluster(0)) and training goes on."""
+    import bench
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq
+    lib = _lib.load()
+    saved_cfg = dict(bench.CFG)
+    try:
+        bench.CFG.update({k: v for k, v in bench.CONFIGS["native"].items() if k != "name"})
+        args = bench.model_args()
+        args.loss_l1_weight, args.loss_cont_weight, args.loss_var_weight, args.learning_rate = 5.0, 0.1, 0.5, 5e-4
+        T, D, B = bench.CFG["T"], bench.CFG["D"], 128
+        assert lib.g2v_dec_rollout_cluster_ok(B, D, int(args.hidden_size)) == 1
+        torch.manual_seed(5)
+        net = Autoencoder_VQVAE(args, D, T).to(DEV)
+        net.train(True)
+        optim = FusedClipAdam(net, lr=5e-4, betas=(0.5, 0.999))
+        x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(2)).to(DEV)
+        for _ in range(3):                                  # eager, capture, replay
+            loss, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        eng = net.engine()
+        snap = [t.clone() for t in (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)]
+        assert lib.g2v_dec_rollout_persist_fault(-1) == 1
+        eng.train_step(x, x, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+        torch.cuda.synchronize()
+        for was, now in zip(snap, (eng.flat, eng.codebook, eng.ema_w, eng.ema_cs, eng.bn_rm, eng.bn_rv, eng.step_counter)):
+            assert torch.equal(was, now), "a faulted step must not be applied"
+        loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0
+        assert lib.g2v_dec_rollout_set_persistent(0) == 0 and lib.g2v_gru_seq_set_cluster(0) == 0
+        assert lib.g2v_dec_rollout_cluster_ok(B, D, int(args.hidden_size)) == 0
+        assert abs(loss2["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"]) and not torch.equal(snap[0], eng.flat)
+        assert int(eng.step_counter) == int(snap[6]) + 1, "exactly one step was applied"
+        loss3, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        assert abs(loss3["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"])
+    finally:
+        bench.CFG.clear()
+        bench.CFG.update(saved_cfg)
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_dec_rollout_set_persistent(1)
+        lib.g2v_gru_seq_set_cluster(1)
 
 
 @pytest.mark.parametrize("B", [256, 4096])
@@ -215,6 +262,7 @@ def test_fault_latched_in_the_middle_of_a_step_leaves_the_whole_model_state_unto
             eng.check_faults()
         assert lib.g2v_dec_rollout_persist_fault(0) == 0
         lib.g2v_dec_rollout_set_persistent(1)               # (check_faults switched it off: this test goes on with the same kernels)
+        lib.g2v_gru_seq_set_cluster(1)
         eng.train_step(x, x, **kw)
         torch.cuda.synchronize()
         for n in names:
@@ -222,6 +270,7 @@ def test_fault_latched_in_the_middle_of_a_step_leaves_the_whole_model_state_unto
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)
+        lib.g2v_gru_seq_set_cluster(1)
 
 
 def test_a_faulting_rank_makes_every_rank_skip_the_step_under_data_parallelism():
@@ -265,3 +314,4 @@ def test_a_faulting_rank_makes_every_rank_skip_the_step_under_data_parallelism()
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)
+        lib.g2v_gru_seq_set_cluster(1)
