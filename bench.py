@@ -637,7 +637,9 @@ def main():
                        "launch": ("eager launches" if graph is None else dp_launch if use_dp else "hipGraph replay"),
                        "wgrad": "bf16x3 split products, f32 accumulate" if a.wgrad_bf16x3 else "f32",
                        "graph_branches_mask": int(eng.overlap),
-                       "decoder_rollout": (lambda r: "one launch per time step" if r == 0 else
+                       "decoder_rollout": (lambda r: ("cluster: one persistent launch each way, (hidden-unit tile x row group) workgroups"
+                                                      if lib.g2v_dec_rollout_cluster_ok(B, CFG["D"], CFG["H"]) else "one launch per time step")
+                                           if r == 0 else
                                            f"persistent: one launch each way, {r} row tile(s) of 16 per workgroup")(
                                                int(lib.g2v_dec_rollout_tiles_per_workgroup(B, CFG["D"], CFG["H"]))),
                        "custom_loss": ("chaser kernel co-resident with the forward rollout + the backward rollout's tile load"
@@ -676,6 +678,19 @@ def main():
                 except Exception as e:   # an extra object of the line, never a reason to lose it
                     print(f"[bench] Part d failed ({type(e).__name__}: {e})", file=sys.stderr)
                     out["text2embedding"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if not a.no_part_d and a.config == "full" and world == 1 and not a.force_dp:
+                # the configuration the reference SHIPS (config/VQ-VAE.yml: B = 128, T = 20, D = 40, H = 200), same step, as a child
+                # process of this one (its own model, its own graph): an extra object of the line like Part d
+                try:
+                    import subprocess
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", "native", "--steps", "200", "--warmup", "10",
+                                        "--no-cpu-baseline", "--no-part-d", "--sustained", "0"], capture_output=True, text=True, timeout=240)
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    out["shipped_config"] = {"workload": d["config"]["workload"], "ms_per_step": d["ms_per_step"], "value": d["value"],
+                                             "unit": d["unit"], "steps": d["steps"], "launch": d["config"].get("launch")}
+                except Exception as e:
+                    print(f"[bench] shipped-config run failed ({type(e).__name__}: {e})", file=sys.stderr)
+                    out["shipped_config"] = {"error": f"{type(e).__name__}: {e}"[:300]}
     if use_dp:
         dist.barrier()
         dist.destroy_process_group()
