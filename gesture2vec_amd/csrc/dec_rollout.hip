@@ -1045,7 +1045,9 @@ static size_t dec_cluster_bwd_xch_bytes(int nblk, int H) {
   return ((size_t)2 * nblk * (16 + 2) * Hp + (size_t)nblk * 4 * nt * 16 * Hp) * 8;
 }
 static size_t dec_cluster_bwd_dyn_lds() { return (size_t)4 * 13 /* DCL_KS */ * 64 * sizeof(float4); }
-static size_t dec_cluster_fwd_dyn_lds() { return ((size_t)4 * DCL_KS + (size_t)4 * 4 /* DSPLIT_DT */) * 64 * sizeof(float4); }
+static size_t dec_cluster_fwd_dyn_lds() {      // W_out fragments, partial out-layer products, Dropout(h0) rows, input-side accumulators
+  return ((size_t)4 * DCL_KS + (size_t)4 * 4 /* DSPLIT_DT */ + (size_t)DCL_KS + 3) * 64 * sizeof(float4);
+}
 static bool dec_cluster_shape(int D, int H) { return !(H == 64 && D == 135) && (H & 3) == 0 && H <= 16 * DCL_KS && D <= 64 && H >= 4; }
 extern "C" size_t g2v_dec_rollout_fwd_workspace(int D, int H) {
   size_t x = PX_BYTES;
@@ -1452,7 +1454,7 @@ __device__ __forceinline__ void dcl_sum_partials(const unsigned long long* rec, 
 }
 
 // GRU cell epilogue of the lane's 4 units (the arithmetic of dec_cell_split_kernel); bs: [b_ih r z n, b_hh r z n][q] in LDS
-__device__ __forceinline__ void dcl_cell_epilogue(const f32x4 (&acc)[3], const float4* xch, const float4 (*bs)[4], int lane, int q,
+__device__ __forceinline__ void dcl_cell_epilogue(const float4* xcx, const float4* xch, const float4 (*bs)[4], int lane, int q,
                                                   const float (&hown)[4], float (&hn)[4], float (&gr_)[4], float (&gz_)[4],
                                                   float (&gn_)[4], float (&gh_)[4]) {
   const float4 bi0 = bs[0][q], bi1 = bs[1][q], bi2 = bs[2][q], bh0 = bs[3][q], bh1 = bs[4][q], bh2 = bs[5][q];
@@ -1460,6 +1462,8 @@ __device__ __forceinline__ void dcl_cell_epilogue(const f32x4 (&acc)[3], const f
   const float bhr[4] = {bh0.x, bh0.y, bh0.z, bh0.w}, bhz[4] = {bh1.x, bh1.y, bh1.z, bh1.w}, bhn[4] = {bh2.x, bh2.y, bh2.z, bh2.w};
   const float4 v0 = xch[lane], v1 = xch[64 + lane], v2 = xch[128 + lane];
   const float ah[3][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w}};
+  const float4 c0 = xcx[lane], c1 = xcx[64 + lane], c2 = xcx[128 + lane];
+  const float acc[3][4] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const float rr = sigmoidf_((acc[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
@@ -1474,19 +1478,23 @@ __device__ __forceinline__ void dcl_cell_epilogue(const f32x4 (&acc)[3], const f
 template <int KS>      // k-steps over H the kernel is built for: 13 (H <= 208: the shipped configurations' H = 200)
 __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   __shared__ float st[2 * 16 * DSPLIT_KS];                                        // mean[H], invstd[H] (offsets as in the split kernels)
-  __shared__ __attribute__((aligned(16))) float4 xch2[2][3 * 64];                // [cell] hidden-side accumulators -> the input-side wave
-  __shared__ __attribute__((aligned(16))) float4 xs_u[KS][64];                   // u_t rows as B fragments ([k-step][lane])
+  __shared__ __attribute__((aligned(16))) float4 xch2[2][3 * 64];                // [cell][gate] hidden-side accumulators
+  __shared__ __attribute__((aligned(16))) float4 xs_u[KS][64];                   // u_t rows as B fragments ([k-step][lane]); then a_t
   __shared__ __attribute__((aligned(16))) float4 xs_h0[KS][64];                  // h0 rows
   __shared__ __attribute__((aligned(16))) float4 xs_h1[KS][64];                  // h1 rows
   __shared__ __attribute__((aligned(16))) float4 xfs[DSPLIT_DT][64];             // xin_{t+1} as B fragments, one D tile per wave
   __shared__ __attribute__((aligned(16))) float4 bias_s[2][6][4];                // [cell][b_ih r z n, b_hh r z n][q]: the tile's units
   __shared__ __attribute__((aligned(16))) float4 wp_s[DSPLIT_DT + 1][64];        // pre_linear fragments of the tile + its bias
   __shared__ __attribute__((aligned(16))) float bnw_s[2 * 16 * DSPLIT_KS];       // BatchNorm weight[H], bias[H] (same offsets as st)
-  extern __shared__ __attribute__((aligned(16))) float4 wo_s[];                  // [D tile][KS][64]: W_out fragments; then [wave][D tile][64]:
-                                                                                  // the waves' partial out-layer products
+  extern __shared__ __attribute__((aligned(16))) float4 wo_s[];                  // [D tile][KS][64]: W_out fragments; [wave][D tile][64]: the
+                                                                                  // waves' partial out-layer products; [KS][64]: Dropout(h0_t)
+                                                                                  // rows; [gate][64]: input-side accumulators
   const int T = a.T, B = a.B, D = a.D, H = a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int cell = wave >> 1, side = wave & 1;                  // waves 0 / 1: cell 0 input / hidden side; 2 / 3: cell 1
+  // wave 1 multiplies the hidden side of cell 0 (all three gates of W_hh0); the waves 0, 2, 3 own one GATE each: its rows of W_ih0,
+  // W_ih1 (the two input sides, on the critical path: 52 MFMAs per wave instead of 156 on one) and of W_hh1
+  const bool xw = wave != 1;
+  const int gx = wave == 0 ? 0 : wave - 1;
   const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const int Hp = nt << 4, ndt = (D + 15) >> 4;
@@ -1498,21 +1506,29 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   const g2v_dec_weights& w = a.w;
   const g2v_dec_saved& sv = a.sv;
   // ---- resident operands (zero beyond H: the products below run over all KS k-steps unconditionally) ---------------------------
-  const float* Wc = cell == 0 ? (side == 0 ? w.w_ih0 : w.w_hh0) : (side == 0 ? w.w_ih1 : w.w_hh1);
-  const float* wr = Wc + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * H;
-  float4 wa[3][KS];
+  float4 wreg[3][KS];      // wave 1: W_hh0 gates r, z, n; the others: W_ih0[gx], W_ih1[gx], W_hh1[gx]
   const int drow = 16 * wave + i;                               // this wave's D tile of the out layer: dt = wave
   const bool dok = wave < ndt && drow < D;
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const float* W = xw ? (m == 0 ? w.w_ih0 : (m == 1 ? w.w_ih1 : w.w_hh1)) : w.w_hh0;
+    const float* wr = W + ((int64_t)(xw ? gx : m) * H + 16 * ft + (wrow_ok ? i : 0)) * H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 16 * ks + 4 * q;
+      const bool kok = k < H;
+      wreg[m][ks] = ld4_or_zero(wr + (kok ? k : 0), kok && wrow_ok);
+    }
+  }
 #pragma unroll
   for (int ks = 0; ks < KS; ++ks) {
     const int k = 16 * ks + 4 * q;
     const bool kok = k < H;
-#pragma unroll
-    for (int g = 0; g < 3; ++g) wa[g][ks] = ld4_or_zero(wr + (int64_t)g * H * H + (kok ? k : 0), kok && wrow_ok);
     wo_s[(wave * KS + ks) * 64 + lane] = ld4_or_zero(w.w_out + (int64_t)(dok ? drow : 0) * H + (kok ? k : 0), kok && dok);
   }
   // operands that are read once per step live in LDS (the weight fragments leave no registers for them)
-  if (side == 0 && i == 0) {
+  if ((wave == 0 || wave == 2) && i == 0) {
+    const int cell = wave >> 1;
     const float* bip = cell == 0 ? w.b_ih0 : w.b_ih1;
     const float* bhp = cell == 0 ? w.b_hh0 : w.b_hh1;
 #pragma unroll
@@ -1545,7 +1561,9 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
     bnw_s[f] = w.bn_w[f];
     bnw_s[16 * DSPLIT_KS + f] = w.bn_b[f];
   }
-  float4* yp_s = wo_s + (size_t)4 * KS * 64;      // [wave][D tile][64]
+  float4* yp_s = wo_s + (size_t)4 * KS * 64;        // [wave][D tile][64]
+  float4* xs_x1 = yp_s + (size_t)4 * DSPLIT_DT * 64; // [KS][64]
+  float4* xcx = xs_x1 + (size_t)KS * 64;             // [gate][64]
   // the rows entering step 1, from the arrays the t = 0 launch wrote: as fragments, zeros in rows / columns that do not exist (the
   // sweeps never touch those entries)
   for (int ks = wave; ks < KS; ks += 4) {
@@ -1554,6 +1572,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
     xs_u[ks][lane] = ld4_or_zero(sv.u + (int64_t)b * H + (ok ? k : 0), ok);
     xs_h0[ks][lane] = ld4_or_zero(sv.h0 + (int64_t)b * H + (ok ? k : 0), ok);
     xs_h1[ks][lane] = ld4_or_zero(sv.h1 + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_x1[ks * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const bool drop = a.training && a.keep_l0 && a.p_drop > 0.f;
   const float scale_l0 = 1.0f / (1.0f - a.p_drop);
@@ -1562,27 +1581,51 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, (int)(2u * (unsigned)nblk * prec * 8u), 0x00020000);
   __amdgpu_buffer_rsrc_t r_h0 = __builtin_amdgcn_make_buffer_rsrc(a.xh0, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
   __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(a.xh1, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
-  float hown[4] = {0.f, 0.f, 0.f, 0.f};      // the epilogue waves: this tile's own state entering the step (h0 / h1 of the lane's 4 units)
-  if (side == 0 && rvalid && fok) {
-    const float4 v = *reinterpret_cast<const float4*>((cell == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0);      // index 0 of the state arrays
+  float hown[4] = {0.f, 0.f, 0.f, 0.f};      // waves 0 / 2: this tile's own h0 / h1 entering the step (the lane's 4 units)
+  if ((wave == 0 || wave == 2) && rvalid && fok) {
+    const float4 v = *reinterpret_cast<const float4*>((wave == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0);      // index 0 of the state arrays
     hown[0] = v.x; hown[1] = v.y; hown[2] = v.z; hown[3] = v.w;
   }
-  lds_barrier();      // the LDS operands above are complete (wave 1 multiplies xs_h0 first thing in the step)
+  lds_barrier();      // the LDS operands above are complete
   for (int t = 1; t < T; ++t) {
     const unsigned par_prev = (unsigned)((t - 1) & 1), par = (unsigned)(t & 1), tag = (unsigned)t;
     DCL_STAMP(0);
-    // ---- cell 0: waves 0 (a_t W_ih0) and 1 (h0_{t-1} W_hh0).  The u_t row is swept by the three waves that wait for it anyway, IN
-    // FRONT of the BatchNorm sums: both wait for the same publish of the previous step, and a round at the fabric costs ~1 us ----------
-    f32x4 acc[3];
-#pragma unroll
-    for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // ---- the hidden sides first (their operands have been in LDS since the previous step): wave 1 all of cell 0's, the gate waves
+    // their gate of cell 1's; then the gate waves sweep the u_t row and add up the BatchNorm sums ------------------------------------
     uint32_t kp = 0x01010101u;
-    if (wave != 1 && t > 1)
-      cx_sweep_tiles<(KS + 2) / 3>(r_u, (par_prev * (unsigned)nblk + (unsigned)rg) * rowrec, wave == 0 ? 0 : wave - 1, 3, nt, nrows, H, tag,
-                                   &xs_u[0][0], lane, a.fault);
+    if (!xw) {
+      f32x4 acc[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xs_h0[ks][lane];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          acc[g] = mfma16(wreg[g][ks].x, x4.x, acc[g]);
+          acc[g] = mfma16(wreg[g][ks].y, x4.y, acc[g]);
+          acc[g] = mfma16(wreg[g][ks].z, x4.z, acc[g]);
+          acc[g] = mfma16(wreg[g][ks].w, x4.w, acc[g]);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 3; ++g) xch2[0][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+    } else {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xs_h1[ks][lane];
+        acc = mfma16(wreg[2][ks].x, x4.x, acc);
+        acc = mfma16(wreg[2][ks].y, x4.y, acc);
+        acc = mfma16(wreg[2][ks].z, x4.z, acc);
+        acc = mfma16(wreg[2][ks].w, x4.w, acc);
+      }
+      xch2[1][gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (t > 1)
+        cx_sweep_tiles<(KS + 2) / 3>(r_u, (par_prev * (unsigned)nblk + (unsigned)rg) * rowrec, gx, 3, nt, nrows, H, tag, &xs_u[0][0], lane, a.fault);
+    }
     // ---- BatchNorm statistics of step t: every feature (each workgroup needs the whole input row) -------------------------------
-    // (by the waves 0, 2, 3: wave 1 multiplies the hidden side of cell 0 meanwhile, its operand has been in LDS since the last step)
-    for (int f = (wave == 0 ? lane : (wave - 1) * 64 + lane); f < H && wave != 1; f += 192) {
+    for (int f = gx * 64 + lane; f < H && xw; f += 192) {
       float mean, var;
       if (a.training) {
         float s1, s2;
@@ -1603,33 +1646,15 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
       st[16 * DSPLIT_KS + f] = bn_invstd_(var);
     }
     DCL_STAMP(1);
-    if (wave == 1) {
-      // (hidden side: its operand has been in LDS since the previous step)
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 x4 = xs_h0[ks][lane];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          acc[g] = mfma16(wa[g][ks].x, x4.x, acc[g]);
-          acc[g] = mfma16(wa[g][ks].y, x4.y, acc[g]);
-          acc[g] = mfma16(wa[g][ks].z, x4.z, acc[g]);
-          acc[g] = mfma16(wa[g][ks].w, x4.w, acc[g]);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 3; ++g) xch2[0][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-    }
     lds_barrier();
     DCL_STAMP(2);
-    if (wave == 0) {
-      if (drop && fok && rvalid) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + f0);
-      DCL_STAMP(3);
-      // a_t = ReLU(BN(u_t)) on the fragments (k-step by k-step in front of its products: the VALU work runs under the MFMAs of the
-      // k-step before); the workgroup's own 16 columns (k-step ft) are the ones it writes out
+    // ---- a_t = ReLU(BN(u_t)) in place, a third of the k-steps per gate wave; the workgroup's own 16 columns (k-step ft) are written out ----
+    if (xw) {
+      if (wave == 0 && drop && fok && rvalid) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + f0);
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        float4 xk;
-        {
+      for (int j = 0; j < (KS + 2) / 3; ++j) {
+        const int ks = gx + 3 * j;
+        if (ks < KS) {      // (uniform)
           const int k = 16 * ks + 4 * q;
           const bool kok = k < H;
           const int kk = kok ? k : 0;
@@ -1640,23 +1665,32 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
           v.y = fmaxf((v.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
           v.z = fmaxf((v.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
           v.w = fmaxf((v.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
-          xk = (kok && rvalid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+          xs_u[ks][lane] = (kok && rvalid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
           if (ks == ft && sv.a && rvalid && kok) *reinterpret_cast<float4*>(sv.a + (int64_t)(t - 1) * BH + (int64_t)b * H + k) = v;
         }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          acc[g] = mfma16(wa[g][ks].x, xk.x, acc[g]);
-          acc[g] = mfma16(wa[g][ks].y, xk.y, acc[g]);
-          acc[g] = mfma16(wa[g][ks].z, xk.z, acc[g]);
-          acc[g] = mfma16(wa[g][ks].w, xk.w, acc[g]);
-        }
       }
-      DCL_STAMP(4);
     }
+    lds_barrier();
+    DCL_STAMP(3);
+    // ---- cell 0, input side: gate gx of a_t W_ih0 per gate wave ------------------------------------------------------------------------
+    if (xw) {
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xs_u[ks][lane];
+        acc = mfma16(wreg[0][ks].x, x4.x, acc);
+        acc = mfma16(wreg[0][ks].y, x4.y, acc);
+        acc = mfma16(wreg[0][ks].z, x4.z, acc);
+        acc = mfma16(wreg[0][ks].w, x4.w, acc);
+      }
+      xcx[gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    DCL_STAMP(4);
+    lds_barrier();
     DCL_STAMP(5);
     if (wave == 0 && rvalid && fok) {
       float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
-      dcl_cell_epilogue(acc, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+      dcl_cell_epilogue(xcx, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
 #pragma unroll
       for (int r = 0; r < 4; ++r) xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * scale_l0 : 0.f) : hn[r];
       cx_publish4(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
@@ -1673,75 +1707,61 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
       for (int r = 0; r < 4; ++r) hown[r] = hn[r];
     }
     DCL_STAMP(6);
-    // ---- cell 1: waves 2 (Dropout(h0_t) W_ih1) and 3 (h1_{t-1} W_hh1); the h0_t row is swept by the other three waves ----------------
-    if (wave != 0 && wave != 2) {
-#pragma unroll
-      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    uint32_t km[KS];      // wave 2: the keep flags of its input fragments, requested in front of the exchange
-    if (wave == 2 && drop) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int k = 16 * ks + 4 * q;
-        const bool ok = k < H && rvalid;
-        km[ks] = ok ? *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + k) : 0u;
-      }
-    }
-    if (wave == 3) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const float4 x4 = xs_h1[ks][lane];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          acc[g] = mfma16(wa[g][ks].x, x4.x, acc[g]);
-          acc[g] = mfma16(wa[g][ks].y, x4.y, acc[g]);
-          acc[g] = mfma16(wa[g][ks].z, x4.z, acc[g]);
-          acc[g] = mfma16(wa[g][ks].w, x4.w, acc[g]);
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 3; ++g) xch2[1][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
-    }
-    // (the h0_t row is swept by the waves 1, 2, 3 -- wave 3 behind its products; wave 0, which has just published its tile, only stores)
+    // ---- the h0_t row: swept by the waves 1, 2, 3 (wave 0 has just published its tile and only stores), each of which also leaves
+    // Dropout(h0_t) of its tiles for cell 1's input side (xs_h0 keeps the undropped row: cell 0's hidden side at step t + 1) --------------
     if (wave != 0) {
+      uint32_t km[(KS + 2) / 3];
+#pragma unroll
+      for (int j = 0; j < (KS + 2) / 3; ++j) {
+        const int k = 16 * (wave - 1 + 3 * j) + 4 * q;
+        const bool ok = drop && wave - 1 + 3 * j < KS && k < H && rvalid;
+        km[j] = ok ? *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)(t - 1) * BH + (int64_t)b * H + k) : 0u;
+      }
 #ifdef G2V_STAMPS
       cx_sweep_tiles<(KS + 2) / 3>(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave - 1, 3, nt, nrows, H, tag, &xs_h0[0][0], lane, a.fault,
                                    (t == 5 && blockIdx.x == 0 && blockIdx.y == 0 && wave == 2) ? g2v_stamps + 128 : nullptr);
 #else
       cx_sweep_tiles<(KS + 2) / 3>(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave - 1, 3, nt, nrows, H, tag, &xs_h0[0][0], lane, a.fault);
 #endif
-    }
-    lds_barrier();
-    if (wave == 2) {
+      if (drop) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations execute in order)
 #pragma unroll
-      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      DCL_STAMP(7);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {      // (xs_h0 keeps the undropped row: wave 1 multiplies it at step t + 1)
-        float4 v = xs_h0[ks][lane];
-        {
-          if (drop) {
-            const uint32_t m = km[ks];
+        for (int j = 0; j < (KS + 2) / 3; ++j) {
+          const int ks = wave - 1 + 3 * j;
+          if (ks < KS) {
+            float4 v = xs_h0[ks][lane];
+            const uint32_t m = km[j];
             v.x = (m & 0xffu) ? v.x * scale_l0 : 0.f;
             v.y = ((m >> 8) & 0xffu) ? v.y * scale_l0 : 0.f;
             v.z = ((m >> 16) & 0xffu) ? v.z * scale_l0 : 0.f;
             v.w = ((m >> 24) & 0xffu) ? v.w * scale_l0 : 0.f;
+            xs_x1[ks * 64 + lane] = v;
           }
         }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          acc[g] = mfma16(wa[g][ks].x, v.x, acc[g]);
-          acc[g] = mfma16(wa[g][ks].y, v.y, acc[g]);
-          acc[g] = mfma16(wa[g][ks].z, v.z, acc[g]);
-          acc[g] = mfma16(wa[g][ks].w, v.w, acc[g]);
-        }
       }
-      DCL_STAMP(8);
     }
+    DCL_STAMP(7);
+    lds_barrier();
+    // ---- cell 1, input side: gate gx of Dropout(h0_t) W_ih1 per gate wave ---------------------------------------------------------------
+    if (xw) {
+      const float4* xin1 = drop ? xs_x1 : &xs_h0[0][0];
+      f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 x4 = xin1[ks * 64 + lane];
+        acc = mfma16(wreg[1][ks].x, x4.x, acc);
+        acc = mfma16(wreg[1][ks].y, x4.y, acc);
+        acc = mfma16(wreg[1][ks].z, x4.z, acc);
+        acc = mfma16(wreg[1][ks].w, x4.w, acc);
+      }
+      xcx[gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    DCL_STAMP(8);
+    lds_barrier();
     DCL_STAMP(9);
     if (wave == 2 && rvalid && fok) {
       float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
-      dcl_cell_epilogue(acc, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+      dcl_cell_epilogue(xcx, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
       cx_publish4(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
       *reinterpret_cast<float4*>(sv.h1 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       if (sv.gates1) {
