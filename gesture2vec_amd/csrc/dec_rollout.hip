@@ -1395,8 +1395,14 @@ __global__ __launch_bounds__(64) void dec_out_pre_split_kernel(DecOutPreArgs a, 
     const int sw_ = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 5 && blockIdx.y == 3) ? 1 : -1);                  \
     if ((threadIdx.x & 63) == 0 && sw_ >= 0 && t == 5) g2v_stamps[(sw_ * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#define DCB_STAMP(k)                                                                                                              \
+  do {                                                                                                                            \
+    const int sw_ = (blockIdx.x == 0 && blockIdx.y == 0) ? 0 : ((blockIdx.x == 5 && blockIdx.y == 3) ? 1 : -1);                  \
+    if ((threadIdx.x & 63) == 0 && sw_ >= 0 && t == 5) g2v_stamps[256 + (sw_ * 4 + (threadIdx.x >> 6)) * 16 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define DCL_STAMP(k)
+#define DCB_STAMP(k)
 #endif
 struct DecClFwdArgs {
   const float* target; const uint8_t* keep95; const uint8_t* keep_l0;
@@ -2012,6 +2018,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
     const bool last = t == T - 1;
     const unsigned tag = (unsigned)(T - t), par = (unsigned)(t & 1), par_next = (unsigned)((t + 1) & 1);
     const bool feedback = a.conditioned && t >= a.n_pre;
+    DCB_STAMP(0);
     // ---- requests that do not depend on this step's exchanges ------------------------------------------------------------------
     // every wave: its k-steps of u_t (ks = wave, wave + 4, ...) for the du stage; waves dt < ndt: dy_t / keep flags of their D tile
     float4 uq[(KS + 3) / 4];
@@ -2064,7 +2071,9 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
         acc_bw += s2;      // (d gamma / d beta accumulate over the steps, in step order: workgroup (0, 0) writes them at the end)
         acc_bb += s1;
       }
+      DCB_STAMP(1);
       lds_barrier();
+      DCB_STAMP(2);
       const float invB = 1.0f / (float)B;
 #pragma unroll
       for (int j = 0; j < (KS + 3) / 4; ++j) {
@@ -2092,6 +2101,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
         }
       }
       lds_barrier();
+      DCB_STAMP(3);
     }
     if (t == 0) break;      // (the last dy stage forms du_0 only)
     // ---- dy_t: + keep95 * 20 * (du_t W_pre^T) where the step's input was its own previous output; as the B fragments of S2 ----------
@@ -2116,7 +2126,9 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
       }
       if (wave < DSPLIT_DT) xs_dy[wave][lane] = make_float4(dyv[0], dyv[1], dyv[2], dyv[3]);
     }
+    DCB_STAMP(4);
     lds_barrier();
+    DCB_STAMP(5);
     // ---- cell 1 (wave 0): dh1 = carry1 + dy_t W_out restricted to the tile; its gate gradients --------------------------------------
     float direct[4] = {0.f, 0.f, 0.f, 0.f};
     if (wave == 0) {
@@ -2148,6 +2160,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
         *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
       }
     }
+    DCB_STAMP(6);
     // ---- the two stages with a partial-product exchange: c = 1 (cell 1's W_hh1 / W_ih1), then c = 0 -----------------------------------
 #pragma unroll
     for (int c = 1; c >= 0; --c) {
@@ -2174,10 +2187,13 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
           }
         }
       }
+      DCB_STAMP(c == 1 ? 7 : 11);
       // wave w adds the partial products of matrix w & 1 from the producers w >> 1, (w >> 1) + 2, ... for this tile
       cx_sweep_tile_sum<NPW>(r_q, q_rg + (unsigned)((1 - c) * 2 + (wave & 1)) * (unsigned)nt * rowrec, rowrec, wave >> 1, 2, nt, ft, nrows, H, tag,
                              &dsum[wave][0], lane, a.fault);
+      DCB_STAMP(c == 1 ? 8 : 12);
       lds_barrier();
+      DCB_STAMP(c == 1 ? 9 : 13);
       if (wave == 0) {
         const float4 h_a = dsum[0][lane], h_b = dsum[2][lane], i_a = dsum[1][lane], i_b = dsum[3][lane];
         const float shh[4] = {h_a.x + h_b.x, h_a.y + h_b.y, h_a.z + h_b.z, h_a.w + h_b.w};
@@ -2235,7 +2251,9 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
         }
       }
     }
+    DCB_STAMP(14);
     lds_barrier();      // (xs_g / dsum / st of this step are done with)
+    DCB_STAMP(15);
   }
   // ---- the gradient of the initial states, d gamma / d beta ---------------------------------------------------------------------
   if (wave == 0 && own) {

@@ -38,3 +38,10 @@ for wg in range(2):
 d = [buf[128 + k] for k in range(16)]
 print("h0 sweep of wg 0 / wave 2: start", d[0] - base0 if (base0 := min(buf[w * 16] for w in range(4))) else 0, "poll rounds", d[15],
       "round completion ticks since sweep start:", [(v - d[0]) for v in d[1:15] if v])
+print("backward (dec_cluster_bwd_kernel), step t = 5: 0 top | 1 dbn swept + sums | 2 barrier | 3 du done | 4 dy stage | 5 barrier | 6 cell 1 (wave 0) | "
+      "7 pair-1 products published | 8 swept | 9 barrier | 11 pair-0 products | 12 swept | 13 barrier | 14 element-wise done | 15 end")
+for wg in range(2):
+    base = min(buf[256 + (wg * 4 + w) * 16] for w in range(4))
+    for w in range(4):
+        st = [buf[256 + (wg * 4 + w) * 16 + k] for k in range(16)]
+        print("bwd wg", wg, "wave", w, [(v - base) if v else None for v in st])
