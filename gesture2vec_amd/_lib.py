@@ -182,6 +182,7 @@ _SIGS = {
     "g2v_attn_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int,
                              c_fp, c_sz, c_fp]),
     "g2v_attn_code_rollout_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "g2v_attn_code_rollout_cluster_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "g2v_attn_code_rollout_blocks": (c_int, [c_int]),
     "g2v_attn_code_rollout_fwd_workspace": (c_sz, [c_int, c_int, c_int]),
     "g2v_attn_code_rollout_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, C.POINTER(CodeDecWeights), C.POINTER(CodeDecSaved), c_fp, c_fp, c_f,

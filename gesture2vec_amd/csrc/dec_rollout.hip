@@ -996,6 +996,7 @@ extern "C" int g2v_read_spans(unsigned long long* out) {
 }
 #endif
 
+int g2v_internal_persist_enabled() { return g_persist != 0 ? 1 : 0; }      // (t2e_rollout.hip: the code decoder's cluster kernel)
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 extern "C" int g2v_dec_rollout_set_persistent(int enable) {

@@ -24,6 +24,7 @@
 #include <stdlib.h>
 
 #include "gru_cells.hpp"
+#include "dec_persist.hpp"      // the cluster exchange primitives (cx_*); not the fault latch
 
 namespace g2v {
 
@@ -838,6 +839,596 @@ __global__ __launch_bounds__(CT_NTHR) void code_step_bwd_att_kernel(CodeBwdArgs 
 
 }  // namespace g2v
 
+// ====================================================================================================================
+// Small batch (round 5): the whole greedy FORWARD rollout without attention as ONE persistent launch of (hidden-unit tile x row
+// group) workgroups -- the cluster scheme of the pose decoder (dec_rollout.hip: dec_cluster_fwd_kernel; protocol in
+// dec_persist.hpp) for the code decoder.  At the reference's B = 128 the per-operator path runs ~9 launches per decode step.
+// Per step and workgroup: hidden sides (operands in LDS since the step before) | sweep the u_t row + the BatchNorm sums of every
+// row group | a_t = ReLU(BN(u_t)) in LDS | cell 0, input side split by gate over three waves | h0 exchange (+ inter-layer dropout) |
+// cell 1 | h1 exchange | logits: the workgroup's K tiles (tile, tile + NT, tile + 2 NT), k-steps split over the four waves | the row
+// argmax: per-workgroup best (value, index) pairs exchanged, every workgroup reduces them in the same order (lowest index among
+// equals, as torch.argmax) | head of the next step: id -> Embedding * keep * 2 gathered by every workgroup, its pre_linear tile and
+// BatchNorm partial sums published.  Writes exactly the arrays g2v_attn_code_rollout_fwd's step kernels write, so either backward
+// (the fused BPTT of this file, the per-operator chain of rollout_t2e.py) runs on them.  H <= 208, K <= 48 NT, no attention.
+// ====================================================================================================================
+namespace g2v {
+constexpr int CCL_KS = 13;          // k-steps over H (H <= 208)
+constexpr int CCL_KT = 3;           // K tiles of the out layer per workgroup
+struct CodeClArgs {
+  const int64_t* codes; const float* h_init; const uint8_t* keep_emb; const uint8_t* keep_l0;
+  g2v_code_dec_weights w; g2v_code_dec_saved sv;
+  unsigned long long* xu;      // [2][nblk] row records: u rows
+  unsigned long long* xp;      // [2][nblk][2][Hp]: BatchNorm partial sums
+  unsigned long long* xh0;     // [2][nblk] row records
+  unsigned long long* xh1;     // [2][nblk] row records
+  unsigned long long* xa;      // [2][nblk][NT][16][2]: per-workgroup best (value, index) of every row
+  unsigned* fault;
+  int S1, B, H, K, n_pre, training;
+  float p_drop;
+};
+__device__ __forceinline__ void ccl_publish4(__amdgpu_buffer_rsrc_t rr, unsigned granule, const float* v, unsigned tag) {
+  u32x4 a, b;
+  a[0] = __float_as_uint(v[0]); a[1] = tag; a[2] = __float_as_uint(v[1]); a[3] = tag;
+  b[0] = __float_as_uint(v[2]); b[1] = tag; b[2] = __float_as_uint(v[3]); b[3] = tag;
+  px_st(rr, granule * 8u, a);
+  px_st(rr, granule * 8u + 16u, b);
+}
+// one granule {value, tag}: poll until the tag is there
+__device__ __forceinline__ unsigned ccl_wait_granule(const unsigned long long* p, unsigned tag, unsigned* fault) {
+  unsigned spins = 0;
+  for (;;) {
+    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(v >> 32) == tag) return (unsigned)v;
+    __builtin_amdgcn_s_sleep(1);
+    if (cx_give_up(spins, fault)) return (unsigned)v;
+  }
+}
+// column f of the per-row-group partial sums [nblk][2][Hp] (granules), summed over the row groups in ascending order
+__device__ __forceinline__ void ccl_sum_partials(const unsigned long long* rec, int nblk, int Hp, int f, unsigned tag, unsigned* fault,
+                                                 float& s1, float& s2) {
+  s1 = 0.f; s2 = 0.f;
+  for (int k0 = 0; k0 < nblk; k0 += 8) {
+    unsigned long long a[8], b[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const bool ok = k0 + j < nblk;
+      const unsigned long long* p = rec + (size_t)(ok ? k0 + j : 0) * 2 * Hp + f;
+      a[j] = ok ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+      b[j] = ok ? __hip_atomic_load(p + Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32);
+    }
+    unsigned spins = 0;
+    for (;;) {
+      bool ok = true;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ok &= (unsigned)(a[j] >> 32) == tag && (unsigned)(b[j] >> 32) == tag;
+      if (ok) break;
+      __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const unsigned long long* p = rec + (size_t)(k0 + j < nblk ? k0 + j : 0) * 2 * Hp + f;
+        if ((unsigned)(a[j] >> 32) != tag) a[j] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(b[j] >> 32) != tag) b[j] = __hip_atomic_load(p + Hp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (cx_give_up(spins, fault)) break;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      s1 += __uint_as_float((unsigned)a[j]);
+      s2 += __uint_as_float((unsigned)b[j]);
+    }
+  }
+}
+// GRU cell epilogue of the lane's 4 units from the six accumulators in LDS (the arithmetic of gru_cell_fwd_epilogue)
+__device__ __forceinline__ void ccl_cell_epilogue(const float4* xcx, const float4* xch, const float4 (*bs)[4], int lane, int q,
+                                                  const float (&hown)[4], float (&hn)[4], float (&gr_)[4], float (&gz_)[4],
+                                                  float (&gn_)[4], float (&gh_)[4]) {
+  const float4 bi0 = bs[0][q], bi1 = bs[1][q], bi2 = bs[2][q], bh0 = bs[3][q], bh1 = bs[4][q], bh2 = bs[5][q];
+  const float bir[4] = {bi0.x, bi0.y, bi0.z, bi0.w}, biz[4] = {bi1.x, bi1.y, bi1.z, bi1.w}, bin[4] = {bi2.x, bi2.y, bi2.z, bi2.w};
+  const float bhr[4] = {bh0.x, bh0.y, bh0.z, bh0.w}, bhz[4] = {bh1.x, bh1.y, bh1.z, bh1.w}, bhn[4] = {bh2.x, bh2.y, bh2.z, bh2.w};
+  const float4 v0 = xch[lane], v1 = xch[64 + lane], v2 = xch[128 + lane];
+  const float ah[3][4] = {{v0.x, v0.y, v0.z, v0.w}, {v1.x, v1.y, v1.z, v1.w}, {v2.x, v2.y, v2.z, v2.w}};
+  const float4 c0 = xcx[lane], c1 = xcx[64 + lane], c2 = xcx[128 + lane];
+  const float acc[3][4] = {{c0.x, c0.y, c0.z, c0.w}, {c1.x, c1.y, c1.z, c1.w}, {c2.x, c2.y, c2.z, c2.w}};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float rr = sigmoidf_((acc[0][r] + bir[r]) + (ah[0][r] + bhr[r]));
+    const float zz = sigmoidf_((acc[1][r] + biz[r]) + (ah[1][r] + bhz[r]));
+    const float ghn = ah[2][r] + bhn[r];
+    const float nn = tanhf_((acc[2][r] + bin[r]) + rr * ghn);
+    hn[r] = (1.0f - zz) * nn + zz * hown[r];
+    gr_[r] = rr; gz_[r] = zz; gn_[r] = nn; gh_[r] = ghn;
+  }
+}
+
+__global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
+  constexpr int KS = CCL_KS;
+  __shared__ float st[2 * 256];                                                   // mean[H], invstd[H]
+  __shared__ float bnw_s[2 * 256];                                                // BatchNorm weight[H], bias[H]
+  __shared__ __attribute__((aligned(16))) float4 xch2[2][3 * 64];                // [cell][gate] hidden-side accumulators
+  __shared__ __attribute__((aligned(16))) float4 xcx[3 * 64];                    // [gate] input-side accumulators
+  __shared__ __attribute__((aligned(16))) float4 xs_u[KS][64];                   // u_t rows as B fragments; a_t; then e_{t+1}
+  __shared__ __attribute__((aligned(16))) float4 xs_h0[KS][64];
+  __shared__ __attribute__((aligned(16))) float4 xs_h1[KS][64];
+  __shared__ __attribute__((aligned(16))) float4 bias_s[2][6][4];
+  __shared__ __attribute__((aligned(16))) float4 up_s[4][64];                    // the waves' partial pre_linear products
+  __shared__ float bv_s[4][16];                                                   // row argmax: per K tile best value / index
+  __shared__ int bk_s[4][16];
+  __shared__ int ids_l[16];
+  extern __shared__ __attribute__((aligned(16))) float4 dyn_s[];                 // W_out fragments [KT][KS][64] | W_pre fragments [KS][64] |
+                                                                                  // partial logits [4][KT][64] | Dropout(h0) rows [KS][64]
+  const int S1 = a.S1, B = a.B, H = a.H, K = a.K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const bool xw = wave != 1;
+  const int gx = wave == 0 ? 0 : wave - 1;
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const int Hp = nt << 4, nkt = (K + 15) >> 4;
+  const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
+  const int b = b0 + (rvalid ? i : 0);
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H;
+  const int64_t BH = (int64_t)B * H;
+  const g2v_code_dec_weights& w = a.w;
+  const g2v_code_dec_saved& sv = a.sv;
+  const bool training = a.training != 0;
+  const int npre = max(1, min(a.n_pre, S1));
+  float4* wo_s = dyn_s;                                   // [KT][KS][64]
+  float4* wp_s = wo_s + (size_t)CCL_KT * KS * 64;         // [KS][64]
+  float4* yp_s = wp_s + (size_t)KS * 64;                  // [4][KT][64]
+  float4* xs_x1 = yp_s + (size_t)4 * CCL_KT * 64;         // [KS][64]
+  // ---- resident: wave 1 W_hh0 (three gates); the gate waves W_ih0[gx], W_ih1[gx], W_hh1[gx] -----------------------------------------
+  float4 wreg[3][KS];
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const float* W = xw ? (m == 0 ? w.w_ih0 : (m == 1 ? w.w_ih1 : w.w_hh1)) : w.w_hh0;
+    const float* wr = W + ((int64_t)(xw ? gx : m) * H + 16 * ft + (wrow_ok ? i : 0)) * H;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int k = 16 * ks + 4 * q;
+      const bool kok = k < H;
+      wreg[m][ks] = ld4_or_zero(wr + (kok ? k : 0), kok && wrow_ok);
+    }
+  }
+  // LDS operands: W_out rows of the workgroup's K tiles (wave j < KT fills tile j), W_pre rows of the tile (wave 3), biases
+  for (int ks = 0; ks < KS; ++ks) {
+    const int k = 16 * ks + 4 * q;
+    const bool kok = k < H;
+    if (wave < CCL_KT) {
+      const int kt = ft + nt * wave, row = 16 * kt + i;
+      const bool ok = kt < nkt && row < K && kok;
+      wo_s[(wave * KS + ks) * 64 + lane] = ld4_or_zero(w.w_out + (int64_t)(ok ? row : 0) * H + (kok ? k : 0), ok);
+    } else {
+      wp_s[ks * 64 + lane] = ld4_or_zero(w.w_pre + (int64_t)(16 * ft + (wrow_ok ? i : 0)) * H + (kok ? k : 0), kok && wrow_ok);
+    }
+  }
+  if ((wave == 0 || wave == 2) && i == 0) {
+    const int cell = wave >> 1;
+    const float* bip = cell == 0 ? w.b_ih0 : w.b_ih1;
+    const float* bhp = cell == 0 ? w.b_hh0 : w.b_hh1;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      bias_s[cell][g][q] = ld4_or_zero(bip + g * H + (fok ? f0 : 0), fok);
+      bias_s[cell][3 + g][q] = ld4_or_zero(bhp + g * H + (fok ? f0 : 0), fok);
+    }
+  }
+  for (int f = tid; f < 256; f += 256) {
+    bnw_s[f] = f < H ? w.bn_w[f] : 0.f;
+    bnw_s[256 + f] = f < H ? w.bn_b[f] : 0.f;
+  }
+  const float4 bp4 = ld4_or_zero(w.b_pre + (fok ? f0 : 0), fok);      // (wave 0's pre_linear epilogue)
+  for (int ks = wave; ks < KS; ks += 4) {
+    const int k = 16 * ks + 4 * q;
+    const bool ok = k < H && rvalid;
+    xs_h0[ks][lane] = ld4_or_zero(a.h_init + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_h1[ks][lane] = ld4_or_zero(a.h_init + BH + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_u[ks][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xs_x1[ks * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  // slot 0 of the saved states = the initial states (the tile's own 16 x 16 block)
+  float hown[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((wave == 0 || wave == 2) && rvalid && fok) {
+    const float4 v = *reinterpret_cast<const float4*>(a.h_init + (wave == 0 ? 0 : BH) + (int64_t)b * H + f0);
+    hown[0] = v.x; hown[1] = v.y; hown[2] = v.z; hown[3] = v.w;
+    *reinterpret_cast<float4*>((wave == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0) = v;
+  }
+  const bool drop = training && a.keep_l0 && a.p_drop > 0.f;
+  const bool edrop = training && a.keep_emb != nullptr;
+  const float scale_l0 = 1.0f / (1.0f - a.p_drop);
+  const unsigned rowrec = 256u * (unsigned)nt, prec = 2u * (unsigned)Hp, arec = (unsigned)nt * 32u;
+  __amdgpu_buffer_rsrc_t r_u = __builtin_amdgcn_make_buffer_rsrc(a.xu, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, (int)(2u * (unsigned)nblk * prec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_h0 = __builtin_amdgcn_make_buffer_rsrc(a.xh0, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(a.xh1, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  if (tid < 16) {      // the code fed at step 0 (always from `codes`)
+    int id = 0;
+    if (tid < nrows) {
+      const int64_t c = a.codes[b0 + tid];
+      id = (c >= 0 && c < K) ? (int)c : 0;
+      if (ft == 0) sv.ids[b0 + tid] = id;
+    }
+    ids_l[tid] = id;
+  }
+  lds_barrier();
+  for (int t = -1; t < S1; ++t) {
+    // iteration t = tail of step t (t >= 0) + head of step t + 1 (t + 1 < S1); t = -1: the head of step 0 only
+    const unsigned tag = (unsigned)(t + 1);      // every record of step t carries tag t + 1 (u_t was published by the head of step t)
+    if (t >= 0) {
+      const unsigned ppar = (unsigned)(t & 1);      // parity of every record of step t: u, BatchNorm sums, h0, h1, argmax
+      // ---- hidden sides; sweep of the u_t row; BatchNorm statistics ------------------------------------------------------------------
+      uint32_t kp = 0x01010101u;
+      if (!xw) {
+        f32x4 acc[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 x4 = xs_h0[ks][lane];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            acc[g] = mfma16(wreg[g][ks].x, x4.x, acc[g]);
+            acc[g] = mfma16(wreg[g][ks].y, x4.y, acc[g]);
+            acc[g] = mfma16(wreg[g][ks].z, x4.z, acc[g]);
+            acc[g] = mfma16(wreg[g][ks].w, x4.w, acc[g]);
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) xch2[0][g * 64 + lane] = make_float4(acc[g][0], acc[g][1], acc[g][2], acc[g][3]);
+      } else {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 x4 = xs_h1[ks][lane];
+          acc = mfma16(wreg[2][ks].x, x4.x, acc);
+          acc = mfma16(wreg[2][ks].y, x4.y, acc);
+          acc = mfma16(wreg[2][ks].z, x4.z, acc);
+          acc = mfma16(wreg[2][ks].w, x4.w, acc);
+        }
+        xch2[1][gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        cx_sweep_tiles<(KS + 2) / 3>(r_u, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, gx, 3, nt, nrows, H, tag, &xs_u[0][0], lane, a.fault);
+      }
+      for (int f = gx * 64 + lane; f < H && xw; f += 192) {
+        float mean, invstd;
+        if (training) {
+          float s1, s2;
+          ccl_sum_partials(a.xp + (size_t)ppar * nblk * prec, nblk, Hp, f, tag, a.fault, s1, s2);
+          const float mv = s1 / (float)B;
+          const float var = fmaxf(s2 / (float)B - mv * mv, 0.f);   // biased batch variance
+          mean = mv + w.b_pre[f];
+          invstd = bn_invstd_(var);
+          if (ft == 0 && rg == 0) {
+            sv.bn_stats[(int64_t)t * 2 * H + f] = mean;
+            sv.bn_stats[(int64_t)t * 2 * H + H + f] = invstd;
+            // running statistics: momentum 0.1, unbiased variance; one update per decode step, in step order; not behind a latched fault
+            if (a.fault == nullptr || __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+              const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
+              w.bn_running_mean[f] = 0.9f * w.bn_running_mean[f] + 0.1f * mean;
+              w.bn_running_var[f] = 0.9f * w.bn_running_var[f] + 0.1f * unb;
+            }
+          }
+        } else {
+          mean = w.bn_running_mean[f];
+          invstd = bn_invstd_(w.bn_running_var[f]);
+        }
+        st[f] = mean;
+        st[256 + f] = invstd;
+      }
+      lds_barrier();
+      // ---- a_t = ReLU(BN(u_t)) in place, a third of the k-steps per gate wave ----------------------------------------------------------
+      if (xw) {
+        if (wave == 0 && drop && fok && rvalid) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)t * BH + (int64_t)b * H + f0);
+#pragma unroll
+        for (int j = 0; j < (KS + 2) / 3; ++j) {
+          const int ks = gx + 3 * j;
+          if (ks < KS) {
+            const int k = 16 * ks + 4 * q;
+            const bool kok = k < H;
+            const int kk = kok ? k : 0;
+            const float4 g4 = *reinterpret_cast<const float4*>(bnw_s + kk), b4 = *reinterpret_cast<const float4*>(bnw_s + 256 + kk);
+            const float4 m4 = *reinterpret_cast<const float4*>(st + kk), i4 = *reinterpret_cast<const float4*>(st + 256 + kk);
+            float4 v = xs_u[ks][lane];
+            v.x = fmaxf((v.x - m4.x) * i4.x * g4.x + b4.x, 0.f);
+            v.y = fmaxf((v.y - m4.y) * i4.y * g4.y + b4.y, 0.f);
+            v.z = fmaxf((v.z - m4.z) * i4.z * g4.z + b4.z, 0.f);
+            v.w = fmaxf((v.w - m4.w) * i4.w * g4.w + b4.w, 0.f);
+            xs_u[ks][lane] = (kok && rvalid) ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ks == ft && sv.a && rvalid && kok) *reinterpret_cast<float4*>(sv.a + (int64_t)t * BH + (int64_t)b * H + k) = v;
+          }
+        }
+      }
+      lds_barrier();
+      // ---- cell 0 -------------------------------------------------------------------------------------------------------------------------
+      if (xw) {
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 x4 = xs_u[ks][lane];
+          acc = mfma16(wreg[0][ks].x, x4.x, acc);
+          acc = mfma16(wreg[0][ks].y, x4.y, acc);
+          acc = mfma16(wreg[0][ks].z, x4.z, acc);
+          acc = mfma16(wreg[0][ks].w, x4.w, acc);
+        }
+        xcx[gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+      lds_barrier();
+      if (wave == 0 && rvalid && fok) {
+        float hn[4], xd[4], gr_[4], gz_[4], gn_[4], gh_[4];
+        ccl_cell_epilogue(xcx, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * scale_l0 : 0.f) : hn[r];
+        cx_publish4(r_h0, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+        *reinterpret_cast<float4*>(sv.h0 + (int64_t)(t + 1) * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (drop && sv.x1) *reinterpret_cast<float4*>(sv.x1 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
+        if (sv.gates0) {
+          float* go = sv.gates0 + (int64_t)t * 4 * BH + (int64_t)b * 4 * H + f0;
+          *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+          *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+          *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+          *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hown[r] = hn[r];
+      }
+      // ---- h0_{t+1} row: waves 1, 2, 3 sweep (wave 0 has just published), each leaves Dropout of its tiles for cell 1 ------------------
+      if (wave != 0) {
+        uint32_t km[(KS + 2) / 3];
+#pragma unroll
+        for (int j = 0; j < (KS + 2) / 3; ++j) {
+          const int k = 16 * (wave - 1 + 3 * j) + 4 * q;
+          const bool ok = drop && wave - 1 + 3 * j < KS && k < H && rvalid;
+          km[j] = ok ? *reinterpret_cast<const uint32_t*>(a.keep_l0 + (int64_t)t * BH + (int64_t)b * H + k) : 0u;
+        }
+        cx_sweep_tiles<(KS + 2) / 3>(r_h0, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, wave - 1, 3, nt, nrows, H, tag, &xs_h0[0][0], lane, a.fault);
+        if (drop) {
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+          for (int j = 0; j < (KS + 2) / 3; ++j) {
+            const int ks = wave - 1 + 3 * j;
+            if (ks < KS) {
+              float4 v = xs_h0[ks][lane];
+              const uint32_t m = km[j];
+              v.x = (m & 0xffu) ? v.x * scale_l0 : 0.f;
+              v.y = ((m >> 8) & 0xffu) ? v.y * scale_l0 : 0.f;
+              v.z = ((m >> 16) & 0xffu) ? v.z * scale_l0 : 0.f;
+              v.w = ((m >> 24) & 0xffu) ? v.w * scale_l0 : 0.f;
+              xs_x1[ks * 64 + lane] = v;
+            }
+          }
+        }
+      }
+      lds_barrier();
+      // ---- cell 1 -------------------------------------------------------------------------------------------------------------------------
+      if (xw) {
+        const float4* xin1 = drop ? xs_x1 : &xs_h0[0][0];
+        f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const float4 x4 = xin1[ks * 64 + lane];
+          acc = mfma16(wreg[1][ks].x, x4.x, acc);
+          acc = mfma16(wreg[1][ks].y, x4.y, acc);
+          acc = mfma16(wreg[1][ks].z, x4.z, acc);
+          acc = mfma16(wreg[1][ks].w, x4.w, acc);
+        }
+        xcx[gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      }
+      lds_barrier();
+      if (wave == 2 && rvalid && fok) {
+        float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
+        ccl_cell_epilogue(xcx, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
+        cx_publish4(r_h1, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+        *reinterpret_cast<float4*>(sv.h1 + (int64_t)(t + 1) * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (sv.gates1) {
+          float* go = sv.gates1 + (int64_t)t * 4 * BH + (int64_t)b * 4 * H + f0;
+          *reinterpret_cast<float4*>(go) = make_float4(gr_[0], gr_[1], gr_[2], gr_[3]);
+          *reinterpret_cast<float4*>(go + H) = make_float4(gz_[0], gz_[1], gz_[2], gz_[3]);
+          *reinterpret_cast<float4*>(go + 2 * H) = make_float4(gn_[0], gn_[1], gn_[2], gn_[3]);
+          *reinterpret_cast<float4*>(go + 3 * H) = make_float4(gh_[0], gh_[1], gh_[2], gh_[3]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hown[r] = hn[r];
+      }
+      // ---- logits_t = out(h1_{t+1}): the row is swept by the waves 0, 1, 3; every wave multiplies its k-steps of the K tiles ------------
+      if (wave != 2)
+        cx_sweep_tiles<(KS + 2) / 3>(r_h1, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, wave == 3 ? 2 : wave, 3, nt, nrows, H, tag, &xs_h1[0][0],
+                                     lane, a.fault);
+      lds_barrier();
+      {
+        f32x4 yq[CCL_KT];
+#pragma unroll
+        for (int j = 0; j < CCL_KT; ++j) yq[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < (KS + 3) / 4; ++jj) {
+          const int ks = wave + 4 * jj;
+          if (ks < KS) {
+            const float4 x4 = xs_h1[ks][lane];
+#pragma unroll
+            for (int j = 0; j < CCL_KT; ++j) {
+              const float4 w4 = wo_s[(j * KS + ks) * 64 + lane];
+              yq[j] = mfma16(w4.x, x4.x, yq[j]);
+              yq[j] = mfma16(w4.y, x4.y, yq[j]);
+              yq[j] = mfma16(w4.z, x4.z, yq[j]);
+              yq[j] = mfma16(w4.w, x4.w, yq[j]);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < CCL_KT; ++j) yp_s[(wave * CCL_KT + j) * 64 + lane] = make_float4(yq[j][0], yq[j][1], yq[j][2], yq[j][3]);
+      }
+      lds_barrier();
+      if (wave < CCL_KT) {
+        // wave j: K tile ft + nt j -- the four partial products added in wave order, + bias, stored; the tile's best (value, index) per row
+        const int kt = ft + nt * wave, k0 = 16 * kt + 4 * q;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw) {
+          const float4 p4 = yp_s[(pw * CCL_KT + wave) * 64 + lane];
+          v[0] += p4.x; v[1] += p4.y; v[2] += p4.z; v[3] += p4.w;
+        }
+        float bv = -INFINITY;
+        int bk = 0x7fffffff;
+        if (kt < nkt && k0 < K) {      // (K % 4 == 0: four columns or none)
+          const float4 bo = *reinterpret_cast<const float4*>(w.b_out + k0);
+          v[0] += bo.x; v[1] += bo.y; v[2] += bo.z; v[3] += bo.w;
+          if (rvalid) *reinterpret_cast<float4*>(sv.logits + ((int64_t)t * B + b) * K + k0) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (v[r] > bv) { bv = v[r]; bk = k0 + r; }      // (ascending index: the first of equals stays)
+        }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float v2 = __shfl_xor(bv, o);
+          const int k2 = __shfl_xor(bk, o);
+          if (v2 > bv || (v2 == bv && k2 < bk)) { bv = v2; bk = k2; }
+        }
+        if (q == 0) { bv_s[wave][i] = bv; bk_s[wave][i] = bk; }
+      }
+      lds_barrier();
+      if (t + 1 < S1) {
+        // ---- the row argmax over all K: every workgroup publishes its best pair per row, then reduces all NT pairs in the same order ----
+        if (wave == 0 && t + 1 >= npre) {
+          unsigned long long* rec = a.xa + ((size_t)ppar * nblk + rg) * arec;
+          if (lane < 16) {
+            float v = bv_s[0][lane];
+            int k = bk_s[0][lane];
+#pragma unroll
+            for (int j = 1; j < CCL_KT; ++j) {
+              const float v2 = bv_s[j][lane];
+              const int k2 = bk_s[j][lane];
+              if (v2 > v || (v2 == v && k2 < k)) { v = v2; k = k2; }
+            }
+            const unsigned long long g0 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+            const unsigned long long g1 = ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k;
+            __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2 + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+          // lane (row i, group q): the pairs of the producers q, q + 4, ... of row i, all requested at once; then over the four groups.
+          // (value descending, index ascending) is a total order: the result does not depend on the order of the comparisons
+          unsigned long long gv[4], gk[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int p = q + 4 * j;
+            const unsigned long long* pp = rec + ((size_t)(p < nt ? p : 0) * 16 + i) * 2;
+            gv[j] = p < nt ? __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32) | 0xff800000ull;
+            gk[j] = p < nt ? __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)tag << 32) | 0x7fffffffull;
+          }
+          unsigned spins = 0;
+          for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ok &= (unsigned)(gv[j] >> 32) == tag && (unsigned)(gk[j] >> 32) == tag;
+            if (ok) break;
+            __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int p = q + 4 * j;
+              const unsigned long long* pp = rec + ((size_t)(p < nt ? p : 0) * 16 + i) * 2;
+              if ((unsigned)(gv[j] >> 32) != tag) gv[j] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if ((unsigned)(gk[j] >> 32) != tag) gk[j] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (cx_give_up(spins, a.fault)) break;
+          }
+          float best = -INFINITY;
+          int bidx = 0x7fffffff;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float v2 = __uint_as_float((unsigned)gv[j]);
+            const int k2 = (int)(unsigned)gk[j];
+            if (v2 > best || (v2 == best && k2 < bidx)) { best = v2; bidx = k2; }
+          }
+#pragma unroll
+          for (int o = 16; o < 64; o <<= 1) {
+            const float v2 = __shfl_xor(best, o);
+            const int k2 = __shfl_xor(bidx, o);
+            if (v2 > best || (v2 == best && k2 < bidx)) { best = v2; bidx = k2; }
+          }
+          if (q == 0) ids_l[i] = (bidx >= 0 && bidx < K) ? bidx : 0;      // (a row of NaNs never compares greater: code 0)
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        }
+        if (tid < 16) {
+          int id = ids_l[tid];
+          if (t + 1 < npre) {
+            id = 0;
+            if (tid < nrows) {
+              const int64_t c = a.codes[(int64_t)(t + 1) * B + b0 + tid];
+              id = (c >= 0 && c < K) ? (int)c : 0;
+            }
+          }
+          if (tid >= nrows) id = 0;
+          ids_l[tid] = id;
+          if (ft == 0 && tid < nrows) sv.ids[(int64_t)(t + 1) * B + b0 + tid] = id;
+        }
+        lds_barrier();
+      }
+    }
+    if (t + 1 >= S1) break;
+    // ---- head of step j = t + 1: e_j = Embedding(id_j) * keep * 2 (every workgroup gathers the rows), u_j tile = pre_linear(e_j) + BN sums ----
+    {
+      const int j = t + 1;
+      const int idr = ids_l[i];
+      for (int ks = wave; ks < KS; ks += 4) {
+        const int k = 16 * ks + 4 * q;
+        const bool ok = k < H && rvalid;
+        float4 e4 = ld4_or_zero(w.emb + (int64_t)idr * H + (ok ? k : 0), ok);
+        if (edrop && ok) {
+          const uint32_t kp2 = *reinterpret_cast<const uint32_t*>(a.keep_emb + ((int64_t)j * B + b) * H + k);
+          e4.x = (kp2 & 0xffu) ? e4.x * 2.0f : 0.f;
+          e4.y = (kp2 & 0xff00u) ? e4.y * 2.0f : 0.f;
+          e4.z = (kp2 & 0xff0000u) ? e4.z * 2.0f : 0.f;
+          e4.w = (kp2 & 0xff000000u) ? e4.w * 2.0f : 0.f;
+        }
+        xs_u[ks][lane] = e4;
+        if (ft == 0 && ok) *reinterpret_cast<float4*>(sv.ec + ((int64_t)j * B + b) * H + k) = e4;
+      }
+      lds_barrier();
+      {
+        f32x4 up = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int jj = 0; jj < (KS + 3) / 4; ++jj) {
+          const int ks = wave + 4 * jj;
+          if (ks < KS) {
+            const float4 x4 = xs_u[ks][lane], w4 = wp_s[ks * 64 + lane];
+            up = mfma16(w4.x, x4.x, up);
+            up = mfma16(w4.y, x4.y, up);
+            up = mfma16(w4.z, x4.z, up);
+            up = mfma16(w4.w, x4.w, up);
+          }
+        }
+        up_s[wave][lane] = make_float4(up[0], up[1], up[2], up[3]);
+      }
+      lds_barrier();
+      if (wave == 0) {
+        float ua[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int pw = 0; pw < 4; ++pw) {
+          const float4 p4 = up_s[pw][lane];
+          ua[0] += p4.x; ua[1] += p4.y; ua[2] += p4.z; ua[3] += p4.w;
+        }
+        float s1[4], s2[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = (rvalid && fok) ? ua[r] : 0.f;
+          s1[r] = reduce16(v);
+          s2[r] = reduce16(v * v);
+        }
+        const unsigned jpar = (unsigned)(j & 1), jtag = (unsigned)(j + 1);
+        if (fok) {
+          if (rvalid) {
+            const float un[4] = {ua[0] + bp4.x, ua[1] + bp4.y, ua[2] + bp4.z, ua[3] + bp4.w};
+            cx_publish4(r_u, (jpar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, jtag);
+            *reinterpret_cast<float4*>(sv.u + (int64_t)j * BH + (int64_t)b * H + f0) = make_float4(un[0], un[1], un[2], un[3]);
+          }
+          if (i == 0) {
+            const unsigned g0 = (jpar * (unsigned)nblk + (unsigned)rg) * prec + (unsigned)f0;
+            ccl_publish4(r_p, g0, s1, jtag);
+            ccl_publish4(r_p, g0 + (unsigned)Hp, s2, jtag);
+          }
+        }
+      }
+      lds_barrier();
+    }
+  }
+}
+}  // namespace g2v
+
 using namespace g2v;
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -864,8 +1455,37 @@ static size_t ct_fwd_pack_floats(int H, int K, int att) {
   return pack_floats(H, 1, Hin) + 4 * pack_floats(H, 3, H) + (size_t)ct_ktiles_alloc(K) * pack_ks(H) * 256 +
          (att ? pack_floats(H, 1, H) : 0);
 }
+// exchange records of code_cluster_fwd_kernel: three row records + the BatchNorm sums + the argmax pairs per (parity, row group)
+static size_t code_cluster_xch_bytes(int nblk, int H) {
+  const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
+  return (size_t)2 * nblk * ((3 * 16 + 2) * Hp + nt * 32) * 8;
+}
+static size_t code_cluster_dyn_lds() { return ((size_t)CCL_KT * CCL_KS + CCL_KS + (size_t)4 * CCL_KT + CCL_KS) * 64 * sizeof(float4); }
+static int ct_device_cus() {
+  static int n = -1;
+  if (n < 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+  }
+  return n;
+}
+int g2v_internal_persist_enabled();      // dec_rollout.hip: g2v_dec_rollout_set_persistent != 0
+// 1: g2v_attn_code_rollout_fwd runs this shape as ONE persistent cluster launch (no attention, H <= 208, at most three K tiles per
+// hidden-unit tile, the (tile x row group) grid with a CU per workgroup) under the current g2v_dec_rollout_set_persistent setting
+extern "C" int g2v_attn_code_rollout_cluster_ok(int S1, int B, int H, int K, int attention) {
+  if (attention || S1 < 1 || B < 1 || H < 16 || (H & 3) || H > 16 * CCL_KS || K < 4 || (K & 3)) return 0;
+  const int nt = (H + 15) >> 4, nblk = (B + 15) >> 4;
+  if (((K + 15) >> 4) > CCL_KT * nt || (int64_t)nt * nblk > ct_device_cus()) return 0;
+  return g2v_internal_persist_enabled() ? 1 : 0;
+}
 extern "C" size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention) {
-  return al256(ct_fwd_pack_floats(H, K, attention) * sizeof(float));
+  size_t x = al256(ct_fwd_pack_floats(H, K, attention) * sizeof(float));
+  if (!attention && (H & 3) == 0 && H >= 16 && H <= 16 * CCL_KS) {      // the cluster kernel's exchange records at its largest grid
+    const int nt = (H + 15) >> 4, cus = ct_device_cus() > 0 ? ct_device_cus() : 256;
+    const size_t c = code_cluster_xch_bytes(cus / nt + 1, H);
+    if (c > x) x = c;
+  }
+  return x;
 }
 
 static int ct_scratch(size_t base_floats) { return (base_floats + 2048) * sizeof(float) <= 160 * 1024 ? 2048 : 1024; }
@@ -897,6 +1517,31 @@ extern "C" int g2v_attn_code_rollout_fwd(const int64_t* codes, const float* h_in
   for (const void* p : al) G2V_REQUIRE(ct_al16(p), "16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const int Hin = att ? 2 * H : H;
+  if (g2v_attn_code_rollout_cluster_ok(S1, B, H, K, att) && code_cluster_xch_bytes(cdiv(B, 16), H) <= workspace_bytes &&
+      (!training || (s->a && s->bn_stats && s->gates0 && s->gates1))) {
+    // small batch: ONE persistent launch of (hidden-unit tile x row group) workgroups (code_cluster_fwd_kernel)
+    static bool attr_set = false;
+    const void* fn = (const void*)code_cluster_fwd_kernel;
+    int nocc = 0;
+    if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)code_cluster_dyn_lds()) == hipSuccess;
+    if (attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, code_cluster_dyn_lds()) == hipSuccess && nocc >= 1) {
+      const int nblk = cdiv(B, 16), nt = (H + 15) >> 4;
+      const size_t Hp = (size_t)nt * 16, rowrec = (size_t)2 * nblk * 16 * Hp;
+      unsigned long long* x0 = reinterpret_cast<unsigned long long*>(workspace);
+      CodeClArgs ca;
+      ca.codes = codes; ca.h_init = h_init; ca.keep_emb = keep_emb; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
+      ca.xu = x0; ca.xh0 = x0 + rowrec; ca.xh1 = x0 + 2 * rowrec; ca.xp = x0 + 3 * rowrec; ca.xa = ca.xp + (size_t)2 * nblk * 2 * Hp;
+      ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
+      ca.S1 = S1; ca.B = B; ca.H = H; ca.K = K; ca.n_pre = n_pre; ca.training = training; ca.p_drop = p_drop;
+      if (hipMemsetAsync(x0, 0, code_cluster_xch_bytes(nblk, H), st) != hipSuccess) {
+        set_error("g2v_attn_code_rollout_fwd: clearing the exchange records failed");
+        return G2V_ERR_LAUNCH;
+      }
+      hipLaunchKernelGGL(code_cluster_fwd_kernel, dim3(nt, nblk), dim3(256), code_cluster_dyn_lds(), st, ca);
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
+  }
   // ---- pack the weights into MFMA fragment order (one launch) ----
   float* p = (float*)workspace;
   PackBatch pb;

@@ -444,6 +444,11 @@ def code_rollout_ok(S1, B, H, K, Tw, att) -> bool:
     return bool(_lib_().g2v_attn_code_rollout_ok(int(S1), int(B), int(H), int(K), int(Tw), int(bool(att))))
 
 
+def code_rollout_cluster_ok(S1, B, H, K, att) -> bool:
+    """g2v_attn_code_rollout_fwd runs this shape as one persistent cluster launch (small batch, no attention: include/g2v.h)"""
+    return bool(_lib_().g2v_attn_code_rollout_cluster_ok(int(S1), int(B), int(H), int(K), int(bool(att))))
+
+
 def code_rollout_fwd(codes, h_init, enc, enc_proj, weights: dict, saved: dict, keep_emb, keep_l0, p_drop, n_pre, training,
                      S1, B, H, K, Tw):
     """g2v_attn_code_rollout_fwd: S1 + 1 launches of the fused decoder-step kernel (weights / saved: dicts of tensors named as

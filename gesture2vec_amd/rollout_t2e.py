@@ -50,8 +50,22 @@ def decoder_params(dec) -> List[torch.Tensor]:
 # few row tiles to fill the chip and the column-split per-operator kernels (one launch each, every CU streaming a slice of the
 # weights) are faster -- the same crossover as the pose decoder's (dec_rollout.hip, "split" kernels).
 FUSED_MIN_ROWS = 1024
+# Below FUSED_MIN_ROWS, without attention, while the (hidden-unit tile x row group) grid has a CU per workgroup (B <= 304 at
+# H = 200): the FORWARD rollout is one persistent cluster launch behind the same C entry (csrc/t2e_rollout.hip:
+# code_cluster_fwd_kernel; round 5: ~9 launches per decode step at the reference's B = 128 before); the backward stays the
+# per-operator chain below, which reads the arrays that launch saved.  False = the per-operator forward (tests, A/B).
+CLUSTER_FORWARD = True
+CLUSTER_CALLS = 0
 FUSED_CALLS = 0          # forwards served by the fused kernels (tests assert that the path under test actually ran)
 LAST_SAVED = None        # weak reference to the last fused forward's saved arrays (tests read the decisions the kernels took)
+
+
+def _cluster_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
+    if not CLUSTER_FORWARD or spec.L != 2 or spec.att or hidden0.shape[1] >= FUSED_MIN_ROWS:
+        return False
+    B, H = hidden0.shape[1], hidden0.shape[2]
+    K = params[5 + 4 * spec.L].shape[0]
+    return ops.code_rollout_ok(spec.steps, B, H, K, 0, False) and ops.code_rollout_cluster_ok(spec.steps, B, H, K, False)
 
 
 def _fused_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
@@ -78,10 +92,14 @@ def _fused_weights(spec, params, H):
     return wd
 
 
-def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
-    """The S1 decode steps as S1 + 1 launches of ONE kernel (include/g2v.h: g2v_attn_code_rollout_fwd)."""
-    global FUSED_CALLS, LAST_SAVED
-    FUSED_CALLS += 1
+def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params, cluster: bool = False):
+    """The S1 decode steps as S1 + 1 launches of ONE kernel (include/g2v.h: g2v_attn_code_rollout_fwd); cluster=True: the same entry
+    at small batch (one persistent launch), with the context laid out for the PER-OPERATOR backward."""
+    global FUSED_CALLS, CLUSTER_CALLS, LAST_SAVED
+    if cluster:
+        CLUSTER_CALLS += 1
+    else:
+        FUSED_CALLS += 1
     S1, att = spec.steps, spec.att
     B, H = hidden0.shape[1], hidden0.shape[2]
     K = params[13].shape[0]
@@ -108,6 +126,19 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params):
     ops.code_rollout_fwd(spec.cod.contiguous(), hidden0.contiguous(), enc, ep, wd, sv, mask_emb, mask_l0,
                          spec.dropout_p if drop else 0.0, spec.n_pre, True, S1, B, H, K, Tw)
     ctx.save_for_backward(hidden0, enc_out, *params)
+    if cluster:
+        # what CodeDecoderRollout.backward's per-operator chain reads, as views of the arrays the launch saved
+        ctx.spec, ctx.dims, ctx.fused, ctx.cell = spec, (S1, B, H, K, Hin, spec.L), False, ops.gru_cell_ok(H, H, B)
+        gru = [(wd["w_ih0"], wd["w_hh0"], wd["b_ih0"], wd["b_hh0"]), (wd["w_ih1"], wd["w_hh1"], wd["b_ih1"], wd["b_hh1"])]
+        ctx.bufs = dict(ids=sv["ids"], EC=sv["ec"], U=sv["u"], A=sv["a"], SM=sv["bn_stats"][:, 0], SI=sv["bn_stats"][:, 1],
+                        Hs=[sv["h0"], sv["h1"]], GATES=[sv["gates0"], sv["gates1"]], mask_emb=mask_emb, mask_l0=mask_l0,
+                        scale_l0=1.0 / (1.0 - spec.dropout_p) if drop else 1.0, emb_w=wd["emb"], pre_w=wd["w_pre"],
+                        out_w=wd["w_out"], gru=gru)
+        LAST_SAVED = {"ids": sv["ids"], "a": sv["a"]}
+        AW = f32(0)
+        ctx.mark_non_differentiable(AW)
+        ctx.set_materialize_grads(False)
+        return full, AW
     ctx.spec, ctx.dims, ctx.fused = spec, (S1, B, H, K, Hin, spec.L), True
     # (the logits are this node's OUTPUT: kept on ctx they would close a reference cycle output -> grad_fn -> ctx -> output, the
     #  step's buffers would live until the garbage collector runs -- inside a hipGraph capture that ended in a segfault of
@@ -161,6 +192,8 @@ class CodeDecoderRollout(torch.autograd.Function):
         L, att, S1 = spec.L, spec.att, spec.steps
         if _fused_ok(hidden0, enc_out, spec, params):
             return _fused_forward(ctx, hidden0, enc_out, spec, params)
+        if _cluster_ok(hidden0, enc_out, spec, params):
+            return _fused_forward(ctx, hidden0, enc_out, spec, params, cluster=True)
         ctx.fused = False
         emb_w, pre_w, pre_b, bn_w, bn_b = params[:5]
         gru = [params[5 + 4 * l: 9 + 4 * l] for l in range(L)]            # (w_ih, w_hh, b_ih, b_hh) per layer

@@ -342,6 +342,7 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
             return ret
         lib.g2v_dec_rollout_persist_fault(1)               # clear
         lib.g2v_gru_seq_set_cluster(0)
+        lib.g2v_dec_rollout_set_persistent(0)              # (the code decoder's cluster forward hangs off this switch)
         if attempt == 1:
             raise RuntimeError(f"persistent kernel fault latch {f} set again on the per-step kernels")
         import warnings

@@ -713,6 +713,12 @@ typedef struct {                 /* gradients (overwritten)                     
 } g2v_code_dec_grads;
 
 int g2v_attn_code_rollout_ok(int S1, int B, int H, int K, int Tw, int attention);
+/* Round 5: 1 where g2v_attn_code_rollout_fwd runs the shape as ONE persistent cluster launch of (hidden-unit tile x row group)
+ * workgroups (csrc/t2e_rollout.hip: code_cluster_fwd_kernel -- the scheme of the pose decoder's cluster kernels, see
+ * g2v_dec_rollout_set_persistent, which also switches this one): no attention, H <= 208, K <= 48 ceil(H / 16), the grid with a CU
+ * per workgroup (B <= 304 at H = 200).  It writes the same arrays as the step kernels, so g2v_attn_code_rollout_bwd or a
+ * per-operator backward run on them unchanged. */
+int g2v_attn_code_rollout_cluster_ok(int S1, int B, int H, int K, int attention);
 int g2v_attn_code_rollout_blocks(int B);
 size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention);
 /* codes (S,B) int64 (rows 0 .. max(1, n_pre) - 1 are read); h_init (2,B,H); enc (Tw,B,H) and enc_proj = enc W_attn[:, H:]^T

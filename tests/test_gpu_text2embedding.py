@@ -16,15 +16,22 @@ def relerr(got, ref):
     return float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-12)
 
 
-@pytest.mark.parametrize("kernels", ["per_operator", "fused_step"])
+@pytest.mark.parametrize("kernels", ["per_operator", "fused_step", "cluster_forward"])
 @pytest.mark.parametrize("name,att", [("t2e_noatt", "False"), ("t2e_att", "True")])
-def test_text2embedding_matches_reference_golden(golden_dir, name, att, kernels, monkeypatch):
+def test_text2embedding_matches_reference_golden(golden_dir, name, att, kernels, monkeypatch, request):
     """kernels = "fused_step": the decode steps run as g2v_attn_code_rollout_fwd / _bwd (csrc/t2e_rollout.hip; selected from 1024
     rows per batch in production, forced here) -- the fused per-step kernels against the REFERENCE's own numbers."""
     from gesture2vec_amd import rollout_t2e
     from gesture2vec_amd.flat import FlatClipAdam
     monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", 1 if kernels == "fused_step" else 1 << 30)
-    calls0 = rollout_t2e.FUSED_CALLS
+    # "cluster_forward" (round 5, no attention only): the forward rollout as one persistent cluster launch + the per-operator backward
+    monkeypatch.setattr(rollout_t2e, "CLUSTER_FORWARD", kernels == "cluster_forward")
+    if kernels == "cluster_forward" and att == "True":
+        pytest.skip("the cluster forward serves the attention-free decoder")
+    from gesture2vec_amd import _lib as _l
+    prev_persist = _l.load().g2v_dec_rollout_set_persistent(0 if kernels == "fused_step" else 1)     # (fused_step: the step kernels, not the
+    request.addfinalizer(lambda: _l.load().g2v_dec_rollout_set_persistent(prev_persist))              #  cluster launch behind the same entry)
+    calls0, ccalls0 = rollout_t2e.FUSED_CALLS, rollout_t2e.CLUSTER_CALLS
     from gesture2vec_amd.model.text2embedding_model import text2embedding_model
     from gesture2vec_amd.train_eval.train_seq2seq import train_iter_text2embedding
     fx = np.load(os.path.join(golden_dir, name + ".npz"))
@@ -59,6 +66,7 @@ def test_text2embedding_matches_reference_golden(golden_dir, name, att, kernels,
                 else:
                     assert prm.grad is not None and relerr(prm.grad, ref) < 5e-4, (n, relerr(prm.grad, ref))
     assert rollout_t2e.FUSED_CALLS - calls0 == (2 if kernels == "fused_step" else 0)
+    assert rollout_t2e.CLUSTER_CALLS - ccalls0 == (2 if kernels == "cluster_forward" else 0)
     for k in fx.files:
         if k.startswith("wN/"):
             n = k[3:]
@@ -275,12 +283,19 @@ def test_fused_step_kernels_match_per_operator_path(att, p, B, n_pre, H, K, monk
     w = torch.randn(B, S, K, generator=g).to(DEV)
     outs = []
     calls0 = rollout_t2e.FUSED_CALLS
-    for net, min_rows in zip(nets, (1, 1 << 30)):
-        monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", min_rows)
-        net.set_dropout_masks(*masks)
-        out, attn = net(ids, lengths, None, codes, None, None)
-        (out * w).sum().backward()
-        outs.append((out.detach(), attn))
+    monkeypatch.setattr(rollout_t2e, "CLUSTER_FORWARD", False)      # (the per-operator leg really is per-operator)
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    prev = lib.g2v_dec_rollout_set_persistent(0)                    # (the fused leg really runs the step kernels: no cluster launch behind the entry)
+    try:
+        for net, min_rows in zip(nets, (1, 1 << 30)):
+            monkeypatch.setattr(rollout_t2e, "FUSED_MIN_ROWS", min_rows)
+            net.set_dropout_masks(*masks)
+            out, attn = net(ids, lengths, None, codes, None, None)
+            (out * w).sum().backward()
+            outs.append((out.detach(), attn))
+    finally:
+        lib.g2v_dec_rollout_set_persistent(prev)
     assert rollout_t2e.FUSED_CALLS - calls0 == 1, "the fused step kernels did not serve this shape (g2v_attn_code_rollout_ok)"
     assert relerr(outs[0][0], outs[1][0].cpu()) < 3e-5
     same = (outs[0][0][:, 1:].argmax(2) == outs[1][0][:, 1:].argmax(2)).all(1)
@@ -292,6 +307,65 @@ def test_fused_step_kernels_match_per_operator_path(att, p, B, n_pre, H, K, monk
     bn0, bn1 = (n.decoder.decoder.pre_linear[1] for n in nets)
     assert relerr(bn0.running_mean, bn1.running_mean.cpu()) < 1e-5 and relerr(bn0.running_var, bn1.running_var.cpu()) < 1e-5
     assert int(bn0.num_batches_tracked) == int(bn1.num_batches_tracked) == S - 1
+    checked = 0
+    for (n, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None or float(pa.grad.abs().max()) == 0.0, n
+            continue
+        assert pa.grad is not None, n
+        if n == "decoder.decoder.pre_linear.0.bias":          # feeds BatchNorm: rounding noise around zero on both sides
+            continue
+        tol = 2e-4 if bool(same.all()) else 5e-2
+        assert relerr(pa.grad, pb.grad.cpu()) < tol, (n, relerr(pa.grad, pb.grad.cpu()))
+        checked += 1
+    assert checked >= 20
+
+
+@pytest.mark.parametrize("p,B,n_pre,H,K", [(0.2, 128, 1, 200, 512), (0.0, 128, 1, 200, 512), (0.2, 37, 3, 200, 512), (0.1, 300, 1, 52, 64),
+                                           (0.2, 16, 1, 48, 40), (0.0, 130, 2, 64, 176)])
+def test_cluster_forward_matches_per_operator_path(p, B, n_pre, H, K, monkeypatch):
+    """Small batch, no attention (round 5): the greedy forward rollout as ONE persistent cluster launch (csrc/t2e_rollout.hip:
+    code_cluster_fwd_kernel, behind g2v_attn_code_rollout_fwd) with the PER-OPERATOR backward on the arrays it saved, against
+    the per-operator forward + backward: the reference's B = 128 / H = 200 / K = 512, ragged row groups, teacher-forced prefixes,
+    H % 16 != 0, 19 row groups, K tiles unevenly spread over the workgroups.  Equal to a few 1e-6 (BatchNorm sums from per-workgroup
+    partial sums, k-split products), the greedy codes fed back are the same."""
+    from gesture2vec_amd import rollout_t2e
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    L, NW, EMB, Tw, S = 2, 50, 30, 9, 6
+    args = argparse.Namespace(hidden_size=H, n_layers=L, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att="False",
+                              n_pre_poses=n_pre, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    g = torch.Generator().manual_seed(16)
+    nets = []
+    for _ in range(2):
+        torch.manual_seed(5)
+        net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(0).randn(NW, EMB).astype(np.float32), None).to(DEV)
+        net.train(True)
+        nets.append(net)
+    nets[1].load_state_dict(nets[0].state_dict())
+    ids = torch.randint(1, NW, (B, Tw), generator=g).to(DEV)
+    lengths = torch.sort(torch.randint(3, Tw + 1, (B,), generator=g), descending=True).values
+    lengths[0] = Tw
+    codes = torch.randint(0, K, (B, S), generator=g).to(DEV)
+    masks = ((torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8).to(DEV),
+             (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None, None)
+    w = torch.randn(B, S, K, generator=g).to(DEV)
+    outs = []
+    calls0 = rollout_t2e.CLUSTER_CALLS
+    for net, cluster in zip(nets, (True, False)):
+        monkeypatch.setattr(rollout_t2e, "CLUSTER_FORWARD", cluster)
+        net.set_dropout_masks(*masks)
+        out, _ = net(ids, lengths, None, codes, None, None)
+        (out * w).sum().backward()
+        outs.append(out.detach())
+    assert rollout_t2e.CLUSTER_CALLS - calls0 == 1, "the cluster kernel did not serve this shape (g2v_attn_code_rollout_cluster_ok)"
+    from gesture2vec_amd import _lib
+    assert _lib.load().g2v_dec_rollout_persist_fault(0) == 0
+    assert relerr(outs[0], outs[1].cpu()) < 3e-5
+    same = (outs[0][:, 1:].argmax(2) == outs[1][:, 1:].argmax(2)).all(1)
+    assert float(same.float().mean()) > 0.995           # (a greedy decision inside fp32 rounding of a tie changes that row's later steps)
+    bn0, bn1 = (n.decoder.decoder.pre_linear[1] for n in nets)
+    assert relerr(bn0.running_mean, bn1.running_mean.cpu()) < 1e-5 and relerr(bn0.running_var, bn1.running_var.cpu()) < 1e-5
     checked = 0
     for (n, pa), (_, pb) in zip(nets[0].named_parameters(), nets[1].named_parameters()):
         if pb.grad is None:
@@ -393,6 +467,7 @@ def test_train_iter_repeats_an_iteration_whose_persistent_kernels_faulted():
             net.set_dropout_masks(*masks)
             assert lib.g2v_dec_rollout_persist_fault(1) == 0
             lib.g2v_gru_seq_set_cluster(1 if fault else 0)      # (the clean run on the kernels the repeated iteration ends up on)
+            lib.g2v_dec_rollout_set_persistent(1 if fault else 0)
             if fault:
                 lib.g2v_dec_rollout_persist_fault(-1)          # as a bounded wait running out would
                 orig = net.forward                               # (the repeated iteration needs the same explicit masks again)
@@ -411,6 +486,7 @@ def test_train_iter_repeats_an_iteration_whose_persistent_kernels_faulted():
     finally:
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_gru_seq_set_cluster(prev)
+        lib.g2v_dec_rollout_set_persistent(1)
     assert states[0][0] == states[1][0]
     for k, v in states[0][1].items():      # the same kernels on the same inputs: the discarded attempt left no trace at all
         assert torch.equal(v, states[1][1][k]), k
