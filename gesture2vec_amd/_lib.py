@@ -183,6 +183,9 @@ _SIGS = {
                              c_fp, c_sz, c_fp]),
     "g2v_attn_code_rollout_ok": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "g2v_attn_code_rollout_cluster_ok": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "g2v_code_cluster_bptt_workspace": (c_sz, [c_int, c_int]),
+    "g2v_code_cluster_bptt": (c_int, [c_fp, C.POINTER(CodeDecWeights), C.POINTER(CodeDecSaved), c_fp, c_f, c_fp, c_fp, c_fp, c_fp,
+                                      c_fp, c_fp, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_attn_code_rollout_blocks": (c_int, [c_int]),
     "g2v_attn_code_rollout_fwd_workspace": (c_sz, [c_int, c_int, c_int]),
     "g2v_attn_code_rollout_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, C.POINTER(CodeDecWeights), C.POINTER(CodeDecSaved), c_fp, c_fp, c_f,

@@ -1427,6 +1427,181 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
     }
   }
 }
+
+// The BPTT through the two GRU cells of the same rollout as ONE persistent cluster launch (round 5).  Without attention nothing
+// but the cells couples two steps (the greedy feedback carries no gradient; BatchNorm's backward and every weight / embedding
+// gradient run afterwards over all steps at once), so a step is: cell 1's gate gradients from dh1 = dLogits W_out (formed for all
+// steps by one dense launch beforehand) + carry1 | its two 3H-long contractions in the partial-product form of the pose decoder's
+// backward cluster (dec_rollout.hip: dec_cluster_bwd_kernel) | cell 0 | its partial products | da_t = dgi0 W_ih0 stored for
+// BatchNorm's backward.  Wave 0 owns the element-wise stages and keeps both carries in registers; two exchanges per step.
+struct CodeClBwdArgs {
+  const float* dh_top;         // (S1,B,H) dLogits_t W_out
+  const uint8_t* keep_l0;      // (S1,B,H) or NULL
+  g2v_code_dec_weights w; g2v_code_dec_saved sv;
+  float* dgi0; float* dgh0; float* dgi1; float* dgh1;      // (S1,B,3H)
+  float* da;                   // (S1,B,H) gradient w.r.t. a_t = ReLU(BN(u_t)) (before the ReLU mask)
+  float* d_hidden0;            // (2,B,H)
+  unsigned long long* xq;      // [nblk][hh1, ih1, hh0, ih0][producer tile] row records: partial products
+  unsigned* fault;
+  int S1, B, H;
+  float p_drop;
+};
+__device__ __forceinline__ void ccl_cell_bwd(const float (&dh)[4], const float4 (&gt)[4], const float4& hp4, float (&g_r)[4],
+                                             float (&g_z)[4], float (&g_n)[4], float (&g_hn)[4], float (&direct)[4]) {
+  const float rr[4] = {gt[0].x, gt[0].y, gt[0].z, gt[0].w}, zz[4] = {gt[1].x, gt[1].y, gt[1].z, gt[1].w},
+              nn[4] = {gt[2].x, gt[2].y, gt[2].z, gt[2].w}, gh[4] = {gt[3].x, gt[3].y, gt[3].z, gt[3].w},
+              hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float dn = dh[r] * (1.0f - zz[r]);
+    const float dz = dh[r] * (hp[r] - nn[r]);
+    const float dnp = dn * (1.0f - nn[r] * nn[r]);
+    g_n[r] = dnp;
+    g_hn[r] = dnp * rr[r];
+    g_r[r] = dnp * gh[r] * rr[r] * (1.0f - rr[r]);
+    g_z[r] = dz * zz[r] * (1.0f - zz[r]);
+    direct[r] = dh[r] * zz[r];
+  }
+}
+__global__ __launch_bounds__(256) void code_cluster_bptt_kernel(CodeClBwdArgs a) {
+  constexpr int KS = CCL_KS, NU = (2 * KS + 3) / 4, NPW = (KS + 1) / 2;
+  __shared__ __attribute__((aligned(16))) float4 xs_g[6][64];      // the stage's gate gradients: dgh r z hn, dgi r z n
+  __shared__ __attribute__((aligned(16))) float4 dsum[4][64];      // [wave] its share of the partial products, summed
+  const int S1 = a.S1, B = a.B, H = a.H, G = 3 * H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
+  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0);
+  const int f0 = 16 * ft + 4 * q;
+  const bool fok = f0 < H, own = rvalid && fok;
+  const int64_t BH = (int64_t)B * H, BG = 3 * BH;
+  const g2v_code_dec_weights& w = a.w;
+  const g2v_code_dec_saved& sv = a.sv;
+  // resident: this wave's (matrix, output tile) units of both pairs: rows g H + f0 + e of the matrix at columns 16 ot + i
+  float4 wq[2][NU][3];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int j = 0; j < NU; ++j) {
+      const int u = wave + 4 * j, m = u >= nt ? 1 : 0, ot = u - m * nt;
+      const float* W = c == 1 ? (m == 0 ? w.w_hh1 : w.w_ih1) : (m == 0 ? w.w_hh0 : w.w_ih0);
+      const int col = 16 * ot + i;
+      const bool ok = u < 2 * nt && fok && col < H;
+#pragma unroll
+      for (int g = 0; g < 3; ++g) {
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ok ? W[((int64_t)g * H + f0 + e) * H + col] : 0.f;
+        wq[c][j][g] = make_float4(v[0], v[1], v[2], v[3]);
+      }
+    }
+  const bool drop = a.keep_l0 && a.p_drop > 0.f;
+  const float scale_l0 = 1.0f / (1.0f - a.p_drop);
+  const unsigned rowrec = 256u * (unsigned)nt;
+  __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(a.xq, 0, (int)((unsigned)nblk * 4u * (unsigned)nt * rowrec * 8u), 0x00020000);
+  const unsigned q_rg = (unsigned)rg * 4u * (unsigned)nt * rowrec;
+  float carry1[4] = {0.f, 0.f, 0.f, 0.f}, carry0[4] = {0.f, 0.f, 0.f, 0.f};      // (wave 0)
+  for (int t = S1 - 1; t >= 0; --t) {
+    const unsigned tag = (unsigned)(S1 - t);
+    const int64_t o4 = (int64_t)t * 4 * BH + (int64_t)b * 4 * H + (fok ? f0 : 0), o1 = (int64_t)t * BH + (int64_t)b * H + (fok ? f0 : 0);
+    float direct[4] = {0.f, 0.f, 0.f, 0.f};
+    float4 gt0[4], hp0 = make_float4(0.f, 0.f, 0.f, 0.f);
+    uint32_t kp = 0x01010101u;
+    if (wave == 0) {
+      // ---- cell 1: dh1 = dLogits_t W_out + carry1; its gate gradients -------------------------------------------------------------------
+      float4 gt1[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        gt1[g] = ld4_or_zero(sv.gates1 + o4 + g * H, own);
+        gt0[g] = ld4_or_zero(sv.gates0 + o4 + g * H, own);
+      }
+      const float4 hp1 = ld4_or_zero(sv.h1 + o1, own);      // (slot t: the state in front of step t)
+      hp0 = ld4_or_zero(sv.h0 + o1, own);
+      if (drop && own) kp = *reinterpret_cast<const uint32_t*>(a.keep_l0 + o1);
+      const float4 d4 = ld4_or_zero(a.dh_top + o1, own);
+      float dh[4] = {d4.x + carry1[0], d4.y + carry1[1], d4.z + carry1[2], d4.w + carry1[3]};
+      float g_r[4], g_z[4], g_n[4], g_hn[4];
+      ccl_cell_bwd(dh, gt1, hp1, g_r, g_z, g_n, g_hn, direct);
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 vr = own ? make_float4(g_r[0], g_r[1], g_r[2], g_r[3]) : z4, vz = own ? make_float4(g_z[0], g_z[1], g_z[2], g_z[3]) : z4;
+      const float4 vn = own ? make_float4(g_n[0], g_n[1], g_n[2], g_n[3]) : z4, vh = own ? make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]) : z4;
+      xs_g[0][lane] = vr; xs_g[1][lane] = vz; xs_g[2][lane] = vh;
+      xs_g[3][lane] = vr; xs_g[4][lane] = vz; xs_g[5][lane] = vn;
+      if (own) {
+        float* gi = a.dgi1 + (int64_t)t * BG + (int64_t)b * G + f0;
+        float* gh = a.dgh1 + (int64_t)t * BG + (int64_t)b * G + f0;
+        *reinterpret_cast<float4*>(gi) = vr; *reinterpret_cast<float4*>(gi + H) = vz; *reinterpret_cast<float4*>(gi + 2 * H) = vn;
+        *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
+      }
+    }
+#pragma unroll
+    for (int c = 1; c >= 0; --c) {
+      lds_barrier();      // xs_g of the stage is complete
+      {
+        const float4 xh0 = xs_g[0][lane], xh1 = xs_g[1][lane], xh2 = xs_g[2][lane];
+        const float4 xi0 = xs_g[3][lane], xi1 = xs_g[4][lane], xi2 = xs_g[5][lane];
+#pragma unroll
+        for (int j = 0; j < NU; ++j) {
+          const int u = wave + 4 * j, m = u >= nt ? 1 : 0, ot = u - m * nt;
+          if (u < 2 * nt) {      // (uniform)
+            const float4 x0 = m ? xi0 : xh0, x1 = m ? xi1 : xh1, x2 = m ? xi2 : xh2;
+            f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc = mfma16(wq[c][j][0].x, x0.x, acc); acc = mfma16(wq[c][j][0].y, x0.y, acc);
+            acc = mfma16(wq[c][j][0].z, x0.z, acc); acc = mfma16(wq[c][j][0].w, x0.w, acc);
+            acc = mfma16(wq[c][j][1].x, x1.x, acc); acc = mfma16(wq[c][j][1].y, x1.y, acc);
+            acc = mfma16(wq[c][j][1].z, x1.z, acc); acc = mfma16(wq[c][j][1].w, x1.w, acc);
+            acc = mfma16(wq[c][j][2].x, x2.x, acc); acc = mfma16(wq[c][j][2].y, x2.y, acc);
+            acc = mfma16(wq[c][j][2].z, x2.z, acc); acc = mfma16(wq[c][j][2].w, x2.w, acc);
+            if (rvalid && 16 * ot + 4 * q < H) {
+              const float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag);
+            }
+          }
+        }
+      }
+      cx_sweep_tile_sum<NPW>(r_q, q_rg + (unsigned)((1 - c) * 2 + (wave & 1)) * (unsigned)nt * rowrec, rowrec, wave >> 1, 2, nt, ft, nrows, H, tag,
+                             &dsum[wave][0], lane, a.fault);
+      lds_barrier();
+      if (wave == 0) {
+        const float4 h_a = dsum[0][lane], h_b = dsum[2][lane], i_a = dsum[1][lane], i_b = dsum[3][lane];
+        const float shh[4] = {h_a.x + h_b.x, h_a.y + h_b.y, h_a.z + h_b.z, h_a.w + h_b.w};
+        const float sih[4] = {i_a.x + i_b.x, i_a.y + i_b.y, i_a.z + i_b.z, i_a.w + i_b.w};
+        if (c == 1) {
+          float dh[4], g_r[4], g_z[4], g_n[4], g_hn[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            carry1[r] = direct[r] + shh[r];
+            float v = sih[r];
+            if (drop) v = ((kp >> (8 * r)) & 0xffu) ? v * scale_l0 : 0.f;
+            dh[r] = v + carry0[r];
+          }
+          ccl_cell_bwd(dh, gt0, hp0, g_r, g_z, g_n, g_hn, direct);
+          const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 vr = own ? make_float4(g_r[0], g_r[1], g_r[2], g_r[3]) : z4, vz = own ? make_float4(g_z[0], g_z[1], g_z[2], g_z[3]) : z4;
+          const float4 vn = own ? make_float4(g_n[0], g_n[1], g_n[2], g_n[3]) : z4, vh = own ? make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]) : z4;
+          xs_g[0][lane] = vr; xs_g[1][lane] = vz; xs_g[2][lane] = vh;
+          xs_g[3][lane] = vr; xs_g[4][lane] = vz; xs_g[5][lane] = vn;
+          if (own) {
+            float* gi = a.dgi0 + (int64_t)t * BG + (int64_t)b * G + f0;
+            float* gh = a.dgh0 + (int64_t)t * BG + (int64_t)b * G + f0;
+            *reinterpret_cast<float4*>(gi) = vr; *reinterpret_cast<float4*>(gi + H) = vz; *reinterpret_cast<float4*>(gi + 2 * H) = vn;
+            *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
+          }
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) carry0[r] = direct[r] + shh[r];
+          if (own) *reinterpret_cast<float4*>(a.da + o1) = make_float4(sih[0], sih[1], sih[2], sih[3]);
+        }
+      }
+    }
+    lds_barrier();      // (xs_g / dsum of this step are done with)
+  }
+  if (wave == 0 && own) {
+    *reinterpret_cast<float4*>(a.d_hidden0 + (int64_t)b * H + f0) = make_float4(carry0[0], carry0[1], carry0[2], carry0[3]);
+    *reinterpret_cast<float4*>(a.d_hidden0 + BH + (int64_t)b * H + f0) = make_float4(carry1[0], carry1[1], carry1[2], carry1[3]);
+  }
+}
 }  // namespace g2v
 
 using namespace g2v;
@@ -1477,6 +1652,52 @@ extern "C" int g2v_attn_code_rollout_cluster_ok(int S1, int B, int H, int K, int
   const int nt = (H + 15) >> 4, nblk = (B + 15) >> 4;
   if (((K + 15) >> 4) > CCL_KT * nt || (int64_t)nt * nblk > ct_device_cus()) return 0;
   return g2v_internal_persist_enabled() ? 1 : 0;
+}
+// The cells' BPTT of the attention-free rollout at small batch as one persistent cluster launch (code_cluster_bptt_kernel; the
+// shapes of g2v_attn_code_rollout_cluster_ok).  dh_top (S1,B,H) = dLogits W_out for every step (g2v_linear_bwd_data); writes dgi0 /
+// dgh0 / dgi1 / dgh1 (S1,B,3H), da (S1,B,H) = the gradient w.r.t. a_t before its ReLU mask (BatchNorm's backward is the caller's
+// next launch), d_hidden0 (2,B,H).  s: gates0 / gates1 / h0 / h1 of the forward.
+extern "C" size_t g2v_code_cluster_bptt_workspace(int B, int H) {
+  const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
+  return (size_t)((B + 15) / 16) * 4 * nt * 16 * Hp * 8;
+}
+extern "C" int g2v_code_cluster_bptt(const float* dh_top, const g2v_code_dec_weights* w, const g2v_code_dec_saved* s,
+                                     const uint8_t* keep_l0, float p_drop, float* dgi0, float* dgh0, float* dgi1, float* dgh1,
+                                     float* da, float* d_hidden0, int S1, int B, int H, void* workspace, size_t workspace_bytes,
+                                     g2v_stream_t stream) {
+  G2V_REQUIRE(dh_top && w && s && dgi0 && dgh0 && dgi1 && dgh1 && da && d_hidden0 && workspace, "null pointer");
+  G2V_REQUIRE(w->w_ih0 && w->w_hh0 && w->w_ih1 && w->w_hh1 && s->gates0 && s->gates1 && s->h0 && s->h1, "missing array");
+  G2V_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "bad dropout probability");
+  if (!g2v_attn_code_rollout_cluster_ok(S1, B, H, 4, 0)) {
+    set_error("g2v_code_cluster_bptt: shape not served (g2v_attn_code_rollout_cluster_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
+  if (workspace_bytes < g2v_code_cluster_bptt_workspace(B, H)) {
+    set_error("g2v_code_cluster_bptt: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  const void* al[] = {dh_top, keep_l0, dgi0, dgh0, dgi1, dgh1, da, d_hidden0, s->gates0, s->gates1, s->h0, s->h1, workspace};
+  for (const void* p : al) G2V_REQUIRE(ct_al16(p), "16-byte alignment");
+  hipStream_t st = (hipStream_t)stream;
+  const void* fn = (const void*)code_cluster_bptt_kernel;
+  int nocc = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, 0) != hipSuccess || nocc < 1) {
+    set_error("g2v_code_cluster_bptt: the kernel does not fit a CU");
+    return G2V_ERR_LAUNCH;
+  }
+  CodeClBwdArgs ca;
+  ca.dh_top = dh_top; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
+  ca.dgi0 = dgi0; ca.dgh0 = dgh0; ca.dgi1 = dgi1; ca.dgh1 = dgh1; ca.da = da; ca.d_hidden0 = d_hidden0;
+  ca.xq = reinterpret_cast<unsigned long long*>(workspace);
+  ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
+  ca.S1 = S1; ca.B = B; ca.H = H; ca.p_drop = p_drop;
+  if (hipMemsetAsync(workspace, 0, g2v_code_cluster_bptt_workspace(B, H), st) != hipSuccess) {
+    set_error("g2v_code_cluster_bptt: clearing the exchange records failed");
+    return G2V_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(code_cluster_bptt_kernel, dim3((H + 15) >> 4, cdiv(B, 16)), dim3(256), 0, st, ca);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
 }
 extern "C" size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention) {
   size_t x = al256(ct_fwd_pack_floats(H, K, attention) * sizeof(float));

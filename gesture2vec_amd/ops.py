@@ -449,6 +449,21 @@ def code_rollout_cluster_ok(S1, B, H, K, att) -> bool:
     return bool(_lib_().g2v_attn_code_rollout_cluster_ok(int(S1), int(B), int(H), int(K), int(bool(att))))
 
 
+def code_cluster_bptt(dh_top, weights: dict, saved: dict, keep_l0, p_drop, S1, B, H):
+    """g2v_code_cluster_bptt: the GRU cells' BPTT of the attention-free rollout as one persistent cluster launch (small batch).
+    Returns (dgi0, dgh0, dgi1, dgh1 (S1,B,3H), da (S1,B,H), d_hidden0 (2,B,H))."""
+    lib = _lib_()
+    dev = dh_top.device
+    f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    dgi0, dgh0, dgi1, dgh1 = f32(S1, B, 3 * H), f32(S1, B, 3 * H), f32(S1, B, 3 * H), f32(S1, B, 3 * H)
+    da, d_h0 = f32(S1, B, H), f32(2, B, H)
+    ws = workspace(lib.g2v_code_cluster_bptt_workspace(B, H), dev, "codebptt")
+    check(lib.g2v_code_cluster_bptt(_p(_chk(dh_top)), C.byref(struct_from(CodeDecWeights, weights)), C.byref(struct_from(CodeDecSaved, saved)),
+                                    _p(keep_l0), float(p_drop), _p(dgi0), _p(dgh0), _p(dgi1), _p(dgh1), _p(da), _p(d_h0), S1, B, H,
+                                    _p(ws), ws.numel(), _stream()), "code_cluster_bptt")
+    return dgi0, dgh0, dgi1, dgh1, da, d_h0
+
+
 def code_rollout_fwd(codes, h_init, enc, enc_proj, weights: dict, saved: dict, keep_emb, keep_l0, p_drop, n_pre, training,
                      S1, B, H, K, Tw):
     """g2v_attn_code_rollout_fwd: S1 + 1 launches of the fused decoder-step kernel (weights / saved: dicts of tensors named as

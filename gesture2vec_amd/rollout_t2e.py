@@ -55,7 +55,9 @@ FUSED_MIN_ROWS = 1024
 # code_cluster_fwd_kernel; round 5: ~9 launches per decode step at the reference's B = 128 before); the backward stays the
 # per-operator chain below, which reads the arrays that launch saved.  False = the per-operator forward (tests, A/B).
 CLUSTER_FORWARD = True
+CLUSTER_BACKWARD = True      # behind a cluster forward: the GRU cells' BPTT as one persistent cluster launch too (g2v_code_cluster_bptt)
 CLUSTER_CALLS = 0
+CLUSTER_BPTT_CALLS = 0
 FUSED_CALLS = 0          # forwards served by the fused kernels (tests assert that the path under test actually ran)
 LAST_SAVED = None        # weak reference to the last fused forward's saved arrays (tests read the decisions the kernels took)
 
@@ -134,6 +136,8 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params, cluster: bo
                         Hs=[sv["h0"], sv["h1"]], GATES=[sv["gates0"], sv["gates1"]], mask_emb=mask_emb, mask_l0=mask_l0,
                         scale_l0=1.0 / (1.0 - spec.dropout_p) if drop else 1.0, emb_w=wd["emb"], pre_w=wd["w_pre"],
                         out_w=wd["w_out"], gru=gru)
+        # (and for the cells' BPTT as a cluster launch: the C structs of the same arrays, without this node's output)
+        ctx.cluster = dict(wd=wd, sv={k: t for k, t in sv.items() if k != "logits"}, p=spec.dropout_p if drop else 0.0)
         LAST_SAVED = {"ids": sv["ids"], "a": sv["a"]}
         AW = f32(0)
         ctx.mark_non_differentiable(AW)
@@ -291,7 +295,17 @@ class CodeDecoderRollout(torch.autograd.Function):
         if att:
             DEC, DHP = f32(S1, B, Hin), f32(S1, B, H)
             D_EP, D_ENC, D_V = torch.empty_like(b["EP"]), torch.empty_like(b["enc"]), f32(H)
-        for t in reversed(range(S1)):
+        cl = getattr(ctx, "cluster", None)
+        if cl is not None and CLUSTER_BACKWARD and not att:
+            # small batch (round 5): the cells' BPTT as ONE persistent cluster launch (include/g2v.h: g2v_code_cluster_bptt); BatchNorm's
+            # backward per step behind it (nothing there feeds the recurrence: the greedy feedback carries no gradient)
+            global CLUSTER_BPTT_CALLS
+            CLUSTER_BPTT_CALLS += 1
+            DGI[0], DGH[0], DGI[1], DGH[1], DA, d_h0 = ops.code_cluster_bptt(DH_top, cl["wd"], cl["sv"], b["mask_l0"], cl["p"], S1, B, H)
+            for t in range(S1):
+                ops.batchnorm_bwd(DA[t], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
+            carry = [d_h0[0], d_h0[1]]
+        for t in (reversed(range(S1)) if not (cl is not None and CLUSTER_BACKWARD and not att) else ()):
             d_in = DH_top[t]                                             # gradient arriving at Hs[l][t+1] from above
             for l in reversed(range(L)):
                 w_ih, w_hh = gru[l][0], gru[l][1]

@@ -719,6 +719,16 @@ int g2v_attn_code_rollout_ok(int S1, int B, int H, int K, int Tw, int attention)
  * per workgroup (B <= 304 at H = 200).  It writes the same arrays as the step kernels, so g2v_attn_code_rollout_bwd or a
  * per-operator backward run on them unchanged. */
 int g2v_attn_code_rollout_cluster_ok(int S1, int B, int H, int K, int attention);
+/* Round 5: for the same shapes, the BPTT through the two GRU cells of the attention-free rollout as ONE persistent cluster launch
+ * (code_cluster_bptt_kernel: the partial-product exchange of the pose decoder's backward cluster).  Nothing but the cells couples
+ * two steps there (the greedy feedback carries no gradient), so the caller forms dh_top (S1,B,H) = dLogits W_out for all steps
+ * first (g2v_linear_bwd_data) and runs BatchNorm's backward, the embedding gradient and every weight gradient afterwards over all
+ * steps at once.  Writes dgi0 / dgh0 / dgi1 / dgh1 (S1,B,3H), da (S1,B,H) = the gradient w.r.t. a_t = ReLU(BN(u_t)) before the
+ * ReLU mask, d_hidden0 (2,B,H); reads s->gates0 / gates1 / h0 / h1; keep_l0 (S1,B,H) or NULL: the inter-layer dropout masks. */
+size_t g2v_code_cluster_bptt_workspace(int B, int H);
+int g2v_code_cluster_bptt(const float* dh_top, const g2v_code_dec_weights* w, const g2v_code_dec_saved* s, const uint8_t* keep_l0,
+                          float p_drop, float* dgi0, float* dgh0, float* dgi1, float* dgh1, float* da, float* d_hidden0,
+                          int S1, int B, int H, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 int g2v_attn_code_rollout_blocks(int B);
 size_t g2v_attn_code_rollout_fwd_workspace(int H, int K, int attention);
 /* codes (S,B) int64 (rows 0 .. max(1, n_pre) - 1 are read); h_init (2,B,H); enc (Tw,B,H) and enc_proj = enc W_attn[:, H:]^T

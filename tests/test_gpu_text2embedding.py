@@ -321,12 +321,14 @@ def test_fused_step_kernels_match_per_operator_path(att, p, B, n_pre, H, K, monk
     assert checked >= 20
 
 
+@pytest.mark.parametrize("bptt", [True, False])
 @pytest.mark.parametrize("p,B,n_pre,H,K", [(0.2, 128, 1, 200, 512), (0.0, 128, 1, 200, 512), (0.2, 37, 3, 200, 512), (0.1, 300, 1, 52, 64),
                                            (0.2, 16, 1, 48, 40), (0.0, 130, 2, 64, 176)])
-def test_cluster_forward_matches_per_operator_path(p, B, n_pre, H, K, monkeypatch):
+def test_cluster_forward_matches_per_operator_path(p, B, n_pre, H, K, bptt, monkeypatch):
     """Small batch, no attention (round 5): the greedy forward rollout as ONE persistent cluster launch (csrc/t2e_rollout.hip:
     code_cluster_fwd_kernel, behind g2v_attn_code_rollout_fwd) with the PER-OPERATOR backward on the arrays it saved, against
-    the per-operator forward + backward: the reference's B = 128 / H = 200 / K = 512, ragged row groups, teacher-forced prefixes,
+    the per-operator forward + backward (bptt = True: the GRU cells' BPTT as one persistent cluster launch too, g2v_code_cluster_bptt):
+    the reference's B = 128 / H = 200 / K = 512, ragged row groups, teacher-forced prefixes,
     H % 16 != 0, 19 row groups, K tiles unevenly spread over the workgroups.  Equal to a few 1e-6 (BatchNorm sums from per-workgroup
     partial sums, k-split products), the greedy codes fed back are the same."""
     from gesture2vec_amd import rollout_t2e
@@ -351,7 +353,8 @@ def test_cluster_forward_matches_per_operator_path(p, B, n_pre, H, K, monkeypatc
              (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None, None)
     w = torch.randn(B, S, K, generator=g).to(DEV)
     outs = []
-    calls0 = rollout_t2e.CLUSTER_CALLS
+    calls0, bcalls0 = rollout_t2e.CLUSTER_CALLS, rollout_t2e.CLUSTER_BPTT_CALLS
+    monkeypatch.setattr(rollout_t2e, "CLUSTER_BACKWARD", bptt)
     for net, cluster in zip(nets, (True, False)):
         monkeypatch.setattr(rollout_t2e, "CLUSTER_FORWARD", cluster)
         net.set_dropout_masks(*masks)
@@ -359,6 +362,7 @@ def test_cluster_forward_matches_per_operator_path(p, B, n_pre, H, K, monkeypatc
         (out * w).sum().backward()
         outs.append(out.detach())
     assert rollout_t2e.CLUSTER_CALLS - calls0 == 1, "the cluster kernel did not serve this shape (g2v_attn_code_rollout_cluster_ok)"
+    assert rollout_t2e.CLUSTER_BPTT_CALLS - bcalls0 == (1 if bptt else 0)
     from gesture2vec_amd import _lib
     assert _lib.load().g2v_dec_rollout_persist_fault(0) == 0
     assert relerr(outs[0], outs[1].cpu()) < 3e-5
