@@ -873,16 +873,6 @@ __device__ __forceinline__ void ccl_publish4(__amdgpu_buffer_rsrc_t rr, unsigned
   px_st(rr, granule * 8u, a);
   px_st(rr, granule * 8u + 16u, b);
 }
-// one granule {value, tag}: poll until the tag is there
-__device__ __forceinline__ unsigned ccl_wait_granule(const unsigned long long* p, unsigned tag, unsigned* fault) {
-  unsigned spins = 0;
-  for (;;) {
-    const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((unsigned)(v >> 32) == tag) return (unsigned)v;
-    __builtin_amdgcn_s_sleep(1);
-    if (cx_give_up(spins, fault)) return (unsigned)v;
-  }
-}
 // column f of the per-row-group partial sums [nblk][2][Hp] (granules), summed over the row groups in ascending order
 __device__ __forceinline__ void ccl_sum_partials(const unsigned long long* rec, int nblk, int Hp, int f, unsigned tag, unsigned* fault,
                                                  float& s1, float& s2) {
