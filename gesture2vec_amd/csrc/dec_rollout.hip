@@ -1406,7 +1406,7 @@ __global__ __launch_bounds__(64) void dec_out_pre_split_kernel(DecOutPreArgs a, 
 #define DCB_STAMP(k)
 #endif
 struct DecClFwdArgs {
-  const float* target; const uint8_t* keep95; const uint8_t* keep_l0;
+  const float* target; const float* h_init; const uint8_t* keep95; const uint8_t* keep_l0;
   g2v_dec_weights w; g2v_dec_saved sv;
   unsigned long long* xu;      // [2][nblk][16][Hp]  u rows
   unsigned long long* xp;      // [2][nblk][2][Hp]   BN partial sums of (u - b), (u - b)^2 per row group
@@ -1571,14 +1571,14 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   float4* yp_s = wo_s + (size_t)4 * KS * 64;        // [wave][D tile][64]
   float4* xs_x1 = yp_s + (size_t)4 * DSPLIT_DT * 64; // [KS][64]
   float4* xcx = xs_x1 + (size_t)KS * 64;             // [gate][64]
-  // the rows entering step 1, from the arrays the t = 0 launch wrote: as fragments, zeros in rows / columns that do not exist (the
-  // sweeps never touch those entries)
+  // the state rows entering step 1 = the initial states (the quantised latent): as fragments, zeros in rows / columns that do not
+  // exist (the sweeps never touch those entries)
   for (int ks = wave; ks < KS; ks += 4) {
     const int k = 16 * ks + 4 * q;
     const bool ok = k < H && rvalid;
-    xs_u[ks][lane] = ld4_or_zero(sv.u + (int64_t)b * H + (ok ? k : 0), ok);
-    xs_h0[ks][lane] = ld4_or_zero(sv.h0 + (int64_t)b * H + (ok ? k : 0), ok);
-    xs_h1[ks][lane] = ld4_or_zero(sv.h1 + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_u[ks][lane] = make_float4(0.f, 0.f, 0.f, 0.f);
+    xs_h0[ks][lane] = ld4_or_zero(a.h_init + (int64_t)b * H + (ok ? k : 0), ok);
+    xs_h1[ks][lane] = ld4_or_zero(a.h_init + BH + (int64_t)b * H + (ok ? k : 0), ok);
     xs_x1[ks * 64 + lane] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const bool drop = a.training && a.keep_l0 && a.p_drop > 0.f;
@@ -1590,13 +1590,16 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(a.xh1, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
   float hown[4] = {0.f, 0.f, 0.f, 0.f};      // waves 0 / 2: this tile's own h0 / h1 entering the step (the lane's 4 units)
   if ((wave == 0 || wave == 2) && rvalid && fok) {
-    const float4 v = *reinterpret_cast<const float4*>((wave == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0);      // index 0 of the state arrays
+    const float4 v = *reinterpret_cast<const float4*>(a.h_init + (wave == 0 ? 0 : BH) + (int64_t)b * H + f0);
     hown[0] = v.x; hown[1] = v.y; hown[2] = v.z; hown[3] = v.w;
+    *reinterpret_cast<float4*>((wave == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0) = v;      // index 0 of the state arrays
   }
   lds_barrier();      // the LDS operands above are complete
-  for (int t = 1; t < T; ++t) {
-    const unsigned par_prev = (unsigned)((t - 1) & 1), par = (unsigned)(t & 1), tag = (unsigned)t;
+  for (int t = 0; t < T; ++t) {
+    // (t = 0: y_0 = the target's first frame, no cells: only the out / pre_linear stage below, which publishes u_1 with tag 1)
+    const unsigned par_prev = (unsigned)((t + 1) & 1), par = (unsigned)(t & 1), tag = (unsigned)t;
     DCL_STAMP(0);
+   if (t > 0) {
     // ---- the hidden sides first (their operands have been in LDS since the previous step): wave 1 all of cell 0's, the gate waves
     // their gate of cell 1's; then the gate waves sweep the u_t row and add up the BatchNorm sums ------------------------------------
     uint32_t kp = 0x01010101u;
@@ -1628,16 +1631,14 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
         acc = mfma16(wreg[2][ks].w, x4.w, acc);
       }
       xch2[1][gx * 64 + lane] = make_float4(acc[0], acc[1], acc[2], acc[3]);
-      if (t > 1)
-        cx_sweep_tiles<(KS + 2) / 3>(r_u, (par_prev * (unsigned)nblk + (unsigned)rg) * rowrec, gx, 3, nt, nrows, H, tag, &xs_u[0][0], lane, a.fault);
+      cx_sweep_tiles<(KS + 2) / 3>(r_u, (par_prev * (unsigned)nblk + (unsigned)rg) * rowrec, gx, 3, nt, nrows, H, tag, &xs_u[0][0], lane, a.fault);
     }
     // ---- BatchNorm statistics of step t: every feature (each workgroup needs the whole input row) -------------------------------
     for (int f = gx * 64 + lane; f < H && xw; f += 192) {
       float mean, var;
       if (a.training) {
         float s1, s2;
-        if (t == 1) sum_partials(sv.bn_partial, nblk, H, f, s1, s2);      // (parity 0: written by the t = 0 launch)
-        else dcl_sum_partials(a.xp + (size_t)par_prev * nblk * prec, nblk, Hp, f, tag, a.fault, s1, s2);
+        dcl_sum_partials(a.xp + (size_t)par_prev * nblk * prec, nblk, Hp, f, tag, a.fault, s1, s2);
         const float mv = s1 / (float)B;
         var = fmaxf(s2 / (float)B - mv * mv, 0.f);     // biased batch variance
         mean = mv + w.b_pre[f];
@@ -1782,6 +1783,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
       for (int r = 0; r < 4; ++r) hown[r] = hn[r];
     }
     DCL_STAMP(10);
+   }
     // ---- y_t = out_layer(h1_t): wave 3 sweeps the row, every wave multiplies its D tile ------------------------------------------------
     const bool has_next = t < T - 1, teacher = has_next && t < a.n_pre;
     float tgv[4];      // teacher-forced inputs / Dropout(0.95) flags of the lane's four y elements: requested in front of the exchange
@@ -1790,10 +1792,10 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
     for (int r = 0; r < 4; ++r) {
       const int d = 16 * wave + 4 * q + r;
       const bool ok = wave < ndt && d < D && rvalid;
-      tgv[r] = (ok && teacher) ? a.target[((int64_t)b * T + t) * D + d] : 0.f;
+      tgv[r] = (ok && (teacher || t == 0)) ? a.target[((int64_t)b * T + t) * D + d] : 0.f;
       k95v[r] = (ok && has_next && a.conditioned) ? a.keep95[(int64_t)t * BD + (int64_t)b * D + d] : 0;
     }
-    if (wave != 2)      // (wave 2 has just published its tile: the other three sweep)
+    if (wave != 2 && t > 0)      // (wave 2 has just published its tile: the other three sweep)
       cx_sweep_tiles<(KS + 2) / 3>(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, wave == 3 ? 2 : wave, 3, nt, nrows, H, tag, &xs_h1[0][0], lane,
                                    a.fault);
     DCL_STAMP(11);
@@ -1840,7 +1842,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int d = 16 * wave + 4 * q + r;
         const bool ok = wave < ndt && d < D && rvalid;
-        const float y = ya[r] + bo[r];
+        const float y = t == 0 ? tgv[r] : ya[r] + bo[r];      // (y_0 = the target's first frame)
         const float tg = tgv[r];
         const uint8_t k95 = k95v[r];
         const float src = teacher ? tg : y;                                           // :1049-1052
@@ -2582,10 +2584,11 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     return G2V_ERR_UNSUPPORTED;
   }
   hipStream_t st = (hipStream_t)stream;
-  // ---- pack the weights into MFMA fragment order (one launch) ----
+  // ---- pack the weights into MFMA fragment order (one launch; the cluster kernel below reads them in place) ----
   PackBatch pb;
   const DecPackF pk = dec_fwd_pack_layout(w, D, H, workspace, pb);
-  if (!prepared) {
+  const bool maybe_cluster = g2v_dec_rollout_cluster_ok(B, D, H) && T >= 3;
+  if (!prepared && !maybe_cluster) {
     launch_pack(pb, st);
     G2V_CHECK_LAUNCH();
   }
@@ -2638,12 +2641,16 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess;
     cluster = attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, dyn) == hipSuccess && nocc >= 1;
   }
+  if (maybe_cluster && !cluster) {      // (the cluster path was declined after all: the per-step kernels need the packed weights)
+    launch_pack(pb, st);
+    G2V_CHECK_LAUNCH();
+  }
   for (int t = 0; t < T; ++t) {
-    if (cluster && t == 1) {
+    if (cluster && t == 0) {
       const size_t Hp = (size_t)((H + 15) & ~15), rowrec = (size_t)2 * dm.nblk * 16 * Hp;
       unsigned long long* x0 = reinterpret_cast<unsigned long long*>((char*)workspace + fwd_pack_bytes_aligned(D, H));
       DecClFwdArgs ca;
-      ca.target = target; ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
+      ca.target = target; ca.h_init = h_init; ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
       ca.xu = x0; ca.xh0 = x0 + rowrec; ca.xh1 = x0 + 2 * rowrec; ca.xp = x0 + 3 * rowrec;
       ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
       ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.training = training;
