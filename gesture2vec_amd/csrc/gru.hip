@@ -824,6 +824,7 @@ struct GruClF {
   int reverse;
 };
 struct GruClB {
+  const float* hn_z; const float* hn_q; const float* hn_gloss; float hn_coef;      // optional: quantiser backward folded into d_hn
   const float* d_hs; const float* hs; const float* h0; const float* gates; const float* w_hh; const float* d_hn;
   float* dgi; float* dgh; float* dh0;
   unsigned long long* xch;     // [2][nblk][16][Gp] granules {dgh value, tag}
@@ -1064,6 +1065,13 @@ __global__ __launch_bounds__(192) void gru_cluster_bwd_kernel(GruClB d0, GruClB 
       } else if (d.d_hn && rvalid && fok) {
         const float4 v = *reinterpret_cast<const float4*>(d.d_hn + (int64_t)b * H + f0);
         dh[0] = v.x; dh[1] = v.y; dh[2] = v.z; dh[3] = v.w;
+        if (d.hn_z) {      // + gloss coef (z - q): vq_bwd_kernel's arithmetic (vq.hip), its launch saved
+          const float c = d.hn_gloss[0] * d.hn_coef;
+          const float4 zv = *reinterpret_cast<const float4*>(d.hn_z + (int64_t)b * H + f0);
+          const float4 qv = *reinterpret_cast<const float4*>(d.hn_q + (int64_t)b * H + f0);
+          dh[0] = fmaf(c, zv.x - qv.x, dh[0]); dh[1] = fmaf(c, zv.y - qv.y, dh[1]);
+          dh[2] = fmaf(c, zv.z - qv.z, dh[2]); dh[3] = fmaf(c, zv.w - qv.w, dh[3]);
+        }
       }
       float g_r[4] = {0.f, 0.f, 0.f, 0.f}, g_z[4] = {0.f, 0.f, 0.f, 0.f}, g_n[4] = {0.f, 0.f, 0.f, 0.f}, g_hn[4] = {0.f, 0.f, 0.f, 0.f};
       if (tn < 0) {                                          // after the last step: the gradient of the initial state
@@ -1738,9 +1746,15 @@ static size_t gru_cluster_max_xch_bytes(int H, bool bwd) {
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16, cus = (size_t)gru_device_cus();
   return (bwd ? cus : cus / nt + 1) * 2 * 16 * Hp * 8;
 }
+static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn);
+// 1: g2v_gru_seq_fwd / _bwd run this shape as the persistent cluster kernels (small batch; see g2v_gru_seq_set_cluster)
+extern "C" int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir) {
+  return (ndir >= 1 && ndir <= 2 && gru_cluster_ok(T, B, ndir, H, nullptr)) ? 1 : 0;
+}
 static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn) {
   if (!g_gru_cluster || !gru_split_ok(B, ndir, H) || T < 2 || T > (1 << 20)) return false;
   if ((int64_t)cdiv(B, 16) * cdiv(H, 16) * ndir > gru_device_cus()) return false;
+  if (fn == nullptr) return true;      // (the shape query: the occupancy check is the launch's)
   int n = 0;
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 192, 0) == hipSuccess && n >= 1;
 }
@@ -2075,11 +2089,19 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     if (fuse) G2V_REQUIRE(dirs[k].w_ih, "dx != NULL needs w_ih");
   }
   const bool fast = gru_fast_ok(H, hs_ld) && (d_hs_ld & 3) == 0;
-  for (int k = 0; k < ndir; ++k)
-    if (dirs[k].hn_z && !(fast && dirs[k].hn_q && dirs[k].hn_gloss && aligned16(dirs[k].hn_z) && aligned16(dirs[k].hn_q))) {
-      set_error("g2v_gru_seq_bwd: the fused quantiser backward (hn_z, hn_q, hn_gloss) needs the H == 64 kernels and 16-byte-aligned slices");
+  // (the fused quantiser backward: the H == 64 kernels, or the small-batch cluster kernel -- g2v_gru_seq_cluster_ok)
+  const bool hn_cluster = !fast && gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_bwd_kernel) &&
+                          gru_cluster_xch_bytes(B, ndir, H, true) <= workspace_bytes;
+  bool hn_any = false;
+  for (int k = 0; k < ndir; ++k) {
+    hn_any = hn_any || dirs[k].hn_z != nullptr;
+    if (dirs[k].hn_z && !((fast || hn_cluster) && dirs[k].d_hn && dirs[k].hn_q && dirs[k].hn_gloss && aligned16(dirs[k].hn_z) &&
+                          aligned16(dirs[k].hn_q))) {
+      set_error("g2v_gru_seq_bwd: the fused quantiser backward (hn_z, hn_q, hn_gloss) needs the H == 64 kernels or the cluster "
+                "kernels (g2v_gru_seq_cluster_ok), d_hn and 16-byte-aligned slices");
       return G2V_ERR_UNSUPPORTED;
     }
+  }
   if (fuse && !(fast && dirs[0].in_dim == H && (ndir == 1 || dirs[1].in_dim == H))) {
     set_error("g2v_gru_seq_bwd: fused input gradient needs H == in_dim == 64 (use g2v_linear_bwd_data otherwise)");
     return G2V_ERR_UNSUPPORTED;
@@ -2176,7 +2198,8 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     if (gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_bwd_kernel) && xbytes <= workspace_bytes) {
       GruClB c[2];
       for (int k = 0; k < ndir; ++k)
-        c[k] = GruClB{dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, dirs[k].w_hh, dirs[k].d_hn, dirs[k].dgi, dirs[k].dgh,
+        c[k] = GruClB{dirs[k].hn_z, dirs[k].hn_q, dirs[k].hn_gloss, dirs[k].hn_coef,
+                      dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, dirs[k].w_hh, dirs[k].d_hn, dirs[k].dgi, dirs[k].dgh,
                       dirs[k].dh0, reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (xbytes / ndir)),
                       dirs[k].reverse};
       if (ndir == 1) c[1] = c[0];
@@ -2189,6 +2212,10 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
                          hs_ld, T, B, H, ro, want_dh0 ? T : T - 1, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
       G2V_CHECK_LAUNCH();
       return G2V_OK;
+    }
+    if (hn_any) {
+      set_error("g2v_gru_seq_bwd: the fused quantiser backward was requested but the cluster kernel does not serve this call");
+      return G2V_ERR_UNSUPPORTED;
     }
     float* carry = p + (size_t)ndir * 3 * H * H;      // [dir][B][H], after the transposed weights (3 H^2 floats: 16-byte multiple)
     for (int k = 0; k < ndir; ++k) launch_transpose(dirs[k].w_hh, p + (size_t)k * 3 * H * H, 3 * H, H, st);

@@ -729,7 +729,7 @@ class VQVAEEngine:
         # ---- quantiser backward: straight-through + commitment (:1285-1292) ------------------------------------
         N = (2 * B * H) // E
         gl = g_loss_vq if g_loss_vq is not None else self.g_loss_vq
-        if self._fuse_vq_bwd and H == 64:
+        if self._fuse_vq_bwd and (H == 64 or self.lib.g2v_gru_seq_cluster_ok(self.T, B, H, 2)):
             # straight-through + commitment gradient formed by the BPTT kernel where it reads its incoming gradient: a 4 us kernel
             # that took 12-15 us beside the decoder's products, plus a kernel boundary, off the critical chain
             self._release()                 # branch 2 (the decoder's weight gradients, forked in backward_decoder)

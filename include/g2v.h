@@ -259,6 +259,9 @@ int g2v_gru_seq_packed_ok(int T, int B, int H);
  * co-resident; a bounded wait that runs out latches g2v_dec_rollout_persist_fault.  This switch (default 1; 0 = one launch per
  * step) exists for parity tests, A/B measurements and the fall-back after a latched fault.  Returns the previous setting. */
 int g2v_gru_seq_set_cluster(int enable);
+/* 1: this shape runs as the cluster kernels under the current setting (then g2v_gru_dir_bwd.hn_z .. hn_coef, the fused quantiser
+ * backward below, are honoured at H != 64 too) */
+int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir);
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
 size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */
@@ -285,7 +288,8 @@ typedef struct {
   const float* x;
   float* dw_hh; float* db_hh; float* dw_ih; float* db_ih;
   float* wslab;
-  /* Optional (hn_z != NULL; H == 64 fast kernels only, G2V_ERR_UNSUPPORTED elsewhere): the quantiser's backward (K5', g2v_vq_bwd
+  /* Optional (hn_z != NULL; the H == 64 fast kernels and the small-batch cluster kernels -- g2v_gru_seq_cluster_ok --,
+   * G2V_ERR_UNSUPPORTED elsewhere): the quantiser's backward (K5', g2v_vq_bwd
    * with a dense quantised tensor) applied where d_hn is read,
    *   d_hn_effective[b,h] = d_hn[b,h] + hn_gloss[0] * hn_coef * (hn_z[b,h] - hn_q[b,h]),
    * i.e. the straight-through gradient plus the commitment term (model/Autoencoder_VQVAE_model.py:1285-1292) when the final
