@@ -189,7 +189,10 @@ class VQVAEEngine:
         # of the rollout's exchange regions (everything that depends on the weights only and is not needed at once) inside
         # branch 0, beside the encoder (a branch of their own costs more at its fork and join than the 25 us it hides).
         # G2V_OVERLAP=0 serialises everything on the caller's stream (debugging).
-        self.overlap = int(os.environ.get("G2V_OVERLAP", "15"))
+        # Bit 4: the encoder's GRU weight gradients beside its input layer's gradient chain -- pays on the generic dims (native
+        # B = 128 1.235 -> 1.206 ms, GENEA dims 0.745 -> 0.727, native B = 4096 7.15 -> 7.10), costs 1.5 % at H = 64 where those
+        # products are fused elsewhere (profiles/r05_u2_branch4.log): on by default for H != 64 only.
+        self.overlap = int(os.environ.get("G2V_OVERLAP", "15" if H == 64 else "31"))
         self.tracked_counters = []          # [(int64 device tensor, increment)]: bumped once per train step on the side branch
         self._prepared = False          # the workspaces of this step's recurrent launches hold their packs already
         # A fork / join costs an event record + wait on the host when launched eagerly and ~10-20 us inside a replayed graph: where
