@@ -1947,6 +1947,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
   __shared__ __attribute__((aligned(16))) float4 xs_dy[DSPLIT_DT][64];           // dy rows (D tiles as k-steps)
   __shared__ __attribute__((aligned(16))) float4 xs_g[6][64];                    // the stage's gate gradients: dgh r z hn, dgi r z n
   __shared__ __attribute__((aligned(16))) float4 dsum[4][64];                    // [wave] its share of the partial products, summed
+  __shared__ __attribute__((aligned(16))) float4 wot_s[DSPLIT_DT][64];           // W_out^T fragments of the tile
   extern __shared__ __attribute__((aligned(16))) float4 wpt_s[];                 // [D tile][KS][64]: W_pre^T fragments
   const int T = a.T, B = a.B, D = a.D, H = a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
@@ -1979,17 +1980,18 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
         wq[c][j][g] = make_float4(v[0], v[1], v[2], v[3]);
       }
     }
-  // W_out^T fragments of the tile (wave 0's dy W_out product): W_out[16 dt + 4 q + e][16 ft + i]
-  float4 wot[DSPLIT_DT];
+  // W_out^T fragments of the tile (wave 0's dy W_out product): W_out[16 dt + 4 q + e][16 ft + i] -- in LDS (registers are short)
+  if (wave == 0) {
 #pragma unroll
-  for (int dt = 0; dt < DSPLIT_DT; ++dt) {
-    float v[4];
+    for (int dt = 0; dt < DSPLIT_DT; ++dt) {
+      float v[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = 16 * dt + 4 * q + e;
-      v[e] = (wrow_ok && d < D) ? w.w_out[(int64_t)d * H + 16 * ft + i] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int d = 16 * dt + 4 * q + e;
+        v[e] = (wrow_ok && d < D) ? w.w_out[(int64_t)d * H + 16 * ft + i] : 0.f;
+      }
+      wot_s[dt][lane] = make_float4(v[0], v[1], v[2], v[3]);
     }
-    wot[dt] = make_float4(v[0], v[1], v[2], v[3]);
   }
   // W_pre^T fragments (rows d, contraction over the H features): wave dt fills its D tile
   for (int ks = 0; ks < KS; ++ks) {
@@ -2139,11 +2141,11 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
 #pragma unroll
       for (int dt = 0; dt < DSPLIT_DT; ++dt) {
         if (dt < ndt) {
-          const float4 x4 = xs_dy[dt][lane];
-          acc = mfma16(wot[dt].x, x4.x, acc);
-          acc = mfma16(wot[dt].y, x4.y, acc);
-          acc = mfma16(wot[dt].z, x4.z, acc);
-          acc = mfma16(wot[dt].w, x4.w, acc);
+          const float4 x4 = xs_dy[dt][lane], w4 = wot_s[dt][lane];
+          acc = mfma16(w4.x, x4.x, acc);
+          acc = mfma16(w4.y, x4.y, acc);
+          acc = mfma16(w4.z, x4.z, acc);
+          acc = mfma16(w4.w, x4.w, acc);
         }
       }
       float dh[4], g_r[4], g_z[4], g_n[4], g_hn[4];
