@@ -2226,6 +2226,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
             *reinterpret_cast<float4*>(gi) = vr; *reinterpret_cast<float4*>(gi + H) = vz; *reinterpret_cast<float4*>(gi + 2 * H) = vn;
             *reinterpret_cast<float4*>(gh) = vr; *reinterpret_cast<float4*>(gh + H) = vz; *reinterpret_cast<float4*>(gh + 2 * H) = vh;
           }
+          DCB_STAMP(10);
         } else {
           // carry0' = dh0 z + dgh0 W_hh0 | da = dgi0 W_ih0 -> ReLU backward -> dbn of step index t - 1 and its BatchNorm sums
           float dbn[4] = {0.f, 0.f, 0.f, 0.f}, dbx[4] = {0.f, 0.f, 0.f, 0.f}, s1[4], s2[4];
