@@ -172,14 +172,49 @@ __device__ __forceinline__ bool cx_give_up(unsigned& spins, unsigned* fault) {
 }
 __device__ __forceinline__ unsigned cx_tile_granule(int tile, int i, int q) { return (unsigned)(((tile * 16 + i) * 4 + q) * 4); }
 // lane (i, q) publishes v[0..3] = columns 16 tile + 4 q .. + 3 of row i
+// xcd_local: every reader of the record runs on the publisher's XCD (cx_cluster_on_one_xcd below) -- a PLAIN store then, which
+// leaves the line in that XCD's L2, where the readers' sc1 loads (they bypass L1 only) find it without the fabric round trip.
 __device__ __forceinline__ void cx_publish4(__amdgpu_buffer_rsrc_t rr, unsigned rec_granule0, int tile, int i, int q, const float* v,
-                                            unsigned tag) {
+                                            unsigned tag, bool xcd_local = false) {
   u32x4 a, b;
   a[0] = __float_as_uint(v[0]); a[1] = tag; a[2] = __float_as_uint(v[1]); a[3] = tag;
   b[0] = __float_as_uint(v[2]); b[1] = tag; b[2] = __float_as_uint(v[3]); b[3] = tag;
   const unsigned off = (rec_granule0 + cx_tile_granule(tile, i, q)) * 8u;
-  px_st(rr, off, a);
-  px_st(rr, off + 16u, b);
+  if (xcd_local) {
+    px_st_l2(rr, off, a);
+    px_st_l2(rr, off + 16u, b);
+  } else {
+    px_st(rr, off, a);
+    px_st(rr, off + 16u, b);
+  }
+}
+// Do the `n` workgroups of this cluster (the ones that exchange row records with each other) run on ONE XCD?  Every workgroup
+// announces the XCC it runs on (HW_REG_XCC_ID + 1, write-through, into word `me` of `words`: zeroed with the exchange records) and
+// reads all n words: all equal => the cluster's records may go through that XCD's L2.  All n workgroups read the same n words, so
+// the cluster decides as one; placement is observed (round-robin over the linear workgroup id), never promised -- a cluster that
+// is not on one XCD simply keeps the write-through stores.  Called by every thread of the workgroup; `flag` is one LDS word.
+__device__ __forceinline__ bool cx_cluster_on_one_xcd(unsigned* words, int n, int me, int* flag, int tid, unsigned* fault) {
+  if (tid == 0) {
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    __hip_atomic_store(words + me, (xcc & 0xfu) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool same = true;
+    unsigned first = 0u;
+    for (int m = 0; m < n; ++m) {
+      unsigned v, spins = 0;
+      for (;;) {
+        v = __hip_atomic_load(words + m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v != 0u) break;
+        __builtin_amdgcn_s_sleep(1);
+        if (cx_give_up(spins, fault)) break;
+      }
+      if (m == 0) first = v;
+      same = same && v == first && v != 0u;
+    }
+    *flag = same ? 1 : 0;
+  }
+  lds_barrier();
+  return *flag != 0;
 }
 // One wave sweeps NTL tiles t0, t0 + tstr, ... (those < nt) of a row record into xs (LDS: [tile][64] float4, fragment layout).
 // Rows >= nrows and columns >= K are never published: zeros are written for them.  First a SENTINEL poll -- lane j watches the

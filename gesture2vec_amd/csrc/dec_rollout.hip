@@ -1034,16 +1034,16 @@ static size_t pack_bwd_total(int D, int H) {
 // [packed forward weights | (256-byte aligned) exchange state of the persistent kernel]
 static size_t fwd_pack_bytes_aligned(int D, int H) { return (pack_fwd_total(D, H) * sizeof(float) + 255) / 256 * 256; }
 // exchange records of dec_cluster_fwd_kernel: three (16 x Hp) row records + one (2 x Hp) record of partial sums per (parity, row group)
-static size_t dec_cluster_fwd_xch_bytes(int nblk, int H) {
+static size_t dec_cluster_fwd_xch_bytes(int nblk, int H) {      // (+ one XCC word per workgroup)
   const size_t Hp = (size_t)((H + 15) & ~15);
-  return (size_t)2 * nblk * (3 * 16 + 2) * Hp * 8;
+  return (size_t)2 * nblk * (3 * 16 + 2) * Hp * 8 + (size_t)nblk * (Hp / 16) * 4 + 16;
 }
 // (H <= 208 = 13 k-steps: with 16 the weight fragments + a sweep's granules no longer fit the register file -- 186 spills)
 constexpr int DCL_KS = 13;
 // backward: dbn row records + partial sums (both parities) and four partial-product row records per (row group, producer tile)
 static size_t dec_cluster_bwd_xch_bytes(int nblk, int H) {
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
-  return ((size_t)2 * nblk * (16 + 2) * Hp + (size_t)nblk * 4 * nt * 16 * Hp) * 8;
+  return ((size_t)2 * nblk * (16 + 2) * Hp + (size_t)nblk * 4 * nt * 16 * Hp) * 8 + (size_t)nblk * nt * 4 + 16;
 }
 static size_t dec_cluster_bwd_dyn_lds() { return (size_t)4 * 13 /* DCL_KS */ * 64 * sizeof(float4); }
 static size_t dec_cluster_fwd_dyn_lds() {      // W_out fragments, partial out-layer products, Dropout(h0) rows, input-side accumulators
@@ -1412,8 +1412,9 @@ struct DecClFwdArgs {
   unsigned long long* xp;      // [2][nblk][2][Hp]   BN partial sums of (u - b), (u - b)^2 per row group
   unsigned long long* xh0;     // [2][nblk][16][Hp]
   unsigned long long* xh1;     // [2][nblk][16][Hp]
+  unsigned* xcc;               // [nblk][nt]: the XCC every workgroup runs on (cx_cluster_on_one_xcd)
   unsigned* fault;
-  int T, B, D, H, n_pre, conditioned, training;
+  int T, B, D, H, n_pre, conditioned, training, nt, nblk;
   float p_drop;
 };
 
@@ -1502,7 +1503,12 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
   // W_ih1 (the two input sides, on the critical path: 52 MFMAs per wave instead of 156 on one) and of W_hh1
   const bool xw = wave != 1;
   const int gx = wave == 0 ? 0 : wave - 1;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  // 1-D grid.  With nblk % 8 == 0 the row group is the FAST index of the linear workgroup id: under the dispatcher's round-robin
+  // placement (workgroup id % 8 = XCD; observed, verified per launch below) the nt tile workgroups of a row group then share an XCD
+  const int nt = a.nt, nblk = a.nblk;
+  const bool rg_fast = (nblk & 7) == 0;
+  const int ft = rg_fast ? (int)blockIdx.x / nblk : (int)blockIdx.x % nt, rg = rg_fast ? (int)blockIdx.x % nblk : (int)blockIdx.x / nt;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const int Hp = nt << 4, ndt = (D + 15) >> 4;
   const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
@@ -1594,7 +1600,8 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
     hown[0] = v.x; hown[1] = v.y; hown[2] = v.z; hown[3] = v.w;
     *reinterpret_cast<float4*>((wave == 0 ? sv.h0 : sv.h1) + (int64_t)b * H + f0) = v;      // index 0 of the state arrays
   }
-  lds_barrier();      // the LDS operands above are complete
+  __shared__ int xcd_flag;
+  const bool l2x = cx_cluster_on_one_xcd(a.xcc + (size_t)rg * nt, nt, ft, &xcd_flag, tid, a.fault);      // (also: the LDS operands above are complete)
   for (int t = 0; t < T; ++t) {
     // (t = 0: y_0 = the target's first frame, no cells: only the out / pre_linear stage below, which publishes u_1 with tag 1)
     const unsigned par_prev = (unsigned)((t + 1) & 1), par = (unsigned)(t & 1), tag = (unsigned)t;
@@ -1701,7 +1708,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
       dcl_cell_epilogue(xcx, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
 #pragma unroll
       for (int r = 0; r < 4; ++r) xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * scale_l0 : 0.f) : hn[r];
-      cx_publish4(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+      cx_publish4(r_h0, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag, l2x);
       *reinterpret_cast<float4*>(sv.h0 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       if (drop && sv.x1) *reinterpret_cast<float4*>(sv.x1 + (int64_t)(t - 1) * BH + (int64_t)b * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
       if (sv.gates0) {
@@ -1770,7 +1777,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
     if (wave == 2 && rvalid && fok) {
       float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
       dcl_cell_epilogue(xcx, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
-      cx_publish4(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+      cx_publish4(r_h1, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag, l2x);
       *reinterpret_cast<float4*>(sv.h1 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       if (sv.gates1) {
         float* go = sv.gates1 + (int64_t)(t - 1) * 4 * BH + (int64_t)b * 4 * H + f0;
@@ -1881,7 +1888,7 @@ __global__ __launch_bounds__(256) void dec_cluster_fwd_kernel(DecClFwdArgs a) {
         if (rvalid) {
           const float4 bp = wp_s[DSPLIT_DT][lane];
           const float un[4] = {ua[0] + bp.x, ua[1] + bp.y, ua[2] + bp.z, ua[3] + bp.w};
-          cx_publish4(r_u, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, tag + 1u);
+          cx_publish4(r_u, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, tag + 1u, l2x);
           *reinterpret_cast<float4*>(sv.u + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(un[0], un[1], un[2], un[3]);
         }
         if (i == 0) {
@@ -1912,8 +1919,9 @@ struct DecClBwdArgs {
   unsigned long long* xd;      // [2][nblk] row records: dbn rows
   unsigned long long* xp;      // [2][nblk][2][Hp]: BatchNorm-backward partial sums
   unsigned long long* xq;      // [nblk][hh1, ih1, hh0, ih0][producer tile] row records: partial products
+  unsigned* xcc;               // [nblk][nt]
   unsigned* fault;
-  int T, B, D, H, n_pre, conditioned;
+  int T, B, D, H, n_pre, conditioned, nt, nblk;
   float p_drop;
 };
 
@@ -1951,7 +1959,10 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float4 wpt_s[];                 // [D tile][KS][64]: W_pre^T fragments
   const int T = a.T, B = a.B, D = a.D, H = a.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  const int nt = a.nt, nblk = a.nblk;      // (1-D grid, the mapping of dec_cluster_fwd_kernel)
+  const bool rg_fast = (nblk & 7) == 0;
+  const int ft = rg_fast ? (int)blockIdx.x / nblk : (int)blockIdx.x % nt, rg = rg_fast ? (int)blockIdx.x % nblk : (int)blockIdx.x / nt;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const int Hp = nt << 4, ndt = (D + 15) >> 4, G = 3 * H;
   const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
@@ -2018,7 +2029,8 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
   const unsigned q_rg = (unsigned)rg * 4u * (unsigned)nt * rowrec;      // this row group's pair records
   float carry1[4] = {0.f, 0.f, 0.f, 0.f}, carry0[4] = {0.f, 0.f, 0.f, 0.f};      // (wave 0)
   float acc_bw = 0.f, acc_bb = 0.f;                                                // d bn weight / bias of feature tid (workgroup (0, 0))
-  lds_barrier();
+  __shared__ int xcd_flag;
+  const bool l2x = cx_cluster_on_one_xcd(a.xcc + (size_t)rg * nt, nt, ft, &xcd_flag, tid, a.fault);
   for (int t = T - 1; t >= 0; --t) {
     const bool last = t == T - 1;
     const unsigned tag = (unsigned)(T - t), par = (unsigned)(t & 1), par_next = (unsigned)((t + 1) & 1);
@@ -2187,7 +2199,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
             acc = mfma16(wq[c][j][2].z, x2.z, acc); acc = mfma16(wq[c][j][2].w, x2.w, acc);
             if (rvalid && 16 * ot + 4 * q < H) {
               const float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag);
+              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag, l2x);
             }
           }
         }
@@ -2241,7 +2253,7 @@ __global__ __launch_bounds__(256) void dec_cluster_bwd_kernel(DecClBwdArgs a) {
             }
           }
           if (own) {
-            cx_publish4(r_d, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, dbn, tag);
+            cx_publish4(r_d, (par * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, dbn, tag, l2x);
             *reinterpret_cast<float4*>(gr.dbn + (int64_t)(t - 1) * BH + (int64_t)b * H + f0) = make_float4(dbn[0], dbn[1], dbn[2], dbn[3]);
           }
 #pragma unroll
@@ -2655,14 +2667,16 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
       DecClFwdArgs ca;
       ca.target = target; ca.h_init = h_init; ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
       ca.xu = x0; ca.xh0 = x0 + rowrec; ca.xh1 = x0 + 2 * rowrec; ca.xp = x0 + 3 * rowrec;
+      ca.xcc = reinterpret_cast<unsigned*>(ca.xp + (size_t)2 * dm.nblk * 2 * Hp);
       ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
       ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.training = training;
+      ca.nt = (H + 15) >> 4; ca.nblk = dm.nblk;
       ca.p_drop = p_drop;
       if (hipMemsetAsync(x0, 0, dec_cluster_fwd_xch_bytes(dm.nblk, H), st) != hipSuccess) {
         set_error("g2v_dec_rollout_fwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(dec_cluster_fwd_kernel<DCL_KS>, dim3((H + 15) >> 4, dm.nblk), dim3(256), dec_cluster_fwd_dyn_lds(), st, ca);
+      hipLaunchKernelGGL(dec_cluster_fwd_kernel<DCL_KS>, dim3(((H + 15) >> 4) * dm.nblk), dim3(256), dec_cluster_fwd_dyn_lds(), st, ca);
       break;
     }
     if (fast) {
@@ -2916,13 +2930,15 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
       DecClBwdArgs ca;
       ca.keep95 = keep95; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s; ca.g = *g;
       ca.xd = x0; ca.xp = x0 + (size_t)2 * nblk * 16 * Hp; ca.xq = ca.xp + (size_t)2 * nblk * 2 * Hp;
+      ca.xcc = reinterpret_cast<unsigned*>(ca.xq + (size_t)nblk * 4 * (Hp / 16) * 16 * Hp);
       ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
       ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.p_drop = p_drop;
+      ca.nt = (H + 15) >> 4; ca.nblk = nblk;
       if (hipMemsetAsync(x0, 0, dec_cluster_bwd_xch_bytes(nblk, H), st) != hipSuccess) {
         set_error("g2v_dec_rollout_bwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(dec_cluster_bwd_kernel<DCL_KS>, dim3((H + 15) >> 4, nblk), dim3(256), dec_cluster_bwd_dyn_lds(), st, ca);
+      hipLaunchKernelGGL(dec_cluster_bwd_kernel<DCL_KS>, dim3(((H + 15) >> 4) * nblk), dim3(256), dec_cluster_bwd_dyn_lds(), st, ca);
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }
