@@ -814,9 +814,9 @@ __global__ __launch_bounds__(64) void gru_step_bwd_kernel(GruStepB d0, GruStepB 
 // read step s - 1.  A workgroup is THREE waves: in the forward each owns one gate's rows of W_hh (the same k-ordered chain per gate
 // as gru_step_fwd_kernel: results bitwise equal), in the backward a third of the 3H-long contraction (three partial chains, summed
 // in a fixed order: equal to summation order); waves 1 and 2 hand their accumulators to wave 0 through LDS.
-// Residency: the workgroups of one (row group, direction) wait for each other, so they must be co-resident -- blockIdx.x is the
-// hidden-unit tile (a partially resident grid holds whole clusters) and the launcher admits the path only while the grid has at
-// most one workgroup per CU.  Every spin is bounded and latches the persistent kernels' fault word (dec_persist.hip) when it runs out.
+// Residency: the workgroups of one (row group, direction) -- a CLUSTER -- wait for each other, so they must be co-resident: the
+// launcher admits the path only while the whole grid has at most one workgroup per CU.  Every spin is bounded and latches the
+// persistent kernels' fault word (dec_persist.hip) when it runs out.  Placement: see GRU_CL_DECODE_GRID.
 struct GruClF {
   const float* gi; const float* w_hh; const float* b_hh; const float* h0;
   float* hs; float* gates; float* h_n;
@@ -834,13 +834,27 @@ struct GruClB {
 // Forward.  sc1 loads are served at the fabric (~25 GB/s per CU: dec_persist.hpp), so a record is swept ONCE per workgroup, with
 // fully used lanes: the three waves take every third tile each and pass the fragments to each other through LDS.
 constexpr int GRU_CL_KSW = (GRU_STEP_KS + 2) / 3;      // tiles a wave sweeps
+// The grid is 1-D.  A CLUSTER is the nt tile workgroups of one (row group, direction).  With `xcc` given and a cluster count that is
+// a multiple of 8 the cluster is the FAST index of the workgroup id, so that under round-robin placement a cluster's workgroups
+// share an XCD (verified per launch: cx_cluster_on_one_xcd) and its records go through that XCD's L2: at B = 128, H = 200, T = 20 in
+// the train step's graph forward 79 -> 74 us, backward 110 -> 97 (r05_aa; the backward on one XCD with write-through records: 116).
+// Without `xcc` the tile is the fast index (a cluster spread over all XCDs, write-through records).
+#define GRU_CL_DECODE_GRID                                                                              \
+  const int ncl_ = nblk * ndir;                                                                         \
+  const bool cl_fast_ = xcc != nullptr && (ncl_ & 7) == 0;                                              \
+  const int cl = cl_fast_ ? (int)blockIdx.x % ncl_ : (int)blockIdx.x / nt;                              \
+  const int ft = cl_fast_ ? (int)blockIdx.x / ncl_ : (int)blockIdx.x % nt;                              \
+  const int rg = cl % nblk, dir = cl / nblk;
 __global__ __launch_bounds__(192) void gru_cluster_fwd_kernel(GruClF d0, GruClF d1, const int32_t* __restrict__ lengths,
-                                                              int64_t hs_ld, int T, int B, int H, RowOff ro, unsigned* fault) {
+                                                              int64_t hs_ld, int T, int B, int H, RowOff ro, unsigned* xcc,
+                                                              int nt, int nblk, int ndir, unsigned* fault) {
   __shared__ __attribute__((aligned(16))) float4 xacc[2][2][64];     // [step parity][wave 1 / 2][lane]
   __shared__ __attribute__((aligned(16))) float4 xs[GRU_STEP_KS + 2][64];      // the state row as B fragments, [k-step][lane]
-  const GruClF d = blockIdx.z == 0 ? d0 : d1;
+  __shared__ int xcd_flag;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  GRU_CL_DECODE_GRID
+  const GruClF d = dir == 0 ? d0 : d1;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const int nks = nt;
   const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
@@ -877,6 +891,7 @@ __global__ __launch_bounds__(192) void gru_cluster_fwd_kernel(GruClF d0, GruClF 
   }
   const unsigned rec_granules = 256u * (unsigned)nt;
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(2u * (unsigned)nblk * rec_granules * 8u), 0x00020000);
+  const bool l2x = xcc != nullptr && cx_cluster_on_one_xcd(xcc + cl * nt, nt, ft, &xcd_flag, tid, fault);
   for (int s = 0; s < T; ++s) {
     const int t = d.reverse ? T - 1 - s : s;
     const bool valid = rvalid && t < len;
@@ -921,7 +936,7 @@ __global__ __launch_bounds__(192) void gru_cluster_fwd_kernel(GruClF d0, GruClF 
           hn[r] = (1.0f - gz[r]) * gn[r] + gz[r] * hp_[r];
         }
       }
-      if (s + 1 < T) cx_publish4(rr, ((unsigned)(s & 1) * (unsigned)nblk + (unsigned)rg) * rec_granules, ft, i, q, hn, (unsigned)(s + 1));
+      if (s + 1 < T) cx_publish4(rr, ((unsigned)(s & 1) * (unsigned)nblk + (unsigned)rg) * rec_granules, ft, i, q, hn, (unsigned)(s + 1), l2x);
       const int64_t row = (int64_t)t * B + b;
       float* ho = d.hs + row * hs_ld + f0;                  // hs_ld may be unaligned: scalar stores
 #pragma unroll
@@ -950,13 +965,16 @@ __global__ __launch_bounds__(192) void gru_cluster_fwd_kernel(GruClF d0, GruClF 
 constexpr int GRU_CL_OT = (GRU_STEP_KS + 2) / 3;      // output tiles per wave
 __global__ __launch_bounds__(192) void gru_cluster_bwd_kernel(GruClB d0, GruClB d1, const int32_t* __restrict__ lengths,
                                                               int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H, RowOff ro,
-                                                              int last_it, unsigned* fault) {
+                                                              int last_it, unsigned* xcc, int nt, int nblk, int ndir,
+                                                              unsigned* fault) {
   __shared__ __attribute__((aligned(16))) float4 xs[3][64];      // this tile's gate gradients (r, z, hn) as B fragments
   __shared__ __attribute__((aligned(16))) float4 dsum3[3][64];   // [wave] its producers' partial products of this tile, [q 16 + row]
-  const GruClB d = blockIdx.z == 0 ? d0 : d1;
+  __shared__ int xcd_flag;
   const int G = 3 * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  GRU_CL_DECODE_GRID
+  const GruClB d = dir == 0 ? d0 : d1;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const bool rvalid = i < nrows;
   const int b = b0 + (rvalid ? i : 0), f0 = 16 * ft + 4 * q;
@@ -981,6 +999,7 @@ __global__ __launch_bounds__(192) void gru_cluster_bwd_kernel(GruClB d0, GruClB 
   const unsigned rec_granules = 256u * (unsigned)nt;
   __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(d.xch, 0, (int)(2u * (unsigned)nblk * (unsigned)nt * rec_granules * 8u), 0x00020000);
   const bool rev = d.reverse != 0;
+  const bool l2x = xcc != nullptr && cx_cluster_on_one_xcd(xcc + cl * nt, nt, ft, &xcd_flag, tid, fault);
   for (int it = 0; it <= last_it; ++it) {
     const int s_next = T - 1 - it;
     const int tn = s_next < 0 ? -1 : (rev ? T - 1 - s_next : s_next);
@@ -1137,7 +1156,7 @@ __global__ __launch_bounds__(192) void gru_cluster_bwd_kernel(GruClB d0, GruClB 
         const int ot = wave + 3 * j;      // the lane's result: batch row i, hidden units 16 ot + 4 q .. + 3
         if (ot < nt && rvalid && 16 * ot + 4 * q < H) {
           const float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
-          cx_publish4(rr, rec0, ot, i, q, v, (unsigned)(it + 1));
+          cx_publish4(rr, rec0, ot, i, q, v, (unsigned)(it + 1), l2x);
         }
       }
     }
@@ -1736,15 +1755,19 @@ static int gru_device_cus() {
 }
 // exchange records of the cluster kernels: forward one (16 x Hp) record of granules per (parity, row group, direction), backward one
 // per (parity, row group, producer tile, direction)
-static size_t gru_cluster_xch_bytes(int B, int ndir, int H, bool bwd) {
+static size_t gru_cluster_rec_bytes(int B, int ndir, int H, bool bwd) {
   const size_t Hp = (size_t)((H + 15) & ~15);
   return (size_t)ndir * 2 * cdiv(B, 16) * (bwd ? Hp / 16 : 1) * 16 * Hp * 8;
+}
+// ... plus one word per workgroup (the XCC it runs on: cx_cluster_on_one_xcd), cleared with the records
+static size_t gru_cluster_xch_bytes(int B, int ndir, int H, bool bwd) {
+  return gru_cluster_rec_bytes(B, ndir, H, bwd) + (size_t)ndir * cdiv(B, 16) * ((H + 15) >> 4) * sizeof(unsigned) + 16;
 }
 // the largest exchange region a cluster launch can need at this H: the grid has at most one workgroup per CU
 static size_t gru_cluster_max_xch_bytes(int H, bool bwd) {
   if ((H & 3) != 0 || H > 16 * GRU_STEP_KS || H == 64 || H < 4) return 0;
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16, cus = (size_t)gru_device_cus();
-  return (bwd ? cus : cus / nt + 1) * 2 * 16 * Hp * 8;
+  return (bwd ? cus : cus / nt + 1) * 2 * 16 * Hp * 8 + cus * sizeof(unsigned) + 16;
 }
 static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn);
 // 1: g2v_gru_seq_fwd / _bwd run this shape as the persistent cluster kernels (small batch; see g2v_gru_seq_set_cluster)
@@ -1955,20 +1978,21 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
       set_error("g2v_gru_seq_fwd: workspace too small");
       return G2V_ERR_WORKSPACE;
     }
-    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, false);
+    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, false), rbytes = gru_cluster_rec_bytes(B, ndir, H, false);
     if (gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_fwd_kernel) && xbytes <= workspace_bytes) {
       // ... or ONE launch for all steps: the same workgroups resident, the state rows exchanged through tagged granules
       GruClF c[2];
       for (int k = 0; k < ndir; ++k)
         c[k] = GruClF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].gates, dirs[k].h_n,
-                      reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (xbytes / ndir)), dirs[k].reverse};
+                      reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (rbytes / ndir)), dirs[k].reverse};
       if (ndir == 1) c[1] = c[0];
       if (hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
         set_error("g2v_gru_seq_fwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(gru_cluster_fwd_kernel, dim3(Hp >> 4, cdiv(B, 16), ndir), dim3(192), 0, st, c[0], c[1], lengths, hs_ld, T,
-                         B, H, ro, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
+      hipLaunchKernelGGL(gru_cluster_fwd_kernel, dim3((Hp >> 4) * cdiv(B, 16) * ndir), dim3(192), 0, st, c[0], c[1], lengths, hs_ld, T,
+                         B, H, ro, reinterpret_cast<unsigned*>((char*)workspace + rbytes), Hp >> 4, cdiv(B, 16), ndir,
+                         const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }
@@ -2194,13 +2218,13 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
   }
   if (split) {
     const int Hp = (H + 15) & ~15;
-    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, true);
+    const size_t xbytes = gru_cluster_xch_bytes(B, ndir, H, true), rbytes = gru_cluster_rec_bytes(B, ndir, H, true);
     if (gru_cluster_ok(T, B, ndir, H, (const void*)gru_cluster_bwd_kernel) && xbytes <= workspace_bytes) {
       GruClB c[2];
       for (int k = 0; k < ndir; ++k)
         c[k] = GruClB{dirs[k].hn_z, dirs[k].hn_q, dirs[k].hn_gloss, dirs[k].hn_coef,
                       dirs[k].d_hs, dirs[k].hs, dirs[k].h0, dirs[k].gates, dirs[k].w_hh, dirs[k].d_hn, dirs[k].dgi, dirs[k].dgh,
-                      dirs[k].dh0, reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (xbytes / ndir)),
+                      dirs[k].dh0, reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (rbytes / ndir)),
                       dirs[k].reverse};
       if (ndir == 1) c[1] = c[0];
       const bool want_dh0 = dirs[0].dh0 || (ndir == 2 && dirs[1].dh0);
@@ -2208,8 +2232,9 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
         set_error("g2v_gru_seq_bwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(gru_cluster_bwd_kernel, dim3(Hp >> 4, cdiv(B, 16), ndir), dim3(192), 0, st, c[0], c[1], lengths, d_hs_ld,
-                         hs_ld, T, B, H, ro, want_dh0 ? T : T - 1, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
+      hipLaunchKernelGGL(gru_cluster_bwd_kernel, dim3((Hp >> 4) * cdiv(B, 16) * ndir), dim3(192), 0, st, c[0], c[1], lengths, d_hs_ld,
+                         hs_ld, T, B, H, ro, want_dh0 ? T : T - 1, reinterpret_cast<unsigned*>((char*)workspace + rbytes), Hp >> 4,
+                         cdiv(B, 16), ndir, const_cast<unsigned*>(g2v_internal_persist_fault_ptr()));
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }

@@ -1386,33 +1386,51 @@ extern "C" size_t g2v_linear_bwd_weight_workspace(int M, int K, int N) {
 // straight from L2 as MFMA fragments (dword loads: 16 lanes x 4 B contiguous along n / k, 4 rows per MFMA; SMW_NB 16-row
 // blocks per request burst, the next burst in flight during the MFMAs), the four partial tiles meet in LDS in a fixed order:
 // deterministic, no slabs, no second launch.  The LDS-tiled split kernel + slab reduction it replaces here cost 17 + 5 us.
-constexpr int SMW_NB = 8;
 struct SmallWgradBatch {
   const float* dy[G2V_TN_BATCH];
   const float* x[G2V_TN_BATCH];
   float* dw[G2V_TN_BATCH];
   float* db[G2V_TN_BATCH];
 };
+// Which (problem, tile group) a workgroup takes.  xpp == 0: grid (groups, problems).  xpp > 0 (1-D grid of 8 slots-per-XCD
+// workgroups, nprob = 8 / xpp problems): workgroup ids go round the 8 XCDs, so XCD j takes problem j / xpp only and every xpp-th tile
+// group of it -- the workgroups of an XCD then stream the rows of ONE problem's operands through that XCD's 4 MiB L2 at about the
+// same pace (four 600 x 200 products at 2560 rows are 33 MB: with every XCD holding tiles of all four, each L2 missed on all of it).
+// Placement only: which workgroup computes a tile does not change the tile's arithmetic.
+__device__ __forceinline__ bool smw_decode_grid(int xpp, int groups, int& prob, int& grp) {
+  if (xpp <= 0) {
+    prob = blockIdx.y; grp = blockIdx.x;
+    return true;
+  }
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  prob = xcd / xpp;
+  grp = xcd % xpp + xpp * slot;
+  return grp < groups;
+}
 // xmap.rows_inner > 0: row m of x is row (m_base + m) of a row-mapped tensor (the leftover rows of the ragged in_layer gradient)
-template <bool KEEP>
-__global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx,
+// NW waves per workgroup split the rows (4, or 16 with half the burst where a product has too few tiles to fill the chip: a wave's
+// rows are a chain of memory round trips -- 640 rows in five bursts -- and that chain, not the arithmetic, is the kernel's time).
+template <bool KEEP, int NW = 4, int SMW_NB = 8>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_smallm_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx,
                                                              const uint8_t* __restrict__ keep, float scale, int M, int K,
                                                              int N, int accumulate, RowMap xmap = RowMap{0, 0, 0, 0},
-                                                             int m_base = 0) {
-  __shared__ float red[3][64 * 4 + 16];
-  const float* __restrict__ dY = sb.dy[blockIdx.y];
-  const float* __restrict__ X = sb.x[blockIdx.y];
-  float* __restrict__ dW = sb.dw[blockIdx.y];
-  float* __restrict__ dB = sb.db[blockIdx.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+                                                             int m_base = 0, int xpp = 0) {
+  __shared__ float red[NW - 1][64 * 4 + 16];
   const int tiles_k = (K + 15) >> 4;
-  const int nt = blockIdx.x / tiles_k, kt = blockIdx.x - nt * tiles_k;
+  int prob, grp;
+  if (!smw_decode_grid(xpp, ((N + 15) >> 4) * tiles_k, prob, grp)) return;
+  const float* __restrict__ dY = sb.dy[prob];
+  const float* __restrict__ X = sb.x[prob];
+  float* __restrict__ dW = sb.dw[prob];
+  float* __restrict__ dB = sb.db[prob];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int nt = grp / tiles_k, kt = grp - nt * tiles_k;
   const int n = nt * 16 + i, k = kt * 16 + i;
   const bool nok = n < N, kok = k < K;
   const float* dyc = dY + (nok ? n : 0);
   const float* xc = X + (kok ? k : 0);
   const uint8_t* kc = KEEP ? keep + (kok ? k : 0) : nullptr;
-  const int per = (((M + 3) / 4) + 15) & ~15;                       // rows per wave, whole 16-row blocks
+  const int per = (((M + NW - 1) / NW) + 15) & ~15;                 // rows per wave, whole 16-row blocks
   const int mb = wave * per, me = mb + per < M ? mb + per : M;
   f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
   float dbs = 0.f;
@@ -1463,7 +1481,7 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
-  for (int w = 0; w < 3; ++w) {
+  for (int w = 0; w < NW - 1; ++w) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] += red[w][lane * 4 + r];
     dbs += red[w][256 + i];
@@ -1489,15 +1507,17 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_kernel(SmallWgradBatch sb,
 // Plain rows only (no keep mask, no row map).
 template <int TN, int TK, int SMW_NB2>
 __global__ __launch_bounds__(256) void gemm_tn_smallm_rt_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx, int M, int K,
-                                                                int N, int accumulate) {
+                                                                int N, int accumulate, int xpp) {
   __shared__ float red[3][TN * TK * 256 + TN * 16];
-  const float* __restrict__ dY = sb.dy[blockIdx.y];
-  const float* __restrict__ X = sb.x[blockIdx.y];
-  float* __restrict__ dW = sb.dw[blockIdx.y];
-  float* __restrict__ dB = sb.db[blockIdx.y];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int groups_k = (((K + 15) >> 4) + TK - 1) / TK;
-  const int ng = blockIdx.x / groups_k, kg = blockIdx.x - ng * groups_k;
+  int prob, grp;
+  if (!smw_decode_grid(xpp, ((((N + 15) >> 4) + TN - 1) / TN) * groups_k, prob, grp)) return;
+  const float* __restrict__ dY = sb.dy[prob];
+  const float* __restrict__ X = sb.x[prob];
+  float* __restrict__ dW = sb.dw[prob];
+  float* __restrict__ dB = sb.db[prob];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int ng = grp / groups_k, kg = grp - ng * groups_k;
   bool nok[TN], kok[TK];
   const float* dyc[TN];
   const float* xc[TK];
@@ -1616,10 +1636,239 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_rt_kernel(SmallWgradBatch 
   }
 }
 
+
+// The same product with the operands STAGED THROUGH LDS: the register-tiled kernel above pulls every MFMA operand as a dword from
+// L2 (16 lanes x 4 B per row: one 64-byte segment per row and instruction) and runs at a fifth of the MFMA rate at the reference's
+// own shape.  Here a wave copies 32 rows x (TN + TK) x 16 columns of its row range with float4 loads (whole 128 / 256-byte row
+// segments) into its own LDS region -- the next 32 rows are in flight in registers meanwhile -- and reads the fragments back as
+// dwords (row stride % 8 == 4 floats: the four row groups of a fragment read land on disjoint banks).  Same row split over the
+// waves, same rows per MFMA (16 blk + 4 q + s), same order of the accumulations and of the cross-wave sum as the two kernels above:
+// bitwise their dW and db.  Needs N, K, lddy, ldx multiples of 4 and 16-byte aligned operands (the launcher checks).
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void gemm_tn_smallm_lds_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx, int M, int K,
+                                                                 int N, int accumulate, int xpp) {
+  constexpr int R = 32, WN = TN * 16, WK = TK * 16, LD = WN + WK + 4;
+  static_assert(LD % 8 == 4, "row stride: the four row groups of a fragment read on disjoint banks");
+  constexpr int STG = R * LD, RED = TN * TK * 256 + TN * 16;
+  constexpr int SM = 4 * STG > 3 * RED ? 4 * STG : 3 * RED;
+  constexpr int NA = R * TN * 4 / 64, NB = R * TK * 4 / 64;      // float4 loads per lane and stage
+  __shared__ __attribute__((aligned(16))) float smem[SM];
+  const int groups_k = (((K + 15) >> 4) + TK - 1) / TK;
+  int prob, grp;
+  if (!smw_decode_grid(xpp, ((((N + 15) >> 4) + TN - 1) / TN) * groups_k, prob, grp)) return;
+  const float* __restrict__ dY = sb.dy[prob];
+  const float* __restrict__ X = sb.x[prob];
+  float* __restrict__ dW = sb.dw[prob];
+  float* __restrict__ dB = sb.db[prob];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int ng = grp / groups_k, kg = grp - ng * groups_k;
+  const int n0 = ng * WN, k0 = kg * WK;
+  const int per = (((M + 3) / 4) + 15) & ~15;                       // rows per wave, whole 16-row blocks (as the 1 x 1 kernel)
+  const int mb = wave * per, me = mb + per < M ? mb + per : M;
+  float* stg = smem + wave * STG;
+  f32x4 acc[TN][TK];
+  float dbs[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    dbs[t] = 0.f;
+#pragma unroll
+    for (int u = 0; u < TK; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  float4 pa[NA], pb[NB];
+  auto fetch = [&](int m0, float4* xa, float4* xb) {      // rows past the range and columns past N / K: zeros (they add nothing)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = lane + 64 * j, r = e / (TN * 4), c = (e % (TN * 4)) * 4;
+      const bool ok = m0 + r < me && n0 + c < N;
+      xa[j] = ld4_or_zero(dY + (ok ? (int64_t)(m0 + r) * lddy + n0 + c : (int64_t)0), ok);
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = lane + 64 * j, r = e / (TK * 4), c = (e % (TK * 4)) * 4;
+      const bool ok = m0 + r < me && k0 + c < K;
+      xb[j] = ld4_or_zero(X + (ok ? (int64_t)(m0 + r) * ldx + k0 + c : (int64_t)0), ok);
+    }
+  };
+  auto stash = [&](const float4* xa, const float4* xb) {
+    __builtin_amdgcn_wave_barrier();      // (the region is this wave's own: its LDS operations execute in order)
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int e = lane + 64 * j, r = e / (TN * 4), c = (e % (TN * 4)) * 4;
+      *reinterpret_cast<float4*>(stg + r * LD + c) = xa[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      const int e = lane + 64 * j, r = e / (TK * 4), c = (e % (TK * 4)) * 4;
+      *reinterpret_cast<float4*>(stg + r * LD + WN + c) = xb[j];
+    }
+  };
+  auto use = [&]() {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int blk = 0; blk < R / 16; ++blk)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const float* row = stg + (16 * blk + 4 * q + s2) * LD + i;
+        float av[TN], bv[TK];
+#pragma unroll
+        for (int t = 0; t < TN; ++t) {
+          av[t] = row[16 * t];
+          dbs[t] += av[t];
+        }
+#pragma unroll
+        for (int u = 0; u < TK; ++u) bv[u] = row[WN + 16 * u];
+#pragma unroll
+        for (int t = 0; t < TN; ++t)
+#pragma unroll
+          for (int u = 0; u < TK; ++u) acc[t][u] = mfma16(av[t], bv[u], acc[t][u]);
+      }
+  };
+  if (mb < me) {
+    fetch(mb, pa, pb);
+    for (int m0 = mb; m0 < me; m0 += R) {      // (two stages in flight, 2 x 4 / 3 x 3 / 1 x 2 tiles: 50-67 us against 53, r05_aa / r05_ab)
+      stash(pa, pb);
+      if (m0 + R < me) fetch(m0 + R, pa, pb);
+      use();
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    dbs[t] += __shfl_xor(dbs[t], 16);
+    dbs[t] += __shfl_xor(dbs[t], 32);
+  }
+  __syncthreads();      // the staging regions are dead: the partial tiles meet in the same memory
+  float (*red)[RED] = reinterpret_cast<float (*)[RED]>(smem);
+  if (wave > 0) {
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+#pragma unroll
+      for (int u = 0; u < TK; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave - 1][(t * TK + u) * 256 + lane * 4 + r] = acc[t][u][r];
+      if (q == 0) red[wave - 1][TN * TK * 256 + t * 16 + i] = dbs[t];
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w)
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+#pragma unroll
+      for (int u = 0; u < TK; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][u][r] += red[w][(t * TK + u) * 256 + lane * 4 + r];
+      dbs[t] += red[w][TN * TK * 256 + t * 16 + i];
+    }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+#pragma unroll
+    for (int u = 0; u < TK; ++u) {
+      const int k = (kg * TK + u) * 16 + i;
+      if (k < K) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int no = (ng * TN + t) * 16 + 4 * q + r;
+          if (no < N) {
+            float* o = dW + (int64_t)no * K + k;
+            *o = accumulate ? *o + acc[t][u][r] : acc[t][u][r];
+          }
+        }
+      }
+    }
+    const int n = (ng * TN + t) * 16 + i;
+    if (dB && kg == 0 && q == 0 && n < N) dB[n] = accumulate ? dB[n] + dbs[t] : dbs[t];
+  }
+}
+
+// ---- the weight gradient of a layer in FRONT of two parallel layers, from their weight-gradient-shaped products --------------------
+// y = x W_in^T + b_in feeds two layers g_p = y W_p^T (p = 0, 1: the two directions' input projections of the bidirectional
+// encoder GRU).  Instead of dy = dg_0 W_0 + dg_1 W_1 ((M x G)(G x H) twice, M = T B rows) and dW_in = dy^T x,
+//   dW_in = W_0^T (dg_0^T x) + W_1^T (dg_1^T x),    db_in = W_0^T (dg_0^T 1) + W_1^T (dg_1^T 1):
+// the inner products P_p = dg_p^T x (G x D) and c_p = column sums of dg_p are ordinary weight-gradient products with K = D (D = 40
+// against H = 200 at the reference's dims: a fifth of the arithmetic of dy, and dy -- which nothing else reads -- is never formed);
+// this kernel is the outer one, contraction over the G rows of (W_p, P_p): one workgroup per 16 x 16 tile of [dW_in | db_in]
+// (column D is the bias), 16 waves: waves 0-7 an eighth of pair 0's rows each, waves 8-15 pair 1's (a wave's rows are ONE request
+// burst at G = 600: the kernel is a memory round trip and a fixed-order sum of the 16 partial tiles).
+__global__ __launch_bounds__(1024) void wgrad_fold2_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                          const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          const float* __restrict__ c0, const float* __restrict__ c1,
+                                                          float* __restrict__ dw, float* __restrict__ db, int G, int H, int D,
+                                                          int accumulate) {
+  __shared__ float red[15][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
+  const int tiles_d = (D + 1 + 15) >> 4;
+  const int ht = blockIdx.x / tiles_d, dt = blockIdx.x - ht * tiles_d;
+  const int h = ht * 16 + i, d = dt * 16 + i;
+  const bool hok = h < H, dok = d <= D;
+  const float* W = (wave >> 3) ? w1 : w0;
+  const float* P = (wave >> 3) ? p1 : p0;
+  const float* Cv = (wave >> 3) ? c1 : c0;
+  const int per = (((G + 7) / 8) + 15) & ~15;
+  const int mb = (wave & 7) * per, me = mb + per < G ? mb + per : G;
+  f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NBK = 5;      // 16-row blocks per request burst
+  for (int m0 = mb; m0 < me; m0 += 16 * NBK) {
+    float av[NBK][4], bv[NBK][4];
+#pragma unroll
+    for (int blk = 0; blk < NBK; ++blk)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) {
+        const int m = m0 + 16 * blk + 4 * q + s2;
+        const bool ok = m < me;
+        const int mc = ok ? m : 0;
+        av[blk][s2] = (ok && hok) ? W[(int64_t)mc * H + h] : 0.f;
+        bv[blk][s2] = (ok && dok) ? (d < D ? P[(int64_t)mc * D + d] : Cv[mc]) : 0.f;
+      }
+#pragma unroll
+    for (int blk = 0; blk < NBK; ++blk)
+#pragma unroll
+      for (int s2 = 0; s2 < 4; ++s2) acc = mfma16(av[blk][s2], bv[blk][s2], acc);
+  }
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave - 1][lane * 4 + r] = acc[r];
+  }
+  __syncthreads();
+  if (wave != 0) return;
+#pragma unroll
+  for (int w = 0; w < 15; ++w)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += red[w][lane * 4 + r];
+  // lane holds out[h = ht*16 + 4 q + r][d = dt*16 + (lane & 15)]
+  if (dok) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ho = ht * 16 + 4 * q + r;
+      if (ho < H) {
+        float* o = d < D ? dw + (int64_t)ho * D + d : db + ho;
+        *o = accumulate ? *o + acc[r] : acc[r];
+      }
+    }
+  }
+}
+extern "C" int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
+                                           const float* c1, float* dw, float* db, int G, int H, int D, int accumulate,
+                                           g2v_stream_t stream) {
+  G2V_REQUIRE(w0 && w1 && p0 && p1 && c0 && c1 && dw && db, "null pointer");
+  G2V_REQUIRE(G > 0 && H > 0 && D > 0, "non-positive size");
+  hipLaunchKernelGGL(wgrad_fold2_kernel, dim3(cdiv(H, 16) * cdiv(D + 1, 16)), dim3(1024), 0, (hipStream_t)stream, w0, w1, p0, p1, c0,
+                     c1, dw, db, G, H, D, accumulate ? 1 : 0);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 // measured at the reference's own VQ-VAE.yml shape (B = 128, T = 20: 2432 / 2560 rows, 600 x 200): the LDS-tiled kernel + slab
 // pass 20.6 + 7 us per product, so the one-launch form keeps the rows BELOW 4096; from 4096 rows the output-blocked wave
 // kernel takes over (the soft quantiser's products at N = 4096: 512 x 128 22 us against 32, 128 x 128 16 against 31)
 static constexpr int g_smallm_wgrad_rows = 4095;
+template <int TN, int TK>
+static void smw_lds_launch(const SmallWgradBatch& sb, int64_t lddy, int64_t ldx, int M, int K, int N, int accumulate, int nprob,
+                           int xpp, hipStream_t st) {
+  const int groups = cdiv(cdiv(N, 16), TN) * cdiv(cdiv(K, 16), TK);
+  hipLaunchKernelGGL((gemm_tn_smallm_lds_kernel<TN, TK>), xpp ? dim3(8 * cdiv(groups, xpp), 1) : dim3(groups, nprob), dim3(256), 0, st,
+                     sb, lddy, ldx, M, K, N, accumulate, xpp);
+}
 
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
@@ -1663,24 +1912,38 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }
-  if (M <= g_smallm_wgrad_rows && rows_inner == 0 && !bf3) {
+  if (M <= g_smallm_wgrad_rows && (rows_inner == 0 || !x_keep) && !bf3) {
+    const bool mapped = rows_inner > 0;      // (a row-mapped x: the one-tile kernels)
+    const RowMap xm1 = mapped ? RowMap{ldx, rows_inner, stride_outer, stride_inner} : RowMap{0, 0, 0, 0};
     SmallWgradBatch sb;
     for (int p = 0; p < G2V_TN_BATCH; ++p) {
       const int pp = p < nprob ? p : 0;
       sb.dy[p] = it[pp].dy; sb.x[p] = it[pp].x; sb.dw[p] = it[pp].dw; sb.db[p] = it[pp].db;
     }
-    const dim3 grid(cdiv(N, 16) * cdiv(K, 16), nprob);
+    // XCD-aware placement (smw_decode_grid) when the problems divide the 8 XCDs and there is more than one
+    const int xpp = nprob > 1 && (8 % nprob) == 0 ? 8 / nprob : 0;
+    const int groups1 = cdiv(N, 16) * cdiv(K, 16), groups2 = cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2);
+    const dim3 grid = xpp ? dim3(8 * cdiv(groups1, xpp), 1) : dim3(groups1, nprob);
     // enough tiles that 2 x 2 of them per workgroup still cover the chip, enough rows that the streaming dominates (four
     // 600 x 200 products at 2432 rows: 72 us against 94; 4 x 2, 3 x 3 and 4 x 4 tiles measured within +-5 % of 2 x 2)
-    if (!x_keep && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
-      hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), dim3(cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2), nprob), dim3(256), 0,
-                         (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate);
+    bool vec_ok = !x_keep && !mapped && M >= 512 && ((N | K | lddy | ldx) & 3) == 0;
+    for (int p2 = 0; p2 < nprob && vec_ok; ++p2)
+      vec_ok = ((reinterpret_cast<uintptr_t>(it[p2].dy) | reinterpret_cast<uintptr_t>(it[p2].x)) & 15) == 0;
+    if (vec_ok && (int64_t)groups2 * nprob >= 256) {
+      // float4-aligned operands: the LDS-staged form (four 600 x 200 products at 2560 rows: 53 us against 70, bitwise the same dW)
+      smw_lds_launch<2, 2>(sb, lddy, ldx, M, K, N, accumulate, nprob, xpp, (hipStream_t)stream);
+    } else if (!x_keep && !mapped && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
+      hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), xpp ? dim3(8 * cdiv(groups2, xpp), 1) : dim3(groups2, nprob), dim3(256), 0,
+                         (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate, xpp);
     else if (x_keep)
       hipLaunchKernelGGL(gemm_tn_smallm_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep, x_scale,
-                         M, K, N, accumulate);
+                         M, K, N, accumulate, RowMap{0, 0, 0, 0}, 0, xpp);
+    else if (M >= 512 && groups1 * nprob <= 256)      // few tiles, many rows: 16 waves split the rows (2560 rows: 30 -> 19 us)
+      hipLaunchKernelGGL((gemm_tn_smallm_kernel<false, 16, 4>), grid, dim3(1024), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep,
+                         x_scale, M, K, N, accumulate, xm1, 0, xpp);
     else
       hipLaunchKernelGGL(gemm_tn_smallm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, sb, lddy, ldx, x_keep, x_scale,
-                         M, K, N, accumulate);
+                         M, K, N, accumulate, xm1, 0, xpp);
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }
@@ -1838,4 +2101,22 @@ extern "C" int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int npro
     return G2V_ERR_WORKSPACE;
   }
   return wgrad_impl(it, nprob, lddy, ldx, 0, 0, 0, nullptr, 1.0f, M, K, N, flags, (float*)workspace, stream);
+}
+extern "C" int g2v_linear_bwd_weight_batch_mapped(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int rows_inner,
+                                                  int64_t stride_outer, int64_t stride_inner, int M, int K, int N, int flags,
+                                                  void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
+  G2V_REQUIRE(items && workspace, "null pointer");
+  G2V_REQUIRE(nprob >= 1 && nprob <= G2V_TN_BATCH, "1..4 problems per call");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0 && rows_inner >= 0, "bad size");
+  WgradItem it[G2V_TN_BATCH];
+  for (int p = 0; p < nprob; ++p) {
+    G2V_REQUIRE(items[p].dy && items[p].x && items[p].dw, "null pointer");
+    it[p] = WgradItem{items[p].dy, items[p].x, items[p].dw, items[p].db};
+  }
+  if (workspace_bytes < (size_t)nprob * g2v_linear_bwd_weight_workspace(M, K, N)) {
+    set_error("g2v_linear_bwd_weight_batch_mapped: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  return wgrad_impl(it, nprob, lddy, ldx, rows_inner, stride_outer, stride_inner, nullptr, 1.0f, M, K, N, flags, (float*)workspace,
+                    stream);
 }

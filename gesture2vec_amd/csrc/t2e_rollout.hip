@@ -862,8 +862,9 @@ struct CodeClArgs {
   unsigned long long* xh0;     // [2][nblk] row records
   unsigned long long* xh1;     // [2][nblk] row records
   unsigned long long* xa;      // [2][nblk][NT][16][2]: per-workgroup best (value, index) of every row
+  unsigned* xcc;               // [nblk][NT]: the XCC every workgroup runs on (cx_cluster_on_one_xcd)
   unsigned* fault;
-  int S1, B, H, K, n_pre, training;
+  int S1, B, H, K, n_pre, training, nt, nblk;
   float p_drop;
 };
 __device__ __forceinline__ void ccl_publish4(__amdgpu_buffer_rsrc_t rr, unsigned granule, const float* v, unsigned tag) {
@@ -944,13 +945,19 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
   __shared__ float bv_s[4][16];                                                   // row argmax: per K tile best value / index
   __shared__ int bk_s[4][16];
   __shared__ int ids_l[16];
+  __shared__ int xcd_flag;
   extern __shared__ __attribute__((aligned(16))) float4 dyn_s[];                 // W_out fragments [KT][KS][64] | W_pre fragments [KS][64] |
                                                                                   // partial logits [4][KT][64] | Dropout(h0) rows [KS][64]
   const int S1 = a.S1, B = a.B, H = a.H, K = a.K;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
   const bool xw = wave != 1;
   const int gx = wave == 0 ? 0 : wave - 1;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  // 1-D grid; with a row-group count that is a multiple of 8 the row group is the FAST index, so that under round-robin placement
+  // the tile workgroups of a row group share an XCD (verified below) and their records go through that XCD's L2
+  const int nt = a.nt, nblk = a.nblk;
+  const bool rg_fast = (nblk & 7) == 0;
+  const int ft = rg_fast ? (int)blockIdx.x / nblk : (int)blockIdx.x % nt, rg = rg_fast ? (int)blockIdx.x % nblk : (int)blockIdx.x / nt;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const int Hp = nt << 4, nkt = (K + 15) >> 4;
   const bool rvalid = i < nrows, wrow_ok = 16 * ft + i < H;
@@ -1029,6 +1036,9 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
   __amdgpu_buffer_rsrc_t r_p = __builtin_amdgcn_make_buffer_rsrc(a.xp, 0, (int)(2u * (unsigned)nblk * prec * 8u), 0x00020000);
   __amdgpu_buffer_rsrc_t r_h0 = __builtin_amdgcn_make_buffer_rsrc(a.xh0, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
   __amdgpu_buffer_rsrc_t r_h1 = __builtin_amdgcn_make_buffer_rsrc(a.xh1, 0, (int)(2u * (unsigned)nblk * rowrec * 8u), 0x00020000);
+  // the row records (u, h0, h1) and the argmax pairs stay inside the row group: through the XCD's L2 when its workgroups share one;
+  // the BatchNorm partial sums cross row groups and keep the write-through stores
+  const bool l2x = cx_cluster_on_one_xcd(a.xcc + rg * nt, nt, ft, &xcd_flag, tid, a.fault);
   if (tid < 16) {      // the code fed at step 0 (always from `codes`)
     int id = 0;
     if (tid < nrows) {
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
         ccl_cell_epilogue(xcx, xch2[0], bias_s[0], lane, q, hown, hn, gr_, gz_, gn_, gh_);
 #pragma unroll
         for (int r = 0; r < 4; ++r) xd[r] = drop ? (((kp >> (8 * r)) & 0xffu) ? hn[r] * scale_l0 : 0.f) : hn[r];
-        cx_publish4(r_h0, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+        cx_publish4(r_h0, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag, l2x);
         *reinterpret_cast<float4*>(sv.h0 + (int64_t)(t + 1) * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         if (drop && sv.x1) *reinterpret_cast<float4*>(sv.x1 + (int64_t)t * BH + (int64_t)b * H + f0) = make_float4(xd[0], xd[1], xd[2], xd[3]);
         if (sv.gates0) {
@@ -1204,7 +1214,7 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
       if (wave == 2 && rvalid && fok) {
         float hn[4], gr_[4], gz_[4], gn_[4], gh_[4];
         ccl_cell_epilogue(xcx, xch2[1], bias_s[1], lane, q, hown, hn, gr_, gz_, gn_, gh_);
-        cx_publish4(r_h1, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag);
+        cx_publish4(r_h1, (ppar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, hn, tag, l2x);
         *reinterpret_cast<float4*>(sv.h1 + (int64_t)(t + 1) * BH + (int64_t)b * H + f0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
         if (sv.gates1) {
           float* go = sv.gates1 + (int64_t)t * 4 * BH + (int64_t)b * 4 * H + f0;
@@ -1287,8 +1297,13 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
             }
             const unsigned long long g0 = ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
             const unsigned long long g1 = ((unsigned long long)tag << 32) | (unsigned long long)(unsigned)k;
-            __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2 + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (l2x) {      // (a plain store: the readers' agent-scope loads find it in this XCD's L2)
+              __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2 + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+              __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(rec + ((size_t)ft * 16 + lane) * 2 + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
           }
           // lane (row i, group q): the pairs of the producers q, q + 4, ... of row i, all requested at once; then over the four groups.
           // (value descending, index ascending) is a total order: the result does not depend on the order of the comparisons
@@ -1403,7 +1418,7 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
         if (fok) {
           if (rvalid) {
             const float un[4] = {ua[0] + bp4.x, ua[1] + bp4.y, ua[2] + bp4.z, ua[3] + bp4.w};
-            cx_publish4(r_u, (jpar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, jtag);
+            cx_publish4(r_u, (jpar * (unsigned)nblk + (unsigned)rg) * rowrec, ft, i, q, un, jtag, l2x);
             *reinterpret_cast<float4*>(sv.u + (int64_t)j * BH + (int64_t)b * H + f0) = make_float4(un[0], un[1], un[2], un[3]);
           }
           if (i == 0) {
@@ -1432,8 +1447,9 @@ struct CodeClBwdArgs {
   float* da;                   // (S1,B,H) gradient w.r.t. a_t = ReLU(BN(u_t)) (before the ReLU mask)
   float* d_hidden0;            // (2,B,H)
   unsigned long long* xq;      // [nblk][hh1, ih1, hh0, ih0][producer tile] row records: partial products
+  unsigned* xcc;               // [nblk][NT]: the XCC every workgroup runs on (cx_cluster_on_one_xcd)
   unsigned* fault;
-  int S1, B, H;
+  int S1, B, H, nt, nblk;
   float p_drop;
 };
 __device__ __forceinline__ void ccl_cell_bwd(const float (&dh)[4], const float4 (&gt)[4], const float4& hp4, float (&g_r)[4],
@@ -1457,9 +1473,15 @@ __global__ __launch_bounds__(256) void code_cluster_bptt_kernel(CodeClBwdArgs a)
   constexpr int KS = CCL_KS, NU = (2 * KS + 3) / 4, NPW = (KS + 1) / 2;
   __shared__ __attribute__((aligned(16))) float4 xs_g[6][64];      // the stage's gate gradients: dgh r z hn, dgi r z n
   __shared__ __attribute__((aligned(16))) float4 dsum[4][64];      // [wave] its share of the partial products, summed
+  __shared__ int xcd_flag;
   const int S1 = a.S1, B = a.B, H = a.H, G = 3 * H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, q = lane >> 4;
-  const int ft = blockIdx.x, rg = blockIdx.y, nblk = gridDim.y, nt = gridDim.x, b0 = rg * 16;
+  // 1-D grid; with a row-group count that is a multiple of 8 the row group is the FAST index, so that under round-robin placement
+  // the tile workgroups of a row group share an XCD (verified below) and their records go through that XCD's L2
+  const int nt = a.nt, nblk = a.nblk;
+  const bool rg_fast = (nblk & 7) == 0;
+  const int ft = rg_fast ? (int)blockIdx.x / nblk : (int)blockIdx.x % nt, rg = rg_fast ? (int)blockIdx.x % nblk : (int)blockIdx.x / nt;
+  const int b0 = rg * 16;
   const int nrows = min(16, B - b0);
   const bool rvalid = i < nrows;
   const int b = b0 + (rvalid ? i : 0);
@@ -1491,6 +1513,7 @@ __global__ __launch_bounds__(256) void code_cluster_bptt_kernel(CodeClBwdArgs a)
   const unsigned rowrec = 256u * (unsigned)nt;
   __amdgpu_buffer_rsrc_t r_q = __builtin_amdgcn_make_buffer_rsrc(a.xq, 0, (int)((unsigned)nblk * 4u * (unsigned)nt * rowrec * 8u), 0x00020000);
   const unsigned q_rg = (unsigned)rg * 4u * (unsigned)nt * rowrec;
+  const bool l2x = cx_cluster_on_one_xcd(a.xcc + rg * nt, nt, ft, &xcd_flag, tid, a.fault);
   float carry1[4] = {0.f, 0.f, 0.f, 0.f}, carry0[4] = {0.f, 0.f, 0.f, 0.f};      // (wave 0)
   for (int t = S1 - 1; t >= 0; --t) {
     const unsigned tag = (unsigned)(S1 - t);
@@ -1545,7 +1568,7 @@ __global__ __launch_bounds__(256) void code_cluster_bptt_kernel(CodeClBwdArgs a)
             acc = mfma16(wq[c][j][2].z, x2.z, acc); acc = mfma16(wq[c][j][2].w, x2.w, acc);
             if (rvalid && 16 * ot + 4 * q < H) {
               const float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag);
+              cx_publish4(r_q, q_rg + ((unsigned)((1 - c) * 2 + m) * (unsigned)nt + (unsigned)ft) * rowrec, ot, i, q, v, tag, l2x);
             }
           }
         }
@@ -1623,8 +1646,9 @@ static size_t ct_fwd_pack_floats(int H, int K, int att) {
 // exchange records of code_cluster_fwd_kernel: three row records + the BatchNorm sums + the argmax pairs per (parity, row group)
 static size_t code_cluster_xch_bytes(int nblk, int H) {
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
-  return (size_t)2 * nblk * ((3 * 16 + 2) * Hp + nt * 32) * 8;
+  return (size_t)2 * nblk * ((3 * 16 + 2) * Hp + nt * 32) * 8 + (size_t)nblk * nt * sizeof(unsigned) + 16;
 }
+static size_t code_cluster_rec_bytes(int nblk, int H) { return code_cluster_xch_bytes(nblk, H) - ((size_t)nblk * ((H + 15) >> 4) * sizeof(unsigned) + 16); }
 static size_t code_cluster_dyn_lds() { return ((size_t)CCL_KT * CCL_KS + CCL_KS + (size_t)4 * CCL_KT + CCL_KS) * 64 * sizeof(float4); }
 static int ct_device_cus() {
   static int n = -1;
@@ -1649,7 +1673,7 @@ extern "C" int g2v_attn_code_rollout_cluster_ok(int S1, int B, int H, int K, int
 // next launch), d_hidden0 (2,B,H).  s: gates0 / gates1 / h0 / h1 of the forward.
 extern "C" size_t g2v_code_cluster_bptt_workspace(int B, int H) {
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16;
-  return (size_t)((B + 15) / 16) * 4 * nt * 16 * Hp * 8;
+  return (size_t)((B + 15) / 16) * 4 * nt * 16 * Hp * 8 + (size_t)((B + 15) / 16) * nt * sizeof(unsigned) + 16;
 }
 extern "C" int g2v_code_cluster_bptt(const float* dh_top, const g2v_code_dec_weights* w, const g2v_code_dec_saved* s,
                                      const uint8_t* keep_l0, float p_drop, float* dgi0, float* dgh0, float* dgi1, float* dgh1,
@@ -1679,13 +1703,15 @@ extern "C" int g2v_code_cluster_bptt(const float* dh_top, const g2v_code_dec_wei
   ca.dh_top = dh_top; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
   ca.dgi0 = dgi0; ca.dgh0 = dgh0; ca.dgi1 = dgi1; ca.dgh1 = dgh1; ca.da = da; ca.d_hidden0 = d_hidden0;
   ca.xq = reinterpret_cast<unsigned long long*>(workspace);
+  ca.nt = (H + 15) >> 4; ca.nblk = cdiv(B, 16);
+  ca.xcc = reinterpret_cast<unsigned*>((char*)workspace + (size_t)ca.nblk * 4 * ca.nt * 16 * (ca.nt * 16) * 8);
   ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
   ca.S1 = S1; ca.B = B; ca.H = H; ca.p_drop = p_drop;
   if (hipMemsetAsync(workspace, 0, g2v_code_cluster_bptt_workspace(B, H), st) != hipSuccess) {
     set_error("g2v_code_cluster_bptt: clearing the exchange records failed");
     return G2V_ERR_LAUNCH;
   }
-  hipLaunchKernelGGL(code_cluster_bptt_kernel, dim3((H + 15) >> 4, cdiv(B, 16)), dim3(256), 0, st, ca);
+  hipLaunchKernelGGL(code_cluster_bptt_kernel, dim3(((H + 15) >> 4) * cdiv(B, 16)), dim3(256), 0, st, ca);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -1742,13 +1768,15 @@ extern "C" int g2v_attn_code_rollout_fwd(const int64_t* codes, const float* h_in
       CodeClArgs ca;
       ca.codes = codes; ca.h_init = h_init; ca.keep_emb = keep_emb; ca.keep_l0 = keep_l0; ca.w = *w; ca.sv = *s;
       ca.xu = x0; ca.xh0 = x0 + rowrec; ca.xh1 = x0 + 2 * rowrec; ca.xp = x0 + 3 * rowrec; ca.xa = ca.xp + (size_t)2 * nblk * 2 * Hp;
+      ca.xcc = reinterpret_cast<unsigned*>((char*)workspace + code_cluster_rec_bytes(nblk, H));
       ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
       ca.S1 = S1; ca.B = B; ca.H = H; ca.K = K; ca.n_pre = n_pre; ca.training = training; ca.p_drop = p_drop;
+      ca.nt = nt; ca.nblk = nblk;
       if (hipMemsetAsync(x0, 0, code_cluster_xch_bytes(nblk, H), st) != hipSuccess) {
         set_error("g2v_attn_code_rollout_fwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
-      hipLaunchKernelGGL(code_cluster_fwd_kernel, dim3(nt, nblk), dim3(256), code_cluster_dyn_lds(), st, ca);
+      hipLaunchKernelGGL(code_cluster_fwd_kernel, dim3(nt * nblk), dim3(256), code_cluster_dyn_lds(), st, ca);
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }

@@ -388,6 +388,7 @@ class VQVAEEngine:
             "gz": z(2, B, H),
             "dgi_f": z(T, B, G), "dgh_f": z(T, B, G), "dgi_b": z(T, B, G), "dgh_b": z(T, B, G),
             "dxin": z(T * B, H),
+            "p_in": z(2, 3 * H, D), "c_in": z(2, 3 * H),       # dgi^T x and the column sums of dgi per direction (g2v_linear_bwd_weight_fold2)
         }
         sv = DecSaved()
         sv.y, sv.xin, sv.u, sv.a = _p(b["y"]), _p(b["dec_xin"]), _p(b["u"]), _p(b["a"])
@@ -425,7 +426,8 @@ class VQVAEEngine:
                        self.lib.g2v_vq_stats_workspace(B, E, K),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
                        self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
-                       4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H))     # batches of four GRU weight gradients
+                       4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H),     # batches of four GRU weight gradients
+                       2 * self.lib.g2v_linear_bwd_weight_workspace(T * B, D, 3 * H))
         b["ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         # scratch of the parallel branches (see _branch): never shared with the main chain
         b["ws_stats"] = torch.zeros(max(self.lib.g2v_vq_stats_workspace(B, E, K), 256), dtype=torch.uint8, device=dev)
@@ -1048,6 +1050,24 @@ class VQVAEEngine:
             return
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
+        elif not self.wgrad_bf16x3:
+            # in_layer's gradient WITHOUT the (T B x H) gradient of its output (nothing else reads it: the layer's input is the
+            # network's input): dW_in = W_f^T (dgi_f^T x) + W_b^T (dgi_b^T x) -- two weight-gradient products with K = D in one
+            # launch and one small fold, instead of two (T B x 3H)(3H x H) products and a weight-gradient product
+            arr = (_lib.WgradItem * 4)()
+            for k, key in enumerate(("f", "b")):
+                arr[k].dy, arr[k].x = _p(b["dgi_" + key]), _p(b["x_drop"]) if drop else _p(in_poses)
+                arr[k].dw, arr[k].db = b["p_in"][k].data_ptr(), b["c_in"][k].data_ptr()
+            if drop:        # the dropped input is a (T B, D) tensor of its own; without dropout the (B,T,D) input in (T,B) row order
+                check(lib.g2v_linear_bwd_weight_batch(arr, 2, G, D, TB, D, G, 0, ws, wsn, st))
+            else:
+                check(lib.g2v_linear_bwd_weight_batch_mapped(arr, 2, G, D, B, D, T * D, TB, D, G, 0, ws, wsn, st))
+            check(lib.g2v_linear_bwd_weight_fold2(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"),
+                                                  b["p_in"][0].data_ptr(), b["p_in"][1].data_ptr(), b["c_in"][0].data_ptr(),
+                                                  b["c_in"][1].data_ptr(), self._g(enc + "in_layer.weight"),
+                                                  self._g(enc + "in_layer.bias"), G, H, D, 0, st))
+            self._join(4)
+            return
         else:
             check(lib.g2v_linear_bwd_data(_p(b["dgi_f"]), G, self._w(enc + "gru.weight_ih_l0"), _p(b["dxin"]), H, TB, H, G, 0, st))
             check(lib.g2v_linear_bwd_data(_p(b["dgi_b"]), G, self._w(enc + "gru.weight_ih_l0_reverse"), _p(b["dxin"]), H, TB, H, G, 1, st))

@@ -132,17 +132,38 @@ def linear_bwd_weight_sum2(dy_a, dy_b, x, N, K, *, M, lddy=None, ldx=None, row_m
     return dw, db
 
 
-def linear_bwd_weight_batch(items, N, K, *, M, lddy=None, ldx=None, accumulate=False, bf16x3=False):
-    """items: up to 4 tuples (dy, x, dw, db-or-None) of ONE shape -> one launch + one slab reduction (large M)."""
+def linear_bwd_weight_batch(items, N, K, *, M, lddy=None, ldx=None, accumulate=False, bf16x3=False, row_map=None):
+    """items: up to 4 tuples (dy, x, dw, db-or-None) of ONE shape -> one launch + one slab reduction (large M).
+    row_map = (rows_inner, stride_outer, stride_inner): x row-mapped as in linear_fwd (g2v_linear_bwd_weight_batch_mapped)."""
     lib = _lib_()
     arr = (_lib.WgradItem * len(items))()
     for k, (dy, x, dw, db) in enumerate(items):
         arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = _p(dy), _p(x), _p(dw), _p(db)
     dev = items[0][0].device
     ws = workspace(len(items) * lib.g2v_linear_bwd_weight_workspace(M, K, N), dev, "bwdw")
+    if row_map is not None:
+        check(lib.g2v_linear_bwd_weight_batch_mapped(arr, len(items), lddy if lddy is not None else N, ldx if ldx is not None else K,
+                                                     row_map[0], row_map[1], row_map[2], M, K, N,
+                                                     int(bool(accumulate)) | (2 if bf16x3 else 0), _p(ws), ws.numel(), _stream()),
+              "linear_bwd_weight_batch_mapped")
+        return
     check(lib.g2v_linear_bwd_weight_batch(arr, len(items), lddy if lddy is not None else N, ldx if ldx is not None else K, M, K, N,
                                           int(bool(accumulate)) | (2 if bf16x3 else 0), _p(ws), ws.numel(), _stream()),
           "linear_bwd_weight_batch")
+
+
+def linear_bwd_weight_fold2(w0, w1, p0, p1, c0, c1, dw=None, db=None, accumulate=False):
+    """dw = w0^T p0 + w1^T p1, db = w0^T c0 + w1^T c1 (g2v_linear_bwd_weight_fold2: the weight gradient of a layer in front of
+    two parallel layers from their weight-gradient-shaped products).  w: (G,H), p: (G,D), c: (G) -> dw (H,D), db (H)."""
+    G, H = w0.shape
+    D = p0.shape[1]
+    if dw is None:
+        dw = torch.empty((H, D), dtype=torch.float32, device=w0.device)
+    if db is None:
+        db = torch.empty((H,), dtype=torch.float32, device=w0.device)
+    check(_lib_().g2v_linear_bwd_weight_fold2(_p(_chk(w0, name="w0")), _p(_chk(w1, name="w1")), _p(p0), _p(p1), _p(c0), _p(c1),
+                                              _p(dw), _p(db), G, H, D, int(bool(accumulate)), _stream()), "linear_bwd_weight_fold2")
+    return dw, db
 
 
 # ------------------------------------------------------------------------------------------ quantiser

@@ -93,7 +93,21 @@ typedef struct {
 } g2v_wgrad_item;
 int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int M, int K, int N,
                                 int flags, void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+/* ... with xin row-mapped as in g2v_linear_fwd (rows_inner / stride_outer / stride_inner: the (B,T,D) network input read in
+ * (T,B) row order), the same map for every item. */
+int g2v_linear_bwd_weight_batch_mapped(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int rows_inner,
+                                       int64_t stride_outer, int64_t stride_inner, int M, int K, int N, int flags,
+                                       void* workspace, size_t workspace_bytes, g2v_stream_t stream);
 size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
+/* The weight gradient of a layer y = x W_in^T + b_in (W_in: [H][D]) that feeds TWO layers g_p = y W_p^T (W_p: [G][H]; the two
+ * directions' input projections of the bidirectional encoder GRU, ref Autoencoder_VQVAE_model.py:447-464 + EncoderRNN.in_layer
+ * :93), from the weight-gradient-shaped products p_p = dg_p^T x ([G][D]) and c_p = column sums of dg_p ([G]) -- both are what
+ * g2v_linear_bwd_weight(_batch)(dy = dg_p, x) returns as dw / db:
+ *     dw[h][d] (+)= sum_g w0[g][h] p0[g][d] + sum_g w1[g][h] p1[g][d],    db[h] (+)= sum_g w0[g][h] c0[g] + sum_g w1[g][h] c1[g]
+ * = autograd's dW_in = (dg_0 W_0 + dg_1 W_1)^T x re-associated (equal to summation order): the (M x H) gradient of y, which
+ * nothing else reads when x is the network's input, is never formed -- D / H of its arithmetic.  Deterministic. */
+int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
+                                const float* c1, float* dw, float* db, int G, int H, int D, int accumulate, g2v_stream_t stream);
 /* dw = (dy_a + dy_b)^T x (+ db = column sums of dy_a + dy_b): the addends are summed as the operand fragments are used --
  * the arithmetic of "add, then g2v_linear_bwd_weight" without the add pass.  The encoder's input layer uses it: its dx
  * arrives as one array per GRU direction (ref Autoencoder_VQVAE_model.py:447-464, the bidirectional nn.GRU's input

@@ -1530,6 +1530,85 @@ def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
         relclose(items[p][2], 2 * first[p][0], 2e-6, f"dw of problem {p} accumulated")
 
 
+@pytest.mark.parametrize("M,N,K,nprob", [(2560, 600, 200, 4), (2432, 600, 200, 3), (640, 600, 200, 4), (2560, 200, 40, 1),
+                                          (2560, 40, 200, 2), (1000, 72, 36, 1)])
+def test_linear_bwd_weight_small_row_counts(ops, M, N, K, nprob):
+    """The weight-gradient kernels below 4096 rows (the reference's own batch size: 19-20 steps x 128 rows): the LDS-staged
+    2 x 2-tile kernel (many tiles, float4-aligned operands), the register-tiled one it replaces for unaligned operands
+    (same rows per MFMA, same accumulation order: BITWISE the same dW / db -- checked by handing the same x over with a row
+    stride that is not a multiple of 4), and the 16-wave form of the one-tile kernel where a product has too few tiles to
+    fill the chip.  All against float64, all deterministic."""
+    items, wide = [], []
+    for p in range(nprob):
+        dy, x = rnd(M, N, seed=60 + p).to(DEV), rnd(M, K, seed=70 + p).to(DEV)
+        items.append((dy, x, torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)))
+        xw = torch.zeros(M, K + 1, device=DEV)
+        xw[:, :K] = x
+        wide.append((dy, xw, torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)))
+    ops.linear_bwd_weight_batch(items, N, K, M=M)
+    first = [(it[2].clone(), it[3].clone()) for it in items]
+    for p in range(nprob):
+        relclose(items[p][2], (items[p][0].double().t() @ items[p][1].double()).float(), 2e-6, f"dw of problem {p} vs float64")
+        relclose(items[p][3], items[p][0].double().sum(0).float(), 1e-5, f"db of problem {p} vs float64")
+    ops.linear_bwd_weight_batch(items, N, K, M=M)
+    ops.linear_bwd_weight_batch(wide, N, K, M=M, ldx=K + 1)
+    for p in range(nprob):
+        assert torch.equal(items[p][2], first[p][0]) and torch.equal(items[p][3], first[p][1]), f"problem {p} not deterministic"
+        if (N + 15) // 16 * ((K + 15) // 16) * nprob > 256:      # (the 16-wave kernel splits the rows differently)
+            assert torch.equal(wide[p][2], first[p][0]), f"dw of problem {p}: unaligned-operand kernel differs"
+            assert torch.equal(wide[p][3], first[p][1]), f"db of problem {p}: unaligned-operand kernel differs"
+        else:
+            relclose(wide[p][2], first[p][0], 2e-6, f"dw of problem {p}, unaligned operands")
+    ops.linear_bwd_weight_batch(items, N, K, M=M, accumulate=True)
+    for p in range(nprob):
+        relclose(items[p][2], 2 * first[p][0], 2e-6, f"dw of problem {p} accumulated")
+
+
+@pytest.mark.parametrize("M,G,H,D", [(2560, 600, 200, 40), (640, 600, 200, 88), (300, 150, 50, 17), (8192, 192, 64, 135)])
+def test_linear_bwd_weight_fold2_equals_the_gradient_through_the_layer_output(ops, M, G, H, D):
+    """g2v_linear_bwd_weight_fold2: dW_in / db_in of a layer feeding two parallel layers, from P_p = dg_p^T x and c_p = column
+    sums of dg_p, against autograd's order (dy = dg_0 W_0 + dg_1 W_1; dW_in = dy^T x; db_in = column sums of dy) in float64 and
+    against that order on the device kernels; accumulate adds."""
+    w = [rnd(G, H, seed=80 + p).to(DEV) * 0.2 for p in range(2)]
+    dg = [rnd(M, G, seed=82 + p).to(DEV) for p in range(2)]
+    x = rnd(M, D, seed=84).to(DEV)
+    items = [(dg[p], x, torch.zeros(G, D, device=DEV), torch.zeros(G, device=DEV)) for p in range(2)]
+    ops.linear_bwd_weight_batch(items, G, D, M=M)
+    dw, db = ops.linear_bwd_weight_fold2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3])
+    dy64 = dg[0].double() @ w[0].double() + dg[1].double() @ w[1].double()
+    relclose(dw, (dy64.t() @ x.double()).float(), 5e-6, "dW_in vs float64")
+    relclose(db, dy64.sum(0).float(), 5e-6, "db_in vs float64")
+    dy = ops.linear_bwd_data(dg[0], w[0])
+    ops.linear_bwd_data(dg[1], w[1], out=dy, accumulate=True)
+    dw_ref, db_ref = ops.linear_bwd_weight(dy, x, H, D)
+    relclose(dw, dw_ref, 5e-6, "dW_in vs the gradient through the layer output")
+    relclose(db, db_ref, 5e-6, "db_in vs the gradient through the layer output")
+    dw2, db2 = ops.linear_bwd_weight_fold2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3])
+    assert torch.equal(dw, dw2) and torch.equal(db, db2), "not deterministic"
+    ops.linear_bwd_weight_fold2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3], dw=dw2, db=db2, accumulate=True)
+    relclose(dw2, 2 * dw, 1e-6, "accumulated dW_in")
+    relclose(db2, 2 * db, 1e-6, "accumulated db_in")
+
+
+@pytest.mark.parametrize("B,T,N,K", [(128, 10, 600, 45), (128, 20, 600, 40), (512, 10, 600, 45), (4096, 10, 600, 45)])
+def test_linear_bwd_weight_batch_with_a_row_mapped_input(ops, B, T, N, K):
+    """g2v_linear_bwd_weight_batch_mapped: two products dg_p^T x with x the (B,T,D) network input read in (T,B) row order --
+    against the same call on a materialised (T B, D) copy and against float64."""
+    M = T * B
+    x_btd = rnd(B, T, K, seed=90).to(DEV)
+    x_tb = x_btd.transpose(0, 1).contiguous().view(M, K)
+    dg = [rnd(M, N, seed=91 + p).to(DEV) for p in range(2)]
+    mapped = [(dg[p], x_btd, torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)) for p in range(2)]
+    plain = [(dg[p], x_tb, torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)) for p in range(2)]
+    ops.linear_bwd_weight_batch(mapped, N, K, M=M, row_map=(B, K, T * K))
+    ops.linear_bwd_weight_batch(plain, N, K, M=M)
+    for p in range(2):
+        ref = (dg[p].double().t() @ x_tb.double()).float()
+        relclose(mapped[p][2], ref, 3e-6, f"dw of problem {p} (mapped) vs float64")
+        relclose(mapped[p][2], plain[p][2], 3e-6, f"dw of problem {p}: mapped vs materialised")
+        relclose(mapped[p][3], dg[p].double().sum(0).float(), 1e-5, f"db of problem {p}")
+
+
 def test_linear_bwd_weight_output_blocked_with_row_map(ops):
     """dW of an in_layer-like product at generic dims (N = 200, K = 40) with the (B,T,D) -> (T,B,D) row map: the
     output-blocked wave kernel's MAPPED instantiation."""
