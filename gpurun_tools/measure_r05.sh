@@ -35,3 +35,4 @@ bash gpurun_tools/r04_prof_t2e.sh 4096 True | head -8; mv gpurun_out/r04_e_kerne
 bash gpurun_tools/r04_prof_cfg.sh native 4096 | head -10; mv gpurun_out/r04_kernel_stats_native_B4096.csv gpurun_out/r05_${tag}_kernel_stats_native_B4096.csv
 bash gpurun_tools/r04_prof_cfg.sh native 128 | head -14; mv gpurun_out/r04_kernel_stats_native_B128.csv gpurun_out/r05_${tag}_kernel_stats_native_B128.csv
 bash gpurun_tools/r04_prof_t2e.sh 128 False | head -12; mv gpurun_out/r04_e_kernel_stats_part_d_B128_attFalse.csv gpurun_out/r05_${tag}_kernel_stats_part_d_B128_noatt.csv
+bash gpurun_tools/r04_tl_cfg.sh native 128 > /dev/null 2>&1; cp gpurun_out/r04_timeline_native_B128_libg2v_hip.txt gpurun_out/r05_${tag}_timeline_native_B128.txt; tail -16 gpurun_out/r05_${tag}_timeline_native_B128.txt
