@@ -35,9 +35,15 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const float* __restrict__ 
                                                       const uint8_t* __restrict__ keep, float scale,
                                                       const float* __restrict__ Bm, int64_t ldb,
                                                       const float* __restrict__ bias, float* __restrict__ Cout,
-                                                      int64_t ldc, int M, int C, int N, int act, int accumulate) {
+                                                      int64_t ldc, int M, int C, int N, int act, int accumulate,
+                                                      const float* __restrict__ Bm_z1 = nullptr,
+                                                      const float* __restrict__ bias_z1 = nullptr,
+                                                      float* __restrict__ Cout_z1 = nullptr) {
   __shared__ __attribute__((aligned(16))) float As[BM * LDT];
   __shared__ __attribute__((aligned(16))) float Bs[BN * LDT];
+  if (blockIdx.z) {      // grid.z = 2 (g2v_linear_fwd_pair): the same A against a second (weight, bias, output)
+    Bm = Bm_z1; bias = bias_z1; Cout = Cout_z1;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int i = lane & 15, q = lane >> 4;
@@ -1333,6 +1339,32 @@ extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64
                      (int64_t)K, bias, y, ldy, M, K, N, act, 0);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
+}
+
+// y_a = act(x w_a^T + b_a), y_b = act(x w_b^T + b_b): the two directions' input projections of a bidirectional GRU layer (ref
+// Autoencoder_VQVAE_model.py:94, nn.GRU(bidirectional=True): weight_ih_l0 / weight_ih_l0_reverse) read the same x.  At small row
+// counts (2560 rows: 400 workgroups per product, 16 us each, back to back) ONE launch with grid.z = 2 runs both; each workgroup's
+// arithmetic is that of g2v_linear_fwd's LDS-tiled kernel (bitwise the same y).  Shapes the other dense kernels serve, and
+// unaligned operands, are two g2v_linear_fwd calls.
+extern "C" int g2v_linear_fwd_pair(const float* x, int64_t ldx, const float* w_a, const float* bias_a, float* y_a, const float* w_b,
+                                   const float* bias_b, float* y_b, int64_t ldy, int M, int K, int N, int act,
+                                   g2v_stream_t stream) {
+  G2V_REQUIRE(x && w_a && w_b && y_a && y_b, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
+  G2V_REQUIRE(act >= 0 && act <= 2, "bad activation");
+  const bool tiled = M > g_smallm_max_rows && N > 192 && !(N == 64 && K == 135);      // (neither launch_smallm, _stream nor _k4)
+  const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_a) |
+                                                       reinterpret_cast<uintptr_t>(w_b)) & 15) == 0;
+  if (tiled && vec && M <= 16384) {
+    RowMap am{ldx, 0, 0, 0};
+    hipLaunchKernelGGL((gemm_nt_kernel<false, true>), dim3(cdiv(M, BM), cdiv(N, BN), 2), dim3(256), 0, (hipStream_t)stream, x, am,
+                       (const uint8_t*)nullptr, 1.0f, w_a, (int64_t)K, bias_a, y_a, ldy, M, K, N, act, 0, w_b, bias_b, y_b);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
+  const int rc = g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_a, bias_a, y_a, ldy, M, K, N, act, stream);
+  if (rc != G2V_OK) return rc;
+  return g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_b, bias_b, y_b, ldy, M, K, N, act, stream);
 }
 
 extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int M, int K,

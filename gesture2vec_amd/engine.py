@@ -643,9 +643,9 @@ class VQVAEEngine:
         # other sizes compute gi with the dense-layer kernel first
         fuse_gi = (H == 64)
         if not fuse_gi:
-            for suf, gi in (("", b["gi_f"]), ("_reverse", b["gi_b"])):
-                check(lib.g2v_linear_fwd(_p(b["xin"]), H, 0, 0, 0, None, 1.0, self._w(enc + "gru.weight_ih_l0" + suf),
-                                         self._w(enc + "gru.bias_ih_l0" + suf), _p(gi), G, T * B, H, G, 0, st))
+            check(lib.g2v_linear_fwd_pair(_p(b["xin"]), H, self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.bias_ih_l0"),
+                                          _p(b["gi_f"]), self._w(enc + "gru.weight_ih_l0_reverse"),
+                                          self._w(enc + "gru.bias_ih_l0_reverse"), _p(b["gi_b"]), G, T * B, H, G, 0, st))
         dirs = (_lib.GruDir * 2)()
         for k, (suf, key, hs_ptr) in enumerate((("", "f", b["hs_f"][1:].data_ptr()), ("_reverse", "b", b["hs_b"].data_ptr()))):
             dirs[k].gi = None if fuse_gi else _p(b["gi_" + key])

@@ -76,6 +76,18 @@ def linear_fwd(x, w, bias=None, act=0, *, M=None, ldx=None, row_map=None, keep=N
     return out
 
 
+def linear_fwd_pair(x, w_a, bias_a, w_b, bias_b, act=0, *, M=None):
+    """(act(x w_a^T + b_a), act(x w_b^T + b_b)) in one launch where that pays (g2v_linear_fwd_pair)."""
+    N, K = w_a.shape
+    if M is None:
+        M = x.numel() // K
+    ya = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    yb = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    check(_lib_().g2v_linear_fwd_pair(_p(x), K, _p(_chk(w_a, name="w_a")), _p(bias_a), _p(ya), _p(_chk(w_b, name="w_b")), _p(bias_b),
+                                      _p(yb), N, M, K, N, act, _stream()), "linear_fwd_pair")
+    return ya, yb
+
+
 def linear_bwd_data(dy, w, *, M=None, lddy=None, out=None, lddx=None, accumulate=False):
     N, K = w.shape
     if M is None:

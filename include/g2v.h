@@ -68,6 +68,12 @@ int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_o
                    const float* w, const float* bias, float* y, int64_t ldy,
                    int M, int K, int N, int act, g2v_stream_t stream);
 
+/* y_a = act(x w_a^T + bias_a), y_b = act(x w_b^T + bias_b) (plain rows, no mask; y_a / y_b share ldy): the input projections of
+ * the two directions of a bidirectional nn.GRU layer (ref Autoencoder_VQVAE_model.py:94: weight_ih_l0 / weight_ih_l0_reverse on
+ * the same input) in ONE launch where that pays (small row counts); results bitwise those of two g2v_linear_fwd calls. */
+int g2v_linear_fwd_pair(const float* x, int64_t ldx, const float* w_a, const float* bias_a, float* y_a, const float* w_b,
+                        const float* bias_b, float* y_b, int64_t ldy, int M, int K, int N, int act, g2v_stream_t stream);
+
 /* dx[m, k] (+)= sum_n dy[m, n] * w[n, k]      (w is the forward weight, [N][K] row-major) */
 int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
                         int M, int K, int N, int accumulate, g2v_stream_t stream);

@@ -1530,6 +1530,20 @@ def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
         relclose(items[p][2], 2 * first[p][0], 2e-6, f"dw of problem {p} accumulated")
 
 
+@pytest.mark.parametrize("M,K,N,act", [(2560, 200, 600, 0), (1280, 200, 600, 1), (2560, 64, 192, 0), (300, 50, 150, 2), (2560, 202, 600, 0)])
+def test_linear_fwd_pair_equals_two_calls(ops, M, K, N, act):
+    """g2v_linear_fwd_pair (both directions' GRU input projections in one launch at small row counts) is BITWISE two
+    g2v_linear_fwd calls, on the shapes it serves itself and on the ones it hands on."""
+    x = rnd(M, K, seed=100).to(DEV)
+    wa, wb = rnd(N, K, seed=101).to(DEV), rnd(N, K, seed=102).to(DEV)
+    ba, bb = rnd(N, seed=103).to(DEV), rnd(N, seed=104).to(DEV)
+    ya, yb = ops.linear_fwd_pair(x, wa, ba, wb, bb, act)
+    assert torch.equal(ya, ops.linear_fwd(x, wa, ba, act)), "first output differs from g2v_linear_fwd"
+    assert torch.equal(yb, ops.linear_fwd(x, wb, bb, act)), "second output differs from g2v_linear_fwd"
+    f = {0: lambda v: v, 1: torch.relu, 2: torch.tanh}[act]
+    relclose(ya, f(x.double() @ wa.double().t() + ba.double()).float(), 5e-5 if act == 2 else 2e-6, "first output vs float64")
+
+
 @pytest.mark.parametrize("M,N,K,nprob", [(2560, 600, 200, 4), (2432, 600, 200, 3), (640, 600, 200, 4), (2560, 200, 40, 1),
                                           (2560, 40, 200, 2), (1000, 72, 36, 1)])
 def test_linear_bwd_weight_small_row_counts(ops, M, N, K, nprob):
