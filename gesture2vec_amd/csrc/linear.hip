@@ -1676,15 +1676,14 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_rt_kernel(SmallWgradBatch 
 // dwords (row stride % 8 == 4 floats: the four row groups of a fragment read land on disjoint banks).  Same row split over the
 // waves, same rows per MFMA (16 blk + 4 q + s), same order of the accumulations and of the cross-wave sum as the two kernels above:
 // bitwise their dW and db.  Needs N, K, lddy, ldx multiples of 4 and 16-byte aligned operands (the launcher checks).
-template <int TN, int TK>
-__global__ __launch_bounds__(256) void gemm_tn_smallm_lds_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx, int M, int K,
-                                                                 int N, int accumulate, int xpp) {
+template <int TN, int TK, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_tn_smallm_lds_kernel(SmallWgradBatch sb, int64_t lddy, int64_t ldx, int M, int K,
+                                                                     int N, int accumulate, int xpp) {
   constexpr int R = 32, WN = TN * 16, WK = TK * 16, LD = WN + WK + 4;
   static_assert(LD % 8 == 4, "row stride: the four row groups of a fragment read on disjoint banks");
   constexpr int STG = R * LD, RED = TN * TK * 256 + TN * 16;
-  constexpr int SM = 4 * STG > 3 * RED ? 4 * STG : 3 * RED;
   constexpr int NA = R * TN * 4 / 64, NB = R * TK * 4 / 64;      // float4 loads per lane and stage
-  __shared__ __attribute__((aligned(16))) float smem[SM];
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // max(NW STG, (NW - 1) RED) floats
   const int groups_k = (((K + 15) >> 4) + TK - 1) / TK;
   int prob, grp;
   if (!smw_decode_grid(xpp, ((((N + 15) >> 4) + TN - 1) / TN) * groups_k, prob, grp)) return;
@@ -1695,7 +1694,7 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_lds_kernel(SmallWgradBatch
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int ng = grp / groups_k, kg = grp - ng * groups_k;
   const int n0 = ng * WN, k0 = kg * WK;
-  const int per = (((M + 3) / 4) + 15) & ~15;                       // rows per wave, whole 16-row blocks (as the 1 x 1 kernel)
+  const int per = (((M + NW - 1) / NW) + 15) & ~15;                 // rows per wave, whole 16-row blocks (NW = 4: as the 1 x 1 kernel)
   const int mb = wave * per, me = mb + per < M ? mb + per : M;
   float* stg = smem + wave * STG;
   f32x4 acc[TN][TK];
@@ -1783,7 +1782,7 @@ __global__ __launch_bounds__(256) void gemm_tn_smallm_lds_kernel(SmallWgradBatch
   __syncthreads();
   if (wave != 0) return;
 #pragma unroll
-  for (int w = 0; w < 3; ++w)
+  for (int w = 0; w < NW - 1; ++w)
 #pragma unroll
     for (int t = 0; t < TN; ++t) {
 #pragma unroll
@@ -1894,13 +1893,19 @@ extern "C" int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, con
 // pass 20.6 + 7 us per product, so the one-launch form keeps the rows BELOW 4096; from 4096 rows the output-blocked wave
 // kernel takes over (the soft quantiser's products at N = 4096: 512 x 128 22 us against 32, 128 x 128 16 against 31)
 static constexpr int g_smallm_wgrad_rows = 4095;
-template <int TN, int TK>
+template <int TN, int TK, int NW>
 static void smw_lds_launch(const SmallWgradBatch& sb, int64_t lddy, int64_t ldx, int M, int K, int N, int accumulate, int nprob,
                            int xpp, hipStream_t st) {
   const int groups = cdiv(cdiv(N, 16), TN) * cdiv(cdiv(K, 16), TK);
-  hipLaunchKernelGGL((gemm_tn_smallm_lds_kernel<TN, TK>), xpp ? dim3(8 * cdiv(groups, xpp), 1) : dim3(groups, nprob), dim3(256), 0, st,
-                     sb, lddy, ldx, M, K, N, accumulate, xpp);
+  constexpr int STG = 32 * (TN * 16 + TK * 16 + 4), RED = TN * TK * 256 + TN * 16;
+  constexpr size_t lds = sizeof(float) * (size_t)(NW * STG > (NW - 1) * RED ? NW * STG : (NW - 1) * RED);
+  static bool attr = false;
+  if (!attr) attr = hipFuncSetAttribute((const void*)gemm_tn_smallm_lds_kernel<TN, TK, NW>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) == hipSuccess;
+  hipLaunchKernelGGL((gemm_tn_smallm_lds_kernel<TN, TK, NW>), xpp ? dim3(8 * cdiv(groups, xpp), 1) : dim3(groups, nprob), dim3(64 * NW),
+                     lds, st, sb, lddy, ldx, M, K, N, accumulate, xpp);
 }
+
 
 // nprob problems of one shape: {dy, x, dw, db}[p].  The wave-autonomous path launches them together (grid.y = problem);
 // the LDS-tiled fallback runs them one after the other.  `slab_stride` floats of workspace per problem.
@@ -1963,7 +1968,10 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
       vec_ok = ((reinterpret_cast<uintptr_t>(it[p2].dy) | reinterpret_cast<uintptr_t>(it[p2].x)) & 15) == 0;
     if (vec_ok && (int64_t)groups2 * nprob >= 256) {
       // float4-aligned operands: the LDS-staged form (four 600 x 200 products at 2560 rows: 53 us against 70, bitwise the same dW)
-      smw_lds_launch<2, 2>(sb, lddy, ldx, M, K, N, accumulate, nprob, xpp, (hipStream_t)stream);
+      // (NW = 8 waves per workgroup, 70 KB of LDS: 60 us against 54 alone, and starved beside the GRU backward cluster -- 110 us;
+      //  the counters of the 4-wave form: MFMA pipe 32 % busy, waves waiting on memory 52 % of their time, no LDS bank conflicts:
+      //  profiles/r05_ai_pmc_smallm_wgrad_4waves.json, r05_aj_lds_wgrad_8waves_ab.log)
+      smw_lds_launch<2, 2, 4>(sb, lddy, ldx, M, K, N, accumulate, nprob, xpp, (hipStream_t)stream);
     } else if (!x_keep && !mapped && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
       hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), xpp ? dim3(8 * cdiv(groups2, xpp), 1) : dim3(groups2, nprob), dim3(256), 0,
                          (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate, xpp);
