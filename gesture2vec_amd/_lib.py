@@ -96,6 +96,8 @@ _SIGS = {
     "g2v_linear_bwd_weight_batch": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_linear_bwd_weight_batch_mapped": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_int, c_int, c_int,
                                                    c_int, c_fp, c_sz, c_fp]),
+    "g2v_linear_bwd_weight_chain2": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
+    "g2v_linear_bwd_weight_fold_chain2": (c_int, [c_fp] * 12 + [c_int, c_int, c_int, c_fp]),
     "g2v_linear_bwd_weight_fold2": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "g2v_vq_assign_blocks": (c_int, [c_int]),
     "g2v_vq_code_sqnorm": (c_int, [c_fp, c_fp, c_int, c_int, c_fp]),

@@ -1821,15 +1821,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn_smallm_lds_kernel(SmallWgradB
 // this kernel is the outer one, contraction over the G rows of (W_p, P_p): one workgroup per 16 x 16 tile of [dW_in | db_in]
 // (column D is the bias), 16 waves: waves 0-7 an eighth of pair 0's rows each, waves 8-15 pair 1's (a wave's rows are ONE request
 // burst at G = 600: the kernel is a memory round trip and a fixed-order sum of the 16 partial tiles).
-__global__ __launch_bounds__(1024) void wgrad_fold2_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
-                                                          const float* __restrict__ p0, const float* __restrict__ p1,
-                                                          const float* __restrict__ c0, const float* __restrict__ c1,
-                                                          float* __restrict__ dw, float* __restrict__ db, int G, int H, int D,
-                                                          int accumulate) {
-  __shared__ float red[15][64 * 4];
+__device__ __forceinline__ void wgrad_fold2_body(int bid, float (*red)[64 * 4], const float* __restrict__ w0,
+                                                 const float* __restrict__ w1, const float* __restrict__ p0,
+                                                 const float* __restrict__ p1, const float* __restrict__ c0,
+                                                 const float* __restrict__ c1, float* __restrict__ dw, float* __restrict__ db, int G,
+                                                 int H, int D, int accumulate) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, q = lane >> 4;
   const int tiles_d = (D + 1 + 15) >> 4;
-  const int ht = blockIdx.x / tiles_d, dt = blockIdx.x - ht * tiles_d;
+  const int ht = bid / tiles_d, dt = bid - ht * tiles_d;
   const int h = ht * 16 + i, d = dt * 16 + i;
   const bool hok = h < H, dok = d <= D;
   const float* W = (wave >> 3) ? w1 : w0;
@@ -1878,6 +1877,121 @@ __global__ __launch_bounds__(1024) void wgrad_fold2_kernel(const float* __restri
     }
   }
 }
+__global__ __launch_bounds__(1024) void wgrad_fold2_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                          const float* __restrict__ p0, const float* __restrict__ p1,
+                                                          const float* __restrict__ c0, const float* __restrict__ c1,
+                                                          float* __restrict__ dw, float* __restrict__ db, int G, int H, int D,
+                                                          int accumulate) {
+  __shared__ float red[15][64 * 4];
+  wgrad_fold2_body(blockIdx.x, red, w0, w1, p0, p1, c0, c1, dw, db, G, H, D, accumulate);
+}
+// ---- the weight gradient of a layer BEHIND a linear layer, from the same products ---------------------------------------------------
+// g = y W^T with y = x W_in^T + b_in (the GRU input projection behind in_layer): dW = dg^T y = (dg^T x) W_in^T + (dg^T 1) b_in^T
+// = P W_in^T + c b_in^T with the P, c of g2v_linear_bwd_weight_fold2 -- a (G x D)(D x H) product instead of (G x M)(M x H).
+// A workgroup takes CHAIN2_ROWS rows g and every h, W_in^T staged in LDS once (where (D + 1) H floats fit); per output element d
+// ascending, then the bias term; blockIdx.y = which of the two (P, c, dW).
+constexpr int CHAIN2_ROWS = 8, CHAIN2_MAXD = 255;      // rows g per workgroup; largest D of the staged form
+// staged form: W_in^T (row D = b_in) and the workgroup's rows of P (column D = c) in LDS; NSUB x 256 threads, sub-group s takes rows
+// s, s + NSUB, ... of the workgroup's CHAIN2_ROWS; per output element d ascending, the bias term last
+template <int NSUB>
+__device__ __forceinline__ void wgrad_chain2_body(int bx, int dir, float* wt, const float* __restrict__ p0, const float* __restrict__ p1,
+                                                  const float* __restrict__ c0, const float* __restrict__ c1,
+                                                  const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                  float* __restrict__ dw0, float* __restrict__ dw1, int G, int H, int D,
+                                                  int accumulate) {
+  constexpr int NT = 256 * NSUB, RPS = CHAIN2_ROWS / NSUB;
+  float* ps = wt + (size_t)(D + 1) * H;      // [CHAIN2_ROWS][D + 1]
+  const float* P = dir ? p1 : p0;
+  const float* Cv = dir ? c1 : c0;
+  float* dW = dir ? dw1 : dw0;
+  const int tid = threadIdx.x, sub = tid >> 8, t = tid & 255, g0 = bx * CHAIN2_ROWS;
+  for (int e = tid; e < H * D; e += NT) {
+    const int h = e / D, d = e - h * D;
+    wt[d * H + h] = w_in[e];
+  }
+  for (int h = tid; h < H; h += NT) wt[D * H + h] = b_in[h];
+  for (int e = tid; e < CHAIN2_ROWS * (D + 1); e += NT) {
+    const int r = e / (D + 1), d = e - r * (D + 1), g = g0 + r;
+    ps[r * (D + 1) + d] = g < G ? (d < D ? P[(int64_t)g * D + d] : Cv[g]) : 0.f;
+  }
+  __syncthreads();
+  for (int h = t; h < H; h += 256) {
+    float acc[RPS];
+#pragma unroll
+    for (int r = 0; r < RPS; ++r) acc[r] = 0.f;
+    for (int d = 0; d <= D; ++d) {
+      const float w = wt[d * H + h];
+#pragma unroll
+      for (int r = 0; r < RPS; ++r) acc[r] = fmaf(ps[(sub + NSUB * r) * (D + 1) + d], w, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < RPS; ++r) {
+      const int g = g0 + sub + NSUB * r;
+      if (g < G) {
+        float* o = dW + (int64_t)g * H + h;
+        *o = accumulate ? *o + acc[r] : acc[r];
+      }
+    }
+  }
+}
+static size_t chain2_lds_bytes(int H, int D) { return sizeof(float) * ((size_t)(D + 1) * H + (size_t)CHAIN2_ROWS * (D + 1)); }
+__global__ __launch_bounds__(256) void wgrad_chain2_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                           const float* __restrict__ c0, const float* __restrict__ c1,
+                                                           const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                           float* __restrict__ dw0, float* __restrict__ dw1, int G, int H, int D,
+                                                           int accumulate, int staged) {
+  extern __shared__ float wt[];
+  if (staged) {
+    wgrad_chain2_body<1>(blockIdx.x, blockIdx.y, wt, p0, p1, c0, c1, w_in, b_in, dw0, dw1, G, H, D, accumulate);
+    return;
+  }
+  const float* P = blockIdx.y ? p1 : p0;
+  const float* Cv = blockIdx.y ? c1 : c0;
+  float* dW = blockIdx.y ? dw1 : dw0;
+  const int tid = threadIdx.x, g0 = blockIdx.x * CHAIN2_ROWS;
+  const int g1 = g0 + CHAIN2_ROWS < G ? g0 + CHAIN2_ROWS : G;
+  for (int g = g0; g < g1; ++g) {
+    const float* pr = P + (int64_t)g * D;
+    const float cg = Cv[g];
+    for (int h = tid; h < H; h += 256) {
+      const float* wr = w_in + (int64_t)h * D;
+      float acc = 0.f;
+      for (int d = 0; d < D; ++d) acc = fmaf(pr[d], wr[d], acc);
+      acc = fmaf(cg, b_in[h], acc);
+      float* o = dW + (int64_t)g * H + h;
+      *o = accumulate ? *o + acc : acc;
+    }
+  }
+}
+// both in ONE launch (they read the same P, c and nothing of each other): workgroups [0, nfold) the fold's tiles, the rest the
+// chain's (row block, direction) pairs with four 256-thread sub-groups; each workgroup's arithmetic is that of the two kernels above
+__global__ __launch_bounds__(1024) void wgrad_fold_chain2_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                                 const float* __restrict__ p0, const float* __restrict__ p1,
+                                                                 const float* __restrict__ c0, const float* __restrict__ c1,
+                                                                 const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                                 float* __restrict__ dw_in, float* __restrict__ db_in,
+                                                                 float* __restrict__ dw0, float* __restrict__ dw1, int G, int H, int D,
+                                                                 int nfold, int nchain_x) {
+  extern __shared__ float sm[];      // max(15 x 256 floats of partial tiles, the chain's staging)
+  if ((int)blockIdx.x < nfold) {
+    wgrad_fold2_body(blockIdx.x, reinterpret_cast<float (*)[64 * 4]>(sm), w0, w1, p0, p1, c0, c1, dw_in, db_in, G, H, D, 0);
+  } else {
+    const int bb = blockIdx.x - nfold;
+    wgrad_chain2_body<4>(bb % nchain_x, bb / nchain_x, sm, p0, p1, c0, c1, w_in, b_in, dw0, dw1, G, H, D, 0);
+  }
+}
+extern "C" int g2v_linear_bwd_weight_chain2(const float* p0, const float* p1, const float* c0, const float* c1, const float* w_in,
+                                            const float* b_in, float* dw0, float* dw1, int G, int H, int D, int accumulate,
+                                            g2v_stream_t stream) {
+  G2V_REQUIRE(p0 && p1 && c0 && c1 && w_in && b_in && dw0 && dw1, "null pointer");
+  G2V_REQUIRE(G > 0 && H > 0 && D > 0 && (int64_t)G * H < (int64_t)1 << 31, "bad size");
+  const size_t lds = chain2_lds_bytes(H, D);
+  const int staged = lds <= 48 * 1024 && D <= CHAIN2_MAXD ? 1 : 0;
+  hipLaunchKernelGGL(wgrad_chain2_kernel, dim3(cdiv(G, CHAIN2_ROWS), 2), dim3(256), staged ? lds : 0, (hipStream_t)stream, p0, p1, c0,
+                     c1, w_in, b_in, dw0, dw1, G, H, D, accumulate ? 1 : 0, staged);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
 extern "C" int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
                                            const float* c1, float* dw, float* db, int G, int H, int D, int accumulate,
                                            g2v_stream_t stream) {
@@ -1885,6 +1999,24 @@ extern "C" int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, con
   G2V_REQUIRE(G > 0 && H > 0 && D > 0, "non-positive size");
   hipLaunchKernelGGL(wgrad_fold2_kernel, dim3(cdiv(H, 16) * cdiv(D + 1, 16)), dim3(1024), 0, (hipStream_t)stream, w0, w1, p0, p1, c0,
                      c1, dw, db, G, H, D, accumulate ? 1 : 0);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+// g2v_linear_bwd_weight_fold2 and g2v_linear_bwd_weight_chain2 (overwrite form) in one launch: bitwise their results.
+extern "C" int g2v_linear_bwd_weight_fold_chain2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
+                                                 const float* c1, const float* w_in, const float* b_in, float* dw_in, float* db_in,
+                                                 float* dw0, float* dw1, int G, int H, int D, g2v_stream_t stream) {
+  G2V_REQUIRE(w0 && w1 && p0 && p1 && c0 && c1 && w_in && b_in && dw_in && db_in && dw0 && dw1, "null pointer");
+  G2V_REQUIRE(G > 0 && H > 0 && D > 0, "non-positive size");
+  const size_t lc = chain2_lds_bytes(H, D), lf = sizeof(float) * 15 * 256;
+  if (lc > 48 * 1024 || D > CHAIN2_MAXD) {      // the chain's staging does not fit: the two launches
+    const int rc = g2v_linear_bwd_weight_fold2(w0, w1, p0, p1, c0, c1, dw_in, db_in, G, H, D, 0, stream);
+    if (rc != G2V_OK) return rc;
+    return g2v_linear_bwd_weight_chain2(p0, p1, c0, c1, w_in, b_in, dw0, dw1, G, H, D, 0, stream);
+  }
+  const int nfold = cdiv(H, 16) * cdiv(D + 1, 16), ncx = cdiv(G, CHAIN2_ROWS);
+  hipLaunchKernelGGL(wgrad_fold_chain2_kernel, dim3(nfold + 2 * ncx), dim3(1024), lc > lf ? lc : lf, (hipStream_t)stream, w0, w1, p0, p1,
+                     c0, c1, w_in, b_in, dw_in, db_in, dw0, dw1, G, H, D, nfold, ncx);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }
@@ -1971,7 +2103,8 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
       // (NW = 8 waves per workgroup, 70 KB of LDS: 60 us against 54 alone, and starved beside the GRU backward cluster -- 110 us;
       //  the counters of the 4-wave form: MFMA pipe 32 % busy, waves waiting on memory 52 % of their time, no LDS bank conflicts:
       //  profiles/r05_ai_pmc_smallm_wgrad_4waves.json, r05_aj_lds_wgrad_8waves_ab.log)
-      smw_lds_launch<2, 2, 4>(sb, lddy, ldx, M, K, N, accumulate, nprob, xpp, (hipStream_t)stream);
+      // 2 x 1 tiles: two / four 600 x 200 products at 2560 rows 27.8 / 50.9 us (2 x 2: 38.6 / 56.6, 1 x 1: 34.8 / 67.1; r05_al log)
+      smw_lds_launch<2, 1, 4>(sb, lddy, ldx, M, K, N, accumulate, nprob, xpp, (hipStream_t)stream);
     } else if (!x_keep && !mapped && M >= 512 && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(cdiv(K, 16), 2) * nprob >= 256)
       hipLaunchKernelGGL((gemm_tn_smallm_rt_kernel<2, 2, 4>), xpp ? dim3(8 * cdiv(groups2, xpp), 1) : dim3(groups2, nprob), dim3(256), 0,
                          (hipStream_t)stream, sb, lddy, ldx, M, K, N, accumulate, xpp);

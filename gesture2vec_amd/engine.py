@@ -1017,12 +1017,39 @@ class VQVAEEngine:
         else:
             check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
+        # generic dims (D < H): in_layer's gradient and the W_ih gradients are re-associated through in_layer
+        # (g2v_linear_bwd_weight_fold2 / _chain2) from P = dgi^T x and c = column sums of dgi per direction
+        fold_in = H != 64 and not self.wgrad_bf16x3
+        chain_ih = fold_in and b["enc_fused_wgrad"] == 0
+        c_in = None
+
+        def p_products():
+            nonlocal c_in
+            arr = (_lib.WgradItem * 4)()
+            # (the column sums of dgi ARE the gradients of bias_ih: written in place when the W_ih gradients are folded too)
+            c_in = [self._g(enc + "gru.bias_ih_l0" + suf) if chain_ih else b["c_in"][k].data_ptr() for k, suf in enumerate(("", "_reverse"))]
+            for k, key in enumerate(("f", "b")):
+                arr[k].dy, arr[k].x = _p(b["dgi_" + key]), _p(b["x_drop"]) if drop else _p(in_poses)
+                arr[k].dw, arr[k].db = b["p_in"][k].data_ptr(), c_in[k]
+            if drop:        # the dropped input is a (T B, D) tensor of its own; without dropout the (B,T,D) input in (T,B) row order
+                check(lib.g2v_linear_bwd_weight_batch(arr, 2, G, D, TB, D, G, 0, ws, wsn, st))
+            else:
+                check(lib.g2v_linear_bwd_weight_batch_mapped(arr, 2, G, D, B, D, T * D, TB, D, G, 0, ws, wsn, st))
+
+        # Small row counts: the products FIRST, in front of the fork -- beside the W_hh gradients' launch they take 42 us instead of
+        # 19, and the fold / chain kernels behind them are what the step's tail waits for (native shape 1.017 -> 1.006 ms).  Large
+        # batch: behind the fork, beside the W_hh gradients (in front of it: native dims at B = 4096 6.38 -> 6.73 ms).
+        p_first = fold_in and TB < 4096
+        if p_first:
+            p_products()
         with self._branch(4):       # beside the input layer's gradient below (joined there)
             _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 4) & 1 else "ws")
             items = [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
                      (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
                      (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
                      (_p(b["dgh_b"]), b["hs_b"][1:].data_ptr(), enc + "gru.weight_hh_l0_reverse", enc + "gru.bias_hh_l0_reverse")]
+            if chain_ih:
+                items = [items[1], items[3]]        # the W_ih gradients: g2v_linear_bwd_weight_chain2 below
             if b["enc_fused_wgrad"] == 1:
                 items = [items[0], items[2]]        # the W_hh gradients came out of the recurrent kernel
             if b["enc_fused_wgrad"] < 2:
@@ -1050,22 +1077,22 @@ class VQVAEEngine:
             return
         if H == 64:
             check(lib.g2v_add_halves(_p(b["gi_f"]), H, _p(b["gi_b"]), H, _p(b["dxin"]), H, TB, H, st))     # sum of the two directions
-        elif not self.wgrad_bf16x3:
+        elif fold_in:
             # in_layer's gradient WITHOUT the (T B x H) gradient of its output (nothing else reads it: the layer's input is the
             # network's input): dW_in = W_f^T (dgi_f^T x) + W_b^T (dgi_b^T x) -- two weight-gradient products with K = D in one
             # launch and one small fold, instead of two (T B x 3H)(3H x H) products and a weight-gradient product
-            arr = (_lib.WgradItem * 4)()
-            for k, key in enumerate(("f", "b")):
-                arr[k].dy, arr[k].x = _p(b["dgi_" + key]), _p(b["x_drop"]) if drop else _p(in_poses)
-                arr[k].dw, arr[k].db = b["p_in"][k].data_ptr(), b["c_in"][k].data_ptr()
-            if drop:        # the dropped input is a (T B, D) tensor of its own; without dropout the (B,T,D) input in (T,B) row order
-                check(lib.g2v_linear_bwd_weight_batch(arr, 2, G, D, TB, D, G, 0, ws, wsn, st))
+            if not p_first:
+                p_products()
+            if chain_ih:      # ... and dW_ih = dgi^T in_layer(x) = (dgi^T x) W_in^T + (dgi^T 1) b_in^T, in the same launch
+                check(lib.g2v_linear_bwd_weight_fold_chain2(
+                    self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"), b["p_in"][0].data_ptr(),
+                    b["p_in"][1].data_ptr(), c_in[0], c_in[1], self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"),
+                    self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"), self._g(enc + "gru.weight_ih_l0"),
+                    self._g(enc + "gru.weight_ih_l0_reverse"), G, H, D, st))
             else:
-                check(lib.g2v_linear_bwd_weight_batch_mapped(arr, 2, G, D, B, D, T * D, TB, D, G, 0, ws, wsn, st))
-            check(lib.g2v_linear_bwd_weight_fold2(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"),
-                                                  b["p_in"][0].data_ptr(), b["p_in"][1].data_ptr(), b["c_in"][0].data_ptr(),
-                                                  b["c_in"][1].data_ptr(), self._g(enc + "in_layer.weight"),
-                                                  self._g(enc + "in_layer.bias"), G, H, D, 0, st))
+                check(lib.g2v_linear_bwd_weight_fold2(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.weight_ih_l0_reverse"),
+                                                      b["p_in"][0].data_ptr(), b["p_in"][1].data_ptr(), c_in[0], c_in[1],
+                                                      self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias"), G, H, D, 0, st))
             self._join(4)
             return
         else:

@@ -178,6 +178,32 @@ def linear_bwd_weight_fold2(w0, w1, p0, p1, c0, c1, dw=None, db=None, accumulate
     return dw, db
 
 
+def linear_bwd_weight_chain2(p0, p1, c0, c1, w_in, b_in, accumulate=False, dw0=None, dw1=None):
+    """dw_p = p_p w_in^T + c_p b_in^T (g2v_linear_bwd_weight_chain2).  p: (G,D), c: (G), w_in: (H,D), b_in: (H) -> two (G,H)."""
+    G, D = p0.shape
+    H = w_in.shape[0]
+    if dw0 is None:
+        dw0 = torch.empty((G, H), dtype=torch.float32, device=p0.device)
+    if dw1 is None:
+        dw1 = torch.empty((G, H), dtype=torch.float32, device=p0.device)
+    check(_lib_().g2v_linear_bwd_weight_chain2(_p(p0), _p(p1), _p(c0), _p(c1), _p(_chk(w_in, name="w_in")), _p(b_in), _p(dw0), _p(dw1),
+                                               G, H, D, int(bool(accumulate)), _stream()), "linear_bwd_weight_chain2")
+    return dw0, dw1
+
+
+def linear_bwd_weight_fold_chain2(w0, w1, p0, p1, c0, c1, w_in, b_in):
+    """linear_bwd_weight_fold2 + linear_bwd_weight_chain2 in one launch -> (dw_in, db_in, dw0, dw1)."""
+    G, H = w0.shape
+    D = p0.shape[1]
+    dev = w0.device
+    dw_in, db_in = torch.empty((H, D), dtype=torch.float32, device=dev), torch.empty((H,), dtype=torch.float32, device=dev)
+    dw0, dw1 = torch.empty((G, H), dtype=torch.float32, device=dev), torch.empty((G, H), dtype=torch.float32, device=dev)
+    check(_lib_().g2v_linear_bwd_weight_fold_chain2(_p(_chk(w0, name="w0")), _p(_chk(w1, name="w1")), _p(p0), _p(p1), _p(c0), _p(c1),
+                                                    _p(_chk(w_in, name="w_in")), _p(b_in), _p(dw_in), _p(db_in), _p(dw0), _p(dw1),
+                                                    G, H, D, _stream()), "linear_bwd_weight_fold_chain2")
+    return dw_in, db_in, dw0, dw1
+
+
 # ------------------------------------------------------------------------------------------ quantiser
 def vq_code_sqnorm(codebook, out=None):
     K, E = codebook.shape

@@ -114,6 +114,16 @@ size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
  * nothing else reads when x is the network's input, is never formed -- D / H of its arithmetic.  Deterministic. */
 int g2v_linear_bwd_weight_fold2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
                                 const float* c1, float* dw, float* db, int G, int H, int D, int accumulate, g2v_stream_t stream);
+/* ... and the weight gradients of those two layers themselves, dW_p = dg_p^T y with y = x W_in^T + b_in, from the same p_p, c_p:
+ *     dw_p[g][h] (+)= sum_d p_p[g][d] w_in[h][d] + c_p[g] b_in[h]        (w_in: [H][D], b_in: [H], dw_p: [G][H])
+ * = autograd's dW_ih = dgi^T in_layer(x) re-associated (ref EncoderRNN: in_layer :93 straight into the GRU :94); db_p = c_p.  A
+ * (G x D)(D x H) product instead of (G x M)(M x H).  Deterministic. */
+int g2v_linear_bwd_weight_chain2(const float* p0, const float* p1, const float* c0, const float* c1, const float* w_in,
+                                 const float* b_in, float* dw0, float* dw1, int G, int H, int D, int accumulate, g2v_stream_t stream);
+/* Both of the above (overwrite form) in ONE launch -- they read the same p, c and nothing of each other; bitwise their results. */
+int g2v_linear_bwd_weight_fold_chain2(const float* w0, const float* w1, const float* p0, const float* p1, const float* c0,
+                                      const float* c1, const float* w_in, const float* b_in, float* dw_in, float* db_in,
+                                      float* dw0, float* dw1, int G, int H, int D, g2v_stream_t stream);
 /* dw = (dy_a + dy_b)^T x (+ db = column sums of dy_a + dy_b): the addends are summed as the operand fragments are used --
  * the arithmetic of "add, then g2v_linear_bwd_weight" without the add pass.  The encoder's input layer uses it: its dx
  * arrives as one array per GRU direction (ref Autoencoder_VQVAE_model.py:447-464, the bidirectional nn.GRU's input

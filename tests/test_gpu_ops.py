@@ -1548,7 +1548,7 @@ def test_linear_fwd_pair_equals_two_calls(ops, M, K, N, act):
                                           (2560, 40, 200, 2), (1000, 72, 36, 1)])
 def test_linear_bwd_weight_small_row_counts(ops, M, N, K, nprob):
     """The weight-gradient kernels below 4096 rows (the reference's own batch size: 19-20 steps x 128 rows): the LDS-staged
-    2 x 2-tile kernel (many tiles, float4-aligned operands), the register-tiled one it replaces for unaligned operands
+    kernel (many tiles, float4-aligned operands), the register-tiled one it replaces for unaligned operands
     (same rows per MFMA, same accumulation order: BITWISE the same dW / db -- checked by handing the same x over with a row
     stride that is not a multiple of 4), and the 16-wave form of the one-tile kernel where a product has too few tiles to
     fill the chip.  All against float64, all deterministic."""
@@ -1597,6 +1597,21 @@ def test_linear_bwd_weight_fold2_equals_the_gradient_through_the_layer_output(op
     dw_ref, db_ref = ops.linear_bwd_weight(dy, x, H, D)
     relclose(dw, dw_ref, 5e-6, "dW_in vs the gradient through the layer output")
     relclose(db, db_ref, 5e-6, "db_in vs the gradient through the layer output")
+    # g2v_linear_bwd_weight_chain2: the two layers' own weight gradients dg_p^T (x W_in^T + b_in) from the same products
+    w_in, b_in = rnd(H, D, seed=85).to(DEV) * 0.3, rnd(H, seed=86).to(DEV)
+    dwa, dwb = ops.linear_bwd_weight_chain2(items[0][2], items[1][2], items[0][3], items[1][3], w_in, b_in)
+    y64 = x.double() @ w_in.double().t() + b_in.double()
+    y = ops.linear_fwd(x, w_in, b_in)
+    for p_, got in enumerate((dwa, dwb)):
+        relclose(got, (dg[p_].double().t() @ y64).float(), 5e-6, f"dW of layer {p_} behind the linear layer vs float64")
+        relclose(got, ops.linear_bwd_weight(dg[p_], y, G, H)[0], 5e-6, f"dW of layer {p_} vs the product with the layer output")
+    dwa2, dwb2 = ops.linear_bwd_weight_chain2(items[0][2], items[1][2], items[0][3], items[1][3], w_in, b_in)
+    assert torch.equal(dwa, dwa2) and torch.equal(dwb, dwb2), "chain2 not deterministic"
+    one = ops.linear_bwd_weight_fold_chain2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3], w_in, b_in)
+    for got, want, what in zip(one, (dw, db, dwa, dwb), ("dW_in", "db_in", "dW of layer 0", "dW of layer 1")):
+        assert torch.equal(got, want), f"{what}: the one-launch form differs from the two kernels"
+    ops.linear_bwd_weight_chain2(items[0][2], items[1][2], items[0][3], items[1][3], w_in, b_in, accumulate=True, dw0=dwa2, dw1=dwb2)
+    relclose(dwa2, 2 * dwa, 1e-6, "accumulated chain2")
     dw2, db2 = ops.linear_bwd_weight_fold2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3])
     assert torch.equal(dw, dw2) and torch.equal(db, db2), "not deterministic"
     ops.linear_bwd_weight_fold2(w[0], w[1], items[0][2], items[1][2], items[0][3], items[1][3], dw=dw2, db=db2, accumulate=True)
