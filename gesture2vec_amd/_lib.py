@@ -139,6 +139,7 @@ _SIGS = {
     "g2v_dec_rollout_set_persistent": (c_int, [c_int]),
     "g2v_gru_seq_set_cluster": (c_int, [c_int]),
     "g2v_gru_seq_cluster_ok": (c_int, [c_int, c_int, c_int, c_int]),
+    "g2v_cluster_exchange_preclear": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_dec_rollout_tiles_per_workgroup": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_cluster_ok": (c_int, [c_int, c_int, c_int]),
     "g2v_dec_rollout_persist_fault": (c_int, [c_int]),

@@ -999,7 +999,11 @@ extern "C" int g2v_read_spans(unsigned long long* out) {
 int g2v_internal_persist_enabled() { return g_persist != 0 ? 1 : 0; }      // (t2e_rollout.hip: the code decoder's cluster kernel)
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
+int g2v_internal_preclear_take(const void* p, size_t need);      // dec_persist.hip
+void g2v_internal_preclear_note(const void* p, size_t n);
+void g2v_internal_preclear_drop(const void* base, size_t bytes);
 extern "C" int g2v_dec_rollout_set_persistent(int enable) {
+  g2v_internal_preclear_drop(nullptr, 0);
   const int prev = g_persist;
   g_persist = enable <= 0 ? 0 : (enable > PERSIST_MAX_TILES_PER_WG ? PERSIST_MAX_TILES_PER_WG : enable);
   return prev;
@@ -2672,7 +2676,8 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
       ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.training = training;
       ca.nt = (H + 15) >> 4; ca.nblk = dm.nblk;
       ca.p_drop = p_drop;
-      if (hipMemsetAsync(x0, 0, dec_cluster_fwd_xch_bytes(dm.nblk, H), st) != hipSuccess) {
+      if (!g2v_internal_preclear_take(x0, dec_cluster_fwd_xch_bytes(dm.nblk, H)) &&
+          hipMemsetAsync(x0, 0, dec_cluster_fwd_xch_bytes(dm.nblk, H), st) != hipSuccess) {
         set_error("g2v_dec_rollout_fwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
@@ -2777,6 +2782,29 @@ extern "C" int g2v_dec_rollout_cluster_ok(int B, int D, int H) {
   if (B <= 0 || !persist_enabled() || !dec_cluster_shape(D, H)) return 0;
   const int nblk = cdiv(B, 16);
   return (nblk <= DSPLIT_MAX_NBLK && (int64_t)nblk * ((H + 15) >> 4) <= device_cu_count()) ? 1 : 0;
+}
+size_t g2v_internal_gru_cluster_region(int T, int B, int H, int ndir, int bwd);      // gru.hip
+// Clear the exchange records of the NEXT persistent cluster launch of this kind over `workspace` now, on `stream`, and note it: that
+// launch then starts with its kernel instead of a memset node (see g2v.h).  kind: 0 / 1 g2v_gru_seq_fwd / _bwd (T, B, H, ndir),
+// 2 / 3 g2v_dec_rollout_fwd / _bwd (B, D, H).  Shapes that do not run as a cluster: nothing happens.
+extern "C" int g2v_cluster_exchange_preclear(int kind, int T, int B, int D, int H, int ndir, void* workspace, size_t workspace_bytes,
+                                             g2v_stream_t stream) {
+  G2V_REQUIRE(workspace, "null pointer");
+  G2V_REQUIRE(kind >= 0 && kind <= 3, "kind: 0 gru fwd, 1 gru bwd, 2 decoder fwd, 3 decoder bwd");
+  size_t off = 0, bytes = 0;
+  if (kind <= 1) {
+    bytes = g2v_internal_gru_cluster_region(T, B, H, ndir, kind);
+  } else if (g2v_dec_rollout_cluster_ok(B, D, H) && T >= 3) {
+    off = kind == 2 ? fwd_pack_bytes_aligned(D, H) : 0;
+    bytes = kind == 2 ? dec_cluster_fwd_xch_bytes(cdiv(B, 16), H) : dec_cluster_bwd_xch_bytes(cdiv(B, 16), H);
+  }
+  if (bytes == 0 || off + bytes > workspace_bytes) return G2V_OK;
+  if (hipMemsetAsync((char*)workspace + off, 0, bytes, (hipStream_t)stream) != hipSuccess) {
+    set_error("g2v_cluster_exchange_preclear: memset failed");
+    return G2V_ERR_LAUNCH;
+  }
+  g2v_internal_preclear_note((char*)workspace + off, bytes);
+  return G2V_OK;
 }
 // 0: one launch per time step; R >= 1: ONE persistent launch each way with R row tiles per workgroup (see g2v.h)
 extern "C" int g2v_dec_rollout_tiles_per_workgroup(int B, int D, int H) {
@@ -2934,7 +2962,8 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
       ca.fault = const_cast<unsigned*>(g2v_internal_persist_fault_ptr());
       ca.T = T; ca.B = B; ca.D = D; ca.H = H; ca.n_pre = n_pre_poses; ca.conditioned = conditioned; ca.p_drop = p_drop;
       ca.nt = (H + 15) >> 4; ca.nblk = nblk;
-      if (hipMemsetAsync(x0, 0, dec_cluster_bwd_xch_bytes(nblk, H), st) != hipSuccess) {
+      if (!g2v_internal_preclear_take(x0, dec_cluster_bwd_xch_bytes(nblk, H)) &&
+          hipMemsetAsync(x0, 0, dec_cluster_bwd_xch_bytes(nblk, H), st) != hipSuccess) {
         set_error("g2v_dec_rollout_bwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }

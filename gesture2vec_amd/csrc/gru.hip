@@ -1740,7 +1740,9 @@ static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 
 // 192-thread workgroup per CU (the workgroups of a row group wait for each other).  g2v_gru_seq_set_cluster(0) keeps the
 // per-step launches (parity tests, A/B).
 static int g_gru_cluster = 1;
+void g2v_internal_preclear_drop(const void* base, size_t bytes);
 extern "C" int g2v_gru_seq_set_cluster(int enable) {
+  g2v_internal_preclear_drop(nullptr, 0);
   const int prev = g_gru_cluster;
   g_gru_cluster = enable ? 1 : 0;
   return prev;
@@ -1769,6 +1771,8 @@ static size_t gru_cluster_max_xch_bytes(int H, bool bwd) {
   const size_t Hp = (size_t)((H + 15) & ~15), nt = Hp / 16, cus = (size_t)gru_device_cus();
   return (bwd ? cus : cus / nt + 1) * 2 * 16 * Hp * 8 + cus * sizeof(unsigned) + 16;
 }
+int g2v_internal_preclear_take(const void* p, size_t need);      // dec_persist.hip
+void g2v_internal_preclear_drop(const void* base, size_t bytes);
 static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn);
 // 1: g2v_gru_seq_fwd / _bwd run this shape as the persistent cluster kernels (small batch; see g2v_gru_seq_set_cluster)
 extern "C" int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir) {
@@ -1782,6 +1786,11 @@ static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn) {
   return hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fn, 192, 0) == hipSuccess && n >= 1;
 }
 
+// the exchange region a cluster launch of this shape clears (offset 0 of its workspace); 0: not a cluster shape
+size_t g2v_internal_gru_cluster_region(int T, int B, int H, int ndir, int bwd) {
+  if (ndir < 1 || ndir > 2 || !gru_cluster_ok(T, B, ndir, H, nullptr)) return 0;
+  return gru_cluster_xch_bytes(B, ndir, H, bwd != 0);
+}
 extern "C" size_t g2v_gru_seq_fwd_workspace(int ndir, int H) {
   const size_t a = (size_t)2 * ndir * pack_floats(H, 3, H), b = gru_split_state_floats(ndir, H);
   const size_t c = gru_cluster_max_xch_bytes(H, false);
@@ -1986,7 +1995,7 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
         c[k] = GruClF{dirs[k].gi, dirs[k].w_hh, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].gates, dirs[k].h_n,
                       reinterpret_cast<unsigned long long*>((char*)workspace + (size_t)k * (rbytes / ndir)), dirs[k].reverse};
       if (ndir == 1) c[1] = c[0];
-      if (hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
+      if (!g2v_internal_preclear_take(workspace, xbytes) && hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
         set_error("g2v_gru_seq_fwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
@@ -1996,6 +2005,7 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }
+    g2v_internal_preclear_drop(workspace, workspace_bytes);      // (per-step launches: a pre-cleared note for this workspace is void)
     float* state = (float*)workspace;                  // [dir][2][B][H]
     for (int s_ = 0; s_ < T; ++s_) {
       GruStepF g[2];
@@ -2228,7 +2238,7 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
                       dirs[k].reverse};
       if (ndir == 1) c[1] = c[0];
       const bool want_dh0 = dirs[0].dh0 || (ndir == 2 && dirs[1].dh0);
-      if (hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
+      if (!g2v_internal_preclear_take(workspace, xbytes) && hipMemsetAsync(workspace, 0, xbytes, st) != hipSuccess) {
         set_error("g2v_gru_seq_bwd: clearing the exchange records failed");
         return G2V_ERR_LAUNCH;
       }
@@ -2238,6 +2248,7 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
       G2V_CHECK_LAUNCH();
       return G2V_OK;
     }
+    g2v_internal_preclear_drop(workspace, workspace_bytes);
     if (hn_any) {
       set_error("g2v_gru_seq_bwd: the fused quantiser backward was requested but the cluster kernel does not serve this call");
       return G2V_ERR_UNSUPPORTED;

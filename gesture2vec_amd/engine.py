@@ -202,6 +202,9 @@ class VQVAEEngine:
         # batch (round 5) -- they pay at every batch size: full shape B = 128 1.035 -> 0.970 ms, B = 512 1.136 -> 1.046, native
         # B = 128 1.352 -> 1.303 (profiles/r05_u_branches_small_batch.log); _branches_ok() asks the library which case a shape is.
         self.overlap_min_rows = int(os.environ.get("G2V_OVERLAP_MIN_ROWS", "1024"))
+        # the cluster launches' exchange records cleared on branch 0 instead of in front of each launch (switches)
+        self.xch_preclear = os.environ.get("G2V_XCH_PRECLEAR", "1") != "0"
+        self._xch_pre = False
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
@@ -675,6 +678,8 @@ class VQVAEEngine:
         b = self.buffers(B)
         drop_in = training and self.p > 0
         fn, ws = (lib.g2v_dec_rollout_fwd_prepared, b["ws_decf"]) if self._prepared else (lib.g2v_dec_rollout_fwd, b["ws"])
+        if self._xch_pre and training:
+            ws = b["ws_decf"]                  # its exchange records were cleared on branch 0 (side())
         fold = b["loss_folded"] = bool(training and chase)
         check(fn(_p(out_poses), _p(b["quant"]), C.byref(self.dec_wstruct()),
                  C.byref((b["sv_loss"] if fold else b["sv"]) if training else b["sv_eval"]), _p(b["keep95"]),
@@ -940,6 +945,8 @@ class VQVAEEngine:
         ws, wsn = _p(b["ws"]), b["ws"].numel()
         drop = self.p > 0
         fn, wsd = (lib.g2v_dec_rollout_bwd_prepared, b["ws_decb"]) if self._prepared else (lib.g2v_dec_rollout_bwd, b["ws"])
+        if self._xch_pre:
+            wsd = b["ws_decb"]
         pre = "decoder.decoder."
         M = (T - 1) * B
         check(fn(C.byref(self.dec_wstruct()), C.byref(b["sv_loss"] if b["loss_folded"] else b["sv"]), C.byref(b["gr"]), _p(b["keep95"]),
@@ -1014,6 +1021,8 @@ class VQVAEEngine:
                     dirs[k].x = _p(b["xin"])
         if self._prepared:
             check(lib.g2v_gru_seq_bwd_prepared(dirs, 2, None, H, H, T, B, H, _p(b["ws_grub"]), b["ws_grub"].numel(), st))
+        elif self._xch_pre:
+            check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, _p(b["ws_grub"]), b["ws_grub"].numel(), st))
         else:
             check(lib.g2v_gru_seq_bwd(dirs, 2, None, H, H, T, B, H, ws, wsn, st))
         TB = T * B
@@ -1148,6 +1157,7 @@ class VQVAEEngine:
         finally:
             self._prepared = False
             self._side_work = None
+            self._xch_pre = False
             self._fused_in_drop = False
             self._defer_commit = False
             if not dp:
@@ -1156,6 +1166,15 @@ class VQVAEEngine:
     def _train_step_local(self, x, target, w_l1, w_cont, w_var, epoch, draw_masks, dp, B):
         self._fused_in_drop = bool(draw_masks and self.p > 0)      # the encoder's input mask is drawn inside its dropout kernel
         def side():                            # branch 0: beside the encoder GRU (forked in forward_encoder), joined before the quantiser
+            if self.xch_preclear and self.H != 64:
+                # generic dims at small batch: the exchange records of the three cluster launches behind the quantiser are cleared
+                # HERE, off the chain, in workspaces only those launches use (g2v_cluster_exchange_preclear; a no-op for shapes
+                # that do not run as clusters)
+                bb = self.buffers(B)
+                for kind, key in ((2, "ws_decf"), (3, "ws_decb"), (1, "ws_grub")):
+                    check(self.lib.g2v_cluster_exchange_preclear(kind, self.T, B, self.D, self.H, 2, _p(bb[key]), bb[key].numel(),
+                                                                 self._stream()))
+                self._xch_pre = True
             if self.quantizer == "ema":
                 self.vq_derive()               # needed first: the quantiser follows the encoder directly
             elif self.quantizer == "gssoft":   # |W_k|^2 of the codebook as it is now: off the chain in front of the fused quantiser kernel

@@ -292,6 +292,16 @@ int g2v_gru_seq_set_cluster(int enable);
 /* 1: this shape runs as the cluster kernels under the current setting (then g2v_gru_dir_bwd.hn_z .. hn_coef, the fused quantiser
  * backward below, are honoured at H != 64 too) */
 int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir);
+/* A persistent cluster launch (g2v_gru_seq_fwd / _bwd, g2v_dec_rollout_fwd / _bwd at the shapes their *_cluster_ok queries
+ * name) clears its exchange records in front of the kernel: a memset of 1-11 MB, 5-12 us on the caller's chain.  A caller that hands
+ * such a call a workspace NOTHING ELSE WRITES can have the records cleared ahead of time, e.g. on a side stream at the start of the
+ * step: this call issues the memset on `stream` now and notes it; the next cluster launch of that kind over this workspace takes
+ * the note (one shot) and starts with its kernel.  The caller orders `stream` in front of that launch and keeps the workspace
+ * untouched in between.  kind: 0 / 1 = g2v_gru_seq_fwd / _bwd (T, B, H, ndir; D ignored), 2 / 3 = g2v_dec_rollout_fwd / _bwd
+ * (T, B, D, H; ndir ignored).  Shapes that do not run as a cluster: G2V_OK, nothing happens.  A launch over the workspace that does
+ * not run as a cluster, and either of the two switches above, forget the note. */
+int g2v_cluster_exchange_preclear(int kind, int T, int B, int D, int H, int ndir, void* workspace, size_t workspace_bytes,
+                                  g2v_stream_t stream);
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
 size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */

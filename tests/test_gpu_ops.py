@@ -1530,6 +1530,35 @@ def test_linear_bwd_weight_batch_matches_single_calls(ops, M, N, K):
         relclose(items[p][2], 2 * first[p][0], 2e-6, f"dw of problem {p} accumulated")
 
 
+def test_cluster_exchange_preclear_clears_cluster_shapes_only(ops):
+    """g2v_cluster_exchange_preclear: the exchange records of the next cluster launch are cleared ahead of time (the engine does
+    that on a side branch; the train-step parity tests at the native dims run through it); shapes that do not run as clusters,
+    and a disabled cluster path, leave the workspace alone."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    T, B, D, H = 20, 128, 40, 200
+    st = torch.cuda.current_stream().cuda_stream
+    for kind, nbytes in ((1, lib.g2v_gru_seq_bwd_workspace(2, H)), (0, lib.g2v_gru_seq_fwd_workspace(2, H)),
+                         (2, lib.g2v_dec_rollout_fwd_workspace(D, H)), (3, lib.g2v_dec_rollout_bwd_workspace(D, H))):
+        ws = torch.full((int(nbytes),), 0xAB, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.g2v_cluster_exchange_preclear(kind, T, B, D, H, 2, ws.data_ptr(), ws.numel(), st), "preclear")
+        torch.cuda.synchronize()
+        cleared = int((ws == 0).sum())
+        assert cleared >= 65536, f"kind {kind}: nothing was cleared at the shipped shape"
+        ws.fill_(0xAB)
+        _lib.check(lib.g2v_cluster_exchange_preclear(kind, T, 4096, D, H, 2, ws.data_ptr(), ws.numel(), st), "preclear")
+        torch.cuda.synchronize()
+        assert bool((ws == 0xAB).all()), f"kind {kind}: a shape that does not run as a cluster was touched"
+    prev = lib.g2v_gru_seq_set_cluster(0)
+    try:
+        ws = torch.full((int(lib.g2v_gru_seq_bwd_workspace(2, H)),), 0xAB, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.g2v_cluster_exchange_preclear(1, T, B, D, H, 2, ws.data_ptr(), ws.numel(), st), "preclear")
+        torch.cuda.synchronize()
+        assert bool((ws == 0xAB).all()), "the disabled cluster path was pre-cleared"
+    finally:
+        lib.g2v_gru_seq_set_cluster(prev)
+
+
 @pytest.mark.parametrize("M,K,N,act", [(2560, 200, 600, 0), (1280, 200, 600, 1), (2560, 64, 192, 0), (300, 50, 150, 2), (2560, 202, 600, 0)])
 def test_linear_fwd_pair_equals_two_calls(ops, M, K, N, act):
     """g2v_linear_fwd_pair (both directions' GRU input projections in one launch at small row counts) is BITWISE two
