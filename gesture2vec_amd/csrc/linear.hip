@@ -2098,7 +2098,7 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     bool vec_ok = !x_keep && !mapped && M >= 512 && ((N | K | lddy | ldx) & 3) == 0;
     for (int p2 = 0; p2 < nprob && vec_ok; ++p2)
       vec_ok = ((reinterpret_cast<uintptr_t>(it[p2].dy) | reinterpret_cast<uintptr_t>(it[p2].x)) & 15) == 0;
-    if (vec_ok && (int64_t)groups2 * nprob >= 256) {
+    if (vec_ok && (int64_t)cdiv(cdiv(N, 16), 2) * cdiv(K, 16) * nprob >= 256) {      // (2 x 1 tiles per workgroup)
       // float4-aligned operands: the LDS-staged form (four 600 x 200 products at 2560 rows: 53 us against 70, bitwise the same dW)
       // (NW = 8 waves per workgroup, 70 KB of LDS: 60 us against 54 alone, and starved beside the GRU backward cluster -- 110 us;
       //  the counters of the 4-wave form: MFMA pipe 32 % busy, waves waiting on memory 52 % of their time, no LDS bank conflicts:

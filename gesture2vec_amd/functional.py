@@ -108,6 +108,49 @@ class EmbeddingFn(torch.autograd.Function):
         return ops.embedding_bwd(g.contiguous(), ids, ctx.V, keep, ctx.scale), None, None, None
 
 
+class EmbedProjectPairFn(torch.autograd.Function):
+    """gi_p = table[ids] W_p^T + b_p for the two directions p of a bidirectional GRU layer fed straight by nn.Embedding (ref
+    text2embedding_model.py EncoderRNN: self.embedding(input_seqs) -> self.gru, no dropout in between), for MANY rows per
+    vocabulary entry: the projection commutes with the gather, so
+        forward : G_p = table W_p^T + b_p (V x 3H, both directions in one launch), gi_p = G_p[ids];
+        backward: S_p = the scatter-add of dgi_p by id (V x 3H: the embedding backward on 3H-wide rows), then
+                  d_table = S_f W_f + S_b W_b,  dW_p = S_p^T table,  db_p = column sums of S_p
+    -- three V-row products per direction instead of three (rows)-row ones.  The forward is bitwise the gather-then-project
+    form (the same dot product per element); the backward equals autograd's to summation order."""
+
+    @staticmethod
+    def forward(ctx, table, ids, w_f, b_f, w_b, b_b):
+        table, ids = table.contiguous(), ids.contiguous().view(-1)
+        w_f, w_b = w_f.contiguous(), w_b.contiguous()
+        g_f, g_b = ops.linear_fwd_pair(table, w_f, b_f, w_b, b_b)
+        gi_f, gi_b = ops.embedding_fwd(g_f, ids), ops.embedding_fwd(g_b, ids)
+        ctx.save_for_backward(table, ids, w_f, w_b)
+        ctx.set_materialize_grads(False)
+        return gi_f, gi_b
+
+    @staticmethod
+    def backward(ctx, d_f, d_b):
+        table, ids, w_f, w_b = ctx.saved_tensors
+        V, (N, K) = table.shape[0], w_f.shape
+        d_table, out, items = None, [], []
+        for d, w in ((d_f, w_f), (d_b, w_b)):
+            if d is None:
+                out += [None, None]
+                continue
+            s = ops.embedding_bwd(d.contiguous().view(-1, N), ids, V)
+            if d_table is None:
+                d_table = ops.linear_bwd_data(s, w)
+            else:
+                ops.linear_bwd_data(s, w, out=d_table, accumulate=True)
+            dw = torch.empty((N, K), dtype=torch.float32, device=table.device)
+            db = torch.empty((N,), dtype=torch.float32, device=table.device)
+            items.append((s, table, dw, db))
+            out += [dw, db]
+        if items:
+            ops.linear_bwd_weight_batch(items, N, K, M=V)      # both directions' dW = S^T table in one launch
+        return d_table, None, out[0], out[1], out[2], out[3]
+
+
 class BatchNormReluFn(torch.autograd.Function):
     """nn.BatchNorm1d(+ReLU) on (B,H): batch statistics (and running-stat update) in training, running stats in eval."""
 

@@ -94,15 +94,22 @@ class EncoderRNN(nn.Module):
         ids_flat = input_seqs.contiguous().view(-1)
         if packed is not None:
             ids_flat = ids_flat.index_select(0, packed[3])
-        x = Fn.EmbeddingFn.apply(self.embedding.weight, ids_flat, None, 1.0)   # (Tw*B, E), or (sum(lengths), E) packed
+        # many rows per vocabulary entry (B = 4096: 49 k packed rows, 3863 words): layer 0's input projections commute with the
+        # gather -- project the TABLE, gather the projected rows (Fn.EmbedProjectPairFn); else embed, then project
+        via_table = ids_flat.numel() >= 2 * self.embedding.weight.shape[0]
+        x = None if via_table else Fn.EmbeddingFn.apply(self.embedding.weight, ids_flat, None, 1.0)   # (Tw*B, E), or (sum(lengths), E) packed
         hiddens, layer_in = [], x
         out_f = out_b = None
         keep, scale = None, 1.0
         for l in range(L):
             g = self.gru
             pk = packed[:3] if (packed is not None and l == 0) else None
-            gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
-                             keep=keep, scale=scale) for suf in ("", "_reverse")]
+            if l == 0 and via_table:
+                gis = list(Fn.EmbedProjectPairFn.apply(self.embedding.weight, ids_flat, g.weight_ih_l0, g.bias_ih_l0,
+                                                       g.weight_ih_l0_reverse, g.bias_ih_l0_reverse))
+            else:
+                gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
+                                 keep=keep, scale=scale) for suf in ("", "_reverse")]
             if pk is None:
                 gis = [gi.view(Tw, B, 3 * H) for gi in gis]
             # both directions of the layer in one launch (each way)

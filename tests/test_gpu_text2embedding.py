@@ -610,3 +610,44 @@ def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
         assert relerr(prm.grad, ref) < 2e-4, (n, relerr(prm.grad, ref))
     assert worst[1] > 0.0
     print("worst gradient error (pinned decisions)", worst)
+
+
+@pytest.mark.parametrize("V,E,H,n", [(60, 300, 200, 5000), (3863, 300, 200, 9000), (17, 20, 12, 700)])
+def test_projecting_the_embedding_table_equals_projecting_the_gathered_rows(V, E, H, n):
+    """Fn.EmbedProjectPairFn (Part d's encoder at many rows per vocabulary entry: project the table, gather the projected rows;
+    scatter-add the gate gradients by word, then three V-row products) against EmbeddingFn + two Fn.linear: forward BITWISE,
+    every gradient to summation order, and against float64."""
+    from gesture2vec_amd import functional as Fn
+    g = torch.Generator().manual_seed(5)
+    table0 = torch.randn(V, E, generator=g)
+    ids = torch.randint(0, V, (n,), generator=g).to(DEV)
+    ws = [(torch.randn(3 * H, E, generator=g) * 0.1, torch.randn(3 * H, generator=g) * 0.1) for _ in range(2)]
+    cot = [torch.randn(n, 3 * H, generator=g).to(DEV) for _ in range(2)]
+
+    def leaves():
+        t = table0.clone().to(DEV).requires_grad_(True)
+        p = [(w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)) for w, b in ws]
+        return t, p
+
+    t1, p1 = leaves()
+    gi = Fn.EmbedProjectPairFn.apply(t1, ids, p1[0][0], p1[0][1], p1[1][0], p1[1][1])
+    (gi[0] * cot[0]).sum().backward(retain_graph=True)
+    (gi[1] * cot[1]).sum().backward()
+    t2, p2 = leaves()
+    x = Fn.EmbeddingFn.apply(t2, ids, None, 1.0)
+    ref = [Fn.linear(x, w, b) for w, b in p2]
+    ((ref[0] * cot[0]).sum() + (ref[1] * cot[1]).sum()).backward()
+    for k in range(2):
+        assert torch.equal(gi[k], ref[k]), f"direction {k}: the projected-table rows differ from the projected rows"
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    assert rel(t1.grad, t2.grad) < 5e-6, ("d table", rel(t1.grad, t2.grad))
+    for k in range(2):
+        assert rel(p1[k][0].grad, p2[k][0].grad) < 5e-6, (k, "dW", rel(p1[k][0].grad, p2[k][0].grad))
+        assert rel(p1[k][1].grad, p2[k][1].grad) < 5e-6, (k, "db", rel(p1[k][1].grad, p2[k][1].grad))
+    # float64: d table = sum_p onehot^T cot_p W_p
+    oh = torch.zeros(n, V, dtype=torch.float64)
+    oh[torch.arange(n), ids.cpu()] = 1.0
+    d64 = sum(oh.t() @ cot[k].cpu().double() @ ws[k][0].double() for k in range(2))
+    assert rel(t1.grad.cpu(), d64) < 5e-6, ("d table vs float64", rel(t1.grad.cpu(), d64))
+    dw64 = (oh.t() @ cot[0].cpu().double()).t() @ table0.double()
+    assert rel(p1[0][0].grad.cpu(), dw64) < 5e-6, ("dW vs float64", rel(p1[0][0].grad.cpu(), dw64))
