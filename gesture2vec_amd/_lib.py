@@ -85,6 +85,7 @@ _SIGS = {
     "g2v_device_ok": (c_int, []),
     "g2v_linear_fwd": (c_int, [c_fp, c_i64, c_int, c_i64, c_i64, c_fp, c_f, c_fp, c_fp, c_fp, c_i64,
                                c_int, c_int, c_int, c_int, c_fp]),
+    "g2v_linear_compose2": (c_int, [c_fp] * 10 + [c_int, c_int, c_int, c_fp]),
     "g2v_linear_fwd_pair": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_int, c_fp]),
     "g2v_linear_bwd_data": (c_int, [c_fp, c_i64, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_int, c_fp]),
     "g2v_linear_bwd_weight_workspace": (c_sz, [c_int, c_int, c_int]),

@@ -1341,6 +1341,75 @@ extern "C" int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64
   return G2V_OK;
 }
 
+// ---- two linear layers in a row as ONE: g_p = (x W_in^T + b_in) W_p^T + b_p = x (W_p W_in)^T + (W_p b_in + b_p) --------------------------
+// in_layer (D -> H) straight into the GRU input projections (H -> 3H, two directions; ref EncoderRNN :93-94) at the shipped dims,
+// where D (40 / 45) < H (200): the composed weights W_p W_in are (3H x D), and projecting x with them is D / H of the arithmetic of
+// projecting the layer's output -- whose only other reader, the weight gradient of W_p, is re-associated through in_layer too
+// (g2v_linear_bwd_weight_chain2).  wc_p[g][d] = sum_h w_p[g][h] w_in[h][d], bc_p[g] = sum_h w_p[g][h] b_in[h] + b_p[g]; one thread
+// per element, h ascending, w_in (+ b_in as a column) and the workgroup's rows of w_p staged in LDS (a 200-long chain of dependent
+// global loads per element was 40 us).  Equal to the two-layer form to rounding.
+__global__ __launch_bounds__(256) void linear_compose2_kernel(const float* __restrict__ w0, const float* __restrict__ b0,
+                                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                                              const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                              float* __restrict__ wc0, float* __restrict__ bc0,
+                                                              float* __restrict__ wc1, float* __restrict__ bc1, int G, int H, int D,
+                                                              int staged) {
+  extern __shared__ float sm[];      // staged: [H][D + 1] = w_in rows with b_in as column D | [rows][H] = this workgroup's rows of w_p
+  const float* W = blockIdx.y ? w1 : w0;
+  const float* Bp = blockIdx.y ? b1 : b0;
+  float* WC = blockIdx.y ? wc1 : wc0;
+  float* BC = blockIdx.y ? bc1 : bc0;
+  const int D1 = D + 1, tid = threadIdx.x;
+  if (staged) {
+    const int rows = 256 / D1, g0 = blockIdx.x * rows;      // (staged implies D + 1 <= 256)
+    float* wt = sm;
+    float* wr = sm + (size_t)H * D1;
+    for (int e = tid; e < H * D1; e += 256) {
+      const int h = e / D1, d = e - h * D1;
+      wt[e] = d < D ? w_in[(int64_t)h * D + d] : b_in[h];
+    }
+    for (int e = tid; e < rows * H; e += 256) {
+      const int r = e / H, g = g0 + r;
+      wr[e] = g < G ? W[(int64_t)g * H + (e - r * H)] : 0.f;
+    }
+    __syncthreads();
+    const int r = tid / D1, d = tid - r * D1, g = g0 + r;
+    if (r >= rows || g >= G) return;
+    const float* a = wr + (size_t)r * H;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int h = 0; h < H; ++h) acc = fmaf(a[h], wt[h * D1 + d], acc);      // (h ascending: the order of the unstaged loop)
+    if (d < D) WC[(int64_t)g * D + d] = acc;
+    else BC[g] = acc + Bp[g];
+    return;
+  }
+  const int e = blockIdx.x * 256 + tid;
+  if (e >= G * D1) return;
+  const int g = e / D1, d = e - g * D1;
+  const float* wr = W + (int64_t)g * H;
+  float acc = 0.f;
+  if (d < D) {
+    for (int h = 0; h < H; ++h) acc = fmaf(wr[h], w_in[(int64_t)h * D + d], acc);
+    WC[(int64_t)g * D + d] = acc;
+  } else {
+    for (int h = 0; h < H; ++h) acc = fmaf(wr[h], b_in[h], acc);
+    BC[g] = acc + Bp[g];
+  }
+}
+extern "C" int g2v_linear_compose2(const float* w0, const float* b0, const float* w1, const float* b1, const float* w_in,
+                                   const float* b_in, float* wc0, float* bc0, float* wc1, float* bc1, int G, int H, int D,
+                                   g2v_stream_t stream) {
+  G2V_REQUIRE(w0 && b0 && w1 && b1 && w_in && b_in && wc0 && bc0 && wc1 && bc1, "null pointer");
+  G2V_REQUIRE(G > 0 && H > 0 && D > 0 && (int64_t)G * (D + 1) < (int64_t)1 << 31, "bad size");
+  const int rows = D + 1 <= 256 ? 256 / (D + 1) : 0;
+  const size_t lds = sizeof(float) * ((size_t)H * (D + 1) + (size_t)rows * H);
+  const int staged = rows > 0 && lds <= 60 * 1024 ? 1 : 0;
+  hipLaunchKernelGGL(linear_compose2_kernel, dim3(staged ? cdiv(G, rows) : cdiv(G * (D + 1), 256), 2), dim3(256), staged ? lds : 0,
+                     (hipStream_t)stream, w0, b0, w1, b1, w_in, b_in, wc0, bc0, wc1, bc1, G, H, D, staged);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 // y_a = act(x w_a^T + b_a), y_b = act(x w_b^T + b_b): the two directions' input projections of a bidirectional GRU layer (ref
 // Autoencoder_VQVAE_model.py:94, nn.GRU(bidirectional=True): weight_ih_l0 / weight_ih_l0_reverse) read the same x.  At small row
 // counts (2560 rows: 400 workgroups per product, 16 us each, back to back) ONE launch with grid.z = 2 runs both; each workgroup's

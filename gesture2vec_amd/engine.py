@@ -205,6 +205,7 @@ class VQVAEEngine:
         # the cluster launches' exchange records cleared on branch 0 instead of in front of each launch (switches)
         self.xch_preclear = os.environ.get("G2V_XCH_PRECLEAR", "1") != "0"
         self._xch_pre = False
+        self.compose_in = True               # in_layer + GRU input projections on composed weights (forward_encoder; A/B only)
         self._branches_on = True
         self._sides: Dict[int, torch.cuda.Stream] = {}
         self._open: list = []
@@ -327,6 +328,14 @@ class VQVAEEngine:
     def _w(self, name):
         return self.view(name).data_ptr()
 
+    def _compose_in(self, b, rows: int, drop_in: bool) -> bool:
+        """generic dims: in_layer + GRU input projections on the composed weights (in_layer's output is then never formed: only where
+        backward_encoder re-associates the W_ih gradients through in_layer, its chain_ih).  Measured (r05_av / r05_aw logs): native
+        dims at B = 4096 6.40 -> 6.13 ms, GENEA 3.23 -> 3.16, native B = 128 0.997 -> 0.992; GENEA dims at B = 128 (no input
+        dropout: two row-mapped launches, D % 4 != 0) 0.597 -> 0.604, hence the last condition."""
+        return (self.compose_in and self.H != 64 and self.D < self.H and not self.wgrad_bf16x3 and b["enc_fused_wgrad"] == 0
+                and (rows >= 4096 or (drop_in and self.D % 4 == 0)))
+
     def _g(self, name):
         return self.view(name, True).data_ptr()
 
@@ -391,6 +400,7 @@ class VQVAEEngine:
             "gz": z(2, B, H),
             "dgi_f": z(T, B, G), "dgh_f": z(T, B, G), "dgi_b": z(T, B, G), "dgh_b": z(T, B, G),
             "dxin": z(T * B, H),
+            "wc_in": z(2, 3 * H, D), "bc_in": z(2, 3 * H),     # W_ih W_in and W_ih b_in + b_ih per direction (g2v_linear_compose2)
             "p_in": z(2, 3 * H, D), "c_in": z(2, 3 * H),       # dgi^T x and the column sums of dgi per direction (g2v_linear_bwd_weight_fold2)
         }
         sv = DecSaved()
@@ -630,8 +640,17 @@ class VQVAEEngine:
         early = side is not None and self.side_early
         if early:
             self._fork(0, side)
+        # Generic dims (D < H): in_layer and the GRU's input projections as ONE layer on the composed weights -- in_layer's output is
+        # never formed (its only other reader, the W_ih gradient, is re-associated through in_layer too: backward_encoder's chain_ih)
+        compose = self._compose_in(b, T * B, drop_in)
         # in_layer (:93)
-        if drop_in:
+        if compose:
+            wc, bc = b["wc_in"], b["bc_in"]
+            check(lib.g2v_linear_compose2(self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.bias_ih_l0"),
+                                          self._w(enc + "gru.weight_ih_l0_reverse"), self._w(enc + "gru.bias_ih_l0_reverse"),
+                                          self._w(enc + "in_layer.weight"), self._w(enc + "in_layer.bias"), wc[0].data_ptr(),
+                                          bc[0].data_ptr(), wc[1].data_ptr(), bc[1].data_ptr(), G, H, D, st))
+        elif drop_in:
             check(lib.g2v_linear_fwd(_p(b["x_drop"]), D, 0, 0, 0, None, 1.0, self._w(enc + "in_layer.weight"),
                                      self._w(enc + "in_layer.bias"), _p(b["xin"]), H, T * B, D, H, 0, st))
         else:
@@ -645,7 +664,15 @@ class VQVAEEngine:
         # H == 64: the input projections x W_ih^T + b_ih are fused into the recurrent kernel (no gi array at all);
         # other sizes compute gi with the dense-layer kernel first
         fuse_gi = (H == 64)
-        if not fuse_gi:
+        if compose:
+            if drop_in:
+                check(lib.g2v_linear_fwd_pair(_p(b["x_drop"]), D, wc[0].data_ptr(), bc[0].data_ptr(), _p(b["gi_f"]), wc[1].data_ptr(),
+                                              bc[1].data_ptr(), _p(b["gi_b"]), G, T * B, D, G, 0, st))
+            else:
+                for k, key in enumerate(("gi_f", "gi_b")):
+                    check(lib.g2v_linear_fwd(_p(in_poses), D, B, D, T * D, None, 1.0, wc[k].data_ptr(), bc[k].data_ptr(), _p(b[key]), G,
+                                             T * B, D, G, 0, st))
+        elif not fuse_gi:
             check(lib.g2v_linear_fwd_pair(_p(b["xin"]), H, self._w(enc + "gru.weight_ih_l0"), self._w(enc + "gru.bias_ih_l0"),
                                           _p(b["gi_f"]), self._w(enc + "gru.weight_ih_l0_reverse"),
                                           self._w(enc + "gru.bias_ih_l0_reverse"), _p(b["gi_b"]), G, T * B, H, G, 0, st))

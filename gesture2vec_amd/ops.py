@@ -76,6 +76,18 @@ def linear_fwd(x, w, bias=None, act=0, *, M=None, ldx=None, row_map=None, keep=N
     return out
 
 
+def linear_compose2(w0, b0, w1, b1, w_in, b_in):
+    """(w_p w_in, w_p b_in + b_p) for p = 0, 1 (g2v_linear_compose2): two linear layers in a row as one."""
+    G, H = w0.shape
+    D = w_in.shape[1]
+    dev = w0.device
+    wc = [torch.empty((G, D), dtype=torch.float32, device=dev) for _ in range(2)]
+    bc = [torch.empty((G,), dtype=torch.float32, device=dev) for _ in range(2)]
+    check(_lib_().g2v_linear_compose2(_p(_chk(w0, name="w0")), _p(b0), _p(_chk(w1, name="w1")), _p(b1), _p(_chk(w_in, name="w_in")),
+                                      _p(b_in), _p(wc[0]), _p(bc[0]), _p(wc[1]), _p(bc[1]), G, H, D, _stream()), "linear_compose2")
+    return wc[0], bc[0], wc[1], bc[1]
+
+
 def linear_fwd_pair(x, w_a, bias_a, w_b, bias_b, act=0, *, M=None):
     """(act(x w_a^T + b_a), act(x w_b^T + b_b)) in one launch where that pays (g2v_linear_fwd_pair)."""
     N, K = w_a.shape

@@ -68,6 +68,14 @@ int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_o
                    const float* w, const float* bias, float* y, int64_t ldy,
                    int M, int K, int N, int act, g2v_stream_t stream);
 
+/* Two linear layers in a row composed into one, for two second layers p = 0, 1 on the same first layer:
+ *     wc_p = w_p w_in ([G][D]),  bc_p = w_p b_in + b_p ([G])     (w_p: [G][H], w_in: [H][D])
+ * so that (x w_in^T + b_in) w_p^T + b_p = x wc_p^T + bc_p: EncoderRNN.in_layer :93 straight into the bidirectional nn.GRU's input
+ * projections :94 at the shipped dims (pose dim < hidden_size): D / H of the arithmetic, equal to the two-layer form to rounding.
+ * The caller then never forms the first layer's output (its gradients: g2v_linear_bwd_weight_fold2 / _chain2). */
+int g2v_linear_compose2(const float* w0, const float* b0, const float* w1, const float* b1, const float* w_in, const float* b_in,
+                        float* wc0, float* bc0, float* wc1, float* bc1, int G, int H, int D, g2v_stream_t stream);
+
 /* y_a = act(x w_a^T + bias_a), y_b = act(x w_b^T + bias_b) (plain rows, no mask; y_a / y_b share ldy): the input projections of
  * the two directions of a bidirectional nn.GRU layer (ref Autoencoder_VQVAE_model.py:94: weight_ih_l0 / weight_ih_l0_reverse on
  * the same input) in ONE launch where that pays (small row counts); results bitwise those of two g2v_linear_fwd calls. */

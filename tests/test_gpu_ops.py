@@ -1559,6 +1559,24 @@ def test_cluster_exchange_preclear_clears_cluster_shapes_only(ops):
         lib.g2v_gru_seq_set_cluster(prev)
 
 
+@pytest.mark.parametrize("G,H,D,M", [(600, 200, 40, 2560), (600, 200, 45, 1280), (36, 12, 5, 100)])
+def test_linear_compose2_equals_the_two_layers_in_a_row(ops, G, H, D, M):
+    """g2v_linear_compose2: (x W_in^T + b_in) W_p^T + b_p = x (W_p W_in)^T + (W_p b_in + b_p) -- the composed weights against
+    float64, and a projection with them against the two-layer form on the device (to rounding)."""
+    w = [rnd(G, H, seed=110 + p).to(DEV) * 0.2 for p in range(2)]
+    bp = [rnd(G, seed=112 + p).to(DEV) for p in range(2)]
+    w_in, b_in = rnd(H, D, seed=114).to(DEV) * 0.3, rnd(H, seed=115).to(DEV)
+    x = rnd(M, D, seed=116).to(DEV)
+    wc0, bc0, wc1, bc1 = ops.linear_compose2(w[0], bp[0], w[1], bp[1], w_in, b_in)
+    y = ops.linear_fwd(x, w_in, b_in)
+    for p, (wc, bc) in enumerate(((wc0, bc0), (wc1, bc1))):
+        relclose(wc, (w[p].double() @ w_in.double()).float(), 2e-6, f"composed weights {p}")
+        relclose(bc, (w[p].double() @ b_in.double() + bp[p].double()).float(), 2e-6, f"composed bias {p}")
+        relclose(ops.linear_fwd(x, wc, bc), ops.linear_fwd(y, w[p], bp[p]), 5e-6, f"projection {p}: composed vs two layers")
+    again = ops.linear_compose2(w[0], bp[0], w[1], bp[1], w_in, b_in)
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(again, (wc0, bc0, wc1, bc1))), "not deterministic"
+
+
 @pytest.mark.parametrize("M,K,N,act", [(2560, 200, 600, 0), (1280, 200, 600, 1), (2560, 64, 192, 0), (300, 50, 150, 2), (2560, 202, 600, 0)])
 def test_linear_fwd_pair_equals_two_calls(ops, M, K, N, act):
     """g2v_linear_fwd_pair (both directions' GRU input projections in one launch at small row counts) is BITWISE two
