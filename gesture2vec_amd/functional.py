@@ -70,6 +70,46 @@ def linear(x, weight, bias=None, keep=None, scale=1.0, act=0):
     return LinearFn.apply(x, weight, bias, keep, float(scale), int(act))
 
 
+class LinearPairFn(torch.autograd.Function):
+    """(x W_a^T + b_a, x W_b^T + b_b): the two directions' input projections of a bidirectional GRU layer on the same input, no
+    mask -- one launch forward where that pays (ops.linear_fwd_pair: bitwise two linear_fwd calls), the two weight gradients as
+    one batched launch, dx = g_a W_a + g_b W_b accumulated in place."""
+
+    @staticmethod
+    def forward(ctx, x, w_a, b_a, w_b, b_b):
+        N, K = w_a.shape
+        xs = x.contiguous().view(-1, K)
+        w_a, w_b = w_a.contiguous(), w_b.contiguous()
+        ya, yb = ops.linear_fwd_pair(xs, w_a, b_a, w_b, b_b)
+        ctx.save_for_backward(xs, w_a, w_b)
+        ctx.xshape = x.shape
+        ctx.set_materialize_grads(False)
+        return ya.view(*x.shape[:-1], N), yb.view(*x.shape[:-1], N)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        xs, w_a, w_b = ctx.saved_tensors
+        N, K = w_a.shape
+        dx, out, items = None, [], []
+        for g, w in ((ga, w_a), (gb, w_b)):
+            if g is None:
+                out += [None, None]
+                continue
+            g = g.contiguous().view(-1, N)
+            if ctx.needs_input_grad[0]:
+                if dx is None:
+                    dx = ops.linear_bwd_data(g, w)
+                else:
+                    ops.linear_bwd_data(g, w, out=dx, accumulate=True)
+            dw = torch.empty((N, K), dtype=torch.float32, device=xs.device)
+            db = torch.empty((N,), dtype=torch.float32, device=xs.device)
+            items.append((g, xs, dw, db))
+            out += [dw, db]
+        if items:
+            ops.linear_bwd_weight_batch(items, N, K, M=xs.shape[0])
+        return (dx.view(ctx.xshape) if dx is not None else None), out[0], out[1], out[2], out[3]
+
+
 class MseFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, target):

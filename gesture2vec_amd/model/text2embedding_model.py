@@ -107,6 +107,9 @@ class EncoderRNN(nn.Module):
             if l == 0 and via_table:
                 gis = list(Fn.EmbedProjectPairFn.apply(self.embedding.weight, ids_flat, g.weight_ih_l0, g.bias_ih_l0,
                                                        g.weight_ih_l0_reverse, g.bias_ih_l0_reverse))
+            elif keep is None:      # no mask on the layer's input: both directions' projections as one Function (one launch each way)
+                gis = list(Fn.LinearPairFn.apply(layer_in, getattr(g, f"weight_ih_l{l}"), getattr(g, f"bias_ih_l{l}"),
+                                                 getattr(g, f"weight_ih_l{l}_reverse"), getattr(g, f"bias_ih_l{l}_reverse")))
             else:
                 gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
                                  keep=keep, scale=scale) for suf in ("", "_reverse")]

@@ -651,3 +651,32 @@ def test_projecting_the_embedding_table_equals_projecting_the_gathered_rows(V, E
     assert rel(t1.grad.cpu(), d64) < 5e-6, ("d table vs float64", rel(t1.grad.cpu(), d64))
     dw64 = (oh.t() @ cot[0].cpu().double()).t() @ table0.double()
     assert rel(p1[0][0].grad.cpu(), dw64) < 5e-6, ("dW vs float64", rel(p1[0][0].grad.cpu(), dw64))
+
+
+@pytest.mark.parametrize("M,K,N", [(1536, 300, 600), (40, 20, 36), (5000, 400, 600)])
+def test_linear_pair_function_equals_two_linear_functions(M, K, N):
+    """Fn.LinearPairFn (both directions' input projections of a bidirectional layer as one autograd Function) against two
+    Fn.linear: outputs bitwise, the input gradient (the two directions' sum) and the weight / bias gradients to summation order."""
+    from gesture2vec_amd import functional as Fn
+    g = torch.Generator().manual_seed(9)
+    x0 = torch.randn(M, K, generator=g)
+    ws = [(torch.randn(N, K, generator=g) * 0.1, torch.randn(N, generator=g) * 0.1) for _ in range(2)]
+    cot = [torch.randn(M, N, generator=g).to(DEV) for _ in range(2)]
+
+    def leaves():
+        x = x0.clone().to(DEV).requires_grad_(True)
+        p = [(w.clone().to(DEV).requires_grad_(True), b.clone().to(DEV).requires_grad_(True)) for w, b in ws]
+        return x, p
+
+    x1, p1 = leaves()
+    ya, yb = Fn.LinearPairFn.apply(x1, p1[0][0], p1[0][1], p1[1][0], p1[1][1])
+    ((ya * cot[0]).sum() + (yb * cot[1]).sum()).backward()
+    x2, p2 = leaves()
+    ref = [Fn.linear(x2, w, b) for w, b in p2]
+    ((ref[0] * cot[0]).sum() + (ref[1] * cot[1]).sum()).backward()
+    assert torch.equal(ya, ref[0]) and torch.equal(yb, ref[1]), "outputs differ"
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    assert rel(x1.grad, x2.grad) < 5e-6, ("dx", rel(x1.grad, x2.grad))
+    for k in range(2):
+        assert rel(p1[k][0].grad, p2[k][0].grad) < 5e-6, (k, "dW", rel(p1[k][0].grad, p2[k][0].grad))
+        assert rel(p1[k][1].grad, p2[k][1].grad) < 5e-6, (k, "db", rel(p1[k][1].grad, p2[k][1].grad))
