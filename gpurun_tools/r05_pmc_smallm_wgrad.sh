@@ -24,7 +24,7 @@ for d in sorted(glob.glob("gpurun_out/pmcw_*")):
             if "gemm_tn_smallm_lds_kernel" in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for c, v in acc.items():
-            res["gemm_tn_smallm_lds_kernel<2,2> 4 x (2560 x 600)^T (2560 x 200)"][c] = round(sum(v) / len(v), 1)
+            res["gemm_tn_smallm_lds_kernel<2,1,4> 4 x (2560 x 600)^T (2560 x 200)"][c] = round(sum(v) / len(v), 1)
 json.dump(res, open("gpurun_out/r05_pmc_smallm_wgrad.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 P
