@@ -2660,6 +2660,7 @@ static int dec_rollout_fwd_impl(const float* target, const float* h_init, const 
     if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) == hipSuccess;
     cluster = attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, dyn) == hipSuccess && nocc >= 1;
   }
+  if (!cluster) g2v_internal_preclear_drop(workspace, workspace_bytes);      // (a pre-cleared note for this workspace is void)
   if (maybe_cluster && !cluster) {      // (the cluster path was declined after all: the per-step kernels need the packed weights)
     launch_pack(pb, st);
     G2V_CHECK_LAUNCH();
@@ -2951,6 +2952,7 @@ static int dec_rollout_bwd_impl(const g2v_dec_weights* w, const g2v_dec_saved* s
       if (!attr_set) attr_set = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dec_cluster_bwd_dyn_lds()) == hipSuccess;
       cluster = attr_set && hipOccupancyMaxActiveBlocksPerMultiprocessor(&nocc, fn, 256, dec_cluster_bwd_dyn_lds()) == hipSuccess && nocc >= 1;
     }
+    if (!cluster) g2v_internal_preclear_drop(workspace, workspace_bytes);
     if (cluster) {
       // ONE persistent launch for the whole BPTT (dec_cluster_bwd_kernel): weights read in place, no transposes
       const size_t Hp = (size_t)((H + 15) & ~15);
