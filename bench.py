@@ -172,12 +172,22 @@ def cpu_baseline(B_main: int):
                     "(explicit per-step formulas, a Python loop over time); reported baselines, not targets"}
 
 
+def _profile_order(path: str):
+    """sort key of a committed profile `rNN_<tag>_...`: round number, then the tag in the order the tags were handed out
+    (a..z, aa..az, ba.. -- shorter first, then alphabetical), so `r05_ba` is newer than `r05_az` is newer than `r05_z`"""
+    import re
+    m = re.match(r"r(\d+)_([a-z]+)_", os.path.basename(path))
+    if not m:
+        return (-1, 0, "")
+    return (int(m.group(1)), len(m.group(2)), m.group(2))
+
+
 def pmc_traffic(kernel: str, N: int):
     """HBM bytes per launch of `kernel` at N rows, from the committed PMC summaries (separate rocprofv3 --pmc passes,
     FETCH_SIZE doubled per the gfx950 correction): profiles/*pmc_traffic.json, newest round first.  None when no
     summary holds this kernel at this size -- never a stale literal."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), key=_profile_order, reverse=True):
         try:
             with open(path) as f:
                 d = json.load(f)
@@ -194,7 +204,7 @@ def in_graph_us(kernel: str):
     rocprofv3 --kernel-trace of this command): there the kernel starts while the branch beside the encoder still holds CUs"""
     import glob
     import re
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_timeline.txt")), reverse=True):
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_step_timeline.txt")), key=_profile_order, reverse=True):
         try:
             for line in open(path):
                 m = re.match(r"\s*[-0-9.]+ dur\s+([0-9.]+) gap", line)
@@ -314,7 +324,10 @@ def part_d(with_cpu: bool):
             ids, lengths, codes = data[0].to("cuda:0"), data[1], data[6].to("cuda:0")
             if att == "False" and B == 128:
                 keep = ({k: v.detach().cpu().clone() for k, v in net.state_dict().items()}, data[0].clone(), data[1].clone(), data[6].clone())
+            from gesture2vec_amd import rollout_t2e as RT
+            calls0 = (RT.FUSED_CALLS, RT.CLUSTER_CALLS)
             g = GraphedText2EmbeddingStep(args, net, opt, ids, lengths, codes)
+            served = (RT.FUSED_CALLS - calls0[0], RT.CLUSTER_CALLS - calls0[1])      # which route the captured step took (counted, not assumed)
             for _ in range(3):
                 g.replay()
             torch.cuda.synchronize()
@@ -338,8 +351,9 @@ def part_d(with_cpu: bool):
             res["runs"].append({"att": att_b, "B": B, "ms_per_step": round(dt / n * 1e3, 4), "samples_per_s": round(B * n / dt, 1),
                                 "loss": round(float(g.loss), 4), "flops_executed": fl, "achieved_TFLOPs": round(tf, 2),
                                 "frac_of_f32_mfma_peak": round(tf / PEAK_F32_MFMA_TFLOPS, 4),
-                                "decoder_steps": ("fused per-step kernels (g2v_attn_code_rollout_fwd / _bwd)"
-                                                  if B >= 1024 else "column-split per-operator kernels (B < 1024)")})
+                                "decoder_steps": ("persistent cluster launches (code_cluster_fwd_kernel / code_cluster_bptt_kernel)" if served[1]
+                                                  else "fused per-step kernels (g2v_attn_code_rollout_fwd / _bwd)" if served[0]
+                                                  else "column-split per-operator kernels")})
             del g, net, opt
     if with_cpu and keep is not None:
         try:
