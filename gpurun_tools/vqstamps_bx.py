@@ -1,10 +1,11 @@
-"""Diagnostic only: shader-clock stamps of the bf16-screened fused VQ kernel (N=4096, E=128, K=512); needs the stamps build
-gpurun_tools/libg2v_vqstamps.so (hipcc -DG2V_VQSTAMPS of the library sources)."""
+"""Diagnostic only: shader-clock stamps of the bf16-screened fused VQ kernel (N=4096, E=128, K=512); needs a stamps build of the
+library (hipcc -DG2V_VQSTAMPS of the sources): argv[1] = flags (default 0), argv[2] = library path (default
+gpurun_tools/libg2v_vqstamps.so)."""
 import ctypes, sys, os
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, root)
 from gesture2vec_amd import _lib
-_lib.LIB_PATH = os.path.join(root, "gpurun_tools", "libg2v_vqstamps.so")
+_lib.LIB_PATH = os.path.abspath(sys.argv[2]) if len(sys.argv) > 2 else os.path.join(root, "gpurun_tools", "libg2v_vqstamps.so")
 import torch
 from gesture2vec_amd import ops
 lib = _lib.load()
@@ -21,9 +22,15 @@ torch.cuda.synchronize()
 raw = ctypes.CDLL(_lib.LIB_PATH)
 buf = (ctypes.c_ulonglong * 128)()
 raw.g2v_read_vqstamps(buf)
-names = ["z staged", "projection + sweep", "scan", "exact chains || decided rows, then the rest", "sync", "sse"]
-print("flags", flags)
+# stamp ids in program order (thread 0 of wave 0; the same ids + 16 from thread 256 = wave 4 where that wave stamps)
+order = [(0, "start"), (1, "z staged | barrier"), (7, "projection done"), (8, "sweep done"), (2, "barrier"), (9, "scan done"),
+         (3, "barrier"), (10, "chains / decided rows done"), (11, "barrier"), (4, "rest finished"), (5, "syncthreads"), (6, "sse written")]
+print("lib", os.path.basename(_lib.LIB_PATH), "flags", flags)
 for b in range(4):
     st = [buf[b * 32 + k] for k in range(32)]
-    print("slot", b, [st[k + 1] - st[k] for k in range(6)], "total", st[6] - st[0])
-print(names)
+    t0 = st[0]
+    w0 = " ".join(f"{name}={st[k] - t0}" for k, name in order if st[k])
+    w4 = " ".join(f"[{k}]={st[16 + k] - t0}" for k in (7, 8, 9, 10) if st[16 + k])
+    fine = " ".join(f"{name}={st[k] - t0}" for k, name in ((12, "scan:threshold"), (13, "scan:compared"), (14, "scan:slot returned"), (15, "scan:listed"),
+                                                          (16, "chains:listed rows in LDS / start"), (17, "chains:dot product done")) if st[k])
+    print(f"slot {b}: wave0: {w0}\n         wave4: {w4}\n         fine:  {fine}")

@@ -203,6 +203,9 @@ def _engine_from_state(sd, D, H, K, T, p, beta=0.25):
 
 
 @pytest.mark.parametrize("B,T,D,H,K,p", [(256, 34, 135, 64, 512, 0.0), (48, 20, 40, 200, 512, 0.2), (37, 10, 45, 200, 400, 0.0),
+                                         (128, 20, 40, 200, 512, 0.2),   # config/VQ-VAE.yml AS SHIPPED (the cluster kernels at their own batch size:
+                                                                         # the shape bench.py's `shipped_config` times)
+                                         (128, 10, 45, 200, 400, 0.0),   # config/VQ-VAE_GENEA.yml dims at the reference's batch size
                                          (1040, 4, 40, 48, 64, 0.1),     # generic dims ABOVE the small-batch split thresholds
                                          (4096, 34, 135, 64, 512, 0.0),  # BASELINE configs[1] = the shape bench.py times
                                          (4096, 34, 135, 64, 512, 0.2),  # ... and with the yml's dropout_prob
