@@ -172,6 +172,7 @@ _SIGS = {
     "g2v_embedding_bwd_ws_bytes": (c_sz, [c_i64, c_int, c_i64]),
     "g2v_embedding_bwd": (c_int, [c_fp, c_fp, c_fp, c_f, c_fp, c_i64, c_int, c_i64, c_int, c_fp, c_sz, c_fp]),
     "g2v_batchnorm_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_bn_running_update_invstd": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_batchnorm_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_cross_entropy_fwd_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_f, c_fp]),
     "g2v_argmax_rows": (c_int, [c_fp, c_i64, c_fp, c_int, c_int, c_fp]),

@@ -372,7 +372,7 @@ __global__ __launch_bounds__(256) void bn_fwd_kernel(const float* __restrict__ x
     if (rl == 0 && fv) {
       const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
       // (the persistent kernels' fault latch: a faulted encoder launch in front of this step must not reach the model state)
-      if (fault == nullptr || *fault == 0u) {
+      if (rm && (fault == nullptr || *fault == 0u)) {      // (rm == NULL: the caller commits later, g2v_bn_running_update_invstd)
         rm[f] = 0.9f * rm[f] + 0.1f * mean;                             // momentum 0.1, unbiased variance
         rv[f] = 0.9f * rv[f] + 0.1f * unb;
       }
@@ -764,10 +764,45 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
 extern "C" int g2v_batchnorm_fwd(const float* x, const float* weight, const float* bias, float* running_mean,
                                  float* running_var, int training, int relu, float* y, float* save_mean,
                                  float* save_invstd, int B, int H, g2v_stream_t stream) {
-  G2V_REQUIRE(x && weight && bias && running_mean && running_var && y, "null pointer");
+  G2V_REQUIRE(x && weight && bias && y, "null pointer");
+  G2V_REQUIRE((running_mean == nullptr) == (running_var == nullptr) && (training || running_mean),
+              "running statistics: both, or (training only) neither");
   G2V_REQUIRE(B > 0 && H > 0, "bad size");
   hipLaunchKernelGGL(bn_fwd_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, x, weight, bias, running_mean,
                      running_var, training, relu, y, save_mean, save_invstd, B, H, g2v_internal_persist_fault_ptr());
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// Deferred commit of the running statistics from the SAVED (mean, 1/sqrt(var + eps)) of `steps` training calls, in call order
+// (momentum 0.1, unbiased variance): Part d's decoder applies its one BatchNorm1d S-1 times per iteration, and a persistent-kernel
+// fault latched AFTER a step's forward (a later decode step, the cells' BPTT, the encoder's backward) must leave the model state
+// as it was (round-5 advisor finding).  var = 1 / invstd^2 - eps, clamped at 0 (relative error <= 3e-7 (var + eps) / var).
+__global__ void bn_running_update_invstd_kernel(const float* __restrict__ mean, const float* __restrict__ invstd, int64_t stride,
+                                                float* __restrict__ rm, float* __restrict__ rv, int steps, int H, int B,
+                                                const unsigned* __restrict__ fault) {
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= H) return;
+  if (fault && *fault != 0u) return;
+  float m = rm[f], v = rv[f];
+  const float unbias = (B > 1) ? (float)B / (float)(B - 1) : 1.0f;
+  for (int s = 0; s < steps; ++s) {
+    const float is = invstd[s * stride + f];
+    const float var = fmaxf(1.0f / (is * is) - 1e-5f, 0.f);
+    m = 0.9f * m + 0.1f * mean[s * stride + f];
+    v = 0.9f * v + 0.1f * (var * unbias);
+  }
+  rm[f] = m;
+  rv[f] = v;
+}
+
+extern "C" int g2v_bn_running_update_invstd(const float* save_mean, const float* save_invstd, int64_t step_stride,
+                                            float* running_mean, float* running_var, int steps, int H, int B,
+                                            g2v_stream_t stream) {
+  G2V_REQUIRE(save_mean && save_invstd && running_mean && running_var, "null pointer");
+  G2V_REQUIRE(steps > 0 && H > 0 && B > 0 && step_stride >= H, "bad size");
+  hipLaunchKernelGGL(bn_running_update_invstd_kernel, dim3(cdiv(H, 256)), dim3(256), 0, (hipStream_t)stream, save_mean, save_invstd,
+                     step_stride, running_mean, running_var, steps, H, B, g2v_internal_persist_fault_ptr());
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

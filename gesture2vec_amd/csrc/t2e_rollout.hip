@@ -169,9 +169,12 @@ __global__ __launch_bounds__(CT_NTHR) void code_step_fwd_kernel(const int64_t* _
           sv.bn_stats[(int64_t)t * 2 * H + f] = mean;
           sv.bn_stats[(int64_t)t * 2 * H + H + f] = invstd;
           // running statistics: momentum 0.1, unbiased variance; one update per decode step, in step order (stream order)
-          const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
-          w.bn_running_mean[f] = 0.9f * w.bn_running_mean[f] + 0.1f * mean;
-          w.bn_running_var[f] = 0.9f * w.bn_running_var[f] + 0.1f * unb;
+          // (bn_running_mean == NULL while training: the caller commits them behind the backward, g2v_bn_running_update_invstd)
+          if (w.bn_running_mean) {
+            const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
+            w.bn_running_mean[f] = 0.9f * w.bn_running_mean[f] + 0.1f * mean;
+            w.bn_running_var[f] = 0.9f * w.bn_running_var[f] + 0.1f * unb;
+          }
         }
       }
     } else {
@@ -1099,7 +1102,8 @@ __global__ __launch_bounds__(256) void code_cluster_fwd_kernel(CodeClArgs a) {
             sv.bn_stats[(int64_t)t * 2 * H + f] = mean;
             sv.bn_stats[(int64_t)t * 2 * H + H + f] = invstd;
             // running statistics: momentum 0.1, unbiased variance; one update per decode step, in step order; not behind a latched fault
-            if (a.fault == nullptr || __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            // (bn_running_mean == NULL while training: the caller commits them behind the backward, g2v_bn_running_update_invstd)
+            if (w.bn_running_mean && (a.fault == nullptr || __hip_atomic_load(a.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u)) {
               const float unb = (B > 1) ? var * (float)B / (float)(B - 1) : var;
               w.bn_running_mean[f] = 0.9f * w.bn_running_mean[f] + 0.1f * mean;
               w.bn_running_var[f] = 0.9f * w.bn_running_var[f] + 0.1f * unb;
@@ -1733,7 +1737,9 @@ extern "C" int g2v_attn_code_rollout_fwd(const int64_t* codes, const float* h_in
                                          int K, int Tw, void* workspace, size_t workspace_bytes, g2v_stream_t stream) {
   G2V_REQUIRE(codes && h_init && w && s && workspace, "null pointer");
   const int att = w->w_attn != nullptr;
-  G2V_REQUIRE(w->emb && w->w_pre && w->b_pre && w->bn_w && w->bn_b && w->bn_running_mean && w->bn_running_var && w->w_ih0 &&
+  G2V_REQUIRE((training ? (w->bn_running_mean == nullptr) == (w->bn_running_var == nullptr) : (w->bn_running_mean && w->bn_running_var)),
+              "BatchNorm running statistics: both or (training only) neither");
+  G2V_REQUIRE(w->emb && w->w_pre && w->b_pre && w->bn_w && w->bn_b && w->w_ih0 &&
               w->w_hh0 && w->b_ih0 && w->b_hh0 && w->w_ih1 && w->w_hh1 && w->b_ih1 && w->b_hh1 && w->w_out && w->b_out,
               "missing weight");
   G2V_REQUIRE(!att || (w->b_attn && w->v_attn && enc && enc_proj && s->hp && s->attw), "attention: missing array");

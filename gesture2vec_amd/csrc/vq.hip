@@ -32,23 +32,9 @@ extern "C" int g2v_read_vqstamps(unsigned long long* out) {
     const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
     if (threadIdx.x == 256 && sb_ >= 0) g2v_vqstamps[sb_ * 32 + 16 + (k)] = __builtin_amdgcn_s_memtime();                  \
   } while (0)
-// VSTAMP_ANY: by the first ACTIVE lane of wave 0 (inside divergent code);  VSTAMP_C: thread 0 into the free slots 16 .. 22
-#define VSTAMP_ANY(k)                                                                                                    \
-  do {                                                                                                                   \
-    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
-    if (threadIdx.x < 64 && sb_ >= 0 && (int)(threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1)                   \
-      g2v_vqstamps[sb_ * 32 + (k)] = __builtin_amdgcn_s_memtime();                                                        \
-  } while (0)
-#define VSTAMP_C(k)                                                                                                      \
-  do {                                                                                                                   \
-    const int sb_ = blockIdx.x == 0 ? 0 : (blockIdx.x == 5 ? 1 : (blockIdx.x == 128 ? 2 : (blockIdx.x == 255 ? 3 : -1))); \
-    if (threadIdx.x == 0 && sb_ >= 0) g2v_vqstamps[sb_ * 32 + 16 + (k)] = __builtin_amdgcn_s_memtime();                  \
-  } while (0)
 #else
 #define VSTAMP(k)
 #define VSTAMP_B(k)
-#define VSTAMP_ANY(k)
-#define VSTAMP_C(k)
 #endif
 
 namespace g2v {
@@ -1586,8 +1572,6 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 // row's threshold.  The candidates get the fp32 kernel's own arithmetic: flat, idx and quantized are bitwise
 // vq_fused_assign_kernel's.  A tile with a non-finite screening value or more than BXF_MAXP candidates takes the exact fp32
 // sweep over all K codes instead (exact_only != 0 forces it: the A/B reference).
-constexpr int BXF_WCAP = 16;      // (row, candidate) pairs ONE WAVE re-evaluates (G2V_BX_VARIANT bit 3)
-constexpr int BXF_MAXC = 48;       // ... of which the code rows fit the LDS staging area (G2V_BX_VARIANT bit 5)
 constexpr int BXF_MAXP = 128;      // (row, candidate) pairs re-evaluated per tile: 8 waves x one 16-pair MFMA tile
 constexpr int BXF_LDH = 128 + 8;   // bf16 elements per LDS row of the hi / lo images: 272 B, conflict-free ds_read_b128 per 16 lanes
 constexpr int BXF_LDE = 512 + 4;   // floats per LDS row of the screening values
@@ -1615,16 +1599,6 @@ struct BxfScalars { float wpf2, bb, pad0, pad1; };      // |W_pre|_F^2, |b|^2 (b
 //     LDS atomicMin on (distance, index) keys -- 1.4 k cycles whatever the number of pairs, where a 16 x 16 x 128 MFMA tile per 16
 //     pairs cost a gather round trip plus a 32-deep dependent MFMA chain behind yet another barrier
 //   | gather + straight-through + SSE.
-// Build-time variants of the body (A/B builds of gpurun_tools/r06_bx_variants.sh; the product build leaves the default):
-//   bit 0  every wave requests its code tiles of the U image in FRONT of the staging barrier (all requests of the launch up front)
-//   bit 4  a workgroup barrier right behind the raw tile's request (all eight tile requests in front of every operand request)
-//   bit 3  per-wave exact chains: no pair list, no barrier between scan and chains, no early finish of decided rows
-//   bit 2  the fp32 codebook pulled into the XCD's L2 at kernel start
-//   bit 1  the candidate scan FOLDED into the sweep: a lane keeps the lower bounds of its own (row, code) values in registers and
-//          compares them with the row's threshold behind the barrier -- no 16 x K array of screening values in LDS
-#ifndef G2V_BX_VARIANT
-#define G2V_BX_VARIANT 0
-#endif
 template <bool EXACT_ONLY>
 __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, const float* __restrict__ Wpf,
                                                  const float* __restrict__ bp, const float* __restrict__ W,
@@ -1655,7 +1629,6 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
   __shared__ int rowcnt[16];
   __shared__ int rowcode[16];
   __shared__ int s_exact, s_np;
-  __shared__ __attribute__((aligned(16))) float Wc[(G2V_BX_VARIANT & 32) ? BXF_MAXC * (128 + 4) : 4];    // COOP_ROWS: the pairs' code rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * VQ_ROWS;
@@ -1667,14 +1640,6 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
   // ---- every request of the first half, in consumption order ----------------------------------------------------------------------
   const int zrow = tid >> 5, zpart = tid & 31;
   const float4 zv = *reinterpret_cast<const float4*>(z + (int64_t)(r0 + (zrow < nrows ? zrow : 0)) * E + 4 * zpart);
-  // bit 4: the hardware lets the OLDEST wave issue its whole run of requests before the next wave issues its first, so wave 7's
-  // rows of the raw tile -- which everything waits for -- used to sit behind 70 KB of the other waves' operand requests: a
-  // workgroup barrier right behind the tile request puts all eight tile requests at the head of the CU's memory pipeline
-  if ((G2V_BX_VARIANT & 16) != 0) {
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-  }
   float4 wp[KS];
 #pragma unroll
   for (int s = 0; s < KS; ++s) wp[s] = *reinterpret_cast<const float4*>(Wpf + ((int64_t)(wave * KS + s) * 64 + lane) * 4);
@@ -1696,28 +1661,6 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
       pq[p] = *reinterpret_cast<const uint4*>(pqk + 16 * ktc + 4 * q);
     }
   };
-  constexpr bool REQ_FRONT = (G2V_BX_VARIANT & 1) != 0, FOLD_SCAN = (G2V_BX_VARIANT & (2 | 8)) != 0, W_TO_L2 = (G2V_BX_VARIANT & 4) != 0;
-  constexpr bool WAVE_CHAINS = (G2V_BX_VARIANT & 8) != 0;            // implies the folded scan
-  constexpr bool COOP_ROWS = (G2V_BX_VARIANT & 32) != 0;             // the candidates' code rows: coalesced loads -> LDS, no touches
-  if (REQ_FRONT) request_u();
-  // The fp32 codebook rows that the exact chains and the gather read are NOT part of the request stream above: a kernel starts
-  // with its XCD's L2 invalidated, so the first touch of a row (the scan, 8 k cycles into the kernel, every CU of the XCD at about
-  // the same time) goes all the way to the memory side.  The workgroups of an XCD (blockIdx % 8, round robin) pull the K rows into
-  // their L2 together, now: wave 7's lane l touches line 64 (blockIdx / 8 mod 32) + l of the 4 K lines; wave 6 the norms' lines.
-  float pw0 = 0.f;
-  if (W_TO_L2) {
-    const int nline = K * (E * 4 / 128);                        // 128-byte lines of the codebook
-    const int line = (((int)blockIdx.x >> 3) & 31) * 64 + lane;
-    if (wave == 7) {
-      for (int l = line; l < nline; l += 2048) {
-        const float* pl = W + (int64_t)l * 32;
-        asm volatile("global_load_dword %0, %1, off" : "=&v"(pw0) : "v"(pl) : "memory");
-      }
-    } else if (wave == 6 && lane * 32 < K) {
-      const float* pl = wsq + lane * 32;
-      asm volatile("global_load_dword %0, %1, off" : "=&v"(pw0) : "v"(pl) : "memory");
-    }
-  }
   __builtin_amdgcn_sched_barrier(0);
   if (tid < 16) {
     rowbest[tid] = ~0ull;
@@ -1757,7 +1700,7 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
   // A wave that is issuing requests into the saturated memory pipeline (~130 cycles each) cannot issue MFMAs meanwhile, and a
   // wave inside the projection's dependent MFMA chain issues nothing else: the two waves of a SIMD (w, w + 4) take turns --
   // waves 0-3 request their code tiles first and project afterwards, waves 4-7 project first and request afterwards.
-  if (!REQ_FRONT && wave < 4) {
+  if (wave < 4) {
     request_u();
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1778,16 +1721,11 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
   }
   VSTAMP(7);
   VSTAMP_B(7);
-  if (!REQ_FRONT && wave >= 4) {
+  if (wave >= 4) {
     __builtin_amdgcn_sched_barrier(0);
     request_u();
     __builtin_amdgcn_sched_barrier(0);
   }
-  float lov[NT][4];       // FOLD_SCAN: lower bounds e_k - r_k of this lane's (row i, code 16 kt + 4 q + r) values; inf = no such code
-#pragma unroll
-  for (int p = 0; p < NT; ++p)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) lov[p][r] = INFINITY;
   {  // ---- screening sweep on the bf16 pipe, in z-space ---------------------------------------------------------------------------
     bf16x8 zh[KB], zl[KB];
 #pragma unroll
@@ -1818,12 +1756,7 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
           emin = fminf(emin, ev_[r] + rk);
           esum += ev_[r];                                  // NaN / inf anywhere poisons the sum
         }
-        if (FOLD_SCAN) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) lov[p][r] = lo[r];
-        } else {
-          *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = make_float4(lo[0], lo[1], lo[2], lo[3]);
-        }
+        *reinterpret_cast<float4*>(Es + i * BXF_LDE + 16 * kt + 4 * q) = make_float4(lo[0], lo[1], lo[2], lo[3]);
       }
     }
     emin = fminf(emin, __shfl_xor(emin, 16));
@@ -1836,23 +1769,52 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
   lds_barrier();
   VSTAMP(2);
   float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f;
-  // one candidate of the list: its slot, and the touch of its code's four cache lines -- the exact chain (another thread, behind
-  // the barrier) then reads them from L1 instead of paying an L2 round trip.  Fire and forget: the values are never used, the
-  // registers are pinned at the end of the kernel.  Returns false once the list is full (the tile takes the exact sweep).
-  auto list_candidate = [&](int& slot, int row, int code) -> bool {
-    if (slot < BXF_MAXP) {
-      p_row[slot] = row;
-      p_code[slot] = code;
+  {  // candidate scan by all 512 threads: thread -> row tid >> 5, 16 of its codes
+    const int row = tid >> 5, c0 = 4 * (tid & 31);          // codes c0 + 128 g + (0..3): a wave-level read is 2 x 512 contiguous bytes
+    float4 e[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) e[g] = 128 * g < K ? *reinterpret_cast<const float4*>(Es + row * BXF_LDE + c0 + 128 * g) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
+    float m = wmin[row];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + row]);
+    const float th = m + marg[row];
+    if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
+    if (tid < 16) xx[tid] = sum8_partials(xxp, tid);
+    const float ev[16] = {e[0].x, e[0].y, e[0].z, e[0].w, e[1].x, e[1].y, e[1].z, e[1].w,
+                          e[2].x, e[2].y, e[2].z, e[2].w, e[3].x, e[3].y, e[3].z, e[3].w};
+    unsigned cm = 0;                      // candidate bits of this thread's 16 codes: branch-free, ONE conditional block per wave
+#pragma unroll
+    for (int c = 0; c < 16; ++c) cm |= (ev[c] <= th) ? (1u << c) : 0u;
+    if (cm) {                             // about 1.4 threads per row get here
+      const int n = __popc(cm);
+      int slot = atomicAdd(&s_np, n);
+      atomicAdd(&rowcnt[row], n);
+      rowcode[row] = c0 + 128 * ((__ffs(cm) - 1) >> 2) + ((__ffs(cm) - 1) & 3);      // THE code of a row that ends with one candidate
+      while (cm) {
+        const int c = __ffs(cm) - 1;
+        cm &= cm - 1;
+        const int code = c0 + 128 * (c >> 2) + (c & 3);
+        if (slot < BXF_MAXP) {
+          p_row[slot] = row;
+          p_code[slot] = code;
+        }
+        ++slot;
+        if (slot > BXF_MAXP) break;       // the list is full: this tile takes the exact sweep, nothing more to list or to touch
+        // touch the code's four cache lines now: the exact chain (another thread, behind the barrier) then reads them from L1
+        // instead of paying an L2 round trip.  Fire and forget: the values are never used, the registers are pinned below.
+        const float* wr = W + (int64_t)code * E;
+        asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:128\n\t"
+                     "global_load_dword %2, %4, off offset:256\n\tglobal_load_dword %3, %4, off offset:384"
+                     : "=&v"(pf0), "=&v"(pf1), "=&v"(pf2), "=&v"(pf3) : "v"(wr) : "memory");
+      }
     }
-    ++slot;
-    if (slot > BXF_MAXP) return false;
-    if (COOP_ROWS) return true;
-    const float* wr = W + (int64_t)code * E;
-    asm volatile("global_load_dword %0, %4, off\n\tglobal_load_dword %1, %4, off offset:128\n\t"
-                 "global_load_dword %2, %4, off offset:256\n\tglobal_load_dword %3, %4, off offset:384"
-                 : "=&v"(pf0), "=&v"(pf1), "=&v"(pf2), "=&v"(pf3) : "v"(wr) : "memory");
-    return true;
-  };
+  }
+  VSTAMP(9);
+  VSTAMP_B(9);
+  lds_barrier();
+  VSTAMP(3);
+  const int P = s_np;
+  bool exact = (s_exact != 0) || P > BXF_MAXP;
   // gather + straight-through + SSE on raw z (:1285-1292) of one row by its 16 threads; the row's SSE goes to rowsse
   auto finish_row = [&](int row, int part, int code) {
     const float* wq_ = W + (int64_t)code * E;
@@ -1873,161 +1835,33 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
     }
   };
   const int frow = (tid & 255) >> 4, fpart = tid & 15;
-  // the fp32 kernel's distance of ONE (projected row, code) pair by the calling thread: its dot product as the 128-long fmaf chain
-  // in the MFMA's k order (s, component, q ascending: measured bitwise equal to the v_mfma_f32_16x16x4_f32 chain,
-  // gpurun_tools/mfma_chain_test.hip), then the row's running minimum of (distance, index) keys = torch.argmin's tie rule
-  auto exact_pair = [&](int row, int code, float xxr, const float* wr) {
-    const float* xr_ = Xf + row * ldx;
-    float4 wv[E / 4];
-#pragma unroll
-    for (int t = 0; t < E / 4; ++t) wv[t] = *reinterpret_cast<const float4*>(wr + 4 * t);
-    const float sq = wsq[code];
-    float a = 0.f;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) {
-      float4 xv[4];
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) xv[qq] = *reinterpret_cast<const float4*>(xr_ + 16 * s + 4 * qq);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].x, xv[qq].x, a);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].y, xv[qq].y, a);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].z, xv[qq].z, a);
-#pragma unroll
-      for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].w, xv[qq].w, a);
-    }
-    VSTAMP_C(1);
-    const float d = (xxr + sq) - 2.0f * a;
-    if (!(fabsf(d) < INFINITY)) s_exact = 1;              // a non-finite exact value: the exact sweep decides (NaN rules)
-    atomicMin(&rowbest[row], bxf_key(d, code));
-  };
-  int P = 0;
-  bool exact;
-  if (WAVE_CHAINS) {
-    // ---- no list, no second barrier: every wave re-evaluates the candidates among ITS OWN screening values --------------------------
-    // (round 6: the list form spent 1.9 k cycles in the scan, a barrier, 2.6 k in one wave's chains behind the touches' L1 fills,
-    // another barrier and a second gather for the rows with several candidates: profiles/r06_a_vqbx_stamps.log)
-    const int orow = tid >> 5, ocol = 4 * (tid & 31);
-    const float4 fo = *reinterpret_cast<const float4*>(Xf + orow * ldx + ocol);       // the projected rows go to global below
-    float m = wmin[i];
-#pragma unroll
-    for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + i]);
-    const float th = m + marg[i];
-    if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
-    // the wave's candidates, enumerated on the scalar unit from one ballot per (tile, component) and dealt to lanes 0, 1, 2, ...:
-    // ANY lane can run a pair's chain (the projected row comes from LDS, the code's row from L2), so a lane never owns two
-    int mine = 0, n = 0;
-#pragma unroll
-    for (int p = 0; p < NT; ++p) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        unsigned long long mk = __ballot(lov[p][r] <= th);
-        while (mk) {
-          const int L = __ffsll((long long)mk) - 1;
-          mk &= mk - 1;
-          const int cand = ((L & 15) << 16) | (16 * (kt0 + 4 * p) + 4 * (L >> 4) + r);
-          mine = lane == n ? cand : mine;
-          ++n;
-        }
-      }
-    }
-    if (n > BXF_WCAP) {
-      if (lane == 0) s_exact = 1;                 // more candidates than a wave re-evaluates: the tile takes the exact sweep
-    } else if (!EXACT_ONLY && lane < n) {
-      exact_pair(mine >> 16, mine & 0xffff, sum8_partials(xxp, mine >> 16), W + (int64_t)(mine & 0xffff) * E);
-    }
-    if (lane == 0 && n) atomicAdd(&s_np, n);      // (diagnostics only)
-    if (orow < nrows) *reinterpret_cast<float4*>(flat_out + (int64_t)(r0 + orow) * E + ocol) = fo;
-    VSTAMP(10);
-    VSTAMP_B(10);
-    lds_barrier();
-    VSTAMP(11);
-    P = s_np;
-    exact = s_exact != 0;
-    if (!exact && tid < 256 && frow < nrows) finish_row(frow, fpart, (int)(unsigned)(rowbest[frow] & 0xffffffffull));
-  } else {
-    if (FOLD_SCAN) {
-      // ---- candidates among the lane's own values: row i, codes 16 (kt0 + 4 p) + 4 q + r ------------------------------------------
-      float m = wmin[i];
-#pragma unroll
-      for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + i]);
-      const float th = m + marg[i];
-      if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
-      VSTAMP(12);
-      if (tid < 16) xx[tid] = sum8_partials(xxp, tid);
-      unsigned cm = 0;
-#pragma unroll
-      for (int p = 0; p < NT; ++p)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cm |= (lov[p][r] <= th) ? (1u << (4 * p + r)) : 0u;
-      VSTAMP(13);
-      if (cm) {
-        const int n = __popc(cm);
-        int slot = atomicAdd(&s_np, n);
-        VSTAMP_ANY(14);
-        atomicAdd(&rowcnt[i], n);
-        const int c1 = __ffs(cm) - 1;
-        rowcode[i] = 16 * (kt0 + 4 * (c1 >> 2)) + 4 * q + (c1 & 3);       // THE code of a row that ends with one candidate
-        while (cm) {
-          const int c = __ffs(cm) - 1;
-          cm &= cm - 1;
-          if (!list_candidate(slot, i, 16 * (kt0 + 4 * (c >> 2)) + 4 * q + (c & 3))) break;
-        }
-        VSTAMP_ANY(15);
-      }
-    } else {  // candidate scan by all 512 threads: thread -> row tid >> 5, 16 of its codes
-      const int row = tid >> 5, c0 = 4 * (tid & 31);          // codes c0 + 128 g + (0..3): a wave-level read is 2 x 512 contiguous bytes
-      float4 e[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) e[g] = 128 * g < K ? *reinterpret_cast<const float4*>(Es + row * BXF_LDE + c0 + 128 * g) : make_float4(INFINITY, INFINITY, INFINITY, INFINITY);
-      float m = wmin[row];
-#pragma unroll
-      for (int w = 1; w < 8; ++w) m = fminf(m, wmin[w * 16 + row]);
-      const float th = m + marg[row];
-      if (__any(!(fabsf(th) < INFINITY)) && lane == 0) s_exact = 1;      // non-finite norms: no usable bound
-      if (tid < 16) xx[tid] = sum8_partials(xxp, tid);
-      const float ev[16] = {e[0].x, e[0].y, e[0].z, e[0].w, e[1].x, e[1].y, e[1].z, e[1].w,
-                            e[2].x, e[2].y, e[2].z, e[2].w, e[3].x, e[3].y, e[3].z, e[3].w};
-      unsigned cm = 0;                      // candidate bits of this thread's 16 codes: branch-free, ONE conditional block per wave
-#pragma unroll
-      for (int c = 0; c < 16; ++c) cm |= (ev[c] <= th) ? (1u << c) : 0u;
-      if (cm) {                             // about 1.4 threads per row get here
-        const int n = __popc(cm);
-        int slot = atomicAdd(&s_np, n);
-        atomicAdd(&rowcnt[row], n);
-        rowcode[row] = c0 + 128 * ((__ffs(cm) - 1) >> 2) + ((__ffs(cm) - 1) & 3);      // THE code of a row that ends with one candidate
-        while (cm) {
-          const int c = __ffs(cm) - 1;
-          cm &= cm - 1;
-          if (!list_candidate(slot, row, c0 + 128 * (c >> 2) + (c & 3))) break;     // the list is full: the tile takes the exact sweep
-        }
-      }
-    }
-  VSTAMP(9);
-  VSTAMP_B(9);
-  lds_barrier();
-  VSTAMP(3);
-  P = s_np;
-  exact = (s_exact != 0) || P > (COOP_ROWS ? BXF_MAXC : BXF_MAXP);
   if (!exact) {
-    if (COOP_ROWS) {
-      // the pairs' code rows, each ONCE, as coalesced half-wave loads (32 lanes x 16 B = one 512-byte row; a wave-instruction
-      // costs the CU's address pipeline ~16-24 cycles whatever its active lanes: 32 per-lane loads of one thread's own row
-      // were 32 such instructions behind 4 touches per candidate) -> LDS; wave w takes pairs 2 w, 2 w + 1 (+ 16, ...)
-      for (int j0 = 2 * wave; j0 < P; j0 += 32) {
-        const int ja = j0 + (lane >> 5), jb = ja + 16;
-        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-        if (ja < P) va = *reinterpret_cast<const float4*>(W + (int64_t)p_code[ja] * E + 4 * (lane & 31));
-        if (jb < P) vb = *reinterpret_cast<const float4*>(W + (int64_t)p_code[jb] * E + 4 * (lane & 31));
-        if (ja < P) *reinterpret_cast<float4*>(Wc + ja * ldx + 4 * (lane & 31)) = va;
-        if (jb < P) *reinterpret_cast<float4*>(Wc + jb * ldx + 4 * (lane & 31)) = vb;
-      }
-      lds_barrier();
-    }
-    VSTAMP_C(0);
     if (tid < P) {     // ---- one pair per thread: the fp32 kernel's dot product of (projected row, code) as its fmaf chain -------------
-      exact_pair(p_row[tid], p_code[tid], xx[p_row[tid]], COOP_ROWS ? Wc + tid * ldx : W + (int64_t)p_code[tid] * E);
+      const int row = p_row[tid], code = p_code[tid];
+      const float* wr = W + (int64_t)code * E;
+      const float* xr_ = Xf + row * ldx;
+      float4 wv[E / 4];
+#pragma unroll
+      for (int t = 0; t < E / 4; ++t) wv[t] = *reinterpret_cast<const float4*>(wr + 4 * t);
+      const float sq = wsq[code];
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        float4 xv[4];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) xv[qq] = *reinterpret_cast<const float4*>(xr_ + 16 * s + 4 * qq);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].x, xv[qq].x, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].y, xv[qq].y, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].z, xv[qq].z, a);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) a = fmaf(wv[4 * s + qq].w, xv[qq].w, a);
+      }
+      const float d = (xx[row] + sq) - 2.0f * a;
+      if (!(fabsf(d) < INFINITY)) s_exact = 1;              // a non-finite exact value: the exact sweep decides (NaN rules)
+      atomicMin(&rowbest[row], bxf_key(d, code));
     } else if (tid >= 256) {
       // ---- beside the chains (waves 4-7): the rows that ended the scan with ONE candidate are decided, finish them now; and the
       // projected rows go to global (the code statistics read them in a later launch)
@@ -2048,11 +1882,10 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
     if (!exact && tid < 256 && frow < nrows && rowcnt[frow] != 1)
       finish_row(frow, fpart, (int)(unsigned)(rowbest[frow] & 0xffffffffull));
   }
-  }
   VSTAMP(4);
   if (exact) {
     // ---- exact fp32 sweep over every code (vq_fused_assign_kernel's arithmetic; slow path) ---------------------------------------
-    const float xr = WAVE_CHAINS ? sum8_partials(xxp, i) : xx[i];
+    const float xr = xx[i];
     float4 xb[KS];
 #pragma unroll
     for (int s = 0; s < KS; ++s) xb[s] = *reinterpret_cast<const float4*>(Xf + i * ldx + 16 * s + 4 * q);
@@ -2126,7 +1959,7 @@ __device__ __forceinline__ void vq_fused_bx_body(const float* __restrict__ z, co
       else atomicAdd(&diag[1], P);
     }
   }
-  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3), "v"(pw0));          // the prefetch destinations stay reserved until here
+  asm volatile("" ::"v"(pf0), "v"(pf1), "v"(pf2), "v"(pf3));          // the prefetch destinations stay reserved until here
   VSTAMP(6);
 }
 

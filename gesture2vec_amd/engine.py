@@ -297,10 +297,10 @@ class VQVAEEngine:
             if n:
                 raise RuntimeError(f"quantiser self-check: the bf16-screened kernel and its exact fp32 sweep disagreed on {n} row(s) "
                                    "(the screening's error radius was violated: please report the codebook / batch)")
-        f = int(self.lib.g2v_dec_rollout_persist_fault(1))
+        f = int(self.lib.g2v_dec_rollout_persist_fault(0))
         if f != 0:
-            self.lib.g2v_dec_rollout_set_persistent(0)
-            self.lib.g2v_gru_seq_set_cluster(0)
+            from .fault_policy import POLICY
+            POLICY.on_fault()          # clears the latch, selects the per-step kernels; re-arms them later (fault_policy.py)
             self._iter_graph = None
             self._open.clear()
             self._deferred.clear()
@@ -311,7 +311,15 @@ class VQVAEEngine:
                                "a workgroup of the launch was not resident (CU mask / another tenant of "
                                "the device?) -- this step's results are invalid and were NOT applied (parameters, Adam moments, "
                                "codebook, EMA and BatchNorm statistics are as before the step); the per-step kernels are selected "
-                               "from now on: repeat the step")
+                               "until the fast path is re-armed (fault_policy.py): repeat the step")
+
+    def rearm(self):
+        """the fast path was switched back on (fault_policy.POLICY.tick() returned True): forget what was planned and captured
+        for the per-step kernels"""
+        self._iter_graph = None
+        self._open.clear()
+        self._deferred.clear()
+        self._bufs.clear()
 
     def _branches_ok(self, B: int) -> bool:
         """large-batch regime (the parallel branches are on): what train_iter replays from a hipGraph"""

@@ -226,6 +226,22 @@ class text2embedding_model(nn.Module):
         # training: the S-1 decode steps as one autograd node (gesture2vec_amd/rollout_t2e.py); False = one node per
         # operator and step (the cross-check, and what inference uses either way)
         self.fused_rollout = True
+        # Trainers set this to a list for the duration of their forward (train_iter_text2embedding, GraphedText2EmbeddingStep): the
+        # decoder rollout then leaves BatchNorm's running statistics alone and `commit_bn_running_stats()` -- called behind the
+        # backward -- applies them from the saved batch statistics unless a persistent kernel of the iteration latched a fault.
+        # None (a plain forward in train mode): committed step by step inside the rollout, as nn.BatchNorm1d does.
+        self.deferred_bn = None
+
+    def commit_bn_running_stats(self) -> None:
+        """Apply the decoder BatchNorm's running-statistics updates that the forward passes since `deferred_bn = []` held back
+        (reference: nn.BatchNorm1d updates them inside every decode step, text2embedding_model.py:286-290 under :701-744).  One
+        launch per held-back rollout, stream-ordered, a no-op on the device while the persistent kernels' fault latch is set."""
+        pend, self.deferred_bn = self.deferred_bn, None
+        if not pend:
+            return
+        bn = self.decoder.decoder.pre_linear[1]
+        for sm, si, stride, steps, B, H in pend:
+            ops.bn_running_update_invstd(sm, si, stride, bn.running_mean, bn.running_var, steps, H, B)
 
     def set_dropout_masks(self, mask_emb, mask_dec_l0=None, mask_enc_l0=None):
         """Explicit keep masks for the next training forward (parity tests): (S-1,B,H) for the code-embedding dropout and
@@ -273,7 +289,7 @@ class text2embedding_model(nn.Module):
             dec = self.decoder.decoder
             bn = dec.pre_linear[1]
             spec = RolloutSpec(cod, S_model - 1, self.n_pre_poses, L, att, self.dropout_prob, mask_emb, mask_l0,
-                               bn.running_mean, bn.running_var)
+                               bn.running_mean, bn.running_var, defer_bn=self.deferred_bn)
             full, attw = CodeDecoderRollout.apply(hidden, enc_out, spec, *decoder_params(dec))   # (S,B,K), slot 0 = one-hot :676-677
             bn.num_batches_tracked += S_model - 1
             attentions_list = [attw[t].unsqueeze(1) for t in range(S_model - 1)] if att else []

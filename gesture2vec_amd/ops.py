@@ -670,6 +670,13 @@ def batchnorm_fwd(x, weight, bias, running_mean, running_var, training, relu=Tru
     return y, sm, si
 
 
+def bn_running_update_invstd(save_mean, save_invstd, step_stride, running_mean, running_var, steps, H, B):
+    """Deferred commit of BatchNorm's running statistics from the saved (mean, invstd) of `steps` training calls that were given
+    no running statistics; a no-op on the device while the persistent kernels' fault latch is set (include/g2v.h)."""
+    check(_lib_().g2v_bn_running_update_invstd(_p(save_mean), _p(save_invstd), int(step_stride), _p(running_mean), _p(running_var),
+                                               int(steps), int(H), int(B), _stream()), "bn_running_update_invstd")
+
+
 def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True, out=None):
     """out: (dx, dw, db) buffers"""
     B, H = x.shape

@@ -27,10 +27,16 @@ from . import ops
 class RolloutSpec:
     """Non-tensor arguments of CodeDecoderRollout (one object so that autograd sees a single opaque input)."""
 
-    def __init__(self, cod, steps, n_pre, L, att, dropout_p, mask_emb, mask_l0, bn_running_mean, bn_running_var):
+    def __init__(self, cod, steps, n_pre, L, att, dropout_p, mask_emb, mask_l0, bn_running_mean, bn_running_var, defer_bn=None):
         self.cod, self.steps, self.n_pre, self.L, self.att, self.dropout_p = cod, steps, n_pre, L, att, dropout_p
         self.mask_emb, self.mask_l0 = mask_emb, mask_l0
         self.bn_running_mean, self.bn_running_var = bn_running_mean, bn_running_var
+        # defer_bn: a list.  The rollout then leaves BatchNorm's running statistics ALONE (the kernels get NULL) and appends
+        # (save_mean, save_invstd, step_stride, steps, B, H) of its S-1 applications: the trainer commits them behind the backward,
+        # where a persistent-kernel fault of any part of the iteration is known (commit_bn: latch-gated on the device)
+        self.defer_bn = defer_bn
+        if defer_bn is not None:
+            self.bn_running_mean = self.bn_running_var = None
 
 
 def decoder_params(dec) -> List[torch.Tensor]:
@@ -59,7 +65,8 @@ CLUSTER_BACKWARD = True      # behind a cluster forward: the GRU cells' BPTT as 
 CLUSTER_CALLS = 0
 CLUSTER_BPTT_CALLS = 0
 FUSED_CALLS = 0          # forwards served by the fused kernels (tests assert that the path under test actually ran)
-LAST_SAVED = None        # weak reference to the last fused forward's saved arrays (tests read the decisions the kernels took)
+LAST_SAVED = None        # the last forward's greedy codes and post-BatchNorm activations, whichever kernels served it (tests read the
+                         # discrete decisions the kernels took and hand them to the oracle)
 
 
 def _cluster_ok(hidden0, enc_out, spec: RolloutSpec, params) -> bool:
@@ -127,6 +134,8 @@ def _fused_forward(ctx, hidden0, enc_out, spec: RolloutSpec, params, cluster: bo
         sv.update(hp=f32(S1, B, H), attw=f32(S1, B, Tw))
     ops.code_rollout_fwd(spec.cod.contiguous(), hidden0.contiguous(), enc, ep, wd, sv, mask_emb, mask_l0,
                          spec.dropout_p if drop else 0.0, spec.n_pre, True, S1, B, H, K, Tw)
+    if spec.defer_bn is not None:
+        spec.defer_bn.append((sv["bn_stats"], sv["bn_stats"].view(-1)[H:], 2 * H, S1, B, H))
     ctx.save_for_backward(hidden0, enc_out, *params)
     if cluster:
         # what CodeDecoderRollout.backward's per-operator chain reads, as views of the arrays the launch saved
@@ -193,6 +202,7 @@ class CodeDecoderRollout(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, hidden0, enc_out, spec: RolloutSpec, *params):
+        global LAST_SAVED
         L, att, S1 = spec.L, spec.att, spec.steps
         if _fused_ok(hidden0, enc_out, spec, params):
             return _fused_forward(ctx, hidden0, enc_out, spec, params)
@@ -265,6 +275,9 @@ class CodeDecoderRollout(torch.autograd.Function):
                         scale_l0=scale_l0, emb_w=emb_w, pre_w=pre_w, out_w=out_w, gru=gru)
         if att:
             ctx.bufs.update(enc=enc, W_h=W_h, W_e=W_e, attn_v=attn_v, EP=EP, HP=HP, AW=AW)
+        LAST_SAVED = {"ids": ids, "a": A}
+        if spec.defer_bn is not None:
+            spec.defer_bn.append((SM, SI, H, S1, B, H))
         ctx.mark_non_differentiable(AW)
         ctx.set_materialize_grads(False)
         return LOGF, AW

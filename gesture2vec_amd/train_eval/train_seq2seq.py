@@ -169,6 +169,9 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
             both = eng.readback.tolist()
             if both[3] != 0.0:
                 eng.check_faults()
+    from ..fault_policy import POLICY
+    if POLICY.tick():              # enough fault-free iterations since the last fault: the persistent / cluster kernels are back
+        eng.rearm()
     loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
     return {"loss": loss}, eng.readback[2].clone()
 
@@ -326,28 +329,35 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
     from .. import _lib
     lib = _lib.load()
+    defer = hasattr(net, "commit_bn_running_stats")
     for attempt in (0, 1):
         optim.zero_grad()
+        if defer:
+            net.deferred_bn = []           # BatchNorm's running statistics: held back until the whole iteration is known to be valid
         outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
         loss = _code_loss(outputs, cluster_targets)
         loss.backward()
+        if defer:
+            net.commit_bn_running_stats()  # behind the backward, latch-gated on the device like clip + Adam below
         optim.step()
         ret = {"loss": loss.item()}
         # The encoder's small-batch GRU kernels keep their workgroups resident for the whole sequence (include/g2v.h:
         # g2v_gru_seq_set_cluster) and latch the persistent kernels' fault word when a bounded wait runs out (a workgroup of the
-        # launch was not resident: CU mask, another tenant).  A faulted iteration changed nothing -- clip + Adam and BatchNorm's
-        # running statistics read the latch on the device -- so it is repeated once on the per-step kernels.
+        # launch was not resident: CU mask, another tenant).  A faulted iteration changed nothing -- clip + Adam and the commit of
+        # BatchNorm's running statistics sit BEHIND the backward and read the latch on the device (round 6: the statistics used
+        # to be committed inside the forward rollout, before a fault of a later step or of the backward could be known) -- so it
+        # is repeated once on the per-step kernels.
         f = int(lib.g2v_dec_rollout_persist_fault(0))      # (one 4-byte read at the point where loss.item() synchronised anyway)
+        from ..fault_policy import POLICY
         if f == 0:
+            POLICY.tick()                                  # (re-arms the fast path after enough clean iterations: nothing is cached here)
             return ret
-        lib.g2v_dec_rollout_persist_fault(1)               # clear
-        lib.g2v_gru_seq_set_cluster(0)
-        lib.g2v_dec_rollout_set_persistent(0)              # (the code decoder's cluster forward hangs off this switch)
+        POLICY.on_fault()                                  # clear the latch; per-step kernels (the code decoder's cluster forward too)
         if attempt == 1:
             raise RuntimeError(f"persistent kernel fault latch {f} set again on the per-step kernels")
         import warnings
         warnings.warn(f"persistent GRU kernels: fault latch {f} (a workgroup of the launch was not resident); the iteration was not "
-                      "applied and is repeated on the per-step kernels, which stay selected", RuntimeWarning)
+                      "applied and is repeated on the per-step kernels, which stay selected until re-armed", RuntimeWarning)
         bn = getattr(getattr(getattr(net, "decoder", None), "decoder", None), "pre_linear", None)
         if bn is not None and hasattr(bn[1], "num_batches_tracked"):
             bn[1].num_batches_tracked -= outputs.shape[1] - 1      # (the repeated iteration counts its decode steps again)
@@ -355,44 +365,128 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
 
 
 class GraphedText2EmbeddingStep:
-    """train_iter_text2embedding as ONE hipGraph: zero_grad -> forward -> CE -> backward -> clip+Adam are captured once and
-    replayed (the operator chain of Part d is ~100 small launches per step: host-bound when launched one by one at the
-    reference's B=128).  Inputs are static device tensors: overwrite `in_text` / `codes` in place between replays (and
-    `lengths` with static_lengths=False).  Dropout masks come from the Philox kernels (device-side counters), so every replay draws fresh masks.
-    `loss` is a device scalar updated by each replay (read it when needed: no per-step host sync)."""
+    """train_iter_text2embedding as ONE hipGraph: zero_grad -> forward -> CE -> backward -> BatchNorm commit -> clip+Adam are
+    captured once and replayed (the operator chain of Part d is ~100 small launches per step: host-bound when launched one by one
+    at the reference's B=128).  Inputs are static device tensors: overwrite `in_text` / `codes` (and, with the default
+    static_lengths=False, `lengths`) in place between replays.  Dropout masks come from the Philox kernels (device-side counters),
+    so every replay draws fresh masks.  `loss` is a device scalar updated by each replay (read it when needed: no per-step host sync).
 
-    def __init__(self, args, net, optim, in_text, in_lengths, codes, warmup: int = 3, static_lengths: bool = True):
+    static_lengths=True (opt-in; bench.py does and says so on its line): the sentence lengths become part of the captured graph --
+    the encoder then runs its layer-0 products on the packed positions only (EncoderRNN.forward), whose row counts are baked into
+    the launches.  Such a graph is valid for THESE lengths only: `set_lengths()` re-captures, and `replay()` refuses a `lengths`
+    argument that differs from the baked tuple.
+
+    Faults (round 6, advisor finding).  The captured step contains persistent cluster kernels at small batch; their fault latch is
+    sticky and every kernel that commits the step reads it, so after ONE residency timeout every later replay would be a silent
+    no-op (parameters frozen, a loss still reported).  `replay()` therefore reads the latch every `check_every` replays (one
+    4-byte read = one host sync; default 32), `read_loss()` always does: on a fault the latch is cleared, the per-step kernels are
+    selected (fault_policy.POLICY, which also re-arms the fast path later), the graph is captured again and the step is repeated.
+    The replays between the fault and its detection changed nothing and are reported in `lost_replays`."""
+
+    def __init__(self, args, net, optim, in_text, in_lengths, codes, warmup: int = 3, static_lengths: bool = False,
+                 check_every: int = 32):
         from ..flat import FlatClipAdam
-        from ..functional import cross_entropy
         if not isinstance(optim, FlatClipAdam):
             raise TypeError("use gesture2vec_amd.flat.FlatClipAdam")
-        dev = in_text.device
+        from .. import _lib
+        self._lib = _lib.load()
         self.in_text = in_text
         self.codes = codes
-        # static_lengths (round 5): the sentence lengths are part of the captured graph -- the encoder then runs its layer-0 products
-        # on the packed positions only (EncoderRNN.forward), whose row counts are baked into the launches: replay with OTHER
-        # lengths needs a new object.  False: lengths stay a device tensor that may be overwritten between replays (padded grid).
-        self.lengths = (in_lengths.cpu() if static_lengths else in_lengths.to(device=dev, dtype=torch.int32).contiguous())
+        self.static_lengths = bool(static_lengths)
         self.net, self.optim = net, optim
+        self.warmup = max(int(warmup), 1)
+        self.check_every = int(check_every)
+        self.replays = self.lost_replays = self.recaptures = 0
+        self._since_check = 0
+        self._set_lengths(in_lengths)
+        self._capture(self.warmup)
 
-        def step():
-            optim.zero_grad()
-            outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
-            loss = _code_loss(outputs, self.codes)
-            loss.backward()
-            optim.step()
-            return loss
+    def _set_lengths(self, in_lengths):
+        dev = self.in_text.device
+        if self.static_lengths:
+            self.lengths = in_lengths.cpu()
+            self._baked = tuple(int(v) for v in self.lengths.tolist())
+        else:
+            self.lengths = in_lengths.to(device=dev, dtype=torch.int32).contiguous()
+            self._baked = None
 
+    def _step(self):
+        net, optim = self.net, self.optim
+        defer = hasattr(net, "commit_bn_running_stats")
+        optim.zero_grad()
+        if defer:
+            net.deferred_bn = []
+        outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
+        loss = _code_loss(outputs, self.codes)
+        loss.backward()
+        if defer:
+            net.commit_bn_running_stats()
+        optim.step()
+        return loss
+
+    def _capture(self, warmup: int):
+        from ..fault_policy import POLICY
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(warmup, 1)):
-                step()
+            for _ in range(warmup):
+                self._step()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = step()
+            self.loss = self._step()
+        self._generation = POLICY.generation
 
-    def replay(self):
+    def set_lengths(self, in_lengths):
+        """new sentence lengths: in place for a device-lengths graph, a re-capture for a static-lengths one"""
+        if self.static_lengths:
+            if tuple(int(v) for v in in_lengths.tolist()) != self._baked:
+                self._set_lengths(in_lengths)
+                self._capture(1)
+                self.recaptures += 1
+        else:
+            self.lengths.copy_(in_lengths.to(device=self.lengths.device, dtype=torch.int32))
+
+    def check_faults(self) -> bool:
+        """True: a persistent kernel of some replay since the last check had latched a fault -- none of those replays was applied;
+        the graph has been re-captured on the per-step kernels, and the capture's eager warm-up step -- a real training step on the
+        current inputs -- stands in for them.  (A re-capture behind a re-armed fast path costs one such extra step too.)"""
+        from ..fault_policy import POLICY
+        n, self._since_check = self._since_check, 0
+        f = int(self._lib.g2v_dec_rollout_persist_fault(0))       # (synchronises with the device)
+        if f == 0:
+            for _ in range(max(n, 1)):
+                if POLICY.tick():
+                    break
+            if POLICY.generation != self._generation:               # the fast path was re-armed: capture it again
+                self._capture(1)
+                self.recaptures += 1
+            return False
+        import warnings
+        POLICY.on_fault()
+        self.lost_replays += n
+        warnings.warn(f"GraphedText2EmbeddingStep: persistent kernel fault latch {f}; the last {n} replay(s) were not applied -- "
+                      "re-capturing on the per-step kernels and repeating one step", RuntimeWarning)
+        bn = getattr(getattr(getattr(self.net, "decoder", None), "decoder", None), "pre_linear", None)
+        if bn is not None and hasattr(bn[1], "num_batches_tracked"):
+            bn[1].num_batches_tracked -= n * (self.codes.shape[1] - 1)     # (the unapplied replays counted their decode steps)
+        self._capture(1)            # (its eager warm-up step IS the repeated step)
+        self.recaptures += 1
+        if int(self._lib.g2v_dec_rollout_persist_fault(0)) != 0:
+            raise RuntimeError("persistent kernel fault latch set again on the per-step kernels")
+        return True
+
+    def replay(self, lengths=None):
+        if lengths is not None and self.static_lengths and tuple(int(v) for v in lengths.tolist()) != self._baked:
+            raise ValueError("this graph was captured with static_lengths=True for other sentence lengths: call set_lengths()")
         self.graph.replay()
+        self.replays += 1
+        self._since_check += 1
+        if self.check_every > 0 and self._since_check >= self.check_every:
+            self.check_faults()
         return self.loss
+
+    def read_loss(self) -> float:
+        """the last replay's loss as a float, behind a fault check (the value of an unapplied replay is never returned)"""
+        self.check_faults()
+        return float(self.loss)

@@ -655,7 +655,8 @@ int g2v_vq_soft_fused_bwd(const float* dh, const float* g_loss, const float* x, 
  *                       zero_first: overwrite instead of accumulate.  ws: g2v_embedding_bwd_ws_bytes(n, dim, V) bytes of
  *                       device scratch (ids outside [0,V) contribute nothing)
  *   g2v_batchnorm_fwd   nn.BatchNorm1d(H) on (B,H) (+ optional fused ReLU), decoder.pre_linear[1:] :286-290; training:
- *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance; save_* for bwd
+ *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance (both NULL while training:
+ *                       left alone, the caller commits them with g2v_bn_running_update_invstd); save_* for bwd
  *   g2v_batchnorm_bwd   dx, dweight, dbias (overwritten) from dy (the ReLU mask is taken from y > 0 when relu)
  *   g2v_cross_entropy_fwd_bwd   loss[0] = mean_r( logsumexp(logits[r]) - logits[r, t_r] ), dlogits = g_scale *
  *                       (softmax - onehot)/M  (torch.nn.CrossEntropyLoss, train_eval/train_seq2seq.py:520-530);
@@ -670,6 +671,13 @@ int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const uint8_t* kee
 int g2v_batchnorm_fwd(const float* x, const float* weight, const float* bias, float* running_mean, float* running_var,
                       int training, int relu, float* y, float* save_mean, float* save_invstd, int B, int H,
                       g2v_stream_t stream);
+/* Deferred commit of the running statistics from the saved (mean, 1/sqrt(var + eps)) of `steps` training calls that were given
+ * running_mean = running_var = NULL (g2v_batchnorm_fwd, g2v_attn_code_rollout_fwd), in call order; row s of either array starts
+ * at + s * step_stride floats.  Does nothing while the persistent kernels' fault latch is set (g2v_dec_rollout_persist_fault):
+ * place it behind the backward, in front of the optimiser step.  Replaces the T-1 in-place updates of the reference's
+ * nn.BatchNorm1d inside the decode loop (model/text2embedding_model.py:286-290 under :701-744). */
+int g2v_bn_running_update_invstd(const float* save_mean, const float* save_invstd, int64_t step_stride, float* running_mean,
+                                 float* running_var, int steps, int H, int B, g2v_stream_t stream);
 int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y, const float* weight, const float* save_mean,
                       const float* save_invstd, int relu, float* dx, float* dw, float* db, int B, int H,
                       g2v_stream_t stream);
@@ -725,7 +733,8 @@ typedef struct {
   const float* b_pre;            /* (H)                                                       */
   const float* bn_w;             /* (H)      pre_linear.1.weight                              */
   const float* bn_b;             /* (H)                                                       */
-  float* bn_running_mean;        /* (H)      updated once per step when training              */
+  float* bn_running_mean;        /* (H)      updated once per step when training; both NULL while training: left alone
+                                  *          (the caller commits them later: g2v_bn_running_update_invstd on bn_stats)        */
   float* bn_running_var;         /* (H)                                                       */
   const float* w_ih0; const float* w_hh0; const float* b_ih0; const float* b_hh0;   /* (3H,H), (3H) */
   const float* w_ih1; const float* w_hh1; const float* b_ih1; const float* b_hh1;

@@ -543,7 +543,10 @@ def test_loss_on_the_step_major_outputs_equals_the_reference_form(att, B, force_
         assert relerr(ga, res[1][1][n].cpu()) < 1e-5, (n, relerr(ga, res[1][1][n].cpu()))
 
 
-@pytest.mark.parametrize("att,B", [("False", 4096), ("True", 1024)])
+@pytest.mark.parametrize("att,B", [("False", 4096), ("True", 1024),
+                                   ("True", 128),      # config/seq2seqtxt.yml as shipped (autoencoder_att: True, B = 128): the cluster
+                                                       # encoder + the small-batch decoder with attention (round-5 verdict, 5d)
+                                   ("False", 128)])    # config/seq2seq.yml as shipped: cluster encoder, cluster decoder rollout + BPTT
 def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
     """Part d END TO END against the CPU oracle (oracle/g2v_oracle.py: t2e_train_step, pinned to the reference's golden vectors)
     at the batch sizes bench.py times -- until round 4 it was checked against the oracle only at the fixtures' B <= 24 and
@@ -585,7 +588,9 @@ def test_text2embedding_train_step_vs_oracle_at_large_batch(att, B):
     # later steps on a handful of rows, which is why this test carried L2 < 1e-3 / max < 2e-2.  The decisions themselves: the
     # greedy codes must be the argmax of the oracle's own logits wherever its top-2 gap is clear of rounding (below).
     sv = rollout_t2e.LAST_SAVED
-    assert sv is not None and sv["ids"].shape == (S - 1, B), "the fused step kernels did not serve this shape"
+    assert sv is not None and sv["ids"].shape == (S - 1, B), "the decoder rollout did not record its decisions"
+    if B >= 1024:
+        assert rollout_t2e.FUSED_CALLS > 0, "the fused step kernels did not serve this shape"
     forced = {"ids": sv["ids"].cpu(), "relu": (sv["a"] > 0).cpu().to(torch.float32)}
     r = O.t2e_train_step(sd, {}, ids, lengths.long(), codes.long(), masks, dict(cfg, forced=forced))
     lo = r["outputs"][:, 1:S - 1]                                  # logits of decode steps 0 .. S-3 decide ids[1 ..]
@@ -680,3 +685,163 @@ def test_linear_pair_function_equals_two_linear_functions(M, K, N):
     for k in range(2):
         assert rel(p1[k][0].grad, p2[k][0].grad) < 5e-6, (k, "dW", rel(p1[k][0].grad, p2[k][0].grad))
         assert rel(p1[k][1].grad, p2[k][1].grad) < 5e-6, (k, "db", rel(p1[k][1].grad, p2[k][1].grad))
+
+
+def _small_t2e(att="False", B=32, H=48, K=64, NW=50, EMB=30, Tw=9, S=6, p=0.1, seed=9):
+    from gesture2vec_amd.flat import FlatClipAdam
+    from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+    args = argparse.Namespace(hidden_size=H, n_layers=2, dropout_prob=p, autoencoder_vq_components=K, autoencoder_att=att,
+                              n_pre_poses=1, n_poses=20, sentence_frame_length=20 * S, text2_embedding_discrete="True",
+                              autoencoder_conditioned="True", autoencoder_fixed_weight="False")
+    g = torch.Generator().manual_seed(3)
+    lengths = torch.sort(torch.randint(2, Tw + 1, (B,), generator=g), descending=True).values
+    lengths[0] = Tw
+    ids = torch.randint(1, NW, (B, Tw), generator=g).to(DEV)
+    codes = torch.randint(0, K, (B, S), generator=g).to(DEV)
+    masks = ((torch.rand(S - 1, B, H, generator=g) < 0.5).to(torch.uint8).to(DEV),
+             (torch.rand(S - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV), None)
+    torch.manual_seed(seed)
+    net = text2embedding_model(args, 135, 20, NW, EMB, np.random.RandomState(2).randn(NW, EMB).astype(np.float32), None).to(DEV)
+    net.train(True)
+    optim = FlatClipAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.999))
+    return args, net, optim, ids, lengths, codes, masks
+
+
+def test_a_fault_latched_after_the_forward_leaves_batchnorm_running_statistics_alone(monkeypatch):
+    """Round-5 advisor finding: Part d's decoder used to commit BatchNorm's running statistics INSIDE the forward rollout, once per
+    decode step, gated only on the fault latch as it stood at that step.  A fault latched LATER in the iteration (a later step,
+    the cells' BPTT, the encoder's backward) left those updates applied, train_iter_text2embedding repeated the iteration, and the
+    same batch statistics were folded in twice.  Now the commit sits behind the backward (g2v_bn_running_update_invstd, latch-
+    gated on the device): the model after [forward, fault, repeated iteration] equals the model after ONE clean iteration, the
+    running statistics included."""
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.fault_policy import POLICY
+    from gesture2vec_amd.train_eval import train_seq2seq as TS
+    lib = _lib.load()
+    states = []
+    prev_c, prev_p = lib.g2v_gru_seq_set_cluster(1), lib.g2v_dec_rollout_set_persistent(1)
+    saved_policy = (POLICY.off, POLICY.clean, POLICY.faults, POLICY.rearms)
+    try:
+        for fault in (False, True):
+            args, net, optim, ids, lengths, codes, masks = _small_t2e()
+            lib.g2v_dec_rollout_persist_fault(1)
+            lib.g2v_gru_seq_set_cluster(1 if fault else 0)      # (the clean run on the kernels the repeated iteration ends up on)
+            lib.g2v_dec_rollout_set_persistent(1 if fault else 0)
+            orig_fwd = net.forward
+
+            def fwd(*a, **k):
+                net.set_dropout_masks(*masks)                    # (the repeated iteration needs the same explicit masks again)
+                return orig_fwd(*a, **k)
+            net.forward = fwd
+            if fault:
+                orig_loss, fired = TS._code_loss, []
+
+                def loss_then_fault(outputs, codes_):
+                    v = orig_loss(outputs, codes_)
+                    if not fired:                                # behind the FORWARD of the first attempt, in front of its backward
+                        fired.append(1)
+                        lib.g2v_dec_rollout_persist_fault(-1)
+                    return v
+                monkeypatch.setattr(TS, "_code_loss", loss_then_fault)
+                with pytest.warns(RuntimeWarning, match="repeated on the per-step kernels"):
+                    r = TS.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+                monkeypatch.setattr(TS, "_code_loss", orig_loss)
+                assert fired
+            else:
+                r = TS.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
+            assert lib.g2v_dec_rollout_persist_fault(0) == 0
+            states.append((r["loss"], {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_gru_seq_set_cluster(prev_c)
+        lib.g2v_dec_rollout_set_persistent(prev_p)
+        POLICY.off, POLICY.clean, POLICY.faults, POLICY.rearms = saved_policy
+    bn0 = states[0][1]["decoder.decoder.pre_linear.1.running_mean"]
+    assert float(bn0.abs().max()) > 0, "the clean iteration did not update the running statistics at all"
+    assert states[0][0] == states[1][0]
+    for k, v in states[0][1].items():
+        assert torch.equal(v, states[1][1][k]), k
+
+
+def test_deferred_batchnorm_commit_equals_the_in_rollout_updates():
+    """The running statistics committed behind the backward from the saved (mean, 1/sqrt(var + eps)) equal the step-by-step updates
+    the rollout makes when it is handed the running statistics (a plain forward in train mode): every decoder route."""
+    from gesture2vec_amd import rollout_t2e
+    for att, B, route in (("False", 32, "cluster"), ("True", 24, "per_operator"), ("False", 40, "per_operator")):
+        got = []
+        for defer in (False, True):
+            args, net, optim, ids, lengths, codes, masks = _small_t2e(att=att, B=B)
+            old = rollout_t2e.CLUSTER_FORWARD
+            rollout_t2e.CLUSTER_FORWARD = route == "cluster"
+            try:
+                net.set_dropout_masks(*masks)
+                if defer:
+                    net.deferred_bn = []
+                out, _ = net(ids, lengths, None, codes, None, None)
+                bn = net.decoder.decoder.pre_linear[1]
+                if defer:
+                    assert float(bn.running_mean.abs().max()) == 0.0, "a deferred forward touched the running statistics"
+                    net.commit_bn_running_stats()
+                    assert net.deferred_bn is None
+                got.append((bn.running_mean.detach().clone(), bn.running_var.detach().clone(), int(bn.num_batches_tracked)))
+            finally:
+                rollout_t2e.CLUSTER_FORWARD = old
+        assert got[0][2] == got[1][2] == codes.shape[1] - 1
+        assert float(got[0][0].abs().max()) > 0
+        assert relerr(got[1][0].cpu(), got[0][0].cpu()) < 1e-6, (att, B, route)
+        assert relerr(got[1][1].cpu(), got[0][1].cpu()) < 2e-6, (att, B, route)
+
+
+def test_graphed_step_detects_a_fault_recaptures_and_the_policy_rearms():
+    """GraphedText2EmbeddingStep (round-5 advisor finding): the captured step holds persistent cluster kernels whose fault latch is
+    sticky and gates every commit -- ONE timeout used to make every later replay a silent no-op.  replay() now reads the latch
+    every `check_every` replays: the unapplied replays are counted, the graph is captured again on the per-step kernels, the step
+    repeated; and fault_policy.POLICY switches the fast path back on after `rearm_after` clean iterations (round-5 verdict,
+    missing #6: one hiccup used to leave a run on the per-step kernels for the rest of the process)."""
+    from gesture2vec_amd import _lib
+    from gesture2vec_amd.fault_policy import POLICY
+    from gesture2vec_amd.train_eval.train_seq2seq import GraphedText2EmbeddingStep
+    lib = _lib.load()
+    prev_c, prev_p = lib.g2v_gru_seq_set_cluster(1), lib.g2v_dec_rollout_set_persistent(1)
+    saved = (POLICY.off, POLICY.clean, POLICY.faults, POLICY.rearms, POLICY.rearm_after, POLICY.max_rearms)
+    try:
+        lib.g2v_dec_rollout_persist_fault(1)
+        POLICY.off, POLICY.clean, POLICY.rearms, POLICY.rearm_after, POLICY.max_rearms = False, 0, 0, 6, 1
+        args, net, optim, ids, lengths, codes, masks = _small_t2e()
+        step = GraphedText2EmbeddingStep(args, net, optim, ids, lengths, codes, check_every=4)
+        for _ in range(4):
+            step.replay()
+        assert step.lost_replays == 0 and step.recaptures == 0
+        w0 = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        lib.g2v_dec_rollout_persist_fault(-1)                    # as a bounded wait running out would
+        with pytest.warns(RuntimeWarning, match="were not applied"):
+            for _ in range(4):
+                step.replay()
+        # the four replays behind the fault changed nothing; then ONE repeated step on the per-step kernels moved the weights
+        assert step.lost_replays == 4 and step.recaptures == 1
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0
+        assert lib.g2v_gru_seq_set_cluster(0) == 0 and POLICY.off      # the per-step kernels are selected
+        moved = [k for k, v in net.state_dict().items() if v.dtype.is_floating_point and not torch.equal(v, w0[k])]
+        assert moved, "the repeated step was not applied"
+        # (3 warm-up steps of the first capture + 4 applied replays + the re-capture's eager step; the 4 unapplied ones do not count)
+        assert int(net.decoder.decoder.pre_linear[1].num_batches_tracked) == (3 + 4 + 1) * (codes.shape[1] - 1)
+        # six clean replays later the fast path is back, and the graph is captured again for it
+        for _ in range(8):
+            step.replay()
+        assert not POLICY.off and POLICY.rearms == 1
+        assert lib.g2v_gru_seq_set_cluster(1) == 1 and lib.g2v_dec_rollout_set_persistent(1) == 1
+        assert step.recaptures == 2
+        loss = step.read_loss()
+        assert np.isfinite(loss)
+        # a static-lengths graph refuses other lengths instead of replaying stale packing (advisor finding)
+        st2 = GraphedText2EmbeddingStep(args, net, optim, ids, lengths, codes, static_lengths=True, check_every=0)
+        other = lengths.clone(); other[-1] = max(1, int(other[-1]) - 1)
+        with pytest.raises(ValueError, match="set_lengths"):
+            st2.replay(other)
+        st2.set_lengths(other)
+        st2.replay(other)
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
+        lib.g2v_gru_seq_set_cluster(prev_c)
+        lib.g2v_dec_rollout_set_persistent(prev_p)
+        POLICY.off, POLICY.clean, POLICY.faults, POLICY.rearms, POLICY.rearm_after, POLICY.max_rearms = saved

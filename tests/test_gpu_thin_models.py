@@ -270,3 +270,33 @@ def test_bulk_assign_route_of_the_quantiser_module():
     W = q._embedding.weight.data
     ref = ops.vq_assign(flat, None, W, ops.vq_code_sqnorm(W), want_quantized=False)[0]
     assert idx.dtype == torch.int64 and torch.equal(idx, ref)
+
+
+def test_bulk_assign_route_of_the_quantiser_module_at_the_shipped_width():
+    """E = 400 (hidden_size 200 x 2 layers: every YAML the reference ships, i.e. every real checkpoint): VQ_Payam_EMA.assign from 2^17
+    rows against the ORACLE's distances (reference :1230-1259: pre_linear, ||x||^2 + ||w||^2 - 2 x w^T, argmin) -- exact indices on
+    every row whose top-2 gap is above fp32 rounding noise, within 1e-3 of the minimum elsewhere -- and against the fp32 kernel on
+    the projected rows (every row)."""
+    from gesture2vec_amd import ops
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import VQ_Payam_EMA
+    from oracle import g2v_oracle as O
+    torch.manual_seed(5)
+    K, E, N = 512, 400, 131072 + 37
+    q = VQ_Payam_EMA(K, E, 0.25, 0.85).to(DEV)
+    z = torch.randn(N, E, device=DEV) * 0.3
+    idx = q.assign(z)
+    assert idx.dtype == torch.int64 and idx.shape == (N,)
+    flat = ops.linear_fwd(z, q.pre_linear.weight.data, q.pre_linear.bias.data)
+    W = q._embedding.weight.data
+    ref_k = ops.vq_assign(flat, None, W, ops.vq_code_sqnorm(W), want_quantized=False)[0]
+    assert torch.equal(idx, ref_k), "bulk route differs from the fp32 kernel"
+    # the oracle on a slice that a CPU finishes in seconds: 8192 rows spread over the batch (incl. the ragged tail)
+    rows = torch.cat([torch.arange(0, N, N // 8000)[:8000], torch.arange(N - 192, N)])
+    flat_o = O.linear(z[rows].cpu(), q.pre_linear.weight.data.cpu(), q.pre_linear.bias.data.cpu())
+    d = O.vq_distances(flat_o, W.cpu())
+    top2 = torch.topk(d, 2, dim=1, largest=False).values
+    safe = (top2[:, 1] - top2[:, 0]) > 1e-4 * torch.clamp(top2[:, 0].abs(), min=1.0)
+    got = idx[rows.to(DEV)].cpu()
+    assert torch.equal(got[safe], d.argmin(1)[safe]), "bulk route differs from the oracle outside the rounding band"
+    assert float((d[torch.arange(len(rows)), got] - top2[:, 0]).max()) <= 1e-3
+    assert int((~safe).sum()) <= len(rows) // 100

@@ -166,6 +166,70 @@ def test_train_steps_match_reference_golden(golden_dir, name):
             assert torch.equal(got.cpu(), ref), n
 
 
+def test_train_steps_match_reference_golden_h200(golden_dir):
+    """The module surface at the width the reference SHIPS (hidden_size = 200, E = 400, K = 512, dropout 0.2: config/VQ-VAE.yml)
+    against two iterations of the REFERENCE's own train_iter_Autoencoder_VQ_seq2seq (tests/golden/make_fixtures_h200.py; SURVEY.md
+    8(c)'s cut-down native fixture): the H = 200 kernels (generic GRU / decoder step kernels at this batch, the E = 400 quantiser)
+    against the reference itself, not only against the oracle."""
+    import _h200
+    from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE
+    from gesture2vec_amd.train_eval.train_seq2seq import FusedClipAdam, train_iter_Autoencoder_VQ_seq2seq
+    fx, sd0 = _h200.load(golden_dir)
+    (B, T, D, H, L, K, n_steps), args = fixture_args(fx)
+    net = Autoencoder_VQVAE(args, D, T)
+    net.load_state_dict(sd0, strict=True)
+    net = net.to(DEV)
+    net.train(True)
+    optim = FusedClipAdam(net, lr=args.learning_rate, betas=(0.5, 0.999))
+    x = torch.from_numpy(fx["x"].copy()).to(DEV)
+    codebook_before = sd0["vq_layer._embedding.weight"].clone()
+    for step in range(1, n_steps + 1):
+        m = _h200.masks(fx, step, B, T, D, H)
+        net.set_dropout_masks(m["dec"].to(DEV), m["in"].to(DEV), m["dec_l0"].to(DEV))
+        loss, perp = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
+        eng = net.engine()
+        b = eng.buffers(B)
+        d_ref = O.vq_distances(torch.from_numpy(fx[f"s{step}/flat_input"].copy()), codebook_before)
+        check_code_indices(b["idx"].cpu().numpy(), fx[f"s{step}/idx"], d_ref, gap=fx[f"s{step}/gap"])
+        assert abs(loss["loss"] - float(fx[f"s{step}/loss"])) <= 1e-5 * abs(float(fx[f"s{step}/loss"]))
+        assert abs(float(perp) - float(fx[f"s{step}/perplexity"])) <= 1e-4 * float(fx[f"s{step}/perplexity"])
+        assert relerr(net.vq_layer._ema_cluster_size, fx[f"s{step}/ema_cluster_size"]) < 1e-5
+        rows = torch.from_numpy(fx[f"s{step}/rows"])
+        assert relerr(net.vq_layer._ema_w.detach().cpu()[rows], fx[f"s{step}/ema_w_rows"]) < 1e-5
+        assert relerr(net.vq_layer._embedding.weight.detach().cpu()[rows], fx[f"s{step}/codebook_after_rows"]) < 1e-4
+        cn = float(net.vq_layer._embedding.weight.detach().double().norm())
+        assert abs(cn - float(fx[f"s{step}/codebook_after_norm"])) <= 1e-5 * cn
+        codebook_before = net.vq_layer._embedding.weight.detach().cpu().clone()
+        assert relerr(b["enc_hidden"], fx[f"s{step}/encoder_hidden"][:2]) < 1e-4
+        assert relerr(b["quant"], fx[f"s{step}/quantized"]) < 1e-4
+        assert relerr(b["y"].transpose(0, 1), fx[f"s{step}/outputs"]) < 1e-4, "reconstructed poses"
+        if step == 1:
+            n_checked = 0
+            for k in fx.files:
+                if not k.startswith("s1/grad_norm/"):
+                    continue
+                n = k[len("s1/grad_norm/"):]
+                assert n in eng.offsets, f"{n} has a gradient in the reference but is not trainable here"
+                g = eng.view(n, True)
+                if n == "decoder.decoder.pre_linear.0.bias":
+                    assert float(g.abs().max()) < 1e-6 and float(fx[k]) < 1e-5       # mathematically zero (feeds BatchNorm)
+                elif float(fx[k]) == 0.0:
+                    assert float(g.abs().max()) == 0.0, n                               # encoder layer 1: dead compute, exactly zero
+                else:
+                    _h200.check_sampled(g, fx[k], fx["s1/grad_sample/" + n], 5e-4, 1e-9, n)
+                n_checked += 1
+            assert n_checked >= 20
+    after = net.state_dict()
+    for k in fx.files:
+        if k.startswith("wN_norm/"):
+            n = k[len("wN_norm/"):]
+            if n in ("decoder.decoder.pre_linear.0.bias", "decoder.decoder.pre_linear.1.running_mean"):
+                continue            # Adam turns the pre-BatchNorm bias gradient's rounding noise into +-lr steps
+            _h200.check_sampled(after[n], fx[k], fx["wN_sample/" + n], 1e-4, 1e-4 if n.startswith("vq_layer._e") else 2e-6, n)
+        if k.startswith("wN_int/"):
+            assert np.array_equal(after[k[len("wN_int/"):]].cpu().numpy(), fx[k]), k
+
+
 @pytest.mark.parametrize("name", ["vqvae_tiny", "vqvae_lite_dropout"])
 def test_eval_forward_matches_reference_golden(golden_dir, name):
     from gesture2vec_amd.model.Autoencoder_VQVAE_model import Autoencoder_VQVAE

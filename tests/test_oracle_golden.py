@@ -90,6 +90,60 @@ def test_vqvae_train_steps_match_reference(golden_dir, name):
                 assert np.array_equal(got, ref), n
 
 
+def test_vqvae_h200_train_steps_match_reference(golden_dir):
+    """The oracle at the width the reference SHIPS (hidden_size = 200, E = 400: config/VQ-VAE.yml:21-22) against two iterations of
+    the reference's own train_iter_Autoencoder_VQ_seq2seq (tests/golden/make_fixtures_h200.py): every H = 200 kernel is checked
+    against this oracle, so the oracle itself must be pinned at H = 200 (round-5 verdict, missing #5)."""
+    import _h200
+    fx, sd = _h200.load(golden_dir)
+    (B, T, D, H, L, K, n_steps), cfg = cfg_from(fx)
+    x = torch.from_numpy(fx["x"].copy())
+    adam = {}
+    for step in range(1, n_steps + 1):
+        r = O.vqvae_train_step(sd, adam, x, _h200.masks(fx, step, B, T, D, H), cfg)
+        safe = fx[f"s{step}/gap"] > 1e-4
+        assert safe.all() or step == 1
+        assert np.array_equal(r["idx"].numpy()[safe], fx[f"s{step}/idx"][safe])
+        np.testing.assert_allclose(float(r["loss"]), float(fx[f"s{step}/loss"]), rtol=2e-6)
+        np.testing.assert_allclose(float(r["loss_vq"]), float(fx[f"s{step}/loss_vq"]), rtol=1e-5)
+        np.testing.assert_allclose(float(r["custom_loss"]), float(fx[f"s{step}/custom_loss"]), rtol=2e-6)
+        np.testing.assert_allclose(float(r["perplexity"]), float(fx[f"s{step}/perplexity"]), rtol=1e-5)
+        np.testing.assert_allclose(sd["vq_layer._ema_cluster_size"].numpy(), fx[f"s{step}/ema_cluster_size"], rtol=1e-5, atol=1e-7)
+        rows = fx[f"s{step}/rows"]
+        np.testing.assert_allclose(sd["vq_layer._ema_w"].numpy()[rows], fx[f"s{step}/ema_w_rows"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(sd["vq_layer._embedding.weight"].numpy()[rows], fx[f"s{step}/codebook_after_rows"], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(float(sd["vq_layer._embedding.weight"].double().norm()), float(fx[f"s{step}/codebook_after_norm"]), rtol=1e-5)
+        np.testing.assert_allclose(r["encoder_hidden"].numpy(), fx[f"s{step}/encoder_hidden"], rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(r["quantized"].numpy(), fx[f"s{step}/quantized"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(r["outputs"].numpy(), fx[f"s{step}/outputs"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(r["flat"].numpy(), fx[f"s{step}/flat_input"], rtol=1e-4, atol=2e-6)
+        if step == 1:
+            n_checked = 0
+            for k in fx.files:
+                if k.startswith("s1/grad_norm/"):
+                    n = k[len("s1/grad_norm/"):]
+                    if n == "decoder.decoder.pre_linear.0.bias":
+                        assert float(r["grads"][n].abs().max()) < 1e-6 and float(fx[k]) < 1e-5     # mathematically zero (feeds BatchNorm)
+                        continue
+                    _h200.check_sampled(r["grads"][n], fx[k], fx["s1/grad_sample/" + n], 2e-4, 1e-9, n)
+                    n_checked += 1
+                if k.startswith("s1/gradnone/"):
+                    assert k[len("s1/gradnone/"):] not in r["grads"], k
+            assert n_checked >= 20
+    for k in fx.files:
+        if k.startswith("wN_norm/"):
+            n = k[len("wN_norm/"):]
+            if n in ("decoder.decoder.pre_linear.0.bias", "decoder.decoder.pre_linear.1.running_mean"):
+                continue            # Adam turns the pre-BatchNorm bias gradient's rounding noise into +-lr steps (see the small fixtures)
+            if n.startswith("vq_layer._ema_w") or n.startswith("vq_layer._embedding"):
+                rt, at = 1e-4, 1e-4
+            else:
+                rt, at = 1e-4, 2e-6
+            _h200.check_sampled(sd[n], fx[k], fx["wN_sample/" + n], rt, at, n)
+        if k.startswith("wN_int/"):
+            assert np.array_equal(sd[k[len("wN_int/"):]].numpy(), fx[k]), k
+
+
 @pytest.mark.parametrize("name", ["vqvae_tiny", "vqvae_lite_dropout"])
 def test_vqvae_eval_forward_matches_reference(golden_dir, name):
     fx = load(golden_dir, name)
