@@ -43,6 +43,12 @@ class WgradItem(C.Structure):
     _fields_ = [(n, c_fp) for n in ("dy", "x", "dw", "db")]
 
 
+class WgradPending(C.Structure):
+    """g2v_wgrad_pending"""
+    _fields_ = ([("slab_w", c_fp * 4), ("out_w", c_fp * 4), ("slab_b", c_fp * 4), ("out_b", c_fp * 4), ("n", c_i64), ("nb", c_i64)] +
+                [(n, c_int) for n in ("nsplit", "nprob", "accumulate", "reserved")])
+
+
 class GruDirBwd(C.Structure):
     """g2v_gru_dir_bwd"""
     _fields_ = ([(n, c_fp) for n in ("d_hs", "d_hn", "hs", "h0", "gates", "w_hh", "dgi", "dgh", "dh0")] + [("reverse", c_int)] +
@@ -97,6 +103,9 @@ _SIGS = {
     "g2v_linear_bwd_weight_batch": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_linear_bwd_weight_batch_mapped": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_int, c_int, c_int,
                                                    c_int, c_fp, c_sz, c_fp]),
+    "g2v_linear_bwd_weight_deferred": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_fp, c_int, c_int, c_int,
+                                               c_int, c_fp, c_sz, C.POINTER(WgradPending), c_fp]),
+    "g2v_linear_bwd_weight_reduce": (c_int, [C.POINTER(WgradPending), c_int, c_fp]),
     "g2v_linear_bwd_weight_chain2": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),
     "g2v_linear_bwd_weight_fold_chain2": (c_int, [c_fp] * 12 + [c_int, c_int, c_int, c_fp]),
     "g2v_linear_bwd_weight_fold2": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_int, c_fp]),

@@ -1223,19 +1223,10 @@ struct SlabBatch {
   const float* slab_b[G2V_TN_BATCH];
   float* out_b[G2V_TN_BATCH];
 };
-__global__ __launch_bounds__(256) void slab_reduce2_kernel(SlabBatch sb, int64_t na, int64_t nb, int nsplit, int accumulate,
-                                                           int nblk_a) {
+// one workgroup's 32 outputs of one family: out[e0 .. e0 + 31] (+)= sum over the nsplit slabs, in the fixed order described above
+__device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slab, float* __restrict__ out, int64_t n, int64_t e0,
+                                                  int nsplit, int accumulate) {
   __shared__ __attribute__((aligned(16))) float red[32][36];
-  const float* __restrict__ slab_a = sb.slab_a[blockIdx.y];
-  float* __restrict__ out_a = sb.out_a[blockIdx.y];
-  const float* __restrict__ slab_b = sb.slab_b[blockIdx.y];
-  float* __restrict__ out_b = sb.out_b[blockIdx.y];
-  const bool first = (int)blockIdx.x < nblk_a;
-  if (!first && slab_b == nullptr) return;            // this problem has no bias gradient
-  const float* slab = first ? slab_a : slab_b;
-  const int64_t n = first ? na : nb;
-  float* out = first ? out_a : out_b;
-  const int64_t e0 = (int64_t)(first ? blockIdx.x : blockIdx.x - nblk_a) * 32;
   const int c4 = threadIdx.x & 7, grp = threadIdx.x >> 3;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if ((n & 3) == 0) {
@@ -1276,6 +1267,35 @@ __global__ __launch_bounds__(256) void slab_reduce2_kernel(SlabBatch sb, int64_t
       out[e] = accumulate ? out[e] + t : t;
     }
   }
+}
+__global__ __launch_bounds__(256) void slab_reduce2_kernel(SlabBatch sb, int64_t na, int64_t nb, int nsplit, int accumulate,
+                                                           int nblk_a) {
+  const bool first = (int)blockIdx.x < nblk_a;
+  const float* __restrict__ slab_b = sb.slab_b[blockIdx.y];
+  if (!first && slab_b == nullptr) return;            // this problem has no bias gradient
+  slab_reduce_block(first ? sb.slab_a[blockIdx.y] : slab_b, first ? sb.out_a[blockIdx.y] : sb.out_b[blockIdx.y], first ? na : nb,
+                    (int64_t)(first ? blockIdx.x : blockIdx.x - nblk_a) * 32, nsplit, accumulate);
+}
+
+// Round 6: the slab reductions of SEVERAL weight-gradient calls in ONE launch, off the chain between the products (a product used
+// to wait for the reduction of the one in front of it, which shared its workspace; beside the encoder's BPTT kernel -- whose two
+// workgroups per CU leave a late-dispatched kernel no registers -- such a reduction took 17-95 us instead of 5:
+// profiles/r05_az_step_timeline.txt).  A 1-D grid; family f (a weight or a bias slab set) owns blocks [first[f], first[f + 1]).
+// The arithmetic of every output is slab_reduce_block's: bitwise the immediate reduction's.
+constexpr int SLAB_MULTI = 24;       // families per launch: up to G2V_WGRAD_PENDING_MAX pending calls x 4 problems x {dw, db}, in chunks
+struct SlabMulti {
+  const float* slab[SLAB_MULTI];
+  float* out[SLAB_MULTI];
+  int64_t n[SLAB_MULTI];
+  int nsplit[SLAB_MULTI];
+  int accumulate[SLAB_MULTI];
+  int first[SLAB_MULTI + 1];
+  int count;
+};
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(SlabMulti sm) {
+  int f = 0;
+  while (f + 1 < sm.count && (int)blockIdx.x >= sm.first[f + 1]) ++f;          // (wave-uniform: <= 24 scalar compares)
+  slab_reduce_block(sm.slab[f], sm.out[f], sm.n[f], (int64_t)((int)blockIdx.x - sm.first[f]) * 32, sm.nsplit[f], sm.accumulate[f]);
 }
 
 static int tn_ntw(int N) { return N <= 64 ? 1 : (N <= 128 ? 2 : 3); }
@@ -2122,7 +2142,8 @@ static bool wgrad_sum2_ok(int M, int K, int N) {
 }
 static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx, int rows_inner, int64_t stride_outer,
                       int64_t stride_inner, const uint8_t* x_keep, float x_scale, int M, int K, int N, int flags,
-                      float* workspace, g2v_stream_t stream, const float* dy2 = nullptr) {
+                      float* workspace, g2v_stream_t stream, const float* dy2 = nullptr, g2v_wgrad_pending* pend = nullptr) {
+  if (pend) pend->nprob = 0;            // (paths without a slab reduction, or that need dw finished at once, leave it empty)
   if (dy2 && !wgrad_sum2_ok(M, K, N)) {
     set_error("g2v_linear_bwd_weight_sum2: shape not served (see g2v_linear_bwd_weight_sum2_ok)");
     return G2V_ERR_UNSUPPORTED;
@@ -2289,6 +2310,13 @@ static int wgrad_impl(const WgradItem* it, int nprob, int64_t lddy, int64_t ldx,
     const int pp = p < nprob ? p : 0;
     sb.slab_a[p] = slab_of(pp); sb.out_a[p] = it[pp].dw; sb.slab_b[p] = slab_db_of(pp); sb.out_b[p] = it[pp].db;
   }
+  if (pend) {       // G2V_WGRAD_DEFER_REDUCE: the caller reduces later (g2v_linear_bwd_weight_reduce); the slabs stay in `workspace`
+    for (int p = 0; p < nprob; ++p) {
+      pend->slab_w[p] = slab_of(p); pend->out_w[p] = it[p].dw; pend->slab_b[p] = slab_db_of(p); pend->out_b[p] = it[p].db;
+    }
+    pend->n = n; pend->nb = N; pend->nsplit = splits; pend->nprob = nprob; pend->accumulate = accumulate;
+    return G2V_OK;
+  }
   // problems without a bias gradient: their bias blocks find slab_b == nullptr and return
   hipLaunchKernelGGL(slab_reduce2_kernel, dim3(cdiv(n, 32) + (any_db ? cdiv(N, 32) : 0), nprob), dim3(256), 0, (hipStream_t)stream,
                      sb, n, (int64_t)N, splits, accumulate, cdiv(n, 32));
@@ -2361,4 +2389,61 @@ extern "C" int g2v_linear_bwd_weight_batch_mapped(const g2v_wgrad_item* items, i
   }
   return wgrad_impl(it, nprob, lddy, ldx, rows_inner, stride_outer, stride_inner, nullptr, 1.0f, M, K, N, flags, (float*)workspace,
                     stream);
+}
+
+// One call for every weight-gradient form (a single product: nprob = 1; the batch; the row-mapped batch; (dy_a + dy_b)^T x: dy_b)
+// whose slab reduction is left to the caller: `pending` describes it (empty when the shape's path has none -- small row counts --
+// or needs dw at once -- ragged row counts, reduced here), g2v_linear_bwd_weight_reduce runs up to G2V_WGRAD_PENDING_MAX of them
+// in one launch.  The slabs live in `workspace` until then: one workspace per pending call.
+extern "C" int g2v_linear_bwd_weight_deferred(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int rows_inner,
+                                              int64_t stride_outer, int64_t stride_inner, const float* dy_b, int M, int K, int N,
+                                              int flags, void* workspace, size_t workspace_bytes, g2v_wgrad_pending* pending,
+                                              g2v_stream_t stream) {
+  G2V_REQUIRE(items && workspace && pending, "null pointer");
+  G2V_REQUIRE(nprob >= 1 && nprob <= G2V_TN_BATCH && (!dy_b || nprob == 1), "1..4 problems per call (1 with dy_b)");
+  G2V_REQUIRE(M > 0 && K > 0 && N > 0 && rows_inner >= 0, "bad size");
+  WgradItem it[G2V_TN_BATCH];
+  for (int p = 0; p < nprob; ++p) {
+    G2V_REQUIRE(items[p].dy && items[p].x && items[p].dw, "null pointer");
+    it[p] = WgradItem{items[p].dy, items[p].x, items[p].dw, items[p].db};
+  }
+  if (workspace_bytes < (size_t)nprob * g2v_linear_bwd_weight_workspace(M, K, N)) {
+    set_error("g2v_linear_bwd_weight_deferred: workspace too small");
+    return G2V_ERR_WORKSPACE;
+  }
+  return wgrad_impl(it, nprob, lddy, ldx, rows_inner, stride_outer, stride_inner, nullptr, 1.0f, M, K, N, flags, (float*)workspace,
+                    stream, dy_b, pending);
+}
+
+extern "C" int g2v_linear_bwd_weight_reduce(const g2v_wgrad_pending* pending, int count, g2v_stream_t stream) {
+  G2V_REQUIRE(pending && count >= 1 && count <= G2V_WGRAD_PENDING_MAX, "1..G2V_WGRAD_PENDING_MAX pending reductions");
+  SlabMulti sm;
+  sm.count = 0;
+  sm.first[0] = 0;
+  auto flush = [&]() {
+    if (sm.count == 0) return;
+    for (int f = sm.count; f < SLAB_MULTI; ++f) {
+      sm.slab[f] = sm.slab[0]; sm.out[f] = sm.out[0]; sm.n[f] = 0; sm.nsplit[f] = 0; sm.accumulate[f] = 0; sm.first[f + 1] = sm.first[sm.count];
+    }
+    hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(sm.first[sm.count]), dim3(256), 0, (hipStream_t)stream, sm);
+    sm.count = 0;
+  };
+  auto add = [&](const float* slab, float* out, int64_t n, int nsplit, int accumulate) {
+    if (sm.count == SLAB_MULTI) flush();
+    const int f = sm.count++;
+    sm.slab[f] = slab; sm.out[f] = out; sm.n[f] = n; sm.nsplit[f] = nsplit; sm.accumulate[f] = accumulate;
+    sm.first[f + 1] = sm.first[f] + (int)cdiv(n, 32);
+  };
+  for (int c = 0; c < count; ++c) {
+    const g2v_wgrad_pending& pd = pending[c];
+    G2V_REQUIRE(pd.nprob >= 0 && pd.nprob <= G2V_TN_BATCH, "corrupt pending record");
+    for (int p = 0; p < pd.nprob; ++p) {
+      G2V_REQUIRE(pd.slab_w[p] && pd.out_w[p] && pd.n > 0 && pd.nsplit > 0, "corrupt pending record");
+      add(pd.slab_w[p], pd.out_w[p], pd.n, pd.nsplit, pd.accumulate);
+      if (pd.slab_b[p] && pd.out_b[p]) add(pd.slab_b[p], pd.out_b[p], pd.nb, pd.nsplit, pd.accumulate);
+    }
+  }
+  flush();
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
 }

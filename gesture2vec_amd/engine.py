@@ -81,6 +81,36 @@ def trainable_layout(D: int, H: int, L: int):
     return out
 
 
+class _DeferredReductions:
+    """The slab reductions of one branch's weight-gradient products, held back and run as ONE launch (include/g2v.h:
+    g2v_linear_bwd_weight_deferred / _reduce).  Every product gets a region of `ws` of its own (its slabs live there until
+    `flush`).  Round 6: a chain of immediate calls made every product wait for the reduction of the one in front of it, and
+    beside the encoder's BPTT kernel -- whose two workgroups per CU leave a late-dispatched kernel no registers -- those
+    reductions took 17-95 us instead of 5 (profiles/r05_az_step_timeline.txt: 133 us of them on the decoder branch's chain)."""
+
+    def __init__(self, eng, ws: torch.Tensor):
+        self.eng, self.ws, self.off, self.pend = eng, ws, 0, []
+
+    def call(self, items, nprob, lddy, ldx, row_map, dy_b, M, K, N, flags):
+        lib = self.eng.lib
+        need = int(nprob * lib.g2v_linear_bwd_weight_workspace(M, K, N))
+        off = self.off
+        self.off = (off + need + 255) & ~255
+        assert self.off <= self.ws.numel(), "deferred weight-gradient workspace too small"
+        pd = _lib.WgradPending()
+        check(lib.g2v_linear_bwd_weight_deferred(items, nprob, lddy, ldx, row_map[0], row_map[1], row_map[2], dy_b, M, K, N, flags,
+                                                 self.ws.data_ptr() + off, need, C.byref(pd), self.eng._stream()))
+        self.pend.append(pd)
+
+    def flush(self):
+        live = [p for p in self.pend if p.nprob > 0]
+        self.pend, self.off = [], 0
+        for k in range(0, len(live), 8):
+            chunk = live[k:k + 8]
+            arr = (_lib.WgradPending * len(chunk))(*chunk)
+            check(self.eng.lib.g2v_linear_bwd_weight_reduce(arr, len(chunk), self.eng._stream()))
+
+
 class VQVAEEngine:
     def __init__(self, D: int, H: int, L: int, K: int, T: int, *, beta: float, dropout_prob: float,
                  n_pre_poses: int = 1, conditioned: bool = True, decay: float = 0.85, eps: float = 1e-5,
@@ -91,6 +121,9 @@ class VQVAEEngine:
         # Opt-in: run the weight-gradient products on the bf16 matrix pipe as 3-term splits (G2V_WGRAD_BF16X3: ~3e-5 max-norm
         # relative error on dW instead of 3e-7; -0.17 ms / step at the BASELINE shape).  Default: exact fp32 MFMA.
         self.wgrad_bf16x3 = False
+        # Round 6: the slab reductions of a branch's weight-gradient products as ONE launch at the branch's end (_DeferredReductions)
+        # instead of one behind every product.  G2V_DEFER_REDUCE=0: the immediate calls (A/B; results are bitwise the same).
+        self.defer_reduce = os.environ.get("G2V_DEFER_REDUCE", "1") != "0"
         self.D, self.H, self.L, self.K, self.T = D, H, L, K, T
         self.E = H * L
         self.beta, self.p, self.n_pre, self.conditioned = float(beta), float(dropout_prob), int(n_pre_poses), bool(conditioned)
@@ -452,9 +485,9 @@ class VQVAEEngine:
         b["ws"] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         # scratch of the parallel branches (see _branch): never shared with the main chain
         b["ws_stats"] = torch.zeros(max(self.lib.g2v_vq_stats_workspace(B, E, K), 256), dtype=torch.uint8, device=dev)
-        b["ws_dec_wgrad"] = torch.zeros(max(self.lib.g2v_linear_bwd_weight_workspace(T * B, max(D, H), 3 * H),
-                                            self.lib.g2v_linear_bwd_weight_workspace(T * B, H, max(D, 3 * H)),
-                                            4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H)),
+        wsz = self.lib.g2v_linear_bwd_weight_workspace
+        # (deferred reductions: the decoder branch's three calls keep their slabs side by side until the branch's one reduction)
+        b["ws_dec_wgrad"] = torch.zeros(4 * wsz(T * B, H, 3 * H) + wsz(T * B, D, H) + wsz(T * B, H, D) + 1024,
                                         dtype=torch.uint8, device=dev)
         # encoder GRU weight gradients accumulated inside its backward kernel (H == 64): 1 = W_hh (0 = separate products and
         # 2 = W_ih as well were measured +50 / +90 us per step in round 3; the kernel keeps both forms, g2v_gru_dir_bwd)
@@ -462,7 +495,8 @@ class VQVAEEngine:
         if b["enc_fused_wgrad"]:
             n = int(self.lib.g2v_gru_seq_bwd_wslab_bytes(B, H))
             b["enc_wslab"] = [torch.zeros(n, dtype=torch.uint8, device=dev) for _ in range(2)]
-        b["ws_enc_wgrad"] = torch.zeros(4 * self.lib.g2v_linear_bwd_weight_workspace(T * B, H, 3 * H), dtype=torch.uint8, device=dev)
+        # (the encoder's: four GRU weight gradients + the input layer's product(s), side by side for the same reason)
+        b["ws_enc_wgrad"] = torch.zeros(4 * wsz(T * B, H, 3 * H) + 2 * wsz(T * B, D, max(H, 3 * H)) + 1024, dtype=torch.uint8, device=dev)
         # dedicated workspaces of the four recurrent launches: prepare_recurrent() fills them ahead of their kernels
         for key, nbytes in (("ws_grub", self.lib.g2v_gru_seq_bwd_workspace(2, H)),
                             ("ws_decf", self.lib.g2v_dec_rollout_fwd_workspace(D, H)), ("ws_decb", self.lib.g2v_dec_rollout_bwd_workspace(D, H))):
@@ -936,23 +970,32 @@ class VQVAEEngine:
         check(lib.g2v_rowscale_combine(_p(g["gs_flat"]), _p(g["gs_rowsum"]), _p(g["gs_t"]), _p(g["gs_dflat"]), N, E, st))
         check(lib.g2v_linear_bwd_data(_p(g["gs_dlv"]), K, self._w(vq + "logvar_layer.weight"), _p(g["gs_dflat"]), E, N, E, K, 1, st))
 
-    def _wgrad_fns(self, b, M_default, ws_key="ws"):
+    def _wgrad_fns(self, b, M_default, ws_key="ws", deferred: Optional[_DeferredReductions] = None):
+        """deferred: the products leave their slab reductions to deferred.flush() (and take their workspace from it)"""
         lib = self.lib
         ws, wsn = _p(b[ws_key]), b[ws_key].numel()
         G, H = 3 * self.H, self.H
+        flags = 2 if self.wgrad_bf16x3 else 0
 
         def wgrad(dy, lddy, x, ldx, wname, bname, N_, K_, rows=M_default, row_map=(0, 0, 0), keep=None, scale=1.0):
+            if deferred is not None and keep is None:
+                arr = (_lib.WgradItem * 1)()
+                arr[0].dy, arr[0].x, arr[0].dw, arr[0].db = dy, x, self._g(wname), self._g(bname) if bname else None
+                deferred.call(arr, 1, lddy, ldx, row_map, None, rows, K_, N_, flags)
+                return
             check(lib.g2v_linear_bwd_weight(dy, lddy, x, ldx, row_map[0], row_map[1], row_map[2], keep, scale,
                                             self._g(wname), self._g(bname) if bname else None, rows, K_, N_,
-                                            2 if self.wgrad_bf16x3 else 0, ws, wsn, self._stream()))
+                                            flags, ws, wsn, self._stream()))
 
         def wgrad4(rows, items):
             """four (3H x H) GRU weight gradients of one shape in ONE launch + one slab reduction"""
             arr = (_lib.WgradItem * 4)()
             for k, (dy, x, wname, bname) in enumerate(items):
                 arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = dy, x, self._g(wname), self._g(bname)
-            check(lib.g2v_linear_bwd_weight_batch(arr, len(items), G, H, rows, H, G, 2 if self.wgrad_bf16x3 else 0, ws, wsn,
-                                                  self._stream()))
+            if deferred is not None:
+                deferred.call(arr, len(items), G, H, (0, 0, 0), None, rows, H, G, flags)
+                return
+            check(lib.g2v_linear_bwd_weight_batch(arr, len(items), G, H, rows, H, G, flags, ws, wsn, self._stream()))
         return wgrad, wgrad4
 
     def _commit_state(self, n_global: Optional[int] = None):
@@ -989,7 +1032,8 @@ class VQVAEEngine:
                  T, B, D, H, _p(wsd), wsd.numel(), st))
         x1 = b["x1"] if drop else b["h0"][1:]
         def products():
-            wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws")
+            dfr = _DeferredReductions(self, b["ws_dec_wgrad"]) if (wgrad_branch and self.defer_reduce) else None
+            wgrad, wgrad4 = self._wgrad_fns(b, M, "ws_dec_wgrad" if wgrad_branch else "ws", deferred=dfr)
             items = [(_p(b["dgi0"]), _p(b["a"]), pre + "gru.weight_ih_l0", pre + "gru.bias_ih_l0"),
                      (_p(b["dgh0"]), _p(b["h0"]), pre + "gru.weight_hh_l0", pre + "gru.bias_hh_l0"),
                      (_p(b["dgi1"]), x1.data_ptr(), pre + "gru.weight_ih_l1", pre + "gru.bias_ih_l1"),
@@ -1007,6 +1051,8 @@ class VQVAEEngine:
             # (the rollout's backward ADDS the feedback path's gradient into dy: this product needs the finished dy, it cannot run
             # beside the rollout -- tried in round 3, wrong by construction)
             wgrad(b["dy"][1:].data_ptr(), D, b["h1"][1:].data_ptr(), H, pre + "out_layer.weight", pre + "out_layer.bias", D, H)
+            if dfr is not None:
+                dfr.flush()             # the branch's ONE slab reduction
             for name in self.frozen:
                 g = self.view(name, True)
                 check(lib.g2v_fill_f32(_p(g), 0.0, g.numel(), self._stream()))
@@ -1086,8 +1132,12 @@ class VQVAEEngine:
         p_first = fold_in and TB < 4096
         if p_first:
             p_products()
+        # Round 6: at H = 64 (the W_ih gradients' product + the input layer's two-addend product behind the BPTT) both leave their
+        # slab reductions to ONE launch behind the second product (dfr_e); the generic dims keep the immediate calls (their tail
+        # is the fold / chain kernels, which read the reduced P, c).
+        dfr_e = _DeferredReductions(self, b["ws_enc_wgrad"]) if (self.defer_reduce and H == 64 and not self.wgrad_bf16x3) else None
         with self._branch(4):       # beside the input layer's gradient below (joined there)
-            _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 4) & 1 else "ws")
+            _, wgrad4s = self._wgrad_fns(b, TB, "ws_enc_wgrad" if (self.overlap >> 4) & 1 else "ws", deferred=dfr_e)
             items = [(_p(b["dgi_f"]), _p(b["xin"]), enc + "gru.weight_ih_l0", enc + "gru.bias_ih_l0"),
                      (_p(b["dgh_f"]), b["hs_f"].data_ptr(), enc + "gru.weight_hh_l0", enc + "gru.bias_hh_l0"),
                      (_p(b["dgi_b"]), _p(b["xin"]), enc + "gru.weight_ih_l0_reverse", enc + "gru.bias_ih_l0_reverse"),
@@ -1106,6 +1156,17 @@ class VQVAEEngine:
                     self._join(2)
                 wgrad4s(TB, items)
         sum2 = H == 64 and not self.wgrad_bf16x3 and lib.g2v_linear_bwd_weight_sum2_ok(TB, D, H)
+        if sum2 and dfr_e is not None:
+            arr = (_lib.WgradItem * 1)()
+            arr[0].dy, arr[0].x = _p(b["gi_f"]), _p(b["x_drop"]) if drop else _p(in_poses)
+            arr[0].dw, arr[0].db = self._g(enc + "in_layer.weight"), self._g(enc + "in_layer.bias")
+            dfr_e.call(arr, 1, H, D, (0, 0, 0) if drop else (B, D, T * D), _p(b["gi_b"]), TB, D, H, 0)
+            self._join(4)
+            dfr_e.flush()
+            return
+        if dfr_e is not None:       # (a shape without the two-addend product: reduce what the branch deferred, go on as before)
+            self._join(4)
+            dfr_e.flush()
         if sum2:
             # the two directions' dx are summed inside the input layer's weight-gradient product (no add pass); with input
             # dropout the layer's input is the dropped tensor the forward left in x_drop

@@ -176,6 +176,36 @@ def linear_bwd_weight_batch(items, N, K, *, M, lddy=None, ldx=None, accumulate=F
           "linear_bwd_weight_batch")
 
 
+def linear_bwd_weight_deferred(calls, *, accumulate=False):
+    """Several weight-gradient calls whose slab reductions run as ONE launch behind the last product (include/g2v.h:
+    g2v_linear_bwd_weight_deferred / _reduce).  calls: list of dicts {items: [(dy, x, dw, db-or-None), ...] of one shape, N, K, M,
+    lddy, ldx, row_map, dy_b}.  Results are bitwise those of the immediate calls."""
+    lib = _lib_()
+    dev = calls[0]["items"][0][0].device
+    need = [len(c["items"]) * int(lib.g2v_linear_bwd_weight_workspace(c["M"], c["K"], c["N"])) for c in calls]
+    offs, tot = [], 0
+    for nb in need:
+        offs.append(tot)
+        tot = (tot + nb + 255) & ~255
+    ws = workspace(tot + 256, dev, "bwdw_deferred")
+    pend = []
+    for c, off, nb in zip(calls, offs, need):
+        arr = (_lib.WgradItem * len(c["items"]))()
+        for k, (dy, x, dw, db) in enumerate(c["items"]):
+            arr[k].dy, arr[k].x, arr[k].dw, arr[k].db = _p(dy), _p(x), _p(dw), _p(db)
+        rm = c.get("row_map") or (0, 0, 0)
+        pd = _lib.WgradPending()
+        check(lib.g2v_linear_bwd_weight_deferred(arr, len(c["items"]), c.get("lddy", c["N"]), c.get("ldx", c["K"]), rm[0], rm[1], rm[2],
+                                                 _p(c.get("dy_b")), c["M"], c["K"], c["N"], int(bool(accumulate)), ws.data_ptr() + off, nb,
+                                                 C.byref(pd), _stream()), "linear_bwd_weight_deferred")
+        pend.append(pd)
+    live = [p_ for p_ in pend if p_.nprob > 0]
+    for k in range(0, len(live), 8):
+        chunk = live[k:k + 8]
+        check(lib.g2v_linear_bwd_weight_reduce((_lib.WgradPending * len(chunk))(*chunk), len(chunk), _stream()), "linear_bwd_weight_reduce")
+    return [p_.nprob for p_ in pend]
+
+
 def linear_bwd_weight_fold2(w0, w1, p0, p1, c0, c1, dw=None, db=None, accumulate=False):
     """dw = w0^T p0 + w1^T p1, db = w0^T c0 + w1^T c1 (g2v_linear_bwd_weight_fold2: the weight gradient of a layer in front of
     two parallel layers from their weight-gradient-shaped products).  w: (G,H), p: (G,D), c: (G) -> dw (H,D), db (H)."""

@@ -112,6 +112,27 @@ int g2v_linear_bwd_weight_batch(const g2v_wgrad_item* items, int nprob, int64_t 
 int g2v_linear_bwd_weight_batch_mapped(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int rows_inner,
                                        int64_t stride_outer, int64_t stride_inner, int M, int K, int N, int flags,
                                        void* workspace, size_t workspace_bytes, g2v_stream_t stream);
+
+/* Deferred slab reductions (round 6).  Every large-M weight-gradient call above is [products into split-M slabs] + [one ordered
+ * reduction of the slabs into dw / db]; a chain of such calls on one stream makes every product wait for the reduction in front
+ * of it.  g2v_linear_bwd_weight_deferred is the union of the calls above -- nprob = 1: one product; rows_inner > 0: xin
+ * row-mapped; dy_b != NULL (nprob = 1): (dy + dy_b)^T xin as g2v_linear_bwd_weight_sum2 -- WITHOUT the reduction: it fills the
+ * caller-owned `pending` record, and g2v_linear_bwd_weight_reduce runs the reductions of up to G2V_WGRAD_PENDING_MAX records in
+ * ONE launch, wherever the caller places it.  Until then the slabs live in `workspace`: one workspace per pending call (same size
+ * rule as the immediate calls).  Results are bitwise those of the immediate calls.  A shape whose path has no slab reduction
+ * (small row counts) or needs dw finished at once (ragged row counts) is completed inside the call and leaves `pending` empty
+ * (nprob = 0), which g2v_linear_bwd_weight_reduce skips.  No hidden state: the record is plain data owned by the caller. */
+#define G2V_WGRAD_PENDING_MAX 8
+typedef struct {
+  const float* slab_w[4]; float* out_w[4];   /* per problem: split-M slabs of dw (nsplit x n floats) and dw itself */
+  const float* slab_b[4]; float* out_b[4];   /* ... of db (nsplit x nb floats), NULL where the item had no db */
+  int64_t n, nb;                             /* N * K and N */
+  int nsplit, nprob, accumulate, reserved;
+} g2v_wgrad_pending;
+int g2v_linear_bwd_weight_deferred(const g2v_wgrad_item* items, int nprob, int64_t lddy, int64_t ldx, int rows_inner,
+                                   int64_t stride_outer, int64_t stride_inner, const float* dy_b, int M, int K, int N, int flags,
+                                   void* workspace, size_t workspace_bytes, g2v_wgrad_pending* pending, g2v_stream_t stream);
+int g2v_linear_bwd_weight_reduce(const g2v_wgrad_pending* pending, int count, g2v_stream_t stream);
 size_t g2v_linear_bwd_weight_workspace(int M, int K, int N);
 /* The weight gradient of a layer y = x W_in^T + b_in (W_in: [H][D]) that feeds TWO layers g_p = y W_p^T (W_p: [G][H]; the two
  * directions' input projections of the bidirectional encoder GRU, ref Autoencoder_VQVAE_model.py:447-464 + EncoderRNN.in_layer

@@ -156,6 +156,49 @@ def test_linear_bwd_weight_of_a_two_addend_gradient(ops, B, T, mapped):
         ops.linear_bwd_weight_sum2(da[:100], db_[:100], x, H, D, M=100)
 
 
+def test_linear_bwd_weight_deferred_reductions_equal_the_immediate_calls(ops):
+    """Round 6: g2v_linear_bwd_weight_deferred + ONE g2v_linear_bwd_weight_reduce for several calls (the backward tail of the train
+    step: a batch of GRU weight gradients, two single products, a row-mapped two-addend product, a small-row-count product that has
+    no slab reduction at all) are BITWISE the immediate calls' dw / db, and accumulate adds onto existing values."""
+    B, T, D, H = 512, 34, 135, 64
+    M, G = T * B, 3 * H
+    def fresh():
+        gru = [(rnd(M, G, seed=60 + p).to(DEV), rnd(M, H, seed=70 + p).to(DEV), torch.zeros(G, H, device=DEV),
+                torch.zeros(G, device=DEV) if p != 1 else None) for p in range(3)]
+        du, xin = rnd(M, H, seed=80).to(DEV), rnd(M, D, seed=81).to(DEV)
+        dyo, h1 = rnd(M, D, seed=82).to(DEV), rnd(M, H, seed=83).to(DEV)
+        da, db_, xb = rnd(M, H, seed=84).to(DEV), rnd(M, H, seed=85).to(DEV), rnd(B, T, D, seed=86).to(DEV)
+        sm_dy, sm_x = rnd(640, 600, seed=87).to(DEV), rnd(640, 200, seed=88).to(DEV)
+        return gru, (du, xin), (dyo, h1), (da, db_, xb), (sm_dy, sm_x)
+    gru, (du, xin), (dyo, h1), (da, db_, xb), (sm_dy, sm_x) = fresh()
+    # immediate
+    ops.linear_bwd_weight_batch(gru, G, H, M=M)
+    ref = [(it[2].clone(), None if it[3] is None else it[3].clone()) for it in gru]
+    ref.append(ops.linear_bwd_weight(du, xin, H, D))
+    ref.append(ops.linear_bwd_weight(dyo, h1, D, H))
+    ref.append(ops.linear_bwd_weight_sum2(da, db_, xb, H, D, M=M, row_map=(B, D, T * D)))
+    ref.append(ops.linear_bwd_weight(sm_dy, sm_x, 600, 200))
+    # deferred
+    z = lambda *s: torch.full(s, float("nan"), device=DEV)
+    gru_d = [(dy, x, z(G, H), None if db is None else z(G)) for (dy, x, _, db) in gru]
+    outs = [(z(H, D), z(H)), (z(D, H), z(D)), (z(H, D), z(H)), (z(600, 200), z(600))]
+    calls = [dict(items=gru_d, N=G, K=H, M=M), dict(items=[(du, xin, *outs[0])], N=H, K=D, M=M),
+             dict(items=[(dyo, h1, *outs[1])], N=D, K=H, M=M),
+             dict(items=[(da, xb, *outs[2])], N=H, K=D, M=M, lddy=H, ldx=D, row_map=(B, D, T * D), dy_b=db_),
+             dict(items=[(sm_dy, sm_x, *outs[3])], N=600, K=200, M=640)]
+    nprob = ops.linear_bwd_weight_deferred(calls)
+    assert nprob[:4] == [3, 1, 1, 1] and nprob[4] == 0, nprob        # (the small-row-count product was completed inside its call)
+    for p in range(3):
+        assert torch.equal(gru_d[p][2], ref[p][0]), f"GRU dw {p}"
+        if gru_d[p][3] is not None:
+            assert torch.equal(gru_d[p][3], ref[p][1]), f"GRU db {p}"
+    for k in range(4):
+        assert torch.equal(outs[k][0], ref[3 + k][0]) and torch.equal(outs[k][1], ref[3 + k][1]), f"product {k}"
+    ops.linear_bwd_weight_deferred(calls[:4], accumulate=True)
+    for k in range(3):
+        relclose(outs[k][0], 2 * ref[3 + k][0], 2e-6, f"accumulated product {k}")
+
+
 def test_linear_bwd_weight_ragged_rows_through_a_row_map(ops):
     """The in_layer gradient of a ragged batch (T B % 16 != 0, x (B,T,D) read in (T,B) order): whole 16-row groups on the
     wave-autonomous kernel, the leftover rows through the same row map on the small-M kernel."""

@@ -266,6 +266,31 @@ def _engine_from_state(sd, D, H, K, T, p, beta=0.25):
     return eng
 
 
+@pytest.mark.parametrize("B,T,D,H,K,p", [(4096, 34, 135, 64, 512, 0.0), (1024, 34, 135, 64, 512, 0.2), (4096, 10, 45, 200, 400, 0.0)])
+def test_deferred_slab_reductions_leave_the_step_bitwise_unchanged(B, T, D, H, K, p):
+    """Round 6: the backward tail's slab reductions run as one launch per branch (VQVAEEngine.defer_reduce, include/g2v.h:
+    g2v_linear_bwd_weight_deferred / _reduce) instead of one behind every product: same products, same slabs, same summation order
+    -- every gradient, the loss and the post-step weights are BITWISE those of the immediate calls."""
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(5)).to(DEV)
+    g = torch.Generator().manual_seed(6)
+    keep95 = (torch.rand(T - 1, B, D, generator=g) < 0.05).to(torch.uint8).to(DEV)
+    m_in = (torch.rand(T, B, D, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None
+    m_l0 = (torch.rand(T - 1, B, H, generator=g) < 1 - p).to(torch.uint8).to(DEV) if p > 0 else None
+    res = []
+    for defer in (True, False):
+        eng = _engine_from_state(sd, D, H, K, T, p)
+        eng.defer_reduce = defer
+        for _ in range(2):
+            eng.set_masks(B, keep95, m_in, m_l0)
+            eng.train_step(x, x, lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5, draw_masks=False)
+        torch.cuda.synchronize()
+        res.append((eng.gflat.clone(), eng.flat.clone(), eng.loss_terms.clone(), eng.gnorm.clone()))
+    for a, b_ in zip(res[0], res[1]):
+        assert torch.equal(a, b_)
+    assert float(res[0][0].abs().max()) > 0
+
+
 @pytest.mark.parametrize("B,T,D,H,K,p", [(256, 34, 135, 64, 512, 0.0), (48, 20, 40, 200, 512, 0.2), (37, 10, 45, 200, 400, 0.0),
                                          (128, 20, 40, 200, 512, 0.2),   # config/VQ-VAE.yml AS SHIPPED (the cluster kernels at their own batch size:
                                                                          # the shape bench.py's `shipped_config` times)
