@@ -1547,6 +1547,169 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
   }
 }
 
+// ---- round 6: the sweep again, built around what limited vq_bx3_sweep_kernel (profiles/r06_d_bulk_*) ---------------------------
+// That kernel ran 560 us at 2^20 rows against 164 us of bf16 matrix-pipe time: (a) 14 vector instructions per (row, code) value
+// -- with two waves per SIMD the SIMD's issue slots, not its matrix pipe, were the bound --, (b) 72 spilled registers (the
+// codebook chunks passed through 32 staging registers on their way to LDS beside 128 registers of row fragments).  Here:
+//   * the codebook chunks go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write, no address
+//     arithmetic in the loop); the LDS image is linear, the 16-byte pieces of a code row XOR-swizzled by the row (source address
+//     and fragment read both: conflict-free ds_read_b128 without padding, which an LDS-DMA destination cannot have);
+//   * everything that is constant per code or per row sits in the ACCUMULATOR'S INITIAL VALUE: acc_0 = -|w_k|^2 / 2 + (c_x / 2) |w_k|
+//     (c_x = 2^-12 |x|: the per-code error radius of round 5), so that the finished accumulator is -L_k / 2 for the lower bound
+//     L_k = e_k - r_k itself -- one fma per value, off the MFMA chain; the codes are ranked by LARGEST accumulator;
+//   * ranking = one v_and_or (code index into the low mantissa bits), one v_med3 (second largest), one v_max: 4 instructions per
+//     value in all, 64 per code tile and wave beside its 48 MFMAs.
+// Decided iff acc_1 - acc_2 >= c_x |w_a| + the packing's truncation (the same rule as before, halved); everything else -- ties,
+// non-finite rows -- goes to the list and gets the fp32 kernel's answer.  A codebook with a non-finite |w_k|^2 sends every row
+// there (flag from the split kernel): a NaN accumulator would otherwise just lose the ranking.
+__global__ __launch_bounds__(256) void vq_bulk_split_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
+                                                            __bf16* __restrict__ Wh, __bf16* __restrict__ Wl,
+                                                            float* __restrict__ wn, float* __restrict__ msv, int* __restrict__ flags,
+                                                            int64_t n, int K) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
+    const float w = W[e];
+    const __bf16 h = (__bf16)w;
+    Wh[e] = h;
+    Wl[e] = (__bf16)(w - (float)h);
+  }
+  for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
+    const float q = wsq[k];
+    wn[k] = sqrtf(q) * 1.001f;          // |w_k| (rounded up), for the PER-CODE error radius of the sweep
+    msv[k] = -0.5f * q;
+    if (!(fabsf(q) < INFINITY)) atomicOr(&flags[1], 1);
+  }
+}
+
+constexpr int BK2_CODES = 64;          // codes per LDS chunk: 16 KB per image
+__global__ __launch_bounds__(256, 2) void vq_bulk_sweep_kernel(const float* __restrict__ flat, const __bf16* __restrict__ Wh,
+                                                               const __bf16* __restrict__ Wl, const float* __restrict__ msv,
+                                                               const float* __restrict__ wn, int64_t* __restrict__ idx_out,
+                                                               int* __restrict__ und_list, int* __restrict__ und_count, int N, int K,
+                                                               int kbits) {
+  constexpr int E = 128, KB = E / 32, RT = 4;
+  __shared__ __attribute__((aligned(16))) __bf16 Ls[2][2][BK2_CODES * E];       // [buffer][hi / lo][code][k], pieces swizzled
+  __shared__ __attribute__((aligned(16))) float Cs[2][2][BK2_CODES];            // [buffer][-|w|^2 / 2, |w|][code]
+  const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r0 = blockIdx.x * 256 + 64 * wave;
+  // ---- the chunk fill: LDS-DMA, 1 KiB (4 code rows) per wave-instruction; wave w moves rows 16 w .. 16 w + 15 of both images ----
+  // lane (g, pos) of instruction j lands at row 4 j + g, piece position pos of the linear image and fetches logical piece pos ^ (row & 15)
+  const int frow = lane >> 4, fpos = lane & 15;
+  auto fill = [&](int c, int buf) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int row = 16 * wave + 4 * jj + frow;
+      const int64_t off = (int64_t)(c * BK2_CODES + row) * E + 8 * (fpos ^ (row & 15));
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wh + off),
+                                       (__attribute__((address_space(3))) void*)&Ls[buf][0][(16 * wave + 4 * jj) * E], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wl + off),
+                                       (__attribute__((address_space(3))) void*)&Ls[buf][1][(16 * wave + 4 * jj) * E], 16, 0, 0);
+    }
+    if (wave == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(msv + c * BK2_CODES + lane),
+                                       (__attribute__((address_space(3))) void*)&Cs[buf][0][0], 4, 0, 0);
+    if (wave == 1)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wn + c * BK2_CODES + lane),
+                                       (__attribute__((address_space(3))) void*)&Cs[buf][1][0], 4, 0, 0);
+  };
+  fill(0, 0);
+  // ---- this wave's rows as B-operand fragments (hi / lo), straight from global; |x|^2 on the way ---------------------------
+  bf16x8 xh[RT][KB], xl[RT][KB];
+  float cxh[RT];                                        // c_x / 2 = 2^-13 |x|
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+    const int row = r0 + 16 * t + i;
+    const float* xp = flat + (int64_t)(row < N ? row : N - 1) * E + 8 * q;
+    float ss = 0.f;
+#pragma unroll
+    for (int s = 0; s < KB; ++s) {
+      const float4 a = *reinterpret_cast<const float4*>(xp + 32 * s), b = *reinterpret_cast<const float4*>(xp + 32 * s + 4);
+      const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const __bf16 h = (__bf16)v[j];
+        xh[t][s][j] = h;
+        xl[t][s][j] = (__bf16)(v[j] - (float)h);
+        ss += v[j] * v[j];
+      }
+    }
+    ss += __shfl_xor(ss, 16);
+    ss += __shfl_xor(ss, 32);
+    cxh[t] = 1.220703125e-4f * sqrtf(ss);
+  }
+  float d1[RT], d2[RT];                                 // largest and second-largest packed accumulator per row (this lane's codes)
+#pragma unroll
+  for (int t = 0; t < RT; ++t) { d1[t] = -INFINITY; d2[t] = -INFINITY; }
+  const unsigned kmask = (1u << kbits) - 1u;
+  const int nch = K / BK2_CODES;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int c = 0; c < nch; ++c) {
+    const int buf = c & 1;
+    if (c + 1 < nch) fill(c + 1, buf ^ 1);       // (buffer buf ^ 1 was last read in iteration c - 1, before the barrier below)
+#pragma unroll
+    for (int tl = 0; tl < BK2_CODES / 16; ++tl) {
+      bf16x8 wh[KB], wl[KB];
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+        const int at = (16 * tl + i) * E + 8 * ((4 * s + q) ^ i);
+        wh[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][0][at]);
+        wl[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][1][at]);
+      }
+      const float4 mv = *reinterpret_cast<const float4*>(&Cs[buf][0][16 * tl + 4 * q]);
+      const float4 nv = *reinterpret_cast<const float4*>(&Cs[buf][1][16 * tl + 4 * q]);
+      f32x4 acc[RT];
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+        acc[t] = (f32x4){fmaf(cxh[t], nv.x, mv.x), fmaf(cxh[t], nv.y, mv.y), fmaf(cxh[t], nv.z, mv.z), fmaf(cxh[t], nv.w, mv.w)};
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh[t][s], acc[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl[t][s], acc[t], 0, 0, 0);
+      }
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh[t][s], acc[t], 0, 0, 0);
+      }
+      const unsigned cb = (unsigned)(c * BK2_CODES + 16 * tl + 4 * q);
+      const unsigned code[4] = {cb, cb + 1u, cb + 2u, cb + 3u};
+#pragma unroll
+      for (int t = 0; t < RT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pk = __uint_as_float((__float_as_uint(acc[t][r]) & ~kmask) | code[r]);
+          d2[t] = __builtin_amdgcn_fmed3f(d1[t], d2[t], pk);      // d1 >= d2 always: the median is the second largest
+          d1[t] = fmaxf(d1[t], pk);                               // (a NaN candidate leaves both untouched)
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+  const float trunc = ldexpf(1.0f, kbits - 22);          // 2 x the relative truncation of a packed accumulator
+  const bool all_undecided = und_count[1] != 0;          // the codebook has a non-finite code
+#pragma unroll
+  for (int t = 0; t < RT; ++t) {
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {                 // (largest, second largest) of two disjoint code sets
+      const float e1 = __shfl_xor(d1[t], o), e2 = __shfl_xor(d2[t], o);
+      d2[t] = fmaxf(fminf(d1[t], e1), fmaxf(d2[t], e2));
+      d1[t] = fmaxf(d1[t], e1);
+    }
+    const int row = r0 + 16 * t + i;
+    if (q == 0 && row < N) {
+      const int ca = (int)(__float_as_uint(d1[t]) & kmask);
+      idx_out[row] = (int64_t)(ca < K ? ca : 0);
+      // acc = -L / 2: decided iff L_b - L_a >= 2 r_a, i.e. acc_1 - acc_2 >= c_x |w_a| (= 2 cxh |w_a|) + the packing's truncation
+      const float margin = 2.0f * cxh[t] * wn[ca < K ? ca : 0] + trunc * fmaxf(fabsf(d1[t]), fabsf(d2[t]));
+      // NaN / inf - inf (rows with non-finite values) compare false: undecided, the exact kernel follows torch.argmin
+      if (all_undecided || !(d1[t] - d2[t] >= margin)) und_list[atomicAdd(und_count, 1)] = row;
+    }
+  }
+}
+
 // ---- fused pre_linear + assign with the distance SCREENING on the bf16 matrix pipe, exact by construction (round 3) ------------
 // At N = 4096 a batch has one 16-row tile per CU; the fp32 kernel above spends 2.8 k cycles on the projection and then 14 k on the
 // 256 fp32 MFMAs per wave of the -2 x W^T contraction, one behind the other.  Only the ARGMIN of that contraction is an output, so
@@ -2178,7 +2341,8 @@ extern "C" int g2v_vq_assign_packed_fwd(const float* flat, const float* z, const
 
 extern "C" size_t g2v_vq_assign_bulk_workspace(int N, int E, int K) {
   if (N <= 0 || E <= 0 || K <= 0) return 0;
-  return 2 * (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256 + (((size_t)K * 4 + 255) & ~(size_t)255) + (size_t)N * 4;
+  // [hi image][lo image][counters][|w_k|][-|w_k|^2 / 2][list of undecided rows]
+  return 2 * (((size_t)K * E * 2 + 255) & ~(size_t)255) + 256 + 2 * (((size_t)K * 4 + 255) & ~(size_t)255) + (size_t)N * 4;
 }
 
 // idx[n] = argmin_k |flat[n] - W[k]|^2 for MANY rows (bulk latent -> code assignment): bf16 split screening + exact fp32
@@ -2203,16 +2367,24 @@ extern "C" int g2v_vq_assign_bulk(const float* flat, const float* codebook, cons
   __bf16* Wh = (__bf16*)w;
   __bf16* Wl = (__bf16*)(w + half);
   int* count = (int*)(w + 2 * half);
+  const size_t kpad = ((size_t)K * 4 + 255) & ~(size_t)255;
   float* wn = (float*)(w + 2 * half + 256);
-  int* list = (int*)(w + 2 * half + 256 + (((size_t)K * 4 + 255) & ~(size_t)255));
-  (void)hipMemsetAsync(count, 0, sizeof(int), st);
-  hipLaunchKernelGGL(vq_bx3_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, wn,
-                     (int64_t)K * E, K);
+  float* msv = (float*)(w + 2 * half + 256 + kpad);
+  int* list = (int*)(w + 2 * half + 256 + 2 * kpad);
+  (void)hipMemsetAsync(count, 0, 2 * sizeof(int), st);        // [0] undecided rows, [1] the codebook has a non-finite code
   int kbits = 1;
   while ((1 << kbits) < K) ++kbits;
   G2V_REQUIRE(kbits <= 13, "codebook larger than 8192 codes");
+#ifdef G2V_BULK_SWEEP_R5        // A/B build: the round-5 sweep (gpurun_tools/r06_bulk_ab.sh)
+  hipLaunchKernelGGL(vq_bx3_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, wn,
+                     (int64_t)K * E, K);
   hipLaunchKernelGGL(vq_bx3_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, code_sqnorm, wn, idx, list, count, N,
                      K, kbits);
+#else
+  hipLaunchKernelGGL(vq_bulk_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, wn, msv,
+                     count, (int64_t)K * E, K);
+  hipLaunchKernelGGL(vq_bulk_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, msv, wn, idx, list, count, N, K, kbits);
+#endif
   hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4, true>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, (const float*)nullptr,
                      codebook, code_sqnorm, idx, (float*)nullptr, (float*)nullptr, (float*)nullptr, N, K, list, count);
   if (undecided) (void)hipMemcpyAsync(undecided, count, sizeof(int), hipMemcpyDeviceToDevice, st);

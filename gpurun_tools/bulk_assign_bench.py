@@ -37,4 +37,4 @@ for scale, tag in ((1.0, "N(0,1) rows and codes"), (0.05, "rows and codes scaled
                    bulk_GBps=round((N * E * 4 + N * 8) / t_bulk / 1e3, 1))
         print(json.dumps(rec)); out.append(rec)
 os.makedirs("gpurun_out", exist_ok=True)
-json.dump(out, open("gpurun_out/r05_vq_bulk_assign_sweep.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r06_vq_bulk_assign_sweep.json", "w"), indent=1)

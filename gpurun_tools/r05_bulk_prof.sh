@@ -8,7 +8,7 @@ f=$(ls gpurun_out/prof_bulk/*/*kernel_stats.csv 2>/dev/null | head -1)
 python3 - "$f" "$lib" <<'P'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
-for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:3]:
+for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"]))[:6]:
     print(f'{sys.argv[2][-16:]} {r["Name"][:60]:60s} calls {int(r["Calls"]):5d} avg_us {float(r["AverageNs"]) / 1e3:9.1f}')
 P
 rm -rf gpurun_out/prof_bulk
