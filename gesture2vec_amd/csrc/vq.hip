@@ -659,9 +659,10 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
   __shared__ int best_k[ROWS];
   __shared__ float red[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int r0 = blockIdx.x * ROWS;
   if (LIST) N = min(N, *row_count);
-  if (r0 >= N) return;
+  // LIST (round 6): a bounded grid walks the list in strides -- the launch used to be sized for N rows, 16 k workgroups of which
+  // ~150 had work, 64 rows each: one round of 30 us; with 16 rows per workgroup the same rows spread over the chip
+  for (int r0 = blockIdx.x * ROWS; r0 < N; r0 += (int)gridDim.x * ROWS) {
   const int nrows = min(ROWS, N - r0);
   const int i = lane & 15, q = lane >> 4;
   for (int e = tid; e < ROWS * (E / 4); e += 256) {     // coalesced float4 staging
@@ -756,7 +757,10 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
       if (dist_min) dist_min[r0 + tid] = d;
     }
   }
-  if (LIST) return;
+  if (LIST) {
+    __syncthreads();          // the staging arrays are reused by the next stride
+    continue;
+  }
   __syncthreads();
   if (quant) {
     float sse = 0.f;
@@ -775,6 +779,8 @@ __global__ __launch_bounds__(256) void vq_assign_rt_kernel(const float* __restri
     if (lane == 0) red[wave] = sse;
     __syncthreads();
     if (tid == 0 && sse_partial) sse_partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
+  break;                     // (one 16 RT-row block per workgroup unless LIST)
   }
 }
 
@@ -1564,8 +1570,7 @@ __global__ __launch_bounds__(256, 2) void vq_bx3_sweep_kernel(const float* __res
 // there (flag from the split kernel): a NaN accumulator would otherwise just lose the ranking.
 __global__ __launch_bounds__(256) void vq_bulk_split_kernel(const float* __restrict__ W, const float* __restrict__ wsq,
                                                             __bf16* __restrict__ Wh, __bf16* __restrict__ Wl,
-                                                            float* __restrict__ wn, float* __restrict__ msv, int* __restrict__ flags,
-                                                            int64_t n, int K) {
+                                                            float2* __restrict__ cst, int* __restrict__ flags, int64_t n, int K) {
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) {
     const float w = W[e];
     const __bf16 h = (__bf16)w;
@@ -1574,21 +1579,20 @@ __global__ __launch_bounds__(256) void vq_bulk_split_kernel(const float* __restr
   }
   for (int k = blockIdx.x * 256 + threadIdx.x; k < K; k += gridDim.x * 256) {
     const float q = wsq[k];
-    wn[k] = sqrtf(q) * 1.001f;          // |w_k| (rounded up), for the PER-CODE error radius of the sweep
-    msv[k] = -0.5f * q;
+    cst[k] = make_float2(-0.5f * q, sqrtf(q) * 1.001f);      // {-|w_k|^2 / 2, |w_k| rounded up (the PER-CODE error radius of the sweep)}
     if (!(fabsf(q) < INFINITY)) atomicOr(&flags[1], 1);
   }
 }
 
 constexpr int BK2_CODES = 64;          // codes per LDS chunk: 16 KB per image
 __global__ __launch_bounds__(256, 2) void vq_bulk_sweep_kernel(const float* __restrict__ flat, const __bf16* __restrict__ Wh,
-                                                               const __bf16* __restrict__ Wl, const float* __restrict__ msv,
-                                                               const float* __restrict__ wn, int64_t* __restrict__ idx_out,
+                                                               const __bf16* __restrict__ Wl, const float2* __restrict__ cst,
+                                                               int64_t* __restrict__ idx_out,
                                                                int* __restrict__ und_list, int* __restrict__ und_count, int N, int K,
                                                                int kbits) {
   constexpr int E = 128, KB = E / 32, RT = 4;
   __shared__ __attribute__((aligned(16))) __bf16 Ls[2][2][BK2_CODES * E];       // [buffer][hi / lo][code][k], pieces swizzled
-  __shared__ __attribute__((aligned(16))) float Cs[2][2][BK2_CODES];            // [buffer][-|w|^2 / 2, |w|][code]
+  __shared__ __attribute__((aligned(16))) float Cs[2][BK2_CODES][2];            // [buffer][code]{-|w|^2 / 2, |w|}
   const int tid = threadIdx.x, lane = tid & 63, i = lane & 15, q = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r0 = blockIdx.x * 256 + 64 * wave;
@@ -1605,13 +1609,14 @@ __global__ __launch_bounds__(256, 2) void vq_bulk_sweep_kernel(const float* __re
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wl + off),
                                        (__attribute__((address_space(3))) void*)&Ls[buf][1][(16 * wave + 4 * jj) * E], 16, 0, 0);
     }
-    if (wave == 0)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(msv + c * BK2_CODES + lane),
-                                       (__attribute__((address_space(3))) void*)&Cs[buf][0][0], 4, 0, 0);
-    if (wave == 1)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wn + c * BK2_CODES + lane),
-                                       (__attribute__((address_space(3))) void*)&Cs[buf][1][0], 4, 0, 0);
+    // the chunk's constants: ONE more LDS-DMA (half a wave, 512 B).  Two of them -- one per array, as the first version had it --
+    // made hipcc put an s_waitcnt vmcnt(0) between them: every wave waited for the chunk it had just requested, at the TOP of
+    // the chunk it was about to compute, and no schedule of the loop below changed the kernel's time (profiles/r06_d_bulk_*)
+    if (wave == 0 && lane < 32)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(cst + c * BK2_CODES + 2 * lane),
+                                       (__attribute__((address_space(3))) void*)&Cs[buf][0][0], 16, 0, 0);
   };
+  VSTAMP(0);
   fill(0, 0);
   // ---- this wave's rows as B-operand fragments (hi / lo), straight from global; |x|^2 on the way ---------------------------
   bf16x8 xh[RT][KB], xl[RT][KB];
@@ -1642,52 +1647,106 @@ __global__ __launch_bounds__(256, 2) void vq_bulk_sweep_kernel(const float* __re
   for (int t = 0; t < RT; ++t) { d1[t] = -INFINITY; d2[t] = -INFINITY; }
   const unsigned kmask = (1u << kbits) - 1u;
   const int nch = K / BK2_CODES;
+  VSTAMP(1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  VSTAMP(2);
+  // ---- the sweep, software-pipelined by hand (three versions, profiles/r06_d_bulk_*): -------------------------------------------
+  // a COLUMN = one 16-code tile against the wave's four row tiles: 48 MFMAs in four k-blocks of 12 (wl.xh, wh.xl, wh.xh per row
+  // tile), on accumulator set `cur`.  In the shadow of k-block s the wave (a) fetches the fragments of k-block s + 1 (of the next
+  // column's k-block 0 behind the last) into the other fragment register set -- they are needed 12 MFMAs later, so the LDS latency
+  // that the first version paid in front of every column (41 % of wave time in s_waitcnt) is hidden --, (b) RANKS row tile s of
+  // the column BEFORE this one (accumulator set `prev`: 4 v_and_or + 8 v_med3; max(a, b) = med3(a, b, +inf), the plain fmaxf costs a
+  // NaN-quieting v_max per operand) and (c) writes the NEXT column's initial values into that freed accumulator (4 fma): 16
+  // vector instructions per 12 MFMAs, one behind each MFMA -- an MFMA owns the SIMD's issue port for 8 of its 16 cycles.
+  f32x4 acc[2][RT];
+#pragma unroll
+  for (int t = 0; t < RT; ++t) acc[1][t] = (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};  // "column before the first": ranks as a no-op
+  unsigned codes[2][4] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};                                    // (-inf packed with code 0 stays -inf)
+  float pinf = INFINITY;
+  asm volatile("" : "+v"(pinf));        // opaque to the compiler: med3(a, b, +inf) folded to fmaxf brings the quieting v_max back
+  auto rank = [&](int t, const f32x4& a, const unsigned (&code)[4]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float pk = __uint_as_float((__float_as_uint(a[r]) & ~kmask) | code[r]);
+      d2[t] = __builtin_amdgcn_fmed3f(d1[t], d2[t], pk);          // d1 >= d2 always: the median is the second largest
+      d1[t] = __builtin_amdgcn_fmed3f(d1[t], pk, pinf);           // the larger of the two (a NaN candidate leaves both untouched)
+    }
+  };
+  auto frag_at = [&](int buf, int img, int tl, int s) -> bf16x8 {
+    return *reinterpret_cast<const bf16x8*>(&Ls[buf][img][(16 * tl + i) * E + 8 * ((4 * s + q) ^ i)]);
+  };
+  auto init4 = [&](f32x4& a, int t, const float4& mv, const float4& nv) {
+    a = (f32x4){fmaf(cxh[t], nv.x, mv.x), fmaf(cxh[t], nv.y, mv.y), fmaf(cxh[t], nv.z, mv.z), fmaf(cxh[t], nv.w, mv.w)};
+  };
+  constexpr int NCOL = BK2_CODES / 16;
   for (int c = 0; c < nch; ++c) {
     const int buf = c & 1;
     if (c + 1 < nch) fill(c + 1, buf ^ 1);       // (buffer buf ^ 1 was last read in iteration c - 1, before the barrier below)
+    // the chunk's first column: its fragments of k-block 0 and its initial values cannot be prepared across the barrier
+    bf16x8 fh[2], fl[2];                                  // two fragment register sets (k-block parity)
+    fh[0] = frag_at(buf, 0, 0, 0);
+    fl[0] = frag_at(buf, 1, 0, 0);
+    auto consts_of = [&](int tl, float4& mv, float4& nv) {          // codes 16 tl + 4 q .. + 3: {m0, n0, m1, n1}, {m2, n2, m3, n3}
+      const float4 a = *reinterpret_cast<const float4*>(&Cs[buf][16 * tl + 4 * q][0]);
+      const float4 b = *reinterpret_cast<const float4*>(&Cs[buf][16 * tl + 4 * q + 2][0]);
+      mv = make_float4(a.x, a.z, b.x, b.z);
+      nv = make_float4(a.y, a.w, b.y, b.w);
+    };
+    {
+      float4 mv, nv;
+      consts_of(0, mv, nv);
 #pragma unroll
-    for (int tl = 0; tl < BK2_CODES / 16; ++tl) {
-      bf16x8 wh[KB], wl[KB];
-#pragma unroll
-      for (int s = 0; s < KB; ++s) {
-        const int at = (16 * tl + i) * E + 8 * ((4 * s + q) ^ i);
-        wh[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][0][at]);
-        wl[s] = *reinterpret_cast<const bf16x8*>(&Ls[buf][1][at]);
-      }
-      const float4 mv = *reinterpret_cast<const float4*>(&Cs[buf][0][16 * tl + 4 * q]);
-      const float4 nv = *reinterpret_cast<const float4*>(&Cs[buf][1][16 * tl + 4 * q]);
-      f32x4 acc[RT];
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-        acc[t] = (f32x4){fmaf(cxh[t], nv.x, mv.x), fmaf(cxh[t], nv.y, mv.y), fmaf(cxh[t], nv.z, mv.z), fmaf(cxh[t], nv.w, mv.w)};
-#pragma unroll
-      for (int s = 0; s < KB; ++s) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[s], xh[t][s], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xl[t][s], acc[t], 0, 0, 0);
-      }
-#pragma unroll
-      for (int s = 0; s < KB; ++s) {
-#pragma unroll
-        for (int t = 0; t < RT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[s], xh[t][s], acc[t], 0, 0, 0);
-      }
-      const unsigned cb = (unsigned)(c * BK2_CODES + 16 * tl + 4 * q);
-      const unsigned code[4] = {cb, cb + 1u, cb + 2u, cb + 3u};
-#pragma unroll
-      for (int t = 0; t < RT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float pk = __uint_as_float((__float_as_uint(acc[t][r]) & ~kmask) | code[r]);
-          d2[t] = __builtin_amdgcn_fmed3f(d1[t], d2[t], pk);      // d1 >= d2 always: the median is the second largest
-          d1[t] = fmaxf(d1[t], pk);                               // (a NaN candidate leaves both untouched)
-        }
+      for (int t = 0; t < RT; ++t) init4(acc[0][t], t, mv, nv);     // (set 1 still holds the previous chunk's last column: ranked below)
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int tl = 0; tl < NCOL; ++tl) {
+      const int cs = tl & 1, ps = cs ^ 1;                 // accumulator sets of this column / of the one before it (NCOL is even)
+      const unsigned cb = (unsigned)(c * BK2_CODES + 16 * tl + 4 * q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) codes[cs][r] = cb + (unsigned)r;
+      float4 mvn = make_float4(0.f, 0.f, 0.f, 0.f), nvn = mvn;
+      if (tl + 1 < NCOL) consts_of(tl + 1, mvn, nvn);       // the next column's constants (same chunk)
+#pragma unroll
+      for (int s = 0; s < KB; ++s) {
+        const int w = s & 1;                              // (KB is even: k-block 0 of every column sits in fragment set 0)
+        if (s + 1 < KB) {
+          fh[w ^ 1] = frag_at(buf, 0, tl, s + 1);
+          fl[w ^ 1] = frag_at(buf, 1, tl, s + 1);
+        } else if (tl + 1 < NCOL) {
+          fh[w ^ 1] = frag_at(buf, 0, tl + 1, 0);
+          fl[w ^ 1] = frag_at(buf, 1, tl + 1, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fl[w], xh[t][s], acc[cs][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[w], xl[t][s], acc[cs][t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < RT; ++t) acc[cs][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fh[w], xh[t][s], acc[cs][t], 0, 0, 0);
+        rank(s, acc[ps][s], codes[ps]);                   // row tile s of the column before this one ...
+        if (tl + 1 < NCOL) init4(acc[ps][s], s, mvn, nvn);     // ... whose accumulator then takes the next column's initial values
+        // the schedule of this k-block: its LDS reads, then one vector instruction behind each MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+      }
+    }
+    if (c < 6) VSTAMP(3 + 2 * c);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's share of the next chunk has landed ...
+    __builtin_amdgcn_s_barrier();                         // ... and so has everybody's; everybody is done with this chunk's buffer
+    if (c < 6) VSTAMP(4 + 2 * c);
   }
+#pragma unroll
+  for (int t = 0; t < RT; ++t) rank(t, acc[1][t], codes[1]);        // the last column (NCOL is even: set 1)
+  VSTAMP(15);
   const float trunc = ldexpf(1.0f, kbits - 22);          // 2 x the relative truncation of a packed accumulator
   const bool all_undecided = und_count[1] != 0;          // the codebook has a non-finite code
 #pragma unroll
@@ -1703,7 +1762,7 @@ __global__ __launch_bounds__(256, 2) void vq_bulk_sweep_kernel(const float* __re
       const int ca = (int)(__float_as_uint(d1[t]) & kmask);
       idx_out[row] = (int64_t)(ca < K ? ca : 0);
       // acc = -L / 2: decided iff L_b - L_a >= 2 r_a, i.e. acc_1 - acc_2 >= c_x |w_a| (= 2 cxh |w_a|) + the packing's truncation
-      const float margin = 2.0f * cxh[t] * wn[ca < K ? ca : 0] + trunc * fmaxf(fabsf(d1[t]), fabsf(d2[t]));
+      const float margin = 2.0f * cxh[t] * cst[ca < K ? ca : 0].y + trunc * fmaxf(fabsf(d1[t]), fabsf(d2[t]));
       // NaN / inf - inf (rows with non-finite values) compare false: undecided, the exact kernel follows torch.argmin
       if (all_undecided || !(d1[t] - d2[t] >= margin)) und_list[atomicAdd(und_count, 1)] = row;
     }
@@ -2381,11 +2440,13 @@ extern "C" int g2v_vq_assign_bulk(const float* flat, const float* codebook, cons
   hipLaunchKernelGGL(vq_bx3_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, code_sqnorm, wn, idx, list, count, N,
                      K, kbits);
 #else
-  hipLaunchKernelGGL(vq_bulk_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, wn, msv,
-                     count, (int64_t)K * E, K);
-  hipLaunchKernelGGL(vq_bulk_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, msv, wn, idx, list, count, N, K, kbits);
+  (void)msv;
+  hipLaunchKernelGGL(vq_bulk_split_kernel, dim3(cdiv((int64_t)K * E, 256)), dim3(256), 0, st, codebook, code_sqnorm, Wh, Wl, (float2*)wn,
+                     count, (int64_t)K * E, K);          // (wn .. : 2 K floats, {-|w_k|^2 / 2, |w_k|} per code)
+  hipLaunchKernelGGL(vq_bulk_sweep_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, flat, Wh, Wl, (const float2*)wn, idx, list, count, N, K,
+                     kbits);
 #endif
-  hipLaunchKernelGGL((vq_assign_rt_kernel<128, 4, true>), dim3(cdiv(N, 64)), dim3(256), 0, st, flat, (const float*)nullptr,
+  hipLaunchKernelGGL((vq_assign_rt_kernel<128, 1, true>), dim3(min(cdiv(N, 16), 2048)), dim3(256), 0, st, flat, (const float*)nullptr,
                      codebook, code_sqnorm, idx, (float*)nullptr, (float*)nullptr, (float*)nullptr, N, K, list, count);
   if (undecided) (void)hipMemcpyAsync(undecided, count, sizeof(int), hipMemcpyDeviceToDevice, st);
   G2V_CHECK_LAUNCH();

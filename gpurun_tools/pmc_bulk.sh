@@ -11,7 +11,7 @@ import csv, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(float)); n = collections.Counter()
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"][:40]
-    if "bx3_sweep" in k or "vq_assign_rt" in k:
+    if "bx3_sweep" in k or "bulk_sweep" in k or "vq_assign_rt" in k:
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); n[(k, r["Counter_Name"])] += 1
 for k, d in acc.items():
     for c, v in d.items():
