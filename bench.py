@@ -315,23 +315,23 @@ def vq_kernel_roofline(eng, B, reps: int = 200):
 def bulk_assign_line():
     """bulk code assignment (g2v_vq_assign_bulk: bf16 3-term split screening on the matrix pipe + exact fp32
     re-check of the undecided rows; reference call sites lmdb_data_loader.py:1274-1281, Clustering.py:151-157) at 2^20 projected
-    rows, E = 128, K = 512: average of 20 calls (events on the launch stream), every index against the fp32 kernel's."""
+    rows, E = 128, K = 512: average of 50 calls behind 100 untimed ones (events on the launch stream), every index against the fp32 kernel's."""
     from gesture2vec_amd import ops
     N, E, K = 1 << 20, 128, 512
     g = torch.Generator().manual_seed(3)
     W = torch.randn(K, E, generator=g).to("cuda:0")
     x = torch.randn(N, E, generator=g).to("cuda:0")
     wsq = ops.vq_code_sqnorm(W)
-    for _ in range(3):
+    for _ in range(100):          # (40 ms: this leg runs behind a minute of host-side baseline work, the GPU's clocks are down)
         ops.vq_assign_bulk(x, W, wsq)
     st = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(st)
-    for _ in range(20):
+    for _ in range(50):
         ops.vq_assign_bulk(x, W, wsq)
     e1.record(st)
     e1.synchronize()
-    us = e0.elapsed_time(e1) * 1e3 / 20
+    us = e0.elapsed_time(e1) * 1e3 / 50
     idx, und = ops.vq_assign_bulk(x, W, wsq, want_undecided=True)
     ref = ops.vq_assign(x, None, W, wsq, want_quantized=False)[0]
     bytes_alg = N * (4 * E + 8)                              # SURVEY.md 8(d): read the row, write the index

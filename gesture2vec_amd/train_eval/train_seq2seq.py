@@ -489,4 +489,4 @@ class GraphedText2EmbeddingStep:
     def read_loss(self) -> float:
         """the last replay's loss as a float, behind a fault check (the value of an unapplied replay is never returned)"""
         self.check_faults()
-        return float(self.loss)
+        return float(self.loss.detach())
