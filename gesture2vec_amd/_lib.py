@@ -103,6 +103,11 @@ _SIGS = {
     "g2v_linear_bwd_weight_batch": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_linear_bwd_weight_batch_mapped": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_int, c_int, c_int,
                                                    c_int, c_fp, c_sz, c_fp]),
+    "g2v_ctx_create": (C.c_void_p, []),
+    "g2v_ctx_destroy": (None, [C.c_void_p]),
+    "g2v_ctx_bind": (C.c_void_p, [C.c_void_p]),
+    "g2v_ctx_set_option": (c_int, [C.c_void_p, c_int, c_int]),
+    "g2v_ctx_get_option": (c_int, [C.c_void_p, c_int]),
     "g2v_linear_bwd_weight_deferred": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_fp, c_int, c_int, c_int,
                                                c_int, c_fp, c_sz, C.POINTER(WgradPending), c_fp]),
     "g2v_linear_bwd_weight_reduce": (c_int, [C.POINTER(WgradPending), c_int, c_fp]),
@@ -258,3 +263,42 @@ def check(rc: int, what: str = ""):
     if rc != 0:
         msg = load().g2v_last_error().decode()
         raise G2VLibraryError(f"g2v call failed ({rc}) {what}: {msg}")
+
+
+OPT_PERSISTENT, OPT_GRU_CLUSTER, OPT_SMALLM_ROWS = 1, 2, 3
+
+
+class Context:
+    """A caller-owned set of the library's three implementation switches (include/g2v.h: g2v_ctx).  `with ctx:` binds it to the
+    calling thread for the duration of the block (re-entrant: the previous binding comes back); every library call inside reads
+    ITS switches.  An engine owns one, so that two engines in one process do not share switches and a residency fault in one
+    does not switch off the fast path of the other (round-5 verdict: "no hidden global state")."""
+
+    def __init__(self):
+        self._lib = load()
+        self._h = self._lib.g2v_ctx_create()
+        if not self._h:
+            raise MemoryError("g2v_ctx_create failed")
+        self._stack = []
+
+    def set(self, option: int, value: int) -> int:
+        return int(self._lib.g2v_ctx_set_option(self._h, int(option), int(value)))
+
+    def get(self, option: int) -> int:
+        return int(self._lib.g2v_ctx_get_option(self._h, int(option)))
+
+    def __enter__(self):
+        self._stack.append(self._lib.g2v_ctx_bind(self._h))
+        return self
+
+    def __exit__(self, *exc):
+        self._lib.g2v_ctx_bind(self._stack.pop())
+        return False
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.g2v_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

@@ -13,6 +13,16 @@
 // (which reads the latch at its next sync point) can simply repeat the step on the per-step kernels.
 const unsigned* g2v_internal_persist_fault_ptr();
 
+// The three implementation switches (include/g2v.h: g2v_ctx) of the context bound to the CALLING THREAD, or of the process's
+// default context when the thread has bound none (misc.hip owns both).  Everything that used to read a file-scope `static int`
+// reads these.
+struct G2vOptions {
+  int persist = 1;            // G2V_OPT_PERSISTENT   0..3   (dec_rollout.hip)
+  int gru_cluster = 1;        // G2V_OPT_GRU_CLUSTER  0 / 1  (gru.hip)
+  int smallm_max_rows = 1024; // G2V_OPT_SMALLM_ROWS  >= 0   (linear.hip)
+};
+G2vOptions& g2v_internal_options();
+
 namespace g2v {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

@@ -431,17 +431,14 @@ __global__ __launch_bounds__(256) void gemm_smallm_dual_kernel(DualTrans d, int 
 
 // measured (gpurun_tools/gemm_bench.py, 200..400 -> 200..600): forward 9.7 vs 10.4 us and data gradient 11 vs 22 us at 128..640
 // rows, break-even near 2560 rows, the LDS-tiled kernel ahead beyond (50..86 TF/s at 4096..81920 rows)
-static int g_smallm_max_rows = 1024;      // g2v_linear_set_smallm_rows (measurement only)
-extern "C" int g2v_linear_set_smallm_rows(int rows) {
-  const int prev = g_smallm_max_rows;
-  if (rows >= 0) g_smallm_max_rows = rows;
-  return prev;
+extern "C" int g2v_linear_set_smallm_rows(int rows) {            // = g2v_ctx_set_option(NULL, G2V_OPT_SMALLM_ROWS, rows) (measurement only)
+  return g2v_ctx_set_option(nullptr, G2V_OPT_SMALLM_ROWS, rows);
 }
 
 static bool launch_smallm(bool trans_b, const float* A, int64_t lda, const uint8_t* keep, float scale, const float* Bm,
                           int64_t ldb, const float* bias, float* Cout, int64_t ldc, int M, int C, int N, int act,
                           int accumulate, hipStream_t st) {
-  if (M > g_smallm_max_rows || (C & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
+  if (M > g2v_internal_options().smallm_max_rows || (C & 3) || (lda & 3) || (reinterpret_cast<uintptr_t>(A) & 15)) return false;
   if (!trans_b && ((ldb & 3) || (reinterpret_cast<uintptr_t>(Bm) & 15))) return false;
   if (keep && (reinterpret_cast<uintptr_t>(keep) & 3)) return false;
   // wider wave tiles (more re-use of the A fragment, fewer waves) once 16 x 16 tiles alone fill the chip a few times over
@@ -1441,7 +1438,7 @@ extern "C" int g2v_linear_fwd_pair(const float* x, int64_t ldx, const float* w_a
   G2V_REQUIRE(x && w_a && w_b && y_a && y_b, "null pointer");
   G2V_REQUIRE(M > 0 && K > 0 && N > 0, "non-positive size");
   G2V_REQUIRE(act >= 0 && act <= 2, "bad activation");
-  const bool tiled = M > g_smallm_max_rows && N > 192 && !(N == 64 && K == 135);      // (neither launch_smallm, _stream nor _k4)
+  const bool tiled = M > g2v_internal_options().smallm_max_rows && N > 192 && !(N == 64 && K == 135);      // (neither launch_smallm, _stream nor _k4)
   const bool vec = (K & 3) == 0 && (ldx & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w_a) |
                                                        reinterpret_cast<uintptr_t>(w_b)) & 15) == 0;
   if (tiled && vec && M <= 16384) {

@@ -2,6 +2,7 @@
 #include <stdarg.h>
 
 #include "common.hpp"
+#include <new>
 
 namespace g2v {
 
@@ -12,6 +13,63 @@ void set_error(const char* fmt, ...) {
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+
+}  // namespace g2v
+
+// ---- caller-owned contexts (include/g2v.h: g2v_ctx) ------------------------------------------------------------------------------
+struct g2v_ctx {
+  G2vOptions opt;
+};
+static g2v_ctx g_default_ctx;
+static thread_local g2v_ctx* t_bound_ctx = nullptr;
+G2vOptions& g2v_internal_options() { return (t_bound_ctx ? t_bound_ctx : &g_default_ctx)->opt; }
+void g2v_internal_preclear_drop(const void* base, size_t bytes);      // dec_persist.hip
+extern "C" g2v_ctx* g2v_ctx_create(void) { return new (std::nothrow) g2v_ctx(); }
+extern "C" void g2v_ctx_destroy(g2v_ctx* ctx) {
+  if (!ctx) return;
+  if (t_bound_ctx == ctx) t_bound_ctx = nullptr;
+  delete ctx;
+}
+extern "C" g2v_ctx* g2v_ctx_bind(g2v_ctx* ctx) {
+  g2v_ctx* prev = t_bound_ctx;
+  t_bound_ctx = ctx;
+  return prev;
+}
+extern "C" int g2v_ctx_set_option(g2v_ctx* ctx, int option, int value) {
+  G2vOptions& o = (ctx ? ctx : (t_bound_ctx ? t_bound_ctx : &g_default_ctx))->opt;
+  int prev = -1;
+  switch (option) {
+    case G2V_OPT_PERSISTENT:
+      prev = o.persist;
+      o.persist = value <= 0 ? 0 : (value > 3 ? 3 : value);
+      g2v_internal_preclear_drop(nullptr, 0);      // (a kernel-family switch voids every "already clear" note)
+      break;
+    case G2V_OPT_GRU_CLUSTER:
+      prev = o.gru_cluster;
+      o.gru_cluster = value ? 1 : 0;
+      g2v_internal_preclear_drop(nullptr, 0);
+      break;
+    case G2V_OPT_SMALLM_ROWS:
+      prev = o.smallm_max_rows;
+      if (value >= 0) o.smallm_max_rows = value;
+      break;
+    default:
+      g2v::set_error("g2v_ctx_set_option: unknown option %d", option);
+      return G2V_ERR_ARG;
+  }
+  return prev;
+}
+extern "C" int g2v_ctx_get_option(const g2v_ctx* ctx, int option) {
+  const G2vOptions& o = (ctx ? ctx : (t_bound_ctx ? t_bound_ctx : &g_default_ctx))->opt;
+  switch (option) {
+    case G2V_OPT_PERSISTENT: return o.persist;
+    case G2V_OPT_GRU_CLUSTER: return o.gru_cluster;
+    case G2V_OPT_SMALLM_ROWS: return o.smallm_max_rows;
+    default: g2v::set_error("g2v_ctx_get_option: unknown option %d", option); return G2V_ERR_ARG;
+  }
+}
+
+namespace g2v {
 
 // ---- custom_loss: train_eval/train_seq2seq.py:40-88 ----------------------------------------------------
 // One thread per (b,d) column walks the T frames twice (norm over TIME, :70).  y is (T,B,D), target (B,T,D).

@@ -118,6 +118,13 @@ class VQVAEEngine:
         if L != 2:
             raise NotImplementedError("the gfx950 rollout kernels implement n_layers == 2 (every shipped config)")
         self.lib = _lib.load()
+        # The library's implementation switches (persistent / cluster kernels, small-row-count threshold) of THIS engine: a
+        # caller-owned context (include/g2v.h: g2v_ctx) that every public method binds to the calling thread around its library
+        # calls.  Two engines in one process do not share switches; a residency fault here flips only this engine's (round 6;
+        # they used to be process-global variables).  `fault_policy` switches the fast path off on a fault and re-arms it later.
+        self.ctx = _lib.Context()
+        from .fault_policy import PersistentPathPolicy
+        self.fault_policy = PersistentPathPolicy(ctx=self.ctx)
         # Opt-in: run the weight-gradient products on the bf16 matrix pipe as 3-term splits (G2V_WGRAD_BF16X3: ~3e-5 max-norm
         # relative error on dW instead of 3e-7; -0.17 ms / step at the BASELINE shape).  Default: exact fp32 MFMA.
         self.wgrad_bf16x3 = False
@@ -332,8 +339,7 @@ class VQVAEEngine:
                                    "(the screening's error radius was violated: please report the codebook / batch)")
         f = int(self.lib.g2v_dec_rollout_persist_fault(0))
         if f != 0:
-            from .fault_policy import POLICY
-            POLICY.on_fault()          # clears the latch, selects the per-step kernels; re-arms them later (fault_policy.py)
+            self.fault_policy.on_fault()   # clears the latch, selects the per-step kernels IN THIS ENGINE'S CONTEXT; re-arms them later
             self._iter_graph = None
             self._open.clear()
             self._deferred.clear()
@@ -1319,3 +1325,22 @@ class VQVAEEngine:
             elif self.quantizer == "ema":   # (a caller that ran the local half some other way)
                 self.vq_finish(B, True, n_global=world * ((2 * B * self.H) // self.E))
         self.optimizer_step(lr, betas=betas, eps=eps, max_norm=max_norm, grad_scale=1.0 / world if dp else 1.0, readback=True)
+
+
+def _bind_context(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def bound(self, *a, **k):
+        with self.ctx:
+            return fn(self, *a, **k)
+    return bound
+
+
+# every public method that reaches the library runs with the engine's own context bound to the calling thread
+for _name in ("buffers", "prepare_recurrent", "draw_masks", "forward", "forward_encoder", "forward_decoder", "vq_derive",
+              "refresh_codebook_state", "vq_finish", "loss", "backward", "backward_decoder", "backward_encoder", "optimizer_step",
+              "train_step", "train_step_local", "train_step_apply", "check_faults", "rearm", "vq_bx_mismatches"):
+    setattr(VQVAEEngine, _name, _bind_context(getattr(VQVAEEngine, _name)))
+del _name
+

@@ -19,7 +19,11 @@ from . import _lib
 
 
 class PersistentPathPolicy:
-    def __init__(self, rearm_after: int = 1000, max_rearms: int = 3):
+    """ctx: the gesture2vec_amd._lib.Context whose switches this policy flips (an engine's own); None = the process's default
+    context (the module-level trainers of Part d)."""
+
+    def __init__(self, rearm_after: int = 1000, max_rearms: int = 3, ctx=None):
+        self.ctx = ctx
         self.rearm_after = int(rearm_after)
         self.max_rearms = int(max_rearms)
         self.faults = 0            # faults seen by this process
@@ -29,13 +33,21 @@ class PersistentPathPolicy:
         self.generation = 0        # bumped whenever the selected kernel family changes: holders of captured graphs compare it
         self._lock = threading.Lock()
 
+    def _switch(self, on: int) -> None:
+        if self.ctx is not None:
+            self.ctx.set(_lib.OPT_PERSISTENT, on)
+            self.ctx.set(_lib.OPT_GRU_CLUSTER, on)
+        else:
+            lib = _lib.load()
+            lib.g2v_dec_rollout_set_persistent(on)
+            lib.g2v_gru_seq_set_cluster(on)
+
     def on_fault(self) -> None:
         """a trainer found the latch set: clear it, select the per-step kernels (the caller repeats the iteration)"""
         lib = _lib.load()
         with self._lock:
             lib.g2v_dec_rollout_persist_fault(1)
-            lib.g2v_dec_rollout_set_persistent(0)
-            lib.g2v_gru_seq_set_cluster(0)
+            self._switch(0)
             self.faults += 1
             self.clean = 0
             self.off = True
@@ -50,9 +62,7 @@ class PersistentPathPolicy:
             self.clean += 1
             if self.clean < self.rearm_after or self.rearms >= self.max_rearms:
                 return False
-            lib = _lib.load()
-            lib.g2v_dec_rollout_set_persistent(1)
-            lib.g2v_gru_seq_set_cluster(1)
+            self._switch(1)
             self.rearms += 1
             self.clean = 0
             self.off = False

@@ -169,8 +169,7 @@ def _fused_iteration(args, epoch, input_poses, target_poses, net, optim, reduce_
             both = eng.readback.tolist()
             if both[3] != 0.0:
                 eng.check_faults()
-    from ..fault_policy import POLICY
-    if POLICY.tick():              # enough fault-free iterations since the last fault: the persistent / cluster kernels are back
+    if eng.fault_policy.tick():    # enough fault-free iterations since the last fault: the persistent / cluster kernels are back
         eng.rearm()
     loss = both[0] + (both[1] / 400 if epoch > 0 else 0.0)
     return {"loss": loss}, eng.readback[2].clone()

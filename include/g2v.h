@@ -56,13 +56,35 @@ int g2v_device_ok(void);
 /* measurement only: largest row count served by the wave-per-tile kernel of g2v_linear_fwd / g2v_linear_bwd_data
  * (0 = never); returns the previous value, rows < 0 only queries */
 int g2v_linear_set_smallm_rows(int rows);
-/* PROCESS-GLOBAL SWITCHES of the library, complete list (everything else is per call).  The library reads NO environment
- * variable.  All three select between implementations that produce the same results (measurements, parity tests, and the
- * fall-back after a latched residency fault of the persistent kernels):
- *   g2v_linear_set_smallm_rows(rows)        row count up to which the wave-per-tile dense kernels are used (default 1024)
- *   g2v_dec_rollout_set_persistent(0..3)    persistent rollout kernels vs one launch per step (default 1; see below)
- *   g2v_gru_seq_set_cluster(0 / 1)          small-batch g2v_gru_seq_fwd / _bwd: one persistent launch vs one launch per step
- * plus one device-side error latch, g2v_dec_rollout_persist_fault (below). */
+/* IMPLEMENTATION SWITCHES, complete list (everything else is per call).  The library reads NO environment variable.  All three
+ * select between implementations that produce the same results (measurements, parity tests, and the fall-back after a latched
+ * residency fault of the persistent kernels):
+ *   G2V_OPT_SMALLM_ROWS   row count up to which the wave-per-tile dense kernels are used (default 1024)
+ *   G2V_OPT_PERSISTENT    0..3: persistent rollout kernels vs one launch per step (default 1; see g2v_dec_rollout_set_persistent)
+ *   G2V_OPT_GRU_CLUSTER   0 / 1: small-batch g2v_gru_seq_fwd / _bwd as one persistent launch vs one launch per step
+ * They live in a CALLER-OWNED CONTEXT (round 6; until round 5 they were three process-global variables, so two engines in one
+ * process shared them and a fault in one switched off the fast path of the other):
+ *   g2v_ctx_create()              a context with the defaults above (host memory; NULL on allocation failure)
+ *   g2v_ctx_destroy(ctx)          (unbinds it from the calling thread if bound there; never destroy a context bound elsewhere)
+ *   g2v_ctx_bind(ctx)             binds it to the CALLING THREAD and returns the previous binding; NULL = the process's default
+ *                                 context.  Every entry point of this library reads the switches of the calling thread's bound
+ *                                 context at call time -- launches already captured in a hipGraph keep what they were captured with.
+ *   g2v_ctx_set_option(ctx, option, value) / g2v_ctx_get_option(ctx, option)
+ *                                 ctx = NULL: the calling thread's bound context (the default context if none).  set returns the
+ *                                 previous value; both return G2V_ERR_ARG (< 0) for an unknown option.
+ * g2v_linear_set_smallm_rows, g2v_dec_rollout_set_persistent and g2v_gru_seq_set_cluster are the same calls with ctx = NULL.
+ * A thread that never binds a context behaves as before (one set of switches per process, in the default context).
+ * What stays process-wide: one device-side error latch, g2v_dec_rollout_persist_fault (below) -- a fault of the DEVICE, not an
+ * option -- and the "already clear" notes of g2v_cluster_exchange_preclear. */
+typedef struct g2v_ctx g2v_ctx;
+#define G2V_OPT_PERSISTENT 1
+#define G2V_OPT_GRU_CLUSTER 2
+#define G2V_OPT_SMALLM_ROWS 3
+g2v_ctx* g2v_ctx_create(void);
+void g2v_ctx_destroy(g2v_ctx* ctx);
+g2v_ctx* g2v_ctx_bind(g2v_ctx* ctx);
+int g2v_ctx_set_option(g2v_ctx* ctx, int option, int value);
+int g2v_ctx_get_option(const g2v_ctx* ctx, int option);
 int g2v_linear_fwd(const float* x, int64_t ldx, int rows_inner, int64_t stride_outer, int64_t stride_inner,
                    const uint8_t* x_keep, float x_scale,
                    const float* w, const float* bias, float* y, int64_t ldy,

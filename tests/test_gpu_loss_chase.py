@@ -169,7 +169,8 @@ def test_latched_fault_reaches_train_iter_and_the_step_is_not_applied(B):
         assert lib.g2v_dec_rollout_persist_fault(0) == 1
         loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
         assert lib.g2v_dec_rollout_persist_fault(0) == 0    # check_faults() cleared the latch ...
-        assert lib.g2v_dec_rollout_set_persistent(0) == 0   # ... and switched the persistent path off
+        assert eng.ctx.get(_lib.OPT_PERSISTENT) == 0        # ... and switched the persistent path off IN THE ENGINE'S OWN CONTEXT
+        assert lib.g2v_ctx_get_option(None, _lib.OPT_PERSISTENT) == 1     # (the process's default context is untouched: round 6)
         assert abs(loss2["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"]) and not torch.equal(snap[0], eng.flat)
         assert int(eng.step_counter) == int(snap[6]) + 1, "exactly one step was applied"
         assert int(net.decoder.decoder.pre_linear[1].num_batches_tracked) == nbt + (T - 1)
@@ -213,8 +214,10 @@ def test_latched_fault_on_the_cluster_kernels_of_the_shipped_shape_is_repeated_o
             assert torch.equal(was, now), "a faulted step must not be applied"
         loss2, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
         assert lib.g2v_dec_rollout_persist_fault(0) == 0
-        assert lib.g2v_dec_rollout_set_persistent(0) == 0 and lib.g2v_gru_seq_set_cluster(0) == 0
-        assert lib.g2v_dec_rollout_cluster_ok(B, D, int(args.hidden_size)) == 0
+        assert eng.ctx.get(_lib.OPT_PERSISTENT) == 0 and eng.ctx.get(_lib.OPT_GRU_CLUSTER) == 0
+        with eng.ctx:
+            assert lib.g2v_dec_rollout_cluster_ok(B, D, int(args.hidden_size)) == 0
+        assert lib.g2v_dec_rollout_cluster_ok(B, D, int(args.hidden_size)) == 1     # (another engine, the default context: still offered)
         assert abs(loss2["loss"] - loss["loss"]) <= 0.05 * abs(loss["loss"]) and not torch.equal(snap[0], eng.flat)
         assert int(eng.step_counter) == int(snap[6]) + 1, "exactly one step was applied"
         loss3, _ = train_iter_Autoencoder_VQ_seq2seq(args, 1, x, x, net, optim)
@@ -261,8 +264,9 @@ def test_fault_latched_in_the_middle_of_a_step_leaves_the_whole_model_state_unto
         with pytest.raises(RuntimeError, match="persistent rollout kernel"):
             eng.check_faults()
         assert lib.g2v_dec_rollout_persist_fault(0) == 0
-        lib.g2v_dec_rollout_set_persistent(1)               # (check_faults switched it off: this test goes on with the same kernels)
-        lib.g2v_gru_seq_set_cluster(1)
+        eng.ctx.set(_lib.OPT_PERSISTENT, 1)                 # (check_faults switched it off: this test goes on with the same kernels)
+        eng.ctx.set(_lib.OPT_GRU_CLUSTER, 1)
+        eng.rearm()
         eng.train_step(x, x, **kw)
         torch.cuda.synchronize()
         for n in names:
@@ -315,3 +319,50 @@ def test_a_faulting_rank_makes_every_rank_skip_the_step_under_data_parallelism()
         lib.g2v_dec_rollout_persist_fault(1)
         lib.g2v_dec_rollout_set_persistent(1)
         lib.g2v_gru_seq_set_cluster(1)
+
+
+def test_two_engines_do_not_share_switches_and_a_fault_in_one_leaves_the_other_on_the_fast_path():
+    """Round 6 (round-5 verdict, boundary): the library's implementation switches live in a caller-owned context (include/g2v.h:
+    g2v_ctx) that each engine binds around its calls.  Engine A latches a fault and falls back to the per-step launches; engine B,
+    in the same process, keeps the persistent kernels; A's policy re-arms A's fast path after its clean interval."""
+    from gesture2vec_amd import _lib
+    lib = _lib.load()
+    D, H, K, T, B = 135, 64, 512, 34, 256
+    sd = O.init_vqvae_state(D, H, 2, K, seed=3)
+    ea, eb = _engine(sd, D, H, K, T, 0.0), _engine(sd, D, H, K, T, 0.0)
+    x = torch.randn(B, T, D, generator=torch.Generator().manual_seed(11)).to(DEV)
+    kw = dict(lr=5e-4, w_l1=5.0, w_cont=0.1, w_var=0.5)
+    try:
+        assert lib.g2v_dec_rollout_persist_fault(1) in (0, 1, 2, 3)
+        ea.train_step(x, x, **kw); eb.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        with ea.ctx:
+            tiles_a = lib.g2v_dec_rollout_tiles_per_workgroup(B, D, H)
+        assert tiles_a >= 1, "this shape is expected on the persistent rollouts"
+        assert lib.g2v_dec_rollout_persist_fault(-1) == 1
+        ea.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="persistent rollout kernel"):
+            ea.check_faults()
+        assert ea.ctx.get(_lib.OPT_PERSISTENT) == 0 and ea.fault_policy.off
+        assert eb.ctx.get(_lib.OPT_PERSISTENT) == 1 and not eb.fault_policy.off
+        with ea.ctx:
+            assert lib.g2v_dec_rollout_tiles_per_workgroup(B, D, H) == 0
+        with eb.ctx:
+            assert lib.g2v_dec_rollout_tiles_per_workgroup(B, D, H) == tiles_a
+        # both keep training: A on the per-step launches, B on the persistent ones -- same arithmetic to rounding
+        ea.train_step(x, x, **kw); eb.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0
+        # A's policy brings A's fast path back after its clean interval
+        ea.fault_policy.rearm_after = 3
+        for _ in range(3):
+            ea.train_step(x, x, **kw)
+            if ea.fault_policy.tick():
+                ea.rearm()
+        assert ea.ctx.get(_lib.OPT_PERSISTENT) == 1 and not ea.fault_policy.off and ea.fault_policy.rearms == 1
+        ea.train_step(x, x, **kw)
+        torch.cuda.synchronize()
+        assert lib.g2v_dec_rollout_persist_fault(0) == 0
+    finally:
+        lib.g2v_dec_rollout_persist_fault(1)
