@@ -50,10 +50,10 @@ static int device_cu_count() {
   }
   return n;
 }
-static int g_persist = 1;      // g2v_dec_rollout_set_persistent (the library reads no environment variable)
-static bool persist_enabled() { return g_persist != 0; }
+// (the switch lives in the calling thread's context: g2v_ctx, G2V_OPT_PERSISTENT; the library reads no environment variable)
+static bool persist_enabled() { return g2v_internal_options().persist != 0; }
 // Row tiles per workgroup of a persistent rollout over `nblk` row tiles: 1 while there is a CU per tile, 2 or 3 beyond that
-// (dec_persist.hip, the *_mt kernels); 0: not offered.  g_persist = 2 / 3 asks for at least that many (parity tests of the
+// (dec_persist.hip, the *_mt kernels); 0: not offered.  G2V_OPT_PERSISTENT 2 / 3 asks for at least that many (parity tests of the
 // multi-tile kernels at small batches).
 constexpr int PERSIST_MAX_TILES_PER_WG = 3;
 static int persist_tiles_per_wg(int nblk) {
@@ -61,7 +61,8 @@ static int persist_tiles_per_wg(int nblk) {
   const int cus = device_cu_count() < PX_MAX_NBLK ? device_cu_count() : PX_MAX_NBLK;
   if (cus <= 0) return 0;
   int r = cdiv(nblk, cus);
-  if (g_persist > r) r = g_persist < nblk ? g_persist : (nblk > 1 ? nblk : 1);
+  const int want = g2v_internal_options().persist;
+  if (want > r) r = want < nblk ? want : (nblk > 1 ? nblk : 1);
   return r <= PERSIST_MAX_TILES_PER_WG ? r : 0;
 }
 
@@ -996,17 +997,14 @@ extern "C" int g2v_read_spans(unsigned long long* out) {
 }
 #endif
 
-int g2v_internal_persist_enabled() { return g_persist != 0 ? 1 : 0; }      // (t2e_rollout.hip: the code decoder's cluster kernel)
+int g2v_internal_persist_enabled() { return g2v_internal_options().persist != 0 ? 1 : 0; }      // (t2e_rollout.hip: the code decoder's cluster kernel)
 extern "C" int g2v_dec_rollout_blocks(int B) { return B > 0 ? cdiv(B, 16) : 0; }
 
 int g2v_internal_preclear_take(const void* p, size_t need);      // dec_persist.hip
 void g2v_internal_preclear_note(const void* p, size_t n);
 void g2v_internal_preclear_drop(const void* base, size_t bytes);
-extern "C" int g2v_dec_rollout_set_persistent(int enable) {
-  g2v_internal_preclear_drop(nullptr, 0);
-  const int prev = g_persist;
-  g_persist = enable <= 0 ? 0 : (enable > PERSIST_MAX_TILES_PER_WG ? PERSIST_MAX_TILES_PER_WG : enable);
-  return prev;
+extern "C" int g2v_dec_rollout_set_persistent(int enable) {      // = g2v_ctx_set_option(NULL, G2V_OPT_PERSISTENT, enable)
+  return g2v_ctx_set_option(nullptr, G2V_OPT_PERSISTENT, enable);
 }
 
 // reduce_partials scratch: 2048 floats (every row segment of the 512-thread generic kernels) where the LDS has room, else 1024

@@ -1739,13 +1739,9 @@ static size_t gru_split_state_floats(int ndir, int H) { return (size_t)ndir * 2 
 // The cluster kernels (gru_cluster_*_kernel): the split path's shapes while the whole grid is resident at once -- at most one
 // 192-thread workgroup per CU (the workgroups of a row group wait for each other).  g2v_gru_seq_set_cluster(0) keeps the
 // per-step launches (parity tests, A/B).
-static int g_gru_cluster = 1;
 void g2v_internal_preclear_drop(const void* base, size_t bytes);
-extern "C" int g2v_gru_seq_set_cluster(int enable) {
-  g2v_internal_preclear_drop(nullptr, 0);
-  const int prev = g_gru_cluster;
-  g_gru_cluster = enable ? 1 : 0;
-  return prev;
+extern "C" int g2v_gru_seq_set_cluster(int enable) {             // = g2v_ctx_set_option(NULL, G2V_OPT_GRU_CLUSTER, enable)
+  return g2v_ctx_set_option(nullptr, G2V_OPT_GRU_CLUSTER, enable);
 }
 static int gru_device_cus() {
   static int n = -1;
@@ -1779,7 +1775,7 @@ extern "C" int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir) {
   return (ndir >= 1 && ndir <= 2 && gru_cluster_ok(T, B, ndir, H, nullptr)) ? 1 : 0;
 }
 static bool gru_cluster_ok(int T, int B, int ndir, int H, const void* fn) {
-  if (!g_gru_cluster || !gru_split_ok(B, ndir, H) || T < 2 || T > (1 << 20)) return false;
+  if (!g2v_internal_options().gru_cluster || !gru_split_ok(B, ndir, H) || T < 2 || T > (1 << 20)) return false;
   if ((int64_t)cdiv(B, 16) * cdiv(H, 16) * ndir > gru_device_cus()) return false;
   if (fn == nullptr) return true;      // (the shape query: the occupancy check is the launch's)
   int n = 0;
