@@ -103,6 +103,7 @@ _SIGS = {
     "g2v_linear_bwd_weight_batch": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_linear_bwd_weight_batch_mapped": (c_int, [C.POINTER(WgradItem), c_int, c_i64, c_i64, c_int, c_i64, c_i64, c_int, c_int, c_int,
                                                    c_int, c_fp, c_sz, c_fp]),
+    "g2v_cluster_exchange_preclear_drop": (c_int, [c_fp, c_sz]),
     "g2v_ctx_create": (C.c_void_p, []),
     "g2v_ctx_destroy": (None, [C.c_void_p]),
     "g2v_ctx_bind": (C.c_void_p, [C.c_void_p]),

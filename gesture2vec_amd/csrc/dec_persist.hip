@@ -1162,35 +1162,7 @@ extern "C" int g2v_dec_rollout_fault_flag(float* flag, int from_flag, g2v_stream
   return G2V_OK;
 }
 
-// ---- "this exchange region is already clear" notes (g2v_cluster_exchange_preclear, dec_rollout.hip) -------------------------------------
-// A cluster launch clears its exchange records in front of the kernel: a memset node of 5-12 us on the caller's chain.  A caller whose
-// workspace nobody else writes can have that done ahead of time on a side branch; the memset is noted here by (address, bytes) and
-// the next cluster launch over exactly that region TAKES the note (one shot) instead of clearing again.  Host-side bookkeeping only
-// (under stream capture it runs once, at capture: the graph then holds the early memset node and no late one).
-struct PreclearNote { const void* p; size_t n; };
-static PreclearNote g_preclear[16];
-static int g_preclear_next = 0;
-void g2v_internal_preclear_note(const void* p, size_t n) {
-  for (auto& e : g_preclear)
-    if (e.p == p) { e.n = n; return; }
-  g_preclear[g_preclear_next] = PreclearNote{p, n};
-  g_preclear_next = (g_preclear_next + 1) % 16;
-}
-int g2v_internal_preclear_take(const void* p, size_t need) {
-  for (auto& e : g_preclear)
-    if (e.p == p && e.p != nullptr) {
-      const bool ok = e.n >= need;
-      e = PreclearNote{nullptr, 0};
-      return ok ? 1 : 0;
-    }
-  return 0;
-}
-// forget every note inside [base, base + bytes) (a launch over that workspace that does not consume one), or all of them
-void g2v_internal_preclear_drop(const void* base, size_t bytes) {
-  for (auto& e : g_preclear)
-    if (e.p != nullptr && (base == nullptr || ((const char*)e.p >= (const char*)base && (const char*)e.p < (const char*)base + bytes)))
-      e = PreclearNote{nullptr, 0};
-}
+// (the "this exchange region is already clear" notes of g2v_cluster_exchange_preclear live in the caller's context: misc.hip)
 const unsigned* g2v_internal_persist_fault_ptr() {
   static const unsigned* p = [] {
     void* q = nullptr;

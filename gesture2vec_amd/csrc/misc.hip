@@ -17,13 +17,50 @@ void set_error(const char* fmt, ...) {
 }  // namespace g2v
 
 // ---- caller-owned contexts (include/g2v.h: g2v_ctx) ------------------------------------------------------------------------------
+// "This exchange region is already clear" notes (g2v_cluster_exchange_preclear, dec_rollout.hip).  A cluster launch clears its
+// exchange records in front of the kernel: a memset node of 5-12 us on the caller's chain.  A caller whose workspace nobody else
+// writes can have that done ahead of time on a side branch; the memset is noted by (address, bytes) and the next cluster launch over
+// exactly that region TAKES the note (one shot) instead of clearing again.  Host-side bookkeeping only (under stream capture it
+// runs once, at capture: the graph then holds the early memset node and no late one -- so a note must be made and taken on the
+// same side of a capture).  Round 6: the table belongs to the caller's CONTEXT (it was one process-global table of 16 entries keyed
+// by raw device address: an engine's stale note could make another engine's launch skip its clear), and
+// g2v_cluster_exchange_preclear_drop lets the owner void notes when a step is abandoned or a workspace is freed.
+struct PreclearNote { const void* p; size_t n; };
 struct g2v_ctx {
   G2vOptions opt;
+  PreclearNote preclear[16] = {};
+  int preclear_next = 0;
 };
 static g2v_ctx g_default_ctx;
 static thread_local g2v_ctx* t_bound_ctx = nullptr;
 G2vOptions& g2v_internal_options() { return (t_bound_ctx ? t_bound_ctx : &g_default_ctx)->opt; }
-void g2v_internal_preclear_drop(const void* base, size_t bytes);      // dec_persist.hip
+static g2v_ctx& cur_ctx() { return *(t_bound_ctx ? t_bound_ctx : &g_default_ctx); }
+void g2v_internal_preclear_note(const void* p, size_t n) {
+  g2v_ctx& c = cur_ctx();
+  for (auto& e : c.preclear)
+    if (e.p == p) { e.n = n; return; }
+  c.preclear[c.preclear_next] = PreclearNote{p, n};
+  c.preclear_next = (c.preclear_next + 1) % 16;
+}
+int g2v_internal_preclear_take(const void* p, size_t need) {
+  for (auto& e : cur_ctx().preclear)
+    if (e.p == p && e.p != nullptr) {
+      const bool ok = e.n >= need;
+      e = PreclearNote{nullptr, 0};
+      return ok ? 1 : 0;
+    }
+  return 0;
+}
+// forget every note inside [base, base + bytes) (a launch over that workspace that does not consume one), or all of them
+void g2v_internal_preclear_drop(const void* base, size_t bytes) {
+  for (auto& e : cur_ctx().preclear)
+    if (e.p != nullptr && (base == nullptr || ((const char*)e.p >= (const char*)base && (const char*)e.p < (const char*)base + bytes)))
+      e = PreclearNote{nullptr, 0};
+}
+extern "C" int g2v_cluster_exchange_preclear_drop(const void* workspace, size_t workspace_bytes) {
+  g2v_internal_preclear_drop(workspace, workspace_bytes);
+  return G2V_OK;
+}
 extern "C" g2v_ctx* g2v_ctx_create(void) { return new (std::nothrow) g2v_ctx(); }
 extern "C" void g2v_ctx_destroy(g2v_ctx* ctx) {
   if (!ctx) return;

@@ -353,8 +353,9 @@ class VQVAEEngine:
                                "until the fast path is re-armed (fault_policy.py): repeat the step")
 
     def rearm(self):
-        """the fast path was switched back on (fault_policy.POLICY.tick() returned True): forget what was planned and captured
+        """the fast path was switched back on (self.fault_policy.tick() returned True): forget what was planned and captured
         for the per-step kernels"""
+        self.lib.g2v_cluster_exchange_preclear_drop(None, 0)
         self._iter_graph = None
         self._open.clear()
         self._deferred.clear()
@@ -1259,6 +1260,10 @@ class VQVAEEngine:
         finally:
             self._prepared = False
             self._side_work = None
+            if self._xch_pre:
+                # a step that ended early (an exception between the pre-clear and the cluster launches) must not leave its
+                # "already clear" notes behind: the next launch over those workspaces clears for itself (advisor finding)
+                self.lib.g2v_cluster_exchange_preclear_drop(None, 0)
             self._xch_pre = False
             self._fused_in_drop = False
             self._defer_commit = False

@@ -75,7 +75,7 @@ int g2v_linear_set_smallm_rows(int rows);
  * g2v_linear_set_smallm_rows, g2v_dec_rollout_set_persistent and g2v_gru_seq_set_cluster are the same calls with ctx = NULL.
  * A thread that never binds a context behaves as before (one set of switches per process, in the default context).
  * What stays process-wide: one device-side error latch, g2v_dec_rollout_persist_fault (below) -- a fault of the DEVICE, not an
- * option -- and the "already clear" notes of g2v_cluster_exchange_preclear. */
+ * option -- . (The "already clear" notes of g2v_cluster_exchange_preclear belong to the bound context too.) */
 typedef struct g2v_ctx g2v_ctx;
 #define G2V_OPT_PERSISTENT 1
 #define G2V_OPT_GRU_CLUSTER 2
@@ -353,6 +353,10 @@ int g2v_gru_seq_cluster_ok(int T, int B, int H, int ndir);
  * not run as a cluster, and either of the two switches above, forget the note. */
 int g2v_cluster_exchange_preclear(int kind, int T, int B, int D, int H, int ndir, void* workspace, size_t workspace_bytes,
                                   g2v_stream_t stream);
+/* Void the "already clear" notes of the calling thread's context that lie inside [workspace, workspace + workspace_bytes)
+ * (workspace = NULL: all of them): for an owner that abandons a step between g2v_cluster_exchange_preclear and the launch that
+ * would have taken the note, or frees / re-purposes the workspace.  The notes belong to the bound context (g2v_ctx above). */
+int g2v_cluster_exchange_preclear_drop(const void* workspace, size_t workspace_bytes);
 
 /* Up to 2 directions per call run in ONE launch (the two directions of a bidirectional layer are independent). */
 size_t g2v_gru_seq_fwd_workspace(int ndir, int H);   /* W_hh in MFMA fragment order */
