@@ -75,7 +75,7 @@ int g2v_linear_set_smallm_rows(int rows);
  * g2v_linear_set_smallm_rows, g2v_dec_rollout_set_persistent and g2v_gru_seq_set_cluster are the same calls with ctx = NULL.
  * A thread that never binds a context behaves as before (one set of switches per process, in the default context).
  * What stays process-wide: one device-side error latch, g2v_dec_rollout_persist_fault (below) -- a fault of the DEVICE, not an
- * option -- . (The "already clear" notes of g2v_cluster_exchange_preclear belong to the bound context too.) */
+ * option.  (The "already clear" notes of g2v_cluster_exchange_preclear belong to the bound context too.) */
 typedef struct g2v_ctx g2v_ctx;
 #define G2V_OPT_PERSISTENT 1
 #define G2V_OPT_GRU_CLUSTER 2
