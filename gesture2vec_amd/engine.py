@@ -129,8 +129,11 @@ class VQVAEEngine:
         # relative error on dW instead of 3e-7; -0.17 ms / step at the BASELINE shape).  Default: exact fp32 MFMA.
         self.wgrad_bf16x3 = False
         # Round 6: the slab reductions of a branch's weight-gradient products as ONE launch at the branch's end (_DeferredReductions)
-        # instead of one behind every product.  G2V_DEFER_REDUCE=0: the immediate calls (A/B; results are bitwise the same).
-        self.defer_reduce = os.environ.get("G2V_DEFER_REDUCE", "1") != "0"
+        # instead of one behind every product (the round-5 verdict's "deferred slab reductions").  Built, bitwise the same results,
+        # and measured: 1.554-1.559 ms against 1.537-1.546 with the immediate calls (same box, 3 x 300 steps,
+        # profiles/r06_c_defer_ab.log) -- the decoder branch's products then run entirely beside the encoder BPTT, which starves
+        # them, instead of partly behind it.  OFF by default; G2V_DEFER_REDUCE=1 / eng.defer_reduce = True select it.
+        self.defer_reduce = os.environ.get("G2V_DEFER_REDUCE", "0") != "0"
         self.D, self.H, self.L, self.K, self.T = D, H, L, K, T
         self.E = H * L
         self.beta, self.p, self.n_pre, self.conditioned = float(beta), float(dropout_prob), int(n_pre_poses), bool(conditioned)

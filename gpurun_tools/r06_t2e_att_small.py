@@ -1,0 +1,34 @@
+"""Round 6: Part d WITH attention at the reference's batch (B = 128): the per-operator decoder (default below 1024 rows) against
+the fused per-step kernels (rollout_t2e.FUSED_MIN_ROWS lowered) -- graph replay, ms per iteration; and the kernel census of one
+iteration of either."""
+import argparse, os, sys, time, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import numpy as np, torch
+from gesture2vec_amd import rollout_t2e
+from gesture2vec_amd.flat import FlatClipAdam
+from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+from gesture2vec_amd.train_eval.train_seq2seq import GraphedText2EmbeddingStep
+from train_text2embedding import SyntheticSentences
+out = []
+for B in (128, 256, 512):
+    for minrows in (1024, 16):
+        rollout_t2e.FUSED_MIN_ROWS = minrows
+        args = argparse.Namespace(hidden_size=200, n_layers=2, dropout_prob=0.2, autoencoder_vq_components=512, autoencoder_att="True",
+                                  n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True", batch_size=B)
+        torch.manual_seed(0)
+        net = text2embedding_model(args, 512, 20, 3863, 300, np.random.RandomState(0).randn(3863, 300).astype(np.float32), None).to("cuda:0")
+        net.train(True)
+        opt = FlatClipAdam(net.parameters(), lr=5e-4)
+        data = list(SyntheticSentences(args, 3863, 1, seed=1))[0]
+        ids, lengths, codes = data[0].to("cuda:0"), data[1], data[6].to("cuda:0")
+        f0 = rollout_t2e.FUSED_CALLS
+        g = GraphedText2EmbeddingStep(args, net, opt, ids, lengths, codes, static_lengths=True, check_every=0)
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize(); t0 = time.perf_counter(); n = 50
+        for _ in range(n):
+            g.replay()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        out.append(dict(B=B, fused_min_rows=minrows, fused=rollout_t2e.FUSED_CALLS > f0, ms=round(dt / n * 1e3, 4), loss=round(g.read_loss(), 4)))
+        print(json.dumps(out[-1]), flush=True)
