@@ -189,6 +189,8 @@ _SIGS = {
     "g2v_batchnorm_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
     "g2v_bn_running_update_invstd": (c_int, [c_fp, c_fp, c_i64, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_batchnorm_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),
+    "g2v_batchnorm_bwd_steps": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_one_hot_rows": (c_int, [c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
     "g2v_cross_entropy_fwd_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_f, c_fp]),
     "g2v_argmax_rows": (c_int, [c_fp, c_i64, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_soft_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),

@@ -26,8 +26,9 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
 // ---- embedding gradient: d_table[v, :] (+)= sum over the tokens r with ids[r] == v of d_out[r, :] * keep * scale --------------
 // No float atomics (round 1 used atomicAdd here, the one kernel of the library whose output depended on arrival order) and no
 // serial walk over a hot row either (a padded batch sends half of all tokens to row 0).
-//   n <= EMB_SMALL_N tokens (the code decoder's per-step lookup at small batch): ONE launch, a wave owns a table row, finds its
-//     tokens with a ballot scan over the ids and adds them in token order.
+//   n <= EMB_SMALL_N tokens (the code decoder's per-step lookup at small batch; round 6: also the word table at the reference's
+//     batch size, 1.5 k packed tokens at B = 128 -- there the sorted form's eight launches were 55 us of a 0.7 ms iteration):
+//     ONE launch, a workgroup owns a table row, finds its tokens with a ballot scan over the ids and adds them in token order.
 //   otherwise the tokens are counting-sorted by table row, STABLY, in O(n) work --
 //       emb_rank_kernel     blocks of 1024 tokens: rank of every token among the equal ids before it in its block (ids held in
 //                           LDS, broadcast compares); (block, row) counts by integer atomicMax of rank + 1
@@ -40,7 +41,7 @@ __global__ void embedding_fwd_kernel(const float* __restrict__ table, const int6
 //                           the chunk goes to partial slot 0, the one that continues beyond it to slot 1
 //       emb_row_finish      rows without tokens are zeroed (overwrite mode); rows that span chunks sum their partials
 //   Either way a fixed summation tree: bitwise reproducible, with ~n / chunk waves of parallelism whatever the id distribution.
-constexpr int EMB_SMALL_N = 1024;
+constexpr int EMB_SMALL_N = 2048;
 constexpr int EMB_TB = 1024;        // tokens per ranking block
 constexpr int EMB_MAX_CHUNK = 128;
 
@@ -76,12 +77,38 @@ __device__ __forceinline__ void emb_load_row(float (&g)[NE], const float* __rest
   }
 }
 
-template <int NE, bool KEEP>     // elements per lane: dim <= 64 * NE.  One workgroup per table row; its 4 waves split the tokens
-__global__ __launch_bounds__(256) void emb_owner_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
-                                                        const uint8_t* __restrict__ keep, float scale,
-                                                        float* __restrict__ d_table, int n, int dim, int64_t V, int accumulate) {
-  constexpr int U = NE <= 5 ? 8 : (NE <= 8 ? 4 : 2);
-  __shared__ float comb[3][64 * NE];
+// the next (up to) U tokens of the ballot mask m, added to acc in token order
+template <int NE, bool KEEP, int U>
+__device__ __forceinline__ void emb_take(unsigned long long& m, float (&acc)[NE], const float* __restrict__ d_out,
+                                         const uint8_t* __restrict__ keep, float scale, int r0, int dim, int lane) {
+  float g[U][NE];
+  bool ok[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    ok[u] = m != 0;
+    const int j = ok[u] ? __builtin_ctzll(m) : 0;
+    m &= m - 1;
+    emb_load_row<NE, KEEP>(g[u], d_out, keep, scale, (int64_t)(r0 + j) * dim, dim, lane, ok[u]);
+  }
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+    if (ok[u]) {
+#pragma unroll
+      for (int k = 0; k < NE; ++k) acc[k] += g[u][k];
+    }
+}
+
+// elements per lane: dim <= 64 * NE.  One workgroup per table row; its EMB_OW waves split the tokens.  (Round 6: 8 waves and up to
+// 16 rows in flight per wave instead of 4 and 8 -- the greedy feedback of an untrained code decoder sends most of a step's tokens
+// to a handful of codes, and a hot row is a serial chain of load rounds per wave: 640 tokens on one row 44 -> 14 us.)
+constexpr int EMB_OW = 8;
+template <int NE, bool KEEP>
+__global__ __launch_bounds__(64 * EMB_OW) void emb_owner_kernel(const float* __restrict__ d_out, const int64_t* __restrict__ ids,
+                                                                const uint8_t* __restrict__ keep, float scale,
+                                                                float* __restrict__ d_table, int n, int dim, int64_t V,
+                                                                int accumulate) {
+  constexpr int U = NE <= 5 ? 16 : (NE <= 8 ? 8 : 4);
+  __shared__ float comb[EMB_OW - 1][64 * NE];
   __shared__ int any_hit;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t v = blockIdx.x;
@@ -90,28 +117,15 @@ __global__ __launch_bounds__(256) void emb_owner_kernel(const float* __restrict_
   float acc[NE];
 #pragma unroll
   for (int k = 0; k < NE; ++k) acc[k] = 0.f;
-  const int per = (n + 3) / 4, lo = wave * per < n ? wave * per : n, hi = lo + per < n ? lo + per : n;
+  const int per = (n + EMB_OW - 1) / EMB_OW, lo = wave * per < n ? wave * per : n, hi = lo + per < n ? lo + per : n;
   bool hit = false;
   for (int r0 = lo; r0 < hi; r0 += 64) {
     const int r = r0 + lane;
     unsigned long long m = __ballot(r < hi && ids[r < hi ? r : lo] == v);
     hit |= m != 0;
-    while (m) {
-      float g[U][NE];
-      bool ok[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        ok[u] = m != 0;
-        const int j = ok[u] ? __builtin_ctzll(m) : 0;
-        m &= m - 1;
-        emb_load_row<NE, KEEP>(g[u], d_out, keep, scale, (int64_t)(r0 + j) * dim, dim, lane, ok[u]);
-      }
-#pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (ok[u]) {
-#pragma unroll
-          for (int k = 0; k < NE; ++k) acc[k] += g[u][k];
-        }
+    while (m) {                 // (m is wave-uniform: a few tokens take the narrow round, a hot row the wide one)
+      if (__popcll(m) > 4) emb_take<NE, KEEP, U>(m, acc, d_out, keep, scale, r0, dim, lane);
+      else emb_take<NE, KEEP, 4>(m, acc, d_out, keep, scale, r0, dim, lane);
     }
   }
   if (hit && lane == 0) any_hit = 1;
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(256) void emb_owner_kernel(const float* __restrict_
   __syncthreads();
   if (wave == 0) {
 #pragma unroll
-    for (int w = 0; w < 3; ++w)
+    for (int w = 0; w < EMB_OW - 1; ++w)
 #pragma unroll
       for (int k = 0; k < NE; ++k) acc[k] += comb[w][lane + 64 * k];
     emb_store_row<NE>(d_table + v * dim, acc, dim, lane, accumulate);
@@ -426,6 +440,61 @@ __global__ __launch_bounds__(256) void bn_bwd_kernel(const float* __restrict__ d
   });
 }
 
+// The same over the `steps` calls of a decode loop whose gradients arrive together (Part d behind the cluster BPTT: nothing of
+// BatchNorm's backward feeds the recurrence): ONE launch, a workgroup walks its 4 features through the steps in call order and
+// leaves the parameters' gradients SUMMED over the steps (what autograd's accumulation over the loop's T-1 nodes produces) --
+// it replaces steps launches + two reductions; dx of a step is bitwise bn_bwd_kernel's.
+__global__ __launch_bounds__(256) void bn_bwd_steps_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ y, const float* __restrict__ w,
+                                                           const float* __restrict__ save_mean,
+                                                           const float* __restrict__ save_invstd, int64_t stat_stride, int relu,
+                                                           float* __restrict__ dx, float* __restrict__ dw,
+                                                           float* __restrict__ db, int steps, int B, int H) {
+  __shared__ float red[BN_RL][BN_FB + 1];
+  const int fl = threadIdx.x & (BN_FB - 1), rl = threadIdx.x / BN_FB;
+  const int f = blockIdx.x * BN_FB + fl;
+  const bool fv = f < H;
+  const int fc = fv ? f : 0;
+  const float wf = w[fc], invB = 1.0f / (float)B;
+  float dws = 0.f, dbs = 0.f;
+  for (int s = 0; s < steps; ++s) {
+    const int64_t base = (int64_t)s * B * H;
+    const float mean = save_mean[s * stat_stride + fc], invstd = save_invstd[s * stat_stride + fc];
+    float s1 = 0.f, s2 = 0.f;
+    bn_rows(rl, B, [&](int r) {
+      const int64_t e = base + (int64_t)r * H + fc;
+      float g = dy[e];
+      if (relu && !(y[e] > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * ((x[e] - mean) * invstd);
+    });
+    const float S1 = bn_block_sum(s1, red, rl, fl);
+    const float S2 = bn_block_sum(s2, red, rl, fl);
+    dbs += S1;
+    dws += S2;
+    if (fv) {
+      const float g0 = wf * invstd;
+      bn_rows(rl, B, [&](int r) {
+        const int64_t e = base + (int64_t)r * H + f;
+        float g = dy[e];
+        if (relu && !(y[e] > 0.f)) g = 0.f;
+        const float xhat = (x[e] - mean) * invstd;
+        dx[e] = g0 * (g - S1 * invB - xhat * S2 * invB);
+      });
+    }
+  }
+  if (fv && rl == 0) { db[f] = dbs; dw[f] = dws; }
+}
+
+// out[r, :] = one_hot(ids[r]) (row r at out + r * ld): slot 0 of Part d's outputs (reference :676-677) without a fill + a scatter
+__global__ __launch_bounds__(256) void one_hot_rows_kernel(const int64_t* __restrict__ ids, float* __restrict__ out, int64_t ld,
+                                                           int M, int K) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * K) return;
+  const int r = (int)(i / K), k = (int)(i - (int64_t)r * K);
+  out[(int64_t)r * ld + k] = ids[r] == (int64_t)k ? 1.0f : 0.0f;
+}
+
 // Large batch (B >= 1024): the kernel above gives the whole batch to H / 4 workgroups and reads 16 bytes per row and thread
 // group (81 us at B = 4096, H = 200: 50 workgroups on a 256-CU chip, a quarter of every fetched line used).  Three short launches
 // instead, every load a full row segment: (1) per 16-row block, thread <-> feature: partial sums of g and g * xhat; (2) the
@@ -719,10 +788,10 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
 #define G2V_EMB_OWNER(NE)                                                                                                    \
   do {                                                                                                                       \
     if (keep)                                                                                                                \
-      hipLaunchKernelGGL((emb_owner_kernel<NE, true>), dim3((unsigned)V), dim3(256), 0, st, d_out, ids, keep, scale, d_table, \
+      hipLaunchKernelGGL((emb_owner_kernel<NE, true>), dim3((unsigned)V), dim3(64 * EMB_OW), 0, st, d_out, ids, keep, scale, d_table, \
                          (int)n, dim, V, acc);                                                                               \
     else                                                                                                                     \
-      hipLaunchKernelGGL((emb_owner_kernel<NE, false>), dim3((unsigned)V), dim3(256), 0, st, d_out, ids, keep, scale,        \
+      hipLaunchKernelGGL((emb_owner_kernel<NE, false>), dim3((unsigned)V), dim3(64 * EMB_OW), 0, st, d_out, ids, keep, scale,        \
                          d_table, (int)n, dim, V, acc);                                                                      \
   } while (0)
     G2V_EMB_DISPATCH(G2V_EMB_OWNER);
@@ -825,6 +894,27 @@ extern "C" int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y
   }
   hipLaunchKernelGGL(bn_bwd_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
                      save_invstd, relu, dx, dw, db, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_batchnorm_bwd_steps(const float* dy, const float* x, const float* y, const float* weight,
+                                       const float* save_mean, const float* save_invstd, int64_t stat_stride, int relu, float* dx,
+                                       float* dw, float* db, int steps, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(dy && x && weight && save_mean && save_invstd && dx && dw && db, "null pointer");
+  G2V_REQUIRE(!relu || y, "y required for the ReLU mask");
+  G2V_REQUIRE(steps > 0 && B > 0 && H > 0 && stat_stride >= H, "bad size");
+  G2V_REQUIRE(B < 1024, "1024 rows or more per step: call g2v_batchnorm_bwd per step (its large-batch kernels)");
+  hipLaunchKernelGGL(bn_bwd_steps_kernel, dim3(cdiv(H, BN_FB)), dim3(256), 0, (hipStream_t)stream, dy, x, y, weight, save_mean,
+                     save_invstd, stat_stride, relu, dx, dw, db, steps, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+extern "C" int g2v_one_hot_rows(const int64_t* ids, float* out, int64_t ld, int M, int K, g2v_stream_t stream) {
+  G2V_REQUIRE(ids && out, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && ld >= K, "bad size");
+  hipLaunchKernelGGL(one_hot_rows_kernel, dim3(cdiv((int64_t)M * K, 256)), dim3(256), 0, (hipStream_t)stream, ids, out, ld, M, K);
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

@@ -53,15 +53,25 @@ class FlatParams:
         src, dst, ns = [], [], []
         self.skipped = []
         base = self.gflat.data_ptr()
-        for p, o in zip(self.params, self.offsets):
+        if getattr(self, "_had_grad", None) is None:
+            self._had_grad = [False] * len(self.params)
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             g = p.grad
             if g is not None:
                 if g.dtype != torch.float32 or not g.is_contiguous():
                     g = g.contiguous().float()
                     p.grad = g
                 src.append(g.data_ptr())
+                self._had_grad[i] = True
             else:
                 src.append(None)
+                if not self._had_grad[i]:
+                    # never received a gradient: its moments are exactly zero, and the fused step with g = m = v = 0 writes
+                    # m = v = 0 and p - lr * 0 / (0 + eps) = p back -> nothing to keep (Part d without attention: the
+                    # encoder's second layer, every iteration)
+                    dst.append(base + 4 * o)
+                    ns.append(p.numel())
+                    continue
                 span = (p.numel() + 3) // 4 * 4
                 if self.skipped and self.skipped[-1][0] + self.skipped[-1][1] == o:
                     self.skipped[-1] = (self.skipped[-1][0], self.skipped[-1][1] + span)

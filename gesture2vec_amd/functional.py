@@ -71,24 +71,29 @@ def linear(x, weight, bias=None, keep=None, scale=1.0, act=0):
 
 
 class LinearPairFn(torch.autograd.Function):
-    """(x W_a^T + b_a, x W_b^T + b_b): the two directions' input projections of a bidirectional GRU layer on the same input, no
-    mask -- one launch forward where that pays (ops.linear_fwd_pair: bitwise two linear_fwd calls), the two weight gradients as
-    one batched launch, dx = g_a W_a + g_b W_b accumulated in place."""
+    """(x W_a^T + b_a, x W_b^T + b_b): the two directions' input projections of a bidirectional GRU layer on the same input --
+    one launch forward where that pays (ops.linear_fwd_pair: bitwise two linear_fwd calls), the two weight gradients as one
+    batched launch, dx = g_a W_a + g_b W_b accumulated in place.  keep / scale (round 6): nn.GRU's inter-layer dropout on the
+    shared input -- x * keep * scale is formed ONCE (the two LinearFn nodes it replaces each masked it in their forward, their
+    weight-gradient and their dx launch, and autograd added the two dx), so the mask-free kernels of both passes apply."""
 
     @staticmethod
-    def forward(ctx, x, w_a, b_a, w_b, b_b):
+    def forward(ctx, x, w_a, b_a, w_b, b_b, keep=None, scale=1.0):
         N, K = w_a.shape
         xs = x.contiguous().view(-1, K)
+        if keep is not None:
+            keep = keep.contiguous().view(-1, K)
+            xs = ops.mask_mul(xs, keep, scale, positive_of=False)
         w_a, w_b = w_a.contiguous(), w_b.contiguous()
         ya, yb = ops.linear_fwd_pair(xs, w_a, b_a, w_b, b_b)
-        ctx.save_for_backward(xs, w_a, w_b)
-        ctx.xshape = x.shape
+        ctx.save_for_backward(xs, w_a, w_b, keep)
+        ctx.xshape, ctx.scale = x.shape, float(scale)
         ctx.set_materialize_grads(False)
         return ya.view(*x.shape[:-1], N), yb.view(*x.shape[:-1], N)
 
     @staticmethod
     def backward(ctx, ga, gb):
-        xs, w_a, w_b = ctx.saved_tensors
+        xs, w_a, w_b, keep = ctx.saved_tensors
         N, K = w_a.shape
         dx, out, items = None, [], []
         for g, w in ((ga, w_a), (gb, w_b)):
@@ -107,7 +112,9 @@ class LinearPairFn(torch.autograd.Function):
             out += [dw, db]
         if items:
             ops.linear_bwd_weight_batch(items, N, K, M=xs.shape[0])
-        return (dx.view(ctx.xshape) if dx is not None else None), out[0], out[1], out[2], out[3]
+        if dx is not None and keep is not None:
+            dx = ops.mask_mul(dx, keep, ctx.scale, positive_of=False)
+        return (dx.view(ctx.xshape) if dx is not None else None), out[0], out[1], out[2], out[3], None, None
 
 
 class MseFn(torch.autograd.Function):
@@ -269,11 +276,14 @@ class GRUBiDirFn(torch.autograd.Function):
         gi_f, gi_b, w_f, w_b = gi_f.contiguous(), gi_b.contiguous(), w_f.contiguous(), w_b.contiguous()
         out = []
         dirs = []
+        # one extra zero step in front of (behind, for the reverse direction) the states: the BPTT's weight-gradient product
+        # reads "the state before step t" as a VIEW of the same buffer (it was two 65 MB cat copies per call at B = 4096).
+        # Both directions in one allocation, reverse first: its zero step (the last) and the forward's (the first) are adjacent
+        # -> one fill.
+        both = torch.empty((2, T + 1, B, H), dtype=torch.float32, device=dev)
+        both.view(2 * (T + 1), B, H)[T:T + 2].zero_()
         for gi, w, b, rev in ((gi_f, w_f, b_f, False), (gi_b, w_b, b_b, True)):
-            # one extra zero step in front of (behind, for the reverse direction) the states: the BPTT's weight-gradient product
-            # reads "the state before step t" as a VIEW of the same buffer (it was two 65 MB cat copies per call at B = 4096)
-            full = torch.empty((T + 1, B, H), dtype=torch.float32, device=dev)
-            full[T if rev else 0].zero_()
+            full = both[0 if rev else 1]
             hs = full[:T] if rev else full[1:]
             h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
             gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
@@ -331,7 +341,7 @@ class CrossEntropyFn(torch.autograd.Function):
             loss, dl = ops.cross_entropy_fwd_bwd(lg, tg, want_grad=True)
         ctx.save_for_backward(dl)
         ctx.shape = logits.shape
-        return loss[0].clone()
+        return loss.view(())          # (a fresh one-element array per call: no copy needed)
 
     @staticmethod
     def backward(ctx, g):

@@ -107,12 +107,10 @@ class EncoderRNN(nn.Module):
             if l == 0 and via_table:
                 gis = list(Fn.EmbedProjectPairFn.apply(self.embedding.weight, ids_flat, g.weight_ih_l0, g.bias_ih_l0,
                                                        g.weight_ih_l0_reverse, g.bias_ih_l0_reverse))
-            elif keep is None:      # no mask on the layer's input: both directions' projections as one Function (one launch each way)
+            else:                   # both directions' projections as one Function (the inter-layer dropout applied once)
                 gis = list(Fn.LinearPairFn.apply(layer_in, getattr(g, f"weight_ih_l{l}"), getattr(g, f"bias_ih_l{l}"),
-                                                 getattr(g, f"weight_ih_l{l}_reverse"), getattr(g, f"bias_ih_l{l}_reverse")))
-            else:
-                gis = [Fn.linear(layer_in, getattr(g, f"weight_ih_l{l}{suf}"), getattr(g, f"bias_ih_l{l}{suf}"),
-                                 keep=keep, scale=scale) for suf in ("", "_reverse")]
+                                                 getattr(g, f"weight_ih_l{l}_reverse"), getattr(g, f"bias_ih_l{l}_reverse"),
+                                                 keep, scale))
             if pk is None:
                 gis = [gi.view(Tw, B, 3 * H) for gi in gis]
             # both directions of the layer in one launch (each way)
@@ -253,6 +251,16 @@ class text2embedding_model(nn.Module):
             self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
         return ops.keep_mask(torch.empty(shape, dtype=torch.uint8, device=dev), keep_prob, self.rng_seed, self._rng_counter)
 
+    def _draw_many(self, want, dev):
+        """The masks of one forward, each at its own Philox offset (counter, counter + 1, ...: what consecutive _draw calls use),
+        and ONE counter bump behind them instead of one per mask."""
+        if self._rng_counter is None or self._rng_counter.device != dev:
+            self._rng_counter = torch.zeros(1, dtype=torch.int64, device=dev)
+        masks = [ops.keep_mask_at(torch.empty(shape, dtype=torch.uint8, device=dev), kp, self.rng_seed, self._rng_counter, k)
+                 for k, (shape, kp) in enumerate(want)]
+        ops.counter_add(self._rng_counter, len(want))
+        return masks
+
     def forward(self, in_text, in_lengths, in_audio, poses, GPT3_embeddings, vid_indices):
         if not in_text.is_cuda:
             raise RuntimeError("text2embedding_model runs on the MI355X kernels only (no CPU fallback)")
@@ -271,11 +279,12 @@ class text2embedding_model(nn.Module):
             if self._masks is not None:
                 mask_emb, mask_l0, mask_enc = self._masks
             else:
-                mask_emb = self._draw((S_model - 1, B, H), 0.5, dev)
+                want = [((S_model - 1, B, H), 0.5)]
                 if self.dropout_prob > 0:
-                    mask_l0 = self._draw((S_model - 1, B, H), 1.0 - self.dropout_prob, dev)
+                    want.append(((S_model - 1, B, H), 1.0 - self.dropout_prob))
                     if att and L > 1:
-                        mask_enc = self._draw((Tw, B, 2 * H), 1.0 - self.dropout_prob, dev)
+                        want.append(((Tw, B, 2 * H), 1.0 - self.dropout_prob))
+                mask_emb, mask_l0, mask_enc = (self._draw_many(want, dev) + [None, None])[:3]
         if att:
             # attention reads encoder_outputs = sum of the LAST layer's directions (:133-135): every layer is evaluated
             enc_out, enc_hidden = self.encoder(ids, in_lengths, None, keep_inter=mask_enc)
@@ -284,7 +293,8 @@ class text2embedding_model(nn.Module):
             # the attention-free decoder reads only encoder_hidden[:L] = the layer-0 final states (:667-669)
             _, enc_hidden = self.encoder(ids, in_lengths, None, n_layers_needed=1, want_outputs=False)
             enc_out = enc_proj = None
-        hidden = enc_hidden[:L]
+        # (a slice that keeps everything still costs a zero fill + a copy in its backward)
+        hidden = enc_hidden[:L] if enc_hidden.shape[0] != L else enc_hidden
         if training and vid_indices is None and self.fused_rollout and S_model > 1:
             dec = self.decoder.decoder
             bn = dec.pre_linear[1]
@@ -297,6 +307,7 @@ class text2embedding_model(nn.Module):
             # the step-major array behind the view: train_iter_text2embedding takes its loss on it directly (the reference's
             # outputs[:, 1:, :].reshape(-1, K) on the view is a 50 MB strided copy each way at B = 4096)
             outputs._g2v_step_major = full
+            outputs._g2v_targets = cod          # (S,B): the loss's targets in the same step-major order (train_seq2seq._code_loss_backward)
             return outputs, attentions_list
         outs: List[torch.Tensor] = [F.one_hot(cod[0], K).to(torch.float32)]          # :676-677
         dec_in = cod[0]

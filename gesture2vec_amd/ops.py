@@ -618,6 +618,17 @@ def keep_mask(out_u8, keep_prob, seed, offset_counter):
     return out_u8
 
 
+def keep_mask_at(out_u8, keep_prob, seed, offset_counter, offset_add):
+    """the mask keep_mask would draw after `offset_add` earlier draws, without bumping the counter (counter_add does, once)"""
+    check(_lib_().g2v_keep_mask_at(_p(_chk(out_u8, torch.uint8)), out_u8.numel(), float(keep_prob), int(seed),
+                                   _p(offset_counter), int(offset_add), _stream()), "keep_mask_at")
+    return out_u8
+
+
+def counter_add(counter, n):
+    check(_lib_().g2v_counter_add(_p(_chk(counter, torch.int64)), int(n), _stream()), "counter_add")
+
+
 def fill(t, v):
     check(_lib_().g2v_fill_f32(_p(t), float(v), t.numel(), _stream()), "fill")
     return t
@@ -705,6 +716,28 @@ def bn_running_update_invstd(save_mean, save_invstd, step_stride, running_mean, 
     no running statistics; a no-op on the device while the persistent kernels' fault latch is set (include/g2v.h)."""
     check(_lib_().g2v_bn_running_update_invstd(_p(save_mean), _p(save_invstd), int(step_stride), _p(running_mean), _p(running_var),
                                                int(steps), int(H), int(B), _stream()), "bn_running_update_invstd")
+
+
+def batchnorm_bwd_steps(dy, x, y, weight, save_mean, save_invstd, relu=True):
+    """BatchNorm's backward of the `steps` calls of a decode loop in one launch: dy, x, y (steps,B,H), save_* (steps,H) ->
+    dx (steps,B,H) and the parameters' gradients summed over the steps (include/g2v.h: g2v_batchnorm_bwd_steps; B < 1024)."""
+    S, B, H = x.shape
+    dx = torch.empty_like(x)
+    dw = torch.empty((H,), dtype=torch.float32, device=x.device)
+    db = torch.empty((H,), dtype=torch.float32, device=x.device)
+    if save_mean.stride(1) != 1 or save_invstd.stride(1) != 1 or save_mean.stride(0) != save_invstd.stride(0):
+        raise ValueError("save_mean / save_invstd: rows of H contiguous floats at one common row stride")
+    check(_lib_().g2v_batchnorm_bwd_steps(_p(_chk(dy)), _p(_chk(x)), _p(_chk(y)), _p(weight), _p(save_mean), _p(save_invstd),
+                                          int(save_mean.stride(0)), int(relu), _p(dx), _p(dw), _p(db), S, B, H, _stream()),
+          "batchnorm_bwd_steps")
+    return dx, dw, db
+
+
+def one_hot_rows(ids, K, out):
+    """out[r, :] = one_hot(ids[r]) (float32; out a (M,K) view with contiguous rows)"""
+    check(_lib_().g2v_one_hot_rows(_p(_chk(ids, torch.int64)), _p(out), int(out.stride(0)), int(ids.numel()), int(K), _stream()),
+          "one_hot_rows")
+    return out
 
 
 def batchnorm_bwd(dy, x, y, weight, save_mean, save_invstd, relu=True, out=None):

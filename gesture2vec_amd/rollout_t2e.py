@@ -169,8 +169,7 @@ def _outputs_buffer(spec: RolloutSpec, S1, B, K, dev):
     """The model's `outputs` in step-major order, (S1 + 1, B, K): slot 0 = one_hot(codes[0]) (reference :676-677), slots 1.. =
     the decode steps' logits, written in place by the kernels (it used to be a torch.cat of the two: a 110 MB copy at B = 4096)."""
     full = torch.empty((S1 + 1, B, K), dtype=torch.float32, device=dev)
-    full[0].zero_()
-    full[0].scatter_(1, spec.cod[0].view(B, 1), 1.0)
+    ops.one_hot_rows(spec.cod[0], K, full[0])
     return full
 
 
@@ -299,26 +298,34 @@ class CodeDecoderRollout(torch.autograd.Function):
         M = S1 * B
         dLOG = dLOG.contiguous()
         DH_top = ops.linear_bwd_data(dLOG.view(M, K), b["out_w"]).view(S1, B, H)        # every step's dLogits W_out at once
-        carry = [torch.zeros((B, H), dtype=torch.float32, device=dev) for _ in range(L)]   # dLoss / d(previous state), per layer
-        carry_next = [f32(B, H) for _ in range(L)]
+        cl = getattr(ctx, "cluster", None)
+        cluster_bptt = cl is not None and CLUSTER_BACKWARD and not att
+        if not cluster_bptt:
+            carry = [torch.zeros((B, H), dtype=torch.float32, device=dev) for _ in range(L)]   # dLoss / d(previous state), per layer
+            carry_next = [f32(B, H) for _ in range(L)]
         DGI = [f32(S1, B, 3 * H) for _ in range(L)]
         DGH = [f32(S1, B, 3 * H) for _ in range(L)]
-        DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
+        if not cluster_bptt:
+            DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
         DXs = [f32(B, H) for _ in range(L)]                             # gradient w.r.t. each layer's input
         if att:
             DEC, DHP = f32(S1, B, Hin), f32(S1, B, H)
             D_EP, D_ENC, D_V = torch.empty_like(b["EP"]), torch.empty_like(b["enc"]), f32(H)
-        cl = getattr(ctx, "cluster", None)
-        if cl is not None and CLUSTER_BACKWARD and not att:
+        if cluster_bptt:
             # small batch (round 5): the cells' BPTT as ONE persistent cluster launch (include/g2v.h: g2v_code_cluster_bptt); BatchNorm's
             # backward per step behind it (nothing there feeds the recurrence: the greedy feedback carries no gradient)
             global CLUSTER_BPTT_CALLS
             CLUSTER_BPTT_CALLS += 1
             DGI[0], DGH[0], DGI[1], DGH[1], DA, d_h0 = ops.code_cluster_bptt(DH_top, cl["wd"], cl["sv"], b["mask_l0"], cl["p"], S1, B, H)
-            for t in range(S1):
-                ops.batchnorm_bwd(DA[t], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
-            carry = [d_h0[0], d_h0[1]]
-        for t in (reversed(range(S1)) if not (cl is not None and CLUSTER_BACKWARD and not att) else ()):
+            if B < 1024:     # every step's BatchNorm backward + the sums over the steps: one launch
+                DU, d_bn_w, d_bn_b = ops.batchnorm_bwd_steps(DA, b["U"], b["A"], bn_w, b["SM"], b["SI"], True)
+            else:
+                DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
+                for t in range(S1):
+                    ops.batchnorm_bwd(DA[t], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
+                d_bn_w, d_bn_b = DBW.sum(0), DBB.sum(0)
+            d_hidden0 = d_h0
+        for t in (reversed(range(S1)) if not cluster_bptt else ()):
             d_in = DH_top[t]                                             # gradient arriving at Hs[l][t+1] from above
             for l in reversed(range(L)):
                 w_ih, w_hh = gru[l][0], gru[l][1]
@@ -363,7 +370,9 @@ class CodeDecoderRollout(torch.autograd.Function):
             g_gru += [dw_ih, dw_hh, db_ih, db_hh]
         for k in range(0, len(items), 4):
             ops.linear_bwd_weight_batch(items[k:k + 4], 3 * H, H, M=M)
-        grads = [d_emb, d_pre_w, d_pre_b, DBW.sum(0), DBB.sum(0)] + g_gru + [d_out_w, d_out_b]
+        if not cluster_bptt:
+            d_bn_w, d_bn_b, d_hidden0 = DBW.sum(0), DBB.sum(0), torch.stack(carry)
+        grads = [d_emb, d_pre_w, d_pre_b, d_bn_w, d_bn_b] + g_gru + [d_out_w, d_out_b]
         d_enc = None
         if att:
             Tw = b["enc"].shape[0]
@@ -372,4 +381,4 @@ class CodeDecoderRollout(torch.autograd.Function):
             ops.linear_bwd_data(D_EP.view(Tw * B, H), b["W_e"], out=D_ENC.view(Tw * B, H), accumulate=True)
             grads += [torch.cat([dW_h, dW_e], 1), d_attn_b, D_V]
             d_enc = D_ENC
-        return (torch.stack(carry), d_enc, None, *grads)
+        return (d_hidden0, d_enc, None, *grads)

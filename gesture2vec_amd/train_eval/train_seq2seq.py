@@ -316,6 +316,28 @@ def _code_loss(outputs, codes):
     return cross_entropy(outputs[:, 1:, :].reshape(-1, K), codes[:, 1:].reshape(-1).long())
 
 
+def _code_loss_backward(outputs, codes):
+    """loss = _code_loss(outputs, codes); loss.backward() -- returns the (detached) loss.  The loss is the root of the iteration's
+    graph, so its backward starts from d loss / d logits with an upstream gradient of exactly 1: when the outputs are the
+    step-major array of the fused rollout node, the cross-entropy kernel's own gradient (it writes softmax - onehot over M beside
+    the loss) is handed to that node directly -- no ones_like fill, no scaling pass, no zero fill of slot 0's rows (the rollout's
+    backward never reads them: outputs[:, 0] is a constant, reference :676-677), no second transposed copy of the targets."""
+    from .. import ops
+    full = getattr(outputs, "_g2v_step_major", None)
+    tgt = getattr(outputs, "_g2v_targets", None)
+    if (full is None or tgt is None or not full.requires_grad or full.shape[0] != outputs.shape[1]
+            or full.shape[1] != outputs.shape[0] or tgt.shape != full.shape[:2] or tgt.dtype != torch.int64):
+        loss = _code_loss(outputs, codes)
+        loss.backward()
+        return loss.detach()
+    S, B, K = full.shape
+    d_full = torch.empty_like(full)
+    with torch.no_grad():
+        loss, _ = ops.cross_entropy_fwd_bwd(full.view(S * B, K)[B:], tgt.view(-1)[B:], want_grad=True, dl_out=d_full.view(S * B, K)[B:])
+    full.backward(gradient=d_full)
+    return loss.view(())
+
+
 def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, target_poses, cluster_targets,
                               GPT3_Embedding, net: torch.nn.Module, optim):
     """One training iteration of Part d (reference :462-538), discrete codes: CrossEntropyLoss over decode steps 1..S-1,
@@ -334,8 +356,7 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         if defer:
             net.deferred_bn = []           # BatchNorm's running statistics: held back until the whole iteration is known to be valid
         outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
-        loss = _code_loss(outputs, cluster_targets)
-        loss.backward()
+        loss = _code_loss_backward(outputs, cluster_targets)
         if defer:
             net.commit_bn_running_stats()  # behind the backward, latch-gated on the device like clip + Adam below
         optim.step()
@@ -416,8 +437,7 @@ class GraphedText2EmbeddingStep:
         if defer:
             net.deferred_bn = []
         outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
-        loss = _code_loss(outputs, self.codes)
-        loss.backward()
+        loss = _code_loss_backward(outputs, self.codes)
         if defer:
             net.commit_bn_running_stats()
         optim.step()

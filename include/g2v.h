@@ -705,6 +705,12 @@ int g2v_vq_soft_fused_bwd(const float* dh, const float* g_loss, const float* x, 
  *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance (both NULL while training:
  *                       left alone, the caller commits them with g2v_bn_running_update_invstd); save_* for bwd
  *   g2v_batchnorm_bwd   dx, dweight, dbias (overwritten) from dy (the ReLU mask is taken from y > 0 when relu)
+ *   g2v_batchnorm_bwd_steps   the same for the `steps` calls of a decode loop in one launch (dy, x, y, dx: (steps,B,H); row s
+ *                       of save_* at + s * stat_stride floats; B < 1024): dx per step bitwise g2v_batchnorm_bwd's, dw / db the
+ *                       SUM over the steps in call order (autograd's accumulation over the loop's T-1 BatchNorm nodes,
+ *                       model/text2embedding_model.py:286-290 under :701-744)
+ *   g2v_one_hot_rows    out[r,:] = one_hot(ids[r]) as float (row r at out + r * ld; an id outside [0,K) gives a zero row):
+ *                       outputs[:, 0, :] of Part d (model/text2embedding_model.py:676-677)
  *   g2v_cross_entropy_fwd_bwd   loss[0] = mean_r( logsumexp(logits[r]) - logits[r, t_r] ), dlogits = g_scale *
  *                       (softmax - onehot)/M  (torch.nn.CrossEntropyLoss, train_eval/train_seq2seq.py:520-530);
  *                       row_loss: M floats of scratch; dlogits may be NULL
@@ -728,6 +734,10 @@ int g2v_bn_running_update_invstd(const float* save_mean, const float* save_invst
 int g2v_batchnorm_bwd(const float* dy, const float* x, const float* y, const float* weight, const float* save_mean,
                       const float* save_invstd, int relu, float* dx, float* dw, float* db, int B, int H,
                       g2v_stream_t stream);
+int g2v_batchnorm_bwd_steps(const float* dy, const float* x, const float* y, const float* weight, const float* save_mean,
+                            const float* save_invstd, int64_t stat_stride, int relu, float* dx, float* dw, float* db, int steps,
+                            int B, int H, g2v_stream_t stream);
+int g2v_one_hot_rows(const int64_t* ids, float* out, int64_t ld, int M, int K, g2v_stream_t stream);
 int g2v_cross_entropy_fwd_bwd(const float* logits, int64_t ld, const int64_t* targets, float* loss, float* row_loss,
                               float* dlogits, int64_t ldd, int M, int K, float g_scale, g2v_stream_t stream);
 int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, int K, g2v_stream_t stream);

@@ -13,14 +13,17 @@ DEV = "cuda:0"
 def test_flat_clip_adam_matches_torch_with_gradless_tensors():
     from gesture2vec_amd.flat import FlatClipAdam
     g = torch.Generator().manual_seed(4)
-    shapes = [(7, 5), (13,), (3, 4, 2), (64, 33), (5,), (9, 9), (1,)]
+    shapes = [(7, 5), (13,), (3, 4, 2), (64, 33), (5,), (9, 9), (1,), (6, 3)]
     mine = [torch.nn.Parameter(torch.randn(*s, generator=g).to(DEV)) for s in shapes]
     ref = [torch.nn.Parameter(p.detach().clone().cpu().double()) for p in mine]
     opt = FlatClipAdam(mine, lr=1e-2, betas=(0.5, 0.999), max_norm=0.7)
     ropt = torch.optim.Adam(ref, lr=1e-2, betas=(0.5, 0.999))
     # step -> tensors without a gradient (2, 3 adjacent: one merged range).  A tensor that drops out stays out: one that came
     # back would see the GLOBAL step count in its bias correction here and its own in torch (documented in flat.py)
-    gradless = {0: (), 1: (2, 3), 2: (2, 3, 5), 3: (0, 2, 3, 5)}
+    # Tensor 7 NEVER receives a gradient (Part d without attention: the encoder's second layer): its moments stay exactly zero,
+    # so the fused step leaves it bitwise alone without the keep / restore copies (round 6).
+    gradless = {0: (7,), 1: (2, 3, 7), 2: (2, 3, 5, 7), 3: (0, 2, 3, 5, 7)}
+    never = mine[7].detach().clone()
     for step in range(4):
         opt.zero_grad()
         ropt.zero_grad(set_to_none=True)
@@ -38,14 +41,19 @@ def test_flat_clip_adam_matches_torch_with_gradless_tensors():
         for k, (p, r) in enumerate(zip(mine, ref)):
             err = float((p.detach().cpu().double() - r.detach()).abs().max())
             assert err <= 2e-6 * max(1.0, float(r.detach().abs().max())), (step, k, err)
+    assert torch.equal(mine[7].detach(), never)
+    o7 = opt.fp.offsets[7]
+    assert float(opt.fp.m[o7:o7 + 18].abs().max()) == 0.0 and float(opt.fp.v[o7:o7 + 18].abs().max()) == 0.0
+    assert all(o != o7 for o, _ in opt.fp.skipped)                  # (no keep / restore range for it)
     # a tensor that skipped a step was left exactly where it was (no moment decay, no stale-momentum move)
     before = mine[6].detach().clone()
     opt.zero_grad()
     for k, p in enumerate(mine):
-        if k != 6:
+        if k not in (6, 7):
             p.grad = torch.ones_like(p)
     opt.step()
     assert torch.equal(mine[6].detach(), before)
+    assert torch.equal(mine[7].detach(), never)
 
 
 def test_copy_segments_zero_fill_and_many_segments():

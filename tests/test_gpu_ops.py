@@ -1276,6 +1276,62 @@ def test_batchnorm_fwd_bwd(ops, B, H, relu):
     assert torch.equal(rme.cpu(), rm)
 
 
+@pytest.mark.parametrize("S,B,H", [(5, 128, 200), (19, 128, 200), (3, 37, 50), (1, 1000, 64), (4, 5, 16)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_batchnorm_bwd_steps_is_the_per_step_kernel_with_the_sums_over_the_steps(ops, S, B, H, relu):
+    """One launch for the S BatchNorm backwards of a decode loop (round 6): dx of every step bitwise the per-step kernel's, the
+    parameters' gradients the sum of the per-step ones in step order (float64 reference within rounding); save_* with the row
+    stride of the rollout's (S, 2, H) statistics array."""
+    x, gy = (rnd(S, B, H, seed=1) * 2 + 0.5).to(DEV), rnd(S, B, H, seed=6).to(DEV)
+    w, b = (1 + 0.1 * rnd(H, seed=2)).to(DEV), (0.1 * rnd(H, seed=3)).to(DEV)
+    stats = torch.empty((S, 2, H), dtype=torch.float32, device=DEV)
+    y = torch.empty_like(x)
+    for t in range(S):
+        ops.batchnorm_fwd(x[t], w, b, None, None, True, relu, out=y[t], save=(stats[t, 0], stats[t, 1]))
+    dx, dw, db = ops.batchnorm_bwd_steps(gy, x, y, w, stats[:, 0], stats[:, 1], relu)
+    dws, dbs = torch.zeros(H, dtype=torch.float64), torch.zeros(H, dtype=torch.float64)
+    acc_w, acc_b = torch.zeros(H, device=DEV), torch.zeros(H, device=DEV)
+    for t in range(S):
+        dxt, dwt, dbt = ops.batchnorm_bwd(gy[t], x[t], y[t], w, stats[t, 0].contiguous(), stats[t, 1].contiguous(), relu)
+        assert torch.equal(dx[t], dxt), f"step {t}: dx differs from the per-step kernel"
+        acc_w, acc_b = acc_w + dwt, acc_b + dbt                      # the same order of additions
+        dws += dwt.double().cpu()
+        dbs += dbt.double().cpu()
+    assert torch.equal(dw, acc_w) and torch.equal(db, acc_b)
+    relclose(dw, dws.float(), 1e-5, "dw over the steps")
+    relclose(db, dbs.float(), 1e-5, "db over the steps")
+    with pytest.raises(Exception):
+        big = torch.zeros((1, 1024, 8), device=DEV)
+        st = torch.ones((1, 2, 8), device=DEV)
+        ops.batchnorm_bwd_steps(big, big, big, torch.ones(8, device=DEV), st[:, 0], st[:, 1], True)
+
+
+@pytest.mark.parametrize("M,K,ld", [(128, 512, 512), (7, 400, 400), (33, 64, 100), (1, 1, 1)])
+def test_one_hot_rows(ops, M, K, ld):
+    ids = torch.randint(0, K, (M,), generator=torch.Generator().manual_seed(3))
+    buf = torch.full((M, ld), 7.0, device=DEV)
+    out = ops.one_hot_rows(ids.to(DEV), K, buf[:, :K])
+    assert torch.equal(out.cpu(), torch.nn.functional.one_hot(ids, K).float())
+    assert (buf[:, K:] == 7.0).all()                                  # nothing written beyond a row's K entries
+    ids[0] = K + 3                                                    # outside [0, K): a zero row
+    out = ops.one_hot_rows(ids.to(DEV), K, buf[:, :K])
+    assert out[0].abs().sum().item() == 0
+
+
+def test_masks_at_offsets_are_the_consecutive_draws(ops):
+    """keep_mask_at(k) + one counter_add(n) == n consecutive keep_mask calls (Part d draws a forward's masks this way)."""
+    off = torch.full((1,), 11, dtype=torch.int64, device=DEV)
+    seq = [ops.keep_mask(torch.empty(5000, dtype=torch.uint8, device=DEV), kp, 77, off).clone() for kp in (0.5, 0.8, 0.8)]
+    assert off.item() == 14
+    off.fill_(11)
+    at = [ops.keep_mask_at(torch.empty(5000, dtype=torch.uint8, device=DEV), kp, 77, off, k) for k, kp in enumerate((0.5, 0.8, 0.8))]
+    assert off.item() == 11
+    ops.counter_add(off, 3)
+    assert off.item() == 14
+    for a_, b_ in zip(seq, at):
+        assert torch.equal(a_, b_)
+
+
 @pytest.mark.parametrize("M,K", [(640, 512), (33, 64), (7, 400)])
 def test_cross_entropy_and_argmax(ops, M, K):
     z = rnd(M, K, seed=1) * 3
@@ -1294,7 +1350,8 @@ def test_cross_entropy_and_argmax(ops, M, K):
 @pytest.mark.parametrize("V,dim,n,pattern", [(300, 300, 1000, "head"), (3863, 300, 25 * 128, "stride"), (514, 200, 6 * 4096, "head"),
                                              (7, 33, 500, "stride"), (40, 1000, 90, "head"), (9, 300, 1000, "one"),
                                              (3863, 300, 30 * 4096, "stride"), (64, 64, 129, "head"), (514, 200, 12 * 4096, "stride"),
-                                             (514, 200, 4096, "uniform"), (514, 200, 128, "uniform")])
+                                             (514, 200, 4096, "uniform"), (514, 200, 128, "uniform"),
+                                             (3863, 300, 1488, "uniform"), (3863, 300, 2048, "head"), (3863, 300, 2049, "head")])
 def test_embedding_fwd_bwd(ops, V, dim, n, pattern):
     table = rnd(V, dim, seed=1)
     ids = torch.randint(0, V, (n,), generator=torch.Generator().manual_seed(2))

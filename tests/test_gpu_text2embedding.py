@@ -734,18 +734,18 @@ def test_a_fault_latched_after_the_forward_leaves_batchnorm_running_statistics_a
                 return orig_fwd(*a, **k)
             net.forward = fwd
             if fault:
-                orig_loss, fired = TS._code_loss, []
+                orig_loss, fired = TS._code_loss_backward, []
 
-                def loss_then_fault(outputs, codes_):
-                    v = orig_loss(outputs, codes_)
+                def fault_then_loss_and_backward(outputs, codes_):
                     if not fired:                                # behind the FORWARD of the first attempt, in front of its backward
                         fired.append(1)
+                        torch.cuda.synchronize()
                         lib.g2v_dec_rollout_persist_fault(-1)
-                    return v
-                monkeypatch.setattr(TS, "_code_loss", loss_then_fault)
+                    return orig_loss(outputs, codes_)
+                monkeypatch.setattr(TS, "_code_loss_backward", fault_then_loss_and_backward)
                 with pytest.warns(RuntimeWarning, match="repeated on the per-step kernels"):
                     r = TS.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
-                monkeypatch.setattr(TS, "_code_loss", orig_loss)
+                monkeypatch.setattr(TS, "_code_loss_backward", orig_loss)
                 assert fired
             else:
                 r = TS.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)
