@@ -407,6 +407,8 @@ def part_d(with_cpu: bool):
                                                   else "fused per-step kernels (g2v_attn_code_rollout_fwd / _bwd)" if served[0]
                                                   else "column-split per-operator kernels")})
             del g, net, opt
+            import gc
+            gc.collect()          # (a captured graph is gone before the next one is captured: ops.reset_side_streams)
     if with_cpu and keep is not None:
         try:
             from oracle import g2v_oracle as O

@@ -50,6 +50,8 @@ class FlatParams:
         whose .grad is None this step gets zeros and is remembered in `self.skipped` (adjacent ones merged into one range):
         torch.optim.Adam (the reference's optimizer) leaves such a parameter and its moments completely untouched, and
         clip_grad_norm_ ignores it; step() reproduces that."""
+        from . import ops
+        ops.join_side()          # (gradients produced on side branches of the iteration: ops.side_branches)
         src, dst, ns = [], [], []
         self.skipped = []
         base = self.gflat.data_ptr()

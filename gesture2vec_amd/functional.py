@@ -95,23 +95,26 @@ class LinearPairFn(torch.autograd.Function):
     def backward(ctx, ga, gb):
         xs, w_a, w_b, keep = ctx.saved_tensors
         N, K = w_a.shape
-        dx, out, items = None, [], []
-        for g, w in ((ga, w_a), (gb, w_b)):
-            if g is None:
-                out += [None, None]
-                continue
-            g = g.contiguous().view(-1, N)
-            if ctx.needs_input_grad[0]:
+        gs = [g.contiguous().view(-1, N) if g is not None else None for g in (ga, gb)]
+        out = [None] * 4
+        live = [k for k in (0, 1) if gs[k] is not None]
+        if live:
+            # nothing downstream waits for the weight gradients: a side branch of the iteration (ops.side_branches), forked
+            # BEFORE the input gradient's launches so that the two run side by side
+            with ops.side_branch(1, keep=[xs] + [gs[k] for k in live], rows=xs.shape[0], min_rows=22000):
+                items = []
+                for k in live:
+                    out[2 * k] = torch.empty((N, K), dtype=torch.float32, device=xs.device)
+                    out[2 * k + 1] = torch.empty((N,), dtype=torch.float32, device=xs.device)
+                    items.append((gs[k], xs, out[2 * k], out[2 * k + 1]))
+                ops.linear_bwd_weight_batch(items, N, K, M=xs.shape[0])
+        dx = None
+        if ctx.needs_input_grad[0]:
+            for k in live:
                 if dx is None:
-                    dx = ops.linear_bwd_data(g, w)
+                    dx = ops.linear_bwd_data(gs[k], (w_a, w_b)[k])
                 else:
-                    ops.linear_bwd_data(g, w, out=dx, accumulate=True)
-            dw = torch.empty((N, K), dtype=torch.float32, device=xs.device)
-            db = torch.empty((N,), dtype=torch.float32, device=xs.device)
-            items.append((g, xs, dw, db))
-            out += [dw, db]
-        if items:
-            ops.linear_bwd_weight_batch(items, N, K, M=xs.shape[0])
+                    ops.linear_bwd_data(gs[k], (w_a, w_b)[k], out=dx, accumulate=True)
         if dx is not None and keep is not None:
             dx = ops.mask_mul(dx, keep, ctx.scale, positive_of=False)
         return (dx.view(ctx.xshape) if dx is not None else None), out[0], out[1], out[2], out[3], None, None
@@ -318,10 +321,12 @@ class GRUBiDirFn(torch.autograd.Function):
             outs.append((dgi, dgh))
         ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H, row_off=row_off)
         items = []
-        for (dgi, dgh), hprev in zip(outs, (hprev_f, hprev_b)):
-            items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
-                          torch.empty((3 * H,), dtype=torch.float32, device=dev)))
-        ops.linear_bwd_weight_batch(items, 3 * H, H, M=T * B)
+        # the W_hh gradients beside the input side's chain (large batches: ops.side_branch has the measured rule)
+        with ops.side_branch(1, keep=[outs[0][1], outs[1][1], full_f, full_b], rows=T * B, min_rows=32768):
+            for (dgi, dgh), hprev in zip(outs, (hprev_f, hprev_b)):
+                items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
+                              torch.empty((3 * H,), dtype=torch.float32, device=dev)))
+            ops.linear_bwd_weight_batch(items, 3 * H, H, M=T * B)
         return outs[0][0], outs[1][0], items[0][2], items[0][3], items[1][2], items[1][3], None, None
 
 

@@ -36,6 +36,83 @@ def _chk(t: torch.Tensor, dtype=torch.float32, name="tensor"):
     return t
 
 
+# ---- side branches (round 6) ------------------------------------------------------------------------------------------------
+# Part d's iteration is an autograd chain on ONE stream; a good part of its backward is weight-gradient work nothing downstream
+# waits for (a layer's, while its input gradient moves on).
+# Inside `with side_branches():` (train_iter_text2embedding, GraphedText2EmbeddingStep) a block under `with side_branch(k, keep)`
+# is launched on side stream k, forked from the current stream; `join_side()` (FlatParams.gather_grads, and the scope's exit)
+# makes the current stream wait for all of them.  Outside such a scope a side_branch block runs inline: somebody who calls
+# backward() and reads .grad without an optimiser step never sees an unjoined stream.
+#   * `keep`: every tensor the block READS that was allocated on the forking stream -- the caching allocator hands a block
+#     back to its own stream's pool the moment the last reference dies (the end of the autograd node), while the side launch may
+#     still be reading; they stay referenced until the join.  What the block ALLOCATES belongs to the side stream's pool and is
+#     only ever recycled there, stream-ordered behind the fork.
+#   * the reusable workspaces are per branch (a tag suffix): two weight-gradient launches on two streams never share slabs.
+#   * a gradient produced on a side stream must not be ACCUMULATED into an existing .grad by autograd (an add on the main
+#     stream); every parameter of Part d's model receives one contribution per iteration and zero_grad() resets to None.
+import contextlib
+import os
+import threading
+
+_side_state = {"active": 0, "streams": {}, "pending": []}
+_side_local = threading.local()
+SIDE_BRANCHES = os.environ.get("G2V_SIDE_BRANCHES", "1") != "0"
+
+
+def join_side():
+    """the current stream waits for every side branch forked since the last join (their kept tensors are released)"""
+    pend, _side_state["pending"] = _side_state["pending"], []
+    if pend:
+        cur = torch.cuda.current_stream()
+        for s, _keep in pend:
+            cur.wait_stream(s)
+
+
+def reset_side_streams():
+    """Forget the cached side streams (new ones are drawn at the next fork).  GraphedText2EmbeddingStep does this in front of every
+    capture: on ROCm 7.2 the replay of the FOURTH multi-stream graph captured over the same side streams in one process, with the
+    third still alive, died inside hipGraphLaunch (gpurun_tools/r06_side_repro.py: seq4 against seq4fresh / seq4gc)."""
+    join_side()
+    _side_state["streams"].clear()
+
+
+@contextlib.contextmanager
+def side_branches(enabled: bool = True):
+    on = bool(enabled) and SIDE_BRANCHES
+    _side_state["active"] += 1 if on else 0
+    try:
+        yield
+    finally:
+        if on:
+            _side_state["active"] -= 1
+            join_side()
+
+
+@contextlib.contextmanager
+def side_branch(k: int = 0, keep=(), rows: int = 1 << 62, min_rows: int = 0):
+    """rows / min_rows: the caller's size rule -- a fork costs two cross-queue edges of the replayed graph (5-10 us each) and the
+    co-running kernels slow each other down; measured on Part d (gpurun_tools/r06_side_mask.py, profiles/r06_i_side_mask.log):
+    the encoder's weight gradients beside its input-gradient chain pay from B = 2048 (-2 ... -4 %), cost 1-3 % at B = 1024 and
+    10 % at B = 128 with attention; the decoder's parameter gradients beside the encoder's BPTT never paid and stay inline."""
+    if not _side_state["active"] or rows < min_rows:
+        yield False
+        return
+    cur = torch.cuda.current_stream()
+    key = (cur.device.index, int(k))
+    s = _side_state["streams"].get(key)
+    if s is None:
+        s = _side_state["streams"][key] = torch.cuda.Stream(device=cur.device)
+    s.wait_stream(cur)
+    prev = getattr(_side_local, "suffix", "")
+    _side_local.suffix = f"@side{int(k)}"
+    try:
+        with torch.cuda.stream(s):
+            yield True
+    finally:
+        _side_local.suffix = prev
+        _side_state["pending"].append((s, keep))
+
+
 _ws_cache = {}
 _ws_retired = []      # superseded workspaces stay allocated: see workspace()
 
@@ -47,7 +124,7 @@ def workspace(nbytes: int, device, tag: str = "ws") -> torch.Tensor:
     (train_eval.train_seq2seq.GraphedText2EmbeddingStep replays ops.* calls), and handing the block back to the caching
     allocator would let a later replay scribble its weight-gradient slabs over whatever tensor reuses the memory.  The cost
     is bounded: sizes only grow, so at most a geometric series of small blocks per tag stays behind."""
-    key = (str(device), tag)
+    key = (str(device), tag + getattr(_side_local, "suffix", ""))
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:

@@ -317,14 +317,7 @@ class CodeDecoderRollout(torch.autograd.Function):
             global CLUSTER_BPTT_CALLS
             CLUSTER_BPTT_CALLS += 1
             DGI[0], DGH[0], DGI[1], DGH[1], DA, d_h0 = ops.code_cluster_bptt(DH_top, cl["wd"], cl["sv"], b["mask_l0"], cl["p"], S1, B, H)
-            if B < 1024:     # every step's BatchNorm backward + the sums over the steps: one launch
-                DU, d_bn_w, d_bn_b = ops.batchnorm_bwd_steps(DA, b["U"], b["A"], bn_w, b["SM"], b["SI"], True)
-            else:
-                DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
-                for t in range(S1):
-                    ops.batchnorm_bwd(DA[t], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
-                d_bn_w, d_bn_b = DBW.sum(0), DBB.sum(0)
-            d_hidden0 = d_h0
+            d_hidden0 = d_h0          # (BatchNorm's backward feeds parameters and the code embedding only: the side branch below)
         for t in (reversed(range(S1)) if not cluster_bptt else ()):
             d_in = DH_top[t]                                             # gradient arriving at Hs[l][t+1] from above
             for l in reversed(range(L)):
@@ -349,6 +342,25 @@ class CodeDecoderRollout(torch.autograd.Function):
                 ops.linear_bwd_data(DHP[t], b["W_h"], out=carry_next[L - 1], accumulate=True)     # the state the attention scored
             carry, carry_next = carry_next, carry
         # ---- everything that did not feed the recurrence: one launch over all (S-1) B rows each ---------------------------
+        d_enc = None
+        if att:      # (the encoder's backward waits for this one: it stays on the chain)
+            Tw = b["enc"].shape[0]
+            ops.linear_bwd_data(D_EP.view(Tw * B, H), b["W_e"], out=D_ENC.view(Tw * B, H), accumulate=True)
+            d_enc = D_ENC
+        if not cluster_bptt:
+            d_hidden0 = torch.stack(carry)
+        # (Nothing downstream waits for the parameters' gradients, but as a side branch of the iteration beside the encoder's
+        #  backward they never paid: ops.side_branch.)
+        if cluster_bptt:
+            if B < 1024:     # every step's BatchNorm backward + the sums over the steps: one launch
+                DU, d_bn_w, d_bn_b = ops.batchnorm_bwd_steps(DA, b["U"], b["A"], bn_w, b["SM"], b["SI"], True)
+            else:
+                DU, DBW, DBB = f32(S1, B, H), f32(S1, H), f32(S1, H)
+                for t in range(S1):
+                    ops.batchnorm_bwd(DA[t], b["U"][t], b["A"][t], bn_w, b["SM"][t], b["SI"][t], True, out=(DU[t], DBW[t], DBB[t]))
+                d_bn_w, d_bn_b = DBW.sum(0), DBB.sum(0)
+        else:
+            d_bn_w, d_bn_b = DBW.sum(0), DBB.sum(0)
         if att:
             d_e = DEC[:, :, :H].contiguous().view(M, H)
         else:
@@ -370,15 +382,9 @@ class CodeDecoderRollout(torch.autograd.Function):
             g_gru += [dw_ih, dw_hh, db_ih, db_hh]
         for k in range(0, len(items), 4):
             ops.linear_bwd_weight_batch(items[k:k + 4], 3 * H, H, M=M)
-        if not cluster_bptt:
-            d_bn_w, d_bn_b, d_hidden0 = DBW.sum(0), DBB.sum(0), torch.stack(carry)
         grads = [d_emb, d_pre_w, d_pre_b, d_bn_w, d_bn_b] + g_gru + [d_out_w, d_out_b]
-        d_enc = None
         if att:
-            Tw = b["enc"].shape[0]
             dW_h, d_attn_b = ops.linear_bwd_weight(DHP.view(M, H), Hs[L - 1][:-1].view(M, H), H, H)
             dW_e, _ = ops.linear_bwd_weight(D_EP.view(Tw * B, H), b["enc"].view(Tw * B, H), H, H, want_bias=False)
-            ops.linear_bwd_data(D_EP.view(Tw * B, H), b["W_e"], out=D_ENC.view(Tw * B, H), accumulate=True)
             grads += [torch.cat([dW_h, dW_e], 1), d_attn_b, D_V]
-            d_enc = D_ENC
         return (d_hidden0, d_enc, None, *grads)

@@ -348,7 +348,7 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         raise TypeError("use gesture2vec_amd.flat.FlatClipAdam (clip + Adam are one fused HIP launch)")
     if args.text2_embedding_discrete != "True":
         raise NotImplementedError("text2_embedding_discrete == 'False' is outside the accelerated hot path")
-    from .. import _lib
+    from .. import _lib, ops
     lib = _lib.load()
     defer = hasattr(net, "commit_bn_running_stats")
     for attempt in (0, 1):
@@ -356,7 +356,8 @@ def train_iter_text2embedding(args, epoch: int, in_text, in_lengths, in_audio, t
         if defer:
             net.deferred_bn = []           # BatchNorm's running statistics: held back until the whole iteration is known to be valid
         outputs, _ = net(in_text, in_lengths, in_audio, cluster_targets, GPT3_Embedding, None)
-        loss = _code_loss_backward(outputs, cluster_targets)
+        with ops.side_branches():          # the backward's parameter gradients beside its chain; joined in front of the optimiser
+            loss = _code_loss_backward(outputs, cluster_targets)
         if defer:
             net.commit_bn_running_stats()  # behind the backward, latch-gated on the device like clip + Adam below
         optim.step()
@@ -431,13 +432,15 @@ class GraphedText2EmbeddingStep:
             self._baked = None
 
     def _step(self):
+        from .. import ops
         net, optim = self.net, self.optim
         defer = hasattr(net, "commit_bn_running_stats")
         optim.zero_grad()
         if defer:
             net.deferred_bn = []
         outputs, _ = net(self.in_text, self.lengths, None, self.codes, None, None)
-        loss = _code_loss_backward(outputs, self.codes)
+        with ops.side_branches():
+            loss = _code_loss_backward(outputs, self.codes)
         if defer:
             net.commit_bn_running_stats()
         optim.step()
@@ -445,6 +448,13 @@ class GraphedText2EmbeddingStep:
 
     def _capture(self, warmup: int):
         from ..fault_policy import POLICY
+        from .. import ops
+        import gc
+        # (a graph this object captured earlier is released before the next capture, and the capture forks onto side streams no
+        #  earlier graph has used: ops.reset_side_streams has the measurement)
+        self.graph = None
+        gc.collect()
+        ops.reset_side_streams()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

@@ -27,8 +27,10 @@ for att in ("False", "True"):
             train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, opt)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         rec = dict(att=att, B=B, eager_ms=round(dt / n * 1e3, 3), eager_samples_per_s=round(B * n / dt, 1))
+        print("eager done", rec, file=sys.stderr, flush=True)
         try:
             g = GraphedText2EmbeddingStep(args, net, opt, ids, lengths, codes, static_lengths=True, check_every=0)
+            print("captured", file=sys.stderr, flush=True)
             for _ in range(3):
                 g.replay()
             torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -39,4 +41,5 @@ for att in ("False", "True"):
         except Exception as e:
             rec["graph_error"] = f"{type(e).__name__}: {e}"[:300]
         out.append(rec)
+        g = None
 print(json.dumps(out))

@@ -1,0 +1,27 @@
+"""Diagnostic: Part d's iteration as a hipGraph, replayed (for rocprofv3 --kernel-trace: the in-graph overlap of the side branches).
+usage: prof_t2e_graph.py B att [side 0/1]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import numpy as np, torch
+from gesture2vec_amd import ops
+from gesture2vec_amd.flat import FlatClipAdam
+from gesture2vec_amd.model.text2embedding_model import text2embedding_model
+from gesture2vec_amd.train_eval.train_seq2seq import GraphedText2EmbeddingStep
+from train_text2embedding import SyntheticSentences
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+att = sys.argv[2] if len(sys.argv) > 2 else "False"
+if len(sys.argv) > 3:
+    ops.SIDE_BRANCHES = sys.argv[3] != "0"
+args = argparse.Namespace(hidden_size=200, n_layers=2, dropout_prob=0.2, autoencoder_vq_components=512, autoencoder_att=att,
+                          n_pre_poses=1, n_poses=20, sentence_frame_length=120, text2_embedding_discrete="True", batch_size=B)
+torch.manual_seed(0)
+net = text2embedding_model(args, 512, 20, 3863, 300, np.random.RandomState(0).randn(3863, 300).astype(np.float32), None).to("cuda:0")
+net.train(True)
+opt = FlatClipAdam(net.parameters(), lr=5e-4)
+data = list(SyntheticSentences(args, 3863, 1, seed=1))[0]
+ids, lengths, codes = data[0].to("cuda:0"), data[1], data[6].to("cuda:0")
+g = GraphedText2EmbeddingStep(args, net, opt, ids, lengths, codes, static_lengths=True, check_every=0)
+for _ in range(12):
+    g.replay()
+torch.cuda.synchronize()

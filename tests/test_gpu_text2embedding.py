@@ -845,3 +845,67 @@ def test_graphed_step_detects_a_fault_recaptures_and_the_policy_rearms():
         lib.g2v_gru_seq_set_cluster(prev_c)
         lib.g2v_dec_rollout_set_persistent(prev_p)
         POLICY.off, POLICY.clean, POLICY.faults, POLICY.rearms, POLICY.rearm_after, POLICY.max_rearms = saved
+
+
+@pytest.mark.parametrize("att,B,H,K", [("False", 2048, 200, 512), ("True", 2048, 200, 512), ("False", 128, 200, 512), ("True", 24, 48, 64)])
+@pytest.mark.parametrize("graphed", [False, True])
+def test_side_branches_of_the_backward_change_nothing(att, B, H, K, graphed, monkeypatch):
+    """Round 6: inside train_iter_text2embedding / GraphedText2EmbeddingStep the encoder's weight gradients run on a side stream
+    beside its input-gradient chain at large batches (ops.side_branches / ops.side_branch: forked in front of the chain, joined in
+    front of the optimiser; below the measured row counts a branch stays inline).  Every kernel is deterministic, so three
+    iterations with and without the branches must leave bitwise the same model, and the explicit-gradient path (backward()
+    outside the scope) must never see a side stream."""
+    from gesture2vec_amd import ops
+    from gesture2vec_amd.train_eval import train_seq2seq as TS
+    states = []
+    mk = lambda: _small_t2e(att=att, B=B, H=H, K=K, NW=300, EMB=300 if H == 200 else 30, Tw=20 if B >= 2048 else 12)
+    for side in (False, True):
+        monkeypatch.setattr(ops, "SIDE_BRANCHES", side)
+        args, net, optim, ids, lengths, codes, masks = mk()
+        orig_fwd = net.forward
+        taken = []
+
+        def fwd(*a, _o=orig_fwd, _n=net, _m=masks, **k):
+            _n.set_dropout_masks(*_m)
+            return _o(*a, **k)
+        net.forward = fwd
+        orig_branch = ops.side_branch
+
+        class Spy:
+            def __init__(self, *a, **k):
+                self.cm = orig_branch(*a, **k)
+
+            def __enter__(self):
+                v = self.cm.__enter__()
+                taken.append(bool(v))
+                return v
+
+            def __exit__(self, *e):
+                return self.cm.__exit__(*e)
+        monkeypatch.setattr(ops, "side_branch", Spy)
+        losses = []
+        if graphed:
+            g = TS.GraphedText2EmbeddingStep(args, net, optim, ids, lengths, codes, warmup=1, static_lengths=True, check_every=0)
+            for _ in range(2):
+                g.replay()
+            losses.append(g.read_loss())
+            del g
+        else:
+            for _ in range(3):
+                losses.append(TS.train_iter_text2embedding(args, 1, ids, lengths, None, None, codes, None, net, optim)["loss"])
+        monkeypatch.setattr(ops, "side_branch", orig_branch)
+        torch.cuda.synchronize()
+        assert not ops._side_state["pending"] and ops._side_state["active"] == 0
+        assert taken, "no side_branch site was reached"
+        assert any(taken) == (side and B >= 2048), (side, B, taken)       # forked exactly where the size rule says so
+        states.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
+    assert states[0][0] == states[1][0], (states[0][0], states[1][0])
+    for k, v in states[0][1].items():
+        assert torch.equal(v, states[1][1][k]), k
+    # outside the scope a branch is inline: plain backward() + .grad needs no join
+    monkeypatch.setattr(ops, "SIDE_BRANCHES", True)
+    args, net, optim, ids, lengths, codes, masks = mk()
+    net.set_dropout_masks(*masks)
+    out, _ = net(ids, lengths, None, codes, None, None)
+    TS._code_loss(out, codes).backward()
+    assert not ops._side_state["pending"]
