@@ -635,15 +635,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   const int b = blockIdx.x;
   float* sc = smem;
   const float* hpr = hp + (int64_t)b * H;
+  // (round 6: every load of a pass is requested before the first tanh -- the loops used to walk H in 64-wide slices and T one
+  //  position at a time, a memory round trip per slice / position: 10 us per call at B = 128, T = 20, H = 200, now 5)
   for (int t0 = wave * 4; t0 < T; t0 += 16) {         // positions t0 .. t0 + 3 of this wave, together
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int f = lane; f < H; f += 64) {
-      const float vf = v[f], hf = hpr[f];
+    for (int f0 = 0; f0 < H; f0 += 256) {             // H <= 256: one pass
+      float e[4][4], vf[4], hf[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u < T ? t0 + u : T - 1;
-        acc[u] += vf * tanhf_(hf + ep[((int64_t)t * B + b) * H + f]);
+      for (int k = 0; k < 4; ++k) {
+        const int f = f0 + lane + 64 * k, fc = f < H ? f : H - 1;
+        vf[k] = f < H ? v[fc] : 0.f;
+        hf[k] = hpr[fc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u < T ? t0 + u : T - 1;
+          e[u][k] = ep[((int64_t)t * B + b) * H + fc];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += vf[k] * tanhf_(hf[k] + e[u][k]);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -670,7 +682,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
   __syncthreads();
   for (int f = threadIdx.x; f < H; f += 256) {
     float c = 0.f;
-    for (int t = 0; t < T; ++t) c += sc[t] * enc[((int64_t)t * B + b) * H + f];
+    for (int t0 = 0; t0 < T; t0 += 8) {
+      float x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) x[u] = enc[((int64_t)(t0 + u < T ? t0 + u : T - 1) * B + b) * H + f];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t0 + u < T) c += sc[t0 + u] * x[u];
+    }
     ctx[(int64_t)b * ldctx + f] = c;
   }
 }
@@ -693,13 +712,22 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   // d_w[t] = <d_ctx, enc[t,b,:]>
   for (int t0 = wave * 4; t0 < T; t0 += 16) {
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int f = lane; f < H; f += 64) {
-      const float dc = dcr[f];
+    for (int f0 = 0; f0 < H; f0 += 256) {             // (loads up front as in the forward)
+      float x[4][4], dc[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int t = t0 + u < T ? t0 + u : T - 1;
-        acc[u] += dc * enc[((int64_t)t * B + b) * H + f];
+      for (int k = 0; k < 4; ++k) {
+        const int f = f0 + lane + 64 * k, fc = f < H ? f : H - 1;
+        dc[k] = f < H ? dcr[fc] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int t = t0 + u < T ? t0 + u : T - 1;
+          x[u][k] = enc[((int64_t)t * B + b) * H + fc];
+        }
       }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] += dc[k] * x[u][k];
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -719,20 +747,30 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const float* __restrict__
   for (int f = threadIdx.x; f < H; f += 256) {
     const float hpf = hp[(int64_t)b * H + f], vf = v[f], dc = dcr[f];
     float dh = 0.f, dvf = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const int64_t row = ((int64_t)t * B + b) * H + f;
-      const float e = tanhf_(hpf + ep[row]);
-      const float de = ds[t] * vf * (1.0f - e * e);
-      dh += de;
-      dvf += ds[t] * e;
-      const float dn = wr[t] * dc;
-      if (accumulate) {
-        d_ep[row] += de;
-        d_enc[row] += dn;
-      } else {
-        d_ep[row] = de;
-        d_enc[row] = dn;
+    // (round 6: five positions' operands -- ep and, when accumulating, the two running gradients -- requested together; the
+    //  read-modify-write per position was a memory round trip per position: 19.8 us per call at T = 20, now 8)
+    for (int t0 = 0; t0 < T; t0 += 5) {
+      float x[5], a0[5], a1[5];
+#pragma unroll
+      for (int u = 0; u < 5; ++u) {
+        const int64_t row = ((int64_t)(t0 + u < T ? t0 + u : T - 1) * B + b) * H + f;
+        x[u] = ep[row];
+        a0[u] = accumulate ? d_ep[row] : 0.f;
+        a1[u] = accumulate ? d_enc[row] : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 5; ++u)
+        if (t0 + u < T) {
+          const int t = t0 + u;
+          const int64_t row = ((int64_t)t * B + b) * H + f;
+          const float e = tanhf_(hpf + x[u]);
+          const float de = ds[t] * vf * (1.0f - e * e);
+          dh += de;
+          dvf += ds[t] * e;
+          const float dn = wr[t] * dc;
+          d_ep[row] = accumulate ? a0[u] + de : de;
+          d_enc[row] = accumulate ? a1[u] + dn : dn;
+        }
     }
     d_hp[(int64_t)b * H + f] = dh;
     dv_partial[(int64_t)b * H + f] = dvf;
