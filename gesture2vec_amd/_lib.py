@@ -192,6 +192,9 @@ _SIGS = {
     "g2v_batchnorm_bwd_steps": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_one_hot_rows": (c_int, [c_fp, c_fp, c_i64, c_int, c_int, c_fp]),
     "g2v_cross_entropy_fwd_bwd": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_f, c_fp]),
+    "g2v_attn_step_fwd": (c_int, [c_fp, c_i64, c_int, c_fp, c_fp, c_fp, c_f, c_fp, c_i64, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
+    "g2v_slab_sum": (c_int, [c_fp, c_int, c_i64, c_fp, c_int, c_fp]),
+    "g2v_linear_fwd_dual": (c_int, [c_fp, c_i64, c_fp, c_fp, c_fp, c_i64, c_int, c_fp, c_fp, c_fp, c_i64, c_int, c_int, c_int, c_fp]),
     "g2v_argmax_rows": (c_int, [c_fp, c_i64, c_fp, c_int, c_int, c_fp]),
     "g2v_vq_soft_fwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_int, c_fp]),
     "g2v_vq_soft_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_fp]),

@@ -429,6 +429,21 @@ __global__ __launch_bounds__(256) void gemm_smallm_dual_kernel(DualTrans d, int 
                                  d.N[p], 0, d.accumulate[p], blockIdx.x * 4 + (threadIdx.x >> 6), d.out_keep[p], d.out_scale[p]);
 }
 
+// Two forward products of the SAME rows in one launch (blockIdx.y): y_p = x W_p^T + b_p -- a decode step of Part d with attention
+// reads the new top state twice, for the logits and for the next step's attention query (g2v_linear_fwd_dual).
+struct DualNT {
+  const float* W[2];
+  const float* bias[2];
+  float* out[2];
+  int64_t ldc[2];
+  int N[2];
+};
+__global__ __launch_bounds__(256) void gemm_smallm_dual_nt_kernel(const float* __restrict__ A, int64_t lda, DualNT d, int M, int C) {
+  const int p = blockIdx.y;
+  smallm_body<false, false, 1, 8>(A, lda, nullptr, 1.0f, d.W[p], (int64_t)C, d.bias[p], d.out[p], d.ldc[p], M, C, d.N[p], 0, 0,
+                                  blockIdx.x * 4 + (threadIdx.x >> 6), nullptr, 1.0f);
+}
+
 // measured (gpurun_tools/gemm_bench.py, 200..400 -> 200..600): forward 9.7 vs 10.4 us and data gradient 11 vs 22 us at 128..640
 // rows, break-even near 2560 rows, the LDS-tiled kernel ahead beyond (50..86 TF/s at 4096..81920 rows)
 extern "C" int g2v_linear_set_smallm_rows(int rows) {            // = g2v_ctx_set_option(NULL, G2V_OPT_SMALLM_ROWS, rows) (measurement only)
@@ -1451,6 +1466,30 @@ extern "C" int g2v_linear_fwd_pair(const float* x, int64_t ldx, const float* w_a
   const int rc = g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_a, bias_a, y_a, ldy, M, K, N, act, stream);
   if (rc != G2V_OK) return rc;
   return g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_b, bias_b, y_b, ldy, M, K, N, act, stream);
+}
+
+// y_a = x w_a^T + b_a (M x N_a), y_b = x w_b^T + b_b (M x N_b): two g2v_linear_fwd calls on the same x; ONE launch (bitwise the
+// two calls' results) where both would run the small-row-count kernel with 16 x 16 wave tiles, two launches otherwise.
+extern "C" int g2v_linear_fwd_dual(const float* x, int64_t ldx, const float* w_a, const float* bias_a, float* y_a, int64_t ldya, int N_a,
+                                   const float* w_b, const float* bias_b, float* y_b, int64_t ldyb, int N_b, int M, int K,
+                                   g2v_stream_t stream) {
+  G2V_REQUIRE(x && w_a && w_b && y_a && y_b, "null pointer");
+  G2V_REQUIRE(M > 0 && K > 0 && N_a > 0 && N_b > 0 && ldx >= K && ldya >= N_a && ldyb >= N_b, "bad size");
+  auto a16 = [](const void* q_) { return (reinterpret_cast<uintptr_t>(q_) & 15) == 0; };
+  const int64_t tiles_a = (int64_t)cdiv(M, 16) * cdiv(N_a, 16), tiles_b = (int64_t)cdiv(M, 16) * cdiv(N_b, 16);
+  if (M <= g2v_internal_options().smallm_max_rows && (K & 3) == 0 && (ldx & 3) == 0 && a16(x) && a16(w_a) && a16(w_b) &&
+      tiles_a <= 2048 && tiles_b <= 2048) {
+    DualNT d;
+    d.W[0] = w_a; d.bias[0] = bias_a; d.out[0] = y_a; d.ldc[0] = ldya; d.N[0] = N_a;
+    d.W[1] = w_b; d.bias[1] = bias_b; d.out[1] = y_b; d.ldc[1] = ldyb; d.N[1] = N_b;
+    const int64_t tiles = tiles_a > tiles_b ? tiles_a : tiles_b;
+    hipLaunchKernelGGL(gemm_smallm_dual_nt_kernel, dim3(cdiv(tiles, 4), 2), dim3(256), 0, (hipStream_t)stream, x, ldx, d, M, K);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
+  const int rc = g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_a, bias_a, y_a, ldya, M, K, N_a, 0, stream);
+  if (rc != G2V_OK) return rc;
+  return g2v_linear_fwd(x, ldx, 0, 0, 0, nullptr, 1.0f, w_b, bias_b, y_b, ldyb, M, K, N_b, 0, stream);
 }
 
 extern "C" int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx, int M, int K,

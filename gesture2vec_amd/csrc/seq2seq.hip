@@ -626,14 +626,12 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 // (four positions in flight per wave), the softmax runs redundantly in every wave, and the feature loops run one thread per
 // feature with the T loads independent.  tanh on the hardware exp / rcp like every other gate of the library.  Softmax runs
 // over ALL T positions (the reference does not mask padded positions; their encoder rows are zero).
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ ep,
-                                                       const float* __restrict__ enc, const float* __restrict__ v,
-                                                       float* __restrict__ weights, float* __restrict__ ctx,
-                                                       int64_t ldctx, int T, int B, int H) {
-  extern __shared__ float smem[];                     // [T] scores / weights
+__device__ __forceinline__ void attn_fwd_row(const float* __restrict__ hp, const float* __restrict__ ep,
+                                             const float* __restrict__ enc, const float* __restrict__ v,
+                                             float* __restrict__ weights, float* __restrict__ ctx, int64_t ldctx, int T, int B,
+                                             int H, float* sc) {      // sc: [T] floats of LDS (scores / weights)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = blockIdx.x;
-  float* sc = smem;
   const float* hpr = hp + (int64_t)b * H;
   // (round 6: every load of a pass is requested before the first tanh -- the loops used to walk H in 64-wide slices and T one
   //  position at a time, a memory round trip per slice / position: 10 us per call at B = 128, T = 20, H = 200, now 5)
@@ -692,6 +690,63 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__
     }
     ctx[(int64_t)b * ldctx + f] = c;
   }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const float* __restrict__ hp, const float* __restrict__ ep,
+                                                       const float* __restrict__ enc, const float* __restrict__ v,
+                                                       float* __restrict__ weights, float* __restrict__ ctx,
+                                                       int64_t ldctx, int T, int B, int H) {
+  extern __shared__ float smem[];
+  attn_fwd_row(hp, ep, enc, v, weights, ctx, ldctx, T, B, H, smem);
+}
+
+// The row-local head of a decode step in ONE launch (round 6; at the reference's batch size a step is a chain of dependent
+// launches of ~5 us each whatever they do): the greedy feedback id = argmax(previous logits row) (lowest index on ties, as
+// g2v_argmax_rows; logits == NULL: the id is given), the code embedding with its Dropout(0.5) mask into the first half of the
+// decoder input row, the attention context into the second half.  One workgroup per batch row.
+__global__ __launch_bounds__(256) void attn_step_fwd_kernel(const float* __restrict__ logits, int64_t ldl, int K,
+                                                            int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                            const uint8_t* __restrict__ keep, float emb_scale,
+                                                            float* __restrict__ ec, int64_t ldec, const float* __restrict__ hp,
+                                                            const float* __restrict__ ep, const float* __restrict__ enc,
+                                                            const float* __restrict__ v, float* __restrict__ weights, int T, int B,
+                                                            int H) {
+  extern __shared__ float smem[];
+  __shared__ float wv[4];
+  __shared__ int wk[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  int64_t id;
+  if (logits) {
+    const float* z = logits + (int64_t)b * ldl;
+    float bv = -INFINITY;
+    int bk = 0x7fffffff;
+    for (int k = threadIdx.x; k < K; k += 256) {
+      const float x = z[k];
+      if (x > bv) { bv = x; bk = k; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float v2 = __shfl_xor(bv, o);
+      const int k2 = __shfl_xor(bk, o);
+      if (v2 > bv || (v2 == bv && k2 < bk)) { bv = v2; bk = k2; }
+    }
+    if (lane == 0) { wv[wave] = bv; wk[wave] = bk; }
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (wv[w] > bv || (wv[w] == bv && wk[w] < bk)) { bv = wv[w]; bk = wk[w]; }
+    id = (int64_t)bk;
+    if (threadIdx.x == 0) ids[b] = id;
+  } else {
+    id = ids[b];
+  }
+  for (int c = threadIdx.x; c < H; c += 256) {
+    float x = (id >= 0 && id < (int64_t)K) ? table[id * H + c] : 0.f;
+    if (keep) x = keep[(int64_t)b * H + c] ? x * emb_scale : 0.f;
+    ec[(int64_t)b * ldec + c] = x;
+  }
+  attn_fwd_row(hp, ep, enc, v, weights, ec + H, ldec, T, B, H, smem);
 }
 
 // Backward of the step above, one workgroup per batch row.  d_ep / d_enc rows of row b are written (or accumulated) by that
@@ -994,11 +1049,33 @@ extern "C" int g2v_attn_fwd(const float* hp, const float* ep, const float* enc, 
   return G2V_OK;
 }
 
+extern "C" int g2v_attn_step_fwd(const float* logits, int64_t ldl, int K, int64_t* ids, const float* table, const uint8_t* keep,
+                                 float emb_scale, float* ec, int64_t ldec, const float* hp, const float* ep, const float* enc,
+                                 const float* v, float* weights, int T, int B, int H, g2v_stream_t stream) {
+  G2V_REQUIRE(ids && table && ec && hp && ep && enc && v && weights, "null pointer");
+  G2V_REQUIRE(T > 0 && B > 0 && H > 0 && K > 0 && ldec >= 2 * (int64_t)H && (!logits || ldl >= K), "bad size");
+  const size_t lds = (size_t)T * sizeof(float);
+  G2V_REQUIRE(lds <= 48 * 1024, "sequence too long for the attention kernel");
+  hipLaunchKernelGGL(attn_step_fwd_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, logits, ldl, K, ids, table, keep, emb_scale,
+                     ec, ldec, hp, ep, enc, v, weights, T, B, H);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
+// out (+)= the sum of `n` slabs of `len` floats in slab order (the fixed-order reduction the library's split products use)
+extern "C" int g2v_slab_sum(const float* slabs, int n, int64_t len, float* out, int accumulate, g2v_stream_t stream) {
+  G2V_REQUIRE(slabs && out, "null pointer");
+  G2V_REQUIRE(n > 0 && len > 0, "bad size");
+  launch_slab_reduce(slabs, n, len, out, accumulate, (hipStream_t)stream);
+  G2V_CHECK_LAUNCH();
+  return G2V_OK;
+}
+
 extern "C" int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, const float* ep, const float* enc,
                             const float* v, const float* weights, float* d_hp, float* d_ep, float* d_enc, float* d_v,
                             int accumulate, int T, int B, int H, void* workspace, size_t workspace_bytes,
                             g2v_stream_t stream) {
-  G2V_REQUIRE(d_ctx && hp && ep && enc && v && weights && d_hp && d_ep && d_enc && d_v && workspace, "null pointer");
+  G2V_REQUIRE(d_ctx && hp && ep && enc && v && weights && d_hp && d_ep && d_enc && workspace, "null pointer");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && ldd >= H, "bad size");
   if (workspace_bytes < g2v_attn_bwd_workspace(B, H)) {
     set_error("g2v_attn_bwd: workspace too small");
@@ -1010,7 +1087,7 @@ extern "C" int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, co
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nblk), dim3(256), lds, (hipStream_t)stream, d_ctx, ldd, hp, ep, enc, v, weights,
                      d_hp, d_ep, d_enc, (float*)workspace, accumulate, T, B, H);
   G2V_CHECK_LAUNCH();
-  launch_slab_reduce((const float*)workspace, nblk, H, d_v, accumulate, (hipStream_t)stream);
+  if (d_v) launch_slab_reduce((const float*)workspace, nblk, H, d_v, accumulate, (hipStream_t)stream);      // (NULL: the caller sums the slabs)
   G2V_CHECK_LAUNCH();
   return G2V_OK;
 }

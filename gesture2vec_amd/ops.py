@@ -865,8 +865,34 @@ def attn_fwd(hp, ep, enc, v, ctx_out=None, ldctx=None, weights=None):
     return weights, ctx_out
 
 
-def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None, out=None, accumulate=False):
-    """out: (d_hp, d_ep, d_enc, d_v) buffers; accumulate adds into d_ep / d_enc / d_v (d_hp is always overwritten)"""
+def attn_step_fwd(logits, ids, table, keep, emb_scale, ec, hp, ep, enc, v, weights):
+    """The row-local head of a decode step in one launch (include/g2v.h: g2v_attn_step_fwd): ids[b] = argmax(logits[b]) (logits
+    None: ids given), ec[b, :H] = table[ids[b]] * keep * emb_scale, ec[b, H:] = attention context, weights (B,T)."""
+    T, B, H = enc.shape
+    K = table.shape[0]
+    check(_lib_().g2v_attn_step_fwd(_p(logits), int(logits.stride(0)) if logits is not None else 0, K, _p(_chk(ids, torch.int64)),
+                                    _p(_chk(table)), _p(keep), float(emb_scale), _p(ec), int(ec.stride(0)), _p(_chk(hp)), _p(_chk(ep)),
+                                    _p(_chk(enc)), _p(_chk(v)), _p(weights), T, B, H, _stream()), "attn_step_fwd")
+
+
+def slab_sum(slabs, out, accumulate=False):
+    """out (+)= slabs.sum(0) in slab order (slabs (n, ...) contiguous)"""
+    n = slabs.shape[0]
+    check(_lib_().g2v_slab_sum(_p(_chk(slabs)), n, slabs.numel() // n, _p(out), int(bool(accumulate)), _stream()), "slab_sum")
+    return out
+
+
+def linear_fwd_dual(x, w_a, bias_a, out_a, w_b, bias_b, out_b):
+    """out_a = x w_a^T + bias_a, out_b = x w_b^T + bias_b: one launch at small row counts (include/g2v.h: g2v_linear_fwd_dual)"""
+    M, K = x.shape
+    check(_lib_().g2v_linear_fwd_dual(_p(x), int(x.stride(0)), _p(_chk(w_a, name="w_a")), _p(bias_a), _p(out_a), int(out_a.stride(0)),
+                                      w_a.shape[0], _p(_chk(w_b, name="w_b")), _p(bias_b), _p(out_b), int(out_b.stride(0)),
+                                      w_b.shape[0], M, K, _stream()), "linear_fwd_dual")
+
+
+def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None, out=None, accumulate=False, dv_slab=None):
+    """out: (d_hp, d_ep, d_enc, d_v) buffers; accumulate adds into d_ep / d_enc / d_v (d_hp is always overwritten).
+    dv_slab (B,H): d_v's per-row partials go there and stay unsummed (d_v is not touched: the caller sums the steps' slabs once)."""
     T, B, H = enc.shape
     dev = enc.device
     if out is not None:
@@ -876,6 +902,11 @@ def attn_bwd(d_ctx, hp, ep, enc, v, weights, ldd=None, out=None, accumulate=Fals
         d_ep = torch.empty((T, B, H), dtype=torch.float32, device=dev)
         d_enc = torch.empty((T, B, H), dtype=torch.float32, device=dev)
         d_v = torch.empty((H,), dtype=torch.float32, device=dev)
+    if dv_slab is not None:
+        check(_lib_().g2v_attn_bwd(d_ctx.data_ptr(), ldd if ldd is not None else H, _p(hp), _p(ep), _p(enc), _p(v), _p(weights),
+                                   _p(d_hp), _p(d_ep), _p(d_enc), None, int(bool(accumulate)), T, B, H, _p(_chk(dv_slab)),
+                                   dv_slab.numel() * 4, _stream()), "attn_bwd")
+        return d_hp, d_ep, d_enc, d_v
     nb = _lib_().g2v_attn_bwd_workspace(B, H)
     ws = workspace(nb, dev, "attn")
     check(_lib_().g2v_attn_bwd(d_ctx.data_ptr(), ldd if ldd is not None else H, _p(hp), _p(ep), _p(enc), _p(v), _p(weights),

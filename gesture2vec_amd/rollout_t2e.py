@@ -245,11 +245,21 @@ class CodeDecoderRollout(torch.autograd.Function):
             HP, AW = f32(S1, B, H), f32(S1, B, Tw)
         else:
             AW = f32(0)
+        # With attention a step's row-local head -- the greedy argmax of the previous logits, the code embedding, the attention
+        # -- is one launch, and the top state is multiplied once for the logits and the NEXT step's query (round 6: at the
+        # reference's batch size a step is a chain of dependent ~5 us launches, 9 -> 7 per step)
+        fused_head = att and B <= 1024
+        if fused_head:
+            ops.linear_fwd(Hs[L - 1][0], W_h, attn_b, out=HP[0])
         for t in range(S1):
-            ops.embedding_fwd(emb_w, ids[t], mask_emb[t], 2.0, out=EC[t], ldo=Hin)            # Embedding + Dropout(0.5)
-            if att:
-                ops.linear_fwd(Hs[L - 1][t], W_h, attn_b, out=HP[t])
-                ops.attn_fwd(HP[t], EP, enc, attn_v, ctx_out=EC[t][:, H:], ldctx=Hin, weights=AW[t])
+            if fused_head:
+                greedy = t >= npre
+                ops.attn_step_fwd(LOG[t - 1] if greedy else None, ids[t], emb_w, mask_emb[t], 2.0, EC[t], HP[t], EP, enc, attn_v, AW[t])
+            else:
+                ops.embedding_fwd(emb_w, ids[t], mask_emb[t], 2.0, out=EC[t], ldo=Hin)            # Embedding + Dropout(0.5)
+                if att:
+                    ops.linear_fwd(Hs[L - 1][t], W_h, attn_b, out=HP[t])
+                    ops.attn_fwd(HP[t], EP, enc, attn_v, ctx_out=EC[t][:, H:], ldctx=Hin, weights=AW[t])
             ops.linear_fwd(EC[t], pre_w, pre_b, out=U[t])
             ops.batchnorm_fwd(U[t], bn_w, bn_b, spec.bn_running_mean, spec.bn_running_var, True, True, out=A[t],
                               save=(SM[t], SI[t]))
@@ -265,8 +275,11 @@ class CodeDecoderRollout(torch.autograd.Function):
                 layer_in = Hs[l][t + 1]
                 if drop:
                     keep, scale = mask_l0[t], scale_l0                   # nn.GRU inter-layer dropout, fused into the next Linear
-            ops.linear_fwd(Hs[L - 1][t + 1], out_w, out_b, out=LOG[t])
-            if t + 1 < S1 and t + 1 >= npre:
+            if fused_head and t + 1 < S1:
+                ops.linear_fwd_dual(Hs[L - 1][t + 1], out_w, out_b, LOG[t], W_h, attn_b, HP[t + 1])
+            else:
+                ops.linear_fwd(Hs[L - 1][t + 1], out_w, out_b, out=LOG[t])
+            if not fused_head and t + 1 < S1 and t + 1 >= npre:
                 ops.argmax_rows(LOG[t], out=ids[t + 1])                  # greedy feedback (:740)
         ctx.save_for_backward(hidden0, enc_out, *params)
         ctx.spec, ctx.dims, ctx.cell = spec, (S1, B, H, K, Hin, L), cell
@@ -311,6 +324,7 @@ class CodeDecoderRollout(torch.autograd.Function):
         if att:
             DEC, DHP = f32(S1, B, Hin), f32(S1, B, H)
             D_EP, D_ENC, D_V = torch.empty_like(b["EP"]), torch.empty_like(b["enc"]), f32(H)
+            DV_SLABS = f32(S1, B, H) if B <= 1024 else None      # d_v's per-row partials of every step: ONE reduction behind the loop
         if cluster_bptt:
             # small batch (round 5): the cells' BPTT as ONE persistent cluster launch (include/g2v.h: g2v_code_cluster_bptt); BatchNorm's
             # backward per step behind it (nothing there feeds the recurrence: the greedy feedback carries no gradient)
@@ -338,12 +352,15 @@ class CodeDecoderRollout(torch.autograd.Function):
             if att:
                 ops.linear_bwd_data(DU[t], b["pre_w"], out=DEC[t])
                 ops.attn_bwd(DEC[t][:, H:], b["HP"][t], b["EP"], b["enc"], b["attn_v"], b["AW"][t], ldd=Hin,
-                             out=(DHP[t], D_EP, D_ENC, D_V), accumulate=(t != S1 - 1))
+                             out=(DHP[t], D_EP, D_ENC, D_V), accumulate=(t != S1 - 1),
+                             dv_slab=DV_SLABS[t] if DV_SLABS is not None else None)
                 ops.linear_bwd_data(DHP[t], b["W_h"], out=carry_next[L - 1], accumulate=True)     # the state the attention scored
             carry, carry_next = carry_next, carry
         # ---- everything that did not feed the recurrence: one launch over all (S-1) B rows each ---------------------------
         d_enc = None
         if att:      # (the encoder's backward waits for this one: it stays on the chain)
+            if DV_SLABS is not None:
+                ops.slab_sum(DV_SLABS.view(S1 * B, H), D_V)
             Tw = b["enc"].shape[0]
             ops.linear_bwd_data(D_EP.view(Tw * B, H), b["W_e"], out=D_ENC.view(Tw * B, H), accumulate=True)
             d_enc = D_ENC

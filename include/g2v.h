@@ -104,6 +104,13 @@ int g2v_linear_compose2(const float* w0, const float* b0, const float* w1, const
 int g2v_linear_fwd_pair(const float* x, int64_t ldx, const float* w_a, const float* bias_a, float* y_a, const float* w_b,
                         const float* bias_b, float* y_b, int64_t ldy, int M, int K, int N, int act, g2v_stream_t stream);
 
+/* y_a = x w_a^T + bias_a (M x N_a, row stride ldya), y_b = x w_b^T + bias_b (M x N_b, ldyb): two g2v_linear_fwd calls on the same
+ * rows -- a decode step of Part d with attention multiplies the new top state twice, for the logits (out :389-391) and for the
+ * next step's attention query (attn :173-185).  One launch at small row counts (bitwise the two calls), two otherwise. */
+int g2v_linear_fwd_dual(const float* x, int64_t ldx, const float* w_a, const float* bias_a, float* y_a, int64_t ldya, int N_a,
+                        const float* w_b, const float* bias_b, float* y_b, int64_t ldyb, int N_b, int M, int K,
+                        g2v_stream_t stream);
+
 /* dx[m, k] (+)= sum_n dy[m, n] * w[n, k]      (w is the forward weight, [N][K] row-major) */
 int g2v_linear_bwd_data(const float* dy, int64_t lddy, const float* w, float* dx, int64_t lddx,
                         int M, int K, int N, int accumulate, g2v_stream_t stream);
@@ -753,10 +760,21 @@ int g2v_argmax_rows(const float* x, int64_t ld, int64_t* out, int M, int K, g2v_
  *                                                              half of the (B,2H) decoder input)
  * g2v_attn_bwd: from d_ctx (row stride ldd) computes d_hp (B,H), d_ep (T,B,H), d_enc (T,B,H) [the direct context
  * term only; the ep path continues through g2v_linear_bwd_data] and d_v (H); accumulate != 0 adds into d_ep / d_enc /
- * d_v (the S-1 decode steps share them).  Deterministic (fixed summation order, no atomics).
+ * d_v (the S-1 decode steps share them).  Deterministic (fixed summation order, no atomics).  d_v == NULL: the per-row
+ * partials (B,H) stay in `workspace` and the caller sums them (g2v_slab_sum; one reduction behind the last step instead of one
+ * per step when every step is handed its own workspace slab).
+ * g2v_attn_step_fwd (round 6): the row-local head of a decode step in one launch -- id[b] = argmax_k logits[b,k] (the greedy
+ * feedback :740, lowest index on ties; logits == NULL: ids[b] is given, the teacher-forced steps), written to ids;
+ * ec[b, :H] = table[id[b], :] * keep[b, :] * emb_scale (Embedding + Dropout(0.5) :340-343; keep may be NULL; table is (K,H));
+ * ec[b, H:2H] = the attention context of g2v_attn_fwd (row b of ec at ec + b * ldec, ldec >= 2H); weights as g2v_attn_fwd.
  * ------------------------------------------------------------------------------------------ */
 int g2v_attn_fwd(const float* hp, const float* ep, const float* enc, const float* v, float* weights, float* ctx,
                  int64_t ldctx, int T, int B, int H, g2v_stream_t stream);
+int g2v_attn_step_fwd(const float* logits, int64_t ldl, int K, int64_t* ids, const float* table, const uint8_t* keep,
+                      float emb_scale, float* ec, int64_t ldec, const float* hp, const float* ep, const float* enc,
+                      const float* v, float* weights, int T, int B, int H, g2v_stream_t stream);
+/* out (+)= slab 0 + slab 1 + ... + slab n-1 (n slabs of `len` floats, added in slab order) */
+int g2v_slab_sum(const float* slabs, int n, int64_t len, float* out, int accumulate, g2v_stream_t stream);
 size_t g2v_attn_bwd_workspace(int B, int H);
 int g2v_attn_bwd(const float* d_ctx, int64_t ldd, const float* hp, const float* ep, const float* enc, const float* v,
                  const float* weights, float* d_hp, float* d_ep, float* d_enc, float* d_v, int accumulate, int T, int B,

@@ -127,6 +127,50 @@ def test_attention_op_matches_torch_reference():
         assert relerr(a, b2.grad) < 2e-5, (n, relerr(a, b2.grad))
 
 
+@pytest.mark.parametrize("T,B,H,K", [(20, 128, 200, 512), (11, 37, 40, 70), (3, 5, 16, 16)])
+def test_fused_step_head_equals_its_three_operators(T, B, H, K):
+    """g2v_attn_step_fwd (round 6: argmax of the previous logits + code embedding with its mask + attention in one launch) against
+    g2v_argmax_rows, g2v_embedding_fwd and g2v_attn_fwd: ids equal (ties included), both halves of the decoder input row and the
+    attention weights bitwise; with given ids (teacher-forced step) likewise.  g2v_linear_fwd_dual against two g2v_linear_fwd calls
+    (bitwise), g2v_slab_sum against a float64 sum, g2v_attn_bwd's unsummed d_v partials against its own reduction."""
+    from gesture2vec_amd import ops
+    g = torch.Generator().manual_seed(11)
+    r = lambda *s: torch.randn(*s, generator=g).to(DEV)
+    logits = r(B, K)
+    logits[1, 3] = logits[1, 7] = 50.0                                     # a tie: the lowest index wins
+    table, hp, ep, enc, v = r(K, H), r(B, H), r(T, B, H), r(T, B, H), r(H)
+    keep = (torch.rand(B, H, generator=g) < 0.5).to(torch.uint8).to(DEV)
+    ids_ref = ops.argmax_rows(logits)
+    assert int(ids_ref[1]) == 3
+    ec_ref = torch.full((B, 2 * H), 7.0, device=DEV)
+    ops.embedding_fwd(table, ids_ref, keep, 2.0, out=ec_ref, ldo=2 * H)
+    w_ref, _ = ops.attn_fwd(hp, ep, enc, v, ctx_out=ec_ref[:, H:], ldctx=2 * H)
+    for given in (False, True):
+        ids = ids_ref.clone() if given else torch.full((B,), -5, dtype=torch.int64, device=DEV)
+        ec, w = torch.full((B, 2 * H), 9.0, device=DEV), torch.empty((B, T), device=DEV)
+        ops.attn_step_fwd(None if given else logits, ids, table, keep, 2.0, ec, hp, ep, enc, v, w)
+        assert torch.equal(ids, ids_ref)
+        assert torch.equal(ec, ec_ref), given
+        assert torch.equal(w, w_ref)
+    # the two products of the top state in one launch
+    x, w_a, b_a, w_b, b_b = r(B, H), r(K, H), r(K), r(H, H), r(H)
+    ya, yb = torch.empty((B, K), device=DEV), torch.empty((B, H), device=DEV)
+    ops.linear_fwd_dual(x, w_a, b_a, ya, w_b, b_b, yb)
+    assert torch.equal(ya, ops.linear_fwd(x, w_a, b_a)) and torch.equal(yb, ops.linear_fwd(x, w_b, b_b))
+    # unsummed d_v partials + one slab sum == the per-call reduction (to summation order)
+    d_ctx = r(B, H)
+    ref = ops.attn_bwd(d_ctx, hp, ep, enc, v, w_ref)
+    slabs = torch.zeros((2, B, H), device=DEV)
+    out = (torch.empty((B, H), device=DEV), torch.empty((T, B, H), device=DEV), torch.empty((T, B, H), device=DEV), torch.full((H,), 3.0, device=DEV))
+    ops.attn_bwd(d_ctx, hp, ep, enc, v, w_ref, out=out, dv_slab=slabs[1])
+    for a_, b_ in zip(out[:3], ref[:3]):
+        assert torch.equal(a_, b_)
+    assert float((out[3] - 3.0).abs().max()) == 0.0                      # d_v untouched
+    dv = ops.slab_sum(slabs.view(2 * B, H), torch.empty((H,), device=DEV))
+    assert relerr(dv.cpu(), ref[3].cpu().double()) < 1e-5
+    assert relerr(dv.cpu(), slabs.double().sum((0, 1)).cpu()) < 1e-6
+
+
 def test_graphed_text2embedding_step_trains():
     """GraphedText2EmbeddingStep: the whole Part-d train iteration replayed from one hipGraph lowers the loss like the
     eager iteration does (same kernels; dropout masks are drawn on the device at every replay)."""
