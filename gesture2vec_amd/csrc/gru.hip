@@ -299,6 +299,203 @@ __global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_fwd_kernel(GruGen
   else gru_seq_fwd_body(d.gi, d.w_hh, d.b_hh, d.h0, lengths, d.reverse, d.hs, hs_ld, d.h_n, d.gates, T, B, H);
 }
 
+// ---- large batch, 192 < H <= 208 (every shipped YAML: H = 200): W_hh RESIDENT in the CU (round 6) ----------------------------------
+// The kernels above re-stream the packed W_hh (3 x 13 tiles x 13 k-blocks = 507 KB) from L2 at EVERY time step, every workgroup the
+// same fragments in the same order at the same moment: 0.65 ms per bidirectional layer at B = 4096, T = 20, a third of the matrix
+// rate, and none of the prefetch depths, tile orders or row-tile counts tried in rounds 3-4 moved it.  A CU of gfx950 has 512 KB of
+// vector registers and 160 KB of LDS -- more than the matrix.  One 256-thread workgroup per 16-row tile (one wave per SIMD, so a
+// wave may use all 512 registers) keeps its share of W_hh for the WHOLE sequence: RES_NREG fragments (a dword per lane each) per
+// wave in registers, the rest in LDS, wave-private, read back with conflict-free ds_read_b32; the state tile is the only other
+// LDS tenant (single-buffered: the new state waits in registers for the step's barrier).  Waves take hidden tiles wave, wave + 4,
+// ...: wave 0 four (624 fragments), the others three (468).  Per (hidden tile, step): 156 MFMAs in the packed k order of
+// wave_gemm_p_rows, then the gate math of gru_seq_fwd_body_v4 -- results BITWISE those of the streaming kernel.  The gi vectors
+// and biases of the wave's next tile travel while the current tile multiplies.
+#ifndef G2V_RES_DIAG
+#define G2V_RES_DIAG 0      // timing experiments only (gpurun_tools/r06_build_res_variants.sh): 1 no stores, 2 no gi loads, 3 no gate math, 4 no LDS weights
+#endif
+constexpr int RES_NREG = 364;                  // multiple of 4 (a packed float4 = 4 consecutive fragments)
+constexpr int RES_KB = 13, RES_NT = 13, RES_LDX = 16 * RES_KB + 4;
+constexpr int RES_FR4 = 4 * 3 * RES_KB * 4, RES_FR3 = 3 * 3 * RES_KB * 4;
+constexpr int RES_LW0 = RES_FR4 - RES_NREG, RES_LW = RES_FR3 - RES_NREG;      // fragments in LDS: wave 0, waves 1..3
+constexpr size_t RES_LDS_BYTES = ((size_t)(RES_LW0 + 3 * RES_LW) * 64 + 16 * RES_LDX) * sizeof(float);
+static_assert(RES_LDS_BYTES <= 160 * 1024, "W_hh share + state tile must fit the CU's LDS");
+
+// (global-address-space accesses: the operands arrive inside a by-value struct, so the compiler would treat them as generic pointers
+//  -- flat loads / stores, behind which every wait is an s_waitcnt vmcnt(0): with ONE wave per SIMD the tile's gate stores then
+//  stood in front of the next tile's gi vectors, 7 us of a 22 us step)
+typedef __attribute__((address_space(1))) const f32x4 res_gc4;
+typedef __attribute__((address_space(1))) f32x4 res_g4;
+__device__ __forceinline__ float4 res_ld4(const float* p) {
+  const f32x4 v = *(res_gc4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void res_st4(float* p, float4 v) { *(res_g4*)p = (f32x4){v.x, v.y, v.z, v.w}; }
+
+template <int NH>      // hidden tiles of this wave
+__device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t* __restrict__ lengths, int64_t hs_ld, int T, int B, int H,
+                                                 const RowOff& ro, float* __restrict__ wl, float* __restrict__ hbuf) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int brow = b0 + (rvalid ? i : 0);
+  const int len = (lengths && rvalid) ? lengths[brow] : T;
+  const float* __restrict__ P = d.w_hh;
+  const float* __restrict__ gi = d.gi;
+  const float* __restrict__ b_hh = d.b_hh;
+  float* __restrict__ hs = d.hs;
+  float* __restrict__ gates = d.gates;
+  const int reverse = d.reverse;
+  // ---- this wave's share of W_hh: fragment f = ((j * 3 + g) * 13 + s) * 4 + c of hidden tile wave + 4 j, gate g, k-block s, sub-step c
+  float wreg[RES_NREG];
+#pragma unroll
+  for (int j = 0; j < NH; ++j)
+#pragma unroll
+    for (int g = 0; g < 3; ++g)
+#pragma unroll
+      for (int s = 0; s < RES_KB; ++s) {
+        const int f = ((j * 3 + g) * RES_KB + s) * 4;
+        const int tile = wave + 4 * j + g * RES_NT;
+        const float4 w4 = res_ld4(P + ((int64_t)(tile * RES_KB + s) * 64 + lane) * 4);
+        if (f < RES_NREG) {
+          wreg[f] = w4.x; wreg[f + 1] = w4.y; wreg[f + 2] = w4.z; wreg[f + 3] = w4.w;
+        } else {
+          float* o = wl + (f - RES_NREG) * 64 + lane;
+          o[0] = w4.x; o[64] = w4.y; o[128] = w4.z; o[192] = w4.w;
+        }
+      }
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  int lmax = T;
+  if (lengths) {
+    lmax = 0;
+    for (int r = 0; r < nrows; ++r) lmax = max(lmax, (int)lengths[b0 + r]);
+    lmax = min(max(lmax, 0), T);
+  }
+  const int s_lo = reverse ? T - lmax : 0, s_hi = reverse ? T : lmax;
+  if (lmax < T) {      // (steps at which no row of the tile is inside its sequence: outputs zero, nothing computed -- as above)
+    const int H4z = H >> 2, nskip = T - lmax;
+    for (int e = tid; e < nskip * nrows * H4z; e += 256) {
+      const int k = e / (nrows * H4z), rem = e - k * nrows * H4z, r = rem / H4z, c = 4 * (rem - r * H4z);
+      const int sk = reverse ? k : lmax + k;
+      const int tk = reverse ? (T - 1 - sk) : sk;
+      res_st4(hs + ((int64_t)tk * B + b0 + r) * hs_ld + c, z4);
+    }
+  }
+  float4 gin[3], bhn[3];
+  auto prefetch = [&](int s, int j) {
+    const int t = reverse ? (T - 1 - s) : s;
+    const int f0 = 16 * (wave + 4 * j) + 4 * q;
+    const bool col = f0 + 3 < H;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) bhn[g] = col ? res_ld4(b_hh + g * H + f0) : z4;
+    const bool ok = rvalid && s < T && t < len && col && (G2V_RES_DIAG != 2);
+    const float* gir = gi + ((ok ? gi_row_base(ro, t, B) + brow : (int64_t)0)) * 3 * H + (ok ? f0 : 0);
+#pragma unroll
+    for (int g = 0; g < 3; ++g) gin[g] = ok ? res_ld4(gir + g * H) : z4;
+  };
+  prefetch(s_lo, 0);
+  __syncthreads();                                   // the state tile (filled by the caller) and every wave's LDS fragments are in place
+  const float* xrow = hbuf + i * RES_LDX + 4 * q;
+  for (int s_ = s_lo; s_ < s_hi; ++s_) {
+    const int t = reverse ? (T - 1 - s_) : s_;
+    float4 hnew[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int ft = wave + 4 * j;
+      float4 gic[3], bh[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) { bh[g] = bhn[g]; gic[g] = gin[g]; }
+      if (j + 1 < NH) prefetch(s_, j + 1); else prefetch(s_ + 1, 0);
+      f32x4 acc[3];
+#pragma unroll
+      for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float4 xn4 = *reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+      for (int s = 0; s < RES_KB; ++s) {
+        const float4 xb4 = xn4;                          // (one k-block ahead, and nothing hoisted further: the scheduler
+        if (s + 1 < RES_KB) xn4 = *reinterpret_cast<const float4*>(xrow + 16 * (s + 1));      //  would otherwise spill weights)
+        const float xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const int f = ((j * 3 + g) * RES_KB + s) * 4 + c;
+            const float w = (f < RES_NREG || G2V_RES_DIAG == 4) ? wreg[f < RES_NREG ? f : f % RES_NREG] : wl[(f - RES_NREG) * 64 + lane];
+            acc[g] = mfma16(w, xb[c], acc[g]);
+          }
+#ifndef RES_SCHED_MASK
+#define RES_SCHED_MASK 0
+#endif
+        __builtin_amdgcn_sched_barrier(RES_SCHED_MASK);
+      }
+      const int f0 = 16 * ft + 4 * q;
+      hnew[j] = z4;
+      if (G2V_RES_DIAG == 3) {
+        hnew[j] = make_float4(acc[0][0] + gic[0].x, acc[1][1] + bh[1].x, acc[2][2], acc[0][3]);
+      } else if (f0 + 3 < H) {
+        const float br[4] = {bh[0].x, bh[0].y, bh[0].z, bh[0].w}, bz[4] = {bh[1].x, bh[1].y, bh[1].z, bh[1].w},
+                    bn[4] = {bh[2].x, bh[2].y, bh[2].z, bh[2].w};
+        const bool valid = rvalid && (t < len);
+        const int64_t row = (int64_t)t * B + brow;
+        const float4 hp4 = *reinterpret_cast<const float4*>(hbuf + i * RES_LDX + f0);
+        const float hp[4] = {hp4.x, hp4.y, hp4.z, hp4.w};
+        const float ir[4] = {gic[0].x, gic[0].y, gic[0].z, gic[0].w}, iz[4] = {gic[1].x, gic[1].y, gic[1].z, gic[1].w},
+                    in_[4] = {gic[2].x, gic[2].y, gic[2].z, gic[2].w};
+        float hn[4], gr[4], gz[4], gn[4], gh[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float rr = sigmoidf_(ir[e] + (acc[0][e] + br[e]));
+          const float zz = sigmoidf_(iz[e] + (acc[1][e] + bz[e]));
+          const float ghn = acc[2][e] + bn[e];
+          const float nn = tanhf_(in_[e] + rr * ghn);
+          const float hnw = (1.0f - zz) * nn + zz * hp[e];
+          hn[e] = valid ? hnw : hp[e];
+          gr[e] = valid ? rr : 0.f; gz[e] = valid ? zz : 0.f; gn[e] = valid ? nn : 0.f; gh[e] = valid ? ghn : 0.f;
+        }
+        hnew[j] = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        if (rvalid && G2V_RES_DIAG != 1) {
+          res_st4(hs + row * hs_ld + f0, valid ? hnew[j] : z4);      // padded positions are zero
+          if (gates) {
+            float* go = gates + row * 4 * H + f0;
+            res_st4(go, make_float4(gr[0], gr[1], gr[2], gr[3]));
+            res_st4(go + H, make_float4(gz[0], gz[1], gz[2], gz[3]));
+            res_st4(go + 2 * H, make_float4(gn[0], gn[1], gn[2], gn[3]));
+            res_st4(go + 3 * H, make_float4(gh[0], gh[1], gh[2], gh[3]));
+          }
+        }
+      }
+    }
+    __syncthreads();                                 // every wave has read the old state for its products and its own elements
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int f0 = 16 * (wave + 4 * j) + 4 * q;
+      if (f0 + 3 < H) *reinterpret_cast<float4*>(hbuf + i * RES_LDX + f0) = hnew[j];
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void gru_res_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths, int64_t hs_ld,
+                                                          int T, int B, int H, RowOff ro) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GruGenF d = blockIdx.y == 0 ? d0 : d1;
+  const int tid = threadIdx.x, wave = tid >> 6;
+  float* hbuf = smem + (size_t)(RES_LW0 + 3 * RES_LW) * 64;
+  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0);
+  for (int e = tid; e < 16 * RES_LDX; e += 256) {
+    const int r = e / RES_LDX, k = e - r * RES_LDX;
+    hbuf[e] = (d.h0 && r < nrows && k < H) ? d.h0[(int64_t)(b0 + r) * H + k] : 0.f;
+  }
+  if (wave == 0) gru_res_fwd_wave<4>(d, lengths, hs_ld, T, B, H, ro, smem, hbuf);
+  else gru_res_fwd_wave<3>(d, lengths, hs_ld, T, B, H, ro, smem + (size_t)(RES_LW0 + (wave - 1) * RES_LW) * 64, hbuf);
+  if (d.h_n)
+    for (int e = tid; e < 16 * H; e += 256) {
+      const int r = e / H, k = e - r * H;
+      if (r < nrows) d.h_n[(int64_t)(b0 + r) * H + k] = hbuf[r * RES_LDX + k];
+    }
+}
+
 // BPTT.  w_hh_t = W_hh^T, (H, 3H) row-major (so that dh_prev = dgh W_hh is again "weights contiguous along
 // the contraction").  LDS: Gs [16][3H padded] (dgh tile = MFMA B operand), dhs [16][H padded] (carry).
 __device__ __forceinline__ void gru_seq_bwd_body(const float* __restrict__ d_hs, int64_t d_hs_ld,
@@ -2047,6 +2244,14 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   bool v4 = (H & 3) == 0 && H <= 256 && (hs_ld & 3) == 0;
   for (int k = 0; k < ndir && v4; ++k)
     v4 = aligned16(dirs[k].gi) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].hs) && aligned16(dirs[k].gates);
+  // large batch, 192 < H <= 208: W_hh resident in the CU for the whole sequence (gru_res_fwd_kernel)
+  const int res_rows = g2v_internal_options().gru_resident_rows;
+  if (v4 && Hp == 16 * RES_KB && res_rows > 0 && B >= res_rows) {
+    (void)hipFuncSetAttribute((const void*)gru_res_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BYTES);
+    hipLaunchKernelGGL(gru_res_fwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), RES_LDS_BYTES, st, g[0], g[1], lengths, hs_ld, T, B, H, ro);
+    G2V_CHECK_LAUNCH();
+    return G2V_OK;
+  }
   // two row tiles per workgroup (every weight fragment multiplies 32 rows: 0.73 against 0.80 ms at the native shape) once that
   // still leaves a workgroup for most CUs
   if (v4 && 2 * lds <= 160 * 1024 && cdiv(B, 32) * ndir >= 192)
