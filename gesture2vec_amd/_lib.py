@@ -271,7 +271,7 @@ def check(rc: int, what: str = ""):
         raise G2VLibraryError(f"g2v call failed ({rc}) {what}: {msg}")
 
 
-OPT_PERSISTENT, OPT_GRU_CLUSTER, OPT_SMALLM_ROWS, OPT_GRU_RESIDENT_ROWS = 1, 2, 3, 4
+OPT_PERSISTENT, OPT_GRU_CLUSTER, OPT_SMALLM_ROWS, OPT_GRU_RESIDENT_ROWS, OPT_GRU_RESIDENT_BWD = 1, 2, 3, 4, 5
 
 
 class Context:

@@ -20,7 +20,8 @@ struct G2vOptions {
   int persist = 1;            // G2V_OPT_PERSISTENT   0..3   (dec_rollout.hip)
   int gru_cluster = 1;        // G2V_OPT_GRU_CLUSTER  0 / 1  (gru.hip)
   int smallm_max_rows = 1024; // G2V_OPT_SMALLM_ROWS  >= 0   (linear.hip)
-  int gru_resident_rows = 1025; // G2V_OPT_GRU_RESIDENT_ROWS  batch rows from which g2v_gru_seq_fwd keeps W_hh in the CU; 0 = never (gru.hip)
+  int gru_resident_rows = 1025; // G2V_OPT_GRU_RESIDENT_ROWS  batch rows from which g2v_gru_seq_fwd / _bwd keep W_hh in the CU; 0 = never (gru.hip)
+  int gru_resident_bwd = 1;     // G2V_OPT_GRU_RESIDENT_BWD   0 / 1: the BPTT too (a resident launch leaves no room on a CU for a co-running kernel)
 };
 G2vOptions& g2v_internal_options();
 

@@ -785,6 +785,210 @@ __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1
 }
 
 
+// ---- large batch, H == 200: the BPTT with W_hh RESIDENT in the CU (round 6; the forward's scheme, gru_res_fwd_kernel) ---------------
+// dh_prev = direct + dgh W_hh contracts over the 3H = 600 gate columns: 13 hidden tiles x 150 k-steps = 1950 weight fragments
+// (the streaming kernel's packed W_hh^T pads the contraction to 608: 1976).  They do not fit beside that kernel's LDS tenants
+// (the gate-gradient tile, the carry tile) and its 24 prefetched vectors per thread, so the step is laid out differently:
+//   * a lane owns the elements the matrix pipe hands it -- (row i, hidden units 16 ft + 4 q .. + 3) of its wave's tiles ft = wave,
+//     wave + 4, ... -- for BOTH phases: the carry dh never leaves its registers, the carry tile is gone from LDS;
+//   * phase 1 (gate gradients, element-wise) writes dgh / dgi and the (16 x 600) gate-gradient tile, the B operand, to LDS;
+//   * phase 2 multiplies all of the wave's tiles together (3-4 independent accumulator chains share every B read), weights from
+//     registers (RESB_W4 / RESB_W3 fragments: the 4-tile wave prefetches 24 saved-tensor vectors, the 3-tile waves 18) and LDS;
+//   * the saved tensors of step s - 1 are requested between the phases.
+// Contraction order: k-steps of 4 in the packed kernel's interleaving (block of 16: sub-step c covers columns 16 s + 4 q + c), the
+// last 8 columns as two plain k-steps -- NOT the streaming kernel's padded grouping: dgi / dgh equal to summation order, not bit
+// for bit (tests: test_gru_resident_*).
+constexpr int RESB_W4 = 344, RESB_W3 = 374;
+constexpr int RESB_H = 200, RESB_G = 3 * RESB_H, RESB_KS = RESB_G / 4, RESB_BLK = RESB_G / 16, RESB_LDG = RESB_G + 4;
+constexpr int RESB_L4 = 4 * RESB_KS - RESB_W4, RESB_L3 = 3 * RESB_KS - RESB_W3;      // fragments in LDS: wave 0, waves 1..3
+constexpr size_t RESB_LDS_BYTES = ((size_t)(RESB_L4 + 3 * RESB_L3) * 64 + 16 * RESB_LDG) * sizeof(float);
+static_assert(RESB_BLK * 16 + 8 == RESB_G, "37 blocks of 16 + two k-steps");
+static_assert(RESB_LDS_BYTES <= 160 * 1024, "W_hh share + gate-gradient tile must fit the CU's LDS");
+struct GruResB {
+  const float* d_hs; const float* d_hn; const float* hs; const float* h0; const float* gates; const float* w_hh;      // w_hh: (3H, H) as the caller holds it
+  float* dgi; float* dgh; float* dh0; int reverse;
+};
+__device__ __forceinline__ float res_ld1(const float* p) { return *(__attribute__((address_space(1))) const float*)p; }
+
+template <int NH, int NW>      // hidden tiles of this wave; its weight fragments in registers
+__device__ __forceinline__ void gru_res_bwd_wave(const GruResB& d, const int32_t* __restrict__ lengths, int64_t d_hs_ld, int64_t hs_ld, int T,
+                                                 int B, const RowOff& ro, float* __restrict__ wl, float* __restrict__ Gs) {
+  constexpr int H = RESB_H, G = RESB_G;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int b0 = blockIdx.x * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0);
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  const int reverse = d.reverse;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // ---- this wave's share of W_hh^T: fragment (j, ks) of hidden tile wave + 4 j: lane (i, q) holds W_hh[k(ks, q)][16 ft + i]
+  float wreg[NW];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int feat = 16 * (wave + 4 * j) + i;
+    const bool fok = feat < H;
+    const float* wc = d.w_hh + (fok ? feat : 0);
+#pragma unroll
+    for (int ks = 0; ks < RESB_KS; ++ks) {
+      const int k = ks < 4 * RESB_BLK ? 16 * (ks >> 2) + 4 * q + (ks & 3) : 16 * RESB_BLK + 4 * (ks - 4 * RESB_BLK) + q;
+      const float w = fok ? res_ld1(wc + (int64_t)k * H) : 0.f;
+      const int f = j * RESB_KS + ks;
+      if (f < NW) wreg[f < NW ? f : 0] = w;
+      else wl[(f - NW) * 64 + lane] = w;
+    }
+  }
+  int f0s[NH];
+  bool col[NH];
+  float4 dh[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    f0s[j] = 16 * (wave + 4 * j) + 4 * q;
+    col[j] = f0s[j] + 3 < H;
+    dh[j] = (d.d_hn && rvalid && col[j]) ? res_ld4(d.d_hn + (int64_t)b * H + f0s[j]) : z4;
+  }
+  int lmax = T;
+  if (lengths) {
+    lmax = 0;
+    for (int r = 0; r < nrows; ++r) lmax = max(lmax, (int)lengths[b0 + r]);
+    lmax = min(max(lmax, 0), T);
+  }
+  const int s_first = reverse ? T - 1 : lmax - 1, s_last = reverse ? T - lmax : 0;      // executed: s_first down to s_last
+  if (lmax < T) {      // (steps at which no row of the tile is inside its sequence: zero gate gradients, nothing computed)
+    const int G4 = G >> 2, nskip = T - lmax;
+    for (int e = tid; e < nskip * nrows * G4; e += 256) {
+      const int k = e / (nrows * G4), rem = e - k * nrows * G4, r = rem / G4, c = 4 * (rem - r * G4);
+      const int sk = reverse ? k : lmax + k;
+      const int tk = reverse ? (T - 1 - sk) : sk;
+      const int64_t rowk = ((int64_t)tk * B + b0 + r) * G + c;
+      if (!ro.on) res_st4(d.dgi + rowk, z4);
+      res_st4(d.dgh + rowk, z4);
+    }
+  }
+  float4 Pr[NH], Pz[NH], Pn[NH], Phn[NH], Php[NH], Pup[NH];
+  auto prefetch = [&](int s) {
+    const int t = reverse ? (T - 1 - s) : s, tprev = reverse ? t + 1 : t - 1;
+    const bool live = rvalid && t < len;
+    const int64_t row = (int64_t)t * B + b;
+    const float* go = d.gates + row * 4 * H;
+    const bool from_h0 = (s == 0) || (tprev >= len);
+    const float* hpp = from_h0 ? (d.h0 ? d.h0 + (int64_t)b * H : nullptr) : d.hs + ((int64_t)tprev * B + b) * hs_ld;
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const bool ok = live && col[j];
+      const int c = ok ? f0s[j] : 0;
+      Pr[j] = ok ? res_ld4(go + c) : z4;
+      Pz[j] = ok ? res_ld4(go + H + c) : z4;
+      Pn[j] = ok ? res_ld4(go + 2 * H + c) : z4;
+      Phn[j] = ok ? res_ld4(go + 3 * H + c) : z4;
+      Php[j] = (ok && hpp) ? res_ld4(hpp + c) : z4;
+      Pup[j] = (ok && d.d_hs) ? res_ld4(d.d_hs + row * d_hs_ld + c) : z4;
+    }
+  };
+  if (s_first >= s_last) prefetch(s_first);
+  const float* xrow = Gs + i * RESB_LDG + 4 * q;
+  for (int s = s_first; s >= s_last; --s) {
+    const int t = reverse ? (T - 1 - s) : s;
+    const bool live = rvalid && t < len;
+    const int64_t row = (int64_t)t * B + b;
+    float4 direct[NH];
+    // phase 1: the gate gradients of this lane's elements (their inputs arrived during the previous step's product)
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      direct[j] = z4;
+      if (!col[j]) continue;
+      const int c = f0s[j];
+      const float dh_in[4] = {dh[j].x, dh[j].y, dh[j].z, dh[j].w};
+      const float rr[4] = {Pr[j].x, Pr[j].y, Pr[j].z, Pr[j].w}, zz[4] = {Pz[j].x, Pz[j].y, Pz[j].z, Pz[j].w};
+      const float nn[4] = {Pn[j].x, Pn[j].y, Pn[j].z, Pn[j].w}, gh[4] = {Phn[j].x, Phn[j].y, Phn[j].z, Phn[j].w};
+      const float hp[4] = {Php[j].x, Php[j].y, Php[j].z, Php[j].w}, up[4] = {Pup[j].x, Pup[j].y, Pup[j].z, Pup[j].w};
+      float g_r[4], g_z[4], g_n[4], g_hn[4], dir[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (live) {
+          const float dhv = dh_in[e] + up[e];
+          const float dn = dhv * (1.0f - zz[e]);
+          const float dz = dhv * (hp[e] - nn[e]);
+          const float dnp = dn * (1.0f - nn[e] * nn[e]);
+          g_n[e] = dnp;
+          g_hn[e] = dnp * rr[e];
+          g_r[e] = dnp * gh[e] * rr[e] * (1.0f - rr[e]);
+          g_z[e] = dz * zz[e] * (1.0f - zz[e]);
+          dir[e] = dhv * zz[e];
+        } else {
+          g_r[e] = g_z[e] = g_n[e] = g_hn[e] = 0.f;
+          dir[e] = dh_in[e];
+        }
+      }
+      const float4 vr = make_float4(g_r[0], g_r[1], g_r[2], g_r[3]), vz = make_float4(g_z[0], g_z[1], g_z[2], g_z[3]),
+                   vn = make_float4(g_n[0], g_n[1], g_n[2], g_n[3]), vh = make_float4(g_hn[0], g_hn[1], g_hn[2], g_hn[3]);
+      if (rvalid) {
+        float* gh_o = d.dgh + row * G + c;
+        res_st4(gh_o, vr); res_st4(gh_o + H, vz); res_st4(gh_o + 2 * H, vh);
+        if (live || !ro.on) {
+          float* gi_o = d.dgi + (gi_row_base(ro, t, B) + b) * G + c;
+          res_st4(gi_o, vr); res_st4(gi_o + H, vz); res_st4(gi_o + 2 * H, vn);
+        }
+      }
+      float* gs = Gs + i * RESB_LDG + c;
+      *reinterpret_cast<float4*>(gs) = vr; *reinterpret_cast<float4*>(gs + H) = vz; *reinterpret_cast<float4*>(gs + 2 * H) = vh;
+      direct[j] = make_float4(dir[0], dir[1], dir[2], dir[3]);
+    }
+    lds_barrier();                                   // the gate-gradient tile is complete (LDS only: the stores above keep travelling)
+    if (s > s_last) prefetch(s - 1);
+    // phase 2: dh_prev = direct + dgh W_hh for all of this wave's tiles at once
+    f32x4 acc[NH];
+#pragma unroll
+    for (int j = 0; j < NH; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float4 xn4 = *reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+    for (int blk = 0; blk < RESB_BLK; ++blk) {
+      const float4 xb4 = xn4;
+      if (blk + 1 < RESB_BLK) xn4 = *reinterpret_cast<const float4*>(xrow + 16 * (blk + 1));
+      const float xb[4] = {xb4.x, xb4.y, xb4.z, xb4.w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+          const int f = j * RESB_KS + 4 * blk + c;
+          const float w = f < NW ? wreg[f < NW ? f : 0] : wl[(f - NW) * 64 + lane];
+          acc[j] = mfma16(w, xb[c], acc[j]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    {
+      const float xa = Gs[i * RESB_LDG + 16 * RESB_BLK + q], xc = Gs[i * RESB_LDG + 16 * RESB_BLK + 4 + q];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < NH; ++j) {
+          const int f = j * RESB_KS + 4 * RESB_BLK + u;
+          const float w = f < NW ? wreg[f < NW ? f : 0] : wl[(f - NW) * 64 + lane];
+          acc[j] = mfma16(w, u == 0 ? xa : xc, acc[j]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+      dh[j] = make_float4(direct[j].x + acc[j][0], direct[j].y + acc[j][1], direct[j].z + acc[j][2], direct[j].w + acc[j][3]);
+    lds_barrier();                                   // every wave has read the tile before the next phase 1 rewrites it
+  }
+  if (d.dh0 && rvalid)
+#pragma unroll
+    for (int j = 0; j < NH; ++j)
+      if (col[j]) res_st4(d.dh0 + (int64_t)b * H + f0s[j], dh[j]);
+}
+
+__global__ __launch_bounds__(256) void gru_res_bwd_kernel(GruResB d0, GruResB d1, const int32_t* __restrict__ lengths, int64_t d_hs_ld,
+                                                          int64_t hs_ld, int T, int B, RowOff ro) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const GruResB d = blockIdx.y == 0 ? d0 : d1;
+  const int wave = threadIdx.x >> 6;
+  float* Gs = smem + (size_t)(RESB_L4 + 3 * RESB_L3) * 64;
+  if (wave == 0) gru_res_bwd_wave<4, RESB_W4>(d, lengths, d_hs_ld, hs_ld, T, B, ro, smem, Gs);
+  else gru_res_bwd_wave<3, RESB_W3>(d, lengths, d_hs_ld, hs_ld, T, B, ro, smem + (size_t)(RESB_L4 + (wave - 1) * RESB_L3) * 64, Gs);
+}
+
 // ---- small batch, generic hidden size: ONE LAUNCH PER TIME STEP, one wave per (16 rows, 16 hidden units, direction) -------
 // The persistent kernels above give a direction only B/16 workgroups, each re-streaming the whole W_hh (3H x H) per step:
 // at B = 128, H = 200 that is 8 busy CUs and ~32 us per step.  A hidden unit's new state needs only ITS three gate rows of
@@ -2476,6 +2680,27 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
     }
     G2V_CHECK_LAUNCH();
     return G2V_OK;
+  }
+  // large batch, H == 200: W_hh resident in the CU for the whole sequence (gru_res_bwd_kernel)
+  {
+    const int res_rows = g2v_internal_options().gru_resident_rows;
+    bool res = H == RESB_H && res_rows > 0 && B >= res_rows && g2v_internal_options().gru_resident_bwd && (hs_ld & 3) == 0 &&
+               (d_hs_ld & 3) == 0;
+    for (int k = 0; k < ndir && res; ++k)
+      res = aligned16(dirs[k].gates) && aligned16(dirs[k].dgi) && aligned16(dirs[k].dgh) && aligned16(dirs[k].hs) && aligned16(dirs[k].h0) &&
+            aligned16(dirs[k].dh0) && aligned16(dirs[k].d_hs) && aligned16(dirs[k].d_hn);
+    if (res) {
+      GruResB r[2];
+      for (int k = 0; k < ndir; ++k)
+        r[k] = GruResB{dirs[k].d_hs, dirs[k].d_hn, dirs[k].hs, dirs[k].h0, dirs[k].gates, dirs[k].w_hh, dirs[k].dgi, dirs[k].dgh,
+                       dirs[k].dh0, dirs[k].reverse};
+      if (ndir == 1) r[1] = r[0];
+      (void)hipFuncSetAttribute((const void*)gru_res_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RESB_LDS_BYTES);
+      hipLaunchKernelGGL(gru_res_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), RESB_LDS_BYTES, st, r[0], r[1], lengths, d_hs_ld, hs_ld,
+                         T, B, ro);
+      G2V_CHECK_LAUNCH();
+      return G2V_OK;
+    }
   }
   GruGenB g[2];
   {

@@ -94,6 +94,10 @@ extern "C" int g2v_ctx_set_option(g2v_ctx* ctx, int option, int value) {
       prev = o.gru_resident_rows;
       if (value >= 0) o.gru_resident_rows = value;
       break;
+    case G2V_OPT_GRU_RESIDENT_BWD:
+      prev = o.gru_resident_bwd;
+      o.gru_resident_bwd = value ? 1 : 0;
+      break;
     default:
       g2v::set_error("g2v_ctx_set_option: unknown option %d", option);
       return G2V_ERR_ARG;
@@ -107,6 +111,7 @@ extern "C" int g2v_ctx_get_option(const g2v_ctx* ctx, int option) {
     case G2V_OPT_GRU_CLUSTER: return o.gru_cluster;
     case G2V_OPT_SMALLM_ROWS: return o.smallm_max_rows;
     case G2V_OPT_GRU_RESIDENT_ROWS: return o.gru_resident_rows;
+    case G2V_OPT_GRU_RESIDENT_BWD: return o.gru_resident_bwd;
     default: g2v::set_error("g2v_ctx_get_option: unknown option %d", option); return G2V_ERR_ARG;
   }
 }

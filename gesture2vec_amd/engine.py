@@ -123,6 +123,10 @@ class VQVAEEngine:
         # calls.  Two engines in one process do not share switches; a residency fault here flips only this engine's (round 6;
         # they used to be process-global variables).  `fault_policy` switches the fast path off on a fault and re-arms it later.
         self.ctx = _lib.Context()
+        # (the encoder's BPTT runs BESIDE the decoder's weight-gradient products here: the W_hh-resident kernel would take every CU
+        #  whole -- native dims at B = 4096 5.90 -> 6.44 ms with it, profiles/r06_n_engine_ab.log -- so this engine keeps the
+        #  streaming BPTT; the resident FORWARD, alone on the chain, stays: 6.02 -> 5.91)
+        self.ctx.set(_lib.OPT_GRU_RESIDENT_BWD, 0)
         from .fault_policy import PersistentPathPolicy
         self.fault_policy = PersistentPathPolicy(ctx=self.ctx)
         # Opt-in: run the weight-gradient products on the bf16 matrix pipe as 3-term splits (G2V_WGRAD_BF16X3: ~3e-5 max-norm

@@ -62,9 +62,13 @@ int g2v_linear_set_smallm_rows(int rows);
  *   G2V_OPT_SMALLM_ROWS   row count up to which the wave-per-tile dense kernels are used (default 1024)
  *   G2V_OPT_PERSISTENT    0..3: persistent rollout kernels vs one launch per step (default 1; see g2v_dec_rollout_set_persistent)
  *   G2V_OPT_GRU_CLUSTER   0 / 1: small-batch g2v_gru_seq_fwd / _bwd as one persistent launch vs one launch per step
- *   G2V_OPT_GRU_RESIDENT_ROWS   batch rows from which g2v_gru_seq_fwd keeps W_hh resident in each CU's registers + LDS for the whole
- *                         sequence (192 < H <= 208; default 1025: every batch beyond the small-batch cluster kernels; 0 = never) instead of streaming it from L2 every step; bitwise
- *                         the same results
+ *   G2V_OPT_GRU_RESIDENT_ROWS   batch rows from which g2v_gru_seq_fwd (192 < H <= 208) and g2v_gru_seq_bwd (H = 200) keep W_hh
+ *                         resident in each CU's registers + LDS for the whole sequence instead of streaming it from L2 every step
+ *                         (default 1025: every batch beyond the small-batch cluster kernels; 0 = never).  Forward: bitwise the
+ *                         streaming kernel's results; BPTT: equal to summation order
+ *   G2V_OPT_GRU_RESIDENT_BWD    0 / 1 (default 1): the BPTT too.  A resident launch takes a CU's whole LDS and register file, so
+ *                         nothing co-resides with it: a caller that runs other launches BESIDE the BPTT (the VQ-VAE engine: the
+ *                         decoder's weight gradients on other queues) turns it off in its context
  * They live in a CALLER-OWNED CONTEXT (round 6; until round 5 they were three process-global variables, so two engines in one
  * process shared them and a fault in one switched off the fast path of the other):
  *   g2v_ctx_create()              a context with the defaults above (host memory; NULL on allocation failure)
@@ -84,6 +88,7 @@ typedef struct g2v_ctx g2v_ctx;
 #define G2V_OPT_GRU_CLUSTER 2
 #define G2V_OPT_SMALLM_ROWS 3
 #define G2V_OPT_GRU_RESIDENT_ROWS 4
+#define G2V_OPT_GRU_RESIDENT_BWD 5
 g2v_ctx* g2v_ctx_create(void);
 void g2v_ctx_destroy(g2v_ctx* ctx);
 g2v_ctx* g2v_ctx_bind(g2v_ctx* ctx);

@@ -709,6 +709,67 @@ def test_gru_seq(ops, T, B, H, reverse, use_len):
     relclose(db_hh, grads_ref[4], 5e-5, "gru db_hh")
 
 
+@pytest.mark.parametrize("T,B,use_len,packed,use_h0", [
+    (6, 2048, False, False, False),      # one workgroup per CU
+    (5, 4100, True, False, True),        # two rounds of workgroups, a ragged last row tile, initial states, lengths
+    (7, 1100, True, True, False),        # packed input projections (Part d's encoder beyond the cluster kernels' batch sizes)
+    (20, 1040, True, True, True),
+])
+def test_gru_resident_kernels_match_the_streaming_kernels(ops, T, B, use_len, packed, use_h0):
+    """Round 6: g2v_gru_seq_fwd / _bwd at large batch and H = 200 keep W_hh RESIDENT in each CU (registers + LDS, gru_res_fwd_kernel /
+    gru_res_bwd_kernel; G2V_OPT_GRU_RESIDENT_ROWS, default: every batch above 1024 rows) instead of streaming it from L2 every step.
+    Forward: the streaming kernel's packed k order -> hs, h_n and the saved gates BITWISE equal.  BPTT: 150 k-steps over the 600
+    gate columns instead of the padded 152 -> dgi, dgh, dh0 equal to summation order.  (Both also run against the oracle:
+    test_gru_seq's B = 2100 / 6200 cases take the resident kernels by default.)  G2V_OPT_GRU_RESIDENT_BWD = 0 keeps the BPTT on
+    the streaming kernel (the VQ-VAE engine's setting)."""
+    from gesture2vec_amd import _lib
+    lib = ops._lib_()
+    H = 200
+    g = torch.Generator().manual_seed(2000 + T + B)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(DEV)
+    lens = row_off = None
+    n_rows = T * B
+    if use_len:
+        lens_h = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+        lens_h[0] = T
+        lens = lens_h.to(torch.int32).to(DEV)
+        if packed:
+            n_t = [int((lens_h > t).sum()) for t in range(T)]
+            row_off = [0] * T
+            for t in range(1, T):
+                row_off[t] = row_off[t - 1] + n_t[t - 1]
+            n_rows = sum(n_t)
+    gi = [r(n_rows, 3 * H) if packed else r(T, B, 3 * H) for _ in range(2)]
+    w_hh, b_hh = [r(3 * H, H) for _ in range(2)], [r(3 * H) for _ in range(2)]
+    h0 = [r(B, H) if use_h0 else None for _ in range(2)]
+    ups = [(r(T, B, H), r(B, H)) for _ in range(2)]
+    prev_rows, prev_bwd = lib.g2v_ctx_get_option(None, _lib.OPT_GRU_RESIDENT_ROWS), lib.g2v_ctx_get_option(None, _lib.OPT_GRU_RESIDENT_BWD)
+    try:
+        res = {}
+        for mode, rows, bwd_on in (("stream", 0, 1), ("resident", 1025, 1), ("resident_fwd_only", 1025, 0)):
+            lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_ROWS, rows)
+            lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, bwd_on)
+            fw = [dict(gi=gi[k], w_hh=w_hh[k], b_hh=b_hh[k], h0=h0[k], hs=torch.full((T, B, H), 7.0, device=DEV),
+                       h_n=torch.empty((B, H), device=DEV), gates=torch.zeros((T, B, 4 * H), device=DEV), reverse=bool(k)) for k in range(2)]
+            ops.gru_dirs_fwd(fw, T, B, H, lengths=lens, row_off=row_off)
+            bw = [dict(d_hs=ups[k][0], d_hn=ups[k][1], hs=fw[k]["hs"], h0=h0[k], gates=fw[k]["gates"], w_hh=w_hh[k],
+                       dgi=torch.full((n_rows, 3 * H) if packed else (T, B, 3 * H), 7.0, device=DEV),
+                       dgh=torch.full((T, B, 3 * H), 7.0, device=DEV), dh0=torch.empty((B, H), device=DEV), reverse=bool(k)) for k in range(2)]
+            ops.gru_dirs_bwd(bw, T, B, H, lengths=lens, row_off=row_off)
+            res[mode] = (fw, bw)
+    finally:
+        lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_ROWS, prev_rows)
+        lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, prev_bwd)
+    rel = lambda a, b: float((a.double() - b.double()).abs().max() / b.double().abs().max().clamp_min(1e-30))
+    for k in range(2):
+        for name in ("hs", "h_n", "gates"):
+            assert torch.equal(res["resident"][0][k][name], res["stream"][0][k][name]), (k, name)
+        for name in ("dgi", "dgh", "dh0"):
+            e = rel(res["resident"][1][k][name], res["stream"][1][k][name])
+            assert e < 5e-6, (k, name, e)
+            assert torch.equal(res["resident_fwd_only"][1][k][name], res["stream"][1][k][name]), (k, name, "the switch did not select the streaming BPTT")
+
+
 @pytest.mark.parametrize("T,B,H,ndir,use_len,packed,use_h0", [
     (20, 128, 200, 2, False, False, False),      # the reference's own VQ-VAE.yml encoder: 208 workgroups of three waves
     (20, 128, 200, 2, True, True, False),        # Part d's encoder at B = 128: packed input projections
