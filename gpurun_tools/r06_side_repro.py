@@ -64,6 +64,9 @@ elif mode == "seq4del":
     for att in ("False", "True"):
         for B in (128, 4096):
             g = run(B, att); del g; gc.collect(); torch.cuda.synchronize(); torch.cuda.empty_cache()
+elif mode == "seq6big":      # six multi-stream graphs (B = 2048 forks the encoder's side branch), each captured while its predecessor is alive
+    for k in range(6):
+        g = run(2048, "True" if k %% 2 else "False", eager=1, warm=1)
 elif mode == "att2":
     g = run(128, "True"); g = run(4096, "True")
 elif mode == "big2":
@@ -71,6 +74,10 @@ elif mode == "big2":
 elif mode == "keepboth":
     g1 = run(128, "False"); g2 = run(128, "False"); g1.replay(); g2.replay(); torch.cuda.synchronize(); print("both ok")
 ''' % ROOT
-for side, mode in ((1, "seq4fresh"), (1, "seq4gc"), (1, "seq4cache"), (1, "seq4sync"), (0, "seq4")):
-    r = subprocess.run([sys.executable, "-c", CHILD, str(side), mode], capture_output=True, text=True, timeout=300)
+modes = [(1, m) for m in sys.argv[1:]] or [(1, "seq4"), (1, "seq6big"), (1, "seq4fresh"), (1, "seq4gc"), (0, "seq4")]
+bad = 0
+for side, mode in modes:
+    r = subprocess.run([sys.executable, "-c", CHILD, str(side), mode], capture_output=True, text=True, timeout=600)
+    bad += r.returncode != 0
     print((side, mode), "rc", r.returncode, r.stdout.strip().replace("\n", " | "), "||", r.stderr.strip()[-500:].replace("\n", " | "))
+sys.exit(1 if bad else 0)

@@ -953,3 +953,19 @@ def test_side_branches_of_the_backward_change_nothing(att, B, H, K, graphed, mon
     out, _ = net(ids, lengths, None, codes, None, None)
     TS._code_loss(out, codes).backward()
     assert not ops._side_state["pending"]
+
+
+def test_many_multi_stream_graphs_in_one_process_replay():
+    """ROCm 7.2: the replay of the fourth multi-stream graph captured in one process over the SAME side streams, with the third still
+    alive, died inside hipGraphLaunch.  GraphedText2EmbeddingStep releases its previous graph and draws fresh side
+    streams before every capture; this runs the sequences that crashed (four graphs over the bench's four configurations, six
+    large-batch graphs in a row, every one captured while its predecessor is alive) in a CHILD process -- a regression would be a
+    segmentation fault of the interpreter, not an exception."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "gpurun_tools", "r06_side_repro.py"), "seq4", "seq6big"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.stdout.count("rc 0") == 2, r.stdout[-2000:]
