@@ -345,6 +345,45 @@ def bulk_assign_line():
                          "hbm_view_frac": round(bytes_alg / (us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}}
 
 
+def gru_resident_line():
+    """one bidirectional GRU layer forward (g2v_gru_seq_fwd, both directions in one launch) at B = 4096, T = 20,
+    H = 200 -- the encoder of the shipped YAMLs at the per-GPU batch of BASELINE configs[2] / [4] -- with W_hh resident in each CU
+    (the default from 1025 rows) and streamed from L2 every step (G2V_OPT_GRU_RESIDENT_ROWS = 0); outputs compared bit for bit."""
+    from gesture2vec_amd import _lib, ops
+    lib = _lib.load()
+    T, B, H = 20, 4096, 200
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to("cuda:0")
+    base = [dict(gi=r(T, B, 3 * H), w_hh=r(3 * H, H), b_hh=r(3 * H), reverse=bool(k)) for k in range(2)]
+    prev = lib.g2v_ctx_get_option(None, _lib.OPT_GRU_RESIDENT_ROWS)
+    res, outs = {}, {}
+    try:
+        for name, rows in (("resident", 1025), ("streaming", 0)):
+            lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_ROWS, rows)
+            dirs = [dict(d, h0=None, hs=torch.empty((T, B, H), device="cuda:0"), h_n=torch.empty((B, H), device="cuda:0"),
+                         gates=torch.empty((T, B, 4 * H), device="cuda:0")) for d in base]
+            for _ in range(20):
+                ops.gru_dirs_fwd(dirs, T, B, H)
+            st = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(30):
+                ops.gru_dirs_fwd(dirs, T, B, H)
+            e1.record(st)
+            e1.synchronize()
+            res[name] = e0.elapsed_time(e1) * 1e3 / 30
+            outs[name] = dirs
+    finally:
+        lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_ROWS, prev)
+    flops = 2 * T * B * 2.0 * (3 * H) * H
+    same = all(torch.equal(outs["resident"][k][n], outs["streaming"][k][n]) for k in range(2) for n in ("hs", "h_n", "gates"))
+    return {"workload": "g2v_gru_seq_fwd, both directions, B = 4096, T = 20, H = 200 (pack of W_hh included)",
+            "resident_us": round(res["resident"], 1), "streaming_us": round(res["streaming"], 1), "bitwise_equal": bool(same),
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "achieved": round(flops / (res["resident"] * 1e-6) / 1e12, 1),
+                         "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(flops / (res["resident"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                         "streaming_frac": round(flops / (res["streaming"] * 1e-6) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}}
+
+
 def part_d(with_cpu: bool):
     """"Also report text2embedding samples/s" -- config 4: n_words 3863, 300-d embeddings, lengths U{4..20} sorted
     descending, codes U{0..511} (B,6), hidden 200, 2 layers, dropout 0.2 (config/seq2seq.yml), `autoencoder_att` False and True;
@@ -786,6 +825,12 @@ def main():
                 except Exception as e:
                     print(f"[bench] bulk-assign leg failed ({type(e).__name__}: {e})", file=sys.stderr)
                     out["bulk_assign"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            if not a.no_part_d and a.config == "full":
+                try:
+                    out["gru_resident"] = gru_resident_line()
+                except Exception as e:
+                    print(f"[bench] gru-resident leg failed ({type(e).__name__}: {e})", file=sys.stderr)
+                    out["gru_resident"] = {"error": f"{type(e).__name__}: {e}"[:300]}
             if not a.no_part_d and a.config == "full" and world == 1 and not a.force_dp:
                 # the configuration the reference SHIPS (config/VQ-VAE.yml: B = 128, T = 20, D = 40, H = 200), same step, as a child
                 # process of this one (its own model, its own graph): an extra object of the line like Part d

@@ -487,6 +487,8 @@ __global__ __launch_bounds__(256) void gru_res_fwd_kernel(GruGenF d0, GruGenF d1
     const int r = e / RES_LDX, k = e - r * RES_LDX;
     hbuf[e] = (d.h0 && r < nrows && k < H) ? d.h0[(int64_t)(b0 + r) * H + k] : 0.f;
   }
+  // (the two instantiations execute the SAME sequence of barriers -- one in front of the loop, two per step, the step range is
+  //  uniform over the workgroup -- so the waves meet at s_barrier although they sit in different code: the hardware counts arrivals)
   if (wave == 0) gru_res_fwd_wave<4>(d, lengths, hs_ld, T, B, H, ro, smem, hbuf);
   else gru_res_fwd_wave<3>(d, lengths, hs_ld, T, B, H, ro, smem + (size_t)(RES_LW0 + (wave - 1) * RES_LW) * 64, hbuf);
   if (d.h_n)
