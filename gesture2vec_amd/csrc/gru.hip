@@ -336,11 +336,6 @@ __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t
                                                  const RowOff& ro, float* __restrict__ wl, float* __restrict__ hbuf) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * 16;
-  const int nrows = min(16, B - b0);
-  const bool rvalid = i < nrows;
-  const int brow = b0 + (rvalid ? i : 0);
-  const int len = (lengths && rvalid) ? lengths[brow] : T;
   const float* __restrict__ P = d.w_hh;
   const float* __restrict__ gi = d.gi;
   const float* __restrict__ b_hh = d.b_hh;
@@ -365,6 +360,23 @@ __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t
           o[0] = w4.x; o[64] = w4.y; o[128] = w4.z; o[192] = w4.w;
         }
       }
+  // (round 6, later: a workgroup walks row tiles blockIdx.x, blockIdx.x + gridDim.x, ... with the matrix loaded ONCE -- at B = 4096 the
+  //  512 tile-workgroups ran as two rounds over the 256 CUs and each round paid ~45 us for its 130 MB of L2 reads)
+  //  Serpentine: tiles x, 2 NP - 1 - x, 2 NP + x, ... (NP = gridDim.x) -- Part d sorts a batch by length, and with the strided walk the
+  //  workgroups of the long sentences took 32 steps where the others took 16: 3.01 -> 3.15 ms at B = 4096.)
+  const int ntiles = (B + 15) >> 4, NP = gridDim.x;
+  for (int k = 0; k * NP < ntiles; ++k) {
+  const int tile = (k & 1) ? (k + 1) * NP - 1 - (int)blockIdx.x : k * NP + (int)blockIdx.x;
+  if (tile >= ntiles) continue;                      // (uniform over the workgroup)
+  const int b0 = tile * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int brow = b0 + (rvalid ? i : 0);
+  const int len = (lengths && rvalid) ? lengths[brow] : T;
+  for (int e = tid; e < 16 * RES_LDX; e += 256) {
+    const int r = e / RES_LDX, k = e - r * RES_LDX;
+    hbuf[e] = (d.h0 && r < nrows && k < H) ? d.h0[(int64_t)(b0 + r) * H + k] : 0.f;
+  }
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   int lmax = T;
   if (lengths) {
@@ -474,28 +486,25 @@ __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t
     }
     __syncthreads();
   }
+  if (d.h_n)
+    for (int e = tid; e < 16 * H; e += 256) {
+      const int r = e / H, k = e - r * H;
+      if (r < nrows) d.h_n[(int64_t)(b0 + r) * H + k] = hbuf[r * RES_LDX + k];
+    }
+  __syncthreads();                                   // (the state tile is free for the next row tile)
+  }
 }
 
 __global__ __launch_bounds__(256) void gru_res_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths, int64_t hs_ld,
                                                           int T, int B, int H, RowOff ro) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const GruGenF d = blockIdx.y == 0 ? d0 : d1;
-  const int tid = threadIdx.x, wave = tid >> 6;
+  const int wave = threadIdx.x >> 6;
   float* hbuf = smem + (size_t)(RES_LW0 + 3 * RES_LW) * 64;
-  const int b0 = blockIdx.x * 16, nrows = min(16, B - b0);
-  for (int e = tid; e < 16 * RES_LDX; e += 256) {
-    const int r = e / RES_LDX, k = e - r * RES_LDX;
-    hbuf[e] = (d.h0 && r < nrows && k < H) ? d.h0[(int64_t)(b0 + r) * H + k] : 0.f;
-  }
-  // (the two instantiations execute the SAME sequence of barriers -- one in front of the loop, two per step, the step range is
-  //  uniform over the workgroup -- so the waves meet at s_barrier although they sit in different code: the hardware counts arrivals)
+  // (the two instantiations execute the SAME sequence of barriers -- per row tile one in front of the loop, two per step, one behind,
+  //  all ranges uniform over the workgroup -- so the waves meet at s_barrier although they sit in different code: the hardware counts arrivals)
   if (wave == 0) gru_res_fwd_wave<4>(d, lengths, hs_ld, T, B, H, ro, smem, hbuf);
   else gru_res_fwd_wave<3>(d, lengths, hs_ld, T, B, H, ro, smem + (size_t)(RES_LW0 + (wave - 1) * RES_LW) * 64, hbuf);
-  if (d.h_n)
-    for (int e = tid; e < 16 * H; e += 256) {
-      const int r = e / H, k = e - r * H;
-      if (r < nrows) d.h_n[(int64_t)(b0 + r) * H + k] = hbuf[r * RES_LDX + k];
-    }
 }
 
 // BPTT.  w_hh_t = W_hh^T, (H, 3H) row-major (so that dh_prev = dgh W_hh is again "weights contiguous along
@@ -818,11 +827,6 @@ __device__ __forceinline__ void gru_res_bwd_wave(const GruResB& d, const int32_t
   constexpr int H = RESB_H, G = RESB_G;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int i = lane & 15, q = lane >> 4;
-  const int b0 = blockIdx.x * 16;
-  const int nrows = min(16, B - b0);
-  const bool rvalid = i < nrows;
-  const int b = b0 + (rvalid ? i : 0);
-  const int len = (lengths && rvalid) ? lengths[b] : T;
   const int reverse = d.reverse;
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // ---- this wave's share of W_hh^T: fragment (j, ks) of hidden tile wave + 4 j: lane (i, q) holds W_hh[k(ks, q)][16 ft + i]
@@ -843,13 +847,23 @@ __device__ __forceinline__ void gru_res_bwd_wave(const GruResB& d, const int32_t
   }
   int f0s[NH];
   bool col[NH];
-  float4 dh[NH];
 #pragma unroll
   for (int j = 0; j < NH; ++j) {
     f0s[j] = 16 * (wave + 4 * j) + 4 * q;
     col[j] = f0s[j] + 3 < H;
-    dh[j] = (d.d_hn && rvalid && col[j]) ? res_ld4(d.d_hn + (int64_t)b * H + f0s[j]) : z4;
   }
+  const int ntiles = (B + 15) >> 4, NP = gridDim.x;
+  for (int k = 0; k * NP < ntiles; ++k) {            // (row tiles in turn, serpentine, the matrix loaded once: see the forward)
+  const int tile = (k & 1) ? (k + 1) * NP - 1 - (int)blockIdx.x : k * NP + (int)blockIdx.x;
+  if (tile >= ntiles) continue;
+  const int b0 = tile * 16;
+  const int nrows = min(16, B - b0);
+  const bool rvalid = i < nrows;
+  const int b = b0 + (rvalid ? i : 0);
+  const int len = (lengths && rvalid) ? lengths[b] : T;
+  float4 dh[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) dh[j] = (d.d_hn && rvalid && col[j]) ? res_ld4(d.d_hn + (int64_t)b * H + f0s[j]) : z4;
   int lmax = T;
   if (lengths) {
     lmax = 0;
@@ -979,6 +993,7 @@ __device__ __forceinline__ void gru_res_bwd_wave(const GruResB& d, const int32_t
 #pragma unroll
     for (int j = 0; j < NH; ++j)
       if (col[j]) res_st4(d.dh0 + (int64_t)b * H + f0s[j], dh[j]);
+  }
 }
 
 __global__ __launch_bounds__(256) void gru_res_bwd_kernel(GruResB d0, GruResB d1, const int32_t* __restrict__ lengths, int64_t d_hs_ld,
@@ -2454,7 +2469,9 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   const int res_rows = g2v_internal_options().gru_resident_rows;
   if (v4 && Hp == 16 * RES_KB && res_rows > 0 && B >= res_rows) {
     (void)hipFuncSetAttribute((const void*)gru_res_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BYTES);
-    hipLaunchKernelGGL(gru_res_fwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), RES_LDS_BYTES, st, g[0], g[1], lengths, hs_ld, T, B, H, ro);
+    const int per_dir = max(1, (gru_device_cus() > 0 ? gru_device_cus() : 256) / ndir);      // one workgroup per CU; each walks its row tiles
+    hipLaunchKernelGGL(gru_res_fwd_kernel, dim3(min(cdiv(B, 16), per_dir), ndir), dim3(256), RES_LDS_BYTES, st, g[0], g[1], lengths, hs_ld,
+                       T, B, H, ro);
     G2V_CHECK_LAUNCH();
     return G2V_OK;
   }
@@ -2698,6 +2715,8 @@ static int gru_seq_bwd_impl(const g2v_gru_dir_bwd* dirs, int ndir, const int32_t
                        dirs[k].dh0, dirs[k].reverse};
       if (ndir == 1) r[1] = r[0];
       (void)hipFuncSetAttribute((const void*)gru_res_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RESB_LDS_BYTES);
+      // (one workgroup per row tile here: with the forward's one-per-CU walk Part d with attention at B = 4096 lost 1.4 % -- the
+      //  side branch's weight gradients wait for a CU until a whole walk is through -- and without attention gained nothing)
       hipLaunchKernelGGL(gru_res_bwd_kernel, dim3(cdiv(B, 16), ndir), dim3(256), RESB_LDS_BYTES, st, r[0], r[1], lengths, d_hs_ld, hs_ld,
                          T, B, ro);
       G2V_CHECK_LAUNCH();
