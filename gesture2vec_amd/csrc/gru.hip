@@ -136,6 +136,19 @@ __device__ __forceinline__ void gru_seq_fwd_body(const float* __restrict__ gi, c
 // n_t' for t' < t) -- what pack_padded_sequence does for the reference.  The dense products that make gi and consume dgi
 // (input projection, its data and weight gradients, the embedding gradient) then run over sum(lengths) rows instead of T x B:
 // 40 % fewer at Part d's lengths U{4..20}.  hs / gates / dgh keep the (T,B,.) layout.  By value: T <= 64.
+// Global-address-space accesses (round 6).  Operands that reach a body through a SELECTED by-value struct (`blockIdx.y == 0 ? d0 : d1`
+// copies the struct to private memory) or through a pointer select with nullptr are generic pointers to the compiler: flat loads /
+// stores, which count in vmcnt AND lgkmcnt and behind which every wait is conservative.  In the resident forward (one wave per SIMD)
+// the tile's gate stores then stood in front of the next tile's gi vectors, 7 us of a 22 us step; in the streaming BPTT the 24
+// prefetched vectors per thread were waited for at the first LDS read of the product phase they were meant to travel behind.
+typedef __attribute__((address_space(1))) const f32x4 res_gc4;
+typedef __attribute__((address_space(1))) f32x4 res_g4;
+__device__ __forceinline__ float4 res_ld4(const float* p) {
+  const f32x4 v = *(res_gc4*)p;
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void res_st4(float* p, float4 v) { *(res_g4*)p = (f32x4){v.x, v.y, v.z, v.w}; }
+
 constexpr int GRU_MAX_OFF = 64;
 struct RowOff {
   int on;
@@ -319,17 +332,6 @@ constexpr int RES_FR4 = 4 * 3 * RES_KB * 4, RES_FR3 = 3 * 3 * RES_KB * 4;
 constexpr int RES_LW0 = RES_FR4 - RES_NREG, RES_LW = RES_FR3 - RES_NREG;      // fragments in LDS: wave 0, waves 1..3
 constexpr size_t RES_LDS_BYTES = ((size_t)(RES_LW0 + 3 * RES_LW) * 64 + 16 * RES_LDX) * sizeof(float);
 static_assert(RES_LDS_BYTES <= 160 * 1024, "W_hh share + state tile must fit the CU's LDS");
-
-// (global-address-space accesses: the operands arrive inside a by-value struct, so the compiler would treat them as generic pointers
-//  -- flat loads / stores, behind which every wait is an s_waitcnt vmcnt(0): with ONE wave per SIMD the tile's gate stores then
-//  stood in front of the next tile's gi vectors, 7 us of a 22 us step)
-typedef __attribute__((address_space(1))) const f32x4 res_gc4;
-typedef __attribute__((address_space(1))) f32x4 res_g4;
-__device__ __forceinline__ float4 res_ld4(const float* p) {
-  const f32x4 v = *(res_gc4*)p;
-  return make_float4(v[0], v[1], v[2], v[3]);
-}
-__device__ __forceinline__ void res_st4(float* p, float4 v) { *(res_g4*)p = (f32x4){v.x, v.y, v.z, v.w}; }
 
 template <int NH>      // hidden tiles of this wave
 __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t* __restrict__ lengths, int64_t hs_ld, int T, int B, int H,
@@ -644,12 +646,12 @@ __device__ __forceinline__ void gru_seq_bwd_body_v4(const float* __restrict__ d_
       const int c4 = cg + TPR * k;
       const bool ok = live && c4 < H4;
       const int c = 4 * (ok ? c4 : 0);
-      P.r[k] = ok ? *reinterpret_cast<const float4*>(go + c) : z4;
-      P.z[k] = ok ? *reinterpret_cast<const float4*>(go + H + c) : z4;
-      P.n[k] = ok ? *reinterpret_cast<const float4*>(go + 2 * H + c) : z4;
-      P.hn[k] = ok ? *reinterpret_cast<const float4*>(go + 3 * H + c) : z4;
-      P.hp[k] = (ok && hpp) ? *reinterpret_cast<const float4*>(hpp + c) : z4;
-      P.up[k] = (ok && d_hs) ? *reinterpret_cast<const float4*>(d_hs + row * d_hs_ld + c) : z4;
+      P.r[k] = ok ? res_ld4(go + c) : z4;
+      P.z[k] = ok ? res_ld4(go + H + c) : z4;
+      P.n[k] = ok ? res_ld4(go + 2 * H + c) : z4;
+      P.hn[k] = ok ? res_ld4(go + 3 * H + c) : z4;
+      P.hp[k] = (ok && hpp) ? res_ld4(hpp + c) : z4;
+      P.up[k] = (ok && d_hs) ? res_ld4(d_hs + row * d_hs_ld + c) : z4;
     }
   };
   // Packed lengths (round 5, see the forward body): steps at which no row of the tile is inside its sequence -- s >= lmax for the
@@ -788,11 +790,24 @@ struct GruGenB {
 template <int V4>      // 0: scalar body; 1: the vector body
 __global__ __launch_bounds__(256) void gru_seq_bwd_kernel(GruGenB d0, GruGenB d1, const int32_t* __restrict__ lengths,
                                                                          int64_t d_hs_ld, int64_t hs_ld, int T, int B, int H, RowOff ro) {
-  const GruGenB d = blockIdx.y == 0 ? d0 : d1;
+  // (pointer by pointer: `blockIdx.y == 0 ? d0 : d1` on the STRUCTS makes a private copy, whose pointers the compiler can no longer
+  //  prove global -- the 24 prefetched vectors per thread became flat loads, which count in lgkmcnt too, so the first LDS wait of
+  //  the product phase waited for the whole prefetch it was meant to hide; found in round 6 via the resident kernels)
+  const bool y0 = blockIdx.y == 0;
+  const float* d_hs = y0 ? d0.d_hs : d1.d_hs;
+  const float* d_hn = y0 ? d0.d_hn : d1.d_hn;
+  const float* hs = y0 ? d0.hs : d1.hs;
+  const float* h0 = y0 ? d0.h0 : d1.h0;
+  const float* gates = y0 ? d0.gates : d1.gates;
+  const float* w_hh_t = y0 ? d0.w_hh_t : d1.w_hh_t;
+  float* dgi = y0 ? d0.dgi : d1.dgi;
+  float* dgh = y0 ? d0.dgh : d1.dgh;
+  float* dh0 = y0 ? d0.dh0 : d1.dh0;
+  const int reverse = y0 ? d0.reverse : d1.reverse;
   if constexpr (V4 > 0)
-    gru_seq_bwd_body_v4<V4>(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H, ro);
+    gru_seq_bwd_body_v4<V4>(d_hs, d_hs_ld, d_hn, hs, hs_ld, h0, gates, w_hh_t, lengths, reverse, dgi, dgh, dh0, T, B, H, ro);
   else
-    gru_seq_bwd_body(d.d_hs, d_hs_ld, d.d_hn, d.hs, hs_ld, d.h0, d.gates, d.w_hh_t, lengths, d.reverse, d.dgi, d.dgh, d.dh0, T, B, H);
+    gru_seq_bwd_body(d_hs, d_hs_ld, d_hn, hs, hs_ld, h0, gates, w_hh_t, lengths, reverse, dgi, dgh, dh0, T, B, H);
 }
 
 

@@ -319,7 +319,9 @@ class GRUBiDirFn(torch.autograd.Function):
             dgh = torch.empty((T, B, 3 * H), dtype=torch.float32, device=dev)
             dirs.append(dict(d_hs=d_hs, d_hn=d_hn, hs=hs, h0=None, gates=gates, w_hh=w, dgi=dgi, dgh=dgh, dh0=None, reverse=rev))
             outs.append((dgi, dgh))
-        ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H, row_off=row_off)
+        # (the W_hh-resident BPTT only while nothing else is in flight: beside a side branch's weight gradients -- the layer above,
+        #  with attention -- it lost to the streaming kernel, 8.54 against 8.45 ms at B = 4096; alone it wins, 3.00 against 3.07)
+        ops.gru_dirs_bwd(dirs, T, B, H, lengths=lengths, d_hs_ld=H, hs_ld=H, row_off=row_off, allow_resident=not ops.side_pending())
         items = []
         # the W_hh gradients beside the input side's chain (large batches: ops.side_branch has the measured rule)
         with ops.side_branch(1, keep=[outs[0][1], outs[1][1], full_f, full_b], rows=T * B, min_rows=32768):

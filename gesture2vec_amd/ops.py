@@ -504,8 +504,15 @@ def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None, row_off=None):
                               ws.numel(), _stream()), "gru_seq_fwd")
 
 
-def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None, row_off=None):
-    """dirs: list of dicts d_hs, d_hn, hs, h0, gates, w_hh, dgi, dgh, dh0, reverse.  row_off: dgi is PACKED (see gru_dirs_fwd)."""
+def side_pending() -> bool:
+    """True while a side branch forked in this iteration has not been joined (its launches may still be running)"""
+    return bool(_side_state["pending"])
+
+
+def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None, row_off=None, allow_resident=True):
+    """dirs: list of dicts d_hs, d_hn, hs, h0, gates, w_hh, dgi, dgh, dh0, reverse.  row_off: dgi is PACKED (see gru_dirs_fwd).
+    allow_resident=False: this call keeps the streaming BPTT whatever G2V_OPT_GRU_RESIDENT_BWD says (a W_hh-resident launch takes
+    every CU whole: a caller with other launches in flight beside it says so)."""
     lib = _lib_()
     arr = (_lib.GruDirBwd * len(dirs))()
     ro = _row_off_array(row_off, T)
@@ -519,8 +526,13 @@ def gru_dirs_bwd(dirs, T, B, H, *, lengths=None, d_hs_ld=None, hs_ld=None, row_o
         arr[k].in_dim = int(d.get("in_dim", 0))
     dev = dirs[0]["hs"].device
     ws = workspace(lib.g2v_gru_seq_bwd_workspace(len(dirs), H), dev, "grubwd")
-    check(lib.g2v_gru_seq_bwd(arr, len(dirs), _p(lengths), d_hs_ld if d_hs_ld is not None else H,
-                              hs_ld if hs_ld is not None else H, T, B, H, _p(ws), ws.numel(), _stream()), "gru_seq_bwd")
+    prev = lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, 0) if not allow_resident else None
+    try:
+        check(lib.g2v_gru_seq_bwd(arr, len(dirs), _p(lengths), d_hs_ld if d_hs_ld is not None else H,
+                                  hs_ld if hs_ld is not None else H, T, B, H, _p(ws), ws.numel(), _stream()), "gru_seq_bwd")
+    finally:
+        if prev is not None:
+            lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, prev)
 
 
 def gru_seq_fwd(gi, w_hh, b_hh, T, B, H, *, h0=None, lengths=None, reverse=False, hs=None, hs_ld=None,

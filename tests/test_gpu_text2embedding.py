@@ -899,10 +899,33 @@ def test_side_branches_of_the_backward_change_nothing(att, B, H, K, graphed, mon
     front of the optimiser; below the measured row counts a branch stays inline).  Every kernel is deterministic, so three
     iterations with and without the branches must leave bitwise the same model, and the explicit-gradient path (backward()
     outside the scope) must never see a side stream."""
-    from gesture2vec_amd import ops
+    from gesture2vec_amd import _lib, ops
     from gesture2vec_amd.train_eval import train_seq2seq as TS
     states = []
     mk = lambda: _small_t2e(att=att, B=B, H=H, K=K, NW=300, EMB=300 if H == 200 else 30, Tw=20 if B >= 2048 else 12)
+    # (the W_hh-resident BPTT is taken only while no side branch is in flight -- with the branches off it would serve BOTH encoder
+    #  layers, with them on only the first, and it equals the streaming kernel to summation order only: pinned off here so that
+    #  both runs launch the same kernels and the comparison stays bit for bit)
+    lib = _lib.load()
+    prev_res = lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, 0)
+    monkeypatch.setattr(ops, "side_pending", lambda: False)
+    try:
+        _run_side_on_off(att, B, graphed, monkeypatch, ops, TS, mk, states)
+    finally:
+        lib.g2v_ctx_set_option(None, _lib.OPT_GRU_RESIDENT_BWD, prev_res)
+    assert states[0][0] == states[1][0], (states[0][0], states[1][0])
+    for k, v in states[0][1].items():
+        assert torch.equal(v, states[1][1][k]), k
+    # outside the scope a branch is inline: plain backward() + .grad needs no join
+    monkeypatch.setattr(ops, "SIDE_BRANCHES", True)
+    args, net, optim, ids, lengths, codes, masks = mk()
+    net.set_dropout_masks(*masks)
+    out, _ = net(ids, lengths, None, codes, None, None)
+    TS._code_loss(out, codes).backward()
+    assert not ops._side_state["pending"]
+
+
+def _run_side_on_off(att, B, graphed, monkeypatch, ops, TS, mk, states):
     for side in (False, True):
         monkeypatch.setattr(ops, "SIDE_BRANCHES", side)
         args, net, optim, ids, lengths, codes, masks = mk()
@@ -943,16 +966,6 @@ def test_side_branches_of_the_backward_change_nothing(att, B, H, K, graphed, mon
         assert taken, "no side_branch site was reached"
         assert any(taken) == (side and B >= 2048), (side, B, taken)       # forked exactly where the size rule says so
         states.append((losses, {k: v.detach().clone() for k, v in net.state_dict().items()}))
-    assert states[0][0] == states[1][0], (states[0][0], states[1][0])
-    for k, v in states[0][1].items():
-        assert torch.equal(v, states[1][1][k]), k
-    # outside the scope a branch is inline: plain backward() + .grad needs no join
-    monkeypatch.setattr(ops, "SIDE_BRANCHES", True)
-    args, net, optim, ids, lengths, codes, masks = mk()
-    net.set_dropout_masks(*masks)
-    out, _ = net(ids, lengths, None, codes, None, None)
-    TS._code_loss(out, codes).backward()
-    assert not ops._side_state["pending"]
 
 
 def test_many_multi_stream_graphs_in_one_process_replay():
