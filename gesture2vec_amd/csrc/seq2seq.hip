@@ -869,7 +869,8 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
   G2V_REQUIRE(dim <= 64 * 16, "embedding dim > 1024");
   G2V_REQUIRE(ws_bytes >= g2v_embedding_bwd_ws_bytes(n, dim, V), "workspace too small (g2v_embedding_bwd_ws_bytes)");
   hipStream_t st = (hipStream_t)stream;
-  const int acc = zero_first ? 0 : 1;         // zero_first: every row is (over)written, rows without tokens with zeros
+  const int acc = (zero_first & 1) ? 0 : 1;   // bit 0: every row is (over)written, rows without tokens with zeros
+  const bool reuse_sort = (zero_first & 2) != 0;      // bit 1: `ws` still holds the sort of THESE ids (the previous call's, same n / V)
 #define G2V_EMB_DISPATCH(LAUNCH)    \
   if (dim <= 64) LAUNCH(1);         \
   else if (dim <= 128) LAUNCH(2);   \
@@ -900,11 +901,13 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
   int* rank = (int*)w;                w += emb_align((size_t)n * 4);
   int* perm = (int*)w;                w += emb_align((size_t)n * 4);
   float* partial = (float*)w;
-  (void)hipMemsetAsync(blockcnt, 0, (size_t)nb * V * 4, st);
-  hipLaunchKernelGGL(emb_rank_kernel, dim3(nb), dim3(EMB_TB), 0, st, ids, n, V, blockcnt, rank);
-  hipLaunchKernelGGL(emb_colscan_kernel, dim3(cdiv(V, 64)), dim3(64), 0, st, blockcnt, nb, V, cnt);
-  hipLaunchKernelGGL(emb_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, off, V);
-  hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, V, blockcnt, off, rank, perm);
+  if (!reuse_sort) {
+    (void)hipMemsetAsync(blockcnt, 0, (size_t)nb * V * 4, st);
+    hipLaunchKernelGGL(emb_rank_kernel, dim3(nb), dim3(EMB_TB), 0, st, ids, n, V, blockcnt, rank);
+    hipLaunchKernelGGL(emb_colscan_kernel, dim3(cdiv(V, 64)), dim3(64), 0, st, blockcnt, nb, V, cnt);
+    hipLaunchKernelGGL(emb_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, off, V);
+    hipLaunchKernelGGL(emb_scatter_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, ids, n, V, blockcnt, off, rank, perm);
+  }
 #define G2V_EMB_SORTED(NE)                                                                                                 \
   do {                                                                                                                     \
     if (keep)                                                                                                              \

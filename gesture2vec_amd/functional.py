@@ -187,7 +187,8 @@ class EmbedProjectPairFn(torch.autograd.Function):
             if d is None:
                 out += [None, None]
                 continue
-            s = ops.embedding_bwd(d.contiguous().view(-1, N), ids, V)
+            # (the second direction scatter-adds by the same words: its counting sort is the first one's, still in the workspace)
+            s = ops.embedding_bwd(d.contiguous().view(-1, N), ids, V, reuse_sort=d_table is not None)
             if d_table is None:
                 d_table = ops.linear_bwd_data(s, w)
             else:

@@ -776,13 +776,14 @@ def embedding_fwd(table, ids, keep=None, scale=1.0, out=None, ldo=None):
     return out
 
 
-def embedding_bwd(d_out, ids, V, keep=None, scale=1.0):
+def embedding_bwd(d_out, ids, V, keep=None, scale=1.0, reuse_sort=False):
+    """reuse_sort: the PREVIOUS embedding_bwd call on this stream had the same ids, n, V and dim (its sort is still in the workspace)"""
     n, dim = d_out.shape
     d_table = torch.empty((V, dim), dtype=torch.float32, device=d_out.device)
     nb = int(_lib_().g2v_embedding_bwd_ws_bytes(n, dim, V))
     ws = workspace(nb, d_out.device, "embedding_bwd")
     check(_lib_().g2v_embedding_bwd(_p(_chk(d_out)), _p(_chk(ids, torch.int64)), _p(keep), float(scale), _p(d_table), n, dim,
-                                    V, 1, _p(ws), nb, _stream()), "embedding_bwd")
+                                    V, 1 | (2 if reuse_sort else 0), _p(ws), nb, _stream()), "embedding_bwd")
     return d_table
 
 

@@ -715,8 +715,10 @@ int g2v_vq_soft_fused_bwd(const float* dh, const float* g_loss, const float* x, 
  *   g2v_embedding_bwd   d_table[v,:] (+)= sum_{r: ids[r]=v} d_out[r,:] * keep * scale.  No float atomics: tokens are counting-
  *                       sorted by row (stable), 128-token chunks of the sorted list are summed in order and rows that span
  *                       chunks add their chunk partials in order -- a fixed summation tree, bitwise reproducible.
- *                       zero_first: overwrite instead of accumulate.  ws: g2v_embedding_bwd_ws_bytes(n, dim, V) bytes of
- *                       device scratch (ids outside [0,V) contribute nothing)
+ *                       zero_first bit 0: overwrite instead of accumulate; bit 1 (round 6): `ws` still holds the sort of THESE
+ *                       ids from the previous call (same ids, n, V, untouched since) -- the sort is skipped (the two directions of
+ *                       a bidirectional layer scatter-add by the same words).  ws: g2v_embedding_bwd_ws_bytes(n, dim, V) bytes
+ *                       of device scratch (ids outside [0,V) contribute nothing)
  *   g2v_batchnorm_fwd   nn.BatchNorm1d(H) on (B,H) (+ optional fused ReLU), decoder.pre_linear[1:] :286-290; training:
  *                       batch statistics, running stats updated with momentum 0.1 / unbiased variance (both NULL while training:
  *                       left alone, the caller commits them with g2v_bn_running_update_invstd); save_* for bwd

@@ -1434,6 +1434,12 @@ def test_embedding_fwd_bwd(ops, V, dim, n, pattern):
     # fixed summation tree (stable counting sort, chunk sums in list order, chunk partials in chunk order): bitwise reproducible
     dt2 = ops.embedding_bwd(g.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
     assert torch.equal(dt, dt2)
+    # a second gradient scatter-added by the SAME ids re-uses the counting sort the previous call left in the workspace (round 6:
+    # the two directions of the encoder's table projection): bitwise the fresh call's result
+    g2 = rnd(n, dim, seed=9)
+    fresh = ops.embedding_bwd(g2.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
+    ops.embedding_bwd(g.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0)
+    assert torch.equal(ops.embedding_bwd(g2.to(DEV), ids.to(DEV), V, keep.to(DEV), 2.0, reuse_sort=True), fresh)
     out2 = ops.embedding_fwd(table.to(DEV), ids.to(DEV))
     assert torch.equal(out2.cpu(), table[ids])
     # ids outside the table contribute nothing (the forward returns zeros for them)
