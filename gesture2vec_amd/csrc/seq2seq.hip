@@ -45,7 +45,9 @@ constexpr int EMB_SMALL_N = 2048;
 constexpr int EMB_TB = 1024;        // tokens per ranking block
 constexpr int EMB_MAX_CHUNK = 128;
 
-static inline int emb_chunk_for(int64_t n) { return n <= 16384 ? 16 : (n <= 32768 ? 32 : (n <= 65536 ? 64 : EMB_MAX_CHUNK)); }
+// (round 6: half the chunk lengths of round 5 -- 1536 instead of 768 one-wave workgroups for Part d's 49 k packed tokens at B = 4096,
+//  where a wave with 2-4 rows in flight is a chain of memory round trips: 87 -> 5x us per call)
+static inline int emb_chunk_for(int64_t n) { return n <= 32768 ? 16 : (n <= 131072 ? 32 : (n <= 262144 ? 64 : EMB_MAX_CHUNK)); }
 
 template <int NE>
 __device__ __forceinline__ void emb_store_row(float* __restrict__ dst, const float (&acc)[NE], int dim, int lane, int accumulate) {
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64) void emb_chunk_sum_kernel(const float* __restri
                                                            const int* __restrict__ off, const int* __restrict__ perm,
                                                            float* __restrict__ d_table, float* __restrict__ partial, int dim,
                                                            int64_t V, int chunk, int accumulate) {
-  constexpr int U = NE <= 5 ? 8 : (NE <= 8 ? 4 : 2);      // rows in flight
+  constexpr int U = NE <= 5 ? 8 : (NE <= 10 ? 4 : 2);     // rows in flight
   constexpr int Q = EMB_MAX_CHUNK / 64;
   const int lane = threadIdx.x;
   const int total = off[V];
@@ -877,6 +879,7 @@ extern "C" int g2v_embedding_bwd(const float* d_out, const int64_t* ids, const u
   else if (dim <= 256) LAUNCH(4);   \
   else if (dim <= 320) LAUNCH(5);   \
   else if (dim <= 512) LAUNCH(8);   \
+  else if (dim <= 640) LAUNCH(10);  \
   else LAUNCH(16)
   if (n <= EMB_SMALL_N) {
 #define G2V_EMB_OWNER(NE)                                                                                                    \
