@@ -35,7 +35,8 @@ class GruDir(C.Structure):
     """g2v_gru_dir"""
     _fields_ = ([(n, c_fp) for n in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates")] + [("reverse", c_int)] +
                 [(n, c_fp) for n in ("x", "w_ih", "b_ih")] + [("in_dim", c_int)] +
-                [("gi_row_off", C.POINTER(C.c_int32))])                 # HOST array of T packed row offsets, or NULL
+                [("gi_row_off", C.POINTER(C.c_int32)),                  # HOST array of T packed row offsets, or NULL
+                 ("gi_gather", c_fp)])                                    # DEVICE int64 row indices into a gi TABLE, or NULL
 
 
 class WgradItem(C.Structure):
@@ -133,6 +134,7 @@ _SIGS = {
                                   c_f, c_f, c_f, c_int, c_fp]),
     "g2v_vq_bwd": (c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_int, c_int, c_f, c_fp]),
     "g2v_gru_seq_packed_ok": (c_int, [c_int, c_int, c_int]),
+    "g2v_gru_seq_gather_ok": (c_int, [c_int, c_int, c_int, c_int]),
     "g2v_gru_seq_fwd_workspace": (c_sz, [c_int, c_int]),
     "g2v_gru_seq_fwd": (c_int, [C.POINTER(GruDir), c_int, c_fp, c_i64, c_int, c_int, c_int, c_fp, c_sz, c_fp]),
     "g2v_gru_seq_bwd_workspace": (c_sz, [c_int, c_int]),

@@ -303,6 +303,7 @@ __device__ __forceinline__ void gru_seq_fwd_body_v4(const float* __restrict__ gi
 // chip idle twice as long.
 struct GruGenF {
   const float* gi; const float* w_hh; const float* b_hh; const float* h0; float* hs; float* h_n; float* gates; int reverse;
+  const int64_t* gather;      // (g2v_gru_dir.gi_gather: gi is a table, row r of the layout is gi + gather[r] * 3H; resident forward only)
 };
 template <int V4>      // 0: scalar body; NR = 1 / 2: the vector body with NR row tiles per workgroup
 __global__ __launch_bounds__(V4 == 2 ? 512 : 256) void gru_seq_fwd_kernel(GruGenF d0, GruGenF d1, const int32_t* __restrict__ lengths,
@@ -397,30 +398,40 @@ __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t
     }
   }
   float4 gin[3], bhn[3];
-  auto prefetch = [&](int s, int j) {
+  // (gathered gi: the table row of this lane's batch row at step s -- one index per (row, step), fetched a step ahead of its use)
+  const int64_t* __restrict__ gather = d.gather;
+  auto src_row = [&](int s) -> int64_t {
+    const int t = reverse ? (T - 1 - s) : s;
+    const bool ok = rvalid && s < T && t < len;
+    const int64_t r = ok ? gi_row_base(ro, t, B) + brow : (int64_t)0;
+    return gather ? (ok ? *(__attribute__((address_space(1))) const int64_t*)(gather + r) : (int64_t)0) : r;
+  };
+  int64_t src_cur = src_row(s_lo), src_nxt = 0;
+  auto prefetch = [&](int s, int j, int64_t src) {
     const int t = reverse ? (T - 1 - s) : s;
     const int f0 = 16 * (wave + 4 * j) + 4 * q;
     const bool col = f0 + 3 < H;
 #pragma unroll
     for (int g = 0; g < 3; ++g) bhn[g] = col ? res_ld4(b_hh + g * H + f0) : z4;
     const bool ok = rvalid && s < T && t < len && col && (G2V_RES_DIAG != 2);
-    const float* gir = gi + ((ok ? gi_row_base(ro, t, B) + brow : (int64_t)0)) * 3 * H + (ok ? f0 : 0);
+    const float* gir = gi + (ok ? src : (int64_t)0) * 3 * H + (ok ? f0 : 0);
 #pragma unroll
     for (int g = 0; g < 3; ++g) gin[g] = ok ? res_ld4(gir + g * H) : z4;
   };
-  prefetch(s_lo, 0);
+  prefetch(s_lo, 0, src_cur);
   __syncthreads();                                   // the state tile (filled by the caller) and every wave's LDS fragments are in place
   const float* xrow = hbuf + i * RES_LDX + 4 * q;
   for (int s_ = s_lo; s_ < s_hi; ++s_) {
     const int t = reverse ? (T - 1 - s_) : s_;
     float4 hnew[NH];
+    src_nxt = src_row(s_ + 1);
 #pragma unroll
     for (int j = 0; j < NH; ++j) {
       const int ft = wave + 4 * j;
       float4 gic[3], bh[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) { bh[g] = bhn[g]; gic[g] = gin[g]; }
-      if (j + 1 < NH) prefetch(s_, j + 1); else prefetch(s_ + 1, 0);
+      if (j + 1 < NH) prefetch(s_, j + 1, src_cur); else prefetch(s_ + 1, 0, src_nxt);
       f32x4 acc[3];
 #pragma unroll
       for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -486,6 +497,7 @@ __device__ __forceinline__ void gru_res_fwd_wave(const GruGenF& d, const int32_t
       const int f0 = 16 * (wave + 4 * j) + 4 * q;
       if (f0 + 3 < H) *reinterpret_cast<float4*>(hbuf + i * RES_LDX + f0) = hnew[j];
     }
+    src_cur = src_nxt;
     __syncthreads();
   }
   if (d.h_n)
@@ -2339,6 +2351,12 @@ extern "C" int g2v_gru_seq_prepare(const float* const* w_hh, const float* const*
 }
 
 // packed gi / dgi (g2v_gru_dir.gi_row_off): the generic kernels with 16-byte accesses, offsets by value in the kernel arguments
+// 1: g2v_gru_seq_fwd would run the W_hh-resident forward for this shape (aligned operands assumed), the one kernel that gathers gi
+extern "C" int g2v_gru_seq_gather_ok(int T, int B, int H, int ndir) {
+  const int res_rows = g2v_internal_options().gru_resident_rows;
+  return (T >= 1 && B >= 1 && ndir >= 1 && ndir <= 2 && (H & 3) == 0 && ((H + 15) & ~15) == 16 * RES_KB && res_rows > 0 && B >= res_rows &&
+          !gru_split_ok(B, ndir, H)) ? 1 : 0;
+}
 extern "C" int g2v_gru_seq_packed_ok(int T, int B, int H) {
   return (T >= 1 && T <= GRU_MAX_OFF && B >= 1 && H >= 4 && (H & 3) == 0 && H <= 256 && H != 64) ? 1 : 0;
 }
@@ -2348,6 +2366,12 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
   G2V_REQUIRE(dirs && workspace, "null pointer");
   G2V_REQUIRE(ndir >= 1 && ndir <= 2, "1 or 2 directions per call");
   G2V_REQUIRE(T > 0 && B > 0 && H > 0 && hs_ld >= H, "bad size");
+  const bool gathered = dirs[0].gi_gather != nullptr;
+  for (int k = 0; k < ndir; ++k) G2V_REQUIRE((dirs[k].gi_gather != nullptr) == gathered && (!gathered || dirs[k].gi), "gathered gi: every direction or none, with its table");
+  if (gathered && !g2v_gru_seq_gather_ok(T, B, H, ndir)) {
+    set_error("g2v_gru_seq_fwd: gi_gather is served by the W_hh-resident forward only (g2v_gru_seq_gather_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   for (int k = 0; k < ndir; ++k) G2V_REQUIRE(dirs[k].w_hh && dirs[k].b_hh && dirs[k].hs, "null pointer");
   if (dirs[0].gi_row_off && !g2v_gru_seq_packed_ok(T, B, H)) {
     set_error("g2v_gru_seq_fwd: packed gi is not served for this shape (g2v_gru_seq_packed_ok)");
@@ -2470,7 +2494,7 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
     pb.n = 0;
     for (int k = 0; k < ndir; ++k) {
       pb.d[pb.n++] = PackDesc{dirs[k].w_hh, pp, H, 3, H, H, H, 0, 0};
-      g[k] = GruGenF{dirs[k].gi, pp, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse};
+      g[k] = GruGenF{dirs[k].gi, pp, dirs[k].b_hh, dirs[k].h0, dirs[k].hs, dirs[k].h_n, dirs[k].gates, dirs[k].reverse, dirs[k].gi_gather};
       pp += pack_floats(H, 3, H);
     }
     launch_pack(pb, st);
@@ -2482,6 +2506,10 @@ static int gru_seq_fwd_impl(const g2v_gru_dir* dirs, int ndir, const int32_t* le
     v4 = aligned16(dirs[k].gi) && aligned16(dirs[k].b_hh) && aligned16(dirs[k].hs) && aligned16(dirs[k].gates);
   // large batch, 192 < H <= 208: W_hh resident in the CU for the whole sequence (gru_res_fwd_kernel)
   const int res_rows = g2v_internal_options().gru_resident_rows;
+  if (gathered && !(v4 && Hp == 16 * RES_KB && res_rows > 0 && B >= res_rows)) {
+    set_error("g2v_gru_seq_fwd: gi_gather is served by the W_hh-resident forward only (g2v_gru_seq_gather_ok)");
+    return G2V_ERR_UNSUPPORTED;
+  }
   if (v4 && Hp == 16 * RES_KB && res_rows > 0 && B >= res_rows) {
     (void)hipFuncSetAttribute((const void*)gru_res_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)RES_LDS_BYTES);
     const int per_dir = max(1, (gru_device_cus() > 0 ? gru_device_cus() : 256) / ndir);      // one workgroup per CU; each walks its row tiles

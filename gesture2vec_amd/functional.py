@@ -266,15 +266,20 @@ class GRUBiDirFn(torch.autograd.Function):
     gi_f / gi_b (T,B,3H) and the recurrent weights; returns (hs_f, hn_f, hs_b, hn_b)."""
 
     @staticmethod
-    def forward(ctx, gi_f, gi_b, w_f, b_f, w_b, b_b, lengths, packed=None):
+    def forward(ctx, gi_f, gi_b, w_f, b_f, w_b, b_b, lengths, packed=None, gather=None):
         """packed = (T, B, row_off): gi_f / gi_b are (sum(lengths), 3H) PACKED arrays (ops.gru_dirs_fwd); their gradients
-        come back packed too."""
+        come back packed too.
+        gather (round 6; needs packed) = int64 ids, one per packed position: gi_f / gi_b are (V, 3H) TABLES (the projected
+        embedding table) and position r reads row gather[r] inside the recurrent kernel (include/g2v.h: gi_gather) -- the two
+        (positions x 3H) gathers are never materialised; the gradients come back as the scatter-add by id, (V, 3H) like the inputs."""
         if packed is None:
             T, B, G = gi_f.shape
             row_off = None
         else:
             T, B, row_off = packed
             G = gi_f.shape[1]
+        if gather is not None and packed is None:
+            raise ValueError("GRUBiDirFn: gather needs the packed layout")
         H = G // 3
         dev = gi_f.device
         gi_f, gi_b, w_f, w_b = gi_f.contiguous(), gi_b.contiguous(), w_f.contiguous(), w_b.contiguous()
@@ -291,23 +296,24 @@ class GRUBiDirFn(torch.autograd.Function):
             hs = full[:T] if rev else full[1:]
             h_n = torch.empty((B, H), dtype=torch.float32, device=dev)
             gates = torch.empty((T, B, 4 * H), dtype=torch.float32, device=dev)
-            dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev, full=full))
+            dirs.append(dict(gi=gi, w_hh=w, b_hh=b, h0=None, hs=hs, h_n=h_n, gates=gates, reverse=rev, full=full, gi_gather=gather))
             out += [hs, h_n]
         ops.gru_dirs_fwd(dirs, T, B, H, lengths=lengths, hs_ld=H, row_off=row_off)
-        ctx.save_for_backward(dirs[0]["full"], dirs[0]["gates"], w_f, dirs[1]["full"], dirs[1]["gates"], w_b, lengths)
+        ctx.save_for_backward(dirs[0]["full"], dirs[0]["gates"], w_f, dirs[1]["full"], dirs[1]["gates"], w_b, lengths, gather)
         ctx.dims = (T, B, H)
-        ctx.packed = (row_off, gi_f.shape[0]) if packed is not None else None
+        ctx.table_rows = gi_f.shape[0]
+        ctx.packed = (row_off, gather.numel() if gather is not None else gi_f.shape[0]) if packed is not None else None
         ctx.set_materialize_grads(False)
         return tuple(out)
 
     @staticmethod
     def backward(ctx, g_hs_f, g_hn_f, g_hs_b, g_hn_b):
-        full_f, gates_f, w_f, full_b, gates_b, w_b, lengths = ctx.saved_tensors
+        full_f, gates_f, w_f, full_b, gates_b, w_b, lengths, gather = ctx.saved_tensors
         T, B, H = ctx.dims
         hs_f, hprev_f = full_f[1:], full_f[:T]                           # (forward() laid the zero step beside the states)
         hs_b, hprev_b = full_b[:T], full_b[1:]
         if all(g is None for g in (g_hs_f, g_hn_f, g_hs_b, g_hn_b)):
-            return (None,) * 8
+            return (None,) * 9
         row_off, n_packed = ctx.packed if ctx.packed is not None else (None, 0)
         dev = hs_f.device
         dirs, outs = [], []
@@ -330,7 +336,10 @@ class GRUBiDirFn(torch.autograd.Function):
                 items.append((dgh, hprev, torch.empty((3 * H, H), dtype=torch.float32, device=dev),
                               torch.empty((3 * H,), dtype=torch.float32, device=dev)))
             ops.linear_bwd_weight_batch(items, 3 * H, H, M=T * B)
-        return outs[0][0], outs[1][0], items[0][2], items[0][3], items[1][2], items[1][3], None, None
+        d_gi = [outs[0][0], outs[1][0]]
+        if gather is not None:      # the inputs were tables: their gradients are the scatter-adds of dgi by id (one sort for both)
+            d_gi = [ops.embedding_bwd(d_gi[0], gather, ctx.table_rows), ops.embedding_bwd(d_gi[1], gather, ctx.table_rows, reuse_sort=True)]
+        return d_gi[0], d_gi[1], items[0][2], items[0][3], items[1][2], items[1][3], None, None, None
 
 
 class CrossEntropyFn(torch.autograd.Function):

@@ -104,7 +104,14 @@ class EncoderRNN(nn.Module):
         for l in range(L):
             g = self.gru
             pk = packed[:3] if (packed is not None and l == 0) else None
-            if l == 0 and via_table:
+            gather = None
+            if l == 0 and via_table and pk is not None and ops.gru_gather_ok(Tw, B, H, 2):
+                # (round 6) ... and where the recurrent kernel can gather (the W_hh-resident forward), the projected TABLES go in
+                # as they are: the two (positions x 3H) gathers, 118 MB each at B = 4096, are never written
+                gis = list(Fn.LinearPairFn.apply(self.embedding.weight, g.weight_ih_l0, g.bias_ih_l0, g.weight_ih_l0_reverse,
+                                                 g.bias_ih_l0_reverse))
+                gather = ids_flat
+            elif l == 0 and via_table:
                 gis = list(Fn.EmbedProjectPairFn.apply(self.embedding.weight, ids_flat, g.weight_ih_l0, g.bias_ih_l0,
                                                        g.weight_ih_l0_reverse, g.bias_ih_l0_reverse))
             else:                   # both directions' projections as one Function (the inter-layer dropout applied once)
@@ -116,7 +123,7 @@ class EncoderRNN(nn.Module):
             # both directions of the layer in one launch (each way)
             out_f, hn_f, out_b, hn_b = Fn.GRUBiDirFn.apply(
                 gis[0], gis[1], getattr(g, f"weight_hh_l{l}"), getattr(g, f"bias_hh_l{l}"),
-                getattr(g, f"weight_hh_l{l}_reverse"), getattr(g, f"bias_hh_l{l}_reverse"), lengths, pk)
+                getattr(g, f"weight_hh_l{l}_reverse"), getattr(g, f"bias_hh_l{l}_reverse"), lengths, pk, gather)
             hiddens += [hn_f, hn_b]
             if l + 1 < L:
                 cat = torch.cat([out_f, out_b], dim=2).view(Tw * B, 2 * H)       # layout only

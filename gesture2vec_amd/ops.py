@@ -484,6 +484,11 @@ def _row_off_array(row_off, T):
     return (C.c_int32 * T)(*[int(v) for v in row_off])
 
 
+def gru_gather_ok(T, B, H, ndir=2) -> bool:
+    """g2v_gru_seq_fwd can gather its input projections from a table (g2v_gru_dir.gi_gather) for this shape"""
+    return bool(_lib_().g2v_gru_seq_gather_ok(int(T), int(B), int(H), int(ndir)))
+
+
 def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None, row_off=None):
     """dirs: list (1 or 2) of dicts gi, w_hh, b_hh, h0, hs, h_n, gates, reverse -- ONE launch for both directions.
     With gi=None and x, w_ih, b_ih, in_dim given the input projection is fused into the kernel (H == in_dim == 64).
@@ -492,7 +497,7 @@ def gru_dirs_fwd(dirs, T, B, H, *, lengths=None, hs_ld=None, row_off=None):
     arr = (_lib.GruDir * len(dirs))()
     ro = _row_off_array(row_off, T)
     for k, d in enumerate(dirs):
-        for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates", "x", "w_ih", "b_ih"):
+        for name in ("gi", "w_hh", "b_hh", "h0", "hs", "h_n", "gates", "x", "w_ih", "b_ih", "gi_gather"):
             setattr(arr[k], name, _p(d.get(name)))
         arr[k].reverse = int(bool(d.get("reverse", False)))
         arr[k].in_dim = int(d.get("in_dim", 0))

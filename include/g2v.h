@@ -345,8 +345,15 @@ typedef struct {          /* one direction of one layer, forward */
    * dense product that makes gi runs over sum(lengths) rows instead of T x B.  T <= 64, the generic kernels with H % 4 == 0
    * (g2v_gru_seq_packed_ok); every direction of the call must carry the same offsets.  hs / gates keep the (T,B,.) layout. */
   const int32_t* gi_row_off;
+  /* Gathered input projections (round 6; NULL = off): gi is a TABLE (V, 3H), and row r of the layout above -- r = t * B + b, or
+   * gi_row_off[t] + b when packed -- is gi + gi_gather[r] * 3H.  The encoder the reference feeds straight from nn.Embedding
+   * (model/text2embedding_model.py:126-131): the projected table G = E W_ih^T + b_ih is gathered inside the recurrent kernel
+   * instead of being materialised per position.  Served by the W_hh-resident forward only: g2v_gru_seq_gather_ok(T, B, H, ndir);
+   * otherwise G2V_ERR_UNSUPPORTED.  Entries of positions outside their sequences are never read. */
+  const int64_t* gi_gather;
 } g2v_gru_dir;
 int g2v_gru_seq_packed_ok(int T, int B, int H);
+int g2v_gru_seq_gather_ok(int T, int B, int H, int ndir);
 /* Round 5.  At small batch (B <= 1024, H % 4 == 0, H <= 256, H != 64) g2v_gru_seq_fwd / _bwd run one launch per time step over
  * (16 rows x 16 hidden units x direction) workgroups.  While that grid fits the device with one workgroup per CU (B = 128 at
  * H = 200, both directions: 208 workgroups) the same workgroups instead stay resident for ALL steps of ONE launch, their W_hh rows

@@ -982,3 +982,38 @@ def test_many_multi_stream_graphs_in_one_process_replay():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.stdout.count("rc 0") == 2, r.stdout[-2000:]
+
+
+@pytest.mark.parametrize("att", ["False", "True"])
+def test_encoder_gathers_the_projected_table_inside_the_recurrent_kernel(att, monkeypatch):
+    """Round 6: at large batch the W_hh-resident GRU forward reads row gather[r] of the projected embedding TABLE for packed
+    position r (g2v_gru_dir.gi_gather) instead of a materialised (positions x 3H) array, and the tables' gradients come back as
+    the scatter-add of dgi by word.  Same arithmetic as the materialised route (Fn.EmbedProjectPairFn): loss bitwise, every
+    gradient to summation order."""
+    from gesture2vec_amd import ops
+    from gesture2vec_amd.train_eval import train_seq2seq as TS
+    res = []
+    for gather in (True, False):
+        if not gather:
+            monkeypatch.setattr(ops, "gru_gather_ok", lambda *a, **k: False)
+        args, net, optim, ids, lengths, codes, masks = _small_t2e(att=att, B=1280, H=200, K=512, NW=300, EMB=300, Tw=12)
+        assert ids.numel() >= 2 * 300                         # many rows per word: the table is projected, not the rows
+        calls = []
+        orig = ops.gru_dirs_fwd
+
+        def spy(dirs, *a, _o=orig, **k):
+            calls.append(dirs[0].get("gi_gather") is not None)
+            return _o(dirs, *a, **k)
+        monkeypatch.setattr(ops, "gru_dirs_fwd", spy)
+        net.set_dropout_masks(*masks)
+        out, _ = net(ids, lengths, None, codes, None, None)
+        loss = TS._code_loss(out, codes)
+        loss.backward()
+        monkeypatch.setattr(ops, "gru_dirs_fwd", orig)
+        assert calls and calls[0] == gather, calls            # layer 0 gathered (or not) as asked
+        res.append((float(loss.detach()), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}))
+    assert res[0][0] == res[1][0]
+    assert res[0][1].keys() == res[1][1].keys()
+    for n, g in res[0][1].items():
+        e = float((g.double() - res[1][1][n].double()).abs().max() / res[1][1][n].double().abs().max().clamp_min(1e-30))
+        assert e < 2e-6, (n, e)
