@@ -770,6 +770,40 @@ def test_gru_resident_kernels_match_the_streaming_kernels(ops, T, B, use_len, pa
             assert torch.equal(res["resident_fwd_only"][1][k][name], res["stream"][1][k][name]), (k, name, "the switch did not select the streaming BPTT")
 
 
+def test_gru_gathered_input_projections(ops):
+    """g2v_gru_dir.gi_gather (round 6): gi as a (V, 3H) table + one int64 row index per packed position, read inside the W_hh-resident
+    forward -- bitwise the run on the materialised gather; shapes that kernel does not serve refuse (no silent fallback)."""
+    from gesture2vec_amd import _lib
+    T, B, H, V = 9, 1100, 200, 57
+    g = torch.Generator().manual_seed(77)
+    r = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(DEV)
+    lens_h = torch.sort(torch.randint(1, T + 1, (B,), generator=g), descending=True).values
+    lens_h[0] = T
+    lens = lens_h.to(torch.int32).to(DEV)
+    n_t = [int((lens_h > t).sum()) for t in range(T)]
+    row_off = [0] * T
+    for t in range(1, T):
+        row_off[t] = row_off[t - 1] + n_t[t - 1]
+    n = sum(n_t)
+    ids = torch.randint(0, V, (n,), generator=g).to(DEV)
+    tables, w_hh, b_hh = [r(V, 3 * H) for _ in range(2)], [r(3 * H, H) for _ in range(2)], [r(3 * H) for _ in range(2)]
+    assert ops.gru_gather_ok(T, B, H, 2) and not ops.gru_gather_ok(T, 64, H, 2) and not ops.gru_gather_ok(T, B, 64, 2)
+    outs = []
+    for gathered in (False, True):
+        dirs = [dict(gi=tables[k] if gathered else tables[k][ids].contiguous(), gi_gather=ids if gathered else None, w_hh=w_hh[k], b_hh=b_hh[k],
+                     h0=None, hs=torch.full((T, B, H), 7.0, device=DEV), h_n=torch.empty((B, H), device=DEV),
+                     gates=torch.zeros((T, B, 4 * H), device=DEV), reverse=bool(k)) for k in range(2)]
+        ops.gru_dirs_fwd(dirs, T, B, H, lengths=lens, row_off=row_off)
+        outs.append(dirs)
+    for k in range(2):
+        for name in ("hs", "h_n", "gates"):
+            assert torch.equal(outs[0][k][name], outs[1][k][name]), (k, name)
+    small = [dict(gi=tables[0], gi_gather=ids[:64 * T], w_hh=w_hh[0], b_hh=b_hh[0], h0=None, hs=torch.empty((T, 64, H), device=DEV),
+                  h_n=torch.empty((64, H), device=DEV), gates=torch.empty((T, 64, 4 * H), device=DEV), reverse=False)]
+    with pytest.raises(_lib.G2VLibraryError, match="resident forward only"):
+        ops.gru_dirs_fwd(small, T, 64, H)
+
+
 @pytest.mark.parametrize("T,B,H,ndir,use_len,packed,use_h0", [
     (20, 128, 200, 2, False, False, False),      # the reference's own VQ-VAE.yml encoder: 208 workgroups of three waves
     (20, 128, 200, 2, True, True, False),        # Part d's encoder at B = 128: packed input projections
